@@ -1,0 +1,88 @@
+/*
+ * vers_hip.h -- C ABI of libvers_hip.so: the MI355X (gfx950) IVFFlat hot path
+ * that drops in behind ashrielbrian/vers's `Index` trait.
+ *
+ * Every entry point names the reference interface it replaces
+ * (paths relative to /root/reference/vers/src).  The Rust-side binding a vers
+ * maintainer would add is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; no C++/torch types cross this boundary;
+ *   - every function returns an int32 status (VERS_OK == 0); nothing unwinds
+ *     across the boundary.  The reference panics where these return
+ *     VERS_ERR_NAN / VERS_ERR_INSUFFICIENT / VERS_ERR_EMPTY; a Rust shim
+ *     turns a non-zero status back into a panic to keep the behaviour;
+ *   - vers_last_error() returns a thread-local message for the last failure;
+ *   - pointers are HOST pointers unless the function name ends in `_dev`;
+ *     `_dev` functions take device pointers plus a hipStream_t (as void*,
+ *     NULL = the null stream), enqueue work and return without synchronising;
+ *   - rows are f32, row-major; host row pitch is passed in BYTES so that a
+ *     Rust Vec<Vector<N>> (#[repr(align(256))], base.rs:14-17, pitch =
+ *     round_up(4*N, 256)) can be handed over without repacking;
+ *   - ids are u64 (Rust usize), distances f32.  All distances are produced
+ *     with the reference's own arithmetic (sequential f32 sum of (a-b)^2, no
+ *     FMA), so they are bit-identical to the reference's, not merely close.
+ */
+#ifndef VERS_HIP_H
+#define VERS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VERS_OK 0
+#define VERS_ERR_INVALID 1      /* bad argument / unsupported size */
+#define VERS_ERR_NAN 2          /* reference: partial_cmp().unwrap() panics on NaN */
+#define VERS_ERR_INSUFFICIENT 3 /* reference: index out of bounds at ivfflat.rs:169 */
+#define VERS_ERR_HIP 4          /* HIP runtime failure */
+#define VERS_ERR_EMPTY 5        /* reference: min_by(..).unwrap() on zero centroids, ivfflat.rs:207 */
+
+#define VERS_METRIC_L2SQ 0    /* Vector::squared_euclidean, base.rs:119-126 (what IVFFlat uses) */
+#define VERS_METRIC_COSDIST 1 /* Vector::cosine_similarity(normalized=true) = 1 - dot, base.rs:153-155 */
+
+#define VERS_MAX_TOPK 64 /* per-wave sorted list holds one key per lane */
+
+/* Thread-local description of the most recent failure on this thread. */
+const char* vers_last_error(void);
+/* ABI version of this header (bumped on incompatible change). */
+int32_t vers_abi_version(void);
+/* Number of visible HIP devices. */
+int32_t vers_device_count(int32_t* out_count);
+
+/* ------------------------------------------------------------------------ *
+ * Flat corpus: brute-force scan.                                            *
+ * Replaces utils::search_exhaustive (utils.rs:68-82): every row scored with *
+ * squared_euclidean, stable ascending sort (ties -> lower index), take k.   *
+ * ------------------------------------------------------------------------ */
+typedef struct vers_flat vers_flat_t;
+
+int32_t vers_flat_create(int32_t device, uint32_t d, vers_flat_t** out);
+int32_t vers_flat_destroy(vers_flat_t* h);
+/* Copies n rows (pitch row_stride_bytes >= 4*d) into HBM; position = vec_id. */
+int32_t vers_flat_upload(vers_flat_t* h, const float* rows, uint64_t n, uint64_t row_stride_bytes);
+/* Adopts rows already in HBM (device pointer, pitch in floats, multiple of 4,
+ * columns d..ld zero); the caller keeps ownership and must keep them alive. */
+int32_t vers_flat_adopt_dev(vers_flat_t* h, const float* rows_dev, uint64_t n, uint64_t ld_floats);
+/* b queries (pitch q_stride_bytes).  out_ids/out_dist: [b * top_k], row q at
+ * q*top_k; out_count[q] = min(top_k, n) results written for query q.
+ * top_k <= VERS_MAX_TOPK. */
+int32_t vers_flat_search(vers_flat_t* h, const float* queries, uint64_t q_stride_bytes, uint32_t b,
+                         uint32_t top_k, uint32_t metric, uint64_t* out_ids, float* out_dist,
+                         uint32_t* out_count);
+/* Same, everything in HBM; queries pitch ldq_floats (any value >= d).  Errors
+ * found on the device (NaN) are latched and reported by vers_flat_poll. */
+int32_t vers_flat_search_dev(vers_flat_t* h, const float* queries_dev, uint64_t ldq_floats, uint32_t b,
+                             uint32_t top_k, uint32_t metric, uint64_t* out_ids_dev, float* out_dist_dev,
+                             uint32_t* out_count_dev, void* stream);
+/* Synchronises `stream` and returns (then clears) the latched device status. */
+int32_t vers_flat_poll(vers_flat_t* h, void* stream);
+/* Duration in ms of the most recent scan-kernel launch of this handle
+ * (HIP events on the launch stream; synchronises on those events). */
+int32_t vers_flat_last_scan_ms(vers_flat_t* h, float* out_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VERS_HIP_H */

@@ -1,0 +1,37 @@
+"""CPU-side checks of the drop-in boundary: the library loads and exports every symbol the
+header declares, and the Python binding table matches the header (no compute: no GPU here)."""
+import ctypes
+import os
+import re
+
+from vers_amd import build as vbuild
+from vers_amd import capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def header_functions():
+    txt = open(os.path.join(ROOT, "include", "vers_hip.h")).read()
+    txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+    return sorted(set(re.findall(r"\b(vers_[a-z0-9_]+)\s*\(", txt)))
+
+
+def test_library_builds_and_exports_every_declared_symbol():
+    so = vbuild.build()
+    lib = ctypes.CDLL(so)
+    names = header_functions()
+    assert len(names) >= 10
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/vers_hip.h but not exported"
+
+
+def test_binding_table_matches_header():
+    assert sorted(capi.SIGNATURES) == header_functions()
+
+
+def test_status_codes_match_header():
+    txt = open(os.path.join(ROOT, "include", "vers_hip.h")).read()
+    for name, val in [("VERS_OK", capi.OK), ("VERS_ERR_INVALID", capi.ERR_INVALID), ("VERS_ERR_NAN", capi.ERR_NAN),
+                      ("VERS_ERR_INSUFFICIENT", capi.ERR_INSUFFICIENT), ("VERS_ERR_HIP", capi.ERR_HIP),
+                      ("VERS_ERR_EMPTY", capi.ERR_EMPTY), ("VERS_MAX_TOPK", capi.MAX_TOPK)]:
+        assert re.search(rf"#define {name} {val}\b", txt), name

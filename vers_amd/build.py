@@ -1,0 +1,73 @@
+"""Builds vers_amd/lib/libvers_hip.so (HIP, gfx950 only) in-tree with hipcc.
+
+hipcc cross-compiles without a GPU; the .so travels to the GPU box with the repo snapshot.
+"""
+from __future__ import annotations
+
+import os
+import shutil
+import subprocess
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(_HERE, "csrc")
+LIBDIR = os.path.join(_HERE, "lib")
+OBJDIR = os.path.join(_HERE, "build")
+LIB = os.path.join(LIBDIR, "libvers_hip.so")
+
+ARCH = "gfx950"
+# -ffp-contract=off: the reference rounds every product and sum separately (no FMA); see csrc/scan.cuh
+CXXFLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", f"--offload-arch={ARCH}",
+            "-Wall", "-Wno-unused-function"]
+
+
+def _hipcc() -> str:
+    for c in (shutil.which("hipcc"), "/opt/rocm/bin/hipcc"):
+        if c and os.path.exists(c):
+            return c
+    raise RuntimeError("hipcc not found: libvers_hip.so cannot be built")
+
+
+def sources():
+    return sorted(f for f in os.listdir(CSRC) if f.endswith(".hip"))
+
+
+def _stale(target: str, deps) -> bool:
+    if not os.path.exists(target):
+        return True
+    t = os.path.getmtime(target)
+    return any(os.path.getmtime(d) > t for d in deps)
+
+
+def build(force: bool = False, verbose: bool = False) -> str:
+    os.makedirs(LIBDIR, exist_ok=True)
+    os.makedirs(OBJDIR, exist_ok=True)
+    hipcc = _hipcc()
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hpp", ".cuh", ".h"))]
+    headers.append(os.path.join(os.path.dirname(_HERE), "include", "vers_hip.h"))
+    objs = []
+    procs = []
+    for src in sources():
+        obj = os.path.join(OBJDIR, src[:-4] + ".o")
+        objs.append(obj)
+        if force or _stale(obj, [os.path.join(CSRC, src)] + headers):
+            cmd = [hipcc] + CXXFLAGS + ["-c", os.path.join(CSRC, src), "-o", obj]
+            if verbose:
+                print(" ".join(cmd))
+            procs.append((src, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)))
+    for src, p in procs:
+        out, _ = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {src}:\n{out}")
+        if verbose and out.strip():
+            print(out)
+    if force or procs or _stale(LIB, objs):
+        cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB] + objs
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return LIB
+
+
+if __name__ == "__main__":
+    import sys
+    print(build(force="--force" in sys.argv, verbose=True))

@@ -1,0 +1,127 @@
+"""ctypes binding of libvers_hip.so (include/vers_hip.h).  No CPU fallback: if the HIP
+library is missing this module raises at import of the symbol table."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libvers_hip.so")
+
+OK, ERR_INVALID, ERR_NAN, ERR_INSUFFICIENT, ERR_HIP, ERR_EMPTY = 0, 1, 2, 3, 4, 5
+METRIC_L2SQ, METRIC_COSDIST = 0, 1
+MAX_TOPK = 64
+
+
+class VersError(RuntimeError):
+    """A non-zero status from the C ABI.  The reference panics where status is NAN /
+    INSUFFICIENT / EMPTY; host wrappers re-raise to keep that behaviour."""
+
+    def __init__(self, status: int, msg: str):
+        super().__init__(f"vers status {status}: {msg}")
+        self.status = status
+
+
+_lib = None
+_fp, _u64p, _u32p, _vp = C.POINTER(C.c_float), C.POINTER(C.c_uint64), C.POINTER(C.c_uint32), C.c_void_p
+
+# name -> (restype, argtypes); one entry per declaration in include/vers_hip.h
+SIGNATURES = {
+    "vers_last_error": (C.c_char_p, []),
+    "vers_abi_version": (C.c_int32, []),
+    "vers_device_count": (C.c_int32, [C.POINTER(C.c_int32)]),
+    "vers_flat_create": (C.c_int32, [C.c_int32, C.c_uint32, C.POINTER(_vp)]),
+    "vers_flat_destroy": (C.c_int32, [_vp]),
+    "vers_flat_upload": (C.c_int32, [_vp, _vp, C.c_uint64, C.c_uint64]),
+    "vers_flat_adopt_dev": (C.c_int32, [_vp, _vp, C.c_uint64, C.c_uint64]),
+    "vers_flat_search": (C.c_int32, [_vp, _vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, _vp, _vp, _vp]),
+    "vers_flat_search_dev": (C.c_int32, [_vp, _vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, _vp, _vp, _vp, _vp]),
+    "vers_flat_poll": (C.c_int32, [_vp, _vp]),
+    "vers_flat_last_scan_ms": (C.c_int32, [_vp, C.POINTER(C.c_float)]),
+}
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise ImportError(f"{LIB_PATH} is missing: build it with `python -m vers_amd.build` "
+                              "(there is no CPU fallback for this path)")
+        L = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(L, name)
+            fn.restype, fn.argtypes = res, args
+        _lib = L
+    return _lib
+
+
+def check(status: int):
+    if status != OK:
+        raise VersError(status, lib().vers_last_error().decode("utf-8", "replace"))
+
+
+def device_count() -> int:
+    n = C.c_int32(0)
+    check(lib().vers_device_count(C.byref(n)))
+    return n.value
+
+
+def _ptr(a):
+    return a.ctypes.data_as(_vp)
+
+
+class FlatCorpus:
+    """Brute-force scan over rows in HBM -- utils::search_exhaustive (utils.rs:68-82)."""
+
+    def __init__(self, d: int, device: int = 0):
+        self.d = int(d)
+        self._h = _vp()
+        check(lib().vers_flat_create(device, self.d, C.byref(self._h)))
+        self._keep = None
+
+    def close(self):
+        if self._h:
+            lib().vers_flat_destroy(self._h)
+            self._h = _vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def upload(self, rows: np.ndarray):
+        rows = np.asarray(rows, dtype=np.float32)
+        assert rows.ndim == 2 and rows.shape[1] == self.d and rows.strides[1] == 4
+        check(lib().vers_flat_upload(self._h, _ptr(rows), rows.shape[0], rows.strides[0] if rows.shape[0] else 4 * self.d))
+        self.n = rows.shape[0]
+
+    def adopt_dev(self, data_ptr: int, n: int, ld: int, keep=None):
+        check(lib().vers_flat_adopt_dev(self._h, _vp(data_ptr), n, ld))
+        self._keep = keep
+        self.n = n
+
+    def search(self, queries: np.ndarray, top_k: int, metric: int = METRIC_L2SQ):
+        """-> (ids [b, top_k] u64, dist [b, top_k] f32, count [b] u32); rows beyond count are unspecified."""
+        q = np.ascontiguousarray(np.atleast_2d(queries), dtype=np.float32)
+        b = q.shape[0]
+        ids = np.zeros((b, max(top_k, 1)), dtype=np.uint64)
+        dist = np.zeros((b, max(top_k, 1)), dtype=np.float32)
+        cnt = np.zeros(b, dtype=np.uint32)
+        check(lib().vers_flat_search(self._h, _ptr(q), q.strides[0], b, top_k, metric, _ptr(ids), _ptr(dist), _ptr(cnt)))
+        return ids[:, :top_k], dist[:, :top_k], cnt
+
+    def search_dev(self, q_ptr: int, ldq: int, b: int, top_k: int, metric: int, ids_ptr: int, dist_ptr: int,
+                   cnt_ptr: int, stream: int = 0):
+        check(lib().vers_flat_search_dev(self._h, _vp(q_ptr), ldq, b, top_k, metric, _vp(ids_ptr), _vp(dist_ptr),
+                                         _vp(cnt_ptr), _vp(stream)))
+
+    def poll(self, stream: int = 0):
+        check(lib().vers_flat_poll(self._h, _vp(stream)))
+
+    def last_scan_ms(self) -> float:
+        ms = C.c_float(0)
+        check(lib().vers_flat_last_scan_ms(self._h, C.byref(ms)))
+        return ms.value

@@ -1,0 +1,38 @@
+// Shared declarations for libvers_hip.so (MI355X / gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include <string>
+
+#include "../../include/vers_hip.h"
+
+namespace vers {
+
+// ---- error plumbing (thread-local message behind vers_last_error) ----------
+void set_error(const std::string& msg);
+int32_t fail(int32_t status, const std::string& msg);
+
+#define VERS_HIP_TRY(expr)                                                                     \
+  do {                                                                                         \
+    hipError_t _e = (expr);                                                                    \
+    if (_e != hipSuccess)                                                                      \
+      return ::vers::fail(VERS_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(_e));    \
+  } while (0)
+
+// ---- geometry of the scan engine (scan.hip) ---------------------------------
+constexpr int kWave = 64;        // CDNA4 wavefront
+constexpr int kChunk = 64;       // f32 columns staged per step (256 B per row)
+constexpr int kLdsStride = 68;   // 64 + 4: 4*odd dwords -> conflict-free ds_read_b128 by row
+constexpr int kWavesPerBlock = 4;
+constexpr int kMaxTopK = 64;     // one sorted key per lane
+
+constexpr uint64_t kKeyMax = 0xFFFFFFFFFFFFFFFFull;
+
+inline uint32_t round_up(uint32_t x, uint32_t m) { return (x + m - 1) / m * m; }
+inline uint64_t round_up64(uint64_t x, uint64_t m) { return (x + m - 1) / m * m; }
+
+// Device-side view of the result of a scan: `k` ascending keys per slot.
+// key = (order-preserving f32 bits << 32) | seq, seq = tie-break position.
+
+}  // namespace vers

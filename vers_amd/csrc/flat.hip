@@ -1,0 +1,361 @@
+// flat.hip -- brute-force scan behind vers_flat_* (replaces utils::search_exhaustive,
+// /root/reference/vers/src/utils.rs:68-82).
+#include <mutex>
+#include <new>
+#include <vector>
+
+#include "scan.cuh"
+
+namespace vers {
+
+// item = (row segment, query group).  slot(q, seg) = q * n_segs + seg.
+template <int QG, bool SEQ_IDS>
+struct FlatSrc {
+  static constexpr bool kSeqIds = SEQ_IDS;
+  const float* rows;
+  uint64_t n;
+  uint32_t ld;
+  uint32_t seg_rows, n_segs;
+  const float* queries;  // QG == 1: [b][ldq]; else interleaved blocks [ceil(b/QG)][ldq][QG]; zero padded
+  uint32_t ldq, b;
+  uint64_t* partials;
+  uint32_t k;
+  const uint32_t* ids;  // SEQ_IDS: row -> seq (vec ids of a permuted corpus)
+
+  __device__ __forceinline__ uint32_t n_items() const { return n_segs * ((b + QG - 1) / QG); }
+  __device__ __forceinline__ void get(uint32_t it, ItemView<QG>& v) const {
+    const uint32_t seg = it % n_segs, qg = it / n_segs;
+    const uint64_t row0 = (uint64_t)seg * seg_rows;
+    v.rows = rows + row0 * ld;
+    v.nrows = (uint32_t)((n - row0 < seg_rows) ? (n - row0) : seg_rows);
+    const uint32_t q0 = qg * QG;
+    v.nq = (b - q0 < (uint32_t)QG) ? (b - q0) : QG;
+    v.qb = queries + (uint64_t)qg * ldq * QG;
+  }
+  __device__ __forceinline__ uint32_t seq_base(uint32_t it, int) const { return (it % n_segs) * seg_rows; }
+  __device__ __forceinline__ const uint32_t* seq_ids(uint32_t it) const { return ids + (uint64_t)(it % n_segs) * seg_rows; }
+  __device__ __forceinline__ uint64_t* out(uint32_t it, int qi) const {
+    const uint32_t seg = it % n_segs, qg = it / n_segs;
+    return partials + ((uint64_t)(qg * QG + qi) * n_segs + seg) * k;
+  }
+};
+
+// one wave per query: top-k of its n_segs partial slots -> (id, dist)
+__global__ __launch_bounds__(kWave) void flat_merge_kernel(const uint64_t* partials, uint32_t n_segs, uint32_t k,
+                                                           uint64_t n, uint64_t* out_ids, float* out_dist,
+                                                           uint32_t* out_count) {
+  const int lane = threadIdx.x;
+  const uint32_t q = blockIdx.x;
+  uint64_t list = wave_merge_keys(partials + (uint64_t)q * n_segs * k, n_segs * k, k, lane);
+  const uint32_t cnt = n < k ? (uint32_t)n : k;
+  if (lane < (int)cnt) {
+    out_ids[(uint64_t)q * k + lane] = (uint32_t)list;
+    out_dist[(uint64_t)q * k + lane] = __uint_as_float(order_bits_to_f32_bits((uint32_t)(list >> 32)));
+  }
+  if (lane == 0) out_count[q] = cnt;
+}
+
+// queries [b][ld_in] (first d valid) -> blocks of qg queries, out[(g*ld_out + j)*qg + qi], zero padded
+// (qg == 1: plain [b][ld_out]).
+__global__ void stage_queries_kernel(const float* in, uint64_t ld_in, uint32_t d, float* out, uint32_t ld_out, uint32_t b,
+                                     uint32_t qg) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t n_groups = (b + qg - 1) / qg;
+  if (i >= (uint64_t)n_groups * ld_out * qg) return;
+  const uint32_t qi = (uint32_t)(i % qg);
+  const uint32_t j = (uint32_t)((i / qg) % ld_out);
+  const uint32_t q = (uint32_t)(i / ((uint64_t)qg * ld_out)) * qg + qi;
+  out[i] = (j < d && q < b) ? in[(uint64_t)q * ld_in + j] : 0.0f;
+}
+
+}  // namespace vers
+
+using namespace vers;
+
+struct vers_flat {
+  int device = 0;
+  uint32_t d = 0, ld = 0;
+  uint64_t n = 0;
+  float* rows = nullptr;
+  bool owned = false;
+  int n_cu = 256;
+  // workspace (grown on demand, never inside a steady-state call)
+  float* q_stage = nullptr;
+  size_t q_stage_cap = 0;
+  float* zero_q = nullptr;
+  uint32_t zero_q_len = 0;
+  uint64_t* partials = nullptr;
+  size_t partials_cap = 0;
+  uint32_t* status_dev = nullptr;
+  uint64_t* o_ids = nullptr;
+  float* o_dist = nullptr;
+  uint32_t* o_cnt = nullptr;
+  size_t o_cap = 0;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  bool ev_valid = false;
+  std::mutex mu;
+};
+
+namespace {
+
+struct DeviceGuard {
+  int prev = 0;
+  explicit DeviceGuard(int dev) {
+    (void)hipGetDevice(&prev);
+    if (prev != dev) (void)hipSetDevice(dev);
+  }
+  ~DeviceGuard() { (void)hipSetDevice(prev); }
+};
+
+template <class T>
+int32_t grow(T*& p, size_t& cap, size_t need) {
+  if (need <= cap) return VERS_OK;
+  if (p) VERS_HIP_TRY(hipFree(p));
+  p = nullptr;
+  cap = 0;
+  VERS_HIP_TRY(hipMalloc((void**)&p, need * sizeof(T)));
+  cap = need;
+  return VERS_OK;
+}
+
+template <int QG, int METRIC>
+int32_t launch_flat_scan(vers_flat* h, const FlatSrc<QG, false>& src, uint32_t n_items, hipStream_t st) {
+  ScanParams p;
+  p.ld = h->ld;
+  p.n_chunks = (h->ld + kChunk - 1) / kChunk;
+  p.k = src.k;
+  p.status = h->status_dev;
+  const uint32_t max_blocks = (uint32_t)h->n_cu * 2u;
+  uint32_t blocks = (n_items + kWavesPerBlock - 1) / kWavesPerBlock;
+  if (blocks > max_blocks) blocks = max_blocks;
+  if (blocks == 0) blocks = 1;
+  const size_t lds = (size_t)kWavesPerBlock * kWave * kLdsStride * sizeof(float);
+  VERS_HIP_TRY(hipEventRecord(h->ev0, st));
+  hipLaunchKernelGGL((scan_kernel<QG, METRIC, FlatSrc<QG, false>>), dim3(blocks), dim3(kWave * kWavesPerBlock), lds, st, src, p);
+  VERS_HIP_TRY(hipGetLastError());
+  VERS_HIP_TRY(hipEventRecord(h->ev1, st));
+  h->ev_valid = true;
+  return VERS_OK;
+}
+
+int32_t flat_search_dev_locked(vers_flat* h, const float* q_dev, uint64_t ldq, uint32_t b, uint32_t top_k,
+                               uint32_t metric, uint64_t* out_ids, float* out_dist, uint32_t* out_count,
+                               hipStream_t st) {
+  if (b == 0) return VERS_OK;
+  if (top_k == 0) {
+    VERS_HIP_TRY(hipMemsetAsync(out_count, 0, sizeof(uint32_t) * b, st));
+    return VERS_OK;
+  }
+  const uint32_t ldq_pad = round_up(h->ld, kChunk);
+  const int QG = b == 1 ? 1 : 8;
+  const uint32_t n_qg = (b + QG - 1) / QG;
+  // queries: a single query is used in place when it is chunk-padded by construction; otherwise
+  // stage a zero padded (QG > 1: interleaved) copy
+  const float* q = q_dev;
+  uint32_t ldq_use = (uint32_t)ldq;
+  if (!(QG == 1 && h->d % kChunk == 0)) {
+    const uint64_t tot = (uint64_t)n_qg * ldq_pad * QG;
+    if (int32_t rc = grow(h->q_stage, h->q_stage_cap, (size_t)tot)) return rc;
+    hipLaunchKernelGGL(stage_queries_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, q_dev, ldq, h->d,
+                       h->q_stage, ldq_pad, b, (uint32_t)QG);
+    VERS_HIP_TRY(hipGetLastError());
+    q = h->q_stage;
+    ldq_use = ldq_pad;
+  }
+  // one item per resident wave when possible (static balance), at least one 64-row tile each
+  const uint32_t target_items = (uint32_t)h->n_cu * 8u;
+  uint64_t per = (h->n * n_qg + target_items - 1) / target_items;
+  uint32_t seg_rows = (uint32_t)round_up64(per ? per : 1, kWave);
+  uint32_t n_segs = (uint32_t)((h->n + seg_rows - 1) / seg_rows);
+  if (n_segs == 0) n_segs = 1;
+  if (int32_t rc = grow(h->partials, h->partials_cap, (size_t)b * n_segs * top_k)) return rc;
+  const uint32_t n_items = n_segs * n_qg;
+
+  auto fill = [&](auto& src) {
+    src.rows = h->rows; src.n = h->n; src.ld = h->ld; src.seg_rows = seg_rows; src.n_segs = n_segs;
+    src.queries = q; src.ldq = ldq_use; src.b = b; src.partials = h->partials;
+    src.k = top_k; src.ids = nullptr;
+  };
+  int32_t rc;
+  if (QG == 1) {
+    FlatSrc<1, false> src; fill(src);
+    rc = metric == VERS_METRIC_L2SQ ? launch_flat_scan<1, 0>(h, src, n_items, st) : launch_flat_scan<1, 1>(h, src, n_items, st);
+  } else {
+    FlatSrc<8, false> src; fill(src);
+    rc = metric == VERS_METRIC_L2SQ ? launch_flat_scan<8, 0>(h, src, n_items, st) : launch_flat_scan<8, 1>(h, src, n_items, st);
+  }
+  if (rc) return rc;
+  hipLaunchKernelGGL(flat_merge_kernel, dim3(b), dim3(kWave), 0, st, h->partials, n_segs, top_k, h->n, out_ids, out_dist,
+                     out_count);
+  VERS_HIP_TRY(hipGetLastError());
+  return VERS_OK;
+}
+
+int32_t check_args(vers_flat* h, uint32_t top_k, uint32_t metric) {
+  if (!h) return fail(VERS_ERR_INVALID, "null handle");
+  if (top_k > VERS_MAX_TOPK) return fail(VERS_ERR_INVALID, "top_k > VERS_MAX_TOPK (64) is not supported");
+  if (metric > VERS_METRIC_COSDIST) return fail(VERS_ERR_INVALID, "unknown metric");
+  if (h->n > 0xFFFFFFFFull) return fail(VERS_ERR_INVALID, "more than 2^32-1 rows per handle");
+  return VERS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t vers_flat_create(int32_t device, uint32_t d, vers_flat_t** out) {
+  if (!out || d == 0) return fail(VERS_ERR_INVALID, "vers_flat_create: bad arguments");
+  int cnt = 0;
+  VERS_HIP_TRY(hipGetDeviceCount(&cnt));
+  if (device < 0 || device >= cnt) return fail(VERS_ERR_INVALID, "vers_flat_create: no such device");
+  DeviceGuard g(device);
+  vers_flat* h = new (std::nothrow) vers_flat();
+  if (!h) return fail(VERS_ERR_INVALID, "out of host memory");
+  h->device = device;
+  h->d = d;
+  h->ld = round_up(d, 4);
+  hipDeviceProp_t prop;
+  VERS_HIP_TRY(hipGetDeviceProperties(&prop, device));
+  h->n_cu = prop.multiProcessorCount;
+  h->zero_q_len = round_up(h->ld, kChunk);
+  VERS_HIP_TRY(hipMalloc((void**)&h->zero_q, h->zero_q_len * sizeof(float)));
+  VERS_HIP_TRY(hipMemset(h->zero_q, 0, h->zero_q_len * sizeof(float)));
+  VERS_HIP_TRY(hipMalloc((void**)&h->status_dev, 16));
+  VERS_HIP_TRY(hipMemset(h->status_dev, 0, 16));
+  VERS_HIP_TRY(hipEventCreate(&h->ev0));
+  VERS_HIP_TRY(hipEventCreate(&h->ev1));
+  *out = h;
+  return VERS_OK;
+}
+
+int32_t vers_flat_destroy(vers_flat_t* h) {
+  if (!h) return VERS_OK;
+  DeviceGuard g(h->device);
+  (void)hipDeviceSynchronize();
+  if (h->owned && h->rows) (void)hipFree(h->rows);
+  for (void* p : {(void*)h->q_stage, (void*)h->zero_q, (void*)h->partials, (void*)h->status_dev, (void*)h->o_ids,
+                  (void*)h->o_dist, (void*)h->o_cnt})
+    if (p) (void)hipFree(p);
+  if (h->ev0) (void)hipEventDestroy(h->ev0);
+  if (h->ev1) (void)hipEventDestroy(h->ev1);
+  delete h;
+  return VERS_OK;
+}
+
+int32_t vers_flat_upload(vers_flat_t* h, const float* rows, uint64_t n, uint64_t row_stride_bytes) {
+  if (!h || (n && !rows) || row_stride_bytes < (uint64_t)h->d * 4 || row_stride_bytes % 4)
+    return fail(VERS_ERR_INVALID, "vers_flat_upload: bad arguments");
+  if (n > 0xFFFFFFFFull) return fail(VERS_ERR_INVALID, "more than 2^32-1 rows per handle");
+  std::lock_guard<std::mutex> lk(h->mu);
+  DeviceGuard g(h->device);
+  if (h->owned && h->rows) VERS_HIP_TRY(hipFree(h->rows));
+  h->rows = nullptr; h->n = 0; h->owned = true;
+  if (n == 0) return VERS_OK;
+  VERS_HIP_TRY(hipMalloc((void**)&h->rows, n * h->ld * sizeof(float)));
+  if (h->ld != h->d) VERS_HIP_TRY(hipMemset(h->rows, 0, n * h->ld * sizeof(float)));
+  VERS_HIP_TRY(hipMemcpy2D(h->rows, (size_t)h->ld * 4, rows, row_stride_bytes, (size_t)h->d * 4, n, hipMemcpyHostToDevice));
+  h->n = n;
+  return VERS_OK;
+}
+
+int32_t vers_flat_adopt_dev(vers_flat_t* h, const float* rows_dev, uint64_t n, uint64_t ld_floats) {
+  if (!h || (n && !rows_dev) || ld_floats < h->d || ld_floats % 4 || ld_floats > 0x3FFFFFFFull)
+    return fail(VERS_ERR_INVALID, "vers_flat_adopt_dev: bad arguments");
+  if (n > 0xFFFFFFFFull) return fail(VERS_ERR_INVALID, "more than 2^32-1 rows per handle");
+  std::lock_guard<std::mutex> lk(h->mu);
+  DeviceGuard g(h->device);
+  if (h->owned && h->rows) VERS_HIP_TRY(hipFree(h->rows));
+  h->rows = const_cast<float*>(rows_dev);
+  h->owned = false;
+  h->n = n;
+  if ((uint32_t)ld_floats != h->ld) {
+    h->ld = (uint32_t)ld_floats;
+    const uint32_t zl = round_up(h->ld, kChunk);
+    if (zl > h->zero_q_len) {
+      VERS_HIP_TRY(hipFree(h->zero_q));
+      VERS_HIP_TRY(hipMalloc((void**)&h->zero_q, zl * sizeof(float)));
+      VERS_HIP_TRY(hipMemset(h->zero_q, 0, zl * sizeof(float)));
+      h->zero_q_len = zl;
+    }
+  }
+  return VERS_OK;
+}
+
+int32_t vers_flat_search_dev(vers_flat_t* h, const float* queries_dev, uint64_t ldq_floats, uint32_t b, uint32_t top_k,
+                             uint32_t metric, uint64_t* out_ids_dev, float* out_dist_dev, uint32_t* out_count_dev,
+                             void* stream) {
+  if (int32_t rc = check_args(h, top_k, metric)) return rc;
+  if (b && (!queries_dev || ldq_floats < h->d || !out_count_dev || (top_k && (!out_ids_dev || !out_dist_dev))))
+    return fail(VERS_ERR_INVALID, "vers_flat_search_dev: bad arguments");
+  std::lock_guard<std::mutex> lk(h->mu);
+  DeviceGuard g(h->device);
+  return flat_search_dev_locked(h, queries_dev, ldq_floats, b, top_k, metric, out_ids_dev, out_dist_dev, out_count_dev,
+                                (hipStream_t)stream);
+}
+
+int32_t vers_flat_poll(vers_flat_t* h, void* stream) {
+  if (!h) return fail(VERS_ERR_INVALID, "null handle");
+  DeviceGuard g(h->device);
+  uint32_t st = 0;
+  VERS_HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+  VERS_HIP_TRY(hipMemcpy(&st, h->status_dev, sizeof(st), hipMemcpyDeviceToHost));
+  if (st) {
+    VERS_HIP_TRY(hipMemset(h->status_dev, 0, sizeof(st)));
+    if (st & 1u) return fail(VERS_ERR_NAN, "NaN distance (the reference panics in partial_cmp().unwrap())");
+  }
+  return VERS_OK;
+}
+
+int32_t vers_flat_search(vers_flat_t* h, const float* queries, uint64_t q_stride_bytes, uint32_t b, uint32_t top_k,
+                         uint32_t metric, uint64_t* out_ids, float* out_dist, uint32_t* out_count) {
+  if (int32_t rc = check_args(h, top_k, metric)) return rc;
+  if (b && (!queries || q_stride_bytes < (uint64_t)h->d * 4 || q_stride_bytes % 4 || !out_count ||
+            (top_k && (!out_ids || !out_dist))))
+    return fail(VERS_ERR_INVALID, "vers_flat_search: bad arguments");
+  if (b == 0) return VERS_OK;
+  std::lock_guard<std::mutex> lk(h->mu);
+  DeviceGuard g(h->device);
+  const uint32_t ldq_pad = round_up(h->ld, kChunk);
+  float* qd = nullptr;
+  VERS_HIP_TRY(hipMalloc((void**)&qd, (size_t)b * ldq_pad * sizeof(float)));
+  int32_t rc = VERS_OK;
+  do {
+    if (hipMemset(qd, 0, (size_t)b * ldq_pad * sizeof(float)) != hipSuccess ||
+        hipMemcpy2D(qd, (size_t)ldq_pad * 4, queries, q_stride_bytes, (size_t)h->d * 4, b, hipMemcpyHostToDevice) != hipSuccess) {
+      rc = fail(VERS_ERR_HIP, "query upload failed");
+      break;
+    }
+    const size_t need = (size_t)b * (top_k ? top_k : 1);
+    if (need > h->o_cap) {
+      size_t c0 = h->o_cap, c1 = h->o_cap, c2 = h->o_cap;
+      if ((rc = grow(h->o_ids, c0, need)) || (rc = grow(h->o_dist, c1, need)) || (rc = grow(h->o_cnt, c2, need))) break;
+      h->o_cap = need;
+    }
+    rc = flat_search_dev_locked(h, qd, ldq_pad, b, top_k, metric, h->o_ids, h->o_dist, h->o_cnt, nullptr);
+    if (rc) break;
+    rc = vers_flat_poll(h, nullptr);
+    if (rc) break;
+    if (top_k) {
+      if (hipMemcpy(out_ids, h->o_ids, need * sizeof(uint64_t), hipMemcpyDeviceToHost) != hipSuccess ||
+          hipMemcpy(out_dist, h->o_dist, need * sizeof(float), hipMemcpyDeviceToHost) != hipSuccess) {
+        rc = fail(VERS_ERR_HIP, "result download failed");
+        break;
+      }
+    }
+    if (hipMemcpy(out_count, h->o_cnt, b * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess)
+      rc = fail(VERS_ERR_HIP, "result download failed");
+  } while (0);
+  (void)hipFree(qd);
+  return rc;
+}
+
+int32_t vers_flat_last_scan_ms(vers_flat_t* h, float* out_ms) {
+  if (!h || !out_ms) return fail(VERS_ERR_INVALID, "bad arguments");
+  if (!h->ev_valid) return fail(VERS_ERR_INVALID, "no scan has been launched on this handle");
+  DeviceGuard g(h->device);
+  VERS_HIP_TRY(hipEventSynchronize(h->ev1));
+  VERS_HIP_TRY(hipEventElapsedTime(out_ms, h->ev0, h->ev1));
+  return VERS_OK;
+}
+
+}  // extern "C"
