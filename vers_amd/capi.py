@@ -110,7 +110,7 @@ class FlatCorpus:
         ids = np.zeros((b, max(top_k, 1)), dtype=np.uint64)
         dist = np.zeros((b, max(top_k, 1)), dtype=np.float32)
         cnt = np.zeros(b, dtype=np.uint32)
-        check(lib().vers_flat_search(self._h, _ptr(q), q.strides[0], b, top_k, metric, _ptr(ids), _ptr(dist), _ptr(cnt)))
+        check(lib().vers_flat_search(self._h, _ptr(q), 4 * q.shape[1], b, top_k, metric, _ptr(ids), _ptr(dist), _ptr(cnt)))
         return ids[:, :top_k], dist[:, :top_k], cnt
 
     def search_dev(self, q_ptr: int, ldq: int, b: int, top_k: int, metric: int, ids_ptr: int, dist_ptr: int,

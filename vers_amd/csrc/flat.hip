@@ -40,13 +40,15 @@ struct FlatSrc {
   }
 };
 
-// one wave per query: top-k of its n_segs partial slots -> (id, dist)
-__global__ __launch_bounds__(kWave) void flat_merge_kernel(const uint64_t* partials, uint32_t n_segs, uint32_t k,
-                                                           uint64_t n, uint64_t* out_ids, float* out_dist,
-                                                           uint32_t* out_count) {
-  const int lane = threadIdx.x;
+// one block per query: top-k of its n_segs partial slots -> (id, dist)
+__global__ __launch_bounds__(kWave * kMergeWaves) void flat_merge_kernel(const uint64_t* partials, uint32_t n_segs,
+                                                                         uint32_t k, uint64_t n, uint64_t* out_ids,
+                                                                         float* out_dist, uint32_t* out_count) {
+  __shared__ uint64_t sh[kMergeWaves][kWave];
   const uint32_t q = blockIdx.x;
-  uint64_t list = wave_merge_keys(partials + (uint64_t)q * n_segs * k, n_segs * k, k, lane);
+  uint64_t list = block_merge_keys(partials + (uint64_t)q * n_segs * k, n_segs * k, k, sh);
+  if (threadIdx.x >= kWave) return;
+  const int lane = threadIdx.x;
   const uint32_t cnt = n < k ? (uint32_t)n : k;
   if (lane < (int)cnt) {
     out_ids[(uint64_t)q * k + lane] = (uint32_t)list;
@@ -185,7 +187,7 @@ int32_t flat_search_dev_locked(vers_flat* h, const float* q_dev, uint64_t ldq, u
     rc = metric == VERS_METRIC_L2SQ ? launch_flat_scan<8, 0>(h, src, n_items, st) : launch_flat_scan<8, 1>(h, src, n_items, st);
   }
   if (rc) return rc;
-  hipLaunchKernelGGL(flat_merge_kernel, dim3(b), dim3(kWave), 0, st, h->partials, n_segs, top_k, h->n, out_ids, out_dist,
+  hipLaunchKernelGGL(flat_merge_kernel, dim3(b), dim3(kWave * kMergeWaves), 0, st, h->partials, n_segs, top_k, h->n, out_ids, out_dist,
                      out_count);
   VERS_HIP_TRY(hipGetLastError());
   return VERS_OK;

@@ -261,13 +261,31 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void scan_kernel(Src src, S
 }
 
 // ---- merge of partial slots ----------------------------------------------------
-// One wave per output group: folds `n_keys` keys (partials, kKeyMax padded) into
-// the top-k.  Used directly by the flat search; the IVF merge adds id mapping.
-__device__ __forceinline__ uint64_t wave_merge_keys(const uint64_t* keys, uint32_t n_keys, uint32_t k, int lane) {
+// One BLOCK of kMergeWaves waves per output group folds `n_keys` keys (partial slots,
+// kKeyMax padded) into the top-k: every wave folds a strided share with several
+// independent loads in flight (the loop is latency-bound otherwise), wave 0 then folds
+// the per-wave lists through LDS.  Returns the final list in wave 0 (other waves: junk).
+constexpr int kMergeWaves = 16;
+__device__ __forceinline__ uint64_t block_merge_keys(const uint64_t* keys, uint32_t n_keys, uint32_t k,
+                                                     uint64_t (*sh)[kWave]) {
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  constexpr int U = 4;
   uint64_t list = kKeyMax;
-  for (uint32_t i = 0; i < n_keys; i += kWave) {
-    uint64_t cand = (i + lane < n_keys) ? keys[i + lane] : kKeyMax;
-    wave_topk_update(list, k, cand, lane);
+  for (uint32_t base = wid * kWave; base < n_keys; base += kMergeWaves * kWave * U) {
+    uint64_t cand[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint32_t i = base + u * (kMergeWaves * kWave) + lane;
+      cand[u] = i < n_keys ? keys[i] : kKeyMax;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) wave_topk_update(list, k, cand[u], lane);
+  }
+  sh[wid][lane] = list;
+  __syncthreads();
+  if (wid == 0) {
+    for (int w = 1; w < kMergeWaves; ++w) wave_topk_update(list, k, sh[w][lane], lane);
   }
   return list;
 }
