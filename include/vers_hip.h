@@ -82,6 +82,28 @@ int32_t vers_flat_poll(vers_flat_t* h, void* stream);
  * (HIP events on the launch stream; synchronises on those events). */
 int32_t vers_flat_last_scan_ms(vers_flat_t* h, float* out_ms);
 
+/* ------------------------------------------------------------------------ *
+ * k-means primitives on host arrays (unit-test / integration surface; the   *
+ * index build below chains the same kernels without leaving the device).    *
+ * ------------------------------------------------------------------------ */
+/* IVFFlatIndex::assign_to_clusters (ivfflat.rs:29-46): out_assign[i] = FIRST
+ * argmin_c squared_euclidean(rows[i], centroids[c]).  out_min_dist (nullable)
+ * receives that minimum.  k == 0 with n > 0 -> VERS_ERR_EMPTY; NaN distance
+ * with k >= 2 -> VERS_ERR_NAN (the reference panics in both cases). */
+int32_t vers_kmeans_assign(int32_t device, const float* rows, uint64_t n, uint64_t row_stride_bytes,
+                           const float* centroids, uint64_t k, uint64_t c_stride_bytes, uint32_t d,
+                           uint64_t* out_assign, float* out_min_dist);
+/* IVFFlatIndex::update_centroids (ivfflat.rs:47-71): per cluster the f32 sum
+ * of its members in ascending row order divided by the count; empty cluster
+ * -> zero vector.  out_centroids is packed [k * d]. */
+int32_t vers_kmeans_update(int32_t device, const float* rows, uint64_t n, uint64_t row_stride_bytes,
+                           const uint64_t* assign, uint64_t k, uint32_t d, float* out_centroids);
+/* IVFFlatIndex::calculate_kmeans_cost (ivfflat.rs:138-149): left-to-right f32
+ * fold of squared_euclidean(rows[i], centroids[assign[i]]). */
+int32_t vers_kmeans_cost(int32_t device, const float* rows, uint64_t n, uint64_t row_stride_bytes,
+                         const float* centroids, uint64_t k, uint64_t c_stride_bytes, const uint64_t* assign,
+                         uint32_t d, float* out_cost);
+
 #ifdef __cplusplus
 }
 #endif

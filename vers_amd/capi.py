@@ -40,6 +40,10 @@ SIGNATURES = {
     "vers_flat_search_dev": (C.c_int32, [_vp, _vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, _vp, _vp, _vp, _vp]),
     "vers_flat_poll": (C.c_int32, [_vp, _vp]),
     "vers_flat_last_scan_ms": (C.c_int32, [_vp, C.POINTER(C.c_float)]),
+    "vers_kmeans_assign": (C.c_int32, [C.c_int32, _vp, C.c_uint64, C.c_uint64, _vp, C.c_uint64, C.c_uint64, C.c_uint32, _vp, _vp]),
+    "vers_kmeans_update": (C.c_int32, [C.c_int32, _vp, C.c_uint64, C.c_uint64, _vp, C.c_uint64, C.c_uint32, _vp]),
+    "vers_kmeans_cost": (C.c_int32, [C.c_int32, _vp, C.c_uint64, C.c_uint64, _vp, C.c_uint64, C.c_uint64, _vp, C.c_uint32,
+                                     C.POINTER(C.c_float)]),
 }
 
 
@@ -125,3 +129,37 @@ class FlatCorpus:
         ms = C.c_float(0)
         check(lib().vers_flat_last_scan_ms(self._h, C.byref(ms)))
         return ms.value
+
+
+# ---- k-means primitives (ivfflat.rs:29-71,138-149) -----------------------------------------
+def _rows(a):
+    a = np.asarray(a, dtype=np.float32)
+    if a.ndim != 2 or (a.shape[0] and a.strides[1] != 4):
+        a = np.ascontiguousarray(a, dtype=np.float32)
+    return a, (a.strides[0] if a.shape[0] > 1 else 4 * a.shape[1])
+
+
+def kmeans_assign(X, Cn, device: int = 0, want_min_dist: bool = False):
+    X, sx = _rows(X); Cn, sc = _rows(Cn)
+    out = np.zeros(X.shape[0], dtype=np.uint64)
+    md = np.zeros(X.shape[0], dtype=np.float32) if want_min_dist else None
+    check(lib().vers_kmeans_assign(device, _ptr(X), X.shape[0], sx, _ptr(Cn), Cn.shape[0], sc, X.shape[1], _ptr(out),
+                                   _ptr(md) if want_min_dist else None))
+    return (out, md) if want_min_dist else out
+
+
+def kmeans_update(X, assign, k: int, device: int = 0):
+    X, sx = _rows(X)
+    assign = np.ascontiguousarray(assign, dtype=np.uint64)
+    out = np.zeros((k, X.shape[1]), dtype=np.float32)
+    check(lib().vers_kmeans_update(device, _ptr(X), X.shape[0], sx, _ptr(assign), k, X.shape[1], _ptr(out)))
+    return out
+
+
+def kmeans_cost(X, Cn, assign, device: int = 0) -> np.float32:
+    X, sx = _rows(X); Cn, sc = _rows(Cn)
+    assign = np.ascontiguousarray(assign, dtype=np.uint64)
+    out = C.c_float(0)
+    check(lib().vers_kmeans_cost(device, _ptr(X), X.shape[0], sx, _ptr(Cn), Cn.shape[0], sc, _ptr(assign), X.shape[1],
+                                 C.byref(out)))
+    return np.float32(out.value)

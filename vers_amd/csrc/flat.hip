@@ -5,6 +5,7 @@
 #include <vector>
 
 #include "scan.cuh"
+#include "util.cuh"
 
 namespace vers {
 
@@ -57,19 +58,6 @@ __global__ __launch_bounds__(kWave * kMergeWaves) void flat_merge_kernel(const u
   if (lane == 0) out_count[q] = cnt;
 }
 
-// queries [b][ld_in] (first d valid) -> blocks of qg queries, out[(g*ld_out + j)*qg + qi], zero padded
-// (qg == 1: plain [b][ld_out]).
-__global__ void stage_queries_kernel(const float* in, uint64_t ld_in, uint32_t d, float* out, uint32_t ld_out, uint32_t b,
-                                     uint32_t qg) {
-  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const uint32_t n_groups = (b + qg - 1) / qg;
-  if (i >= (uint64_t)n_groups * ld_out * qg) return;
-  const uint32_t qi = (uint32_t)(i % qg);
-  const uint32_t j = (uint32_t)((i / qg) % ld_out);
-  const uint32_t q = (uint32_t)(i / ((uint64_t)qg * ld_out)) * qg + qi;
-  out[i] = (j < d && q < b) ? in[(uint64_t)q * ld_in + j] : 0.0f;
-}
-
 }  // namespace vers
 
 using namespace vers;
@@ -99,26 +87,6 @@ struct vers_flat {
 };
 
 namespace {
-
-struct DeviceGuard {
-  int prev = 0;
-  explicit DeviceGuard(int dev) {
-    (void)hipGetDevice(&prev);
-    if (prev != dev) (void)hipSetDevice(dev);
-  }
-  ~DeviceGuard() { (void)hipSetDevice(prev); }
-};
-
-template <class T>
-int32_t grow(T*& p, size_t& cap, size_t need) {
-  if (need <= cap) return VERS_OK;
-  if (p) VERS_HIP_TRY(hipFree(p));
-  p = nullptr;
-  cap = 0;
-  VERS_HIP_TRY(hipMalloc((void**)&p, need * sizeof(T)));
-  cap = need;
-  return VERS_OK;
-}
 
 template <int QG, int METRIC>
 int32_t launch_flat_scan(vers_flat* h, const FlatSrc<QG, false>& src, uint32_t n_items, hipStream_t st) {
@@ -158,9 +126,7 @@ int32_t flat_search_dev_locked(vers_flat* h, const float* q_dev, uint64_t ldq, u
   if (!(QG == 1 && h->d % kChunk == 0)) {
     const uint64_t tot = (uint64_t)n_qg * ldq_pad * QG;
     if (int32_t rc = grow(h->q_stage, h->q_stage_cap, (size_t)tot)) return rc;
-    hipLaunchKernelGGL(stage_queries_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, st, q_dev, ldq, h->d,
-                       h->q_stage, ldq_pad, b, (uint32_t)QG);
-    VERS_HIP_TRY(hipGetLastError());
+    if (int32_t rc = launch_stage_queries(q_dev, ldq, h->d, h->q_stage, ldq_pad, b, (uint32_t)QG, st)) return rc;
     q = h->q_stage;
     ldq_use = ldq_pad;
   }

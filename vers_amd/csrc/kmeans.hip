@@ -1,0 +1,365 @@
+// kmeans.hip -- the k-means steps of IVFFlatIndex::build_index on the device
+// (reference: /root/reference/vers/src/indexes/ivfflat.rs:29-100,138-149).
+//
+// Every step keeps the reference's arithmetic ORDER, so results are bit-identical:
+//   assign : per (point, centroid) the sequential f32 sum of (c-x)^2 -- the scan engine with the
+//            centroid matrix as the "corpus" (lane == centroid) and 8 points per wave as uniform
+//            operands; first-minimum tie rule through the (dist, centroid index) key; top-1.
+//   update : per (cluster, column) the sum over members in ascending point index, then / count.
+//   cost   : strict left-to-right fold of the per-point minimum distances (one lane: the fold is
+//            inherently serial; it reads 4 bytes per point and is ~1e-3 of an assign pass).
+#include <mutex>
+#include <vector>
+
+#include "kmeans.hpp"
+#include "scan.cuh"
+#include "util.cuh"
+
+namespace vers {
+
+int32_t DevBuf::reserve(size_t bytes) {
+  if (bytes <= cap) return VERS_OK;
+  release();
+  VERS_HIP_TRY(hipMalloc(&p, bytes));
+  cap = bytes;
+  return VERS_OK;
+}
+void DevBuf::release() {
+  if (p) (void)hipFree(p);
+  p = nullptr;
+  cap = 0;
+}
+
+// ---- assign -------------------------------------------------------------------------
+template <int QG>
+struct AssignSrc {
+  static constexpr bool kSeqIds = false;
+  const float* C;
+  uint32_t k;
+  const float* qblocks;  // [ceil(nb/QG)][ldq][QG]
+  uint32_t ldq, nb;
+  uint64_t* keys;  // [nb]
+  __device__ __forceinline__ uint32_t n_items() const { return (nb + QG - 1) / QG; }
+  __device__ __forceinline__ void get(uint32_t it, ItemView<QG>& v) const {
+    v.rows = C;
+    v.nrows = k;
+    v.nq = (nb - it * QG < (uint32_t)QG) ? (nb - it * QG) : QG;
+    v.qb = qblocks + (uint64_t)it * ldq * QG;
+  }
+  __device__ __forceinline__ uint32_t seq_base(uint32_t, int) const { return 0; }
+  __device__ __forceinline__ const uint32_t* seq_ids(uint32_t) const { return nullptr; }
+  __device__ __forceinline__ uint64_t* out(uint32_t it, int qi) const { return keys + (uint64_t)it * QG + qi; }
+};
+
+__global__ void keys_to_assign_kernel(const uint64_t* keys, uint32_t nb, uint32_t* assign, float* mind) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nb) return;
+  const uint64_t key = keys[i];
+  assign[i] = (uint32_t)key;
+  if (mind) mind[i] = __uint_as_float(order_bits_to_f32_bits((uint32_t)(key >> 32)));
+}
+
+int32_t km_assign(const float* X, uint64_t n, const float* C, uint32_t k, uint32_t d, uint32_t ld, uint32_t* out_assign,
+                  float* out_mind, KMeansScratch& ws, int n_cu, hipStream_t st) {
+  constexpr int QG = 8;
+  if (n == 0) return VERS_OK;
+  const uint32_t ldq = round_up(ld, kChunk);
+  // batch so that the interleaved staging stays ~<= 1 GiB
+  uint64_t batch = (1ull << 30) / ((uint64_t)ldq * 4);
+  batch = batch / QG * QG;
+  if (batch < (uint64_t)QG * 1024) batch = (uint64_t)QG * 1024;
+  if (batch > n) batch = round_up64(n, QG);
+  if (int32_t rc = ws.qblocks.reserve(batch * ldq * sizeof(float))) return rc;
+  if (int32_t rc = ws.keys.reserve(batch * sizeof(uint64_t))) return rc;
+  if (int32_t rc = ws.status.reserve(16)) return rc;
+  ScanParams p;
+  p.ld = ld;
+  p.n_chunks = (ld + kChunk - 1) / kChunk;
+  p.k = 1;
+  p.status = ws.status.as<uint32_t>();
+  const size_t lds = (size_t)kWavesPerBlock * kWave * kLdsStride * sizeof(float);
+  for (uint64_t i0 = 0; i0 < n; i0 += batch) {
+    const uint32_t nb = (uint32_t)((n - i0 < batch) ? (n - i0) : batch);
+    if (int32_t rc = launch_stage_queries(X + i0 * ld, ld, d, ws.qblocks.as<float>(), ldq, nb, QG, st)) return rc;
+    AssignSrc<QG> src;
+    src.C = C; src.k = k; src.qblocks = ws.qblocks.as<float>(); src.ldq = ldq; src.nb = nb; src.keys = ws.keys.as<uint64_t>();
+    const uint32_t n_items = (nb + QG - 1) / QG;
+    uint32_t blocks = (n_items + kWavesPerBlock - 1) / kWavesPerBlock;
+    if (blocks > (uint32_t)n_cu * 2u) blocks = (uint32_t)n_cu * 2u;
+    hipLaunchKernelGGL((scan_kernel<QG, 0, AssignSrc<QG>>), dim3(blocks), dim3(kWave * kWavesPerBlock), lds, st, src, p);
+    VERS_HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(keys_to_assign_kernel, dim3((nb + 255) / 256), dim3(256), 0, st, ws.keys.as<uint64_t>(), nb,
+                       out_assign + i0, out_mind ? out_mind + i0 : nullptr);
+    VERS_HIP_TRY(hipGetLastError());
+  }
+  return VERS_OK;
+}
+
+// ---- group ----------------------------------------------------------------------------
+__global__ void count_kernel(const uint32_t* assign, uint32_t n, uint32_t* counts) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) atomicAdd(&counts[assign[i]], 1u);
+}
+
+// single block: starts[0..k] = exclusive prefix of counts
+__global__ __launch_bounds__(1024) void exclusive_scan_kernel(const uint32_t* counts, uint32_t k, uint32_t* starts) {
+  __shared__ uint32_t sh[1024];
+  __shared__ uint32_t carry;
+  if (threadIdx.x == 0) carry = 0;
+  __syncthreads();
+  for (uint32_t base = 0; base < k; base += 1024) {
+    const uint32_t i = base + threadIdx.x;
+    const uint32_t v = i < k ? counts[i] : 0;
+    sh[threadIdx.x] = v;
+    __syncthreads();
+    for (uint32_t off = 1; off < 1024; off <<= 1) {
+      uint32_t t = threadIdx.x >= off ? sh[threadIdx.x - off] : 0;
+      __syncthreads();
+      sh[threadIdx.x] += t;
+      __syncthreads();
+    }
+    const uint32_t incl = sh[threadIdx.x];
+    if (i < k) starts[i] = carry + incl - v;
+    __syncthreads();
+    if (threadIdx.x == 1023) carry += incl;
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) starts[k] = carry;
+}
+
+int32_t km_group(const uint32_t* assign, uint32_t n, uint32_t k, uint32_t* sorted_ids, uint32_t* counts, uint32_t* starts,
+                 KMeansScratch& ws, hipStream_t st) {
+  VERS_HIP_TRY(hipMemsetAsync(counts, 0, (size_t)k * sizeof(uint32_t), st));
+  if (n) {
+    hipLaunchKernelGGL(count_kernel, dim3((n + 255) / 256), dim3(256), 0, st, assign, n, counts);
+    VERS_HIP_TRY(hipGetLastError());
+  }
+  hipLaunchKernelGGL(exclusive_scan_kernel, dim3(1), dim3(1024), 0, st, counts, k, starts);
+  VERS_HIP_TRY(hipGetLastError());
+  const size_t tb = group_by_cluster_temp_bytes(n, k);
+  if (int32_t rc = ws.sort_tmp.reserve(tb)) return rc;
+  return group_by_cluster(assign, n, k, sorted_ids, ws.sort_tmp.p, tb, st);
+}
+
+// ---- update -----------------------------------------------------------------------------
+// thread = one (cluster, column); members visited in list order (ascending point index);
+// 8 independent row loads in flight, the adds stay strictly ordered.
+__global__ __launch_bounds__(256) void update_kernel(const float* X, uint32_t ld, const uint32_t* sorted_ids,
+                                                     const uint32_t* starts, float* Cnew) {
+  const uint32_t c = blockIdx.x;
+  const uint32_t col = blockIdx.y * 256 + threadIdx.x;
+  if (col >= ld) return;
+  const uint32_t s = starts[c], e = starts[c + 1];
+  float acc = 0.0f;
+  uint32_t t = s;
+  for (; t + 8 <= e; t += 8) {
+    float v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = X[(uint64_t)sorted_ids[t + u] * ld + col];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) acc = __fadd_rn(acc, v[u]);
+  }
+  for (; t < e; ++t) acc = __fadd_rn(acc, X[(uint64_t)sorted_ids[t] * ld + col]);
+  Cnew[(uint64_t)c * ld + col] = e > s ? __fdiv_rn(acc, (float)(e - s)) : 0.0f;
+}
+
+int32_t km_update(const float* X, uint32_t ld, const uint32_t* sorted_ids, const uint32_t* starts, uint32_t k, float* Cnew,
+                  hipStream_t st) {
+  if (k == 0) return VERS_OK;
+  hipLaunchKernelGGL(update_kernel, dim3(k, (ld + 255) / 256), dim3(256), 0, st, X, ld, sorted_ids, starts, Cnew);
+  VERS_HIP_TRY(hipGetLastError());
+  return VERS_OK;
+}
+
+// ---- cost -------------------------------------------------------------------------------
+__global__ void cost_fold_kernel(const float* v, uint64_t n, float* out) {
+  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+  float acc = 0.0f;
+  uint64_t i = 0;
+  for (; i + 16 <= n; i += 16) {
+    float t[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) t[u] = v[i + u];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) acc = __fadd_rn(acc, t[u]);
+  }
+  for (; i < n; ++i) acc = __fadd_rn(acc, v[i]);
+  *out = acc;
+}
+
+int32_t km_cost_fold(const float* mind, uint64_t n, float* out_dev, hipStream_t st) {
+  hipLaunchKernelGGL(cost_fold_kernel, dim3(1), dim3(64), 0, st, mind, n, out_dev);
+  VERS_HIP_TRY(hipGetLastError());
+  return VERS_OK;
+}
+
+__global__ void differs_kernel(const uint32_t* a, const uint32_t* b, uint64_t n, uint32_t* flag) {
+  bool diff = false;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (uint64_t)gridDim.x * blockDim.x)
+    diff |= a[i] != b[i];
+  if (diff) atomicOr(flag, 1u);
+}
+
+int32_t km_differs(const float* a, const float* b, uint64_t n_words, uint32_t* flag_dev, hipStream_t st) {
+  VERS_HIP_TRY(hipMemsetAsync(flag_dev, 0, sizeof(uint32_t), st));
+  if (n_words == 0) return VERS_OK;
+  uint64_t blocks = (n_words + 255) / 256;
+  if (blocks > 2048) blocks = 2048;
+  hipLaunchKernelGGL(differs_kernel, dim3((unsigned)blocks), dim3(256), 0, st, (const uint32_t*)a, (const uint32_t*)b, n_words,
+                     flag_dev);
+  VERS_HIP_TRY(hipGetLastError());
+  return VERS_OK;
+}
+
+// D(x_i, c_{a_i}) for a GIVEN assignment (standalone cost primitive; build_index gets these
+// for free from the assign pass).  One lane per point, strictly ordered columns.
+__global__ void pair_dist_kernel(const float* X, const float* C, const uint32_t* assign, uint64_t n, uint32_t ld,
+                                 float* out) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const f32x4* x = reinterpret_cast<const f32x4*>(X + i * ld);
+  const f32x4* c = reinterpret_cast<const f32x4*>(C + (uint64_t)assign[i] * ld);
+  float acc = 0.0f;
+  for (uint32_t j = 0; j < ld / 4; ++j) {
+    const f32x4 xv = x[j], cv = c[j];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float t = __fsub_rn(xv[u], cv[u]);
+      acc = __fadd_rn(acc, __fmul_rn(t, t));
+    }
+  }
+  out[i] = acc;
+}
+
+}  // namespace vers
+
+// ======================================================================================
+// C ABI: k-means primitives on host arrays (unit-test and integration surface).
+// ======================================================================================
+using namespace vers;
+
+namespace {
+
+int32_t upload_rows(DevBuf& buf, const float* rows, uint64_t n, uint64_t stride_bytes, uint32_t d, uint32_t ld) {
+  if (int32_t rc = buf.reserve((n ? n : 1) * (size_t)ld * sizeof(float))) return rc;
+  if (n == 0) return VERS_OK;
+  if (ld != d) VERS_HIP_TRY(hipMemset(buf.p, 0, n * (size_t)ld * sizeof(float)));
+  VERS_HIP_TRY(hipMemcpy2D(buf.p, (size_t)ld * 4, rows, stride_bytes, (size_t)d * 4, n, hipMemcpyHostToDevice));
+  return VERS_OK;
+}
+
+int32_t device_cus(int device, int* n_cu) {
+  int cnt = 0;
+  VERS_HIP_TRY(hipGetDeviceCount(&cnt));
+  if (device < 0 || device >= cnt) return fail(VERS_ERR_INVALID, "no such device");
+  hipDeviceProp_t prop;
+  VERS_HIP_TRY(hipGetDeviceProperties(&prop, device));
+  *n_cu = prop.multiProcessorCount;
+  return VERS_OK;
+}
+
+int32_t check_status_word(DevBuf& status, uint32_t k) {
+  uint32_t st = 0;
+  VERS_HIP_TRY(hipMemcpy(&st, status.p, sizeof(st), hipMemcpyDeviceToHost));
+  VERS_HIP_TRY(hipMemset(status.p, 0, sizeof(st)));
+  // the reference only panics once a NaN is COMPARED, which needs at least two centroids
+  if ((st & 1u) && k >= 2) return fail(VERS_ERR_NAN, "NaN distance in assign_to_clusters (reference panics)");
+  return VERS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t vers_kmeans_assign(int32_t device, const float* rows, uint64_t n, uint64_t row_stride_bytes, const float* centroids,
+                           uint64_t k, uint64_t c_stride_bytes, uint32_t d, uint64_t* out_assign, float* out_min_dist) {
+  if (d == 0 || (n && (!rows || !out_assign)) || (k && !centroids) || row_stride_bytes < (uint64_t)d * 4 ||
+      (k && c_stride_bytes < (uint64_t)d * 4) || n > 0xFFFFFFFFull || k > 0xFFFFFFFFull)
+    return fail(VERS_ERR_INVALID, "vers_kmeans_assign: bad arguments");
+  if (n == 0) return VERS_OK;
+  if (k == 0) return fail(VERS_ERR_EMPTY, "min_by over zero centroids (reference: unwrap on None)");
+  int n_cu = 0;
+  if (int32_t rc = device_cus(device, &n_cu)) return rc;
+  DeviceGuard g(device);
+  const uint32_t ld = round_up(d, 4);
+  KMeansScratch ws;
+  DevBuf X, C, A, M;
+  if (int32_t rc = upload_rows(X, rows, n, row_stride_bytes, d, ld)) return rc;
+  if (int32_t rc = upload_rows(C, centroids, k, c_stride_bytes, d, ld)) return rc;
+  if (int32_t rc = A.reserve(n * sizeof(uint32_t))) return rc;
+  if (int32_t rc = M.reserve(n * sizeof(float))) return rc;
+  if (int32_t rc = ws.status.reserve(16)) return rc;
+  VERS_HIP_TRY(hipMemset(ws.status.p, 0, 16));
+  if (int32_t rc = km_assign(X.as<float>(), n, C.as<float>(), (uint32_t)k, d, ld, A.as<uint32_t>(), M.as<float>(), ws, n_cu,
+                             nullptr))
+    return rc;
+  VERS_HIP_TRY(hipDeviceSynchronize());
+  if (int32_t rc = check_status_word(ws.status, (uint32_t)k)) return rc;
+  std::vector<uint32_t> a32(n);
+  VERS_HIP_TRY(hipMemcpy(a32.data(), A.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  for (uint64_t i = 0; i < n; ++i) out_assign[i] = a32[i];
+  if (out_min_dist) VERS_HIP_TRY(hipMemcpy(out_min_dist, M.p, n * sizeof(float), hipMemcpyDeviceToHost));
+  return VERS_OK;
+}
+
+int32_t vers_kmeans_update(int32_t device, const float* rows, uint64_t n, uint64_t row_stride_bytes, const uint64_t* assign,
+                           uint64_t k, uint32_t d, float* out_centroids) {
+  if (d == 0 || (n && (!rows || !assign)) || (k && !out_centroids) || row_stride_bytes < (uint64_t)d * 4 ||
+      n > 0xFFFFFFFFull || k > 0xFFFFFFFFull)
+    return fail(VERS_ERR_INVALID, "vers_kmeans_update: bad arguments");
+  if (k == 0) return VERS_OK;
+  for (uint64_t i = 0; i < n; ++i)
+    if (assign[i] >= k) return fail(VERS_ERR_INVALID, "vers_kmeans_update: assignment out of range");
+  int n_cu = 0;
+  if (int32_t rc = device_cus(device, &n_cu)) return rc;
+  DeviceGuard g(device);
+  const uint32_t ld = round_up(d, 4);
+  KMeansScratch ws;
+  DevBuf X, A, S, CN;
+  if (int32_t rc = upload_rows(X, rows, n, row_stride_bytes, d, ld)) return rc;
+  std::vector<uint32_t> a32(n ? n : 1);
+  for (uint64_t i = 0; i < n; ++i) a32[i] = (uint32_t)assign[i];
+  if (int32_t rc = A.reserve((n ? n : 1) * sizeof(uint32_t))) return rc;
+  if (n) VERS_HIP_TRY(hipMemcpy(A.p, a32.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice));
+  if (int32_t rc = S.reserve((n ? n : 1) * sizeof(uint32_t))) return rc;
+  if (int32_t rc = ws.counts.reserve((2 * k + 1) * sizeof(uint32_t))) return rc;
+  if (int32_t rc = CN.reserve(k * (size_t)ld * sizeof(float))) return rc;
+  uint32_t* counts = ws.counts.as<uint32_t>();
+  uint32_t* starts = counts + k;
+  if (int32_t rc = km_group(A.as<uint32_t>(), (uint32_t)n, (uint32_t)k, S.as<uint32_t>(), counts, starts, ws, nullptr)) return rc;
+  if (int32_t rc = km_update(X.as<float>(), ld, S.as<uint32_t>(), starts, (uint32_t)k, CN.as<float>(), nullptr)) return rc;
+  VERS_HIP_TRY(hipMemcpy2D(out_centroids, (size_t)d * 4, CN.p, (size_t)ld * 4, (size_t)d * 4, k, hipMemcpyDeviceToHost));
+  return VERS_OK;
+}
+
+int32_t vers_kmeans_cost(int32_t device, const float* rows, uint64_t n, uint64_t row_stride_bytes, const float* centroids,
+                         uint64_t k, uint64_t c_stride_bytes, const uint64_t* assign, uint32_t d, float* out_cost) {
+  if (d == 0 || !out_cost || (n && (!rows || !assign || !centroids)) || row_stride_bytes < (uint64_t)d * 4 ||
+      (k && c_stride_bytes < (uint64_t)d * 4) || n > 0xFFFFFFFFull)
+    return fail(VERS_ERR_INVALID, "vers_kmeans_cost: bad arguments");
+  for (uint64_t i = 0; i < n; ++i)
+    if (assign[i] >= k) return fail(VERS_ERR_INVALID, "vers_kmeans_cost: assignment out of range");
+  int n_cu = 0;
+  if (int32_t rc = device_cus(device, &n_cu)) return rc;
+  DeviceGuard g(device);
+  const uint32_t ld = round_up(d, 4);
+  DevBuf X, C, A, M, O;
+  if (int32_t rc = upload_rows(X, rows, n, row_stride_bytes, d, ld)) return rc;
+  if (int32_t rc = upload_rows(C, centroids, k, c_stride_bytes, d, ld)) return rc;
+  std::vector<uint32_t> a32(n ? n : 1);
+  for (uint64_t i = 0; i < n; ++i) a32[i] = (uint32_t)assign[i];
+  if (int32_t rc = A.reserve((n ? n : 1) * sizeof(uint32_t))) return rc;
+  if (n) VERS_HIP_TRY(hipMemcpy(A.p, a32.data(), n * sizeof(uint32_t), hipMemcpyHostToDevice));
+  if (int32_t rc = M.reserve((n ? n : 1) * sizeof(float))) return rc;
+  if (int32_t rc = O.reserve(16)) return rc;
+  if (n) {
+    hipLaunchKernelGGL(pair_dist_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, X.as<float>(), C.as<float>(),
+                       A.as<uint32_t>(), n, ld, M.as<float>());
+    VERS_HIP_TRY(hipGetLastError());
+  }
+  if (int32_t rc = km_cost_fold(M.as<float>(), n, O.as<float>(), nullptr)) return rc;
+  VERS_HIP_TRY(hipMemcpy(out_cost, O.p, sizeof(float), hipMemcpyDeviceToHost));
+  return VERS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,53 @@
+// kmeans.hpp -- device-level k-means steps shared by kmeans.hip (C ABI primitives) and
+// ivf.hip (build_index).  All pointers are device pointers; nothing synchronises unless noted.
+#pragma once
+#include "common.hpp"
+
+namespace vers {
+
+// ---- sort.hip ---------------------------------------------------------------------
+size_t group_by_cluster_temp_bytes(uint32_t n, uint32_t k);
+int32_t group_by_cluster(const uint32_t* assign, uint32_t n, uint32_t k, uint32_t* sorted_ids, void* temp,
+                         size_t temp_bytes, hipStream_t st);
+
+// ---- kmeans.hip ---------------------------------------------------------------------
+// Simple owning device buffer (grow-only).
+struct DevBuf {
+  void* p = nullptr;
+  size_t cap = 0;
+  int32_t reserve(size_t bytes);
+  void release();
+  template <class T> T* as() const { return (T*)p; }
+  ~DevBuf() { release(); }
+};
+
+struct KMeansScratch {
+  DevBuf qblocks;   // interleaved point blocks of one assign batch
+  DevBuf keys;      // u64 argmin keys of one assign batch
+  DevBuf sort_tmp;  // group_by_cluster temp
+  DevBuf status;    // u32 status word(s)
+  DevBuf counts;    // u32 [k] + starts [k+1]
+  DevBuf misc;      // cost scalar, equality flag
+};
+
+// assign_to_clusters (ivfflat.rs:29-46): out_assign[i] = first argmin_c D(X[i], C[c]);
+// out_mind[i] (optional) = that minimum distance, bit-exact D(X[i], C[assign[i]]).
+// status bit0 is set on a NaN distance.  X [n][ld], C [k][ld] zero padded to ld.
+int32_t km_assign(const float* X, uint64_t n, const float* C, uint32_t k, uint32_t d, uint32_t ld, uint32_t* out_assign,
+                  float* out_mind, KMeansScratch& ws, int n_cu, hipStream_t st);
+
+// counts[k], starts[k+1] (exclusive prefix), sorted_ids[n] grouped by cluster, ascending inside.
+int32_t km_group(const uint32_t* assign, uint32_t n, uint32_t k, uint32_t* sorted_ids, uint32_t* counts, uint32_t* starts,
+                 KMeansScratch& ws, hipStream_t st);
+
+// update_centroids (ivfflat.rs:47-71): Cnew[c] = (0 + x_i1 + x_i2 + ...) / count in ascending i, 0 if empty.
+int32_t km_update(const float* X, uint32_t ld, const uint32_t* sorted_ids, const uint32_t* starts, uint32_t k,
+                  float* Cnew, hipStream_t st);
+
+// calculate_kmeans_cost (ivfflat.rs:138-149): strict left-to-right f32 fold of mind[0..n); result at *out_dev.
+int32_t km_cost_fold(const float* mind, uint64_t n, float* out_dev, hipStream_t st);
+
+// bitwise equality of two f32 arrays (to_hashkey comparison, ivfflat.rs:84-93); *flag_dev = 1 if ANY word differs.
+int32_t km_differs(const float* a, const float* b, uint64_t n_words, uint32_t* flag_dev, hipStream_t st);
+
+}  // namespace vers
