@@ -104,6 +104,76 @@ int32_t vers_kmeans_cost(int32_t device, const float* rows, uint64_t n, uint64_t
                          const float* centroids, uint64_t k, uint64_t c_stride_bytes, const uint64_t* assign,
                          uint32_t d, float* out_cost);
 
+/* ------------------------------------------------------------------------ *
+ * IVFFlat index.  The handle is the DEVICE CACHE of the five fields of       *
+ * IVFFlatIndex<N> (ivfflat.rs:8-15); the host side (Rust) keeps owning        *
+ * values / centroids / assignments / ids for serde and rebuilds the cache    *
+ * with vers_ivf_upload after Index::load_index (base.rs:45-58).              *
+ * ------------------------------------------------------------------------ */
+typedef struct vers_ivf vers_ivf_t;
+
+int32_t vers_ivf_create(int32_t device, uint32_t d, vers_ivf_t** out);
+int32_t vers_ivf_destroy(vers_ivf_t* h);
+
+/* IVFFlatIndex::build_index(num_clusters, num_attempts, max_iterations, &vectors)
+ * (ivfflat.rs:102-136), k-means included (build_kmeans :73-100, cost :138-149).
+ * init_indices [num_attempts * num_clusters]: the draws of initialize_centroids
+ * (ivfflat.rs:18-27: k indices WITH replacement from an unseeded thread_rng) are made
+ * by the caller, so the Rust shim keeps using rand::thread_rng and tests can inject.
+ * Outputs (host, caller-owned, nullable): out_centroids [k*d] packed, out_assignments
+ * [n], out_cost (best cost), out_kept (0 when no attempt beat +inf, e.g. num_attempts
+ * == 0: the index then has EMPTY centroids/assignments exactly like the reference),
+ * out_iterations [num_attempts] loop bodies executed per attempt. */
+int32_t vers_ivf_build(vers_ivf_t* h, const float* rows, uint64_t n, uint64_t row_stride_bytes,
+                       uint64_t num_clusters, uint64_t num_attempts, uint64_t max_iterations,
+                       const uint64_t* init_indices, float* out_centroids, uint64_t* out_assignments,
+                       float* out_cost, int32_t* out_kept, uint64_t* out_iterations);
+/* Same with the vectors already in HBM (pitch ld_floats == round_up(d,4), pad columns zero). */
+int32_t vers_ivf_build_dev(vers_ivf_t* h, const float* rows_dev, uint64_t n, uint64_t ld_floats,
+                           uint64_t num_clusters, uint64_t num_attempts, uint64_t max_iterations,
+                           const uint64_t* init_indices, float* out_centroids, uint64_t* out_assignments,
+                           float* out_cost, int32_t* out_kept, uint64_t* out_iterations);
+/* Rebuilds the device cache from the host fields (after Index::load_index): values,
+ * centroids, assignments; ids[c] is implied (ascending positions with assignments == c,
+ * which is what build_index + add produce). */
+int32_t vers_ivf_upload(vers_ivf_t* h, const float* rows, uint64_t n, uint64_t row_stride_bytes,
+                        const float* centroids, uint64_t k, uint64_t c_stride_bytes,
+                        const uint64_t* assignments);
+/* Index::add (ivfflat.rs:200-213): nearest centroid by first minimum; the new vector gets
+ * vec_id = assignments.len() (the reference ignores the caller's vec_id, :209) and is appended
+ * to that list.  Returns both so the host can mirror values/assignments/ids. */
+int32_t vers_ivf_add(vers_ivf_t* h, const float* row, uint64_t* out_cluster, uint64_t* out_vec_id);
+/* Index::search_approximate (ivfflat.rs:153-198) for b queries.
+ *   nprobe == 0 : the reference's semantics -- nearest list, spill into the next-nearest while
+ *                 fewer than top_k results; results CONCATENATED per list (not globally sorted);
+ *                 fewer than top_k vectors reachable -> VERS_ERR_INSUFFICIENT (reference panics).
+ *   nprobe >= 1 : extension named by BASELINE.json (not in the reference): all rows of the nprobe
+ *                 nearest lists, one global stable order by (distance, probe rank, list position).
+ * out_ids/out_dist [b*top_k], out_count[q] results for query q.  top_k, nprobe <= 64. */
+int32_t vers_ivf_search(vers_ivf_t* h, const float* queries, uint64_t q_stride_bytes, uint32_t b,
+                        uint32_t top_k, uint32_t nprobe, uint64_t* out_ids, float* out_dist,
+                        uint32_t* out_count);
+int32_t vers_ivf_search_dev(vers_ivf_t* h, const float* queries_dev, uint64_t ldq_floats, uint32_t b,
+                            uint32_t top_k, uint32_t nprobe, uint64_t* out_ids_dev, float* out_dist_dev,
+                            uint32_t* out_count_dev, void* stream);
+/* Synchronises `stream`, returns and clears the status latched by _dev calls. */
+int32_t vers_ivf_poll(vers_ivf_t* h, void* stream);
+/* utils::search_exhaustive (utils.rs:68-82) over the index's own values (ties -> lower vec_id);
+ * the recall ground truth. */
+int32_t vers_ivf_search_exhaustive(vers_ivf_t* h, const float* queries, uint64_t q_stride_bytes, uint32_t b,
+                                   uint32_t top_k, uint32_t metric, uint64_t* out_ids, float* out_dist,
+                                   uint32_t* out_count);
+int32_t vers_ivf_search_exhaustive_dev(vers_ivf_t* h, const float* queries_dev, uint64_t ldq_floats,
+                                       uint32_t b, uint32_t top_k, uint32_t metric, uint64_t* out_ids_dev,
+                                       float* out_dist_dev, uint32_t* out_count_dev, void* stream);
+/* n = vectors in the index (assignments.len()), k = centroids, longest list. */
+int32_t vers_ivf_info(vers_ivf_t* h, uint64_t* out_n, uint64_t* out_k, uint64_t* out_max_list_len);
+int32_t vers_ivf_list_lengths(vers_ivf_t* h, uint64_t* out_lengths /* [k] */);
+/* Measurement hook: the most recent inverted-list scan launch -- duration (HIP events on its
+ * stream), rows of the union of probed lists (algorithmic), rows actually streamed, work items. */
+int32_t vers_ivf_last_scan(vers_ivf_t* h, float* out_ms, uint64_t* out_union_rows,
+                           uint64_t* out_streamed_rows, uint32_t* out_items);
+
 #ifdef __cplusplus
 }
 #endif

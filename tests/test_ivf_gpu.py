@@ -1,0 +1,138 @@
+"""GPU parity of build_index / add / search_approximate (vers_ivf_*) -- reads like the harness the
+reference itself would run (utils.rs:117-184): build -> add -> save -> load -> search, checked
+against the golden fixtures and the oracle.  Bar: bit-exact (ids, order, distance bits, centroid
+bits, cost bits)."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import c_oracle as co
+from tests import datagen as dg
+from tests.golden import make_golden as mg
+from vers_amd import capi
+from vers_amd.index import IVFFlatIndex
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def check_search(index, g, nm, Q, k_clusters, tag_fn):
+    for top_k in (1, 10, 50):
+        for tag, nprobe in [("search", 0), ("nprobe1", 1), ("nprobe4", 4), (f"nprobe{k_clusters}", k_clusters)]:
+            gi = g[f"{nm}/{tag}/k{top_k}/ids"]; gd = g[f"{nm}/{tag}/k{top_k}/dist_bits"]; gc = g[f"{nm}/{tag}/k{top_k}/count"]
+            ids, dist, cnt = index.search_batch(Q, top_k, nprobe)          # batched
+            assert np.array_equal(cnt, gc), (tag, top_k)
+            for qi in range(Q.shape[0]):
+                c = int(gc[qi])
+                assert np.array_equal(ids[qi, :c], gi[qi, :c]), (tag, top_k, qi)
+                assert np.array_equal(bits(dist[qi, :c]), gd[qi, :c]), (tag, top_k, qi)
+            i1, d1, c1 = index.search_batch(Q[2], top_k, nprobe)           # single query path
+            c = int(gc[2])
+            assert c1[0] == c and np.array_equal(i1[0, :c], gi[2, :c]) and np.array_equal(bits(d1[0, :c]), gd[2, :c])
+
+
+@pytest.mark.parametrize("cs", mg.KMEANS_CASES, ids=lambda c: c["name"])
+def test_build_add_save_load_search_golden(cs, golden_km, tmp_path):
+    g, nm = golden_km, cs["name"]
+    X = mg.corpus(cs); k, n, d = cs["k"], cs["n"], cs["d"]
+    init = g[nm + "/init"]
+    index = IVFFlatIndex.build_index(k, cs["attempts"], cs["iters"], X, init_indices=init)
+    assert np.array_equal(bits(index.centroids), g[nm + "/build_C_bits"])
+    assert np.array_equal(index.assignments, g[nm + "/build_assign"])
+    assert bits(np.array([index.cost]))[0] == g[nm + "/build_cost_bits"][0]
+    assert np.array_equal(np.sort(np.concatenate([np.asarray(l, dtype=np.int64) for l in index.ids])), np.arange(n))
+    assert np.array_equal(index.list_lengths(), np.array([len(l) for l in index.ids], dtype=np.uint64))
+    # add three vectors; the caller's vec_id is ignored (ivfflat.rs:209)
+    extra = dg.dist_u(cs["seed"] + 7, 3, d)
+    for x, want in zip(extra, g[nm + "/add_clusters"]):
+        c, vid = index.add(x, vec_id=123456)
+        assert c == want and vid == len(index.assignments) - 1
+    Q = mg.queries(cs["seed"] + 3, 6, d, index.values); Q[1] = extra[1]
+    check_search(index, g, nm, Q, k, None)
+    # save -> load -> search again (utils.rs:140-148): the device cache is rebuilt from the host fields
+    path = os.path.join(tmp_path, "ivfflat.index")
+    index.save_index(path)
+    re = IVFFlatIndex.load_index(path, d)
+    assert re.num_centroids == k and np.array_equal(re.assignments, index.assignments) and re.ids == index.ids
+    check_search(re, g, nm, Q, k, None)
+    # Index::search_approximate proper: list of (vec_id, squared_l2); self-retrieval at exactly 0.0
+    r = re.search_approximate(index.values[n + 1], 1)
+    assert r[0][0] == n + 1 and r[0][1] == 0.0
+    index.close(); re.close()
+
+
+def test_batched_grouping_many_queries_per_list():
+    # 200 queries over 12 lists: every list is shared by many queries (QG=8 blocks, several groups per list)
+    n, d, k = 4000, 64, 12
+    X = dg.dist_c(0x77, n, d, 12, dg.default_sigma(d))
+    init = mg.init_draws(5, 1, k, n)
+    index = IVFFlatIndex.build_index(k, 1, 5, X, init_indices=init)
+    Q = dg.dist_c(0x78, 200, d, 12, dg.default_sigma(d))
+    for nprobe, top_k in [(0, 10), (3, 10), (12, 64), (1, 1)]:
+        ids, dist, cnt = index.search_batch(Q, top_k, nprobe)
+        for qi in range(0, 200, 7):
+            if nprobe == 0:
+                oi, od = co.search_approximate(index.values, index.centroids, index.ids, Q[qi], top_k)
+            else:
+                oi, od = co.search_nprobe(index.values, index.centroids, index.ids, Q[qi], top_k, nprobe)
+            assert cnt[qi] == len(oi)
+            assert np.array_equal(ids[qi, :len(oi)], oi) and np.array_equal(bits(dist[qi, :len(oi)]), bits(od))
+    # recall ground truth path: exhaustive over the index's values == utils::search_exhaustive
+    ids, dist, cnt = index.search_exhaustive(Q[:9], 10)
+    for qi in range(9):
+        oi, od = co.search_exhaustive(index.values, Q[qi], 10)
+        assert np.array_equal(ids[qi], oi) and np.array_equal(bits(dist[qi]), bits(od))
+    index.close()
+
+
+def test_reference_error_semantics():
+    d = 6
+    X = dg.dist_u(1, 40, d)
+    # num_attempts == 0 keeps nothing: empty centroids; search panics (ivfflat.rs:169), add panics (:207)
+    empty = IVFFlatIndex.build_index(4, 0, 5, X, init_indices=np.zeros(0, dtype=np.uint64))
+    assert empty.centroids.shape[0] == 0 and empty.assignments.size == 0 and len(empty.ids) == 4
+    with pytest.raises(capi.VersError) as e:
+        empty.search_approximate(X[0], 3)
+    assert e.value.status == capi.ERR_INSUFFICIENT
+    with pytest.raises(capi.VersError) as e:
+        empty.add(X[0], 0)
+    assert e.value.status == capi.ERR_EMPTY
+    assert empty.search_approximate(X[0], 0) == []      # top_k == 0 never touches the centroids
+    index = IVFFlatIndex.build_index(4, 1, 5, X, init_indices=np.array([0, 1, 2, 3], dtype=np.uint64))
+    # more results than vectors -> the reference runs out of clusters and panics
+    with pytest.raises(capi.VersError) as e:
+        index.search_approximate(X[0], 41)
+    assert e.value.status == capi.ERR_INSUFFICIENT
+    assert len(index.search_approximate(X[0], 40)) == 40   # exactly all of them: spills through every list
+    # nprobe extension returns what exists instead
+    ids, dist, cnt = index.search_batch(X[:2], 50, nprobe=4)
+    assert list(cnt) == [40, 40]
+    # NaN query -> panic in partial_cmp().unwrap()
+    q = X[0].copy(); q[0] = np.nan
+    with pytest.raises(capi.VersError) as e:
+        index.search_approximate(q, 3)
+    assert e.value.status == capi.ERR_NAN
+    assert index.search_approximate(X[5], 1)[0] == (5, np.float32(0.0))
+    index.close(); empty.close()
+
+
+def test_add_overflows_slack_and_relayouts():
+    d, n, k = 16, 300, 3
+    X = dg.dist_c(21, n, d, 3, dg.default_sigma(d))
+    index = IVFFlatIndex.build_index(k, 1, 4, X, init_indices=np.array([0, 1, 2], dtype=np.uint64))
+    extra = dg.dist_c(22, 400, d, 3, dg.default_sigma(d), seed_c=21 ^ 0xC0FFEE)   # far more than the slack of any list
+    for x in extra:
+        c, _ = index.add(x)
+        assert c == co.add_cluster(index.centroids, x)
+    assert index.info()[0] == n + 400
+    for q in (extra[7], X[3], dg.dist_u(5, 1, d)[0]):
+        for top_k, nprobe in [(10, 0), (64, 2)]:
+            ids, dist, cnt = index.search_batch(q, top_k, nprobe)
+            oi, od = (co.search_approximate(index.values, index.centroids, index.ids, q, top_k) if nprobe == 0 else
+                      co.search_nprobe(index.values, index.centroids, index.ids, q, top_k, nprobe))
+            assert np.array_equal(ids[0, :len(oi)], oi) and np.array_equal(bits(dist[0, :len(oi)]), bits(od))
+    index.close()

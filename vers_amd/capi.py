@@ -40,6 +40,23 @@ SIGNATURES = {
     "vers_flat_search_dev": (C.c_int32, [_vp, _vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, _vp, _vp, _vp, _vp]),
     "vers_flat_poll": (C.c_int32, [_vp, _vp]),
     "vers_flat_last_scan_ms": (C.c_int32, [_vp, C.POINTER(C.c_float)]),
+    "vers_ivf_create": (C.c_int32, [C.c_int32, C.c_uint32, C.POINTER(_vp)]),
+    "vers_ivf_destroy": (C.c_int32, [_vp]),
+    "vers_ivf_build": (C.c_int32, [_vp, _vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, _vp, _vp, _vp,
+                                   C.POINTER(C.c_float), C.POINTER(C.c_int32), _vp]),
+    "vers_ivf_build_dev": (C.c_int32, [_vp, _vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, _vp, _vp, _vp,
+                                       C.POINTER(C.c_float), C.POINTER(C.c_int32), _vp]),
+    "vers_ivf_upload": (C.c_int32, [_vp, _vp, C.c_uint64, C.c_uint64, _vp, C.c_uint64, C.c_uint64, _vp]),
+    "vers_ivf_add": (C.c_int32, [_vp, _vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "vers_ivf_search": (C.c_int32, [_vp, _vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, _vp, _vp, _vp]),
+    "vers_ivf_search_dev": (C.c_int32, [_vp, _vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, _vp, _vp, _vp, _vp]),
+    "vers_ivf_poll": (C.c_int32, [_vp, _vp]),
+    "vers_ivf_search_exhaustive": (C.c_int32, [_vp, _vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, _vp, _vp, _vp]),
+    "vers_ivf_search_exhaustive_dev": (C.c_int32, [_vp, _vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, _vp, _vp, _vp, _vp]),
+    "vers_ivf_info": (C.c_int32, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "vers_ivf_list_lengths": (C.c_int32, [_vp, _vp]),
+    "vers_ivf_last_scan": (C.c_int32, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
+                                       C.POINTER(C.c_uint32)]),
     "vers_kmeans_assign": (C.c_int32, [C.c_int32, _vp, C.c_uint64, C.c_uint64, _vp, C.c_uint64, C.c_uint64, C.c_uint32, _vp, _vp]),
     "vers_kmeans_update": (C.c_int32, [C.c_int32, _vp, C.c_uint64, C.c_uint64, _vp, C.c_uint64, C.c_uint32, _vp]),
     "vers_kmeans_cost": (C.c_int32, [C.c_int32, _vp, C.c_uint64, C.c_uint64, _vp, C.c_uint64, C.c_uint64, _vp, C.c_uint32,

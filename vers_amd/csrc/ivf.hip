@@ -1,0 +1,1070 @@
+// ivf.hip -- the IVFFlat index behind vers_ivf_*: build_index / add / search_approximate
+// of /root/reference/vers/src/indexes/ivfflat.rs on one MI355X.
+//
+// Device layout (HBM): the reference keeps `values` in vec_id order and gathers list members
+// through `ids` (ivfflat.rs:172-174).  Here rows are stored CLUSTER-MAJOR: list c occupies the
+// contiguous rows [list_off[c], list_off[c]+list_len[c]) in the reference's list order
+// (ascending vec_id for built rows, append order for added ones), followed by slack for `add`;
+// row_ids[] maps a storage row back to its vec_id.  A list scan is therefore one linear,
+// fully coalesced HBM stream.
+//
+// search = coarse scan over the centroids (top-P keys) -> plan (which lists, per-query sequence
+// bases, reference spill plan) -> group (query,list) pairs by list so a list is streamed once for
+// up to 8 queries -> inverted-list scan (scan.cuh engine) -> per-query merge + id mapping.
+// Everything is planned on the device; the host never waits inside a search.
+#include <algorithm>
+#include <mutex>
+#include <vector>
+
+#include "kmeans.hpp"
+#include "scan.cuh"
+#include "util.cuh"
+
+namespace vers {
+
+constexpr uint32_t kNoList = 0xFFFFFFFFu;
+constexpr uint32_t kStNaN = 1u, kStInsufficient = 2u, kStSpillTooDeep = 4u;
+
+// ---- sources for the scan engine -----------------------------------------------------------
+// coarse quantiser / exhaustive scan: item = (row segment, query group), slot(q, seg) = q*n_segs + seg
+template <int QG, bool SEQ_IDS>
+struct SegSrc {
+  static constexpr bool kSeqIds = SEQ_IDS;
+  const float* rows;
+  uint64_t n;
+  uint32_t ld;
+  uint32_t seg_rows, n_segs;
+  const float* queries;  // QG == 1: [b][ldq]; else interleaved blocks
+  uint32_t ldq, b;
+  uint64_t* partials;
+  uint32_t k;
+  const uint32_t* ids;
+  __device__ __forceinline__ uint32_t n_items() const { return n_segs * ((b + QG - 1) / QG); }
+  __device__ __forceinline__ void get(uint32_t it, ItemView<QG>& v) const {
+    const uint32_t seg = it % n_segs, qg = it / n_segs;
+    const uint64_t row0 = (uint64_t)seg * seg_rows;
+    v.rows = rows + row0 * ld;
+    v.nrows = (uint32_t)((n - row0 < seg_rows) ? (n - row0) : seg_rows);
+    const uint32_t q0 = qg * QG;
+    v.nq = (b - q0 < (uint32_t)QG) ? (b - q0) : QG;
+    v.qb = queries + (uint64_t)qg * ldq * QG;
+  }
+  __device__ __forceinline__ uint32_t seq_base(uint32_t it, int) const { return (it % n_segs) * seg_rows; }
+  __device__ __forceinline__ const uint32_t* seq_ids(uint32_t it) const { return ids + (uint64_t)(it % n_segs) * seg_rows; }
+  __device__ __forceinline__ uint64_t* out(uint32_t it, int qi) const {
+    const uint32_t seg = it % n_segs, qg = it / n_segs;
+    return partials + ((uint64_t)(qg * QG + qi) * n_segs + seg) * k;
+  }
+};
+
+struct ItemDesc {
+  uint32_t list, group, seg;
+};
+
+// inverted-list scan: item = (list, query group of the list, row segment of the list)
+template <int QG>
+struct IvfSrc {
+  static constexpr bool kSeqIds = false;
+  const float* rows;
+  uint32_t ld;
+  const uint32_t* list_off;  // storage row of each (local) list
+  const uint32_t* list_len;
+  const ItemDesc* items;
+  const uint32_t* n_items_dev;
+  const uint32_t* cnt;        // pairs per list
+  const uint32_t* pair_off;   // first pair of each list
+  const uint32_t* pairs;      // pair -> q*P + j
+  const uint32_t* group_off;  // first group id of each list
+  const float* qblocks;       // QG > 1: [group][ldq][QG]
+  const float* qp;            // QG == 1: padded queries [b][ldq]
+  uint32_t ldq, P, S_max, k_keep, seg_rows;
+  const uint32_t* pj_pref;    // [b*P] sequence base of probe j of query q
+  uint64_t* partials;         // [b*P*S_max][k_keep]
+
+  __device__ __forceinline__ uint32_t n_items() const { return *n_items_dev; }
+  __device__ __forceinline__ void get(uint32_t it, ItemView<QG>& v) const {
+    const ItemDesc d = items[it];
+    const uint32_t r0 = d.seg * seg_rows;
+    v.rows = rows + ((uint64_t)list_off[d.list] + r0) * ld;
+    const uint32_t len = list_len[d.list];
+    v.nrows = len - r0 < seg_rows ? len - r0 : seg_rows;
+    const uint32_t c = cnt[d.list] - d.group * QG;
+    v.nq = c < (uint32_t)QG ? c : QG;
+    if (QG == 1) v.qb = qp + (uint64_t)(pairs[pair_off[d.list] + d.group] / P) * ldq;
+    else v.qb = qblocks + (uint64_t)(group_off[d.list] + d.group) * ldq * QG;
+  }
+  __device__ __forceinline__ uint32_t pair_of(uint32_t it, int qi) const {
+    const ItemDesc d = items[it];
+    return pairs[pair_off[d.list] + d.group * QG + qi];
+  }
+  __device__ __forceinline__ uint32_t seq_base(uint32_t it, int qi) const {
+    return pj_pref[pair_of(it, qi)] + items[it].seg * seg_rows;
+  }
+  __device__ __forceinline__ const uint32_t* seq_ids(uint32_t) const { return nullptr; }
+  __device__ __forceinline__ uint64_t* out(uint32_t it, int qi) const {
+    return partials + ((uint64_t)pair_of(it, qi) * S_max + items[it].seg) * k_keep;
+  }
+};
+
+// ---- small kernels of the search pipeline -----------------------------------------------------
+// coarse merge: one block per query, top-P centroid keys (ascending (dist, centroid index))
+__global__ __launch_bounds__(kWave * kMergeWaves) void coarse_merge_kernel(const uint64_t* partials, uint32_t n_segs,
+                                                                           uint32_t P, uint64_t* probe) {
+  __shared__ uint64_t sh[kMergeWaves][kWave];
+  const uint32_t q = blockIdx.x;
+  uint64_t list = block_merge_keys(partials + (uint64_t)q * n_segs * P, n_segs * P, P, sh);
+  if (threadIdx.x < P) probe[(uint64_t)q * P + threadIdx.x] = list;
+}
+
+// plan: thread per query.  nprobe mode: every probed list is scanned, pj_pref = running row count.
+// reference mode (ivfflat.rs:166-195): walk the ranked lists, list j contributes
+// take_j = min(remainder, len_j) until remainder == 0; out of lists -> the reference panics.
+// owner (nullable): only lists with owner[L] == rank are scanned on this GPU.
+__global__ void plan_kernel(const uint64_t* probe, uint32_t b, uint32_t P, uint32_t k_lists, uint32_t top_k,
+                            int ref_mode, const uint32_t* list_len, const uint8_t* owner, uint32_t rank,
+                            uint32_t* pj_list, uint32_t* pj_pref, uint32_t* pj_take, uint32_t* np, uint32_t* cnt,
+                            uint32_t* status) {
+  const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= b) return;
+  uint32_t pref = 0, rem = top_k, n_planned = 0;
+  bool done = false;
+  for (uint32_t j = 0; j < P; ++j) {
+    const uint64_t key = probe[(uint64_t)q * P + j];
+    uint32_t L = kNoList, take = 0;
+    uint32_t len = 0;
+    if (key != kKeyMax && !done) {
+      L = (uint32_t)key;
+      len = list_len[L];
+      if (ref_mode) {
+        take = rem < len ? rem : len;
+        rem -= take;
+        n_planned = j + 1;
+        if (rem == 0) done = true;
+      } else {
+        take = top_k;
+        n_planned = j + 1;
+      }
+    }
+    const bool scan = L != kNoList && len > 0 && take > 0 && (owner == nullptr || owner[L] == rank);
+    pj_list[(uint64_t)q * P + j] = scan ? L : kNoList;
+    pj_pref[(uint64_t)q * P + j] = pref;
+    pj_take[(uint64_t)q * P + j] = take;
+    if (scan) atomicAdd(&cnt[L], 1u);
+    pref += len;
+  }
+  np[q] = n_planned;
+  if (ref_mode && rem > 0 && top_k > 0) atomicOr(status, P >= k_lists ? kStInsufficient : kStSpillTooDeep);
+}
+
+// group: single block.  Per list: pairs, groups (ceil(cnt/QG)), items (groups * segments); exclusive
+// prefix sums of all three; totals + traffic statistics.
+struct GroupTotals {
+  uint32_t n_items, n_groups, n_pairs, pad;
+  uint64_t union_rows;     // sum of len over lists probed by at least one query (algorithmic rows)
+  uint64_t streamed_rows;  // rows the scan items actually stream (a list is re-read per query group)
+};
+
+__global__ __launch_bounds__(1024) void group_kernel(const uint32_t* cnt, const uint32_t* list_len, uint32_t k_lists,
+                                                     uint32_t QG, uint32_t seg_rows, uint32_t* pair_off,
+                                                     uint32_t* group_off, uint32_t* item_off, GroupTotals* tot) {
+  __shared__ uint32_t sp[1024], sg[1024], si[1024];
+  __shared__ uint32_t cp, cg, ci;
+  __shared__ unsigned long long ur, sr;
+  if (threadIdx.x == 0) { cp = cg = ci = 0; ur = sr = 0; }
+  __syncthreads();
+  unsigned long long my_ur = 0, my_sr = 0;
+  for (uint32_t base = 0; base < k_lists; base += 1024) {
+    const uint32_t L = base + threadIdx.x;
+    uint32_t c = 0, g = 0, it = 0;
+    if (L < k_lists) {
+      c = cnt[L];
+      if (c) {
+        const uint32_t len = list_len[L];
+        g = (c + QG - 1) / QG;
+        it = g * ((len + seg_rows - 1) / seg_rows);
+        my_ur += len;
+        my_sr += (unsigned long long)len * g;
+      }
+    }
+    sp[threadIdx.x] = c; sg[threadIdx.x] = g; si[threadIdx.x] = it;
+    __syncthreads();
+    for (uint32_t off = 1; off < 1024; off <<= 1) {
+      uint32_t a = 0, bb = 0, cc = 0;
+      if (threadIdx.x >= off) { a = sp[threadIdx.x - off]; bb = sg[threadIdx.x - off]; cc = si[threadIdx.x - off]; }
+      __syncthreads();
+      sp[threadIdx.x] += a; sg[threadIdx.x] += bb; si[threadIdx.x] += cc;
+      __syncthreads();
+    }
+    if (L < k_lists) {
+      pair_off[L] = cp + sp[threadIdx.x] - c;
+      group_off[L] = cg + sg[threadIdx.x] - g;
+      item_off[L] = ci + si[threadIdx.x] - it;
+    }
+    __syncthreads();
+    if (threadIdx.x == 1023) { cp += sp[1023]; cg += sg[1023]; ci += si[1023]; }
+    __syncthreads();
+  }
+  atomicAdd(&ur, my_ur);
+  atomicAdd(&sr, my_sr);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    tot->n_items = ci; tot->n_groups = cg; tot->n_pairs = cp; tot->pad = 0;
+    tot->union_rows = ur; tot->streamed_rows = sr;
+  }
+}
+
+// scatter: pairs of a list become contiguous (order inside a list is arbitrary and irrelevant:
+// every (query, list) result goes to its own slot)
+__global__ void scatter_pairs_kernel(const uint32_t* pj_list, uint32_t n_pj, const uint32_t* pair_off, uint32_t* fill,
+                                     uint32_t* pairs) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n_pj) return;
+  const uint32_t L = pj_list[i];
+  if (L == kNoList) return;
+  pairs[pair_off[L] + atomicAdd(&fill[L], 1u)] = i;
+}
+
+// items + group descriptors: thread per list
+struct GroupDesc {
+  uint32_t pair_start, nq;
+};
+__global__ void items_kernel(const uint32_t* cnt, const uint32_t* list_len, uint32_t k_lists, uint32_t QG,
+                             uint32_t seg_rows, const uint32_t* pair_off, const uint32_t* group_off,
+                             const uint32_t* item_off, ItemDesc* items, GroupDesc* groups) {
+  const uint32_t L = blockIdx.x * blockDim.x + threadIdx.x;
+  if (L >= k_lists) return;
+  const uint32_t c = cnt[L];
+  if (!c) return;
+  const uint32_t n_g = (c + QG - 1) / QG, n_s = (list_len[L] + seg_rows - 1) / seg_rows;
+  uint32_t o = item_off[L];
+  for (uint32_t g = 0; g < n_g; ++g) {
+    groups[group_off[L] + g] = GroupDesc{pair_off[L] + g * QG, (c - g * QG < QG) ? c - g * QG : QG};
+    for (uint32_t s = 0; s < n_s; ++s) items[o++] = ItemDesc{L, g, s};
+  }
+}
+
+// interleaved query block of every group: qblocks[(g*ldq + col)*QG + qi]
+__global__ void gather_qblocks_kernel(const GroupDesc* groups, const GroupTotals* tot, const uint32_t* pairs, uint32_t P,
+                                      const float* qp, uint32_t ldq, uint32_t QG, float* qblocks) {
+  const uint32_t g = blockIdx.x;
+  if (g >= tot->n_groups) return;
+  const GroupDesc gd = groups[g];
+  for (uint32_t i = threadIdx.x; i < ldq * QG; i += blockDim.x) {
+    const uint32_t qi = i % QG, col = i / QG;
+    float v = 0.0f;
+    if (qi < gd.nq) v = qp[(uint64_t)(pairs[gd.pair_start + qi] / P) * ldq + col];
+    qblocks[(uint64_t)g * ldq * QG + i] = v;
+  }
+}
+
+// final merge + id mapping: one block per query
+__global__ __launch_bounds__(kWave * kMergeWaves) void ivf_merge_kernel(
+    const uint64_t* partials, uint32_t P, uint32_t S_max, uint32_t k_keep, int ref_mode, const uint32_t* np,
+    const uint32_t* pj_list, const uint32_t* pj_pref, const uint32_t* pj_take, const uint32_t* list_off,
+    const uint32_t* row_ids, uint64_t* out_ids, float* out_dist, uint32_t* out_count, uint64_t* out_keys) {
+  __shared__ uint64_t sh[kMergeWaves][kWave];
+  const uint32_t q = blockIdx.x;
+  const int lane = threadIdx.x & 63;
+  const bool w0 = threadIdx.x < kWave;
+  const uint64_t* pq = partials + (uint64_t)q * P * S_max * k_keep;
+  uint32_t written = 0;
+  const uint32_t n_groups = ref_mode ? np[q] : 1;
+  for (uint32_t grp = 0; grp < n_groups; ++grp) {
+    uint64_t list;
+    uint32_t take;
+    if (ref_mode) {
+      take = pj_take[(uint64_t)q * P + grp];
+      if (take == 0) continue;  // uniform per block
+      list = block_merge_keys(pq + (uint64_t)grp * S_max * k_keep, S_max * k_keep, k_keep, sh);
+    } else {
+      take = k_keep;
+      list = block_merge_keys(pq, P * S_max * k_keep, k_keep, sh);
+    }
+    if (w0) {
+      const bool have = lane < (int)take && list != kKeyMax;
+      if (have) {
+        const uint32_t seq = (uint32_t)list;
+        uint32_t j = grp;
+        if (!ref_mode) {
+          j = 0;
+          for (uint32_t t = 0; t < P; ++t)
+            if (pj_pref[(uint64_t)q * P + t] <= seq && pj_list[(uint64_t)q * P + t] != kNoList) j = t;
+        }
+        const uint32_t L = pj_list[(uint64_t)q * P + j];
+        const uint32_t row = list_off[L] + (seq - pj_pref[(uint64_t)q * P + j]);
+        const uint64_t o = (uint64_t)q * k_keep + written + lane;
+        out_ids[o] = row_ids[row];
+        out_dist[o] = __uint_as_float(order_bits_to_f32_bits((uint32_t)(list >> 32)));
+        if (out_keys) out_keys[o] = list;
+      }
+      written += (uint32_t)__popcll(__ballot(have));
+    }
+  }
+  if (w0 && lane == 0) out_count[q] = written;
+  if (w0 && out_keys && lane >= (int)written && lane < (int)k_keep) out_keys[(uint64_t)q * k_keep + lane] = kKeyMax;
+}
+
+// exhaustive merge for the IVF handle (seq == vec_id already)
+__global__ __launch_bounds__(kWave * kMergeWaves) void seg_merge_kernel(const uint64_t* partials, uint32_t n_segs, uint32_t k,
+                                                                        uint64_t* out_ids, float* out_dist,
+                                                                        uint32_t* out_count) {
+  __shared__ uint64_t sh[kMergeWaves][kWave];
+  const uint32_t q = blockIdx.x;
+  uint64_t list = block_merge_keys(partials + (uint64_t)q * n_segs * k, n_segs * k, k, sh);
+  if (threadIdx.x >= kWave) return;
+  const int lane = threadIdx.x;
+  const bool have = lane < (int)k && list != kKeyMax;
+  if (have) {
+    out_ids[(uint64_t)q * k + lane] = (uint32_t)list;
+    out_dist[(uint64_t)q * k + lane] = __uint_as_float(order_bits_to_f32_bits((uint32_t)(list >> 32)));
+  }
+  const uint32_t cnt = (uint32_t)__popcll(__ballot(have));
+  if (lane == 0) out_count[q] = cnt;
+}
+
+// ---- storage construction ---------------------------------------------------------------------
+// rows of X (vec_id order) -> cluster-major storage; grid-stride over (sorted position, float4 column)
+__global__ void gather_rows_kernel(const float* X, uint32_t ld, const uint32_t* sorted_ids, const uint32_t* assign,
+                                   const uint32_t* starts, const uint32_t* list_off, uint64_t n, float* rows,
+                                   uint32_t* row_ids) {
+  const uint32_t ld4 = ld / 4;
+  const uint64_t total = n * ld4;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t p = i / ld4;
+    const uint32_t c4 = (uint32_t)(i % ld4);
+    const uint32_t id = sorted_ids[p];
+    const uint32_t c = assign[id];
+    const uint64_t dst = (uint64_t)list_off[c] + (p - starts[c]);
+    reinterpret_cast<f32x4*>(rows + dst * ld)[c4] = reinterpret_cast<const f32x4*>(X + (uint64_t)id * ld)[c4];
+    if (c4 == 0) row_ids[dst] = id;
+  }
+}
+
+__global__ void gather_init_kernel(const float* X, uint32_t ld, const uint32_t* idx, uint32_t k, float* C) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (uint64_t)k * ld) return;
+  C[i] = X[(uint64_t)idx[i / ld] * ld + (i % ld)];
+}
+
+__global__ void u32_to_u64_kernel(const uint32_t* in, uint64_t n, uint64_t* out) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = in[i];
+}
+
+}  // namespace vers
+
+using namespace vers;
+
+// =================================================================================================
+struct vers_ivf {
+  int device = 0, n_cu = 256;
+  uint32_t d = 0, ld = 0, ldq = 0;
+  // index state (device cache of the reference's five fields, ivfflat.rs:9-15)
+  uint32_t k = 0;         // num_centroids; 0 = no index / nothing kept
+  uint64_t n_total = 0;   // assignments.len(): next vec_id handed out by add
+  DevBuf centroids, rows, row_ids, list_off, list_len;
+  std::vector<uint32_t> h_off, h_len, h_cap;
+  uint64_t cap_rows = 0;
+  uint32_t max_len = 0;
+  // scratch
+  KMeansScratch km;
+  DevBuf qp, qil, cpart, probe, pj, lists, pairs, items, groups, qblocks, partials, status, o_ids, o_dist, o_cnt, xpart;
+  hipEvent_t ev0 = nullptr, ev1 = nullptr;
+  bool ev_valid = false;
+  GroupTotals last_tot{};
+  bool tot_valid = false;
+  std::mutex mu;
+};
+
+namespace {
+
+int32_t sync_status(vers_ivf* h, hipStream_t st) {
+  uint32_t s = 0;
+  VERS_HIP_TRY(hipStreamSynchronize(st));
+  VERS_HIP_TRY(hipMemcpy(&s, h->status.p, sizeof(s), hipMemcpyDeviceToHost));
+  if (s) {
+    VERS_HIP_TRY(hipMemset(h->status.p, 0, sizeof(s)));
+    if (s & kStNaN) return fail(VERS_ERR_NAN, "NaN distance (the reference panics in partial_cmp().unwrap())");
+    if (s & kStInsufficient)
+      return fail(VERS_ERR_INSUFFICIENT, "fewer than top_k vectors reachable (reference: index out of bounds, ivfflat.rs:169)");
+    if (s & kStSpillTooDeep) return fail(VERS_ERR_INVALID, "search_approximate would spill past 64 lists (unsupported)");
+  }
+  return VERS_OK;
+}
+
+// Lays the lists out cluster-major with slack and fills them from X (vec_id order).
+// d_assign/d_sorted/d_starts are device arrays for the n rows of X.
+int32_t build_storage(vers_ivf* h, const float* X, uint64_t n, const uint32_t* d_assign, const uint32_t* d_sorted,
+                      const uint32_t* d_counts, const uint32_t* d_starts, uint32_t k, hipStream_t st) {
+  h->h_len.assign(k, 0);
+  h->h_off.assign(k, 0);
+  h->h_cap.assign(k, 0);
+  if (k) VERS_HIP_TRY(hipMemcpyAsync(h->h_len.data(), d_counts, (size_t)k * 4, hipMemcpyDeviceToHost, st));
+  VERS_HIP_TRY(hipStreamSynchronize(st));
+  uint64_t off = 0;
+  h->max_len = 0;
+  for (uint32_t c = 0; c < k; ++c) {
+    const uint32_t len = h->h_len[c];
+    const uint32_t cap = round_up(len + std::max<uint32_t>(64u, len / 16u), 64u);
+    h->h_off[c] = (uint32_t)off;
+    h->h_cap[c] = cap;
+    off += cap;
+    h->max_len = std::max(h->max_len, len);
+    if (off > 0xFFFFFFFFull) return fail(VERS_ERR_INVALID, "more than 2^32-1 storage rows on one GPU");
+  }
+  h->cap_rows = off;
+  if (int32_t rc = h->rows.reserve((off ? off : 1) * (size_t)h->ld * sizeof(float))) return rc;
+  if (int32_t rc = h->row_ids.reserve((off ? off : 1) * sizeof(uint32_t))) return rc;
+  if (int32_t rc = h->list_off.reserve((k ? k : 1) * sizeof(uint32_t))) return rc;
+  if (int32_t rc = h->list_len.reserve((k ? k : 1) * sizeof(uint32_t))) return rc;
+  VERS_HIP_TRY(hipMemsetAsync(h->row_ids.p, 0xFF, (off ? off : 1) * sizeof(uint32_t), st));
+  if (k) {
+    VERS_HIP_TRY(hipMemcpyAsync(h->list_off.p, h->h_off.data(), (size_t)k * 4, hipMemcpyHostToDevice, st));
+    VERS_HIP_TRY(hipMemcpyAsync(h->list_len.p, h->h_len.data(), (size_t)k * 4, hipMemcpyHostToDevice, st));
+  }
+  if (n) {
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(h->n_cu * 8), dim3(256), 0, st, X, h->ld, d_sorted, d_assign, d_starts,
+                       h->list_off.as<uint32_t>(), n, h->rows.as<float>(), h->row_ids.as<uint32_t>());
+    VERS_HIP_TRY(hipGetLastError());
+  }
+  VERS_HIP_TRY(hipStreamSynchronize(st));
+  h->k = k;
+  h->n_total = n;
+  return VERS_OK;
+}
+
+// index from (X, centroids already in h->centroids, device assignments)
+int32_t install_index(vers_ivf* h, const float* X, uint64_t n, const uint32_t* d_assign, uint32_t k, hipStream_t st) {
+  DevBuf sorted;
+  if (int32_t rc = sorted.reserve((n ? n : 1) * sizeof(uint32_t))) return rc;
+  if (int32_t rc = h->km.counts.reserve((2 * (size_t)k + 2) * sizeof(uint32_t))) return rc;
+  uint32_t* counts = h->km.counts.as<uint32_t>();
+  uint32_t* starts = counts + k;
+  if (int32_t rc = km_group(d_assign, (uint32_t)n, k, sorted.as<uint32_t>(), counts, starts, h->km, st)) return rc;
+  return build_storage(h, X, n, d_assign, sorted.as<uint32_t>(), counts, starts, k, st);
+}
+
+// build_kmeans + best-of-attempts (ivfflat.rs:73-121) on device-resident X; leaves the winning
+// centroids in h->centroids and assignments in best_assign.
+int32_t run_build(vers_ivf* h, const float* X, uint64_t n, uint32_t k, uint64_t num_attempts, uint64_t max_iterations,
+                  const uint64_t* init_indices, DevBuf& best_assign, float* out_cost, int32_t* out_kept,
+                  uint64_t* out_iterations, hipStream_t st) {
+  const uint32_t ld = h->ld;
+  DevBuf C, Cn, assign, mind, sorted, idx, bestC;
+  const size_t cbytes = ((size_t)k * ld ? (size_t)k * ld : 1) * sizeof(float);
+  if (int32_t rc = C.reserve(cbytes)) return rc;
+  if (int32_t rc = Cn.reserve(cbytes)) return rc;
+  if (int32_t rc = bestC.reserve(cbytes)) return rc;
+  if (int32_t rc = assign.reserve((n ? n : 1) * 4)) return rc;
+  if (int32_t rc = best_assign.reserve((n ? n : 1) * 4)) return rc;
+  if (int32_t rc = mind.reserve((n ? n : 1) * 4)) return rc;
+  if (int32_t rc = sorted.reserve((n ? n : 1) * 4)) return rc;
+  if (int32_t rc = idx.reserve((k ? k : 1) * 4)) return rc;
+  if (int32_t rc = h->km.counts.reserve((2 * (size_t)k + 2) * 4)) return rc;
+  if (int32_t rc = h->km.misc.reserve(64)) return rc;
+  if (int32_t rc = h->km.status.reserve(16)) return rc;
+  VERS_HIP_TRY(hipMemsetAsync(h->km.status.p, 0, 16, st));
+  uint32_t* counts = h->km.counts.as<uint32_t>();
+  uint32_t* starts = counts + k;
+  float* cost_dev = h->km.misc.as<float>();
+  uint32_t* flag_dev = h->km.misc.as<uint32_t>() + 4;
+  float best = INFINITY;
+  *out_kept = 0;
+  std::vector<uint32_t> idx32(k ? k : 1);
+  for (uint64_t a = 0; a < num_attempts; ++a) {
+    if (n > 0 && k == 0) return fail(VERS_ERR_EMPTY, "build_index with zero clusters: min_by over no centroids (reference panics)");
+    for (uint32_t c = 0; c < k; ++c) {
+      const uint64_t ix = init_indices[a * k + c];
+      if (ix >= n) return fail(VERS_ERR_INVALID, "vers_ivf_build: init index out of range");
+      idx32[c] = (uint32_t)ix;
+    }
+    if (k) {
+      VERS_HIP_TRY(hipMemcpyAsync(idx.p, idx32.data(), (size_t)k * 4, hipMemcpyHostToDevice, st));
+      VERS_HIP_TRY(hipStreamSynchronize(st));  // idx32 is reused by the next attempt
+      hipLaunchKernelGGL(gather_init_kernel, dim3((unsigned)(((uint64_t)k * ld + 255) / 256)), dim3(256), 0, st, X, ld,
+                         idx.as<uint32_t>(), k, C.as<float>());
+      VERS_HIP_TRY(hipGetLastError());
+    }
+    uint64_t iters = 0;
+    for (uint64_t it = 0; it < max_iterations; ++it) {
+      if (int32_t rc = km_assign(X, n, C.as<float>(), k, h->d, ld, assign.as<uint32_t>(), nullptr, h->km, h->n_cu, st)) return rc;
+      if (int32_t rc = km_group(assign.as<uint32_t>(), (uint32_t)n, k, sorted.as<uint32_t>(), counts, starts, h->km, st)) return rc;
+      if (int32_t rc = km_update(X, ld, sorted.as<uint32_t>(), starts, k, Cn.as<float>(), st)) return rc;
+      if (int32_t rc = km_differs(C.as<float>(), Cn.as<float>(), (uint64_t)k * ld, flag_dev, st)) return rc;
+      uint32_t differs = 0;
+      VERS_HIP_TRY(hipMemcpyAsync(&differs, flag_dev, 4, hipMemcpyDeviceToHost, st));
+      VERS_HIP_TRY(hipStreamSynchronize(st));
+      ++iters;
+      if (!differs) break;  // ivfflat.rs:91-93: bitwise equal -> keep the OLD centroids and stop
+      std::swap(C.p, Cn.p);
+      std::swap(C.cap, Cn.cap);
+    }
+    if (out_iterations) out_iterations[a] = iters;
+    if (int32_t rc = km_assign(X, n, C.as<float>(), k, h->d, ld, assign.as<uint32_t>(), mind.as<float>(), h->km, h->n_cu, st)) return rc;
+    if (int32_t rc = km_cost_fold(mind.as<float>(), n, cost_dev, st)) return rc;
+    float cost = 0.0f;
+    uint32_t stw = 0;
+    VERS_HIP_TRY(hipMemcpyAsync(&cost, cost_dev, 4, hipMemcpyDeviceToHost, st));
+    VERS_HIP_TRY(hipMemcpyAsync(&stw, h->km.status.p, 4, hipMemcpyDeviceToHost, st));
+    VERS_HIP_TRY(hipStreamSynchronize(st));
+    if ((stw & 1u) && k >= 2) {
+      VERS_HIP_TRY(hipMemset(h->km.status.p, 0, 16));
+      return fail(VERS_ERR_NAN, "NaN distance in assign_to_clusters (reference panics)");
+    }
+    if (cost < best) {  // strict: the first best attempt wins (ivfflat.rs:116)
+      best = cost;
+      *out_kept = 1;
+      VERS_HIP_TRY(hipMemcpyAsync(bestC.p, C.p, cbytes, hipMemcpyDeviceToDevice, st));
+      VERS_HIP_TRY(hipMemcpyAsync(best_assign.p, assign.p, (n ? n : 1) * 4, hipMemcpyDeviceToDevice, st));
+    }
+  }
+  *out_cost = best;
+  if (*out_kept) {
+    if (int32_t rc = h->centroids.reserve(cbytes)) return rc;
+    VERS_HIP_TRY(hipMemcpyAsync(h->centroids.p, bestC.p, cbytes, hipMemcpyDeviceToDevice, st));
+  }
+  VERS_HIP_TRY(hipStreamSynchronize(st));
+  return VERS_OK;
+}
+
+int32_t build_common(vers_ivf* h, const float* X, uint64_t n, uint64_t num_clusters, uint64_t num_attempts,
+                     uint64_t max_iterations, const uint64_t* init_indices, float* out_centroids, uint64_t* out_assignments,
+                     float* out_cost, int32_t* out_kept, uint64_t* out_iterations) {
+  const uint32_t k = (uint32_t)num_clusters;
+  DevBuf best_assign;
+  float cost = INFINITY;
+  int32_t kept = 0;
+  if (int32_t rc = run_build(h, X, n, k, num_attempts, max_iterations, init_indices, best_assign, &cost, &kept, out_iterations,
+                             nullptr))
+    return rc;
+  if (out_cost) *out_cost = cost;
+  if (out_kept) *out_kept = kept;
+  if (!kept) {
+    // nothing kept: centroids and assignments stay EMPTY, ids = num_clusters empty lists (ivfflat.rs:109-110,123)
+    h->k = 0;
+    h->n_total = 0;
+    h->cap_rows = 0;
+    h->max_len = 0;
+    h->h_len.clear(); h->h_off.clear(); h->h_cap.clear();
+    return VERS_OK;
+  }
+  if (int32_t rc = install_index(h, X, n, best_assign.as<uint32_t>(), k, nullptr)) return rc;
+  if (out_centroids && k)
+    VERS_HIP_TRY(hipMemcpy2D(out_centroids, (size_t)h->d * 4, h->centroids.p, (size_t)h->ld * 4, (size_t)h->d * 4, k,
+                             hipMemcpyDeviceToHost));
+  if (out_assignments && n) {
+    DevBuf a64;
+    if (int32_t rc = a64.reserve(n * 8)) return rc;
+    hipLaunchKernelGGL(u32_to_u64_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, best_assign.as<uint32_t>(), n,
+                       a64.as<uint64_t>());
+    VERS_HIP_TRY(hipGetLastError());
+    VERS_HIP_TRY(hipMemcpy(out_assignments, a64.p, n * 8, hipMemcpyDeviceToHost));
+  }
+  return VERS_OK;
+}
+
+// ---- search ---------------------------------------------------------------------------------------
+template <int QG, bool SEQ_IDS>
+int32_t launch_seg_scan(vers_ivf* h, const SegSrc<QG, SEQ_IDS>& src, uint32_t n_items, int metric, hipStream_t st) {
+  ScanParams p;
+  p.ld = h->ld;
+  p.n_chunks = (h->ld + kChunk - 1) / kChunk;
+  p.k = src.k;
+  p.status = h->status.as<uint32_t>();
+  uint32_t blocks = (n_items + kWavesPerBlock - 1) / kWavesPerBlock;
+  if (blocks > (uint32_t)h->n_cu * 2u) blocks = (uint32_t)h->n_cu * 2u;
+  if (blocks == 0) blocks = 1;
+  const size_t lds = (size_t)kWavesPerBlock * kWave * kLdsStride * sizeof(float);
+  if (metric == 0)
+    hipLaunchKernelGGL((scan_kernel<QG, 0, SegSrc<QG, SEQ_IDS>>), dim3(blocks), dim3(kWave * kWavesPerBlock), lds, st, src, p);
+  else
+    hipLaunchKernelGGL((scan_kernel<QG, 1, SegSrc<QG, SEQ_IDS>>), dim3(blocks), dim3(kWave * kWavesPerBlock), lds, st, src, p);
+  VERS_HIP_TRY(hipGetLastError());
+  return VERS_OK;
+}
+
+// queries (device, pitch ldq_in) -> h->qp [b][ldq] zero padded; returns the pointer/pitch to use
+int32_t stage_plain_queries(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint32_t b, const float** q_out,
+                            hipStream_t st) {
+  if (int32_t rc = h->qp.reserve((size_t)b * h->ldq * sizeof(float))) return rc;
+  if (int32_t rc = launch_stage_queries(q_dev, ldq_in, h->d, h->qp.as<float>(), h->ldq, b, 1, st)) return rc;
+  *q_out = h->qp.as<float>();
+  return VERS_OK;
+}
+
+// coarse quantiser (ivfflat.rs:155-161): top-P centroids per query as ascending (dist, index) keys in h->probe
+int32_t coarse(vers_ivf* h, const float* qp, uint32_t b, uint32_t P, hipStream_t st) {
+  const int QG = b == 1 ? 1 : 8;
+  const uint32_t n_qg = (b + QG - 1) / QG;
+  const float* q = qp;
+  if (QG != 1) {
+    if (int32_t rc = h->qil.reserve((size_t)n_qg * h->ldq * QG * sizeof(float))) return rc;
+    if (int32_t rc = launch_stage_queries(qp, h->ldq, h->ldq, h->qil.as<float>(), h->ldq, b, QG, st)) return rc;
+    q = h->qil.as<float>();
+  }
+  const uint32_t target_items = (uint32_t)h->n_cu * 8u;
+  uint64_t per = ((uint64_t)h->k * n_qg + target_items - 1) / target_items;
+  const uint32_t seg_rows = (uint32_t)round_up64(per ? per : 1, kWave);
+  const uint32_t n_segs = (h->k + seg_rows - 1) / seg_rows;
+  if (int32_t rc = h->cpart.reserve((size_t)b * n_segs * P * sizeof(uint64_t))) return rc;
+  if (int32_t rc = h->probe.reserve((size_t)b * P * sizeof(uint64_t))) return rc;
+  auto fill = [&](auto& src) {
+    src.rows = h->centroids.as<float>(); src.n = h->k; src.ld = h->ld; src.seg_rows = seg_rows; src.n_segs = n_segs;
+    src.queries = q; src.ldq = h->ldq; src.b = b; src.partials = h->cpart.as<uint64_t>(); src.k = P; src.ids = nullptr;
+  };
+  int32_t rc;
+  if (QG == 1) {
+    SegSrc<1, false> src; fill(src);
+    rc = launch_seg_scan(h, src, n_segs * n_qg, 0, st);
+  } else {
+    SegSrc<8, false> src; fill(src);
+    rc = launch_seg_scan(h, src, n_segs * n_qg, 0, st);
+  }
+  if (rc) return rc;
+  hipLaunchKernelGGL(coarse_merge_kernel, dim3(b), dim3(kWave * kMergeWaves), 0, st, h->cpart.as<uint64_t>(), n_segs, P,
+                     h->probe.as<uint64_t>());
+  VERS_HIP_TRY(hipGetLastError());
+  return VERS_OK;
+}
+
+template <int QG>
+int32_t launch_ivf_scan(vers_ivf* h, const IvfSrc<QG>& src, uint32_t items_bound, hipStream_t st) {
+  ScanParams p;
+  p.ld = h->ld;
+  p.n_chunks = (h->ld + kChunk - 1) / kChunk;
+  p.k = src.k_keep;
+  p.status = h->status.as<uint32_t>();
+  uint32_t blocks = (items_bound + kWavesPerBlock - 1) / kWavesPerBlock;
+  if (blocks > (uint32_t)h->n_cu * 2u) blocks = (uint32_t)h->n_cu * 2u;
+  if (blocks == 0) blocks = 1;
+  const size_t lds = (size_t)kWavesPerBlock * kWave * kLdsStride * sizeof(float);
+  VERS_HIP_TRY(hipEventRecord(h->ev0, st));
+  hipLaunchKernelGGL((scan_kernel<QG, 0, IvfSrc<QG>>), dim3(blocks), dim3(kWave * kWavesPerBlock), lds, st, src, p);
+  VERS_HIP_TRY(hipGetLastError());
+  VERS_HIP_TRY(hipEventRecord(h->ev1, st));
+  h->ev_valid = true;
+  return VERS_OK;
+}
+
+// search_approximate for b queries.  nprobe == 0: the reference's own semantics (nearest list,
+// spill while short; results concatenated per list).  nprobe >= 1: extension, global top-k
+// over the nprobe nearest lists.
+int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint32_t b, uint32_t top_k, uint32_t nprobe,
+                          uint64_t* out_ids, float* out_dist, uint32_t* out_count, uint64_t* out_keys, hipStream_t st) {
+  if (b == 0) return VERS_OK;
+  if (top_k == 0) {
+    VERS_HIP_TRY(hipMemsetAsync(out_count, 0, sizeof(uint32_t) * b, st));
+    return VERS_OK;
+  }
+  if (h->k == 0) return fail(VERS_ERR_INSUFFICIENT, "search on an index without centroids (reference: index out of bounds, ivfflat.rs:169)");
+  const int ref_mode = nprobe == 0;
+  const uint32_t P = ref_mode ? std::min<uint32_t>(h->k, kMaxTopK) : std::min<uint32_t>(nprobe, h->k);
+  if (P > (uint32_t)kMaxTopK) return fail(VERS_ERR_INVALID, "nprobe > 64 is not supported");
+  const float* qp = nullptr;
+  if (int32_t rc = stage_plain_queries(h, q_dev, ldq_in, b, &qp, st)) return rc;
+  if (int32_t rc = coarse(h, qp, b, P, st)) return rc;
+
+  // geometry of the list scan
+  const uint64_t n_pj = (uint64_t)b * P;
+  const uint64_t pairs_est = ref_mode ? b : n_pj;
+  const uint64_t lists_est = std::min<uint64_t>(h->k, pairs_est);
+  const int QG = (b == 1 || pairs_est < 2 * lists_est) ? 1 : 8;
+  const uint64_t groups_bound = QG == 1 ? n_pj : (n_pj / QG + std::min<uint64_t>(h->k, n_pj));
+  uint32_t seg_rows;
+  if (b == 1) seg_rows = kWave;
+  else {
+    const uint64_t groups_est = std::max<uint64_t>(1, std::max<uint64_t>(pairs_est / QG, lists_est));
+    const uint64_t segs_wanted = std::max<uint64_t>(1, ((uint64_t)h->n_cu * 32 + groups_est - 1) / groups_est);
+    const uint64_t avg_len = std::max<uint64_t>(1, h->n_total / std::max<uint32_t>(1, h->k));
+    seg_rows = (uint32_t)round_up64(std::max<uint64_t>(1, (avg_len + segs_wanted - 1) / segs_wanted), kWave);
+  }
+  const uint32_t S_max = std::max<uint32_t>(1, (h->max_len + seg_rows - 1) / seg_rows);
+  const uint64_t items_bound = groups_bound * S_max;
+  if (items_bound > 0x7FFFFFFFull) return fail(VERS_ERR_INVALID, "search batch too large");
+
+  const uint32_t k_l = h->k;
+  // pj: list, pref, take per (q, j); np per q.   lists: cnt, fill | pair_off, group_off, item_off | totals
+  if (int32_t rc = h->pj.reserve((3 * n_pj + b) * sizeof(uint32_t))) return rc;
+  if (int32_t rc = h->lists.reserve((5 * (size_t)k_l) * sizeof(uint32_t) + sizeof(GroupTotals) + 64)) return rc;
+  if (int32_t rc = h->pairs.reserve(n_pj * sizeof(uint32_t))) return rc;
+  if (int32_t rc = h->items.reserve(std::max<uint64_t>(1, items_bound) * sizeof(ItemDesc))) return rc;
+  if (int32_t rc = h->groups.reserve(std::max<uint64_t>(1, groups_bound) * sizeof(GroupDesc))) return rc;
+  if (QG != 1)
+    if (int32_t rc = h->qblocks.reserve(groups_bound * h->ldq * QG * sizeof(float))) return rc;
+  const size_t part_bytes = (size_t)n_pj * S_max * top_k * sizeof(uint64_t);
+  if (int32_t rc = h->partials.reserve(part_bytes)) return rc;
+  uint32_t* pj_list = h->pj.as<uint32_t>();
+  uint32_t* pj_pref = pj_list + n_pj;
+  uint32_t* pj_take = pj_pref + n_pj;
+  uint32_t* np = pj_take + n_pj;
+  uint32_t* cnt = h->lists.as<uint32_t>();
+  uint32_t* fill = cnt + k_l;
+  uint32_t* pair_off = fill + k_l;
+  uint32_t* group_off = pair_off + k_l;
+  uint32_t* item_off = group_off + k_l;
+  GroupTotals* tot = (GroupTotals*)(((uintptr_t)(item_off + k_l) + 15) & ~(uintptr_t)15);
+
+  VERS_HIP_TRY(hipMemsetAsync(cnt, 0, 2 * (size_t)k_l * sizeof(uint32_t), st));
+  VERS_HIP_TRY(hipMemsetAsync(h->partials.p, 0xFF, part_bytes, st));
+  hipLaunchKernelGGL(plan_kernel, dim3((b + 127) / 128), dim3(128), 0, st, h->probe.as<uint64_t>(), b, P, k_l, top_k, ref_mode,
+                     h->list_len.as<uint32_t>(), (const uint8_t*)nullptr, 0u, pj_list, pj_pref, pj_take, np, cnt,
+                     h->status.as<uint32_t>());
+  VERS_HIP_TRY(hipGetLastError());
+  hipLaunchKernelGGL(group_kernel, dim3(1), dim3(1024), 0, st, cnt, h->list_len.as<uint32_t>(), k_l, (uint32_t)QG, seg_rows,
+                     pair_off, group_off, item_off, tot);
+  VERS_HIP_TRY(hipGetLastError());
+  hipLaunchKernelGGL(scatter_pairs_kernel, dim3((unsigned)((n_pj + 255) / 256)), dim3(256), 0, st, pj_list, (uint32_t)n_pj, pair_off,
+                     fill, h->pairs.as<uint32_t>());
+  VERS_HIP_TRY(hipGetLastError());
+  hipLaunchKernelGGL(items_kernel, dim3((k_l + 127) / 128), dim3(128), 0, st, cnt, h->list_len.as<uint32_t>(), k_l, (uint32_t)QG,
+                     seg_rows, pair_off, group_off, item_off, h->items.as<ItemDesc>(), h->groups.as<GroupDesc>());
+  VERS_HIP_TRY(hipGetLastError());
+  if (QG != 1) {
+    hipLaunchKernelGGL(gather_qblocks_kernel, dim3((unsigned)groups_bound), dim3(256), 0, st, h->groups.as<GroupDesc>(), tot,
+                       h->pairs.as<uint32_t>(), P, qp, h->ldq, (uint32_t)QG, h->qblocks.as<float>());
+    VERS_HIP_TRY(hipGetLastError());
+  }
+  auto fill_src = [&](auto& src) {
+    src.rows = h->rows.as<float>(); src.ld = h->ld; src.list_off = h->list_off.as<uint32_t>();
+    src.list_len = h->list_len.as<uint32_t>(); src.items = h->items.as<ItemDesc>(); src.n_items_dev = &tot->n_items;
+    src.cnt = cnt; src.pair_off = pair_off; src.pairs = h->pairs.as<uint32_t>(); src.group_off = group_off;
+    src.qblocks = h->qblocks.as<float>(); src.qp = qp; src.ldq = h->ldq; src.P = P; src.S_max = S_max; src.k_keep = top_k;
+    src.seg_rows = seg_rows; src.pj_pref = pj_pref; src.partials = h->partials.as<uint64_t>();
+  };
+  int32_t rc;
+  if (QG == 1) {
+    IvfSrc<1> src; fill_src(src);
+    rc = launch_ivf_scan(h, src, (uint32_t)items_bound, st);
+  } else {
+    IvfSrc<8> src; fill_src(src);
+    rc = launch_ivf_scan(h, src, (uint32_t)items_bound, st);
+  }
+  if (rc) return rc;
+  hipLaunchKernelGGL(ivf_merge_kernel, dim3(b), dim3(kWave * kMergeWaves), 0, st, h->partials.as<uint64_t>(), P, S_max, top_k,
+                     ref_mode, np, pj_list, pj_pref, pj_take, h->list_off.as<uint32_t>(), h->row_ids.as<uint32_t>(), out_ids,
+                     out_dist, out_count, out_keys);
+  VERS_HIP_TRY(hipGetLastError());
+  h->tot_valid = true;
+  return VERS_OK;
+}
+
+int32_t exhaustive_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint32_t b, uint32_t top_k, uint32_t metric,
+                              uint64_t* out_ids, float* out_dist, uint32_t* out_count, hipStream_t st) {
+  if (b == 0) return VERS_OK;
+  if (top_k == 0) {
+    VERS_HIP_TRY(hipMemsetAsync(out_count, 0, sizeof(uint32_t) * b, st));
+    return VERS_OK;
+  }
+  const int QG = b == 1 ? 1 : 8;
+  const uint32_t n_qg = (b + QG - 1) / QG;
+  if (int32_t rc = h->qil.reserve((size_t)n_qg * h->ldq * QG * sizeof(float))) return rc;
+  if (int32_t rc = launch_stage_queries(q_dev, ldq_in, h->d, h->qil.as<float>(), h->ldq, b, QG, st)) return rc;
+  const uint32_t target_items = (uint32_t)h->n_cu * 8u;
+  uint64_t per = (h->cap_rows * n_qg + target_items - 1) / target_items;
+  const uint32_t seg_rows = (uint32_t)round_up64(per ? per : 1, kWave);
+  uint32_t n_segs = (uint32_t)((h->cap_rows + seg_rows - 1) / seg_rows);
+  if (n_segs == 0) n_segs = 1;
+  if (int32_t rc = h->xpart.reserve((size_t)b * n_segs * top_k * sizeof(uint64_t))) return rc;
+  auto fill = [&](auto& src) {
+    src.rows = h->rows.as<float>(); src.n = h->cap_rows; src.ld = h->ld; src.seg_rows = seg_rows; src.n_segs = n_segs;
+    src.queries = h->qil.as<float>(); src.ldq = h->ldq; src.b = b; src.partials = h->xpart.as<uint64_t>(); src.k = top_k;
+    src.ids = h->row_ids.as<uint32_t>();
+  };
+  int32_t rc;
+  if (QG == 1) {
+    SegSrc<1, true> src; fill(src);
+    rc = launch_seg_scan(h, src, n_segs * n_qg, (int)metric, st);
+  } else {
+    SegSrc<8, true> src; fill(src);
+    rc = launch_seg_scan(h, src, n_segs * n_qg, (int)metric, st);
+  }
+  if (rc) return rc;
+  hipLaunchKernelGGL(seg_merge_kernel, dim3(b), dim3(kWave * kMergeWaves), 0, st, h->xpart.as<uint64_t>(), n_segs, top_k, out_ids,
+                     out_dist, out_count);
+  VERS_HIP_TRY(hipGetLastError());
+  return VERS_OK;
+}
+
+// re-lays the storage out with fresh slack (called when a list is full)
+int32_t relayout(vers_ivf* h) {
+  const uint32_t k = h->k;
+  std::vector<uint32_t> noff(k), ncap(k);
+  uint64_t off = 0;
+  for (uint32_t c = 0; c < k; ++c) {
+    const uint32_t len = h->h_len[c];
+    ncap[c] = round_up(len + std::max<uint32_t>(64u, len / 8u), 64u);
+    noff[c] = (uint32_t)off;
+    off += ncap[c];
+    if (off > 0xFFFFFFFFull) return fail(VERS_ERR_INVALID, "more than 2^32-1 storage rows on one GPU");
+  }
+  DevBuf nrows, nids;
+  if (int32_t rc = nrows.reserve((off ? off : 1) * (size_t)h->ld * sizeof(float))) return rc;
+  if (int32_t rc = nids.reserve((off ? off : 1) * sizeof(uint32_t))) return rc;
+  VERS_HIP_TRY(hipMemset(nids.p, 0xFF, (off ? off : 1) * sizeof(uint32_t)));
+  for (uint32_t c = 0; c < k; ++c) {
+    if (!h->h_len[c]) continue;
+    VERS_HIP_TRY(hipMemcpyAsync(nrows.as<float>() + (size_t)noff[c] * h->ld, h->rows.as<float>() + (size_t)h->h_off[c] * h->ld,
+                                (size_t)h->h_len[c] * h->ld * sizeof(float), hipMemcpyDeviceToDevice, nullptr));
+    VERS_HIP_TRY(hipMemcpyAsync(nids.as<uint32_t>() + noff[c], h->row_ids.as<uint32_t>() + h->h_off[c],
+                                (size_t)h->h_len[c] * sizeof(uint32_t), hipMemcpyDeviceToDevice, nullptr));
+  }
+  VERS_HIP_TRY(hipDeviceSynchronize());
+  std::swap(h->rows.p, nrows.p); std::swap(h->rows.cap, nrows.cap);
+  std::swap(h->row_ids.p, nids.p); std::swap(h->row_ids.cap, nids.cap);
+  h->h_off = noff; h->h_cap = ncap; h->cap_rows = off;
+  VERS_HIP_TRY(hipMemcpy(h->list_off.p, h->h_off.data(), (size_t)k * 4, hipMemcpyHostToDevice));
+  return VERS_OK;
+}
+
+int32_t ensure_out(vers_ivf* h, size_t need, uint32_t b) {
+  if (int32_t rc = h->o_ids.reserve(need * sizeof(uint64_t))) return rc;
+  if (int32_t rc = h->o_dist.reserve(need * sizeof(float))) return rc;
+  return h->o_cnt.reserve((size_t)b * sizeof(uint32_t));
+}
+
+int32_t upload_queries(const float* queries, uint64_t stride_bytes, uint32_t b, uint32_t d, DevBuf& buf) {
+  if (int32_t rc = buf.reserve((size_t)b * d * sizeof(float))) return rc;
+  VERS_HIP_TRY(hipMemcpy2D(buf.p, (size_t)d * 4, queries, stride_bytes, (size_t)d * 4, b, hipMemcpyHostToDevice));
+  return VERS_OK;
+}
+
+int32_t download_results(vers_ivf* h, uint32_t b, uint32_t top_k, uint64_t* out_ids, float* out_dist, uint32_t* out_count) {
+  const size_t need = (size_t)b * top_k;
+  if (need) {
+    VERS_HIP_TRY(hipMemcpy(out_ids, h->o_ids.p, need * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    VERS_HIP_TRY(hipMemcpy(out_dist, h->o_dist.p, need * sizeof(float), hipMemcpyDeviceToHost));
+  }
+  VERS_HIP_TRY(hipMemcpy(out_count, h->o_cnt.p, (size_t)b * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  return VERS_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t vers_ivf_create(int32_t device, uint32_t d, vers_ivf_t** out) {
+  if (!out || d == 0) return fail(VERS_ERR_INVALID, "vers_ivf_create: bad arguments");
+  int cnt = 0;
+  VERS_HIP_TRY(hipGetDeviceCount(&cnt));
+  if (device < 0 || device >= cnt) return fail(VERS_ERR_INVALID, "vers_ivf_create: no such device");
+  DeviceGuard g(device);
+  vers_ivf* h = new (std::nothrow) vers_ivf();
+  if (!h) return fail(VERS_ERR_INVALID, "out of host memory");
+  h->device = device;
+  h->d = d;
+  h->ld = round_up(d, 4);
+  h->ldq = round_up(h->ld, kChunk);
+  hipDeviceProp_t prop;
+  VERS_HIP_TRY(hipGetDeviceProperties(&prop, device));
+  h->n_cu = prop.multiProcessorCount;
+  if (int32_t rc = h->status.reserve(16)) return rc;
+  VERS_HIP_TRY(hipMemset(h->status.p, 0, 16));
+  VERS_HIP_TRY(hipEventCreate(&h->ev0));
+  VERS_HIP_TRY(hipEventCreate(&h->ev1));
+  *out = h;
+  return VERS_OK;
+}
+
+int32_t vers_ivf_destroy(vers_ivf_t* h) {
+  if (!h) return VERS_OK;
+  DeviceGuard g(h->device);
+  (void)hipDeviceSynchronize();
+  if (h->ev0) (void)hipEventDestroy(h->ev0);
+  if (h->ev1) (void)hipEventDestroy(h->ev1);
+  delete h;
+  return VERS_OK;
+}
+
+int32_t vers_ivf_build(vers_ivf_t* h, const float* rows, uint64_t n, uint64_t row_stride_bytes, uint64_t num_clusters,
+                       uint64_t num_attempts, uint64_t max_iterations, const uint64_t* init_indices, float* out_centroids,
+                       uint64_t* out_assignments, float* out_cost, int32_t* out_kept, uint64_t* out_iterations) {
+  if (!h || (n && !rows) || row_stride_bytes < (uint64_t)(h ? h->d : 0) * 4 || row_stride_bytes % 4 ||
+      (num_attempts * num_clusters && !init_indices) || n > 0xFFFFFFFFull || num_clusters > 0xFFFFFFFFull)
+    return fail(VERS_ERR_INVALID, "vers_ivf_build: bad arguments");
+  std::lock_guard<std::mutex> lk(h->mu);
+  DeviceGuard g(h->device);
+  DevBuf X;
+  if (int32_t rc = X.reserve((n ? n : 1) * (size_t)h->ld * sizeof(float))) return rc;
+  if (n) {
+    if (h->ld != h->d) VERS_HIP_TRY(hipMemset(X.p, 0, n * (size_t)h->ld * sizeof(float)));
+    VERS_HIP_TRY(hipMemcpy2D(X.p, (size_t)h->ld * 4, rows, row_stride_bytes, (size_t)h->d * 4, n, hipMemcpyHostToDevice));
+  }
+  return build_common(h, X.as<float>(), n, num_clusters, num_attempts, max_iterations, init_indices, out_centroids,
+                      out_assignments, out_cost, out_kept, out_iterations);
+}
+
+int32_t vers_ivf_build_dev(vers_ivf_t* h, const float* rows_dev, uint64_t n, uint64_t ld_floats, uint64_t num_clusters,
+                           uint64_t num_attempts, uint64_t max_iterations, const uint64_t* init_indices, float* out_centroids,
+                           uint64_t* out_assignments, float* out_cost, int32_t* out_kept, uint64_t* out_iterations) {
+  if (!h || (n && !rows_dev) || ld_floats != (h ? h->ld : 0) || (num_attempts * num_clusters && !init_indices) ||
+      n > 0xFFFFFFFFull || num_clusters > 0xFFFFFFFFull)
+    return fail(VERS_ERR_INVALID, "vers_ivf_build_dev: bad arguments (ld_floats must equal round_up(d, 4))");
+  std::lock_guard<std::mutex> lk(h->mu);
+  DeviceGuard g(h->device);
+  return build_common(h, rows_dev, n, num_clusters, num_attempts, max_iterations, init_indices, out_centroids, out_assignments,
+                      out_cost, out_kept, out_iterations);
+}
+
+int32_t vers_ivf_upload(vers_ivf_t* h, const float* rows, uint64_t n, uint64_t row_stride_bytes, const float* centroids,
+                        uint64_t k, uint64_t c_stride_bytes, const uint64_t* assignments) {
+  if (!h || (n && (!rows || !assignments)) || (k && !centroids) || row_stride_bytes < (uint64_t)(h ? h->d : 0) * 4 ||
+      (k && c_stride_bytes < (uint64_t)h->d * 4) || n > 0xFFFFFFFFull || k > 0xFFFFFFFFull)
+    return fail(VERS_ERR_INVALID, "vers_ivf_upload: bad arguments");
+  std::vector<uint32_t> a32(n ? n : 1);
+  for (uint64_t i = 0; i < n; ++i) {
+    if (assignments[i] >= k) return fail(VERS_ERR_INVALID, "vers_ivf_upload: assignment out of range");
+    a32[i] = (uint32_t)assignments[i];
+  }
+  std::lock_guard<std::mutex> lk(h->mu);
+  DeviceGuard g(h->device);
+  DevBuf X, A;
+  if (int32_t rc = X.reserve((n ? n : 1) * (size_t)h->ld * sizeof(float))) return rc;
+  if (int32_t rc = A.reserve((n ? n : 1) * 4)) return rc;
+  if (n) {
+    if (h->ld != h->d) VERS_HIP_TRY(hipMemset(X.p, 0, n * (size_t)h->ld * sizeof(float)));
+    VERS_HIP_TRY(hipMemcpy2D(X.p, (size_t)h->ld * 4, rows, row_stride_bytes, (size_t)h->d * 4, n, hipMemcpyHostToDevice));
+    VERS_HIP_TRY(hipMemcpy(A.p, a32.data(), n * 4, hipMemcpyHostToDevice));
+  }
+  const size_t cbytes = ((size_t)k * h->ld ? (size_t)k * h->ld : 1) * sizeof(float);
+  if (int32_t rc = h->centroids.reserve(cbytes)) return rc;
+  if (k) {
+    VERS_HIP_TRY(hipMemset(h->centroids.p, 0, cbytes));
+    VERS_HIP_TRY(hipMemcpy2D(h->centroids.p, (size_t)h->ld * 4, centroids, c_stride_bytes, (size_t)h->d * 4, k, hipMemcpyHostToDevice));
+  }
+  return install_index(h, X.as<float>(), n, A.as<uint32_t>(), (uint32_t)k, nullptr);
+}
+
+int32_t vers_ivf_add(vers_ivf_t* h, const float* row, uint64_t* out_cluster, uint64_t* out_vec_id) {
+  if (!h || !row) return fail(VERS_ERR_INVALID, "vers_ivf_add: bad arguments");
+  std::lock_guard<std::mutex> lk(h->mu);
+  DeviceGuard g(h->device);
+  if (h->k == 0) return fail(VERS_ERR_EMPTY, "add on an index without centroids (reference: unwrap on None, ivfflat.rs:207)");
+  if (h->n_total >= 0xFFFFFFFEull) return fail(VERS_ERR_INVALID, "vec_id space exhausted");
+  DevBuf q;
+  if (int32_t rc = upload_queries(row, (uint64_t)h->d * 4, 1, h->d, q)) return rc;
+  const float* qp = nullptr;
+  if (int32_t rc = stage_plain_queries(h, q.as<float>(), h->d, 1, &qp, nullptr)) return rc;
+  if (int32_t rc = coarse(h, qp, 1, 1, nullptr)) return rc;  // first-minimum centroid (ivfflat.rs:201-207)
+  uint64_t key = 0;
+  VERS_HIP_TRY(hipMemcpy(&key, h->probe.p, sizeof(key), hipMemcpyDeviceToHost));
+  uint32_t stw = 0;
+  VERS_HIP_TRY(hipMemcpy(&stw, h->status.p, 4, hipMemcpyDeviceToHost));
+  if (stw) VERS_HIP_TRY(hipMemset(h->status.p, 0, 4));
+  if ((stw & kStNaN) && h->k >= 2) return fail(VERS_ERR_NAN, "NaN distance in add (reference panics)");
+  const uint32_t c = (uint32_t)key;
+  if (h->h_len[c] == h->h_cap[c])
+    if (int32_t rc = relayout(h)) return rc;
+  const uint32_t pos = h->h_off[c] + h->h_len[c];
+  const uint32_t vid = (uint32_t)h->n_total;  // the caller's vec_id is ignored, as in the reference (ivfflat.rs:209)
+  VERS_HIP_TRY(hipMemcpy(h->rows.as<float>() + (size_t)pos * h->ld, qp, (size_t)h->ld * sizeof(float), hipMemcpyDeviceToDevice));
+  VERS_HIP_TRY(hipMemcpy(h->row_ids.as<uint32_t>() + pos, &vid, 4, hipMemcpyHostToDevice));
+  h->h_len[c] += 1;
+  VERS_HIP_TRY(hipMemcpy(h->list_len.as<uint32_t>() + c, &h->h_len[c], 4, hipMemcpyHostToDevice));
+  h->max_len = std::max(h->max_len, h->h_len[c]);
+  h->n_total += 1;
+  if (out_cluster) *out_cluster = c;
+  if (out_vec_id) *out_vec_id = vid;
+  return VERS_OK;
+}
+
+int32_t vers_ivf_search_dev(vers_ivf_t* h, const float* queries_dev, uint64_t ldq_floats, uint32_t b, uint32_t top_k,
+                            uint32_t nprobe, uint64_t* out_ids_dev, float* out_dist_dev, uint32_t* out_count_dev, void* stream) {
+  if (!h) return fail(VERS_ERR_INVALID, "null handle");
+  if (top_k > VERS_MAX_TOPK) return fail(VERS_ERR_INVALID, "top_k > VERS_MAX_TOPK (64) is not supported");
+  if (b && (!queries_dev || ldq_floats < h->d || !out_count_dev || (top_k && (!out_ids_dev || !out_dist_dev))))
+    return fail(VERS_ERR_INVALID, "vers_ivf_search_dev: bad arguments");
+  std::lock_guard<std::mutex> lk(h->mu);
+  DeviceGuard g(h->device);
+  return search_dev_locked(h, queries_dev, ldq_floats, b, top_k, nprobe, out_ids_dev, out_dist_dev, out_count_dev, nullptr,
+                           (hipStream_t)stream);
+}
+
+int32_t vers_ivf_poll(vers_ivf_t* h, void* stream) {
+  if (!h) return fail(VERS_ERR_INVALID, "null handle");
+  DeviceGuard g(h->device);
+  return sync_status(h, (hipStream_t)stream);
+}
+
+int32_t vers_ivf_search(vers_ivf_t* h, const float* queries, uint64_t q_stride_bytes, uint32_t b, uint32_t top_k,
+                        uint32_t nprobe, uint64_t* out_ids, float* out_dist, uint32_t* out_count) {
+  if (!h) return fail(VERS_ERR_INVALID, "null handle");
+  if (top_k > VERS_MAX_TOPK) return fail(VERS_ERR_INVALID, "top_k > VERS_MAX_TOPK (64) is not supported");
+  if (b && (!queries || q_stride_bytes < (uint64_t)h->d * 4 || q_stride_bytes % 4 || !out_count || (top_k && (!out_ids || !out_dist))))
+    return fail(VERS_ERR_INVALID, "vers_ivf_search: bad arguments");
+  if (b == 0) return VERS_OK;
+  std::lock_guard<std::mutex> lk(h->mu);
+  DeviceGuard g(h->device);
+  DevBuf q;
+  if (int32_t rc = upload_queries(queries, q_stride_bytes, b, h->d, q)) return rc;
+  if (int32_t rc = ensure_out(h, (size_t)b * std::max<uint32_t>(top_k, 1), b)) return rc;
+  if (int32_t rc = search_dev_locked(h, q.as<float>(), h->d, b, top_k, nprobe, h->o_ids.as<uint64_t>(), h->o_dist.as<float>(),
+                                     h->o_cnt.as<uint32_t>(), nullptr, nullptr))
+    return rc;
+  if (int32_t rc = sync_status(h, nullptr)) return rc;
+  return download_results(h, b, top_k, out_ids, out_dist, out_count);
+}
+
+int32_t vers_ivf_search_exhaustive_dev(vers_ivf_t* h, const float* queries_dev, uint64_t ldq_floats, uint32_t b, uint32_t top_k,
+                                       uint32_t metric, uint64_t* out_ids_dev, float* out_dist_dev, uint32_t* out_count_dev,
+                                       void* stream) {
+  if (!h) return fail(VERS_ERR_INVALID, "null handle");
+  if (top_k > VERS_MAX_TOPK || metric > VERS_METRIC_COSDIST) return fail(VERS_ERR_INVALID, "unsupported top_k / metric");
+  if (b && (!queries_dev || ldq_floats < h->d || !out_count_dev || (top_k && (!out_ids_dev || !out_dist_dev))))
+    return fail(VERS_ERR_INVALID, "vers_ivf_search_exhaustive_dev: bad arguments");
+  std::lock_guard<std::mutex> lk(h->mu);
+  DeviceGuard g(h->device);
+  return exhaustive_dev_locked(h, queries_dev, ldq_floats, b, top_k, metric, out_ids_dev, out_dist_dev, out_count_dev,
+                               (hipStream_t)stream);
+}
+
+int32_t vers_ivf_search_exhaustive(vers_ivf_t* h, const float* queries, uint64_t q_stride_bytes, uint32_t b, uint32_t top_k,
+                                   uint32_t metric, uint64_t* out_ids, float* out_dist, uint32_t* out_count) {
+  if (!h) return fail(VERS_ERR_INVALID, "null handle");
+  if (top_k > VERS_MAX_TOPK || metric > VERS_METRIC_COSDIST) return fail(VERS_ERR_INVALID, "unsupported top_k / metric");
+  if (b && (!queries || q_stride_bytes < (uint64_t)h->d * 4 || q_stride_bytes % 4 || !out_count || (top_k && (!out_ids || !out_dist))))
+    return fail(VERS_ERR_INVALID, "vers_ivf_search_exhaustive: bad arguments");
+  if (b == 0) return VERS_OK;
+  std::lock_guard<std::mutex> lk(h->mu);
+  DeviceGuard g(h->device);
+  DevBuf q;
+  if (int32_t rc = upload_queries(queries, q_stride_bytes, b, h->d, q)) return rc;
+  if (int32_t rc = ensure_out(h, (size_t)b * std::max<uint32_t>(top_k, 1), b)) return rc;
+  if (int32_t rc = exhaustive_dev_locked(h, q.as<float>(), h->d, b, top_k, metric, h->o_ids.as<uint64_t>(), h->o_dist.as<float>(),
+                                         h->o_cnt.as<uint32_t>(), nullptr))
+    return rc;
+  if (int32_t rc = sync_status(h, nullptr)) return rc;
+  return download_results(h, b, top_k, out_ids, out_dist, out_count);
+}
+
+int32_t vers_ivf_info(vers_ivf_t* h, uint64_t* out_n, uint64_t* out_k, uint64_t* out_max_list_len) {
+  if (!h) return fail(VERS_ERR_INVALID, "null handle");
+  if (out_n) *out_n = h->n_total;
+  if (out_k) *out_k = h->k;
+  if (out_max_list_len) *out_max_list_len = h->max_len;
+  return VERS_OK;
+}
+
+int32_t vers_ivf_list_lengths(vers_ivf_t* h, uint64_t* out_lengths) {
+  if (!h || (h->k && !out_lengths)) return fail(VERS_ERR_INVALID, "bad arguments");
+  for (uint32_t c = 0; c < h->k; ++c) out_lengths[c] = h->h_len[c];
+  return VERS_OK;
+}
+
+int32_t vers_ivf_last_scan(vers_ivf_t* h, float* out_ms, uint64_t* out_union_rows, uint64_t* out_streamed_rows,
+                           uint32_t* out_items) {
+  if (!h) return fail(VERS_ERR_INVALID, "null handle");
+  if (!h->ev_valid || !h->tot_valid) return fail(VERS_ERR_INVALID, "no list scan has been launched on this handle");
+  DeviceGuard g(h->device);
+  VERS_HIP_TRY(hipEventSynchronize(h->ev1));
+  if (out_ms) VERS_HIP_TRY(hipEventElapsedTime(out_ms, h->ev0, h->ev1));
+  const uint32_t* item_off_end = h->lists.as<uint32_t>() + 5 * (size_t)h->k;
+  const GroupTotals* tot = (const GroupTotals*)(((uintptr_t)item_off_end + 15) & ~(uintptr_t)15);
+  GroupTotals t;
+  VERS_HIP_TRY(hipMemcpy(&t, tot, sizeof(t), hipMemcpyDeviceToHost));
+  if (out_union_rows) *out_union_rows = t.union_rows;
+  if (out_streamed_rows) *out_streamed_rows = t.streamed_rows;
+  if (out_items) *out_items = t.n_items;
+  return VERS_OK;
+}
+
+}  // extern "C"

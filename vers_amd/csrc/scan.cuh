@@ -237,7 +237,8 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void scan_kernel(Src src, S
       tile_chunk_compute<QG, METRIC>(acc, tile, lane, v.qb, c);
       if (cn == 0) {  // tile finished: fold its 64 candidates into the per-query lists
         const uint32_t row = t * kWave + lane;
-        const bool valid = row < v.nrows;
+        // kSeqIds: rows whose id is 0xFFFFFFFF are unused storage slack, not vectors
+        const bool valid = row < v.nrows && (!Src::kSeqIds || sid != 0xFFFFFFFFu);
 #pragma unroll
         for (int qi = 0; qi < QG; ++qi) {
           if (qi < (int)v.nq) {
@@ -282,6 +283,7 @@ __device__ __forceinline__ uint64_t block_merge_keys(const uint64_t* keys, uint3
 #pragma unroll
     for (int u = 0; u < U; ++u) wave_topk_update(list, k, cand[u], lane);
   }
+  __syncthreads();  // `sh` may still be read by wave 0 of a previous call
   sh[wid][lane] = list;
   __syncthreads();
   if (wid == 0) {

@@ -1,0 +1,184 @@
+"""Host-side mirror of vers's IVFFlatIndex (reference: vers/src/indexes/ivfflat.rs) on top of the
+C ABI -- the Python stand-in for the Rust `impl Index<N> for IVFFlatIndexHip<N>` shown in
+INTEGRATION.md.  Same method names, argument meaning and error behaviour as the reference: the
+five fields stay host-owned (for save_index/load_index), the device handle is a cache.
+
+A reference panic surfaces as capi.VersError (status NAN / INSUFFICIENT / EMPTY).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import struct
+
+import numpy as np
+
+from . import capi
+from .capi import _ptr, _vp, check, lib
+
+
+class IVFFlatIndex:
+    def __init__(self, d: int, device: int = 0):
+        self.d = int(d)
+        self.device = device
+        self._h = _vp()
+        check(lib().vers_ivf_create(device, self.d, C.byref(self._h)))
+        # the reference's fields, in its order (ivfflat.rs:9-15)
+        self.num_centroids = 0
+        self.values = np.zeros((0, self.d), dtype=np.float32)
+        self.centroids = np.zeros((0, self.d), dtype=np.float32)
+        self.assignments = np.zeros(0, dtype=np.uint64)
+        self.ids = []  # list of python lists of vec ids
+        self.cost = np.float32(np.inf)
+        self.iterations = None
+
+    def close(self):
+        if self._h:
+            lib().vers_ivf_destroy(self._h)
+            self._h = _vp()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- IVFFlatIndex::build_index (ivfflat.rs:102-136) -----------------------------------------
+    @classmethod
+    def build_index(cls, num_clusters: int, num_attempts: int, max_iterations: int, vectors, init_indices=None,
+                    rng=None, device: int = 0) -> "IVFFlatIndex":
+        vectors = np.ascontiguousarray(vectors, dtype=np.float32)
+        n, d = vectors.shape
+        self = cls(d, device)
+        if init_indices is None:
+            # initialize_centroids (ivfflat.rs:18-27): k draws WITH replacement per attempt
+            rng = rng or np.random.default_rng()
+            init_indices = rng.integers(0, max(n, 1), size=num_attempts * num_clusters)
+        init = np.ascontiguousarray(np.asarray(init_indices).reshape(-1), dtype=np.uint64)
+        assert init.size == num_attempts * num_clusters
+        cent = np.zeros((num_clusters, d), dtype=np.float32)
+        asg = np.zeros(n, dtype=np.uint64)
+        cost = C.c_float(0); kept = C.c_int32(0)
+        iters = np.zeros(max(num_attempts, 1), dtype=np.uint64)
+        check(lib().vers_ivf_build(self._h, _ptr(vectors), n, 4 * d, num_clusters, num_attempts, max_iterations,
+                                   _ptr(init), _ptr(cent), _ptr(asg), C.byref(cost), C.byref(kept), _ptr(iters)))
+        self.num_centroids = num_clusters
+        self.values = vectors.copy()  # ivfflat.rs:131 vectors.clone()
+        self.cost = np.float32(cost.value)
+        self.iterations = iters[:num_attempts]
+        if kept.value:
+            self.centroids, self.assignments = cent, asg
+        else:  # nothing beat +inf: empty centroids/assignments (ivfflat.rs:109-110)
+            self.centroids = np.zeros((0, d), dtype=np.float32)
+            self.assignments = np.zeros(0, dtype=np.uint64)
+        self.ids = [[] for _ in range(num_clusters)]
+        for vec_id, c in enumerate(self.assignments):  # ivfflat.rs:123-127
+            self.ids[int(c)].append(vec_id)
+        return self
+
+    # -- Index::add (ivfflat.rs:200-213) ------------------------------------------------------------
+    def add(self, embedding, vec_id: int = 0):
+        """`vec_id` is accepted and ignored, exactly like the reference (ivfflat.rs:209)."""
+        e = np.ascontiguousarray(embedding, dtype=np.float32).reshape(self.d)
+        c = C.c_uint64(0); vid = C.c_uint64(0)
+        check(lib().vers_ivf_add(self._h, _ptr(e), C.byref(c), C.byref(vid)))
+        assert vid.value == len(self.assignments)
+        self.values = np.concatenate([self.values, e[None]], axis=0)
+        self.assignments = np.concatenate([self.assignments, np.array([c.value], dtype=np.uint64)])
+        self.ids[c.value].append(int(vid.value))
+        return int(c.value), int(vid.value)
+
+    # -- Index::search_approximate (ivfflat.rs:153-198) ---------------------------------------------
+    def search_approximate(self, query, top_k: int):
+        ids, dist, cnt = self.search_batch(np.asarray(query, dtype=np.float32).reshape(1, self.d), top_k, nprobe=0)
+        return [(int(i), np.float32(x)) for i, x in zip(ids[0, :cnt[0]], dist[0, :cnt[0]])]
+
+    def search_batch(self, queries, top_k: int, nprobe: int = 0):
+        q = np.ascontiguousarray(np.atleast_2d(queries), dtype=np.float32)
+        b = q.shape[0]
+        ids = np.zeros((b, max(top_k, 1)), dtype=np.uint64)
+        dist = np.zeros((b, max(top_k, 1)), dtype=np.float32)
+        cnt = np.zeros(b, dtype=np.uint32)
+        check(lib().vers_ivf_search(self._h, _ptr(q), 4 * self.d, b, top_k, nprobe, _ptr(ids), _ptr(dist), _ptr(cnt)))
+        return ids[:, :top_k], dist[:, :top_k], cnt
+
+    def search_exhaustive(self, queries, top_k: int, metric: int = capi.METRIC_L2SQ):
+        q = np.ascontiguousarray(np.atleast_2d(queries), dtype=np.float32)
+        b = q.shape[0]
+        ids = np.zeros((b, max(top_k, 1)), dtype=np.uint64)
+        dist = np.zeros((b, max(top_k, 1)), dtype=np.float32)
+        cnt = np.zeros(b, dtype=np.uint32)
+        check(lib().vers_ivf_search_exhaustive(self._h, _ptr(q), 4 * self.d, b, top_k, metric, _ptr(ids), _ptr(dist), _ptr(cnt)))
+        return ids[:, :top_k], dist[:, :top_k], cnt
+
+    # -- device cache -----------------------------------------------------------------------------------
+    def _upload(self):
+        v = np.ascontiguousarray(self.values, dtype=np.float32)
+        c = np.ascontiguousarray(self.centroids, dtype=np.float32)
+        a = np.ascontiguousarray(self.assignments, dtype=np.uint64)
+        check(lib().vers_ivf_upload(self._h, _ptr(v), v.shape[0], 4 * self.d, _ptr(c), c.shape[0], 4 * self.d, _ptr(a)))
+
+    def info(self):
+        n = C.c_uint64(0); k = C.c_uint64(0); m = C.c_uint64(0)
+        check(lib().vers_ivf_info(self._h, C.byref(n), C.byref(k), C.byref(m)))
+        return n.value, k.value, m.value
+
+    def list_lengths(self):
+        _, k, _ = self.info()
+        out = np.zeros(max(k, 1), dtype=np.uint64)
+        check(lib().vers_ivf_list_lengths(self._h, _ptr(out)))
+        return out[:k]
+
+    def last_scan(self):
+        ms = C.c_float(0); u = C.c_uint64(0); s = C.c_uint64(0); it = C.c_uint32(0)
+        check(lib().vers_ivf_last_scan(self._h, C.byref(ms), C.byref(u), C.byref(s), C.byref(it)))
+        return dict(ms=ms.value, union_rows=u.value, streamed_rows=s.value, items=it.value)
+
+    # -- Index::save_index / load_index (base.rs:31-58) ---------------------------------------------
+    # bincode 1.3.3 default options: little endian, fixed-width ints, usize/len as u64, struct = fields in
+    # order without tags, Vec<T> = u64 len + items, [f32; N] through serde_arrays = N raw f32 (no length).
+    # (bincode / serde_arrays sources are not vendored in the reference: layout restated from their
+    # published format -- "parity unpinned" for this row, see DESIGN.md.)
+    def save_index(self, file_path: str):
+        with open(file_path, "wb") as f:
+            f.write(struct.pack("<Q", self.num_centroids))
+            for mat in (self.values, self.centroids):
+                m = np.ascontiguousarray(mat, dtype="<f4")
+                f.write(struct.pack("<Q", m.shape[0])); f.write(m.tobytes())
+            a = np.ascontiguousarray(self.assignments, dtype="<u8")
+            f.write(struct.pack("<Q", a.size)); f.write(a.tobytes())
+            f.write(struct.pack("<Q", len(self.ids)))
+            for lst in self.ids:
+                l = np.asarray(lst, dtype="<u8")
+                f.write(struct.pack("<Q", l.size)); f.write(l.tobytes())
+
+    @classmethod
+    def load_index(cls, file_path: str, d: int, device: int = 0) -> "IVFFlatIndex":
+        """`d` plays the role of the const generic N of IVFFlatIndex<N>."""
+        with open(file_path, "rb") as f:
+            buf = f.read()
+        off = 0
+
+        def u64():
+            nonlocal off
+            (v,) = struct.unpack_from("<Q", buf, off); off += 8
+            return v
+
+        def take(dtype, count):
+            nonlocal off
+            nbytes = count * np.dtype(dtype).itemsize
+            if off + nbytes > len(buf):
+                raise IOError("Deserialization error: unexpected end of file")
+            a = np.frombuffer(buf, dtype=dtype, count=count, offset=off).copy(); off += nbytes
+            return a
+
+        try:
+            self = cls(d, device)
+            self.num_centroids = u64()
+            self.values = take("<f4", u64() * d).reshape(-1, d)
+            self.centroids = take("<f4", u64() * d).reshape(-1, d)
+            self.assignments = take("<u8", u64())
+            self.ids = [list(map(int, take("<u8", u64()))) for _ in range(u64())]
+        except struct.error as e:
+            raise IOError(f"Deserialization error: {e}")
+        self._upload()
+        return self
