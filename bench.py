@@ -1,0 +1,213 @@
+#!/usr/bin/env python3
+"""bench.py -- BASELINE.json's metric on BASELINE.json's config:
+queries/sec + recall@10, IVFFlat N=10M d=768 nlist=4096 nprobe=32, batch=1024 queries.
+
+A "step" = one pass of the hot path over one batch of 1024 synthetic queries:
+vers_ivf_search_dev (coarse quantiser -> plan -> inverted-list scan -> merge), queries and
+outputs resident in HBM.  The corpus is synthetic (tests/datagen.py "Dist-C": clustered unit
+vectors), generated in HBM by vers_gen_rows_dev; the index is built on the device by
+vers_ivf_build_dev (k-means: attempts=1, --kmeans-iters iterations) before the timed region.
+
+Prints ONE JSON line (rank 0).  Extra keys: `roofline` (dominant kernel = the inverted-list scan,
+algorithmic bytes = bytes of the union of probed lists + centroids), `cpu_baseline` (the C
+restatement of the reference path, oracle/vers_oracle.c, timed on one host core on a bounded
+sample of the same queries), `recall_at_10`.
+
+Multi-GPU (`torchrun ... bench.py --gpus N`): strong scaling -- the SAME 10M corpus and the same
+query batches; the inverted lists are sharded across ranks (LPT by list length), every rank runs
+the replicated coarse quantiser and scans only its lists, partial top-k are exchanged with one
+RCCL all-gather and merged on every rank.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); 6290 GB/s is the measured copy ceiling
+
+
+def log(*a):
+    print(*a, file=sys.stderr, flush=True)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--n", type=int, default=10_000_000)
+    ap.add_argument("--d", type=int, default=768)
+    ap.add_argument("--nlist", type=int, default=4096)
+    ap.add_argument("--nprobe", type=int, default=32)
+    ap.add_argument("--batch", type=int, default=1024)
+    ap.add_argument("--top-k", type=int, default=10)
+    ap.add_argument("--kmeans-iters", type=int, default=4)
+    ap.add_argument("--modes-per-list", type=int, default=16)
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg")
+    ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-recall", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch
+    torch.cuda.set_device(local_rank)
+    dev = torch.device(f"cuda:{local_rank}")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    from tests import datagen as dg
+    from vers_amd import capi
+    from vers_amd.index import IVFFlatIndex
+
+    n, d, nlist, nprobe, B, top_k = args.n, args.d, args.nlist, args.nprobe, args.batch, args.top_k
+    ld = (d + 3) // 4 * 4
+    # Dist-C with 16 modes per list.  (SURVEY.md 8d suggested nlist/4 modes; measured on MI355X that
+    # degenerates: 4 iterations of k-means leave 3/4 of the lists empty and the rest at 4x the mean, so
+    # a query would probe ~1 real list instead of nprobe.  16 modes/list gives balanced lists of ~N/nlist.)
+    n_modes = max(1, args.modes_per_list * nlist)
+    sigma = float(dg.default_sigma(d))
+    SEED_X, SEED_Q, SEED_C = 0x5EED0001, 0x5EED0002, 0x5EEDC0DE
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+
+    # ---- corpus + index (not timed) -----------------------------------------------------------------
+    t0 = time.perf_counter()
+    X = torch.empty(n, ld, dtype=torch.float32, device=dev)
+    capi.gen_rows_dev(X.data_ptr(), n, d, ld, 1, SEED_X, SEED_C, n_modes, sigma)
+    torch.cuda.synchronize()
+    t_gen = time.perf_counter() - t0
+    init = (dg.mix64(np.uint64(0xB01D) + np.arange(nlist, dtype=np.uint64)) % np.uint64(n)).astype(np.uint64)
+    index = IVFFlatIndex(d, device=local_rank)
+    t0 = time.perf_counter()
+    kept = index.build_dev(X.data_ptr(), n, nlist, 1, args.kmeans_iters, init)
+    t_build = time.perf_counter() - t0
+    assert kept
+    del X
+    torch.cuda.empty_cache()
+    lens = index.list_lengths()
+    if rank == 0:
+        log(f"[bench] corpus {n}x{d} generated in {t_gen:.1f}s; build_index (k-means {int(index.iterations[0])} iters + final assign) "
+            f"{t_build:.1f}s; cost {float(index.cost):.1f}; list len min/mean/max {int(lens.min())}/{lens.mean():.0f}/{int(lens.max())}")
+    if world > 1:
+        raise SystemExit("multi-GPU sharding lands in the next commit")
+
+    # ---- queries: distinct batches drawn from the same distribution (not from the corpus) -------------
+    n_batches = max(1, min(args.steps + args.warmup, 8))
+    Q = torch.empty(n_batches * B, ld, dtype=torch.float32, device=dev)
+    capi.gen_rows_dev(Q.data_ptr(), n_batches * B, d, ld, 1, SEED_Q, SEED_C, n_modes, sigma)
+    ids = torch.zeros(B, top_k, dtype=torch.int64, device=dev)
+    dst = torch.zeros(B, top_k, dtype=torch.float32, device=dev)
+    cnt = torch.zeros(B, dtype=torch.int32, device=dev)
+    st = torch.cuda.current_stream().cuda_stream
+
+    def step(i):
+        qb = Q[(i % n_batches) * B:]
+        index.search_dev(qb.data_ptr(), ld, B, top_k, nprobe, ids.data_ptr(), dst.data_ptr(), cnt.data_ptr(), st)
+
+    for i in range(args.warmup):
+        step(i)
+    index.poll(st)
+    index.scan_times(reset=True)
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        step(args.warmup + i)
+    barrier()
+    elapsed = time.perf_counter() - t0
+    index.poll(st)  # NaN / insufficient latch -> raises
+    ls = index.last_scan()
+    scan_ms = index.scan_times(reset=True)
+    if dist is not None:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    qps = args.steps * B / elapsed
+
+    # ---- roofline of the dominant kernel (inverted-list scan), last batch's geometry -----------------
+    scan_mean_ms = float(np.mean(scan_ms)) if len(scan_ms) else float("nan")
+    algo_bytes = ls["union_rows"] * d * 4 + nlist * d * 4
+    achieved = algo_bytes / (scan_mean_ms * 1e-3) / 1e9
+    roofline = {"bound": "hbm", "kernel": "scan_kernel<8,0,IvfSrc<8>> (inverted-list scan)", "achieved": round(achieved, 1),
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "algorithmic_bytes_per_launch": int(algo_bytes), "streamed_bytes_per_launch": int(ls["streamed_rows"] * d * 4),
+                "launch_ms": round(scan_mean_ms, 4), "launches_timed": int(len(scan_ms)), "work_items": int(ls["items"])}
+
+    # ---- recall@10 against the exact scan (utils::search_exhaustive over the same values) --------------
+    last = args.warmup + args.steps - 1
+    recall = None
+    ids_h = ids.cpu().numpy().astype(np.uint64); dst_h = dst.cpu().numpy(); cnt_h = cnt.cpu().numpy()
+    if not args.no_recall:
+        nq_r = min(B, 1024)
+        eids = torch.zeros(nq_r, top_k, dtype=torch.int64, device=dev)
+        edst = torch.zeros(nq_r, top_k, dtype=torch.float32, device=dev)
+        ecnt = torch.zeros(nq_r, dtype=torch.int32, device=dev)
+        qb = Q[(last % n_batches) * B:]
+        t0 = time.perf_counter()
+        index.search_exhaustive_dev(qb.data_ptr(), ld, nq_r, top_k, 0, eids.data_ptr(), edst.data_ptr(), ecnt.data_ptr(), st)
+        index.poll(st)
+        t_ex = time.perf_counter() - t0
+        e = eids.cpu().numpy().astype(np.uint64)
+        hits = sum(len(set(ids_h[q, :cnt_h[q]].tolist()) & set(e[q].tolist())) for q in range(nq_r))
+        recall = hits / float(nq_r * top_k)
+        log(f"[bench] recall@{top_k} = {recall:.4f} over {nq_r} queries (exact scan took {t_ex:.2f}s)")
+
+    # ---- CPU baseline: the C restatement of the reference path on one host core -----------------------
+    cpu = None
+    if rank == 0 and not args.no_cpu:
+        from oracle import c_oracle as co
+        cent = index.get_centroids()
+        qh = Q[(last % n_batches) * B:(last % n_batches) * B + B, :d].cpu().numpy()
+        t_cpu, n_cpu, mismatches = 0.0, 0, 0
+        while t_cpu < args.cpu_seconds and n_cpu < B:
+            q = qh[n_cpu]
+            t0 = time.perf_counter()
+            ranked, _ = co.search_exhaustive(cent, q, nprobe)            # all centroid distances + stable sort
+            t_cpu += time.perf_counter() - t0
+            parts = [index.get_list(int(c)) for c in ranked]             # D2H of the probed lists: not timed
+            rows = np.concatenate([p[0] for p in parts], axis=0); rid = np.concatenate([p[1] for p in parts])
+            t0 = time.perf_counter()
+            pos, dd = co.search_exhaustive(rows, q, top_k)               # score every probed row, stable sort, take k
+            t_cpu += time.perf_counter() - t0
+            ok = (np.array_equal(rid[pos.astype(np.int64)], ids_h[n_cpu, :len(pos)])
+                  and np.array_equal(dd.view(np.uint32), dst_h[n_cpu, :len(pos)].view(np.uint32)))
+            mismatches += 0 if ok else 1
+            n_cpu += 1
+        cpu = {"value": round(n_cpu / t_cpu, 3), "unit": "queries/sec", "cores": 1, "kind": "port",
+               "sample": f"{n_cpu} queries of the last timed batch, nprobe={nprobe}, same index (lists read back from HBM); "
+                         f"single thread like the reference's serial search_approximate",
+               "gpu_matches_cpu_bitwise": mismatches == 0, "mismatching_queries": mismatches}
+        log(f"[bench] cpu baseline {cpu['value']} q/s on 1 core over {n_cpu} queries; GPU==CPU bitwise: {mismatches == 0}")
+
+    if rank == 0:
+        out = {"metric": "queries/sec + recall@10, IVFFlat N=10M d=768", "value": round(qps, 1), "unit": "queries/sec",
+               "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
+               "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+               "recall_at_10": None if recall is None else round(recall, 4),
+               "config": {"workload": f"IVFFlat search_approximate, nprobe extension: N={n} d={d} nlist={nlist} nprobe={nprobe} "
+                                      f"batch={B} top_k={top_k}, f32, clustered unit vectors (Dist-C)",
+                          "n": n, "d": d, "nlist": nlist, "nprobe": nprobe, "batch": B, "top_k": top_k,
+                          "kmeans_iters": int(index.iterations[0]), "parallelism": f"lists sharded over {world} GPU(s)"},
+               "roofline": roofline, "cpu_baseline": cpu}
+        print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

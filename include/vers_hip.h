@@ -174,6 +174,27 @@ int32_t vers_ivf_list_lengths(vers_ivf_t* h, uint64_t* out_lengths /* [k] */);
 int32_t vers_ivf_last_scan(vers_ivf_t* h, float* out_ms, uint64_t* out_union_rows,
                            uint64_t* out_streamed_rows, uint32_t* out_items);
 
+/* Durations (ms) of the most recent list-scan launches, oldest first (ring of 64); reset != 0
+ * empties the ring.  Lets bench.py time every launch of the timed region without stalling it. */
+int32_t vers_ivf_scan_times(vers_ivf_t* h, float* out_ms, uint32_t cap, uint32_t* out_n, int32_t reset);
+/* Reads inverted list `cluster` back to the host in list order: rows (pitch row_stride_bytes) and
+ * vec ids; out_rows / out_ids may be NULL to query the length only.  (ids[c] and values of the
+ * reference, for host-side serde and for the CPU baseline of bench.py.) */
+int32_t vers_ivf_get_list(vers_ivf_t* h, uint64_t cluster, float* out_rows, uint64_t row_stride_bytes,
+                          uint64_t* out_ids, uint64_t cap_rows, uint64_t* out_len);
+int32_t vers_ivf_get_centroids(vers_ivf_t* h, float* out_centroids, uint64_t c_stride_bytes);
+
+/* ------------------------------------------------------------------------ *
+ * Measurement tooling (bench.py): deterministic synthetic vectors written   *
+ * straight into HBM; bit-identical to tests/datagen.py on the host.          *
+ * kind 0 = uniform on the sphere, kind 1 = clustered (n_modes centres drawn  *
+ * as kind 0 from seed_centres, row = normalize(centre[row % n_modes] +       *
+ * sigma * noise)).  Rows start_row .. start_row+n-1 of the stream `seed`.    *
+ * ------------------------------------------------------------------------ */
+int32_t vers_gen_rows_dev(float* out_dev, uint64_t n, uint32_t d, uint64_t ld_floats, uint32_t kind,
+                          uint64_t seed, uint64_t seed_centres, uint32_t n_modes, float sigma,
+                          uint64_t start_row, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

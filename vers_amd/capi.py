@@ -57,6 +57,11 @@ SIGNATURES = {
     "vers_ivf_list_lengths": (C.c_int32, [_vp, _vp]),
     "vers_ivf_last_scan": (C.c_int32, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
                                        C.POINTER(C.c_uint32)]),
+    "vers_ivf_scan_times": (C.c_int32, [_vp, _vp, C.c_uint32, C.POINTER(C.c_uint32), C.c_int32]),
+    "vers_ivf_get_list": (C.c_int32, [_vp, C.c_uint64, _vp, C.c_uint64, _vp, C.c_uint64, C.POINTER(C.c_uint64)]),
+    "vers_ivf_get_centroids": (C.c_int32, [_vp, _vp, C.c_uint64]),
+    "vers_gen_rows_dev": (C.c_int32, [_vp, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint32,
+                                      C.c_float, C.c_uint64, _vp]),
     "vers_kmeans_assign": (C.c_int32, [C.c_int32, _vp, C.c_uint64, C.c_uint64, _vp, C.c_uint64, C.c_uint64, C.c_uint32, _vp, _vp]),
     "vers_kmeans_update": (C.c_int32, [C.c_int32, _vp, C.c_uint64, C.c_uint64, _vp, C.c_uint64, C.c_uint32, _vp]),
     "vers_kmeans_cost": (C.c_int32, [C.c_int32, _vp, C.c_uint64, C.c_uint64, _vp, C.c_uint64, C.c_uint64, _vp, C.c_uint32,
@@ -180,3 +185,9 @@ def kmeans_cost(X, Cn, assign, device: int = 0) -> np.float32:
     check(lib().vers_kmeans_cost(device, _ptr(X), X.shape[0], sx, _ptr(Cn), Cn.shape[0], sc, _ptr(assign), X.shape[1],
                                  C.byref(out)))
     return np.float32(out.value)
+
+
+def gen_rows_dev(out_ptr: int, n: int, d: int, ld: int, kind: int, seed: int, seed_centres: int = 0, n_modes: int = 1,
+                 sigma: float = 0.0, start_row: int = 0, stream: int = 0):
+    check(lib().vers_gen_rows_dev(_vp(out_ptr), n, d, ld, kind, seed, seed_centres, n_modes, C.c_float(float(sigma)),
+                                  start_row, _vp(stream)))

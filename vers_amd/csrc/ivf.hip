@@ -369,8 +369,9 @@ struct vers_ivf {
   // scratch
   KMeansScratch km;
   DevBuf qp, qil, cpart, probe, pj, lists, pairs, items, groups, qblocks, partials, status, o_ids, o_dist, o_cnt, xpart;
-  hipEvent_t ev0 = nullptr, ev1 = nullptr;
-  bool ev_valid = false;
+  static constexpr uint32_t kEvRing = 64;  // scan-launch timing ring (measurement hook)
+  hipEvent_t ev0[kEvRing] = {}, ev1[kEvRing] = {};
+  uint64_t ev_count = 0;
   GroupTotals last_tot{};
   bool tot_valid = false;
   std::mutex mu;
@@ -638,11 +639,12 @@ int32_t launch_ivf_scan(vers_ivf* h, const IvfSrc<QG>& src, uint32_t items_bound
   if (blocks > (uint32_t)h->n_cu * 2u) blocks = (uint32_t)h->n_cu * 2u;
   if (blocks == 0) blocks = 1;
   const size_t lds = (size_t)kWavesPerBlock * kWave * kLdsStride * sizeof(float);
-  VERS_HIP_TRY(hipEventRecord(h->ev0, st));
+  const uint32_t slot = (uint32_t)(h->ev_count % vers_ivf::kEvRing);
+  VERS_HIP_TRY(hipEventRecord(h->ev0[slot], st));
   hipLaunchKernelGGL((scan_kernel<QG, 0, IvfSrc<QG>>), dim3(blocks), dim3(kWave * kWavesPerBlock), lds, st, src, p);
   VERS_HIP_TRY(hipGetLastError());
-  VERS_HIP_TRY(hipEventRecord(h->ev1, st));
-  h->ev_valid = true;
+  VERS_HIP_TRY(hipEventRecord(h->ev1[slot], st));
+  h->ev_count += 1;
   return VERS_OK;
 }
 
@@ -859,8 +861,10 @@ int32_t vers_ivf_create(int32_t device, uint32_t d, vers_ivf_t** out) {
   h->n_cu = prop.multiProcessorCount;
   if (int32_t rc = h->status.reserve(16)) return rc;
   VERS_HIP_TRY(hipMemset(h->status.p, 0, 16));
-  VERS_HIP_TRY(hipEventCreate(&h->ev0));
-  VERS_HIP_TRY(hipEventCreate(&h->ev1));
+  for (uint32_t i = 0; i < vers_ivf::kEvRing; ++i) {
+    VERS_HIP_TRY(hipEventCreate(&h->ev0[i]));
+    VERS_HIP_TRY(hipEventCreate(&h->ev1[i]));
+  }
   *out = h;
   return VERS_OK;
 }
@@ -869,8 +873,10 @@ int32_t vers_ivf_destroy(vers_ivf_t* h) {
   if (!h) return VERS_OK;
   DeviceGuard g(h->device);
   (void)hipDeviceSynchronize();
-  if (h->ev0) (void)hipEventDestroy(h->ev0);
-  if (h->ev1) (void)hipEventDestroy(h->ev1);
+  for (uint32_t i = 0; i < vers_ivf::kEvRing; ++i) {
+    if (h->ev0[i]) (void)hipEventDestroy(h->ev0[i]);
+    if (h->ev1[i]) (void)hipEventDestroy(h->ev1[i]);
+  }
   delete h;
   return VERS_OK;
 }
@@ -1053,10 +1059,11 @@ int32_t vers_ivf_list_lengths(vers_ivf_t* h, uint64_t* out_lengths) {
 int32_t vers_ivf_last_scan(vers_ivf_t* h, float* out_ms, uint64_t* out_union_rows, uint64_t* out_streamed_rows,
                            uint32_t* out_items) {
   if (!h) return fail(VERS_ERR_INVALID, "null handle");
-  if (!h->ev_valid || !h->tot_valid) return fail(VERS_ERR_INVALID, "no list scan has been launched on this handle");
+  if (h->ev_count == 0 || !h->tot_valid) return fail(VERS_ERR_INVALID, "no list scan has been launched on this handle");
   DeviceGuard g(h->device);
-  VERS_HIP_TRY(hipEventSynchronize(h->ev1));
-  if (out_ms) VERS_HIP_TRY(hipEventElapsedTime(out_ms, h->ev0, h->ev1));
+  const uint32_t slot = (uint32_t)((h->ev_count - 1) % vers_ivf::kEvRing);
+  VERS_HIP_TRY(hipEventSynchronize(h->ev1[slot]));
+  if (out_ms) VERS_HIP_TRY(hipEventElapsedTime(out_ms, h->ev0[slot], h->ev1[slot]));
   const uint32_t* item_off_end = h->lists.as<uint32_t>() + 5 * (size_t)h->k;
   const GroupTotals* tot = (const GroupTotals*)(((uintptr_t)item_off_end + 15) & ~(uintptr_t)15);
   GroupTotals t;
@@ -1064,6 +1071,51 @@ int32_t vers_ivf_last_scan(vers_ivf_t* h, float* out_ms, uint64_t* out_union_row
   if (out_union_rows) *out_union_rows = t.union_rows;
   if (out_streamed_rows) *out_streamed_rows = t.streamed_rows;
   if (out_items) *out_items = t.n_items;
+  return VERS_OK;
+}
+
+int32_t vers_ivf_scan_times(vers_ivf_t* h, float* out_ms, uint32_t cap, uint32_t* out_n, int32_t reset) {
+  if (!h || !out_n || (cap && !out_ms)) return fail(VERS_ERR_INVALID, "bad arguments");
+  DeviceGuard g(h->device);
+  const uint64_t have = std::min<uint64_t>(h->ev_count, vers_ivf::kEvRing);
+  const uint32_t n = (uint32_t)std::min<uint64_t>(have, cap);
+  for (uint32_t i = 0; i < n; ++i) {  // oldest first among the last n launches
+    const uint32_t slot = (uint32_t)((h->ev_count - n + i) % vers_ivf::kEvRing);
+    VERS_HIP_TRY(hipEventSynchronize(h->ev1[slot]));
+    VERS_HIP_TRY(hipEventElapsedTime(&out_ms[i], h->ev0[slot], h->ev1[slot]));
+  }
+  *out_n = n;
+  if (reset) h->ev_count = 0;
+  return VERS_OK;
+}
+
+int32_t vers_ivf_get_list(vers_ivf_t* h, uint64_t cluster, float* out_rows, uint64_t row_stride_bytes, uint64_t* out_ids,
+                          uint64_t cap_rows, uint64_t* out_len) {
+  if (!h || cluster >= h->k || !out_len) return fail(VERS_ERR_INVALID, "vers_ivf_get_list: bad arguments");
+  std::lock_guard<std::mutex> lk(h->mu);
+  DeviceGuard g(h->device);
+  const uint32_t len = h->h_len[cluster];
+  *out_len = len;
+  if (!out_rows && !out_ids) return VERS_OK;
+  if (cap_rows < len || (out_rows && row_stride_bytes < (uint64_t)h->d * 4)) return fail(VERS_ERR_INVALID, "vers_ivf_get_list: buffer too small");
+  if (len == 0) return VERS_OK;
+  if (out_rows)
+    VERS_HIP_TRY(hipMemcpy2D(out_rows, row_stride_bytes, h->rows.as<float>() + (size_t)h->h_off[cluster] * h->ld, (size_t)h->ld * 4,
+                             (size_t)h->d * 4, len, hipMemcpyDeviceToHost));
+  if (out_ids) {
+    std::vector<uint32_t> ids(len);
+    VERS_HIP_TRY(hipMemcpy(ids.data(), h->row_ids.as<uint32_t>() + h->h_off[cluster], (size_t)len * 4, hipMemcpyDeviceToHost));
+    for (uint32_t i = 0; i < len; ++i) out_ids[i] = ids[i];
+  }
+  return VERS_OK;
+}
+
+int32_t vers_ivf_get_centroids(vers_ivf_t* h, float* out_centroids, uint64_t c_stride_bytes) {
+  if (!h || (h->k && !out_centroids) || c_stride_bytes < (uint64_t)h->d * 4) return fail(VERS_ERR_INVALID, "bad arguments");
+  if (h->k == 0) return VERS_OK;
+  DeviceGuard g(h->device);
+  VERS_HIP_TRY(hipMemcpy2D(out_centroids, c_stride_bytes, h->centroids.p, (size_t)h->ld * 4, (size_t)h->d * 4, h->k,
+                           hipMemcpyDeviceToHost));
   return VERS_OK;
 }
 

@@ -133,6 +133,49 @@ class IVFFlatIndex:
         check(lib().vers_ivf_last_scan(self._h, C.byref(ms), C.byref(u), C.byref(s), C.byref(it)))
         return dict(ms=ms.value, union_rows=u.value, streamed_rows=s.value, items=it.value)
 
+    def scan_times(self, reset: bool = True):
+        ms = np.zeros(64, dtype=np.float32); n = C.c_uint32(0)
+        check(lib().vers_ivf_scan_times(self._h, _ptr(ms), 64, C.byref(n), 1 if reset else 0))
+        return ms[:n.value].copy()
+
+    def get_list(self, cluster: int):
+        ln = C.c_uint64(0)
+        check(lib().vers_ivf_get_list(self._h, cluster, None, 0, None, 0, C.byref(ln)))
+        rows = np.zeros((ln.value, self.d), dtype=np.float32); ids = np.zeros(ln.value, dtype=np.uint64)
+        check(lib().vers_ivf_get_list(self._h, cluster, _ptr(rows), 4 * self.d, _ptr(ids), ln.value, C.byref(ln)))
+        return rows, ids
+
+    def get_centroids(self):
+        _, k, _ = self.info()
+        c = np.zeros((k, self.d), dtype=np.float32)
+        check(lib().vers_ivf_get_centroids(self._h, _ptr(c), 4 * self.d))
+        return c
+
+    # device-resident entry points (bench.py): torch tensors are passed as raw pointers
+    def build_dev(self, rows_ptr: int, n: int, num_clusters: int, num_attempts: int, max_iterations: int, init_indices):
+        init = np.ascontiguousarray(np.asarray(init_indices).reshape(-1), dtype=np.uint64)
+        cost = C.c_float(0); kept = C.c_int32(0)
+        iters = np.zeros(max(num_attempts, 1), dtype=np.uint64)
+        ld = (self.d + 3) // 4 * 4
+        check(lib().vers_ivf_build_dev(self._h, _vp(rows_ptr), n, ld, num_clusters, num_attempts, max_iterations, _ptr(init),
+                                       None, None, C.byref(cost), C.byref(kept), _ptr(iters)))
+        self.num_centroids = num_clusters
+        self.cost = np.float32(cost.value); self.iterations = iters[:num_attempts]
+        return bool(kept.value)
+
+    def search_dev(self, q_ptr: int, ldq: int, b: int, top_k: int, nprobe: int, ids_ptr: int, dist_ptr: int, cnt_ptr: int,
+                   stream: int = 0):
+        check(lib().vers_ivf_search_dev(self._h, _vp(q_ptr), ldq, b, top_k, nprobe, _vp(ids_ptr), _vp(dist_ptr), _vp(cnt_ptr),
+                                        _vp(stream)))
+
+    def search_exhaustive_dev(self, q_ptr: int, ldq: int, b: int, top_k: int, metric: int, ids_ptr: int, dist_ptr: int,
+                              cnt_ptr: int, stream: int = 0):
+        check(lib().vers_ivf_search_exhaustive_dev(self._h, _vp(q_ptr), ldq, b, top_k, metric, _vp(ids_ptr), _vp(dist_ptr),
+                                                   _vp(cnt_ptr), _vp(stream)))
+
+    def poll(self, stream: int = 0):
+        check(lib().vers_ivf_poll(self._h, _vp(stream)))
+
     # -- Index::save_index / load_index (base.rs:31-58) ---------------------------------------------
     # bincode 1.3.3 default options: little endian, fixed-width ints, usize/len as u64, struct = fields in
     # order without tags, Vec<T> = u64 len + items, [f32; N] through serde_arrays = N raw f32 (no length).
