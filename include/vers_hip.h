@@ -62,9 +62,9 @@ int32_t vers_flat_create(int32_t device, uint32_t d, vers_flat_t** out);
 int32_t vers_flat_destroy(vers_flat_t* h);
 /* Copies n rows (pitch row_stride_bytes >= 4*d) into HBM; position = vec_id. */
 int32_t vers_flat_upload(vers_flat_t* h, const float* rows, uint64_t n, uint64_t row_stride_bytes);
-/* Adopts rows already in HBM (device pointer, pitch in floats, multiple of 4,
- * columns d..ld zero); the caller keeps ownership and must keep them alive. */
-int32_t vers_flat_adopt_dev(vers_flat_t* h, const float* rows_dev, uint64_t n, uint64_t ld_floats);
+/* Same from rows already in HBM (row-major, pitch ld_floats >= d).  The handle keeps its own
+ * copy in the scan layout (lane-transposed 64-row tiles); the caller's buffer can be freed. */
+int32_t vers_flat_upload_dev(vers_flat_t* h, const float* rows_dev, uint64_t n, uint64_t ld_floats);
 /* b queries (pitch q_stride_bytes).  out_ids/out_dist: [b * top_k], row q at
  * q*top_k; out_count[q] = min(top_k, n) results written for query q.
  * top_k <= VERS_MAX_TOPK. */
@@ -128,7 +128,7 @@ int32_t vers_ivf_build(vers_ivf_t* h, const float* rows, uint64_t n, uint64_t ro
                        uint64_t num_clusters, uint64_t num_attempts, uint64_t max_iterations,
                        const uint64_t* init_indices, float* out_centroids, uint64_t* out_assignments,
                        float* out_cost, int32_t* out_kept, uint64_t* out_iterations);
-/* Same with the vectors already in HBM (pitch ld_floats == round_up(d,4), pad columns zero). */
+/* Same with the vectors already in HBM (row-major, pitch ld_floats >= d, a multiple of 4). */
 int32_t vers_ivf_build_dev(vers_ivf_t* h, const float* rows_dev, uint64_t n, uint64_t ld_floats,
                            uint64_t num_clusters, uint64_t num_attempts, uint64_t max_iterations,
                            const uint64_t* init_indices, float* out_centroids, uint64_t* out_assignments,

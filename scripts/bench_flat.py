@@ -25,7 +25,8 @@ for i in range(args.corpora):
     x = torch.randn(args.n, ld, device=dev)
     x = x / x.norm(dim=1, keepdim=True)
     fc = capi.FlatCorpus(args.d)
-    fc.adopt_dev(x.data_ptr(), args.n, ld, keep=x)
+    fc.upload_dev(x.data_ptr(), args.n, ld)
+    fc._keep = x
     corp.append(fc)
 q = torch.randn(args.b, args.d, device=dev); q = q / q.norm(dim=1, keepdim=True)
 ids = torch.zeros(args.b, args.k, dtype=torch.int64, device=dev)

@@ -35,7 +35,7 @@ SIGNATURES = {
     "vers_flat_create": (C.c_int32, [C.c_int32, C.c_uint32, C.POINTER(_vp)]),
     "vers_flat_destroy": (C.c_int32, [_vp]),
     "vers_flat_upload": (C.c_int32, [_vp, _vp, C.c_uint64, C.c_uint64]),
-    "vers_flat_adopt_dev": (C.c_int32, [_vp, _vp, C.c_uint64, C.c_uint64]),
+    "vers_flat_upload_dev": (C.c_int32, [_vp, _vp, C.c_uint64, C.c_uint64]),
     "vers_flat_search": (C.c_int32, [_vp, _vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, _vp, _vp, _vp]),
     "vers_flat_search_dev": (C.c_int32, [_vp, _vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, _vp, _vp, _vp, _vp]),
     "vers_flat_poll": (C.c_int32, [_vp, _vp]),
@@ -69,12 +69,30 @@ SIGNATURES = {
 }
 
 
+def _preload_hip_runtime():
+    """One HIP runtime per process: when PyTorch-ROCm is installed it bundles its own libamdhip64;
+    loading /opt/rocm's copy first (through libvers_hip.so) and torch's later gives torch a second
+    runtime that sees no GPU.  Map torch's copy first so both sides share it (torch is plumbing for
+    device memory / streams / RCCL in tests and bench.py)."""
+    import importlib.util
+    spec = importlib.util.find_spec("torch")
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def lib():
     global _lib
     if _lib is None:
         if not os.path.exists(LIB_PATH):
             raise ImportError(f"{LIB_PATH} is missing: build it with `python -m vers_amd.build` "
                               "(there is no CPU fallback for this path)")
+        _preload_hip_runtime()
         L = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(L, name)
@@ -124,9 +142,8 @@ class FlatCorpus:
         check(lib().vers_flat_upload(self._h, _ptr(rows), rows.shape[0], rows.strides[0] if rows.shape[0] else 4 * self.d))
         self.n = rows.shape[0]
 
-    def adopt_dev(self, data_ptr: int, n: int, ld: int, keep=None):
-        check(lib().vers_flat_adopt_dev(self._h, _vp(data_ptr), n, ld))
-        self._keep = keep
+    def upload_dev(self, data_ptr: int, n: int, ld: int):
+        check(lib().vers_flat_upload_dev(self._h, _vp(data_ptr), n, ld))
         self.n = n
 
     def search(self, queries: np.ndarray, top_k: int, metric: int = METRIC_L2SQ):

@@ -22,8 +22,8 @@ int32_t fail(int32_t status, const std::string& msg);
 
 // ---- geometry of the scan engine (scan.hip) ---------------------------------
 constexpr int kWave = 64;        // CDNA4 wavefront
-constexpr int kChunk = 64;       // f32 columns staged per step (256 B per row)
-constexpr int kLdsStride = 68;   // 64 + 4: 4*odd dwords -> conflict-free ds_read_b128 by row
+constexpr int kChunk = 32;       // f32 columns consumed per step
+constexpr int kLoads = kChunk / 4;  // float4 loads per lane per step (1 KiB per wave each)
 constexpr int kWavesPerBlock = 4;
 constexpr int kMaxTopK = 64;     // one sorted key per lane
 
@@ -31,6 +31,8 @@ constexpr uint64_t kKeyMax = 0xFFFFFFFFFFFFFFFFull;
 
 inline uint32_t round_up(uint32_t x, uint32_t m) { return (x + m - 1) / m * m; }
 inline uint64_t round_up64(uint64_t x, uint64_t m) { return (x + m - 1) / m * m; }
+// a work item is addressed through one 32-bit buffer descriptor: keep it under 2 GiB
+inline uint64_t max_seg_rows(uint32_t ld) { return ((1ull << 31) / ((uint64_t)ld * 4)) / 64 * 64; }
 
 // Device-side view of the result of a scan: `k` ascending keys per slot.
 // key = (order-preserving f32 bits << 32) | seq, seq = tie-break position.

@@ -1,5 +1,6 @@
 // flat.hip -- brute-force scan behind vers_flat_* (replaces utils::search_exhaustive,
 // /root/reference/vers/src/utils.rs:68-82).
+#include <algorithm>
 #include <mutex>
 #include <new>
 #include <vector>
@@ -13,10 +14,10 @@ namespace vers {
 template <int QG, bool SEQ_IDS>
 struct FlatSrc {
   static constexpr bool kSeqIds = SEQ_IDS;
-  const float* rows;
+  const float* rows;  // blocked tiles
   uint64_t n;
   uint32_t ld;
-  uint32_t seg_rows, n_segs;
+  uint32_t seg_rows, n_segs;  // seg_rows is a multiple of 64
   const float* queries;  // QG == 1: [b][ldq]; else interleaved blocks [ceil(b/QG)][ldq][QG]; zero padded
   uint32_t ldq, b;
   uint64_t* partials;
@@ -64,10 +65,10 @@ using namespace vers;
 
 struct vers_flat {
   int device = 0;
-  uint32_t d = 0, ld = 0;
+  uint32_t d = 0, ld = 0;  // ld = round_up(d, kChunk): columns of the blocked corpus and of padded queries
   uint64_t n = 0;
-  float* rows = nullptr;
-  bool owned = false;
+  float* rows = nullptr;   // lane-transposed tiles (scan.cuh)
+  size_t rows_cap = 0;
   int n_cu = 256;
   // workspace (grown on demand, never inside a steady-state call)
   float* q_stage = nullptr;
@@ -92,16 +93,15 @@ template <int QG, int METRIC>
 int32_t launch_flat_scan(vers_flat* h, const FlatSrc<QG, false>& src, uint32_t n_items, hipStream_t st) {
   ScanParams p;
   p.ld = h->ld;
-  p.n_chunks = (h->ld + kChunk - 1) / kChunk;
+  p.n_chunks = h->ld / kChunk;
   p.k = src.k;
   p.status = h->status_dev;
-  const uint32_t max_blocks = (uint32_t)h->n_cu * 2u;
+  const uint32_t max_blocks = (uint32_t)h->n_cu * (QG == 1 ? 5u : 3u);  // resident waves: 20 / 12 per CU
   uint32_t blocks = (n_items + kWavesPerBlock - 1) / kWavesPerBlock;
   if (blocks > max_blocks) blocks = max_blocks;
   if (blocks == 0) blocks = 1;
-  const size_t lds = (size_t)kWavesPerBlock * kWave * kLdsStride * sizeof(float);
   VERS_HIP_TRY(hipEventRecord(h->ev0, st));
-  hipLaunchKernelGGL((scan_kernel<QG, METRIC, FlatSrc<QG, false>>), dim3(blocks), dim3(kWave * kWavesPerBlock), lds, st, src, p);
+  hipLaunchKernelGGL((scan_kernel<QG, METRIC, FlatSrc<QG, false>>), dim3(blocks), dim3(kWave * kWavesPerBlock), 0, st, src, p);
   VERS_HIP_TRY(hipGetLastError());
   VERS_HIP_TRY(hipEventRecord(h->ev1, st));
   h->ev_valid = true;
@@ -116,14 +116,14 @@ int32_t flat_search_dev_locked(vers_flat* h, const float* q_dev, uint64_t ldq, u
     VERS_HIP_TRY(hipMemsetAsync(out_count, 0, sizeof(uint32_t) * b, st));
     return VERS_OK;
   }
-  const uint32_t ldq_pad = round_up(h->ld, kChunk);
+  const uint32_t ldq_pad = h->ld;
   const int QG = b == 1 ? 1 : 8;
   const uint32_t n_qg = (b + QG - 1) / QG;
   // queries: a single query is used in place when it is chunk-padded by construction; otherwise
   // stage a zero padded (QG > 1: interleaved) copy
   const float* q = q_dev;
   uint32_t ldq_use = (uint32_t)ldq;
-  if (!(QG == 1 && h->d % kChunk == 0)) {
+  if (!(QG == 1 && h->d == h->ld)) {
     const uint64_t tot = (uint64_t)n_qg * ldq_pad * QG;
     if (int32_t rc = grow(h->q_stage, h->q_stage_cap, (size_t)tot)) return rc;
     if (int32_t rc = launch_stage_queries(q_dev, ldq, h->d, h->q_stage, ldq_pad, b, (uint32_t)QG, st)) return rc;
@@ -131,9 +131,9 @@ int32_t flat_search_dev_locked(vers_flat* h, const float* q_dev, uint64_t ldq, u
     ldq_use = ldq_pad;
   }
   // one item per resident wave when possible (static balance), at least one 64-row tile each
-  const uint32_t target_items = (uint32_t)h->n_cu * 8u;
+  const uint32_t target_items = (uint32_t)h->n_cu * (QG == 1 ? 20u : 12u);
   uint64_t per = (h->n * n_qg + target_items - 1) / target_items;
-  uint32_t seg_rows = (uint32_t)round_up64(per ? per : 1, kWave);
+  uint32_t seg_rows = (uint32_t)std::min<uint64_t>(round_up64(per ? per : 1, kWave), max_seg_rows(h->ld));
   uint32_t n_segs = (uint32_t)((h->n + seg_rows - 1) / seg_rows);
   if (n_segs == 0) n_segs = 1;
   if (int32_t rc = grow(h->partials, h->partials_cap, (size_t)b * n_segs * top_k)) return rc;
@@ -181,11 +181,11 @@ int32_t vers_flat_create(int32_t device, uint32_t d, vers_flat_t** out) {
   if (!h) return fail(VERS_ERR_INVALID, "out of host memory");
   h->device = device;
   h->d = d;
-  h->ld = round_up(d, 4);
+  h->ld = round_up(d, kChunk);
   hipDeviceProp_t prop;
   VERS_HIP_TRY(hipGetDeviceProperties(&prop, device));
   h->n_cu = prop.multiProcessorCount;
-  h->zero_q_len = round_up(h->ld, kChunk);
+  h->zero_q_len = h->ld;
   VERS_HIP_TRY(hipMalloc((void**)&h->zero_q, h->zero_q_len * sizeof(float)));
   VERS_HIP_TRY(hipMemset(h->zero_q, 0, h->zero_q_len * sizeof(float)));
   VERS_HIP_TRY(hipMalloc((void**)&h->status_dev, 16));
@@ -200,7 +200,7 @@ int32_t vers_flat_destroy(vers_flat_t* h) {
   if (!h) return VERS_OK;
   DeviceGuard g(h->device);
   (void)hipDeviceSynchronize();
-  if (h->owned && h->rows) (void)hipFree(h->rows);
+  if (h->rows) (void)hipFree(h->rows);
   for (void* p : {(void*)h->q_stage, (void*)h->zero_q, (void*)h->partials, (void*)h->status_dev, (void*)h->o_ids,
                   (void*)h->o_dist, (void*)h->o_cnt})
     if (p) (void)hipFree(p);
@@ -216,36 +216,31 @@ int32_t vers_flat_upload(vers_flat_t* h, const float* rows, uint64_t n, uint64_t
   if (n > 0xFFFFFFFFull) return fail(VERS_ERR_INVALID, "more than 2^32-1 rows per handle");
   std::lock_guard<std::mutex> lk(h->mu);
   DeviceGuard g(h->device);
-  if (h->owned && h->rows) VERS_HIP_TRY(hipFree(h->rows));
-  h->rows = nullptr; h->n = 0; h->owned = true;
+  h->n = 0;
+  if (int32_t rc = grow(h->rows, h->rows_cap, (size_t)std::max<uint64_t>(1, blocked_floats(n, h->ld)))) return rc;
   if (n == 0) return VERS_OK;
-  VERS_HIP_TRY(hipMalloc((void**)&h->rows, n * h->ld * sizeof(float)));
-  if (h->ld != h->d) VERS_HIP_TRY(hipMemset(h->rows, 0, n * h->ld * sizeof(float)));
-  VERS_HIP_TRY(hipMemcpy2D(h->rows, (size_t)h->ld * 4, rows, row_stride_bytes, (size_t)h->d * 4, n, hipMemcpyHostToDevice));
-  h->n = n;
-  return VERS_OK;
+  float* tmp = nullptr;  // row-major staging, re-laid out on the device
+  VERS_HIP_TRY(hipMalloc((void**)&tmp, n * (size_t)h->d * sizeof(float)));
+  int32_t rc = VERS_OK;
+  if (hipMemcpy2D(tmp, (size_t)h->d * 4, rows, row_stride_bytes, (size_t)h->d * 4, n, hipMemcpyHostToDevice) != hipSuccess)
+    rc = fail(VERS_ERR_HIP, "corpus upload failed");
+  if (!rc) rc = launch_to_blocked(tmp, h->d, h->d, n, h->rows, h->ld, nullptr);
+  (void)hipDeviceSynchronize();
+  (void)hipFree(tmp);
+  if (!rc) h->n = n;
+  return rc;
 }
 
-int32_t vers_flat_adopt_dev(vers_flat_t* h, const float* rows_dev, uint64_t n, uint64_t ld_floats) {
-  if (!h || (n && !rows_dev) || ld_floats < h->d || ld_floats % 4 || ld_floats > 0x3FFFFFFFull)
-    return fail(VERS_ERR_INVALID, "vers_flat_adopt_dev: bad arguments");
+int32_t vers_flat_upload_dev(vers_flat_t* h, const float* rows_dev, uint64_t n, uint64_t ld_floats) {
+  if (!h || (n && !rows_dev) || ld_floats < h->d) return fail(VERS_ERR_INVALID, "vers_flat_upload_dev: bad arguments");
   if (n > 0xFFFFFFFFull) return fail(VERS_ERR_INVALID, "more than 2^32-1 rows per handle");
   std::lock_guard<std::mutex> lk(h->mu);
   DeviceGuard g(h->device);
-  if (h->owned && h->rows) VERS_HIP_TRY(hipFree(h->rows));
-  h->rows = const_cast<float*>(rows_dev);
-  h->owned = false;
+  h->n = 0;
+  if (int32_t rc = grow(h->rows, h->rows_cap, (size_t)std::max<uint64_t>(1, blocked_floats(n, h->ld)))) return rc;
+  if (int32_t rc = launch_to_blocked(rows_dev, ld_floats, h->d, n, h->rows, h->ld, nullptr)) return rc;
+  VERS_HIP_TRY(hipDeviceSynchronize());
   h->n = n;
-  if ((uint32_t)ld_floats != h->ld) {
-    h->ld = (uint32_t)ld_floats;
-    const uint32_t zl = round_up(h->ld, kChunk);
-    if (zl > h->zero_q_len) {
-      VERS_HIP_TRY(hipFree(h->zero_q));
-      VERS_HIP_TRY(hipMalloc((void**)&h->zero_q, zl * sizeof(float)));
-      VERS_HIP_TRY(hipMemset(h->zero_q, 0, zl * sizeof(float)));
-      h->zero_q_len = zl;
-    }
-  }
   return VERS_OK;
 }
 
@@ -283,7 +278,7 @@ int32_t vers_flat_search(vers_flat_t* h, const float* queries, uint64_t q_stride
   if (b == 0) return VERS_OK;
   std::lock_guard<std::mutex> lk(h->mu);
   DeviceGuard g(h->device);
-  const uint32_t ldq_pad = round_up(h->ld, kChunk);
+  const uint32_t ldq_pad = h->ld;
   float* qd = nullptr;
   VERS_HIP_TRY(hipMalloc((void**)&qd, (size_t)b * ldq_pad * sizeof(float)));
   int32_t rc = VERS_OK;

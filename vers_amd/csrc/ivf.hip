@@ -5,8 +5,9 @@
 // through `ids` (ivfflat.rs:172-174).  Here rows are stored CLUSTER-MAJOR: list c occupies the
 // contiguous rows [list_off[c], list_off[c]+list_len[c]) in the reference's list order
 // (ascending vec_id for built rows, append order for added ones), followed by slack for `add`;
-// row_ids[] maps a storage row back to its vec_id.  A list scan is therefore one linear,
-// fully coalesced HBM stream.
+// row_ids[] maps a storage row back to its vec_id.  Lists start on 64-row boundaries and the rows
+// themselves are held in lane-transposed 64-row tiles (scan.cuh), so a list scan is one linear HBM
+// stream of contiguous 1 KiB wave loads.
 //
 // search = coarse scan over the centroids (top-P keys) -> plan (which lists, per-query sequence
 // bases, reference spill plan) -> group (query,list) pairs by list so a list is streamed once for
@@ -323,11 +324,12 @@ __global__ __launch_bounds__(kWave * kMergeWaves) void seg_merge_kernel(const ui
 }
 
 // ---- storage construction ---------------------------------------------------------------------
-// rows of X (vec_id order) -> cluster-major storage; grid-stride over (sorted position, float4 column)
-__global__ void gather_rows_kernel(const float* X, uint32_t ld, const uint32_t* sorted_ids, const uint32_t* assign,
-                                   const uint32_t* starts, const uint32_t* list_off, uint64_t n, float* rows,
-                                   uint32_t* row_ids) {
-  const uint32_t ld4 = ld / 4;
+// rows of X (vec_id order, row-major pitch ldx) -> cluster-major storage in lane-transposed tiles;
+// grid-stride over (sorted position, float4 column)
+__global__ void gather_rows_kernel(const float* X, uint32_t ldx, uint32_t ld, const uint32_t* sorted_ids,
+                                   const uint32_t* assign, const uint32_t* starts, const uint32_t* list_off, uint64_t n,
+                                   float* rows, uint32_t* row_ids) {
+  const uint32_t ld4 = ld / 4, ldx4 = ldx / 4;
   const uint64_t total = n * ld4;
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
     const uint64_t p = i / ld4;
@@ -335,15 +337,25 @@ __global__ void gather_rows_kernel(const float* X, uint32_t ld, const uint32_t* 
     const uint32_t id = sorted_ids[p];
     const uint32_t c = assign[id];
     const uint64_t dst = (uint64_t)list_off[c] + (p - starts[c]);
-    reinterpret_cast<f32x4*>(rows + dst * ld)[c4] = reinterpret_cast<const f32x4*>(X + (uint64_t)id * ld)[c4];
+    f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (c4 < ldx4) v = reinterpret_cast<const f32x4*>(X + (uint64_t)id * ldx)[c4];
+    *reinterpret_cast<f32x4*>(rows + blocked_index(dst, c4 * 4, ld)) = v;
     if (c4 == 0) row_ids[dst] = id;
   }
 }
 
-__global__ void gather_init_kernel(const float* X, uint32_t ld, const uint32_t* idx, uint32_t k, float* C) {
+// one padded row (ld floats, row-major) -> storage row `dst` of the blocked matrix
+__global__ void scatter_row_kernel(const float* row, uint32_t ld, uint64_t dst, float* rows) {
+  const uint32_t c4 = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c4 < ld / 4)
+    *reinterpret_cast<f32x4*>(rows + blocked_index(dst, c4 * 4, ld)) = reinterpret_cast<const f32x4*>(row)[c4];
+}
+
+__global__ void gather_init_kernel(const float* X, uint32_t ldx, uint32_t ldc, const uint32_t* idx, uint32_t k, float* C) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= (uint64_t)k * ld) return;
-  C[i] = X[(uint64_t)idx[i / ld] * ld + (i % ld)];
+  if (i >= (uint64_t)k * ldc) return;
+  const uint32_t j = (uint32_t)(i % ldc);
+  C[i] = j < ldx ? X[(uint64_t)idx[i / ldc] * ldx + j] : 0.0f;
 }
 
 __global__ void u32_to_u64_kernel(const uint32_t* in, uint64_t n, uint64_t* out) {
@@ -358,11 +370,16 @@ using namespace vers;
 // =================================================================================================
 struct vers_ivf {
   int device = 0, n_cu = 256;
-  uint32_t d = 0, ld = 0, ldq = 0;
+  uint32_t d = 0;
+  uint32_t ldx = 0;  // pitch of row-major matrices (X, centroids): round_up(d, 4)
+  uint32_t ld = 0;   // columns of blocked matrices and padded queries: round_up(d, kChunk)
+  uint32_t ldq = 0;  // == ld
   // index state (device cache of the reference's five fields, ivfflat.rs:9-15)
   uint32_t k = 0;         // num_centroids; 0 = no index / nothing kept
   uint64_t n_total = 0;   // assignments.len(): next vec_id handed out by add
-  DevBuf centroids, rows, row_ids, list_off, list_len;
+  DevBuf centroids;    // [k][ldx] row-major (k-means, read-back)
+  DevBuf centroids_b;  // the same in lane-transposed tiles (coarse quantiser)
+  DevBuf rows, row_ids, list_off, list_len;
   std::vector<uint32_t> h_off, h_len, h_cap;
   uint64_t cap_rows = 0;
   uint32_t max_len = 0;
@@ -395,8 +412,9 @@ int32_t sync_status(vers_ivf* h, hipStream_t st) {
 
 // Lays the lists out cluster-major with slack and fills them from X (vec_id order).
 // d_assign/d_sorted/d_starts are device arrays for the n rows of X.
-int32_t build_storage(vers_ivf* h, const float* X, uint64_t n, const uint32_t* d_assign, const uint32_t* d_sorted,
-                      const uint32_t* d_counts, const uint32_t* d_starts, uint32_t k, hipStream_t st) {
+int32_t build_storage(vers_ivf* h, const float* X, uint32_t ldx, uint64_t n, const uint32_t* d_assign,
+                      const uint32_t* d_sorted, const uint32_t* d_counts, const uint32_t* d_starts, uint32_t k,
+                      hipStream_t st) {
   h->h_len.assign(k, 0);
   h->h_off.assign(k, 0);
   h->h_cap.assign(k, 0);
@@ -424,10 +442,13 @@ int32_t build_storage(vers_ivf* h, const float* X, uint64_t n, const uint32_t* d
     VERS_HIP_TRY(hipMemcpyAsync(h->list_len.p, h->h_len.data(), (size_t)k * 4, hipMemcpyHostToDevice, st));
   }
   if (n) {
-    hipLaunchKernelGGL(gather_rows_kernel, dim3(h->n_cu * 8), dim3(256), 0, st, X, h->ld, d_sorted, d_assign, d_starts,
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(h->n_cu * 8), dim3(256), 0, st, X, ldx, h->ld, d_sorted, d_assign, d_starts,
                        h->list_off.as<uint32_t>(), n, h->rows.as<float>(), h->row_ids.as<uint32_t>());
     VERS_HIP_TRY(hipGetLastError());
   }
+  // centroids in the scan layout for the coarse quantiser
+  if (int32_t rc = h->centroids_b.reserve(std::max<uint64_t>(1, blocked_floats(k, h->ld)) * sizeof(float))) return rc;
+  if (int32_t rc = launch_to_blocked(h->centroids.as<float>(), h->ldx, h->d, k, h->centroids_b.as<float>(), h->ld, st)) return rc;
   VERS_HIP_TRY(hipStreamSynchronize(st));
   h->k = k;
   h->n_total = n;
@@ -435,22 +456,23 @@ int32_t build_storage(vers_ivf* h, const float* X, uint64_t n, const uint32_t* d
 }
 
 // index from (X, centroids already in h->centroids, device assignments)
-int32_t install_index(vers_ivf* h, const float* X, uint64_t n, const uint32_t* d_assign, uint32_t k, hipStream_t st) {
+int32_t install_index(vers_ivf* h, const float* X, uint32_t ldx, uint64_t n, const uint32_t* d_assign, uint32_t k,
+                      hipStream_t st) {
   DevBuf sorted;
   if (int32_t rc = sorted.reserve((n ? n : 1) * sizeof(uint32_t))) return rc;
   if (int32_t rc = h->km.counts.reserve((2 * (size_t)k + 2) * sizeof(uint32_t))) return rc;
   uint32_t* counts = h->km.counts.as<uint32_t>();
   uint32_t* starts = counts + k;
   if (int32_t rc = km_group(d_assign, (uint32_t)n, k, sorted.as<uint32_t>(), counts, starts, h->km, st)) return rc;
-  return build_storage(h, X, n, d_assign, sorted.as<uint32_t>(), counts, starts, k, st);
+  return build_storage(h, X, ldx, n, d_assign, sorted.as<uint32_t>(), counts, starts, k, st);
 }
 
 // build_kmeans + best-of-attempts (ivfflat.rs:73-121) on device-resident X; leaves the winning
 // centroids in h->centroids and assignments in best_assign.
-int32_t run_build(vers_ivf* h, const float* X, uint64_t n, uint32_t k, uint64_t num_attempts, uint64_t max_iterations,
+int32_t run_build(vers_ivf* h, const float* X, uint32_t ldx, uint64_t n, uint32_t k, uint64_t num_attempts, uint64_t max_iterations,
                   const uint64_t* init_indices, DevBuf& best_assign, float* out_cost, int32_t* out_kept,
                   uint64_t* out_iterations, hipStream_t st) {
-  const uint32_t ld = h->ld;
+  const uint32_t ld = h->ldx;  // centroids live row-major with pitch ldx during k-means
   DevBuf C, Cn, assign, mind, sorted, idx, bestC;
   const size_t cbytes = ((size_t)k * ld ? (size_t)k * ld : 1) * sizeof(float);
   if (int32_t rc = C.reserve(cbytes)) return rc;
@@ -482,15 +504,15 @@ int32_t run_build(vers_ivf* h, const float* X, uint64_t n, uint32_t k, uint64_t 
     if (k) {
       VERS_HIP_TRY(hipMemcpyAsync(idx.p, idx32.data(), (size_t)k * 4, hipMemcpyHostToDevice, st));
       VERS_HIP_TRY(hipStreamSynchronize(st));  // idx32 is reused by the next attempt
-      hipLaunchKernelGGL(gather_init_kernel, dim3((unsigned)(((uint64_t)k * ld + 255) / 256)), dim3(256), 0, st, X, ld,
+      hipLaunchKernelGGL(gather_init_kernel, dim3((unsigned)(((uint64_t)k * ld + 255) / 256)), dim3(256), 0, st, X, ldx, ld,
                          idx.as<uint32_t>(), k, C.as<float>());
       VERS_HIP_TRY(hipGetLastError());
     }
     uint64_t iters = 0;
     for (uint64_t it = 0; it < max_iterations; ++it) {
-      if (int32_t rc = km_assign(X, n, C.as<float>(), k, h->d, ld, assign.as<uint32_t>(), nullptr, h->km, h->n_cu, st)) return rc;
+      if (int32_t rc = km_assign(X, ldx, n, C.as<float>(), ld, k, h->d, assign.as<uint32_t>(), nullptr, h->km, h->n_cu, st)) return rc;
       if (int32_t rc = km_group(assign.as<uint32_t>(), (uint32_t)n, k, sorted.as<uint32_t>(), counts, starts, h->km, st)) return rc;
-      if (int32_t rc = km_update(X, ld, sorted.as<uint32_t>(), starts, k, Cn.as<float>(), st)) return rc;
+      if (int32_t rc = km_update(X, ldx, sorted.as<uint32_t>(), starts, k, Cn.as<float>(), ld, st)) return rc;
       if (int32_t rc = km_differs(C.as<float>(), Cn.as<float>(), (uint64_t)k * ld, flag_dev, st)) return rc;
       uint32_t differs = 0;
       VERS_HIP_TRY(hipMemcpyAsync(&differs, flag_dev, 4, hipMemcpyDeviceToHost, st));
@@ -501,7 +523,7 @@ int32_t run_build(vers_ivf* h, const float* X, uint64_t n, uint32_t k, uint64_t 
       std::swap(C.cap, Cn.cap);
     }
     if (out_iterations) out_iterations[a] = iters;
-    if (int32_t rc = km_assign(X, n, C.as<float>(), k, h->d, ld, assign.as<uint32_t>(), mind.as<float>(), h->km, h->n_cu, st)) return rc;
+    if (int32_t rc = km_assign(X, ldx, n, C.as<float>(), ld, k, h->d, assign.as<uint32_t>(), mind.as<float>(), h->km, h->n_cu, st)) return rc;
     if (int32_t rc = km_cost_fold(mind.as<float>(), n, cost_dev, st)) return rc;
     float cost = 0.0f;
     uint32_t stw = 0;
@@ -528,15 +550,15 @@ int32_t run_build(vers_ivf* h, const float* X, uint64_t n, uint32_t k, uint64_t 
   return VERS_OK;
 }
 
-int32_t build_common(vers_ivf* h, const float* X, uint64_t n, uint64_t num_clusters, uint64_t num_attempts,
+int32_t build_common(vers_ivf* h, const float* X, uint32_t ldx, uint64_t n, uint64_t num_clusters, uint64_t num_attempts,
                      uint64_t max_iterations, const uint64_t* init_indices, float* out_centroids, uint64_t* out_assignments,
                      float* out_cost, int32_t* out_kept, uint64_t* out_iterations) {
   const uint32_t k = (uint32_t)num_clusters;
   DevBuf best_assign;
   float cost = INFINITY;
   int32_t kept = 0;
-  if (int32_t rc = run_build(h, X, n, k, num_attempts, max_iterations, init_indices, best_assign, &cost, &kept, out_iterations,
-                             nullptr))
+  if (int32_t rc = run_build(h, X, ldx, n, k, num_attempts, max_iterations, init_indices, best_assign, &cost, &kept,
+                             out_iterations, nullptr))
     return rc;
   if (out_cost) *out_cost = cost;
   if (out_kept) *out_kept = kept;
@@ -549,9 +571,9 @@ int32_t build_common(vers_ivf* h, const float* X, uint64_t n, uint64_t num_clust
     h->h_len.clear(); h->h_off.clear(); h->h_cap.clear();
     return VERS_OK;
   }
-  if (int32_t rc = install_index(h, X, n, best_assign.as<uint32_t>(), k, nullptr)) return rc;
+  if (int32_t rc = install_index(h, X, ldx, n, best_assign.as<uint32_t>(), k, nullptr)) return rc;
   if (out_centroids && k)
-    VERS_HIP_TRY(hipMemcpy2D(out_centroids, (size_t)h->d * 4, h->centroids.p, (size_t)h->ld * 4, (size_t)h->d * 4, k,
+    VERS_HIP_TRY(hipMemcpy2D(out_centroids, (size_t)h->d * 4, h->centroids.p, (size_t)h->ldx * 4, (size_t)h->d * 4, k,
                              hipMemcpyDeviceToHost));
   if (out_assignments && n) {
     DevBuf a64;
@@ -569,17 +591,16 @@ template <int QG, bool SEQ_IDS>
 int32_t launch_seg_scan(vers_ivf* h, const SegSrc<QG, SEQ_IDS>& src, uint32_t n_items, int metric, hipStream_t st) {
   ScanParams p;
   p.ld = h->ld;
-  p.n_chunks = (h->ld + kChunk - 1) / kChunk;
+  p.n_chunks = h->ld / kChunk;
   p.k = src.k;
   p.status = h->status.as<uint32_t>();
   uint32_t blocks = (n_items + kWavesPerBlock - 1) / kWavesPerBlock;
-  if (blocks > (uint32_t)h->n_cu * 2u) blocks = (uint32_t)h->n_cu * 2u;
+  if (blocks > (uint32_t)h->n_cu * (QG == 1 ? 5u : 3u)) blocks = (uint32_t)h->n_cu * (QG == 1 ? 5u : 3u);
   if (blocks == 0) blocks = 1;
-  const size_t lds = (size_t)kWavesPerBlock * kWave * kLdsStride * sizeof(float);
   if (metric == 0)
-    hipLaunchKernelGGL((scan_kernel<QG, 0, SegSrc<QG, SEQ_IDS>>), dim3(blocks), dim3(kWave * kWavesPerBlock), lds, st, src, p);
+    hipLaunchKernelGGL((scan_kernel<QG, 0, SegSrc<QG, SEQ_IDS>>), dim3(blocks), dim3(kWave * kWavesPerBlock), 0, st, src, p);
   else
-    hipLaunchKernelGGL((scan_kernel<QG, 1, SegSrc<QG, SEQ_IDS>>), dim3(blocks), dim3(kWave * kWavesPerBlock), lds, st, src, p);
+    hipLaunchKernelGGL((scan_kernel<QG, 1, SegSrc<QG, SEQ_IDS>>), dim3(blocks), dim3(kWave * kWavesPerBlock), 0, st, src, p);
   VERS_HIP_TRY(hipGetLastError());
   return VERS_OK;
 }
@@ -603,14 +624,14 @@ int32_t coarse(vers_ivf* h, const float* qp, uint32_t b, uint32_t P, hipStream_t
     if (int32_t rc = launch_stage_queries(qp, h->ldq, h->ldq, h->qil.as<float>(), h->ldq, b, QG, st)) return rc;
     q = h->qil.as<float>();
   }
-  const uint32_t target_items = (uint32_t)h->n_cu * 8u;
+  const uint32_t target_items = (uint32_t)h->n_cu * (QG == 1 ? 20u : 12u);
   uint64_t per = ((uint64_t)h->k * n_qg + target_items - 1) / target_items;
-  const uint32_t seg_rows = (uint32_t)round_up64(per ? per : 1, kWave);
+  const uint32_t seg_rows = (uint32_t)std::min<uint64_t>(round_up64(per ? per : 1, kWave), max_seg_rows(h->ld));
   const uint32_t n_segs = (h->k + seg_rows - 1) / seg_rows;
   if (int32_t rc = h->cpart.reserve((size_t)b * n_segs * P * sizeof(uint64_t))) return rc;
   if (int32_t rc = h->probe.reserve((size_t)b * P * sizeof(uint64_t))) return rc;
   auto fill = [&](auto& src) {
-    src.rows = h->centroids.as<float>(); src.n = h->k; src.ld = h->ld; src.seg_rows = seg_rows; src.n_segs = n_segs;
+    src.rows = h->centroids_b.as<float>(); src.n = h->k; src.ld = h->ld; src.seg_rows = seg_rows; src.n_segs = n_segs;
     src.queries = q; src.ldq = h->ldq; src.b = b; src.partials = h->cpart.as<uint64_t>(); src.k = P; src.ids = nullptr;
   };
   int32_t rc;
@@ -632,16 +653,15 @@ template <int QG>
 int32_t launch_ivf_scan(vers_ivf* h, const IvfSrc<QG>& src, uint32_t items_bound, hipStream_t st) {
   ScanParams p;
   p.ld = h->ld;
-  p.n_chunks = (h->ld + kChunk - 1) / kChunk;
+  p.n_chunks = h->ld / kChunk;
   p.k = src.k_keep;
   p.status = h->status.as<uint32_t>();
   uint32_t blocks = (items_bound + kWavesPerBlock - 1) / kWavesPerBlock;
-  if (blocks > (uint32_t)h->n_cu * 2u) blocks = (uint32_t)h->n_cu * 2u;
+  if (blocks > (uint32_t)h->n_cu * (QG == 1 ? 5u : 3u)) blocks = (uint32_t)h->n_cu * (QG == 1 ? 5u : 3u);
   if (blocks == 0) blocks = 1;
-  const size_t lds = (size_t)kWavesPerBlock * kWave * kLdsStride * sizeof(float);
   const uint32_t slot = (uint32_t)(h->ev_count % vers_ivf::kEvRing);
   VERS_HIP_TRY(hipEventRecord(h->ev0[slot], st));
-  hipLaunchKernelGGL((scan_kernel<QG, 0, IvfSrc<QG>>), dim3(blocks), dim3(kWave * kWavesPerBlock), lds, st, src, p);
+  hipLaunchKernelGGL((scan_kernel<QG, 0, IvfSrc<QG>>), dim3(blocks), dim3(kWave * kWavesPerBlock), 0, st, src, p);
   VERS_HIP_TRY(hipGetLastError());
   VERS_HIP_TRY(hipEventRecord(h->ev1[slot], st));
   h->ev_count += 1;
@@ -761,9 +781,9 @@ int32_t exhaustive_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, 
   const uint32_t n_qg = (b + QG - 1) / QG;
   if (int32_t rc = h->qil.reserve((size_t)n_qg * h->ldq * QG * sizeof(float))) return rc;
   if (int32_t rc = launch_stage_queries(q_dev, ldq_in, h->d, h->qil.as<float>(), h->ldq, b, QG, st)) return rc;
-  const uint32_t target_items = (uint32_t)h->n_cu * 8u;
+  const uint32_t target_items = (uint32_t)h->n_cu * (QG == 1 ? 20u : 12u);
   uint64_t per = (h->cap_rows * n_qg + target_items - 1) / target_items;
-  const uint32_t seg_rows = (uint32_t)round_up64(per ? per : 1, kWave);
+  const uint32_t seg_rows = (uint32_t)std::min<uint64_t>(round_up64(per ? per : 1, kWave), max_seg_rows(h->ld));
   uint32_t n_segs = (uint32_t)((h->cap_rows + seg_rows - 1) / seg_rows);
   if (n_segs == 0) n_segs = 1;
   if (int32_t rc = h->xpart.reserve((size_t)b * n_segs * top_k * sizeof(uint64_t))) return rc;
@@ -805,8 +825,9 @@ int32_t relayout(vers_ivf* h) {
   VERS_HIP_TRY(hipMemset(nids.p, 0xFF, (off ? off : 1) * sizeof(uint32_t)));
   for (uint32_t c = 0; c < k; ++c) {
     if (!h->h_len[c]) continue;
+    // lists start on tile boundaries, so whole 64-row tiles move as they are
     VERS_HIP_TRY(hipMemcpyAsync(nrows.as<float>() + (size_t)noff[c] * h->ld, h->rows.as<float>() + (size_t)h->h_off[c] * h->ld,
-                                (size_t)h->h_len[c] * h->ld * sizeof(float), hipMemcpyDeviceToDevice, nullptr));
+                                (size_t)round_up(h->h_len[c], 64) * h->ld * sizeof(float), hipMemcpyDeviceToDevice, nullptr));
     VERS_HIP_TRY(hipMemcpyAsync(nids.as<uint32_t>() + noff[c], h->row_ids.as<uint32_t>() + h->h_off[c],
                                 (size_t)h->h_len[c] * sizeof(uint32_t), hipMemcpyDeviceToDevice, nullptr));
   }
@@ -854,8 +875,9 @@ int32_t vers_ivf_create(int32_t device, uint32_t d, vers_ivf_t** out) {
   if (!h) return fail(VERS_ERR_INVALID, "out of host memory");
   h->device = device;
   h->d = d;
-  h->ld = round_up(d, 4);
-  h->ldq = round_up(h->ld, kChunk);
+  h->ldx = round_up(d, 4);
+  h->ld = round_up(d, kChunk);
+  h->ldq = h->ld;
   hipDeviceProp_t prop;
   VERS_HIP_TRY(hipGetDeviceProperties(&prop, device));
   h->n_cu = prop.multiProcessorCount;
@@ -890,24 +912,24 @@ int32_t vers_ivf_build(vers_ivf_t* h, const float* rows, uint64_t n, uint64_t ro
   std::lock_guard<std::mutex> lk(h->mu);
   DeviceGuard g(h->device);
   DevBuf X;
-  if (int32_t rc = X.reserve((n ? n : 1) * (size_t)h->ld * sizeof(float))) return rc;
+  if (int32_t rc = X.reserve((n ? n : 1) * (size_t)h->ldx * sizeof(float))) return rc;
   if (n) {
-    if (h->ld != h->d) VERS_HIP_TRY(hipMemset(X.p, 0, n * (size_t)h->ld * sizeof(float)));
-    VERS_HIP_TRY(hipMemcpy2D(X.p, (size_t)h->ld * 4, rows, row_stride_bytes, (size_t)h->d * 4, n, hipMemcpyHostToDevice));
+    if (h->ldx != h->d) VERS_HIP_TRY(hipMemset(X.p, 0, n * (size_t)h->ldx * sizeof(float)));
+    VERS_HIP_TRY(hipMemcpy2D(X.p, (size_t)h->ldx * 4, rows, row_stride_bytes, (size_t)h->d * 4, n, hipMemcpyHostToDevice));
   }
-  return build_common(h, X.as<float>(), n, num_clusters, num_attempts, max_iterations, init_indices, out_centroids,
+  return build_common(h, X.as<float>(), h->ldx, n, num_clusters, num_attempts, max_iterations, init_indices, out_centroids,
                       out_assignments, out_cost, out_kept, out_iterations);
 }
 
 int32_t vers_ivf_build_dev(vers_ivf_t* h, const float* rows_dev, uint64_t n, uint64_t ld_floats, uint64_t num_clusters,
                            uint64_t num_attempts, uint64_t max_iterations, const uint64_t* init_indices, float* out_centroids,
                            uint64_t* out_assignments, float* out_cost, int32_t* out_kept, uint64_t* out_iterations) {
-  if (!h || (n && !rows_dev) || ld_floats != (h ? h->ld : 0) || (num_attempts * num_clusters && !init_indices) ||
-      n > 0xFFFFFFFFull || num_clusters > 0xFFFFFFFFull)
-    return fail(VERS_ERR_INVALID, "vers_ivf_build_dev: bad arguments (ld_floats must equal round_up(d, 4))");
+  if (!h || (n && !rows_dev) || ld_floats < (h ? h->d : 0) || ld_floats % 4 || ld_floats > 0x3FFFFFFFull ||
+      (num_attempts * num_clusters && !init_indices) || n > 0xFFFFFFFFull || num_clusters > 0xFFFFFFFFull)
+    return fail(VERS_ERR_INVALID, "vers_ivf_build_dev: bad arguments (ld_floats must be >= d and a multiple of 4)");
   std::lock_guard<std::mutex> lk(h->mu);
   DeviceGuard g(h->device);
-  return build_common(h, rows_dev, n, num_clusters, num_attempts, max_iterations, init_indices, out_centroids, out_assignments,
+  return build_common(h, rows_dev, (uint32_t)ld_floats, n, num_clusters, num_attempts, max_iterations, init_indices, out_centroids, out_assignments,
                       out_cost, out_kept, out_iterations);
 }
 
@@ -924,20 +946,20 @@ int32_t vers_ivf_upload(vers_ivf_t* h, const float* rows, uint64_t n, uint64_t r
   std::lock_guard<std::mutex> lk(h->mu);
   DeviceGuard g(h->device);
   DevBuf X, A;
-  if (int32_t rc = X.reserve((n ? n : 1) * (size_t)h->ld * sizeof(float))) return rc;
+  if (int32_t rc = X.reserve((n ? n : 1) * (size_t)h->ldx * sizeof(float))) return rc;
   if (int32_t rc = A.reserve((n ? n : 1) * 4)) return rc;
   if (n) {
-    if (h->ld != h->d) VERS_HIP_TRY(hipMemset(X.p, 0, n * (size_t)h->ld * sizeof(float)));
-    VERS_HIP_TRY(hipMemcpy2D(X.p, (size_t)h->ld * 4, rows, row_stride_bytes, (size_t)h->d * 4, n, hipMemcpyHostToDevice));
+    if (h->ldx != h->d) VERS_HIP_TRY(hipMemset(X.p, 0, n * (size_t)h->ldx * sizeof(float)));
+    VERS_HIP_TRY(hipMemcpy2D(X.p, (size_t)h->ldx * 4, rows, row_stride_bytes, (size_t)h->d * 4, n, hipMemcpyHostToDevice));
     VERS_HIP_TRY(hipMemcpy(A.p, a32.data(), n * 4, hipMemcpyHostToDevice));
   }
-  const size_t cbytes = ((size_t)k * h->ld ? (size_t)k * h->ld : 1) * sizeof(float);
+  const size_t cbytes = ((size_t)k * h->ldx ? (size_t)k * h->ldx : 1) * sizeof(float);
   if (int32_t rc = h->centroids.reserve(cbytes)) return rc;
   if (k) {
     VERS_HIP_TRY(hipMemset(h->centroids.p, 0, cbytes));
-    VERS_HIP_TRY(hipMemcpy2D(h->centroids.p, (size_t)h->ld * 4, centroids, c_stride_bytes, (size_t)h->d * 4, k, hipMemcpyHostToDevice));
+    VERS_HIP_TRY(hipMemcpy2D(h->centroids.p, (size_t)h->ldx * 4, centroids, c_stride_bytes, (size_t)h->d * 4, k, hipMemcpyHostToDevice));
   }
-  return install_index(h, X.as<float>(), n, A.as<uint32_t>(), (uint32_t)k, nullptr);
+  return install_index(h, X.as<float>(), h->ldx, n, A.as<uint32_t>(), (uint32_t)k, nullptr);
 }
 
 int32_t vers_ivf_add(vers_ivf_t* h, const float* row, uint64_t* out_cluster, uint64_t* out_vec_id) {
@@ -962,7 +984,9 @@ int32_t vers_ivf_add(vers_ivf_t* h, const float* row, uint64_t* out_cluster, uin
     if (int32_t rc = relayout(h)) return rc;
   const uint32_t pos = h->h_off[c] + h->h_len[c];
   const uint32_t vid = (uint32_t)h->n_total;  // the caller's vec_id is ignored, as in the reference (ivfflat.rs:209)
-  VERS_HIP_TRY(hipMemcpy(h->rows.as<float>() + (size_t)pos * h->ld, qp, (size_t)h->ld * sizeof(float), hipMemcpyDeviceToDevice));
+  hipLaunchKernelGGL(scatter_row_kernel, dim3((h->ld / 4 + 63) / 64), dim3(64), 0, nullptr, qp, h->ld, (uint64_t)pos,
+                     h->rows.as<float>());
+  VERS_HIP_TRY(hipGetLastError());
   VERS_HIP_TRY(hipMemcpy(h->row_ids.as<uint32_t>() + pos, &vid, 4, hipMemcpyHostToDevice));
   h->h_len[c] += 1;
   VERS_HIP_TRY(hipMemcpy(h->list_len.as<uint32_t>() + c, &h->h_len[c], 4, hipMemcpyHostToDevice));
@@ -1099,9 +1123,13 @@ int32_t vers_ivf_get_list(vers_ivf_t* h, uint64_t cluster, float* out_rows, uint
   if (!out_rows && !out_ids) return VERS_OK;
   if (cap_rows < len || (out_rows && row_stride_bytes < (uint64_t)h->d * 4)) return fail(VERS_ERR_INVALID, "vers_ivf_get_list: buffer too small");
   if (len == 0) return VERS_OK;
-  if (out_rows)
-    VERS_HIP_TRY(hipMemcpy2D(out_rows, row_stride_bytes, h->rows.as<float>() + (size_t)h->h_off[cluster] * h->ld, (size_t)h->ld * 4,
-                             (size_t)h->d * 4, len, hipMemcpyDeviceToHost));
+  if (out_rows) {
+    DevBuf tmp;
+    if (int32_t rc = tmp.reserve((size_t)len * h->d * sizeof(float))) return rc;
+    if (int32_t rc = launch_from_blocked(h->rows.as<float>(), h->ld, h->h_off[cluster], len, h->d, tmp.as<float>(), h->d, nullptr))
+      return rc;
+    VERS_HIP_TRY(hipMemcpy2D(out_rows, row_stride_bytes, tmp.p, (size_t)h->d * 4, (size_t)h->d * 4, len, hipMemcpyDeviceToHost));
+  }
   if (out_ids) {
     std::vector<uint32_t> ids(len);
     VERS_HIP_TRY(hipMemcpy(ids.data(), h->row_ids.as<uint32_t>() + h->h_off[cluster], (size_t)len * 4, hipMemcpyDeviceToHost));
@@ -1114,7 +1142,7 @@ int32_t vers_ivf_get_centroids(vers_ivf_t* h, float* out_centroids, uint64_t c_s
   if (!h || (h->k && !out_centroids) || c_stride_bytes < (uint64_t)h->d * 4) return fail(VERS_ERR_INVALID, "bad arguments");
   if (h->k == 0) return VERS_OK;
   DeviceGuard g(h->device);
-  VERS_HIP_TRY(hipMemcpy2D(out_centroids, c_stride_bytes, h->centroids.p, (size_t)h->ld * 4, (size_t)h->d * 4, h->k,
+  VERS_HIP_TRY(hipMemcpy2D(out_centroids, c_stride_bytes, h->centroids.p, (size_t)h->ldx * 4, (size_t)h->d * 4, h->k,
                            hipMemcpyDeviceToHost));
   return VERS_OK;
 }

@@ -34,7 +34,7 @@ void DevBuf::release() {
 template <int QG>
 struct AssignSrc {
   static constexpr bool kSeqIds = false;
-  const float* C;
+  const float* C;  // centroids, lane-transposed tiles
   uint32_t k;
   const float* qblocks;  // [ceil(nb/QG)][ldq][QG]
   uint32_t ldq, nb;
@@ -59,11 +59,13 @@ __global__ void keys_to_assign_kernel(const uint64_t* keys, uint32_t nb, uint32_
   if (mind) mind[i] = __uint_as_float(order_bits_to_f32_bits((uint32_t)(key >> 32)));
 }
 
-int32_t km_assign(const float* X, uint64_t n, const float* C, uint32_t k, uint32_t d, uint32_t ld, uint32_t* out_assign,
-                  float* out_mind, KMeansScratch& ws, int n_cu, hipStream_t st) {
+int32_t km_assign(const float* X, uint32_t ldx, uint64_t n, const float* C, uint32_t ldc, uint32_t k, uint32_t d,
+                  uint32_t* out_assign, float* out_mind, KMeansScratch& ws, int n_cu, hipStream_t st) {
   constexpr int QG = 8;
   if (n == 0) return VERS_OK;
-  const uint32_t ldq = round_up(ld, kChunk);
+  const uint32_t ldq = round_up(d, kChunk);  // columns of the blocked centroids == padded point length
+  if (int32_t rc = ws.cblocked.reserve(blocked_floats(k, ldq) * sizeof(float))) return rc;
+  if (int32_t rc = launch_to_blocked(C, ldc, d, k, ws.cblocked.as<float>(), ldq, st)) return rc;
   // batch so that the interleaved staging stays ~<= 1 GiB
   uint64_t batch = (1ull << 30) / ((uint64_t)ldq * 4);
   batch = batch / QG * QG;
@@ -73,20 +75,19 @@ int32_t km_assign(const float* X, uint64_t n, const float* C, uint32_t k, uint32
   if (int32_t rc = ws.keys.reserve(batch * sizeof(uint64_t))) return rc;
   if (int32_t rc = ws.status.reserve(16)) return rc;
   ScanParams p;
-  p.ld = ld;
-  p.n_chunks = (ld + kChunk - 1) / kChunk;
+  p.ld = ldq;
+  p.n_chunks = ldq / kChunk;
   p.k = 1;
   p.status = ws.status.as<uint32_t>();
-  const size_t lds = (size_t)kWavesPerBlock * kWave * kLdsStride * sizeof(float);
   for (uint64_t i0 = 0; i0 < n; i0 += batch) {
     const uint32_t nb = (uint32_t)((n - i0 < batch) ? (n - i0) : batch);
-    if (int32_t rc = launch_stage_queries(X + i0 * ld, ld, d, ws.qblocks.as<float>(), ldq, nb, QG, st)) return rc;
+    if (int32_t rc = launch_stage_queries(X + i0 * ldx, ldx, d, ws.qblocks.as<float>(), ldq, nb, QG, st)) return rc;
     AssignSrc<QG> src;
-    src.C = C; src.k = k; src.qblocks = ws.qblocks.as<float>(); src.ldq = ldq; src.nb = nb; src.keys = ws.keys.as<uint64_t>();
+    src.C = ws.cblocked.as<float>(); src.k = k; src.qblocks = ws.qblocks.as<float>(); src.ldq = ldq; src.nb = nb; src.keys = ws.keys.as<uint64_t>();
     const uint32_t n_items = (nb + QG - 1) / QG;
     uint32_t blocks = (n_items + kWavesPerBlock - 1) / kWavesPerBlock;
-    if (blocks > (uint32_t)n_cu * 2u) blocks = (uint32_t)n_cu * 2u;
-    hipLaunchKernelGGL((scan_kernel<QG, 0, AssignSrc<QG>>), dim3(blocks), dim3(kWave * kWavesPerBlock), lds, st, src, p);
+    if (blocks > (uint32_t)n_cu * 3u) blocks = (uint32_t)n_cu * 3u;
+    hipLaunchKernelGGL((scan_kernel<QG, 0, AssignSrc<QG>>), dim3(blocks), dim3(kWave * kWavesPerBlock), 0, st, src, p);
     VERS_HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(keys_to_assign_kernel, dim3((nb + 255) / 256), dim3(256), 0, st, ws.keys.as<uint64_t>(), nb,
                        out_assign + i0, out_mind ? out_mind + i0 : nullptr);
@@ -145,10 +146,14 @@ int32_t km_group(const uint32_t* assign, uint32_t n, uint32_t k, uint32_t* sorte
 // thread = one (cluster, column); members visited in list order (ascending point index);
 // 8 independent row loads in flight, the adds stay strictly ordered.
 __global__ __launch_bounds__(256) void update_kernel(const float* X, uint32_t ld, const uint32_t* sorted_ids,
-                                                     const uint32_t* starts, float* Cnew) {
+                                                     const uint32_t* starts, float* Cnew, uint32_t ldc) {
   const uint32_t c = blockIdx.x;
   const uint32_t col = blockIdx.y * 256 + threadIdx.x;
-  if (col >= ld) return;
+  if (col >= ldc) return;
+  if (col >= ld) {  // beyond the data pitch: padding stays zero
+    Cnew[(uint64_t)c * ldc + col] = 0.0f;
+    return;
+  }
   const uint32_t s = starts[c], e = starts[c + 1];
   float acc = 0.0f;
   uint32_t t = s;
@@ -160,13 +165,13 @@ __global__ __launch_bounds__(256) void update_kernel(const float* X, uint32_t ld
     for (int u = 0; u < 8; ++u) acc = __fadd_rn(acc, v[u]);
   }
   for (; t < e; ++t) acc = __fadd_rn(acc, X[(uint64_t)sorted_ids[t] * ld + col]);
-  Cnew[(uint64_t)c * ld + col] = e > s ? __fdiv_rn(acc, (float)(e - s)) : 0.0f;
+  Cnew[(uint64_t)c * ldc + col] = e > s ? __fdiv_rn(acc, (float)(e - s)) : 0.0f;
 }
 
 int32_t km_update(const float* X, uint32_t ld, const uint32_t* sorted_ids, const uint32_t* starts, uint32_t k, float* Cnew,
-                  hipStream_t st) {
+                  uint32_t ldc, hipStream_t st) {
   if (k == 0) return VERS_OK;
-  hipLaunchKernelGGL(update_kernel, dim3(k, (ld + 255) / 256), dim3(256), 0, st, X, ld, sorted_ids, starts, Cnew);
+  hipLaunchKernelGGL(update_kernel, dim3(k, (ldc + 255) / 256), dim3(256), 0, st, X, ld, sorted_ids, starts, Cnew, ldc);
   VERS_HIP_TRY(hipGetLastError());
   return VERS_OK;
 }
@@ -290,7 +295,7 @@ int32_t vers_kmeans_assign(int32_t device, const float* rows, uint64_t n, uint64
   if (int32_t rc = M.reserve(n * sizeof(float))) return rc;
   if (int32_t rc = ws.status.reserve(16)) return rc;
   VERS_HIP_TRY(hipMemset(ws.status.p, 0, 16));
-  if (int32_t rc = km_assign(X.as<float>(), n, C.as<float>(), (uint32_t)k, d, ld, A.as<uint32_t>(), M.as<float>(), ws, n_cu,
+  if (int32_t rc = km_assign(X.as<float>(), ld, n, C.as<float>(), ld, (uint32_t)k, d, A.as<uint32_t>(), M.as<float>(), ws, n_cu,
                              nullptr))
     return rc;
   VERS_HIP_TRY(hipDeviceSynchronize());
@@ -327,7 +332,7 @@ int32_t vers_kmeans_update(int32_t device, const float* rows, uint64_t n, uint64
   uint32_t* counts = ws.counts.as<uint32_t>();
   uint32_t* starts = counts + k;
   if (int32_t rc = km_group(A.as<uint32_t>(), (uint32_t)n, (uint32_t)k, S.as<uint32_t>(), counts, starts, ws, nullptr)) return rc;
-  if (int32_t rc = km_update(X.as<float>(), ld, S.as<uint32_t>(), starts, (uint32_t)k, CN.as<float>(), nullptr)) return rc;
+  if (int32_t rc = km_update(X.as<float>(), ld, S.as<uint32_t>(), starts, (uint32_t)k, CN.as<float>(), ld, nullptr)) return rc;
   VERS_HIP_TRY(hipMemcpy2D(out_centroids, (size_t)d * 4, CN.p, (size_t)ld * 4, (size_t)d * 4, k, hipMemcpyDeviceToHost));
   return VERS_OK;
 }

@@ -22,6 +22,7 @@ struct DevBuf {
 };
 
 struct KMeansScratch {
+  DevBuf cblocked;  // centroids in the scan layout (lane-transposed tiles)
   DevBuf qblocks;   // interleaved point blocks of one assign batch
   DevBuf keys;      // u64 argmin keys of one assign batch
   DevBuf sort_tmp;  // group_by_cluster temp
@@ -32,17 +33,17 @@ struct KMeansScratch {
 
 // assign_to_clusters (ivfflat.rs:29-46): out_assign[i] = first argmin_c D(X[i], C[c]);
 // out_mind[i] (optional) = that minimum distance, bit-exact D(X[i], C[assign[i]]).
-// status bit0 is set on a NaN distance.  X [n][ld], C [k][ld] zero padded to ld.
-int32_t km_assign(const float* X, uint64_t n, const float* C, uint32_t k, uint32_t d, uint32_t ld, uint32_t* out_assign,
-                  float* out_mind, KMeansScratch& ws, int n_cu, hipStream_t st);
+// status bit0 is set on a NaN distance.  X [n][ldx], C [k][ldc] row-major (pad columns zero).
+int32_t km_assign(const float* X, uint32_t ldx, uint64_t n, const float* C, uint32_t ldc, uint32_t k, uint32_t d,
+                  uint32_t* out_assign, float* out_mind, KMeansScratch& ws, int n_cu, hipStream_t st);
 
 // counts[k], starts[k+1] (exclusive prefix), sorted_ids[n] grouped by cluster, ascending inside.
 int32_t km_group(const uint32_t* assign, uint32_t n, uint32_t k, uint32_t* sorted_ids, uint32_t* counts, uint32_t* starts,
                  KMeansScratch& ws, hipStream_t st);
 
 // update_centroids (ivfflat.rs:47-71): Cnew[c] = (0 + x_i1 + x_i2 + ...) / count in ascending i, 0 if empty.
-int32_t km_update(const float* X, uint32_t ld, const uint32_t* sorted_ids, const uint32_t* starts, uint32_t k,
-                  float* Cnew, hipStream_t st);
+int32_t km_update(const float* X, uint32_t ldx, const uint32_t* sorted_ids, const uint32_t* starts, uint32_t k,
+                  float* Cnew, uint32_t ldc, hipStream_t st);
 
 // calculate_kmeans_cost (ivfflat.rs:138-149): strict left-to-right f32 fold of mind[0..n); result at *out_dev.
 int32_t km_cost_fold(const float* mind, uint64_t n, float* out_dev, hipStream_t st);

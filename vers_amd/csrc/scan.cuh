@@ -7,8 +7,9 @@
 // evaluated strictly left to right in f32 with separately rounded multiply and
 // add (vers base.rs:119-126; Rust never contracts or re-associates).  Each
 // LANE owns one corpus row and walks its columns in order, so the result is
-// bit-identical to the reference; the 64 rows of a wave are transposed through
-// a private LDS tile so that HBM is still read with full-line coalesced loads.
+// bit-identical to the reference; the matrix is stored in HBM in lane-transposed
+// 64-row tiles (below) so that every wave-level load is one contiguous 1 KiB read
+// that lands directly in the lanes that own the rows -- no LDS, no shuffles.
 #pragma once
 #include "common.hpp"
 
@@ -69,46 +70,33 @@ __device__ __forceinline__ void wave_topk_update(uint64_t& list, uint32_t k, uin
   }
 }
 
-// ---- the tile engine ---------------------------------------------------------
-// One wave, one tile of up to 64 rows (lane == row), QG queries at once.
-//   rows      first row of the item (uniform), pitch ld floats (multiple of 4)
-//   row0      first row of this tile inside the item
-//   nrows     rows in the item (rows >= nrows contribute zeros and are ignored)
-//   q[QG]     uniform query pointers, zero padded to n_chunks*64 floats
-//   tile      this wave's private LDS tile [64][kLdsStride]
-// METRIC 0: acc = sum (x-q)^2      METRIC 1: acc = sum x*q   (caller does 1-acc)
+// ---- HBM layout: lane-transposed tiles ---------------------------------------------------------
+// A scanned matrix (corpus lists, centroids) is stored in tiles of 64 rows.  Inside tile t
+// (base = t*64*ld floats) element (r, j) lives at ((j/4)*64 + r)*4 + (j%4): for each group of 4
+// columns the 64 rows' float4s are contiguous (1 KiB).  One `buffer_load_dwordx4` per wave is then
+// a single contiguous 1 KiB read AND delivers to lane r exactly row r's 4 columns: the row-per-lane
+// operand layout the ordered f32 chain needs, with no LDS transpose and perfectly sequential HBM
+// streaming (a wave walks its tile front to back).  ld is a multiple of kChunk (zero padded).
+__host__ __device__ __forceinline__ uint64_t blocked_index(uint64_t row, uint32_t col, uint32_t ld) {
+  return (row >> 6) * 64ull * ld + ((uint64_t)(col >> 2) * 64 + (row & 63)) * 4 + (col & 3);
+}
+
 struct TileLoader {
   __amdgpu_buffer_rsrc_t rsrc;
-  uint32_t ld_bytes;      // row pitch in bytes
-  uint32_t voff_lane;     // (lane>>4)*ld_bytes + (lane&15)*16
-  uint32_t col_byte;      // (lane&15)*16
-  uint32_t lds_write_off; // float index inside the tile for i = 0
+  uint32_t lane_off;    // lane * 16 bytes
+  uint32_t tile_bytes;  // 64 * ld * 4
 
-  __device__ __forceinline__ void init(const float* rows, uint64_t item_bytes, uint32_t ld, int lane) {
-    rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)rows, 0, (int)(uint32_t)item_bytes, 0x00020000);
-    ld_bytes = ld * 4u;
-    col_byte = (uint32_t)(lane & 15) * 16u;
-    voff_lane = (uint32_t)(lane >> 4) * ld_bytes + col_byte;
-    lds_write_off = (uint32_t)(lane >> 4) * kLdsStride + (uint32_t)(lane & 15) * 4u;
+  __device__ __forceinline__ void init(const float* base, uint64_t item_bytes, uint32_t ld, int lane) {
+    rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)(uint32_t)item_bytes, 0x00020000);
+    lane_off = (uint32_t)lane * 16u;
+    tile_bytes = ld * 256u;
   }
-  // issue the 16 loads of (tile row0, chunk c); rows past the item read 0 (buffer bounds check),
-  // columns past the pitch are zeroed in stage() -- NOT here, a select on the loaded value would
-  // make the compiler wait for the load right after issuing it and kill the prefetch.
-  __device__ __forceinline__ void issue(u32x4 (&r)[16], uint32_t row0, uint32_t c) const {
-    const uint32_t chunk_byte = c * (kChunk * 4u);
-    const uint32_t voff = voff_lane + chunk_byte;
-    const uint32_t sbase = row0 * ld_bytes;  // uniform
+  // the kLoads float4 loads of (tile, chunk c): everything but the lane offset is wave-uniform -> soffset
+  __device__ __forceinline__ void issue(u32x4 (&r)[kLoads], uint32_t tile, uint32_t c) const {
+    const uint32_t soff = tile * tile_bytes + c * (kLoads * 1024u);
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      // the row offset must sit in voffset: soffset is not part of the hardware range check
-      r[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, voff + (sbase + (uint32_t)i * 4u * ld_bytes), 0, 0);
-    }
-  }
-  __device__ __forceinline__ void stage(const u32x4 (&r)[16], float* tile, uint32_t c) const {
-    const bool col_ok = c * (kChunk * 4u) + col_byte < ld_bytes;
-#pragma unroll
-    for (int i = 0; i < 16; ++i)
-      *reinterpret_cast<u32x4*>(tile + lds_write_off + i * 4 * kLdsStride) = col_ok ? r[i] : u32x4{0u, 0u, 0u, 0u};
+    for (int i = 0; i < kLoads; ++i)
+      r[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane_off, soff + (uint32_t)i * 1024u, 0);
   }
 };
 
@@ -116,24 +104,21 @@ struct TileLoader {
 // item's queries are stored INTERLEAVED, qb[col * QG + qi], so that one s_load_dwordx8
 // brings element `col` of all 8 queries and adjacent SGPR pairs feed v_pk_*_f32:
 // two queries per VALU instruction, each still its own strictly ordered f32 chain.
-template <int QG, int METRIC>
-__device__ __forceinline__ void tile_chunk_compute(f32x2 (&acc)[(QG + 1) / 2], const float* tile, int lane,
+// NP = number of live query PAIRS (dead pairs cost nothing).
+template <int QG, int NP, int METRIC>
+__device__ __forceinline__ void tile_chunk_compute(f32x2 (&acc)[(QG + 1) / 2], const u32x4 (&r)[kLoads],
                                                    const float* qb, uint32_t c) {
-  const float* myrow = tile + lane * kLdsStride;
   if constexpr (QG == 1) {
     cfloat_as4* qs = (cfloat_as4*)(qb + c * kChunk);
     float a = acc[0][0];
 #pragma unroll
-    for (int j16 = 0; j16 < 4; ++j16) {
-      f32x4 x[4];
+    for (int i = 0; i < kLoads; ++i) {
 #pragma unroll
-      for (int u = 0; u < 4; ++u) x[u] = *reinterpret_cast<const f32x4*>(myrow + j16 * 16 + u * 4);
-#pragma unroll
-      for (int u = 0; u < 16; ++u) {
-        float xv = x[u >> 2][u & 3];
-        float sv = qs[j16 * 16 + u];
+      for (int u = 0; u < 4; ++u) {
+        const float xv = __uint_as_float(r[i][u]);
+        const float sv = qs[i * 4 + u];
         if (METRIC == 0) {
-          float t = __fsub_rn(xv, sv);
+          const float t = __fsub_rn(xv, sv);
           a = __fadd_rn(a, __fmul_rn(t, t));
         } else {
           a = __fadd_rn(a, __fmul_rn(xv, sv));
@@ -144,17 +129,15 @@ __device__ __forceinline__ void tile_chunk_compute(f32x2 (&acc)[(QG + 1) / 2], c
   } else {
     typedef __attribute__((address_space(4))) const f32x2 cf32x2_as4;
     cf32x2_as4* qs = (cf32x2_as4*)(qb + (size_t)c * kChunk * QG);
-    // rolled over groups of 4 columns: unrolling the whole chunk lets the scheduler hoist every
-    // scalar load (64 * QG SGPRs) and spill the SGPR file.
-#pragma unroll 1
-    for (int j4 = 0; j4 < kChunk / 4; ++j4) {
-      f32x4 x = *reinterpret_cast<const f32x4*>(myrow + j4 * 4);
+#pragma unroll
+    for (int i = 0; i < kLoads; ++i) {
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const f32x2 xx = {x[u], x[u]};
+        const float xv = __uint_as_float(r[i][u]);
+        const f32x2 xx = {xv, xv};
 #pragma unroll
-        for (int p = 0; p < QG / 2; ++p) {
-          const f32x2 sv = qs[(j4 * 4 + u) * (QG / 2) + p];
+        for (int p = 0; p < NP; ++p) {
+          const f32x2 sv = qs[(i * 4 + u) * (QG / 2) + p];
           if (METRIC == 0) {
             const f32x2 t = xx - sv;
             acc[p] = acc[p] + t * t;
@@ -185,78 +168,103 @@ __device__ __forceinline__ void tile_chunk_compute(f32x2 (&acc)[(QG + 1) / 2], c
 //   const uint32_t* seq_ids(it) const
 template <int QG>
 struct ItemView {
-  const float* rows;   // first row of the item
+  const float* rows;   // first tile of the item (blocked layout, 64-row aligned)
   uint32_t nrows;      // rows in the item
   uint32_t nq;         // live queries (<= QG)
   const float* qb;     // QG == 1: the query; else the item's interleaved query block [col][QG]
 };                     // (zero padded to n_chunks*64 columns; dead query slots are zeros)
 
 struct ScanParams {
-  uint32_t ld;        // row pitch in floats (multiple of 4)
-  uint32_t n_chunks;  // ceil(ld / 64)
+  uint32_t ld;        // columns of the blocked matrix (multiple of kChunk)
+  uint32_t n_chunks;  // ld / kChunk
   uint32_t k;         // keys kept per query (<= 64)
   uint32_t* status;   // device word: bit0 = NaN seen
 };
 
+// One work item, NP live query pairs (QG == 1: NP == 1).
+template <int QG, int NP, int METRIC, class Src>
+__device__ __forceinline__ void scan_item(const Src& src, const ScanParams& p, uint32_t it, const ItemView<QG>& v, int lane,
+                                          bool& nan_seen) {
+  uint64_t list[QG];
+#pragma unroll
+  for (int qi = 0; qi < QG; ++qi) list[qi] = kKeyMax;
+  const uint32_t n_tiles = (v.nrows + kWave - 1) / kWave;
+  TileLoader L;
+  L.init(v.rows, (uint64_t)n_tiles * kWave * p.ld * 4u, p.ld, lane);
+  const uint32_t n_steps = n_tiles * p.n_chunks;
+  f32x2 acc[(QG + 1) / 2];
+#pragma unroll
+  for (int p2 = 0; p2 < (QG + 1) / 2; ++p2) acc[p2] = f32x2{0.0f, 0.0f};
+  uint32_t sid = 0;
+  if (Src::kSeqIds && lane < (int)v.nrows) sid = src.seq_ids(it)[lane];  // older than every prefetch below
+
+  // end of a tile: fold its 64 candidates into the per-query lists
+  auto tile_done = [&](uint32_t t) {
+    const uint32_t row = t * kWave + lane;
+    // kSeqIds: rows whose id is 0xFFFFFFFF are unused storage slack, not vectors
+    const bool valid = row < v.nrows && (!Src::kSeqIds || sid != 0xFFFFFFFFu);
+#pragma unroll
+    for (int qi = 0; qi < QG; ++qi) {
+      if (qi < 2 * NP && qi < (int)v.nq) {
+        const float a = acc[qi >> 1][qi & 1];
+        const float dist = METRIC == 0 ? a : __fsub_rn(1.0f, a);
+        nan_seen |= valid && (dist != dist);
+        const uint32_t seq = Src::kSeqIds ? sid : src.seq_base(it, qi) + row;
+        const uint64_t cand = valid ? make_key(dist, seq) : kKeyMax;
+        wave_topk_update(list[qi], p.k, cand, lane);
+      }
+      acc[qi >> 1][qi & 1] = 0.0f;
+    }
+    if (Src::kSeqIds) {
+      const uint32_t nr = (t + 1) * kWave + lane;
+      sid = nr < v.nrows ? src.seq_ids(it)[nr] : 0xFFFFFFFFu;
+    }
+  };
+
+  // register double buffer: while buffer A is consumed, the loads of the next step fly into B
+  u32x4 ra[kLoads], rb[kLoads];
+  uint32_t t = 0, c = 0;  // (tile, chunk) of the step being consumed
+  if (n_steps) L.issue(ra, 0, 0);
+  for (uint32_t s = 0; s < n_steps; s += 2) {
+    uint32_t t1 = t, c1 = c + 1;
+    if (c1 == p.n_chunks) { c1 = 0; t1 = t + 1; }
+    if (s + 1 < n_steps) L.issue(rb, t1, c1);
+    tile_chunk_compute<QG, NP, METRIC>(acc, ra, v.qb, c);
+    if (c1 == 0) tile_done(t);
+    if (s + 1 >= n_steps) break;
+    uint32_t t2 = t1, c2 = c1 + 1;
+    if (c2 == p.n_chunks) { c2 = 0; t2 = t1 + 1; }
+    if (s + 2 < n_steps) L.issue(ra, t2, c2);
+    tile_chunk_compute<QG, NP, METRIC>(acc, rb, v.qb, c1);
+    if (c2 == 0) tile_done(t1);
+    t = t2; c = c2;
+  }
+#pragma unroll
+  for (int qi = 0; qi < QG; ++qi)
+    if (qi < 2 * NP && qi < (int)v.nq && lane < (int)p.k) src.out(it, qi)[lane] = list[qi];
+}
+
 template <int QG, int METRIC, class Src>
 __global__ __launch_bounds__(kWave * kWavesPerBlock) void scan_kernel(Src src, ScanParams p) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  float* tile = lds + wid * (kWave * kLdsStride);
   const uint32_t n_waves = gridDim.x * kWavesPerBlock;
   const uint32_t n_items = src.n_items();
   bool nan_seen = false;
-
   for (uint32_t it = blockIdx.x * kWavesPerBlock + wid; it < n_items; it += n_waves) {
     ItemView<QG> v;
     src.get(it, v);
-    uint64_t list[QG];
-#pragma unroll
-    for (int qi = 0; qi < QG; ++qi) list[qi] = kKeyMax;
-
-    TileLoader L;
-    L.init(v.rows, (uint64_t)v.nrows * p.ld * 4u, p.ld, lane);
-    const uint32_t n_tiles = (v.nrows + kWave - 1) / kWave;
-    const uint32_t n_steps = n_tiles * p.n_chunks;
-    u32x4 r[16];
-    uint32_t sid = 0;
-    if (Src::kSeqIds && lane < (int)v.nrows) sid = src.seq_ids(it)[lane];  // older than every prefetch below
-    L.issue(r, 0, 0);
-    f32x2 acc[(QG + 1) / 2];
-#pragma unroll
-    for (int p2 = 0; p2 < (QG + 1) / 2; ++p2) acc[p2] = f32x2{0.0f, 0.0f};
-    uint32_t t = 0, c = 0;
-    for (uint32_t s = 0; s < n_steps; ++s) {
-      L.stage(r, tile, c);
-      uint32_t tn = t, cn = c + 1;
-      if (cn == p.n_chunks) { cn = 0; tn = t + 1; }
-      uint32_t sid_next = 0;
-      if (Src::kSeqIds && cn == 0 && tn * kWave + lane < v.nrows) sid_next = src.seq_ids(it)[tn * kWave + lane];
-      if (s + 1 < n_steps) L.issue(r, tn * kWave, cn);  // prefetch the next step under this step's math
-      tile_chunk_compute<QG, METRIC>(acc, tile, lane, v.qb, c);
-      if (cn == 0) {  // tile finished: fold its 64 candidates into the per-query lists
-        const uint32_t row = t * kWave + lane;
-        // kSeqIds: rows whose id is 0xFFFFFFFF are unused storage slack, not vectors
-        const bool valid = row < v.nrows && (!Src::kSeqIds || sid != 0xFFFFFFFFu);
-#pragma unroll
-        for (int qi = 0; qi < QG; ++qi) {
-          if (qi < (int)v.nq) {
-            float dist = METRIC == 0 ? acc[qi >> 1][qi & 1] : __fsub_rn(1.0f, acc[qi >> 1][qi & 1]);
-            nan_seen |= valid && (dist != dist);
-            uint32_t seq = Src::kSeqIds ? sid : src.seq_base(it, qi) + row;
-            uint64_t cand = valid ? make_key(dist, seq) : kKeyMax;
-            wave_topk_update(list[qi], p.k, cand, lane);
-          }
-          acc[qi >> 1][qi & 1] = 0.0f;
-        }
-        sid = sid_next;
+    if constexpr (QG == 1) {
+      scan_item<1, 1, METRIC>(src, p, it, v, lane, nan_seen);
+    } else {
+      static_assert(QG == 8, "query groups are 1 or 8 wide");
+      switch ((v.nq + 1) >> 1) {  // wave-uniform: dead query pairs are not computed
+        case 1: scan_item<8, 1, METRIC>(src, p, it, v, lane, nan_seen); break;
+        case 2: scan_item<8, 2, METRIC>(src, p, it, v, lane, nan_seen); break;
+        case 3: scan_item<8, 3, METRIC>(src, p, it, v, lane, nan_seen); break;
+        default: scan_item<8, 4, METRIC>(src, p, it, v, lane, nan_seen); break;
       }
-      t = tn; c = cn;
     }
-#pragma unroll
-    for (int qi = 0; qi < QG; ++qi)
-      if (qi < (int)v.nq && lane < (int)p.k) src.out(it, qi)[lane] = list[qi];
   }
   if (__ballot(nan_seen) != 0 && lane == 0) atomicOr(p.status, 1u);
 }
