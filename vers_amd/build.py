@@ -16,7 +16,7 @@ LIB = os.path.join(LIBDIR, "libvers_hip.so")
 
 ARCH = "gfx950"
 # -ffp-contract=off: the reference rounds every product and sum separately (no FMA); see csrc/scan.cuh
-CXXFLAGS = ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", f"--offload-arch={ARCH}",
+CXXFLAGS = os.environ.get("VERS_EXTRA_CXXFLAGS", "").split() + ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", f"--offload-arch={ARCH}",
             "-Wall", "-Wno-unused-function"]
 
 

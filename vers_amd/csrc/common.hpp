@@ -24,10 +24,13 @@ int32_t fail(int32_t status, const std::string& msg);
 constexpr int kWave = 64;        // CDNA4 wavefront
 constexpr int kChunk = 32;       // f32 columns consumed per step
 constexpr int kLoads = kChunk / 4;  // float4 loads per lane per step (1 KiB per wave each)
+constexpr int kColAlign = 2 * kChunk;  // blocked matrices / padded queries: columns padded to this
 constexpr int kWavesPerBlock = 4;
 constexpr int kMaxTopK = 64;     // one sorted key per lane
 
 constexpr uint64_t kKeyMax = 0xFFFFFFFFFFFFFFFFull;
+
+uint32_t scan_debug_flags();  // env VERS_SCAN_DEBUG (diagnosis only; 0 in production)
 
 inline uint32_t round_up(uint32_t x, uint32_t m) { return (x + m - 1) / m * m; }
 inline uint64_t round_up64(uint64_t x, uint64_t m) { return (x + m - 1) / m * m; }

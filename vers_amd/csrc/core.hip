@@ -1,4 +1,6 @@
 // core.hip -- error plumbing and misc entry points of libvers_hip.so.
+#include <cstdlib>
+
 #include "common.hpp"
 
 namespace vers {
@@ -7,6 +9,13 @@ void set_error(const std::string& msg) { g_last_error = msg; }
 int32_t fail(int32_t status, const std::string& msg) {
   g_last_error = msg;
   return status;
+}
+uint32_t scan_debug_flags() {
+  static const uint32_t flags = [] {
+    const char* e = getenv("VERS_SCAN_DEBUG");
+    return e ? (uint32_t)strtoul(e, nullptr, 0) : 0u;
+  }();
+  return flags;
 }
 }  // namespace vers
 

@@ -40,6 +40,7 @@ struct FlatSrc {
     const uint32_t seg = it % n_segs, qg = it / n_segs;
     return partials + ((uint64_t)(qg * QG + qi) * n_segs + seg) * k;
   }
+  __device__ __forceinline__ uint32_t bound_slot(uint32_t it, int qi) const { return (it / n_segs) * QG + qi; }
 };
 
 // one block per query: top-k of its n_segs partial slots -> (id, dist)
@@ -65,7 +66,7 @@ using namespace vers;
 
 struct vers_flat {
   int device = 0;
-  uint32_t d = 0, ld = 0;  // ld = round_up(d, kChunk): columns of the blocked corpus and of padded queries
+  uint32_t d = 0, ld = 0;  // ld = round_up(d, kColAlign): columns of the blocked corpus and of padded queries
   uint64_t n = 0;
   float* rows = nullptr;   // lane-transposed tiles (scan.cuh)
   size_t rows_cap = 0;
@@ -75,8 +76,9 @@ struct vers_flat {
   size_t q_stage_cap = 0;
   float* zero_q = nullptr;
   uint32_t zero_q_len = 0;
-  uint64_t* partials = nullptr;
+  uint64_t* partials = nullptr;  // partial slots, then one pruning bound per query
   size_t partials_cap = 0;
+  size_t bounds_off = 0;
   uint32_t* status_dev = nullptr;
   uint64_t* o_ids = nullptr;
   float* o_dist = nullptr;
@@ -96,6 +98,8 @@ int32_t launch_flat_scan(vers_flat* h, const FlatSrc<QG, false>& src, uint32_t n
   p.n_chunks = h->ld / kChunk;
   p.k = src.k;
   p.status = h->status_dev;
+  p.debug = scan_debug_flags();
+  p.bounds = nullptr;  // every item of a query runs concurrently here: a shared bound prunes nothing and its atomics contend
   const uint32_t max_blocks = (uint32_t)h->n_cu * (QG == 1 ? 5u : 3u);  // resident waves: 20 / 12 per CU
   uint32_t blocks = (n_items + kWavesPerBlock - 1) / kWavesPerBlock;
   if (blocks > max_blocks) blocks = max_blocks;
@@ -136,7 +140,9 @@ int32_t flat_search_dev_locked(vers_flat* h, const float* q_dev, uint64_t ldq, u
   uint32_t seg_rows = (uint32_t)std::min<uint64_t>(round_up64(per ? per : 1, kWave), max_seg_rows(h->ld));
   uint32_t n_segs = (uint32_t)((h->n + seg_rows - 1) / seg_rows);
   if (n_segs == 0) n_segs = 1;
-  if (int32_t rc = grow(h->partials, h->partials_cap, (size_t)b * n_segs * top_k)) return rc;
+  h->bounds_off = (size_t)b * n_segs * top_k;
+  if (int32_t rc = grow(h->partials, h->partials_cap, h->bounds_off + (size_t)n_qg * QG)) return rc;
+  VERS_HIP_TRY(hipMemsetAsync(h->partials + h->bounds_off, 0xFF, (size_t)n_qg * QG * sizeof(uint64_t), st));
   const uint32_t n_items = n_segs * n_qg;
 
   auto fill = [&](auto& src) {
@@ -181,7 +187,7 @@ int32_t vers_flat_create(int32_t device, uint32_t d, vers_flat_t** out) {
   if (!h) return fail(VERS_ERR_INVALID, "out of host memory");
   h->device = device;
   h->d = d;
-  h->ld = round_up(d, kChunk);
+  h->ld = round_up(d, kColAlign);
   hipDeviceProp_t prop;
   VERS_HIP_TRY(hipGetDeviceProperties(&prop, device));
   h->n_cu = prop.multiProcessorCount;

@@ -56,6 +56,7 @@ struct SegSrc {
     const uint32_t seg = it % n_segs, qg = it / n_segs;
     return partials + ((uint64_t)(qg * QG + qi) * n_segs + seg) * k;
   }
+  __device__ __forceinline__ uint32_t bound_slot(uint32_t it, int qi) const { return (it / n_segs) * QG + qi; }
 };
 
 struct ItemDesc {
@@ -79,6 +80,7 @@ struct IvfSrc {
   const float* qblocks;       // QG > 1: [group][ldq][QG]
   const float* qp;            // QG == 1: padded queries [b][ldq]
   uint32_t ldq, P, S_max, k_keep, seg_rows;
+  uint32_t bound_per_pair;    // reference mode merges per (query, list); nprobe mode per query
   const uint32_t* pj_pref;    // [b*P] sequence base of probe j of query q
   uint64_t* partials;         // [b*P*S_max][k_keep]
 
@@ -104,6 +106,10 @@ struct IvfSrc {
   __device__ __forceinline__ const uint32_t* seq_ids(uint32_t) const { return nullptr; }
   __device__ __forceinline__ uint64_t* out(uint32_t it, int qi) const {
     return partials + ((uint64_t)pair_of(it, qi) * S_max + items[it].seg) * k_keep;
+  }
+  __device__ __forceinline__ uint32_t bound_slot(uint32_t it, int qi) const {
+    const uint32_t pr = pair_of(it, qi);
+    return bound_per_pair ? pr : pr / P * P;
   }
 };
 
@@ -372,7 +378,7 @@ struct vers_ivf {
   int device = 0, n_cu = 256;
   uint32_t d = 0;
   uint32_t ldx = 0;  // pitch of row-major matrices (X, centroids): round_up(d, 4)
-  uint32_t ld = 0;   // columns of blocked matrices and padded queries: round_up(d, kChunk)
+  uint32_t ld = 0;   // columns of blocked matrices and padded queries: round_up(d, kColAlign)
   uint32_t ldq = 0;  // == ld
   // index state (device cache of the reference's five fields, ivfflat.rs:9-15)
   uint32_t k = 0;         // num_centroids; 0 = no index / nothing kept
@@ -385,10 +391,12 @@ struct vers_ivf {
   uint32_t max_len = 0;
   // scratch
   KMeansScratch km;
+  DevBuf seg_bounds;
   DevBuf qp, qil, cpart, probe, pj, lists, pairs, items, groups, qblocks, partials, status, o_ids, o_dist, o_cnt, xpart;
   static constexpr uint32_t kEvRing = 64;  // scan-launch timing ring (measurement hook)
   hipEvent_t ev0[kEvRing] = {}, ev1[kEvRing] = {};
   uint64_t ev_count = 0;
+  size_t ivf_bounds_off = 0;  // pruning bounds live behind the partial slots (one memset)
   GroupTotals last_tot{};
   bool tot_valid = false;
   std::mutex mu;
@@ -594,6 +602,11 @@ int32_t launch_seg_scan(vers_ivf* h, const SegSrc<QG, SEQ_IDS>& src, uint32_t n_
   p.n_chunks = h->ld / kChunk;
   p.k = src.k;
   p.status = h->status.as<uint32_t>();
+  const size_t nb = (size_t)((src.b + QG - 1) / QG) * QG;  // one pruning bound per query
+  if (int32_t rc = h->seg_bounds.reserve(nb * sizeof(uint64_t))) return rc;
+  VERS_HIP_TRY(hipMemsetAsync(h->seg_bounds.p, 0xFF, nb * sizeof(uint64_t), st));
+  p.debug = 0;
+  p.bounds = nullptr;  // items of a query are concurrent: nothing to prune, and the atomics would contend
   uint32_t blocks = (n_items + kWavesPerBlock - 1) / kWavesPerBlock;
   if (blocks > (uint32_t)h->n_cu * (QG == 1 ? 5u : 3u)) blocks = (uint32_t)h->n_cu * (QG == 1 ? 5u : 3u);
   if (blocks == 0) blocks = 1;
@@ -656,6 +669,8 @@ int32_t launch_ivf_scan(vers_ivf* h, const IvfSrc<QG>& src, uint32_t items_bound
   p.n_chunks = h->ld / kChunk;
   p.k = src.k_keep;
   p.status = h->status.as<uint32_t>();
+  p.debug = scan_debug_flags();
+  p.bounds = scan_debug_flags() & 8u ? h->partials.as<uint64_t>() + h->ivf_bounds_off : nullptr;
   uint32_t blocks = (items_bound + kWavesPerBlock - 1) / kWavesPerBlock;
   if (blocks > (uint32_t)h->n_cu * (QG == 1 ? 5u : 3u)) blocks = (uint32_t)h->n_cu * (QG == 1 ? 5u : 3u);
   if (blocks == 0) blocks = 1;
@@ -690,16 +705,22 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
   const uint64_t n_pj = (uint64_t)b * P;
   const uint64_t pairs_est = ref_mode ? b : n_pj;
   const uint64_t lists_est = std::min<uint64_t>(h->k, pairs_est);
-  const int QG = (b == 1 || pairs_est < 2 * lists_est) ? 1 : 8;
+  // query-group width of the list scan: a list shared by more queries than one group holds is streamed
+  // once per group, so pick the width from the expected queries per list
+  const int QG = (b == 1 || pairs_est < 2 * lists_est) ? 1 : (pairs_est >= 6 * lists_est ? 16 : 8);
   const uint64_t groups_bound = QG == 1 ? n_pj : (n_pj / QG + std::min<uint64_t>(h->k, n_pj));
   uint32_t seg_rows;
   if (b == 1) seg_rows = kWave;
   else {
     const uint64_t groups_est = std::max<uint64_t>(1, std::max<uint64_t>(pairs_est / QG, lists_est));
-    const uint64_t segs_wanted = std::max<uint64_t>(1, ((uint64_t)h->n_cu * 32 + groups_est - 1) / groups_est);
+    // ~128 items per CU: short segments keep the waves of a CU on the same (list, query group), i.e. on the
+    // same scalar-cache lines of query operands, and even out the tail (measured: 320-row segments at
+    // N=10M/nlist=4096/batch=1024 are 18 % faster than 1280-row ones)
+    const uint64_t segs_wanted = std::max<uint64_t>(1, ((uint64_t)h->n_cu * 128 + groups_est - 1) / groups_est);
     const uint64_t avg_len = std::max<uint64_t>(1, h->n_total / std::max<uint32_t>(1, h->k));
     seg_rows = (uint32_t)round_up64(std::max<uint64_t>(1, (avg_len + segs_wanted - 1) / segs_wanted), kWave);
   }
+  if (const char* e = getenv("VERS_SEG_ROWS")) seg_rows = (uint32_t)round_up64(std::max(64l, atol(e)), kWave);  // tuning knob
   const uint32_t S_max = std::max<uint32_t>(1, (h->max_len + seg_rows - 1) / seg_rows);
   const uint64_t items_bound = groups_bound * S_max;
   if (items_bound > 0x7FFFFFFFull) return fail(VERS_ERR_INVALID, "search batch too large");
@@ -713,7 +734,8 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
   if (int32_t rc = h->groups.reserve(std::max<uint64_t>(1, groups_bound) * sizeof(GroupDesc))) return rc;
   if (QG != 1)
     if (int32_t rc = h->qblocks.reserve(groups_bound * h->ldq * QG * sizeof(float))) return rc;
-  const size_t part_bytes = (size_t)n_pj * S_max * top_k * sizeof(uint64_t);
+  h->ivf_bounds_off = (size_t)n_pj * S_max * top_k;
+  const size_t part_bytes = (h->ivf_bounds_off + n_pj) * sizeof(uint64_t);  // slots + one bound per (query, probe)
   if (int32_t rc = h->partials.reserve(part_bytes)) return rc;
   uint32_t* pj_list = h->pj.as<uint32_t>();
   uint32_t* pj_pref = pj_list + n_pj;
@@ -752,13 +774,17 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
     src.cnt = cnt; src.pair_off = pair_off; src.pairs = h->pairs.as<uint32_t>(); src.group_off = group_off;
     src.qblocks = h->qblocks.as<float>(); src.qp = qp; src.ldq = h->ldq; src.P = P; src.S_max = S_max; src.k_keep = top_k;
     src.seg_rows = seg_rows; src.pj_pref = pj_pref; src.partials = h->partials.as<uint64_t>();
+    src.bound_per_pair = ref_mode ? 1u : 0u;
   };
   int32_t rc;
   if (QG == 1) {
     IvfSrc<1> src; fill_src(src);
     rc = launch_ivf_scan(h, src, (uint32_t)items_bound, st);
-  } else {
+  } else if (QG == 8) {
     IvfSrc<8> src; fill_src(src);
+    rc = launch_ivf_scan(h, src, (uint32_t)items_bound, st);
+  } else {
+    IvfSrc<16> src; fill_src(src);
     rc = launch_ivf_scan(h, src, (uint32_t)items_bound, st);
   }
   if (rc) return rc;
@@ -876,7 +902,7 @@ int32_t vers_ivf_create(int32_t device, uint32_t d, vers_ivf_t** out) {
   h->device = device;
   h->d = d;
   h->ldx = round_up(d, 4);
-  h->ld = round_up(d, kChunk);
+  h->ld = round_up(d, kColAlign);
   h->ldq = h->ld;
   hipDeviceProp_t prop;
   VERS_HIP_TRY(hipGetDeviceProperties(&prop, device));

@@ -49,6 +49,7 @@ struct AssignSrc {
   __device__ __forceinline__ uint32_t seq_base(uint32_t, int) const { return 0; }
   __device__ __forceinline__ const uint32_t* seq_ids(uint32_t) const { return nullptr; }
   __device__ __forceinline__ uint64_t* out(uint32_t it, int qi) const { return keys + (uint64_t)it * QG + qi; }
+  __device__ __forceinline__ uint32_t bound_slot(uint32_t, int) const { return 0; }
 };
 
 __global__ void keys_to_assign_kernel(const uint64_t* keys, uint32_t nb, uint32_t* assign, float* mind) {
@@ -63,7 +64,7 @@ int32_t km_assign(const float* X, uint32_t ldx, uint64_t n, const float* C, uint
                   uint32_t* out_assign, float* out_mind, KMeansScratch& ws, int n_cu, hipStream_t st) {
   constexpr int QG = 8;
   if (n == 0) return VERS_OK;
-  const uint32_t ldq = round_up(d, kChunk);  // columns of the blocked centroids == padded point length
+  const uint32_t ldq = round_up(d, kColAlign);  // columns of the blocked centroids == padded point length
   if (int32_t rc = ws.cblocked.reserve(blocked_floats(k, ldq) * sizeof(float))) return rc;
   if (int32_t rc = launch_to_blocked(C, ldc, d, k, ws.cblocked.as<float>(), ldq, st)) return rc;
   // batch so that the interleaved staging stays ~<= 1 GiB
@@ -79,6 +80,8 @@ int32_t km_assign(const float* X, uint32_t ldx, uint64_t n, const float* C, uint
   p.n_chunks = ldq / kChunk;
   p.k = 1;
   p.status = ws.status.as<uint32_t>();
+  p.debug = 0;
+  p.bounds = nullptr;  // one item sees all centroids of its points: nothing to share
   for (uint64_t i0 = 0; i0 < n; i0 += batch) {
     const uint32_t nb = (uint32_t)((n - i0 < batch) ? (n - i0) : batch);
     if (int32_t rc = launch_stage_queries(X + i0 * ldx, ldx, d, ws.qblocks.as<float>(), ldq, nb, QG, st)) return rc;

@@ -42,30 +42,40 @@ __device__ __forceinline__ uint64_t readlane64(uint64_t v, int lane /*uniform*/)
   uint32_t hi = __builtin_amdgcn_readlane((uint32_t)(v >> 32), lane);
   return ((uint64_t)hi << 32) | lo;
 }
-// value of lane-1 (lane 0 receives `fill`)
-__device__ __forceinline__ uint64_t shift_up1_64(uint64_t v, uint64_t fill, int lane) {
-  uint32_t lo = __shfl_up((uint32_t)v, 1, 64);
-  uint32_t hi = __shfl_up((uint32_t)(v >> 32), 1, 64);
-  uint64_t r = ((uint64_t)hi << 32) | lo;
-  return lane == 0 ? fill : r;
+// a value that is the same in every lane, moved to the scalar file
+__device__ __forceinline__ uint64_t uniform64(uint64_t v) {
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)v);
+  const uint32_t hi = __builtin_amdgcn_readfirstlane((uint32_t)(v >> 32));
+  return ((uint64_t)hi << 32) | lo;
+}
+// value of lane-1 (lane 0 receives 0): DPP wave_shr:1, a plain VALU move -- no LDS round trip
+__device__ __forceinline__ uint64_t shift_up1_64(uint64_t v) {
+  const uint32_t lo = __builtin_amdgcn_update_dpp(0u, (uint32_t)v, 0x138, 0xf, 0xf, false);
+  const uint32_t hi = __builtin_amdgcn_update_dpp(0u, (uint32_t)(v >> 32), 0x138, 0xf, 0xf, false);
+  return ((uint64_t)hi << 32) | lo;
 }
 
 // Sorted list of the 64 smallest keys seen so far, one per lane (ascending by
 // lane).  `cand` is one candidate per lane (kKeyMax = none).  Only candidates
-// below the current k-th key are inserted; keys are unique (seq differs), so
+// below min(current k-th key, bound) are inserted; keys are unique (seq differs), so
 // the order is total and the result equals a stable sort by (dist, seq).
-__device__ __forceinline__ void wave_topk_update(uint64_t& list, uint32_t k, uint64_t cand, int lane) {
+// `bound` is any key known to have at least k keys at or below it among ALL candidates of the
+// final merge (a finished work item's k-th key, shared through memory): larger keys can never
+// reach the final top-k, so dropping them changes nothing in the result.
+__device__ __forceinline__ void wave_topk_update(uint64_t& list, uint32_t k, uint64_t cand, uint64_t bound) {
   uint64_t thr = readlane64(list, (int)k - 1);
+  thr = thr < bound ? thr : bound;
   uint64_t m = __ballot(cand < thr);
   while (m) {
     int src = __ffsll((unsigned long long)m) - 1;
     m &= m - 1;
     uint64_t x = readlane64(cand, src);
     if (x < thr) {
-      uint64_t prev = shift_up1_64(list, 0, lane);
+      uint64_t prev = shift_up1_64(list);
       uint64_t mx = prev > x ? prev : x;
       list = x < list ? mx : list;
-      thr = readlane64(list, (int)k - 1);
+      uint64_t kth = readlane64(list, (int)k - 1);
+      thr = kth < thr ? kth : thr;
     }
   }
 }
@@ -76,7 +86,7 @@ __device__ __forceinline__ void wave_topk_update(uint64_t& list, uint32_t k, uin
 // columns the 64 rows' float4s are contiguous (1 KiB).  One `buffer_load_dwordx4` per wave is then
 // a single contiguous 1 KiB read AND delivers to lane r exactly row r's 4 columns: the row-per-lane
 // operand layout the ordered f32 chain needs, with no LDS transpose and perfectly sequential HBM
-// streaming (a wave walks its tile front to back).  ld is a multiple of kChunk (zero padded).
+// streaming (a wave walks its tile front to back).  ld is a multiple of kColAlign (zero padded).
 __host__ __device__ __forceinline__ uint64_t blocked_index(uint64_t row, uint32_t col, uint32_t ld) {
   return (row >> 6) * 64ull * ld + ((uint64_t)(col >> 2) * 64 + (row & 63)) * 4 + (col & 3);
 }
@@ -99,6 +109,25 @@ struct TileLoader {
       r[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane_off, soff + (uint32_t)i * 1024u, 0);
   }
 };
+
+// (x[H], x[H]) - (q.x, q.y) and (x[H], x[H]) * (q.x, q.y): one v_pk_*_f32 whose VGPR operand is a
+// natural register pair of the loaded float4 with element H broadcast by op_sel, and whose other
+// operand is an SGPR pair holding the same column of two queries.  Register-only asm: nothing for
+// the compiler to count or wait for.  IEEE: x - q is computed as x + (-q), exact same result.
+template <int H>
+__device__ __forceinline__ f32x2 pk_bcast_sub(f32x2 x, f32x2 q) {
+  f32x2 t;
+  if (H == 0) asm("v_pk_add_f32 %0, %1, %2 op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(t) : "v"(x), "s"(q));
+  else asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(t) : "v"(x), "s"(q));
+  return t;
+}
+template <int H>
+__device__ __forceinline__ f32x2 pk_bcast_mul(f32x2 x, f32x2 q) {
+  f32x2 t;
+  if (H == 0) asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(t) : "v"(x), "s"(q));
+  else asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(t) : "v"(x), "s"(q));
+  return t;
+}
 
 // Query operands are wave-uniform and come in through the scalar path.  For QG > 1 the
 // item's queries are stored INTERLEAVED, qb[col * QG + qi], so that one s_load_dwordx8
@@ -129,20 +158,32 @@ __device__ __forceinline__ void tile_chunk_compute(f32x2 (&acc)[(QG + 1) / 2], c
   } else {
     typedef __attribute__((address_space(4))) const f32x2 cf32x2_as4;
     cf32x2_as4* qs = (cf32x2_as4*)(qb + (size_t)c * kChunk * QG);
+    // Scalar loads return out of order, so every use waits for ALL outstanding ones (lgkmcnt(0)):
+    // fetch the query operands of a whole batch of kQBatch columns first, then do the batch's math,
+    // so that one scalar-cache round trip is amortised over kQBatch * NP * 3 packed instructions.
+    constexpr int kQBatch = NP <= 4 ? 8 : 4;  // columns per batch: <= 64 SGPRs of query data
 #pragma unroll
-    for (int i = 0; i < kLoads; ++i) {
+    for (int b0 = 0; b0 < kChunk; b0 += kQBatch) {
+      f32x2 qv[kQBatch][NP];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const float xv = __uint_as_float(r[i][u]);
-        const f32x2 xx = {xv, xv};
+      for (int j = 0; j < kQBatch; ++j)
+#pragma unroll
+        for (int p = 0; p < NP; ++p) qv[j][p] = qs[(b0 + j) * (QG / 2) + p];
+#pragma unroll
+      for (int j = 0; j < kQBatch; ++j) {
+        const int i = (b0 + j) >> 2, u = (b0 + j) & 3;
+        // the loaded float4 as two natural register pairs; one column is broadcast to both halves of
+        // the packed op by op_sel (see pk_bcast_*), so no {x, x} pair is ever materialised
+        const f32x2 xp = u < 2 ? f32x2{__uint_as_float(r[i][0]), __uint_as_float(r[i][1])}
+                               : f32x2{__uint_as_float(r[i][2]), __uint_as_float(r[i][3])};
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
-          const f32x2 sv = qs[(i * 4 + u) * (QG / 2) + p];
           if (METRIC == 0) {
-            const f32x2 t = xx - sv;
+            const f32x2 t = (u & 1) ? pk_bcast_sub<1>(xp, qv[j][p]) : pk_bcast_sub<0>(xp, qv[j][p]);
             acc[p] = acc[p] + t * t;
           } else {
-            acc[p] = acc[p] + xx * sv;
+            const f32x2 t = (u & 1) ? pk_bcast_mul<1>(xp, qv[j][p]) : pk_bcast_mul<0>(xp, qv[j][p]);
+            acc[p] = acc[p] + t;
           }
         }
       }
@@ -166,6 +207,7 @@ __device__ __forceinline__ void tile_chunk_compute(f32x2 (&acc)[(QG + 1) / 2], c
 //   uint64_t* out(it, qi) const              partial slot (k keys) for query qi
 //   static constexpr bool kSeqIds            seq = seq_ids(it)[row] instead of seq_base + row
 //   const uint32_t* seq_ids(it) const
+//   uint32_t bound_slot(it, qi) const        index into ScanParams::bounds of the merge group of (it, qi)
 template <int QG>
 struct ItemView {
   const float* rows;   // first tile of the item (blocked layout, 64-row aligned)
@@ -175,23 +217,29 @@ struct ItemView {
 };                     // (zero padded to n_chunks*64 columns; dead query slots are zeros)
 
 struct ScanParams {
-  uint32_t ld;        // columns of the blocked matrix (multiple of kChunk)
-  uint32_t n_chunks;  // ld / kChunk
+  uint32_t ld;        // columns of the blocked matrix (multiple of kColAlign)
+  uint32_t n_chunks;  // ld / kChunk (even)
   uint32_t k;         // keys kept per query (<= 64)
   uint32_t* status;   // device word: bit0 = NaN seen
+  uint64_t* bounds;   // nullable: shared pruning bound per merge group (Src::bound_slot), kKeyMax initialised
+  uint32_t debug;     // diagnosis only (env VERS_SCAN_DEBUG): 1 skip top-k, 2 skip math, 4 one query column
 };
 
 // One work item, NP live query pairs (QG == 1: NP == 1).
 template <int QG, int NP, int METRIC, class Src>
 __device__ __forceinline__ void scan_item(const Src& src, const ScanParams& p, uint32_t it, const ItemView<QG>& v, int lane,
                                           bool& nan_seen) {
-  uint64_t list[QG];
+  uint64_t list[QG], bound[QG];
 #pragma unroll
-  for (int qi = 0; qi < QG; ++qi) list[qi] = kKeyMax;
+  for (int qi = 0; qi < QG; ++qi) {
+    list[qi] = kKeyMax;
+    bound[qi] = kKeyMax;
+    if (p.bounds != nullptr && qi < 2 * NP && qi < (int)v.nq)  // relaxed agent-scope read: a stale value only prunes less
+      bound[qi] = uniform64(__hip_atomic_load(p.bounds + src.bound_slot(it, qi), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+  }
   const uint32_t n_tiles = (v.nrows + kWave - 1) / kWave;
   TileLoader L;
   L.init(v.rows, (uint64_t)n_tiles * kWave * p.ld * 4u, p.ld, lane);
-  const uint32_t n_steps = n_tiles * p.n_chunks;
   f32x2 acc[(QG + 1) / 2];
 #pragma unroll
   for (int p2 = 0; p2 < (QG + 1) / 2; ++p2) acc[p2] = f32x2{0.0f, 0.0f};
@@ -205,13 +253,13 @@ __device__ __forceinline__ void scan_item(const Src& src, const ScanParams& p, u
     const bool valid = row < v.nrows && (!Src::kSeqIds || sid != 0xFFFFFFFFu);
 #pragma unroll
     for (int qi = 0; qi < QG; ++qi) {
-      if (qi < 2 * NP && qi < (int)v.nq) {
+      if (qi < 2 * NP && qi < (int)v.nq && !(p.debug & 1u)) {
         const float a = acc[qi >> 1][qi & 1];
         const float dist = METRIC == 0 ? a : __fsub_rn(1.0f, a);
         nan_seen |= valid && (dist != dist);
         const uint32_t seq = Src::kSeqIds ? sid : src.seq_base(it, qi) + row;
         const uint64_t cand = valid ? make_key(dist, seq) : kKeyMax;
-        wave_topk_update(list[qi], p.k, cand, lane);
+        wave_topk_update(list[qi], p.k, cand, bound[qi]);
       }
       acc[qi >> 1][qi & 1] = 0.0f;
     }
@@ -221,27 +269,36 @@ __device__ __forceinline__ void scan_item(const Src& src, const ScanParams& p, u
     }
   };
 
-  // register double buffer: while buffer A is consumed, the loads of the next step fly into B
+  // Register double buffer: while buffer A is consumed, the loads of the next chunk fly into B.
+  // Chunks come in pairs (ld is a multiple of 2*kChunk) and EVERY load is issued unconditionally
+  // (the one past the end re-reads the last tile): a branch around a prefetch would make the
+  // compiler's vmcnt bookkeeping assume the shorter queue and wait for the prefetch itself.
   u32x4 ra[kLoads], rb[kLoads];
-  uint32_t t = 0, c = 0;  // (tile, chunk) of the step being consumed
-  if (n_steps) L.issue(ra, 0, 0);
-  for (uint32_t s = 0; s < n_steps; s += 2) {
-    uint32_t t1 = t, c1 = c + 1;
-    if (c1 == p.n_chunks) { c1 = 0; t1 = t + 1; }
-    if (s + 1 < n_steps) L.issue(rb, t1, c1);
-    tile_chunk_compute<QG, NP, METRIC>(acc, ra, v.qb, c);
-    if (c1 == 0) tile_done(t);
-    if (s + 1 >= n_steps) break;
-    uint32_t t2 = t1, c2 = c1 + 1;
-    if (c2 == p.n_chunks) { c2 = 0; t2 = t1 + 1; }
-    if (s + 2 < n_steps) L.issue(ra, t2, c2);
-    tile_chunk_compute<QG, NP, METRIC>(acc, rb, v.qb, c1);
-    if (c2 == 0) tile_done(t1);
-    t = t2; c = c2;
+  const uint32_t last_tile = n_tiles ? n_tiles - 1 : 0;
+  if (n_tiles) L.issue(ra, 0, 0);
+  for (uint32_t t = 0; t < n_tiles; ++t) {
+    for (uint32_t c = 0; c < p.n_chunks; c += 2) {
+      L.issue(rb, t, c + 1);
+      if (!(p.debug & 2u)) tile_chunk_compute<QG, NP, METRIC>(acc, ra, v.qb, (p.debug & 4u) ? 0 : c);
+      else acc[0][0] += __uint_as_float(ra[0][0] ^ ra[kLoads - 1][3]);
+      const bool tile_end = c + 2 == p.n_chunks;
+      const uint32_t tn = tile_end ? (t < last_tile ? t + 1 : last_tile) : t;
+      L.issue(ra, tn, tile_end ? 0 : c + 2);
+      if (!(p.debug & 2u)) tile_chunk_compute<QG, NP, METRIC>(acc, rb, v.qb, (p.debug & 4u) ? 0 : c + 1);
+      else acc[0][0] += __uint_as_float(rb[0][0] ^ rb[kLoads - 1][3]);
+    }
+    tile_done(t);
   }
 #pragma unroll
-  for (int qi = 0; qi < QG; ++qi)
-    if (qi < 2 * NP && qi < (int)v.nq && lane < (int)p.k) src.out(it, qi)[lane] = list[qi];
+  for (int qi = 0; qi < QG; ++qi) {
+    if (qi < 2 * NP && qi < (int)v.nq) {
+      if (lane < (int)p.k) src.out(it, qi)[lane] = list[qi];
+      if (p.bounds != nullptr) {  // publish this item's k-th key (if it has k) as a bound for later items
+        const uint64_t kth = readlane64(list[qi], (int)p.k - 1);
+        if (kth < bound[qi] && lane == 0) atomicMin((unsigned long long*)(p.bounds + src.bound_slot(it, qi)), (unsigned long long)kth);
+      }
+    }
+  }
 }
 
 template <int QG, int METRIC, class Src>
@@ -256,13 +313,20 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void scan_kernel(Src src, S
     src.get(it, v);
     if constexpr (QG == 1) {
       scan_item<1, 1, METRIC>(src, p, it, v, lane, nan_seen);
-    } else {
-      static_assert(QG == 8, "query groups are 1 or 8 wide");
+    } else if constexpr (QG == 8) {
       switch ((v.nq + 1) >> 1) {  // wave-uniform: dead query pairs are not computed
         case 1: scan_item<8, 1, METRIC>(src, p, it, v, lane, nan_seen); break;
         case 2: scan_item<8, 2, METRIC>(src, p, it, v, lane, nan_seen); break;
         case 3: scan_item<8, 3, METRIC>(src, p, it, v, lane, nan_seen); break;
         default: scan_item<8, 4, METRIC>(src, p, it, v, lane, nan_seen); break;
+      }
+    } else {
+      static_assert(QG == 16, "query groups are 1, 8 or 16 wide");
+      switch ((v.nq + 3) >> 2) {  // in steps of two pairs: bounds the code size (instruction cache)
+        case 1: scan_item<16, 2, METRIC>(src, p, it, v, lane, nan_seen); break;
+        case 2: scan_item<16, 4, METRIC>(src, p, it, v, lane, nan_seen); break;
+        case 3: scan_item<16, 6, METRIC>(src, p, it, v, lane, nan_seen); break;
+        default: scan_item<16, 8, METRIC>(src, p, it, v, lane, nan_seen); break;
       }
     }
   }
@@ -289,13 +353,13 @@ __device__ __forceinline__ uint64_t block_merge_keys(const uint64_t* keys, uint3
       cand[u] = i < n_keys ? keys[i] : kKeyMax;
     }
 #pragma unroll
-    for (int u = 0; u < U; ++u) wave_topk_update(list, k, cand[u], lane);
+    for (int u = 0; u < U; ++u) wave_topk_update(list, k, cand[u], kKeyMax);
   }
   __syncthreads();  // `sh` may still be read by wave 0 of a previous call
   sh[wid][lane] = list;
   __syncthreads();
   if (wid == 0) {
-    for (int w = 1; w < kMergeWaves; ++w) wave_topk_update(list, k, sh[w][lane], lane);
+    for (int w = 1; w < kMergeWaves; ++w) wave_topk_update(list, k, sh[w][lane], kKeyMax);
   }
   return list;
 }
