@@ -44,7 +44,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--n", type=int, default=10_000_000)
+    ap.add_argument("--rows", type=int, default=10_000_000, help="corpus size N")
     ap.add_argument("--d", type=int, default=768)
     ap.add_argument("--nlist", type=int, default=4096)
     ap.add_argument("--nprobe", type=int, default=32)
@@ -61,18 +61,25 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     import torch
-    torch.cuda.set_device(local_rank)
-    dev = torch.device(f"cuda:{local_rank}")
+    # one process per GPU.  (VERS_BENCH_BACKEND=gloo + fewer GPUs than ranks is a debugging aid only: it lets
+    # the multi-rank code path run on a 1-GPU box, staging the all-gather through host memory.)
+    backend = os.environ.get("VERS_BENCH_BACKEND", "nccl")
+    dev_index = local_rank % max(1, torch.cuda.device_count()) if backend != "nccl" else local_rank
+    torch.cuda.set_device(dev_index)
+    dev = torch.device(f"cuda:{dev_index}")
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     from tests import datagen as dg
     from vers_amd import capi
     from vers_amd.index import IVFFlatIndex
 
-    n, d, nlist, nprobe, B, top_k = args.n, args.d, args.nlist, args.nprobe, args.batch, args.top_k
+    n, d, nlist, nprobe, B, top_k = args.rows, args.d, args.nlist, args.nprobe, args.batch, args.top_k
     ld = (d + 3) // 4 * 4
     # Dist-C with 16 modes per list.  (SURVEY.md 8d suggested nlist/4 modes; measured on MI355X that
     # degenerates: 4 iterations of k-means leave 3/4 of the lists empty and the rest at 4x the mean, so
@@ -93,7 +100,9 @@ def main():
     torch.cuda.synchronize()
     t_gen = time.perf_counter() - t0
     init = (dg.mix64(np.uint64(0xB01D) + np.arange(nlist, dtype=np.uint64)) % np.uint64(n)).astype(np.uint64)
-    index = IVFFlatIndex(d, device=local_rank)
+    index = IVFFlatIndex(d, device=dev_index)
+    if world > 1:
+        index.set_shard(rank, world)  # every rank runs the same deterministic build and keeps only its lists
     t0 = time.perf_counter()
     kept = index.build_dev(X.data_ptr(), n, nlist, 1, args.kmeans_iters, init)
     t_build = time.perf_counter() - t0
@@ -104,8 +113,10 @@ def main():
     if rank == 0:
         log(f"[bench] corpus {n}x{d} generated in {t_gen:.1f}s; build_index (k-means {int(index.iterations[0])} iters + final assign) "
             f"{t_build:.1f}s; cost {float(index.cost):.1f}; list len min/mean/max {int(lens.min())}/{lens.mean():.0f}/{int(lens.max())}")
-    if world > 1:
-        raise SystemExit("multi-GPU sharding lands in the next commit")
+    if world > 1 and rank == 0:
+        own = index.owners()
+        log(f"[bench] lists sharded over {world} ranks (LPT): rows per rank "
+            f"{[int(lens[own == r].sum()) for r in range(world)]}")
 
     # ---- queries: distinct batches drawn from the same distribution (not from the corpus) -------------
     n_batches = max(1, min(args.steps + args.warmup, 8))
@@ -116,9 +127,26 @@ def main():
     cnt = torch.zeros(B, dtype=torch.int32, device=dev)
     st = torch.cuda.current_stream().cuda_stream
 
+    part = torch.empty(2, B, top_k, dtype=torch.int64, device=dev)            # [keys | vec ids] of this rank
+    allp = torch.empty(world, 2, B, top_k, dtype=torch.int64, device=dev)
+
+    def exchange():
+        if backend == "nccl":
+            dist.all_gather_into_tensor(allp, part)                             # the ONE collective per batch (RCCL)
+        else:
+            h = [torch.empty(2, B, top_k, dtype=torch.int64) for _ in range(world)]
+            dist.all_gather(h, part.cpu())
+            allp.copy_(torch.stack(h).to(dev))
+
     def step(i):
         qb = Q[(i % n_batches) * B:]
-        index.search_dev(qb.data_ptr(), ld, B, top_k, nprobe, ids.data_ptr(), dst.data_ptr(), cnt.data_ptr(), st)
+        if world == 1:
+            index.search_dev(qb.data_ptr(), ld, B, top_k, nprobe, ids.data_ptr(), dst.data_ptr(), cnt.data_ptr(), st)
+        else:
+            index.search_partial_dev(qb.data_ptr(), ld, B, top_k, nprobe, part[0].data_ptr(), part[1].data_ptr(), st)
+            exchange()
+            IVFFlatIndex.merge_partials_dev(allp.data_ptr(), allp.data_ptr() + 8 * B * top_k, 2 * B * top_k, world, B, top_k,
+                                            nprobe, ids.data_ptr(), dst.data_ptr(), cnt.data_ptr(), st)
 
     for i in range(args.warmup):
         step(i)
@@ -143,7 +171,7 @@ def main():
     scan_mean_ms = float(np.mean(scan_ms)) if len(scan_ms) else float("nan")
     algo_bytes = ls["union_rows"] * d * 4 + nlist * d * 4
     achieved = algo_bytes / (scan_mean_ms * 1e-3) / 1e9
-    roofline = {"bound": "hbm", "kernel": "scan_kernel<8,0,IvfSrc<8>> (inverted-list scan)", "achieved": round(achieved, 1),
+    roofline = {"bound": "hbm", "kernel": "scan_kernel<QG,0,IvfSrc<QG>> (inverted-list scan; QG = 16 at this shape)", "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
                 "algorithmic_bytes_per_launch": int(algo_bytes), "streamed_bytes_per_launch": int(ls["streamed_rows"] * d * 4),
                 "launch_ms": round(scan_mean_ms, 4), "launches_timed": int(len(scan_ms)), "work_items": int(ls["items"])}
@@ -163,13 +191,21 @@ def main():
         index.poll(st)
         t_ex = time.perf_counter() - t0
         e = eids.cpu().numpy().astype(np.uint64)
+        if world > 1:  # each rank scanned only its rows: combine the per-rank exact top-k by (distance, vec id)
+            ed = edst.cpu().numpy(); ec = ecnt.cpu().numpy()
+            ed[np.arange(top_k)[None, :] >= ec[:, None]] = np.inf
+            gl = [None] * world
+            dist.all_gather_object(gl, (e, ed))
+            ae = np.concatenate([g[0] for g in gl], axis=1); ad = np.concatenate([g[1] for g in gl], axis=1)
+            order = np.lexsort((ae, ad), axis=1)[:, :top_k]
+            e = np.take_along_axis(ae, order, axis=1)
         hits = sum(len(set(ids_h[q, :cnt_h[q]].tolist()) & set(e[q].tolist())) for q in range(nq_r))
         recall = hits / float(nq_r * top_k)
         log(f"[bench] recall@{top_k} = {recall:.4f} over {nq_r} queries (exact scan took {t_ex:.2f}s)")
 
     # ---- CPU baseline: the C restatement of the reference path on one host core -----------------------
     cpu = None
-    if rank == 0 and not args.no_cpu:
+    if rank == 0 and world == 1 and not args.no_cpu:
         from oracle import c_oracle as co
         cent = index.get_centroids()
         qh = Q[(last % n_batches) * B:(last % n_batches) * B + B, :d].cpu().numpy()

@@ -174,6 +174,29 @@ int32_t vers_ivf_list_lengths(vers_ivf_t* h, uint64_t* out_lengths /* [k] */);
 int32_t vers_ivf_last_scan(vers_ivf_t* h, float* out_ms, uint64_t* out_union_rows,
                            uint64_t* out_streamed_rows, uint32_t* out_items);
 
+/* ---- one process per GPU: the corpus shards BY CLUSTER ------------------------------------------
+ * Every rank holds the centroids and all list LENGTHS, but stores only the lists it owns.  A search
+ * runs the (cheap, replicated) coarse quantiser everywhere, scans the local lists, and yields a
+ * partial top-k as (key, vec_id) pairs; key = (order-preserving distance bits << 32) | sequence
+ * number of the row in the query's probe order, identical on every rank, so that ONE all-gather of
+ * [b][top_k] pairs (RCCL, done by the caller) followed by vers_topk_merge_dev reproduces the
+ * single-GPU result bit for bit.  No reference analogue (the reference is single-process). */
+/* Deterministic LPT plan (host only, no GPU): owner rank of every list from the list lengths. */
+int32_t vers_shard_plan(const uint64_t* list_lengths, uint64_t k, uint32_t world, uint8_t* out_owner);
+/* Before build/upload: this handle keeps only the lists vers_shard_plan gives to `rank`. */
+int32_t vers_ivf_set_shard(vers_ivf_t* h, uint32_t rank, uint32_t world);
+int32_t vers_ivf_owners(vers_ivf_t* h, uint8_t* out_owner /* [k] */);
+/* Local part of search_approximate: out_keys/out_ids [b*top_k], kKeyMax (all ones) padded. */
+int32_t vers_ivf_search_partial_dev(vers_ivf_t* h, const float* queries_dev, uint64_t ldq_floats, uint32_t b,
+                                    uint32_t top_k, uint32_t nprobe, uint64_t* out_keys_dev,
+                                    uint64_t* out_ids_dev, void* stream);
+/* Merge of the gathered partials into final results: rank r's keys at keys_dev + r*rank_stride
+ * ([b][top_k], rank_stride in elements), ids likewise -- so one all-gathered [world][2][b][top_k]
+ * buffer serves both with rank_stride = 2*b*top_k. */
+int32_t vers_topk_merge_dev(const uint64_t* keys_dev, const uint64_t* ids_dev, uint64_t rank_stride, uint32_t world,
+                            uint32_t b, uint32_t top_k, uint32_t nprobe, uint64_t* out_ids_dev,
+                            float* out_dist_dev, uint32_t* out_count_dev, void* stream);
+
 /* Durations (ms) of the most recent list-scan launches, oldest first (ring of 64); reset != 0
  * empties the ring.  Lets bench.py time every launch of the timed region without stalling it. */
 int32_t vers_ivf_scan_times(vers_ivf_t* h, float* out_ms, uint32_t cap, uint32_t* out_n, int32_t reset);

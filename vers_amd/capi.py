@@ -57,6 +57,11 @@ SIGNATURES = {
     "vers_ivf_list_lengths": (C.c_int32, [_vp, _vp]),
     "vers_ivf_last_scan": (C.c_int32, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64),
                                        C.POINTER(C.c_uint32)]),
+    "vers_shard_plan": (C.c_int32, [_vp, C.c_uint64, C.c_uint32, _vp]),
+    "vers_ivf_set_shard": (C.c_int32, [_vp, C.c_uint32, C.c_uint32]),
+    "vers_ivf_owners": (C.c_int32, [_vp, _vp]),
+    "vers_ivf_search_partial_dev": (C.c_int32, [_vp, _vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, _vp, _vp, _vp]),
+    "vers_topk_merge_dev": (C.c_int32, [_vp, _vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _vp, _vp, _vp, _vp]),
     "vers_ivf_scan_times": (C.c_int32, [_vp, _vp, C.c_uint32, C.POINTER(C.c_uint32), C.c_int32]),
     "vers_ivf_get_list": (C.c_int32, [_vp, C.c_uint64, _vp, C.c_uint64, _vp, C.c_uint64, C.POINTER(C.c_uint64)]),
     "vers_ivf_get_centroids": (C.c_int32, [_vp, _vp, C.c_uint64]),
@@ -208,3 +213,11 @@ def gen_rows_dev(out_ptr: int, n: int, d: int, ld: int, kind: int, seed: int, se
                  sigma: float = 0.0, start_row: int = 0, stream: int = 0):
     check(lib().vers_gen_rows_dev(_vp(out_ptr), n, d, ld, kind, seed, seed_centres, n_modes, C.c_float(float(sigma)),
                                   start_row, _vp(stream)))
+
+
+def shard_plan(list_lengths, world: int) -> np.ndarray:
+    """Owner rank of every inverted list (deterministic LPT; host only, runs without a GPU)."""
+    lens = np.ascontiguousarray(list_lengths, dtype=np.uint64)
+    owner = np.zeros(max(lens.size, 1), dtype=np.uint8)
+    check(lib().vers_shard_plan(_ptr(lens), lens.size, world, _ptr(owner)))
+    return owner[:lens.size]

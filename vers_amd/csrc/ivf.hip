@@ -14,6 +14,7 @@
 // up to 8 queries -> inverted-list scan (scan.cuh engine) -> per-query merge + id mapping.
 // Everything is planned on the device; the host never waits inside a search.
 #include <algorithm>
+#include <cstdlib>
 #include <mutex>
 #include <vector>
 
@@ -22,6 +23,23 @@
 #include "util.cuh"
 
 namespace vers {
+
+// Longest-processing-time assignment of whole inverted lists to GPUs: lists by (length desc, index asc),
+// each to the currently least loaded rank (ties -> lowest rank).  Deterministic, so every process
+// derives the same plan from the same list lengths without talking to the others.
+void shard_plan(const uint64_t* lens, uint64_t k, uint32_t world, uint8_t* owner) {
+  std::vector<uint64_t> order(k);
+  for (uint64_t i = 0; i < k; ++i) order[i] = i;
+  std::stable_sort(order.begin(), order.end(), [&](uint64_t a, uint64_t b) { return lens[a] > lens[b]; });
+  std::vector<uint64_t> load(world ? world : 1, 0);
+  for (uint64_t i : order) {
+    uint32_t best = 0;
+    for (uint32_t r = 1; r < world; ++r)
+      if (load[r] < load[best]) best = r;
+    owner[i] = (uint8_t)best;
+    load[best] += lens[i];
+  }
+}
 
 constexpr uint32_t kNoList = 0xFFFFFFFFu;
 constexpr uint32_t kStNaN = 1u, kStInsufficient = 2u, kStSpillTooDeep = 4u;
@@ -276,12 +294,17 @@ __global__ __launch_bounds__(kWave * kMergeWaves) void ivf_merge_kernel(
   const uint64_t* pq = partials + (uint64_t)q * P * S_max * k_keep;
   uint32_t written = 0;
   const uint32_t n_groups = ref_mode ? np[q] : 1;
+  if (w0 && out_keys && lane < (int)k_keep) out_keys[(uint64_t)q * k_keep + lane] = kKeyMax;  // holes = other GPUs' lists
   for (uint32_t grp = 0; grp < n_groups; ++grp) {
     uint64_t list;
     uint32_t take;
     if (ref_mode) {
       take = pj_take[(uint64_t)q * P + grp];
       if (take == 0) continue;  // uniform per block
+      if (pj_list[(uint64_t)q * P + grp] == kNoList) {  // scanned by the GPU that owns the list: keep its positions
+        written += take;
+        continue;
+      }
       list = block_merge_keys(pq + (uint64_t)grp * S_max * k_keep, S_max * k_keep, k_keep, sh);
     } else {
       take = k_keep;
@@ -304,11 +327,10 @@ __global__ __launch_bounds__(kWave * kMergeWaves) void ivf_merge_kernel(
         out_dist[o] = __uint_as_float(order_bits_to_f32_bits((uint32_t)(list >> 32)));
         if (out_keys) out_keys[o] = list;
       }
-      written += (uint32_t)__popcll(__ballot(have));
+      written += ref_mode ? take : (uint32_t)__popcll(__ballot(have));
     }
   }
   if (w0 && lane == 0) out_count[q] = written;
-  if (w0 && out_keys && lane >= (int)written && lane < (int)k_keep) out_keys[(uint64_t)q * k_keep + lane] = kKeyMax;
 }
 
 // exhaustive merge for the IVF handle (seq == vec_id already)
@@ -329,12 +351,51 @@ __global__ __launch_bounds__(kWave * kMergeWaves) void seg_merge_kernel(const ui
   if (lane == 0) out_count[q] = cnt;
 }
 
+// cross-GPU merge of per-rank partial results ([world][b][k] keys + ids, kKeyMax padded): one wave per query.
+// nprobe mode: global top-k by key.  reference mode: position p of the output belongs to exactly one rank
+// (the owner of the list that position came from), so the merge is a position-wise minimum.
+__global__ __launch_bounds__(kWave) void rank_merge_kernel(const uint64_t* keys, const uint64_t* ids, uint64_t rank_stride,
+                                                           uint32_t world, uint32_t b, uint32_t k, int ref_mode,
+                                                           uint64_t* out_ids, float* out_dist, uint32_t* out_count) {
+  const uint32_t q = blockIdx.x;
+  const int lane = threadIdx.x;
+  uint64_t key = kKeyMax, id = 0;
+  if (ref_mode) {
+    if (lane < (int)k)
+      for (uint32_t r = 0; r < world; ++r) {
+        const uint64_t kk = keys[r * rank_stride + (uint64_t)q * k + lane];
+        if (kk < key) { key = kk; id = ids[r * rank_stride + (uint64_t)q * k + lane]; }
+      }
+  } else {
+    uint64_t list = kKeyMax;
+    const uint32_t n = world * k;
+    for (uint32_t i = 0; i < n; i += kWave) {
+      uint64_t cand = kKeyMax;
+      if (i + lane < n) cand = keys[(uint64_t)((i + lane) / k) * rank_stride + (uint64_t)q * k + (i + lane) % k];
+      wave_topk_update(list, k, cand, kKeyMax);
+    }
+    key = lane < (int)k ? list : kKeyMax;
+    if (key != kKeyMax)  // keys are unique: find where this one came from to pick up its id
+      for (uint32_t i = 0; i < n; ++i) {
+        const uint64_t o = (uint64_t)(i / k) * rank_stride + (uint64_t)q * k + i % k;
+        if (keys[o] == key) { id = ids[o]; break; }
+      }
+  }
+  const bool have = key != kKeyMax;
+  if (have) {
+    out_ids[(uint64_t)q * k + lane] = id;
+    out_dist[(uint64_t)q * k + lane] = __uint_as_float(order_bits_to_f32_bits((uint32_t)(key >> 32)));
+  }
+  const uint32_t cnt = (uint32_t)__popcll(__ballot(have));
+  if (lane == 0) out_count[q] = cnt;
+}
+
 // ---- storage construction ---------------------------------------------------------------------
 // rows of X (vec_id order, row-major pitch ldx) -> cluster-major storage in lane-transposed tiles;
 // grid-stride over (sorted position, float4 column)
 __global__ void gather_rows_kernel(const float* X, uint32_t ldx, uint32_t ld, const uint32_t* sorted_ids,
-                                   const uint32_t* assign, const uint32_t* starts, const uint32_t* list_off, uint64_t n,
-                                   float* rows, uint32_t* row_ids) {
+                                   const uint32_t* assign, const uint32_t* starts, const uint32_t* list_off,
+                                   const uint8_t* owner, uint32_t rank, uint64_t n, float* rows, uint32_t* row_ids) {
   const uint32_t ld4 = ld / 4, ldx4 = ldx / 4;
   const uint64_t total = n * ld4;
   for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
@@ -342,6 +403,7 @@ __global__ void gather_rows_kernel(const float* X, uint32_t ldx, uint32_t ld, co
     const uint32_t c4 = (uint32_t)(i % ld4);
     const uint32_t id = sorted_ids[p];
     const uint32_t c = assign[id];
+    if (owner != nullptr && owner[c] != rank) continue;  // another GPU's list
     const uint64_t dst = (uint64_t)list_off[c] + (p - starts[c]);
     f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
     if (c4 < ldx4) v = reinterpret_cast<const f32x4*>(X + (uint64_t)id * ldx)[c4];
@@ -386,7 +448,11 @@ struct vers_ivf {
   DevBuf centroids;    // [k][ldx] row-major (k-means, read-back)
   DevBuf centroids_b;  // the same in lane-transposed tiles (coarse quantiser)
   DevBuf rows, row_ids, list_off, list_len;
-  std::vector<uint32_t> h_off, h_len, h_cap;
+  std::vector<uint32_t> h_off, h_len, h_cap;  // h_len = GLOBAL list lengths; h_off/h_cap only meaningful for owned lists
+  // sharding by cluster across GPUs (one process per GPU): this handle stores only lists with owner == rank
+  uint32_t rank = 0, world = 1;
+  std::vector<uint8_t> h_owner;
+  DevBuf owner;
   uint64_t cap_rows = 0;
   uint32_t max_len = 0;
   // scratch
@@ -430,15 +496,23 @@ int32_t build_storage(vers_ivf* h, const float* X, uint32_t ldx, uint64_t n, con
   VERS_HIP_TRY(hipStreamSynchronize(st));
   uint64_t off = 0;
   h->max_len = 0;
+  h->h_owner.assign(k, 0);
+  if (h->world > 1) {
+    std::vector<uint64_t> l64(h->h_len.begin(), h->h_len.end());
+    shard_plan(l64.data(), k, h->world, h->h_owner.data());
+  }
   for (uint32_t c = 0; c < k; ++c) {
     const uint32_t len = h->h_len[c];
-    const uint32_t cap = round_up(len + std::max<uint32_t>(64u, len / 16u), 64u);
+    const bool mine = h->h_owner[c] == h->rank;
+    const uint32_t cap = mine ? round_up(len + std::max<uint32_t>(64u, len / 16u), 64u) : 0u;
     h->h_off[c] = (uint32_t)off;
     h->h_cap[c] = cap;
     off += cap;
     h->max_len = std::max(h->max_len, len);
     if (off > 0xFFFFFFFFull) return fail(VERS_ERR_INVALID, "more than 2^32-1 storage rows on one GPU");
   }
+  if (int32_t rc = h->owner.reserve(k ? k : 1)) return rc;
+  if (k) VERS_HIP_TRY(hipMemcpyAsync(h->owner.p, h->h_owner.data(), k, hipMemcpyHostToDevice, st));
   h->cap_rows = off;
   if (int32_t rc = h->rows.reserve((off ? off : 1) * (size_t)h->ld * sizeof(float))) return rc;
   if (int32_t rc = h->row_ids.reserve((off ? off : 1) * sizeof(uint32_t))) return rc;
@@ -451,7 +525,8 @@ int32_t build_storage(vers_ivf* h, const float* X, uint32_t ldx, uint64_t n, con
   }
   if (n) {
     hipLaunchKernelGGL(gather_rows_kernel, dim3(h->n_cu * 8), dim3(256), 0, st, X, ldx, h->ld, d_sorted, d_assign, d_starts,
-                       h->list_off.as<uint32_t>(), n, h->rows.as<float>(), h->row_ids.as<uint32_t>());
+                       h->list_off.as<uint32_t>(), h->world > 1 ? h->owner.as<uint8_t>() : (const uint8_t*)nullptr, h->rank, n,
+                       h->rows.as<float>(), h->row_ids.as<uint32_t>());
     VERS_HIP_TRY(hipGetLastError());
   }
   // centroids in the scan layout for the coarse quantiser
@@ -751,8 +826,8 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
   VERS_HIP_TRY(hipMemsetAsync(cnt, 0, 2 * (size_t)k_l * sizeof(uint32_t), st));
   VERS_HIP_TRY(hipMemsetAsync(h->partials.p, 0xFF, part_bytes, st));
   hipLaunchKernelGGL(plan_kernel, dim3((b + 127) / 128), dim3(128), 0, st, h->probe.as<uint64_t>(), b, P, k_l, top_k, ref_mode,
-                     h->list_len.as<uint32_t>(), (const uint8_t*)nullptr, 0u, pj_list, pj_pref, pj_take, np, cnt,
-                     h->status.as<uint32_t>());
+                     h->list_len.as<uint32_t>(), h->world > 1 ? h->owner.as<uint8_t>() : (const uint8_t*)nullptr, h->rank, pj_list,
+                     pj_pref, pj_take, np, cnt, h->status.as<uint32_t>());
   VERS_HIP_TRY(hipGetLastError());
   hipLaunchKernelGGL(group_kernel, dim3(1), dim3(1024), 0, st, cnt, h->list_len.as<uint32_t>(), k_l, (uint32_t)QG, seg_rows,
                      pair_off, group_off, item_off, tot);
@@ -840,7 +915,7 @@ int32_t relayout(vers_ivf* h) {
   uint64_t off = 0;
   for (uint32_t c = 0; c < k; ++c) {
     const uint32_t len = h->h_len[c];
-    ncap[c] = round_up(len + std::max<uint32_t>(64u, len / 8u), 64u);
+    ncap[c] = h->h_owner[c] == h->rank ? round_up(len + std::max<uint32_t>(64u, len / 8u), 64u) : 0u;
     noff[c] = (uint32_t)off;
     off += ncap[c];
     if (off > 0xFFFFFFFFull) return fail(VERS_ERR_INVALID, "more than 2^32-1 storage rows on one GPU");
@@ -850,7 +925,7 @@ int32_t relayout(vers_ivf* h) {
   if (int32_t rc = nids.reserve((off ? off : 1) * sizeof(uint32_t))) return rc;
   VERS_HIP_TRY(hipMemset(nids.p, 0xFF, (off ? off : 1) * sizeof(uint32_t)));
   for (uint32_t c = 0; c < k; ++c) {
-    if (!h->h_len[c]) continue;
+    if (!h->h_len[c] || h->h_owner[c] != h->rank) continue;
     // lists start on tile boundaries, so whole 64-row tiles move as they are
     VERS_HIP_TRY(hipMemcpyAsync(nrows.as<float>() + (size_t)noff[c] * h->ld, h->rows.as<float>() + (size_t)h->h_off[c] * h->ld,
                                 (size_t)round_up(h->h_len[c], 64) * h->ld * sizeof(float), hipMemcpyDeviceToDevice, nullptr));
@@ -1006,14 +1081,16 @@ int32_t vers_ivf_add(vers_ivf_t* h, const float* row, uint64_t* out_cluster, uin
   if (stw) VERS_HIP_TRY(hipMemset(h->status.p, 0, 4));
   if ((stw & kStNaN) && h->k >= 2) return fail(VERS_ERR_NAN, "NaN distance in add (reference panics)");
   const uint32_t c = (uint32_t)key;
-  if (h->h_len[c] == h->h_cap[c])
-    if (int32_t rc = relayout(h)) return rc;
-  const uint32_t pos = h->h_off[c] + h->h_len[c];
   const uint32_t vid = (uint32_t)h->n_total;  // the caller's vec_id is ignored, as in the reference (ivfflat.rs:209)
-  hipLaunchKernelGGL(scatter_row_kernel, dim3((h->ld / 4 + 63) / 64), dim3(64), 0, nullptr, qp, h->ld, (uint64_t)pos,
-                     h->rows.as<float>());
-  VERS_HIP_TRY(hipGetLastError());
-  VERS_HIP_TRY(hipMemcpy(h->row_ids.as<uint32_t>() + pos, &vid, 4, hipMemcpyHostToDevice));
+  if (h->h_owner[c] == h->rank) {  // sharded: every rank picks the same list, only its owner stores the row
+    if (h->h_len[c] == h->h_cap[c])
+      if (int32_t rc = relayout(h)) return rc;
+    const uint32_t pos = h->h_off[c] + h->h_len[c];
+    hipLaunchKernelGGL(scatter_row_kernel, dim3((h->ld / 4 + 63) / 64), dim3(64), 0, nullptr, qp, h->ld, (uint64_t)pos,
+                       h->rows.as<float>());
+    VERS_HIP_TRY(hipGetLastError());
+    VERS_HIP_TRY(hipMemcpy(h->row_ids.as<uint32_t>() + pos, &vid, 4, hipMemcpyHostToDevice));
+  }
   h->h_len[c] += 1;
   VERS_HIP_TRY(hipMemcpy(h->list_len.as<uint32_t>() + c, &h->h_len[c], 4, hipMemcpyHostToDevice));
   h->max_len = std::max(h->max_len, h->h_len[c]);
@@ -1033,6 +1110,54 @@ int32_t vers_ivf_search_dev(vers_ivf_t* h, const float* queries_dev, uint64_t ld
   DeviceGuard g(h->device);
   return search_dev_locked(h, queries_dev, ldq_floats, b, top_k, nprobe, out_ids_dev, out_dist_dev, out_count_dev, nullptr,
                            (hipStream_t)stream);
+}
+
+int32_t vers_shard_plan(const uint64_t* list_lengths, uint64_t k, uint32_t world, uint8_t* out_owner) {
+  if ((k && (!list_lengths || !out_owner)) || world == 0 || world > 255) return fail(VERS_ERR_INVALID, "vers_shard_plan: bad arguments");
+  shard_plan(list_lengths, k, world, out_owner);
+  return VERS_OK;
+}
+
+int32_t vers_ivf_set_shard(vers_ivf_t* h, uint32_t rank, uint32_t world) {
+  if (!h || world == 0 || world > 255 || rank >= world) return fail(VERS_ERR_INVALID, "vers_ivf_set_shard: bad arguments");
+  std::lock_guard<std::mutex> lk(h->mu);
+  if (h->k != 0) return fail(VERS_ERR_INVALID, "vers_ivf_set_shard: call before build / upload");
+  h->rank = rank;
+  h->world = world;
+  return VERS_OK;
+}
+
+int32_t vers_ivf_owners(vers_ivf_t* h, uint8_t* out_owner) {
+  if (!h || (h->k && !out_owner)) return fail(VERS_ERR_INVALID, "bad arguments");
+  for (uint32_t c = 0; c < h->k; ++c) out_owner[c] = h->h_owner[c];
+  return VERS_OK;
+}
+
+int32_t vers_ivf_search_partial_dev(vers_ivf_t* h, const float* queries_dev, uint64_t ldq_floats, uint32_t b, uint32_t top_k,
+                                    uint32_t nprobe, uint64_t* out_keys_dev, uint64_t* out_ids_dev, void* stream) {
+  if (!h) return fail(VERS_ERR_INVALID, "null handle");
+  if (top_k == 0 || top_k > VERS_MAX_TOPK) return fail(VERS_ERR_INVALID, "top_k must be in 1..VERS_MAX_TOPK");
+  if (b && (!queries_dev || ldq_floats < h->d || !out_keys_dev || !out_ids_dev))
+    return fail(VERS_ERR_INVALID, "vers_ivf_search_partial_dev: bad arguments");
+  std::lock_guard<std::mutex> lk(h->mu);
+  DeviceGuard g(h->device);
+  // distances and counts of the local part are scratch here: the cross-GPU merge recomputes them
+  if (int32_t rc = ensure_out(h, (size_t)b * top_k, b)) return rc;
+  return search_dev_locked(h, queries_dev, ldq_floats, b, top_k, nprobe, out_ids_dev, h->o_dist.as<float>(), h->o_cnt.as<uint32_t>(),
+                           out_keys_dev, (hipStream_t)stream);
+}
+
+int32_t vers_topk_merge_dev(const uint64_t* keys_dev, const uint64_t* ids_dev, uint64_t rank_stride, uint32_t world, uint32_t b,
+                            uint32_t top_k, uint32_t nprobe, uint64_t* out_ids_dev, float* out_dist_dev, uint32_t* out_count_dev,
+                            void* stream) {
+  if (rank_stride < (uint64_t)b * top_k) return fail(VERS_ERR_INVALID, "vers_topk_merge_dev: rank_stride < b * top_k");
+  if (world == 0 || top_k == 0 || top_k > VERS_MAX_TOPK || (b && (!keys_dev || !ids_dev || !out_ids_dev || !out_dist_dev || !out_count_dev)))
+    return fail(VERS_ERR_INVALID, "vers_topk_merge_dev: bad arguments");
+  if (b == 0) return VERS_OK;
+  hipLaunchKernelGGL(rank_merge_kernel, dim3(b), dim3(kWave), 0, (hipStream_t)stream, keys_dev, ids_dev, rank_stride, world, b, top_k,
+                     nprobe == 0 ? 1 : 0, out_ids_dev, out_dist_dev, out_count_dev);
+  VERS_HIP_TRY(hipGetLastError());
+  return VERS_OK;
 }
 
 int32_t vers_ivf_poll(vers_ivf_t* h, void* stream) {
@@ -1147,6 +1272,7 @@ int32_t vers_ivf_get_list(vers_ivf_t* h, uint64_t cluster, float* out_rows, uint
   const uint32_t len = h->h_len[cluster];
   *out_len = len;
   if (!out_rows && !out_ids) return VERS_OK;
+  if (h->h_owner[cluster] != h->rank) return fail(VERS_ERR_INVALID, "vers_ivf_get_list: list is stored on another GPU (see vers_ivf_owners)");
   if (cap_rows < len || (out_rows && row_stride_bytes < (uint64_t)h->d * 4)) return fail(VERS_ERR_INVALID, "vers_ivf_get_list: buffer too small");
   if (len == 0) return VERS_OK;
   if (out_rows) {

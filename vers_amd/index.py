@@ -173,6 +173,27 @@ class IVFFlatIndex:
         check(lib().vers_ivf_search_exhaustive_dev(self._h, _vp(q_ptr), ldq, b, top_k, metric, _vp(ids_ptr), _vp(dist_ptr),
                                                    _vp(cnt_ptr), _vp(stream)))
 
+    # -- sharding by cluster, one process per GPU -----------------------------------------------------------
+    def set_shard(self, rank: int, world: int):
+        check(lib().vers_ivf_set_shard(self._h, rank, world))
+
+    def owners(self):
+        _, k, _ = self.info()
+        o = np.zeros(max(k, 1), dtype=np.uint8)
+        check(lib().vers_ivf_owners(self._h, _ptr(o)))
+        return o[:k]
+
+    def search_partial_dev(self, q_ptr: int, ldq: int, b: int, top_k: int, nprobe: int, keys_ptr: int, ids_ptr: int,
+                           stream: int = 0):
+        check(lib().vers_ivf_search_partial_dev(self._h, _vp(q_ptr), ldq, b, top_k, nprobe, _vp(keys_ptr), _vp(ids_ptr),
+                                                _vp(stream)))
+
+    @staticmethod
+    def merge_partials_dev(keys_ptr: int, ids_ptr: int, rank_stride: int, world: int, b: int, top_k: int, nprobe: int,
+                           out_ids_ptr: int, out_dist_ptr: int, out_cnt_ptr: int, stream: int = 0):
+        check(lib().vers_topk_merge_dev(_vp(keys_ptr), _vp(ids_ptr), rank_stride, world, b, top_k, nprobe, _vp(out_ids_ptr),
+                                        _vp(out_dist_ptr), _vp(out_cnt_ptr), _vp(stream)))
+
     def poll(self, stream: int = 0):
         check(lib().vers_ivf_poll(self._h, _vp(stream)))
 
