@@ -10,37 +10,39 @@
 
 namespace vers {
 
-// item = (row segment, query group).  slot(q, seg) = q * n_segs + seg.
+// item = (row segment, query group).  slot(q, seg) = q * n_segs + seg.  For QG > 1 the segments of a query
+// group are padded to a multiple of 4 (empty items) so that every quad of items shares one query block.
 template <int QG, bool SEQ_IDS>
 struct FlatSrc {
   static constexpr bool kSeqIds = SEQ_IDS;
   const float* rows;  // blocked tiles
   uint64_t n;
   uint32_t ld;
-  uint32_t seg_rows, n_segs;  // seg_rows is a multiple of 64
+  uint32_t seg_rows, n_segs, n_segs_pad;  // seg_rows is a multiple of 64
   const float* queries;  // QG == 1: [b][ldq]; else interleaved blocks [ceil(b/QG)][ldq][QG]; zero padded
   uint32_t ldq, b;
   uint64_t* partials;
   uint32_t k;
   const uint32_t* ids;  // SEQ_IDS: row -> seq (vec ids of a permuted corpus)
 
-  __device__ __forceinline__ uint32_t n_items() const { return n_segs * ((b + QG - 1) / QG); }
+  __device__ __forceinline__ uint32_t n_items() const { return n_segs_pad * ((b + QG - 1) / QG); }
   __device__ __forceinline__ void get(uint32_t it, ItemView<QG>& v) const {
-    const uint32_t seg = it % n_segs, qg = it / n_segs;
-    const uint64_t row0 = (uint64_t)seg * seg_rows;
+    const uint32_t seg = it % n_segs_pad, qg = it / n_segs_pad;
+    const bool real = seg < n_segs;
+    const uint64_t row0 = real ? (uint64_t)seg * seg_rows : 0;
     v.rows = rows + row0 * ld;
-    v.nrows = (uint32_t)((n - row0 < seg_rows) ? (n - row0) : seg_rows);
+    v.nrows = real ? (uint32_t)((n - row0 < seg_rows) ? (n - row0) : seg_rows) : 0u;
     const uint32_t q0 = qg * QG;
     v.nq = (b - q0 < (uint32_t)QG) ? (b - q0) : QG;
     v.qb = queries + (uint64_t)qg * ldq * QG;
   }
-  __device__ __forceinline__ uint32_t seq_base(uint32_t it, int) const { return (it % n_segs) * seg_rows; }
-  __device__ __forceinline__ const uint32_t* seq_ids(uint32_t it) const { return ids + (uint64_t)(it % n_segs) * seg_rows; }
+  __device__ __forceinline__ uint32_t seq_base(uint32_t it, int) const { return (it % n_segs_pad) * seg_rows; }
+  __device__ __forceinline__ const uint32_t* seq_ids(uint32_t it) const { return ids + (uint64_t)(it % n_segs_pad) * seg_rows; }
   __device__ __forceinline__ uint64_t* out(uint32_t it, int qi) const {
-    const uint32_t seg = it % n_segs, qg = it / n_segs;
+    const uint32_t seg = it % n_segs_pad, qg = it / n_segs_pad;
     return partials + ((uint64_t)(qg * QG + qi) * n_segs + seg) * k;
   }
-  __device__ __forceinline__ uint32_t bound_slot(uint32_t it, int qi) const { return (it / n_segs) * QG + qi; }
+  __device__ __forceinline__ uint32_t bound_slot(uint32_t it, int qi) const { return (it / n_segs_pad) * QG + qi; }
 };
 
 // one block per query: top-k of its n_segs partial slots -> (id, dist)
@@ -100,12 +102,14 @@ int32_t launch_flat_scan(vers_flat* h, const FlatSrc<QG, false>& src, uint32_t n
   p.status = h->status_dev;
   p.debug = scan_debug_flags();
   p.bounds = nullptr;  // every item of a query runs concurrently here: a shared bound prunes nothing and its atomics contend
-  const uint32_t max_blocks = (uint32_t)h->n_cu * (QG == 1 ? 5u : 3u);  // resident waves: 20 / 12 per CU
+  const size_t lds = scan_lds_bytes(QG, h->ld);
+  if (int32_t rc = scan_prepare_launch(scan_kernel<QG, METRIC, FlatSrc<QG, false>>, lds)) return rc;
+  const uint32_t max_blocks = (uint32_t)h->n_cu * scan_blocks_per_cu(QG, h->ld);
   uint32_t blocks = (n_items + kWavesPerBlock - 1) / kWavesPerBlock;
   if (blocks > max_blocks) blocks = max_blocks;
   if (blocks == 0) blocks = 1;
   VERS_HIP_TRY(hipEventRecord(h->ev0, st));
-  hipLaunchKernelGGL((scan_kernel<QG, METRIC, FlatSrc<QG, false>>), dim3(blocks), dim3(kWave * kWavesPerBlock), 0, st, src, p);
+  hipLaunchKernelGGL((scan_kernel<QG, METRIC, FlatSrc<QG, false>>), dim3(blocks), dim3(kWave * kWavesPerBlock), lds, st, src, p);
   VERS_HIP_TRY(hipGetLastError());
   VERS_HIP_TRY(hipEventRecord(h->ev1, st));
   h->ev_valid = true;
@@ -135,7 +139,7 @@ int32_t flat_search_dev_locked(vers_flat* h, const float* q_dev, uint64_t ldq, u
     ldq_use = ldq_pad;
   }
   // one item per resident wave when possible (static balance), at least one 64-row tile each
-  const uint32_t target_items = (uint32_t)h->n_cu * (QG == 1 ? 20u : 12u);
+  const uint32_t target_items = (uint32_t)h->n_cu * scan_blocks_per_cu(QG, h->ld) * kWavesPerBlock;
   uint64_t per = (h->n * n_qg + target_items - 1) / target_items;
   uint32_t seg_rows = (uint32_t)std::min<uint64_t>(round_up64(per ? per : 1, kWave), max_seg_rows(h->ld));
   uint32_t n_segs = (uint32_t)((h->n + seg_rows - 1) / seg_rows);
@@ -143,10 +147,11 @@ int32_t flat_search_dev_locked(vers_flat* h, const float* q_dev, uint64_t ldq, u
   h->bounds_off = (size_t)b * n_segs * top_k;
   if (int32_t rc = grow(h->partials, h->partials_cap, h->bounds_off + (size_t)n_qg * QG)) return rc;
   VERS_HIP_TRY(hipMemsetAsync(h->partials + h->bounds_off, 0xFF, (size_t)n_qg * QG * sizeof(uint64_t), st));
-  const uint32_t n_items = n_segs * n_qg;
+  const uint32_t n_segs_pad = QG == 1 ? n_segs : round_up(n_segs, 4);
+  const uint32_t n_items = n_segs_pad * n_qg;
 
   auto fill = [&](auto& src) {
-    src.rows = h->rows; src.n = h->n; src.ld = h->ld; src.seg_rows = seg_rows; src.n_segs = n_segs;
+    src.rows = h->rows; src.n = h->n; src.ld = h->ld; src.seg_rows = seg_rows; src.n_segs = n_segs; src.n_segs_pad = n_segs_pad;
     src.queries = q; src.ldq = ldq_use; src.b = b; src.partials = h->partials;
     src.k = top_k; src.ids = nullptr;
   };

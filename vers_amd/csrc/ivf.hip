@@ -45,38 +45,41 @@ constexpr uint32_t kNoList = 0xFFFFFFFFu;
 constexpr uint32_t kStNaN = 1u, kStInsufficient = 2u, kStSpillTooDeep = 4u;
 
 // ---- sources for the scan engine -----------------------------------------------------------
-// coarse quantiser / exhaustive scan: item = (row segment, query group), slot(q, seg) = q*n_segs + seg
+// coarse quantiser / exhaustive scan: item = (row segment, query group), slot(q, seg) = q*n_segs + seg;
+// QG > 1: segments padded to a multiple of 4 with empty items (quads share a query block, scan.cuh)
 template <int QG, bool SEQ_IDS>
 struct SegSrc {
   static constexpr bool kSeqIds = SEQ_IDS;
   const float* rows;
   uint64_t n;
   uint32_t ld;
-  uint32_t seg_rows, n_segs;
+  uint32_t seg_rows, n_segs, n_segs_pad;
   const float* queries;  // QG == 1: [b][ldq]; else interleaved blocks
   uint32_t ldq, b;
   uint64_t* partials;
   uint32_t k;
   const uint32_t* ids;
-  __device__ __forceinline__ uint32_t n_items() const { return n_segs * ((b + QG - 1) / QG); }
+  __device__ __forceinline__ uint32_t n_items() const { return n_segs_pad * ((b + QG - 1) / QG); }
   __device__ __forceinline__ void get(uint32_t it, ItemView<QG>& v) const {
-    const uint32_t seg = it % n_segs, qg = it / n_segs;
-    const uint64_t row0 = (uint64_t)seg * seg_rows;
+    const uint32_t seg = it % n_segs_pad, qg = it / n_segs_pad;
+    const bool real = seg < n_segs;
+    const uint64_t row0 = real ? (uint64_t)seg * seg_rows : 0;
     v.rows = rows + row0 * ld;
-    v.nrows = (uint32_t)((n - row0 < seg_rows) ? (n - row0) : seg_rows);
+    v.nrows = real ? (uint32_t)((n - row0 < seg_rows) ? (n - row0) : seg_rows) : 0u;
     const uint32_t q0 = qg * QG;
     v.nq = (b - q0 < (uint32_t)QG) ? (b - q0) : QG;
     v.qb = queries + (uint64_t)qg * ldq * QG;
   }
-  __device__ __forceinline__ uint32_t seq_base(uint32_t it, int) const { return (it % n_segs) * seg_rows; }
-  __device__ __forceinline__ const uint32_t* seq_ids(uint32_t it) const { return ids + (uint64_t)(it % n_segs) * seg_rows; }
+  __device__ __forceinline__ uint32_t seq_base(uint32_t it, int) const { return (it % n_segs_pad) * seg_rows; }
+  __device__ __forceinline__ const uint32_t* seq_ids(uint32_t it) const { return ids + (uint64_t)(it % n_segs_pad) * seg_rows; }
   __device__ __forceinline__ uint64_t* out(uint32_t it, int qi) const {
-    const uint32_t seg = it % n_segs, qg = it / n_segs;
+    const uint32_t seg = it % n_segs_pad, qg = it / n_segs_pad;
     return partials + ((uint64_t)(qg * QG + qi) * n_segs + seg) * k;
   }
-  __device__ __forceinline__ uint32_t bound_slot(uint32_t it, int qi) const { return (it / n_segs) * QG + qi; }
+  __device__ __forceinline__ uint32_t bound_slot(uint32_t it, int qi) const { return (it / n_segs_pad) * QG + qi; }
 };
 
+constexpr uint32_t kNoSeg = 0xFFFFFFFFu;  // padding item of a quad
 struct ItemDesc {
   uint32_t list, group, seg;
 };
@@ -105,10 +108,11 @@ struct IvfSrc {
   __device__ __forceinline__ uint32_t n_items() const { return *n_items_dev; }
   __device__ __forceinline__ void get(uint32_t it, ItemView<QG>& v) const {
     const ItemDesc d = items[it];
-    const uint32_t r0 = d.seg * seg_rows;
+    const bool real = d.seg != kNoSeg;
+    const uint32_t r0 = real ? d.seg * seg_rows : 0;
     v.rows = rows + ((uint64_t)list_off[d.list] + r0) * ld;
     const uint32_t len = list_len[d.list];
-    v.nrows = len - r0 < seg_rows ? len - r0 : seg_rows;
+    v.nrows = real ? (len - r0 < seg_rows ? len - r0 : seg_rows) : 0u;
     const uint32_t c = cnt[d.list] - d.group * QG;
     v.nq = c < (uint32_t)QG ? c : QG;
     if (QG == 1) v.qb = qp + (uint64_t)(pairs[pair_off[d.list] + d.group] / P) * ldq;
@@ -206,7 +210,8 @@ __global__ __launch_bounds__(1024) void group_kernel(const uint32_t* cnt, const 
       if (c) {
         const uint32_t len = list_len[L];
         g = (c + QG - 1) / QG;
-        it = g * ((len + seg_rows - 1) / seg_rows);
+        const uint32_t n_s = (len + seg_rows - 1) / seg_rows;
+        it = g * (QG == 1 ? n_s : (n_s + 3) / 4 * 4);  // QG > 1: quads of items share a query block
         my_ur += len;
         my_sr += (unsigned long long)len * g;
       }
@@ -261,10 +266,19 @@ __global__ void items_kernel(const uint32_t* cnt, const uint32_t* list_len, uint
   const uint32_t c = cnt[L];
   if (!c) return;
   const uint32_t n_g = (c + QG - 1) / QG, n_s = (list_len[L] + seg_rows - 1) / seg_rows;
+  const uint32_t n_s_pad = QG == 1 ? n_s : (n_s + 3) / 4 * 4;
   uint32_t o = item_off[L];
-  for (uint32_t g = 0; g < n_g; ++g) {
+  for (uint32_t g = 0; g < n_g; ++g)
     groups[group_off[L] + g] = GroupDesc{pair_off[L] + g * QG, (c - g * QG < QG) ? c - g * QG : QG};
-    for (uint32_t s = 0; s < n_s; ++s) items[o++] = ItemDesc{L, g, s};
+  if (QG == 1) {
+    for (uint32_t g = 0; g < n_g; ++g)
+      for (uint32_t s = 0; s < n_s; ++s) items[o++] = ItemDesc{L, g, s};
+  } else {
+    // quads of segments outermost, query groups inside: the groups that re-read the same rows are
+    // neighbours in the item order, and scan_kernel's XCD remap runs neighbours on one XCD's L2
+    for (uint32_t s0 = 0; s0 < n_s_pad; s0 += 4)
+      for (uint32_t g = 0; g < n_g; ++g)
+        for (uint32_t s = s0; s < s0 + 4; ++s) items[o++] = ItemDesc{L, g, s < n_s ? s : kNoSeg};
   }
 }
 
@@ -677,18 +691,20 @@ int32_t launch_seg_scan(vers_ivf* h, const SegSrc<QG, SEQ_IDS>& src, uint32_t n_
   p.n_chunks = h->ld / kChunk;
   p.k = src.k;
   p.status = h->status.as<uint32_t>();
-  const size_t nb = (size_t)((src.b + QG - 1) / QG) * QG;  // one pruning bound per query
-  if (int32_t rc = h->seg_bounds.reserve(nb * sizeof(uint64_t))) return rc;
-  VERS_HIP_TRY(hipMemsetAsync(h->seg_bounds.p, 0xFF, nb * sizeof(uint64_t), st));
   p.debug = 0;
   p.bounds = nullptr;  // items of a query are concurrent: nothing to prune, and the atomics would contend
+  const size_t lds = scan_lds_bytes(QG, h->ld);
   uint32_t blocks = (n_items + kWavesPerBlock - 1) / kWavesPerBlock;
-  if (blocks > (uint32_t)h->n_cu * (QG == 1 ? 5u : 3u)) blocks = (uint32_t)h->n_cu * (QG == 1 ? 5u : 3u);
+  const uint32_t max_blocks = (uint32_t)h->n_cu * scan_blocks_per_cu(QG, h->ld);
+  if (blocks > max_blocks) blocks = max_blocks;
   if (blocks == 0) blocks = 1;
-  if (metric == 0)
-    hipLaunchKernelGGL((scan_kernel<QG, 0, SegSrc<QG, SEQ_IDS>>), dim3(blocks), dim3(kWave * kWavesPerBlock), 0, st, src, p);
-  else
-    hipLaunchKernelGGL((scan_kernel<QG, 1, SegSrc<QG, SEQ_IDS>>), dim3(blocks), dim3(kWave * kWavesPerBlock), 0, st, src, p);
+  if (metric == 0) {
+    if (int32_t rc = scan_prepare_launch(scan_kernel<QG, 0, SegSrc<QG, SEQ_IDS>>, lds)) return rc;
+    hipLaunchKernelGGL((scan_kernel<QG, 0, SegSrc<QG, SEQ_IDS>>), dim3(blocks), dim3(kWave * kWavesPerBlock), lds, st, src, p);
+  } else {
+    if (int32_t rc = scan_prepare_launch(scan_kernel<QG, 1, SegSrc<QG, SEQ_IDS>>, lds)) return rc;
+    hipLaunchKernelGGL((scan_kernel<QG, 1, SegSrc<QG, SEQ_IDS>>), dim3(blocks), dim3(kWave * kWavesPerBlock), lds, st, src, p);
+  }
   VERS_HIP_TRY(hipGetLastError());
   return VERS_OK;
 }
@@ -712,23 +728,25 @@ int32_t coarse(vers_ivf* h, const float* qp, uint32_t b, uint32_t P, hipStream_t
     if (int32_t rc = launch_stage_queries(qp, h->ldq, h->ldq, h->qil.as<float>(), h->ldq, b, QG, st)) return rc;
     q = h->qil.as<float>();
   }
-  const uint32_t target_items = (uint32_t)h->n_cu * (QG == 1 ? 20u : 12u);
+  const uint32_t target_items = (uint32_t)h->n_cu * scan_blocks_per_cu(QG, h->ld) * kWavesPerBlock;
   uint64_t per = ((uint64_t)h->k * n_qg + target_items - 1) / target_items;
   const uint32_t seg_rows = (uint32_t)std::min<uint64_t>(round_up64(per ? per : 1, kWave), max_seg_rows(h->ld));
   const uint32_t n_segs = (h->k + seg_rows - 1) / seg_rows;
   if (int32_t rc = h->cpart.reserve((size_t)b * n_segs * P * sizeof(uint64_t))) return rc;
   if (int32_t rc = h->probe.reserve((size_t)b * P * sizeof(uint64_t))) return rc;
+  const uint32_t n_segs_pad = QG == 1 ? n_segs : round_up(n_segs, 4);
   auto fill = [&](auto& src) {
     src.rows = h->centroids_b.as<float>(); src.n = h->k; src.ld = h->ld; src.seg_rows = seg_rows; src.n_segs = n_segs;
+    src.n_segs_pad = n_segs_pad;
     src.queries = q; src.ldq = h->ldq; src.b = b; src.partials = h->cpart.as<uint64_t>(); src.k = P; src.ids = nullptr;
   };
   int32_t rc;
   if (QG == 1) {
     SegSrc<1, false> src; fill(src);
-    rc = launch_seg_scan(h, src, n_segs * n_qg, 0, st);
+    rc = launch_seg_scan(h, src, n_segs_pad * n_qg, 0, st);
   } else {
     SegSrc<8, false> src; fill(src);
-    rc = launch_seg_scan(h, src, n_segs * n_qg, 0, st);
+    rc = launch_seg_scan(h, src, n_segs_pad * n_qg, 0, st);
   }
   if (rc) return rc;
   hipLaunchKernelGGL(coarse_merge_kernel, dim3(b), dim3(kWave * kMergeWaves), 0, st, h->cpart.as<uint64_t>(), n_segs, P,
@@ -746,12 +764,15 @@ int32_t launch_ivf_scan(vers_ivf* h, const IvfSrc<QG>& src, uint32_t items_bound
   p.status = h->status.as<uint32_t>();
   p.debug = scan_debug_flags();
   p.bounds = scan_debug_flags() & 8u ? h->partials.as<uint64_t>() + h->ivf_bounds_off : nullptr;
+  const size_t lds = scan_lds_bytes(QG, h->ld);
+  if (int32_t rc = scan_prepare_launch(scan_kernel<QG, 0, IvfSrc<QG>>, lds)) return rc;
   uint32_t blocks = (items_bound + kWavesPerBlock - 1) / kWavesPerBlock;
-  if (blocks > (uint32_t)h->n_cu * (QG == 1 ? 5u : 3u)) blocks = (uint32_t)h->n_cu * (QG == 1 ? 5u : 3u);
+  const uint32_t max_blocks = (uint32_t)h->n_cu * scan_blocks_per_cu(QG, h->ld);
+  if (blocks > max_blocks) blocks = max_blocks;
   if (blocks == 0) blocks = 1;
   const uint32_t slot = (uint32_t)(h->ev_count % vers_ivf::kEvRing);
   VERS_HIP_TRY(hipEventRecord(h->ev0[slot], st));
-  hipLaunchKernelGGL((scan_kernel<QG, 0, IvfSrc<QG>>), dim3(blocks), dim3(kWave * kWavesPerBlock), 0, st, src, p);
+  hipLaunchKernelGGL((scan_kernel<QG, 0, IvfSrc<QG>>), dim3(blocks), dim3(kWave * kWavesPerBlock), lds, st, src, p);
   VERS_HIP_TRY(hipGetLastError());
   VERS_HIP_TRY(hipEventRecord(h->ev1[slot], st));
   h->ev_count += 1;
@@ -782,7 +803,8 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
   const uint64_t lists_est = std::min<uint64_t>(h->k, pairs_est);
   // query-group width of the list scan: a list shared by more queries than one group holds is streamed
   // once per group, so pick the width from the expected queries per list
-  const int QG = (b == 1 || pairs_est < 2 * lists_est) ? 1 : (pairs_est >= 6 * lists_est ? 16 : 8);
+  int QG = (b == 1 || pairs_est < 2 * lists_est) ? 1 : (pairs_est >= 6 * lists_est ? 16 : 8);
+  if (const char* e = getenv("VERS_QG")) { const int q = atoi(e); if (QG != 1 && (q == 8 || q == 16)) QG = q; }  // tuning knob
   const uint64_t groups_bound = QG == 1 ? n_pj : (n_pj / QG + std::min<uint64_t>(h->k, n_pj));
   uint32_t seg_rows;
   if (b == 1) seg_rows = kWave;
@@ -797,7 +819,7 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
   }
   if (const char* e = getenv("VERS_SEG_ROWS")) seg_rows = (uint32_t)round_up64(std::max(64l, atol(e)), kWave);  // tuning knob
   const uint32_t S_max = std::max<uint32_t>(1, (h->max_len + seg_rows - 1) / seg_rows);
-  const uint64_t items_bound = groups_bound * S_max;
+  const uint64_t items_bound = groups_bound * (QG == 1 ? S_max : round_up(S_max, 4));
   if (items_bound > 0x7FFFFFFFull) return fail(VERS_ERR_INVALID, "search batch too large");
 
   const uint32_t k_l = h->k;
@@ -882,24 +904,26 @@ int32_t exhaustive_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, 
   const uint32_t n_qg = (b + QG - 1) / QG;
   if (int32_t rc = h->qil.reserve((size_t)n_qg * h->ldq * QG * sizeof(float))) return rc;
   if (int32_t rc = launch_stage_queries(q_dev, ldq_in, h->d, h->qil.as<float>(), h->ldq, b, QG, st)) return rc;
-  const uint32_t target_items = (uint32_t)h->n_cu * (QG == 1 ? 20u : 12u);
+  const uint32_t target_items = (uint32_t)h->n_cu * scan_blocks_per_cu(QG, h->ld) * kWavesPerBlock;
   uint64_t per = (h->cap_rows * n_qg + target_items - 1) / target_items;
   const uint32_t seg_rows = (uint32_t)std::min<uint64_t>(round_up64(per ? per : 1, kWave), max_seg_rows(h->ld));
   uint32_t n_segs = (uint32_t)((h->cap_rows + seg_rows - 1) / seg_rows);
   if (n_segs == 0) n_segs = 1;
   if (int32_t rc = h->xpart.reserve((size_t)b * n_segs * top_k * sizeof(uint64_t))) return rc;
+  const uint32_t n_segs_pad = QG == 1 ? n_segs : round_up(n_segs, 4);
   auto fill = [&](auto& src) {
     src.rows = h->rows.as<float>(); src.n = h->cap_rows; src.ld = h->ld; src.seg_rows = seg_rows; src.n_segs = n_segs;
+    src.n_segs_pad = n_segs_pad;
     src.queries = h->qil.as<float>(); src.ldq = h->ldq; src.b = b; src.partials = h->xpart.as<uint64_t>(); src.k = top_k;
     src.ids = h->row_ids.as<uint32_t>();
   };
   int32_t rc;
   if (QG == 1) {
     SegSrc<1, true> src; fill(src);
-    rc = launch_seg_scan(h, src, n_segs * n_qg, (int)metric, st);
+    rc = launch_seg_scan(h, src, n_segs_pad * n_qg, (int)metric, st);
   } else {
     SegSrc<8, true> src; fill(src);
-    rc = launch_seg_scan(h, src, n_segs * n_qg, (int)metric, st);
+    rc = launch_seg_scan(h, src, n_segs_pad * n_qg, (int)metric, st);
   }
   if (rc) return rc;
   hipLaunchKernelGGL(seg_merge_kernel, dim3(b), dim3(kWave * kMergeWaves), 0, st, h->xpart.as<uint64_t>(), n_segs, top_k, out_ids,

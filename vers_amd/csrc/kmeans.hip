@@ -31,31 +31,42 @@ void DevBuf::release() {
 }
 
 // ---- assign -------------------------------------------------------------------------
+// item = (group of QG points, quarter of the centroid matrix): a quad of items shares the points' query
+// block (scan.cuh), each wave keeps the running first-minimum over its quarter of the centroids.
 template <int QG>
 struct AssignSrc {
   static constexpr bool kSeqIds = false;
   const float* C;  // centroids, lane-transposed tiles
-  uint32_t k;
+  uint32_t k, ld;
+  uint32_t seg_rows;     // centroids per quarter (multiple of 64)
   const float* qblocks;  // [ceil(nb/QG)][ldq][QG]
   uint32_t ldq, nb;
-  uint64_t* keys;  // [nb]
-  __device__ __forceinline__ uint32_t n_items() const { return (nb + QG - 1) / QG; }
+  uint64_t* keys;  // [nb][4]: one key per (point, centroid quarter)
+  __device__ __forceinline__ uint32_t n_items() const { return ((nb + QG - 1) / QG) * 4; }
   __device__ __forceinline__ void get(uint32_t it, ItemView<QG>& v) const {
-    v.rows = C;
-    v.nrows = k;
-    v.nq = (nb - it * QG < (uint32_t)QG) ? (nb - it * QG) : QG;
-    v.qb = qblocks + (uint64_t)it * ldq * QG;
+    const uint32_t g = it >> 2, w = it & 3;
+    const uint32_t r0 = w * seg_rows;
+    v.rows = C + (uint64_t)(r0 < k ? r0 : 0) * ld;
+    v.nrows = r0 < k ? (k - r0 < seg_rows ? k - r0 : seg_rows) : 0u;
+    v.nq = (nb - g * QG < (uint32_t)QG) ? (nb - g * QG) : QG;
+    v.qb = qblocks + (uint64_t)g * ldq * QG;
   }
-  __device__ __forceinline__ uint32_t seq_base(uint32_t, int) const { return 0; }
+  __device__ __forceinline__ uint32_t seq_base(uint32_t it, int) const { return (it & 3) * seg_rows; }
   __device__ __forceinline__ const uint32_t* seq_ids(uint32_t) const { return nullptr; }
-  __device__ __forceinline__ uint64_t* out(uint32_t it, int qi) const { return keys + (uint64_t)it * QG + qi; }
+  __device__ __forceinline__ uint64_t* out(uint32_t it, int qi) const { return keys + ((uint64_t)(it >> 2) * QG + qi) * 4 + (it & 3); }
   __device__ __forceinline__ uint32_t bound_slot(uint32_t, int) const { return 0; }
 };
 
+// first minimum over the (up to) four quarter keys of each point: keys order = (distance, centroid index)
 __global__ void keys_to_assign_kernel(const uint64_t* keys, uint32_t nb, uint32_t* assign, float* mind) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nb) return;
-  const uint64_t key = keys[i];
+  uint64_t key = keys[(uint64_t)i * 4];
+#pragma unroll
+  for (int w = 1; w < 4; ++w) {
+    const uint64_t kw = keys[(uint64_t)i * 4 + w];
+    key = kw < key ? kw : key;
+  }
   assign[i] = (uint32_t)key;
   if (mind) mind[i] = __uint_as_float(order_bits_to_f32_bits((uint32_t)(key >> 32)));
 }
@@ -73,7 +84,7 @@ int32_t km_assign(const float* X, uint32_t ldx, uint64_t n, const float* C, uint
   if (batch < (uint64_t)QG * 1024) batch = (uint64_t)QG * 1024;
   if (batch > n) batch = round_up64(n, QG);
   if (int32_t rc = ws.qblocks.reserve(batch * ldq * sizeof(float))) return rc;
-  if (int32_t rc = ws.keys.reserve(batch * sizeof(uint64_t))) return rc;
+  if (int32_t rc = ws.keys.reserve(batch * 4 * sizeof(uint64_t))) return rc;
   if (int32_t rc = ws.status.reserve(16)) return rc;
   ScanParams p;
   p.ld = ldq;
@@ -81,16 +92,21 @@ int32_t km_assign(const float* X, uint32_t ldx, uint64_t n, const float* C, uint
   p.k = 1;
   p.status = ws.status.as<uint32_t>();
   p.debug = 0;
-  p.bounds = nullptr;  // one item sees all centroids of its points: nothing to share
+  p.bounds = nullptr;  // the four quarter-items of a point group run side by side: nothing to share
+  const size_t lds = scan_lds_bytes(QG, ldq);
+  if (int32_t rc = scan_prepare_launch(scan_kernel<QG, 0, AssignSrc<QG>>, lds)) return rc;
+  const uint32_t seg_rows = round_up((k + 3) / 4, 64);
   for (uint64_t i0 = 0; i0 < n; i0 += batch) {
     const uint32_t nb = (uint32_t)((n - i0 < batch) ? (n - i0) : batch);
     if (int32_t rc = launch_stage_queries(X + i0 * ldx, ldx, d, ws.qblocks.as<float>(), ldq, nb, QG, st)) return rc;
     AssignSrc<QG> src;
-    src.C = ws.cblocked.as<float>(); src.k = k; src.qblocks = ws.qblocks.as<float>(); src.ldq = ldq; src.nb = nb; src.keys = ws.keys.as<uint64_t>();
-    const uint32_t n_items = (nb + QG - 1) / QG;
-    uint32_t blocks = (n_items + kWavesPerBlock - 1) / kWavesPerBlock;
-    if (blocks > (uint32_t)n_cu * 3u) blocks = (uint32_t)n_cu * 3u;
-    hipLaunchKernelGGL((scan_kernel<QG, 0, AssignSrc<QG>>), dim3(blocks), dim3(kWave * kWavesPerBlock), 0, st, src, p);
+    src.C = ws.cblocked.as<float>(); src.k = k; src.ld = ldq; src.seg_rows = seg_rows; src.qblocks = ws.qblocks.as<float>();
+    src.ldq = ldq; src.nb = nb; src.keys = ws.keys.as<uint64_t>();
+    VERS_HIP_TRY(hipMemsetAsync(ws.keys.p, 0xFF, (size_t)nb * 4 * sizeof(uint64_t), st));  // empty quarters stay "no candidate"
+    uint32_t blocks = (nb + QG - 1) / QG;  // one block per quad of items
+    const uint32_t max_blocks = (uint32_t)n_cu * scan_blocks_per_cu(QG, ldq);
+    if (blocks > max_blocks) blocks = max_blocks;
+    hipLaunchKernelGGL((scan_kernel<QG, 0, AssignSrc<QG>>), dim3(blocks), dim3(kWave * kWavesPerBlock), lds, st, src, p);
     VERS_HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(keys_to_assign_kernel, dim3((nb + 255) / 256), dim3(256), 0, st, ws.keys.as<uint64_t>(), nb,
                        out_assign + i0, out_mind ? out_mind + i0 : nullptr);

@@ -110,30 +110,30 @@ struct TileLoader {
   }
 };
 
-// (x[H], x[H]) - (q.x, q.y) and (x[H], x[H]) * (q.x, q.y): one v_pk_*_f32 whose VGPR operand is a
+// (x[H], x[H]) - (q.x, q.y) and (x[H], x[H]) * (q.x, q.y): one v_pk_*_f32 whose first operand is a
 // natural register pair of the loaded float4 with element H broadcast by op_sel, and whose other
-// operand is an SGPR pair holding the same column of two queries.  Register-only asm: nothing for
-// the compiler to count or wait for.  IEEE: x - q is computed as x + (-q), exact same result.
+// operand is a register pair holding the same column of two queries.  Register-only asm: nothing
+// for the compiler to count or wait for.  IEEE: x - q is computed as x + (-q), exact same result.
 template <int H>
 __device__ __forceinline__ f32x2 pk_bcast_sub(f32x2 x, f32x2 q) {
   f32x2 t;
-  if (H == 0) asm("v_pk_add_f32 %0, %1, %2 op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(t) : "v"(x), "s"(q));
-  else asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(t) : "v"(x), "s"(q));
+  if (H == 0) asm("v_pk_add_f32 %0, %1, %2 op_sel_hi:[0,1] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(t) : "v"(x), "v"(q));
+  else asm("v_pk_add_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1] neg_lo:[0,1] neg_hi:[0,1]" : "=v"(t) : "v"(x), "v"(q));
   return t;
 }
 template <int H>
 __device__ __forceinline__ f32x2 pk_bcast_mul(f32x2 x, f32x2 q) {
   f32x2 t;
-  if (H == 0) asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(t) : "v"(x), "s"(q));
-  else asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(t) : "v"(x), "s"(q));
+  if (H == 0) asm("v_pk_mul_f32 %0, %1, %2 op_sel_hi:[0,1]" : "=v"(t) : "v"(x), "v"(q));
+  else asm("v_pk_mul_f32 %0, %1, %2 op_sel:[1,0] op_sel_hi:[1,1]" : "=v"(t) : "v"(x), "v"(q));
   return t;
 }
 
-// Query operands are wave-uniform and come in through the scalar path.  For QG > 1 the
-// item's queries are stored INTERLEAVED, qb[col * QG + qi], so that one s_load_dwordx8
-// brings element `col` of all 8 queries and adjacent SGPR pairs feed v_pk_*_f32:
-// two queries per VALU instruction, each still its own strictly ordered f32 chain.
-// NP = number of live query PAIRS (dead pairs cost nothing).
+// Query operands are wave-uniform.  QG == 1: the query comes in through the scalar path (one
+// vector shared by every wave: scalar-cache resident).  QG > 1: the item's queries are stored
+// INTERLEAVED, qb[col * QG + qi], so that adjacent pairs feed v_pk_*_f32: two queries per VALU
+// instruction, each still its own strictly ordered f32 chain.  NP = live query PAIRS (dead pairs
+// cost nothing).  `qb` is a global pointer for QG == 1 and an LDS pointer for QG > 1.
 template <int QG, int NP, int METRIC>
 __device__ __forceinline__ void tile_chunk_compute(f32x2 (&acc)[(QG + 1) / 2], const u32x4 (&r)[kLoads],
                                                    const float* qb, uint32_t c) {
@@ -156,34 +156,36 @@ __device__ __forceinline__ void tile_chunk_compute(f32x2 (&acc)[(QG + 1) / 2], c
     }
     acc[0][0] = a;
   } else {
-    typedef __attribute__((address_space(4))) const f32x2 cf32x2_as4;
-    cf32x2_as4* qs = (cf32x2_as4*)(qb + (size_t)c * kChunk * QG);
-    // Scalar loads return out of order, so every use waits for ALL outstanding ones (lgkmcnt(0)):
-    // fetch the query operands of a whole batch of kQBatch columns first, then do the batch's math,
-    // so that one scalar-cache round trip is amortised over kQBatch * NP * 3 packed instructions.
-    constexpr int kQBatch = NP <= 4 ? 8 : 4;  // columns per batch: <= 64 SGPRs of query data
+    // Batched: the work item's interleaved query block [col][QG] sits in LDS (staged once per block
+    // item by the four waves that share it).  A wave-uniform ds_read_b128 broadcasts one column of 4
+    // queries; LDS returns in order, so the compiler pipelines the reads under counted lgkmcnt
+    // waits -- unlike scalar loads, whose out-of-order return forces lgkmcnt(0) at every use and
+    // whose re-fetch per tile went all the way to HBM.
+    static_assert(NP % 2 == 0, "query pairs are consumed two at a time (one ds_read_b128)");
+    const f32x4* ql = reinterpret_cast<const f32x4*>(qb) + (size_t)c * kChunk * (QG / 4);
 #pragma unroll
-    for (int b0 = 0; b0 < kChunk; b0 += kQBatch) {
-      f32x2 qv[kQBatch][NP];
+    for (int i = 0; i < kLoads; ++i) {
+      // the loaded float4 as two natural register pairs; one column is broadcast to both halves of
+      // the packed op by op_sel (see pk_bcast_*), so no {x, x} pair is ever materialised
+      const f32x2 xlo = {__uint_as_float(r[i][0]), __uint_as_float(r[i][1])};
+      const f32x2 xhi = {__uint_as_float(r[i][2]), __uint_as_float(r[i][3])};
 #pragma unroll
-      for (int j = 0; j < kQBatch; ++j)
+      for (int u = 0; u < 4; ++u) {
+        const f32x2 xp = u < 2 ? xlo : xhi;
 #pragma unroll
-        for (int p = 0; p < NP; ++p) qv[j][p] = qs[(b0 + j) * (QG / 2) + p];
-#pragma unroll
-      for (int j = 0; j < kQBatch; ++j) {
-        const int i = (b0 + j) >> 2, u = (b0 + j) & 3;
-        // the loaded float4 as two natural register pairs; one column is broadcast to both halves of
-        // the packed op by op_sel (see pk_bcast_*), so no {x, x} pair is ever materialised
-        const f32x2 xp = u < 2 ? f32x2{__uint_as_float(r[i][0]), __uint_as_float(r[i][1])}
-                               : f32x2{__uint_as_float(r[i][2]), __uint_as_float(r[i][3])};
-#pragma unroll
-        for (int p = 0; p < NP; ++p) {
+        for (int h = 0; h < NP / 2; ++h) {
+          const f32x4 q4 = ql[(i * 4 + u) * (QG / 4) + h];
+          const f32x2 q01 = {q4[0], q4[1]}, q23 = {q4[2], q4[3]};
           if (METRIC == 0) {
-            const f32x2 t = (u & 1) ? pk_bcast_sub<1>(xp, qv[j][p]) : pk_bcast_sub<0>(xp, qv[j][p]);
-            acc[p] = acc[p] + t * t;
+            const f32x2 t0 = (u & 1) ? pk_bcast_sub<1>(xp, q01) : pk_bcast_sub<0>(xp, q01);
+            const f32x2 t1 = (u & 1) ? pk_bcast_sub<1>(xp, q23) : pk_bcast_sub<0>(xp, q23);
+            acc[2 * h] = acc[2 * h] + t0 * t0;
+            acc[2 * h + 1] = acc[2 * h + 1] + t1 * t1;
           } else {
-            const f32x2 t = (u & 1) ? pk_bcast_mul<1>(xp, qv[j][p]) : pk_bcast_mul<0>(xp, qv[j][p]);
-            acc[p] = acc[p] + t;
+            const f32x2 t0 = (u & 1) ? pk_bcast_mul<1>(xp, q01) : pk_bcast_mul<0>(xp, q01);
+            const f32x2 t1 = (u & 1) ? pk_bcast_mul<1>(xp, q23) : pk_bcast_mul<0>(xp, q23);
+            acc[2 * h] = acc[2 * h] + t0;
+            acc[2 * h + 1] = acc[2 * h + 1] + t1;
           }
         }
       }
@@ -201,8 +203,8 @@ __device__ __forceinline__ void tile_chunk_compute(f32x2 (&acc)[(QG + 1) / 2], c
 // device memory (planned on the device, no host sync).
 //
 // Src interface (all arguments wave-uniform):
-//   uint32_t n_items() const
-//   void     get(it, ItemView<QG>&) const
+//   uint32_t n_items() const                 QG > 1: a multiple of 4, quads share a query block
+//   void     get(it, ItemView<QG>&) const    nrows == 0 marks a padding item
 //   uint32_t seq_base(it, qi) const          seq of the item's first row for query qi
 //   uint64_t* out(it, qi) const              partial slot (k keys) for query qi
 //   static constexpr bool kSeqIds            seq = seq_ids(it)[row] instead of seq_base + row
@@ -245,6 +247,15 @@ __device__ __forceinline__ void scan_item(const Src& src, const ScanParams& p, u
   for (int p2 = 0; p2 < (QG + 1) / 2; ++p2) acc[p2] = f32x2{0.0f, 0.0f};
   uint32_t sid = 0;
   if (Src::kSeqIds && lane < (int)v.nrows) sid = src.seq_ids(it)[lane];  // older than every prefetch below
+  // Per-query item constants (sequence base, output slot) are fetched ONCE, lane qi holding query qi's,
+  // and read back with v_readlane: a memory load inside the streaming loop would be waited for with
+  // vmcnt(0) and drain the whole prefetch ring at every tile boundary.
+  uint32_t vseq = 0;
+  uint64_t vout = 0;
+  if (lane < QG && lane < (int)v.nq) {
+    vseq = Src::kSeqIds ? 0u : src.seq_base(it, lane);
+    vout = (uint64_t)src.out(it, lane);
+  }
 
   // end of a tile: fold its 64 candidates into the per-query lists
   auto tile_done = [&](uint32_t t) {
@@ -257,7 +268,7 @@ __device__ __forceinline__ void scan_item(const Src& src, const ScanParams& p, u
         const float a = acc[qi >> 1][qi & 1];
         const float dist = METRIC == 0 ? a : __fsub_rn(1.0f, a);
         nan_seen |= valid && (dist != dist);
-        const uint32_t seq = Src::kSeqIds ? sid : src.seq_base(it, qi) + row;
+        const uint32_t seq = Src::kSeqIds ? sid : (uint32_t)__builtin_amdgcn_readlane((int)vseq, qi) + row;
         const uint64_t cand = valid ? make_key(dist, seq) : kKeyMax;
         wave_topk_update(list[qi], p.k, cand, bound[qi]);
       }
@@ -269,30 +280,49 @@ __device__ __forceinline__ void scan_item(const Src& src, const ScanParams& p, u
     }
   };
 
-  // Register double buffer: while buffer A is consumed, the loads of the next chunk fly into B.
-  // Chunks come in pairs (ld is a multiple of 2*kChunk) and EVERY load is issued unconditionally
-  // (the one past the end re-reads the last tile): a branch around a prefetch would make the
-  // compiler's vmcnt bookkeeping assume the shorter queue and wait for the prefetch itself.
-  u32x4 ra[kLoads], rb[kLoads];
-  const uint32_t last_tile = n_tiles ? n_tiles - 1 : 0;
-  if (n_tiles) L.issue(ra, 0, 0);
-  for (uint32_t t = 0; t < n_tiles; ++t) {
-    for (uint32_t c = 0; c < p.n_chunks; c += 2) {
-      L.issue(rb, t, c + 1);
-      if (!(p.debug & 2u)) tile_chunk_compute<QG, NP, METRIC>(acc, ra, v.qb, (p.debug & 4u) ? 0 : c);
-      else acc[0][0] += __uint_as_float(ra[0][0] ^ ra[kLoads - 1][3]);
-      const bool tile_end = c + 2 == p.n_chunks;
-      const uint32_t tn = tile_end ? (t < last_tile ? t + 1 : last_tile) : t;
-      L.issue(ra, tn, tile_end ? 0 : c + 2);
-      if (!(p.debug & 2u)) tile_chunk_compute<QG, NP, METRIC>(acc, rb, v.qb, (p.debug & 4u) ? 0 : c + 1);
-      else acc[0][0] += __uint_as_float(rb[0][0] ^ rb[kLoads - 1][3]);
+  // Register ring of kBufs chunk buffers: while one is consumed, the loads of the next kBufs-1 chunks
+  // are in flight (3 KiB... 24 KiB per wave).  Bytes in flight per CU, not wave count, is what keeps HBM
+  // busy while the VALU works: fewer, fatter waves win (measured: 2-deep ring at 3-4 waves/SIMD left
+  // memory and math un-overlapped).  The (tile, chunk) walk is flattened into
+  // steps and EVERY load is issued unconditionally (steps past the end re-read the last chunk): a
+  // branch around a prefetch would make the compiler's vmcnt bookkeeping assume the shorter queue and
+  // wait for the prefetch itself.
+  // Depth: 4 for the single-query kernels (little per-wave state, memory-bound: 24 KiB in flight per wave);
+  // 2 for the batched ones, whose math is bound by the LDS return bus feeding the query operands (one
+  // ds_read_b128 per 6 packed instructions, 8 LDS cycles per CU each) and wants 3-4 waves per SIMD more
+  // than it wants deeper prefetch (measured both ways).
+  constexpr int kBufs = QG == 1 ? 4 : 2;
+  u32x4 buf[kBufs][kLoads];
+  const uint32_t n_steps = n_tiles * p.n_chunks;
+  uint32_t ti = 0, ci = 0;  // (tile, chunk) the next issue fetches
+  auto issue_next = [&](u32x4 (&r)[kLoads]) {
+    L.issue(r, ti, ci);
+    if (ci + 1 < p.n_chunks) ++ci;
+    else if (ti + 1 < n_tiles) { ci = 0; ++ti; }  // else: stay on the last chunk (harmless re-read)
+  };
+  if (n_steps) {
+#pragma unroll
+    for (int b = 0; b < kBufs - 1; ++b) issue_next(buf[b]);
+  }
+  uint32_t tc = 0, cc = 0;  // (tile, chunk) being consumed
+  for (uint32_t s0 = 0; s0 < n_steps; s0 += kBufs) {
+#pragma unroll
+    for (int b = 0; b < kBufs; ++b) {
+      issue_next(buf[(b + kBufs - 1) % kBufs]);
+      if (s0 + b < n_steps) {  // uniform; no vector-memory op inside
+        if (!(p.debug & 2u)) tile_chunk_compute<QG, NP, METRIC>(acc, buf[b], v.qb, (p.debug & 4u) ? 0 : cc);
+        else acc[0][0] += __uint_as_float(buf[b][0][0] ^ buf[b][kLoads - 1][3]);
+        if (++cc == p.n_chunks) {
+          cc = 0;
+          tile_done(tc++);
+        }
+      }
     }
-    tile_done(t);
   }
 #pragma unroll
   for (int qi = 0; qi < QG; ++qi) {
     if (qi < 2 * NP && qi < (int)v.nq) {
-      if (lane < (int)p.k) src.out(it, qi)[lane] = list[qi];
+      if (lane < (int)p.k) reinterpret_cast<uint64_t*>(readlane64(vout, qi))[lane] = list[qi];
       if (p.bounds != nullptr) {  // publish this item's k-th key (if it has k) as a bound for later items
         const uint64_t kth = readlane64(list[qi], (int)p.k - 1);
         if (kth < bound[qi] && lane == 0) atomicMin((unsigned long long*)(p.bounds + src.bound_slot(it, qi)), (unsigned long long)kth);
@@ -301,36 +331,77 @@ __device__ __forceinline__ void scan_item(const Src& src, const ScanParams& p, u
   }
 }
 
+// QG == 1: waves are independent (persistent-style stride over items).
+// QG  > 1: items come in QUADS that share one query block (same list & query group, four row
+// segments; Src pads with empty items): the block's four waves stage the block's interleaved
+// query block into LDS once and each scans its own segment against it.
 template <int QG, int METRIC, class Src>
 __global__ __launch_bounds__(kWave * kWavesPerBlock) void scan_kernel(Src src, ScanParams p) {
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  const uint32_t n_waves = gridDim.x * kWavesPerBlock;
   const uint32_t n_items = src.n_items();
   bool nan_seen = false;
-  for (uint32_t it = blockIdx.x * kWavesPerBlock + wid; it < n_items; it += n_waves) {
-    ItemView<QG> v;
-    src.get(it, v);
-    if constexpr (QG == 1) {
+  if constexpr (QG == 1) {
+    const uint32_t n_waves = gridDim.x * kWavesPerBlock;
+    for (uint32_t it = blockIdx.x * kWavesPerBlock + wid; it < n_items; it += n_waves) {
+      ItemView<QG> v;
+      src.get(it, v);
       scan_item<1, 1, METRIC>(src, p, it, v, lane, nan_seen);
-    } else if constexpr (QG == 8) {
-      switch ((v.nq + 1) >> 1) {  // wave-uniform: dead query pairs are not computed
-        case 1: scan_item<8, 1, METRIC>(src, p, it, v, lane, nan_seen); break;
-        case 2: scan_item<8, 2, METRIC>(src, p, it, v, lane, nan_seen); break;
-        case 3: scan_item<8, 3, METRIC>(src, p, it, v, lane, nan_seen); break;
-        default: scan_item<8, 4, METRIC>(src, p, it, v, lane, nan_seen); break;
-      }
-    } else {
-      static_assert(QG == 16, "query groups are 1, 8 or 16 wide");
-      switch ((v.nq + 3) >> 2) {  // in steps of two pairs: bounds the code size (instruction cache)
-        case 1: scan_item<16, 2, METRIC>(src, p, it, v, lane, nan_seen); break;
-        case 2: scan_item<16, 4, METRIC>(src, p, it, v, lane, nan_seen); break;
-        case 3: scan_item<16, 6, METRIC>(src, p, it, v, lane, nan_seen); break;
-        default: scan_item<16, 8, METRIC>(src, p, it, v, lane, nan_seen); break;
+    }
+  } else {
+    static_assert(QG == 8 || QG == 16, "query groups are 1, 8 or 16 wide");
+    static_assert(kWavesPerBlock == 4, "items are padded to quads");
+    extern __shared__ __attribute__((aligned(16))) float qlds[];
+    const uint32_t n_quads = n_items / 4;
+    const uint32_t n4 = p.ld * (QG / 4);  // float4s of one query block
+    for (uint32_t b0 = blockIdx.x; b0 < (n_quads + 15u) / 16u * 16u; b0 += gridDim.x) {
+      // XCD-aware order (speed only, any placement is correct): blocks b and b+8 are observed to share
+      // an XCD, so within each run of 16 block-items give them NEIGHBOURING quads -- quads that stream
+      // the same rows for different query groups then meet in one XCD's L2 instead of both going to HBM.
+      const uint32_t r16 = b0 & 15u;
+      const uint32_t bi = (b0 & ~15u) + ((r16 & 7u) << 1) + (r16 >> 3);
+      if (bi >= n_quads) continue;  // block-uniform
+      const uint32_t it = bi * 4 + wid;
+      ItemView<QG> v;
+      src.get(it, v);  // v.qb / v.nq are the same for the four items of the quad
+      __syncthreads();  // the previous quad's readers are done with the LDS block
+      const f32x4* g = reinterpret_cast<const f32x4*>(v.qb);
+      for (uint32_t i = threadIdx.x; i < n4; i += kWave * kWavesPerBlock) reinterpret_cast<f32x4*>(qlds)[i] = g[i];
+      __syncthreads();
+      v.qb = qlds;
+      if (v.nrows == 0) continue;  // padding item (wave-uniform; barriers are outside)
+      const uint32_t np2 = (v.nq + 3) >> 2;  // live pairs, in steps of two (one ds_read_b128 each)
+      if constexpr (QG == 8) {
+        if (np2 <= 1) scan_item<8, 2, METRIC>(src, p, it, v, lane, nan_seen);
+        else scan_item<8, 4, METRIC>(src, p, it, v, lane, nan_seen);
+      } else {
+        switch (np2) {  // wave-uniform: dead query pairs are not computed
+          case 1: scan_item<16, 2, METRIC>(src, p, it, v, lane, nan_seen); break;
+          case 2: scan_item<16, 4, METRIC>(src, p, it, v, lane, nan_seen); break;
+          case 3: scan_item<16, 6, METRIC>(src, p, it, v, lane, nan_seen); break;
+          default: scan_item<16, 8, METRIC>(src, p, it, v, lane, nan_seen); break;
+        }
       }
     }
   }
   if (__ballot(nan_seen) != 0 && lane == 0) atomicOr(p.status, 1u);
+}
+
+// dynamic LDS of a batched scan launch (one interleaved query block) and the resident blocks per CU it allows
+inline size_t scan_lds_bytes(int QG, uint32_t ld) { return QG == 1 ? 0 : (size_t)ld * QG * sizeof(float); }
+inline uint32_t scan_blocks_per_cu(int QG, uint32_t ld) {
+  if (QG == 1) return 3;                                   // 12 waves/CU at <= 168 VGPRs
+  const size_t b = scan_lds_bytes(QG, ld);
+  const uint32_t by_lds = (uint32_t)((160u * 1024u) / (b ? b : 1));
+  const uint32_t by_vgpr = QG == 8 ? 4 : 3;                // <= 128 / <= 168 VGPRs
+  return by_lds < 1 ? 1 : (by_lds > by_vgpr ? by_vgpr : by_lds);
+}
+template <class K>
+inline int32_t scan_prepare_launch(K kernel, size_t lds_bytes) {
+  if (lds_bytes > 160u * 1024u) return fail(VERS_ERR_INVALID, "vector dimension too large for a batched scan (query block exceeds LDS)");
+  if (lds_bytes > 48u * 1024u)
+    VERS_HIP_TRY(hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_bytes));
+  return VERS_OK;
 }
 
 // ---- merge of partial slots ----------------------------------------------------
