@@ -1,0 +1,78 @@
+"""Host-side mirror of the reference's demo harness for IVFFlat (vers/src/utils.rs:7-66,117-184 and the
+commented-out call in main.rs:60-68) -- BASELINE.json config 1 ("plumbing").  Same sequence, same quirks:
+
+  load_wiki_vector : skip the header line, whitespace split, f32 parse; the word "queen" is HELD OUT raw
+                     (un-normalised); every other row is normalised with base.rs:99-105 arithmetic.
+  run_test         : vectors.push(raw queen) ; index.add(normalize(queen), vec_id) ; save_index ;
+                     load_index ; search_approximate(RAW queen vector, 10) ; print word + sqrt(dist).
+
+The arithmetic that decides results (build / add / search) runs on the GPU through the C ABI; this file only
+does what the reference does on the host around it.
+"""
+from __future__ import annotations
+
+import os
+
+import numpy as np
+
+from .index import IVFFlatIndex
+
+
+def _normalize_rows(a: np.ndarray) -> np.ndarray:
+    """Vector::normalize (base.rs:95-105): sequential f32 dot, sqrt, true division; |v| < 1e-6 -> unchanged."""
+    a = np.ascontiguousarray(a, dtype=np.float32)
+    m = np.sqrt(np.add.accumulate((a * a).astype(np.float32), axis=1, dtype=np.float32)[:, -1]).astype(np.float32)
+    out = a.copy()
+    big = ~(m < np.float32(1e-6))
+    out[big] = (a[big] / m[big, None]).astype(np.float32)
+    return out
+
+
+def load_wiki_vector(file_path: str, d: int):
+    """utils.rs:7-66.  Returns (all_vecs [n, d] f32, word_to_idx, idx_to_word, test_embs [(word, raw emb)])."""
+    words, rows, test_embs = [], [], []
+    with open(file_path, "r", encoding="utf-8") as f:
+        next(f)  # header line (utils.rs:26 skip(1))
+        for line in f:
+            parts = line.split()
+            word = parts[0]
+            emb = np.array([np.float32(x) for x in parts[1:]], dtype=np.float32)
+            if emb.size != d:
+                raise ValueError(f"expected {d} values for {word!r}")  # try_into().unwrap() panics in the reference
+            if word == "queen":
+                test_embs.append((word, emb))
+                continue
+            words.append(word)
+            rows.append(emb)
+    all_vecs = _normalize_rows(np.stack(rows)) if rows else np.zeros((0, d), dtype=np.float32)
+    word_to_idx = {w: i for i, w in enumerate(words)}
+    idx_to_word = {i: w for i, w in enumerate(words)}
+    return all_vecs, word_to_idx, idx_to_word, test_embs
+
+
+def run_test(index: IVFFlatIndex, index_file_name: str, vectors: list, word_to_idx: dict, idx_to_word: dict, test_embs):
+    """utils.rs:117-158 for T = IVFFlatIndex.  `vectors` is a python list of rows (the reference's Vec<Vector<N>>)."""
+    for word, emb in test_embs:
+        vec_id = len(vectors)
+        vectors.append(np.asarray(emb, dtype=np.float32).copy())        # raw, un-normalised (utils.rs:129-131)
+        idx_to_word[vec_id] = word
+        word_to_idx[word] = vec_id
+        index.add(_normalize_rows(emb[None])[0], vec_id)                # utils.rs:136
+    index.save_index(index_file_name)                                   # utils.rs:140
+    reload_index = IVFFlatIndex.load_index(index_file_name, index.d, index.device)   # utils.rs:145
+    results = reload_index.search_approximate(vectors[word_to_idx["queen"]], 10)     # utils.rs:148: the RAW vector
+    out = [(idx_to_word[i], np.sqrt(np.float32(dist), dtype=np.float32)) for i, dist in results]  # utils.rs:151-157
+    reload_index.close()
+    return out, results
+
+
+def test_ivfflat(vectors: np.ndarray, word_to_idx: dict, idx_to_word: dict, num_clusters: int, num_attempts: int,
+                 max_iterations: int, test_embs, init_indices=None, index_file_name: str = "ivfflat.index", device: int = 0):
+    """utils.rs:160-184.  `init_indices` injects the reference's unseeded centroid draws (ivfflat.rs:18-27)."""
+    ivfflat = IVFFlatIndex.build_index(num_clusters, num_attempts, max_iterations, vectors, init_indices=init_indices,
+                                       device=device)
+    vec_list = [v for v in np.asarray(vectors, dtype=np.float32)]
+    try:
+        return run_test(ivfflat, index_file_name, vec_list, word_to_idx, idx_to_word, test_embs)
+    finally:
+        ivfflat.close()
