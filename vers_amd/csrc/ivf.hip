@@ -810,12 +810,12 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
   if (b == 1) seg_rows = kWave;
   else {
     const uint64_t groups_est = std::max<uint64_t>(1, std::max<uint64_t>(pairs_est / QG, lists_est));
-    // ~128 items per CU: short segments keep the waves of a CU on the same (list, query group), i.e. on the
-    // same scalar-cache lines of query operands, and even out the tail (measured: 320-row segments at
-    // N=10M/nlist=4096/batch=1024 are 18 % faster than 1280-row ones)
-    const uint64_t segs_wanted = std::max<uint64_t>(1, ((uint64_t)h->n_cu * 128 + groups_est - 1) / groups_est);
+    // ~160 items per CU: short segments give every (list, query group) several quads and even out the tail
+    // (measured at N=10M/nlist=4096/batch=1024: 256-row segments 9.0 ms, 640-row 10.6 ms)
+    const uint64_t segs_wanted = std::max<uint64_t>(1, ((uint64_t)h->n_cu * 160 + groups_est - 1) / groups_est);
     const uint64_t avg_len = std::max<uint64_t>(1, h->n_total / std::max<uint32_t>(1, h->k));
-    seg_rows = (uint32_t)round_up64(std::max<uint64_t>(1, (avg_len + segs_wanted - 1) / segs_wanted), kWave);
+    // whole tile PAIRS (the batched kernel walks two tiles per step)
+    seg_rows = (uint32_t)round_up64(std::max<uint64_t>(1, (avg_len + segs_wanted - 1) / segs_wanted), QG == 1 ? kWave : 2 * kWave);
   }
   if (const char* e = getenv("VERS_SEG_ROWS")) seg_rows = (uint32_t)round_up64(std::max(64l, atol(e)), kWave);  // tuning knob
   const uint32_t S_max = std::max<uint32_t>(1, (h->max_len + seg_rows - 1) / seg_rows);
