@@ -171,8 +171,17 @@ def main():
     scan_mean_ms = float(np.mean(scan_ms)) if len(scan_ms) else float("nan")
     algo_bytes = ls["union_rows"] * d * 4 + nlist * d * 4
     achieved = algo_bytes / (scan_mean_ms * 1e-3) / 1e9
+    # HBM traffic of the same kernel from the PMC passes of the committed rocprofv3 run (bench.py cannot collect
+    # counters itself); used only when it was measured on this exact configuration.
+    traffic = None
+    try:
+        tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
+        if tj["config"] == {"rows": n, "d": d, "nlist": nlist, "nprobe": nprobe, "batch": B} and world == 1:
+            traffic = tj["hbm_read_bytes_per_launch"]
+    except (OSError, KeyError, ValueError):
+        pass
     roofline = {"bound": "hbm", "kernel": "scan_kernel<QG,0,IvfSrc<QG>> (inverted-list scan; QG = 16 at this shape)", "achieved": round(achieved, 1),
-                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+                "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "algorithmic_bytes_per_launch": int(algo_bytes), "streamed_bytes_per_launch": int(ls["streamed_rows"] * d * 4),
                 "launch_ms": round(scan_mean_ms, 4), "launches_timed": int(len(scan_ms)), "work_items": int(ls["items"])}
 
