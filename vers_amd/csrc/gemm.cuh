@@ -1,0 +1,195 @@
+// gemm.cuh -- the batched query x centroid contraction of the coarse quantiser on the f32 matrix
+// cores (v_mfma_f32_32x32x2_f32), with exact re-scoring and a certificate.
+//
+// The reference ranks centroids by the ordered f32 sum of (c-q)^2 (ivfflat.rs:155-161).  A GEMM
+// cannot reproduce that rounding, so it is used ONLY to pre-select: for a batch of queries
+//     G[m][n] = |c_n|^2 - 2 <q_m, c_n>                 (f32 MFMA, 1024 x 4096 x 768 at cfg3)
+// approximates D(c_n, q_m) - |q_m|^2.  Per query the P+S smallest G are taken (S = slack), their
+// distances are re-computed in the reference's own arithmetic (one lane per candidate, ordered
+// chain), sorted by the exact (distance, index) key, and the result is CERTIFIED: with
+// tau = largest selected G and E a rigorous bound on |G + |q|^2 - D_ref| (both roundings, below),
+// every unselected centroid has D_ref >= tau + |q|^2 - E; if the P-th exact distance is below that,
+// no unselected centroid can be among the true top-P and the output equals the exact coarse
+// quantiser bit for bit.  A query that fails the certificate is re-done exactly by its own wave
+// (all centroids, ordered chains) -- rare, and never wrong.
+//
+// Error bound (u = 2^-24, d = padded length, S = |q|^2 + max|c|^2, all sums of non-negative terms
+// or Cauchy-Schwarz):  |D_ref - T| <= (d+2) u T <= 2(d+2) u S ;  |c|^2, |q|^2 by ordered sums:
+// <= d u |.|^2 each ;  MFMA dot = k-ordered fma chain: <= d u |q||c| <= d u S / 2, doubled ;
+// two final roundings <= 2 u (3S).   Total <= (5d + 16) u S =: E.
+#pragma once
+#include "scan.cuh"
+
+namespace vers {
+
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+
+constexpr int kGemmBM = 128, kGemmBN = 128, kGemmBK = 32;
+constexpr int kGemmLds = kGemmBK + 4;  // row pitch in floats: 4*odd -> conflict-free ds_read_b128 by row
+
+// |c_n|^2 (ordered sum; any rounding is covered by E) for n < k, +inf for padding rows
+static __global__ void row_norms_kernel(const float* C, uint32_t ld, uint32_t k, uint32_t k_pad, float* out) {
+  const uint32_t n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= k_pad) return;
+  if (n >= k) { out[n] = __builtin_inff(); return; }
+  const f32x4* p = reinterpret_cast<const f32x4*>(C + (uint64_t)n * ld);
+  float acc = 0.0f;
+  for (uint32_t j = 0; j < ld / 4; ++j) {
+    const f32x4 v = p[j];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc = __fadd_rn(acc, __fmul_rn(v[u], v[u]));
+  }
+  out[n] = acc;
+}
+
+// G[m][n] = cnorm[n] - 2 * sum_k Q[m][k] * C[n][k].   Q [M_pad][K], C [N_pad][K] row-major, K % 32 == 0,
+// M_pad % 128 == 0, N_pad % 128 == 0.  Block = 4 waves, 128 x 128 tile; wave = 64 x 64 (2 x 2 MFMA tiles).
+// LDS tiles hold k permuted as [row][h = k & 1][s = k >> 1] so that lane (r, h) reads its 16 operands
+// of a K-tile (k = 2s + h) as four contiguous ds_read_b128.
+static __global__ __launch_bounds__(256) void coarse_gemm_kernel(const float* __restrict__ Q, const float* __restrict__ C,
+                                                                 const float* __restrict__ cnorm, uint32_t K, uint32_t N_pad,
+                                                                 float* __restrict__ G) {
+  __shared__ __attribute__((aligned(16))) float As[kGemmBM * kGemmLds];
+  __shared__ __attribute__((aligned(16))) float Bs[kGemmBN * kGemmLds];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wr = wid >> 1, wc = wid & 1;  // wave position inside the block tile
+  const uint32_t m0 = blockIdx.y * kGemmBM, n0 = blockIdx.x * kGemmBN;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.0f;
+
+  // staging map: 128 rows x 8 float4 per matrix = 1024 float4, 4 per thread
+  const int srow = tid >> 3, sc4 = tid & 7;  // rows srow + 32*i
+  f32x4 ra[4], rb[4];
+  auto gload = [&](uint32_t k0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      ra[i] = *reinterpret_cast<const f32x4*>(Q + (uint64_t)(m0 + srow + 32 * i) * K + k0 + sc4 * 4);
+      rb[i] = *reinterpret_cast<const f32x4*>(C + (uint64_t)(n0 + srow + 32 * i) * K + k0 + sc4 * 4);
+    }
+  };
+  auto lstore = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      // k = 4*sc4 + {0,1,2,3} -> (h, s) = (0, 2*sc4), (1, 2*sc4), (0, 2*sc4+1), (1, 2*sc4+1)
+      float* a = As + (srow + 32 * i) * kGemmLds + 2 * sc4;
+      float* b = Bs + (srow + 32 * i) * kGemmLds + 2 * sc4;
+      *reinterpret_cast<f32x2*>(a) = f32x2{ra[i][0], ra[i][2]};
+      *reinterpret_cast<f32x2*>(a + 16) = f32x2{ra[i][1], ra[i][3]};
+      *reinterpret_cast<f32x2*>(b) = f32x2{rb[i][0], rb[i][2]};
+      *reinterpret_cast<f32x2*>(b + 16) = f32x2{rb[i][1], rb[i][3]};
+    }
+  };
+  const int r = lane & 31, hh = lane >> 5;
+  gload(0);
+  for (uint32_t k0 = 0; k0 < K; k0 += kGemmBK) {
+    __syncthreads();  // previous tile's readers done
+    lstore();
+    __syncthreads();
+    if (k0 + kGemmBK < K) gload(k0 + kGemmBK);  // next tile in flight under the MFMAs
+    f32x4 fa[2][4], fb[2][4];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int v4 = 0; v4 < 4; ++v4) {
+        fa[t][v4] = *reinterpret_cast<const f32x4*>(As + (wr * 64 + t * 32 + r) * kGemmLds + hh * 16 + v4 * 4);
+        fb[t][v4] = *reinterpret_cast<const f32x4*>(Bs + (wc * 64 + t * 32 + r) * kGemmLds + hh * 16 + v4 * 4);
+      }
+#pragma unroll
+    for (int s = 0; s < 16; ++s)
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a][s >> 2][s & 3], fb[b][s >> 2][s & 3], acc[a][b], 0, 0, 0);
+  }
+  // epilogue: C/D layout col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const uint32_t n = n0 + wc * 64 + b * 32 + r;
+      const float cn = cnorm[n];
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const uint32_t m = m0 + wr * 64 + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+        G[(uint64_t)m * N_pad + n] = cn - 2.0f * acc[a][b][e];
+      }
+    }
+}
+
+// One wave per query: select the PS smallest G of its row, re-score them exactly, sort by the exact key,
+// certify, fall back to the full exact scan for this query if the certificate fails.
+// C_rm: centroids row-major [k][ldc] (pad columns zero); qp: padded queries [b][ldq].
+// probe[q][0..P) receives ascending (exact distance, centroid index) keys -- the exact coarse output.
+static __global__ __launch_bounds__(kWave) void coarse_select_rescore_kernel(
+    const float* G, uint32_t N_pad, uint32_t k, const float* C_rm, uint32_t ldc, const float* qp, uint32_t ldq, uint32_t d_pad,
+    float cmax2, uint32_t P, uint32_t PS, uint64_t* probe, uint32_t* status, uint32_t* fallback_count) {
+  const uint32_t q = blockIdx.x;
+  const int lane = threadIdx.x;
+  const float* g = G + (uint64_t)q * N_pad;
+  // (1) PS smallest approximate values; key = (order bits of G, centroid index)
+  uint64_t sel = kKeyMax;
+  for (uint32_t n0 = 0; n0 < k; n0 += kWave) {
+    const uint32_t n = n0 + lane;
+    const uint64_t cand = n < k ? make_key(g[n], n) : kKeyMax;
+    wave_topk_update(sel, PS, cand, kKeyMax);
+  }
+  const uint32_t n_sel = PS < k ? PS : k;
+  const float tau = __uint_as_float(order_bits_to_f32_bits((uint32_t)(readlane64(sel, (int)n_sel - 1) >> 32)));
+  // (2) exact re-score: lane l < n_sel owns candidate centroid l; the query element is wave-uniform
+  const float* qv = qp + (uint64_t)q * ldq;
+  const bool have = lane < (int)n_sel;
+  const uint32_t ci = have ? (uint32_t)sel : 0u;
+  const float* cv = C_rm + (uint64_t)ci * ldc;
+  float acc = 0.0f, qn = 0.0f;
+  for (uint32_t j = 0; j < ldc; j += 4) {
+    const f32x4 c4 = *reinterpret_cast<const f32x4*>(cv + j);
+    const f32x4 q4 = *reinterpret_cast<const f32x4*>(qv + j);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const float t = __fsub_rn(c4[u], q4[u]);
+      acc = __fadd_rn(acc, __fmul_rn(t, t));
+      qn = __fadd_rn(qn, __fmul_rn(q4[u], q4[u]));
+    }
+  }
+  bool nan_seen = have && (acc != acc);
+  uint64_t exact = kKeyMax;
+  wave_topk_update(exact, n_sel, have ? make_key(acc, ci) : kKeyMax, kKeyMax);  // sorted by (exact distance, index)
+  // (3) certificate
+  const uint32_t Pq = P < k ? P : k;
+  const float dP = __uint_as_float(order_bits_to_f32_bits((uint32_t)(readlane64(exact, (int)Pq - 1) >> 32)));
+  const float E = (5.0f * (float)d_pad + 16.0f) * 5.9604645e-08f * (qn + cmax2);
+  const bool certified = (n_sel >= k) || (dP < tau + qn - E);  // NaN anywhere -> false -> exact path decides
+  if (!certified) {
+    // exact fallback for this query: every centroid, ordered chain per lane
+    if (lane == 0) atomicAdd(fallback_count, 1u);
+    exact = kKeyMax;
+    for (uint32_t n0 = 0; n0 < k; n0 += kWave) {
+      const uint32_t n = n0 + lane;
+      float a2 = 0.0f;
+      if (n < k) {
+        const float* cc = C_rm + (uint64_t)n * ldc;
+        for (uint32_t j = 0; j < ldc; j += 4) {
+          const f32x4 c4 = *reinterpret_cast<const f32x4*>(cc + j);
+          const f32x4 q4 = *reinterpret_cast<const f32x4*>(qv + j);
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            const float t = __fsub_rn(c4[u], q4[u]);
+            a2 = __fadd_rn(a2, __fmul_rn(t, t));
+          }
+        }
+        nan_seen |= a2 != a2;
+      }
+      wave_topk_update(exact, Pq, n < k ? make_key(a2, n) : kKeyMax, kKeyMax);
+    }
+  }
+  if (lane < (int)P) probe[(uint64_t)q * P + lane] = lane < (int)Pq ? exact : kKeyMax;
+  if (__ballot(nan_seen) != 0 && lane == 0) atomicOr(status, 1u);
+}
+
+}  // namespace vers

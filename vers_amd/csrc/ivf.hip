@@ -18,6 +18,7 @@
 #include <mutex>
 #include <vector>
 
+#include "gemm.cuh"
 #include "kmeans.hpp"
 #include "scan.cuh"
 #include "util.cuh"
@@ -460,7 +461,15 @@ struct vers_ivf {
   uint32_t k = 0;         // num_centroids; 0 = no index / nothing kept
   uint64_t n_total = 0;   // assignments.len(): next vec_id handed out by add
   DevBuf centroids;    // [k][ldx] row-major (k-means, read-back)
-  DevBuf centroids_b;  // the same in lane-transposed tiles (coarse quantiser)
+  DevBuf centroids_b;  // the same in lane-transposed tiles (exact coarse quantiser)
+  // MFMA pre-selection of the batched coarse quantiser (gemm.cuh)
+  DevBuf centroids_g;  // row-major [k_pad][ldq], zero padded
+  DevBuf cnorm;        // |c|^2 [k_pad], +inf in the padding
+  DevBuf gbuf;         // G [M_pad][k_pad]
+  DevBuf coarse_stat;  // u32: queries that failed the certificate and were re-done exactly
+  float cmax2 = 0.0f;
+  uint32_t k_pad = 0;
+  uint64_t mfma_batches = 0;
   DevBuf rows, row_ids, list_off, list_len;
   std::vector<uint32_t> h_off, h_len, h_cap;  // h_len = GLOBAL list lengths; h_off/h_cap only meaningful for owned lists
   // sharding by cluster across GPUs (one process per GPU): this handle stores only lists with owner == rank
@@ -493,7 +502,7 @@ int32_t sync_status(vers_ivf* h, hipStream_t st) {
     if (s & kStNaN) return fail(VERS_ERR_NAN, "NaN distance (the reference panics in partial_cmp().unwrap())");
     if (s & kStInsufficient)
       return fail(VERS_ERR_INSUFFICIENT, "fewer than top_k vectors reachable (reference: index out of bounds, ivfflat.rs:169)");
-    if (s & kStSpillTooDeep) return fail(VERS_ERR_INVALID, "search_approximate would spill past 64 lists (unsupported)");
+    if (s & kStSpillTooDeep) return fail(VERS_ERR_INVALID, "search_approximate would spill past 48 lists (unsupported)");
   }
   return VERS_OK;
 }
@@ -546,7 +555,22 @@ int32_t build_storage(vers_ivf* h, const float* X, uint32_t ldx, uint64_t n, con
   // centroids in the scan layout for the coarse quantiser
   if (int32_t rc = h->centroids_b.reserve(std::max<uint64_t>(1, blocked_floats(k, h->ld)) * sizeof(float))) return rc;
   if (int32_t rc = launch_to_blocked(h->centroids.as<float>(), h->ldx, h->d, k, h->centroids_b.as<float>(), h->ld, st)) return rc;
+  // operands of the MFMA pre-selection
+  h->k_pad = round_up(k ? k : 1, kGemmBN);
+  if (int32_t rc = h->centroids_g.reserve((size_t)h->k_pad * h->ldq * sizeof(float))) return rc;
+  if (int32_t rc = h->cnorm.reserve((size_t)h->k_pad * sizeof(float))) return rc;
+  if (int32_t rc = h->coarse_stat.reserve(16)) return rc;
+  VERS_HIP_TRY(hipMemsetAsync(h->centroids_g.p, 0, (size_t)h->k_pad * h->ldq * sizeof(float), st));
+  VERS_HIP_TRY(hipMemsetAsync(h->coarse_stat.p, 0, 16, st));
+  if (int32_t rc = launch_stage_queries(h->centroids.as<float>(), h->ldx, h->d, h->centroids_g.as<float>(), h->ldq, k, 1, st)) return rc;
+  hipLaunchKernelGGL(row_norms_kernel, dim3((h->k_pad + 255) / 256), dim3(256), 0, st, h->centroids_g.as<float>(), h->ldq, k, h->k_pad,
+                     h->cnorm.as<float>());
+  VERS_HIP_TRY(hipGetLastError());
+  std::vector<float> cn(k ? k : 1, 0.0f);
+  if (k) VERS_HIP_TRY(hipMemcpyAsync(cn.data(), h->cnorm.p, (size_t)k * sizeof(float), hipMemcpyDeviceToHost, st));
   VERS_HIP_TRY(hipStreamSynchronize(st));
+  h->cmax2 = 0.0f;
+  for (uint32_t c = 0; c < k; ++c) h->cmax2 = std::max(h->cmax2, cn[c]);  // NaN centroids never raise it; they fail the certificate
   h->k = k;
   h->n_total = n;
   return VERS_OK;
@@ -712,7 +736,8 @@ int32_t launch_seg_scan(vers_ivf* h, const SegSrc<QG, SEQ_IDS>& src, uint32_t n_
 // queries (device, pitch ldq_in) -> h->qp [b][ldq] zero padded; returns the pointer/pitch to use
 int32_t stage_plain_queries(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint32_t b, const float** q_out,
                             hipStream_t st) {
-  if (int32_t rc = h->qp.reserve((size_t)b * h->ldq * sizeof(float))) return rc;
+  // rows padded to the GEMM tile (the MFMA pre-selection reads whole 128-row tiles; extra rows are ignored)
+  if (int32_t rc = h->qp.reserve((size_t)round_up(b, kGemmBM) * h->ldq * sizeof(float))) return rc;
   if (int32_t rc = launch_stage_queries(q_dev, ldq_in, h->d, h->qp.as<float>(), h->ldq, b, 1, st)) return rc;
   *q_out = h->qp.as<float>();
   return VERS_OK;
@@ -720,6 +745,23 @@ int32_t stage_plain_queries(vers_ivf* h, const float* q_dev, uint64_t ldq_in, ui
 
 // coarse quantiser (ivfflat.rs:155-161): top-P centroids per query as ascending (dist, index) keys in h->probe
 int32_t coarse(vers_ivf* h, const float* qp, uint32_t b, uint32_t P, hipStream_t st) {
+  // batches: MFMA pre-selection + exact re-score + certificate (gemm.cuh); same output, bit for bit
+  static const int coarse_mode = [] { const char* e = getenv("VERS_COARSE"); return e ? atoi(e) : 0; }();  // 1 = always exact, 2 = force fallback
+  if (b >= 32 && coarse_mode != 1 && qp == h->qp.as<float>()) {
+    const uint32_t M_pad = round_up(b, kGemmBM);
+    const uint32_t PS = std::min<uint32_t>(kMaxTopK, P + 16);
+    if (int32_t rc = h->gbuf.reserve((size_t)M_pad * h->k_pad * sizeof(float))) return rc;
+    if (int32_t rc = h->probe.reserve((size_t)b * P * sizeof(uint64_t))) return rc;
+    hipLaunchKernelGGL(coarse_gemm_kernel, dim3(h->k_pad / kGemmBN, M_pad / kGemmBM), dim3(256), 0, st, qp, h->centroids_g.as<float>(),
+                       h->cnorm.as<float>(), h->ldq, h->k_pad, h->gbuf.as<float>());
+    VERS_HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(coarse_select_rescore_kernel, dim3(b), dim3(kWave), 0, st, h->gbuf.as<float>(), h->k_pad, h->k,
+                       h->centroids_g.as<float>(), h->ldq, qp, h->ldq, h->ldq, coarse_mode == 2 ? __builtin_inff() : h->cmax2, P, PS,
+                       h->probe.as<uint64_t>(), h->status.as<uint32_t>(), h->coarse_stat.as<uint32_t>());
+    VERS_HIP_TRY(hipGetLastError());
+    h->mfma_batches += 1;
+    return VERS_OK;
+  }
   const int QG = b == 1 ? 1 : 8;
   const uint32_t n_qg = (b + QG - 1) / QG;
   const float* q = qp;
@@ -791,7 +833,9 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
   }
   if (h->k == 0) return fail(VERS_ERR_INSUFFICIENT, "search on an index without centroids (reference: index out of bounds, ivfflat.rs:169)");
   const int ref_mode = nprobe == 0;
-  const uint32_t P = ref_mode ? std::min<uint32_t>(h->k, kMaxTopK) : std::min<uint32_t>(nprobe, h->k);
+  // reference mode ranks the 48 nearest lists (48 + 16 slack = one key per lane in the MFMA pre-selection);
+  // a spill deeper than that is refused (kStSpillTooDeep) -- it needs > 47 consecutive near-empty lists
+  const uint32_t P = ref_mode ? std::min<uint32_t>(h->k, 48u) : std::min<uint32_t>(nprobe, h->k);
   if (P > (uint32_t)kMaxTopK) return fail(VERS_ERR_INVALID, "nprobe > 64 is not supported");
   const float* qp = nullptr;
   if (int32_t rc = stage_plain_queries(h, q_dev, ldq_in, b, &qp, st)) return rc;
@@ -1270,6 +1314,16 @@ int32_t vers_ivf_last_scan(vers_ivf_t* h, float* out_ms, uint64_t* out_union_row
   if (out_union_rows) *out_union_rows = t.union_rows;
   if (out_streamed_rows) *out_streamed_rows = t.streamed_rows;
   if (out_items) *out_items = t.n_items;
+  return VERS_OK;
+}
+
+int32_t vers_ivf_coarse_stats(vers_ivf_t* h, uint64_t* out_mfma_batches, uint64_t* out_fallback_queries) {
+  if (!h) return fail(VERS_ERR_INVALID, "null handle");
+  DeviceGuard g(h->device);
+  uint32_t fb = 0;
+  if (h->coarse_stat.p) VERS_HIP_TRY(hipMemcpy(&fb, h->coarse_stat.p, 4, hipMemcpyDeviceToHost));
+  if (out_mfma_batches) *out_mfma_batches = h->mfma_batches;
+  if (out_fallback_queries) *out_fallback_queries = fb;
   return VERS_OK;
 }
 
