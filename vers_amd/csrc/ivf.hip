@@ -283,6 +283,66 @@ __global__ void items_kernel(const uint32_t* cnt, const uint32_t* list_len, uint
   }
 }
 
+// Single query: coarse merge + plan + group + scatter + items in ONE launch (the five small kernels above cost
+// ~20 us each in launch + latency, more than the 60 us list scan they prepare).  One block: 16 waves merge the
+// coarse partial slots, wave 0 then plans with lane j = probe rank j.  Every probed list is distinct here, so a
+// pair is its own group; only the table entries of probed lists are written (no memset of the per-list arrays).
+__global__ __launch_bounds__(kWave * kMergeWaves) void plan1_kernel(
+    const uint64_t* cpart, uint32_t n_segs_c, uint32_t P, uint32_t k_lists, uint32_t top_k, int ref_mode, const uint32_t* list_len,
+    const uint8_t* owner, uint32_t rank, uint32_t seg_rows, uint64_t* probe, uint32_t* pj_list, uint32_t* pj_pref, uint32_t* pj_take,
+    uint32_t* np, uint32_t* cnt, uint32_t* pair_off, uint32_t* group_off, uint32_t* pairs, ItemDesc* items, GroupDesc* groups,
+    GroupTotals* tot, uint32_t* status) {
+  __shared__ uint64_t sh[kMergeWaves][kWave];
+  const uint64_t list = block_merge_keys(cpart, n_segs_c * P, P, sh);
+  if (threadIdx.x >= kWave) return;
+  const int lane = threadIdx.x;
+  const uint64_t key = lane < (int)P ? list : kKeyMax;
+  if (lane < (int)P) probe[lane] = key;
+  const uint32_t L = key != kKeyMax ? (uint32_t)key : kNoList;
+  const uint32_t len = L != kNoList ? list_len[L] : 0u;
+  auto excl_scan = [&](uint32_t v) {  // exclusive prefix sum over the 64 lanes
+    uint32_t inc = v;
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) {
+      const uint32_t t = __shfl_up(inc, off, kWave);
+      if (lane >= off) inc += t;
+    }
+    return inc - v;
+  };
+  const uint32_t pref = excl_scan(len);
+  const uint32_t total_rows = (uint32_t)__shfl(pref + len, kWave - 1, kWave);
+  // reference mode (ivfflat.rs:166-195) in closed form: list j is visited while the rows before it do not yet
+  // fill top_k, and contributes take_j = min(len_j, top_k - rows before it)
+  const bool visited = L != kNoList && (!ref_mode || pref < top_k);
+  const uint32_t take = !visited ? 0u : (ref_mode ? (len < top_k - pref ? len : top_k - pref) : top_k);
+  const bool scan = visited && len > 0 && take > 0 && (owner == nullptr || owner[L] == rank);
+  if (lane < (int)P) {
+    pj_list[lane] = scan ? L : kNoList;
+    pj_pref[lane] = pref;
+    pj_take[lane] = take;
+  }
+  const uint64_t vmask = __ballot(visited), smask = __ballot(scan);
+  if (lane == 0) {
+    np[0] = (uint32_t)__popcll(vmask);
+    if (ref_mode && top_k > 0 && total_rows < top_k) atomicOr(status, P >= k_lists ? kStInsufficient : kStSpillTooDeep);
+  }
+  const uint32_t n_s = scan ? (len + seg_rows - 1) / seg_rows : 0u;
+  const uint32_t item0 = excl_scan(n_s);
+  const uint32_t pidx = (uint32_t)__popcll(smask & ((1ull << lane) - 1ull));
+  if (scan) {
+    cnt[L] = 1; pair_off[L] = pidx; group_off[L] = pidx;
+    pairs[pidx] = (uint32_t)lane;  // q*P + j with q = 0
+    groups[pidx] = GroupDesc{pidx, 1u};
+    for (uint32_t sgi = 0; sgi < n_s; ++sgi) items[item0 + sgi] = ItemDesc{L, 0u, sgi};
+  }
+  const uint32_t n_items = (uint32_t)__shfl(item0 + n_s, kWave - 1, kWave);
+  const uint32_t rows_scanned = (uint32_t)__shfl(excl_scan(scan ? len : 0u) + (scan ? len : 0u), kWave - 1, kWave);
+  if (lane == 0) {
+    tot->n_items = n_items; tot->n_groups = (uint32_t)__popcll(smask); tot->n_pairs = tot->n_groups; tot->pad = 0;
+    tot->union_rows = rows_scanned; tot->streamed_rows = rows_scanned;
+  }
+}
+
 // interleaved query block of every group: qblocks[(g*ldq + col)*QG + qi]
 __global__ void gather_qblocks_kernel(const GroupDesc* groups, const GroupTotals* tot, const uint32_t* pairs, uint32_t P,
                                       const float* qp, uint32_t ldq, uint32_t QG, float* qblocks) {
@@ -744,7 +804,9 @@ int32_t stage_plain_queries(vers_ivf* h, const float* q_dev, uint64_t ldq_in, ui
 }
 
 // coarse quantiser (ivfflat.rs:155-161): top-P centroids per query as ascending (dist, index) keys in h->probe
-int32_t coarse(vers_ivf* h, const float* qp, uint32_t b, uint32_t P, hipStream_t st) {
+// out_n_segs != nullptr: stop after the scan (partial slots in h->cpart) and report the slot count per query --
+// the single-query path merges them inside plan1_kernel.
+int32_t coarse(vers_ivf* h, const float* qp, uint32_t b, uint32_t P, hipStream_t st, uint32_t* out_n_segs = nullptr) {
   // batches: MFMA pre-selection + exact re-score + certificate (gemm.cuh); same output, bit for bit
   static const int coarse_mode = [] { const char* e = getenv("VERS_COARSE"); return e ? atoi(e) : 0; }();  // 1 = always exact, 2 = force fallback
   if (b >= 32 && coarse_mode != 1 && qp == h->qp.as<float>()) {
@@ -791,6 +853,10 @@ int32_t coarse(vers_ivf* h, const float* qp, uint32_t b, uint32_t P, hipStream_t
     rc = launch_seg_scan(h, src, n_segs_pad * n_qg, 0, st);
   }
   if (rc) return rc;
+  if (out_n_segs) {
+    *out_n_segs = n_segs;
+    return VERS_OK;
+  }
   hipLaunchKernelGGL(coarse_merge_kernel, dim3(b), dim3(kWave * kMergeWaves), 0, st, h->cpart.as<uint64_t>(), n_segs, P,
                      h->probe.as<uint64_t>());
   VERS_HIP_TRY(hipGetLastError());
@@ -839,7 +905,8 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
   if (P > (uint32_t)kMaxTopK) return fail(VERS_ERR_INVALID, "nprobe > 64 is not supported");
   const float* qp = nullptr;
   if (int32_t rc = stage_plain_queries(h, q_dev, ldq_in, b, &qp, st)) return rc;
-  if (int32_t rc = coarse(h, qp, b, P, st)) return rc;
+  uint32_t n_segs_c = 0;
+  if (int32_t rc = coarse(h, qp, b, P, st, b == 1 ? &n_segs_c : nullptr)) return rc;
 
   // geometry of the list scan
   const uint64_t n_pj = (uint64_t)b * P;
@@ -889,8 +956,15 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
   uint32_t* item_off = group_off + k_l;
   GroupTotals* tot = (GroupTotals*)(((uintptr_t)(item_off + k_l) + 15) & ~(uintptr_t)15);
 
-  VERS_HIP_TRY(hipMemsetAsync(cnt, 0, 2 * (size_t)k_l * sizeof(uint32_t), st));
   VERS_HIP_TRY(hipMemsetAsync(h->partials.p, 0xFF, part_bytes, st));
+  if (b == 1) {
+    hipLaunchKernelGGL(plan1_kernel, dim3(1), dim3(kWave * kMergeWaves), 0, st, h->cpart.as<uint64_t>(), n_segs_c, P, k_l, top_k,
+                       ref_mode, h->list_len.as<uint32_t>(), h->world > 1 ? h->owner.as<uint8_t>() : (const uint8_t*)nullptr, h->rank,
+                       seg_rows, h->probe.as<uint64_t>(), pj_list, pj_pref, pj_take, np, cnt, pair_off, group_off,
+                       h->pairs.as<uint32_t>(), h->items.as<ItemDesc>(), h->groups.as<GroupDesc>(), tot, h->status.as<uint32_t>());
+    VERS_HIP_TRY(hipGetLastError());
+  } else {
+  VERS_HIP_TRY(hipMemsetAsync(cnt, 0, 2 * (size_t)k_l * sizeof(uint32_t), st));
   hipLaunchKernelGGL(plan_kernel, dim3((b + 127) / 128), dim3(128), 0, st, h->probe.as<uint64_t>(), b, P, k_l, top_k, ref_mode,
                      h->list_len.as<uint32_t>(), h->world > 1 ? h->owner.as<uint8_t>() : (const uint8_t*)nullptr, h->rank, pj_list,
                      pj_pref, pj_take, np, cnt, h->status.as<uint32_t>());
@@ -909,6 +983,7 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
                        h->pairs.as<uint32_t>(), P, qp, h->ldq, (uint32_t)QG, h->qblocks.as<float>());
     VERS_HIP_TRY(hipGetLastError());
   }
+  }  // b > 1
   auto fill_src = [&](auto& src) {
     src.rows = h->rows.as<float>(); src.ld = h->ld; src.list_off = h->list_off.as<uint32_t>();
     src.list_len = h->list_len.as<uint32_t>(); src.items = h->items.as<ItemDesc>(); src.n_items_dev = &tot->n_items;
