@@ -14,6 +14,7 @@
 // up to 8 queries -> inverted-list scan (scan.cuh engine) -> per-query merge + id mapping.
 // Everything is planned on the device; the host never waits inside a search.
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <mutex>
 #include <vector>
@@ -540,7 +541,7 @@ struct vers_ivf {
   uint32_t max_len = 0;
   // scratch
   KMeansScratch km;
-  DevBuf seg_bounds;
+  DevBuf seg_bounds, stamps, quad_counter;
   DevBuf qp, qil, cpart, probe, pj, lists, pairs, items, groups, qblocks, partials, status, o_ids, o_dist, o_cnt, xpart;
   static constexpr uint32_t kEvRing = 64;  // scan-launch timing ring (measurement hook)
   hipEvent_t ev0[kEvRing] = {}, ev1[kEvRing] = {};
@@ -776,6 +777,8 @@ int32_t launch_seg_scan(vers_ivf* h, const SegSrc<QG, SEQ_IDS>& src, uint32_t n_
   p.k = src.k;
   p.status = h->status.as<uint32_t>();
   p.debug = 0;
+  p.stamps = nullptr;
+  p.next_quad = nullptr;
   p.bounds = nullptr;  // items of a query are concurrent: nothing to prune, and the atomics would contend
   const size_t lds = scan_lds_bytes(QG, h->ld);
   uint32_t blocks = (n_items + kWavesPerBlock - 1) / kWavesPerBlock;
@@ -871,7 +874,21 @@ int32_t launch_ivf_scan(vers_ivf* h, const IvfSrc<QG>& src, uint32_t items_bound
   p.k = src.k_keep;
   p.status = h->status.as<uint32_t>();
   p.debug = scan_debug_flags();
-  p.bounds = scan_debug_flags() & 8u ? h->partials.as<uint64_t>() + h->ivf_bounds_off : nullptr;
+  p.stamps = nullptr;
+  if (p.debug & 16u) {  // diagnosis only
+    if (int32_t rc = h->stamps.reserve(64)) return rc;
+    VERS_HIP_TRY(hipMemsetAsync(h->stamps.p, 0, 64, st));
+    p.stamps = h->stamps.as<unsigned long long>();
+  }
+  // pruning bounds shared between the items of a merge group (they run at different times here, unlike the flat
+  // scans); VERS_SCAN_DEBUG bit 3 switches them off for A/B runs
+  p.bounds = (QG != 1 && !(scan_debug_flags() & 8u)) ? h->partials.as<uint64_t>() + h->ivf_bounds_off : nullptr;
+  p.next_quad = nullptr;
+  if (QG != 1 && !(scan_debug_flags() & 32u)) {
+    if (int32_t rc = h->quad_counter.reserve(16)) return rc;
+    VERS_HIP_TRY(hipMemsetAsync(h->quad_counter.p, 0, 16, st));
+    p.next_quad = h->quad_counter.as<uint32_t>();
+  }
   const size_t lds = scan_lds_bytes(QG, h->ld);
   if (int32_t rc = scan_prepare_launch(scan_kernel<QG, 0, IvfSrc<QG>>, lds)) return rc;
   uint32_t blocks = (items_bound + kWavesPerBlock - 1) / kWavesPerBlock;
@@ -1389,6 +1406,14 @@ int32_t vers_ivf_last_scan(vers_ivf_t* h, float* out_ms, uint64_t* out_union_row
   if (out_union_rows) *out_union_rows = t.union_rows;
   if (out_streamed_rows) *out_streamed_rows = t.streamed_rows;
   if (out_items) *out_items = t.n_items;
+  if ((scan_debug_flags() & 16u) && h->stamps.p) {  // diagnosis only: per-wave phase cycles of the last launch
+    unsigned long long sv[8] = {};
+    VERS_HIP_TRY(hipMemcpy(sv, h->stamps.p, 64, hipMemcpyDeviceToHost));
+    fprintf(stderr, "[vers stamps] items %llu: per item avg cycles: wait-for-loads %.0f  math %.0f  fold %.0f | per wave-quad-slot (%llu): stage %.0f  barrier-wait %.0f\n",
+            sv[4], sv[4] ? (double)sv[0] / sv[4] : 0.0, sv[4] ? (double)sv[1] / sv[4] : 0.0, sv[4] ? (double)sv[2] / sv[4] : 0.0,
+            sv[6], sv[6] ? (double)sv[3] / sv[6] : 0.0, sv[6] ? (double)sv[5] / sv[6] : 0.0);
+    fprintf(stderr, "[vers stamps] shader clock during the kernel: %.0f MHz\n", (double)sv[7] / (double)(1 << 20) * 100.0);
+  }
   return VERS_OK;
 }
 

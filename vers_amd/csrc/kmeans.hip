@@ -92,6 +92,8 @@ int32_t km_assign(const float* X, uint32_t ldx, uint64_t n, const float* C, uint
   p.k = 1;
   p.status = ws.status.as<uint32_t>();
   p.debug = 0;
+  p.stamps = nullptr;
+  p.next_quad = nullptr;
   p.bounds = nullptr;  // the four quarter-items of a point group run side by side: nothing to share
   const size_t lds = scan_lds_bytes(QG, ldq);
   if (int32_t rc = scan_prepare_launch(scan_kernel<QG, 0, AssignSrc<QG>>, lds)) return rc;

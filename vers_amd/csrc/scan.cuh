@@ -295,7 +295,9 @@ struct ScanParams {
   uint32_t k;         // keys kept per query (<= 64)
   uint32_t* status;   // device word: bit0 = NaN seen
   uint64_t* bounds;   // nullable: shared pruning bound per merge group (Src::bound_slot), kKeyMax initialised
-  uint32_t debug;     // diagnosis only (env VERS_SCAN_DEBUG): 1 skip top-k, 2 skip math, 4 one query column
+  uint32_t debug;     // diagnosis only (env VERS_SCAN_DEBUG): 1 skip top-k, 2 skip math, 4 one query column, 16 stamp phases
+  uint32_t* next_quad;  // batched kernels: device counter for dynamic quad hand-out (zeroed per launch) or nullptr
+  unsigned long long* stamps;  // debug & 16: [0] cycles waiting for loads, [1] math, [2] top-k fold, [3] item setup, [4] waves
 };
 
 // One work item, NP live query pairs (QG == 1: NP == 1).
@@ -419,9 +421,15 @@ __device__ __forceinline__ void scan_item2(const Src& src, const ScanParams& p, 
   for (int p2 = 0; p2 < QG / 2; ++p2) accA[p2] = accB[p2] = f32x2{0.0f, 0.0f};
   uint32_t vseq = 0;
   uint64_t vout = 0;
+  uint64_t vbound = kKeyMax;  // shared pruning bound of query `lane`'s merge group (see wave_topk_update)
+  uint64_t* bslot = nullptr;
   if (lane < QG && lane < (int)v.nq) {  // per-query constants once, lane qi = query qi (see scan_item)
     vseq = Src::kSeqIds ? 0u : src.seq_base(it, lane);
     vout = (uint64_t)src.out(it, lane);
+    if (p.bounds != nullptr) {
+      bslot = p.bounds + src.bound_slot(it, lane);
+      vbound = __hip_atomic_load(bslot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // stale = prunes less, never wrong
+    }
   }
   auto fold = [&](f32x2 (&acc)[QG / 2], uint32_t t) {
     const uint32_t row = t * kWave + lane;
@@ -439,8 +447,9 @@ __device__ __forceinline__ void scan_item2(const Src& src, const ScanParams& p, 
         nan_seen |= valid && (dist != dist);
         const uint32_t seq = Src::kSeqIds ? sid : (uint32_t)__builtin_amdgcn_readlane((int)vseq, qi) + row;
         const uint64_t cand = valid ? make_key(dist, seq) : kKeyMax;
-        if (t == 0 && p.k <= 16) wave_topk_fill(list[qi], p.k, cand, lane);
-        else wave_topk_update(list[qi], p.k, cand, kKeyMax);
+        const uint64_t bnd = p.bounds != nullptr ? readlane64(vbound, qi) : kKeyMax;
+        if (t == 0 && p.k <= 16 && bnd == kKeyMax) wave_topk_fill(list[qi], p.k, cand, lane);
+        else wave_topk_update(list[qi], p.k, cand, bnd);
       }
       acc[qi >> 1][qi & 1] = 0.0f;
     }
@@ -462,25 +471,53 @@ __device__ __forceinline__ void scan_item2(const Src& src, const ScanParams& p, 
   };
   if (n_steps) issue_next(buf[0]);
   uint32_t pc = 0, cc = 0;
+  const bool stamp = (p.debug & 16u) != 0;  // diagnosis build path: where do a wave's cycles go
+  unsigned long long t_wait = 0, t_math = 0, t_fold = 0;
   for (uint32_t s0 = 0; s0 < n_steps; s0 += 2) {
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
       issue_next(buf[b ^ 1]);
       if (s0 + b < n_steps) {  // uniform; no vector-memory op inside (except kSeqIds)
+        unsigned long long t0 = 0, t1 = 0, t2 = 0;
+        if (stamp) {
+          t0 = __builtin_amdgcn_s_memtime();
+          __builtin_amdgcn_s_waitcnt(0x4F70);  // vmcnt(16): this step's loads have landed
+          t1 = __builtin_amdgcn_s_memtime();
+        }
         if (!(p.debug & 2u)) tile_chunk_compute2<QG, NP, METRIC>(accA, accB, buf[b], v.qb, cc);
         else accA[0][0] += __uint_as_float(buf[b][0][0] ^ buf[b][2 * kLoads - 1][3]);
+        if (stamp) {
+          asm volatile("" :: "v"(accA[0]), "v"(accB[0]));
+          t2 = __builtin_amdgcn_s_memtime();
+          t_wait += t1 - t0;
+          t_math += t2 - t1;
+        }
         if (++cc == p.n_chunks) {
           cc = 0;
           fold(accA, 2 * pc);
           fold(accB, 2 * pc + 1);
           ++pc;
+          if (stamp) t_fold += __builtin_amdgcn_s_memtime() - t2;
         }
       }
     }
   }
+  if (stamp && lane == 0) {
+    atomicAdd(p.stamps + 0, t_wait);
+    atomicAdd(p.stamps + 1, t_math);
+    atomicAdd(p.stamps + 2, t_fold);
+    atomicAdd(p.stamps + 4, 1ull);
+  }
+  uint64_t kth = kKeyMax;  // lane qi collects query qi's k-th key
 #pragma unroll
   for (int qi = 0; qi < QG; ++qi)
-    if (qi < 2 * NP && qi < (int)v.nq && lane < (int)p.k) reinterpret_cast<uint64_t*>(readlane64(vout, qi))[lane] = list[qi];
+    if (qi < 2 * NP && qi < (int)v.nq) {
+      if (lane < (int)p.k) reinterpret_cast<uint64_t*>(readlane64(vout, qi))[lane] = list[qi];
+      const uint64_t kq = readlane64(list[qi], (int)p.k - 1);
+      if (lane == qi) kth = kq;
+    }
+  // publish a full list's k-th key as a bound for the items of the same merge group that start later
+  if (bslot != nullptr && kth < vbound) atomicMin((unsigned long long*)bslot, (unsigned long long)kth);
 }
 
 // QG == 1: waves are independent (persistent-style stride over items).
@@ -493,6 +530,8 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void scan_kernel(Src src, S
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const uint32_t n_items = src.n_items();
   bool nan_seen = false;
+  const unsigned long long clk0 = (p.debug & 16u) ? __builtin_amdgcn_s_memtime() : 0ull;
+  const unsigned long long rt0 = (p.debug & 16u) ? __builtin_amdgcn_s_memrealtime() : 0ull;
   if constexpr (QG == 1) {
     const uint32_t n_waves = gridDim.x * kWavesPerBlock;
     for (uint32_t it = blockIdx.x * kWavesPerBlock + wid; it < n_items; it += n_waves) {
@@ -506,20 +545,31 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void scan_kernel(Src src, S
     extern __shared__ __attribute__((aligned(16))) float qlds[];
     const uint32_t n_quads = n_items / 4;
     const uint32_t n4 = p.ld * (QG / 4);  // float4s of one query block
-    for (uint32_t b0 = blockIdx.x; b0 < (n_quads + 15u) / 16u * 16u; b0 += gridDim.x) {
-      // XCD-aware order (speed only, any placement is correct): blocks b and b+8 are observed to share
-      // an XCD, so within each run of 16 block-items give them NEIGHBOURING quads -- quads that stream
-      // the same rows for different query groups then meet in one XCD's L2 instead of both going to HBM.
-      const uint32_t r16 = b0 & 15u;
-      const uint32_t bi = (b0 & ~15u) + ((r16 & 7u) << 1) + (r16 >> 3);
-      if (bi >= n_quads) continue;  // block-uniform
+    // Quads are handed out dynamically (one agent-scope atomic per quad, ~100 us of work each): lists differ
+    // 5x in length, a static stride leaves a long tail.  p.next_quad is zeroed by the launcher; nullptr = static.
+    uint32_t* nq_lds = reinterpret_cast<uint32_t*>(qlds + (size_t)p.ld * QG);  // one word behind the query block
+    for (uint32_t b0 = blockIdx.x;; b0 += gridDim.x) {
+      uint32_t bi = b0;
+      if (p.next_quad != nullptr) {
+        if (threadIdx.x == 0) *nq_lds = atomicAdd(p.next_quad, 1u);
+        __syncthreads();
+        bi = *nq_lds;  // every wave reads it before the next write: two barriers follow below
+      }
+      if (bi >= n_quads) break;  // block-uniform
       const uint32_t it = bi * 4 + wid;
       ItemView<QG> v;
       src.get(it, v);  // v.qb / v.nq are the same for the four items of the quad
+      const unsigned long long ts0 = (p.debug & 16u) ? __builtin_amdgcn_s_memtime() : 0ull;
       __syncthreads();  // the previous quad's readers are done with the LDS block
+      const unsigned long long ts1 = (p.debug & 16u) ? __builtin_amdgcn_s_memtime() : 0ull;
       const f32x4* g = reinterpret_cast<const f32x4*>(v.qb);
       for (uint32_t i = threadIdx.x; i < n4; i += kWave * kWavesPerBlock) reinterpret_cast<f32x4*>(qlds)[i] = g[i];
       __syncthreads();
+      if ((p.debug & 16u) && lane == 0) {
+        atomicAdd(p.stamps + 3, __builtin_amdgcn_s_memtime() - ts1);  // staging the query block
+        atomicAdd(p.stamps + 5, ts1 - ts0);                           // waiting for the quad's slowest wave
+        atomicAdd(p.stamps + 6, 1ull);
+      }
       v.qb = qlds;
       if (v.nrows == 0) continue;  // padding item (wave-uniform; barriers are outside)
       const uint32_t np2 = (v.nq + 3) >> 2;  // live pairs, in steps of two (one ds_read_b128 each)
@@ -536,11 +586,16 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void scan_kernel(Src src, S
       }
     }
   }
+  if constexpr (QG != 1) {
+    if ((p.debug & 16u) && blockIdx.x == 0 && threadIdx.x == 0) {  // shader clock = d(memtime)/d(memrealtime) * 100 MHz
+      p.stamps[7] = ((__builtin_amdgcn_s_memtime() - clk0) << 20) / ((__builtin_amdgcn_s_memrealtime() - rt0) | 1ull);
+    }
+  }
   if (__ballot(nan_seen) != 0 && lane == 0) atomicOr(p.status, 1u);
 }
 
 // dynamic LDS of a batched scan launch (one interleaved query block) and the resident blocks per CU it allows
-inline size_t scan_lds_bytes(int QG, uint32_t ld) { return QG == 1 ? 0 : (size_t)ld * QG * sizeof(float); }
+inline size_t scan_lds_bytes(int QG, uint32_t ld) { return QG == 1 ? 0 : (size_t)ld * QG * sizeof(float) + 16; }
 inline uint32_t scan_blocks_per_cu(int QG, uint32_t ld) {
   if (QG == 1) return 3;                                   // 12 waves/CU at <= 168 VGPRs
   const size_t b = scan_lds_bytes(QG, ld);
