@@ -134,10 +134,15 @@ static __global__ __launch_bounds__(kWave) void coarse_select_rescore_kernel(
   const float* g = G + (uint64_t)q * N_pad;
   // (1) PS smallest approximate values; key = (order bits of G, centroid index)
   uint64_t sel = kKeyMax;
-  for (uint32_t n0 = 0; n0 < k; n0 += kWave) {
-    const uint32_t n = n0 + lane;
-    const uint64_t cand = n < k ? make_key(g[n], n) : kKeyMax;
-    wave_topk_update(sel, PS, cand, kKeyMax);
+  for (uint32_t n0 = 0; n0 < k; n0 += 16 * kWave) {  // the kernel is one wave per query and latency-bound:
+    float gv[16];                                     // sixteen independent loads in flight per round trip
+#pragma unroll
+    for (int u = 0; u < 16; ++u) gv[u] = n0 + u * kWave + lane < k ? g[n0 + u * kWave + lane] : 0.0f;
+#pragma unroll
+    for (int u = 0; u < 16; ++u) {
+      const uint32_t n = n0 + u * kWave + lane;
+      wave_topk_update(sel, PS, n < k ? make_key(gv[u], n) : kKeyMax, kKeyMax);
+    }
   }
   const uint32_t n_sel = PS < k ? PS : k;
   const float tau = __uint_as_float(order_bits_to_f32_bits((uint32_t)(readlane64(sel, (int)n_sel - 1) >> 32)));
@@ -147,14 +152,19 @@ static __global__ __launch_bounds__(kWave) void coarse_select_rescore_kernel(
   const uint32_t ci = have ? (uint32_t)sel : 0u;
   const float* cv = C_rm + (uint64_t)ci * ldc;
   float acc = 0.0f, qn = 0.0f;
-  for (uint32_t j = 0; j < ldc; j += 4) {
-    const f32x4 c4 = *reinterpret_cast<const f32x4*>(cv + j);
-    const f32x4 q4 = *reinterpret_cast<const f32x4*>(qv + j);
+  for (uint32_t j = 0; j < ldc; j += 64) {  // ldc is a multiple of 64; 16 row loads in flight (each lane walks its own row)
+    f32x4 c4[16];
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const float t = __fsub_rn(c4[u], q4[u]);
-      acc = __fadd_rn(acc, __fmul_rn(t, t));
-      qn = __fadd_rn(qn, __fmul_rn(q4[u], q4[u]));
+    for (int w = 0; w < 16; ++w) c4[w] = *reinterpret_cast<const f32x4*>(cv + j + 4 * w);
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+      const f32x4 q4 = *reinterpret_cast<const f32x4*>(qv + j + 4 * w);  // wave-uniform
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float t = __fsub_rn(c4[w][u], q4[u]);
+        acc = __fadd_rn(acc, __fmul_rn(t, t));
+        qn = __fadd_rn(qn, __fmul_rn(q4[u], q4[u]));
+      }
     }
   }
   bool nan_seen = have && (acc != acc);

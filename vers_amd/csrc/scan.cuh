@@ -229,8 +229,18 @@ __device__ __forceinline__ void tile_chunk_compute(f32x2 (&acc)[(QG + 1) / 2], c
 template <int QG, int NP, int METRIC>
 __device__ __forceinline__ void tile_chunk_compute2(f32x2 (&accA)[QG / 2], f32x2 (&accB)[QG / 2],
                                                     const u32x4 (&r)[2 * kLoads], const float* qb, uint32_t c) {
-  static_assert(NP % 2 == 0, "query pairs are consumed two at a time (one ds_read_b128)");
-  const f32x4* ql = reinterpret_cast<const f32x4*>(qb) + (size_t)c * kChunk * (QG / 4);
+  const float* ql = qb + (size_t)c * kChunk * QG;
+  auto pair_step = [&](f32x2& aA, f32x2& aB, f32x2 xa, f32x2 xb, f32x2 q, int odd) {
+    if (METRIC == 0) {
+      const f32x2 a = odd ? pk_bcast_sub<1>(xa, q) : pk_bcast_sub<0>(xa, q);
+      const f32x2 b = odd ? pk_bcast_sub<1>(xb, q) : pk_bcast_sub<0>(xb, q);
+      aA = aA + a * a;
+      aB = aB + b * b;
+    } else {
+      aA = aA + (odd ? pk_bcast_mul<1>(xa, q) : pk_bcast_mul<0>(xa, q));
+      aB = aB + (odd ? pk_bcast_mul<1>(xb, q) : pk_bcast_mul<0>(xb, q));
+    }
+  };
 #pragma unroll
   for (int i = 0; i < kLoads; ++i) {
     const f32x2 aLo = {__uint_as_float(r[i][0]), __uint_as_float(r[i][1])};
@@ -240,25 +250,16 @@ __device__ __forceinline__ void tile_chunk_compute2(f32x2 (&accA)[QG / 2], f32x2
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       const f32x2 xa = u < 2 ? aLo : aHi, xb = u < 2 ? bLo : bHi;
+      const float* qc = ql + (i * 4 + u) * QG;  // this column's QG query values (wave-uniform LDS address)
 #pragma unroll
-      for (int h = 0; h < NP / 2; ++h) {
-        const f32x4 q4 = ql[(i * 4 + u) * (QG / 4) + h];
-        const f32x2 q01 = {q4[0], q4[1]}, q23 = {q4[2], q4[3]};
-        if (METRIC == 0) {
-          const f32x2 a0 = (u & 1) ? pk_bcast_sub<1>(xa, q01) : pk_bcast_sub<0>(xa, q01);
-          const f32x2 a1 = (u & 1) ? pk_bcast_sub<1>(xa, q23) : pk_bcast_sub<0>(xa, q23);
-          const f32x2 b0 = (u & 1) ? pk_bcast_sub<1>(xb, q01) : pk_bcast_sub<0>(xb, q01);
-          const f32x2 b1 = (u & 1) ? pk_bcast_sub<1>(xb, q23) : pk_bcast_sub<0>(xb, q23);
-          accA[2 * h] = accA[2 * h] + a0 * a0;
-          accA[2 * h + 1] = accA[2 * h + 1] + a1 * a1;
-          accB[2 * h] = accB[2 * h] + b0 * b0;
-          accB[2 * h + 1] = accB[2 * h + 1] + b1 * b1;
-        } else {
-          accA[2 * h] = accA[2 * h] + ((u & 1) ? pk_bcast_mul<1>(xa, q01) : pk_bcast_mul<0>(xa, q01));
-          accA[2 * h + 1] = accA[2 * h + 1] + ((u & 1) ? pk_bcast_mul<1>(xa, q23) : pk_bcast_mul<0>(xa, q23));
-          accB[2 * h] = accB[2 * h] + ((u & 1) ? pk_bcast_mul<1>(xb, q01) : pk_bcast_mul<0>(xb, q01));
-          accB[2 * h + 1] = accB[2 * h + 1] + ((u & 1) ? pk_bcast_mul<1>(xb, q23) : pk_bcast_mul<0>(xb, q23));
-        }
+      for (int h = 0; h < NP / 2; ++h) {  // two query pairs per ds_read_b128
+        const f32x4 q4 = *reinterpret_cast<const f32x4*>(qc + 4 * h);
+        pair_step(accA[2 * h], accB[2 * h], xa, xb, f32x2{q4[0], q4[1]}, u & 1);
+        pair_step(accA[2 * h + 1], accB[2 * h + 1], xa, xb, f32x2{q4[2], q4[3]}, u & 1);
+      }
+      if constexpr (NP % 2 == 1) {  // odd live pair count: the last pair alone (ds_read_b64)
+        const f32x2 q2 = *reinterpret_cast<const f32x2*>(qc + 2 * (NP - 1));
+        pair_step(accA[NP - 1], accB[NP - 1], xa, xb, q2, u & 1);
       }
     }
   }
@@ -572,15 +573,26 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void scan_kernel(Src src, S
       }
       v.qb = qlds;
       if (v.nrows == 0) continue;  // padding item (wave-uniform; barriers are outside)
-      const uint32_t np2 = (v.nq + 3) >> 2;  // live pairs, in steps of two (one ds_read_b128 each)
+      // Live query pairs: dead pairs are not computed (wave-uniform dispatch), single-pair granularity (odd counts
+      // take one ds_read_b64).  VERS_SCAN_DEBUG bit 6 = steps of two pairs, for A/B runs: measured 3.5 % slower
+      // on the same box at cfg3.
+      const uint32_t np = (p.debug & 64u) ? (((v.nq + 3) >> 2) << 1) : ((v.nq + 1) >> 1);
       if constexpr (QG == 8) {
-        if (np2 <= 1) scan_item2<8, 2, METRIC>(src, p, it, v, lane, nan_seen);
-        else scan_item2<8, 4, METRIC>(src, p, it, v, lane, nan_seen);
+        switch (np) {
+          case 1: scan_item2<8, 1, METRIC>(src, p, it, v, lane, nan_seen); break;
+          case 2: scan_item2<8, 2, METRIC>(src, p, it, v, lane, nan_seen); break;
+          case 3: scan_item2<8, 3, METRIC>(src, p, it, v, lane, nan_seen); break;
+          default: scan_item2<8, 4, METRIC>(src, p, it, v, lane, nan_seen); break;
+        }
       } else {
-        switch (np2) {  // wave-uniform: dead query pairs are not computed (2 variants instead of 4 measured 6 % slower)
-          case 1: scan_item2<16, 2, METRIC>(src, p, it, v, lane, nan_seen); break;
-          case 2: scan_item2<16, 4, METRIC>(src, p, it, v, lane, nan_seen); break;
-          case 3: scan_item2<16, 6, METRIC>(src, p, it, v, lane, nan_seen); break;
+        switch (np) {
+          case 1: scan_item2<16, 1, METRIC>(src, p, it, v, lane, nan_seen); break;
+          case 2: scan_item2<16, 2, METRIC>(src, p, it, v, lane, nan_seen); break;
+          case 3: scan_item2<16, 3, METRIC>(src, p, it, v, lane, nan_seen); break;
+          case 4: scan_item2<16, 4, METRIC>(src, p, it, v, lane, nan_seen); break;
+          case 5: scan_item2<16, 5, METRIC>(src, p, it, v, lane, nan_seen); break;
+          case 6: scan_item2<16, 6, METRIC>(src, p, it, v, lane, nan_seen); break;
+          case 7: scan_item2<16, 7, METRIC>(src, p, it, v, lane, nan_seen); break;
           default: scan_item2<16, 8, METRIC>(src, p, it, v, lane, nan_seen); break;
         }
       }
