@@ -212,6 +212,22 @@ def main():
         recall = hits / float(nq_r * top_k)
         log(f"[bench] recall@{top_k} = {recall:.4f} over {nq_r} queries (exact scan took {t_ex:.2f}s)")
 
+    # ---- full-size property: self-retrieval -------------------------------------------------------------------
+    # a stored row queried bit-identically comes back first at distance exactly 0.0 (assign and search use the same
+    # symmetric ordered distance and the same first-minimum rule: ivfflat.rs:36-43 vs :159-160)
+    self_ok = None
+    if world == 1:
+        own = [c for c in range(0, nlist, max(1, nlist // 8)) if lens[c] > 0][:8]
+        rows_ids = [index.get_list(c) for c in own]
+        sq = np.stack([r[0][len(r[1]) // 2] for r in rows_ids]); sid = np.array([r[1][len(r[1]) // 2] for r in rows_ids])
+        sqd = torch.from_numpy(sq).to(dev)
+        sids = torch.zeros(len(own), top_k, dtype=torch.int64, device=dev); sdst = torch.zeros(len(own), top_k, device=dev)
+        scnt = torch.zeros(len(own), dtype=torch.int32, device=dev)
+        index.search_dev(sqd.data_ptr(), d, len(own), top_k, nprobe, sids.data_ptr(), sdst.data_ptr(), scnt.data_ptr(), st)
+        index.poll(st)
+        self_ok = bool((sids[:, 0].cpu().numpy().astype(np.uint64) == sid).all() and (sdst[:, 0].cpu().numpy() == 0.0).all())
+        log(f"[bench] self-retrieval of {len(own)} stored rows at N={n}: {'ok' if self_ok else 'FAILED'}")
+
     # ---- CPU baseline: the C restatement of the reference path on one host core -----------------------
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu:
@@ -243,7 +259,7 @@ def main():
         out = {"metric": "queries/sec + recall@10, IVFFlat N=10M d=768", "value": round(qps, 1), "unit": "queries/sec",
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
                "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-               "recall_at_10": None if recall is None else round(recall, 4),
+               "recall_at_10": None if recall is None else round(recall, 4), "self_retrieval_ok": self_ok,
                "config": {"workload": f"IVFFlat search_approximate, nprobe extension: N={n} d={d} nlist={nlist} nprobe={nprobe} "
                                       f"batch={B} top_k={top_k}, f32, clustered unit vectors (Dist-C)",
                           "n": n, "d": d, "nlist": nlist, "nprobe": nprobe, "batch": B, "top_k": top_k,
