@@ -45,6 +45,7 @@ void shard_plan(const uint64_t* lens, uint64_t k, uint32_t world, uint8_t* owner
 
 constexpr uint32_t kNoList = 0xFFFFFFFFu;
 constexpr uint32_t kStNaN = 1u, kStInsufficient = 2u, kStSpillTooDeep = 4u;
+constexpr int32_t kRetrySpill = 1001;  // internal: reference-mode spill ran past the ranked lists, retry deeper if possible
 
 // ---- sources for the scan engine -----------------------------------------------------------
 // coarse quantiser / exhaustive scan: item = (row segment, query group), slot(q, seg) = q*n_segs + seg;
@@ -529,6 +530,7 @@ struct vers_ivf {
   DevBuf gbuf;         // G [M_pad][k_pad]
   DevBuf coarse_stat;  // u32: queries that failed the certificate and were re-done exactly
   float cmax2 = 0.0f;
+  bool ref_deep = false;  // reference-mode retry: rank 64 lists with the exact coarse quantiser (no slack needed)
   uint32_t k_pad = 0;
   uint64_t mfma_batches = 0;
   DevBuf rows, row_ids, list_off, list_len;
@@ -563,7 +565,10 @@ int32_t sync_status(vers_ivf* h, hipStream_t st) {
     if (s & kStNaN) return fail(VERS_ERR_NAN, "NaN distance (the reference panics in partial_cmp().unwrap())");
     if (s & kStInsufficient)
       return fail(VERS_ERR_INSUFFICIENT, "fewer than top_k vectors reachable (reference: index out of bounds, ivfflat.rs:169)");
-    if (s & kStSpillTooDeep) return fail(VERS_ERR_INVALID, "search_approximate would spill past 48 lists (unsupported)");
+    if (s & kStSpillTooDeep) {
+      fail(VERS_ERR_INVALID, "search_approximate would spill past the ranked lists (48 through the MFMA pre-selection, 64 exact; deeper is unsupported)");
+      return kRetrySpill;
+    }
   }
   return VERS_OK;
 }
@@ -812,7 +817,7 @@ int32_t stage_plain_queries(vers_ivf* h, const float* q_dev, uint64_t ldq_in, ui
 int32_t coarse(vers_ivf* h, const float* qp, uint32_t b, uint32_t P, hipStream_t st, uint32_t* out_n_segs = nullptr) {
   // batches: MFMA pre-selection + exact re-score + certificate (gemm.cuh); same output, bit for bit
   static const int coarse_mode = [] { const char* e = getenv("VERS_COARSE"); return e ? atoi(e) : 0; }();  // 1 = always exact, 2 = force fallback
-  if (b >= 32 && coarse_mode != 1 && qp == h->qp.as<float>()) {
+  if (b >= 32 && coarse_mode != 1 && !h->ref_deep && qp == h->qp.as<float>()) {
     const uint32_t M_pad = round_up(b, kGemmBM);
     const uint32_t PS = std::min<uint32_t>(kMaxTopK, P + 16);
     if (int32_t rc = h->gbuf.reserve((size_t)M_pad * h->k_pad * sizeof(float))) return rc;
@@ -918,7 +923,7 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
   const int ref_mode = nprobe == 0;
   // reference mode ranks the 48 nearest lists (48 + 16 slack = one key per lane in the MFMA pre-selection);
   // a spill deeper than that is refused (kStSpillTooDeep) -- it needs > 47 consecutive near-empty lists
-  const uint32_t P = ref_mode ? std::min<uint32_t>(h->k, 48u) : std::min<uint32_t>(nprobe, h->k);
+  const uint32_t P = ref_mode ? std::min<uint32_t>(h->k, h->ref_deep ? 64u : 48u) : std::min<uint32_t>(nprobe, h->k);
   if (P > (uint32_t)kMaxTopK) return fail(VERS_ERR_INVALID, "nprobe > 64 is not supported");
   const float* qp = nullptr;
   if (int32_t rc = stage_plain_queries(h, q_dev, ldq_in, b, &qp, st)) return rc;
@@ -1323,7 +1328,8 @@ int32_t vers_topk_merge_dev(const uint64_t* keys_dev, const uint64_t* ids_dev, u
 int32_t vers_ivf_poll(vers_ivf_t* h, void* stream) {
   if (!h) return fail(VERS_ERR_INVALID, "null handle");
   DeviceGuard g(h->device);
-  return sync_status(h, (hipStream_t)stream);
+  const int32_t rc = sync_status(h, (hipStream_t)stream);
+  return rc == kRetrySpill ? VERS_ERR_INVALID : rc;
 }
 
 int32_t vers_ivf_search(vers_ivf_t* h, const float* queries, uint64_t q_stride_bytes, uint32_t b, uint32_t top_k,
@@ -1341,7 +1347,16 @@ int32_t vers_ivf_search(vers_ivf_t* h, const float* queries, uint64_t q_stride_b
   if (int32_t rc = search_dev_locked(h, q.as<float>(), h->d, b, top_k, nprobe, h->o_ids.as<uint64_t>(), h->o_dist.as<float>(),
                                      h->o_cnt.as<uint32_t>(), nullptr, nullptr))
     return rc;
-  if (int32_t rc = sync_status(h, nullptr)) return rc;
+  int32_t rc = sync_status(h, nullptr);
+  if (rc == kRetrySpill && h->k > 48) {  // rank deeper (64 lists, exact coarse quantiser) and try once more
+    h->ref_deep = true;
+    rc = search_dev_locked(h, q.as<float>(), h->d, b, top_k, nprobe, h->o_ids.as<uint64_t>(), h->o_dist.as<float>(),
+                           h->o_cnt.as<uint32_t>(), nullptr, nullptr);
+    h->ref_deep = false;
+    if (rc) return rc;
+    rc = sync_status(h, nullptr);
+  }
+  if (rc) return rc == kRetrySpill ? VERS_ERR_INVALID : rc;
   return download_results(h, b, top_k, out_ids, out_dist, out_count);
 }
 
@@ -1373,7 +1388,7 @@ int32_t vers_ivf_search_exhaustive(vers_ivf_t* h, const float* queries, uint64_t
   if (int32_t rc = exhaustive_dev_locked(h, q.as<float>(), h->d, b, top_k, metric, h->o_ids.as<uint64_t>(), h->o_dist.as<float>(),
                                          h->o_cnt.as<uint32_t>(), nullptr))
     return rc;
-  if (int32_t rc = sync_status(h, nullptr)) return rc;
+  if (int32_t rc = sync_status(h, nullptr)) return rc == kRetrySpill ? VERS_ERR_INVALID : rc;
   return download_results(h, b, top_k, out_ids, out_dist, out_count);
 }
 
