@@ -111,8 +111,13 @@ def main():
     torch.cuda.empty_cache()
     lens = index.list_lengths()
     if rank == 0:
+        import zlib
+        fp = zlib.crc32(np.ascontiguousarray(index.get_centroids()).tobytes(), zlib.crc32(np.ascontiguousarray(lens).tobytes()))
+        mp, mf = capi.assign_stats()
         log(f"[bench] corpus {n}x{d} generated in {t_gen:.1f}s; build_index (k-means {int(index.iterations[0])} iters + final assign) "
-            f"{t_build:.1f}s; cost {float(index.cost):.1f}; list len min/mean/max {int(lens.min())}/{lens.mean():.0f}/{int(lens.max())}")
+            f"{t_build:.1f}s; cost {float(index.cost):.1f} (bits {np.float32(index.cost).view(np.uint32):#010x}); "
+            f"list len min/mean/max {int(lens.min())}/{lens.mean():.0f}/{int(lens.max())}; "
+            f"index fingerprint (centroid bits + list lengths) {fp:#010x}; matrix-core assign: {mp} points, {mf} re-done exactly")
     if world > 1 and rank == 0:
         own = index.owners()
         log(f"[bench] lists sharded over {world} ranks (LPT): rows per rank "

@@ -93,6 +93,10 @@ int32_t vers_flat_last_scan_ms(vers_flat_t* h, float* out_ms);
 int32_t vers_kmeans_assign(int32_t device, const float* rows, uint64_t n, uint64_t row_stride_bytes,
                            const float* centroids, uint64_t k, uint64_t c_stride_bytes, uint32_t d,
                            uint64_t* out_assign, float* out_min_dist);
+/* Diagnostics of the matrix-core assign path (large builds; VERS_ASSIGN=1 forces the exact scan, =2 the
+ * matrix cores): process-wide number of points assigned through it and how many of those failed the
+ * certificate and were re-done by the exact scan.  Results are bit-identical either way. */
+int32_t vers_assign_stats(uint64_t* out_points, uint64_t* out_fallbacks, int32_t reset);
 /* IVFFlatIndex::update_centroids (ivfflat.rs:47-71): per cluster the f32 sum
  * of its members in ascending row order divided by the count; empty cluster
  * -> zero vector.  out_centroids is packed [k * d]. */

@@ -11,12 +11,12 @@ out=sys.argv[1]
 cnt=collections.defaultdict(list)
 for f in glob.glob(out+'/pmc/**/*counter_collection.csv',recursive=True):
     for r in csv.DictReader(open(f)):
-        if 'coarse_gemm' in r['Kernel_Name']: cnt[r['Counter_Name']].append(float(r['Counter_Value']))
+        if 'dist_gemm_kernel<false' in r['Kernel_Name']: cnt[r['Counter_Name']].append(float(r['Counter_Value']))
 dur=[]
 for f in glob.glob(out+'/trace/**/*kernel_trace.csv',recursive=True):
     for r in csv.DictReader(open(f)):
-        if 'coarse_gemm' in r['Kernel_Name']: dur.append((int(r['End_Timestamp'])-int(r['Start_Timestamp']))/1e3)
-print("coarse_gemm_kernel: [1024 x 768] . [768 x 4096] f32, v_mfma_f32_32x32x2_f32")
+        if 'dist_gemm_kernel<false' in r['Kernel_Name']: dur.append((int(r['End_Timestamp'])-int(r['Start_Timestamp']))/1e3)
+print("dist_gemm_kernel<false_kernel: [1024 x 768] . [768 x 4096] f32, v_mfma_f32_32x32x2_f32")
 for k,v in sorted(cnt.items()): print("  %-30s mean %.5g (n=%d)"%(k,sum(v)/len(v),len(v)))
 if dur:
     d=sum(dur)/len(dur); fl=2*1024*4096*768

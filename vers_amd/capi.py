@@ -69,6 +69,7 @@ SIGNATURES = {
     "vers_gen_rows_dev": (C.c_int32, [_vp, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint32,
                                       C.c_float, C.c_uint64, _vp]),
     "vers_kmeans_assign": (C.c_int32, [C.c_int32, _vp, C.c_uint64, C.c_uint64, _vp, C.c_uint64, C.c_uint64, C.c_uint32, _vp, _vp]),
+    "vers_assign_stats": (C.c_int32, [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_int32]),
     "vers_kmeans_update": (C.c_int32, [C.c_int32, _vp, C.c_uint64, C.c_uint64, _vp, C.c_uint64, C.c_uint32, _vp]),
     "vers_kmeans_cost": (C.c_int32, [C.c_int32, _vp, C.c_uint64, C.c_uint64, _vp, C.c_uint64, C.c_uint64, _vp, C.c_uint32,
                                      C.POINTER(C.c_float)]),
@@ -222,3 +223,10 @@ def shard_plan(list_lengths, world: int) -> np.ndarray:
     owner = np.zeros(max(lens.size, 1), dtype=np.uint8)
     check(lib().vers_shard_plan(_ptr(lens), lens.size, world, _ptr(owner)))
     return owner[:lens.size]
+
+
+def assign_stats(reset=False):
+    """(points assigned through the matrix-core path, of which re-done exactly) -- process-wide diagnostics."""
+    a, b = C.c_uint64(0), C.c_uint64(0)
+    check(lib().vers_assign_stats(C.byref(a), C.byref(b), 1 if reset else 0))
+    return int(a.value), int(b.value)

@@ -46,9 +46,13 @@ static __global__ void row_norms_kernel(const float* C, uint32_t ld, uint32_t k,
 // M_pad % 128 == 0, N_pad % 128 == 0.  Block = 4 waves, 128 x 128 tile; wave = 64 x 64 (2 x 2 MFMA tiles).
 // LDS tiles hold k permuted as [row][h = k & 1][s = k >> 1] so that lane (r, h) reads its 16 operands
 // of a K-tile (k = 2s + h) as four contiguous ds_read_b128.
-static __global__ __launch_bounds__(256) void coarse_gemm_kernel(const float* __restrict__ Q, const float* __restrict__ C,
-                                                                 const float* __restrict__ cnorm, uint32_t K, uint32_t N_pad,
-                                                                 float* __restrict__ G) {
+// NORM_ROWS = false: G[m][n] = norm[n] - 2 dot (coarse quantiser: m = query, n = centroid);
+// NORM_ROWS = true : G[m][n] = norm[m] - 2 dot (k-means assign: m = centroid, n = point, so that a point's
+//                    values are a coalesced column walk for the per-point selection).
+template <bool NORM_ROWS>
+static __global__ __launch_bounds__(256) void dist_gemm_kernel(const float* __restrict__ Q, const float* __restrict__ C,
+                                                               const float* __restrict__ cnorm, uint32_t K, uint32_t N_pad,
+                                                               float* __restrict__ G) {
   __shared__ __attribute__((aligned(16))) float As[kGemmBM * kGemmLds];
   __shared__ __attribute__((aligned(16))) float Bs[kGemmBN * kGemmLds];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -113,11 +117,11 @@ static __global__ __launch_bounds__(256) void coarse_gemm_kernel(const float* __
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
       const uint32_t n = n0 + wc * 64 + b * 32 + r;
-      const float cn = cnorm[n];
+      const float cn = NORM_ROWS ? 0.0f : cnorm[n];
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const uint32_t m = m0 + wr * 64 + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
-        G[(uint64_t)m * N_pad + n] = cn - 2.0f * acc[a][b][e];
+        G[(uint64_t)m * N_pad + n] = (NORM_ROWS ? cnorm[m] : cn) - 2.0f * acc[a][b][e];
       }
     }
 }
@@ -200,6 +204,95 @@ static __global__ __launch_bounds__(kWave) void coarse_select_rescore_kernel(
   }
   if (lane < (int)P) probe[(uint64_t)q * P + lane] = lane < (int)Pq ? exact : kKeyMax;
   if (__ballot(nan_seen) != 0 && lane == 0) atomicOr(status, 1u);
+}
+
+// ---- k-means assign through the matrix cores (ivfflat.rs:29-46) -----------------------------------------
+// Gt[c][i] = |c|^2 - 2 <x_i, c> for a batch of points (dist_gemm_kernel<true>).  Per point: best and
+// second-best approximate value over all centroids (thread per point, coalesced column walk).
+static __global__ void assign_argmin2_kernel(const float* Gt, uint32_t n_pad, uint32_t k, uint32_t nb, uint32_t* best, float* g2) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nb) return;
+  float v1 = __builtin_inff(), v2 = __builtin_inff();
+  uint32_t c1 = 0;
+  bool nan = false;
+#pragma unroll 8
+  for (uint32_t c = 0; c < k; ++c) {
+    const float g = Gt[(uint64_t)c * n_pad + i];
+    nan |= g != g;
+    if (g < v1) { v2 = v1; v1 = g; c1 = c; }  // strict: the first of equal values stays the candidate
+    else if (g < v2 || g == v1) v2 = g;       // a tie with the candidate is NOT certified (v2 == v1)
+  }
+  best[i] = c1;
+  g2[i] = nan ? __builtin_nanf("") : v2;      // NaN / inf never certify (assign_rescore_kernel)
+}
+
+// Exact D(x_i, c_best) in reference arithmetic (one lane per point) + certificate: every other centroid has
+// approximate value >= g2, hence exact distance >= g2 + |x|^2 - E; if the candidate's exact distance is strictly
+// below that it is the unique first minimum.  Otherwise the point is queued for the exact scan.
+static __global__ void assign_rescore_kernel(const float* X, uint32_t ldx, const float* C_rm, uint32_t ldc, uint32_t d, uint32_t d_pad,
+                                             const float* cmax2_dev, const uint32_t* best, const float* g2, uint32_t nb, uint32_t k,
+                                             uint32_t i_base, uint32_t* assign, float* mind, uint32_t* fb_list, uint32_t* fb_count,
+                                             uint32_t* status) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nb) return;
+  const uint32_t c = best[i];
+  const float* x = X + (uint64_t)i * ldx;
+  const float* cv = C_rm + (uint64_t)c * ldc;
+  float acc = 0.0f, xn = 0.0f;
+  uint32_t j = 0;
+  if (((ldx | ldc) & 3u) == 0) {
+    for (; j + 4 <= d; j += 4) {
+      const f32x4 x4 = *reinterpret_cast<const f32x4*>(x + j);
+      const f32x4 c4 = *reinterpret_cast<const f32x4*>(cv + j);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float t = __fsub_rn(x4[u], c4[u]);  // data_point.squared_euclidean(centroid): ivfflat.rs:37
+        acc = __fadd_rn(acc, __fmul_rn(t, t));
+        xn = __fadd_rn(xn, __fmul_rn(x4[u], x4[u]));
+      }
+    }
+  }
+  for (; j < d; ++j) {
+    const float t = __fsub_rn(x[j], cv[j]);
+    acc = __fadd_rn(acc, __fmul_rn(t, t));
+    xn = __fadd_rn(xn, __fmul_rn(x[j], x[j]));
+  }
+  const float tau = g2[i];
+  const float E = (5.0f * (float)d_pad + 16.0f) * 5.9604645e-08f * (xn + *cmax2_dev);
+  const float lower = tau + xn - E;  // NaN if anything overflowed
+  const bool finite = tau < __builtin_inff() && E < __builtin_inff();
+  const bool certified = k == 1 || (finite && acc < lower);
+  assign[i] = c;
+  if (mind) mind[i] = acc;
+  if (!certified) fb_list[atomicAdd(fb_count, 1u)] = i + i_base;
+  else if (acc != acc) atomicOr(status, 1u);
+}
+
+// max over the finite-or-inf |c|^2 (NaN never raises it: such centroids fail every certificate through G)
+static __global__ __launch_bounds__(256) void max_norm_kernel(const float* cnorm, uint32_t k, float* out) {
+  __shared__ float sh[256];
+  float m = 0.0f;
+  for (uint32_t c = threadIdx.x; c < k; c += 256) m = fmaxf(m, cnorm[c]);
+  sh[threadIdx.x] = m;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if ((int)threadIdx.x < off) sh[threadIdx.x] = fmaxf(sh[threadIdx.x], sh[threadIdx.x + off]);
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) *out = sh[0];
+}
+
+static __global__ void gather_points_kernel(const float* X, uint32_t ldx, const uint32_t* list, uint32_t n_list, float* out) {
+  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= (uint64_t)n_list * ldx) return;
+  out[t] = X[(uint64_t)list[t / ldx] * ldx + t % ldx];
+}
+static __global__ void scatter_assign_kernel(const uint32_t* list, uint32_t n_list, const uint32_t* a_in, const float* m_in,
+                                             uint32_t* assign, float* mind) {
+  const uint32_t t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t >= n_list) return;
+  assign[list[t]] = a_in[t];
+  if (mind) mind[list[t]] = m_in[t];
 }
 
 }  // namespace vers

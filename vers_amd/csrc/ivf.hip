@@ -680,6 +680,7 @@ int32_t run_build(vers_ivf* h, const float* X, uint32_t ldx, uint64_t n, uint32_
   uint32_t* flag_dev = h->km.misc.as<uint32_t>() + 4;
   float best = INFINITY;
   *out_kept = 0;
+  const bool mfma = km_use_mfma(n, k, h->d);
   std::vector<uint32_t> idx32(k ? k : 1);
   for (uint64_t a = 0; a < num_attempts; ++a) {
     if (n > 0 && k == 0) return fail(VERS_ERR_EMPTY, "build_index with zero clusters: min_by over no centroids (reference panics)");
@@ -697,7 +698,7 @@ int32_t run_build(vers_ivf* h, const float* X, uint32_t ldx, uint64_t n, uint32_
     }
     uint64_t iters = 0;
     for (uint64_t it = 0; it < max_iterations; ++it) {
-      if (int32_t rc = km_assign(X, ldx, n, C.as<float>(), ld, k, h->d, assign.as<uint32_t>(), nullptr, h->km, h->n_cu, st)) return rc;
+      if (int32_t rc = (mfma ? km_assign_mfma : km_assign)(X, ldx, n, C.as<float>(), ld, k, h->d, assign.as<uint32_t>(), nullptr, h->km, h->n_cu, st)) return rc;
       if (int32_t rc = km_group(assign.as<uint32_t>(), (uint32_t)n, k, sorted.as<uint32_t>(), counts, starts, h->km, st)) return rc;
       if (int32_t rc = km_update(X, ldx, sorted.as<uint32_t>(), starts, k, Cn.as<float>(), ld, st)) return rc;
       if (int32_t rc = km_differs(C.as<float>(), Cn.as<float>(), (uint64_t)k * ld, flag_dev, st)) return rc;
@@ -710,7 +711,7 @@ int32_t run_build(vers_ivf* h, const float* X, uint32_t ldx, uint64_t n, uint32_
       std::swap(C.cap, Cn.cap);
     }
     if (out_iterations) out_iterations[a] = iters;
-    if (int32_t rc = km_assign(X, ldx, n, C.as<float>(), ld, k, h->d, assign.as<uint32_t>(), mind.as<float>(), h->km, h->n_cu, st)) return rc;
+    if (int32_t rc = (mfma ? km_assign_mfma : km_assign)(X, ldx, n, C.as<float>(), ld, k, h->d, assign.as<uint32_t>(), mind.as<float>(), h->km, h->n_cu, st)) return rc;
     if (int32_t rc = km_cost_fold(mind.as<float>(), n, cost_dev, st)) return rc;
     float cost = 0.0f;
     uint32_t stw = 0;
@@ -822,7 +823,7 @@ int32_t coarse(vers_ivf* h, const float* qp, uint32_t b, uint32_t P, hipStream_t
     const uint32_t PS = std::min<uint32_t>(kMaxTopK, P + 16);
     if (int32_t rc = h->gbuf.reserve((size_t)M_pad * h->k_pad * sizeof(float))) return rc;
     if (int32_t rc = h->probe.reserve((size_t)b * P * sizeof(uint64_t))) return rc;
-    hipLaunchKernelGGL(coarse_gemm_kernel, dim3(h->k_pad / kGemmBN, M_pad / kGemmBM), dim3(256), 0, st, qp, h->centroids_g.as<float>(),
+    hipLaunchKernelGGL(dist_gemm_kernel<false>, dim3(h->k_pad / kGemmBN, M_pad / kGemmBM), dim3(256), 0, st, qp, h->centroids_g.as<float>(),
                        h->cnorm.as<float>(), h->ldq, h->k_pad, h->gbuf.as<float>());
     VERS_HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(coarse_select_rescore_kernel, dim3(b), dim3(kWave), 0, st, h->gbuf.as<float>(), h->k_pad, h->k,

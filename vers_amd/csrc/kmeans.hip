@@ -8,10 +8,13 @@
 //   update : per (cluster, column) the sum over members in ascending point index, then / count.
 //   cost   : strict left-to-right fold of the per-point minimum distances (one lane: the fold is
 //            inherently serial; it reads 4 bytes per point and is ~1e-3 of an assign pass).
+#include <atomic>
+#include <cstdlib>
 #include <mutex>
 #include <vector>
 
 #include "kmeans.hpp"
+#include "gemm.cuh"
 #include "scan.cuh"
 #include "util.cuh"
 
@@ -112,6 +115,85 @@ int32_t km_assign(const float* X, uint32_t ldx, uint64_t n, const float* C, uint
     VERS_HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(keys_to_assign_kernel, dim3((nb + 255) / 256), dim3(256), 0, st, ws.keys.as<uint64_t>(), nb,
                        out_assign + i0, out_mind ? out_mind + i0 : nullptr);
+    VERS_HIP_TRY(hipGetLastError());
+  }
+  return VERS_OK;
+}
+
+// ---- assign through the matrix cores ------------------------------------------------------
+static std::atomic<uint64_t> g_mfma_points{0}, g_mfma_fallbacks{0};
+
+bool km_use_mfma(uint64_t n, uint32_t k, uint32_t d) {
+  static const int mode = [] {
+    const char* e = getenv("VERS_ASSIGN");
+    return e ? atoi(e) : 0;
+  }();
+  if (k < 2 || n == 0) return false;
+  if (mode == 1) return false;
+  if (mode == 2) return true;
+  return (double)n * k * d >= 1e11;  // below this the exact scan is a few ms and the extra launches do not pay
+}
+
+int32_t km_assign_mfma(const float* X, uint32_t ldx, uint64_t n, const float* C, uint32_t ldc, uint32_t k, uint32_t d,
+                       uint32_t* out_assign, float* out_mind, KMeansScratch& ws, int n_cu, hipStream_t st) {
+  if (n == 0) return VERS_OK;
+  const uint32_t ldq = round_up(d, kColAlign);
+  const uint32_t k_pad = round_up(k, kGemmBM);
+  if (int32_t rc = ws.cg.reserve((size_t)k_pad * ldq * sizeof(float))) return rc;
+  if (int32_t rc = ws.cnorm.reserve(((size_t)k_pad + 4) * sizeof(float))) return rc;
+  if (int32_t rc = ws.status.reserve(16)) return rc;
+  if (int32_t rc = ws.fb.reserve((n + 4) * sizeof(uint32_t))) return rc;
+  uint32_t* fb_list = ws.fb.as<uint32_t>();
+  uint32_t* fb_count = fb_list + n;
+  float* cmax2_dev = ws.cnorm.as<float>() + k_pad;
+  VERS_HIP_TRY(hipMemsetAsync(ws.cg.p, 0, (size_t)k_pad * ldq * sizeof(float), st));
+  VERS_HIP_TRY(hipMemsetAsync(fb_count, 0, sizeof(uint32_t), st));
+  if (int32_t rc = launch_stage_queries(C, ldc, d, ws.cg.as<float>(), ldq, k, 1, st)) return rc;
+  hipLaunchKernelGGL(row_norms_kernel, dim3((k_pad + 255) / 256), dim3(256), 0, st, ws.cg.as<float>(), ldq, k, k_pad, ws.cnorm.as<float>());
+  hipLaunchKernelGGL(max_norm_kernel, dim3(1), dim3(256), 0, st, ws.cnorm.as<float>(), k, cmax2_dev);
+  VERS_HIP_TRY(hipGetLastError());
+  // point batch: Gt stays <= 2 GiB
+  uint64_t mb = ((1ull << 31) / ((uint64_t)k_pad * 4)) / kGemmBN * kGemmBN;
+  if (mb > 131072) mb = 131072;
+  if (mb < (uint64_t)kGemmBN) mb = kGemmBN;
+  if (mb > round_up64(n, kGemmBN)) mb = round_up64(n, kGemmBN);
+  if (int32_t rc = ws.gt.reserve((size_t)k_pad * mb * sizeof(float))) return rc;
+  if (int32_t rc = ws.best.reserve(mb * 8)) return rc;
+  uint32_t* best = ws.best.as<uint32_t>();
+  float* g2 = ws.best.as<float>() + mb;
+  const bool in_place_ok = ldx == ldq;
+  for (uint64_t i0 = 0; i0 < n; i0 += mb) {
+    const uint32_t nb = (uint32_t)((n - i0 < mb) ? (n - i0) : mb);
+    const uint32_t nb_pad = round_up(nb, kGemmBN);
+    const float* xb = X + i0 * ldx;
+    if (!in_place_ok || nb_pad != nb) {  // pad the columns / the tail rows through a staged copy
+      if (int32_t rc = ws.xp.reserve((size_t)mb * ldq * sizeof(float))) return rc;
+      if (nb_pad != nb) VERS_HIP_TRY(hipMemsetAsync(ws.xp.as<float>() + (size_t)nb * ldq, 0, (size_t)(nb_pad - nb) * ldq * sizeof(float), st));
+      if (int32_t rc = launch_stage_queries(xb, ldx, d, ws.xp.as<float>(), ldq, nb, 1, st)) return rc;
+      xb = ws.xp.as<float>();
+    }
+    hipLaunchKernelGGL(dist_gemm_kernel<true>, dim3(nb_pad / kGemmBN, k_pad / kGemmBM), dim3(256), 0, st, ws.cg.as<float>(), xb,
+                       ws.cnorm.as<float>(), ldq, nb_pad, ws.gt.as<float>());
+    hipLaunchKernelGGL(assign_argmin2_kernel, dim3((nb + 255) / 256), dim3(256), 0, st, ws.gt.as<float>(), nb_pad, k, nb, best, g2);
+    hipLaunchKernelGGL(assign_rescore_kernel, dim3((nb + 63) / 64), dim3(64), 0, st, X + i0 * ldx, ldx, C, ldc, d, ldq, cmax2_dev, best, g2,
+                       nb, k, (uint32_t)i0, out_assign + i0, out_mind ? out_mind + i0 : nullptr, fb_list, fb_count, ws.status.as<uint32_t>());
+    VERS_HIP_TRY(hipGetLastError());
+  }
+  uint32_t nf = 0;
+  VERS_HIP_TRY(hipMemcpyAsync(&nf, fb_count, 4, hipMemcpyDeviceToHost, st));
+  VERS_HIP_TRY(hipStreamSynchronize(st));
+  g_mfma_points += n;
+  g_mfma_fallbacks += nf;
+  if (nf) {  // uncertified points: the exact scan decides (order of fb_list is irrelevant: results are scattered by index)
+    if (int32_t rc = ws.xf.reserve((size_t)nf * ldx * sizeof(float))) return rc;
+    if (int32_t rc = ws.fa.reserve((size_t)nf * 4)) return rc;
+    if (int32_t rc = ws.fm.reserve((size_t)nf * 4)) return rc;
+    const uint64_t words = (uint64_t)nf * ldx;
+    hipLaunchKernelGGL(gather_points_kernel, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st, X, ldx, fb_list, nf, ws.xf.as<float>());
+    VERS_HIP_TRY(hipGetLastError());
+    if (int32_t rc = km_assign(ws.xf.as<float>(), ldx, nf, C, ldc, k, d, ws.fa.as<uint32_t>(), ws.fm.as<float>(), ws, n_cu, st)) return rc;
+    hipLaunchKernelGGL(scatter_assign_kernel, dim3((nf + 255) / 256), dim3(256), 0, st, fb_list, nf, ws.fa.as<uint32_t>(), ws.fm.as<float>(),
+                       out_assign, out_mind);
     VERS_HIP_TRY(hipGetLastError());
   }
   return VERS_OK;
@@ -316,8 +398,8 @@ int32_t vers_kmeans_assign(int32_t device, const float* rows, uint64_t n, uint64
   if (int32_t rc = M.reserve(n * sizeof(float))) return rc;
   if (int32_t rc = ws.status.reserve(16)) return rc;
   VERS_HIP_TRY(hipMemset(ws.status.p, 0, 16));
-  if (int32_t rc = km_assign(X.as<float>(), ld, n, C.as<float>(), ld, (uint32_t)k, d, A.as<uint32_t>(), M.as<float>(), ws, n_cu,
-                             nullptr))
+  if (int32_t rc = (km_use_mfma(n, (uint32_t)k, d) ? km_assign_mfma : km_assign)(X.as<float>(), ld, n, C.as<float>(), ld, (uint32_t)k, d,
+                                                                                 A.as<uint32_t>(), M.as<float>(), ws, n_cu, nullptr))
     return rc;
   VERS_HIP_TRY(hipDeviceSynchronize());
   if (int32_t rc = check_status_word(ws.status, (uint32_t)k)) return rc;
@@ -325,6 +407,13 @@ int32_t vers_kmeans_assign(int32_t device, const float* rows, uint64_t n, uint64
   VERS_HIP_TRY(hipMemcpy(a32.data(), A.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
   for (uint64_t i = 0; i < n; ++i) out_assign[i] = a32[i];
   if (out_min_dist) VERS_HIP_TRY(hipMemcpy(out_min_dist, M.p, n * sizeof(float), hipMemcpyDeviceToHost));
+  return VERS_OK;
+}
+
+int32_t vers_assign_stats(uint64_t* out_points, uint64_t* out_fallbacks, int32_t reset) {
+  if (out_points) *out_points = g_mfma_points.load();
+  if (out_fallbacks) *out_fallbacks = g_mfma_fallbacks.load();
+  if (reset) { g_mfma_points = 0; g_mfma_fallbacks = 0; }
   return VERS_OK;
 }
 

@@ -29,6 +29,14 @@ struct KMeansScratch {
   DevBuf status;    // u32 status word(s)
   DevBuf counts;    // u32 [k] + starts [k+1]
   DevBuf misc;      // cost scalar, equality flag
+  // matrix-core assign (km_assign_mfma)
+  DevBuf cg;        // centroids row-major [k_pad][ldq], zero padded
+  DevBuf cnorm;     // |c|^2 [k_pad] (+inf padding) + max at [k_pad]
+  DevBuf xp;        // staged point batch [mb][ldq] when X cannot be used in place
+  DevBuf gt;        // Gt [k_pad][mb]
+  DevBuf best;      // u32 [mb] candidate + f32 [mb] second-best value
+  DevBuf fb;        // u32 [n] uncertified points + counter at [n]
+  DevBuf xf, fa, fm;  // gathered uncertified points and their exact results
 };
 
 // assign_to_clusters (ivfflat.rs:29-46): out_assign[i] = first argmin_c D(X[i], C[c]);
@@ -36,6 +44,14 @@ struct KMeansScratch {
 // status bit0 is set on a NaN distance.  X [n][ldx], C [k][ldc] row-major (pad columns zero).
 int32_t km_assign(const float* X, uint32_t ldx, uint64_t n, const float* C, uint32_t ldc, uint32_t k, uint32_t d,
                   uint32_t* out_assign, float* out_mind, KMeansScratch& ws, int n_cu, hipStream_t st);
+
+// Same contract and same bits as km_assign, through the f32 matrix cores: Gt = |c|^2 - 2 C X^T per point batch,
+// per-point best / second-best approximate value, exact re-score of the candidate in the reference's arithmetic,
+// certificate, and the exact scan (km_assign) for the points that fail it.  Synchronises the stream once.
+int32_t km_assign_mfma(const float* X, uint32_t ldx, uint64_t n, const float* C, uint32_t ldc, uint32_t k, uint32_t d,
+                       uint32_t* out_assign, float* out_mind, KMeansScratch& ws, int n_cu, hipStream_t st);
+// policy: VERS_ASSIGN = 1 exact scan, 2 matrix cores always, otherwise by problem size
+bool km_use_mfma(uint64_t n, uint32_t k, uint32_t d);
 
 // counts[k], starts[k+1] (exclusive prefix), sorted_ids[n] grouped by cluster, ascending inside.
 int32_t km_group(const uint32_t* assign, uint32_t n, uint32_t k, uint32_t* sorted_ids, uint32_t* counts, uint32_t* starts,
