@@ -178,14 +178,22 @@ def main():
     achieved = algo_bytes / (scan_mean_ms * 1e-3) / 1e9
     # HBM traffic of the same kernel from the PMC passes of the committed rocprofv3 run (bench.py cannot collect
     # counters itself); used only when it was measured on this exact configuration.
+    pst = index.prescan_stats()
+    mfma_scan = pst["batches"] > 0
+    kernel_name = ("prescan_kernel<IvfSrc<16>> (inverted-list scan on the f32 matrix cores; exact finish in ivf_rescore_kernel)" if mfma_scan
+                   else "scan_kernel<QG,0,IvfSrc<QG>> (inverted-list scan, ordered f32 chains; QG = 16 at this shape)")
     traffic = None
     try:
         tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
-        if tj["config"] == {"rows": n, "d": d, "nlist": nlist, "nprobe": nprobe, "batch": B} and world == 1:
+        if (tj["config"] == {"rows": n, "d": d, "nlist": nlist, "nprobe": nprobe, "batch": B} and world == 1
+                and tj["kernel"].startswith("prescan_kernel") == mfma_scan):
             traffic = tj["hbm_read_bytes_per_launch"]
     except (OSError, KeyError, ValueError):
         pass
-    roofline = {"bound": "hbm", "kernel": "scan_kernel<QG,0,IvfSrc<QG>> (inverted-list scan; QG = 16 at this shape)", "achieved": round(achieved, 1),
+    if rank == 0:
+        log(f"[bench] list scan on the matrix cores: {pst['batches']} batches, {pst['fallback_queries']} queries failed the certificate "
+            f"and were re-scanned exactly")
+    roofline = {"bound": "hbm", "kernel": kernel_name, "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
                 "algorithmic_bytes_per_launch": int(algo_bytes), "streamed_bytes_per_launch": int(ls["streamed_rows"] * d * 4),
                 "launch_ms": round(scan_mean_ms, 4), "launches_timed": int(len(scan_ms)), "work_items": int(ls["items"])}

@@ -204,6 +204,10 @@ int32_t vers_topk_merge_dev(const uint64_t* keys_dev, const uint64_t* ids_dev, u
 /* Batched coarse quantiser statistics: batches that went through the MFMA pre-selection (f32 matrix cores +
  * exact re-score + certificate, csrc/gemm.cuh) and queries whose certificate failed and were re-done exactly. */
 int32_t vers_ivf_coarse_stats(vers_ivf_t* h, uint64_t* out_mfma_batches, uint64_t* out_fallback_queries);
+/* Batched list scan statistics (nprobe mode): batches whose list scan ran on the matrix cores (pre-selection +
+ * exact re-score + certificate, csrc/prescan.cuh) and queries whose certificate failed and were re-scanned
+ * exactly.  Results are bit-identical either way; VERS_PRESCAN=0 keeps the ordered-chain scan for every batch. */
+int32_t vers_ivf_prescan_stats(vers_ivf_t* h, uint64_t* out_batches, uint64_t* out_fallback_queries);
 /* Durations (ms) of the most recent list-scan launches, oldest first (ring of 64); reset != 0
  * empties the ring.  Lets bench.py time every launch of the timed region without stalling it. */
 int32_t vers_ivf_scan_times(vers_ivf_t* h, float* out_ms, uint32_t cap, uint32_t* out_n, int32_t reset);

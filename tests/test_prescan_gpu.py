@@ -1,0 +1,91 @@
+"""Batched list scan on the f32 matrix cores (csrc/prescan.cuh): MFMA pre-selection + exact re-score + certificate
++ exact re-scan of uncertified queries must return the SAME bits as the ordered-chain scan and the oracle --
+ids, order, distance bits -- on clustered, uniform and heavily tied data, ragged lists, after add(), and with the
+certificate forced to fail."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+BODY = r'''
+import numpy as np
+from oracle import c_oracle as co
+from tests import datagen as dg
+from tests.golden import make_golden as mg
+from vers_amd.index import IVFFlatIndex
+
+def check(ix, Q, top_k, nprobe, step=7):
+    ids, dist, cnt = ix.search_batch(Q, top_k, nprobe)
+    for qi in range(0, Q.shape[0], step):
+        oi, od = co.search_nprobe(ix.values, ix.centroids, ix.ids, Q[qi], top_k, nprobe)
+        assert cnt[qi] == len(oi), (nprobe, top_k, qi, cnt[qi], len(oi))
+        assert np.array_equal(ids[qi, :len(oi)], oi), (nprobe, top_k, qi, ids[qi, :len(oi)], oi)
+        assert np.array_equal(dist[qi, :len(oi)].view(np.uint32), od.view(np.uint32)), (nprobe, top_k, qi)
+
+total = 0
+# (1) clustered data, several shapes (d = 300 pads to 320 columns; lists are ragged: lengths not multiples of 64)
+for seed, n, d, k, b, nprobe, top_ks in [(0x81, 9000, 96, 48, 160, 8, (1, 10, 26)), (0x82, 5000, 300, 32, 96, 6, (10,)),
+                                         (0x83, 3000, 768, 24, 80, 5, (10, 20))]:
+    X = dg.dist_c(seed, n, d, 4 * k, dg.default_sigma(d))
+    ix = IVFFlatIndex.build_index(k, 1, 3, X, init_indices=mg.init_draws(seed, 1, k, n))
+    Q = dg.dist_c(seed + 0x100, b, d, 4 * k, dg.default_sigma(d)); Q[3] = X[17]
+    for top_k in top_ks:
+        check(ix, Q, top_k, nprobe)
+        total += 1
+    if seed == 0x81:
+        for i in range(70):  # add(): the new rows' norms are maintained incrementally; one list outgrows its slack
+            ix.add(Q[i % 5] * np.float32(1.0 + i / 512.0), 0)
+        check(ix, Q, 10, nprobe)
+        total += 1
+        check(ix, Q, 27, nprobe)   # top_k + slack > 32 keys: stays on the ordered-chain scan
+# (2) uniform data: distances concentrate, many near-ties around the k-th
+X = dg.dist_u(0x91, 6000, 64)
+ix = IVFFlatIndex.build_index(40, 1, 2, X, init_indices=mg.init_draws(0x91, 1, 40, 6000))
+check(ix, dg.dist_u(0x92, 128, 64), 10, 8)
+total += 1
+# (3) heavy ties: every vector stored 40 times -> exact ties far denser than the slack; seq order must decide
+B = dg.dist_c(0xA1, 150, 32, 30, dg.default_sigma(32))
+X = np.repeat(B, 40, axis=0)
+ix = IVFFlatIndex.build_index(16, 1, 2, X, init_indices=mg.init_draws(0xA1, 1, 16, X.shape[0]))
+Q = dg.dist_c(0xA2, 64, 32, 30, dg.default_sigma(32)); Q[0] = B[5]
+check(ix, Q, 10, 6, step=3)
+total += 1
+st = ix.prescan_stats()
+print("TIES", st["batches"], st["fallback_queries"])
+# (4) large magnitudes: |x|^2 overflows while the distances stay finite -> nothing is finite on the matrix cores,
+#     every query is re-scanned exactly
+big = lambda s, n: (np.float32(1.5e19) * (np.float32(1.0) + np.float32(1e-3) * dg.dist_u(s, n, 16))).astype(np.float32)
+X = big(0xB1, 2000)
+ix = IVFFlatIndex.build_index(8, 1, 2, X, init_indices=mg.init_draws(0xB1, 1, 8, 2000))
+check(ix, big(0xB2, 64), 5, 4, step=5)
+st = ix.prescan_stats()
+print("HUGE", st["batches"], st["fallback_queries"])
+print("TOTAL", total)
+'''
+
+
+def run(env_extra):
+    env = dict(os.environ); env.update(env_extra); env["PYTHONPATH"] = ROOT
+    r = subprocess.run([sys.executable, "-c", BODY], capture_output=True, text=True, env=env, cwd=ROOT, timeout=1200)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    return {l.split()[0]: tuple(int(v) for v in l.split()[1:]) for l in r.stdout.splitlines() if l[:4] in ("TIES", "HUGE", "TOTA")}
+
+
+def test_matrix_core_list_scan_is_bit_exact():
+    out = run({})
+    assert out["TIES"][0] == 1 and out["TIES"][1] > 0          # ties denser than the slack fail the certificate ...
+    assert out["HUGE"] == (1, 64)                               # ... and so does every query whose values overflow
+
+
+def test_forced_certificate_failure_is_exact():
+    out = run({"VERS_PRESCAN": "2"})
+    assert out["TIES"] == (1, 64)
+
+
+def test_ordered_chain_scan_still_available():
+    out = run({"VERS_PRESCAN": "0"})
+    assert out["TIES"] == (0, 0) and out["HUGE"] == (0, 0)

@@ -63,6 +63,7 @@ SIGNATURES = {
     "vers_ivf_search_partial_dev": (C.c_int32, [_vp, _vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, _vp, _vp, _vp]),
     "vers_topk_merge_dev": (C.c_int32, [_vp, _vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _vp, _vp, _vp, _vp]),
     "vers_ivf_coarse_stats": (C.c_int32, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "vers_ivf_prescan_stats": (C.c_int32, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "vers_ivf_scan_times": (C.c_int32, [_vp, _vp, C.c_uint32, C.POINTER(C.c_uint32), C.c_int32]),
     "vers_ivf_get_list": (C.c_int32, [_vp, C.c_uint64, _vp, C.c_uint64, _vp, C.c_uint64, C.POINTER(C.c_uint64)]),
     "vers_ivf_get_centroids": (C.c_int32, [_vp, _vp, C.c_uint64]),

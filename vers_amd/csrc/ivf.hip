@@ -21,6 +21,7 @@
 
 #include "gemm.cuh"
 #include "kmeans.hpp"
+#include "prescan.cuh"
 #include "scan.cuh"
 #include "util.cuh"
 
@@ -124,6 +125,10 @@ struct IvfSrc {
   __device__ __forceinline__ uint32_t pair_of(uint32_t it, int qi) const {
     const ItemDesc d = items[it];
     return pairs[pair_off[d.list] + d.group * QG + qi];
+  }
+  __device__ __forceinline__ uint32_t storage_row(uint32_t it) const {  // first storage row of the item
+    const ItemDesc d = items[it];
+    return list_off[d.list] + (d.seg != kNoSeg ? d.seg * seg_rows : 0u);
   }
   __device__ __forceinline__ uint32_t seq_base(uint32_t it, int qi) const {
     return pj_pref[pair_of(it, qi)] + items[it].seg * seg_rows;
@@ -346,16 +351,19 @@ __global__ __launch_bounds__(kWave * kMergeWaves) void plan1_kernel(
 }
 
 // interleaved query block of every group: qblocks[(g*ldq + col)*QG + qi]
+// mfma != 0 (QG == 16): the matrix-core operand layout of prescan.cuh, qblocks[(g*ldq/4 + c4)*64 + qi*4 + u] =
+// -2 * q[4 c4 + u] (the scaling is exact)
 __global__ void gather_qblocks_kernel(const GroupDesc* groups, const GroupTotals* tot, const uint32_t* pairs, uint32_t P,
-                                      const float* qp, uint32_t ldq, uint32_t QG, float* qblocks) {
+                                      const float* qp, uint32_t ldq, uint32_t QG, int mfma, float* qblocks) {
   const uint32_t g = blockIdx.x;
   if (g >= tot->n_groups) return;
   const GroupDesc gd = groups[g];
   for (uint32_t i = threadIdx.x; i < ldq * QG; i += blockDim.x) {
-    const uint32_t qi = i % QG, col = i / QG;
+    const uint32_t qi = mfma ? (i >> 2) & 15u : i % QG;
+    const uint32_t col = mfma ? ((i >> 6) << 2) + (i & 3u) : i / QG;
     float v = 0.0f;
     if (qi < gd.nq) v = qp[(uint64_t)(pairs[gd.pair_start + qi] / P) * ldq + col];
-    qblocks[(uint64_t)g * ldq * QG + i] = v;
+    qblocks[(uint64_t)g * ldq * QG + i] = mfma ? -2.0f * v : v;
   }
 }
 
@@ -544,6 +552,9 @@ struct vers_ivf {
   // scratch
   KMeansScratch km;
   DevBuf seg_bounds, stamps, quad_counter;
+  // matrix-core list scan (prescan.cuh): |x|^2 per storage row, [0] max |x|^2 bits, [1] certificate failures (running)
+  DevBuf xnorm, pre_misc, qfail, fb_part;
+  uint64_t pre_batches = 0;
   DevBuf qp, qil, cpart, probe, pj, lists, pairs, items, groups, qblocks, partials, status, o_ids, o_dist, o_cnt, xpart;
   static constexpr uint32_t kEvRing = 64;  // scan-launch timing ring (measurement hook)
   hipEvent_t ev0[kEvRing] = {}, ev1[kEvRing] = {};
@@ -569,6 +580,22 @@ int32_t sync_status(vers_ivf* h, hipStream_t st) {
       fail(VERS_ERR_INVALID, "search_approximate would spill past the ranked lists (48 through the MFMA pre-selection, 64 exact; deeper is unsupported)");
       return kRetrySpill;
     }
+  }
+  return VERS_OK;
+}
+
+// |x|^2 of storage rows [r_begin, r_end) for the matrix-core list scan; a full refresh also resets the maximum
+int32_t refresh_norms(vers_ivf* h, uint64_t r_begin, uint64_t r_end, hipStream_t st) {
+  if (int32_t rc = h->pre_misc.reserve(64)) return rc;
+  const bool full = r_begin == 0 && r_end == h->cap_rows;
+  if (full) {
+    if (int32_t rc = h->xnorm.reserve((h->cap_rows ? h->cap_rows : 1) * sizeof(float))) return rc;
+    VERS_HIP_TRY(hipMemsetAsync(h->pre_misc.p, 0, 64, st));
+  }
+  if (r_end > r_begin) {
+    hipLaunchKernelGGL(blocked_row_norms_kernel, dim3((unsigned)((r_end - r_begin + 255) / 256)), dim3(256), 0, st, h->rows.as<float>(), h->ld,
+                       h->row_ids.as<uint32_t>(), r_begin, r_end, h->xnorm.as<float>(), h->pre_misc.as<uint32_t>());
+    VERS_HIP_TRY(hipGetLastError());
   }
   return VERS_OK;
 }
@@ -639,7 +666,7 @@ int32_t build_storage(vers_ivf* h, const float* X, uint32_t ldx, uint64_t n, con
   for (uint32_t c = 0; c < k; ++c) h->cmax2 = std::max(h->cmax2, cn[c]);  // NaN centroids never raise it; they fail the certificate
   h->k = k;
   h->n_total = n;
-  return VERS_OK;
+  return refresh_norms(h, 0, h->cap_rows, st);
 }
 
 // index from (X, centroids already in h->centroids, device assignments)
@@ -910,6 +937,45 @@ int32_t launch_ivf_scan(vers_ivf* h, const IvfSrc<QG>& src, uint32_t items_bound
   return VERS_OK;
 }
 
+// the matrix-core list scan (prescan.cuh); timed through the same event ring as launch_ivf_scan
+int32_t launch_prescan(vers_ivf* h, const IvfSrc<kPreQ>& src, uint32_t items_bound, uint32_t kp, uint32_t* qflags, hipStream_t st) {
+  PreParams p;
+  p.ld = h->ld;
+  p.n_chunks = h->ld / kChunk;
+  p.kp = kp;
+  p.status = h->status.as<uint32_t>();
+  p.bounds32 = reinterpret_cast<uint32_t*>(h->partials.as<uint64_t>() + h->ivf_bounds_off);  // 0xFF-initialised with the slots
+  p.qflags = qflags;
+  p.xnorm = h->xnorm.as<float>();
+  p.debug = scan_debug_flags();
+  p.stamps = nullptr;
+  if (p.debug & 16u) {
+    if (int32_t rc = h->stamps.reserve(64)) return rc;
+    VERS_HIP_TRY(hipMemsetAsync(h->stamps.p, 0, 64, st));
+    p.stamps = h->stamps.as<unsigned long long>();
+  }
+  p.next_quad = nullptr;
+  if (!(p.debug & 32u)) {
+    if (int32_t rc = h->quad_counter.reserve(16)) return rc;
+    VERS_HIP_TRY(hipMemsetAsync(h->quad_counter.p, 0, 16, st));
+    p.next_quad = h->quad_counter.as<uint32_t>();
+  }
+  const size_t lds = prescan_lds_bytes(h->ld, kp);
+  if (int32_t rc = scan_prepare_launch(prescan_kernel<IvfSrc<kPreQ>>, lds)) return rc;
+  uint32_t blocks = (items_bound + kWavesPerBlock - 1) / kWavesPerBlock;
+  const uint32_t per_cu = std::max<uint32_t>(1, std::min<uint32_t>(2, (uint32_t)((160u * 1024u) / lds)));
+  const uint32_t max_blocks = (uint32_t)h->n_cu * per_cu;
+  if (blocks > max_blocks) blocks = max_blocks;
+  if (blocks == 0) blocks = 1;
+  const uint32_t slot = (uint32_t)(h->ev_count % vers_ivf::kEvRing);
+  VERS_HIP_TRY(hipEventRecord(h->ev0[slot], st));
+  hipLaunchKernelGGL((prescan_kernel<IvfSrc<kPreQ>>), dim3(blocks), dim3(kWave * kWavesPerBlock), lds, st, src, p);
+  VERS_HIP_TRY(hipGetLastError());
+  VERS_HIP_TRY(hipEventRecord(h->ev1[slot], st));
+  h->ev_count += 1;
+  return VERS_OK;
+}
+
 // search_approximate for b queries.  nprobe == 0: the reference's own semantics (nearest list,
 // spill while short; results concatenated per list).  nprobe >= 1: extension, global top-k
 // over the nprobe nearest lists.
@@ -939,6 +1005,14 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
   // once per group, so pick the width from the expected queries per list
   int QG = (b == 1 || pairs_est < 2 * lists_est) ? 1 : (pairs_est >= 6 * lists_est ? 16 : 8);
   if (const char* e = getenv("VERS_QG")) { const int q = atoi(e); if (QG != 1 && (q == 8 || q == 16)) QG = q; }  // tuning knob
+  // Batches in nprobe mode: the list scan runs on the matrix cores with an exact finish (prescan.cuh); same bits.
+  // VERS_PRESCAN=0 keeps the ordered-chain scan, =2 makes every certificate fail (exercises the exact fallback).
+  static const int pre_mode = [] { const char* e = getenv("VERS_PRESCAN"); return e ? atoi(e) : 1; }();
+  const uint32_t kp = std::min<uint32_t>(kPreMaxKp, std::max<uint32_t>(top_k + 6, top_k + top_k / 2));
+  const bool use_pre = QG != 1 && !ref_mode && pre_mode != 0 && top_k + 6 <= kPreMaxKp &&
+                       prescan_lds_bytes(h->ld, kp) <= 160u * 1024u;
+  if (use_pre) QG = kPreQ;
+  const uint32_t k_keep = use_pre ? kp : top_k;
   const uint64_t groups_bound = QG == 1 ? n_pj : (n_pj / QG + std::min<uint64_t>(h->k, n_pj));
   uint32_t seg_rows;
   if (b == 1) seg_rows = kWave;
@@ -965,7 +1039,7 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
   if (int32_t rc = h->groups.reserve(std::max<uint64_t>(1, groups_bound) * sizeof(GroupDesc))) return rc;
   if (QG != 1)
     if (int32_t rc = h->qblocks.reserve(groups_bound * h->ldq * QG * sizeof(float))) return rc;
-  h->ivf_bounds_off = (size_t)n_pj * S_max * top_k;
+  h->ivf_bounds_off = (size_t)n_pj * S_max * k_keep;
   const size_t part_bytes = (h->ivf_bounds_off + n_pj) * sizeof(uint64_t);  // slots + one bound per (query, probe)
   if (int32_t rc = h->partials.reserve(part_bytes)) return rc;
   uint32_t* pj_list = h->pj.as<uint32_t>();
@@ -1003,7 +1077,7 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
   VERS_HIP_TRY(hipGetLastError());
   if (QG != 1) {
     hipLaunchKernelGGL(gather_qblocks_kernel, dim3((unsigned)groups_bound), dim3(256), 0, st, h->groups.as<GroupDesc>(), tot,
-                       h->pairs.as<uint32_t>(), P, qp, h->ldq, (uint32_t)QG, h->qblocks.as<float>());
+                       h->pairs.as<uint32_t>(), P, qp, h->ldq, (uint32_t)QG, use_pre ? 1 : 0, h->qblocks.as<float>());
     VERS_HIP_TRY(hipGetLastError());
   }
   }  // b > 1
@@ -1011,11 +1085,39 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
     src.rows = h->rows.as<float>(); src.ld = h->ld; src.list_off = h->list_off.as<uint32_t>();
     src.list_len = h->list_len.as<uint32_t>(); src.items = h->items.as<ItemDesc>(); src.n_items_dev = &tot->n_items;
     src.cnt = cnt; src.pair_off = pair_off; src.pairs = h->pairs.as<uint32_t>(); src.group_off = group_off;
-    src.qblocks = h->qblocks.as<float>(); src.qp = qp; src.ldq = h->ldq; src.P = P; src.S_max = S_max; src.k_keep = top_k;
+    src.qblocks = h->qblocks.as<float>(); src.qp = qp; src.ldq = h->ldq; src.P = P; src.S_max = S_max; src.k_keep = k_keep;
     src.seg_rows = seg_rows; src.pj_pref = pj_pref; src.partials = h->partials.as<uint64_t>();
     src.bound_per_pair = ref_mode ? 1u : 0u;
   };
   int32_t rc;
+  if (use_pre) {
+    IvfSrc<kPreQ> src; fill_src(src);
+    // fail_list [b] + its count [1] (+3 pad) + qflags [n_pj]; partial lists of the exact re-scan
+    if (int32_t rc2 = h->qfail.reserve((b + 4 + n_pj) * sizeof(uint32_t))) return rc2;
+    if (int32_t rc2 = h->fb_part.reserve((size_t)n_pj * kMergeWaves * top_k * sizeof(uint64_t))) return rc2;
+    VERS_HIP_TRY(hipMemsetAsync(h->qfail.p, 0, (b + 4 + n_pj) * sizeof(uint32_t), st));
+    uint32_t* fail_list = h->qfail.as<uint32_t>();
+    uint32_t* qflags = fail_list + b + 4;
+    if (int32_t rc2 = launch_prescan(h, src, (uint32_t)items_bound, kp, qflags, st)) return rc2;
+    RescoreArgs a;
+    a.partials = h->partials.as<uint64_t>(); a.P = P; a.S_max = S_max; a.kp = kp; a.top_k = top_k; a.d_pad = h->ld;
+    a.pj_list = pj_list; a.pj_pref = pj_pref; a.list_off = h->list_off.as<uint32_t>(); a.row_ids = h->row_ids.as<uint32_t>();
+    a.rows = h->rows.as<float>(); a.ld = h->ld; a.qp = qp; a.ldq = h->ldq; a.xmax2_bits = h->pre_misc.as<uint32_t>();
+    a.qflags = qflags; a.force_fail = pre_mode == 2; a.fail_list = fail_list; a.stats = h->pre_misc.as<uint32_t>() + 1;
+    a.status = h->status.as<uint32_t>(); a.out_ids = out_ids; a.out_dist = out_dist; a.out_count = out_count; a.out_keys = out_keys;
+    hipLaunchKernelGGL(ivf_rescore_kernel, dim3(b), dim3(kWave * kMergeWaves), (size_t)h->ld * sizeof(float), st, a);
+    VERS_HIP_TRY(hipGetLastError());
+    const uint32_t fb_slots = std::min<uint32_t>(b, 64);
+    hipLaunchKernelGGL(fallback_scan_kernel, dim3(P, fb_slots), dim3(kWave * kMergeWaves), 0, st, a, (const uint32_t*)h->list_len.as<uint32_t>(),
+                       (const uint32_t*)fail_list, (const uint32_t*)(fail_list + b), h->fb_part.as<uint64_t>());
+    VERS_HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(fallback_merge_kernel, dim3(fb_slots), dim3(kWave * kMergeWaves), 0, st, a, (const uint32_t*)fail_list,
+                       (const uint32_t*)(fail_list + b), (const uint64_t*)h->fb_part.as<uint64_t>());
+    VERS_HIP_TRY(hipGetLastError());
+    h->pre_batches += 1;
+    h->tot_valid = true;
+    return VERS_OK;
+  }
   if (QG == 1) {
     IvfSrc<1> src; fill_src(src);
     rc = launch_ivf_scan(h, src, (uint32_t)items_bound, st);
@@ -1103,6 +1205,8 @@ int32_t relayout(vers_ivf* h) {
   std::swap(h->row_ids.p, nids.p); std::swap(h->row_ids.cap, nids.cap);
   h->h_off = noff; h->h_cap = ncap; h->cap_rows = off;
   VERS_HIP_TRY(hipMemcpy(h->list_off.p, h->h_off.data(), (size_t)k * 4, hipMemcpyHostToDevice));
+  if (int32_t rc = refresh_norms(h, 0, h->cap_rows, nullptr)) return rc;
+  VERS_HIP_TRY(hipDeviceSynchronize());
   return VERS_OK;
 }
 
@@ -1256,6 +1360,7 @@ int32_t vers_ivf_add(vers_ivf_t* h, const float* row, uint64_t* out_cluster, uin
                        h->rows.as<float>());
     VERS_HIP_TRY(hipGetLastError());
     VERS_HIP_TRY(hipMemcpy(h->row_ids.as<uint32_t>() + pos, &vid, 4, hipMemcpyHostToDevice));
+    if (int32_t rc = refresh_norms(h, pos, (uint64_t)pos + 1, nullptr)) return rc;
   }
   h->h_len[c] += 1;
   VERS_HIP_TRY(hipMemcpy(h->list_len.as<uint32_t>() + c, &h->h_len[c], 4, hipMemcpyHostToDevice));
@@ -1439,6 +1544,16 @@ int32_t vers_ivf_coarse_stats(vers_ivf_t* h, uint64_t* out_mfma_batches, uint64_
   uint32_t fb = 0;
   if (h->coarse_stat.p) VERS_HIP_TRY(hipMemcpy(&fb, h->coarse_stat.p, 4, hipMemcpyDeviceToHost));
   if (out_mfma_batches) *out_mfma_batches = h->mfma_batches;
+  if (out_fallback_queries) *out_fallback_queries = fb;
+  return VERS_OK;
+}
+
+int32_t vers_ivf_prescan_stats(vers_ivf_t* h, uint64_t* out_batches, uint64_t* out_fallback_queries) {
+  if (!h) return fail(VERS_ERR_INVALID, "null handle");
+  DeviceGuard g(h->device);
+  uint32_t fb = 0;
+  if (h->pre_misc.p) VERS_HIP_TRY(hipMemcpy(&fb, h->pre_misc.as<uint32_t>() + 1, 4, hipMemcpyDeviceToHost));
+  if (out_batches) *out_batches = h->pre_batches;
   if (out_fallback_queries) *out_fallback_queries = fb;
   return VERS_OK;
 }

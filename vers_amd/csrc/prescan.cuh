@@ -1,0 +1,445 @@
+// prescan.cuh -- batched inverted-list scan on the f32 matrix cores with an exact finish (nprobe mode, L2).
+//
+// The reference's distance is an ordered f32 chain (scan.cuh); a matrix-core contraction cannot reproduce its
+// rounding, so -- exactly as in the coarse quantiser (gemm.cuh) -- it is used to PRE-SELECT and the result is
+// then made exact:
+//   (1) prescan_kernel: per work item (64-row tiles of one list segment x the <= 16 queries of one group)
+//         val[r][n] = |x_r|^2 - 2 <x_r, q_n>          v_mfma_f32_16x16x1_4b_f32, lane == row operand layout
+//       which approximates D_ref(x_r, q_n) - |q_n|^2 within E (below).  Per query the kp = top_k + slack smallest
+//       (val, seq) keys of the item are kept (sorted lists in LDS); a threshold shared live between all items of a
+//       query (atomicMin in HBM, re-read every tile pair) makes list inserts rare after the first few tiles.
+//   (2) ivf_rescore_kernel: per query, merge the partial lists into the kp globally smallest approximate keys,
+//       recompute those kp distances in the reference's own arithmetic (lane per candidate, ordered chain), sort
+//       by the exact (distance, seq) key and emit the top_k.  CERTIFICATE: with tau_k the k-th smallest val,
+//       a member t of the true top-k has D_t <= (k-th smallest upper bound) <= tau_k + |q|^2 + E, hence
+//       val_t <= D_t - |q|^2 + E <= tau_k + 2E; every row outside the kp list has val >= val[kp-1].  So if
+//       val[kp-1] > tau_k + 2E (or the list is not full) the true top-k is inside the list and the output equals
+//       the exact scan bit for bit.
+//   (3) ivf_fallback_kernel: queries that fail the certificate (ties / near-ties denser than the slack, non-finite
+//       values) are re-scanned exactly by their own block.  Rare, and never wrong.
+//
+// E: |val + |q|^2 - D_ref| <= (5 d + 32) u (|q|^2 + max|x|^2), u = 2^-24, d = padded length -- the bound derived
+// in gemm.cuh with one more product in the chain (the |x|^2 term rides through the MFMA as an extra k step) and
+// slack for the roundings of the test itself, which is evaluated in f64.
+#pragma once
+#include "scan.cuh"
+
+namespace vers {
+
+typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+
+constexpr int kPreQ = 16;        // queries per group: one 16x16x1 4-block MFMA covers 64 rows x 16 queries
+constexpr uint32_t kPreMaxKp = 32;  // widest per-item list (LDS: 4 waves x 16 queries x kp keys)
+
+struct PreParams {
+  uint32_t ld, n_chunks, kp;
+  uint32_t* status;
+  uint32_t* bounds32;   // per merge group: order bits of the smallest known kp-th val (0xFFFFFFFF = none yet)
+  uint32_t* qflags;     // per merge group: != 0 -> a non-finite val was seen, the query must be re-done exactly
+  uint32_t* next_quad;
+  const float* xnorm;   // |x|^2 per storage row
+  uint32_t debug;
+  unsigned long long* stamps;
+};
+
+inline size_t prescan_lds_bytes(uint32_t ld, uint32_t kp) {
+  return (size_t)ld * kPreQ * sizeof(float) + 16 + (size_t)kWavesPerBlock * kPreQ * kp * sizeof(uint64_t);
+}
+
+// |x|^2 of every storage row of the blocked matrix (thread per row: consecutive rows are consecutive float4s) and
+// the maximum over the rows that hold a vector.
+static __global__ void blocked_row_norms_kernel(const float* rows, uint32_t ld, const uint32_t* row_ids, uint64_t r_begin, uint64_t r_end,
+                                                float* xnorm, uint32_t* xmax2_bits) {
+  const uint64_t r = r_begin + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= r_end) return;
+  const f32x4* p = reinterpret_cast<const f32x4*>(rows + (r >> 6) * 64ull * ld) + (r & 63);
+  float acc = 0.0f;
+  for (uint32_t j = 0; j < ld / 4; ++j) {
+    const f32x4 v = p[(uint64_t)j * 64];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) acc = __fadd_rn(acc, __fmul_rn(v[u], v[u]));
+  }
+  xnorm[r] = acc;
+  if (row_ids[r] != 0xFFFFFFFFu && acc == acc) atomicMax(xmax2_bits, __float_as_uint(acc));  // acc >= 0: bit order == value order
+}
+
+// One work item of the matrix-core scan: two 64-row tiles per step against the group's 16 query columns.
+template <class Src>
+__device__ __forceinline__ void prescan_item(const Src& src, const PreParams& p, uint32_t it, const ItemView<kPreQ>& v, int lane,
+                                             const float* qm, uint64_t* lists) {
+  const int n = lane & 15, quarter = lane >> 4;
+  const uint32_t kp = p.kp;
+  const bool live = n < (int)v.nq;
+  uint32_t vseq = 0, vslot = 0;
+  uint64_t vout = 0;
+  float thr = -__builtin_inff();  // dead query columns never hit
+  if (live) {
+    vseq = src.seq_base(it, n);
+    vslot = src.bound_slot(it, n);
+    const uint32_t b0 = __hip_atomic_load(p.bounds32 + vslot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    thr = b0 == 0xFFFFFFFFu ? __builtin_inff() : __uint_as_float(order_bits_to_f32_bits(b0));
+    if (lane < kPreQ) vout = (uint64_t)src.out(it, lane);
+  }
+  for (uint32_t i = lane; i < kPreQ * kp; i += kWave) lists[i] = kKeyMax;
+
+  const uint32_t n_tiles = (v.nrows + kWave - 1) / kWave;
+  const uint32_t n_pairs = (n_tiles + 1) / 2;
+  const uint32_t last_tile = n_tiles ? n_tiles - 1 : 0;
+  TileLoader L;
+  L.init(v.rows, (uint64_t)n_tiles * kWave * p.ld * 4u, p.ld, lane);
+  const float* xn_item = p.xnorm + src.storage_row(it);
+  f32x16_t accA, accB;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) accA[e] = accB[e] = 0.0f;
+  bool bad = false;
+
+  // insert one key into query nn's sorted LDS list (lane i = i-th key); lowers the threshold of nn's lanes and
+  // publishes the new kp-th val for the other items of the query
+  auto insert = [&](int nn, uint64_t key) {
+    uint64_t* Ln = lists + (uint32_t)nn * kp;
+    const uint64_t cur = lane < (int)kp ? Ln[lane] : kKeyMax;
+    const uint64_t kth = readlane64(cur, (int)kp - 1);
+    if (key < kth) {
+      const uint64_t prev = shift_up1_64(cur);
+      const uint64_t mx = prev > key ? prev : key;
+      const uint64_t nw = key < cur ? mx : cur;
+      if (lane < (int)kp) Ln[lane] = nw;
+      const uint64_t k2 = readlane64(nw, (int)kp - 1);
+      if (k2 != kKeyMax) {
+        const uint32_t kb = (uint32_t)(k2 >> 32);
+        const float nt = __uint_as_float(order_bits_to_f32_bits(kb));
+        if (n == nn) thr = nt < thr ? nt : thr;
+        if (lane == nn) atomicMin(p.bounds32 + vslot, kb);
+      }
+    }
+  };
+
+  // end of a tile: acc already holds val (the |x|^2 term went through the matrix core); rows of lane:
+  // 16*(e>>2) + 4*quarter + (e&3)
+  auto fold = [&](f32x16_t& acc, uint32_t t, bool tile_real) {
+    const uint32_t r0 = t * kWave + 4u * (uint32_t)quarter;
+    if (!tile_real || (t + 1) * kWave > v.nrows) {  // ragged tail (uniform branch): rows past the segment never hit
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const uint32_t row = r0 + 16u * (e >> 2) + (e & 3);
+        if (!tile_real || row >= v.nrows) acc[e] = __builtin_nanf("");
+        else bad |= live && !(__builtin_fabsf(acc[e]) < __builtin_inff());
+      }
+    } else if (live) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) bad |= !(__builtin_fabsf(acc[e]) < __builtin_inff());
+    }
+    uint64_t any = 0;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) any |= __ballot(acc[e] <= thr);
+    if (any != 0 && !(p.debug & 1u)) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        uint64_t m = __ballot(acc[e] <= thr);
+        while (m) {
+          const int s = __ffsll((unsigned long long)m) - 1;
+          m &= m - 1;
+          const float fv = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(acc[e]), s));
+          const uint32_t sq = (uint32_t)__builtin_amdgcn_readlane((int)vseq, s) + t * kWave + 16u * (e >> 2) + 4u * ((uint32_t)s >> 4) + (e & 3);
+          insert(s & 15, make_key(fv, sq));
+          m &= __ballot(acc[e] <= thr);  // the threshold may just have dropped
+        }
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+  };
+
+  // 2-deep register ring over (tile pair, chunk) steps; every load unconditional (see scan_item).  The ring also
+  // carries, per step, the pair's two |x|^2 operands (lane == row) and a fresh copy of the shared threshold.
+  u32x4 buf[2][2 * kLoads];
+  float xnA[2], xnB[2];
+  uint32_t gthr[2];
+  const uint32_t n_steps = n_pairs * p.n_chunks;
+  uint32_t pi = 0, ci = 0;
+  auto issue_next = [&](int b) {
+    const uint32_t tA = 2 * pi, tB = 2 * pi + 1 < n_tiles ? 2 * pi + 1 : last_tile;
+    gthr[b] = __hip_atomic_load(p.bounds32 + vslot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    xnA[b] = xn_item[tA * kWave + lane];
+    xnB[b] = xn_item[tB * kWave + lane];
+    const uint32_t soffA = tA * L.tile_bytes + ci * (kLoads * 1024u), soffB = tB * L.tile_bytes + ci * (kLoads * 1024u);
+#pragma unroll
+    for (int i = 0; i < kLoads; ++i) buf[b][i] = __builtin_amdgcn_raw_buffer_load_b128(L.rsrc, L.lane_off, soffA + (uint32_t)i * 1024u, 0);
+#pragma unroll
+    for (int i = 0; i < kLoads; ++i) buf[b][kLoads + i] = __builtin_amdgcn_raw_buffer_load_b128(L.rsrc, L.lane_off, soffB + (uint32_t)i * 1024u, 0);
+    if (ci + 1 < p.n_chunks) ++ci;
+    else if (pi + 1 < n_pairs) { ci = 0; ++pi; }
+  };
+  if (n_steps) issue_next(0);
+  uint32_t pc = 0, cc = 0;
+  const bool stamp = (p.debug & 16u) != 0;
+  unsigned long long t_wait = 0, t_math = 0, t_fold = 0;
+  for (uint32_t s0 = 0; s0 < n_steps; s0 += 2) {
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      issue_next(b ^ 1);
+      if (s0 + b < n_steps) {
+        unsigned long long t0 = 0, t1 = 0, t2 = 0;
+        if (stamp) {
+          t0 = __builtin_amdgcn_s_memtime();
+          __builtin_amdgcn_s_waitcnt(0x4F70 | 3);  // vmcnt(19): this step's loads have landed
+          t1 = __builtin_amdgcn_s_memtime();
+        }
+        if (!(p.debug & 2u)) {
+          const f32x4* ql = reinterpret_cast<const f32x4*>(qm) + ((size_t)cc * kLoads * kPreQ + n);
+#pragma unroll
+          for (int i = 0; i < kLoads; ++i) {
+            const f32x4 q4 = ql[i * kPreQ];  // (-2 q_n)[4 columns]: lanes of one query column read one address
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              accA = __builtin_amdgcn_mfma_f32_16x16x1f32(__uint_as_float(buf[b][i][u]), q4[u], accA, 0, 0, 0);
+              accB = __builtin_amdgcn_mfma_f32_16x16x1f32(__uint_as_float(buf[b][kLoads + i][u]), q4[u], accB, 0, 0, 0);
+            }
+          }
+        } else {
+          accA[0] += __uint_as_float(buf[b][0][0] ^ buf[b][2 * kLoads - 1][3]);
+        }
+        if (stamp) {
+          asm volatile("" ::"v"(accA[0]), "v"(accB[0]));
+          t2 = __builtin_amdgcn_s_memtime();
+          t_wait += t1 - t0;
+          t_math += t2 - t1;
+        }
+        if (++cc == p.n_chunks) {
+          cc = 0;
+          accA = __builtin_amdgcn_mfma_f32_16x16x1f32(xnA[b], 1.0f, accA, 0, 0, 0);  // + |x_row|^2 for every query column
+          accB = __builtin_amdgcn_mfma_f32_16x16x1f32(xnB[b], 1.0f, accB, 0, 0, 0);
+          if (live && gthr[b] != 0xFFFFFFFFu) {
+            const float g = __uint_as_float(order_bits_to_f32_bits(gthr[b]));
+            thr = g < thr ? g : thr;
+          }
+          fold(accA, 2 * pc, true);
+          fold(accB, 2 * pc + 1, 2 * pc + 1 < n_tiles);
+          ++pc;
+          if (stamp) t_fold += __builtin_amdgcn_s_memtime() - t2;
+        }
+      }
+    }
+  }
+  if (stamp && lane == 0) {
+    atomicAdd(p.stamps + 0, t_wait);
+    atomicAdd(p.stamps + 1, t_math);
+    atomicAdd(p.stamps + 2, t_fold);
+    atomicAdd(p.stamps + 4, 1ull);
+  }
+  if (bad) p.qflags[vslot] = 1u;
+#pragma unroll
+  for (int qi = 0; qi < kPreQ; ++qi)
+    if (qi < (int)v.nq && lane < (int)kp) reinterpret_cast<uint64_t*>(readlane64(vout, qi))[lane] = lists[(uint32_t)qi * kp + lane];
+}
+
+// Quads of items share one query block, staged once per quad into LDS in the MFMA operand layout
+// qm[(c4 * 16 + n) * 4 + u] = -2 * q_n[4 c4 + u] (written so by gather_qblocks_kernel).
+template <class Src>
+__global__ __launch_bounds__(kWave * kWavesPerBlock) void prescan_kernel(Src src, PreParams p) {
+  static_assert(kWavesPerBlock == 4, "items are padded to quads");
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  extern __shared__ __attribute__((aligned(16))) float qlds[];
+  uint32_t* nq_lds = reinterpret_cast<uint32_t*>(qlds + (size_t)p.ld * kPreQ);
+  uint64_t* lists = reinterpret_cast<uint64_t*>(qlds + (size_t)p.ld * kPreQ + 4) + (size_t)wid * kPreQ * p.kp;
+  const uint32_t n_quads = src.n_items() / 4;
+  const uint32_t n4 = p.ld * (kPreQ / 4);
+  const unsigned long long clk0 = (p.debug & 16u) ? __builtin_amdgcn_s_memtime() : 0ull;
+  const unsigned long long rt0 = (p.debug & 16u) ? __builtin_amdgcn_s_memrealtime() : 0ull;
+  for (uint32_t b0 = blockIdx.x;; b0 += gridDim.x) {
+    uint32_t bi = b0;
+    if (p.next_quad != nullptr) {
+      if (threadIdx.x == 0) *nq_lds = atomicAdd(p.next_quad, 1u);
+      __syncthreads();
+      bi = *nq_lds;
+    }
+    if (bi >= n_quads) break;
+    const uint32_t it = bi * 4 + wid;
+    ItemView<kPreQ> v;
+    src.get(it, v);
+    __syncthreads();  // the previous quad's readers are done with the LDS block
+    const f32x4* g = reinterpret_cast<const f32x4*>(v.qb);
+    for (uint32_t i = threadIdx.x; i < n4; i += kWave * kWavesPerBlock) reinterpret_cast<f32x4*>(qlds)[i] = g[i];
+    __syncthreads();
+    if (v.nrows == 0) continue;  // padding item
+    prescan_item(src, p, it, v, lane, qlds, lists);
+  }
+  if ((p.debug & 16u) && blockIdx.x == 0 && threadIdx.x == 0)
+    p.stamps[7] = ((__builtin_amdgcn_s_memtime() - clk0) << 20) / ((__builtin_amdgcn_s_memrealtime() - rt0) | 1ull);
+}
+
+// ---- exact finish ---------------------------------------------------------------------------------
+struct RescoreArgs {
+  const uint64_t* partials;  // [b*P*S_max][kp] approximate keys
+  uint32_t P, S_max, kp, top_k, d_pad;
+  const uint32_t* pj_list;
+  const uint32_t* pj_pref;
+  const uint32_t* list_off;
+  const uint32_t* row_ids;
+  const float* rows;
+  uint32_t ld;
+  const float* qp;  // padded queries [b][ldq]
+  uint32_t ldq;
+  const uint32_t* xmax2_bits;
+  const uint32_t* qflags;  // [b*P], slot q*P
+  int force_fail;          // testing: nothing certifies
+  uint32_t* fail_list;     // [b] out: queries to redo exactly, [b] = their count
+  uint32_t* stats;         // [0] += failed queries
+  uint32_t* status;
+  uint64_t* out_ids;
+  float* out_dist;
+  uint32_t* out_count;
+  uint64_t* out_keys;
+};
+
+// storage row of a sequence number (position in the query's concatenated probe order)
+__device__ __forceinline__ uint32_t seq_to_row(uint32_t seq, const uint32_t* pj_list, const uint32_t* pj_pref, uint32_t P,
+                                               const uint32_t* list_off) {
+  uint32_t j = 0;
+  for (uint32_t t = 0; t < P; ++t)
+    if (pj_pref[t] <= seq && pj_list[t] != 0xFFFFFFFFu) j = t;
+  return list_off[pj_list[j]] + (seq - pj_pref[j]);
+}
+
+__device__ __forceinline__ void emit_topk(uint64_t fin, uint32_t q, uint32_t top_k, int lane, const uint32_t* pj_list, const uint32_t* pj_pref,
+                                          uint32_t P, const uint32_t* list_off, const uint32_t* row_ids, uint64_t* out_ids, float* out_dist,
+                                          uint32_t* out_count, uint64_t* out_keys) {
+  const bool have = lane < (int)top_k && fin != kKeyMax;
+  const uint64_t o = (uint64_t)q * top_k + lane;
+  if (lane < (int)top_k && out_keys) out_keys[o] = have ? fin : kKeyMax;
+  if (have) {
+    out_ids[o] = row_ids[seq_to_row((uint32_t)fin, pj_list, pj_pref, P, list_off)];
+    out_dist[o] = __uint_as_float(order_bits_to_f32_bits((uint32_t)(fin >> 32)));
+  }
+  const uint64_t hm = __ballot(have);
+  if (lane == 0) out_count[q] = (uint32_t)__popcll(hm);
+}
+
+__global__ __launch_bounds__(kWave * kMergeWaves) void ivf_rescore_kernel(RescoreArgs a) {
+  __shared__ uint64_t sh[kMergeWaves][kWave];
+  extern __shared__ __attribute__((aligned(16))) float qs[];  // the query, padded
+  const uint32_t q = blockIdx.x;
+  const int lane = threadIdx.x & 63;
+  const float* qrow = a.qp + (uint64_t)q * a.ldq;
+  for (uint32_t i = threadIdx.x; i < a.ld; i += blockDim.x) qs[i] = qrow[i];
+  const uint64_t list = block_merge_keys(a.partials + (uint64_t)q * a.P * a.S_max * a.kp, a.P * a.S_max * a.kp, a.kp, sh);
+  __syncthreads();
+  if (threadIdx.x >= kWave) return;
+  const uint32_t* pl = a.pj_list + (uint64_t)q * a.P;
+  const uint32_t* pp = a.pj_pref + (uint64_t)q * a.P;
+  const bool valid = lane < (int)a.kp && list != kKeyMax;
+  const uint32_t cnt = (uint32_t)__popcll(__ballot(valid));
+  // |q|^2 (any order; inflated below) and the certificate in f64
+  float qn = 0.0f;
+  for (uint32_t i = 0; i < a.ld; ++i) qn = __fadd_rn(qn, __fmul_rn(qs[i], qs[i]));
+  const double u = 5.9604644775390625e-08;
+  const double S = (double)qn * (1.0 + (double)a.d_pad * 2.0 * u) + (double)__uint_as_float(*a.xmax2_bits);
+  const double E = (5.0 * (double)a.d_pad + 32.0) * u * S;
+  const float val = __uint_as_float(order_bits_to_f32_bits((uint32_t)(list >> 32)));
+  bool certified = true;
+  if (cnt >= a.kp && cnt > 0) {  // a full list may have cut rows off: the kp-th val must clear tau_k + 2E
+    const uint32_t kk = a.top_k < cnt ? a.top_k : cnt;
+    const double tau = (double)__uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(val), (int)kk - 1));
+    const double top = (double)__uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(val), (int)a.kp - 1));
+    certified = top > tau + 2.0 * E;  // false for NaN / inf
+  }
+  if (a.qflags[(uint64_t)q * a.P] != 0 || a.force_fail) certified = false;
+  if (!certified) {  // queued: the fallback kernels write this query's results
+    if (lane == 0) { a.fail_list[atomicAdd(a.fail_list + gridDim.x, 1u)] = q; atomicAdd(a.stats, 1u); }
+    return;
+  }
+  // exact distances of the kp candidates: lane per candidate, the reference's ordered chain
+  uint64_t cand = kKeyMax;
+  if (valid) {
+    const uint32_t seq = (uint32_t)list;
+    const uint32_t row = seq_to_row(seq, pl, pp, a.P, a.list_off);
+    const f32x4* xp = reinterpret_cast<const f32x4*>(a.rows + (uint64_t)(row >> 6) * 64ull * a.ld) + (row & 63);
+    const f32x4* q4p = reinterpret_cast<const f32x4*>(qs);
+    float acc = 0.0f;
+#pragma unroll 8
+    for (uint32_t j = 0; j < a.ld / 4; ++j) {
+      const f32x4 x4 = xp[(uint64_t)j * 64];
+      const f32x4 q4 = q4p[j];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float t = __fsub_rn(x4[c], q4[c]);
+        acc = __fadd_rn(acc, __fmul_rn(t, t));
+      }
+    }
+    if (acc != acc) atomicOr(a.status, 1u);
+    cand = make_key(acc, seq);
+  }
+  uint64_t fin = kKeyMax;
+  wave_topk_update(fin, a.top_k, cand, kKeyMax);
+  emit_topk(fin, q, a.top_k, lane, pl, pp, a.P, a.list_off, a.row_ids, a.out_ids, a.out_dist, a.out_count, a.out_keys);
+}
+
+// Exact re-scan of the probed lists of the queries that failed the certificate.  ivf_rescore_kernel queued them;
+// block (j, slot) scans probe j of every slot-th queued query with the ordered chain -- 16 waves, each the ring-
+// pipelined single-query item of scan.cuh over its share of the list's tiles -- and leaves 16 partial top-k lists;
+// fallback_merge_kernel folds a query's P x 16 lists and emits.  Both exit at once when nothing is queued.
+struct FbSrc {
+  static constexpr bool kSeqIds = false;
+  uint64_t* out_ptr;
+  uint32_t seq0;
+  __device__ __forceinline__ uint32_t seq_base(uint32_t, int) const { return seq0; }
+  __device__ __forceinline__ const uint32_t* seq_ids(uint32_t) const { return nullptr; }
+  __device__ __forceinline__ uint64_t* out(uint32_t, int) const { return out_ptr; }
+  __device__ __forceinline__ uint32_t bound_slot(uint32_t, int) const { return 0; }
+};
+
+__global__ __launch_bounds__(kWave * kMergeWaves) void fallback_scan_kernel(RescoreArgs a, const uint32_t* list_len, const uint32_t* fail_list,
+                                                                            const uint32_t* fail_count, uint64_t* fb_part) {
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t n_fail = *fail_count;
+  const uint32_t j = blockIdx.x;
+  ScanParams p;
+  p.ld = a.ld; p.n_chunks = a.ld / kChunk; p.k = a.top_k; p.status = a.status; p.bounds = nullptr; p.debug = 0;
+  p.next_quad = nullptr; p.stamps = nullptr;
+  bool nan_seen = false;
+  for (uint32_t i = blockIdx.y; i < n_fail; i += gridDim.y) {
+    const uint32_t q = fail_list[i];
+    uint64_t* out = fb_part + (((uint64_t)q * a.P + j) * kMergeWaves + wid) * a.top_k;
+    const uint32_t Lj = a.pj_list[(uint64_t)q * a.P + j];
+    uint32_t len = 0, t0 = 0, t1 = 0;
+    if (Lj != 0xFFFFFFFFu) {
+      len = list_len[Lj];
+      const uint32_t n_tiles = (len + kWave - 1) / kWave, per = (n_tiles + kMergeWaves - 1) / kMergeWaves;
+      t0 = (uint32_t)wid * per < n_tiles ? (uint32_t)wid * per : n_tiles;
+      t1 = t0 + per < n_tiles ? t0 + per : n_tiles;
+    }
+    if (t1 <= t0) {  // nothing for this wave: an empty slot
+      if (lane < (int)a.top_k) out[lane] = kKeyMax;
+      continue;
+    }
+    ItemView<1> v;
+    v.rows = a.rows + ((uint64_t)a.list_off[Lj] + (uint64_t)t0 * kWave) * a.ld;
+    v.nrows = (t1 * kWave < len ? t1 * kWave : len) - t0 * kWave;
+    v.nq = 1;
+    v.qb = a.qp + (uint64_t)q * a.ldq;
+    FbSrc src;
+    src.out_ptr = out;
+    src.seq0 = a.pj_pref[(uint64_t)q * a.P + j] + t0 * kWave;
+    scan_item<1, 1, 0>(src, p, 0u, v, lane, nan_seen);
+  }
+  if (__ballot(nan_seen) != 0 && lane == 0) atomicOr(a.status, 1u);
+}
+
+__global__ __launch_bounds__(kWave * kMergeWaves) void fallback_merge_kernel(RescoreArgs a, const uint32_t* fail_list, const uint32_t* fail_count,
+                                                                             const uint64_t* fb_part) {
+  __shared__ uint64_t sh[kMergeWaves][kWave];
+  const uint32_t n_fail = *fail_count;
+  const int lane = threadIdx.x & 63;
+  for (uint32_t i = blockIdx.x; i < n_fail; i += gridDim.x) {
+    const uint32_t q = fail_list[i];
+    const uint32_t n_keys = a.P * kMergeWaves * a.top_k;
+    const uint64_t list = block_merge_keys(fb_part + (uint64_t)q * n_keys, n_keys, a.top_k, sh);
+    if (threadIdx.x < kWave)
+      emit_topk(list, q, a.top_k, lane, a.pj_list + (uint64_t)q * a.P, a.pj_pref + (uint64_t)q * a.P, a.P, a.list_off, a.row_ids, a.out_ids,
+                a.out_dist, a.out_count, a.out_keys);
+  }
+}
+
+}  // namespace vers
