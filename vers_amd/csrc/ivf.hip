@@ -84,6 +84,17 @@ struct SegSrc {
 };
 
 constexpr uint32_t kNoSeg = 0xFFFFFFFFu;  // padding item of a quad
+// Row segments of one list.  seg_target == 0: fixed seg_rows.  Otherwise (matrix-core scan) the list is cut into
+// 4 * ceil(len / (4 * seg_target)) nearly equal whole-tile segments, so that the four waves of a quad -- which
+// share a query block and a barrier -- carry the same load whatever the list length.
+__host__ __device__ __forceinline__ uint32_t list_seg_rows(uint32_t len, uint32_t seg_rows, uint32_t seg_target) {
+  if (seg_target == 0) return seg_rows;
+  uint32_t n_quads = (len + 4 * seg_target - 1) / (4 * seg_target);
+  if (n_quads == 0) n_quads = 1;
+  const uint32_t per = (len + 4 * n_quads - 1) / (4 * n_quads);
+  const uint32_t seg = (per + 63) / 64 * 64;
+  return seg ? seg : 64u;
+}
 struct ItemDesc {
   uint32_t list, group, seg;
 };
@@ -104,7 +115,7 @@ struct IvfSrc {
   const uint32_t* group_off;  // first group id of each list
   const float* qblocks;       // QG > 1: [group][ldq][QG]
   const float* qp;            // QG == 1: padded queries [b][ldq]
-  uint32_t ldq, P, S_max, k_keep, seg_rows;
+  uint32_t ldq, P, S_max, k_keep, seg_rows, seg_target;
   uint32_t bound_per_pair;    // reference mode merges per (query, list); nprobe mode per query
   const uint32_t* pj_pref;    // [b*P] sequence base of probe j of query q
   uint64_t* partials;         // [b*P*S_max][k_keep]
@@ -113,10 +124,11 @@ struct IvfSrc {
   __device__ __forceinline__ void get(uint32_t it, ItemView<QG>& v) const {
     const ItemDesc d = items[it];
     const bool real = d.seg != kNoSeg;
-    const uint32_t r0 = real ? d.seg * seg_rows : 0;
-    v.rows = rows + ((uint64_t)list_off[d.list] + r0) * ld;
     const uint32_t len = list_len[d.list];
-    v.nrows = real ? (len - r0 < seg_rows ? len - r0 : seg_rows) : 0u;
+    const uint32_t sr = list_seg_rows(len, seg_rows, seg_target);
+    const uint32_t r0 = real ? d.seg * sr : 0;
+    v.rows = rows + ((uint64_t)list_off[d.list] + r0) * ld;
+    v.nrows = real ? (len - r0 < sr ? len - r0 : sr) : 0u;
     const uint32_t c = cnt[d.list] - d.group * QG;
     v.nq = c < (uint32_t)QG ? c : QG;
     if (QG == 1) v.qb = qp + (uint64_t)(pairs[pair_off[d.list] + d.group] / P) * ldq;
@@ -128,10 +140,11 @@ struct IvfSrc {
   }
   __device__ __forceinline__ uint32_t storage_row(uint32_t it) const {  // first storage row of the item
     const ItemDesc d = items[it];
-    return list_off[d.list] + (d.seg != kNoSeg ? d.seg * seg_rows : 0u);
+    return list_off[d.list] + (d.seg != kNoSeg ? d.seg * list_seg_rows(list_len[d.list], seg_rows, seg_target) : 0u);
   }
   __device__ __forceinline__ uint32_t seq_base(uint32_t it, int qi) const {
-    return pj_pref[pair_of(it, qi)] + items[it].seg * seg_rows;
+    const ItemDesc d = items[it];
+    return pj_pref[pairs[pair_off[d.list] + d.group * QG + qi]] + d.seg * list_seg_rows(list_len[d.list], seg_rows, seg_target);
   }
   __device__ __forceinline__ const uint32_t* seq_ids(uint32_t) const { return nullptr; }
   __device__ __forceinline__ uint64_t* out(uint32_t it, int qi) const {
@@ -202,7 +215,7 @@ struct GroupTotals {
 };
 
 __global__ __launch_bounds__(1024) void group_kernel(const uint32_t* cnt, const uint32_t* list_len, uint32_t k_lists,
-                                                     uint32_t QG, uint32_t seg_rows, uint32_t* pair_off,
+                                                     uint32_t QG, uint32_t seg_rows, uint32_t seg_target, uint32_t* pair_off,
                                                      uint32_t* group_off, uint32_t* item_off, GroupTotals* tot) {
   __shared__ uint32_t sp[1024], sg[1024], si[1024];
   __shared__ uint32_t cp, cg, ci;
@@ -218,7 +231,8 @@ __global__ __launch_bounds__(1024) void group_kernel(const uint32_t* cnt, const 
       if (c) {
         const uint32_t len = list_len[L];
         g = (c + QG - 1) / QG;
-        const uint32_t n_s = (len + seg_rows - 1) / seg_rows;
+        const uint32_t sr = list_seg_rows(len, seg_rows, seg_target);
+        const uint32_t n_s = (len + sr - 1) / sr;
         it = g * (QG == 1 ? n_s : (n_s + 3) / 4 * 4);  // QG > 1: quads of items share a query block
         my_ur += len;
         my_sr += (unsigned long long)len * g;
@@ -267,13 +281,14 @@ struct GroupDesc {
   uint32_t pair_start, nq;
 };
 __global__ void items_kernel(const uint32_t* cnt, const uint32_t* list_len, uint32_t k_lists, uint32_t QG,
-                             uint32_t seg_rows, const uint32_t* pair_off, const uint32_t* group_off,
+                             uint32_t seg_rows, uint32_t seg_target, const uint32_t* pair_off, const uint32_t* group_off,
                              const uint32_t* item_off, ItemDesc* items, GroupDesc* groups) {
   const uint32_t L = blockIdx.x * blockDim.x + threadIdx.x;
   if (L >= k_lists) return;
   const uint32_t c = cnt[L];
   if (!c) return;
-  const uint32_t n_g = (c + QG - 1) / QG, n_s = (list_len[L] + seg_rows - 1) / seg_rows;
+  const uint32_t sr = list_seg_rows(list_len[L], seg_rows, seg_target);
+  const uint32_t n_g = (c + QG - 1) / QG, n_s = (list_len[L] + sr - 1) / sr;
   const uint32_t n_s_pad = QG == 1 ? n_s : (n_s + 3) / 4 * 4;
   uint32_t o = item_off[L];
   for (uint32_t g = 0; g < n_g; ++g)
@@ -351,16 +366,16 @@ __global__ __launch_bounds__(kWave * kMergeWaves) void plan1_kernel(
 }
 
 // interleaved query block of every group: qblocks[(g*ldq + col)*QG + qi]
-// mfma != 0 (QG == 16): the matrix-core operand layout of prescan.cuh, qblocks[(g*ldq/4 + c4)*64 + qi*4 + u] =
-// -2 * q[4 c4 + u] (the scaling is exact)
+// mfma != 0 (QG == 32): the matrix-core operand layout of prescan.cuh, per group
+// [((c4 * 2 + set) * 16 + n) * 4 + u] = -2 * q_{16 set + n}[4 c4 + u] (the scaling is exact)
 __global__ void gather_qblocks_kernel(const GroupDesc* groups, const GroupTotals* tot, const uint32_t* pairs, uint32_t P,
                                       const float* qp, uint32_t ldq, uint32_t QG, int mfma, float* qblocks) {
   const uint32_t g = blockIdx.x;
   if (g >= tot->n_groups) return;
   const GroupDesc gd = groups[g];
   for (uint32_t i = threadIdx.x; i < ldq * QG; i += blockDim.x) {
-    const uint32_t qi = mfma ? (i >> 2) & 15u : i % QG;
-    const uint32_t col = mfma ? ((i >> 6) << 2) + (i & 3u) : i / QG;
+    const uint32_t qi = mfma ? (i >> 2) & 31u : i % QG;
+    const uint32_t col = mfma ? ((i >> 7) << 2) + (i & 3u) : i / QG;
     float v = 0.0f;
     if (qi < gd.nq) v = qp[(uint64_t)(pairs[gd.pair_start + qi] / P) * ldq + col];
     qblocks[(uint64_t)g * ldq * QG + i] = mfma ? -2.0f * v : v;
@@ -909,8 +924,8 @@ int32_t launch_ivf_scan(vers_ivf* h, const IvfSrc<QG>& src, uint32_t items_bound
   p.debug = scan_debug_flags();
   p.stamps = nullptr;
   if (p.debug & 16u) {  // diagnosis only
-    if (int32_t rc = h->stamps.reserve(64)) return rc;
-    VERS_HIP_TRY(hipMemsetAsync(h->stamps.p, 0, 64, st));
+    if (int32_t rc = h->stamps.reserve(128)) return rc;
+    VERS_HIP_TRY(hipMemsetAsync(h->stamps.p, 0, 128, st));
     p.stamps = h->stamps.as<unsigned long long>();
   }
   // pruning bounds shared between the items of a merge group (they run at different times here, unlike the flat
@@ -950,8 +965,8 @@ int32_t launch_prescan(vers_ivf* h, const IvfSrc<kPreQ>& src, uint32_t items_bou
   p.debug = scan_debug_flags();
   p.stamps = nullptr;
   if (p.debug & 16u) {
-    if (int32_t rc = h->stamps.reserve(64)) return rc;
-    VERS_HIP_TRY(hipMemsetAsync(h->stamps.p, 0, 64, st));
+    if (int32_t rc = h->stamps.reserve(128)) return rc;
+    VERS_HIP_TRY(hipMemsetAsync(h->stamps.p, 0, 128, st));
     p.stamps = h->stamps.as<unsigned long long>();
   }
   p.next_quad = nullptr;
@@ -963,7 +978,8 @@ int32_t launch_prescan(vers_ivf* h, const IvfSrc<kPreQ>& src, uint32_t items_bou
   const size_t lds = prescan_lds_bytes(h->ld, kp);
   if (int32_t rc = scan_prepare_launch(prescan_kernel<IvfSrc<kPreQ>>, lds)) return rc;
   uint32_t blocks = (items_bound + kWavesPerBlock - 1) / kWavesPerBlock;
-  const uint32_t per_cu = std::max<uint32_t>(1, std::min<uint32_t>(2, (uint32_t)((160u * 1024u) / lds)));
+  uint32_t per_cu = std::max<uint32_t>(1, std::min<uint32_t>(2, (uint32_t)((160u * 1024u) / lds)));  // 1 at d = 768 (measured: as fast as 2)
+  if (const char* e = getenv("VERS_PRE_BLOCKS_PER_CU")) per_cu = std::max(1, atoi(e));  // tuning knob
   const uint32_t max_blocks = (uint32_t)h->n_cu * per_cu;
   if (blocks > max_blocks) blocks = max_blocks;
   if (blocks == 0) blocks = 1;
@@ -1008,13 +1024,16 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
   // Batches in nprobe mode: the list scan runs on the matrix cores with an exact finish (prescan.cuh); same bits.
   // VERS_PRESCAN=0 keeps the ordered-chain scan, =2 makes every certificate fail (exercises the exact fallback).
   static const int pre_mode = [] { const char* e = getenv("VERS_PRESCAN"); return e ? atoi(e) : 1; }();
-  const uint32_t kp = std::min<uint32_t>(kPreMaxKp, std::max<uint32_t>(top_k + 6, top_k + top_k / 2));
+  // slack of 10 keys: at cfg3 a slack of 6 left ~2 of 1024 queries uncertified per batch, 10 none
+  uint32_t kp = std::min<uint32_t>(kPreMaxKp, std::max<uint32_t>(top_k + 10, top_k + top_k / 2));
+  if (const char* e = getenv("VERS_PRE_SLACK")) kp = std::min<uint32_t>(kPreMaxKp, top_k + std::max(1, atoi(e)));  // tuning knob
   const bool use_pre = QG != 1 && !ref_mode && pre_mode != 0 && top_k + 6 <= kPreMaxKp &&
                        prescan_lds_bytes(h->ld, kp) <= 160u * 1024u;
   if (use_pre) QG = kPreQ;
   const uint32_t k_keep = use_pre ? kp : top_k;
   const uint64_t groups_bound = QG == 1 ? n_pj : (n_pj / QG + std::min<uint64_t>(h->k, n_pj));
   uint32_t seg_rows;
+  const uint64_t avg_len_all = std::max<uint64_t>(1, h->n_total / std::max<uint32_t>(1, h->k));
   if (b == 1) seg_rows = kWave;
   else {
     const uint64_t groups_est = std::max<uint64_t>(1, std::max<uint64_t>(pairs_est / QG, lists_est));
@@ -1025,8 +1044,14 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
     // whole tile PAIRS (the batched kernel walks two tiles per step)
     seg_rows = (uint32_t)round_up64(std::max<uint64_t>(1, (avg_len + segs_wanted - 1) / segs_wanted), QG == 1 ? kWave : 2 * kWave);
   }
+  // matrix-core scan: an average list is one quad of items (per-item set-up and the 4-wave barrier amortise over
+  // ~10 tiles; measured at cfg3: 640-row targets beat 256- and 1024-row ones)
+  if (use_pre) seg_rows = (uint32_t)round_up64(std::max<uint64_t>(256, (avg_len_all + 3) / 4), kWave);
   if (const char* e = getenv("VERS_SEG_ROWS")) seg_rows = (uint32_t)round_up64(std::max(64l, atol(e)), kWave);  // tuning knob
-  const uint32_t S_max = std::max<uint32_t>(1, (h->max_len + seg_rows - 1) / seg_rows);
+  // matrix-core scan: per-list balanced segments of about seg_rows rows (list_seg_rows)
+  const uint32_t seg_target = use_pre ? seg_rows : 0u;
+  const uint32_t S_max = use_pre ? 4 * std::max<uint32_t>(1, (h->max_len + 4 * seg_target - 1) / (4 * seg_target))
+                                 : std::max<uint32_t>(1, (h->max_len + seg_rows - 1) / seg_rows);
   const uint64_t items_bound = groups_bound * (QG == 1 ? S_max : round_up(S_max, 4));
   if (items_bound > 0x7FFFFFFFull) return fail(VERS_ERR_INVALID, "search batch too large");
 
@@ -1066,14 +1091,14 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
                      h->list_len.as<uint32_t>(), h->world > 1 ? h->owner.as<uint8_t>() : (const uint8_t*)nullptr, h->rank, pj_list,
                      pj_pref, pj_take, np, cnt, h->status.as<uint32_t>());
   VERS_HIP_TRY(hipGetLastError());
-  hipLaunchKernelGGL(group_kernel, dim3(1), dim3(1024), 0, st, cnt, h->list_len.as<uint32_t>(), k_l, (uint32_t)QG, seg_rows,
+  hipLaunchKernelGGL(group_kernel, dim3(1), dim3(1024), 0, st, cnt, h->list_len.as<uint32_t>(), k_l, (uint32_t)QG, seg_rows, seg_target,
                      pair_off, group_off, item_off, tot);
   VERS_HIP_TRY(hipGetLastError());
   hipLaunchKernelGGL(scatter_pairs_kernel, dim3((unsigned)((n_pj + 255) / 256)), dim3(256), 0, st, pj_list, (uint32_t)n_pj, pair_off,
                      fill, h->pairs.as<uint32_t>());
   VERS_HIP_TRY(hipGetLastError());
   hipLaunchKernelGGL(items_kernel, dim3((k_l + 127) / 128), dim3(128), 0, st, cnt, h->list_len.as<uint32_t>(), k_l, (uint32_t)QG,
-                     seg_rows, pair_off, group_off, item_off, h->items.as<ItemDesc>(), h->groups.as<GroupDesc>());
+                     seg_rows, seg_target, pair_off, group_off, item_off, h->items.as<ItemDesc>(), h->groups.as<GroupDesc>());
   VERS_HIP_TRY(hipGetLastError());
   if (QG != 1) {
     hipLaunchKernelGGL(gather_qblocks_kernel, dim3((unsigned)groups_bound), dim3(256), 0, st, h->groups.as<GroupDesc>(), tot,
@@ -1086,7 +1111,7 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
     src.list_len = h->list_len.as<uint32_t>(); src.items = h->items.as<ItemDesc>(); src.n_items_dev = &tot->n_items;
     src.cnt = cnt; src.pair_off = pair_off; src.pairs = h->pairs.as<uint32_t>(); src.group_off = group_off;
     src.qblocks = h->qblocks.as<float>(); src.qp = qp; src.ldq = h->ldq; src.P = P; src.S_max = S_max; src.k_keep = k_keep;
-    src.seg_rows = seg_rows; src.pj_pref = pj_pref; src.partials = h->partials.as<uint64_t>();
+    src.seg_rows = seg_rows; src.seg_target = seg_target; src.pj_pref = pj_pref; src.partials = h->partials.as<uint64_t>();
     src.bound_per_pair = ref_mode ? 1u : 0u;
   };
   int32_t rc;
@@ -1528,8 +1553,11 @@ int32_t vers_ivf_last_scan(vers_ivf_t* h, float* out_ms, uint64_t* out_union_row
   if (out_streamed_rows) *out_streamed_rows = t.streamed_rows;
   if (out_items) *out_items = t.n_items;
   if ((scan_debug_flags() & 16u) && h->stamps.p) {  // diagnosis only: per-wave phase cycles of the last launch
-    unsigned long long sv[8] = {};
-    VERS_HIP_TRY(hipMemcpy(sv, h->stamps.p, 64, hipMemcpyDeviceToHost));
+    unsigned long long sv[16] = {};
+    VERS_HIP_TRY(hipMemcpy(sv, h->stamps.p, 128, hipMemcpyDeviceToHost));
+    if (sv[10])
+      fprintf(stderr, "[vers stamps] matrix-core scan, per item avg cycles: prologue %.0f  step loop %.0f (of which issuing loads %.0f)  epilogue %.0f\n",
+              (double)sv[9] / sv[4], (double)sv[10] / sv[4], (double)sv[8] / sv[4], (double)sv[11] / sv[4]);
     fprintf(stderr, "[vers stamps] items %llu: per item avg cycles: wait-for-loads %.0f  math %.0f  fold %.0f | per wave-quad-slot (%llu): stage %.0f  barrier-wait %.0f\n",
             sv[4], sv[4] ? (double)sv[0] / sv[4] : 0.0, sv[4] ? (double)sv[1] / sv[4] : 0.0, sv[4] ? (double)sv[2] / sv[4] : 0.0,
             sv[6], sv[6] ? (double)sv[3] / sv[6] : 0.0, sv[6] ? (double)sv[5] / sv[6] : 0.0);

@@ -3,7 +3,7 @@
 // The reference's distance is an ordered f32 chain (scan.cuh); a matrix-core contraction cannot reproduce its
 // rounding, so -- exactly as in the coarse quantiser (gemm.cuh) -- it is used to PRE-SELECT and the result is
 // then made exact:
-//   (1) prescan_kernel: per work item (64-row tiles of one list segment x the <= 16 queries of one group)
+//   (1) prescan_kernel: per work item (64-row tiles of one list segment x the <= 32 queries of one group)
 //         val[r][n] = |x_r|^2 - 2 <x_r, q_n>          v_mfma_f32_16x16x1_4b_f32, lane == row operand layout
 //       which approximates D_ref(x_r, q_n) - |q_n|^2 within E (below).  Per query the kp = top_k + slack smallest
 //       (val, seq) keys of the item are kept (sorted lists in LDS); a threshold shared live between all items of a
@@ -22,13 +22,20 @@
 // in gemm.cuh with one more product in the chain (the |x|^2 term rides through the MFMA as an extra k step) and
 // slack for the roundings of the test itself, which is evaluated in f64.
 #pragma once
+#include <type_traits>
+
 #include "scan.cuh"
 
 namespace vers {
 
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 
-constexpr int kPreQ = 16;        // queries per group: one 16x16x1 4-block MFMA covers 64 rows x 16 queries
+constexpr int kPreQ = 32;        // queries per group: two sets of 16 (one 16x16x1 4-block MFMA covers 64 rows x 16 queries)
+#ifndef VERS_PRE_RING
+#define VERS_PRE_RING 2
+#endif
+constexpr int kPreRing = VERS_PRE_RING;  // steps of 16 KiB in flight per wave (2 or 3; measured equal); one wave per SIMD
+static_assert(kPreRing == 2 || kPreRing == 3, "ring depth");
 constexpr uint32_t kPreMaxKp = 32;  // widest per-item list (LDS: 4 waves x 16 queries x kp keys)
 
 struct PreParams {
@@ -63,22 +70,32 @@ static __global__ void blocked_row_norms_kernel(const float* rows, uint32_t ld, 
   if (row_ids[r] != 0xFFFFFFFFu && acc == acc) atomicMax(xmax2_bits, __float_as_uint(acc));  // acc >= 0: bit order == value order
 }
 
-// One work item of the matrix-core scan: two 64-row tiles per step against the group's 16 query columns.
+// One work item of the matrix-core scan: two 64-row tiles per step against the group's query columns, in one or
+// two sets of 16 (the second set only when the group holds more than 16 queries: same row operands, so a list
+// probed by up to 32 queries is streamed once).
 template <class Src>
 __device__ __forceinline__ void prescan_item(const Src& src, const PreParams& p, uint32_t it, const ItemView<kPreQ>& v, int lane,
                                              const float* qm, uint64_t* lists) {
   const int n = lane & 15, quarter = lane >> 4;
   const uint32_t kp = p.kp;
-  const bool live = n < (int)v.nq;
-  uint32_t vseq = 0, vslot = 0;
-  uint64_t vout = 0;
-  float thr = -__builtin_inff();  // dead query columns never hit
-  if (live) {
-    vseq = src.seq_base(it, n);
-    vslot = src.bound_slot(it, n);
-    const uint32_t b0 = __hip_atomic_load(p.bounds32 + vslot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    thr = b0 == 0xFFFFFFFFu ? __builtin_inff() : __uint_as_float(order_bits_to_f32_bits(b0));
-    if (lane < kPreQ) vout = (uint64_t)src.out(it, lane);
+  const bool two = v.nq > 16;  // wave-uniform
+  const bool stamp = (p.debug & 16u) != 0;  // diagnosis: where do a wave's cycles go
+  const unsigned long long tp0 = stamp ? __builtin_amdgcn_s_memtime() : 0ull;
+  bool live[2];
+  uint32_t vseq[2] = {0, 0}, vslot[2] = {0, 0};
+  uint64_t vout[2] = {0, 0};
+  float thr[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    live[s] = s * 16 + n < (int)v.nq;
+    thr[s] = -__builtin_inff();  // dead query columns never hit
+    if (live[s]) {
+      vseq[s] = src.seq_base(it, s * 16 + n);
+      vslot[s] = src.bound_slot(it, s * 16 + n);
+      const uint32_t b0 = __hip_atomic_load(p.bounds32 + vslot[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      thr[s] = b0 == 0xFFFFFFFFu ? __builtin_inff() : __uint_as_float(order_bits_to_f32_bits(b0));
+      if (lane < 16) vout[s] = (uint64_t)src.out(it, s * 16 + lane);
+    }
   }
   for (uint32_t i = lane; i < kPreQ * kp; i += kWave) lists[i] = kKeyMax;
 
@@ -88,9 +105,11 @@ __device__ __forceinline__ void prescan_item(const Src& src, const PreParams& p,
   TileLoader L;
   L.init(v.rows, (uint64_t)n_tiles * kWave * p.ld * 4u, p.ld, lane);
   const float* xn_item = p.xnorm + src.storage_row(it);
-  f32x16_t accA, accB;
+  f32x16_t acc[2][2];  // [set][tile of the pair]
 #pragma unroll
-  for (int e = 0; e < 16; ++e) accA[e] = accB[e] = 0.0f;
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[s][0][e] = acc[s][1][e] = 0.0f;
   bool bad = false;
 
   // insert one key into query nn's sorted LDS list (lane i = i-th key); lowers the threshold of nn's lanes and
@@ -108,58 +127,68 @@ __device__ __forceinline__ void prescan_item(const Src& src, const PreParams& p,
       if (k2 != kKeyMax) {
         const uint32_t kb = (uint32_t)(k2 >> 32);
         const float nt = __uint_as_float(order_bits_to_f32_bits(kb));
-        if (n == nn) thr = nt < thr ? nt : thr;
-        if (lane == nn) atomicMin(p.bounds32 + vslot, kb);
+        if (n == (nn & 15)) {
+          if (nn < 16) thr[0] = nt < thr[0] ? nt : thr[0];
+          else thr[1] = nt < thr[1] ? nt : thr[1];
+        }
+        if (lane == (nn & 15)) atomicMin(p.bounds32 + (nn < 16 ? vslot[0] : vslot[1]), kb);
       }
     }
   };
 
-  // end of a tile: acc already holds val (the |x|^2 term went through the matrix core); rows of lane:
-  // 16*(e>>2) + 4*quarter + (e&3)
-  auto fold = [&](f32x16_t& acc, uint32_t t, bool tile_real) {
+  // end of a tile for query set S: acc already holds val (the |x|^2 term went through the matrix core); rows of
+  // a lane: 16*(e>>2) + 4*quarter + (e&3)
+  auto fold = [&](auto set_tag, f32x16_t& a, uint32_t t, bool tile_real) {
+    constexpr int S = decltype(set_tag)::value;
     const uint32_t r0 = t * kWave + 4u * (uint32_t)quarter;
     if (!tile_real || (t + 1) * kWave > v.nrows) {  // ragged tail (uniform branch): rows past the segment never hit
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const uint32_t row = r0 + 16u * (e >> 2) + (e & 3);
-        if (!tile_real || row >= v.nrows) acc[e] = __builtin_nanf("");
-        else bad |= live && !(__builtin_fabsf(acc[e]) < __builtin_inff());
+        if (!tile_real || row >= v.nrows) a[e] = __builtin_nanf("");
+        else bad |= live[S] && !(__builtin_fabsf(a[e]) < __builtin_inff());
       }
-    } else if (live) {
+    } else if (live[S]) {
 #pragma unroll
-      for (int e = 0; e < 16; ++e) bad |= !(__builtin_fabsf(acc[e]) < __builtin_inff());
+      for (int e = 0; e < 16; ++e) bad |= !(__builtin_fabsf(a[e]) < __builtin_inff());
     }
     uint64_t any = 0;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) any |= __ballot(acc[e] <= thr);
+    for (int e = 0; e < 16; ++e) any |= __ballot(a[e] <= thr[S]);
     if (any != 0 && !(p.debug & 1u)) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        uint64_t m = __ballot(acc[e] <= thr);
+        uint64_t m = __ballot(a[e] <= thr[S]);
         while (m) {
-          const int s = __ffsll((unsigned long long)m) - 1;
+          const int sl = __ffsll((unsigned long long)m) - 1;
           m &= m - 1;
-          const float fv = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(acc[e]), s));
-          const uint32_t sq = (uint32_t)__builtin_amdgcn_readlane((int)vseq, s) + t * kWave + 16u * (e >> 2) + 4u * ((uint32_t)s >> 4) + (e & 3);
-          insert(s & 15, make_key(fv, sq));
-          m &= __ballot(acc[e] <= thr);  // the threshold may just have dropped
+          const float fv = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(a[e]), sl));
+          const uint32_t sq = (uint32_t)__builtin_amdgcn_readlane((int)vseq[S], sl) + t * kWave + 16u * (e >> 2) + 4u * ((uint32_t)sl >> 4) + (e & 3);
+          insert(S * 16 + (sl & 15), make_key(fv, sq));
+          m &= __ballot(a[e] <= thr[S]);  // the threshold may just have dropped
         }
       }
     }
 #pragma unroll
-    for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+    for (int e = 0; e < 16; ++e) a[e] = 0.0f;
   };
+  using Set0 = std::integral_constant<int, 0>;
+  using Set1 = std::integral_constant<int, 1>;
 
-  // 2-deep register ring over (tile pair, chunk) steps; every load unconditional (see scan_item).  The ring also
-  // carries, per step, the pair's two |x|^2 operands (lane == row) and a fresh copy of the shared threshold.
-  u32x4 buf[2][2 * kLoads];
-  float xnA[2], xnB[2];
-  uint32_t gthr[2];
+  // Register ring of kPreRing (tile pair, chunk) steps; every load unconditional (see scan_item).  The ring also
+  // carries, per step, the pair's two |x|^2 operands (lane == row) and fresh copies of the shared thresholds.
+  // Ring slots are compile-time constants (integral_constant tags): a run-time slot index would put the ring
+  // in scratch memory.
+  u32x4 buf[kPreRing][2 * kLoads];
+  float xnA[kPreRing], xnB[kPreRing];
+  uint32_t gthr[kPreRing][2];
   const uint32_t n_steps = n_pairs * p.n_chunks;
   uint32_t pi = 0, ci = 0;
-  auto issue_next = [&](int b) {
+  auto issue_next = [&](auto btag) {
+    constexpr int b = decltype(btag)::value;
     const uint32_t tA = 2 * pi, tB = 2 * pi + 1 < n_tiles ? 2 * pi + 1 : last_tile;
-    gthr[b] = __hip_atomic_load(p.bounds32 + vslot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    gthr[b][0] = __hip_atomic_load(p.bounds32 + vslot[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    gthr[b][1] = __hip_atomic_load(p.bounds32 + vslot[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     xnA[b] = xn_item[tA * kWave + lane];
     xnB[b] = xn_item[tB * kWave + lane];
     const uint32_t soffA = tA * L.tile_bytes + ci * (kLoads * 1024u), soffB = tB * L.tile_bytes + ci * (kLoads * 1024u);
@@ -170,73 +199,115 @@ __device__ __forceinline__ void prescan_item(const Src& src, const PreParams& p,
     if (ci + 1 < p.n_chunks) ++ci;
     else if (pi + 1 < n_pairs) { ci = 0; ++pi; }
   };
-  if (n_steps) issue_next(0);
+  if (n_steps) {
+    issue_next(std::integral_constant<int, 0>{});
+    if constexpr (kPreRing == 3) issue_next(std::integral_constant<int, 1>{});
+  }
   uint32_t pc = 0, cc = 0;
-  const bool stamp = (p.debug & 16u) != 0;
-  unsigned long long t_wait = 0, t_math = 0, t_fold = 0;
-  for (uint32_t s0 = 0; s0 < n_steps; s0 += 2) {
+  unsigned long long t_wait = 0, t_math = 0, t_fold = 0, t_issue = 0;
+  const unsigned long long tp1 = stamp ? __builtin_amdgcn_s_memtime() : 0ull;
+  auto step = [&](auto btag, uint32_t s0) {
+    constexpr int B = decltype(btag)::value;
+    const unsigned long long ti0 = stamp ? __builtin_amdgcn_s_memtime() : 0ull;
+    // (issuing the refill in one burst costs ~100 cycles per load once the chip is HBM-bound -- back-pressure, not
+    // work; spreading the loads between the MFMA groups was measured 5 % SLOWER: the stall then blocks the in-order
+    // MFMA stream as well)
+    issue_next(std::integral_constant<int, (B + kPreRing - 1) % kPreRing>{});
+    if (s0 + B < n_steps) {
+      unsigned long long t0 = 0, t1 = 0, t2 = 0;
+      if (stamp) {
+        t0 = __builtin_amdgcn_s_memtime();
+        t_issue += t0 - ti0;
+        __builtin_amdgcn_s_waitcnt(kPreRing == 2 ? (0x4F70 | 4) : (0x8F70 | 8));  // vmcnt(20 / 40): this step's loads have landed
+        t1 = __builtin_amdgcn_s_memtime();
+      }
+      if (!(p.debug & 2u)) {
+        // qm[((c4 * 2 + set) * 16 + n) * 4 + u] = (-2 q_{16 set + n})[4 c4 + u]
+        const f32x4* ql = reinterpret_cast<const f32x4*>(qm) + ((size_t)cc * kLoads * kPreQ + n);
 #pragma unroll
-    for (int b = 0; b < 2; ++b) {
-      issue_next(b ^ 1);
-      if (s0 + b < n_steps) {
-        unsigned long long t0 = 0, t1 = 0, t2 = 0;
-        if (stamp) {
-          t0 = __builtin_amdgcn_s_memtime();
-          __builtin_amdgcn_s_waitcnt(0x4F70 | 3);  // vmcnt(19): this step's loads have landed
-          t1 = __builtin_amdgcn_s_memtime();
+        for (int i = 0; i < kLoads; ++i) {
+          const f32x4 q4 = ql[i * kPreQ];  // lanes of one query column read one address
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x1f32(__uint_as_float(buf[B][i][u]), q4[u], acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x1f32(__uint_as_float(buf[B][kLoads + i][u]), q4[u], acc[0][1], 0, 0, 0);
+          }
         }
-        if (!(p.debug & 2u)) {
-          const f32x4* ql = reinterpret_cast<const f32x4*>(qm) + ((size_t)cc * kLoads * kPreQ + n);
+        if (two) {
 #pragma unroll
           for (int i = 0; i < kLoads; ++i) {
-            const f32x4 q4 = ql[i * kPreQ];  // (-2 q_n)[4 columns]: lanes of one query column read one address
+            const f32x4 q4 = ql[i * kPreQ + 16];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-              accA = __builtin_amdgcn_mfma_f32_16x16x1f32(__uint_as_float(buf[b][i][u]), q4[u], accA, 0, 0, 0);
-              accB = __builtin_amdgcn_mfma_f32_16x16x1f32(__uint_as_float(buf[b][kLoads + i][u]), q4[u], accB, 0, 0, 0);
+              acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x1f32(__uint_as_float(buf[B][i][u]), q4[u], acc[1][0], 0, 0, 0);
+              acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x1f32(__uint_as_float(buf[B][kLoads + i][u]), q4[u], acc[1][1], 0, 0, 0);
             }
           }
-        } else {
-          accA[0] += __uint_as_float(buf[b][0][0] ^ buf[b][2 * kLoads - 1][3]);
         }
-        if (stamp) {
-          asm volatile("" ::"v"(accA[0]), "v"(accB[0]));
-          t2 = __builtin_amdgcn_s_memtime();
-          t_wait += t1 - t0;
-          t_math += t2 - t1;
-        }
-        if (++cc == p.n_chunks) {
-          cc = 0;
-          accA = __builtin_amdgcn_mfma_f32_16x16x1f32(xnA[b], 1.0f, accA, 0, 0, 0);  // + |x_row|^2 for every query column
-          accB = __builtin_amdgcn_mfma_f32_16x16x1f32(xnB[b], 1.0f, accB, 0, 0, 0);
-          if (live && gthr[b] != 0xFFFFFFFFu) {
-            const float g = __uint_as_float(order_bits_to_f32_bits(gthr[b]));
-            thr = g < thr ? g : thr;
+      } else {
+        acc[0][0][0] += __uint_as_float(buf[B][0][0] ^ buf[B][2 * kLoads - 1][3]);
+      }
+      if (stamp) {
+        asm volatile("" ::"v"(acc[0][0][0]), "v"(acc[0][1][0]));
+        t2 = __builtin_amdgcn_s_memtime();
+        t_wait += t1 - t0;
+        t_math += t2 - t1;
+      }
+      if (++cc == p.n_chunks) {
+        cc = 0;
+        const bool b_real = 2 * pc + 1 < n_tiles;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          if (live[s] && gthr[B][s] != 0xFFFFFFFFu) {
+            const float g = __uint_as_float(order_bits_to_f32_bits(gthr[B][s]));
+            thr[s] = g < thr[s] ? g : thr[s];
           }
-          fold(accA, 2 * pc, true);
-          fold(accB, 2 * pc + 1, 2 * pc + 1 < n_tiles);
-          ++pc;
-          if (stamp) t_fold += __builtin_amdgcn_s_memtime() - t2;
         }
+        acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x1f32(xnA[B], 1.0f, acc[0][0], 0, 0, 0);  // + |x_row|^2 for every query column
+        acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x1f32(xnB[B], 1.0f, acc[0][1], 0, 0, 0);
+        fold(Set0{}, acc[0][0], 2 * pc, true);
+        fold(Set0{}, acc[0][1], 2 * pc + 1, b_real);
+        if (two) {
+          acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x1f32(xnA[B], 1.0f, acc[1][0], 0, 0, 0);
+          acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x1f32(xnB[B], 1.0f, acc[1][1], 0, 0, 0);
+          fold(Set1{}, acc[1][0], 2 * pc, true);
+          fold(Set1{}, acc[1][1], 2 * pc + 1, b_real);
+        }
+        ++pc;
+        if (stamp) t_fold += __builtin_amdgcn_s_memtime() - t2;
       }
     }
+  };
+  for (uint32_t s0 = 0; s0 < n_steps; s0 += kPreRing) {
+    step(std::integral_constant<int, 0>{}, s0);
+    step(std::integral_constant<int, 1>{}, s0);
+    if constexpr (kPreRing == 3) step(std::integral_constant<int, 2>{}, s0);
   }
+  const unsigned long long te0 = stamp ? __builtin_amdgcn_s_memtime() : 0ull;
   if (stamp && lane == 0) {
     atomicAdd(p.stamps + 0, t_wait);
     atomicAdd(p.stamps + 1, t_math);
     atomicAdd(p.stamps + 2, t_fold);
     atomicAdd(p.stamps + 4, 1ull);
+    atomicAdd(p.stamps + 8, t_issue);
+    atomicAdd(p.stamps + 9, tp1 - tp0);    // item prologue
+    atomicAdd(p.stamps + 10, te0 - tp1);   // whole step loop
   }
-  if (bad) p.qflags[vslot] = 1u;
+  if (bad) {  // a non-finite val in either set: both of this lane's queries go to the exact re-scan
+    if (live[0]) p.qflags[vslot[0]] = 1u;
+    if (live[1]) p.qflags[vslot[1]] = 1u;
+  }
 #pragma unroll
   for (int qi = 0; qi < kPreQ; ++qi)
-    if (qi < (int)v.nq && lane < (int)kp) reinterpret_cast<uint64_t*>(readlane64(vout, qi))[lane] = lists[(uint32_t)qi * kp + lane];
+    if (qi < (int)v.nq && lane < (int)kp)
+      reinterpret_cast<uint64_t*>(readlane64(qi < 16 ? vout[0] : vout[1], qi & 15))[lane] = lists[(uint32_t)qi * kp + lane];
+  if (stamp && lane == 0) atomicAdd(p.stamps + 11, __builtin_amdgcn_s_memtime() - te0);  // item epilogue
 }
 
 // Quads of items share one query block, staged once per quad into LDS in the MFMA operand layout
-// qm[(c4 * 16 + n) * 4 + u] = -2 * q_n[4 c4 + u] (written so by gather_qblocks_kernel).
+// qm[((c4 * 2 + set) * 16 + n) * 4 + u] = -2 * q_{16 set + n}[4 c4 + u] (written so by gather_qblocks_kernel).
 template <class Src>
-__global__ __launch_bounds__(kWave * kWavesPerBlock) void prescan_kernel(Src src, PreParams p) {
+__global__ __launch_bounds__(kWave * kWavesPerBlock) __attribute__((amdgpu_waves_per_eu(1, 1))) void prescan_kernel(Src src, PreParams p) {
   static_assert(kWavesPerBlock == 4, "items are padded to quads");
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -258,10 +329,17 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void prescan_kernel(Src src
     const uint32_t it = bi * 4 + wid;
     ItemView<kPreQ> v;
     src.get(it, v);
+    const unsigned long long ts0 = (p.debug & 16u) ? __builtin_amdgcn_s_memtime() : 0ull;
     __syncthreads();  // the previous quad's readers are done with the LDS block
+    const unsigned long long ts1 = (p.debug & 16u) ? __builtin_amdgcn_s_memtime() : 0ull;
     const f32x4* g = reinterpret_cast<const f32x4*>(v.qb);
     for (uint32_t i = threadIdx.x; i < n4; i += kWave * kWavesPerBlock) reinterpret_cast<f32x4*>(qlds)[i] = g[i];
     __syncthreads();
+    if ((p.debug & 16u) && lane == 0) {
+      atomicAdd(p.stamps + 3, __builtin_amdgcn_s_memtime() - ts1);  // staging the query block
+      atomicAdd(p.stamps + 5, ts1 - ts0);                           // waiting for the quad's slowest wave
+      atomicAdd(p.stamps + 6, 1ull);
+    }
     if (v.nrows == 0) continue;  // padding item
     prescan_item(src, p, it, v, lane, qlds, lists);
   }
