@@ -1049,8 +1049,11 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
   if (use_pre) seg_rows = (uint32_t)round_up64(std::max<uint64_t>(256, (avg_len_all + 3) / 4), kWave);
   if (const char* e = getenv("VERS_SEG_ROWS")) seg_rows = (uint32_t)round_up64(std::max(64l, atol(e)), kWave);  // tuning knob
   // matrix-core scan: per-list balanced segments of about seg_rows rows (list_seg_rows)
-  const uint32_t seg_target = use_pre ? seg_rows : 0u;
-  const uint32_t S_max = use_pre ? 4 * std::max<uint32_t>(1, (h->max_len + 4 * seg_target - 1) / (4 * seg_target))
+  // per-list balanced segments (list_seg_rows): same-box A/B at cfg3 5.96 ms vs 6.27 ms with fixed 640-row segments;
+  // VERS_SEG_BALANCED=0 switches them off
+  static const bool seg_balanced = [] { const char* e = getenv("VERS_SEG_BALANCED"); return !e || atoi(e) != 0; }();
+  const uint32_t seg_target = use_pre && seg_balanced ? seg_rows : 0u;
+  const uint32_t S_max = seg_target ? 4 * std::max<uint32_t>(1, (h->max_len + 4 * seg_target - 1) / (4 * seg_target))
                                  : std::max<uint32_t>(1, (h->max_len + seg_rows - 1) / seg_rows);
   const uint64_t items_bound = groups_bound * (QG == 1 ? S_max : round_up(S_max, 4));
   if (items_bound > 0x7FFFFFFFull) return fail(VERS_ERR_INVALID, "search batch too large");

@@ -73,9 +73,17 @@ static __global__ void blocked_row_norms_kernel(const float* rows, uint32_t ld, 
 // One work item of the matrix-core scan: two 64-row tiles per step against the group's query columns, in one or
 // two sets of 16 (the second set only when the group holds more than 16 queries: same row operands, so a list
 // probed by up to 32 queries is streamed once).
-template <class Src>
+// `stage` (block-wide: barrier, copy the quad's query block into LDS, barrier) is called exactly once, AFTER the
+// item's first tile loads are in flight: the CU's memory pipeline keeps streaming while the block stages.
+template <class Src, class Stage>
 __device__ __forceinline__ void prescan_item(const Src& src, const PreParams& p, uint32_t it, const ItemView<kPreQ>& v, int lane,
-                                             const float* qm, uint64_t* lists) {
+                                             const float* qm, uint64_t* lists, Stage&& stage) {
+  if (v.nrows == 0) {  // padding item of the quad (wave-uniform): only the block-wide part
+    stage();
+    return;
+  }
+  const bool stage_first = (p.debug & 128u) != 0;  // A/B knob: stage before anything is in flight
+  if (stage_first) stage();
   const int n = lane & 15, quarter = lane >> 4;
   const uint32_t kp = p.kp;
   const bool two = v.nq > 16;  // wave-uniform
@@ -203,6 +211,7 @@ __device__ __forceinline__ void prescan_item(const Src& src, const PreParams& p,
     issue_next(std::integral_constant<int, 0>{});
     if constexpr (kPreRing == 3) issue_next(std::integral_constant<int, 1>{});
   }
+  if (!stage_first) stage();
   uint32_t pc = 0, cc = 0;
   unsigned long long t_wait = 0, t_math = 0, t_fold = 0, t_issue = 0;
   const unsigned long long tp1 = stamp ? __builtin_amdgcn_s_memtime() : 0ull;
@@ -328,20 +337,29 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) __attribute__((amdgpu_waves
     if (bi >= n_quads) break;
     const uint32_t it = bi * 4 + wid;
     ItemView<kPreQ> v;
-    src.get(it, v);
-    const unsigned long long ts0 = (p.debug & 16u) ? __builtin_amdgcn_s_memtime() : 0ull;
-    __syncthreads();  // the previous quad's readers are done with the LDS block
-    const unsigned long long ts1 = (p.debug & 16u) ? __builtin_amdgcn_s_memtime() : 0ull;
-    const f32x4* g = reinterpret_cast<const f32x4*>(v.qb);
-    for (uint32_t i = threadIdx.x; i < n4; i += kWave * kWavesPerBlock) reinterpret_cast<f32x4*>(qlds)[i] = g[i];
-    __syncthreads();
-    if ((p.debug & 16u) && lane == 0) {
-      atomicAdd(p.stamps + 3, __builtin_amdgcn_s_memtime() - ts1);  // staging the query block
-      atomicAdd(p.stamps + 5, ts1 - ts0);                           // waiting for the quad's slowest wave
-      atomicAdd(p.stamps + 6, 1ull);
-    }
-    if (v.nrows == 0) continue;  // padding item
-    prescan_item(src, p, it, v, lane, qlds, lists);
+    src.get(it, v);  // v.qb / v.nq are the same for the four items of the quad
+    auto stage = [&]() {
+      const unsigned long long ts0 = (p.debug & 16u) ? __builtin_amdgcn_s_memtime() : 0ull;
+      __syncthreads();  // the previous quad's readers are done with the LDS block
+      const unsigned long long ts1 = (p.debug & 16u) ? __builtin_amdgcn_s_memtime() : 0ull;
+      const f32x4* g = reinterpret_cast<const f32x4*>(v.qb);
+      f32x4* l4 = reinterpret_cast<f32x4*>(qlds);
+      if (v.nq > 16) {
+        for (uint32_t i = threadIdx.x; i < n4; i += kWave * kWavesPerBlock) l4[i] = g[i];
+      } else {  // one set of query columns: every other 256-byte run of the block
+        for (uint32_t i = threadIdx.x; i < n4 / 2; i += kWave * kWavesPerBlock) {
+          const uint32_t j = (i >> 4) * 32 + (i & 15);
+          l4[j] = g[j];
+        }
+      }
+      __syncthreads();
+      if ((p.debug & 16u) && lane == 0) {
+        atomicAdd(p.stamps + 3, __builtin_amdgcn_s_memtime() - ts1);  // staging the query block
+        atomicAdd(p.stamps + 5, ts1 - ts0);                           // waiting for the quad's slowest wave
+        atomicAdd(p.stamps + 6, 1ull);
+      }
+    };
+    prescan_item(src, p, it, v, lane, qlds, lists, stage);
   }
   if ((p.debug & 16u) && blockIdx.x == 0 && threadIdx.x == 0)
     p.stamps[7] = ((__builtin_amdgcn_s_memtime() - clk0) << 20) / ((__builtin_amdgcn_s_memrealtime() - rt0) | 1ull);
