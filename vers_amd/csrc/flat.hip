@@ -15,6 +15,7 @@ namespace vers {
 template <int QG, bool SEQ_IDS>
 struct FlatSrc {
   static constexpr bool kSeqIds = SEQ_IDS;
+  static constexpr bool kStreamOnce = true;
   const float* rows;  // blocked tiles
   uint64_t n;
   uint32_t ld;

@@ -54,6 +54,7 @@ constexpr int32_t kRetrySpill = 1001;  // internal: reference-mode spill ran pas
 template <int QG, bool SEQ_IDS>
 struct SegSrc {
   static constexpr bool kSeqIds = SEQ_IDS;
+  static constexpr bool kStreamOnce = SEQ_IDS;  // exhaustive scan of the stored rows: once; coarse quantiser: centroids are re-read
   const float* rows;
   uint64_t n;
   uint32_t ld;
@@ -103,6 +104,7 @@ struct ItemDesc {
 template <int QG>
 struct IvfSrc {
   static constexpr bool kSeqIds = false;
+  static constexpr bool kStreamOnce = true;
   const float* rows;
   uint32_t ld;
   const uint32_t* list_off;  // storage row of each (local) list

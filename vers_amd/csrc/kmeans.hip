@@ -39,6 +39,7 @@ void DevBuf::release() {
 template <int QG>
 struct AssignSrc {
   static constexpr bool kSeqIds = false;
+  static constexpr bool kStreamOnce = false;  // the centroid matrix is re-read by every point group
   const float* C;  // centroids, lane-transposed tiles
   uint32_t k, ld;
   uint32_t seg_rows;     // centroids per quarter (multiple of 64)

@@ -36,6 +36,10 @@ constexpr int kPreQ = 32;        // queries per group: two sets of 16 (one 16x16
 #endif
 constexpr int kPreRing = VERS_PRE_RING;  // steps of 16 KiB in flight per wave (2 or 3; measured equal); one wave per SIMD
 static_assert(kPreRing == 2 || kPreRing == 3, "ring depth");
+#ifndef VERS_PRE_AUX
+#define VERS_PRE_AUX 2
+#endif
+constexpr int kPreAux = VERS_PRE_AUX;  // cache policy of the row-tile loads: 2 = nt (streamed once); same-box A/B at cfg3: -1.8 % vs default
 constexpr uint32_t kPreMaxKp = 32;  // widest per-item list (LDS: 4 waves x 16 queries x kp keys)
 
 struct PreParams {
@@ -201,9 +205,9 @@ __device__ __forceinline__ void prescan_item(const Src& src, const PreParams& p,
     xnB[b] = xn_item[tB * kWave + lane];
     const uint32_t soffA = tA * L.tile_bytes + ci * (kLoads * 1024u), soffB = tB * L.tile_bytes + ci * (kLoads * 1024u);
 #pragma unroll
-    for (int i = 0; i < kLoads; ++i) buf[b][i] = __builtin_amdgcn_raw_buffer_load_b128(L.rsrc, L.lane_off, soffA + (uint32_t)i * 1024u, 0);
+    for (int i = 0; i < kLoads; ++i) buf[b][i] = __builtin_amdgcn_raw_buffer_load_b128(L.rsrc, L.lane_off, soffA + (uint32_t)i * 1024u, kPreAux);
 #pragma unroll
-    for (int i = 0; i < kLoads; ++i) buf[b][kLoads + i] = __builtin_amdgcn_raw_buffer_load_b128(L.rsrc, L.lane_off, soffB + (uint32_t)i * 1024u, 0);
+    for (int i = 0; i < kLoads; ++i) buf[b][kLoads + i] = __builtin_amdgcn_raw_buffer_load_b128(L.rsrc, L.lane_off, soffB + (uint32_t)i * 1024u, kPreAux);
     if (ci + 1 < p.n_chunks) ++ci;
     else if (pi + 1 < n_pairs) { ci = 0; ++pi; }
   };
@@ -477,6 +481,7 @@ __global__ __launch_bounds__(kWave * kMergeWaves) void ivf_rescore_kernel(Rescor
 // fallback_merge_kernel folds a query's P x 16 lists and emits.  Both exit at once when nothing is queued.
 struct FbSrc {
   static constexpr bool kSeqIds = false;
+  static constexpr bool kStreamOnce = true;
   uint64_t* out_ptr;
   uint32_t seq0;
   __device__ __forceinline__ uint32_t seq_base(uint32_t, int) const { return seq0; }

@@ -120,6 +120,15 @@ __host__ __device__ __forceinline__ uint64_t blocked_index(uint64_t row, uint32_
   return (row >> 6) * 64ull * ld + ((uint64_t)(col >> 2) * 64 + (row & 63)) * 4 + (col & 3);
 }
 
+// Cache policy of a tile load: rows that a launch streams once (corpus / inverted lists) are loaded non-temporal
+// (aux = 2) -- same-box A/B: cfg2 flat scan 95.9 -> 91-94 us, single-query list scan 62.2 -> 57.9 us; matrices that
+// every work item re-reads (centroids) keep the default policy so that they stay in L2.  Src::kStreamOnce selects.
+#ifndef VERS_TILE_AUX
+#define VERS_TILE_AUX 2
+#endif
+template <bool STREAM_ONCE>
+constexpr int tile_aux() { return STREAM_ONCE ? VERS_TILE_AUX : 0; }
+
 struct TileLoader {
   __amdgpu_buffer_rsrc_t rsrc;
   uint32_t lane_off;    // lane * 16 bytes
@@ -131,11 +140,12 @@ struct TileLoader {
     tile_bytes = ld * 256u;
   }
   // the kLoads float4 loads of (tile, chunk c): everything but the lane offset is wave-uniform -> soffset
+  template <int AUX>
   __device__ __forceinline__ void issue(u32x4 (&r)[kLoads], uint32_t tile, uint32_t c) const {
     const uint32_t soff = tile * tile_bytes + c * (kLoads * 1024u);
 #pragma unroll
     for (int i = 0; i < kLoads; ++i)
-      r[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane_off, soff + (uint32_t)i * 1024u, 0);
+      r[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane_off, soff + (uint32_t)i * 1024u, AUX);
   }
 };
 
@@ -280,6 +290,7 @@ __device__ __forceinline__ void tile_chunk_compute2(f32x2 (&accA)[QG / 2], f32x2
 //   uint32_t seq_base(it, qi) const          seq of the item's first row for query qi
 //   uint64_t* out(it, qi) const              partial slot (k keys) for query qi
 //   static constexpr bool kSeqIds            seq = seq_ids(it)[row] instead of seq_base + row
+//   static constexpr bool kStreamOnce        rows are read once per launch: non-temporal tile loads
 //   const uint32_t* seq_ids(it) const
 //   uint32_t bound_slot(it, qi) const        index into ScanParams::bounds of the merge group of (it, qi)
 template <int QG>
@@ -371,7 +382,7 @@ __device__ __forceinline__ void scan_item(const Src& src, const ScanParams& p, u
   const uint32_t n_steps = n_tiles * p.n_chunks;
   uint32_t ti = 0, ci = 0;  // (tile, chunk) the next issue fetches
   auto issue_next = [&](u32x4 (&r)[kLoads]) {
-    L.issue(r, ti, ci);
+    L.template issue<tile_aux<Src::kStreamOnce>()>(r, ti, ci);
     if (ci + 1 < p.n_chunks) ++ci;
     else if (ti + 1 < n_tiles) { ci = 0; ++ti; }  // else: stay on the last chunk (harmless re-read)
   };
@@ -464,9 +475,9 @@ __device__ __forceinline__ void scan_item2(const Src& src, const ScanParams& p, 
     const uint32_t tA = 2 * pi, tB = 2 * pi + 1 < n_tiles ? 2 * pi + 1 : last_tile;  // odd tail: B re-reads, rows masked
     const uint32_t soffA = tA * L.tile_bytes + ci * (kLoads * 1024u), soffB = tB * L.tile_bytes + ci * (kLoads * 1024u);
 #pragma unroll
-    for (int i = 0; i < kLoads; ++i) r[i] = __builtin_amdgcn_raw_buffer_load_b128(L.rsrc, L.lane_off, soffA + (uint32_t)i * 1024u, 0);
+    for (int i = 0; i < kLoads; ++i) r[i] = __builtin_amdgcn_raw_buffer_load_b128(L.rsrc, L.lane_off, soffA + (uint32_t)i * 1024u, tile_aux<Src::kStreamOnce>());
 #pragma unroll
-    for (int i = 0; i < kLoads; ++i) r[kLoads + i] = __builtin_amdgcn_raw_buffer_load_b128(L.rsrc, L.lane_off, soffB + (uint32_t)i * 1024u, 0);
+    for (int i = 0; i < kLoads; ++i) r[kLoads + i] = __builtin_amdgcn_raw_buffer_load_b128(L.rsrc, L.lane_off, soffB + (uint32_t)i * 1024u, tile_aux<Src::kStreamOnce>());
     if (ci + 1 < p.n_chunks) ++ci;
     else if (pi + 1 < n_pairs) { ci = 0; ++pi; }
   };
