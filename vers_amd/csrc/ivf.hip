@@ -140,6 +140,10 @@ struct IvfSrc {
     const ItemDesc d = items[it];
     return pairs[pair_off[d.list] + d.group * QG + qi];
   }
+  __device__ __forceinline__ const float* query_row(uint32_t it, uint32_t qi) const {  // padded query of slot qi
+    const ItemDesc d = items[it];
+    return qp + (uint64_t)(pairs[pair_off[d.list] + d.group * QG + qi] / P) * ldq;
+  }
   __device__ __forceinline__ uint32_t storage_row(uint32_t it) const {  // first storage row of the item
     const ItemDesc d = items[it];
     return list_off[d.list] + (d.seg != kNoSeg ? d.seg * list_seg_rows(list_len[d.list], seg_rows, seg_target) : 0u);
@@ -414,16 +418,13 @@ __global__ __launch_bounds__(kWave * kMergeWaves) void ivf_merge_kernel(
     }
     if (w0) {
       const bool have = lane < (int)take && list != kKeyMax;
+      uint32_t row = 0;
+      if (ref_mode) {
+        if (have) row = list_off[pj_list[(uint64_t)q * P + grp]] + ((uint32_t)list - pj_pref[(uint64_t)q * P + grp]);
+      } else {
+        row = wave_seq_rows(list, have, lane, pj_list + (uint64_t)q * P, pj_pref + (uint64_t)q * P, P, list_off);
+      }
       if (have) {
-        const uint32_t seq = (uint32_t)list;
-        uint32_t j = grp;
-        if (!ref_mode) {
-          j = 0;
-          for (uint32_t t = 0; t < P; ++t)
-            if (pj_pref[(uint64_t)q * P + t] <= seq && pj_list[(uint64_t)q * P + t] != kNoList) j = t;
-        }
-        const uint32_t L = pj_list[(uint64_t)q * P + j];
-        const uint32_t row = list_off[L] + (seq - pj_pref[(uint64_t)q * P + j]);
         const uint64_t o = (uint64_t)q * k_keep + written + lane;
         out_ids[o] = row_ids[row];
         out_dist[o] = __uint_as_float(order_bits_to_f32_bits((uint32_t)(list >> 32)));
@@ -1067,7 +1068,7 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
   if (int32_t rc = h->pairs.reserve(n_pj * sizeof(uint32_t))) return rc;
   if (int32_t rc = h->items.reserve(std::max<uint64_t>(1, items_bound) * sizeof(ItemDesc))) return rc;
   if (int32_t rc = h->groups.reserve(std::max<uint64_t>(1, groups_bound) * sizeof(GroupDesc))) return rc;
-  if (QG != 1)
+  if (QG != 1 && !use_pre)
     if (int32_t rc = h->qblocks.reserve(groups_bound * h->ldq * QG * sizeof(float))) return rc;
   h->ivf_bounds_off = (size_t)n_pj * S_max * k_keep;
   const size_t part_bytes = (h->ivf_bounds_off + n_pj) * sizeof(uint64_t);  // slots + one bound per (query, probe)
@@ -1105,7 +1106,7 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
   hipLaunchKernelGGL(items_kernel, dim3((k_l + 127) / 128), dim3(128), 0, st, cnt, h->list_len.as<uint32_t>(), k_l, (uint32_t)QG,
                      seg_rows, seg_target, pair_off, group_off, item_off, h->items.as<ItemDesc>(), h->groups.as<GroupDesc>());
   VERS_HIP_TRY(hipGetLastError());
-  if (QG != 1) {
+  if (QG != 1 && !use_pre) {  // (the matrix-core scan gathers its query block from qp while staging it)
     hipLaunchKernelGGL(gather_qblocks_kernel, dim3((unsigned)groups_bound), dim3(256), 0, st, h->groups.as<GroupDesc>(), tot,
                        h->pairs.as<uint32_t>(), P, qp, h->ldq, (uint32_t)QG, use_pre ? 1 : 0, h->qblocks.as<float>());
     VERS_HIP_TRY(hipGetLastError());
@@ -1135,7 +1136,10 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
     a.rows = h->rows.as<float>(); a.ld = h->ld; a.qp = qp; a.ldq = h->ldq; a.xmax2_bits = h->pre_misc.as<uint32_t>();
     a.qflags = qflags; a.force_fail = pre_mode == 2; a.fail_list = fail_list; a.stats = h->pre_misc.as<uint32_t>() + 1;
     a.status = h->status.as<uint32_t>(); a.out_ids = out_ids; a.out_dist = out_dist; a.out_count = out_count; a.out_keys = out_keys;
-    hipLaunchKernelGGL(ivf_rescore_kernel, dim3(b), dim3(kWave * kMergeWaves), (size_t)h->ld * sizeof(float), st, a);
+    const int stage_rows = rescore_lds_bytes(h->ld, kp, true) <= 144u * 1024u ? 1 : 0;
+    const size_t rs_lds = rescore_lds_bytes(h->ld, kp, stage_rows != 0);
+    if (int32_t rc2 = scan_prepare_launch(ivf_rescore_kernel, rs_lds)) return rc2;
+    hipLaunchKernelGGL(ivf_rescore_kernel, dim3(b), dim3(kWave * kRescoreWaves), rs_lds, st, a, stage_rows);
     VERS_HIP_TRY(hipGetLastError());
     const uint32_t fb_slots = std::min<uint32_t>(b, 64);
     hipLaunchKernelGGL(fallback_scan_kernel, dim3(P, fb_slots), dim3(kWave * kMergeWaves), 0, st, a, (const uint32_t*)h->list_len.as<uint32_t>(),

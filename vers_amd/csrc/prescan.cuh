@@ -346,14 +346,17 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) __attribute__((amdgpu_waves
       const unsigned long long ts0 = (p.debug & 16u) ? __builtin_amdgcn_s_memtime() : 0ull;
       __syncthreads();  // the previous quad's readers are done with the LDS block
       const unsigned long long ts1 = (p.debug & 16u) ? __builtin_amdgcn_s_memtime() : 0ull;
-      const f32x4* g = reinterpret_cast<const f32x4*>(v.qb);
+      // Gather straight from the padded queries (L2-resident): thread -> query slot n = i & 31 (fixed per thread),
+      // float4 column c4 = i >> 5; consecutive lanes write consecutive LDS float4s (conflict-free), the 16-byte
+      // global reads are uncoalesced but come out of L2 and are all independent.
       f32x4* l4 = reinterpret_cast<f32x4*>(qlds);
-      if (v.nq > 16) {
-        for (uint32_t i = threadIdx.x; i < n4; i += kWave * kWavesPerBlock) l4[i] = g[i];
-      } else {  // one set of query columns: every other 256-byte run of the block
-        for (uint32_t i = threadIdx.x; i < n4 / 2; i += kWave * kWavesPerBlock) {
-          const uint32_t j = (i >> 4) * 32 + (i & 15);
-          l4[j] = g[j];
+      const uint32_t slot = threadIdx.x & 31u;
+      const float* qrow = slot < v.nq ? src.query_row(it, slot) : nullptr;  // v.nq is the same for the quad's four items
+      if (v.nq > 16 || slot < 16) {
+        for (uint32_t i = threadIdx.x; i < n4; i += kWave * kWavesPerBlock) {
+          f32x4 x = {0.0f, 0.0f, 0.0f, 0.0f};
+          if (qrow != nullptr) x = *reinterpret_cast<const f32x4*>(qrow + 4 * (i >> 5));
+          l4[i] = -2.0f * x;  // exact scaling; the matrix core then yields -2 <x, q> directly
         }
       }
       __syncthreads();
@@ -393,13 +396,25 @@ struct RescoreArgs {
   uint64_t* out_keys;
 };
 
-// storage row of a sequence number (position in the query's concatenated probe order)
-__device__ __forceinline__ uint32_t seq_to_row(uint32_t seq, const uint32_t* pj_list, const uint32_t* pj_pref, uint32_t P,
-                                               const uint32_t* list_off) {
-  uint32_t j = 0;
-  for (uint32_t t = 0; t < P; ++t)
-    if (pj_pref[t] <= seq && pj_list[t] != 0xFFFFFFFFu) j = t;
-  return list_off[pj_list[j]] + (seq - pj_pref[j]);
+// Storage row of the key held by each lane (nprobe mode): seq = position in the query's concatenated probe order,
+// pj_pref = first position of probe j.  Whole-wave: lane t holds probe t's (pref, list); per key one ballot finds the
+// last scanned probe that starts at or before seq (a per-lane loop over the P probes is 2 P dependent-latency loads).
+__device__ __forceinline__ uint32_t wave_seq_rows(uint64_t key, bool valid, int lane, const uint32_t* pj_list, const uint32_t* pj_pref,
+                                                  uint32_t P, const uint32_t* list_off) {
+  const uint32_t pref = lane < (int)P ? pj_pref[lane] : 0u;
+  const uint32_t lst = lane < (int)P ? pj_list[lane] : 0xFFFFFFFFu;
+  uint32_t my_list = 0xFFFFFFFFu, my_off = 0;
+  uint64_t todo = __ballot(valid);
+  while (todo) {
+    const int c = __ffsll((unsigned long long)todo) - 1;
+    todo &= todo - 1;
+    const uint32_t seq = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)key, c);
+    const uint64_t m = __ballot(lst != 0xFFFFFFFFu && pref <= seq);
+    const int j = 63 - __builtin_clzll((unsigned long long)(m | 1ull));
+    const uint32_t lj = (uint32_t)__builtin_amdgcn_readlane((int)lst, j), pj = (uint32_t)__builtin_amdgcn_readlane((int)pref, j);
+    if (lane == c) { my_list = lj; my_off = seq - pj; }
+  }
+  return valid && my_list != 0xFFFFFFFFu ? list_off[my_list] + my_off : 0xFFFFFFFFu;
 }
 
 __device__ __forceinline__ void emit_topk(uint64_t fin, uint32_t q, uint32_t top_k, int lane, const uint32_t* pj_list, const uint32_t* pj_pref,
@@ -408,67 +423,141 @@ __device__ __forceinline__ void emit_topk(uint64_t fin, uint32_t q, uint32_t top
   const bool have = lane < (int)top_k && fin != kKeyMax;
   const uint64_t o = (uint64_t)q * top_k + lane;
   if (lane < (int)top_k && out_keys) out_keys[o] = have ? fin : kKeyMax;
+  const uint32_t row = wave_seq_rows(fin, have, lane, pj_list, pj_pref, P, list_off);
   if (have) {
-    out_ids[o] = row_ids[seq_to_row((uint32_t)fin, pj_list, pj_pref, P, list_off)];
+    out_ids[o] = row_ids[row];
     out_dist[o] = __uint_as_float(order_bits_to_f32_bits((uint32_t)(fin >> 32)));
   }
   const uint64_t hm = __ballot(have);
   if (lane == 0) out_count[q] = (uint32_t)__popcll(hm);
 }
 
-__global__ __launch_bounds__(kWave * kMergeWaves) void ivf_rescore_kernel(RescoreArgs a) {
-  __shared__ uint64_t sh[kMergeWaves][kWave];
-  extern __shared__ __attribute__((aligned(16))) float qs[];  // the query, padded
+// Block of 4 waves per query.  All waves merge the partial lists; then the kp candidate rows are fetched into LDS
+// cooperatively (kp x ld/4 independent float4 loads over 256 threads -- a lane walking its own row straight from
+// HBM is a chain of ld/4 dependent-latency loads) and wave 0 runs the ordered chains out of LDS.
+// stage_rows == 0 (rows too long for LDS): the chains read HBM directly.
+constexpr int kRescoreWaves = 4;
+inline size_t rescore_lds_bytes(uint32_t ld, uint32_t kp, bool stage_rows) {
+  return ((size_t)ld + (stage_rows ? (size_t)kp * (ld + 4) : 0)) * sizeof(float);
+}
+__global__ __launch_bounds__(kWave * kRescoreWaves) void ivf_rescore_kernel(RescoreArgs a, int stage_rows) {
+  __shared__ uint64_t sh[kRescoreWaves][kWave];
+  __shared__ uint32_t srow[kWave];
+  __shared__ float sred[kRescoreWaves];
+  extern __shared__ __attribute__((aligned(16))) float dyn[];  // the query, padded; then kp staged rows of pitch ld + 4
+  float* qs = dyn;
+  float* xs = dyn + a.ld;
   const uint32_t q = blockIdx.x;
   const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const float* qrow = a.qp + (uint64_t)q * a.ldq;
-  for (uint32_t i = threadIdx.x; i < a.ld; i += blockDim.x) qs[i] = qrow[i];
-  const uint64_t list = block_merge_keys(a.partials + (uint64_t)q * a.P * a.S_max * a.kp, a.P * a.S_max * a.kp, a.kp, sh);
+  float qpart = 0.0f;
+  for (uint32_t i = threadIdx.x; i < a.ld; i += blockDim.x) {
+    const float v = qrow[i];
+    qs[i] = v;
+    qpart = __fadd_rn(qpart, __fmul_rn(v, v));  // |q|^2 in any order: the bound inflates it
+  }
+  // merge the partial lists: every wave folds a strided share, wave 0 folds the four results
+  const uint32_t n_keys = a.P * a.S_max * a.kp;
+  const uint64_t* keys = a.partials + (uint64_t)q * n_keys;
+  uint64_t list = kKeyMax;
+  constexpr int U = 4;
+  for (uint32_t base = wid * kWave; base < n_keys; base += kRescoreWaves * kWave * U) {
+    uint64_t cand[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint32_t i = base + u * (kRescoreWaves * kWave) + lane;
+      cand[u] = i < n_keys ? keys[i] : kKeyMax;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) wave_topk_update(list, a.kp, cand[u], kKeyMax);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) qpart += __shfl_xor(qpart, off, kWave);
+  sh[wid][lane] = list;
+  if (lane == 0) sred[wid] = qpart;
   __syncthreads();
-  if (threadIdx.x >= kWave) return;
   const uint32_t* pl = a.pj_list + (uint64_t)q * a.P;
   const uint32_t* pp = a.pj_pref + (uint64_t)q * a.P;
-  const bool valid = lane < (int)a.kp && list != kKeyMax;
-  const uint32_t cnt = (uint32_t)__popcll(__ballot(valid));
-  // |q|^2 (any order; inflated below) and the certificate in f64
-  float qn = 0.0f;
-  for (uint32_t i = 0; i < a.ld; ++i) qn = __fadd_rn(qn, __fmul_rn(qs[i], qs[i]));
-  const double u = 5.9604644775390625e-08;
-  const double S = (double)qn * (1.0 + (double)a.d_pad * 2.0 * u) + (double)__uint_as_float(*a.xmax2_bits);
-  const double E = (5.0 * (double)a.d_pad + 32.0) * u * S;
-  const float val = __uint_as_float(order_bits_to_f32_bits((uint32_t)(list >> 32)));
-  bool certified = true;
-  if (cnt >= a.kp && cnt > 0) {  // a full list may have cut rows off: the kp-th val must clear tau_k + 2E
-    const uint32_t kk = a.top_k < cnt ? a.top_k : cnt;
-    const double tau = (double)__uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(val), (int)kk - 1));
-    const double top = (double)__uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(val), (int)a.kp - 1));
-    certified = top > tau + 2.0 * E;  // false for NaN / inf
+  __shared__ uint32_t s_failed;
+  bool survivor = false;
+  if (wid == 0) {
+    for (int w = 1; w < kRescoreWaves; ++w) wave_topk_update(list, a.kp, sh[w][lane], kKeyMax);
+    const bool valid = lane < (int)a.kp && list != kKeyMax;
+    const uint32_t cnt = (uint32_t)__popcll(__ballot(valid));
+    float qn = 0.0f;
+    for (int w = 0; w < kRescoreWaves; ++w) qn += sred[w];
+    const double u = 5.9604644775390625e-08;
+    const double S = (double)qn * (1.0 + (double)a.d_pad * 2.0 * u) + (double)__uint_as_float(*a.xmax2_bits);
+    const double E = (5.0 * (double)a.d_pad + 32.0) * u * S;
+    const float val = __uint_as_float(order_bits_to_f32_bits((uint32_t)(list >> 32)));
+    bool certified = true;
+    double lim = __builtin_inf();
+    if (cnt > 0) {
+      const uint32_t kk = a.top_k < cnt ? a.top_k : cnt;
+      const double tau = (double)__uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(val), (int)kk - 1));
+      lim = tau + 2.0 * E;  // a member of the true top-k has val <= tau_k + 2E (header)
+      if (cnt >= a.kp) {    // a full list may have cut rows off: the kp-th val must clear the limit
+        const double top = (double)__uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(val), (int)a.kp - 1));
+        certified = top > lim;  // false for NaN / inf
+      }
+    }
+    if (a.qflags[(uint64_t)q * a.P] != 0 || a.force_fail) certified = false;
+    // only candidates inside the limit can reach the top-k: the others are not worth their 3 KiB gather
+    survivor = certified && valid && !((double)val > lim);
+    srow[lane] = wave_seq_rows(list, survivor, lane, pl, pp, a.P, a.list_off);
+    if (lane == 0) {
+      s_failed = certified ? 0u : 1u;
+      if (!certified) { a.fail_list[atomicAdd(a.fail_list + gridDim.x, 1u)] = q; atomicAdd(a.stats, 1u); }  // the fallback kernels redo it
+    }
   }
-  if (a.qflags[(uint64_t)q * a.P] != 0 || a.force_fail) certified = false;
-  if (!certified) {  // queued: the fallback kernels write this query's results
-    if (lane == 0) { a.fail_list[atomicAdd(a.fail_list + gridDim.x, 1u)] = q; atomicAdd(a.stats, 1u); }
-    return;
+  __syncthreads();
+  if (s_failed) return;
+  if (stage_rows) {
+    const uint32_t n4 = a.ld / 4, pitch = a.ld + 4;
+    for (uint32_t idx = threadIdx.x; idx < a.kp * n4; idx += blockDim.x) {
+      const uint32_t c = idx / n4, j = idx - c * n4;
+      const uint32_t row = srow[c];
+      if (row != 0xFFFFFFFFu)
+        *reinterpret_cast<f32x4*>(xs + (size_t)c * pitch + 4 * j) =
+            (reinterpret_cast<const f32x4*>(a.rows + (uint64_t)(row >> 6) * 64ull * a.ld) + (row & 63))[(uint64_t)j * 64];
+    }
+    __syncthreads();
   }
+  if (wid != 0) return;
+  const bool valid = survivor;
   // exact distances of the kp candidates: lane per candidate, the reference's ordered chain
   uint64_t cand = kKeyMax;
   if (valid) {
-    const uint32_t seq = (uint32_t)list;
-    const uint32_t row = seq_to_row(seq, pl, pp, a.P, a.list_off);
-    const f32x4* xp = reinterpret_cast<const f32x4*>(a.rows + (uint64_t)(row >> 6) * 64ull * a.ld) + (row & 63);
+    const uint32_t row = srow[lane];
     const f32x4* q4p = reinterpret_cast<const f32x4*>(qs);
     float acc = 0.0f;
-#pragma unroll 8
-    for (uint32_t j = 0; j < a.ld / 4; ++j) {
-      const f32x4 x4 = xp[(uint64_t)j * 64];
-      const f32x4 q4 = q4p[j];
+    if (stage_rows) {
+      const f32x4* xp = reinterpret_cast<const f32x4*>(xs + (size_t)lane * (a.ld + 4));
+      for (uint32_t j = 0; j < a.ld / 4; ++j) {
+        const f32x4 x4 = xp[j];
+        const f32x4 q4 = q4p[j];
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
-        const float t = __fsub_rn(x4[c], q4[c]);
-        acc = __fadd_rn(acc, __fmul_rn(t, t));
+        for (int c = 0; c < 4; ++c) {
+          const float t = __fsub_rn(x4[c], q4[c]);
+          acc = __fadd_rn(acc, __fmul_rn(t, t));
+        }
+      }
+    } else {
+      const f32x4* xp = reinterpret_cast<const f32x4*>(a.rows + (uint64_t)(row >> 6) * 64ull * a.ld) + (row & 63);
+#pragma unroll 8
+      for (uint32_t j = 0; j < a.ld / 4; ++j) {
+        const f32x4 x4 = xp[(uint64_t)j * 64];
+        const f32x4 q4 = q4p[j];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const float t = __fsub_rn(x4[c], q4[c]);
+          acc = __fadd_rn(acc, __fmul_rn(t, t));
+        }
       }
     }
     if (acc != acc) atomicOr(a.status, 1u);
-    cand = make_key(acc, seq);
+    cand = make_key(acc, (uint32_t)list);
   }
   uint64_t fin = kKeyMax;
   wave_topk_update(fin, a.top_k, cand, kKeyMax);
