@@ -118,6 +118,7 @@ struct IvfSrc {
   const float* qblocks;       // QG > 1: [group][ldq][QG]
   const float* qp;            // QG == 1: padded queries [b][ldq]
   uint32_t ldq, P, S_max, k_keep, seg_rows, seg_target;
+  uint32_t halves;            // partial slots per (pair, segment): the matrix-core scan may walk an item with two waves
   uint32_t bound_per_pair;    // reference mode merges per (query, list); nprobe mode per query
   const uint32_t* pj_pref;    // [b*P] sequence base of probe j of query q
   uint64_t* partials;         // [b*P*S_max][k_keep]
@@ -153,8 +154,8 @@ struct IvfSrc {
     return pj_pref[pairs[pair_off[d.list] + d.group * QG + qi]] + d.seg * list_seg_rows(list_len[d.list], seg_rows, seg_target);
   }
   __device__ __forceinline__ const uint32_t* seq_ids(uint32_t) const { return nullptr; }
-  __device__ __forceinline__ uint64_t* out(uint32_t it, int qi) const {
-    return partials + ((uint64_t)pair_of(it, qi) * S_max + items[it].seg) * k_keep;
+  __device__ __forceinline__ uint64_t* out(uint32_t it, int qi, int half = 0) const {  // S_max counts slots (segments * halves)
+    return partials + ((uint64_t)pair_of(it, qi) * S_max + items[it].seg * halves + half) * k_keep;
   }
   __device__ __forceinline__ uint32_t bound_slot(uint32_t it, int qi) const {
     const uint32_t pr = pair_of(it, qi);
@@ -956,7 +957,7 @@ int32_t launch_ivf_scan(vers_ivf* h, const IvfSrc<QG>& src, uint32_t items_bound
 }
 
 // the matrix-core list scan (prescan.cuh); timed through the same event ring as launch_ivf_scan
-int32_t launch_prescan(vers_ivf* h, const IvfSrc<kPreQ>& src, uint32_t items_bound, uint32_t kp, uint32_t* qflags, hipStream_t st) {
+int32_t launch_prescan(vers_ivf* h, const IvfSrc<kPreQ>& src, uint32_t items_bound, uint32_t kp, uint32_t* qflags, bool use_g, hipStream_t st) {
   PreParams p;
   p.ld = h->ld;
   p.n_chunks = h->ld / kChunk;
@@ -978,8 +979,8 @@ int32_t launch_prescan(vers_ivf* h, const IvfSrc<kPreQ>& src, uint32_t items_bou
     VERS_HIP_TRY(hipMemsetAsync(h->quad_counter.p, 0, 16, st));
     p.next_quad = h->quad_counter.as<uint32_t>();
   }
-  const size_t lds = prescan_lds_bytes(h->ld, kp);
-  if (int32_t rc = scan_prepare_launch(prescan_kernel<IvfSrc<kPreQ>>, lds)) return rc;
+  const size_t lds = use_g ? prescan_lds_bytes_g(h->ld, kp) : prescan_lds_bytes(h->ld, kp);
+  if (int32_t rc = use_g ? scan_prepare_launch(prescan_kernel_g<IvfSrc<kPreQ>>, lds) : scan_prepare_launch(prescan_kernel<IvfSrc<kPreQ>>, lds)) return rc;
   uint32_t blocks = (items_bound + kWavesPerBlock - 1) / kWavesPerBlock;
   uint32_t per_cu = std::max<uint32_t>(1, std::min<uint32_t>(2, (uint32_t)((160u * 1024u) / lds)));  // 1 at d = 768 (measured: as fast as 2)
   if (const char* e = getenv("VERS_PRE_BLOCKS_PER_CU")) per_cu = std::max(1, atoi(e));  // tuning knob
@@ -988,7 +989,8 @@ int32_t launch_prescan(vers_ivf* h, const IvfSrc<kPreQ>& src, uint32_t items_bou
   if (blocks == 0) blocks = 1;
   const uint32_t slot = (uint32_t)(h->ev_count % vers_ivf::kEvRing);
   VERS_HIP_TRY(hipEventRecord(h->ev0[slot], st));
-  hipLaunchKernelGGL((prescan_kernel<IvfSrc<kPreQ>>), dim3(blocks), dim3(kWave * kWavesPerBlock), lds, st, src, p);
+  if (use_g) hipLaunchKernelGGL((prescan_kernel_g<IvfSrc<kPreQ>>), dim3(blocks), dim3(kWave * kPreWavesG), lds, st, src, p);
+  else hipLaunchKernelGGL((prescan_kernel<IvfSrc<kPreQ>>), dim3(blocks), dim3(kWave * kWavesPerBlock), lds, st, src, p);
   VERS_HIP_TRY(hipGetLastError());
   VERS_HIP_TRY(hipEventRecord(h->ev1[slot], st));
   h->ev_count += 1;
@@ -1056,9 +1058,13 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
   // VERS_SEG_BALANCED=0 switches them off
   static const bool seg_balanced = [] { const char* e = getenv("VERS_SEG_BALANCED"); return !e || atoi(e) != 0; }();
   const uint32_t seg_target = use_pre && seg_balanced ? seg_rows : 0u;
-  const uint32_t S_max = seg_target ? 4 * std::max<uint32_t>(1, (h->max_len + 4 * seg_target - 1) / (4 * seg_target))
-                                 : std::max<uint32_t>(1, (h->max_len + seg_rows - 1) / seg_rows);
-  const uint64_t items_bound = groups_bound * (QG == 1 ? S_max : round_up(S_max, 4));
+  // variant of the matrix-core scan: two waves per item (prescan_kernel_g) unless VERS_PRE_G=0
+  static const bool pre_g = [] { const char* e = getenv("VERS_PRE_G"); return !e || atoi(e) != 0; }();
+  const bool use_g = use_pre && pre_g && prescan_lds_bytes_g(h->ld, kp) <= 160u * 1024u;
+  const uint32_t pre_halves = use_g ? (uint32_t)kPreHalves : 1u;
+  const uint32_t S_max = pre_halves * (seg_target ? 4 * std::max<uint32_t>(1, (h->max_len + 4 * seg_target - 1) / (4 * seg_target))
+                                                  : std::max<uint32_t>(1, (h->max_len + seg_rows - 1) / seg_rows));
+  const uint64_t items_bound = groups_bound * (QG == 1 ? S_max : round_up(S_max / pre_halves, 4));
   if (items_bound > 0x7FFFFFFFull) return fail(VERS_ERR_INVALID, "search batch too large");
 
   const uint32_t k_l = h->k;
@@ -1118,6 +1124,7 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
     src.cnt = cnt; src.pair_off = pair_off; src.pairs = h->pairs.as<uint32_t>(); src.group_off = group_off;
     src.qblocks = h->qblocks.as<float>(); src.qp = qp; src.ldq = h->ldq; src.P = P; src.S_max = S_max; src.k_keep = k_keep;
     src.seg_rows = seg_rows; src.seg_target = seg_target; src.pj_pref = pj_pref; src.partials = h->partials.as<uint64_t>();
+    src.halves = pre_halves;
     src.bound_per_pair = ref_mode ? 1u : 0u;
   };
   int32_t rc;
@@ -1129,7 +1136,7 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
     VERS_HIP_TRY(hipMemsetAsync(h->qfail.p, 0, (b + 4 + n_pj) * sizeof(uint32_t), st));
     uint32_t* fail_list = h->qfail.as<uint32_t>();
     uint32_t* qflags = fail_list + b + 4;
-    if (int32_t rc2 = launch_prescan(h, src, (uint32_t)items_bound, kp, qflags, st)) return rc2;
+    if (int32_t rc2 = launch_prescan(h, src, (uint32_t)items_bound, kp, qflags, use_g, st)) return rc2;
     RescoreArgs a;
     a.partials = h->partials.as<uint64_t>(); a.P = P; a.S_max = S_max; a.kp = kp; a.top_k = top_k; a.d_pad = h->ld;
     a.pj_list = pj_list; a.pj_pref = pj_pref; a.list_off = h->list_off.as<uint32_t>(); a.row_ids = h->row_ids.as<uint32_t>();

@@ -106,7 +106,7 @@ __device__ __forceinline__ void prescan_item(const Src& src, const PreParams& p,
       vslot[s] = src.bound_slot(it, s * 16 + n);
       const uint32_t b0 = __hip_atomic_load(p.bounds32 + vslot[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       thr[s] = b0 == 0xFFFFFFFFu ? __builtin_inff() : __uint_as_float(order_bits_to_f32_bits(b0));
-      if (lane < 16) vout[s] = (uint64_t)src.out(it, s * 16 + lane);
+      if (lane < 16) vout[s] = (uint64_t)src.out(it, s * 16 + lane, 0);
     }
   }
   for (uint32_t i = lane; i < kPreQ * kp; i += kWave) lists[i] = kKeyMax;
@@ -367,6 +367,269 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) __attribute__((amdgpu_waves
       }
     };
     prescan_item(src, p, it, v, lane, qlds, lists, stage);
+  }
+  if ((p.debug & 16u) && blockIdx.x == 0 && threadIdx.x == 0)
+    p.stamps[7] = ((__builtin_amdgcn_s_memtime() - clk0) << 20) / ((__builtin_amdgcn_s_memrealtime() - rt0) | 1ull);
+}
+
+// ---- variant: two waves per item, eight per block ---------------------------------------------------
+// Same algorithm, other occupancy: the block still owns a quad of items and ONE query block in LDS, but every
+// item is walked by a pair of waves (first / second half of its tiles, one tile per step), so each SIMD holds
+// two waves (<= 256 registers each).  While one wave of a SIMD sits in the back-pressure of an HBM-bound load
+// burst the other issues its MFMAs -- with a single wave per SIMD those two phases add up (stamps: a third of
+// the step loop was load issue).
+constexpr int kPreHalves = 2;
+constexpr int kPreWavesG = 4 * kPreHalves;
+inline size_t prescan_lds_bytes_g(uint32_t ld, uint32_t kp) {
+  return (size_t)ld * kPreQ * sizeof(float) + 16 + (size_t)kPreWavesG * kPreQ * kp * sizeof(uint64_t);
+}
+
+template <class Src, class Stage>
+__device__ __forceinline__ void prescan_item_g(const Src& src, const PreParams& p, uint32_t it, const ItemView<kPreQ>& v, int half, int lane,
+                                               const float* qm, uint64_t* lists, Stage&& stage) {
+  const uint32_t n_tiles = (v.nrows + kWave - 1) / kWave;
+  const uint32_t t_half = (n_tiles + 1) / 2;
+  const uint32_t t_begin = half ? t_half : 0u, t_end = half ? n_tiles : t_half;
+  if (t_begin >= t_end) {  // padding item, or a one-tile item's second half (wave-uniform): only the block-wide part
+    stage();
+    return;
+  }
+  const int n = lane & 15, quarter = lane >> 4;
+  const uint32_t kp = p.kp;
+  const bool two = v.nq > 16;  // wave-uniform
+  const bool stamp = (p.debug & 16u) != 0;
+  const unsigned long long tp0 = stamp ? __builtin_amdgcn_s_memtime() : 0ull;
+  // the first tile loads go out before anything else: they fly while the item is set up and the block stages
+  TileLoader L;
+  L.init(v.rows, (uint64_t)n_tiles * kWave * p.ld * 4u, p.ld, lane);
+  const float* xn_item = p.xnorm + src.storage_row(it);
+  constexpr int R = 2;  // ring of (tile, chunk) steps, 8 KiB each (a third slot spills: 256 registers per wave)
+  u32x4 buf[R][kLoads];
+  float xn[R];
+  uint32_t gthr[R][2];
+  const uint32_t n_steps = (t_end - t_begin) * p.n_chunks;
+  uint32_t ti = t_begin, ci = 0;
+  uint32_t vslot[2] = {0, 0};
+  auto issue_next = [&](auto btag, bool with_thr) {
+    constexpr int b = decltype(btag)::value;
+    if (with_thr) {
+      gthr[b][0] = __hip_atomic_load(p.bounds32 + vslot[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      gthr[b][1] = __hip_atomic_load(p.bounds32 + vslot[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      gthr[b][0] = gthr[b][1] = 0xFFFFFFFFu;
+    }
+    xn[b] = xn_item[ti * kWave + lane];
+    const uint32_t soff = ti * L.tile_bytes + ci * (kLoads * 1024u);
+#pragma unroll
+    for (int i = 0; i < kLoads; ++i) buf[b][i] = __builtin_amdgcn_raw_buffer_load_b128(L.rsrc, L.lane_off, soff + (uint32_t)i * 1024u, kPreAux);
+    if (ci + 1 < p.n_chunks) ++ci;
+    else if (ti + 1 < t_end) { ci = 0; ++ti; }
+  };
+  issue_next(std::integral_constant<int, 0>{}, false);
+
+  bool live[2];
+  uint32_t vseq[2] = {0, 0};
+  uint64_t vout[2] = {0, 0};
+  float thr[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    live[s] = s * 16 + n < (int)v.nq;
+    thr[s] = -__builtin_inff();  // dead query columns never hit
+    if (live[s]) {
+      vseq[s] = src.seq_base(it, s * 16 + n);
+      vslot[s] = src.bound_slot(it, s * 16 + n);
+      const uint32_t b0 = __hip_atomic_load(p.bounds32 + vslot[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      thr[s] = b0 == 0xFFFFFFFFu ? __builtin_inff() : __uint_as_float(order_bits_to_f32_bits(b0));
+      if (lane < 16) vout[s] = (uint64_t)src.out(it, s * 16 + lane, half);
+    }
+  }
+  for (uint32_t i = lane; i < kPreQ * kp; i += kWave) lists[i] = kKeyMax;
+  f32x16_t acc[2];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[0][e] = acc[1][e] = 0.0f;
+  bool bad = false;
+
+  auto insert = [&](int nn, uint64_t key) {  // see prescan_item
+    uint64_t* Ln = lists + (uint32_t)nn * kp;
+    const uint64_t cur = lane < (int)kp ? Ln[lane] : kKeyMax;
+    const uint64_t kth = readlane64(cur, (int)kp - 1);
+    if (key < kth) {
+      const uint64_t prev = shift_up1_64(cur);
+      const uint64_t mx = prev > key ? prev : key;
+      const uint64_t nw = key < cur ? mx : cur;
+      if (lane < (int)kp) Ln[lane] = nw;
+      const uint64_t k2 = readlane64(nw, (int)kp - 1);
+      if (k2 != kKeyMax) {
+        const uint32_t kb = (uint32_t)(k2 >> 32);
+        const float nt = __uint_as_float(order_bits_to_f32_bits(kb));
+        if (n == (nn & 15)) {
+          if (nn < 16) thr[0] = nt < thr[0] ? nt : thr[0];
+          else thr[1] = nt < thr[1] ? nt : thr[1];
+        }
+        if (lane == (nn & 15)) atomicMin(p.bounds32 + (nn < 16 ? vslot[0] : vslot[1]), kb);
+      }
+    }
+  };
+  auto fold = [&](auto set_tag, f32x16_t& a, uint32_t t) {  // see prescan_item
+    constexpr int S = decltype(set_tag)::value;
+    const uint32_t r0 = t * kWave + 4u * (uint32_t)quarter;
+    if ((t + 1) * kWave > v.nrows) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const uint32_t row = r0 + 16u * (e >> 2) + (e & 3);
+        if (row >= v.nrows) a[e] = __builtin_nanf("");
+        else bad |= live[S] && !(__builtin_fabsf(a[e]) < __builtin_inff());
+      }
+    } else if (live[S]) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) bad |= !(__builtin_fabsf(a[e]) < __builtin_inff());
+    }
+    uint64_t any = 0;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) any |= __ballot(a[e] <= thr[S]);
+    if (any != 0 && !(p.debug & 1u)) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        uint64_t m = __ballot(a[e] <= thr[S]);
+        while (m) {
+          const int sl = __ffsll((unsigned long long)m) - 1;
+          m &= m - 1;
+          const float fv = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(a[e]), sl));
+          const uint32_t sq = (uint32_t)__builtin_amdgcn_readlane((int)vseq[S], sl) + t * kWave + 16u * (e >> 2) + 4u * ((uint32_t)sl >> 4) + (e & 3);
+          insert(S * 16 + (sl & 15), make_key(fv, sq));
+          m &= __ballot(a[e] <= thr[S]);
+        }
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < 16; ++e) a[e] = 0.0f;
+  };
+  using Set0 = std::integral_constant<int, 0>;
+  using Set1 = std::integral_constant<int, 1>;
+
+  stage();
+  uint32_t tc = t_begin, cc = 0;
+  unsigned long long t_math = 0, t_fold = 0, t_issue = 0;
+  const unsigned long long tp1 = stamp ? __builtin_amdgcn_s_memtime() : 0ull;
+  auto step = [&](auto btag, uint32_t s0) {
+    constexpr int B = decltype(btag)::value;
+    const unsigned long long ti0 = stamp ? __builtin_amdgcn_s_memtime() : 0ull;
+    issue_next(std::integral_constant<int, (B + R - 1) % R>{}, true);
+    if (s0 + B < n_steps) {
+      unsigned long long t1 = 0, t2 = 0;
+      if (stamp) { t1 = __builtin_amdgcn_s_memtime(); t_issue += t1 - ti0; }
+      if (!(p.debug & 2u)) {
+        const f32x4* ql = reinterpret_cast<const f32x4*>(qm) + ((size_t)cc * kLoads * kPreQ + n);
+#pragma unroll
+        for (int i = 0; i < kLoads; ++i) {
+          const f32x4 q4 = ql[i * kPreQ];
+#pragma unroll
+          for (int u = 0; u < 4; ++u) acc[0] = __builtin_amdgcn_mfma_f32_16x16x1f32(__uint_as_float(buf[B][i][u]), q4[u], acc[0], 0, 0, 0);
+        }
+        if (two) {
+#pragma unroll
+          for (int i = 0; i < kLoads; ++i) {
+            const f32x4 q4 = ql[i * kPreQ + 16];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc[1] = __builtin_amdgcn_mfma_f32_16x16x1f32(__uint_as_float(buf[B][i][u]), q4[u], acc[1], 0, 0, 0);
+          }
+        }
+      } else {
+        acc[0][0] += __uint_as_float(buf[B][0][0] ^ buf[B][kLoads - 1][3]);
+      }
+      if (stamp) {
+        asm volatile("" ::"v"(acc[0][0]));
+        t2 = __builtin_amdgcn_s_memtime();
+        t_math += t2 - t1;
+      }
+      if (++cc == p.n_chunks) {
+        cc = 0;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          if (live[s] && gthr[B][s] != 0xFFFFFFFFu) {
+            const float g = __uint_as_float(order_bits_to_f32_bits(gthr[B][s]));
+            thr[s] = g < thr[s] ? g : thr[s];
+          }
+        }
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x1f32(xn[B], 1.0f, acc[0], 0, 0, 0);  // + |x_row|^2 for every query column
+        fold(Set0{}, acc[0], tc);
+        if (two) {
+          acc[1] = __builtin_amdgcn_mfma_f32_16x16x1f32(xn[B], 1.0f, acc[1], 0, 0, 0);
+          fold(Set1{}, acc[1], tc);
+        }
+        ++tc;
+        if (stamp) t_fold += __builtin_amdgcn_s_memtime() - t2;
+      }
+    }
+  };
+  for (uint32_t s0 = 0; s0 < n_steps; s0 += R) {
+    step(std::integral_constant<int, 0>{}, s0);
+    step(std::integral_constant<int, 1>{}, s0);
+  }
+  const unsigned long long te0 = stamp ? __builtin_amdgcn_s_memtime() : 0ull;
+  if (stamp && lane == 0) {
+    atomicAdd(p.stamps + 1, t_math);
+    atomicAdd(p.stamps + 2, t_fold);
+    atomicAdd(p.stamps + 4, 1ull);
+    atomicAdd(p.stamps + 8, t_issue);
+    atomicAdd(p.stamps + 9, tp1 - tp0);
+    atomicAdd(p.stamps + 10, te0 - tp1);
+  }
+  if (bad) {
+    if (live[0]) p.qflags[vslot[0]] = 1u;
+    if (live[1]) p.qflags[vslot[1]] = 1u;
+  }
+#pragma unroll
+  for (int qi = 0; qi < kPreQ; ++qi)
+    if (qi < (int)v.nq && lane < (int)kp)
+      reinterpret_cast<uint64_t*>(readlane64(qi < 16 ? vout[0] : vout[1], qi & 15))[lane] = lists[(uint32_t)qi * kp + lane];
+  if (stamp && lane == 0) atomicAdd(p.stamps + 11, __builtin_amdgcn_s_memtime() - te0);
+}
+
+template <class Src>
+__global__ __launch_bounds__(kWave * kPreWavesG) __attribute__((amdgpu_waves_per_eu(2, 2))) void prescan_kernel_g(Src src, PreParams p) {
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  extern __shared__ __attribute__((aligned(16))) float qlds[];
+  uint32_t* nq_lds = reinterpret_cast<uint32_t*>(qlds + (size_t)p.ld * kPreQ);
+  uint64_t* lists = reinterpret_cast<uint64_t*>(qlds + (size_t)p.ld * kPreQ + 4) + (size_t)wid * kPreQ * p.kp;
+  const uint32_t n_quads = src.n_items() / 4;
+  const uint32_t n4 = p.ld * (kPreQ / 4);
+  const unsigned long long clk0 = (p.debug & 16u) ? __builtin_amdgcn_s_memtime() : 0ull;
+  const unsigned long long rt0 = (p.debug & 16u) ? __builtin_amdgcn_s_memrealtime() : 0ull;
+  for (uint32_t b0 = blockIdx.x;; b0 += gridDim.x) {
+    uint32_t bi = b0;
+    if (p.next_quad != nullptr) {
+      if (threadIdx.x == 0) *nq_lds = atomicAdd(p.next_quad, 1u);
+      __syncthreads();
+      bi = *nq_lds;
+    }
+    if (bi >= n_quads) break;
+    const uint32_t it = bi * 4 + (wid & 3);
+    ItemView<kPreQ> v;
+    src.get(it, v);
+    auto stage = [&]() {
+      const unsigned long long ts0 = (p.debug & 16u) ? __builtin_amdgcn_s_memtime() : 0ull;
+      __syncthreads();
+      const unsigned long long ts1 = (p.debug & 16u) ? __builtin_amdgcn_s_memtime() : 0ull;
+      f32x4* l4 = reinterpret_cast<f32x4*>(qlds);
+      const uint32_t slot = threadIdx.x & 31u;
+      const float* qrow = slot < v.nq ? src.query_row(it, slot) : nullptr;
+      if (v.nq > 16 || slot < 16) {
+        for (uint32_t i = threadIdx.x; i < n4; i += kWave * kPreWavesG) {
+          f32x4 x = {0.0f, 0.0f, 0.0f, 0.0f};
+          if (qrow != nullptr) x = *reinterpret_cast<const f32x4*>(qrow + 4 * (i >> 5));
+          l4[i] = -2.0f * x;
+        }
+      }
+      __syncthreads();
+      if ((p.debug & 16u) && lane == 0) {
+        atomicAdd(p.stamps + 3, __builtin_amdgcn_s_memtime() - ts1);
+        atomicAdd(p.stamps + 5, ts1 - ts0);
+        atomicAdd(p.stamps + 6, 1ull);
+      }
+    };
+    prescan_item_g(src, p, it, v, wid >> 2, lane, qlds, lists, stage);
   }
   if ((p.debug & 16u) && blockIdx.x == 0 && threadIdx.x == 0)
     p.stamps[7] = ((__builtin_amdgcn_s_memtime() - clk0) << 20) / ((__builtin_amdgcn_s_memrealtime() - rt0) | 1ull);
