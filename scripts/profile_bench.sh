@@ -17,6 +17,7 @@ pass() { # name counters...
 pass sq1 SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY
 pass sq2 SQ_INSTS_VALU SQ_INSTS_SMEM SQ_INSTS_SALU SQ_INSTS_LDS SQ_INST_CYCLES_SMEM SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_INST_LEVEL_SMEM
 pass fetch FETCH_SIZE
+pass mfma SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_F32 SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAVES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE
 pass write WRITE_SIZE
 python3 "$ROOT/scripts/summarize_prof.py" "$OUT" > "$OUT/summary.txt" 2>&1
 tail -60 "$OUT/summary.txt"
