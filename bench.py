@@ -55,6 +55,8 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-recall", action="store_true")
+    ap.add_argument("--dist-build", action="store_true",
+                    help="N > 1: shard the k-means assign step over the ranks (one all-gather per pass) instead of building replicated")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -102,7 +104,9 @@ def main():
     init = (dg.mix64(np.uint64(0xB01D) + np.arange(nlist, dtype=np.uint64)) % np.uint64(n)).astype(np.uint64)
     index = IVFFlatIndex(d, device=dev_index)
     if world > 1:
-        index.set_shard(rank, world)  # every rank runs the same deterministic build and keeps only its lists
+        index.set_shard(rank, world)  # every rank ends with the same deterministic index and keeps only its lists
+        if args.dist_build:
+            index.set_build_shard(rank, world)  # (the build is outside the timed region either way)
     t0 = time.perf_counter()
     kept = index.build_dev(X.data_ptr(), n, nlist, 1, args.kmeans_iters, init)
     t_build = time.perf_counter() - t0

@@ -190,6 +190,19 @@ int32_t vers_shard_plan(const uint64_t* list_lengths, uint64_t k, uint32_t world
 /* Before build/upload: this handle keeps only the lists vers_shard_plan gives to `rank`. */
 int32_t vers_ivf_set_shard(vers_ivf_t* h, uint32_t rank, uint32_t world);
 int32_t vers_ivf_owners(vers_ivf_t* h, uint8_t* out_owner /* [k] */);
+/* build_index across processes (one per GPU, every process holds all rows): assign_to_clusters (ivfflat.rs:29-46,
+ * ~all of the build time) is sharded by point range -- process `rank` assigns rows [rank*chunk, (rank+1)*chunk) --
+ * and after each pass the library calls `exchange(ctx, assign_dev, min_dist_dev, n_padded, chunk)`: the caller
+ * all-gathers IN PLACE (its own chunk sits at offset rank*chunk; u32 assignments, f32 minimum distances, the
+ * latter nullable) with whatever collective it owns (RCCL all-gather over xGMI in vers_amd/dist.py) and returns 0.
+ * update_centroids, the cost fold and the convergence test then run replicated, in the reference's order, on every
+ * process, so centroids / assignments / cost are bit-identical to the single-process build.  Set before build. */
+typedef int32_t (*vers_assign_exchange_fn)(void* ctx, uint32_t* assign_dev, float* min_dist_dev, uint64_t n_padded,
+                                           uint64_t chunk);
+int32_t vers_ivf_set_build_shard(vers_ivf_t* h, uint32_t rank, uint32_t world, vers_assign_exchange_fn exchange,
+                                 void* ctx);
+/* Device-to-device copy (synchronous) for callers that hold raw device pointers only (the exchange callback). */
+int32_t vers_dev_copy(void* dst_dev, const void* src_dev, uint64_t bytes);
 /* Local part of search_approximate: out_keys/out_ids [b*top_k], kKeyMax (all ones) padded. */
 int32_t vers_ivf_search_partial_dev(vers_ivf_t* h, const float* queries_dev, uint64_t ldq_floats, uint32_t b,
                                     uint32_t top_k, uint32_t nprobe, uint64_t* out_keys_dev,

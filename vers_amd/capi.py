@@ -64,6 +64,8 @@ SIGNATURES = {
     "vers_topk_merge_dev": (C.c_int32, [_vp, _vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _vp, _vp, _vp, _vp]),
     "vers_ivf_coarse_stats": (C.c_int32, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "vers_ivf_prescan_stats": (C.c_int32, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
+    "vers_ivf_set_build_shard": (C.c_int32, [_vp, C.c_uint32, C.c_uint32, _vp, _vp]),
+    "vers_dev_copy": (C.c_int32, [_vp, _vp, C.c_uint64]),
     "vers_ivf_scan_times": (C.c_int32, [_vp, _vp, C.c_uint32, C.POINTER(C.c_uint32), C.c_int32]),
     "vers_ivf_get_list": (C.c_int32, [_vp, C.c_uint64, _vp, C.c_uint64, _vp, C.c_uint64, C.POINTER(C.c_uint64)]),
     "vers_ivf_get_centroids": (C.c_int32, [_vp, _vp, C.c_uint64]),
@@ -231,3 +233,7 @@ def assign_stats(reset=False):
     a, b = C.c_uint64(0), C.c_uint64(0)
     check(lib().vers_assign_stats(C.byref(a), C.byref(b), 1 if reset else 0))
     return int(a.value), int(b.value)
+
+
+# exchange callback of the sharded build (include/vers_hip.h: vers_assign_exchange_fn)
+ASSIGN_EXCHANGE_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64)

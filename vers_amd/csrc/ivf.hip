@@ -564,6 +564,10 @@ struct vers_ivf {
   std::vector<uint32_t> h_off, h_len, h_cap;  // h_len = GLOBAL list lengths; h_off/h_cap only meaningful for owned lists
   // sharding by cluster across GPUs (one process per GPU): this handle stores only lists with owner == rank
   uint32_t rank = 0, world = 1;
+  // build_index with the assign step sharded by point range across processes (vers_ivf_set_build_shard)
+  uint32_t build_rank = 0, build_world = 1;
+  vers_assign_exchange_fn build_exchange = nullptr;
+  void* build_exchange_ctx = nullptr;
   std::vector<uint8_t> h_owner;
   DevBuf owner;
   uint64_t cap_rows = 0;
@@ -706,14 +710,32 @@ int32_t run_build(vers_ivf* h, const float* X, uint32_t ldx, uint64_t n, uint32_
                   const uint64_t* init_indices, DevBuf& best_assign, float* out_cost, int32_t* out_kept,
                   uint64_t* out_iterations, hipStream_t st) {
   const uint32_t ld = h->ldx;  // centroids live row-major with pitch ldx during k-means
+  // Point range of this process for assign_to_clusters: [a_begin, a_end) of equal-sized chunks; after every pass the
+  // caller's exchange (one all-gather) makes all n assignments (and minimum distances) valid everywhere.  Every
+  // other step (update, cost, convergence test) runs replicated and in the reference's order on every process.
+  const uint64_t a_chunk = h->build_world > 1 ? round_up64((n + h->build_world - 1) / h->build_world, 64) : n;
+  const uint64_t a_pad = h->build_world > 1 ? a_chunk * h->build_world : n;
+  const uint64_t a_begin = std::min<uint64_t>(n, (uint64_t)h->build_rank * a_chunk), a_end = std::min<uint64_t>(n, a_begin + a_chunk);
+  auto assign_pass = [&](bool mfma, const float* Cc, uint32_t* a_out, float* m_out) -> int32_t {
+    if (a_end > a_begin)
+      if (int32_t rc = (mfma ? km_assign_mfma : km_assign)(X + a_begin * ldx, ldx, a_end - a_begin, Cc, ld, k, h->d, a_out + a_begin,
+                                                           m_out ? m_out + a_begin : nullptr, h->km, h->n_cu, st))
+        return rc;
+    if (h->build_world > 1) {
+      VERS_HIP_TRY(hipStreamSynchronize(st));
+      if (int32_t rc = h->build_exchange(h->build_exchange_ctx, a_out, m_out, a_pad, a_chunk))
+        return fail(VERS_ERR_INVALID, "vers_ivf_build: the assign exchange callback failed (status " + std::to_string(rc) + ")");
+    }
+    return VERS_OK;
+  };
   DevBuf C, Cn, assign, mind, sorted, idx, bestC;
   const size_t cbytes = ((size_t)k * ld ? (size_t)k * ld : 1) * sizeof(float);
   if (int32_t rc = C.reserve(cbytes)) return rc;
   if (int32_t rc = Cn.reserve(cbytes)) return rc;
   if (int32_t rc = bestC.reserve(cbytes)) return rc;
-  if (int32_t rc = assign.reserve((n ? n : 1) * 4)) return rc;
+  if (int32_t rc = assign.reserve((a_pad ? a_pad : 1) * 4)) return rc;
   if (int32_t rc = best_assign.reserve((n ? n : 1) * 4)) return rc;
-  if (int32_t rc = mind.reserve((n ? n : 1) * 4)) return rc;
+  if (int32_t rc = mind.reserve((a_pad ? a_pad : 1) * 4)) return rc;
   if (int32_t rc = sorted.reserve((n ? n : 1) * 4)) return rc;
   if (int32_t rc = idx.reserve((k ? k : 1) * 4)) return rc;
   if (int32_t rc = h->km.counts.reserve((2 * (size_t)k + 2) * 4)) return rc;
@@ -726,7 +748,7 @@ int32_t run_build(vers_ivf* h, const float* X, uint32_t ldx, uint64_t n, uint32_
   uint32_t* flag_dev = h->km.misc.as<uint32_t>() + 4;
   float best = INFINITY;
   *out_kept = 0;
-  const bool mfma = km_use_mfma(n, k, h->d);
+  const bool mfma = km_use_mfma(a_end - a_begin, k, h->d) || (h->build_world > 1 && km_use_mfma(n, k, h->d));
   std::vector<uint32_t> idx32(k ? k : 1);
   for (uint64_t a = 0; a < num_attempts; ++a) {
     if (n > 0 && k == 0) return fail(VERS_ERR_EMPTY, "build_index with zero clusters: min_by over no centroids (reference panics)");
@@ -744,7 +766,7 @@ int32_t run_build(vers_ivf* h, const float* X, uint32_t ldx, uint64_t n, uint32_
     }
     uint64_t iters = 0;
     for (uint64_t it = 0; it < max_iterations; ++it) {
-      if (int32_t rc = (mfma ? km_assign_mfma : km_assign)(X, ldx, n, C.as<float>(), ld, k, h->d, assign.as<uint32_t>(), nullptr, h->km, h->n_cu, st)) return rc;
+      if (int32_t rc = assign_pass(mfma, C.as<float>(), assign.as<uint32_t>(), nullptr)) return rc;
       if (int32_t rc = km_group(assign.as<uint32_t>(), (uint32_t)n, k, sorted.as<uint32_t>(), counts, starts, h->km, st)) return rc;
       if (int32_t rc = km_update(X, ldx, sorted.as<uint32_t>(), starts, k, Cn.as<float>(), ld, st)) return rc;
       if (int32_t rc = km_differs(C.as<float>(), Cn.as<float>(), (uint64_t)k * ld, flag_dev, st)) return rc;
@@ -757,7 +779,7 @@ int32_t run_build(vers_ivf* h, const float* X, uint32_t ldx, uint64_t n, uint32_
       std::swap(C.cap, Cn.cap);
     }
     if (out_iterations) out_iterations[a] = iters;
-    if (int32_t rc = (mfma ? km_assign_mfma : km_assign)(X, ldx, n, C.as<float>(), ld, k, h->d, assign.as<uint32_t>(), mind.as<float>(), h->km, h->n_cu, st)) return rc;
+    if (int32_t rc = assign_pass(mfma, C.as<float>(), assign.as<uint32_t>(), mind.as<float>())) return rc;
     if (int32_t rc = km_cost_fold(mind.as<float>(), n, cost_dev, st)) return rc;
     float cost = 0.0f;
     uint32_t stw = 0;
@@ -1436,6 +1458,19 @@ int32_t vers_ivf_set_shard(vers_ivf_t* h, uint32_t rank, uint32_t world) {
   if (h->k != 0) return fail(VERS_ERR_INVALID, "vers_ivf_set_shard: call before build / upload");
   h->rank = rank;
   h->world = world;
+  return VERS_OK;
+}
+
+int32_t vers_ivf_set_build_shard(vers_ivf_t* h, uint32_t rank, uint32_t world, vers_assign_exchange_fn exchange, void* ctx) {
+  if (!h || world == 0 || rank >= world || (world > 1 && !exchange)) return fail(VERS_ERR_INVALID, "vers_ivf_set_build_shard: bad arguments");
+  std::lock_guard<std::mutex> lk(h->mu);
+  h->build_rank = rank; h->build_world = world; h->build_exchange = world > 1 ? exchange : nullptr; h->build_exchange_ctx = ctx;
+  return VERS_OK;
+}
+
+int32_t vers_dev_copy(void* dst_dev, const void* src_dev, uint64_t bytes) {
+  if ((!dst_dev || !src_dev) && bytes) return fail(VERS_ERR_INVALID, "vers_dev_copy: null pointer");
+  VERS_HIP_TRY(hipMemcpy(dst_dev, src_dev, bytes, hipMemcpyDeviceToDevice));
   return VERS_OK;
 }
 

@@ -45,10 +45,13 @@ class IVFFlatIndex:
     # -- IVFFlatIndex::build_index (ivfflat.rs:102-136) -----------------------------------------
     @classmethod
     def build_index(cls, num_clusters: int, num_attempts: int, max_iterations: int, vectors, init_indices=None,
-                    rng=None, device: int = 0) -> "IVFFlatIndex":
+                    rng=None, device: int = 0, build_shard=None) -> "IVFFlatIndex":
+        """build_shard = (rank, world[, group]): assign step sharded over processes, see set_build_shard."""
         vectors = np.ascontiguousarray(vectors, dtype=np.float32)
         n, d = vectors.shape
         self = cls(d, device)
+        if build_shard is not None:
+            self.set_build_shard(*build_shard)
         if init_indices is None:
             # initialize_centroids (ivfflat.rs:18-27): k draws WITH replacement per attempt
             rng = rng or np.random.default_rng()
@@ -186,6 +189,32 @@ class IVFFlatIndex:
     # -- sharding by cluster, one process per GPU -----------------------------------------------------------
     def set_shard(self, rank: int, world: int):
         check(lib().vers_ivf_set_shard(self._h, rank, world))
+
+    def set_build_shard(self, rank: int, world: int, group=None):
+        """build_index with assign_to_clusters sharded by point range over the processes of `group` (one per GPU,
+        every process passes the same rows): one all-gather of the u32 assignments (and, on the last pass, the f32
+        minimum distances) per k-means pass -- vers_amd.dist.all_gather_chunks_inplace, RCCL on the GPUs.  The
+        result is bit-identical to the single-process build."""
+        from . import capi as _capi
+        if world <= 1:
+            check(lib().vers_ivf_set_build_shard(self._h, 0, 1, None, None))
+            self._exchange_cb = None
+            return
+        from .dist import all_gather_chunks_inplace
+
+        def _exchange(_ctx, assign_ptr, mind_ptr, n_padded, chunk):
+            try:
+                all_gather_chunks_inplace(assign_ptr, "int32", n_padded, chunk, rank, self.device, group)
+                if mind_ptr:
+                    all_gather_chunks_inplace(mind_ptr, "float32", n_padded, chunk, rank, self.device, group)
+                return 0
+            except Exception as e:  # never unwind through the C frame
+                import sys
+                print(f"[vers] assign exchange failed: {e!r}", file=sys.stderr, flush=True)
+                return 1
+
+        self._exchange_cb = _capi.ASSIGN_EXCHANGE_FN(_exchange)  # keep alive as long as the handle may call it
+        check(lib().vers_ivf_set_build_shard(self._h, rank, world, C.cast(self._exchange_cb, C.c_void_p), None))
 
     def owners(self):
         _, k, _ = self.info()
