@@ -1163,10 +1163,10 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
     a.partials = h->partials.as<uint64_t>(); a.P = P; a.S_max = S_max; a.kp = kp; a.top_k = top_k; a.d_pad = h->ld;
     a.pj_list = pj_list; a.pj_pref = pj_pref; a.list_off = h->list_off.as<uint32_t>(); a.row_ids = h->row_ids.as<uint32_t>();
     a.rows = h->rows.as<float>(); a.ld = h->ld; a.qp = qp; a.ldq = h->ldq; a.xmax2_bits = h->pre_misc.as<uint32_t>();
-    a.qflags = qflags; a.force_fail = pre_mode == 2; a.fail_list = fail_list; a.stats = h->pre_misc.as<uint32_t>() + 1;
+    a.qflags = qflags; a.force_fail = pre_mode == 2; a.debug = scan_debug_flags(); a.fail_list = fail_list; a.stats = h->pre_misc.as<uint32_t>() + 1;
     a.status = h->status.as<uint32_t>(); a.out_ids = out_ids; a.out_dist = out_dist; a.out_count = out_count; a.out_keys = out_keys;
-    const int stage_rows = rescore_lds_bytes(h->ld, kp, true) <= 144u * 1024u ? 1 : 0;
-    const size_t rs_lds = rescore_lds_bytes(h->ld, kp, stage_rows != 0);
+    const int stage_rows = rescore_lds_bytes(h->ld, true) <= 144u * 1024u ? 1 : 0;
+    const size_t rs_lds = rescore_lds_bytes(h->ld, stage_rows != 0);
     if (int32_t rc2 = scan_prepare_launch(ivf_rescore_kernel, rs_lds)) return rc2;
     hipLaunchKernelGGL(ivf_rescore_kernel, dim3(b), dim3(kWave * kRescoreWaves), rs_lds, st, a, stage_rows);
     VERS_HIP_TRY(hipGetLastError());

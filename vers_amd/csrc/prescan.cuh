@@ -380,13 +380,13 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) __attribute__((amdgpu_waves
 // the step loop was load issue).
 constexpr int kPreHalves = 2;
 constexpr int kPreWavesG = 4 * kPreHalves;
-inline size_t prescan_lds_bytes_g(uint32_t ld, uint32_t kp) {
-  return (size_t)ld * kPreQ * sizeof(float) + 16 + (size_t)kPreWavesG * kPreQ * kp * sizeof(uint64_t);
+inline size_t prescan_lds_bytes_g(uint32_t ld, uint32_t kp) {  // query block | hand-out word | lists | 64-float scratch per wave
+  return (size_t)ld * kPreQ * sizeof(float) + 16 + (size_t)kPreWavesG * kPreQ * kp * sizeof(uint64_t) + (size_t)kPreWavesG * kWave * sizeof(float);
 }
 
 template <class Src, class Stage>
 __device__ __forceinline__ void prescan_item_g(const Src& src, const PreParams& p, uint32_t it, const ItemView<kPreQ>& v, int half, int lane,
-                                               const float* qm, uint64_t* lists, Stage&& stage) {
+                                               const float* qm, uint64_t* lists, float* scratch, Stage&& stage) {
   const uint32_t n_tiles = (v.nrows + kWave - 1) / kWave;
   const uint32_t t_half = (n_tiles + 1) / 2;
   const uint32_t t_begin = half ? t_half : 0u, t_end = half ? n_tiles : t_half;
@@ -483,6 +483,38 @@ __device__ __forceinline__ void prescan_item_g(const Src& src, const PreParams& 
     } else if (live[S]) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) bad |= !(__builtin_fabsf(a[e]) < __builtin_inff());
+    }
+    // Cold start: a query without any threshold yet would push all 64 rows of the item's first tile through
+    // 64 serial list inserts (~400 cycles each; with all waves of the launch starting cold that was ~0.4 ms of
+    // the kernel).  Instead the tile's 64 vals of such a query are transposed through a 64-float LDS scratch
+    // (lane == row again) and the kp smallest are extracted by wave-min rounds straight into the list.
+    if (t == t_begin && !(p.debug & 1u)) {
+      const bool cold = live[S] && thr[S] == __builtin_inff();
+      uint32_t qmask = (uint32_t)(__ballot(cold) & 0xFFFFull);  // lanes 0..15: one per query column
+      while (qmask) {
+        const int nn = __builtin_ctz(qmask);
+        qmask &= qmask - 1;
+        if (n == nn) {
+#pragma unroll
+          for (int bk = 0; bk < 4; ++bk)
+            *reinterpret_cast<f32x4*>(scratch + 16 * bk + 4 * quarter) = f32x4{a[4 * bk], a[4 * bk + 1], a[4 * bk + 2], a[4 * bk + 3]};
+        }
+        const float fv = scratch[lane];
+        const uint32_t sq = (uint32_t)__builtin_amdgcn_readlane((int)vseq[S], nn) + t * kWave + (uint32_t)lane;
+        uint64_t lst = kKeyMax;
+        wave_topk_fill(lst, kp, fv == fv ? make_key(fv, sq) : kKeyMax, lane);  // NaN = rows past the segment / non-finite (flagged)
+        if (lane < (int)kp) lists[(uint32_t)(S * 16 + nn) * kp + lane] = lst;
+        const uint64_t k2 = readlane64(lst, (int)kp - 1);
+        if (k2 != kKeyMax) {
+          const uint32_t kb = (uint32_t)(k2 >> 32);
+          if (n == nn) thr[S] = __uint_as_float(order_bits_to_f32_bits(kb));
+          if (lane == nn) atomicMin(p.bounds32 + vslot[S], kb);
+        }
+      }
+      if (cold) {  // this tile of these queries is done
+#pragma unroll
+        for (int e = 0; e < 16; ++e) a[e] = __builtin_nanf("");
+      }
     }
     uint64_t any = 0;
 #pragma unroll
@@ -593,6 +625,7 @@ __global__ __launch_bounds__(kWave * kPreWavesG) __attribute__((amdgpu_waves_per
   extern __shared__ __attribute__((aligned(16))) float qlds[];
   uint32_t* nq_lds = reinterpret_cast<uint32_t*>(qlds + (size_t)p.ld * kPreQ);
   uint64_t* lists = reinterpret_cast<uint64_t*>(qlds + (size_t)p.ld * kPreQ + 4) + (size_t)wid * kPreQ * p.kp;
+  float* scratch = reinterpret_cast<float*>(reinterpret_cast<uint64_t*>(qlds + (size_t)p.ld * kPreQ + 4) + (size_t)kPreWavesG * kPreQ * p.kp) + wid * kWave;
   const uint32_t n_quads = src.n_items() / 4;
   const uint32_t n4 = p.ld * (kPreQ / 4);
   const unsigned long long clk0 = (p.debug & 16u) ? __builtin_amdgcn_s_memtime() : 0ull;
@@ -629,7 +662,7 @@ __global__ __launch_bounds__(kWave * kPreWavesG) __attribute__((amdgpu_waves_per
         atomicAdd(p.stamps + 6, 1ull);
       }
     };
-    prescan_item_g(src, p, it, v, wid >> 2, lane, qlds, lists, stage);
+    prescan_item_g(src, p, it, v, wid >> 2, lane, qlds, lists, scratch, stage);
   }
   if ((p.debug & 16u) && blockIdx.x == 0 && threadIdx.x == 0)
     p.stamps[7] = ((__builtin_amdgcn_s_memtime() - clk0) << 20) / ((__builtin_amdgcn_s_memrealtime() - rt0) | 1ull);
@@ -650,6 +683,7 @@ struct RescoreArgs {
   const uint32_t* xmax2_bits;
   const uint32_t* qflags;  // [b*P], slot q*P
   int force_fail;          // testing: nothing certifies
+  uint32_t debug;          // diagnosis (VERS_SCAN_DEBUG): 512 skip the row gather + chains, 1024 merge only 1/8 of the slots
   uint32_t* fail_list;     // [b] out: queries to redo exactly, [b] = their count
   uint32_t* stats;         // [0] += failed queries
   uint32_t* status;
@@ -695,25 +729,35 @@ __device__ __forceinline__ void emit_topk(uint64_t fin, uint32_t q, uint32_t top
   if (lane == 0) out_count[q] = (uint32_t)__popcll(hm);
 }
 
-// Block of 4 waves per query.  All waves merge the partial lists; then the kp candidate rows are fetched into LDS
-// cooperatively (kp x ld/4 independent float4 loads over 256 threads -- a lane walking its own row straight from
-// HBM is a chain of ld/4 dependent-latency loads) and wave 0 runs the ordered chains out of LDS.
-// stage_rows == 0 (rows too long for LDS): the chains read HBM directly.
+// Block of 4 waves per query.  All waves merge the partial lists; wave 0 evaluates the certificate; the surviving
+// candidates' rows are then staged through LDS kRescoreChunk at a time, cooperatively (independent float4 gathers
+// over 256 threads -- a lane walking its own row straight from HBM is a chain of ld/4 dependent-latency loads) and
+// wave 0 runs the ordered chains out of LDS.  The block is a chain of ~8 dependent memory round trips, so what
+// matters is blocks in flight: 8 staged rows (27 KB of LDS at d = 768) allow 5 blocks per CU, the whole batch in
+// one round (staging all k+10 rows at once: 2 blocks per CU, 110 us instead of 45 at cfg3).
+// stage_rows == 0 (rows too long even for that): the chains read HBM directly.
 constexpr int kRescoreWaves = 4;
-inline size_t rescore_lds_bytes(uint32_t ld, uint32_t kp, bool stage_rows) {
-  return ((size_t)ld + (stage_rows ? (size_t)kp * (ld + 4) : 0)) * sizeof(float);
+constexpr uint32_t kRescoreChunk = 8;
+inline size_t rescore_lds_bytes(uint32_t ld, bool stage_rows) {
+  return ((size_t)ld + (stage_rows ? (size_t)kRescoreChunk * (ld + 4) : 0)) * sizeof(float);
 }
 __global__ __launch_bounds__(kWave * kRescoreWaves) void ivf_rescore_kernel(RescoreArgs a, int stage_rows) {
   __shared__ uint64_t sh[kRescoreWaves][kWave];
   __shared__ uint32_t srow[kWave];
   __shared__ float sred[kRescoreWaves];
-  extern __shared__ __attribute__((aligned(16))) float dyn[];  // the query, padded; then kp staged rows of pitch ld + 4
+  __shared__ uint32_t s_failed, s_nsurv;
+  extern __shared__ __attribute__((aligned(16))) float dyn[];  // the query, padded; then staged rows of pitch ld + 4
   float* qs = dyn;
   float* xs = dyn + a.ld;
   const uint32_t q = blockIdx.x;
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const float* qrow = a.qp + (uint64_t)q * a.ldq;
+  const uint32_t* pl = a.pj_list + (uint64_t)q * a.P;
+  const uint32_t* pp = a.pj_pref + (uint64_t)q * a.P;
+  // everything that does not depend on the merge is requested up front
+  const uint32_t flag0 = a.qflags[(uint64_t)q * a.P];
+  const uint32_t xmax_bits = *a.xmax2_bits;
   float qpart = 0.0f;
   for (uint32_t i = threadIdx.x; i < a.ld; i += blockDim.x) {
     const float v = qrow[i];
@@ -721,8 +765,9 @@ __global__ __launch_bounds__(kWave * kRescoreWaves) void ivf_rescore_kernel(Resc
     qpart = __fadd_rn(qpart, __fmul_rn(v, v));  // |q|^2 in any order: the bound inflates it
   }
   // merge the partial lists: every wave folds a strided share, wave 0 folds the four results
-  const uint32_t n_keys = a.P * a.S_max * a.kp;
-  const uint64_t* keys = a.partials + (uint64_t)q * n_keys;
+  const uint32_t n_keys_all = a.P * a.S_max * a.kp;
+  const uint32_t n_keys = (a.debug & 1024u) ? n_keys_all / 8 : n_keys_all;
+  const uint64_t* keys = a.partials + (uint64_t)q * n_keys_all;
   uint64_t list = kKeyMax;
   constexpr int U = 4;
   for (uint32_t base = wid * kWave; base < n_keys; base += kRescoreWaves * kWave * U) {
@@ -740,10 +785,7 @@ __global__ __launch_bounds__(kWave * kRescoreWaves) void ivf_rescore_kernel(Resc
   sh[wid][lane] = list;
   if (lane == 0) sred[wid] = qpart;
   __syncthreads();
-  const uint32_t* pl = a.pj_list + (uint64_t)q * a.P;
-  const uint32_t* pp = a.pj_pref + (uint64_t)q * a.P;
-  __shared__ uint32_t s_failed;
-  bool survivor = false;
+  uint64_t mine = kKeyMax;  // wave 0: the survivors, compacted to lanes 0..n_surv-1
   if (wid == 0) {
     for (int w = 1; w < kRescoreWaves; ++w) wave_topk_update(list, a.kp, sh[w][lane], kKeyMax);
     const bool valid = lane < (int)a.kp && list != kKeyMax;
@@ -751,7 +793,7 @@ __global__ __launch_bounds__(kWave * kRescoreWaves) void ivf_rescore_kernel(Resc
     float qn = 0.0f;
     for (int w = 0; w < kRescoreWaves; ++w) qn += sred[w];
     const double u = 5.9604644775390625e-08;
-    const double S = (double)qn * (1.0 + (double)a.d_pad * 2.0 * u) + (double)__uint_as_float(*a.xmax2_bits);
+    const double S = (double)qn * (1.0 + (double)a.d_pad * 2.0 * u) + (double)__uint_as_float(xmax_bits);
     const double E = (5.0 * (double)a.d_pad + 32.0) * u * S;
     const float val = __uint_as_float(order_bits_to_f32_bits((uint32_t)(list >> 32)));
     bool certified = true;
@@ -765,63 +807,77 @@ __global__ __launch_bounds__(kWave * kRescoreWaves) void ivf_rescore_kernel(Resc
         certified = top > lim;  // false for NaN / inf
       }
     }
-    if (a.qflags[(uint64_t)q * a.P] != 0 || a.force_fail) certified = false;
-    // only candidates inside the limit can reach the top-k: the others are not worth their 3 KiB gather
-    survivor = certified && valid && !((double)val > lim);
+    if (flag0 != 0 || a.force_fail) certified = false;
+    // only candidates inside the limit can reach the top-k: the others are not worth their 3 KiB gather.
+    // The list is sorted by val, so the survivors are a prefix: lanes 0..n_surv-1.
+    const bool survivor = certified && valid && !((double)val > lim);
+    const uint32_t n_surv = (uint32_t)__popcll(__ballot(survivor));
+    mine = survivor ? list : kKeyMax;
     srow[lane] = wave_seq_rows(list, survivor, lane, pl, pp, a.P, a.list_off);
     if (lane == 0) {
       s_failed = certified ? 0u : 1u;
+      s_nsurv = n_surv;
       if (!certified) { a.fail_list[atomicAdd(a.fail_list + gridDim.x, 1u)] = q; atomicAdd(a.stats, 1u); }  // the fallback kernels redo it
     }
   }
   __syncthreads();
   if (s_failed) return;
+  const uint32_t n_surv = s_nsurv;
+  if (a.debug & 512u) {
+    if (wid == 0) emit_topk(list, q, a.top_k, lane, pl, pp, a.P, a.list_off, a.row_ids, a.out_ids, a.out_dist, a.out_count, a.out_keys);
+    return;
+  }
+  // exact distances of the survivors: lane per candidate, the reference's ordered chain
+  uint64_t cand = kKeyMax;
+  bool nan_seen = false;
+  const f32x4* q4p = reinterpret_cast<const f32x4*>(qs);
   if (stage_rows) {
     const uint32_t n4 = a.ld / 4, pitch = a.ld + 4;
-    for (uint32_t idx = threadIdx.x; idx < a.kp * n4; idx += blockDim.x) {
-      const uint32_t c = idx / n4, j = idx - c * n4;
-      const uint32_t row = srow[c];
-      if (row != 0xFFFFFFFFu)
+    for (uint32_t c0 = 0; c0 < n_surv; c0 += kRescoreChunk) {  // block-uniform
+      const uint32_t nc = n_surv - c0 < kRescoreChunk ? n_surv - c0 : kRescoreChunk;
+      for (uint32_t idx = threadIdx.x; idx < nc * n4; idx += blockDim.x) {
+        const uint32_t c = idx / n4, j = idx - c * n4;
+        const uint32_t row = srow[c0 + c];
         *reinterpret_cast<f32x4*>(xs + (size_t)c * pitch + 4 * j) =
             (reinterpret_cast<const f32x4*>(a.rows + (uint64_t)(row >> 6) * 64ull * a.ld) + (row & 63))[(uint64_t)j * 64];
+      }
+      __syncthreads();
+      if (wid == 0 && (uint32_t)lane >= c0 && (uint32_t)lane < c0 + nc) {
+        const f32x4* xp = reinterpret_cast<const f32x4*>(xs + (size_t)((uint32_t)lane - c0) * pitch);
+        float acc = 0.0f;
+        for (uint32_t j = 0; j < n4; ++j) {
+          const f32x4 x4 = xp[j];
+          const f32x4 q4 = q4p[j];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const float t = __fsub_rn(x4[c], q4[c]);
+            acc = __fadd_rn(acc, __fmul_rn(t, t));
+          }
+        }
+        nan_seen |= acc != acc;
+        cand = make_key(acc, (uint32_t)mine);
+      }
+      __syncthreads();  // the chunk's readers are done before the next one is staged
     }
-    __syncthreads();
+  } else if (wid == 0 && (uint32_t)lane < n_surv) {
+    const uint32_t row = srow[lane];
+    const f32x4* xp = reinterpret_cast<const f32x4*>(a.rows + (uint64_t)(row >> 6) * 64ull * a.ld) + (row & 63);
+    float acc = 0.0f;
+#pragma unroll 8
+    for (uint32_t j = 0; j < a.ld / 4; ++j) {
+      const f32x4 x4 = xp[(uint64_t)j * 64];
+      const f32x4 q4 = q4p[j];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const float t = __fsub_rn(x4[c], q4[c]);
+        acc = __fadd_rn(acc, __fmul_rn(t, t));
+      }
+    }
+    nan_seen |= acc != acc;
+    cand = make_key(acc, (uint32_t)mine);
   }
   if (wid != 0) return;
-  const bool valid = survivor;
-  // exact distances of the kp candidates: lane per candidate, the reference's ordered chain
-  uint64_t cand = kKeyMax;
-  if (valid) {
-    const uint32_t row = srow[lane];
-    const f32x4* q4p = reinterpret_cast<const f32x4*>(qs);
-    float acc = 0.0f;
-    if (stage_rows) {
-      const f32x4* xp = reinterpret_cast<const f32x4*>(xs + (size_t)lane * (a.ld + 4));
-      for (uint32_t j = 0; j < a.ld / 4; ++j) {
-        const f32x4 x4 = xp[j];
-        const f32x4 q4 = q4p[j];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const float t = __fsub_rn(x4[c], q4[c]);
-          acc = __fadd_rn(acc, __fmul_rn(t, t));
-        }
-      }
-    } else {
-      const f32x4* xp = reinterpret_cast<const f32x4*>(a.rows + (uint64_t)(row >> 6) * 64ull * a.ld) + (row & 63);
-#pragma unroll 8
-      for (uint32_t j = 0; j < a.ld / 4; ++j) {
-        const f32x4 x4 = xp[(uint64_t)j * 64];
-        const f32x4 q4 = q4p[j];
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const float t = __fsub_rn(x4[c], q4[c]);
-          acc = __fadd_rn(acc, __fmul_rn(t, t));
-        }
-      }
-    }
-    if (acc != acc) atomicOr(a.status, 1u);
-    cand = make_key(acc, (uint32_t)list);
-  }
+  if (__ballot(nan_seen) != 0 && lane == 0) atomicOr(a.status, 1u);
   uint64_t fin = kKeyMax;
   wave_topk_update(fin, a.top_k, cand, kKeyMax);
   emit_topk(fin, q, a.top_k, lane, pl, pp, a.P, a.list_off, a.row_ids, a.out_ids, a.out_dist, a.out_count, a.out_keys);
