@@ -157,6 +157,10 @@ struct IvfSrc {
   __device__ __forceinline__ uint64_t* out(uint32_t it, int qi, int half = 0) const {  // S_max counts slots (segments * halves)
     return partials + ((uint64_t)pair_of(it, qi) * S_max + items[it].seg * halves + half) * k_keep;
   }
+  // slot of a whole quad of segments (prescan_kernel_g: one list per query and block); S_max counts quads there
+  __device__ __forceinline__ uint64_t* out_quad(uint32_t it0, int qi) const {
+    return partials + ((uint64_t)pair_of(it0, qi) * S_max + (items[it0].seg >> 2)) * k_keep;
+  }
   __device__ __forceinline__ uint32_t bound_slot(uint32_t it, int qi) const {
     const uint32_t pr = pair_of(it, qi);
     return bound_per_pair ? pr : pr / P * P;
@@ -1083,10 +1087,12 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
   // variant of the matrix-core scan: two waves per item (prescan_kernel_g) unless VERS_PRE_G=0
   static const bool pre_g = [] { const char* e = getenv("VERS_PRE_G"); return !e || atoi(e) != 0; }();
   const bool use_g = use_pre && pre_g && prescan_lds_bytes_g(h->ld, kp) <= 160u * 1024u;
-  const uint32_t pre_halves = use_g ? (uint32_t)kPreHalves : 1u;
-  const uint32_t S_max = pre_halves * (seg_target ? 4 * std::max<uint32_t>(1, (h->max_len + 4 * seg_target - 1) / (4 * seg_target))
-                                                  : std::max<uint32_t>(1, (h->max_len + seg_rows - 1) / seg_rows));
-  const uint64_t items_bound = groups_bound * (QG == 1 ? S_max : round_up(S_max / pre_halves, 4));
+  const uint32_t pre_halves = 1u;
+  // segments per list at most; partial slots per (query, probe): one per segment, or one per QUAD of segments (use_g)
+  const uint32_t S_seg = seg_target ? 4 * std::max<uint32_t>(1, (h->max_len + 4 * seg_target - 1) / (4 * seg_target))
+                                    : std::max<uint32_t>(1, (h->max_len + seg_rows - 1) / seg_rows);
+  const uint32_t S_max = use_g ? (S_seg + 3) / 4 : S_seg;
+  const uint64_t items_bound = groups_bound * (QG == 1 ? S_seg : round_up(S_seg, 4));
   if (items_bound > 0x7FFFFFFFull) return fail(VERS_ERR_INVALID, "search batch too large");
 
   const uint32_t k_l = h->k;

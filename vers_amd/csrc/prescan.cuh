@@ -378,15 +378,23 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) __attribute__((amdgpu_waves
 // two waves (<= 256 registers each).  While one wave of a SIMD sits in the back-pressure of an HBM-bound load
 // burst the other issues its MFMAs -- with a single wave per SIMD those two phases add up (stamps: a third of
 // the step loop was load issue).
+// The eight waves of a block work on ONE list segment quad against the same queries, so they also share ONE
+// sorted list per query in LDS (a spin lock per query, taken for the ~50 instructions of an insert): the list
+// sees ~2400 rows instead of an item half's ~220, fills at once, and its last val -- the threshold every wave
+// re-reads per tile and the value published to the other blocks of the query -- is close to the query's global
+// one.  (With a list per wave the shared threshold stalled near "the kp-th of the best 220 rows": ~900 inserts
+// per query and batch instead of the ~170 a perfectly shared threshold needs; inserts were 0.38 ms of 5.3 ms.)
+// It also shrinks the partial slots to one per (query, list, quad): 8x fewer keys for the exact finish to merge.
 constexpr int kPreHalves = 2;
 constexpr int kPreWavesG = 4 * kPreHalves;
-inline size_t prescan_lds_bytes_g(uint32_t ld, uint32_t kp) {  // query block | hand-out word | lists | 64-float scratch per wave
-  return (size_t)ld * kPreQ * sizeof(float) + 16 + (size_t)kPreWavesG * kPreQ * kp * sizeof(uint64_t) + (size_t)kPreWavesG * kWave * sizeof(float);
+inline size_t prescan_lds_bytes_g(uint32_t ld, uint32_t kp) {  // query block | hand-out word | lists | locks | 64-float scratch per wave
+  return (size_t)ld * kPreQ * sizeof(float) + 16 + (size_t)kPreQ * kp * sizeof(uint64_t) + kPreQ * sizeof(uint32_t) +
+         (size_t)kPreWavesG * kWave * sizeof(float);
 }
 
 template <class Src, class Stage>
 __device__ __forceinline__ void prescan_item_g(const Src& src, const PreParams& p, uint32_t it, const ItemView<kPreQ>& v, int half, int lane,
-                                               const float* qm, uint64_t* lists, float* scratch, Stage&& stage) {
+                                               const float* qm, uint64_t* blk, uint32_t* locks, float* scratch, Stage&& stage) {
   const uint32_t n_tiles = (v.nrows + kWave - 1) / kWave;
   const uint32_t t_half = (n_tiles + 1) / 2;
   const uint32_t t_begin = half ? t_half : 0u, t_end = half ? n_tiles : t_half;
@@ -429,7 +437,6 @@ __device__ __forceinline__ void prescan_item_g(const Src& src, const PreParams& 
 
   bool live[2];
   uint32_t vseq[2] = {0, 0};
-  uint64_t vout[2] = {0, 0};
   float thr[2];
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
@@ -440,36 +447,38 @@ __device__ __forceinline__ void prescan_item_g(const Src& src, const PreParams& 
       vslot[s] = src.bound_slot(it, s * 16 + n);
       const uint32_t b0 = __hip_atomic_load(p.bounds32 + vslot[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       thr[s] = b0 == 0xFFFFFFFFu ? __builtin_inff() : __uint_as_float(order_bits_to_f32_bits(b0));
-      if (lane < 16) vout[s] = (uint64_t)src.out(it, s * 16 + lane, half);
     }
   }
-  for (uint32_t i = lane; i < kPreQ * kp; i += kWave) lists[i] = kKeyMax;
   f32x16_t acc[2];
 #pragma unroll
   for (int e = 0; e < 16; ++e) acc[0][e] = acc[1][e] = 0.0f;
   bool bad = false;
 
-  auto insert = [&](int nn, uint64_t key) {  // see prescan_item
-    uint64_t* Ln = lists + (uint32_t)nn * kp;
-    const uint64_t cur = lane < (int)kp ? Ln[lane] : kKeyMax;
-    const uint64_t kth = readlane64(cur, (int)kp - 1);
-    if (key < kth) {
-      const uint64_t prev = shift_up1_64(cur);
-      const uint64_t mx = prev > key ? prev : key;
-      const uint64_t nw = key < cur ? mx : cur;
-      if (lane < (int)kp) Ln[lane] = nw;
-      const uint64_t k2 = readlane64(nw, (int)kp - 1);
-      if (k2 != kKeyMax) {
-        const uint32_t kb = (uint32_t)(k2 >> 32);
-        const float nt = __uint_as_float(order_bits_to_f32_bits(kb));
-        if (n == (nn & 15)) {
-          if (nn < 16) thr[0] = nt < thr[0] ? nt : thr[0];
-          else thr[1] = nt < thr[1] ? nt : thr[1];
-        }
-        if (lane == (nn & 15)) atomicMin(p.bounds32 + (nn < 16 ? vslot[0] : vslot[1]), kb);
+  // Fold per-lane candidate keys (kKeyMax = none) into query nn's block-wide sorted list under its lock.  Within a
+  // wave LDS operations issue and complete in order, so the exchange that takes the lock precedes the list read and
+  // the list write precedes the store that frees it; the fences only pin the compiler.
+  auto merge_into = [&](int nn, uint64_t cand) {
+    if (lane == 0)
+      while (__hip_atomic_exchange(locks + nn, 1u, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u) __builtin_amdgcn_s_sleep(1);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    uint64_t* Ln = blk + (uint32_t)nn * kp;
+    uint64_t cur = lane < (int)kp ? Ln[lane] : kKeyMax;
+    wave_topk_update(cur, kp, cand, kKeyMax);
+    if (lane < (int)kp) Ln[lane] = cur;
+    const uint64_t k2 = readlane64(cur, (int)kp - 1);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lane == 0) __hip_atomic_store(locks + nn, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    if (k2 != kKeyMax) {  // full: its last val bounds the query's kp-th smallest val
+      const uint32_t kb = (uint32_t)(k2 >> 32);
+      const float nt = __uint_as_float(order_bits_to_f32_bits(kb));
+      if (n == (nn & 15)) {
+        if (nn < 16) thr[0] = nt < thr[0] ? nt : thr[0];
+        else thr[1] = nt < thr[1] ? nt : thr[1];
       }
+      if (lane == (nn & 15)) atomicMin(p.bounds32 + (nn < 16 ? vslot[0] : vslot[1]), kb);
     }
   };
+  auto insert = [&](int nn, uint64_t key) { merge_into(nn, lane == 0 ? key : kKeyMax); };
   auto fold = [&](auto set_tag, f32x16_t& a, uint32_t t) {  // see prescan_item
     constexpr int S = decltype(set_tag)::value;
     const uint32_t r0 = t * kWave + 4u * (uint32_t)quarter;
@@ -487,7 +496,7 @@ __device__ __forceinline__ void prescan_item_g(const Src& src, const PreParams& 
     // Cold start: a query without any threshold yet would push all 64 rows of the item's first tile through
     // 64 serial list inserts (~400 cycles each; with all waves of the launch starting cold that was ~0.4 ms of
     // the kernel).  Instead the tile's 64 vals of such a query are transposed through a 64-float LDS scratch
-    // (lane == row again) and the kp smallest are extracted by wave-min rounds straight into the list.
+    // (lane == row again), the kp smallest are extracted by wave-min rounds and merged into the block's list.
     if (t == t_begin && !(p.debug & 1u)) {
       const bool cold = live[S] && thr[S] == __builtin_inff();
       uint32_t qmask = (uint32_t)(__ballot(cold) & 0xFFFFull);  // lanes 0..15: one per query column
@@ -503,13 +512,7 @@ __device__ __forceinline__ void prescan_item_g(const Src& src, const PreParams& 
         const uint32_t sq = (uint32_t)__builtin_amdgcn_readlane((int)vseq[S], nn) + t * kWave + (uint32_t)lane;
         uint64_t lst = kKeyMax;
         wave_topk_fill(lst, kp, fv == fv ? make_key(fv, sq) : kKeyMax, lane);  // NaN = rows past the segment / non-finite (flagged)
-        if (lane < (int)kp) lists[(uint32_t)(S * 16 + nn) * kp + lane] = lst;
-        const uint64_t k2 = readlane64(lst, (int)kp - 1);
-        if (k2 != kKeyMax) {
-          const uint32_t kb = (uint32_t)(k2 >> 32);
-          if (n == nn) thr[S] = __uint_as_float(order_bits_to_f32_bits(kb));
-          if (lane == nn) atomicMin(p.bounds32 + vslot[S], kb);
-        }
+        merge_into(S * 16 + nn, lane < (int)kp ? lst : kKeyMax);
       }
       if (cold) {  // this tile of these queries is done
 #pragma unroll
@@ -578,9 +581,18 @@ __device__ __forceinline__ void prescan_item_g(const Src& src, const PreParams& 
         cc = 0;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-          if (live[s] && gthr[B][s] != 0xFFFFFFFFu) {
-            const float g = __uint_as_float(order_bits_to_f32_bits(gthr[B][s]));
-            thr[s] = g < thr[s] ? g : thr[s];
+          if (live[s]) {
+            if (gthr[B][s] != 0xFFFFFFFFu) {  // other blocks of the query
+              const float g = __uint_as_float(order_bits_to_f32_bits(gthr[B][s]));
+              thr[s] = g < thr[s] ? g : thr[s];
+            }
+            // this block's list (the other seven waves'): the high word of its last key
+            const uint32_t bh = __hip_atomic_load(reinterpret_cast<const uint32_t*>(blk + (uint32_t)(s * 16 + n) * kp + (kp - 1)) + 1,
+                                                  __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (bh != 0xFFFFFFFFu) {
+              const float g = __uint_as_float(order_bits_to_f32_bits(bh));
+              thr[s] = g < thr[s] ? g : thr[s];
+            }
           }
         }
         acc[0] = __builtin_amdgcn_mfma_f32_16x16x1f32(xn[B], 1.0f, acc[0], 0, 0, 0);  // + |x_row|^2 for every query column
@@ -611,10 +623,6 @@ __device__ __forceinline__ void prescan_item_g(const Src& src, const PreParams& 
     if (live[0]) p.qflags[vslot[0]] = 1u;
     if (live[1]) p.qflags[vslot[1]] = 1u;
   }
-#pragma unroll
-  for (int qi = 0; qi < kPreQ; ++qi)
-    if (qi < (int)v.nq && lane < (int)kp)
-      reinterpret_cast<uint64_t*>(readlane64(qi < 16 ? vout[0] : vout[1], qi & 15))[lane] = lists[(uint32_t)qi * kp + lane];
   if (stamp && lane == 0) atomicAdd(p.stamps + 11, __builtin_amdgcn_s_memtime() - te0);
 }
 
@@ -624,12 +632,21 @@ __global__ __launch_bounds__(kWave * kPreWavesG) __attribute__((amdgpu_waves_per
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   extern __shared__ __attribute__((aligned(16))) float qlds[];
   uint32_t* nq_lds = reinterpret_cast<uint32_t*>(qlds + (size_t)p.ld * kPreQ);
-  uint64_t* lists = reinterpret_cast<uint64_t*>(qlds + (size_t)p.ld * kPreQ + 4) + (size_t)wid * kPreQ * p.kp;
-  float* scratch = reinterpret_cast<float*>(reinterpret_cast<uint64_t*>(qlds + (size_t)p.ld * kPreQ + 4) + (size_t)kPreWavesG * kPreQ * p.kp) + wid * kWave;
+  uint64_t* blk = reinterpret_cast<uint64_t*>(qlds + (size_t)p.ld * kPreQ + 4);  // [32 queries][kp] sorted keys, shared by the 8 waves
+  uint32_t* locks = reinterpret_cast<uint32_t*>(blk + (size_t)kPreQ * p.kp);
+  float* scratch = reinterpret_cast<float*>(locks + kPreQ) + wid * kWave;
   const uint32_t n_quads = src.n_items() / 4;
   const uint32_t n4 = p.ld * (kPreQ / 4);
   const unsigned long long clk0 = (p.debug & 16u) ? __builtin_amdgcn_s_memtime() : 0ull;
   const unsigned long long rt0 = (p.debug & 16u) ? __builtin_amdgcn_s_memrealtime() : 0ull;
+  uint32_t prev_it0 = 0xFFFFFFFFu, prev_nq = 0;  // the quad whose lists still sit in LDS
+  auto write_out = [&]() {  // block-wide, between barriers: the finished quad's lists -> its partial slots
+    if (prev_it0 == 0xFFFFFFFFu) return;
+    for (uint32_t t = threadIdx.x; t < prev_nq * p.kp; t += kWave * kPreWavesG) {
+      const uint32_t qi = t / p.kp, j = t - qi * p.kp;
+      src.out_quad(prev_it0, (int)qi)[j] = blk[t];
+    }
+  };
   for (uint32_t b0 = blockIdx.x;; b0 += gridDim.x) {
     uint32_t bi = b0;
     if (p.next_quad != nullptr) {
@@ -643,8 +660,12 @@ __global__ __launch_bounds__(kWave * kPreWavesG) __attribute__((amdgpu_waves_per
     src.get(it, v);
     auto stage = [&]() {
       const unsigned long long ts0 = (p.debug & 16u) ? __builtin_amdgcn_s_memtime() : 0ull;
-      __syncthreads();
+      __syncthreads();  // every wave is done with the previous quad: its lists are final
       const unsigned long long ts1 = (p.debug & 16u) ? __builtin_amdgcn_s_memtime() : 0ull;
+      write_out();
+      __syncthreads();
+      for (uint32_t t = threadIdx.x; t < kPreQ * p.kp; t += kWave * kPreWavesG) blk[t] = kKeyMax;
+      if (threadIdx.x < kPreQ) locks[threadIdx.x] = 0u;
       f32x4* l4 = reinterpret_cast<f32x4*>(qlds);
       const uint32_t slot = threadIdx.x & 31u;
       const float* qrow = slot < v.nq ? src.query_row(it, slot) : nullptr;
@@ -662,8 +683,12 @@ __global__ __launch_bounds__(kWave * kPreWavesG) __attribute__((amdgpu_waves_per
         atomicAdd(p.stamps + 6, 1ull);
       }
     };
-    prescan_item_g(src, p, it, v, wid >> 2, lane, qlds, lists, scratch, stage);
+    prescan_item_g(src, p, it, v, wid >> 2, lane, qlds, blk, locks, scratch, stage);
+    prev_it0 = bi * 4;
+    prev_nq = v.nq;
   }
+  __syncthreads();
+  write_out();
   if ((p.debug & 16u) && blockIdx.x == 0 && threadIdx.x == 0)
     p.stamps[7] = ((__builtin_amdgcn_s_memtime() - clk0) << 20) / ((__builtin_amdgcn_s_memrealtime() - rt0) | 1ull);
 }
