@@ -181,40 +181,41 @@ __global__ __launch_bounds__(kWave * kMergeWaves) void coarse_merge_kernel(const
 // reference mode (ivfflat.rs:166-195): walk the ranked lists, list j contributes
 // take_j = min(remainder, len_j) until remainder == 0; out of lists -> the reference panics.
 // owner (nullable): only lists with owner[L] == rank are scanned on this GPU.
-__global__ void plan_kernel(const uint64_t* probe, uint32_t b, uint32_t P, uint32_t k_lists, uint32_t top_k,
-                            int ref_mode, const uint32_t* list_len, const uint8_t* owner, uint32_t rank,
-                            uint32_t* pj_list, uint32_t* pj_pref, uint32_t* pj_take, uint32_t* np, uint32_t* cnt,
-                            uint32_t* status) {
-  const uint32_t q = blockIdx.x * blockDim.x + threadIdx.x;
+__global__ __launch_bounds__(256) void plan_kernel(const uint64_t* probe, uint32_t b, uint32_t P, uint32_t k_lists, uint32_t top_k,
+                                                   int ref_mode, const uint32_t* list_len, const uint8_t* owner, uint32_t rank,
+                                                   uint32_t* pj_list, uint32_t* pj_pref, uint32_t* pj_take, uint32_t* np, uint32_t* cnt,
+                                                   uint32_t* status) {
+  // one WAVE per query, lane j = probe rank j (P <= 64): the walk of the ranked lists in closed form -- list j is
+  // visited while the rows before it do not yet fill top_k and contributes take_j = min(len_j, top_k - rows before)
+  // (a thread per query walking its P probes was 2 P dependent-latency loads: 36 us at b = 1024)
+  const uint32_t q = blockIdx.x * (blockDim.x / kWave) + (threadIdx.x >> 6);
   if (q >= b) return;
-  uint32_t pref = 0, rem = top_k, n_planned = 0;
-  bool done = false;
-  for (uint32_t j = 0; j < P; ++j) {
-    const uint64_t key = probe[(uint64_t)q * P + j];
-    uint32_t L = kNoList, take = 0;
-    uint32_t len = 0;
-    if (key != kKeyMax && !done) {
-      L = (uint32_t)key;
-      len = list_len[L];
-      if (ref_mode) {
-        take = rem < len ? rem : len;
-        rem -= take;
-        n_planned = j + 1;
-        if (rem == 0) done = true;
-      } else {
-        take = top_k;
-        n_planned = j + 1;
-      }
-    }
-    const bool scan = L != kNoList && len > 0 && take > 0 && (owner == nullptr || owner[L] == rank);
-    pj_list[(uint64_t)q * P + j] = scan ? L : kNoList;
-    pj_pref[(uint64_t)q * P + j] = pref;
-    pj_take[(uint64_t)q * P + j] = take;
-    if (scan) atomicAdd(&cnt[L], 1u);
-    pref += len;
+  const int lane = threadIdx.x & 63;
+  const uint64_t key = lane < (int)P ? probe[(uint64_t)q * P + lane] : kKeyMax;
+  const uint32_t L = key != kKeyMax ? (uint32_t)key : kNoList;
+  const uint32_t len = L != kNoList ? list_len[L] : 0u;
+  uint32_t inc = len;
+#pragma unroll
+  for (int off = 1; off < kWave; off <<= 1) {
+    const uint32_t t = __shfl_up(inc, off, kWave);
+    if (lane >= off) inc += t;
   }
-  np[q] = n_planned;
-  if (ref_mode && rem > 0 && top_k > 0) atomicOr(status, P >= k_lists ? kStInsufficient : kStSpillTooDeep);
+  const uint32_t pref = inc - len;
+  const uint32_t total_rows = (uint32_t)__shfl(inc, kWave - 1, kWave);
+  const bool visited = L != kNoList && (!ref_mode || pref < top_k);
+  const uint32_t take = !visited ? 0u : (ref_mode ? (len < top_k - pref ? len : top_k - pref) : top_k);
+  const bool scan = visited && len > 0 && take > 0 && (owner == nullptr || owner[L] == rank);
+  if (lane < (int)P) {
+    pj_list[(uint64_t)q * P + lane] = scan ? L : kNoList;
+    pj_pref[(uint64_t)q * P + lane] = pref;
+    pj_take[(uint64_t)q * P + lane] = take;
+  }
+  if (scan) atomicAdd(&cnt[L], 1u);
+  const uint64_t vmask = __ballot(visited);
+  if (lane == 0) {
+    np[q] = (uint32_t)__popcll(vmask);
+    if (ref_mode && top_k > 0 && total_rows < top_k) atomicOr(status, P >= k_lists ? kStInsufficient : kStSpillTooDeep);
+  }
 }
 
 // group: single block.  Per list: pairs, groups (ceil(cnt/QG)), items (groups * segments); exclusive
@@ -228,47 +229,74 @@ struct GroupTotals {
 __global__ __launch_bounds__(1024) void group_kernel(const uint32_t* cnt, const uint32_t* list_len, uint32_t k_lists,
                                                      uint32_t QG, uint32_t seg_rows, uint32_t seg_target, uint32_t* pair_off,
                                                      uint32_t* group_off, uint32_t* item_off, GroupTotals* tot) {
-  __shared__ uint32_t sp[1024], sg[1024], si[1024];
-  __shared__ uint32_t cp, cg, ci;
+  // three exclusive prefix sums over the lists in one pass: wave scans by shuffles, 16 wave totals through LDS,
+  // a running carry between rounds of 1024 lists (the LDS Hillis-Steele version was 26 us at 4096 lists)
+  __shared__ uint32_t wp[16], wg[16], wi[16];
   __shared__ unsigned long long ur, sr;
-  if (threadIdx.x == 0) { cp = cg = ci = 0; ur = sr = 0; }
-  __syncthreads();
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  if (threadIdx.x == 0) { ur = sr = 0; }
+  uint32_t cp = 0, cg = 0, ci = 0;  // carries (identical in every thread)
   unsigned long long my_ur = 0, my_sr = 0;
-  for (uint32_t base = 0; base < k_lists; base += 1024) {
-    const uint32_t L = base + threadIdx.x;
-    uint32_t c = 0, g = 0, it = 0;
-    if (L < k_lists) {
-      c = cnt[L];
+  auto wave_incl = [&](uint32_t x) {
+#pragma unroll
+    for (int off = 1; off < kWave; off <<= 1) {
+      const uint32_t t = __shfl_up(x, off, kWave);
+      if (lane >= off) x += t;
+    }
+    return x;
+  };
+  for (uint32_t base0 = 0; base0 < k_lists; base0 += 8 * 1024) {
+    // all loads of up to eight rounds first (independent), then the scans: the rounds were latency chains
+    uint32_t cs[8], ls[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const uint32_t L = base0 + r * 1024 + threadIdx.x;
+      cs[r] = L < k_lists ? cnt[L] : 0u;
+      ls[r] = L < k_lists ? list_len[L] : 0u;
+    }
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      const uint32_t L = base0 + r * 1024 + threadIdx.x;
+      if (base0 + r * 1024 >= k_lists) break;  // block-uniform
+      const uint32_t c = cs[r];
+      uint32_t g = 0, it = 0;
       if (c) {
-        const uint32_t len = list_len[L];
+        const uint32_t len = ls[r];
         g = (c + QG - 1) / QG;
-        const uint32_t sr = list_seg_rows(len, seg_rows, seg_target);
-        const uint32_t n_s = (len + sr - 1) / sr;
+        const uint32_t sr2 = list_seg_rows(len, seg_rows, seg_target);
+        const uint32_t n_s = (len + sr2 - 1) / sr2;
         it = g * (QG == 1 ? n_s : (n_s + 3) / 4 * 4);  // QG > 1: quads of items share a query block
         my_ur += len;
         my_sr += (unsigned long long)len * g;
       }
-    }
-    sp[threadIdx.x] = c; sg[threadIdx.x] = g; si[threadIdx.x] = it;
-    __syncthreads();
-    for (uint32_t off = 1; off < 1024; off <<= 1) {
-      uint32_t a = 0, bb = 0, cc = 0;
-      if (threadIdx.x >= off) { a = sp[threadIdx.x - off]; bb = sg[threadIdx.x - off]; cc = si[threadIdx.x - off]; }
+      const uint32_t ip = wave_incl(c), ig = wave_incl(g), ii = wave_incl(it);
+      __syncthreads();  // previous round's readers of wp/wg/wi are done
+      if (lane == kWave - 1) { wp[wid] = ip; wg[wid] = ig; wi[wid] = ii; }
       __syncthreads();
-      sp[threadIdx.x] += a; sg[threadIdx.x] += bb; si[threadIdx.x] += cc;
-      __syncthreads();
+      uint32_t bp = 0, bg = 0, bi2 = 0, tp = 0, tg = 0, ti2 = 0;
+#pragma unroll
+      for (int w = 0; w < 16; ++w) {
+        if (w < wid) { bp += wp[w]; bg += wg[w]; bi2 += wi[w]; }
+        tp += wp[w]; tg += wg[w]; ti2 += wi[w];
+      }
+      if (L < k_lists) {
+        pair_off[L] = cp + bp + ip - c;
+        group_off[L] = cg + bg + ig - g;
+        item_off[L] = ci + bi2 + ii - it;
+      }
+      cp += tp; cg += tg; ci += ti2;
     }
-    if (L < k_lists) {
-      pair_off[L] = cp + sp[threadIdx.x] - c;
-      group_off[L] = cg + sg[threadIdx.x] - g;
-      item_off[L] = ci + si[threadIdx.x] - it;
-    }
-    __syncthreads();
-    if (threadIdx.x == 1023) { cp += sp[1023]; cg += sg[1023]; ci += si[1023]; }
-    __syncthreads();
   }
-  atomicAdd(&ur, my_ur);
-  atomicAdd(&sr, my_sr);
+  __syncthreads();
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {  // (1024 threads adding into two LDS words one by one was most of this kernel)
+    my_ur += __shfl_xor(my_ur, off, kWave);
+    my_sr += __shfl_xor(my_sr, off, kWave);
+  }
+  if (lane == 0) {
+    atomicAdd(&ur, my_ur);
+    atomicAdd(&sr, my_sr);
+  }
   __syncthreads();
   if (threadIdx.x == 0) {
     tot->n_items = ci; tot->n_groups = cg; tot->n_pairs = cp; tot->pad = 0;
@@ -1127,7 +1155,7 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
     VERS_HIP_TRY(hipGetLastError());
   } else {
   VERS_HIP_TRY(hipMemsetAsync(cnt, 0, 2 * (size_t)k_l * sizeof(uint32_t), st));
-  hipLaunchKernelGGL(plan_kernel, dim3((b + 127) / 128), dim3(128), 0, st, h->probe.as<uint64_t>(), b, P, k_l, top_k, ref_mode,
+  hipLaunchKernelGGL(plan_kernel, dim3((b + 3) / 4), dim3(256), 0, st, h->probe.as<uint64_t>(), b, P, k_l, top_k, ref_mode,
                      h->list_len.as<uint32_t>(), h->world > 1 ? h->owner.as<uint8_t>() : (const uint8_t*)nullptr, h->rank, pj_list,
                      pj_pref, pj_take, np, cnt, h->status.as<uint32_t>());
   VERS_HIP_TRY(hipGetLastError());
