@@ -1086,8 +1086,9 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
   // slack of 10 keys: at cfg3 a slack of 6 left ~2 of 1024 queries uncertified per batch, 10 none
   uint32_t kp = std::min<uint32_t>(kPreMaxKp, std::max<uint32_t>(top_k + 10, top_k + top_k / 2));
   if (const char* e = getenv("VERS_PRE_SLACK")) kp = std::min<uint32_t>(kPreMaxKp, top_k + std::max(1, atoi(e)));  // tuning knob
-  const bool use_pre = QG != 1 && !ref_mode && pre_mode != 0 && top_k + 6 <= kPreMaxKp &&
-                       prescan_lds_bytes(h->ld, kp) <= 160u * 1024u;
+  static const bool pre_g = [] { const char* e = getenv("VERS_PRE_G"); return !e || atoi(e) != 0; }();  // 0: the 4-wave variant
+  const bool fits4 = prescan_lds_bytes(h->ld, kp) <= 160u * 1024u, fits8 = prescan_lds_bytes_g(h->ld, kp) <= 160u * 1024u;
+  const bool use_pre = QG != 1 && !ref_mode && pre_mode != 0 && top_k + 6 <= kPreMaxKp && (fits4 || fits8);
   if (use_pre) QG = kPreQ;
   const uint32_t k_keep = use_pre ? kp : top_k;
   const uint64_t groups_bound = QG == 1 ? n_pj : (n_pj / QG + std::min<uint64_t>(h->k, n_pj));
@@ -1112,9 +1113,8 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
   // VERS_SEG_BALANCED=0 switches them off
   static const bool seg_balanced = [] { const char* e = getenv("VERS_SEG_BALANCED"); return !e || atoi(e) != 0; }();
   const uint32_t seg_target = use_pre && seg_balanced ? seg_rows : 0u;
-  // variant of the matrix-core scan: two waves per item (prescan_kernel_g) unless VERS_PRE_G=0
-  static const bool pre_g = [] { const char* e = getenv("VERS_PRE_G"); return !e || atoi(e) != 0; }();
-  const bool use_g = use_pre && pre_g && prescan_lds_bytes_g(h->ld, kp) <= 160u * 1024u;
+  // variant of the matrix-core scan: two waves per item and block-wide lists (prescan_kernel_g) unless VERS_PRE_G=0
+  const bool use_g = use_pre && fits8 && (pre_g || !fits4);
   const uint32_t pre_halves = 1u;
   // segments per list at most; partial slots per (query, probe): one per segment, or one per QUAD of segments (use_g)
   const uint32_t S_seg = seg_target ? 4 * std::max<uint32_t>(1, (h->max_len + 4 * seg_target - 1) / (4 * seg_target))
