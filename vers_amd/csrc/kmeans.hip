@@ -281,19 +281,34 @@ int32_t km_update(const float* X, uint32_t ld, const uint32_t* sorted_ids, const
 }
 
 // ---- cost -------------------------------------------------------------------------------
-__global__ void cost_fold_kernel(const float* v, uint64_t n, float* out) {
-  if (blockIdx.x != 0 || threadIdx.x != 0) return;
+// The fold is one dependent chain of n f32 adds (the reference's .fold(0.0, |acc, val| acc + val)); what can be
+// taken off the chain is everything else: one wave loads 256 values per step with a single coalesced float4 per
+// lane (double buffered), v_readlane hands them to the chain in index order as scalar operands.  ~6 cycles per
+// element instead of one scalar-thread load + add (~56 cycles): 0.26 s -> ~0.03 s at n = 10M.
+__global__ __launch_bounds__(kWave) void cost_fold_kernel(const float* v, uint64_t n, float* out) {
+  if (blockIdx.x != 0) return;
+  const int lane = threadIdx.x;
   float acc = 0.0f;
-  uint64_t i = 0;
-  for (; i + 16 <= n; i += 16) {
-    float t[16];
+  const uint64_t n_blk = n / 256;
+  const bool aligned = (reinterpret_cast<uintptr_t>(v) & 15u) == 0;
+  uint64_t done = 0;
+  if (aligned && n_blk) {
+    const f32x4* v4 = reinterpret_cast<const f32x4*>(v);
+    f32x4 cur = v4[lane];
+    for (uint64_t bk = 0; bk < n_blk; ++bk) {
+      const uint64_t nb = bk + 1 < n_blk ? bk + 1 : bk;
+      const f32x4 nxt = v4[nb * 64 + lane];  // in flight under this block's chain
 #pragma unroll
-    for (int u = 0; u < 16; ++u) t[u] = v[i + u];
+      for (int j = 0; j < kWave; ++j)
 #pragma unroll
-    for (int u = 0; u < 16; ++u) acc = __fadd_rn(acc, t[u]);
+        for (int u = 0; u < 4; ++u)
+          acc = __fadd_rn(acc, __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(cur[u]), j)));
+      cur = nxt;
+    }
+    done = n_blk * 256;
   }
-  for (; i < n; ++i) acc = __fadd_rn(acc, v[i]);
-  *out = acc;
+  for (uint64_t i = done; i < n; ++i) acc = __fadd_rn(acc, v[i]);  // tail (and unaligned input): every lane, same value
+  if (lane == 0) *out = acc;
 }
 
 int32_t km_cost_fold(const float* mind, uint64_t n, float* out_dev, hipStream_t st) {
