@@ -184,7 +184,7 @@ __global__ __launch_bounds__(kWave * kMergeWaves) void coarse_merge_kernel(const
 __global__ __launch_bounds__(256) void plan_kernel(const uint64_t* probe, uint32_t b, uint32_t P, uint32_t k_lists, uint32_t top_k,
                                                    int ref_mode, const uint32_t* list_len, const uint8_t* owner, uint32_t rank,
                                                    uint32_t* pj_list, uint32_t* pj_pref, uint32_t* pj_take, uint32_t* np, uint32_t* cnt,
-                                                   uint32_t* status) {
+                                                   uint32_t* hot, uint32_t hot_ranks, uint32_t* status) {
   // one WAVE per query, lane j = probe rank j (P <= 64): the walk of the ranked lists in closed form -- list j is
   // visited while the rows before it do not yet fill top_k and contributes take_j = min(len_j, top_k - rows before)
   // (a thread per query walking its P probes was 2 P dependent-latency loads: 36 us at b = 1024)
@@ -211,6 +211,7 @@ __global__ __launch_bounds__(256) void plan_kernel(const uint64_t* probe, uint32
     pj_take[(uint64_t)q * P + lane] = take;
   }
   if (scan) atomicAdd(&cnt[L], 1u);
+  if (scan && lane < (int)hot_ranks) hot[L] = 1u;  // this query's tightest thresholds come from here (group_kernel orders the work)
   const uint64_t vmask = __ballot(visited);
   if (lane == 0) {
     np[q] = (uint32_t)__popcll(vmask);
@@ -227,15 +228,18 @@ struct GroupTotals {
 };
 
 __global__ __launch_bounds__(1024) void group_kernel(const uint32_t* cnt, const uint32_t* list_len, uint32_t k_lists,
-                                                     uint32_t QG, uint32_t seg_rows, uint32_t seg_target, uint32_t* pair_off,
-                                                     uint32_t* group_off, uint32_t* item_off, GroupTotals* tot) {
+                                                     uint32_t QG, uint32_t seg_rows, uint32_t seg_target, const uint32_t* hot,
+                                                     uint32_t* pair_off, uint32_t* group_off, uint32_t* item_off, GroupTotals* tot) {
+  // Work order: the items of "hot" lists (nearest or second nearest list of some query) come first, so that every
+  // query's threshold is tight before the bulk of its lists is scanned (the scan hands quads out in item order);
+  // item_off = position among the hot items, or (all hot items) + position among the others.
   // three exclusive prefix sums over the lists in one pass: wave scans by shuffles, 16 wave totals through LDS,
   // a running carry between rounds of 1024 lists (the LDS Hillis-Steele version was 26 us at 4096 lists)
-  __shared__ uint32_t wp[16], wg[16], wi[16];
+  __shared__ uint32_t wp[16], wg[16], wi[16], wh[16];
   __shared__ unsigned long long ur, sr;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   if (threadIdx.x == 0) { ur = sr = 0; }
-  uint32_t cp = 0, cg = 0, ci = 0;  // carries (identical in every thread)
+  uint32_t cp = 0, cg = 0, ci = 0, ch = 0;  // carries (identical in every thread); ci: other lists' items, ch: hot lists' items
   unsigned long long my_ur = 0, my_sr = 0;
   auto wave_incl = [&](uint32_t x) {
 #pragma unroll
@@ -247,12 +251,13 @@ __global__ __launch_bounds__(1024) void group_kernel(const uint32_t* cnt, const 
   };
   for (uint32_t base0 = 0; base0 < k_lists; base0 += 8 * 1024) {
     // all loads of up to eight rounds first (independent), then the scans: the rounds were latency chains
-    uint32_t cs[8], ls[8];
+    uint32_t cs[8], ls[8], hs[8];
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
       const uint32_t L = base0 + r * 1024 + threadIdx.x;
       cs[r] = L < k_lists ? cnt[L] : 0u;
       ls[r] = L < k_lists ? list_len[L] : 0u;
+      hs[r] = L < k_lists ? hot[L] : 0u;
     }
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
@@ -269,22 +274,24 @@ __global__ __launch_bounds__(1024) void group_kernel(const uint32_t* cnt, const 
         my_ur += len;
         my_sr += (unsigned long long)len * g;
       }
-      const uint32_t ip = wave_incl(c), ig = wave_incl(g), ii = wave_incl(it);
-      __syncthreads();  // previous round's readers of wp/wg/wi are done
-      if (lane == kWave - 1) { wp[wid] = ip; wg[wid] = ig; wi[wid] = ii; }
+      const bool is_hot = hs[r] != 0;
+      const uint32_t it_c = is_hot ? 0u : it, it_h = is_hot ? it : 0u;
+      const uint32_t ip = wave_incl(c), ig = wave_incl(g), ii = wave_incl(it_c), ih = wave_incl(it_h);
+      __syncthreads();  // previous round's readers of wp/wg/wi/wh are done
+      if (lane == kWave - 1) { wp[wid] = ip; wg[wid] = ig; wi[wid] = ii; wh[wid] = ih; }
       __syncthreads();
-      uint32_t bp = 0, bg = 0, bi2 = 0, tp = 0, tg = 0, ti2 = 0;
+      uint32_t bp = 0, bg = 0, bi2 = 0, bh = 0, tp = 0, tg = 0, ti2 = 0, th = 0;
 #pragma unroll
       for (int w = 0; w < 16; ++w) {
-        if (w < wid) { bp += wp[w]; bg += wg[w]; bi2 += wi[w]; }
-        tp += wp[w]; tg += wg[w]; ti2 += wi[w];
+        if (w < wid) { bp += wp[w]; bg += wg[w]; bi2 += wi[w]; bh += wh[w]; }
+        tp += wp[w]; tg += wg[w]; ti2 += wi[w]; th += wh[w];
       }
       if (L < k_lists) {
         pair_off[L] = cp + bp + ip - c;
         group_off[L] = cg + bg + ig - g;
-        item_off[L] = ci + bi2 + ii - it;
+        item_off[L] = is_hot ? ch + bh + ih - it_h : ci + bi2 + ii - it_c;  // the others are shifted below
       }
-      cp += tp; cg += tg; ci += ti2;
+      cp += tp; cg += tg; ci += ti2; ch += th;
     }
   }
   __syncthreads();
@@ -298,8 +305,10 @@ __global__ __launch_bounds__(1024) void group_kernel(const uint32_t* cnt, const 
     atomicAdd(&sr, my_sr);
   }
   __syncthreads();
+  for (uint32_t L = threadIdx.x; L < k_lists; L += 1024)
+    if (cnt[L] != 0 && hot[L] == 0) item_off[L] += ch;  // (each thread shifts entries it wrote itself: L % 1024 == threadIdx.x)
   if (threadIdx.x == 0) {
-    tot->n_items = ci; tot->n_groups = cg; tot->n_pairs = cp; tot->pad = 0;
+    tot->n_items = ci + ch; tot->n_groups = cg; tot->n_pairs = cp; tot->pad = 0;
     tot->union_rows = ur; tot->streamed_rows = sr;
   }
 }
@@ -1126,7 +1135,7 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
   const uint32_t k_l = h->k;
   // pj: list, pref, take per (q, j); np per q.   lists: cnt, fill | pair_off, group_off, item_off | totals
   if (int32_t rc = h->pj.reserve((3 * n_pj + b) * sizeof(uint32_t))) return rc;
-  if (int32_t rc = h->lists.reserve((5 * (size_t)k_l) * sizeof(uint32_t) + sizeof(GroupTotals) + 64)) return rc;
+  if (int32_t rc = h->lists.reserve((6 * (size_t)k_l) * sizeof(uint32_t) + sizeof(GroupTotals) + 64)) return rc;
   if (int32_t rc = h->pairs.reserve(n_pj * sizeof(uint32_t))) return rc;
   if (int32_t rc = h->items.reserve(std::max<uint64_t>(1, items_bound) * sizeof(ItemDesc))) return rc;
   if (int32_t rc = h->groups.reserve(std::max<uint64_t>(1, groups_bound) * sizeof(GroupDesc))) return rc;
@@ -1141,7 +1150,8 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
   uint32_t* np = pj_take + n_pj;
   uint32_t* cnt = h->lists.as<uint32_t>();
   uint32_t* fill = cnt + k_l;
-  uint32_t* pair_off = fill + k_l;
+  uint32_t* hot = fill + k_l;  // lists that are the nearest or second nearest list of some query: scanned first
+  uint32_t* pair_off = hot + k_l;
   uint32_t* group_off = pair_off + k_l;
   uint32_t* item_off = group_off + k_l;
   GroupTotals* tot = (GroupTotals*)(((uintptr_t)(item_off + k_l) + 15) & ~(uintptr_t)15);
@@ -1154,13 +1164,14 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
                        h->pairs.as<uint32_t>(), h->items.as<ItemDesc>(), h->groups.as<GroupDesc>(), tot, h->status.as<uint32_t>());
     VERS_HIP_TRY(hipGetLastError());
   } else {
-  VERS_HIP_TRY(hipMemsetAsync(cnt, 0, 2 * (size_t)k_l * sizeof(uint32_t), st));
+  static const uint32_t hot_ranks = [] { const char* e = getenv("VERS_HOT_FIRST"); return e ? (uint32_t)atoi(e) : 1u; }();  // A/B knob
+  VERS_HIP_TRY(hipMemsetAsync(cnt, 0, 3 * (size_t)k_l * sizeof(uint32_t), st));
   hipLaunchKernelGGL(plan_kernel, dim3((b + 3) / 4), dim3(256), 0, st, h->probe.as<uint64_t>(), b, P, k_l, top_k, ref_mode,
                      h->list_len.as<uint32_t>(), h->world > 1 ? h->owner.as<uint8_t>() : (const uint8_t*)nullptr, h->rank, pj_list,
-                     pj_pref, pj_take, np, cnt, h->status.as<uint32_t>());
+                     pj_pref, pj_take, np, cnt, hot, hot_ranks, h->status.as<uint32_t>());
   VERS_HIP_TRY(hipGetLastError());
   hipLaunchKernelGGL(group_kernel, dim3(1), dim3(1024), 0, st, cnt, h->list_len.as<uint32_t>(), k_l, (uint32_t)QG, seg_rows, seg_target,
-                     pair_off, group_off, item_off, tot);
+                     (const uint32_t*)hot, pair_off, group_off, item_off, tot);
   VERS_HIP_TRY(hipGetLastError());
   hipLaunchKernelGGL(scatter_pairs_kernel, dim3((unsigned)((n_pj + 255) / 256)), dim3(256), 0, st, pj_list, (uint32_t)n_pj, pair_off,
                      fill, h->pairs.as<uint32_t>());
@@ -1630,7 +1641,7 @@ int32_t vers_ivf_last_scan(vers_ivf_t* h, float* out_ms, uint64_t* out_union_row
   const uint32_t slot = (uint32_t)((h->ev_count - 1) % vers_ivf::kEvRing);
   VERS_HIP_TRY(hipEventSynchronize(h->ev1[slot]));
   if (out_ms) VERS_HIP_TRY(hipEventElapsedTime(out_ms, h->ev0[slot], h->ev1[slot]));
-  const uint32_t* item_off_end = h->lists.as<uint32_t>() + 5 * (size_t)h->k;
+  const uint32_t* item_off_end = h->lists.as<uint32_t>() + 6 * (size_t)h->k;
   const GroupTotals* tot = (const GroupTotals*)(((uintptr_t)item_off_end + 15) & ~(uintptr_t)15);
   GroupTotals t;
   VERS_HIP_TRY(hipMemcpy(&t, tot, sizeof(t), hipMemcpyDeviceToHost));
