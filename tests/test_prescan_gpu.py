@@ -28,7 +28,7 @@ def check(ix, Q, top_k, nprobe, step=7):
 
 total = 0
 # (1) clustered data, several shapes (d = 300 pads to 320 columns; lists are ragged: lengths not multiples of 64)
-for seed, n, d, k, b, nprobe, top_ks in [(0x81, 9000, 96, 48, 160, 8, (1, 10, 26)), (0x82, 5000, 300, 32, 96, 6, (10,)),
+for seed, n, d, k, b, nprobe, top_ks in [(0x81, 9000, 96, 48, 160, 8, (1, 10, 26, 54)), (0x82, 5000, 300, 32, 96, 6, (10,)),
                                          (0x83, 3000, 768, 24, 80, 5, (10, 20)),
                                          # d = 1152: only the 8-wave variant's LDS layout fits; d = 1536: none does (ordered chains)
                                          (0x84, 1500, 1152, 12, 64, 4, (10,)), (0x85, 1200, 1536, 12, 64, 4, (10,))]:
@@ -43,7 +43,8 @@ for seed, n, d, k, b, nprobe, top_ks in [(0x81, 9000, 96, 48, 160, 8, (1, 10, 26
             ix.add(Q[i % 5] * np.float32(1.0 + i / 512.0), 0)
         check(ix, Q, 10, nprobe)
         total += 1
-        check(ix, Q, 27, nprobe)   # top_k + slack > 32 keys: stays on the ordered-chain scan
+        check(ix, Q, 40, nprobe)   # wide lists (50 keys): only the 8-wave variant's LDS layout holds them
+        check(ix, Q, 60, nprobe)   # top_k + slack > 64 keys: stays on the ordered-chain scan
 # (2) uniform data: distances concentrate, many near-ties around the k-th
 X = dg.dist_u(0x91, 6000, 64)
 ix = IVFFlatIndex.build_index(40, 1, 2, X, init_indices=mg.init_draws(0x91, 1, 40, 6000))

@@ -40,7 +40,7 @@ static_assert(kPreRing == 2 || kPreRing == 3, "ring depth");
 #define VERS_PRE_AUX 2
 #endif
 constexpr int kPreAux = VERS_PRE_AUX;  // cache policy of the row-tile loads: 2 = nt (streamed once); same-box A/B at cfg3: -1.8 % vs default
-constexpr uint32_t kPreMaxKp = 32;  // widest per-item list (LDS: 4 waves x 16 queries x kp keys)
+constexpr uint32_t kPreMaxKp = 64;  // widest list: one sorted key per lane
 
 struct PreParams {
   uint32_t ld, n_chunks, kp;
