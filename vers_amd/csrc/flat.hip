@@ -77,6 +77,8 @@ struct vers_flat {
   // workspace (grown on demand, never inside a steady-state call)
   float* q_stage = nullptr;
   size_t q_stage_cap = 0;
+  float* q_up = nullptr;  // host-pointer calls: uploaded queries (grow-only: no allocation in a steady-state call)
+  size_t q_up_cap = 0;
   float* zero_q = nullptr;
   uint32_t zero_q_len = 0;
   uint64_t* partials = nullptr;  // partial slots, then one pruning bound per query
@@ -215,7 +217,7 @@ int32_t vers_flat_destroy(vers_flat_t* h) {
   DeviceGuard g(h->device);
   (void)hipDeviceSynchronize();
   if (h->rows) (void)hipFree(h->rows);
-  for (void* p : {(void*)h->q_stage, (void*)h->zero_q, (void*)h->partials, (void*)h->status_dev, (void*)h->o_ids,
+  for (void* p : {(void*)h->q_stage, (void*)h->q_up, (void*)h->zero_q, (void*)h->partials, (void*)h->status_dev, (void*)h->o_ids,
                   (void*)h->o_dist, (void*)h->o_cnt})
     if (p) (void)hipFree(p);
   if (h->ev0) (void)hipEventDestroy(h->ev0);
@@ -293,8 +295,8 @@ int32_t vers_flat_search(vers_flat_t* h, const float* queries, uint64_t q_stride
   std::lock_guard<std::mutex> lk(h->mu);
   DeviceGuard g(h->device);
   const uint32_t ldq_pad = h->ld;
-  float* qd = nullptr;
-  VERS_HIP_TRY(hipMalloc((void**)&qd, (size_t)b * ldq_pad * sizeof(float)));
+  if (int32_t rc0 = grow(h->q_up, h->q_up_cap, (size_t)b * ldq_pad)) return rc0;
+  float* qd = h->q_up;
   int32_t rc = VERS_OK;
   do {
     if (hipMemset(qd, 0, (size_t)b * ldq_pad * sizeof(float)) != hipSuccess ||
@@ -322,7 +324,6 @@ int32_t vers_flat_search(vers_flat_t* h, const float* queries, uint64_t q_stride
     if (hipMemcpy(out_count, h->o_cnt, b * sizeof(uint32_t), hipMemcpyDeviceToHost) != hipSuccess)
       rc = fail(VERS_ERR_HIP, "result download failed");
   } while (0);
-  (void)hipFree(qd);
   return rc;
 }
 

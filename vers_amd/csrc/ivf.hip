@@ -16,6 +16,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
 #include <mutex>
 #include <vector>
 
@@ -624,6 +625,12 @@ struct vers_ivf {
   hipEvent_t ev0[kEvRing] = {}, ev1[kEvRing] = {};
   uint64_t ev_count = 0;
   size_t ivf_bounds_off = 0;  // pruning bounds live behind the partial slots (one memset)
+  // host-pointer entry points: one pinned staging buffer, one device buffer for queries, one for the packed
+  // results, one stream -- a call is one H2D copy, the kernels, one D2H copy and ONE synchronisation
+  DevBuf io_q, io_out;
+  void* io_pin = nullptr;
+  size_t io_pin_cap = 0;
+  hipStream_t io_stream = nullptr;
   GroupTotals last_tot{};
   bool tot_valid = false;
   std::mutex mu;
@@ -631,10 +638,15 @@ struct vers_ivf {
 
 namespace {
 
+int32_t status_to_rc(vers_ivf* h, uint32_t s);
 int32_t sync_status(vers_ivf* h, hipStream_t st) {
   uint32_t s = 0;
   VERS_HIP_TRY(hipStreamSynchronize(st));
   VERS_HIP_TRY(hipMemcpy(&s, h->status.p, sizeof(s), hipMemcpyDeviceToHost));
+  return status_to_rc(h, s);
+}
+// maps (and clears) the device status word of a finished search: the reference's panics
+int32_t status_to_rc(vers_ivf* h, uint32_t s) {
   if (s) {
     VERS_HIP_TRY(hipMemset(h->status.p, 0, sizeof(s)));
     if (s & kStNaN) return fail(VERS_ERR_NAN, "NaN distance (the reference panics in partial_cmp().unwrap())");
@@ -1340,6 +1352,63 @@ int32_t download_results(vers_ivf* h, uint32_t b, uint32_t top_k, uint64_t* out_
   return VERS_OK;
 }
 
+// ---- host-pointer calls: staged through pinned memory, one synchronisation -----------------------------
+struct HostIo {
+  size_t q_bytes, ids_off, dist_off, cnt_off, st_off, out_bytes;
+  float* q_dev;
+  uint64_t* ids_dev;
+  float* dist_dev;
+  uint32_t* cnt_dev;
+};
+
+int32_t host_io_begin(vers_ivf* h, const float* queries, uint64_t stride_bytes, uint32_t b, uint32_t top_k, HostIo& io) {
+  const size_t need = (size_t)b * std::max<uint32_t>(top_k, 1);
+  io.q_bytes = (size_t)b * h->d * sizeof(float);
+  io.ids_off = 0;
+  io.dist_off = need * sizeof(uint64_t);
+  io.cnt_off = io.dist_off + need * sizeof(float);
+  io.st_off = io.cnt_off + (size_t)b * sizeof(uint32_t);
+  io.out_bytes = io.st_off + 16;
+  if (!h->io_stream) VERS_HIP_TRY(hipStreamCreateWithFlags(&h->io_stream, hipStreamNonBlocking));
+  if (int32_t rc = h->io_q.reserve(io.q_bytes)) return rc;
+  if (int32_t rc = h->io_out.reserve(io.out_bytes)) return rc;
+  const size_t pin_need = std::max(io.q_bytes, io.out_bytes);
+  if (pin_need > h->io_pin_cap) {
+    if (h->io_pin) (void)hipHostFree(h->io_pin);
+    h->io_pin = nullptr; h->io_pin_cap = 0;
+    VERS_HIP_TRY(hipHostMalloc(&h->io_pin, pin_need, hipHostMallocDefault));
+    h->io_pin_cap = pin_need;
+  }
+  char* base = (char*)h->io_out.p;
+  io.q_dev = h->io_q.as<float>();
+  io.ids_dev = (uint64_t*)(base + io.ids_off);
+  io.dist_dev = (float*)(base + io.dist_off);
+  io.cnt_dev = (uint32_t*)(base + io.cnt_off);
+  for (uint32_t i = 0; i < b; ++i)
+    std::memcpy((char*)h->io_pin + (size_t)i * h->d * 4, (const char*)queries + (size_t)i * stride_bytes, (size_t)h->d * 4);
+  VERS_HIP_TRY(hipMemcpyAsync(io.q_dev, h->io_pin, io.q_bytes, hipMemcpyHostToDevice, h->io_stream));
+  return VERS_OK;
+}
+
+// copies results + status word back, waits once, maps the status; *out_status_rc carries kRetrySpill etc.
+int32_t host_io_end(vers_ivf* h, const HostIo& io, uint32_t b, uint32_t top_k, uint64_t* out_ids, float* out_dist, uint32_t* out_count) {
+  char* base = (char*)h->io_out.p;
+  VERS_HIP_TRY(hipMemcpyAsync(base + io.st_off, h->status.p, sizeof(uint32_t), hipMemcpyDeviceToDevice, h->io_stream));
+  VERS_HIP_TRY(hipMemcpyAsync(h->io_pin, base, io.out_bytes, hipMemcpyDeviceToHost, h->io_stream));
+  VERS_HIP_TRY(hipStreamSynchronize(h->io_stream));
+  const char* pin = (const char*)h->io_pin;
+  uint32_t s = 0;
+  std::memcpy(&s, pin + io.st_off, sizeof(s));
+  if (int32_t rc = status_to_rc(h, s)) return rc;
+  const size_t need = (size_t)b * top_k;
+  if (need) {
+    std::memcpy(out_ids, pin + io.ids_off, need * sizeof(uint64_t));
+    std::memcpy(out_dist, pin + io.dist_off, need * sizeof(float));
+  }
+  std::memcpy(out_count, pin + io.cnt_off, (size_t)b * sizeof(uint32_t));
+  return VERS_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -1378,6 +1447,8 @@ int32_t vers_ivf_destroy(vers_ivf_t* h) {
     if (h->ev0[i]) (void)hipEventDestroy(h->ev0[i]);
     if (h->ev1[i]) (void)hipEventDestroy(h->ev1[i]);
   }
+  if (h->io_pin) (void)hipHostFree(h->io_pin);
+  if (h->io_stream) (void)hipStreamDestroy(h->io_stream);
   delete h;
   return VERS_OK;
 }
@@ -1568,23 +1639,18 @@ int32_t vers_ivf_search(vers_ivf_t* h, const float* queries, uint64_t q_stride_b
   if (b == 0) return VERS_OK;
   std::lock_guard<std::mutex> lk(h->mu);
   DeviceGuard g(h->device);
-  DevBuf q;
-  if (int32_t rc = upload_queries(queries, q_stride_bytes, b, h->d, q)) return rc;
-  if (int32_t rc = ensure_out(h, (size_t)b * std::max<uint32_t>(top_k, 1), b)) return rc;
-  if (int32_t rc = search_dev_locked(h, q.as<float>(), h->d, b, top_k, nprobe, h->o_ids.as<uint64_t>(), h->o_dist.as<float>(),
-                                     h->o_cnt.as<uint32_t>(), nullptr, nullptr))
-    return rc;
-  int32_t rc = sync_status(h, nullptr);
+  HostIo io;
+  if (int32_t rc = host_io_begin(h, queries, q_stride_bytes, b, top_k, io)) return rc;
+  if (int32_t rc = search_dev_locked(h, io.q_dev, h->d, b, top_k, nprobe, io.ids_dev, io.dist_dev, io.cnt_dev, nullptr, h->io_stream)) return rc;
+  int32_t rc = host_io_end(h, io, b, top_k, out_ids, out_dist, out_count);
   if (rc == kRetrySpill && h->k > 48) {  // rank deeper (64 lists, exact coarse quantiser) and try once more
     h->ref_deep = true;
-    rc = search_dev_locked(h, q.as<float>(), h->d, b, top_k, nprobe, h->o_ids.as<uint64_t>(), h->o_dist.as<float>(),
-                           h->o_cnt.as<uint32_t>(), nullptr, nullptr);
+    rc = search_dev_locked(h, io.q_dev, h->d, b, top_k, nprobe, io.ids_dev, io.dist_dev, io.cnt_dev, nullptr, h->io_stream);
     h->ref_deep = false;
     if (rc) return rc;
-    rc = sync_status(h, nullptr);
+    rc = host_io_end(h, io, b, top_k, out_ids, out_dist, out_count);
   }
-  if (rc) return rc == kRetrySpill ? VERS_ERR_INVALID : rc;
-  return download_results(h, b, top_k, out_ids, out_dist, out_count);
+  return rc == kRetrySpill ? VERS_ERR_INVALID : rc;
 }
 
 int32_t vers_ivf_search_exhaustive_dev(vers_ivf_t* h, const float* queries_dev, uint64_t ldq_floats, uint32_t b, uint32_t top_k,
@@ -1609,14 +1675,11 @@ int32_t vers_ivf_search_exhaustive(vers_ivf_t* h, const float* queries, uint64_t
   if (b == 0) return VERS_OK;
   std::lock_guard<std::mutex> lk(h->mu);
   DeviceGuard g(h->device);
-  DevBuf q;
-  if (int32_t rc = upload_queries(queries, q_stride_bytes, b, h->d, q)) return rc;
-  if (int32_t rc = ensure_out(h, (size_t)b * std::max<uint32_t>(top_k, 1), b)) return rc;
-  if (int32_t rc = exhaustive_dev_locked(h, q.as<float>(), h->d, b, top_k, metric, h->o_ids.as<uint64_t>(), h->o_dist.as<float>(),
-                                         h->o_cnt.as<uint32_t>(), nullptr))
-    return rc;
-  if (int32_t rc = sync_status(h, nullptr)) return rc == kRetrySpill ? VERS_ERR_INVALID : rc;
-  return download_results(h, b, top_k, out_ids, out_dist, out_count);
+  HostIo io;
+  if (int32_t rc = host_io_begin(h, queries, q_stride_bytes, b, top_k, io)) return rc;
+  if (int32_t rc = exhaustive_dev_locked(h, io.q_dev, h->d, b, top_k, metric, io.ids_dev, io.dist_dev, io.cnt_dev, h->io_stream)) return rc;
+  const int32_t rc = host_io_end(h, io, b, top_k, out_ids, out_dist, out_count);
+  return rc == kRetrySpill ? VERS_ERR_INVALID : rc;
 }
 
 int32_t vers_ivf_info(vers_ivf_t* h, uint64_t* out_n, uint64_t* out_k, uint64_t* out_max_list_len) {
