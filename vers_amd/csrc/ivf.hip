@@ -600,6 +600,7 @@ struct vers_ivf {
   DevBuf coarse_stat;  // u32: queries that failed the certificate and were re-done exactly
   float cmax2 = 0.0f;
   bool ref_deep = false;  // reference-mode retry: rank 64 lists with the exact coarse quantiser (no slack needed)
+  bool ref_shallow = false;  // host-pointer calls try 16 ranked lists first (a spill past the nearest few lists is rare)
   uint32_t k_pad = 0;
   uint64_t mfma_batches = 0;
   DevBuf rows, row_ids, list_off, list_len;
@@ -1086,7 +1087,7 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
   const int ref_mode = nprobe == 0;
   // reference mode ranks the 48 nearest lists (48 + 16 slack = one key per lane in the MFMA pre-selection);
   // a spill deeper than that is refused (kStSpillTooDeep) -- it needs > 47 consecutive near-empty lists
-  const uint32_t P = ref_mode ? std::min<uint32_t>(h->k, h->ref_deep ? 64u : 48u) : std::min<uint32_t>(nprobe, h->k);
+  const uint32_t P = ref_mode ? std::min<uint32_t>(h->k, h->ref_deep ? 64u : (h->ref_shallow ? 16u : 48u)) : std::min<uint32_t>(nprobe, h->k);
   if (P > (uint32_t)kMaxTopK) return fail(VERS_ERR_INVALID, "nprobe > 64 is not supported");
   const float* qp = nullptr;
   if (int32_t rc = stage_plain_queries(h, q_dev, ldq_in, b, &qp, st)) return rc;
@@ -1641,14 +1642,18 @@ int32_t vers_ivf_search(vers_ivf_t* h, const float* queries, uint64_t q_stride_b
   DeviceGuard g(h->device);
   HostIo io;
   if (int32_t rc = host_io_begin(h, queries, q_stride_bytes, b, top_k, io)) return rc;
-  if (int32_t rc = search_dev_locked(h, io.q_dev, h->d, b, top_k, nprobe, io.ids_dev, io.dist_dev, io.cnt_dev, nullptr, h->io_stream)) return rc;
-  int32_t rc = host_io_end(h, io, b, top_k, out_ids, out_dist, out_count);
-  if (rc == kRetrySpill && h->k > 48) {  // rank deeper (64 lists, exact coarse quantiser) and try once more
-    h->ref_deep = true;
+  // Reference mode ranks only as many lists as the spill may need: 16 first (the merge of the coarse partial lists
+  // and the plan are what a single-query call waits for), then 48, then 64 with the exact coarse quantiser.
+  int32_t rc = VERS_OK;
+  for (int attempt = nprobe == 0 ? 0 : 1; attempt < 3; ++attempt) {
+    h->ref_shallow = attempt == 0;
+    h->ref_deep = attempt == 2;
     rc = search_dev_locked(h, io.q_dev, h->d, b, top_k, nprobe, io.ids_dev, io.dist_dev, io.cnt_dev, nullptr, h->io_stream);
-    h->ref_deep = false;
+    h->ref_shallow = h->ref_deep = false;
     if (rc) return rc;
     rc = host_io_end(h, io, b, top_k, out_ids, out_dist, out_count);
+    if (rc != kRetrySpill) break;
+    if ((attempt == 0 && h->k <= 16) || (attempt == 1 && h->k <= 48)) break;  // every list was ranked already
   }
   return rc == kRetrySpill ? VERS_ERR_INVALID : rc;
 }
