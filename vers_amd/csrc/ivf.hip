@@ -1090,7 +1090,8 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
   const uint32_t P = ref_mode ? std::min<uint32_t>(h->k, h->ref_deep ? 64u : (h->ref_shallow ? 16u : 48u)) : std::min<uint32_t>(nprobe, h->k);
   if (P > (uint32_t)kMaxTopK) return fail(VERS_ERR_INVALID, "nprobe > 64 is not supported");
   const float* qp = nullptr;
-  if (int32_t rc = stage_plain_queries(h, q_dev, ldq_in, b, &qp, st)) return rc;
+  if (b == 1 && h->d == h->ldq && (reinterpret_cast<uintptr_t>(q_dev) & 15u) == 0) qp = q_dev;  // a single unpadded-is-padded query: no staging launch
+  else if (int32_t rc = stage_plain_queries(h, q_dev, ldq_in, b, &qp, st)) return rc;
   uint32_t n_segs_c = 0;
   if (int32_t rc = coarse(h, qp, b, P, st, b == 1 ? &n_segs_c : nullptr)) return rc;
 
