@@ -227,7 +227,8 @@ def main():
             e = np.take_along_axis(ae, order, axis=1)
         hits = sum(len(set(ids_h[q, :cnt_h[q]].tolist()) & set(e[q].tolist())) for q in range(nq_r))
         recall = hits / float(nq_r * top_k)
-        log(f"[bench] recall@{top_k} = {recall:.4f} over {nq_r} queries (exact scan took {t_ex:.2f}s)")
+        if rank == 0:
+            log(f"[bench] recall@{top_k} = {recall:.4f} over {nq_r} queries (exact scan took {t_ex:.2f}s)")
 
     # ---- full-size property: self-retrieval -------------------------------------------------------------------
     # a stored row queried bit-identically comes back first at distance exactly 0.0 (assign and search use the same
