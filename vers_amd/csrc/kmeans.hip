@@ -175,7 +175,7 @@ int32_t km_assign_mfma(const float* X, uint32_t ldx, uint64_t n, const float* C,
     }
     hipLaunchKernelGGL(dist_gemm_kernel<true>, dim3(nb_pad / kGemmBN, k_pad / kGemmBM), dim3(256), 0, st, ws.cg.as<float>(), xb,
                        ws.cnorm.as<float>(), ldq, nb_pad, ws.gt.as<float>());
-    hipLaunchKernelGGL(assign_argmin2_kernel, dim3((nb + 255) / 256), dim3(256), 0, st, ws.gt.as<float>(), nb_pad, k, nb, best, g2);
+    hipLaunchKernelGGL(assign_argmin2_kernel, dim3((nb + kWave - 1) / kWave), dim3(kWave * kArgminWaves), 0, st, ws.gt.as<float>(), nb_pad, k, nb, best, g2);
     hipLaunchKernelGGL(assign_rescore_kernel, dim3((nb + 63) / 64), dim3(64), 0, st, X + i0 * ldx, ldx, C, ldc, d, ldq, cmax2_dev, best, g2,
                        nb, k, (uint32_t)i0, out_assign + i0, out_mind ? out_mind + i0 : nullptr, fb_list, fb_count, ws.status.as<uint32_t>());
     VERS_HIP_TRY(hipGetLastError());
