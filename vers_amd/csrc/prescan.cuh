@@ -411,7 +411,10 @@ __device__ __forceinline__ void prescan_item_g(const Src& src, const PreParams& 
   TileLoader L;
   L.init(v.rows, (uint64_t)n_tiles * kWave * p.ld * 4u, p.ld, lane);
   const float* xn_item = p.xnorm + src.storage_row(it);
-  constexpr int R = 2;  // ring of (tile, chunk) steps, 8 KiB each (a third slot spills: 256 registers per wave)
+#ifndef VERS_PRE_RING_G
+#define VERS_PRE_RING_G 2
+#endif
+  constexpr int R = VERS_PRE_RING_G;  // ring of (tile, chunk) steps, 8 KiB each
   u32x4 buf[R][kLoads];
   float xn[R];
   uint32_t gthr[R][2];
@@ -434,6 +437,7 @@ __device__ __forceinline__ void prescan_item_g(const Src& src, const PreParams& 
     else if (ti + 1 < t_end) { ci = 0; ++ti; }
   };
   issue_next(std::integral_constant<int, 0>{}, false);
+  if constexpr (R == 3) issue_next(std::integral_constant<int, 1>{}, false);
 
   bool live[2];
   uint32_t vseq[2] = {0, 0};
@@ -609,6 +613,7 @@ __device__ __forceinline__ void prescan_item_g(const Src& src, const PreParams& 
   for (uint32_t s0 = 0; s0 < n_steps; s0 += R) {
     step(std::integral_constant<int, 0>{}, s0);
     step(std::integral_constant<int, 1>{}, s0);
+    if constexpr (R == 3) step(std::integral_constant<int, 2>{}, s0);
   }
   const unsigned long long te0 = stamp ? __builtin_amdgcn_s_memtime() : 0ull;
   if (stamp && lane == 0) {
