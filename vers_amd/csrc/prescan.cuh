@@ -3,20 +3,22 @@
 // The reference's distance is an ordered f32 chain (scan.cuh); a matrix-core contraction cannot reproduce its
 // rounding, so -- exactly as in the coarse quantiser (gemm.cuh) -- it is used to PRE-SELECT and the result is
 // then made exact:
-//   (1) prescan_kernel: per work item (64-row tiles of one list segment x the <= 32 queries of one group)
+//   (1) prescan_kernel_g (default; prescan_kernel is the 4-wave variant): per block a quad of row segments of one
+//       list x the <= 32 queries of one group,
 //         val[r][n] = |x_r|^2 - 2 <x_r, q_n>          v_mfma_f32_16x16x1_4b_f32, lane == row operand layout
 //       which approximates D_ref(x_r, q_n) - |q_n|^2 within E (below).  Per query the kp = top_k + slack smallest
-//       (val, seq) keys of the item are kept (sorted lists in LDS); a threshold shared live between all items of a
-//       query (atomicMin in HBM, re-read every tile pair) makes list inserts rare after the first few tiles.
+//       (val, seq) keys are kept in ONE sorted list per block in LDS (per wave in the 4-wave variant); the list's
+//       last val is the threshold a tile's vals are compared with, shared live with the query's other blocks
+//       (atomicMin in HBM, re-read every tile), so that list inserts are rare after the first few tiles.
 //   (2) ivf_rescore_kernel: per query, merge the partial lists into the kp globally smallest approximate keys,
-//       recompute those kp distances in the reference's own arithmetic (lane per candidate, ordered chain), sort
-//       by the exact (distance, seq) key and emit the top_k.  CERTIFICATE: with tau_k the k-th smallest val,
-//       a member t of the true top-k has D_t <= (k-th smallest upper bound) <= tau_k + |q|^2 + E, hence
-//       val_t <= D_t - |q|^2 + E <= tau_k + 2E; every row outside the kp list has val >= val[kp-1].  So if
-//       val[kp-1] > tau_k + 2E (or the list is not full) the true top-k is inside the list and the output equals
-//       the exact scan bit for bit.
-//   (3) ivf_fallback_kernel: queries that fail the certificate (ties / near-ties denser than the slack, non-finite
-//       values) are re-scanned exactly by their own block.  Rare, and never wrong.
+//       recompute the distances of the survivors (below) in the reference's own arithmetic (lane per candidate,
+//       ordered chain), sort by the exact (distance, seq) key and emit the top_k.  CERTIFICATE: with tau_k the
+//       k-th smallest val, a member t of the true top-k has D_t <= (k-th smallest upper bound) <= tau_k + |q|^2 + E,
+//       hence val_t <= D_t - |q|^2 + E <= tau_k + 2E; every row outside the kp list has val >= val[kp-1].  So if
+//       val[kp-1] > tau_k + 2E (or the list is not full) the true top-k is inside the list -- more precisely among
+//       its entries with val <= tau_k + 2E, the survivors -- and the output equals the exact scan bit for bit.
+//   (3) fallback_scan_kernel + fallback_merge_kernel: queries that fail the certificate (ties / near-ties denser
+//       than the slack, non-finite values) are queued and re-scanned exactly.  Rare, and never wrong.
 //
 // E: |val + |q|^2 - D_ref| <= (5 d + 32) u (|q|^2 + max|x|^2), u = 2^-24, d = padded length -- the bound derived
 // in gemm.cuh with one more product in the chain (the |x|^2 term rides through the MFMA as an extra k step) and
