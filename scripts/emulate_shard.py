@@ -1,0 +1,31 @@
+"""What ONE rank of an N-GPU sharded search does per step, measured on one GPU: the full cfg3 index is built,
+only the lists LPT gives to rank R of W are kept (vers_ivf_set_shard), and search_partial_dev is timed for the
+full 1024-query batches.  No all-gather / merge (they need the other ranks): add ~0.1 ms for those.
+usage: python scripts/emulate_shard.py W [R]"""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+from tests import datagen as dg
+from vers_amd import capi
+from vers_amd.index import IVFFlatIndex
+W = int(sys.argv[1]); R = int(sys.argv[2]) if len(sys.argv) > 2 else 0
+n, d, nlist, nprobe, B, top_k = 10_000_000, 768, 4096, 32, 1024, 10
+dev = torch.device("cuda:0")
+X = torch.empty(n, d, dtype=torch.float32, device=dev)
+capi.gen_rows_dev(X.data_ptr(), n, d, d, 1, 0x5EED0001, 0x5EEDC0DE, 16 * nlist, float(dg.default_sigma(d)))
+init = (dg.mix64(np.uint64(0xB01D) + np.arange(nlist, dtype=np.uint64)) % np.uint64(n)).astype(np.uint64)
+ix = IVFFlatIndex(d, device=0)
+if W > 1: ix.set_shard(R, W)
+ix.build_dev(X.data_ptr(), n, nlist, 1, 4, init)
+del X
+Q = torch.empty(8 * B, d, dtype=torch.float32, device=dev)
+capi.gen_rows_dev(Q.data_ptr(), 8 * B, d, d, 1, 0x5EED0002, 0x5EEDC0DE, 16 * nlist, float(dg.default_sigma(d)))
+keys = torch.empty(B, top_k, dtype=torch.int64, device=dev); ids = torch.empty(B, top_k, dtype=torch.int64, device=dev)
+st = torch.cuda.current_stream().cuda_stream
+def step(i): ix.search_partial_dev(Q[(i % 8) * B:].data_ptr(), d, B, top_k, nprobe, keys.data_ptr(), ids.data_ptr(), st)
+for i in range(3): step(i)
+torch.cuda.synchronize(); ix.scan_times(reset=True); t0 = time.perf_counter()
+for i in range(20): step(3 + i)
+torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 20
+ix.poll(st)
+print(f"world={W} rank={R}: {dt*1e3:.3f} ms per step for this rank (list scan {float(np.mean(ix.scan_times()))*1e3:.0f} us)")
