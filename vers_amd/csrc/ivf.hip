@@ -633,6 +633,7 @@ struct vers_ivf {
   size_t io_pin_cap = 0;
   hipStream_t io_stream = nullptr;
   GroupTotals last_tot{};
+  const GroupTotals* tot_dev = nullptr;  // device totals of the last planned search
   bool tot_valid = false;
   std::mutex mu;
 };
@@ -1033,7 +1034,8 @@ int32_t launch_ivf_scan(vers_ivf* h, const IvfSrc<QG>& src, uint32_t items_bound
 }
 
 // the matrix-core list scan (prescan.cuh); timed through the same event ring as launch_ivf_scan
-int32_t launch_prescan(vers_ivf* h, const IvfSrc<kPreQ>& src, uint32_t items_bound, uint32_t kp, uint32_t* qflags, bool use_g, hipStream_t st) {
+int32_t launch_prescan(vers_ivf* h, const IvfSrc<kPreQ>& src, uint32_t items_bound, uint32_t kp, uint32_t* qflags, uint32_t* quad_ctr,
+                       bool use_g, hipStream_t st) {
   PreParams p;
   p.ld = h->ld;
   p.n_chunks = h->ld / kChunk;
@@ -1049,12 +1051,7 @@ int32_t launch_prescan(vers_ivf* h, const IvfSrc<kPreQ>& src, uint32_t items_bou
     VERS_HIP_TRY(hipMemsetAsync(h->stamps.p, 0, 128, st));
     p.stamps = h->stamps.as<unsigned long long>();
   }
-  p.next_quad = nullptr;
-  if (!(p.debug & 32u)) {
-    if (int32_t rc = h->quad_counter.reserve(16)) return rc;
-    VERS_HIP_TRY(hipMemsetAsync(h->quad_counter.p, 0, 16, st));
-    p.next_quad = h->quad_counter.as<uint32_t>();
-  }
+  p.next_quad = (p.debug & 32u) ? nullptr : quad_ctr;  // zeroed with the planning tables
   const size_t lds = use_g ? prescan_lds_bytes_g(h->ld, kp) : prescan_lds_bytes(h->ld, kp);
   if (int32_t rc = use_g ? scan_prepare_launch(prescan_kernel_g<IvfSrc<kPreQ>>, lds) : scan_prepare_launch(prescan_kernel<IvfSrc<kPreQ>>, lds)) return rc;
   uint32_t blocks = (items_bound + kWavesPerBlock - 1) / kWavesPerBlock;
@@ -1149,7 +1146,10 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
   const uint32_t k_l = h->k;
   // pj: list, pref, take per (q, j); np per q.   lists: cnt, fill | pair_off, group_off, item_off | totals
   if (int32_t rc = h->pj.reserve((3 * n_pj + b) * sizeof(uint32_t))) return rc;
-  if (int32_t rc = h->lists.reserve((6 * (size_t)k_l) * sizeof(uint32_t) + sizeof(GroupTotals) + 64)) return rc;
+  // one zero-initialised zone per batch (ONE memset): cnt, fill, hot per list | quad hand-out counter | queue of
+  // uncertified queries + its count | non-finite flags per (query, probe)
+  const size_t zero_words = 3 * (size_t)k_l + 4 + (use_pre ? (size_t)b + 4 + n_pj : 0);
+  if (int32_t rc = h->lists.reserve((zero_words + 3 * (size_t)k_l) * sizeof(uint32_t) + sizeof(GroupTotals) + 64)) return rc;
   if (int32_t rc = h->pairs.reserve(n_pj * sizeof(uint32_t))) return rc;
   if (int32_t rc = h->items.reserve(std::max<uint64_t>(1, items_bound) * sizeof(ItemDesc))) return rc;
   if (int32_t rc = h->groups.reserve(std::max<uint64_t>(1, groups_bound) * sizeof(GroupDesc))) return rc;
@@ -1164,11 +1164,15 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
   uint32_t* np = pj_take + n_pj;
   uint32_t* cnt = h->lists.as<uint32_t>();
   uint32_t* fill = cnt + k_l;
-  uint32_t* hot = fill + k_l;  // lists that are the nearest or second nearest list of some query: scanned first
-  uint32_t* pair_off = hot + k_l;
+  uint32_t* hot = fill + k_l;  // lists that are the nearest list of some query: scanned first
+  uint32_t* quad_ctr = hot + k_l;
+  uint32_t* fail_list = quad_ctr + 4;            // (matrix-core scan only)
+  uint32_t* qflags = fail_list + b + 4;
+  uint32_t* pair_off = cnt + zero_words;
   uint32_t* group_off = pair_off + k_l;
   uint32_t* item_off = group_off + k_l;
   GroupTotals* tot = (GroupTotals*)(((uintptr_t)(item_off + k_l) + 15) & ~(uintptr_t)15);
+  h->tot_dev = tot;
 
   VERS_HIP_TRY(hipMemsetAsync(h->partials.p, 0xFF, part_bytes, st));
   if (b == 1) {
@@ -1179,7 +1183,7 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
     VERS_HIP_TRY(hipGetLastError());
   } else {
   static const uint32_t hot_ranks = [] { const char* e = getenv("VERS_HOT_FIRST"); return e ? (uint32_t)atoi(e) : 1u; }();  // A/B knob
-  VERS_HIP_TRY(hipMemsetAsync(cnt, 0, 3 * (size_t)k_l * sizeof(uint32_t), st));
+  VERS_HIP_TRY(hipMemsetAsync(cnt, 0, zero_words * sizeof(uint32_t), st));
   hipLaunchKernelGGL(plan_kernel, dim3((b + 3) / 4), dim3(256), 0, st, h->probe.as<uint64_t>(), b, P, k_l, top_k, ref_mode,
                      h->list_len.as<uint32_t>(), h->world > 1 ? h->owner.as<uint8_t>() : (const uint8_t*)nullptr, h->rank, pj_list,
                      pj_pref, pj_take, np, cnt, hot, hot_ranks, h->status.as<uint32_t>());
@@ -1211,13 +1215,9 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
   int32_t rc;
   if (use_pre) {
     IvfSrc<kPreQ> src; fill_src(src);
-    // fail_list [b] + its count [1] (+3 pad) + qflags [n_pj]; partial lists of the exact re-scan
-    if (int32_t rc2 = h->qfail.reserve((b + 4 + n_pj) * sizeof(uint32_t))) return rc2;
+    // partial lists of the exact re-scan (fail_list [b] + its count, qflags [n_pj]: in the zeroed zone above)
     if (int32_t rc2 = h->fb_part.reserve((size_t)n_pj * kMergeWaves * top_k * sizeof(uint64_t))) return rc2;
-    VERS_HIP_TRY(hipMemsetAsync(h->qfail.p, 0, (b + 4 + n_pj) * sizeof(uint32_t), st));
-    uint32_t* fail_list = h->qfail.as<uint32_t>();
-    uint32_t* qflags = fail_list + b + 4;
-    if (int32_t rc2 = launch_prescan(h, src, (uint32_t)items_bound, kp, qflags, use_g, st)) return rc2;
+    if (int32_t rc2 = launch_prescan(h, src, (uint32_t)items_bound, kp, qflags, quad_ctr, use_g, st)) return rc2;
     RescoreArgs a;
     a.partials = h->partials.as<uint64_t>(); a.P = P; a.S_max = S_max; a.kp = kp; a.top_k = top_k; a.d_pad = h->ld;
     a.pj_list = pj_list; a.pj_pref = pj_pref; a.list_off = h->list_off.as<uint32_t>(); a.row_ids = h->row_ids.as<uint32_t>();
@@ -1710,8 +1710,8 @@ int32_t vers_ivf_last_scan(vers_ivf_t* h, float* out_ms, uint64_t* out_union_row
   const uint32_t slot = (uint32_t)((h->ev_count - 1) % vers_ivf::kEvRing);
   VERS_HIP_TRY(hipEventSynchronize(h->ev1[slot]));
   if (out_ms) VERS_HIP_TRY(hipEventElapsedTime(out_ms, h->ev0[slot], h->ev1[slot]));
-  const uint32_t* item_off_end = h->lists.as<uint32_t>() + 6 * (size_t)h->k;
-  const GroupTotals* tot = (const GroupTotals*)(((uintptr_t)item_off_end + 15) & ~(uintptr_t)15);
+  const GroupTotals* tot = h->tot_dev;
+  if (!tot) return fail(VERS_ERR_INVALID, "vers_ivf_last_scan: no list scan has run on this handle");
   GroupTotals t;
   VERS_HIP_TRY(hipMemcpy(&t, tot, sizeof(t), hipMemcpyDeviceToHost));
   if (out_union_rows) *out_union_rows = t.union_rows;
