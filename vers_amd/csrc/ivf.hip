@@ -119,7 +119,6 @@ struct IvfSrc {
   const float* qblocks;       // QG > 1: [group][ldq][QG]
   const float* qp;            // QG == 1: padded queries [b][ldq]
   uint32_t ldq, P, S_max, k_keep, seg_rows, seg_target;
-  uint32_t halves;            // partial slots per (pair, segment): the matrix-core scan may walk an item with two waves
   uint32_t bound_per_pair;    // reference mode merges per (query, list); nprobe mode per query
   const uint32_t* pj_pref;    // [b*P] sequence base of probe j of query q
   uint64_t* partials;         // [b*P*S_max][k_keep]
@@ -155,10 +154,10 @@ struct IvfSrc {
     return pj_pref[pairs[pair_off[d.list] + d.group * QG + qi]] + d.seg * list_seg_rows(list_len[d.list], seg_rows, seg_target);
   }
   __device__ __forceinline__ const uint32_t* seq_ids(uint32_t) const { return nullptr; }
-  __device__ __forceinline__ uint64_t* out(uint32_t it, int qi, int half = 0) const {  // S_max counts slots (segments * halves)
-    return partials + ((uint64_t)pair_of(it, qi) * S_max + items[it].seg * halves + half) * k_keep;
+  __device__ __forceinline__ uint64_t* out(uint32_t it, int qi) const {  // ordered-chain scan: S_max counts segments
+    return partials + ((uint64_t)pair_of(it, qi) * S_max + items[it].seg) * k_keep;
   }
-  // slot of a whole quad of segments (prescan_kernel_g: one list per query and block); S_max counts quads there
+  // slot of a whole quad of segments (matrix-core scan: one list per query and block); S_max counts quads there
   __device__ __forceinline__ uint64_t* out_quad(uint32_t it0, int qi) const {
     return partials + ((uint64_t)pair_of(it0, qi) * S_max + (items[it0].seg >> 2)) * k_keep;
   }
@@ -1035,7 +1034,7 @@ int32_t launch_ivf_scan(vers_ivf* h, const IvfSrc<QG>& src, uint32_t items_bound
 
 // the matrix-core list scan (prescan.cuh); timed through the same event ring as launch_ivf_scan
 int32_t launch_prescan(vers_ivf* h, const IvfSrc<kPreQ>& src, uint32_t items_bound, uint32_t kp, uint32_t* qflags, uint32_t* quad_ctr,
-                       bool use_g, hipStream_t st) {
+                       hipStream_t st) {
   PreParams p;
   p.ld = h->ld;
   p.n_chunks = h->ld / kChunk;
@@ -1052,8 +1051,8 @@ int32_t launch_prescan(vers_ivf* h, const IvfSrc<kPreQ>& src, uint32_t items_bou
     p.stamps = h->stamps.as<unsigned long long>();
   }
   p.next_quad = (p.debug & 32u) ? nullptr : quad_ctr;  // zeroed with the planning tables
-  const size_t lds = use_g ? prescan_lds_bytes_g(h->ld, kp) : prescan_lds_bytes(h->ld, kp);
-  if (int32_t rc = use_g ? scan_prepare_launch(prescan_kernel_g<IvfSrc<kPreQ>>, lds) : scan_prepare_launch(prescan_kernel<IvfSrc<kPreQ>>, lds)) return rc;
+  const size_t lds = prescan_lds_bytes_g(h->ld, kp);
+  if (int32_t rc = scan_prepare_launch(prescan_kernel_g<IvfSrc<kPreQ>>, lds)) return rc;
   uint32_t blocks = (items_bound + kWavesPerBlock - 1) / kWavesPerBlock;
   uint32_t per_cu = std::max<uint32_t>(1, std::min<uint32_t>(2, (uint32_t)((160u * 1024u) / lds)));  // 1 at d = 768 (measured: as fast as 2)
   if (const char* e = getenv("VERS_PRE_BLOCKS_PER_CU")) per_cu = std::max(1, atoi(e));  // tuning knob
@@ -1062,8 +1061,7 @@ int32_t launch_prescan(vers_ivf* h, const IvfSrc<kPreQ>& src, uint32_t items_bou
   if (blocks == 0) blocks = 1;
   const uint32_t slot = (uint32_t)(h->ev_count % vers_ivf::kEvRing);
   VERS_HIP_TRY(hipEventRecord(h->ev0[slot], st));
-  if (use_g) hipLaunchKernelGGL((prescan_kernel_g<IvfSrc<kPreQ>>), dim3(blocks), dim3(kWave * kPreWavesG), lds, st, src, p);
-  else hipLaunchKernelGGL((prescan_kernel<IvfSrc<kPreQ>>), dim3(blocks), dim3(kWave * kWavesPerBlock), lds, st, src, p);
+  hipLaunchKernelGGL((prescan_kernel_g<IvfSrc<kPreQ>>), dim3(blocks), dim3(kWave * kPreWavesG), lds, st, src, p);
   VERS_HIP_TRY(hipGetLastError());
   VERS_HIP_TRY(hipEventRecord(h->ev1[slot], st));
   h->ev_count += 1;
@@ -1106,9 +1104,8 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
   // slack of 10 keys: at cfg3 a slack of 6 left ~2 of 1024 queries uncertified per batch, 10 none
   uint32_t kp = std::min<uint32_t>(kPreMaxKp, std::max<uint32_t>(top_k + 10, top_k + top_k / 2));
   if (const char* e = getenv("VERS_PRE_SLACK")) kp = std::min<uint32_t>(kPreMaxKp, top_k + std::max(1, atoi(e)));  // tuning knob
-  static const bool pre_g = [] { const char* e = getenv("VERS_PRE_G"); return !e || atoi(e) != 0; }();  // 0: the 4-wave variant
-  const bool fits4 = prescan_lds_bytes(h->ld, kp) <= 160u * 1024u, fits8 = prescan_lds_bytes_g(h->ld, kp) <= 160u * 1024u;
-  const bool use_pre = QG != 1 && !ref_mode && pre_mode != 0 && top_k + 6 <= kPreMaxKp && (fits4 || fits8);
+  const bool use_pre = QG != 1 && !ref_mode && pre_mode != 0 && top_k + 6 <= kPreMaxKp &&
+                       prescan_lds_bytes_g(h->ld, kp) <= 160u * 1024u;  // the query block of 32 padded queries must fit LDS
   if (use_pre) QG = kPreQ;
   const uint32_t k_keep = use_pre ? kp : top_k;
   const uint64_t groups_bound = QG == 1 ? n_pj : (n_pj / QG + std::min<uint64_t>(h->k, n_pj));
@@ -1124,7 +1121,7 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
     // whole tile PAIRS (the batched kernel walks two tiles per step)
     seg_rows = (uint32_t)round_up64(std::max<uint64_t>(1, (avg_len + segs_wanted - 1) / segs_wanted), QG == 1 ? kWave : 2 * kWave);
   }
-  // matrix-core scan: an average list is one quad of items (per-item set-up and the 4-wave barrier amortise over
+  // matrix-core scan: an average list is one quad of items (per-item set-up and the block's barriers amortise over
   // ~10 tiles; measured at cfg3: 640-row targets beat 256- and 1024-row ones)
   if (use_pre) seg_rows = (uint32_t)round_up64(std::max<uint64_t>(256, (avg_len_all + 3) / 4), kWave);
   if (const char* e = getenv("VERS_SEG_ROWS")) seg_rows = (uint32_t)round_up64(std::max(64l, atol(e)), kWave);  // tuning knob
@@ -1133,13 +1130,10 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
   // VERS_SEG_BALANCED=0 switches them off
   static const bool seg_balanced = [] { const char* e = getenv("VERS_SEG_BALANCED"); return !e || atoi(e) != 0; }();
   const uint32_t seg_target = use_pre && seg_balanced ? seg_rows : 0u;
-  // variant of the matrix-core scan: two waves per item and block-wide lists (prescan_kernel_g) unless VERS_PRE_G=0
-  const bool use_g = use_pre && fits8 && (pre_g || !fits4);
-  const uint32_t pre_halves = 1u;
-  // segments per list at most; partial slots per (query, probe): one per segment, or one per QUAD of segments (use_g)
+  // segments per list at most; partial slots per (query, probe): one per segment, or one per QUAD of segments (matrix-core scan)
   const uint32_t S_seg = seg_target ? 4 * std::max<uint32_t>(1, (h->max_len + 4 * seg_target - 1) / (4 * seg_target))
                                     : std::max<uint32_t>(1, (h->max_len + seg_rows - 1) / seg_rows);
-  const uint32_t S_max = use_g ? (S_seg + 3) / 4 : S_seg;
+  const uint32_t S_max = use_pre ? (S_seg + 3) / 4 : S_seg;
   const uint64_t items_bound = groups_bound * (QG == 1 ? S_seg : round_up(S_seg, 4));
   if (items_bound > 0x7FFFFFFFull) return fail(VERS_ERR_INVALID, "search batch too large");
 
@@ -1209,7 +1203,6 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
     src.cnt = cnt; src.pair_off = pair_off; src.pairs = h->pairs.as<uint32_t>(); src.group_off = group_off;
     src.qblocks = h->qblocks.as<float>(); src.qp = qp; src.ldq = h->ldq; src.P = P; src.S_max = S_max; src.k_keep = k_keep;
     src.seg_rows = seg_rows; src.seg_target = seg_target; src.pj_pref = pj_pref; src.partials = h->partials.as<uint64_t>();
-    src.halves = pre_halves;
     src.bound_per_pair = ref_mode ? 1u : 0u;
   };
   int32_t rc;
@@ -1217,7 +1210,7 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
     IvfSrc<kPreQ> src; fill_src(src);
     // partial lists of the exact re-scan (fail_list [b] + its count, qflags [n_pj]: in the zeroed zone above)
     if (int32_t rc2 = h->fb_part.reserve((size_t)n_pj * kMergeWaves * top_k * sizeof(uint64_t))) return rc2;
-    if (int32_t rc2 = launch_prescan(h, src, (uint32_t)items_bound, kp, qflags, quad_ctr, use_g, st)) return rc2;
+    if (int32_t rc2 = launch_prescan(h, src, (uint32_t)items_bound, kp, qflags, quad_ctr, st)) return rc2;
     RescoreArgs a;
     a.partials = h->partials.as<uint64_t>(); a.P = P; a.S_max = S_max; a.kp = kp; a.top_k = top_k; a.d_pad = h->ld;
     a.pj_list = pj_list; a.pj_pref = pj_pref; a.list_off = h->list_off.as<uint32_t>(); a.row_ids = h->row_ids.as<uint32_t>();

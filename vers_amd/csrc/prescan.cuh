@@ -3,11 +3,11 @@
 // The reference's distance is an ordered f32 chain (scan.cuh); a matrix-core contraction cannot reproduce its
 // rounding, so -- exactly as in the coarse quantiser (gemm.cuh) -- it is used to PRE-SELECT and the result is
 // then made exact:
-//   (1) prescan_kernel_g (default; prescan_kernel is the 4-wave variant): per block a quad of row segments of one
+//   (1) prescan_kernel_g: per block a quad of row segments of one
 //       list x the <= 32 queries of one group,
 //         val[r][n] = |x_r|^2 - 2 <x_r, q_n>          v_mfma_f32_16x16x1_4b_f32, lane == row operand layout
 //       which approximates D_ref(x_r, q_n) - |q_n|^2 within E (below).  Per query the kp = top_k + slack smallest
-//       (val, seq) keys are kept in ONE sorted list per block in LDS (per wave in the 4-wave variant); the list's
+//       (val, seq) keys are kept in ONE sorted list per block in LDS; the list's
 //       last val is the threshold a tile's vals are compared with, shared live with the query's other blocks
 //       (atomicMin in HBM, re-read every tile), so that list inserts are rare after the first few tiles.
 //   (2) ivf_rescore_kernel: per query, merge the partial lists into the kp globally smallest approximate keys,
@@ -33,11 +33,6 @@ namespace vers {
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
 
 constexpr int kPreQ = 32;        // queries per group: two sets of 16 (one 16x16x1 4-block MFMA covers 64 rows x 16 queries)
-#ifndef VERS_PRE_RING
-#define VERS_PRE_RING 2
-#endif
-constexpr int kPreRing = VERS_PRE_RING;  // steps of 16 KiB in flight per wave (2 or 3; measured equal); one wave per SIMD
-static_assert(kPreRing == 2 || kPreRing == 3, "ring depth");
 #ifndef VERS_PRE_AUX
 #define VERS_PRE_AUX 2
 #endif
@@ -55,9 +50,6 @@ struct PreParams {
   unsigned long long* stamps;
 };
 
-inline size_t prescan_lds_bytes(uint32_t ld, uint32_t kp) {
-  return (size_t)ld * kPreQ * sizeof(float) + 16 + (size_t)kWavesPerBlock * kPreQ * kp * sizeof(uint64_t);
-}
 
 // |x|^2 of every storage row of the blocked matrix (thread per row: consecutive rows are consecutive float4s) and
 // the maximum over the rows that hold a vector.
@@ -76,319 +68,20 @@ static __global__ void blocked_row_norms_kernel(const float* rows, uint32_t ld, 
   if (row_ids[r] != 0xFFFFFFFFu && acc == acc) atomicMax(xmax2_bits, __float_as_uint(acc));  // acc >= 0: bit order == value order
 }
 
-// One work item of the matrix-core scan: two 64-row tiles per step against the group's query columns, in one or
-// two sets of 16 (the second set only when the group holds more than 16 queries: same row operands, so a list
-// probed by up to 32 queries is streamed once).
-// `stage` (block-wide: barrier, copy the quad's query block into LDS, barrier) is called exactly once, AFTER the
-// item's first tile loads are in flight: the CU's memory pipeline keeps streaming while the block stages.
-template <class Src, class Stage>
-__device__ __forceinline__ void prescan_item(const Src& src, const PreParams& p, uint32_t it, const ItemView<kPreQ>& v, int lane,
-                                             const float* qm, uint64_t* lists, Stage&& stage) {
-  if (v.nrows == 0) {  // padding item of the quad (wave-uniform): only the block-wide part
-    stage();
-    return;
-  }
-  const bool stage_first = (p.debug & 128u) != 0;  // A/B knob: stage before anything is in flight
-  if (stage_first) stage();
-  const int n = lane & 15, quarter = lane >> 4;
-  const uint32_t kp = p.kp;
-  const bool two = v.nq > 16;  // wave-uniform
-  const bool stamp = (p.debug & 16u) != 0;  // diagnosis: where do a wave's cycles go
-  const unsigned long long tp0 = stamp ? __builtin_amdgcn_s_memtime() : 0ull;
-  bool live[2];
-  uint32_t vseq[2] = {0, 0}, vslot[2] = {0, 0};
-  uint64_t vout[2] = {0, 0};
-  float thr[2];
-#pragma unroll
-  for (int s = 0; s < 2; ++s) {
-    live[s] = s * 16 + n < (int)v.nq;
-    thr[s] = -__builtin_inff();  // dead query columns never hit
-    if (live[s]) {
-      vseq[s] = src.seq_base(it, s * 16 + n);
-      vslot[s] = src.bound_slot(it, s * 16 + n);
-      const uint32_t b0 = __hip_atomic_load(p.bounds32 + vslot[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      thr[s] = b0 == 0xFFFFFFFFu ? __builtin_inff() : __uint_as_float(order_bits_to_f32_bits(b0));
-      if (lane < 16) vout[s] = (uint64_t)src.out(it, s * 16 + lane, 0);
-    }
-  }
-  for (uint32_t i = lane; i < kPreQ * kp; i += kWave) lists[i] = kKeyMax;
-
-  const uint32_t n_tiles = (v.nrows + kWave - 1) / kWave;
-  const uint32_t n_pairs = (n_tiles + 1) / 2;
-  const uint32_t last_tile = n_tiles ? n_tiles - 1 : 0;
-  TileLoader L;
-  L.init(v.rows, (uint64_t)n_tiles * kWave * p.ld * 4u, p.ld, lane);
-  const float* xn_item = p.xnorm + src.storage_row(it);
-  f32x16_t acc[2][2];  // [set][tile of the pair]
-#pragma unroll
-  for (int s = 0; s < 2; ++s)
-#pragma unroll
-    for (int e = 0; e < 16; ++e) acc[s][0][e] = acc[s][1][e] = 0.0f;
-  bool bad = false;
-
-  // insert one key into query nn's sorted LDS list (lane i = i-th key); lowers the threshold of nn's lanes and
-  // publishes the new kp-th val for the other items of the query
-  auto insert = [&](int nn, uint64_t key) {
-    uint64_t* Ln = lists + (uint32_t)nn * kp;
-    const uint64_t cur = lane < (int)kp ? Ln[lane] : kKeyMax;
-    const uint64_t kth = readlane64(cur, (int)kp - 1);
-    if (key < kth) {
-      const uint64_t prev = shift_up1_64(cur);
-      const uint64_t mx = prev > key ? prev : key;
-      const uint64_t nw = key < cur ? mx : cur;
-      if (lane < (int)kp) Ln[lane] = nw;
-      const uint64_t k2 = readlane64(nw, (int)kp - 1);
-      if (k2 != kKeyMax) {
-        const uint32_t kb = (uint32_t)(k2 >> 32);
-        const float nt = __uint_as_float(order_bits_to_f32_bits(kb));
-        if (n == (nn & 15)) {
-          if (nn < 16) thr[0] = nt < thr[0] ? nt : thr[0];
-          else thr[1] = nt < thr[1] ? nt : thr[1];
-        }
-        if (lane == (nn & 15)) atomicMin(p.bounds32 + (nn < 16 ? vslot[0] : vslot[1]), kb);
-      }
-    }
-  };
-
-  // end of a tile for query set S: acc already holds val (the |x|^2 term went through the matrix core); rows of
-  // a lane: 16*(e>>2) + 4*quarter + (e&3)
-  auto fold = [&](auto set_tag, f32x16_t& a, uint32_t t, bool tile_real) {
-    constexpr int S = decltype(set_tag)::value;
-    const uint32_t r0 = t * kWave + 4u * (uint32_t)quarter;
-    if (!tile_real || (t + 1) * kWave > v.nrows) {  // ragged tail (uniform branch): rows past the segment never hit
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const uint32_t row = r0 + 16u * (e >> 2) + (e & 3);
-        if (!tile_real || row >= v.nrows) a[e] = __builtin_nanf("");
-        else bad |= live[S] && !(__builtin_fabsf(a[e]) < __builtin_inff());
-      }
-    } else if (live[S]) {
-#pragma unroll
-      for (int e = 0; e < 16; ++e) bad |= !(__builtin_fabsf(a[e]) < __builtin_inff());
-    }
-    uint64_t any = 0;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) any |= __ballot(a[e] <= thr[S]);
-    if (any != 0 && !(p.debug & 1u)) {
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        uint64_t m = __ballot(a[e] <= thr[S]);
-        while (m) {
-          const int sl = __ffsll((unsigned long long)m) - 1;
-          m &= m - 1;
-          const float fv = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(a[e]), sl));
-          const uint32_t sq = (uint32_t)__builtin_amdgcn_readlane((int)vseq[S], sl) + t * kWave + 16u * (e >> 2) + 4u * ((uint32_t)sl >> 4) + (e & 3);
-          insert(S * 16 + (sl & 15), make_key(fv, sq));
-          m &= __ballot(a[e] <= thr[S]);  // the threshold may just have dropped
-        }
-      }
-    }
-#pragma unroll
-    for (int e = 0; e < 16; ++e) a[e] = 0.0f;
-  };
-  using Set0 = std::integral_constant<int, 0>;
-  using Set1 = std::integral_constant<int, 1>;
-
-  // Register ring of kPreRing (tile pair, chunk) steps; every load unconditional (see scan_item).  The ring also
-  // carries, per step, the pair's two |x|^2 operands (lane == row) and fresh copies of the shared thresholds.
-  // Ring slots are compile-time constants (integral_constant tags): a run-time slot index would put the ring
-  // in scratch memory.
-  u32x4 buf[kPreRing][2 * kLoads];
-  float xnA[kPreRing], xnB[kPreRing];
-  uint32_t gthr[kPreRing][2];
-  const uint32_t n_steps = n_pairs * p.n_chunks;
-  uint32_t pi = 0, ci = 0;
-  auto issue_next = [&](auto btag) {
-    constexpr int b = decltype(btag)::value;
-    const uint32_t tA = 2 * pi, tB = 2 * pi + 1 < n_tiles ? 2 * pi + 1 : last_tile;
-    gthr[b][0] = __hip_atomic_load(p.bounds32 + vslot[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    gthr[b][1] = __hip_atomic_load(p.bounds32 + vslot[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    xnA[b] = xn_item[tA * kWave + lane];
-    xnB[b] = xn_item[tB * kWave + lane];
-    const uint32_t soffA = tA * L.tile_bytes + ci * (kLoads * 1024u), soffB = tB * L.tile_bytes + ci * (kLoads * 1024u);
-#pragma unroll
-    for (int i = 0; i < kLoads; ++i) buf[b][i] = __builtin_amdgcn_raw_buffer_load_b128(L.rsrc, L.lane_off, soffA + (uint32_t)i * 1024u, kPreAux);
-#pragma unroll
-    for (int i = 0; i < kLoads; ++i) buf[b][kLoads + i] = __builtin_amdgcn_raw_buffer_load_b128(L.rsrc, L.lane_off, soffB + (uint32_t)i * 1024u, kPreAux);
-    if (ci + 1 < p.n_chunks) ++ci;
-    else if (pi + 1 < n_pairs) { ci = 0; ++pi; }
-  };
-  if (n_steps) {
-    issue_next(std::integral_constant<int, 0>{});
-    if constexpr (kPreRing == 3) issue_next(std::integral_constant<int, 1>{});
-  }
-  if (!stage_first) stage();
-  uint32_t pc = 0, cc = 0;
-  unsigned long long t_wait = 0, t_math = 0, t_fold = 0, t_issue = 0;
-  const unsigned long long tp1 = stamp ? __builtin_amdgcn_s_memtime() : 0ull;
-  auto step = [&](auto btag, uint32_t s0) {
-    constexpr int B = decltype(btag)::value;
-    const unsigned long long ti0 = stamp ? __builtin_amdgcn_s_memtime() : 0ull;
-    // (issuing the refill in one burst costs ~100 cycles per load once the chip is HBM-bound -- back-pressure, not
-    // work; spreading the loads between the MFMA groups was measured 5 % SLOWER: the stall then blocks the in-order
-    // MFMA stream as well)
-    issue_next(std::integral_constant<int, (B + kPreRing - 1) % kPreRing>{});
-    if (s0 + B < n_steps) {
-      unsigned long long t0 = 0, t1 = 0, t2 = 0;
-      if (stamp) {
-        t0 = __builtin_amdgcn_s_memtime();
-        t_issue += t0 - ti0;
-        __builtin_amdgcn_s_waitcnt(kPreRing == 2 ? (0x4F70 | 4) : (0x8F70 | 8));  // vmcnt(20 / 40): this step's loads have landed
-        t1 = __builtin_amdgcn_s_memtime();
-      }
-      if (!(p.debug & 2u)) {
-        // qm[((c4 * 2 + set) * 16 + n) * 4 + u] = (-2 q_{16 set + n})[4 c4 + u]
-        const f32x4* ql = reinterpret_cast<const f32x4*>(qm) + ((size_t)cc * kLoads * kPreQ + n);
-#pragma unroll
-        for (int i = 0; i < kLoads; ++i) {
-          const f32x4 q4 = ql[i * kPreQ];  // lanes of one query column read one address
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x1f32(__uint_as_float(buf[B][i][u]), q4[u], acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x1f32(__uint_as_float(buf[B][kLoads + i][u]), q4[u], acc[0][1], 0, 0, 0);
-          }
-        }
-        if (two) {
-#pragma unroll
-          for (int i = 0; i < kLoads; ++i) {
-            const f32x4 q4 = ql[i * kPreQ + 16];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-              acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x1f32(__uint_as_float(buf[B][i][u]), q4[u], acc[1][0], 0, 0, 0);
-              acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x1f32(__uint_as_float(buf[B][kLoads + i][u]), q4[u], acc[1][1], 0, 0, 0);
-            }
-          }
-        }
-      } else {
-        acc[0][0][0] += __uint_as_float(buf[B][0][0] ^ buf[B][2 * kLoads - 1][3]);
-      }
-      if (stamp) {
-        asm volatile("" ::"v"(acc[0][0][0]), "v"(acc[0][1][0]));
-        t2 = __builtin_amdgcn_s_memtime();
-        t_wait += t1 - t0;
-        t_math += t2 - t1;
-      }
-      if (++cc == p.n_chunks) {
-        cc = 0;
-        const bool b_real = 2 * pc + 1 < n_tiles;
-#pragma unroll
-        for (int s = 0; s < 2; ++s) {
-          if (live[s] && gthr[B][s] != 0xFFFFFFFFu) {
-            const float g = __uint_as_float(order_bits_to_f32_bits(gthr[B][s]));
-            thr[s] = g < thr[s] ? g : thr[s];
-          }
-        }
-        acc[0][0] = __builtin_amdgcn_mfma_f32_16x16x1f32(xnA[B], 1.0f, acc[0][0], 0, 0, 0);  // + |x_row|^2 for every query column
-        acc[0][1] = __builtin_amdgcn_mfma_f32_16x16x1f32(xnB[B], 1.0f, acc[0][1], 0, 0, 0);
-        fold(Set0{}, acc[0][0], 2 * pc, true);
-        fold(Set0{}, acc[0][1], 2 * pc + 1, b_real);
-        if (two) {
-          acc[1][0] = __builtin_amdgcn_mfma_f32_16x16x1f32(xnA[B], 1.0f, acc[1][0], 0, 0, 0);
-          acc[1][1] = __builtin_amdgcn_mfma_f32_16x16x1f32(xnB[B], 1.0f, acc[1][1], 0, 0, 0);
-          fold(Set1{}, acc[1][0], 2 * pc, true);
-          fold(Set1{}, acc[1][1], 2 * pc + 1, b_real);
-        }
-        ++pc;
-        if (stamp) t_fold += __builtin_amdgcn_s_memtime() - t2;
-      }
-    }
-  };
-  for (uint32_t s0 = 0; s0 < n_steps; s0 += kPreRing) {
-    step(std::integral_constant<int, 0>{}, s0);
-    step(std::integral_constant<int, 1>{}, s0);
-    if constexpr (kPreRing == 3) step(std::integral_constant<int, 2>{}, s0);
-  }
-  const unsigned long long te0 = stamp ? __builtin_amdgcn_s_memtime() : 0ull;
-  if (stamp && lane == 0) {
-    atomicAdd(p.stamps + 0, t_wait);
-    atomicAdd(p.stamps + 1, t_math);
-    atomicAdd(p.stamps + 2, t_fold);
-    atomicAdd(p.stamps + 4, 1ull);
-    atomicAdd(p.stamps + 8, t_issue);
-    atomicAdd(p.stamps + 9, tp1 - tp0);    // item prologue
-    atomicAdd(p.stamps + 10, te0 - tp1);   // whole step loop
-  }
-  if (bad) {  // a non-finite val in either set: both of this lane's queries go to the exact re-scan
-    if (live[0]) p.qflags[vslot[0]] = 1u;
-    if (live[1]) p.qflags[vslot[1]] = 1u;
-  }
-#pragma unroll
-  for (int qi = 0; qi < kPreQ; ++qi)
-    if (qi < (int)v.nq && lane < (int)kp)
-      reinterpret_cast<uint64_t*>(readlane64(qi < 16 ? vout[0] : vout[1], qi & 15))[lane] = lists[(uint32_t)qi * kp + lane];
-  if (stamp && lane == 0) atomicAdd(p.stamps + 11, __builtin_amdgcn_s_memtime() - te0);  // item epilogue
-}
-
-// Quads of items share one query block, staged once per quad into LDS in the MFMA operand layout
-// qm[((c4 * 2 + set) * 16 + n) * 4 + u] = -2 * q_{16 set + n}[4 c4 + u] (written so by gather_qblocks_kernel).
-template <class Src>
-__global__ __launch_bounds__(kWave * kWavesPerBlock) __attribute__((amdgpu_waves_per_eu(1, 1))) void prescan_kernel(Src src, PreParams p) {
-  static_assert(kWavesPerBlock == 4, "items are padded to quads");
-  const int lane = threadIdx.x & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  extern __shared__ __attribute__((aligned(16))) float qlds[];
-  uint32_t* nq_lds = reinterpret_cast<uint32_t*>(qlds + (size_t)p.ld * kPreQ);
-  uint64_t* lists = reinterpret_cast<uint64_t*>(qlds + (size_t)p.ld * kPreQ + 4) + (size_t)wid * kPreQ * p.kp;
-  const uint32_t n_quads = src.n_items() / 4;
-  const uint32_t n4 = p.ld * (kPreQ / 4);
-  const unsigned long long clk0 = (p.debug & 16u) ? __builtin_amdgcn_s_memtime() : 0ull;
-  const unsigned long long rt0 = (p.debug & 16u) ? __builtin_amdgcn_s_memrealtime() : 0ull;
-  for (uint32_t b0 = blockIdx.x;; b0 += gridDim.x) {
-    uint32_t bi = b0;
-    if (p.next_quad != nullptr) {
-      if (threadIdx.x == 0) *nq_lds = atomicAdd(p.next_quad, 1u);
-      __syncthreads();
-      bi = *nq_lds;
-    }
-    if (bi >= n_quads) break;
-    const uint32_t it = bi * 4 + wid;
-    ItemView<kPreQ> v;
-    src.get(it, v);  // v.qb / v.nq are the same for the four items of the quad
-    auto stage = [&]() {
-      const unsigned long long ts0 = (p.debug & 16u) ? __builtin_amdgcn_s_memtime() : 0ull;
-      __syncthreads();  // the previous quad's readers are done with the LDS block
-      const unsigned long long ts1 = (p.debug & 16u) ? __builtin_amdgcn_s_memtime() : 0ull;
-      // Gather straight from the padded queries (L2-resident): thread -> query slot n = i & 31 (fixed per thread),
-      // float4 column c4 = i >> 5; consecutive lanes write consecutive LDS float4s (conflict-free), the 16-byte
-      // global reads are uncoalesced but come out of L2 and are all independent.
-      f32x4* l4 = reinterpret_cast<f32x4*>(qlds);
-      const uint32_t slot = threadIdx.x & 31u;
-      const float* qrow = slot < v.nq ? src.query_row(it, slot) : nullptr;  // v.nq is the same for the quad's four items
-      if (v.nq > 16 || slot < 16) {
-        for (uint32_t i = threadIdx.x; i < n4; i += kWave * kWavesPerBlock) {
-          f32x4 x = {0.0f, 0.0f, 0.0f, 0.0f};
-          if (qrow != nullptr) x = *reinterpret_cast<const f32x4*>(qrow + 4 * (i >> 5));
-          l4[i] = -2.0f * x;  // exact scaling; the matrix core then yields -2 <x, q> directly
-        }
-      }
-      __syncthreads();
-      if ((p.debug & 16u) && lane == 0) {
-        atomicAdd(p.stamps + 3, __builtin_amdgcn_s_memtime() - ts1);  // staging the query block
-        atomicAdd(p.stamps + 5, ts1 - ts0);                           // waiting for the quad's slowest wave
-        atomicAdd(p.stamps + 6, 1ull);
-      }
-    };
-    prescan_item(src, p, it, v, lane, qlds, lists, stage);
-  }
-  if ((p.debug & 16u) && blockIdx.x == 0 && threadIdx.x == 0)
-    p.stamps[7] = ((__builtin_amdgcn_s_memtime() - clk0) << 20) / ((__builtin_amdgcn_s_memrealtime() - rt0) | 1ull);
-}
-
-// ---- variant: two waves per item, eight per block ---------------------------------------------------
-// Same algorithm, other occupancy: the block still owns a quad of items and ONE query block in LDS, but every
-// item is walked by a pair of waves (first / second half of its tiles, one tile per step), so each SIMD holds
-// two waves (<= 256 registers each).  While one wave of a SIMD sits in the back-pressure of an HBM-bound load
-// burst the other issues its MFMAs -- with a single wave per SIMD those two phases add up (stamps: a third of
-// the step loop was load issue).
-// The eight waves of a block work on ONE list segment quad against the same queries, so they also share ONE
-// sorted list per query in LDS (a spin lock per query, taken for the ~50 instructions of an insert): the list
-// sees ~2400 rows instead of an item half's ~220, fills at once, and its last val -- the threshold every wave
-// re-reads per tile and the value published to the other blocks of the query -- is close to the query's global
-// one.  (With a list per wave the shared threshold stalled near "the kp-th of the best 220 rows": ~900 inserts
-// per query and batch instead of the ~170 a perfectly shared threshold needs; inserts were 0.38 ms of 5.3 ms.)
-// It also shrinks the partial slots to one per (query, list, quad): 8x fewer keys for the exact finish to merge.
-constexpr int kPreHalves = 2;
-constexpr int kPreWavesG = 4 * kPreHalves;
+// ---- the scan kernel: a quad of row segments x one query block per block of eight waves ----------------
+// The block owns a quad of row segments of one list and ONE query block in LDS (<= 32 queries as two sets of 16:
+// the second set only when the group holds more than 16 queries -- same row operands, so a list probed by up to
+// 32 queries is streamed once).  Every segment is walked by a pair of waves (first / second half of its tiles, one
+// 64-row tile x 32 columns per step), so each SIMD holds two waves (<= 256 registers each): while one wave sits in
+// the back-pressure of an HBM-bound load burst (~100 cycles per load) the other issues its MFMAs -- with one wave
+// per SIMD those phases add up (measured 5.80 vs 5.34 ms; that 4-wave variant is in the history of this file).
+// The eight waves also share ONE sorted list per query in LDS (a spin lock per query, taken for the ~50
+// instructions of an insert): the list sees ~2400 rows instead of an item half's ~220, fills at once, and its last
+// val -- the threshold every wave re-reads per tile and the value published to the other blocks of the query -- is
+// close to the query's global one.  (With a list per wave the shared threshold stalled near "the kp-th of the best
+// 220 rows": ~900 inserts per query and batch instead of the ~170 a perfectly shared threshold needs; inserts
+// were 0.38 ms of 5.3 ms.)  One partial slot per (query, list, quad) goes to the exact finish.
+constexpr int kPreWavesG = 8;  // 4 items x 2 waves
 inline size_t prescan_lds_bytes_g(uint32_t ld, uint32_t kp) {  // query block | hand-out word | lists | locks | 64-float scratch per wave
   return (size_t)ld * kPreQ * sizeof(float) + 16 + (size_t)kPreQ * kp * sizeof(uint64_t) + kPreQ * sizeof(uint32_t) +
          (size_t)kPreWavesG * kWave * sizeof(float);
@@ -485,7 +178,10 @@ __device__ __forceinline__ void prescan_item_g(const Src& src, const PreParams& 
     }
   };
   auto insert = [&](int nn, uint64_t key) { merge_into(nn, lane == 0 ? key : kKeyMax); };
-  auto fold = [&](auto set_tag, f32x16_t& a, uint32_t t) {  // see prescan_item
+  // End of a tile for query set S: acc already holds val (the |x|^2 term went through the matrix core).  Each lane holds
+  // 16 vals of ONE query column (lane & 15), rows 16*(e>>2) + 4*quarter + (e&3): one compare per register against the
+  // lane's threshold decides whether anything happens at all.
+  auto fold = [&](auto set_tag, f32x16_t& a, uint32_t t) {
     constexpr int S = decltype(set_tag)::value;
     const uint32_t r0 = t * kWave + 4u * (uint32_t)quarter;
     if ((t + 1) * kWave > v.nrows) {
