@@ -414,19 +414,17 @@ __global__ __launch_bounds__(kWave * kMergeWaves) void plan1_kernel(
 }
 
 // interleaved query block of every group: qblocks[(g*ldq + col)*QG + qi]
-// mfma != 0 (QG == 32): the matrix-core operand layout of prescan.cuh, per group
-// [((c4 * 2 + set) * 16 + n) * 4 + u] = -2 * q_{16 set + n}[4 c4 + u] (the scaling is exact)
+// (ordered-chain batched scans only: the matrix-core scan gathers its query block from qp while staging it)
 __global__ void gather_qblocks_kernel(const GroupDesc* groups, const GroupTotals* tot, const uint32_t* pairs, uint32_t P,
-                                      const float* qp, uint32_t ldq, uint32_t QG, int mfma, float* qblocks) {
+                                      const float* qp, uint32_t ldq, uint32_t QG, float* qblocks) {
   const uint32_t g = blockIdx.x;
   if (g >= tot->n_groups) return;
   const GroupDesc gd = groups[g];
   for (uint32_t i = threadIdx.x; i < ldq * QG; i += blockDim.x) {
-    const uint32_t qi = mfma ? (i >> 2) & 31u : i % QG;
-    const uint32_t col = mfma ? ((i >> 7) << 2) + (i & 3u) : i / QG;
+    const uint32_t qi = i % QG, col = i / QG;
     float v = 0.0f;
     if (qi < gd.nq) v = qp[(uint64_t)(pairs[gd.pair_start + qi] / P) * ldq + col];
-    qblocks[(uint64_t)g * ldq * QG + i] = mfma ? -2.0f * v : v;
+    qblocks[(uint64_t)g * ldq * QG + i] = v;
   }
 }
 
@@ -618,7 +616,7 @@ struct vers_ivf {
   KMeansScratch km;
   DevBuf seg_bounds, stamps, quad_counter;
   // matrix-core list scan (prescan.cuh): |x|^2 per storage row, [0] max |x|^2 bits, [1] certificate failures (running)
-  DevBuf xnorm, pre_misc, qfail, fb_part;
+  DevBuf xnorm, pre_misc, fb_part;
   uint64_t pre_batches = 0;
   DevBuf qp, qil, cpart, probe, pj, lists, pairs, items, groups, qblocks, partials, status, o_ids, o_dist, o_cnt, xpart;
   static constexpr uint32_t kEvRing = 64;  // scan-launch timing ring (measurement hook)
@@ -1193,7 +1191,7 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
   VERS_HIP_TRY(hipGetLastError());
   if (QG != 1 && !use_pre) {  // (the matrix-core scan gathers its query block from qp while staging it)
     hipLaunchKernelGGL(gather_qblocks_kernel, dim3((unsigned)groups_bound), dim3(256), 0, st, h->groups.as<GroupDesc>(), tot,
-                       h->pairs.as<uint32_t>(), P, qp, h->ldq, (uint32_t)QG, use_pre ? 1 : 0, h->qblocks.as<float>());
+                       h->pairs.as<uint32_t>(), P, qp, h->ldq, (uint32_t)QG, h->qblocks.as<float>());
     VERS_HIP_TRY(hipGetLastError());
   }
   }  // b > 1
