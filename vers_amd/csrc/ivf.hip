@@ -617,6 +617,7 @@ struct vers_ivf {
   DevBuf seg_bounds, stamps, quad_counter;
   // matrix-core list scan (prescan.cuh): |x|^2 per storage row, [0] max |x|^2 bits, [1] certificate failures (running)
   DevBuf xnorm, pre_misc, fb_part;
+  DevBuf rows_bf;  // experimental (VERS_SHADOW=1): bf16 shadow of the rows for the matrix-core pre-selection (+50 % memory)
   uint64_t pre_batches = 0;
   DevBuf qp, qil, cpart, probe, pj, lists, pairs, items, groups, qblocks, partials, status, o_ids, o_dist, o_cnt, xpart;
   static constexpr uint32_t kEvRing = 64;  // scan-launch timing ring (measurement hook)
@@ -666,6 +667,17 @@ int32_t refresh_norms(vers_ivf* h, uint64_t r_begin, uint64_t r_end, hipStream_t
   if (full) {
     if (int32_t rc = h->xnorm.reserve((h->cap_rows ? h->cap_rows : 1) * sizeof(float))) return rc;
     VERS_HIP_TRY(hipMemsetAsync(h->pre_misc.p, 0, 64, st));
+  }
+  static const bool shadow = [] { const char* e = getenv("VERS_SHADOW"); return e && atoi(e) != 0; }();
+  if (shadow) {
+    if (full)
+      if (int32_t rc = h->rows_bf.reserve((h->cap_rows ? h->cap_rows : 1) * (size_t)h->ld * sizeof(uint16_t))) return rc;
+    if (r_end > r_begin && h->rows_bf.p) {
+      const uint64_t work = (r_end - r_begin) * (h->ld / 8);
+      hipLaunchKernelGGL(rows_to_bf16_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, st, h->rows.as<float>(), h->ld, r_begin, r_end,
+                         h->rows_bf.as<uint16_t>());
+      VERS_HIP_TRY(hipGetLastError());
+    }
   }
   if (r_end > r_begin) {
     hipLaunchKernelGGL(blocked_row_norms_kernel, dim3((unsigned)((r_end - r_begin + 255) / 256)), dim3(256), 0, st, h->rows.as<float>(), h->ld,
@@ -1032,8 +1044,9 @@ int32_t launch_ivf_scan(vers_ivf* h, const IvfSrc<QG>& src, uint32_t items_bound
 
 // the matrix-core list scan (prescan.cuh); timed through the same event ring as launch_ivf_scan
 int32_t launch_prescan(vers_ivf* h, const IvfSrc<kPreQ>& src, uint32_t items_bound, uint32_t kp, uint32_t* qflags, uint32_t* quad_ctr,
-                       hipStream_t st) {
+                       bool shadow, hipStream_t st) {
   PreParams p;
+  p.rows_bf = shadow ? h->rows_bf.as<uint16_t>() : nullptr;
   p.ld = h->ld;
   p.n_chunks = h->ld / kChunk;
   p.kp = kp;
@@ -1050,7 +1063,7 @@ int32_t launch_prescan(vers_ivf* h, const IvfSrc<kPreQ>& src, uint32_t items_bou
   }
   p.next_quad = (p.debug & 32u) ? nullptr : quad_ctr;  // zeroed with the planning tables
   const size_t lds = prescan_lds_bytes_g(h->ld, kp);
-  if (int32_t rc = scan_prepare_launch(prescan_kernel_g<IvfSrc<kPreQ>>, lds)) return rc;
+  if (int32_t rc = shadow ? scan_prepare_launch(prescan_kernel_g<true, IvfSrc<kPreQ>>, lds) : scan_prepare_launch(prescan_kernel_g<false, IvfSrc<kPreQ>>, lds)) return rc;
   uint32_t blocks = (items_bound + kWavesPerBlock - 1) / kWavesPerBlock;
   uint32_t per_cu = std::max<uint32_t>(1, std::min<uint32_t>(2, (uint32_t)((160u * 1024u) / lds)));  // 1 at d = 768 (measured: as fast as 2)
   if (const char* e = getenv("VERS_PRE_BLOCKS_PER_CU")) per_cu = std::max(1, atoi(e));  // tuning knob
@@ -1059,7 +1072,8 @@ int32_t launch_prescan(vers_ivf* h, const IvfSrc<kPreQ>& src, uint32_t items_bou
   if (blocks == 0) blocks = 1;
   const uint32_t slot = (uint32_t)(h->ev_count % vers_ivf::kEvRing);
   VERS_HIP_TRY(hipEventRecord(h->ev0[slot], st));
-  hipLaunchKernelGGL((prescan_kernel_g<IvfSrc<kPreQ>>), dim3(blocks), dim3(kWave * kPreWavesG), lds, st, src, p);
+  if (shadow) hipLaunchKernelGGL((prescan_kernel_g<true, IvfSrc<kPreQ>>), dim3(blocks), dim3(kWave * kPreWavesG), lds, st, src, p);
+  else hipLaunchKernelGGL((prescan_kernel_g<false, IvfSrc<kPreQ>>), dim3(blocks), dim3(kWave * kPreWavesG), lds, st, src, p);
   VERS_HIP_TRY(hipGetLastError());
   VERS_HIP_TRY(hipEventRecord(h->ev1[slot], st));
   h->ev_count += 1;
@@ -1101,6 +1115,9 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
   static const int pre_mode = [] { const char* e = getenv("VERS_PRESCAN"); return e ? atoi(e) : 1; }();
   // slack of 10 keys: at cfg3 a slack of 6 left ~2 of 1024 queries uncertified per batch, 10 none
   uint32_t kp = std::min<uint32_t>(kPreMaxKp, std::max<uint32_t>(top_k + 10, top_k + top_k / 2));
+  // bf16 shadow rows (experimental): the certificate window is ~9x wider, measured <= 33 rows inside it at top_k = 10
+  const bool use_shadow = h->rows_bf.p != nullptr && h->rows_bf.cap >= h->cap_rows * (size_t)h->ld * sizeof(uint16_t);
+  if (use_shadow) kp = std::min<uint32_t>(kPreMaxKp, top_k + 38);
   if (const char* e = getenv("VERS_PRE_SLACK")) kp = std::min<uint32_t>(kPreMaxKp, top_k + std::max(1, atoi(e)));  // tuning knob
   const bool use_pre = QG != 1 && !ref_mode && pre_mode != 0 && top_k + 6 <= kPreMaxKp &&
                        prescan_lds_bytes_g(h->ld, kp) <= 160u * 1024u;  // the query block of 32 padded queries must fit LDS
@@ -1208,12 +1225,12 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
     IvfSrc<kPreQ> src; fill_src(src);
     // partial lists of the exact re-scan (fail_list [b] + its count, qflags [n_pj]: in the zeroed zone above)
     if (int32_t rc2 = h->fb_part.reserve((size_t)n_pj * kMergeWaves * top_k * sizeof(uint64_t))) return rc2;
-    if (int32_t rc2 = launch_prescan(h, src, (uint32_t)items_bound, kp, qflags, quad_ctr, st)) return rc2;
+    if (int32_t rc2 = launch_prescan(h, src, (uint32_t)items_bound, kp, qflags, quad_ctr, use_shadow, st)) return rc2;
     RescoreArgs a;
     a.partials = h->partials.as<uint64_t>(); a.P = P; a.S_max = S_max; a.kp = kp; a.top_k = top_k; a.d_pad = h->ld;
     a.pj_list = pj_list; a.pj_pref = pj_pref; a.list_off = h->list_off.as<uint32_t>(); a.row_ids = h->row_ids.as<uint32_t>();
     a.rows = h->rows.as<float>(); a.ld = h->ld; a.qp = qp; a.ldq = h->ldq; a.xmax2_bits = h->pre_misc.as<uint32_t>();
-    a.qflags = qflags; a.force_fail = pre_mode == 2; a.debug = scan_debug_flags(); a.fail_list = fail_list; a.stats = h->pre_misc.as<uint32_t>() + 1;
+    a.qflags = qflags; a.force_fail = pre_mode == 2; a.shadow = use_shadow ? 1 : 0; a.debug = scan_debug_flags(); a.fail_list = fail_list; a.stats = h->pre_misc.as<uint32_t>() + 1;
     a.status = h->status.as<uint32_t>(); a.out_ids = out_ids; a.out_dist = out_dist; a.out_count = out_count; a.out_keys = out_keys;
     const int stage_rows = rescore_lds_bytes(h->ld, true) <= 144u * 1024u ? 1 : 0;
     const size_t rs_lds = rescore_lds_bytes(h->ld, stage_rows != 0);

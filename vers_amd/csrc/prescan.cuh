@@ -46,10 +46,35 @@ struct PreParams {
   uint32_t* qflags;     // per merge group: != 0 -> a non-finite val was seen, the query must be re-done exactly
   uint32_t* next_quad;
   const float* xnorm;   // |x|^2 per storage row
+  const uint16_t* rows_bf;  // BF16 shadow of the rows (experimental, VERS_SHADOW=1): tiles of 64 rows x 8 columns per 1 KiB
   uint32_t debug;
   unsigned long long* stamps;
 };
 
+
+// f32 tiles -> bf16 shadow tiles (round to nearest even): element (r, c) of a 64-row tile moves from
+// ((c/4)*64 + r)*4 + c%4 (floats) to ((c/8)*64 + r)*8 + c%8 (bf16).  Thread = (row, group of 8 columns).
+static __global__ void rows_to_bf16_kernel(const float* rows, uint32_t ld, uint64_t r_begin, uint64_t r_end, uint16_t* rows_bf) {
+  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint32_t g8 = ld / 8;
+  const uint64_t r = r_begin + t / g8;
+  const uint32_t j = (uint32_t)(t % g8);
+  if (r >= r_end) return;
+  const float* src = rows + (r >> 6) * 64ull * ld;
+  uint16_t out[8];
+#pragma unroll
+  for (int h = 0; h < 2; ++h) {
+    const f32x4 x = *reinterpret_cast<const f32x4*>(src + ((uint64_t)(2 * j + h) * 64 + (r & 63)) * 4);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const uint32_t b = __float_as_uint(x[u]);
+      out[4 * h + u] = (uint16_t)((b + 0x7FFFu + ((b >> 16) & 1u)) >> 16);  // RNE (NaN / inf rows are flagged by the non-finite check anyway)
+    }
+  }
+  uint16_t* dst = rows_bf + (r >> 6) * 64ull * ld + ((uint64_t)j * 64 + (r & 63)) * 8;
+  *reinterpret_cast<u32x4*>(dst) = u32x4{(uint32_t)out[0] | ((uint32_t)out[1] << 16), (uint32_t)out[2] | ((uint32_t)out[3] << 16),
+                                         (uint32_t)out[4] | ((uint32_t)out[5] << 16), (uint32_t)out[6] | ((uint32_t)out[7] << 16)};
+}
 
 // |x|^2 of every storage row of the blocked matrix (thread per row: consecutive rows are consecutive float4s) and
 // the maximum over the rows that hold a vector.
@@ -87,7 +112,9 @@ inline size_t prescan_lds_bytes_g(uint32_t ld, uint32_t kp) {  // query block | 
          (size_t)kPreWavesG * kWave * sizeof(float);
 }
 
-template <class Src, class Stage>
+// BF: the row operand comes from the bf16 shadow copy (half the HBM bytes): a float4 load brings 8 columns of the
+// lane's row, expanded to f32 in the VALU (shift / mask) for the same f32 MFMA; the query operand stays f32.
+template <bool BF, class Src, class Stage>
 __device__ __forceinline__ void prescan_item_g(const Src& src, const PreParams& p, uint32_t it, const ItemView<kPreQ>& v, int half, int lane,
                                                const float* qm, uint64_t* blk, uint32_t* locks, float* scratch, Stage&& stage) {
   const uint32_t n_tiles = (v.nrows + kWave - 1) / kWave;
@@ -104,7 +131,13 @@ __device__ __forceinline__ void prescan_item_g(const Src& src, const PreParams& 
   const unsigned long long tp0 = stamp ? __builtin_amdgcn_s_memtime() : 0ull;
   // the first tile loads go out before anything else: they fly while the item is set up and the block stages
   TileLoader L;
-  L.init(v.rows, (uint64_t)n_tiles * kWave * p.ld * 4u, p.ld, lane);
+  if (BF) {
+    L.init(reinterpret_cast<const float*>(p.rows_bf + (uint64_t)src.storage_row(it) * p.ld), (uint64_t)n_tiles * kWave * p.ld * 2u, p.ld, lane);
+    L.tile_bytes = p.ld * 128u;
+  } else {
+    L.init(v.rows, (uint64_t)n_tiles * kWave * p.ld * 4u, p.ld, lane);
+  }
+  const uint32_t nch = BF ? p.ld / 64u : p.n_chunks;  // steps per tile: 8 loads = 64 bf16 columns or 32 f32 columns
   const float* xn_item = p.xnorm + src.storage_row(it);
 #ifndef VERS_PRE_RING_G
 #define VERS_PRE_RING_G 2
@@ -113,7 +146,7 @@ __device__ __forceinline__ void prescan_item_g(const Src& src, const PreParams& 
   u32x4 buf[R][kLoads];
   float xn[R];
   uint32_t gthr[R][2];
-  const uint32_t n_steps = (t_end - t_begin) * p.n_chunks;
+  const uint32_t n_steps = (t_end - t_begin) * nch;
   uint32_t ti = t_begin, ci = 0;
   uint32_t vslot[2] = {0, 0};
   auto issue_next = [&](auto btag, bool with_thr) {
@@ -128,7 +161,7 @@ __device__ __forceinline__ void prescan_item_g(const Src& src, const PreParams& 
     const uint32_t soff = ti * L.tile_bytes + ci * (kLoads * 1024u);
 #pragma unroll
     for (int i = 0; i < kLoads; ++i) buf[b][i] = __builtin_amdgcn_raw_buffer_load_b128(L.rsrc, L.lane_off, soff + (uint32_t)i * 1024u, kPreAux);
-    if (ci + 1 < p.n_chunks) ++ci;
+    if (ci + 1 < nch) ++ci;
     else if (ti + 1 < t_end) { ci = 0; ++ti; }
   };
   issue_next(std::integral_constant<int, 0>{}, false);
@@ -256,19 +289,44 @@ __device__ __forceinline__ void prescan_item_g(const Src& src, const PreParams& 
       unsigned long long t1 = 0, t2 = 0;
       if (stamp) { t1 = __builtin_amdgcn_s_memtime(); t_issue += t1 - ti0; }
       if (!(p.debug & 2u)) {
-        const f32x4* ql = reinterpret_cast<const f32x4*>(qm) + ((size_t)cc * kLoads * kPreQ + n);
-#pragma unroll
-        for (int i = 0; i < kLoads; ++i) {
-          const f32x4 q4 = ql[i * kPreQ];
-#pragma unroll
-          for (int u = 0; u < 4; ++u) acc[0] = __builtin_amdgcn_mfma_f32_16x16x1f32(__uint_as_float(buf[B][i][u]), q4[u], acc[0], 0, 0, 0);
-        }
-        if (two) {
+        if constexpr (!BF) {
+          const f32x4* ql = reinterpret_cast<const f32x4*>(qm) + ((size_t)cc * kLoads * kPreQ + n);
 #pragma unroll
           for (int i = 0; i < kLoads; ++i) {
-            const f32x4 q4 = ql[i * kPreQ + 16];
+            const f32x4 q4 = ql[i * kPreQ];
 #pragma unroll
-            for (int u = 0; u < 4; ++u) acc[1] = __builtin_amdgcn_mfma_f32_16x16x1f32(__uint_as_float(buf[B][i][u]), q4[u], acc[1], 0, 0, 0);
+            for (int u = 0; u < 4; ++u) acc[0] = __builtin_amdgcn_mfma_f32_16x16x1f32(__uint_as_float(buf[B][i][u]), q4[u], acc[0], 0, 0, 0);
+          }
+          if (two) {
+#pragma unroll
+            for (int i = 0; i < kLoads; ++i) {
+              const f32x4 q4 = ql[i * kPreQ + 16];
+#pragma unroll
+              for (int u = 0; u < 4; ++u) acc[1] = __builtin_amdgcn_mfma_f32_16x16x1f32(__uint_as_float(buf[B][i][u]), q4[u], acc[1], 0, 0, 0);
+            }
+          }
+        } else {
+          const f32x4* ql = reinterpret_cast<const f32x4*>(qm) + ((size_t)cc * 2 * kLoads * kPreQ + n);  // 16 float4 columns per step
+#pragma unroll
+          for (int i = 0; i < kLoads; ++i) {
+            float xe[8];  // the load's 8 columns, bf16 -> f32
+#pragma unroll
+            for (int w = 0; w < 4; ++w) {
+              xe[2 * w] = __uint_as_float(buf[B][i][w] << 16);
+              xe[2 * w + 1] = __uint_as_float(buf[B][i][w] & 0xFFFF0000u);
+            }
+            const f32x4 qa = ql[(2 * i) * kPreQ], qb = ql[(2 * i + 1) * kPreQ];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc[0] = __builtin_amdgcn_mfma_f32_16x16x1f32(xe[u], qa[u], acc[0], 0, 0, 0);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc[0] = __builtin_amdgcn_mfma_f32_16x16x1f32(xe[4 + u], qb[u], acc[0], 0, 0, 0);
+            if (two) {
+              const f32x4 qc = ql[(2 * i) * kPreQ + 16], qd = ql[(2 * i + 1) * kPreQ + 16];
+#pragma unroll
+              for (int u = 0; u < 4; ++u) acc[1] = __builtin_amdgcn_mfma_f32_16x16x1f32(xe[u], qc[u], acc[1], 0, 0, 0);
+#pragma unroll
+              for (int u = 0; u < 4; ++u) acc[1] = __builtin_amdgcn_mfma_f32_16x16x1f32(xe[4 + u], qd[u], acc[1], 0, 0, 0);
+            }
           }
         }
       } else {
@@ -279,7 +337,7 @@ __device__ __forceinline__ void prescan_item_g(const Src& src, const PreParams& 
         t2 = __builtin_amdgcn_s_memtime();
         t_math += t2 - t1;
       }
-      if (++cc == p.n_chunks) {
+      if (++cc == nch) {
         cc = 0;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
@@ -329,7 +387,7 @@ __device__ __forceinline__ void prescan_item_g(const Src& src, const PreParams& 
   if (stamp && lane == 0) atomicAdd(p.stamps + 11, __builtin_amdgcn_s_memtime() - te0);
 }
 
-template <class Src>
+template <bool BF, class Src>
 __global__ __launch_bounds__(kWave * kPreWavesG) __attribute__((amdgpu_waves_per_eu(2, 2))) void prescan_kernel_g(Src src, PreParams p) {
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -386,7 +444,7 @@ __global__ __launch_bounds__(kWave * kPreWavesG) __attribute__((amdgpu_waves_per
         atomicAdd(p.stamps + 6, 1ull);
       }
     };
-    prescan_item_g(src, p, it, v, wid >> 2, lane, qlds, blk, locks, scratch, stage);
+    prescan_item_g<BF>(src, p, it, v, wid >> 2, lane, qlds, blk, locks, scratch, stage);
     prev_it0 = bi * 4;
     prev_nq = v.nq;
   }
@@ -411,6 +469,7 @@ struct RescoreArgs {
   const uint32_t* xmax2_bits;
   const uint32_t* qflags;  // [b*P], slot q*P
   int force_fail;          // testing: nothing certifies
+  int shadow;              // the vals came from the bf16 shadow: the bound grows by 2^-8 |x||q|
   uint32_t debug;          // diagnosis (VERS_SCAN_DEBUG): 512 skip the row gather + chains, 1024 merge only 1/8 of the slots
   uint32_t* fail_list;     // [b] out: queries to redo exactly, [b] = their count
   uint32_t* stats;         // [0] += failed queries
@@ -522,7 +581,9 @@ __global__ __launch_bounds__(kWave * kRescoreWaves) void ivf_rescore_kernel(Resc
     for (int w = 0; w < kRescoreWaves; ++w) qn += sred[w];
     const double u = 5.9604644775390625e-08;
     const double S = (double)qn * (1.0 + (double)a.d_pad * 2.0 * u) + (double)__uint_as_float(xmax_bits);
-    const double E = (5.0 * (double)a.d_pad + 32.0) * u * S;
+    double E = (5.0 * (double)a.d_pad + 32.0) * u * S;
+    if (a.shadow)  // |x_j - bf16(x_j)| <= 2^-9 |x_j|  =>  |2 <x - x~, q>| <= 2^-8 |x||q| (inflated for the roundings of |x~|)
+      E = E * 1.01 + 0.00390625 * 1.004 * __builtin_sqrt((double)__uint_as_float(xmax_bits) * (double)qn * (1.0 + (double)a.d_pad * 2.0 * u));
     const float val = __uint_as_float(order_bits_to_f32_bits((uint32_t)(list >> 32)));
     bool certified = true;
     double lim = __builtin_inf();
