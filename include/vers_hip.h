@@ -221,6 +221,12 @@ int32_t vers_ivf_coarse_stats(vers_ivf_t* h, uint64_t* out_mfma_batches, uint64_
  * exact re-score + certificate, csrc/prescan.cuh) and queries whose certificate failed and were re-scanned
  * exactly.  Results are bit-identical either way; VERS_PRESCAN=0 keeps the ordered-chain scan for every batch. */
 int32_t vers_ivf_prescan_stats(vers_ivf_t* h, uint64_t* out_batches, uint64_t* out_fallback_queries);
+/* EXPERIMENTAL (VERS_SHADOW=1 at build / upload time, off by default): a bf16 shadow copy of the stored rows feeds
+ * the matrix-core pre-selection of batched searches -- half the HBM bytes per scan, +50 % corpus memory, wider
+ * certificate window, same exact finish (results stay bit-identical).  Skipped when the allocation fails; switched off
+ * for the handle when more than 1/8 of the queries failed the certificate (data with many near-ties).
+ * out_active: 1 = in use. */
+int32_t vers_ivf_shadow_state(vers_ivf_t* h, int32_t* out_active, uint64_t* out_bytes);
 /* Durations (ms) of the most recent list-scan launches, oldest first (ring of 64); reset != 0
  * empties the ring.  Lets bench.py time every launch of the timed region without stalling it. */
 int32_t vers_ivf_scan_times(vers_ivf_t* h, float* out_ms, uint32_t cap, uint32_t* out_n, int32_t reset);

@@ -12,6 +12,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 BODY = r'''
+import os
 import numpy as np
 from oracle import c_oracle as co
 from tests import datagen as dg
@@ -59,6 +60,16 @@ check(ix, Q, 10, 6, step=3)
 total += 1
 st = ix.prescan_stats()
 print("TIES", st["batches"], st["fallback_queries"])
+# ... the experimental bf16 shadow keeps 48 keys: it takes 100 copies of every vector to defeat its certificate, and
+# then the failure watch must switch it off for the handle (once 1/8 of >= 256 queries had to be re-scanned exactly)
+if os.environ.get("VERS_SHADOW", "0") == "1" and os.environ.get("VERS_PRESCAN", "1") == "1":
+    X2 = np.repeat(B[:60], 100, axis=0)
+    ix2 = IVFFlatIndex.build_index(8, 1, 2, X2, init_indices=mg.init_draws(0xA3, 1, 8, X2.shape[0]))
+    assert ix2.shadow_state()["active"]
+    for rep in range(6):
+        check(ix2, Q, 10, 4, step=9)
+    assert not ix2.shadow_state()["active"], "the failure watch did not switch the shadow off"
+    check(ix2, Q, 10, 4, step=5)
 # (4) large magnitudes: |x|^2 overflows while the distances stay finite -> nothing is finite on the matrix cores,
 #     every query is re-scanned exactly
 big = lambda s, n: (np.float32(1.5e19) * (np.float32(1.0) + np.float32(1e-3) * dg.dist_u(s, n, 16))).astype(np.float32)
@@ -93,3 +104,7 @@ def test_ordered_chain_scan_still_available():
     out = run({"VERS_PRESCAN": "0"})
     assert out["TIES"] == (0, 0) and out["HUGE"] == (0, 0)
 
+
+def test_experimental_bf16_shadow_is_bit_exact_and_watched():
+    out = run({"VERS_SHADOW": "1"})       # bf16 rows feed the pre-selection; the failure watch switches it off on heavily tied data
+    assert out["TIES"][0] == 1 and out["HUGE"] == (1, 64)

@@ -307,26 +307,41 @@ __device__ __forceinline__ void prescan_item_g(const Src& src, const PreParams& 
           }
         } else {
           const f32x4* ql = reinterpret_cast<const f32x4*>(qm) + ((size_t)cc * 2 * kLoads * kPreQ + n);  // 16 float4 columns per step
+          // The expansions are VALU writes; gfx950 lets a VALU instruction issue in the shadow of an MFMA, and the
+          // 4-block MFMA still reads its A/B registers in its late passes: the compiler re-used an operand register of
+          // an in-flight MFMA as the destination of the next shift (seen in the ISA; rows 16*3 + 4*q + 3 came out one
+          // load short).  So: expand half a step into its own registers while no MFMA is in flight (the previous one
+          // gets 32 cycles), fence the scheduler, then run ds_read + MFMA only.
 #pragma unroll
-          for (int i = 0; i < kLoads; ++i) {
-            float xe[8];  // the load's 8 columns, bf16 -> f32
+          for (int h2 = 0; h2 < 2; ++h2) {
+            float xe[kLoads / 2][8];
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7");
 #pragma unroll
-            for (int w = 0; w < 4; ++w) {
-              xe[2 * w] = __uint_as_float(buf[B][i][w] << 16);
-              xe[2 * w + 1] = __uint_as_float(buf[B][i][w] & 0xFFFF0000u);
+            for (int i = 0; i < kLoads / 2; ++i)
+#pragma unroll
+              for (int w = 0; w < 4; ++w) {
+                xe[i][2 * w] = __uint_as_float(buf[B][h2 * (kLoads / 2) + i][w] << 16);
+                xe[i][2 * w + 1] = __uint_as_float(buf[B][h2 * (kLoads / 2) + i][w] & 0xFFFF0000u);
+              }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int i = 0; i < kLoads / 2; ++i) {
+              const int li = h2 * (kLoads / 2) + i;
+              const f32x4 qa = ql[(2 * li) * kPreQ], qb = ql[(2 * li + 1) * kPreQ];
+#pragma unroll
+              for (int u = 0; u < 4; ++u) acc[0] = __builtin_amdgcn_mfma_f32_16x16x1f32(xe[i][u], qa[u], acc[0], 0, 0, 0);
+#pragma unroll
+              for (int u = 0; u < 4; ++u) acc[0] = __builtin_amdgcn_mfma_f32_16x16x1f32(xe[i][4 + u], qb[u], acc[0], 0, 0, 0);
+              if (two) {
+                const f32x4 qc = ql[(2 * li) * kPreQ + 16], qd = ql[(2 * li + 1) * kPreQ + 16];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) acc[1] = __builtin_amdgcn_mfma_f32_16x16x1f32(xe[i][u], qc[u], acc[1], 0, 0, 0);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) acc[1] = __builtin_amdgcn_mfma_f32_16x16x1f32(xe[i][4 + u], qd[u], acc[1], 0, 0, 0);
+              }
             }
-            const f32x4 qa = ql[(2 * i) * kPreQ], qb = ql[(2 * i + 1) * kPreQ];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) acc[0] = __builtin_amdgcn_mfma_f32_16x16x1f32(xe[u], qa[u], acc[0], 0, 0, 0);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) acc[0] = __builtin_amdgcn_mfma_f32_16x16x1f32(xe[4 + u], qb[u], acc[0], 0, 0, 0);
-            if (two) {
-              const f32x4 qc = ql[(2 * i) * kPreQ + 16], qd = ql[(2 * i + 1) * kPreQ + 16];
-#pragma unroll
-              for (int u = 0; u < 4; ++u) acc[1] = __builtin_amdgcn_mfma_f32_16x16x1f32(xe[u], qc[u], acc[1], 0, 0, 0);
-#pragma unroll
-              for (int u = 0; u < 4; ++u) acc[1] = __builtin_amdgcn_mfma_f32_16x16x1f32(xe[4 + u], qd[u], acc[1], 0, 0, 0);
-            }
+            __builtin_amdgcn_sched_barrier(0);
           }
         }
       } else {

@@ -146,6 +146,11 @@ class IVFFlatIndex:
         check(lib().vers_ivf_prescan_stats(self._h, C.byref(a), C.byref(b)))
         return dict(batches=a.value, fallback_queries=b.value)
 
+    def shadow_state(self):
+        a = C.c_int32(0); b = C.c_uint64(0)
+        check(lib().vers_ivf_shadow_state(self._h, C.byref(a), C.byref(b)))
+        return dict(active=bool(a.value), bytes=int(b.value))
+
     def scan_times(self, reset: bool = True):
         ms = np.zeros(64, dtype=np.float32); n = C.c_uint32(0)
         check(lib().vers_ivf_scan_times(self._h, _ptr(ms), 64, C.byref(n), 1 if reset else 0))
