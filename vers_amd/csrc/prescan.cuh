@@ -307,42 +307,39 @@ __device__ __forceinline__ void prescan_item_g(const Src& src, const PreParams& 
           }
         } else {
           const f32x4* ql = reinterpret_cast<const f32x4*>(qm) + ((size_t)cc * 2 * kLoads * kPreQ + n);  // 16 float4 columns per step
-          // The expansions are VALU writes; gfx950 lets a VALU instruction issue in the shadow of an MFMA, and the
-          // 4-block MFMA still reads its A/B registers in its late passes: the compiler re-used an operand register of
-          // an in-flight MFMA as the destination of the next shift (seen in the ISA; rows 16*3 + 4*q + 3 came out one
-          // load short).  So: expand half a step into its own registers while no MFMA is in flight (the previous one
-          // gets 32 cycles), fence the scheduler, then run ds_read + MFMA only.
+          // One asm block per load: 8 expansions (VALU), wait states, 8 MFMAs.  An MFMA that reads a register a VALU
+          // instruction wrote just before it sees stale lanes: the hardware does not interlock that pair, the compiler's
+          // wait-state model was a cycle short here (compiler-scheduled expansions left lanes 51/55/59/63 of the A
+          // operand stale: rows 48 + 4*quarter + 3 came out one load short), and scripts/probe/mfma_chain.hip reproduces
+          // the stale read in isolation.  Inside the block the distance is explicit; the operands of the builtin MFMAs of
+          // the f32 path come from memory and LDS loads only (s_waitcnt-ordered), never from the VALU.
+          auto load_group = [&](f32x16_t& av, const u32x4& w, const f32x4& qlo, const f32x4& qhi) {
+            float t0, t1, t2, t3, t4, t5, t6, t7;
+            asm volatile(
+                "v_lshlrev_b32 %1, 16, %9\n\tv_and_b32 %2, 0xffff0000, %9\n\t"
+                "v_lshlrev_b32 %3, 16, %10\n\tv_and_b32 %4, 0xffff0000, %10\n\t"
+                "v_lshlrev_b32 %5, 16, %11\n\tv_and_b32 %6, 0xffff0000, %11\n\t"
+                "v_lshlrev_b32 %7, 16, %12\n\tv_and_b32 %8, 0xffff0000, %12\n\t"
+                "s_nop 4\n\t"
+                "v_mfma_f32_16x16x1_4b_f32 %0, %1, %13, %0\n\tv_mfma_f32_16x16x1_4b_f32 %0, %2, %14, %0\n\t"
+                "v_mfma_f32_16x16x1_4b_f32 %0, %3, %15, %0\n\tv_mfma_f32_16x16x1_4b_f32 %0, %4, %16, %0\n\t"
+                "v_mfma_f32_16x16x1_4b_f32 %0, %5, %17, %0\n\tv_mfma_f32_16x16x1_4b_f32 %0, %6, %18, %0\n\t"
+                "v_mfma_f32_16x16x1_4b_f32 %0, %7, %19, %0\n\tv_mfma_f32_16x16x1_4b_f32 %0, %8, %20, %0"
+                : "+v"(av), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5), "=&v"(t6), "=&v"(t7)
+                : "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(qlo[0]), "v"(qlo[1]), "v"(qlo[2]), "v"(qlo[3]), "v"(qhi[0]), "v"(qhi[1]),
+                  "v"(qhi[2]), "v"(qhi[3]));
+          };
 #pragma unroll
-          for (int h2 = 0; h2 < 2; ++h2) {
-            float xe[kLoads / 2][8];
-            __builtin_amdgcn_sched_barrier(0);
-            asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7");
-#pragma unroll
-            for (int i = 0; i < kLoads / 2; ++i)
-#pragma unroll
-              for (int w = 0; w < 4; ++w) {
-                xe[i][2 * w] = __uint_as_float(buf[B][h2 * (kLoads / 2) + i][w] << 16);
-                xe[i][2 * w + 1] = __uint_as_float(buf[B][h2 * (kLoads / 2) + i][w] & 0xFFFF0000u);
-              }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int i = 0; i < kLoads / 2; ++i) {
-              const int li = h2 * (kLoads / 2) + i;
-              const f32x4 qa = ql[(2 * li) * kPreQ], qb = ql[(2 * li + 1) * kPreQ];
-#pragma unroll
-              for (int u = 0; u < 4; ++u) acc[0] = __builtin_amdgcn_mfma_f32_16x16x1f32(xe[i][u], qa[u], acc[0], 0, 0, 0);
-#pragma unroll
-              for (int u = 0; u < 4; ++u) acc[0] = __builtin_amdgcn_mfma_f32_16x16x1f32(xe[i][4 + u], qb[u], acc[0], 0, 0, 0);
-              if (two) {
-                const f32x4 qc = ql[(2 * li) * kPreQ + 16], qd = ql[(2 * li + 1) * kPreQ + 16];
-#pragma unroll
-                for (int u = 0; u < 4; ++u) acc[1] = __builtin_amdgcn_mfma_f32_16x16x1f32(xe[i][u], qc[u], acc[1], 0, 0, 0);
-#pragma unroll
-                for (int u = 0; u < 4; ++u) acc[1] = __builtin_amdgcn_mfma_f32_16x16x1f32(xe[i][4 + u], qd[u], acc[1], 0, 0, 0);
-              }
+          for (int i = 0; i < kLoads; ++i) {
+            const f32x4 qa = ql[(2 * i) * kPreQ], qb = ql[(2 * i + 1) * kPreQ];
+            load_group(acc[0], buf[B][i], qa, qb);
+            if (two) {
+              const f32x4 qc = ql[(2 * i) * kPreQ + 16], qd = ql[(2 * i + 1) * kPreQ + 16];
+              load_group(acc[1], buf[B][i], qc, qd);
             }
-            __builtin_amdgcn_sched_barrier(0);
           }
+          // the compiler cannot see the MFMAs inside the blocks: give the last one its passes before anything reads acc
+          asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");
         }
       } else {
         acc[0][0] += __uint_as_float(buf[B][0][0] ^ buf[B][kLoads - 1][3]);
