@@ -26,6 +26,7 @@ def check(ix, Q, top_k, nprobe, step=7):
         assert cnt[qi] == len(oi), (nprobe, top_k, qi, cnt[qi], len(oi))
         assert np.array_equal(ids[qi, :len(oi)], oi), (nprobe, top_k, qi, ids[qi, :len(oi)], oi)
         assert np.array_equal(dist[qi, :len(oi)].view(np.uint32), od.view(np.uint32)), (nprobe, top_k, qi)
+        assert not ids[qi, len(oi):].any() and not dist[qi, len(oi):].any()   # past the count: zeros, not stale memory
 
 total = 0
 # (1) clustered data, several shapes (d = 300 pads to 320 columns; lists are ragged: lengths not multiples of 64)
@@ -70,6 +71,13 @@ if os.environ.get("VERS_SHADOW", "0") == "1" and os.environ.get("VERS_PRESCAN", 
         check(ix2, Q, 10, 4, step=9)
     assert not ix2.shadow_state()["active"], "the failure watch did not switch the shadow off"
     check(ix2, Q, 10, 4, step=5)
+# (3b) duplicated rows leave k-means clusters empty (zero centroids at distance |q|^2 = 1, nearer than other modes'
+#      centroids): most queries probe nothing but empty lists and must come back with count 0
+X = dg.dist_c(0xC1, 4500, 130, 72, dg.default_sigma(130)); X[2250:] = X[:2250]
+ix = IVFFlatIndex.build_index(72, 1, 2, X, init_indices=mg.init_draws(0xC1, 1, 72, 4500))
+Qe = dg.dist_c(0xC2, 140, 130, 72, dg.default_sigma(130))
+check(ix, Qe, 10, 3, step=1)
+print("EMPTY", int((ix.search_batch(Qe, 10, 3)[2] == 0).sum()))
 # (4) large magnitudes: |x|^2 overflows while the distances stay finite -> nothing is finite on the matrix cores,
 #     every query is re-scanned exactly
 big = lambda s, n: (np.float32(1.5e19) * (np.float32(1.0) + np.float32(1e-3) * dg.dist_u(s, n, 16))).astype(np.float32)

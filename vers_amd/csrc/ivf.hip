@@ -1428,6 +1428,7 @@ int32_t host_io_begin(vers_ivf* h, const float* queries, uint64_t stride_bytes, 
   for (uint32_t i = 0; i < b; ++i)
     std::memcpy((char*)h->io_pin + (size_t)i * h->d * 4, (const char*)queries + (size_t)i * stride_bytes, (size_t)h->d * 4);
   VERS_HIP_TRY(hipMemcpyAsync(io.q_dev, h->io_pin, io.q_bytes, hipMemcpyHostToDevice, h->io_stream));
+  VERS_HIP_TRY(hipMemsetAsync(h->io_out.p, 0, io.out_bytes, h->io_stream));  // entries past a query's count come back as zeros, not stale memory
   return VERS_OK;
 }
 
