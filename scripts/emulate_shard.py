@@ -28,4 +28,5 @@ torch.cuda.synchronize(); ix.scan_times(reset=True); t0 = time.perf_counter()
 for i in range(20): step(3 + i)
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 20
 ix.poll(st)
+if os.environ.get("VERS_SCAN_DEBUG"): print("last scan:", ix.last_scan())   # (prints the phase stamps with VERS_SCAN_DEBUG=16)
 print(f"world={W} rank={R}: {dt*1e3:.3f} ms per step for this rank (list scan {float(np.mean(ix.scan_times()))*1e3:.0f} us)")

@@ -210,7 +210,6 @@ __device__ __forceinline__ void prescan_item_g(const Src& src, const PreParams& 
       if (lane == (nn & 15)) atomicMin(p.bounds32 + (nn < 16 ? vslot[0] : vslot[1]), kb);
     }
   };
-  auto insert = [&](int nn, uint64_t key) { merge_into(nn, lane == 0 ? key : kKeyMax); };
   // End of a tile for query set S: acc already holds val (the |x|^2 term went through the matrix core).  Each lane holds
   // 16 vals of ONE query column (lane & 15), rows 16*(e>>2) + 4*quarter + (e&3): one compare per register against the
   // lane's threshold decides whether anything happens at all.
@@ -258,17 +257,45 @@ __device__ __forceinline__ void prescan_item_g(const Src& src, const PreParams& 
 #pragma unroll
     for (int e = 0; e < 16; ++e) any |= __ballot(a[e] <= thr[S]);
     if (any != 0 && !(p.debug & 1u)) {
+      // All candidates of one query column go into its list under ONE lock hold: the column's rows sit in lanes
+      // nn, nn+16, nn+32, nn+48 of the 16 registers, so 16 four-candidate merges (a ballot each when nothing passes).
+      // (One lock round trip per candidate was ~400 cycles; a rank of an 8-way sharded index sees only ~4 lists per
+      // query, its thresholds stay loose and a tile often carries several candidates of the same query.)
+      uint32_t qmask = (uint32_t)((any | (any >> 16) | (any >> 32) | (any >> 48)) & 0xFFFFull);
+      const uint32_t sq0 = vseq[S] + t * kWave + 4u * (uint32_t)quarter;
+      while (qmask) {
+        const int nn = __builtin_ctz(qmask);
+        qmask &= qmask - 1;
+        const int ql = S * 16 + nn;
+        const bool mine = n == nn;
+        if (__ballot(mine && a[0] <= thr[S]) == 0) {  // (thr may have tightened since `any` was taken: look again before locking)
+          uint64_t again = 0;
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        uint64_t m = __ballot(a[e] <= thr[S]);
-        while (m) {
-          const int sl = __ffsll((unsigned long long)m) - 1;
-          m &= m - 1;
-          const float fv = __uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(a[e]), sl));
-          const uint32_t sq = (uint32_t)__builtin_amdgcn_readlane((int)vseq[S], sl) + t * kWave + 16u * (e >> 2) + 4u * ((uint32_t)sl >> 4) + (e & 3);
-          insert(S * 16 + (sl & 15), make_key(fv, sq));
-          m &= __ballot(a[e] <= thr[S]);
+          for (int e = 1; e < 16; ++e) again |= __ballot(mine && a[e] <= thr[S]);
+          if (again == 0) continue;
         }
+        if (lane == 0)
+          while (__hip_atomic_exchange(locks + ql, 1u, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u) __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        uint64_t* Ln = blk + (uint32_t)ql * kp;
+        uint64_t cur = lane < (int)kp ? Ln[lane] : kKeyMax;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const bool c = mine && a[e] <= thr[S];
+          if (__ballot(c) != 0) {
+            wave_topk_update(cur, kp, c ? make_key(a[e], sq0 + 16u * (e >> 2) + (e & 3)) : kKeyMax, kKeyMax);
+            const uint32_t kh = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(cur >> 32), (int)kp - 1);
+            if (kh != 0xFFFFFFFFu && mine) {  // full: the later registers are tested against the tightened threshold
+              const float nt = __uint_as_float(order_bits_to_f32_bits(kh));
+              thr[S] = nt < thr[S] ? nt : thr[S];
+            }
+          }
+        }
+        if (lane < (int)kp) Ln[lane] = cur;
+        const uint32_t kb = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(cur >> 32), (int)kp - 1);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) __hip_atomic_store(locks + ql, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (kb != 0xFFFFFFFFu && lane == nn) atomicMin(p.bounds32 + vslot[S], kb);
       }
     }
 #pragma unroll
@@ -409,7 +436,6 @@ __global__ __launch_bounds__(kWave * kPreWavesG) __attribute__((amdgpu_waves_per
   uint32_t* locks = reinterpret_cast<uint32_t*>(blk + (size_t)kPreQ * p.kp);
   float* scratch = reinterpret_cast<float*>(locks + kPreQ) + wid * kWave;
   const uint32_t n_quads = src.n_items() / 4;
-  const uint32_t n4 = p.ld * (kPreQ / 4);
   const unsigned long long clk0 = (p.debug & 16u) ? __builtin_amdgcn_s_memtime() : 0ull;
   const unsigned long long rt0 = (p.debug & 16u) ? __builtin_amdgcn_s_memrealtime() : 0ull;
   uint32_t prev_it0 = 0xFFFFFFFFu, prev_nq = 0;  // the quad whose lists still sit in LDS
@@ -431,8 +457,26 @@ __global__ __launch_bounds__(kWave * kPreWavesG) __attribute__((amdgpu_waves_per
     const uint32_t it = bi * 4 + (wid & 3);
     ItemView<kPreQ> v;
     src.get(it, v);
+    // The quad's query block: <= 32 padded queries gathered from their rows, scaled by -2, in the MFMA operand
+    // layout l4[column group * 32 + slot].  Every thread serves ONE slot (512 % 32 == 0; 16 slots when the group
+    // holds <= 16 queries, so that all threads load) and its row pointer is resolved here, ahead of the barrier.
+    const uint32_t ns = v.nq > 16 ? 32u : 16u;
+    const uint32_t slot = threadIdx.x & (ns - 1u), cg0 = threadIdx.x / ns, cg_step = (kWave * kPreWavesG) / ns;
+    const float* qrow = slot < v.nq ? src.query_row(it, slot) : nullptr;
     auto stage = [&]() {
       const unsigned long long ts0 = (p.debug & 16u) ? __builtin_amdgcn_s_memtime() : 0ull;
+      // the first kStageU loads of every thread go out BEFORE the barriers (they fly while the slowest wave of the
+      // previous quad finishes and its lists are written out); one load at a time behind the barriers was ~7 us per
+      // quad at d = 768 -- 7 % of the launch
+      constexpr int kStageU = 12;
+      const uint32_t n_cg = p.ld / 4u;
+      f32x4 x[kStageU];
+#pragma unroll
+      for (int u = 0; u < kStageU; ++u) {
+        const uint32_t cg = cg0 + (uint32_t)u * cg_step;
+        x[u] = f32x4{0.0f, 0.0f, 0.0f, 0.0f};
+        if (qrow != nullptr && cg < n_cg) x[u] = *reinterpret_cast<const f32x4*>(qrow + 4 * cg);
+      }
       __syncthreads();  // every wave is done with the previous quad: its lists are final
       const unsigned long long ts1 = (p.debug & 16u) ? __builtin_amdgcn_s_memtime() : 0ull;
       write_out();
@@ -440,14 +484,15 @@ __global__ __launch_bounds__(kWave * kPreWavesG) __attribute__((amdgpu_waves_per
       for (uint32_t t = threadIdx.x; t < kPreQ * p.kp; t += kWave * kPreWavesG) blk[t] = kKeyMax;
       if (threadIdx.x < kPreQ) locks[threadIdx.x] = 0u;
       f32x4* l4 = reinterpret_cast<f32x4*>(qlds);
-      const uint32_t slot = threadIdx.x & 31u;
-      const float* qrow = slot < v.nq ? src.query_row(it, slot) : nullptr;
-      if (v.nq > 16 || slot < 16) {
-        for (uint32_t i = threadIdx.x; i < n4; i += kWave * kPreWavesG) {
-          f32x4 x = {0.0f, 0.0f, 0.0f, 0.0f};
-          if (qrow != nullptr) x = *reinterpret_cast<const f32x4*>(qrow + 4 * (i >> 5));
-          l4[i] = -2.0f * x;
-        }
+#pragma unroll
+      for (int u = 0; u < kStageU; ++u) {
+        const uint32_t cg = cg0 + (uint32_t)u * cg_step;
+        if (cg < n_cg) l4[cg * kPreQ + slot] = -2.0f * x[u];
+      }
+      for (uint32_t cg = cg0 + kStageU * cg_step; cg < n_cg; cg += cg_step) {  // (wider rows than kStageU rounds cover)
+        f32x4 y = {0.0f, 0.0f, 0.0f, 0.0f};
+        if (qrow != nullptr) y = *reinterpret_cast<const f32x4*>(qrow + 4 * cg);
+        l4[cg * kPreQ + slot] = -2.0f * y;
       }
       __syncthreads();
       if ((p.debug & 16u) && lane == 0) {
