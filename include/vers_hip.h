@@ -178,6 +178,14 @@ int32_t vers_ivf_list_lengths(vers_ivf_t* h, uint64_t* out_lengths /* [k] */);
 int32_t vers_ivf_last_scan(vers_ivf_t* h, float* out_ms, uint64_t* out_union_rows,
                            uint64_t* out_streamed_rows, uint32_t* out_items);
 
+/* Throughput serving loops (extension; no reference counterpart -- ivfflat.rs:155-161 ranks the lists inside the
+ * search itself): stage the queries of the NEXT batch and rank its lists on a side stream of the handle while the
+ * current batch's list scan runs on `stream`.  A following vers_ivf_search_dev / vers_ivf_search_partial_dev call with
+ * the SAME queries_dev, ldq_floats, b and nprobe picks the prepared result up (same bits) instead of computing it;
+ * the query block must not change in between.  Two batches can be prepared at a time; a no-op for nprobe == 0 and
+ * for batches the coarse quantiser does not run on the matrix cores for (b < 32). */
+int32_t vers_ivf_coarse_ahead_dev(vers_ivf_t* h, const float* queries_dev, uint64_t ldq_floats, uint32_t b, uint32_t nprobe, void* stream);
+
 /* ---- one process per GPU: the corpus shards BY CLUSTER ------------------------------------------
  * Every rank holds the centroids and all list LENGTHS, but stores only the lists it owns.  A search
  * runs the (cheap, replicated) coarse quantiser everywhere, scans the local lists, and yields a

@@ -22,7 +22,10 @@ Q = torch.empty(8 * B, d, dtype=torch.float32, device=dev)
 capi.gen_rows_dev(Q.data_ptr(), 8 * B, d, d, 1, 0x5EED0002, 0x5EEDC0DE, 16 * nlist, float(dg.default_sigma(d)))
 keys = torch.empty(B, top_k, dtype=torch.int64, device=dev); ids = torch.empty(B, top_k, dtype=torch.int64, device=dev)
 st = torch.cuda.current_stream().cuda_stream
-def step(i): ix.search_partial_dev(Q[(i % 8) * B:].data_ptr(), d, B, top_k, nprobe, keys.data_ptr(), ids.data_ptr(), st)
+AHEAD = os.environ.get("AHEAD", "0") != "0"   # next batch's coarse quantiser on the side stream (bench.py --ahead)
+def step(i):
+    if AHEAD: ix.coarse_ahead_dev(Q[((i + 1) % 8) * B:].data_ptr(), d, B, nprobe, st)
+    ix.search_partial_dev(Q[(i % 8) * B:].data_ptr(), d, B, top_k, nprobe, keys.data_ptr(), ids.data_ptr(), st)
 for i in range(3): step(i)
 torch.cuda.synchronize(); ix.scan_times(reset=True); t0 = time.perf_counter()
 for i in range(20): step(3 + i)

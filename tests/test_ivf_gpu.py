@@ -136,3 +136,36 @@ def test_add_overflows_slack_and_relayouts():
                       co.search_nprobe(index.values, index.centroids, index.ids, q, top_k, nprobe))
             assert np.array_equal(ids[0, :len(oi)], oi) and np.array_equal(bits(dist[0, :len(oi)]), bits(od))
     index.close()
+
+
+def test_coarse_ahead_is_bit_identical():
+    """vers_ivf_coarse_ahead_dev: the next batch's staged queries + ranked lists computed on the side stream must give
+    the same bits as the search computing them itself -- alternating slots, a stale slot, a batch never searched."""
+    import torch
+    from tests.golden import make_golden as mg
+    n, d, k, b, top_k, nprobe = 20000, 96, 64, 256, 10, 8
+    X = dg.dist_c(0x51, n, d, 4 * k, dg.default_sigma(d))
+    ix = IVFFlatIndex.build_index(k, 1, 3, X, init_indices=mg.init_draws(0x51, 1, k, n))
+    dev = torch.device("cuda:0")
+    Q = torch.from_numpy(dg.dist_c(0x52, 6 * b, d, 4 * k, dg.default_sigma(d))).to(dev)
+    st = torch.cuda.current_stream().cuda_stream
+
+    def run(i, ahead_of=None):
+        ids = torch.zeros(b, top_k, dtype=torch.int64, device=dev); dst = torch.zeros(b, top_k, dtype=torch.float32, device=dev)
+        cnt = torch.zeros(b, dtype=torch.int32, device=dev)
+        if ahead_of is not None:
+            ix.coarse_ahead_dev(Q[ahead_of * b:].data_ptr(), d, b, nprobe, st)
+        ix.search_dev(Q[i * b:].data_ptr(), d, b, top_k, nprobe, ids.data_ptr(), dst.data_ptr(), cnt.data_ptr(), st)
+        ix.poll(st)
+        return ids.cpu().numpy(), dst.cpu().numpy().view(np.uint32), cnt.cpu().numpy()
+
+    want = [run(i) for i in range(6)]
+    ix.coarse_ahead_dev(Q.data_ptr(), d, b, nprobe, st)
+    got = [run(i, ahead_of=(i + 1) % 6) for i in range(6)]                # pipelined loop: every search finds its slot
+    got += [run(3, ahead_of=5), run(5), run(0, ahead_of=0), run(1)]        # out of order / prepared-for-itself / stale slot left behind
+    for g, w in zip(got, want + [want[3], want[5], want[0], want[1]]):
+        assert all(np.array_equal(a, c) for a, c in zip(g, w))
+    ix.add(X[7] * np.float32(1.01), 0)                                      # lists change, centroids do not: slots stay valid
+    ix.coarse_ahead_dev(Q[2 * b:].data_ptr(), d, b, nprobe, st)
+    a = run(2); ix2 = run(2)
+    assert all(np.array_equal(x, y) for x, y in zip(a, ix2))

@@ -637,6 +637,23 @@ struct vers_ivf {
   void* io_pin = nullptr;
   size_t io_pin_cap = 0;
   hipStream_t io_stream = nullptr;
+  // Coarse quantiser one batch ahead (vers_ivf_coarse_ahead_dev): staged queries + ranked lists of the NEXT batch are
+  // computed on a side stream while the current batch's list scan runs; two slots alternate (one is read by the search
+  // in flight while the other is written).  ready: recorded on the side stream after the slot's kernels; freed: recorded
+  // on the consuming search's stream after its last kernel.
+  struct CoarseAhead {
+    DevBuf qp, probe;
+    const float* q_dev = nullptr;
+    uint64_t ldq_in = 0;
+    uint32_t b = 0, P = 0;
+    bool valid = false, ready_rec = false, freed_rec = false;
+    hipEvent_t ready = nullptr, freed = nullptr;
+  };
+  CoarseAhead ahead[2];
+  uint32_t ahead_next = 0;
+  hipStream_t ahead_stream = nullptr;
+  hipEvent_t ahead_in = nullptr;
+  uint64_t ahead_used = 0;  // searches that consumed a slot (statistics)
   GroupTotals last_tot{};
   const GroupTotals* tot_dev = nullptr;  // device totals of the last planned search
   bool tot_valid = false;
@@ -674,6 +691,7 @@ int32_t refresh_norms(vers_ivf* h, uint64_t r_begin, uint64_t r_end, hipStream_t
   if (full) {
     if (int32_t rc = h->xnorm.reserve((h->cap_rows ? h->cap_rows : 1) * sizeof(float))) return rc;
     VERS_HIP_TRY(hipMemsetAsync(h->pre_misc.p, 0, 64, st));
+    for (auto& a : h->ahead) a.valid = false;  // a new index: ranked lists computed ahead belong to the old centroids
   }
   // EXPERIMENTAL, off unless VERS_SHADOW=1: bit-exact on every test and A/B run of its final form,
   // but an earlier arrangement of the same arithmetic came out wrong in accumulator register 15 for a reason that is
@@ -963,26 +981,35 @@ int32_t stage_plain_queries(vers_ivf* h, const float* q_dev, uint64_t ldq_in, ui
   return VERS_OK;
 }
 
+inline int coarse_mode() {  // VERS_COARSE: 1 = always exact, 2 = every certificate fails
+  static const int m = [] { const char* e = getenv("VERS_COARSE"); return e ? atoi(e) : 0; }();
+  return m;
+}
+inline bool coarse_on_matrix_cores(const vers_ivf* h, uint32_t b) { return b >= 32 && coarse_mode() != 1 && !h->ref_deep; }
+// batches: MFMA pre-selection + exact re-score + certificate (gemm.cuh); same output as the exact scan, bit for bit.
+// qp: staged queries [round_up(b, kGemmBM)][ldq]; probe_out [b][P].  h->gbuf is the only scratch.
+int32_t coarse_mfma(vers_ivf* h, const float* qp, uint32_t b, uint32_t P, uint64_t* probe_out, hipStream_t st) {
+  const uint32_t M_pad = round_up(b, kGemmBM);
+  const uint32_t PS = std::min<uint32_t>(kMaxTopK, P + 16);
+  if (int32_t rc = h->gbuf.reserve((size_t)M_pad * h->k_pad * sizeof(float))) return rc;
+  hipLaunchKernelGGL(dist_gemm_kernel<false>, dim3(h->k_pad / kGemmBN, M_pad / kGemmBM), dim3(256), 0, st, qp, h->centroids_g.as<float>(),
+                     h->cnorm.as<float>(), h->ldq, h->k_pad, h->gbuf.as<float>());
+  VERS_HIP_TRY(hipGetLastError());
+  hipLaunchKernelGGL(coarse_select_rescore_kernel, dim3(b), dim3(kWave), 0, st, h->gbuf.as<float>(), h->k_pad, h->k,
+                     h->centroids_g.as<float>(), h->ldq, qp, h->ldq, h->ldq, coarse_mode() == 2 ? __builtin_inff() : h->cmax2, P, PS,
+                     probe_out, h->status.as<uint32_t>(), h->coarse_stat.as<uint32_t>());
+  VERS_HIP_TRY(hipGetLastError());
+  h->mfma_batches += 1;
+  return VERS_OK;
+}
+
 // coarse quantiser (ivfflat.rs:155-161): top-P centroids per query as ascending (dist, index) keys in h->probe
 // out_n_segs != nullptr: stop after the scan (partial slots in h->cpart) and report the slot count per query --
 // the single-query path merges them inside plan1_kernel.
 int32_t coarse(vers_ivf* h, const float* qp, uint32_t b, uint32_t P, hipStream_t st, uint32_t* out_n_segs = nullptr) {
-  // batches: MFMA pre-selection + exact re-score + certificate (gemm.cuh); same output, bit for bit
-  static const int coarse_mode = [] { const char* e = getenv("VERS_COARSE"); return e ? atoi(e) : 0; }();  // 1 = always exact, 2 = force fallback
-  if (b >= 32 && coarse_mode != 1 && !h->ref_deep && qp == h->qp.as<float>()) {
-    const uint32_t M_pad = round_up(b, kGemmBM);
-    const uint32_t PS = std::min<uint32_t>(kMaxTopK, P + 16);
-    if (int32_t rc = h->gbuf.reserve((size_t)M_pad * h->k_pad * sizeof(float))) return rc;
+  if (coarse_on_matrix_cores(h, b) && qp == h->qp.as<float>()) {
     if (int32_t rc = h->probe.reserve((size_t)b * P * sizeof(uint64_t))) return rc;
-    hipLaunchKernelGGL(dist_gemm_kernel<false>, dim3(h->k_pad / kGemmBN, M_pad / kGemmBM), dim3(256), 0, st, qp, h->centroids_g.as<float>(),
-                       h->cnorm.as<float>(), h->ldq, h->k_pad, h->gbuf.as<float>());
-    VERS_HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(coarse_select_rescore_kernel, dim3(b), dim3(kWave), 0, st, h->gbuf.as<float>(), h->k_pad, h->k,
-                       h->centroids_g.as<float>(), h->ldq, qp, h->ldq, h->ldq, coarse_mode == 2 ? __builtin_inff() : h->cmax2, P, PS,
-                       h->probe.as<uint64_t>(), h->status.as<uint32_t>(), h->coarse_stat.as<uint32_t>());
-    VERS_HIP_TRY(hipGetLastError());
-    h->mfma_batches += 1;
-    return VERS_OK;
+    return coarse_mfma(h, qp, b, P, h->probe.as<uint64_t>(), st);
   }
   const int QG = b == 1 ? 1 : 8;
   const uint32_t n_qg = (b + QG - 1) / QG;
@@ -1116,10 +1143,25 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
   const uint32_t P = ref_mode ? std::min<uint32_t>(h->k, h->ref_deep ? 64u : (h->ref_shallow ? 16u : 48u)) : std::min<uint32_t>(nprobe, h->k);
   if (P > (uint32_t)kMaxTopK) return fail(VERS_ERR_INVALID, "nprobe > 64 is not supported");
   const float* qp = nullptr;
-  if (b == 1 && h->d == h->ldq && (reinterpret_cast<uintptr_t>(q_dev) & 15u) == 0) qp = q_dev;  // a single unpadded-is-padded query: no staging launch
-  else if (int32_t rc = stage_plain_queries(h, q_dev, ldq_in, b, &qp, st)) return rc;
+  const uint64_t* probe = nullptr;
+  vers_ivf::CoarseAhead* took = nullptr;
+  for (auto& a : h->ahead)
+    if (a.valid && !ref_mode && a.q_dev == q_dev && a.ldq_in == ldq_in && a.b == b && a.P == P) took = &a;
   uint32_t n_segs_c = 0;
-  if (int32_t rc = coarse(h, qp, b, P, st, b == 1 ? &n_segs_c : nullptr)) return rc;
+  if (took) {  // staged queries and ranked lists of this batch were computed ahead (vers_ivf_coarse_ahead_dev)
+    VERS_HIP_TRY(hipStreamWaitEvent(st, took->ready, 0));
+    qp = took->qp.as<float>();
+    probe = took->probe.as<uint64_t>();
+    took->valid = false;
+    h->ahead_used += 1;
+  } else {
+    for (auto& a : h->ahead)  // h->gbuf is shared with a look-ahead in flight: let it finish first
+      if (a.ready_rec) VERS_HIP_TRY(hipStreamWaitEvent(st, a.ready, 0));
+    if (b == 1 && h->d == h->ldq && (reinterpret_cast<uintptr_t>(q_dev) & 15u) == 0) qp = q_dev;  // a single unpadded-is-padded query: no staging launch
+    else if (int32_t rc = stage_plain_queries(h, q_dev, ldq_in, b, &qp, st)) return rc;
+    if (int32_t rc = coarse(h, qp, b, P, st, b == 1 ? &n_segs_c : nullptr)) return rc;
+    probe = h->probe.as<uint64_t>();
+  }
 
   // geometry of the list scan
   const uint64_t n_pj = (uint64_t)b * P;
@@ -1216,7 +1258,7 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
   } else {
   static const uint32_t hot_ranks = [] { const char* e = getenv("VERS_HOT_FIRST"); return e ? (uint32_t)atoi(e) : 1u; }();  // A/B knob
   VERS_HIP_TRY(hipMemsetAsync(cnt, 0, zero_words * sizeof(uint32_t), st));
-  hipLaunchKernelGGL(plan_kernel, dim3((b + 3) / 4), dim3(256), 0, st, h->probe.as<uint64_t>(), b, P, k_l, top_k, ref_mode,
+  hipLaunchKernelGGL(plan_kernel, dim3((b + 3) / 4), dim3(256), 0, st, probe, b, P, k_l, top_k, ref_mode,
                      h->list_len.as<uint32_t>(), h->world > 1 ? h->owner.as<uint8_t>() : (const uint8_t*)nullptr, h->rank, pj_list,
                      pj_pref, pj_take, np, cnt, hot, hot_ranks, h->status.as<uint32_t>());
   VERS_HIP_TRY(hipGetLastError());
@@ -1277,6 +1319,7 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
     }
     h->pre_batches += 1;
     h->tot_valid = true;
+    if (took) { VERS_HIP_TRY(hipEventRecord(took->freed, st)); took->freed_rec = true; }
     return VERS_OK;
   }
   if (QG == 1) {
@@ -1295,6 +1338,41 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
                      out_dist, out_count, out_keys);
   VERS_HIP_TRY(hipGetLastError());
   h->tot_valid = true;
+  if (took) { VERS_HIP_TRY(hipEventRecord(took->freed, st)); took->freed_rec = true; }
+  return VERS_OK;
+}
+
+// Stage the queries of a coming batch and rank its lists on the side stream (see vers_ivf::CoarseAhead).
+int32_t coarse_ahead_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint32_t b, uint32_t nprobe, hipStream_t st) {
+  if (b == 0 || nprobe == 0 || h->k == 0 || !coarse_on_matrix_cores(h, b)) return VERS_OK;  // nothing to gain: the search does it itself
+  const uint32_t P = std::min<uint32_t>(nprobe, h->k);
+  if (P > (uint32_t)kMaxTopK) return fail(VERS_ERR_INVALID, "nprobe > 64 is not supported");
+  if (!h->ahead_stream) {
+    VERS_HIP_TRY(hipStreamCreateWithFlags(&h->ahead_stream, hipStreamNonBlocking));
+    VERS_HIP_TRY(hipEventCreateWithFlags(&h->ahead_in, hipEventDisableTiming));
+    for (auto& a : h->ahead) {
+      VERS_HIP_TRY(hipEventCreateWithFlags(&a.ready, hipEventDisableTiming));
+      VERS_HIP_TRY(hipEventCreateWithFlags(&a.freed, hipEventDisableTiming));
+    }
+  }
+  for (auto& a : h->ahead)
+    if (a.valid && a.q_dev == q_dev && a.ldq_in == ldq_in && a.b == b && a.P == P) return VERS_OK;  // already prepared
+  vers_ivf::CoarseAhead& a = h->ahead[h->ahead_next];
+  h->ahead_next ^= 1u;
+  hipStream_t side = h->ahead_stream;
+  // after everything already queued on the caller's stream (whatever produced the queries; any search still using
+  // h->gbuf), and after the search that read this slot last
+  VERS_HIP_TRY(hipEventRecord(h->ahead_in, st));
+  VERS_HIP_TRY(hipStreamWaitEvent(side, h->ahead_in, 0));
+  if (a.freed_rec) VERS_HIP_TRY(hipStreamWaitEvent(side, a.freed, 0));
+  a.valid = false;
+  if (int32_t rc = a.qp.reserve((size_t)round_up(b, kGemmBM) * h->ldq * sizeof(float))) return rc;
+  if (int32_t rc = a.probe.reserve((size_t)b * P * sizeof(uint64_t))) return rc;
+  if (int32_t rc = launch_stage_queries(q_dev, ldq_in, h->d, a.qp.as<float>(), h->ldq, b, 1, side)) return rc;
+  if (int32_t rc = coarse_mfma(h, a.qp.as<float>(), b, P, a.probe.as<uint64_t>(), side)) return rc;
+  VERS_HIP_TRY(hipEventRecord(a.ready, side));
+  a.ready_rec = true;
+  a.q_dev = q_dev; a.ldq_in = ldq_in; a.b = b; a.P = P; a.valid = true;
   return VERS_OK;
 }
 
@@ -1492,6 +1570,12 @@ int32_t vers_ivf_destroy(vers_ivf_t* h) {
   if (h->io_pin) (void)hipHostFree(h->io_pin);
   if (h->fail_watch) (void)hipHostFree(h->fail_watch);
   if (h->io_stream) (void)hipStreamDestroy(h->io_stream);
+  if (h->ahead_stream) {
+    (void)hipStreamSynchronize(h->ahead_stream);
+    (void)hipStreamDestroy(h->ahead_stream);
+    (void)hipEventDestroy(h->ahead_in);
+    for (auto& a : h->ahead) { (void)hipEventDestroy(a.ready); (void)hipEventDestroy(a.freed); }
+  }
   delete h;
   return VERS_OK;
 }
@@ -1651,6 +1735,14 @@ int32_t vers_ivf_search_partial_dev(vers_ivf_t* h, const float* queries_dev, uin
   if (int32_t rc = ensure_out(h, (size_t)b * top_k, b)) return rc;
   return search_dev_locked(h, queries_dev, ldq_floats, b, top_k, nprobe, out_ids_dev, h->o_dist.as<float>(), h->o_cnt.as<uint32_t>(),
                            out_keys_dev, (hipStream_t)stream);
+}
+
+int32_t vers_ivf_coarse_ahead_dev(vers_ivf_t* h, const float* queries_dev, uint64_t ldq_floats, uint32_t b, uint32_t nprobe, void* stream) {
+  if (!h) return fail(VERS_ERR_INVALID, "null handle");
+  if (b && (!queries_dev || ldq_floats < h->d)) return fail(VERS_ERR_INVALID, "vers_ivf_coarse_ahead_dev: bad arguments");
+  std::lock_guard<std::mutex> lk(h->mu);
+  DeviceGuard g(h->device);
+  return coarse_ahead_locked(h, queries_dev, ldq_floats, b, nprobe, (hipStream_t)stream);
 }
 
 int32_t vers_topk_merge_dev(const uint64_t* keys_dev, const uint64_t* ids_dev, uint64_t rank_stride, uint32_t world, uint32_t b,

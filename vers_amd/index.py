@@ -227,6 +227,11 @@ class IVFFlatIndex:
         check(lib().vers_ivf_owners(self._h, _ptr(o)))
         return o[:k]
 
+    def coarse_ahead_dev(self, q_ptr: int, ldq: int, b: int, nprobe: int, stream: int = 0):
+        """Stage and rank the NEXT batch's queries on the handle's side stream while the current batch is scanned
+        (vers_ivf_coarse_ahead_dev); the following search of the same query block picks the result up."""
+        check(lib().vers_ivf_coarse_ahead_dev(self._h, _vp(q_ptr), ldq, b, nprobe, _vp(stream)))
+
     def search_partial_dev(self, q_ptr: int, ldq: int, b: int, top_k: int, nprobe: int, keys_ptr: int, ids_ptr: int,
                            stream: int = 0):
         check(lib().vers_ivf_search_partial_dev(self._h, _vp(q_ptr), ldq, b, top_k, nprobe, _vp(keys_ptr), _vp(ids_ptr),
