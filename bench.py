@@ -188,7 +188,7 @@ def main():
     # counters itself); used only when it was measured on this exact configuration.
     pst = index.prescan_stats()
     mfma_scan = pst["batches"] > 0
-    kernel_name = ("prescan_kernel_g<IvfSrc<32>> (inverted-list scan on the f32 matrix cores; exact finish in ivf_rescore_kernel)" if mfma_scan
+    kernel_name = ("prescan_kernel_g<false, IvfSrc<32>> (inverted-list scan on the f32 matrix cores; exact finish in ivf_rescore_kernel)" if mfma_scan
                    else "scan_kernel<QG,0,IvfSrc<QG>> (inverted-list scan, ordered f32 chains; QG = 16 at this shape)")
     traffic = None
     try:
