@@ -1859,6 +1859,7 @@ int32_t vers_ivf_last_scan(vers_ivf_t* h, float* out_ms, uint64_t* out_union_row
     fprintf(stderr, "[vers stamps] items %llu: per item avg cycles: wait-for-loads %.0f  math %.0f  fold %.0f | per wave-quad-slot (%llu): stage %.0f  barrier-wait %.0f\n",
             sv[4], sv[4] ? (double)sv[0] / sv[4] : 0.0, sv[4] ? (double)sv[1] / sv[4] : 0.0, sv[4] ? (double)sv[2] / sv[4] : 0.0,
             sv[6], sv[6] ? (double)sv[3] / sv[6] : 0.0, sv[6] ? (double)sv[5] / sv[6] : 0.0);
+    fprintf(stderr, "[vers stamps] list merges under a lock %llu, candidates offered to them %llu\n", sv[12], sv[13]);
     fprintf(stderr, "[vers stamps] shader clock during the kernel: %.0f MHz\n", (double)sv[7] / (double)(1 << 20) * 100.0);
   }
   return VERS_OK;

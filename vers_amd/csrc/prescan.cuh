@@ -185,6 +185,11 @@ __device__ __forceinline__ void prescan_item_g(const Src& src, const PreParams& 
 #pragma unroll
   for (int e = 0; e < 16; ++e) acc[0][e] = acc[1][e] = 0.0f;
   bool bad = false;
+  // The eight waves of the block walk their tiles at the same pace and fold the same queries at the end of each:
+  // every wave starts its round over the query columns at its own offset, so that they do not all queue for the
+  // lock of the same list (bit i of a rotated mask = column (i + rot) & 15).
+  const int rot = (int)(((it & 3u) << 1 | (uint32_t)half) << 1);
+  auto rot16 = [&](uint32_t m) { return ((m >> rot) | (m << (16 - rot))) & 0xFFFFu; };
 
   // Fold per-lane candidate keys (kKeyMax = none) into query nn's block-wide sorted list under its lock.  Within a
   // wave LDS operations issue and complete in order, so the exchange that takes the lock precedes the list read and
@@ -231,11 +236,11 @@ __device__ __forceinline__ void prescan_item_g(const Src& src, const PreParams& 
     // 64 serial list inserts (~400 cycles each; with all waves of the launch starting cold that was ~0.4 ms of
     // the kernel).  Instead the tile's 64 vals of such a query are transposed through a 64-float LDS scratch
     // (lane == row again), the kp smallest are extracted by wave-min rounds and merged into the block's list.
-    if (t == t_begin && !(p.debug & 1u)) {
+    if (t == t_begin && !(p.debug & (1u | 2048u))) {  // (2048: ablation -- cold queries take the insert path)
       const bool cold = live[S] && thr[S] == __builtin_inff();
-      uint32_t qmask = (uint32_t)(__ballot(cold) & 0xFFFFull);  // lanes 0..15: one per query column
+      uint32_t qmask = rot16((uint32_t)(__ballot(cold) & 0xFFFFull));  // lanes 0..15: one per query column
       while (qmask) {
-        const int nn = __builtin_ctz(qmask);
+        const int nn = (__builtin_ctz(qmask) + rot) & 15;
         qmask &= qmask - 1;
         if (n == nn) {
 #pragma unroll
@@ -256,15 +261,15 @@ __device__ __forceinline__ void prescan_item_g(const Src& src, const PreParams& 
     uint64_t any = 0;
 #pragma unroll
     for (int e = 0; e < 16; ++e) any |= __ballot(a[e] <= thr[S]);
-    if (any != 0 && !(p.debug & 1u)) {
+    if (any != 0 && !(p.debug & (1u | 4096u))) {  // (4096: ablation -- only the cold-start fills insert)
       // All candidates of one query column go into its list under ONE lock hold: the column's rows sit in lanes
       // nn, nn+16, nn+32, nn+48 of the 16 registers, so 16 four-candidate merges (a ballot each when nothing passes).
       // (One lock round trip per candidate was ~400 cycles; a rank of an 8-way sharded index sees only ~4 lists per
       // query, its thresholds stay loose and a tile often carries several candidates of the same query.)
-      uint32_t qmask = (uint32_t)((any | (any >> 16) | (any >> 32) | (any >> 48)) & 0xFFFFull);
+      uint32_t qmask = rot16((uint32_t)((any | (any >> 16) | (any >> 32) | (any >> 48)) & 0xFFFFull));
       const uint32_t sq0 = vseq[S] + t * kWave + 4u * (uint32_t)quarter;
       while (qmask) {
-        const int nn = __builtin_ctz(qmask);
+        const int nn = (__builtin_ctz(qmask) + rot) & 15;
         qmask &= qmask - 1;
         const int ql = S * 16 + nn;
         const bool mine = n == nn;
@@ -274,15 +279,18 @@ __device__ __forceinline__ void prescan_item_g(const Src& src, const PreParams& 
           for (int e = 1; e < 16; ++e) again |= __ballot(mine && a[e] <= thr[S]);
           if (again == 0) continue;
         }
-        if (lane == 0)
+        if (lane == 0 && !(p.debug & 16384u))
           while (__hip_atomic_exchange(locks + ql, 1u, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u) __builtin_amdgcn_s_sleep(1);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         uint64_t* Ln = blk + (uint32_t)ql * kp;
         uint64_t cur = lane < (int)kp ? Ln[lane] : kKeyMax;
+        if (stamp && lane == 0) atomicAdd(p.stamps + 12, 1ull);
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
           const bool c = mine && a[e] <= thr[S];
-          if (__ballot(c) != 0) {
+          const uint64_t cm = __ballot(c);
+          if (cm != 0) {
+            if (stamp && lane == 0) atomicAdd(p.stamps + 13, (unsigned long long)__popcll(cm));
             wave_topk_update(cur, kp, c ? make_key(a[e], sq0 + 16u * (e >> 2) + (e & 3)) : kKeyMax, kKeyMax);
             const uint32_t kh = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(cur >> 32), (int)kp - 1);
             if (kh != 0xFFFFFFFFu && mine) {  // full: the later registers are tested against the tightened threshold
@@ -295,7 +303,7 @@ __device__ __forceinline__ void prescan_item_g(const Src& src, const PreParams& 
         const uint32_t kb = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(cur >> 32), (int)kp - 1);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         if (lane == 0) __hip_atomic_store(locks + ql, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (kb != 0xFFFFFFFFu && lane == nn) atomicMin(p.bounds32 + vslot[S], kb);
+        if (kb != 0xFFFFFFFFu && lane == nn && !(p.debug & 8192u)) atomicMin(p.bounds32 + vslot[S], kb);
       }
     }
 #pragma unroll
