@@ -258,14 +258,16 @@ __device__ __forceinline__ void prescan_item_g(const Src& src, const PreParams& 
         for (int e = 0; e < 16; ++e) a[e] = __builtin_nanf("");
       }
     }
-    uint64_t any = 0;
+    // Which of the lane's 16 vals pass its query's threshold: one bit per register.  A query column's rows sit in
+    // lanes nn, nn+16, nn+32, nn+48, so the OR of those four masks (scalar) tells which registers carry candidates.
+    uint32_t pm = 0;
 #pragma unroll
-    for (int e = 0; e < 16; ++e) any |= __ballot(a[e] <= thr[S]);
+    for (int e = 0; e < 16; ++e) pm |= a[e] <= thr[S] ? 1u << e : 0u;
+    const uint64_t any = __ballot(pm != 0);
     if (any != 0 && !(p.debug & (1u | 4096u))) {  // (4096: ablation -- only the cold-start fills insert)
-      // All candidates of one query column go into its list under ONE lock hold: the column's rows sit in lanes
-      // nn, nn+16, nn+32, nn+48 of the 16 registers, so 16 four-candidate merges (a ballot each when nothing passes).
-      // (One lock round trip per candidate was ~400 cycles; a rank of an 8-way sharded index sees only ~4 lists per
-      // query, its thresholds stay loose and a tile often carries several candidates of the same query.)
+      // All candidates of one query column go into its list under ONE lock hold, register by register (four lanes
+      // each); registers without a candidate cost a scalar bit test.  (One lock round trip per candidate was ~400
+      // cycles; per-register ballots inside the hold were most of the remaining instructions of a merge.)
       uint32_t qmask = rot16((uint32_t)((any | (any >> 16) | (any >> 32) | (any >> 48)) & 0xFFFFull));
       const uint32_t sq0 = vseq[S] + t * kWave + 4u * (uint32_t)quarter;
       while (qmask) {
@@ -273,37 +275,33 @@ __device__ __forceinline__ void prescan_item_g(const Src& src, const PreParams& 
         qmask &= qmask - 1;
         const int ql = S * 16 + nn;
         const bool mine = n == nn;
-        if (__ballot(mine && a[0] <= thr[S]) == 0) {  // (thr may have tightened since `any` was taken: look again before locking)
-          uint64_t again = 0;
-#pragma unroll
-          for (int e = 1; e < 16; ++e) again |= __ballot(mine && a[e] <= thr[S]);
-          if (again == 0) continue;
-        }
+        const uint32_t em = (uint32_t)__builtin_amdgcn_readlane((int)pm, nn) | (uint32_t)__builtin_amdgcn_readlane((int)pm, nn + 16) |
+                            (uint32_t)__builtin_amdgcn_readlane((int)pm, nn + 32) | (uint32_t)__builtin_amdgcn_readlane((int)pm, nn + 48);
         if (lane == 0 && !(p.debug & 16384u))
           while (__hip_atomic_exchange(locks + ql, 1u, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u) __builtin_amdgcn_s_sleep(1);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
         uint64_t* Ln = blk + (uint32_t)ql * kp;
         uint64_t cur = lane < (int)kp ? Ln[lane] : kKeyMax;
-        if (stamp && lane == 0) atomicAdd(p.stamps + 12, 1ull);
+        if (stamp) {
+          const unsigned long long nc = (unsigned long long)__popc(em);  // (registers with a candidate; <= 4 candidates each)
+          if (lane == 0) { atomicAdd(p.stamps + 12, 1ull); atomicAdd(p.stamps + 13, nc); }
+        }
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-          const bool c = mine && a[e] <= thr[S];
-          const uint64_t cm = __ballot(c);
-          if (cm != 0) {
-            if (stamp && lane == 0) atomicAdd(p.stamps + 13, (unsigned long long)__popcll(cm));
+          if (em & (1u << e)) {  // (wave-uniform)
+            const bool c = mine && (pm >> e & 1u) != 0;
             wave_topk_update(cur, kp, c ? make_key(a[e], sq0 + 16u * (e >> 2) + (e & 3)) : kKeyMax, kKeyMax);
-            const uint32_t kh = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(cur >> 32), (int)kp - 1);
-            if (kh != 0xFFFFFFFFu && mine) {  // full: the later registers are tested against the tightened threshold
-              const float nt = __uint_as_float(order_bits_to_f32_bits(kh));
-              thr[S] = nt < thr[S] ? nt : thr[S];
-            }
           }
         }
         if (lane < (int)kp) Ln[lane] = cur;
         const uint32_t kb = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(cur >> 32), (int)kp - 1);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         if (lane == 0) __hip_atomic_store(locks + ql, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (kb != 0xFFFFFFFFu && lane == nn && !(p.debug & 8192u)) atomicMin(p.bounds32 + vslot[S], kb);
+        if (kb != 0xFFFFFFFFu) {  // full: its last val bounds the query's kp-th smallest val
+          const float nt = __uint_as_float(order_bits_to_f32_bits(kb));
+          if (mine) thr[S] = nt < thr[S] ? nt : thr[S];
+          if (lane == nn && !(p.debug & 8192u)) atomicMin(p.bounds32 + vslot[S], kb);
+        }
       }
     }
 #pragma unroll
