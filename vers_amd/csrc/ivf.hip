@@ -693,9 +693,10 @@ int32_t refresh_norms(vers_ivf* h, uint64_t r_begin, uint64_t r_end, hipStream_t
     VERS_HIP_TRY(hipMemsetAsync(h->pre_misc.p, 0, 64, st));
     for (auto& a : h->ahead) a.valid = false;  // a new index: ranked lists computed ahead belong to the old centroids
   }
-  // EXPERIMENTAL, off unless VERS_SHADOW=1: bit-exact on every test and A/B run of its final form,
-  // but an earlier arrangement of the same arithmetic came out wrong in accumulator register 15 for a reason that is
-  // not understood -- not a default until it is.
+  // EXPERIMENTAL, off unless VERS_SHADOW=1: bit-exact on every test, fuzz and A/B run of its final
+  // form.  An earlier arrangement of the same arithmetic came out wrong in accumulator register 15 (an MFMA reading an
+  // operand the VALU had just written: prescan.cuh, scripts/probe/mfma_chain.hip); correctness that depends on instruction
+  // placement soaks before it becomes a default.
   static const bool shadow = [] { const char* e = getenv("VERS_SHADOW"); return e && atoi(e) != 0; }();
   if (shadow) {
     if (full) {
