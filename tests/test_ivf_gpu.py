@@ -169,3 +169,37 @@ def test_coarse_ahead_is_bit_identical():
     ix.coarse_ahead_dev(Q[2 * b:].data_ptr(), d, b, nprobe, st)
     a = run(2); ix2 = run(2)
     assert all(np.array_equal(x, y) for x, y in zip(a, ix2))
+
+
+def test_concurrent_searches_from_threads():
+    """`search_approximate(&self)` is a shared borrow in the reference (ivfflat.rs:153): many threads may search one
+    index at once.  The handle serialises them internally; every thread must get the serial answers, bit for bit."""
+    import threading
+    n, d, k = 12000, 64, 32
+    X = dg.dist_c(0x61, n, d, 4 * k, dg.default_sigma(d))
+    ix = IVFFlatIndex.build_index(k, 1, 3, X, init_indices=mg.init_draws(0x61, 1, k, n))
+    Q = dg.dist_c(0x62, 96, d, 4 * k, dg.default_sigma(d))
+    want_single = [ix.search_approximate(Q[i], 10) for i in range(Q.shape[0])]
+    want_batch = ix.search_batch(Q, 10, 6)
+    errors = []
+
+    def worker(t):
+        try:
+            for rep in range(3):
+                for i in range(t, Q.shape[0], 8):                     # reference mode, one query per call
+                    got = ix.search_approximate(Q[i], 10)
+                    assert [g[0] for g in got] == [w[0] for w in want_single[i]]
+                    assert np.array_equal(np.array([g[1] for g in got], dtype=np.float32).view(np.uint32),
+                                          np.array([w[1] for w in want_single[i]], dtype=np.float32).view(np.uint32))
+                ids, dist, cnt = ix.search_batch(Q, 10, 6)           # batched extension, all threads at once
+                assert np.array_equal(ids, want_batch[0]) and np.array_equal(cnt, want_batch[2])
+                assert np.array_equal(dist.view(np.uint32), want_batch[1].view(np.uint32))
+        except Exception as e:  # noqa: BLE001 -- reported below, in the main thread
+            errors.append((t, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(t,)) for t in range(8)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors[:3]
