@@ -215,6 +215,12 @@ int32_t vers_dev_copy(void* dst_dev, const void* src_dev, uint64_t bytes);
 int32_t vers_ivf_search_partial_dev(vers_ivf_t* h, const float* queries_dev, uint64_t ldq_floats, uint32_t b,
                                     uint32_t top_k, uint32_t nprobe, uint64_t* out_keys_dev,
                                     uint64_t* out_ids_dev, void* stream);
+/* Local part of utils::search_exhaustive (utils.rs:68-82) over the rows this rank stores: keys = (order-preserving
+ * distance bits << 32) | vec_id -- the reference's stable order, ties to the lower index -- so the same all-gather +
+ * vers_topk_merge_dev (any nprobe >= 1: global top-k by key) yields the brute-force result of the whole corpus. */
+int32_t vers_ivf_search_exhaustive_partial_dev(vers_ivf_t* h, const float* queries_dev, uint64_t ldq_floats, uint32_t b,
+                                               uint32_t top_k, uint32_t metric, uint64_t* out_keys_dev,
+                                               uint64_t* out_ids_dev, void* stream);
 /* Merge of the gathered partials into final results: rank r's keys at keys_dev + r*rank_stride
  * ([b][top_k], rank_stride in elements), ids likewise -- so one all-gathered [world][2][b][top_k]
  * buffer serves both with rank_stride = 2*b*top_k. */

@@ -74,6 +74,21 @@ def test_sharded_search_equals_unsharded(world):
             o_i, o_d = (co.search_approximate(whole.values, whole.centroids, whole.ids, Q[q], top_k) if nprobe == 0 else
                         co.search_nprobe(whole.values, whole.centroids, whole.ids, Q[q], top_k, nprobe))
             assert np.array_equal(gi[q, :len(o_i)], o_i) and np.array_equal(bits(gd[q, :len(o_i)]), bits(o_d))
+    # brute force (utils::search_exhaustive) over the row shards: same all-gather + merge, both metrics
+    for metric, top_k in [(capi.METRIC_L2SQ, 10), (capi.METRIC_COSDIST, 7), (capi.METRIC_L2SQ, 64)]:
+        keys = torch.empty(world, b, top_k, dtype=torch.int64, device="cuda")
+        ids = torch.empty(world, b, top_k, dtype=torch.int64, device="cuda")
+        for r, ix in enumerate(shards):
+            ix.search_exhaustive_partial_dev(Qd.data_ptr(), d, b, top_k, metric, keys[r].data_ptr(), ids[r].data_ptr())
+            ix.poll()
+        oi = torch.zeros(b, top_k, dtype=torch.int64, device="cuda")
+        od = torch.zeros(b, top_k, dtype=torch.float32, device="cuda")
+        oc = torch.zeros(b, dtype=torch.int32, device="cuda")
+        IVFFlatIndex.merge_partials_dev(keys.data_ptr(), ids.data_ptr(), b * top_k, world, b, top_k, 1, oi.data_ptr(), od.data_ptr(), oc.data_ptr())
+        torch.cuda.synchronize()
+        wi, wd, wc = whole.search_exhaustive(Q, top_k, metric)
+        assert np.array_equal(oc.cpu().numpy(), wc) and np.array_equal(oi.cpu().numpy().astype(np.uint64), wi)
+        assert np.array_equal(bits(od.cpu().numpy()), bits(wd))
     for ix in shards:
         ix.close()
     whole.close()

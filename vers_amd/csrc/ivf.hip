@@ -533,6 +533,18 @@ __global__ __launch_bounds__(kWave) void rank_merge_kernel(const uint64_t* keys,
   if (lane == 0) out_count[q] = cnt;
 }
 
+// local exhaustive results -> (key, vec_id) pairs for the cross-GPU merge: key = (order bits of the distance << 32) |
+// vec_id, the reference's stable order (utils.rs:77: ties -> lower index); kKeyMax padded
+__global__ void pack_exhaustive_keys_kernel(const uint64_t* ids, const float* dist, const uint32_t* cnt, uint32_t b, uint32_t k,
+                                            uint64_t* out_keys, uint64_t* out_ids) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= b * k) return;
+  const uint32_t q = i / k, j = i - q * k;
+  const bool have = j < cnt[q];
+  out_keys[i] = have ? make_key(dist[i], (uint32_t)ids[i]) : kKeyMax;
+  out_ids[i] = have ? ids[i] : ~0ull;
+}
+
 // ---- storage construction ---------------------------------------------------------------------
 // rows of X (vec_id order, row-major pitch ldx) -> cluster-major storage in lane-transposed tiles;
 // grid-stride over (sorted position, float4 column)
@@ -1804,6 +1816,25 @@ int32_t vers_ivf_search_exhaustive_dev(vers_ivf_t* h, const float* queries_dev, 
   DeviceGuard g(h->device);
   return exhaustive_dev_locked(h, queries_dev, ldq_floats, b, top_k, metric, out_ids_dev, out_dist_dev, out_count_dev,
                                (hipStream_t)stream);
+}
+
+int32_t vers_ivf_search_exhaustive_partial_dev(vers_ivf_t* h, const float* queries_dev, uint64_t ldq_floats, uint32_t b, uint32_t top_k,
+                                               uint32_t metric, uint64_t* out_keys_dev, uint64_t* out_ids_dev, void* stream) {
+  if (!h) return fail(VERS_ERR_INVALID, "null handle");
+  if (top_k == 0 || top_k > VERS_MAX_TOPK || metric > VERS_METRIC_COSDIST) return fail(VERS_ERR_INVALID, "unsupported top_k / metric");
+  if (b && (!queries_dev || ldq_floats < h->d || !out_keys_dev || !out_ids_dev))
+    return fail(VERS_ERR_INVALID, "vers_ivf_search_exhaustive_partial_dev: bad arguments");
+  if (b == 0) return VERS_OK;
+  std::lock_guard<std::mutex> lk(h->mu);
+  DeviceGuard g(h->device);
+  if (int32_t rc = ensure_out(h, (size_t)b * top_k, b)) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  if (int32_t rc = exhaustive_dev_locked(h, queries_dev, ldq_floats, b, top_k, metric, h->o_ids.as<uint64_t>(), h->o_dist.as<float>(),
+                                         h->o_cnt.as<uint32_t>(), st)) return rc;
+  hipLaunchKernelGGL(pack_exhaustive_keys_kernel, dim3((b * top_k + 255) / 256), dim3(256), 0, st, (const uint64_t*)h->o_ids.as<uint64_t>(),
+                     (const float*)h->o_dist.as<float>(), (const uint32_t*)h->o_cnt.as<uint32_t>(), b, top_k, out_keys_dev, out_ids_dev);
+  VERS_HIP_TRY(hipGetLastError());
+  return VERS_OK;
 }
 
 int32_t vers_ivf_search_exhaustive(vers_ivf_t* h, const float* queries, uint64_t q_stride_bytes, uint32_t b, uint32_t top_k,

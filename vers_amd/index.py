@@ -232,6 +232,12 @@ class IVFFlatIndex:
         (vers_ivf_coarse_ahead_dev); the following search of the same query block picks the result up."""
         check(lib().vers_ivf_coarse_ahead_dev(self._h, _vp(q_ptr), ldq, b, nprobe, _vp(stream)))
 
+    def search_exhaustive_partial_dev(self, q_ptr: int, ldq: int, b: int, top_k: int, metric: int, keys_ptr: int, ids_ptr: int,
+                                      stream: int = 0):
+        """Brute force over this rank's rows as (key, vec_id) pairs for merge_partials_dev (rows shard with the lists)."""
+        check(lib().vers_ivf_search_exhaustive_partial_dev(self._h, _vp(q_ptr), ldq, b, top_k, metric, _vp(keys_ptr), _vp(ids_ptr),
+                                                           _vp(stream)))
+
     def search_partial_dev(self, q_ptr: int, ldq: int, b: int, top_k: int, nprobe: int, keys_ptr: int, ids_ptr: int,
                            stream: int = 0):
         check(lib().vers_ivf_search_partial_dev(self._h, _vp(q_ptr), ldq, b, top_k, nprobe, _vp(keys_ptr), _vp(ids_ptr),
