@@ -1,7 +1,7 @@
 """Extended randomised check of the batched nprobe path (matrix-core list scan + exact finish) against the
 oracle: random n / d / lists / batch / nprobe / top_k, duplicated rows (ties), adds.  Every query of every batch
 is compared against a second run through the ordered-chain scan on the same handle state (bit equality), and a
-sample against the C oracle.  Development aid: python scripts/fuzz_prescan.py [seconds]"""
+sample against the C oracle.  Development aid: python scripts/fuzz_prescan.py [seconds [first seed]]"""
 import os, subprocess, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -46,7 +46,7 @@ def run(seed, env_extra, path):
     return r.stdout.strip().splitlines()[-1]
 
 budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
-t0 = time.time(); seed = 1000; n_ok = 0
+t0 = time.time(); seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1000; n_ok = 0
 while time.time() - t0 < budget:
     a = run(seed, {}, "/tmp/fz_a.npz"); bq = run(seed, {"VERS_PRESCAN": "0"}, "/tmp/fz_b.npz")
     A, B = np.load("/tmp/fz_a.npz"), np.load("/tmp/fz_b.npz")
