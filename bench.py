@@ -260,14 +260,31 @@ def main():
         while t_cpu < args.cpu_seconds and n_cpu < B:
             q = qh[n_cpu]
             t0 = time.perf_counter()
-            ranked, _ = co.search_exhaustive(cent, q, nprobe)            # all centroid distances + stable sort
+            ranked, _ = co.search_exhaustive(cent, q, nprobe if nprobe else cent.shape[0])  # all centroid distances + stable sort
             t_cpu += time.perf_counter() - t0
-            parts = [index.get_list(int(c)) for c in ranked]             # D2H of the probed lists: not timed
-            rows = np.concatenate([p[0] for p in parts], axis=0); rid = np.concatenate([p[1] for p in parts])
-            t0 = time.perf_counter()
-            pos, dd = co.search_exhaustive(rows, q, top_k)               # score every probed row, stable sort, take k
-            t_cpu += time.perf_counter() - t0
-            ok = (np.array_equal(rid[pos.astype(np.int64)], ids_h[n_cpu, :len(pos)])
+            if nprobe:
+                parts = [index.get_list(int(c)) for c in ranked]         # D2H of the probed lists: not timed
+                rows = np.concatenate([p[0] for p in parts], axis=0); rid = np.concatenate([p[1] for p in parts])
+                t0 = time.perf_counter()
+                pos, dd = co.search_exhaustive(rows, q, top_k)           # score every probed row, stable sort, take k
+                t_cpu += time.perf_counter() - t0
+                got_ids = rid[pos.astype(np.int64)]
+            else:  # the reference's own walk (ivfflat.rs:166-195): list j gives its top-min(remainder, len), concatenated
+                g_ids, g_d, rem = [], [], top_k
+                for c in ranked:
+                    rows, rid = index.get_list(int(c))                   # (not timed)
+                    if len(rid) == 0:
+                        continue
+                    t0 = time.perf_counter()
+                    pos, dl = co.search_exhaustive(rows, q, top_k)
+                    t_cpu += time.perf_counter() - t0
+                    take = min(rem, len(pos))
+                    g_ids.append(rid[pos[:take].astype(np.int64)]); g_d.append(dl[:take]); rem -= take
+                    if rem == 0:
+                        break
+                got_ids = np.concatenate(g_ids); dd = np.concatenate(g_d)
+                pos = got_ids
+            ok = (np.array_equal(got_ids, ids_h[n_cpu, :len(pos)])
                   and np.array_equal(dd.view(np.uint32), dst_h[n_cpu, :len(pos)].view(np.uint32)))
             mismatches += 0 if ok else 1
             n_cpu += 1
@@ -282,7 +299,7 @@ def main():
                "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 4),
                "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
                "recall_at_10": None if recall is None else round(recall, 4), "self_retrieval_ok": self_ok,
-               "config": {"workload": f"IVFFlat search_approximate, nprobe extension: N={n} d={d} nlist={nlist} nprobe={nprobe} "
+               "config": {"workload": f"IVFFlat search_approximate, {'nprobe extension' if nprobe else 'reference mode (nearest list + spill)'}: N={n} d={d} nlist={nlist} nprobe={nprobe} "
                                       f"batch={B} top_k={top_k}, f32, clustered unit vectors (Dist-C)",
                           "n": n, "d": d, "nlist": nlist, "nprobe": nprobe, "batch": B, "top_k": top_k,
                           "kmeans_iters": int(index.iterations[0]), "parallelism": f"lists sharded over {world} GPU(s)"},
