@@ -107,16 +107,15 @@ static __global__ void blocked_row_norms_kernel(const float* rows, uint32_t ld, 
 // 220 rows": ~900 inserts per query and batch instead of the ~170 a perfectly shared threshold needs; inserts
 // were 0.38 ms of 5.3 ms.)  One partial slot per (query, list, quad) goes to the exact finish.
 constexpr int kPreWavesG = 8;  // 4 items x 2 waves
-inline size_t prescan_lds_bytes_g(uint32_t ld, uint32_t kp) {  // query block | hand-out word | lists | locks | 64-float scratch per wave
-  return (size_t)ld * kPreQ * sizeof(float) + 16 + (size_t)kPreQ * kp * sizeof(uint64_t) + kPreQ * sizeof(uint32_t) +
-         (size_t)kPreWavesG * kWave * sizeof(float);
+inline size_t prescan_lds_bytes_g(uint32_t ld, uint32_t kp) {  // query block | hand-out word | lists | locks
+  return (size_t)ld * kPreQ * sizeof(float) + 16 + (size_t)kPreQ * kp * sizeof(uint64_t) + kPreQ * sizeof(uint32_t);
 }
 
 // BF: the row operand comes from the bf16 shadow copy (half the HBM bytes): a float4 load brings 8 columns of the
 // lane's row, expanded to f32 in the VALU (shift / mask) for the same f32 MFMA; the query operand stays f32.
 template <bool BF, class Src, class Stage>
 __device__ __forceinline__ void prescan_item_g(const Src& src, const PreParams& p, uint32_t it, const ItemView<kPreQ>& v, int half, int lane,
-                                               const float* qm, uint64_t* blk, uint32_t* locks, float* scratch, Stage&& stage) {
+                                               const float* qm, uint64_t* blk, uint32_t* locks, Stage&& stage) {
   const uint32_t n_tiles = (v.nrows + kWave - 1) / kWave;
   const uint32_t t_half = (n_tiles + 1) / 2;
   const uint32_t t_begin = half ? t_half : 0u, t_end = half ? n_tiles : t_half;
@@ -191,30 +190,6 @@ __device__ __forceinline__ void prescan_item_g(const Src& src, const PreParams& 
   const int rot = (int)(((it & 3u) << 1 | (uint32_t)half) << 1);
   auto rot16 = [&](uint32_t m) { return ((m >> rot) | (m << (16 - rot))) & 0xFFFFu; };
 
-  // Fold per-lane candidate keys (kKeyMax = none) into query nn's block-wide sorted list under its lock.  Within a
-  // wave LDS operations issue and complete in order, so the exchange that takes the lock precedes the list read and
-  // the list write precedes the store that frees it; the fences only pin the compiler.
-  auto merge_into = [&](int nn, uint64_t cand) {
-    if (lane == 0)
-      while (__hip_atomic_exchange(locks + nn, 1u, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u) __builtin_amdgcn_s_sleep(1);
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-    uint64_t* Ln = blk + (uint32_t)nn * kp;
-    uint64_t cur = lane < (int)kp ? Ln[lane] : kKeyMax;
-    wave_topk_update(cur, kp, cand, kKeyMax);
-    if (lane < (int)kp) Ln[lane] = cur;
-    const uint64_t k2 = readlane64(cur, (int)kp - 1);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    if (lane == 0) __hip_atomic_store(locks + nn, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-    if (k2 != kKeyMax) {  // full: its last val bounds the query's kp-th smallest val
-      const uint32_t kb = (uint32_t)(k2 >> 32);
-      const float nt = __uint_as_float(order_bits_to_f32_bits(kb));
-      if (n == (nn & 15)) {
-        if (nn < 16) thr[0] = nt < thr[0] ? nt : thr[0];
-        else thr[1] = nt < thr[1] ? nt : thr[1];
-      }
-      if (lane == (nn & 15)) atomicMin(p.bounds32 + (nn < 16 ? vslot[0] : vslot[1]), kb);
-    }
-  };
   // End of a tile for query set S: acc already holds val (the |x|^2 term went through the matrix core).  Each lane holds
   // 16 vals of ONE query column (lane & 15), rows 16*(e>>2) + 4*quarter + (e&3): one compare per register against the
   // lane's threshold decides whether anything happens at all.
@@ -232,32 +207,9 @@ __device__ __forceinline__ void prescan_item_g(const Src& src, const PreParams& 
 #pragma unroll
       for (int e = 0; e < 16; ++e) bad |= !(__builtin_fabsf(a[e]) < __builtin_inff());
     }
-    // Cold start: a query without any threshold yet would push all 64 rows of the item's first tile through
-    // 64 serial list inserts (~400 cycles each; with all waves of the launch starting cold that was ~0.4 ms of
-    // the kernel).  Instead the tile's 64 vals of such a query are transposed through a 64-float LDS scratch
-    // (lane == row again), the kp smallest are extracted by wave-min rounds and merged into the block's list.
-    if (t == t_begin && !(p.debug & (1u | 2048u))) {  // (2048: ablation -- cold queries take the insert path)
-      const bool cold = live[S] && thr[S] == __builtin_inff();
-      uint32_t qmask = rot16((uint32_t)(__ballot(cold) & 0xFFFFull));  // lanes 0..15: one per query column
-      while (qmask) {
-        const int nn = (__builtin_ctz(qmask) + rot) & 15;
-        qmask &= qmask - 1;
-        if (n == nn) {
-#pragma unroll
-          for (int bk = 0; bk < 4; ++bk)
-            *reinterpret_cast<f32x4*>(scratch + 16 * bk + 4 * quarter) = f32x4{a[4 * bk], a[4 * bk + 1], a[4 * bk + 2], a[4 * bk + 3]};
-        }
-        const float fv = scratch[lane];
-        const uint32_t sq = (uint32_t)__builtin_amdgcn_readlane((int)vseq[S], nn) + t * kWave + (uint32_t)lane;
-        uint64_t lst = kKeyMax;
-        wave_topk_fill(lst, kp, fv == fv ? make_key(fv, sq) : kKeyMax, lane);  // NaN = rows past the segment / non-finite (flagged)
-        merge_into(S * 16 + nn, lane < (int)kp ? lst : kKeyMax);
-      }
-      if (cold) {  // this tile of these queries is done
-#pragma unroll
-        for (int e = 0; e < 16; ++e) a[e] = __builtin_nanf("");
-      }
-    }
+    // (A query without a threshold yet -- thr = +inf -- passes all its finite vals: they enter the list in one lock
+    // hold like any other candidates.  A dedicated first-tile path, LDS transpose + wave-min extraction, measured no
+    // faster once the merges were batched: 4.82 / 4.83 ms on one GPU, 0.816 / 0.803 ms at 8 ranks with / without it.)
     // Which of the lane's 16 vals pass its query's threshold: one bit per register.  A query column's rows sit in
     // lanes nn, nn+16, nn+32, nn+48, so the OR of those four masks (scalar) tells which registers carry candidates.
     uint32_t pm = 0;
@@ -440,7 +392,6 @@ __global__ __launch_bounds__(kWave * kPreWavesG) __attribute__((amdgpu_waves_per
   uint32_t* nq_lds = reinterpret_cast<uint32_t*>(qlds + (size_t)p.ld * kPreQ);
   uint64_t* blk = reinterpret_cast<uint64_t*>(qlds + (size_t)p.ld * kPreQ + 4);  // [32 queries][kp] sorted keys, shared by the 8 waves
   uint32_t* locks = reinterpret_cast<uint32_t*>(blk + (size_t)kPreQ * p.kp);
-  float* scratch = reinterpret_cast<float*>(locks + kPreQ) + wid * kWave;
   const uint32_t n_quads = src.n_items() / 4;
   const unsigned long long clk0 = (p.debug & 16u) ? __builtin_amdgcn_s_memtime() : 0ull;
   const unsigned long long rt0 = (p.debug & 16u) ? __builtin_amdgcn_s_memrealtime() : 0ull;
@@ -507,7 +458,7 @@ __global__ __launch_bounds__(kWave * kPreWavesG) __attribute__((amdgpu_waves_per
         atomicAdd(p.stamps + 6, 1ull);
       }
     };
-    prescan_item_g<BF>(src, p, it, v, wid >> 2, lane, qlds, blk, locks, scratch, stage);
+    prescan_item_g<BF>(src, p, it, v, wid >> 2, lane, qlds, blk, locks, stage);
     prev_it0 = bi * 4;
     prev_nq = v.nq;
   }
