@@ -32,4 +32,6 @@ for i in range(20): step(3 + i)
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 20
 ix.poll(st)
 if os.environ.get("VERS_SCAN_DEBUG"): print("last scan:", ix.last_scan())   # (prints the phase stamps with VERS_SCAN_DEBUG=16)
-print(f"world={W} rank={R}: {dt*1e3:.3f} ms per step for this rank (list scan {float(np.mean(ix.scan_times()))*1e3:.0f} us)")
+pst = ix.prescan_stats()
+print(f"world={W} rank={R}: {dt*1e3:.3f} ms per step for this rank (list scan {float(np.mean(ix.scan_times()))*1e3:.0f} us; "
+      f"{pst['fallback_queries']} of {pst['batches'] * B} queries re-scanned exactly)")
