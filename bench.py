@@ -13,10 +13,12 @@ algorithmic bytes = bytes of the union of probed lists + centroids), `cpu_baseli
 restatement of the reference path, oracle/vers_oracle.c, timed on one host core on a bounded
 sample of the same queries), `recall_at_10`.
 
-Multi-GPU (`torchrun ... bench.py --gpus N`): strong scaling -- the SAME 10M corpus and the same
-query batches; the inverted lists are sharded across ranks (LPT by list length), every rank runs
-the replicated coarse quantiser and scans only its lists, partial top-k are exchanged with one
-RCCL all-gather and merged on every rank.
+Multi-GPU (`python bench.py --gpus N`, which starts its own N ranks, or `torchrun ... bench.py --gpus N`): strong
+scaling -- the SAME corpus and the same query batches.  No rank ever holds the corpus: rank r generates only rows
+[r*N/W, (r+1)*N/W), build_index runs row-sharded (vers_ivf_build_sharded_dev: local assign, chained exact centroid
+sums, rows shipped to the owners of their lists with one all-to-all), the inverted lists end up sharded by cluster
+(LPT by list length); per batch every rank runs the replicated coarse quantiser and scans only its lists, partial
+top-k are exchanged with ONE RCCL all-gather and merged on every rank.
 """
 from __future__ import annotations
 
@@ -57,13 +59,19 @@ def main():
     ap.add_argument("--no-recall", action="store_true")
     ap.add_argument("--ahead", action="store_true", help="compute the next batch's coarse quantiser on a side stream under the current "
                     "list scan (vers_ivf_coarse_ahead_dev; same-box A/B at cfg3: +0.8 %% -- the scan already fills the chip)")
-    ap.add_argument("--dist-build", action="store_true",
-                    help="N > 1: shard the k-means assign step over the ranks (one all-gather per pass) instead of building replicated")
     args = ap.parse_args()
+
+    # `python bench.py --gpus N` outside a launcher: this process becomes the parent of N ranks.  It has not touched
+    # the GPU (torch is not even imported yet) and never will; it relays rank 0's JSON line and the ranks' status.
+    from vers_amd.launch import spawn_ranks, under_launcher
+    if args.gpus > 1 and not under_launcher():
+        sys.exit(spawn_ranks(os.path.abspath(__file__), sys.argv[1:], args.gpus))
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != max(1, args.gpus):
+        log(f"[bench] --gpus {args.gpus} but the launcher started {world} rank(s): reporting n_gpus = {world}")
     import torch
     # one process per GPU.  (VERS_BENCH_BACKEND=gloo + fewer GPUs than ranks is a debugging aid only: it lets
     # the multi-rank code path run on a 1-GPU box, staging the all-gather through host memory.)
@@ -98,24 +106,30 @@ def main():
             dist.barrier()
 
     # ---- corpus + index (not timed) -----------------------------------------------------------------
+    # rank r generates and holds ONLY rows [lo, hi) (the generator is counter-based: any row on any GPU)
+    lo, hi = rank * n // world, (rank + 1) * n // world
     t0 = time.perf_counter()
-    X = torch.empty(n, ld, dtype=torch.float32, device=dev)
-    capi.gen_rows_dev(X.data_ptr(), n, d, ld, 1, SEED_X, SEED_C, n_modes, sigma)
+    X = torch.empty(hi - lo, ld, dtype=torch.float32, device=dev)
+    capi.gen_rows_dev(X.data_ptr(), hi - lo, d, ld, 1, SEED_X, SEED_C, n_modes, sigma, start_row=lo)
     torch.cuda.synchronize()
     t_gen = time.perf_counter() - t0
     init = (dg.mix64(np.uint64(0xB01D) + np.arange(nlist, dtype=np.uint64)) % np.uint64(n)).astype(np.uint64)
     index = IVFFlatIndex(d, device=dev_index)
-    if world > 1:
-        index.set_shard(rank, world)  # every rank ends with the same deterministic index and keeps only its lists
-        if args.dist_build:
-            index.set_build_shard(rank, world)  # (the build is outside the timed region either way)
+    capi.mem_stats(reset_peak=True)
     t0 = time.perf_counter()
-    kept = index.build_dev(X.data_ptr(), n, nlist, 1, args.kmeans_iters, init)
+    comm = None
+    if world > 1:
+        from vers_amd.dist import TorchComm
+        comm = TorchComm(device=dev_index)
+        kept = index.build_sharded_dev(X.data_ptr(), hi - lo, ld, lo, n, nlist, 1, args.kmeans_iters, init, comm)
+    else:
+        kept = index.build_dev(X.data_ptr(), n, nlist, 1, args.kmeans_iters, init)
     t_build = time.perf_counter() - t0
     assert kept
     del X
     torch.cuda.empty_cache()
     lens = index.list_lengths()
+    mem_now, mem_peak = capi.mem_stats()
     if rank == 0:
         import zlib
         fp = zlib.crc32(np.ascontiguousarray(index.get_centroids()).tobytes(), zlib.crc32(np.ascontiguousarray(lens).tobytes()))
@@ -126,6 +140,9 @@ def main():
             f"index fingerprint (centroid bits + list lengths) {fp:#010x}; matrix-core assign: {mp} points, {mf} re-done exactly")
     if world > 1 and rank == 0:
         own = index.owners()
+        log(f"[bench] row-sharded build over {world} ranks: {hi - lo} rows generated per rank, library device memory peak "
+            f"{mem_peak / 1e9:.2f} GB / now {mem_now / 1e9:.2f} GB on rank 0 (whole corpus: {n * d * 4 / 1e9:.2f} GB); "
+            f"exchange calls {comm.calls}, bytes {comm.bytes}")
         log(f"[bench] lists sharded over {world} ranks (LPT): rows per rank "
             f"{[int(lens[own == r].sum()) for r in range(world)]}")
 

@@ -38,6 +38,7 @@ extern "C" {
 #define VERS_ERR_INSUFFICIENT 3 /* reference: index out of bounds at ivfflat.rs:169 */
 #define VERS_ERR_HIP 4          /* HIP runtime failure */
 #define VERS_ERR_EMPTY 5        /* reference: min_by(..).unwrap() on zero centroids, ivfflat.rs:207 */
+#define VERS_ERR_COMM 6         /* a vers_comm_t callback of the host reported failure */
 
 #define VERS_METRIC_L2SQ 0    /* Vector::squared_euclidean, base.rs:119-126 (what IVFFlat uses) */
 #define VERS_METRIC_COSDIST 1 /* Vector::cosine_similarity(normalized=true) = 1 - dot, base.rs:153-155 */
@@ -124,19 +125,22 @@ int32_t vers_ivf_destroy(vers_ivf_t* h);
  * init_indices [num_attempts * num_clusters]: the draws of initialize_centroids
  * (ivfflat.rs:18-27: k indices WITH replacement from an unseeded thread_rng) are made
  * by the caller, so the Rust shim keeps using rand::thread_rng and tests can inject.
- * Outputs (host, caller-owned, nullable): out_centroids [k*d] packed, out_assignments
- * [n], out_cost (best cost), out_kept (0 when no attempt beat +inf, e.g. num_attempts
- * == 0: the index then has EMPTY centroids/assignments exactly like the reference),
- * out_iterations [num_attempts] loop bodies executed per attempt. */
+ * Outputs (host, caller-owned, nullable): out_centroids k rows of pitch c_stride_bytes
+ * (>= 4*d; a Vec<Vector<N>> is written in place with its own pitch round_up(4*N, 256),
+ * bytes between rows are left untouched), out_assignments [n], out_cost (best cost),
+ * out_kept (0 when no attempt beat +inf, e.g. num_attempts == 0: the index then has
+ * EMPTY centroids/assignments exactly like the reference), out_iterations
+ * [num_attempts] loop bodies executed per attempt. */
 int32_t vers_ivf_build(vers_ivf_t* h, const float* rows, uint64_t n, uint64_t row_stride_bytes,
                        uint64_t num_clusters, uint64_t num_attempts, uint64_t max_iterations,
-                       const uint64_t* init_indices, float* out_centroids, uint64_t* out_assignments,
-                       float* out_cost, int32_t* out_kept, uint64_t* out_iterations);
-/* Same with the vectors already in HBM (row-major, pitch ld_floats >= d, a multiple of 4). */
+                       const uint64_t* init_indices, float* out_centroids, uint64_t c_stride_bytes,
+                       uint64_t* out_assignments, float* out_cost, int32_t* out_kept, uint64_t* out_iterations);
+/* Same with the vectors already in HBM (row-major, pitch ld_floats >= d, a multiple of 4; columns
+ * d .. ld_floats-1 are the caller's padding: never read into the index, they may hold anything). */
 int32_t vers_ivf_build_dev(vers_ivf_t* h, const float* rows_dev, uint64_t n, uint64_t ld_floats,
                            uint64_t num_clusters, uint64_t num_attempts, uint64_t max_iterations,
-                           const uint64_t* init_indices, float* out_centroids, uint64_t* out_assignments,
-                           float* out_cost, int32_t* out_kept, uint64_t* out_iterations);
+                           const uint64_t* init_indices, float* out_centroids, uint64_t c_stride_bytes,
+                           uint64_t* out_assignments, float* out_cost, int32_t* out_kept, uint64_t* out_iterations);
 /* Rebuilds the device cache from the host fields (after Index::load_index): values,
  * centroids, assignments; ids[c] is implied (ascending positions with assignments == c,
  * which is what build_index + add produce). */
@@ -198,19 +202,48 @@ int32_t vers_shard_plan(const uint64_t* list_lengths, uint64_t k, uint32_t world
 /* Before build/upload: this handle keeps only the lists vers_shard_plan gives to `rank`. */
 int32_t vers_ivf_set_shard(vers_ivf_t* h, uint32_t rank, uint32_t world);
 int32_t vers_ivf_owners(vers_ivf_t* h, uint8_t* out_owner /* [k] */);
-/* build_index across processes (one per GPU, every process holds all rows): assign_to_clusters (ivfflat.rs:29-46,
- * ~all of the build time) is sharded by point range -- process `rank` assigns rows [rank*chunk, (rank+1)*chunk) --
- * and after each pass the library calls `exchange(ctx, assign_dev, min_dist_dev, n_padded, chunk)`: the caller
- * all-gathers IN PLACE (its own chunk sits at offset rank*chunk; u32 assignments, f32 minimum distances, the
- * latter nullable) with whatever collective it owns (RCCL all-gather over xGMI in vers_amd/dist.py) and returns 0.
- * update_centroids, the cost fold and the convergence test then run replicated, in the reference's order, on every
- * process, so centroids / assignments / cost are bit-identical to the single-process build.  Set before build. */
-typedef int32_t (*vers_assign_exchange_fn)(void* ctx, uint32_t* assign_dev, float* min_dist_dev, uint64_t n_padded,
-                                           uint64_t chunk);
-int32_t vers_ivf_set_build_shard(vers_ivf_t* h, uint32_t rank, uint32_t world, vers_assign_exchange_fn exchange,
-                                 void* ctx);
-/* Device-to-device copy (synchronous) for callers that hold raw device pointers only (the exchange callback). */
-int32_t vers_dev_copy(void* dst_dev, const void* src_dev, uint64_t bytes);
+/* ---- build_index over a ROW-SHARDED corpus (one process per GPU; no process ever holds all rows) ----------
+ * The library owns no communicator: the host hands it one as a table of callbacks over device buffers (RCCL over
+ * xGMI in vers_amd/dist.py through torch.distributed; a Rust host would put its own RCCL communicator behind the
+ * same five functions).  Every callback is SYNCHRONOUS from the library's point of view: the library has
+ * synchronised its stream before the call, and the data is in place when the callback returns 0.
+ *   all_gather   : recv_dev[r*bytes .. (r+1)*bytes) = rank r's send_dev[0 .. bytes)
+ *   send / recv  : point to point with `peer` (the chain of running sums below)
+ *   broadcast    : buf_dev of `root` to everyone
+ *   all_to_all_v : byte counts / offsets per peer, [world] each (rows to the owners of their lists) */
+typedef struct vers_comm {
+  void* ctx;
+  uint32_t rank, world;
+  int32_t (*all_gather)(void* ctx, const void* send_dev, void* recv_dev, uint64_t bytes);
+  int32_t (*send)(void* ctx, const void* buf_dev, uint64_t bytes, uint32_t peer);
+  int32_t (*recv)(void* ctx, void* buf_dev, uint64_t bytes, uint32_t peer);
+  int32_t (*broadcast)(void* ctx, void* buf_dev, uint64_t bytes, uint32_t root);
+  int32_t (*all_to_all_v)(void* ctx, const void* send_dev, const uint64_t* send_bytes, const uint64_t* send_off,
+                          void* recv_dev, const uint64_t* recv_bytes, const uint64_t* recv_off);
+} vers_comm_t;
+/* IVFFlatIndex::build_index (ivfflat.rs:102-136) where rank r holds rows [row_begin, row_begin + n_local) of the
+ * n_total vectors (contiguous ascending ranges in rank order; checked).  Bit-identical to the single-process build:
+ *   assign_to_clusters (:29-46)  every rank assigns its own rows -- no exchange;
+ *   update_centroids   (:47-71)  the reference adds the members of a cluster in ascending vec_id; rank r CONTINUES
+ *                                rank r-1's per-cluster running sums over its own range (k*d*4 bytes hop to the next
+ *                                rank, 12.6 MB at k=4096 d=768), the last rank divides by the all-gathered counts
+ *                                and broadcasts the centroids.  (A reduce-scatter of partial sums re-associates the
+ *                                f32 additions and cannot match the reference's order.)
+ *   cost               (:138-149) the f32 fold over the points is chained through the ranks the same way (4 bytes);
+ *   lists              (:123-127) lists are dealt to ranks by vers_shard_plan over the global lengths; every rank
+ *                                sends each row to the owner of its list (ONE all_to_all_v), where rows arrive in
+ *                                rank order = ascending vec_id.
+ * init_indices are GLOBAL row indices.  On return the handle is sharded by cluster exactly like
+ * vers_ivf_set_shard(rank, world) + build: centroids and all list lengths everywhere, rows of the owned lists only.
+ * out_assignments_local (host, nullable): [n_local] clusters of this rank's rows. */
+int32_t vers_ivf_build_sharded_dev(vers_ivf_t* h, const float* rows_dev, uint64_t n_local, uint64_t ld_floats,
+                                   uint64_t row_begin, uint64_t n_total, uint64_t num_clusters, uint64_t num_attempts,
+                                   uint64_t max_iterations, const uint64_t* init_indices, const vers_comm_t* comm,
+                                   uint64_t* out_assignments_local, float* out_cost, int32_t* out_kept,
+                                   uint64_t* out_iterations);
+/* Device memory the library holds in this process right now (rows, ids, scratch of every handle) and its high-water
+ * mark since the last reset -- lets a test assert that no rank of a sharded build ever allocated the whole corpus. */
+int32_t vers_mem_stats(uint64_t* out_bytes_now, uint64_t* out_bytes_peak, int32_t reset_peak);
 /* Local part of search_approximate: out_keys/out_ids [b*top_k], kKeyMax (all ones) padded. */
 int32_t vers_ivf_search_partial_dev(vers_ivf_t* h, const float* queries_dev, uint64_t ldq_floats, uint32_t b,
                                     uint32_t top_k, uint32_t nprobe, uint64_t* out_keys_dev,

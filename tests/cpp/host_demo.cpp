@@ -8,8 +8,6 @@
 
 #include "../../vers_amd/host/ivfflat.hpp"
 
-constexpr size_t N = 40;
-using V = vers::Vector<N>;
 
 static std::vector<uint8_t> slurp(const char* p) {
   FILE* f = std::fopen(p, "rb");
@@ -21,8 +19,11 @@ static std::vector<uint8_t> slurp(const char* p) {
   return b;
 }
 
-int main(int argc, char** argv) {
-  if (argc < 3) return 2;
+// N = 40: pitch 256 B for 160 B of data; N = 300: pitch 1280 B for 1200 B (the wiki-300d shape of the reference's
+// demo, utils.rs:173) -- in both the centroids come back IN PLACE into a Vec<Vector<N>> with that pitch.
+template <size_t N>
+int run(char** argv) {
+  using V = vers::Vector<N>;
   const auto buf = slurp(argv[1]);
   const uint8_t* p = buf.data();
   auto u64 = [&]() { uint64_t x; std::memcpy(&x, p, 8); p += 8; return x; };
@@ -38,6 +39,10 @@ int main(int argc, char** argv) {
   try {
     auto index = vers::IVFFlatIndex<N>::build_index(k, 1, iters, X, &init);
     for (uint64_t i = 0; i < n; ++i) bad += index.assignments[i] != u64();            // expected assignments
+    for (uint64_t c = 0; c < k; ++c) {                                                 // expected centroid bits
+      bad += std::memcmp(index.centroids[c].v, p, N * 4) != 0;
+      p += N * 4;
+    }
     index.add(extra, 12345);                                                          // vec_id ignored
     bad += index.assignments.size() != n + 1;
     index.save_index(argv[2]);
@@ -52,7 +57,7 @@ int main(int argc, char** argv) {
         bad += (i >= r.size()) || r[i].first != id || got != bits;
       }
     }
-    auto ex = vers::search_exhaustive<N>(re.values, Q[0], 5);
+    auto ex = vers::template search_exhaustive<N>(re.values, Q[0], 5);
     for (int i = 0; i < 5; ++i) { const uint64_t id = u64(); bad += ex[i].first != id; }
     // reference panics surface as vers::Panic: more results than vectors
     bool threw = false;
@@ -64,4 +69,12 @@ int main(int argc, char** argv) {
   }
   std::printf("host_demo mismatches=%d\n", bad);
   return bad ? 1 : 0;
+}
+
+int main(int argc, char** argv) {
+  if (argc < 4) return 2;
+  const int n = std::atoi(argv[3]);
+  if (n == 40) return run<40>(argv);
+  if (n == 300) return run<300>(argv);
+  return 2;
 }

@@ -1,0 +1,42 @@
+"""bench.py end to end on small shapes: the default single-GPU line carries the contract's keys, and `--gpus 2`
+starts its own two ranks (sharing the one GPU of the test box through gloo: VERS_BENCH_BACKEND=gloo), builds the
+index ROW-SHARDED and reports n_gpus = 2 with the same results (recall against the exact scan)."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SMALL = ["--rows", "20000", "--d", "64", "--nlist", "16", "--nprobe", "4", "--batch", "64", "--steps", "2", "--warmup", "1"]
+
+
+def run_bench(*extra, env=None):
+    e = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    e.update(env or {})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + SMALL + list(extra), capture_output=True, text=True, timeout=900, env=e)
+    assert r.returncode == 0, r.stderr[-4000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout
+    return json.loads(lines[0]), r.stderr
+
+
+def test_bench_single_gpu_line():
+    out, _ = run_bench("--cpu-seconds", "2")
+    assert out["n_gpus"] == 1 and out["unit"] == "queries/sec" and out["value"] > 0
+    for key in ("roofline", "cpu_baseline", "recall_at_10", "config", "ms_per_step", "scaling", "dtype"):
+        assert key in out
+    assert out["roofline"]["bound"] == "hbm" and 0 < out["roofline"]["frac"] < 1.5
+    assert out["cpu_baseline"]["gpu_matches_cpu_bitwise"] is True
+    assert out["self_retrieval_ok"] is True
+
+
+def test_bench_gpus_2_spawns_ranks_and_builds_row_sharded():
+    one, _ = run_bench("--no-cpu")
+    two, err = run_bench("--gpus", "2", "--no-cpu", env={"VERS_BENCH_BACKEND": "gloo"})
+    assert two["n_gpus"] == 2
+    assert "row-sharded build over 2 ranks: 10000 rows generated per rank" in err
+    assert two["recall_at_10"] == one["recall_at_10"]
+    assert two["config"]["kmeans_iters"] == one["config"]["kmeans_iters"]

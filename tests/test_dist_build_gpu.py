@@ -1,6 +1,9 @@
-"""build_index with the assign step sharded across processes (vers_ivf_set_build_shard): two and three processes
-share the one GPU of the test box and exchange through gloo (RCCL on a real node, same code path around it); every
-process must end with the single-process result -- centroid bits, assignments, cost bits -- which is the oracle's."""
+"""build_index over a ROW-SHARDED corpus (vers_ivf_build_sharded_dev): two and three processes share the one GPU of the
+test box and exchange through gloo (RCCL on a real node: same library code, same vers_comm_t callbacks).  Rank r holds
+only rows [begin_r, end_r) -- ragged ranges -- and must end with the single-process result, which is the oracle's:
+centroid bits, assignments, cost bits (the running sums and the cost fold are CHAINED through the ranks in the
+reference's ascending order: ivfflat.rs:47-71, 138-149), the lists dealt by LPT with rows in ascending vec_id
+(ivfflat.rs:123-127), and the sharded search over them == the oracle's search."""
 import os
 import socket
 
@@ -9,6 +12,15 @@ import pytest
 import torch.multiprocessing as mp
 
 pytestmark = pytest.mark.gpu
+
+N, D, K = 5003, 96, 70            # n is not a multiple of anything: ragged ranges, ragged tiles
+ATTEMPTS, ITERS = 2, 5
+
+
+def ranges(world):
+    cuts = [0] + [int(N * (r + 1) / world) + (7 * r if r + 1 < world else 0) for r in range(world)]
+    cuts[-1] = N
+    return cuts
 
 
 def worker(rank, world, port, force_mfma, ret):
@@ -20,15 +32,42 @@ def worker(rank, world, port, force_mfma, ret):
     dist.init_process_group("gloo", rank=rank, world_size=world)
     from tests import datagen as dg
     from tests.golden import make_golden as mg
+    from vers_amd import capi
+    from vers_amd.dist import TorchComm, all_gather_partials
     from vers_amd.index import IVFFlatIndex
-    n, d, k = 5003, 96, 70            # n is not a multiple of the 64-row chunk granularity: ragged last chunk
-    X = dg.dist_c(0xD1, n, d, 210, dg.default_sigma(d))
-    init = mg.init_draws(0xD1, 2, k, n)
-    ix = IVFFlatIndex.build_index(k, 2, 5, X, init_indices=init, device=0, build_shard=(rank, world))
-    q = dg.dist_c(0xD2, 40, d, 210, dg.default_sigma(d))
-    ids, dist_, cnt = ix.search_batch(q, 10, 6)
-    ret[rank] = (np.ascontiguousarray(ix.centroids).view(np.uint32).copy(), np.asarray(ix.assignments).copy(),
-                 np.float32(ix.cost).view(np.uint32), ids.copy(), dist_.view(np.uint32).copy())
+    cuts = ranges(world)
+    lo, hi = cuts[rank], cuts[rank + 1]
+    X = dg.dist_c(0xD1, N, D, 210, dg.default_sigma(D))
+    init = mg.init_draws(0xD1, ATTEMPTS, K, N)
+    ld = 100                                          # pitch wider than d: the padding columns carry junk
+    Xl = torch.full((hi - lo, ld), float("nan"), dtype=torch.float32, device="cuda")
+    Xl[:, :D] = torch.from_numpy(X[lo:hi]).cuda()
+    torch.cuda.synchronize()
+    capi.mem_stats(reset_peak=True)
+    comm = TorchComm(device=0)
+    ix = IVFFlatIndex(D, device=0)
+    kept = ix.build_sharded_dev(Xl.data_ptr(), hi - lo, ld, lo, N, K, ATTEMPTS, ITERS, init, comm, want_assignments=True)
+    _, peak = capi.mem_stats()
+    lens = ix.list_lengths(); own = ix.owners()
+    lists = {int(c): ix.get_list(int(c)) for c in range(K) if own[c] == rank}
+    # sharded search: partial top-k per rank, ONE all-gather, merge
+    Q = dg.dist_c(0xD2, 40, D, 210, dg.default_sigma(D))
+    Qd = torch.from_numpy(Q).cuda()
+    res = {}
+    for nprobe, top_k in [(0, 10), (6, 10)]:
+        part = torch.empty(2, 40, top_k, dtype=torch.int64, device="cuda")
+        ix.search_partial_dev(Qd.data_ptr(), D, 40, top_k, nprobe, part[0].data_ptr(), part[1].data_ptr())
+        ix.poll()
+        allp = all_gather_partials(part.cpu()).cuda()
+        oi = torch.zeros(40, top_k, dtype=torch.int64, device="cuda"); od = torch.zeros(40, top_k, device="cuda")
+        oc = torch.zeros(40, dtype=torch.int32, device="cuda")
+        IVFFlatIndex.merge_partials_dev(allp.data_ptr(), allp.data_ptr() + 8 * 40 * top_k, 2 * 40 * top_k, world, 40, top_k, nprobe,
+                                        oi.data_ptr(), od.data_ptr(), oc.data_ptr())
+        torch.cuda.synchronize()
+        res[nprobe] = (oi.cpu().numpy().astype(np.uint64), od.cpu().numpy().view(np.uint32), oc.cpu().numpy())
+    ret[rank] = dict(kept=kept, cent=np.ascontiguousarray(ix.get_centroids()).view(np.uint32).copy(), asg=ix.local_assignments.copy(),
+                     cost=np.float32(ix.cost).view(np.uint32), iters=ix.iterations.copy(), lens=lens, own=own, lists=lists,
+                     peak=peak, res=res, calls=dict(comm.calls), bytes=dict(comm.bytes))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -40,19 +79,65 @@ def free_port():
 
 
 @pytest.mark.parametrize("world,force_mfma", [(2, False), (3, True)])
-def test_sharded_assign_build_is_bit_exact(world, force_mfma):
+def test_row_sharded_build_is_bit_exact(world, force_mfma):
     from oracle import c_oracle as co
     from tests import datagen as dg
     from tests.golden import make_golden as mg
+    from vers_amd import capi
     mgr = mp.Manager()
     ret = mgr.dict()
     mp.spawn(worker, args=(world, free_port(), force_mfma, ret), nprocs=world, join=True)
-    n, d, k = 5003, 96, 70
-    X = dg.dist_c(0xD1, n, d, 210, dg.default_sigma(d))
-    o = co.build_index(X, k, 2, 5, mg.init_draws(0xD1, 2, k, n))
+    X = dg.dist_c(0xD1, N, D, 210, dg.default_sigma(D))
+    o = co.build_index(X, K, ATTEMPTS, ITERS, mg.init_draws(0xD1, ATTEMPTS, K, N))
+    o_lens = np.array([len(l) for l in o["ids"]], dtype=np.uint64)
+    owner = capi.shard_plan(o_lens, world)
+    cuts = ranges(world)
+    Q = dg.dist_c(0xD2, 40, D, 210, dg.default_sigma(D))
     for r in range(world):
-        cb, a, cost_bits, ids, db = ret[r]
-        assert np.array_equal(cb, np.ascontiguousarray(o["centroids"]).view(np.uint32)), r
-        assert np.array_equal(a, o["assignments"]), r
-        assert cost_bits == np.float32(o["cost"]).view(np.uint32), r
-        assert np.array_equal(ids, ret[0][3]) and np.array_equal(db, ret[0][4])
+        g = ret[r]
+        assert g["kept"]
+        assert np.array_equal(g["cent"], np.ascontiguousarray(o["centroids"]).view(np.uint32)), r
+        assert np.array_equal(g["asg"], o["assignments"][cuts[r]:cuts[r + 1]]), r
+        assert g["cost"] == np.float32(o["cost"]).view(np.uint32), r
+        assert np.array_equal(g["iters"], ret[0]["iters"]), r
+        assert np.array_equal(g["lens"], o_lens) and np.array_equal(g["own"], owner), r
+        for c, (rows, ids) in g["lists"].items():          # ascending vec_id inside a list, the rows themselves bit for bit
+            assert np.array_equal(ids, np.asarray(o["ids"][c], dtype=np.uint64)), (r, c)
+            assert np.array_equal(rows.view(np.uint32), X[np.asarray(o["ids"][c], dtype=np.int64)].view(np.uint32)), (r, c)
+        assert set(g["lists"]) == {c for c in range(K) if owner[c] == r}
+        # no rank ever held the corpus: its share of the rows (k-means input is the caller's) + exchange + storage
+        share = (cuts[r + 1] - cuts[r]) * D * 4
+        assert g["peak"] < 6 * share + (8 << 20), (r, g["peak"], share)
+        # the chain: per k-means pass one recv + one send of k*ld*4 bytes except at the ends
+        assert g["calls"]["all_to_all_v"] == 2
+        for nprobe, (gi, gd, gc) in g["res"].items():
+            for q in range(40):
+                oi, od = (co.search_approximate(X, o["centroids"], o["ids"], Q[q], 10) if nprobe == 0 else
+                          co.search_nprobe(X, o["centroids"], o["ids"], Q[q], 10, nprobe))
+                assert gc[q] == len(oi) and np.array_equal(gi[q, :len(oi)], oi) and np.array_equal(gd[q, :len(oi)], od.view(np.uint32)), (r, nprobe, q)
+
+
+def test_sharded_entry_point_with_one_rank_equals_plain_build():
+    """world == 1 through vers_ivf_build_sharded_dev (no callbacks are called) == vers_ivf_build."""
+    import ctypes as C
+    import torch
+    from oracle import c_oracle as co
+    from tests import datagen as dg
+    from tests.golden import make_golden as mg
+    from vers_amd.dist import VersComm
+    from vers_amd.index import IVFFlatIndex
+
+    class One:
+        struct = VersComm(None, 0, 1)
+        def ptr(self):
+            return C.byref(self.struct)
+    n, d, k = 1500, 40, 12
+    X = dg.dist_c(0xE1, n, d, 30, dg.default_sigma(d))
+    init = mg.init_draws(0xE1, 1, k, n)
+    ix = IVFFlatIndex(d)
+    Xd = torch.from_numpy(X).cuda()
+    assert ix.build_sharded_dev(Xd.data_ptr(), n, d, 0, n, k, 1, 4, init, One(), want_assignments=True)
+    o = co.build_index(X, k, 1, 4, init)
+    assert np.array_equal(ix.local_assignments, o["assignments"])
+    assert np.array_equal(ix.get_centroids().view(np.uint32), np.ascontiguousarray(o["centroids"]).view(np.uint32))
+    assert np.float32(ix.cost).view(np.uint32) == np.float32(o["cost"]).view(np.uint32)

@@ -29,9 +29,10 @@ def test_cpp_host_mirror_compiles_and_links(tmp_path):
 
 
 @pytest.mark.gpu
-def test_cpp_host_demo_matches_oracle(tmp_path):
+@pytest.mark.parametrize("d", [40, 300])  # 300: Vector<300> has pitch 1280 B for 1200 B of data (80 B of padding per row)
+def test_cpp_host_demo_matches_oracle(tmp_path, d):
     exe = compile_demo(str(tmp_path))
-    n, d, k, iters, top_k, n_q = 900, 40, 9, 4, 10, 5
+    n, k, iters, top_k, n_q = 900, 9, 4, 10, 5
     X = dg.dist_c(0x71, n, d, 12, dg.default_sigma(d))
     init = mg.init_draws(2, 1, k, n)
     b = co.build_index(X, k, 1, iters, init)
@@ -42,6 +43,7 @@ def test_cpp_host_demo_matches_oracle(tmp_path):
     Q = dg.dist_c(0x73, n_q, d, 12, dg.default_sigma(d)); Q[1] = extra
     blob = struct.pack("<5Q", n, k, iters, top_k, n_q) + X.tobytes() + init.astype("<u8").tobytes() + extra.tobytes() + Q.tobytes()
     blob += b["assignments"].astype("<u8").tobytes()
+    blob += np.ascontiguousarray(b["centroids"], dtype="<f4").tobytes()
     for q in Q:
         oi, od = co.search_approximate(values, b["centroids"], ids, q, top_k)
         blob += struct.pack("<Q", len(oi))
@@ -51,5 +53,5 @@ def test_cpp_host_demo_matches_oracle(tmp_path):
     blob += ei.astype("<u8").tobytes()
     fx = os.path.join(tmp_path, "fixture.bin")
     open(fx, "wb").write(blob)
-    r = subprocess.run([exe, fx, os.path.join(tmp_path, "ivfflat.index")], capture_output=True, text=True, timeout=300)
+    r = subprocess.run([exe, fx, os.path.join(tmp_path, "ivfflat.index"), str(d)], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "mismatches=0" in r.stdout, r.stdout + r.stderr

@@ -33,7 +33,7 @@ def test_sharded_search_equals_unsharded(world):
         cent = np.zeros((k, d), np.float32); asg = np.zeros(n, np.uint64)
         import ctypes as C
         cost = C.c_float(0); kept = C.c_int32(0)
-        capi.check(capi.lib().vers_ivf_build(ix._h, capi._ptr(X), n, 4 * d, k, 1, 4, capi._ptr(init), capi._ptr(cent),
+        capi.check(capi.lib().vers_ivf_build(ix._h, capi._ptr(X), n, 4 * d, k, 1, 4, capi._ptr(init), capi._ptr(cent), 4 * d,
                                              capi._ptr(asg), C.byref(cost), C.byref(kept), None))
         assert np.array_equal(asg, whole.assignments) and np.array_equal(bits(cent), bits(whole.centroids))
         shards.append(ix)

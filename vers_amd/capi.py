@@ -10,7 +10,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libvers_hip.so")
 
-OK, ERR_INVALID, ERR_NAN, ERR_INSUFFICIENT, ERR_HIP, ERR_EMPTY = 0, 1, 2, 3, 4, 5
+OK, ERR_INVALID, ERR_NAN, ERR_INSUFFICIENT, ERR_HIP, ERR_EMPTY, ERR_COMM = 0, 1, 2, 3, 4, 5, 6
 METRIC_L2SQ, METRIC_COSDIST = 0, 1
 MAX_TOPK = 64
 
@@ -42,9 +42,9 @@ SIGNATURES = {
     "vers_flat_last_scan_ms": (C.c_int32, [_vp, C.POINTER(C.c_float)]),
     "vers_ivf_create": (C.c_int32, [C.c_int32, C.c_uint32, C.POINTER(_vp)]),
     "vers_ivf_destroy": (C.c_int32, [_vp]),
-    "vers_ivf_build": (C.c_int32, [_vp, _vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, _vp, _vp, _vp,
+    "vers_ivf_build": (C.c_int32, [_vp, _vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, _vp, _vp, C.c_uint64, _vp,
                                    C.POINTER(C.c_float), C.POINTER(C.c_int32), _vp]),
-    "vers_ivf_build_dev": (C.c_int32, [_vp, _vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, _vp, _vp, _vp,
+    "vers_ivf_build_dev": (C.c_int32, [_vp, _vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, _vp, _vp, C.c_uint64, _vp,
                                        C.POINTER(C.c_float), C.POINTER(C.c_int32), _vp]),
     "vers_ivf_upload": (C.c_int32, [_vp, _vp, C.c_uint64, C.c_uint64, _vp, C.c_uint64, C.c_uint64, _vp]),
     "vers_ivf_add": (C.c_int32, [_vp, _vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
@@ -67,8 +67,9 @@ SIGNATURES = {
     "vers_ivf_coarse_stats": (C.c_int32, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "vers_ivf_prescan_stats": (C.c_int32, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "vers_ivf_shadow_state": (C.c_int32, [_vp, C.POINTER(C.c_int32), C.POINTER(C.c_uint64)]),
-    "vers_ivf_set_build_shard": (C.c_int32, [_vp, C.c_uint32, C.c_uint32, _vp, _vp]),
-    "vers_dev_copy": (C.c_int32, [_vp, _vp, C.c_uint64]),
+    "vers_ivf_build_sharded_dev": (C.c_int32, [_vp, _vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64,
+                                               C.c_uint64, _vp, _vp, _vp, C.POINTER(C.c_float), C.POINTER(C.c_int32), _vp]),
+    "vers_mem_stats": (C.c_int32, [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_int32]),
     "vers_ivf_scan_times": (C.c_int32, [_vp, _vp, C.c_uint32, C.POINTER(C.c_uint32), C.c_int32]),
     "vers_ivf_get_list": (C.c_int32, [_vp, C.c_uint64, _vp, C.c_uint64, _vp, C.c_uint64, C.POINTER(C.c_uint64)]),
     "vers_ivf_get_centroids": (C.c_int32, [_vp, _vp, C.c_uint64]),
@@ -238,5 +239,8 @@ def assign_stats(reset=False):
     return int(a.value), int(b.value)
 
 
-# exchange callback of the sharded build (include/vers_hip.h: vers_assign_exchange_fn)
-ASSIGN_EXCHANGE_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64)
+def mem_stats(reset_peak=False):
+    """(bytes of device memory the library holds now, high-water mark since the last reset) -- process-wide."""
+    a, b = C.c_uint64(0), C.c_uint64(0)
+    check(lib().vers_mem_stats(C.byref(a), C.byref(b), 1 if reset_peak else 0))
+    return int(a.value), int(b.value)

@@ -21,7 +21,7 @@ uint32_t scan_debug_flags() {
 
 extern "C" {
 const char* vers_last_error(void) { return vers::g_last_error.c_str(); }
-int32_t vers_abi_version(void) { return 1; }
+int32_t vers_abi_version(void) { return 2; }  // 2: c_stride_bytes on vers_ivf_build*
 int32_t vers_device_count(int32_t* out_count) {
   if (!out_count) return vers::fail(VERS_ERR_INVALID, "null out_count");
   int n = 0;

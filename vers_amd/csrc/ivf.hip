@@ -548,7 +548,8 @@ __global__ void pack_exhaustive_keys_kernel(const uint64_t* ids, const float* di
 // ---- storage construction ---------------------------------------------------------------------
 // rows of X (vec_id order, row-major pitch ldx) -> cluster-major storage in lane-transposed tiles;
 // grid-stride over (sorted position, float4 column)
-__global__ void gather_rows_kernel(const float* X, uint32_t ldx, uint32_t ld, const uint32_t* sorted_ids,
+// (columns >= d of X are the caller's padding and may hold anything: they are stored as zeros)
+__global__ void gather_rows_kernel(const float* X, uint32_t ldx, uint32_t d, uint32_t ld, const uint32_t* sorted_ids,
                                    const uint32_t* assign, const uint32_t* starts, const uint32_t* list_off,
                                    const uint8_t* owner, uint32_t rank, uint64_t n, float* rows, uint32_t* row_ids) {
   const uint32_t ld4 = ld / 4, ldx4 = ldx / 4;
@@ -561,7 +562,12 @@ __global__ void gather_rows_kernel(const float* X, uint32_t ldx, uint32_t ld, co
     if (owner != nullptr && owner[c] != rank) continue;  // another GPU's list
     const uint64_t dst = (uint64_t)list_off[c] + (p - starts[c]);
     f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
-    if (c4 < ldx4) v = reinterpret_cast<const f32x4*>(X + (uint64_t)id * ldx)[c4];
+    if (c4 < ldx4 && c4 * 4 < d) {
+      v = reinterpret_cast<const f32x4*>(X + (uint64_t)id * ldx)[c4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (c4 * 4 + u >= d) v[u] = 0.0f;
+    }
     *reinterpret_cast<f32x4*>(rows + blocked_index(dst, c4 * 4, ld)) = v;
     if (c4 == 0) row_ids[dst] = id;
   }
@@ -574,11 +580,11 @@ __global__ void scatter_row_kernel(const float* row, uint32_t ld, uint64_t dst, 
     *reinterpret_cast<f32x4*>(rows + blocked_index(dst, c4 * 4, ld)) = reinterpret_cast<const f32x4*>(row)[c4];
 }
 
-__global__ void gather_init_kernel(const float* X, uint32_t ldx, uint32_t ldc, const uint32_t* idx, uint32_t k, float* C) {
+__global__ void gather_init_kernel(const float* X, uint32_t ldx, uint32_t d, uint32_t ldc, const uint32_t* idx, uint32_t k, float* C) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= (uint64_t)k * ldc) return;
   const uint32_t j = (uint32_t)(i % ldc);
-  C[i] = j < ldx ? X[(uint64_t)idx[i / ldc] * ldx + j] : 0.0f;
+  C[i] = j < d ? X[(uint64_t)idx[i / ldc] * ldx + j] : 0.0f;
 }
 
 __global__ void u32_to_u64_kernel(const uint32_t* in, uint64_t n, uint64_t* out) {
@@ -616,10 +622,6 @@ struct vers_ivf {
   std::vector<uint32_t> h_off, h_len, h_cap;  // h_len = GLOBAL list lengths; h_off/h_cap only meaningful for owned lists
   // sharding by cluster across GPUs (one process per GPU): this handle stores only lists with owner == rank
   uint32_t rank = 0, world = 1;
-  // build_index with the assign step sharded by point range across processes (vers_ivf_set_build_shard)
-  uint32_t build_rank = 0, build_world = 1;
-  vers_assign_exchange_fn build_exchange = nullptr;
-  void* build_exchange_ctx = nullptr;
   std::vector<uint8_t> h_owner;
   DevBuf owner;
   uint64_t cap_rows = 0;
@@ -666,6 +668,10 @@ struct vers_ivf {
   hipStream_t ahead_stream = nullptr;
   hipEvent_t ahead_in = nullptr;
   uint64_t ahead_used = 0;  // searches that consumed a slot (statistics)
+  // status words: [0] latched by _dev calls and reported by vers_ivf_poll; [1] used by host-pointer calls and add, which
+  // synchronise and consume it themselves under the handle's mutex -- so neither side eats the other's bits
+  uint32_t st_slot = 0;
+  uint32_t* st_word() const { return status.as<uint32_t>() + st_slot; }
   GroupTotals last_tot{};
   const GroupTotals* tot_dev = nullptr;  // device totals of the last planned search
   bool tot_valid = false;
@@ -674,17 +680,23 @@ struct vers_ivf {
 
 namespace {
 
-int32_t status_to_rc(vers_ivf* h, uint32_t s);
-int32_t sync_status(vers_ivf* h, hipStream_t st) {
+int32_t status_to_rc(vers_ivf* h, uint32_t s, uint32_t slot);
+int32_t sync_status(vers_ivf* h, hipStream_t st) {  // the word of the _dev calls
   uint32_t s = 0;
   VERS_HIP_TRY(hipStreamSynchronize(st));
   VERS_HIP_TRY(hipMemcpy(&s, h->status.p, sizeof(s), hipMemcpyDeviceToHost));
-  return status_to_rc(h, s);
+  return status_to_rc(h, s, 0);
 }
+// host-pointer calls and add run with status word 1 while they hold the handle's mutex
+struct HostStatusSlot {
+  vers_ivf* h;
+  explicit HostStatusSlot(vers_ivf* hh) : h(hh) { h->st_slot = 1; }
+  ~HostStatusSlot() { h->st_slot = 0; }
+};
 // maps (and clears) the device status word of a finished search: the reference's panics
-int32_t status_to_rc(vers_ivf* h, uint32_t s) {
+int32_t status_to_rc(vers_ivf* h, uint32_t s, uint32_t slot) {
   if (s) {
-    VERS_HIP_TRY(hipMemset(h->status.p, 0, sizeof(s)));
+    VERS_HIP_TRY(hipMemset(h->status.as<uint32_t>() + slot, 0, sizeof(s)));
     if (s & kStNaN) return fail(VERS_ERR_NAN, "NaN distance (the reference panics in partial_cmp().unwrap())");
     if (s & kStInsufficient)
       return fail(VERS_ERR_INSUFFICIENT, "fewer than top_k vectors reachable (reference: index out of bounds, ivfflat.rs:169)");
@@ -716,7 +728,7 @@ int32_t refresh_norms(vers_ivf* h, uint64_t r_begin, uint64_t r_end, hipStream_t
       if (need > h->rows_bf.cap) {  // optional memory: a failed allocation just leaves the f32 rows in charge
         h->rows_bf.release();
         void* pbf = nullptr;
-        if (hipMalloc(&pbf, need) == hipSuccess) { h->rows_bf.p = pbf; h->rows_bf.cap = need; }
+        if (hipMalloc(&pbf, need) == hipSuccess) { h->rows_bf.p = pbf; h->rows_bf.cap = need; dev_mem_account((int64_t)need); }
         else (void)hipGetLastError();
       }
       h->shadow_off = false; h->shadow_queries = 0;  // (the failure counter in pre_misc was just zeroed)
@@ -737,16 +749,26 @@ int32_t refresh_norms(vers_ivf* h, uint64_t r_begin, uint64_t r_end, hipStream_t
   return VERS_OK;
 }
 
-// Lays the lists out cluster-major with slack and fills them from X (vec_id order).
-// d_assign/d_sorted/d_starts are device arrays for the n rows of X.
-int32_t build_storage(vers_ivf* h, const float* X, uint32_t ldx, uint64_t n, const uint32_t* d_assign,
-                      const uint32_t* d_sorted, const uint32_t* d_counts, const uint32_t* d_starts, uint32_t k,
-                      hipStream_t st) {
-  h->h_len.assign(k, 0);
+// ---- build: storage layout, row placement, k-means ------------------------------------------------------------
+// How the rows of a build are spread over processes.  comm == nullptr: one process holds all n rows.
+struct BuildShard {
+  const vers_comm_t* comm = nullptr;
+  uint32_t rank = 0, world = 1;
+  uint64_t row_begin = 0;  // global index of this process's first row
+  uint64_t n_total = 0;    // rows over all processes
+};
+
+int32_t comm_rc(int32_t rc, const char* what) {
+  if (rc) return fail(VERS_ERR_COMM, std::string("vers_comm_t::") + what + " reported failure (status " + std::to_string(rc) + ")");
+  return VERS_OK;
+}
+
+// Storage plan from the GLOBAL list lengths: owners (LPT when sharded), offsets and capacities of the owned lists,
+// device tables, zeroed row ids.
+int32_t plan_storage(vers_ivf* h, const uint32_t* lens, uint32_t k, hipStream_t st) {
+  h->h_len.assign(lens, lens + k);
   h->h_off.assign(k, 0);
   h->h_cap.assign(k, 0);
-  if (k) VERS_HIP_TRY(hipMemcpyAsync(h->h_len.data(), d_counts, (size_t)k * 4, hipMemcpyDeviceToHost, st));
-  VERS_HIP_TRY(hipStreamSynchronize(st));
   uint64_t off = 0;
   h->max_len = 0;
   h->h_owner.assign(k, 0);
@@ -776,16 +798,14 @@ int32_t build_storage(vers_ivf* h, const float* X, uint32_t ldx, uint64_t n, con
     VERS_HIP_TRY(hipMemcpyAsync(h->list_off.p, h->h_off.data(), (size_t)k * 4, hipMemcpyHostToDevice, st));
     VERS_HIP_TRY(hipMemcpyAsync(h->list_len.p, h->h_len.data(), (size_t)k * 4, hipMemcpyHostToDevice, st));
   }
-  if (n) {
-    hipLaunchKernelGGL(gather_rows_kernel, dim3(h->n_cu * 8), dim3(256), 0, st, X, ldx, h->ld, d_sorted, d_assign, d_starts,
-                       h->list_off.as<uint32_t>(), h->world > 1 ? h->owner.as<uint8_t>() : (const uint8_t*)nullptr, h->rank, n,
-                       h->rows.as<float>(), h->row_ids.as<uint32_t>());
-    VERS_HIP_TRY(hipGetLastError());
-  }
-  // centroids in the scan layout for the coarse quantiser
+  return VERS_OK;
+}
+
+// Everything of the index that derives from h->centroids and the stored rows: centroids in the scan layout and as
+// MFMA operands, |c|^2, |x|^2.  The index is complete (and the stream idle) on return.
+int32_t finish_index(vers_ivf* h, uint32_t k, uint64_t n_total, hipStream_t st) {
   if (int32_t rc = h->centroids_b.reserve(std::max<uint64_t>(1, blocked_floats(k, h->ld)) * sizeof(float))) return rc;
   if (int32_t rc = launch_to_blocked(h->centroids.as<float>(), h->ldx, h->d, k, h->centroids_b.as<float>(), h->ld, st)) return rc;
-  // operands of the MFMA pre-selection
   h->k_pad = round_up(k ? k : 1, kGemmBN);
   if (int32_t rc = h->centroids_g.reserve((size_t)h->k_pad * h->ldq * sizeof(float))) return rc;
   if (int32_t rc = h->cnorm.reserve((size_t)h->k_pad * sizeof(float))) return rc;
@@ -802,11 +822,16 @@ int32_t build_storage(vers_ivf* h, const float* X, uint32_t ldx, uint64_t n, con
   h->cmax2 = 0.0f;
   for (uint32_t c = 0; c < k; ++c) h->cmax2 = std::max(h->cmax2, cn[c]);  // NaN centroids never raise it; they fail the certificate
   h->k = k;
-  h->n_total = n;
-  return refresh_norms(h, 0, h->cap_rows, st);
+  h->n_total = n_total;
+  if (int32_t rc = refresh_norms(h, 0, h->cap_rows, st)) return rc;
+  // |x|^2, max |x|^2 and the optional shadow were queued on `st`; searches run on other (possibly non-blocking)
+  // streams and a certificate evaluated against a stale maximum would be unsound: the index is complete on return
+  VERS_HIP_TRY(hipStreamSynchronize(st));
+  return VERS_OK;
 }
 
-// index from (X, centroids already in h->centroids, device assignments)
+// index from (X in vec_id order -- ALL rows in this process --, centroids already in h->centroids, device assignments);
+// with vers_ivf_set_shard only the owned lists are stored.
 int32_t install_index(vers_ivf* h, const float* X, uint32_t ldx, uint64_t n, const uint32_t* d_assign, uint32_t k,
                       hipStream_t st) {
   DevBuf sorted;
@@ -815,74 +840,315 @@ int32_t install_index(vers_ivf* h, const float* X, uint32_t ldx, uint64_t n, con
   uint32_t* counts = h->km.counts.as<uint32_t>();
   uint32_t* starts = counts + k;
   if (int32_t rc = km_group(d_assign, (uint32_t)n, k, sorted.as<uint32_t>(), counts, starts, h->km, st)) return rc;
-  return build_storage(h, X, ldx, n, d_assign, sorted.as<uint32_t>(), counts, starts, k, st);
+  std::vector<uint32_t> lens(k ? k : 1, 0);
+  if (k) VERS_HIP_TRY(hipMemcpyAsync(lens.data(), counts, (size_t)k * 4, hipMemcpyDeviceToHost, st));
+  VERS_HIP_TRY(hipStreamSynchronize(st));
+  if (int32_t rc = plan_storage(h, lens.data(), k, st)) return rc;
+  if (n) {
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(h->n_cu * 8), dim3(256), 0, st, X, ldx, h->d, h->ld, sorted.as<uint32_t>(), d_assign, starts,
+                       h->list_off.as<uint32_t>(), h->world > 1 ? h->owner.as<uint8_t>() : (const uint8_t*)nullptr, h->rank, n,
+                       h->rows.as<float>(), h->row_ids.as<uint32_t>());
+    VERS_HIP_TRY(hipGetLastError());
+  }
+  return finish_index(h, k, n, st);
 }
 
-// build_kmeans + best-of-attempts (ivfflat.rs:73-121) on device-resident X; leaves the winning
-// centroids in h->centroids and assignments in best_assign.
-int32_t run_build(vers_ivf* h, const float* X, uint32_t ldx, uint64_t n, uint32_t k, uint64_t num_attempts, uint64_t max_iterations,
-                  const uint64_t* init_indices, DevBuf& best_assign, float* out_cost, int32_t* out_kept,
+// One destination segment of the row exchange: `count` consecutive rows of the receive buffer (one source rank's
+// members of one owned list, ascending vec_id) go to storage rows dest, dest + 1, ...
+struct RecvSeg {
+  uint32_t src_row, count, dest, pad;
+};
+
+// send side: local rows in (destination rank, cluster, ascending index) order, row-major pitch ldp, + their vec ids
+__global__ void pack_rows_kernel(const float* X, uint32_t ldx, uint32_t d, uint32_t ldp, const uint32_t* sorted_ids, const uint32_t* assign,
+                                 const uint32_t* starts, const uint32_t* send_base, uint32_t row_begin, uint64_t n, float* out, uint32_t* out_ids) {
+  const uint32_t ldp4 = ldp / 4, ldx4 = ldx / 4;
+  const uint64_t total = n * ldp4;
+  for (uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (uint64_t)gridDim.x * blockDim.x) {
+    const uint64_t p = i / ldp4;
+    const uint32_t c4 = (uint32_t)(i % ldp4);
+    const uint32_t id = sorted_ids[p];
+    const uint32_t c = assign[id];
+    const uint64_t dst = (uint64_t)send_base[c] + (p - starts[c]);
+    f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (c4 < ldx4 && c4 * 4 < d) {
+      v = reinterpret_cast<const f32x4*>(X + (uint64_t)id * ldx)[c4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u)
+        if (c4 * 4 + u >= d) v[u] = 0.0f;
+    }
+    reinterpret_cast<f32x4*>(out + dst * ldp)[c4] = v;
+    if (c4 == 0) out_ids[dst] = row_begin + id;
+  }
+}
+
+// receive side: block per segment, rows into the lane-transposed tiles of their list
+__global__ __launch_bounds__(256) void unpack_rows_kernel(const float* in, uint32_t ldp, const uint32_t* in_ids, const RecvSeg* segs, uint32_t ld,
+                                                          float* rows, uint32_t* row_ids) {
+  const RecvSeg sg = segs[blockIdx.x];
+  const uint32_t ld4 = ld / 4, ldp4 = ldp / 4;
+  const uint64_t total = (uint64_t)sg.count * ld4;
+  for (uint64_t i = threadIdx.x; i < total; i += blockDim.x) {
+    const uint32_t r = (uint32_t)(i / ld4), c4 = (uint32_t)(i % ld4);
+    f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+    if (c4 < ldp4) v = reinterpret_cast<const f32x4*>(in + (uint64_t)(sg.src_row + r) * ldp)[c4];
+    *reinterpret_cast<f32x4*>(rows + blocked_index((uint64_t)sg.dest + r, c4 * 4, ld)) = v;
+    if (c4 == 0) row_ids[sg.dest + r] = in_ids[sg.src_row + r];
+  }
+}
+
+__global__ void sum_counts_kernel(const uint32_t* counts_all, uint32_t world, uint32_t k, uint32_t* out) {
+  const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= k) return;
+  uint32_t s = 0;
+  for (uint32_t r = 0; r < world; ++r) s += counts_all[(uint64_t)r * k + c];
+  out[c] = s;
+}
+
+__global__ void scatter_centroid_rows_kernel(const float* tmp, uint32_t ld, const uint32_t* dst_c, uint32_t cnt, float* C) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (uint64_t)cnt * ld) return;
+  C[(uint64_t)dst_c[i / ld] * ld + i % ld] = tmp[i];
+}
+
+// Row-sharded install (ivfflat.rs:123-127 across processes): the lists are dealt to the ranks by LPT over the GLOBAL
+// lengths and every rank ships each of its rows to the owner of the row's list with ONE all_to_all_v (rows) + one for
+// the vec ids.  A rank sends its rows ordered by (destination, cluster, ascending local index); ranks hold ascending
+// ranges, so concatenating the sources in rank order inside a list IS the reference's ascending vec_id order.
+int32_t install_index_sharded(vers_ivf* h, const float* X, uint32_t ldx, uint64_t n_loc, const BuildShard& sh, const uint32_t* d_assign,
+                              uint32_t k, hipStream_t st) {
+  const vers_comm_t* cm = sh.comm;
+  const uint32_t W = sh.world, me = sh.rank;
+  DevBuf sorted, counts_all_d;
+  if (int32_t rc = sorted.reserve((n_loc ? n_loc : 1) * sizeof(uint32_t))) return rc;
+  if (int32_t rc = h->km.counts.reserve((2 * (size_t)k + 2) * sizeof(uint32_t))) return rc;
+  uint32_t* counts = h->km.counts.as<uint32_t>();
+  uint32_t* starts = counts + k;
+  if (int32_t rc = km_group(d_assign, (uint32_t)n_loc, k, sorted.as<uint32_t>(), counts, starts, h->km, st)) return rc;
+  if (int32_t rc = counts_all_d.reserve((size_t)W * (k ? k : 1) * 4)) return rc;
+  VERS_HIP_TRY(hipStreamSynchronize(st));
+  if (k)
+    if (int32_t rc = comm_rc(cm->all_gather(cm->ctx, counts, counts_all_d.p, (uint64_t)k * 4), "all_gather")) return rc;
+  std::vector<uint32_t> ca((size_t)W * (k ? k : 1), 0), starts_h((size_t)k + 1, 0);
+  if (k) {
+    VERS_HIP_TRY(hipMemcpy(ca.data(), counts_all_d.p, (size_t)W * k * 4, hipMemcpyDeviceToHost));
+    VERS_HIP_TRY(hipMemcpy(starts_h.data(), starts, ((size_t)k + 1) * 4, hipMemcpyDeviceToHost));
+  }
+  std::vector<uint32_t> lens(k ? k : 1, 0);
+  for (uint32_t c = 0; c < k; ++c) {
+    uint64_t s = 0;
+    for (uint32_t r = 0; r < W; ++r) s += ca[(size_t)r * k + c];
+    if (s > 0xFFFFFFFFull) return fail(VERS_ERR_INVALID, "a list longer than 2^32-1 rows");
+    lens[c] = (uint32_t)s;
+  }
+  h->rank = me;
+  h->world = W;
+  if (int32_t rc = plan_storage(h, lens.data(), k, st)) return rc;
+  // send plan: rows for destination t = my members of the lists t owns, clusters ascending
+  const uint32_t ldp = h->ldx;  // packed rows travel with the k-means pitch (d rounded up to 4 floats)
+  std::vector<uint64_t> send_rows(W, 0), send_off_rows(W, 0), recv_rows(W, 0), recv_off_rows(W, 0);
+  for (uint32_t c = 0; c < k; ++c) send_rows[h->h_owner[c]] += ca[(size_t)me * k + c];
+  for (uint32_t t = 1; t < W; ++t) send_off_rows[t] = send_off_rows[t - 1] + send_rows[t - 1];
+  std::vector<uint32_t> send_base(k ? k : 1, 0);
+  {
+    std::vector<uint64_t> cur(send_off_rows);
+    for (uint32_t c = 0; c < k; ++c) {
+      send_base[c] = (uint32_t)cur[h->h_owner[c]];
+      cur[h->h_owner[c]] += ca[(size_t)me * k + c];
+    }
+  }
+  // receive plan: from source s my owned lists' members, clusters ascending
+  std::vector<RecvSeg> segs;
+  for (uint32_t s = 0; s < W; ++s) {
+    for (uint32_t c = 0; c < k; ++c)
+      if (h->h_owner[c] == me) recv_rows[s] += ca[(size_t)s * k + c];
+    if (s) recv_off_rows[s] = recv_off_rows[s - 1] + recv_rows[s - 1];
+  }
+  {
+    std::vector<uint32_t> before(k ? k : 1, 0);  // members of list c that came from ranks before s
+    for (uint32_t s = 0; s < W; ++s) {
+      uint64_t r0 = recv_off_rows[s];
+      for (uint32_t c = 0; c < k; ++c) {
+        if (h->h_owner[c] != me) continue;
+        const uint32_t cnt = ca[(size_t)s * k + c];
+        if (cnt) segs.push_back(RecvSeg{(uint32_t)r0, cnt, h->h_off[c] + before[c], 0u});
+        r0 += cnt;
+        before[c] += cnt;
+      }
+    }
+  }
+  const uint64_t n_recv = recv_off_rows[W - 1] + recv_rows[W - 1];
+  if (n_recv > 0xFFFFFFFFull) return fail(VERS_ERR_INVALID, "more than 2^32-1 rows received by one rank");
+  DevBuf sbuf, sids, rbuf, rids, dbase, dsegs;
+  if (int32_t rc = sbuf.reserve((n_loc ? n_loc : 1) * (size_t)ldp * 4)) return rc;
+  if (int32_t rc = sids.reserve((n_loc ? n_loc : 1) * 4)) return rc;
+  if (int32_t rc = rbuf.reserve((n_recv ? n_recv : 1) * (size_t)ldp * 4)) return rc;
+  if (int32_t rc = rids.reserve((n_recv ? n_recv : 1) * 4)) return rc;
+  if (int32_t rc = dbase.reserve((k ? k : 1) * 4)) return rc;
+  if (int32_t rc = dsegs.reserve((segs.size() ? segs.size() : 1) * sizeof(RecvSeg))) return rc;
+  if (k) VERS_HIP_TRY(hipMemcpyAsync(dbase.p, send_base.data(), (size_t)k * 4, hipMemcpyHostToDevice, st));
+  if (!segs.empty()) VERS_HIP_TRY(hipMemcpyAsync(dsegs.p, segs.data(), segs.size() * sizeof(RecvSeg), hipMemcpyHostToDevice, st));
+  if (n_loc) {
+    hipLaunchKernelGGL(pack_rows_kernel, dim3(h->n_cu * 8), dim3(256), 0, st, X, ldx, h->d, ldp, sorted.as<uint32_t>(), d_assign, starts,
+                       dbase.as<uint32_t>(), (uint32_t)sh.row_begin, n_loc, sbuf.as<float>(), sids.as<uint32_t>());
+    VERS_HIP_TRY(hipGetLastError());
+  }
+  VERS_HIP_TRY(hipStreamSynchronize(st));
+  std::vector<uint64_t> sb(W), so(W), rb(W), ro(W);
+  for (uint32_t t = 0; t < W; ++t) {
+    sb[t] = send_rows[t] * ldp * 4; so[t] = send_off_rows[t] * ldp * 4;
+    rb[t] = recv_rows[t] * ldp * 4; ro[t] = recv_off_rows[t] * ldp * 4;
+  }
+  if (int32_t rc = comm_rc(cm->all_to_all_v(cm->ctx, sbuf.p, sb.data(), so.data(), rbuf.p, rb.data(), ro.data()), "all_to_all_v")) return rc;
+  for (uint32_t t = 0; t < W; ++t) {
+    sb[t] = send_rows[t] * 4; so[t] = send_off_rows[t] * 4;
+    rb[t] = recv_rows[t] * 4; ro[t] = recv_off_rows[t] * 4;
+  }
+  if (int32_t rc = comm_rc(cm->all_to_all_v(cm->ctx, sids.p, sb.data(), so.data(), rids.p, rb.data(), ro.data()), "all_to_all_v")) return rc;
+  sbuf.release();
+  sids.release();
+  // (capacity slack and tile padding of the storage are zero rows: (0 - q)^2 terms never enter a result, ids stay 0xFFFFFFFF)
+  VERS_HIP_TRY(hipMemsetAsync(h->rows.p, 0, (h->cap_rows ? h->cap_rows : 1) * (size_t)h->ld * sizeof(float), st));
+  if (!segs.empty()) {
+    hipLaunchKernelGGL(unpack_rows_kernel, dim3((unsigned)segs.size()), dim3(256), 0, st, rbuf.as<float>(), ldp, rids.as<uint32_t>(),
+                       dsegs.as<RecvSeg>(), h->ld, h->rows.as<float>(), h->row_ids.as<uint32_t>());
+    VERS_HIP_TRY(hipGetLastError());
+  }
+  VERS_HIP_TRY(hipStreamSynchronize(st));
+  rbuf.release();
+  rids.release();
+  return finish_index(h, k, sh.n_total, st);
+}
+
+// build_kmeans + best-of-attempts (ivfflat.rs:73-121) on device-resident rows -- ALL of them (sh.comm == nullptr) or
+// this process's contiguous range of a row-sharded corpus; leaves the winning centroids in h->centroids and the
+// assignments of the LOCAL rows in best_assign.  Same arithmetic order either way (see vers_hip.h).
+int32_t run_build(vers_ivf* h, const float* X, uint32_t ldx, uint64_t n, const BuildShard& sh, uint32_t k, uint64_t num_attempts,
+                  uint64_t max_iterations, const uint64_t* init_indices, DevBuf& best_assign, float* out_cost, int32_t* out_kept,
                   uint64_t* out_iterations, hipStream_t st) {
   const uint32_t ld = h->ldx;  // centroids live row-major with pitch ldx during k-means
-  // Point range of this process for assign_to_clusters: [a_begin, a_end) of equal-sized chunks; after every pass the
-  // caller's exchange (one all-gather) makes all n assignments (and minimum distances) valid everywhere.  Every
-  // other step (update, cost, convergence test) runs replicated and in the reference's order on every process.
-  const uint64_t a_chunk = h->build_world > 1 ? round_up64((n + h->build_world - 1) / h->build_world, 64) : n;
-  const uint64_t a_pad = h->build_world > 1 ? a_chunk * h->build_world : n;
-  const uint64_t a_begin = std::min<uint64_t>(n, (uint64_t)h->build_rank * a_chunk), a_end = std::min<uint64_t>(n, a_begin + a_chunk);
-  auto assign_pass = [&](bool mfma, const float* Cc, uint32_t* a_out, float* m_out) -> int32_t {
-    if (a_end > a_begin)
-      if (int32_t rc = (mfma ? km_assign_mfma : km_assign)(X + a_begin * ldx, ldx, a_end - a_begin, Cc, ld, k, h->d, a_out + a_begin,
-                                                           m_out ? m_out + a_begin : nullptr, h->km, h->n_cu, st))
-        return rc;
-    if (h->build_world > 1) {
-      VERS_HIP_TRY(hipStreamSynchronize(st));
-      if (int32_t rc = h->build_exchange(h->build_exchange_ctx, a_out, m_out, a_pad, a_chunk))
-        return fail(VERS_ERR_INVALID, "vers_ivf_build: the assign exchange callback failed (status " + std::to_string(rc) + ")");
+  const vers_comm_t* cm = sh.comm;
+  const uint32_t W = sh.world, me = sh.rank;
+  const bool multi = cm != nullptr && W > 1;
+  // the ranges of all ranks (contiguous, ascending, covering 0 .. n_total)
+  std::vector<uint64_t> begins(W + 1, 0);
+  begins[W] = sh.n_total;
+  if (multi) {
+    DevBuf mine, all;
+    if (int32_t rc = mine.reserve(16)) return rc;
+    if (int32_t rc = all.reserve(16 * (size_t)W)) return rc;
+    const uint64_t my[2] = {sh.row_begin, n};
+    VERS_HIP_TRY(hipMemcpy(mine.p, my, 16, hipMemcpyHostToDevice));
+    if (int32_t rc = comm_rc(cm->all_gather(cm->ctx, mine.p, all.p, 16), "all_gather")) return rc;
+    std::vector<uint64_t> rg(2 * (size_t)W);
+    VERS_HIP_TRY(hipMemcpy(rg.data(), all.p, 16 * (size_t)W, hipMemcpyDeviceToHost));
+    uint64_t expect = 0;
+    for (uint32_t r = 0; r < W; ++r) {
+      if (rg[2 * r] != expect) return fail(VERS_ERR_INVALID, "vers_ivf_build_sharded_dev: the ranks' row ranges are not contiguous and ascending in rank order");
+      begins[r] = rg[2 * r];
+      expect += rg[2 * r + 1];
     }
-    return VERS_OK;
-  };
-  DevBuf C, Cn, assign, mind, sorted, idx, bestC;
+    if (expect != sh.n_total) return fail(VERS_ERR_INVALID, "vers_ivf_build_sharded_dev: the ranks' row counts do not add up to n_total");
+  }
+  DevBuf C, Cn, S, assign, mind, sorted, idx, idx2, bestC, counts_all, counts_g, tmp_rows, ctl, ctl_all;
   const size_t cbytes = ((size_t)k * ld ? (size_t)k * ld : 1) * sizeof(float);
   if (int32_t rc = C.reserve(cbytes)) return rc;
   if (int32_t rc = Cn.reserve(cbytes)) return rc;
   if (int32_t rc = bestC.reserve(cbytes)) return rc;
-  if (int32_t rc = assign.reserve((a_pad ? a_pad : 1) * 4)) return rc;
+  if (int32_t rc = assign.reserve((n ? n : 1) * 4)) return rc;
   if (int32_t rc = best_assign.reserve((n ? n : 1) * 4)) return rc;
-  if (int32_t rc = mind.reserve((a_pad ? a_pad : 1) * 4)) return rc;
+  if (int32_t rc = mind.reserve((n ? n : 1) * 4)) return rc;
   if (int32_t rc = sorted.reserve((n ? n : 1) * 4)) return rc;
   if (int32_t rc = idx.reserve((k ? k : 1) * 4)) return rc;
   if (int32_t rc = h->km.counts.reserve((2 * (size_t)k + 2) * 4)) return rc;
   if (int32_t rc = h->km.misc.reserve(64)) return rc;
   if (int32_t rc = h->km.status.reserve(16)) return rc;
+  if (multi) {
+    if (int32_t rc = S.reserve(cbytes)) return rc;
+    if (int32_t rc = idx2.reserve((k ? k : 1) * 4)) return rc;
+    if (int32_t rc = tmp_rows.reserve(cbytes)) return rc;
+    if (int32_t rc = counts_all.reserve((size_t)W * (k ? k : 1) * 4)) return rc;
+    if (int32_t rc = counts_g.reserve((k ? k : 1) * 4)) return rc;
+    if (int32_t rc = ctl.reserve(16)) return rc;
+    if (int32_t rc = ctl_all.reserve(16 * (size_t)W)) return rc;
+  }
   VERS_HIP_TRY(hipMemsetAsync(h->km.status.p, 0, 16, st));
   uint32_t* counts = h->km.counts.as<uint32_t>();
   uint32_t* starts = counts + k;
   float* cost_dev = h->km.misc.as<float>();
+  float* cost_in = cost_dev + 1;
   uint32_t* flag_dev = h->km.misc.as<uint32_t>() + 4;
   float best = INFINITY;
   *out_kept = 0;
-  const bool mfma = km_use_mfma(a_end - a_begin, k, h->d) || (h->build_world > 1 && km_use_mfma(n, k, h->d));
-  std::vector<uint32_t> idx32(k ? k : 1);
+  const bool mfma = km_use_mfma(n, k, h->d);
+  auto assign_pass = [&](const float* Cc, uint32_t* a_out, float* m_out) -> int32_t {
+    if (n == 0) return VERS_OK;
+    return (mfma ? km_assign_mfma : km_assign)(X, ldx, n, Cc, ld, k, h->d, a_out, m_out, h->km, h->n_cu, st);
+  };
+  std::vector<uint32_t> src32(k ? k : 1), dst32(k ? k : 1);
   for (uint64_t a = 0; a < num_attempts; ++a) {
-    if (n > 0 && k == 0) return fail(VERS_ERR_EMPTY, "build_index with zero clusters: min_by over no centroids (reference panics)");
-    for (uint32_t c = 0; c < k; ++c) {
-      const uint64_t ix = init_indices[a * k + c];
-      if (ix >= n) return fail(VERS_ERR_INVALID, "vers_ivf_build: init index out of range");
-      idx32[c] = (uint32_t)ix;
-    }
-    if (k) {
-      VERS_HIP_TRY(hipMemcpyAsync(idx.p, idx32.data(), (size_t)k * 4, hipMemcpyHostToDevice, st));
-      VERS_HIP_TRY(hipStreamSynchronize(st));  // idx32 is reused by the next attempt
-      hipLaunchKernelGGL(gather_init_kernel, dim3((unsigned)(((uint64_t)k * ld + 255) / 256)), dim3(256), 0, st, X, ldx, ld,
-                         idx.as<uint32_t>(), k, C.as<float>());
+    if (sh.n_total > 0 && k == 0) return fail(VERS_ERR_EMPTY, "build_index with zero clusters: min_by over no centroids (reference panics)");
+    for (uint32_t c = 0; c < k; ++c)
+      if (init_indices[a * k + c] >= sh.n_total) return fail(VERS_ERR_INVALID, "vers_ivf_build: init index out of range");
+    // initialize_centroids (ivfflat.rs:18-27, draws injected): C[c] = row init[c].  Sharded: the rows drawn from rank
+    // r's range are gathered there and broadcast (bit copies), everyone scatters them to their centroid slots.
+    for (uint32_t r = 0; r < W && k; ++r) {
+      uint32_t cnt = 0;
+      for (uint32_t c = 0; c < k; ++c) {
+        const uint64_t ix = init_indices[a * k + c];
+        if (ix >= begins[r] && ix < begins[r + 1]) { src32[cnt] = (uint32_t)(ix - begins[r]); dst32[cnt] = c; ++cnt; }
+      }
+      if (!multi) {  // one process: straight into C
+        VERS_HIP_TRY(hipMemcpyAsync(idx.p, src32.data(), (size_t)k * 4, hipMemcpyHostToDevice, st));
+        VERS_HIP_TRY(hipStreamSynchronize(st));  // src32 is reused by the next attempt
+        hipLaunchKernelGGL(gather_init_kernel, dim3((unsigned)(((uint64_t)k * ld + 255) / 256)), dim3(256), 0, st, X, ldx, h->d, ld,
+                           idx.as<uint32_t>(), k, C.as<float>());
+        VERS_HIP_TRY(hipGetLastError());
+        break;
+      }
+      if (cnt == 0) continue;
+      if (r == me) {
+        VERS_HIP_TRY(hipMemcpyAsync(idx.p, src32.data(), (size_t)cnt * 4, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL(gather_init_kernel, dim3((unsigned)(((uint64_t)cnt * ld + 255) / 256)), dim3(256), 0, st, X, ldx, h->d, ld,
+                           idx.as<uint32_t>(), cnt, tmp_rows.as<float>());
+        VERS_HIP_TRY(hipGetLastError());
+      }
+      VERS_HIP_TRY(hipMemcpyAsync(idx2.p, dst32.data(), (size_t)cnt * 4, hipMemcpyHostToDevice, st));
+      VERS_HIP_TRY(hipStreamSynchronize(st));
+      if (int32_t rc = comm_rc(cm->broadcast(cm->ctx, tmp_rows.p, (uint64_t)cnt * ld * 4, r), "broadcast")) return rc;
+      hipLaunchKernelGGL(scatter_centroid_rows_kernel, dim3((unsigned)(((uint64_t)cnt * ld + 255) / 256)), dim3(256), 0, st,
+                         tmp_rows.as<float>(), ld, idx2.as<uint32_t>(), cnt, C.as<float>());
       VERS_HIP_TRY(hipGetLastError());
+      VERS_HIP_TRY(hipStreamSynchronize(st));  // dst32 / tmp_rows are reused by the next source rank
     }
     uint64_t iters = 0;
     for (uint64_t it = 0; it < max_iterations; ++it) {
-      if (int32_t rc = assign_pass(mfma, C.as<float>(), assign.as<uint32_t>(), nullptr)) return rc;
+      if (int32_t rc = assign_pass(C.as<float>(), assign.as<uint32_t>(), nullptr)) return rc;
       if (int32_t rc = km_group(assign.as<uint32_t>(), (uint32_t)n, k, sorted.as<uint32_t>(), counts, starts, h->km, st)) return rc;
-      if (int32_t rc = km_update(X, ldx, sorted.as<uint32_t>(), starts, k, Cn.as<float>(), ld, st)) return rc;
+      if (!multi) {
+        if (int32_t rc = km_update(X, ldx, h->d, sorted.as<uint32_t>(), starts, counts, k, Cn.as<float>(), ld, st)) return rc;
+      } else if (k) {
+        // update_centroids over the sharded rows (ivfflat.rs:47-71): global member counts by all-gather (integers),
+        // running sums CHAINED through the ranks in ascending-range order, division on the last rank, broadcast.
+        VERS_HIP_TRY(hipStreamSynchronize(st));
+        if (int32_t rc = comm_rc(cm->all_gather(cm->ctx, counts, counts_all.p, (uint64_t)k * 4), "all_gather")) return rc;
+        hipLaunchKernelGGL(sum_counts_kernel, dim3((k + 255) / 256), dim3(256), 0, st, counts_all.as<uint32_t>(), W, k, counts_g.as<uint32_t>());
+        VERS_HIP_TRY(hipGetLastError());
+        if (me == 0) VERS_HIP_TRY(hipMemsetAsync(S.p, 0, cbytes, st));
+        else {
+          VERS_HIP_TRY(hipStreamSynchronize(st));
+          if (int32_t rc = comm_rc(cm->recv(cm->ctx, S.p, (uint64_t)k * ld * 4, me - 1), "recv")) return rc;
+        }
+        if (int32_t rc = km_update_sums(X, ldx, h->d, sorted.as<uint32_t>(), starts, k, S.as<float>(), ld, st)) return rc;
+        if (me + 1 < W) {
+          VERS_HIP_TRY(hipStreamSynchronize(st));
+          if (int32_t rc = comm_rc(cm->send(cm->ctx, S.p, (uint64_t)k * ld * 4, me + 1), "send")) return rc;
+        } else {
+          if (int32_t rc = km_finish_centroids(S.as<float>(), counts_g.as<uint32_t>(), k, ld, Cn.as<float>(), st)) return rc;
+        }
+        VERS_HIP_TRY(hipStreamSynchronize(st));
+        if (int32_t rc = comm_rc(cm->broadcast(cm->ctx, Cn.p, (uint64_t)k * ld * 4, W - 1), "broadcast")) return rc;
+      }
       if (int32_t rc = km_differs(C.as<float>(), Cn.as<float>(), (uint64_t)k * ld, flag_dev, st)) return rc;
       uint32_t differs = 0;
       VERS_HIP_TRY(hipMemcpyAsync(&differs, flag_dev, 4, hipMemcpyDeviceToHost, st));
@@ -893,12 +1159,32 @@ int32_t run_build(vers_ivf* h, const float* X, uint32_t ldx, uint64_t n, uint32_
       std::swap(C.cap, Cn.cap);
     }
     if (out_iterations) out_iterations[a] = iters;
-    if (int32_t rc = assign_pass(mfma, C.as<float>(), assign.as<uint32_t>(), mind.as<float>())) return rc;
-    if (int32_t rc = km_cost_fold(mind.as<float>(), n, cost_dev, st)) return rc;
-    float cost = 0.0f;
+    if (int32_t rc = assign_pass(C.as<float>(), assign.as<uint32_t>(), mind.as<float>())) return rc;
+    // calculate_kmeans_cost (ivfflat.rs:138-149): one left-to-right f32 fold over ALL points -- chained like the sums
+    const float* fold_init = nullptr;
+    if (multi && me > 0) {
+      VERS_HIP_TRY(hipStreamSynchronize(st));
+      if (int32_t rc = comm_rc(cm->recv(cm->ctx, cost_in, 4, me - 1), "recv")) return rc;
+      fold_init = cost_in;
+    }
+    if (int32_t rc = km_cost_fold(mind.as<float>(), n, fold_init, cost_dev, st)) return rc;
     uint32_t stw = 0;
+    if (multi) {
+      VERS_HIP_TRY(hipStreamSynchronize(st));
+      if (me + 1 < W)
+        if (int32_t rc = comm_rc(cm->send(cm->ctx, cost_dev, 4, me + 1), "send")) return rc;
+      if (int32_t rc = comm_rc(cm->broadcast(cm->ctx, cost_dev, 4, W - 1), "broadcast")) return rc;
+      // a NaN distance anywhere fails the build everywhere (the reference panics)
+      VERS_HIP_TRY(hipMemcpyAsync(ctl.p, h->km.status.p, 16, hipMemcpyDeviceToDevice, st));
+      VERS_HIP_TRY(hipStreamSynchronize(st));
+      if (int32_t rc = comm_rc(cm->all_gather(cm->ctx, ctl.p, ctl_all.p, 16), "all_gather")) return rc;
+      std::vector<uint32_t> sw(4 * (size_t)W);
+      VERS_HIP_TRY(hipMemcpy(sw.data(), ctl_all.p, 16 * (size_t)W, hipMemcpyDeviceToHost));
+      for (uint32_t r = 0; r < W; ++r) stw |= sw[4 * r];
+    }
+    float cost = 0.0f;
     VERS_HIP_TRY(hipMemcpyAsync(&cost, cost_dev, 4, hipMemcpyDeviceToHost, st));
-    VERS_HIP_TRY(hipMemcpyAsync(&stw, h->km.status.p, 4, hipMemcpyDeviceToHost, st));
+    if (!multi) VERS_HIP_TRY(hipMemcpyAsync(&stw, h->km.status.p, 4, hipMemcpyDeviceToHost, st));
     VERS_HIP_TRY(hipStreamSynchronize(st));
     if ((stw & 1u) && k >= 2) {
       VERS_HIP_TRY(hipMemset(h->km.status.p, 0, 16));
@@ -920,14 +1206,14 @@ int32_t run_build(vers_ivf* h, const float* X, uint32_t ldx, uint64_t n, uint32_
   return VERS_OK;
 }
 
-int32_t build_common(vers_ivf* h, const float* X, uint32_t ldx, uint64_t n, uint64_t num_clusters, uint64_t num_attempts,
-                     uint64_t max_iterations, const uint64_t* init_indices, float* out_centroids, uint64_t* out_assignments,
-                     float* out_cost, int32_t* out_kept, uint64_t* out_iterations) {
+int32_t build_common(vers_ivf* h, const float* X, uint32_t ldx, uint64_t n, const BuildShard& sh, uint64_t num_clusters, uint64_t num_attempts,
+                     uint64_t max_iterations, const uint64_t* init_indices, float* out_centroids, uint64_t c_stride_bytes,
+                     uint64_t* out_assignments, float* out_cost, int32_t* out_kept, uint64_t* out_iterations) {
   const uint32_t k = (uint32_t)num_clusters;
   DevBuf best_assign;
   float cost = INFINITY;
   int32_t kept = 0;
-  if (int32_t rc = run_build(h, X, ldx, n, k, num_attempts, max_iterations, init_indices, best_assign, &cost, &kept,
+  if (int32_t rc = run_build(h, X, ldx, n, sh, k, num_attempts, max_iterations, init_indices, best_assign, &cost, &kept,
                              out_iterations, nullptr))
     return rc;
   if (out_cost) *out_cost = cost;
@@ -941,9 +1227,13 @@ int32_t build_common(vers_ivf* h, const float* X, uint32_t ldx, uint64_t n, uint
     h->h_len.clear(); h->h_off.clear(); h->h_cap.clear();
     return VERS_OK;
   }
-  if (int32_t rc = install_index(h, X, ldx, n, best_assign.as<uint32_t>(), k, nullptr)) return rc;
+  if (sh.comm != nullptr && sh.world > 1) {
+    if (int32_t rc = install_index_sharded(h, X, ldx, n, sh, best_assign.as<uint32_t>(), k, nullptr)) return rc;
+  } else {
+    if (int32_t rc = install_index(h, X, ldx, n, best_assign.as<uint32_t>(), k, nullptr)) return rc;
+  }
   if (out_centroids && k)
-    VERS_HIP_TRY(hipMemcpy2D(out_centroids, (size_t)h->d * 4, h->centroids.p, (size_t)h->ldx * 4, (size_t)h->d * 4, k,
+    VERS_HIP_TRY(hipMemcpy2D(out_centroids, (size_t)c_stride_bytes, h->centroids.p, (size_t)h->ldx * 4, (size_t)h->d * 4, k,
                              hipMemcpyDeviceToHost));
   if (out_assignments && n) {
     DevBuf a64;
@@ -963,7 +1253,7 @@ int32_t launch_seg_scan(vers_ivf* h, const SegSrc<QG, SEQ_IDS>& src, uint32_t n_
   p.ld = h->ld;
   p.n_chunks = h->ld / kChunk;
   p.k = src.k;
-  p.status = h->status.as<uint32_t>();
+  p.status = h->st_word();
   p.debug = 0;
   p.stamps = nullptr;
   p.next_quad = nullptr;
@@ -994,6 +1284,34 @@ int32_t stage_plain_queries(vers_ivf* h, const float* q_dev, uint64_t ldq_in, ui
   return VERS_OK;
 }
 
+// Tuning / A-B knobs of the search path (environment, read ONCE per process; DESIGN.md section 5 "Switches").
+struct SearchKnobs {
+  int qg = 0;            // VERS_QG: 8 or 16 forces the ordered-chain group width
+  int pre_slack = 0;     // VERS_PRE_SLACK: slack keys of the matrix-core lists
+  long seg_rows = 0;     // VERS_SEG_ROWS
+  int pre_blocks_per_cu = 0;  // VERS_PRE_BLOCKS_PER_CU
+  int pre_mode = 1;      // VERS_PRESCAN: 0 ordered chains for batches too, 2 every certificate fails
+  bool seg_balanced = true;   // VERS_SEG_BALANCED
+  uint32_t hot_ranks = 1;     // VERS_HOT_FIRST
+  int graph = 1;         // VERS_GRAPH
+};
+inline const SearchKnobs& knobs() {
+  static const SearchKnobs k = [] {
+    SearchKnobs s;
+    auto geti = [](const char* n, long dflt) { const char* e = getenv(n); return e ? atol(e) : dflt; };
+    s.qg = (int)geti("VERS_QG", 0);
+    s.pre_slack = (int)geti("VERS_PRE_SLACK", 0);
+    s.seg_rows = geti("VERS_SEG_ROWS", 0);
+    s.pre_blocks_per_cu = (int)geti("VERS_PRE_BLOCKS_PER_CU", 0);
+    s.pre_mode = (int)geti("VERS_PRESCAN", 1);
+    s.seg_balanced = geti("VERS_SEG_BALANCED", 1) != 0;
+    s.hot_ranks = (uint32_t)geti("VERS_HOT_FIRST", 1);
+    s.graph = (int)geti("VERS_GRAPH", 1);
+    return s;
+  }();
+  return k;
+}
+
 inline int coarse_mode() {  // VERS_COARSE: 1 = always exact, 2 = every certificate fails
   static const int m = [] { const char* e = getenv("VERS_COARSE"); return e ? atoi(e) : 0; }();
   return m;
@@ -1010,7 +1328,7 @@ int32_t coarse_mfma(vers_ivf* h, const float* qp, uint32_t b, uint32_t P, uint64
   VERS_HIP_TRY(hipGetLastError());
   hipLaunchKernelGGL(coarse_select_rescore_kernel, dim3(b), dim3(kWave), 0, st, h->gbuf.as<float>(), h->k_pad, h->k,
                      h->centroids_g.as<float>(), h->ldq, qp, h->ldq, h->ldq, coarse_mode() == 2 ? __builtin_inff() : h->cmax2, P, PS,
-                     probe_out, h->status.as<uint32_t>(), h->coarse_stat.as<uint32_t>());
+                     probe_out, h->st_word(), h->coarse_stat.as<uint32_t>());
   VERS_HIP_TRY(hipGetLastError());
   h->mfma_batches += 1;
   return VERS_OK;
@@ -1069,7 +1387,7 @@ int32_t launch_ivf_scan(vers_ivf* h, const IvfSrc<QG>& src, uint32_t items_bound
   p.ld = h->ld;
   p.n_chunks = h->ld / kChunk;
   p.k = src.k_keep;
-  p.status = h->status.as<uint32_t>();
+  p.status = h->st_word();
   p.debug = scan_debug_flags();
   p.stamps = nullptr;
   if (p.debug & 16u) {  // diagnosis only
@@ -1109,7 +1427,7 @@ int32_t launch_prescan(vers_ivf* h, const IvfSrc<kPreQ>& src, uint32_t items_bou
   p.ld = h->ld;
   p.n_chunks = h->ld / kChunk;
   p.kp = kp;
-  p.status = h->status.as<uint32_t>();
+  p.status = h->st_word();
   p.bounds32 = reinterpret_cast<uint32_t*>(h->partials.as<uint64_t>() + h->ivf_bounds_off);  // 0xFF-initialised with the slots
   p.qflags = qflags;
   p.xnorm = h->xnorm.as<float>();
@@ -1125,7 +1443,7 @@ int32_t launch_prescan(vers_ivf* h, const IvfSrc<kPreQ>& src, uint32_t items_bou
   if (int32_t rc = shadow ? scan_prepare_launch(prescan_kernel_g<true, IvfSrc<kPreQ>>, lds) : scan_prepare_launch(prescan_kernel_g<false, IvfSrc<kPreQ>>, lds)) return rc;
   uint32_t blocks = (items_bound + kWavesPerBlock - 1) / kWavesPerBlock;
   uint32_t per_cu = std::max<uint32_t>(1, std::min<uint32_t>(2, (uint32_t)((160u * 1024u) / lds)));  // 1 at d = 768 (measured: as fast as 2)
-  if (const char* e = getenv("VERS_PRE_BLOCKS_PER_CU")) per_cu = std::max(1, atoi(e));  // tuning knob
+  if (knobs().pre_blocks_per_cu > 0) per_cu = (uint32_t)knobs().pre_blocks_per_cu;  // tuning knob
   const uint32_t max_blocks = (uint32_t)h->n_cu * per_cu;
   if (blocks > max_blocks) blocks = max_blocks;
   if (blocks == 0) blocks = 1;
@@ -1183,10 +1501,10 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
   // query-group width of the list scan: a list shared by more queries than one group holds is streamed
   // once per group, so pick the width from the expected queries per list
   int QG = (b == 1 || pairs_est < 2 * lists_est) ? 1 : (pairs_est >= 6 * lists_est ? 16 : 8);
-  if (const char* e = getenv("VERS_QG")) { const int q = atoi(e); if (QG != 1 && (q == 8 || q == 16)) QG = q; }  // tuning knob
+  if (QG != 1 && (knobs().qg == 8 || knobs().qg == 16)) QG = knobs().qg;  // tuning knob
   // Batches in nprobe mode: the list scan runs on the matrix cores with an exact finish (prescan.cuh); same bits.
   // VERS_PRESCAN=0 keeps the ordered-chain scan, =2 makes every certificate fail (exercises the exact fallback).
-  static const int pre_mode = [] { const char* e = getenv("VERS_PRESCAN"); return e ? atoi(e) : 1; }();
+  const int pre_mode = knobs().pre_mode;
   // slack of 10 keys: at cfg3 a slack of 6 left ~2 of 1024 queries uncertified per batch, 10 none
   uint32_t kp = std::min<uint32_t>(kPreMaxKp, std::max<uint32_t>(top_k + 10, top_k + top_k / 2));
   // bf16 shadow rows (experimental): the certificate window is ~9x wider, measured <= 33 rows inside it at top_k = 10
@@ -1196,7 +1514,7 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
     if ((uint64_t)failed * 8 > h->shadow_queries) { h->shadow_off = true; use_shadow = false; }
   }
   if (use_shadow) kp = std::min<uint32_t>(kPreMaxKp, top_k + 38);
-  if (const char* e = getenv("VERS_PRE_SLACK")) kp = std::min<uint32_t>(kPreMaxKp, top_k + std::max(1, atoi(e)));  // tuning knob
+  if (knobs().pre_slack > 0) kp = std::min<uint32_t>(kPreMaxKp, top_k + (uint32_t)knobs().pre_slack);  // tuning knob
   const bool use_pre = QG != 1 && !ref_mode && pre_mode != 0 && top_k + 6 <= kPreMaxKp &&
                        prescan_lds_bytes_g(h->ld, kp) <= 160u * 1024u;  // the query block of 32 padded queries must fit LDS
   if (use_pre) QG = kPreQ;
@@ -1217,11 +1535,11 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
   // matrix-core scan: an average list is one quad of items (per-item set-up and the block's barriers amortise over
   // ~10 tiles; measured at cfg3: 640-row targets beat 256- and 1024-row ones)
   if (use_pre) seg_rows = (uint32_t)round_up64(std::max<uint64_t>(256, (avg_len_all + 3) / 4), kWave);
-  if (const char* e = getenv("VERS_SEG_ROWS")) seg_rows = (uint32_t)round_up64(std::max(64l, atol(e)), kWave);  // tuning knob
+  if (knobs().seg_rows > 0) seg_rows = (uint32_t)round_up64(std::max(64l, knobs().seg_rows), kWave);  // tuning knob
   // matrix-core scan: per-list balanced segments of about seg_rows rows (list_seg_rows)
   // per-list balanced segments (list_seg_rows): same-box A/B at cfg3 5.96 ms vs 6.27 ms with fixed 640-row segments;
   // VERS_SEG_BALANCED=0 switches them off
-  static const bool seg_balanced = [] { const char* e = getenv("VERS_SEG_BALANCED"); return !e || atoi(e) != 0; }();
+  const bool seg_balanced = knobs().seg_balanced;
   const uint32_t seg_target = use_pre && seg_balanced ? seg_rows : 0u;
   // segments per list at most; partial slots per (query, probe): one per segment, or one per QUAD of segments (matrix-core scan)
   const uint32_t S_seg = seg_target ? 4 * std::max<uint32_t>(1, (h->max_len + 4 * seg_target - 1) / (4 * seg_target))
@@ -1266,14 +1584,14 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
     hipLaunchKernelGGL(plan1_kernel, dim3(1), dim3(kWave * kMergeWaves), 0, st, h->cpart.as<uint64_t>(), n_segs_c, P, k_l, top_k,
                        ref_mode, h->list_len.as<uint32_t>(), h->world > 1 ? h->owner.as<uint8_t>() : (const uint8_t*)nullptr, h->rank,
                        seg_rows, h->probe.as<uint64_t>(), pj_list, pj_pref, pj_take, np, cnt, pair_off, group_off,
-                       h->pairs.as<uint32_t>(), h->items.as<ItemDesc>(), h->groups.as<GroupDesc>(), tot, h->status.as<uint32_t>());
+                       h->pairs.as<uint32_t>(), h->items.as<ItemDesc>(), h->groups.as<GroupDesc>(), tot, h->st_word());
     VERS_HIP_TRY(hipGetLastError());
   } else {
-  static const uint32_t hot_ranks = [] { const char* e = getenv("VERS_HOT_FIRST"); return e ? (uint32_t)atoi(e) : 1u; }();  // A/B knob
+  const uint32_t hot_ranks = knobs().hot_ranks;  // A/B knob
   VERS_HIP_TRY(hipMemsetAsync(cnt, 0, zero_words * sizeof(uint32_t), st));
   hipLaunchKernelGGL(plan_kernel, dim3((b + 3) / 4), dim3(256), 0, st, probe, b, P, k_l, top_k, ref_mode,
                      h->list_len.as<uint32_t>(), h->world > 1 ? h->owner.as<uint8_t>() : (const uint8_t*)nullptr, h->rank, pj_list,
-                     pj_pref, pj_take, np, cnt, hot, hot_ranks, h->status.as<uint32_t>());
+                     pj_pref, pj_take, np, cnt, hot, hot_ranks, h->st_word());
   VERS_HIP_TRY(hipGetLastError());
   hipLaunchKernelGGL(group_kernel, dim3(1), dim3(1024), 0, st, cnt, h->list_len.as<uint32_t>(), k_l, (uint32_t)QG, seg_rows, seg_target,
                      (const uint32_t*)hot, pair_off, group_off, item_off, tot);
@@ -1309,7 +1627,7 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
     a.pj_list = pj_list; a.pj_pref = pj_pref; a.list_off = h->list_off.as<uint32_t>(); a.row_ids = h->row_ids.as<uint32_t>();
     a.rows = h->rows.as<float>(); a.ld = h->ld; a.qp = qp; a.ldq = h->ldq; a.xmax2_bits = h->pre_misc.as<uint32_t>();
     a.qflags = qflags; a.force_fail = pre_mode == 2; a.shadow = use_shadow ? 1 : 0; a.debug = scan_debug_flags(); a.fail_list = fail_list; a.stats = h->pre_misc.as<uint32_t>() + 1;
-    a.status = h->status.as<uint32_t>(); a.out_ids = out_ids; a.out_dist = out_dist; a.out_count = out_count; a.out_keys = out_keys;
+    a.status = h->st_word(); a.out_ids = out_ids; a.out_dist = out_dist; a.out_count = out_count; a.out_keys = out_keys;
     const int stage_rows = rescore_lds_bytes(h->ld, true) <= 144u * 1024u ? 1 : 0;
     const size_t rs_lds = rescore_lds_bytes(h->ld, stage_rows != 0);
     if (int32_t rc2 = scan_prepare_launch(ivf_rescore_kernel, rs_lds)) return rc2;
@@ -1519,20 +1837,19 @@ int32_t host_io_begin(vers_ivf* h, const float* queries, uint64_t stride_bytes, 
   for (uint32_t i = 0; i < b; ++i)
     std::memcpy((char*)h->io_pin + (size_t)i * h->d * 4, (const char*)queries + (size_t)i * stride_bytes, (size_t)h->d * 4);
   VERS_HIP_TRY(hipMemcpyAsync(io.q_dev, h->io_pin, io.q_bytes, hipMemcpyHostToDevice, h->io_stream));
-  VERS_HIP_TRY(hipMemsetAsync(h->io_out.p, 0, io.out_bytes, h->io_stream));  // entries past a query's count come back as zeros, not stale memory
   return VERS_OK;
 }
 
 // copies results + status word back, waits once, maps the status; *out_status_rc carries kRetrySpill etc.
 int32_t host_io_end(vers_ivf* h, const HostIo& io, uint32_t b, uint32_t top_k, uint64_t* out_ids, float* out_dist, uint32_t* out_count) {
   char* base = (char*)h->io_out.p;
-  VERS_HIP_TRY(hipMemcpyAsync(base + io.st_off, h->status.p, sizeof(uint32_t), hipMemcpyDeviceToDevice, h->io_stream));
+  VERS_HIP_TRY(hipMemcpyAsync(base + io.st_off, h->st_word(), sizeof(uint32_t), hipMemcpyDeviceToDevice, h->io_stream));
   VERS_HIP_TRY(hipMemcpyAsync(h->io_pin, base, io.out_bytes, hipMemcpyDeviceToHost, h->io_stream));
   VERS_HIP_TRY(hipStreamSynchronize(h->io_stream));
   const char* pin = (const char*)h->io_pin;
   uint32_t s = 0;
   std::memcpy(&s, pin + io.st_off, sizeof(s));
-  if (int32_t rc = status_to_rc(h, s)) return rc;
+  if (int32_t rc = status_to_rc(h, s, h->st_slot)) return rc;
   const size_t need = (size_t)b * top_k;
   if (need) {
     std::memcpy(out_ids, pin + io.ids_off, need * sizeof(uint64_t));
@@ -1559,14 +1876,21 @@ int32_t vers_ivf_create(int32_t device, uint32_t d, vers_ivf_t** out) {
   h->ldx = round_up(d, 4);
   h->ld = round_up(d, kColAlign);
   h->ldq = h->ld;
-  hipDeviceProp_t prop;
-  VERS_HIP_TRY(hipGetDeviceProperties(&prop, device));
-  h->n_cu = prop.multiProcessorCount;
-  if (int32_t rc = h->status.reserve(16)) return rc;
-  VERS_HIP_TRY(hipMemset(h->status.p, 0, 16));
-  for (uint32_t i = 0; i < vers_ivf::kEvRing; ++i) {
-    VERS_HIP_TRY(hipEventCreate(&h->ev0[i]));
-    VERS_HIP_TRY(hipEventCreate(&h->ev1[i]));
+  const int32_t rc = [&]() -> int32_t {
+    hipDeviceProp_t prop;
+    VERS_HIP_TRY(hipGetDeviceProperties(&prop, device));
+    h->n_cu = prop.multiProcessorCount;
+    if (int32_t rc2 = h->status.reserve(16)) return rc2;
+    VERS_HIP_TRY(hipMemset(h->status.p, 0, 16));
+    for (uint32_t i = 0; i < vers_ivf::kEvRing; ++i) {
+      VERS_HIP_TRY(hipEventCreate(&h->ev0[i]));
+      VERS_HIP_TRY(hipEventCreate(&h->ev1[i]));
+    }
+    return VERS_OK;
+  }();
+  if (rc != VERS_OK) {  // nothing half-made leaks: destroy releases whatever was created
+    (void)vers_ivf_destroy(h);
+    return rc;
   }
   *out = h;
   return VERS_OK;
@@ -1595,9 +1919,11 @@ int32_t vers_ivf_destroy(vers_ivf_t* h) {
 
 int32_t vers_ivf_build(vers_ivf_t* h, const float* rows, uint64_t n, uint64_t row_stride_bytes, uint64_t num_clusters,
                        uint64_t num_attempts, uint64_t max_iterations, const uint64_t* init_indices, float* out_centroids,
-                       uint64_t* out_assignments, float* out_cost, int32_t* out_kept, uint64_t* out_iterations) {
+                       uint64_t c_stride_bytes, uint64_t* out_assignments, float* out_cost, int32_t* out_kept,
+                       uint64_t* out_iterations) {
   if (!h || (n && !rows) || row_stride_bytes < (uint64_t)(h ? h->d : 0) * 4 || row_stride_bytes % 4 ||
-      (num_attempts * num_clusters && !init_indices) || n > 0xFFFFFFFFull || num_clusters > 0xFFFFFFFFull)
+      (num_attempts * num_clusters && !init_indices) || n > 0xFFFFFFFFull || num_clusters > 0xFFFFFFFFull ||
+      (out_centroids && num_clusters && c_stride_bytes < (uint64_t)h->d * 4))
     return fail(VERS_ERR_INVALID, "vers_ivf_build: bad arguments");
   std::lock_guard<std::mutex> lk(h->mu);
   DeviceGuard g(h->device);
@@ -1607,20 +1933,53 @@ int32_t vers_ivf_build(vers_ivf_t* h, const float* rows, uint64_t n, uint64_t ro
     if (h->ldx != h->d) VERS_HIP_TRY(hipMemset(X.p, 0, n * (size_t)h->ldx * sizeof(float)));
     VERS_HIP_TRY(hipMemcpy2D(X.p, (size_t)h->ldx * 4, rows, row_stride_bytes, (size_t)h->d * 4, n, hipMemcpyHostToDevice));
   }
-  return build_common(h, X.as<float>(), h->ldx, n, num_clusters, num_attempts, max_iterations, init_indices, out_centroids,
-                      out_assignments, out_cost, out_kept, out_iterations);
+  BuildShard one;
+  one.n_total = n;
+  return build_common(h, X.as<float>(), h->ldx, n, one, num_clusters, num_attempts, max_iterations, init_indices, out_centroids,
+                      c_stride_bytes, out_assignments, out_cost, out_kept, out_iterations);
 }
 
 int32_t vers_ivf_build_dev(vers_ivf_t* h, const float* rows_dev, uint64_t n, uint64_t ld_floats, uint64_t num_clusters,
                            uint64_t num_attempts, uint64_t max_iterations, const uint64_t* init_indices, float* out_centroids,
-                           uint64_t* out_assignments, float* out_cost, int32_t* out_kept, uint64_t* out_iterations) {
+                           uint64_t c_stride_bytes, uint64_t* out_assignments, float* out_cost, int32_t* out_kept,
+                           uint64_t* out_iterations) {
   if (!h || (n && !rows_dev) || ld_floats < (h ? h->d : 0) || ld_floats % 4 || ld_floats > 0x3FFFFFFFull ||
-      (num_attempts * num_clusters && !init_indices) || n > 0xFFFFFFFFull || num_clusters > 0xFFFFFFFFull)
+      (num_attempts * num_clusters && !init_indices) || n > 0xFFFFFFFFull || num_clusters > 0xFFFFFFFFull ||
+      (out_centroids && num_clusters && c_stride_bytes < (uint64_t)h->d * 4))
     return fail(VERS_ERR_INVALID, "vers_ivf_build_dev: bad arguments (ld_floats must be >= d and a multiple of 4)");
   std::lock_guard<std::mutex> lk(h->mu);
   DeviceGuard g(h->device);
-  return build_common(h, rows_dev, (uint32_t)ld_floats, n, num_clusters, num_attempts, max_iterations, init_indices, out_centroids, out_assignments,
-                      out_cost, out_kept, out_iterations);
+  BuildShard one;
+  one.n_total = n;
+  return build_common(h, rows_dev, (uint32_t)ld_floats, n, one, num_clusters, num_attempts, max_iterations, init_indices, out_centroids, c_stride_bytes,
+                      out_assignments, out_cost, out_kept, out_iterations);
+}
+
+int32_t vers_ivf_build_sharded_dev(vers_ivf_t* h, const float* rows_dev, uint64_t n_local, uint64_t ld_floats, uint64_t row_begin,
+                                   uint64_t n_total, uint64_t num_clusters, uint64_t num_attempts, uint64_t max_iterations,
+                                   const uint64_t* init_indices, const vers_comm_t* comm, uint64_t* out_assignments_local, float* out_cost,
+                                   int32_t* out_kept, uint64_t* out_iterations) {
+  if (!h || !comm || (n_local && !rows_dev) || ld_floats < (h ? h->d : 0) || ld_floats % 4 || ld_floats > 0x3FFFFFFFull ||
+      (num_attempts * num_clusters && !init_indices) || n_total > 0xFFFFFFFFull || n_local > n_total || row_begin > n_total - n_local ||
+      num_clusters > 0xFFFFFFFFull)
+    return fail(VERS_ERR_INVALID, "vers_ivf_build_sharded_dev: bad arguments (ld_floats must be >= d and a multiple of 4; vec ids are 32-bit)");
+  if (comm->world == 0 || comm->world > 255 || comm->rank >= comm->world ||
+      (comm->world > 1 && (!comm->all_gather || !comm->send || !comm->recv || !comm->broadcast || !comm->all_to_all_v)))
+    return fail(VERS_ERR_INVALID, "vers_ivf_build_sharded_dev: incomplete vers_comm_t");
+  std::lock_guard<std::mutex> lk(h->mu);
+  DeviceGuard g(h->device);
+  BuildShard sh;
+  sh.comm = comm->world > 1 ? comm : nullptr;
+  sh.rank = comm->rank; sh.world = comm->world; sh.row_begin = row_begin; sh.n_total = n_total;
+  if (comm->world == 1 && (row_begin != 0 || n_local != n_total)) return fail(VERS_ERR_INVALID, "vers_ivf_build_sharded_dev: a single rank must hold every row");
+  if (comm->world == 1) { h->rank = 0; h->world = 1; }
+  return build_common(h, rows_dev, (uint32_t)ld_floats, n_local, sh, num_clusters, num_attempts, max_iterations, init_indices, nullptr, 0,
+                      out_assignments_local, out_cost, out_kept, out_iterations);
+}
+
+int32_t vers_mem_stats(uint64_t* out_bytes_now, uint64_t* out_bytes_peak, int32_t reset_peak) {
+  dev_mem_stats(out_bytes_now, out_bytes_peak, reset_peak != 0);
+  return VERS_OK;
 }
 
 int32_t vers_ivf_upload(vers_ivf_t* h, const float* rows, uint64_t n, uint64_t row_stride_bytes, const float* centroids,
@@ -1657,6 +2016,7 @@ int32_t vers_ivf_add(vers_ivf_t* h, const float* row, uint64_t* out_cluster, uin
   std::lock_guard<std::mutex> lk(h->mu);
   DeviceGuard g(h->device);
   if (h->k == 0) return fail(VERS_ERR_EMPTY, "add on an index without centroids (reference: unwrap on None, ivfflat.rs:207)");
+  HostStatusSlot slot(h);  // a NaN / spill status latched by an asynchronous _dev search stays there for vers_ivf_poll
   if (h->n_total >= 0xFFFFFFFEull) return fail(VERS_ERR_INVALID, "vec_id space exhausted");
   DevBuf q;
   if (int32_t rc = upload_queries(row, (uint64_t)h->d * 4, 1, h->d, q)) return rc;
@@ -1666,8 +2026,8 @@ int32_t vers_ivf_add(vers_ivf_t* h, const float* row, uint64_t* out_cluster, uin
   uint64_t key = 0;
   VERS_HIP_TRY(hipMemcpy(&key, h->probe.p, sizeof(key), hipMemcpyDeviceToHost));
   uint32_t stw = 0;
-  VERS_HIP_TRY(hipMemcpy(&stw, h->status.p, 4, hipMemcpyDeviceToHost));
-  if (stw) VERS_HIP_TRY(hipMemset(h->status.p, 0, 4));
+  VERS_HIP_TRY(hipMemcpy(&stw, h->st_word(), 4, hipMemcpyDeviceToHost));
+  if (stw) VERS_HIP_TRY(hipMemset(h->st_word(), 0, 4));
   if ((stw & kStNaN) && h->k >= 2) return fail(VERS_ERR_NAN, "NaN distance in add (reference panics)");
   const uint32_t c = (uint32_t)key;
   const uint32_t vid = (uint32_t)h->n_total;  // the caller's vec_id is ignored, as in the reference (ivfflat.rs:209)
@@ -1714,19 +2074,6 @@ int32_t vers_ivf_set_shard(vers_ivf_t* h, uint32_t rank, uint32_t world) {
   if (h->k != 0) return fail(VERS_ERR_INVALID, "vers_ivf_set_shard: call before build / upload");
   h->rank = rank;
   h->world = world;
-  return VERS_OK;
-}
-
-int32_t vers_ivf_set_build_shard(vers_ivf_t* h, uint32_t rank, uint32_t world, vers_assign_exchange_fn exchange, void* ctx) {
-  if (!h || world == 0 || rank >= world || (world > 1 && !exchange)) return fail(VERS_ERR_INVALID, "vers_ivf_set_build_shard: bad arguments");
-  std::lock_guard<std::mutex> lk(h->mu);
-  h->build_rank = rank; h->build_world = world; h->build_exchange = world > 1 ? exchange : nullptr; h->build_exchange_ctx = ctx;
-  return VERS_OK;
-}
-
-int32_t vers_dev_copy(void* dst_dev, const void* src_dev, uint64_t bytes) {
-  if ((!dst_dev || !src_dev) && bytes) return fail(VERS_ERR_INVALID, "vers_dev_copy: null pointer");
-  VERS_HIP_TRY(hipMemcpy(dst_dev, src_dev, bytes, hipMemcpyDeviceToDevice));
   return VERS_OK;
 }
 
@@ -1787,6 +2134,7 @@ int32_t vers_ivf_search(vers_ivf_t* h, const float* queries, uint64_t q_stride_b
   if (b == 0) return VERS_OK;
   std::lock_guard<std::mutex> lk(h->mu);
   DeviceGuard g(h->device);
+  HostStatusSlot slot(h);
   HostIo io;
   if (int32_t rc = host_io_begin(h, queries, q_stride_bytes, b, top_k, io)) return rc;
   // Reference mode ranks only as many lists as the spill may need: 16 first (the merge of the coarse partial lists
@@ -1795,6 +2143,8 @@ int32_t vers_ivf_search(vers_ivf_t* h, const float* queries, uint64_t q_stride_b
   for (int attempt = nprobe == 0 ? 0 : 1; attempt < 3; ++attempt) {
     h->ref_shallow = attempt == 0;
     h->ref_deep = attempt == 2;
+    // every attempt starts from zeros: entries past a query's count must not carry a previous attempt's values
+    VERS_HIP_TRY(hipMemsetAsync(h->io_out.p, 0, io.out_bytes, h->io_stream));
     rc = search_dev_locked(h, io.q_dev, h->d, b, top_k, nprobe, io.ids_dev, io.dist_dev, io.cnt_dev, nullptr, h->io_stream);
     h->ref_shallow = h->ref_deep = false;
     if (rc) return rc;
@@ -1846,8 +2196,10 @@ int32_t vers_ivf_search_exhaustive(vers_ivf_t* h, const float* queries, uint64_t
   if (b == 0) return VERS_OK;
   std::lock_guard<std::mutex> lk(h->mu);
   DeviceGuard g(h->device);
+  HostStatusSlot slot(h);
   HostIo io;
   if (int32_t rc = host_io_begin(h, queries, q_stride_bytes, b, top_k, io)) return rc;
+  VERS_HIP_TRY(hipMemsetAsync(h->io_out.p, 0, io.out_bytes, h->io_stream));  // entries past a query's count come back as zeros
   if (int32_t rc = exhaustive_dev_locked(h, io.q_dev, h->d, b, top_k, metric, io.ids_dev, io.dist_dev, io.cnt_dev, h->io_stream)) return rc;
   const int32_t rc = host_io_end(h, io, b, top_k, out_ids, out_dist, out_count);
   return rc == kRetrySpill ? VERS_ERR_INVALID : rc;

@@ -20,15 +20,32 @@
 
 namespace vers {
 
+// process-wide accounting of the device memory held through DevBuf (vers_mem_stats)
+static std::atomic<uint64_t> g_dev_now{0}, g_dev_peak{0};
+void dev_mem_account(int64_t delta) {
+  const uint64_t now = g_dev_now.fetch_add((uint64_t)delta) + (uint64_t)delta;
+  uint64_t pk = g_dev_peak.load();
+  while (now > pk && !g_dev_peak.compare_exchange_weak(pk, now)) {}
+}
+void dev_mem_stats(uint64_t* now, uint64_t* peak, bool reset_peak) {
+  if (now) *now = g_dev_now.load();
+  if (peak) *peak = g_dev_peak.load();
+  if (reset_peak) g_dev_peak = g_dev_now.load();
+}
+
 int32_t DevBuf::reserve(size_t bytes) {
   if (bytes <= cap) return VERS_OK;
   release();
   VERS_HIP_TRY(hipMalloc(&p, bytes));
   cap = bytes;
+  dev_mem_account((int64_t)bytes);
   return VERS_OK;
 }
 void DevBuf::release() {
-  if (p) (void)hipFree(p);
+  if (p) {
+    (void)hipFree(p);
+    dev_mem_account(-(int64_t)cap);
+  }
   p = nullptr;
   cap = 0;
 }
@@ -162,7 +179,7 @@ int32_t km_assign_mfma(const float* X, uint32_t ldx, uint64_t n, const float* C,
   if (int32_t rc = ws.best.reserve(mb * 8)) return rc;
   uint32_t* best = ws.best.as<uint32_t>();
   float* g2 = ws.best.as<float>() + mb;
-  const bool in_place_ok = ldx == ldq;
+  const bool in_place_ok = ldx == ldq && d == ldq;  // (padding columns of the caller's X may hold anything: stage them away)
   for (uint64_t i0 = 0; i0 < n; i0 += mb) {
     const uint32_t nb = (uint32_t)((n - i0 < mb) ? (n - i0) : mb);
     const uint32_t nb_pad = round_up(nb, kGemmBN);
@@ -248,18 +265,17 @@ int32_t km_group(const uint32_t* assign, uint32_t n, uint32_t k, uint32_t* sorte
 
 // ---- update -----------------------------------------------------------------------------
 // thread = one (cluster, column); members visited in list order (ascending point index);
-// 8 independent row loads in flight, the adds stay strictly ordered.
-__global__ __launch_bounds__(256) void update_kernel(const float* X, uint32_t ld, const uint32_t* sorted_ids,
-                                                     const uint32_t* starts, float* Cnew, uint32_t ldc) {
+// 8 independent row loads in flight, the adds stay strictly ordered.  The sum CONTINUES from S[c][col]: zero for a
+// single process (the reference starts from Vector([0.0; N]), ivfflat.rs:49), the previous rank's running sum when
+// the rows are sharded over processes in ascending ranges -- the order of the additions is the reference's either way.
+__global__ __launch_bounds__(256) void update_sums_kernel(const float* X, uint32_t ld, uint32_t d, const uint32_t* sorted_ids,
+                                                          const uint32_t* starts, float* S, uint32_t ldc) {
   const uint32_t c = blockIdx.x;
   const uint32_t col = blockIdx.y * 256 + threadIdx.x;
   if (col >= ldc) return;
-  if (col >= ld) {  // beyond the data pitch: padding stays zero
-    Cnew[(uint64_t)c * ldc + col] = 0.0f;
-    return;
-  }
+  if (col >= d) return;  // beyond the vector: the padding of S stays zero (the caller's padding columns of X may hold anything)
   const uint32_t s = starts[c], e = starts[c + 1];
-  float acc = 0.0f;
+  float acc = S[(uint64_t)c * ldc + col];
   uint32_t t = s;
   for (; t + 8 <= e; t += 8) {
     float v[8];
@@ -269,15 +285,39 @@ __global__ __launch_bounds__(256) void update_kernel(const float* X, uint32_t ld
     for (int u = 0; u < 8; ++u) acc = __fadd_rn(acc, v[u]);
   }
   for (; t < e; ++t) acc = __fadd_rn(acc, X[(uint64_t)sorted_ids[t] * ld + col]);
-  Cnew[(uint64_t)c * ldc + col] = e > s ? __fdiv_rn(acc, (float)(e - s)) : 0.0f;
+  S[(uint64_t)c * ldc + col] = acc;
 }
 
-int32_t km_update(const float* X, uint32_t ld, const uint32_t* sorted_ids, const uint32_t* starts, uint32_t k, float* Cnew,
-                  uint32_t ldc, hipStream_t st) {
+// centroid = sum / (count as f32), empty cluster -> zero vector (ivfflat.rs:58-68); counts are the GLOBAL member counts
+__global__ void finish_centroids_kernel(const float* S, const uint32_t* counts, uint32_t k, uint32_t ldc, float* Cnew) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (uint64_t)k * ldc) return;
+  const uint32_t n = counts[i / ldc];
+  Cnew[i] = n ? __fdiv_rn(S[i], (float)n) : 0.0f;
+}
+
+int32_t km_update_sums(const float* X, uint32_t ld, uint32_t d, const uint32_t* sorted_ids, const uint32_t* starts, uint32_t k, float* S,
+                       uint32_t ldc, hipStream_t st) {
   if (k == 0) return VERS_OK;
-  hipLaunchKernelGGL(update_kernel, dim3(k, (ldc + 255) / 256), dim3(256), 0, st, X, ld, sorted_ids, starts, Cnew, ldc);
+  hipLaunchKernelGGL(update_sums_kernel, dim3(k, (ldc + 255) / 256), dim3(256), 0, st, X, ld, d, sorted_ids, starts, S, ldc);
   VERS_HIP_TRY(hipGetLastError());
   return VERS_OK;
+}
+
+int32_t km_finish_centroids(const float* S, const uint32_t* counts, uint32_t k, uint32_t ldc, float* Cnew, hipStream_t st) {
+  if (k == 0) return VERS_OK;
+  hipLaunchKernelGGL(finish_centroids_kernel, dim3((unsigned)(((uint64_t)k * ldc + 255) / 256)), dim3(256), 0, st, S, counts, k, ldc, Cnew);
+  VERS_HIP_TRY(hipGetLastError());
+  return VERS_OK;
+}
+
+int32_t km_update(const float* X, uint32_t ld, uint32_t d, const uint32_t* sorted_ids, const uint32_t* starts, const uint32_t* counts, uint32_t k,
+                  float* Cnew, uint32_t ldc, hipStream_t st) {
+  if (k == 0) return VERS_OK;
+  // single process: the running sums live in Cnew itself (zeroed, summed, divided in place)
+  VERS_HIP_TRY(hipMemsetAsync(Cnew, 0, (size_t)k * ldc * sizeof(float), st));
+  if (int32_t rc = km_update_sums(X, ld, d, sorted_ids, starts, k, Cnew, ldc, st)) return rc;
+  return km_finish_centroids(Cnew, counts, k, ldc, Cnew, st);
 }
 
 // ---- cost -------------------------------------------------------------------------------
@@ -285,10 +325,10 @@ int32_t km_update(const float* X, uint32_t ld, const uint32_t* sorted_ids, const
 // taken off the chain is everything else: one wave loads 256 values per step with a single coalesced float4 per
 // lane (double buffered), v_readlane hands them to the chain in index order as scalar operands.  ~6 cycles per
 // element instead of one scalar-thread load + add (~56 cycles): 0.26 s -> ~0.03 s at n = 10M.
-__global__ __launch_bounds__(kWave) void cost_fold_kernel(const float* v, uint64_t n, float* out) {
+__global__ __launch_bounds__(kWave) void cost_fold_kernel(const float* v, uint64_t n, const float* init, float* out) {
   if (blockIdx.x != 0) return;
   const int lane = threadIdx.x;
-  float acc = 0.0f;
+  float acc = init ? *init : 0.0f;  // the fold continues the previous rank's partial cost when the points are sharded
   const uint64_t n_blk = n / 256;
   const bool aligned = (reinterpret_cast<uintptr_t>(v) & 15u) == 0;
   uint64_t done = 0;
@@ -311,8 +351,8 @@ __global__ __launch_bounds__(kWave) void cost_fold_kernel(const float* v, uint64
   if (lane == 0) *out = acc;
 }
 
-int32_t km_cost_fold(const float* mind, uint64_t n, float* out_dev, hipStream_t st) {
-  hipLaunchKernelGGL(cost_fold_kernel, dim3(1), dim3(64), 0, st, mind, n, out_dev);
+int32_t km_cost_fold(const float* mind, uint64_t n, const float* init_dev, float* out_dev, hipStream_t st) {
+  hipLaunchKernelGGL(cost_fold_kernel, dim3(1), dim3(64), 0, st, mind, n, init_dev, out_dev);
   VERS_HIP_TRY(hipGetLastError());
   return VERS_OK;
 }
@@ -458,7 +498,7 @@ int32_t vers_kmeans_update(int32_t device, const float* rows, uint64_t n, uint64
   uint32_t* counts = ws.counts.as<uint32_t>();
   uint32_t* starts = counts + k;
   if (int32_t rc = km_group(A.as<uint32_t>(), (uint32_t)n, (uint32_t)k, S.as<uint32_t>(), counts, starts, ws, nullptr)) return rc;
-  if (int32_t rc = km_update(X.as<float>(), ld, S.as<uint32_t>(), starts, (uint32_t)k, CN.as<float>(), ld, nullptr)) return rc;
+  if (int32_t rc = km_update(X.as<float>(), ld, d, S.as<uint32_t>(), starts, counts, (uint32_t)k, CN.as<float>(), ld, nullptr)) return rc;
   VERS_HIP_TRY(hipMemcpy2D(out_centroids, (size_t)d * 4, CN.p, (size_t)ld * 4, (size_t)d * 4, k, hipMemcpyDeviceToHost));
   return VERS_OK;
 }
@@ -488,7 +528,7 @@ int32_t vers_kmeans_cost(int32_t device, const float* rows, uint64_t n, uint64_t
                        A.as<uint32_t>(), n, ld, M.as<float>());
     VERS_HIP_TRY(hipGetLastError());
   }
-  if (int32_t rc = km_cost_fold(M.as<float>(), n, O.as<float>(), nullptr)) return rc;
+  if (int32_t rc = km_cost_fold(M.as<float>(), n, nullptr, O.as<float>(), nullptr)) return rc;
   VERS_HIP_TRY(hipMemcpy(out_cost, O.p, sizeof(float), hipMemcpyDeviceToHost));
   return VERS_OK;
 }

@@ -21,6 +21,9 @@ struct DevBuf {
   ~DevBuf() { release(); }
 };
 
+void dev_mem_stats(uint64_t* now, uint64_t* peak, bool reset_peak);  // bytes held through DevBuf, process-wide
+void dev_mem_account(int64_t delta);  // for the one allocation made outside DevBuf::reserve
+
 struct KMeansScratch {
   DevBuf cblocked;  // centroids in the scan layout (lane-transposed tiles)
   DevBuf qblocks;   // interleaved point blocks of one assign batch
@@ -58,11 +61,17 @@ int32_t km_group(const uint32_t* assign, uint32_t n, uint32_t k, uint32_t* sorte
                  KMeansScratch& ws, hipStream_t st);
 
 // update_centroids (ivfflat.rs:47-71): Cnew[c] = (0 + x_i1 + x_i2 + ...) / count in ascending i, 0 if empty.
-int32_t km_update(const float* X, uint32_t ldx, const uint32_t* sorted_ids, const uint32_t* starts, uint32_t k,
-                  float* Cnew, uint32_t ldc, hipStream_t st);
+int32_t km_update(const float* X, uint32_t ldx, uint32_t d, const uint32_t* sorted_ids, const uint32_t* starts, const uint32_t* counts,
+                  uint32_t k, float* Cnew, uint32_t ldc, hipStream_t st);
+// The two halves of it for rows sharded over processes: S[c] += members of c among these rows, ascending (S carries the
+// running sums of the ranks before this one); the last rank divides by the GLOBAL counts.
+int32_t km_update_sums(const float* X, uint32_t ldx, uint32_t d, const uint32_t* sorted_ids, const uint32_t* starts, uint32_t k, float* S,
+                       uint32_t ldc, hipStream_t st);
+int32_t km_finish_centroids(const float* S, const uint32_t* counts, uint32_t k, uint32_t ldc, float* Cnew, hipStream_t st);
 
-// calculate_kmeans_cost (ivfflat.rs:138-149): strict left-to-right f32 fold of mind[0..n); result at *out_dev.
-int32_t km_cost_fold(const float* mind, uint64_t n, float* out_dev, hipStream_t st);
+// calculate_kmeans_cost (ivfflat.rs:138-149): strict left-to-right f32 fold of mind[0..n) starting from *init_dev
+// (nullptr = 0.0: the fold of a single process); result at *out_dev.
+int32_t km_cost_fold(const float* mind, uint64_t n, const float* init_dev, float* out_dev, hipStream_t st);
 
 // bitwise equality of two f32 arrays (to_hashkey comparison, ivfflat.rs:84-93); *flag_dev = 1 if ANY word differs.
 int32_t km_differs(const float* a, const float* b, uint64_t n_words, uint32_t* flag_dev, hipStream_t st);

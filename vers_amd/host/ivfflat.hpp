@@ -72,16 +72,17 @@ class IVFFlatIndex {
       draws.resize(num_attempts * num_clusters);
       for (auto& x : draws) x = vectors.empty() ? 0 : rng() % vectors.size();
     }
-    std::vector<float> cent(num_clusters * N ? num_clusters * N : 1);
+    // centroids are written straight into the Vec<Vector<N>> with ITS pitch (sizeof(Vector<N>) = round_up(4N, 256))
+    std::vector<Vector<N>> cent(num_clusters);
     std::vector<uint64_t> asg(vectors.size() ? vectors.size() : 1);
     float cost = 0; int32_t kept = 0;
     check(vers_ivf_build(ix.h_, vectors.empty() ? nullptr : vectors[0].v, vectors.size(), sizeof(Vector<N>), num_clusters,
-                         num_attempts, max_iterations, draws.data(), cent.data(), asg.data(), &cost, &kept, nullptr));
+                         num_attempts, max_iterations, draws.data(), cent.empty() ? nullptr : cent[0].v, sizeof(Vector<N>),
+                         asg.data(), &cost, &kept, nullptr));
     ix.num_centroids = num_clusters;
     ix.values = vectors;  // ivfflat.rs:131 vectors.clone()
     if (kept) {
-      ix.centroids.resize(num_clusters);
-      for (size_t c = 0; c < num_clusters; ++c) std::memcpy(ix.centroids[c].v, &cent[c * N], N * sizeof(float));
+      ix.centroids = std::move(cent);
       ix.assignments.assign(asg.begin(), asg.begin() + vectors.size());
     }  // else: nothing beat +inf -> empty centroids / assignments (ivfflat.rs:109-110)
     ix.ids.assign(num_clusters, {});

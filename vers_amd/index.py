@@ -45,13 +45,10 @@ class IVFFlatIndex:
     # -- IVFFlatIndex::build_index (ivfflat.rs:102-136) -----------------------------------------
     @classmethod
     def build_index(cls, num_clusters: int, num_attempts: int, max_iterations: int, vectors, init_indices=None,
-                    rng=None, device: int = 0, build_shard=None) -> "IVFFlatIndex":
-        """build_shard = (rank, world[, group]): assign step sharded over processes, see set_build_shard."""
+                    rng=None, device: int = 0) -> "IVFFlatIndex":
         vectors = np.ascontiguousarray(vectors, dtype=np.float32)
         n, d = vectors.shape
         self = cls(d, device)
-        if build_shard is not None:
-            self.set_build_shard(*build_shard)
         if init_indices is None:
             # initialize_centroids (ivfflat.rs:18-27): k draws WITH replacement per attempt
             rng = rng or np.random.default_rng()
@@ -63,7 +60,7 @@ class IVFFlatIndex:
         cost = C.c_float(0); kept = C.c_int32(0)
         iters = np.zeros(max(num_attempts, 1), dtype=np.uint64)
         check(lib().vers_ivf_build(self._h, _ptr(vectors), n, 4 * d, num_clusters, num_attempts, max_iterations,
-                                   _ptr(init), _ptr(cent), _ptr(asg), C.byref(cost), C.byref(kept), _ptr(iters)))
+                                   _ptr(init), _ptr(cent), 4 * d, _ptr(asg), C.byref(cost), C.byref(kept), _ptr(iters)))
         self.num_centroids = num_clusters
         self.values = vectors.copy()  # ivfflat.rs:131 vectors.clone()
         self.cost = np.float32(cost.value)
@@ -176,7 +173,7 @@ class IVFFlatIndex:
         iters = np.zeros(max(num_attempts, 1), dtype=np.uint64)
         ld = (self.d + 3) // 4 * 4
         check(lib().vers_ivf_build_dev(self._h, _vp(rows_ptr), n, ld, num_clusters, num_attempts, max_iterations, _ptr(init),
-                                       None, None, C.byref(cost), C.byref(kept), _ptr(iters)))
+                                       None, 0, None, C.byref(cost), C.byref(kept), _ptr(iters)))
         self.num_centroids = num_clusters
         self.cost = np.float32(cost.value); self.iterations = iters[:num_attempts]
         return bool(kept.value)
@@ -195,31 +192,23 @@ class IVFFlatIndex:
     def set_shard(self, rank: int, world: int):
         check(lib().vers_ivf_set_shard(self._h, rank, world))
 
-    def set_build_shard(self, rank: int, world: int, group=None):
-        """build_index with assign_to_clusters sharded by point range over the processes of `group` (one per GPU,
-        every process passes the same rows): one all-gather of the u32 assignments (and, on the last pass, the f32
-        minimum distances) per k-means pass -- vers_amd.dist.all_gather_chunks_inplace, RCCL on the GPUs.  The
-        result is bit-identical to the single-process build."""
-        from . import capi as _capi
-        if world <= 1:
-            check(lib().vers_ivf_set_build_shard(self._h, 0, 1, None, None))
-            self._exchange_cb = None
-            return
-        from .dist import all_gather_chunks_inplace
-
-        def _exchange(_ctx, assign_ptr, mind_ptr, n_padded, chunk):
-            try:
-                all_gather_chunks_inplace(assign_ptr, "int32", n_padded, chunk, rank, self.device, group)
-                if mind_ptr:
-                    all_gather_chunks_inplace(mind_ptr, "float32", n_padded, chunk, rank, self.device, group)
-                return 0
-            except Exception as e:  # never unwind through the C frame
-                import sys
-                print(f"[vers] assign exchange failed: {e!r}", file=sys.stderr, flush=True)
-                return 1
-
-        self._exchange_cb = _capi.ASSIGN_EXCHANGE_FN(_exchange)  # keep alive as long as the handle may call it
-        check(lib().vers_ivf_set_build_shard(self._h, rank, world, C.cast(self._exchange_cb, C.c_void_p), None))
+    def build_sharded_dev(self, rows_ptr: int, n_local: int, ld: int, row_begin: int, n_total: int, num_clusters: int,
+                          num_attempts: int, max_iterations: int, init_indices, comm, want_assignments: bool = False):
+        """build_index over a ROW-SHARDED corpus (vers_ivf_build_sharded_dev): this process holds rows
+        [row_begin, row_begin + n_local) of n_total in HBM; `comm` is a vers_amd.dist.TorchComm (RCCL on the GPUs).
+        Bit-identical to the single-process build; afterwards the handle holds the lists LPT deals to comm.rank."""
+        init = np.ascontiguousarray(np.asarray(init_indices).reshape(-1), dtype=np.uint64)
+        cost = C.c_float(0); kept = C.c_int32(0)
+        iters = np.zeros(max(num_attempts, 1), dtype=np.uint64)
+        asg = np.zeros(max(n_local, 1), dtype=np.uint64) if want_assignments else None
+        check(lib().vers_ivf_build_sharded_dev(self._h, _vp(rows_ptr), n_local, ld, row_begin, n_total, num_clusters, num_attempts,
+                                               max_iterations, _ptr(init), comm.ptr(), _ptr(asg) if want_assignments else None,
+                                               C.byref(cost), C.byref(kept), _ptr(iters)))
+        self.num_centroids = num_clusters
+        self.cost = np.float32(cost.value); self.iterations = iters[:num_attempts]
+        if want_assignments:
+            self.local_assignments = asg[:n_local]
+        return bool(kept.value)
 
     def owners(self):
         _, k, _ = self.info()
