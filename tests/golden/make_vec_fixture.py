@@ -1,4 +1,4 @@
-"""Writes tests/golden/wiki_like_300d.vec (a small stand-in for fastText wiki-news-300d-1M.vec, which the
+"""Writes tests/golden/wiki_like_300d.vec.gz (a 2,000-word stand-in for fastText wiki-news-300d-1M.vec, which the
 reference fetches from the network and does not bundle) and tests/golden/wiki_like_expected.npz: what the
 reference harness sequence (utils.rs:7-66,117-184; main.rs:60-68 parameters k=20, iters=10, attempts
 reduced to 2 with injected draws) must print for it, computed by the C oracle and cross-checked against the
@@ -19,12 +19,12 @@ from tests import datagen as dg  # noqa: E402
 from tests.golden.make_golden import bits, init_draws, same  # noqa: E402
 
 OUT = os.path.dirname(os.path.abspath(__file__))
-N_WORDS, D, K, ATTEMPTS, ITERS = 250, 300, 20, 2, 10
-QUEEN_AT = 137
+N_WORDS, D, K, ATTEMPTS, ITERS = 2000, 300, 20, 2, 10   # ~2,000 words x 300, contains "queen"
+QUEEN_AT = 1137
 
 
 def raw_rows():
-    x = dg.dist_c(0x51C0, N_WORDS, D, 25, dg.default_sigma(D))
+    x = dg.dist_c(0x51C0, N_WORDS, D, 60, dg.default_sigma(D))
     scale = (1.0 + (np.arange(N_WORDS) % 7)[:, None] * 0.25).astype(np.float32)   # un-normalised, like fastText
     return (np.round(x * scale * 1024.0) / 1024.0).astype(np.float32)
 
@@ -58,9 +58,12 @@ def expected():
 
 if __name__ == "__main__":
     raw = raw_rows(); ws = words()
-    with open(os.path.join(OUT, "wiki_like_300d.vec"), "w") as f:
-        f.write(f"{N_WORDS} {D}\n")
+    import gzip
+    # gzip with mtime 0: the committed file is reproducible; tests gunzip it into a temp dir (the reference's loader
+    # reads plain text).  Values are multiples of 2^-10: at most 10 decimals, trailing zeros dropped.
+    with gzip.GzipFile(os.path.join(OUT, "wiki_like_300d.vec.gz"), "wb", compresslevel=9, mtime=0) as f:
+        f.write(f"{N_WORDS} {D}\n".encode())
         for w, r in zip(ws, raw):
-            f.write(w + " " + " ".join(f"{v:.10f}" for v in r) + "\n")
+            f.write((w + " " + " ".join((f"{v:.10f}".rstrip("0").rstrip(".") or "0") for v in r) + "\n").encode())
     np.savez_compressed(os.path.join(OUT, "wiki_like_expected.npz"), **expected())
-    print("wrote wiki_like_300d.vec", os.path.getsize(os.path.join(OUT, "wiki_like_300d.vec")), "bytes")
+    print("wrote wiki_like_300d.vec.gz", os.path.getsize(os.path.join(OUT, "wiki_like_300d.vec.gz")), "bytes")

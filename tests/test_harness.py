@@ -10,7 +10,17 @@ import pytest
 from tests.golden import make_vec_fixture as mv
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-VEC = os.path.join(ROOT, "tests", "golden", "wiki_like_300d.vec")
+VEC_GZ = os.path.join(ROOT, "tests", "golden", "wiki_like_300d.vec.gz")
+
+
+@pytest.fixture(scope="module")
+def VEC(tmp_path_factory):
+    """the committed fixture is gzipped (2,000 words x 300: 1.2 MB instead of 6 MB); the loader reads plain text"""
+    import gzip
+    p = os.path.join(tmp_path_factory.mktemp("vec"), "wiki_like_300d.vec")
+    with gzip.open(VEC_GZ, "rb") as src, open(p, "wb") as dst:
+        dst.write(src.read())
+    return p
 
 
 @pytest.fixture(scope="module")
@@ -18,7 +28,7 @@ def expected():
     return np.load(os.path.join(ROOT, "tests", "golden", "wiki_like_expected.npz"))
 
 
-def test_loader_matches_reference_contract(expected):
+def test_loader_matches_reference_contract(expected, VEC):
     from vers_amd.harness import load_wiki_vector
     vecs, w2i, i2w, test_embs = load_wiki_vector(VEC, 300)
     assert vecs.shape == (mv.N_WORDS - 1, 300) and "queen" not in w2i and len(i2w) == mv.N_WORDS - 1
@@ -30,7 +40,7 @@ def test_loader_matches_reference_contract(expected):
 
 
 @pytest.mark.gpu
-def test_ivfflat_demo_sequence(expected, tmp_path):
+def test_ivfflat_demo_sequence(expected, tmp_path, VEC):
     from vers_amd.harness import load_wiki_vector, test_ivfflat as run_ivfflat
     vecs, w2i, i2w, test_embs = load_wiki_vector(VEC, 300)
     printed, results = run_ivfflat(vecs, w2i, i2w, mv.K, mv.ATTEMPTS, mv.ITERS, test_embs, init_indices=expected["init"],
@@ -40,3 +50,42 @@ def test_ivfflat_demo_sequence(expected, tmp_path):
     assert np.array_equal(np.array([d for _, d in results], dtype=np.float32).view(np.uint32), expected["result_dist_bits"])
     assert np.array_equal(np.array([s for _, s in printed], dtype=np.float32).view(np.uint32), expected["result_sqrt_bits"])
     assert w2i["queen"] == mv.N_WORDS - 1 and printed[0][0] == "queen"   # the added (normalised) queen is its raw self's nearest
+
+
+def test_rust_display_of_f32():
+    """`Distance: {}` (utils.rs:155) prints an f32 the way Rust's Display does: shortest round-trip, positional"""
+    from vers_amd.harness import fmt_f32
+    assert fmt_f32(np.float32(1.0)) == "1" and fmt_f32(np.float32(0.5)) == "0.5" and fmt_f32(np.float32(0.1)) == "0.1"
+    assert fmt_f32(np.float32(1e-7)) == "0.0000001" and fmt_f32(np.float32(16777216.0)) == "16777216"
+    assert fmt_f32(np.float32(0.0)) == "0" and fmt_f32(np.sqrt(np.float32(2.0))) == "1.4142135"
+
+
+@pytest.mark.gpu
+def test_cli_prints_the_reference_lines(expected, tmp_path):
+    """python -m vers_amd.harness <file.vec.gz> 20 2 10 --seed S: the demo end to end on the GPU, lines as the reference
+    prints them; ids / distances of the result lines == the oracle run with the same (seeded) draws."""
+    import subprocess
+    import sys
+    from oracle import c_oracle as co
+    from vers_amd.harness import fmt_f32, load_wiki_vector
+    import gzip
+    plain = os.path.join(tmp_path, "w.vec")
+    with gzip.open(VEC_GZ, "rb") as src, open(plain, "wb") as dst:
+        dst.write(src.read())
+    r = subprocess.run([sys.executable, "-m", "vers_amd.harness", VEC_GZ, str(mv.K), "2", str(mv.ITERS), "--seed", "7", "--index-file",
+                        os.path.join(tmp_path, "ivfflat.index")], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    assert r.returncode == 0, r.stderr
+    lines = r.stdout.splitlines()
+    assert lines[0] == "IVFFlat Index:-----" and lines[1] == f"Inserting queen {mv.N_WORDS - 1}" and lines[2] == "Index saved successfully!"
+    vecs, w2i, i2w, test_embs = load_wiki_vector(plain, 300)
+    init = np.random.default_rng(7).integers(0, len(vecs), size=2 * mv.K)
+    b = co.build_index(vecs, mv.K, 2, mv.ITERS, init)
+    qn = co.normalize(test_embs[0][1][None])[0]
+    c = co.add_cluster(b["centroids"], qn)
+    ids = [list(l) for l in b["ids"]]; ids[c].append(len(vecs))
+    values = np.concatenate([vecs, qn[None]], axis=0)
+    ri, rd = co.search_approximate(values, b["centroids"], ids, test_embs[0][1], 10)
+    i2w[len(vecs)] = "queen"
+    want = [f"{i}. Word: {i2w[int(v)]}. Distance: {fmt_f32(np.sqrt(np.float32(dd), dtype=np.float32))}" for i, (v, dd) in enumerate(zip(ri, rd))]
+    assert lines[3:3 + len(want)] == want
+    assert lines[3 + len(want)].startswith("Time taken to test: ")

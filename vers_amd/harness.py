@@ -50,29 +50,96 @@ def load_wiki_vector(file_path: str, d: int):
     return all_vecs, word_to_idx, idx_to_word, test_embs
 
 
-def run_test(index: IVFFlatIndex, index_file_name: str, vectors: list, word_to_idx: dict, idx_to_word: dict, test_embs):
-    """utils.rs:117-158 for T = IVFFlatIndex.  `vectors` is a python list of rows (the reference's Vec<Vector<N>>)."""
+def fmt_f32(x) -> str:
+    """Rust's `{}` for an f32: the shortest decimal that round-trips, never in scientific notation."""
+    x = np.float32(x)
+    if np.isnan(x):
+        return "NaN"
+    if np.isinf(x):
+        return "inf" if x > 0 else "-inf"
+    return np.format_float_positional(x, unique=True, trim="-")
+
+
+def run_test(index: IVFFlatIndex, index_file_name: str, vectors: list, word_to_idx: dict, idx_to_word: dict, test_embs,
+             echo=None):
+    """utils.rs:117-158 for T = IVFFlatIndex.  `vectors` is a python list of rows (the reference's Vec<Vector<N>>).
+    echo: callable that receives the lines the reference println!s (the CLI passes print)."""
+    say = echo or (lambda _line: None)
     for word, emb in test_embs:
         vec_id = len(vectors)
         vectors.append(np.asarray(emb, dtype=np.float32).copy())        # raw, un-normalised (utils.rs:129-131)
+        say(f"Inserting {word} {vec_id}")                               # utils.rs:133
         idx_to_word[vec_id] = word
         word_to_idx[word] = vec_id
         index.add(_normalize_rows(emb[None])[0], vec_id)                # utils.rs:136
-    index.save_index(index_file_name)                                   # utils.rs:140
+    try:
+        index.save_index(index_file_name)                               # utils.rs:140-143
+        say("Index saved successfully!")
+    except OSError as e:
+        import sys
+        print(f"Index save failed: {e}", file=sys.stderr)
     reload_index = IVFFlatIndex.load_index(index_file_name, index.d, index.device)   # utils.rs:145
     results = reload_index.search_approximate(vectors[word_to_idx["queen"]], 10)     # utils.rs:148: the RAW vector
     out = [(idx_to_word[i], np.sqrt(np.float32(dist), dtype=np.float32)) for i, dist in results]  # utils.rs:151-157
+    for i, (word, dist) in enumerate(out):
+        say(f"{i}. Word: {word}. Distance: {fmt_f32(dist)}")
     reload_index.close()
     return out, results
 
 
 def test_ivfflat(vectors: np.ndarray, word_to_idx: dict, idx_to_word: dict, num_clusters: int, num_attempts: int,
-                 max_iterations: int, test_embs, init_indices=None, index_file_name: str = "ivfflat.index", device: int = 0):
+                 max_iterations: int, test_embs, init_indices=None, index_file_name: str = "ivfflat.index", device: int = 0,
+                 echo=None):
     """utils.rs:160-184.  `init_indices` injects the reference's unseeded centroid draws (ivfflat.rs:18-27)."""
+    if echo:
+        echo("IVFFlat Index:-----")                                     # utils.rs:169
     ivfflat = IVFFlatIndex.build_index(num_clusters, num_attempts, max_iterations, vectors, init_indices=init_indices,
                                        device=device)
     vec_list = [v for v in np.asarray(vectors, dtype=np.float32)]
     try:
-        return run_test(ivfflat, index_file_name, vec_list, word_to_idx, idx_to_word, test_embs)
+        return run_test(ivfflat, index_file_name, vec_list, word_to_idx, idx_to_word, test_embs, echo=echo)
     finally:
         ivfflat.close()
+
+
+def main(argv=None) -> int:
+    """The reference's demo (main.rs:54-68 with the IVFFlat call enabled: k=20, attempts=3, iterations=10) as a command:
+         python -m vers_amd.harness <file.vec> [num_clusters [num_attempts [max_iterations]]] [--seed S] [--index-file P]
+    load -> build_index -> add(normalize(queen)) -> save_index -> load_index -> search_approximate(raw queen, 10) on the
+    MI355X, printing the reference's own lines (utils.rs:133,141,151-157,169).  The vector length is read from the
+    file's first data line (the reference fixes it at compile time: const DIM = 300).  --seed makes the centroid draws
+    of initialize_centroids reproducible (numpy default_rng; the reference draws from an unseeded thread_rng)."""
+    import argparse
+    import gzip
+    import time
+    ap = argparse.ArgumentParser(prog="python -m vers_amd.harness", description=main.__doc__)
+    ap.add_argument("vec_file")
+    ap.add_argument("num_clusters", nargs="?", type=int, default=20)
+    ap.add_argument("num_attempts", nargs="?", type=int, default=3)
+    ap.add_argument("max_iterations", nargs="?", type=int, default=10)
+    ap.add_argument("--seed", type=int, default=None)
+    ap.add_argument("--index-file", default="ivfflat.index")
+    ap.add_argument("--device", type=int, default=0)
+    a = ap.parse_args(argv)
+    path = a.vec_file
+    opener = gzip.open if path.endswith(".gz") else open
+    with opener(path, "rt", encoding="utf-8") as f:
+        next(f)
+        d = len(f.readline().split()) - 1
+    if path.endswith(".gz"):  # the loader reads plain text like the reference's: unpack next to the index file
+        plain = os.path.splitext(a.index_file)[0] + ".vec"
+        with gzip.open(path, "rb") as src, open(plain, "wb") as dst:
+            dst.write(src.read())
+        path = plain
+    vecs, w2i, i2w, test_embs = load_wiki_vector(path, d)
+    rng = np.random.default_rng(a.seed)
+    init = rng.integers(0, max(len(vecs), 1), size=a.num_attempts * a.num_clusters)
+    t0 = time.perf_counter()
+    test_ivfflat(vecs, w2i, i2w, a.num_clusters, a.num_attempts, a.max_iterations, test_embs, init_indices=init,
+                 index_file_name=a.index_file, device=a.device, echo=print)
+    print(f"Time taken to test: {time.perf_counter() - t0:.6f}s")        # main.rs:101-102 (Duration's {:?})
+    return 0
+
+
+if __name__ == "__main__":
+    raise SystemExit(main())

@@ -242,51 +242,65 @@ class IVFFlatIndex:
         check(lib().vers_ivf_poll(self._h, _vp(stream)))
 
     # -- Index::save_index / load_index (base.rs:31-58) ---------------------------------------------
-    # bincode 1.3.3 default options: little endian, fixed-width ints, usize/len as u64, struct = fields in
-    # order without tags, Vec<T> = u64 len + items, [f32; N] through serde_arrays = N raw f32 (no length).
-    # (bincode / serde_arrays sources are not vendored in the reference: layout restated from their
-    # published format -- "parity unpinned" for this row, see DESIGN.md.)
     def save_index(self, file_path: str):
-        with open(file_path, "wb") as f:
-            f.write(struct.pack("<Q", self.num_centroids))
-            for mat in (self.values, self.centroids):
-                m = np.ascontiguousarray(mat, dtype="<f4")
-                f.write(struct.pack("<Q", m.shape[0])); f.write(m.tobytes())
-            a = np.ascontiguousarray(self.assignments, dtype="<u8")
-            f.write(struct.pack("<Q", a.size)); f.write(a.tobytes())
-            f.write(struct.pack("<Q", len(self.ids)))
-            for lst in self.ids:
-                l = np.asarray(lst, dtype="<u8")
-                f.write(struct.pack("<Q", l.size)); f.write(l.tobytes())
+        write_index_file(file_path, self.num_centroids, self.values, self.centroids, self.assignments, self.ids)
 
     @classmethod
     def load_index(cls, file_path: str, d: int, device: int = 0) -> "IVFFlatIndex":
         """`d` plays the role of the const generic N of IVFFlatIndex<N>."""
-        with open(file_path, "rb") as f:
-            buf = f.read()
-        off = 0
-
-        def u64():
-            nonlocal off
-            (v,) = struct.unpack_from("<Q", buf, off); off += 8
-            return v
-
-        def take(dtype, count):
-            nonlocal off
-            nbytes = count * np.dtype(dtype).itemsize
-            if off + nbytes > len(buf):
-                raise IOError("Deserialization error: unexpected end of file")
-            a = np.frombuffer(buf, dtype=dtype, count=count, offset=off).copy(); off += nbytes
-            return a
-
-        try:
-            self = cls(d, device)
-            self.num_centroids = u64()
-            self.values = take("<f4", u64() * d).reshape(-1, d)
-            self.centroids = take("<f4", u64() * d).reshape(-1, d)
-            self.assignments = take("<u8", u64())
-            self.ids = [list(map(int, take("<u8", u64()))) for _ in range(u64())]
-        except struct.error as e:
-            raise IOError(f"Deserialization error: {e}")
+        f = read_index_file(file_path, d)
+        self = cls(d, device)
+        self.num_centroids, self.values, self.centroids = f["num_centroids"], f["values"], f["centroids"]
+        self.assignments, self.ids = f["assignments"], f["ids"]
         self._upload()
         return self
+
+
+# The index file of Index::save_index (base.rs:31-43): bincode 1.3.3 with default options over the five fields of
+# IVFFlatIndex<N> in declaration order (ivfflat.rs:9-15) -- little endian, fixed-width integers, usize and every
+# length as u64, a struct is its fields back to back without tags or names, Vec<T> = u64 length + items,
+# Vector<N>([f32; N]) through serde_arrays = N raw f32 WITHOUT a length (a fixed-size array is a tuple to serde), and
+# no padding: the 256-byte alignment of Vector<N> exists in memory only.  (bincode / serde_arrays sources are not
+# vendored in the reference: layout restated from their published format -- "parity unpinned" for this row, see
+# DESIGN.md; tests/test_index_file.py pins these rules byte by byte and against the C++ host mirror.)
+def write_index_file(file_path, num_centroids, values, centroids, assignments, ids):
+    with open(file_path, "wb") as f:
+        f.write(struct.pack("<Q", int(num_centroids)))
+        for mat in (values, centroids):
+            m = np.ascontiguousarray(mat, dtype="<f4")
+            f.write(struct.pack("<Q", m.shape[0])); f.write(m.tobytes())
+        a = np.ascontiguousarray(assignments, dtype="<u8")
+        f.write(struct.pack("<Q", a.size)); f.write(a.tobytes())
+        f.write(struct.pack("<Q", len(ids)))
+        for lst in ids:
+            l = np.asarray(lst, dtype="<u8")
+            f.write(struct.pack("<Q", l.size)); f.write(l.tobytes())
+
+
+def read_index_file(file_path, d: int) -> dict:
+    """The five fields; raises IOError("Deserialization error: ...") like base.rs:52-57 on a short or oversized file."""
+    with open(file_path, "rb") as f:
+        buf = f.read()
+    off = 0
+
+    def u64():
+        nonlocal off
+        if off + 8 > len(buf):
+            raise IOError("Deserialization error: unexpected end of file")
+        (v,) = struct.unpack_from("<Q", buf, off); off += 8
+        return v
+
+    def take(dtype, count):
+        nonlocal off
+        nbytes = count * np.dtype(dtype).itemsize
+        if off + nbytes > len(buf):
+            raise IOError("Deserialization error: unexpected end of file")
+        a = np.frombuffer(buf, dtype=dtype, count=count, offset=off).copy(); off += nbytes
+        return a
+
+    out = {"num_centroids": u64()}
+    out["values"] = take("<f4", u64() * d).reshape(-1, d)
+    out["centroids"] = take("<f4", u64() * d).reshape(-1, d)
+    out["assignments"] = take("<u8", u64())
+    out["ids"] = [list(map(int, take("<u8", u64()))) for _ in range(u64())]
+    return out
