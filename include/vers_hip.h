@@ -119,6 +119,14 @@ typedef struct vers_ivf vers_ivf_t;
 
 int32_t vers_ivf_create(int32_t device, uint32_t d, vers_ivf_t** out);
 int32_t vers_ivf_destroy(vers_ivf_t* h);
+/* Metric of the index (extension; set before build / upload).  VERS_METRIC_L2SQ (default) is what
+ * the reference's IVFFlat computes everywhere (ivfflat.rs:37-38,146,159,175,205).  VERS_METRIC_COSDIST puts
+ * Vector::cosine_similarity(normalized=true) = 1 - dot_product (base.rs:91-93,153-155: sequential f32 dot) in each of
+ * those places -- assign_to_clusters, the k-means cost, add, the ranking of the lists and the scoring of their rows
+ * -- with the same first-minimum / stable-sort rules; centroids stay plain means (not re-normalised), as in the
+ * reference.  Results carry the bits of the sequential f32 arithmetic in both metrics. */
+int32_t vers_ivf_set_metric(vers_ivf_t* h, uint32_t metric);
+int32_t vers_ivf_get_metric(vers_ivf_t* h, uint32_t* out_metric);
 
 /* IVFFlatIndex::build_index(num_clusters, num_attempts, max_iterations, &vectors)
  * (ivfflat.rs:102-136), k-means included (build_kmeans :73-100, cost :138-149).

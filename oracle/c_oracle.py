@@ -66,6 +66,21 @@ def lib():
         L.vo_search_nprobe.argtypes = [fp, fp, C.c_uint64, C.c_uint64, u64p, u64p, fp, C.c_uint64, C.c_uint64, u64p, fp]
         L.vo_add_cluster.restype = C.c_int64
         L.vo_add_cluster.argtypes = [fp, C.c_uint64, C.c_uint64, fp]
+        # the same with a metric argument (0 = squared L2 as the reference, 1 = cosine distance 1 - dot: extension)
+        L.vo_assign_m.restype = C.c_int
+        L.vo_assign_m.argtypes = L.vo_assign.argtypes + [C.c_int]
+        L.vo_cost_m.restype = C.c_float
+        L.vo_cost_m.argtypes = L.vo_cost.argtypes + [C.c_int]
+        L.vo_kmeans_m.restype = C.c_int
+        L.vo_kmeans_m.argtypes = L.vo_kmeans.argtypes + [C.c_int]
+        L.vo_build_m.restype = C.c_int
+        L.vo_build_m.argtypes = L.vo_build.argtypes + [C.c_int]
+        L.vo_search_m.restype = C.c_int64
+        L.vo_search_m.argtypes = L.vo_search.argtypes + [C.c_int]
+        L.vo_search_nprobe_m.restype = C.c_int64
+        L.vo_search_nprobe_m.argtypes = L.vo_search_nprobe.argtypes + [C.c_int]
+        L.vo_add_cluster_m.restype = C.c_int64
+        L.vo_add_cluster_m.argtypes = L.vo_add_cluster.argtypes + [C.c_int]
     return _lib
 
 
@@ -112,10 +127,10 @@ def search_exhaustive(data, query, top_k, metric=0):
     return ids[:m], dist[:m]
 
 
-def assign_to_clusters(X, Cn):
+def assign_to_clusters(X, Cn, metric=0):
     X, px = _f(X); Cn, pc = _f(Cn)
     out = np.empty(X.shape[0], dtype=np.uint64)
-    _chk(lib().vo_assign(px, X.shape[0], pc, Cn.shape[0], X.shape[1], out.ctypes.data_as(C.POINTER(C.c_uint64))))
+    _chk(lib().vo_assign_m(px, X.shape[0], pc, Cn.shape[0], X.shape[1], out.ctypes.data_as(C.POINTER(C.c_uint64)), metric))
     return out
 
 
@@ -126,27 +141,27 @@ def update_centroids(X, assign, k):
     return out
 
 
-def kmeans_cost(X, Cn, assign) -> np.float32:
+def kmeans_cost(X, Cn, assign, metric=0) -> np.float32:
     X, px = _f(X); Cn, pc = _f(Cn); assign, pa = _u(assign)
-    return np.float32(lib().vo_cost(px, X.shape[0], pc, pa, X.shape[1]))
+    return np.float32(lib().vo_cost_m(px, X.shape[0], pc, pa, X.shape[1], metric))
 
 
-def build_kmeans(X, k, max_iterations, init_idx):
+def build_kmeans(X, k, max_iterations, init_idx, metric=0):
     X, px = _f(X); init_idx, pi = _u(init_idx)
     n, d = X.shape
     Cn = np.empty((k, d), dtype=np.float32); a = np.empty(n, dtype=np.uint64); it = C.c_uint64(0)
-    _chk(lib().vo_kmeans(px, n, d, k, max_iterations, pi, Cn.ctypes.data_as(C.POINTER(C.c_float)),
-                         a.ctypes.data_as(C.POINTER(C.c_uint64)), C.byref(it)))
+    _chk(lib().vo_kmeans_m(px, n, d, k, max_iterations, pi, Cn.ctypes.data_as(C.POINTER(C.c_float)),
+                           a.ctypes.data_as(C.POINTER(C.c_uint64)), C.byref(it), metric))
     return Cn, a, int(it.value)
 
 
-def build_index(X, k, num_attempts, max_iterations, init_idx):
+def build_index(X, k, num_attempts, max_iterations, init_idx, metric=0):
     X, px = _f(X); init_idx, pi = _u(np.asarray(init_idx).reshape(-1))
     n, d = X.shape
     Cn = np.zeros((k, d), dtype=np.float32); a = np.zeros(n, dtype=np.uint64)
     cost = C.c_float(0); kept = C.c_int(0); best = C.c_uint64(0)
-    _chk(lib().vo_build(px, n, d, k, num_attempts, max_iterations, pi, Cn.ctypes.data_as(C.POINTER(C.c_float)),
-                        a.ctypes.data_as(C.POINTER(C.c_uint64)), C.byref(cost), C.byref(kept), C.byref(best)))
+    _chk(lib().vo_build_m(px, n, d, k, num_attempts, max_iterations, pi, Cn.ctypes.data_as(C.POINTER(C.c_float)),
+                          a.ctypes.data_as(C.POINTER(C.c_uint64)), C.byref(cost), C.byref(kept), C.byref(best), metric))
     if not kept.value:
         Cn = np.zeros((0, d), dtype=np.float32); a = np.zeros(0, dtype=np.uint64)
     ids = [np.nonzero(a == c)[0].astype(np.uint64) for c in range(k)]
@@ -162,27 +177,27 @@ def csr(ids):
     return off, np.ascontiguousarray(flat, dtype=np.uint64)
 
 
-def search_approximate(values, centroids, ids, query, top_k):
+def search_approximate(values, centroids, ids, query, top_k, metric=0):
     values, pv = _f(values); centroids, pc = _f(centroids); query, pq = _f(query)
     off, flat = csr(ids)
     oi = np.empty(max(1, top_k), dtype=np.uint64); od = np.empty(max(1, top_k), dtype=np.float32)
-    m = _chk(lib().vo_search(pv, pc, centroids.shape[0], values.shape[1] if values.ndim == 2 else centroids.shape[1],
-                             off.ctypes.data_as(C.POINTER(C.c_uint64)), flat.ctypes.data_as(C.POINTER(C.c_uint64)),
-                             pq, top_k, oi.ctypes.data_as(C.POINTER(C.c_uint64)), od.ctypes.data_as(C.POINTER(C.c_float))))
+    m = _chk(lib().vo_search_m(pv, pc, centroids.shape[0], values.shape[1] if values.ndim == 2 else centroids.shape[1],
+                               off.ctypes.data_as(C.POINTER(C.c_uint64)), flat.ctypes.data_as(C.POINTER(C.c_uint64)),
+                               pq, top_k, oi.ctypes.data_as(C.POINTER(C.c_uint64)), od.ctypes.data_as(C.POINTER(C.c_float)), metric))
     return oi[:m], od[:m]
 
 
-def search_nprobe(values, centroids, ids, query, top_k, nprobe):
+def search_nprobe(values, centroids, ids, query, top_k, nprobe, metric=0):
     values, pv = _f(values); centroids, pc = _f(centroids); query, pq = _f(query)
     off, flat = csr(ids)
     oi = np.empty(max(1, top_k), dtype=np.uint64); od = np.empty(max(1, top_k), dtype=np.float32)
-    m = _chk(lib().vo_search_nprobe(pv, pc, centroids.shape[0], values.shape[1],
-                                    off.ctypes.data_as(C.POINTER(C.c_uint64)), flat.ctypes.data_as(C.POINTER(C.c_uint64)),
-                                    pq, top_k, nprobe, oi.ctypes.data_as(C.POINTER(C.c_uint64)),
-                                    od.ctypes.data_as(C.POINTER(C.c_float))))
+    m = _chk(lib().vo_search_nprobe_m(pv, pc, centroids.shape[0], values.shape[1],
+                                      off.ctypes.data_as(C.POINTER(C.c_uint64)), flat.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                      pq, top_k, nprobe, oi.ctypes.data_as(C.POINTER(C.c_uint64)),
+                                      od.ctypes.data_as(C.POINTER(C.c_float)), metric))
     return oi[:m], od[:m]
 
 
-def add_cluster(centroids, x) -> int:
+def add_cluster(centroids, x, metric=0) -> int:
     centroids, pc = _f(centroids); x, px = _f(x)
-    return int(_chk(lib().vo_add_cluster(pc, centroids.shape[0], centroids.shape[1], px)))
+    return int(_chk(lib().vo_add_cluster_m(pc, centroids.shape[0], centroids.shape[1], px, metric)))

@@ -62,6 +62,12 @@ def cosine_distance(a, b) -> np.ndarray:
     return (f32(1.0) - dot(a, b)).astype(f32)
 
 
+def _dist(a, b, metric=0) -> np.ndarray:
+    """metric 0: squared_euclidean (what ivfflat.rs calls everywhere); 1: cosine distance 1 - dot (base.rs:153-155) in
+    the same places -- the metric EXTENSION of SURVEY.md 8f-3, not a reference code path."""
+    return squared_euclidean(a, b) if metric == 0 else cosine_distance(a, b)
+
+
 def _stable_order(dist: np.ndarray) -> np.ndarray:
     """sorted_by(partial_cmp().unwrap()): stable ascending; NaN panics once compared."""
     if dist.size >= 2 and np.isnan(dist).any():
@@ -77,7 +83,7 @@ def search_exhaustive(data, query, top_k, metric=0):
     return order.astype(np.uint64), dist[order]
 
 
-def assign_to_clusters(X, C) -> np.ndarray:
+def assign_to_clusters(X, C, metric=0) -> np.ndarray:
     """ivfflat.rs:29-46 -- first minimum wins (min_by); NaN panics when k >= 2."""
     X = np.asarray(X, dtype=f32)
     C = np.asarray(C, dtype=f32)
@@ -88,7 +94,7 @@ def assign_to_clusters(X, C) -> np.ndarray:
     out = np.empty(X.shape[0], dtype=np.uint64)
     step = max(1, (1 << 22) // max(1, C.shape[0] * X.shape[1]))
     for s in range(0, X.shape[0], step):
-        D = squared_euclidean(X[s:s + step, None, :], C[None, :, :])  # [rows, k]
+        D = _dist(X[s:s + step, None, :], C[None, :, :], metric)  # [rows, k]
         if C.shape[0] >= 2 and np.isnan(D).any():
             raise RefPanic("NaN distance in assign_to_clusters")
         out[s:s + step] = np.argmin(D, axis=1)  # np.argmin returns the first minimum
@@ -110,30 +116,30 @@ def update_centroids(X, assign, k) -> np.ndarray:
     return out
 
 
-def kmeans_cost(X, C, assign) -> np.float32:
+def kmeans_cost(X, C, assign, metric=0) -> np.float32:
     """ivfflat.rs:138-149 -- fold(0.0, +) over per-point distances in data order."""
-    per_point = squared_euclidean(np.asarray(X, dtype=f32), np.asarray(C, dtype=f32)[assign])
+    per_point = _dist(np.asarray(X, dtype=f32), np.asarray(C, dtype=f32)[assign], metric)
     if per_point.size == 0:
         return f32(0.0)
     return np.add.accumulate(per_point, dtype=f32)[-1]
 
 
-def build_kmeans(X, k, max_iterations, init_idx):
+def build_kmeans(X, k, max_iterations, init_idx, metric=0):
     """ivfflat.rs:73-100 with the unseeded draw (ivfflat.rs:18-27) injected as init_idx."""
     X = np.asarray(X, dtype=f32)
     C = X[np.asarray(init_idx, dtype=np.int64)].copy()
     iters = 0
     for _ in range(max_iterations):
-        a = assign_to_clusters(X, C)
+        a = assign_to_clusters(X, C, metric)
         Cn = update_centroids(X, a, k)
         iters += 1
         if C.view(np.uint32).tobytes() == Cn.view(np.uint32).tobytes():  # to_hashkey equality
             break
         C = Cn
-    return C, assign_to_clusters(X, C), iters
+    return C, assign_to_clusters(X, C, metric), iters
 
 
-def build_index(X, k, num_attempts, max_iterations, init_idx):
+def build_index(X, k, num_attempts, max_iterations, init_idx, metric=0):
     """ivfflat.rs:102-136.  Returns dict(centroids, assignments, ids, cost, kept)."""
     X = np.asarray(X, dtype=f32)
     best = f32(np.inf)
@@ -142,19 +148,19 @@ def build_index(X, k, num_attempts, max_iterations, init_idx):
     kept = False
     init_idx = np.asarray(init_idx).reshape(num_attempts, k) if num_attempts else init_idx
     for a in range(num_attempts):
-        C, asg, _ = build_kmeans(X, k, max_iterations, init_idx[a])
-        cost = kmeans_cost(X, C, asg)
+        C, asg, _ = build_kmeans(X, k, max_iterations, init_idx[a], metric)
+        cost = kmeans_cost(X, C, asg, metric)
         if cost < best:
             best, bc, ba, kept = cost, C, asg, True
     ids = [np.nonzero(ba == c)[0].astype(np.uint64) for c in range(k)]  # ascending vec_id
     return dict(centroids=bc, assignments=ba, ids=ids, cost=best, kept=kept)
 
 
-def search_approximate(values, centroids, ids, query, top_k):
+def search_approximate(values, centroids, ids, query, top_k, metric=0):
     """ivfflat.rs:153-198 -- nearest list, spill to the next while short; concatenation."""
     values = np.asarray(values, dtype=f32)
     centroids = np.asarray(centroids, dtype=f32)
-    cd = squared_euclidean(centroids, query) if centroids.shape[0] else np.zeros(0, f32)
+    cd = _dist(centroids, query, metric) if centroids.shape[0] else np.zeros(0, f32)
     ranked = _stable_order(cd)
     out_i, out_d = [], []
     curr, remainder = 0, top_k
@@ -162,7 +168,7 @@ def search_approximate(values, centroids, ids, query, top_k):
         if curr >= len(ranked):
             raise RefPanic("index out of bounds: nearest_centroids[curr_cluster]")
         lst = np.asarray(ids[ranked[curr]], dtype=np.int64)
-        dist = squared_euclidean(values[lst], query) if lst.size else np.zeros(0, f32)
+        dist = _dist(values[lst], query, metric) if lst.size else np.zeros(0, f32)
         order = _stable_order(dist)[:top_k]
         if order.size < remainder:
             out_i += list(lst[order]); out_d += list(dist[order])
@@ -174,24 +180,24 @@ def search_approximate(values, centroids, ids, query, top_k):
     return np.asarray(out_i, dtype=np.uint64), np.asarray(out_d, dtype=f32)
 
 
-def search_nprobe(values, centroids, ids, query, top_k, nprobe):
+def search_nprobe(values, centroids, ids, query, top_k, nprobe, metric=0):
     """Extension (not in the reference): all rows of the nprobe nearest
     lists, one global stable sort over the concatenation in probe-rank order, take top_k."""
     values = np.asarray(values, dtype=f32)
-    cd = squared_euclidean(np.asarray(centroids, dtype=f32), query)
+    cd = _dist(np.asarray(centroids, dtype=f32), query, metric)
     ranked = _stable_order(cd)[:nprobe]
     cat = np.concatenate([np.asarray(ids[c], dtype=np.int64) for c in ranked]) if len(ranked) else np.zeros(0, np.int64)
-    dist = squared_euclidean(values[cat], query) if cat.size else np.zeros(0, f32)
+    dist = _dist(values[cat], query, metric) if cat.size else np.zeros(0, f32)
     order = _stable_order(dist)[:top_k]
     return cat[order].astype(np.uint64), dist[order]
 
 
-def add_cluster(centroids, x) -> int:
+def add_cluster(centroids, x, metric=0) -> int:
     """ivfflat.rs:200-207 -- first-minimum centroid for an added vector."""
     centroids = np.asarray(centroids, dtype=f32)
     if centroids.shape[0] == 0:
         raise RefPanic("min_by on empty centroids -> unwrap on None")
-    cd = squared_euclidean(centroids, x)
+    cd = _dist(centroids, x, metric)
     if cd.size >= 2 and np.isnan(cd).any():
         raise RefPanic("NaN distance in add")
     return int(np.argmin(cd))

@@ -79,6 +79,14 @@ float vo_cosine_distance(const float *a, const float *b, size_t d) {
   return 1.0f - vo_dot(a, b, d);
 }
 
+/* The IVF functions below take `metric`: 0 = squared_euclidean (what ivfflat.rs calls everywhere: :37-38,146,159,
+ * 175,205), 1 = cosine distance 1 - dot (base.rs:153-155) in the same places -- the "cosine/dot" IVF of SURVEY.md
+ * 8f-3, an EXTENSION: the reference's IVFFlat has no metric switch.  Everything else (first-minimum, stable sorts,
+ * spill walk, ascending-order sums, no re-normalisation of centroids) is the reference's code path unchanged. */
+static float vo_dist(const float *a, const float *b, size_t d, int metric) {
+  return metric == 0 ? vo_squared_euclidean(a, b, d) : vo_cosine_distance(a, b, d);
+}
+
 /* ---- stable sort of (index, distance) pairs ------------------------------
  * itertools::sorted_by == collect + slice::sort_by (stable).  Any stable sort
  * yields the same permutation under a total order; NaN makes
@@ -148,16 +156,16 @@ int64_t vo_search_exhaustive(const float *data, uint64_t n, uint64_t d, uint64_t
 /* min_by over centroids, comparator recomputes both distances; first minimum
  * wins (Iterator::min_by keeps the earlier element on Ordering::Equal);
  * NaN -> panic when k >= 2; k == 0 -> unwrap on None panics. */
-int vo_assign(const float *X, uint64_t n, const float *C, uint64_t k, uint64_t d,
-              uint64_t *out) {
+int vo_assign_m(const float *X, uint64_t n, const float *C, uint64_t k, uint64_t d,
+                uint64_t *out, int metric) {
   if (k == 0) return n ? VO_ERR_EMPTY : VO_OK;
   for (uint64_t i = 0; i < n; ++i) {
     const float *x = X + i * d;
     uint64_t best = 0;
-    float bd = vo_squared_euclidean(x, C, d);
+    float bd = vo_dist(x, C, d, metric);
     if (k >= 2 && isnan(bd)) return VO_ERR_NAN;
     for (uint64_t c = 1; c < k; ++c) {
-      float dc = vo_squared_euclidean(x, C + c * d, d);
+      float dc = vo_dist(x, C + c * d, d, metric);
       if (isnan(dc)) return VO_ERR_NAN;
       if (dc < bd) {
         bd = dc;
@@ -167,6 +175,10 @@ int vo_assign(const float *X, uint64_t n, const float *C, uint64_t k, uint64_t d
     out[i] = best;
   }
   return VO_OK;
+}
+
+int vo_assign(const float *X, uint64_t n, const float *C, uint64_t k, uint64_t d, uint64_t *out) {
+  return vo_assign_m(X, n, C, k, d, out, 0);
 }
 
 /* ---- ivfflat.rs:47-71  update_centroids ---------------------------------- */
@@ -195,13 +207,16 @@ void vo_update(const float *X, uint64_t n, const uint64_t *assign, uint64_t k, u
 }
 
 /* ---- ivfflat.rs:138-149  calculate_kmeans_cost --------------------------- */
-float vo_cost(const float *X, uint64_t n, const float *C, const uint64_t *assign, uint64_t d) {
+float vo_cost_m(const float *X, uint64_t n, const float *C, const uint64_t *assign, uint64_t d, int metric) {
   float acc = 0.0f;
   for (uint64_t i = 0; i < n; ++i) {
-    float v = vo_squared_euclidean(X + i * d, C + assign[i] * d, d);
+    float v = vo_dist(X + i * d, C + assign[i] * d, d, metric);
     acc = acc + v;
   }
   return acc;
+}
+float vo_cost(const float *X, uint64_t n, const float *C, const uint64_t *assign, uint64_t d) {
+  return vo_cost_m(X, n, C, assign, d, 0);
 }
 
 /* ---- ivfflat.rs:73-100  build_kmeans ------------------------------------- */
@@ -211,13 +226,13 @@ float vo_cost(const float *X, uint64_t n, const float *C, const uint64_t *assign
  * bitwise compare (to_hashkey base.rs:113-117 == f32::to_bits equality),
  * break if equal else centroids=new; final assign with the last centroids.
  * iters_run = number of loop bodies executed (including the one that broke). */
-int vo_kmeans(const float *X, uint64_t n, uint64_t d, uint64_t k, uint64_t max_iterations,
-              const uint64_t *init_idx, float *C, uint64_t *assign, uint64_t *iters_run) {
+int vo_kmeans_m(const float *X, uint64_t n, uint64_t d, uint64_t k, uint64_t max_iterations,
+                const uint64_t *init_idx, float *C, uint64_t *assign, uint64_t *iters_run, int metric) {
   for (uint64_t c = 0; c < k; ++c) memcpy(C + c * d, X + init_idx[c] * d, d * sizeof(float));
   float *Cn = (float *)malloc((k * d + 1) * sizeof(float));
   uint64_t it = 0;
   for (uint64_t i = 0; i < max_iterations; ++i) {
-    int rc = vo_assign(X, n, C, k, d, assign);
+    int rc = vo_assign_m(X, n, C, k, d, assign, metric);
     if (rc != VO_OK) {
       free(Cn);
       return rc;
@@ -229,7 +244,11 @@ int vo_kmeans(const float *X, uint64_t n, uint64_t d, uint64_t k, uint64_t max_i
   }
   free(Cn);
   if (iters_run) *iters_run = it;
-  return vo_assign(X, n, C, k, d, assign);
+  return vo_assign_m(X, n, C, k, d, assign, metric);
+}
+int vo_kmeans(const float *X, uint64_t n, uint64_t d, uint64_t k, uint64_t max_iterations,
+              const uint64_t *init_idx, float *C, uint64_t *assign, uint64_t *iters_run) {
+  return vo_kmeans_m(X, n, d, k, max_iterations, init_idx, C, assign, iters_run, 0);
 }
 
 /* ---- ivfflat.rs:102-136  build_index (k-means part) ---------------------- */
@@ -238,21 +257,21 @@ int vo_kmeans(const float *X, uint64_t n, uint64_t d, uint64_t k, uint64_t max_i
  * *kept = 0 and the index has EMPTY centroids/assignments.  init_idx holds
  * num_attempts * k injected draws.  The inverted lists (ivfflat.rs:123-127)
  * are ids[c] = ascending vec_ids with assign == c; callers derive them. */
-int vo_build(const float *X, uint64_t n, uint64_t d, uint64_t k, uint64_t num_attempts,
-             uint64_t max_iterations, const uint64_t *init_idx, float *C, uint64_t *assign,
-             float *best_cost_out, int *kept, uint64_t *best_attempt) {
+int vo_build_m(const float *X, uint64_t n, uint64_t d, uint64_t k, uint64_t num_attempts,
+               uint64_t max_iterations, const uint64_t *init_idx, float *C, uint64_t *assign,
+               float *best_cost_out, int *kept, uint64_t *best_attempt, int metric) {
   float best = INFINITY;
   *kept = 0;
   float *Ct = (float *)malloc((k * d + 1) * sizeof(float));
   uint64_t *at = (uint64_t *)malloc((n ? n : 1) * sizeof(uint64_t));
   for (uint64_t a = 0; a < num_attempts; ++a) {
-    int rc = vo_kmeans(X, n, d, k, max_iterations, init_idx + a * k, Ct, at, NULL);
+    int rc = vo_kmeans_m(X, n, d, k, max_iterations, init_idx + a * k, Ct, at, NULL, metric);
     if (rc != VO_OK) {
       free(Ct);
       free(at);
       return rc;
     }
-    float cost = vo_cost(X, n, Ct, at, d);
+    float cost = vo_cost_m(X, n, Ct, at, d, metric);
     if (cost < best) {
       best = cost;
       memcpy(C, Ct, k * d * sizeof(float));
@@ -266,20 +285,25 @@ int vo_build(const float *X, uint64_t n, uint64_t d, uint64_t k, uint64_t num_at
   *best_cost_out = best;
   return VO_OK;
 }
+int vo_build(const float *X, uint64_t n, uint64_t d, uint64_t k, uint64_t num_attempts,
+             uint64_t max_iterations, const uint64_t *init_idx, float *C, uint64_t *assign,
+             float *best_cost_out, int *kept, uint64_t *best_attempt) {
+  return vo_build_m(X, n, d, k, num_attempts, max_iterations, init_idx, C, assign, best_cost_out, kept, best_attempt, 0);
+}
 
 /* ---- the index as five flat arrays (ivfflat.rs:8-15) ---------------------
  * values[n*d], centroids[k*d], assignments[n], and the inverted lists in CSR
  * form: list_off[k+1], list_ids[n] (ids[c] = list_ids[list_off[c]..list_off[c+1]]). */
 
 /* ---- ivfflat.rs:153-198  search_approximate ------------------------------ */
-int64_t vo_search(const float *values, const float *centroids, uint64_t k, uint64_t d,
-                  const uint64_t *list_off, const uint64_t *list_ids, const float *query,
-                  uint64_t top_k, uint64_t *out_ids, float *out_dist) {
+int64_t vo_search_m(const float *values, const float *centroids, uint64_t k, uint64_t d,
+                    const uint64_t *list_off, const uint64_t *list_ids, const float *query,
+                    uint64_t top_k, uint64_t *out_ids, float *out_dist, int metric) {
   /* :155-161 all centroid distances, centroid.squared_euclidean(&query), stable sort */
   vo_pair *cent = (vo_pair *)malloc((k ? k : 1) * sizeof(vo_pair));
   for (uint64_t c = 0; c < k; ++c) {
     cent[c].id = c;
-    cent[c].dist = vo_squared_euclidean(centroids + c * d, query, d);
+    cent[c].dist = vo_dist(centroids + c * d, query, d, metric);
   }
   int rc = stable_sort_by_dist(cent, k);
   if (rc != VO_OK) {
@@ -298,7 +322,7 @@ int64_t vo_search(const float *values, const float *centroids, uint64_t k, uint6
     vo_pair *p = (vo_pair *)malloc((len ? len : 1) * sizeof(vo_pair));
     for (uint64_t t = 0; t < len; ++t) { /* :172-175 */
       p[t].id = ids[t];
-      p[t].dist = vo_squared_euclidean(values + ids[t] * d, query, d);
+      p[t].dist = vo_dist(values + ids[t] * d, query, d, metric);
     }
     rc = stable_sort_by_dist(p, len); /* :176 */
     if (rc != VO_OK) {
@@ -327,6 +351,11 @@ int64_t vo_search(const float *values, const float *centroids, uint64_t k, uint6
   free(cent);
   return (int64_t)n_out;
 }
+int64_t vo_search(const float *values, const float *centroids, uint64_t k, uint64_t d,
+                  const uint64_t *list_off, const uint64_t *list_ids, const float *query,
+                  uint64_t top_k, uint64_t *out_ids, float *out_dist) {
+  return vo_search_m(values, centroids, k, d, list_off, list_ids, query, top_k, out_ids, out_dist, 0);
+}
 
 /* ---- extension (NOT in the reference): nprobe search ----------------------
  * BASELINE.json cfg3/cfg4 name nprobe=32.  Definition:
@@ -334,14 +363,14 @@ int64_t vo_search(const float *values, const float *centroids, uint64_t k, uint6
  * stable sort by distance over the concatenation in probe-rank order (so ties
  * break by probe rank, then position in the list), take top_k.  With P=1 and
  * |list| >= top_k this equals vo_search. */
-int64_t vo_search_nprobe(const float *values, const float *centroids, uint64_t k, uint64_t d,
-                         const uint64_t *list_off, const uint64_t *list_ids,
-                         const float *query, uint64_t top_k, uint64_t nprobe,
-                         uint64_t *out_ids, float *out_dist) {
+int64_t vo_search_nprobe_m(const float *values, const float *centroids, uint64_t k, uint64_t d,
+                           const uint64_t *list_off, const uint64_t *list_ids,
+                           const float *query, uint64_t top_k, uint64_t nprobe,
+                           uint64_t *out_ids, float *out_dist, int metric) {
   vo_pair *cent = (vo_pair *)malloc((k ? k : 1) * sizeof(vo_pair));
   for (uint64_t c = 0; c < k; ++c) {
     cent[c].id = c;
-    cent[c].dist = vo_squared_euclidean(centroids + c * d, query, d);
+    cent[c].dist = vo_dist(centroids + c * d, query, d, metric);
   }
   int rc = stable_sort_by_dist(cent, k);
   if (rc != VO_OK) {
@@ -356,7 +385,7 @@ int64_t vo_search_nprobe(const float *values, const float *centroids, uint64_t k
     uint64_t c = cent[j].id;
     for (uint64_t t = list_off[c]; t < list_off[c + 1]; ++t) {
       p[o].id = list_ids[t];
-      p[o++].dist = vo_squared_euclidean(values + list_ids[t] * d, query, d);
+      p[o++].dist = vo_dist(values + list_ids[t] * d, query, d, metric);
     }
   }
   free(cent);
@@ -373,18 +402,24 @@ int64_t vo_search_nprobe(const float *values, const float *centroids, uint64_t k
   free(p);
   return (int64_t)m;
 }
+int64_t vo_search_nprobe(const float *values, const float *centroids, uint64_t k, uint64_t d,
+                         const uint64_t *list_off, const uint64_t *list_ids,
+                         const float *query, uint64_t top_k, uint64_t nprobe,
+                         uint64_t *out_ids, float *out_dist) {
+  return vo_search_nprobe_m(values, centroids, k, d, list_off, list_ids, query, top_k, nprobe, out_ids, out_dist, 0);
+}
 
 /* ---- ivfflat.rs:200-213  add (the centroid choice) ------------------------ */
 /* min_by over (i, centroid.squared_euclidean(&embedding)), first minimum;
  * the caller's vec_id is ignored by the reference (:209). NaN -> panic when
  * k >= 2; k == 0 -> unwrap on None. Returns the chosen cluster or an error. */
-int64_t vo_add_cluster(const float *centroids, uint64_t k, uint64_t d, const float *x) {
+int64_t vo_add_cluster_m(const float *centroids, uint64_t k, uint64_t d, const float *x, int metric) {
   if (k == 0) return VO_ERR_EMPTY;
   uint64_t best = 0;
-  float bd = vo_squared_euclidean(centroids, x, d);
+  float bd = vo_dist(centroids, x, d, metric);
   if (k >= 2 && isnan(bd)) return VO_ERR_NAN;
   for (uint64_t c = 1; c < k; ++c) {
-    float dc = vo_squared_euclidean(centroids + c * d, x, d);
+    float dc = vo_dist(centroids + c * d, x, d, metric);
     if (isnan(dc)) return VO_ERR_NAN;
     if (dc < bd) {
       bd = dc;
@@ -392,4 +427,7 @@ int64_t vo_add_cluster(const float *centroids, uint64_t k, uint64_t d, const flo
     }
   }
   return (int64_t)best;
+}
+int64_t vo_add_cluster(const float *centroids, uint64_t k, uint64_t d, const float *x) {
+  return vo_add_cluster_m(centroids, k, d, x, 0);
 }

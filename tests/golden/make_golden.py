@@ -189,8 +189,70 @@ def make_kmeans():
     print("kmeans_search.npz", len(out), "arrays")
 
 
+COS_CASES = [
+    dict(name="cos_n2500_d32_k16", kind="c", seed=0x5EED0201, n=2500, d=32, n_modes=10, k=16, iters=8, attempts=2),
+    dict(name="cos_n700_d300_k20", kind="c", seed=0x5EED0211, n=700, d=300, n_modes=6, k=20, iters=6, attempts=1),
+    dict(name="cos_n400_d8_k5_dup", kind="u", seed=0x5EED0221, n=400, d=8, dup=25, k=5, iters=5, attempts=1),
+]
+
+
+def make_cosdist():
+    """The metric extension: IVFFlat with cosine distance 1 - dot (base.rs:153-155) wherever
+    ivfflat.rs calls squared_euclidean -- build_index, add, search_approximate, and the nprobe extension."""
+    out = {}
+    for cs in COS_CASES:
+        X = corpus(cs)
+        k, n, d = cs["k"], cs["n"], cs["d"]
+        init = init_draws(cs["seed"] ^ 0xABCD, cs["attempts"], k, n)
+        bc = co.build_index(X, k, cs["attempts"], cs["iters"], init, metric=1)
+        bn = no.build_index(X, k, cs["attempts"], cs["iters"], init, metric=1)
+        same(bc["centroids"], bn["centroids"], cs["name"] + " build C")
+        same(bc["assignments"], bn["assignments"], cs["name"] + " build a")
+        same(np.array([bc["cost"]]), np.array([bn["cost"]]), cs["name"] + " build cost")
+        out[f"{cs['name']}/init"] = init
+        out[f"{cs['name']}/build_C_bits"] = bits(bc["centroids"])
+        out[f"{cs['name']}/build_assign"] = bc["assignments"]
+        out[f"{cs['name']}/build_cost_bits"] = bits(np.array([bc["cost"]]))
+        out[f"{cs['name']}/crc"] = np.array([crc(X)], dtype=np.uint32)
+        values = X.copy(); ids = [list(l) for l in bc["ids"]]; assign = list(bc["assignments"])
+        extra = dg.dist_u(cs["seed"] + 7, 3, d)
+        add_clusters = []
+        for x in extra:
+            cc, cn = co.add_cluster(bc["centroids"], x, metric=1), no.add_cluster(bc["centroids"], x, metric=1)
+            assert cc == cn
+            add_clusters.append(cc)
+            ids[cc].append(len(assign)); assign.append(cc)
+            values = np.concatenate([values, x[None]], axis=0)
+        out[f"{cs['name']}/add_clusters"] = np.array(add_clusters, dtype=np.uint64)
+        Q = queries(cs["seed"] + 3, 6, d, values)
+        Q[1] = extra[1]
+        out[f"{cs['name']}/crc_q"] = np.array([crc(Q), crc(extra)], dtype=np.uint32)
+        for top_k in (1, 10, 40):
+            for nprobe in (0, 1, 4, k):
+                ri, rd, cnt = [], [], []
+                for q in Q:
+                    if nprobe == 0:
+                        ic, dc = co.search_approximate(values, bc["centroids"], ids, q, top_k, metric=1)
+                        i_n, dn = no.search_approximate(values, bc["centroids"], ids, q, top_k, metric=1)
+                    else:
+                        ic, dc = co.search_nprobe(values, bc["centroids"], ids, q, top_k, nprobe, metric=1)
+                        i_n, dn = no.search_nprobe(values, bc["centroids"], ids, q, top_k, nprobe, metric=1)
+                    same(ic, i_n, cs["name"] + " ids"); same(dc, dn, cs["name"] + " dist")
+                    pad = top_k - len(ic)
+                    ri.append(np.concatenate([ic, np.full(pad, np.uint64(M64))]))
+                    rd.append(np.concatenate([bits(dc), np.zeros(pad, np.uint32)])); cnt.append(len(ic))
+                out[f"{cs['name']}/nprobe{nprobe}/k{top_k}/ids"] = np.stack(ri)
+                out[f"{cs['name']}/nprobe{nprobe}/k{top_k}/dist_bits"] = np.stack(rd)
+                out[f"{cs['name']}/nprobe{nprobe}/k{top_k}/count"] = np.array(cnt, dtype=np.uint32)
+    np.savez_compressed(os.path.join(OUT, "ivf_cosdist.npz"), **out)
+    print("ivf_cosdist.npz", len(out), "arrays")
+
+
 M64 = 0xFFFFFFFFFFFFFFFF
 
 if __name__ == "__main__":
-    make_flat()
-    make_kmeans()
+    import sys as _sys
+    if "--cosdist-only" not in _sys.argv:
+        make_flat()
+        make_kmeans()
+    make_cosdist()

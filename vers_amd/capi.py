@@ -42,6 +42,8 @@ SIGNATURES = {
     "vers_flat_last_scan_ms": (C.c_int32, [_vp, C.POINTER(C.c_float)]),
     "vers_ivf_create": (C.c_int32, [C.c_int32, C.c_uint32, C.POINTER(_vp)]),
     "vers_ivf_destroy": (C.c_int32, [_vp]),
+    "vers_ivf_set_metric": (C.c_int32, [_vp, C.c_uint32]),
+    "vers_ivf_get_metric": (C.c_int32, [_vp, C.POINTER(C.c_uint32)]),
     "vers_ivf_build": (C.c_int32, [_vp, _vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, _vp, _vp, C.c_uint64, _vp,
                                    C.POINTER(C.c_float), C.POINTER(C.c_int32), _vp]),
     "vers_ivf_build_dev": (C.c_int32, [_vp, _vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, _vp, _vp, C.c_uint64, _vp,

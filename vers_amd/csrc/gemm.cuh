@@ -49,10 +49,12 @@ static __global__ void row_norms_kernel(const float* C, uint32_t ld, uint32_t k,
 // NORM_ROWS = false: G[m][n] = norm[n] - 2 dot (coarse quantiser: m = query, n = centroid);
 // NORM_ROWS = true : G[m][n] = norm[m] - 2 dot (k-means assign: m = centroid, n = point, so that a point's
 //                    values are a coalesced column walk for the per-point selection).
+// metric 1 (cosine distance 1 - dot, base.rs:153-155): G = -dot, which approximates D_ref - 1; the padding rows /
+// columns of the operands are zero, so padded entries come out as 0 (the selections only look at real ones).
 template <bool NORM_ROWS>
 static __global__ __launch_bounds__(256) void dist_gemm_kernel(const float* __restrict__ Q, const float* __restrict__ C,
                                                                const float* __restrict__ cnorm, uint32_t K, uint32_t N_pad,
-                                                               float* __restrict__ G) {
+                                                               float* __restrict__ G, int metric) {
   __shared__ __attribute__((aligned(16))) float As[kGemmBM * kGemmLds];
   __shared__ __attribute__((aligned(16))) float Bs[kGemmBN * kGemmLds];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -117,11 +119,11 @@ static __global__ __launch_bounds__(256) void dist_gemm_kernel(const float* __re
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
       const uint32_t n = n0 + wc * 64 + b * 32 + r;
-      const float cn = NORM_ROWS ? 0.0f : cnorm[n];
+      const float cn = (NORM_ROWS || metric) ? 0.0f : cnorm[n];
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         const uint32_t m = m0 + wr * 64 + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
-        G[(uint64_t)m * N_pad + n] = (NORM_ROWS ? cnorm[m] : cn) - 2.0f * acc[a][b][e];
+        G[(uint64_t)m * N_pad + n] = metric ? -acc[a][b][e] : (NORM_ROWS ? cnorm[m] : cn) - 2.0f * acc[a][b][e];
       }
     }
 }
@@ -132,7 +134,7 @@ static __global__ __launch_bounds__(256) void dist_gemm_kernel(const float* __re
 // probe[q][0..P) receives ascending (exact distance, centroid index) keys -- the exact coarse output.
 static __global__ __launch_bounds__(kWave) void coarse_select_rescore_kernel(
     const float* G, uint32_t N_pad, uint32_t k, const float* C_rm, uint32_t ldc, const float* qp, uint32_t ldq, uint32_t d_pad,
-    float cmax2, uint32_t P, uint32_t PS, uint64_t* probe, uint32_t* status, uint32_t* fallback_count) {
+    float cmax2, uint32_t P, uint32_t PS, uint64_t* probe, uint32_t* status, uint32_t* fallback_count, int metric) {
   const uint32_t q = blockIdx.x;
   const int lane = threadIdx.x;
   const float* g = G + (uint64_t)q * N_pad;
@@ -165,20 +167,26 @@ static __global__ __launch_bounds__(kWave) void coarse_select_rescore_kernel(
       const f32x4 q4 = *reinterpret_cast<const f32x4*>(qv + j + 4 * w);  // wave-uniform
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const float t = __fsub_rn(c4[w][u], q4[u]);
-        acc = __fadd_rn(acc, __fmul_rn(t, t));
+        if (metric == 0) {
+          const float t = __fsub_rn(c4[w][u], q4[u]);
+          acc = __fadd_rn(acc, __fmul_rn(t, t));
+        } else {
+          acc = __fadd_rn(acc, __fmul_rn(c4[w][u], q4[u]));
+        }
         qn = __fadd_rn(qn, __fmul_rn(q4[u], q4[u]));
       }
     }
   }
+  if (metric) acc = __fsub_rn(1.0f, acc);  // cosine distance: 1 - dot (base.rs:153-155)
   bool nan_seen = have && (acc != acc);
   uint64_t exact = kKeyMax;
   wave_topk_update(exact, n_sel, have ? make_key(acc, ci) : kKeyMax, kKeyMax);  // sorted by (exact distance, index)
   // (3) certificate
   const uint32_t Pq = P < k ? P : k;
   const float dP = __uint_as_float(order_bits_to_f32_bits((uint32_t)(readlane64(exact, (int)Pq - 1) >> 32)));
-  const float E = (5.0f * (float)d_pad + 16.0f) * 5.9604645e-08f * (qn + cmax2);
-  const bool certified = (n_sel >= k) || (dP < tau + qn - E);  // NaN anywhere -> false -> exact path decides
+  // metric 1: G ~ D_ref - 1 with |D_ref - (1 + G)| <= u (1 + 2 |q||c|) + 3.03 d u |q||c| < (5d + 16) u (|q|^2 + max|c|^2 + 1)
+  const float E = (5.0f * (float)d_pad + 16.0f) * 5.9604645e-08f * (qn + cmax2 + (metric ? 1.0f : 0.0f));
+  const bool certified = (n_sel >= k) || (dP < tau + (metric ? 1.0f : qn) - E);  // NaN anywhere -> false -> exact path decides
   if (!certified) {
     // exact fallback for this query: every centroid, ordered chain per lane
     if (lane == 0) atomicAdd(fallback_count, 1u);
@@ -193,10 +201,15 @@ static __global__ __launch_bounds__(kWave) void coarse_select_rescore_kernel(
           const f32x4 q4 = *reinterpret_cast<const f32x4*>(qv + j);
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
-            const float t = __fsub_rn(c4[u], q4[u]);
-            a2 = __fadd_rn(a2, __fmul_rn(t, t));
+            if (metric == 0) {
+              const float t = __fsub_rn(c4[u], q4[u]);
+              a2 = __fadd_rn(a2, __fmul_rn(t, t));
+            } else {
+              a2 = __fadd_rn(a2, __fmul_rn(c4[u], q4[u]));
+            }
           }
         }
+        if (metric) a2 = __fsub_rn(1.0f, a2);
         nan_seen |= a2 != a2;
       }
       wave_topk_update(exact, Pq, n < k ? make_key(a2, n) : kKeyMax, kKeyMax);
@@ -264,7 +277,7 @@ static __global__ __launch_bounds__(kWave * kArgminWaves) void assign_argmin2_ke
 static __global__ void assign_rescore_kernel(const float* X, uint32_t ldx, const float* C_rm, uint32_t ldc, uint32_t d, uint32_t d_pad,
                                              const float* cmax2_dev, const uint32_t* best, const float* g2, uint32_t nb, uint32_t k,
                                              uint32_t i_base, uint32_t* assign, float* mind, uint32_t* fb_list, uint32_t* fb_count,
-                                             uint32_t* status) {
+                                             uint32_t* status, int metric) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nb) return;
   const uint32_t c = best[i];
@@ -278,20 +291,29 @@ static __global__ void assign_rescore_kernel(const float* X, uint32_t ldx, const
       const f32x4 c4 = *reinterpret_cast<const f32x4*>(cv + j);
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
-        const float t = __fsub_rn(x4[u], c4[u]);  // data_point.squared_euclidean(centroid): ivfflat.rs:37
-        acc = __fadd_rn(acc, __fmul_rn(t, t));
+        if (metric == 0) {
+          const float t = __fsub_rn(x4[u], c4[u]);  // data_point.squared_euclidean(centroid): ivfflat.rs:37
+          acc = __fadd_rn(acc, __fmul_rn(t, t));
+        } else {
+          acc = __fadd_rn(acc, __fmul_rn(x4[u], c4[u]));
+        }
         xn = __fadd_rn(xn, __fmul_rn(x4[u], x4[u]));
       }
     }
   }
   for (; j < d; ++j) {
-    const float t = __fsub_rn(x[j], cv[j]);
-    acc = __fadd_rn(acc, __fmul_rn(t, t));
+    if (metric == 0) {
+      const float t = __fsub_rn(x[j], cv[j]);
+      acc = __fadd_rn(acc, __fmul_rn(t, t));
+    } else {
+      acc = __fadd_rn(acc, __fmul_rn(x[j], cv[j]));
+    }
     xn = __fadd_rn(xn, __fmul_rn(x[j], x[j]));
   }
+  if (metric) acc = __fsub_rn(1.0f, acc);
   const float tau = g2[i];
-  const float E = (5.0f * (float)d_pad + 16.0f) * 5.9604645e-08f * (xn + *cmax2_dev);
-  const float lower = tau + xn - E;  // NaN if anything overflowed
+  const float E = (5.0f * (float)d_pad + 16.0f) * 5.9604645e-08f * (xn + *cmax2_dev + (metric ? 1.0f : 0.0f));
+  const float lower = tau + (metric ? 1.0f : xn) - E;  // NaN if anything overflowed
   const bool finite = tau < __builtin_inff() && E < __builtin_inff();
   const bool certified = k == 1 || (finite && acc < lower);
   assign[i] = c;

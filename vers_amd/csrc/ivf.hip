@@ -600,6 +600,7 @@ using namespace vers;
 struct vers_ivf {
   int device = 0, n_cu = 256;
   uint32_t d = 0;
+  int metric = 0;    // VERS_METRIC_L2SQ (the reference) or VERS_METRIC_COSDIST in every distance of build / add / search
   uint32_t ldx = 0;  // pitch of row-major matrices (X, centroids): round_up(d, 4)
   uint32_t ld = 0;   // columns of blocked matrices and padded queries: round_up(d, kColAlign)
   uint32_t ldq = 0;  // == ld
@@ -1083,7 +1084,7 @@ int32_t run_build(vers_ivf* h, const float* X, uint32_t ldx, uint64_t n, const B
   const bool mfma = km_use_mfma(n, k, h->d);
   auto assign_pass = [&](const float* Cc, uint32_t* a_out, float* m_out) -> int32_t {
     if (n == 0) return VERS_OK;
-    return (mfma ? km_assign_mfma : km_assign)(X, ldx, n, Cc, ld, k, h->d, a_out, m_out, h->km, h->n_cu, st);
+    return (mfma ? km_assign_mfma : km_assign)(X, ldx, n, Cc, ld, k, h->d, a_out, m_out, h->km, h->n_cu, st, h->metric);
   };
   std::vector<uint32_t> src32(k ? k : 1), dst32(k ? k : 1);
   for (uint64_t a = 0; a < num_attempts; ++a) {
@@ -1324,11 +1325,11 @@ int32_t coarse_mfma(vers_ivf* h, const float* qp, uint32_t b, uint32_t P, uint64
   const uint32_t PS = std::min<uint32_t>(kMaxTopK, P + 16);
   if (int32_t rc = h->gbuf.reserve((size_t)M_pad * h->k_pad * sizeof(float))) return rc;
   hipLaunchKernelGGL(dist_gemm_kernel<false>, dim3(h->k_pad / kGemmBN, M_pad / kGemmBM), dim3(256), 0, st, qp, h->centroids_g.as<float>(),
-                     h->cnorm.as<float>(), h->ldq, h->k_pad, h->gbuf.as<float>());
+                     h->cnorm.as<float>(), h->ldq, h->k_pad, h->gbuf.as<float>(), h->metric);
   VERS_HIP_TRY(hipGetLastError());
   hipLaunchKernelGGL(coarse_select_rescore_kernel, dim3(b), dim3(kWave), 0, st, h->gbuf.as<float>(), h->k_pad, h->k,
                      h->centroids_g.as<float>(), h->ldq, qp, h->ldq, h->ldq, coarse_mode() == 2 ? __builtin_inff() : h->cmax2, P, PS,
-                     probe_out, h->st_word(), h->coarse_stat.as<uint32_t>());
+                     probe_out, h->st_word(), h->coarse_stat.as<uint32_t>(), h->metric);
   VERS_HIP_TRY(hipGetLastError());
   h->mfma_batches += 1;
   return VERS_OK;
@@ -1365,10 +1366,10 @@ int32_t coarse(vers_ivf* h, const float* qp, uint32_t b, uint32_t P, hipStream_t
   int32_t rc;
   if (QG == 1) {
     SegSrc<1, false> src; fill(src);
-    rc = launch_seg_scan(h, src, n_segs_pad * n_qg, 0, st);
+    rc = launch_seg_scan(h, src, n_segs_pad * n_qg, h->metric, st);
   } else {
     SegSrc<8, false> src; fill(src);
-    rc = launch_seg_scan(h, src, n_segs_pad * n_qg, 0, st);
+    rc = launch_seg_scan(h, src, n_segs_pad * n_qg, h->metric, st);
   }
   if (rc) return rc;
   if (out_n_segs) {
@@ -1405,14 +1406,15 @@ int32_t launch_ivf_scan(vers_ivf* h, const IvfSrc<QG>& src, uint32_t items_bound
     p.next_quad = h->quad_counter.as<uint32_t>();
   }
   const size_t lds = scan_lds_bytes(QG, h->ld);
-  if (int32_t rc = scan_prepare_launch(scan_kernel<QG, 0, IvfSrc<QG>>, lds)) return rc;
+  if (int32_t rc = h->metric ? scan_prepare_launch(scan_kernel<QG, 1, IvfSrc<QG>>, lds) : scan_prepare_launch(scan_kernel<QG, 0, IvfSrc<QG>>, lds)) return rc;
   uint32_t blocks = (items_bound + kWavesPerBlock - 1) / kWavesPerBlock;
   const uint32_t max_blocks = (uint32_t)h->n_cu * scan_blocks_per_cu(QG, h->ld);
   if (blocks > max_blocks) blocks = max_blocks;
   if (blocks == 0) blocks = 1;
   const uint32_t slot = (uint32_t)(h->ev_count % vers_ivf::kEvRing);
   VERS_HIP_TRY(hipEventRecord(h->ev0[slot], st));
-  hipLaunchKernelGGL((scan_kernel<QG, 0, IvfSrc<QG>>), dim3(blocks), dim3(kWave * kWavesPerBlock), lds, st, src, p);
+  if (h->metric) hipLaunchKernelGGL((scan_kernel<QG, 1, IvfSrc<QG>>), dim3(blocks), dim3(kWave * kWavesPerBlock), lds, st, src, p);
+  else hipLaunchKernelGGL((scan_kernel<QG, 0, IvfSrc<QG>>), dim3(blocks), dim3(kWave * kWavesPerBlock), lds, st, src, p);
   VERS_HIP_TRY(hipGetLastError());
   VERS_HIP_TRY(hipEventRecord(h->ev1[slot], st));
   h->ev_count += 1;
@@ -1432,6 +1434,7 @@ int32_t launch_prescan(vers_ivf* h, const IvfSrc<kPreQ>& src, uint32_t items_bou
   p.qflags = qflags;
   p.xnorm = h->xnorm.as<float>();
   p.debug = scan_debug_flags();
+  p.metric = (uint32_t)h->metric;
   p.stamps = nullptr;
   if (p.debug & 16u) {
     if (int32_t rc = h->stamps.reserve(128)) return rc;
@@ -1626,7 +1629,7 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
     a.partials = h->partials.as<uint64_t>(); a.P = P; a.S_max = S_max; a.kp = kp; a.top_k = top_k; a.d_pad = h->ld;
     a.pj_list = pj_list; a.pj_pref = pj_pref; a.list_off = h->list_off.as<uint32_t>(); a.row_ids = h->row_ids.as<uint32_t>();
     a.rows = h->rows.as<float>(); a.ld = h->ld; a.qp = qp; a.ldq = h->ldq; a.xmax2_bits = h->pre_misc.as<uint32_t>();
-    a.qflags = qflags; a.force_fail = pre_mode == 2; a.shadow = use_shadow ? 1 : 0; a.debug = scan_debug_flags(); a.fail_list = fail_list; a.stats = h->pre_misc.as<uint32_t>() + 1;
+    a.qflags = qflags; a.metric = h->metric; a.force_fail = pre_mode == 2; a.shadow = use_shadow ? 1 : 0; a.debug = scan_debug_flags(); a.fail_list = fail_list; a.stats = h->pre_misc.as<uint32_t>() + 1;
     a.status = h->st_word(); a.out_ids = out_ids; a.out_dist = out_dist; a.out_count = out_count; a.out_keys = out_keys;
     const int stage_rows = rescore_lds_bytes(h->ld, true) <= 144u * 1024u ? 1 : 0;
     const size_t rs_lds = rescore_lds_bytes(h->ld, stage_rows != 0);
@@ -1893,6 +1896,20 @@ int32_t vers_ivf_create(int32_t device, uint32_t d, vers_ivf_t** out) {
     return rc;
   }
   *out = h;
+  return VERS_OK;
+}
+
+int32_t vers_ivf_set_metric(vers_ivf_t* h, uint32_t metric) {
+  if (!h || metric > VERS_METRIC_COSDIST) return fail(VERS_ERR_INVALID, "vers_ivf_set_metric: bad arguments");
+  std::lock_guard<std::mutex> lk(h->mu);
+  if (h->k != 0 && (int)metric != h->metric) return fail(VERS_ERR_INVALID, "vers_ivf_set_metric: call before build / upload");
+  h->metric = (int)metric;
+  return VERS_OK;
+}
+
+int32_t vers_ivf_get_metric(vers_ivf_t* h, uint32_t* out_metric) {
+  if (!h || !out_metric) return fail(VERS_ERR_INVALID, "bad arguments");
+  *out_metric = (uint32_t)h->metric;
   return VERS_OK;
 }
 

@@ -93,7 +93,7 @@ __global__ void keys_to_assign_kernel(const uint64_t* keys, uint32_t nb, uint32_
 }
 
 int32_t km_assign(const float* X, uint32_t ldx, uint64_t n, const float* C, uint32_t ldc, uint32_t k, uint32_t d,
-                  uint32_t* out_assign, float* out_mind, KMeansScratch& ws, int n_cu, hipStream_t st) {
+                  uint32_t* out_assign, float* out_mind, KMeansScratch& ws, int n_cu, hipStream_t st, int metric) {
   constexpr int QG = 8;
   if (n == 0) return VERS_OK;
   const uint32_t ldq = round_up(d, kColAlign);  // columns of the blocked centroids == padded point length
@@ -117,7 +117,7 @@ int32_t km_assign(const float* X, uint32_t ldx, uint64_t n, const float* C, uint
   p.next_quad = nullptr;
   p.bounds = nullptr;  // the four quarter-items of a point group run side by side: nothing to share
   const size_t lds = scan_lds_bytes(QG, ldq);
-  if (int32_t rc = scan_prepare_launch(scan_kernel<QG, 0, AssignSrc<QG>>, lds)) return rc;
+  if (int32_t rc = metric ? scan_prepare_launch(scan_kernel<QG, 1, AssignSrc<QG>>, lds) : scan_prepare_launch(scan_kernel<QG, 0, AssignSrc<QG>>, lds)) return rc;
   const uint32_t seg_rows = round_up((k + 3) / 4, 64);
   for (uint64_t i0 = 0; i0 < n; i0 += batch) {
     const uint32_t nb = (uint32_t)((n - i0 < batch) ? (n - i0) : batch);
@@ -129,7 +129,8 @@ int32_t km_assign(const float* X, uint32_t ldx, uint64_t n, const float* C, uint
     uint32_t blocks = (nb + QG - 1) / QG;  // one block per quad of items
     const uint32_t max_blocks = (uint32_t)n_cu * scan_blocks_per_cu(QG, ldq);
     if (blocks > max_blocks) blocks = max_blocks;
-    hipLaunchKernelGGL((scan_kernel<QG, 0, AssignSrc<QG>>), dim3(blocks), dim3(kWave * kWavesPerBlock), lds, st, src, p);
+    if (metric) hipLaunchKernelGGL((scan_kernel<QG, 1, AssignSrc<QG>>), dim3(blocks), dim3(kWave * kWavesPerBlock), lds, st, src, p);
+    else hipLaunchKernelGGL((scan_kernel<QG, 0, AssignSrc<QG>>), dim3(blocks), dim3(kWave * kWavesPerBlock), lds, st, src, p);
     VERS_HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(keys_to_assign_kernel, dim3((nb + 255) / 256), dim3(256), 0, st, ws.keys.as<uint64_t>(), nb,
                        out_assign + i0, out_mind ? out_mind + i0 : nullptr);
@@ -153,7 +154,7 @@ bool km_use_mfma(uint64_t n, uint32_t k, uint32_t d) {
 }
 
 int32_t km_assign_mfma(const float* X, uint32_t ldx, uint64_t n, const float* C, uint32_t ldc, uint32_t k, uint32_t d,
-                       uint32_t* out_assign, float* out_mind, KMeansScratch& ws, int n_cu, hipStream_t st) {
+                       uint32_t* out_assign, float* out_mind, KMeansScratch& ws, int n_cu, hipStream_t st, int metric) {
   if (n == 0) return VERS_OK;
   const uint32_t ldq = round_up(d, kColAlign);
   const uint32_t k_pad = round_up(k, kGemmBM);
@@ -191,10 +192,10 @@ int32_t km_assign_mfma(const float* X, uint32_t ldx, uint64_t n, const float* C,
       xb = ws.xp.as<float>();
     }
     hipLaunchKernelGGL(dist_gemm_kernel<true>, dim3(nb_pad / kGemmBN, k_pad / kGemmBM), dim3(256), 0, st, ws.cg.as<float>(), xb,
-                       ws.cnorm.as<float>(), ldq, nb_pad, ws.gt.as<float>());
+                       ws.cnorm.as<float>(), ldq, nb_pad, ws.gt.as<float>(), metric);
     hipLaunchKernelGGL(assign_argmin2_kernel, dim3((nb + kWave - 1) / kWave), dim3(kWave * kArgminWaves), 0, st, ws.gt.as<float>(), nb_pad, k, nb, best, g2);
     hipLaunchKernelGGL(assign_rescore_kernel, dim3((nb + 63) / 64), dim3(64), 0, st, X + i0 * ldx, ldx, C, ldc, d, ldq, cmax2_dev, best, g2,
-                       nb, k, (uint32_t)i0, out_assign + i0, out_mind ? out_mind + i0 : nullptr, fb_list, fb_count, ws.status.as<uint32_t>());
+                       nb, k, (uint32_t)i0, out_assign + i0, out_mind ? out_mind + i0 : nullptr, fb_list, fb_count, ws.status.as<uint32_t>(), metric);
     VERS_HIP_TRY(hipGetLastError());
   }
   uint32_t nf = 0;
@@ -209,7 +210,7 @@ int32_t km_assign_mfma(const float* X, uint32_t ldx, uint64_t n, const float* C,
     const uint64_t words = (uint64_t)nf * ldx;
     hipLaunchKernelGGL(gather_points_kernel, dim3((unsigned)((words + 255) / 256)), dim3(256), 0, st, X, ldx, fb_list, nf, ws.xf.as<float>());
     VERS_HIP_TRY(hipGetLastError());
-    if (int32_t rc = km_assign(ws.xf.as<float>(), ldx, nf, C, ldc, k, d, ws.fa.as<uint32_t>(), ws.fm.as<float>(), ws, n_cu, st)) return rc;
+    if (int32_t rc = km_assign(ws.xf.as<float>(), ldx, nf, C, ldc, k, d, ws.fa.as<uint32_t>(), ws.fm.as<float>(), ws, n_cu, st, metric)) return rc;
     hipLaunchKernelGGL(scatter_assign_kernel, dim3((nf + 255) / 256), dim3(256), 0, st, fb_list, nf, ws.fa.as<uint32_t>(), ws.fm.as<float>(),
                        out_assign, out_mind);
     VERS_HIP_TRY(hipGetLastError());
@@ -455,7 +456,7 @@ int32_t vers_kmeans_assign(int32_t device, const float* rows, uint64_t n, uint64
   if (int32_t rc = ws.status.reserve(16)) return rc;
   VERS_HIP_TRY(hipMemset(ws.status.p, 0, 16));
   if (int32_t rc = (km_use_mfma(n, (uint32_t)k, d) ? km_assign_mfma : km_assign)(X.as<float>(), ld, n, C.as<float>(), ld, (uint32_t)k, d,
-                                                                                 A.as<uint32_t>(), M.as<float>(), ws, n_cu, nullptr))
+                                                                                 A.as<uint32_t>(), M.as<float>(), ws, n_cu, nullptr, 0))
     return rc;
   VERS_HIP_TRY(hipDeviceSynchronize());
   if (int32_t rc = check_status_word(ws.status, (uint32_t)k)) return rc;

@@ -45,14 +45,15 @@ struct KMeansScratch {
 // assign_to_clusters (ivfflat.rs:29-46): out_assign[i] = first argmin_c D(X[i], C[c]);
 // out_mind[i] (optional) = that minimum distance, bit-exact D(X[i], C[assign[i]]).
 // status bit0 is set on a NaN distance.  X [n][ldx], C [k][ldc] row-major (pad columns zero).
+// metric 0: squared L2 (the reference); 1: cosine distance 1 - dot (base.rs:153-155) -- the metric extension.
 int32_t km_assign(const float* X, uint32_t ldx, uint64_t n, const float* C, uint32_t ldc, uint32_t k, uint32_t d,
-                  uint32_t* out_assign, float* out_mind, KMeansScratch& ws, int n_cu, hipStream_t st);
+                  uint32_t* out_assign, float* out_mind, KMeansScratch& ws, int n_cu, hipStream_t st, int metric);
 
 // Same contract and same bits as km_assign, through the f32 matrix cores: Gt = |c|^2 - 2 C X^T per point batch,
 // per-point best / second-best approximate value, exact re-score of the candidate in the reference's arithmetic,
 // certificate, and the exact scan (km_assign) for the points that fail it.  Synchronises the stream once.
 int32_t km_assign_mfma(const float* X, uint32_t ldx, uint64_t n, const float* C, uint32_t ldc, uint32_t k, uint32_t d,
-                       uint32_t* out_assign, float* out_mind, KMeansScratch& ws, int n_cu, hipStream_t st);
+                       uint32_t* out_assign, float* out_mind, KMeansScratch& ws, int n_cu, hipStream_t st, int metric);
 // policy: VERS_ASSIGN = 1 exact scan, 2 matrix cores always, otherwise by problem size
 bool km_use_mfma(uint64_t n, uint32_t k, uint32_t d);
 

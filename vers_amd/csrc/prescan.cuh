@@ -48,6 +48,7 @@ struct PreParams {
   const float* xnorm;   // |x|^2 per storage row
   const uint16_t* rows_bf;  // BF16 shadow of the rows (experimental, VERS_SHADOW=1): tiles of 64 rows x 8 columns per 1 KiB
   uint32_t debug;
+  uint32_t metric;      // 0: val = |x|^2 - 2<x,q> ~ D_ref - |q|^2 ; 1 (cosine distance 1 - dot): val = -<x,q> ~ D_ref - 1
   unsigned long long* stamps;
 };
 
@@ -352,10 +353,11 @@ __device__ __forceinline__ void prescan_item_g(const Src& src, const PreParams& 
             }
           }
         }
-        acc[0] = __builtin_amdgcn_mfma_f32_16x16x1f32(xn[B], 1.0f, acc[0], 0, 0, 0);  // + |x_row|^2 for every query column
+        const float nrm = p.metric ? 0.0f : 1.0f;  // (the cosine-distance val has no |x|^2 term)
+        acc[0] = __builtin_amdgcn_mfma_f32_16x16x1f32(xn[B], nrm, acc[0], 0, 0, 0);  // + |x_row|^2 for every query column
         fold(Set0{}, acc[0], tc);
         if (two) {
-          acc[1] = __builtin_amdgcn_mfma_f32_16x16x1f32(xn[B], 1.0f, acc[1], 0, 0, 0);
+          acc[1] = __builtin_amdgcn_mfma_f32_16x16x1f32(xn[B], nrm, acc[1], 0, 0, 0);
           fold(Set1{}, acc[1], tc);
         }
         ++tc;
@@ -414,7 +416,8 @@ __global__ __launch_bounds__(kWave * kPreWavesG) __attribute__((amdgpu_waves_per
     const uint32_t it = bi * 4 + (wid & 3);
     ItemView<kPreQ> v;
     src.get(it, v);
-    // The quad's query block: <= 32 padded queries gathered from their rows, scaled by -2, in the MFMA operand
+    const float qscale = p.metric ? -1.0f : -2.0f;
+    // The quad's query block: <= 32 padded queries gathered from their rows, scaled by -2 (-1: cosine distance), in the MFMA operand
     // layout l4[column group * 32 + slot].  Every thread serves ONE slot (512 % 32 == 0; 16 slots when the group
     // holds <= 16 queries, so that all threads load) and its row pointer is resolved here, ahead of the barrier.
     const uint32_t ns = v.nq > 16 ? 32u : 16u;
@@ -444,12 +447,12 @@ __global__ __launch_bounds__(kWave * kPreWavesG) __attribute__((amdgpu_waves_per
 #pragma unroll
       for (int u = 0; u < kStageU; ++u) {
         const uint32_t cg = cg0 + (uint32_t)u * cg_step;
-        if (cg < n_cg) l4[cg * kPreQ + slot] = -2.0f * x[u];
+        if (cg < n_cg) l4[cg * kPreQ + slot] = qscale * x[u];
       }
       for (uint32_t cg = cg0 + kStageU * cg_step; cg < n_cg; cg += cg_step) {  // (wider rows than kStageU rounds cover)
         f32x4 y = {0.0f, 0.0f, 0.0f, 0.0f};
         if (qrow != nullptr) y = *reinterpret_cast<const f32x4*>(qrow + 4 * cg);
-        l4[cg * kPreQ + slot] = -2.0f * y;
+        l4[cg * kPreQ + slot] = qscale * y;
       }
       __syncthreads();
       if ((p.debug & 16u) && lane == 0) {
@@ -482,6 +485,7 @@ struct RescoreArgs {
   uint32_t ldq;
   const uint32_t* xmax2_bits;
   const uint32_t* qflags;  // [b*P], slot q*P
+  int metric;              // 0 squared L2, 1 cosine distance 1 - dot (the exact chains and the bound follow it)
   int force_fail;          // testing: nothing certifies
   int shadow;              // the vals came from the bf16 shadow: the bound grows by 2^-8 |x||q|
   uint32_t debug;          // diagnosis (VERS_SCAN_DEBUG): 512 skip the row gather + chains, 1024 merge only 1/8 of the slots
@@ -594,7 +598,7 @@ __global__ __launch_bounds__(kWave * kRescoreWaves) void ivf_rescore_kernel(Resc
     float qn = 0.0f;
     for (int w = 0; w < kRescoreWaves; ++w) qn += sred[w];
     const double u = 5.9604644775390625e-08;
-    const double S = (double)qn * (1.0 + (double)a.d_pad * 2.0 * u) + (double)__uint_as_float(xmax_bits);
+    const double S = (double)qn * (1.0 + (double)a.d_pad * 2.0 * u) + (double)__uint_as_float(xmax_bits) + (a.metric ? 1.0 : 0.0);
     double E = (5.0 * (double)a.d_pad + 32.0) * u * S;
     if (a.shadow)  // |x_j - bf16(x_j)| <= 2^-9 |x_j|  =>  |2 <x - x~, q>| <= 2^-8 |x||q| (inflated for the roundings of |x~|)
       E = E * 1.01 + 0.00390625 * 1.004 * __builtin_sqrt((double)__uint_as_float(xmax_bits) * (double)qn * (1.0 + (double)a.d_pad * 2.0 * u));
@@ -653,10 +657,15 @@ __global__ __launch_bounds__(kWave * kRescoreWaves) void ivf_rescore_kernel(Resc
           const f32x4 q4 = q4p[j];
 #pragma unroll
           for (int c = 0; c < 4; ++c) {
-            const float t = __fsub_rn(x4[c], q4[c]);
-            acc = __fadd_rn(acc, __fmul_rn(t, t));
+            if (a.metric == 0) {
+              const float t = __fsub_rn(x4[c], q4[c]);
+              acc = __fadd_rn(acc, __fmul_rn(t, t));
+            } else {
+              acc = __fadd_rn(acc, __fmul_rn(x4[c], q4[c]));
+            }
           }
         }
+        if (a.metric) acc = __fsub_rn(1.0f, acc);
         nan_seen |= acc != acc;
         cand = make_key(acc, (uint32_t)mine);
       }
@@ -672,10 +681,15 @@ __global__ __launch_bounds__(kWave * kRescoreWaves) void ivf_rescore_kernel(Resc
       const f32x4 q4 = q4p[j];
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
-        const float t = __fsub_rn(x4[c], q4[c]);
-        acc = __fadd_rn(acc, __fmul_rn(t, t));
+        if (a.metric == 0) {
+          const float t = __fsub_rn(x4[c], q4[c]);
+          acc = __fadd_rn(acc, __fmul_rn(t, t));
+        } else {
+          acc = __fadd_rn(acc, __fmul_rn(x4[c], q4[c]));
+        }
       }
     }
+    if (a.metric) acc = __fsub_rn(1.0f, acc);
     nan_seen |= acc != acc;
     cand = make_key(acc, (uint32_t)mine);
   }
@@ -734,7 +748,8 @@ __global__ __launch_bounds__(kWave * kMergeWaves) void fallback_scan_kernel(Resc
     FbSrc src;
     src.out_ptr = out;
     src.seq0 = a.pj_pref[(uint64_t)q * a.P + j] + t0 * kWave;
-    scan_item<1, 1, 0>(src, p, 0u, v, lane, nan_seen);
+    if (a.metric == 0) scan_item<1, 1, 0>(src, p, 0u, v, lane, nan_seen);
+    else scan_item<1, 1, 1>(src, p, 0u, v, lane, nan_seen);
   }
   if (__ballot(nan_seen) != 0 && lane == 0) atomicOr(a.status, 1u);
 }

@@ -17,11 +17,16 @@ from .capi import _ptr, _vp, check, lib
 
 
 class IVFFlatIndex:
-    def __init__(self, d: int, device: int = 0):
+    def __init__(self, d: int, device: int = 0, metric: int = capi.METRIC_L2SQ):
+        """metric: METRIC_L2SQ = the reference's IVFFlat; METRIC_COSDIST = 1 - dot (base.rs:153-155) in every distance
+        of build / add / search (extension, vers_ivf_set_metric)."""
         self.d = int(d)
         self.device = device
+        self.metric = int(metric)
         self._h = _vp()
         check(lib().vers_ivf_create(device, self.d, C.byref(self._h)))
+        if self.metric != capi.METRIC_L2SQ:
+            check(lib().vers_ivf_set_metric(self._h, self.metric))
         # the reference's fields, in its order (ivfflat.rs:9-15)
         self.num_centroids = 0
         self.values = np.zeros((0, self.d), dtype=np.float32)
@@ -45,10 +50,10 @@ class IVFFlatIndex:
     # -- IVFFlatIndex::build_index (ivfflat.rs:102-136) -----------------------------------------
     @classmethod
     def build_index(cls, num_clusters: int, num_attempts: int, max_iterations: int, vectors, init_indices=None,
-                    rng=None, device: int = 0) -> "IVFFlatIndex":
+                    rng=None, device: int = 0, metric: int = capi.METRIC_L2SQ) -> "IVFFlatIndex":
         vectors = np.ascontiguousarray(vectors, dtype=np.float32)
         n, d = vectors.shape
-        self = cls(d, device)
+        self = cls(d, device, metric)
         if init_indices is None:
             # initialize_centroids (ivfflat.rs:18-27): k draws WITH replacement per attempt
             rng = rng or np.random.default_rng()
@@ -246,10 +251,11 @@ class IVFFlatIndex:
         write_index_file(file_path, self.num_centroids, self.values, self.centroids, self.assignments, self.ids)
 
     @classmethod
-    def load_index(cls, file_path: str, d: int, device: int = 0) -> "IVFFlatIndex":
-        """`d` plays the role of the const generic N of IVFFlatIndex<N>."""
+    def load_index(cls, file_path: str, d: int, device: int = 0, metric: int = capi.METRIC_L2SQ) -> "IVFFlatIndex":
+        """`d` plays the role of the const generic N of IVFFlatIndex<N>.  (The file has no metric field -- the
+        reference has no metric switch -- so a cosine-distance index is reloaded with metric=METRIC_COSDIST.)"""
         f = read_index_file(file_path, d)
-        self = cls(d, device)
+        self = cls(d, device, metric)
         self.num_centroids, self.values, self.centroids = f["num_centroids"], f["values"], f["centroids"]
         self.assignments, self.ids = f["assignments"], f["ids"]
         self._upload()
