@@ -134,24 +134,106 @@ static __global__ __launch_bounds__(256) void dist_gemm_kernel(const float* __re
 // probe[q][0..P) receives ascending (exact distance, centroid index) keys -- the exact coarse output.
 static __global__ __launch_bounds__(kWave) void coarse_select_rescore_kernel(
     const float* G, uint32_t N_pad, uint32_t k, const float* C_rm, uint32_t ldc, const float* qp, uint32_t ldq, uint32_t d_pad,
-    float cmax2, uint32_t P, uint32_t PS, uint64_t* probe, uint32_t* status, uint32_t* fallback_count, int metric) {
+    float cmax2, uint32_t P, uint32_t PS, uint64_t* probe, uint32_t* status, uint32_t* fallback_count, int metric,
+    unsigned long long* stamps) {
   const uint32_t q = blockIdx.x;
   const int lane = threadIdx.x;
+  const unsigned long long t0 = stamps ? __builtin_amdgcn_s_memtime() : 0ull;
   const float* g = G + (uint64_t)q * N_pad;
-  // (1) PS smallest approximate values; key = (order bits of G, centroid index)
+  // (1) PS smallest approximate values; key = (order bits of G, centroid index).
+  // A chunk of 4096 values sits in registers (64 per lane, ONE round trip of independent loads).  Instead of offering them
+  // to a sorted list one by one (~260 serial inserts of ~150 cycles: 88 k cycles per query, as much as the exact
+  // re-score), the PS-th smallest VALUE is bracketed by bisection on the order bits -- count(g <= T) over the chunk is
+  // 64 compares per lane and one wave reduction -- until PS <= count <= 64; the survivors are compacted through LDS,
+  // sorted across the lanes (bitonic network) and merged with the best of the previous chunks.  Every key among the
+  // chunk's PS smallest passes the filter (ties at T included), so `sel` is exactly what the serial inserts produce.
+  __shared__ uint64_t s_keys[kWave];
   uint64_t sel = kKeyMax;
-  for (uint32_t n0 = 0; n0 < k; n0 += 16 * kWave) {  // the kernel is one wave per query and latency-bound:
-    float gv[16];                                     // sixteen independent loads in flight per round trip
+  constexpr int kR = 64;  // registers per lane and chunk
+  for (uint32_t n0 = 0; n0 < k; n0 += kR * kWave) {
+    uint32_t gb[kR];
+    float gv[kR];
 #pragma unroll
-    for (int u = 0; u < 16; ++u) gv[u] = n0 + u * kWave + lane < k ? g[n0 + u * kWave + lane] : 0.0f;
+    for (int r = 0; r < kR; ++r) {  // UNCONDITIONAL loads (clamped index): a branch around a load makes the compiler wait for
+      const uint32_t n = n0 + r * kWave + lane;  // each one with vmcnt(0) -- 64 serial round trips, 60 k cycles per query
+      gv[r] = g[n < k ? n : k - 1];
+    }
 #pragma unroll
-    for (int u = 0; u < 16; ++u) {
-      const uint32_t n = n0 + u * kWave + lane;
-      wave_topk_update(sel, PS, n < k ? make_key(gv[u], n) : kKeyMax, kKeyMax);
+    for (int r = 0; r < kR; ++r) {
+      const uint32_t n = n0 + r * kWave + lane;
+      gb[r] = n < k ? f32_to_order_bits(gv[r]) : 0xFFFFFFFFu;
+    }
+    const uint32_t n_chunk = k - n0 < (uint32_t)(kR * kWave) ? k - n0 : (uint32_t)(kR * kWave);
+    auto count_le = [&](uint32_t T) {
+      uint32_t c = 0;
+#pragma unroll
+      for (int r = 0; r < kR; ++r) c += gb[r] <= T ? 1u : 0u;
+      return wave_sum_u32(c);  // (padding entries are 0xFFFFFFFF: counted only at T = 0xFFFFFFFF)
+    };
+    uint32_t T = 0xFFFFFFFFu;  // a chunk of at most 64 values: all of them (padding is excluded by its index below)
+    uint64_t cur = kKeyMax;
+    bool serial = false;
+    if (n_chunk > (uint32_t)kWave) {
+      uint32_t mn = 0xFFFFFFFFu, mx = 0u;
+#pragma unroll
+      for (int r = 0; r < kR; ++r) {
+        mn = gb[r] < mn ? gb[r] : mn;
+        mx = (gb[r] != 0xFFFFFFFFu && gb[r] > mx) ? gb[r] : mx;
+      }
+      uint32_t lo = wave_min_u32(mn), hi = wave_max_u32(mx), c = count_le(hi);  // c: values that are not NaN
+      if (c < PS) serial = true;  // NaNs would have to fill the list: the ordered inserts handle it (never on sane data)
+      else {
+        // invariant (order bits): count(<= hi) = c >= PS, and the PS-th smallest value is >= lo.  The split point is chosen
+        // in the VALUE domain where the G of a query are spread roughly evenly -- aim at a count a little above PS:
+        // 2-4 counting passes instead of ~25 steps of blind bisection over the 32-bit key space -- and clamped into
+        // [lo, hi - 1] in the bit domain, so that every step shrinks the bracket whatever the values are.
+        while (c > (uint32_t)kWave && lo < hi) {
+          const float lf = __uint_as_float(order_bits_to_f32_bits(lo)), hf = __uint_as_float(order_bits_to_f32_bits(hi));
+          float frac = (float)(PS + 8u) / (float)c;
+          frac = frac < 0.0625f ? 0.0625f : (frac > 0.5f ? 0.5f : frac);
+          uint32_t mid = f32_to_order_bits(lf + (hf - lf) * frac);
+          if (!(mid >= lo && mid < hi)) mid = lo + ((hi - lo) >> 1);  // inf / NaN / rounding: plain bisection step
+          const uint32_t cm = count_le(mid);
+          if (cm >= PS) { hi = mid; c = cm; }
+          else lo = mid + 1;
+        }
+        T = hi;
+        serial = c > (uint32_t)kWave;  // more than 64 values at or below the PS-th: the ordered inserts decide by index
+      }
+    }
+    if (!serial) {
+      uint32_t base = 0;
+#pragma unroll
+      for (int r = 0; r < kR; ++r) {
+        const bool in = gb[r] <= T && (n0 + r * kWave + lane) < k;
+        const uint64_t m = __ballot(in);
+        if (in) s_keys[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = ((uint64_t)gb[r] << 32) | (n0 + r * kWave + lane);
+        base += (uint32_t)__popcll(m);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+      __builtin_amdgcn_s_barrier();  // (one wave per block: orders the LDS writes before the reads below)
+      cur = (uint32_t)lane < base ? s_keys[lane] : kKeyMax;
+      __builtin_amdgcn_s_barrier();
+      wave_bitonic_sort64(cur, lane);
+      if (n0 == 0) sel = cur;
+      else {  // the 64 smallest of (best so far, this chunk)
+        const uint64_t rev = shfl_idx64(cur, kWave - 1 - lane);
+        sel = sel < rev ? sel : rev;
+        wave_bitonic_merge64(sel, lane);
+      }
+    } else {
+#pragma unroll
+      for (int r = 0; r < kR; ++r) {
+        const uint32_t n = n0 + r * kWave + lane;
+        wave_topk_update(sel, kWave, n < k ? (((uint64_t)gb[r] << 32) | n) : kKeyMax, kKeyMax);
+      }
     }
   }
+  // (lanes >= PS hold larger keys of the last merge: not candidates)
+  if (lane >= (int)PS) sel = kKeyMax;
   const uint32_t n_sel = PS < k ? PS : k;
   const float tau = __uint_as_float(order_bits_to_f32_bits((uint32_t)(readlane64(sel, (int)n_sel - 1) >> 32)));
+  const unsigned long long t1 = stamps ? __builtin_amdgcn_s_memtime() : 0ull;
   // (2) exact re-score: lane l < n_sel owns candidate centroid l; the query element is wave-uniform
   const float* qv = qp + (uint64_t)q * ldq;
   const bool have = lane < (int)n_sel;
@@ -179,6 +261,7 @@ static __global__ __launch_bounds__(kWave) void coarse_select_rescore_kernel(
   }
   if (metric) acc = __fsub_rn(1.0f, acc);  // cosine distance: 1 - dot (base.rs:153-155)
   bool nan_seen = have && (acc != acc);
+  const unsigned long long t2 = stamps ? __builtin_amdgcn_s_memtime() : 0ull;
   uint64_t exact = kKeyMax;
   wave_topk_update(exact, n_sel, have ? make_key(acc, ci) : kKeyMax, kKeyMax);  // sorted by (exact distance, index)
   // (3) certificate
@@ -217,6 +300,10 @@ static __global__ __launch_bounds__(kWave) void coarse_select_rescore_kernel(
   }
   if (lane < (int)P) probe[(uint64_t)q * P + lane] = lane < (int)Pq ? exact : kKeyMax;
   if (__ballot(nan_seen) != 0 && lane == 0) atomicOr(status, 1u);
+  if (stamps && lane == 0) {
+    const unsigned long long t3 = __builtin_amdgcn_s_memtime();
+    atomicAdd(stamps + 24, t1 - t0); atomicAdd(stamps + 25, t2 - t1); atomicAdd(stamps + 26, t3 - t2); atomicAdd(stamps + 27, 1ull);
+  }
 }
 
 // ---- k-means assign through the matrix cores (ivfflat.rs:29-46) -----------------------------------------

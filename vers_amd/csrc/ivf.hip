@@ -177,23 +177,41 @@ __global__ __launch_bounds__(kWave * kMergeWaves) void coarse_merge_kernel(const
   if (threadIdx.x < P) probe[(uint64_t)q * P + threadIdx.x] = list;
 }
 
-// plan: thread per query.  nprobe mode: every probed list is scanned, pj_pref = running row count.
-// reference mode (ivfflat.rs:166-195): walk the ranked lists, list j contributes
-// take_j = min(remainder, len_j) until remainder == 0; out of lists -> the reference panics.
-// owner (nullable): only lists with owner[L] == rank are scanned on this GPU.
-__global__ __launch_bounds__(256) void plan_kernel(const uint64_t* probe, uint32_t b, uint32_t P, uint32_t k_lists, uint32_t top_k,
-                                                   int ref_mode, const uint32_t* list_len, const uint8_t* owner, uint32_t rank,
-                                                   uint32_t* pj_list, uint32_t* pj_pref, uint32_t* pj_take, uint32_t* np, uint32_t* cnt,
-                                                   uint32_t* hot, uint32_t hot_ranks, uint32_t* status) {
-  // one WAVE per query, lane j = probe rank j (P <= 64): the walk of the ranked lists in closed form -- list j is
-  // visited while the rows before it do not yet fill top_k and contributes take_j = min(len_j, top_k - rows before)
-  // (a thread per query walking its P probes was 2 P dependent-latency loads: 36 us at b = 1024)
-  const uint32_t q = blockIdx.x * (blockDim.x / kWave) + (threadIdx.x >> 6);
-  if (q >= b) return;
-  const int lane = threadIdx.x & 63;
+// ---- planning of a batch: ONE cooperative launch (plan_fused_kernel) ---------------------------------------------
+// fill (zero the per-batch tables, 0xFF the partial slots) | plan (wave per query) | group (block 0: three prefix sums
+// over the lists) | scatter pairs + item / group descriptors, separated by grid-wide barriers.  Round 1 issued these as
+// two fills and four kernels: ~45 us of launches and dependent start-up gaps per batch next to ~15 us of work, a
+// cost that does not shrink when the lists are sharded over GPUs.
+constexpr uint32_t kPlanBlocks = 64, kPlanThreads = 1024;  // 64 <= CUs: every block is resident, the barriers cannot deadlock
+
+// Grid-wide barrier on a monotonically increasing counter in device memory (never reset: `target` counts arrivals
+// since the handle was created, compared modulo 2^32).
+__device__ __forceinline__ void grid_barrier(uint32_t* ctr, uint32_t target) {
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __threadfence();
+    __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    // (relaxed polls: an acquire load per poll invalidates caches and slowed the one working block 2x; one fence after)
+    while ((int32_t)(__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) __builtin_amdgcn_s_sleep(16);
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    __threadfence();
+  }
+  __syncthreads();
+}
+
+// plan: one WAVE per query, lane j = probe rank j (P <= 64).  nprobe mode: every probed list is scanned, pj_pref =
+// running row count.  reference mode (ivfflat.rs:166-195): the walk of the ranked lists in closed form -- list j is
+// visited while the rows before it do not yet fill top_k and contributes take_j = min(len_j, top_k - rows before);
+// out of lists -> the reference panics.  owner (nullable): only lists with owner[L] == rank are scanned on this GPU.
+__device__ __forceinline__ void plan_query(uint32_t q, int lane, const uint64_t* probe, uint32_t P, uint32_t k_lists, uint32_t top_k,
+                                           int ref_mode, const uint32_t* list_len, const uint8_t* owner, uint32_t rank,
+                                           uint32_t* pj_list, uint32_t* pj_pref, uint32_t* pj_take, uint32_t* np, uint32_t* cnt,
+                                           uint32_t* hot, uint32_t hot_ranks, uint32_t* status, uint32_t* pj_nq, uint32_t seg_rows,
+                                           uint32_t seg_target, const uint32_t* list_slot) {
   const uint64_t key = lane < (int)P ? probe[(uint64_t)q * P + lane] : kKeyMax;
-  const uint32_t L = key != kKeyMax ? (uint32_t)key : kNoList;
+  const uint32_t L = key != kKeyMax ? (uint32_t)key : kNoList;  // centroid index; the tables below are addressed by its SLOT
   const uint32_t len = L != kNoList ? list_len[L] : 0u;
+  const uint32_t slot = L != kNoList ? list_slot[L] : kNoList;
   uint32_t inc = len;
 #pragma unroll
   for (int off = 1; off < kWave; off <<= 1) {
@@ -206,12 +224,16 @@ __global__ __launch_bounds__(256) void plan_kernel(const uint64_t* probe, uint32
   const uint32_t take = !visited ? 0u : (ref_mode ? (len < top_k - pref ? len : top_k - pref) : top_k);
   const bool scan = visited && len > 0 && take > 0 && (owner == nullptr || owner[L] == rank);
   if (lane < (int)P) {
-    pj_list[(uint64_t)q * P + lane] = scan ? L : kNoList;
+    pj_list[(uint64_t)q * P + lane] = scan ? slot : kNoList;
     pj_pref[(uint64_t)q * P + lane] = pref;
     pj_take[(uint64_t)q * P + lane] = take;
+    if (pj_nq) {  // matrix-core scan: one partial slot per quad of segments of a scanned list
+      const uint32_t sr = list_seg_rows(len, seg_rows, seg_target);
+      pj_nq[(uint64_t)q * P + lane] = scan ? ((len + sr - 1) / sr + 3) / 4 : 0u;
+    }
   }
-  if (scan) atomicAdd(&cnt[L], 1u);
-  if (scan && lane < (int)hot_ranks) hot[L] = 1u;  // this query's tightest thresholds come from here (group_kernel orders the work)
+  if (scan) atomicAdd(&cnt[slot], 1u);
+  if (scan && lane < (int)hot_ranks) hot[slot] = 1u;  // this query's tightest thresholds come from here (the group step orders the work)
   const uint64_t vmask = __ballot(visited);
   if (lane == 0) {
     np[q] = (uint32_t)__popcll(vmask);
@@ -219,7 +241,7 @@ __global__ __launch_bounds__(256) void plan_kernel(const uint64_t* probe, uint32
   }
 }
 
-// group: single block.  Per list: pairs, groups (ceil(cnt/QG)), items (groups * segments); exclusive
+// group: ONE block of 1024 threads.  Per list: pairs, groups (ceil(cnt/QG)), items (groups * segments); exclusive
 // prefix sums of all three; totals + traffic statistics.
 struct GroupTotals {
   uint32_t n_items, n_groups, n_pairs, pad;
@@ -227,12 +249,12 @@ struct GroupTotals {
   uint64_t streamed_rows;  // rows the scan items actually stream (a list is re-read per query group)
 };
 
-__global__ __launch_bounds__(1024) void group_kernel(const uint32_t* cnt, const uint32_t* list_len, uint32_t k_lists,
-                                                     uint32_t QG, uint32_t seg_rows, uint32_t seg_target, const uint32_t* hot,
-                                                     uint32_t* pair_off, uint32_t* group_off, uint32_t* item_off, GroupTotals* tot) {
-  // Work order: the items of "hot" lists (nearest or second nearest list of some query) come first, so that every
-  // query's threshold is tight before the bulk of its lists is scanned (the scan hands quads out in item order);
-  // item_off = position among the hot items, or (all hot items) + position among the others.
+// All tables are in SLOT order (lists by descending length, see vers_ivf::list_slot).  Work order of the scan = hot
+// lists first (nearest list of some query: their thresholds must be tight before the bulk is scanned), then the others
+// in slot order, i.e. LONGEST FIRST.
+__device__ __forceinline__ void group_lists(const uint32_t* cnt, const uint32_t* list_len, uint32_t k_lists, uint32_t QG, uint32_t seg_rows,
+                                            uint32_t seg_target, const uint32_t* hot, uint32_t* pair_off,
+                                            uint32_t* group_off, uint32_t* item_off, GroupTotals* tot) {
   // three exclusive prefix sums over the lists in one pass: wave scans by shuffles, 16 wave totals through LDS,
   // a running carry between rounds of 1024 lists (the LDS Hillis-Steele version was 26 us at 4096 lists)
   __shared__ uint32_t wp[16], wg[16], wi[16], wh[16];
@@ -254,15 +276,16 @@ __global__ __launch_bounds__(1024) void group_kernel(const uint32_t* cnt, const 
     uint32_t cs[8], ls[8], hs[8];
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
-      const uint32_t L = base0 + r * 1024 + threadIdx.x;
-      cs[r] = L < k_lists ? cnt[L] : 0u;
-      ls[r] = L < k_lists ? list_len[L] : 0u;
-      hs[r] = L < k_lists ? hot[L] : 0u;
+      const uint32_t i = base0 + r * 1024 + threadIdx.x;
+      cs[r] = i < k_lists ? cnt[i] : 0u;
+      ls[r] = i < k_lists ? list_len[i] : 0u;
+      hs[r] = i < k_lists ? hot[i] : 0u;
     }
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
-      const uint32_t L = base0 + r * 1024 + threadIdx.x;
+      const uint32_t i = base0 + r * 1024 + threadIdx.x;
       if (base0 + r * 1024 >= k_lists) break;  // block-uniform
+      const uint32_t L = i;
       const uint32_t c = cs[r];
       uint32_t g = 0, it = 0;
       if (c) {
@@ -286,7 +309,7 @@ __global__ __launch_bounds__(1024) void group_kernel(const uint32_t* cnt, const 
         if (w < wid) { bp += wp[w]; bg += wg[w]; bi2 += wi[w]; bh += wh[w]; }
         tp += wp[w]; tg += wg[w]; ti2 += wi[w]; th += wh[w];
       }
-      if (L < k_lists) {
+      if (i < k_lists) {
         pair_off[L] = cp + bp + ip - c;
         group_off[L] = cg + bg + ig - g;
         item_off[L] = is_hot ? ch + bh + ih - it_h : ci + bi2 + ii - it_c;  // the others are shifted below
@@ -305,34 +328,21 @@ __global__ __launch_bounds__(1024) void group_kernel(const uint32_t* cnt, const 
     atomicAdd(&sr, my_sr);
   }
   __syncthreads();
-  for (uint32_t L = threadIdx.x; L < k_lists; L += 1024)
-    if (cnt[L] != 0 && hot[L] == 0) item_off[L] += ch;  // (each thread shifts entries it wrote itself: L % 1024 == threadIdx.x)
+  for (uint32_t L = threadIdx.x; L < k_lists; L += 1024)  // (each thread shifts entries it wrote itself: L % 1024 == threadIdx.x)
+    if (cnt[L] != 0 && hot[L] == 0) item_off[L] += ch;
   if (threadIdx.x == 0) {
     tot->n_items = ci + ch; tot->n_groups = cg; tot->n_pairs = cp; tot->pad = 0;
     tot->union_rows = ur; tot->streamed_rows = sr;
   }
 }
 
-// scatter: pairs of a list become contiguous (order inside a list is arbitrary and irrelevant:
-// every (query, list) result goes to its own slot)
-__global__ void scatter_pairs_kernel(const uint32_t* pj_list, uint32_t n_pj, const uint32_t* pair_off, uint32_t* fill,
-                                     uint32_t* pairs) {
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n_pj) return;
-  const uint32_t L = pj_list[i];
-  if (L == kNoList) return;
-  pairs[pair_off[L] + atomicAdd(&fill[L], 1u)] = i;
-}
-
-// items + group descriptors: thread per list
+// items + group descriptors of one list
 struct GroupDesc {
   uint32_t pair_start, nq;
 };
-__global__ void items_kernel(const uint32_t* cnt, const uint32_t* list_len, uint32_t k_lists, uint32_t QG,
-                             uint32_t seg_rows, uint32_t seg_target, const uint32_t* pair_off, const uint32_t* group_off,
-                             const uint32_t* item_off, ItemDesc* items, GroupDesc* groups) {
-  const uint32_t L = blockIdx.x * blockDim.x + threadIdx.x;
-  if (L >= k_lists) return;
+__device__ __forceinline__ void list_items(uint32_t L, const uint32_t* cnt, const uint32_t* list_len, uint32_t QG, uint32_t seg_rows,
+                                           uint32_t seg_target, const uint32_t* pair_off, const uint32_t* group_off, const uint32_t* item_off,
+                                           ItemDesc* items, GroupDesc* groups) {
   const uint32_t c = cnt[L];
   if (!c) return;
   const uint32_t sr = list_seg_rows(list_len[L], seg_rows, seg_target);
@@ -353,6 +363,70 @@ __global__ void items_kernel(const uint32_t* cnt, const uint32_t* list_len, uint
   }
 }
 
+struct PlanArgs {
+  const uint64_t* probe;
+  uint32_t b, P, k_lists, top_k;
+  int ref_mode;
+  const uint32_t* list_len;   // by centroid index
+  const uint8_t* owner;
+  uint32_t rank;
+  const uint32_t* list_slot;  // centroid index -> slot
+  const uint32_t* slot_len;   // list lengths in slot order
+  uint32_t *pj_list, *pj_pref, *pj_take, *np;
+  uint32_t* pj_nq;              // nullable (matrix-core scan only)
+  uint32_t *cnt, *fill, *hot;   // start of the zero-initialised zone (zero_words u32 from cnt)
+  uint32_t zero_words;
+  uint32_t *pair_off, *group_off, *item_off;
+  GroupTotals* tot;
+  uint32_t* pairs;
+  ItemDesc* items;
+  GroupDesc* groups;
+  uint32_t QG, seg_rows, seg_target, hot_ranks;
+  uint32_t* status;
+  u32x4* ff_begin;       // 0xFF-filled here: the pruning bounds (matrix-core scan; its slots need no fill: ivf_rescore_kernel
+  uint64_t ff_vec16;     // reads written slots only).  This many 16-byte words.
+  uint32_t* grid_ctr;
+  uint32_t ctr_base;     // arrivals at the counter before this launch
+  unsigned long long* stamps;  // diagnosis (VERS_SCAN_DEBUG & 16): [16..21] 100 MHz clock at the phase boundaries, block 0
+};
+
+__global__ __launch_bounds__(kPlanThreads) void plan_fused_kernel(PlanArgs a) {
+  const uint32_t tid = blockIdx.x * kPlanThreads + threadIdx.x, nthreads = kPlanBlocks * kPlanThreads;
+  const int lane = threadIdx.x & 63;
+  auto stamp = [&](int i) { if (a.stamps && tid == 0) a.stamps[16 + i] = __builtin_amdgcn_s_memrealtime(); };
+  stamp(0);
+  // (A) tables of this batch
+  for (uint32_t i = tid; i < a.zero_words; i += nthreads) a.cnt[i] = 0u;
+  const u32x4 ff = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+  for (uint64_t i = tid; i < a.ff_vec16; i += nthreads) a.ff_begin[i] = ff;
+  stamp(1);
+  grid_barrier(a.grid_ctr, a.ctr_base + kPlanBlocks);
+  stamp(2);
+  // (B) plan
+  const uint32_t n_waves = nthreads / kWave;
+  for (uint32_t q = tid / kWave; q < a.b; q += n_waves)
+    plan_query(q, lane, a.probe, a.P, a.k_lists, a.top_k, a.ref_mode, a.list_len, a.owner, a.rank, a.pj_list, a.pj_pref, a.pj_take, a.np,
+               a.cnt, a.hot, a.hot_ranks, a.status, a.pj_nq, a.seg_rows, a.seg_target, a.list_slot);
+  grid_barrier(a.grid_ctr, a.ctr_base + 2 * kPlanBlocks);
+  stamp(3);
+  // (C) group
+  if (blockIdx.x == 0)
+    group_lists(a.cnt, a.slot_len, a.k_lists, a.QG, a.seg_rows, a.seg_target, a.hot, a.pair_off, a.group_off, a.item_off, a.tot);
+  stamp(4);
+  grid_barrier(a.grid_ctr, a.ctr_base + 3 * kPlanBlocks);
+  stamp(5);
+  // (D) pairs of a list become contiguous (order inside a list is arbitrary and irrelevant: every (query, list)
+  // result goes to its own slot); item and group descriptors
+  const uint32_t n_pj = a.b * a.P;
+  for (uint32_t i = tid; i < n_pj; i += nthreads) {
+    const uint32_t L = a.pj_list[i];
+    if (L != kNoList) a.pairs[a.pair_off[L] + atomicAdd(&a.fill[L], 1u)] = i;
+  }
+  for (uint32_t L = tid; L < a.k_lists; L += nthreads)
+    list_items(L, a.cnt, a.slot_len, a.QG, a.seg_rows, a.seg_target, a.pair_off, a.group_off, a.item_off, a.items, a.groups);
+  stamp(6);
+}
+
 // Single query: coarse merge + plan + group + scatter + items in ONE launch (the five small kernels above cost
 // ~20 us each in launch + latency, more than the 60 us list scan they prepare).  One block: 16 waves merge the
 // coarse partial slots, wave 0 then plans with lane j = probe rank j.  Every probed list is distinct here, so a
@@ -361,7 +435,7 @@ __global__ __launch_bounds__(kWave * kMergeWaves) void plan1_kernel(
     const uint64_t* cpart, uint32_t n_segs_c, uint32_t P, uint32_t k_lists, uint32_t top_k, int ref_mode, const uint32_t* list_len,
     const uint8_t* owner, uint32_t rank, uint32_t seg_rows, uint64_t* probe, uint32_t* pj_list, uint32_t* pj_pref, uint32_t* pj_take,
     uint32_t* np, uint32_t* cnt, uint32_t* pair_off, uint32_t* group_off, uint32_t* pairs, ItemDesc* items, GroupDesc* groups,
-    GroupTotals* tot, uint32_t* status) {
+    GroupTotals* tot, uint32_t* status, const uint32_t* list_slot) {
   __shared__ uint64_t sh[kMergeWaves][kWave];
   const uint64_t list = block_merge_keys(cpart, n_segs_c * P, P, sh);
   if (threadIdx.x >= kWave) return;
@@ -370,6 +444,7 @@ __global__ __launch_bounds__(kWave * kMergeWaves) void plan1_kernel(
   if (lane < (int)P) probe[lane] = key;
   const uint32_t L = key != kKeyMax ? (uint32_t)key : kNoList;
   const uint32_t len = L != kNoList ? list_len[L] : 0u;
+  const uint32_t slot = L != kNoList ? list_slot[L] : kNoList;  // the tables and items name a list by its slot (vers_ivf::list_slot)
   auto excl_scan = [&](uint32_t v) {  // exclusive prefix sum over the 64 lanes
     uint32_t inc = v;
 #pragma unroll
@@ -387,7 +462,7 @@ __global__ __launch_bounds__(kWave * kMergeWaves) void plan1_kernel(
   const uint32_t take = !visited ? 0u : (ref_mode ? (len < top_k - pref ? len : top_k - pref) : top_k);
   const bool scan = visited && len > 0 && take > 0 && (owner == nullptr || owner[L] == rank);
   if (lane < (int)P) {
-    pj_list[lane] = scan ? L : kNoList;
+    pj_list[lane] = scan ? slot : kNoList;
     pj_pref[lane] = pref;
     pj_take[lane] = take;
   }
@@ -400,10 +475,10 @@ __global__ __launch_bounds__(kWave * kMergeWaves) void plan1_kernel(
   const uint32_t item0 = excl_scan(n_s);
   const uint32_t pidx = (uint32_t)__popcll(smask & ((1ull << lane) - 1ull));
   if (scan) {
-    cnt[L] = 1; pair_off[L] = pidx; group_off[L] = pidx;
+    cnt[slot] = 1; pair_off[slot] = pidx; group_off[slot] = pidx;
     pairs[pidx] = (uint32_t)lane;  // q*P + j with q = 0
     groups[pidx] = GroupDesc{pidx, 1u};
-    for (uint32_t sgi = 0; sgi < n_s; ++sgi) items[item0 + sgi] = ItemDesc{L, 0u, sgi};
+    for (uint32_t sgi = 0; sgi < n_s; ++sgi) items[item0 + sgi] = ItemDesc{slot, 0u, sgi};
   }
   const uint32_t n_items = (uint32_t)__shfl(item0 + n_s, kWave - 1, kWave);
   const uint32_t rows_scanned = (uint32_t)__shfl(excl_scan(scan ? len : 0u) + (scan ? len : 0u), kWave - 1, kWave);
@@ -620,6 +695,16 @@ struct vers_ivf {
   uint32_t k_pad = 0;
   uint64_t mfma_batches = 0;
   DevBuf rows, row_ids, list_off, list_len;
+  // SLOT space: the per-batch planning tables, the work items and the scan kernels address a list by its SLOT =
+  // rank among the lists by descending length (ties by index).  plan_query translates a centroid index into a slot
+  // once (list_slot); every table the later stages read is then contiguous in work order: the group step's prefix
+  // sums run longest list first -- the dynamic hand-out ends on short quads instead of starting a 5x longer list on
+  // the last free CU (8-way sharded list scan 744 -> 670 us, same box) -- without a single gather.
+  DevBuf list_slot;        // [k] centroid index -> slot
+  DevBuf slot_off, slot_len;  // list_off / list_len in slot order
+  std::vector<uint32_t> h_slot;
+  DevBuf grid_ctr;         // arrival counter of plan_fused_kernel's grid barriers (monotonic, never reset)
+  uint32_t plan_launches = 0;
   std::vector<uint32_t> h_off, h_len, h_cap;  // h_len = GLOBAL list lengths; h_off/h_cap only meaningful for owned lists
   // sharding by cluster across GPUs (one process per GPU): this handle stores only lists with owner == rank
   uint32_t rank = 0, world = 1;
@@ -789,6 +874,21 @@ int32_t plan_storage(vers_ivf* h, const uint32_t* lens, uint32_t k, hipStream_t 
   }
   if (int32_t rc = h->owner.reserve(k ? k : 1)) return rc;
   if (k) VERS_HIP_TRY(hipMemcpyAsync(h->owner.p, h->h_owner.data(), k, hipMemcpyHostToDevice, st));
+  {  // longest lists first (stable: ties by index); add() changes lengths by one at a time, the order is kept as it is
+    std::vector<uint32_t> ord(k), so(k ? k : 1), sl(k ? k : 1);
+    for (uint32_t c = 0; c < k; ++c) ord[c] = c;
+    std::stable_sort(ord.begin(), ord.end(), [&](uint32_t x, uint32_t y) { return h->h_len[x] > h->h_len[y]; });
+    h->h_slot.assign(k, 0);
+    for (uint32_t i = 0; i < k; ++i) { h->h_slot[ord[i]] = i; so[i] = h->h_off[ord[i]]; sl[i] = h->h_len[ord[i]]; }
+    if (int32_t rc = h->list_slot.reserve((k ? k : 1) * sizeof(uint32_t))) return rc;
+    if (int32_t rc = h->slot_off.reserve((k ? k : 1) * sizeof(uint32_t))) return rc;
+    if (int32_t rc = h->slot_len.reserve((k ? k : 1) * sizeof(uint32_t))) return rc;
+    if (k) {
+      VERS_HIP_TRY(hipMemcpy(h->list_slot.p, h->h_slot.data(), (size_t)k * 4, hipMemcpyHostToDevice));
+      VERS_HIP_TRY(hipMemcpy(h->slot_off.p, so.data(), (size_t)k * 4, hipMemcpyHostToDevice));
+      VERS_HIP_TRY(hipMemcpy(h->slot_len.p, sl.data(), (size_t)k * 4, hipMemcpyHostToDevice));
+    }
+  }
   h->cap_rows = off;
   if (int32_t rc = h->rows.reserve((off ? off : 1) * (size_t)h->ld * sizeof(float))) return rc;
   if (int32_t rc = h->row_ids.reserve((off ? off : 1) * sizeof(uint32_t))) return rc;
@@ -1329,7 +1429,8 @@ int32_t coarse_mfma(vers_ivf* h, const float* qp, uint32_t b, uint32_t P, uint64
   VERS_HIP_TRY(hipGetLastError());
   hipLaunchKernelGGL(coarse_select_rescore_kernel, dim3(b), dim3(kWave), 0, st, h->gbuf.as<float>(), h->k_pad, h->k,
                      h->centroids_g.as<float>(), h->ldq, qp, h->ldq, h->ldq, coarse_mode() == 2 ? __builtin_inff() : h->cmax2, P, PS,
-                     probe_out, h->st_word(), h->coarse_stat.as<uint32_t>(), h->metric);
+                     probe_out, h->st_word(), h->coarse_stat.as<uint32_t>(), h->metric,
+                     (scan_debug_flags() & 16u) && h->stamps.p ? h->stamps.as<unsigned long long>() : (unsigned long long*)nullptr);
   VERS_HIP_TRY(hipGetLastError());
   h->mfma_batches += 1;
   return VERS_OK;
@@ -1392,7 +1493,7 @@ int32_t launch_ivf_scan(vers_ivf* h, const IvfSrc<QG>& src, uint32_t items_bound
   p.debug = scan_debug_flags();
   p.stamps = nullptr;
   if (p.debug & 16u) {  // diagnosis only
-    if (int32_t rc = h->stamps.reserve(128)) return rc;
+    if (int32_t rc = h->stamps.reserve(256)) return rc;
     VERS_HIP_TRY(hipMemsetAsync(h->stamps.p, 0, 128, st));
     p.stamps = h->stamps.as<unsigned long long>();
   }
@@ -1437,7 +1538,7 @@ int32_t launch_prescan(vers_ivf* h, const IvfSrc<kPreQ>& src, uint32_t items_bou
   p.metric = (uint32_t)h->metric;
   p.stamps = nullptr;
   if (p.debug & 16u) {
-    if (int32_t rc = h->stamps.reserve(128)) return rc;
+    if (int32_t rc = h->stamps.reserve(256)) return rc;
     VERS_HIP_TRY(hipMemsetAsync(h->stamps.p, 0, 128, st));
     p.stamps = h->stamps.as<unsigned long long>();
   }
@@ -1553,7 +1654,7 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
 
   const uint32_t k_l = h->k;
   // pj: list, pref, take per (q, j); np per q.   lists: cnt, fill | pair_off, group_off, item_off | totals
-  if (int32_t rc = h->pj.reserve((3 * n_pj + b) * sizeof(uint32_t))) return rc;
+  if (int32_t rc = h->pj.reserve((4 * n_pj + b) * sizeof(uint32_t))) return rc;
   // one zero-initialised zone per batch (ONE memset): cnt, fill, hot per list | quad hand-out counter | queue of
   // uncertified queries + its count | non-finite flags per (query, probe)
   const size_t zero_words = 3 * (size_t)k_l + 4 + (use_pre ? (size_t)b + 4 + n_pj : 0);
@@ -1563,13 +1664,14 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
   if (int32_t rc = h->groups.reserve(std::max<uint64_t>(1, groups_bound) * sizeof(GroupDesc))) return rc;
   if (QG != 1 && !use_pre)
     if (int32_t rc = h->qblocks.reserve(groups_bound * h->ldq * QG * sizeof(float))) return rc;
-  h->ivf_bounds_off = (size_t)n_pj * S_max * k_keep;
+  h->ivf_bounds_off = ((size_t)n_pj * S_max * k_keep + 1) & ~(size_t)1;  // (even: the bounds start 16-byte aligned)
   const size_t part_bytes = (h->ivf_bounds_off + n_pj) * sizeof(uint64_t);  // slots + one bound per (query, probe)
-  if (int32_t rc = h->partials.reserve(part_bytes)) return rc;
+  if (int32_t rc = h->partials.reserve(part_bytes + 16)) return rc;
   uint32_t* pj_list = h->pj.as<uint32_t>();
   uint32_t* pj_pref = pj_list + n_pj;
   uint32_t* pj_take = pj_pref + n_pj;
   uint32_t* np = pj_take + n_pj;
+  uint32_t* pj_nq = np + b;
   uint32_t* cnt = h->lists.as<uint32_t>();
   uint32_t* fill = cnt + k_l;
   uint32_t* hot = fill + k_l;  // lists that are the nearest list of some query: scanned first
@@ -1582,28 +1684,40 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
   GroupTotals* tot = (GroupTotals*)(((uintptr_t)(item_off + k_l) + 15) & ~(uintptr_t)15);
   h->tot_dev = tot;
 
-  VERS_HIP_TRY(hipMemsetAsync(h->partials.p, 0xFF, part_bytes, st));
   if (b == 1) {
+    VERS_HIP_TRY(hipMemsetAsync(h->partials.p, 0xFF, part_bytes, st));
     hipLaunchKernelGGL(plan1_kernel, dim3(1), dim3(kWave * kMergeWaves), 0, st, h->cpart.as<uint64_t>(), n_segs_c, P, k_l, top_k,
                        ref_mode, h->list_len.as<uint32_t>(), h->world > 1 ? h->owner.as<uint8_t>() : (const uint8_t*)nullptr, h->rank,
                        seg_rows, h->probe.as<uint64_t>(), pj_list, pj_pref, pj_take, np, cnt, pair_off, group_off,
-                       h->pairs.as<uint32_t>(), h->items.as<ItemDesc>(), h->groups.as<GroupDesc>(), tot, h->st_word());
+                       h->pairs.as<uint32_t>(), h->items.as<ItemDesc>(), h->groups.as<GroupDesc>(), tot, h->st_word(),
+                       (const uint32_t*)h->list_slot.as<uint32_t>());
     VERS_HIP_TRY(hipGetLastError());
   } else {
-  const uint32_t hot_ranks = knobs().hot_ranks;  // A/B knob
-  VERS_HIP_TRY(hipMemsetAsync(cnt, 0, zero_words * sizeof(uint32_t), st));
-  hipLaunchKernelGGL(plan_kernel, dim3((b + 3) / 4), dim3(256), 0, st, probe, b, P, k_l, top_k, ref_mode,
-                     h->list_len.as<uint32_t>(), h->world > 1 ? h->owner.as<uint8_t>() : (const uint8_t*)nullptr, h->rank, pj_list,
-                     pj_pref, pj_take, np, cnt, hot, hot_ranks, h->st_word());
-  VERS_HIP_TRY(hipGetLastError());
-  hipLaunchKernelGGL(group_kernel, dim3(1), dim3(1024), 0, st, cnt, h->list_len.as<uint32_t>(), k_l, (uint32_t)QG, seg_rows, seg_target,
-                     (const uint32_t*)hot, pair_off, group_off, item_off, tot);
-  VERS_HIP_TRY(hipGetLastError());
-  hipLaunchKernelGGL(scatter_pairs_kernel, dim3((unsigned)((n_pj + 255) / 256)), dim3(256), 0, st, pj_list, (uint32_t)n_pj, pair_off,
-                     fill, h->pairs.as<uint32_t>());
-  VERS_HIP_TRY(hipGetLastError());
-  hipLaunchKernelGGL(items_kernel, dim3((k_l + 127) / 128), dim3(128), 0, st, cnt, h->list_len.as<uint32_t>(), k_l, (uint32_t)QG,
-                     seg_rows, seg_target, pair_off, group_off, item_off, h->items.as<ItemDesc>(), h->groups.as<GroupDesc>());
+  // ONE cooperative launch: table fills | plan | group | scatter + items (plan_fused_kernel)
+  PlanArgs pa;
+  pa.probe = probe; pa.b = b; pa.P = P; pa.k_lists = k_l; pa.top_k = top_k; pa.ref_mode = ref_mode;
+  pa.list_len = h->list_len.as<uint32_t>(); pa.owner = h->world > 1 ? h->owner.as<uint8_t>() : (const uint8_t*)nullptr; pa.rank = h->rank;
+  pa.list_slot = h->list_slot.as<uint32_t>(); pa.slot_len = h->slot_len.as<uint32_t>();
+  pa.pj_list = pj_list; pa.pj_pref = pj_pref; pa.pj_take = pj_take; pa.np = np; pa.pj_nq = use_pre ? pj_nq : nullptr;
+  pa.cnt = cnt; pa.fill = fill; pa.hot = hot; pa.zero_words = (uint32_t)zero_words;
+  pa.pair_off = pair_off; pa.group_off = group_off; pa.item_off = item_off; pa.tot = tot;
+  pa.pairs = h->pairs.as<uint32_t>(); pa.items = h->items.as<ItemDesc>(); pa.groups = h->groups.as<GroupDesc>();
+  pa.QG = (uint32_t)QG; pa.seg_rows = seg_rows; pa.seg_target = seg_target; pa.hot_ranks = knobs().hot_ranks;
+  pa.status = h->st_word();
+  if (use_pre) {  // only the bounds behind the slots (n_pj words of 8 bytes; ivf_bounds_off * 8 is a multiple of 16 here? made so below)
+    pa.ff_begin = reinterpret_cast<u32x4*>(h->partials.as<uint64_t>() + h->ivf_bounds_off); pa.ff_vec16 = ((size_t)n_pj * 8 + 15) / 16;
+  } else {        // ordered-chain scans: ivf_merge_kernel reads every slot -- a full-width fill ahead of the planning kernel
+    VERS_HIP_TRY(hipMemsetAsync(h->partials.p, 0xFF, part_bytes, st));
+    pa.ff_begin = nullptr; pa.ff_vec16 = 0;
+  }
+  pa.stamps = nullptr;
+  if (scan_debug_flags() & 16u) {
+    if (int32_t rc = h->stamps.reserve(256)) return rc;
+    pa.stamps = h->stamps.as<unsigned long long>();
+  }
+  pa.grid_ctr = h->grid_ctr.as<uint32_t>(); pa.ctr_base = h->plan_launches * 3u * kPlanBlocks;
+  h->plan_launches += 1;
+  hipLaunchKernelGGL(plan_fused_kernel, dim3(kPlanBlocks), dim3(kPlanThreads), 0, st, pa);
   VERS_HIP_TRY(hipGetLastError());
   if (QG != 1 && !use_pre) {  // (the matrix-core scan gathers its query block from qp while staging it)
     hipLaunchKernelGGL(gather_qblocks_kernel, dim3((unsigned)groups_bound), dim3(256), 0, st, h->groups.as<GroupDesc>(), tot,
@@ -1612,8 +1726,8 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
   }
   }  // b > 1
   auto fill_src = [&](auto& src) {
-    src.rows = h->rows.as<float>(); src.ld = h->ld; src.list_off = h->list_off.as<uint32_t>();
-    src.list_len = h->list_len.as<uint32_t>(); src.items = h->items.as<ItemDesc>(); src.n_items_dev = &tot->n_items;
+    src.rows = h->rows.as<float>(); src.ld = h->ld; src.list_off = h->slot_off.as<uint32_t>();  // (items name lists by slot)
+    src.list_len = h->slot_len.as<uint32_t>(); src.items = h->items.as<ItemDesc>(); src.n_items_dev = &tot->n_items;
     src.cnt = cnt; src.pair_off = pair_off; src.pairs = h->pairs.as<uint32_t>(); src.group_off = group_off;
     src.qblocks = h->qblocks.as<float>(); src.qp = qp; src.ldq = h->ldq; src.P = P; src.S_max = S_max; src.k_keep = k_keep;
     src.seg_rows = seg_rows; src.seg_target = seg_target; src.pj_pref = pj_pref; src.partials = h->partials.as<uint64_t>();
@@ -1627,7 +1741,7 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
     if (int32_t rc2 = launch_prescan(h, src, (uint32_t)items_bound, kp, qflags, quad_ctr, use_shadow, st)) return rc2;
     RescoreArgs a;
     a.partials = h->partials.as<uint64_t>(); a.P = P; a.S_max = S_max; a.kp = kp; a.top_k = top_k; a.d_pad = h->ld;
-    a.pj_list = pj_list; a.pj_pref = pj_pref; a.list_off = h->list_off.as<uint32_t>(); a.row_ids = h->row_ids.as<uint32_t>();
+    a.pj_list = pj_list; a.pj_pref = pj_pref; a.pj_nq = pj_nq; a.list_off = h->slot_off.as<uint32_t>(); a.row_ids = h->row_ids.as<uint32_t>();
     a.rows = h->rows.as<float>(); a.ld = h->ld; a.qp = qp; a.ldq = h->ldq; a.xmax2_bits = h->pre_misc.as<uint32_t>();
     a.qflags = qflags; a.metric = h->metric; a.force_fail = pre_mode == 2; a.shadow = use_shadow ? 1 : 0; a.debug = scan_debug_flags(); a.fail_list = fail_list; a.stats = h->pre_misc.as<uint32_t>() + 1;
     a.status = h->st_word(); a.out_ids = out_ids; a.out_dist = out_dist; a.out_count = out_count; a.out_keys = out_keys;
@@ -1637,7 +1751,7 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
     hipLaunchKernelGGL(ivf_rescore_kernel, dim3(b), dim3(kWave * kRescoreWaves), rs_lds, st, a, stage_rows);
     VERS_HIP_TRY(hipGetLastError());
     const uint32_t fb_slots = std::min<uint32_t>(b, 64);
-    hipLaunchKernelGGL(fallback_scan_kernel, dim3(P, fb_slots), dim3(kWave * kMergeWaves), 0, st, a, (const uint32_t*)h->list_len.as<uint32_t>(),
+    hipLaunchKernelGGL(fallback_scan_kernel, dim3(P, fb_slots), dim3(kWave * kMergeWaves), 0, st, a, (const uint32_t*)h->slot_len.as<uint32_t>(),
                        (const uint32_t*)fail_list, (const uint32_t*)(fail_list + b), h->fb_part.as<uint64_t>());
     VERS_HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(fallback_merge_kernel, dim3(fb_slots), dim3(kWave * kMergeWaves), 0, st, a, (const uint32_t*)fail_list,
@@ -1668,7 +1782,7 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
   }
   if (rc) return rc;
   hipLaunchKernelGGL(ivf_merge_kernel, dim3(b), dim3(kWave * kMergeWaves), 0, st, h->partials.as<uint64_t>(), P, S_max, top_k,
-                     ref_mode, np, pj_list, pj_pref, pj_take, h->list_off.as<uint32_t>(), h->row_ids.as<uint32_t>(), out_ids,
+                     ref_mode, np, pj_list, pj_pref, pj_take, h->slot_off.as<uint32_t>(), h->row_ids.as<uint32_t>(), out_ids,
                      out_dist, out_count, out_keys);
   VERS_HIP_TRY(hipGetLastError());
   h->tot_valid = true;
@@ -1778,6 +1892,11 @@ int32_t relayout(vers_ivf* h) {
   std::swap(h->row_ids.p, nids.p); std::swap(h->row_ids.cap, nids.cap);
   h->h_off = noff; h->h_cap = ncap; h->cap_rows = off;
   VERS_HIP_TRY(hipMemcpy(h->list_off.p, h->h_off.data(), (size_t)k * 4, hipMemcpyHostToDevice));
+  {
+    std::vector<uint32_t> so(k ? k : 1);
+    for (uint32_t c = 0; c < k; ++c) so[h->h_slot[c]] = h->h_off[c];
+    if (k) VERS_HIP_TRY(hipMemcpy(h->slot_off.p, so.data(), (size_t)k * 4, hipMemcpyHostToDevice));
+  }
   if (int32_t rc = refresh_norms(h, 0, h->cap_rows, nullptr)) return rc;
   VERS_HIP_TRY(hipDeviceSynchronize());
   return VERS_OK;
@@ -1885,6 +2004,12 @@ int32_t vers_ivf_create(int32_t device, uint32_t d, vers_ivf_t** out) {
     h->n_cu = prop.multiProcessorCount;
     if (int32_t rc2 = h->status.reserve(16)) return rc2;
     VERS_HIP_TRY(hipMemset(h->status.p, 0, 16));
+    if (int32_t rc2 = h->grid_ctr.reserve(16)) return rc2;
+    VERS_HIP_TRY(hipMemset(h->grid_ctr.p, 0, 16));
+    if (scan_debug_flags() & 16u) {  // diagnosis: in-kernel phase stamps
+      if (int32_t rc2 = h->stamps.reserve(256)) return rc2;
+      VERS_HIP_TRY(hipMemset(h->stamps.p, 0, 256));
+    }
     for (uint32_t i = 0; i < vers_ivf::kEvRing; ++i) {
       VERS_HIP_TRY(hipEventCreate(&h->ev0[i]));
       VERS_HIP_TRY(hipEventCreate(&h->ev1[i]));
@@ -2060,6 +2185,7 @@ int32_t vers_ivf_add(vers_ivf_t* h, const float* row, uint64_t* out_cluster, uin
   }
   h->h_len[c] += 1;
   VERS_HIP_TRY(hipMemcpy(h->list_len.as<uint32_t>() + c, &h->h_len[c], 4, hipMemcpyHostToDevice));
+  VERS_HIP_TRY(hipMemcpy(h->slot_len.as<uint32_t>() + h->h_slot[c], &h->h_len[c], 4, hipMemcpyHostToDevice));
   h->max_len = std::max(h->max_len, h->h_len[c]);
   h->n_total += 1;
   if (out_cluster) *out_cluster = c;
@@ -2252,8 +2378,15 @@ int32_t vers_ivf_last_scan(vers_ivf_t* h, float* out_ms, uint64_t* out_union_row
   if (out_streamed_rows) *out_streamed_rows = t.streamed_rows;
   if (out_items) *out_items = t.n_items;
   if ((scan_debug_flags() & 16u) && h->stamps.p) {  // diagnosis only: per-wave phase cycles of the last launch
-    unsigned long long sv[16] = {};
-    VERS_HIP_TRY(hipMemcpy(sv, h->stamps.p, 128, hipMemcpyDeviceToHost));
+    unsigned long long sv[32] = {};
+    VERS_HIP_TRY(hipMemcpy(sv, h->stamps.p, 256, hipMemcpyDeviceToHost));
+    if (sv[27])
+      fprintf(stderr, "[vers stamps] coarse select, per query avg cycles: select %.0f  exact re-score %.0f  sort+certify+emit %.0f\n",
+              (double)sv[24] / sv[27], (double)sv[25] / sv[27], (double)sv[26] / sv[27]);
+    if (sv[22])
+      fprintf(stderr, "[vers stamps] planning kernel, block 0 (us): fills %.1f  barrier %.1f  plan %.1f+barrier  group %.1f  barrier %.1f  scatter+items %.1f\n",
+              (sv[17] - sv[16]) / 100.0, (sv[18] - sv[17]) / 100.0, (sv[19] - sv[18]) / 100.0, (sv[20] - sv[19]) / 100.0, (sv[21] - sv[20]) / 100.0,
+              (sv[22] - sv[21]) / 100.0);
     if (sv[10])
       fprintf(stderr, "[vers stamps] matrix-core scan, per item avg cycles: prologue %.0f  step loop %.0f (of which issuing loads %.0f)  epilogue %.0f\n",
               (double)sv[9] / sv[4], (double)sv[10] / sv[4], (double)sv[8] / sv[4], (double)sv[11] / sv[4]);

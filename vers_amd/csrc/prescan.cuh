@@ -108,15 +108,45 @@ static __global__ void blocked_row_norms_kernel(const float* rows, uint32_t ld, 
 // 220 rows": ~900 inserts per query and batch instead of the ~170 a perfectly shared threshold needs; inserts
 // were 0.38 ms of 5.3 ms.)  One partial slot per (query, list, quad) goes to the exact finish.
 constexpr int kPreWavesG = 8;  // 4 items x 2 waves
-inline size_t prescan_lds_bytes_g(uint32_t ld, uint32_t kp) {  // query block | hand-out word | lists | locks
-  return (size_t)ld * kPreQ * sizeof(float) + 16 + (size_t)kPreQ * kp * sizeof(uint64_t) + kPreQ * sizeof(uint32_t);
+// Candidate buffer of a query in LDS: `cap` unsorted keys.  kp <= 40 (top_k <= 30 with the default slack): 64 keys, one
+// wave-wide bitonic sort compacts it; wider lists: 128 keys (two sorts + a bitonic merge).  At least 24 free slots after
+// every compaction.
+__host__ __device__ inline uint32_t pre_cap(uint32_t kp) { return kp <= 40u ? 64u : 128u; }
+inline size_t prescan_lds_bytes_g(uint32_t ld, uint32_t kp) {  // query block | hand-out word | buffers | cnt, done, thr, locks
+  return (size_t)ld * kPreQ * sizeof(float) + 16 + (size_t)kPreQ * pre_cap(kp) * sizeof(uint64_t) + 4 * kPreQ * sizeof(uint32_t);
+}
+
+// ---- per-query candidate buffers of a block (LDS) ---------------------------------------------------------------
+// The eight waves of a block share, per query, an UNSORTED buffer of `cap` keys with a fill counter.  A lane whose
+// vals pass the query's threshold reserves slots with ONE LDS atomic add (all 64 lanes, all queries of the set, in a
+// single instruction) and stores its keys: no lock, no sorted insert.  Only when a buffer overflows does one wave take
+// the query's lock, wait until every reserved slot has been written (`done` counter), sort the buffer across its 64
+// lanes (bitonic network on ds_bpermute: ~250 instructions), keep the kp smallest keys and publish the kp-th val as the
+// query's new threshold (to this block through LDS, to the query's other blocks through bounds32).  Pruning stays sound
+// for the same reason as before: a val above the kp-th smallest of ANY subset of a query's candidates cannot be among
+// its kp smallest, and a compaction only drops keys above the kp-th of the buffer.
+// (Round 1 kept a sorted list per query and inserted under the lock: 3-5 k cycles per merge, 110-140 us per launch at
+// every shard count -- DESIGN.md section 6.  An append is ~10 instructions per candidate.)
+// The n_valid (<= cap) keys of a buffer -> ascending over the lanes (kKeyMax padded); lanes >= 64 of a 128-key buffer
+// are folded in: the 64 smallest of the union come out.  Whole wave.
+__device__ __forceinline__ uint64_t buffer_sorted(const uint64_t* bq, uint32_t n_valid, uint32_t cap, int lane) {
+  uint64_t k0 = (uint32_t)lane < n_valid ? bq[lane] : kKeyMax;
+  wave_bitonic_sort64(k0, lane);
+  if (cap > (uint32_t)kWave && n_valid > (uint32_t)kWave) {  // (wave-uniform)
+    uint64_t k1 = (uint32_t)lane + kWave < n_valid ? bq[kWave + lane] : kKeyMax;
+    wave_bitonic_sort64(k1, lane);
+    const uint64_t k1r = shfl_idx64(k1, kWave - 1 - lane);
+    k0 = k0 < k1r ? k0 : k1r;  // ascending vs descending: the element-wise minimum holds the 64 smallest, as a bitonic sequence
+    wave_bitonic_merge64(k0, lane);
+  }
+  return k0;
 }
 
 // BF: the row operand comes from the bf16 shadow copy (half the HBM bytes): a float4 load brings 8 columns of the
 // lane's row, expanded to f32 in the VALU (shift / mask) for the same f32 MFMA; the query operand stays f32.
 template <bool BF, class Src, class Stage>
 __device__ __forceinline__ void prescan_item_g(const Src& src, const PreParams& p, uint32_t it, const ItemView<kPreQ>& v, int half, int lane,
-                                               const float* qm, uint64_t* blk, uint32_t* locks, Stage&& stage) {
+                                               const float* qm, uint64_t* cbuf, uint32_t* ctl, Stage&& stage) {
   const uint32_t n_tiles = (v.nrows + kWave - 1) / kWave;
   const uint32_t t_half = (n_tiles + 1) / 2;
   const uint32_t t_begin = half ? t_half : 0u, t_end = half ? n_tiles : t_half;
@@ -125,7 +155,11 @@ __device__ __forceinline__ void prescan_item_g(const Src& src, const PreParams& 
     return;
   }
   const int n = lane & 15, quarter = lane >> 4;
-  const uint32_t kp = p.kp;
+  const uint32_t kp = p.kp, cap = pre_cap(p.kp);
+  uint32_t* const cnt = ctl;                 // [32] slots reserved in the query's buffer (may run past cap: overflow)
+  uint32_t* const done = ctl + kPreQ;        // [32] slots written
+  uint32_t* const thrq = ctl + 2 * kPreQ;    // [32] order bits of the block's threshold of the query (0xFFFFFFFF: none yet)
+  uint32_t* const locks = ctl + 3 * kPreQ;   // [32] compaction locks
   const bool two = v.nq > 16;  // wave-uniform
   const bool stamp = (p.debug & 16u) != 0;
   const unsigned long long tp0 = stamp ? __builtin_amdgcn_s_memtime() : 0ull;
@@ -185,11 +219,9 @@ __device__ __forceinline__ void prescan_item_g(const Src& src, const PreParams& 
 #pragma unroll
   for (int e = 0; e < 16; ++e) acc[0][e] = acc[1][e] = 0.0f;
   bool bad = false;
-  // The eight waves of the block walk their tiles at the same pace and fold the same queries at the end of each:
-  // every wave starts its round over the query columns at its own offset, so that they do not all queue for the
-  // lock of the same list (bit i of a rotated mask = column (i + rot) & 15).
+  // The eight waves of the block walk their tiles at the same pace and meet the same full buffers: every wave starts
+  // its round over the overflowed query columns at its own offset, so that they do not all queue for the same lock.
   const int rot = (int)(((it & 3u) << 1 | (uint32_t)half) << 1);
-  auto rot16 = [&](uint32_t m) { return ((m >> rot) | (m << (16 - rot))) & 0xFFFFu; };
 
   // End of a tile for query set S: acc already holds val (the |x|^2 term went through the matrix core).  Each lane holds
   // 16 vals of ONE query column (lane & 15), rows 16*(e>>2) + 4*quarter + (e&3): one compare per register against the
@@ -208,53 +240,85 @@ __device__ __forceinline__ void prescan_item_g(const Src& src, const PreParams& 
 #pragma unroll
       for (int e = 0; e < 16; ++e) bad |= !(__builtin_fabsf(a[e]) < __builtin_inff());
     }
-    // (A query without a threshold yet -- thr = +inf -- passes all its finite vals: they enter the list in one lock
-    // hold like any other candidates.  A dedicated first-tile path, LDS transpose + wave-min extraction, measured no
-    // faster once the merges were batched: 4.82 / 4.83 ms on one GPU, 0.816 / 0.803 ms at 8 ranks with / without it.)
-    // Which of the lane's 16 vals pass its query's threshold: one bit per register.  A query column's rows sit in
-    // lanes nn, nn+16, nn+32, nn+48, so the OR of those four masks (scalar) tells which registers carry candidates.
+    // Which of the lane's 16 vals pass its query's threshold: one bit per register.  (A query without a threshold yet
+    // -- thr = +inf -- passes all its finite vals; the first overflow's compaction gives it one.)
     uint32_t pm = 0;
 #pragma unroll
     for (int e = 0; e < 16; ++e) pm |= a[e] <= thr[S] ? 1u << e : 0u;
-    const uint64_t any = __ballot(pm != 0);
-    if (any != 0 && !(p.debug & (1u | 4096u))) {  // (4096: ablation -- only the cold-start fills insert)
-      // All candidates of one query column go into its list under ONE lock hold, register by register (four lanes
-      // each); registers without a candidate cost a scalar bit test.  (One lock round trip per candidate was ~400
-      // cycles; per-register ballots inside the hold were most of the remaining instructions of a merge.)
-      uint32_t qmask = rot16((uint32_t)((any | (any >> 16) | (any >> 32) | (any >> 48)) & 0xFFFFull));
+    if (__ballot(pm != 0) != 0 && !(p.debug & 1u)) {
+      const uint32_t q = (uint32_t)(S * 16 + n);
+      uint64_t* const bq = cbuf + (size_t)q * cap;
       const uint32_t sq0 = vseq[S] + t * kWave + 4u * (uint32_t)quarter;
-      while (qmask) {
-        const int nn = (__builtin_ctz(qmask) + rot) & 15;
-        qmask &= qmask - 1;
-        const int ql = S * 16 + nn;
-        const bool mine = n == nn;
-        const uint32_t em = (uint32_t)__builtin_amdgcn_readlane((int)pm, nn) | (uint32_t)__builtin_amdgcn_readlane((int)pm, nn + 16) |
-                            (uint32_t)__builtin_amdgcn_readlane((int)pm, nn + 32) | (uint32_t)__builtin_amdgcn_readlane((int)pm, nn + 48);
-        if (lane == 0 && !(p.debug & 16384u))
-          while (__hip_atomic_exchange(locks + ql, 1u, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u) __builtin_amdgcn_s_sleep(1);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        uint64_t* Ln = blk + (uint32_t)ql * kp;
-        uint64_t cur = lane < (int)kp ? Ln[lane] : kKeyMax;
-        if (stamp) {
-          const unsigned long long nc = (unsigned long long)__popc(em);  // (registers with a candidate; <= 4 candidates each)
-          if (lane == 0) { atomicAdd(p.stamps + 12, 1ull); atomicAdd(p.stamps + 13, nc); }
-        }
+      // reserve + store: every lane for its own query column, the whole wave in one LDS atomic.  Bits of `pend` that found
+      // a slot are cleared; the others (buffer full) stay for the slow path.
+      auto append = [&](uint32_t& pend) {
+        const uint32_t c = (uint32_t)__popc(pend);
+        uint32_t pos = 0, nw = 0;
+        if (c) pos = __hip_atomic_fetch_add(cnt + q, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
-          if (em & (1u << e)) {  // (wave-uniform)
-            const bool c = mine && (pm >> e & 1u) != 0;
-            wave_topk_update(cur, kp, c ? make_key(a[e], sq0 + 16u * (e >> 2) + (e & 3)) : kKeyMax, kKeyMax);
+          if (pend >> e & 1u) {
+            if (pos < cap) {
+              bq[pos] = make_key(a[e], sq0 + 16u * (e >> 2) + (e & 3));
+              pend &= ~(1u << e);
+              ++nw;
+            }
+            ++pos;
           }
         }
-        if (lane < (int)kp) Ln[lane] = cur;
-        const uint32_t kb = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(cur >> 32), (int)kp - 1);
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        if (lane == 0) __hip_atomic_store(locks + ql, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-        if (kb != 0xFFFFFFFFu) {  // full: its last val bounds the query's kp-th smallest val
-          const float nt = __uint_as_float(order_bits_to_f32_bits(kb));
-          if (mine) thr[S] = nt < thr[S] ? nt : thr[S];
-          if (lane == nn && !(p.debug & 8192u)) atomicMin(p.bounds32 + vslot[S], kb);
+        if (nw) __hip_atomic_fetch_add(done + q, nw, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);  // (after the stores)
+      };
+      uint32_t pend = pm;
+      append(pend);
+      if (stamp) {
+        const unsigned long long nc = (unsigned long long)__popcll(__ballot(pm != 0));
+        if (lane == 0) atomicAdd(p.stamps + 13, nc);
+      }
+      uint64_t ovf = __ballot(pend != 0);
+      while (ovf) {  // some query's buffer is full: compact it under its lock, then place what is still worth placing
+        const uint64_t ovr = rot ? (ovf >> rot) | (ovf << (64 - rot)) : ovf;
+        const int L = (__ffsll((unsigned long long)ovr) - 1 + rot) & 63;
+        const uint32_t qq = (uint32_t)__builtin_amdgcn_readlane((int)q, L);
+        const bool mine = q == qq && pend != 0;
+        uint64_t* const bqq = cbuf + (size_t)qq * cap;
+        if (lane == 0)
+          while (__hip_atomic_exchange(locks + qq, 1u, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u) __builtin_amdgcn_s_sleep(1);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        for (;;) {
+          const uint32_t cv = (uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(cnt + qq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+          if (cv >= cap) {
+            // every reservation below cap belongs to a wave that is on its way to store it without needing this lock
+            while ((uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(done + qq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) != cap)
+              __builtin_amdgcn_s_sleep(1);
+            const uint64_t srt = buffer_sorted(bqq, cap, cap, lane);
+            if (lane < (int)kp) bqq[lane] = srt;
+            const uint32_t kb = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(srt >> 32), (int)kp - 1);  // cap keys >= kp: always a real key
+            if (lane == 0) {
+              __hip_atomic_store(thrq + qq, kb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              __hip_atomic_store(done + qq, kp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // buffer, done and threshold before the counter re-opens it
+            if (lane == 0) __hip_atomic_store(cnt + qq, kp, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (lane == (int)(qq & 15u) && !(p.debug & 8192u)) atomicMin(p.bounds32 + vslot[S], kb);
+            if (stamp && lane == 0) atomicAdd(p.stamps + 12, 1ull);
+          }
+          uint32_t mp = 0;
+          if (mine) {  // the threshold moved: most of what was pending is no longer a candidate
+            const uint32_t bh = __hip_atomic_load(thrq + qq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (bh != 0xFFFFFFFFu) {
+              const float g = __uint_as_float(order_bits_to_f32_bits(bh));
+              thr[S] = g < thr[S] ? g : thr[S];
+            }
+#pragma unroll
+            for (int e = 0; e < 16; ++e) mp |= ((pend >> e & 1u) && a[e] <= thr[S]) ? 1u << e : 0u;
+          }
+          append(mp);
+          if (mine) pend = mp;
+          if (__ballot(mine && pend != 0) == 0) break;
         }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        if (lane == 0) __hip_atomic_store(locks + qq, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        ovf = __ballot(pend != 0);
       }
     }
 #pragma unroll
@@ -344,9 +408,8 @@ __device__ __forceinline__ void prescan_item_g(const Src& src, const PreParams& 
               const float g = __uint_as_float(order_bits_to_f32_bits(gthr[B][s]));
               thr[s] = g < thr[s] ? g : thr[s];
             }
-            // this block's list (the other seven waves'): the high word of its last key
-            const uint32_t bh = __hip_atomic_load(reinterpret_cast<const uint32_t*>(blk + (uint32_t)(s * 16 + n) * kp + (kp - 1)) + 1,
-                                                  __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            // this block's threshold of the query (set by whichever wave compacted its buffer last)
+            const uint32_t bh = __hip_atomic_load(thrq + (uint32_t)(s * 16 + n), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             if (bh != 0xFFFFFFFFu) {
               const float g = __uint_as_float(order_bits_to_f32_bits(bh));
               thr[s] = g < thr[s] ? g : thr[s];
@@ -392,17 +455,21 @@ __global__ __launch_bounds__(kWave * kPreWavesG) __attribute__((amdgpu_waves_per
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   extern __shared__ __attribute__((aligned(16))) float qlds[];
   uint32_t* nq_lds = reinterpret_cast<uint32_t*>(qlds + (size_t)p.ld * kPreQ);
-  uint64_t* blk = reinterpret_cast<uint64_t*>(qlds + (size_t)p.ld * kPreQ + 4);  // [32 queries][kp] sorted keys, shared by the 8 waves
-  uint32_t* locks = reinterpret_cast<uint32_t*>(blk + (size_t)kPreQ * p.kp);
+  const uint32_t cap = pre_cap(p.kp);
+  uint64_t* buf = reinterpret_cast<uint64_t*>(qlds + (size_t)p.ld * kPreQ + 4);  // [32 queries][cap] candidate keys, shared by the 8 waves
+  uint32_t* ctl = reinterpret_cast<uint32_t*>(buf + (size_t)kPreQ * cap);         // cnt | done | thr | locks, [32] each
   const uint32_t n_quads = src.n_items() / 4;
   const unsigned long long clk0 = (p.debug & 16u) ? __builtin_amdgcn_s_memtime() : 0ull;
   const unsigned long long rt0 = (p.debug & 16u) ? __builtin_amdgcn_s_memrealtime() : 0ull;
   uint32_t prev_it0 = 0xFFFFFFFFu, prev_nq = 0;  // the quad whose lists still sit in LDS
-  auto write_out = [&]() {  // block-wide, between barriers: the finished quad's lists -> its partial slots
+  auto write_out = [&]() {  // block-wide, between barriers: the finished quad's buffers -> sorted kp keys in its partial slots
     if (prev_it0 == 0xFFFFFFFFu) return;
-    for (uint32_t t = threadIdx.x; t < prev_nq * p.kp; t += kWave * kPreWavesG) {
-      const uint32_t qi = t / p.kp, j = t - qi * p.kp;
-      src.out_quad(prev_it0, (int)qi)[j] = blk[t];
+    for (uint32_t qi = (uint32_t)wid; qi < prev_nq; qi += kPreWavesG) {  // a wave per query
+      const uint32_t cv = ctl[qi];
+      const uint64_t srt = buffer_sorted(buf + (size_t)qi * cap, cv < cap ? cv : cap, cap, lane);
+      if (lane < (int)p.kp) src.out_quad(prev_it0, (int)qi)[lane] = srt;
+      if (lane == (int)p.kp - 1 && srt != kKeyMax && !(p.debug & 8192u))  // a full list: its last val bounds the query's kp-th smallest
+        atomicMin(p.bounds32 + src.bound_slot(prev_it0, (int)qi), (uint32_t)(srt >> 32));
     }
   };
   for (uint32_t b0 = blockIdx.x;; b0 += gridDim.x) {
@@ -441,8 +508,7 @@ __global__ __launch_bounds__(kWave * kPreWavesG) __attribute__((amdgpu_waves_per
       const unsigned long long ts1 = (p.debug & 16u) ? __builtin_amdgcn_s_memtime() : 0ull;
       write_out();
       __syncthreads();
-      for (uint32_t t = threadIdx.x; t < kPreQ * p.kp; t += kWave * kPreWavesG) blk[t] = kKeyMax;
-      if (threadIdx.x < kPreQ) locks[threadIdx.x] = 0u;
+      if (threadIdx.x < 4 * kPreQ) ctl[threadIdx.x] = (threadIdx.x >> 5) == 2 ? 0xFFFFFFFFu : 0u;  // empty buffers, no threshold, locks open
       f32x4* l4 = reinterpret_cast<f32x4*>(qlds);
 #pragma unroll
       for (int u = 0; u < kStageU; ++u) {
@@ -461,7 +527,7 @@ __global__ __launch_bounds__(kWave * kPreWavesG) __attribute__((amdgpu_waves_per
         atomicAdd(p.stamps + 6, 1ull);
       }
     };
-    prescan_item_g<BF>(src, p, it, v, wid >> 2, lane, qlds, blk, locks, stage);
+    prescan_item_g<BF>(src, p, it, v, wid >> 2, lane, qlds, buf, ctl, stage);
     prev_it0 = bi * 4;
     prev_nq = v.nq;
   }
@@ -477,6 +543,7 @@ struct RescoreArgs {
   uint32_t P, S_max, kp, top_k, d_pad;
   const uint32_t* pj_list;
   const uint32_t* pj_pref;
+  const uint32_t* pj_nq;     // [b*P] partial slots the scan WROTE for (query, probe): the quads of the list, 0 if not scanned here
   const uint32_t* list_off;
   const uint32_t* row_ids;
   const float* rows;
@@ -569,18 +636,21 @@ __global__ __launch_bounds__(kWave * kRescoreWaves) void ivf_rescore_kernel(Resc
     qs[i] = v;
     qpart = __fadd_rn(qpart, __fmul_rn(v, v));  // |q|^2 in any order: the bound inflates it
   }
-  // merge the partial lists: every wave folds a strided share, wave 0 folds the four results
-  const uint32_t n_keys_all = a.P * a.S_max * a.kp;
-  const uint32_t n_keys = (a.debug & 1024u) ? n_keys_all / 8 : n_keys_all;
-  const uint64_t* keys = a.partials + (uint64_t)q * n_keys_all;
+  // merge the partial lists: every wave folds a strided share of the slots the scan wrote, wave 0 folds the four
+  // results.  Only WRITTEN slots are read -- slot (probe j, quad s) exists iff s < pj_nq[j] -- so the slot array needs
+  // no 0xFF fill per batch (10 MB at cfg3, and at 8 ranks 7/8 of the slots belong to other GPUs' lists).
+  const uint32_t n_slots = a.P * a.S_max;
+  const uint64_t* keys = a.partials + (uint64_t)q * n_slots * a.kp;
+  const uint32_t* nqp = a.pj_nq + (uint64_t)q * a.P;
   uint64_t list = kKeyMax;
   constexpr int U = 4;
-  for (uint32_t base = wid * kWave; base < n_keys; base += kRescoreWaves * kWave * U) {
+  for (uint32_t s0 = (uint32_t)wid * U; s0 < n_slots; s0 += kRescoreWaves * U) {
     uint64_t cand[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const uint32_t i = base + u * (kRescoreWaves * kWave) + lane;
-      cand[u] = i < n_keys ? keys[i] : kKeyMax;
+      const uint32_t sl = s0 + u;
+      const bool live = sl < n_slots && (sl % a.S_max) < nqp[sl / a.S_max] && !((a.debug & 1024u) && sl >= n_slots / 8);
+      cand[u] = (live && lane < (int)a.kp) ? keys[(uint64_t)sl * a.kp + lane] : kKeyMax;
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) wave_topk_update(list, a.kp, cand[u], kKeyMax);

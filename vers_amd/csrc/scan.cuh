@@ -93,6 +93,27 @@ __device__ __forceinline__ uint32_t wave_min_u32(uint32_t x) {
   return (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
 }
 
+// Sum / maximum of a u32 over the 64 lanes, same DPP pattern (row-wise inclusive scan by doubling, then row broadcasts).
+__device__ __forceinline__ uint32_t wave_sum_u32(uint32_t x) {
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);  // row_shr:1
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);  // row_shr:2
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false);  // row_shr:4
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false);  // row_shr:8: lane 15 of a row = row sum
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);  // row_bcast:15 into rows 1, 3
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2, 3
+  return (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
+}
+__device__ __forceinline__ uint32_t wave_max_u32(uint32_t x) {
+  uint32_t y;
+  y = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false); x = x > y ? x : y;
+  y = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false); x = x > y ? x : y;
+  y = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false); x = x > y ? x : y;
+  y = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false); x = x > y ? x : y;
+  y = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false); x = x > y ? x : y;
+  y = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false); x = x > y ? x : y;
+  return (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
+}
+
 // First fold of a work item: the list is EMPTY, so all 64 candidates would pass the threshold and be
 // inserted one by one.  Instead pull out the k smallest directly (k rounds of: wave minimum of the
 // distance bits, then of the sequence among the ties) and write them into lanes 0..k-1 in order.
@@ -109,6 +130,36 @@ __device__ __forceinline__ void wave_topk_fill(uint64_t& list, uint32_t k, uint6
   }
 }
 
+// ---- sorting network over the 64 lanes of a wave (ds_bpermute shuffles, no LDS memory) ------------------------
+__device__ __forceinline__ uint64_t shfl_xor64(uint64_t v, int m) {
+  const uint32_t lo = (uint32_t)__shfl_xor((int)(uint32_t)v, m, kWave), hi = (uint32_t)__shfl_xor((int)(uint32_t)(v >> 32), m, kWave);
+  return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint64_t shfl_idx64(uint64_t v, int src) {
+  const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)v, src, kWave), hi = (uint32_t)__shfl((int)(uint32_t)(v >> 32), src, kWave);
+  return ((uint64_t)hi << 32) | lo;
+}
+// the last stage of a bitonic sort: a bitonic sequence over the 64 lanes -> ascending
+__device__ __forceinline__ void wave_bitonic_merge64(uint64_t& key, int lane) {
+#pragma unroll
+  for (int j = 32; j > 0; j >>= 1) {
+    const uint64_t o = shfl_xor64(key, j);
+    const bool lower = (lane & j) == 0;
+    key = (lower == (key < o)) ? key : o;  // lower lane keeps the minimum, upper lane the maximum
+  }
+}
+__device__ __forceinline__ void wave_bitonic_sort64(uint64_t& key, int lane) {
+#pragma unroll
+  for (int k = 2; k <= kWave; k <<= 1) {
+#pragma unroll
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      const uint64_t o = shfl_xor64(key, j);
+      const bool up = (lane & k) == 0 || k == kWave;  // direction of this lane's k-block (the last stage: all ascending)
+      const bool lower = (lane & j) == 0;
+      key = ((lower == up) == (key < o)) ? key : o;
+    }
+  }
+}
 // ---- HBM layout: lane-transposed tiles ---------------------------------------------------------
 // A scanned matrix (corpus lists, centroids) is stored in tiles of 64 rows.  Inside tile t
 // (base = t*64*ld floats) element (r, j) lives at ((j/4)*64 + r)*4 + (j%4): for each group of 4
