@@ -57,6 +57,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="budget of the CPU baseline leg")
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-recall", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the untimed extra measurements (single query, coarse GEMM, flat cfg2, Dist-U recall)")
     ap.add_argument("--ahead", action="store_true", help="compute the next batch's coarse quantiser on a side stream under the current "
                     "list scan (vers_ivf_coarse_ahead_dev; same-box A/B at cfg3: +0.8 %% -- the scan already fills the chip)")
     args = ap.parse_args()
@@ -207,20 +208,23 @@ def main():
     mfma_scan = pst["batches"] > 0
     kernel_name = ("prescan_kernel_g<false, IvfSrc<32>> (inverted-list scan on the f32 matrix cores; exact finish in ivf_rescore_kernel)" if mfma_scan
                    else "scan_kernel<QG,0,IvfSrc<QG>> (inverted-list scan, ordered f32 chains; QG = 16 at this shape)")
-    traffic = None
-    try:
-        tj = json.load(open(os.path.join(ROOT, "profiles", "r01_traffic.json")))
-        if (tj["config"] == {"rows": n, "d": d, "nlist": nlist, "nprobe": nprobe, "batch": B} and world == 1
-                and tj["kernel"].startswith("prescan_kernel") == mfma_scan):
-            traffic = tj["hbm_read_bytes_per_launch"]
-    except (OSError, KeyError, ValueError):
-        pass
+    traffic, traffic_source = None, None
+    for tf in ("r02_traffic.json", "r01_traffic.json"):  # newest PMC run of this exact configuration
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", tf)))
+            if (tj["config"] == {"rows": n, "d": d, "nlist": nlist, "nprobe": nprobe, "batch": B} and world == 1
+                    and tj["kernel"].startswith("prescan_kernel") == mfma_scan):
+                traffic = tj["hbm_read_bytes_per_launch"]
+                traffic_source = f"profiles/{tf}: rocprofv3 --pmc FETCH_SIZE pass of this configuration (committed; not collected in this run)"
+                break
+        except (OSError, KeyError, ValueError):
+            pass
     if rank == 0:
         log(f"[bench] list scan on the matrix cores: {pst['batches']} batches, {pst['fallback_queries']} queries failed the certificate "
             f"and were re-scanned exactly")
     roofline = {"bound": "hbm", "kernel": kernel_name, "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "algorithmic_bytes_per_launch": int(algo_bytes), "streamed_bytes_per_launch": int(ls["streamed_rows"] * d * 4),
+                "traffic_source": traffic_source, "algorithmic_bytes_per_launch": int(algo_bytes), "streamed_bytes_per_launch": int(ls["streamed_rows"] * d * 4),
                 "launch_ms": round(scan_mean_ms, 4), "launches_timed": int(len(scan_ms)), "work_items": int(ls["items"])}
 
     # ---- recall@10 against the exact scan (utils::search_exhaustive over the same values) --------------
@@ -267,49 +271,185 @@ def main():
         self_ok = bool((sids[:, 0].cpu().numpy().astype(np.uint64) == sid).all() and (sdst[:, 0].cpu().numpy() == 0.0).all())
         log(f"[bench] self-retrieval of {len(own)} stored rows at N={n}: {'ok' if self_ok else 'FAILED'}")
 
-    # ---- CPU baseline: the C restatement of the reference path on one host core -----------------------
-    cpu = None
+    # ---- extra measurements, outside the timed region (north_star's other targets) ---------------
+    extra = {}
+    MFMA_F32_PEAK_TF = 157.3  # v_mfma_f32_32x32x2_f32 dense peak (MI355X_MICROARCH.md)
+    if rank == 0:
+        try:  # the batched coarse quantiser of the last timed step: queries x centroids on the f32 matrix cores
+            cm = index.last_coarse_ms()
+            tf = 2.0 * B * nlist * d / (cm["gemm_ms"] * 1e-3) / 1e12
+            extra["coarse_gemm"] = {"kernel": "dist_gemm_kernel<false> (v_mfma_f32_32x32x2_f32, 128x128 block tiles)", "shape": [B, nlist, d],
+                                    "us": round(cm["gemm_ms"] * 1e3, 1), "tflops": round(tf, 1), "peak_tflops": MFMA_F32_PEAK_TF,
+                                    "frac": round(tf / MFMA_F32_PEAK_TF, 4), "select_rescore_us": round(cm["select_ms"] * 1e3, 1)}
+        except capi.VersError:
+            pass
+    if rank == 0 and world == 1 and not args.no_extra:
+        # (a) single query (B = 1): the list-scan kernel alone (HIP events around its launch) over distinct queries, priced
+        # on the bytes of the lists each query actually probed; and the pipelined end-to-end time per query
+        nq1 = min(64, B)
+        ms1, by1 = [], []
+        for i in range(nq1 + 4):
+            index.search_dev(Q[i:].data_ptr(), ld, 1, top_k, nprobe, ids.data_ptr(), dst.data_ptr(), cnt.data_ptr(), st)
+            l1 = index.last_scan()
+            if i >= 4:
+                ms1.append(l1["ms"]); by1.append(l1["union_rows"] * d * 4)
+        index.poll(st)
+        n_e2e = 200
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for i in range(n_e2e):
+            index.search_dev(Q[(i % (n_batches * B)):].data_ptr(), ld, 1, top_k, nprobe, ids.data_ptr(), dst.data_ptr(), cnt.data_ptr(), st)
+        torch.cuda.synchronize(); e2e = (time.perf_counter() - t0) / n_e2e
+        index.poll(st)
+        gbs1 = float(np.sum(by1)) / (float(np.sum(ms1)) * 1e-3) / 1e9
+        extra["single_query"] = {"kernel": "scan_kernel<1,0,IvfSrc<1>> (ordered f32 chains, one query)", "queries": nq1,
+                                 "list_scan_us": round(float(np.mean(ms1)) * 1e3, 1), "probed_list_bytes": int(np.mean(by1)),
+                                 "achieved_GBs": round(gbs1, 1), "frac": round(gbs1 / HBM_PEAK_GBS, 4),
+                                 "end_to_end_us": round(e2e * 1e6, 1), "end_to_end_qps": round(1.0 / e2e, 1)}
+        log(f"[bench] single query: list scan {extra['single_query']['list_scan_us']} us for {np.mean(by1) / 1e6:.0f} MB = "
+            f"{gbs1:.0f} GB/s ({gbs1 / HBM_PEAK_GBS:.2f} of peak); end to end {e2e * 1e6:.1f} us per query")
+        # (b) BASELINE.json cfg2: brute-force scan N = 1M, d = 128, one query; FOUR corpora in rotation (2 GB > the 256 MiB
+        # Infinity Cache), kernel time from HIP events
+        n2, d2, rot = 1_000_000, 128, 4
+        flats = []
+        for r in range(rot):
+            Xf = torch.empty(n2, d2, dtype=torch.float32, device=dev)
+            capi.gen_rows_dev(Xf.data_ptr(), n2, d2, d2, 0, SEED_X + 0x100 + r)
+            fc = capi.FlatCorpus(d2, device=dev_index); fc.upload_dev(Xf.data_ptr(), n2, d2); flats.append(fc)
+            del Xf
+        Qf = torch.empty(64, d2, dtype=torch.float32, device=dev)
+        capi.gen_rows_dev(Qf.data_ptr(), 64, d2, d2, 0, SEED_Q + 0x100)
+        fi = torch.zeros(1, top_k, dtype=torch.int64, device=dev); fd = torch.zeros(1, top_k, device=dev); fcn = torch.zeros(1, dtype=torch.int32, device=dev)
+        msf = {0: [], 1: []}
+        for metric in (0, 1):
+            for i in range(8 + 64):
+                fc = flats[i % rot]
+                fc.search_dev(Qf[i % 64:].data_ptr(), d2, 1, top_k, metric, fi.data_ptr(), fd.data_ptr(), fcn.data_ptr(), st)
+                fc.poll(st)
+                if i >= 8:
+                    msf[metric].append(fc.last_scan_ms())
+        for fc in flats:
+            fc.close()
+        fb = n2 * d2 * 4
+        extra["flat_cfg2"] = {"workload": f"brute-force scan N={n2} d={d2} f32, one query, {rot} corpora in rotation", "algorithmic_bytes": fb,
+                              "l2sq": {"scan_us": round(float(np.mean(msf[0])) * 1e3, 1), "achieved_GBs": round(fb / (np.mean(msf[0]) * 1e-3) / 1e9, 1),
+                                       "frac": round(fb / (np.mean(msf[0]) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+                              "cosdist": {"scan_us": round(float(np.mean(msf[1])) * 1e3, 1), "achieved_GBs": round(fb / (np.mean(msf[1]) * 1e-3) / 1e9, 1),
+                                          "frac": round(fb / (np.mean(msf[1]) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}}
+        log(f"[bench] cfg2 flat scan: {extra['flat_cfg2']['l2sq']['scan_us']} us = {extra['flat_cfg2']['l2sq']['frac']} of peak (L2), "
+            f"{extra['flat_cfg2']['cosdist']['scan_us']} us (1 - dot)")
+        # (c) recall on the worst case: Dist-U (uniform on the sphere -- nothing for the lists to cluster on), same N / nlist / nprobe
+        if not args.no_recall:
+            Xu = torch.empty(n, ld, dtype=torch.float32, device=dev)
+            capi.gen_rows_dev(Xu.data_ptr(), n, d, ld, 0, SEED_X + 7)
+            iu = IVFFlatIndex(d, device=dev_index)
+            iu.build_dev(Xu.data_ptr(), n, nlist, 1, args.kmeans_iters, init)
+            del Xu
+            torch.cuda.empty_cache()
+            nq_u = min(B, 256)
+            Qu = torch.empty(nq_u, ld, dtype=torch.float32, device=dev)
+            capi.gen_rows_dev(Qu.data_ptr(), nq_u, d, ld, 0, SEED_Q + 7)
+            ui = torch.zeros(nq_u, top_k, dtype=torch.int64, device=dev); ud = torch.zeros(nq_u, top_k, device=dev); uc = torch.zeros(nq_u, dtype=torch.int32, device=dev)
+            ei = torch.zeros(nq_u, top_k, dtype=torch.int64, device=dev); ed = torch.zeros(nq_u, top_k, device=dev); ec = torch.zeros(nq_u, dtype=torch.int32, device=dev)
+            iu.search_dev(Qu.data_ptr(), ld, nq_u, top_k, nprobe, ui.data_ptr(), ud.data_ptr(), uc.data_ptr(), st)
+            iu.search_exhaustive_dev(Qu.data_ptr(), ld, nq_u, top_k, 0, ei.data_ptr(), ed.data_ptr(), ec.data_ptr(), st)
+            iu.poll(st)
+            a_, e_ = ui.cpu().numpy(), ei.cpu().numpy()
+            ru = sum(len(set(a_[q].tolist()) & set(e_[q].tolist())) for q in range(nq_u)) / float(nq_u * top_k)
+            extra["recall_at_10_dist_u"] = {"value": round(ru, 4), "queries": nq_u, "note": "uniform sphere: the worst case for an inverted file "
+                                            f"(nprobe/nlist = {nprobe}/{nlist} of the lists); the headline corpus is Dist-C"}
+            log(f"[bench] recall@{top_k} on Dist-U (uniform sphere), same N / nlist / nprobe: {ru:.4f} over {nq_u} queries")
+            iu.close()
+            torch.cuda.empty_cache()
+
+    # ---- CPU baseline: the C restatement of the reference path (oracle/vers_oracle.c) on the host cores ----------
+    # Per sampled query the lists the reference would touch are read back from HBM into a sub-index with all nlist
+    # centroids (the other lists stay empty) -- not timed -- and ONE call of vo_search_nprobe / vo_search on it is timed:
+    # every centroid distance + stable sort, the per-candidate row gather through the id lists (ivfflat.rs:172-175),
+    # every row distance + stable sort.  First on one thread (the reference's search_approximate is serial), then the same
+    # call for independent queries on all host cores ("embarrassingly parallel over queries").
+    cpu, cpu_all = None, None
     if rank == 0 and world == 1 and not args.no_cpu:
+        import ctypes as C
+        from concurrent.futures import ThreadPoolExecutor
         from oracle import c_oracle as co
-        cent = index.get_centroids()
+        cent = np.ascontiguousarray(index.get_centroids())
         qh = Q[(last % n_batches) * B:(last % n_batches) * B + B, :d].cpu().numpy()
-        t_cpu, n_cpu, mismatches = 0.0, 0, 0
-        while t_cpu < args.cpu_seconds and n_cpu < B:
-            q = qh[n_cpu]
-            t0 = time.perf_counter()
-            ranked, _ = co.search_exhaustive(cent, q, nprobe if nprobe else cent.shape[0])  # all centroid distances + stable sort
-            t_cpu += time.perf_counter() - t0
-            if nprobe:
-                parts = [index.get_list(int(c)) for c in ranked]         # D2H of the probed lists: not timed
-                rows = np.concatenate([p[0] for p in parts], axis=0); rid = np.concatenate([p[1] for p in parts])
-                t0 = time.perf_counter()
-                pos, dd = co.search_exhaustive(rows, q, top_k)           # score every probed row, stable sort, take k
-                t_cpu += time.perf_counter() - t0
-                got_ids = rid[pos.astype(np.int64)]
-            else:  # the reference's own walk (ivfflat.rs:166-195): list j gives its top-min(remainder, len), concatenated
-                g_ids, g_d, rem = [], [], top_k
-                for c in ranked:
-                    rows, rid = index.get_list(int(c))                   # (not timed)
-                    if len(rid) == 0:
-                        continue
-                    t0 = time.perf_counter()
-                    pos, dl = co.search_exhaustive(rows, q, top_k)
-                    t_cpu += time.perf_counter() - t0
-                    take = min(rem, len(pos))
-                    g_ids.append(rid[pos[:take].astype(np.int64)]); g_d.append(dl[:take]); rem -= take
+        fp_, u64p = C.POINTER(C.c_float), C.POINTER(C.c_uint64)
+
+        def sub_index(q):
+            ranked, _ = co.search_exhaustive(cent, q, nlist)
+            lists, rem = [], top_k
+            for c in ranked[:nprobe] if nprobe else ranked:
+                rows, rid = index.get_list(int(c))
+                lists.append((int(c), rows, rid))
+                if not nprobe:
+                    rem -= min(rem, len(rid))
                     if rem == 0:
                         break
-                got_ids = np.concatenate(g_ids); dd = np.concatenate(g_d)
-                pos = got_ids
-            ok = (np.array_equal(got_ids, ids_h[n_cpu, :len(pos)])
-                  and np.array_equal(dd.view(np.uint32), dst_h[n_cpu, :len(pos)].view(np.uint32)))
+            off = np.zeros(nlist + 1, dtype=np.uint64)
+            for c, rows, rid in lists:
+                off[c + 1] = len(rid)
+            off = np.cumsum(off).astype(np.uint64)
+            vals = np.zeros((max(1, int(off[-1])), d), dtype=np.float32); vid = np.zeros(max(1, int(off[-1])), dtype=np.uint64)
+            for c, rows, rid in lists:
+                vals[int(off[c]):int(off[c + 1])] = rows; vid[int(off[c]):int(off[c + 1])] = rid
+            return vals, vid, off, np.arange(max(1, int(off[-1])), dtype=np.uint64)
+
+        def run_one(q, sub):
+            vals, vid, off, loc = sub
+            oi = np.zeros(max(1, top_k), dtype=np.uint64); od = np.zeros(max(1, top_k), dtype=np.float32)
+            t0 = time.perf_counter()
+            if nprobe:
+                m = co.lib().vo_search_nprobe_m(vals.ctypes.data_as(fp_), cent.ctypes.data_as(fp_), nlist, d, off.ctypes.data_as(u64p),
+                                                loc.ctypes.data_as(u64p), q.ctypes.data_as(fp_), top_k, nprobe, oi.ctypes.data_as(u64p),
+                                                od.ctypes.data_as(fp_), 0)
+            else:
+                m = co.lib().vo_search_m(vals.ctypes.data_as(fp_), cent.ctypes.data_as(fp_), nlist, d, off.ctypes.data_as(u64p),
+                                         loc.ctypes.data_as(u64p), q.ctypes.data_as(fp_), top_k, oi.ctypes.data_as(u64p), od.ctypes.data_as(fp_), 0)
+            dt = time.perf_counter() - t0
+            assert m >= 0, f"oracle status {m}"
+            return dt, vid[oi[:m].astype(np.int64)], od[:m]
+
+        t_cpu, n_cpu, mismatches = 0.0, 0, 0
+        while t_cpu < args.cpu_seconds and n_cpu < B:
+            q = np.ascontiguousarray(qh[n_cpu])
+            dt, got_ids, dd = run_one(q, sub_index(q))
+            t_cpu += dt
+            ok = (np.array_equal(got_ids, ids_h[n_cpu, :len(got_ids)]) and cnt_h[n_cpu] == len(got_ids)
+                  and np.array_equal(dd.view(np.uint32), dst_h[n_cpu, :len(dd)].view(np.uint32)))
             mismatches += 0 if ok else 1
             n_cpu += 1
+        mode = f"nprobe={nprobe}" if nprobe else "reference mode (nearest list + spill)"
         cpu = {"value": round(n_cpu / t_cpu, 3), "unit": "queries/sec", "cores": 1, "kind": "port",
-               "sample": f"{n_cpu} queries of the last timed batch, nprobe={nprobe}, same index (lists read back from HBM); "
-                         f"single thread like the reference's serial search_approximate",
+               "sample": f"{n_cpu} queries of the last timed batch, {mode}: one vo_search{'_nprobe' if nprobe else ''} call per query on a sub-index read "
+                         f"back from HBM (all {nlist} centroids, the lists the query touches; incl. centroid ranking, per-candidate row gather, "
+                         f"stable sorts); single thread like the reference's serial search_approximate",
                "gpu_matches_cpu_bitwise": mismatches == 0, "mismatching_queries": mismatches}
         log(f"[bench] cpu baseline {cpu['value']} q/s on 1 core over {n_cpu} queries; GPU==CPU bitwise: {mismatches == 0}")
+        # all host cores, one query per thread (the C call releases the GIL)
+        cores = os.cpu_count() or 1
+        per_q = t_cpu / max(1, n_cpu)
+        n_par = int(max(min(cores, B), min(4 * cores, (args.cpu_seconds * cores) / max(per_q, 1e-6))))
+        n_par = min(n_par, B)
+        if n_par > 0:
+            pick = [(n_cpu + i) % B for i in range(n_par)]  # further queries of the batch (wrapping around on small batches)
+            qs = [np.ascontiguousarray(qh[i]) for i in pick]
+            subs = [sub_index(q) for q in qs]                                   # (not timed)
+            t0 = time.perf_counter()
+            with ThreadPoolExecutor(max_workers=cores) as ex:
+                res = list(ex.map(lambda a: run_one(*a), zip(qs, subs)))
+            wall = time.perf_counter() - t0
+            bad = sum(0 if (np.array_equal(r[1], ids_h[pick[i], :len(r[1])]) and
+                            np.array_equal(r[2].view(np.uint32), dst_h[pick[i], :len(r[2])].view(np.uint32))) else 1 for i, r in enumerate(res))
+            model = ""
+            try:
+                model = next(l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name"))
+            except (OSError, StopIteration):
+                pass
+            cpu_all = {"value": round(n_par / wall, 3), "unit": "queries/sec", "cores": cores, "kind": "port", "cpu_model": model,
+                       "sample": f"{n_par} further queries of the same batch, one per thread on {cores} threads (independent searches; the "
+                                 f"reference itself searches serially)", "gpu_matches_cpu_bitwise": bad == 0}
+            log(f"[bench] cpu baseline on all {cores} host threads ({model}): {cpu_all['value']} q/s over {n_par} queries; GPU==CPU bitwise: {bad == 0}")
 
     if rank == 0:
         out = {"metric": "queries/sec + recall@10, IVFFlat N=10M d=768", "value": round(qps, 1), "unit": "queries/sec",
@@ -320,7 +460,7 @@ def main():
                                       f"batch={B} top_k={top_k}, f32, clustered unit vectors (Dist-C)",
                           "n": n, "d": d, "nlist": nlist, "nprobe": nprobe, "batch": B, "top_k": top_k,
                           "kmeans_iters": int(index.iterations[0]), "parallelism": f"lists sharded over {world} GPU(s)"},
-               "roofline": roofline, "cpu_baseline": cpu}
+               "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_all_cores": cpu_all, "extra": extra}
         print(json.dumps(out), flush=True)
     if dist is not None:
         dist.destroy_process_group()

@@ -269,6 +269,10 @@ int32_t vers_topk_merge_dev(const uint64_t* keys_dev, const uint64_t* ids_dev, u
                             uint32_t b, uint32_t top_k, uint32_t nprobe, uint64_t* out_ids_dev,
                             float* out_dist_dev, uint32_t* out_count_dev, void* stream);
 
+/* Measurement hook: durations (HIP events on the search's stream) of the two kernels of the most recent batched
+ * coarse quantiser -- the queries x centroids contraction on the f32 matrix cores (2*b*k*d flop) and the selection /
+ * exact re-score / certificate kernel behind it. */
+int32_t vers_ivf_last_coarse_ms(vers_ivf_t* h, float* out_gemm_ms, float* out_select_ms);
 /* Batched coarse quantiser statistics: batches that went through the MFMA pre-selection (f32 matrix cores +
  * exact re-score + certificate, csrc/gemm.cuh) and queries whose certificate failed and were re-done exactly. */
 int32_t vers_ivf_coarse_stats(vers_ivf_t* h, uint64_t* out_mfma_batches, uint64_t* out_fallback_queries);

@@ -31,11 +31,14 @@ def test_bench_single_gpu_line():
     assert out["roofline"]["bound"] == "hbm" and 0 < out["roofline"]["frac"] < 1.5
     assert out["cpu_baseline"]["gpu_matches_cpu_bitwise"] is True
     assert out["self_retrieval_ok"] is True
+    assert out["cpu_baseline_all_cores"]["cores"] >= 1 and out["cpu_baseline_all_cores"]["gpu_matches_cpu_bitwise"] is True
+    ex = out["extra"]
+    assert ex["single_query"]["list_scan_us"] > 0 and ex["flat_cfg2"]["l2sq"]["frac"] > 0 and 0 <= ex["recall_at_10_dist_u"]["value"] <= 1
 
 
 def test_bench_gpus_2_spawns_ranks_and_builds_row_sharded():
-    one, _ = run_bench("--no-cpu")
-    two, err = run_bench("--gpus", "2", "--no-cpu", env={"VERS_BENCH_BACKEND": "gloo"})
+    one, _ = run_bench("--no-cpu", "--no-extra")
+    two, err = run_bench("--gpus", "2", "--no-cpu", "--no-extra", env={"VERS_BENCH_BACKEND": "gloo"})
     assert two["n_gpus"] == 2
     assert "row-sharded build over 2 ranks: 10000 rows generated per rank" in err
     assert two["recall_at_10"] == one["recall_at_10"]

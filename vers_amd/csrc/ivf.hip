@@ -729,6 +729,8 @@ struct vers_ivf {
   DevBuf qp, qil, cpart, probe, pj, lists, pairs, items, groups, qblocks, partials, status, o_ids, o_dist, o_cnt, xpart;
   static constexpr uint32_t kEvRing = 64;  // scan-launch timing ring (measurement hook)
   hipEvent_t ev0[kEvRing] = {}, ev1[kEvRing] = {};
+  hipEvent_t evc[3] = {};  // batched coarse quantiser of the most recent search: before the GEMM | after it | after select / re-score
+  bool evc_valid = false;
   uint64_t ev_count = 0;
   size_t ivf_bounds_off = 0;  // pruning bounds live behind the partial slots (one memset)
   // host-pointer entry points: one pinned staging buffer, one device buffer for queries, one for the packed
@@ -1424,14 +1426,18 @@ int32_t coarse_mfma(vers_ivf* h, const float* qp, uint32_t b, uint32_t P, uint64
   const uint32_t M_pad = round_up(b, kGemmBM);
   const uint32_t PS = std::min<uint32_t>(kMaxTopK, P + 16);
   if (int32_t rc = h->gbuf.reserve((size_t)M_pad * h->k_pad * sizeof(float))) return rc;
+  const bool timed = st != h->ahead_stream || h->ahead_stream == nullptr;  // (the look-ahead stream is not the measured one)
+  if (timed) VERS_HIP_TRY(hipEventRecord(h->evc[0], st));
   hipLaunchKernelGGL(dist_gemm_kernel<false>, dim3(h->k_pad / kGemmBN, M_pad / kGemmBM), dim3(256), 0, st, qp, h->centroids_g.as<float>(),
                      h->cnorm.as<float>(), h->ldq, h->k_pad, h->gbuf.as<float>(), h->metric);
   VERS_HIP_TRY(hipGetLastError());
+  if (timed) VERS_HIP_TRY(hipEventRecord(h->evc[1], st));
   hipLaunchKernelGGL(coarse_select_rescore_kernel, dim3(b), dim3(kWave), 0, st, h->gbuf.as<float>(), h->k_pad, h->k,
                      h->centroids_g.as<float>(), h->ldq, qp, h->ldq, h->ldq, coarse_mode() == 2 ? __builtin_inff() : h->cmax2, P, PS,
                      probe_out, h->st_word(), h->coarse_stat.as<uint32_t>(), h->metric,
                      (scan_debug_flags() & 16u) && h->stamps.p ? h->stamps.as<unsigned long long>() : (unsigned long long*)nullptr);
   VERS_HIP_TRY(hipGetLastError());
+  if (timed) { VERS_HIP_TRY(hipEventRecord(h->evc[2], st)); h->evc_valid = true; }
   h->mfma_batches += 1;
   return VERS_OK;
 }
@@ -2014,6 +2020,7 @@ int32_t vers_ivf_create(int32_t device, uint32_t d, vers_ivf_t** out) {
       VERS_HIP_TRY(hipEventCreate(&h->ev0[i]));
       VERS_HIP_TRY(hipEventCreate(&h->ev1[i]));
     }
+    for (auto& e : h->evc) VERS_HIP_TRY(hipEventCreate(&e));
     return VERS_OK;
   }();
   if (rc != VERS_OK) {  // nothing half-made leaks: destroy releases whatever was created
@@ -2046,6 +2053,8 @@ int32_t vers_ivf_destroy(vers_ivf_t* h) {
     if (h->ev0[i]) (void)hipEventDestroy(h->ev0[i]);
     if (h->ev1[i]) (void)hipEventDestroy(h->ev1[i]);
   }
+  for (auto& e : h->evc)
+    if (e) (void)hipEventDestroy(e);
   if (h->io_pin) (void)hipHostFree(h->io_pin);
   if (h->fail_watch) (void)hipHostFree(h->fail_watch);
   if (h->io_stream) (void)hipStreamDestroy(h->io_stream);
@@ -2396,6 +2405,16 @@ int32_t vers_ivf_last_scan(vers_ivf_t* h, float* out_ms, uint64_t* out_union_row
     fprintf(stderr, "[vers stamps] list merges under a lock %llu, candidates offered to them %llu\n", sv[12], sv[13]);
     fprintf(stderr, "[vers stamps] shader clock during the kernel: %.0f MHz\n", (double)sv[7] / (double)(1 << 20) * 100.0);
   }
+  return VERS_OK;
+}
+
+int32_t vers_ivf_last_coarse_ms(vers_ivf_t* h, float* out_gemm_ms, float* out_select_ms) {
+  if (!h) return fail(VERS_ERR_INVALID, "null handle");
+  if (!h->evc_valid) return fail(VERS_ERR_INVALID, "no batched coarse quantiser has run on the matrix cores on this handle");
+  DeviceGuard g(h->device);
+  VERS_HIP_TRY(hipEventSynchronize(h->evc[2]));
+  if (out_gemm_ms) VERS_HIP_TRY(hipEventElapsedTime(out_gemm_ms, h->evc[0], h->evc[1]));
+  if (out_select_ms) VERS_HIP_TRY(hipEventElapsedTime(out_select_ms, h->evc[1], h->evc[2]));
   return VERS_OK;
 }
 

@@ -138,6 +138,11 @@ class IVFFlatIndex:
         check(lib().vers_ivf_last_scan(self._h, C.byref(ms), C.byref(u), C.byref(s), C.byref(it)))
         return dict(ms=ms.value, union_rows=u.value, streamed_rows=s.value, items=it.value)
 
+    def last_coarse_ms(self):
+        a = C.c_float(0); b = C.c_float(0)
+        check(lib().vers_ivf_last_coarse_ms(self._h, C.byref(a), C.byref(b)))
+        return dict(gemm_ms=a.value, select_ms=b.value)
+
     def coarse_stats(self):
         a = C.c_uint64(0); b = C.c_uint64(0)
         check(lib().vers_ivf_coarse_stats(self._h, C.byref(a), C.byref(b)))
