@@ -15,6 +15,7 @@ B3="--steps 20 --warmup 5 --no-cpu --no-recall --no-extra"
 B1="--batch 1 --steps 300 --warmup 20 --no-cpu --no-recall --no-extra --kmeans-iters 2"
 run() { # tag, counters ("" = kernel trace + stats), program args...
   local tag=$1 ctr=$2; shift 2
+  mkdir -p "$OUT/$(dirname "$tag")"
   if [ -z "$ctr" ]; then rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/$tag" -- python3 "$@" > "$OUT/$tag.log" 2>&1
   else rocprofv3 --pmc $ctr --output-format csv -d "$OUT/$tag" -- python3 "$@" > "$OUT/$tag.log" 2>&1; fi
 }
