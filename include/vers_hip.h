@@ -43,7 +43,8 @@ extern "C" {
 #define VERS_METRIC_L2SQ 0    /* Vector::squared_euclidean, base.rs:119-126 (what IVFFlat uses) */
 #define VERS_METRIC_COSDIST 1 /* Vector::cosine_similarity(normalized=true) = 1 - dot, base.rs:153-155 */
 
-#define VERS_MAX_TOPK 64 /* per-wave sorted list holds one key per lane */
+#define VERS_MAX_TOPK 64 /* one key per lane: the width of the brute-force scans (vers_flat_*, vers_ivf_search_exhaustive*).
+                          * vers_ivf_search* take any top_k and nprobe: beyond 64 the result comes 64 ranks per pass. */
 
 /* Thread-local description of the most recent failure on this thread. */
 const char* vers_last_error(void);
@@ -165,7 +166,10 @@ int32_t vers_ivf_add(vers_ivf_t* h, const float* row, uint64_t* out_cluster, uin
  *                 fewer than top_k vectors reachable -> VERS_ERR_INSUFFICIENT (reference panics).
  *   nprobe >= 1 : extension named by BASELINE.json (not in the reference): all rows of the nprobe
  *                 nearest lists, one global stable order by (distance, probe rank, list position).
- * out_ids/out_dist [b*top_k], out_count[q] results for query q.  top_k, nprobe <= 64. */
+ * out_ids/out_dist [b*top_k], out_count[q] results for query q.  Any top_k and nprobe (like the reference: its walk has
+ * no cap); top_k <= 54 and nprobe <= 64 is the fast domain (matrix-core list scan), wider results take one ordered-chain
+ * pass per 64 ranks.  Reference mode through the host-pointer call follows the spill through ALL lists if it must; a
+ * device-pointer call ranks 48 lists and latches VERS_ERR_INVALID (vers_ivf_poll) when the spill would run past them. */
 int32_t vers_ivf_search(vers_ivf_t* h, const float* queries, uint64_t q_stride_bytes, uint32_t b,
                         uint32_t top_k, uint32_t nprobe, uint64_t* out_ids, float* out_dist,
                         uint32_t* out_count);

@@ -1,0 +1,96 @@
+"""No caps where the reference has none (ivfflat.rs:166-195): top_k in {65, 100, 256} and nprobe = 128 against the oracle
+bit for bit (results wider than one key per lane come 64 ranks per pass), the reference-mode spill walked through more
+than 64 empty lists, and the cross-GPU merge of wide partial results."""
+import numpy as np
+import pytest
+
+from oracle import c_oracle as co
+from tests import datagen as dg
+from tests.golden import make_golden as mg
+from vers_amd import capi
+from vers_amd.index import IVFFlatIndex
+
+pytestmark = pytest.mark.gpu
+
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+
+def check(ix, Q, top_k, nprobe, qs):
+    ids, dist, cnt = ix.search_batch(Q, top_k, nprobe)
+    for qi in qs:
+        oi, od = (co.search_approximate(ix.values, ix.centroids, ix.ids, Q[qi], top_k) if nprobe == 0 else
+                  co.search_nprobe(ix.values, ix.centroids, ix.ids, Q[qi], top_k, nprobe))
+        assert cnt[qi] == len(oi), (top_k, nprobe, qi, cnt[qi], len(oi))
+        assert np.array_equal(ids[qi, :len(oi)], oi), (top_k, nprobe, qi)
+        assert np.array_equal(bits(dist[qi, :len(oi)]), bits(od)), (top_k, nprobe, qi)
+
+
+def test_wide_top_k_and_many_probes():
+    n, d, k = 9000, 48, 160
+    X = dg.dist_c(0x701, n, d, 300, dg.default_sigma(d))
+    X[100:140] = X[7]                                   # 41 identical rows: ties across a pass boundary decided by list position
+    ix = IVFFlatIndex.build_index(k, 1, 3, X, init_indices=mg.init_draws(0x701, 1, k, n))
+    Q = dg.dist_c(0x702, 48, d, 300, dg.default_sigma(d)); Q[5] = X[7]
+    for top_k in (65, 100, 256):
+        for nprobe in (0, 3, 32, 128, 200):               # 200 > k: every list
+            check(ix, Q, top_k, nprobe, range(0, 48, 5))
+    check(ix, Q, 10, 128, range(0, 48, 7))                # many probes, narrow result
+    check(ix, Q[:1], 100, 128, [0])                       # a single query through the generic planner (P > 64)
+    check(ix, Q[:1], 100, 0, [0])
+    # top_k larger than the number of reachable vectors: nprobe mode returns what there is
+    ids, dist, cnt = ix.search_batch(Q[:4], 300, 1)
+    for qi in range(4):
+        oi, od = co.search_nprobe(ix.values, ix.centroids, ix.ids, Q[qi], 300, 1)
+        assert cnt[qi] == len(oi) and np.array_equal(ids[qi, :len(oi)], oi)
+    ix.close()
+
+
+def test_reference_spill_through_more_than_64_empty_lists():
+    """k = 150 centroids of which 140 are duplicates of one row -> their lists are empty (ties go to the lowest index) and
+    ALL rank ahead of the far lists for queries near that row: the walk of ivfflat.rs:166-195 crosses > 64 empty lists."""
+    n, d, k = 600, 16, 150
+    X = dg.dist_c(0x711, n, d, 8, dg.default_sigma(d))
+    init = mg.init_draws(0x711, 1, k, n)
+    init[:140] = init[0]
+    ix = IVFFlatIndex.build_index(k, 1, 0, X, init_indices=init)     # max_iterations = 0: the drawn centroids stay
+    lens = ix.list_lengths()
+    assert int((lens == 0).sum()) >= 130
+    Q = np.stack([X[int(init[0])] + np.float32(1e-3) * dg.dist_u(0x712 + i, 1, d)[0] for i in range(6)]).astype(np.float32)
+    for top_k in (10, 80, 590):
+        check(ix, Q, top_k, 0, range(6))
+    with pytest.raises(capi.VersError) as e:               # more results than vectors: the reference panics (index out of bounds)
+        ix.search_batch(Q[:1], n + 1, 0)
+    assert e.value.status == capi.ERR_INSUFFICIENT
+    ix.close()
+
+
+def test_cross_gpu_merge_of_wide_partials():
+    import torch
+    n, d, k, world, b = 4000, 32, 40, 3, 9
+    X = dg.dist_c(0x721, n, d, 60, dg.default_sigma(d))
+    init = mg.init_draws(0x721, 1, k, n)
+    whole = IVFFlatIndex.build_index(k, 1, 3, X, init_indices=init)
+    shards = []
+    for r in range(world):
+        ix = IVFFlatIndex(d); ix.set_shard(r, world)
+        ix.values, ix.centroids, ix.assignments = whole.values, whole.centroids, whole.assignments
+        ix._upload(); shards.append(ix)
+    Q = dg.dist_c(0x722, b, d, 60, dg.default_sigma(d))
+    Qd = torch.from_numpy(Q).cuda()
+    for nprobe, top_k in [(0, 100), (12, 150), (40, 70)]:
+        keys = torch.empty(world, b, top_k, dtype=torch.int64, device="cuda"); ids = torch.empty(world, b, top_k, dtype=torch.int64, device="cuda")
+        for r, ix in enumerate(shards):
+            ix.search_partial_dev(Qd.data_ptr(), d, b, top_k, nprobe, keys[r].data_ptr(), ids[r].data_ptr()); ix.poll()
+        oi = torch.zeros(b, top_k, dtype=torch.int64, device="cuda"); od = torch.zeros(b, top_k, device="cuda"); oc = torch.zeros(b, dtype=torch.int32, device="cuda")
+        IVFFlatIndex.merge_partials_dev(keys.data_ptr(), ids.data_ptr(), b * top_k, world, b, top_k, nprobe, oi.data_ptr(), od.data_ptr(), oc.data_ptr())
+        torch.cuda.synchronize()
+        gi, gd, gc = oi.cpu().numpy().astype(np.uint64), od.cpu().numpy(), oc.cpu().numpy()
+        for q in range(b):
+            o_i, o_d = (co.search_approximate(whole.values, whole.centroids, whole.ids, Q[q], top_k) if nprobe == 0 else
+                        co.search_nprobe(whole.values, whole.centroids, whole.ids, Q[q], top_k, nprobe))
+            assert gc[q] == len(o_i) and np.array_equal(gi[q, :len(o_i)], o_i) and np.array_equal(bits(gd[q, :len(o_i)]), bits(o_d)), (nprobe, top_k, q)
+    for ix in shards:
+        ix.close()
+    whole.close()

@@ -106,7 +106,7 @@ int32_t launch_flat_scan(vers_flat* h, const FlatSrc<QG, false>& src, uint32_t n
   p.debug = scan_debug_flags();
   p.stamps = nullptr;
   p.next_quad = nullptr;
-  p.bounds = nullptr;  // every item of a query runs concurrently here: a shared bound prunes nothing and its atomics contend
+  p.bounds = nullptr; p.lower = nullptr;  // every item of a query runs concurrently here: a shared bound prunes nothing and its atomics contend
   const size_t lds = scan_lds_bytes(QG, h->ld);
   if (int32_t rc = scan_prepare_launch(scan_kernel<QG, METRIC, FlatSrc<QG, false>>, lds)) return rc;
   const uint32_t max_blocks = (uint32_t)h->n_cu * scan_blocks_per_cu(QG, h->ld);

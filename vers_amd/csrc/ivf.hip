@@ -168,13 +168,15 @@ struct IvfSrc {
 };
 
 // ---- small kernels of the search pipeline -----------------------------------------------------
-// coarse merge: one block per query, top-P centroid keys (ascending (dist, centroid index))
-__global__ __launch_bounds__(kWave * kMergeWaves) void coarse_merge_kernel(const uint64_t* partials, uint32_t n_segs,
-                                                                           uint32_t P, uint64_t* probe) {
+// coarse merge: one block per query, top-P centroid keys (ascending (dist, centroid index)).  P > 64: 64 ranks per pass
+// (ScanParams::lower) -- this pass's keys go to probe[q][rank0 ..], its last key becomes the next pass's lower bound.
+__global__ __launch_bounds__(kWave * kMergeWaves) void coarse_merge_kernel(const uint64_t* partials, uint32_t n_segs, uint32_t k_pass,
+                                                                           uint32_t P, uint32_t rank0, uint64_t* probe, uint64_t* lower_out) {
   __shared__ uint64_t sh[kMergeWaves][kWave];
   const uint32_t q = blockIdx.x;
-  uint64_t list = block_merge_keys(partials + (uint64_t)q * n_segs * P, n_segs * P, P, sh);
-  if (threadIdx.x < P) probe[(uint64_t)q * P + threadIdx.x] = list;
+  uint64_t list = block_merge_keys(partials + (uint64_t)q * n_segs * k_pass, n_segs * k_pass, k_pass, sh);
+  if (threadIdx.x < k_pass) probe[(uint64_t)q * P + rank0 + threadIdx.x] = list;
+  if (lower_out != nullptr && threadIdx.x == k_pass - 1) lower_out[q] = list;  // (kKeyMax when the centroids ran out: the next pass finds nothing)
 }
 
 // ---- planning of a batch: ONE cooperative launch (plan_fused_kernel) ---------------------------------------------
@@ -208,36 +210,41 @@ __device__ __forceinline__ void plan_query(uint32_t q, int lane, const uint64_t*
                                            uint32_t* pj_list, uint32_t* pj_pref, uint32_t* pj_take, uint32_t* np, uint32_t* cnt,
                                            uint32_t* hot, uint32_t hot_ranks, uint32_t* status, uint32_t* pj_nq, uint32_t seg_rows,
                                            uint32_t seg_target, const uint32_t* list_slot) {
-  const uint64_t key = lane < (int)P ? probe[(uint64_t)q * P + lane] : kKeyMax;
-  const uint32_t L = key != kKeyMax ? (uint32_t)key : kNoList;  // centroid index; the tables below are addressed by its SLOT
-  const uint32_t len = L != kNoList ? list_len[L] : 0u;
-  const uint32_t slot = L != kNoList ? list_slot[L] : kNoList;
-  uint32_t inc = len;
+  // lane j of chunk c = probe rank 64c + j; the running row count carries from chunk to chunk (P <= 64: one chunk)
+  uint32_t carry = 0, n_visited = 0;
+  for (uint32_t c0 = 0; c0 < P; c0 += kWave) {
+    const uint32_t j = c0 + (uint32_t)lane;
+    const uint64_t key = j < P ? probe[(uint64_t)q * P + j] : kKeyMax;
+    const uint32_t L = key != kKeyMax ? (uint32_t)key : kNoList;  // centroid index; the tables below are addressed by its SLOT
+    const uint32_t len = L != kNoList ? list_len[L] : 0u;
+    const uint32_t slot = L != kNoList ? list_slot[L] : kNoList;
+    uint32_t inc = len;
 #pragma unroll
-  for (int off = 1; off < kWave; off <<= 1) {
-    const uint32_t t = __shfl_up(inc, off, kWave);
-    if (lane >= off) inc += t;
-  }
-  const uint32_t pref = inc - len;
-  const uint32_t total_rows = (uint32_t)__shfl(inc, kWave - 1, kWave);
-  const bool visited = L != kNoList && (!ref_mode || pref < top_k);
-  const uint32_t take = !visited ? 0u : (ref_mode ? (len < top_k - pref ? len : top_k - pref) : top_k);
-  const bool scan = visited && len > 0 && take > 0 && (owner == nullptr || owner[L] == rank);
-  if (lane < (int)P) {
-    pj_list[(uint64_t)q * P + lane] = scan ? slot : kNoList;
-    pj_pref[(uint64_t)q * P + lane] = pref;
-    pj_take[(uint64_t)q * P + lane] = take;
-    if (pj_nq) {  // matrix-core scan: one partial slot per quad of segments of a scanned list
-      const uint32_t sr = list_seg_rows(len, seg_rows, seg_target);
-      pj_nq[(uint64_t)q * P + lane] = scan ? ((len + sr - 1) / sr + 3) / 4 : 0u;
+    for (int off = 1; off < kWave; off <<= 1) {
+      const uint32_t t = __shfl_up(inc, off, kWave);
+      if (lane >= off) inc += t;
     }
+    const uint32_t pref = carry + inc - len;
+    carry += (uint32_t)__shfl(inc, kWave - 1, kWave);
+    const bool visited = L != kNoList && (!ref_mode || pref < top_k);
+    const uint32_t take = !visited ? 0u : (ref_mode ? (len < top_k - pref ? len : top_k - pref) : top_k);
+    const bool scan = visited && len > 0 && take > 0 && (owner == nullptr || owner[L] == rank);
+    if (j < P) {
+      pj_list[(uint64_t)q * P + j] = scan ? slot : kNoList;
+      pj_pref[(uint64_t)q * P + j] = pref;
+      pj_take[(uint64_t)q * P + j] = take;
+      if (pj_nq) {  // matrix-core scan: one partial slot per quad of segments of a scanned list
+        const uint32_t sr = list_seg_rows(len, seg_rows, seg_target);
+        pj_nq[(uint64_t)q * P + j] = scan ? ((len + sr - 1) / sr + 3) / 4 : 0u;
+      }
+    }
+    if (scan) atomicAdd(&cnt[slot], 1u);
+    if (scan && j < hot_ranks) hot[slot] = 1u;  // this query's tightest thresholds come from here (the group step orders the work)
+    n_visited += (uint32_t)__popcll(__ballot(visited));
   }
-  if (scan) atomicAdd(&cnt[slot], 1u);
-  if (scan && lane < (int)hot_ranks) hot[slot] = 1u;  // this query's tightest thresholds come from here (the group step orders the work)
-  const uint64_t vmask = __ballot(visited);
   if (lane == 0) {
-    np[q] = (uint32_t)__popcll(vmask);
-    if (ref_mode && top_k > 0 && total_rows < top_k) atomicOr(status, P >= k_lists ? kStInsufficient : kStSpillTooDeep);
+    np[q] = n_visited;
+    if (ref_mode && top_k > 0 && carry < top_k) atomicOr(status, P >= k_lists ? kStInsufficient : kStSpillTooDeep);
   }
 }
 
@@ -503,52 +510,67 @@ __global__ void gather_qblocks_kernel(const GroupDesc* groups, const GroupTotals
   }
 }
 
-// final merge + id mapping: one block per query
+// final merge + id mapping: one block per query.  Results wider than 64 keys come 64 ranks per pass (ScanParams::lower):
+// this pass emits ranks rank0 .. rank0+63 of every merge group into output row q (pitch top_k) and leaves the group's
+// last key as the next pass's lower bound.
 __global__ __launch_bounds__(kWave * kMergeWaves) void ivf_merge_kernel(
     const uint64_t* partials, uint32_t P, uint32_t S_max, uint32_t k_keep, int ref_mode, const uint32_t* np,
     const uint32_t* pj_list, const uint32_t* pj_pref, const uint32_t* pj_take, const uint32_t* list_off,
-    const uint32_t* row_ids, uint64_t* out_ids, float* out_dist, uint32_t* out_count, uint64_t* out_keys) {
+    const uint32_t* row_ids, uint32_t top_k, uint32_t rank0, uint64_t* out_ids, float* out_dist, uint32_t* out_count, uint64_t* out_keys,
+    uint64_t* lower_out) {
   __shared__ uint64_t sh[kMergeWaves][kWave];
   const uint32_t q = blockIdx.x;
   const int lane = threadIdx.x & 63;
   const bool w0 = threadIdx.x < kWave;
   const uint64_t* pq = partials + (uint64_t)q * P * S_max * k_keep;
+  const uint64_t o_base = (uint64_t)q * top_k;
   uint32_t written = 0;
   const uint32_t n_groups = ref_mode ? np[q] : 1;
-  if (w0 && out_keys && lane < (int)k_keep) out_keys[(uint64_t)q * k_keep + lane] = kKeyMax;  // holes = other GPUs' lists
+  if (w0 && out_keys && rank0 == 0)
+    for (uint32_t i = (uint32_t)lane; i < top_k; i += kWave) out_keys[o_base + i] = kKeyMax;  // holes = other GPUs' lists
   for (uint32_t grp = 0; grp < n_groups; ++grp) {
     uint64_t list;
-    uint32_t take;
+    uint32_t n_emit;
     if (ref_mode) {
-      take = pj_take[(uint64_t)q * P + grp];
+      const uint32_t take = pj_take[(uint64_t)q * P + grp];
       if (take == 0) continue;  // uniform per block
-      if (pj_list[(uint64_t)q * P + grp] == kNoList) {  // scanned by the GPU that owns the list: keep its positions
+      n_emit = take > rank0 ? (take - rank0 < (uint32_t)kWave ? take - rank0 : (uint32_t)kWave) : 0u;
+      if (pj_list[(uint64_t)q * P + grp] == kNoList || n_emit == 0) {  // scanned by the GPU that owns the list / this pair is complete
         written += take;
         continue;
       }
       list = block_merge_keys(pq + (uint64_t)grp * S_max * k_keep, S_max * k_keep, k_keep, sh);
+      if (w0) {
+        const bool have = lane < (int)n_emit && list != kKeyMax;
+        const uint32_t row = have ? list_off[pj_list[(uint64_t)q * P + grp]] + ((uint32_t)list - pj_pref[(uint64_t)q * P + grp]) : 0u;
+        if (have) {
+          const uint64_t o = o_base + written + rank0 + lane;
+          out_ids[o] = row_ids[row];
+          out_dist[o] = __uint_as_float(order_bits_to_f32_bits((uint32_t)(list >> 32)));
+          if (out_keys) out_keys[o] = list;
+        }
+        if (lower_out && lane == kWave - 1) lower_out[(uint64_t)q * P + grp] = list;
+      }
+      written += take;
     } else {
-      take = k_keep;
+      n_emit = top_k - rank0 < (uint32_t)kWave ? top_k - rank0 : (uint32_t)kWave;
       list = block_merge_keys(pq, P * S_max * k_keep, k_keep, sh);
-    }
-    if (w0) {
-      const bool have = lane < (int)take && list != kKeyMax;
-      uint32_t row = 0;
-      if (ref_mode) {
-        if (have) row = list_off[pj_list[(uint64_t)q * P + grp]] + ((uint32_t)list - pj_pref[(uint64_t)q * P + grp]);
-      } else {
-        row = wave_seq_rows(list, have, lane, pj_list + (uint64_t)q * P, pj_pref + (uint64_t)q * P, P, list_off);
+      if (w0) {
+        const bool have = lane < (int)n_emit && list != kKeyMax;
+        const uint32_t row = wave_seq_rows(list, have, lane, pj_list + (uint64_t)q * P, pj_pref + (uint64_t)q * P, P, list_off);
+        if (have) {
+          const uint64_t o = o_base + rank0 + lane;
+          out_ids[o] = row_ids[row];
+          out_dist[o] = __uint_as_float(order_bits_to_f32_bits((uint32_t)(list >> 32)));
+          if (out_keys) out_keys[o] = list;
+        }
+        if (lower_out && lane == kWave - 1) lower_out[(uint64_t)q * P] = list;
+        const uint32_t cnt = (uint32_t)__popcll(__ballot(have));
+        written = rank0 == 0 || cnt ? rank0 + cnt : 0xFFFFFFFFu;  // (a later pass that finds nothing leaves the count alone)
       }
-      if (have) {
-        const uint64_t o = (uint64_t)q * k_keep + written + lane;
-        out_ids[o] = row_ids[row];
-        out_dist[o] = __uint_as_float(order_bits_to_f32_bits((uint32_t)(list >> 32)));
-        if (out_keys) out_keys[o] = list;
-      }
-      written += ref_mode ? take : (uint32_t)__popcll(__ballot(have));
     }
   }
-  if (w0 && lane == 0) out_count[q] = written;
+  if (w0 && lane == 0 && written != 0xFFFFFFFFu && (ref_mode ? rank0 == 0 : true)) out_count[q] = written;
 }
 
 // exhaustive merge for the IVF handle (seq == vec_id already)
@@ -577,35 +599,43 @@ __global__ __launch_bounds__(kWave) void rank_merge_kernel(const uint64_t* keys,
                                                            uint64_t* out_ids, float* out_dist, uint32_t* out_count) {
   const uint32_t q = blockIdx.x;
   const int lane = threadIdx.x;
-  uint64_t key = kKeyMax, id = 0;
-  if (ref_mode) {
-    if (lane < (int)k)
-      for (uint32_t r = 0; r < world; ++r) {
-        const uint64_t kk = keys[r * rank_stride + (uint64_t)q * k + lane];
-        if (kk < key) { key = kk; id = ids[r * rank_stride + (uint64_t)q * k + lane]; }
+  uint32_t total = 0;
+  uint64_t lower = 0;  // nprobe mode, k > 64: 64 ranks per pass, keys at or below the previous pass's last key are skipped
+  for (uint32_t r0 = 0; r0 < k; r0 += kWave) {
+    const uint32_t kk = k - r0 < (uint32_t)kWave ? k - r0 : (uint32_t)kWave;
+    uint64_t key = kKeyMax, id = 0;
+    if (ref_mode) {
+      if (lane < (int)kk)
+        for (uint32_t r = 0; r < world; ++r) {
+          const uint64_t kx = keys[r * rank_stride + (uint64_t)q * k + r0 + lane];
+          if (kx < key) { key = kx; id = ids[r * rank_stride + (uint64_t)q * k + r0 + lane]; }
+        }
+    } else {
+      uint64_t list = kKeyMax;
+      const uint32_t n = world * k;
+      for (uint32_t i = 0; i < n; i += kWave) {
+        uint64_t cand = kKeyMax;
+        if (i + lane < n) cand = keys[(uint64_t)((i + lane) / k) * rank_stride + (uint64_t)q * k + (i + lane) % k];
+        if (cand <= lower) cand = kKeyMax;
+        wave_topk_update(list, kk, cand, kKeyMax);
       }
-  } else {
-    uint64_t list = kKeyMax;
-    const uint32_t n = world * k;
-    for (uint32_t i = 0; i < n; i += kWave) {
-      uint64_t cand = kKeyMax;
-      if (i + lane < n) cand = keys[(uint64_t)((i + lane) / k) * rank_stride + (uint64_t)q * k + (i + lane) % k];
-      wave_topk_update(list, k, cand, kKeyMax);
+      key = lane < (int)kk ? list : kKeyMax;
+      if (key != kKeyMax)  // keys are unique: find where this one came from to pick up its id
+        for (uint32_t i = 0; i < n; ++i) {
+          const uint64_t o = (uint64_t)(i / k) * rank_stride + (uint64_t)q * k + i % k;
+          if (keys[o] == key) { id = ids[o]; break; }
+        }
+      lower = readlane64(list, (int)kk - 1);
     }
-    key = lane < (int)k ? list : kKeyMax;
-    if (key != kKeyMax)  // keys are unique: find where this one came from to pick up its id
-      for (uint32_t i = 0; i < n; ++i) {
-        const uint64_t o = (uint64_t)(i / k) * rank_stride + (uint64_t)q * k + i % k;
-        if (keys[o] == key) { id = ids[o]; break; }
-      }
+    const bool have = key != kKeyMax;
+    if (have) {
+      out_ids[(uint64_t)q * k + r0 + lane] = id;
+      out_dist[(uint64_t)q * k + r0 + lane] = __uint_as_float(order_bits_to_f32_bits((uint32_t)(key >> 32)));
+    }
+    total += (uint32_t)__popcll(__ballot(have));
+    if (!ref_mode && lower == kKeyMax) break;  // fewer keys than ranks: nothing left for later passes
   }
-  const bool have = key != kKeyMax;
-  if (have) {
-    out_ids[(uint64_t)q * k + lane] = id;
-    out_dist[(uint64_t)q * k + lane] = __uint_as_float(order_bits_to_f32_bits((uint32_t)(key >> 32)));
-  }
-  const uint32_t cnt = (uint32_t)__popcll(__ballot(have));
-  if (lane == 0) out_count[q] = cnt;
+  if (lane == 0) out_count[q] = total;
 }
 
 // local exhaustive results -> (key, vec_id) pairs for the cross-GPU merge: key = (order bits of the distance << 32) |
@@ -691,6 +721,7 @@ struct vers_ivf {
   DevBuf coarse_stat;  // u32: queries that failed the certificate and were re-done exactly
   float cmax2 = 0.0f;
   bool ref_deep = false;  // reference-mode retry: rank 64 lists with the exact coarse quantiser (no slack needed)
+  bool ref_all = false;      // last resort of a reference-mode host call: every list is ranked (the spill may walk through all of them)
   bool ref_shallow = false;  // host-pointer calls try 16 ranked lists first (a spill past the nearest few lists is rare)
   uint32_t k_pad = 0;
   uint64_t mfma_batches = 0;
@@ -726,6 +757,7 @@ struct vers_ivf {
   uint32_t* fail_watch = nullptr;       // pinned: cumulative certificate failures as of the last finished batch
   uint64_t shadow_queries = 0;          // queries sent through the shadow path since the counter was last zeroed
   uint64_t pre_batches = 0;
+  DevBuf clower, lower;  // lower bounds of multi-pass results (coarse ranking of more than 64 lists; top_k > 64)
   DevBuf qp, qil, cpart, probe, pj, lists, pairs, items, groups, qblocks, partials, status, o_ids, o_dist, o_cnt, xpart;
   static constexpr uint32_t kEvRing = 64;  // scan-launch timing ring (measurement hook)
   hipEvent_t ev0[kEvRing] = {}, ev1[kEvRing] = {};
@@ -789,7 +821,7 @@ int32_t status_to_rc(vers_ivf* h, uint32_t s, uint32_t slot) {
     if (s & kStInsufficient)
       return fail(VERS_ERR_INSUFFICIENT, "fewer than top_k vectors reachable (reference: index out of bounds, ivfflat.rs:169)");
     if (s & kStSpillTooDeep) {
-      fail(VERS_ERR_INVALID, "search_approximate would spill past the ranked lists (48 through the MFMA pre-selection, 64 exact; deeper is unsupported)");
+      fail(VERS_ERR_INVALID, "search_approximate spills past the lists this device-pointer call ranked (48): the host-pointer entry point retries with every list");
       return kRetrySpill;
     }
   }
@@ -1351,7 +1383,8 @@ int32_t build_common(vers_ivf* h, const float* X, uint32_t ldx, uint64_t n, cons
 
 // ---- search ---------------------------------------------------------------------------------------
 template <int QG, bool SEQ_IDS>
-int32_t launch_seg_scan(vers_ivf* h, const SegSrc<QG, SEQ_IDS>& src, uint32_t n_items, int metric, hipStream_t st) {
+int32_t launch_seg_scan(vers_ivf* h, const SegSrc<QG, SEQ_IDS>& src, uint32_t n_items, int metric, hipStream_t st,
+                        const uint64_t* lower = nullptr) {
   ScanParams p;
   p.ld = h->ld;
   p.n_chunks = h->ld / kChunk;
@@ -1361,6 +1394,7 @@ int32_t launch_seg_scan(vers_ivf* h, const SegSrc<QG, SEQ_IDS>& src, uint32_t n_
   p.stamps = nullptr;
   p.next_quad = nullptr;
   p.bounds = nullptr;  // items of a query are concurrent: nothing to prune, and the atomics would contend
+  p.lower = lower;     // (P > 64 ranked lists: 64 ranks per pass)
   const size_t lds = scan_lds_bytes(QG, h->ld);
   uint32_t blocks = (n_items + kWavesPerBlock - 1) / kWavesPerBlock;
   const uint32_t max_blocks = (uint32_t)h->n_cu * scan_blocks_per_cu(QG, h->ld);
@@ -1446,7 +1480,7 @@ int32_t coarse_mfma(vers_ivf* h, const float* qp, uint32_t b, uint32_t P, uint64
 // out_n_segs != nullptr: stop after the scan (partial slots in h->cpart) and report the slot count per query --
 // the single-query path merges them inside plan1_kernel.
 int32_t coarse(vers_ivf* h, const float* qp, uint32_t b, uint32_t P, hipStream_t st, uint32_t* out_n_segs = nullptr) {
-  if (coarse_on_matrix_cores(h, b) && qp == h->qp.as<float>()) {
+  if (coarse_on_matrix_cores(h, b) && qp == h->qp.as<float>() && P + 16 <= (uint32_t)kMaxTopK) {  // (the selection keeps P + 16 keys: one per lane)
     if (int32_t rc = h->probe.reserve((size_t)b * P * sizeof(uint64_t))) return rc;
     return coarse_mfma(h, qp, b, P, h->probe.as<uint64_t>(), st);
   }
@@ -1462,35 +1496,42 @@ int32_t coarse(vers_ivf* h, const float* qp, uint32_t b, uint32_t P, hipStream_t
   uint64_t per = ((uint64_t)h->k * n_qg + target_items - 1) / target_items;
   const uint32_t seg_rows = (uint32_t)std::min<uint64_t>(round_up64(per ? per : 1, kWave), max_seg_rows(h->ld));
   const uint32_t n_segs = (h->k + seg_rows - 1) / seg_rows;
-  if (int32_t rc = h->cpart.reserve((size_t)b * n_segs * P * sizeof(uint64_t))) return rc;
+  const uint32_t kw = std::min<uint32_t>(P, kMaxTopK);  // keys per partial slot: one per lane; P > 64 takes ceil(P / 64) passes
+  if (int32_t rc = h->cpart.reserve((size_t)b * n_segs * kw * sizeof(uint64_t))) return rc;
   if (int32_t rc = h->probe.reserve((size_t)b * P * sizeof(uint64_t))) return rc;
+  if (P > (uint32_t)kMaxTopK)
+    if (int32_t rc = h->clower.reserve((size_t)b * sizeof(uint64_t))) return rc;
   const uint32_t n_segs_pad = QG == 1 ? n_segs : round_up(n_segs, 4);
-  auto fill = [&](auto& src) {
-    src.rows = h->centroids_b.as<float>(); src.n = h->k; src.ld = h->ld; src.seg_rows = seg_rows; src.n_segs = n_segs;
-    src.n_segs_pad = n_segs_pad;
-    src.queries = q; src.ldq = h->ldq; src.b = b; src.partials = h->cpart.as<uint64_t>(); src.k = P; src.ids = nullptr;
-  };
-  int32_t rc;
-  if (QG == 1) {
-    SegSrc<1, false> src; fill(src);
-    rc = launch_seg_scan(h, src, n_segs_pad * n_qg, h->metric, st);
-  } else {
-    SegSrc<8, false> src; fill(src);
-    rc = launch_seg_scan(h, src, n_segs_pad * n_qg, h->metric, st);
+  for (uint32_t rank0 = 0; rank0 < P; rank0 += kMaxTopK) {
+    const uint32_t k_pass = std::min<uint32_t>(kMaxTopK, P - rank0);
+    const uint64_t* lower = rank0 ? h->clower.as<uint64_t>() : nullptr;
+    auto fill = [&](auto& src) {
+      src.rows = h->centroids_b.as<float>(); src.n = h->k; src.ld = h->ld; src.seg_rows = seg_rows; src.n_segs = n_segs;
+      src.n_segs_pad = n_segs_pad;
+      src.queries = q; src.ldq = h->ldq; src.b = b; src.partials = h->cpart.as<uint64_t>(); src.k = k_pass; src.ids = nullptr;
+    };
+    int32_t rc;
+    if (QG == 1) {
+      SegSrc<1, false> src; fill(src);
+      rc = launch_seg_scan(h, src, n_segs_pad * n_qg, h->metric, st, lower);
+    } else {
+      SegSrc<8, false> src; fill(src);
+      rc = launch_seg_scan(h, src, n_segs_pad * n_qg, h->metric, st, lower);
+    }
+    if (rc) return rc;
+    if (out_n_segs) {  // (single query, P <= 64: plan1_kernel merges the slots itself)
+      *out_n_segs = n_segs;
+      return VERS_OK;
+    }
+    hipLaunchKernelGGL(coarse_merge_kernel, dim3(b), dim3(kWave * kMergeWaves), 0, st, h->cpart.as<uint64_t>(), n_segs, k_pass, P, rank0,
+                       h->probe.as<uint64_t>(), P > (uint32_t)kMaxTopK ? h->clower.as<uint64_t>() : (uint64_t*)nullptr);
+    VERS_HIP_TRY(hipGetLastError());
   }
-  if (rc) return rc;
-  if (out_n_segs) {
-    *out_n_segs = n_segs;
-    return VERS_OK;
-  }
-  hipLaunchKernelGGL(coarse_merge_kernel, dim3(b), dim3(kWave * kMergeWaves), 0, st, h->cpart.as<uint64_t>(), n_segs, P,
-                     h->probe.as<uint64_t>());
-  VERS_HIP_TRY(hipGetLastError());
   return VERS_OK;
 }
 
 template <int QG>
-int32_t launch_ivf_scan(vers_ivf* h, const IvfSrc<QG>& src, uint32_t items_bound, hipStream_t st) {
+int32_t launch_ivf_scan(vers_ivf* h, const IvfSrc<QG>& src, uint32_t items_bound, hipStream_t st, const uint64_t* lower = nullptr) {
   ScanParams p;
   p.ld = h->ld;
   p.n_chunks = h->ld / kChunk;
@@ -1506,6 +1547,7 @@ int32_t launch_ivf_scan(vers_ivf* h, const IvfSrc<QG>& src, uint32_t items_bound
   // pruning bounds shared between the items of a merge group (they run at different times here, unlike the flat
   // scans); VERS_SCAN_DEBUG bit 3 switches them off for A/B runs
   p.bounds = (QG != 1 && !(scan_debug_flags() & 8u)) ? h->partials.as<uint64_t>() + h->ivf_bounds_off : nullptr;
+  p.lower = lower;
   p.next_quad = nullptr;
   if (QG != 1 && !(scan_debug_flags() & 32u)) {
     if (int32_t rc = h->quad_counter.reserve(16)) return rc;
@@ -1581,8 +1623,12 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
   const int ref_mode = nprobe == 0;
   // reference mode ranks the 48 nearest lists (48 + 16 slack = one key per lane in the MFMA pre-selection);
   // a spill deeper than that is refused (kStSpillTooDeep) -- it needs > 47 consecutive near-empty lists
-  const uint32_t P = ref_mode ? std::min<uint32_t>(h->k, h->ref_deep ? 64u : (h->ref_shallow ? 16u : 48u)) : std::min<uint32_t>(nprobe, h->k);
-  if (P > (uint32_t)kMaxTopK) return fail(VERS_ERR_INVALID, "nprobe > 64 is not supported");
+  // (host-pointer calls retry deeper: 16, 48, 64 and finally ALL lists, h->ref_all -- the reference walks as far as it must)
+  const uint32_t P = ref_mode ? std::min<uint32_t>(h->k, h->ref_all ? h->k : (h->ref_deep ? 64u : (h->ref_shallow ? 16u : 48u)))
+                              : std::min<uint32_t>(nprobe, h->k);
+  // one key per lane is the width of every list in the kernels: more ranked lists (P > 64) or more results (top_k > 64)
+  // are produced 64 ranks per pass (ScanParams::lower), on the ordered-chain kernels
+  const bool one1 = b == 1 && P <= (uint32_t)kMaxTopK;  // single query: coarse merge + plan fused in plan1_kernel
   const float* qp = nullptr;
   const uint64_t* probe = nullptr;
   vers_ivf::CoarseAhead* took = nullptr;
@@ -1600,7 +1646,7 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
       if (a.ready_rec) VERS_HIP_TRY(hipStreamWaitEvent(st, a.ready, 0));
     if (b == 1 && h->d == h->ldq && (reinterpret_cast<uintptr_t>(q_dev) & 15u) == 0) qp = q_dev;  // a single unpadded-is-padded query: no staging launch
     else if (int32_t rc = stage_plain_queries(h, q_dev, ldq_in, b, &qp, st)) return rc;
-    if (int32_t rc = coarse(h, qp, b, P, st, b == 1 ? &n_segs_c : nullptr)) return rc;
+    if (int32_t rc = coarse(h, qp, b, P, st, one1 ? &n_segs_c : nullptr)) return rc;
     probe = h->probe.as<uint64_t>();
   }
 
@@ -1625,14 +1671,15 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
   }
   if (use_shadow) kp = std::min<uint32_t>(kPreMaxKp, top_k + 38);
   if (knobs().pre_slack > 0) kp = std::min<uint32_t>(kPreMaxKp, top_k + (uint32_t)knobs().pre_slack);  // tuning knob
-  const bool use_pre = QG != 1 && !ref_mode && pre_mode != 0 && top_k + 6 <= kPreMaxKp &&
+  const bool use_pre = QG != 1 && !ref_mode && pre_mode != 0 && top_k + 6 <= kPreMaxKp && P <= (uint32_t)kMaxTopK &&
                        prescan_lds_bytes_g(h->ld, kp) <= 160u * 1024u;  // the query block of 32 padded queries must fit LDS
   if (use_pre) QG = kPreQ;
-  const uint32_t k_keep = use_pre ? kp : top_k;
+  const uint32_t k_keep = use_pre ? kp : std::min<uint32_t>(top_k, kMaxTopK);
+  const uint32_t n_pass = use_pre ? 1u : (top_k + kMaxTopK - 1) / kMaxTopK;  // 64 result ranks per pass
   const uint64_t groups_bound = QG == 1 ? n_pj : (n_pj / QG + std::min<uint64_t>(h->k, n_pj));
   uint32_t seg_rows;
   const uint64_t avg_len_all = std::max<uint64_t>(1, h->n_total / std::max<uint32_t>(1, h->k));
-  if (b == 1) seg_rows = kWave;
+  if (b == 1) seg_rows = kWave;  // (cut finer below when one query probes very many lists)
   else {
     const uint64_t groups_est = std::max<uint64_t>(1, std::max<uint64_t>(pairs_est / QG, lists_est));
     // ~160 items per CU: short segments give every (list, query group) several quads and even out the tail
@@ -1690,7 +1737,9 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
   GroupTotals* tot = (GroupTotals*)(((uintptr_t)(item_off + k_l) + 15) & ~(uintptr_t)15);
   h->tot_dev = tot;
 
-  if (b == 1) {
+  if (n_pass > 1)
+    if (int32_t rc = h->lower.reserve(n_pj * sizeof(uint64_t))) return rc;
+  if (one1) {
     VERS_HIP_TRY(hipMemsetAsync(h->partials.p, 0xFF, part_bytes, st));
     hipLaunchKernelGGL(plan1_kernel, dim3(1), dim3(kWave * kMergeWaves), 0, st, h->cpart.as<uint64_t>(), n_segs_c, P, k_l, top_k,
                        ref_mode, h->list_len.as<uint32_t>(), h->world > 1 ? h->owner.as<uint8_t>() : (const uint8_t*)nullptr, h->rank,
@@ -1699,7 +1748,7 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
                        (const uint32_t*)h->list_slot.as<uint32_t>());
     VERS_HIP_TRY(hipGetLastError());
   } else {
-  // ONE cooperative launch: table fills | plan | group | scatter + items (plan_fused_kernel)
+  // ONE cooperative launch: table fills | plan | group | scatter + items (plan_fused_kernel); also a single query with P > 64
   PlanArgs pa;
   pa.probe = probe; pa.b = b; pa.P = P; pa.k_lists = k_l; pa.top_k = top_k; pa.ref_mode = ref_mode;
   pa.list_len = h->list_len.as<uint32_t>(); pa.owner = h->world > 1 ? h->owner.as<uint8_t>() : (const uint8_t*)nullptr; pa.rank = h->rank;
@@ -1730,7 +1779,7 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
                        h->pairs.as<uint32_t>(), P, qp, h->ldq, (uint32_t)QG, h->qblocks.as<float>());
     VERS_HIP_TRY(hipGetLastError());
   }
-  }  // b > 1
+  }  // batch planning
   auto fill_src = [&](auto& src) {
     src.rows = h->rows.as<float>(); src.ld = h->ld; src.list_off = h->slot_off.as<uint32_t>();  // (items name lists by slot)
     src.list_len = h->slot_len.as<uint32_t>(); src.items = h->items.as<ItemDesc>(); src.n_items_dev = &tot->n_items;
@@ -1776,21 +1825,27 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
     if (took) { VERS_HIP_TRY(hipEventRecord(took->freed, st)); took->freed_rec = true; }
     return VERS_OK;
   }
-  if (QG == 1) {
-    IvfSrc<1> src; fill_src(src);
-    rc = launch_ivf_scan(h, src, (uint32_t)items_bound, st);
-  } else if (QG == 8) {
-    IvfSrc<8> src; fill_src(src);
-    rc = launch_ivf_scan(h, src, (uint32_t)items_bound, st);
-  } else {
-    IvfSrc<16> src; fill_src(src);
-    rc = launch_ivf_scan(h, src, (uint32_t)items_bound, st);
+  // ordered-chain scans: 64 result ranks per pass (one pass for top_k <= 64)
+  for (uint32_t pass = 0; pass < n_pass; ++pass) {
+    const uint64_t* lower = pass ? h->lower.as<uint64_t>() : nullptr;
+    if (pass) VERS_HIP_TRY(hipMemsetAsync(h->partials.p, 0xFF, part_bytes, st));  // slots and pruning bounds of the previous pass
+    if (QG == 1) {
+      IvfSrc<1> src; fill_src(src);
+      rc = launch_ivf_scan(h, src, (uint32_t)items_bound, st, lower);
+    } else if (QG == 8) {
+      IvfSrc<8> src; fill_src(src);
+      rc = launch_ivf_scan(h, src, (uint32_t)items_bound, st, lower);
+    } else {
+      IvfSrc<16> src; fill_src(src);
+      rc = launch_ivf_scan(h, src, (uint32_t)items_bound, st, lower);
+    }
+    if (rc) return rc;
+    hipLaunchKernelGGL(ivf_merge_kernel, dim3(b), dim3(kWave * kMergeWaves), 0, st, h->partials.as<uint64_t>(), P, S_max, k_keep,
+                       ref_mode, np, pj_list, pj_pref, pj_take, h->slot_off.as<uint32_t>(), h->row_ids.as<uint32_t>(), top_k,
+                       pass * (uint32_t)kMaxTopK, out_ids, out_dist, out_count, out_keys,
+                       n_pass > 1 ? h->lower.as<uint64_t>() : (uint64_t*)nullptr);
+    VERS_HIP_TRY(hipGetLastError());
   }
-  if (rc) return rc;
-  hipLaunchKernelGGL(ivf_merge_kernel, dim3(b), dim3(kWave * kMergeWaves), 0, st, h->partials.as<uint64_t>(), P, S_max, top_k,
-                     ref_mode, np, pj_list, pj_pref, pj_take, h->slot_off.as<uint32_t>(), h->row_ids.as<uint32_t>(), out_ids,
-                     out_dist, out_count, out_keys);
-  VERS_HIP_TRY(hipGetLastError());
   h->tot_valid = true;
   if (took) { VERS_HIP_TRY(hipEventRecord(took->freed, st)); took->freed_rec = true; }
   return VERS_OK;
@@ -1800,7 +1855,7 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
 int32_t coarse_ahead_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint32_t b, uint32_t nprobe, hipStream_t st) {
   if (b == 0 || nprobe == 0 || h->k == 0 || !coarse_on_matrix_cores(h, b)) return VERS_OK;  // nothing to gain: the search does it itself
   const uint32_t P = std::min<uint32_t>(nprobe, h->k);
-  if (P > (uint32_t)kMaxTopK) return fail(VERS_ERR_INVALID, "nprobe > 64 is not supported");
+  if (P + 16 > (uint32_t)kMaxTopK) return VERS_OK;  // ranked exactly inside the search (more lists than the matrix-core selection holds)
   if (!h->ahead_stream) {
     VERS_HIP_TRY(hipStreamCreateWithFlags(&h->ahead_stream, hipStreamNonBlocking));
     VERS_HIP_TRY(hipEventCreateWithFlags(&h->ahead_in, hipEventDisableTiming));
@@ -2205,7 +2260,6 @@ int32_t vers_ivf_add(vers_ivf_t* h, const float* row, uint64_t* out_cluster, uin
 int32_t vers_ivf_search_dev(vers_ivf_t* h, const float* queries_dev, uint64_t ldq_floats, uint32_t b, uint32_t top_k,
                             uint32_t nprobe, uint64_t* out_ids_dev, float* out_dist_dev, uint32_t* out_count_dev, void* stream) {
   if (!h) return fail(VERS_ERR_INVALID, "null handle");
-  if (top_k > VERS_MAX_TOPK) return fail(VERS_ERR_INVALID, "top_k > VERS_MAX_TOPK (64) is not supported");
   if (b && (!queries_dev || ldq_floats < h->d || !out_count_dev || (top_k && (!out_ids_dev || !out_dist_dev))))
     return fail(VERS_ERR_INVALID, "vers_ivf_search_dev: bad arguments");
   std::lock_guard<std::mutex> lk(h->mu);
@@ -2238,7 +2292,7 @@ int32_t vers_ivf_owners(vers_ivf_t* h, uint8_t* out_owner) {
 int32_t vers_ivf_search_partial_dev(vers_ivf_t* h, const float* queries_dev, uint64_t ldq_floats, uint32_t b, uint32_t top_k,
                                     uint32_t nprobe, uint64_t* out_keys_dev, uint64_t* out_ids_dev, void* stream) {
   if (!h) return fail(VERS_ERR_INVALID, "null handle");
-  if (top_k == 0 || top_k > VERS_MAX_TOPK) return fail(VERS_ERR_INVALID, "top_k must be in 1..VERS_MAX_TOPK");
+  if (top_k == 0) return fail(VERS_ERR_INVALID, "vers_ivf_search_partial_dev: top_k must be at least 1");
   if (b && (!queries_dev || ldq_floats < h->d || !out_keys_dev || !out_ids_dev))
     return fail(VERS_ERR_INVALID, "vers_ivf_search_partial_dev: bad arguments");
   std::lock_guard<std::mutex> lk(h->mu);
@@ -2261,7 +2315,7 @@ int32_t vers_topk_merge_dev(const uint64_t* keys_dev, const uint64_t* ids_dev, u
                             uint32_t top_k, uint32_t nprobe, uint64_t* out_ids_dev, float* out_dist_dev, uint32_t* out_count_dev,
                             void* stream) {
   if (rank_stride < (uint64_t)b * top_k) return fail(VERS_ERR_INVALID, "vers_topk_merge_dev: rank_stride < b * top_k");
-  if (world == 0 || top_k == 0 || top_k > VERS_MAX_TOPK || (b && (!keys_dev || !ids_dev || !out_ids_dev || !out_dist_dev || !out_count_dev)))
+  if (world == 0 || top_k == 0 || (b && (!keys_dev || !ids_dev || !out_ids_dev || !out_dist_dev || !out_count_dev)))
     return fail(VERS_ERR_INVALID, "vers_topk_merge_dev: bad arguments");
   if (b == 0) return VERS_OK;
   hipLaunchKernelGGL(rank_merge_kernel, dim3(b), dim3(kWave), 0, (hipStream_t)stream, keys_dev, ids_dev, rank_stride, world, b, top_k,
@@ -2280,7 +2334,6 @@ int32_t vers_ivf_poll(vers_ivf_t* h, void* stream) {
 int32_t vers_ivf_search(vers_ivf_t* h, const float* queries, uint64_t q_stride_bytes, uint32_t b, uint32_t top_k,
                         uint32_t nprobe, uint64_t* out_ids, float* out_dist, uint32_t* out_count) {
   if (!h) return fail(VERS_ERR_INVALID, "null handle");
-  if (top_k > VERS_MAX_TOPK) return fail(VERS_ERR_INVALID, "top_k > VERS_MAX_TOPK (64) is not supported");
   if (b && (!queries || q_stride_bytes < (uint64_t)h->d * 4 || q_stride_bytes % 4 || !out_count || (top_k && (!out_ids || !out_dist))))
     return fail(VERS_ERR_INVALID, "vers_ivf_search: bad arguments");
   if (b == 0) return VERS_OK;
@@ -2290,19 +2343,28 @@ int32_t vers_ivf_search(vers_ivf_t* h, const float* queries, uint64_t q_stride_b
   HostIo io;
   if (int32_t rc = host_io_begin(h, queries, q_stride_bytes, b, top_k, io)) return rc;
   // Reference mode ranks only as many lists as the spill may need: 16 first (the merge of the coarse partial lists
-  // and the plan are what a single-query call waits for), then 48, then 64 with the exact coarse quantiser.
+  // and the plan are what a single-query call waits for), then 48, then 64 with the exact coarse quantiser, and as
+  // the last resort ALL of them (ivfflat.rs:166-195 walks the ranked lists as far as it must -- many empty lists with
+  // zero centroids make that real); the batch then goes in slices so that the (query, list) tables stay small.
   int32_t rc = VERS_OK;
-  for (int attempt = nprobe == 0 ? 0 : 1; attempt < 3; ++attempt) {
+  for (int attempt = nprobe == 0 ? 0 : 1; attempt < 4; ++attempt) {
     h->ref_shallow = attempt == 0;
     h->ref_deep = attempt == 2;
+    h->ref_all = attempt == 3;
     // every attempt starts from zeros: entries past a query's count must not carry a previous attempt's values
     VERS_HIP_TRY(hipMemsetAsync(h->io_out.p, 0, io.out_bytes, h->io_stream));
-    rc = search_dev_locked(h, io.q_dev, h->d, b, top_k, nprobe, io.ids_dev, io.dist_dev, io.cnt_dev, nullptr, h->io_stream);
-    h->ref_shallow = h->ref_deep = false;
+    const uint32_t slice = attempt == 3 ? std::max<uint32_t>(1u, 65536u / std::max<uint32_t>(1u, h->k)) : b;
+    rc = VERS_OK;
+    for (uint32_t q0 = 0; q0 < b && rc == VERS_OK; q0 += slice) {
+      const uint32_t bq = std::min(slice, b - q0);
+      rc = search_dev_locked(h, io.q_dev + (size_t)q0 * h->d, h->d, bq, top_k, nprobe, io.ids_dev + (size_t)q0 * top_k,
+                             io.dist_dev + (size_t)q0 * top_k, io.cnt_dev + q0, nullptr, h->io_stream);
+    }
+    h->ref_shallow = h->ref_deep = h->ref_all = false;
     if (rc) return rc;
     rc = host_io_end(h, io, b, top_k, out_ids, out_dist, out_count);
     if (rc != kRetrySpill) break;
-    if ((attempt == 0 && h->k <= 16) || (attempt == 1 && h->k <= 48)) break;  // every list was ranked already
+    if ((attempt == 0 && h->k <= 16) || (attempt == 1 && h->k <= 48) || (attempt == 2 && h->k <= 64)) break;  // every list was ranked already
   }
   return rc == kRetrySpill ? VERS_ERR_INVALID : rc;
 }

@@ -115,7 +115,7 @@ int32_t km_assign(const float* X, uint32_t ldx, uint64_t n, const float* C, uint
   p.debug = 0;
   p.stamps = nullptr;
   p.next_quad = nullptr;
-  p.bounds = nullptr;  // the four quarter-items of a point group run side by side: nothing to share
+  p.bounds = nullptr; p.lower = nullptr;  // the four quarter-items of a point group run side by side: nothing to share
   const size_t lds = scan_lds_bytes(QG, ldq);
   if (int32_t rc = metric ? scan_prepare_launch(scan_kernel<QG, 1, AssignSrc<QG>>, lds) : scan_prepare_launch(scan_kernel<QG, 0, AssignSrc<QG>>, lds)) return rc;
   const uint32_t seg_rows = round_up((k + 3) / 4, 64);

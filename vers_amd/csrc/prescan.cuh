@@ -570,18 +570,22 @@ struct RescoreArgs {
 // last scanned probe that starts at or before seq (a per-lane loop over the P probes is 2 P dependent-latency loads).
 __device__ __forceinline__ uint32_t wave_seq_rows(uint64_t key, bool valid, int lane, const uint32_t* pj_list, const uint32_t* pj_pref,
                                                   uint32_t P, const uint32_t* list_off) {
-  const uint32_t pref = lane < (int)P ? pj_pref[lane] : 0u;
-  const uint32_t lst = lane < (int)P ? pj_list[lane] : 0xFFFFFFFFu;
   uint32_t my_list = 0xFFFFFFFFu, my_off = 0;
-  uint64_t todo = __ballot(valid);
-  while (todo) {
-    const int c = __ffsll((unsigned long long)todo) - 1;
-    todo &= todo - 1;
-    const uint32_t seq = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)key, c);
-    const uint64_t m = __ballot(lst != 0xFFFFFFFFu && pref <= seq);
-    const int j = 63 - __builtin_clzll((unsigned long long)(m | 1ull));
-    const uint32_t lj = (uint32_t)__builtin_amdgcn_readlane((int)lst, j), pj = (uint32_t)__builtin_amdgcn_readlane((int)pref, j);
-    if (lane == c) { my_list = lj; my_off = seq - pj; }
+  for (uint32_t c0 = 0; c0 < P; c0 += kWave) {  // 64 probes per chunk (pj_pref ascends with the probe rank: a later match overrides)
+    const uint32_t j0 = c0 + (uint32_t)lane;
+    const uint32_t pref = j0 < P ? pj_pref[j0] : 0u;
+    const uint32_t lst = j0 < P ? pj_list[j0] : 0xFFFFFFFFu;
+    uint64_t todo = __ballot(valid);
+    while (todo) {
+      const int c = __ffsll((unsigned long long)todo) - 1;
+      todo &= todo - 1;
+      const uint32_t seq = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)key, c);
+      const uint64_t m = __ballot(lst != 0xFFFFFFFFu && pref <= seq);
+      if (m == 0) continue;
+      const int j = 63 - __builtin_clzll((unsigned long long)m);
+      const uint32_t lj = (uint32_t)__builtin_amdgcn_readlane((int)lst, j), pj = (uint32_t)__builtin_amdgcn_readlane((int)pref, j);
+      if (lane == c) { my_list = lj; my_off = seq - pj; }
+    }
   }
   return valid && my_list != 0xFFFFFFFFu ? list_off[my_list] + my_off : 0xFFFFFFFFu;
 }
@@ -792,7 +796,7 @@ __global__ __launch_bounds__(kWave * kMergeWaves) void fallback_scan_kernel(Resc
   const uint32_t n_fail = *fail_count;
   const uint32_t j = blockIdx.x;
   ScanParams p;
-  p.ld = a.ld; p.n_chunks = a.ld / kChunk; p.k = a.top_k; p.status = a.status; p.bounds = nullptr; p.debug = 0;
+  p.ld = a.ld; p.n_chunks = a.ld / kChunk; p.k = a.top_k; p.status = a.status; p.bounds = nullptr; p.lower = nullptr; p.debug = 0;
   p.next_quad = nullptr; p.stamps = nullptr;
   bool nan_seen = false;
   for (uint32_t i = blockIdx.y; i < n_fail; i += gridDim.y) {

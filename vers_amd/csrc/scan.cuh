@@ -358,6 +358,9 @@ struct ScanParams {
   uint32_t k;         // keys kept per query (<= 64)
   uint32_t* status;   // device word: bit0 = NaN seen
   uint64_t* bounds;   // nullable: shared pruning bound per merge group (Src::bound_slot), kKeyMax initialised
+  const uint64_t* lower;  // nullable: per merge group (Src::bound_slot) the last key of the PREVIOUS pass -- keys <= it are dropped.
+                          // Results wider than one key per lane (top_k or nprobe > 64) are produced 64 ranks per pass: keys are
+                          // unique and totally ordered, so pass p holds exactly ranks 64p .. 64p+63 of the full order.
   uint32_t debug;     // diagnosis only (env VERS_SCAN_DEBUG): 1 skip top-k, 2 skip math, 4 one query column, 16 stamp phases
   uint32_t* next_quad;  // batched kernels: device counter for dynamic quad hand-out (zeroed per launch) or nullptr
   unsigned long long* stamps;  // debug & 16: [0] cycles waiting for loads, [1] math, [2] top-k fold, [3] item setup, [4] waves
@@ -375,6 +378,8 @@ __device__ __forceinline__ void scan_item(const Src& src, const ScanParams& p, u
     if (p.bounds != nullptr && qi < 2 * NP && qi < (int)v.nq)  // relaxed agent-scope read: a stale value only prunes less
       bound[qi] = uniform64(__hip_atomic_load(p.bounds + src.bound_slot(it, qi), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
   }
+  uint64_t vlower = 0;  // lane qi: query qi's exclusive lower bound (0 = none: no key is 0)
+  if (p.lower != nullptr && lane < QG && lane < (int)v.nq) vlower = p.lower[src.bound_slot(it, lane)];
   const uint32_t n_tiles = (v.nrows + kWave - 1) / kWave;
   TileLoader L;
   L.init(v.rows, (uint64_t)n_tiles * kWave * p.ld * 4u, p.ld, lane);
@@ -405,7 +410,8 @@ __device__ __forceinline__ void scan_item(const Src& src, const ScanParams& p, u
         const float dist = METRIC == 0 ? a : __fsub_rn(1.0f, a);
         nan_seen |= valid && (dist != dist);
         const uint32_t seq = Src::kSeqIds ? sid : (uint32_t)__builtin_amdgcn_readlane((int)vseq, qi) + row;
-        const uint64_t cand = valid ? make_key(dist, seq) : kKeyMax;
+        uint64_t cand = valid ? make_key(dist, seq) : kKeyMax;
+        if (p.lower != nullptr && cand <= readlane64(vlower, qi)) cand = kKeyMax;  // ranked in an earlier pass
         if (t == 0 && p.k <= 16 && bound[qi] == kKeyMax) wave_topk_fill(list[qi], p.k, cand, lane);
         else wave_topk_update(list[qi], p.k, cand, bound[qi]);
       }
@@ -485,10 +491,12 @@ __device__ __forceinline__ void scan_item2(const Src& src, const ScanParams& p, 
   uint32_t vseq = 0;
   uint64_t vout = 0;
   uint64_t vbound = kKeyMax;  // shared pruning bound of query `lane`'s merge group (see wave_topk_update)
+  uint64_t vlower = 0;        // exclusive lower bound of query `lane` (multi-pass results, see ScanParams::lower)
   uint64_t* bslot = nullptr;
   if (lane < QG && lane < (int)v.nq) {  // per-query constants once, lane qi = query qi (see scan_item)
     vseq = Src::kSeqIds ? 0u : src.seq_base(it, lane);
     vout = (uint64_t)src.out(it, lane);
+    if (p.lower != nullptr) vlower = p.lower[src.bound_slot(it, lane)];
     if (p.bounds != nullptr) {
       bslot = p.bounds + src.bound_slot(it, lane);
       vbound = __hip_atomic_load(bslot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // stale = prunes less, never wrong
@@ -509,7 +517,8 @@ __device__ __forceinline__ void scan_item2(const Src& src, const ScanParams& p, 
         const float dist = METRIC == 0 ? a : __fsub_rn(1.0f, a);
         nan_seen |= valid && (dist != dist);
         const uint32_t seq = Src::kSeqIds ? sid : (uint32_t)__builtin_amdgcn_readlane((int)vseq, qi) + row;
-        const uint64_t cand = valid ? make_key(dist, seq) : kKeyMax;
+        uint64_t cand = valid ? make_key(dist, seq) : kKeyMax;
+        if (p.lower != nullptr && cand <= readlane64(vlower, qi)) cand = kKeyMax;  // ranked in an earlier pass
         const uint64_t bnd = p.bounds != nullptr ? readlane64(vbound, qi) : kKeyMax;
         if (t == 0 && p.k <= 16 && bnd == kKeyMax) wave_topk_fill(list[qi], p.k, cand, lane);
         else wave_topk_update(list[qi], p.k, cand, bnd);
