@@ -30,8 +30,18 @@ for i in range(3): step(i)
 torch.cuda.synchronize(); ix.scan_times(reset=True); t0 = time.perf_counter()
 for i in range(20): step(3 + i)
 torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / 20
+# the merge of the gathered partials (vers_topk_merge_dev): W copies of this rank's partial stand in for the all-gather's
+# output -- the kernel's time does not depend on whose keys they are
+allp = torch.empty(W, 2, B, top_k, dtype=torch.int64, device=dev)
+oi = torch.zeros(B, top_k, dtype=torch.int64, device=dev); od = torch.zeros(B, top_k, device=dev); oc = torch.zeros(B, dtype=torch.int32, device=dev)
+for r in range(W): allp[r, 0].copy_(keys); allp[r, 1].copy_(ids)
+torch.cuda.synchronize(); tm0 = time.perf_counter()
+for i in range(50):
+    IVFFlatIndex.merge_partials_dev(allp.data_ptr(), allp.data_ptr() + 8 * B * top_k, 2 * B * top_k, W, B, top_k, nprobe, oi.data_ptr(), od.data_ptr(), oc.data_ptr(), st)
+torch.cuda.synchronize(); t_merge = (time.perf_counter() - tm0) / 50
 ix.poll(st)
 if os.environ.get("VERS_SCAN_DEBUG"): print("last scan:", ix.last_scan())   # (prints the phase stamps with VERS_SCAN_DEBUG=16)
 pst = ix.prescan_stats()
 print(f"world={W} rank={R}: {dt*1e3:.3f} ms per step for this rank (list scan {float(np.mean(ix.scan_times()))*1e3:.0f} us; "
-      f"{pst['fallback_queries']} of {pst['batches'] * B} queries re-scanned exactly)")
+      f"{pst['fallback_queries']} of {pst['batches'] * B} queries re-scanned exactly); merge of the {W} gathered partials {t_merge*1e6:.0f} us "
+      f"(pipelined launches); all-gather payload {2 * B * top_k * 8} B per rank")
