@@ -51,10 +51,17 @@ static __global__ void row_norms_kernel(const float* C, uint32_t ld, uint32_t k,
 //                    values are a coalesced column walk for the per-point selection).
 // metric 1 (cosine distance 1 - dot, base.rs:153-155): G = -dot, which approximates D_ref - 1; the padding rows /
 // columns of the operands are zero, so padded entries come out as 0 (the selections only look at real ones).
+// NORM_ROWS = true does not write G at all: its epilogue reduces the block's 128 x 128 tile to, per point (column),
+// the smallest value, its centroid and the second smallest over the tile's 128 centroids (rows m < k_rows) and writes
+// that triple to part_*[blockIdx.y][n] -- 12 bytes per (row tile, point) instead of 512; assign_argmin_merge_kernel
+// folds the k/128 triples of a point.  (Round 1 wrote Gt -- 2.1 GB per 131072-point batch at k = 4096 -- and read it
+// back in a separate arg-min kernel.)
 template <bool NORM_ROWS>
 static __global__ __launch_bounds__(256) void dist_gemm_kernel(const float* __restrict__ Q, const float* __restrict__ C,
                                                                const float* __restrict__ cnorm, uint32_t K, uint32_t N_pad,
-                                                               float* __restrict__ G, int metric) {
+                                                               float* __restrict__ G, int metric, uint32_t k_rows = 0,
+                                                               float* __restrict__ part_v1 = nullptr, uint32_t* __restrict__ part_c1 = nullptr,
+                                                               float* __restrict__ part_v2 = nullptr) {
   __shared__ __attribute__((aligned(16))) float As[kGemmBM * kGemmLds];
   __shared__ __attribute__((aligned(16))) float Bs[kGemmBN * kGemmLds];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
@@ -114,18 +121,75 @@ static __global__ __launch_bounds__(256) void dist_gemm_kernel(const float* __re
           acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a][s >> 2][s & 3], fb[b][s >> 2][s & 3], acc[a][b], 0, 0, 0);
   }
   // epilogue: C/D layout col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+  if constexpr (!NORM_ROWS) {
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const uint32_t n = n0 + wc * 64 + b * 32 + r;
+        const float cn = metric ? 0.0f : cnorm[n];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const uint32_t m = m0 + wr * 64 + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+          G[(uint64_t)m * N_pad + n] = metric ? -acc[a][b][e] : cn - 2.0f * acc[a][b][e];
+        }
+      }
+  } else {
+    // per point: (smallest value, its centroid, second smallest) over this tile's centroids.  A tie with the candidate makes
+    // second == best, a NaN makes second NaN: neither certifies (assign_rescore_kernel) and the exact scan decides --
+    // so the order in which equal values meet does not matter here.
+    auto fold = [](float& v1, uint32_t& c1, float& v2, float w1, uint32_t d1, float w2) {
+      const bool nan = (v2 != v2) || (w2 != w2);
+      if (w1 < v1) { v2 = v1 < w2 ? v1 : w2; v1 = w1; c1 = d1; }
+      else { const float t = w1 < v2 ? w1 : v2; v2 = t; }  // includes w1 == v1: second == best
+      if (nan) v2 = __builtin_nanf("");
+    };
+    float bv1[2], bv2[2];
+    uint32_t bc1[2];
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
-      const uint32_t n = n0 + wc * 64 + b * 32 + r;
-      const float cn = (NORM_ROWS || metric) ? 0.0f : cnorm[n];
+      float v1 = __builtin_inff(), v2 = __builtin_inff();
+      uint32_t c1 = m0 + wr * 64 + 4 * hh;
+      bool nan = false;
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const uint32_t m = m0 + wr * 64 + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
-        G[(uint64_t)m * N_pad + n] = metric ? -acc[a][b][e] : (NORM_ROWS ? cnorm[m] : cn) - 2.0f * acc[a][b][e];
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const uint32_t m = m0 + wr * 64 + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+          float g = metric ? -acc[a][b][e] : cnorm[m] - 2.0f * acc[a][b][e];
+          if (m >= k_rows) g = __builtin_inff();  // padding centroids (zero rows) are not candidates
+          nan |= g != g;
+          if (g < v1) { v2 = v1; v1 = g; c1 = m; }
+          else if (g < v2 || g == v1) v2 = g;
+        }
+      if (nan) v2 = __builtin_nanf("");
+      // the other half of the rows sits in lane ^ 32
+      const float w1 = __shfl_xor(v1, 32, kWave), w2 = __shfl_xor(v2, 32, kWave);
+      const uint32_t d1 = (uint32_t)__shfl_xor((int)c1, 32, kWave);
+      fold(v1, c1, v2, w1, d1, w2);
+      bv1[b] = v1; bc1[b] = c1; bv2[b] = v2;
+    }
+    // rows 64..127 of the tile belong to the waves wr == 1: through LDS (the operand tiles are dead by now)
+    __syncthreads();
+    float* xs = As;  // [wc][b][r][3]
+    if (wr == 1 && hh == 0) {
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        float* t = xs + ((wc * 2 + b) * 32 + r) * 3;
+        t[0] = bv1[b]; t[1] = __uint_as_float(bc1[b]); t[2] = bv2[b];
       }
     }
+    __syncthreads();
+    if (wr == 0 && hh == 0) {
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const float* t = xs + ((wc * 2 + b) * 32 + r) * 3;
+        fold(bv1[b], bc1[b], bv2[b], t[0], __float_as_uint(t[1]), t[2]);
+        const uint64_t o = (uint64_t)blockIdx.y * N_pad + n0 + wc * 64 + b * 32 + r;
+        part_v1[o] = bv1[b]; part_c1[o] = bc1[b]; part_v2[o] = bv2[b];
+      }
+    }
+  }
 }
 
 // One wave per query: select the PS smallest G of its row, re-score them exactly, sort by the exact key,
@@ -307,48 +371,23 @@ static __global__ __launch_bounds__(kWave) void coarse_select_rescore_kernel(
 }
 
 // ---- k-means assign through the matrix cores (ivfflat.rs:29-46) -----------------------------------------
-// Gt[c][i] = |c|^2 - 2 <x_i, c> for a batch of points (dist_gemm_kernel<true>).  Per point: best and
-// second-best approximate value over all centroids (thread per point, coalesced column walk).
-// Block = 16 waves x 64 points: wave w walks centroids [w*k/16, (w+1)*k/16) for the block's 64 points (coalesced
-// 256-byte rows of Gt), the 16 partial (best, index, second) triples are folded in centroid order through LDS.
-// (One thread per point over all k centroids left 8192-point batches at k = 65536 with 128 waves on the chip:
-// 5.4 ms per batch next to an 8.1 ms GEMM.)
-constexpr int kArgminWaves = 16;
-static __global__ __launch_bounds__(kWave * kArgminWaves) void assign_argmin2_kernel(const float* Gt, uint32_t n_pad, uint32_t k, uint32_t nb,
-                                                                                   uint32_t* best, float* g2) {
-  __shared__ float s1[kArgminWaves][kWave], s2[kArgminWaves][kWave];
-  __shared__ uint32_t sc[kArgminWaves][kWave];
-  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
-  const uint32_t i = blockIdx.x * kWave + lane;
-  const uint32_t per = (k + kArgminWaves - 1) / kArgminWaves;
-  const uint32_t c_begin = (uint32_t)w * per < k ? (uint32_t)w * per : k, c_end = c_begin + per < k ? c_begin + per : k;
-  float v1 = __builtin_inff(), v2 = __builtin_inff();
-  uint32_t c1 = c_begin;
-  bool nan = false;
-  if (i < nb) {
-#pragma unroll 8
-    for (uint32_t c = c_begin; c < c_end; ++c) {
-      const float g = Gt[(uint64_t)c * n_pad + i];
-      nan |= g != g;
-      if (g < v1) { v2 = v1; v1 = g; c1 = c; }  // strict: the first of equal values stays the candidate
-      else if (g < v2 || g == v1) v2 = g;       // a tie with the candidate is NOT certified (v2 == v1)
-    }
-  }
-  s1[w][lane] = v1;
-  s2[w][lane] = nan ? __builtin_nanf("") : v2;
-  sc[w][lane] = c1;
-  __syncthreads();
-  if (w != 0 || i >= nb) return;
-  float a1 = s1[0][lane], a2 = s2[0][lane];
-  uint32_t ac = sc[0][lane];
+// dist_gemm_kernel<true> leaves, per (tile of 128 centroids, point), the best / second-best approximate value
+// |c|^2 - 2 <x, c> (or -<x, c>) and the best's centroid.  Thread per point: fold the k/128 triples in ascending
+// centroid order (coalesced: consecutive threads read consecutive points of one tile row).
+static __global__ void assign_argmin_merge_kernel(const float* part_v1, const uint32_t* part_c1, const float* part_v2, uint32_t n_tiles,
+                                                  uint32_t n_pad, uint32_t nb, uint32_t* best, float* g2) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= nb) return;
+  float a1 = part_v1[i], a2 = part_v2[i];
+  uint32_t ac = part_c1[i];
   bool any_nan = a2 != a2;
-  for (int ww = 1; ww < kArgminWaves; ++ww) {  // ascending centroid ranges: a later equal value never replaces the candidate
-    const float b1 = s1[ww][lane], b2 = s2[ww][lane];
+  for (uint32_t t = 1; t < n_tiles; ++t) {  // ascending centroid ranges: a later equal value never replaces the candidate
+    const float b1 = part_v1[(uint64_t)t * n_pad + i], b2 = part_v2[(uint64_t)t * n_pad + i];
     any_nan |= b2 != b2;
     if (b1 < a1) {
       a2 = a1 < b2 ? a1 : b2;
       a1 = b1;
-      ac = sc[ww][lane];
+      ac = part_c1[(uint64_t)t * n_pad + i];
     } else {
       const float m = b1 < a2 ? b1 : a2;  // includes b1 == a1: second == best, not certified
       a2 = m;

@@ -171,12 +171,16 @@ int32_t km_assign_mfma(const float* X, uint32_t ldx, uint64_t n, const float* C,
   hipLaunchKernelGGL(row_norms_kernel, dim3((k_pad + 255) / 256), dim3(256), 0, st, ws.cg.as<float>(), ldq, k, k_pad, ws.cnorm.as<float>());
   hipLaunchKernelGGL(max_norm_kernel, dim3(1), dim3(256), 0, st, ws.cnorm.as<float>(), k, cmax2_dev);
   VERS_HIP_TRY(hipGetLastError());
-  // point batch: Gt stays <= 2 GiB
-  uint64_t mb = ((1ull << 31) / ((uint64_t)k_pad * 4)) / kGemmBN * kGemmBN;
+  // point batch: the per-(centroid tile, point) triples stay <= 1 GiB (the GEMM never writes its product)
+  const uint32_t n_tiles = k_pad / kGemmBM;
+  uint64_t mb = ((1ull << 30) / ((uint64_t)n_tiles * 12)) / kGemmBN * kGemmBN;
   if (mb > 131072) mb = 131072;
   if (mb < (uint64_t)kGemmBN) mb = kGemmBN;
   if (mb > round_up64(n, kGemmBN)) mb = round_up64(n, kGemmBN);
-  if (int32_t rc = ws.gt.reserve((size_t)k_pad * mb * sizeof(float))) return rc;
+  if (int32_t rc = ws.gt.reserve((size_t)n_tiles * mb * 12)) return rc;
+  float* part_v1 = ws.gt.as<float>();
+  uint32_t* part_c1 = ws.gt.as<uint32_t>() + (size_t)n_tiles * mb;
+  float* part_v2 = ws.gt.as<float>() + 2 * (size_t)n_tiles * mb;
   if (int32_t rc = ws.best.reserve(mb * 8)) return rc;
   uint32_t* best = ws.best.as<uint32_t>();
   float* g2 = ws.best.as<float>() + mb;
@@ -191,9 +195,11 @@ int32_t km_assign_mfma(const float* X, uint32_t ldx, uint64_t n, const float* C,
       if (int32_t rc = launch_stage_queries(xb, ldx, d, ws.xp.as<float>(), ldq, nb, 1, st)) return rc;
       xb = ws.xp.as<float>();
     }
+    // (the triples are addressed with pitch mb: nb_pad <= mb)
     hipLaunchKernelGGL(dist_gemm_kernel<true>, dim3(nb_pad / kGemmBN, k_pad / kGemmBM), dim3(256), 0, st, ws.cg.as<float>(), xb,
-                       ws.cnorm.as<float>(), ldq, nb_pad, ws.gt.as<float>(), metric);
-    hipLaunchKernelGGL(assign_argmin2_kernel, dim3((nb + kWave - 1) / kWave), dim3(kWave * kArgminWaves), 0, st, ws.gt.as<float>(), nb_pad, k, nb, best, g2);
+                       ws.cnorm.as<float>(), ldq, (uint32_t)mb, (float*)nullptr, metric, k, part_v1, part_c1, part_v2);
+    hipLaunchKernelGGL(assign_argmin_merge_kernel, dim3((nb + 255) / 256), dim3(256), 0, st, (const float*)part_v1, (const uint32_t*)part_c1,
+                       (const float*)part_v2, n_tiles, (uint32_t)mb, nb, best, g2);
     hipLaunchKernelGGL(assign_rescore_kernel, dim3((nb + 63) / 64), dim3(64), 0, st, X + i0 * ldx, ldx, C, ldc, d, ldq, cmax2_dev, best, g2,
                        nb, k, (uint32_t)i0, out_assign + i0, out_mind ? out_mind + i0 : nullptr, fb_list, fb_count, ws.status.as<uint32_t>(), metric);
     VERS_HIP_TRY(hipGetLastError());
