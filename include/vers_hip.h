@@ -195,11 +195,13 @@ int32_t vers_ivf_last_scan(vers_ivf_t* h, float* out_ms, uint64_t* out_union_row
                            uint64_t* out_streamed_rows, uint32_t* out_items);
 
 /* Throughput serving loops (extension; no reference counterpart -- ivfflat.rs:155-161 ranks the lists inside the
- * search itself): stage the queries of the NEXT batch and rank its lists on a side stream of the handle while the
- * current batch's list scan runs on `stream`.  A following vers_ivf_search_dev / vers_ivf_search_partial_dev call with
- * the SAME queries_dev, ldq_floats, b and nprobe picks the prepared result up (same bits) instead of computing it;
- * the query block must not change in between.  Two batches can be prepared at a time; a no-op for nprobe == 0 and
- * for batches the coarse quantiser does not run on the matrix cores for (b < 32). */
+ * search itself): note the queries of the NEXT batch; the following search on this handle (the current batch) then
+ * stages them and ranks their lists on a side stream of the handle right behind its own list-scan launch, i.e. under its
+ * exact finish, which leaves the chip mostly idle.  A later vers_ivf_search_dev / vers_ivf_search_partial_dev call with
+ * the SAME queries_dev, ldq_floats, b and nprobe picks the prepared result up (same bits) instead of computing it; the
+ * query block must not change in between.  Two batches can be prepared at a time; a no-op for nprobe == 0, for more than
+ * 48 probes and for batches the coarse quantiser does not run on the matrix cores for (b < 32).  `stream` is ignored
+ * (kept for ABI stability): the work is ordered on the stream of the search that starts it. */
 int32_t vers_ivf_coarse_ahead_dev(vers_ivf_t* h, const float* queries_dev, uint64_t ldq_floats, uint32_t b, uint32_t nprobe, void* stream);
 
 /* ---- one process per GPU: the corpus shards BY CLUSTER ------------------------------------------
@@ -253,6 +255,11 @@ int32_t vers_ivf_build_sharded_dev(vers_ivf_t* h, const float* rows_dev, uint64_
                                    uint64_t max_iterations, const uint64_t* init_indices, const vers_comm_t* comm,
                                    uint64_t* out_assignments_local, float* out_cost, int32_t* out_kept,
                                    uint64_t* out_iterations);
+/* Process-wide tuning switches (the environment variables of DESIGN.md section 5 are read once; this sets one at run time
+ * for same-process A/B measurements).  "gemm_x3": bit 0 the k-means assign contraction, bit 1 the coarse quantiser's
+ * contraction run as three bf16 MFMA products of hi/lo-split operands (default 3) instead of the f32 MFMA kernel (0).
+ * Results are bit-identical either way: both are pre-filters behind an exact re-score and a certificate. */
+int32_t vers_set_option(const char* name, int64_t value);
 /* Device memory the library holds in this process right now (rows, ids, scratch of every handle) and its high-water
  * mark since the last reset -- lets a test assert that no rank of a sharded build ever allocated the whole corpus. */
 int32_t vers_mem_stats(uint64_t* out_bytes_now, uint64_t* out_bytes_peak, int32_t reset_peak);

@@ -72,6 +72,7 @@ SIGNATURES = {
     "vers_ivf_shadow_state": (C.c_int32, [_vp, C.POINTER(C.c_int32), C.POINTER(C.c_uint64)]),
     "vers_ivf_build_sharded_dev": (C.c_int32, [_vp, _vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64,
                                                C.c_uint64, _vp, _vp, _vp, C.POINTER(C.c_float), C.POINTER(C.c_int32), _vp]),
+    "vers_set_option": (C.c_int32, [C.c_char_p, C.c_int64]),
     "vers_mem_stats": (C.c_int32, [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_int32]),
     "vers_ivf_scan_times": (C.c_int32, [_vp, _vp, C.c_uint32, C.POINTER(C.c_uint32), C.c_int32]),
     "vers_ivf_get_list": (C.c_int32, [_vp, C.c_uint64, _vp, C.c_uint64, _vp, C.c_uint64, C.POINTER(C.c_uint64)]),
@@ -240,6 +241,10 @@ def assign_stats(reset=False):
     a, b = C.c_uint64(0), C.c_uint64(0)
     check(lib().vers_assign_stats(C.byref(a), C.byref(b), 1 if reset else 0))
     return int(a.value), int(b.value)
+
+
+def set_option(name: str, value: int):
+    check(lib().vers_set_option(name.encode(), int(value)))
 
 
 def mem_stats(reset_peak=False):

@@ -42,6 +42,87 @@ static __global__ void row_norms_kernel(const float* C, uint32_t ld, uint32_t k,
   out[n] = acc;
 }
 
+// Epilogue shared by the two contraction kernels (the C/D layout of the 32x32 MFMAs does not depend on the input type):
+// col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).  `lds` is the block's (dead) operand storage.
+template <bool NORM_ROWS>
+__device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[2][2], float* lds, const float* __restrict__ cnorm, uint32_t N_pad,
+                                              float* __restrict__ G, int metric, uint32_t k_rows, float* __restrict__ part_v1,
+                                              uint32_t* __restrict__ part_c1, float* __restrict__ part_v2, uint32_t m0, uint32_t n0, int wr,
+                                              int wc, int r, int hh) {
+  float* As = lds;
+  // epilogue: C/D layout col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
+  if constexpr (!NORM_ROWS) {
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const uint32_t n = n0 + wc * 64 + b * 32 + r;
+        const float cn = metric ? 0.0f : cnorm[n];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const uint32_t m = m0 + wr * 64 + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+          G[(uint64_t)m * N_pad + n] = metric ? -acc[a][b][e] : cn - 2.0f * acc[a][b][e];
+        }
+      }
+  } else {
+    // per point: (smallest value, its centroid, second smallest) over this tile's centroids.  A tie with the candidate makes
+    // second == best, a NaN makes second NaN: neither certifies (assign_rescore_kernel) and the exact scan decides --
+    // so the order in which equal values meet does not matter here.
+    auto fold = [](float& v1, uint32_t& c1, float& v2, float w1, uint32_t d1, float w2) {
+      const bool nan = (v2 != v2) || (w2 != w2);
+      if (w1 < v1) { v2 = v1 < w2 ? v1 : w2; v1 = w1; c1 = d1; }
+      else { const float t = w1 < v2 ? w1 : v2; v2 = t; }  // includes w1 == v1: second == best
+      if (nan) v2 = __builtin_nanf("");
+    };
+    float bv1[2], bv2[2];
+    uint32_t bc1[2];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      float v1 = __builtin_inff(), v2 = __builtin_inff();
+      uint32_t c1 = m0 + wr * 64 + 4 * hh;
+      bool nan = false;
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          const uint32_t m = m0 + wr * 64 + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+          float g = metric ? -acc[a][b][e] : cnorm[m] - 2.0f * acc[a][b][e];
+          if (m >= k_rows) g = __builtin_inff();  // padding centroids (zero rows) are not candidates
+          nan |= g != g;
+          if (g < v1) { v2 = v1; v1 = g; c1 = m; }
+          else if (g < v2 || g == v1) v2 = g;
+        }
+      if (nan) v2 = __builtin_nanf("");
+      // the other half of the rows sits in lane ^ 32
+      const float w1 = __shfl_xor(v1, 32, kWave), w2 = __shfl_xor(v2, 32, kWave);
+      const uint32_t d1 = (uint32_t)__shfl_xor((int)c1, 32, kWave);
+      fold(v1, c1, v2, w1, d1, w2);
+      bv1[b] = v1; bc1[b] = c1; bv2[b] = v2;
+    }
+    // rows 64..127 of the tile belong to the waves wr == 1: through LDS (the operand tiles are dead by now)
+    __syncthreads();
+    float* xs = As;  // [wc][b][r][3]
+    if (wr == 1 && hh == 0) {
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        float* t = xs + ((wc * 2 + b) * 32 + r) * 3;
+        t[0] = bv1[b]; t[1] = __uint_as_float(bc1[b]); t[2] = bv2[b];
+      }
+    }
+    __syncthreads();
+    if (wr == 0 && hh == 0) {
+#pragma unroll
+      for (int b = 0; b < 2; ++b) {
+        const float* t = xs + ((wc * 2 + b) * 32 + r) * 3;
+        fold(bv1[b], bc1[b], bv2[b], t[0], __float_as_uint(t[1]), t[2]);
+        const uint64_t o = (uint64_t)blockIdx.y * N_pad + n0 + wc * 64 + b * 32 + r;
+        part_v1[o] = bv1[b]; part_c1[o] = bc1[b]; part_v2[o] = bv2[b];
+      }
+    }
+  }
+}
+
+
 // G[m][n] = cnorm[n] - 2 * sum_k Q[m][k] * C[n][k].   Q [M_pad][K], C [N_pad][K] row-major, K % 32 == 0,
 // M_pad % 128 == 0, N_pad % 128 == 0.  Block = 4 waves, 128 x 128 tile; wave = 64 x 64 (2 x 2 MFMA tiles).
 // LDS tiles hold k permuted as [row][h = k & 1][s = k >> 1] so that lane (r, h) reads its 16 operands
@@ -120,76 +201,99 @@ static __global__ __launch_bounds__(256) void dist_gemm_kernel(const float* __re
         for (int b = 0; b < 2; ++b)
           acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[a][s >> 2][s & 3], fb[b][s >> 2][s & 3], acc[a][b], 0, 0, 0);
   }
-  // epilogue: C/D layout col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
-  if constexpr (!NORM_ROWS) {
+  gemm_epilogue<NORM_ROWS>(acc, As, cnorm, N_pad, G, metric, k_rows, part_v1, part_c1, part_v2, m0, n0, wr, wc, r, hh);
+}
+
+// ---- the same contraction as THREE bf16 MFMA products of hi/lo-split operands -----------------------------------------
+// x = hi + lo + r with hi = bf16(x), lo = bf16(x - hi) (both round-to-nearest; x - hi is exact), |r| <= 2^-18 |x|.
+//     <a, b> ~ <a_hi, b_hi> + <a_hi, b_lo> + <a_lo, b_hi>          (v_mfma_f32_32x32x16_bf16, f32 accumulation)
+// drops <a_lo, b_lo> and the residuals: |error| <= 3 * 2^-18 |a||b| on top of the f32 accumulation error that the f32
+// kernel has too -- 1.1e-5 |a||b| against a certificate bound E of 2.3e-4 (|a|^2 + |b|^2) at d = 768.  The consumers add
+// kX3Slack * (|q|^2 + max|c|^2) to their E (coarse_select_rescore_kernel, assign_rescore_kernel), so the product is a
+// PRE-FILTER exactly like the f32 one: results stay the reference's bits.  The matrix cores run bf16 at 16x the f32
+// rate, three products = 5.3x fewer MFMA cycles; the kernel is then bound by its operand traffic (global -> split in
+// registers -> LDS -> fragments), not by the MFMAs.
+constexpr float kX3Slack = 1.6e-5f;  // >= 2 * 3 * 2^-18 (G = norm - 2 dot doubles the dot's error), rounded up
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+constexpr int kX3Pitch = 40;  // bf16 per LDS row: 32 of a K-tile + 8 of padding (80 bytes: conflict-free ds_read_b128 by row)
+
+template <bool NORM_ROWS>
+static __global__ __launch_bounds__(256) void dist_gemm_x3_kernel(const float* __restrict__ Q, const float* __restrict__ C,
+                                                                  const float* __restrict__ cnorm, uint32_t K, uint32_t N_pad,
+                                                                  float* __restrict__ G, int metric, uint32_t k_rows = 0,
+                                                                  float* __restrict__ part_v1 = nullptr, uint32_t* __restrict__ part_c1 = nullptr,
+                                                                  float* __restrict__ part_v2 = nullptr) {
+  // [matrix A|B][part hi|lo][128 rows][kX3Pitch] bf16 = 40 KB
+  __shared__ __attribute__((aligned(16))) __bf16 T[2][2][kGemmBM * kX3Pitch];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wr = wid >> 1, wc = wid & 1;
+  const uint32_t m0 = blockIdx.y * kGemmBM, n0 = blockIdx.x * kGemmBN;
+  f32x16 acc[2][2];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < 2; ++a)
 #pragma unroll
-      for (int b = 0; b < 2; ++b) {
-        const uint32_t n = n0 + wc * 64 + b * 32 + r;
-        const float cn = metric ? 0.0f : cnorm[n];
+    for (int b = 0; b < 2; ++b)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const uint32_t m = m0 + wr * 64 + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
-          G[(uint64_t)m * N_pad + n] = metric ? -acc[a][b][e] : cn - 2.0f * acc[a][b][e];
-        }
+      for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.0f;
+  const int srow = tid >> 3, sc4 = tid & 7;  // rows srow + 32*i, float4 column sc4
+  f32x4 ra[4], rb[4];
+  auto gload = [&](uint32_t k0) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      ra[i] = *reinterpret_cast<const f32x4*>(Q + (uint64_t)(m0 + srow + 32 * i) * K + k0 + sc4 * 4);
+      rb[i] = *reinterpret_cast<const f32x4*>(C + (uint64_t)(n0 + srow + 32 * i) * K + k0 + sc4 * 4);
+    }
+  };
+  auto split_store = [&](const f32x4& x, __bf16* hi_row, __bf16* lo_row) {
+    bf16x4 h, l;
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      h[u] = (__bf16)x[u];
+      l[u] = (__bf16)(x[u] - (float)h[u]);
+    }
+    *reinterpret_cast<bf16x4*>(hi_row + sc4 * 4) = h;
+    *reinterpret_cast<bf16x4*>(lo_row + sc4 * 4) = l;
+  };
+  auto lstore = [&]() {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = srow + 32 * i;
+      split_store(ra[i], T[0][0] + row * kX3Pitch, T[0][1] + row * kX3Pitch);
+      split_store(rb[i], T[1][0] + row * kX3Pitch, T[1][1] + row * kX3Pitch);
+    }
+  };
+  const int r = lane & 31, hh = lane >> 5;
+  gload(0);
+  for (uint32_t k0 = 0; k0 < K; k0 += kGemmBK) {
+    __syncthreads();  // previous tile's readers done
+    lstore();
+    __syncthreads();
+    if (k0 + kGemmBK < K) gload(k0 + kGemmBK);  // next tile in flight under the MFMAs
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {  // two k-steps of 16
+      bf16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int ko = 16 * s2 + 8 * hh;
+        ah[t] = *reinterpret_cast<const bf16x8*>(T[0][0] + (wr * 64 + t * 32 + r) * kX3Pitch + ko);
+        al[t] = *reinterpret_cast<const bf16x8*>(T[0][1] + (wr * 64 + t * 32 + r) * kX3Pitch + ko);
+        bh[t] = *reinterpret_cast<const bf16x8*>(T[1][0] + (wc * 64 + t * 32 + r) * kX3Pitch + ko);
+        bl[t] = *reinterpret_cast<const bf16x8*>(T[1][1] + (wc * 64 + t * 32 + r) * kX3Pitch + ko);
       }
-  } else {
-    // per point: (smallest value, its centroid, second smallest) over this tile's centroids.  A tie with the candidate makes
-    // second == best, a NaN makes second NaN: neither certifies (assign_rescore_kernel) and the exact scan decides --
-    // so the order in which equal values meet does not matter here.
-    auto fold = [](float& v1, uint32_t& c1, float& v2, float w1, uint32_t d1, float w2) {
-      const bool nan = (v2 != v2) || (w2 != w2);
-      if (w1 < v1) { v2 = v1 < w2 ? v1 : w2; v1 = w1; c1 = d1; }
-      else { const float t = w1 < v2 ? w1 : v2; v2 = t; }  // includes w1 == v1: second == best
-      if (nan) v2 = __builtin_nanf("");
-    };
-    float bv1[2], bv2[2];
-    uint32_t bc1[2];
-#pragma unroll
-    for (int b = 0; b < 2; ++b) {
-      float v1 = __builtin_inff(), v2 = __builtin_inff();
-      uint32_t c1 = m0 + wr * 64 + 4 * hh;
-      bool nan = false;
 #pragma unroll
       for (int a = 0; a < 2; ++a)
 #pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          const uint32_t m = m0 + wr * 64 + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
-          float g = metric ? -acc[a][b][e] : cnorm[m] - 2.0f * acc[a][b][e];
-          if (m >= k_rows) g = __builtin_inff();  // padding centroids (zero rows) are not candidates
-          nan |= g != g;
-          if (g < v1) { v2 = v1; v1 = g; c1 = m; }
-          else if (g < v2 || g == v1) v2 = g;
+        for (int b = 0; b < 2; ++b) {
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a], bh[b], acc[a][b], 0, 0, 0);  // small terms first
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bl[b], acc[a][b], 0, 0, 0);
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bh[b], acc[a][b], 0, 0, 0);
         }
-      if (nan) v2 = __builtin_nanf("");
-      // the other half of the rows sits in lane ^ 32
-      const float w1 = __shfl_xor(v1, 32, kWave), w2 = __shfl_xor(v2, 32, kWave);
-      const uint32_t d1 = (uint32_t)__shfl_xor((int)c1, 32, kWave);
-      fold(v1, c1, v2, w1, d1, w2);
-      bv1[b] = v1; bc1[b] = c1; bv2[b] = v2;
-    }
-    // rows 64..127 of the tile belong to the waves wr == 1: through LDS (the operand tiles are dead by now)
-    __syncthreads();
-    float* xs = As;  // [wc][b][r][3]
-    if (wr == 1 && hh == 0) {
-#pragma unroll
-      for (int b = 0; b < 2; ++b) {
-        float* t = xs + ((wc * 2 + b) * 32 + r) * 3;
-        t[0] = bv1[b]; t[1] = __uint_as_float(bc1[b]); t[2] = bv2[b];
-      }
-    }
-    __syncthreads();
-    if (wr == 0 && hh == 0) {
-#pragma unroll
-      for (int b = 0; b < 2; ++b) {
-        const float* t = xs + ((wc * 2 + b) * 32 + r) * 3;
-        fold(bv1[b], bc1[b], bv2[b], t[0], __float_as_uint(t[1]), t[2]);
-        const uint64_t o = (uint64_t)blockIdx.y * N_pad + n0 + wc * 64 + b * 32 + r;
-        part_v1[o] = bv1[b]; part_c1[o] = bc1[b]; part_v2[o] = bv2[b];
-      }
     }
   }
+  __syncthreads();  // (the epilogue re-uses the operand storage)
+  gemm_epilogue<NORM_ROWS>(acc, reinterpret_cast<float*>(&T[0][0][0]), cnorm, N_pad, G, metric, k_rows, part_v1, part_c1, part_v2, m0, n0, wr, wc,
+                           r, hh);
 }
 
 // One wave per query: select the PS smallest G of its row, re-score them exactly, sort by the exact key,
@@ -332,7 +436,7 @@ static __global__ __launch_bounds__(kWave) void coarse_select_rescore_kernel(
   const uint32_t Pq = P < k ? P : k;
   const float dP = __uint_as_float(order_bits_to_f32_bits((uint32_t)(readlane64(exact, (int)Pq - 1) >> 32)));
   // metric 1: G ~ D_ref - 1 with |D_ref - (1 + G)| <= u (1 + 2 |q||c|) + 3.03 d u |q||c| < (5d + 16) u (|q|^2 + max|c|^2 + 1)
-  const float E = (5.0f * (float)d_pad + 16.0f) * 5.9604645e-08f * (qn + cmax2 + (metric ? 1.0f : 0.0f));
+  const float E = ((5.0f * (float)d_pad + 16.0f) * 5.9604645e-08f + kX3Slack) * (qn + cmax2 + (metric ? 1.0f : 0.0f));  // (+ the bf16x3 product's share)
   const bool certified = (n_sel >= k) || (dP < tau + (metric ? 1.0f : qn) - E);  // NaN anywhere -> false -> exact path decides
   if (!certified) {
     // exact fallback for this query: every centroid, ordered chain per lane
@@ -438,7 +542,7 @@ static __global__ void assign_rescore_kernel(const float* X, uint32_t ldx, const
   }
   if (metric) acc = __fsub_rn(1.0f, acc);
   const float tau = g2[i];
-  const float E = (5.0f * (float)d_pad + 16.0f) * 5.9604645e-08f * (xn + *cmax2_dev + (metric ? 1.0f : 0.0f));
+  const float E = ((5.0f * (float)d_pad + 16.0f) * 5.9604645e-08f + kX3Slack) * (xn + *cmax2_dev + (metric ? 1.0f : 0.0f));
   const float lower = tau + (metric ? 1.0f : xn) - E;  // NaN if anything overflowed
   const bool finite = tau < __builtin_inff() && E < __builtin_inff();
   const bool certified = k == 1 || (finite && acc < lower);

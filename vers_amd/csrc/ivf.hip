@@ -753,6 +753,12 @@ struct vers_ivf {
   // the failure counter is watched through a pinned word and the shadow is switched off for the handle when more
   // than 1/8 of the queries had to be re-scanned exactly.
   DevBuf rows_bf;
+  // Row-major second copy of the stored rows for the exact finish: a candidate row of the lane-transposed tile layout is
+  // 192 separate 16-byte pieces (one per 64-byte sector: 4x the useful bytes, 74 us per batch of 1024 at cfg3 whatever the
+  // shard count); row-major it is 3 KB of whole sectors.  Spent only from idle HBM: allocated when the rows take at most a
+  // quarter of the device's memory (VERS_ROWMAJOR = 0 never, 1 whenever the allocation succeeds); without it the finish
+  // gathers from the tiles as before.  Same bits either way.
+  DevBuf rows_rm;
   bool shadow_off = false;
   uint32_t* fail_watch = nullptr;       // pinned: cumulative certificate failures as of the last finished batch
   uint64_t shadow_queries = 0;          // queries sent through the shadow path since the counter was last zeroed
@@ -784,6 +790,16 @@ struct vers_ivf {
     hipEvent_t ready = nullptr, freed = nullptr;
   };
   CoarseAhead ahead[2];
+  // A look-ahead request is DEFERRED: vers_ivf_coarse_ahead_dev only notes it, and the next search on the handle starts
+  // it right behind its own list-scan launch -- the side stream then works under that search's exact finish (a chain of
+  // dependent row gathers: 9 % VALU-active, 82 % of its wave cycles waiting) instead of competing with the scan, which
+  // fills every CU and the HBM pipe (round 1 started it at once and measured no gain).
+  struct PendingAhead {
+    bool set = false;
+    const float* q_dev = nullptr;
+    uint64_t ldq_in = 0;
+    uint32_t b = 0, nprobe = 0;
+  } pending;
   uint32_t ahead_next = 0;
   hipStream_t ahead_stream = nullptr;
   hipEvent_t ahead_in = nullptr;
@@ -801,6 +817,13 @@ struct vers_ivf {
 namespace {
 
 int32_t status_to_rc(vers_ivf* h, uint32_t s, uint32_t slot);
+int32_t coarse_ahead_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint32_t b, uint32_t nprobe, hipStream_t st);
+// starts a noted look-ahead behind whatever the caller has just queued on `st` (see vers_ivf::PendingAhead)
+inline int32_t start_pending_ahead(vers_ivf* h, hipStream_t st) {
+  if (!h->pending.set) return VERS_OK;
+  h->pending.set = false;
+  return coarse_ahead_locked(h, h->pending.q_dev, h->pending.ldq_in, h->pending.b, h->pending.nprobe, st);
+}
 int32_t sync_status(vers_ivf* h, hipStream_t st) {  // the word of the _dev calls
   uint32_t s = 0;
   VERS_HIP_TRY(hipStreamSynchronize(st));
@@ -860,6 +883,25 @@ int32_t refresh_norms(vers_ivf* h, uint64_t r_begin, uint64_t r_end, hipStream_t
                          h->rows_bf.as<uint16_t>());
       VERS_HIP_TRY(hipGetLastError());
     }
+  }
+  {
+    static const int rm_mode = [] { const char* e = getenv("VERS_ROWMAJOR"); return e ? atoi(e) : -1; }();
+    if (full) {
+      size_t free_b = 0, total_b = 0;
+      (void)hipMemGetInfo(&free_b, &total_b);
+      const size_t need = (h->cap_rows ? h->cap_rows : 1) * (size_t)h->ld * sizeof(float);
+      const bool want = rm_mode == 1 || (rm_mode != 0 && need <= total_b / 4);
+      if (!want || need > h->rows_rm.cap) h->rows_rm.release();
+      if (want && h->rows_rm.p == nullptr) {  // optional memory: a failed allocation leaves the tile gather in charge
+        void* prm = nullptr;
+        if (need + (size_t(2) << 30) <= free_b && hipMalloc(&prm, need) == hipSuccess) { h->rows_rm.p = prm; h->rows_rm.cap = need; dev_mem_account((int64_t)need); }
+        else (void)hipGetLastError();
+      }
+    }
+    if (r_end > r_begin && h->rows_rm.p)
+      if (int32_t rc = launch_from_blocked(h->rows.as<float>(), h->ld, r_begin, r_end - r_begin, h->ld, h->rows_rm.as<float>() + r_begin * (size_t)h->ld,
+                                           h->ld, st))
+        return rc;
   }
   if (r_end > r_begin) {
     hipLaunchKernelGGL(blocked_row_norms_kernel, dim3((unsigned)((r_end - r_begin + 255) / 256)), dim3(256), 0, st, h->rows.as<float>(), h->ld,
@@ -1462,8 +1504,12 @@ int32_t coarse_mfma(vers_ivf* h, const float* qp, uint32_t b, uint32_t P, uint64
   if (int32_t rc = h->gbuf.reserve((size_t)M_pad * h->k_pad * sizeof(float))) return rc;
   const bool timed = st != h->ahead_stream || h->ahead_stream == nullptr;  // (the look-ahead stream is not the measured one)
   if (timed) VERS_HIP_TRY(hipEventRecord(h->evc[0], st));
-  hipLaunchKernelGGL(dist_gemm_kernel<false>, dim3(h->k_pad / kGemmBN, M_pad / kGemmBM), dim3(256), 0, st, qp, h->centroids_g.as<float>(),
-                     h->cnorm.as<float>(), h->ldq, h->k_pad, h->gbuf.as<float>(), h->metric);
+  if (gemm_x3_mask() & 2)
+    hipLaunchKernelGGL(dist_gemm_x3_kernel<false>, dim3(h->k_pad / kGemmBN, M_pad / kGemmBM), dim3(256), 0, st, qp, h->centroids_g.as<float>(),
+                       h->cnorm.as<float>(), h->ldq, h->k_pad, h->gbuf.as<float>(), h->metric);
+  else
+    hipLaunchKernelGGL(dist_gemm_kernel<false>, dim3(h->k_pad / kGemmBN, M_pad / kGemmBM), dim3(256), 0, st, qp, h->centroids_g.as<float>(),
+                       h->cnorm.as<float>(), h->ldq, h->k_pad, h->gbuf.as<float>(), h->metric);
   VERS_HIP_TRY(hipGetLastError());
   if (timed) VERS_HIP_TRY(hipEventRecord(h->evc[1], st));
   hipLaunchKernelGGL(coarse_select_rescore_kernel, dim3(b), dim3(kWave), 0, st, h->gbuf.as<float>(), h->k_pad, h->k,
@@ -1634,6 +1680,7 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
   vers_ivf::CoarseAhead* took = nullptr;
   for (auto& a : h->ahead)
     if (a.valid && !ref_mode && a.q_dev == q_dev && a.ldq_in == ldq_in && a.b == b && a.P == P) took = &a;
+  if (h->pending.set && h->pending.q_dev == q_dev && h->pending.ldq_in == ldq_in && h->pending.b == b) h->pending.set = false;  // this very batch: computed inline below
   uint32_t n_segs_c = 0;
   if (took) {  // staged queries and ranked lists of this batch were computed ahead (vers_ivf_coarse_ahead_dev)
     VERS_HIP_TRY(hipStreamWaitEvent(st, took->ready, 0));
@@ -1792,12 +1839,13 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
   if (use_pre) {
     IvfSrc<kPreQ> src; fill_src(src);
     // partial lists of the exact re-scan (fail_list [b] + its count, qflags [n_pj]: in the zeroed zone above)
-    if (int32_t rc2 = h->fb_part.reserve((size_t)n_pj * kMergeWaves * top_k * sizeof(uint64_t))) return rc2;
+    if (int32_t rc2 = h->fb_part.reserve((size_t)std::min<uint32_t>(b, 64) * P * kMergeWaves * top_k * sizeof(uint64_t))) return rc2;
     if (int32_t rc2 = launch_prescan(h, src, (uint32_t)items_bound, kp, qflags, quad_ctr, use_shadow, st)) return rc2;
+    if (int32_t rc2 = start_pending_ahead(h, st)) return rc2;  // the next batch's coarse quantiser: under this batch's exact finish
     RescoreArgs a;
     a.partials = h->partials.as<uint64_t>(); a.P = P; a.S_max = S_max; a.kp = kp; a.top_k = top_k; a.d_pad = h->ld;
     a.pj_list = pj_list; a.pj_pref = pj_pref; a.pj_nq = pj_nq; a.list_off = h->slot_off.as<uint32_t>(); a.row_ids = h->row_ids.as<uint32_t>();
-    a.rows = h->rows.as<float>(); a.ld = h->ld; a.qp = qp; a.ldq = h->ldq; a.xmax2_bits = h->pre_misc.as<uint32_t>();
+    a.rows = h->rows.as<float>(); a.rows_rm = h->rows_rm.as<float>(); a.ld = h->ld; a.qp = qp; a.ldq = h->ldq; a.xmax2_bits = h->pre_misc.as<uint32_t>();
     a.qflags = qflags; a.metric = h->metric; a.force_fail = pre_mode == 2; a.shadow = use_shadow ? 1 : 0; a.debug = scan_debug_flags(); a.fail_list = fail_list; a.stats = h->pre_misc.as<uint32_t>() + 1;
     a.status = h->st_word(); a.out_ids = out_ids; a.out_dist = out_dist; a.out_count = out_count; a.out_keys = out_keys;
     const int stage_rows = rescore_lds_bytes(h->ld, true) <= 144u * 1024u ? 1 : 0;
@@ -1805,12 +1853,9 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
     if (int32_t rc2 = scan_prepare_launch(ivf_rescore_kernel, rs_lds)) return rc2;
     hipLaunchKernelGGL(ivf_rescore_kernel, dim3(b), dim3(kWave * kRescoreWaves), rs_lds, st, a, stage_rows);
     VERS_HIP_TRY(hipGetLastError());
-    const uint32_t fb_slots = std::min<uint32_t>(b, 64);
-    hipLaunchKernelGGL(fallback_scan_kernel, dim3(P, fb_slots), dim3(kWave * kMergeWaves), 0, st, a, (const uint32_t*)h->slot_len.as<uint32_t>(),
+    const uint32_t fb_blocks = std::min<uint32_t>(b, 64);
+    hipLaunchKernelGGL(fallback_kernel, dim3(fb_blocks), dim3(kWave * kMergeWaves), 0, st, a, (const uint32_t*)h->slot_len.as<uint32_t>(),
                        (const uint32_t*)fail_list, (const uint32_t*)(fail_list + b), h->fb_part.as<uint64_t>());
-    VERS_HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(fallback_merge_kernel, dim3(fb_slots), dim3(kWave * kMergeWaves), 0, st, a, (const uint32_t*)fail_list,
-                       (const uint32_t*)(fail_list + b), (const uint64_t*)h->fb_part.as<uint64_t>());
     VERS_HIP_TRY(hipGetLastError());
     if (use_shadow) {  // feed the watch word (see vers_ivf::rows_bf)
       if (!h->fail_watch) {
@@ -1840,6 +1885,8 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
       rc = launch_ivf_scan(h, src, (uint32_t)items_bound, st, lower);
     }
     if (rc) return rc;
+    if (pass == 0)
+      if (int32_t rc2 = start_pending_ahead(h, st)) return rc2;
     hipLaunchKernelGGL(ivf_merge_kernel, dim3(b), dim3(kWave * kMergeWaves), 0, st, h->partials.as<uint64_t>(), P, S_max, k_keep,
                        ref_mode, np, pj_list, pj_pref, pj_take, h->slot_off.as<uint32_t>(), h->row_ids.as<uint32_t>(), top_k,
                        pass * (uint32_t)kMaxTopK, out_ids, out_dist, out_count, out_keys,
@@ -2183,6 +2230,12 @@ int32_t vers_ivf_build_sharded_dev(vers_ivf_t* h, const float* rows_dev, uint64_
                       out_assignments_local, out_cost, out_kept, out_iterations);
 }
 
+int32_t vers_set_option(const char* name, int64_t value) {
+  if (!name) return fail(VERS_ERR_INVALID, "vers_set_option: null name");
+  if (std::strcmp(name, "gemm_x3") == 0) { set_gemm_x3_mask((int)value); return VERS_OK; }
+  return fail(VERS_ERR_INVALID, std::string("vers_set_option: unknown option ") + name);
+}
+
 int32_t vers_mem_stats(uint64_t* out_bytes_now, uint64_t* out_bytes_peak, int32_t reset_peak) {
   dev_mem_stats(out_bytes_now, out_bytes_peak, reset_peak != 0);
   return VERS_OK;
@@ -2307,8 +2360,10 @@ int32_t vers_ivf_coarse_ahead_dev(vers_ivf_t* h, const float* queries_dev, uint6
   if (!h) return fail(VERS_ERR_INVALID, "null handle");
   if (b && (!queries_dev || ldq_floats < h->d)) return fail(VERS_ERR_INVALID, "vers_ivf_coarse_ahead_dev: bad arguments");
   std::lock_guard<std::mutex> lk(h->mu);
-  DeviceGuard g(h->device);
-  return coarse_ahead_locked(h, queries_dev, ldq_floats, b, nprobe, (hipStream_t)stream);
+  (void)stream;  // (the look-ahead is ordered behind the list scan of the NEXT search on this handle, on that search's stream)
+  h->pending.set = b != 0 && nprobe != 0;
+  h->pending.q_dev = queries_dev; h->pending.ldq_in = ldq_floats; h->pending.b = b; h->pending.nprobe = nprobe;
+  return VERS_OK;
 }
 
 int32_t vers_topk_merge_dev(const uint64_t* keys_dev, const uint64_t* ids_dev, uint64_t rank_stride, uint32_t world, uint32_t b,

@@ -142,6 +142,18 @@ int32_t km_assign(const float* X, uint32_t ldx, uint64_t n, const float* C, uint
 // ---- assign through the matrix cores ------------------------------------------------------
 static std::atomic<uint64_t> g_mfma_points{0}, g_mfma_fallbacks{0};
 
+static std::atomic<int> g_x3_mask{-1};
+int gemm_x3_mask() {
+  int m = g_x3_mask.load();
+  if (m < 0) {  // default: both contractions as bf16x3 (build 3.3 -> 2.1 s, coarse GEMM 62 -> ~25 us, same bits)
+    const char* e = getenv("VERS_GEMM_X3");
+    m = e ? atoi(e) : 3;
+    g_x3_mask = m;
+  }
+  return m;
+}
+void set_gemm_x3_mask(int m) { g_x3_mask = m & 3; }
+
 bool km_use_mfma(uint64_t n, uint32_t k, uint32_t d) {
   static const int mode = [] {
     const char* e = getenv("VERS_ASSIGN");
@@ -196,8 +208,12 @@ int32_t km_assign_mfma(const float* X, uint32_t ldx, uint64_t n, const float* C,
       xb = ws.xp.as<float>();
     }
     // (the triples are addressed with pitch mb: nb_pad <= mb)
-    hipLaunchKernelGGL(dist_gemm_kernel<true>, dim3(nb_pad / kGemmBN, k_pad / kGemmBM), dim3(256), 0, st, ws.cg.as<float>(), xb,
-                       ws.cnorm.as<float>(), ldq, (uint32_t)mb, (float*)nullptr, metric, k, part_v1, part_c1, part_v2);
+    if (gemm_x3_mask() & 1)
+      hipLaunchKernelGGL(dist_gemm_x3_kernel<true>, dim3(nb_pad / kGemmBN, k_pad / kGemmBM), dim3(256), 0, st, ws.cg.as<float>(), xb,
+                         ws.cnorm.as<float>(), ldq, (uint32_t)mb, (float*)nullptr, metric, k, part_v1, part_c1, part_v2);
+    else
+      hipLaunchKernelGGL(dist_gemm_kernel<true>, dim3(nb_pad / kGemmBN, k_pad / kGemmBM), dim3(256), 0, st, ws.cg.as<float>(), xb,
+                         ws.cnorm.as<float>(), ldq, (uint32_t)mb, (float*)nullptr, metric, k, part_v1, part_c1, part_v2);
     hipLaunchKernelGGL(assign_argmin_merge_kernel, dim3((nb + 255) / 256), dim3(256), 0, st, (const float*)part_v1, (const uint32_t*)part_c1,
                        (const float*)part_v2, n_tiles, (uint32_t)mb, nb, best, g2);
     hipLaunchKernelGGL(assign_rescore_kernel, dim3((nb + 63) / 64), dim3(64), 0, st, X + i0 * ldx, ldx, C, ldc, d, ldq, cmax2_dev, best, g2,

@@ -17,7 +17,7 @@
 //       hence val_t <= D_t - |q|^2 + E <= tau_k + 2E; every row outside the kp list has val >= val[kp-1].  So if
 //       val[kp-1] > tau_k + 2E (or the list is not full) the true top-k is inside the list -- more precisely among
 //       its entries with val <= tau_k + 2E, the survivors -- and the output equals the exact scan bit for bit.
-//   (3) fallback_scan_kernel + fallback_merge_kernel: queries that fail the certificate (ties / near-ties denser
+//   (3) fallback_kernel: queries that fail the certificate (ties / near-ties denser
 //       than the slack, non-finite values) are queued and re-scanned exactly.  Rare, and never wrong.
 //
 // E: |val + |q|^2 - D_ref| <= (5 d + 32) u (|q|^2 + max|x|^2), u = 2^-24, d = padded length -- the bound derived
@@ -547,6 +547,7 @@ struct RescoreArgs {
   const uint32_t* list_off;
   const uint32_t* row_ids;
   const float* rows;
+  const float* rows_rm;  // nullable: the same rows row-major [cap_rows][ld] (whole-sector gathers for the exact finish)
   uint32_t ld;
   const float* qp;  // padded queries [b][ldq]
   uint32_t ldq;
@@ -720,7 +721,8 @@ __global__ __launch_bounds__(kWave * kRescoreWaves) void ivf_rescore_kernel(Resc
         const uint32_t c = idx / n4, j = idx - c * n4;
         const uint32_t row = srow[c0 + c];
         *reinterpret_cast<f32x4*>(xs + (size_t)c * pitch + 4 * j) =
-            (reinterpret_cast<const f32x4*>(a.rows + (uint64_t)(row >> 6) * 64ull * a.ld) + (row & 63))[(uint64_t)j * 64];
+            a.rows_rm ? reinterpret_cast<const f32x4*>(a.rows_rm + (uint64_t)row * a.ld)[j]  // consecutive threads: consecutive 16 bytes of a row
+                      : (reinterpret_cast<const f32x4*>(a.rows + (uint64_t)(row >> 6) * 64ull * a.ld) + (row & 63))[(uint64_t)j * 64];
       }
       __syncthreads();
       if (wid == 0 && (uint32_t)lane >= c0 && (uint32_t)lane < c0 + nc) {
@@ -747,11 +749,13 @@ __global__ __launch_bounds__(kWave * kRescoreWaves) void ivf_rescore_kernel(Resc
     }
   } else if (wid == 0 && (uint32_t)lane < n_surv) {
     const uint32_t row = srow[lane];
-    const f32x4* xp = reinterpret_cast<const f32x4*>(a.rows + (uint64_t)(row >> 6) * 64ull * a.ld) + (row & 63);
+    const f32x4* xp = a.rows_rm ? reinterpret_cast<const f32x4*>(a.rows_rm + (uint64_t)row * a.ld)
+                                : reinterpret_cast<const f32x4*>(a.rows + (uint64_t)(row >> 6) * 64ull * a.ld) + (row & 63);
+    const uint64_t xstep = a.rows_rm ? 1 : 64;
     float acc = 0.0f;
 #pragma unroll 8
     for (uint32_t j = 0; j < a.ld / 4; ++j) {
-      const f32x4 x4 = xp[(uint64_t)j * 64];
+      const f32x4 x4 = xp[(uint64_t)j * xstep];
       const f32x4 q4 = q4p[j];
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
@@ -774,10 +778,7 @@ __global__ __launch_bounds__(kWave * kRescoreWaves) void ivf_rescore_kernel(Resc
   emit_topk(fin, q, a.top_k, lane, pl, pp, a.P, a.list_off, a.row_ids, a.out_ids, a.out_dist, a.out_count, a.out_keys);
 }
 
-// Exact re-scan of the probed lists of the queries that failed the certificate.  ivf_rescore_kernel queued them;
-// block (j, slot) scans probe j of every slot-th queued query with the ordered chain -- 16 waves, each the ring-
-// pipelined single-query item of scan.cuh over its share of the list's tiles -- and leaves 16 partial top-k lists;
-// fallback_merge_kernel folds a query's P x 16 lists and emits.  Both exit at once when nothing is queued.
+// Exact re-scan of the probed lists of the queries that failed the certificate.  ivf_rescore_kernel queued them.
 struct FbSrc {
   static constexpr bool kSeqIds = false;
   static constexpr bool kStreamOnce = true;
@@ -789,58 +790,59 @@ struct FbSrc {
   __device__ __forceinline__ uint32_t bound_slot(uint32_t, int) const { return 0; }
 };
 
-__global__ __launch_bounds__(kWave * kMergeWaves) void fallback_scan_kernel(RescoreArgs a, const uint32_t* list_len, const uint32_t* fail_list,
-                                                                            const uint32_t* fail_count, uint64_t* fb_part) {
+// ONE launch: block i takes every gridDim.x-th queued query, scans its P probed lists one after the other (16 waves, each
+// the ring-pipelined single-query item of scan.cuh over its share of the list's tiles), folds the P x 16 partial lists and
+// emits.  Exits at once when nothing is queued -- the normal case: 64 blocks, ~3 us.  (Round 1 used a P x 64 grid of
+// 1024-thread blocks plus a merge launch: 11.5 us per batch with nothing to do, and 2048 fat blocks in the way of
+// whatever else wants the CUs.)  A queued query costs one CU a pass over its lists (~1-2 ms at cfg3): rare by design.
+__global__ __launch_bounds__(kWave * kMergeWaves) void fallback_kernel(RescoreArgs a, const uint32_t* list_len, const uint32_t* fail_list,
+                                                                       const uint32_t* fail_count, uint64_t* fb_part) {
+  __shared__ uint64_t sh[kMergeWaves][kWave];
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const uint32_t n_fail = *fail_count;
-  const uint32_t j = blockIdx.x;
   ScanParams p;
   p.ld = a.ld; p.n_chunks = a.ld / kChunk; p.k = a.top_k; p.status = a.status; p.bounds = nullptr; p.lower = nullptr; p.debug = 0;
   p.next_quad = nullptr; p.stamps = nullptr;
   bool nan_seen = false;
-  for (uint32_t i = blockIdx.y; i < n_fail; i += gridDim.y) {
-    const uint32_t q = fail_list[i];
-    uint64_t* out = fb_part + (((uint64_t)q * a.P + j) * kMergeWaves + wid) * a.top_k;
-    const uint32_t Lj = a.pj_list[(uint64_t)q * a.P + j];
-    uint32_t len = 0, t0 = 0, t1 = 0;
-    if (Lj != 0xFFFFFFFFu) {
-      len = list_len[Lj];
-      const uint32_t n_tiles = (len + kWave - 1) / kWave, per = (n_tiles + kMergeWaves - 1) / kMergeWaves;
-      t0 = (uint32_t)wid * per < n_tiles ? (uint32_t)wid * per : n_tiles;
-      t1 = t0 + per < n_tiles ? t0 + per : n_tiles;
-    }
-    if (t1 <= t0) {  // nothing for this wave: an empty slot
-      if (lane < (int)a.top_k) out[lane] = kKeyMax;
-      continue;
-    }
-    ItemView<1> v;
-    v.rows = a.rows + ((uint64_t)a.list_off[Lj] + (uint64_t)t0 * kWave) * a.ld;
-    v.nrows = (t1 * kWave < len ? t1 * kWave : len) - t0 * kWave;
-    v.nq = 1;
-    v.qb = a.qp + (uint64_t)q * a.ldq;
-    FbSrc src;
-    src.out_ptr = out;
-    src.seq0 = a.pj_pref[(uint64_t)q * a.P + j] + t0 * kWave;
-    if (a.metric == 0) scan_item<1, 1, 0>(src, p, 0u, v, lane, nan_seen);
-    else scan_item<1, 1, 1>(src, p, 0u, v, lane, nan_seen);
-  }
-  if (__ballot(nan_seen) != 0 && lane == 0) atomicOr(a.status, 1u);
-}
-
-__global__ __launch_bounds__(kWave * kMergeWaves) void fallback_merge_kernel(RescoreArgs a, const uint32_t* fail_list, const uint32_t* fail_count,
-                                                                             const uint64_t* fb_part) {
-  __shared__ uint64_t sh[kMergeWaves][kWave];
-  const uint32_t n_fail = *fail_count;
-  const int lane = threadIdx.x & 63;
+  uint64_t* mine = fb_part + (uint64_t)blockIdx.x * a.P * kMergeWaves * a.top_k;  // this block's P x 16 partial lists
   for (uint32_t i = blockIdx.x; i < n_fail; i += gridDim.x) {
     const uint32_t q = fail_list[i];
+    for (uint32_t j = 0; j < a.P; ++j) {
+      uint64_t* out = mine + ((uint64_t)j * kMergeWaves + wid) * a.top_k;
+      const uint32_t Lj = a.pj_list[(uint64_t)q * a.P + j];
+      uint32_t len = 0, t0 = 0, t1 = 0;
+      if (Lj != 0xFFFFFFFFu) {
+        len = list_len[Lj];
+        const uint32_t n_tiles = (len + kWave - 1) / kWave, per = (n_tiles + kMergeWaves - 1) / kMergeWaves;
+        t0 = (uint32_t)wid * per < n_tiles ? (uint32_t)wid * per : n_tiles;
+        t1 = t0 + per < n_tiles ? t0 + per : n_tiles;
+      }
+      if (t1 <= t0) {  // nothing for this wave: an empty slot
+        if (lane < (int)a.top_k) out[lane] = kKeyMax;
+        continue;
+      }
+      ItemView<1> v;
+      v.rows = a.rows + ((uint64_t)a.list_off[Lj] + (uint64_t)t0 * kWave) * a.ld;
+      v.nrows = (t1 * kWave < len ? t1 * kWave : len) - t0 * kWave;
+      v.nq = 1;
+      v.qb = a.qp + (uint64_t)q * a.ldq;
+      FbSrc src;
+      src.out_ptr = out;
+      src.seq0 = a.pj_pref[(uint64_t)q * a.P + j] + t0 * kWave;
+      if (a.metric == 0) scan_item<1, 1, 0>(src, p, 0u, v, lane, nan_seen);
+      else scan_item<1, 1, 1>(src, p, 0u, v, lane, nan_seen);
+    }
+    __threadfence_block();
+    __syncthreads();  // every wave's partial lists are written
     const uint32_t n_keys = a.P * kMergeWaves * a.top_k;
-    const uint64_t list = block_merge_keys(fb_part + (uint64_t)q * n_keys, n_keys, a.top_k, sh);
+    const uint64_t list = block_merge_keys(mine, n_keys, a.top_k, sh);
     if (threadIdx.x < kWave)
       emit_topk(list, q, a.top_k, lane, a.pj_list + (uint64_t)q * a.P, a.pj_pref + (uint64_t)q * a.P, a.P, a.list_off, a.row_ids, a.out_ids,
                 a.out_dist, a.out_count, a.out_keys);
+    __syncthreads();  // the slots are reused by the block's next query
   }
+  if (__ballot(nan_seen) != 0 && lane == 0) atomicOr(a.status, 1u);
 }
 
 }  // namespace vers
