@@ -15,6 +15,7 @@ pytestmark = pytest.mark.gpu
 
 N, D, K = 5003, 96, 70            # n is not a multiple of anything: ragged ranges, ragged tiles
 ATTEMPTS, ITERS = 2, 5
+SHAPES = {"small": (5003, 96, 70, 2, 5), "cfg5_replica": (200_000, 64, 256, 1, 3)}   # cfg5 down-scaled (N=200k, k=256)
 
 
 def ranges(world):
@@ -23,7 +24,9 @@ def ranges(world):
     return cuts
 
 
-def worker(rank, world, port, force_mfma, ret):
+def worker(rank, world, port, force_mfma, ret, shape="small"):
+    global N, D, K, ATTEMPTS, ITERS
+    N, D, K, ATTEMPTS, ITERS = SHAPES[shape]
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     if force_mfma:
         os.environ["VERS_ASSIGN"] = "2"
@@ -78,15 +81,17 @@ def free_port():
         return s.getsockname()[1]
 
 
-@pytest.mark.parametrize("world,force_mfma", [(2, False), (3, True)])
-def test_row_sharded_build_is_bit_exact(world, force_mfma):
+@pytest.mark.parametrize("world,force_mfma,shape", [(2, False, "small"), (3, True, "small"), (2, True, "cfg5_replica")])
+def test_row_sharded_build_is_bit_exact(world, force_mfma, shape):
     from oracle import c_oracle as co
     from tests import datagen as dg
     from tests.golden import make_golden as mg
     from vers_amd import capi
+    global N, D, K, ATTEMPTS, ITERS
+    N, D, K, ATTEMPTS, ITERS = SHAPES[shape]
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(worker, args=(world, free_port(), force_mfma, ret), nprocs=world, join=True)
+    mp.spawn(worker, args=(world, free_port(), force_mfma, ret, shape), nprocs=world, join=True)
     X = dg.dist_c(0xD1, N, D, 210, dg.default_sigma(D))
     o = co.build_index(X, K, ATTEMPTS, ITERS, mg.init_draws(0xD1, ATTEMPTS, K, N))
     o_lens = np.array([len(l) for l in o["ids"]], dtype=np.uint64)
@@ -107,11 +112,11 @@ def test_row_sharded_build_is_bit_exact(world, force_mfma):
         assert set(g["lists"]) == {c for c in range(K) if owner[c] == r}
         # no rank ever held the corpus: its share of the rows (k-means input is the caller's) + exchange + storage
         share = (cuts[r + 1] - cuts[r]) * D * 4
-        assert g["peak"] < 6 * share + (8 << 20), (r, g["peak"], share)
+        assert g["peak"] < 6 * share + (64 << 20), (r, g["peak"], share)
         # the chain: per k-means pass one recv + one send of k*ld*4 bytes except at the ends
         assert g["calls"]["all_to_all_v"] == 2
         for nprobe, (gi, gd, gc) in g["res"].items():
-            for q in range(40):
+            for q in range(0, 40, 1 if shape == "small" else 8):
                 oi, od = (co.search_approximate(X, o["centroids"], o["ids"], Q[q], 10) if nprobe == 0 else
                           co.search_nprobe(X, o["centroids"], o["ids"], Q[q], 10, nprobe))
                 assert gc[q] == len(oi) and np.array_equal(gi[q, :len(oi)], oi) and np.array_equal(gd[q, :len(oi)], od.view(np.uint32)), (r, nprobe, q)

@@ -755,9 +755,10 @@ struct vers_ivf {
   DevBuf rows_bf;
   // Row-major second copy of the stored rows for the exact finish: a candidate row of the lane-transposed tile layout is
   // 192 separate 16-byte pieces (one per 64-byte sector: 4x the useful bytes, 74 us per batch of 1024 at cfg3 whatever the
-  // shard count); row-major it is 3 KB of whole sectors.  Spent only from idle HBM: allocated when the rows take at most a
-  // quarter of the device's memory (VERS_ROWMAJOR = 0 never, 1 whenever the allocation succeeds); without it the finish
-  // gathers from the tiles as before.  Same bits either way.
+  // shard count); row-major it is 3 KB of whole sectors.  OPT-IN (VERS_ROWMAJOR=1; -1 = whenever the rows take at most a
+  // quarter of the device's memory): measured at cfg3, same box -- exact finish 74 -> 53 us, but the list scan 10 us
+  // slower with twice the rows mapped, net -8 us per step at 8 ranks and nothing on one GPU: not worth doubling the
+  // corpus memory by default.  Same bits either way.
   DevBuf rows_rm;
   bool shadow_off = false;
   uint32_t* fail_watch = nullptr;       // pinned: cumulative certificate failures as of the last finished batch
@@ -885,12 +886,12 @@ int32_t refresh_norms(vers_ivf* h, uint64_t r_begin, uint64_t r_end, hipStream_t
     }
   }
   {
-    static const int rm_mode = [] { const char* e = getenv("VERS_ROWMAJOR"); return e ? atoi(e) : -1; }();
+    static const int rm_mode = [] { const char* e = getenv("VERS_ROWMAJOR"); return e ? atoi(e) : 0; }();  // opt-in: see vers_ivf::rows_rm
     if (full) {
       size_t free_b = 0, total_b = 0;
       (void)hipMemGetInfo(&free_b, &total_b);
       const size_t need = (h->cap_rows ? h->cap_rows : 1) * (size_t)h->ld * sizeof(float);
-      const bool want = rm_mode == 1 || (rm_mode != 0 && need <= total_b / 4);
+      const bool want = rm_mode == 1 || (rm_mode < 0 && need <= total_b / 4);
       if (!want || need > h->rows_rm.cap) h->rows_rm.release();
       if (want && h->rows_rm.p == nullptr) {  // optional memory: a failed allocation leaves the tile gather in charge
         void* prm = nullptr;
