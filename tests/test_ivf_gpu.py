@@ -173,7 +173,8 @@ def test_coarse_ahead_is_bit_identical():
 
 def test_concurrent_searches_from_threads():
     """`search_approximate(&self)` is a shared borrow in the reference (ivfflat.rs:153): many threads may search one
-    index at once.  The handle serialises them internally; every thread must get the serial answers, bit for bit."""
+    index at once.  Every call leases its own workspace (scratch, status words, staging stream), so the threads enqueue
+    side by side; every thread must get the serial answers, bit for bit."""
     import threading
     n, d, k = 12000, 64, 32
     X = dg.dist_c(0x61, n, d, 4 * k, dg.default_sigma(d))
@@ -203,3 +204,33 @@ def test_concurrent_searches_from_threads():
     for th in threads:
         th.join()
     assert not errors, errors[:3]
+
+    # device-pointer calls from four threads, each on its OWN stream, all in flight together; one poll per stream
+    import torch
+    Qd = torch.from_numpy(Q).cuda()
+    torch.cuda.synchronize()
+    outs = {}
+
+    def dev_worker(t):
+        try:
+            st = torch.cuda.Stream()
+            ids = torch.zeros(6, 96, 10, dtype=torch.int64, device="cuda"); dist = torch.zeros(6, 96, 10, device="cuda")
+            cnt = torch.zeros(6, 96, dtype=torch.int32, device="cuda")
+            for rep in range(6):   # back to back, no synchronisation in between
+                ix.search_dev(Qd.data_ptr(), d, 96, 10, 6, ids[rep].data_ptr(), dist[rep].data_ptr(), cnt[rep].data_ptr(), st.cuda_stream)
+            ix.poll(st.cuda_stream)
+            outs[t] = (ids.cpu().numpy().astype(np.uint64), dist.cpu().numpy(), cnt.cpu().numpy())
+        except Exception as e:  # noqa: BLE001
+            errors.append((t, repr(e)))
+
+    threads = [threading.Thread(target=dev_worker, args=(t,)) for t in range(4)]
+    for th in threads:
+        th.start()
+    for th in threads:
+        th.join()
+    assert not errors, errors[:3]
+    for t in range(4):
+        gi, gd, gc = outs[t]
+        for rep in range(6):
+            assert np.array_equal(gc[rep], want_batch[2]), (t, rep)
+            assert np.array_equal(gi[rep], want_batch[0]) and np.array_equal(gd[rep].view(np.uint32), want_batch[1].view(np.uint32)), (t, rep)

@@ -17,7 +17,11 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <atomic>
+#include <condition_variable>
+#include <memory>
 #include <mutex>
+#include <shared_mutex>
 #include <vector>
 
 #include "gemm.cuh"
@@ -702,68 +706,19 @@ __global__ void u32_to_u64_kernel(const uint32_t* in, uint64_t n, uint64_t* out)
 using namespace vers;
 
 // =================================================================================================
-struct vers_ivf {
-  int device = 0, n_cu = 256;
-  uint32_t d = 0;
-  int metric = 0;    // VERS_METRIC_L2SQ (the reference) or VERS_METRIC_COSDIST in every distance of build / add / search
-  uint32_t ldx = 0;  // pitch of row-major matrices (X, centroids): round_up(d, 4)
-  uint32_t ld = 0;   // columns of blocked matrices and padded queries: round_up(d, kColAlign)
-  uint32_t ldq = 0;  // == ld
-  // index state (device cache of the reference's five fields, ivfflat.rs:9-15)
-  uint32_t k = 0;         // num_centroids; 0 = no index / nothing kept
-  uint64_t n_total = 0;   // assignments.len(): next vec_id handed out by add
-  DevBuf centroids;    // [k][ldx] row-major (k-means, read-back)
-  DevBuf centroids_b;  // the same in lane-transposed tiles (exact coarse quantiser)
-  // MFMA pre-selection of the batched coarse quantiser (gemm.cuh)
-  DevBuf centroids_g;  // row-major [k_pad][ldq], zero padded
-  DevBuf cnorm;        // |c|^2 [k_pad], +inf in the padding
-  DevBuf gbuf;         // G [M_pad][k_pad]
-  DevBuf coarse_stat;  // u32: queries that failed the certificate and were re-done exactly
-  float cmax2 = 0.0f;
-  bool ref_deep = false;  // reference-mode retry: rank 64 lists with the exact coarse quantiser (no slack needed)
+// Everything a search call MUTATES lives in a workspace, not in the handle: scratch buffers, status words, the timing
+// ring, the host-pointer staging, the look-ahead slots.  Search_approximate(&self) is legal from many threads in the
+// reference (plain Vecs behind a shared borrow); here every call leases a workspace from the handle's pool
+// (a lease = a pop under a short mutex), so concurrent callers enqueue side by side on their own streams instead of
+// queueing behind one per-handle mutex as in round 1.  A workspace that changes streams is ordered by its `done` event.
+struct SearchWs {
+  DevBuf gbuf;         // G [M_pad][k_pad] of the batched coarse quantiser
+  bool ref_deep = false;     // reference-mode retry: rank 64 lists with the exact coarse quantiser (no slack needed)
   bool ref_all = false;      // last resort of a reference-mode host call: every list is ranked (the spill may walk through all of them)
   bool ref_shallow = false;  // host-pointer calls try 16 ranked lists first (a spill past the nearest few lists is rare)
-  uint32_t k_pad = 0;
-  uint64_t mfma_batches = 0;
-  DevBuf rows, row_ids, list_off, list_len;
-  // SLOT space: the per-batch planning tables, the work items and the scan kernels address a list by its SLOT =
-  // rank among the lists by descending length (ties by index).  plan_query translates a centroid index into a slot
-  // once (list_slot); every table the later stages read is then contiguous in work order: the group step's prefix
-  // sums run longest list first -- the dynamic hand-out ends on short quads instead of starting a 5x longer list on
-  // the last free CU (8-way sharded list scan 744 -> 670 us, same box) -- without a single gather.
-  DevBuf list_slot;        // [k] centroid index -> slot
-  DevBuf slot_off, slot_len;  // list_off / list_len in slot order
-  std::vector<uint32_t> h_slot;
   DevBuf grid_ctr;         // arrival counter of plan_fused_kernel's grid barriers (monotonic, never reset)
   uint32_t plan_launches = 0;
-  std::vector<uint32_t> h_off, h_len, h_cap;  // h_len = GLOBAL list lengths; h_off/h_cap only meaningful for owned lists
-  // sharding by cluster across GPUs (one process per GPU): this handle stores only lists with owner == rank
-  uint32_t rank = 0, world = 1;
-  std::vector<uint8_t> h_owner;
-  DevBuf owner;
-  uint64_t cap_rows = 0;
-  uint32_t max_len = 0;
-  // scratch
-  KMeansScratch km;
-  DevBuf seg_bounds, stamps, quad_counter;
-  // matrix-core list scan (prescan.cuh): |x|^2 per storage row, [0] max |x|^2 bits, [1] certificate failures (running)
-  DevBuf xnorm, pre_misc, fb_part;
-  // bf16 shadow of the rows for the matrix-core pre-selection (+50 % corpus memory; VERS_SHADOW=0 or a failed
-  // allocation: the f32 rows feed it).  The wider certificate window makes it sensitive to data with many near-ties:
-  // the failure counter is watched through a pinned word and the shadow is switched off for the handle when more
-  // than 1/8 of the queries had to be re-scanned exactly.
-  DevBuf rows_bf;
-  // Row-major second copy of the stored rows for the exact finish: a candidate row of the lane-transposed tile layout is
-  // 192 separate 16-byte pieces (one per 64-byte sector: 4x the useful bytes, 74 us per batch of 1024 at cfg3 whatever the
-  // shard count); row-major it is 3 KB of whole sectors.  OPT-IN (VERS_ROWMAJOR=1; -1 = whenever the rows take at most a
-  // quarter of the device's memory): measured at cfg3, same box -- exact finish 74 -> 53 us, but the list scan 10 us
-  // slower with twice the rows mapped, net -8 us per step at 8 ranks and nothing on one GPU: not worth doubling the
-  // corpus memory by default.  Same bits either way.
-  DevBuf rows_rm;
-  bool shadow_off = false;
-  uint32_t* fail_watch = nullptr;       // pinned: cumulative certificate failures as of the last finished batch
-  uint64_t shadow_queries = 0;          // queries sent through the shadow path since the counter was last zeroed
-  uint64_t pre_batches = 0;
+  DevBuf seg_bounds, stamps, quad_counter, fb_part;
   DevBuf clower, lower;  // lower bounds of multi-pass results (coarse ranking of more than 64 lists; top_k > 64)
   DevBuf qp, qil, cpart, probe, pj, lists, pairs, items, groups, qblocks, partials, status, o_ids, o_dist, o_cnt, xpart;
   static constexpr uint32_t kEvRing = 64;  // scan-launch timing ring (measurement hook)
@@ -779,9 +734,9 @@ struct vers_ivf {
   size_t io_pin_cap = 0;
   hipStream_t io_stream = nullptr;
   // Coarse quantiser one batch ahead (vers_ivf_coarse_ahead_dev): staged queries + ranked lists of the NEXT batch are
-  // computed on a side stream while the current batch's list scan runs; two slots alternate (one is read by the search
-  // in flight while the other is written).  ready: recorded on the side stream after the slot's kernels; freed: recorded
-  // on the consuming search's stream after its last kernel.
+  // computed on a side stream; two slots alternate (one is read by the search in flight while the other is written).
+  // ready: recorded on the side stream after the slot's kernels; freed: recorded on the consuming search's stream after
+  // its last kernel.  (Per workspace: a single-threaded serving loop always leases the same one.)
   struct CoarseAhead {
     DevBuf qp, probe;
     const float* q_dev = nullptr;
@@ -791,6 +746,78 @@ struct vers_ivf {
     hipEvent_t ready = nullptr, freed = nullptr;
   };
   CoarseAhead ahead[2];
+  uint32_t ahead_next = 0;
+  hipStream_t ahead_stream = nullptr;
+  hipEvent_t ahead_in = nullptr;
+  // status words: [0] latched by _dev calls and reported by vers_ivf_poll; [1] used by host-pointer calls and add, which
+  // synchronise and consume it themselves -- so neither side eats the other's bits
+  uint32_t st_slot = 0;
+  uint32_t* st_word() const { return status.as<uint32_t>() + st_slot; }
+  GroupTotals last_tot{};
+  const GroupTotals* tot_dev = nullptr;  // device totals of the last planned search
+  bool tot_valid = false;
+  // lease bookkeeping
+  hipEvent_t done = nullptr;         // recorded on the leasing call's stream when the call has queued its last operation
+  hipStream_t last_stream = nullptr;
+  bool used = false;
+};
+static thread_local SearchWs* W = nullptr;  // the workspace leased by the call running on this thread
+
+struct vers_ivf {
+  int device = 0, n_cu = 256;
+  uint32_t d = 0;
+  int metric = 0;    // VERS_METRIC_L2SQ (the reference) or VERS_METRIC_COSDIST in every distance of build / add / search
+  uint32_t ldx = 0;  // pitch of row-major matrices (X, centroids): round_up(d, 4)
+  uint32_t ld = 0;   // columns of blocked matrices and padded queries: round_up(d, kColAlign)
+  uint32_t ldq = 0;  // == ld
+  // index state (device cache of the reference's five fields, ivfflat.rs:9-15): read-only for searches
+  uint32_t k = 0;         // num_centroids; 0 = no index / nothing kept
+  uint64_t n_total = 0;   // assignments.len(): next vec_id handed out by add
+  DevBuf centroids;    // [k][ldx] row-major (k-means, read-back)
+  DevBuf centroids_b;  // the same in lane-transposed tiles (exact coarse quantiser)
+  // MFMA pre-selection of the batched coarse quantiser (gemm.cuh)
+  DevBuf centroids_g;  // row-major [k_pad][ldq], zero padded
+  DevBuf cnorm;        // |c|^2 [k_pad], +inf in the padding
+  DevBuf coarse_stat;  // u32: queries that failed the certificate and were re-done exactly
+  float cmax2 = 0.0f;
+  uint32_t k_pad = 0;
+  std::atomic<uint64_t> mfma_batches{0};
+  DevBuf rows, row_ids, list_off, list_len;
+  // SLOT space: the per-batch planning tables, the work items and the scan kernels address a list by its SLOT =
+  // rank among the lists by descending length (ties by index).  plan_query translates a centroid index into a slot
+  // once (list_slot); every table the later stages read is then contiguous in work order: the group step's prefix
+  // sums run longest list first -- the dynamic hand-out ends on short quads instead of starting a 5x longer list on
+  // the last free CU (8-way sharded list scan 744 -> 670 us, same box) -- without a single gather.
+  DevBuf list_slot;        // [k] centroid index -> slot
+  DevBuf slot_off, slot_len;  // list_off / list_len in slot order
+  std::vector<uint32_t> h_slot;
+  std::vector<uint32_t> h_off, h_len, h_cap;  // h_len = GLOBAL list lengths; h_off/h_cap only meaningful for owned lists
+  // sharding by cluster across GPUs (one process per GPU): this handle stores only lists with owner == rank
+  uint32_t rank = 0, world = 1;
+  std::vector<uint8_t> h_owner;
+  DevBuf owner;
+  uint64_t cap_rows = 0;
+  uint32_t max_len = 0;
+  KMeansScratch km;  // build scratch (build / upload hold the handle exclusively)
+  // matrix-core list scan (prescan.cuh): |x|^2 per storage row, [0] max |x|^2 bits, [1] certificate failures (running)
+  DevBuf xnorm, pre_misc;
+  // bf16 shadow of the rows for the matrix-core pre-selection (+50 % corpus memory; VERS_SHADOW=0 or a failed
+  // allocation: the f32 rows feed it).  The wider certificate window makes it sensitive to data with many near-ties:
+  // the failure counter is watched through a pinned word and the shadow is switched off for the handle when more
+  // than 1/8 of the queries had to be re-scanned exactly.
+  DevBuf rows_bf;
+  // Row-major second copy of the stored rows for the exact finish: a candidate row of the lane-transposed tile layout is
+  // 192 separate 16-byte pieces (one per 64-byte sector: 4x the useful bytes, 74 us per batch of 1024 at cfg3 whatever the
+  // shard count); row-major it is 3 KB of whole sectors.  OPT-IN (VERS_ROWMAJOR=1; -1 = whenever the rows take at most a
+  // quarter of the device's memory): measured at cfg3, same box -- exact finish 74 -> 53 us, but the list scan 10 us
+  // slower with twice the rows mapped, net -8 us per step at 8 ranks and nothing on one GPU: not worth doubling the
+  // corpus memory by default.  Same bits either way.
+  DevBuf rows_rm;
+  std::atomic<bool> shadow_off{false};
+  uint32_t* fail_watch = nullptr;       // pinned: cumulative certificate failures as of the last finished batch
+  std::atomic<uint64_t> shadow_queries{0};  // queries sent through the shadow path since the counter was last zeroed
+  std::atomic<uint64_t> pre_batches{0};
+  std::atomic<uint64_t> ahead_used{0};  // searches that consumed a look-ahead slot (statistics)
   // A look-ahead request is DEFERRED: vers_ivf_coarse_ahead_dev only notes it, and the next search on the handle starts
   // it right behind its own list-scan launch -- the side stream then works under that search's exact finish (a chain of
   // dependent row gathers: 9 % VALU-active, 82 % of its wave cycles waiting) instead of competing with the scan, which
@@ -800,47 +827,158 @@ struct vers_ivf {
     const float* q_dev = nullptr;
     uint64_t ldq_in = 0;
     uint32_t b = 0, nprobe = 0;
-  } pending;
-  uint32_t ahead_next = 0;
-  hipStream_t ahead_stream = nullptr;
-  hipEvent_t ahead_in = nullptr;
-  uint64_t ahead_used = 0;  // searches that consumed a slot (statistics)
-  // status words: [0] latched by _dev calls and reported by vers_ivf_poll; [1] used by host-pointer calls and add, which
-  // synchronise and consume it themselves under the handle's mutex -- so neither side eats the other's bits
-  uint32_t st_slot = 0;
-  uint32_t* st_word() const { return status.as<uint32_t>() + st_slot; }
-  GroupTotals last_tot{};
-  const GroupTotals* tot_dev = nullptr;  // device totals of the last planned search
-  bool tot_valid = false;
-  std::mutex mu;
+  } pending;  // (guarded by pool_mu)
+  // searches / reads hold `index` shared, build / upload / add / set_* exclusively
+  std::shared_mutex index;
+  std::mutex pool_mu;
+  std::condition_variable pool_cv;
+  std::vector<std::unique_ptr<SearchWs>> pool;
+  std::vector<SearchWs*> free_ws;
+  SearchWs* last_ws = nullptr;  // the measurement hooks (vers_ivf_last_scan, ...) read the workspace of the most recent call
+  static constexpr size_t kMaxWs = 16;
 };
 
 namespace {
 
 int32_t status_to_rc(vers_ivf* h, uint32_t s, uint32_t slot);
+
+// ---- workspaces ------------------------------------------------------------------------------------------------
+int32_t ws_init(SearchWs& w) {
+  if (int32_t rc = w.status.reserve(16)) return rc;
+  VERS_HIP_TRY(hipMemset(w.status.p, 0, 16));
+  if (int32_t rc = w.grid_ctr.reserve(16)) return rc;
+  VERS_HIP_TRY(hipMemset(w.grid_ctr.p, 0, 16));
+  if (scan_debug_flags() & 16u) {  // diagnosis: in-kernel phase stamps
+    if (int32_t rc = w.stamps.reserve(256)) return rc;
+    VERS_HIP_TRY(hipMemset(w.stamps.p, 0, 256));
+  }
+  for (uint32_t i = 0; i < SearchWs::kEvRing; ++i) {
+    VERS_HIP_TRY(hipEventCreate(&w.ev0[i]));
+    VERS_HIP_TRY(hipEventCreate(&w.ev1[i]));
+  }
+  for (auto& e : w.evc) VERS_HIP_TRY(hipEventCreate(&e));
+  VERS_HIP_TRY(hipEventCreateWithFlags(&w.done, hipEventDisableTiming));
+  return VERS_OK;
+}
+void ws_destroy(SearchWs& w) {
+  for (uint32_t i = 0; i < SearchWs::kEvRing; ++i) {
+    if (w.ev0[i]) (void)hipEventDestroy(w.ev0[i]);
+    if (w.ev1[i]) (void)hipEventDestroy(w.ev1[i]);
+  }
+  for (auto& e : w.evc)
+    if (e) (void)hipEventDestroy(e);
+  if (w.done) (void)hipEventDestroy(w.done);
+  if (w.io_pin) (void)hipHostFree(w.io_pin);
+  if (w.io_stream) (void)hipStreamDestroy(w.io_stream);
+  if (w.ahead_stream) {
+    (void)hipStreamSynchronize(w.ahead_stream);
+    (void)hipStreamDestroy(w.ahead_stream);
+    (void)hipEventDestroy(w.ahead_in);
+    for (auto& a : w.ahead) { (void)hipEventDestroy(a.ready); (void)hipEventDestroy(a.freed); }
+  }
+}
+// One call's lease of a workspace (see SearchWs).  order_on(stream): the call is about to queue work on `stream`; if
+// the workspace was last used on another stream, that stream's work on it must finish first.
+struct WsLease {
+  vers_ivf* h;
+  SearchWs* ws = nullptr;
+  SearchWs* prev;
+  hipStream_t st = nullptr;
+  int32_t rc = VERS_OK;
+  explicit WsLease(vers_ivf* hh) : h(hh), prev(W) {
+    {
+      std::unique_lock<std::mutex> lk(h->pool_mu);
+      for (;;) {
+        if (!h->free_ws.empty()) { ws = h->free_ws.back(); h->free_ws.pop_back(); break; }
+        if (h->pool.size() < vers_ivf::kMaxWs) {
+          h->pool.emplace_back(new SearchWs());
+          ws = h->pool.back().get();
+          break;
+        }
+        h->pool_cv.wait(lk);
+      }
+    }
+    if (!ws->done) rc = ws_init(*ws);
+    W = ws;
+  }
+  int32_t order_on(hipStream_t stream) {
+    st = stream;
+    if (ws->used && ws->last_stream != stream) VERS_HIP_TRY(hipStreamWaitEvent(stream, ws->done, 0));
+    return VERS_OK;
+  }
+  ~WsLease() {
+    if (ws->done) {
+      (void)hipEventRecord(ws->done, st);
+      ws->used = true;
+      ws->last_stream = st;
+    }
+    W = prev;
+    {
+      std::lock_guard<std::mutex> lk(h->pool_mu);
+      h->free_ws.push_back(ws);  // LIFO: a single-threaded loop keeps getting the same workspace (and its look-ahead slots)
+      h->last_ws = ws;
+    }
+    h->pool_cv.notify_one();
+  }
+};
+// the measurement hooks look at the workspace of the most recent call
+struct UseLastWs {
+  SearchWs* prev;
+  bool ok;
+  explicit UseLastWs(vers_ivf* h) : prev(W) {
+    std::lock_guard<std::mutex> lk(h->pool_mu);
+    ok = h->last_ws != nullptr;
+    if (ok) W = h->last_ws;
+  }
+  ~UseLastWs() { W = prev; }
+};
 int32_t coarse_ahead_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint32_t b, uint32_t nprobe, hipStream_t st);
 // starts a noted look-ahead behind whatever the caller has just queued on `st` (see vers_ivf::PendingAhead)
 inline int32_t start_pending_ahead(vers_ivf* h, hipStream_t st) {
-  if (!h->pending.set) return VERS_OK;
-  h->pending.set = false;
-  return coarse_ahead_locked(h, h->pending.q_dev, h->pending.ldq_in, h->pending.b, h->pending.nprobe, st);
+  vers_ivf::PendingAhead p;
+  {
+    std::lock_guard<std::mutex> lk(h->pool_mu);
+    p = h->pending;
+    h->pending.set = false;
+  }
+  if (!p.set) return VERS_OK;
+  return coarse_ahead_locked(h, p.q_dev, p.ldq_in, p.b, p.nprobe, st);
 }
-int32_t sync_status(vers_ivf* h, hipStream_t st) {  // the word of the _dev calls
-  uint32_t s = 0;
+int32_t sync_status(vers_ivf* h, hipStream_t st) {  // word 0 (the _dev calls) of EVERY workspace: whichever calls ran on `st`
   VERS_HIP_TRY(hipStreamSynchronize(st));
-  VERS_HIP_TRY(hipMemcpy(&s, h->status.p, sizeof(s), hipMemcpyDeviceToHost));
-  return status_to_rc(h, s, 0);
+  std::vector<SearchWs*> all;
+  {
+    std::lock_guard<std::mutex> lk(h->pool_mu);
+    for (auto& w : h->pool) all.push_back(w.get());
+  }
+  uint32_t s = 0;
+  for (SearchWs* w : all) {
+    if (!w->status.p) continue;
+    uint32_t sw = 0;
+    VERS_HIP_TRY(hipMemcpy(&sw, w->status.p, sizeof(sw), hipMemcpyDeviceToHost));
+    if (sw) VERS_HIP_TRY(hipMemset(w->status.p, 0, sizeof(sw)));
+    s |= sw;
+  }
+  if (!s) return VERS_OK;
+  if (s & kStNaN) return fail(VERS_ERR_NAN, "NaN distance (the reference panics in partial_cmp().unwrap())");
+  if (s & kStInsufficient)
+    return fail(VERS_ERR_INSUFFICIENT, "fewer than top_k vectors reachable (reference: index out of bounds, ivfflat.rs:169)");
+  if (s & kStSpillTooDeep) {
+    fail(VERS_ERR_INVALID, "search_approximate spills past the lists this device-pointer call ranked (48): the host-pointer entry point retries with every list");
+    return kRetrySpill;
+  }
+  return VERS_OK;
 }
 // host-pointer calls and add run with status word 1 while they hold the handle's mutex
 struct HostStatusSlot {
-  vers_ivf* h;
-  explicit HostStatusSlot(vers_ivf* hh) : h(hh) { h->st_slot = 1; }
-  ~HostStatusSlot() { h->st_slot = 0; }
+  SearchWs* w;
+  explicit HostStatusSlot(vers_ivf*) : w(W) { w->st_slot = 1; }
+  ~HostStatusSlot() { w->st_slot = 0; }
 };
 // maps (and clears) the device status word of a finished search: the reference's panics
 int32_t status_to_rc(vers_ivf* h, uint32_t s, uint32_t slot) {
   if (s) {
-    VERS_HIP_TRY(hipMemset(h->status.as<uint32_t>() + slot, 0, sizeof(s)));
+    VERS_HIP_TRY(hipMemset(W->status.as<uint32_t>() + slot, 0, sizeof(s)));
     if (s & kStNaN) return fail(VERS_ERR_NAN, "NaN distance (the reference panics in partial_cmp().unwrap())");
     if (s & kStInsufficient)
       return fail(VERS_ERR_INSUFFICIENT, "fewer than top_k vectors reachable (reference: index out of bounds, ivfflat.rs:169)");
@@ -859,7 +997,8 @@ int32_t refresh_norms(vers_ivf* h, uint64_t r_begin, uint64_t r_end, hipStream_t
   if (full) {
     if (int32_t rc = h->xnorm.reserve((h->cap_rows ? h->cap_rows : 1) * sizeof(float))) return rc;
     VERS_HIP_TRY(hipMemsetAsync(h->pre_misc.p, 0, 64, st));
-    for (auto& a : h->ahead) a.valid = false;  // a new index: ranked lists computed ahead belong to the old centroids
+    for (auto& w : h->pool)  // a new index: ranked lists computed ahead belong to the old centroids (the caller holds the handle exclusively)
+      for (auto& a : w->ahead) a.valid = false;
   }
   // EXPERIMENTAL, off unless VERS_SHADOW=1: bit-exact on every test, fuzz and A/B run of its final
   // form.  An earlier arrangement of the same arithmetic came out wrong in accumulator register 15 (an MFMA reading an
@@ -876,7 +1015,8 @@ int32_t refresh_norms(vers_ivf* h, uint64_t r_begin, uint64_t r_end, hipStream_t
         else (void)hipGetLastError();
       }
       h->shadow_off = false; h->shadow_queries = 0;  // (the failure counter in pre_misc was just zeroed)
-      if (h->fail_watch) *h->fail_watch = 0;
+      if (!h->fail_watch) VERS_HIP_TRY(hipHostMalloc((void**)&h->fail_watch, 64, hipHostMallocDefault));
+      *h->fail_watch = 0;
     }
     if (r_end > r_begin && h->rows_bf.p) {
       const uint64_t work = (r_end - r_begin) * (h->ld / 8);
@@ -1432,7 +1572,7 @@ int32_t launch_seg_scan(vers_ivf* h, const SegSrc<QG, SEQ_IDS>& src, uint32_t n_
   p.ld = h->ld;
   p.n_chunks = h->ld / kChunk;
   p.k = src.k;
-  p.status = h->st_word();
+  p.status = W->st_word();
   p.debug = 0;
   p.stamps = nullptr;
   p.next_quad = nullptr;
@@ -1454,13 +1594,13 @@ int32_t launch_seg_scan(vers_ivf* h, const SegSrc<QG, SEQ_IDS>& src, uint32_t n_
   return VERS_OK;
 }
 
-// queries (device, pitch ldq_in) -> h->qp [b][ldq] zero padded; returns the pointer/pitch to use
+// queries (device, pitch ldq_in) -> W->qp [b][ldq] zero padded; returns the pointer/pitch to use
 int32_t stage_plain_queries(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint32_t b, const float** q_out,
                             hipStream_t st) {
   // rows padded to the GEMM tile (the MFMA pre-selection reads whole 128-row tiles; extra rows are ignored)
-  if (int32_t rc = h->qp.reserve((size_t)round_up(b, kGemmBM) * h->ldq * sizeof(float))) return rc;
-  if (int32_t rc = launch_stage_queries(q_dev, ldq_in, h->d, h->qp.as<float>(), h->ldq, b, 1, st)) return rc;
-  *q_out = h->qp.as<float>();
+  if (int32_t rc = W->qp.reserve((size_t)round_up(b, kGemmBM) * h->ldq * sizeof(float))) return rc;
+  if (int32_t rc = launch_stage_queries(q_dev, ldq_in, h->d, W->qp.as<float>(), h->ldq, b, 1, st)) return rc;
+  *q_out = W->qp.as<float>();
   return VERS_OK;
 }
 
@@ -1496,66 +1636,66 @@ inline int coarse_mode() {  // VERS_COARSE: 1 = always exact, 2 = every certific
   static const int m = [] { const char* e = getenv("VERS_COARSE"); return e ? atoi(e) : 0; }();
   return m;
 }
-inline bool coarse_on_matrix_cores(const vers_ivf* h, uint32_t b) { return b >= 32 && coarse_mode() != 1 && !h->ref_deep; }
+inline bool coarse_on_matrix_cores(const vers_ivf* h, uint32_t b) { return b >= 32 && coarse_mode() != 1 && !W->ref_deep; }
 // batches: MFMA pre-selection + exact re-score + certificate (gemm.cuh); same output as the exact scan, bit for bit.
-// qp: staged queries [round_up(b, kGemmBM)][ldq]; probe_out [b][P].  h->gbuf is the only scratch.
+// qp: staged queries [round_up(b, kGemmBM)][ldq]; probe_out [b][P].  W->gbuf is the only scratch.
 int32_t coarse_mfma(vers_ivf* h, const float* qp, uint32_t b, uint32_t P, uint64_t* probe_out, hipStream_t st) {
   const uint32_t M_pad = round_up(b, kGemmBM);
   const uint32_t PS = std::min<uint32_t>(kMaxTopK, P + 16);
-  if (int32_t rc = h->gbuf.reserve((size_t)M_pad * h->k_pad * sizeof(float))) return rc;
-  const bool timed = st != h->ahead_stream || h->ahead_stream == nullptr;  // (the look-ahead stream is not the measured one)
-  if (timed) VERS_HIP_TRY(hipEventRecord(h->evc[0], st));
+  if (int32_t rc = W->gbuf.reserve((size_t)M_pad * h->k_pad * sizeof(float))) return rc;
+  const bool timed = st != W->ahead_stream || W->ahead_stream == nullptr;  // (the look-ahead stream is not the measured one)
+  if (timed) VERS_HIP_TRY(hipEventRecord(W->evc[0], st));
   if (gemm_x3_mask() & 2)
     hipLaunchKernelGGL(dist_gemm_x3_kernel<false>, dim3(h->k_pad / kGemmBN, M_pad / kGemmBM), dim3(256), 0, st, qp, h->centroids_g.as<float>(),
-                       h->cnorm.as<float>(), h->ldq, h->k_pad, h->gbuf.as<float>(), h->metric);
+                       h->cnorm.as<float>(), h->ldq, h->k_pad, W->gbuf.as<float>(), h->metric);
   else
     hipLaunchKernelGGL(dist_gemm_kernel<false>, dim3(h->k_pad / kGemmBN, M_pad / kGemmBM), dim3(256), 0, st, qp, h->centroids_g.as<float>(),
-                       h->cnorm.as<float>(), h->ldq, h->k_pad, h->gbuf.as<float>(), h->metric);
+                       h->cnorm.as<float>(), h->ldq, h->k_pad, W->gbuf.as<float>(), h->metric);
   VERS_HIP_TRY(hipGetLastError());
-  if (timed) VERS_HIP_TRY(hipEventRecord(h->evc[1], st));
-  hipLaunchKernelGGL(coarse_select_rescore_kernel, dim3(b), dim3(kWave), 0, st, h->gbuf.as<float>(), h->k_pad, h->k,
+  if (timed) VERS_HIP_TRY(hipEventRecord(W->evc[1], st));
+  hipLaunchKernelGGL(coarse_select_rescore_kernel, dim3(b), dim3(kWave), 0, st, W->gbuf.as<float>(), h->k_pad, h->k,
                      h->centroids_g.as<float>(), h->ldq, qp, h->ldq, h->ldq, coarse_mode() == 2 ? __builtin_inff() : h->cmax2, P, PS,
-                     probe_out, h->st_word(), h->coarse_stat.as<uint32_t>(), h->metric,
-                     (scan_debug_flags() & 16u) && h->stamps.p ? h->stamps.as<unsigned long long>() : (unsigned long long*)nullptr);
+                     probe_out, W->st_word(), h->coarse_stat.as<uint32_t>(), h->metric,
+                     (scan_debug_flags() & 16u) && W->stamps.p ? W->stamps.as<unsigned long long>() : (unsigned long long*)nullptr);
   VERS_HIP_TRY(hipGetLastError());
-  if (timed) { VERS_HIP_TRY(hipEventRecord(h->evc[2], st)); h->evc_valid = true; }
+  if (timed) { VERS_HIP_TRY(hipEventRecord(W->evc[2], st)); W->evc_valid = true; }
   h->mfma_batches += 1;
   return VERS_OK;
 }
 
-// coarse quantiser (ivfflat.rs:155-161): top-P centroids per query as ascending (dist, index) keys in h->probe
-// out_n_segs != nullptr: stop after the scan (partial slots in h->cpart) and report the slot count per query --
+// coarse quantiser (ivfflat.rs:155-161): top-P centroids per query as ascending (dist, index) keys in W->probe
+// out_n_segs != nullptr: stop after the scan (partial slots in W->cpart) and report the slot count per query --
 // the single-query path merges them inside plan1_kernel.
 int32_t coarse(vers_ivf* h, const float* qp, uint32_t b, uint32_t P, hipStream_t st, uint32_t* out_n_segs = nullptr) {
-  if (coarse_on_matrix_cores(h, b) && qp == h->qp.as<float>() && P + 16 <= (uint32_t)kMaxTopK) {  // (the selection keeps P + 16 keys: one per lane)
-    if (int32_t rc = h->probe.reserve((size_t)b * P * sizeof(uint64_t))) return rc;
-    return coarse_mfma(h, qp, b, P, h->probe.as<uint64_t>(), st);
+  if (coarse_on_matrix_cores(h, b) && qp == W->qp.as<float>() && P + 16 <= (uint32_t)kMaxTopK) {  // (the selection keeps P + 16 keys: one per lane)
+    if (int32_t rc = W->probe.reserve((size_t)b * P * sizeof(uint64_t))) return rc;
+    return coarse_mfma(h, qp, b, P, W->probe.as<uint64_t>(), st);
   }
   const int QG = b == 1 ? 1 : 8;
   const uint32_t n_qg = (b + QG - 1) / QG;
   const float* q = qp;
   if (QG != 1) {
-    if (int32_t rc = h->qil.reserve((size_t)n_qg * h->ldq * QG * sizeof(float))) return rc;
-    if (int32_t rc = launch_stage_queries(qp, h->ldq, h->ldq, h->qil.as<float>(), h->ldq, b, QG, st)) return rc;
-    q = h->qil.as<float>();
+    if (int32_t rc = W->qil.reserve((size_t)n_qg * h->ldq * QG * sizeof(float))) return rc;
+    if (int32_t rc = launch_stage_queries(qp, h->ldq, h->ldq, W->qil.as<float>(), h->ldq, b, QG, st)) return rc;
+    q = W->qil.as<float>();
   }
   const uint32_t target_items = (uint32_t)h->n_cu * scan_blocks_per_cu(QG, h->ld) * kWavesPerBlock;
   uint64_t per = ((uint64_t)h->k * n_qg + target_items - 1) / target_items;
   const uint32_t seg_rows = (uint32_t)std::min<uint64_t>(round_up64(per ? per : 1, kWave), max_seg_rows(h->ld));
   const uint32_t n_segs = (h->k + seg_rows - 1) / seg_rows;
   const uint32_t kw = std::min<uint32_t>(P, kMaxTopK);  // keys per partial slot: one per lane; P > 64 takes ceil(P / 64) passes
-  if (int32_t rc = h->cpart.reserve((size_t)b * n_segs * kw * sizeof(uint64_t))) return rc;
-  if (int32_t rc = h->probe.reserve((size_t)b * P * sizeof(uint64_t))) return rc;
+  if (int32_t rc = W->cpart.reserve((size_t)b * n_segs * kw * sizeof(uint64_t))) return rc;
+  if (int32_t rc = W->probe.reserve((size_t)b * P * sizeof(uint64_t))) return rc;
   if (P > (uint32_t)kMaxTopK)
-    if (int32_t rc = h->clower.reserve((size_t)b * sizeof(uint64_t))) return rc;
+    if (int32_t rc = W->clower.reserve((size_t)b * sizeof(uint64_t))) return rc;
   const uint32_t n_segs_pad = QG == 1 ? n_segs : round_up(n_segs, 4);
   for (uint32_t rank0 = 0; rank0 < P; rank0 += kMaxTopK) {
     const uint32_t k_pass = std::min<uint32_t>(kMaxTopK, P - rank0);
-    const uint64_t* lower = rank0 ? h->clower.as<uint64_t>() : nullptr;
+    const uint64_t* lower = rank0 ? W->clower.as<uint64_t>() : nullptr;
     auto fill = [&](auto& src) {
       src.rows = h->centroids_b.as<float>(); src.n = h->k; src.ld = h->ld; src.seg_rows = seg_rows; src.n_segs = n_segs;
       src.n_segs_pad = n_segs_pad;
-      src.queries = q; src.ldq = h->ldq; src.b = b; src.partials = h->cpart.as<uint64_t>(); src.k = k_pass; src.ids = nullptr;
+      src.queries = q; src.ldq = h->ldq; src.b = b; src.partials = W->cpart.as<uint64_t>(); src.k = k_pass; src.ids = nullptr;
     };
     int32_t rc;
     if (QG == 1) {
@@ -1570,8 +1710,8 @@ int32_t coarse(vers_ivf* h, const float* qp, uint32_t b, uint32_t P, hipStream_t
       *out_n_segs = n_segs;
       return VERS_OK;
     }
-    hipLaunchKernelGGL(coarse_merge_kernel, dim3(b), dim3(kWave * kMergeWaves), 0, st, h->cpart.as<uint64_t>(), n_segs, k_pass, P, rank0,
-                       h->probe.as<uint64_t>(), P > (uint32_t)kMaxTopK ? h->clower.as<uint64_t>() : (uint64_t*)nullptr);
+    hipLaunchKernelGGL(coarse_merge_kernel, dim3(b), dim3(kWave * kMergeWaves), 0, st, W->cpart.as<uint64_t>(), n_segs, k_pass, P, rank0,
+                       W->probe.as<uint64_t>(), P > (uint32_t)kMaxTopK ? W->clower.as<uint64_t>() : (uint64_t*)nullptr);
     VERS_HIP_TRY(hipGetLastError());
   }
   return VERS_OK;
@@ -1583,23 +1723,23 @@ int32_t launch_ivf_scan(vers_ivf* h, const IvfSrc<QG>& src, uint32_t items_bound
   p.ld = h->ld;
   p.n_chunks = h->ld / kChunk;
   p.k = src.k_keep;
-  p.status = h->st_word();
+  p.status = W->st_word();
   p.debug = scan_debug_flags();
   p.stamps = nullptr;
   if (p.debug & 16u) {  // diagnosis only
-    if (int32_t rc = h->stamps.reserve(256)) return rc;
-    VERS_HIP_TRY(hipMemsetAsync(h->stamps.p, 0, 128, st));
-    p.stamps = h->stamps.as<unsigned long long>();
+    if (int32_t rc = W->stamps.reserve(256)) return rc;
+    VERS_HIP_TRY(hipMemsetAsync(W->stamps.p, 0, 128, st));
+    p.stamps = W->stamps.as<unsigned long long>();
   }
   // pruning bounds shared between the items of a merge group (they run at different times here, unlike the flat
   // scans); VERS_SCAN_DEBUG bit 3 switches them off for A/B runs
-  p.bounds = (QG != 1 && !(scan_debug_flags() & 8u)) ? h->partials.as<uint64_t>() + h->ivf_bounds_off : nullptr;
+  p.bounds = (QG != 1 && !(scan_debug_flags() & 8u)) ? W->partials.as<uint64_t>() + W->ivf_bounds_off : nullptr;
   p.lower = lower;
   p.next_quad = nullptr;
   if (QG != 1 && !(scan_debug_flags() & 32u)) {
-    if (int32_t rc = h->quad_counter.reserve(16)) return rc;
-    VERS_HIP_TRY(hipMemsetAsync(h->quad_counter.p, 0, 16, st));
-    p.next_quad = h->quad_counter.as<uint32_t>();
+    if (int32_t rc = W->quad_counter.reserve(16)) return rc;
+    VERS_HIP_TRY(hipMemsetAsync(W->quad_counter.p, 0, 16, st));
+    p.next_quad = W->quad_counter.as<uint32_t>();
   }
   const size_t lds = scan_lds_bytes(QG, h->ld);
   if (int32_t rc = h->metric ? scan_prepare_launch(scan_kernel<QG, 1, IvfSrc<QG>>, lds) : scan_prepare_launch(scan_kernel<QG, 0, IvfSrc<QG>>, lds)) return rc;
@@ -1607,13 +1747,13 @@ int32_t launch_ivf_scan(vers_ivf* h, const IvfSrc<QG>& src, uint32_t items_bound
   const uint32_t max_blocks = (uint32_t)h->n_cu * scan_blocks_per_cu(QG, h->ld);
   if (blocks > max_blocks) blocks = max_blocks;
   if (blocks == 0) blocks = 1;
-  const uint32_t slot = (uint32_t)(h->ev_count % vers_ivf::kEvRing);
-  VERS_HIP_TRY(hipEventRecord(h->ev0[slot], st));
+  const uint32_t slot = (uint32_t)(W->ev_count % SearchWs::kEvRing);
+  VERS_HIP_TRY(hipEventRecord(W->ev0[slot], st));
   if (h->metric) hipLaunchKernelGGL((scan_kernel<QG, 1, IvfSrc<QG>>), dim3(blocks), dim3(kWave * kWavesPerBlock), lds, st, src, p);
   else hipLaunchKernelGGL((scan_kernel<QG, 0, IvfSrc<QG>>), dim3(blocks), dim3(kWave * kWavesPerBlock), lds, st, src, p);
   VERS_HIP_TRY(hipGetLastError());
-  VERS_HIP_TRY(hipEventRecord(h->ev1[slot], st));
-  h->ev_count += 1;
+  VERS_HIP_TRY(hipEventRecord(W->ev1[slot], st));
+  W->ev_count += 1;
   return VERS_OK;
 }
 
@@ -1625,17 +1765,17 @@ int32_t launch_prescan(vers_ivf* h, const IvfSrc<kPreQ>& src, uint32_t items_bou
   p.ld = h->ld;
   p.n_chunks = h->ld / kChunk;
   p.kp = kp;
-  p.status = h->st_word();
-  p.bounds32 = reinterpret_cast<uint32_t*>(h->partials.as<uint64_t>() + h->ivf_bounds_off);  // 0xFF-initialised with the slots
+  p.status = W->st_word();
+  p.bounds32 = reinterpret_cast<uint32_t*>(W->partials.as<uint64_t>() + W->ivf_bounds_off);  // 0xFF-initialised with the slots
   p.qflags = qflags;
   p.xnorm = h->xnorm.as<float>();
   p.debug = scan_debug_flags();
   p.metric = (uint32_t)h->metric;
   p.stamps = nullptr;
   if (p.debug & 16u) {
-    if (int32_t rc = h->stamps.reserve(256)) return rc;
-    VERS_HIP_TRY(hipMemsetAsync(h->stamps.p, 0, 128, st));
-    p.stamps = h->stamps.as<unsigned long long>();
+    if (int32_t rc = W->stamps.reserve(256)) return rc;
+    VERS_HIP_TRY(hipMemsetAsync(W->stamps.p, 0, 128, st));
+    p.stamps = W->stamps.as<unsigned long long>();
   }
   p.next_quad = (p.debug & 32u) ? nullptr : quad_ctr;  // zeroed with the planning tables
   const size_t lds = prescan_lds_bytes_g(h->ld, kp);
@@ -1646,13 +1786,13 @@ int32_t launch_prescan(vers_ivf* h, const IvfSrc<kPreQ>& src, uint32_t items_bou
   const uint32_t max_blocks = (uint32_t)h->n_cu * per_cu;
   if (blocks > max_blocks) blocks = max_blocks;
   if (blocks == 0) blocks = 1;
-  const uint32_t slot = (uint32_t)(h->ev_count % vers_ivf::kEvRing);
-  VERS_HIP_TRY(hipEventRecord(h->ev0[slot], st));
+  const uint32_t slot = (uint32_t)(W->ev_count % SearchWs::kEvRing);
+  VERS_HIP_TRY(hipEventRecord(W->ev0[slot], st));
   if (shadow) hipLaunchKernelGGL((prescan_kernel_g<true, IvfSrc<kPreQ>>), dim3(blocks), dim3(kWave * kPreWavesG), lds, st, src, p);
   else hipLaunchKernelGGL((prescan_kernel_g<false, IvfSrc<kPreQ>>), dim3(blocks), dim3(kWave * kPreWavesG), lds, st, src, p);
   VERS_HIP_TRY(hipGetLastError());
-  VERS_HIP_TRY(hipEventRecord(h->ev1[slot], st));
-  h->ev_count += 1;
+  VERS_HIP_TRY(hipEventRecord(W->ev1[slot], st));
+  W->ev_count += 1;
   return VERS_OK;
 }
 
@@ -1670,18 +1810,21 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
   const int ref_mode = nprobe == 0;
   // reference mode ranks the 48 nearest lists (48 + 16 slack = one key per lane in the MFMA pre-selection);
   // a spill deeper than that is refused (kStSpillTooDeep) -- it needs > 47 consecutive near-empty lists
-  // (host-pointer calls retry deeper: 16, 48, 64 and finally ALL lists, h->ref_all -- the reference walks as far as it must)
-  const uint32_t P = ref_mode ? std::min<uint32_t>(h->k, h->ref_all ? h->k : (h->ref_deep ? 64u : (h->ref_shallow ? 16u : 48u)))
+  // (host-pointer calls retry deeper: 16, 48, 64 and finally ALL lists, W->ref_all -- the reference walks as far as it must)
+  const uint32_t P = ref_mode ? std::min<uint32_t>(h->k, W->ref_all ? h->k : (W->ref_deep ? 64u : (W->ref_shallow ? 16u : 48u)))
                               : std::min<uint32_t>(nprobe, h->k);
   // one key per lane is the width of every list in the kernels: more ranked lists (P > 64) or more results (top_k > 64)
   // are produced 64 ranks per pass (ScanParams::lower), on the ordered-chain kernels
   const bool one1 = b == 1 && P <= (uint32_t)kMaxTopK;  // single query: coarse merge + plan fused in plan1_kernel
   const float* qp = nullptr;
   const uint64_t* probe = nullptr;
-  vers_ivf::CoarseAhead* took = nullptr;
-  for (auto& a : h->ahead)
+  SearchWs::CoarseAhead* took = nullptr;
+  for (auto& a : W->ahead)
     if (a.valid && !ref_mode && a.q_dev == q_dev && a.ldq_in == ldq_in && a.b == b && a.P == P) took = &a;
-  if (h->pending.set && h->pending.q_dev == q_dev && h->pending.ldq_in == ldq_in && h->pending.b == b) h->pending.set = false;  // this very batch: computed inline below
+  {
+    std::lock_guard<std::mutex> lk(h->pool_mu);
+    if (h->pending.set && h->pending.q_dev == q_dev && h->pending.ldq_in == ldq_in && h->pending.b == b) h->pending.set = false;  // this very batch: computed inline below
+  }
   uint32_t n_segs_c = 0;
   if (took) {  // staged queries and ranked lists of this batch were computed ahead (vers_ivf_coarse_ahead_dev)
     VERS_HIP_TRY(hipStreamWaitEvent(st, took->ready, 0));
@@ -1690,12 +1833,12 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
     took->valid = false;
     h->ahead_used += 1;
   } else {
-    for (auto& a : h->ahead)  // h->gbuf is shared with a look-ahead in flight: let it finish first
+    for (auto& a : W->ahead)  // W->gbuf is shared with a look-ahead in flight: let it finish first
       if (a.ready_rec) VERS_HIP_TRY(hipStreamWaitEvent(st, a.ready, 0));
     if (b == 1 && h->d == h->ldq && (reinterpret_cast<uintptr_t>(q_dev) & 15u) == 0) qp = q_dev;  // a single unpadded-is-padded query: no staging launch
     else if (int32_t rc = stage_plain_queries(h, q_dev, ldq_in, b, &qp, st)) return rc;
     if (int32_t rc = coarse(h, qp, b, P, st, one1 ? &n_segs_c : nullptr)) return rc;
-    probe = h->probe.as<uint64_t>();
+    probe = W->probe.as<uint64_t>();
   }
 
   // geometry of the list scan
@@ -1755,25 +1898,25 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
 
   const uint32_t k_l = h->k;
   // pj: list, pref, take per (q, j); np per q.   lists: cnt, fill | pair_off, group_off, item_off | totals
-  if (int32_t rc = h->pj.reserve((4 * n_pj + b) * sizeof(uint32_t))) return rc;
+  if (int32_t rc = W->pj.reserve((4 * n_pj + b) * sizeof(uint32_t))) return rc;
   // one zero-initialised zone per batch (ONE memset): cnt, fill, hot per list | quad hand-out counter | queue of
   // uncertified queries + its count | non-finite flags per (query, probe)
   const size_t zero_words = 3 * (size_t)k_l + 4 + (use_pre ? (size_t)b + 4 + n_pj : 0);
-  if (int32_t rc = h->lists.reserve((zero_words + 3 * (size_t)k_l) * sizeof(uint32_t) + sizeof(GroupTotals) + 64)) return rc;
-  if (int32_t rc = h->pairs.reserve(n_pj * sizeof(uint32_t))) return rc;
-  if (int32_t rc = h->items.reserve(std::max<uint64_t>(1, items_bound) * sizeof(ItemDesc))) return rc;
-  if (int32_t rc = h->groups.reserve(std::max<uint64_t>(1, groups_bound) * sizeof(GroupDesc))) return rc;
+  if (int32_t rc = W->lists.reserve((zero_words + 3 * (size_t)k_l) * sizeof(uint32_t) + sizeof(GroupTotals) + 64)) return rc;
+  if (int32_t rc = W->pairs.reserve(n_pj * sizeof(uint32_t))) return rc;
+  if (int32_t rc = W->items.reserve(std::max<uint64_t>(1, items_bound) * sizeof(ItemDesc))) return rc;
+  if (int32_t rc = W->groups.reserve(std::max<uint64_t>(1, groups_bound) * sizeof(GroupDesc))) return rc;
   if (QG != 1 && !use_pre)
-    if (int32_t rc = h->qblocks.reserve(groups_bound * h->ldq * QG * sizeof(float))) return rc;
-  h->ivf_bounds_off = ((size_t)n_pj * S_max * k_keep + 1) & ~(size_t)1;  // (even: the bounds start 16-byte aligned)
-  const size_t part_bytes = (h->ivf_bounds_off + n_pj) * sizeof(uint64_t);  // slots + one bound per (query, probe)
-  if (int32_t rc = h->partials.reserve(part_bytes + 16)) return rc;
-  uint32_t* pj_list = h->pj.as<uint32_t>();
+    if (int32_t rc = W->qblocks.reserve(groups_bound * h->ldq * QG * sizeof(float))) return rc;
+  W->ivf_bounds_off = ((size_t)n_pj * S_max * k_keep + 1) & ~(size_t)1;  // (even: the bounds start 16-byte aligned)
+  const size_t part_bytes = (W->ivf_bounds_off + n_pj) * sizeof(uint64_t);  // slots + one bound per (query, probe)
+  if (int32_t rc = W->partials.reserve(part_bytes + 16)) return rc;
+  uint32_t* pj_list = W->pj.as<uint32_t>();
   uint32_t* pj_pref = pj_list + n_pj;
   uint32_t* pj_take = pj_pref + n_pj;
   uint32_t* np = pj_take + n_pj;
   uint32_t* pj_nq = np + b;
-  uint32_t* cnt = h->lists.as<uint32_t>();
+  uint32_t* cnt = W->lists.as<uint32_t>();
   uint32_t* fill = cnt + k_l;
   uint32_t* hot = fill + k_l;  // lists that are the nearest list of some query: scanned first
   uint32_t* quad_ctr = hot + k_l;
@@ -1783,16 +1926,16 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
   uint32_t* group_off = pair_off + k_l;
   uint32_t* item_off = group_off + k_l;
   GroupTotals* tot = (GroupTotals*)(((uintptr_t)(item_off + k_l) + 15) & ~(uintptr_t)15);
-  h->tot_dev = tot;
+  W->tot_dev = tot;
 
   if (n_pass > 1)
-    if (int32_t rc = h->lower.reserve(n_pj * sizeof(uint64_t))) return rc;
+    if (int32_t rc = W->lower.reserve(n_pj * sizeof(uint64_t))) return rc;
   if (one1) {
-    VERS_HIP_TRY(hipMemsetAsync(h->partials.p, 0xFF, part_bytes, st));
-    hipLaunchKernelGGL(plan1_kernel, dim3(1), dim3(kWave * kMergeWaves), 0, st, h->cpart.as<uint64_t>(), n_segs_c, P, k_l, top_k,
+    VERS_HIP_TRY(hipMemsetAsync(W->partials.p, 0xFF, part_bytes, st));
+    hipLaunchKernelGGL(plan1_kernel, dim3(1), dim3(kWave * kMergeWaves), 0, st, W->cpart.as<uint64_t>(), n_segs_c, P, k_l, top_k,
                        ref_mode, h->list_len.as<uint32_t>(), h->world > 1 ? h->owner.as<uint8_t>() : (const uint8_t*)nullptr, h->rank,
-                       seg_rows, h->probe.as<uint64_t>(), pj_list, pj_pref, pj_take, np, cnt, pair_off, group_off,
-                       h->pairs.as<uint32_t>(), h->items.as<ItemDesc>(), h->groups.as<GroupDesc>(), tot, h->st_word(),
+                       seg_rows, W->probe.as<uint64_t>(), pj_list, pj_pref, pj_take, np, cnt, pair_off, group_off,
+                       W->pairs.as<uint32_t>(), W->items.as<ItemDesc>(), W->groups.as<GroupDesc>(), tot, W->st_word(),
                        (const uint32_t*)h->list_slot.as<uint32_t>());
     VERS_HIP_TRY(hipGetLastError());
   } else {
@@ -1804,51 +1947,51 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
   pa.pj_list = pj_list; pa.pj_pref = pj_pref; pa.pj_take = pj_take; pa.np = np; pa.pj_nq = use_pre ? pj_nq : nullptr;
   pa.cnt = cnt; pa.fill = fill; pa.hot = hot; pa.zero_words = (uint32_t)zero_words;
   pa.pair_off = pair_off; pa.group_off = group_off; pa.item_off = item_off; pa.tot = tot;
-  pa.pairs = h->pairs.as<uint32_t>(); pa.items = h->items.as<ItemDesc>(); pa.groups = h->groups.as<GroupDesc>();
+  pa.pairs = W->pairs.as<uint32_t>(); pa.items = W->items.as<ItemDesc>(); pa.groups = W->groups.as<GroupDesc>();
   pa.QG = (uint32_t)QG; pa.seg_rows = seg_rows; pa.seg_target = seg_target; pa.hot_ranks = knobs().hot_ranks;
-  pa.status = h->st_word();
+  pa.status = W->st_word();
   if (use_pre) {  // only the bounds behind the slots (n_pj words of 8 bytes; ivf_bounds_off * 8 is a multiple of 16 here? made so below)
-    pa.ff_begin = reinterpret_cast<u32x4*>(h->partials.as<uint64_t>() + h->ivf_bounds_off); pa.ff_vec16 = ((size_t)n_pj * 8 + 15) / 16;
+    pa.ff_begin = reinterpret_cast<u32x4*>(W->partials.as<uint64_t>() + W->ivf_bounds_off); pa.ff_vec16 = ((size_t)n_pj * 8 + 15) / 16;
   } else {        // ordered-chain scans: ivf_merge_kernel reads every slot -- a full-width fill ahead of the planning kernel
-    VERS_HIP_TRY(hipMemsetAsync(h->partials.p, 0xFF, part_bytes, st));
+    VERS_HIP_TRY(hipMemsetAsync(W->partials.p, 0xFF, part_bytes, st));
     pa.ff_begin = nullptr; pa.ff_vec16 = 0;
   }
   pa.stamps = nullptr;
   if (scan_debug_flags() & 16u) {
-    if (int32_t rc = h->stamps.reserve(256)) return rc;
-    pa.stamps = h->stamps.as<unsigned long long>();
+    if (int32_t rc = W->stamps.reserve(256)) return rc;
+    pa.stamps = W->stamps.as<unsigned long long>();
   }
-  pa.grid_ctr = h->grid_ctr.as<uint32_t>(); pa.ctr_base = h->plan_launches * 3u * kPlanBlocks;
-  h->plan_launches += 1;
+  pa.grid_ctr = W->grid_ctr.as<uint32_t>(); pa.ctr_base = W->plan_launches * 3u * kPlanBlocks;
+  W->plan_launches += 1;
   hipLaunchKernelGGL(plan_fused_kernel, dim3(kPlanBlocks), dim3(kPlanThreads), 0, st, pa);
   VERS_HIP_TRY(hipGetLastError());
   if (QG != 1 && !use_pre) {  // (the matrix-core scan gathers its query block from qp while staging it)
-    hipLaunchKernelGGL(gather_qblocks_kernel, dim3((unsigned)groups_bound), dim3(256), 0, st, h->groups.as<GroupDesc>(), tot,
-                       h->pairs.as<uint32_t>(), P, qp, h->ldq, (uint32_t)QG, h->qblocks.as<float>());
+    hipLaunchKernelGGL(gather_qblocks_kernel, dim3((unsigned)groups_bound), dim3(256), 0, st, W->groups.as<GroupDesc>(), tot,
+                       W->pairs.as<uint32_t>(), P, qp, h->ldq, (uint32_t)QG, W->qblocks.as<float>());
     VERS_HIP_TRY(hipGetLastError());
   }
   }  // batch planning
   auto fill_src = [&](auto& src) {
     src.rows = h->rows.as<float>(); src.ld = h->ld; src.list_off = h->slot_off.as<uint32_t>();  // (items name lists by slot)
-    src.list_len = h->slot_len.as<uint32_t>(); src.items = h->items.as<ItemDesc>(); src.n_items_dev = &tot->n_items;
-    src.cnt = cnt; src.pair_off = pair_off; src.pairs = h->pairs.as<uint32_t>(); src.group_off = group_off;
-    src.qblocks = h->qblocks.as<float>(); src.qp = qp; src.ldq = h->ldq; src.P = P; src.S_max = S_max; src.k_keep = k_keep;
-    src.seg_rows = seg_rows; src.seg_target = seg_target; src.pj_pref = pj_pref; src.partials = h->partials.as<uint64_t>();
+    src.list_len = h->slot_len.as<uint32_t>(); src.items = W->items.as<ItemDesc>(); src.n_items_dev = &tot->n_items;
+    src.cnt = cnt; src.pair_off = pair_off; src.pairs = W->pairs.as<uint32_t>(); src.group_off = group_off;
+    src.qblocks = W->qblocks.as<float>(); src.qp = qp; src.ldq = h->ldq; src.P = P; src.S_max = S_max; src.k_keep = k_keep;
+    src.seg_rows = seg_rows; src.seg_target = seg_target; src.pj_pref = pj_pref; src.partials = W->partials.as<uint64_t>();
     src.bound_per_pair = ref_mode ? 1u : 0u;
   };
   int32_t rc;
   if (use_pre) {
     IvfSrc<kPreQ> src; fill_src(src);
     // partial lists of the exact re-scan (fail_list [b] + its count, qflags [n_pj]: in the zeroed zone above)
-    if (int32_t rc2 = h->fb_part.reserve((size_t)std::min<uint32_t>(b, 64) * P * kMergeWaves * top_k * sizeof(uint64_t))) return rc2;
+    if (int32_t rc2 = W->fb_part.reserve((size_t)std::min<uint32_t>(b, 64) * P * kMergeWaves * top_k * sizeof(uint64_t))) return rc2;
     if (int32_t rc2 = launch_prescan(h, src, (uint32_t)items_bound, kp, qflags, quad_ctr, use_shadow, st)) return rc2;
     if (int32_t rc2 = start_pending_ahead(h, st)) return rc2;  // the next batch's coarse quantiser: under this batch's exact finish
     RescoreArgs a;
-    a.partials = h->partials.as<uint64_t>(); a.P = P; a.S_max = S_max; a.kp = kp; a.top_k = top_k; a.d_pad = h->ld;
+    a.partials = W->partials.as<uint64_t>(); a.P = P; a.S_max = S_max; a.kp = kp; a.top_k = top_k; a.d_pad = h->ld;
     a.pj_list = pj_list; a.pj_pref = pj_pref; a.pj_nq = pj_nq; a.list_off = h->slot_off.as<uint32_t>(); a.row_ids = h->row_ids.as<uint32_t>();
     a.rows = h->rows.as<float>(); a.rows_rm = h->rows_rm.as<float>(); a.ld = h->ld; a.qp = qp; a.ldq = h->ldq; a.xmax2_bits = h->pre_misc.as<uint32_t>();
     a.qflags = qflags; a.metric = h->metric; a.force_fail = pre_mode == 2; a.shadow = use_shadow ? 1 : 0; a.debug = scan_debug_flags(); a.fail_list = fail_list; a.stats = h->pre_misc.as<uint32_t>() + 1;
-    a.status = h->st_word(); a.out_ids = out_ids; a.out_dist = out_dist; a.out_count = out_count; a.out_keys = out_keys;
+    a.status = W->st_word(); a.out_ids = out_ids; a.out_dist = out_dist; a.out_count = out_count; a.out_keys = out_keys;
     const int stage_rows = rescore_lds_bytes(h->ld, true) <= 144u * 1024u ? 1 : 0;
     const size_t rs_lds = rescore_lds_bytes(h->ld, stage_rows != 0);
     if (int32_t rc2 = scan_prepare_launch(ivf_rescore_kernel, rs_lds)) return rc2;
@@ -1856,25 +1999,21 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
     VERS_HIP_TRY(hipGetLastError());
     const uint32_t fb_blocks = std::min<uint32_t>(b, 64);
     hipLaunchKernelGGL(fallback_kernel, dim3(fb_blocks), dim3(kWave * kMergeWaves), 0, st, a, (const uint32_t*)h->slot_len.as<uint32_t>(),
-                       (const uint32_t*)fail_list, (const uint32_t*)(fail_list + b), h->fb_part.as<uint64_t>());
+                       (const uint32_t*)fail_list, (const uint32_t*)(fail_list + b), W->fb_part.as<uint64_t>());
     VERS_HIP_TRY(hipGetLastError());
     if (use_shadow) {  // feed the watch word (see vers_ivf::rows_bf)
-      if (!h->fail_watch) {
-        VERS_HIP_TRY(hipHostMalloc((void**)&h->fail_watch, 64, hipHostMallocDefault));
-        *h->fail_watch = 0;
-      }
       h->shadow_queries += b;
       VERS_HIP_TRY(hipMemcpyAsync(h->fail_watch, h->pre_misc.as<uint32_t>() + 1, 4, hipMemcpyDeviceToHost, st));
     }
     h->pre_batches += 1;
-    h->tot_valid = true;
+    W->tot_valid = true;
     if (took) { VERS_HIP_TRY(hipEventRecord(took->freed, st)); took->freed_rec = true; }
     return VERS_OK;
   }
   // ordered-chain scans: 64 result ranks per pass (one pass for top_k <= 64)
   for (uint32_t pass = 0; pass < n_pass; ++pass) {
-    const uint64_t* lower = pass ? h->lower.as<uint64_t>() : nullptr;
-    if (pass) VERS_HIP_TRY(hipMemsetAsync(h->partials.p, 0xFF, part_bytes, st));  // slots and pruning bounds of the previous pass
+    const uint64_t* lower = pass ? W->lower.as<uint64_t>() : nullptr;
+    if (pass) VERS_HIP_TRY(hipMemsetAsync(W->partials.p, 0xFF, part_bytes, st));  // slots and pruning bounds of the previous pass
     if (QG == 1) {
       IvfSrc<1> src; fill_src(src);
       rc = launch_ivf_scan(h, src, (uint32_t)items_bound, st, lower);
@@ -1888,39 +2027,39 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
     if (rc) return rc;
     if (pass == 0)
       if (int32_t rc2 = start_pending_ahead(h, st)) return rc2;
-    hipLaunchKernelGGL(ivf_merge_kernel, dim3(b), dim3(kWave * kMergeWaves), 0, st, h->partials.as<uint64_t>(), P, S_max, k_keep,
+    hipLaunchKernelGGL(ivf_merge_kernel, dim3(b), dim3(kWave * kMergeWaves), 0, st, W->partials.as<uint64_t>(), P, S_max, k_keep,
                        ref_mode, np, pj_list, pj_pref, pj_take, h->slot_off.as<uint32_t>(), h->row_ids.as<uint32_t>(), top_k,
                        pass * (uint32_t)kMaxTopK, out_ids, out_dist, out_count, out_keys,
-                       n_pass > 1 ? h->lower.as<uint64_t>() : (uint64_t*)nullptr);
+                       n_pass > 1 ? W->lower.as<uint64_t>() : (uint64_t*)nullptr);
     VERS_HIP_TRY(hipGetLastError());
   }
-  h->tot_valid = true;
+  W->tot_valid = true;
   if (took) { VERS_HIP_TRY(hipEventRecord(took->freed, st)); took->freed_rec = true; }
   return VERS_OK;
 }
 
-// Stage the queries of a coming batch and rank its lists on the side stream (see vers_ivf::CoarseAhead).
+// Stage the queries of a coming batch and rank its lists on the side stream (see SearchWs::CoarseAhead).
 int32_t coarse_ahead_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint32_t b, uint32_t nprobe, hipStream_t st) {
   if (b == 0 || nprobe == 0 || h->k == 0 || !coarse_on_matrix_cores(h, b)) return VERS_OK;  // nothing to gain: the search does it itself
   const uint32_t P = std::min<uint32_t>(nprobe, h->k);
   if (P + 16 > (uint32_t)kMaxTopK) return VERS_OK;  // ranked exactly inside the search (more lists than the matrix-core selection holds)
-  if (!h->ahead_stream) {
-    VERS_HIP_TRY(hipStreamCreateWithFlags(&h->ahead_stream, hipStreamNonBlocking));
-    VERS_HIP_TRY(hipEventCreateWithFlags(&h->ahead_in, hipEventDisableTiming));
-    for (auto& a : h->ahead) {
+  if (!W->ahead_stream) {
+    VERS_HIP_TRY(hipStreamCreateWithFlags(&W->ahead_stream, hipStreamNonBlocking));
+    VERS_HIP_TRY(hipEventCreateWithFlags(&W->ahead_in, hipEventDisableTiming));
+    for (auto& a : W->ahead) {
       VERS_HIP_TRY(hipEventCreateWithFlags(&a.ready, hipEventDisableTiming));
       VERS_HIP_TRY(hipEventCreateWithFlags(&a.freed, hipEventDisableTiming));
     }
   }
-  for (auto& a : h->ahead)
+  for (auto& a : W->ahead)
     if (a.valid && a.q_dev == q_dev && a.ldq_in == ldq_in && a.b == b && a.P == P) return VERS_OK;  // already prepared
-  vers_ivf::CoarseAhead& a = h->ahead[h->ahead_next];
-  h->ahead_next ^= 1u;
-  hipStream_t side = h->ahead_stream;
+  SearchWs::CoarseAhead& a = W->ahead[W->ahead_next];
+  W->ahead_next ^= 1u;
+  hipStream_t side = W->ahead_stream;
   // after everything already queued on the caller's stream (whatever produced the queries; any search still using
-  // h->gbuf), and after the search that read this slot last
-  VERS_HIP_TRY(hipEventRecord(h->ahead_in, st));
-  VERS_HIP_TRY(hipStreamWaitEvent(side, h->ahead_in, 0));
+  // W->gbuf), and after the search that read this slot last
+  VERS_HIP_TRY(hipEventRecord(W->ahead_in, st));
+  VERS_HIP_TRY(hipStreamWaitEvent(side, W->ahead_in, 0));
   if (a.freed_rec) VERS_HIP_TRY(hipStreamWaitEvent(side, a.freed, 0));
   a.valid = false;
   if (int32_t rc = a.qp.reserve((size_t)round_up(b, kGemmBM) * h->ldq * sizeof(float))) return rc;
@@ -1942,19 +2081,19 @@ int32_t exhaustive_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, 
   }
   const int QG = b == 1 ? 1 : 8;
   const uint32_t n_qg = (b + QG - 1) / QG;
-  if (int32_t rc = h->qil.reserve((size_t)n_qg * h->ldq * QG * sizeof(float))) return rc;
-  if (int32_t rc = launch_stage_queries(q_dev, ldq_in, h->d, h->qil.as<float>(), h->ldq, b, QG, st)) return rc;
+  if (int32_t rc = W->qil.reserve((size_t)n_qg * h->ldq * QG * sizeof(float))) return rc;
+  if (int32_t rc = launch_stage_queries(q_dev, ldq_in, h->d, W->qil.as<float>(), h->ldq, b, QG, st)) return rc;
   const uint32_t target_items = (uint32_t)h->n_cu * scan_blocks_per_cu(QG, h->ld) * kWavesPerBlock;
   uint64_t per = (h->cap_rows * n_qg + target_items - 1) / target_items;
   const uint32_t seg_rows = (uint32_t)std::min<uint64_t>(round_up64(per ? per : 1, kWave), max_seg_rows(h->ld));
   uint32_t n_segs = (uint32_t)((h->cap_rows + seg_rows - 1) / seg_rows);
   if (n_segs == 0) n_segs = 1;
-  if (int32_t rc = h->xpart.reserve((size_t)b * n_segs * top_k * sizeof(uint64_t))) return rc;
+  if (int32_t rc = W->xpart.reserve((size_t)b * n_segs * top_k * sizeof(uint64_t))) return rc;
   const uint32_t n_segs_pad = QG == 1 ? n_segs : round_up(n_segs, 4);
   auto fill = [&](auto& src) {
     src.rows = h->rows.as<float>(); src.n = h->cap_rows; src.ld = h->ld; src.seg_rows = seg_rows; src.n_segs = n_segs;
     src.n_segs_pad = n_segs_pad;
-    src.queries = h->qil.as<float>(); src.ldq = h->ldq; src.b = b; src.partials = h->xpart.as<uint64_t>(); src.k = top_k;
+    src.queries = W->qil.as<float>(); src.ldq = h->ldq; src.b = b; src.partials = W->xpart.as<uint64_t>(); src.k = top_k;
     src.ids = h->row_ids.as<uint32_t>();
   };
   int32_t rc;
@@ -1966,7 +2105,7 @@ int32_t exhaustive_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, 
     rc = launch_seg_scan(h, src, n_segs_pad * n_qg, (int)metric, st);
   }
   if (rc) return rc;
-  hipLaunchKernelGGL(seg_merge_kernel, dim3(b), dim3(kWave * kMergeWaves), 0, st, h->xpart.as<uint64_t>(), n_segs, top_k, out_ids,
+  hipLaunchKernelGGL(seg_merge_kernel, dim3(b), dim3(kWave * kMergeWaves), 0, st, W->xpart.as<uint64_t>(), n_segs, top_k, out_ids,
                      out_dist, out_count);
   VERS_HIP_TRY(hipGetLastError());
   return VERS_OK;
@@ -2012,9 +2151,9 @@ int32_t relayout(vers_ivf* h) {
 }
 
 int32_t ensure_out(vers_ivf* h, size_t need, uint32_t b) {
-  if (int32_t rc = h->o_ids.reserve(need * sizeof(uint64_t))) return rc;
-  if (int32_t rc = h->o_dist.reserve(need * sizeof(float))) return rc;
-  return h->o_cnt.reserve((size_t)b * sizeof(uint32_t));
+  if (int32_t rc = W->o_ids.reserve(need * sizeof(uint64_t))) return rc;
+  if (int32_t rc = W->o_dist.reserve(need * sizeof(float))) return rc;
+  return W->o_cnt.reserve((size_t)b * sizeof(uint32_t));
 }
 
 int32_t upload_queries(const float* queries, uint64_t stride_bytes, uint32_t b, uint32_t d, DevBuf& buf) {
@@ -2026,10 +2165,10 @@ int32_t upload_queries(const float* queries, uint64_t stride_bytes, uint32_t b, 
 int32_t download_results(vers_ivf* h, uint32_t b, uint32_t top_k, uint64_t* out_ids, float* out_dist, uint32_t* out_count) {
   const size_t need = (size_t)b * top_k;
   if (need) {
-    VERS_HIP_TRY(hipMemcpy(out_ids, h->o_ids.p, need * sizeof(uint64_t), hipMemcpyDeviceToHost));
-    VERS_HIP_TRY(hipMemcpy(out_dist, h->o_dist.p, need * sizeof(float), hipMemcpyDeviceToHost));
+    VERS_HIP_TRY(hipMemcpy(out_ids, W->o_ids.p, need * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    VERS_HIP_TRY(hipMemcpy(out_dist, W->o_dist.p, need * sizeof(float), hipMemcpyDeviceToHost));
   }
-  VERS_HIP_TRY(hipMemcpy(out_count, h->o_cnt.p, (size_t)b * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  VERS_HIP_TRY(hipMemcpy(out_count, W->o_cnt.p, (size_t)b * sizeof(uint32_t), hipMemcpyDeviceToHost));
   return VERS_OK;
 }
 
@@ -2050,37 +2189,38 @@ int32_t host_io_begin(vers_ivf* h, const float* queries, uint64_t stride_bytes, 
   io.cnt_off = io.dist_off + need * sizeof(float);
   io.st_off = io.cnt_off + (size_t)b * sizeof(uint32_t);
   io.out_bytes = io.st_off + 16;
-  if (!h->io_stream) VERS_HIP_TRY(hipStreamCreateWithFlags(&h->io_stream, hipStreamNonBlocking));
-  if (int32_t rc = h->io_q.reserve(io.q_bytes)) return rc;
-  if (int32_t rc = h->io_out.reserve(io.out_bytes)) return rc;
+  if (!W->io_stream) VERS_HIP_TRY(hipStreamCreateWithFlags(&W->io_stream, hipStreamNonBlocking));
+  if (W->used && W->last_stream != W->io_stream) VERS_HIP_TRY(hipStreamWaitEvent(W->io_stream, W->done, 0));
+  if (int32_t rc = W->io_q.reserve(io.q_bytes)) return rc;
+  if (int32_t rc = W->io_out.reserve(io.out_bytes)) return rc;
   const size_t pin_need = std::max(io.q_bytes, io.out_bytes);
-  if (pin_need > h->io_pin_cap) {
-    if (h->io_pin) (void)hipHostFree(h->io_pin);
-    h->io_pin = nullptr; h->io_pin_cap = 0;
-    VERS_HIP_TRY(hipHostMalloc(&h->io_pin, pin_need, hipHostMallocDefault));
-    h->io_pin_cap = pin_need;
+  if (pin_need > W->io_pin_cap) {
+    if (W->io_pin) (void)hipHostFree(W->io_pin);
+    W->io_pin = nullptr; W->io_pin_cap = 0;
+    VERS_HIP_TRY(hipHostMalloc(&W->io_pin, pin_need, hipHostMallocDefault));
+    W->io_pin_cap = pin_need;
   }
-  char* base = (char*)h->io_out.p;
-  io.q_dev = h->io_q.as<float>();
+  char* base = (char*)W->io_out.p;
+  io.q_dev = W->io_q.as<float>();
   io.ids_dev = (uint64_t*)(base + io.ids_off);
   io.dist_dev = (float*)(base + io.dist_off);
   io.cnt_dev = (uint32_t*)(base + io.cnt_off);
   for (uint32_t i = 0; i < b; ++i)
-    std::memcpy((char*)h->io_pin + (size_t)i * h->d * 4, (const char*)queries + (size_t)i * stride_bytes, (size_t)h->d * 4);
-  VERS_HIP_TRY(hipMemcpyAsync(io.q_dev, h->io_pin, io.q_bytes, hipMemcpyHostToDevice, h->io_stream));
+    std::memcpy((char*)W->io_pin + (size_t)i * h->d * 4, (const char*)queries + (size_t)i * stride_bytes, (size_t)h->d * 4);
+  VERS_HIP_TRY(hipMemcpyAsync(io.q_dev, W->io_pin, io.q_bytes, hipMemcpyHostToDevice, W->io_stream));
   return VERS_OK;
 }
 
 // copies results + status word back, waits once, maps the status; *out_status_rc carries kRetrySpill etc.
 int32_t host_io_end(vers_ivf* h, const HostIo& io, uint32_t b, uint32_t top_k, uint64_t* out_ids, float* out_dist, uint32_t* out_count) {
-  char* base = (char*)h->io_out.p;
-  VERS_HIP_TRY(hipMemcpyAsync(base + io.st_off, h->st_word(), sizeof(uint32_t), hipMemcpyDeviceToDevice, h->io_stream));
-  VERS_HIP_TRY(hipMemcpyAsync(h->io_pin, base, io.out_bytes, hipMemcpyDeviceToHost, h->io_stream));
-  VERS_HIP_TRY(hipStreamSynchronize(h->io_stream));
-  const char* pin = (const char*)h->io_pin;
+  char* base = (char*)W->io_out.p;
+  VERS_HIP_TRY(hipMemcpyAsync(base + io.st_off, W->st_word(), sizeof(uint32_t), hipMemcpyDeviceToDevice, W->io_stream));
+  VERS_HIP_TRY(hipMemcpyAsync(W->io_pin, base, io.out_bytes, hipMemcpyDeviceToHost, W->io_stream));
+  VERS_HIP_TRY(hipStreamSynchronize(W->io_stream));
+  const char* pin = (const char*)W->io_pin;
   uint32_t s = 0;
   std::memcpy(&s, pin + io.st_off, sizeof(s));
-  if (int32_t rc = status_to_rc(h, s, h->st_slot)) return rc;
+  if (int32_t rc = status_to_rc(h, s, W->st_slot)) return rc;
   const size_t need = (size_t)b * top_k;
   if (need) {
     std::memcpy(out_ids, pin + io.ids_off, need * sizeof(uint64_t));
@@ -2111,20 +2251,7 @@ int32_t vers_ivf_create(int32_t device, uint32_t d, vers_ivf_t** out) {
     hipDeviceProp_t prop;
     VERS_HIP_TRY(hipGetDeviceProperties(&prop, device));
     h->n_cu = prop.multiProcessorCount;
-    if (int32_t rc2 = h->status.reserve(16)) return rc2;
-    VERS_HIP_TRY(hipMemset(h->status.p, 0, 16));
-    if (int32_t rc2 = h->grid_ctr.reserve(16)) return rc2;
-    VERS_HIP_TRY(hipMemset(h->grid_ctr.p, 0, 16));
-    if (scan_debug_flags() & 16u) {  // diagnosis: in-kernel phase stamps
-      if (int32_t rc2 = h->stamps.reserve(256)) return rc2;
-      VERS_HIP_TRY(hipMemset(h->stamps.p, 0, 256));
-    }
-    for (uint32_t i = 0; i < vers_ivf::kEvRing; ++i) {
-      VERS_HIP_TRY(hipEventCreate(&h->ev0[i]));
-      VERS_HIP_TRY(hipEventCreate(&h->ev1[i]));
-    }
-    for (auto& e : h->evc) VERS_HIP_TRY(hipEventCreate(&e));
-    return VERS_OK;
+    return VERS_OK;  // (workspaces -- status words, events, scratch -- are made when calls lease them)
   }();
   if (rc != VERS_OK) {  // nothing half-made leaks: destroy releases whatever was created
     (void)vers_ivf_destroy(h);
@@ -2136,7 +2263,7 @@ int32_t vers_ivf_create(int32_t device, uint32_t d, vers_ivf_t** out) {
 
 int32_t vers_ivf_set_metric(vers_ivf_t* h, uint32_t metric) {
   if (!h || metric > VERS_METRIC_COSDIST) return fail(VERS_ERR_INVALID, "vers_ivf_set_metric: bad arguments");
-  std::lock_guard<std::mutex> lk(h->mu);
+  std::unique_lock<std::shared_mutex> lk(h->index);
   if (h->k != 0 && (int)metric != h->metric) return fail(VERS_ERR_INVALID, "vers_ivf_set_metric: call before build / upload");
   h->metric = (int)metric;
   return VERS_OK;
@@ -2152,21 +2279,8 @@ int32_t vers_ivf_destroy(vers_ivf_t* h) {
   if (!h) return VERS_OK;
   DeviceGuard g(h->device);
   (void)hipDeviceSynchronize();
-  for (uint32_t i = 0; i < vers_ivf::kEvRing; ++i) {
-    if (h->ev0[i]) (void)hipEventDestroy(h->ev0[i]);
-    if (h->ev1[i]) (void)hipEventDestroy(h->ev1[i]);
-  }
-  for (auto& e : h->evc)
-    if (e) (void)hipEventDestroy(e);
-  if (h->io_pin) (void)hipHostFree(h->io_pin);
+  for (auto& w : h->pool) ws_destroy(*w);
   if (h->fail_watch) (void)hipHostFree(h->fail_watch);
-  if (h->io_stream) (void)hipStreamDestroy(h->io_stream);
-  if (h->ahead_stream) {
-    (void)hipStreamSynchronize(h->ahead_stream);
-    (void)hipStreamDestroy(h->ahead_stream);
-    (void)hipEventDestroy(h->ahead_in);
-    for (auto& a : h->ahead) { (void)hipEventDestroy(a.ready); (void)hipEventDestroy(a.freed); }
-  }
   delete h;
   return VERS_OK;
 }
@@ -2179,7 +2293,7 @@ int32_t vers_ivf_build(vers_ivf_t* h, const float* rows, uint64_t n, uint64_t ro
       (num_attempts * num_clusters && !init_indices) || n > 0xFFFFFFFFull || num_clusters > 0xFFFFFFFFull ||
       (out_centroids && num_clusters && c_stride_bytes < (uint64_t)h->d * 4))
     return fail(VERS_ERR_INVALID, "vers_ivf_build: bad arguments");
-  std::lock_guard<std::mutex> lk(h->mu);
+  std::unique_lock<std::shared_mutex> lk(h->index);
   DeviceGuard g(h->device);
   DevBuf X;
   if (int32_t rc = X.reserve((n ? n : 1) * (size_t)h->ldx * sizeof(float))) return rc;
@@ -2201,7 +2315,7 @@ int32_t vers_ivf_build_dev(vers_ivf_t* h, const float* rows_dev, uint64_t n, uin
       (num_attempts * num_clusters && !init_indices) || n > 0xFFFFFFFFull || num_clusters > 0xFFFFFFFFull ||
       (out_centroids && num_clusters && c_stride_bytes < (uint64_t)h->d * 4))
     return fail(VERS_ERR_INVALID, "vers_ivf_build_dev: bad arguments (ld_floats must be >= d and a multiple of 4)");
-  std::lock_guard<std::mutex> lk(h->mu);
+  std::unique_lock<std::shared_mutex> lk(h->index);
   DeviceGuard g(h->device);
   BuildShard one;
   one.n_total = n;
@@ -2220,7 +2334,7 @@ int32_t vers_ivf_build_sharded_dev(vers_ivf_t* h, const float* rows_dev, uint64_
   if (comm->world == 0 || comm->world > 255 || comm->rank >= comm->world ||
       (comm->world > 1 && (!comm->all_gather || !comm->send || !comm->recv || !comm->broadcast || !comm->all_to_all_v)))
     return fail(VERS_ERR_INVALID, "vers_ivf_build_sharded_dev: incomplete vers_comm_t");
-  std::lock_guard<std::mutex> lk(h->mu);
+  std::unique_lock<std::shared_mutex> lk(h->index);
   DeviceGuard g(h->device);
   BuildShard sh;
   sh.comm = comm->world > 1 ? comm : nullptr;
@@ -2252,7 +2366,7 @@ int32_t vers_ivf_upload(vers_ivf_t* h, const float* rows, uint64_t n, uint64_t r
     if (assignments[i] >= k) return fail(VERS_ERR_INVALID, "vers_ivf_upload: assignment out of range");
     a32[i] = (uint32_t)assignments[i];
   }
-  std::lock_guard<std::mutex> lk(h->mu);
+  std::unique_lock<std::shared_mutex> lk(h->index);
   DeviceGuard g(h->device);
   DevBuf X, A;
   if (int32_t rc = X.reserve((n ? n : 1) * (size_t)h->ldx * sizeof(float))) return rc;
@@ -2273,8 +2387,12 @@ int32_t vers_ivf_upload(vers_ivf_t* h, const float* rows, uint64_t n, uint64_t r
 
 int32_t vers_ivf_add(vers_ivf_t* h, const float* row, uint64_t* out_cluster, uint64_t* out_vec_id) {
   if (!h || !row) return fail(VERS_ERR_INVALID, "vers_ivf_add: bad arguments");
-  std::lock_guard<std::mutex> lk(h->mu);
+  std::unique_lock<std::shared_mutex> lk(h->index);
   DeviceGuard g(h->device);
+  VERS_HIP_TRY(hipDeviceSynchronize());  // searches still in flight on any stream read the rows and tables this call changes
+  WsLease lease(h);
+  if (lease.rc) return lease.rc;
+  if (int32_t rc = lease.order_on(nullptr)) return rc;
   if (h->k == 0) return fail(VERS_ERR_EMPTY, "add on an index without centroids (reference: unwrap on None, ivfflat.rs:207)");
   HostStatusSlot slot(h);  // a NaN / spill status latched by an asynchronous _dev search stays there for vers_ivf_poll
   if (h->n_total >= 0xFFFFFFFEull) return fail(VERS_ERR_INVALID, "vec_id space exhausted");
@@ -2284,10 +2402,10 @@ int32_t vers_ivf_add(vers_ivf_t* h, const float* row, uint64_t* out_cluster, uin
   if (int32_t rc = stage_plain_queries(h, q.as<float>(), h->d, 1, &qp, nullptr)) return rc;
   if (int32_t rc = coarse(h, qp, 1, 1, nullptr)) return rc;  // first-minimum centroid (ivfflat.rs:201-207)
   uint64_t key = 0;
-  VERS_HIP_TRY(hipMemcpy(&key, h->probe.p, sizeof(key), hipMemcpyDeviceToHost));
+  VERS_HIP_TRY(hipMemcpy(&key, W->probe.p, sizeof(key), hipMemcpyDeviceToHost));
   uint32_t stw = 0;
-  VERS_HIP_TRY(hipMemcpy(&stw, h->st_word(), 4, hipMemcpyDeviceToHost));
-  if (stw) VERS_HIP_TRY(hipMemset(h->st_word(), 0, 4));
+  VERS_HIP_TRY(hipMemcpy(&stw, W->st_word(), 4, hipMemcpyDeviceToHost));
+  if (stw) VERS_HIP_TRY(hipMemset(W->st_word(), 0, 4));
   if ((stw & kStNaN) && h->k >= 2) return fail(VERS_ERR_NAN, "NaN distance in add (reference panics)");
   const uint32_t c = (uint32_t)key;
   const uint32_t vid = (uint32_t)h->n_total;  // the caller's vec_id is ignored, as in the reference (ivfflat.rs:209)
@@ -2316,8 +2434,11 @@ int32_t vers_ivf_search_dev(vers_ivf_t* h, const float* queries_dev, uint64_t ld
   if (!h) return fail(VERS_ERR_INVALID, "null handle");
   if (b && (!queries_dev || ldq_floats < h->d || !out_count_dev || (top_k && (!out_ids_dev || !out_dist_dev))))
     return fail(VERS_ERR_INVALID, "vers_ivf_search_dev: bad arguments");
-  std::lock_guard<std::mutex> lk(h->mu);
+  std::shared_lock<std::shared_mutex> lk(h->index);
   DeviceGuard g(h->device);
+  WsLease lease(h);
+  if (lease.rc) return lease.rc;
+  if (int32_t rc = lease.order_on((hipStream_t)stream)) return rc;
   return search_dev_locked(h, queries_dev, ldq_floats, b, top_k, nprobe, out_ids_dev, out_dist_dev, out_count_dev, nullptr,
                            (hipStream_t)stream);
 }
@@ -2330,7 +2451,7 @@ int32_t vers_shard_plan(const uint64_t* list_lengths, uint64_t k, uint32_t world
 
 int32_t vers_ivf_set_shard(vers_ivf_t* h, uint32_t rank, uint32_t world) {
   if (!h || world == 0 || world > 255 || rank >= world) return fail(VERS_ERR_INVALID, "vers_ivf_set_shard: bad arguments");
-  std::lock_guard<std::mutex> lk(h->mu);
+  std::unique_lock<std::shared_mutex> lk(h->index);
   if (h->k != 0) return fail(VERS_ERR_INVALID, "vers_ivf_set_shard: call before build / upload");
   h->rank = rank;
   h->world = world;
@@ -2349,18 +2470,21 @@ int32_t vers_ivf_search_partial_dev(vers_ivf_t* h, const float* queries_dev, uin
   if (top_k == 0) return fail(VERS_ERR_INVALID, "vers_ivf_search_partial_dev: top_k must be at least 1");
   if (b && (!queries_dev || ldq_floats < h->d || !out_keys_dev || !out_ids_dev))
     return fail(VERS_ERR_INVALID, "vers_ivf_search_partial_dev: bad arguments");
-  std::lock_guard<std::mutex> lk(h->mu);
+  std::shared_lock<std::shared_mutex> lk(h->index);
   DeviceGuard g(h->device);
+  WsLease lease(h);
+  if (lease.rc) return lease.rc;
+  if (int32_t rc = lease.order_on((hipStream_t)stream)) return rc;
   // distances and counts of the local part are scratch here: the cross-GPU merge recomputes them
   if (int32_t rc = ensure_out(h, (size_t)b * top_k, b)) return rc;
-  return search_dev_locked(h, queries_dev, ldq_floats, b, top_k, nprobe, out_ids_dev, h->o_dist.as<float>(), h->o_cnt.as<uint32_t>(),
+  return search_dev_locked(h, queries_dev, ldq_floats, b, top_k, nprobe, out_ids_dev, W->o_dist.as<float>(), W->o_cnt.as<uint32_t>(),
                            out_keys_dev, (hipStream_t)stream);
 }
 
 int32_t vers_ivf_coarse_ahead_dev(vers_ivf_t* h, const float* queries_dev, uint64_t ldq_floats, uint32_t b, uint32_t nprobe, void* stream) {
   if (!h) return fail(VERS_ERR_INVALID, "null handle");
   if (b && (!queries_dev || ldq_floats < h->d)) return fail(VERS_ERR_INVALID, "vers_ivf_coarse_ahead_dev: bad arguments");
-  std::lock_guard<std::mutex> lk(h->mu);
+  std::lock_guard<std::mutex> lk(h->pool_mu);
   (void)stream;  // (the look-ahead is ordered behind the list scan of the NEXT search on this handle, on that search's stream)
   h->pending.set = b != 0 && nprobe != 0;
   h->pending.q_dev = queries_dev; h->pending.ldq_in = ldq_floats; h->pending.b = b; h->pending.nprobe = nprobe;
@@ -2393,30 +2517,33 @@ int32_t vers_ivf_search(vers_ivf_t* h, const float* queries, uint64_t q_stride_b
   if (b && (!queries || q_stride_bytes < (uint64_t)h->d * 4 || q_stride_bytes % 4 || !out_count || (top_k && (!out_ids || !out_dist))))
     return fail(VERS_ERR_INVALID, "vers_ivf_search: bad arguments");
   if (b == 0) return VERS_OK;
-  std::lock_guard<std::mutex> lk(h->mu);
+  std::shared_lock<std::shared_mutex> lk(h->index);
   DeviceGuard g(h->device);
+  WsLease lease(h);
+  if (lease.rc) return lease.rc;
   HostStatusSlot slot(h);
   HostIo io;
   if (int32_t rc = host_io_begin(h, queries, q_stride_bytes, b, top_k, io)) return rc;
+  lease.st = W->io_stream;
   // Reference mode ranks only as many lists as the spill may need: 16 first (the merge of the coarse partial lists
   // and the plan are what a single-query call waits for), then 48, then 64 with the exact coarse quantiser, and as
   // the last resort ALL of them (ivfflat.rs:166-195 walks the ranked lists as far as it must -- many empty lists with
   // zero centroids make that real); the batch then goes in slices so that the (query, list) tables stay small.
   int32_t rc = VERS_OK;
   for (int attempt = nprobe == 0 ? 0 : 1; attempt < 4; ++attempt) {
-    h->ref_shallow = attempt == 0;
-    h->ref_deep = attempt == 2;
-    h->ref_all = attempt == 3;
+    W->ref_shallow = attempt == 0;
+    W->ref_deep = attempt == 2;
+    W->ref_all = attempt == 3;
     // every attempt starts from zeros: entries past a query's count must not carry a previous attempt's values
-    VERS_HIP_TRY(hipMemsetAsync(h->io_out.p, 0, io.out_bytes, h->io_stream));
+    VERS_HIP_TRY(hipMemsetAsync(W->io_out.p, 0, io.out_bytes, W->io_stream));
     const uint32_t slice = attempt == 3 ? std::max<uint32_t>(1u, 65536u / std::max<uint32_t>(1u, h->k)) : b;
     rc = VERS_OK;
     for (uint32_t q0 = 0; q0 < b && rc == VERS_OK; q0 += slice) {
       const uint32_t bq = std::min(slice, b - q0);
       rc = search_dev_locked(h, io.q_dev + (size_t)q0 * h->d, h->d, bq, top_k, nprobe, io.ids_dev + (size_t)q0 * top_k,
-                             io.dist_dev + (size_t)q0 * top_k, io.cnt_dev + q0, nullptr, h->io_stream);
+                             io.dist_dev + (size_t)q0 * top_k, io.cnt_dev + q0, nullptr, W->io_stream);
     }
-    h->ref_shallow = h->ref_deep = h->ref_all = false;
+    W->ref_shallow = W->ref_deep = W->ref_all = false;
     if (rc) return rc;
     rc = host_io_end(h, io, b, top_k, out_ids, out_dist, out_count);
     if (rc != kRetrySpill) break;
@@ -2432,8 +2559,11 @@ int32_t vers_ivf_search_exhaustive_dev(vers_ivf_t* h, const float* queries_dev, 
   if (top_k > VERS_MAX_TOPK || metric > VERS_METRIC_COSDIST) return fail(VERS_ERR_INVALID, "unsupported top_k / metric");
   if (b && (!queries_dev || ldq_floats < h->d || !out_count_dev || (top_k && (!out_ids_dev || !out_dist_dev))))
     return fail(VERS_ERR_INVALID, "vers_ivf_search_exhaustive_dev: bad arguments");
-  std::lock_guard<std::mutex> lk(h->mu);
+  std::shared_lock<std::shared_mutex> lk(h->index);
   DeviceGuard g(h->device);
+  WsLease lease(h);
+  if (lease.rc) return lease.rc;
+  if (int32_t rc = lease.order_on((hipStream_t)stream)) return rc;
   return exhaustive_dev_locked(h, queries_dev, ldq_floats, b, top_k, metric, out_ids_dev, out_dist_dev, out_count_dev,
                                (hipStream_t)stream);
 }
@@ -2445,14 +2575,17 @@ int32_t vers_ivf_search_exhaustive_partial_dev(vers_ivf_t* h, const float* queri
   if (b && (!queries_dev || ldq_floats < h->d || !out_keys_dev || !out_ids_dev))
     return fail(VERS_ERR_INVALID, "vers_ivf_search_exhaustive_partial_dev: bad arguments");
   if (b == 0) return VERS_OK;
-  std::lock_guard<std::mutex> lk(h->mu);
+  std::shared_lock<std::shared_mutex> lk(h->index);
   DeviceGuard g(h->device);
+  WsLease lease(h);
+  if (lease.rc) return lease.rc;
+  if (int32_t rc = lease.order_on((hipStream_t)stream)) return rc;
   if (int32_t rc = ensure_out(h, (size_t)b * top_k, b)) return rc;
   hipStream_t st = (hipStream_t)stream;
-  if (int32_t rc = exhaustive_dev_locked(h, queries_dev, ldq_floats, b, top_k, metric, h->o_ids.as<uint64_t>(), h->o_dist.as<float>(),
-                                         h->o_cnt.as<uint32_t>(), st)) return rc;
-  hipLaunchKernelGGL(pack_exhaustive_keys_kernel, dim3((b * top_k + 255) / 256), dim3(256), 0, st, (const uint64_t*)h->o_ids.as<uint64_t>(),
-                     (const float*)h->o_dist.as<float>(), (const uint32_t*)h->o_cnt.as<uint32_t>(), b, top_k, out_keys_dev, out_ids_dev);
+  if (int32_t rc = exhaustive_dev_locked(h, queries_dev, ldq_floats, b, top_k, metric, W->o_ids.as<uint64_t>(), W->o_dist.as<float>(),
+                                         W->o_cnt.as<uint32_t>(), st)) return rc;
+  hipLaunchKernelGGL(pack_exhaustive_keys_kernel, dim3((b * top_k + 255) / 256), dim3(256), 0, st, (const uint64_t*)W->o_ids.as<uint64_t>(),
+                     (const float*)W->o_dist.as<float>(), (const uint32_t*)W->o_cnt.as<uint32_t>(), b, top_k, out_keys_dev, out_ids_dev);
   VERS_HIP_TRY(hipGetLastError());
   return VERS_OK;
 }
@@ -2464,13 +2597,16 @@ int32_t vers_ivf_search_exhaustive(vers_ivf_t* h, const float* queries, uint64_t
   if (b && (!queries || q_stride_bytes < (uint64_t)h->d * 4 || q_stride_bytes % 4 || !out_count || (top_k && (!out_ids || !out_dist))))
     return fail(VERS_ERR_INVALID, "vers_ivf_search_exhaustive: bad arguments");
   if (b == 0) return VERS_OK;
-  std::lock_guard<std::mutex> lk(h->mu);
+  std::shared_lock<std::shared_mutex> lk(h->index);
   DeviceGuard g(h->device);
+  WsLease lease(h);
+  if (lease.rc) return lease.rc;
   HostStatusSlot slot(h);
   HostIo io;
   if (int32_t rc = host_io_begin(h, queries, q_stride_bytes, b, top_k, io)) return rc;
-  VERS_HIP_TRY(hipMemsetAsync(h->io_out.p, 0, io.out_bytes, h->io_stream));  // entries past a query's count come back as zeros
-  if (int32_t rc = exhaustive_dev_locked(h, io.q_dev, h->d, b, top_k, metric, io.ids_dev, io.dist_dev, io.cnt_dev, h->io_stream)) return rc;
+  lease.st = W->io_stream;
+  VERS_HIP_TRY(hipMemsetAsync(W->io_out.p, 0, io.out_bytes, W->io_stream));  // entries past a query's count come back as zeros
+  if (int32_t rc = exhaustive_dev_locked(h, io.q_dev, h->d, b, top_k, metric, io.ids_dev, io.dist_dev, io.cnt_dev, W->io_stream)) return rc;
   const int32_t rc = host_io_end(h, io, b, top_k, out_ids, out_dist, out_count);
   return rc == kRetrySpill ? VERS_ERR_INVALID : rc;
 }
@@ -2492,21 +2628,24 @@ int32_t vers_ivf_list_lengths(vers_ivf_t* h, uint64_t* out_lengths) {
 int32_t vers_ivf_last_scan(vers_ivf_t* h, float* out_ms, uint64_t* out_union_rows, uint64_t* out_streamed_rows,
                            uint32_t* out_items) {
   if (!h) return fail(VERS_ERR_INVALID, "null handle");
-  if (h->ev_count == 0 || !h->tot_valid) return fail(VERS_ERR_INVALID, "no list scan has been launched on this handle");
+  UseLastWs use_ws(h);
+  if (!use_ws.ok) return fail(VERS_ERR_INVALID, "no search has run on this handle");
+  if (!h) return fail(VERS_ERR_INVALID, "null handle");
+  if (W->ev_count == 0 || !W->tot_valid) return fail(VERS_ERR_INVALID, "no list scan has been launched on this handle");
   DeviceGuard g(h->device);
-  const uint32_t slot = (uint32_t)((h->ev_count - 1) % vers_ivf::kEvRing);
-  VERS_HIP_TRY(hipEventSynchronize(h->ev1[slot]));
-  if (out_ms) VERS_HIP_TRY(hipEventElapsedTime(out_ms, h->ev0[slot], h->ev1[slot]));
-  const GroupTotals* tot = h->tot_dev;
+  const uint32_t slot = (uint32_t)((W->ev_count - 1) % SearchWs::kEvRing);
+  VERS_HIP_TRY(hipEventSynchronize(W->ev1[slot]));
+  if (out_ms) VERS_HIP_TRY(hipEventElapsedTime(out_ms, W->ev0[slot], W->ev1[slot]));
+  const GroupTotals* tot = W->tot_dev;
   if (!tot) return fail(VERS_ERR_INVALID, "vers_ivf_last_scan: no list scan has run on this handle");
   GroupTotals t;
   VERS_HIP_TRY(hipMemcpy(&t, tot, sizeof(t), hipMemcpyDeviceToHost));
   if (out_union_rows) *out_union_rows = t.union_rows;
   if (out_streamed_rows) *out_streamed_rows = t.streamed_rows;
   if (out_items) *out_items = t.n_items;
-  if ((scan_debug_flags() & 16u) && h->stamps.p) {  // diagnosis only: per-wave phase cycles of the last launch
+  if ((scan_debug_flags() & 16u) && W->stamps.p) {  // diagnosis only: per-wave phase cycles of the last launch
     unsigned long long sv[32] = {};
-    VERS_HIP_TRY(hipMemcpy(sv, h->stamps.p, 256, hipMemcpyDeviceToHost));
+    VERS_HIP_TRY(hipMemcpy(sv, W->stamps.p, 256, hipMemcpyDeviceToHost));
     if (sv[27])
       fprintf(stderr, "[vers stamps] coarse select, per query avg cycles: select %.0f  exact re-score %.0f  sort+certify+emit %.0f\n",
               (double)sv[24] / sv[27], (double)sv[25] / sv[27], (double)sv[26] / sv[27]);
@@ -2528,11 +2667,14 @@ int32_t vers_ivf_last_scan(vers_ivf_t* h, float* out_ms, uint64_t* out_union_row
 
 int32_t vers_ivf_last_coarse_ms(vers_ivf_t* h, float* out_gemm_ms, float* out_select_ms) {
   if (!h) return fail(VERS_ERR_INVALID, "null handle");
-  if (!h->evc_valid) return fail(VERS_ERR_INVALID, "no batched coarse quantiser has run on the matrix cores on this handle");
+  UseLastWs use_ws(h);
+  if (!use_ws.ok) return fail(VERS_ERR_INVALID, "no search has run on this handle");
+  if (!h) return fail(VERS_ERR_INVALID, "null handle");
+  if (!W->evc_valid) return fail(VERS_ERR_INVALID, "no batched coarse quantiser has run on the matrix cores on this handle");
   DeviceGuard g(h->device);
-  VERS_HIP_TRY(hipEventSynchronize(h->evc[2]));
-  if (out_gemm_ms) VERS_HIP_TRY(hipEventElapsedTime(out_gemm_ms, h->evc[0], h->evc[1]));
-  if (out_select_ms) VERS_HIP_TRY(hipEventElapsedTime(out_select_ms, h->evc[1], h->evc[2]));
+  VERS_HIP_TRY(hipEventSynchronize(W->evc[2]));
+  if (out_gemm_ms) VERS_HIP_TRY(hipEventElapsedTime(out_gemm_ms, W->evc[0], W->evc[1]));
+  if (out_select_ms) VERS_HIP_TRY(hipEventElapsedTime(out_select_ms, W->evc[1], W->evc[2]));
   return VERS_OK;
 }
 
@@ -2565,23 +2707,26 @@ int32_t vers_ivf_shadow_state(vers_ivf_t* h, int32_t* out_active, uint64_t* out_
 
 int32_t vers_ivf_scan_times(vers_ivf_t* h, float* out_ms, uint32_t cap, uint32_t* out_n, int32_t reset) {
   if (!h || !out_n || (cap && !out_ms)) return fail(VERS_ERR_INVALID, "bad arguments");
+  UseLastWs use_ws(h);
+  if (!use_ws.ok) { *out_n = 0; return VERS_OK; }  // no search yet
+  if (!h || !out_n || (cap && !out_ms)) return fail(VERS_ERR_INVALID, "bad arguments");
   DeviceGuard g(h->device);
-  const uint64_t have = std::min<uint64_t>(h->ev_count, vers_ivf::kEvRing);
+  const uint64_t have = std::min<uint64_t>(W->ev_count, SearchWs::kEvRing);
   const uint32_t n = (uint32_t)std::min<uint64_t>(have, cap);
   for (uint32_t i = 0; i < n; ++i) {  // oldest first among the last n launches
-    const uint32_t slot = (uint32_t)((h->ev_count - n + i) % vers_ivf::kEvRing);
-    VERS_HIP_TRY(hipEventSynchronize(h->ev1[slot]));
-    VERS_HIP_TRY(hipEventElapsedTime(&out_ms[i], h->ev0[slot], h->ev1[slot]));
+    const uint32_t slot = (uint32_t)((W->ev_count - n + i) % SearchWs::kEvRing);
+    VERS_HIP_TRY(hipEventSynchronize(W->ev1[slot]));
+    VERS_HIP_TRY(hipEventElapsedTime(&out_ms[i], W->ev0[slot], W->ev1[slot]));
   }
   *out_n = n;
-  if (reset) h->ev_count = 0;
+  if (reset) W->ev_count = 0;
   return VERS_OK;
 }
 
 int32_t vers_ivf_get_list(vers_ivf_t* h, uint64_t cluster, float* out_rows, uint64_t row_stride_bytes, uint64_t* out_ids,
                           uint64_t cap_rows, uint64_t* out_len) {
   if (!h || cluster >= h->k || !out_len) return fail(VERS_ERR_INVALID, "vers_ivf_get_list: bad arguments");
-  std::lock_guard<std::mutex> lk(h->mu);
+  std::shared_lock<std::shared_mutex> lk(h->index);
   DeviceGuard g(h->device);
   const uint32_t len = h->h_len[cluster];
   *out_len = len;
