@@ -74,17 +74,20 @@ if pk and f3:
                      "correction": "gfx950 reports half the bytes of wide coalesced streaming reads (MI355X_MICROARCH.md, HBM section): x2",
                      "source": "profiles/r02_summary.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `python3 bench.py --steps 20 --warmup 5 --no-cpu --no-recall --no-extra`)"}
 m = pmc("cfg3/pmc_mfma")
-for sub, label, flops in (("dist_gemm_kernel<false", "coarse GEMM [1024 x 768].[768 x 4096]", 2 * 1024 * 4096 * 768), ("prescan_kernel_g", "list scan", None)):
-    busy, _ = mean_of(m, sub, "SQ_VALU_MFMA_BUSY_CYCLES", 5); gui, _ = mean_of(m, sub, "GRBM_GUI_ACTIVE", 5)
+for sub, label, flops in (("dist_gemm_x3_kernel<false", "coarse contraction [1024 x 768].[768 x 4096] as 3 bf16 products (production)", 2 * 1024 * 4096 * 768),
+                          ("dist_gemm_kernel<false", "coarse contraction, f32 MFMA kernel (bench.py extra.coarse_gemm_f32)", 2 * 1024 * 4096 * 768),
+                          ("prescan_kernel_g", "list scan", None)):
+    busy, _ = mean_of(m, sub, "SQ_VALU_MFMA_BUSY_CYCLES", 2); gui, _ = mean_of(m, sub, "GRBM_GUI_ACTIVE", 2)
     d = [v for k, v in a3.items() if sub in k]
     if busy and gui and d:
         dd = d[0][5:]
-        extra = f"; {flops/(sum(dd)/len(dd))/1e6:.1f} TFLOP/s mean, {flops/min(dd)/1e6:.1f} best = {flops/(sum(dd)/len(dd))/1e6/157.3*100:.1f} % / {flops/min(dd)/1e6/157.3*100:.1f} % of the 157.3 TFLOP/s f32 MFMA peak" if flops else ""
+        dd = d[0][5:] if len(d[0]) > 5 else d[0]
+        extra = f"; {flops/(sum(dd)/len(dd))/1e6:.1f} algorithmic TFLOP/s mean, {flops/min(dd)/1e6:.1f} best = {flops/(sum(dd)/len(dd))/1e6/157.3*100:.1f} % / {flops/min(dd)/1e6/157.3*100:.1f} % of the 157.3 TFLOP/s f32 MFMA peak" if flops else ""
         # busy cycles are summed over the chip's 1024 SIMDs, GRBM_GUI_ACTIVE over its 8 XCDs
         print(f"{label}: SQ_VALU_MFMA_BUSY_CYCLES {busy:.4g} / 1024 SIMDs = {busy/1024:.4g} busy cycles per SIMD; GRBM_GUI_ACTIVE {gui:.4g} / 8 XCDs = "
               f"{gui/8:.4g} kernel cycles -> MFMA-busy {busy/1024/(gui/8)*100:.1f} %; kernel mean {sum(dd)/len(dd):.1f} us (trace){extra}")
 sq = pmc("cfg3/pmc_sq")
-for sub in ("prescan_kernel_g", "coarse_select_rescore", "ivf_rescore_kernel", "plan_fused_kernel"):
+for sub in ("prescan_kernel_g", "coarse_select_rescore", "ivf_rescore_kernel", "plan_fused_kernel", "dist_gemm_x3_kernel<false", "dist_gemm_x3_kernel<true"):
     wc, _ = mean_of(sq, sub, "SQ_WAVE_CYCLES", 5); va, _ = mean_of(sq, sub, "SQ_ACTIVE_INST_VALU", 5); wa, _ = mean_of(sq, sub, "SQ_WAIT_ANY", 5)
     if wc:
         print(f"{sub}: VALU-active {100*(va or 0)/wc:.0f} % of wave cycles, waiting (any) {100*(wa or 0)/wc:.0f} %")
@@ -121,6 +124,8 @@ if len(idx) >= 20:
     while j > 0 and "stage" not in rows[j]["Kernel_Name"]:
         j -= 1
     sel = rows[j:]
+    last = max(i for i, r in enumerate(sel) if "fallback_kernel" in r["Kernel_Name"] or "ivf_merge_kernel" in r["Kernel_Name"])
+    sel = sel[:last + 1]  # (the script times the cross-GPU merge on copies of the partials afterwards: not part of the steps)
     agg = {}
     tot = 0.0
     for r in sel:
