@@ -285,10 +285,10 @@ int32_t vers_topk_merge_dev(const uint64_t* keys_dev, const uint64_t* ids_dev, u
  * exact re-score / certificate kernel behind it. */
 int32_t vers_ivf_last_coarse_ms(vers_ivf_t* h, float* out_gemm_ms, float* out_select_ms);
 /* Batched coarse quantiser statistics: batches that went through the MFMA pre-selection (f32 matrix cores +
- * exact re-score + certificate, csrc/gemm.cuh) and queries whose certificate failed and were re-done exactly. */
+ * exact re-score + certificate, csrc/gemm.hip.h) and queries whose certificate failed and were re-done exactly. */
 int32_t vers_ivf_coarse_stats(vers_ivf_t* h, uint64_t* out_mfma_batches, uint64_t* out_fallback_queries);
 /* Batched list scan statistics (nprobe mode): batches whose list scan ran on the matrix cores (pre-selection +
- * exact re-score + certificate, csrc/prescan.cuh) and queries whose certificate failed and were re-scanned
+ * exact re-score + certificate, csrc/prescan.hip.h) and queries whose certificate failed and were re-scanned
  * exactly.  Results are bit-identical either way; VERS_PRESCAN=0 keeps the ordered-chain scan for every batch. */
 int32_t vers_ivf_prescan_stats(vers_ivf_t* h, uint64_t* out_batches, uint64_t* out_fallback_queries);
 /* EXPERIMENTAL (VERS_SHADOW=1 at build / upload time, off by default): a bf16 shadow copy of the stored rows feeds

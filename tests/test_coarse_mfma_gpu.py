@@ -1,4 +1,4 @@
-"""Batched coarse quantiser on the f32 matrix cores (csrc/gemm.cuh): MFMA pre-selection + exact re-score +
+"""Batched coarse quantiser on the f32 matrix cores (csrc/gemm.hip.h): MFMA pre-selection + exact re-score +
 certificate must give the SAME probe lists -- hence bit-identical search results -- as the exact path, and the
 certificate's fallback (forced here through VERS_COARSE=2) must too."""
 import os

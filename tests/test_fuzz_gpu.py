@@ -1,6 +1,7 @@
 """Randomised sweep of shapes through the C ABI against the oracle (bit-exact): odd dimensions, tiny and
 single-row lists, more lists than vectors, batch sizes around the query-group widths (8/16) and the MFMA
-threshold (32), every top_k/nprobe regime, adds between searches."""
+threshold (32), every top_k/nprobe regime incl. results and probe counts wider than one key per lane, both
+metrics, adds between searches."""
 import numpy as np
 import pytest
 
@@ -24,13 +25,15 @@ CASES = [
 ]
 
 
+@pytest.mark.parametrize("metric", [0, 1], ids=["l2sq", "cosdist"])
 @pytest.mark.parametrize("n,d,k,iters,b", CASES)
-def test_random_shapes(n, d, k, iters, b):
-    rng = np.random.default_rng(n * 31 + d)
+def test_random_shapes(n, d, k, iters, b, metric):
     X = dg.dist_c(n + d, n, d, max(2, k // 2), dg.default_sigma(d))
+    if metric:  # rows of different lengths: 1 - dot is then not a monotone function of the L2 distance
+        X = (X * (0.5 + (np.arange(n) % 5)[:, None] * 0.375)).astype(np.float32)
     init = mg.init_draws(n ^ d, 1, k, n)
-    ix = IVFFlatIndex.build_index(k, 1, iters, X, init_indices=init)
-    ob = co.build_index(X, k, 1, iters, init)
+    ix = IVFFlatIndex.build_index(k, 1, iters, X, init_indices=init, metric=metric)
+    ob = co.build_index(X, k, 1, iters, init, metric=metric)
     assert np.array_equal(ix.assignments, ob["assignments"]) and np.array_equal(bits(ix.centroids), bits(ob["centroids"]))
     assert bits(np.array([ix.cost]))[0] == bits(np.array([ob["cost"]]))[0]
     for x in dg.dist_u(n + 5, 3, d):
@@ -38,14 +41,14 @@ def test_random_shapes(n, d, k, iters, b):
     Q = dg.dist_c(n + d + 1, b, d, max(2, k // 2), dg.default_sigma(d))
     Q[0] = ix.values[n // 2]
     total = ix.values.shape[0]
-    for top_k in sorted({1, min(7, total), min(64, total)}):
-        for nprobe in sorted({0, 1, min(3, k), min(k, 64)}):
+    for top_k in sorted({1, min(7, total), min(64, total), min(150, total)}):   # 150: results wider than one key per lane
+        for nprobe in sorted({0, 1, min(3, k), min(k, 64), min(k, 100)}):          # 100: more ranked lists than one key per lane
             ids, dist, cnt = ix.search_batch(Q, top_k, nprobe)
             for qi in list(range(0, b, max(1, b // 6))) + [b - 1]:
                 if nprobe == 0:
-                    oi, od = co.search_approximate(ix.values, ix.centroids, ix.ids, Q[qi], top_k)
+                    oi, od = co.search_approximate(ix.values, ix.centroids, ix.ids, Q[qi], top_k, metric=metric)
                 else:
-                    oi, od = co.search_nprobe(ix.values, ix.centroids, ix.ids, Q[qi], top_k, nprobe)
+                    oi, od = co.search_nprobe(ix.values, ix.centroids, ix.ids, Q[qi], top_k, nprobe, metric=metric)
                 assert cnt[qi] == len(oi), (top_k, nprobe, qi)
                 assert np.array_equal(ids[qi, :len(oi)], oi), (top_k, nprobe, qi)
                 assert np.array_equal(bits(dist[qi, :len(oi)]), bits(od)), (top_k, nprobe, qi)
@@ -53,9 +56,9 @@ def test_random_shapes(n, d, k, iters, b):
             i1, d1, c1 = ix.search_batch(Q[b // 2], top_k, nprobe)
             assert c1[0] == cnt[b // 2] and np.array_equal(i1[0, :c1[0]], ids[b // 2, :c1[0]]) and np.array_equal(bits(d1[0, :c1[0]]), bits(dist[b // 2, :c1[0]]))
     # exhaustive == utils::search_exhaustive over the same values, both metrics, batched and single
-    for metric in (0, 1):
-        ids, dist, cnt = ix.search_exhaustive(Q[:min(b, 9)], min(10, total), metric)
+    for m2 in (0, 1):
+        ids, dist, cnt = ix.search_exhaustive(Q[:min(b, 9)], min(10, total), m2)
         for qi in range(min(b, 9)):
-            oi, od = co.search_exhaustive(ix.values, Q[qi], min(10, total), metric)
-            assert np.array_equal(ids[qi, :len(oi)], oi) and np.array_equal(bits(dist[qi, :len(oi)]), bits(od)), (metric, qi)
+            oi, od = co.search_exhaustive(ix.values, Q[qi], min(10, total), m2)
+            assert np.array_equal(ids[qi, :len(oi)], oi) and np.array_equal(bits(dist[qi, :len(oi)]), bits(od)), (m2, qi)
     ix.close()

@@ -1,4 +1,4 @@
-"""Batched list scan on the f32 matrix cores (csrc/prescan.cuh): MFMA pre-selection + exact re-score + certificate
+"""Batched list scan on the f32 matrix cores (csrc/prescan.hip.h): MFMA pre-selection + exact re-score + certificate
 + exact re-scan of uncertified queries must return the SAME bits as the ordered-chain scan and the oracle --
 ids, order, distance bits -- on clustered, uniform and heavily tied data, ragged lists, after add(), and with the
 certificate forced to fail."""

@@ -15,7 +15,7 @@ OBJDIR = os.path.join(_HERE, "build")
 LIB = os.path.join(LIBDIR, "libvers_hip.so")
 
 ARCH = "gfx950"
-# -ffp-contract=off: the reference rounds every product and sum separately (no FMA); see csrc/scan.cuh
+# -ffp-contract=off: the reference rounds every product and sum separately (no FMA); see csrc/scan.hip.h
 CXXFLAGS = os.environ.get("VERS_EXTRA_CXXFLAGS", "").split() + ["-O3", "-std=c++17", "-fPIC", "-ffp-contract=off", "-fno-fast-math", f"--offload-arch={ARCH}",
             "-Wall", "-Wno-unused-function"]
 
@@ -42,7 +42,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(LIBDIR, exist_ok=True)
     os.makedirs(OBJDIR, exist_ok=True)
     hipcc = _hipcc()
-    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hpp", ".cuh", ".h"))]
+    headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hpp", ".hip.h", ".h"))]
     headers.append(os.path.join(os.path.dirname(_HERE), "include", "vers_hip.h"))
     objs = []
     procs = []

@@ -5,8 +5,8 @@
 #include <new>
 #include <vector>
 
-#include "scan.cuh"
-#include "util.cuh"
+#include "scan.hip.h"
+#include "util.hip.h"
 
 namespace vers {
 
@@ -71,7 +71,7 @@ struct vers_flat {
   int device = 0;
   uint32_t d = 0, ld = 0;  // ld = round_up(d, kColAlign): columns of the blocked corpus and of padded queries
   uint64_t n = 0;
-  float* rows = nullptr;   // lane-transposed tiles (scan.cuh)
+  float* rows = nullptr;   // lane-transposed tiles (scan.hip.h)
   size_t rows_cap = 0;
   int n_cu = 256;
   // workspace (grown on demand, never inside a steady-state call)

@@ -1,4 +1,4 @@
-// gemm.cuh -- the batched query x centroid contraction of the coarse quantiser on the f32 matrix
+// gemm.hip.h -- the batched query x centroid contraction of the coarse quantiser on the f32 matrix
 // cores (v_mfma_f32_32x32x2_f32), with exact re-scoring and a certificate.
 //
 // The reference ranks centroids by the ordered f32 sum of (c-q)^2 (ivfflat.rs:155-161).  A GEMM
@@ -18,7 +18,7 @@
 // <= d u |.|^2 each ;  MFMA dot = k-ordered fma chain: <= d u |q||c| <= d u S / 2, doubled ;
 // two final roundings <= 2 u (3S).   Total <= (5d + 16) u S =: E.
 #pragma once
-#include "scan.cuh"
+#include "scan.hip.h"
 
 namespace vers {
 

@@ -4,7 +4,7 @@
 // sequential f32 dot, sqrt, true division), so any row can be re-generated on the host.
 #include "common.hpp"
 #include "kmeans.hpp"
-#include "util.cuh"
+#include "util.hip.h"
 
 namespace vers {
 

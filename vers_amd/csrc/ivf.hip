@@ -6,12 +6,12 @@
 // contiguous rows [list_off[c], list_off[c]+list_len[c]) in the reference's list order
 // (ascending vec_id for built rows, append order for added ones), followed by slack for `add`;
 // row_ids[] maps a storage row back to its vec_id.  Lists start on 64-row boundaries and the rows
-// themselves are held in lane-transposed 64-row tiles (scan.cuh), so a list scan is one linear HBM
+// themselves are held in lane-transposed 64-row tiles (scan.hip.h), so a list scan is one linear HBM
 // stream of contiguous 1 KiB wave loads.
 //
 // search = coarse scan over the centroids (top-P keys) -> plan (which lists, per-query sequence
 // bases, reference spill plan) -> group (query,list) pairs by list so a list is streamed once for
-// up to 8 queries -> inverted-list scan (scan.cuh engine) -> per-query merge + id mapping.
+// up to 8 queries -> inverted-list scan (scan.hip.h engine) -> per-query merge + id mapping.
 // Everything is planned on the device; the host never waits inside a search.
 #include <algorithm>
 #include <cstdio>
@@ -24,11 +24,11 @@
 #include <shared_mutex>
 #include <vector>
 
-#include "gemm.cuh"
+#include "gemm.hip.h"
 #include "kmeans.hpp"
-#include "prescan.cuh"
-#include "scan.cuh"
-#include "util.cuh"
+#include "prescan.hip.h"
+#include "scan.hip.h"
+#include "util.hip.h"
 
 namespace vers {
 
@@ -55,7 +55,7 @@ constexpr int32_t kRetrySpill = 1001;  // internal: reference-mode spill ran pas
 
 // ---- sources for the scan engine -----------------------------------------------------------
 // coarse quantiser / exhaustive scan: item = (row segment, query group), slot(q, seg) = q*n_segs + seg;
-// QG > 1: segments padded to a multiple of 4 with empty items (quads share a query block, scan.cuh)
+// QG > 1: segments padded to a multiple of 4 with empty items (quads share a query block, scan.hip.h)
 template <int QG, bool SEQ_IDS>
 struct SegSrc {
   static constexpr bool kSeqIds = SEQ_IDS;
@@ -775,7 +775,7 @@ struct vers_ivf {
   uint64_t n_total = 0;   // assignments.len(): next vec_id handed out by add
   DevBuf centroids;    // [k][ldx] row-major (k-means, read-back)
   DevBuf centroids_b;  // the same in lane-transposed tiles (exact coarse quantiser)
-  // MFMA pre-selection of the batched coarse quantiser (gemm.cuh)
+  // MFMA pre-selection of the batched coarse quantiser (gemm.hip.h)
   DevBuf centroids_g;  // row-major [k_pad][ldq], zero padded
   DevBuf cnorm;        // |c|^2 [k_pad], +inf in the padding
   DevBuf coarse_stat;  // u32: queries that failed the certificate and were re-done exactly
@@ -799,7 +799,7 @@ struct vers_ivf {
   uint64_t cap_rows = 0;
   uint32_t max_len = 0;
   KMeansScratch km;  // build scratch (build / upload hold the handle exclusively)
-  // matrix-core list scan (prescan.cuh): |x|^2 per storage row, [0] max |x|^2 bits, [1] certificate failures (running)
+  // matrix-core list scan (prescan.hip.h): |x|^2 per storage row, [0] max |x|^2 bits, [1] certificate failures (running)
   DevBuf xnorm, pre_misc;
   // bf16 shadow of the rows for the matrix-core pre-selection (+50 % corpus memory; VERS_SHADOW=0 or a failed
   // allocation: the f32 rows feed it).  The wider certificate window makes it sensitive to data with many near-ties:
@@ -1002,7 +1002,7 @@ int32_t refresh_norms(vers_ivf* h, uint64_t r_begin, uint64_t r_end, hipStream_t
   }
   // EXPERIMENTAL, off unless VERS_SHADOW=1: bit-exact on every test, fuzz and A/B run of its final
   // form.  An earlier arrangement of the same arithmetic came out wrong in accumulator register 15 (an MFMA reading an
-  // operand the VALU had just written: prescan.cuh, scripts/probe/mfma_chain.hip); correctness that depends on instruction
+  // operand the VALU had just written: prescan.hip.h, scripts/probe/mfma_chain.hip); correctness that depends on instruction
   // placement soaks before it becomes a default.
   static const bool shadow = [] { const char* e = getenv("VERS_SHADOW"); return e && atoi(e) != 0; }();
   if (shadow) {
@@ -1637,7 +1637,7 @@ inline int coarse_mode() {  // VERS_COARSE: 1 = always exact, 2 = every certific
   return m;
 }
 inline bool coarse_on_matrix_cores(const vers_ivf* h, uint32_t b) { return b >= 32 && coarse_mode() != 1 && !W->ref_deep; }
-// batches: MFMA pre-selection + exact re-score + certificate (gemm.cuh); same output as the exact scan, bit for bit.
+// batches: MFMA pre-selection + exact re-score + certificate (gemm.hip.h); same output as the exact scan, bit for bit.
 // qp: staged queries [round_up(b, kGemmBM)][ldq]; probe_out [b][P].  W->gbuf is the only scratch.
 int32_t coarse_mfma(vers_ivf* h, const float* qp, uint32_t b, uint32_t P, uint64_t* probe_out, hipStream_t st) {
   const uint32_t M_pad = round_up(b, kGemmBM);
@@ -1757,7 +1757,7 @@ int32_t launch_ivf_scan(vers_ivf* h, const IvfSrc<QG>& src, uint32_t items_bound
   return VERS_OK;
 }
 
-// the matrix-core list scan (prescan.cuh); timed through the same event ring as launch_ivf_scan
+// the matrix-core list scan (prescan.hip.h); timed through the same event ring as launch_ivf_scan
 int32_t launch_prescan(vers_ivf* h, const IvfSrc<kPreQ>& src, uint32_t items_bound, uint32_t kp, uint32_t* qflags, uint32_t* quad_ctr,
                        bool shadow, hipStream_t st) {
   PreParams p;
@@ -1849,7 +1849,7 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
   // once per group, so pick the width from the expected queries per list
   int QG = (b == 1 || pairs_est < 2 * lists_est) ? 1 : (pairs_est >= 6 * lists_est ? 16 : 8);
   if (QG != 1 && (knobs().qg == 8 || knobs().qg == 16)) QG = knobs().qg;  // tuning knob
-  // Batches in nprobe mode: the list scan runs on the matrix cores with an exact finish (prescan.cuh); same bits.
+  // Batches in nprobe mode: the list scan runs on the matrix cores with an exact finish (prescan.hip.h); same bits.
   // VERS_PRESCAN=0 keeps the ordered-chain scan, =2 makes every certificate fail (exercises the exact fallback).
   const int pre_mode = knobs().pre_mode;
   // slack of 10 keys: at cfg3 a slack of 6 left ~2 of 1024 queries uncertified per batch, 10 none

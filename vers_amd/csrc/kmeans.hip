@@ -14,9 +14,9 @@
 #include <vector>
 
 #include "kmeans.hpp"
-#include "gemm.cuh"
-#include "scan.cuh"
-#include "util.cuh"
+#include "gemm.hip.h"
+#include "scan.hip.h"
+#include "util.hip.h"
 
 namespace vers {
 
@@ -52,7 +52,7 @@ void DevBuf::release() {
 
 // ---- assign -------------------------------------------------------------------------
 // item = (group of QG points, quarter of the centroid matrix): a quad of items shares the points' query
-// block (scan.cuh), each wave keeps the running first-minimum over its quarter of the centroids.
+// block (scan.hip.h), each wave keeps the running first-minimum over its quarter of the centroids.
 template <int QG>
 struct AssignSrc {
   static constexpr bool kSeqIds = false;

@@ -1,7 +1,7 @@
-// prescan.cuh -- batched inverted-list scan on the f32 matrix cores with an exact finish (nprobe mode, L2).
+// prescan.hip.h -- batched inverted-list scan on the f32 matrix cores with an exact finish (nprobe mode, L2).
 //
-// The reference's distance is an ordered f32 chain (scan.cuh); a matrix-core contraction cannot reproduce its
-// rounding, so -- exactly as in the coarse quantiser (gemm.cuh) -- it is used to PRE-SELECT and the result is
+// The reference's distance is an ordered f32 chain (scan.hip.h); a matrix-core contraction cannot reproduce its
+// rounding, so -- exactly as in the coarse quantiser (gemm.hip.h) -- it is used to PRE-SELECT and the result is
 // then made exact:
 //   (1) prescan_kernel_g: per block a quad of row segments of one
 //       list x the <= 32 queries of one group,
@@ -21,12 +21,12 @@
 //       than the slack, non-finite values) are queued and re-scanned exactly.  Rare, and never wrong.
 //
 // E: |val + |q|^2 - D_ref| <= (5 d + 32) u (|q|^2 + max|x|^2), u = 2^-24, d = padded length -- the bound derived
-// in gemm.cuh with one more product in the chain (the |x|^2 term rides through the MFMA as an extra k step) and
+// in gemm.hip.h with one more product in the chain (the |x|^2 term rides through the MFMA as an extra k step) and
 // slack for the roundings of the test itself, which is evaluated in f64.
 #pragma once
 #include <type_traits>
 
-#include "scan.cuh"
+#include "scan.hip.h"
 
 namespace vers {
 
@@ -791,7 +791,7 @@ struct FbSrc {
 };
 
 // ONE launch: block i takes every gridDim.x-th queued query, scans its P probed lists one after the other (16 waves, each
-// the ring-pipelined single-query item of scan.cuh over its share of the list's tiles), folds the P x 16 partial lists and
+// the ring-pipelined single-query item of scan.hip.h over its share of the list's tiles), folds the P x 16 partial lists and
 // emits.  Exits at once when nothing is queued -- the normal case: 64 blocks, ~3 us.  (Round 1 used a P x 64 grid of
 // 1024-thread blocks plus a merge launch: 11.5 us per batch with nothing to do, and 2048 fat blocks in the way of
 // whatever else wants the CUs.)  A queued query costs one CU a pass over its lists (~1-2 ms at cfg3): rare by design.

@@ -1,4 +1,4 @@
-// scan.cuh -- the exact-order distance engine and wave top-k shared by every
+// scan.hip.h -- the exact-order distance engine and wave top-k shared by every
 // kernel of the path (flat scan, coarse quantiser, inverted-list scan, k-means
 // assign).  gfx950 only.
 //

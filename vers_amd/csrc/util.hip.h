@@ -1,4 +1,4 @@
-// util.cuh -- small host/device helpers shared by the translation units of libvers_hip.so.
+// util.hip.h -- small host/device helpers shared by the translation units of libvers_hip.so.
 #pragma once
 #include "common.hpp"
 
@@ -47,7 +47,7 @@ inline int32_t launch_stage_queries(const float* in, uint64_t ld_in, uint32_t d,
   return VERS_OK;
 }
 
-// ---- row-major <-> lane-transposed tiles (layout: scan.cuh, blocked_index) -----------------------
+// ---- row-major <-> lane-transposed tiles (layout: scan.hip.h, blocked_index) -----------------------
 // in: [n][ld_in] row-major (first d columns valid).  out: ceil(n/64) tiles of 64 x ld; rows >= n and
 // columns >= d are zero.  One thread per output float4.
 static __global__ void to_blocked_kernel(const float* in, uint64_t ld_in, uint32_t d, uint64_t n, float* out, uint32_t ld) {
