@@ -258,7 +258,9 @@ int32_t vers_ivf_build_sharded_dev(vers_ivf_t* h, const float* rows_dev, uint64_
 /* Process-wide tuning switches (the environment variables of DESIGN.md section 5 are read once; this sets one at run time
  * for same-process A/B measurements).  "gemm_x3": bit 0 the k-means assign contraction, bit 1 the coarse quantiser's
  * contraction run as three bf16 MFMA products of hi/lo-split operands (default 3) instead of the f32 MFMA kernel (0).
- * Results are bit-identical either way: both are pre-filters behind an exact re-score and a certificate. */
+ * Results are bit-identical either way: both are pre-filters behind an exact re-score and a certificate.
+ * "shadow": 1 (default) = indexes built / uploaded from now on keep an fp16 shadow of their rows for the batched list
+ * scan (vers_ivf_shadow_state); 0 = none, and searches on existing handles read their f32 rows until it is 1 again. */
 int32_t vers_set_option(const char* name, int64_t value);
 /* Device memory the library holds in this process right now (rows, ids, scratch of every handle) and its high-water
  * mark since the last reset -- lets a test assert that no rank of a sharded build ever allocated the whole corpus. */
@@ -291,11 +293,11 @@ int32_t vers_ivf_coarse_stats(vers_ivf_t* h, uint64_t* out_mfma_batches, uint64_
  * exact re-score + certificate, csrc/prescan.hip.h) and queries whose certificate failed and were re-scanned
  * exactly.  Results are bit-identical either way; VERS_PRESCAN=0 keeps the ordered-chain scan for every batch. */
 int32_t vers_ivf_prescan_stats(vers_ivf_t* h, uint64_t* out_batches, uint64_t* out_fallback_queries);
-/* EXPERIMENTAL (VERS_SHADOW=1 at build / upload time, off by default): a bf16 shadow copy of the stored rows feeds
- * the matrix-core pre-selection of batched searches -- half the HBM bytes per scan, +50 % corpus memory, wider
- * certificate window, same exact finish (results stay bit-identical).  Skipped when the allocation fails; switched off
- * for the handle when more than 1/8 of the queries failed the certificate (data with many near-ties).
- * out_active: 1 = in use. */
+/* An fp16 shadow copy of the stored rows (+50 % corpus memory) feeds the matrix-core pre-selection of batched searches:
+ * half the HBM bytes per list scan, a ~2x wider certificate window, the same exact f32 finish -- results stay
+ * bit-identical.  On by default (VERS_SHADOW=0 or vers_set_option("shadow", 0) before build / upload: f32 rows feed the
+ * scan); skipped when its allocation fails; switched off for the handle when more than 1/8 of the queries failed the
+ * certificate (data with many near-ties, or elements outside fp16's range).  out_active: 1 = in use. */
 int32_t vers_ivf_shadow_state(vers_ivf_t* h, int32_t* out_active, uint64_t* out_bytes);
 /* Durations (ms) of the most recent list-scan launches, oldest first (ring of 64); reset != 0
  * empties the ring.  Lets bench.py time every launch of the timed region without stalling it. */

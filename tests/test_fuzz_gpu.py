@@ -1,7 +1,7 @@
 """Randomised sweep of shapes through the C ABI against the oracle (bit-exact): odd dimensions, tiny and
 single-row lists, more lists than vectors, batch sizes around the query-group widths (8/16) and the MFMA
 threshold (32), every top_k/nprobe regime incl. results and probe counts wider than one key per lane, both
-metrics, adds between searches."""
+metrics, the batched list scan fed by the fp16 shadow rows (default) and by the f32 rows, adds between searches."""
 import numpy as np
 import pytest
 
@@ -25,14 +25,23 @@ CASES = [
 ]
 
 
+@pytest.fixture
+def shadow_option(request):
+    capi.set_option("shadow", request.param)   # (the handle reads it at build time)
+    yield request.param
+    capi.set_option("shadow", 1)
+
+
+@pytest.mark.parametrize("shadow_option", [1, 0], ids=["fp16shadow", "f32rows"], indirect=True)
 @pytest.mark.parametrize("metric", [0, 1], ids=["l2sq", "cosdist"])
 @pytest.mark.parametrize("n,d,k,iters,b", CASES)
-def test_random_shapes(n, d, k, iters, b, metric):
+def test_random_shapes(n, d, k, iters, b, metric, shadow_option):
     X = dg.dist_c(n + d, n, d, max(2, k // 2), dg.default_sigma(d))
     if metric:  # rows of different lengths: 1 - dot is then not a monotone function of the L2 distance
         X = (X * (0.5 + (np.arange(n) % 5)[:, None] * 0.375)).astype(np.float32)
     init = mg.init_draws(n ^ d, 1, k, n)
     ix = IVFFlatIndex.build_index(k, 1, iters, X, init_indices=init, metric=metric)
+    assert ix.shadow_state()["active"] == bool(shadow_option)
     ob = co.build_index(X, k, 1, iters, init, metric=metric)
     assert np.array_equal(ix.assignments, ob["assignments"]) and np.array_equal(bits(ix.centroids), bits(ob["centroids"]))
     assert bits(np.array([ix.cost]))[0] == bits(np.array([ob["cost"]]))[0]

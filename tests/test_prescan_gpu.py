@@ -1,4 +1,5 @@
-"""Batched list scan on the f32 matrix cores (csrc/prescan.hip.h): MFMA pre-selection + exact re-score + certificate
+"""Batched list scan on the matrix cores (csrc/prescan.hip.h; fp16 shadow rows by default, f32 rows with VERS_SHADOW=0):
+MFMA pre-selection + exact re-score + certificate
 + exact re-scan of uncertified queries must return the SAME bits as the ordered-chain scan and the oracle --
 ids, order, distance bits -- on clustered, uniform and heavily tied data, ragged lists, after add(), and with the
 certificate forced to fail."""
@@ -61,9 +62,9 @@ check(ix, Q, 10, 6, step=3)
 total += 1
 st = ix.prescan_stats()
 print("TIES", st["batches"], st["fallback_queries"])
-# ... the experimental bf16 shadow keeps 48 keys: it takes 100 copies of every vector to defeat its certificate, and
-# then the failure watch must switch it off for the handle (once 1/8 of >= 256 queries had to be re-scanned exactly)
-if os.environ.get("VERS_SHADOW", "0") == "1" and os.environ.get("VERS_PRESCAN", "1") == "1":
+# ... the fp16 shadow (the default) keeps top_k + 24 keys: 100 copies of every vector defeat its certificate on every query,
+# and then the failure watch must switch it off for the handle (once 1/8 of >= 256 queries had to be re-scanned exactly)
+if os.environ.get("VERS_SHADOW", "1") != "0" and os.environ.get("VERS_PRESCAN", "1") == "1":
     X2 = np.repeat(B[:60], 100, axis=0)
     ix2 = IVFFlatIndex.build_index(8, 1, 2, X2, init_indices=mg.init_draws(0xA3, 1, 8, X2.shape[0]))
     assert ix2.shadow_state()["active"]
@@ -71,6 +72,14 @@ if os.environ.get("VERS_SHADOW", "0") == "1" and os.environ.get("VERS_PRESCAN", 
         check(ix2, Q, 10, 4, step=9)
     assert not ix2.shadow_state()["active"], "the failure watch did not switch the shadow off"
     check(ix2, Q, 10, 4, step=5)
+# (3a) ONE query of the batch fails (it equals a vector stored 70 times, the others see no ties): its exact re-scan is
+#      spread over a whole group of blocks, each list cut into chunks of tiles
+X = dg.dist_c(0xD1, 6000, 96, 40, dg.default_sigma(96)); X[100:170] = X[100]
+ix = IVFFlatIndex.build_index(10, 1, 2, X, init_indices=mg.init_draws(0xD1, 1, 10, 6000))
+Qs = dg.dist_c(0xD2, 48, 96, 40, dg.default_sigma(96)); Qs[5] = X[100]
+f0 = ix.prescan_stats()["fallback_queries"]
+check(ix, Qs, 10, 6, step=1)
+print("ONE", ix.prescan_stats()["fallback_queries"] - f0)
 # (3b) duplicated rows leave k-means clusters empty (zero centroids at distance |q|^2 = 1, nearer than other modes'
 #      centroids): most queries probe nothing but empty lists and must come back with count 0
 X = dg.dist_c(0xC1, 4500, 130, 72, dg.default_sigma(130)); X[2250:] = X[:2250]
@@ -94,25 +103,28 @@ def run(env_extra):
     env = dict(os.environ); env.update(env_extra); env["PYTHONPATH"] = ROOT
     r = subprocess.run([sys.executable, "-c", BODY], capture_output=True, text=True, env=env, cwd=ROOT, timeout=1200)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
-    return {l.split()[0]: tuple(int(v) for v in l.split()[1:]) for l in r.stdout.splitlines() if l[:4] in ("TIES", "HUGE", "TOTA")}
+    return {l.split()[0]: tuple(int(v) for v in l.split()[1:]) for l in r.stdout.splitlines() if l[:4] in ("TIES", "HUGE", "TOTA") or l[:3] == "ONE"}
 
 
 def test_matrix_core_list_scan_is_bit_exact():
-    out = run({})
+    out = run({})                                               # the default: fp16 shadow rows feed the pre-selection
     assert out["TIES"][0] == 1 and out["TIES"][1] > 0          # ties denser than the slack fail the certificate ...
     assert out["HUGE"] == (1, 64)                               # ... and so does every query whose values overflow
+    assert out["ONE"] == (1,)
+
+
+def test_f32_rows_feed_the_scan_without_the_shadow():
+    out = run({"VERS_SHADOW": "0"})
+    assert out["TIES"][0] == 1 and out["TIES"][1] > 0 and out["HUGE"] == (1, 64) and out["ONE"] == (1,)
 
 
 def test_forced_certificate_failure_is_exact():
     out = run({"VERS_PRESCAN": "2"})
+    assert out["TIES"] == (1, 64)
+    out = run({"VERS_PRESCAN": "2", "VERS_SHADOW": "0"})
     assert out["TIES"] == (1, 64)
 
 
 def test_ordered_chain_scan_still_available():
     out = run({"VERS_PRESCAN": "0"})
     assert out["TIES"] == (0, 0) and out["HUGE"] == (0, 0)
-
-
-def test_experimental_bf16_shadow_is_bit_exact_and_watched():
-    out = run({"VERS_SHADOW": "1"})       # bf16 rows feed the pre-selection; the failure watch switches it off on heavily tied data
-    assert out["TIES"][0] == 1 and out["HUGE"] == (1, 64)

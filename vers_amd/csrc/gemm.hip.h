@@ -42,6 +42,26 @@ static __global__ void row_norms_kernel(const float* C, uint32_t ld, uint32_t k,
   out[n] = acc;
 }
 
+// Block -> tile.  The grid is one-dimensional and the hardware deals consecutive workgroups round-robin over the 8 XCDs,
+// each with its own 4 MB L2.  grp == 0: column tile fastest (a small problem that is resident as a whole: the coarse
+// quantiser).  grp > 0 (needs m_tiles % (8 * grp) == 0): XCD x owns the row tiles [x * m_tiles/8, (x+1) * m_tiles/8) and
+// walks them in chunks of grp tiles (grp * 128 rows of the M operand = 1.5 MB at K = 768 stay in ITS L2) against every
+// column tile in turn, so a column tile is fetched once per chunk and XCD -- and because the XCDs advance in step, one
+// of those 8 fetches comes from HBM and seven from the Infinity Cache.  The k-means assign pass (M = centroids, N = the
+// batch of points, 400 MB) with the plain order re-read the points from HBM once per centroid tile: 32 x at k = 4096.
+__device__ __forceinline__ void gemm_tile_coords(uint32_t m_tiles, uint32_t n_tiles, uint32_t grp, uint32_t& tm, uint32_t& tn) {
+  const uint32_t L = blockIdx.x;
+  if (grp == 0) { tn = L % n_tiles; tm = L / n_tiles; return; }
+  const uint32_t xcd = L & 7u, j = L >> 3, per_xcd = m_tiles >> 3;
+  const uint32_t chunk = j / (grp * n_tiles), w = j % (grp * n_tiles);
+  tn = w / grp;
+  tm = xcd * per_xcd + chunk * grp + w % grp;
+}
+inline uint32_t gemm_tile_group(uint32_t m_tiles) {  // host side: the chunk for an M operand that is worth keeping in L2
+  for (uint32_t g : {4u, 2u, 1u}) if (m_tiles % (8u * g) == 0) return g;
+  return 0;
+}
+
 // Epilogue shared by the two contraction kernels (the C/D layout of the 32x32 MFMAs does not depend on the input type):
 // col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5).  `lds` is the block's (dead) operand storage.
 template <bool NORM_ROWS>
@@ -115,7 +135,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[2][2], float* lds, c
       for (int b = 0; b < 2; ++b) {
         const float* t = xs + ((wc * 2 + b) * 32 + r) * 3;
         fold(bv1[b], bc1[b], bv2[b], t[0], __float_as_uint(t[1]), t[2]);
-        const uint64_t o = (uint64_t)blockIdx.y * N_pad + n0 + wc * 64 + b * 32 + r;
+        const uint64_t o = (uint64_t)(m0 / kGemmBM) * N_pad + n0 + wc * 64 + b * 32 + r;
         part_v1[o] = bv1[b]; part_c1[o] = bc1[b]; part_v2[o] = bv2[b];
       }
     }
@@ -134,20 +154,22 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[2][2], float* lds, c
 // columns of the operands are zero, so padded entries come out as 0 (the selections only look at real ones).
 // NORM_ROWS = true does not write G at all: its epilogue reduces the block's 128 x 128 tile to, per point (column),
 // the smallest value, its centroid and the second smallest over the tile's 128 centroids (rows m < k_rows) and writes
-// that triple to part_*[blockIdx.y][n] -- 12 bytes per (row tile, point) instead of 512; assign_argmin_merge_kernel
+// that triple to part_*[row tile][n] -- 12 bytes per (row tile, point) instead of 512; assign_argmin_merge_kernel
 // folds the k/128 triples of a point.  (Round 1 wrote Gt -- 2.1 GB per 131072-point batch at k = 4096 -- and read it
 // back in a separate arg-min kernel.)
 template <bool NORM_ROWS>
 static __global__ __launch_bounds__(256) void dist_gemm_kernel(const float* __restrict__ Q, const float* __restrict__ C,
                                                                const float* __restrict__ cnorm, uint32_t K, uint32_t N_pad,
-                                                               float* __restrict__ G, int metric, uint32_t k_rows = 0,
+                                                               float* __restrict__ G, int metric, uint32_t m_tiles, uint32_t n_tiles, uint32_t grp, uint32_t k_rows = 0,
                                                                float* __restrict__ part_v1 = nullptr, uint32_t* __restrict__ part_c1 = nullptr,
                                                                float* __restrict__ part_v2 = nullptr) {
   __shared__ __attribute__((aligned(16))) float As[kGemmBM * kGemmLds];
   __shared__ __attribute__((aligned(16))) float Bs[kGemmBN * kGemmLds];
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wr = wid >> 1, wc = wid & 1;  // wave position inside the block tile
-  const uint32_t m0 = blockIdx.y * kGemmBM, n0 = blockIdx.x * kGemmBN;
+  uint32_t tile_m, tile_n;
+  gemm_tile_coords(m_tiles, n_tiles, grp, tile_m, tile_n);
+  const uint32_t m0 = tile_m * kGemmBM, n0 = tile_n * kGemmBN;
   f32x16 acc[2][2];
 #pragma unroll
   for (int a = 0; a < 2; ++a)
@@ -217,18 +239,27 @@ constexpr float kX3Slack = 1.6e-5f;  // >= 2 * 3 * 2^-18 (G = norm - 2 dot doubl
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
 constexpr int kX3Pitch = 40;  // bf16 per LDS row: 32 of a K-tile + 8 of padding (80 bytes: conflict-free ds_read_b128 by row)
+constexpr size_t kX3LdsBytes = 2 * 2 * 2 * (size_t)kGemmBM * kX3Pitch * 2;  // two buffers x A|B x hi|lo = 80 KB: two blocks per CU
 
 template <bool NORM_ROWS>
-static __global__ __launch_bounds__(256) void dist_gemm_x3_kernel(const float* __restrict__ Q, const float* __restrict__ C,
+static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void dist_gemm_x3_kernel(const float* __restrict__ Q, const float* __restrict__ C,
                                                                   const float* __restrict__ cnorm, uint32_t K, uint32_t N_pad,
-                                                                  float* __restrict__ G, int metric, uint32_t k_rows = 0,
+                                                                  float* __restrict__ G, int metric, uint32_t m_tiles, uint32_t n_tiles, uint32_t grp, uint32_t k_rows = 0,
                                                                   float* __restrict__ part_v1 = nullptr, uint32_t* __restrict__ part_c1 = nullptr,
                                                                   float* __restrict__ part_v2 = nullptr) {
-  // [matrix A|B][part hi|lo][128 rows][kX3Pitch] bf16 = 40 KB
-  __shared__ __attribute__((aligned(16))) __bf16 T[2][2][kGemmBM * kX3Pitch];
+  // [buffer][matrix A|B][part hi|lo][128 rows][kX3Pitch] bf16 = 2 x 40 KB: the split tile of step k+1 is written while the
+  // MFMAs of step k read the other buffer (ONE barrier per K-tile), and the global loads run TWO tiles ahead in
+  // registers -- with the MFMA time of a tile down to ~770 cycles a single tile of prefetch no longer covers the L2 /
+  // Infinity-Cache latency (the first cut of this kernel, single-buffered with one tile of prefetch: 3.83 ms per
+  // 131072 x 4096 x 768 assign batch).
+  extern __shared__ __attribute__((aligned(16))) __bf16 T[];
+  constexpr int kPart = kGemmBM * kX3Pitch;  // one [128][kX3Pitch] array
+  auto Tp = [&](int buf, int mat, int part) { return T + ((buf * 2 + mat) * 2 + part) * kPart; };
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int wr = wid >> 1, wc = wid & 1;
-  const uint32_t m0 = blockIdx.y * kGemmBM, n0 = blockIdx.x * kGemmBN;
+  uint32_t tile_m, tile_n;
+  gemm_tile_coords(m_tiles, n_tiles, grp, tile_m, tile_n);
+  const uint32_t m0 = tile_m * kGemmBM, n0 = tile_n * kGemmBN;
   f32x16 acc[2][2];
 #pragma unroll
   for (int a = 0; a < 2; ++a)
@@ -237,12 +268,13 @@ static __global__ __launch_bounds__(256) void dist_gemm_x3_kernel(const float* _
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.0f;
   const int srow = tid >> 3, sc4 = tid & 7;  // rows srow + 32*i, float4 column sc4
-  f32x4 ra[4], rb[4];
-  auto gload = [&](uint32_t k0) {
+  f32x4 ra[2][4], rb[2][4];
+  auto gload = [&](auto stag, uint32_t k0) {
+    constexpr int S = decltype(stag)::value;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      ra[i] = *reinterpret_cast<const f32x4*>(Q + (uint64_t)(m0 + srow + 32 * i) * K + k0 + sc4 * 4);
-      rb[i] = *reinterpret_cast<const f32x4*>(C + (uint64_t)(n0 + srow + 32 * i) * K + k0 + sc4 * 4);
+      ra[S][i] = *reinterpret_cast<const f32x4*>(Q + (uint64_t)(m0 + srow + 32 * i) * K + k0 + sc4 * 4);
+      rb[S][i] = *reinterpret_cast<const f32x4*>(C + (uint64_t)(n0 + srow + 32 * i) * K + k0 + sc4 * 4);
     }
   };
   auto split_store = [&](const f32x4& x, __bf16* hi_row, __bf16* lo_row) {
@@ -255,31 +287,27 @@ static __global__ __launch_bounds__(256) void dist_gemm_x3_kernel(const float* _
     *reinterpret_cast<bf16x4*>(hi_row + sc4 * 4) = h;
     *reinterpret_cast<bf16x4*>(lo_row + sc4 * 4) = l;
   };
-  auto lstore = [&]() {
+  auto lstore = [&](auto stag, int buf) {
+    constexpr int S = decltype(stag)::value;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int row = srow + 32 * i;
-      split_store(ra[i], T[0][0] + row * kX3Pitch, T[0][1] + row * kX3Pitch);
-      split_store(rb[i], T[1][0] + row * kX3Pitch, T[1][1] + row * kX3Pitch);
+      split_store(ra[S][i], Tp(buf, 0, 0) + row * kX3Pitch, Tp(buf, 0, 1) + row * kX3Pitch);
+      split_store(rb[S][i], Tp(buf, 1, 0) + row * kX3Pitch, Tp(buf, 1, 1) + row * kX3Pitch);
     }
   };
   const int r = lane & 31, hh = lane >> 5;
-  gload(0);
-  for (uint32_t k0 = 0; k0 < K; k0 += kGemmBK) {
-    __syncthreads();  // previous tile's readers done
-    lstore();
-    __syncthreads();
-    if (k0 + kGemmBK < K) gload(k0 + kGemmBK);  // next tile in flight under the MFMAs
+  auto compute = [&](int buf) {
 #pragma unroll
     for (int s2 = 0; s2 < 2; ++s2) {  // two k-steps of 16
       bf16x8 ah[2], al[2], bh[2], bl[2];
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
         const int ko = 16 * s2 + 8 * hh;
-        ah[t] = *reinterpret_cast<const bf16x8*>(T[0][0] + (wr * 64 + t * 32 + r) * kX3Pitch + ko);
-        al[t] = *reinterpret_cast<const bf16x8*>(T[0][1] + (wr * 64 + t * 32 + r) * kX3Pitch + ko);
-        bh[t] = *reinterpret_cast<const bf16x8*>(T[1][0] + (wc * 64 + t * 32 + r) * kX3Pitch + ko);
-        bl[t] = *reinterpret_cast<const bf16x8*>(T[1][1] + (wc * 64 + t * 32 + r) * kX3Pitch + ko);
+        ah[t] = *reinterpret_cast<const bf16x8*>(Tp(buf, 0, 0) + (wr * 64 + t * 32 + r) * kX3Pitch + ko);
+        al[t] = *reinterpret_cast<const bf16x8*>(Tp(buf, 0, 1) + (wr * 64 + t * 32 + r) * kX3Pitch + ko);
+        bh[t] = *reinterpret_cast<const bf16x8*>(Tp(buf, 1, 0) + (wc * 64 + t * 32 + r) * kX3Pitch + ko);
+        bl[t] = *reinterpret_cast<const bf16x8*>(Tp(buf, 1, 1) + (wc * 64 + t * 32 + r) * kX3Pitch + ko);
       }
 #pragma unroll
       for (int a = 0; a < 2; ++a)
@@ -290,10 +318,51 @@ static __global__ __launch_bounds__(256) void dist_gemm_x3_kernel(const float* _
           acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bh[b], acc[a][b], 0, 0, 0);
         }
     }
+  };
+  using S0 = std::integral_constant<int, 0>;
+  using S1 = std::integral_constant<int, 1>;
+  // tiles: t = k0 / 32.  Registers hold tiles t+1 (slot (t+1)&1) and t+2 while LDS buffer t&1 is read.
+  const uint32_t k_tiles = K / kGemmBK;
+  gload(S0{}, 0);
+  if (k_tiles > 1) gload(S1{}, kGemmBK);
+  lstore(S0{}, 0);
+  if (k_tiles > 2) gload(S0{}, 2 * kGemmBK);
+  __syncthreads();
+  for (uint32_t t = 0; t < k_tiles; t += 2) {
+    // even tile t: LDS buffer 0; registers: slot 1 = tile t+1, slot 0 = tile t+2
+    if (t + 1 < k_tiles) lstore(S1{}, 1);             // tile t+1 -> buffer 1 (its readers finished before the last barrier)
+    if (t + 3 < k_tiles) gload(S1{}, (t + 3) * kGemmBK);
+    compute(0);
+    __syncthreads();
+    if (t + 1 >= k_tiles) break;
+    // odd tile t+1: LDS buffer 1; registers: slot 0 = tile t+2, slot 1 = tile t+3
+    if (t + 2 < k_tiles) lstore(S0{}, 0);
+    if (t + 4 < k_tiles) gload(S0{}, (t + 4) * kGemmBK);
+    compute(1);
+    __syncthreads();
   }
   __syncthreads();  // (the epilogue re-uses the operand storage)
-  gemm_epilogue<NORM_ROWS>(acc, reinterpret_cast<float*>(&T[0][0][0]), cnorm, N_pad, G, metric, k_rows, part_v1, part_c1, part_v2, m0, n0, wr, wc,
-                           r, hh);
+  gemm_epilogue<NORM_ROWS>(acc, reinterpret_cast<float*>(T), cnorm, N_pad, G, metric, k_rows, part_v1, part_c1, part_v2, m0, n0, wr, wc, r, hh);
+}
+
+// Launch of either contraction kernel (the bf16x3 one needs the attribute for its 80 KB of dynamic LDS: set once per
+// instantiation and process).
+template <bool NORM_ROWS>
+inline hipError_t launch_gemm(bool x3, uint32_t m_tiles, uint32_t n_tiles, hipStream_t st, const float* Q, const float* C, const float* cnorm,
+                              uint32_t K, uint32_t N_pad, float* G, uint32_t metric, uint32_t k_rows = 0, float* part_v1 = nullptr,
+                              uint32_t* part_c1 = nullptr, float* part_v2 = nullptr) {
+  const uint32_t grp = NORM_ROWS ? gemm_tile_group(m_tiles) : 0;
+  if (!x3) {
+    hipLaunchKernelGGL(dist_gemm_kernel<NORM_ROWS>, dim3(m_tiles * n_tiles), dim3(256), 0, st, Q, C, cnorm, K, N_pad, G, metric, m_tiles, n_tiles,
+                       grp, k_rows, part_v1, part_c1, part_v2);
+    return hipGetLastError();
+  }
+  static const hipError_t attr = hipFuncSetAttribute((const void*)dist_gemm_x3_kernel<NORM_ROWS>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                     (int)kX3LdsBytes);
+  if (attr != hipSuccess) return attr;
+  hipLaunchKernelGGL(dist_gemm_x3_kernel<NORM_ROWS>, dim3(m_tiles * n_tiles), dim3(256), kX3LdsBytes, st, Q, C, cnorm, K, N_pad, G, metric, m_tiles,
+                     n_tiles, grp, k_rows, part_v1, part_c1, part_v2);
+  return hipGetLastError();
 }
 
 // One wave per query: select the PS smallest G of its row, re-score them exactly, sort by the exact key,

@@ -718,7 +718,7 @@ struct SearchWs {
   bool ref_shallow = false;  // host-pointer calls try 16 ranked lists first (a spill past the nearest few lists is rare)
   DevBuf grid_ctr;         // arrival counter of plan_fused_kernel's grid barriers (monotonic, never reset)
   uint32_t plan_launches = 0;
-  DevBuf seg_bounds, stamps, quad_counter, fb_part;
+  DevBuf seg_bounds, stamps, quad_counter, fb_part, fb_ctr;
   DevBuf clower, lower;  // lower bounds of multi-pass results (coarse ranking of more than 64 lists; top_k > 64)
   DevBuf qp, qil, cpart, probe, pj, lists, pairs, items, groups, qblocks, partials, status, o_ids, o_dist, o_cnt, xpart;
   static constexpr uint32_t kEvRing = 64;  // scan-launch timing ring (measurement hook)
@@ -814,6 +814,7 @@ struct vers_ivf {
   // corpus memory by default.  Same bits either way.
   DevBuf rows_rm;
   std::atomic<bool> shadow_off{false};
+  bool shadow_valid = false;            // rows_bf mirrors every stored row of the CURRENT index (written under the exclusive lock)
   uint32_t* fail_watch = nullptr;       // pinned: cumulative certificate failures as of the last finished batch
   std::atomic<uint64_t> shadow_queries{0};  // queries sent through the shadow path since the counter was last zeroed
   std::atomic<uint64_t> pre_batches{0};
@@ -990,6 +991,11 @@ int32_t status_to_rc(vers_ivf* h, uint32_t s, uint32_t slot) {
   return VERS_OK;
 }
 
+inline std::atomic<int>& shadow_mode_ref() {  // VERS_SHADOW (default 1) / vers_set_option("shadow", v)
+  static std::atomic<int> m{[] { const char* e = getenv("VERS_SHADOW"); return e ? (atoi(e) != 0 ? 1 : 0) : 1; }()};
+  return m;
+}
+inline int shadow_mode() { return shadow_mode_ref().load(std::memory_order_relaxed); }
 // |x|^2 of storage rows [r_begin, r_end) for the matrix-core list scan; a full refresh also resets the maximum
 int32_t refresh_norms(vers_ivf* h, uint64_t r_begin, uint64_t r_end, hipStream_t st) {
   if (int32_t rc = h->pre_misc.reserve(64)) return rc;
@@ -1000,11 +1006,10 @@ int32_t refresh_norms(vers_ivf* h, uint64_t r_begin, uint64_t r_end, hipStream_t
     for (auto& w : h->pool)  // a new index: ranked lists computed ahead belong to the old centroids (the caller holds the handle exclusively)
       for (auto& a : w->ahead) a.valid = false;
   }
-  // EXPERIMENTAL, off unless VERS_SHADOW=1: bit-exact on every test, fuzz and A/B run of its final
-  // form.  An earlier arrangement of the same arithmetic came out wrong in accumulator register 15 (an MFMA reading an
-  // operand the VALU had just written: prescan.hip.h, scripts/probe/mfma_chain.hip); correctness that depends on instruction
-  // placement soaks before it becomes a default.
-  static const bool shadow = [] { const char* e = getenv("VERS_SHADOW"); return e && atoi(e) != 0; }();
+  // fp16 shadow of the rows for the matrix-core list scan of batches (prescan.hip.h): on unless VERS_SHADOW=0 /
+  // vers_set_option("shadow", 0) at build / upload time.
+  const bool shadow = shadow_mode() != 0;
+  if (full) h->shadow_valid = false;
   if (shadow) {
     if (full) {
       const size_t need = (h->cap_rows ? h->cap_rows : 1) * (size_t)h->ld * sizeof(uint16_t);
@@ -1014,16 +1019,22 @@ int32_t refresh_norms(vers_ivf* h, uint64_t r_begin, uint64_t r_end, hipStream_t
         if (hipMalloc(&pbf, need) == hipSuccess) { h->rows_bf.p = pbf; h->rows_bf.cap = need; dev_mem_account((int64_t)need); }
         else (void)hipGetLastError();
       }
+      h->shadow_valid = h->rows_bf.p != nullptr && h->rows_bf.cap >= need;
       h->shadow_off = false; h->shadow_queries = 0;  // (the failure counter in pre_misc was just zeroed)
       if (!h->fail_watch) VERS_HIP_TRY(hipHostMalloc((void**)&h->fail_watch, 64, hipHostMallocDefault));
       *h->fail_watch = 0;
     }
-    if (r_end > r_begin && h->rows_bf.p) {
+    if (r_end > r_begin && h->shadow_valid) {
       const uint64_t work = (r_end - r_begin) * (h->ld / 8);
-      hipLaunchKernelGGL(rows_to_bf16_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, st, h->rows.as<float>(), h->ld, r_begin, r_end,
+      hipLaunchKernelGGL(rows_to_f16_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, st, h->rows.as<float>(), h->ld, r_begin, r_end,
                          h->rows_bf.as<uint16_t>());
+      hipLaunchKernelGGL(shadow_residual_kernel, dim3((unsigned)((r_end - r_begin + 255) / 256)), dim3(256), 0, st, h->rows.as<float>(), h->ld,
+                         h->row_ids.as<uint32_t>(), r_begin, r_end, h->pre_misc.as<uint32_t>() + 2);
       VERS_HIP_TRY(hipGetLastError());
     }
+  } else {
+    h->shadow_valid = false;  // rows changed without their shadow following
+    if (full) h->rows_bf.release();
   }
   {
     static const int rm_mode = [] { const char* e = getenv("VERS_ROWMAJOR"); return e ? atoi(e) : 0; }();  // opt-in: see vers_ivf::rows_rm
@@ -1645,13 +1656,8 @@ int32_t coarse_mfma(vers_ivf* h, const float* qp, uint32_t b, uint32_t P, uint64
   if (int32_t rc = W->gbuf.reserve((size_t)M_pad * h->k_pad * sizeof(float))) return rc;
   const bool timed = st != W->ahead_stream || W->ahead_stream == nullptr;  // (the look-ahead stream is not the measured one)
   if (timed) VERS_HIP_TRY(hipEventRecord(W->evc[0], st));
-  if (gemm_x3_mask() & 2)
-    hipLaunchKernelGGL(dist_gemm_x3_kernel<false>, dim3(h->k_pad / kGemmBN, M_pad / kGemmBM), dim3(256), 0, st, qp, h->centroids_g.as<float>(),
-                       h->cnorm.as<float>(), h->ldq, h->k_pad, W->gbuf.as<float>(), h->metric);
-  else
-    hipLaunchKernelGGL(dist_gemm_kernel<false>, dim3(h->k_pad / kGemmBN, M_pad / kGemmBM), dim3(256), 0, st, qp, h->centroids_g.as<float>(),
-                       h->cnorm.as<float>(), h->ldq, h->k_pad, W->gbuf.as<float>(), h->metric);
-  VERS_HIP_TRY(hipGetLastError());
+  VERS_HIP_TRY(launch_gemm<false>((gemm_x3_mask() & 2) != 0, M_pad / kGemmBM, h->k_pad / kGemmBN, st, qp, h->centroids_g.as<float>(),
+                                  h->cnorm.as<float>(), h->ldq, h->k_pad, W->gbuf.as<float>(), h->metric));
   if (timed) VERS_HIP_TRY(hipEventRecord(W->evc[1], st));
   hipLaunchKernelGGL(coarse_select_rescore_kernel, dim3(b), dim3(kWave), 0, st, W->gbuf.as<float>(), h->k_pad, h->k,
                      h->centroids_g.as<float>(), h->ldq, qp, h->ldq, h->ldq, coarse_mode() == 2 ? __builtin_inff() : h->cmax2, P, PS,
@@ -1855,12 +1861,14 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
   // slack of 10 keys: at cfg3 a slack of 6 left ~2 of 1024 queries uncertified per batch, 10 none
   uint32_t kp = std::min<uint32_t>(kPreMaxKp, std::max<uint32_t>(top_k + 10, top_k + top_k / 2));
   // bf16 shadow rows (experimental): the certificate window is ~9x wider, measured <= 33 rows inside it at top_k = 10
-  bool use_shadow = !h->shadow_off && h->rows_bf.p != nullptr && h->rows_bf.cap >= h->cap_rows * (size_t)h->ld * sizeof(uint16_t);
+  bool use_shadow = shadow_mode() != 0 && !h->shadow_off && h->shadow_valid && h->rows_bf.p != nullptr &&
+                    h->rows_bf.cap >= h->cap_rows * (size_t)h->ld * sizeof(uint16_t);
   if (use_shadow && h->fail_watch && h->shadow_queries >= 256) {  // (lags by the batches still in flight: errs on the side of keeping it)
     const uint32_t failed = *reinterpret_cast<volatile uint32_t*>(h->fail_watch);
     if ((uint64_t)failed * 8 > h->shadow_queries) { h->shadow_off = true; use_shadow = false; }
   }
-  if (use_shadow) kp = std::min<uint32_t>(kPreMaxKp, top_k + 38);
+  // (fp16 rows: the window is ~2x the f32 one.  At cfg3 a slack of 10 left ~0.5 of 1024 queries per batch uncertified, 16 none)
+  if (use_shadow) kp = std::min<uint32_t>(kPreMaxKp, top_k + std::max<uint32_t>(24, top_k));
   if (knobs().pre_slack > 0) kp = std::min<uint32_t>(kPreMaxKp, top_k + (uint32_t)knobs().pre_slack);  // tuning knob
   const bool use_pre = QG != 1 && !ref_mode && pre_mode != 0 && top_k + 6 <= kPreMaxKp && P <= (uint32_t)kMaxTopK &&
                        prescan_lds_bytes_g(h->ld, kp) <= 160u * 1024u;  // the query block of 32 padded queries must fit LDS
@@ -1983,7 +1991,13 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
   if (use_pre) {
     IvfSrc<kPreQ> src; fill_src(src);
     // partial lists of the exact re-scan (fail_list [b] + its count, qflags [n_pj]: in the zeroed zone above)
-    if (int32_t rc2 = W->fb_part.reserve((size_t)std::min<uint32_t>(b, 64) * P * kMergeWaves * top_k * sizeof(uint64_t))) return rc2;
+    uint32_t fb_blocks = kFallbackBlocks;  // (a power of two; fewer when P x top_k is large: at most 32 MB of partial lists)
+    while (fb_blocks > 16 && fallback_part_keys(fb_blocks, P, top_k) * sizeof(uint64_t) > (size_t(32) << 20)) fb_blocks /= 2;
+    if (int32_t rc2 = W->fb_part.reserve(fallback_part_keys(fb_blocks, P, top_k) * sizeof(uint64_t))) return rc2;
+    if (!W->fb_ctr.p) {  // group counters of fallback_kernel: zero once, the kernel leaves them zero
+      if (int32_t rc2 = W->fb_ctr.reserve((2 * kFallbackBlocks + 1) * sizeof(uint32_t))) return rc2;
+      VERS_HIP_TRY(hipMemsetAsync(W->fb_ctr.p, 0, (2 * kFallbackBlocks + 1) * sizeof(uint32_t), st));
+    }
     if (int32_t rc2 = launch_prescan(h, src, (uint32_t)items_bound, kp, qflags, quad_ctr, use_shadow, st)) return rc2;
     if (int32_t rc2 = start_pending_ahead(h, st)) return rc2;  // the next batch's coarse quantiser: under this batch's exact finish
     RescoreArgs a;
@@ -1997,9 +2011,8 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
     if (int32_t rc2 = scan_prepare_launch(ivf_rescore_kernel, rs_lds)) return rc2;
     hipLaunchKernelGGL(ivf_rescore_kernel, dim3(b), dim3(kWave * kRescoreWaves), rs_lds, st, a, stage_rows);
     VERS_HIP_TRY(hipGetLastError());
-    const uint32_t fb_blocks = std::min<uint32_t>(b, 64);
     hipLaunchKernelGGL(fallback_kernel, dim3(fb_blocks), dim3(kWave * kMergeWaves), 0, st, a, (const uint32_t*)h->slot_len.as<uint32_t>(),
-                       (const uint32_t*)fail_list, (const uint32_t*)(fail_list + b), W->fb_part.as<uint64_t>());
+                       (const uint32_t*)fail_list, (const uint32_t*)(fail_list + b), W->fb_part.as<uint64_t>(), W->fb_ctr.as<uint32_t>());
     VERS_HIP_TRY(hipGetLastError());
     if (use_shadow) {  // feed the watch word (see vers_ivf::rows_bf)
       h->shadow_queries += b;
@@ -2348,6 +2361,7 @@ int32_t vers_ivf_build_sharded_dev(vers_ivf_t* h, const float* rows_dev, uint64_
 int32_t vers_set_option(const char* name, int64_t value) {
   if (!name) return fail(VERS_ERR_INVALID, "vers_set_option: null name");
   if (std::strcmp(name, "gemm_x3") == 0) { set_gemm_x3_mask((int)value); return VERS_OK; }
+  if (std::strcmp(name, "shadow") == 0) { shadow_mode_ref().store(value != 0 ? 1 : 0); return VERS_OK; }
   return fail(VERS_ERR_INVALID, std::string("vers_set_option: unknown option ") + name);
 }
 
@@ -2700,7 +2714,7 @@ int32_t vers_ivf_prescan_stats(vers_ivf_t* h, uint64_t* out_batches, uint64_t* o
 
 int32_t vers_ivf_shadow_state(vers_ivf_t* h, int32_t* out_active, uint64_t* out_bytes) {
   if (!h) return fail(VERS_ERR_INVALID, "null handle");
-  if (out_active) *out_active = (h->rows_bf.p != nullptr && !h->shadow_off) ? 1 : 0;
+  if (out_active) *out_active = (shadow_mode() != 0 && h->shadow_valid && h->rows_bf.p != nullptr && !h->shadow_off) ? 1 : 0;
   if (out_bytes) *out_bytes = h->rows_bf.p ? (uint64_t)h->rows_bf.cap : 0;
   return VERS_OK;
 }

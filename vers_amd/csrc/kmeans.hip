@@ -208,12 +208,8 @@ int32_t km_assign_mfma(const float* X, uint32_t ldx, uint64_t n, const float* C,
       xb = ws.xp.as<float>();
     }
     // (the triples are addressed with pitch mb: nb_pad <= mb)
-    if (gemm_x3_mask() & 1)
-      hipLaunchKernelGGL(dist_gemm_x3_kernel<true>, dim3(nb_pad / kGemmBN, k_pad / kGemmBM), dim3(256), 0, st, ws.cg.as<float>(), xb,
-                         ws.cnorm.as<float>(), ldq, (uint32_t)mb, (float*)nullptr, metric, k, part_v1, part_c1, part_v2);
-    else
-      hipLaunchKernelGGL(dist_gemm_kernel<true>, dim3(nb_pad / kGemmBN, k_pad / kGemmBM), dim3(256), 0, st, ws.cg.as<float>(), xb,
-                         ws.cnorm.as<float>(), ldq, (uint32_t)mb, (float*)nullptr, metric, k, part_v1, part_c1, part_v2);
+    VERS_HIP_TRY(launch_gemm<true>((gemm_x3_mask() & 1) != 0, k_pad / kGemmBM, nb_pad / kGemmBN, st, ws.cg.as<float>(), xb, ws.cnorm.as<float>(), ldq,
+                                   (uint32_t)mb, (float*)nullptr, metric, k, part_v1, part_c1, part_v2));
     hipLaunchKernelGGL(assign_argmin_merge_kernel, dim3((nb + 255) / 256), dim3(256), 0, st, (const float*)part_v1, (const uint32_t*)part_c1,
                        (const float*)part_v2, n_tiles, (uint32_t)mb, nb, best, g2);
     hipLaunchKernelGGL(assign_rescore_kernel, dim3((nb + 63) / 64), dim3(64), 0, st, X + i0 * ldx, ldx, C, ldc, d, ldq, cmax2_dev, best, g2,

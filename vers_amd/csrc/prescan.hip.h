@@ -31,6 +31,8 @@
 namespace vers {
 
 typedef __attribute__((ext_vector_type(16))) float f32x16_t;
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
+typedef __attribute__((ext_vector_type(4))) _Float16 f16x4_t;
 
 constexpr int kPreQ = 32;        // queries per group: two sets of 16 (one 16x16x1 4-block MFMA covers 64 rows x 16 queries)
 #ifndef VERS_PRE_AUX
@@ -46,35 +48,63 @@ struct PreParams {
   uint32_t* qflags;     // per merge group: != 0 -> a non-finite val was seen, the query must be re-done exactly
   uint32_t* next_quad;
   const float* xnorm;   // |x|^2 per storage row
-  const uint16_t* rows_bf;  // BF16 shadow of the rows (experimental, VERS_SHADOW=1): tiles of 64 rows x 8 columns per 1 KiB
+  const uint16_t* rows_bf;  // fp16 shadow of the rows (rows_to_f16_kernel), nullptr: the f32 rows feed the scan
   uint32_t debug;
   uint32_t metric;      // 0: val = |x|^2 - 2<x,q> ~ D_ref - |q|^2 ; 1 (cosine distance 1 - dot): val = -<x,q> ~ D_ref - 1
   unsigned long long* stamps;
 };
 
 
-// f32 tiles -> bf16 shadow tiles (round to nearest even): element (r, c) of a 64-row tile moves from
-// ((c/4)*64 + r)*4 + c%4 (floats) to ((c/8)*64 + r)*8 + c%8 (bf16).  Thread = (row, group of 8 columns).
-static __global__ void rows_to_bf16_kernel(const float* rows, uint32_t ld, uint64_t r_begin, uint64_t r_end, uint16_t* rows_bf) {
+// f32 tiles -> fp16 shadow tiles (round to nearest even), laid out as the A operand of v_mfma_f32_32x32x16_f16: a
+// 64-row tile is ld/16 column blocks x 2 row halves of 1 KiB pieces; in piece (cb, h) lane l holds the 8 columns
+// 16*cb + 8*(l >> 5) ... + 7 of row 32*h + (l & 31), so that ONE 16-byte load per lane is the operand of one MFMA
+// (32 rows x 16 columns), with no VALU instruction between the load and the matrix core.  Element (r, c) of a tile moves
+// from ((c/4)*64 + r)*4 + c%4 (floats) to (((c/16)*2 + r/32)*64 + (c%16)/8*32 + r%32)*8 + c%8 (halves).
+// fp16, not bf16: 11 significant bits instead of 8 make the certificate window of the exact finish 8x narrower (round 2's
+// first shadow was bf16: ~25 rows per query inside the window at cfg3 and 1 % of the queries beyond the 48 a candidate
+// list holds; fp16: as many as with f32 rows).  Elements beyond +-65504 become inf (the row's vals are then non-finite
+// and its queries are re-done exactly); tiny ones lose relative precision in fp16's subnormal range -- both are covered
+// by shadow_residual_kernel's MEASURED bound rather than a formula.
+// Thread = (row, group of 8 columns).
+static __global__ void rows_to_f16_kernel(const float* rows, uint32_t ld, uint64_t r_begin, uint64_t r_end, uint16_t* rows_h) {
   const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   const uint32_t g8 = ld / 8;
   const uint64_t r = r_begin + t / g8;
   const uint32_t j = (uint32_t)(t % g8);
   if (r >= r_end) return;
   const float* src = rows + (r >> 6) * 64ull * ld;
-  uint16_t out[8];
+  f16x8_t out;
 #pragma unroll
   for (int h = 0; h < 2; ++h) {
     const f32x4 x = *reinterpret_cast<const f32x4*>(src + ((uint64_t)(2 * j + h) * 64 + (r & 63)) * 4);
 #pragma unroll
+    for (int u = 0; u < 4; ++u) out[4 * h + u] = (_Float16)x[u];  // v_cvt_f16_f32: RNE, inf / NaN preserved
+  }
+  const uint32_t rr = (uint32_t)(r & 63);
+  uint16_t* dst = rows_h + (r >> 6) * 64ull * ld + ((uint64_t)((j >> 1) * 2 + (rr >> 5)) * 64 + (j & 1) * 32 + (rr & 31)) * 8;
+  *reinterpret_cast<f16x8_t*>(dst) = out;
+}
+
+// max over the stored rows of |x - fp16(x)|^2 (thread per row, like blocked_row_norms_kernel): the exact finish bounds
+// the shadow's error of a val by 2 |<x - x~, q>| <= 2 R |q| with this R.  x - fp16(x) is exact in f32 (the two are within
+// a factor of two of each other, or the difference is below fp16's subnormal spacing and x itself is tiny); the sum of
+// squares is inflated for its own roundings where it is used.  A finite element that overflows fp16 gives R = inf: no
+// certificate holds and the shadow switches itself off (vers_ivf::rows_bf).
+static __global__ void shadow_residual_kernel(const float* rows, uint32_t ld, const uint32_t* row_ids, uint64_t r_begin, uint64_t r_end,
+                                              uint32_t* rmax2_bits) {
+  const uint64_t r = r_begin + (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= r_end || row_ids[r] == 0xFFFFFFFFu) return;
+  const f32x4* p = reinterpret_cast<const f32x4*>(rows + (r >> 6) * 64ull * ld) + (r & 63);
+  float acc = 0.0f;
+  for (uint32_t j = 0; j < ld / 4; ++j) {
+    const f32x4 v = p[(uint64_t)j * 64];
+#pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const uint32_t b = __float_as_uint(x[u]);
-      out[4 * h + u] = (uint16_t)((b + 0x7FFFu + ((b >> 16) & 1u)) >> 16);  // RNE (NaN / inf rows are flagged by the non-finite check anyway)
+      const float dlt = v[u] - (float)(_Float16)v[u];
+      acc = __fadd_rn(acc, __fmul_rn(dlt, dlt));
     }
   }
-  uint16_t* dst = rows_bf + (r >> 6) * 64ull * ld + ((uint64_t)j * 64 + (r & 63)) * 8;
-  *reinterpret_cast<u32x4*>(dst) = u32x4{(uint32_t)out[0] | ((uint32_t)out[1] << 16), (uint32_t)out[2] | ((uint32_t)out[3] << 16),
-                                         (uint32_t)out[4] | ((uint32_t)out[5] << 16), (uint32_t)out[6] | ((uint32_t)out[7] << 16)};
+  if (acc == acc) atomicMax(rmax2_bits, __float_as_uint(acc));  // acc >= 0: bit order == value order (NaN rows: flagged by their vals)
 }
 
 // |x|^2 of every storage row of the blocked matrix (thread per row: consecutive rows are consecutive float4s) and
@@ -142,8 +172,14 @@ __device__ __forceinline__ uint64_t buffer_sorted(const uint64_t* bq, uint32_t n
   return k0;
 }
 
-// BF: the row operand comes from the bf16 shadow copy (half the HBM bytes): a float4 load brings 8 columns of the
-// lane's row, expanded to f32 in the VALU (shift / mask) for the same f32 MFMA; the query operand stays f32.
+// BF: the row operand comes from the fp16 shadow copy (half the HBM bytes) and goes from the load straight into
+// v_mfma_f32_32x32x16_f16 (rows_to_f16_kernel writes the shadow in that operand's layout); the query block sits in LDS
+// as fp16 hi + lo parts of the scaled f32 query (q' = hi + lo up to 2^-22 |q'|), one MFMA each: the fp16 x fp16 products
+// are exact in f32, so val errs by the shadow's own rounding (2^-12 per element) and nothing else of that order.  32 rows
+// x 16 columns x 32 queries per 8-pass MFMA: the matrix cores need 1/8 of the f32 path's cycles and the kernel is bound
+// by the (halved) HBM stream alone.  The accumulator layout differs from the f32 path's (16x16x1 in 4 blocks: a lane =
+// one of 16 query columns x 2 sets): here a lane holds query column lane & 31 and 16 of the 32 rows of a tile half h:
+// rows 32*h + 8*(e >> 2) + 4*(lane >> 5) + (e & 3).
 template <bool BF, class Src, class Stage>
 __device__ __forceinline__ void prescan_item_g(const Src& src, const PreParams& p, uint32_t it, const ItemView<kPreQ>& v, int half, int lane,
                                                const float* qm, uint64_t* cbuf, uint32_t* ctl, Stage&& stage) {
@@ -154,13 +190,14 @@ __device__ __forceinline__ void prescan_item_g(const Src& src, const PreParams& 
     stage();
     return;
   }
-  const int n = lane & 15, quarter = lane >> 4;
+  constexpr int kSets = BF ? 1 : 2;   // query columns a lane serves (accumulator layouts: see above)
+  const int n = BF ? (lane & 31) : (lane & 15), quarter = BF ? (lane >> 5) : (lane >> 4);
   const uint32_t kp = p.kp, cap = pre_cap(p.kp);
   uint32_t* const cnt = ctl;                 // [32] slots reserved in the query's buffer (may run past cap: overflow)
   uint32_t* const done = ctl + kPreQ;        // [32] slots written
   uint32_t* const thrq = ctl + 2 * kPreQ;    // [32] order bits of the block's threshold of the query (0xFFFFFFFF: none yet)
   uint32_t* const locks = ctl + 3 * kPreQ;   // [32] compaction locks
-  const bool two = v.nq > 16;  // wave-uniform
+  const bool two = !BF && v.nq > 16;  // wave-uniform
   const bool stamp = (p.debug & 16u) != 0;
   const unsigned long long tp0 = stamp ? __builtin_amdgcn_s_memtime() : 0ull;
   // the first tile loads go out before anything else: they fly while the item is set up and the block stages
@@ -171,7 +208,7 @@ __device__ __forceinline__ void prescan_item_g(const Src& src, const PreParams& 
   } else {
     L.init(v.rows, (uint64_t)n_tiles * kWave * p.ld * 4u, p.ld, lane);
   }
-  const uint32_t nch = BF ? p.ld / 64u : p.n_chunks;  // steps per tile: 8 loads = 64 bf16 columns or 32 f32 columns
+  const uint32_t nch = BF ? p.ld / 64u : p.n_chunks;  // steps per tile: 8 loads = 64 bf16 columns (x 2 row halves) or 32 f32 columns
   const float* xn_item = p.xnorm + src.storage_row(it);
 #ifndef VERS_PRE_RING_G
 #define VERS_PRE_RING_G 2
@@ -187,7 +224,7 @@ __device__ __forceinline__ void prescan_item_g(const Src& src, const PreParams& 
     constexpr int b = decltype(btag)::value;
     if (with_thr) {
       gthr[b][0] = __hip_atomic_load(p.bounds32 + vslot[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      gthr[b][1] = __hip_atomic_load(p.bounds32 + vslot[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      gthr[b][1] = kSets == 2 ? __hip_atomic_load(p.bounds32 + vslot[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xFFFFFFFFu;
     } else {
       gthr[b][0] = gthr[b][1] = 0xFFFFFFFFu;
     }
@@ -206,7 +243,7 @@ __device__ __forceinline__ void prescan_item_g(const Src& src, const PreParams& 
   float thr[2];
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
-    live[s] = s * 16 + n < (int)v.nq;
+    live[s] = s < kSets && s * 16 + n < (int)v.nq;
     thr[s] = -__builtin_inff();  // dead query columns never hit
     if (live[s]) {
       vseq[s] = src.seq_base(it, s * 16 + n);
@@ -226,13 +263,15 @@ __device__ __forceinline__ void prescan_item_g(const Src& src, const PreParams& 
   // End of a tile for query set S: acc already holds val (the |x|^2 term went through the matrix core).  Each lane holds
   // 16 vals of ONE query column (lane & 15), rows 16*(e>>2) + 4*quarter + (e&3): one compare per register against the
   // lane's threshold decides whether anything happens at all.
-  auto fold = [&](auto set_tag, f32x16_t& a, uint32_t t) {
+  // (BF: S = 0 and `h` is the row half of the tile the accumulator covers)
+  auto fold = [&](auto set_tag, f32x16_t& a, uint32_t t, uint32_t h) {
     constexpr int S = decltype(set_tag)::value;
-    const uint32_t r0 = t * kWave + 4u * (uint32_t)quarter;
+    constexpr uint32_t kRowStep = BF ? 8u : 16u;  // rows between the lane's register groups of four
+    const uint32_t r0 = t * kWave + 32u * h + 4u * (uint32_t)quarter;
     if ((t + 1) * kWave > v.nrows) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        const uint32_t row = r0 + 16u * (e >> 2) + (e & 3);
+        const uint32_t row = r0 + kRowStep * (e >> 2) + (e & 3);
         if (row >= v.nrows) a[e] = __builtin_nanf("");
         else bad |= live[S] && !(__builtin_fabsf(a[e]) < __builtin_inff());
       }
@@ -248,7 +287,7 @@ __device__ __forceinline__ void prescan_item_g(const Src& src, const PreParams& 
     if (__ballot(pm != 0) != 0 && !(p.debug & 1u)) {
       const uint32_t q = (uint32_t)(S * 16 + n);
       uint64_t* const bq = cbuf + (size_t)q * cap;
-      const uint32_t sq0 = vseq[S] + t * kWave + 4u * (uint32_t)quarter;
+      const uint32_t sq0 = vseq[S] + r0;
       // reserve + store: every lane for its own query column, the whole wave in one LDS atomic.  Bits of `pend` that found
       // a slot are cleared; the others (buffer full) stay for the slow path.
       auto append = [&](uint32_t& pend) {
@@ -259,7 +298,7 @@ __device__ __forceinline__ void prescan_item_g(const Src& src, const PreParams& 
         for (int e = 0; e < 16; ++e) {
           if (pend >> e & 1u) {
             if (pos < cap) {
-              bq[pos] = make_key(a[e], sq0 + 16u * (e >> 2) + (e & 3));
+              bq[pos] = make_key(a[e], sq0 + kRowStep * (e >> 2) + (e & 3));
               pend &= ~(1u << e);
               ++nw;
             }
@@ -299,7 +338,7 @@ __device__ __forceinline__ void prescan_item_g(const Src& src, const PreParams& 
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // buffer, done and threshold before the counter re-opens it
             if (lane == 0) __hip_atomic_store(cnt + qq, kp, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (lane == (int)(qq & 15u) && !(p.debug & 8192u)) atomicMin(p.bounds32 + vslot[S], kb);
+            if (lane == (int)(BF ? qq : (qq & 15u)) && !(p.debug & 8192u)) atomicMin(p.bounds32 + vslot[S], kb);
             if (stamp && lane == 0) atomicAdd(p.stamps + 12, 1ull);
           }
           uint32_t mp = 0;
@@ -356,40 +395,19 @@ __device__ __forceinline__ void prescan_item_g(const Src& src, const PreParams& 
             }
           }
         } else {
-          const f32x4* ql = reinterpret_cast<const f32x4*>(qm) + ((size_t)cc * 2 * kLoads * kPreQ + n);  // 16 float4 columns per step
-          // One asm block per load: 8 expansions (VALU), wait states, 8 MFMAs.  An MFMA that reads a register a VALU
-          // instruction wrote just before it sees stale lanes: the hardware does not interlock that pair, the compiler's
-          // wait-state model was a cycle short here (compiler-scheduled expansions left lanes 51/55/59/63 of the A
-          // operand stale: rows 48 + 4*quarter + 3 came out one load short), and scripts/probe/mfma_chain.hip reproduces
-          // the stale read in isolation.  Inside the block the distance is explicit; the operands of the builtin MFMAs of
-          // the f32 path come from memory and LDS loads only (s_waitcnt-ordered), never from the VALU.
-          auto load_group = [&](f32x16_t& av, const u32x4& w, const f32x4& qlo, const f32x4& qhi) {
-            float t0, t1, t2, t3, t4, t5, t6, t7;
-            asm volatile(
-                "v_lshlrev_b32 %1, 16, %9\n\tv_and_b32 %2, 0xffff0000, %9\n\t"
-                "v_lshlrev_b32 %3, 16, %10\n\tv_and_b32 %4, 0xffff0000, %10\n\t"
-                "v_lshlrev_b32 %5, 16, %11\n\tv_and_b32 %6, 0xffff0000, %11\n\t"
-                "v_lshlrev_b32 %7, 16, %12\n\tv_and_b32 %8, 0xffff0000, %12\n\t"
-                "s_nop 4\n\t"
-                "v_mfma_f32_16x16x1_4b_f32 %0, %1, %13, %0\n\tv_mfma_f32_16x16x1_4b_f32 %0, %2, %14, %0\n\t"
-                "v_mfma_f32_16x16x1_4b_f32 %0, %3, %15, %0\n\tv_mfma_f32_16x16x1_4b_f32 %0, %4, %16, %0\n\t"
-                "v_mfma_f32_16x16x1_4b_f32 %0, %5, %17, %0\n\tv_mfma_f32_16x16x1_4b_f32 %0, %6, %18, %0\n\t"
-                "v_mfma_f32_16x16x1_4b_f32 %0, %7, %19, %0\n\tv_mfma_f32_16x16x1_4b_f32 %0, %8, %20, %0"
-                : "+v"(av), "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3), "=&v"(t4), "=&v"(t5), "=&v"(t6), "=&v"(t7)
-                : "v"(w[0]), "v"(w[1]), "v"(w[2]), "v"(w[3]), "v"(qlo[0]), "v"(qlo[1]), "v"(qlo[2]), "v"(qlo[3]), "v"(qhi[0]), "v"(qhi[1]),
-                  "v"(qhi[2]), "v"(qhi[3]));
-          };
+          // query block: [hi | lo][column block of 16][64 lanes] x 16 bytes, lane = octet * 32 + query (the B operand's layout)
+          const f16x8_t* qh = reinterpret_cast<const f16x8_t*>(qm) + ((size_t)cc * (kLoads / 2) * kWave + lane);
+          const f16x8_t* ql = qh + (size_t)(p.ld / 16u) * kWave;
 #pragma unroll
-          for (int i = 0; i < kLoads; ++i) {
-            const f32x4 qa = ql[(2 * i) * kPreQ], qb = ql[(2 * i + 1) * kPreQ];
-            load_group(acc[0], buf[B][i], qa, qb);
-            if (two) {
-              const f32x4 qc = ql[(2 * i) * kPreQ + 16], qd = ql[(2 * i + 1) * kPreQ + 16];
-              load_group(acc[1], buf[B][i], qc, qd);
+          for (int cb = 0; cb < kLoads / 2; ++cb) {
+            const f16x8_t bh = qh[cb * kWave], bl = ql[cb * kWave];
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+              const f16x8_t ar = __builtin_bit_cast(f16x8_t, buf[B][2 * cb + hf]);
+              acc[hf] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ar, bl, acc[hf], 0, 0, 0);  // (small term first)
+              acc[hf] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ar, bh, acc[hf], 0, 0, 0);
             }
           }
-          // the compiler cannot see the MFMAs inside the blocks: give the last one its passes before anything reads acc
-          asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 7\n\ts_nop 7" ::: "memory");
         }
       } else {
         acc[0][0] += __uint_as_float(buf[B][0][0] ^ buf[B][kLoads - 1][3]);
@@ -416,12 +434,20 @@ __device__ __forceinline__ void prescan_item_g(const Src& src, const PreParams& 
             }
           }
         }
-        const float nrm = p.metric ? 0.0f : 1.0f;  // (the cosine-distance val has no |x|^2 term)
-        acc[0] = __builtin_amdgcn_mfma_f32_16x16x1f32(xn[B], nrm, acc[0], 0, 0, 0);  // + |x_row|^2 for every query column
-        fold(Set0{}, acc[0], tc);
-        if (two) {
-          acc[1] = __builtin_amdgcn_mfma_f32_16x16x1f32(xn[B], nrm, acc[1], 0, 0, 0);
-          fold(Set1{}, acc[1], tc);
+        const float nrm = p.metric ? 0.0f : 1.0f;  // (the cosine-distance val has no |x|^2 term; 0 * NaN still flags a bad row)
+        if constexpr (BF) {
+          // + |x_row|^2 for every query column: A[i][k] = xn of lane (i, k) = row 32k + i of the tile, B[k][j] = (k == h)
+          acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(xn[B], quarter == 0 ? nrm : 0.0f, acc[0], 0, 0, 0);
+          fold(Set0{}, acc[0], tc, 0u);
+          acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(xn[B], quarter == 1 ? nrm : 0.0f, acc[1], 0, 0, 0);
+          fold(Set0{}, acc[1], tc, 1u);
+        } else {
+          acc[0] = __builtin_amdgcn_mfma_f32_16x16x1f32(xn[B], nrm, acc[0], 0, 0, 0);  // + |x_row|^2 for every query column
+          fold(Set0{}, acc[0], tc, 0u);
+          if (two) {
+            acc[1] = __builtin_amdgcn_mfma_f32_16x16x1f32(xn[B], nrm, acc[1], 0, 0, 0);
+            fold(Set1{}, acc[1], tc, 0u);
+          }
         }
         ++tc;
         if (stamp) t_fold += __builtin_amdgcn_s_memtime() - t2;
@@ -487,7 +513,7 @@ __global__ __launch_bounds__(kWave * kPreWavesG) __attribute__((amdgpu_waves_per
     // The quad's query block: <= 32 padded queries gathered from their rows, scaled by -2 (-1: cosine distance), in the MFMA operand
     // layout l4[column group * 32 + slot].  Every thread serves ONE slot (512 % 32 == 0; 16 slots when the group
     // holds <= 16 queries, so that all threads load) and its row pointer is resolved here, ahead of the barrier.
-    const uint32_t ns = v.nq > 16 ? 32u : 16u;
+    const uint32_t ns = (BF || v.nq > 16) ? 32u : 16u;
     const uint32_t slot = threadIdx.x & (ns - 1u), cg0 = threadIdx.x / ns, cg_step = (kWave * kPreWavesG) / ns;
     const float* qrow = slot < v.nq ? src.query_row(it, slot) : nullptr;
     auto stage = [&]() {
@@ -510,15 +536,32 @@ __global__ __launch_bounds__(kWave * kPreWavesG) __attribute__((amdgpu_waves_per
       __syncthreads();
       if (threadIdx.x < 4 * kPreQ) ctl[threadIdx.x] = (threadIdx.x >> 5) == 2 ? 0xFFFFFFFFu : 0u;  // empty buffers, no threshold, locks open
       f32x4* l4 = reinterpret_cast<f32x4*>(qlds);
+      auto put = [&](uint32_t cg, const f32x4& y) {  // columns 4*cg .. 4*cg + 3 of the thread's query, already scaled
+        if constexpr (BF) {
+          // hi = fp16(y), lo = fp16(y - hi) into the B operand layout of the 32x32x16 MFMA (prescan_item_g)
+          f16x4_t hi, lo;
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            hi[u] = (_Float16)y[u];
+            lo[u] = (_Float16)(y[u] - (float)hi[u]);
+          }
+          _Float16* qb = reinterpret_cast<_Float16*>(qlds);
+          const uint32_t at = (((cg >> 2) * 2u + ((cg >> 1) & 1u)) * 32u + slot) * 8u + (cg & 1u) * 4u;
+          *reinterpret_cast<f16x4_t*>(qb + at) = hi;
+          *reinterpret_cast<f16x4_t*>(qb + (size_t)p.ld * kPreQ + at) = lo;
+        } else {
+          l4[cg * kPreQ + slot] = y;
+        }
+      };
 #pragma unroll
       for (int u = 0; u < kStageU; ++u) {
         const uint32_t cg = cg0 + (uint32_t)u * cg_step;
-        if (cg < n_cg) l4[cg * kPreQ + slot] = qscale * x[u];
+        if (cg < n_cg) put(cg, qscale * x[u]);
       }
       for (uint32_t cg = cg0 + kStageU * cg_step; cg < n_cg; cg += cg_step) {  // (wider rows than kStageU rounds cover)
         f32x4 y = {0.0f, 0.0f, 0.0f, 0.0f};
         if (qrow != nullptr) y = *reinterpret_cast<const f32x4*>(qrow + 4 * cg);
-        l4[cg * kPreQ + slot] = qscale * y;
+        put(cg, qscale * y);
       }
       __syncthreads();
       if ((p.debug & 16u) && lane == 0) {
@@ -675,8 +718,15 @@ __global__ __launch_bounds__(kWave * kRescoreWaves) void ivf_rescore_kernel(Resc
     const double u = 5.9604644775390625e-08;
     const double S = (double)qn * (1.0 + (double)a.d_pad * 2.0 * u) + (double)__uint_as_float(xmax_bits) + (a.metric ? 1.0 : 0.0);
     double E = (5.0 * (double)a.d_pad + 32.0) * u * S;
-    if (a.shadow)  // |x_j - bf16(x_j)| <= 2^-9 |x_j|  =>  |2 <x - x~, q>| <= 2^-8 |x||q| (inflated for the roundings of |x~|)
-      E = E * 1.01 + 0.00390625 * 1.004 * __builtin_sqrt((double)__uint_as_float(xmax_bits) * (double)qn * (1.0 + (double)a.d_pad * 2.0 * u));
+    // fp16 shadow: |val~ - val| <= 2 |<x - x~, q>| + 2 |<x~, q - q~>| with (a) |<x - x~, q>| <= R |q|, R = the MEASURED largest
+    // |x - fp16(x)| over the stored rows (shadow_residual_kernel), and (b) the query's hi + lo split leaving at most
+    // 2^-22 |q'_j| + 2^-24 per element (fp16 subnormal spacing) of q' = -2q behind: sum_j |x~_j| (...) <= 2^-21 |x||q| +
+    // 2^-24 sqrt(d) |x|.  Inflated by 1 % for the roundings of R^2, |q|^2, |x~| vs |x| and of this arithmetic.
+    if (a.shadow) {
+      const double xm = __builtin_sqrt((double)__uint_as_float(xmax_bits)), qm2 = __builtin_sqrt((double)qn);
+      const double R = __builtin_sqrt((double)__uint_as_float(a.xmax2_bits[2]));
+      E = E * 1.01 + 1.01 * (2.0 * R * qm2 + 4.76837158203125e-07 * xm * qm2 + 5.9604644775390625e-08 * __builtin_sqrt((double)a.d_pad) * xm);
+    }
     const float val = __uint_as_float(order_bits_to_f32_bits((uint32_t)(list >> 32)));
     bool certified = true;
     double lim = __builtin_inf();
@@ -790,59 +840,109 @@ struct FbSrc {
   __device__ __forceinline__ uint32_t bound_slot(uint32_t, int) const { return 0; }
 };
 
-// ONE launch: block i takes every gridDim.x-th queued query, scans its P probed lists one after the other (16 waves, each
-// the ring-pipelined single-query item of scan.hip.h over its share of the list's tiles), folds the P x 16 partial lists and
-// emits.  Exits at once when nothing is queued -- the normal case: 64 blocks, ~3 us.  (Round 1 used a P x 64 grid of
-// 1024-thread blocks plus a merge launch: 11.5 us per batch with nothing to do, and 2048 fat blocks in the way of
-// whatever else wants the CUs.)  A queued query costs one CU a pass over its lists (~1-2 ms at cfg3): rare by design.
+// ONE launch of kFallbackBlocks persistent blocks; exits at once when nothing is queued (the normal case: ~3 us).
+// The blocks split into n_groups groups of G (G = the largest power of two <= blocks / queued queries, at most 64): a group
+// takes every n_groups-th queued query and spreads its P probed lists -- in C = ceil(G / P) chunks of tiles each when the
+// group is larger than P -- over its members; a member's 16 waves share a chunk's tiles (the ring-pipelined single-query
+// item of scan.hip.h) and leave 16 partial lists per chunk in the group's slot.  The member that arrives last (a counter per
+// group) folds the slot and emits; the others wait for that before the slot is reused for the group's next query.  With at
+// least as many queued queries as blocks G = 1: a block per query, no waiting.  (Round 1 and the first cut of this kernel
+// gave a queued query to ONE block: 32 lists = 240 MB at cfg3 through a single CU, ~6 ms -- a cliff behind every failed
+// certificate.  Spread over 64 CUs it is ~60 us.)  ctr: [2 * groups + 1] words, zero between launches (the last block out
+// clears them).
+constexpr uint32_t kFallbackBlocks = 128;
+inline size_t fallback_part_keys(uint32_t blocks, uint32_t P, uint32_t top_k) {  // >= n_groups * P * C chunks for every G
+  return (size_t)blocks * (P > 2 ? P : 2) * kMergeWaves * top_k;
+}
 __global__ __launch_bounds__(kWave * kMergeWaves) void fallback_kernel(RescoreArgs a, const uint32_t* list_len, const uint32_t* fail_list,
-                                                                       const uint32_t* fail_count, uint64_t* fb_part) {
+                                                                       const uint32_t* fail_count, uint64_t* fb_part, uint32_t* ctr) {
   __shared__ uint64_t sh[kMergeWaves][kWave];
+  __shared__ uint32_t s_last;
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const uint32_t n_fail = *fail_count;
+  if (n_fail == 0) return;
+  uint32_t G = 1;
+  while (G < 64u && 2u * G * n_fail <= gridDim.x) G *= 2u;
+  const uint32_t n_groups = gridDim.x / G;
+  const uint32_t gidx = blockIdx.x / G, g = blockIdx.x % G;
+  const uint32_t C = (G + a.P - 1) / a.P, chunks = a.P * C;
   ScanParams p;
   p.ld = a.ld; p.n_chunks = a.ld / kChunk; p.k = a.top_k; p.status = a.status; p.bounds = nullptr; p.lower = nullptr; p.debug = 0;
   p.next_quad = nullptr; p.stamps = nullptr;
   bool nan_seen = false;
-  uint64_t* mine = fb_part + (uint64_t)blockIdx.x * a.P * kMergeWaves * a.top_k;  // this block's P x 16 partial lists
-  for (uint32_t i = blockIdx.x; i < n_fail; i += gridDim.x) {
-    const uint32_t q = fail_list[i];
-    for (uint32_t j = 0; j < a.P; ++j) {
-      uint64_t* out = mine + ((uint64_t)j * kMergeWaves + wid) * a.top_k;
-      const uint32_t Lj = a.pj_list[(uint64_t)q * a.P + j];
-      uint32_t len = 0, t0 = 0, t1 = 0;
-      if (Lj != 0xFFFFFFFFu) {
-        len = list_len[Lj];
-        const uint32_t n_tiles = (len + kWave - 1) / kWave, per = (n_tiles + kMergeWaves - 1) / kMergeWaves;
-        t0 = (uint32_t)wid * per < n_tiles ? (uint32_t)wid * per : n_tiles;
-        t1 = t0 + per < n_tiles ? t0 + per : n_tiles;
+  uint64_t* slot = fb_part + (uint64_t)gidx * chunks * kMergeWaves * a.top_k;  // the group's chunks x 16 partial lists
+  uint32_t* arrived = ctr + 2 * gidx;
+  uint32_t* merged = ctr + 2 * gidx + 1;
+  uint32_t round = 0;
+  if (gidx < n_groups) {
+    for (uint32_t i = gidx; i < n_fail; i += n_groups, ++round) {
+      const uint32_t q = fail_list[i];
+      for (uint32_t u = g; u < chunks; u += G) {
+        const uint32_t j = u / C, c = u % C;
+        uint64_t* out = slot + ((uint64_t)u * kMergeWaves + wid) * a.top_k;
+        const uint32_t Lj = a.pj_list[(uint64_t)q * a.P + j];
+        uint32_t len = 0, t0 = 0, t1 = 0;
+        if (Lj != 0xFFFFFFFFu) {
+          len = list_len[Lj];
+          const uint32_t n_tiles = (len + kWave - 1) / kWave, per_c = (n_tiles + C - 1) / C;
+          const uint32_t c0 = c * per_c < n_tiles ? c * per_c : n_tiles, c1 = c0 + per_c < n_tiles ? c0 + per_c : n_tiles;
+          const uint32_t per = (c1 - c0 + kMergeWaves - 1) / kMergeWaves;
+          t0 = c0 + (uint32_t)wid * per < c1 ? c0 + (uint32_t)wid * per : c1;
+          t1 = t0 + per < c1 ? t0 + per : c1;
+        }
+        if (t1 <= t0) {  // nothing for this wave: an empty slot
+          if (lane < (int)a.top_k) out[lane] = kKeyMax;
+          continue;
+        }
+        ItemView<1> v;
+        v.rows = a.rows + ((uint64_t)a.list_off[Lj] + (uint64_t)t0 * kWave) * a.ld;
+        v.nrows = (t1 * kWave < len ? t1 * kWave : len) - t0 * kWave;
+        v.nq = 1;
+        v.qb = a.qp + (uint64_t)q * a.ldq;
+        FbSrc src;
+        src.out_ptr = out;
+        src.seq0 = a.pj_pref[(uint64_t)q * a.P + j] + t0 * kWave;
+        if (a.metric == 0) scan_item<1, 1, 0>(src, p, 0u, v, lane, nan_seen);
+        else scan_item<1, 1, 1>(src, p, 0u, v, lane, nan_seen);
       }
-      if (t1 <= t0) {  // nothing for this wave: an empty slot
-        if (lane < (int)a.top_k) out[lane] = kKeyMax;
-        continue;
+      __threadfence();   // this member's partial lists, device-wide, before it counts as arrived
+      __syncthreads();
+      bool fold = true;
+      if (G > 1) {
+        if (threadIdx.x == 0) {
+          const uint32_t prev = __hip_atomic_fetch_add(arrived, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+          s_last = prev + 1u == (round + 1u) * G ? 1u : 0u;
+        }
+        __syncthreads();
+        fold = s_last != 0u;
+        if (fold) __threadfence();  // the other members' lists
       }
-      ItemView<1> v;
-      v.rows = a.rows + ((uint64_t)a.list_off[Lj] + (uint64_t)t0 * kWave) * a.ld;
-      v.nrows = (t1 * kWave < len ? t1 * kWave : len) - t0 * kWave;
-      v.nq = 1;
-      v.qb = a.qp + (uint64_t)q * a.ldq;
-      FbSrc src;
-      src.out_ptr = out;
-      src.seq0 = a.pj_pref[(uint64_t)q * a.P + j] + t0 * kWave;
-      if (a.metric == 0) scan_item<1, 1, 0>(src, p, 0u, v, lane, nan_seen);
-      else scan_item<1, 1, 1>(src, p, 0u, v, lane, nan_seen);
+      if (fold) {
+        const uint32_t n_keys = chunks * kMergeWaves * a.top_k;
+        const uint64_t list = block_merge_keys(slot, n_keys, a.top_k, sh);
+        if (threadIdx.x < kWave)
+          emit_topk(list, q, a.top_k, lane, a.pj_list + (uint64_t)q * a.P, a.pj_pref + (uint64_t)q * a.P, a.P, a.list_off, a.row_ids, a.out_ids,
+                    a.out_dist, a.out_count, a.out_keys);
+        __syncthreads();  // the slot is reused by the group's next query
+        if (G > 1 && threadIdx.x == 0) __hip_atomic_store(merged, round + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      if (G > 1 && i + n_groups < n_fail) {  // the slot is free once its fold is done
+        if (threadIdx.x == 0)
+          while (__hip_atomic_load(merged, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < round + 1u) __builtin_amdgcn_s_sleep(16);
+        __syncthreads();
+      }
     }
-    __threadfence_block();
-    __syncthreads();  // every wave's partial lists are written
-    const uint32_t n_keys = a.P * kMergeWaves * a.top_k;
-    const uint64_t list = block_merge_keys(mine, n_keys, a.top_k, sh);
-    if (threadIdx.x < kWave)
-      emit_topk(list, q, a.top_k, lane, a.pj_list + (uint64_t)q * a.P, a.pj_pref + (uint64_t)q * a.P, a.P, a.list_off, a.row_ids, a.out_ids,
-                a.out_dist, a.out_count, a.out_keys);
-    __syncthreads();  // the slots are reused by the block's next query
   }
   if (__ballot(nan_seen) != 0 && lane == 0) atomicOr(a.status, 1u);
+  // the last block out leaves the counters zero for the next launch
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t* out_ctr = ctr + 2 * gridDim.x;
+    if (__hip_atomic_fetch_add(out_ctr, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) + 1u == gridDim.x) {
+      for (uint32_t w = 0; w <= 2 * gridDim.x; ++w) __hip_atomic_store(ctr + w, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
 }
 
 }  // namespace vers
