@@ -58,6 +58,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-recall", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the untimed extra measurements (single query, coarse GEMM, flat cfg2, Dist-U recall)")
+    ap.add_argument("--streams", type=int, default=1, help="batches in flight: consecutive batches rotate over this many HIP streams")
     ap.add_argument("--ahead", action="store_true", help="compute the next batch's coarse quantiser on a side stream under the current "
                     "list scan (vers_ivf_coarse_ahead_dev; same-box A/B at cfg3: +0.8 %% -- the scan already fills the chip)")
     args = ap.parse_args()
@@ -151,37 +152,48 @@ def main():
     n_batches = max(1, min(args.steps + args.warmup, 8))
     Q = torch.empty(n_batches * B, ld, dtype=torch.float32, device=dev)
     capi.gen_rows_dev(Q.data_ptr(), n_batches * B, d, ld, 1, SEED_Q, SEED_C, n_modes, sigma)
-    ids = torch.zeros(B, top_k, dtype=torch.int64, device=dev)
-    dst = torch.zeros(B, top_k, dtype=torch.float32, device=dev)
-    cnt = torch.zeros(B, dtype=torch.int32, device=dev)
-    st = torch.cuda.current_stream().cuda_stream
+    # Batches in flight: consecutive batches go to `--streams` HIP streams in rotation, each with its own output buffers (a
+    # server's request pipelining: one batch's coarse quantiser / planning / exact finish run in the shadows of another's
+    # HBM-bound list scan).  Every batch is still one complete search; the timed region ends when all of them are done.
+    S = max(1, args.streams)
+    # (never the legacy null stream next to others: with it and two more streams in rotation the HIP runtime's implicit
+    # null-stream ordering left the GPU waiting forever -- three created streams run fine)
+    streams = [torch.cuda.current_stream()] if S == 1 else [torch.cuda.Stream(device=dev) for _ in range(S)]
+    outs = [dict(ids=torch.zeros(B, top_k, dtype=torch.int64, device=dev), dst=torch.zeros(B, top_k, dtype=torch.float32, device=dev),
+                 cnt=torch.zeros(B, dtype=torch.int32, device=dev),
+                 part=torch.empty(2, B, top_k, dtype=torch.int64, device=dev),           # [keys | vec ids] of this rank
+                 allp=torch.empty(world, 2, B, top_k, dtype=torch.int64, device=dev)) for _ in range(S)]
+    ids, dst, cnt = outs[0]["ids"], outs[0]["dst"], outs[0]["cnt"]
+    st = streams[0].cuda_stream
+    torch.cuda.synchronize()
 
-    part = torch.empty(2, B, top_k, dtype=torch.int64, device=dev)            # [keys | vec ids] of this rank
-    allp = torch.empty(world, 2, B, top_k, dtype=torch.int64, device=dev)
-
-    def exchange():
+    def exchange(o):
         if backend == "nccl":
-            dist.all_gather_into_tensor(allp, part)                             # the ONE collective per batch (RCCL)
+            dist.all_gather_into_tensor(o["allp"], o["part"])                   # the ONE collective per batch (RCCL), on the batch's stream
         else:
             h = [torch.empty(2, B, top_k, dtype=torch.int64) for _ in range(world)]
-            dist.all_gather(h, part.cpu())
-            allp.copy_(torch.stack(h).to(dev))
+            dist.all_gather(h, o["part"].cpu())
+            o["allp"].copy_(torch.stack(h).to(dev))
 
     def step(i):
         qb = Q[(i % n_batches) * B:]
-        if args.ahead:  # the NEXT batch's coarse quantiser runs on a side stream under this batch's list scan
-            index.coarse_ahead_dev(Q[((i + 1) % n_batches) * B:].data_ptr(), ld, B, nprobe, st)
-        if world == 1:
-            index.search_dev(qb.data_ptr(), ld, B, top_k, nprobe, ids.data_ptr(), dst.data_ptr(), cnt.data_ptr(), st)
-        else:
-            index.search_partial_dev(qb.data_ptr(), ld, B, top_k, nprobe, part[0].data_ptr(), part[1].data_ptr(), st)
-            exchange()
-            IVFFlatIndex.merge_partials_dev(allp.data_ptr(), allp.data_ptr() + 8 * B * top_k, 2 * B * top_k, world, B, top_k,
-                                            nprobe, ids.data_ptr(), dst.data_ptr(), cnt.data_ptr(), st)
+        o = outs[i % S]
+        with torch.cuda.stream(streams[i % S]):
+            sh = streams[i % S].cuda_stream
+            if args.ahead:  # the NEXT batch's coarse quantiser runs on a side stream under this batch's list scan
+                index.coarse_ahead_dev(Q[((i + 1) % n_batches) * B:].data_ptr(), ld, B, nprobe, sh)
+            if world == 1:
+                index.search_dev(qb.data_ptr(), ld, B, top_k, nprobe, o["ids"].data_ptr(), o["dst"].data_ptr(), o["cnt"].data_ptr(), sh)
+            else:
+                index.search_partial_dev(qb.data_ptr(), ld, B, top_k, nprobe, o["part"][0].data_ptr(), o["part"][1].data_ptr(), sh)
+                exchange(o)
+                IVFFlatIndex.merge_partials_dev(o["allp"].data_ptr(), o["allp"].data_ptr() + 8 * B * top_k, 2 * B * top_k, world, B, top_k,
+                                                nprobe, o["ids"].data_ptr(), o["dst"].data_ptr(), o["cnt"].data_ptr(), sh)
 
     for i in range(args.warmup):
         step(i)
-    index.poll(st)
+    for x in streams:
+        index.poll(x.cuda_stream)
     index.scan_times(reset=True)
     barrier()
     t0 = time.perf_counter()
@@ -189,7 +201,10 @@ def main():
         step(args.warmup + i)
     barrier()
     elapsed = time.perf_counter() - t0
-    index.poll(st)  # NaN / insufficient latch -> raises
+    for x in streams:
+        index.poll(x.cuda_stream)  # NaN / insufficient latch -> raises
+    last_o = outs[(args.warmup + args.steps - 1) % S]   # the results of the last timed batch (recall, CPU comparison)
+    ids, dst, cnt = last_o["ids"], last_o["dst"], last_o["cnt"]
     ls = index.last_scan()
     scan_ms = index.scan_times(reset=True)
     if dist is not None:
@@ -199,21 +214,31 @@ def main():
     qps = args.steps * B / elapsed
 
     # ---- roofline of the dominant kernel (inverted-list scan), last batch's geometry -----------------
+    # Algorithmic bytes = what the kernel's algorithm has to read: the rows of the union of probed lists in the form the
+    # kernel streams them -- the fp16 shadow (2 B per element + 4 B of |x|^2 per row) by default, the f32 rows with
+    # VERS_SHADOW=0 / on the ordered-chain path -- plus the centroids (SURVEY 8d counts them with the batch).  The f32-row
+    # figure of SURVEY 8d for the same launch is reported next to it (`f32_rows_equivalent`): the shadow kernel beats that
+    # roofline because it does not read those bytes, not because it streams faster than HBM.
     scan_mean_ms = float(np.mean(scan_ms)) if len(scan_ms) else float("nan")
-    algo_bytes = ls["union_rows"] * d * 4 + nlist * d * 4
-    achieved = algo_bytes / (scan_mean_ms * 1e-3) / 1e9
-    # HBM traffic of the same kernel from the PMC passes of the committed rocprofv3 run (bench.py cannot collect
-    # counters itself); used only when it was measured on this exact configuration.
     pst = index.prescan_stats()
     mfma_scan = pst["batches"] > 0
-    kernel_name = ("prescan_kernel_g<false, IvfSrc<32>> (inverted-list scan on the f32 matrix cores; exact finish in ivf_rescore_kernel)" if mfma_scan
+    shadow = mfma_scan and index.shadow_state()["active"]
+    f32_bytes = ls["union_rows"] * d * 4 + nlist * d * 4
+    algo_bytes = ls["union_rows"] * (d * 2 + 4) + nlist * d * 4 if shadow else f32_bytes
+    streamed = ls["streamed_rows"] * (d * 2 + 4) if shadow else ls["streamed_rows"] * d * 4
+    achieved = algo_bytes / (scan_mean_ms * 1e-3) / 1e9
+    # HBM traffic of the same kernel from the PMC passes of the committed rocprofv3 run (bench.py cannot collect
+    # counters itself); used only when it was measured on this exact configuration and kernel.
+    kernel_id = ("prescan_kernel_g<true" if shadow else "prescan_kernel_g<false") if mfma_scan else "scan_kernel"
+    kernel_name = ("prescan_kernel_g<true, IvfSrc<32>> (inverted-list scan: fp16 shadow rows -> v_mfma_f32_32x32x16_f16; exact f32 finish in ivf_rescore_kernel)" if shadow
+                   else "prescan_kernel_g<false, IvfSrc<32>> (inverted-list scan on the f32 matrix cores; exact finish in ivf_rescore_kernel)" if mfma_scan
                    else "scan_kernel<QG,0,IvfSrc<QG>> (inverted-list scan, ordered f32 chains; QG = 16 at this shape)")
     traffic, traffic_source = None, None
     for tf in ("r02_traffic.json", "r01_traffic.json"):  # newest PMC run of this exact configuration
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", tf)))
             if (tj["config"] == {"rows": n, "d": d, "nlist": nlist, "nprobe": nprobe, "batch": B} and world == 1
-                    and tj["kernel"].startswith("prescan_kernel") == mfma_scan):
+                    and tj["kernel"].startswith(kernel_id)):
                 traffic = tj["hbm_read_bytes_per_launch"]
                 traffic_source = f"profiles/{tf}: rocprofv3 --pmc FETCH_SIZE pass of this configuration (committed; not collected in this run)"
                 break
@@ -221,11 +246,16 @@ def main():
             pass
     if rank == 0:
         log(f"[bench] list scan on the matrix cores: {pst['batches']} batches, {pst['fallback_queries']} queries failed the certificate "
-            f"and were re-scanned exactly")
+            f"and were re-scanned exactly; fp16 shadow rows {'in use' if shadow else 'not in use'}")
     roofline = {"bound": "hbm", "kernel": kernel_name, "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-                "traffic_source": traffic_source, "algorithmic_bytes_per_launch": int(algo_bytes), "streamed_bytes_per_launch": int(ls["streamed_rows"] * d * 4),
+                "traffic_source": traffic_source, "algorithmic_bytes_per_launch": int(algo_bytes), "streamed_bytes_per_launch": int(streamed),
+                "row_operand": "fp16 shadow of the rows, 2 B/element (results are the exact f32 bits)" if shadow else "f32 rows",
                 "launch_ms": round(scan_mean_ms, 4), "launches_timed": int(len(scan_ms)), "work_items": int(ls["items"])}
+    if shadow:
+        roofline["f32_rows_equivalent"] = {"bytes_per_launch": int(f32_bytes), "GBs": round(f32_bytes / (scan_mean_ms * 1e-3) / 1e9, 1),
+                                           "frac_of_peak": round(f32_bytes / (scan_mean_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                           "note": "SURVEY 8d's f32 bytes of the same union of lists over this launch time: above 1 because the kernel reads the half-size shadow instead"}
 
     # ---- recall@10 against the exact scan (utils::search_exhaustive over the same values) --------------
     last = args.warmup + args.steps - 1
@@ -297,6 +327,22 @@ def main():
                 capi.set_option("gemm_x3", 3)
         except capi.VersError:
             pass
+    if rank == 0 and world == 1 and not args.no_extra and shadow:
+        # the same batches with the f32 rows feeding the list scan (round 1's kernel; same index, same results): what the shadow buys
+        try:
+            capi.set_option("shadow", 0)
+            index.scan_times(reset=True)
+            for i in range(4):
+                index.search_dev(Q[(i % n_batches) * B:].data_ptr(), ld, B, top_k, nprobe, ids.data_ptr(), dst.data_ptr(), cnt.data_ptr(), st)
+            index.poll(st)
+            ms32 = index.scan_times(reset=True)[1:]
+            if len(ms32):
+                m = float(np.mean(ms32))
+                extra["list_scan_f32_rows"] = {"kernel": "prescan_kernel_g<false, IvfSrc<32>> (f32 rows -> v_mfma_f32_16x16x1_4b_f32)", "launch_ms": round(m, 4),
+                                               "algorithmic_bytes_per_launch": int(f32_bytes), "achieved_GBs": round(f32_bytes / (m * 1e-3) / 1e9, 1),
+                                               "frac": round(f32_bytes / (m * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+        finally:
+            capi.set_option("shadow", 1)
     if rank == 0 and world == 1 and not args.no_extra:
         # (a) single query (B = 1): the list-scan kernel alone (HIP events around its launch) over distinct queries, priced
         # on the bytes of the lists each query actually probed; and the pipelined end-to-end time per query

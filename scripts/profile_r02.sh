@@ -11,7 +11,7 @@ ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
 OUT=$ROOT/gpurun_out/prof_r02
 rm -rf "$OUT"; mkdir -p "$OUT"
 cd /tmp && export TMPDIR=/tmp
-B3="--steps 20 --warmup 5 --no-cpu --no-recall"   # (with the extra block: it times the f32 MFMA kernel of the coarse contraction too)
+B3="--steps 20 --warmup 5 --no-cpu --no-recall"   # (with the extra block: it also times the f32 MFMA kernel of the coarse contraction and the list scan on f32 rows)
 B1="--batch 1 --steps 300 --warmup 20 --no-cpu --no-recall --no-extra --kmeans-iters 2"
 run() { # tag, counters ("" = kernel trace + stats), program args...
   local tag=$1 ctr=$2; shift 2

@@ -61,34 +61,37 @@ def mean_of(cnt, kernel_sub, counter, warm=0):
 facts = {}
 # ---- cfg3 batch 1024 ----
 a3 = show_trace("cfg3 batch 1024 (bench.py --steps 20 --warmup 5)", "cfg3/trace", 5)
-f3, n3 = mean_of(pmc("cfg3/pmc_fetch"), "prescan_kernel_g", "FETCH_SIZE", 5)
-w3, _ = mean_of(pmc("cfg3/pmc_write"), "prescan_kernel_g", "WRITE_SIZE", 5)
-pk = [v for k, v in a3.items() if "prescan_kernel_g" in k]
+# the production list-scan kernel: <true = fp16 shadow rows (default), <false = f32 rows (VERS_SHADOW=0; also run by bench.py's extra block)
+PK = "prescan_kernel_g<true" if any("prescan_kernel_g<true" in k for k in a3) else "prescan_kernel_g<false"
+f3, n3 = mean_of(pmc("cfg3/pmc_fetch"), PK, "FETCH_SIZE", 5)
+w3, _ = mean_of(pmc("cfg3/pmc_write"), PK, "WRITE_SIZE", 5)
+pk = [v for k, v in a3.items() if PK in k]
 if pk and f3:
     d = pk[0][5:]
-    print(f"prescan_kernel_g: mean {sum(d)/len(d):.1f} us over {len(d)} warm dispatches (min {min(d):.1f}); FETCH_SIZE mean {f3:.0f} KB over {n3} "
+    print(f"{PK}...>: mean {sum(d)/len(d):.1f} us over {len(d)} warm dispatches (min {min(d):.1f}); FETCH_SIZE mean {f3:.0f} KB over {n3} "
           f"dispatches -> HBM read bytes per launch = FETCH_SIZE * 1024 * 2 = {f3*1024*2:.4g}; WRITE_SIZE mean {w3 or 0:.0f} KB")
-    facts["cfg3"] = {"kernel": "prescan_kernel_g<false, IvfSrc<32>>", "config": {"rows": 10000000, "d": 768, "nlist": 4096, "nprobe": 32, "batch": 1024},
+    facts["cfg3"] = {"kernel": PK + ", IvfSrc<32>>", "config": {"rows": 10000000, "d": 768, "nlist": 4096, "nprobe": 32, "batch": 1024},
                      "FETCH_SIZE_KB_mean": f3, "WRITE_SIZE_KB_mean": w3, "hbm_read_bytes_per_launch": int(f3 * 1024 * 2),
                      "kernel_mean_us": sum(d) / len(d), "kernel_min_us": min(d),
                      "correction": "gfx950 reports half the bytes of wide coalesced streaming reads (MI355X_MICROARCH.md, HBM section): x2",
-                     "source": "profiles/r02_summary.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `python3 bench.py --steps 20 --warmup 5 --no-cpu --no-recall --no-extra`)"}
+                     "source": "profiles/r02_summary.txt (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of `python3 bench.py --steps 20 --warmup 5 --no-cpu --no-recall`)"}
 m = pmc("cfg3/pmc_mfma")
 for sub, label, flops in (("dist_gemm_x3_kernel<false", "coarse contraction [1024 x 768].[768 x 4096] as 3 bf16 products (production)", 2 * 1024 * 4096 * 768),
                           ("dist_gemm_kernel<false", "coarse contraction, f32 MFMA kernel (bench.py extra.coarse_gemm_f32)", 2 * 1024 * 4096 * 768),
-                          ("prescan_kernel_g", "list scan", None)):
+                          ("prescan_kernel_g<true", "list scan, fp16 shadow rows (production)", None),
+                          ("prescan_kernel_g<false", "list scan, f32 rows (bench.py extra.list_scan_f32_rows)", None)):
     busy, _ = mean_of(m, sub, "SQ_VALU_MFMA_BUSY_CYCLES", 2); gui, _ = mean_of(m, sub, "GRBM_GUI_ACTIVE", 2)
     d = [v for k, v in a3.items() if sub in k]
     if busy and gui and d:
-        dd = d[0][5:]
-        dd = d[0][5:] if len(d[0]) > 5 else d[0]
+        dd = d[0][5:] if len(d[0]) > 5 else d[0][1:] if len(d[0]) > 1 else d[0]
         extra = f"; {flops/(sum(dd)/len(dd))/1e6:.1f} algorithmic TFLOP/s mean, {flops/min(dd)/1e6:.1f} best = {flops/(sum(dd)/len(dd))/1e6/157.3*100:.1f} % / {flops/min(dd)/1e6/157.3*100:.1f} % of the 157.3 TFLOP/s f32 MFMA peak" if flops else ""
         # busy cycles are summed over the chip's 1024 SIMDs, GRBM_GUI_ACTIVE over its 8 XCDs
         print(f"{label}: SQ_VALU_MFMA_BUSY_CYCLES {busy:.4g} / 1024 SIMDs = {busy/1024:.4g} busy cycles per SIMD; GRBM_GUI_ACTIVE {gui:.4g} / 8 XCDs = "
               f"{gui/8:.4g} kernel cycles -> MFMA-busy {busy/1024/(gui/8)*100:.1f} %; kernel mean {sum(dd)/len(dd):.1f} us (trace){extra}")
 sq = pmc("cfg3/pmc_sq")
-for sub in ("prescan_kernel_g", "coarse_select_rescore", "ivf_rescore_kernel", "plan_fused_kernel", "dist_gemm_x3_kernel<false", "dist_gemm_x3_kernel<true"):
-    wc, _ = mean_of(sq, sub, "SQ_WAVE_CYCLES", 5); va, _ = mean_of(sq, sub, "SQ_ACTIVE_INST_VALU", 5); wa, _ = mean_of(sq, sub, "SQ_WAIT_ANY", 5)
+for sub in ("prescan_kernel_g<true", "prescan_kernel_g<false", "coarse_select_rescore", "ivf_rescore_kernel", "plan_fused_kernel", "dist_gemm_x3_kernel<false", "dist_gemm_x3_kernel<true"):
+    warm = 1 if sub == "prescan_kernel_g<false" else 5
+    wc, _ = mean_of(sq, sub, "SQ_WAVE_CYCLES", warm); va, _ = mean_of(sq, sub, "SQ_ACTIVE_INST_VALU", warm); wa, _ = mean_of(sq, sub, "SQ_WAIT_ANY", warm)
     if wc:
         print(f"{sub}: VALU-active {100*(va or 0)/wc:.0f} % of wave cycles, waiting (any) {100*(wa or 0)/wc:.0f} %")
 print()
