@@ -275,8 +275,11 @@ struct GroupTotals {
 __device__ __forceinline__ void group_lists(const uint32_t* cnt, const uint32_t* list_len, uint32_t k_lists, uint32_t QG, uint32_t seg_rows,
                                             uint32_t seg_target, const uint32_t* hot, uint32_t* pair_off,
                                             uint32_t* group_off, uint32_t* item_off, GroupTotals* tot) {
-  // three exclusive prefix sums over the lists in one pass: wave scans by shuffles, 16 wave totals through LDS,
-  // a running carry between rounds of 1024 lists (the LDS Hillis-Steele version was 26 us at 4096 lists)
+  // four exclusive prefix sums over the lists (pairs, groups, items of hot lists, items of the others) in rounds of 4096
+  // lists: a thread owns FOUR consecutive lists (three 16-byte loads, a serial scan in registers), the waves scan the
+  // thread totals by shuffles, 16 wave totals go through LDS, a running carry links the rounds.  One round and two block
+  // barriers at 4096 lists (a thread per list took four rounds of two barriers, each round a chain of dependent LDS and
+  // shuffle steps: 20 us of the planning kernel's 40-55; the LDS Hillis-Steele version before it 26 us).
   __shared__ uint32_t wp[16], wg[16], wi[16], wh[16];
   __shared__ unsigned long long ur, sr;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
@@ -291,51 +294,66 @@ __device__ __forceinline__ void group_lists(const uint32_t* cnt, const uint32_t*
     }
     return x;
   };
-  for (uint32_t base0 = 0; base0 < k_lists; base0 += 8 * 1024) {
-    // all loads of up to eight rounds first (independent), then the scans: the rounds were latency chains
-    uint32_t cs[8], ls[8], hs[8];
+  // whole 16-byte vectors when every table starts on one (they are carved out of one allocation: true when k, b are multiples of 4)
+  const bool vec_ok = (k_lists & 3u) == 0 &&
+                      (((uintptr_t)cnt | (uintptr_t)list_len | (uintptr_t)hot | (uintptr_t)pair_off | (uintptr_t)group_off | (uintptr_t)item_off) & 15u) == 0;
+  for (uint32_t base0 = 0; base0 < k_lists; base0 += 4 * 1024) {
+    const uint32_t i0 = base0 + 4u * threadIdx.x;
+    uint32_t c4[4] = {0, 0, 0, 0}, l4[4] = {0, 0, 0, 0}, h4[4] = {0, 0, 0, 0};
+    if (vec_ok && i0 < k_lists) {
+      const u32x4 cv = *reinterpret_cast<const u32x4*>(cnt + i0), lv = *reinterpret_cast<const u32x4*>(list_len + i0),
+                  hv = *reinterpret_cast<const u32x4*>(hot + i0);
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      const uint32_t i = base0 + r * 1024 + threadIdx.x;
-      cs[r] = i < k_lists ? cnt[i] : 0u;
-      ls[r] = i < k_lists ? list_len[i] : 0u;
-      hs[r] = i < k_lists ? hot[i] : 0u;
+      for (int e = 0; e < 4; ++e) { c4[e] = cv[e]; l4[e] = lv[e]; h4[e] = hv[e]; }
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (i0 + e < k_lists) { c4[e] = cnt[i0 + e]; l4[e] = list_len[i0 + e]; h4[e] = hot[i0 + e]; }
     }
+    uint32_t g4[4], ic4[4], ih4[4];
+    uint32_t tp = 0, tg = 0, tic = 0, tih = 0;  // the thread's totals
 #pragma unroll
-    for (int r = 0; r < 8; ++r) {
-      const uint32_t i = base0 + r * 1024 + threadIdx.x;
-      if (base0 + r * 1024 >= k_lists) break;  // block-uniform
-      const uint32_t L = i;
-      const uint32_t c = cs[r];
+    for (int e = 0; e < 4; ++e) {
       uint32_t g = 0, it = 0;
-      if (c) {
-        const uint32_t len = ls[r];
-        g = (c + QG - 1) / QG;
-        const uint32_t sr2 = list_seg_rows(len, seg_rows, seg_target);
-        const uint32_t n_s = (len + sr2 - 1) / sr2;
+      if (c4[e]) {
+        g = (c4[e] + QG - 1) / QG;
+        const uint32_t sr2 = list_seg_rows(l4[e], seg_rows, seg_target);
+        const uint32_t n_s = (l4[e] + sr2 - 1) / sr2;
         it = g * (QG == 1 ? n_s : (n_s + 3) / 4 * 4);  // QG > 1: quads of items share a query block
-        my_ur += len;
-        my_sr += (unsigned long long)len * g;
+        my_ur += l4[e];
+        my_sr += (unsigned long long)l4[e] * g;
       }
-      const bool is_hot = hs[r] != 0;
-      const uint32_t it_c = is_hot ? 0u : it, it_h = is_hot ? it : 0u;
-      const uint32_t ip = wave_incl(c), ig = wave_incl(g), ii = wave_incl(it_c), ih = wave_incl(it_h);
-      __syncthreads();  // previous round's readers of wp/wg/wi/wh are done
-      if (lane == kWave - 1) { wp[wid] = ip; wg[wid] = ig; wi[wid] = ii; wh[wid] = ih; }
-      __syncthreads();
-      uint32_t bp = 0, bg = 0, bi2 = 0, bh = 0, tp = 0, tg = 0, ti2 = 0, th = 0;
-#pragma unroll
-      for (int w = 0; w < 16; ++w) {
-        if (w < wid) { bp += wp[w]; bg += wg[w]; bi2 += wi[w]; bh += wh[w]; }
-        tp += wp[w]; tg += wg[w]; ti2 += wi[w]; th += wh[w];
-      }
-      if (i < k_lists) {
-        pair_off[L] = cp + bp + ip - c;
-        group_off[L] = cg + bg + ig - g;
-        item_off[L] = is_hot ? ch + bh + ih - it_h : ci + bi2 + ii - it_c;  // the others are shifted below
-      }
-      cp += tp; cg += tg; ci += ti2; ch += th;
+      g4[e] = g; ic4[e] = h4[e] ? 0u : it; ih4[e] = h4[e] ? it : 0u;
+      tp += c4[e]; tg += g; tic += ic4[e]; tih += ih4[e];
     }
+    const uint32_t ip = wave_incl(tp), ig = wave_incl(tg), ii = wave_incl(tic), ih = wave_incl(tih);
+    __syncthreads();  // previous round's readers of wp/wg/wi/wh are done
+    if (lane == kWave - 1) { wp[wid] = ip; wg[wid] = ig; wi[wid] = ii; wh[wid] = ih; }
+    __syncthreads();
+    uint32_t bp = 0, bg = 0, bi2 = 0, bh = 0, rp = 0, rg = 0, ri = 0, rh = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+      if (w < wid) { bp += wp[w]; bg += wg[w]; bi2 += wi[w]; bh += wh[w]; }
+      rp += wp[w]; rg += wg[w]; ri += wi[w]; rh += wh[w];
+    }
+    // exclusive offsets of the thread's first list, then along its four
+    uint32_t op = cp + bp + ip - tp, og = cg + bg + ig - tg, oc = ci + bi2 + ii - tic, oh = ch + bh + ih - tih;
+    uint32_t po[4], go[4], io[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      po[e] = op; go[e] = og; io[e] = h4[e] ? oh : oc;  // (the others' item offsets are shifted behind the hot lists' below)
+      op += c4[e]; og += g4[e]; oc += ic4[e]; oh += ih4[e];
+    }
+    if (vec_ok && i0 < k_lists) {
+      *reinterpret_cast<u32x4*>(pair_off + i0) = u32x4{po[0], po[1], po[2], po[3]};
+      *reinterpret_cast<u32x4*>(group_off + i0) = u32x4{go[0], go[1], go[2], go[3]};
+      *reinterpret_cast<u32x4*>(item_off + i0) = u32x4{io[0], io[1], io[2], io[3]};
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (i0 + e < k_lists) { pair_off[i0 + e] = po[e]; group_off[i0 + e] = go[e]; item_off[i0 + e] = io[e]; }
+    }
+    cp += rp; cg += rg; ci += ri; ch += rh;
   }
   __syncthreads();
 #pragma unroll
@@ -348,8 +366,12 @@ __device__ __forceinline__ void group_lists(const uint32_t* cnt, const uint32_t*
     atomicAdd(&sr, my_sr);
   }
   __syncthreads();
-  for (uint32_t L = threadIdx.x; L < k_lists; L += 1024)  // (each thread shifts entries it wrote itself: L % 1024 == threadIdx.x)
-    if (cnt[L] != 0 && hot[L] == 0) item_off[L] += ch;
+  for (uint32_t base0 = 0; base0 < k_lists; base0 += 4 * 1024)  // (each thread shifts the entries it wrote itself)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const uint32_t L = base0 + 4u * threadIdx.x + e;
+      if (L < k_lists && cnt[L] != 0 && hot[L] == 0) item_off[L] += ch;
+    }
   if (threadIdx.x == 0) {
     tot->n_items = ci + ch; tot->n_groups = cg; tot->n_pairs = cp; tot->pad = 0;
     tot->union_rows = ur; tot->streamed_rows = sr;
@@ -1696,7 +1718,9 @@ int32_t coarse_mfma(vers_ivf* h, const float* qp, uint32_t b, uint32_t P, uint64
 // out_n_segs != nullptr: stop after the scan (partial slots in W->cpart) and report the slot count per query --
 // the single-query path merges them inside plan1_kernel.
 int32_t coarse(vers_ivf* h, const float* qp, uint32_t b, uint32_t P, hipStream_t st, uint32_t* out_n_segs = nullptr) {
-  if (coarse_on_matrix_cores(h, b) && qp == W->qp.as<float>() && P + 16 <= (uint32_t)kMaxTopK) {  // (the selection keeps P + 16 keys: one per lane)
+  // (the contraction reads whole 128-row tiles: the staged block is padded to them, a caller's block used in place is a whole
+  // number of them; the selection keeps P + 16 keys: one per lane)
+  if (coarse_on_matrix_cores(h, b) && (qp == W->qp.as<float>() || b % kGemmBM == 0) && P + 16 <= (uint32_t)kMaxTopK) {
     if (int32_t rc = W->probe.reserve((size_t)b * P * sizeof(uint64_t))) return rc;
     return coarse_mfma(h, qp, b, P, W->probe.as<uint64_t>(), st);
   }
@@ -1864,7 +1888,9 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
   } else {
     for (auto& a : W->ahead)  // W->gbuf is shared with a look-ahead in flight: let it finish first
       if (a.ready_rec) VERS_HIP_TRY(hipStreamWaitEvent(st, a.ready, 0));
-    if (b == 1 && h->d == h->ldq && (reinterpret_cast<uintptr_t>(q_dev) & 15u) == 0) qp = q_dev;  // a single unpadded-is-padded query: no staging launch
+    // the caller's block as it is when its layout already is the staged one: no padding columns to zero (d == ldq), the same
+    // pitch, and -- the matrix-core contraction reads whole 128-row tiles -- a whole number of tiles (or a single query)
+    if (h->d == h->ldq && (reinterpret_cast<uintptr_t>(q_dev) & 15u) == 0 && (b == 1 || (ldq_in == h->ldq && b % kGemmBM == 0))) qp = q_dev;
     else if (int32_t rc = stage_plain_queries(h, q_dev, ldq_in, b, &qp, st)) return rc;
     if (int32_t rc = coarse(h, qp, b, P, st, one1 ? &n_segs_c : nullptr)) return rc;
     probe = W->probe.as<uint64_t>();
@@ -2048,12 +2074,10 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
     hipLaunchKernelGGL(ivf_rescore_kernel, dim3(b), dim3(kWave * kRescoreWaves), rs_lds, st, a, stage_rows);
     VERS_HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(fallback_kernel, dim3(fb_blocks), dim3(kWave * kMergeWaves), 0, st, a, (const uint32_t*)h->slot_len.as<uint32_t>(),
-                       (const uint32_t*)fail_list, (const uint32_t*)(fail_list + b), W->fb_part.as<uint64_t>(), W->fb_ctr.as<uint32_t>());
+                       (const uint32_t*)fail_list, (const uint32_t*)(fail_list + b), W->fb_part.as<uint64_t>(), W->fb_ctr.as<uint32_t>(),
+                       use_shadow ? h->fail_watch : (uint32_t*)nullptr);
     VERS_HIP_TRY(hipGetLastError());
-    if (use_shadow) {  // feed the watch word (see vers_ivf::rows_bf)
-      h->shadow_queries += b;
-      VERS_HIP_TRY(hipMemcpyAsync(h->fail_watch, h->pre_misc.as<uint32_t>() + 1, 4, hipMemcpyDeviceToHost, st));
-    }
+    if (use_shadow) h->shadow_queries += b;  // (fallback_kernel writes the running failure count to the pinned watch word)
     h->pre_batches += 1;
     W->tot_valid = true;
     if (took) { VERS_HIP_TRY(hipEventRecord(took->freed, st)); took->freed_rec = true; }

@@ -855,13 +855,17 @@ inline size_t fallback_part_keys(uint32_t blocks, uint32_t P, uint32_t top_k) { 
   return (size_t)blocks * (P > 2 ? P : 2) * kMergeWaves * top_k;
 }
 __global__ __launch_bounds__(kWave * kMergeWaves) void fallback_kernel(RescoreArgs a, const uint32_t* list_len, const uint32_t* fail_list,
-                                                                       const uint32_t* fail_count, uint64_t* fb_part, uint32_t* ctr) {
+                                                                       const uint32_t* fail_count, uint64_t* fb_part, uint32_t* ctr,
+                                                                       uint32_t* watch) {
   __shared__ uint64_t sh[kMergeWaves][kWave];
   __shared__ uint32_t s_last;
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const uint32_t n_fail = *fail_count;
   if (n_fail == 0) return;
+  // `watch` (nullable): pinned host word the host polls to retire an fp16 shadow that fails too often; a.stats[0] is final
+  // for this batch (ivf_rescore_kernel, which counts, is done) and only moves when queries were queued
+  if (watch != nullptr && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(watch, a.stats[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   uint32_t G = 1;
   while (G < 64u && 2u * G * n_fail <= gridDim.x) G *= 2u;
   const uint32_t n_groups = gridDim.x / G;
