@@ -60,7 +60,7 @@ def mean_of(cnt, kernel_sub, counter, warm=0):
 
 facts = {}
 # ---- cfg3 batch 1024 ----
-a3 = show_trace("cfg3 batch 1024 (bench.py --steps 20 --warmup 5)", "cfg3/trace", 5)
+a3 = show_trace("cfg3 batch 1024 (bench.py --steps 20 --warmup 5)", "cfg3/trace", 5, top=30)
 # the production list-scan kernel: <true = fp16 shadow rows (default), <false = f32 rows (VERS_SHADOW=0; also run by bench.py's extra block)
 PK = "prescan_kernel_g<true" if any("prescan_kernel_g<true" in k for k in a3) else "prescan_kernel_g<false"
 f3, n3 = mean_of(pmc("cfg3/pmc_fetch"), PK, "FETCH_SIZE", 5)
@@ -123,8 +123,10 @@ for f in glob.glob(os.path.join(out, "shard8/trace", "**", "*kernel_trace.csv"),
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 idx = [i for i, r in enumerate(rows) if "prescan_kernel" in r["Kernel_Name"]]
 if len(idx) >= 20:
-    j = idx[-20]
-    while j > 0 and "stage" not in rows[j]["Kernel_Name"]:
+    j = idx[-20]   # back to the first kernel of that step: the query staging, or -- when the caller's block is used in place -- the contraction
+    while j > 0 and "stage_queries" not in rows[j]["Kernel_Name"] and "dist_gemm" not in rows[j]["Kernel_Name"]:
+        j -= 1
+    if j > 0 and "stage_queries" in rows[j - 1]["Kernel_Name"]:
         j -= 1
     sel = rows[j:]
     last = max(i for i, r in enumerate(sel) if "fallback_kernel" in r["Kernel_Name"] or "ivf_merge_kernel" in r["Kernel_Name"])
