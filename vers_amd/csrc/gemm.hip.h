@@ -238,16 +238,41 @@ static __global__ __launch_bounds__(256) void dist_gemm_kernel(const float* __re
 constexpr float kX3Slack = 1.6e-5f;  // >= 2 * 3 * 2^-18 (G = norm - 2 dot doubles the dot's error), rounded up
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
-constexpr int kX3Pitch = 40;  // bf16 per LDS row: 32 of a K-tile + 8 of padding (80 bytes: conflict-free ds_read_b128 by row)
-constexpr size_t kX3LdsBytes = 2 * 2 * 2 * (size_t)kGemmBM * kX3Pitch * 2;  // two buffers x A|B x hi|lo = 80 KB: two blocks per CU
+// LDS rows are the 32 bf16 of a K-tile, 64 bytes, unpadded; the four 16-byte chunks of row r sit at chunk ^ ((r >> 2) & 3).
+// A ds_read_b128 is served in groups of 16 lanes = 16 rows with r % 4 and (r >> 2) % 4 covering all 16 combinations, so the
+// group touches all 64 banks once; the 8-byte split stores of 16 consecutive threads cover two whole rows = 32 banks once.
+// (The first cut padded rows to 80 bytes: conflict-free reads, but every split store 2-way conflicted -- a third of the
+// kernel's LDS cycles by SQ_LDS_BANK_CONFLICT.)
+constexpr int kX3Pitch = 32;
+__device__ __forceinline__ int x3_chunk(int row, int chunk) { return (chunk ^ ((row >> 2) & 3)) * 8; }  // bf16 offset inside the row
+constexpr size_t kX3LdsBytes = 2 * 2 * 2 * (size_t)kGemmBM * kX3Pitch * 2;  // two buffers x A|B x hi|lo = 64 KB: two blocks per CU
 
-template <bool NORM_ROWS>
+// x -> bf16 hi, lo (both round-to-nearest; the split the kernel below otherwise does on the fly), for an operand that many
+// blocks re-read: the centroids -- M operand of the k-means assign pass (split once per pass), N operand of the coarse
+// quantiser (split when the index is installed).  PRE bit 0: the M operand comes pre-split (Qh, Ql), bit 1: the N operand.
+static __global__ void split_bf16_kernel(const float* __restrict__ x, uint64_t n4, __bf16* __restrict__ hi, __bf16* __restrict__ lo) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n4) return;
+  const f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
+  bf16x4 h, l;
+#pragma unroll
+  for (int u = 0; u < 4; ++u) {
+    h[u] = (__bf16)v[u];
+    l[u] = (__bf16)(v[u] - (float)h[u]);
+  }
+  reinterpret_cast<bf16x4*>(hi)[i] = h;
+  reinterpret_cast<bf16x4*>(lo)[i] = l;
+}
+
+template <bool NORM_ROWS, int PRE>
 static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2))) void dist_gemm_x3_kernel(const float* __restrict__ Q, const float* __restrict__ C,
+                                                                  const __bf16* __restrict__ Qh, const __bf16* __restrict__ Ql,
+                                                                  const __bf16* __restrict__ Ch, const __bf16* __restrict__ Cl,
                                                                   const float* __restrict__ cnorm, uint32_t K, uint32_t N_pad,
                                                                   float* __restrict__ G, int metric, uint32_t m_tiles, uint32_t n_tiles, uint32_t grp, uint32_t k_rows = 0,
                                                                   float* __restrict__ part_v1 = nullptr, uint32_t* __restrict__ part_c1 = nullptr,
                                                                   float* __restrict__ part_v2 = nullptr) {
-  // [buffer][matrix A|B][part hi|lo][128 rows][kX3Pitch] bf16 = 2 x 40 KB: the split tile of step k+1 is written while the
+  // [buffer][matrix A|B][part hi|lo][128 rows][kX3Pitch] bf16 = 2 x 32 KB: the split tile of step k+1 is written while the
   // MFMAs of step k read the other buffer (ONE barrier per K-tile), and the global loads run TWO tiles ahead in
   // registers -- with the MFMA time of a tile down to ~770 cycles a single tile of prefetch no longer covers the L2 /
   // Infinity-Cache latency (the first cut of this kernel, single-buffered with one tile of prefetch: 3.83 ms per
@@ -268,32 +293,61 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.0f;
   const int srow = tid >> 3, sc4 = tid & 7;  // rows srow + 32*i, float4 column sc4
+  // an f32 operand: 4 float4 per thread and tile; a pre-split one: 2 x 16 bytes of hi ([0], [1]) and of lo ([2], [3]) --
+  // thread t serves (row, 16-byte chunk) = ((t + 256 i) >> 2, (t + 256 i) & 3), i = 0, 1
   f32x4 ra[2][4], rb[2][4];
   auto gload = [&](auto stag, uint32_t k0) {
     constexpr int S = decltype(stag)::value;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      ra[S][i] = *reinterpret_cast<const f32x4*>(Q + (uint64_t)(m0 + srow + 32 * i) * K + k0 + sc4 * 4);
-      rb[S][i] = *reinterpret_cast<const f32x4*>(C + (uint64_t)(n0 + srow + 32 * i) * K + k0 + sc4 * 4);
+      if constexpr (!(PRE & 1)) ra[S][i] = *reinterpret_cast<const f32x4*>(Q + (uint64_t)(m0 + srow + 32 * i) * K + k0 + sc4 * 4);
+      if constexpr (!(PRE & 2)) rb[S][i] = *reinterpret_cast<const f32x4*>(C + (uint64_t)(n0 + srow + 32 * i) * K + k0 + sc4 * 4);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int idx = tid + 256 * i;
+      if constexpr (PRE & 1) {
+        const uint64_t at = (uint64_t)(m0 + (idx >> 2)) * K + k0 + (idx & 3) * 8;
+        ra[S][i] = *reinterpret_cast<const f32x4*>(Qh + at);
+        ra[S][2 + i] = *reinterpret_cast<const f32x4*>(Ql + at);
+      }
+      if constexpr (PRE & 2) {
+        const uint64_t at = (uint64_t)(n0 + (idx >> 2)) * K + k0 + (idx & 3) * 8;
+        rb[S][i] = *reinterpret_cast<const f32x4*>(Ch + at);
+        rb[S][2 + i] = *reinterpret_cast<const f32x4*>(Cl + at);
+      }
     }
   };
-  auto split_store = [&](const f32x4& x, __bf16* hi_row, __bf16* lo_row) {
+  auto split_store = [&](const f32x4& x, int row, __bf16* hi_row, __bf16* lo_row) {
     bf16x4 h, l;
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
       h[u] = (__bf16)x[u];
       l[u] = (__bf16)(x[u] - (float)h[u]);
     }
-    *reinterpret_cast<bf16x4*>(hi_row + sc4 * 4) = h;
-    *reinterpret_cast<bf16x4*>(lo_row + sc4 * 4) = l;
+    const int at = x3_chunk(row, sc4 >> 1) + (sc4 & 1) * 4;
+    *reinterpret_cast<bf16x4*>(hi_row + at) = h;
+    *reinterpret_cast<bf16x4*>(lo_row + at) = l;
   };
   auto lstore = [&](auto stag, int buf) {
     constexpr int S = decltype(stag)::value;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int row = srow + 32 * i;
-      split_store(ra[S][i], Tp(buf, 0, 0) + row * kX3Pitch, Tp(buf, 0, 1) + row * kX3Pitch);
-      split_store(rb[S][i], Tp(buf, 1, 0) + row * kX3Pitch, Tp(buf, 1, 1) + row * kX3Pitch);
+      if constexpr (!(PRE & 1)) split_store(ra[S][i], row, Tp(buf, 0, 0) + row * kX3Pitch, Tp(buf, 0, 1) + row * kX3Pitch);
+      if constexpr (!(PRE & 2)) split_store(rb[S][i], row, Tp(buf, 1, 0) + row * kX3Pitch, Tp(buf, 1, 1) + row * kX3Pitch);
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int idx = tid + 256 * i, row = idx >> 2, at = row * kX3Pitch + x3_chunk(row, idx & 3);
+      if constexpr (PRE & 1) {
+        *reinterpret_cast<f32x4*>(Tp(buf, 0, 0) + at) = ra[S][i];
+        *reinterpret_cast<f32x4*>(Tp(buf, 0, 1) + at) = ra[S][2 + i];
+      }
+      if constexpr (PRE & 2) {
+        *reinterpret_cast<f32x4*>(Tp(buf, 1, 0) + at) = rb[S][i];
+        *reinterpret_cast<f32x4*>(Tp(buf, 1, 1) + at) = rb[S][2 + i];
+      }
     }
   };
   const int r = lane & 31, hh = lane >> 5;
@@ -303,7 +357,7 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2
       bf16x8 ah[2], al[2], bh[2], bl[2];
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
-        const int ko = 16 * s2 + 8 * hh;
+        const int ko = x3_chunk(r, 2 * s2 + hh);  // (the row offsets wr * 64 + t * 32 do not change (row >> 2) & 3)
         ah[t] = *reinterpret_cast<const bf16x8*>(Tp(buf, 0, 0) + (wr * 64 + t * 32 + r) * kX3Pitch + ko);
         al[t] = *reinterpret_cast<const bf16x8*>(Tp(buf, 0, 1) + (wr * 64 + t * 32 + r) * kX3Pitch + ko);
         bh[t] = *reinterpret_cast<const bf16x8*>(Tp(buf, 1, 0) + (wc * 64 + t * 32 + r) * kX3Pitch + ko);
@@ -321,23 +375,26 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2
   };
   using S0 = std::integral_constant<int, 0>;
   using S1 = std::integral_constant<int, 1>;
-  // tiles: t = k0 / 32.  Registers hold tiles t+1 (slot (t+1)&1) and t+2 while LDS buffer t&1 is read.
-  const uint32_t k_tiles = K / kGemmBK;
+  // tiles: t = k0 / 32.  Registers hold tiles t+1 (slot (t+1)&1) and t+2 while LDS buffer t&1 is read.  K is a multiple of
+  // 64 (kColAlign): an even number of tiles, so the loop body is a straight pair of steps; past the end the prefetch re-reads
+  // the last tile and the store goes to a buffer nobody reads any more (branches around them cost the compiler's counted
+  // waits and a copy of the 64 accumulator registers per step).
+  const uint32_t k_tiles = K / kGemmBK, k_last = K - kGemmBK;
+  auto kclamp = [&](uint32_t t) { const uint32_t k0 = t * kGemmBK; return k0 < k_last ? k0 : k_last; };
   gload(S0{}, 0);
-  if (k_tiles > 1) gload(S1{}, kGemmBK);
+  gload(S1{}, kclamp(1));
   lstore(S0{}, 0);
-  if (k_tiles > 2) gload(S0{}, 2 * kGemmBK);
+  gload(S0{}, kclamp(2));
   __syncthreads();
   for (uint32_t t = 0; t < k_tiles; t += 2) {
     // even tile t: LDS buffer 0; registers: slot 1 = tile t+1, slot 0 = tile t+2
-    if (t + 1 < k_tiles) lstore(S1{}, 1);             // tile t+1 -> buffer 1 (its readers finished before the last barrier)
-    if (t + 3 < k_tiles) gload(S1{}, (t + 3) * kGemmBK);
+    lstore(S1{}, 1);             // tile t+1 -> buffer 1 (its readers finished before the last barrier)
+    gload(S1{}, kclamp(t + 3));
     compute(0);
     __syncthreads();
-    if (t + 1 >= k_tiles) break;
     // odd tile t+1: LDS buffer 1; registers: slot 0 = tile t+2, slot 1 = tile t+3
-    if (t + 2 < k_tiles) lstore(S0{}, 0);
-    if (t + 4 < k_tiles) gload(S0{}, (t + 4) * kGemmBK);
+    lstore(S0{}, 0);
+    gload(S0{}, kclamp(t + 4));
     compute(1);
     __syncthreads();
   }
@@ -347,21 +404,35 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2
 
 // Launch of either contraction kernel (the bf16x3 one needs the attribute for its 80 KB of dynamic LDS: set once per
 // instantiation and process).
+// sh / sl: the centroid operand pre-split by split_bf16_kernel (nullable: split on the fly) -- the M operand of the assign
+// pass (NORM_ROWS), the N operand of the coarse quantiser.
 template <bool NORM_ROWS>
 inline hipError_t launch_gemm(bool x3, uint32_t m_tiles, uint32_t n_tiles, hipStream_t st, const float* Q, const float* C, const float* cnorm,
                               uint32_t K, uint32_t N_pad, float* G, uint32_t metric, uint32_t k_rows = 0, float* part_v1 = nullptr,
-                              uint32_t* part_c1 = nullptr, float* part_v2 = nullptr) {
+                              uint32_t* part_c1 = nullptr, float* part_v2 = nullptr, const __bf16* sh = nullptr, const __bf16* sl = nullptr) {
   const uint32_t grp = NORM_ROWS ? gemm_tile_group(m_tiles) : 0;
   if (!x3) {
     hipLaunchKernelGGL(dist_gemm_kernel<NORM_ROWS>, dim3(m_tiles * n_tiles), dim3(256), 0, st, Q, C, cnorm, K, N_pad, G, metric, m_tiles, n_tiles,
                        grp, k_rows, part_v1, part_c1, part_v2);
     return hipGetLastError();
   }
-  static const hipError_t attr = hipFuncSetAttribute((const void*)dist_gemm_x3_kernel<NORM_ROWS>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                                     (int)kX3LdsBytes);
-  if (attr != hipSuccess) return attr;
-  hipLaunchKernelGGL(dist_gemm_x3_kernel<NORM_ROWS>, dim3(m_tiles * n_tiles), dim3(256), kX3LdsBytes, st, Q, C, cnorm, K, N_pad, G, metric, m_tiles,
-                     n_tiles, grp, k_rows, part_v1, part_c1, part_v2);
+  constexpr int kPreBit = NORM_ROWS ? 1 : 2;
+  auto go = [&](auto pre_tag) {
+    constexpr int PRE = decltype(pre_tag)::value;
+    static const hipError_t attr = hipFuncSetAttribute((const void*)dist_gemm_x3_kernel<NORM_ROWS, PRE>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                                       (int)kX3LdsBytes);
+    if (attr != hipSuccess) return attr;
+    const __bf16* qh = NORM_ROWS ? sh : nullptr; const __bf16* ql = NORM_ROWS ? sl : nullptr;
+    const __bf16* ch = NORM_ROWS ? nullptr : sh; const __bf16* cl = NORM_ROWS ? nullptr : sl;
+    hipLaunchKernelGGL((dist_gemm_x3_kernel<NORM_ROWS, PRE>), dim3(m_tiles * n_tiles), dim3(256), kX3LdsBytes, st, Q, C, qh, ql, ch, cl, cnorm, K,
+                       N_pad, G, metric, m_tiles, n_tiles, grp, k_rows, part_v1, part_c1, part_v2);
+    return hipGetLastError();
+  };
+  return (sh && sl) ? go(std::integral_constant<int, kPreBit>{}) : go(std::integral_constant<int, 0>{});
+}
+inline hipError_t launch_split_bf16(const float* x, uint64_t n_floats, __bf16* hi, __bf16* lo, hipStream_t st) {  // n_floats % 4 == 0
+  const uint64_t n4 = n_floats / 4;
+  hipLaunchKernelGGL(split_bf16_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, st, x, n4, hi, lo);
   return hipGetLastError();
 }
 

@@ -808,6 +808,7 @@ struct vers_ivf {
   DevBuf centroids_b;  // the same in lane-transposed tiles (exact coarse quantiser)
   // MFMA pre-selection of the batched coarse quantiser (gemm.hip.h)
   DevBuf centroids_g;  // row-major [k_pad][ldq], zero padded
+  DevBuf centroids_gs; // the same split into bf16 hi | lo halves [2][k_pad][ldq]
   DevBuf cnorm;        // |c|^2 [k_pad], +inf in the padding
   DevBuf coarse_stat;  // u32: queries that failed the certificate and were re-done exactly
   float cmax2 = 0.0f;
@@ -1190,6 +1191,11 @@ int32_t finish_index(vers_ivf* h, uint32_t k, uint64_t n_total, hipStream_t st) 
   hipLaunchKernelGGL(row_norms_kernel, dim3((h->k_pad + 255) / 256), dim3(256), 0, st, h->centroids_g.as<float>(), h->ldq, k, h->k_pad,
                      h->cnorm.as<float>());
   VERS_HIP_TRY(hipGetLastError());
+  {  // bf16 hi | lo halves of the same matrix: the N operand of the batched coarse quantiser's bf16x3 contraction
+    const size_t ne = (size_t)h->k_pad * h->ldq;
+    if (int32_t rc = h->centroids_gs.reserve(2 * ne * sizeof(uint16_t))) return rc;
+    VERS_HIP_TRY(launch_split_bf16(h->centroids_g.as<float>(), ne, h->centroids_gs.as<__bf16>(), h->centroids_gs.as<__bf16>() + ne, st));
+  }
   std::vector<float> cn(k ? k : 1, 0.0f);
   if (k) VERS_HIP_TRY(hipMemcpyAsync(cn.data(), h->cnorm.p, (size_t)k * sizeof(float), hipMemcpyDeviceToHost, st));
   VERS_HIP_TRY(hipStreamSynchronize(st));
@@ -1701,8 +1707,10 @@ int32_t coarse_mfma(vers_ivf* h, const float* qp, uint32_t b, uint32_t P, uint64
   if (int32_t rc = W->gbuf.reserve((size_t)M_pad * h->k_pad * sizeof(float))) return rc;
   const bool timed = st != W->ahead_stream || W->ahead_stream == nullptr;  // (the look-ahead stream is not the measured one)
   if (timed) VERS_HIP_TRY(hipEventRecord(W->evc[0], st));
+  const __bf16* cs = h->centroids_gs.as<__bf16>();
   VERS_HIP_TRY(launch_gemm<false>((gemm_x3_mask() & 2) != 0, M_pad / kGemmBM, h->k_pad / kGemmBN, st, qp, h->centroids_g.as<float>(),
-                                  h->cnorm.as<float>(), h->ldq, h->k_pad, W->gbuf.as<float>(), h->metric));
+                                  h->cnorm.as<float>(), h->ldq, h->k_pad, W->gbuf.as<float>(), h->metric, 0, nullptr, nullptr, nullptr, cs,
+                                  cs ? cs + (size_t)h->k_pad * h->ldq : nullptr));
   if (timed) VERS_HIP_TRY(hipEventRecord(W->evc[1], st));
   hipLaunchKernelGGL(coarse_select_rescore_kernel, dim3(b), dim3(kWave), 0, st, W->gbuf.as<float>(), h->k_pad, h->k,
                      h->centroids_g.as<float>(), h->ldq, qp, h->ldq, h->ldq, coarse_mode() == 2 ? __builtin_inff() : h->cmax2, P, PS,

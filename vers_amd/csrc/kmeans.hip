@@ -183,6 +183,13 @@ int32_t km_assign_mfma(const float* X, uint32_t ldx, uint64_t n, const float* C,
   hipLaunchKernelGGL(row_norms_kernel, dim3((k_pad + 255) / 256), dim3(256), 0, st, ws.cg.as<float>(), ldq, k, k_pad, ws.cnorm.as<float>());
   hipLaunchKernelGGL(max_norm_kernel, dim3(1), dim3(256), 0, st, ws.cnorm.as<float>(), k, cmax2_dev);
   VERS_HIP_TRY(hipGetLastError());
+  const __bf16 *cg_h = nullptr, *cg_l = nullptr;
+  if (gemm_x3_mask() & 1) {  // every block of the pass re-reads the centroids: split them into bf16 hi / lo once, not per tile
+    const size_t ne = (size_t)k_pad * ldq;
+    if (int32_t rc = ws.cg_s.reserve(2 * ne * sizeof(uint16_t))) return rc;
+    VERS_HIP_TRY(launch_split_bf16(ws.cg.as<float>(), ne, ws.cg_s.as<__bf16>(), ws.cg_s.as<__bf16>() + ne, st));
+    cg_h = ws.cg_s.as<__bf16>(); cg_l = cg_h + ne;
+  }
   // point batch: the per-(centroid tile, point) triples stay <= 1 GiB (the GEMM never writes its product)
   const uint32_t n_tiles = k_pad / kGemmBM;
   uint64_t mb = ((1ull << 30) / ((uint64_t)n_tiles * 12)) / kGemmBN * kGemmBN;
@@ -209,7 +216,7 @@ int32_t km_assign_mfma(const float* X, uint32_t ldx, uint64_t n, const float* C,
     }
     // (the triples are addressed with pitch mb: nb_pad <= mb)
     VERS_HIP_TRY(launch_gemm<true>((gemm_x3_mask() & 1) != 0, k_pad / kGemmBM, nb_pad / kGemmBN, st, ws.cg.as<float>(), xb, ws.cnorm.as<float>(), ldq,
-                                   (uint32_t)mb, (float*)nullptr, metric, k, part_v1, part_c1, part_v2));
+                                   (uint32_t)mb, (float*)nullptr, metric, k, part_v1, part_c1, part_v2, cg_h, cg_l));
     hipLaunchKernelGGL(assign_argmin_merge_kernel, dim3((nb + 255) / 256), dim3(256), 0, st, (const float*)part_v1, (const uint32_t*)part_c1,
                        (const float*)part_v2, n_tiles, (uint32_t)mb, nb, best, g2);
     hipLaunchKernelGGL(assign_rescore_kernel, dim3((nb + 63) / 64), dim3(64), 0, st, X + i0 * ldx, ldx, C, ldc, d, ldq, cmax2_dev, best, g2,

@@ -34,6 +34,7 @@ struct KMeansScratch {
   DevBuf misc;      // cost scalar, equality flag
   // matrix-core assign (km_assign_mfma)
   DevBuf cg;        // centroids row-major [k_pad][ldq], zero padded
+  DevBuf cg_s;      // the same as bf16 hi | lo halves [2][k_pad][ldq] (operand of the bf16x3 contraction, split once per pass)
   DevBuf cnorm;     // |c|^2 [k_pad] (+inf padding) + max at [k_pad]
   DevBuf xp;        // staged point batch [mb][ldq] when X cannot be used in place
   DevBuf gt;        // Gt [k_pad][mb]
