@@ -95,6 +95,18 @@ ix = IVFFlatIndex.build_index(8, 1, 2, X, init_indices=mg.init_draws(0xB1, 1, 8,
 check(ix, big(0xB2, 64), 5, 4, step=5)
 st = ix.prescan_stats()
 print("HUGE", st["batches"], st["fallback_queries"])
+# (5) tiny magnitudes: the elements sit in fp16's subnormal range, the shadow keeps one or two bits of them -- the measured
+#     residual makes the certificate fail instead of trusting it, and the results stay the oracle's
+tiny = lambda s, n: (np.float32(3e-7) * dg.dist_c(s, n, 48, 24, dg.default_sigma(48))).astype(np.float32)
+X = tiny(0xE1, 3000)
+ix = IVFFlatIndex.build_index(12, 1, 2, X, init_indices=mg.init_draws(0xE1, 1, 12, 3000))
+check(ix, tiny(0xE2, 72), 10, 5, step=4)
+# (6) large but representable magnitudes (|x| ~ 300): nothing special happens
+X = (np.float32(300.0) * dg.dist_c(0xE3, 3000, 48, 24, dg.default_sigma(48))).astype(np.float32)
+ix = IVFFlatIndex.build_index(12, 1, 2, X, init_indices=mg.init_draws(0xE3, 1, 12, 3000))
+f0 = ix.prescan_stats()["fallback_queries"]
+check(ix, (np.float32(300.0) * dg.dist_c(0xE4, 72, 48, 24, dg.default_sigma(48))).astype(np.float32), 10, 5, step=4)
+print("BIG", ix.prescan_stats()["fallback_queries"] - f0)
 print("TOTAL", total)
 '''
 
@@ -103,14 +115,14 @@ def run(env_extra):
     env = dict(os.environ); env.update(env_extra); env["PYTHONPATH"] = ROOT
     r = subprocess.run([sys.executable, "-c", BODY], capture_output=True, text=True, env=env, cwd=ROOT, timeout=1200)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
-    return {l.split()[0]: tuple(int(v) for v in l.split()[1:]) for l in r.stdout.splitlines() if l[:4] in ("TIES", "HUGE", "TOTA") or l[:3] == "ONE"}
+    return {l.split()[0]: tuple(int(v) for v in l.split()[1:]) for l in r.stdout.splitlines() if l[:4] in ("TIES", "HUGE", "TOTA") or l[:3] in ("ONE", "BIG")}
 
 
 def test_matrix_core_list_scan_is_bit_exact():
     out = run({})                                               # the default: fp16 shadow rows feed the pre-selection
     assert out["TIES"][0] == 1 and out["TIES"][1] > 0          # ties denser than the slack fail the certificate ...
     assert out["HUGE"] == (1, 64)                               # ... and so does every query whose values overflow
-    assert out["ONE"] == (1,)
+    assert out["ONE"] == (1,) and out["BIG"] == (0,)
 
 
 def test_f32_rows_feed_the_scan_without_the_shadow():
