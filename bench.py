@@ -58,7 +58,6 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-recall", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the untimed extra measurements (single query, coarse GEMM, flat cfg2, Dist-U recall)")
-    ap.add_argument("--streams", type=int, default=1, help="batches in flight: consecutive batches rotate over this many HIP streams")
     ap.add_argument("--ahead", action="store_true", help="compute the next batch's coarse quantiser on a side stream under the current "
                     "list scan (vers_ivf_coarse_ahead_dev; same-box A/B at cfg3: +0.8 %% -- the scan already fills the chip)")
     args = ap.parse_args()
@@ -152,13 +151,11 @@ def main():
     n_batches = max(1, min(args.steps + args.warmup, 8))
     Q = torch.empty(n_batches * B, ld, dtype=torch.float32, device=dev)
     capi.gen_rows_dev(Q.data_ptr(), n_batches * B, d, ld, 1, SEED_Q, SEED_C, n_modes, sigma)
-    # Batches in flight: consecutive batches go to `--streams` HIP streams in rotation, each with its own output buffers (a
-    # server's request pipelining: one batch's coarse quantiser / planning / exact finish run in the shadows of another's
-    # HBM-bound list scan).  Every batch is still one complete search; the timed region ends when all of them are done.
-    S = max(1, args.streams)
-    # (never the legacy null stream next to others: with it and two more streams in rotation the HIP runtime's implicit
-    # null-stream ordering left the GPU waiting forever -- three created streams run fine)
-    streams = [torch.cuda.current_stream()] if S == 1 else [torch.cuda.Stream(device=dev) for _ in range(S)]
+    # One batch at a time on the current stream (a single host thread's batches share one workspace of the handle and are
+    # ordered through it; rotating them over 2-3 streams with a workspace each measured +1 % / +3 %: every large kernel of
+    # the step fills whole CUs, there is nothing to overlap with -- and hung the GPU in some stream mixes: not kept).
+    S = 1
+    streams = [torch.cuda.current_stream()]
     outs = [dict(ids=torch.zeros(B, top_k, dtype=torch.int64, device=dev), dst=torch.zeros(B, top_k, dtype=torch.float32, device=dev),
                  cnt=torch.zeros(B, dtype=torch.int32, device=dev),
                  part=torch.empty(2, B, top_k, dtype=torch.int64, device=dev),           # [keys | vec ids] of this rank
@@ -318,7 +315,7 @@ def main():
                                                 index.last_coarse_ms())
             if world == 1 and not args.no_extra:
                 capi.set_option("gemm_x3", 1)
-                for i in range(3):
+                for i in range(16):  # (the GPU has idled through the recall / CPU legs: a few dozen ms of work bring the clocks back up)
                     index.search_dev(Q[(i % n_batches) * B:].data_ptr(), ld, B, top_k, nprobe, ids.data_ptr(), dst.data_ptr(), cnt.data_ptr(), st)
                 index.poll(st)
                 f32e = coarse_entry("dist_gemm_kernel<false> (v_mfma_f32_32x32x2_f32, 128x128 block tiles)", index.last_coarse_ms())
@@ -527,7 +524,7 @@ def main():
                "config": {"workload": f"IVFFlat search_approximate, {'nprobe extension' if nprobe else 'reference mode (nearest list + spill)'}: N={n} d={d} nlist={nlist} nprobe={nprobe} "
                                       f"batch={B} top_k={top_k}, f32, clustered unit vectors (Dist-C)",
                           "n": n, "d": d, "nlist": nlist, "nprobe": nprobe, "batch": B, "top_k": top_k,
-                          "kmeans_iters": int(index.iterations[0]), "parallelism": f"lists sharded over {world} GPU(s)", "batches_in_flight": S},
+                          "kmeans_iters": int(index.iterations[0]), "parallelism": f"lists sharded over {world} GPU(s)"},
                "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_all_cores": cpu_all, "extra": extra}
         if shadow:
             out["result_precision"] = ("every returned id, order and distance is the reference's exact f32 result (compared bitwise with the CPU restatement in "

@@ -234,3 +234,29 @@ def test_concurrent_searches_from_threads():
         for rep in range(6):
             assert np.array_equal(gc[rep], want_batch[2]), (t, rep)
             assert np.array_equal(gi[rep], want_batch[0]) and np.array_equal(gd[rep].view(np.uint32), want_batch[1].view(np.uint32)), (t, rep)
+
+
+def test_batches_in_flight_on_rotating_streams():
+    """ONE host thread rotating its batches over three created streams: the calls share the handle's most recent workspace,
+    which orders them across the streams (its `done` event), and every batch is the serial answer."""
+    import torch
+    n, d, k = 20000, 96, 40
+    X = dg.dist_c(0x71, n, d, 4 * k, dg.default_sigma(d))
+    ix = IVFFlatIndex.build_index(k, 1, 3, X, init_indices=mg.init_draws(0x71, 1, k, n))
+    Q = dg.dist_c(0x72, 4 * 128, d, 4 * k, dg.default_sigma(d))
+    want = [ix.search_batch(Q[i * 128:(i + 1) * 128], 10, 8) for i in range(4)]
+    Qd = torch.from_numpy(Q).cuda()
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    reps = 12
+    ids = torch.zeros(reps, 128, 10, dtype=torch.int64, device="cuda"); dist = torch.zeros(reps, 128, 10, device="cuda")
+    cnt = torch.zeros(reps, 128, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    for r in range(reps):   # back to back, no synchronisation in between
+        st = streams[r % 3]
+        ix.search_dev(Qd[(r % 4) * 128:].data_ptr(), d, 128, 10, 8, ids[r].data_ptr(), dist[r].data_ptr(), cnt[r].data_ptr(), st.cuda_stream)
+    for st in streams:
+        ix.poll(st.cuda_stream)
+    gi, gd, gc = ids.cpu().numpy().astype(np.uint64), dist.cpu().numpy(), cnt.cpu().numpy()
+    for r in range(reps):
+        w = want[r % 4]
+        assert np.array_equal(gc[r], w[2]) and np.array_equal(gi[r], w[0]) and np.array_equal(gd[r].view(np.uint32), w[1].view(np.uint32)), r

@@ -190,15 +190,6 @@ __global__ __launch_bounds__(kWave * kMergeWaves) void coarse_merge_kernel(const
 // cost that does not shrink when the lists are sharded over GPUs.
 constexpr uint32_t kPlanBlocks = 64, kPlanThreads = 1024;  // 64 <= CUs: every block is resident, the barriers cannot deadlock
 
-// Process-wide: the last plan_fused_kernel launched on each device (see its launch site).
-struct PlanGate {
-  static constexpr int kDevs = 16;
-  struct Dev { hipEvent_t ev = nullptr; hipStream_t last = nullptr; bool recorded = false; };
-  std::mutex mu;
-  Dev dev[kDevs];
-};
-inline PlanGate& plan_gate() { static PlanGate g; return g; }
-
 // Grid-wide barrier on a monotonically increasing counter in device memory (never reset: `target` counts arrivals
 // since the handle was created, compared modulo 2^32).
 __device__ __forceinline__ void grid_barrier(uint32_t* ctr, uint32_t target) {
@@ -918,25 +909,11 @@ struct WsLease {
   SearchWs* prev;
   hipStream_t st = nullptr;
   int32_t rc = VERS_OK;
-  // `want`: the stream the call will queue on, when it is known up front (the _dev entry points).  A free workspace that was
-  // last used on that stream (or never) is preferred, then one whose last work has already finished, then a new one (up to
-  // kStreamWs of them are created for this reason): a caller that rotates its batches over a few streams gets a workspace
-  // per stream and its batches overlap, instead of all of them queueing behind one workspace's `done` event.
-  static constexpr size_t kStreamWs = 4;
-  explicit WsLease(vers_ivf* hh, hipStream_t want = nullptr, bool has_want = false) : h(hh), prev(W) {
+  explicit WsLease(vers_ivf* hh) : h(hh), prev(W) {
     {
       std::unique_lock<std::mutex> lk(h->pool_mu);
       for (;;) {
-        if (has_want && !h->free_ws.empty()) {
-          int pick = -1;
-          for (int i = (int)h->free_ws.size() - 1; i >= 0 && pick < 0; --i)
-            if (!h->free_ws[i]->used || h->free_ws[i]->last_stream == want) pick = i;
-          for (int i = (int)h->free_ws.size() - 1; i >= 0 && pick < 0; --i)
-            if (h->free_ws[i]->done && hipEventQuery(h->free_ws[i]->done) == hipSuccess) pick = i;
-          if (pick < 0) (void)hipGetLastError();  // (hipErrorNotReady of the queries)
-          if (pick < 0 && h->pool.size() >= kStreamWs) pick = (int)h->free_ws.size() - 1;
-          if (pick >= 0) { ws = h->free_ws[pick]; h->free_ws.erase(h->free_ws.begin() + pick); break; }
-        } else if (!h->free_ws.empty()) { ws = h->free_ws.back(); h->free_ws.pop_back(); break; }
+        if (!h->free_ws.empty()) { ws = h->free_ws.back(); h->free_ws.pop_back(); break; }
         if (h->pool.size() < vers_ivf::kMaxWs) {
           h->pool.emplace_back(new SearchWs());
           ws = h->pool.back().get();
@@ -1675,7 +1652,6 @@ struct SearchKnobs {
   int pre_mode = 1;      // VERS_PRESCAN: 0 ordered chains for batches too, 2 every certificate fails
   bool seg_balanced = true;   // VERS_SEG_BALANCED
   uint32_t hot_ranks = 1;     // VERS_HOT_FIRST
-  int graph = 1;         // VERS_GRAPH
 };
 inline const SearchKnobs& knobs() {
   static const SearchKnobs k = [] {
@@ -1688,7 +1664,6 @@ inline const SearchKnobs& knobs() {
     s.pre_mode = (int)geti("VERS_PRESCAN", 1);
     s.seg_balanced = geti("VERS_SEG_BALANCED", 1) != 0;
     s.hot_ranks = (uint32_t)geti("VERS_HOT_FIRST", 1);
-    s.graph = (int)geti("VERS_GRAPH", 1);
     return s;
   }();
   return k;
@@ -2028,21 +2003,8 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
   }
   pa.grid_ctr = W->grid_ctr.as<uint32_t>(); pa.ctr_base = W->plan_launches * 3u * kPlanBlocks;
   W->plan_launches += 1;
-  {
-    // ONE grid-barrier kernel at a time per device: its blocks spin until all 64 of them are resident, each takes a whole
-    // CU (1024 threads x 128 registers), and so do the blocks of the list scans that other streams may have in flight.
-    // Two or three such kernels from different streams, each partly resident, hung the GPU (bench.py --streams 3: every
-    // call on its own workspace and stream); chained through an event they cost nothing (~40 us each) and cannot.
-    PlanGate& gate = plan_gate();
-    std::lock_guard<std::mutex> lk(gate.mu);
-    PlanGate::Dev& gd = gate.dev[h->device & (PlanGate::kDevs - 1)];
-    if (!gd.ev) VERS_HIP_TRY(hipEventCreateWithFlags(&gd.ev, hipEventDisableTiming));
-    if (gd.recorded && gd.last != st) VERS_HIP_TRY(hipStreamWaitEvent(st, gd.ev, 0));
-    hipLaunchKernelGGL(plan_fused_kernel, dim3(kPlanBlocks), dim3(kPlanThreads), 0, st, pa);
-    VERS_HIP_TRY(hipGetLastError());
-    VERS_HIP_TRY(hipEventRecord(gd.ev, st));
-    gd.recorded = true; gd.last = st;
-  }
+  hipLaunchKernelGGL(plan_fused_kernel, dim3(kPlanBlocks), dim3(kPlanThreads), 0, st, pa);
+  VERS_HIP_TRY(hipGetLastError());
   if (QG != 1 && !use_pre) {  // (the matrix-core scan gathers its query block from qp while staging it)
     hipLaunchKernelGGL(gather_qblocks_kernel, dim3((unsigned)groups_bound), dim3(256), 0, st, W->groups.as<GroupDesc>(), tot,
                        W->pairs.as<uint32_t>(), P, qp, h->ldq, (uint32_t)QG, W->qblocks.as<float>());
@@ -2518,7 +2480,7 @@ int32_t vers_ivf_search_dev(vers_ivf_t* h, const float* queries_dev, uint64_t ld
     return fail(VERS_ERR_INVALID, "vers_ivf_search_dev: bad arguments");
   std::shared_lock<std::shared_mutex> lk(h->index);
   DeviceGuard g(h->device);
-  WsLease lease(h, (hipStream_t)stream, true);
+  WsLease lease(h);
   if (lease.rc) return lease.rc;
   if (int32_t rc = lease.order_on((hipStream_t)stream)) return rc;
   return search_dev_locked(h, queries_dev, ldq_floats, b, top_k, nprobe, out_ids_dev, out_dist_dev, out_count_dev, nullptr,
@@ -2554,7 +2516,7 @@ int32_t vers_ivf_search_partial_dev(vers_ivf_t* h, const float* queries_dev, uin
     return fail(VERS_ERR_INVALID, "vers_ivf_search_partial_dev: bad arguments");
   std::shared_lock<std::shared_mutex> lk(h->index);
   DeviceGuard g(h->device);
-  WsLease lease(h, (hipStream_t)stream, true);
+  WsLease lease(h);
   if (lease.rc) return lease.rc;
   if (int32_t rc = lease.order_on((hipStream_t)stream)) return rc;
   // distances and counts of the local part are scratch here: the cross-GPU merge recomputes them
@@ -2643,7 +2605,7 @@ int32_t vers_ivf_search_exhaustive_dev(vers_ivf_t* h, const float* queries_dev, 
     return fail(VERS_ERR_INVALID, "vers_ivf_search_exhaustive_dev: bad arguments");
   std::shared_lock<std::shared_mutex> lk(h->index);
   DeviceGuard g(h->device);
-  WsLease lease(h, (hipStream_t)stream, true);
+  WsLease lease(h);
   if (lease.rc) return lease.rc;
   if (int32_t rc = lease.order_on((hipStream_t)stream)) return rc;
   return exhaustive_dev_locked(h, queries_dev, ldq_floats, b, top_k, metric, out_ids_dev, out_dist_dev, out_count_dev,
@@ -2659,7 +2621,7 @@ int32_t vers_ivf_search_exhaustive_partial_dev(vers_ivf_t* h, const float* queri
   if (b == 0) return VERS_OK;
   std::shared_lock<std::shared_mutex> lk(h->index);
   DeviceGuard g(h->device);
-  WsLease lease(h, (hipStream_t)stream, true);
+  WsLease lease(h);
   if (lease.rc) return lease.rc;
   if (int32_t rc = lease.order_on((hipStream_t)stream)) return rc;
   if (int32_t rc = ensure_out(h, (size_t)b * top_k, b)) return rc;
