@@ -824,7 +824,7 @@ struct vers_ivf {
   KMeansScratch km;  // build scratch (build / upload hold the handle exclusively)
   // matrix-core list scan (prescan.hip.h): |x|^2 per storage row, [0] max |x|^2 bits, [1] certificate failures (running)
   DevBuf xnorm, pre_misc;
-  // bf16 shadow of the rows for the matrix-core pre-selection (+50 % corpus memory; VERS_SHADOW=0 or a failed
+  // fp16 shadow of the rows for the matrix-core pre-selection (+50 % corpus memory; VERS_SHADOW=0 or a failed
   // allocation: the f32 rows feed it).  The wider certificate window makes it sensitive to data with many near-ties:
   // the failure counter is watched through a pinned word and the shadow is switched off for the handle when more
   // than 1/8 of the queries had to be re-scanned exactly.
@@ -1892,7 +1892,7 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
   const int pre_mode = knobs().pre_mode;
   // slack of 10 keys: at cfg3 a slack of 6 left ~2 of 1024 queries uncertified per batch, 10 none
   uint32_t kp = std::min<uint32_t>(kPreMaxKp, std::max<uint32_t>(top_k + 10, top_k + top_k / 2));
-  // bf16 shadow rows (experimental): the certificate window is ~9x wider, measured <= 33 rows inside it at top_k = 10
+  // fp16 shadow rows: the certificate window is ~2x the f32 rows' (measured residual, prescan.hip.h)
   bool use_shadow = shadow_mode() != 0 && !h->shadow_off && h->shadow_valid && h->rows_bf.p != nullptr &&
                     h->rows_bf.cap >= h->cap_rows * (size_t)h->ld * sizeof(uint16_t);
   if (use_shadow && h->fail_watch && h->shadow_queries >= 256) {  // (lags by the batches still in flight: errs on the side of keeping it)

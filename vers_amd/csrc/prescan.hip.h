@@ -1,11 +1,12 @@
-// prescan.hip.h -- batched inverted-list scan on the f32 matrix cores with an exact finish (nprobe mode, L2).
+// prescan.hip.h -- batched inverted-list scan on the matrix cores with an exact finish (nprobe mode): fp16 shadow rows ->
+// v_mfma_f32_32x32x16_f16 by default (half the HBM bytes), f32 rows -> v_mfma_f32_16x16x1_4b_f32 with VERS_SHADOW=0.
 //
 // The reference's distance is an ordered f32 chain (scan.hip.h); a matrix-core contraction cannot reproduce its
 // rounding, so -- exactly as in the coarse quantiser (gemm.hip.h) -- it is used to PRE-SELECT and the result is
 // then made exact:
 //   (1) prescan_kernel_g: per block a quad of row segments of one
 //       list x the <= 32 queries of one group,
-//         val[r][n] = |x_r|^2 - 2 <x_r, q_n>          v_mfma_f32_16x16x1_4b_f32, lane == row operand layout
+//         val[r][n] = |x_r|^2 - 2 <x_r, q_n>          (the row operand exactly as one 16-byte load per lane delivers it)
 //       which approximates D_ref(x_r, q_n) - |q_n|^2 within E (below).  Per query the kp = top_k + slack smallest
 //       (val, seq) keys are kept in ONE sorted list per block in LDS; the list's
 //       last val is the threshold a tile's vals are compared with, shared live with the query's other blocks
@@ -22,7 +23,8 @@
 //
 // E: |val + |q|^2 - D_ref| <= (5 d + 32) u (|q|^2 + max|x|^2), u = 2^-24, d = padded length -- the bound derived
 // in gemm.hip.h with one more product in the chain (the |x|^2 term rides through the MFMA as an extra k step) and
-// slack for the roundings of the test itself, which is evaluated in f64.
+// slack for the roundings of the test itself, which is evaluated in f64.  The fp16 shadow adds its MEASURED rounding residual
+// (shadow_residual_kernel: max |x - fp16(x)| over the stored rows) and the query split's remainder: ivf_rescore_kernel.
 #pragma once
 #include <type_traits>
 
@@ -598,7 +600,7 @@ struct RescoreArgs {
   const uint32_t* qflags;  // [b*P], slot q*P
   int metric;              // 0 squared L2, 1 cosine distance 1 - dot (the exact chains and the bound follow it)
   int force_fail;          // testing: nothing certifies
-  int shadow;              // the vals came from the bf16 shadow: the bound grows by 2^-8 |x||q|
+  int shadow;              // the vals came from the fp16 shadow: the bound grows by its measured residual (xmax2_bits[2])
   uint32_t debug;          // diagnosis (VERS_SCAN_DEBUG): 512 skip the row gather + chains, 1024 merge only 1/8 of the slots
   uint32_t* fail_list;     // [b] out: queries to redo exactly, [b] = their count
   uint32_t* stats;         // [0] += failed queries
