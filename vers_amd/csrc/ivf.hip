@@ -1036,10 +1036,12 @@ int32_t refresh_norms(vers_ivf* h, uint64_t r_begin, uint64_t r_end, hipStream_t
   if (shadow) {
     if (full) {
       const size_t need = (h->cap_rows ? h->cap_rows : 1) * (size_t)h->ld * sizeof(uint16_t);
-      if (need > h->rows_bf.cap) {  // optional memory: a failed allocation just leaves the f32 rows in charge
+      if (need > h->rows_bf.cap) {  // optional memory: without it (or with less than 4 GB left for the searches' scratch) the f32 rows stay in charge
         h->rows_bf.release();
+        size_t free_b = 0, total_b = 0;
+        (void)hipMemGetInfo(&free_b, &total_b);
         void* pbf = nullptr;
-        if (hipMalloc(&pbf, need) == hipSuccess) { h->rows_bf.p = pbf; h->rows_bf.cap = need; dev_mem_account((int64_t)need); }
+        if (need + (size_t(4) << 30) <= free_b && hipMalloc(&pbf, need) == hipSuccess) { h->rows_bf.p = pbf; h->rows_bf.cap = need; dev_mem_account((int64_t)need); }
         else (void)hipGetLastError();
       }
       h->shadow_valid = h->rows_bf.p != nullptr && h->rows_bf.cap >= need;
