@@ -80,6 +80,16 @@ Qs = dg.dist_c(0xD2, 48, 96, 40, dg.default_sigma(96)); Qs[5] = X[100]
 f0 = ix.prescan_stats()["fallback_queries"]
 check(ix, Qs, 10, 6, step=1)
 print("ONE", ix.prescan_stats()["fallback_queries"] - f0)
+# ... and TEN of them (ten different vectors stored 70 times each): groups of 8 blocks, two chunks of tiles per list
+for v in range(10):
+    X[1000 + 100 * v:1070 + 100 * v] = X[1000 + 100 * v]
+ix = IVFFlatIndex.build_index(10, 1, 2, X, init_indices=mg.init_draws(0xD1, 1, 10, 6000))
+Qs = dg.dist_c(0xD2, 48, 96, 40, dg.default_sigma(96))
+for v in range(10):
+    Qs[3 + 4 * v] = X[1000 + 100 * v]
+f0 = ix.prescan_stats()["fallback_queries"]
+check(ix, Qs, 10, 6, step=1)
+print("TEN", ix.prescan_stats()["fallback_queries"] - f0)
 # (3b) duplicated rows leave k-means clusters empty (zero centroids at distance |q|^2 = 1, nearer than other modes'
 #      centroids): most queries probe nothing but empty lists and must come back with count 0
 X = dg.dist_c(0xC1, 4500, 130, 72, dg.default_sigma(130)); X[2250:] = X[:2250]
@@ -115,19 +125,19 @@ def run(env_extra):
     env = dict(os.environ); env.update(env_extra); env["PYTHONPATH"] = ROOT
     r = subprocess.run([sys.executable, "-c", BODY], capture_output=True, text=True, env=env, cwd=ROOT, timeout=1200)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
-    return {l.split()[0]: tuple(int(v) for v in l.split()[1:]) for l in r.stdout.splitlines() if l[:4] in ("TIES", "HUGE", "TOTA") or l[:3] in ("ONE", "BIG")}
+    return {l.split()[0]: tuple(int(v) for v in l.split()[1:]) for l in r.stdout.splitlines() if l[:4] in ("TIES", "HUGE", "TOTA") or l[:3] in ("ONE", "BIG", "TEN")}
 
 
 def test_matrix_core_list_scan_is_bit_exact():
     out = run({})                                               # the default: fp16 shadow rows feed the pre-selection
     assert out["TIES"][0] == 1 and out["TIES"][1] > 0          # ties denser than the slack fail the certificate ...
     assert out["HUGE"] == (1, 64)                               # ... and so does every query whose values overflow
-    assert out["ONE"] == (1,) and out["BIG"] == (0,)
+    assert out["ONE"] == (1,) and out["BIG"] == (0,) and out["TEN"][0] >= 10
 
 
 def test_f32_rows_feed_the_scan_without_the_shadow():
     out = run({"VERS_SHADOW": "0"})
-    assert out["TIES"][0] == 1 and out["TIES"][1] > 0 and out["HUGE"] == (1, 64) and out["ONE"] == (1,)
+    assert out["TIES"][0] == 1 and out["TIES"][1] > 0 and out["HUGE"] == (1, 64) and out["ONE"] == (1,) and out["TEN"][0] >= 10
 
 
 def test_forced_certificate_failure_is_exact():
