@@ -1,5 +1,5 @@
 #!/bin/bash
-# bf16 shadow vs f32 rows on the same index and queries: results must be identical bit for bit
+# fp16 shadow rows (the default) vs f32 rows (VERS_SHADOW=0) on the same index and queries: results must be identical bit for bit
 cd "$(dirname "$0")/.."
 cmp() { python - "$1" <<'PY'
 import numpy as np, sys
