@@ -526,6 +526,8 @@ def main():
                           "n": n, "d": d, "nlist": nlist, "nprobe": nprobe, "batch": B, "top_k": top_k,
                           "kmeans_iters": int(index.iterations[0]), "parallelism": f"lists sharded over {world} GPU(s)"},
                "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_all_cores": cpu_all, "extra": extra}
+        if shadow and "list_scan_f32_rows" in extra:
+            out["value_f32_rows"] = extra["list_scan_f32_rows"]["whole_step_queries_per_sec"]  # the same step with VERS_SHADOW=0 (8 batches, untimed region)
         if shadow:
             out["result_precision"] = ("every returned id, order and distance is the reference's exact f32 result (compared bitwise with the CPU restatement in "
                                         "this run: cpu_baseline.gpu_matches_cpu_bitwise); the dominant kernel PRE-SELECTS candidates on an fp16 copy of the rows and "
