@@ -299,6 +299,10 @@ int32_t vers_ivf_prescan_stats(vers_ivf_t* h, uint64_t* out_batches, uint64_t* o
  * scan); skipped when its allocation fails; switched off for the handle when more than 1/8 of the queries failed the
  * certificate (data with many near-ties, or elements outside fp16's range).  out_active: 1 = in use. */
 int32_t vers_ivf_shadow_state(vers_ivf_t* h, int32_t* out_active, uint64_t* out_bytes);
+/* TEST HOOK: overwrites every storage row that holds no vector (slack behind the lists, tile padding: uninitialised
+ * device memory in production) with `value` (inf, NaN, 1e30 ...) and rebuilds the derived arrays.  Results and certificate
+ * statistics must not depend on what those rows hold (tests/test_prescan_gpu.py). */
+int32_t vers_ivf_test_poison_slack(vers_ivf_t* h, float value);
 /* Durations (ms) of the most recent list-scan launches, oldest first (ring of 64); reset != 0
  * empties the ring.  Lets bench.py time every launch of the timed region without stalling it. */
 int32_t vers_ivf_scan_times(vers_ivf_t* h, float* out_ms, uint32_t cap, uint32_t* out_n, int32_t reset);

@@ -117,6 +117,16 @@ ix = IVFFlatIndex.build_index(12, 1, 2, X, init_indices=mg.init_draws(0xE3, 1, 1
 f0 = ix.prescan_stats()["fallback_queries"]
 check(ix, (np.float32(300.0) * dg.dist_c(0xE4, 72, 48, 24, dg.default_sigma(48))).astype(np.float32), 10, 5, step=4)
 print("BIG", ix.prescan_stats()["fallback_queries"] - f0)
+# (7) what the rows that hold no vector contain (slack behind the lists, tile padding: uninitialised memory) must not matter:
+#     inf / NaN there once reached the real rows of the same tile through a 0-weighted term of the |x|^2 MFMA of the fp16 scan
+Qb = (np.float32(300.0) * dg.dist_c(0xE4, 72, 48, 24, dg.default_sigma(48))).astype(np.float32)
+worst = 0
+for v in (float("inf"), float("nan"), -1.0e30, 1.5e19):
+    ix.test_poison_slack(v)
+    f0 = ix.prescan_stats()["fallback_queries"]
+    check(ix, Qb, 10, 5, step=4)
+    worst = max(worst, ix.prescan_stats()["fallback_queries"] - f0)
+print("SLACK", worst)
 print("TOTAL", total)
 '''
 
@@ -125,19 +135,19 @@ def run(env_extra):
     env = dict(os.environ); env.update(env_extra); env["PYTHONPATH"] = ROOT
     r = subprocess.run([sys.executable, "-c", BODY], capture_output=True, text=True, env=env, cwd=ROOT, timeout=1200)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
-    return {l.split()[0]: tuple(int(v) for v in l.split()[1:]) for l in r.stdout.splitlines() if l[:4] in ("TIES", "HUGE", "TOTA") or l[:3] in ("ONE", "BIG", "TEN")}
+    return {l.split()[0]: tuple(int(v) for v in l.split()[1:]) for l in r.stdout.splitlines() if l[:4] in ("TIES", "HUGE", "TOTA") or l[:3] in ("ONE", "BIG", "TEN") or l[:5] == "SLACK"}
 
 
 def test_matrix_core_list_scan_is_bit_exact():
     out = run({})                                               # the default: fp16 shadow rows feed the pre-selection
     assert out["TIES"][0] == 1 and out["TIES"][1] > 0          # ties denser than the slack fail the certificate ...
     assert out["HUGE"] == (1, 64)                               # ... and so does every query whose values overflow
-    assert out["ONE"] == (1,) and out["BIG"] == (0,) and out["TEN"][0] >= 10
+    assert out["ONE"] == (1,) and out["BIG"] == (0,) and out["TEN"][0] >= 10 and out["SLACK"] == (0,)
 
 
 def test_f32_rows_feed_the_scan_without_the_shadow():
     out = run({"VERS_SHADOW": "0"})
-    assert out["TIES"][0] == 1 and out["TIES"][1] > 0 and out["HUGE"] == (1, 64) and out["ONE"] == (1,) and out["TEN"][0] >= 10
+    assert out["TIES"][0] == 1 and out["TIES"][1] > 0 and out["HUGE"] == (1, 64) and out["ONE"] == (1,) and out["TEN"][0] >= 10 and out["BIG"] == (0,) and out["SLACK"] == (0,)
 
 
 def test_forced_certificate_failure_is_exact():

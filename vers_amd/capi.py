@@ -70,6 +70,7 @@ SIGNATURES = {
     "vers_ivf_coarse_stats": (C.c_int32, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "vers_ivf_prescan_stats": (C.c_int32, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "vers_ivf_shadow_state": (C.c_int32, [_vp, C.POINTER(C.c_int32), C.POINTER(C.c_uint64)]),
+    "vers_ivf_test_poison_slack": (C.c_int32, [_vp, C.c_float]),
     "vers_ivf_build_sharded_dev": (C.c_int32, [_vp, _vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64,
                                                C.c_uint64, _vp, _vp, _vp, C.POINTER(C.c_float), C.POINTER(C.c_int32), _vp]),
     "vers_set_option": (C.c_int32, [C.c_char_p, C.c_int64]),

@@ -2751,6 +2751,30 @@ int32_t vers_ivf_shadow_state(vers_ivf_t* h, int32_t* out_active, uint64_t* out_
   return VERS_OK;
 }
 
+// test hook: every storage row that holds no vector (slack behind the lists, tile padding) gets `value` in all its columns,
+// then the derived arrays (|x|^2, fp16 shadow, residual) are rebuilt -- what uninitialised device memory may look like
+static __global__ void poison_slack_kernel(float* rows, uint32_t ld, const uint32_t* row_ids, uint64_t n_rows, float value) {
+  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t r = t / (ld / 4);
+  const uint32_t j = (uint32_t)(t % (ld / 4));
+  if (r >= n_rows || row_ids[r] != 0xFFFFFFFFu) return;
+  reinterpret_cast<f32x4*>(rows + (r >> 6) * 64ull * ld)[(uint64_t)j * 64 + (r & 63)] = f32x4{value, value, value, value};
+}
+int32_t vers_ivf_test_poison_slack(vers_ivf_t* h, float value) {
+  if (!h) return fail(VERS_ERR_INVALID, "null handle");
+  std::unique_lock<std::shared_mutex> lk(h->index);
+  DeviceGuard g(h->device);
+  VERS_HIP_TRY(hipDeviceSynchronize());
+  if (h->cap_rows == 0) return VERS_OK;
+  const uint64_t work = h->cap_rows * (h->ld / 4);
+  hipLaunchKernelGGL(poison_slack_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, nullptr, h->rows.as<float>(), h->ld,
+                     (const uint32_t*)h->row_ids.as<uint32_t>(), h->cap_rows, value);
+  VERS_HIP_TRY(hipGetLastError());
+  if (int32_t rc = refresh_norms(h, 0, h->cap_rows, nullptr)) return rc;
+  VERS_HIP_TRY(hipDeviceSynchronize());
+  return VERS_OK;
+}
+
 int32_t vers_ivf_scan_times(vers_ivf_t* h, float* out_ms, uint32_t cap, uint32_t* out_n, int32_t reset) {
   if (!h || !out_n || (cap && !out_ms)) return fail(VERS_ERR_INVALID, "bad arguments");
   UseLastWs use_ws(h);

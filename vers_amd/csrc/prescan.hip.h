@@ -122,8 +122,14 @@ static __global__ void blocked_row_norms_kernel(const float* rows, uint32_t ld, 
 #pragma unroll
     for (int u = 0; u < 4; ++u) acc = __fadd_rn(acc, __fmul_rn(v[u], v[u]));
   }
-  xnorm[r] = acc;
-  if (row_ids[r] != 0xFFFFFFFFu && acc == acc) atomicMax(xmax2_bits, __float_as_uint(acc));  // acc >= 0: bit order == value order
+  // A storage row that holds no vector (slack behind a list, tile padding) is uninitialised memory: its |x|^2 must still be
+  // FINITE.  In the fp16 scan |x|^2 enters through v_mfma_f32_32x32x2_f32 with B = 1 on one k-slice and 0 on the other: a real
+  // row i gets xn[i] * 1 + xn[32 + i] * 0, and inf * 0 or NaN * 0 of a slack row in the same tile would poison it (seen: an index
+  // built into memory a freed index with 1.5e19-sized values had used -- 60-odd of 72 queries non-finite and re-scanned exactly,
+  // in one process out of six).  The 4-block f32 MFMA has no such cross term.
+  const bool holds_vector = row_ids[r] != 0xFFFFFFFFu;
+  xnorm[r] = holds_vector ? acc : 0.0f;
+  if (holds_vector && acc == acc) atomicMax(xmax2_bits, __float_as_uint(acc));  // acc >= 0: bit order == value order
 }
 
 // ---- the scan kernel: a quad of row segments x one query block per block of eight waves ----------------

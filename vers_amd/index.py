@@ -158,6 +158,10 @@ class IVFFlatIndex:
         check(lib().vers_ivf_shadow_state(self._h, C.byref(a), C.byref(b)))
         return dict(active=bool(a.value), bytes=int(b.value))
 
+    def test_poison_slack(self, value: float):
+        """Test hook: fill the storage rows that hold no vector with `value` (what uninitialised memory may look like)."""
+        check(lib().vers_ivf_test_poison_slack(self._h, C.c_float(value)))
+
     def scan_times(self, reset: bool = True):
         ms = np.zeros(64, dtype=np.float32); n = C.c_uint32(0)
         check(lib().vers_ivf_scan_times(self._h, _ptr(ms), 64, C.byref(n), 1 if reset else 0))
