@@ -1014,6 +1014,15 @@ int32_t status_to_rc(vers_ivf* h, uint32_t s, uint32_t slot) {
   return VERS_OK;
 }
 
+// test hook: every storage row that holds no vector (slack behind the lists, tile padding) gets `value` in all its columns,
+// then the derived arrays (|x|^2, fp16 shadow, residual) are rebuilt -- what uninitialised device memory may look like
+static __global__ void poison_slack_kernel(float* rows, uint32_t ld, const uint32_t* row_ids, uint64_t n_rows, float value) {
+  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const uint64_t r = t / (ld / 4);
+  const uint32_t j = (uint32_t)(t % (ld / 4));
+  if (r >= n_rows || row_ids[r] != 0xFFFFFFFFu) return;
+  reinterpret_cast<f32x4*>(rows + (r >> 6) * 64ull * ld)[(uint64_t)j * 64 + (r & 63)] = f32x4{value, value, value, value};
+}
 inline std::atomic<int>& shadow_mode_ref() {  // VERS_SHADOW (default 1) / vers_set_option("shadow", v)
   static std::atomic<int> m{[] { const char* e = getenv("VERS_SHADOW"); return e ? (atoi(e) != 0 ? 1 : 0) : 1; }()};
   return m;
@@ -1182,6 +1191,16 @@ int32_t finish_index(vers_ivf* h, uint32_t k, uint64_t n_total, hipStream_t st) 
   for (uint32_t c = 0; c < k; ++c) h->cmax2 = std::max(h->cmax2, cn[c]);  // NaN centroids never raise it; they fail the certificate
   h->k = k;
   h->n_total = n_total;
+  {  // diagnosis (VERS_POISON_SLACK=inf|nan|<number>): every new index starts with that value in the rows that hold no vector
+    static const char* poison = getenv("VERS_POISON_SLACK");
+    if (poison && h->cap_rows) {
+      const float v = (float)atof(poison);  // ("inf" and "nan" parse as such)
+      const uint64_t work = h->cap_rows * (h->ld / 4);
+      hipLaunchKernelGGL(poison_slack_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, st, h->rows.as<float>(), h->ld,
+                         (const uint32_t*)h->row_ids.as<uint32_t>(), h->cap_rows, v);
+      VERS_HIP_TRY(hipGetLastError());
+    }
+  }
   if (int32_t rc = refresh_norms(h, 0, h->cap_rows, st)) return rc;
   // |x|^2, max |x|^2 and the optional shadow were queued on `st`; searches run on other (possibly non-blocking)
   // streams and a certificate evaluated against a stale maximum would be unsound: the index is complete on return
@@ -2751,15 +2770,6 @@ int32_t vers_ivf_shadow_state(vers_ivf_t* h, int32_t* out_active, uint64_t* out_
   return VERS_OK;
 }
 
-// test hook: every storage row that holds no vector (slack behind the lists, tile padding) gets `value` in all its columns,
-// then the derived arrays (|x|^2, fp16 shadow, residual) are rebuilt -- what uninitialised device memory may look like
-static __global__ void poison_slack_kernel(float* rows, uint32_t ld, const uint32_t* row_ids, uint64_t n_rows, float value) {
-  const uint64_t t = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
-  const uint64_t r = t / (ld / 4);
-  const uint32_t j = (uint32_t)(t % (ld / 4));
-  if (r >= n_rows || row_ids[r] != 0xFFFFFFFFu) return;
-  reinterpret_cast<f32x4*>(rows + (r >> 6) * 64ull * ld)[(uint64_t)j * 64 + (r & 63)] = f32x4{value, value, value, value};
-}
 int32_t vers_ivf_test_poison_slack(vers_ivf_t* h, float value) {
   if (!h) return fail(VERS_ERR_INVALID, "null handle");
   std::unique_lock<std::shared_mutex> lk(h->index);
