@@ -39,6 +39,13 @@ int32_t DevBuf::reserve(size_t bytes) {
   VERS_HIP_TRY(hipMalloc(&p, bytes));
   cap = bytes;
   dev_mem_account((int64_t)bytes);
+  // diagnosis (VERS_POISON_ALLOC=<byte>): every new device buffer starts filled with that byte instead of whatever the
+  // allocator hands out -- nothing may depend on uninitialised scratch (the GPU suite passes under 0x7f, 0xa5 and 0x00)
+  static const int poison = [] { const char* e = getenv("VERS_POISON_ALLOC"); return e ? (int)strtol(e, nullptr, 0) & 0xFF : -1; }();
+  if (poison >= 0) {
+    VERS_HIP_TRY(hipMemset(p, poison, bytes));
+    VERS_HIP_TRY(hipDeviceSynchronize());
+  }
   return VERS_OK;
 }
 void DevBuf::release() {
