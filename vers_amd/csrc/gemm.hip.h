@@ -647,7 +647,7 @@ static __global__ void assign_argmin_merge_kernel(const float* part_v1, const ui
 static __global__ void assign_rescore_kernel(const float* X, uint32_t ldx, const float* C_rm, uint32_t ldc, uint32_t d, uint32_t d_pad,
                                              const float* cmax2_dev, const uint32_t* best, const float* g2, uint32_t nb, uint32_t k,
                                              uint32_t i_base, uint32_t* assign, float* mind, uint32_t* fb_list, uint32_t* fb_count,
-                                             uint32_t* status, int metric) {
+                                             uint32_t* status, int metric, float* fb_thr = nullptr) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nb) return;
   const uint32_t c = best[i];
@@ -688,8 +688,97 @@ static __global__ void assign_rescore_kernel(const float* X, uint32_t ldx, const
   const bool certified = k == 1 || (finite && acc < lower);
   assign[i] = c;
   if (mind) mind[i] = acc;
-  if (!certified) fb_list[atomicAdd(fb_count, 1u)] = i + i_base;
-  else if (acc != acc) atomicOr(status, 1u);
+  if (!certified) {
+    const uint32_t pos = atomicAdd(fb_count, 1u);
+    fb_list[pos] = i + i_base;
+    // (for assign_tile_rescan_kernel) the true first minimum c* has D(c*) <= acc, hence G(c*) <= acc - |x|^2 + E: only centroid
+    // tiles whose smallest G is at or below that can hold it.  NaN / inf: no tile is excluded.
+    if (fb_thr) fb_thr[pos] = (acc - (metric ? 1.0f : xn)) + 1.01f * E;
+  } else if (acc != acc) atomicOr(status, 1u);
+}
+
+// Uncertified points at LARGE k (cfg5: 65536 centroids): the exact re-scan of a point against all centroids costs k chains,
+// but the per-tile minima of G that the contraction's epilogue left (part_v1, still in place for this batch) say which tiles
+// of 128 centroids can hold the point's first minimum at all -- one or two of 512.  One wave per queued point of this batch:
+// the candidate tiles' centroids get their exact ordered chains (lane per centroid), first minimum by (distance, index).
+// More than kRescanTiles candidate tiles (forced-failure tests, degenerate data) or a NaN: the point goes to the full exact
+// scan like before (fb2).  At k = 65536 the full scan of the ~3 % uncertified points was 19 % of a k-means pass.
+constexpr uint32_t kRescanTiles = 8;
+static __global__ __launch_bounds__(kWave) void assign_tile_rescan_kernel(
+    const float* X, uint32_t ldx, const float* C_rm, uint32_t ldc, uint32_t d, uint32_t k, const float* part_v1, uint32_t n_tiles,
+    uint32_t pitch, uint32_t i_base, uint32_t nb, const uint32_t* fb_list, const float* fb_thr, const uint32_t* fb_count, uint32_t* assign,
+    float* mind, uint32_t* fb2_list, uint32_t* fb2_count, int metric) {
+  const int lane = threadIdx.x;
+  const uint32_t n_q = *fb_count;
+  for (uint32_t e = blockIdx.x; e < n_q; e += gridDim.x) {
+    const uint32_t idx = fb_list[e];
+    if (idx < i_base || idx >= i_base + nb) continue;  // (another batch's entry: its tile minima are gone)
+    const uint32_t i = idx - i_base;
+    const float T = fb_thr[e];
+    const float* x = X + (uint64_t)idx * ldx;
+    uint64_t best = kKeyMax;
+    uint32_t n_cand = 0;
+    bool nan = false;
+    for (uint32_t t0 = 0; t0 < n_tiles && n_cand <= kRescanTiles; t0 += kWave) {
+      const uint32_t t = t0 + (uint32_t)lane;
+      const float v = t < n_tiles ? part_v1[(uint64_t)t * pitch + i] : __builtin_inff();
+      uint64_t m = __ballot(t < n_tiles && !(v > T));  // (NaN on either side: candidate)
+      while (m && n_cand <= kRescanTiles) {
+        const uint32_t tl = (uint32_t)__ffsll((unsigned long long)m) - 1u;
+        m &= m - 1;
+        if (++n_cand > kRescanTiles) break;
+#pragma unroll 1
+        for (uint32_t h = 0; h < 2; ++h) {
+          const uint32_t c = (t0 + tl) * kGemmBM + h * kWave + (uint32_t)lane;
+          if (c < k) {
+            const float* cv = C_rm + (uint64_t)c * ldc;
+            float acc = 0.0f;
+            uint32_t j = 0;
+            if (((ldx | ldc) & 3u) == 0) {
+              for (; j + 4 <= d; j += 4) {
+                const f32x4 x4 = *reinterpret_cast<const f32x4*>(x + j);
+                const f32x4 c4 = *reinterpret_cast<const f32x4*>(cv + j);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                  if (metric == 0) {
+                    const float tt = __fsub_rn(x4[u], c4[u]);
+                    acc = __fadd_rn(acc, __fmul_rn(tt, tt));
+                  } else {
+                    acc = __fadd_rn(acc, __fmul_rn(x4[u], c4[u]));
+                  }
+                }
+              }
+            }
+            for (; j < d; ++j) {
+              if (metric == 0) {
+                const float tt = __fsub_rn(x[j], cv[j]);
+                acc = __fadd_rn(acc, __fmul_rn(tt, tt));
+              } else {
+                acc = __fadd_rn(acc, __fmul_rn(x[j], cv[j]));
+              }
+            }
+            if (metric) acc = __fsub_rn(1.0f, acc);
+            nan |= acc != acc;
+            const uint64_t key = make_key(acc, c);
+            best = key < best ? key : best;
+          }
+        }
+      }
+    }
+    const bool defer = n_cand > kRescanTiles || n_cand == 0 || __ballot(nan) != 0;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const uint64_t o = shfl_xor64(best, off);
+      best = o < best ? o : best;
+    }
+    if (lane == 0) {
+      if (defer || best == kKeyMax) fb2_list[atomicAdd(fb2_count, 1u)] = idx;
+      else {
+        assign[idx] = (uint32_t)best;
+        if (mind) mind[idx] = __uint_as_float(order_bits_to_f32_bits((uint32_t)(best >> 32)));
+      }
+    }
+  }
 }
 
 // max over the finite-or-inf |c|^2 (NaN never raises it: such centroids fail every certificate through G)

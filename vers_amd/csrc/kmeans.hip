@@ -186,6 +186,16 @@ int32_t km_assign_mfma(const float* X, uint32_t ldx, uint64_t n, const float* C,
   float* cmax2_dev = ws.cnorm.as<float>() + k_pad;
   VERS_HIP_TRY(hipMemsetAsync(ws.cg.p, 0, (size_t)k_pad * ldq * sizeof(float), st));
   VERS_HIP_TRY(hipMemsetAsync(fb_count, 0, sizeof(uint32_t), st));
+  // large k: uncertified points first go through the tile-limited re-scan (assign_tile_rescan_kernel); what it cannot settle
+  // lands in fb_list like before
+  static const bool tiles_on = [] { const char* e = getenv("VERS_ASSIGN_TILES"); return !e || atoi(e) != 0; }();
+  const bool tile_rescan = tiles_on && k_pad / kGemmBM >= 64;
+  uint32_t* fbq_list = nullptr; uint32_t* fbq_count = nullptr; float* fbq_thr = nullptr;
+  if (tile_rescan) {
+    if (int32_t rc = ws.fbq.reserve((2 * n + 4) * sizeof(uint32_t))) return rc;
+    fbq_list = ws.fbq.as<uint32_t>(); fbq_count = fbq_list + n; fbq_thr = ws.fbq.as<float>() + n + 4;
+    VERS_HIP_TRY(hipMemsetAsync(fbq_count, 0, sizeof(uint32_t), st));
+  }
   if (int32_t rc = launch_stage_queries(C, ldc, d, ws.cg.as<float>(), ldq, k, 1, st)) return rc;
   hipLaunchKernelGGL(row_norms_kernel, dim3((k_pad + 255) / 256), dim3(256), 0, st, ws.cg.as<float>(), ldq, k, k_pad, ws.cnorm.as<float>());
   hipLaunchKernelGGL(max_norm_kernel, dim3(1), dim3(256), 0, st, ws.cnorm.as<float>(), k, cmax2_dev);
@@ -227,7 +237,12 @@ int32_t km_assign_mfma(const float* X, uint32_t ldx, uint64_t n, const float* C,
     hipLaunchKernelGGL(assign_argmin_merge_kernel, dim3((nb + 255) / 256), dim3(256), 0, st, (const float*)part_v1, (const uint32_t*)part_c1,
                        (const float*)part_v2, n_tiles, (uint32_t)mb, nb, best, g2);
     hipLaunchKernelGGL(assign_rescore_kernel, dim3((nb + 63) / 64), dim3(64), 0, st, X + i0 * ldx, ldx, C, ldc, d, ldq, cmax2_dev, best, g2,
-                       nb, k, (uint32_t)i0, out_assign + i0, out_mind ? out_mind + i0 : nullptr, fb_list, fb_count, ws.status.as<uint32_t>(), metric);
+                       nb, k, (uint32_t)i0, out_assign + i0, out_mind ? out_mind + i0 : nullptr, tile_rescan ? fbq_list : fb_list,
+                       tile_rescan ? fbq_count : fb_count, ws.status.as<uint32_t>(), metric, fbq_thr);
+    if (tile_rescan)
+      hipLaunchKernelGGL(assign_tile_rescan_kernel, dim3(2048), dim3(kWave), 0, st, X, ldx, C, ldc, d, k, (const float*)part_v1, n_tiles,
+                         (uint32_t)mb, (uint32_t)i0, nb, (const uint32_t*)fbq_list, (const float*)fbq_thr, (const uint32_t*)fbq_count, out_assign,
+                         out_mind, fb_list, fb_count, metric);
     VERS_HIP_TRY(hipGetLastError());
   }
   uint32_t nf = 0;

@@ -40,6 +40,7 @@ struct KMeansScratch {
   DevBuf gt;        // Gt [k_pad][mb]
   DevBuf best;      // u32 [mb] candidate + f32 [mb] second-best value
   DevBuf fb;        // u32 [n] uncertified points + counter at [n]
+  DevBuf fbq;       // large k: u32 [n] points queued for the tile re-scan + counter at [n], f32 [n] their G thresholds
   DevBuf xf, fa, fm;  // gathered uncertified points and their exact results
 };
 
