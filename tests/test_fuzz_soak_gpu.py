@@ -3,7 +3,7 @@ through the matrix-core list scan (fp16 shadow rows, the default) AND through th
 state in separate processes; all queries of both must agree bit for bit, and a sample must equal the C oracle.
 
 In the suite it draws for VERS_FUZZ_SECONDS (default 25 s: four to five configurations, a different slice per first seed);
-the long soak is the same test with VERS_FUZZ_SECONDS=600 / 1200 (577 + 1,134 + 566 configurations clean on the round-2 kernels)."""
+the long soak is the same test with VERS_FUZZ_SECONDS=600 / 1200 (577 + 1,134 + 566 + 852 configurations clean on the round-2 kernels)."""
 import os
 import subprocess
 import sys
