@@ -58,9 +58,12 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-recall", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the untimed extra measurements (single query, coarse GEMM, flat cfg2, Dist-U recall)")
+    ap.add_argument("--f32-rows", action="store_true", help="no fp16 shadow: the f32 rows feed the batched list scan (round 1's configuration; same as VERS_SHADOW=0)")
     ap.add_argument("--ahead", action="store_true", help="compute the next batch's coarse quantiser on a side stream under the current "
                     "list scan (vers_ivf_coarse_ahead_dev; same-box A/B at cfg3: +0.8 %% -- the scan already fills the chip)")
     args = ap.parse_args()
+    if args.f32_rows:
+        os.environ["VERS_SHADOW"] = "0"   # (read once by the library when it loads; the ranks inherit it)
 
     # `python bench.py --gpus N` outside a launcher: this process becomes the parent of N ranks.  It has not touched
     # the GPU (torch is not even imported yet) and never will; it relays rank 0's JSON line and the ranks' status.
