@@ -160,3 +160,11 @@ def test_forced_certificate_failure_is_exact():
 def test_ordered_chain_scan_still_available():
     out = run({"VERS_PRESCAN": "0"})
     assert out["TIES"] == (0, 0) and out["HUGE"] == (0, 0)
+
+
+def test_results_do_not_depend_on_uninitialised_memory():
+    """The same body with NaN in every storage row that holds no vector and 0x7f in every new device buffer of the library
+    (diagnosis knobs of DESIGN.md section 5): the oracle comparisons inside hold and the certificate statistics do not move."""
+    out = run({"VERS_POISON_SLACK": "nan", "VERS_POISON_ALLOC": "0x7f"})
+    assert out["TIES"][0] == 1 and out["TIES"][1] > 0 and out["HUGE"] == (1, 64)
+    assert out["ONE"] == (1,) and out["BIG"] == (0,) and out["TEN"][0] >= 10 and out["SLACK"] == (0,)
