@@ -18,6 +18,7 @@
 // <= d u |.|^2 each ;  MFMA dot = k-ordered fma chain: <= d u |q||c| <= d u S / 2, doubled ;
 // two final roundings <= 2 u (3S).   Total <= (5d + 16) u S =: E.
 #pragma once
+#include "plan.hip.h"
 #include "scan.hip.h"
 
 namespace vers {
@@ -440,10 +441,11 @@ inline hipError_t launch_split_bf16(const float* x, uint64_t n_floats, __bf16* h
 // certify, fall back to the full exact scan for this query if the certificate fails.
 // C_rm: centroids row-major [k][ldc] (pad columns zero); qp: padded queries [b][ldq].
 // probe[q][0..P) receives ascending (exact distance, centroid index) keys -- the exact coarse output.
+// pq.b != 0: the query's plan (plan.hip.h step 1) is made right here -- lane j holds the key of probe rank j.
 static __global__ __launch_bounds__(kWave) void coarse_select_rescore_kernel(
     const float* G, uint32_t N_pad, uint32_t k, const float* C_rm, uint32_t ldc, const float* qp, uint32_t ldq, uint32_t d_pad,
     float cmax2, uint32_t P, uint32_t PS, uint64_t* probe, uint32_t* status, uint32_t* fallback_count, int metric,
-    unsigned long long* stamps) {
+    unsigned long long* stamps, PlanQ pq) {
   const uint32_t q = blockIdx.x;
   const int lane = threadIdx.x;
   const unsigned long long t0 = stamps ? __builtin_amdgcn_s_memtime() : 0ull;
@@ -608,6 +610,11 @@ static __global__ __launch_bounds__(kWave) void coarse_select_rescore_kernel(
   }
   if (lane < (int)P) probe[(uint64_t)q * P + lane] = lane < (int)Pq ? exact : kKeyMax;
   if (__ballot(nan_seen) != 0 && lane == 0) atomicOr(status, 1u);
+  if (pq.b) {  // P <= 48 here: one chunk
+    uint32_t carry = 0, n_visited = 0;
+    plan_query_chunk(pq, q, lane, 0u, lane < (int)Pq ? exact : kKeyMax, carry, n_visited);
+    plan_query_finish(pq, q, lane, carry, n_visited);
+  }
   if (stamps && lane == 0) {
     const unsigned long long t3 = __builtin_amdgcn_s_memtime();
     atomicAdd(stamps + 24, t1 - t0); atomicAdd(stamps + 25, t2 - t1); atomicAdd(stamps + 26, t3 - t2); atomicAdd(stamps + 27, 1ull);

@@ -26,6 +26,7 @@
 
 #include "gemm.hip.h"
 #include "kmeans.hpp"
+#include "plan.hip.h"
 #include "prescan.hip.h"
 #include "scan.hip.h"
 #include "util.hip.h"
@@ -49,8 +50,6 @@ void shard_plan(const uint64_t* lens, uint64_t k, uint32_t world, uint8_t* owner
   }
 }
 
-constexpr uint32_t kNoList = 0xFFFFFFFFu;
-constexpr uint32_t kStNaN = 1u, kStInsufficient = 2u, kStSpillTooDeep = 4u;
 constexpr int32_t kRetrySpill = 1001;  // internal: reference-mode spill ran past the ranked lists, retry deeper if possible
 
 // ---- sources for the scan engine -----------------------------------------------------------
@@ -87,22 +86,6 @@ struct SegSrc {
     return partials + ((uint64_t)(qg * QG + qi) * n_segs + seg) * k;
   }
   __device__ __forceinline__ uint32_t bound_slot(uint32_t it, int qi) const { return (it / n_segs_pad) * QG + qi; }
-};
-
-constexpr uint32_t kNoSeg = 0xFFFFFFFFu;  // padding item of a quad
-// Row segments of one list.  seg_target == 0: fixed seg_rows.  Otherwise (matrix-core scan) the list is cut into
-// 4 * ceil(len / (4 * seg_target)) nearly equal whole-tile segments, so that the four waves of a quad -- which
-// share a query block and a barrier -- carry the same load whatever the list length.
-__host__ __device__ __forceinline__ uint32_t list_seg_rows(uint32_t len, uint32_t seg_rows, uint32_t seg_target) {
-  if (seg_target == 0) return seg_rows;
-  uint32_t n_quads = (len + 4 * seg_target - 1) / (4 * seg_target);
-  if (n_quads == 0) n_quads = 1;
-  const uint32_t per = (len + 4 * n_quads - 1) / (4 * n_quads);
-  const uint32_t seg = (per + 63) / 64 * 64;
-  return seg ? seg : 64u;
-}
-struct ItemDesc {
-  uint32_t list, group, seg;
 };
 
 // inverted-list scan: item = (list, query group of the list, row segment of the list)
@@ -183,96 +166,59 @@ __global__ __launch_bounds__(kWave * kMergeWaves) void coarse_merge_kernel(const
   if (lower_out != nullptr && threadIdx.x == k_pass - 1) lower_out[q] = list;  // (kKeyMax when the centroids ran out: the next pass finds nothing)
 }
 
-// ---- planning of a batch: ONE cooperative launch (plan_fused_kernel) ---------------------------------------------
-// fill (zero the per-batch tables, 0xFF the partial slots) | plan (wave per query) | group (block 0: three prefix sums
-// over the lists) | scatter pairs + item / group descriptors, separated by grid-wide barriers.  Round 1 issued these as
-// two fills and four kernels: ~45 us of launches and dependent start-up gaps per batch next to ~15 us of work, a
-// cost that does not shrink when the lists are sharded over GPUs.
-constexpr uint32_t kPlanBlocks = 64, kPlanThreads = 1024;  // 64 <= CUs: every block is resident, the barriers cannot deadlock
-
-// Grid-wide barrier on a monotonically increasing counter in device memory (never reset: `target` counts arrivals
-// since the handle was created, compared modulo 2^32).
-__device__ __forceinline__ void grid_barrier(uint32_t* ctr, uint32_t target) {
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    __threadfence();
-    __hip_atomic_fetch_add(ctr, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    // (relaxed polls: an acquire load per poll invalidates caches and slowed the one working block 2x; one fence after)
-    while ((int32_t)(__hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) - target) < 0) __builtin_amdgcn_s_sleep(16);
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    __threadfence();
-  }
-  __syncthreads();
-}
-
-// plan: one WAVE per query, lane j = probe rank j (P <= 64).  nprobe mode: every probed list is scanned, pj_pref =
-// running row count.  reference mode (ivfflat.rs:166-195): the walk of the ranked lists in closed form -- list j is
-// visited while the rows before it do not yet fill top_k and contributes take_j = min(len_j, top_k - rows before);
-// out of lists -> the reference panics.  owner (nullable): only lists with owner[L] == rank are scanned on this GPU.
-__device__ __forceinline__ void plan_query(uint32_t q, int lane, const uint64_t* probe, uint32_t P, uint32_t k_lists, uint32_t top_k,
-                                           int ref_mode, const uint32_t* list_len, const uint8_t* owner, uint32_t rank,
-                                           uint32_t* pj_list, uint32_t* pj_pref, uint32_t* pj_take, uint32_t* np, uint32_t* cnt,
-                                           uint32_t* hot, uint32_t hot_ranks, uint32_t* status, uint32_t* pj_nq, uint32_t seg_rows,
-                                           uint32_t seg_target, const uint32_t* list_slot) {
-  // lane j of chunk c = probe rank 64c + j; the running row count carries from chunk to chunk (P <= 64: one chunk)
+// ---- planning of a batch (plan.hip.h): no cross-block waiting anywhere -------------------------------------------
+// Step (1) standalone: a wave per query reads its ranked lists from `probe` (exact coarse quantiser, a look-ahead slot,
+// more than 64 ranked lists).  Batches ranked on the matrix cores get this step in the tail of the selection kernel.
+__global__ __launch_bounds__(256) void plan_queries_kernel(PlanQ a, const uint64_t* probe) {
+  const uint32_t q = blockIdx.x * 4u + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (q >= a.b) return;  // (whole waves)
   uint32_t carry = 0, n_visited = 0;
-  for (uint32_t c0 = 0; c0 < P; c0 += kWave) {
+  for (uint32_t c0 = 0; c0 < a.P; c0 += kWave) {  // lane j of chunk c = probe rank 64c + j; the running row count carries over
     const uint32_t j = c0 + (uint32_t)lane;
-    const uint64_t key = j < P ? probe[(uint64_t)q * P + j] : kKeyMax;
-    const uint32_t L = key != kKeyMax ? (uint32_t)key : kNoList;  // centroid index; the tables below are addressed by its SLOT
-    const uint32_t len = L != kNoList ? list_len[L] : 0u;
-    const uint32_t slot = L != kNoList ? list_slot[L] : kNoList;
-    uint32_t inc = len;
-#pragma unroll
-    for (int off = 1; off < kWave; off <<= 1) {
-      const uint32_t t = __shfl_up(inc, off, kWave);
-      if (lane >= off) inc += t;
-    }
-    const uint32_t pref = carry + inc - len;
-    carry += (uint32_t)__shfl(inc, kWave - 1, kWave);
-    const bool visited = L != kNoList && (!ref_mode || pref < top_k);
-    const uint32_t take = !visited ? 0u : (ref_mode ? (len < top_k - pref ? len : top_k - pref) : top_k);
-    const bool scan = visited && len > 0 && take > 0 && (owner == nullptr || owner[L] == rank);
-    if (j < P) {
-      pj_list[(uint64_t)q * P + j] = scan ? slot : kNoList;
-      pj_pref[(uint64_t)q * P + j] = pref;
-      pj_take[(uint64_t)q * P + j] = take;
-      if (pj_nq) {  // matrix-core scan: one partial slot per quad of segments of a scanned list
-        const uint32_t sr = list_seg_rows(len, seg_rows, seg_target);
-        pj_nq[(uint64_t)q * P + j] = scan ? ((len + sr - 1) / sr + 3) / 4 : 0u;
-      }
-    }
-    if (scan) atomicAdd(&cnt[slot], 1u);
-    if (scan && j < hot_ranks) hot[slot] = 1u;  // this query's tightest thresholds come from here (the group step orders the work)
-    n_visited += (uint32_t)__popcll(__ballot(visited));
+    plan_query_chunk(a, q, lane, c0, j < a.P ? probe[(uint64_t)q * a.P + j] : kKeyMax, carry, n_visited);
   }
-  if (lane == 0) {
-    np[q] = n_visited;
-    if (ref_mode && top_k > 0 && carry < top_k) atomicOr(status, P >= k_lists ? kStInsufficient : kStSpillTooDeep);
-  }
+  plan_query_finish(a, q, lane, carry, n_visited);
 }
 
-// group: ONE block of 1024 threads.  Per list: pairs, groups (ceil(cnt/QG)), items (groups * segments); exclusive
-// prefix sums of all three; totals + traffic statistics.
-struct GroupTotals {
-  uint32_t n_items, n_groups, n_pairs, pad;
-  uint64_t union_rows;     // sum of len over lists probed by at least one query (algorithmic rows)
-  uint64_t streamed_rows;  // rows the scan items actually stream (a list is re-read per query group)
-};
-
+// Steps (2) + (3): ONE ordinary launch of up to 64 blocks.  EVERY block runs the prefix sums over all lists (per list:
+// pairs, groups = ceil(cnt / QG), items = groups * segments; a few microseconds of L2 reads) and keeps / stores the
+// entries of the lists it OWNS -- granules of four consecutive slots dealt round-robin over the blocks -- then scatters
+// the pairs of its lists and writes their item / group descriptors.  Nothing waits for another block.
 // All tables are in SLOT order (lists by descending length, see vers_ivf::list_slot).  Work order of the scan = hot
 // lists first (nearest list of some query: their thresholds must be tight before the bulk is scanned), then the others
 // in slot order, i.e. LONGEST FIRST.
-__device__ __forceinline__ void group_lists(const uint32_t* cnt, const uint32_t* list_len, uint32_t k_lists, uint32_t QG, uint32_t seg_rows,
-                                            uint32_t seg_target, const uint32_t* hot, uint32_t* pair_off,
-                                            uint32_t* group_off, uint32_t* item_off, GroupTotals* tot) {
-  // four exclusive prefix sums over the lists (pairs, groups, items of hot lists, items of the others) in rounds of 4096
-  // lists: a thread owns FOUR consecutive lists (three 16-byte loads, a serial scan in registers), the waves scan the
-  // thread totals by shuffles, 16 wave totals go through LDS, a running carry links the rounds.  One round and two block
-  // barriers at 4096 lists (a thread per list took four rounds of two barriers, each round a chain of dependent LDS and
-  // shuffle steps: 20 us of the planning kernel's 40-55; the LDS Hillis-Steele version before it 26 us).
+constexpr uint32_t kGroupThreads = 1024, kGroupMaxBlocks = 64;
+struct GroupArgs {
+  uint32_t b, P, k_lists, QG, seg_rows, seg_target;
+  const uint32_t* slot_len;   // list lengths in slot order
+  const uint32_t* cnt;        // pairs per list (plan_query)
+  const uint32_t* hot;
+  uint32_t* fill;             // zeroed with cnt
+  const uint32_t* pj_list;
+  uint32_t *pair_off, *group_off, *item_off;
+  GroupTotals* tot;
+  uint32_t* pairs;
+  ItemDesc* items;
+  GroupDesc* groups;
+  u32x4* ff_begin;       // 0xFF-filled here: the pruning bounds (matrix-core scan; its slots need no fill: ivf_rescore_kernel
+  uint64_t ff_vec16;     // reads written slots only).  This many 16-byte words.
+  unsigned long long* stamps;  // diagnosis (VERS_SCAN_DEBUG & 16): [16..19] 100 MHz clock at the phase boundaries, block 0
+};
+// a table entry this block stored itself a phase ago: read past the vector L1 (which may hold the line from before the store)
+__device__ __forceinline__ uint32_t ld_l2(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
+__device__ __forceinline__ bool owns_list(uint32_t L) { return ((L >> 2) % gridDim.x) == blockIdx.x; }
+
+// Four exclusive prefix sums over the lists (pairs, groups, items of hot lists, items of the others) in rounds of 4096
+// lists: a thread owns FOUR consecutive lists (three 16-byte loads, a serial scan in registers), the waves scan the
+// thread totals by shuffles, 16 wave totals go through LDS, a running carry links the rounds.  One round and two block
+// barriers at 4096 lists.
+__device__ __forceinline__ void group_lists(const GroupArgs& a) {
   __shared__ uint32_t wp[16], wg[16], wi[16], wh[16];
   __shared__ unsigned long long ur, sr;
+  const uint32_t* cnt = a.cnt; const uint32_t* list_len = a.slot_len; const uint32_t* hot = a.hot;
+  const uint32_t k_lists = a.k_lists, QG = a.QG;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   if (threadIdx.x == 0) { ur = sr = 0; }
   uint32_t cp = 0, cg = 0, ci = 0, ch = 0;  // carries (identical in every thread); ci: other lists' items, ch: hot lists' items
@@ -287,8 +233,8 @@ __device__ __forceinline__ void group_lists(const uint32_t* cnt, const uint32_t*
   };
   // whole 16-byte vectors when every table starts on one (they are carved out of one allocation: true when k, b are multiples of 4)
   const bool vec_ok = (k_lists & 3u) == 0 &&
-                      (((uintptr_t)cnt | (uintptr_t)list_len | (uintptr_t)hot | (uintptr_t)pair_off | (uintptr_t)group_off | (uintptr_t)item_off) & 15u) == 0;
-  for (uint32_t base0 = 0; base0 < k_lists; base0 += 4 * 1024) {
+                      (((uintptr_t)cnt | (uintptr_t)list_len | (uintptr_t)hot | (uintptr_t)a.pair_off | (uintptr_t)a.group_off | (uintptr_t)a.item_off) & 15u) == 0;
+  for (uint32_t base0 = 0; base0 < k_lists; base0 += 4 * kGroupThreads) {
     const uint32_t i0 = base0 + 4u * threadIdx.x;
     uint32_t c4[4] = {0, 0, 0, 0}, l4[4] = {0, 0, 0, 0}, h4[4] = {0, 0, 0, 0};
     if (vec_ok && i0 < k_lists) {
@@ -308,7 +254,7 @@ __device__ __forceinline__ void group_lists(const uint32_t* cnt, const uint32_t*
       uint32_t g = 0, it = 0;
       if (c4[e]) {
         g = (c4[e] + QG - 1) / QG;
-        const uint32_t sr2 = list_seg_rows(l4[e], seg_rows, seg_target);
+        const uint32_t sr2 = list_seg_rows(l4[e], a.seg_rows, a.seg_target);
         const uint32_t n_s = (l4[e] + sr2 - 1) / sr2;
         it = g * (QG == 1 ? n_s : (n_s + 3) / 4 * 4);  // QG > 1: quads of items share a query block
         my_ur += l4[e];
@@ -335,14 +281,16 @@ __device__ __forceinline__ void group_lists(const uint32_t* cnt, const uint32_t*
       po[e] = op; go[e] = og; io[e] = h4[e] ? oh : oc;  // (the others' item offsets are shifted behind the hot lists' below)
       op += c4[e]; og += g4[e]; oc += ic4[e]; oh += ih4[e];
     }
-    if (vec_ok && i0 < k_lists) {
-      *reinterpret_cast<u32x4*>(pair_off + i0) = u32x4{po[0], po[1], po[2], po[3]};
-      *reinterpret_cast<u32x4*>(group_off + i0) = u32x4{go[0], go[1], go[2], go[3]};
-      *reinterpret_cast<u32x4*>(item_off + i0) = u32x4{io[0], io[1], io[2], io[3]};
-    } else {
+    if (i0 < k_lists && owns_list(i0)) {  // the granule's owner stores its entries
+      if (vec_ok) {
+        *reinterpret_cast<u32x4*>(a.pair_off + i0) = u32x4{po[0], po[1], po[2], po[3]};
+        *reinterpret_cast<u32x4*>(a.group_off + i0) = u32x4{go[0], go[1], go[2], go[3]};
+        *reinterpret_cast<u32x4*>(a.item_off + i0) = u32x4{io[0], io[1], io[2], io[3]};
+      } else {
 #pragma unroll
-      for (int e = 0; e < 4; ++e)
-        if (i0 + e < k_lists) { pair_off[i0 + e] = po[e]; group_off[i0 + e] = go[e]; item_off[i0 + e] = io[e]; }
+        for (int e = 0; e < 4; ++e)
+          if (i0 + e < k_lists) { a.pair_off[i0 + e] = po[e]; a.group_off[i0 + e] = go[e]; a.item_off[i0 + e] = io[e]; }
+      }
     }
     cp += rp; cg += rg; ci += ri; ch += rh;
   }
@@ -357,107 +305,71 @@ __device__ __forceinline__ void group_lists(const uint32_t* cnt, const uint32_t*
     atomicAdd(&sr, my_sr);
   }
   __syncthreads();
-  for (uint32_t base0 = 0; base0 < k_lists; base0 += 4 * 1024)  // (each thread shifts the entries it wrote itself)
+  for (uint32_t base0 = 0; base0 < k_lists; base0 += 4 * kGroupThreads) {  // (each thread shifts the entries it wrote itself)
+    const uint32_t i0 = base0 + 4u * threadIdx.x;
+    if (i0 >= k_lists || !owns_list(i0)) continue;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      const uint32_t L = base0 + 4u * threadIdx.x + e;
-      if (L < k_lists && cnt[L] != 0 && hot[L] == 0) item_off[L] += ch;
+      const uint32_t L = i0 + e;
+      if (L < k_lists && cnt[L] != 0 && hot[L] == 0) a.item_off[L] += ch;
     }
-  if (threadIdx.x == 0) {
-    tot->n_items = ci + ch; tot->n_groups = cg; tot->n_pairs = cp; tot->pad = 0;
-    tot->union_rows = ur; tot->streamed_rows = sr;
+  }
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    a.tot->n_items = ci + ch; a.tot->n_groups = cg; a.tot->n_pairs = cp; a.tot->pad = 0;
+    a.tot->union_rows = ur; a.tot->streamed_rows = sr;
   }
 }
 
-// items + group descriptors of one list
-struct GroupDesc {
-  uint32_t pair_start, nq;
-};
-__device__ __forceinline__ void list_items(uint32_t L, const uint32_t* cnt, const uint32_t* list_len, uint32_t QG, uint32_t seg_rows,
-                                           uint32_t seg_target, const uint32_t* pair_off, const uint32_t* group_off, const uint32_t* item_off,
-                                           ItemDesc* items, GroupDesc* groups) {
-  const uint32_t c = cnt[L];
+// items + group descriptors of one list (of this block: the offsets are its own stores of the phase before)
+__device__ __forceinline__ void list_items(uint32_t L, const GroupArgs& a) {
+  const uint32_t c = a.cnt[L];
   if (!c) return;
-  const uint32_t sr = list_seg_rows(list_len[L], seg_rows, seg_target);
-  const uint32_t n_g = (c + QG - 1) / QG, n_s = (list_len[L] + sr - 1) / sr;
+  const uint32_t QG = a.QG, len = a.slot_len[L];
+  const uint32_t sr = list_seg_rows(len, a.seg_rows, a.seg_target);
+  const uint32_t n_g = (c + QG - 1) / QG, n_s = (len + sr - 1) / sr;
   const uint32_t n_s_pad = QG == 1 ? n_s : (n_s + 3) / 4 * 4;
-  uint32_t o = item_off[L];
-  for (uint32_t g = 0; g < n_g; ++g)
-    groups[group_off[L] + g] = GroupDesc{pair_off[L] + g * QG, (c - g * QG < QG) ? c - g * QG : QG};
+  uint32_t o = ld_l2(a.item_off + L);
+  const uint32_t g0 = ld_l2(a.group_off + L), p0 = ld_l2(a.pair_off + L);
+  for (uint32_t g = 0; g < n_g; ++g) a.groups[g0 + g] = GroupDesc{p0 + g * QG, (c - g * QG < QG) ? c - g * QG : QG};
   if (QG == 1) {
     for (uint32_t g = 0; g < n_g; ++g)
-      for (uint32_t s = 0; s < n_s; ++s) items[o++] = ItemDesc{L, g, s};
+      for (uint32_t s = 0; s < n_s; ++s) a.items[o++] = ItemDesc{L, g, s};
   } else {
     // quads of segments outermost, query groups inside: the groups that re-read the same rows are
     // neighbours in the item order, and scan_kernel's XCD remap runs neighbours on one XCD's L2
     for (uint32_t s0 = 0; s0 < n_s_pad; s0 += 4)
       for (uint32_t g = 0; g < n_g; ++g)
-        for (uint32_t s = s0; s < s0 + 4; ++s) items[o++] = ItemDesc{L, g, s < n_s ? s : kNoSeg};
+        for (uint32_t s = s0; s < s0 + 4; ++s) a.items[o++] = ItemDesc{L, g, s < n_s ? s : kNoSeg};
   }
 }
 
-struct PlanArgs {
-  const uint64_t* probe;
-  uint32_t b, P, k_lists, top_k;
-  int ref_mode;
-  const uint32_t* list_len;   // by centroid index
-  const uint8_t* owner;
-  uint32_t rank;
-  const uint32_t* list_slot;  // centroid index -> slot
-  const uint32_t* slot_len;   // list lengths in slot order
-  uint32_t *pj_list, *pj_pref, *pj_take, *np;
-  uint32_t* pj_nq;              // nullable (matrix-core scan only)
-  uint32_t *cnt, *fill, *hot;   // start of the zero-initialised zone (zero_words u32 from cnt)
-  uint32_t zero_words;
-  uint32_t *pair_off, *group_off, *item_off;
-  GroupTotals* tot;
-  uint32_t* pairs;
-  ItemDesc* items;
-  GroupDesc* groups;
-  uint32_t QG, seg_rows, seg_target, hot_ranks;
-  uint32_t* status;
-  u32x4* ff_begin;       // 0xFF-filled here: the pruning bounds (matrix-core scan; its slots need no fill: ivf_rescore_kernel
-  uint64_t ff_vec16;     // reads written slots only).  This many 16-byte words.
-  uint32_t* grid_ctr;
-  uint32_t ctr_base;     // arrivals at the counter before this launch
-  unsigned long long* stamps;  // diagnosis (VERS_SCAN_DEBUG & 16): [16..21] 100 MHz clock at the phase boundaries, block 0
-};
-
-__global__ __launch_bounds__(kPlanThreads) void plan_fused_kernel(PlanArgs a) {
-  const uint32_t tid = blockIdx.x * kPlanThreads + threadIdx.x, nthreads = kPlanBlocks * kPlanThreads;
-  const int lane = threadIdx.x & 63;
+__global__ __launch_bounds__(kGroupThreads) void group_scatter_kernel(GroupArgs a) {
+  const uint32_t tid = blockIdx.x * kGroupThreads + threadIdx.x, nthreads = gridDim.x * kGroupThreads;
   auto stamp = [&](int i) { if (a.stamps && tid == 0) a.stamps[16 + i] = __builtin_amdgcn_s_memrealtime(); };
   stamp(0);
-  // (A) tables of this batch
-  for (uint32_t i = tid; i < a.zero_words; i += nthreads) a.cnt[i] = 0u;
   const u32x4 ff = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
   for (uint64_t i = tid; i < a.ff_vec16; i += nthreads) a.ff_begin[i] = ff;
+  group_lists(a);
+  __threadfence();  // this block's table entries are in L2 before it reads them back
+  __syncthreads();
   stamp(1);
-  grid_barrier(a.grid_ctr, a.ctr_base + kPlanBlocks);
-  stamp(2);
-  // (B) plan
-  const uint32_t n_waves = nthreads / kWave;
-  for (uint32_t q = tid / kWave; q < a.b; q += n_waves)
-    plan_query(q, lane, a.probe, a.P, a.k_lists, a.top_k, a.ref_mode, a.list_len, a.owner, a.rank, a.pj_list, a.pj_pref, a.pj_take, a.np,
-               a.cnt, a.hot, a.hot_ranks, a.status, a.pj_nq, a.seg_rows, a.seg_target, a.list_slot);
-  grid_barrier(a.grid_ctr, a.ctr_base + 2 * kPlanBlocks);
-  stamp(3);
-  // (C) group
-  if (blockIdx.x == 0)
-    group_lists(a.cnt, a.slot_len, a.k_lists, a.QG, a.seg_rows, a.seg_target, a.hot, a.pair_off, a.group_off, a.item_off, a.tot);
-  stamp(4);
-  grid_barrier(a.grid_ctr, a.ctr_base + 3 * kPlanBlocks);
-  stamp(5);
-  // (D) pairs of a list become contiguous (order inside a list is arbitrary and irrelevant: every (query, list)
-  // result goes to its own slot); item and group descriptors
+  // pairs of a list become contiguous (order inside a list is arbitrary and irrelevant: every (query, list) result goes
+  // to its own slot): each block picks the pairs of ITS lists out of the whole table
   const uint32_t n_pj = a.b * a.P;
-  for (uint32_t i = tid; i < n_pj; i += nthreads) {
+  for (uint32_t i = threadIdx.x; i < n_pj; i += kGroupThreads) {
     const uint32_t L = a.pj_list[i];
-    if (L != kNoList) a.pairs[a.pair_off[L] + atomicAdd(&a.fill[L], 1u)] = i;
+    if (L != kNoList && owns_list(L)) a.pairs[ld_l2(a.pair_off + L) + atomicAdd(&a.fill[L], 1u)] = i;
   }
-  for (uint32_t L = tid; L < a.k_lists; L += nthreads)
-    list_items(L, a.cnt, a.slot_len, a.QG, a.seg_rows, a.seg_target, a.pair_off, a.group_off, a.item_off, a.items, a.groups);
-  stamp(6);
+  stamp(2);
+  // item and group descriptors of its lists: granule g = blockIdx.x + n * gridDim.x, four lists each
+  const uint32_t n_gran = (a.k_lists + 3) / 4;
+  for (uint32_t w = threadIdx.x; ; w += kGroupThreads) {
+    const uint32_t gran = blockIdx.x + (w >> 2) * gridDim.x;
+    if (gran >= n_gran) break;
+    const uint32_t L = 4 * gran + (w & 3u);
+    if (L < a.k_lists) list_items(L, a);
+  }
+  stamp(3);
 }
 
 // Single query: coarse merge + plan + group + scatter + items in ONE launch (the five small kernels above cost
@@ -738,8 +650,6 @@ struct SearchWs {
   bool ref_deep = false;     // reference-mode retry: rank 64 lists with the exact coarse quantiser (no slack needed)
   bool ref_all = false;      // last resort of a reference-mode host call: every list is ranked (the spill may walk through all of them)
   bool ref_shallow = false;  // host-pointer calls try 16 ranked lists first (a spill past the nearest few lists is rare)
-  DevBuf grid_ctr;         // arrival counter of plan_fused_kernel's grid barriers (monotonic, never reset)
-  uint32_t plan_launches = 0;
   DevBuf seg_bounds, stamps, quad_counter, fb_part, fb_ctr;
   DevBuf clower, lower;  // lower bounds of multi-pass results (coarse ranking of more than 64 lists; top_k > 64)
   DevBuf qp, qil, cpart, probe, pj, lists, pairs, items, groups, qblocks, partials, status, o_ids, o_dist, o_cnt, xpart;
@@ -870,8 +780,6 @@ int32_t status_to_rc(vers_ivf* h, uint32_t s, uint32_t slot);
 int32_t ws_init(SearchWs& w) {
   if (int32_t rc = w.status.reserve(16)) return rc;
   VERS_HIP_TRY(hipMemset(w.status.p, 0, 16));
-  if (int32_t rc = w.grid_ctr.reserve(16)) return rc;
-  VERS_HIP_TRY(hipMemset(w.grid_ctr.p, 0, 16));
   if (scan_debug_flags() & 16u) {  // diagnosis: in-kernel phase stamps
     if (int32_t rc = w.stamps.reserve(256)) return rc;
     VERS_HIP_TRY(hipMemset(w.stamps.p, 0, 256));
@@ -1697,7 +1605,8 @@ inline int coarse_mode() {  // VERS_COARSE: 1 = always exact, 2 = every certific
 inline bool coarse_on_matrix_cores(const vers_ivf* h, uint32_t b) { return b >= 32 && coarse_mode() != 1 && !W->ref_deep; }
 // batches: MFMA pre-selection + exact re-score + certificate (gemm.hip.h); same output as the exact scan, bit for bit.
 // qp: staged queries [round_up(b, kGemmBM)][ldq]; probe_out [b][P].  W->gbuf is the only scratch.
-int32_t coarse_mfma(vers_ivf* h, const float* qp, uint32_t b, uint32_t P, uint64_t* probe_out, hipStream_t st) {
+// plan != nullptr: the selection kernel also makes every query's plan (plan.hip.h step 1) in its tail.
+int32_t coarse_mfma(vers_ivf* h, const float* qp, uint32_t b, uint32_t P, uint64_t* probe_out, hipStream_t st, const PlanQ* plan = nullptr) {
   const uint32_t M_pad = round_up(b, kGemmBM);
   const uint32_t PS = std::min<uint32_t>(kMaxTopK, P + 16);
   if (int32_t rc = W->gbuf.reserve((size_t)M_pad * h->k_pad * sizeof(float))) return rc;
@@ -1711,7 +1620,8 @@ int32_t coarse_mfma(vers_ivf* h, const float* qp, uint32_t b, uint32_t P, uint64
   hipLaunchKernelGGL(coarse_select_rescore_kernel, dim3(b), dim3(kWave), 0, st, W->gbuf.as<float>(), h->k_pad, h->k,
                      h->centroids_g.as<float>(), h->ldq, qp, h->ldq, h->ldq, coarse_mode() == 2 ? __builtin_inff() : h->cmax2, P, PS,
                      probe_out, W->st_word(), h->coarse_stat.as<uint32_t>(), h->metric,
-                     (scan_debug_flags() & 16u) && W->stamps.p ? W->stamps.as<unsigned long long>() : (unsigned long long*)nullptr);
+                     (scan_debug_flags() & 16u) && W->stamps.p ? W->stamps.as<unsigned long long>() : (unsigned long long*)nullptr,
+                     plan ? *plan : PlanQ{});
   VERS_HIP_TRY(hipGetLastError());
   if (timed) { VERS_HIP_TRY(hipEventRecord(W->evc[2], st)); W->evc_valid = true; }
   h->mfma_batches += 1;
@@ -1721,12 +1631,16 @@ int32_t coarse_mfma(vers_ivf* h, const float* qp, uint32_t b, uint32_t P, uint64
 // coarse quantiser (ivfflat.rs:155-161): top-P centroids per query as ascending (dist, index) keys in W->probe
 // out_n_segs != nullptr: stop after the scan (partial slots in W->cpart) and report the slot count per query --
 // the single-query path merges them inside plan1_kernel.
-int32_t coarse(vers_ivf* h, const float* qp, uint32_t b, uint32_t P, hipStream_t st, uint32_t* out_n_segs = nullptr) {
+// plan / planned (nullable): when the ranking runs on the matrix cores the queries' plans are made in the same launch and
+// *planned is set; otherwise the caller plans from W->probe (plan_queries_kernel).
+int32_t coarse(vers_ivf* h, const float* qp, uint32_t b, uint32_t P, hipStream_t st, uint32_t* out_n_segs = nullptr,
+               const PlanQ* plan = nullptr, bool* planned = nullptr) {
   // (the contraction reads whole 128-row tiles: the staged block is padded to them, a caller's block used in place is a whole
   // number of them; the selection keeps P + 16 keys: one per lane)
   if (coarse_on_matrix_cores(h, b) && (qp == W->qp.as<float>() || b % kGemmBM == 0) && P + 16 <= (uint32_t)kMaxTopK) {
     if (int32_t rc = W->probe.reserve((size_t)b * P * sizeof(uint64_t))) return rc;
-    return coarse_mfma(h, qp, b, P, W->probe.as<uint64_t>(), st);
+    if (planned) *planned = plan != nullptr;
+    return coarse_mfma(h, qp, b, P, W->probe.as<uint64_t>(), st, plan);
   }
   const int QG = b == 1 ? 1 : 8;
   const uint32_t n_qg = (b + QG - 1) / QG;
@@ -1882,24 +1796,6 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
     std::lock_guard<std::mutex> lk(h->pool_mu);
     if (h->pending.set && h->pending.q_dev == q_dev && h->pending.ldq_in == ldq_in && h->pending.b == b) h->pending.set = false;  // this very batch: computed inline below
   }
-  uint32_t n_segs_c = 0;
-  if (took) {  // staged queries and ranked lists of this batch were computed ahead (vers_ivf_coarse_ahead_dev)
-    VERS_HIP_TRY(hipStreamWaitEvent(st, took->ready, 0));
-    qp = took->qp.as<float>();
-    probe = took->probe.as<uint64_t>();
-    took->valid = false;
-    h->ahead_used += 1;
-  } else {
-    for (auto& a : W->ahead)  // W->gbuf is shared with a look-ahead in flight: let it finish first
-      if (a.ready_rec) VERS_HIP_TRY(hipStreamWaitEvent(st, a.ready, 0));
-    // the caller's block as it is when its layout already is the staged one: no padding columns to zero (d == ldq), the same
-    // pitch, and -- the matrix-core contraction reads whole 128-row tiles -- a whole number of tiles (or a single query)
-    if (h->d == h->ldq && (reinterpret_cast<uintptr_t>(q_dev) & 15u) == 0 && (b == 1 || (ldq_in == h->ldq && b % kGemmBM == 0))) qp = q_dev;
-    else if (int32_t rc = stage_plain_queries(h, q_dev, ldq_in, b, &qp, st)) return rc;
-    if (int32_t rc = coarse(h, qp, b, P, st, one1 ? &n_segs_c : nullptr)) return rc;
-    probe = W->probe.as<uint64_t>();
-  }
-
   // geometry of the list scan
   const uint64_t n_pj = (uint64_t)b * P;
   const uint64_t pairs_est = ref_mode ? b : n_pj;
@@ -1989,6 +1885,35 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
   GroupTotals* tot = (GroupTotals*)(((uintptr_t)(item_off + k_l) + 15) & ~(uintptr_t)15);
   W->tot_dev = tot;
 
+  // The per-batch tables are zeroed FIRST: the queries' plans (counts per list, hot marks) are made in the tail of the coarse
+  // quantiser's selection kernel when it runs on the matrix cores, by plan_queries_kernel otherwise.
+  PlanQ pq;
+  pq.b = b; pq.P = P; pq.k_lists = k_l; pq.top_k = top_k; pq.ref_mode = ref_mode;
+  pq.list_len = h->list_len.as<uint32_t>(); pq.owner = h->world > 1 ? h->owner.as<uint8_t>() : (const uint8_t*)nullptr; pq.rank = h->rank;
+  pq.list_slot = h->list_slot.as<uint32_t>();
+  pq.pj_list = pj_list; pq.pj_pref = pj_pref; pq.pj_take = pj_take; pq.np = np; pq.pj_nq = use_pre ? pj_nq : nullptr;
+  pq.cnt = cnt; pq.hot = hot; pq.hot_ranks = knobs().hot_ranks; pq.seg_rows = seg_rows; pq.seg_target = seg_target;
+  pq.status = W->st_word();
+  bool planned = false;
+  if (!one1) VERS_HIP_TRY(hipMemsetAsync(cnt, 0, zero_words * sizeof(uint32_t), st));
+  uint32_t n_segs_c = 0;
+  if (took) {  // staged queries and ranked lists of this batch were computed ahead (vers_ivf_coarse_ahead_dev)
+    VERS_HIP_TRY(hipStreamWaitEvent(st, took->ready, 0));
+    qp = took->qp.as<float>();
+    probe = took->probe.as<uint64_t>();
+    took->valid = false;
+    h->ahead_used += 1;
+  } else {
+    for (auto& a : W->ahead)  // W->gbuf is shared with a look-ahead in flight: let it finish first
+      if (a.ready_rec) VERS_HIP_TRY(hipStreamWaitEvent(st, a.ready, 0));
+    // the caller's block as it is when its layout already is the staged one: no padding columns to zero (d == ldq), the same
+    // pitch, and -- the matrix-core contraction reads whole 128-row tiles -- a whole number of tiles (or a single query)
+    if (h->d == h->ldq && (reinterpret_cast<uintptr_t>(q_dev) & 15u) == 0 && (b == 1 || (ldq_in == h->ldq && b % kGemmBM == 0))) qp = q_dev;
+    else if (int32_t rc = stage_plain_queries(h, q_dev, ldq_in, b, &qp, st)) return rc;
+    if (int32_t rc = coarse(h, qp, b, P, st, one1 ? &n_segs_c : nullptr, one1 ? nullptr : &pq, &planned)) return rc;
+    probe = W->probe.as<uint64_t>();
+  }
+
   if (n_pass > 1)
     if (int32_t rc = W->lower.reserve(n_pj * sizeof(uint64_t))) return rc;
   if (one1) {
@@ -2000,31 +1925,30 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
                        (const uint32_t*)h->list_slot.as<uint32_t>());
     VERS_HIP_TRY(hipGetLastError());
   } else {
-  // ONE cooperative launch: table fills | plan | group | scatter + items (plan_fused_kernel); also a single query with P > 64
-  PlanArgs pa;
-  pa.probe = probe; pa.b = b; pa.P = P; pa.k_lists = k_l; pa.top_k = top_k; pa.ref_mode = ref_mode;
-  pa.list_len = h->list_len.as<uint32_t>(); pa.owner = h->world > 1 ? h->owner.as<uint8_t>() : (const uint8_t*)nullptr; pa.rank = h->rank;
-  pa.list_slot = h->list_slot.as<uint32_t>(); pa.slot_len = h->slot_len.as<uint32_t>();
-  pa.pj_list = pj_list; pa.pj_pref = pj_pref; pa.pj_take = pj_take; pa.np = np; pa.pj_nq = use_pre ? pj_nq : nullptr;
-  pa.cnt = cnt; pa.fill = fill; pa.hot = hot; pa.zero_words = (uint32_t)zero_words;
-  pa.pair_off = pair_off; pa.group_off = group_off; pa.item_off = item_off; pa.tot = tot;
-  pa.pairs = W->pairs.as<uint32_t>(); pa.items = W->items.as<ItemDesc>(); pa.groups = W->groups.as<GroupDesc>();
-  pa.QG = (uint32_t)QG; pa.seg_rows = seg_rows; pa.seg_target = seg_target; pa.hot_ranks = knobs().hot_ranks;
-  pa.status = W->st_word();
-  if (use_pre) {  // only the bounds behind the slots (n_pj words of 8 bytes; ivf_bounds_off * 8 is a multiple of 16 here? made so below)
-    pa.ff_begin = reinterpret_cast<u32x4*>(W->partials.as<uint64_t>() + W->ivf_bounds_off); pa.ff_vec16 = ((size_t)n_pj * 8 + 15) / 16;
-  } else {        // ordered-chain scans: ivf_merge_kernel reads every slot -- a full-width fill ahead of the planning kernel
-    VERS_HIP_TRY(hipMemsetAsync(W->partials.p, 0xFF, part_bytes, st));
-    pa.ff_begin = nullptr; pa.ff_vec16 = 0;
+  // (also a single query with P > 64)
+  if (!planned) {
+    hipLaunchKernelGGL(plan_queries_kernel, dim3((b + 3) / 4), dim3(256), 0, st, pq, probe);
+    VERS_HIP_TRY(hipGetLastError());
   }
-  pa.stamps = nullptr;
+  GroupArgs ga;
+  ga.b = b; ga.P = P; ga.k_lists = k_l; ga.QG = (uint32_t)QG; ga.seg_rows = seg_rows; ga.seg_target = seg_target;
+  ga.slot_len = h->slot_len.as<uint32_t>(); ga.cnt = cnt; ga.hot = hot; ga.fill = fill; ga.pj_list = pj_list;
+  ga.pair_off = pair_off; ga.group_off = group_off; ga.item_off = item_off; ga.tot = tot;
+  ga.pairs = W->pairs.as<uint32_t>(); ga.items = W->items.as<ItemDesc>(); ga.groups = W->groups.as<GroupDesc>();
+  if (use_pre) {  // only the bounds behind the slots (n_pj words of 8 bytes, 16-byte aligned: ivf_bounds_off is even)
+    ga.ff_begin = reinterpret_cast<u32x4*>(W->partials.as<uint64_t>() + W->ivf_bounds_off); ga.ff_vec16 = ((size_t)n_pj * 8 + 15) / 16;
+  } else {        // ordered-chain scans: ivf_merge_kernel reads every slot -- a full-width fill
+    VERS_HIP_TRY(hipMemsetAsync(W->partials.p, 0xFF, part_bytes, st));
+    ga.ff_begin = nullptr; ga.ff_vec16 = 0;
+  }
+  ga.stamps = nullptr;
   if (scan_debug_flags() & 16u) {
     if (int32_t rc = W->stamps.reserve(256)) return rc;
-    pa.stamps = W->stamps.as<unsigned long long>();
+    ga.stamps = W->stamps.as<unsigned long long>();
   }
-  pa.grid_ctr = W->grid_ctr.as<uint32_t>(); pa.ctr_base = W->plan_launches * 3u * kPlanBlocks;
-  W->plan_launches += 1;
-  hipLaunchKernelGGL(plan_fused_kernel, dim3(kPlanBlocks), dim3(kPlanThreads), 0, st, pa);
+  // blocks: enough that a block's share of the pairs and lists is small next to the (redundant) prefix sums
+  const uint32_t g_blocks = (uint32_t)std::min<uint64_t>(kGroupMaxBlocks, std::max<uint64_t>(1, (n_pj + 2047) / 2048 + k_l / 256));
+  hipLaunchKernelGGL(group_scatter_kernel, dim3(g_blocks), dim3(kGroupThreads), 0, st, ga);
   VERS_HIP_TRY(hipGetLastError());
   if (QG != 1 && !use_pre) {  // (the matrix-core scan gathers its query block from qp while staging it)
     hipLaunchKernelGGL(gather_qblocks_kernel, dim3((unsigned)groups_bound), dim3(256), 0, st, W->groups.as<GroupDesc>(), tot,
