@@ -89,3 +89,44 @@ def test_cli_prints_the_reference_lines(expected, tmp_path):
     want = [f"{i}. Word: {i2w[int(v)]}. Distance: {fmt_f32(np.sqrt(np.float32(dd), dtype=np.float32))}" for i, (v, dd) in enumerate(zip(ri, rd))]
     assert lines[3:3 + len(want)] == want
     assert lines[3 + len(want)].startswith("Time taken to test: ")
+    assert sorted(os.listdir(tmp_path)) == ["ivfflat.index", "w.vec"]   # the gzipped input is read in place: no stray unpacked copy
+
+
+def test_parse_f32_is_correctly_rounded():
+    """utils.rs:31-36 `parse::<f32>()` rounds the DECIMAL once; going through an f64 rounds twice.  Witnesses: decimals a
+    hair off the midpoint of two f32 whose f64 is exactly that midpoint (the cast then ties to even, the wrong way)."""
+    from decimal import Decimal, getcontext
+    from fractions import Fraction
+    from vers_amd.harness import parse_f32
+    w = "1.00000017881393432617187499"                     # just below the midpoint of 1+2^-23 and 1+2^-22
+    assert parse_f32(w).view(np.uint32) == 0x3F800001 and np.float32(float(w)).view(np.uint32) == 0x3F800002
+    assert parse_f32("1.000000178813934326171875").view(np.uint32) == 0x3F800002      # the exact tie: to even
+    assert parse_f32("1.00000017881393432617187501").view(np.uint32) == 0x3F800002
+    assert parse_f32("-1.00000017881393432617187499").view(np.uint32) == 0xBF800001
+    getcontext().prec = 400
+    rng = np.random.default_rng(5)
+    for bits in rng.integers(1, 0x7F000000, size=300):     # subnormal and normal f32, midpoint to the next one up
+        f = np.uint32(bits).view(np.float32)
+        nb = np.nextafter(f, np.float32(np.inf))
+        mid = (Fraction(float(f)) + Fraction(float(nb))) / 2
+        md = Decimal(mid.numerator) / Decimal(mid.denominator)
+        eps = Decimal(10) ** (md.adjusted() - 60)
+        even, odd = (f, nb) if (int(bits) & 1) == 0 else (nb, f)
+        assert parse_f32(str(md)).view(np.uint32) == even.view(np.uint32)
+        assert parse_f32(str(md + eps)).view(np.uint32) == nb.view(np.uint32)
+        assert parse_f32(str(md - eps)).view(np.uint32) == f.view(np.uint32)
+    # the overflow boundary (f32::MAX + half an ulp) and plain values
+    assert parse_f32("3.40282356779733661637539395458142568447e38") == np.finfo(np.float32).max
+    assert np.isinf(parse_f32("3.40282356779733661637539395458142568448e38")) and np.isinf(parse_f32("1e39"))
+    assert parse_f32("0.1").view(np.uint32) == np.float32(0.1).view(np.uint32) and parse_f32("-0.0").view(np.uint32) == 0x80000000
+    assert np.isnan(parse_f32("NaN")) and np.isinf(parse_f32("-inf"))
+    with pytest.raises(ValueError):
+        parse_f32("1_0.5")                                  # Python's float() takes it, Rust's parse does not
+
+
+def test_loader_reads_the_gzipped_fixture_in_place(expected, tmp_path):
+    """no unpacked copy is written anywhere (the CLI used to leave `<index stem>.vec` next to the index file)"""
+    from vers_amd.harness import load_wiki_vector
+    before = set(os.listdir(tmp_path))
+    vecs, w2i, i2w, test_embs = load_wiki_vector(VEC_GZ, 300)
+    assert np.uint32(zlib.crc32(vecs.tobytes())) == expected["normalized_crc"][0] and set(os.listdir(tmp_path)) == before

@@ -28,15 +28,65 @@ def _normalize_rows(a: np.ndarray) -> np.ndarray:
     return out
 
 
+_F32_MAX = float(np.finfo(np.float32).max)
+_F32_OVERFLOW_TIE = _F32_MAX + 2.0 ** 103  # the midpoint between f32::MAX and 2^128: decimals at or above it parse to inf
+
+
+def parse_f32(text: str) -> np.float32:
+    """`str::parse::<f32>()` (utils.rs:31-36): the decimal CORRECTLY rounded to f32 (nearest, ties to even).
+    float() is correctly rounded to f64; rounding that once more is off by one ulp exactly when the f64 lands on the
+    midpoint of two neighbouring f32 while the decimal itself does not (double rounding: "1.00000017881393432617187499"
+    is below the midpoint of 1+2^-23 and 1+2^-22, its f64 IS that midpoint and ties-to-even then picks the wrong side).
+    Only those inputs take the exact path (a rational comparison); everything else is one float() and one cast."""
+    if "_" in text:
+        raise ValueError(f"invalid float literal {text!r}")  # Python accepts 1_000, Rust does not (the reference panics on unwrap)
+    d = float(text)
+    if d != d or d in (float("inf"), float("-inf")):
+        return np.float32(d)
+    with np.errstate(over="ignore"):
+        f = np.float32(d)
+    fd = float(f)
+    if fd == d:
+        return f  # the f64 is an f32: nothing was rounded the second time
+    if np.isinf(f):  # |d| beyond f32::MAX's rounding boundary -- or exactly ON it with the decimal a hair below
+        if abs(d) != _F32_OVERFLOW_TIE:
+            return f
+        from decimal import Decimal
+        from fractions import Fraction
+        exact = abs(Fraction(Decimal(text)))
+        return f if exact >= Fraction(_F32_OVERFLOW_TIE) else np.float32(np.copysign(_F32_MAX, d))
+    nb = float(np.nextafter(f, np.float32(np.inf if d > fd else -np.inf)))
+    if np.isinf(nb):
+        nb = float(np.copysign(2.0 ** 128, d))
+    if (fd + nb) / 2.0 != d:
+        return f  # not a tie in f64: the cast rounded the right way
+    from decimal import Decimal
+    from fractions import Fraction
+    exact, mid = Fraction(Decimal(text)), Fraction(d)
+    if exact == mid:
+        return f  # a true tie: to even, which is what the cast did
+    other = np.float32(nb) if abs(nb) <= _F32_MAX else np.float32(np.copysign(np.inf, d))
+    lo, hi = (f, other) if fd < nb else (other, f)
+    return hi if exact > mid else lo
+
+
+def _open_text(file_path: str):
+    """plain text like the reference's file, or the same gzipped (the committed fixture): no unpacked copy is left behind"""
+    if str(file_path).endswith(".gz"):
+        import gzip
+        return gzip.open(file_path, "rt", encoding="utf-8")
+    return open(file_path, "r", encoding="utf-8")
+
+
 def load_wiki_vector(file_path: str, d: int):
     """utils.rs:7-66.  Returns (all_vecs [n, d] f32, word_to_idx, idx_to_word, test_embs [(word, raw emb)])."""
     words, rows, test_embs = [], [], []
-    with open(file_path, "r", encoding="utf-8") as f:
+    with _open_text(file_path) as f:
         next(f)  # header line (utils.rs:26 skip(1))
         for line in f:
             parts = line.split()
             word = parts[0]
-            emb = np.array([np.float32(x) for x in parts[1:]], dtype=np.float32)
+            emb = np.array([parse_f32(x) for x in parts[1:]], dtype=np.float32)
             if emb.size != d:
                 raise ValueError(f"expected {d} values for {word!r}")  # try_into().unwrap() panics in the reference
             if word == "queen":
@@ -110,7 +160,6 @@ def main(argv=None) -> int:
     file's first data line (the reference fixes it at compile time: const DIM = 300).  --seed makes the centroid draws
     of initialize_centroids reproducible (numpy default_rng; the reference draws from an unseeded thread_rng)."""
     import argparse
-    import gzip
     import time
     ap = argparse.ArgumentParser(prog="python -m vers_amd.harness", description=main.__doc__)
     ap.add_argument("vec_file")
@@ -122,15 +171,9 @@ def main(argv=None) -> int:
     ap.add_argument("--device", type=int, default=0)
     a = ap.parse_args(argv)
     path = a.vec_file
-    opener = gzip.open if path.endswith(".gz") else open
-    with opener(path, "rt", encoding="utf-8") as f:
+    with _open_text(path) as f:
         next(f)
         d = len(f.readline().split()) - 1
-    if path.endswith(".gz"):  # the loader reads plain text like the reference's: unpack next to the index file
-        plain = os.path.splitext(a.index_file)[0] + ".vec"
-        with gzip.open(path, "rb") as src, open(plain, "wb") as dst:
-            dst.write(src.read())
-        path = plain
     vecs, w2i, i2w, test_embs = load_wiki_vector(path, d)
     rng = np.random.default_rng(a.seed)
     init = rng.integers(0, max(len(vecs), 1), size=a.num_attempts * a.num_clusters)
