@@ -544,16 +544,37 @@ static __global__ __launch_bounds__(kWave) void coarse_select_rescore_kernel(
   const uint32_t n_sel = PS < k ? PS : k;
   const float tau = __uint_as_float(order_bits_to_f32_bits((uint32_t)(readlane64(sel, (int)n_sel - 1) >> 32)));
   const unsigned long long t1 = stamps ? __builtin_amdgcn_s_memtime() : 0ull;
-  // (2) exact re-score: lane l < n_sel owns candidate centroid l; the query element is wave-uniform
+  // (2) exact re-score: lane l owns candidate centroid l; the query element is wave-uniform.
+  // |q|^2 first (any summation order: E covers d u |q|^2, a tree of partial sums errs less), because E decides WHICH
+  // candidates are worth their 3 KB row: with g_P the P-th smallest G, the P nearest-by-G candidates all have
+  // D_ref <= g_P + |q|^2 + E, so the P-th exact distance is at most that, while a candidate with G > g_P + 2E has
+  // D_ref >= G + |q|^2 - E > g_P + |q|^2 + E: strictly behind P others -- it cannot be among the top P and is not read.
+  // (Round 2 re-scored all P + 16: 151 MB of centroid rows per batch from the Infinity Cache at cfg3; ~P + 3 are needed.)
   const float* qv = qp + (uint64_t)q * ldq;
-  const bool have = lane < (int)n_sel;
-  const uint32_t ci = have ? (uint32_t)sel : 0u;
+  float qn = 0.0f;
+  for (uint32_t j = 4u * (uint32_t)lane; j < ldc; j += 4u * kWave) {
+    const f32x4 q4 = *reinterpret_cast<const f32x4*>(qv + j);
+    qn += q4[0] * q4[0] + q4[1] * q4[1] + q4[2] * q4[2] + q4[3] * q4[3];
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) qn += __shfl_xor(qn, off, kWave);
+  const float E = ((5.0f * (float)d_pad + 16.0f) * 5.9604645e-08f + kX3Slack) * (qn + cmax2 + (metric ? 1.0f : 0.0f));  // (+ the bf16x3 product's share)
+  const uint32_t Pq = P < k ? P : k;
+  const float gP = __uint_as_float(order_bits_to_f32_bits((uint32_t)(readlane64(sel, (int)Pq - 1) >> 32)));
+  const float gl = __uint_as_float(order_bits_to_f32_bits((uint32_t)(sel >> 32)));
+  const bool have = lane < (int)n_sel && !(gl > gP + 2.0f * E);  // (negated: NaN / inf anywhere keeps the candidate)
+  const uint32_t ci = have ? (uint32_t)sel : (uint32_t)readlane64(sel, 0);  // idle lanes re-read lane 0's row (one broadcast line)
   const float* cv = C_rm + (uint64_t)ci * ldc;
-  float acc = 0.0f, qn = 0.0f;
-  for (uint32_t j = 0; j < ldc; j += 64) {  // ldc is a multiple of 64; 16 row loads in flight (each lane walks its own row)
-    f32x4 c4[16];
+  float acc = 0.0f;
+  // 64 columns per step, 16 independent 16-byte loads per lane (each lane walks its own row), the NEXT step's loads in
+  // flight under this step's chain (a wave per query and SIMD: nothing else hides the Infinity Cache's latency; the
+  // unpipelined loop spent 82 k of the kernel's 120 k cycles per query here).  Loads are unconditional (clamped to the
+  // last step: a branch around a load costs a vmcnt(0)).
+  auto load16 = [&](f32x4 (&c4)[16], uint32_t j) {
 #pragma unroll
     for (int w = 0; w < 16; ++w) c4[w] = *reinterpret_cast<const f32x4*>(cv + j + 4 * w);
+  };
+  auto chain16 = [&](const f32x4 (&c4)[16], uint32_t j) {
 #pragma unroll
     for (int w = 0; w < 16; ++w) {
       const f32x4 q4 = *reinterpret_cast<const f32x4*>(qv + j + 4 * w);  // wave-uniform
@@ -565,8 +586,18 @@ static __global__ __launch_bounds__(kWave) void coarse_select_rescore_kernel(
         } else {
           acc = __fadd_rn(acc, __fmul_rn(c4[w][u], q4[u]));
         }
-        qn = __fadd_rn(qn, __fmul_rn(q4[u], q4[u]));
       }
+    }
+  };
+  {
+    f32x4 ca[16], cb[16];
+    const uint32_t last = ldc - 64;  // ldc is a multiple of 64
+    load16(ca, 0);
+    for (uint32_t j = 0; j < ldc; j += 128) {
+      load16(cb, j + 64 <= last ? j + 64 : last);
+      chain16(ca, j);
+      load16(ca, j + 128 <= last ? j + 128 : last);
+      if (j + 64 < ldc) chain16(cb, j + 64);
     }
   }
   if (metric) acc = __fsub_rn(1.0f, acc);  // cosine distance: 1 - dot (base.rs:153-155)
@@ -575,10 +606,8 @@ static __global__ __launch_bounds__(kWave) void coarse_select_rescore_kernel(
   uint64_t exact = kKeyMax;
   wave_topk_update(exact, n_sel, have ? make_key(acc, ci) : kKeyMax, kKeyMax);  // sorted by (exact distance, index)
   // (3) certificate
-  const uint32_t Pq = P < k ? P : k;
   const float dP = __uint_as_float(order_bits_to_f32_bits((uint32_t)(readlane64(exact, (int)Pq - 1) >> 32)));
   // metric 1: G ~ D_ref - 1 with |D_ref - (1 + G)| <= u (1 + 2 |q||c|) + 3.03 d u |q||c| < (5d + 16) u (|q|^2 + max|c|^2 + 1)
-  const float E = ((5.0f * (float)d_pad + 16.0f) * 5.9604645e-08f + kX3Slack) * (qn + cmax2 + (metric ? 1.0f : 0.0f));  // (+ the bf16x3 product's share)
   const bool certified = (n_sel >= k) || (dP < tau + (metric ? 1.0f : qn) - E);  // NaN anywhere -> false -> exact path decides
   if (!certified) {
     // exact fallback for this query: every centroid, ordered chain per lane

@@ -214,7 +214,7 @@ __device__ __forceinline__ bool owns_list(uint32_t L) { return ((L >> 2) % gridD
 // lists: a thread owns FOUR consecutive lists (three 16-byte loads, a serial scan in registers), the waves scan the
 // thread totals by shuffles, 16 wave totals go through LDS, a running carry links the rounds.  One round and two block
 // barriers at 4096 lists.
-__device__ __forceinline__ void group_lists(const GroupArgs& a) {
+__device__ __forceinline__ void group_lists(const GroupArgs& a, uint32_t* tab) {
   __shared__ uint32_t wp[16], wg[16], wi[16], wh[16];
   __shared__ unsigned long long ur, sr;
   const uint32_t* cnt = a.cnt; const uint32_t* list_len = a.slot_len; const uint32_t* hot = a.hot;
@@ -281,6 +281,11 @@ __device__ __forceinline__ void group_lists(const GroupArgs& a) {
       po[e] = op; go[e] = og; io[e] = h4[e] ? oh : oc;  // (the others' item offsets are shifted behind the hot lists' below)
       op += c4[e]; og += g4[e]; oc += ic4[e]; oh += ih4[e];
     }
+    if (tab != nullptr) {  // first pair of EVERY list, block-local: the scatter below is then dealt by pair, not by list
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (i0 + e < k_lists) tab[i0 + e] = po[e];
+    }
     if (i0 < k_lists && owns_list(i0)) {  // the granule's owner stores its entries
       if (vec_ok) {
         *reinterpret_cast<u32x4*>(a.pair_off + i0) = u32x4{po[0], po[1], po[2], po[3]};
@@ -343,22 +348,36 @@ __device__ __forceinline__ void list_items(uint32_t L, const GroupArgs& a) {
   }
 }
 
+constexpr uint32_t kGroupTabMax = 8192;  // lists whose first-pair table a block keeps in LDS (32 KB)
 __global__ __launch_bounds__(kGroupThreads) void group_scatter_kernel(GroupArgs a) {
+  extern __shared__ uint32_t pair_tab[];  // [k_lists] when k_lists <= kGroupTabMax
   const uint32_t tid = blockIdx.x * kGroupThreads + threadIdx.x, nthreads = gridDim.x * kGroupThreads;
   auto stamp = [&](int i) { if (a.stamps && tid == 0) a.stamps[16 + i] = __builtin_amdgcn_s_memrealtime(); };
   stamp(0);
+  const bool use_tab = a.k_lists <= kGroupTabMax;
   const u32x4 ff = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
   for (uint64_t i = tid; i < a.ff_vec16; i += nthreads) a.ff_begin[i] = ff;
-  group_lists(a);
+  group_lists(a, use_tab ? pair_tab : nullptr);
   __threadfence();  // this block's table entries are in L2 before it reads them back
   __syncthreads();
   stamp(1);
   // pairs of a list become contiguous (order inside a list is arbitrary and irrelevant: every (query, list) result goes
-  // to its own slot): each block picks the pairs of ITS lists out of the whole table
+  // to its own slot)
   const uint32_t n_pj = a.b * a.P;
-  for (uint32_t i = threadIdx.x; i < n_pj; i += kGroupThreads) {
-    const uint32_t L = a.pj_list[i];
-    if (L != kNoList && owns_list(L)) a.pairs[ld_l2(a.pair_off + L) + atomicAdd(&a.fill[L], 1u)] = i;
+  if (use_tab) {  // every block knows every list's first pair: the pairs are dealt over ALL threads of the grid
+    for (uint32_t i = tid; i < n_pj; i += nthreads) {
+      const uint32_t L = a.pj_list[i];
+      if (L != kNoList) a.pairs[pair_tab[L] + atomicAdd(&a.fill[L], 1u)] = i;
+    }
+  } else {  // more lists than the table holds: each block picks the pairs of ITS lists out of the whole table (8 independent loads a time)
+    for (uint32_t i0 = threadIdx.x; i0 < n_pj; i0 += 8 * kGroupThreads) {
+      uint32_t Ls[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) Ls[u] = i0 + u * kGroupThreads < n_pj ? a.pj_list[i0 + u * kGroupThreads] : kNoList;
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (Ls[u] != kNoList && owns_list(Ls[u])) a.pairs[ld_l2(a.pair_off + Ls[u]) + atomicAdd(&a.fill[Ls[u]], 1u)] = i0 + u * kGroupThreads;
+    }
   }
   stamp(2);
   // item and group descriptors of its lists: granule g = blockIdx.x + n * gridDim.x, four lists each
@@ -1948,7 +1967,7 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
   }
   // blocks: enough that a block's share of the pairs and lists is small next to the (redundant) prefix sums
   const uint32_t g_blocks = (uint32_t)std::min<uint64_t>(kGroupMaxBlocks, std::max<uint64_t>(1, (n_pj + 2047) / 2048 + k_l / 256));
-  hipLaunchKernelGGL(group_scatter_kernel, dim3(g_blocks), dim3(kGroupThreads), 0, st, ga);
+  hipLaunchKernelGGL(group_scatter_kernel, dim3(g_blocks), dim3(kGroupThreads), k_l <= kGroupTabMax ? (size_t)k_l * sizeof(uint32_t) : 0, st, ga);
   VERS_HIP_TRY(hipGetLastError());
   if (QG != 1 && !use_pre) {  // (the matrix-core scan gathers its query block from qp while staging it)
     hipLaunchKernelGGL(gather_qblocks_kernel, dim3((unsigned)groups_bound), dim3(256), 0, st, W->groups.as<GroupDesc>(), tot,
@@ -2638,10 +2657,9 @@ int32_t vers_ivf_last_scan(vers_ivf_t* h, float* out_ms, uint64_t* out_union_row
     if (sv[27])
       fprintf(stderr, "[vers stamps] coarse select, per query avg cycles: select %.0f  exact re-score %.0f  sort+certify+emit %.0f\n",
               (double)sv[24] / sv[27], (double)sv[25] / sv[27], (double)sv[26] / sv[27]);
-    if (sv[22])
-      fprintf(stderr, "[vers stamps] planning kernel, block 0 (us): fills %.1f  barrier %.1f  plan %.1f+barrier  group %.1f  barrier %.1f  scatter+items %.1f\n",
-              (sv[17] - sv[16]) / 100.0, (sv[18] - sv[17]) / 100.0, (sv[19] - sv[18]) / 100.0, (sv[20] - sv[19]) / 100.0, (sv[21] - sv[20]) / 100.0,
-              (sv[22] - sv[21]) / 100.0);
+    if (sv[19])
+      fprintf(stderr, "[vers stamps] group / scatter kernel, block 0 (us): fill + prefix sums %.1f  scatter %.1f  items %.1f\n",
+              (sv[17] - sv[16]) / 100.0, (sv[18] - sv[17]) / 100.0, (sv[19] - sv[18]) / 100.0);
     if (sv[10])
       fprintf(stderr, "[vers stamps] matrix-core scan, per item avg cycles: prologue %.0f  step loop %.0f (of which issuing loads %.0f)  epilogue %.0f\n",
               (double)sv[9] / sv[4], (double)sv[10] / sv[4], (double)sv[8] / sv[4], (double)sv[11] / sv[4]);

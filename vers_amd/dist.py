@@ -157,29 +157,38 @@ class TorchComm:
 
         def run():
             s_tot = max((so[i] + sb[i] for i in range(W)), default=0); r_tot = max((ro[i] + rb[i] for i in range(W)), default=0)
-            s = self._wrap(send_ptr, s_tot) if s_tot else torch.empty(0, dtype=torch.uint8)
-            r = self._wrap(recv_ptr, r_tot) if r_tot else torch.empty(0, dtype=torch.uint8)
+            on_gpu = self.device is not None
+            rccl = self.backend == "nccl" and on_gpu
+            # a rank with nothing to send (or receive) still takes part in the collective: on RCCL its empty operand must be a
+            # DEVICE tensor of the collective's dtype like everybody else's (a CPU u8 placeholder is rejected on that rank
+            # only, and its peers then hang inside the collective)
+            dev = torch.device("cuda", self.device) if on_gpu else torch.device("cpu")
+            empty = torch.empty(0, dtype=torch.uint8, device=dev if rccl else torch.device("cpu"))
+            s = self._wrap(send_ptr, s_tot) if s_tot else empty
+            r = self._wrap(recv_ptr, r_tot) if r_tot else empty
             contiguous = all(so[i] == sum(sb[:i]) for i in range(W)) and all(ro[i] == sum(rb[:i]) for i in range(W))
-            if self.backend == "nccl" and self.device is not None and contiguous and all(x % 4 == 0 for x in sb + rb):
+            if rccl and contiguous and all(x % 4 == 0 for x in sb + rb):
                 # RCCL all-to-all in 4-byte words (rows are f32, ids u32): one collective over xGMI
-                dist.all_to_all_single(r.view(torch.float32) if r_tot else r, s.view(torch.float32) if s_tot else s,
-                                       [x // 4 for x in rb], [x // 4 for x in sb], group=self.group)
+                dist.all_to_all_single(r.view(torch.float32), s.view(torch.float32), [x // 4 for x in rb], [x // 4 for x in sb],
+                                       group=self.group)
                 return
-            # gloo has no all-to-all: pairwise non-blocking send / recv (tests only)
             hs = s.cpu() if self._staged() else s
             hr = torch.empty(r_tot, dtype=torch.uint8) if self._staged() else r
-            reqs = []
+            ops = []
             for p in range(W):
                 if p == self.rank:
                     if sb[p]:
                         hr[ro[p]:ro[p] + rb[p]].copy_(hs[so[p]:so[p] + sb[p]])
                     continue
                 if rb[p]:
-                    reqs.append(dist.irecv(hr[ro[p]:ro[p] + rb[p]], self._global_rank(p), group=self.group))
+                    ops.append(dist.P2POp(dist.irecv, hr[ro[p]:ro[p] + rb[p]], self._global_rank(p), group=self.group))
                 if sb[p]:
-                    reqs.append(dist.isend(hs[so[p]:so[p] + sb[p]].contiguous(), self._global_rank(p), group=self.group))
-            for q in reqs:
-                q.wait()
+                    ops.append(dist.P2POp(dist.isend, hs[so[p]:so[p] + sb[p]].contiguous(), self._global_rank(p), group=self.group))
+            # ONE batch: RCCL fuses the sends and receives of a batch into a single grouped launch; issued one by one, both
+            # sides' receive kernels can queue ahead of their sends and wait for each other.  (gloo: plain non-blocking pairs.)
+            if ops:
+                for q in dist.batch_isend_irecv(ops):
+                    q.wait()
             if self._staged() and r_tot:
                 r.copy_(hr)
         return self._guard("all_to_all_v", sum(sb), run)
