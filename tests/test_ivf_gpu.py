@@ -260,3 +260,49 @@ def test_batches_in_flight_on_rotating_streams():
     for r in range(reps):
         w = want[r % 4]
         assert np.array_equal(gc[r], w[2]) and np.array_equal(gi[r], w[0]) and np.array_equal(gd[r].view(np.uint32), w[1].view(np.uint32)), r
+
+
+def test_poll_reports_only_the_polled_streams_calls():
+    """The status a device-pointer call latches belongs to ITS stream: thread B's poll must not consume (or be handed)
+    thread A's INSUFFICIENT.  A: reference mode with top_k beyond the whole index (the reference panics, ivfflat.rs:169);
+    B: clean nprobe batches, in flight at the same time on another stream.  Round 2 read and cleared word 0 of EVERY
+    workspace in whichever poll came first."""
+    import threading
+    import torch
+    n, d, k = 600, 32, 8
+    X = dg.dist_c(0x81, n, d, 4 * k, dg.default_sigma(d))
+    ix = IVFFlatIndex.build_index(k, 1, 2, X, init_indices=mg.init_draws(0x81, 1, k, n))
+    Q = torch.from_numpy(dg.dist_c(0x82, 64, d, 4 * k, dg.default_sigma(d))).cuda()
+    want = ix.search_batch(Q.cpu().numpy(), 10, 4)
+    torch.cuda.synchronize()
+    res, errors = {}, []
+    gate = threading.Barrier(2)
+
+    def worker(name, top_k, nprobe):
+        try:
+            st = torch.cuda.Stream()
+            ids = torch.zeros(64, top_k, dtype=torch.int64, device="cuda"); dist = torch.zeros(64, top_k, device="cuda")
+            cnt = torch.zeros(64, dtype=torch.int32, device="cuda")
+            polls = []
+            for rep in range(8):
+                gate.wait()
+                for _ in range(3):
+                    ix.search_dev(Q.data_ptr(), d, 64, top_k, nprobe, ids.data_ptr(), dist.data_ptr(), cnt.data_ptr(), st.cuda_stream)
+                gate.wait()                                  # both threads have queued their calls before either polls
+                try:
+                    ix.poll(st.cuda_stream)
+                    polls.append(0)
+                except capi.VersError as e:                  # the binding raises on a non-zero status
+                    polls.append(e.status)
+            res[name] = (polls, ids.cpu().numpy().astype(np.uint64), dist.cpu().numpy(), cnt.cpu().numpy())
+        except Exception as e:  # noqa: BLE001
+            errors.append((name, repr(e)))
+            gate.abort()
+
+    ta = threading.Thread(target=worker, args=("A", 700, 0)); tb = threading.Thread(target=worker, args=("B", 10, 4))
+    ta.start(); tb.start(); ta.join(); tb.join()
+    assert not errors, errors
+    assert res["A"][0] == [capi.ERR_INSUFFICIENT] * 8, res["A"][0]
+    assert res["B"][0] == [0] * 8, res["B"][0]
+    assert np.array_equal(res["B"][1], want[0]) and np.array_equal(res["B"][3], want[2])
+    assert np.array_equal(res["B"][2].view(np.uint32), want[1].view(np.uint32))

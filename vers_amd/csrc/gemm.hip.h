@@ -603,8 +603,8 @@ static __global__ __launch_bounds__(kWave) void coarse_select_rescore_kernel(
   if (metric) acc = __fsub_rn(1.0f, acc);  // cosine distance: 1 - dot (base.rs:153-155)
   bool nan_seen = have && (acc != acc);
   const unsigned long long t2 = stamps ? __builtin_amdgcn_s_memtime() : 0ull;
-  uint64_t exact = kKeyMax;
-  wave_topk_update(exact, n_sel, have ? make_key(acc, ci) : kKeyMax, kKeyMax);  // sorted by (exact distance, index)
+  uint64_t exact = have ? make_key(acc, ci) : kKeyMax;  // sorted by (exact distance, index): one bitonic network
+  wave_bitonic_sort64(exact, lane);                     // (~35 ordered inserts of ~150 cycles each before)
   // (3) certificate
   const float dP = __uint_as_float(order_bits_to_f32_bits((uint32_t)(readlane64(exact, (int)Pq - 1) >> 32)));
   // metric 1: G ~ D_ref - 1 with |D_ref - (1 + G)| <= u (1 + 2 |q||c|) + 3.03 d u |q||c| < (5d + 16) u (|q|^2 + max|c|^2 + 1)

@@ -281,10 +281,10 @@ __device__ __forceinline__ void group_lists(const GroupArgs& a, uint32_t* tab) {
       po[e] = op; go[e] = og; io[e] = h4[e] ? oh : oc;  // (the others' item offsets are shifted behind the hot lists' below)
       op += c4[e]; og += g4[e]; oc += ic4[e]; oh += ih4[e];
     }
-    if (tab != nullptr) {  // first pair of EVERY list, block-local: the scatter below is then dealt by pair, not by list
-#pragma unroll
+    if (tab != nullptr) {  // first pair of EVERY list, block-local: the scatter below is then dealt by pair, not by list;
+#pragma unroll         // first group / item of the lists this block describes
       for (int e = 0; e < 4; ++e)
-        if (i0 + e < k_lists) tab[i0 + e] = po[e];
+        if (i0 + e < k_lists) { tab[i0 + e] = po[e]; tab[k_lists + i0 + e] = go[e]; tab[2 * k_lists + i0 + e] = io[e]; }
     }
     if (i0 < k_lists && owns_list(i0)) {  // the granule's owner stores its entries
       if (vec_ok) {
@@ -312,11 +312,16 @@ __device__ __forceinline__ void group_lists(const GroupArgs& a, uint32_t* tab) {
   __syncthreads();
   for (uint32_t base0 = 0; base0 < k_lists; base0 += 4 * kGroupThreads) {  // (each thread shifts the entries it wrote itself)
     const uint32_t i0 = base0 + 4u * threadIdx.x;
-    if (i0 >= k_lists || !owns_list(i0)) continue;
+    if (i0 >= k_lists) continue;
+    const bool mine = owns_list(i0);
+    if (!mine && tab == nullptr) continue;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
       const uint32_t L = i0 + e;
-      if (L < k_lists && cnt[L] != 0 && hot[L] == 0) a.item_off[L] += ch;
+      if (L < k_lists && cnt[L] != 0 && hot[L] == 0) {
+        if (mine) a.item_off[L] += ch;
+        if (tab != nullptr) tab[2 * k_lists + L] += ch;
+      }
     }
   }
   if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -326,15 +331,15 @@ __device__ __forceinline__ void group_lists(const GroupArgs& a, uint32_t* tab) {
 }
 
 // items + group descriptors of one list (of this block: the offsets are its own stores of the phase before)
-__device__ __forceinline__ void list_items(uint32_t L, const GroupArgs& a) {
+__device__ __forceinline__ void list_items(uint32_t L, const GroupArgs& a, const uint32_t* tab) {
   const uint32_t c = a.cnt[L];
   if (!c) return;
   const uint32_t QG = a.QG, len = a.slot_len[L];
   const uint32_t sr = list_seg_rows(len, a.seg_rows, a.seg_target);
   const uint32_t n_g = (c + QG - 1) / QG, n_s = (len + sr - 1) / sr;
   const uint32_t n_s_pad = QG == 1 ? n_s : (n_s + 3) / 4 * 4;
-  uint32_t o = ld_l2(a.item_off + L);
-  const uint32_t g0 = ld_l2(a.group_off + L), p0 = ld_l2(a.pair_off + L);
+  uint32_t o = tab ? tab[2 * a.k_lists + L] : ld_l2(a.item_off + L);
+  const uint32_t g0 = tab ? tab[a.k_lists + L] : ld_l2(a.group_off + L), p0 = tab ? tab[L] : ld_l2(a.pair_off + L);
   for (uint32_t g = 0; g < n_g; ++g) a.groups[g0 + g] = GroupDesc{p0 + g * QG, (c - g * QG < QG) ? c - g * QG : QG};
   if (QG == 1) {
     for (uint32_t g = 0; g < n_g; ++g)
@@ -348,9 +353,9 @@ __device__ __forceinline__ void list_items(uint32_t L, const GroupArgs& a) {
   }
 }
 
-constexpr uint32_t kGroupTabMax = 8192;  // lists whose first-pair table a block keeps in LDS (32 KB)
+constexpr uint32_t kGroupTabMax = 8192;  // lists whose three offset tables a block keeps in LDS (96 KB)
 __global__ __launch_bounds__(kGroupThreads) void group_scatter_kernel(GroupArgs a) {
-  extern __shared__ uint32_t pair_tab[];  // [k_lists] when k_lists <= kGroupTabMax
+  extern __shared__ uint32_t pair_tab[];  // first pair | group | item of every list: [3][k_lists] when k_lists <= kGroupTabMax
   const uint32_t tid = blockIdx.x * kGroupThreads + threadIdx.x, nthreads = gridDim.x * kGroupThreads;
   auto stamp = [&](int i) { if (a.stamps && tid == 0) a.stamps[16 + i] = __builtin_amdgcn_s_memrealtime(); };
   stamp(0);
@@ -358,7 +363,10 @@ __global__ __launch_bounds__(kGroupThreads) void group_scatter_kernel(GroupArgs 
   const u32x4 ff = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
   for (uint64_t i = tid; i < a.ff_vec16; i += nthreads) a.ff_begin[i] = ff;
   group_lists(a, use_tab ? pair_tab : nullptr);
-  __threadfence();  // this block's table entries are in L2 before it reads them back
+  // what a block reads back below it stored ITSELF: its stores only have to have reached ITS L2 (release at workgroup
+  // scope = wait for them; an agent-scope fence writes the whole L2 back -- that alone was 8 us here) and the read-backs
+  // go past the vector L1 (ld_l2).  With the LDS tables nothing is read back at all.
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
   __syncthreads();
   stamp(1);
   // pairs of a list become contiguous (order inside a list is arbitrary and irrelevant: every (query, list) result goes
@@ -386,7 +394,7 @@ __global__ __launch_bounds__(kGroupThreads) void group_scatter_kernel(GroupArgs 
     const uint32_t gran = blockIdx.x + (w >> 2) * gridDim.x;
     if (gran >= n_gran) break;
     const uint32_t L = 4 * gran + (w & 3u);
-    if (L < a.k_lists) list_items(L, a);
+    if (L < a.k_lists) list_items(L, a, use_tab ? pair_tab : nullptr);
   }
   stamp(3);
 }
@@ -702,8 +710,11 @@ struct SearchWs {
   hipEvent_t ahead_in = nullptr;
   // status words: [0] latched by _dev calls and reported by vers_ivf_poll; [1] used by host-pointer calls and add, which
   // synchronise and consume it themselves -- so neither side eats the other's bits
+  // Word 0 of a DEVICE-pointer call is not the workspace's but its STREAM's (vers_ivf::stream_word): vers_ivf_poll(stream)
+  // then reports exactly the calls that ran on that stream -- whichever workspaces they leased, whatever other threads run.
   uint32_t st_slot = 0;
-  uint32_t* st_word() const { return status.as<uint32_t>() + st_slot; }
+  uint32_t* st_dev = nullptr;  // the leasing _dev call's stream word
+  uint32_t* st_word() const { return st_slot == 0 && st_dev ? st_dev : status.as<uint32_t>() + st_slot; }
   GroupTotals last_tot{};
   const GroupTotals* tot_dev = nullptr;  // device totals of the last planned search
   bool tot_valid = false;
@@ -781,6 +792,31 @@ struct vers_ivf {
     uint64_t ldq_in = 0;
     uint32_t b = 0, nprobe = 0;
   } pending;  // (guarded by pool_mu)
+  // Status words of the device-pointer calls, one per stream the handle has seen (first come, first served; streams beyond
+  // the table share its last word): latched by the kernels of the calls queued on that stream, read and cleared ON that
+  // stream by vers_ivf_poll -- so a poll never consumes another stream's panic, and never clears a word while a kernel of
+  // its own stream can still set it.
+  static constexpr uint32_t kStreamWords = 64;
+  DevBuf st_words;
+  std::mutex st_mu;
+  std::vector<hipStream_t> st_streams;
+  uint32_t* st_pin = nullptr;  // pinned landing word of the polls (guarded by st_mu)
+  int32_t stream_word(hipStream_t st, uint32_t** out) {
+    std::lock_guard<std::mutex> lk(st_mu);
+    if (!st_words.p) {
+      if (int32_t rc = st_words.reserve(kStreamWords * sizeof(uint32_t))) return rc;
+      VERS_HIP_TRY(hipMemset(st_words.p, 0, kStreamWords * sizeof(uint32_t)));
+      VERS_HIP_TRY(hipHostMalloc((void**)&st_pin, 64, hipHostMallocDefault));
+    }
+    uint32_t i = 0;
+    while (i < st_streams.size() && st_streams[i] != st) ++i;
+    if (i == st_streams.size()) {
+      if (i < kStreamWords - 1) st_streams.push_back(st);
+      else i = kStreamWords - 1;  // the overflow word, shared
+    }
+    *out = st_words.as<uint32_t>() + i;
+    return VERS_OK;
+  }
   // searches / reads hold `index` shared, build / upload / add / set_* exclusively
   std::shared_mutex index;
   std::mutex pool_mu;
@@ -855,9 +891,10 @@ struct WsLease {
   int32_t order_on(hipStream_t stream) {
     st = stream;
     if (ws->used && ws->last_stream != stream) VERS_HIP_TRY(hipStreamWaitEvent(stream, ws->done, 0));
-    return VERS_OK;
+    return h->stream_word(stream, &ws->st_dev);
   }
   ~WsLease() {
+    ws->st_dev = nullptr;
     if (ws->done) {
       (void)hipEventRecord(ws->done, st);
       ws->used = true;
@@ -895,20 +932,16 @@ inline int32_t start_pending_ahead(vers_ivf* h, hipStream_t st) {
   if (!p.set) return VERS_OK;
   return coarse_ahead_locked(h, p.q_dev, p.ldq_in, p.b, p.nprobe, st);
 }
-int32_t sync_status(vers_ivf* h, hipStream_t st) {  // word 0 (the _dev calls) of EVERY workspace: whichever calls ran on `st`
-  VERS_HIP_TRY(hipStreamSynchronize(st));
-  std::vector<SearchWs*> all;
-  {
-    std::lock_guard<std::mutex> lk(h->pool_mu);
-    for (auto& w : h->pool) all.push_back(w.get());
-  }
+int32_t sync_status(vers_ivf* h, hipStream_t st) {  // the word of the _dev calls queued on `st` (vers_ivf::stream_word), read and cleared on `st`
+  uint32_t* word = nullptr;
+  if (int32_t rc = h->stream_word(st, &word)) return rc;
   uint32_t s = 0;
-  for (SearchWs* w : all) {
-    if (!w->status.p) continue;
-    uint32_t sw = 0;
-    VERS_HIP_TRY(hipMemcpy(&sw, w->status.p, sizeof(sw), hipMemcpyDeviceToHost));
-    if (sw) VERS_HIP_TRY(hipMemset(w->status.p, 0, sizeof(sw)));
-    s |= sw;
+  {
+    std::lock_guard<std::mutex> lk(h->st_mu);  // (one landing word)
+    VERS_HIP_TRY(hipMemcpyAsync(h->st_pin, word, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    VERS_HIP_TRY(hipMemsetAsync(word, 0, sizeof(uint32_t), st));  // stream order: behind every kernel that could set it, ahead of the next call's
+    VERS_HIP_TRY(hipStreamSynchronize(st));
+    s = *reinterpret_cast<volatile uint32_t*>(h->st_pin);
   }
   if (!s) return VERS_OK;
   if (s & kStNaN) return fail(VERS_ERR_NAN, "NaN distance (the reference panics in partial_cmp().unwrap())");
@@ -1967,7 +2000,9 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
   }
   // blocks: enough that a block's share of the pairs and lists is small next to the (redundant) prefix sums
   const uint32_t g_blocks = (uint32_t)std::min<uint64_t>(kGroupMaxBlocks, std::max<uint64_t>(1, (n_pj + 2047) / 2048 + k_l / 256));
-  hipLaunchKernelGGL(group_scatter_kernel, dim3(g_blocks), dim3(kGroupThreads), k_l <= kGroupTabMax ? (size_t)k_l * sizeof(uint32_t) : 0, st, ga);
+  const size_t g_lds = k_l <= kGroupTabMax ? 3 * (size_t)k_l * sizeof(uint32_t) : 0;
+  if (int32_t rc = scan_prepare_launch(group_scatter_kernel, g_lds)) return rc;
+  hipLaunchKernelGGL(group_scatter_kernel, dim3(g_blocks), dim3(kGroupThreads), g_lds, st, ga);
   VERS_HIP_TRY(hipGetLastError());
   if (QG != 1 && !use_pre) {  // (the matrix-core scan gathers its query block from qp while staging it)
     hipLaunchKernelGGL(gather_qblocks_kernel, dim3((unsigned)groups_bound), dim3(256), 0, st, W->groups.as<GroupDesc>(), tot,
@@ -2288,6 +2323,7 @@ int32_t vers_ivf_destroy(vers_ivf_t* h) {
   (void)hipDeviceSynchronize();
   for (auto& w : h->pool) ws_destroy(*w);
   if (h->fail_watch) (void)hipHostFree(h->fail_watch);
+  if (h->st_pin) (void)hipHostFree(h->st_pin);
   delete h;
   return VERS_OK;
 }

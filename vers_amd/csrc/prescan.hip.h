@@ -885,7 +885,6 @@ __global__ __launch_bounds__(kWave * kMergeWaves) void fallback_kernel(RescoreAr
   bool nan_seen = false;
   uint64_t* slot = fb_part + (uint64_t)gidx * chunks * kMergeWaves * a.top_k;  // the group's chunks x 16 partial lists
   uint32_t* arrived = ctr + 2 * gidx;
-  uint32_t* merged = ctr + 2 * gidx + 1;
   uint32_t round = 0;
   if (gidx < n_groups) {
     for (uint32_t i = gidx; i < n_fail; i += n_groups, ++round) {
@@ -936,14 +935,12 @@ __global__ __launch_bounds__(kWave * kMergeWaves) void fallback_kernel(RescoreAr
         if (threadIdx.x < kWave)
           emit_topk(list, q, a.top_k, lane, a.pj_list + (uint64_t)q * a.P, a.pj_pref + (uint64_t)q * a.P, a.P, a.list_off, a.row_ids, a.out_ids,
                     a.out_dist, a.out_count, a.out_keys);
-        __syncthreads();  // the slot is reused by the group's next query
-        if (G > 1 && threadIdx.x == 0) __hip_atomic_store(merged, round + 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        __syncthreads();  // (G == 1: the block's slot is reused by its next query)
       }
-      if (G > 1 && i + n_groups < n_fail) {  // the slot is free once its fold is done
-        if (threadIdx.x == 0)
-          while (__hip_atomic_load(merged, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < round + 1u) __builtin_amdgcn_s_sleep(16);
-        __syncthreads();
-      }
+      // No block ever WAITS for another one here.  A group's slot would be reused only by a second query of the same group,
+      // and a group of G > 1 blocks never has one: G > 1 implies G * n_fail <= gridDim.x (the loop above), i.e.
+      // n_groups = gridDim.x / G >= n_fail, so i + n_groups >= n_fail for every i.  (Round 2 carried a spin on a `merged`
+      // word for that case -- dead code, but a cross-block spin nonetheless; with G == 1 the block is alone on its slot.)
     }
   }
   if (__ballot(nan_seen) != 0 && lane == 0) atomicOr(a.status, 1u);
