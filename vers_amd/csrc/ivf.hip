@@ -872,11 +872,24 @@ struct WsLease {
   SearchWs* prev;
   hipStream_t st = nullptr;
   int32_t rc = VERS_OK;
-  explicit WsLease(vers_ivf* hh) : h(hh), prev(W) {
+  // dev_stream: a device-pointer call names the stream it will queue on.  It gets the free workspace that last ran on
+  // that stream if there is one (no cross-stream ordering needed: batches a host keeps in flight on two or three streams
+  // each get their own scratch and overlap on the GPU -- the small latency-bound kernels of one batch under the list scan
+  // of another), else a fresh one while the pool may grow, else the most recently freed (ordered by its `done` event).
+  explicit WsLease(vers_ivf* hh, bool dev = false, hipStream_t dev_stream = nullptr) : h(hh), prev(W) {
     {
       std::unique_lock<std::mutex> lk(h->pool_mu);
       for (;;) {
-        if (!h->free_ws.empty()) { ws = h->free_ws.back(); h->free_ws.pop_back(); break; }
+        if (dev && !h->free_ws.empty()) {
+          size_t pick = h->free_ws.size();
+          for (size_t i = h->free_ws.size(); i-- > 0;)
+            if (h->free_ws[i]->used && h->free_ws[i]->last_stream == dev_stream) { pick = i; break; }
+          if (pick == h->free_ws.size() && h->pool.size() >= vers_ivf::kMaxWs) pick = h->free_ws.size() - 1;
+          if (pick == h->free_ws.size())
+            for (size_t i = h->free_ws.size(); i-- > 0;)
+              if (!h->free_ws[i]->used) { pick = i; break; }
+          if (pick != h->free_ws.size()) { ws = h->free_ws[pick]; h->free_ws.erase(h->free_ws.begin() + (long)pick); break; }
+        } else if (!h->free_ws.empty()) { ws = h->free_ws.back(); h->free_ws.pop_back(); break; }
         if (h->pool.size() < vers_ivf::kMaxWs) {
           h->pool.emplace_back(new SearchWs());
           ws = h->pool.back().get();
@@ -2480,7 +2493,7 @@ int32_t vers_ivf_search_dev(vers_ivf_t* h, const float* queries_dev, uint64_t ld
     return fail(VERS_ERR_INVALID, "vers_ivf_search_dev: bad arguments");
   std::shared_lock<std::shared_mutex> lk(h->index);
   DeviceGuard g(h->device);
-  WsLease lease(h);
+  WsLease lease(h, true, (hipStream_t)stream);
   if (lease.rc) return lease.rc;
   if (int32_t rc = lease.order_on((hipStream_t)stream)) return rc;
   return search_dev_locked(h, queries_dev, ldq_floats, b, top_k, nprobe, out_ids_dev, out_dist_dev, out_count_dev, nullptr,
@@ -2516,7 +2529,7 @@ int32_t vers_ivf_search_partial_dev(vers_ivf_t* h, const float* queries_dev, uin
     return fail(VERS_ERR_INVALID, "vers_ivf_search_partial_dev: bad arguments");
   std::shared_lock<std::shared_mutex> lk(h->index);
   DeviceGuard g(h->device);
-  WsLease lease(h);
+  WsLease lease(h, true, (hipStream_t)stream);
   if (lease.rc) return lease.rc;
   if (int32_t rc = lease.order_on((hipStream_t)stream)) return rc;
   // distances and counts of the local part are scratch here: the cross-GPU merge recomputes them
@@ -2605,7 +2618,7 @@ int32_t vers_ivf_search_exhaustive_dev(vers_ivf_t* h, const float* queries_dev, 
     return fail(VERS_ERR_INVALID, "vers_ivf_search_exhaustive_dev: bad arguments");
   std::shared_lock<std::shared_mutex> lk(h->index);
   DeviceGuard g(h->device);
-  WsLease lease(h);
+  WsLease lease(h, true, (hipStream_t)stream);
   if (lease.rc) return lease.rc;
   if (int32_t rc = lease.order_on((hipStream_t)stream)) return rc;
   return exhaustive_dev_locked(h, queries_dev, ldq_floats, b, top_k, metric, out_ids_dev, out_dist_dev, out_count_dev,
@@ -2621,7 +2634,7 @@ int32_t vers_ivf_search_exhaustive_partial_dev(vers_ivf_t* h, const float* queri
   if (b == 0) return VERS_OK;
   std::shared_lock<std::shared_mutex> lk(h->index);
   DeviceGuard g(h->device);
-  WsLease lease(h);
+  WsLease lease(h, true, (hipStream_t)stream);
   if (lease.rc) return lease.rc;
   if (int32_t rc = lease.order_on((hipStream_t)stream)) return rc;
   if (int32_t rc = ensure_out(h, (size_t)b * top_k, b)) return rc;
