@@ -1,0 +1,41 @@
+"""Many batches in flight on one index: host threads x streams, certificates forced to fail, for tens of seconds.
+
+Round 2's planning kernel separated its phases by a SPINNING grid barrier (64 blocks that each take a whole CU).  With a
+few of those in flight at once -- one per host thread / per stream with its own workspace -- the resident blocks of one
+launch hold the CUs the missing blocks of another need and the GPU hangs (scripts/probe/spin_residency.hip reproduces the
+mechanism with a bounded spin).  No kernel of the search path waits for another block any more (plan.hip.h); this is the
+test that the old code could not be allowed to run.  The work happens in a CHILD process: a hung child is killed and the
+test fails -- a process that has touched the GPU is never re-exec'd."""
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+SECONDS = float(os.environ.get("VERS_STRESS_SECONDS", "30"))
+
+
+def _run(seconds, env_extra):
+    env = dict(os.environ, **env_extra)
+    try:
+        r = subprocess.run([sys.executable, "-m", "tests.stress_main", str(seconds), "4", "3"], cwd=ROOT, env=env, capture_output=True,
+                           text=True, timeout=seconds * 3 + 240)
+    except subprocess.TimeoutExpired as e:  # the child is killed by subprocess.run; nothing is retried
+        pytest.fail(f"stress child did not finish (hung GPU work?): {e}")
+    assert r.returncode == 0 and "STRESS OK" in r.stdout, (r.stdout[-2000:], r.stderr[-2000:])
+    return dict(kv.split("=") for kv in r.stdout.split("STRESS OK", 1)[1].split())
+
+
+@pytest.mark.gpu
+def test_threads_x_streams_with_every_certificate_failing():
+    """4 device-pointer threads x 3 streams each + 1 host-pointer thread; VERS_PRESCAN=2 / VERS_COARSE=2: every query of every
+    batch goes through the exact fallbacks (fallback_kernel's block groups, the exact coarse ranking), all bit-exact."""
+    out = _run(SECONDS * 2 / 3, {"VERS_PRESCAN": "2", "VERS_COARSE": "2"})
+    assert int(out["batches"]) >= 12 and int(out["rescanned_queries"]) > 0
+
+
+@pytest.mark.gpu
+def test_threads_x_streams_production_paths():
+    out = _run(SECONDS / 3, {})
+    assert int(out["batches"]) >= 12 and int(out["host_calls"]) >= 16
