@@ -99,6 +99,12 @@ int32_t vers_kmeans_assign(int32_t device, const float* rows, uint64_t n, uint64
  * matrix cores): process-wide number of points assigned through it and how many of those failed the
  * certificate and were re-done by the exact scan.  Results are bit-identical either way. */
 int32_t vers_assign_stats(uint64_t* out_points, uint64_t* out_fallbacks, int32_t reset);
+/* Measurement hook: where the time of this process's build_index / k-means calls went (HIP events on the build's
+ * stream).  out[8]: [0] ms in the assign contraction launches (queries x centroids on the matrix cores, ivfflat.rs:29-46),
+ * [1] their count, [2] their algorithmic flop (2 * points * k * d), [3] wall ms of whole matrix-core assign passes (contraction
+ * + arg-min + exact re-score + exact re-scans), [4] passes, [5] ms in update_centroids (:47-71), [6] ms in the cost fold
+ * (:138-149), [7] points whose certificate failed and were settled by the exact kernels.  reset != 0 zeroes them. */
+int32_t vers_build_stats(double* out8, int32_t reset);
 /* IVFFlatIndex::update_centroids (ivfflat.rs:47-71): per cluster the f32 sum
  * of its members in ascending row order divided by the count; empty cluster
  * -> zero vector.  out_centroids is packed [k * d]. */

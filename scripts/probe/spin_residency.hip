@@ -44,11 +44,11 @@ __global__ __launch_bounds__(kThreads) void spin_grid(unsigned* ctr, unsigned ba
   }
 }
 // a terminating kernel whose blocks take a whole CU each for `ticks` (the matrix-core list scan's shape: 256 blocks, 8 waves, 130 KB LDS)
-__global__ __launch_bounds__(512) void filler(unsigned long long ticks) {
+__global__ __launch_bounds__(512) void filler(unsigned long long ticks, unsigned long long stagger) {  // block i runs ticks + i * stagger
   extern __shared__ unsigned lds[];
   lds[threadIdx.x] = 0;
-  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
-  while (__builtin_amdgcn_s_memrealtime() - t0 < ticks) __builtin_amdgcn_s_sleep(32);
+  const unsigned long long t0 = __builtin_amdgcn_s_memrealtime(), dur = ticks + blockIdx.x * stagger;
+  while (__builtin_amdgcn_s_memrealtime() - t0 < dur) __builtin_amdgcn_s_sleep(32);
 }
 
 int main(int argc, char** argv) {
@@ -59,7 +59,10 @@ int main(int argc, char** argv) {
   hipDeviceProp_t prop; CK(hipGetDeviceProperties(&prop, 0));
   printf("device: %s, %d CUs; spin grid = %u blocks x %u threads, one block per CU; deadline %.0f ms\n", prop.name, prop.multiProcessorCount,
          kBlocks, kThreads, deadline / 1e5);
-  for (int with_filler = 0; with_filler <= 1; ++with_filler)
+  // mode 0: W spin grids on an idle chip | 1: each stream alternates list-scan-shaped launches and spin grids |
+  // 2: ONE list-scan-shaped launch holds every CU and its blocks end one by one (1 us apart) while W spin grids, each on its
+  //    own stream, are already queued: the CUs that come free are dealt to the waiting grids
+  for (int with_filler = 0; with_filler <= 2; ++with_filler)
     for (int W : {1, 2, 3, 4, 5, 6, 8}) {
       std::vector<hipStream_t> st(W);
       std::vector<unsigned*> ctr(W);
@@ -67,9 +70,11 @@ int main(int argc, char** argv) {
       for (int i = 0; i < W; ++i) { CK(hipStreamCreateWithFlags(&st[i], hipStreamNonBlocking)); CK(hipMalloc(&ctr[i], 64)); CK(hipMemset(ctr[i], 0, 64)); }
       CK(hipDeviceSynchronize());
       unsigned bad_launches = 0;
+      hipStream_t st0; CK(hipStreamCreateWithFlags(&st0, hipStreamNonBlocking));
       for (int r = 0; r < rounds; ++r) {
+        if (with_filler == 2) hipLaunchKernelGGL(filler, dim3(256), dim3(512), 130 * 1024, st0, 30000ull /* 300 us */, 100ull /* + 1 us per block */);
         for (int i = 0; i < W; ++i) {
-          if (with_filler) hipLaunchKernelGGL(filler, dim3(256), dim3(512), 130 * 1024, st[i], 20000ull /* 200 us */);
+          if (with_filler == 1) hipLaunchKernelGGL(filler, dim3(256), dim3(512), 130 * 1024, st[i], 20000ull /* 200 us */, 0ull);
           hipLaunchKernelGGL(spin_grid, dim3(kBlocks), dim3(kThreads), kWholeCuLds, st[i], ctr[i], (unsigned)r * 3u * kBlocks, deadline, out + i);
         }
         CK(hipDeviceSynchronize());
@@ -90,7 +95,8 @@ int main(int argc, char** argv) {
       std::vector<Out> h(W); CK(hipMemcpy(h.data(), out, sizeof(Out) * W, hipMemcpyDeviceToHost));
       unsigned long long mw = 0; for (auto& o : h) mw = o.max_wait_ticks > mw ? o.max_wait_ticks : mw;
       printf("%s  W=%d concurrent spin grids (%3d whole CUs wanted): %d rounds, %u with a timed-out barrier (= a hang without the deadline); longest barrier wait %.1f us\n",
-             with_filler ? "with whole-CU list-scan blocks in between" : "spin grids only                         ", W, W * (int)kBlocks, rounds, bad_launches, mw / 100.0);
+             with_filler == 2 ? "queued behind ONE draining list scan     " : with_filler ? "with whole-CU list-scan blocks in between" : "spin grids only                          ", W, W * (int)kBlocks, rounds, bad_launches, mw / 100.0);
+      CK(hipStreamDestroy(st0));
       for (int i = 0; i < W; ++i) { CK(hipStreamDestroy(st[i])); CK(hipFree(ctr[i])); }
       CK(hipFree(out));
     }

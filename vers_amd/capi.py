@@ -82,6 +82,7 @@ SIGNATURES = {
                                       C.c_float, C.c_uint64, _vp]),
     "vers_kmeans_assign": (C.c_int32, [C.c_int32, _vp, C.c_uint64, C.c_uint64, _vp, C.c_uint64, C.c_uint64, C.c_uint32, _vp, _vp]),
     "vers_assign_stats": (C.c_int32, [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_int32]),
+    "vers_build_stats": (C.c_int32, [C.POINTER(C.c_double), C.c_int32]),
     "vers_kmeans_update": (C.c_int32, [C.c_int32, _vp, C.c_uint64, C.c_uint64, _vp, C.c_uint64, C.c_uint32, _vp]),
     "vers_kmeans_cost": (C.c_int32, [C.c_int32, _vp, C.c_uint64, C.c_uint64, _vp, C.c_uint64, C.c_uint64, _vp, C.c_uint32,
                                      C.POINTER(C.c_float)]),
@@ -242,6 +243,14 @@ def assign_stats(reset=False):
     a, b = C.c_uint64(0), C.c_uint64(0)
     check(lib().vers_assign_stats(C.byref(a), C.byref(b), 1 if reset else 0))
     return int(a.value), int(b.value)
+
+
+def build_stats(reset=False) -> dict:
+    """Where the build_index time of this process went (vers_build_stats; HIP events on the build's stream)."""
+    v = (C.c_double * 8)()
+    check(lib().vers_build_stats(v, 1 if reset else 0))
+    keys = ("gemm_ms", "gemm_launches", "gemm_flop", "assign_ms", "assign_passes", "update_ms", "cost_ms", "redone_points")
+    return dict(zip(keys, (float(x) for x in v)))
 
 
 def set_option(name: str, value: int):

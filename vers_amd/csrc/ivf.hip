@@ -1477,7 +1477,9 @@ int32_t run_build(vers_ivf* h, const float* X, uint32_t ldx, uint64_t n, const B
       if (int32_t rc = assign_pass(C.as<float>(), assign.as<uint32_t>(), nullptr)) return rc;
       if (int32_t rc = km_group(assign.as<uint32_t>(), (uint32_t)n, k, sorted.as<uint32_t>(), counts, starts, h->km, st)) return rc;
       if (!multi) {
+        km_timer_begin(st);
         if (int32_t rc = km_update(X, ldx, h->d, sorted.as<uint32_t>(), starts, counts, k, Cn.as<float>(), ld, st)) return rc;
+        km_timer_end(st, &build_stats().update_ms);
       } else if (k) {
         // update_centroids over the sharded rows (ivfflat.rs:47-71): global member counts by all-gather (integers),
         // running sums CHAINED through the ranks in ascending-range order, division on the last rank, broadcast.
@@ -1518,7 +1520,9 @@ int32_t run_build(vers_ivf* h, const float* X, uint32_t ldx, uint64_t n, const B
       if (int32_t rc = comm_rc(cm->recv(cm->ctx, cost_in, 4, me - 1), "recv")) return rc;
       fold_init = cost_in;
     }
+    km_timer_begin(st);
     if (int32_t rc = km_cost_fold(mind.as<float>(), n, fold_init, cost_dev, st)) return rc;
+    km_timer_end(st, &build_stats().cost_ms);
     uint32_t stw = 0;
     if (multi) {
       VERS_HIP_TRY(hipStreamSynchronize(st));
@@ -1548,6 +1552,7 @@ int32_t run_build(vers_ivf* h, const float* X, uint32_t ldx, uint64_t n, const B
       VERS_HIP_TRY(hipMemcpyAsync(best_assign.p, assign.p, (n ? n : 1) * 4, hipMemcpyDeviceToDevice, st));
     }
   }
+  km_timers_collect();
   *out_cost = best;
   if (*out_kept) {
     if (int32_t rc = h->centroids.reserve(cbytes)) return rc;

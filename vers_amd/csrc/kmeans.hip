@@ -13,6 +13,10 @@
 #include <mutex>
 #include <vector>
 
+#include <chrono>
+#include <mutex>
+#include <vector>
+
 #include "kmeans.hpp"
 #include "gemm.hip.h"
 #include "scan.hip.h"
@@ -149,6 +153,46 @@ int32_t km_assign(const float* X, uint32_t ldx, uint64_t n, const float* C, uint
 // ---- assign through the matrix cores ------------------------------------------------------
 static std::atomic<uint64_t> g_mfma_points{0}, g_mfma_fallbacks{0};
 
+// ---- build timing (vers_build_stats) -------------------------------------------------------------------------------
+static std::mutex g_bs_mu;
+static BuildStats g_bs;
+BuildStats& build_stats() { return g_bs; }
+namespace {
+struct Stretch { hipEvent_t a = nullptr, b = nullptr; double* acc = nullptr; bool open = false; };
+std::vector<Stretch> g_stretches;   // (guarded by g_bs_mu)
+std::vector<hipEvent_t> g_ev_pool;
+hipEvent_t ev_get() {
+  if (!g_ev_pool.empty()) { hipEvent_t e = g_ev_pool.back(); g_ev_pool.pop_back(); return e; }
+  hipEvent_t e = nullptr;
+  if (hipEventCreate(&e) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  return e;
+}
+}  // namespace
+void km_timer_begin(hipStream_t st) {
+  std::lock_guard<std::mutex> lk(g_bs_mu);
+  Stretch s; s.a = ev_get(); s.b = ev_get(); s.open = true;
+  if (s.a) (void)hipEventRecord(s.a, st);
+  g_stretches.push_back(s);
+}
+void km_timer_end(hipStream_t st, double* acc) {
+  std::lock_guard<std::mutex> lk(g_bs_mu);
+  for (size_t i = g_stretches.size(); i-- > 0;)
+    if (g_stretches[i].open) { g_stretches[i].open = false; g_stretches[i].acc = acc; if (g_stretches[i].b) (void)hipEventRecord(g_stretches[i].b, st); return; }
+}
+void km_timers_collect() {
+  std::lock_guard<std::mutex> lk(g_bs_mu);
+  std::vector<Stretch> keep;
+  for (auto& s : g_stretches) {
+    if (s.open) { keep.push_back(s); continue; }
+    float ms = 0.0f;
+    if (s.a && s.b && hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) { if (s.acc) *s.acc += ms; }
+    else (void)hipGetLastError();
+    if (s.a) g_ev_pool.push_back(s.a);
+    if (s.b) g_ev_pool.push_back(s.b);
+  }
+  g_stretches.swap(keep);
+}
+
 static std::atomic<int> g_x3_mask{-1};
 int gemm_x3_mask() {
   int m = g_x3_mask.load();
@@ -221,6 +265,7 @@ int32_t km_assign_mfma(const float* X, uint32_t ldx, uint64_t n, const float* C,
   uint32_t* best = ws.best.as<uint32_t>();
   float* g2 = ws.best.as<float>() + mb;
   const bool in_place_ok = ldx == ldq && d == ldq;  // (padding columns of the caller's X may hold anything: stage them away)
+  const auto wall0 = std::chrono::steady_clock::now();
   for (uint64_t i0 = 0; i0 < n; i0 += mb) {
     const uint32_t nb = (uint32_t)((n - i0 < mb) ? (n - i0) : mb);
     const uint32_t nb_pad = round_up(nb, kGemmBN);
@@ -232,8 +277,11 @@ int32_t km_assign_mfma(const float* X, uint32_t ldx, uint64_t n, const float* C,
       xb = ws.xp.as<float>();
     }
     // (the triples are addressed with pitch mb: nb_pad <= mb)
+    km_timer_begin(st);
     VERS_HIP_TRY(launch_gemm<true>((gemm_x3_mask() & 1) != 0, k_pad / kGemmBM, nb_pad / kGemmBN, st, ws.cg.as<float>(), xb, ws.cnorm.as<float>(), ldq,
                                    (uint32_t)mb, (float*)nullptr, metric, k, part_v1, part_c1, part_v2, cg_h, cg_l));
+    km_timer_end(st, &g_bs.gemm_ms);
+    g_bs.gemm_launches += 1; g_bs.gemm_flop += 2.0 * (double)nb * (double)k * (double)d;
     hipLaunchKernelGGL(assign_argmin_merge_kernel, dim3((nb + 255) / 256), dim3(256), 0, st, (const float*)part_v1, (const uint32_t*)part_c1,
                        (const float*)part_v2, n_tiles, (uint32_t)mb, nb, best, g2);
     hipLaunchKernelGGL(assign_rescore_kernel, dim3((nb + 63) / 64), dim3(64), 0, st, X + i0 * ldx, ldx, C, ldc, d, ldq, cmax2_dev, best, g2,
@@ -261,7 +309,11 @@ int32_t km_assign_mfma(const float* X, uint32_t ldx, uint64_t n, const float* C,
     hipLaunchKernelGGL(scatter_assign_kernel, dim3((nf + 255) / 256), dim3(256), 0, st, fb_list, nf, ws.fa.as<uint32_t>(), ws.fm.as<float>(),
                        out_assign, out_mind);
     VERS_HIP_TRY(hipGetLastError());
+    VERS_HIP_TRY(hipStreamSynchronize(st));
   }
+  km_timers_collect();
+  g_bs.assign_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
+  g_bs.assign_passes += 1; g_bs.redone_points += nf;
   return VERS_OK;
 }
 
@@ -511,6 +563,17 @@ int32_t vers_kmeans_assign(int32_t device, const float* rows, uint64_t n, uint64
   VERS_HIP_TRY(hipMemcpy(a32.data(), A.p, n * sizeof(uint32_t), hipMemcpyDeviceToHost));
   for (uint64_t i = 0; i < n; ++i) out_assign[i] = a32[i];
   if (out_min_dist) VERS_HIP_TRY(hipMemcpy(out_min_dist, M.p, n * sizeof(float), hipMemcpyDeviceToHost));
+  return VERS_OK;
+}
+
+int32_t vers_build_stats(double* out, int32_t reset) {
+  km_timers_collect();
+  std::lock_guard<std::mutex> lk(g_bs_mu);
+  if (out) {
+    out[0] = g_bs.gemm_ms; out[1] = g_bs.gemm_launches; out[2] = g_bs.gemm_flop; out[3] = g_bs.assign_ms; out[4] = g_bs.assign_passes;
+    out[5] = g_bs.update_ms; out[6] = g_bs.cost_ms; out[7] = g_bs.redone_points;
+  }
+  if (reset) g_bs = BuildStats{};
   return VERS_OK;
 }
 

@@ -63,6 +63,24 @@ bool km_use_mfma(uint64_t n, uint32_t k, uint32_t d);
 int gemm_x3_mask();
 void set_gemm_x3_mask(int m);  // (vers_set_option: same-process A/B in bench.py)
 
+// Measurement hook (vers_build_stats): where the time of the builds of this process went.  HIP events on the build's stream,
+// read at the synchronisation points the build has anyway.
+struct BuildStats {
+  double gemm_ms = 0;        // assign contraction launches (dist_gemm*_kernel<true>), summed
+  double gemm_launches = 0;
+  double gemm_flop = 0;      // 2 * points * k * d of those launches (algorithmic: unpadded)
+  double assign_ms = 0;      // whole matrix-core assign passes (contraction + arg-min merge + exact re-score + exact re-scans), host wall clock
+  double assign_passes = 0;
+  double update_ms = 0;      // update_centroids (grouping excluded)
+  double cost_ms = 0;        // the one-lane cost fold
+  double redone_points = 0;  // points whose certificate failed (settled by the exact kernels)
+};
+BuildStats& build_stats();
+// elapsed time of a stretch of a stream, added to *acc when the stream next synchronises (km_timers_collect)
+void km_timer_begin(hipStream_t st);
+void km_timer_end(hipStream_t st, double* acc);
+void km_timers_collect();  // call after a stream synchronisation: folds every finished stretch into its accumulator
+
 // counts[k], starts[k+1] (exclusive prefix), sorted_ids[n] grouped by cluster, ascending inside.
 int32_t km_group(const uint32_t* assign, uint32_t n, uint32_t k, uint32_t* sorted_ids, uint32_t* counts, uint32_t* starts,
                  KMeansScratch& ws, hipStream_t st);
