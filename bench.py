@@ -59,6 +59,9 @@ def main():
     ap.add_argument("--no-recall", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the untimed extra measurements (single query, coarse GEMM, flat cfg2, Dist-U recall)")
     ap.add_argument("--f32-rows", action="store_true", help="no fp16 shadow: the f32 rows feed the batched list scan (round 1's configuration; same as VERS_SHADOW=0)")
+    ap.add_argument("--streams", type=int, default=2, help="batches in flight: step i is queued on stream i %% S with its own outputs and workspace, so "
+                    "the small latency-bound kernels of one batch (coarse quantiser, planning, exact finish) run under the list scan of "
+                    "another; every step's work is inside the timed region (1 = strictly one batch after the other)")
     ap.add_argument("--ahead", action="store_true", help="compute the next batch's coarse quantiser on a side stream under the current "
                     "list scan (vers_ivf_coarse_ahead_dev; same-box A/B at cfg3: +0.8 %% -- the scan already fills the chip)")
     args = ap.parse_args()
@@ -120,6 +123,7 @@ def main():
     init = (dg.mix64(np.uint64(0xB01D) + np.arange(nlist, dtype=np.uint64)) % np.uint64(n)).astype(np.uint64)
     index = IVFFlatIndex(d, device=dev_index)
     capi.mem_stats(reset_peak=True)
+    capi.build_stats(reset=True)
     t0 = time.perf_counter()
     comm = None
     if world > 1:
@@ -130,6 +134,7 @@ def main():
         kept = index.build_dev(X.data_ptr(), n, nlist, 1, args.kmeans_iters, init)
     t_build = time.perf_counter() - t0
     assert kept
+    bst = capi.build_stats(reset=True)
     del X
     torch.cuda.empty_cache()
     lens = index.list_lengths()
@@ -154,17 +159,19 @@ def main():
     n_batches = max(1, min(args.steps + args.warmup, 8))
     Q = torch.empty(n_batches * B, ld, dtype=torch.float32, device=dev)
     capi.gen_rows_dev(Q.data_ptr(), n_batches * B, d, ld, 1, SEED_Q, SEED_C, n_modes, sigma)
-    # One batch at a time on the current stream (a single host thread's batches share one workspace of the handle and are
-    # ordered through it; rotating them over 2-3 streams with a workspace each measured +1 % / +3 %: every large kernel of
-    # the step fills whole CUs, there is nothing to overlap with -- and hung the GPU in some stream mixes: not kept).
-    S = 1
-    streams = [torch.cuda.current_stream()]
+    # S batches in flight: step i runs on stream i % S with its own outputs; the library gives a stream's calls their own
+    # workspace.  The list scan fills every CU, but what surrounds it -- coarse quantiser, planning, exact finish: a dozen
+    # latency-bound launches that do NOT shrink when the lists are sharded over GPUs -- overlaps with another batch's scan.
+    # (Round 2 measured this and backed off because the planning kernel's spinning grid barrier could hang the GPU with
+    # several of them in flight; nothing in the search path waits for another block any more: DESIGN.md section 5.)
+    S = max(1, args.streams)
+    streams = [torch.cuda.current_stream()] if S == 1 else [torch.cuda.Stream() for _ in range(S)]
     outs = [dict(ids=torch.zeros(B, top_k, dtype=torch.int64, device=dev), dst=torch.zeros(B, top_k, dtype=torch.float32, device=dev),
                  cnt=torch.zeros(B, dtype=torch.int32, device=dev),
                  part=torch.empty(2, B, top_k, dtype=torch.int64, device=dev),           # [keys | vec ids] of this rank
                  allp=torch.empty(world, 2, B, top_k, dtype=torch.int64, device=dev)) for _ in range(S)]
     ids, dst, cnt = outs[0]["ids"], outs[0]["dst"], outs[0]["cnt"]
-    st = streams[0].cuda_stream
+    st = torch.cuda.current_stream().cuda_stream   # the untimed legs below run one call at a time on the default stream
     torch.cuda.synchronize()
 
     def exchange(o):
@@ -304,6 +311,62 @@ def main():
     # ---- extra measurements, outside the timed region (north_star's other targets) ---------------
     extra = {}
     MFMA_F32_PEAK_TF = 157.3  # v_mfma_f32_32x32x2_f32 dense peak (MI355X_MICROARCH.md)
+    BF16_DENSE_PEAK_TF = 2500.0  # v_mfma_f32_32x32x16_bf16 dense peak (same guide); the contraction spends THREE bf16 products per f32 one
+
+    def assign_entry(bs, shape_pts, k_, wall_s, note):
+        """k-means assign (ivfflat.rs:29-46) as the build just ran it: the contraction launches by HIP events (vers_build_stats)"""
+        if bs["gemm_launches"] <= 0 or bs["gemm_ms"] <= 0:
+            return None
+        tf = bs["gemm_flop"] / (bs["gemm_ms"] * 1e-3) / 1e12
+        e = {"kernel": "dist_gemm_x3_kernel<true> (points x centroids, 3 x v_mfma_f32_32x32x16_bf16 on hi/lo-split operands; arg-min fused into the epilogue)",
+             "shape": [int(shape_pts), int(k_), d], "launches": int(bs["gemm_launches"]), "us_per_launch": round(bs["gemm_ms"] / bs["gemm_launches"] * 1e3, 1),
+             "algorithmic_tflops": round(tf, 1), "frac_of_bf16_dense_div3": round(tf / (BF16_DENSE_PEAK_TF / 3.0), 4), "frac_of_f32_mfma_peak": round(tf / MFMA_F32_PEAK_TF, 4),
+             "assign_pass_ms": round(bs["assign_ms"] / max(1.0, bs["assign_passes"]), 2), "assign_passes": int(bs["assign_passes"]),
+             "points_redone_exactly_pct": round(100.0 * bs["redone_points"] / max(1.0, bs["gemm_flop"] / (2.0 * k_ * d)), 3),
+             "update_centroids_ms_total": round(bs["update_ms"], 2), "cost_fold_ms_total": round(bs["cost_ms"], 2), "build_index_s": round(wall_s, 3), "note": note}
+        for pf in ("r03_kmeans.json",):  # MFMA-busy of this kernel from the committed PMC pass (bench.py cannot collect counters itself)
+            try:
+                pj = json.load(open(os.path.join(ROOT, "profiles", pf)))
+                e["mfma_busy_pct"] = pj["mfma_busy_pct"].get(str(int(k_)))
+                e["mfma_busy_source"] = f"profiles/{pf}: rocprofv3 --pmc pass (committed; not collected in this run)"
+            except (OSError, KeyError, ValueError, AttributeError):
+                pass
+        return e
+
+    if rank == 0:
+        sst = index.shadow_state()
+        hbm_total = int(torch.cuda.get_device_properties(dev).total_memory)
+        rows_stored = max(1, n if world == 1 else int(lens[index.owners() == rank].sum()))
+        per_row = float(mem_now) / rows_stored
+        per_row_noshadow = float(mem_now - sst["bytes"]) / rows_stored
+        extra["memory"] = {"library_bytes_now": int(mem_now), "library_bytes_peak_during_build": int(mem_peak), "shadow_bytes": int(sst["bytes"]), "shadow_active": bool(sst["active"]),
+                           "bytes_per_stored_row": round(per_row, 1), "bytes_per_stored_row_without_shadow": round(per_row_noshadow, 1), "hbm_bytes": hbm_total,
+                           "max_N_per_gpu_with_shadow": int((hbm_total - (8 << 30)) / per_row), "max_N_per_gpu_without_shadow": int((hbm_total - (8 << 30)) / per_row_noshadow),
+                           "note": "rows incl. list slack + row ids + |x|^2 (+ fp16 shadow); 8 GB set aside for per-batch scratch and the caller"}
+        extra["build_index_s"] = round(t_build, 3)
+        ke = assign_entry(bst, min(131072, hi - lo), nlist, t_build, f"the timed index's own build: N={n} over {world} rank(s), k={nlist}, {int(index.iterations[0])} iterations + final assign")
+        if ke:
+            extra["kmeans_assign"] = ke
+            log(f"[bench] k-means assign contraction [{ke['shape'][0]}x{nlist}x{d}]: {ke['us_per_launch']} us per launch = {ke['algorithmic_tflops']} algorithmic TFLOP/s "
+                f"({ke['points_redone_exactly_pct']} % of the points re-done exactly); update {ke['update_centroids_ms_total']} ms, cost fold {ke['cost_fold_ms_total']} ms in a {t_build:.2f} s build")
+    if rank == 0 and world == 1 and not args.no_extra and d == 768:
+        # cfg5's cluster count on one GPU: N = 1M, k = 65536, one iteration + the final assign (2 passes)
+        nk, kk = 1_048_576, 65536
+        Xk = torch.empty(nk, ld, dtype=torch.float32, device=dev)
+        capi.gen_rows_dev(Xk.data_ptr(), nk, d, ld, 1, SEED_X + 0x200, SEED_C, n_modes, sigma)
+        ik = IVFFlatIndex(d, device=dev_index)
+        initk = (dg.mix64(np.uint64(0xB16C) + np.arange(kk, dtype=np.uint64)) % np.uint64(nk)).astype(np.uint64)
+        capi.build_stats(reset=True)
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        ik.build_dev(Xk.data_ptr(), nk, kk, 1, 1, initk)
+        tk = time.perf_counter() - t0
+        bk = capi.build_stats(reset=True)
+        ik.close(); del Xk
+        torch.cuda.empty_cache()
+        ke = assign_entry(bk, min(131072, nk), kk, tk, f"BASELINE.json cfg5's cluster count on one GPU: N={nk}, k={kk}, 1 iteration + final assign")
+        if ke:
+            extra["kmeans_assign_k65536"] = ke
+            log(f"[bench] k-means at k=65536 (N={nk}): build {tk:.2f} s, contraction {ke['algorithmic_tflops']} algorithmic TFLOP/s, {ke['points_redone_exactly_pct']} % re-done exactly")
     if rank == 0:
         # the batched coarse quantiser's contraction, queries x centroids [B x d].[d x nlist]: the production kernel (three bf16
         # MFMA products of hi/lo-split operands) as timed in the last step, and the f32 MFMA kernel on the same batch (same
@@ -327,30 +390,58 @@ def main():
                 capi.set_option("gemm_x3", 3)
         except capi.VersError:
             pass
+    def timed_steps(np_):
+        """the timed region's loop again (same warm-up, same step count, same streams) with another nprobe / row operand"""
+        def stp(i):
+            o = outs[i % S]
+            sh = streams[i % S].cuda_stream
+            index.search_dev(Q[(i % n_batches) * B:].data_ptr(), ld, B, top_k, np_, o["ids"].data_ptr(), o["dst"].data_ptr(), o["cnt"].data_ptr(), sh)
+        for i in range(args.warmup):
+            stp(i)
+        for x in streams:
+            index.poll(x.cuda_stream)
+        index.scan_times(reset=True)
+        torch.cuda.synchronize(); t_ = time.perf_counter()
+        for i in range(args.steps):
+            stp(args.warmup + i)
+        torch.cuda.synchronize(); t_ = time.perf_counter() - t_
+        for x in streams:
+            index.poll(x.cuda_stream)
+        return t_, index.scan_times(reset=True)
+
     if rank == 0 and world == 1 and not args.no_extra and shadow:
-        # the same batches with the f32 rows feeding the list scan (round 1's kernel; same index, same results): what the shadow buys
+        # the same steps with the f32 rows feeding the list scan (round 1's kernel; same index, same results): what the shadow
+        # buys, and SURVEY 8d's f32-row figure of the headline -- same warm-up, step count and streams as the timed region
         try:
             capi.set_option("shadow", 0)
-            for i in range(2):  # warm (the f32 kernel's first launch, clocks)
-                index.search_dev(Q[(i % n_batches) * B:].data_ptr(), ld, B, top_k, nprobe, ids.data_ptr(), dst.data_ptr(), cnt.data_ptr(), st)
-            index.poll(st)
-            index.scan_times(reset=True)
-            n32 = 8
-            torch.cuda.synchronize(); t32 = time.perf_counter()
-            for i in range(n32):
-                index.search_dev(Q[(i % n_batches) * B:].data_ptr(), ld, B, top_k, nprobe, ids.data_ptr(), dst.data_ptr(), cnt.data_ptr(), st)
-            torch.cuda.synchronize(); t32 = time.perf_counter() - t32
-            index.poll(st)
-            ms32 = index.scan_times(reset=True)
+            t32, ms32 = timed_steps(nprobe)
             if len(ms32):
                 m = float(np.mean(ms32))
                 extra["list_scan_f32_rows"] = {"kernel": "prescan_kernel_g<false, IvfSrc<32>> (f32 rows -> v_mfma_f32_16x16x1_4b_f32)", "launch_ms": round(m, 4),
                                                "algorithmic_bytes_per_launch": int(f32_bytes), "achieved_GBs": round(f32_bytes / (m * 1e-3) / 1e9, 1),
-                                               "frac": round(f32_bytes / (m * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                                               "whole_step_ms": round(t32 / n32 * 1e3, 4), "whole_step_queries_per_sec": round(n32 * B / t32, 1),
-                                               "note": "the same index and batches with vers_set_option('shadow', 0): round 1's configuration (VERS_SHADOW=0 makes it the whole run)"}
+                                               "frac": round(f32_bytes / (m * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "steps": args.steps, "warmup": args.warmup,
+                                               "whole_step_ms": round(t32 / args.steps * 1e3, 4), "whole_step_queries_per_sec": round(args.steps * B / t32, 1),
+                                               "note": "the same index and batches with vers_set_option('shadow', 0), timed like the headline (after it): round 1's configuration (VERS_SHADOW=0 / --f32-rows makes it the whole run)"}
         finally:
             capi.set_option("shadow", 1)
+    if rank == 0 and world == 1 and not args.no_extra and nprobe != 0:
+        # the reference's OWN mode (nprobe = 0: nearest list, spill while short, ivfflat.rs:166-195) on the same index and batches
+        tr, msr = timed_steps(0)
+        n1r = 100
+        torch.cuda.synchronize(); t0 = time.perf_counter()
+        for i in range(n1r):
+            index.search_dev(Q[(i % (n_batches * B)):].data_ptr(), ld, 1, top_k, 0, ids.data_ptr(), dst.data_ptr(), cnt.data_ptr(), st)
+        torch.cuda.synchronize(); e1r = (time.perf_counter() - t0) / n1r
+        index.poll(st)
+        # one more batch, kept for the bitwise comparison with vo_search in the CPU leg
+        refo = dict(ids=torch.zeros(B, top_k, dtype=torch.int64, device=dev), dst=torch.zeros(B, top_k, device=dev), cnt=torch.zeros(B, dtype=torch.int32, device=dev))
+        index.search_dev(Q[(last % n_batches) * B:].data_ptr(), ld, B, top_k, 0, refo["ids"].data_ptr(), refo["dst"].data_ptr(), refo["cnt"].data_ptr(), st)
+        index.poll(st)
+        extra["reference_mode"] = {"workload": "search_approximate exactly as the reference walks it (nprobe = 0: nearest list + spill), same index / batches",
+                                   "batch_ms_per_step": round(tr / args.steps * 1e3, 4), "batch_queries_per_sec": round(args.steps * B / tr, 1),
+                                   "list_scan_ms": round(float(np.mean(msr)), 4) if len(msr) else None, "steps": args.steps,
+                                   "single_query_end_to_end_us": round(e1r * 1e6, 1)}
+        log(f"[bench] reference mode (nprobe=0): {extra['reference_mode']['batch_queries_per_sec']} q/s in batches of {B}, {e1r * 1e6:.1f} us per single query")
     if rank == 0 and world == 1 and not args.no_extra:
         # (a) single query (B = 1): the list-scan kernel alone (HIP events around its launch) over distinct queries, priced
         # on the bytes of the lists each query actually probed; and the pipelined end-to-end time per query
@@ -428,6 +519,35 @@ def main():
             log(f"[bench] recall@{top_k} on Dist-U (uniform sphere), same N / nlist / nprobe: {ru:.4f} over {nq_u} queries")
             iu.close()
             torch.cuda.empty_cache()
+            # (d) between the two: Dist-C with TWICE the noise (its norm about equals the centre's: the modes overlap), 10 k-means
+            # iterations, recall@10 against the exact scan as a function of nprobe
+            Xm = torch.empty(n, ld, dtype=torch.float32, device=dev)
+            capi.gen_rows_dev(Xm.data_ptr(), n, d, ld, 1, SEED_X + 9, SEED_C, n_modes, 2.0 * sigma)
+            im = IVFFlatIndex(d, device=dev_index)
+            t0 = time.perf_counter()
+            im.build_dev(Xm.data_ptr(), n, nlist, 1, 10, init)
+            t_bm = time.perf_counter() - t0
+            del Xm
+            torch.cuda.empty_cache()
+            nq_m = min(B, 256)
+            Qm = torch.empty(nq_m, ld, dtype=torch.float32, device=dev)
+            capi.gen_rows_dev(Qm.data_ptr(), nq_m, d, ld, 1, SEED_Q + 9, SEED_C, n_modes, 2.0 * sigma)
+            mi = torch.zeros(nq_m, top_k, dtype=torch.int64, device=dev); md = torch.zeros(nq_m, top_k, device=dev); mc = torch.zeros(nq_m, dtype=torch.int32, device=dev)
+            xi = torch.zeros(nq_m, top_k, dtype=torch.int64, device=dev); xd = torch.zeros(nq_m, top_k, device=dev); xc = torch.zeros(nq_m, dtype=torch.int32, device=dev)
+            im.search_exhaustive_dev(Qm.data_ptr(), ld, nq_m, top_k, 0, xi.data_ptr(), xd.data_ptr(), xc.data_ptr(), st)
+            im.poll(st)
+            e_ = xi.cpu().numpy()
+            table = {}
+            for npb in (1, 8, 32, 128):
+                im.search_dev(Qm.data_ptr(), ld, nq_m, top_k, min(npb, nlist), mi.data_ptr(), md.data_ptr(), mc.data_ptr(), st)
+                im.poll(st)
+                a_ = mi.cpu().numpy(); c_ = mc.cpu().numpy()
+                table[str(npb)] = round(sum(len(set(a_[q, :c_[q]].tolist()) & set(e_[q].tolist())) for q in range(nq_m)) / float(nq_m * top_k), 4)
+            extra["recall_vs_nprobe_noisy_dist_c"] = {"recall_at_10": table, "queries": nq_m, "kmeans_iterations": int(im.iterations[0]), "build_index_s": round(t_bm, 2),
+                                                      "distribution": f"Dist-C, {n_modes} modes, sigma x 2 (noise norm ~ centre norm), same N / d / nlist"}
+            log(f"[bench] recall@{top_k} vs nprobe on the noisy Dist-C (sigma x 2, {int(im.iterations[0])} k-means iterations): {table}")
+            im.close()
+            torch.cuda.empty_cache()
 
     # ---- CPU baseline: the C restatement of the reference path (oracle/vers_oracle.c) on the host cores ----------
     # Per sampled query the lists the reference would touch are read back from HBM into a sub-index with all nlist
@@ -435,7 +555,7 @@ def main():
     # every centroid distance + stable sort, the per-candidate row gather through the id lists (ivfflat.rs:172-175),
     # every row distance + stable sort.  First on one thread (the reference's search_approximate is serial), then the same
     # call for independent queries on all host cores ("embarrassingly parallel over queries").
-    cpu, cpu_all = None, None
+    cpu, cpu_all, cpu_km = None, None, None
     if rank == 0 and world == 1 and not args.no_cpu:
         import ctypes as C
         from concurrent.futures import ThreadPoolExecutor
@@ -444,7 +564,7 @@ def main():
         qh = Q[(last % n_batches) * B:(last % n_batches) * B + B, :d].cpu().numpy()
         fp_, u64p = C.POINTER(C.c_float), C.POINTER(C.c_uint64)
 
-        def sub_index(q):
+        def sub_index(q, nprobe=nprobe):
             ranked, _ = co.search_exhaustive(cent, q, nlist)
             lists, rem = [], top_k
             for c in ranked[:nprobe] if nprobe else ranked:
@@ -463,7 +583,7 @@ def main():
                 vals[int(off[c]):int(off[c + 1])] = rows; vid[int(off[c]):int(off[c + 1])] = rid
             return vals, vid, off, np.arange(max(1, int(off[-1])), dtype=np.uint64)
 
-        def run_one(q, sub):
+        def run_one(q, sub, nprobe=nprobe):
             vals, vid, off, loc = sub
             oi = np.zeros(max(1, top_k), dtype=np.uint64); od = np.zeros(max(1, top_k), dtype=np.float32)
             t0 = time.perf_counter()
@@ -496,6 +616,11 @@ def main():
         log(f"[bench] cpu baseline {cpu['value']} q/s on 1 core over {n_cpu} queries; GPU==CPU bitwise: {mismatches == 0}")
         # all host cores, one query per thread (the C call releases the GIL)
         cores = os.cpu_count() or 1
+        model = ""
+        try:
+            model = next(l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name"))
+        except (OSError, StopIteration):
+            pass
         per_q = t_cpu / max(1, n_cpu)
         n_par = int(max(min(cores, B), min(4 * cores, (args.cpu_seconds * cores) / max(per_q, 1e-6))))
         n_par = min(n_par, B)
@@ -509,15 +634,97 @@ def main():
             wall = time.perf_counter() - t0
             bad = sum(0 if (np.array_equal(r[1], ids_h[pick[i], :len(r[1])]) and
                             np.array_equal(r[2].view(np.uint32), dst_h[pick[i], :len(r[2])].view(np.uint32))) else 1 for i, r in enumerate(res))
-            model = ""
-            try:
-                model = next(l.split(":", 1)[1].strip() for l in open("/proc/cpuinfo") if l.startswith("model name"))
-            except (OSError, StopIteration):
-                pass
             cpu_all = {"value": round(n_par / wall, 3), "unit": "queries/sec", "cores": cores, "kind": "port", "cpu_model": model,
                        "sample": f"{n_par} further queries of the same batch, one per thread on {cores} threads (independent searches; the "
                                  f"reference itself searches serially)", "gpu_matches_cpu_bitwise": bad == 0}
             log(f"[bench] cpu baseline on all {cores} host threads ({model}): {cpu_all['value']} q/s over {n_par} queries; GPU==CPU bitwise: {bad == 0}")
+
+        # ---- the reference's own mode: GPU batch of extra.reference_mode against vo_search, bit for bit ----------------------
+        if "reference_mode" in extra:
+            ri, rd, rc_ = refo["ids"].cpu().numpy().astype(np.uint64), refo["dst"].cpu().numpy(), refo["cnt"].cpu().numpy()
+            t_ref, n_ref, bad_ref = 0.0, 0, 0
+            while t_ref < max(2.0, args.cpu_seconds / 4) and n_ref < min(B, 256):
+                q = np.ascontiguousarray(qh[n_ref])
+                dt, gi, gd = run_one(q, sub_index(q, 0), 0)
+                t_ref += dt
+                ok = len(gi) == rc_[n_ref] and np.array_equal(gi, ri[n_ref, :len(gi)]) and np.array_equal(gd.view(np.uint32), rd[n_ref, :len(gd)].view(np.uint32))
+                bad_ref += 0 if ok else 1
+                n_ref += 1
+            extra["reference_mode"].update({"cpu_queries_per_sec_1_core": round(n_ref / t_ref, 2), "cpu_sample": f"{n_ref} queries, one vo_search call each",
+                                            "gpu_matches_cpu_bitwise": bad_ref == 0})
+            log(f"[bench] reference mode: CPU restatement {n_ref / t_ref:.1f} q/s on 1 core over {n_ref} queries; GPU==CPU bitwise: {bad_ref == 0}")
+
+        # ---- cfg2 on the host: utils::search_exhaustive (utils.rs:68-82), N = 1M d = 128, against the GPU flat scan ------------
+        if not args.no_extra and "flat_cfg2" in extra:
+            n2, d2 = 1_000_000, 128
+            Xf = torch.empty(n2, d2, dtype=torch.float32, device=dev)
+            capi.gen_rows_dev(Xf.data_ptr(), n2, d2, d2, 0, SEED_X + 0x100)
+            fc = capi.FlatCorpus(d2, device=dev_index); fc.upload_dev(Xf.data_ptr(), n2, d2)
+            Qf = torch.empty(64, d2, dtype=torch.float32, device=dev)
+            capi.gen_rows_dev(Qf.data_ptr(), 64, d2, d2, 0, SEED_Q + 0x100)
+            Xh, Qh2 = Xf.cpu().numpy(), Qf.cpu().numpy()
+            del Xf
+            gi2, gd2, _gc2 = fc.search(Qh2, top_k)
+            fc.close()
+            t2, n2q, bad2 = 0.0, 0, 0
+            while t2 < max(2.0, args.cpu_seconds / 4) and n2q < 64:
+                t0 = time.perf_counter(); oi, od = co.search_exhaustive(Xh, Qh2[n2q], top_k); t2 += time.perf_counter() - t0
+                bad2 += 0 if (np.array_equal(oi, gi2[n2q]) and np.array_equal(od.view(np.uint32), gd2[n2q].view(np.uint32))) else 1
+                n2q += 1
+            t0 = time.perf_counter()
+            with ThreadPoolExecutor(max_workers=min(cores, 64)) as ex:
+                list(ex.map(lambda i: co.search_exhaustive(Xh, Qh2[i], top_k), range(64)))
+            w2 = time.perf_counter() - t0
+            extra["flat_cfg2"]["cpu_baseline"] = {"value": round(n2q / t2, 3), "unit": "queries/sec", "cores": 1, "kind": "port", "us_per_query": round(t2 / n2q * 1e6, 0),
+                                                  "sample": f"{n2q} queries, one vo_search_exhaustive call each over the same {n2} x {d2} corpus (stable sort of all N distances)",
+                                                  "all_cores": {"value": round(64 / w2, 2), "cores": min(cores, 64), "sample": "64 queries, one per thread"},
+                                                  "gpu_matches_cpu_bitwise": bad2 == 0}
+            log(f"[bench] cfg2 on the host: {n2q / t2:.2f} q/s on 1 core, {64 / w2:.1f} q/s on {min(cores, 64)} threads; GPU==CPU bitwise: {bad2 == 0}")
+            del Xh
+
+        # ---- k-means on the host: assign_to_clusters on all cores (= rayon par_iter, ivfflat.rs:31),
+        # update_centroids + calculate_kmeans_cost serial like the reference; a bounded sample of N = 1M, k = nlist, same d
+        n_km = min(n, 1_000_000)
+        Xk = torch.empty(n_km, ld, dtype=torch.float32, device=dev)
+        capi.gen_rows_dev(Xk.data_ptr(), n_km, d, ld, 1, SEED_X, SEED_C, n_modes, sigma)
+        Xkh = np.ascontiguousarray(Xk[:, :d].cpu().numpy())
+        del Xk
+        chunk = 4
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(max_workers=cores) as ex:   # first wave: one small task per thread -> the rate
+            first = list(ex.map(lambda i: co.assign_to_clusters(Xkh[i * chunk:(i + 1) * chunk], cent), range(cores)))
+        rate = cores * chunk / (time.perf_counter() - t0)
+        n_as = int(min(n_km, max(cores * chunk, rate * args.cpu_seconds)))
+        per = max(1, n_as // (cores * 4))
+        n_as = per * (n_as // per)
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(max_workers=cores) as ex:
+            parts = list(ex.map(lambda i: co.assign_to_clusters(Xkh[i * per:(i + 1) * per], cent), range(n_as // per)))
+        t_as = time.perf_counter() - t0
+        a_cpu = np.concatenate(parts)
+        a_gpu = capi.kmeans_assign(Xkh[:n_as], cent, device=dev_index)
+        n_uc = min(n_km, 200_000)   # serial legs: a chain of d dependent adds per row (~1 us at d = 768)
+        a_all = capi.kmeans_assign(Xkh[:n_uc], cent, device=dev_index)
+        t0 = time.perf_counter(); c_cpu = co.update_centroids(Xkh[:n_uc], a_all, nlist); t_up = time.perf_counter() - t0
+        t0 = time.perf_counter(); cost_cpu = co.kmeans_cost(Xkh[:n_uc], cent, a_all); t_co = time.perf_counter() - t0
+        c_gpu = capi.kmeans_update(Xkh[:n_uc], a_all, nlist, device=dev_index)
+        cost_gpu = capi.kmeans_cost(Xkh[:n_uc], cent, a_all, device=dev_index)
+        pass_flop = 2.0 * n_as * nlist * d
+        cpu_km = {"assign_to_clusters": {"points": n_as, "k": nlist, "d": d, "seconds": round(t_as, 2), "cores": cores,
+                                         "points_per_sec": round(n_as / t_as, 1), "gflops_2nkd": round(pass_flop / t_as / 1e9, 1),
+                                         "seconds_per_pass_at_N_1M": round(1e6 / (n_as / t_as), 1),
+                                         "seconds_per_pass_extrapolated_cfg5": round(50e6 * 65536 / (n_as * nlist / t_as), 0),
+                                         "gpu_matches_cpu": bool(np.array_equal(a_cpu, a_gpu))},
+                  "update_centroids": {"points": n_uc, "seconds": round(t_up, 3), "cores": 1, "seconds_per_pass_at_N_1M": round(t_up * 1e6 / n_uc, 2),
+                                       "gpu_matches_cpu_bitwise": bool(np.array_equal(c_cpu.view(np.uint32), c_gpu.view(np.uint32)))},
+                  "calculate_kmeans_cost": {"points": n_uc, "seconds": round(t_co, 3), "cores": 1, "seconds_per_pass_at_N_1M": round(t_co * 1e6 / n_uc, 2),
+                                            "gpu_matches_cpu_bitwise": bool(np.float32(cost_cpu).view(np.uint32) == np.float32(cost_gpu).view(np.uint32))},
+                  "kind": "port", "cpu_model": model,
+                  "sample": f"rows 0..{n_as} of the bench corpus against the index's {nlist} centroids for assign (all {cores} threads, one slice per task), "
+                            f"rows 0..{n_uc} for the serial update / cost; C restatement of ivfflat.rs:29-71,138-149 (vo_assign / vo_update / vo_cost)"}
+        log(f"[bench] k-means on the host: assign {n_as} points x {nlist} centroids in {t_as:.1f} s on {cores} threads = {pass_flop / t_as / 1e9:.0f} GFLOP/s "
+            f"(GPU == CPU: {cpu_km['assign_to_clusters']['gpu_matches_cpu']}); update {t_up:.2f} s, cost {t_co:.2f} s for {n_uc} points on 1 core")
+        del Xkh
 
     if rank == 0:
         out = {"metric": "queries/sec + recall@10, IVFFlat N=10M d=768", "value": round(qps, 1), "unit": "queries/sec",
@@ -527,10 +734,10 @@ def main():
                "config": {"workload": f"IVFFlat search_approximate, {'nprobe extension' if nprobe else 'reference mode (nearest list + spill)'}: N={n} d={d} nlist={nlist} nprobe={nprobe} "
                                       f"batch={B} top_k={top_k}, f32, clustered unit vectors (Dist-C)",
                           "n": n, "d": d, "nlist": nlist, "nprobe": nprobe, "batch": B, "top_k": top_k,
-                          "kmeans_iters": int(index.iterations[0]), "parallelism": f"lists sharded over {world} GPU(s)"},
-               "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_all_cores": cpu_all, "extra": extra}
+                          "kmeans_iters": int(index.iterations[0]), "parallelism": f"lists sharded over {world} GPU(s)", "batches_in_flight": S},
+               "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_all_cores": cpu_all, "cpu_baseline_kmeans": cpu_km, "extra": extra}
         if shadow and "list_scan_f32_rows" in extra:
-            out["value_f32_rows"] = extra["list_scan_f32_rows"]["whole_step_queries_per_sec"]  # the same step with VERS_SHADOW=0 (8 batches, untimed region)
+            out["value_f32_rows"] = extra["list_scan_f32_rows"]["whole_step_queries_per_sec"]  # the same steps with VERS_SHADOW=0, timed like the headline, after it
         if shadow:
             out["result_precision"] = ("every returned id, order and distance is the reference's exact f32 result (compared bitwise with the CPU restatement in "
                                         "this run: cpu_baseline.gpu_matches_cpu_bitwise); the dominant kernel PRE-SELECTS candidates on an fp16 copy of the rows and "
