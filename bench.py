@@ -59,7 +59,7 @@ def main():
     ap.add_argument("--no-recall", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the untimed extra measurements (single query, coarse GEMM, flat cfg2, Dist-U recall)")
     ap.add_argument("--f32-rows", action="store_true", help="no fp16 shadow: the f32 rows feed the batched list scan (round 1's configuration; same as VERS_SHADOW=0)")
-    ap.add_argument("--streams", type=int, default=2, help="batches in flight: step i is queued on stream i %% S with its own outputs and workspace, so "
+    ap.add_argument("--streams", type=int, default=3, help="batches in flight: step i is queued on stream i %% S with its own outputs and workspace, so "
                     "the small latency-bound kernels of one batch (coarse quantiser, planning, exact finish) run under the list scan of "
                     "another; every step's work is inside the timed region (1 = strictly one batch after the other)")
     ap.add_argument("--ahead", action="store_true", help="compute the next batch's coarse quantiser on a side stream under the current "
@@ -390,7 +390,7 @@ def main():
                 capi.set_option("gemm_x3", 3)
         except capi.VersError:
             pass
-    def timed_steps(np_):
+    def timed_steps(np_, S=S):
         """the timed region's loop again (same warm-up, same step count, same streams) with another nprobe / row operand"""
         def stp(i):
             o = outs[i % S]
@@ -409,6 +409,18 @@ def main():
             index.poll(x.cuda_stream)
         return t_, index.scan_times(reset=True)
 
+    if rank == 0 and world == 1 and S > 1:
+        # the same steps strictly one batch after the other (--streams 1): the step's latency, and the dominant kernel's duration
+        # when nothing else shares the chip with it (in the timed region other batches' small kernels run beside it)
+        t1s, ms1s = timed_steps(nprobe, 1)
+        if len(ms1s):
+            m1 = float(np.mean(ms1s))
+            roofline["one_batch_in_flight"] = {"launch_ms": round(m1, 4), "achieved": round(algo_bytes / (m1 * 1e-3) / 1e9, 1),
+                                               "frac": round(algo_bytes / (m1 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "launches_timed": int(len(ms1s)),
+                                               "whole_step_ms": round(t1s / args.steps * 1e3, 4), "whole_step_queries_per_sec": round(args.steps * B / t1s, 1),
+                                               "note": f"the same {args.steps} steps on ONE stream (after the timed region): the kernel alone on the chip; "
+                                                       f"the headline keeps {S} batches in flight and its launch_ms includes what runs beside the scan"}
+            log(f"[bench] one batch in flight: {t1s / args.steps * 1e3:.3f} ms per step, list scan {m1:.3f} ms = {roofline['one_batch_in_flight']['frac']} of peak")
     if rank == 0 and world == 1 and not args.no_extra and shadow:
         # the same steps with the f32 rows feeding the list scan (round 1's kernel; same index, same results): what the shadow
         # buys, and SURVEY 8d's f32-row figure of the headline -- same warm-up, step count and streams as the timed region
@@ -694,7 +706,7 @@ def main():
         with ThreadPoolExecutor(max_workers=cores) as ex:   # first wave: one small task per thread -> the rate
             first = list(ex.map(lambda i: co.assign_to_clusters(Xkh[i * chunk:(i + 1) * chunk], cent), range(cores)))
         rate = cores * chunk / (time.perf_counter() - t0)
-        n_as = int(min(n_km, max(cores * chunk, rate * args.cpu_seconds)))
+        n_as = int(min(n_km, max(cores * chunk, 0.3 * rate * args.cpu_seconds)))  # (the first wave runs hot in cache: the long run is ~3x slower per point)
         per = max(1, n_as // (cores * 4))
         n_as = per * (n_as // per)
         t0 = time.perf_counter()

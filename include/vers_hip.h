@@ -43,8 +43,9 @@ extern "C" {
 #define VERS_METRIC_L2SQ 0    /* Vector::squared_euclidean, base.rs:119-126 (what IVFFlat uses) */
 #define VERS_METRIC_COSDIST 1 /* Vector::cosine_similarity(normalized=true) = 1 - dot, base.rs:153-155 */
 
-#define VERS_MAX_TOPK 64 /* one key per lane: the width of the brute-force scans (vers_flat_*, vers_ivf_search_exhaustive*).
-                          * vers_ivf_search* take any top_k and nprobe: beyond 64 the result comes 64 ranks per pass. */
+#define VERS_MAX_TOPK 64 /* one key per lane: the width of a result list inside the kernels.  NOT a limit of any entry point:
+                          * every search takes any top_k (and nprobe) like the reference; beyond 64 the result comes 64 ranks
+                          * per pass. */
 
 /* Thread-local description of the most recent failure on this thread. */
 const char* vers_last_error(void);
@@ -68,8 +69,7 @@ int32_t vers_flat_upload(vers_flat_t* h, const float* rows, uint64_t n, uint64_t
  * copy in the scan layout (lane-transposed 64-row tiles); the caller's buffer can be freed. */
 int32_t vers_flat_upload_dev(vers_flat_t* h, const float* rows_dev, uint64_t n, uint64_t ld_floats);
 /* b queries (pitch q_stride_bytes).  out_ids/out_dist: [b * top_k], row q at
- * q*top_k; out_count[q] = min(top_k, n) results written for query q.
- * top_k <= VERS_MAX_TOPK. */
+ * q*top_k; out_count[q] = min(top_k, n) results written for query q.  Any top_k (utils.rs:79 `take(k)` has no cap). */
 int32_t vers_flat_search(vers_flat_t* h, const float* queries, uint64_t q_stride_bytes, uint32_t b,
                          uint32_t top_k, uint32_t metric, uint64_t* out_ids, float* out_dist,
                          uint32_t* out_count);
@@ -174,8 +174,9 @@ int32_t vers_ivf_add(vers_ivf_t* h, const float* row, uint64_t* out_cluster, uin
  *                 nearest lists, one global stable order by (distance, probe rank, list position).
  * out_ids/out_dist [b*top_k], out_count[q] results for query q.  Any top_k and nprobe (like the reference: its walk has
  * no cap); top_k <= 54 and nprobe <= 64 is the fast domain (matrix-core list scan), wider results take one ordered-chain
- * pass per 64 ranks.  Reference mode through the host-pointer call follows the spill through ALL lists if it must; a
- * device-pointer call ranks 48 lists and latches VERS_ERR_INVALID (vers_ivf_poll) when the spill would run past them. */
+ * pass per 64 ranks.  Reference mode follows the spill through ALL lists if it must (like the reference's walk): the
+ * host-pointer call retries deeper, a device-pointer call -- which cannot come back -- ranks up front as many lists as the
+ * list lengths can make the walk need (48 unless the index holds that many near-empty lists). */
 int32_t vers_ivf_search(vers_ivf_t* h, const float* queries, uint64_t q_stride_bytes, uint32_t b,
                         uint32_t top_k, uint32_t nprobe, uint64_t* out_ids, float* out_dist,
                         uint32_t* out_count);

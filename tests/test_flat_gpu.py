@@ -69,10 +69,31 @@ def test_flat_edge_cases():
     assert e.value.status == capi.ERR_NAN
     ids, dist, cnt = fc.search(X[0], 3)   # the latch is cleared, the handle still works
     assert ids[0, 0] == 0
-    # unsupported top_k
-    with pytest.raises(capi.VersError) as e:
-        fc.search(X[0], 65)
-    assert e.value.status == capi.ERR_INVALID
+    # top_k beyond one key per lane: 64 ranks per pass, still min(top_k, n) results (utils.rs:79 take(k) has no cap)
+    ids, dist, cnt = fc.search(X[0], 65)
+    assert cnt[0] == 50 and sorted(ids[0, :50]) == list(range(50))
+    fc.close()
+
+
+def test_flat_results_wider_than_a_wave():
+    """utils::search_exhaustive (utils.rs:68-82) takes ANY k: stable sort of all n distances, take(k).  top_k in {65, 256, 1000}
+    comes 64 ranks per pass on the device; single query and batch, both metrics, against the oracle bit for bit."""
+    n, d = 3000, 40
+    X = dg.dist_c(0x41, n, d, 30, dg.default_sigma(d))
+    X[100] = X[7]; X[2000] = X[7]                      # exact duplicates: ties are ordered by index across pass boundaries too
+    Q = np.concatenate([dg.dist_c(0x42, 4, d, 30, dg.default_sigma(d)), X[7:8]])
+    fc = capi.FlatCorpus(d)
+    fc.upload(X)
+    for metric in (0, 1):
+        for top_k in (65, 256, 1000, 3500):
+            ids, dist, cnt = fc.search(Q, top_k, metric)
+            i1, d1, c1 = fc.search(Q[4], top_k, metric)
+            for qi in range(Q.shape[0]):
+                oi, od = co.search_exhaustive(X, Q[qi], top_k, metric)
+                m = min(top_k, n)
+                assert cnt[qi] == m and len(oi) == m
+                assert np.array_equal(ids[qi, :m], oi) and np.array_equal(bits(dist[qi, :m]), bits(od)), (metric, top_k, qi)
+            assert c1[0] == min(top_k, n) and np.array_equal(i1[0, :c1[0]], ids[4, :c1[0]]) and np.array_equal(bits(d1[0, :c1[0]]), bits(dist[4, :c1[0]]))
     fc.close()
 
 

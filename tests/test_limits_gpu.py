@@ -63,6 +63,24 @@ def test_reference_spill_through_more_than_64_empty_lists():
     with pytest.raises(capi.VersError) as e:               # more results than vectors: the reference panics (index out of bounds)
         ix.search_batch(Q[:1], n + 1, 0)
     assert e.value.status == capi.ERR_INSUFFICIENT
+    # the DEVICE-pointer entry cannot come back for a deeper ranking: it ranks as deep as the list lengths can make the walk
+    # need (here: through all 140 empty lists) instead of latching INVALID as round 2 did past 48 lists
+    import torch
+    Qd = torch.from_numpy(Q).cuda()
+    for top_k in (10, 80, 590):
+        for b in (6, 1):
+            ids = torch.zeros(b, top_k, dtype=torch.int64, device="cuda"); dist = torch.zeros(b, top_k, device="cuda"); cnt = torch.zeros(b, dtype=torch.int32, device="cuda")
+            ix.search_dev(Qd.data_ptr(), d, b, top_k, 0, ids.data_ptr(), dist.data_ptr(), cnt.data_ptr())
+            ix.poll()
+            gi, gd, gc = ids.cpu().numpy().astype(np.uint64), dist.cpu().numpy(), cnt.cpu().numpy()
+            for qi in range(b):
+                oi, od = co.search_approximate(ix.values, ix.centroids, ix.ids, Q[qi], top_k)
+                assert gc[qi] == len(oi) and np.array_equal(gi[qi, :len(oi)], oi) and np.array_equal(bits(gd[qi, :len(oi)]), bits(od)), (top_k, b, qi)
+    ids = torch.zeros(1, n + 1, dtype=torch.int64, device="cuda"); dist = torch.zeros(1, n + 1, device="cuda"); cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
+    ix.search_dev(Qd.data_ptr(), d, 1, n + 1, 0, ids.data_ptr(), dist.data_ptr(), cnt.data_ptr())
+    with pytest.raises(capi.VersError) as e:
+        ix.poll()
+    assert e.value.status == capi.ERR_INSUFFICIENT
     ix.close()
 
 
@@ -94,3 +112,43 @@ def test_cross_gpu_merge_of_wide_partials():
     for ix in shards:
         ix.close()
     whole.close()
+
+
+def test_exhaustive_over_the_index_wider_than_a_wave():
+    """vers_ivf_search_exhaustive* = utils::search_exhaustive (utils.rs:68-82) over the index's own values: any top_k, 64 ranks per
+    pass; the sharded partial + merge path likewise (ranks split over three handles)."""
+    import torch
+    n, d, k = 2500, 24, 12
+    X = dg.dist_c(0x731, n, d, 36, dg.default_sigma(d))
+    X[40] = X[9]; X[1900] = X[9]
+    ix = IVFFlatIndex.build_index(k, 1, 3, X, init_indices=mg.init_draws(0x731, 1, k, n))
+    ix.add(X[9].copy())                                          # a third duplicate, in an `add` slot
+    vals = ix.values
+    Q = np.concatenate([dg.dist_c(0x732, 3, d, 36, dg.default_sigma(d)), X[9:10]])
+    for metric in (0, 1):
+        for top_k in (65, 256, 1000):
+            ids, dist, cnt = ix.search_exhaustive(Q, top_k, metric)
+            for q in range(Q.shape[0]):
+                oi, od = co.search_exhaustive(vals, Q[q], top_k, metric)
+                assert cnt[q] == len(oi) and np.array_equal(ids[q, :len(oi)], oi) and np.array_equal(bits(dist[q, :len(oi)]), bits(od)), (metric, top_k, q)
+    # sharded: every rank ranks its own rows, one gather + vers_topk_merge_dev gives the whole corpus's answer
+    world, b, top_k = 3, Q.shape[0], 200
+    shards = []
+    for r in range(world):
+        s = IVFFlatIndex(d); s.set_shard(r, world)
+        s.values, s.centroids, s.assignments = ix.values, ix.centroids, ix.assignments
+        s._upload(); shards.append(s)
+    Qd = torch.from_numpy(Q).cuda()
+    keys = torch.empty(world, b, top_k, dtype=torch.int64, device="cuda"); idb = torch.empty(world, b, top_k, dtype=torch.int64, device="cuda")
+    for r, s in enumerate(shards):
+        s.search_exhaustive_partial_dev(Qd.data_ptr(), d, b, top_k, 0, keys[r].data_ptr(), idb[r].data_ptr()); s.poll()
+    oi_ = torch.zeros(b, top_k, dtype=torch.int64, device="cuda"); od_ = torch.zeros(b, top_k, device="cuda"); oc_ = torch.zeros(b, dtype=torch.int32, device="cuda")
+    IVFFlatIndex.merge_partials_dev(keys.data_ptr(), idb.data_ptr(), b * top_k, world, b, top_k, 1, oi_.data_ptr(), od_.data_ptr(), oc_.data_ptr())
+    torch.cuda.synchronize()
+    gi, gd, gc = oi_.cpu().numpy().astype(np.uint64), od_.cpu().numpy(), oc_.cpu().numpy()
+    for q in range(b):
+        oi, od = co.search_exhaustive(vals, Q[q], top_k, 0)
+        assert gc[q] == len(oi) and np.array_equal(gi[q, :len(oi)], oi) and np.array_equal(bits(gd[q, :len(oi)]), bits(od)), q
+    for s in shards:
+        s.close()
+    ix.close()

@@ -46,21 +46,23 @@ struct FlatSrc {
   __device__ __forceinline__ uint32_t bound_slot(uint32_t it, int qi) const { return (it / n_segs_pad) * QG + qi; }
 };
 
-// one block per query: top-k of its n_segs partial slots -> (id, dist)
-__global__ __launch_bounds__(kWave * kMergeWaves) void flat_merge_kernel(const uint64_t* partials, uint32_t n_segs,
-                                                                         uint32_t k, uint64_t n, uint64_t* out_ids,
-                                                                         float* out_dist, uint32_t* out_count) {
+// one block per query: the k smallest keys of its n_segs partial slots -> (id, dist) at ranks rank0 .. rank0 + k - 1 of output
+// row q (pitch top_k).  top_k > 64 comes 64 ranks per pass (ScanParams::lower): this pass's last key is the next one's bound.
+__global__ __launch_bounds__(kWave * kMergeWaves) void flat_merge_kernel(const uint64_t* partials, uint32_t n_segs, uint32_t k, uint64_t n,
+                                                                         uint32_t top_k, uint32_t rank0, uint64_t* out_ids, float* out_dist,
+                                                                         uint32_t* out_count, uint64_t* lower_out) {
   __shared__ uint64_t sh[kMergeWaves][kWave];
   const uint32_t q = blockIdx.x;
   uint64_t list = block_merge_keys(partials + (uint64_t)q * n_segs * k, n_segs * k, k, sh);
   if (threadIdx.x >= kWave) return;
   const int lane = threadIdx.x;
-  const uint32_t cnt = n < k ? (uint32_t)n : k;
-  if (lane < (int)cnt) {
-    out_ids[(uint64_t)q * k + lane] = (uint32_t)list;
-    out_dist[(uint64_t)q * k + lane] = __uint_as_float(order_bits_to_f32_bits((uint32_t)(list >> 32)));
+  const uint32_t total = n < top_k ? (uint32_t)n : top_k;  // utils.rs:79 take(k) of n sorted rows
+  if (lane < (int)k && rank0 + (uint32_t)lane < total) {
+    out_ids[(uint64_t)q * top_k + rank0 + lane] = (uint32_t)list;
+    out_dist[(uint64_t)q * top_k + rank0 + lane] = __uint_as_float(order_bits_to_f32_bits((uint32_t)(list >> 32)));
   }
-  if (lane == 0) out_count[q] = cnt;
+  if (lower_out != nullptr && lane == (int)k - 1) lower_out[q] = list;  // (kKeyMax when the rows ran out: the next pass finds nothing)
+  if (lane == 0 && rank0 == 0) out_count[q] = total;
 }
 
 }  // namespace vers
@@ -83,6 +85,8 @@ struct vers_flat {
   uint32_t zero_q_len = 0;
   uint64_t* partials = nullptr;  // partial slots, then one pruning bound per query
   size_t partials_cap = 0;
+  uint64_t* lower = nullptr;     // top_k > 64: the previous pass's last key per query
+  size_t lower_cap = 0;
   size_t bounds_off = 0;
   uint32_t* status_dev = nullptr;
   uint64_t* o_ids = nullptr;
@@ -97,7 +101,7 @@ struct vers_flat {
 namespace {
 
 template <int QG, int METRIC>
-int32_t launch_flat_scan(vers_flat* h, const FlatSrc<QG, false>& src, uint32_t n_items, hipStream_t st) {
+int32_t launch_flat_scan(vers_flat* h, const FlatSrc<QG, false>& src, uint32_t n_items, hipStream_t st, const uint64_t* lower) {
   ScanParams p;
   p.ld = h->ld;
   p.n_chunks = h->ld / kChunk;
@@ -106,17 +110,18 @@ int32_t launch_flat_scan(vers_flat* h, const FlatSrc<QG, false>& src, uint32_t n
   p.debug = scan_debug_flags();
   p.stamps = nullptr;
   p.next_quad = nullptr;
-  p.bounds = nullptr; p.lower = nullptr;  // every item of a query runs concurrently here: a shared bound prunes nothing and its atomics contend
+  p.bounds = nullptr;  // every item of a query runs concurrently here: a shared bound prunes nothing and its atomics contend
+  p.lower = lower;     // (top_k > 64: ranks 64p .. 64p + 63 in pass p)
   const size_t lds = scan_lds_bytes(QG, h->ld);
   if (int32_t rc = scan_prepare_launch(scan_kernel<QG, METRIC, FlatSrc<QG, false>>, lds)) return rc;
   const uint32_t max_blocks = (uint32_t)h->n_cu * scan_blocks_per_cu(QG, h->ld);
   uint32_t blocks = (n_items + kWavesPerBlock - 1) / kWavesPerBlock;
   if (blocks > max_blocks) blocks = max_blocks;
   if (blocks == 0) blocks = 1;
-  VERS_HIP_TRY(hipEventRecord(h->ev0, st));
+  if (lower == nullptr) VERS_HIP_TRY(hipEventRecord(h->ev0, st));  // (the measurement hook times the first pass)
   hipLaunchKernelGGL((scan_kernel<QG, METRIC, FlatSrc<QG, false>>), dim3(blocks), dim3(kWave * kWavesPerBlock), lds, st, src, p);
   VERS_HIP_TRY(hipGetLastError());
-  VERS_HIP_TRY(hipEventRecord(h->ev1, st));
+  if (lower == nullptr) VERS_HIP_TRY(hipEventRecord(h->ev1, st));
   h->ev_valid = true;
   return VERS_OK;
 }
@@ -149,35 +154,43 @@ int32_t flat_search_dev_locked(vers_flat* h, const float* q_dev, uint64_t ldq, u
   uint32_t seg_rows = (uint32_t)std::min<uint64_t>(round_up64(per ? per : 1, kWave), max_seg_rows(h->ld));
   uint32_t n_segs = (uint32_t)((h->n + seg_rows - 1) / seg_rows);
   if (n_segs == 0) n_segs = 1;
-  h->bounds_off = (size_t)b * n_segs * top_k;
+  // one key per lane is the width of every list in the kernels: wider results come 64 ranks per pass -- keys are unique and
+  // totally ordered, pass p holds exactly ranks 64p .. 64p + 63, selected by an exclusive lower bound (utils.rs:68-82 has no cap)
+  const uint32_t k_w = std::min<uint32_t>(top_k, kMaxTopK);
+  h->bounds_off = (size_t)b * n_segs * k_w;
   if (int32_t rc = grow(h->partials, h->partials_cap, h->bounds_off + (size_t)n_qg * QG)) return rc;
   VERS_HIP_TRY(hipMemsetAsync(h->partials + h->bounds_off, 0xFF, (size_t)n_qg * QG * sizeof(uint64_t), st));
+  if (top_k > (uint32_t)kMaxTopK)
+    if (int32_t rc = grow(h->lower, h->lower_cap, (size_t)b)) return rc;
   const uint32_t n_segs_pad = QG == 1 ? n_segs : round_up(n_segs, 4);
   const uint32_t n_items = n_segs_pad * n_qg;
 
-  auto fill = [&](auto& src) {
-    src.rows = h->rows; src.n = h->n; src.ld = h->ld; src.seg_rows = seg_rows; src.n_segs = n_segs; src.n_segs_pad = n_segs_pad;
-    src.queries = q; src.ldq = ldq_use; src.b = b; src.partials = h->partials;
-    src.k = top_k; src.ids = nullptr;
-  };
-  int32_t rc;
-  if (QG == 1) {
-    FlatSrc<1, false> src; fill(src);
-    rc = metric == VERS_METRIC_L2SQ ? launch_flat_scan<1, 0>(h, src, n_items, st) : launch_flat_scan<1, 1>(h, src, n_items, st);
-  } else {
-    FlatSrc<8, false> src; fill(src);
-    rc = metric == VERS_METRIC_L2SQ ? launch_flat_scan<8, 0>(h, src, n_items, st) : launch_flat_scan<8, 1>(h, src, n_items, st);
+  for (uint32_t rank0 = 0; rank0 < top_k; rank0 += kMaxTopK) {
+    const uint32_t k_pass = std::min<uint32_t>(kMaxTopK, top_k - rank0);
+    const uint64_t* lower = rank0 ? h->lower : nullptr;
+    auto fill = [&](auto& src) {
+      src.rows = h->rows; src.n = h->n; src.ld = h->ld; src.seg_rows = seg_rows; src.n_segs = n_segs; src.n_segs_pad = n_segs_pad;
+      src.queries = q; src.ldq = ldq_use; src.b = b; src.partials = h->partials;
+      src.k = k_pass; src.ids = nullptr;
+    };
+    int32_t rc;
+    if (QG == 1) {
+      FlatSrc<1, false> src; fill(src);
+      rc = metric == VERS_METRIC_L2SQ ? launch_flat_scan<1, 0>(h, src, n_items, st, lower) : launch_flat_scan<1, 1>(h, src, n_items, st, lower);
+    } else {
+      FlatSrc<8, false> src; fill(src);
+      rc = metric == VERS_METRIC_L2SQ ? launch_flat_scan<8, 0>(h, src, n_items, st, lower) : launch_flat_scan<8, 1>(h, src, n_items, st, lower);
+    }
+    if (rc) return rc;
+    hipLaunchKernelGGL(flat_merge_kernel, dim3(b), dim3(kWave * kMergeWaves), 0, st, h->partials, n_segs, k_pass, h->n, top_k, rank0, out_ids,
+                       out_dist, out_count, top_k > (uint32_t)kMaxTopK ? h->lower : (uint64_t*)nullptr);
+    VERS_HIP_TRY(hipGetLastError());
   }
-  if (rc) return rc;
-  hipLaunchKernelGGL(flat_merge_kernel, dim3(b), dim3(kWave * kMergeWaves), 0, st, h->partials, n_segs, top_k, h->n, out_ids, out_dist,
-                     out_count);
-  VERS_HIP_TRY(hipGetLastError());
   return VERS_OK;
 }
 
 int32_t check_args(vers_flat* h, uint32_t top_k, uint32_t metric) {
   if (!h) return fail(VERS_ERR_INVALID, "null handle");
-  if (top_k > VERS_MAX_TOPK) return fail(VERS_ERR_INVALID, "top_k > VERS_MAX_TOPK (64) is not supported");
   if (metric > VERS_METRIC_COSDIST) return fail(VERS_ERR_INVALID, "unknown metric");
   if (h->n > 0xFFFFFFFFull) return fail(VERS_ERR_INVALID, "more than 2^32-1 rows per handle");
   return VERS_OK;
@@ -217,7 +230,7 @@ int32_t vers_flat_destroy(vers_flat_t* h) {
   DeviceGuard g(h->device);
   (void)hipDeviceSynchronize();
   if (h->rows) (void)hipFree(h->rows);
-  for (void* p : {(void*)h->q_stage, (void*)h->q_up, (void*)h->zero_q, (void*)h->partials, (void*)h->status_dev, (void*)h->o_ids,
+  for (void* p : {(void*)h->q_stage, (void*)h->q_up, (void*)h->zero_q, (void*)h->partials, (void*)h->lower, (void*)h->status_dev, (void*)h->o_ids,
                   (void*)h->o_dist, (void*)h->o_cnt})
     if (p) (void)hipFree(p);
   if (h->ev0) (void)hipEventDestroy(h->ev0);

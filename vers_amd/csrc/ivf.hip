@@ -538,10 +538,11 @@ __global__ __launch_bounds__(kWave * kMergeWaves) void ivf_merge_kernel(
   if (w0 && lane == 0 && written != 0xFFFFFFFFu && (ref_mode ? rank0 == 0 : true)) out_count[q] = written;
 }
 
-// exhaustive merge for the IVF handle (seq == vec_id already)
-__global__ __launch_bounds__(kWave * kMergeWaves) void seg_merge_kernel(const uint64_t* partials, uint32_t n_segs, uint32_t k,
-                                                                        uint64_t* out_ids, float* out_dist,
-                                                                        uint32_t* out_count) {
+// exhaustive merge for the IVF handle (seq == vec_id already): ranks rank0 .. rank0 + k - 1 of output row q (pitch top_k);
+// top_k > 64 comes 64 ranks per pass (ScanParams::lower)
+__global__ __launch_bounds__(kWave * kMergeWaves) void seg_merge_kernel(const uint64_t* partials, uint32_t n_segs, uint32_t k, uint32_t top_k,
+                                                                        uint32_t rank0, uint64_t* out_ids, float* out_dist,
+                                                                        uint32_t* out_count, uint64_t* lower_out) {
   __shared__ uint64_t sh[kMergeWaves][kWave];
   const uint32_t q = blockIdx.x;
   uint64_t list = block_merge_keys(partials + (uint64_t)q * n_segs * k, n_segs * k, k, sh);
@@ -549,11 +550,12 @@ __global__ __launch_bounds__(kWave * kMergeWaves) void seg_merge_kernel(const ui
   const int lane = threadIdx.x;
   const bool have = lane < (int)k && list != kKeyMax;
   if (have) {
-    out_ids[(uint64_t)q * k + lane] = (uint32_t)list;
-    out_dist[(uint64_t)q * k + lane] = __uint_as_float(order_bits_to_f32_bits((uint32_t)(list >> 32)));
+    out_ids[(uint64_t)q * top_k + rank0 + lane] = (uint32_t)list;
+    out_dist[(uint64_t)q * top_k + rank0 + lane] = __uint_as_float(order_bits_to_f32_bits((uint32_t)(list >> 32)));
   }
+  if (lower_out != nullptr && lane == (int)k - 1) lower_out[q] = list;  // (kKeyMax when the rows ran out: the next pass finds nothing)
   const uint32_t cnt = (uint32_t)__popcll(__ballot(have));
-  if (lane == 0) out_count[q] = cnt;
+  if (lane == 0 && (rank0 == 0 || cnt)) out_count[q] = rank0 + cnt;
 }
 
 // cross-GPU merge of per-rank partial results ([world][b][k] keys + ids, kKeyMax padded): one wave per query.
@@ -754,6 +756,15 @@ struct vers_ivf {
   DevBuf list_slot;        // [k] centroid index -> slot
   DevBuf slot_off, slot_len;  // list_off / list_len in slot order
   std::vector<uint32_t> h_slot;
+  // Reference mode from device pointers cannot come back for a deeper ranking (the host-pointer entry retries; a _dev call
+  // only latches a status), so the depth is decided UP FRONT from what the host knows: the walk of ivfflat.rs:166-195 stops
+  // once top_k rows are gathered, and ANY P lists hold at least the sum of the P SHORTEST lists' lengths.  len_asc_prefix[i]
+  // = rows in the i + 1 shortest lists (as of build / upload; add() only lengthens lists, the bound stays valid).
+  std::vector<uint64_t> len_asc_prefix;
+  uint32_t lists_that_always_suffice(uint32_t top_k) const {  // smallest P such that every set of P lists holds >= top_k rows (k if none)
+    const auto it = std::lower_bound(len_asc_prefix.begin(), len_asc_prefix.end(), (uint64_t)top_k);
+    return it == len_asc_prefix.end() ? (uint32_t)len_asc_prefix.size() : (uint32_t)(it - len_asc_prefix.begin()) + 1u;
+  }
   std::vector<uint32_t> h_off, h_len, h_cap;  // h_len = GLOBAL list lengths; h_off/h_cap only meaningful for owned lists
   // sharding by cluster across GPUs (one process per GPU): this handle stores only lists with owner == rank
   uint32_t rank = 0, world = 1;
@@ -1123,6 +1134,13 @@ int32_t plan_storage(vers_ivf* h, const uint32_t* lens, uint32_t k, hipStream_t 
       VERS_HIP_TRY(hipMemcpy(h->slot_off.p, so.data(), (size_t)k * 4, hipMemcpyHostToDevice));
       VERS_HIP_TRY(hipMemcpy(h->slot_len.p, sl.data(), (size_t)k * 4, hipMemcpyHostToDevice));
     }
+  }
+  {
+    std::vector<uint32_t> asc(h->h_len);
+    std::sort(asc.begin(), asc.end());
+    h->len_asc_prefix.assign(k, 0);
+    uint64_t run = 0;
+    for (uint32_t i = 0; i < k; ++i) { run += asc[i]; h->len_asc_prefix[i] = run; }
   }
   h->cap_rows = off;
   if (int32_t rc = h->rows.reserve((off ? off : 1) * (size_t)h->ld * sizeof(float))) return rc;
@@ -1852,8 +1870,11 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
   // reference mode ranks the 48 nearest lists (48 + 16 slack = one key per lane in the MFMA pre-selection);
   // a spill deeper than that is refused (kStSpillTooDeep) -- it needs > 47 consecutive near-empty lists
   // (host-pointer calls retry deeper: 16, 48, 64 and finally ALL lists, W->ref_all -- the reference walks as far as it must)
-  const uint32_t P = ref_mode ? std::min<uint32_t>(h->k, W->ref_all ? h->k : (W->ref_deep ? 64u : (W->ref_shallow ? 16u : 48u)))
-                              : std::min<uint32_t>(nprobe, h->k);
+  uint32_t P_ref = W->ref_all ? h->k : (W->ref_deep ? 64u : (W->ref_shallow ? 16u : 48u));
+  // a device-pointer call cannot retry: it ranks as many lists as the list lengths can make the walk need (vers_ivf::len_asc_prefix)
+  // -- 48 unless the index has that many near-empty lists; then the exact ranking runs 64 ranks per pass
+  if (ref_mode && W->st_slot == 0) P_ref = std::max<uint32_t>(P_ref, h->lists_that_always_suffice(top_k));
+  const uint32_t P = ref_mode ? std::min<uint32_t>(h->k, P_ref) : std::min<uint32_t>(nprobe, h->k);
   // one key per lane is the width of every list in the kernels: more ranked lists (P > 64) or more results (top_k > 64)
   // are produced 64 ranks per pass (ScanParams::lower), on the ordered-chain kernels
   const bool one1 = b == 1 && P <= (uint32_t)kMaxTopK;  // single query: coarse merge + plan fused in plan1_kernel
@@ -2148,30 +2169,36 @@ int32_t exhaustive_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, 
   const uint32_t seg_rows = (uint32_t)std::min<uint64_t>(round_up64(per ? per : 1, kWave), max_seg_rows(h->ld));
   uint32_t n_segs = (uint32_t)((h->cap_rows + seg_rows - 1) / seg_rows);
   if (n_segs == 0) n_segs = 1;
-  if (int32_t rc = W->xpart.reserve((size_t)b * n_segs * top_k * sizeof(uint64_t))) return rc;
+  const uint32_t k_w = std::min<uint32_t>(top_k, kMaxTopK);  // one key per lane; wider results: 64 ranks per pass (utils.rs:68-82 has no cap)
+  if (int32_t rc = W->xpart.reserve((size_t)b * n_segs * k_w * sizeof(uint64_t))) return rc;
+  if (top_k > (uint32_t)kMaxTopK)
+    if (int32_t rc = W->lower.reserve((size_t)b * sizeof(uint64_t))) return rc;
   const uint32_t n_segs_pad = QG == 1 ? n_segs : round_up(n_segs, 4);
-  auto fill = [&](auto& src) {
-    src.rows = h->rows.as<float>(); src.n = h->cap_rows; src.ld = h->ld; src.seg_rows = seg_rows; src.n_segs = n_segs;
-    src.n_segs_pad = n_segs_pad;
-    src.queries = W->qil.as<float>(); src.ldq = h->ldq; src.b = b; src.partials = W->xpart.as<uint64_t>(); src.k = top_k;
-    src.ids = h->row_ids.as<uint32_t>();
-  };
-  int32_t rc;
-  if (QG == 1) {
-    SegSrc<1, true> src; fill(src);
-    rc = launch_seg_scan(h, src, n_segs_pad * n_qg, (int)metric, st);
-  } else {
-    SegSrc<8, true> src; fill(src);
-    rc = launch_seg_scan(h, src, n_segs_pad * n_qg, (int)metric, st);
+  for (uint32_t rank0 = 0; rank0 < top_k; rank0 += kMaxTopK) {
+    const uint32_t k_pass = std::min<uint32_t>(kMaxTopK, top_k - rank0);
+    const uint64_t* lower = rank0 ? W->lower.as<uint64_t>() : nullptr;
+    auto fill = [&](auto& src) {
+      src.rows = h->rows.as<float>(); src.n = h->cap_rows; src.ld = h->ld; src.seg_rows = seg_rows; src.n_segs = n_segs;
+      src.n_segs_pad = n_segs_pad;
+      src.queries = W->qil.as<float>(); src.ldq = h->ldq; src.b = b; src.partials = W->xpart.as<uint64_t>(); src.k = k_pass;
+      src.ids = h->row_ids.as<uint32_t>();
+    };
+    int32_t rc;
+    if (QG == 1) {
+      SegSrc<1, true> src; fill(src);
+      rc = launch_seg_scan(h, src, n_segs_pad * n_qg, (int)metric, st, lower);
+    } else {
+      SegSrc<8, true> src; fill(src);
+      rc = launch_seg_scan(h, src, n_segs_pad * n_qg, (int)metric, st, lower);
+    }
+    if (rc) return rc;
+    hipLaunchKernelGGL(seg_merge_kernel, dim3(b), dim3(kWave * kMergeWaves), 0, st, W->xpart.as<uint64_t>(), n_segs, k_pass, top_k, rank0, out_ids,
+                       out_dist, out_count, top_k > (uint32_t)kMaxTopK ? W->lower.as<uint64_t>() : (uint64_t*)nullptr);
+    VERS_HIP_TRY(hipGetLastError());
   }
-  if (rc) return rc;
-  hipLaunchKernelGGL(seg_merge_kernel, dim3(b), dim3(kWave * kMergeWaves), 0, st, W->xpart.as<uint64_t>(), n_segs, top_k, out_ids,
-                     out_dist, out_count);
-  VERS_HIP_TRY(hipGetLastError());
   return VERS_OK;
 }
 
-// re-lays the storage out with fresh slack (called when a list is full)
 int32_t relayout(vers_ivf* h) {
   const uint32_t k = h->k;
   std::vector<uint32_t> noff(k), ncap(k);
@@ -2618,7 +2645,7 @@ int32_t vers_ivf_search_exhaustive_dev(vers_ivf_t* h, const float* queries_dev, 
                                        uint32_t metric, uint64_t* out_ids_dev, float* out_dist_dev, uint32_t* out_count_dev,
                                        void* stream) {
   if (!h) return fail(VERS_ERR_INVALID, "null handle");
-  if (top_k > VERS_MAX_TOPK || metric > VERS_METRIC_COSDIST) return fail(VERS_ERR_INVALID, "unsupported top_k / metric");
+  if (metric > VERS_METRIC_COSDIST) return fail(VERS_ERR_INVALID, "unknown metric");
   if (b && (!queries_dev || ldq_floats < h->d || !out_count_dev || (top_k && (!out_ids_dev || !out_dist_dev))))
     return fail(VERS_ERR_INVALID, "vers_ivf_search_exhaustive_dev: bad arguments");
   std::shared_lock<std::shared_mutex> lk(h->index);
@@ -2633,7 +2660,7 @@ int32_t vers_ivf_search_exhaustive_dev(vers_ivf_t* h, const float* queries_dev, 
 int32_t vers_ivf_search_exhaustive_partial_dev(vers_ivf_t* h, const float* queries_dev, uint64_t ldq_floats, uint32_t b, uint32_t top_k,
                                                uint32_t metric, uint64_t* out_keys_dev, uint64_t* out_ids_dev, void* stream) {
   if (!h) return fail(VERS_ERR_INVALID, "null handle");
-  if (top_k == 0 || top_k > VERS_MAX_TOPK || metric > VERS_METRIC_COSDIST) return fail(VERS_ERR_INVALID, "unsupported top_k / metric");
+  if (top_k == 0 || metric > VERS_METRIC_COSDIST) return fail(VERS_ERR_INVALID, "unsupported top_k / metric");
   if (b && (!queries_dev || ldq_floats < h->d || !out_keys_dev || !out_ids_dev))
     return fail(VERS_ERR_INVALID, "vers_ivf_search_exhaustive_partial_dev: bad arguments");
   if (b == 0) return VERS_OK;
@@ -2655,7 +2682,7 @@ int32_t vers_ivf_search_exhaustive_partial_dev(vers_ivf_t* h, const float* queri
 int32_t vers_ivf_search_exhaustive(vers_ivf_t* h, const float* queries, uint64_t q_stride_bytes, uint32_t b, uint32_t top_k,
                                    uint32_t metric, uint64_t* out_ids, float* out_dist, uint32_t* out_count) {
   if (!h) return fail(VERS_ERR_INVALID, "null handle");
-  if (top_k > VERS_MAX_TOPK || metric > VERS_METRIC_COSDIST) return fail(VERS_ERR_INVALID, "unsupported top_k / metric");
+  if (metric > VERS_METRIC_COSDIST) return fail(VERS_ERR_INVALID, "unknown metric");
   if (b && (!queries || q_stride_bytes < (uint64_t)h->d * 4 || q_stride_bytes % 4 || !out_count || (top_k && (!out_ids || !out_dist))))
     return fail(VERS_ERR_INVALID, "vers_ivf_search_exhaustive: bad arguments");
   if (b == 0) return VERS_OK;
@@ -2783,22 +2810,29 @@ int32_t vers_ivf_test_poison_slack(vers_ivf_t* h, float value) {
 
 int32_t vers_ivf_scan_times(vers_ivf_t* h, float* out_ms, uint32_t cap, uint32_t* out_n, int32_t reset) {
   if (!h || !out_n || (cap && !out_ms)) return fail(VERS_ERR_INVALID, "bad arguments");
-  UseLastWs use_ws(h);
-  if (!use_ws.ok) { *out_n = 0; return VERS_OK; }  // no search yet
-  if (!h || !out_n || (cap && !out_ms)) return fail(VERS_ERR_INVALID, "bad arguments");
   DeviceGuard g(h->device);
-  const uint64_t have = std::min<uint64_t>(W->ev_count, SearchWs::kEvRing);
-  const uint32_t n = (uint32_t)std::min<uint64_t>(have, cap);
-  for (uint32_t i = 0; i < n; ++i) {  // oldest first among the last n launches
-    const uint32_t slot = (uint32_t)((W->ev_count - n + i) % SearchWs::kEvRing);
-    VERS_HIP_TRY(hipEventSynchronize(W->ev1[slot]));
-    VERS_HIP_TRY(hipEventElapsedTime(&out_ms[i], W->ev0[slot], W->ev1[slot]));
+  // every workspace's ring (batches kept in flight on several streams lease one each); within a ring oldest first.  The
+  // caller has stopped issuing searches (a measurement hook): the rings are read without leasing.
+  std::vector<SearchWs*> all;
+  {
+    std::lock_guard<std::mutex> lk(h->pool_mu);
+    for (auto& w : h->pool) all.push_back(w.get());
+  }
+  uint32_t n = 0;
+  for (SearchWs* w : all) {
+    if (!w->done) continue;  // never initialised
+    const uint64_t have = std::min<uint64_t>(w->ev_count, SearchWs::kEvRing);
+    for (uint64_t i = 0; i < have && n < cap; ++i) {
+      const uint32_t slot = (uint32_t)((w->ev_count - have + i) % SearchWs::kEvRing);
+      VERS_HIP_TRY(hipEventSynchronize(w->ev1[slot]));
+      VERS_HIP_TRY(hipEventElapsedTime(&out_ms[n], w->ev0[slot], w->ev1[slot]));
+      ++n;
+    }
+    if (reset) w->ev_count = 0;
   }
   *out_n = n;
-  if (reset) W->ev_count = 0;
   return VERS_OK;
 }
-
 int32_t vers_ivf_get_list(vers_ivf_t* h, uint64_t cluster, float* out_rows, uint64_t row_stride_bytes, uint64_t* out_ids,
                           uint64_t cap_rows, uint64_t* out_len) {
   if (!h || cluster >= h->k || !out_len) return fail(VERS_ERR_INVALID, "vers_ivf_get_list: bad arguments");

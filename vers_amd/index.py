@@ -163,8 +163,8 @@ class IVFFlatIndex:
         check(lib().vers_ivf_test_poison_slack(self._h, C.c_float(value)))
 
     def scan_times(self, reset: bool = True):
-        ms = np.zeros(64, dtype=np.float32); n = C.c_uint32(0)
-        check(lib().vers_ivf_scan_times(self._h, _ptr(ms), 64, C.byref(n), 1 if reset else 0))
+        ms = np.zeros(1024, dtype=np.float32); n = C.c_uint32(0)   # (a ring of 64 per workspace; one workspace per stream in flight)
+        check(lib().vers_ivf_scan_times(self._h, _ptr(ms), 1024, C.byref(n), 1 if reset else 0))
         return ms[:n.value].copy()
 
     def get_list(self, cluster: int):
