@@ -310,6 +310,11 @@ int32_t vers_ivf_shadow_state(vers_ivf_t* h, int32_t* out_active, uint64_t* out_
  * device memory in production) with `value` (inf, NaN, 1e30 ...) and rebuilds the derived arrays.  Results and certificate
  * statistics must not depend on what those rows hold (tests/test_prescan_gpu.py). */
 int32_t vers_ivf_test_poison_slack(vers_ivf_t* h, float value);
+/* TEST HOOK: one wave of the matrix-core instruction a pre-filter uses, accumulated over K exactly as the kernels do, on
+ * caller-chosen operands (tests/test_mfma_model_gpu.py measures the accumulation error the certificates' bounds assume).
+ * kind 0 v_mfma_f32_32x32x16_f16, 1 v_mfma_f32_32x32x16_bf16 (A, B: 16-bit patterns), 2 v_mfma_f32_32x32x2_f32,
+ * 3 v_mfma_f32_16x16x1_4b_f32 (f32).  A [rows][K], B [K][cols] row-major; rows x cols = 32 x 32 (kind 3: 64 x 16); host pointers. */
+int32_t vers_test_mfma(int32_t device, uint32_t kind, const void* A, const void* B, uint32_t K, float* out_C);
 /* Durations (ms) of the most recent list-scan launches, oldest first (ring of 64); reset != 0
  * empties the ring.  Lets bench.py time every launch of the timed region without stalling it. */
 int32_t vers_ivf_scan_times(vers_ivf_t* h, float* out_ms, uint32_t cap, uint32_t* out_n, int32_t reset);

@@ -83,6 +83,7 @@ SIGNATURES = {
     "vers_kmeans_assign": (C.c_int32, [C.c_int32, _vp, C.c_uint64, C.c_uint64, _vp, C.c_uint64, C.c_uint64, C.c_uint32, _vp, _vp]),
     "vers_assign_stats": (C.c_int32, [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_int32]),
     "vers_build_stats": (C.c_int32, [C.POINTER(C.c_double), C.c_int32]),
+    "vers_test_mfma": (C.c_int32, [C.c_int32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_float)]),
     "vers_kmeans_update": (C.c_int32, [C.c_int32, _vp, C.c_uint64, C.c_uint64, _vp, C.c_uint64, C.c_uint32, _vp]),
     "vers_kmeans_cost": (C.c_int32, [C.c_int32, _vp, C.c_uint64, C.c_uint64, _vp, C.c_uint64, C.c_uint64, _vp, C.c_uint32,
                                      C.POINTER(C.c_float)]),
@@ -251,6 +252,20 @@ def build_stats(reset=False) -> dict:
     check(lib().vers_build_stats(v, 1 if reset else 0))
     keys = ("gemm_ms", "gemm_launches", "gemm_flop", "assign_ms", "assign_passes", "update_ms", "cost_ms", "redone_points")
     return dict(zip(keys, (float(x) for x in v)))
+
+
+def test_mfma(kind: int, A: np.ndarray, B: np.ndarray, device: int = 0) -> np.ndarray:
+    """TEST HOOK (vers_test_mfma): A [rows, K] x B [K, cols] on one wave of the matrix-core instruction `kind`, f32 result."""
+    A = np.ascontiguousarray(A); B = np.ascontiguousarray(B)
+    rows, cols = (64, 16) if kind == 3 else (32, 32)
+    assert A.shape[0] == rows and B.shape[1] == cols and A.shape[1] == B.shape[0] and A.dtype == B.dtype
+    assert A.dtype == (np.uint16 if kind <= 1 else np.float32)
+    out = np.zeros((rows, cols), dtype=np.float32)
+    check(lib().vers_test_mfma(device, kind, A.ctypes.data_as(C.c_void_p), B.ctypes.data_as(C.c_void_p), A.shape[1], _ptr(out)))
+    return out
+
+
+test_mfma.__test__ = False  # (not a pytest test)
 
 
 def set_option(name: str, value: int):
