@@ -261,7 +261,7 @@ def test_mfma(kind: int, A: np.ndarray, B: np.ndarray, device: int = 0) -> np.nd
     assert A.shape[0] == rows and B.shape[1] == cols and A.shape[1] == B.shape[0] and A.dtype == B.dtype
     assert A.dtype == (np.uint16 if kind <= 1 else np.float32)
     out = np.zeros((rows, cols), dtype=np.float32)
-    check(lib().vers_test_mfma(device, kind, A.ctypes.data_as(C.c_void_p), B.ctypes.data_as(C.c_void_p), A.shape[1], _ptr(out)))
+    check(lib().vers_test_mfma(device, kind, A.ctypes.data_as(C.c_void_p), B.ctypes.data_as(C.c_void_p), A.shape[1], out.ctypes.data_as(_fp)))
     return out
 
 
