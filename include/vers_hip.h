@@ -310,6 +310,14 @@ int32_t vers_ivf_shadow_state(vers_ivf_t* h, int32_t* out_active, uint64_t* out_
  * device memory in production) with `value` (inf, NaN, 1e30 ...) and rebuilds the derived arrays.  Results and certificate
  * statistics must not depend on what those rows hold (tests/test_prescan_gpu.py). */
 int32_t vers_ivf_test_poison_slack(vers_ivf_t* h, float value);
+/* TEST HOOK: the raw pre-filter values of query q of the most recent batched nprobe search on this handle -- every (row, val)
+ * the matrix-core list scan left in its partial lists (up to kp per probed list quad), the row as its vec_id, `val` exactly as
+ * the certificate saw it (|x|^2 - 2 <x~, q>, or -<x~, q> for the cosine distance) and the bound the certificate charges that
+ * candidate.  The test computes the reference's distance of each row and checks | val + |q|^2 - D_ref | <= bound.
+ * out_info[8]: |q|^2, max |x|^2, shadow residual R^2, the bound for rows outside the list, its candidate-independent part,
+ * kp, shadow in use, metric.  *out_n = values available (may exceed cap). */
+int32_t vers_ivf_test_last_vals(vers_ivf_t* h, uint32_t q, uint64_t* out_vec_ids, float* out_vals, double* out_bound, uint32_t cap,
+                                uint32_t* out_n, double* out_info8);
 /* TEST HOOK: one wave of the matrix-core instruction a pre-filter uses, accumulated over K exactly as the kernels do, on
  * caller-chosen operands (tests/test_mfma_model_gpu.py measures the accumulation error the certificates' bounds assume).
  * kind 0 v_mfma_f32_32x32x16_f16, 1 v_mfma_f32_32x32x16_bf16 (A, B: 16-bit patterns), 2 v_mfma_f32_32x32x2_f32,

@@ -83,6 +83,7 @@ SIGNATURES = {
     "vers_kmeans_assign": (C.c_int32, [C.c_int32, _vp, C.c_uint64, C.c_uint64, _vp, C.c_uint64, C.c_uint64, C.c_uint32, _vp, _vp]),
     "vers_assign_stats": (C.c_int32, [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_int32]),
     "vers_build_stats": (C.c_int32, [C.POINTER(C.c_double), C.c_int32]),
+    "vers_ivf_test_last_vals": (C.c_int32, [_vp, C.c_uint32, _u64p, _fp, C.POINTER(C.c_double), C.c_uint32, _u32p, C.POINTER(C.c_double)]),
     "vers_test_mfma": (C.c_int32, [C.c_int32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_float)]),
     "vers_kmeans_update": (C.c_int32, [C.c_int32, _vp, C.c_uint64, C.c_uint64, _vp, C.c_uint64, C.c_uint32, _vp]),
     "vers_kmeans_cost": (C.c_int32, [C.c_int32, _vp, C.c_uint64, C.c_uint64, _vp, C.c_uint64, C.c_uint64, _vp, C.c_uint32,

@@ -717,6 +717,8 @@ struct SearchWs {
   uint32_t st_slot = 0;
   uint32_t* st_dev = nullptr;  // the leasing _dev call's stream word
   uint32_t* st_word() const { return st_slot == 0 && st_dev ? st_dev : status.as<uint32_t>() + st_slot; }
+  // geometry of the most recent matrix-core list scan on this workspace (TEST HOOK vers_ivf_test_last_vals)
+  struct LastPre { bool valid = false; uint32_t b = 0, P = 0, S_max = 0, kp = 0, top_k = 0; const float* qp = nullptr; int shadow = 0; } last_pre;
   GroupTotals last_tot{};
   const GroupTotals* tot_dev = nullptr;  // device totals of the last planned search
   bool tot_valid = false;
@@ -2085,6 +2087,8 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
                        (const uint32_t*)fail_list, (const uint32_t*)(fail_list + b), W->fb_part.as<uint64_t>(), W->fb_ctr.as<uint32_t>(),
                        use_shadow ? h->fail_watch : (uint32_t*)nullptr);
     VERS_HIP_TRY(hipGetLastError());
+    W->last_pre.valid = true; W->last_pre.b = b; W->last_pre.P = P; W->last_pre.S_max = S_max; W->last_pre.kp = kp; W->last_pre.top_k = top_k;
+    W->last_pre.qp = qp; W->last_pre.shadow = use_shadow ? 1 : 0;
     if (use_shadow) h->shadow_queries += b;  // (fallback_kernel writes the running failure count to the pinned watch word)
     h->pre_batches += 1;
     W->tot_valid = true;
@@ -2805,6 +2809,59 @@ int32_t vers_ivf_test_poison_slack(vers_ivf_t* h, float value) {
   VERS_HIP_TRY(hipGetLastError());
   if (int32_t rc = refresh_norms(h, 0, h->cap_rows, nullptr)) return rc;
   VERS_HIP_TRY(hipDeviceSynchronize());
+  return VERS_OK;
+}
+
+int32_t vers_ivf_test_last_vals(vers_ivf_t* h, uint32_t q, uint64_t* out_vec_ids, float* out_vals, double* out_bound, uint32_t cap, uint32_t* out_n,
+                                double* out_info) {
+  if (!h || !out_n || (cap && (!out_vec_ids || !out_vals || !out_bound))) return fail(VERS_ERR_INVALID, "bad arguments");
+  std::shared_lock<std::shared_mutex> lk(h->index);
+  UseLastWs use_ws(h);
+  if (!use_ws.ok || !W->last_pre.valid) return fail(VERS_ERR_INVALID, "vers_ivf_test_last_vals: the most recent search did not run the matrix-core list scan");
+  const auto lp = W->last_pre;
+  if (q >= lp.b) return fail(VERS_ERR_INVALID, "vers_ivf_test_last_vals: no such query in the last batch");
+  DeviceGuard g(h->device);
+  VERS_HIP_TRY(hipDeviceSynchronize());
+  const uint32_t P = lp.P, S = lp.S_max, kp = lp.kp;
+  const uint64_t n_pj = (uint64_t)lp.b * P;
+  std::vector<uint64_t> keys((size_t)P * S * kp);
+  std::vector<uint32_t> pl(P), pp(P), pn(P);
+  const uint32_t* pj = W->pj.as<uint32_t>();
+  VERS_HIP_TRY(hipMemcpy(keys.data(), W->partials.as<uint64_t>() + (uint64_t)q * P * S * kp, keys.size() * 8, hipMemcpyDeviceToHost));
+  VERS_HIP_TRY(hipMemcpy(pl.data(), pj + (uint64_t)q * P, P * 4, hipMemcpyDeviceToHost));
+  VERS_HIP_TRY(hipMemcpy(pp.data(), pj + n_pj + (uint64_t)q * P, P * 4, hipMemcpyDeviceToHost));
+  VERS_HIP_TRY(hipMemcpy(pn.data(), pj + 3 * n_pj + lp.b + (uint64_t)q * P, P * 4, hipMemcpyDeviceToHost));
+  std::vector<float> qrow(h->ldq);
+  VERS_HIP_TRY(hipMemcpy(qrow.data(), lp.qp + (uint64_t)q * h->ldq, (size_t)h->ldq * 4, hipMemcpyDeviceToHost));
+  uint32_t misc[4] = {0, 0, 0, 0};
+  VERS_HIP_TRY(hipMemcpy(misc, h->pre_misc.p, 16, hipMemcpyDeviceToHost));
+  double qn = 0.0;
+  for (uint32_t j = 0; j < h->ldq; ++j) qn += (double)qrow[j] * (double)qrow[j];
+  float xmax2, r2;
+  memcpy(&xmax2, &misc[0], 4); memcpy(&r2, &misc[2], 4);
+  const PreBound pb = pre_bound(qn, (double)xmax2, lp.shadow ? (double)r2 : 0.0, h->ld, h->metric, lp.shadow);
+  if (out_info) { out_info[0] = qn; out_info[1] = xmax2; out_info[2] = lp.shadow ? r2 : 0.0; out_info[3] = pb.global; out_info[4] = pb.common; out_info[5] = kp; out_info[6] = lp.shadow; out_info[7] = h->metric; }
+  uint32_t n = 0;
+  for (uint32_t j = 0; j < P; ++j) {
+    if (pl[j] == kNoList) continue;
+    uint32_t off_j = 0;
+    VERS_HIP_TRY(hipMemcpy(&off_j, h->slot_off.as<uint32_t>() + pl[j], 4, hipMemcpyDeviceToHost));
+    for (uint32_t sq = 0; sq < pn[j] && sq < S; ++sq)
+      for (uint32_t i = 0; i < kp; ++i) {
+        const uint64_t key = keys[((size_t)j * S + sq) * kp + i];
+        if (key == kKeyMax) continue;
+        if (n < cap) {
+          const uint32_t row = off_j + ((uint32_t)key - pp[j]);
+          uint32_t vid = 0;
+          VERS_HIP_TRY(hipMemcpy(&vid, h->row_ids.as<uint32_t>() + row, 4, hipMemcpyDeviceToHost));
+          const uint32_t vb = order_bits_to_f32_bits((uint32_t)(key >> 32));
+          float v; memcpy(&v, &vb, 4);
+          out_vec_ids[n] = vid; out_vals[n] = v; out_bound[n] = pb.of((double)v);
+        }
+        ++n;
+      }
+  }
+  *out_n = n;
   return VERS_OK;
 }
 

@@ -588,6 +588,59 @@ __global__ __launch_bounds__(kWave * kPreWavesG) __attribute__((amdgpu_waves_per
     p.stamps[7] = ((__builtin_amdgcn_s_memtime() - clk0) << 20) / ((__builtin_amdgcn_s_memrealtime() - rt0) | 1ull);
 }
 
+// ---- the certificate's bound (host + device: the kernel evaluates it per candidate, vers_ivf_test_last_vals per dumped val) ---
+// How far a pre-filter value `val` (|x|^2 - 2 <x~, q> on the matrix cores, or -<x~, q> for the cosine distance) can be from
+// the reference's ordered-chain distance of the same row: | val + |q|^2 - D_ref |  (cosine: | 1 + val - D_ref |), u = 2^-24.
+//   (1) the reference's own chain: sub, mul and d adds, each rounded: |D_ref - T| <= (d + 2) u T / (1 - (d + 2) u), T = the exact
+//       squared distance of the f32 operands -- PER CANDIDATE, T <= val + |q|^2 + (2..5) (round 2 charged every candidate the
+//       global 2 (d + 2) u (|q|^2 + max |x|^2): a row at distance 0.6 paid for one at 4);
+//   (2) |x|^2 as stored (xnorm, an ordered f32 sum) and |q|^2 as the finish sums it (any order): (d + 1) u each, of max |x|^2
+//       and |q|^2;
+//   (3) the matrix cores: products of two 16-bit (or f32 x f32 into f32) operands accumulated in f32 -- modelled as d
+//       roundings of u sum |x_i q'_i| <= u |x||q'| (Cauchy-Schwarz), q' = -2q.  MEASURED on this chip: at most 9 (f16, bf16)
+//       / 25 (f32) such roundings over d = 768 for adversarial operands, fp16 subnormals are not flushed
+//       (tests/test_mfma_model_gpu.py, profiles/r03_mfma_model.txt) -- a 30x margin under the model's d;
+//   (4) |x|^2 riding through the matrix core as one more k-step, the final f32 of the accumulator: a few u (|q|^2 + max|x|^2);
+//   (5) fp16 shadow rows: 2 |<x - x~, q>| <= 2 R |q| with R = the MEASURED largest |x - fp16(x)| over the stored rows
+//       (shadow_residual_kernel), and the query's fp16 hi + lo split leaving <= 2^-22 |q'_j| + 2^-24 per element behind:
+//       sum_j |x~_j| (...) <= 2^-21 |x||q| + 2^-24 sqrt(d) |x|.
+// Everything but (1) is the same for every candidate of a query: bound_common.  (1) is bound_chain(val).  A row NOT in the
+// candidate list has an unknown T <= 2 (|q|^2 + max|x|^2): bound_global.  1 % inflation covers the roundings of this
+// arithmetic itself and of R^2, |q|^2, |x~| vs |x|.
+struct PreBound {
+  double common;   // (2) .. (5)
+  double chain_k;  // (d + 3) u: the chain's relative error, one u of slack for the 1 / (1 - (d + 2) u)
+  double offset;   // val + offset ~ T (squared L2: |q|^2; cosine distance: val + 1 ~ D, no chain term of this form)
+  double global;   // bound for a row outside the list
+  int metric;
+  __host__ __device__ double of(double val) const {  // per-candidate bound
+    if (metric) return global;
+    double T = val + offset + common;
+    T = T > 0.0 ? T : 0.0;
+    return common + chain_k * T;
+  }
+};
+__host__ __device__ inline PreBound pre_bound(double qn, double xmax2, double R2, uint32_t d_pad, int metric, int shadow) {
+  const double u = 5.9604644775390625e-08, d = (double)d_pad;
+  const double qnU = qn * (1.0 + 2.0 * d * u);  // |q|^2 from its rounded sum
+  const double S = qnU + xmax2 + (metric ? 1.0 : 0.0);
+  const double xm = __builtin_sqrt(xmax2), qm = __builtin_sqrt(qnU);
+  PreBound b;
+  b.metric = metric;
+  double sh = 0.0;
+  if (shadow) sh = 1.01 * (2.0 * __builtin_sqrt(R2) * qm + 4.76837158203125e-07 * xm * qm + 5.9604644775390625e-08 * __builtin_sqrt(d) * xm);
+  // the round-2 bound, kept for rows outside the list and for the cosine distance: (5 d + 32) u S (+ shadow)
+  b.global = (5.0 * d + 32.0) * u * S * (shadow ? 1.01 : 1.0) + sh;
+  // (2) (d + 1) u (max|x|^2 + |q|^2)   (3) d u |x| |2 q| (the hi + lo split doubles the accumulation steps, not the partial sums' size:
+  // 2 d roundings of u |x||q'| / ... kept at the model's 2 d u |x||q| per pass: x 2 with the shadow)   (4) 16 u S
+  const double mf = (shadow ? 2.0 : 1.0) * 2.0 * d * u * xm * qm;
+  b.common = ((d + 1.0) * u * (xmax2 + qnU) + mf + 16.0 * u * S) * 1.01 + sh;
+  b.chain_k = (d + 3.0) * u;
+  b.offset = qnU;
+  if (b.common > b.global) b.common = b.global;  // (never looser than the bound it replaces)
+  return b;
+}
+
 // ---- exact finish ---------------------------------------------------------------------------------
 struct RescoreArgs {
   const uint64_t* partials;  // [b*P*S_max][kp] approximate keys
@@ -723,34 +776,36 @@ __global__ __launch_bounds__(kWave * kRescoreWaves) void ivf_rescore_kernel(Resc
     const uint32_t cnt = (uint32_t)__popcll(__ballot(valid));
     float qn = 0.0f;
     for (int w = 0; w < kRescoreWaves; ++w) qn += sred[w];
-    const double u = 5.9604644775390625e-08;
-    const double S = (double)qn * (1.0 + (double)a.d_pad * 2.0 * u) + (double)__uint_as_float(xmax_bits) + (a.metric ? 1.0 : 0.0);
-    double E = (5.0 * (double)a.d_pad + 32.0) * u * S;
-    // fp16 shadow: |val~ - val| <= 2 |<x - x~, q>| + 2 |<x~, q - q~>| with (a) |<x - x~, q>| <= R |q|, R = the MEASURED largest
-    // |x - fp16(x)| over the stored rows (shadow_residual_kernel), and (b) the query's hi + lo split leaving at most
-    // 2^-22 |q'_j| + 2^-24 per element (fp16 subnormal spacing) of q' = -2q behind: sum_j |x~_j| (...) <= 2^-21 |x||q| +
-    // 2^-24 sqrt(d) |x|.  Inflated by 1 % for the roundings of R^2, |q|^2, |x~| vs |x| and of this arithmetic.
-    if (a.shadow) {
-      const double xm = __builtin_sqrt((double)__uint_as_float(xmax_bits)), qm2 = __builtin_sqrt((double)qn);
-      const double R = __builtin_sqrt((double)__uint_as_float(a.xmax2_bits[2]));
-      E = E * 1.01 + 1.01 * (2.0 * R * qm2 + 4.76837158203125e-07 * xm * qm2 + 5.9604644775390625e-08 * __builtin_sqrt((double)a.d_pad) * xm);
-    }
+    const PreBound pb = pre_bound((double)qn, (double)__uint_as_float(xmax_bits), a.shadow ? (double)__uint_as_float(a.xmax2_bits[2]) : 0.0, a.d_pad, a.metric,
+                                  a.shadow);
     const float val = __uint_as_float(order_bits_to_f32_bits((uint32_t)(list >> 32)));
+    const double e_mine = pb.of((double)val);  // this candidate's own bound (NaN / inf vals: NaN / inf, handled by the negated compares)
     bool certified = true;
     double lim = __builtin_inf();
     if (cnt > 0) {
+      // With tau the k-th smallest val and e_k the largest bound among the k smallest vals, the k-th smallest D_ref over ALL
+      // rows is at most tau + |q|^2 + e_k; a row r can be among the true top-k only if val_r - e_r <= tau + e_k.  Rows in the
+      // list: e_r = their own bound (survivors below).  Rows cut off by a full list have val >= the list's last val and the
+      // global bound: the last val must clear tau + e_k + E_global.
       const uint32_t kk = a.top_k < cnt ? a.top_k : cnt;
       const double tau = (double)__uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(val), (int)kk - 1));
-      lim = tau + 2.0 * E;  // a member of the true top-k has val <= tau_k + 2E (header)
+      double ek = lane < (int)kk ? e_mine : 0.0;
+      if (!(ek == ek)) ek = __builtin_inf();
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        const double o = __shfl_xor(ek, off, kWave);
+        ek = o > ek ? o : ek;
+      }
+      lim = tau + ek;
       if (cnt >= a.kp) {    // a full list may have cut rows off: the kp-th val must clear the limit
         const double top = (double)__uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(val), (int)a.kp - 1));
-        certified = top > lim;  // false for NaN / inf
+        certified = top > lim + pb.global;  // false for NaN / inf
       }
     }
     if (flag0 != 0 || a.force_fail) certified = false;
     // only candidates inside the limit can reach the top-k: the others are not worth their 3 KiB gather.
     // The list is sorted by val, so the survivors are a prefix: lanes 0..n_surv-1.
-    const bool survivor = certified && valid && !((double)val > lim);
+    const bool survivor = certified && valid && !((double)val - e_mine > lim);
     const uint32_t n_surv = (uint32_t)__popcll(__ballot(survivor));
     mine = survivor ? list : kKeyMax;
     srow[lane] = wave_seq_rows(list, survivor, lane, pl, pp, a.P, a.list_off);
