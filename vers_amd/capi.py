@@ -83,8 +83,8 @@ SIGNATURES = {
     "vers_kmeans_assign": (C.c_int32, [C.c_int32, _vp, C.c_uint64, C.c_uint64, _vp, C.c_uint64, C.c_uint64, C.c_uint32, _vp, _vp]),
     "vers_assign_stats": (C.c_int32, [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_int32]),
     "vers_build_stats": (C.c_int32, [C.POINTER(C.c_double), C.c_int32]),
-    "vers_ivf_test_last_vals": (C.c_int32, [_vp, C.c_uint32, _u64p, _fp, C.POINTER(C.c_double), C.c_uint32, _u32p, C.POINTER(C.c_double)]),
-    "vers_test_mfma": (C.c_int32, [C.c_int32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.POINTER(C.c_float)]),
+    "vers_ivf_test_last_vals": (C.c_int32, [_vp, C.c_uint32, _vp, _vp, _vp, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_double)]),
+    "vers_test_mfma": (C.c_int32, [C.c_int32, C.c_uint32, _vp, _vp, C.c_uint32, _vp]),
     "vers_kmeans_update": (C.c_int32, [C.c_int32, _vp, C.c_uint64, C.c_uint64, _vp, C.c_uint64, C.c_uint32, _vp]),
     "vers_kmeans_cost": (C.c_int32, [C.c_int32, _vp, C.c_uint64, C.c_uint64, _vp, C.c_uint64, C.c_uint64, _vp, C.c_uint32,
                                      C.POINTER(C.c_float)]),
@@ -262,7 +262,7 @@ def test_mfma(kind: int, A: np.ndarray, B: np.ndarray, device: int = 0) -> np.nd
     assert A.shape[0] == rows and B.shape[1] == cols and A.shape[1] == B.shape[0] and A.dtype == B.dtype
     assert A.dtype == (np.uint16 if kind <= 1 else np.float32)
     out = np.zeros((rows, cols), dtype=np.float32)
-    check(lib().vers_test_mfma(device, kind, A.ctypes.data_as(C.c_void_p), B.ctypes.data_as(C.c_void_p), A.shape[1], out.ctypes.data_as(_fp)))
+    check(lib().vers_test_mfma(device, kind, _ptr(A), _ptr(B), A.shape[1], _ptr(out)))
     return out
 
 

@@ -1097,6 +1097,25 @@ int32_t comm_rc(int32_t rc, const char* what) {
   return VERS_OK;
 }
 
+// Failure propagation of the row-sharded build: every callback is a rendezvous, so a rank that returned early (a failed
+// allocation, a HIP error in its assign pass) would leave its peers blocked inside the next one -- under RCCL a spinning
+// kernel until the watchdog fires.  At the points where a rank can fail on its own, right before the ranks next meet, all
+// ranks exchange how they fared (one 4-byte all_gather) and LEAVE TOGETHER when anyone failed.  (What cannot be agreed on
+// is a failure of the communicator itself: the host must abort the process group when any rank returns non-zero.)
+int32_t agree(const vers_comm_t* cm, uint32_t W, int32_t my_rc, const char* where) {
+  if (cm == nullptr || W <= 1) return my_rc;
+  DevBuf mine, all;
+  if (mine.reserve(16) || all.reserve(16 * (size_t)W)) return my_rc ? my_rc : fail(VERS_ERR_HIP, "out of device memory");
+  if (hipMemcpy(mine.p, &my_rc, 4, hipMemcpyHostToDevice) != hipSuccess) return my_rc ? my_rc : fail(VERS_ERR_HIP, "hipMemcpy failed");
+  if (int32_t rc = comm_rc(cm->all_gather(cm->ctx, mine.p, all.p, 4), "all_gather")) return my_rc ? my_rc : rc;
+  std::vector<int32_t> got(W, 0);
+  if (hipMemcpy(got.data(), all.p, 4 * (size_t)W, hipMemcpyDeviceToHost) != hipSuccess) return my_rc ? my_rc : fail(VERS_ERR_HIP, "hipMemcpy failed");
+  if (my_rc) return my_rc;
+  for (uint32_t r = 0; r < W; ++r)
+    if (got[r]) return fail(VERS_ERR_COMM, std::string("rank ") + std::to_string(r) + " failed in " + where + " (status " + std::to_string(got[r]) + "): every rank leaves the build");
+  return VERS_OK;
+}
+
 // Storage plan from the GLOBAL list lengths: owners (LPT when sharded), offsets and capacities of the owned lists,
 // device tables, zeroed row ids.
 int32_t plan_storage(vers_ivf* h, const uint32_t* lens, uint32_t k, hipStream_t st) {
@@ -1314,7 +1333,7 @@ int32_t install_index_sharded(vers_ivf* h, const float* X, uint32_t ldx, uint64_
   }
   h->rank = me;
   h->world = W;
-  if (int32_t rc = plan_storage(h, lens.data(), k, st)) return rc;
+  const int32_t rc_plan = plan_storage(h, lens.data(), k, st);  // (a failure here -- the rows of the owned lists do not fit -- is agreed on below, with the exchange buffers)
   // send plan: rows for destination t = my members of the lists t owns, clusters ascending
   const uint32_t ldp = h->ldx;  // packed rows travel with the k-means pitch (d rounded up to 4 floats)
   std::vector<uint64_t> send_rows(W, 0), send_off_rows(W, 0), recv_rows(W, 0), recv_off_rows(W, 0);
@@ -1349,14 +1368,19 @@ int32_t install_index_sharded(vers_ivf* h, const float* X, uint32_t ldx, uint64_
     }
   }
   const uint64_t n_recv = recv_off_rows[W - 1] + recv_rows[W - 1];
-  if (n_recv > 0xFFFFFFFFull) return fail(VERS_ERR_INVALID, "more than 2^32-1 rows received by one rank");
   DevBuf sbuf, sids, rbuf, rids, dbase, dsegs;
-  if (int32_t rc = sbuf.reserve((n_loc ? n_loc : 1) * (size_t)ldp * 4)) return rc;
-  if (int32_t rc = sids.reserve((n_loc ? n_loc : 1) * 4)) return rc;
-  if (int32_t rc = rbuf.reserve((n_recv ? n_recv : 1) * (size_t)ldp * 4)) return rc;
-  if (int32_t rc = rids.reserve((n_recv ? n_recv : 1) * 4)) return rc;
-  if (int32_t rc = dbase.reserve((k ? k : 1) * 4)) return rc;
-  if (int32_t rc = dsegs.reserve((segs.size() ? segs.size() : 1) * sizeof(RecvSeg))) return rc;
+  const int32_t rc_alloc = [&]() -> int32_t {
+    if (rc_plan) return rc_plan;
+    if (n_recv > 0xFFFFFFFFull) return fail(VERS_ERR_INVALID, "more than 2^32-1 rows received by one rank");
+    if (int32_t rc = sbuf.reserve((n_loc ? n_loc : 1) * (size_t)ldp * 4)) return rc;
+    if (int32_t rc = sids.reserve((n_loc ? n_loc : 1) * 4)) return rc;
+    if (int32_t rc = rbuf.reserve((n_recv ? n_recv : 1) * (size_t)ldp * 4)) return rc;
+    if (int32_t rc = rids.reserve((n_recv ? n_recv : 1) * 4)) return rc;
+    if (int32_t rc = dbase.reserve((k ? k : 1) * 4)) return rc;
+    if (int32_t rc = dsegs.reserve((segs.size() ? segs.size() : 1) * sizeof(RecvSeg))) return rc;
+    return VERS_OK;
+  }();
+  if (int32_t rc = agree(cm, W, rc_alloc, "the exchange buffers of the rows-to-owners all_to_all_v")) return rc;  // (storage + send + receive: the build's peak)
   if (k) VERS_HIP_TRY(hipMemcpyAsync(dbase.p, send_base.data(), (size_t)k * 4, hipMemcpyHostToDevice, st));
   if (!segs.empty()) VERS_HIP_TRY(hipMemcpyAsync(dsegs.p, segs.data(), segs.size() * sizeof(RecvSeg), hipMemcpyHostToDevice, st));
   if (n_loc) {
@@ -1423,26 +1447,30 @@ int32_t run_build(vers_ivf* h, const float* X, uint32_t ldx, uint64_t n, const B
   }
   DevBuf C, Cn, S, assign, mind, sorted, idx, idx2, bestC, counts_all, counts_g, tmp_rows, ctl, ctl_all;
   const size_t cbytes = ((size_t)k * ld ? (size_t)k * ld : 1) * sizeof(float);
-  if (int32_t rc = C.reserve(cbytes)) return rc;
-  if (int32_t rc = Cn.reserve(cbytes)) return rc;
-  if (int32_t rc = bestC.reserve(cbytes)) return rc;
-  if (int32_t rc = assign.reserve((n ? n : 1) * 4)) return rc;
-  if (int32_t rc = best_assign.reserve((n ? n : 1) * 4)) return rc;
-  if (int32_t rc = mind.reserve((n ? n : 1) * 4)) return rc;
-  if (int32_t rc = sorted.reserve((n ? n : 1) * 4)) return rc;
-  if (int32_t rc = idx.reserve((k ? k : 1) * 4)) return rc;
-  if (int32_t rc = h->km.counts.reserve((2 * (size_t)k + 2) * 4)) return rc;
-  if (int32_t rc = h->km.misc.reserve(64)) return rc;
-  if (int32_t rc = h->km.status.reserve(16)) return rc;
-  if (multi) {
-    if (int32_t rc = S.reserve(cbytes)) return rc;
-    if (int32_t rc = idx2.reserve((k ? k : 1) * 4)) return rc;
-    if (int32_t rc = tmp_rows.reserve(cbytes)) return rc;
-    if (int32_t rc = counts_all.reserve((size_t)W * (k ? k : 1) * 4)) return rc;
-    if (int32_t rc = counts_g.reserve((k ? k : 1) * 4)) return rc;
-    if (int32_t rc = ctl.reserve(16)) return rc;
-    if (int32_t rc = ctl_all.reserve(16 * (size_t)W)) return rc;
-  }
+  const int32_t rc_alloc = [&]() -> int32_t {
+    if (int32_t rc = C.reserve(cbytes)) return rc;
+    if (int32_t rc = Cn.reserve(cbytes)) return rc;
+    if (int32_t rc = bestC.reserve(cbytes)) return rc;
+    if (int32_t rc = assign.reserve((n ? n : 1) * 4)) return rc;
+    if (int32_t rc = best_assign.reserve((n ? n : 1) * 4)) return rc;
+    if (int32_t rc = mind.reserve((n ? n : 1) * 4)) return rc;
+    if (int32_t rc = sorted.reserve((n ? n : 1) * 4)) return rc;
+    if (int32_t rc = idx.reserve((k ? k : 1) * 4)) return rc;
+    if (int32_t rc = h->km.counts.reserve((2 * (size_t)k + 2) * 4)) return rc;
+    if (int32_t rc = h->km.misc.reserve(64)) return rc;
+    if (int32_t rc = h->km.status.reserve(16)) return rc;
+    if (multi) {
+      if (int32_t rc = S.reserve(cbytes)) return rc;
+      if (int32_t rc = idx2.reserve((k ? k : 1) * 4)) return rc;
+      if (int32_t rc = tmp_rows.reserve(cbytes)) return rc;
+      if (int32_t rc = counts_all.reserve((size_t)W * (k ? k : 1) * 4)) return rc;
+      if (int32_t rc = counts_g.reserve((k ? k : 1) * 4)) return rc;
+      if (int32_t rc = ctl.reserve(16)) return rc;
+      if (int32_t rc = ctl_all.reserve(16 * (size_t)W)) return rc;
+    }
+    return VERS_OK;
+  }();
+  if (int32_t rc = agree(multi ? cm : nullptr, W, rc_alloc, "the build's allocations")) return rc;
   VERS_HIP_TRY(hipMemsetAsync(h->km.status.p, 0, 16, st));
   uint32_t* counts = h->km.counts.as<uint32_t>();
   uint32_t* starts = counts + k;
@@ -1494,7 +1522,7 @@ int32_t run_build(vers_ivf* h, const float* X, uint32_t ldx, uint64_t n, const B
     }
     uint64_t iters = 0;
     for (uint64_t it = 0; it < max_iterations; ++it) {
-      if (int32_t rc = assign_pass(C.as<float>(), assign.as<uint32_t>(), nullptr)) return rc;
+      if (int32_t rc = agree(multi ? cm : nullptr, W, assign_pass(C.as<float>(), assign.as<uint32_t>(), nullptr), "assign_to_clusters")) return rc;
       if (int32_t rc = km_group(assign.as<uint32_t>(), (uint32_t)n, k, sorted.as<uint32_t>(), counts, starts, h->km, st)) return rc;
       if (!multi) {
         km_timer_begin(st);
@@ -1532,7 +1560,7 @@ int32_t run_build(vers_ivf* h, const float* X, uint32_t ldx, uint64_t n, const B
       std::swap(C.cap, Cn.cap);
     }
     if (out_iterations) out_iterations[a] = iters;
-    if (int32_t rc = assign_pass(C.as<float>(), assign.as<uint32_t>(), mind.as<float>())) return rc;
+    if (int32_t rc = agree(multi ? cm : nullptr, W, assign_pass(C.as<float>(), assign.as<uint32_t>(), mind.as<float>()), "the final assign_to_clusters")) return rc;
     // calculate_kmeans_cost (ivfflat.rs:138-149): one left-to-right f32 fold over ALL points -- chained like the sums
     const float* fold_init = nullptr;
     if (multi && me > 0) {

@@ -166,7 +166,7 @@ class IVFFlatIndex:
         """TEST HOOK (vers_ivf_test_last_vals): (vec_ids, vals, per-candidate bounds, info dict) of query q of the last batched nprobe search"""
         ids = np.zeros(cap, dtype=np.uint64); vals = np.zeros(cap, dtype=np.float32); bnd = np.zeros(cap, dtype=np.float64)
         n = C.c_uint32(0); info = (C.c_double * 8)()
-        check(lib().vers_ivf_test_last_vals(self._h, q, _ptr(ids), _ptr(vals), bnd.ctypes.data_as(C.POINTER(C.c_double)), cap, C.byref(n), info))
+        check(lib().vers_ivf_test_last_vals(self._h, q, _ptr(ids), _ptr(vals), _ptr(bnd), cap, C.byref(n), info))
         m = min(n.value, cap)
         keys = ("qn", "xmax2", "r2", "bound_outside", "bound_common", "kp", "shadow", "metric")
         return ids[:m].copy(), vals[:m].copy(), bnd[:m].copy(), dict(zip(keys, (float(x) for x in info)))
