@@ -407,13 +407,10 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2
 // instantiation and process).
 // sh / sl: the centroid operand pre-split by split_bf16_kernel (nullable: split on the fly) -- the M operand of the assign
 // pass (NORM_ROWS), the N operand of the coarse quantiser.
-// nh / nl (assign pass only): the POINT batch pre-split the same way (one pass over the batch instead of every one of the
-// k / 128 blocks that read a point tile splitting it again: 116 of the 140 VALU instructions a thread issued per tile step).
 template <bool NORM_ROWS>
 inline hipError_t launch_gemm(bool x3, uint32_t m_tiles, uint32_t n_tiles, hipStream_t st, const float* Q, const float* C, const float* cnorm,
                               uint32_t K, uint32_t N_pad, float* G, uint32_t metric, uint32_t k_rows = 0, float* part_v1 = nullptr,
-                              uint32_t* part_c1 = nullptr, float* part_v2 = nullptr, const __bf16* sh = nullptr, const __bf16* sl = nullptr,
-                              const __bf16* nh = nullptr, const __bf16* nl = nullptr) {
+                              uint32_t* part_c1 = nullptr, float* part_v2 = nullptr, const __bf16* sh = nullptr, const __bf16* sl = nullptr) {
   const uint32_t grp = NORM_ROWS ? gemm_tile_group(m_tiles) : 0;
   if (!x3) {
     hipLaunchKernelGGL(dist_gemm_kernel<NORM_ROWS>, dim3(m_tiles * n_tiles), dim3(256), 0, st, Q, C, cnorm, K, N_pad, G, metric, m_tiles, n_tiles,
@@ -427,12 +424,11 @@ inline hipError_t launch_gemm(bool x3, uint32_t m_tiles, uint32_t n_tiles, hipSt
                                                        (int)kX3LdsBytes);
     if (attr != hipSuccess) return attr;
     const __bf16* qh = NORM_ROWS ? sh : nullptr; const __bf16* ql = NORM_ROWS ? sl : nullptr;
-    const __bf16* ch = NORM_ROWS ? nh : sh; const __bf16* cl = NORM_ROWS ? nl : sl;
+    const __bf16* ch = NORM_ROWS ? nullptr : sh; const __bf16* cl = NORM_ROWS ? nullptr : sl;
     hipLaunchKernelGGL((dist_gemm_x3_kernel<NORM_ROWS, PRE>), dim3(m_tiles * n_tiles), dim3(256), kX3LdsBytes, st, Q, C, qh, ql, ch, cl, cnorm, K,
                        N_pad, G, metric, m_tiles, n_tiles, grp, k_rows, part_v1, part_c1, part_v2);
     return hipGetLastError();
   };
-  if (NORM_ROWS && sh && sl && nh && nl) return go(std::integral_constant<int, 3>{});
   return (sh && sl) ? go(std::integral_constant<int, kPreBit>{}) : go(std::integral_constant<int, 0>{});
 }
 inline hipError_t launch_split_bf16(const float* x, uint64_t n_floats, __bf16* hi, __bf16* lo, hipStream_t st) {  // n_floats % 4 == 0

@@ -276,19 +276,10 @@ int32_t km_assign_mfma(const float* X, uint32_t ldx, uint64_t n, const float* C,
       if (int32_t rc = launch_stage_queries(xb, ldx, d, ws.xp.as<float>(), ldq, nb, 1, st)) return rc;
       xb = ws.xp.as<float>();
     }
-    // the point batch as bf16 hi | lo, split ONCE (VERS_SPLIT_POINTS=0: every block splits its tiles on the fly, round 2)
-    const __bf16 *xh = nullptr, *xl = nullptr;
-    static const bool split_points = [] { const char* e = getenv("VERS_SPLIT_POINTS"); return !e || atoi(e) != 0; }();
-    if (cg_h && split_points) {
-      const size_t ne = (size_t)nb_pad * ldq;
-      if (int32_t rc = ws.xs.reserve(2 * (size_t)mb * ldq * sizeof(uint16_t))) return rc;
-      VERS_HIP_TRY(launch_split_bf16(xb, ne, ws.xs.as<__bf16>(), ws.xs.as<__bf16>() + (size_t)mb * ldq, st));
-      xh = ws.xs.as<__bf16>(); xl = xh + (size_t)mb * ldq;
-    }
     // (the triples are addressed with pitch mb: nb_pad <= mb)
     km_timer_begin(st);
     VERS_HIP_TRY(launch_gemm<true>((gemm_x3_mask() & 1) != 0, k_pad / kGemmBM, nb_pad / kGemmBN, st, ws.cg.as<float>(), xb, ws.cnorm.as<float>(), ldq,
-                                   (uint32_t)mb, (float*)nullptr, metric, k, part_v1, part_c1, part_v2, cg_h, cg_l, xh, xl));
+                                   (uint32_t)mb, (float*)nullptr, metric, k, part_v1, part_c1, part_v2, cg_h, cg_l));
     km_timer_end(st, &g_bs.gemm_ms);
     g_bs.gemm_launches += 1; g_bs.gemm_flop += 2.0 * (double)nb * (double)k * (double)d;
     hipLaunchKernelGGL(assign_argmin_merge_kernel, dim3((nb + 255) / 256), dim3(256), 0, st, (const float*)part_v1, (const uint32_t*)part_c1,
