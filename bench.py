@@ -147,6 +147,25 @@ def main():
             f"{t_build:.1f}s; cost {float(index.cost):.1f} (bits {np.float32(index.cost).view(np.uint32):#010x}); "
             f"list len min/mean/max {int(lens.min())}/{lens.mean():.0f}/{int(lens.max())}; "
             f"index fingerprint (centroid bits + list lengths) {fp:#010x}; matrix-core assign: {mp} points, {mf} re-done exactly")
+    sharded_build = None
+    if world > 1:
+        # every rank's peak of library memory during the row-sharded build (its rows are the caller's: generated above)
+        pk = torch.tensor([float(mem_peak), float(mem_now), float(hi - lo) * ld * 4.0], device=dev, dtype=torch.float64)
+        allpk = [torch.zeros_like(pk) for _ in range(world)]
+        if backend == "nccl":
+            dist.all_gather(allpk, pk)
+        else:
+            hl = [torch.zeros(3, dtype=torch.float64) for _ in range(world)]
+            dist.all_gather(hl, pk.cpu()); allpk = hl
+        if rank == 0:
+            sharded_build = {"rows_per_rank": hi - lo, "rank_rows_gb": round((hi - lo) * ld * 4 / 1e9, 2), "whole_corpus_gb": round(n * d * 4 / 1e9, 2),
+                             "library_mem_peak_gb_per_rank": [round(float(t[0]) / 1e9, 2) for t in allpk],
+                             "library_mem_after_build_gb_per_rank": [round(float(t[1]) / 1e9, 2) for t in allpk],
+                             "peak_over_rank_rows": round(max(float(t[0]) / max(1.0, float(t[2])) for t in allpk), 3),
+                             "exchange_calls": dict(comm.calls), "exchange_bytes": dict(comm.bytes),
+                             "exchange_seconds_rank0": {k_: round(v_, 3) for k_, v_ in comm.seconds.items()},
+                             "chain_hop_ms": round(1e3 * (comm.seconds["send"] + comm.seconds["recv"]) / max(1, comm.calls["send"] + comm.calls["recv"]), 2),
+                             "build_index_s": round(t_build, 2), "backend": backend}
     if world > 1 and rank == 0:
         own = index.owners()
         log(f"[bench] row-sharded build over {world} ranks: {hi - lo} rows generated per rank, library device memory peak "
@@ -344,6 +363,8 @@ def main():
                            "max_N_per_gpu_with_shadow": int((hbm_total - (8 << 30)) / per_row), "max_N_per_gpu_without_shadow": int((hbm_total - (8 << 30)) / per_row_noshadow),
                            "note": "rows incl. list slack + row ids + |x|^2 (+ fp16 shadow); 8 GB set aside for per-batch scratch and the caller"}
         extra["build_index_s"] = round(t_build, 3)
+        if sharded_build:
+            extra["sharded_build"] = sharded_build
         ke = assign_entry(bst, min(131072, hi - lo), nlist, t_build, f"the timed index's own build: N={n} over {world} rank(s), k={nlist}, {int(index.iterations[0])} iterations + final assign")
         if ke:
             extra["kmeans_assign"] = ke

@@ -112,7 +112,7 @@ def test_row_sharded_build_is_bit_exact(world, force_mfma, shape):
         assert set(g["lists"]) == {c for c in range(K) if owner[c] == r}
         # no rank ever held the corpus: its share of the rows (k-means input is the caller's) + exchange + storage
         share = (cuts[r + 1] - cuts[r]) * D * 4
-        assert g["peak"] < 6 * share + (64 << 20), (r, g["peak"], share)
+        assert g["peak"] < 4.5 * share + (64 << 20), (r, g["peak"], share)   # measured 4.1-4.3 x (storage + send + receive on top of nothing else)
         # the chain: per k-means pass one recv + one send of k*ld*4 bytes except at the ends
         assert g["calls"]["all_to_all_v"] == 2
         for nprobe, (gi, gd, gc) in g["res"].items():
@@ -146,3 +146,64 @@ def test_sharded_entry_point_with_one_rank_equals_plain_build():
     assert np.array_equal(ix.local_assignments, o["assignments"])
     assert np.array_equal(ix.get_centroids().view(np.uint32), np.ascontiguousarray(o["centroids"]).view(np.uint32))
     assert np.float32(ix.cost).view(np.uint32) == np.float32(o["cost"]).view(np.uint32)
+
+
+# ---- BASELINE.json cfg5's cluster count, row-sharded -------------------------------------------------------------------
+BIGK = dict(n=1_048_576, d=768, k=65536, iters=1)
+
+
+def bigk_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import zlib
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from tests import datagen as dg
+    from vers_amd import capi
+    from vers_amd.dist import TorchComm
+    from vers_amd.index import IVFFlatIndex
+    n, d, k, iters = BIGK["n"], BIGK["d"], BIGK["k"], BIGK["iters"]
+    lo, hi = rank * n // world, (rank + 1) * n // world
+    X = torch.empty(hi - lo, d, dtype=torch.float32, device="cuda")
+    capi.gen_rows_dev(X.data_ptr(), hi - lo, d, d, 1, 0xC5, 0xC6, 4 * k, float(dg.default_sigma(d)), start_row=lo)
+    init = (dg.mix64(np.uint64(0xC7) + np.arange(k, dtype=np.uint64)) % np.uint64(n)).astype(np.uint64)
+    capi.mem_stats(reset_peak=True)
+    ix = IVFFlatIndex(d, device=0)
+    if world > 1:
+        comm = TorchComm(device=0)
+        kept = ix.build_sharded_dev(X.data_ptr(), hi - lo, d, lo, n, k, 1, iters, init, comm)
+        calls, nbytes = dict(comm.calls), dict(comm.bytes)
+    else:
+        kept = ix.build_dev(X.data_ptr(), n, k, 1, iters, init)
+        calls, nbytes = {}, {}
+    _, peak = capi.mem_stats()
+    lens = ix.list_lengths()
+    own = ix.owners() if world > 1 else np.zeros(k, dtype=np.uint8)
+    sample = {int(c): ix.get_list(int(c))[1] for c in range(0, k, 4099) if own[c] == rank}
+    ret[(world, rank)] = dict(kept=kept, cent_crc=zlib.crc32(np.ascontiguousarray(ix.get_centroids()).tobytes()), cost=np.float32(ix.cost).view(np.uint32),
+                              iters=ix.iterations.copy(), lens=lens, sample=sample, peak=peak, share=(hi - lo) * d * 4, calls=calls, bytes=nbytes)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_row_sharded_build_at_cfg5_cluster_count_equals_the_single_process_build():
+    """k = 65536 centroids (BASELINE.json cfg5), N = 1M x 768 generated shard-locally on the device: two ranks (gloo, one GPU)
+    against one process -- centroid bits, cost bits, iteration count, every list length, sampled list contents.  (The oracle
+    is too slow at this size: the single-process device build is itself pinned to it at small sizes above and in
+    tests/test_bigk_gpu.py.)  Also the memory claim at a size where it means something: peak < 4.5 x the rank's rows."""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(bigk_worker, args=(1, free_port(), ret), nprocs=1, join=True)
+    mp.spawn(bigk_worker, args=(2, free_port(), ret), nprocs=2, join=True)
+    one = ret[(1, 0)]
+    assert one["kept"]
+    for r in range(2):
+        g = ret[(2, r)]
+        assert g["kept"] and g["cent_crc"] == one["cent_crc"] and g["cost"] == one["cost"], r
+        assert np.array_equal(g["iters"], one["iters"]) and np.array_equal(g["lens"], one["lens"]), r
+        for c, ids in g["sample"].items():
+            assert np.array_equal(ids, one["sample"][c]), (r, c)
+        # rows of the rank + storage of its lists + send + receive buffers + k-means scratch (201 MB of centroids x a few) ...
+        assert g["peak"] < 4.5 * g["share"] + (2 << 30), (r, g["peak"], g["share"])
+        assert g["calls"]["all_to_all_v"] == 2
+    assert set(ret[(2, 0)]["sample"]) | set(ret[(2, 1)]["sample"]) == set(one["sample"])

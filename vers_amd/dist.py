@@ -67,6 +67,7 @@ class TorchComm:
         self.backend = dist.get_backend(group)
         self.calls = {"all_gather": 0, "send": 0, "recv": 0, "broadcast": 0, "all_to_all_v": 0}
         self.bytes = dict(self.calls)
+        self.seconds = {k: 0.0 for k in self.calls}   # host wall clock inside each callback (incl. its synchronisation)
         self._cbs = (_AG(self._all_gather), _SR(self._send), _SR(self._recv), _BC(self._broadcast), _A2A(self._all_to_all_v))
         self.struct = VersComm(None, self.rank, self.world, *self._cbs)
 
@@ -91,11 +92,14 @@ class TorchComm:
             torch.cuda.synchronize(self.device)
 
     def _guard(self, name, nbytes, fn):
+        import time
+        t0 = time.perf_counter()
         try:
             self.calls[name] += 1
             self.bytes[name] += int(nbytes)
             fn()
             self._sync()
+            self.seconds[name] += time.perf_counter() - t0
             return 0
         except Exception as e:  # never unwind through the C frame
             print(f"[vers comm] {name} failed on rank {self.rank}: {e!r}", file=sys.stderr, flush=True)
