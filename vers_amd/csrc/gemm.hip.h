@@ -18,6 +18,8 @@
 // <= d u |.|^2 each ;  MFMA dot = k-ordered fma chain: <= d u |q||c| <= d u S / 2, doubled ;
 // two final roundings <= 2 u (3S).   Total <= (5d + 16) u S =: E.
 #pragma once
+#include <cstdlib>
+
 #include "plan.hip.h"
 #include "scan.hip.h"
 
@@ -401,6 +403,186 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2
   }
   __syncthreads();  // (the epilogue re-uses the operand storage)
   gemm_epilogue<NORM_ROWS>(acc, reinterpret_cast<float*>(T), cnorm, N_pad, G, metric, k_rows, part_v1, part_c1, part_v2, m0, n0, wr, wc, r, hh);
+}
+
+// ---- the assign contraction on 256 x 256 block tiles ---------------------------------------------------------------------
+// The 128 x 128 kernel above moves 32 KB of operands from L2 / Infinity Cache into LDS per 3.1 MFLOP of bf16 products; with
+// two blocks per CU on 256 CUs that is 11.5 TB/s at its measured 305 algorithmic TFLOP/s -- the wall it runs into (a split of
+// the point operand hoisted out of the kernel changed nothing: the VALU work hides behind that traffic; MFMA-busy 44 %).
+// Here a block of EIGHT waves owns 256 centroids x 256 points: each wave a 64 x 128 sub-tile (2 x 4 MFMA tiles, 128
+// accumulator registers), 64 KB of operands per K-tile for FOUR times the products -- half the bytes per flop from L2, and 12
+// instead of 16 fragment reads per 24 MFMAs from LDS.  One block per CU (128 KB of LDS: two buffers), two waves per SIMD as
+// before.  Assign pass only (NORM_ROWS: M = centroids, pre-split into bf16 hi | lo once per pass; N = the point batch, f32,
+// split while it is staged); k_pad and the batch must be multiples of 256, otherwise the 128 x 128 kernel runs.
+// The coarse quantiser (1024 x 4096) would be 64 such blocks on 256 CUs and stays on the 128 x 128 tiles.
+constexpr int kGemmWide = 256;
+constexpr size_t kX3WLdsBytes = 2 * 2 * 2 * (size_t)kGemmWide * kX3Pitch * 2;  // two buffers x A|B x hi|lo = 128 KB
+static __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void dist_gemm_x3w_kernel(
+    const float* __restrict__ X, const __bf16* __restrict__ Ch, const __bf16* __restrict__ Cl, const float* __restrict__ cnorm, uint32_t K,
+    uint32_t N_pad, int metric, uint32_t m_tiles, uint32_t n_tiles, uint32_t grp, uint32_t k_rows, float* __restrict__ part_v1,
+    uint32_t* __restrict__ part_c1, float* __restrict__ part_v2) {
+  extern __shared__ __attribute__((aligned(16))) __bf16 T[];
+  constexpr int kPart = kGemmWide * kX3Pitch;
+  auto Tp = [&](int buf, int mat, int part) { return T + ((buf * 2 + mat) * 2 + part) * kPart; };
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wr = wid >> 1, wc = wid & 1;  // wave rows 0..3 (64 centroids each), wave columns 0..1 (128 points each)
+  uint32_t tile_m, tile_n;
+  gemm_tile_coords(m_tiles, n_tiles, grp, tile_m, tile_n);
+  const uint32_t m0 = tile_m * kGemmWide, n0 = tile_n * kGemmWide;
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.0f;
+  // staging registers of ONE tile: centroids 256 rows x 4 chunks of 16 bytes per part (thread t: chunks t, t + 512), points
+  // 256 rows x 8 float4 (thread t: slots t + 512 i, i < 4)
+  f32x4 ra[4], rb[4];
+  auto gload = [&](uint32_t k0) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int idx = tid + 512 * i;
+      const uint64_t at = (uint64_t)(m0 + (idx >> 2)) * K + k0 + (idx & 3) * 8;
+      ra[i] = *reinterpret_cast<const f32x4*>(Ch + at);
+      ra[2 + i] = *reinterpret_cast<const f32x4*>(Cl + at);
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int idx = tid + 512 * i;
+      rb[i] = *reinterpret_cast<const f32x4*>(X + (uint64_t)(n0 + (idx >> 3)) * K + k0 + (idx & 7) * 4);
+    }
+  };
+  auto lstore = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int idx = tid + 512 * i, row = idx >> 2, at = row * kX3Pitch + x3_chunk(row, idx & 3);
+      *reinterpret_cast<f32x4*>(Tp(buf, 0, 0) + at) = ra[i];
+      *reinterpret_cast<f32x4*>(Tp(buf, 0, 1) + at) = ra[2 + i];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int idx = tid + 512 * i, row = idx >> 3, c4 = idx & 7;
+      bf16x4 h, l;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        h[u] = (__bf16)rb[i][u];
+        l[u] = (__bf16)(rb[i][u] - (float)h[u]);
+      }
+      const int at = row * kX3Pitch + x3_chunk(row, c4 >> 1) + (c4 & 1) * 4;
+      *reinterpret_cast<bf16x4*>(Tp(buf, 1, 0) + at) = h;
+      *reinterpret_cast<bf16x4*>(Tp(buf, 1, 1) + at) = l;
+    }
+  };
+  const int r = lane & 31, hh = lane >> 5;
+  auto compute = [&](int buf) {
+#pragma unroll
+    for (int s2 = 0; s2 < 2; ++s2) {  // two k-steps of 16
+      const int ko = x3_chunk(r, 2 * s2 + hh);  // (row offsets that are multiples of 32 do not change (row >> 2) & 3)
+      bf16x8 ah[2], al[2], bh[4], bl[4];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        ah[t] = *reinterpret_cast<const bf16x8*>(Tp(buf, 0, 0) + (wr * 64 + t * 32 + r) * kX3Pitch + ko);
+        al[t] = *reinterpret_cast<const bf16x8*>(Tp(buf, 0, 1) + (wr * 64 + t * 32 + r) * kX3Pitch + ko);
+      }
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        bh[t] = *reinterpret_cast<const bf16x8*>(Tp(buf, 1, 0) + (wc * 128 + t * 32 + r) * kX3Pitch + ko);
+        bl[t] = *reinterpret_cast<const bf16x8*>(Tp(buf, 1, 1) + (wc * 128 + t * 32 + r) * kX3Pitch + ko);
+      }
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a], bh[b], acc[a][b], 0, 0, 0);  // small terms first
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bl[b], acc[a][b], 0, 0, 0);
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bh[b], acc[a][b], 0, 0, 0);
+        }
+    }
+  };
+  // tile t is computed out of LDS buffer t & 1 while the registers bring tile t + 2 in; past the end the prefetch re-reads the
+  // last tile and the store goes to a buffer nobody reads any more (no branches around loads: the compiler's counted waits)
+  const uint32_t k_tiles = K / kGemmBK, k_last = K - kGemmBK;
+  auto kclamp = [&](uint32_t t) { const uint32_t k0 = t * kGemmBK; return k0 < k_last ? k0 : k_last; };
+  gload(0);
+  lstore(0);
+  gload(kclamp(1));
+  __syncthreads();
+  for (uint32_t t = 0; t < k_tiles; ++t) {
+    lstore((int)((t + 1) & 1));  // tile t + 1 (its buffer's readers finished before the last barrier)
+    gload(kclamp(t + 2));
+    compute((int)(t & 1));
+    __syncthreads();
+  }
+  // epilogue: per point (column) the smallest value, its centroid and the second smallest over each 128-centroid row tile
+  // (the unit assign_argmin_merge_kernel / assign_tile_rescan_kernel work in): same rules as gemm_epilogue<true>
+  auto fold = [](float& v1, uint32_t& c1, float& v2, float w1, uint32_t d1, float w2) {
+    const bool nan = (v2 != v2) || (w2 != w2);
+    if (w1 < v1) { v2 = v1 < w2 ? v1 : w2; v1 = w1; c1 = d1; }
+    else { const float t = w1 < v2 ? w1 : v2; v2 = t; }
+    if (nan) v2 = __builtin_nanf("");
+  };
+  float bv1[4], bv2[4];
+  uint32_t bc1[4];
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    float v1 = __builtin_inff(), v2 = __builtin_inff();
+    uint32_t c1 = m0 + wr * 64 + 4 * hh;
+    bool nan = false;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const uint32_t m = m0 + wr * 64 + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+        float g = metric ? -acc[a][b][e] : cnorm[m] - 2.0f * acc[a][b][e];
+        if (m >= k_rows) g = __builtin_inff();  // padding centroids (zero rows) are not candidates
+        nan |= g != g;
+        if (g < v1) { v2 = v1; v1 = g; c1 = m; }
+        else if (g < v2 || g == v1) v2 = g;
+      }
+    if (nan) v2 = __builtin_nanf("");
+    const float w1 = __shfl_xor(v1, 32, kWave), w2 = __shfl_xor(v2, 32, kWave);  // the other half of the rows sits in lane ^ 32
+    const uint32_t d1 = (uint32_t)__shfl_xor((int)c1, 32, kWave);
+    fold(v1, c1, v2, w1, d1, w2);
+    bv1[b] = v1; bc1[b] = c1; bv2[b] = v2;
+  }
+  // rows 64..127 of a 128-centroid tile belong to the odd wave rows: through LDS (the operand tiles are dead by now: the
+  // loop ended on a barrier)
+  float* xs = reinterpret_cast<float*>(T);  // [wr >> 1][wc][b][r][3]
+  if ((wr & 1) == 1 && hh == 0) {
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      float* t = xs + ((((wr >> 1) * 2 + wc) * 4 + b) * 32 + r) * 3;
+      t[0] = bv1[b]; t[1] = __uint_as_float(bc1[b]); t[2] = bv2[b];
+    }
+  }
+  __syncthreads();
+  if ((wr & 1) == 0 && hh == 0) {
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const float* t = xs + ((((wr >> 1) * 2 + wc) * 4 + b) * 32 + r) * 3;
+      fold(bv1[b], bc1[b], bv2[b], t[0], __float_as_uint(t[1]), t[2]);
+      const uint64_t o = (uint64_t)(m0 / kGemmBM + (wr >> 1)) * N_pad + n0 + wc * 128 + b * 32 + r;
+      part_v1[o] = bv1[b]; part_c1[o] = bc1[b]; part_v2[o] = bv2[b];
+    }
+  }
+}
+// assign pass through the wide kernel when the shapes allow it (VERS_GEMM_WIDE=0: never)
+inline bool gemm_wide_ok(uint32_t k_pad, uint32_t nb_pad, bool have_split) {
+  static const bool on = [] { const char* e = getenv("VERS_GEMM_WIDE"); return !e || atoi(e) != 0; }();
+  return on && have_split && k_pad % kGemmWide == 0 && nb_pad % kGemmWide == 0;
+}
+inline hipError_t launch_gemm_wide(uint32_t k_pad, uint32_t nb_pad, hipStream_t st, const float* X, const __bf16* ch, const __bf16* cl, const float* cnorm,
+                                   uint32_t K, uint32_t N_pad, uint32_t metric, uint32_t k_rows, float* part_v1, uint32_t* part_c1, float* part_v2) {
+  static const hipError_t attr = hipFuncSetAttribute((const void*)dist_gemm_x3w_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kX3WLdsBytes);
+  if (attr != hipSuccess) return attr;
+  const uint32_t m_tiles = k_pad / kGemmWide, n_tiles = nb_pad / kGemmWide;
+  // each XCD keeps `grp` centroid tiles (256 rows x K x 4 B of hi | lo = 768 KB at K = 768) in its L2 and walks the point tiles
+  uint32_t grp = 0;
+  for (uint32_t g : {2u, 1u}) if (m_tiles % (8u * g) == 0) { grp = g; break; }
+  hipLaunchKernelGGL(dist_gemm_x3w_kernel, dim3(m_tiles * n_tiles), dim3(512), kX3WLdsBytes, st, X, ch, cl, cnorm, K, N_pad, (int)metric, m_tiles, n_tiles,
+                     grp, k_rows, part_v1, part_c1, part_v2);
+  return hipGetLastError();
 }
 
 // Launch of either contraction kernel (the bf16x3 one needs the attribute for its 80 KB of dynamic LDS: set once per

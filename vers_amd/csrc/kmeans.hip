@@ -253,10 +253,13 @@ int32_t km_assign_mfma(const float* X, uint32_t ldx, uint64_t n, const float* C,
   }
   // point batch: the per-(centroid tile, point) triples stay <= 1 GiB (the GEMM never writes its product)
   const uint32_t n_tiles = k_pad / kGemmBM;
-  uint64_t mb = ((1ull << 30) / ((uint64_t)n_tiles * 12)) / kGemmBN * kGemmBN;
+  // (batches in whole 256-point tiles when the wide contraction kernel can run: gemm_wide_ok)
+  const bool wide = gemm_wide_ok(k_pad, kGemmWide, cg_h != nullptr);
+  const uint64_t bn = wide ? (uint64_t)kGemmWide : (uint64_t)kGemmBN;
+  uint64_t mb = ((1ull << 30) / ((uint64_t)n_tiles * 12)) / bn * bn;
   if (mb > 131072) mb = 131072;
-  if (mb < (uint64_t)kGemmBN) mb = kGemmBN;
-  if (mb > round_up64(n, kGemmBN)) mb = round_up64(n, kGemmBN);
+  if (mb < bn) mb = bn;
+  if (mb > round_up64(n, bn)) mb = round_up64(n, bn);
   if (int32_t rc = ws.gt.reserve((size_t)n_tiles * mb * 12)) return rc;
   float* part_v1 = ws.gt.as<float>();
   uint32_t* part_c1 = ws.gt.as<uint32_t>() + (size_t)n_tiles * mb;
@@ -268,7 +271,7 @@ int32_t km_assign_mfma(const float* X, uint32_t ldx, uint64_t n, const float* C,
   const auto wall0 = std::chrono::steady_clock::now();
   for (uint64_t i0 = 0; i0 < n; i0 += mb) {
     const uint32_t nb = (uint32_t)((n - i0 < mb) ? (n - i0) : mb);
-    const uint32_t nb_pad = round_up(nb, kGemmBN);
+    const uint32_t nb_pad = round_up(nb, (uint32_t)bn);
     const float* xb = X + i0 * ldx;
     if (!in_place_ok || nb_pad != nb) {  // pad the columns / the tail rows through a staged copy
       if (int32_t rc = ws.xp.reserve((size_t)mb * ldq * sizeof(float))) return rc;
@@ -278,8 +281,11 @@ int32_t km_assign_mfma(const float* X, uint32_t ldx, uint64_t n, const float* C,
     }
     // (the triples are addressed with pitch mb: nb_pad <= mb)
     km_timer_begin(st);
-    VERS_HIP_TRY(launch_gemm<true>((gemm_x3_mask() & 1) != 0, k_pad / kGemmBM, nb_pad / kGemmBN, st, ws.cg.as<float>(), xb, ws.cnorm.as<float>(), ldq,
-                                   (uint32_t)mb, (float*)nullptr, metric, k, part_v1, part_c1, part_v2, cg_h, cg_l));
+    if (wide)
+      VERS_HIP_TRY(launch_gemm_wide(k_pad, nb_pad, st, xb, cg_h, cg_l, ws.cnorm.as<float>(), ldq, (uint32_t)mb, metric, k, part_v1, part_c1, part_v2));
+    else
+      VERS_HIP_TRY(launch_gemm<true>((gemm_x3_mask() & 1) != 0, k_pad / kGemmBM, nb_pad / kGemmBN, st, ws.cg.as<float>(), xb, ws.cnorm.as<float>(), ldq,
+                                     (uint32_t)mb, (float*)nullptr, metric, k, part_v1, part_c1, part_v2, cg_h, cg_l));
     km_timer_end(st, &g_bs.gemm_ms);
     g_bs.gemm_launches += 1; g_bs.gemm_flop += 2.0 * (double)nb * (double)k * (double)d;
     hipLaunchKernelGGL(assign_argmin_merge_kernel, dim3((nb + 255) / 256), dim3(256), 0, st, (const float*)part_v1, (const uint32_t*)part_c1,
