@@ -1,0 +1,39 @@
+#!/bin/bash
+# Round-3 evidence for profiles/: kernel traces (warm: means reproduce the bench line) and PMC passes (own runs, never
+# combined with other trace domains) of
+#   cfg3 batch 1024, one batch in flight   bench.py --streams 1        -> prescan_kernel_g, coarse kernels, group_scatter, ivf_rescore
+#   cfg3 batch 1024, bench default         bench.py (3 in flight)      -> the same launches with other batches beside them
+#   cfg3 single query                      bench.py --batch 1          -> scan_kernel<1,0,IvfSrc<1>>
+#   cfg2 flat scan                         scripts/bench_flat.py       -> scan_kernel<1,0,FlatSrc>
+#   k-means assign                         scripts/bench_assign.py     -> dist_gemm_x3w_kernel (+ MFMA-busy by PMC)
+#   8-way shard                            scripts/emulate_shard.py 8  -> per-kernel us of one rank's step, 1 and 3 batches in flight
+# usage (GPU box): bash scripts/profile_r03.sh ; outputs under gpurun_out/prof_r03/
+set -u
+ROOT=${GRAFT_REPO_ROOT:-$(cd "$(dirname "$0")/.." && pwd)}
+OUT=$ROOT/gpurun_out/prof_r03
+rm -rf "$OUT"; mkdir -p "$OUT"
+cd /tmp && export TMPDIR=/tmp
+B3="--streams 1 --steps 20 --warmup 5 --no-cpu --no-recall"
+B1="--batch 1 --streams 1 --steps 300 --warmup 20 --no-cpu --no-recall --no-extra --kmeans-iters 2"
+run() { # tag, counters ("" = kernel trace + stats), program args...
+  local tag=$1 ctr=$2; shift 2
+  mkdir -p "$OUT/$(dirname "$tag")"
+  if [ -z "$ctr" ]; then rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/$tag" -- python3 "$@" > "$OUT/$tag.log" 2>&1
+  else rocprofv3 --pmc $ctr --output-format csv -d "$OUT/$tag" -- python3 "$@" > "$OUT/$tag.log" 2>&1; fi
+}
+run cfg3/trace "" "$ROOT/bench.py" $B3
+run cfg3/pmc_fetch "FETCH_SIZE" "$ROOT/bench.py" $B3
+run cfg3/pmc_write "WRITE_SIZE" "$ROOT/bench.py" $B3
+run cfg3/pmc_mfma "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_INSTS_VALU_MFMA_MOPS_F32 SQ_WAVES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE" "$ROOT/bench.py" $B3
+run cfg3/pmc_sq "SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_LDS" "$ROOT/bench.py" $B3
+run cfg3_s3/trace "" "$ROOT/bench.py" --steps 20 --warmup 5 --no-cpu --no-recall --no-extra
+run b1/trace "" "$ROOT/bench.py" $B1
+run b1/pmc_fetch "FETCH_SIZE" "$ROOT/bench.py" $B1
+run flat/trace "" "$ROOT/scripts/bench_flat.py"
+run flat/pmc_fetch "FETCH_SIZE" "$ROOT/scripts/bench_flat.py"
+run kmeans/trace "" "$ROOT/scripts/bench_assign.py"
+run kmeans/pmc_mfma "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES SQ_WAVES SQ_WAVE_CYCLES GRBM_GUI_ACTIVE" "$ROOT/scripts/bench_assign.py"
+run shard8/trace "" "$ROOT/scripts/emulate_shard.py" 8 0
+STREAMS=3 run shard8_s3/trace "" "$ROOT/scripts/emulate_shard.py" 8 0
+python3 "$ROOT/scripts/summarize_r03.py" "$OUT" > "$OUT/summary.txt" 2>&1
+cat "$OUT/summary.txt"
