@@ -214,7 +214,7 @@ __device__ __forceinline__ bool owns_list(uint32_t L) { return ((L >> 2) % gridD
 // lists: a thread owns FOUR consecutive lists (three 16-byte loads, a serial scan in registers), the waves scan the
 // thread totals by shuffles, 16 wave totals go through LDS, a running carry links the rounds.  One round and two block
 // barriers at 4096 lists.
-__device__ __forceinline__ void group_lists(const GroupArgs& a, uint32_t* tab) {
+__device__ __forceinline__ uint32_t group_lists(const GroupArgs& a, uint32_t* tab) {
   __shared__ uint32_t wp[16], wg[16], wi[16], wh[16];
   __shared__ unsigned long long ur, sr;
   const uint32_t* cnt = a.cnt; const uint32_t* list_len = a.slot_len; const uint32_t* hot = a.hot;
@@ -299,46 +299,37 @@ __device__ __forceinline__ void group_lists(const GroupArgs& a, uint32_t* tab) {
     }
     cp += rp; cg += rg; ci += ri; ch += rh;
   }
-  __syncthreads();
+  // (the item offsets of the lists that are not hot are stored UNSHIFTED: their only reader, list_items below, adds the hot
+  // lists' total `ch` -- identical in every thread -- itself; round 2 read every entry back and rewrote it)
+  if (blockIdx.x == 0) {  // traffic statistics of the batch: one block's job
+    __syncthreads();
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) {  // (1024 threads adding into two LDS words one by one was most of this kernel)
-    my_ur += __shfl_xor(my_ur, off, kWave);
-    my_sr += __shfl_xor(my_sr, off, kWave);
-  }
-  if (lane == 0) {
-    atomicAdd(&ur, my_ur);
-    atomicAdd(&sr, my_sr);
-  }
-  __syncthreads();
-  for (uint32_t base0 = 0; base0 < k_lists; base0 += 4 * kGroupThreads) {  // (each thread shifts the entries it wrote itself)
-    const uint32_t i0 = base0 + 4u * threadIdx.x;
-    if (i0 >= k_lists) continue;
-    const bool mine = owns_list(i0);
-    if (!mine && tab == nullptr) continue;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      const uint32_t L = i0 + e;
-      if (L < k_lists && cnt[L] != 0 && hot[L] == 0) {
-        if (mine) a.item_off[L] += ch;
-        if (tab != nullptr) tab[2 * k_lists + L] += ch;
-      }
+    for (int off = 32; off > 0; off >>= 1) {  // (1024 threads adding into two LDS words one by one was most of this kernel)
+      my_ur += __shfl_xor(my_ur, off, kWave);
+      my_sr += __shfl_xor(my_sr, off, kWave);
+    }
+    if (lane == 0) {
+      atomicAdd(&ur, my_ur);
+      atomicAdd(&sr, my_sr);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      a.tot->n_items = ci + ch; a.tot->n_groups = cg; a.tot->n_pairs = cp; a.tot->pad = 0;
+      a.tot->union_rows = ur; a.tot->streamed_rows = sr;
     }
   }
-  if (blockIdx.x == 0 && threadIdx.x == 0) {
-    a.tot->n_items = ci + ch; a.tot->n_groups = cg; a.tot->n_pairs = cp; a.tot->pad = 0;
-    a.tot->union_rows = ur; a.tot->streamed_rows = sr;
-  }
+  return ch;
 }
 
 // items + group descriptors of one list (of this block: the offsets are its own stores of the phase before)
-__device__ __forceinline__ void list_items(uint32_t L, const GroupArgs& a, const uint32_t* tab) {
+__device__ __forceinline__ void list_items(uint32_t L, const GroupArgs& a, const uint32_t* tab, uint32_t hot_items) {
   const uint32_t c = a.cnt[L];
   if (!c) return;
   const uint32_t QG = a.QG, len = a.slot_len[L];
   const uint32_t sr = list_seg_rows(len, a.seg_rows, a.seg_target);
   const uint32_t n_g = (c + QG - 1) / QG, n_s = (len + sr - 1) / sr;
   const uint32_t n_s_pad = QG == 1 ? n_s : (n_s + 3) / 4 * 4;
-  uint32_t o = tab ? tab[2 * a.k_lists + L] : ld_l2(a.item_off + L);
+  uint32_t o = (tab ? tab[2 * a.k_lists + L] : ld_l2(a.item_off + L)) + (a.hot[L] ? 0u : hot_items);  // work order: hot lists first
   const uint32_t g0 = tab ? tab[a.k_lists + L] : ld_l2(a.group_off + L), p0 = tab ? tab[L] : ld_l2(a.pair_off + L);
   for (uint32_t g = 0; g < n_g; ++g) a.groups[g0 + g] = GroupDesc{p0 + g * QG, (c - g * QG < QG) ? c - g * QG : QG};
   if (QG == 1) {
@@ -362,7 +353,7 @@ __global__ __launch_bounds__(kGroupThreads) void group_scatter_kernel(GroupArgs 
   const bool use_tab = a.k_lists <= kGroupTabMax;
   const u32x4 ff = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
   for (uint64_t i = tid; i < a.ff_vec16; i += nthreads) a.ff_begin[i] = ff;
-  group_lists(a, use_tab ? pair_tab : nullptr);
+  const uint32_t hot_items = group_lists(a, use_tab ? pair_tab : nullptr);
   // what a block reads back below it stored ITSELF: its stores only have to have reached ITS L2 (release at workgroup
   // scope = wait for them; an agent-scope fence writes the whole L2 back -- that alone was 8 us here) and the read-backs
   // go past the vector L1 (ld_l2).  With the LDS tables nothing is read back at all.
@@ -394,7 +385,7 @@ __global__ __launch_bounds__(kGroupThreads) void group_scatter_kernel(GroupArgs 
     const uint32_t gran = blockIdx.x + (w >> 2) * gridDim.x;
     if (gran >= n_gran) break;
     const uint32_t L = 4 * gran + (w & 3u);
-    if (L < a.k_lists) list_items(L, a, use_tab ? pair_tab : nullptr);
+    if (L < a.k_lists) list_items(L, a, use_tab ? pair_tab : nullptr, hot_items);
   }
   stamp(3);
 }
