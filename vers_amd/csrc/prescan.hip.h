@@ -824,7 +824,6 @@ __global__ __launch_bounds__(kWave * kRescoreWaves) void ivf_rescore_kernel(Resc
     const uint32_t n_surv = (uint32_t)__popcll(__ballot(survivor));
     mine = survivor ? list : kKeyMax;
     srow[lane] = wave_seq_rows(list, survivor, lane, pl, pp, a.P, a.list_off);
-    sh[1][lane] = mine;  // (the waves that chain a survivor need its sequence number; sh[w] of the merge is dead by now)
     if (lane == 0) {
       s_failed = certified ? 0u : 1u;
       s_nsurv = n_surv;
@@ -843,54 +842,19 @@ __global__ __launch_bounds__(kWave * kRescoreWaves) void ivf_rescore_kernel(Resc
   bool nan_seen = false;
   const f32x4* q4p = reinterpret_cast<const f32x4*>(qs);
   if (stage_rows) {
-    // Every WAVE stages and chains its own two rows per round (survivor i: round i / 8, wave (i % 8) / 2), out of its own
-    // quarter of the staging area -- no block barrier inside the loop -- with the NEXT round's pieces already in flight in
-    // registers while this round's chains run (a chain is 3 d dependent VALU steps whatever the number of active lanes:
-    // ~3.8 us at d = 768; a gather round trip about as much).  Round 2 staged eight rows block-wide, waited, chained them in
-    // wave 0 and synchronised twice per round: gather + chain + barriers in series, 45 of the kernel's 84 us at 8 ranks.
     const uint32_t n4 = a.ld / 4, pitch = a.ld + 4;
-    constexpr uint32_t kRowsPerWave = kRescoreChunk / kRescoreWaves;  // 2
-    constexpr uint32_t kMaxPieces = 8;                                 // f32x4 per lane and round kept in registers: ld <= 1024 (else they are re-read)
-    float* my_xs = xs + (size_t)wid * kRowsPerWave * pitch;
-    const uint32_t n_rounds = (n_surv + kRescoreChunk - 1) / kRescoreChunk;
-    const uint32_t per_lane = (kRowsPerWave * n4 + kWave - 1) / kWave;  // pieces a lane fetches per round
-    const bool in_regs = per_lane <= kMaxPieces;
-    f32x4 pre[kMaxPieces];
-    // piece t of this wave's rows in round rnd.  ALWAYS a valid address (clamped to the last piece / the last survivor): the
-    // loads are unconditional -- a branch around a load costs a vmcnt(0) each -- and what a clamped load brings is never chained
-    auto piece_ptr = [&](uint32_t rnd, uint32_t t) -> const f32x4* {
-      t = t < kRowsPerWave * n4 ? t : kRowsPerWave * n4 - 1;
-      const uint32_t rr = t / n4, j = t - rr * n4;
-      uint32_t ci = rnd * kRescoreChunk + (uint32_t)wid * kRowsPerWave + rr;
-      ci = ci < n_surv ? ci : n_surv - 1;
-      const uint32_t row = srow[ci];
-      return a.rows_rm ? reinterpret_cast<const f32x4*>(a.rows_rm + (uint64_t)row * a.ld) + j  // consecutive lanes: consecutive 16 bytes of a row
-                       : reinterpret_cast<const f32x4*>(a.rows + (uint64_t)(row >> 6) * 64ull * a.ld) + (row & 63) + (uint64_t)j * 64;
-    };
-    auto fetch = [&](uint32_t rnd) {
-#pragma unroll
-      for (uint32_t u = 0; u < kMaxPieces; ++u)
-        if (u < per_lane) pre[u] = *piece_ptr(rnd, (uint32_t)lane + u * kWave);  // (wave-uniform condition)
-    };
-    if (in_regs && n_rounds) fetch(0);
-    for (uint32_t rnd = 0; rnd < n_rounds; ++rnd) {
-      if (in_regs) {
-#pragma unroll
-        for (uint32_t u = 0; u < kMaxPieces; ++u) {
-          const uint32_t t = (uint32_t)lane + u * kWave;
-          if (u < per_lane && t < kRowsPerWave * n4) *reinterpret_cast<f32x4*>(my_xs + (size_t)(t / n4) * pitch + 4 * (t % n4)) = pre[u];
-        }
-        if (rnd + 1 < n_rounds) fetch(rnd + 1);
-      } else {
-        for (uint32_t t = (uint32_t)lane; t < kRowsPerWave * n4; t += kWave) {
-          *reinterpret_cast<f32x4*>(my_xs + (size_t)(t / n4) * pitch + 4 * (t % n4)) = *piece_ptr(rnd, t);
-        }
+    for (uint32_t c0 = 0; c0 < n_surv; c0 += kRescoreChunk) {  // block-uniform
+      const uint32_t nc = n_surv - c0 < kRescoreChunk ? n_surv - c0 : kRescoreChunk;
+      for (uint32_t idx = threadIdx.x; idx < nc * n4; idx += blockDim.x) {
+        const uint32_t c = idx / n4, j = idx - c * n4;
+        const uint32_t row = srow[c0 + c];
+        *reinterpret_cast<f32x4*>(xs + (size_t)c * pitch + 4 * j) =
+            a.rows_rm ? reinterpret_cast<const f32x4*>(a.rows_rm + (uint64_t)row * a.ld)[j]  // consecutive threads: consecutive 16 bytes of a row
+                      : (reinterpret_cast<const f32x4*>(a.rows + (uint64_t)(row >> 6) * 64ull * a.ld) + (row & 63))[(uint64_t)j * 64];
       }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();  // (LDS operations of one wave complete in order: its own stores are visible to its loads)
-      const uint32_t ci = rnd * kRescoreChunk + (uint32_t)wid * kRowsPerWave + (uint32_t)lane;
-      if ((uint32_t)lane < kRowsPerWave && ci < n_surv) {
-        const f32x4* xp = reinterpret_cast<const f32x4*>(my_xs + (size_t)lane * pitch);
+      __syncthreads();
+      if (wid == 0 && (uint32_t)lane >= c0 && (uint32_t)lane < c0 + nc) {
+        const f32x4* xp = reinterpret_cast<const f32x4*>(xs + (size_t)((uint32_t)lane - c0) * pitch);
         float acc = 0.0f;
         for (uint32_t j = 0; j < n4; ++j) {
           const f32x4 x4 = xp[j];
@@ -907,14 +871,10 @@ __global__ __launch_bounds__(kWave * kRescoreWaves) void ivf_rescore_kernel(Resc
         }
         if (a.metric) acc = __fsub_rn(1.0f, acc);
         nan_seen |= acc != acc;
-        sh[0][ci] = make_key(acc, (uint32_t)sh[1][ci]);  // (sh[1][i] holds survivor i's approximate key: its low word is the sequence number)
+        cand = make_key(acc, (uint32_t)mine);
       }
-      __builtin_amdgcn_wave_barrier();  // the chains are done with the rows before the next round overwrites them
+      __syncthreads();  // the chunk's readers are done before the next one is staged
     }
-    if (__ballot(nan_seen) != 0 && lane == 0) atomicOr(a.status, 1u);
-    nan_seen = false;
-    __syncthreads();
-    if (wid == 0) cand = (uint32_t)lane < n_surv ? sh[0][lane] : kKeyMax;
   } else if (wid == 0 && (uint32_t)lane < n_surv) {
     const uint32_t row = srow[lane];
     const f32x4* xp = a.rows_rm ? reinterpret_cast<const f32x4*>(a.rows_rm + (uint64_t)row * a.ld)
