@@ -1952,6 +1952,17 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
   // matrix-core scan: an average list is one quad of items (per-item set-up and the block's barriers amortise over
   // ~10 tiles; measured at cfg3: 640-row targets beat 256- and 1024-row ones)
   if (use_pre) seg_rows = (uint32_t)round_up64(std::max<uint64_t>(256, (avg_len_all + 3) / 4), kWave);
+  if (use_pre) {
+    // ... unless that leaves fewer than ~8 quads per CU -- the lists sharded over GPUs: 2.7 at 8 ranks, the last third of the
+    // launch half empty.  Then the lists are cut finer; the scan hands quads out in RUNS and stages once per run of one list
+    // (prescan_kernel_g), so the finer cut costs no staging while work is plentiful and balances the tail.
+    const uint64_t lists_here = std::max<uint64_t>(1, lists_est / std::max<uint32_t>(1, h->world));
+    const uint64_t quads_est = lists_here * std::max<uint64_t>(1, pairs_est / std::max<uint64_t>(1, lists_est * kPreQ));
+    static const int fine_max = [] { const char* e = getenv("VERS_FINE_QUADS"); return e ? atoi(e) : 4; }();  // A/B knob: 1 = never
+    uint32_t fine = 1;
+    while ((int)fine < fine_max && quads_est * fine < 8ull * (uint64_t)h->n_cu && seg_rows / (2 * fine) >= 128) fine *= 2;
+    seg_rows = (uint32_t)round_up64(seg_rows / fine, kWave);
+  }
   if (knobs().seg_rows > 0) seg_rows = (uint32_t)round_up64(std::max(64l, knobs().seg_rows), kWave);  // tuning knob
   // matrix-core scan: per-list balanced segments of about seg_rows rows (list_seg_rows)
   // per-list balanced segments (list_seg_rows): same-box A/B at cfg3 5.96 ms vs 6.27 ms with fixed 640-row segments;

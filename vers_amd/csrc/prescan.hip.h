@@ -495,25 +495,47 @@ __global__ __launch_bounds__(kWave * kPreWavesG) __attribute__((amdgpu_waves_per
   const uint32_t n_quads = src.n_items() / 4;
   const unsigned long long clk0 = (p.debug & 16u) ? __builtin_amdgcn_s_memtime() : 0ull;
   const unsigned long long rt0 = (p.debug & 16u) ? __builtin_amdgcn_s_memrealtime() : 0ull;
-  uint32_t prev_it0 = 0xFFFFFFFFu, prev_nq = 0;  // the quad whose lists still sit in LDS
-  auto write_out = [&]() {  // block-wide, between barriers: the finished quad's buffers -> sorted kp keys in its partial slots
-    if (prev_it0 == 0xFFFFFFFFu) return;
+  // Quads are handed out in RUNS (guided self-scheduling): a block takes `remaining / (2 * blocks)` consecutive quads at a time,
+  // at most kMaxRun, down to one at the end of the launch -- long stretches while there is plenty of work, single quads when
+  // the last CUs are being filled.  Consecutive quads of one (list, query group) share their query block and their candidate
+  // buffers: the block stages ONCE for them and leaves ONE partial slot (the first quad's; the others' are written empty).
+  // That is what lets the host cut the lists of a SHARDED scan into finer quads (2.7 whole-list quads per CU at 8 ranks left
+  // the last third of the launch half empty) without paying the 6 us of staging per quad.
+  constexpr uint32_t kMaxRun = 8;
+  uint32_t run_first = 0xFFFFFFFFu, run_last = 0, prev_nq = 0;  // the quads whose lists still sit in LDS (one merged run)
+  uint32_t cur_list = 0xFFFFFFFFu, cur_group = 0;
+  auto write_out = [&]() {  // block-wide, between barriers: the finished run's buffers -> sorted kp keys in its first quad's partial slots
+    if (run_first == 0xFFFFFFFFu) return;
     for (uint32_t qi = (uint32_t)wid; qi < prev_nq; qi += kPreWavesG) {  // a wave per query
       const uint32_t cv = ctl[qi];
       const uint64_t srt = buffer_sorted(buf + (size_t)qi * cap, cv < cap ? cv : cap, cap, lane);
-      if (lane < (int)p.kp) src.out_quad(prev_it0, (int)qi)[lane] = srt;
+      if (lane < (int)p.kp) {
+        src.out_quad(run_first * 4, (int)qi)[lane] = srt;
+        for (uint32_t b = run_first + 1; b <= run_last; ++b) src.out_quad(b * 4, (int)qi)[lane] = kKeyMax;  // (the exact finish reads every slot of a scanned list)
+      }
       if (lane == (int)p.kp - 1 && srt != kKeyMax && !(p.debug & 8192u))  // a full list: its last val bounds the query's kp-th smallest
-        atomicMin(p.bounds32 + src.bound_slot(prev_it0, (int)qi), (uint32_t)(srt >> 32));
+        atomicMin(p.bounds32 + src.bound_slot(run_first * 4, (int)qi), (uint32_t)(srt >> 32));
     }
   };
   for (uint32_t b0 = blockIdx.x;; b0 += gridDim.x) {
-    uint32_t bi = b0;
+    uint32_t start = b0, count = 1;
     if (p.next_quad != nullptr) {
-      if (threadIdx.x == 0) *nq_lds = atomicAdd(p.next_quad, 1u);
+      if (threadIdx.x == 0) {
+        const uint32_t seen = __hip_atomic_load(p.next_quad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        uint32_t r = seen < n_quads ? (n_quads - seen) / (2u * gridDim.x) : 1u;
+        r = r < 1u ? 1u : (r > kMaxRun ? kMaxRun : r);
+        nq_lds[0] = atomicAdd(p.next_quad, r);
+        nq_lds[1] = r;
+      }
       __syncthreads();
-      bi = *nq_lds;
+      start = nq_lds[0]; count = nq_lds[1];
     }
-    if (bi >= n_quads) break;
+    if (start >= n_quads) break;
+    const uint32_t end = start + count < n_quads ? start + count : n_quads;
+    for (uint32_t bi = start; bi < end; ++bi) {
+    const ItemDesc d0 = src.items[4 * bi];
+    // (block-uniform.  Only the quad right behind the run's last one: the slots written empty must be this block's own)
+    const bool cont = run_first != 0xFFFFFFFFu && bi == run_last + 1 && d0.list == cur_list && d0.group == cur_group;
     const uint32_t it = bi * 4 + (wid & 3);
     ItemView<kPreQ> v;
     src.get(it, v);
@@ -523,7 +545,7 @@ __global__ __launch_bounds__(kWave * kPreWavesG) __attribute__((amdgpu_waves_per
     // holds <= 16 queries, so that all threads load) and its row pointer is resolved here, ahead of the barrier.
     const uint32_t ns = (BF || v.nq > 16) ? 32u : 16u;
     const uint32_t slot = threadIdx.x & (ns - 1u), cg0 = threadIdx.x / ns, cg_step = (kWave * kPreWavesG) / ns;
-    const float* qrow = slot < v.nq ? src.query_row(it, slot) : nullptr;
+    const float* qrow = (!cont && slot < v.nq) ? src.query_row(it, slot) : nullptr;
     auto stage = [&]() {
       const unsigned long long ts0 = (p.debug & 16u) ? __builtin_amdgcn_s_memtime() : 0ull;
       // the first kStageU loads of every thread go out BEFORE the barriers (they fly while the slowest wave of the
@@ -578,9 +600,16 @@ __global__ __launch_bounds__(kWave * kPreWavesG) __attribute__((amdgpu_waves_per
         atomicAdd(p.stamps + 6, 1ull);
       }
     };
-    prescan_item_g<BF>(src, p, it, v, wid >> 2, lane, qlds, buf, ctl, stage);
-    prev_it0 = bi * 4;
-    prev_nq = v.nq;
+    if (cont) {  // same query block, same buffers: nothing to stage, nothing to wait for
+      prescan_item_g<BF>(src, p, it, v, wid >> 2, lane, qlds, buf, ctl, [] {});
+      run_last = bi;
+    } else {
+      prescan_item_g<BF>(src, p, it, v, wid >> 2, lane, qlds, buf, ctl, stage);
+      run_first = run_last = bi;
+      cur_list = d0.list; cur_group = d0.group;
+      prev_nq = v.nq;
+    }
+    }  // quads of the run
   }
   __syncthreads();
   write_out();
