@@ -417,6 +417,12 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2
 // The coarse quantiser (1024 x 4096) would be 64 such blocks on 256 CUs and stays on the 128 x 128 tiles.
 constexpr int kGemmWide = 256;
 constexpr size_t kX3WLdsBytes = 2 * 2 * 2 * (size_t)kGemmWide * kX3Pitch * 2;  // two buffers x A|B x hi|lo = 128 KB
+// SCHED = 1: the tile step is written as  fragment reads -> [MFMAs with the SPLIT of the next tile's point operand between
+// them] x 2 k-steps -> LDS stores of the next tile -> global loads -> barrier,  with scheduling groups that ask for one MFMA
+// followed by two VALU instructions: the split's conversions issue in the shadow of the matrix cores (a wave cannot issue its
+// next MFMA for ~28 cycles anyway) instead of in a phase of their own in which -- the eight waves of the block moving in
+// lockstep -- the matrix cores idle.  SCHED = 0 is the plain order (stores of tile t + 1, loads of t + 2, compute t).
+template <int SCHED>
 static __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void dist_gemm_x3w_kernel(
     const float* __restrict__ X, const __bf16* __restrict__ Ch, const __bf16* __restrict__ Cl, const float* __restrict__ cnorm, uint32_t K,
     uint32_t N_pad, int metric, uint32_t m_tiles, uint32_t n_tiles, uint32_t grp, uint32_t k_rows, float* __restrict__ part_v1,
@@ -508,11 +514,71 @@ static __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2
   lstore(0);
   gload(kclamp(1));
   __syncthreads();
-  for (uint32_t t = 0; t < k_tiles; ++t) {
-    lstore((int)((t + 1) & 1));  // tile t + 1 (its buffer's readers finished before the last barrier)
-    gload(kclamp(t + 2));
-    compute((int)(t & 1));
-    __syncthreads();
+  if constexpr (SCHED == 0) {
+    for (uint32_t t = 0; t < k_tiles; ++t) {
+      lstore((int)((t + 1) & 1));  // tile t + 1 (its buffer's readers finished before the last barrier)
+      gload(kclamp(t + 2));
+      compute((int)(t & 1));
+      __syncthreads();
+    }
+  } else {
+    for (uint32_t t = 0; t < k_tiles; ++t) {
+      const int buf = (int)(t & 1), nbuf = buf ^ 1;
+      bf16x4 sh[4], sl[4];  // the next tile's point slots of this thread, split
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const int ko = x3_chunk(r, 2 * s2 + hh);
+        bf16x8 ah[2], al[2], bh[4], bl[4];
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+          ah[tt] = *reinterpret_cast<const bf16x8*>(Tp(buf, 0, 0) + (wr * 64 + tt * 32 + r) * kX3Pitch + ko);
+          al[tt] = *reinterpret_cast<const bf16x8*>(Tp(buf, 0, 1) + (wr * 64 + tt * 32 + r) * kX3Pitch + ko);
+        }
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+          bh[tt] = *reinterpret_cast<const bf16x8*>(Tp(buf, 1, 0) + (wc * 128 + tt * 32 + r) * kX3Pitch + ko);
+          bl[tt] = *reinterpret_cast<const bf16x8*>(Tp(buf, 1, 1) + (wc * 128 + tt * 32 + r) * kX3Pitch + ko);
+        }
+#pragma unroll
+        for (int i = 2 * s2; i < 2 * s2 + 2; ++i)  // half of the split per k-step
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            sh[i][u] = (__bf16)rb[i][u];
+            sl[i][u] = (__bf16)(rb[i][u] - (float)sh[i][u]);
+          }
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int b = 0; b < 4; ++b) {
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a], bh[b], acc[a][b], 0, 0, 0);  // small terms first
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bl[b], acc[a][b], 0, 0, 0);
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bh[b], acc[a][b], 0, 0, 0);
+          }
+        // the order asked of the scheduler for this k-step: its fragment reads, then MFMA / VALU / VALU ...
+        __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);  // DS reads
+#pragma unroll
+        for (int g = 0; g < 24; ++g) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one MFMA
+          __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);  // two VALU
+        }
+      }
+      // tile t + 1 into the other buffer (its readers finished before the last barrier), then the loads of tile t + 2
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int idx = tid + 512 * i, row = idx >> 2, at = row * kX3Pitch + x3_chunk(row, idx & 3);
+        *reinterpret_cast<f32x4*>(Tp(nbuf, 0, 0) + at) = ra[i];
+        *reinterpret_cast<f32x4*>(Tp(nbuf, 0, 1) + at) = ra[2 + i];
+      }
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const int idx = tid + 512 * i, row = idx >> 3, c4 = idx & 7;
+        const int at = row * kX3Pitch + x3_chunk(row, c4 >> 1) + (c4 & 1) * 4;
+        *reinterpret_cast<bf16x4*>(Tp(nbuf, 1, 0) + at) = sh[i];
+        *reinterpret_cast<bf16x4*>(Tp(nbuf, 1, 1) + at) = sl[i];
+      }
+      gload(kclamp(t + 2));
+      __syncthreads();
+    }
   }
   // epilogue: per point (column) the smallest value, its centroid and the second smallest over each 128-centroid row tile
   // (the unit assign_argmin_merge_kernel / assign_tile_rescan_kernel work in): same rules as gemm_epilogue<true>
@@ -568,20 +634,29 @@ static __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2
   }
 }
 // assign pass through the wide kernel when the shapes allow it (VERS_GEMM_WIDE=0: never)
+inline int gemm_wide_mode() {  // VERS_GEMM_WIDE: 0 = never, 1 = plain order, 2 = interleaved (default)
+  static const int m = [] { const char* e = getenv("VERS_GEMM_WIDE"); return e ? atoi(e) : 2; }();
+  return m;
+}
 inline bool gemm_wide_ok(uint32_t k_pad, uint32_t nb_pad, bool have_split) {
-  static const bool on = [] { const char* e = getenv("VERS_GEMM_WIDE"); return !e || atoi(e) != 0; }();
-  return on && have_split && k_pad % kGemmWide == 0 && nb_pad % kGemmWide == 0;
+  return gemm_wide_mode() != 0 && have_split && k_pad % kGemmWide == 0 && nb_pad % kGemmWide == 0;
 }
 inline hipError_t launch_gemm_wide(uint32_t k_pad, uint32_t nb_pad, hipStream_t st, const float* X, const __bf16* ch, const __bf16* cl, const float* cnorm,
                                    uint32_t K, uint32_t N_pad, uint32_t metric, uint32_t k_rows, float* part_v1, uint32_t* part_c1, float* part_v2) {
-  static const hipError_t attr = hipFuncSetAttribute((const void*)dist_gemm_x3w_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kX3WLdsBytes);
-  if (attr != hipSuccess) return attr;
+  static const hipError_t attr0 = hipFuncSetAttribute((const void*)dist_gemm_x3w_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kX3WLdsBytes);
+  static const hipError_t attr1 = hipFuncSetAttribute((const void*)dist_gemm_x3w_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kX3WLdsBytes);
+  if (attr0 != hipSuccess) return attr0;
+  if (attr1 != hipSuccess) return attr1;
   const uint32_t m_tiles = k_pad / kGemmWide, n_tiles = nb_pad / kGemmWide;
   // each XCD keeps `grp` centroid tiles (256 rows x K x 4 B of hi | lo = 768 KB at K = 768) in its L2 and walks the point tiles
   uint32_t grp = 0;
   for (uint32_t g : {2u, 1u}) if (m_tiles % (8u * g) == 0) { grp = g; break; }
-  hipLaunchKernelGGL(dist_gemm_x3w_kernel, dim3(m_tiles * n_tiles), dim3(512), kX3WLdsBytes, st, X, ch, cl, cnorm, K, N_pad, (int)metric, m_tiles, n_tiles,
-                     grp, k_rows, part_v1, part_c1, part_v2);
+  if (gemm_wide_mode() == 1)
+    hipLaunchKernelGGL(dist_gemm_x3w_kernel<0>, dim3(m_tiles * n_tiles), dim3(512), kX3WLdsBytes, st, X, ch, cl, cnorm, K, N_pad, (int)metric, m_tiles,
+                       n_tiles, grp, k_rows, part_v1, part_c1, part_v2);
+  else
+    hipLaunchKernelGGL(dist_gemm_x3w_kernel<1>, dim3(m_tiles * n_tiles), dim3(512), kX3WLdsBytes, st, X, ch, cl, cnorm, K, N_pad, (int)metric, m_tiles,
+                       n_tiles, grp, k_rows, part_v1, part_c1, part_v2);
   return hipGetLastError();
 }
 

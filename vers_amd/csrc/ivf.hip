@@ -1958,7 +1958,10 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
     // (prescan_kernel_g), so the finer cut costs no staging while work is plentiful and balances the tail.
     const uint64_t lists_here = std::max<uint64_t>(1, lists_est / std::max<uint32_t>(1, h->world));
     const uint64_t quads_est = lists_here * std::max<uint64_t>(1, pairs_est / std::max<uint64_t>(1, lists_est * kPreQ));
-    static const int fine_max = [] { const char* e = getenv("VERS_FINE_QUADS"); return e ? atoi(e) : 4; }();  // A/B knob: 1 = never
+    // (measured, same box, 8 ranks: 392 us with whole-list quads, 425 with four quads per list, 0.497 / 0.523 / 0.537 ms per step
+    // with three batches in flight at 1 / 2 / 4 -- a short item pays its pipeline fill and its waves' waits for each other
+    // whatever the staging costs: OFF by default, VERS_FINE_QUADS=2|4 to try)
+    static const int fine_max = [] { const char* e = getenv("VERS_FINE_QUADS"); return e ? atoi(e) : 1; }();
     uint32_t fine = 1;
     while ((int)fine < fine_max && quads_est * fine < 8ull * (uint64_t)h->n_cu && seg_rows / (2 * fine) >= 128) fine *= 2;
     seg_rows = (uint32_t)round_up64(seg_rows / fine, kWave);
