@@ -398,8 +398,12 @@ __global__ __launch_bounds__(kWave * kMergeWaves) void plan1_kernel(
     const uint64_t* cpart, uint32_t n_segs_c, uint32_t P, uint32_t k_lists, uint32_t top_k, int ref_mode, const uint32_t* list_len,
     const uint8_t* owner, uint32_t rank, uint32_t seg_rows, uint64_t* probe, uint32_t* pj_list, uint32_t* pj_pref, uint32_t* pj_take,
     uint32_t* np, uint32_t* cnt, uint32_t* pair_off, uint32_t* group_off, uint32_t* pairs, ItemDesc* items, GroupDesc* groups,
-    GroupTotals* tot, uint32_t* status, const uint32_t* list_slot) {
+    GroupTotals* tot, uint32_t* status, const uint32_t* list_slot, u32x4* ff_begin, uint32_t ff_vec16) {
   __shared__ uint64_t sh[kMergeWaves][kWave];
+  {  // the list scan's partial slots start out empty (all ones): the block's 1024 threads do it here instead of a memset launch of its own
+    const u32x4 ff = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+    for (uint32_t i = threadIdx.x; i < ff_vec16; i += kWave * kMergeWaves) ff_begin[i] = ff;
+  }
   const uint64_t list = block_merge_keys(cpart, n_segs_c * P, P, sh);
   if (threadIdx.x >= kWave) return;
   const int lane = threadIdx.x;
@@ -2043,12 +2047,14 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
   if (n_pass > 1)
     if (int32_t rc = W->lower.reserve(n_pj * sizeof(uint64_t))) return rc;
   if (one1) {
-    VERS_HIP_TRY(hipMemsetAsync(W->partials.p, 0xFF, part_bytes, st));
+    const bool fill_in_kernel = part_bytes <= (size_t(4) << 20);  // (a block fills a few hundred KB faster than a launch costs)
+    if (!fill_in_kernel) VERS_HIP_TRY(hipMemsetAsync(W->partials.p, 0xFF, part_bytes, st));
     hipLaunchKernelGGL(plan1_kernel, dim3(1), dim3(kWave * kMergeWaves), 0, st, W->cpart.as<uint64_t>(), n_segs_c, P, k_l, top_k,
                        ref_mode, h->list_len.as<uint32_t>(), h->world > 1 ? h->owner.as<uint8_t>() : (const uint8_t*)nullptr, h->rank,
                        seg_rows, W->probe.as<uint64_t>(), pj_list, pj_pref, pj_take, np, cnt, pair_off, group_off,
                        W->pairs.as<uint32_t>(), W->items.as<ItemDesc>(), W->groups.as<GroupDesc>(), tot, W->st_word(),
-                       (const uint32_t*)h->list_slot.as<uint32_t>());
+                       (const uint32_t*)h->list_slot.as<uint32_t>(), reinterpret_cast<u32x4*>(W->partials.p),
+                       fill_in_kernel ? (uint32_t)((part_bytes + 15) / 16) : 0u);
     VERS_HIP_TRY(hipGetLastError());
   } else {
   // (also a single query with P > 64)
