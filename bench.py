@@ -181,8 +181,8 @@ def main():
     # S batches in flight: step i runs on stream i % S with its own outputs; the library gives a stream's calls their own
     # workspace.  The list scan fills every CU, but what surrounds it -- coarse quantiser, planning, exact finish: a dozen
     # latency-bound launches that do NOT shrink when the lists are sharded over GPUs -- overlaps with another batch's scan.
-    # (Round 2 measured this and backed off because the planning kernel's spinning grid barrier could hang the GPU with
-    # several of them in flight; nothing in the search path waits for another block any more: DESIGN.md section 5.)
+    # (Round 2 measured this and backed off because the GPU hung in some stream mixes -- its planning kernel spun on a grid
+    # barrier; nothing in the search path waits for another block any more: DESIGN.md section 5.)
     S = max(1, args.streams)
     streams = [torch.cuda.current_stream()] if S == 1 else [torch.cuda.Stream() for _ in range(S)]
     outs = [dict(ids=torch.zeros(B, top_k, dtype=torch.int64, device=dev), dst=torch.zeros(B, top_k, dtype=torch.float32, device=dev),

@@ -1,10 +1,11 @@
 """Many batches in flight on one index: host threads x streams, certificates forced to fail, for tens of seconds.
 
-Round 2's planning kernel separated its phases by a SPINNING grid barrier (64 blocks that each take a whole CU).  With a
-few of those in flight at once -- one per host thread / per stream with its own workspace -- the resident blocks of one
-launch hold the CUs the missing blocks of another need and the GPU hangs (scripts/probe/spin_residency.hip reproduces the
-mechanism with a bounded spin).  No kernel of the search path waits for another block any more (plan.hip.h); this is the
-test that the old code could not be allowed to run.  The work happens in a CHILD process: a hung child is killed and the
+Round 2's planning kernel separated its phases by a SPINNING grid barrier (64 blocks that each take a whole CU), launched
+without any co-residency guarantee, and round 2 saw the GPU hang with several calls of one handle in flight on different streams;
+it backed off to one workspace per host thread without finding the trigger.  (A bounded-spin probe of the suspected mechanism,
+scripts/probe/spin_residency.hip, does NOT deadlock on this chip -- its dispatcher serves queued grids whole -- so the trigger is
+still unidentified: DESIGN.md section 5.)  What changed is the code: no kernel of the search path waits for another block any more
+(plan.hip.h), and this is the test that the old code could not be allowed to run.  The work happens in a CHILD process: a hung child is killed and the
 test fails -- a process that has touched the GPU is never re-exec'd."""
 import os
 import subprocess

@@ -7,8 +7,8 @@
 //   (2) per list : how many (query, probe) pairs, groups and work items; exclusive prefix sums over the lists
 //   (3) scatter  : pairs grouped by list, item / group descriptors
 // Rounds 1-2 ran them in one launch separated by a software grid barrier (spinning on a device counter).  A spinning
-// grid needs all its blocks co-resident, which nothing guarantees once several streams / an RCCL kernel share the CUs
-// ("the hang"): partially resident spinners of two launches can hold exactly the CU slots the
+// grid needs all its blocks co-resident, which a plain launch does not promise once several streams / an RCCL kernel share
+// the CUs ("the hang"): partially resident spinners of two launches could hold exactly the CU slots the
 // other's missing blocks need.  Here nothing spins: step (1) runs in the TAIL of the coarse quantiser's selection
 // kernel (its lane j holds the key of probe rank j -- plan_query's operand), steps (2)+(3) are ONE ordinary launch in
 // which every block computes the (cheap) prefix sums REDUNDANTLY and then serves the lists it owns (list % blocks).
