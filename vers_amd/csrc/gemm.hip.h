@@ -634,143 +634,7 @@ static __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2
   }
 }
 // assign pass through the wide kernel when the shapes allow it (VERS_GEMM_WIDE=0: never)
-// ---- the same 256 x 256 block tile with ONE wave per SIMD ------------------------------------------------------------------
-// Four waves, each a 128 x 128 sub-tile: 16 MFMA tiles = 256 accumulator registers, possible because a lone wave on a SIMD
-// owns all 512 registers.  Per k-step a wave reads 16 fragments (4 row tiles + 4 column tiles, hi | lo each) for 48 MFMAs --
-// a third of a read per MFMA, against a half in the eight-wave kernel and two thirds in the 128 x 128 one -- and a wave's 128
-// rows ARE one 128-centroid tile of the arg-min epilogue: no cross-wave fold, no LDS, no barrier there.  With nobody else on
-// the SIMD the wave has to hide its own latencies: the column fragments of the next k-step are read while the last row tile
-// of this one is multiplied, the row fragments one tile ahead, the next K-tile's split between the MFMAs.
-static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(1, 1))) void dist_gemm_x3v_kernel(
-    const float* __restrict__ X, const __bf16* __restrict__ Ch, const __bf16* __restrict__ Cl, const float* __restrict__ cnorm, uint32_t K,
-    uint32_t N_pad, int metric, uint32_t m_tiles, uint32_t n_tiles, uint32_t grp, uint32_t k_rows, float* __restrict__ part_v1,
-    uint32_t* __restrict__ part_c1, float* __restrict__ part_v2) {
-  extern __shared__ __attribute__((aligned(16))) __bf16 T[];
-  constexpr int kPart = kGemmWide * kX3Pitch;
-  auto Tp = [&](int buf, int mat, int part) { return T + ((buf * 2 + mat) * 2 + part) * kPart; };
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
-  const int wr = wid >> 1, wc = wid & 1;  // wave rows 0..1 (128 centroids each), wave columns 0..1 (128 points each)
-  uint32_t tile_m, tile_n;
-  gemm_tile_coords(m_tiles, n_tiles, grp, tile_m, tile_n);
-  const uint32_t m0 = tile_m * kGemmWide, n0 = tile_n * kGemmWide;
-  f32x16 acc[4][4];
-#pragma unroll
-  for (int a = 0; a < 4; ++a)
-#pragma unroll
-    for (int b = 0; b < 4; ++b)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.0f;
-  // staging registers of ONE tile: centroids 256 rows x 4 chunks of 16 bytes per part (thread t: chunks t + 256 i, i < 4),
-  // points 256 rows x 8 float4 (thread t: slots t + 256 i, i < 8)
-  f32x4 ra[8], rb[8];
-  auto gload = [&](uint32_t k0) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int idx = tid + 256 * i;
-      const uint64_t at = (uint64_t)(m0 + (idx >> 2)) * K + k0 + (idx & 3) * 8;
-      ra[i] = *reinterpret_cast<const f32x4*>(Ch + at);
-      ra[4 + i] = *reinterpret_cast<const f32x4*>(Cl + at);
-    }
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      const int idx = tid + 256 * i;
-      rb[i] = *reinterpret_cast<const f32x4*>(X + (uint64_t)(n0 + (idx >> 3)) * K + k0 + (idx & 7) * 4);
-    }
-  };
-  auto store_a = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      const int idx = tid + 256 * i, row = idx >> 2, at = row * kX3Pitch + x3_chunk(row, idx & 3);
-      *reinterpret_cast<f32x4*>(Tp(buf, 0, 0) + at) = ra[i];
-      *reinterpret_cast<f32x4*>(Tp(buf, 0, 1) + at) = ra[4 + i];
-    }
-  };
-  auto split_store_b = [&](int buf, int i) {  // slot i of the thread's eight point slots
-    const int idx = tid + 256 * i, row = idx >> 3, c4 = idx & 7;
-    bf16x4 h, l;
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      h[u] = (__bf16)rb[i][u];
-      l[u] = (__bf16)(rb[i][u] - (float)h[u]);
-    }
-    const int at = row * kX3Pitch + x3_chunk(row, c4 >> 1) + (c4 & 1) * 4;
-    *reinterpret_cast<bf16x4*>(Tp(buf, 1, 0) + at) = h;
-    *reinterpret_cast<bf16x4*>(Tp(buf, 1, 1) + at) = l;
-  };
-  const int r = lane & 31, hh = lane >> 5;
-  const uint32_t k_tiles = K / kGemmBK, k_last = K - kGemmBK;
-  auto kclamp = [&](uint32_t t) { const uint32_t k0 = t * kGemmBK; return k0 < k_last ? k0 : k_last; };
-  gload(0);
-  store_a(0);
-#pragma unroll
-  for (int i = 0; i < 8; ++i) split_store_b(0, i);
-  gload(kclamp(1));
-  __syncthreads();
-  for (uint32_t t = 0; t < k_tiles; ++t) {
-    const int buf = (int)(t & 1), nbuf = buf ^ 1;
-#pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) {  // two k-steps of 16
-      const int ko = x3_chunk(r, 2 * s2 + hh);
-      bf16x8 bh[4], bl[4];
-#pragma unroll
-      for (int tt = 0; tt < 4; ++tt) {
-        bh[tt] = *reinterpret_cast<const bf16x8*>(Tp(buf, 1, 0) + (wc * 128 + tt * 32 + r) * kX3Pitch + ko);
-        bl[tt] = *reinterpret_cast<const bf16x8*>(Tp(buf, 1, 1) + (wc * 128 + tt * 32 + r) * kX3Pitch + ko);
-      }
-#pragma unroll
-      for (int a = 0; a < 4; ++a) {
-        const bf16x8 ah = *reinterpret_cast<const bf16x8*>(Tp(buf, 0, 0) + (wr * 128 + a * 32 + r) * kX3Pitch + ko);
-        const bf16x8 al = *reinterpret_cast<const bf16x8*>(Tp(buf, 0, 1) + (wr * 128 + a * 32 + r) * kX3Pitch + ko);
-        // the next tile's staging between the MFMAs: one point slot per row tile (8 slots over the 8 row-tile rounds of a K-tile)
-        split_store_b(nbuf, s2 * 4 + a);
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[b], acc[a][b], 0, 0, 0);  // small terms first
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[b], acc[a][b], 0, 0, 0);
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[b], acc[a][b], 0, 0, 0);
-        }
-      }
-    }
-    store_a(nbuf);
-    gload(kclamp(t + 2));
-    __syncthreads();
-  }
-  // epilogue: a wave's 128 rows are one 128-centroid tile: per point (column) the smallest value, its centroid and the second
-  // smallest, straight to the partial arrays (same rules as gemm_epilogue<true>)
-  auto fold = [](float& v1, uint32_t& c1, float& v2, float w1, uint32_t d1, float w2) {
-    const bool nan = (v2 != v2) || (w2 != w2);
-    if (w1 < v1) { v2 = v1 < w2 ? v1 : w2; v1 = w1; c1 = d1; }
-    else { const float t = w1 < v2 ? w1 : v2; v2 = t; }
-    if (nan) v2 = __builtin_nanf("");
-  };
-#pragma unroll
-  for (int b = 0; b < 4; ++b) {
-    float v1 = __builtin_inff(), v2 = __builtin_inff();
-    uint32_t c1 = m0 + wr * 128 + 4 * hh;
-    bool nan = false;
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const uint32_t m = m0 + wr * 128 + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
-        float g = metric ? -acc[a][b][e] : cnorm[m] - 2.0f * acc[a][b][e];
-        if (m >= k_rows) g = __builtin_inff();  // padding centroids (zero rows) are not candidates
-        nan |= g != g;
-        if (g < v1) { v2 = v1; v1 = g; c1 = m; }
-        else if (g < v2 || g == v1) v2 = g;
-      }
-    if (nan) v2 = __builtin_nanf("");
-    const float w1 = __shfl_xor(v1, 32, kWave), w2 = __shfl_xor(v2, 32, kWave);  // the other half of the rows sits in lane ^ 32
-    const uint32_t d1 = (uint32_t)__shfl_xor((int)c1, 32, kWave);
-    fold(v1, c1, v2, w1, d1, w2);
-    if (hh == 0) {
-      const uint64_t o = (uint64_t)(m0 / kGemmBM + wr) * N_pad + n0 + wc * 128 + b * 32 + r;
-      part_v1[o] = v1; part_c1[o] = c1; part_v2[o] = v2;
-    }
-  }
-}
-
-inline int gemm_wide_mode() {  // VERS_GEMM_WIDE: 0 = never, 1 = eight waves, plain order, 2 = eight waves, interleaved (default), 3 = four waves of 128 x 128
+inline int gemm_wide_mode() {  // VERS_GEMM_WIDE: 0 = never, 1 = plain order, 2 = interleaved (default)
   static const int m = [] { const char* e = getenv("VERS_GEMM_WIDE"); return e ? atoi(e) : 2; }();
   return m;
 }
@@ -787,12 +651,7 @@ inline hipError_t launch_gemm_wide(uint32_t k_pad, uint32_t nb_pad, hipStream_t 
   // each XCD keeps `grp` centroid tiles (256 rows x K x 4 B of hi | lo = 768 KB at K = 768) in its L2 and walks the point tiles
   uint32_t grp = 0;
   for (uint32_t g : {2u, 1u}) if (m_tiles % (8u * g) == 0) { grp = g; break; }
-  if (gemm_wide_mode() == 3) {
-    static const hipError_t attrv = hipFuncSetAttribute((const void*)dist_gemm_x3v_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kX3WLdsBytes);
-    if (attrv != hipSuccess) return attrv;
-    hipLaunchKernelGGL(dist_gemm_x3v_kernel, dim3(m_tiles * n_tiles), dim3(256), kX3WLdsBytes, st, X, ch, cl, cnorm, K, N_pad, (int)metric, m_tiles,
-                       n_tiles, grp, k_rows, part_v1, part_c1, part_v2);
-  } else if (gemm_wide_mode() == 1)
+  if (gemm_wide_mode() == 1)
     hipLaunchKernelGGL(dist_gemm_x3w_kernel<0>, dim3(m_tiles * n_tiles), dim3(512), kX3WLdsBytes, st, X, ch, cl, cnorm, K, N_pad, (int)metric, m_tiles,
                        n_tiles, grp, k_rows, part_v1, part_c1, part_v2);
   else
