@@ -808,13 +808,13 @@ struct vers_ivf {
   DevBuf st_words;
   std::mutex st_mu;
   std::vector<hipStream_t> st_streams;
-  uint32_t* st_pin = nullptr;  // pinned landing word of the polls (guarded by st_mu)
-  int32_t stream_word(hipStream_t st, uint32_t** out) {
+  uint32_t* st_pin = nullptr;  // pinned landing words of the polls, one per stream word (no lock is held while a poll waits for its stream)
+  int32_t stream_word(hipStream_t st, uint32_t** out, uint32_t** out_pin = nullptr) {
     std::lock_guard<std::mutex> lk(st_mu);
     if (!st_words.p) {
       if (int32_t rc = st_words.reserve(kStreamWords * sizeof(uint32_t))) return rc;
       VERS_HIP_TRY(hipMemset(st_words.p, 0, kStreamWords * sizeof(uint32_t)));
-      VERS_HIP_TRY(hipHostMalloc((void**)&st_pin, 64, hipHostMallocDefault));
+      VERS_HIP_TRY(hipHostMalloc((void**)&st_pin, kStreamWords * sizeof(uint32_t), hipHostMallocDefault));
     }
     uint32_t i = 0;
     while (i < st_streams.size() && st_streams[i] != st) ++i;
@@ -823,6 +823,7 @@ struct vers_ivf {
       else i = kStreamWords - 1;  // the overflow word, shared
     }
     *out = st_words.as<uint32_t>() + i;
+    if (out_pin) *out_pin = st_pin + i;
     return VERS_OK;
   }
   // searches / reads hold `index` shared, build / upload / add / set_* exclusively
@@ -954,16 +955,13 @@ inline int32_t start_pending_ahead(vers_ivf* h, hipStream_t st) {
   return coarse_ahead_locked(h, p.q_dev, p.ldq_in, p.b, p.nprobe, st);
 }
 int32_t sync_status(vers_ivf* h, hipStream_t st) {  // the word of the _dev calls queued on `st` (vers_ivf::stream_word), read and cleared on `st`
-  uint32_t* word = nullptr;
-  if (int32_t rc = h->stream_word(st, &word)) return rc;
-  uint32_t s = 0;
-  {
-    std::lock_guard<std::mutex> lk(h->st_mu);  // (one landing word)
-    VERS_HIP_TRY(hipMemcpyAsync(h->st_pin, word, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-    VERS_HIP_TRY(hipMemsetAsync(word, 0, sizeof(uint32_t), st));  // stream order: behind every kernel that could set it, ahead of the next call's
-    VERS_HIP_TRY(hipStreamSynchronize(st));
-    s = *reinterpret_cast<volatile uint32_t*>(h->st_pin);
-  }
+  uint32_t *word = nullptr, *pin = nullptr;
+  if (int32_t rc = h->stream_word(st, &word, &pin)) return rc;
+  // (the stream's own landing word: no lock is held while this waits for the stream -- searches on other streams go on)
+  VERS_HIP_TRY(hipMemcpyAsync(pin, word, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+  VERS_HIP_TRY(hipMemsetAsync(word, 0, sizeof(uint32_t), st));  // stream order: behind every kernel that could set it, ahead of the next call's
+  VERS_HIP_TRY(hipStreamSynchronize(st));
+  const uint32_t s = *reinterpret_cast<volatile uint32_t*>(pin);
   if (!s) return VERS_OK;
   if (s & kStNaN) return fail(VERS_ERR_NAN, "NaN distance (the reference panics in partial_cmp().unwrap())");
   if (s & kStInsufficient)
