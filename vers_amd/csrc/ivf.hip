@@ -118,6 +118,7 @@ struct IvfSrc {
     const uint32_t sr = list_seg_rows(len, seg_rows, seg_target);
     const uint32_t r0 = real ? d.seg * sr : 0;
     v.rows = rows + ((uint64_t)list_off[d.list] + r0) * ld;
+    v.row0 = r0;
     v.nrows = real ? (len - r0 < sr ? len - r0 : sr) : 0u;
     const uint32_t c = cnt[d.list] - d.group * QG;
     v.nq = c < (uint32_t)QG ? c : QG;
@@ -152,6 +153,7 @@ struct IvfSrc {
     const uint32_t pr = pair_of(it, qi);
     return bound_per_pair ? pr : pr / P * P;
   }
+  __device__ __forceinline__ uint32_t slot_of_pair(uint32_t pr) const { return bound_per_pair ? pr : pr / P * P; }
 };
 
 // ---- small kernels of the search pipeline -----------------------------------------------------

@@ -151,7 +151,7 @@ constexpr int kPreWavesG = 8;  // 4 items x 2 waves
 // every compaction.
 __host__ __device__ inline uint32_t pre_cap(uint32_t kp) { return kp <= 40u ? 64u : 128u; }
 inline size_t prescan_lds_bytes_g(uint32_t ld, uint32_t kp) {  // query block | hand-out word | buffers | cnt, done, thr, locks
-  return (size_t)ld * kPreQ * sizeof(float) + 16 + (size_t)kPreQ * pre_cap(kp) * sizeof(uint64_t) + 4 * kPreQ * sizeof(uint32_t);
+  return (size_t)ld * kPreQ * sizeof(float) + 16 + (size_t)kPreQ * pre_cap(kp) * sizeof(uint64_t) + 6 * kPreQ * sizeof(uint32_t);  // (+ pair | sequence base of the quad's queries)
 }
 
 // ---- per-query candidate buffers of a block (LDS) ---------------------------------------------------------------
@@ -205,6 +205,12 @@ __device__ __forceinline__ void prescan_item_g(const Src& src, const PreParams& 
   uint32_t* const done = ctl + kPreQ;        // [32] slots written
   uint32_t* const thrq = ctl + 2 * kPreQ;    // [32] order bits of the block's threshold of the query (0xFFFFFFFF: none yet)
   uint32_t* const locks = ctl + 3 * kPreQ;   // [32] compaction locks
+  // [32] (query, probe) pair of each query of the quad and [32] the sequence number of that probe's first row: resolved ONCE per
+  // staged query block by 32 threads (stage) instead of by every lane of every wave of every item through a chain of five
+  // dependent global loads (items -> pair_off -> pairs -> pj_pref, then the bound word): 5-8 us per item, which is what made
+  // short items expensive
+  const uint32_t* const qpair = ctl + 4 * kPreQ;
+  const uint32_t* const qpref = ctl + 5 * kPreQ;
   const bool two = !BF && v.nq > 16;  // wave-uniform
   const bool stamp = (p.debug & 16u) != 0;
   const unsigned long long tp0 = stamp ? __builtin_amdgcn_s_memtime() : 0ull;
@@ -249,17 +255,6 @@ __device__ __forceinline__ void prescan_item_g(const Src& src, const PreParams& 
   bool live[2];
   uint32_t vseq[2] = {0, 0};
   float thr[2];
-#pragma unroll
-  for (int s = 0; s < 2; ++s) {
-    live[s] = s < kSets && s * 16 + n < (int)v.nq;
-    thr[s] = -__builtin_inff();  // dead query columns never hit
-    if (live[s]) {
-      vseq[s] = src.seq_base(it, s * 16 + n);
-      vslot[s] = src.bound_slot(it, s * 16 + n);
-      const uint32_t b0 = __hip_atomic_load(p.bounds32 + vslot[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      thr[s] = b0 == 0xFFFFFFFFu ? __builtin_inff() : __uint_as_float(order_bits_to_f32_bits(b0));
-    }
-  }
   f32x16_t acc[2];
 #pragma unroll
   for (int e = 0; e < 16; ++e) acc[0][e] = acc[1][e] = 0.0f;
@@ -375,6 +370,18 @@ __device__ __forceinline__ void prescan_item_g(const Src& src, const PreParams& 
   using Set1 = std::integral_constant<int, 1>;
 
   stage();
+  // (after the block-wide part: the quad's pair / sequence-base table in LDS is what stage() filled -- or left, for the next quad of a run)
+#pragma unroll
+  for (int s = 0; s < 2; ++s) {
+    live[s] = s < kSets && s * 16 + n < (int)v.nq;
+    thr[s] = -__builtin_inff();  // dead query columns never hit
+    if (live[s]) {
+      vseq[s] = qpref[s * 16 + n] + v.row0;
+      vslot[s] = src.slot_of_pair(qpair[s * 16 + n]);
+      const uint32_t b0 = __hip_atomic_load(p.bounds32 + vslot[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      thr[s] = b0 == 0xFFFFFFFFu ? __builtin_inff() : __uint_as_float(order_bits_to_f32_bits(b0));
+    }
+  }
   uint32_t tc = t_begin, cc = 0;
   unsigned long long t_math = 0, t_fold = 0, t_issue = 0;
   const unsigned long long tp1 = stamp ? __builtin_amdgcn_s_memtime() : 0ull;
@@ -565,6 +572,11 @@ __global__ __launch_bounds__(kWave * kPreWavesG) __attribute__((amdgpu_waves_per
       write_out();
       __syncthreads();
       if (threadIdx.x < 4 * kPreQ) ctl[threadIdx.x] = (threadIdx.x >> 5) == 2 ? 0xFFFFFFFFu : 0u;  // empty buffers, no threshold, locks open
+      if (threadIdx.x < v.nq) {  // the quad's queries: their (query, probe) pair and the sequence number of the probe's first row
+        const uint32_t pr = src.pair_of(bi * 4, (int)threadIdx.x);
+        ctl[4 * kPreQ + threadIdx.x] = pr;
+        ctl[5 * kPreQ + threadIdx.x] = src.pj_pref[pr];
+      }
       f32x4* l4 = reinterpret_cast<f32x4*>(qlds);
       auto put = [&](uint32_t cg, const f32x4& y) {  // columns 4*cg .. 4*cg + 3 of the thread's query, already scaled
         if constexpr (BF) {

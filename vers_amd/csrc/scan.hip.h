@@ -350,6 +350,7 @@ struct ItemView {
   uint32_t nrows;      // rows in the item
   uint32_t nq;         // live queries (<= QG)
   const float* qb;     // QG == 1: the query; else the item's interleaved query block [col][QG]
+  uint32_t row0 = 0;   // inverted-list items: the item's first row inside its list (sequence numbers; set by IvfSrc only)
 };                     // (zero padded to n_chunks*64 columns; dead query slots are zeros)
 
 struct ScanParams {
