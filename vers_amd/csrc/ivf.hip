@@ -642,6 +642,53 @@ __global__ void gather_rows_kernel(const float* X, uint32_t ldx, uint32_t d, uin
   }
 }
 
+// The same placement, one BLOCK per destination tile of 64 storage rows: the 64 source rows are read as they lie (3 KB
+// contiguous each), turned through LDS 64 float4 columns at a time, and written as the tile's contiguous 1 KiB pieces.
+// (gather_rows_kernel above writes every float4 to its own piece: 16 useful bytes per 64-byte sector and a stride of 1 KiB
+// between consecutive threads -- 69 ms for N = 10M x 768, 0.9 TB/s, the largest serial-looking kernel of build_index.)
+// tile_list[t] = the list tile t belongs to (lists start on tile boundaries); rows of the tile past the list's length are
+// written as zeros (slack for `add`), their row_ids stay 0xFFFFFFFF.
+constexpr uint32_t kGatherCols4 = 64;  // float4 columns per pass: 64 rows x 65 float4 = 66.5 KB of LDS
+__global__ __launch_bounds__(256) void gather_tiles_kernel(const float* X, uint32_t ldx, uint32_t d, uint32_t ld, const uint32_t* sorted_ids,
+                                                           const uint32_t* starts, const uint32_t* list_off, const uint32_t* list_len,
+                                                           const uint32_t* tile_list, float* rows, uint32_t* row_ids) {
+  extern __shared__ __attribute__((aligned(16))) f32x4 tl[];  // [64][kGatherCols4 + 1]
+  __shared__ uint32_t s_id[kWave];
+  const uint32_t t = blockIdx.x, c = tile_list[t];
+  const uint32_t row0 = t * 64u, in_list0 = row0 - list_off[c], len = list_len[c];
+  const uint32_t n_valid = in_list0 < len ? (len - in_list0 < 64u ? len - in_list0 : 64u) : 0u;
+  if (threadIdx.x < 64) {
+    const uint32_t id = threadIdx.x < n_valid ? sorted_ids[starts[c] + in_list0 + threadIdx.x] : 0xFFFFFFFFu;
+    s_id[threadIdx.x] = id;
+    if (threadIdx.x < n_valid) row_ids[row0 + threadIdx.x] = id;
+  }
+  __syncthreads();
+  const uint32_t ld4 = ld / 4, ldx4 = ldx / 4;
+  f32x4* tile = reinterpret_cast<f32x4*>(rows + (uint64_t)t * 64ull * ld);
+  constexpr uint32_t kPitch = kGatherCols4 + 1;
+  for (uint32_t c0 = 0; c0 < ld4; c0 += kGatherCols4) {
+    const uint32_t nc = ld4 - c0 < kGatherCols4 ? ld4 - c0 : kGatherCols4;
+    for (uint32_t i = threadIdx.x; i < 64u * kGatherCols4; i += 256u) {  // a row's float4s by consecutive threads
+      const uint32_t r = i / kGatherCols4, j = i % kGatherCols4, c4 = c0 + j;
+      f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+      const uint32_t id = s_id[r];
+      if (j < nc && id != 0xFFFFFFFFu && c4 < ldx4 && c4 * 4 < d) {
+        v = reinterpret_cast<const f32x4*>(X + (uint64_t)id * ldx)[c4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (c4 * 4 + u >= d) v[u] = 0.0f;  // (columns >= d of X are the caller's padding and may hold anything)
+      }
+      tl[r * kPitch + j] = v;
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < 64u * nc; i += 256u) {  // a piece's 64 rows by consecutive threads: 1 KiB contiguous
+      const uint32_t j = i / 64u, r = i % 64u;
+      tile[(uint64_t)(c0 + j) * 64 + r] = tl[r * kPitch + j];
+    }
+    __syncthreads();
+  }
+}
+
 // one padded row (ld floats, row-major) -> storage row `dst` of the blocked matrix
 __global__ void scatter_row_kernel(const float* row, uint32_t ld, uint64_t dst, float* rows) {
   const uint32_t c4 = blockIdx.x * blockDim.x + threadIdx.x;
@@ -747,6 +794,7 @@ struct vers_ivf {
   uint32_t k_pad = 0;
   std::atomic<uint64_t> mfma_batches{0};
   DevBuf rows, row_ids, list_off, list_len;
+  DevBuf tile_list;  // [cap_rows / 64] the list a storage tile belongs to (build: gather_tiles_kernel)
   // SLOT space: the per-batch planning tables, the work items and the scan kernels address a list by its SLOT =
   // rank among the lists by descending length (ties by index).  plan_query translates a centroid index into a slot
   // once (list_slot); every table the later stages read is then contiguous in work order: the group step's prefix
@@ -1159,6 +1207,13 @@ int32_t plan_storage(vers_ivf* h, const uint32_t* lens, uint32_t k, hipStream_t 
     for (uint32_t i = 0; i < k; ++i) { run += asc[i]; h->len_asc_prefix[i] = run; }
   }
   h->cap_rows = off;
+  {
+    std::vector<uint32_t> tl((size_t)(off / 64) ? (size_t)(off / 64) : 1, 0u);
+    for (uint32_t c = 0; c < k; ++c)
+      for (uint32_t r = 0; r < h->h_cap[c]; r += 64) tl[(h->h_off[c] + r) / 64] = c;
+    if (int32_t rc = h->tile_list.reserve(tl.size() * sizeof(uint32_t))) return rc;
+    VERS_HIP_TRY(hipMemcpy(h->tile_list.p, tl.data(), tl.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+  }
   if (int32_t rc = h->rows.reserve((off ? off : 1) * (size_t)h->ld * sizeof(float))) return rc;
   if (int32_t rc = h->row_ids.reserve((off ? off : 1) * sizeof(uint32_t))) return rc;
   if (int32_t rc = h->list_off.reserve((k ? k : 1) * sizeof(uint32_t))) return rc;
@@ -1230,6 +1285,14 @@ int32_t install_index(vers_ivf* h, const float* X, uint32_t ldx, uint64_t n, con
   VERS_HIP_TRY(hipStreamSynchronize(st));
   if (int32_t rc = plan_storage(h, lens.data(), k, st)) return rc;
   if (n) {
+    static const bool by_tile = [] { const char* e = getenv("VERS_GATHER_TILES"); return !e || atoi(e) != 0; }();
+    if (by_tile && h->cap_rows >= 64) {
+      const size_t lds = 64 * (size_t)(kGatherCols4 + 1) * sizeof(f32x4);
+      if (int32_t rc = scan_prepare_launch(gather_tiles_kernel, lds)) return rc;
+      hipLaunchKernelGGL(gather_tiles_kernel, dim3((unsigned)(h->cap_rows / 64)), dim3(256), lds, st, X, ldx, h->d, h->ld, sorted.as<uint32_t>(),
+                         (const uint32_t*)starts, h->list_off.as<uint32_t>(), h->list_len.as<uint32_t>(), h->tile_list.as<uint32_t>(),
+                         h->rows.as<float>(), h->row_ids.as<uint32_t>());
+    } else
     hipLaunchKernelGGL(gather_rows_kernel, dim3(h->n_cu * 8), dim3(256), 0, st, X, ldx, h->d, h->ld, sorted.as<uint32_t>(), d_assign, starts,
                        h->list_off.as<uint32_t>(), h->world > 1 ? h->owner.as<uint8_t>() : (const uint8_t*)nullptr, h->rank, n,
                        h->rows.as<float>(), h->row_ids.as<uint32_t>());
