@@ -233,10 +233,9 @@ int32_t km_assign_mfma(const float* X, uint32_t ldx, uint64_t n, const float* C,
   // large k: uncertified points first go through the tile-limited re-scan (assign_tile_rescan_kernel); what it cannot settle
   // lands in fb_list like before
   static const bool tiles_on = [] { const char* e = getenv("VERS_ASSIGN_TILES"); return !e || atoi(e) != 0; }();
-  // (from 8 tiles = k >= 1024 on.  Round 2 used it from 64 tiles only and sent the uncertified points of smaller k through
-  // the full exact scan: at k = 4096, N = 10M that scan -- 0.9 % of the points against all 4096 centroids -- was 76 ms of a
-  // 237 ms pass; the tile minima name one or two tiles of 128 centroids per point.  VERS_ASSIGN_TILES_MIN to move it.)
-  static const uint32_t tiles_min = [] { const char* e = getenv("VERS_ASSIGN_TILES_MIN"); return e ? (uint32_t)atoi(e) : 8u; }();
+  // (from 64 tiles = k >= 8192 on: measured at k = 4096, N = 4M with VERS_ASSIGN_TILES_MIN=8 the pass gets 3 % SLOWER, 104.6 vs
+  // 101.1 ms -- a launch of 2048 waves per batch against one exact scan of the 1.6 % uncertified points at the end; same bits)
+  static const uint32_t tiles_min = [] { const char* e = getenv("VERS_ASSIGN_TILES_MIN"); return e ? (uint32_t)atoi(e) : 64u; }();
   const bool tile_rescan = tiles_on && k_pad / kGemmBM >= tiles_min;
   uint32_t* fbq_list = nullptr; uint32_t* fbq_count = nullptr; float* fbq_thr = nullptr;
   if (tile_rescan) {
