@@ -649,18 +649,22 @@ __global__ void gather_rows_kernel(const float* X, uint32_t ldx, uint32_t d, uin
 // tile_list[t] = the list tile t belongs to (lists start on tile boundaries); rows of the tile past the list's length are
 // written as zeros (slack for `add`), their row_ids stay 0xFFFFFFFF.
 constexpr uint32_t kGatherCols4 = 64;  // float4 columns per pass: 64 rows x 65 float4 = 66.5 KB of LDS
+// row_src != nullptr (the receive side of the row-sharded build): storage row r holds source row row_src[r] of X (0xFFFFFFFF: none)
+// and its vec id is src_ids[that row]; otherwise the source of a row follows from the cluster-sorted order (sorted_ids / starts).
 __global__ __launch_bounds__(256) void gather_tiles_kernel(const float* X, uint32_t ldx, uint32_t d, uint32_t ld, const uint32_t* sorted_ids,
                                                            const uint32_t* starts, const uint32_t* list_off, const uint32_t* list_len,
-                                                           const uint32_t* tile_list, float* rows, uint32_t* row_ids) {
+                                                           const uint32_t* tile_list, float* rows, uint32_t* row_ids,
+                                                           const uint32_t* row_src = nullptr, const uint32_t* src_ids = nullptr) {
   extern __shared__ __attribute__((aligned(16))) f32x4 tl[];  // [64][kGatherCols4 + 1]
   __shared__ uint32_t s_id[kWave];
   const uint32_t t = blockIdx.x, c = tile_list[t];
   const uint32_t row0 = t * 64u, in_list0 = row0 - list_off[c], len = list_len[c];
   const uint32_t n_valid = in_list0 < len ? (len - in_list0 < 64u ? len - in_list0 : 64u) : 0u;
   if (threadIdx.x < 64) {
-    const uint32_t id = threadIdx.x < n_valid ? sorted_ids[starts[c] + in_list0 + threadIdx.x] : 0xFFFFFFFFu;
+    uint32_t id = 0xFFFFFFFFu;
+    if (threadIdx.x < n_valid) id = row_src ? row_src[row0 + threadIdx.x] : sorted_ids[starts[c] + in_list0 + threadIdx.x];
     s_id[threadIdx.x] = id;
-    if (threadIdx.x < n_valid) row_ids[row0 + threadIdx.x] = id;
+    if (id != 0xFFFFFFFFu) row_ids[row0 + threadIdx.x] = src_ids ? src_ids[id] : id;
   }
   __syncthreads();
   const uint32_t ld4 = ld / 4, ldx4 = ldx / 4;
@@ -1345,6 +1349,12 @@ __global__ __launch_bounds__(256) void unpack_rows_kernel(const float* in, uint3
   }
 }
 
+// storage row -> row of the receive buffer, from the segments (a block per segment)
+__global__ void fill_row_src_kernel(const RecvSeg* segs, uint32_t* row_src) {
+  const RecvSeg sg = segs[blockIdx.x];
+  for (uint32_t r = threadIdx.x; r < sg.count; r += blockDim.x) row_src[sg.dest + r] = sg.src_row + r;
+}
+
 __global__ void sum_counts_kernel(const uint32_t* counts_all, uint32_t world, uint32_t k, uint32_t* out) {
   const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= k) return;
@@ -1461,11 +1471,28 @@ int32_t install_index_sharded(vers_ivf* h, const float* X, uint32_t ldx, uint64_
   sbuf.release();
   sids.release();
   // (capacity slack and tile padding of the storage are zero rows: (0 - q)^2 terms never enter a result, ids stay 0xFFFFFFFF)
-  VERS_HIP_TRY(hipMemsetAsync(h->rows.p, 0, (h->cap_rows ? h->cap_rows : 1) * (size_t)h->ld * sizeof(float), st));
-  if (!segs.empty()) {
-    hipLaunchKernelGGL(unpack_rows_kernel, dim3((unsigned)segs.size()), dim3(256), 0, st, rbuf.as<float>(), ldp, rids.as<uint32_t>(),
-                       dsegs.as<RecvSeg>(), h->ld, h->rows.as<float>(), h->row_ids.as<uint32_t>());
+  static const bool by_tile = [] { const char* e = getenv("VERS_GATHER_TILES"); return !e || atoi(e) != 0; }();
+  if (by_tile && h->cap_rows >= 64 && !segs.empty()) {
+    // whole destination tiles through LDS (gather_tiles_kernel), every tile written completely: no memset of the storage
+    DevBuf row_src;
+    if (int32_t rc = row_src.reserve(h->cap_rows * sizeof(uint32_t))) return rc;
+    VERS_HIP_TRY(hipMemsetAsync(row_src.p, 0xFF, h->cap_rows * sizeof(uint32_t), st));
+    hipLaunchKernelGGL(fill_row_src_kernel, dim3((unsigned)segs.size()), dim3(256), 0, st, dsegs.as<RecvSeg>(), row_src.as<uint32_t>());
+    const size_t lds = 64 * (size_t)(kGatherCols4 + 1) * sizeof(f32x4);
+    if (int32_t rc = scan_prepare_launch(gather_tiles_kernel, lds)) return rc;
+    hipLaunchKernelGGL(gather_tiles_kernel, dim3((unsigned)(h->cap_rows / 64)), dim3(256), lds, st, rbuf.as<float>(), ldp, h->d, h->ld,
+                       (const uint32_t*)nullptr, (const uint32_t*)nullptr, h->list_off.as<uint32_t>(), h->list_len.as<uint32_t>(),
+                       h->tile_list.as<uint32_t>(), h->rows.as<float>(), h->row_ids.as<uint32_t>(), (const uint32_t*)row_src.as<uint32_t>(),
+                       (const uint32_t*)rids.as<uint32_t>());
     VERS_HIP_TRY(hipGetLastError());
+    VERS_HIP_TRY(hipStreamSynchronize(st));  // (row_src goes out of scope)
+  } else {
+    VERS_HIP_TRY(hipMemsetAsync(h->rows.p, 0, (h->cap_rows ? h->cap_rows : 1) * (size_t)h->ld * sizeof(float), st));
+    if (!segs.empty()) {
+      hipLaunchKernelGGL(unpack_rows_kernel, dim3((unsigned)segs.size()), dim3(256), 0, st, rbuf.as<float>(), ldp, rids.as<uint32_t>(),
+                         dsegs.as<RecvSeg>(), h->ld, h->rows.as<float>(), h->row_ids.as<uint32_t>());
+      VERS_HIP_TRY(hipGetLastError());
+    }
   }
   VERS_HIP_TRY(hipStreamSynchronize(st));
   rbuf.release();
