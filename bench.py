@@ -201,7 +201,7 @@ def main():
             dist.all_gather(h, o["part"].cpu())
             o["allp"].copy_(torch.stack(h).to(dev))
 
-    def step(i):
+    def step(i, S=S):
         qb = Q[(i % n_batches) * B:]
         o = outs[i % S]
         with torch.cuda.stream(streams[i % S]):
@@ -238,6 +238,22 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     qps = args.steps * B / elapsed
+    scan_ms_one = None
+    if world > 1 and S > 1:
+        # every rank: the same steps one batch after the other -- the dominant kernel's duration without the queueing behind other
+        # batches' scans that an event pair measures when several are in flight (see the one-GPU leg below)
+        for i in range(args.warmup):
+            step(i, 1)
+        index.poll(streams[0].cuda_stream)
+        index.scan_times(reset=True)
+        barrier()
+        t1 = time.perf_counter()
+        for i in range(args.steps):
+            step(args.warmup + i, 1)
+        barrier()
+        t1 = time.perf_counter() - t1
+        index.poll(streams[0].cuda_stream)
+        scan_ms_one = (index.scan_times(reset=True), t1)
 
     # ---- roofline of the dominant kernel (inverted-list scan), last batch's geometry -----------------
     # Algorithmic bytes = what the kernel's algorithm has to read: the rows of the union of probed lists in the form the
@@ -430,6 +446,13 @@ def main():
             index.poll(x.cuda_stream)
         return t_, index.scan_times(reset=True)
 
+    if rank == 0 and world > 1 and scan_ms_one is not None and len(scan_ms_one[0]):
+        m1 = float(np.mean(scan_ms_one[0]))
+        roofline["timed_region"] = {"launch_ms": roofline["launch_ms"], "achieved": roofline["achieved"], "frac": roofline["frac"], "launches_timed": roofline["launches_timed"],
+                                    "note": f"event pairs around the launches of the timed region, {S} batches in flight: includes the time a launch waits for the CUs another batch's scan still holds"}
+        roofline.update({"launch_ms": round(m1, 4), "achieved": round(algo_bytes / (m1 * 1e-3) / 1e9, 1), "frac": round(algo_bytes / (m1 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                         "launches_timed": int(len(scan_ms_one[0])), "measured_on": f"the same {args.steps} steps, one batch in flight, right after the timed region (rank 0's launches)"})
+        roofline["one_batch_in_flight"] = {"whole_step_ms": round(scan_ms_one[1] / args.steps * 1e3, 4), "whole_step_queries_per_sec": round(args.steps * B / scan_ms_one[1], 1)}
     if rank == 0 and world == 1 and S > 1:
         # With several batches in flight an event pair around a list-scan launch also measures how long the launch QUEUED behind
         # another batch's scan (two scans cannot share the chip: each block takes a whole CU) -- not the kernel.  The roofline of the
