@@ -152,3 +152,32 @@ def test_exhaustive_over_the_index_wider_than_a_wave():
     for s in shards:
         s.close()
     ix.close()
+
+
+@pytest.mark.parametrize("metric", [0, 1], ids=["l2sq", "cosdist"])
+def test_single_query_coarse_over_several_phases_of_chunks(metric):
+    """coarse1_kernel walks a centroid tile in phases of 16 chunks of 32 columns: d = 1100 is three phases (the register
+    buffers alternate A/B/A) with a partial last one, k = 130 three tiles with a partial last one; d = 40 a single phase of
+    two chunks; NaN in a query must still latch the reference's panic (partial_cmp().unwrap())."""
+    for n, d, k in ((1800, 1100, 130), (700, 40, 70), (300, 513, 3)):
+        X = dg.dist_c(0x9100 + d, n, d, max(2, k // 2), dg.default_sigma(d))
+        if metric:
+            X = (X * (0.5 + (np.arange(n) % 5)[:, None] * 0.375)).astype(np.float32)
+        ix = IVFFlatIndex.build_index(k, 1, 2, X, init_indices=mg.init_draws(0x9100 + d, 1, k, n), metric=metric)
+        Q = dg.dist_c(0x9200 + d, 6, d, max(2, k // 2), dg.default_sigma(d)); Q[3] = X[11]
+        for top_k in (1, 10, 64):
+            for nprobe in (0, 1, min(k, 7), min(k, 64)):
+                for qi in range(6):
+                    oi, od = (co.search_approximate(ix.values, ix.centroids, ix.ids, Q[qi], top_k, metric=metric) if nprobe == 0 else
+                              co.search_nprobe(ix.values, ix.centroids, ix.ids, Q[qi], top_k, nprobe, metric=metric))
+                    i1, d1, c1 = ix.search_batch(Q[qi], top_k, nprobe)   # one query: the fused coarse quantiser + plan
+                    assert c1[0] == len(oi), (d, top_k, nprobe, qi)
+                    assert np.array_equal(i1[0, :len(oi)], oi), (d, top_k, nprobe, qi)
+                    assert np.array_equal(bits(d1[0, :len(oi)]), bits(od)), (d, top_k, nprobe, qi)
+        q = Q[0].copy(); q[d - 1] = np.nan                                # (the last column: the last chunk of the last phase)
+        with pytest.raises(capi.VersError) as e:
+            ix.search_batch(q, 3, 4)
+        assert e.value.status == capi.ERR_NAN
+        i1, d1, c1 = ix.search_batch(Q[3], 1, 1)                         # the handle is usable afterwards
+        assert d1[0, 0] == (np.float32(0.0) if metric == 0 else d1[0, 0]) and c1[0] == 1
+        ix.close()

@@ -8,7 +8,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "libvers_hip.so")
+# (VERS_LIB_PATH: another build of the same library -- same-box A/B runs of compile-time variants, scripts/ab_variant.sh)
+LIB_PATH = os.environ.get("VERS_LIB_PATH") or os.path.join(_HERE, "lib", "libvers_hip.so")
 
 OK, ERR_INVALID, ERR_NAN, ERR_INSUFFICIENT, ERR_HIP, ERR_EMPTY, ERR_COMM = 0, 1, 2, 3, 4, 5, 6
 METRIC_L2SQ, METRIC_COSDIST = 0, 1

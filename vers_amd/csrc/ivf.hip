@@ -392,28 +392,27 @@ __global__ __launch_bounds__(kGroupThreads) void group_scatter_kernel(GroupArgs 
   stamp(3);
 }
 
-// Single query: coarse merge + plan + group + scatter + items in ONE launch (the five small kernels above cost
-// ~20 us each in launch + latency, more than the 60 us list scan they prepare).  One block: 16 waves merge the
-// coarse partial slots, wave 0 then plans with lane j = probe rank j.  Every probed list is distinct here, so a
-// pair is its own group; only the table entries of probed lists are written (no memset of the per-list arrays).
-__global__ __launch_bounds__(kWave * kMergeWaves) void plan1_kernel(
-    const uint64_t* cpart, uint32_t n_segs_c, uint32_t P, uint32_t k_lists, uint32_t top_k, int ref_mode, const uint32_t* list_len,
-    const uint8_t* owner, uint32_t rank, uint32_t seg_rows, uint64_t* probe, uint32_t* pj_list, uint32_t* pj_pref, uint32_t* pj_take,
-    uint32_t* np, uint32_t* cnt, uint32_t* pair_off, uint32_t* group_off, uint32_t* pairs, ItemDesc* items, GroupDesc* groups,
-    GroupTotals* tot, uint32_t* status, const uint32_t* list_slot, u32x4* ff_begin, uint32_t ff_vec16) {
-  __shared__ uint64_t sh[kMergeWaves][kWave];
-  {  // the list scan's partial slots start out empty (all ones): the block's 1024 threads do it here instead of a memset launch of its own
-    const u32x4 ff = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
-    for (uint32_t i = threadIdx.x; i < ff_vec16; i += kWave * kMergeWaves) ff_begin[i] = ff;
-  }
-  const uint64_t list = block_merge_keys(cpart, n_segs_c * P, P, sh);
+// Single query: coarse merge + plan + group + scatter + items by ONE block (the five small kernels above cost
+// ~20 us each in launch + latency, more than the 60 us list scan they prepare): 16 waves merge the coarse partial
+// slots, wave 0 then plans with lane j = probe rank j.  Every probed list is distinct here, so a pair is its own
+// group; only the table entries of probed lists are written (no memset of the per-list arrays).
+struct Plan1Args {
+  const uint64_t* cpart; uint32_t n_segs_c, P, k_lists, top_k; int ref_mode;
+  const uint32_t* list_len; const uint8_t* owner; uint32_t rank, seg_rows;
+  uint64_t* probe; uint32_t *pj_list, *pj_pref, *pj_take, *np, *cnt, *pair_off, *group_off, *pairs;
+  ItemDesc* items; GroupDesc* groups; GroupTotals* tot; uint32_t* status; const uint32_t* list_slot;
+  u32x4* ff_begin; uint32_t ff_vec16;  // the list scan's partial slots: filled with all ones (empty) by whoever plans
+};
+__device__ __forceinline__ void plan1_block(const Plan1Args& a, uint64_t (*sh)[kWave]) {
+  const uint64_t list = block_merge_keys(a.cpart, a.n_segs_c * a.P, a.P, sh);
   if (threadIdx.x >= kWave) return;
   const int lane = threadIdx.x;
+  const uint32_t P = a.P, top_k = a.top_k;
   const uint64_t key = lane < (int)P ? list : kKeyMax;
-  if (lane < (int)P) probe[lane] = key;
+  if (lane < (int)P) a.probe[lane] = key;
   const uint32_t L = key != kKeyMax ? (uint32_t)key : kNoList;
-  const uint32_t len = L != kNoList ? list_len[L] : 0u;
-  const uint32_t slot = L != kNoList ? list_slot[L] : kNoList;  // the tables and items name a list by its slot (vers_ivf::list_slot)
+  const uint32_t len = L != kNoList ? a.list_len[L] : 0u;
+  const uint32_t slot = L != kNoList ? a.list_slot[L] : kNoList;  // the tables and items name a list by its slot (vers_ivf::list_slot)
   auto excl_scan = [&](uint32_t v) {  // exclusive prefix sum over the 64 lanes
     uint32_t inc = v;
 #pragma unroll
@@ -427,33 +426,172 @@ __global__ __launch_bounds__(kWave * kMergeWaves) void plan1_kernel(
   const uint32_t total_rows = (uint32_t)__shfl(pref + len, kWave - 1, kWave);
   // reference mode (ivfflat.rs:166-195) in closed form: list j is visited while the rows before it do not yet
   // fill top_k, and contributes take_j = min(len_j, top_k - rows before it)
-  const bool visited = L != kNoList && (!ref_mode || pref < top_k);
-  const uint32_t take = !visited ? 0u : (ref_mode ? (len < top_k - pref ? len : top_k - pref) : top_k);
-  const bool scan = visited && len > 0 && take > 0 && (owner == nullptr || owner[L] == rank);
+  const bool visited = L != kNoList && (!a.ref_mode || pref < top_k);
+  const uint32_t take = !visited ? 0u : (a.ref_mode ? (len < top_k - pref ? len : top_k - pref) : top_k);
+  const bool scan = visited && len > 0 && take > 0 && (a.owner == nullptr || a.owner[L] == a.rank);
   if (lane < (int)P) {
-    pj_list[lane] = scan ? slot : kNoList;
-    pj_pref[lane] = pref;
-    pj_take[lane] = take;
+    a.pj_list[lane] = scan ? slot : kNoList;
+    a.pj_pref[lane] = pref;
+    a.pj_take[lane] = take;
   }
   const uint64_t vmask = __ballot(visited), smask = __ballot(scan);
   if (lane == 0) {
-    np[0] = (uint32_t)__popcll(vmask);
-    if (ref_mode && top_k > 0 && total_rows < top_k) atomicOr(status, P >= k_lists ? kStInsufficient : kStSpillTooDeep);
+    a.np[0] = (uint32_t)__popcll(vmask);
+    if (a.ref_mode && top_k > 0 && total_rows < top_k) atomicOr(a.status, P >= a.k_lists ? kStInsufficient : kStSpillTooDeep);
   }
-  const uint32_t n_s = scan ? (len + seg_rows - 1) / seg_rows : 0u;
+  const uint32_t n_s = scan ? (len + a.seg_rows - 1) / a.seg_rows : 0u;
   const uint32_t item0 = excl_scan(n_s);
   const uint32_t pidx = (uint32_t)__popcll(smask & ((1ull << lane) - 1ull));
   if (scan) {
-    cnt[slot] = 1; pair_off[slot] = pidx; group_off[slot] = pidx;
-    pairs[pidx] = (uint32_t)lane;  // q*P + j with q = 0
-    groups[pidx] = GroupDesc{pidx, 1u};
-    for (uint32_t sgi = 0; sgi < n_s; ++sgi) items[item0 + sgi] = ItemDesc{slot, 0u, sgi};
+    a.cnt[slot] = 1; a.pair_off[slot] = pidx; a.group_off[slot] = pidx;
+    a.pairs[pidx] = (uint32_t)lane;  // q*P + j with q = 0
+    a.groups[pidx] = GroupDesc{pidx, 1u};
+    for (uint32_t sgi = 0; sgi < n_s; ++sgi) a.items[item0 + sgi] = ItemDesc{slot, 0u, sgi};
   }
   const uint32_t n_items = (uint32_t)__shfl(item0 + n_s, kWave - 1, kWave);
   const uint32_t rows_scanned = (uint32_t)__shfl(excl_scan(scan ? len : 0u) + (scan ? len : 0u), kWave - 1, kWave);
   if (lane == 0) {
-    tot->n_items = n_items; tot->n_groups = (uint32_t)__popcll(smask); tot->n_pairs = tot->n_groups; tot->pad = 0;
-    tot->union_rows = rows_scanned; tot->streamed_rows = rows_scanned;
+    a.tot->n_items = n_items; a.tot->n_groups = (uint32_t)__popcll(smask); a.tot->n_pairs = a.tot->n_groups; a.tot->pad = 0;
+    a.tot->union_rows = rows_scanned; a.tot->streamed_rows = rows_scanned;
+  }
+}
+__global__ __launch_bounds__(kWave * kMergeWaves) void plan1_kernel(Plan1Args a) {
+  __shared__ uint64_t sh[kMergeWaves][kWave];
+  {  // the block's 1024 threads fill the slots here instead of a memset launch of its own
+    const u32x4 ff = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+    for (uint32_t i = threadIdx.x; i < a.ff_vec16; i += kWave * kMergeWaves) a.ff_begin[i] = ff;
+  }
+  plan1_block(a, sh);
+}
+
+// Single query, coarse quantiser (ivfflat.rs:155-161) AND the plan in one launch.  The ordered-chain scan gives a 64-centroid
+// tile to ONE wave, which walks its 192 KiB with 24 KiB in flight: eight dependent round trips, 24 us for 12.6 MB that sit in
+// the caches.  Here a tile belongs to a BLOCK of 16 waves: wave w loads chunk w (32 columns of the 64 rows) of every phase of
+// 16 chunks -- the whole tile is in flight at once -- and computes its rows' PRODUCTS (x - q)^2 (or x * q), which do not depend
+// on the running sum, into LDS; wave 0 then walks the strictly ordered chain acc = acc + m_j over the products: the same
+// operations on the same operands in the same order as scan_item's chain (base.rs:119-126), one dependent add per column
+// instead of three instructions.  The block that finishes last (a device counter; nobody waits for anybody) merges the
+// tiles' slots and plans (plan1_block).
+struct Coarse1Args {
+  const float* cent;  // lane-transposed 64-row tiles
+  uint32_t k, ld, n_chunks;
+  const float* q;     // the query, zero padded to ld
+  uint64_t* cpart;    // [tiles][P]
+  uint32_t P;
+  uint32_t* ctr;      // zero between launches (the last block resets it)
+  uint32_t* status;
+  unsigned long long* stamps;  // diagnosis (VERS_SCAN_DEBUG & 16): [32..39] 100 MHz clock at the phase boundaries of the LAST block
+};
+constexpr int kC1Phase = 16;  // chunks of a phase = waves of the block
+constexpr size_t kC1LdsBytes = (size_t)kC1Phase * kLoads * kWave * sizeof(f32x4);  // 128 KiB of products
+static_assert(kC1Phase == kMergeWaves, "the planning tail needs the merge's 16 waves");
+static_assert(kC1LdsBytes >= sizeof(uint64_t) * kMergeWaves * kWave, "the merge's exchange area reuses the product buffer");
+template <int METRIC>
+__global__ __launch_bounds__(kWave * kC1Phase) void coarse1_kernel(Coarse1Args c, Plan1Args a) {
+  extern __shared__ __attribute__((aligned(16))) f32x4 prod[];  // [chunk of the phase][load][lane]
+  __shared__ uint32_t s_last;
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t tile = blockIdx.x;
+  unsigned long long ts[5] = {};
+  auto stamp = [&](int i) { if (c.stamps) ts[i] = __builtin_amdgcn_s_memrealtime(); };
+  stamp(0);
+  {  // the list scan's partial slots start out empty: every block fills its share while its loads are in flight
+    const u32x4 ff = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
+    for (uint32_t i = blockIdx.x * (kWave * kC1Phase) + threadIdx.x; i < a.ff_vec16; i += gridDim.x * (kWave * kC1Phase)) a.ff_begin[i] = ff;
+  }
+  const uint32_t tile_bytes = c.ld * 256u;
+  const __amdgpu_buffer_rsrc_t rsrc =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(c.cent + (uint64_t)tile * kWave * c.ld), 0, (int)tile_bytes, 0x00020000);
+  const uint32_t lane_off = (uint32_t)lane * 16u;
+  // (chunks past the end of the tile are out of the descriptor's range: they load zeros and are never used)
+  auto issue = [&](u32x4 (&r)[kLoads], uint32_t ch) {
+#pragma unroll
+    for (int i = 0; i < kLoads; ++i) r[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane_off, ch * (kLoads * 1024u) + (uint32_t)i * 1024u, 0);
+  };
+  auto products = [&](const u32x4 (&r)[kLoads], uint32_t ch) {
+    cfloat_as4* qs = (cfloat_as4*)(c.q + ch * kChunk);
+#pragma unroll
+    for (int i = 0; i < kLoads; ++i) {
+      f32x4 m;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float xv = __uint_as_float(r[i][u]);
+        const float sv = qs[i * 4 + u];
+        if (METRIC == 0) {
+          const float t = __fsub_rn(xv, sv);
+          m[u] = __fmul_rn(t, t);
+        } else {
+          m[u] = __fmul_rn(xv, sv);
+        }
+      }
+      prod[(wid * kLoads + i) * kWave + lane] = m;
+    }
+  };
+  u32x4 bufA[kLoads], bufB[kLoads];
+  float acc = 0.0f;
+  auto phase = [&](const u32x4 (&cur)[kLoads], u32x4 (&nxt)[kLoads], uint32_t c0) {
+    issue(nxt, c0 + kC1Phase + (uint32_t)wid);  // the next phase's chunk: in flight under this phase's chain
+    if (c0 + (uint32_t)wid < c.n_chunks) products(cur, c0 + (uint32_t)wid);
+    __syncthreads();
+    if (c0 == 0) stamp(1);
+    if (wid == 0) {
+      const uint32_t nch = c.n_chunks - c0 < (uint32_t)kC1Phase ? c.n_chunks - c0 : (uint32_t)kC1Phase;
+      // (two register buffers: the next chunk's products are on their way from LDS while this chunk's 32 adds run)
+      auto ld = [&](f32x4 (&m)[kLoads], uint32_t s) {
+#pragma unroll
+        for (int i = 0; i < kLoads; ++i) m[i] = prod[(s * kLoads + i) * kWave + lane];
+      };
+      auto add = [&](const f32x4 (&m)[kLoads]) {
+#pragma unroll
+        for (int i = 0; i < kLoads; ++i)
+#pragma unroll
+          for (int u = 0; u < 4; ++u) acc = __fadd_rn(acc, m[i][u]);
+      };
+      f32x4 mA[kLoads], mB[kLoads];
+      ld(mA, 0);
+      for (uint32_t s = 0; s < nch; s += 2) {
+        ld(mB, s + 1 < nch ? s + 1 : s);
+        add(mA);
+        if (s + 1 < nch) {
+          ld(mA, s + 2 < nch ? s + 2 : s + 1);
+          add(mB);
+        }
+      }
+    }
+    __syncthreads();
+  };
+  issue(bufA, (uint32_t)wid);
+  for (uint32_t c0 = 0; c0 < c.n_chunks; c0 += 2 * kC1Phase) {
+    phase(bufA, bufB, c0);
+    if (c0 + kC1Phase < c.n_chunks) phase(bufB, bufA, c0 + kC1Phase);
+  }
+  stamp(2);
+  if (wid == 0) {
+    const uint32_t row = tile * kWave + (uint32_t)lane;
+    const bool valid = row < c.k;
+    const float dist = METRIC == 0 ? acc : __fsub_rn(1.0f, acc);
+    if (__ballot(valid && dist != dist) != 0 && lane == 0) atomicOr(c.status, kStNaN);
+    uint64_t key = valid ? make_key(dist, row) : kKeyMax;
+    wave_bitonic_sort64(key, lane);
+    // The slot is read by ANOTHER BLOCK OF THE SAME LAUNCH: it is stored at agent scope -- written through this XCD's L2 -- so
+    // that no L2 write-back (the release fence at agent scope: measured 2 us here with 8 blocks per XCD, 47 us over the 368
+    // blocks of a single-query list scan) is needed; once the stores have completed the block counts itself finished.
+    if (lane < (int)c.P) __hip_atomic_store(c.cpart + (uint64_t)tile * c.P + lane, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    if (lane == 0) s_last = __hip_atomic_fetch_add(c.ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == gridDim.x ? 1u : 0u;
+  }
+  __syncthreads();
+  if (!s_last) return;
+  stamp(3);
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // the other blocks' slots: drop what this CU / L2 may hold of them
+  if (threadIdx.x == 0) *c.ctr = 0u;  // (the next launch on this workspace is ordered behind this one)
+  stamp(4);
+  plan1_block(a, reinterpret_cast<uint64_t(*)[kWave]>(prod));
+  if (c.stamps && threadIdx.x == 0) {
+    for (int i = 0; i < 5; ++i) c.stamps[32 + i] = ts[i];
+    c.stamps[37] = __builtin_amdgcn_s_memrealtime();
+    c.stamps[38] = blockIdx.x;
   }
 }
 
@@ -475,64 +613,75 @@ __global__ void gather_qblocks_kernel(const GroupDesc* groups, const GroupTotals
 // final merge + id mapping: one block per query.  Results wider than 64 keys come 64 ranks per pass (ScanParams::lower):
 // this pass emits ranks rank0 .. rank0+63 of every merge group into output row q (pitch top_k) and leaves the group's
 // last key as the next pass's lower bound.
-__global__ __launch_bounds__(kWave * kMergeWaves) void ivf_merge_kernel(
-    const uint64_t* partials, uint32_t P, uint32_t S_max, uint32_t k_keep, int ref_mode, const uint32_t* np,
-    const uint32_t* pj_list, const uint32_t* pj_pref, const uint32_t* pj_take, const uint32_t* list_off,
-    const uint32_t* row_ids, uint32_t top_k, uint32_t rank0, uint64_t* out_ids, float* out_dist, uint32_t* out_count, uint64_t* out_keys,
-    uint64_t* lower_out) {
-  __shared__ uint64_t sh[kMergeWaves][kWave];
-  const uint32_t q = blockIdx.x;
+struct MergeArgs {
+  const uint64_t* partials; uint32_t P, S_max, k_keep; int ref_mode;
+  const uint32_t *np, *pj_list, *pj_pref, *pj_take, *list_off, *row_ids;
+  uint32_t top_k, rank0;
+  uint64_t* out_ids; float* out_dist; uint32_t* out_count; uint64_t* out_keys; uint64_t* lower_out;
+};
+template <int NW>
+__device__ __forceinline__ void ivf_merge_block(const MergeArgs& m, uint32_t q, uint64_t (*sh)[kWave]) {
+  const uint32_t P = m.P, S_max = m.S_max, k_keep = m.k_keep, top_k = m.top_k, rank0 = m.rank0;
   const int lane = threadIdx.x & 63;
   const bool w0 = threadIdx.x < kWave;
-  const uint64_t* pq = partials + (uint64_t)q * P * S_max * k_keep;
+  const uint64_t* pq = m.partials + (uint64_t)q * P * S_max * k_keep;
   const uint64_t o_base = (uint64_t)q * top_k;
   uint32_t written = 0;
-  const uint32_t n_groups = ref_mode ? np[q] : 1;
-  if (w0 && out_keys && rank0 == 0)
-    for (uint32_t i = (uint32_t)lane; i < top_k; i += kWave) out_keys[o_base + i] = kKeyMax;  // holes = other GPUs' lists
+  const uint32_t n_groups = m.ref_mode ? m.np[q] : 1;
+  SeqRowsPre pre = {};  // (nprobe mode, P <= 64: what maps a key to its storage row, in flight under the merge)
+  const bool pre_ok = !m.ref_mode && P <= (uint32_t)kWave;
+  if (w0 && pre_ok) pre = wave_seq_rows_load(lane, m.pj_list + (uint64_t)q * P, m.pj_pref + (uint64_t)q * P, P);
+  auto mid = [&]() { if (w0 && pre_ok) wave_seq_rows_load2(pre, m.list_off); };
+  if (w0 && m.out_keys && rank0 == 0)
+    for (uint32_t i = (uint32_t)lane; i < top_k; i += kWave) m.out_keys[o_base + i] = kKeyMax;  // holes = other GPUs' lists
   for (uint32_t grp = 0; grp < n_groups; ++grp) {
     uint64_t list;
     uint32_t n_emit;
-    if (ref_mode) {
-      const uint32_t take = pj_take[(uint64_t)q * P + grp];
+    if (m.ref_mode) {
+      const uint32_t take = m.pj_take[(uint64_t)q * P + grp];
       if (take == 0) continue;  // uniform per block
       n_emit = take > rank0 ? (take - rank0 < (uint32_t)kWave ? take - rank0 : (uint32_t)kWave) : 0u;
-      if (pj_list[(uint64_t)q * P + grp] == kNoList || n_emit == 0) {  // scanned by the GPU that owns the list / this pair is complete
+      if (m.pj_list[(uint64_t)q * P + grp] == kNoList || n_emit == 0) {  // scanned by the GPU that owns the list / this pair is complete
         written += take;
         continue;
       }
-      list = block_merge_keys(pq + (uint64_t)grp * S_max * k_keep, S_max * k_keep, k_keep, sh);
+      list = block_merge_keys<NW>(pq + (uint64_t)grp * S_max * k_keep, S_max * k_keep, k_keep, sh);
       if (w0) {
         const bool have = lane < (int)n_emit && list != kKeyMax;
-        const uint32_t row = have ? list_off[pj_list[(uint64_t)q * P + grp]] + ((uint32_t)list - pj_pref[(uint64_t)q * P + grp]) : 0u;
+        const uint32_t row = have ? m.list_off[m.pj_list[(uint64_t)q * P + grp]] + ((uint32_t)list - m.pj_pref[(uint64_t)q * P + grp]) : 0u;
         if (have) {
           const uint64_t o = o_base + written + rank0 + lane;
-          out_ids[o] = row_ids[row];
-          out_dist[o] = __uint_as_float(order_bits_to_f32_bits((uint32_t)(list >> 32)));
-          if (out_keys) out_keys[o] = list;
+          m.out_ids[o] = m.row_ids[row];
+          m.out_dist[o] = __uint_as_float(order_bits_to_f32_bits((uint32_t)(list >> 32)));
+          if (m.out_keys) m.out_keys[o] = list;
         }
-        if (lower_out && lane == kWave - 1) lower_out[(uint64_t)q * P + grp] = list;
+        if (m.lower_out && lane == kWave - 1) m.lower_out[(uint64_t)q * P + grp] = list;
       }
       written += take;
     } else {
       n_emit = top_k - rank0 < (uint32_t)kWave ? top_k - rank0 : (uint32_t)kWave;
-      list = block_merge_keys(pq, P * S_max * k_keep, k_keep, sh);
+      list = block_merge_keys<NW>(pq, P * S_max * k_keep, k_keep, sh, mid);
       if (w0) {
         const bool have = lane < (int)n_emit && list != kKeyMax;
-        const uint32_t row = wave_seq_rows(list, have, lane, pj_list + (uint64_t)q * P, pj_pref + (uint64_t)q * P, P, list_off);
+        const uint32_t row = pre_ok ? wave_seq_rows_map(list, have, lane, pre)
+                                    : wave_seq_rows(list, have, lane, m.pj_list + (uint64_t)q * P, m.pj_pref + (uint64_t)q * P, P, m.list_off);
         if (have) {
           const uint64_t o = o_base + rank0 + lane;
-          out_ids[o] = row_ids[row];
-          out_dist[o] = __uint_as_float(order_bits_to_f32_bits((uint32_t)(list >> 32)));
-          if (out_keys) out_keys[o] = list;
+          m.out_ids[o] = m.row_ids[row];
+          m.out_dist[o] = __uint_as_float(order_bits_to_f32_bits((uint32_t)(list >> 32)));
+          if (m.out_keys) m.out_keys[o] = list;
         }
-        if (lower_out && lane == kWave - 1) lower_out[(uint64_t)q * P] = list;
+        if (m.lower_out && lane == kWave - 1) m.lower_out[(uint64_t)q * P] = list;
         const uint32_t cnt = (uint32_t)__popcll(__ballot(have));
         written = rank0 == 0 || cnt ? rank0 + cnt : 0xFFFFFFFFu;  // (a later pass that finds nothing leaves the count alone)
       }
     }
   }
-  if (w0 && lane == 0 && written != 0xFFFFFFFFu && (ref_mode ? rank0 == 0 : true)) out_count[q] = written;
+  if (w0 && lane == 0 && written != 0xFFFFFFFFu && (m.ref_mode ? rank0 == 0 : true)) m.out_count[q] = written;
+}
+__global__ __launch_bounds__(kWave * kMergeWaves) void ivf_merge_kernel(MergeArgs m) {
+  __shared__ uint64_t sh[kMergeWaves][kWave];
+  ivf_merge_block<kMergeWaves>(m, blockIdx.x, sh);
 }
 
 // exhaustive merge for the IVF handle (seq == vec_id already): ranks rank0 .. rank0 + k - 1 of output row q (pitch top_k);
@@ -727,7 +876,7 @@ struct SearchWs {
   bool ref_deep = false;     // reference-mode retry: rank 64 lists with the exact coarse quantiser (no slack needed)
   bool ref_all = false;      // last resort of a reference-mode host call: every list is ranked (the spill may walk through all of them)
   bool ref_shallow = false;  // host-pointer calls try 16 ranked lists first (a spill past the nearest few lists is rare)
-  DevBuf seg_bounds, stamps, quad_counter, fb_part, fb_ctr;
+  DevBuf seg_bounds, stamps, quad_counter, fb_part, fb_ctr, c1_ctr;  // (c1_ctr: coarse1_kernel's finished-blocks counter)
   DevBuf clower, lower;  // lower bounds of multi-pass results (coarse ranking of more than 64 lists; top_k > 64)
   DevBuf qp, qil, cpart, probe, pj, lists, pairs, items, groups, qblocks, partials, status, o_ids, o_dist, o_cnt, xpart;
   static constexpr uint32_t kEvRing = 64;  // scan-launch timing ring (measurement hook)
@@ -899,8 +1048,8 @@ int32_t ws_init(SearchWs& w) {
   if (int32_t rc = w.status.reserve(16)) return rc;
   VERS_HIP_TRY(hipMemset(w.status.p, 0, 16));
   if (scan_debug_flags() & 16u) {  // diagnosis: in-kernel phase stamps
-    if (int32_t rc = w.stamps.reserve(256)) return rc;
-    VERS_HIP_TRY(hipMemset(w.stamps.p, 0, 256));
+    if (int32_t rc = w.stamps.reserve(512)) return rc;
+    VERS_HIP_TRY(hipMemset(w.stamps.p, 0, 512));
   }
   for (uint32_t i = 0; i < SearchWs::kEvRing; ++i) {
     VERS_HIP_TRY(hipEventCreate(&w.ev0[i]));
@@ -1775,6 +1924,14 @@ int32_t stage_plain_queries(vers_ivf* h, const float* q_dev, uint64_t ldq_in, ui
   return VERS_OK;
 }
 
+// finished-blocks counter of coarse1_kernel: zero once, the kernel leaves it zero
+int32_t ensure_block_counters(vers_ivf* h, hipStream_t st) {
+  if (W->c1_ctr.p) return VERS_OK;
+  if (int32_t rc = W->c1_ctr.reserve(16)) return rc;
+  VERS_HIP_TRY(hipMemsetAsync(W->c1_ctr.p, 0, 16, st));
+  return VERS_OK;
+}
+
 // Tuning / A-B knobs of the search path (environment, read ONCE per process; DESIGN.md section 5 "Switches").
 struct SearchKnobs {
   int qg = 0;            // VERS_QG: 8 or 16 forces the ordered-chain group width
@@ -1901,7 +2058,7 @@ int32_t launch_ivf_scan(vers_ivf* h, const IvfSrc<QG>& src, uint32_t items_bound
   p.debug = scan_debug_flags();
   p.stamps = nullptr;
   if (p.debug & 16u) {  // diagnosis only
-    if (int32_t rc = W->stamps.reserve(256)) return rc;
+    if (int32_t rc = W->stamps.reserve(512)) return rc;
     VERS_HIP_TRY(hipMemsetAsync(W->stamps.p, 0, 128, st));
     p.stamps = W->stamps.as<unsigned long long>();
   }
@@ -1947,7 +2104,7 @@ int32_t launch_prescan(vers_ivf* h, const IvfSrc<kPreQ>& src, uint32_t items_bou
   p.metric = (uint32_t)h->metric;
   p.stamps = nullptr;
   if (p.debug & 16u) {
-    if (int32_t rc = W->stamps.reserve(256)) return rc;
+    if (int32_t rc = W->stamps.reserve(512)) return rc;
     VERS_HIP_TRY(hipMemsetAsync(W->stamps.p, 0, 128, st));
     p.stamps = W->stamps.as<unsigned long long>();
   }
@@ -1993,6 +2150,14 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
   // one key per lane is the width of every list in the kernels: more ranked lists (P > 64) or more results (top_k > 64)
   // are produced 64 ranks per pass (ScanParams::lower), on the ordered-chain kernels
   const bool one1 = b == 1 && P <= (uint32_t)kMaxTopK;  // single query: coarse merge + plan fused in plan1_kernel
+  // ... and the coarse scan with them in coarse1_kernel (VERS_COARSE1=0: the ordered-chain scan + plan1_kernel, for A/B runs)
+  static const bool c1_on = [] { const char* e = getenv("VERS_COARSE1"); return e ? atoi(e) != 0 : true; }();
+  const bool one1_fused = one1 && c1_on;
+  if (one1_fused) {
+    if (int32_t rc = W->cpart.reserve((size_t)((h->k + kWave - 1) / kWave) * P * sizeof(uint64_t))) return rc;
+    if (int32_t rc = W->probe.reserve((size_t)P * sizeof(uint64_t))) return rc;
+    if (int32_t rc = ensure_block_counters(h, st)) return rc;
+  }
   const float* qp = nullptr;
   const uint64_t* probe = nullptr;
   SearchWs::CoarseAhead* took = nullptr;
@@ -2130,7 +2295,8 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
     // pitch, and -- the matrix-core contraction reads whole 128-row tiles -- a whole number of tiles (or a single query)
     if (h->d == h->ldq && (reinterpret_cast<uintptr_t>(q_dev) & 15u) == 0 && (b == 1 || (ldq_in == h->ldq && b % kGemmBM == 0))) qp = q_dev;
     else if (int32_t rc = stage_plain_queries(h, q_dev, ldq_in, b, &qp, st)) return rc;
-    if (int32_t rc = coarse(h, qp, b, P, st, one1 ? &n_segs_c : nullptr, one1 ? nullptr : &pq, &planned)) return rc;
+    if (!one1_fused)
+      if (int32_t rc = coarse(h, qp, b, P, st, one1 ? &n_segs_c : nullptr, one1 ? nullptr : &pq, &planned)) return rc;
     probe = W->probe.as<uint64_t>();
   }
 
@@ -2139,12 +2305,33 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
   if (one1) {
     const bool fill_in_kernel = part_bytes <= (size_t(4) << 20);  // (a block fills a few hundred KB faster than a launch costs)
     if (!fill_in_kernel) VERS_HIP_TRY(hipMemsetAsync(W->partials.p, 0xFF, part_bytes, st));
-    hipLaunchKernelGGL(plan1_kernel, dim3(1), dim3(kWave * kMergeWaves), 0, st, W->cpart.as<uint64_t>(), n_segs_c, P, k_l, top_k,
-                       ref_mode, h->list_len.as<uint32_t>(), h->world > 1 ? h->owner.as<uint8_t>() : (const uint8_t*)nullptr, h->rank,
-                       seg_rows, W->probe.as<uint64_t>(), pj_list, pj_pref, pj_take, np, cnt, pair_off, group_off,
-                       W->pairs.as<uint32_t>(), W->items.as<ItemDesc>(), W->groups.as<GroupDesc>(), tot, W->st_word(),
-                       (const uint32_t*)h->list_slot.as<uint32_t>(), reinterpret_cast<u32x4*>(W->partials.p),
-                       fill_in_kernel ? (uint32_t)((part_bytes + 15) / 16) : 0u);
+    Plan1Args pa;
+    pa.cpart = W->cpart.as<uint64_t>(); pa.n_segs_c = n_segs_c; pa.P = P; pa.k_lists = k_l; pa.top_k = top_k; pa.ref_mode = ref_mode;
+    pa.list_len = h->list_len.as<uint32_t>(); pa.owner = h->world > 1 ? h->owner.as<uint8_t>() : (const uint8_t*)nullptr; pa.rank = h->rank;
+    pa.seg_rows = seg_rows; pa.probe = W->probe.as<uint64_t>(); pa.pj_list = pj_list; pa.pj_pref = pj_pref; pa.pj_take = pj_take; pa.np = np;
+    pa.cnt = cnt; pa.pair_off = pair_off; pa.group_off = group_off; pa.pairs = W->pairs.as<uint32_t>(); pa.items = W->items.as<ItemDesc>();
+    pa.groups = W->groups.as<GroupDesc>(); pa.tot = tot; pa.status = W->st_word(); pa.list_slot = h->list_slot.as<uint32_t>();
+    pa.ff_begin = reinterpret_cast<u32x4*>(W->partials.p); pa.ff_vec16 = fill_in_kernel ? (uint32_t)((part_bytes + 15) / 16) : 0u;
+    if (one1_fused) {  // coarse quantiser + plan in one launch: a block per 64-centroid tile, the last one to finish plans
+      Coarse1Args ca;
+      ca.cent = h->centroids_b.as<float>(); ca.k = k_l; ca.ld = h->ld; ca.n_chunks = h->ld / kChunk; ca.q = qp; ca.cpart = W->cpart.as<uint64_t>();
+      ca.P = P; ca.ctr = W->c1_ctr.as<uint32_t>(); ca.status = W->st_word();
+      ca.stamps = nullptr;
+      if (scan_debug_flags() & 16u) {
+        if (int32_t rc = W->stamps.reserve(512)) return rc;
+        ca.stamps = W->stamps.as<unsigned long long>();
+      }
+      pa.n_segs_c = (k_l + kWave - 1) / kWave;
+      if (h->metric) {
+        if (int32_t rc = scan_prepare_launch(coarse1_kernel<1>, kC1LdsBytes)) return rc;
+        hipLaunchKernelGGL(coarse1_kernel<1>, dim3(pa.n_segs_c), dim3(kWave * kC1Phase), kC1LdsBytes, st, ca, pa);
+      } else {
+        if (int32_t rc = scan_prepare_launch(coarse1_kernel<0>, kC1LdsBytes)) return rc;
+        hipLaunchKernelGGL(coarse1_kernel<0>, dim3(pa.n_segs_c), dim3(kWave * kC1Phase), kC1LdsBytes, st, ca, pa);
+      }
+    } else {
+      hipLaunchKernelGGL(plan1_kernel, dim3(1), dim3(kWave * kMergeWaves), 0, st, pa);
+    }
     VERS_HIP_TRY(hipGetLastError());
   } else {
   // (also a single query with P > 64)
@@ -2165,7 +2352,7 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
   }
   ga.stamps = nullptr;
   if (scan_debug_flags() & 16u) {
-    if (int32_t rc = W->stamps.reserve(256)) return rc;
+    if (int32_t rc = W->stamps.reserve(512)) return rc;
     ga.stamps = W->stamps.as<unsigned long long>();
   }
   // blocks: enough that a block's share of the pairs and lists is small next to the (redundant) prefix sums
@@ -2228,6 +2415,11 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
   for (uint32_t pass = 0; pass < n_pass; ++pass) {
     const uint64_t* lower = pass ? W->lower.as<uint64_t>() : nullptr;
     if (pass) VERS_HIP_TRY(hipMemsetAsync(W->partials.p, 0xFF, part_bytes, st));  // slots and pruning bounds of the previous pass
+    MergeArgs ma;
+    ma.partials = W->partials.as<uint64_t>(); ma.P = P; ma.S_max = S_max; ma.k_keep = k_keep; ma.ref_mode = ref_mode; ma.np = np;
+    ma.pj_list = pj_list; ma.pj_pref = pj_pref; ma.pj_take = pj_take; ma.list_off = h->slot_off.as<uint32_t>(); ma.row_ids = h->row_ids.as<uint32_t>();
+    ma.top_k = top_k; ma.rank0 = pass * (uint32_t)kMaxTopK; ma.out_ids = out_ids; ma.out_dist = out_dist; ma.out_count = out_count; ma.out_keys = out_keys;
+    ma.lower_out = n_pass > 1 ? W->lower.as<uint64_t>() : (uint64_t*)nullptr;
     if (QG == 1) {
       IvfSrc<1> src; fill_src(src);
       rc = launch_ivf_scan(h, src, (uint32_t)items_bound, st, lower);
@@ -2241,10 +2433,7 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
     if (rc) return rc;
     if (pass == 0)
       if (int32_t rc2 = start_pending_ahead(h, st)) return rc2;
-    hipLaunchKernelGGL(ivf_merge_kernel, dim3(b), dim3(kWave * kMergeWaves), 0, st, W->partials.as<uint64_t>(), P, S_max, k_keep,
-                       ref_mode, np, pj_list, pj_pref, pj_take, h->slot_off.as<uint32_t>(), h->row_ids.as<uint32_t>(), top_k,
-                       pass * (uint32_t)kMaxTopK, out_ids, out_dist, out_count, out_keys,
-                       n_pass > 1 ? W->lower.as<uint64_t>() : (uint64_t*)nullptr);
+    hipLaunchKernelGGL(ivf_merge_kernel, dim3(b), dim3(kWave * kMergeWaves), 0, st, ma);
     VERS_HIP_TRY(hipGetLastError());
   }
   W->tot_valid = true;
@@ -2866,8 +3055,12 @@ int32_t vers_ivf_last_scan(vers_ivf_t* h, float* out_ms, uint64_t* out_union_row
   if (out_streamed_rows) *out_streamed_rows = t.streamed_rows;
   if (out_items) *out_items = t.n_items;
   if ((scan_debug_flags() & 16u) && W->stamps.p) {  // diagnosis only: per-wave phase cycles of the last launch
-    unsigned long long sv[32] = {};
-    VERS_HIP_TRY(hipMemcpy(sv, W->stamps.p, 256, hipMemcpyDeviceToHost));
+    unsigned long long sv[64] = {};
+    VERS_HIP_TRY(hipMemcpy(sv, W->stamps.p, std::min<size_t>(512, W->stamps.cap), hipMemcpyDeviceToHost));
+    if (W->stamps.cap >= 512 && sv[37])
+      fprintf(stderr, "[vers stamps] single-query coarse + plan kernel, its last block %llu (us): loads + products %.2f  chains %.2f  sort + publish %.2f  "
+              "acquire %.2f  merge + plan %.2f\n", sv[38], (sv[33] - sv[32]) / 100.0, (sv[34] - sv[33]) / 100.0, (sv[35] - sv[34]) / 100.0,
+              (sv[36] - sv[35]) / 100.0, (sv[37] - sv[36]) / 100.0);
     if (sv[27])
       fprintf(stderr, "[vers stamps] coarse select, per query avg cycles: select %.0f  exact re-score %.0f  sort+certify+emit %.0f\n",
               (double)sv[24] / sv[27], (double)sv[25] / sv[27], (double)sv[26] / sv[27]);

@@ -736,6 +736,35 @@ __device__ __forceinline__ uint32_t wave_seq_rows(uint64_t key, bool valid, int 
   return valid && my_list != 0xFFFFFFFFu ? list_off[my_list] + my_off : 0xFFFFFFFFu;
 }
 
+// The same for P <= 64 with the per-probe operands (and the lists' storage rows, which depend on them) loaded AHEAD of whatever
+// produces the keys: two dependent round trips off the tail of a merge.
+struct SeqRowsPre { uint32_t pref, lst, loff; };
+__device__ __forceinline__ SeqRowsPre wave_seq_rows_load(int lane, const uint32_t* pj_list, const uint32_t* pj_pref, uint32_t P) {
+  SeqRowsPre r;
+  r.pref = lane < (int)P ? pj_pref[lane] : 0u;
+  r.lst = lane < (int)P ? pj_list[lane] : 0xFFFFFFFFu;
+  r.loff = 0u;
+  return r;
+}
+__device__ __forceinline__ void wave_seq_rows_load2(SeqRowsPre& r, const uint32_t* list_off) {  // (the dependent half: a round trip later)
+  r.loff = r.lst != 0xFFFFFFFFu ? list_off[r.lst] : 0u;
+}
+__device__ __forceinline__ uint32_t wave_seq_rows_map(uint64_t key, bool valid, int lane, const SeqRowsPre& r) {
+  uint32_t row = 0xFFFFFFFFu;
+  uint64_t todo = __ballot(valid);
+  while (todo) {
+    const int c = __ffsll((unsigned long long)todo) - 1;
+    todo &= todo - 1;
+    const uint32_t seq = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)key, c);
+    const uint64_t m = __ballot(r.lst != 0xFFFFFFFFu && r.pref <= seq);
+    if (m == 0) continue;
+    const int j = 63 - __builtin_clzll((unsigned long long)m);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)r.loff, j), pj = (uint32_t)__builtin_amdgcn_readlane((int)r.pref, j);
+    if (lane == c) row = lo + (seq - pj);
+  }
+  return row;
+}
+
 __device__ __forceinline__ void emit_topk(uint64_t fin, uint32_t q, uint32_t top_k, int lane, const uint32_t* pj_list, const uint32_t* pj_pref,
                                           uint32_t P, const uint32_t* list_off, const uint32_t* row_ids, uint64_t* out_ids, float* out_dist,
                                           uint32_t* out_count, uint64_t* out_keys) {

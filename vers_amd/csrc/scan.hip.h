@@ -712,61 +712,89 @@ __device__ __forceinline__ uint64_t wave_merge2_sorted(uint64_t a, uint64_t b, i
   wave_bitonic_merge64(m, lane);
   return m;
 }
+// A block barrier that orders LDS traffic only.  __syncthreads() also waits for every outstanding global access of the wave
+// (vmcnt(0)): in the merges below that would stall a wave on loads it has deliberately left in flight (the next stage's
+// operands) -- 2 us per barrier at HBM latency.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 // cross-wave tree over per-wave ascending lists (through sh); result in wave 0
+template <int NW = kMergeWaves>
 __device__ __forceinline__ uint64_t block_tree_merge(uint64_t acc, uint64_t (*sh)[kWave], int wid, int lane) {
-  __syncthreads();  // `sh` may still be read by a previous call
+  lds_barrier();  // `sh` may still be read by a previous call
   sh[wid][lane] = acc;
-  __syncthreads();
+  lds_barrier();
 #pragma unroll
-  for (int stride = kMergeWaves / 2; stride >= 1; stride >>= 1) {
+  for (int stride = NW / 2; stride >= 1; stride >>= 1) {
     if (wid < stride) acc = wave_merge2_sorted(acc, sh[wid + stride][lane], lane);
-    __syncthreads();
+    lds_barrier();
     if (wid < stride) sh[wid][lane] = acc;
-    __syncthreads();
+    lds_barrier();
   }
   return acc;
 }
-__device__ __forceinline__ uint64_t block_merge_keys(const uint64_t* slots, uint32_t n_keys, uint32_t k, uint64_t (*sh)[kWave]) {
+// NW = waves of the calling block (a power of two; `sh` holds NW rows).  `mid` runs once in every wave after the first round of
+// loads has been consumed: the place for a caller's dependent load whose operand was requested before the call.
+struct MergeNoOp { __device__ __forceinline__ void operator()() const {} };
+template <int NW = kMergeWaves, class Mid = MergeNoOp>
+__device__ __forceinline__ uint64_t block_merge_keys(const uint64_t* slots, uint32_t n_keys, uint32_t k, uint64_t (*sh)[kWave],
+                                                     Mid&& mid = Mid()) {
   __shared__ uint32_t s_cand[kWave + 2];  // candidate slot ids, [kWave] their count, [kWave + 1] unused
   __shared__ uint64_t s_T;
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const uint32_t n_slots = n_keys / k;
   uint64_t acc = kKeyMax;
-  if (n_slots <= (uint32_t)(4 * kMergeWaves)) {
+  if (n_slots <= (uint32_t)(4 * NW)) {
     // few slots: every wave merges its share (independent loads first), then the tree
     constexpr int U = 4;
     uint64_t v[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const uint32_t sl = (uint32_t)wid + (uint32_t)u * kMergeWaves;
+      const uint32_t sl = (uint32_t)wid + (uint32_t)u * NW;
       v[u] = (sl < n_slots && lane < (int)k) ? slots[(uint64_t)sl * k + lane] : kKeyMax;
     }
+    acc = v[0];
 #pragma unroll
-    for (int u = 0; u < U; ++u) acc = wave_merge2_sorted(acc, v[u], lane);
-    return block_tree_merge(acc, sh, wid, lane);
+    for (int u = 1; u < U; ++u) acc = wave_merge2_sorted(acc, v[u], lane);
+    mid();
+    return block_tree_merge<NW>(acc, sh, wid, lane);
   }
   // (1) T = the k-th smallest head
   if (threadIdx.x == 0) s_cand[kWave] = 0u;
   uint64_t heads = kKeyMax;  // this wave's k smallest heads, ascending
-  for (uint32_t s0 = (uint32_t)wid * kWave; s0 < n_slots; s0 += kMergeWaves * kWave * 4) {
+  // The first kKeep * NW * 64 heads (2048 with four waves) stay in registers for step (2); all their loads are issued before the
+  // first is used.  (Re-reading them in step (2) cost 5 dependent L2 round trips = 4 us of the single-query merge with four waves.)
+  constexpr int kKeep = 8;
+  uint64_t hk[kKeep];
+#pragma unroll
+  for (int j = 0; j < kKeep; ++j) {
+    const uint32_t sl = (uint32_t)j * (NW * kWave) + (uint32_t)wid * kWave + lane;
+    hk[j] = sl < n_slots ? slots[(uint64_t)sl * k] : kKeyMax;
+  }
+  // (the first 64 heads meet an empty list: pulling out the k smallest directly costs k rounds of wave minima, against up to 64
+  // ordered inserts -- 3.5 us with four waves; later heads mostly fail the threshold)
+  if (k <= 32) wave_topk_fill(heads, k, hk[0], lane);
+  else wave_topk_update(heads, k, hk[0], kKeyMax);
+#pragma unroll
+  for (int j = 1; j < kKeep; ++j)
+    if ((uint32_t)j * (NW * kWave) < n_slots) wave_topk_update(heads, k, hk[j], kKeyMax);  // (block-uniform)
+  constexpr uint32_t kKept = (uint32_t)kKeep * NW * kWave;
+  for (uint32_t s0 = kKept + (uint32_t)wid * kWave; s0 < n_slots; s0 += NW * kWave * 4) {
     uint64_t hd[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const uint32_t sl = s0 + (uint32_t)u * (kMergeWaves * kWave) + lane;
+      const uint32_t sl = s0 + (uint32_t)u * (NW * kWave) + lane;
       hd[u] = sl < n_slots ? slots[(uint64_t)sl * k] : kKeyMax;
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) wave_topk_update(heads, k, hd[u], kKeyMax);
   }
-  heads = block_tree_merge(heads, sh, wid, lane);
+  mid();
+  heads = block_tree_merge<NW>(heads, sh, wid, lane);
   if (wid == 0 && lane == (int)k - 1) s_T = heads;  // kKeyMax when fewer than k slots hold a key: every non-empty slot is a candidate
-  __syncthreads();
+  lds_barrier();
   const uint64_t T = s_T;
   // (2) the slots that can contribute: head <= T (at most k: keys are unique)
-  for (uint32_t s0 = (uint32_t)wid * kWave; s0 < n_slots; s0 += kMergeWaves * kWave) {
-    const uint32_t sl = s0 + lane;
-    const uint64_t hd = sl < n_slots ? slots[(uint64_t)sl * k] : kKeyMax;
+  auto offer = [&](uint32_t sl, uint64_t hd) {
     const bool in = hd != kKeyMax && hd <= T;
     const uint64_t m = __ballot(in);
     if (m) {
@@ -775,21 +803,27 @@ __device__ __forceinline__ uint64_t block_merge_keys(const uint64_t* slots, uint
       base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
       if (in) s_cand[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = sl;
     }
+  };
+#pragma unroll
+  for (int j = 0; j < kKeep; ++j) offer((uint32_t)j * (NW * kWave) + (uint32_t)wid * kWave + lane, hk[j]);
+  for (uint32_t s0 = kKept + (uint32_t)wid * kWave; s0 < n_slots; s0 += NW * kWave) {
+    const uint32_t sl = s0 + lane;
+    offer(sl, sl < n_slots ? slots[(uint64_t)sl * k] : kKeyMax);
   }
-  __syncthreads();
+  lds_barrier();
   const uint32_t n_cand = s_cand[kWave];  // <= k <= 64
-  // (3) merge the candidates: wave w takes candidates w, w + 16, ...
-  {
+  // (3) merge the candidates: wave w takes candidates w, w + NW, ... (four loads in flight at a time)
+  for (uint32_t c0 = 0; c0 < n_cand; c0 += 4 * NW) {
     uint64_t v[4];
 #pragma unroll
     for (int u = 0; u < 4; ++u) {
-      const uint32_t ci = (uint32_t)wid + (uint32_t)u * kMergeWaves;
+      const uint32_t ci = c0 + (uint32_t)wid + (uint32_t)u * NW;
       v[u] = (ci < n_cand && lane < (int)k) ? slots[(uint64_t)s_cand[ci] * k + lane] : kKeyMax;
     }
 #pragma unroll
     for (int u = 0; u < 4; ++u) acc = wave_merge2_sorted(acc, v[u], lane);
   }
-  return block_tree_merge(acc, sh, wid, lane);
+  return block_tree_merge<NW>(acc, sh, wid, lane);
 }
 
 }  // namespace vers
