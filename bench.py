@@ -216,6 +216,8 @@ def main():
                 IVFFlatIndex.merge_partials_dev(o["allp"].data_ptr(), o["allp"].data_ptr() + 8 * B * top_k, 2 * B * top_k, world, B, top_k,
                                                 nprobe, o["ids"].data_ptr(), o["dst"].data_ptr(), o["cnt"].data_ptr(), sh)
 
+    if B == 1:  # (--batch 1: the run's roofline comes from the event records single-query calls do not make unless asked)
+        capi.set_option("scan_events", 1)
     for i in range(args.warmup):
         step(i)
     for x in streams:
@@ -511,12 +513,14 @@ def main():
         # on the bytes of the lists each query actually probed; and the pipelined end-to-end time per query
         nq1 = min(64, B)
         ms1, by1 = [], []
+        capi.set_option("scan_events", 1)   # (single-query calls are not bracketed by event records unless asked: 5.5-6 us per call)
         for i in range(nq1 + 4):
             index.search_dev(Q[i:].data_ptr(), ld, 1, top_k, nprobe, ids.data_ptr(), dst.data_ptr(), cnt.data_ptr(), st)
             l1 = index.last_scan()
             if i >= 4:
                 ms1.append(l1["ms"]); by1.append(l1["union_rows"] * d * 4)
         index.poll(st)
+        capi.set_option("scan_events", 2)
         n_e2e = 200
         torch.cuda.synchronize(); t0 = time.perf_counter()
         for i in range(n_e2e):
@@ -524,7 +528,7 @@ def main():
         torch.cuda.synchronize(); e2e = (time.perf_counter() - t0) / n_e2e
         index.poll(st)
         gbs1 = float(np.sum(by1)) / (float(np.sum(ms1)) * 1e-3) / 1e9
-        extra["single_query"] = {"kernel": "scan_kernel<1,0,IvfSrc<1>> (ordered f32 chains, one query)", "queries": nq1,
+        extra["single_query"] = {"kernel": "scan1_kernel<0> (ordered f32 chains, one query, one 64-row tile per wave)", "queries": nq1,
                                  "list_scan_us": round(float(np.mean(ms1)) * 1e3, 1), "probed_list_bytes": int(np.mean(by1)),
                                  "achieved_GBs": round(gbs1, 1), "frac": round(gbs1 / HBM_PEAK_GBS, 4),
                                  "end_to_end_us": round(e2e * 1e6, 1), "end_to_end_qps": round(1.0 / e2e, 1)}

@@ -267,7 +267,10 @@ int32_t vers_ivf_build_sharded_dev(vers_ivf_t* h, const float* rows_dev, uint64_
  * contraction run as three bf16 MFMA products of hi/lo-split operands (default 3) instead of the f32 MFMA kernel (0).
  * Results are bit-identical either way: both are pre-filters behind an exact re-score and a certificate.
  * "shadow": 1 (default) = indexes built / uploaded from now on keep an fp16 shadow of their rows for the batched list
- * scan (vers_ivf_shadow_state); 0 = none, and searches on existing handles read their f32 rows until it is 1 again. */
+ * scan (vers_ivf_shadow_state); 0 = none, and searches on existing handles read their f32 rows until it is 1 again.
+ * "scan_events": HIP event records around every list-scan launch, the source of vers_ivf_last_scan's / vers_ivf_scan_times'
+ * times: 1 always, 0 never, 2 (default; VERS_SCAN_EVENTS) for batches only -- the two records cost a single-query call
+ * 5.5-6 us of ~100, so b == 1 calls are not timed unless asked. */
 int32_t vers_set_option(const char* name, int64_t value);
 /* Device memory the library holds in this process right now (rows, ids, scratch of every handle) and its high-water
  * mark since the last reset -- lets a test assert that no rank of a sharded build ever allocated the whole corpus. */

@@ -3,7 +3,7 @@
 # combined with other trace domains) of
 #   cfg3 batch 1024, one batch in flight   bench.py --streams 1        -> prescan_kernel_g, coarse kernels, group_scatter, ivf_rescore
 #   cfg3 batch 1024, bench default         bench.py (3 in flight)      -> the same launches with other batches beside them
-#   cfg3 single query                      bench.py --batch 1          -> scan_kernel<1,0,IvfSrc<1>>
+#   cfg3 single query                      bench.py --batch 1          -> coarse1_kernel, scan1_kernel, ivf_merge_kernel
 #   cfg2 flat scan                         scripts/bench_flat.py       -> scan_kernel<1,0,FlatSrc>
 #   k-means assign                         scripts/bench_assign.py     -> dist_gemm_x3w_kernel (+ MFMA-busy by PMC)
 #   8-way shard                            scripts/emulate_shard.py 8  -> per-kernel us of one rank's step, 1 and 3 batches in flight

@@ -6,7 +6,7 @@ rows = []
 for f in glob.glob(sys.argv[1] + '/**/*kernel_trace.csv', recursive=True):
     rows += list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
-anchor = sys.argv[2] if len(sys.argv) > 2 else 'IvfSrc<1>'
+anchor = sys.argv[2] if len(sys.argv) > 2 else 'scan1_kernel'
 idx = [i for i, r in enumerate(rows) if anchor in r['Kernel_Name']]
 idx = idx[len(idx) // 2:]  # the warm half
 per = idx[1] - idx[0]

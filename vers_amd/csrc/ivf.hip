@@ -156,6 +156,56 @@ struct IvfSrc {
   __device__ __forceinline__ uint32_t slot_of_pair(uint32_t pr) const { return bound_per_pair ? pr : pr / P * P; }
 };
 
+// Single query (planned by plan1_block): an item is a 16-byte RECORD -- where its rows are, how many, the sequence number of the
+// first and its partial slot -- so that a wave reaches its first tile load after ONE round trip.  Through IvfSrc it is five
+// dependent ones (item count -> item -> the list's tables -> pair -> sequence base): ~3 us of a 58 us launch in which every wave
+// has exactly one item.
+struct Item1Rec {
+  uint32_t row0;   // storage row of the item's first row
+  uint32_t nrows;
+  uint32_t seq0;   // sequence number of the first row (the probe's base + the segment's offset in its list)
+  uint32_t out;    // partial slot, in units of k_keep keys: pair * S_max + segment
+};
+struct Rec1Src {  // what scan_item asks of its source, answered from the record in registers
+  static constexpr bool kSeqIds = false;
+  static constexpr bool kStreamOnce = true;
+  Item1Rec r;
+  uint64_t* partials;
+  uint32_t k_keep, S_max, bound_per_pair;
+  __device__ __forceinline__ uint32_t seq_base(uint32_t, int) const { return r.seq0; }
+  __device__ __forceinline__ const uint32_t* seq_ids(uint32_t) const { return nullptr; }
+  __device__ __forceinline__ uint64_t* out(uint32_t, int) const { return partials + (uint64_t)r.out * k_keep; }
+  __device__ __forceinline__ uint32_t bound_slot(uint32_t, int) const { return bound_per_pair ? r.out / S_max : 0u; }
+};
+struct Scan1Args {
+  const float* rows; const Item1Rec* recs; const uint32_t* n_items_dev; const float* qp;
+  uint64_t* partials; uint32_t k_keep, S_max, bound_per_pair;
+};
+template <int METRIC>
+__global__ __launch_bounds__(kWave * kWavesPerBlock) void scan1_kernel(Scan1Args a, ScanParams p) {
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t n_waves = gridDim.x * kWavesPerBlock;
+  uint32_t it = blockIdx.x * kWavesPerBlock + wid;
+  // (both loads go out together: the record buffer holds at least one entry per launched wave, a stale one is never used)
+  const uint32_t n_items = *a.n_items_dev;
+  Rec1Src src;
+  src.r = a.recs[it];
+  src.partials = a.partials; src.k_keep = a.k_keep; src.S_max = a.S_max; src.bound_per_pair = a.bound_per_pair;
+  bool nan_seen = false;
+  while (it < n_items) {
+    ItemView<1> v;
+    v.rows = a.rows + (uint64_t)src.r.row0 * p.ld;
+    v.nrows = src.r.nrows;
+    v.nq = 1;
+    v.qb = a.qp;
+    scan_item<1, 1, METRIC>(src, p, it, v, lane, nan_seen);
+    it += n_waves;
+    if (it < n_items) src.r = a.recs[it];
+  }
+  if (__ballot(nan_seen) != 0 && lane == 0) atomicOr(p.status, 1u);
+}
+
 // ---- small kernels of the search pipeline -----------------------------------------------------
 // coarse merge: one block per query, top-P centroid keys (ascending (dist, centroid index)).  P > 64: 64 ranks per pass
 // (ScanParams::lower) -- this pass's keys go to probe[q][rank0 ..], its last key becomes the next pass's lower bound.
@@ -401,12 +451,15 @@ struct Plan1Args {
   const uint32_t* list_len; const uint8_t* owner; uint32_t rank, seg_rows;
   uint64_t* probe; uint32_t *pj_list, *pj_pref, *pj_take, *np, *cnt, *pair_off, *group_off, *pairs;
   ItemDesc* items; GroupDesc* groups; GroupTotals* tot; uint32_t* status; const uint32_t* list_slot;
+  Item1Rec* recs = nullptr; const uint32_t *slot_off = nullptr, *slot_len = nullptr; uint32_t S_max = 0;  // recs != nullptr: the items as records (scan1_kernel)
   u32x4* ff_begin; uint32_t ff_vec16;  // the list scan's partial slots: filled with all ones (empty) by whoever plans
+  unsigned long long* dbg = nullptr;
 };
 __device__ __forceinline__ void plan1_block(const Plan1Args& a, uint64_t (*sh)[kWave]) {
   const uint64_t list = block_merge_keys(a.cpart, a.n_segs_c * a.P, a.P, sh);
   if (threadIdx.x >= kWave) return;
   const int lane = threadIdx.x;
+  if (a.dbg && lane == 0) a.dbg[48] = __builtin_amdgcn_s_memrealtime();
   const uint32_t P = a.P, top_k = a.top_k;
   const uint64_t key = lane < (int)P ? list : kKeyMax;
   if (lane < (int)P) a.probe[lane] = key;
@@ -423,6 +476,7 @@ __device__ __forceinline__ void plan1_block(const Plan1Args& a, uint64_t (*sh)[k
     return inc - v;
   };
   const uint32_t pref = excl_scan(len);
+  if (a.dbg && lane == 0) a.dbg[49] = __builtin_amdgcn_s_memrealtime();
   const uint32_t total_rows = (uint32_t)__shfl(pref + len, kWave - 1, kWave);
   // reference mode (ivfflat.rs:166-195) in closed form: list j is visited while the rows before it do not yet
   // fill top_k, and contributes take_j = min(len_j, top_k - rows before it)
@@ -446,8 +500,17 @@ __device__ __forceinline__ void plan1_block(const Plan1Args& a, uint64_t (*sh)[k
     a.cnt[slot] = 1; a.pair_off[slot] = pidx; a.group_off[slot] = pidx;
     a.pairs[pidx] = (uint32_t)lane;  // q*P + j with q = 0
     a.groups[pidx] = GroupDesc{pidx, 1u};
-    for (uint32_t sgi = 0; sgi < n_s; ++sgi) a.items[item0 + sgi] = ItemDesc{slot, 0u, sgi};
+    if (a.recs) {
+      const uint32_t loff = a.slot_off[slot], llen = a.slot_len[slot];  // (the stored length: what IvfSrc::get cuts the segments from)
+      for (uint32_t sgi = 0; sgi < n_s; ++sgi) {
+        const uint32_t r0 = sgi * a.seg_rows;
+        a.recs[item0 + sgi] = Item1Rec{loff + r0, llen - r0 < a.seg_rows ? llen - r0 : a.seg_rows, pref + r0, (uint32_t)lane * a.S_max + sgi};
+      }
+    } else {
+      for (uint32_t sgi = 0; sgi < n_s; ++sgi) a.items[item0 + sgi] = ItemDesc{slot, 0u, sgi};
+    }
   }
+  if (a.dbg && lane == 0) a.dbg[50] = __builtin_amdgcn_s_memrealtime();
   const uint32_t n_items = (uint32_t)__shfl(item0 + n_s, kWave - 1, kWave);
   const uint32_t rows_scanned = (uint32_t)__shfl(excl_scan(scan ? len : 0u) + (scan ? len : 0u), kWave - 1, kWave);
   if (lane == 0) {
@@ -884,6 +947,7 @@ struct SearchWs {
   hipEvent_t evc[3] = {};  // batched coarse quantiser of the most recent search: before the GEMM | after it | after select / re-score
   bool evc_valid = false;
   uint64_t ev_count = 0;
+  bool ev_on = true;  // this search brackets its list-scan launch with event records (scan_events_ref)
   size_t ivf_bounds_off = 0;  // pruning bounds live behind the partial slots (one memset)
   // host-pointer entry points: one pinned staging buffer, one device buffer for queries, one for the packed
   // results, one stream -- a call is one H2D copy, the kernels, one D2H copy and ONE synchronisation
@@ -1204,6 +1268,13 @@ static __global__ void poison_slack_kernel(float* rows, uint32_t ld, const uint3
   const uint32_t j = (uint32_t)(t % (ld / 4));
   if (r >= n_rows || row_ids[r] != 0xFFFFFFFFu) return;
   reinterpret_cast<f32x4*>(rows + (r >> 6) * 64ull * ld)[(uint64_t)j * 64 + (r & 63)] = f32x4{value, value, value, value};
+}
+// vers_set_option("scan_events", v): HIP event records around every list-scan launch (vers_ivf_last_scan / vers_ivf_scan_times).
+// 1 always, 0 never, 2 (default) for batches only: the two records cost a single-query call 5.5-6 us of ~100 (same-box A/B,
+// scripts/bench_host_b1.py), a batch of 1024 nothing measurable.
+inline std::atomic<int>& scan_events_ref() {
+  static std::atomic<int> m{[] { const char* e = getenv("VERS_SCAN_EVENTS"); return e ? atoi(e) : 2; }()};
+  return m;
 }
 inline std::atomic<int>& shadow_mode_ref() {  // VERS_SHADOW (default 1) / vers_set_option("shadow", v)
   static std::atomic<int> m{[] { const char* e = getenv("VERS_SHADOW"); return e ? (atoi(e) != 0 ? 1 : 0) : 1; }()};
@@ -2079,12 +2150,43 @@ int32_t launch_ivf_scan(vers_ivf* h, const IvfSrc<QG>& src, uint32_t items_bound
   if (blocks > max_blocks) blocks = max_blocks;
   if (blocks == 0) blocks = 1;
   const uint32_t slot = (uint32_t)(W->ev_count % SearchWs::kEvRing);
-  VERS_HIP_TRY(hipEventRecord(W->ev0[slot], st));
+  if (W->ev_on) VERS_HIP_TRY(hipEventRecord(W->ev0[slot], st));
   if (h->metric) hipLaunchKernelGGL((scan_kernel<QG, 1, IvfSrc<QG>>), dim3(blocks), dim3(kWave * kWavesPerBlock), lds, st, src, p);
   else hipLaunchKernelGGL((scan_kernel<QG, 0, IvfSrc<QG>>), dim3(blocks), dim3(kWave * kWavesPerBlock), lds, st, src, p);
   VERS_HIP_TRY(hipGetLastError());
-  VERS_HIP_TRY(hipEventRecord(W->ev1[slot], st));
-  W->ev_count += 1;
+  if (W->ev_on) {
+    VERS_HIP_TRY(hipEventRecord(W->ev1[slot], st));
+    W->ev_count += 1;
+  }
+  return VERS_OK;
+}
+
+// a single query's list scan over item records (scan1_kernel); timed through the same event ring
+int32_t launch_scan1(vers_ivf* h, const Scan1Args& a, uint32_t items_bound, hipStream_t st, const uint64_t* lower) {
+  ScanParams p;
+  p.ld = h->ld;
+  p.n_chunks = h->ld / kChunk;
+  p.k = a.k_keep;
+  p.status = W->st_word();
+  p.debug = scan_debug_flags() & ~16u;
+  p.stamps = nullptr;
+  p.bounds = nullptr;
+  p.lower = lower;
+  p.next_quad = nullptr;
+  uint32_t blocks = (items_bound + kWavesPerBlock - 1) / kWavesPerBlock;  // (W->items holds items_bound + 4 records: one per launched wave)
+  const uint32_t max_blocks = (uint32_t)h->n_cu * scan_blocks_per_cu(1, h->ld);
+  if (blocks > max_blocks) blocks = max_blocks;
+  if (blocks == 0) blocks = 1;
+  const bool no_ev = !W->ev_on;
+  const uint32_t slot = (uint32_t)(W->ev_count % SearchWs::kEvRing);
+  if (!no_ev) VERS_HIP_TRY(hipEventRecord(W->ev0[slot], st));
+  if (h->metric) hipLaunchKernelGGL(scan1_kernel<1>, dim3(blocks), dim3(kWave * kWavesPerBlock), 0, st, a, p);
+  else hipLaunchKernelGGL(scan1_kernel<0>, dim3(blocks), dim3(kWave * kWavesPerBlock), 0, st, a, p);
+  VERS_HIP_TRY(hipGetLastError());
+  if (!no_ev) {
+    VERS_HIP_TRY(hipEventRecord(W->ev1[slot], st));
+    W->ev_count += 1;
+  }
   return VERS_OK;
 }
 
@@ -2118,12 +2220,14 @@ int32_t launch_prescan(vers_ivf* h, const IvfSrc<kPreQ>& src, uint32_t items_bou
   if (blocks > max_blocks) blocks = max_blocks;
   if (blocks == 0) blocks = 1;
   const uint32_t slot = (uint32_t)(W->ev_count % SearchWs::kEvRing);
-  VERS_HIP_TRY(hipEventRecord(W->ev0[slot], st));
+  if (W->ev_on) VERS_HIP_TRY(hipEventRecord(W->ev0[slot], st));
   if (shadow) hipLaunchKernelGGL((prescan_kernel_g<true, IvfSrc<kPreQ>>), dim3(blocks), dim3(kWave * kPreWavesG), lds, st, src, p);
   else hipLaunchKernelGGL((prescan_kernel_g<false, IvfSrc<kPreQ>>), dim3(blocks), dim3(kWave * kPreWavesG), lds, st, src, p);
   VERS_HIP_TRY(hipGetLastError());
-  VERS_HIP_TRY(hipEventRecord(W->ev1[slot], st));
-  W->ev_count += 1;
+  if (W->ev_on) {
+    VERS_HIP_TRY(hipEventRecord(W->ev1[slot], st));
+    W->ev_count += 1;
+  }
   return VERS_OK;
 }
 
@@ -2139,6 +2243,7 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
   }
   if (h->k == 0) return fail(VERS_ERR_INSUFFICIENT, "search on an index without centroids (reference: index out of bounds, ivfflat.rs:169)");
   const int ref_mode = nprobe == 0;
+  { const int ev = scan_events_ref().load(); W->ev_on = ev == 1 || (ev == 2 && b > 1); }
   // reference mode ranks the 48 nearest lists (48 + 16 slack = one key per lane in the MFMA pre-selection);
   // a spill deeper than that is refused (kStSpillTooDeep) -- it needs > 47 consecutive near-empty lists
   // (host-pointer calls retry deeper: 16, 48, 64 and finally ALL lists, W->ref_all -- the reference walks as far as it must)
@@ -2246,7 +2351,7 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
   const size_t zero_words = 3 * (size_t)k_l + 4 + (use_pre ? (size_t)b + 4 + n_pj : 0);
   if (int32_t rc = W->lists.reserve((zero_words + 3 * (size_t)k_l) * sizeof(uint32_t) + sizeof(GroupTotals) + 64)) return rc;
   if (int32_t rc = W->pairs.reserve(n_pj * sizeof(uint32_t))) return rc;
-  if (int32_t rc = W->items.reserve(std::max<uint64_t>(1, items_bound) * sizeof(ItemDesc))) return rc;
+  if (int32_t rc = W->items.reserve(one1 ? (items_bound + 4) * sizeof(Item1Rec) : std::max<uint64_t>(1, items_bound) * sizeof(ItemDesc))) return rc;
   if (int32_t rc = W->groups.reserve(std::max<uint64_t>(1, groups_bound) * sizeof(GroupDesc))) return rc;
   if (QG != 1 && !use_pre)
     if (int32_t rc = W->qblocks.reserve(groups_bound * h->ldq * QG * sizeof(float))) return rc;
@@ -2312,6 +2417,7 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
     pa.cnt = cnt; pa.pair_off = pair_off; pa.group_off = group_off; pa.pairs = W->pairs.as<uint32_t>(); pa.items = W->items.as<ItemDesc>();
     pa.groups = W->groups.as<GroupDesc>(); pa.tot = tot; pa.status = W->st_word(); pa.list_slot = h->list_slot.as<uint32_t>();
     pa.ff_begin = reinterpret_cast<u32x4*>(W->partials.p); pa.ff_vec16 = fill_in_kernel ? (uint32_t)((part_bytes + 15) / 16) : 0u;
+    pa.recs = W->items.as<Item1Rec>(); pa.slot_off = h->slot_off.as<uint32_t>(); pa.slot_len = h->slot_len.as<uint32_t>(); pa.S_max = S_max;
     if (one1_fused) {  // coarse quantiser + plan in one launch: a block per 64-centroid tile, the last one to finish plans
       Coarse1Args ca;
       ca.cent = h->centroids_b.as<float>(); ca.k = k_l; ca.ld = h->ld; ca.n_chunks = h->ld / kChunk; ca.q = qp; ca.cpart = W->cpart.as<uint64_t>();
@@ -2320,6 +2426,7 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
       if (scan_debug_flags() & 16u) {
         if (int32_t rc = W->stamps.reserve(512)) return rc;
         ca.stamps = W->stamps.as<unsigned long long>();
+        pa.dbg = ca.stamps;
       }
       pa.n_segs_c = (k_l + kWave - 1) / kWave;
       if (h->metric) {
@@ -2420,7 +2527,12 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
     ma.pj_list = pj_list; ma.pj_pref = pj_pref; ma.pj_take = pj_take; ma.list_off = h->slot_off.as<uint32_t>(); ma.row_ids = h->row_ids.as<uint32_t>();
     ma.top_k = top_k; ma.rank0 = pass * (uint32_t)kMaxTopK; ma.out_ids = out_ids; ma.out_dist = out_dist; ma.out_count = out_count; ma.out_keys = out_keys;
     ma.lower_out = n_pass > 1 ? W->lower.as<uint64_t>() : (uint64_t*)nullptr;
-    if (QG == 1) {
+    if (one1) {  // the single query's items are records (plan1_block)
+      Scan1Args sa;
+      sa.rows = h->rows.as<float>(); sa.recs = W->items.as<Item1Rec>(); sa.n_items_dev = &tot->n_items; sa.qp = qp;
+      sa.partials = W->partials.as<uint64_t>(); sa.k_keep = k_keep; sa.S_max = S_max; sa.bound_per_pair = ref_mode ? 1u : 0u;
+      rc = launch_scan1(h, sa, (uint32_t)items_bound, st, lower);
+    } else if (QG == 1) {
       IvfSrc<1> src; fill_src(src);
       rc = launch_ivf_scan(h, src, (uint32_t)items_bound, st, lower);
     } else if (QG == 8) {
@@ -2759,6 +2871,7 @@ int32_t vers_set_option(const char* name, int64_t value) {
   if (!name) return fail(VERS_ERR_INVALID, "vers_set_option: null name");
   if (std::strcmp(name, "gemm_x3") == 0) { set_gemm_x3_mask((int)value); return VERS_OK; }
   if (std::strcmp(name, "shadow") == 0) { shadow_mode_ref().store(value != 0 ? 1 : 0); return VERS_OK; }
+  if (std::strcmp(name, "scan_events") == 0) { scan_events_ref().store(value < 0 || value > 2 ? 2 : (int)value); return VERS_OK; }
   return fail(VERS_ERR_INVALID, std::string("vers_set_option: unknown option ") + name);
 }
 
@@ -3061,6 +3174,7 @@ int32_t vers_ivf_last_scan(vers_ivf_t* h, float* out_ms, uint64_t* out_union_row
       fprintf(stderr, "[vers stamps] single-query coarse + plan kernel, its last block %llu (us): loads + products %.2f  chains %.2f  sort + publish %.2f  "
               "acquire %.2f  merge + plan %.2f\n", sv[38], (sv[33] - sv[32]) / 100.0, (sv[34] - sv[33]) / 100.0, (sv[35] - sv[34]) / 100.0,
               (sv[36] - sv[35]) / 100.0, (sv[37] - sv[36]) / 100.0);
+    if (sv[50]) fprintf(stderr, "[vers stamps]   merge %.2f  list tables + scan %.2f  plan stores %.2f  rest %.2f\n", (sv[48] - sv[36]) / 100.0, (sv[49] - sv[48]) / 100.0, (sv[50] - sv[49]) / 100.0, (sv[37] - sv[50]) / 100.0);
     if (sv[27])
       fprintf(stderr, "[vers stamps] coarse select, per query avg cycles: select %.0f  exact re-score %.0f  sort+certify+emit %.0f\n",
               (double)sv[24] / sv[27], (double)sv[25] / sv[27], (double)sv[26] / sv[27]);
