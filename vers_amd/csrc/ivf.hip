@@ -600,7 +600,6 @@ __global__ __launch_bounds__(kWave * kC1Phase) void coarse1_kernel(Coarse1Args c
     if (c0 == 0) stamp(1);
     if (wid == 0) {
       const uint32_t nch = c.n_chunks - c0 < (uint32_t)kC1Phase ? c.n_chunks - c0 : (uint32_t)kC1Phase;
-      // (two register buffers: the next chunk's products are on their way from LDS while this chunk's 32 adds run)
       auto ld = [&](f32x4 (&m)[kLoads], uint32_t s) {
 #pragma unroll
         for (int i = 0; i < kLoads; ++i) m[i] = prod[(s * kLoads + i) * kWave + lane];
@@ -611,13 +610,17 @@ __global__ __launch_bounds__(kWave * kC1Phase) void coarse1_kernel(Coarse1Args c
 #pragma unroll
           for (int u = 0; u < 4; ++u) acc = __fadd_rn(acc, m[i][u]);
       };
+      // (two register buffers: the next chunk's products are on their way from LDS while this chunk's 32 adds run.  The chain itself is
+      // the floor: a dependent v_add_f32 issues every ~8 cycles, 768 of them are ~3 us; fully unrolled phases with the reads pinned two
+      // half-chunks ahead measured 3.5 us against this loop's 3.7)
       f32x4 mA[kLoads], mB[kLoads];
+      const uint32_t last = nch - 1;
       ld(mA, 0);
       for (uint32_t s = 0; s < nch; s += 2) {
-        ld(mB, s + 1 < nch ? s + 1 : s);
+        ld(mB, s + 1 < nch ? s + 1 : last);
         add(mA);
         if (s + 1 < nch) {
-          ld(mA, s + 2 < nch ? s + 2 : s + 1);
+          ld(mA, s + 2 < nch ? s + 2 : last);
           add(mB);
         }
       }
@@ -742,9 +745,10 @@ __device__ __forceinline__ void ivf_merge_block(const MergeArgs& m, uint32_t q, 
   }
   if (w0 && lane == 0 && written != 0xFFFFFFFFu && (m.ref_mode ? rank0 == 0 : true)) m.out_count[q] = written;
 }
-__global__ __launch_bounds__(kWave * kMergeWaves) void ivf_merge_kernel(MergeArgs m) {
-  __shared__ uint64_t sh[kMergeWaves][kWave];
-  ivf_merge_block<kMergeWaves>(m, blockIdx.x, sh);
+template <int NW>
+__global__ __launch_bounds__(kWave * NW) void ivf_merge_kernel(MergeArgs m) {
+  __shared__ uint64_t sh[NW][kWave];
+  ivf_merge_block<NW>(m, blockIdx.x, sh);
 }
 
 // exhaustive merge for the IVF handle (seq == vec_id already): ranks rank0 .. rank0 + k - 1 of output row q (pitch top_k);
@@ -2545,7 +2549,11 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
     if (rc) return rc;
     if (pass == 0)
       if (int32_t rc2 = start_pending_ahead(h, st)) return rc2;
-    hipLaunchKernelGGL(ivf_merge_kernel, dim3(b), dim3(kWave * kMergeWaves), 0, st, ma);
+    // four waves while a wave can hold its share of the slots' heads in registers (2048 slots of a merge group: two tree levels
+    // instead of four; same box, single query: 94.2 -> 91.6 us, reference mode 59.0 -> 55.3), sixteen beyond
+    const uint64_t slots_per_group = ref_mode ? S_max : (uint64_t)P * S_max;
+    if (slots_per_group <= 2048) hipLaunchKernelGGL(ivf_merge_kernel<4>, dim3(b), dim3(kWave * 4), 0, st, ma);
+    else hipLaunchKernelGGL(ivf_merge_kernel<kMergeWaves>, dim3(b), dim3(kWave * kMergeWaves), 0, st, ma);
     VERS_HIP_TRY(hipGetLastError());
   }
   W->tot_valid = true;
