@@ -2553,10 +2553,10 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
     if (rc) return rc;
     if (pass == 0)
       if (int32_t rc2 = start_pending_ahead(h, st)) return rc2;
-    // four waves while a wave can hold its share of the slots' heads in registers (2048 slots of a merge group: two tree levels
+    // four waves while a wave can hold its share of the slots' heads in registers (4096 slots of a merge group: two tree levels
     // instead of four; same box, single query: 94.2 -> 91.6 us, reference mode 59.0 -> 55.3), sixteen beyond
     const uint64_t slots_per_group = ref_mode ? S_max : (uint64_t)P * S_max;
-    if (slots_per_group <= 2048) hipLaunchKernelGGL(ivf_merge_kernel<4>, dim3(b), dim3(kWave * 4), 0, st, ma);
+    if (slots_per_group <= 4096) hipLaunchKernelGGL(ivf_merge_kernel<4>, dim3(b), dim3(kWave * 4), 0, st, ma);
     else hipLaunchKernelGGL(ivf_merge_kernel<kMergeWaves>, dim3(b), dim3(kWave * kMergeWaves), 0, st, ma);
     VERS_HIP_TRY(hipGetLastError());
   }

@@ -761,9 +761,9 @@ __device__ __forceinline__ uint64_t block_merge_keys(const uint64_t* slots, uint
   // (1) T = the k-th smallest head
   if (threadIdx.x == 0) s_cand[kWave] = 0u;
   uint64_t heads = kKeyMax;  // this wave's k smallest heads, ascending
-  // The first kKeep * NW * 64 heads (2048 with four waves) stay in registers for step (2); all their loads are issued before the
+  // The first kKeep * NW * 64 heads (4096 with four waves) stay in registers for step (2); all their loads are issued before the
   // first is used.  (Re-reading them in step (2) cost 5 dependent L2 round trips = 4 us of the single-query merge with four waves.)
-  constexpr int kKeep = 8;
+  constexpr int kKeep = 16;
   uint64_t hk[kKeep];
 #pragma unroll
   for (int j = 0; j < kKeep; ++j) {
