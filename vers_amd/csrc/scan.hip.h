@@ -758,59 +758,124 @@ __device__ __forceinline__ uint64_t block_merge_keys(const uint64_t* slots, uint
     mid();
     return block_tree_merge<NW>(acc, sh, wid, lane);
   }
-  // (1) T = the k-th smallest head
-  if (threadIdx.x == 0) s_cand[kWave] = 0u;
-  uint64_t heads = kKeyMax;  // this wave's k smallest heads, ascending
-  // The first kKeep * NW * 64 heads (4096 with four waves) stay in registers for step (2); all their loads are issued before the
-  // first is used.  (Re-reading them in step (2) cost 5 dependent L2 round trips = 4 us of the single-query merge with four waves.)
+  // (1) + (2): the slots that can contribute are those whose head is at or below T = the k-th smallest head (at most k: keys are
+  // unique).  Found in time that does not depend on the data:
+  //   (a) every wave loads its share of the heads (all loads before the first use; they stay in registers) and bounds its own
+  //       k-th smallest head from above: T0_w = the k-th smallest of its LANE minima (one sort of 64 keys).  T0 = min over the
+  //       waves bounds T from above;
+  //   (b) the heads at or below T0 -- a few dozen -- go with their slot numbers into ONE list in LDS (an LDS atomic per register
+  //       that has any); wave 0 sorts them (one or two sorts of 64), reads T off lane k - 1 and marks the list's entries <= T.
+  // More than 128 heads at or below T0 (fewer heads than k per wave, adversarial data): the exact fallback below.
+  // (Before: every wave offered its registers one by one to a sorted list -- an ordered insert per head passing the running
+  // threshold, 2 us in a wave that meets the best lists' slots first and 6 us in one that meets them last, the block waiting for
+  // its slowest wave --, a tree over the waves' lists, and a second pass over the heads against T.)
+  __shared__ uint64_t s_lh[128];
+  __shared__ uint32_t s_ls[128];
+  __shared__ uint64_t s_T0[NW];
+  __shared__ uint32_t s_n;
+  if (threadIdx.x == 0) { s_cand[kWave] = 0u; s_n = 0u; }
   constexpr int kKeep = 16;
+  constexpr uint32_t kKept = (uint32_t)kKeep * NW * kWave;
   uint64_t hk[kKeep];
 #pragma unroll
   for (int j = 0; j < kKeep; ++j) {
     const uint32_t sl = (uint32_t)j * (NW * kWave) + (uint32_t)wid * kWave + lane;
     hk[j] = sl < n_slots ? slots[(uint64_t)sl * k] : kKeyMax;
   }
-  // (the first 64 heads meet an empty list: pulling out the k smallest directly costs k rounds of wave minima, against up to 64
-  // ordered inserts -- 3.5 us with four waves; later heads mostly fail the threshold)
-  if (k <= 32) wave_topk_fill(heads, k, hk[0], lane);
-  else wave_topk_update(heads, k, hk[0], kKeyMax);
+  uint64_t vmin = hk[0];
 #pragma unroll
-  for (int j = 1; j < kKeep; ++j)
-    if ((uint32_t)j * (NW * kWave) < n_slots) wave_topk_update(heads, k, hk[j], kKeyMax);  // (block-uniform)
-  constexpr uint32_t kKept = (uint32_t)kKeep * NW * kWave;
-  for (uint32_t s0 = kKept + (uint32_t)wid * kWave; s0 < n_slots; s0 += NW * kWave * 4) {
-    uint64_t hd[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const uint32_t sl = s0 + (uint32_t)u * (NW * kWave) + lane;
-      hd[u] = sl < n_slots ? slots[(uint64_t)sl * k] : kKeyMax;
-    }
-#pragma unroll
-    for (int u = 0; u < 4; ++u) wave_topk_update(heads, k, hd[u], kKeyMax);
+  for (int j = 1; j < kKeep; ++j) vmin = hk[j] < vmin ? hk[j] : vmin;
+  uint64_t T0w;
+  {  // (the k-th smallest LANE MINIMUM: k heads of the wave are at or below it.  A cheaper bound -- the largest of the 16 quad minima,
+     // for k <= 16 -- let hundreds of heads through at cfg3, where one wave holds the nearest list's slots and the others do not)
+    uint64_t srt = vmin;
+    if (n_slots > 128u) wave_bitonic_sort64(srt, lane);     // (block-uniform; at most 128 slots: the list below holds them all)
+    T0w = n_slots > 128u ? readlane64(srt, (int)k - 1) : kKeyMax;
   }
+  if (lane == 0) s_T0[wid] = T0w;
   mid();
-  heads = block_tree_merge<NW>(heads, sh, wid, lane);
-  if (wid == 0 && lane == (int)k - 1) s_T = heads;  // kKeyMax when fewer than k slots hold a key: every non-empty slot is a candidate
   lds_barrier();
-  const uint64_t T = s_T;
-  // (2) the slots that can contribute: head <= T (at most k: keys are unique)
-  auto offer = [&](uint32_t sl, uint64_t hd) {
-    const bool in = hd != kKeyMax && hd <= T;
+  uint64_t T0 = s_T0[0];
+#pragma unroll
+  for (int w = 1; w < NW; ++w) T0 = s_T0[w] < T0 ? s_T0[w] : T0;
+  auto list_add = [&](uint32_t sl, uint64_t hd) {
+    const bool in = hd != kKeyMax && hd <= T0;
     const uint64_t m = __ballot(in);
     if (m) {
       uint32_t base = 0;
-      if (lane == 0) base = atomicAdd(&s_cand[kWave], (uint32_t)__popcll(m));
+      if (lane == 0) base = atomicAdd(&s_n, (uint32_t)__popcll(m));
       base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
-      if (in) s_cand[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = sl;
+      const uint32_t at = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+      if (in && at < 128u) { s_lh[at] = hd; s_ls[at] = sl; }
     }
   };
 #pragma unroll
-  for (int j = 0; j < kKeep; ++j) offer((uint32_t)j * (NW * kWave) + (uint32_t)wid * kWave + lane, hk[j]);
-  for (uint32_t s0 = kKept + (uint32_t)wid * kWave; s0 < n_slots; s0 += NW * kWave) {
+  for (int j = 0; j < kKeep; ++j)
+    if ((uint32_t)j * (NW * kWave) < n_slots) list_add((uint32_t)j * (NW * kWave) + (uint32_t)wid * kWave + lane, hk[j]);  // (block-uniform)
+  for (uint32_t s0 = kKept + (uint32_t)wid * kWave; s0 < n_slots; s0 += NW * kWave) {  // (heads beyond the registers: T0 bounds T all the same)
     const uint32_t sl = s0 + lane;
-    offer(sl, sl < n_slots ? slots[(uint64_t)sl * k] : kKeyMax);
+    list_add(sl, sl < n_slots ? slots[(uint64_t)sl * k] : kKeyMax);
   }
   lds_barrier();
+  const uint32_t n_list = s_n;
+  if (n_list <= 128u) {
+    if (wid == 0) {
+      const uint64_t h0 = (uint32_t)lane < n_list ? s_lh[lane] : kKeyMax;
+      const uint64_t h1 = (uint32_t)lane + kWave < n_list ? s_lh[kWave + lane] : kKeyMax;
+      uint64_t srt = h0;
+      wave_bitonic_sort64(srt, lane);
+      if (n_list > (uint32_t)kWave) {  // (wave-uniform)
+        uint64_t s1 = h1;
+        wave_bitonic_sort64(s1, lane);
+        srt = wave_merge2_sorted(srt, s1, lane);
+      }
+      const uint64_t T = readlane64(srt, (int)k - 1);  // kKeyMax when fewer than k slots hold a key: every non-empty slot is a candidate
+      const bool in0 = h0 != kKeyMax && h0 <= T, in1 = h1 != kKeyMax && h1 <= T;
+      const uint64_t m0 = __ballot(in0), m1 = __ballot(in1);
+      const uint32_t c0 = (uint32_t)__popcll(m0);
+      if (in0) s_cand[(uint32_t)__popcll(m0 & ((1ull << lane) - 1ull))] = s_ls[lane];
+      if (in1) s_cand[c0 + (uint32_t)__popcll(m1 & ((1ull << lane) - 1ull))] = s_ls[kWave + lane];
+      if (lane == 0) s_cand[kWave] = c0 + (uint32_t)__popcll(m1);
+    }
+    lds_barrier();
+  } else {
+    // exact fallback: the waves' k smallest heads by ordered inserts, a tree over the waves, a second pass against T
+    uint64_t heads = kKeyMax;
+#pragma unroll
+    for (int j = 0; j < kKeep; ++j)
+      if ((uint32_t)j * (NW * kWave) < n_slots) wave_topk_update(heads, k, hk[j], kKeyMax);  // (block-uniform)
+    for (uint32_t s0 = kKept + (uint32_t)wid * kWave; s0 < n_slots; s0 += NW * kWave * 4) {
+      uint64_t hd[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const uint32_t sl = s0 + (uint32_t)u * (NW * kWave) + lane;
+        hd[u] = sl < n_slots ? slots[(uint64_t)sl * k] : kKeyMax;
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) wave_topk_update(heads, k, hd[u], kKeyMax);
+    }
+    heads = block_tree_merge<NW>(heads, sh, wid, lane);
+    if (wid == 0 && lane == (int)k - 1) s_T = heads;
+    lds_barrier();
+    const uint64_t T = s_T;
+    auto offer = [&](uint32_t sl, uint64_t hd) {
+      const bool in = hd != kKeyMax && hd <= T;
+      const uint64_t m = __ballot(in);
+      if (m) {
+        uint32_t base = 0;
+        if (lane == 0) base = atomicAdd(&s_cand[kWave], (uint32_t)__popcll(m));
+        base = (uint32_t)__builtin_amdgcn_readfirstlane((int)base);
+        if (in) s_cand[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = sl;
+      }
+    };
+#pragma unroll
+    for (int j = 0; j < kKeep; ++j) offer((uint32_t)j * (NW * kWave) + (uint32_t)wid * kWave + lane, hk[j]);
+    for (uint32_t s0 = kKept + (uint32_t)wid * kWave; s0 < n_slots; s0 += NW * kWave) {
+      const uint32_t sl = s0 + lane;
+      offer(sl, sl < n_slots ? slots[(uint64_t)sl * k] : kKeyMax);
+    }
+    lds_barrier();
+  }
   const uint32_t n_cand = s_cand[kWave];  // <= k <= 64
   // (3) merge the candidates: wave w takes candidates w, w + NW, ... (four loads in flight at a time)
   for (uint32_t c0 = 0; c0 < n_cand; c0 += 4 * NW) {
