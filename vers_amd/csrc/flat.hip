@@ -48,12 +48,14 @@ struct FlatSrc {
 
 // one block per query: the k smallest keys of its n_segs partial slots -> (id, dist) at ranks rank0 .. rank0 + k - 1 of output
 // row q (pitch top_k).  top_k > 64 comes 64 ranks per pass (ScanParams::lower): this pass's last key is the next one's bound.
-__global__ __launch_bounds__(kWave * kMergeWaves) void flat_merge_kernel(const uint64_t* partials, uint32_t n_segs, uint32_t k, uint64_t n,
-                                                                         uint32_t top_k, uint32_t rank0, uint64_t* out_ids, float* out_dist,
-                                                                         uint32_t* out_count, uint64_t* lower_out) {
-  __shared__ uint64_t sh[kMergeWaves][kWave];
+// NW = waves of the block: four while a wave holds its share of the slots' heads in registers (4096 slots), sixteen beyond
+template <int NW>
+__global__ __launch_bounds__(kWave * NW) void flat_merge_kernel(const uint64_t* partials, uint32_t n_segs, uint32_t k, uint64_t n,
+                                                                uint32_t top_k, uint32_t rank0, uint64_t* out_ids, float* out_dist,
+                                                                uint32_t* out_count, uint64_t* lower_out) {
+  __shared__ uint64_t sh[NW][kWave];
   const uint32_t q = blockIdx.x;
-  uint64_t list = block_merge_keys(partials + (uint64_t)q * n_segs * k, n_segs * k, k, sh);
+  uint64_t list = block_merge_keys<NW>(partials + (uint64_t)q * n_segs * k, n_segs * k, k, sh);
   if (threadIdx.x >= kWave) return;
   const int lane = threadIdx.x;
   const uint32_t total = n < top_k ? (uint32_t)n : top_k;  // utils.rs:79 take(k) of n sorted rows
@@ -182,8 +184,11 @@ int32_t flat_search_dev_locked(vers_flat* h, const float* q_dev, uint64_t ldq, u
       rc = metric == VERS_METRIC_L2SQ ? launch_flat_scan<8, 0>(h, src, n_items, st, lower) : launch_flat_scan<8, 1>(h, src, n_items, st, lower);
     }
     if (rc) return rc;
-    hipLaunchKernelGGL(flat_merge_kernel, dim3(b), dim3(kWave * kMergeWaves), 0, st, h->partials, n_segs, k_pass, h->n, top_k, rank0, out_ids,
-                       out_dist, out_count, top_k > (uint32_t)kMaxTopK ? h->lower : (uint64_t*)nullptr);
+    uint64_t* lower_out = top_k > (uint32_t)kMaxTopK ? h->lower : (uint64_t*)nullptr;
+    if (n_segs <= 4096) hipLaunchKernelGGL(flat_merge_kernel<4>, dim3(b), dim3(kWave * 4), 0, st, h->partials, n_segs, k_pass, h->n, top_k, rank0, out_ids,
+                                           out_dist, out_count, lower_out);
+    else hipLaunchKernelGGL(flat_merge_kernel<kMergeWaves>, dim3(b), dim3(kWave * kMergeWaves), 0, st, h->partials, n_segs, k_pass, h->n, top_k, rank0,
+                            out_ids, out_dist, out_count, lower_out);
     VERS_HIP_TRY(hipGetLastError());
   }
   return VERS_OK;
