@@ -97,6 +97,11 @@ for sub in ("prescan_kernel_g<true", "prescan_kernel_g<false", "coarse_select_re
 print()
 # ---- single query ----
 a1 = show_trace("cfg3 single query (bench.py --batch 1 --steps 300 --warmup 20)", "b1/trace", 20, top=8)
+for nm in ("coarse1_kernel", "scan1_kernel", "ivf_merge_kernel"):  # the query's own three launches (the table above is led by the build)
+    for k, v in a1.items():
+        if nm in k and len(v) > 20:
+            d = v[20:]
+            print(f"  {short(k)[:70]:70s} mean {sum(d)/len(d):6.1f} us (min {min(d):.1f}) over {len(d)} warm dispatches")
 f1, n1 = mean_of(pmc("b1/pmc_fetch"), "scan1_kernel", "FETCH_SIZE", 20)
 k1 = [v for k, v in a1.items() if "scan1_kernel" in k or "scan_kernel<1, 0, IvfSrc<1>" in k.replace("vers::", "")]
 if k1 and f1:
