@@ -306,3 +306,29 @@ def test_poll_reports_only_the_polled_streams_calls():
     assert res["B"][0] == [0] * 8, res["B"][0]
     assert np.array_equal(res["B"][1], want[0]) and np.array_equal(res["B"][3], want[2])
     assert np.array_equal(res["B"][2].view(np.uint32), want[1].view(np.uint32))
+
+
+def test_scan_events_option_times_single_query_scans_only_on_request():
+    """vers_set_option("scan_events", v): the event records around the list-scan launch (vers_ivf_scan_times / vers_ivf_last_scan) cost a
+    single-query call 5.5-6 us, so by default (2) only batches make them; 1 = every call, 0 = none."""
+    n, d, k = 3000, 24, 12
+    X = dg.dist_c(0x5EC1, n, d, 6, dg.default_sigma(d))
+    ix = IVFFlatIndex.build_index(k, 1, 2, X, init_indices=mg.init_draws(0x5EC1, 1, k, n))
+    Q = dg.dist_c(0x5EC2, 40, d, 6, dg.default_sigma(d))
+    try:
+        ix.search_batch(Q, 5, 3); ix.scan_times(reset=True)
+        for _ in range(3):
+            ix.search_batch(Q[1], 5, 3)                 # default: single queries are not timed
+        assert len(ix.scan_times(reset=True)) == 0
+        ix.search_batch(Q, 5, 3)                        # ... batches are
+        assert len(ix.scan_times(reset=True)) == 1
+        capi.set_option("scan_events", 1)
+        r1 = ix.search_batch(Q[1], 5, 3)
+        assert ix.last_scan()["ms"] > 0.0 and len(ix.scan_times(reset=True)) == 1
+        capi.set_option("scan_events", 0)
+        r0 = ix.search_batch(Q, 5, 3)
+        assert len(ix.scan_times(reset=True)) == 0
+        assert np.array_equal(r1[0], r0[0][1:2]) and np.array_equal(bits(r1[1]), bits(r0[1][1:2]))   # timing never touches results
+    finally:
+        capi.set_option("scan_events", 2)
+        ix.close()
