@@ -455,8 +455,9 @@ struct Plan1Args {
   u32x4* ff_begin; uint32_t ff_vec16;  // the list scan's partial slots: filled with all ones (empty) by whoever plans
   unsigned long long* dbg = nullptr;
 };
+template <bool COHERENT>  // the coarse slots come from other blocks of this launch (coarse1_kernel)
 __device__ __forceinline__ void plan1_block(const Plan1Args& a, uint64_t (*sh)[kWave]) {
-  const uint64_t list = block_merge_keys(a.cpart, a.n_segs_c * a.P, a.P, sh);
+  const uint64_t list = block_merge_keys<kMergeWaves, MergeNoOp, COHERENT>(a.cpart, a.n_segs_c * a.P, a.P, sh);
   if (threadIdx.x >= kWave) return;
   const int lane = threadIdx.x;
   if (a.dbg && lane == 0) a.dbg[48] = __builtin_amdgcn_s_memrealtime();
@@ -466,6 +467,8 @@ __device__ __forceinline__ void plan1_block(const Plan1Args& a, uint64_t (*sh)[k
   const uint32_t L = key != kKeyMax ? (uint32_t)key : kNoList;
   const uint32_t len = L != kNoList ? a.list_len[L] : 0u;
   const uint32_t slot = L != kNoList ? a.list_slot[L] : kNoList;  // the tables and items name a list by its slot (vers_ivf::list_slot)
+  // (the records' operands depend on the slot: requested here, they arrive under the prefix sums below)
+  const uint32_t loff = (a.recs && slot != kNoList) ? a.slot_off[slot] : 0u, llen = (a.recs && slot != kNoList) ? a.slot_len[slot] : 0u;
   auto excl_scan = [&](uint32_t v) {  // exclusive prefix sum over the 64 lanes
     uint32_t inc = v;
 #pragma unroll
@@ -501,7 +504,7 @@ __device__ __forceinline__ void plan1_block(const Plan1Args& a, uint64_t (*sh)[k
     a.pairs[pidx] = (uint32_t)lane;  // q*P + j with q = 0
     a.groups[pidx] = GroupDesc{pidx, 1u};
     if (a.recs) {
-      const uint32_t loff = a.slot_off[slot], llen = a.slot_len[slot];  // (the stored length: what IvfSrc::get cuts the segments from)
+      // (llen: the stored length, what IvfSrc::get cuts the segments from)
       for (uint32_t sgi = 0; sgi < n_s; ++sgi) {
         const uint32_t r0 = sgi * a.seg_rows;
         a.recs[item0 + sgi] = Item1Rec{loff + r0, llen - r0 < a.seg_rows ? llen - r0 : a.seg_rows, pref + r0, (uint32_t)lane * a.S_max + sgi};
@@ -524,7 +527,7 @@ __global__ __launch_bounds__(kWave * kMergeWaves) void plan1_kernel(Plan1Args a)
     const u32x4 ff = {0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu, 0xFFFFFFFFu};
     for (uint32_t i = threadIdx.x; i < a.ff_vec16; i += kWave * kMergeWaves) a.ff_begin[i] = ff;
   }
-  plan1_block(a, sh);
+  plan1_block<false>(a, sh);
 }
 
 // Single query, coarse quantiser (ivfflat.rs:155-161) AND the plan in one launch.  The ordered-chain scan gives a 64-centroid
@@ -650,10 +653,11 @@ __global__ __launch_bounds__(kWave * kC1Phase) void coarse1_kernel(Coarse1Args c
   __syncthreads();
   if (!s_last) return;
   stamp(3);
-  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");  // the other blocks' slots: drop what this CU / L2 may hold of them
+  // (no acquire fence: it would invalidate this XCD's L2 and send the plan's table loads to memory -- 2 x 1.5 us of dependent
+  // round trips; the other blocks' slots are read at agent scope instead, block_merge_keys<.., COHERENT>)
   if (threadIdx.x == 0) *c.ctr = 0u;  // (the next launch on this workspace is ordered behind this one)
   stamp(4);
-  plan1_block(a, reinterpret_cast<uint64_t(*)[kWave]>(prod));
+  plan1_block<true>(a, reinterpret_cast<uint64_t(*)[kWave]>(prod));
   if (c.stamps && threadIdx.x == 0) {
     for (int i = 0; i < 5; ++i) c.stamps[32 + i] = ts[i];
     c.stamps[37] = __builtin_amdgcn_s_memrealtime();

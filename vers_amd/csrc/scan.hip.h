@@ -734,9 +734,20 @@ __device__ __forceinline__ uint64_t block_tree_merge(uint64_t acc, uint64_t (*sh
 // NW = waves of the calling block (a power of two; `sh` holds NW rows).  `mid` runs once in every wave after the first round of
 // loads has been consumed: the place for a caller's dependent load whose operand was requested before the call.
 struct MergeNoOp { __device__ __forceinline__ void operator()() const {} };
-template <int NW = kMergeWaves, class Mid = MergeNoOp>
-__device__ __forceinline__ uint64_t block_merge_keys(const uint64_t* slots, uint32_t n_keys, uint32_t k, uint64_t (*sh)[kWave],
+// COHERENT: the slots were written by OTHER BLOCKS OF THE SAME LAUNCH (at agent scope: written through); they are read at agent
+// scope too -- past whatever this XCD's L2 holds of them -- instead of behind an acquire fence, which would invalidate the L2 and
+// send every later load of the block (the plan's tables) to memory as well.
+template <int NW = kMergeWaves, class Mid = MergeNoOp, bool COHERENT = false>
+__device__ __forceinline__ uint64_t block_merge_keys(const uint64_t* slots_in, uint32_t n_keys, uint32_t k, uint64_t (*sh)[kWave],
                                                      Mid&& mid = Mid()) {
+  struct SlotView {
+    const uint64_t* p;
+    __device__ __forceinline__ uint64_t operator[](uint64_t i) const {
+      if constexpr (COHERENT) return __hip_atomic_load(p + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else return p[i];
+    }
+  };
+  const SlotView slots{slots_in};
   __shared__ uint32_t s_cand[kWave + 2];  // candidate slot ids, [kWave] their count, [kWave + 1] unused
   __shared__ uint64_t s_T;
   const int lane = threadIdx.x & 63;
