@@ -453,14 +453,14 @@ struct Plan1Args {
   ItemDesc* items; GroupDesc* groups; GroupTotals* tot; uint32_t* status; const uint32_t* list_slot;
   Item1Rec* recs = nullptr; const uint32_t *slot_off = nullptr, *slot_len = nullptr; uint32_t S_max = 0;  // recs != nullptr: the items as records (scan1_kernel)
   u32x4* ff_begin; uint32_t ff_vec16;  // the list scan's partial slots: filled with all ones (empty) by whoever plans
-  unsigned long long* dbg = nullptr;
+  unsigned long long* stamps = nullptr;  // diagnosis (VERS_SCAN_DEBUG & 16): [48..50] 100 MHz clock after the merge, the list tables, the plan's stores
 };
 template <bool COHERENT>  // the coarse slots come from other blocks of this launch (coarse1_kernel)
 __device__ __forceinline__ void plan1_block(const Plan1Args& a, uint64_t (*sh)[kWave]) {
   const uint64_t list = block_merge_keys<kMergeWaves, MergeNoOp, COHERENT>(a.cpart, a.n_segs_c * a.P, a.P, sh);
   if (threadIdx.x >= kWave) return;
   const int lane = threadIdx.x;
-  if (a.dbg && lane == 0) a.dbg[48] = __builtin_amdgcn_s_memrealtime();
+  if (a.stamps && lane == 0) a.stamps[48] = __builtin_amdgcn_s_memrealtime();
   const uint32_t P = a.P, top_k = a.top_k;
   const uint64_t key = lane < (int)P ? list : kKeyMax;
   if (lane < (int)P) a.probe[lane] = key;
@@ -479,7 +479,7 @@ __device__ __forceinline__ void plan1_block(const Plan1Args& a, uint64_t (*sh)[k
     return inc - v;
   };
   const uint32_t pref = excl_scan(len);
-  if (a.dbg && lane == 0) a.dbg[49] = __builtin_amdgcn_s_memrealtime();
+  if (a.stamps && lane == 0) a.stamps[49] = __builtin_amdgcn_s_memrealtime();
   const uint32_t total_rows = (uint32_t)__shfl(pref + len, kWave - 1, kWave);
   // reference mode (ivfflat.rs:166-195) in closed form: list j is visited while the rows before it do not yet
   // fill top_k, and contributes take_j = min(len_j, top_k - rows before it)
@@ -513,7 +513,7 @@ __device__ __forceinline__ void plan1_block(const Plan1Args& a, uint64_t (*sh)[k
       for (uint32_t sgi = 0; sgi < n_s; ++sgi) a.items[item0 + sgi] = ItemDesc{slot, 0u, sgi};
     }
   }
-  if (a.dbg && lane == 0) a.dbg[50] = __builtin_amdgcn_s_memrealtime();
+  if (a.stamps && lane == 0) a.stamps[50] = __builtin_amdgcn_s_memrealtime();
   const uint32_t n_items = (uint32_t)__shfl(item0 + n_s, kWave - 1, kWave);
   const uint32_t rows_scanned = (uint32_t)__shfl(excl_scan(scan ? len : 0u) + (scan ? len : 0u), kWave - 1, kWave);
   if (lane == 0) {
@@ -2437,7 +2437,7 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
       if (scan_debug_flags() & 16u) {
         if (int32_t rc = W->stamps.reserve(512)) return rc;
         ca.stamps = W->stamps.as<unsigned long long>();
-        pa.dbg = ca.stamps;
+        pa.stamps = ca.stamps;
       }
       pa.n_segs_c = (k_l + kWave - 1) / kWave;
       if (h->metric) {
