@@ -34,6 +34,11 @@ def test_bench_single_gpu_line():
     assert out["cpu_baseline_all_cores"]["cores"] >= 1 and out["cpu_baseline_all_cores"]["gpu_matches_cpu_bitwise"] is True
     ex = out["extra"]
     assert ex["single_query"]["list_scan_us"] > 0 and ex["flat_cfg2"]["l2sq"]["frac"] > 0 and 0 <= ex["recall_at_10_dist_u"]["value"] <= 1
+    # every leg the line promises is there (a leg that raises is logged, not dropped silently: the coarse contraction's entries
+    # went missing from round 3's line for a while because the legs before it left a single query as the handle's last call)
+    for key in ("coarse_gemm", "coarse_gemm_f32", "reference_mode", "list_scan_f32_rows", "memory"):  # (kmeans_assign: matrix-core builds only)
+        assert key in ex, (key, sorted(ex))
+    assert ex["coarse_gemm"]["us"] > 0 and ex["coarse_gemm_f32"]["us"] > 0 and ex["single_query"]["end_to_end_us"] > 0
 
 
 def test_bench_gpus_2_spawns_ranks_and_builds_row_sharded():
