@@ -416,10 +416,15 @@ def main():
             return {"kernel": kernel, "shape": [B, nlist, d], "us": round(cm["gemm_ms"] * 1e3, 1), "algorithmic_tflops": round(tf, 1),
                     "select_rescore_us": round(cm["select_ms"] * 1e3, 1)}
         try:
-            if world == 1:  # (the legs above left other calls -- single queries, exact scans -- as the handle's last: a few batches again)
-                for i in range(8):
+            # (the legs above left other calls -- single queries, exact scans -- as the handle's last: a few batches again; with the
+            # lists sharded, this rank's part of the search: no collective)
+            for i in range(8):
+                if world == 1:
                     index.search_dev(Q[(i % n_batches) * B:].data_ptr(), ld, B, top_k, nprobe, ids.data_ptr(), dst.data_ptr(), cnt.data_ptr(), st)
-                index.poll(st)
+                else:
+                    index.search_partial_dev(Q[(i % n_batches) * B:].data_ptr(), ld, B, top_k, nprobe, outs[0]["part"][0].data_ptr(),
+                                             outs[0]["part"][1].data_ptr(), st)
+            index.poll(st)
             extra["coarse_gemm"] = coarse_entry("dist_gemm_x3_kernel<false> (3 x v_mfma_f32_32x32x16_bf16 on hi/lo-split operands, 128x128 block tiles)",
                                                 index.last_coarse_ms())
             if world == 1 and not args.no_extra:
