@@ -123,7 +123,11 @@ __device__ __forceinline__ void wave_topk_fill(uint64_t& list, uint32_t k, uint6
     const uint32_t hi = (uint32_t)(cand >> 32), lo = (uint32_t)cand;
     if (__ballot(cand != kKeyMax) == 0) break;  // nothing left (a NaN key has all-ones distance bits but a real seq)
     const uint32_t m = wave_min_u32(hi);
-    const uint32_t m2 = wave_min_u32(hi == m ? lo : 0xFFFFFFFFu);
+    // (ties on the distance bits are rare: with ONE lane at the minimum its sequence number is read off that lane; the second
+    // reduction over the tied lanes is a chain of seven dependent DPP steps)
+    const uint64_t tie = __ballot(hi == m);
+    const uint32_t m2 = (tie & (tie - 1)) == 0 ? (uint32_t)__builtin_amdgcn_readlane((int)lo, __ffsll((unsigned long long)tie) - 1)
+                                                : wave_min_u32(hi == m ? lo : 0xFFFFFFFFu);
     const uint64_t x = ((uint64_t)m << 32) | m2;
     if (lane == (int)j) list = x;
     if (cand == x) cand = kKeyMax;
