@@ -167,8 +167,9 @@ int32_t flat_search_dev_locked(vers_flat* h, const float* q_dev, uint64_t ldq, u
   const uint32_t n_segs_pad = QG == 1 ? n_segs : round_up(n_segs, 4);
   const uint32_t n_items = n_segs_pad * n_qg;
 
-  for (uint32_t rank0 = 0; rank0 < top_k; rank0 += kMaxTopK) {
-    const uint32_t k_pass = std::min<uint32_t>(kMaxTopK, top_k - rank0);
+  // (a pass past the last row finds nothing: top_k = 100000 on n = 1000 is 16 passes, not 1563; 64-bit rank: no wrap near 2^32)
+  for (uint64_t rank0 = 0; rank0 < top_k && (rank0 == 0 || rank0 < h->n); rank0 += kMaxTopK) {
+    const uint32_t k_pass = (uint32_t)std::min<uint64_t>(kMaxTopK, top_k - rank0);
     const uint64_t* lower = rank0 ? h->lower : nullptr;
     auto fill = [&](auto& src) {
       src.rows = h->rows; src.n = h->n; src.ld = h->ld; src.seg_rows = seg_rows; src.n_segs = n_segs; src.n_segs_pad = n_segs_pad;
@@ -185,9 +186,9 @@ int32_t flat_search_dev_locked(vers_flat* h, const float* q_dev, uint64_t ldq, u
     }
     if (rc) return rc;
     uint64_t* lower_out = top_k > (uint32_t)kMaxTopK ? h->lower : (uint64_t*)nullptr;
-    if (n_segs <= 4096) hipLaunchKernelGGL(flat_merge_kernel<4>, dim3(b), dim3(kWave * 4), 0, st, h->partials, n_segs, k_pass, h->n, top_k, rank0, out_ids,
+    if (n_segs <= 4096) hipLaunchKernelGGL(flat_merge_kernel<4>, dim3(b), dim3(kWave * 4), 0, st, h->partials, n_segs, k_pass, h->n, top_k, (uint32_t)rank0, out_ids,
                                            out_dist, out_count, lower_out);
-    else hipLaunchKernelGGL(flat_merge_kernel<kMergeWaves>, dim3(b), dim3(kWave * kMergeWaves), 0, st, h->partials, n_segs, k_pass, h->n, top_k, rank0,
+    else hipLaunchKernelGGL(flat_merge_kernel<kMergeWaves>, dim3(b), dim3(kWave * kMergeWaves), 0, st, h->partials, n_segs, k_pass, h->n, top_k, (uint32_t)rank0,
                             out_ids, out_dist, out_count, lower_out);
     VERS_HIP_TRY(hipGetLastError());
   }

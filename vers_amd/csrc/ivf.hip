@@ -645,9 +645,12 @@ __global__ __launch_bounds__(kWave * kC1Phase) void coarse1_kernel(Coarse1Args c
     wave_bitonic_sort64(key, lane);
     // The slot is read by ANOTHER BLOCK OF THE SAME LAUNCH: it is stored at agent scope -- written through this XCD's L2 -- so
     // that no L2 write-back (the release fence at agent scope: measured 2 us here with 8 blocks per XCD, 47 us over the 368
-    // blocks of a single-query list scan) is needed; once the stores have completed the block counts itself finished.
+    // blocks of a single-query list scan) is needed; once the stores have COMPLETED the block counts itself finished.
+    // A workgroup-scope release does not wait for global stores on gfx950 (only lgkmcnt): the wait is spelled out -- vmcnt(0)
+    // retires the write-through stores (they are acknowledged by the L2 they were written through to) before the counter moves.
+    // (Round 3 shipped without it: store, s_waitcnt lgkmcnt(0), atomic add -- the last block could have merged a stale slot.)
     if (lane < (int)c.P) __hip_atomic_store(c.cpart + (uint64_t)tile * c.P + lane, key, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     if (lane == 0) s_last = __hip_atomic_fetch_add(c.ctr, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u == gridDim.x ? 1u : 0u;
   }
   __syncthreads();
@@ -1082,12 +1085,18 @@ struct vers_ivf {
   // the table share its last word): latched by the kernels of the calls queued on that stream, read and cleared ON that
   // stream by vers_ivf_poll -- so a poll never consumes another stream's panic, and never clears a word while a kernel of
   // its own stream can still set it.
-  static constexpr uint32_t kStreamWords = 64;
+  // (Round 3 kept 64 words and let the streams beyond share the last one: a poll on one of them could consume another stream's
+  // status.  Now 1024 words and an error beyond -- no word is ever shared.)
+  static constexpr uint32_t kStreamWords = 1024;
   DevBuf st_words;
   std::mutex st_mu;
   std::vector<hipStream_t> st_streams;
-  uint32_t* st_pin = nullptr;  // pinned landing words of the polls, one per stream word (no lock is held while a poll waits for its stream)
-  int32_t stream_word(hipStream_t st, uint32_t** out, uint32_t** out_pin = nullptr) {
+  uint32_t* st_pin = nullptr;  // pinned landing words of the polls, one per stream word (no handle-wide lock is held while a poll waits for its stream)
+  // Two threads polling the SAME stream share its landing word: copy / clear / wait / read is one critical section per word
+  // (interleaved, the second poll's copy could land a 0 over the first one's latched status before it is read).
+  static constexpr uint32_t kPollLocks = 64;
+  std::mutex st_poll_mu[kPollLocks];
+  int32_t stream_word(hipStream_t st, uint32_t** out, uint32_t** out_pin = nullptr, std::mutex** out_mu = nullptr) {
     std::lock_guard<std::mutex> lk(st_mu);
     if (!st_words.p) {
       if (int32_t rc = st_words.reserve(kStreamWords * sizeof(uint32_t))) return rc;
@@ -1097,11 +1106,12 @@ struct vers_ivf {
     uint32_t i = 0;
     while (i < st_streams.size() && st_streams[i] != st) ++i;
     if (i == st_streams.size()) {
-      if (i < kStreamWords - 1) st_streams.push_back(st);
-      else i = kStreamWords - 1;  // the overflow word, shared
+      if (i >= kStreamWords) return fail(VERS_ERR_INVALID, "more than 1024 distinct streams used with one handle: no status word left for this one");
+      st_streams.push_back(st);
     }
     *out = st_words.as<uint32_t>() + i;
     if (out_pin) *out_pin = st_pin + i;
+    if (out_mu) *out_mu = &st_poll_mu[i % kPollLocks];
     return VERS_OK;
   }
   // searches / reads hold `index` shared, build / upload / add / set_* exclusively
@@ -1234,12 +1244,17 @@ inline int32_t start_pending_ahead(vers_ivf* h, hipStream_t st) {
 }
 int32_t sync_status(vers_ivf* h, hipStream_t st) {  // the word of the _dev calls queued on `st` (vers_ivf::stream_word), read and cleared on `st`
   uint32_t *word = nullptr, *pin = nullptr;
-  if (int32_t rc = h->stream_word(st, &word, &pin)) return rc;
-  // (the stream's own landing word: no lock is held while this waits for the stream -- searches on other streams go on)
-  VERS_HIP_TRY(hipMemcpyAsync(pin, word, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
-  VERS_HIP_TRY(hipMemsetAsync(word, 0, sizeof(uint32_t), st));  // stream order: behind every kernel that could set it, ahead of the next call's
-  VERS_HIP_TRY(hipStreamSynchronize(st));
-  const uint32_t s = *reinterpret_cast<volatile uint32_t*>(pin);
+  std::mutex* poll_mu = nullptr;
+  if (int32_t rc = h->stream_word(st, &word, &pin, &poll_mu)) return rc;
+  uint32_t s = 0;
+  {
+    // (the stream's own landing word, under the word's own lock: searches and polls on other streams go on while this waits)
+    std::lock_guard<std::mutex> lk(*poll_mu);
+    VERS_HIP_TRY(hipMemcpyAsync(pin, word, sizeof(uint32_t), hipMemcpyDeviceToHost, st));
+    VERS_HIP_TRY(hipMemsetAsync(word, 0, sizeof(uint32_t), st));  // stream order: behind every kernel that could set it, ahead of the next call's
+    VERS_HIP_TRY(hipStreamSynchronize(st));
+    s = *reinterpret_cast<volatile uint32_t*>(pin);
+  }
   if (!s) return VERS_OK;
   if (s & kStNaN) return fail(VERS_ERR_NAN, "NaN distance (the reference panics in partial_cmp().unwrap())");
   if (s & kStInsufficient)
@@ -1368,6 +1383,7 @@ struct BuildShard {
   uint32_t rank = 0, world = 1;
   uint64_t row_begin = 0;  // global index of this process's first row
   uint64_t n_total = 0;    // rows over all processes
+  const struct Agreement* agree = nullptr;  // (multi-process builds: made by build_common before the first collective)
 };
 
 int32_t comm_rc(int32_t rc, const char* what) {
@@ -1380,19 +1396,41 @@ int32_t comm_rc(int32_t rc, const char* what) {
 // kernel until the watchdog fires.  At the points where a rank can fail on its own, right before the ranks next meet, all
 // ranks exchange how they fared (one 4-byte all_gather) and LEAVE TOGETHER when anyone failed.  (What cannot be agreed on
 // is a failure of the communicator itself: the host must abort the process group when any rank returns non-zero.)
-int32_t agree(const vers_comm_t* cm, uint32_t W, int32_t my_rc, const char* where) {
-  if (cm == nullptr || W <= 1) return my_rc;
+// The 4 + 4 W bytes it needs are allocated ONCE per build, before the first collective (Agreement::init: a failure there is
+// returned before any rank has entered a rendezvous -- the host aborts the group as for any non-zero return): agree() itself
+// never allocates, and it ALWAYS enters the all_gather -- with its error code when the local staging copy failed -- so that
+// an out-of-memory rank, the very situation it exists for, cannot strand its peers inside the collective.
+struct Agreement {
+  const vers_comm_t* cm = nullptr;
+  uint32_t W = 1;
   DevBuf mine, all;
-  if (mine.reserve(16) || all.reserve(16 * (size_t)W)) return my_rc ? my_rc : fail(VERS_ERR_HIP, "out of device memory");
-  if (hipMemcpy(mine.p, &my_rc, 4, hipMemcpyHostToDevice) != hipSuccess) return my_rc ? my_rc : fail(VERS_ERR_HIP, "hipMemcpy failed");
-  if (int32_t rc = comm_rc(cm->all_gather(cm->ctx, mine.p, all.p, 4), "all_gather")) return my_rc ? my_rc : rc;
-  std::vector<int32_t> got(W, 0);
-  if (hipMemcpy(got.data(), all.p, 4 * (size_t)W, hipMemcpyDeviceToHost) != hipSuccess) return my_rc ? my_rc : fail(VERS_ERR_HIP, "hipMemcpy failed");
-  if (my_rc) return my_rc;
-  for (uint32_t r = 0; r < W; ++r)
-    if (got[r]) return fail(VERS_ERR_COMM, std::string("rank ") + std::to_string(r) + " failed in " + where + " (status " + std::to_string(got[r]) + "): every rank leaves the build");
-  return VERS_OK;
-}
+  int32_t init(const vers_comm_t* comm, uint32_t world) {
+    cm = comm; W = world;
+    if (cm == nullptr || W <= 1) return VERS_OK;
+    if (int32_t rc = mine.reserve(16)) return rc;
+    if (int32_t rc = all.reserve(16 * (size_t)W)) return rc;
+    VERS_HIP_TRY(hipMemset(mine.p, 0, 16));
+    return VERS_OK;
+  }
+  int32_t operator()(int32_t my_rc, const char* where) const {
+    if (cm == nullptr || W <= 1) return my_rc;
+    int32_t word = my_rc;
+    bool staged = hipMemcpy(mine.p, &word, 4, hipMemcpyHostToDevice) == hipSuccess;
+    if (!staged) {  // (the device is in trouble: say so with whatever still works, then meet the peers all the same)
+      (void)hipGetLastError();
+      staged = hipMemset(mine.p, 0xFF, 4) == hipSuccess;
+      if (!staged) (void)hipGetLastError();
+      if (!my_rc) my_rc = fail(VERS_ERR_HIP, "hipMemcpy failed while staging the agreement word");
+    }
+    if (int32_t rc = comm_rc(cm->all_gather(cm->ctx, mine.p, all.p, 4), "all_gather")) return my_rc ? my_rc : rc;
+    std::vector<int32_t> got(W, 0);
+    if (hipMemcpy(got.data(), all.p, 4 * (size_t)W, hipMemcpyDeviceToHost) != hipSuccess) return my_rc ? my_rc : fail(VERS_ERR_HIP, "hipMemcpy failed");
+    if (my_rc) return my_rc;
+    for (uint32_t r = 0; r < W; ++r)
+      if (got[r]) return fail(VERS_ERR_COMM, std::string("rank ") + std::to_string(r) + " failed in " + where + " (status " + std::to_string(got[r]) + "): every rank leaves the build");
+    return VERS_OK;
+  }
+};
 
 // Storage plan from the GLOBAL list lengths: owners (LPT when sharded), offsets and capacities of the owned lists,
 // device tables, zeroed row ids.
@@ -1609,13 +1647,19 @@ int32_t install_index_sharded(vers_ivf* h, const float* X, uint32_t ldx, uint64_
   const vers_comm_t* cm = sh.comm;
   const uint32_t W = sh.world, me = sh.rank;
   DevBuf sorted, counts_all_d;
-  if (int32_t rc = sorted.reserve((n_loc ? n_loc : 1) * sizeof(uint32_t))) return rc;
-  if (int32_t rc = h->km.counts.reserve((2 * (size_t)k + 2) * sizeof(uint32_t))) return rc;
-  uint32_t* counts = h->km.counts.as<uint32_t>();
-  uint32_t* starts = counts + k;
-  if (int32_t rc = km_group(d_assign, (uint32_t)n_loc, k, sorted.as<uint32_t>(), counts, starts, h->km, st)) return rc;
-  if (int32_t rc = counts_all_d.reserve((size_t)W * (k ? k : 1) * 4)) return rc;
-  VERS_HIP_TRY(hipStreamSynchronize(st));
+  uint32_t* counts = nullptr;
+  uint32_t* starts = nullptr;
+  const int32_t rc_group = [&]() -> int32_t {  // (local work ahead of the first rendezvous of the install: agreed on before anyone enters it)
+    if (int32_t rc = sorted.reserve((n_loc ? n_loc : 1) * sizeof(uint32_t))) return rc;
+    if (int32_t rc = h->km.counts.reserve((2 * (size_t)k + 2) * sizeof(uint32_t))) return rc;
+    counts = h->km.counts.as<uint32_t>();
+    starts = counts + k;
+    if (int32_t rc = km_group(d_assign, (uint32_t)n_loc, k, sorted.as<uint32_t>(), counts, starts, h->km, st)) return rc;
+    if (int32_t rc = counts_all_d.reserve((size_t)W * (k ? k : 1) * 4)) return rc;
+    VERS_HIP_TRY(hipStreamSynchronize(st));
+    return VERS_OK;
+  }();
+  if (int32_t rc = sh.agree ? (*sh.agree)(rc_group, "grouping the local rows by list") : rc_group) return rc;
   if (k)
     if (int32_t rc = comm_rc(cm->all_gather(cm->ctx, counts, counts_all_d.p, (uint64_t)k * 4), "all_gather")) return rc;
   std::vector<uint32_t> ca((size_t)W * (k ? k : 1), 0), starts_h((size_t)k + 1, 0);
@@ -1679,7 +1723,7 @@ int32_t install_index_sharded(vers_ivf* h, const float* X, uint32_t ldx, uint64_
     if (int32_t rc = dsegs.reserve((segs.size() ? segs.size() : 1) * sizeof(RecvSeg))) return rc;
     return VERS_OK;
   }();
-  if (int32_t rc = agree(cm, W, rc_alloc, "the exchange buffers of the rows-to-owners all_to_all_v")) return rc;  // (storage + send + receive: the build's peak)
+  if (int32_t rc = sh.agree ? (*sh.agree)(rc_alloc, "the exchange buffers of the rows-to-owners all_to_all_v") : rc_alloc) return rc;  // (storage + send + receive: the build's peak)
   if (k) VERS_HIP_TRY(hipMemcpyAsync(dbase.p, send_base.data(), (size_t)k * 4, hipMemcpyHostToDevice, st));
   if (!segs.empty()) VERS_HIP_TRY(hipMemcpyAsync(dsegs.p, segs.data(), segs.size() * sizeof(RecvSeg), hipMemcpyHostToDevice, st));
   if (n_loc) {
@@ -1786,7 +1830,8 @@ int32_t run_build(vers_ivf* h, const float* X, uint32_t ldx, uint64_t n, const B
     }
     return VERS_OK;
   }();
-  if (int32_t rc = agree(multi ? cm : nullptr, W, rc_alloc, "the build's allocations")) return rc;
+  auto agree = [&](int32_t rc, const char* where) -> int32_t { return multi && sh.agree ? (*sh.agree)(rc, where) : rc; };
+  if (int32_t rc = agree(rc_alloc, "the build's allocations")) return rc;
   VERS_HIP_TRY(hipMemsetAsync(h->km.status.p, 0, 16, st));
   uint32_t* counts = h->km.counts.as<uint32_t>();
   uint32_t* starts = counts + k;
@@ -1838,33 +1883,41 @@ int32_t run_build(vers_ivf* h, const float* X, uint32_t ldx, uint64_t n, const B
     }
     uint64_t iters = 0;
     for (uint64_t it = 0; it < max_iterations; ++it) {
-      if (int32_t rc = agree(multi ? cm : nullptr, W, assign_pass(C.as<float>(), assign.as<uint32_t>(), nullptr), "assign_to_clusters")) return rc;
-      if (int32_t rc = km_group(assign.as<uint32_t>(), (uint32_t)n, k, sorted.as<uint32_t>(), counts, starts, h->km, st)) return rc;
+      {  // assign + grouping are local: what a rank's own failure there was is agreed on before the ranks next meet
+        int32_t rc_a = assign_pass(C.as<float>(), assign.as<uint32_t>(), nullptr);
+        if (!rc_a) rc_a = km_group(assign.as<uint32_t>(), (uint32_t)n, k, sorted.as<uint32_t>(), counts, starts, h->km, st);
+        if (int32_t rc = agree(rc_a, "assign_to_clusters")) return rc;
+      }
       if (!multi) {
-        km_timer_begin(st);
+        KmTimer t(st, &BuildStats::update_ms);
         if (int32_t rc = km_update(X, ldx, h->d, sorted.as<uint32_t>(), starts, counts, k, Cn.as<float>(), ld, st)) return rc;
-        km_timer_end(st, &build_stats().update_ms);
       } else if (k) {
         // update_centroids over the sharded rows (ivfflat.rs:47-71): global member counts by all-gather (integers),
         // running sums CHAINED through the ranks in ascending-range order, division on the last rank, broadcast.
-        VERS_HIP_TRY(hipStreamSynchronize(st));
+        // A LOCAL failure (a HIP error, a failed launch) is remembered and the rank still walks through every rendezvous
+        // of the pass -- its peers are waiting in them -- and all ranks leave together at the agreement behind the broadcast.
+        int32_t rc_u = VERS_OK;
+        auto local = [&](int32_t rc) { if (rc && !rc_u) rc_u = rc; };
+        auto hip_local = [&](hipError_t e, const char* what) { if (e != hipSuccess) { (void)hipGetLastError(); local(fail(VERS_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e))); } };
+        hip_local(hipStreamSynchronize(st), "hipStreamSynchronize");
         if (int32_t rc = comm_rc(cm->all_gather(cm->ctx, counts, counts_all.p, (uint64_t)k * 4), "all_gather")) return rc;
         hipLaunchKernelGGL(sum_counts_kernel, dim3((k + 255) / 256), dim3(256), 0, st, counts_all.as<uint32_t>(), W, k, counts_g.as<uint32_t>());
-        VERS_HIP_TRY(hipGetLastError());
-        if (me == 0) VERS_HIP_TRY(hipMemsetAsync(S.p, 0, cbytes, st));
+        hip_local(hipGetLastError(), "sum_counts_kernel");
+        if (me == 0) hip_local(hipMemsetAsync(S.p, 0, cbytes, st), "hipMemsetAsync");
         else {
-          VERS_HIP_TRY(hipStreamSynchronize(st));
+          hip_local(hipStreamSynchronize(st), "hipStreamSynchronize");
           if (int32_t rc = comm_rc(cm->recv(cm->ctx, S.p, (uint64_t)k * ld * 4, me - 1), "recv")) return rc;
         }
-        if (int32_t rc = km_update_sums(X, ldx, h->d, sorted.as<uint32_t>(), starts, k, S.as<float>(), ld, st)) return rc;
-        if (me + 1 < W) {
-          VERS_HIP_TRY(hipStreamSynchronize(st));
-          if (int32_t rc = comm_rc(cm->send(cm->ctx, S.p, (uint64_t)k * ld * 4, me + 1), "send")) return rc;
-        } else {
-          if (int32_t rc = km_finish_centroids(S.as<float>(), counts_g.as<uint32_t>(), k, ld, Cn.as<float>(), st)) return rc;
+        {
+          KmTimer t(st, &BuildStats::update_ms);  // (this rank's share of the chained sums; the hops are the host's collectives)
+          local(km_update_sums(X, ldx, h->d, sorted.as<uint32_t>(), starts, k, S.as<float>(), ld, st));
+          if (me + 1 == W) local(km_finish_centroids(S.as<float>(), counts_g.as<uint32_t>(), k, ld, Cn.as<float>(), st));
         }
-        VERS_HIP_TRY(hipStreamSynchronize(st));
+        hip_local(hipStreamSynchronize(st), "hipStreamSynchronize");
+        if (me + 1 < W)
+          if (int32_t rc = comm_rc(cm->send(cm->ctx, S.p, (uint64_t)k * ld * 4, me + 1), "send")) return rc;
         if (int32_t rc = comm_rc(cm->broadcast(cm->ctx, Cn.p, (uint64_t)k * ld * 4, W - 1), "broadcast")) return rc;
+        if (int32_t rc = agree(rc_u, "update_centroids")) return rc;
       }
       if (int32_t rc = km_differs(C.as<float>(), Cn.as<float>(), (uint64_t)k * ld, flag_dev, st)) return rc;
       uint32_t differs = 0;
@@ -1876,7 +1929,7 @@ int32_t run_build(vers_ivf* h, const float* X, uint32_t ldx, uint64_t n, const B
       std::swap(C.cap, Cn.cap);
     }
     if (out_iterations) out_iterations[a] = iters;
-    if (int32_t rc = agree(multi ? cm : nullptr, W, assign_pass(C.as<float>(), assign.as<uint32_t>(), mind.as<float>()), "the final assign_to_clusters")) return rc;
+    if (int32_t rc = agree(assign_pass(C.as<float>(), assign.as<uint32_t>(), mind.as<float>()), "the final assign_to_clusters")) return rc;
     // calculate_kmeans_cost (ivfflat.rs:138-149): one left-to-right f32 fold over ALL points -- chained like the sums
     const float* fold_init = nullptr;
     if (multi && me > 0) {
@@ -1884,9 +1937,12 @@ int32_t run_build(vers_ivf* h, const float* X, uint32_t ldx, uint64_t n, const B
       if (int32_t rc = comm_rc(cm->recv(cm->ctx, cost_in, 4, me - 1), "recv")) return rc;
       fold_init = cost_in;
     }
-    km_timer_begin(st);
-    if (int32_t rc = km_cost_fold(mind.as<float>(), n, fold_init, cost_dev, st)) return rc;
-    km_timer_end(st, &build_stats().cost_ms);
+    int32_t rc_fold;
+    {
+      KmTimer t(st, &BuildStats::cost_ms);
+      rc_fold = km_cost_fold(mind.as<float>(), n, fold_init, cost_dev, st);
+    }
+    if (!multi && rc_fold) return rc_fold;  // (sharded: the rank still hands a word on and is heard at the agreement below)
     uint32_t stw = 0;
     if (multi) {
       VERS_HIP_TRY(hipStreamSynchronize(st));
@@ -1900,6 +1956,7 @@ int32_t run_build(vers_ivf* h, const float* X, uint32_t ldx, uint64_t n, const B
       std::vector<uint32_t> sw(4 * (size_t)W);
       VERS_HIP_TRY(hipMemcpy(sw.data(), ctl_all.p, 16 * (size_t)W, hipMemcpyDeviceToHost));
       for (uint32_t r = 0; r < W; ++r) stw |= sw[4 * r];
+      if (int32_t rc = agree(rc_fold, "calculate_kmeans_cost")) return rc;
     }
     float cost = 0.0f;
     VERS_HIP_TRY(hipMemcpyAsync(&cost, cost_dev, 4, hipMemcpyDeviceToHost, st));
@@ -1926,13 +1983,18 @@ int32_t run_build(vers_ivf* h, const float* X, uint32_t ldx, uint64_t n, const B
   return VERS_OK;
 }
 
-int32_t build_common(vers_ivf* h, const float* X, uint32_t ldx, uint64_t n, const BuildShard& sh, uint64_t num_clusters, uint64_t num_attempts,
+int32_t build_common(vers_ivf* h, const float* X, uint32_t ldx, uint64_t n, const BuildShard& sh_in, uint64_t num_clusters, uint64_t num_attempts,
                      uint64_t max_iterations, const uint64_t* init_indices, float* out_centroids, uint64_t c_stride_bytes,
                      uint64_t* out_assignments, float* out_cost, int32_t* out_kept, uint64_t* out_iterations) {
   const uint32_t k = (uint32_t)num_clusters;
   DevBuf best_assign;
   float cost = INFINITY;
   int32_t kept = 0;
+  // the agreement's words exist before the first collective of the build (see Agreement)
+  Agreement ag;
+  if (int32_t rc = ag.init(sh_in.comm, sh_in.world)) return rc;
+  BuildShard sh = sh_in;
+  sh.agree = &ag;
   if (int32_t rc = run_build(h, X, ldx, n, sh, k, num_attempts, max_iterations, init_indices, best_assign, &cost, &kept,
                              out_iterations, nullptr))
     return rc;
@@ -2310,7 +2372,8 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
                        prescan_lds_bytes_g(h->ld, kp) <= 160u * 1024u;  // the query block of 32 padded queries must fit LDS
   if (use_pre) QG = kPreQ;
   const uint32_t k_keep = use_pre ? kp : std::min<uint32_t>(top_k, kMaxTopK);
-  const uint32_t n_pass = use_pre ? 1u : (top_k + kMaxTopK - 1) / kMaxTopK;  // 64 result ranks per pass
+  // 64 result ranks per pass; no pass beyond the rows the index holds (top_k = 100000 on 1000 rows: 16 passes, not 1563)
+  const uint32_t n_pass = use_pre ? 1u : (uint32_t)((std::min<uint64_t>(top_k, std::max<uint64_t>(1, h->n_total)) + kMaxTopK - 1) / kMaxTopK);
   const uint64_t groups_bound = QG == 1 ? n_pj : (n_pj / QG + std::min<uint64_t>(h->k, n_pj));
   uint32_t seg_rows;
   const uint64_t avg_len_all = std::max<uint64_t>(1, h->n_total / std::max<uint32_t>(1, h->k));
@@ -2624,8 +2687,9 @@ int32_t exhaustive_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, 
   if (top_k > (uint32_t)kMaxTopK)
     if (int32_t rc = W->lower.reserve((size_t)b * sizeof(uint64_t))) return rc;
   const uint32_t n_segs_pad = QG == 1 ? n_segs : round_up(n_segs, 4);
-  for (uint32_t rank0 = 0; rank0 < top_k; rank0 += kMaxTopK) {
-    const uint32_t k_pass = std::min<uint32_t>(kMaxTopK, top_k - rank0);
+  // (a pass past the last stored row finds nothing; 64-bit rank: no wrap near 2^32)
+  for (uint64_t rank0 = 0; rank0 < top_k && (rank0 == 0 || rank0 < h->cap_rows); rank0 += kMaxTopK) {
+    const uint32_t k_pass = (uint32_t)std::min<uint64_t>(kMaxTopK, top_k - rank0);
     const uint64_t* lower = rank0 ? W->lower.as<uint64_t>() : nullptr;
     auto fill = [&](auto& src) {
       src.rows = h->rows.as<float>(); src.n = h->cap_rows; src.ld = h->ld; src.seg_rows = seg_rows; src.n_segs = n_segs;
@@ -2642,7 +2706,7 @@ int32_t exhaustive_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, 
       rc = launch_seg_scan(h, src, n_segs_pad * n_qg, (int)metric, st, lower);
     }
     if (rc) return rc;
-    hipLaunchKernelGGL(seg_merge_kernel, dim3(b), dim3(kWave * kMergeWaves), 0, st, W->xpart.as<uint64_t>(), n_segs, k_pass, top_k, rank0, out_ids,
+    hipLaunchKernelGGL(seg_merge_kernel, dim3(b), dim3(kWave * kMergeWaves), 0, st, W->xpart.as<uint64_t>(), n_segs, k_pass, top_k, (uint32_t)rank0, out_ids,
                        out_dist, out_count, top_k > (uint32_t)kMaxTopK ? W->lower.as<uint64_t>() : (uint64_t*)nullptr);
     VERS_HIP_TRY(hipGetLastError());
   }

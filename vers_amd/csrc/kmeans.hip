@@ -155,37 +155,43 @@ static std::atomic<uint64_t> g_mfma_points{0}, g_mfma_fallbacks{0};
 
 // ---- build timing (vers_build_stats) -------------------------------------------------------------------------------
 static std::mutex g_bs_mu;
-static BuildStats g_bs;
-BuildStats& build_stats() { return g_bs; }
+static BuildStats g_bs;  // (guarded by g_bs_mu)
+void build_stats_add(double BuildStats::*field, double v) {
+  std::lock_guard<std::mutex> lk(g_bs_mu);
+  g_bs.*field += v;
+}
 namespace {
-struct Stretch { hipEvent_t a = nullptr, b = nullptr; double* acc = nullptr; bool open = false; };
-std::vector<Stretch> g_stretches;   // (guarded by g_bs_mu)
-std::vector<hipEvent_t> g_ev_pool;
+struct Stretch { hipEvent_t a = nullptr, b = nullptr; double BuildStats::*field = nullptr; };
+std::vector<Stretch> g_stretches;   // closed stretches whose events have not been read yet (guarded by g_bs_mu)
+std::vector<hipEvent_t> g_ev_pool;  // (guarded by g_bs_mu)
 hipEvent_t ev_get() {
-  if (!g_ev_pool.empty()) { hipEvent_t e = g_ev_pool.back(); g_ev_pool.pop_back(); return e; }
+  {
+    std::lock_guard<std::mutex> lk(g_bs_mu);
+    if (!g_ev_pool.empty()) { hipEvent_t e = g_ev_pool.back(); g_ev_pool.pop_back(); return e; }
+  }
   hipEvent_t e = nullptr;
   if (hipEventCreate(&e) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
   return e;
 }
 }  // namespace
-void km_timer_begin(hipStream_t st) {
-  std::lock_guard<std::mutex> lk(g_bs_mu);
-  Stretch s; s.a = ev_get(); s.b = ev_get(); s.open = true;
-  if (s.a) (void)hipEventRecord(s.a, st);
-  g_stretches.push_back(s);
+KmTimer::KmTimer(hipStream_t stream, double BuildStats::*f) : st(stream), field(f), a(ev_get()), b(ev_get()) {
+  if (a) (void)hipEventRecord(a, st);
 }
-void km_timer_end(hipStream_t st, double* acc) {
+KmTimer::~KmTimer() {
+  if (b) (void)hipEventRecord(b, st);
   std::lock_guard<std::mutex> lk(g_bs_mu);
-  for (size_t i = g_stretches.size(); i-- > 0;)
-    if (g_stretches[i].open) { g_stretches[i].open = false; g_stretches[i].acc = acc; if (g_stretches[i].b) (void)hipEventRecord(g_stretches[i].b, st); return; }
+  Stretch s; s.a = a; s.b = b; s.field = field;
+  g_stretches.push_back(s);
 }
 void km_timers_collect() {
   std::lock_guard<std::mutex> lk(g_bs_mu);
   std::vector<Stretch> keep;
   for (auto& s : g_stretches) {
-    if (s.open) { keep.push_back(s); continue; }
+    // (another thread's build may have closed a stretch its stream has not reached yet: it stays for that build's collect)
+    if (s.b && hipEventQuery(s.b) == hipErrorNotReady) { keep.push_back(s); continue; }
+    (void)hipGetLastError();
     float ms = 0.0f;
-    if (s.a && s.b && hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) { if (s.acc) *s.acc += ms; }
+    if (s.a && s.b && hipEventElapsedTime(&ms, s.a, s.b) == hipSuccess) { if (s.field) g_bs.*(s.field) += ms; }
     else (void)hipGetLastError();
     if (s.a) g_ev_pool.push_back(s.a);
     if (s.b) g_ev_pool.push_back(s.b);
@@ -283,14 +289,16 @@ int32_t km_assign_mfma(const float* X, uint32_t ldx, uint64_t n, const float* C,
       xb = ws.xp.as<float>();
     }
     // (the triples are addressed with pitch mb: nb_pad <= mb)
-    km_timer_begin(st);
-    if (wide)
-      VERS_HIP_TRY(launch_gemm_wide(k_pad, nb_pad, st, xb, cg_h, cg_l, ws.cnorm.as<float>(), ldq, (uint32_t)mb, metric, k, part_v1, part_c1, part_v2));
-    else
-      VERS_HIP_TRY(launch_gemm<true>((gemm_x3_mask() & 1) != 0, k_pad / kGemmBM, nb_pad / kGemmBN, st, ws.cg.as<float>(), xb, ws.cnorm.as<float>(), ldq,
-                                     (uint32_t)mb, (float*)nullptr, metric, k, part_v1, part_c1, part_v2, cg_h, cg_l));
-    km_timer_end(st, &g_bs.gemm_ms);
-    g_bs.gemm_launches += 1; g_bs.gemm_flop += 2.0 * (double)nb * (double)k * (double)d;
+    {
+      KmTimer t(st, &BuildStats::gemm_ms);
+      if (wide)
+        VERS_HIP_TRY(launch_gemm_wide(k_pad, nb_pad, st, xb, cg_h, cg_l, ws.cnorm.as<float>(), ldq, (uint32_t)mb, metric, k, part_v1, part_c1, part_v2));
+      else
+        VERS_HIP_TRY(launch_gemm<true>((gemm_x3_mask() & 1) != 0, k_pad / kGemmBM, nb_pad / kGemmBN, st, ws.cg.as<float>(), xb, ws.cnorm.as<float>(), ldq,
+                                       (uint32_t)mb, (float*)nullptr, metric, k, part_v1, part_c1, part_v2, cg_h, cg_l));
+    }
+    build_stats_add(&BuildStats::gemm_launches, 1.0);
+    build_stats_add(&BuildStats::gemm_flop, 2.0 * (double)nb * (double)k * (double)d);
     hipLaunchKernelGGL(assign_argmin_merge_kernel, dim3((nb + 255) / 256), dim3(256), 0, st, (const float*)part_v1, (const uint32_t*)part_c1,
                        (const float*)part_v2, n_tiles, (uint32_t)mb, nb, best, g2);
     hipLaunchKernelGGL(assign_rescore_kernel, dim3((nb + 63) / 64), dim3(64), 0, st, X + i0 * ldx, ldx, C, ldc, d, ldq, cmax2_dev, best, g2,
@@ -321,8 +329,9 @@ int32_t km_assign_mfma(const float* X, uint32_t ldx, uint64_t n, const float* C,
     VERS_HIP_TRY(hipStreamSynchronize(st));
   }
   km_timers_collect();
-  g_bs.assign_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count();
-  g_bs.assign_passes += 1; g_bs.redone_points += nf;
+  build_stats_add(&BuildStats::assign_ms, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - wall0).count());
+  build_stats_add(&BuildStats::assign_passes, 1.0);
+  build_stats_add(&BuildStats::redone_points, (double)nf);
   return VERS_OK;
 }
 

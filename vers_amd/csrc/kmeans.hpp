@@ -75,10 +75,20 @@ struct BuildStats {
   double cost_ms = 0;        // the one-lane cost fold
   double redone_points = 0;  // points whose certificate failed (settled by the exact kernels)
 };
-BuildStats& build_stats();
-// elapsed time of a stretch of a stream, added to *acc when the stream next synchronises (km_timers_collect)
-void km_timer_begin(hipStream_t st);
-void km_timer_end(hipStream_t st, double* acc);
+// Every update of the process-wide statistics goes through these (one mutex: builds of several handles may run side by side).
+void build_stats_add(double BuildStats::*field, double v);
+// Elapsed time of a stretch of a stream, added to BuildStats::*field when the stream next synchronises (km_timers_collect).
+// RAII: the stretch belongs to the scope that opened it -- it is closed on every path out of it (an early error return
+// used to leave it open and its two events leaked), and two builds on two threads cannot close each other's stretches.
+struct KmTimer {
+  hipStream_t st;
+  double BuildStats::*field;
+  hipEvent_t a = nullptr, b = nullptr;
+  KmTimer(hipStream_t stream, double BuildStats::*f);
+  ~KmTimer();
+  KmTimer(const KmTimer&) = delete;
+  KmTimer& operator=(const KmTimer&) = delete;
+};
 void km_timers_collect();  // call after a stream synchronisation: folds every finished stretch into its accumulator
 
 // counts[k], starts[k+1] (exclusive prefix), sorted_ids[n] grouped by cluster, ascending inside.
