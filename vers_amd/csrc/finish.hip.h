@@ -1,0 +1,423 @@
+// finish.hip.h -- the exact finish of the matrix-core list scan (prescan.hip.h, steps (2) and (3)): ivf_rescore_kernel merges a
+// query's partial candidate lists, evaluates the certificate, recomputes the survivors' distances in the reference's own
+// arithmetic (ordered f32 chain, base.rs:119-126) and emits the top-k (ivfflat.rs:176-195); fallback_kernel re-scans the
+// probed lists of the queries whose certificate failed, exactly.  Included by ivf_search.hip only (the kernels have
+// external linkage).
+#pragma once
+#include "prescan.hip.h"
+
+namespace vers {
+
+// ---- exact finish ---------------------------------------------------------------------------------
+struct RescoreArgs {
+  const uint64_t* partials;  // [b*P*S_max][kp] approximate keys
+  uint32_t P, S_max, kp, top_k, d_pad;
+  const uint32_t* pj_list;
+  const uint32_t* pj_pref;
+  const uint32_t* pj_nq;     // [b*P] partial slots the scan WROTE for (query, probe): the quads of the list, 0 if not scanned here
+  const uint32_t* list_off;
+  const uint32_t* row_ids;
+  const float* rows;
+  const float* rows_rm;  // nullable: the same rows row-major [cap_rows][ld] (whole-sector gathers for the exact finish)
+  uint32_t ld;
+  const float* qp;  // padded queries [b][ldq]
+  uint32_t ldq;
+  const uint32_t* xmax2_bits;
+  const uint32_t* qflags;  // [b*P], slot q*P
+  int metric;              // 0 squared L2, 1 cosine distance 1 - dot (the exact chains and the bound follow it)
+  int force_fail;          // testing: nothing certifies
+  int shadow;              // the vals came from the fp16 shadow: the bound grows by its measured residual (xmax2_bits[2])
+  uint32_t debug;          // diagnosis (VERS_SCAN_DEBUG): 512 skip the row gather + chains, 1024 merge only 1/8 of the slots
+  uint32_t* fail_list;     // [b] out: queries to redo exactly, [b] = their count
+  uint32_t* stats;         // [0] += failed queries
+  uint32_t* status;
+  uint64_t* out_ids;
+  float* out_dist;
+  uint32_t* out_count;
+  uint64_t* out_keys;
+};
+
+// Storage row of the key held by each lane (nprobe mode): seq = position in the query's concatenated probe order,
+// pj_pref = first position of probe j.  Whole-wave: lane t holds probe t's (pref, list); per key one ballot finds the
+// last scanned probe that starts at or before seq (a per-lane loop over the P probes is 2 P dependent-latency loads).
+__device__ __forceinline__ uint32_t wave_seq_rows(uint64_t key, bool valid, int lane, const uint32_t* pj_list, const uint32_t* pj_pref,
+                                                  uint32_t P, const uint32_t* list_off) {
+  uint32_t my_list = 0xFFFFFFFFu, my_off = 0;
+  for (uint32_t c0 = 0; c0 < P; c0 += kWave) {  // 64 probes per chunk (pj_pref ascends with the probe rank: a later match overrides)
+    const uint32_t j0 = c0 + (uint32_t)lane;
+    const uint32_t pref = j0 < P ? pj_pref[j0] : 0u;
+    const uint32_t lst = j0 < P ? pj_list[j0] : 0xFFFFFFFFu;
+    uint64_t todo = __ballot(valid);
+    while (todo) {
+      const int c = __ffsll((unsigned long long)todo) - 1;
+      todo &= todo - 1;
+      const uint32_t seq = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)key, c);
+      const uint64_t m = __ballot(lst != 0xFFFFFFFFu && pref <= seq);
+      if (m == 0) continue;
+      const int j = 63 - __builtin_clzll((unsigned long long)m);
+      const uint32_t lj = (uint32_t)__builtin_amdgcn_readlane((int)lst, j), pj = (uint32_t)__builtin_amdgcn_readlane((int)pref, j);
+      if (lane == c) { my_list = lj; my_off = seq - pj; }
+    }
+  }
+  return valid && my_list != 0xFFFFFFFFu ? list_off[my_list] + my_off : 0xFFFFFFFFu;
+}
+
+// The same for P <= 64 with the per-probe operands (and the lists' storage rows, which depend on them) loaded AHEAD of whatever
+// produces the keys: two dependent round trips off the tail of a merge.
+struct SeqRowsPre { uint32_t pref, lst, loff; };
+__device__ __forceinline__ SeqRowsPre wave_seq_rows_load(int lane, const uint32_t* pj_list, const uint32_t* pj_pref, uint32_t P) {
+  SeqRowsPre r;
+  r.pref = lane < (int)P ? pj_pref[lane] : 0u;
+  r.lst = lane < (int)P ? pj_list[lane] : 0xFFFFFFFFu;
+  r.loff = 0u;
+  return r;
+}
+__device__ __forceinline__ void wave_seq_rows_load2(SeqRowsPre& r, const uint32_t* list_off) {  // (the dependent half: a round trip later)
+  r.loff = r.lst != 0xFFFFFFFFu ? list_off[r.lst] : 0u;
+}
+__device__ __forceinline__ uint32_t wave_seq_rows_map(uint64_t key, bool valid, int lane, const SeqRowsPre& r) {
+  uint32_t row = 0xFFFFFFFFu;
+  uint64_t todo = __ballot(valid);
+  while (todo) {
+    const int c = __ffsll((unsigned long long)todo) - 1;
+    todo &= todo - 1;
+    const uint32_t seq = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)key, c);
+    const uint64_t m = __ballot(r.lst != 0xFFFFFFFFu && r.pref <= seq);
+    if (m == 0) continue;
+    const int j = 63 - __builtin_clzll((unsigned long long)m);
+    const uint32_t lo = (uint32_t)__builtin_amdgcn_readlane((int)r.loff, j), pj = (uint32_t)__builtin_amdgcn_readlane((int)r.pref, j);
+    if (lane == c) row = lo + (seq - pj);
+  }
+  return row;
+}
+
+__device__ __forceinline__ void emit_topk(uint64_t fin, uint32_t q, uint32_t top_k, int lane, const uint32_t* pj_list, const uint32_t* pj_pref,
+                                          uint32_t P, const uint32_t* list_off, const uint32_t* row_ids, uint64_t* out_ids, float* out_dist,
+                                          uint32_t* out_count, uint64_t* out_keys) {
+  const bool have = lane < (int)top_k && fin != kKeyMax;
+  const uint64_t o = (uint64_t)q * top_k + lane;
+  if (lane < (int)top_k && out_keys) out_keys[o] = have ? fin : kKeyMax;
+  const uint32_t row = wave_seq_rows(fin, have, lane, pj_list, pj_pref, P, list_off);
+  if (have) {
+    out_ids[o] = row_ids[row];
+    out_dist[o] = __uint_as_float(order_bits_to_f32_bits((uint32_t)(fin >> 32)));
+  }
+  const uint64_t hm = __ballot(have);
+  if (lane == 0) out_count[q] = (uint32_t)__popcll(hm);
+}
+
+// Block of 4 waves per query.  All waves merge the partial lists; wave 0 evaluates the certificate; the surviving
+// candidates' rows are then staged through LDS kRescoreChunk at a time, cooperatively (independent float4 gathers
+// over 256 threads -- a lane walking its own row straight from HBM is a chain of ld/4 dependent-latency loads) and
+// wave 0 runs the ordered chains out of LDS.  The block is a chain of ~8 dependent memory round trips, so what
+// matters is blocks in flight: 8 staged rows (27 KB of LDS at d = 768) allow 5 blocks per CU, the whole batch in
+// one round (staging all k+10 rows at once: 2 blocks per CU, 110 us instead of 45 at cfg3).
+// stage_rows == 0 (rows too long even for that): the chains read HBM directly.
+constexpr int kRescoreWaves = 4;
+constexpr uint32_t kRescoreChunk = 8;
+inline size_t rescore_lds_bytes(uint32_t ld, bool stage_rows) {
+  return ((size_t)ld + (stage_rows ? (size_t)kRescoreChunk * (ld + 4) : 0)) * sizeof(float);
+}
+__global__ __launch_bounds__(kWave * kRescoreWaves) void ivf_rescore_kernel(RescoreArgs a, int stage_rows) {
+  __shared__ uint64_t sh[kRescoreWaves][kWave];
+  __shared__ uint32_t srow[kWave];
+  __shared__ float sred[kRescoreWaves];
+  __shared__ uint32_t s_failed, s_nsurv;
+  extern __shared__ __attribute__((aligned(16))) float dyn[];  // the query, padded; then staged rows of pitch ld + 4
+  float* qs = dyn;
+  float* xs = dyn + a.ld;
+  const uint32_t q = blockIdx.x;
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const float* qrow = a.qp + (uint64_t)q * a.ldq;
+  const uint32_t* pl = a.pj_list + (uint64_t)q * a.P;
+  const uint32_t* pp = a.pj_pref + (uint64_t)q * a.P;
+  // everything that does not depend on the merge is requested up front
+  const uint32_t flag0 = a.qflags[(uint64_t)q * a.P];
+  const uint32_t xmax_bits = *a.xmax2_bits;
+  float qpart = 0.0f;
+  for (uint32_t i = threadIdx.x; i < a.ld; i += blockDim.x) {
+    const float v = qrow[i];
+    qs[i] = v;
+    qpart = __fadd_rn(qpart, __fmul_rn(v, v));  // |q|^2 in any order: the bound inflates it
+  }
+  // merge the partial lists: every wave folds a strided share of the slots the scan wrote, wave 0 folds the four
+  // results.  Only WRITTEN slots are read -- slot (probe j, quad s) exists iff s < pj_nq[j] -- so the slot array needs
+  // no 0xFF fill per batch (10 MB at cfg3, and at 8 ranks 7/8 of the slots belong to other GPUs' lists).
+  const uint64_t* keys = a.partials + (uint64_t)q * a.P * a.S_max * a.kp;
+  const uint32_t* nqp = a.pj_nq + (uint64_t)q * a.P;
+  uint64_t list = kKeyMax;
+  constexpr int U = 4;
+  // lane j = probe j (P <= 64 on this path): the slots it wrote, and where they start in the compact order of LIVE slots.  At
+  // 8 ranks 4 of a query's 32 probes are local: 8 live slots of 64 -- one round of independent loads instead of four rounds of
+  // a count load followed by a key load each (20 of the kernel's 84 us there).
+  const uint32_t my_nq = lane < (int)a.P ? (nqp[lane] < a.S_max ? nqp[lane] : a.S_max) : 0u;
+  uint32_t incl = my_nq;
+#pragma unroll
+  for (int off = 1; off < kWave; off <<= 1) {
+    const uint32_t t = __shfl_up(incl, off, kWave);
+    if (lane >= off) incl += t;
+  }
+  const uint32_t excl = incl - my_nq;
+  uint32_t n_live = (uint32_t)__shfl(incl, kWave - 1, kWave);
+  if (a.debug & 1024u) n_live = n_live / 8;
+  for (uint32_t s0 = (uint32_t)wid * U; s0 < n_live; s0 += kRescoreWaves * U) {
+    uint64_t cand[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint32_t c = s0 + u;  // compact index -> (probe j, quad c - first slot of j): the last lane whose slots start at or before c
+      const uint64_t m = __ballot(my_nq != 0 && excl <= c);
+      const int j = m ? 63 - __builtin_clzll((unsigned long long)m) : 0;
+      const uint32_t e_j = (uint32_t)__builtin_amdgcn_readlane((int)excl, j);
+      const uint32_t sl = (uint32_t)j * a.S_max + (c - e_j);
+      cand[u] = (c < n_live && lane < (int)a.kp) ? keys[(uint64_t)sl * a.kp + lane] : kKeyMax;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) wave_topk_update(list, a.kp, cand[u], kKeyMax);
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) qpart += __shfl_xor(qpart, off, kWave);
+  sh[wid][lane] = list;
+  if (lane == 0) sred[wid] = qpart;
+  __syncthreads();
+  uint64_t mine = kKeyMax;  // wave 0: the survivors, compacted to lanes 0..n_surv-1
+  if (wid == 0) {
+    for (int w = 1; w < kRescoreWaves; ++w) wave_topk_update(list, a.kp, sh[w][lane], kKeyMax);
+    const bool valid = lane < (int)a.kp && list != kKeyMax;
+    const uint32_t cnt = (uint32_t)__popcll(__ballot(valid));
+    float qn = 0.0f;
+    for (int w = 0; w < kRescoreWaves; ++w) qn += sred[w];
+    const PreBound pb = pre_bound((double)qn, (double)__uint_as_float(xmax_bits), a.shadow ? (double)__uint_as_float(a.xmax2_bits[2]) : 0.0, a.d_pad, a.metric,
+                                  a.shadow);
+    const float val = __uint_as_float(order_bits_to_f32_bits((uint32_t)(list >> 32)));
+    const double e_mine = pb.of((double)val);  // this candidate's own bound (NaN / inf vals: NaN / inf, handled by the negated compares)
+    bool certified = true;
+    double lim = __builtin_inf();
+    if (cnt > 0) {
+      // With tau the k-th smallest val and e_k the largest bound among the k smallest vals, the k-th smallest D_ref over ALL
+      // rows is at most tau + |q|^2 + e_k; a row r can be among the true top-k only if val_r - e_r <= tau + e_k.  Rows in the
+      // list: e_r = their own bound (survivors below).  Rows cut off by a full list have val >= the list's last val and the
+      // global bound: the last val must clear tau + e_k + E_global.
+      const uint32_t kk = a.top_k < cnt ? a.top_k : cnt;
+      const double tau = (double)__uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(val), (int)kk - 1));
+      double ek = lane < (int)kk ? e_mine : 0.0;
+      if (!(ek == ek)) ek = __builtin_inf();
+#pragma unroll
+      for (int off = 32; off > 0; off >>= 1) {
+        const double o = __shfl_xor(ek, off, kWave);
+        ek = o > ek ? o : ek;
+      }
+      lim = tau + ek;
+      if (cnt >= a.kp) {    // a full list may have cut rows off: the kp-th val must clear the limit
+        const double top = (double)__uint_as_float(__builtin_amdgcn_readlane(__float_as_uint(val), (int)a.kp - 1));
+        certified = top > lim + pb.global;  // false for NaN / inf
+      }
+    }
+    if (flag0 != 0 || a.force_fail) certified = false;
+    // only candidates inside the limit can reach the top-k: the others are not worth their 3 KiB gather.
+    // The list is sorted by val, so the survivors are a prefix: lanes 0..n_surv-1.
+    const bool survivor = certified && valid && !((double)val - e_mine > lim);
+    const uint32_t n_surv = (uint32_t)__popcll(__ballot(survivor));
+    mine = survivor ? list : kKeyMax;
+    srow[lane] = wave_seq_rows(list, survivor, lane, pl, pp, a.P, a.list_off);
+    if (lane == 0) {
+      s_failed = certified ? 0u : 1u;
+      s_nsurv = n_surv;
+      if (!certified) { a.fail_list[atomicAdd(a.fail_list + gridDim.x, 1u)] = q; atomicAdd(a.stats, 1u); }  // the fallback kernels redo it
+    }
+  }
+  __syncthreads();
+  if (s_failed) return;
+  const uint32_t n_surv = s_nsurv;
+  if (a.debug & 512u) {
+    if (wid == 0) emit_topk(list, q, a.top_k, lane, pl, pp, a.P, a.list_off, a.row_ids, a.out_ids, a.out_dist, a.out_count, a.out_keys);
+    return;
+  }
+  // exact distances of the survivors: lane per candidate, the reference's ordered chain
+  uint64_t cand = kKeyMax;
+  bool nan_seen = false;
+  const f32x4* q4p = reinterpret_cast<const f32x4*>(qs);
+  if (stage_rows) {
+    const uint32_t n4 = a.ld / 4, pitch = a.ld + 4;
+    for (uint32_t c0 = 0; c0 < n_surv; c0 += kRescoreChunk) {  // block-uniform
+      const uint32_t nc = n_surv - c0 < kRescoreChunk ? n_surv - c0 : kRescoreChunk;
+      for (uint32_t idx = threadIdx.x; idx < nc * n4; idx += blockDim.x) {
+        const uint32_t c = idx / n4, j = idx - c * n4;
+        const uint32_t row = srow[c0 + c];
+        *reinterpret_cast<f32x4*>(xs + (size_t)c * pitch + 4 * j) =
+            a.rows_rm ? reinterpret_cast<const f32x4*>(a.rows_rm + (uint64_t)row * a.ld)[j]  // consecutive threads: consecutive 16 bytes of a row
+                      : (reinterpret_cast<const f32x4*>(a.rows + (uint64_t)(row >> 6) * 64ull * a.ld) + (row & 63))[(uint64_t)j * 64];
+      }
+      __syncthreads();
+      if (wid == 0 && (uint32_t)lane >= c0 && (uint32_t)lane < c0 + nc) {
+        const f32x4* xp = reinterpret_cast<const f32x4*>(xs + (size_t)((uint32_t)lane - c0) * pitch);
+        float acc = 0.0f;
+        for (uint32_t j = 0; j < n4; ++j) {
+          const f32x4 x4 = xp[j];
+          const f32x4 q4 = q4p[j];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            if (a.metric == 0) {
+              const float t = __fsub_rn(x4[c], q4[c]);
+              acc = __fadd_rn(acc, __fmul_rn(t, t));
+            } else {
+              acc = __fadd_rn(acc, __fmul_rn(x4[c], q4[c]));
+            }
+          }
+        }
+        if (a.metric) acc = __fsub_rn(1.0f, acc);
+        nan_seen |= acc != acc;
+        cand = make_key(acc, (uint32_t)mine);
+      }
+      __syncthreads();  // the chunk's readers are done before the next one is staged
+    }
+  } else if (wid == 0 && (uint32_t)lane < n_surv) {
+    const uint32_t row = srow[lane];
+    const f32x4* xp = a.rows_rm ? reinterpret_cast<const f32x4*>(a.rows_rm + (uint64_t)row * a.ld)
+                                : reinterpret_cast<const f32x4*>(a.rows + (uint64_t)(row >> 6) * 64ull * a.ld) + (row & 63);
+    const uint64_t xstep = a.rows_rm ? 1 : 64;
+    float acc = 0.0f;
+#pragma unroll 8
+    for (uint32_t j = 0; j < a.ld / 4; ++j) {
+      const f32x4 x4 = xp[(uint64_t)j * xstep];
+      const f32x4 q4 = q4p[j];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        if (a.metric == 0) {
+          const float t = __fsub_rn(x4[c], q4[c]);
+          acc = __fadd_rn(acc, __fmul_rn(t, t));
+        } else {
+          acc = __fadd_rn(acc, __fmul_rn(x4[c], q4[c]));
+        }
+      }
+    }
+    if (a.metric) acc = __fsub_rn(1.0f, acc);
+    nan_seen |= acc != acc;
+    cand = make_key(acc, (uint32_t)mine);
+  }
+  if (wid != 0) return;
+  if (__ballot(nan_seen) != 0 && lane == 0) atomicOr(a.status, 1u);
+  uint64_t fin = kKeyMax;
+  wave_topk_update(fin, a.top_k, cand, kKeyMax);
+  emit_topk(fin, q, a.top_k, lane, pl, pp, a.P, a.list_off, a.row_ids, a.out_ids, a.out_dist, a.out_count, a.out_keys);
+}
+
+// Exact re-scan of the probed lists of the queries that failed the certificate.  ivf_rescore_kernel queued them.
+struct FbSrc {
+  static constexpr bool kSeqIds = false;
+  static constexpr bool kStreamOnce = true;
+  uint64_t* out_ptr;
+  uint32_t seq0;
+  __device__ __forceinline__ uint32_t seq_base(uint32_t, int) const { return seq0; }
+  __device__ __forceinline__ const uint32_t* seq_ids(uint32_t) const { return nullptr; }
+  __device__ __forceinline__ uint64_t* out(uint32_t, int) const { return out_ptr; }
+  __device__ __forceinline__ uint32_t bound_slot(uint32_t, int) const { return 0; }
+};
+
+// ONE launch of kFallbackBlocks persistent blocks; exits at once when nothing is queued (the normal case: ~3 us).
+// The blocks split into n_groups groups of G (G = the largest power of two <= blocks / queued queries, at most 64): a group
+// takes every n_groups-th queued query and spreads its P probed lists -- in C = ceil(G / P) chunks of tiles each when the
+// group is larger than P -- over its members; a member's 16 waves share a chunk's tiles (the ring-pipelined single-query
+// item of scan.hip.h) and leave 16 partial lists per chunk in the group's slot.  The member that arrives last (a counter per
+// group) folds the slot and emits; the others wait for that before the slot is reused for the group's next query.  With at
+// least as many queued queries as blocks G = 1: a block per query, no waiting.  (Round 1 and the first cut of this kernel
+// gave a queued query to ONE block: 32 lists = 240 MB at cfg3 through a single CU, ~6 ms -- a cliff behind every failed
+// certificate.  Spread over 64 CUs it is ~60 us.)  ctr: [2 * groups + 1] words, zero between launches (the last block out
+// clears them).
+constexpr uint32_t kFallbackBlocks = 128;
+inline size_t fallback_part_keys(uint32_t blocks, uint32_t P, uint32_t top_k) {  // >= n_groups * P * C chunks for every G
+  return (size_t)blocks * (P > 2 ? P : 2) * kMergeWaves * top_k;
+}
+__global__ __launch_bounds__(kWave * kMergeWaves) void fallback_kernel(RescoreArgs a, const uint32_t* list_len, const uint32_t* fail_list,
+                                                                       const uint32_t* fail_count, uint64_t* fb_part, uint32_t* ctr,
+                                                                       uint32_t* watch) {
+  __shared__ uint64_t sh[kMergeWaves][kWave];
+  __shared__ uint32_t s_last;
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t n_fail = *fail_count;
+  if (n_fail == 0) return;
+  // `watch` (nullable): pinned host word the host polls to retire an fp16 shadow that fails too often; a.stats[0] is final
+  // for this batch (ivf_rescore_kernel, which counts, is done) and only moves when queries were queued
+  if (watch != nullptr && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(watch, a.stats[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  uint32_t G = 1;
+  while (G < 64u && 2u * G * n_fail <= gridDim.x) G *= 2u;
+  const uint32_t n_groups = gridDim.x / G;
+  const uint32_t gidx = blockIdx.x / G, g = blockIdx.x % G;
+  const uint32_t C = (G + a.P - 1) / a.P, chunks = a.P * C;
+  ScanParams p;
+  p.ld = a.ld; p.n_chunks = a.ld / kChunk; p.k = a.top_k; p.status = a.status; p.bounds = nullptr; p.lower = nullptr; p.debug = 0;
+  p.next_quad = nullptr; p.stamps = nullptr;
+  bool nan_seen = false;
+  uint64_t* slot = fb_part + (uint64_t)gidx * chunks * kMergeWaves * a.top_k;  // the group's chunks x 16 partial lists
+  uint32_t* arrived = ctr + 2 * gidx;
+  uint32_t round = 0;
+  if (gidx < n_groups) {
+    for (uint32_t i = gidx; i < n_fail; i += n_groups, ++round) {
+      const uint32_t q = fail_list[i];
+      for (uint32_t u = g; u < chunks; u += G) {
+        const uint32_t j = u / C, c = u % C;
+        uint64_t* out = slot + ((uint64_t)u * kMergeWaves + wid) * a.top_k;
+        const uint32_t Lj = a.pj_list[(uint64_t)q * a.P + j];
+        uint32_t len = 0, t0 = 0, t1 = 0;
+        if (Lj != 0xFFFFFFFFu) {
+          len = list_len[Lj];
+          const uint32_t n_tiles = (len + kWave - 1) / kWave, per_c = (n_tiles + C - 1) / C;
+          const uint32_t c0 = c * per_c < n_tiles ? c * per_c : n_tiles, c1 = c0 + per_c < n_tiles ? c0 + per_c : n_tiles;
+          const uint32_t per = (c1 - c0 + kMergeWaves - 1) / kMergeWaves;
+          t0 = c0 + (uint32_t)wid * per < c1 ? c0 + (uint32_t)wid * per : c1;
+          t1 = t0 + per < c1 ? t0 + per : c1;
+        }
+        if (t1 <= t0) {  // nothing for this wave: an empty slot
+          if (lane < (int)a.top_k) out[lane] = kKeyMax;
+          continue;
+        }
+        ItemView<1> v;
+        v.rows = a.rows + ((uint64_t)a.list_off[Lj] + (uint64_t)t0 * kWave) * a.ld;
+        v.nrows = (t1 * kWave < len ? t1 * kWave : len) - t0 * kWave;
+        v.nq = 1;
+        v.qb = a.qp + (uint64_t)q * a.ldq;
+        FbSrc src;
+        src.out_ptr = out;
+        src.seq0 = a.pj_pref[(uint64_t)q * a.P + j] + t0 * kWave;
+        if (a.metric == 0) scan_item<1, 1, 0>(src, p, 0u, v, lane, nan_seen);
+        else scan_item<1, 1, 1>(src, p, 0u, v, lane, nan_seen);
+      }
+      __threadfence();   // this member's partial lists, device-wide, before it counts as arrived
+      __syncthreads();
+      bool fold = true;
+      if (G > 1) {
+        if (threadIdx.x == 0) {
+          const uint32_t prev = __hip_atomic_fetch_add(arrived, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+          s_last = prev + 1u == (round + 1u) * G ? 1u : 0u;
+        }
+        __syncthreads();
+        fold = s_last != 0u;
+        if (fold) __threadfence();  // the other members' lists
+      }
+      if (fold) {
+        const uint32_t n_keys = chunks * kMergeWaves * a.top_k;
+        const uint64_t list = block_merge_keys(slot, n_keys, a.top_k, sh);
+        if (threadIdx.x < kWave)
+          emit_topk(list, q, a.top_k, lane, a.pj_list + (uint64_t)q * a.P, a.pj_pref + (uint64_t)q * a.P, a.P, a.list_off, a.row_ids, a.out_ids,
+                    a.out_dist, a.out_count, a.out_keys);
+        __syncthreads();  // (G == 1: the block's slot is reused by its next query)
+      }
+      // No block ever WAITS for another one here.  A group's slot would be reused only by a second query of the same group,
+      // and a group of G > 1 blocks never has one: G > 1 implies G * n_fail <= gridDim.x (the loop above), i.e.
+      // n_groups = gridDim.x / G >= n_fail, so i + n_groups >= n_fail for every i.  (Round 2 carried a spin on a `merged`
+      // word for that case -- dead code, but a cross-block spin nonetheless; with G == 1 the block is alone on its slot.)
+    }
+  }
+  if (__ballot(nan_seen) != 0 && lane == 0) atomicOr(a.status, 1u);
+  // the last block out leaves the counters zero for the next launch
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    uint32_t* out_ctr = ctr + 2 * gridDim.x;
+    if (__hip_atomic_fetch_add(out_ctr, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) + 1u == gridDim.x) {
+      for (uint32_t w = 0; w <= 2 * gridDim.x; ++w) __hip_atomic_store(ctr + w, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+}  // namespace vers

@@ -1,0 +1,176 @@
+// ivf_hooks.hip -- measurement and TEST hooks of the IVFFlat handle: timings of the last launches, planner / certificate
+// statistics, the dump of the matrix-core scan's partial lists (tests/test_certificate_gpu.py), slack poisoning.
+#include "ivf_handle.hpp"
+#include "prescan.hip.h"
+
+extern "C" {
+
+int32_t vers_ivf_last_scan(vers_ivf_t* h, float* out_ms, uint64_t* out_union_rows, uint64_t* out_streamed_rows,
+                           uint32_t* out_items) {
+  if (!h) return fail(VERS_ERR_INVALID, "null handle");
+  UseLastWs use_ws(h);
+  if (!use_ws.ok) return fail(VERS_ERR_INVALID, "no search has run on this handle");
+  if (!h) return fail(VERS_ERR_INVALID, "null handle");
+  if (W->ev_count == 0 || !W->tot_valid) return fail(VERS_ERR_INVALID, "no list scan has been launched on this handle");
+  DeviceGuard g(h->device);
+  const uint32_t slot = (uint32_t)((W->ev_count - 1) % SearchWs::kEvRing);
+  VERS_HIP_TRY(hipEventSynchronize(W->ev1[slot]));
+  if (out_ms) VERS_HIP_TRY(hipEventElapsedTime(out_ms, W->ev0[slot], W->ev1[slot]));
+  const GroupTotals* tot = W->tot_dev;
+  if (!tot) return fail(VERS_ERR_INVALID, "vers_ivf_last_scan: no list scan has run on this handle");
+  GroupTotals t;
+  VERS_HIP_TRY(hipMemcpy(&t, tot, sizeof(t), hipMemcpyDeviceToHost));
+  if (out_union_rows) *out_union_rows = t.union_rows;
+  if (out_streamed_rows) *out_streamed_rows = t.streamed_rows;
+  if (out_items) *out_items = t.n_items;
+  if ((scan_debug_flags() & 16u) && W->stamps.p) {  // diagnosis only: per-wave phase cycles of the last launch
+    unsigned long long sv[64] = {};
+    VERS_HIP_TRY(hipMemcpy(sv, W->stamps.p, std::min<size_t>(512, W->stamps.cap), hipMemcpyDeviceToHost));
+    if (W->stamps.cap >= 512 && sv[37])
+      fprintf(stderr, "[vers stamps] single-query coarse + plan kernel, its last block %llu (us): loads + products %.2f  chains %.2f  sort + publish %.2f  "
+              "acquire %.2f  merge + plan %.2f\n", sv[38], (sv[33] - sv[32]) / 100.0, (sv[34] - sv[33]) / 100.0, (sv[35] - sv[34]) / 100.0,
+              (sv[36] - sv[35]) / 100.0, (sv[37] - sv[36]) / 100.0);
+    if (sv[50]) fprintf(stderr, "[vers stamps]   merge %.2f  list tables + scan %.2f  plan stores %.2f  rest %.2f\n", (sv[48] - sv[36]) / 100.0, (sv[49] - sv[48]) / 100.0, (sv[50] - sv[49]) / 100.0, (sv[37] - sv[50]) / 100.0);
+    if (sv[27])
+      fprintf(stderr, "[vers stamps] coarse select, per query avg cycles: select %.0f  exact re-score %.0f  sort+certify+emit %.0f\n",
+              (double)sv[24] / sv[27], (double)sv[25] / sv[27], (double)sv[26] / sv[27]);
+    if (sv[19])
+      fprintf(stderr, "[vers stamps] group / scatter kernel, block 0 (us): fill + prefix sums %.1f  scatter %.1f  items %.1f\n",
+              (sv[17] - sv[16]) / 100.0, (sv[18] - sv[17]) / 100.0, (sv[19] - sv[18]) / 100.0);
+    if (sv[10])
+      fprintf(stderr, "[vers stamps] matrix-core scan, per item avg cycles: prologue %.0f  step loop %.0f (of which issuing loads %.0f)  epilogue %.0f\n",
+              (double)sv[9] / sv[4], (double)sv[10] / sv[4], (double)sv[8] / sv[4], (double)sv[11] / sv[4]);
+    fprintf(stderr, "[vers stamps] items %llu: per item avg cycles: wait-for-loads %.0f  math %.0f  fold %.0f | per wave-quad-slot (%llu): stage %.0f  barrier-wait %.0f\n",
+            sv[4], sv[4] ? (double)sv[0] / sv[4] : 0.0, sv[4] ? (double)sv[1] / sv[4] : 0.0, sv[4] ? (double)sv[2] / sv[4] : 0.0,
+            sv[6], sv[6] ? (double)sv[3] / sv[6] : 0.0, sv[6] ? (double)sv[5] / sv[6] : 0.0);
+    fprintf(stderr, "[vers stamps] list merges under a lock %llu, candidates offered to them %llu\n", sv[12], sv[13]);
+    fprintf(stderr, "[vers stamps] shader clock during the kernel: %.0f MHz\n", (double)sv[7] / (double)(1 << 20) * 100.0);
+  }
+  return VERS_OK;
+}
+
+int32_t vers_ivf_last_coarse_ms(vers_ivf_t* h, float* out_gemm_ms, float* out_select_ms) {
+  if (!h) return fail(VERS_ERR_INVALID, "null handle");
+  UseLastWs use_ws(h);
+  if (!use_ws.ok) return fail(VERS_ERR_INVALID, "no search has run on this handle");
+  if (!h) return fail(VERS_ERR_INVALID, "null handle");
+  if (!W->evc_valid) return fail(VERS_ERR_INVALID, "no batched coarse quantiser has run on the matrix cores on this handle");
+  DeviceGuard g(h->device);
+  VERS_HIP_TRY(hipEventSynchronize(W->evc[2]));
+  if (out_gemm_ms) VERS_HIP_TRY(hipEventElapsedTime(out_gemm_ms, W->evc[0], W->evc[1]));
+  if (out_select_ms) VERS_HIP_TRY(hipEventElapsedTime(out_select_ms, W->evc[1], W->evc[2]));
+  return VERS_OK;
+}
+
+int32_t vers_ivf_coarse_stats(vers_ivf_t* h, uint64_t* out_mfma_batches, uint64_t* out_fallback_queries) {
+  if (!h) return fail(VERS_ERR_INVALID, "null handle");
+  DeviceGuard g(h->device);
+  uint32_t fb = 0;
+  if (h->coarse_stat.p) VERS_HIP_TRY(hipMemcpy(&fb, h->coarse_stat.p, 4, hipMemcpyDeviceToHost));
+  if (out_mfma_batches) *out_mfma_batches = h->mfma_batches;
+  if (out_fallback_queries) *out_fallback_queries = fb;
+  return VERS_OK;
+}
+
+int32_t vers_ivf_prescan_stats(vers_ivf_t* h, uint64_t* out_batches, uint64_t* out_fallback_queries) {
+  if (!h) return fail(VERS_ERR_INVALID, "null handle");
+  DeviceGuard g(h->device);
+  uint32_t fb = 0;
+  if (h->pre_misc.p) VERS_HIP_TRY(hipMemcpy(&fb, h->pre_misc.as<uint32_t>() + 1, 4, hipMemcpyDeviceToHost));
+  if (out_batches) *out_batches = h->pre_batches;
+  if (out_fallback_queries) *out_fallback_queries = fb;
+  return VERS_OK;
+}
+
+int32_t vers_ivf_test_poison_slack(vers_ivf_t* h, float value) {
+  if (!h) return fail(VERS_ERR_INVALID, "null handle");
+  std::unique_lock<std::shared_mutex> lk(h->index);
+  DeviceGuard g(h->device);
+  VERS_HIP_TRY(hipDeviceSynchronize());
+  if (h->cap_rows == 0) return VERS_OK;
+  if (int32_t rc = poison_slack(h, value, nullptr)) return rc;
+  if (int32_t rc = refresh_norms(h, 0, h->cap_rows, nullptr)) return rc;
+  VERS_HIP_TRY(hipDeviceSynchronize());
+  return VERS_OK;
+}
+
+int32_t vers_ivf_test_last_vals(vers_ivf_t* h, uint32_t q, uint64_t* out_vec_ids, float* out_vals, double* out_bound, uint32_t cap, uint32_t* out_n,
+                                double* out_info) {
+  if (!h || !out_n || (cap && (!out_vec_ids || !out_vals || !out_bound))) return fail(VERS_ERR_INVALID, "bad arguments");
+  std::shared_lock<std::shared_mutex> lk(h->index);
+  UseLastWs use_ws(h);
+  if (!use_ws.ok || !W->last_pre.valid) return fail(VERS_ERR_INVALID, "vers_ivf_test_last_vals: the most recent search did not run the matrix-core list scan");
+  const auto lp = W->last_pre;
+  if (q >= lp.b) return fail(VERS_ERR_INVALID, "vers_ivf_test_last_vals: no such query in the last batch");
+  DeviceGuard g(h->device);
+  VERS_HIP_TRY(hipDeviceSynchronize());
+  const uint32_t P = lp.P, S = lp.S_max, kp = lp.kp;
+  const uint64_t n_pj = (uint64_t)lp.b * P;
+  std::vector<uint64_t> keys((size_t)P * S * kp);
+  std::vector<uint32_t> pl(P), pp(P), pn(P);
+  const uint32_t* pj = W->pj.as<uint32_t>();
+  VERS_HIP_TRY(hipMemcpy(keys.data(), W->partials.as<uint64_t>() + (uint64_t)q * P * S * kp, keys.size() * 8, hipMemcpyDeviceToHost));
+  VERS_HIP_TRY(hipMemcpy(pl.data(), pj + (uint64_t)q * P, P * 4, hipMemcpyDeviceToHost));
+  VERS_HIP_TRY(hipMemcpy(pp.data(), pj + n_pj + (uint64_t)q * P, P * 4, hipMemcpyDeviceToHost));
+  VERS_HIP_TRY(hipMemcpy(pn.data(), pj + 3 * n_pj + lp.b + (uint64_t)q * P, P * 4, hipMemcpyDeviceToHost));
+  std::vector<float> qrow(h->ldq);
+  VERS_HIP_TRY(hipMemcpy(qrow.data(), lp.qp + (uint64_t)q * h->ldq, (size_t)h->ldq * 4, hipMemcpyDeviceToHost));
+  uint32_t misc[4] = {0, 0, 0, 0};
+  VERS_HIP_TRY(hipMemcpy(misc, h->pre_misc.p, 16, hipMemcpyDeviceToHost));
+  double qn = 0.0;
+  for (uint32_t j = 0; j < h->ldq; ++j) qn += (double)qrow[j] * (double)qrow[j];
+  float xmax2, r2;
+  memcpy(&xmax2, &misc[0], 4); memcpy(&r2, &misc[2], 4);
+  const PreBound pb = pre_bound(qn, (double)xmax2, lp.shadow ? (double)r2 : 0.0, h->ld, h->metric, lp.shadow);
+  if (out_info) { out_info[0] = qn; out_info[1] = xmax2; out_info[2] = lp.shadow ? r2 : 0.0; out_info[3] = pb.global; out_info[4] = pb.common; out_info[5] = kp; out_info[6] = lp.shadow; out_info[7] = h->metric; }
+  uint32_t n = 0;
+  for (uint32_t j = 0; j < P; ++j) {
+    if (pl[j] == kNoList) continue;
+    uint32_t off_j = 0;
+    VERS_HIP_TRY(hipMemcpy(&off_j, h->slot_off.as<uint32_t>() + pl[j], 4, hipMemcpyDeviceToHost));
+    for (uint32_t sq = 0; sq < pn[j] && sq < S; ++sq)
+      for (uint32_t i = 0; i < kp; ++i) {
+        const uint64_t key = keys[((size_t)j * S + sq) * kp + i];
+        if (key == kKeyMax) continue;
+        if (n < cap) {
+          const uint32_t row = off_j + ((uint32_t)key - pp[j]);
+          uint32_t vid = 0;
+          VERS_HIP_TRY(hipMemcpy(&vid, h->row_ids.as<uint32_t>() + row, 4, hipMemcpyDeviceToHost));
+          const uint32_t vb = order_bits_to_f32_bits((uint32_t)(key >> 32));
+          float v; memcpy(&v, &vb, 4);
+          out_vec_ids[n] = vid; out_vals[n] = v; out_bound[n] = pb.of((double)v);
+        }
+        ++n;
+      }
+  }
+  *out_n = n;
+  return VERS_OK;
+}
+
+int32_t vers_ivf_scan_times(vers_ivf_t* h, float* out_ms, uint32_t cap, uint32_t* out_n, int32_t reset) {
+  if (!h || !out_n || (cap && !out_ms)) return fail(VERS_ERR_INVALID, "bad arguments");
+  DeviceGuard g(h->device);
+  // every workspace's ring (batches kept in flight on several streams lease one each); within a ring oldest first.  The
+  // caller has stopped issuing searches (a measurement hook): the rings are read without leasing.
+  std::vector<SearchWs*> all;
+  {
+    std::lock_guard<std::mutex> lk(h->pool_mu);
+    for (auto& w : h->pool) all.push_back(w.get());
+  }
+  uint32_t n = 0;
+  for (SearchWs* w : all) {
+    if (!w->done) continue;  // never initialised
+    const uint64_t have = std::min<uint64_t>(w->ev_count, SearchWs::kEvRing);
+    for (uint64_t i = 0; i < have && n < cap; ++i) {
+      const uint32_t slot = (uint32_t)((w->ev_count - have + i) % SearchWs::kEvRing);
+      VERS_HIP_TRY(hipEventSynchronize(w->ev1[slot]));
+      VERS_HIP_TRY(hipEventElapsedTime(&out_ms[n], w->ev0[slot], w->ev1[slot]));
+      ++n;
+    }
+    if (reset) w->ev_count = 0;
+  }
+  *out_n = n;
+  return VERS_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,720 @@
+// ivf_search.hip -- the second half of search_approximate (ivfflat.rs:166-198): the inverted-list scans (single query: item
+// records; batches in nprobe mode: matrix-core pre-selection + exact finish, prescan.hip.h; otherwise the ordered-chain
+// engine, scan.hip.h), the per-query merges + id mapping, the exhaustive scan of the stored rows (utils.rs:68-82), the
+// cross-GPU merge of partial results, host-pointer staging, and the search entry points of the C ABI.
+#include "finish.hip.h"
+#include "ivf_src.hip.h"
+
+namespace vers {
+
+template <int METRIC>
+__global__ __launch_bounds__(kWave * kWavesPerBlock) void scan1_kernel(Scan1Args a, ScanParams p) {
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t n_waves = gridDim.x * kWavesPerBlock;
+  uint32_t it = blockIdx.x * kWavesPerBlock + wid;
+  // (both loads go out together: the record buffer holds at least one entry per launched wave, a stale one is never used)
+  const uint32_t n_items = *a.n_items_dev;
+  Rec1Src src;
+  src.r = a.recs[it];
+  src.partials = a.partials; src.k_keep = a.k_keep; src.S_max = a.S_max; src.bound_per_pair = a.bound_per_pair;
+  bool nan_seen = false;
+  while (it < n_items) {
+    ItemView<1> v;
+    v.rows = a.rows + (uint64_t)src.r.row0 * p.ld;
+    v.nrows = src.r.nrows;
+    v.nq = 1;
+    v.qb = a.qp;
+    scan_item<1, 1, METRIC>(src, p, it, v, lane, nan_seen);
+    it += n_waves;
+    if (it < n_items) src.r = a.recs[it];
+  }
+  if (__ballot(nan_seen) != 0 && lane == 0) atomicOr(p.status, 1u);
+}
+
+// final merge + id mapping: one block per query.  Results wider than 64 keys come 64 ranks per pass (ScanParams::lower):
+// this pass emits ranks rank0 .. rank0+63 of every merge group into output row q (pitch top_k) and leaves the group's
+// last key as the next pass's lower bound.
+struct MergeArgs {
+  const uint64_t* partials; uint32_t P, S_max, k_keep; int ref_mode;
+  const uint32_t *np, *pj_list, *pj_pref, *pj_take, *list_off, *row_ids;
+  uint32_t top_k, rank0;
+  uint64_t* out_ids; float* out_dist; uint32_t* out_count; uint64_t* out_keys; uint64_t* lower_out;
+  const uint32_t* st_word = nullptr; uint32_t* st_host = nullptr;  // host-pointer single-query call: the stream's status word goes out with the result
+};
+template <int NW>
+__device__ __forceinline__ void ivf_merge_block(const MergeArgs& m, uint32_t q, uint64_t (*sh)[kWave]) {
+  const uint32_t P = m.P, S_max = m.S_max, k_keep = m.k_keep, top_k = m.top_k, rank0 = m.rank0;
+  const int lane = threadIdx.x & 63;
+  const bool w0 = threadIdx.x < kWave;
+  const uint64_t* pq = m.partials + (uint64_t)q * P * S_max * k_keep;
+  const uint64_t o_base = (uint64_t)q * top_k;
+  uint32_t written = 0;
+  const uint32_t n_groups = m.ref_mode ? m.np[q] : 1;
+  SeqRowsPre pre = {};  // (nprobe mode, P <= 64: what maps a key to its storage row, in flight under the merge)
+  const bool pre_ok = !m.ref_mode && P <= (uint32_t)kWave;
+  if (w0 && pre_ok) pre = wave_seq_rows_load(lane, m.pj_list + (uint64_t)q * P, m.pj_pref + (uint64_t)q * P, P);
+  auto mid = [&]() { if (w0 && pre_ok) wave_seq_rows_load2(pre, m.list_off); };
+  if (w0 && m.out_keys && rank0 == 0)
+    for (uint32_t i = (uint32_t)lane; i < top_k; i += kWave) m.out_keys[o_base + i] = kKeyMax;  // holes = other GPUs' lists
+  for (uint32_t grp = 0; grp < n_groups; ++grp) {
+    uint64_t list;
+    uint32_t n_emit;
+    if (m.ref_mode) {
+      const uint32_t take = m.pj_take[(uint64_t)q * P + grp];
+      if (take == 0) continue;  // uniform per block
+      n_emit = take > rank0 ? (take - rank0 < (uint32_t)kWave ? take - rank0 : (uint32_t)kWave) : 0u;
+      if (m.pj_list[(uint64_t)q * P + grp] == kNoList || n_emit == 0) {  // scanned by the GPU that owns the list / this pair is complete
+        written += take;
+        continue;
+      }
+      list = block_merge_keys<NW>(pq + (uint64_t)grp * S_max * k_keep, S_max * k_keep, k_keep, sh);
+      if (w0) {
+        const bool have = lane < (int)n_emit && list != kKeyMax;
+        const uint32_t row = have ? m.list_off[m.pj_list[(uint64_t)q * P + grp]] + ((uint32_t)list - m.pj_pref[(uint64_t)q * P + grp]) : 0u;
+        if (have) {
+          const uint64_t o = o_base + written + rank0 + lane;
+          m.out_ids[o] = m.row_ids[row];
+          m.out_dist[o] = __uint_as_float(order_bits_to_f32_bits((uint32_t)(list >> 32)));
+          if (m.out_keys) m.out_keys[o] = list;
+        }
+        if (m.lower_out && lane == kWave - 1) m.lower_out[(uint64_t)q * P + grp] = list;
+      }
+      written += take;
+    } else {
+      n_emit = top_k - rank0 < (uint32_t)kWave ? top_k - rank0 : (uint32_t)kWave;
+      list = block_merge_keys<NW>(pq, P * S_max * k_keep, k_keep, sh, mid);
+      if (w0) {
+        const bool have = lane < (int)n_emit && list != kKeyMax;
+        const uint32_t row = pre_ok ? wave_seq_rows_map(list, have, lane, pre)
+                                    : wave_seq_rows(list, have, lane, m.pj_list + (uint64_t)q * P, m.pj_pref + (uint64_t)q * P, P, m.list_off);
+        if (have) {
+          const uint64_t o = o_base + rank0 + lane;
+          m.out_ids[o] = m.row_ids[row];
+          m.out_dist[o] = __uint_as_float(order_bits_to_f32_bits((uint32_t)(list >> 32)));
+          if (m.out_keys) m.out_keys[o] = list;
+        }
+        if (m.lower_out && lane == kWave - 1) m.lower_out[(uint64_t)q * P] = list;
+        const uint32_t cnt = (uint32_t)__popcll(__ballot(have));
+        written = rank0 == 0 || cnt ? rank0 + cnt : 0xFFFFFFFFu;  // (a later pass that finds nothing leaves the count alone)
+      }
+    }
+  }
+  if (w0 && lane == 0 && written != 0xFFFFFFFFu && (m.ref_mode ? rank0 == 0 : true)) m.out_count[q] = written;
+  if (m.st_host && threadIdx.x == 0) *m.st_host = __hip_atomic_load(m.st_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <int NW>
+__global__ __launch_bounds__(kWave * NW) void ivf_merge_kernel(MergeArgs m) {
+  __shared__ uint64_t sh[NW][kWave];
+  ivf_merge_block<NW>(m, blockIdx.x, sh);
+}
+
+// exhaustive merge for the IVF handle (seq == vec_id already): ranks rank0 .. rank0 + k - 1 of output row q (pitch top_k);
+// top_k > 64 comes 64 ranks per pass (ScanParams::lower)
+__global__ __launch_bounds__(kWave * kMergeWaves) void seg_merge_kernel(const uint64_t* partials, uint32_t n_segs, uint32_t k, uint32_t top_k,
+                                                                        uint32_t rank0, uint64_t* out_ids, float* out_dist,
+                                                                        uint32_t* out_count, uint64_t* lower_out) {
+  __shared__ uint64_t sh[kMergeWaves][kWave];
+  const uint32_t q = blockIdx.x;
+  uint64_t list = block_merge_keys(partials + (uint64_t)q * n_segs * k, n_segs * k, k, sh);
+  if (threadIdx.x >= kWave) return;
+  const int lane = threadIdx.x;
+  const bool have = lane < (int)k && list != kKeyMax;
+  if (have) {
+    out_ids[(uint64_t)q * top_k + rank0 + lane] = (uint32_t)list;
+    out_dist[(uint64_t)q * top_k + rank0 + lane] = __uint_as_float(order_bits_to_f32_bits((uint32_t)(list >> 32)));
+  }
+  if (lower_out != nullptr && lane == (int)k - 1) lower_out[q] = list;  // (kKeyMax when the rows ran out: the next pass finds nothing)
+  const uint32_t cnt = (uint32_t)__popcll(__ballot(have));
+  if (lane == 0 && (rank0 == 0 || cnt)) out_count[q] = rank0 + cnt;
+}
+
+// cross-GPU merge of per-rank partial results ([world][b][k] keys + ids, kKeyMax padded): one wave per query.
+// nprobe mode: global top-k by key.  reference mode: position p of the output belongs to exactly one rank
+// (the owner of the list that position came from), so the merge is a position-wise minimum.
+__global__ __launch_bounds__(kWave) void rank_merge_kernel(const uint64_t* keys, const uint64_t* ids, uint64_t rank_stride,
+                                                           uint32_t world, uint32_t b, uint32_t k, int ref_mode,
+                                                           uint64_t* out_ids, float* out_dist, uint32_t* out_count) {
+  const uint32_t q = blockIdx.x;
+  const int lane = threadIdx.x;
+  uint32_t total = 0;
+  uint64_t lower = 0;  // nprobe mode, k > 64: 64 ranks per pass, keys at or below the previous pass's last key are skipped
+  for (uint32_t r0 = 0; r0 < k; r0 += kWave) {
+    const uint32_t kk = k - r0 < (uint32_t)kWave ? k - r0 : (uint32_t)kWave;
+    uint64_t key = kKeyMax, id = 0;
+    if (ref_mode) {
+      if (lane < (int)kk)
+        for (uint32_t r = 0; r < world; ++r) {
+          const uint64_t kx = keys[r * rank_stride + (uint64_t)q * k + r0 + lane];
+          if (kx < key) { key = kx; id = ids[r * rank_stride + (uint64_t)q * k + r0 + lane]; }
+        }
+    } else {
+      uint64_t list = kKeyMax;
+      const uint32_t n = world * k;
+      for (uint32_t i = 0; i < n; i += kWave) {
+        uint64_t cand = kKeyMax;
+        if (i + lane < n) cand = keys[(uint64_t)((i + lane) / k) * rank_stride + (uint64_t)q * k + (i + lane) % k];
+        if (cand <= lower) cand = kKeyMax;
+        wave_topk_update(list, kk, cand, kKeyMax);
+      }
+      key = lane < (int)kk ? list : kKeyMax;
+      if (key != kKeyMax)  // keys are unique: find where this one came from to pick up its id
+        for (uint32_t i = 0; i < n; ++i) {
+          const uint64_t o = (uint64_t)(i / k) * rank_stride + (uint64_t)q * k + i % k;
+          if (keys[o] == key) { id = ids[o]; break; }
+        }
+      lower = readlane64(list, (int)kk - 1);
+    }
+    const bool have = key != kKeyMax;
+    if (have) {
+      out_ids[(uint64_t)q * k + r0 + lane] = id;
+      out_dist[(uint64_t)q * k + r0 + lane] = __uint_as_float(order_bits_to_f32_bits((uint32_t)(key >> 32)));
+    }
+    total += (uint32_t)__popcll(__ballot(have));
+    if (!ref_mode && lower == kKeyMax) break;  // fewer keys than ranks: nothing left for later passes
+  }
+  if (lane == 0) out_count[q] = total;
+}
+
+// local exhaustive results -> (key, vec_id) pairs for the cross-GPU merge: key = (order bits of the distance << 32) |
+// vec_id, the reference's stable order (utils.rs:77: ties -> lower index); kKeyMax padded
+__global__ void pack_exhaustive_keys_kernel(const uint64_t* ids, const float* dist, const uint32_t* cnt, uint32_t b, uint32_t k,
+                                            uint64_t* out_keys, uint64_t* out_ids) {
+  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= b * k) return;
+  const uint32_t q = i / k, j = i - q * k;
+  const bool have = j < cnt[q];
+  out_keys[i] = have ? make_key(dist[i], (uint32_t)ids[i]) : kKeyMax;
+  out_ids[i] = have ? ids[i] : ~0ull;
+}
+
+}  // namespace vers
+
+namespace vers {
+namespace ivf {
+
+template <int QG>
+int32_t launch_ivf_scan(vers_ivf* h, const IvfSrc<QG>& src, uint32_t items_bound, hipStream_t st, const uint64_t* lower = nullptr) {
+  ScanParams p;
+  p.ld = h->ld;
+  p.n_chunks = h->ld / kChunk;
+  p.k = src.k_keep;
+  p.status = W->st_word();
+  p.debug = scan_debug_flags();
+  p.stamps = nullptr;
+  if (p.debug & 16u) {  // diagnosis only
+    if (int32_t rc = W->stamps.reserve(512)) return rc;
+    VERS_HIP_TRY(hipMemsetAsync(W->stamps.p, 0, 128, st));
+    p.stamps = W->stamps.as<unsigned long long>();
+  }
+  // pruning bounds shared between the items of a merge group (they run at different times here, unlike the flat
+  // scans); VERS_SCAN_DEBUG bit 3 switches them off for A/B runs
+  p.bounds = (QG != 1 && !(scan_debug_flags() & 8u)) ? W->partials.as<uint64_t>() + W->ivf_bounds_off : nullptr;
+  p.lower = lower;
+  p.next_quad = nullptr;
+  if (QG != 1 && !(scan_debug_flags() & 32u)) {
+    if (int32_t rc = W->quad_counter.reserve(16)) return rc;
+    VERS_HIP_TRY(hipMemsetAsync(W->quad_counter.p, 0, 16, st));
+    p.next_quad = W->quad_counter.as<uint32_t>();
+  }
+  const size_t lds = scan_lds_bytes(QG, h->ld);
+  if (int32_t rc = h->metric ? scan_prepare_launch(scan_kernel<QG, 1, IvfSrc<QG>>, lds) : scan_prepare_launch(scan_kernel<QG, 0, IvfSrc<QG>>, lds)) return rc;
+  uint32_t blocks = (items_bound + kWavesPerBlock - 1) / kWavesPerBlock;
+  const uint32_t max_blocks = (uint32_t)h->n_cu * scan_blocks_per_cu(QG, h->ld);
+  if (blocks > max_blocks) blocks = max_blocks;
+  if (blocks == 0) blocks = 1;
+  const uint32_t slot = (uint32_t)(W->ev_count % SearchWs::kEvRing);
+  if (W->ev_on) VERS_HIP_TRY(hipEventRecord(W->ev0[slot], st));
+  if (h->metric) hipLaunchKernelGGL((scan_kernel<QG, 1, IvfSrc<QG>>), dim3(blocks), dim3(kWave * kWavesPerBlock), lds, st, src, p);
+  else hipLaunchKernelGGL((scan_kernel<QG, 0, IvfSrc<QG>>), dim3(blocks), dim3(kWave * kWavesPerBlock), lds, st, src, p);
+  VERS_HIP_TRY(hipGetLastError());
+  if (W->ev_on) {
+    VERS_HIP_TRY(hipEventRecord(W->ev1[slot], st));
+    W->ev_count += 1;
+  }
+  return VERS_OK;
+}
+
+// a single query's list scan over item records (scan1_kernel); timed through the same event ring
+int32_t launch_scan1(vers_ivf* h, const Scan1Args& a, uint32_t items_bound, hipStream_t st, const uint64_t* lower) {
+  ScanParams p;
+  p.ld = h->ld;
+  p.n_chunks = h->ld / kChunk;
+  p.k = a.k_keep;
+  p.status = W->st_word();
+  p.debug = scan_debug_flags() & ~16u;
+  p.stamps = nullptr;
+  p.bounds = nullptr;
+  p.lower = lower;
+  p.next_quad = nullptr;
+  uint32_t blocks = (items_bound + kWavesPerBlock - 1) / kWavesPerBlock;  // (W->items holds items_bound + 4 records: one per launched wave)
+  const uint32_t max_blocks = (uint32_t)h->n_cu * scan_blocks_per_cu(1, h->ld);
+  if (blocks > max_blocks) blocks = max_blocks;
+  if (blocks == 0) blocks = 1;
+  const bool no_ev = !W->ev_on;
+  const uint32_t slot = (uint32_t)(W->ev_count % SearchWs::kEvRing);
+  if (!no_ev) VERS_HIP_TRY(hipEventRecord(W->ev0[slot], st));
+  if (h->metric) hipLaunchKernelGGL(scan1_kernel<1>, dim3(blocks), dim3(kWave * kWavesPerBlock), 0, st, a, p);
+  else hipLaunchKernelGGL(scan1_kernel<0>, dim3(blocks), dim3(kWave * kWavesPerBlock), 0, st, a, p);
+  VERS_HIP_TRY(hipGetLastError());
+  if (!no_ev) {
+    VERS_HIP_TRY(hipEventRecord(W->ev1[slot], st));
+    W->ev_count += 1;
+  }
+  return VERS_OK;
+}
+
+// the matrix-core list scan (prescan.hip.h); timed through the same event ring as launch_ivf_scan
+int32_t launch_prescan(vers_ivf* h, const IvfSrc<kPreQ>& src, uint32_t items_bound, uint32_t kp, uint32_t* qflags, uint32_t* quad_ctr,
+                       bool shadow, hipStream_t st) {
+  PreParams p;
+  p.rows_bf = shadow ? h->rows_bf.as<uint16_t>() : nullptr;
+  p.ld = h->ld;
+  p.n_chunks = h->ld / kChunk;
+  p.kp = kp;
+  p.status = W->st_word();
+  p.bounds32 = reinterpret_cast<uint32_t*>(W->partials.as<uint64_t>() + W->ivf_bounds_off);  // 0xFF-initialised with the slots
+  p.qflags = qflags;
+  p.xnorm = h->xnorm.as<float>();
+  p.debug = scan_debug_flags();
+  p.metric = (uint32_t)h->metric;
+  p.stamps = nullptr;
+  if (p.debug & 16u) {
+    if (int32_t rc = W->stamps.reserve(512)) return rc;
+    VERS_HIP_TRY(hipMemsetAsync(W->stamps.p, 0, 128, st));
+    p.stamps = W->stamps.as<unsigned long long>();
+  }
+  p.next_quad = (p.debug & 32u) ? nullptr : quad_ctr;  // zeroed with the planning tables
+  const size_t lds = prescan_lds_bytes_g(h->ld, kp);
+  if (int32_t rc = shadow ? scan_prepare_launch(prescan_kernel_g<true, IvfSrc<kPreQ>>, lds) : scan_prepare_launch(prescan_kernel_g<false, IvfSrc<kPreQ>>, lds)) return rc;
+  uint32_t blocks = (items_bound + kWavesPerBlock - 1) / kWavesPerBlock;
+  uint32_t per_cu = std::max<uint32_t>(1, std::min<uint32_t>(2, (uint32_t)((160u * 1024u) / lds)));  // 1 at d = 768 (measured: as fast as 2)
+  if (knobs().pre_blocks_per_cu > 0) per_cu = (uint32_t)knobs().pre_blocks_per_cu;  // tuning knob
+  const uint32_t max_blocks = (uint32_t)h->n_cu * per_cu;
+  if (blocks > max_blocks) blocks = max_blocks;
+  if (blocks == 0) blocks = 1;
+  const uint32_t slot = (uint32_t)(W->ev_count % SearchWs::kEvRing);
+  if (W->ev_on) VERS_HIP_TRY(hipEventRecord(W->ev0[slot], st));
+  if (shadow) hipLaunchKernelGGL((prescan_kernel_g<true, IvfSrc<kPreQ>>), dim3(blocks), dim3(kWave * kPreWavesG), lds, st, src, p);
+  else hipLaunchKernelGGL((prescan_kernel_g<false, IvfSrc<kPreQ>>), dim3(blocks), dim3(kWave * kPreWavesG), lds, st, src, p);
+  VERS_HIP_TRY(hipGetLastError());
+  if (W->ev_on) {
+    VERS_HIP_TRY(hipEventRecord(W->ev1[slot], st));
+    W->ev_count += 1;
+  }
+  return VERS_OK;
+}
+
+// search_approximate for b queries.  nprobe == 0: the reference's own semantics (nearest list,
+// spill while short; results concatenated per list).  nprobe >= 1: extension, global top-k
+// over the nprobe nearest lists.
+int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint32_t b, uint32_t top_k, uint32_t nprobe,
+                          uint64_t* out_ids, float* out_dist, uint32_t* out_count, uint64_t* out_keys, hipStream_t st) {
+  if (b == 0) return VERS_OK;
+  if (top_k == 0) {
+    VERS_HIP_TRY(hipMemsetAsync(out_count, 0, sizeof(uint32_t) * b, st));
+    return VERS_OK;
+  }
+  if (h->k == 0) return fail(VERS_ERR_INSUFFICIENT, "search on an index without centroids (reference: index out of bounds, ivfflat.rs:169)");
+  SearchPlan s;
+  if (int32_t rc = plan_search(h, q_dev, ldq_in, b, top_k, nprobe, st, s)) return rc;
+  const uint32_t P = s.P, kp = s.kp, k_keep = s.k_keep, n_pass = s.n_pass, seg_rows = s.seg_rows, seg_target = s.seg_target, S_max = s.S_max;
+  const int ref_mode = s.ref_mode, QG = s.QG, pre_mode = s.pre_mode;
+  const bool one1 = s.one1, use_pre = s.use_pre, use_shadow = s.use_shadow;
+  const uint64_t items_bound = s.items_bound;
+  const size_t part_bytes = s.part_bytes;
+  uint32_t *const pj_list = s.pj_list, *const pj_pref = s.pj_pref, *const pj_take = s.pj_take, *const np = s.np, *const pj_nq = s.pj_nq;
+  uint32_t *const cnt = s.cnt, *const pair_off = s.pair_off, *const group_off = s.group_off, *const quad_ctr = s.quad_ctr;
+  uint32_t *const fail_list = s.fail_list, *const qflags = s.qflags;
+  GroupTotals* const tot = s.tot;
+  const float* const qp = s.qp;
+  SearchWs::CoarseAhead* const took = s.took;
+  auto fill_src = [&](auto& src) {
+    src.rows = h->rows.as<float>(); src.ld = h->ld; src.list_off = h->slot_off.as<uint32_t>();  // (items name lists by slot)
+    src.list_len = h->slot_len.as<uint32_t>(); src.items = W->items.as<ItemDesc>(); src.n_items_dev = &tot->n_items;
+    src.cnt = cnt; src.pair_off = pair_off; src.pairs = W->pairs.as<uint32_t>(); src.group_off = group_off;
+    src.qblocks = W->qblocks.as<float>(); src.qp = qp; src.ldq = h->ldq; src.P = P; src.S_max = S_max; src.k_keep = k_keep;
+    src.seg_rows = seg_rows; src.seg_target = seg_target; src.pj_pref = pj_pref; src.partials = W->partials.as<uint64_t>();
+    src.bound_per_pair = ref_mode ? 1u : 0u;
+  };
+  int32_t rc;
+  if (use_pre) {
+    IvfSrc<kPreQ> src; fill_src(src);
+    // partial lists of the exact re-scan (fail_list [b] + its count, qflags [n_pj]: in the zeroed zone above)
+    uint32_t fb_blocks = kFallbackBlocks;  // (a power of two; fewer when P x top_k is large: at most 32 MB of partial lists)
+    while (fb_blocks > 16 && fallback_part_keys(fb_blocks, P, top_k) * sizeof(uint64_t) > (size_t(32) << 20)) fb_blocks /= 2;
+    if (int32_t rc2 = W->fb_part.reserve(fallback_part_keys(fb_blocks, P, top_k) * sizeof(uint64_t))) return rc2;
+    if (!W->fb_ctr.p) {  // group counters of fallback_kernel: zero once, the kernel leaves them zero
+      if (int32_t rc2 = W->fb_ctr.reserve((2 * kFallbackBlocks + 1) * sizeof(uint32_t))) return rc2;
+      VERS_HIP_TRY(hipMemsetAsync(W->fb_ctr.p, 0, (2 * kFallbackBlocks + 1) * sizeof(uint32_t), st));
+    }
+    if (int32_t rc2 = launch_prescan(h, src, (uint32_t)items_bound, kp, qflags, quad_ctr, use_shadow, st)) return rc2;
+    if (int32_t rc2 = start_pending_ahead(h, st)) return rc2;  // the next batch's coarse quantiser: under this batch's exact finish
+    RescoreArgs a;
+    a.partials = W->partials.as<uint64_t>(); a.P = P; a.S_max = S_max; a.kp = kp; a.top_k = top_k; a.d_pad = h->ld;
+    a.pj_list = pj_list; a.pj_pref = pj_pref; a.pj_nq = pj_nq; a.list_off = h->slot_off.as<uint32_t>(); a.row_ids = h->row_ids.as<uint32_t>();
+    a.rows = h->rows.as<float>(); a.rows_rm = h->rows_rm.as<float>(); a.ld = h->ld; a.qp = qp; a.ldq = h->ldq; a.xmax2_bits = h->pre_misc.as<uint32_t>();
+    a.qflags = qflags; a.metric = h->metric; a.force_fail = pre_mode == 2; a.shadow = use_shadow ? 1 : 0; a.debug = scan_debug_flags(); a.fail_list = fail_list; a.stats = h->pre_misc.as<uint32_t>() + 1;
+    a.status = W->st_word(); a.out_ids = out_ids; a.out_dist = out_dist; a.out_count = out_count; a.out_keys = out_keys;
+    const int stage_rows = rescore_lds_bytes(h->ld, true) <= 144u * 1024u ? 1 : 0;
+    const size_t rs_lds = rescore_lds_bytes(h->ld, stage_rows != 0);
+    if (int32_t rc2 = scan_prepare_launch(ivf_rescore_kernel, rs_lds)) return rc2;
+    hipLaunchKernelGGL(ivf_rescore_kernel, dim3(b), dim3(kWave * kRescoreWaves), rs_lds, st, a, stage_rows);
+    VERS_HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(fallback_kernel, dim3(fb_blocks), dim3(kWave * kMergeWaves), 0, st, a, (const uint32_t*)h->slot_len.as<uint32_t>(),
+                       (const uint32_t*)fail_list, (const uint32_t*)(fail_list + b), W->fb_part.as<uint64_t>(), W->fb_ctr.as<uint32_t>(),
+                       use_shadow ? h->fail_watch : (uint32_t*)nullptr);
+    VERS_HIP_TRY(hipGetLastError());
+    W->last_pre.valid = true; W->last_pre.b = b; W->last_pre.P = P; W->last_pre.S_max = S_max; W->last_pre.kp = kp; W->last_pre.top_k = top_k;
+    W->last_pre.qp = qp; W->last_pre.shadow = use_shadow ? 1 : 0;
+    if (use_shadow) h->shadow_queries += b;  // (fallback_kernel writes the running failure count to the pinned watch word)
+    h->pre_batches += 1;
+    W->tot_valid = true;
+    if (took) { VERS_HIP_TRY(hipEventRecord(took->freed, st)); took->freed_rec = true; }
+    return VERS_OK;
+  }
+  // ordered-chain scans: 64 result ranks per pass (one pass for top_k <= 64)
+  for (uint32_t pass = 0; pass < n_pass; ++pass) {
+    const uint64_t* lower = pass ? W->lower.as<uint64_t>() : nullptr;
+    if (pass) VERS_HIP_TRY(hipMemsetAsync(W->partials.p, 0xFF, part_bytes, st));  // slots and pruning bounds of the previous pass
+    MergeArgs ma;
+    ma.partials = W->partials.as<uint64_t>(); ma.P = P; ma.S_max = S_max; ma.k_keep = k_keep; ma.ref_mode = ref_mode; ma.np = np;
+    ma.pj_list = pj_list; ma.pj_pref = pj_pref; ma.pj_take = pj_take; ma.list_off = h->slot_off.as<uint32_t>(); ma.row_ids = h->row_ids.as<uint32_t>();
+    ma.top_k = top_k; ma.rank0 = pass * (uint32_t)kMaxTopK; ma.out_ids = out_ids; ma.out_dist = out_dist; ma.out_count = out_count; ma.out_keys = out_keys;
+    ma.lower_out = n_pass > 1 ? W->lower.as<uint64_t>() : (uint64_t*)nullptr;
+    if (W->st_host && pass + 1 == n_pass) { ma.st_word = W->st_word(); ma.st_host = W->st_host; }
+    if (one1) {  // the single query's items are records (plan1_block)
+      Scan1Args sa;
+      sa.rows = h->rows.as<float>(); sa.recs = W->items.as<Item1Rec>(); sa.n_items_dev = &tot->n_items; sa.qp = qp;
+      sa.partials = W->partials.as<uint64_t>(); sa.k_keep = k_keep; sa.S_max = S_max; sa.bound_per_pair = ref_mode ? 1u : 0u;
+      rc = launch_scan1(h, sa, (uint32_t)items_bound, st, lower);
+    } else if (QG == 1) {
+      IvfSrc<1> src; fill_src(src);
+      rc = launch_ivf_scan(h, src, (uint32_t)items_bound, st, lower);
+    } else if (QG == 8) {
+      IvfSrc<8> src; fill_src(src);
+      rc = launch_ivf_scan(h, src, (uint32_t)items_bound, st, lower);
+    } else {
+      IvfSrc<16> src; fill_src(src);
+      rc = launch_ivf_scan(h, src, (uint32_t)items_bound, st, lower);
+    }
+    if (rc) return rc;
+    if (pass == 0)
+      if (int32_t rc2 = start_pending_ahead(h, st)) return rc2;
+    // four waves while a wave can hold its share of the slots' heads in registers (4096 slots of a merge group: two tree levels
+    // instead of four; same box, single query: 94.2 -> 91.6 us, reference mode 59.0 -> 55.3), sixteen beyond
+    const uint64_t slots_per_group = ref_mode ? S_max : (uint64_t)P * S_max;
+    if (slots_per_group <= 4096) hipLaunchKernelGGL(ivf_merge_kernel<4>, dim3(b), dim3(kWave * 4), 0, st, ma);
+    else hipLaunchKernelGGL(ivf_merge_kernel<kMergeWaves>, dim3(b), dim3(kWave * kMergeWaves), 0, st, ma);
+    VERS_HIP_TRY(hipGetLastError());
+  }
+  W->tot_valid = true;
+  if (took) { VERS_HIP_TRY(hipEventRecord(took->freed, st)); took->freed_rec = true; }
+  return VERS_OK;
+}
+
+int32_t exhaustive_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint32_t b, uint32_t top_k, uint32_t metric,
+                              uint64_t* out_ids, float* out_dist, uint32_t* out_count, hipStream_t st) {
+  if (b == 0) return VERS_OK;
+  if (top_k == 0) {
+    VERS_HIP_TRY(hipMemsetAsync(out_count, 0, sizeof(uint32_t) * b, st));
+    return VERS_OK;
+  }
+  const int QG = b == 1 ? 1 : 8;
+  const uint32_t n_qg = (b + QG - 1) / QG;
+  if (int32_t rc = W->qil.reserve((size_t)n_qg * h->ldq * QG * sizeof(float))) return rc;
+  if (int32_t rc = launch_stage_queries(q_dev, ldq_in, h->d, W->qil.as<float>(), h->ldq, b, QG, st)) return rc;
+  const uint32_t target_items = (uint32_t)h->n_cu * scan_blocks_per_cu(QG, h->ld) * kWavesPerBlock;
+  uint64_t per = (h->cap_rows * n_qg + target_items - 1) / target_items;
+  const uint32_t seg_rows = (uint32_t)std::min<uint64_t>(round_up64(per ? per : 1, kWave), max_seg_rows(h->ld));
+  uint32_t n_segs = (uint32_t)((h->cap_rows + seg_rows - 1) / seg_rows);
+  if (n_segs == 0) n_segs = 1;
+  const uint32_t k_w = std::min<uint32_t>(top_k, kMaxTopK);  // one key per lane; wider results: 64 ranks per pass (utils.rs:68-82 has no cap)
+  if (int32_t rc = W->xpart.reserve((size_t)b * n_segs * k_w * sizeof(uint64_t))) return rc;
+  if (top_k > (uint32_t)kMaxTopK)
+    if (int32_t rc = W->lower.reserve((size_t)b * sizeof(uint64_t))) return rc;
+  const uint32_t n_segs_pad = QG == 1 ? n_segs : round_up(n_segs, 4);
+  // (a pass past the last stored row finds nothing; 64-bit rank: no wrap near 2^32)
+  for (uint64_t rank0 = 0; rank0 < top_k && (rank0 == 0 || rank0 < h->cap_rows); rank0 += kMaxTopK) {
+    const uint32_t k_pass = (uint32_t)std::min<uint64_t>(kMaxTopK, top_k - rank0);
+    const uint64_t* lower = rank0 ? W->lower.as<uint64_t>() : nullptr;
+    auto fill = [&](auto& src) {
+      src.rows = h->rows.as<float>(); src.n = h->cap_rows; src.ld = h->ld; src.seg_rows = seg_rows; src.n_segs = n_segs;
+      src.n_segs_pad = n_segs_pad;
+      src.queries = W->qil.as<float>(); src.ldq = h->ldq; src.b = b; src.partials = W->xpart.as<uint64_t>(); src.k = k_pass;
+      src.ids = h->row_ids.as<uint32_t>();
+    };
+    int32_t rc;
+    if (QG == 1) {
+      SegSrc<1, true> src; fill(src);
+      rc = launch_seg_scan(h, src, n_segs_pad * n_qg, (int)metric, st, lower);
+    } else {
+      SegSrc<8, true> src; fill(src);
+      rc = launch_seg_scan(h, src, n_segs_pad * n_qg, (int)metric, st, lower);
+    }
+    if (rc) return rc;
+    hipLaunchKernelGGL(seg_merge_kernel, dim3(b), dim3(kWave * kMergeWaves), 0, st, W->xpart.as<uint64_t>(), n_segs, k_pass, top_k, (uint32_t)rank0, out_ids,
+                       out_dist, out_count, top_k > (uint32_t)kMaxTopK ? W->lower.as<uint64_t>() : (uint64_t*)nullptr);
+    VERS_HIP_TRY(hipGetLastError());
+  }
+  return VERS_OK;
+}
+
+int32_t ensure_out(vers_ivf* h, size_t need, uint32_t b) {
+  if (int32_t rc = W->o_ids.reserve(need * sizeof(uint64_t))) return rc;
+  if (int32_t rc = W->o_dist.reserve(need * sizeof(float))) return rc;
+  return W->o_cnt.reserve((size_t)b * sizeof(uint32_t));
+}
+
+int32_t upload_queries(const float* queries, uint64_t stride_bytes, uint32_t b, uint32_t d, DevBuf& buf) {
+  if (int32_t rc = buf.reserve((size_t)b * d * sizeof(float))) return rc;
+  VERS_HIP_TRY(hipMemcpy2D(buf.p, (size_t)d * 4, queries, stride_bytes, (size_t)d * 4, b, hipMemcpyHostToDevice));
+  return VERS_OK;
+}
+
+int32_t download_results(vers_ivf* h, uint32_t b, uint32_t top_k, uint64_t* out_ids, float* out_dist, uint32_t* out_count) {
+  const size_t need = (size_t)b * top_k;
+  if (need) {
+    VERS_HIP_TRY(hipMemcpy(out_ids, W->o_ids.p, need * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    VERS_HIP_TRY(hipMemcpy(out_dist, W->o_dist.p, need * sizeof(float), hipMemcpyDeviceToHost));
+  }
+  VERS_HIP_TRY(hipMemcpy(out_count, W->o_cnt.p, (size_t)b * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  return VERS_OK;
+}
+
+// ---- host-pointer calls: staged through pinned memory, one synchronisation -----------------------------
+struct HostIo {
+  bool direct = false;  // single query: the kernels write ids / distances / count / status straight into the pinned block
+  size_t q_bytes, ids_off, dist_off, cnt_off, st_off, out_bytes;
+  float* q_dev;
+  uint64_t* ids_dev;
+  float* dist_dev;
+  uint32_t* cnt_dev;
+};
+
+int32_t host_io_begin(vers_ivf* h, const float* queries, uint64_t stride_bytes, uint32_t b, uint32_t top_k, HostIo& io, bool direct = false) {
+  const size_t need = (size_t)b * std::max<uint32_t>(top_k, 1);
+  io.q_bytes = (size_t)b * h->d * sizeof(float);
+  io.ids_off = 0;
+  io.dist_off = need * sizeof(uint64_t);
+  io.cnt_off = io.dist_off + need * sizeof(float);
+  io.st_off = io.cnt_off + (size_t)b * sizeof(uint32_t);
+  io.out_bytes = io.st_off + 16;
+  if (!W->io_stream) VERS_HIP_TRY(hipStreamCreateWithFlags(&W->io_stream, hipStreamNonBlocking));
+  if (W->used && W->last_stream != W->io_stream) VERS_HIP_TRY(hipStreamWaitEvent(W->io_stream, W->done, 0));
+  if (int32_t rc = W->io_q.reserve(io.q_bytes)) return rc;
+  if (int32_t rc = W->io_out.reserve(io.out_bytes)) return rc;
+  // (a single query's results are written into the pinned block by the merge launch itself -- no memset, no device-to-device
+  // and device-to-host copies behind the search: three stream operations of ~4 us each, 124 -> 112 us per call; the query's bytes
+  // and the results do not share pinned bytes then.  Letting coarse1_kernel read the QUERY from the pinned block too instead of
+  // the H2D copy measured the same: not kept)
+  io.direct = direct;
+  const size_t q_pin = (io.q_bytes + 63) & ~(size_t)63;
+  const size_t pin_need = io.direct ? q_pin + io.out_bytes : std::max(io.q_bytes, io.out_bytes);
+  if (pin_need > W->io_pin_cap) {
+    if (W->io_pin) (void)hipHostFree(W->io_pin);
+    W->io_pin = nullptr; W->io_pin_cap = 0;
+    VERS_HIP_TRY(hipHostMalloc(&W->io_pin, pin_need, hipHostMallocDefault));
+    W->io_pin_cap = pin_need;
+  }
+  char* base = io.direct ? (char*)W->io_pin + q_pin : (char*)W->io_out.p;
+  io.q_dev = W->io_q.as<float>();
+  io.ids_dev = (uint64_t*)(base + io.ids_off);
+  io.dist_dev = (float*)(base + io.dist_off);
+  io.cnt_dev = (uint32_t*)(base + io.cnt_off);
+  for (uint32_t i = 0; i < b; ++i)
+    std::memcpy((char*)W->io_pin + (size_t)i * h->d * 4, (const char*)queries + (size_t)i * stride_bytes, (size_t)h->d * 4);
+  VERS_HIP_TRY(hipMemcpyAsync(io.q_dev, W->io_pin, io.q_bytes, hipMemcpyHostToDevice, W->io_stream));
+  return VERS_OK;
+}
+
+// copies results + status word back, waits once, maps the status; *out_status_rc carries kRetrySpill etc.
+int32_t host_io_end(vers_ivf* h, const HostIo& io, uint32_t b, uint32_t top_k, uint64_t* out_ids, float* out_dist, uint32_t* out_count) {
+  const char* pin = (const char*)W->io_pin;
+  if (io.direct) {
+    pin = (const char*)io.ids_dev - io.ids_off;
+    VERS_HIP_TRY(hipStreamSynchronize(W->io_stream));
+  } else {
+    char* base = (char*)W->io_out.p;
+    VERS_HIP_TRY(hipMemcpyAsync(base + io.st_off, W->st_word(), sizeof(uint32_t), hipMemcpyDeviceToDevice, W->io_stream));
+    VERS_HIP_TRY(hipMemcpyAsync(W->io_pin, base, io.out_bytes, hipMemcpyDeviceToHost, W->io_stream));
+    VERS_HIP_TRY(hipStreamSynchronize(W->io_stream));
+  }
+  uint32_t s = 0;
+  std::memcpy(&s, pin + io.st_off, sizeof(s));
+  if (int32_t rc = status_to_rc(h, s, W->st_slot)) return rc;
+  const size_t need = (size_t)b * top_k;
+  if (need) {
+    std::memcpy(out_ids, pin + io.ids_off, need * sizeof(uint64_t));
+    std::memcpy(out_dist, pin + io.dist_off, need * sizeof(float));
+  }
+  std::memcpy(out_count, pin + io.cnt_off, (size_t)b * sizeof(uint32_t));
+  return VERS_OK;
+}
+
+}  // namespace ivf
+}  // namespace vers
+
+extern "C" {
+
+int32_t vers_ivf_search_dev(vers_ivf_t* h, const float* queries_dev, uint64_t ldq_floats, uint32_t b, uint32_t top_k,
+                            uint32_t nprobe, uint64_t* out_ids_dev, float* out_dist_dev, uint32_t* out_count_dev, void* stream) {
+  if (!h) return fail(VERS_ERR_INVALID, "null handle");
+  if (b && (!queries_dev || ldq_floats < h->d || !out_count_dev || (top_k && (!out_ids_dev || !out_dist_dev))))
+    return fail(VERS_ERR_INVALID, "vers_ivf_search_dev: bad arguments");
+  std::shared_lock<std::shared_mutex> lk(h->index);
+  DeviceGuard g(h->device);
+  WsLease lease(h, true, (hipStream_t)stream);
+  if (lease.rc) return lease.rc;
+  if (int32_t rc = lease.order_on((hipStream_t)stream)) return rc;
+  return search_dev_locked(h, queries_dev, ldq_floats, b, top_k, nprobe, out_ids_dev, out_dist_dev, out_count_dev, nullptr,
+                           (hipStream_t)stream);
+}
+
+int32_t vers_ivf_search_partial_dev(vers_ivf_t* h, const float* queries_dev, uint64_t ldq_floats, uint32_t b, uint32_t top_k,
+                                    uint32_t nprobe, uint64_t* out_keys_dev, uint64_t* out_ids_dev, void* stream) {
+  if (!h) return fail(VERS_ERR_INVALID, "null handle");
+  if (top_k == 0) return fail(VERS_ERR_INVALID, "vers_ivf_search_partial_dev: top_k must be at least 1");
+  if (b && (!queries_dev || ldq_floats < h->d || !out_keys_dev || !out_ids_dev))
+    return fail(VERS_ERR_INVALID, "vers_ivf_search_partial_dev: bad arguments");
+  std::shared_lock<std::shared_mutex> lk(h->index);
+  DeviceGuard g(h->device);
+  WsLease lease(h, true, (hipStream_t)stream);
+  if (lease.rc) return lease.rc;
+  if (int32_t rc = lease.order_on((hipStream_t)stream)) return rc;
+  // distances and counts of the local part are scratch here: the cross-GPU merge recomputes them
+  if (int32_t rc = ensure_out(h, (size_t)b * top_k, b)) return rc;
+  return search_dev_locked(h, queries_dev, ldq_floats, b, top_k, nprobe, out_ids_dev, W->o_dist.as<float>(), W->o_cnt.as<uint32_t>(),
+                           out_keys_dev, (hipStream_t)stream);
+}
+
+int32_t vers_ivf_coarse_ahead_dev(vers_ivf_t* h, const float* queries_dev, uint64_t ldq_floats, uint32_t b, uint32_t nprobe, void* stream) {
+  if (!h) return fail(VERS_ERR_INVALID, "null handle");
+  if (b && (!queries_dev || ldq_floats < h->d)) return fail(VERS_ERR_INVALID, "vers_ivf_coarse_ahead_dev: bad arguments");
+  std::lock_guard<std::mutex> lk(h->pool_mu);
+  (void)stream;  // (the look-ahead is ordered behind the list scan of the NEXT search on this handle, on that search's stream)
+  h->pending.set = b != 0 && nprobe != 0;
+  h->pending.q_dev = queries_dev; h->pending.ldq_in = ldq_floats; h->pending.b = b; h->pending.nprobe = nprobe;
+  return VERS_OK;
+}
+
+int32_t vers_topk_merge_dev(const uint64_t* keys_dev, const uint64_t* ids_dev, uint64_t rank_stride, uint32_t world, uint32_t b,
+                            uint32_t top_k, uint32_t nprobe, uint64_t* out_ids_dev, float* out_dist_dev, uint32_t* out_count_dev,
+                            void* stream) {
+  if (rank_stride < (uint64_t)b * top_k) return fail(VERS_ERR_INVALID, "vers_topk_merge_dev: rank_stride < b * top_k");
+  if (world == 0 || top_k == 0 || (b && (!keys_dev || !ids_dev || !out_ids_dev || !out_dist_dev || !out_count_dev)))
+    return fail(VERS_ERR_INVALID, "vers_topk_merge_dev: bad arguments");
+  if (b == 0) return VERS_OK;
+  hipLaunchKernelGGL(rank_merge_kernel, dim3(b), dim3(kWave), 0, (hipStream_t)stream, keys_dev, ids_dev, rank_stride, world, b, top_k,
+                     nprobe == 0 ? 1 : 0, out_ids_dev, out_dist_dev, out_count_dev);
+  VERS_HIP_TRY(hipGetLastError());
+  return VERS_OK;
+}
+
+int32_t vers_ivf_search(vers_ivf_t* h, const float* queries, uint64_t q_stride_bytes, uint32_t b, uint32_t top_k,
+                        uint32_t nprobe, uint64_t* out_ids, float* out_dist, uint32_t* out_count) {
+  if (!h) return fail(VERS_ERR_INVALID, "null handle");
+  if (b && (!queries || q_stride_bytes < (uint64_t)h->d * 4 || q_stride_bytes % 4 || !out_count || (top_k && (!out_ids || !out_dist))))
+    return fail(VERS_ERR_INVALID, "vers_ivf_search: bad arguments");
+  if (b == 0) return VERS_OK;
+  std::shared_lock<std::shared_mutex> lk(h->index);
+  DeviceGuard g(h->device);
+  WsLease lease(h);
+  if (lease.rc) return lease.rc;
+  HostStatusSlot slot(h);
+  HostIo io;
+  if (int32_t rc = host_io_begin(h, queries, q_stride_bytes, b, top_k, io, b == 1 && top_k > 0)) return rc;
+  lease.st = W->io_stream;
+  // Reference mode ranks only as many lists as the spill may need: 16 first (the merge of the coarse partial lists
+  // and the plan are what a single-query call waits for), then 48, then 64 with the exact coarse quantiser, and as
+  // the last resort ALL of them (ivfflat.rs:166-195 walks the ranked lists as far as it must -- many empty lists with
+  // zero centroids make that real); the batch then goes in slices so that the (query, list) tables stay small.
+  int32_t rc = VERS_OK;
+  for (int attempt = nprobe == 0 ? 0 : 1; attempt < 4; ++attempt) {
+    W->ref_shallow = attempt == 0;
+    W->ref_deep = attempt == 2;
+    W->ref_all = attempt == 3;
+    // every attempt starts from zeros: entries past a query's count must not carry a previous attempt's values
+    if (io.direct) {  // (nothing of this workspace is in flight: the previous call / attempt ended with a synchronisation)
+      std::memset((char*)io.ids_dev - io.ids_off, 0, io.out_bytes);
+      W->st_host = (uint32_t*)((char*)io.ids_dev - io.ids_off + io.st_off);
+    } else {
+      VERS_HIP_TRY(hipMemsetAsync(W->io_out.p, 0, io.out_bytes, W->io_stream));
+    }
+    const uint32_t slice = attempt == 3 ? std::max<uint32_t>(1u, 65536u / std::max<uint32_t>(1u, h->k)) : b;
+    rc = VERS_OK;
+    for (uint32_t q0 = 0; q0 < b && rc == VERS_OK; q0 += slice) {
+      const uint32_t bq = std::min(slice, b - q0);
+      rc = search_dev_locked(h, io.q_dev + (size_t)q0 * h->d, h->d, bq, top_k, nprobe, io.ids_dev + (size_t)q0 * top_k,
+                             io.dist_dev + (size_t)q0 * top_k, io.cnt_dev + q0, nullptr, W->io_stream);
+    }
+    W->ref_shallow = W->ref_deep = W->ref_all = false;
+    W->st_host = nullptr;
+    if (rc) return rc;
+    rc = host_io_end(h, io, b, top_k, out_ids, out_dist, out_count);
+    if (rc != kRetrySpill) break;
+    if ((attempt == 0 && h->k <= 16) || (attempt == 1 && h->k <= 48) || (attempt == 2 && h->k <= 64)) break;  // every list was ranked already
+  }
+  return rc == kRetrySpill ? VERS_ERR_INVALID : rc;
+}
+
+int32_t vers_ivf_search_exhaustive_dev(vers_ivf_t* h, const float* queries_dev, uint64_t ldq_floats, uint32_t b, uint32_t top_k,
+                                       uint32_t metric, uint64_t* out_ids_dev, float* out_dist_dev, uint32_t* out_count_dev,
+                                       void* stream) {
+  if (!h) return fail(VERS_ERR_INVALID, "null handle");
+  if (metric > VERS_METRIC_COSDIST) return fail(VERS_ERR_INVALID, "unknown metric");
+  if (b && (!queries_dev || ldq_floats < h->d || !out_count_dev || (top_k && (!out_ids_dev || !out_dist_dev))))
+    return fail(VERS_ERR_INVALID, "vers_ivf_search_exhaustive_dev: bad arguments");
+  std::shared_lock<std::shared_mutex> lk(h->index);
+  DeviceGuard g(h->device);
+  WsLease lease(h, true, (hipStream_t)stream);
+  if (lease.rc) return lease.rc;
+  if (int32_t rc = lease.order_on((hipStream_t)stream)) return rc;
+  return exhaustive_dev_locked(h, queries_dev, ldq_floats, b, top_k, metric, out_ids_dev, out_dist_dev, out_count_dev,
+                               (hipStream_t)stream);
+}
+
+int32_t vers_ivf_search_exhaustive_partial_dev(vers_ivf_t* h, const float* queries_dev, uint64_t ldq_floats, uint32_t b, uint32_t top_k,
+                                               uint32_t metric, uint64_t* out_keys_dev, uint64_t* out_ids_dev, void* stream) {
+  if (!h) return fail(VERS_ERR_INVALID, "null handle");
+  if (top_k == 0 || metric > VERS_METRIC_COSDIST) return fail(VERS_ERR_INVALID, "unsupported top_k / metric");
+  if (b && (!queries_dev || ldq_floats < h->d || !out_keys_dev || !out_ids_dev))
+    return fail(VERS_ERR_INVALID, "vers_ivf_search_exhaustive_partial_dev: bad arguments");
+  if (b == 0) return VERS_OK;
+  std::shared_lock<std::shared_mutex> lk(h->index);
+  DeviceGuard g(h->device);
+  WsLease lease(h, true, (hipStream_t)stream);
+  if (lease.rc) return lease.rc;
+  if (int32_t rc = lease.order_on((hipStream_t)stream)) return rc;
+  if (int32_t rc = ensure_out(h, (size_t)b * top_k, b)) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  if (int32_t rc = exhaustive_dev_locked(h, queries_dev, ldq_floats, b, top_k, metric, W->o_ids.as<uint64_t>(), W->o_dist.as<float>(),
+                                         W->o_cnt.as<uint32_t>(), st)) return rc;
+  hipLaunchKernelGGL(pack_exhaustive_keys_kernel, dim3((b * top_k + 255) / 256), dim3(256), 0, st, (const uint64_t*)W->o_ids.as<uint64_t>(),
+                     (const float*)W->o_dist.as<float>(), (const uint32_t*)W->o_cnt.as<uint32_t>(), b, top_k, out_keys_dev, out_ids_dev);
+  VERS_HIP_TRY(hipGetLastError());
+  return VERS_OK;
+}
+
+int32_t vers_ivf_search_exhaustive(vers_ivf_t* h, const float* queries, uint64_t q_stride_bytes, uint32_t b, uint32_t top_k,
+                                   uint32_t metric, uint64_t* out_ids, float* out_dist, uint32_t* out_count) {
+  if (!h) return fail(VERS_ERR_INVALID, "null handle");
+  if (metric > VERS_METRIC_COSDIST) return fail(VERS_ERR_INVALID, "unknown metric");
+  if (b && (!queries || q_stride_bytes < (uint64_t)h->d * 4 || q_stride_bytes % 4 || !out_count || (top_k && (!out_ids || !out_dist))))
+    return fail(VERS_ERR_INVALID, "vers_ivf_search_exhaustive: bad arguments");
+  if (b == 0) return VERS_OK;
+  std::shared_lock<std::shared_mutex> lk(h->index);
+  DeviceGuard g(h->device);
+  WsLease lease(h);
+  if (lease.rc) return lease.rc;
+  HostStatusSlot slot(h);
+  HostIo io;
+  if (int32_t rc = host_io_begin(h, queries, q_stride_bytes, b, top_k, io)) return rc;
+  lease.st = W->io_stream;
+  VERS_HIP_TRY(hipMemsetAsync(W->io_out.p, 0, io.out_bytes, W->io_stream));  // entries past a query's count come back as zeros
+  if (int32_t rc = exhaustive_dev_locked(h, io.q_dev, h->d, b, top_k, metric, io.ids_dev, io.dist_dev, io.cnt_dev, W->io_stream)) return rc;
+  const int32_t rc = host_io_end(h, io, b, top_k, out_ids, out_dist, out_count);
+  return rc == kRetrySpill ? VERS_ERR_INVALID : rc;
+}
+
+}  // extern "C"

@@ -1,5 +1,5 @@
 // kmeans.hpp -- device-level k-means steps shared by kmeans.hip (C ABI primitives) and
-// ivf.hip (build_index).  All pointers are device pointers; nothing synchronises unless noted.
+// ivf_build.hip (build_index).  All pointers are device pointers; nothing synchronises unless noted.
 #pragma once
 #include "common.hpp"
 

@@ -14,7 +14,7 @@
 
 namespace vers {
 
-typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;  // (prescan.hip.h's operand type; that header defines kernels of ivf.hip)
+typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;  // (prescan.hip.h's operand type; that header defines kernels of the index)
 
 // kind 0: f16 32x32x16 | 1: bf16 32x32x16 | 2: f32 32x32x2 | 3: f32 16x16x1, four blocks
 // A [rows][K] row-major, B [K][cols] row-major (rows x cols = 32 x 32; kind 3: 64 x 16), 16-bit operands as bit patterns.
