@@ -162,6 +162,12 @@ int32_t vers_ivf_build_dev(vers_ivf_t* h, const float* rows_dev, uint64_t n, uin
 int32_t vers_ivf_upload(vers_ivf_t* h, const float* rows, uint64_t n, uint64_t row_stride_bytes,
                         const float* centroids, uint64_t k, uint64_t c_stride_bytes,
                         const uint64_t* assignments);
+/* The same from DEVICE-resident fields (a host that keeps `values` in HBM, or re-shards one built index over another
+ * world with vers_ivf_set_shard): rows row-major with pitch ld_floats >= d (a multiple of 4; the padding columns may hold
+ * anything), centroids with pitch c_ld_floats >= d, assignments as the reference's usize = u64.  Synchronous. */
+int32_t vers_ivf_upload_dev(vers_ivf_t* h, const float* rows_dev, uint64_t n, uint64_t ld_floats,
+                            const float* centroids_dev, uint64_t k, uint64_t c_ld_floats,
+                            const uint64_t* assignments_dev);
 /* Index::add (ivfflat.rs:200-213): nearest centroid by first minimum; the new vector gets
  * vec_id = assignments.len() (the reference ignores the caller's vec_id, :209) and is appended
  * to that list.  Returns both so the host can mirror values/assignments/ids. */

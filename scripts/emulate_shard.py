@@ -1,54 +1,99 @@
-"""What ONE rank of an N-GPU sharded search does per step, measured on one GPU: the full cfg3 index is built,
-only the lists LPT gives to rank R of W are kept (vers_ivf_set_shard), and search_partial_dev is timed for the
-full 1024-query batches.  No all-gather / merge (they need the other ranks): add ~0.1 ms for those.
-usage: python scripts/emulate_shard.py W [R]"""
-import os, sys, time
+"""What EVERY rank of a W-GPU sharded search does per step, measured on one GPU (cfg3: N=10M d=768 nlist=4096 nprobe=32,
+batches of 1024).  The index is built ONCE; for every world size W and every rank R of it a fresh handle takes the lists LPT
+deals to (R, W) from the device-resident fields (vers_ivf_set_shard + vers_ivf_upload_dev) and search_partial_dev is timed on
+the full 1024-query batches, one batch in flight and three (what bench.py runs).  A synchronous all-gather makes the step of
+a W-GPU search the SLOWEST rank's: the table reports per-rank step, max and mean, and the rows each rank scanned.
+Not included: the all-gather itself (it needs the other ranks; 160 KiB per rank); the merge of the gathered partials is
+timed on W copies of a rank's own partial.
+usage: python scripts/emulate_shard.py [W ...]        (default 1 2 4 8; env STREAMS="1,3" STEPS=20 OUT=gpurun_out/emulate_shard.json)"""
+import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from tests import datagen as dg
 from vers_amd import capi
 from vers_amd.index import IVFFlatIndex
-W = int(sys.argv[1]); R = int(sys.argv[2]) if len(sys.argv) > 2 else 0
-n, d, nlist, nprobe, B, top_k = 10_000_000, 768, 4096, 32, 1024, 10
+
+worlds = [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]
+n = int(os.environ.get("ROWS", 10_000_000)); d = int(os.environ.get("DIM", 768)); nlist = int(os.environ.get("NLIST", 4096))
+nprobe, B, top_k = 32, int(os.environ.get("BATCH", 1024)), 10
+STREAMS = [int(s) for s in os.environ.get("STREAMS", "1,3").split(",")]
+NSTEP = int(os.environ.get("STEPS", "20"))
+RANKS = os.environ.get("RANKS")  # e.g. "0,3": only these ranks of every world (quick looks)
 dev = torch.device("cuda:0")
 X = torch.empty(n, d, dtype=torch.float32, device=dev)
 capi.gen_rows_dev(X.data_ptr(), n, d, d, 1, 0x5EED0001, 0x5EEDC0DE, 16 * nlist, float(dg.default_sigma(d)))
 init = (dg.mix64(np.uint64(0xB01D) + np.arange(nlist, dtype=np.uint64)) % np.uint64(n)).astype(np.uint64)
-ix = IVFFlatIndex(d, device=0)
-if W > 1: ix.set_shard(R, W)
-ix.build_dev(X.data_ptr(), n, nlist, 1, 4, init)
-del X
-Q = torch.empty(8 * B, d, dtype=torch.float32, device=dev)
-capi.gen_rows_dev(Q.data_ptr(), 8 * B, d, d, 1, 0x5EED0002, 0x5EEDC0DE, 16 * nlist, float(dg.default_sigma(d)))
-NS = int(os.environ.get("STREAMS", "1"))       # batches in flight: step i runs on stream i % NS with its own outputs
-keys_s = [torch.empty(B, top_k, dtype=torch.int64, device=dev) for _ in range(NS)]
-ids_s = [torch.empty(B, top_k, dtype=torch.int64, device=dev) for _ in range(NS)]
-keys, ids = keys_s[0], ids_s[0]
-_stream_objs = [torch.cuda.Stream() for _ in range(NS)] if NS > 1 else []
-streams = [torch.cuda.current_stream().cuda_stream] if NS == 1 else [so.cuda_stream for so in _stream_objs]
-st = streams[0]
-AHEAD = os.environ.get("AHEAD", "0") != "0"   # next batch's coarse quantiser on the side stream (bench.py --ahead)
-def step(i):
-    s = i % NS
-    if AHEAD: ix.coarse_ahead_dev(Q[((i + 1) % 8) * B:].data_ptr(), d, B, nprobe, streams[s])
-    ix.search_partial_dev(Q[(i % 8) * B:].data_ptr(), d, B, top_k, nprobe, keys_s[s].data_ptr(), ids_s[s].data_ptr(), streams[s])
-NSTEP = int(os.environ.get("STEPS", "20"))
-for i in range(6): step(i)
-torch.cuda.synchronize(); ix.scan_times(reset=True); t0 = time.perf_counter()
-for i in range(NSTEP): step(6 + i)
-torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / NSTEP
-# the merge of the gathered partials (vers_topk_merge_dev): W copies of this rank's partial stand in for the all-gather's
-# output -- the kernel's time does not depend on whose keys they are
-allp = torch.empty(W, 2, B, top_k, dtype=torch.int64, device=dev)
-oi = torch.zeros(B, top_k, dtype=torch.int64, device=dev); od = torch.zeros(B, top_k, device=dev); oc = torch.zeros(B, dtype=torch.int32, device=dev)
-for r in range(W): allp[r, 0].copy_(keys); allp[r, 1].copy_(ids)
-torch.cuda.synchronize(); tm0 = time.perf_counter()
-for i in range(50):
-    IVFFlatIndex.merge_partials_dev(allp.data_ptr(), allp.data_ptr() + 8 * B * top_k, 2 * B * top_k, W, B, top_k, nprobe, oi.data_ptr(), od.data_ptr(), oc.data_ptr(), st)
-torch.cuda.synchronize(); t_merge = (time.perf_counter() - tm0) / 50
-for s_ in streams: ix.poll(s_)
-if os.environ.get("VERS_SCAN_DEBUG"): print("last scan:", ix.last_scan())   # (prints the phase stamps with VERS_SCAN_DEBUG=16)
-pst = ix.prescan_stats()
-print(f"world={W} rank={R} streams={NS}: {dt*1e3:.3f} ms per step for this rank (list scan {float(np.mean(ix.scan_times()))*1e3:.0f} us; "
-      f"{pst['fallback_queries']} of {pst['batches'] * B} queries re-scanned exactly); merge of the {W} gathered partials {t_merge*1e6:.0f} us "
-      f"(pipelined launches); all-gather payload {2 * B * top_k * 8} B per rank")
+t0 = time.perf_counter()
+ix0 = IVFFlatIndex(d, device=0)
+ix0.build_dev(X.data_ptr(), n, nlist, 1, 4, init, want_fields=True)
+t_build = time.perf_counter() - t0
+lens = ix0.list_lengths()
+Cd = torch.from_numpy(np.ascontiguousarray(ix0.centroids)).to(dev)
+Ad = torch.from_numpy(ix0.assignments.astype(np.int64)).to(dev)
+ix0.close(); del ix0
+NQB = 8
+Q = torch.empty(NQB * B, d, dtype=torch.float32, device=dev)
+capi.gen_rows_dev(Q.data_ptr(), NQB * B, d, d, 1, 0x5EED0002, 0x5EEDC0DE, 16 * nlist, float(dg.default_sigma(d)))
+max_s = max(STREAMS)
+keys_s = [torch.empty(B, top_k, dtype=torch.int64, device=dev) for _ in range(max_s)]
+ids_s = [torch.empty(B, top_k, dtype=torch.int64, device=dev) for _ in range(max_s)]
+stream_objs = [torch.cuda.Stream() for _ in range(max_s)]
+out = {"config": dict(rows=n, d=d, nlist=nlist, nprobe=nprobe, batch=B, top_k=top_k, steps=NSTEP), "build_s": round(t_build, 2), "worlds": {}}
+for W in worlds:
+    owner = capi.shard_plan(lens, W) if W > 1 else np.zeros(nlist, np.uint8)
+    ranks = range(W) if not RANKS else [int(r) for r in RANKS.split(",") if int(r) < W]
+    rows_w = []
+    for R in ranks:
+        ix = IVFFlatIndex(d, device=0)
+        if W > 1: ix.set_shard(R, W)
+        ix.upload_dev(X.data_ptr(), n, d, Cd.data_ptr(), nlist, d, Ad.data_ptr())
+        rec = {"rank": R, "stored_rows": int(lens[owner == R].sum())}
+        for NS in STREAMS:
+            streams = [torch.cuda.current_stream().cuda_stream] if NS == 1 else [so.cuda_stream for so in stream_objs[:NS]]
+            def step(i):
+                s = i % NS
+                ix.search_partial_dev(Q[(i % NQB) * B:].data_ptr(), d, B, top_k, nprobe, keys_s[s].data_ptr(), ids_s[s].data_ptr(), streams[s])
+            for i in range(6): step(i)
+            torch.cuda.synchronize(); ix.scan_times(reset=True); t0 = time.perf_counter()
+            for i in range(NSTEP): step(6 + i)
+            torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / NSTEP
+            rec[f"step_ms_s{NS}"] = round(dt * 1e3, 4)
+            rec[f"scan_us_s{NS}"] = round(float(np.mean(ix.scan_times())) * 1e3, 1)
+            for s_ in streams: ix.poll(s_)
+        # rows of the batch this rank scanned (the union of its probed lists), averaged over the NQB batches
+        ur = []
+        for i in range(NQB):
+            ix.search_partial_dev(Q[i * B:].data_ptr(), d, B, top_k, nprobe, keys_s[0].data_ptr(), ids_s[0].data_ptr(), torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize(); ur.append(ix.last_scan()["union_rows"])
+        rec["probed_rows"] = int(np.mean(ur))
+        # the merge of the gathered partials (vers_topk_merge_dev): W copies of this rank's partial stand in for the all-gather's output
+        allp = torch.empty(W, 2, B, top_k, dtype=torch.int64, device=dev)
+        oi = torch.zeros(B, top_k, dtype=torch.int64, device=dev); od = torch.zeros(B, top_k, device=dev); oc = torch.zeros(B, dtype=torch.int32, device=dev)
+        for r in range(W): allp[r, 0].copy_(keys_s[0]); allp[r, 1].copy_(ids_s[0])
+        st = torch.cuda.current_stream().cuda_stream
+        torch.cuda.synchronize(); tm0 = time.perf_counter()
+        for i in range(50):
+            IVFFlatIndex.merge_partials_dev(allp.data_ptr(), allp.data_ptr() + 8 * B * top_k, 2 * B * top_k, W, B, top_k, nprobe, oi.data_ptr(), od.data_ptr(), oc.data_ptr(), st)
+        torch.cuda.synchronize(); rec["merge_us"] = round((time.perf_counter() - tm0) / 50 * 1e6, 1)
+        pst = ix.prescan_stats(); rec["rescanned_queries"] = int(pst["fallback_queries"])
+        ix.close(); del ix
+        rows_w.append(rec)
+        print(json.dumps({"world": W, **rec}), flush=True)
+    summ = {"ranks": rows_w}
+    for NS in STREAMS:
+        v = np.array([r[f"step_ms_s{NS}"] for r in rows_w])
+        summ[f"step_ms_s{NS}"] = {"max": float(v.max()), "mean": round(float(v.mean()), 4), "max_over_mean": round(float(v.max() / v.mean()), 3)}
+    pr = np.array([r["probed_rows"] for r in rows_w], dtype=np.float64)
+    summ["probed_rows"] = {"max": int(pr.max()), "mean": int(pr.mean()), "max_over_mean": round(float(pr.max() / pr.mean()), 3)}
+    summ["all_gather_bytes_per_rank"] = 2 * B * top_k * 8
+    out["worlds"][str(W)] = summ
+    print(f"== world {W}: " + "  ".join(f"S={NS}: max {summ[f'step_ms_s{NS}']['max']:.3f} mean {summ[f'step_ms_s{NS}']['mean']:.3f} ms" for NS in STREAMS) +
+          f"  probed rows max/mean {summ['probed_rows']['max_over_mean']}", flush=True)
+if "1" in out["worlds"]:
+    for NS in STREAMS:
+        one = out["worlds"]["1"][f"step_ms_s{NS}"]["max"]
+        out[f"predicted_speedup_s{NS}"] = {w: round(one / out["worlds"][w][f"step_ms_s{NS}"]["max"], 2) for w in out["worlds"]}
+path = os.environ.get("OUT", "gpurun_out/emulate_shard.json")
+os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
+json.dump(out, open(path, "w"), indent=1)
+print(json.dumps({k: v for k, v in out.items() if k.startswith("predicted")}))

@@ -92,3 +92,58 @@ def test_sharded_search_equals_unsharded(world):
     for ix in shards:
         ix.close()
     whole.close()
+
+
+def test_upload_dev_reshards_one_built_index_from_device_fields():
+    """vers_ivf_upload_dev: the device cache from DEVICE-resident values / centroids / assignments (junk in the rows' padding
+    columns), whole and with set_shard for worlds 2 and 4 -- every handle's lists, ids and search results equal the index
+    build_index made (this is how scripts/emulate_shard.py walks every rank of every world over ONE build)."""
+    import torch
+    n, d, k, ld = 2500, 50, 20, 56
+    X = dg.dist_c(0x61, n, d, 25, dg.default_sigma(d))
+    init = mg.init_draws(5, 1, k, n)
+    whole = IVFFlatIndex.build_index(k, 1, 5, X, init_indices=init)
+    Xp = np.full((n, ld), np.nan, dtype=np.float32); Xp[:, :d] = X
+    Xd = torch.from_numpy(Xp).cuda()
+    Cd = torch.from_numpy(np.ascontiguousarray(whole.centroids)).cuda()
+    Ad = torch.from_numpy(whole.assignments.astype(np.int64)).cuda()
+    b, top_k = 21, 10
+    Q = dg.dist_c(0x62, b, d, 25, dg.default_sigma(d))
+    Qd = torch.from_numpy(Q).cuda()
+    for world in (1, 2, 4):
+        shards = []
+        for r in range(world):
+            ix = IVFFlatIndex(d)
+            if world > 1:
+                ix.set_shard(r, world)
+            ix.upload_dev(Xd.data_ptr(), n, ld, Cd.data_ptr(), k, d, Ad.data_ptr())
+            assert np.array_equal(ix.list_lengths(), whole.list_lengths())
+            shards.append(ix)
+        owners = shards[0].owners()
+        for c in range(k):  # stored lists: rows and ids as the reference's ids[c] / values
+            rows, ids = shards[int(owners[c])].get_list(c)
+            assert np.array_equal(ids, np.asarray(whole.ids[c], dtype=np.uint64)) and np.array_equal(bits(rows), bits(X[ids.astype(np.int64)]))
+        for nprobe in (0, 6):
+            keys = torch.empty(world, b, top_k, dtype=torch.int64, device="cuda")
+            ids = torch.empty(world, b, top_k, dtype=torch.int64, device="cuda")
+            for r, ix in enumerate(shards):
+                ix.search_partial_dev(Qd.data_ptr(), d, b, top_k, nprobe, keys[r].data_ptr(), ids[r].data_ptr())
+                ix.poll()
+            oi = torch.zeros(b, top_k, dtype=torch.int64, device="cuda")
+            od = torch.zeros(b, top_k, dtype=torch.float32, device="cuda")
+            oc = torch.zeros(b, dtype=torch.int32, device="cuda")
+            IVFFlatIndex.merge_partials_dev(keys.data_ptr(), ids.data_ptr(), b * top_k, world, b, top_k, nprobe, oi.data_ptr(), od.data_ptr(), oc.data_ptr())
+            torch.cuda.synchronize()
+            wi, wd, wc = whole.search_batch(Q, top_k, nprobe)
+            assert np.array_equal(oc.cpu().numpy(), wc)
+            for q in range(b):
+                c = int(wc[q])
+                assert np.array_equal(oi.cpu().numpy().astype(np.uint64)[q, :c], wi[q, :c]) and np.array_equal(bits(od.cpu().numpy()[q, :c]), bits(wd[q, :c]))
+        for ix in shards:
+            ix.close()
+    # an assignment out of range is refused
+    Ad[7] = k
+    ix = IVFFlatIndex(d)
+    with pytest.raises(capi.VersError):
+        ix.upload_dev(Xd.data_ptr(), n, ld, Cd.data_ptr(), k, d, Ad.data_ptr())
+    ix.close(); whole.close()

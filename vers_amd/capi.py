@@ -50,6 +50,7 @@ SIGNATURES = {
     "vers_ivf_build_dev": (C.c_int32, [_vp, _vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, _vp, _vp, C.c_uint64, _vp,
                                        C.POINTER(C.c_float), C.POINTER(C.c_int32), _vp]),
     "vers_ivf_upload": (C.c_int32, [_vp, _vp, C.c_uint64, C.c_uint64, _vp, C.c_uint64, C.c_uint64, _vp]),
+    "vers_ivf_upload_dev": (C.c_int32, [_vp, _vp, C.c_uint64, C.c_uint64, _vp, C.c_uint64, C.c_uint64, _vp]),
     "vers_ivf_add": (C.c_int32, [_vp, _vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "vers_ivf_search": (C.c_int32, [_vp, _vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, _vp, _vp, _vp]),
     "vers_ivf_search_dev": (C.c_int32, [_vp, _vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, _vp, _vp, _vp, _vp]),

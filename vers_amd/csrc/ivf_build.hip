@@ -107,6 +107,15 @@ __global__ void gather_init_kernel(const float* X, uint32_t ldx, uint32_t d, uin
   C[i] = j < d ? X[(uint64_t)idx[i / ldc] * ldx + j] : 0.0f;
 }
 
+// device-resident `assignments` (usize = u64 in the reference) -> the u32 the kernels use; *bad != 0: one of them is >= k
+__global__ void u64_to_u32_checked_kernel(const uint64_t* in, uint64_t n, uint64_t k, uint32_t* out, uint32_t* bad) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const uint64_t v = in[i];
+  if (v >= k) *bad = 1u;
+  out[i] = (uint32_t)v;
+}
+
 __global__ void u32_to_u64_kernel(const uint32_t* in, uint64_t n, uint64_t* out) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = in[i];
@@ -986,6 +995,34 @@ int32_t vers_ivf_upload(vers_ivf_t* h, const float* rows, uint64_t n, uint64_t r
     VERS_HIP_TRY(hipMemcpy2D(h->centroids.p, (size_t)h->ldx * 4, centroids, c_stride_bytes, (size_t)h->d * 4, k, hipMemcpyHostToDevice));
   }
   return install_index(h, X.as<float>(), h->ldx, n, A.as<uint32_t>(), (uint32_t)k, nullptr);
+}
+
+int32_t vers_ivf_upload_dev(vers_ivf_t* h, const float* rows_dev, uint64_t n, uint64_t ld_floats, const float* centroids_dev, uint64_t k,
+                            uint64_t c_ld_floats, const uint64_t* assignments_dev) {
+  if (!h || (n && (!rows_dev || !assignments_dev)) || (k && !centroids_dev) || ld_floats < (uint64_t)(h ? h->d : 0) || ld_floats % 4 ||
+      ld_floats > 0x3FFFFFFFull || (k && c_ld_floats < (uint64_t)h->d) || n > 0xFFFFFFFFull || k > 0xFFFFFFFFull)
+    return fail(VERS_ERR_INVALID, "vers_ivf_upload_dev: bad arguments (ld_floats must be >= d and a multiple of 4)");
+  std::unique_lock<std::shared_mutex> lk(h->index);
+  DeviceGuard g(h->device);
+  DevBuf A, bad;
+  if (int32_t rc = A.reserve((n ? n : 1) * 4)) return rc;
+  if (int32_t rc = bad.reserve(16)) return rc;
+  VERS_HIP_TRY(hipMemset(bad.p, 0, 16));
+  if (n) {
+    hipLaunchKernelGGL(u64_to_u32_checked_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, assignments_dev, n, k, A.as<uint32_t>(),
+                       bad.as<uint32_t>());
+    VERS_HIP_TRY(hipGetLastError());
+  }
+  uint32_t any_bad = 0;
+  VERS_HIP_TRY(hipMemcpy(&any_bad, bad.p, 4, hipMemcpyDeviceToHost));
+  if (any_bad) return fail(VERS_ERR_INVALID, "vers_ivf_upload_dev: assignment out of range");
+  const size_t cbytes = ((size_t)k * h->ldx ? (size_t)k * h->ldx : 1) * sizeof(float);
+  if (int32_t rc = h->centroids.reserve(cbytes)) return rc;
+  if (k) {
+    VERS_HIP_TRY(hipMemset(h->centroids.p, 0, cbytes));
+    VERS_HIP_TRY(hipMemcpy2D(h->centroids.p, (size_t)h->ldx * 4, centroids_dev, (size_t)c_ld_floats * 4, (size_t)h->d * 4, k, hipMemcpyDeviceToDevice));
+  }
+  return install_index(h, rows_dev, (uint32_t)ld_floats, n, A.as<uint32_t>(), (uint32_t)k, nullptr);
 }
 
 int32_t vers_ivf_add(vers_ivf_t* h, const float* row, uint64_t* out_cluster, uint64_t* out_vec_id) {

@@ -190,16 +190,30 @@ class IVFFlatIndex:
         return c
 
     # device-resident entry points (bench.py): torch tensors are passed as raw pointers
-    def build_dev(self, rows_ptr: int, n: int, num_clusters: int, num_attempts: int, max_iterations: int, init_indices):
+    def build_dev(self, rows_ptr: int, n: int, num_clusters: int, num_attempts: int, max_iterations: int, init_indices,
+                  want_fields: bool = False):
+        """build_index on rows already in HBM.  want_fields: also bring `centroids` and `assignments` (the reference's
+        fields, ivfflat.rs:11-13) back to the host -- what upload_dev / save_index need."""
         init = np.ascontiguousarray(np.asarray(init_indices).reshape(-1), dtype=np.uint64)
         cost = C.c_float(0); kept = C.c_int32(0)
         iters = np.zeros(max(num_attempts, 1), dtype=np.uint64)
         ld = (self.d + 3) // 4 * 4
+        cent = np.zeros((num_clusters, self.d), dtype=np.float32) if want_fields else None
+        asg = np.zeros(max(n, 1), dtype=np.uint64) if want_fields else None
         check(lib().vers_ivf_build_dev(self._h, _vp(rows_ptr), n, ld, num_clusters, num_attempts, max_iterations, _ptr(init),
-                                       None, 0, None, C.byref(cost), C.byref(kept), _ptr(iters)))
+                                       _ptr(cent) if want_fields else None, 4 * self.d if want_fields else 0,
+                                       _ptr(asg) if want_fields else None, C.byref(cost), C.byref(kept), _ptr(iters)))
         self.num_centroids = num_clusters
         self.cost = np.float32(cost.value); self.iterations = iters[:num_attempts]
+        if want_fields and kept.value:
+            self.centroids, self.assignments = cent, asg[:n]
         return bool(kept.value)
+
+    def upload_dev(self, rows_ptr: int, n: int, ld: int, centroids_ptr: int, k: int, c_ld: int, assignments_ptr: int):
+        """Device cache from DEVICE-resident fields (vers_ivf_upload_dev): rows [n][ld] f32, centroids [k][c_ld] f32,
+        assignments [n] u64.  With set_shard only the lists LPT deals to this rank are stored."""
+        check(lib().vers_ivf_upload_dev(self._h, _vp(rows_ptr), n, ld, _vp(centroids_ptr), k, c_ld, _vp(assignments_ptr)))
+        self.num_centroids = k
 
     def search_dev(self, q_ptr: int, ldq: int, b: int, top_k: int, nprobe: int, ids_ptr: int, dist_ptr: int, cnt_ptr: int,
                    stream: int = 0):
