@@ -298,6 +298,31 @@ int32_t vers_topk_merge_dev(const uint64_t* keys_dev, const uint64_t* ids_dev, u
                             uint32_t b, uint32_t top_k, uint32_t nprobe, uint64_t* out_ids_dev,
                             float* out_dist_dev, uint32_t* out_count_dev, void* stream);
 
+/* ---- sharded search WITHOUT the host in the loop ----------------------------------------------------------------
+ * The ONE exchange of a sharded search (all-gather of the per-rank partial top-k) as a stream-ordered
+ * callback: all_gather_async queues, on `stream`, an all-gather of `bytes` bytes per rank from send_dev into recv_dev
+ * ([world][bytes], rank order) and returns without synchronising.  include/vers_comm_rccl.h fills one from an
+ * ncclComm_t (ncclAllGather on the batch's stream: RCCL over xGMI); tests put gloo behind the same signature. */
+typedef struct vers_gather {
+  void* ctx;
+  uint32_t rank, world;
+  int32_t (*all_gather_async)(void* ctx, const void* send_dev, void* recv_dev, uint64_t bytes, void* stream);
+} vers_gather_t;
+/* search_approximate over lists sharded by cluster (vers_ivf_set_shard / vers_ivf_build_sharded_dev), end to end on
+ * `stream`: local partial search -> g->all_gather_async of [2][b][top_k] u64 (keys | ids) -> merge of the world's
+ * partials (vers_topk_merge_dev) into out_*_dev.  Nothing synchronises; the gather buffers belong to the workspace the
+ * call leases (one per stream in flight), so batches kept in flight on several streams overlap.  Every rank must issue
+ * its calls in the same order.  g == NULL: a single process, no exchange (same as vers_ivf_search_dev).  Results are bit-identical to the
+ * unsharded index; statuses latch per stream (vers_ivf_poll). */
+int32_t vers_ivf_search_sharded_dev(vers_ivf_t* h, const vers_gather_t* g, const float* queries_dev, uint64_t ldq_floats,
+                                    uint32_t b, uint32_t top_k, uint32_t nprobe, uint64_t* out_ids_dev,
+                                    float* out_dist_dev, uint32_t* out_count_dev, void* stream);
+/* utils::search_exhaustive (utils.rs:68-82) over the rows sharded across the ranks, the same way. */
+int32_t vers_ivf_search_exhaustive_sharded_dev(vers_ivf_t* h, const vers_gather_t* g, const float* queries_dev,
+                                               uint64_t ldq_floats, uint32_t b, uint32_t top_k, uint32_t metric,
+                                               uint64_t* out_ids_dev, float* out_dist_dev, uint32_t* out_count_dev,
+                                               void* stream);
+
 /* Measurement hook: durations (HIP events on the search's stream) of the two kernels of the most recent batched
  * coarse quantiser -- the queries x centroids contraction on the f32 matrix cores (2*b*k*d flop) and the selection /
  * exact re-score / certificate kernel behind it. */

@@ -39,3 +39,66 @@ def test_torch_comm_rccl_world1_device_buffers():
         assert float(a[3]) == -7.0
     finally:
         dist.destroy_process_group()
+
+
+def test_libvers_rccl_world1_gather_build_callbacks_and_sharded_search():
+    """libvers_rccl.so (include/vers_comm_rccl.h) with a one-rank communicator on the test box's GPU: the library makes its
+    own ncclComm_t from a unique id (no torch.distributed anywhere), the search's exchange is ONE ncclAllGather queued on the
+    caller's stream (vers_gather_t), the build's five callbacks run on device buffers, and vers_ivf_search_sharded_dev /
+    vers_ivf_build_sharded_dev through them equal the plain calls bit for bit.  (Peers: RCCL refuses two ranks on one GPU;
+    worlds 2 and 3 run the same entry points over gloo in test_dist_build_gpu.py.)"""
+    import torch
+    from tests import datagen as dg
+    from tests.golden import make_golden as mg
+    from vers_amd import rccl
+    from vers_amd.index import IVFFlatIndex
+    cm = rccl.RcclComm(rccl.RcclComm.unique_id(), 0, 1, 0)
+    try:
+        g = cm._gather
+        assert (g.rank, g.world) == (0, 1)
+        side = torch.cuda.Stream()
+        a = torch.arange(4096, dtype=torch.float32, device="cuda"); b = torch.zeros(4096, dtype=torch.float32, device="cuda")
+        torch.cuda.synchronize()
+        assert g.all_gather_async(g.ctx, a.data_ptr(), b.data_ptr(), 4096 * 4, side.cuda_stream) == 0
+        side.synchronize()
+        assert torch.equal(a, b)
+        st = cm._comm
+        c = torch.zeros(4096, dtype=torch.float32, device="cuda")
+        assert st.all_gather(st.ctx, a.data_ptr(), c.data_ptr(), 4096 * 4) == 0 and torch.equal(a, c)
+        assert st.broadcast(st.ctx, c.data_ptr(), 4096 * 4, 0) == 0 and torch.equal(a, c)
+        e = torch.zeros(4096, dtype=torch.float32, device="cuda")
+        sb = (C.c_uint64 * 1)(4096 * 4); so = (C.c_uint64 * 1)(0)
+        assert st.all_to_all_v(st.ctx, a.data_ptr(), sb, so, e.data_ptr(), sb, so) == 0 and torch.equal(a, e)
+        # build through the RCCL-backed vers_comm_t (one rank: no callback is needed, the entry point takes it all the same),
+        # then the sharded search entry: partial -> ncclAllGather on the stream -> merge
+        n, d, k = 3000, 64, 16
+        X = dg.dist_c(0xA1, n, d, 40, dg.default_sigma(d))
+        init = mg.init_draws(0xA1, 1, k, n)
+        whole = IVFFlatIndex.build_index(k, 1, 4, X, init_indices=init)
+        ix = IVFFlatIndex(d)
+        Xd = torch.from_numpy(X).cuda()
+        assert ix.build_sharded_dev(Xd.data_ptr(), n, d, 0, n, k, 1, 4, init, cm, want_assignments=True)
+        assert np.array_equal(ix.local_assignments, whole.assignments)
+        b_, top_k = 33, 10
+        Q = dg.dist_c(0xA2, b_, d, 40, dg.default_sigma(d))
+        Qd = torch.from_numpy(Q).cuda()
+        for nprobe in (0, 5):
+            oi = torch.zeros(b_, top_k, dtype=torch.int64, device="cuda"); od = torch.zeros(b_, top_k, device="cuda")
+            oc = torch.zeros(b_, dtype=torch.int32, device="cuda")
+            for rep in range(3):  # (several calls in flight on the stream: the gather buffers are the leased workspace's)
+                ix.search_sharded_dev(cm.gather_ptr(), Qd.data_ptr(), d, b_, top_k, nprobe, oi.data_ptr(), od.data_ptr(), oc.data_ptr(), side.cuda_stream)
+            ix.poll(side.cuda_stream)
+            wi, wd, wc = whole.search_batch(Q, top_k, nprobe)
+            assert np.array_equal(oc.cpu().numpy(), wc)
+            for q in range(b_):
+                c_ = int(wc[q])
+                assert np.array_equal(oi.cpu().numpy().astype(np.uint64)[q, :c_], wi[q, :c_])
+                assert np.array_equal(od.cpu().numpy()[q, :c_].view(np.uint32), wd[q, :c_].view(np.uint32))
+        oi = torch.zeros(b_, top_k, dtype=torch.int64, device="cuda"); od = torch.zeros(b_, top_k, device="cuda"); oc = torch.zeros(b_, dtype=torch.int32, device="cuda")
+        ix.search_exhaustive_sharded_dev(cm.gather_ptr(), Qd.data_ptr(), d, b_, top_k, 0, oi.data_ptr(), od.data_ptr(), oc.data_ptr(), side.cuda_stream)
+        ix.poll(side.cuda_stream)
+        wi, wd, wc = whole.search_exhaustive(Q, top_k)
+        assert np.array_equal(oi.cpu().numpy().astype(np.uint64), wi) and np.array_equal(od.cpu().numpy().view(np.uint32), wd.view(np.uint32))
+        ix.close(); whole.close()
+    finally:
+        cm.close()

@@ -36,7 +36,7 @@ def worker(rank, world, port, force_mfma, ret, shape="small"):
     from tests import datagen as dg
     from tests.golden import make_golden as mg
     from vers_amd import capi
-    from vers_amd.dist import TorchComm, all_gather_partials
+    from vers_amd.dist import TorchComm, TorchGather, all_gather_partials
     from vers_amd.index import IVFFlatIndex
     cuts = ranges(world)
     lo, hi = cuts[rank], cuts[rank + 1]
@@ -57,6 +57,7 @@ def worker(rank, world, port, force_mfma, ret, shape="small"):
     Q = dg.dist_c(0xD2, 40, D, 210, dg.default_sigma(D))
     Qd = torch.from_numpy(Q).cuda()
     res = {}
+    gather = TorchGather(device=0)
     for nprobe, top_k in [(0, 10), (6, 10)]:
         part = torch.empty(2, 40, top_k, dtype=torch.int64, device="cuda")
         ix.search_partial_dev(Qd.data_ptr(), D, 40, top_k, nprobe, part[0].data_ptr(), part[1].data_ptr())
@@ -68,6 +69,28 @@ def worker(rank, world, port, force_mfma, ret, shape="small"):
                                         oi.data_ptr(), od.data_ptr(), oc.data_ptr())
         torch.cuda.synchronize()
         res[nprobe] = (oi.cpu().numpy().astype(np.uint64), od.cpu().numpy().view(np.uint32), oc.cpu().numpy())
+        # the same through vers_ivf_search_sharded_dev: partial -> the exchange callback (gloo behind vers_gather_t) -> merge, one call
+        si = torch.zeros(40, top_k, dtype=torch.int64, device="cuda"); sd = torch.zeros(40, top_k, device="cuda")
+        sc = torch.zeros(40, dtype=torch.int32, device="cuda")
+        side = torch.cuda.Stream()
+        ix.search_sharded_dev(gather.ptr(), Qd.data_ptr(), D, 40, top_k, nprobe, si.data_ptr(), sd.data_ptr(), sc.data_ptr(), side.cuda_stream)
+        ix.poll(side.cuda_stream)
+        assert torch.equal(sc, oc)
+        for q in range(40):
+            c = int(oc[q])
+            assert torch.equal(si[q, :c], oi[q, :c]) and torch.equal(sd[q, :c].view(torch.int32), od[q, :c].view(torch.int32)), (rank, nprobe, q)
+    # brute force over the row shards through the same exchange == the gathered partials merged by hand
+    part = torch.empty(2, 40, 10, dtype=torch.int64, device="cuda")
+    ix.search_exhaustive_partial_dev(Qd.data_ptr(), D, 40, 10, capi.METRIC_L2SQ, part[0].data_ptr(), part[1].data_ptr())
+    ix.poll()
+    allp = all_gather_partials(part.cpu()).cuda()
+    oi = torch.zeros(40, 10, dtype=torch.int64, device="cuda"); od = torch.zeros(40, 10, device="cuda"); oc = torch.zeros(40, dtype=torch.int32, device="cuda")
+    IVFFlatIndex.merge_partials_dev(allp.data_ptr(), allp.data_ptr() + 8 * 40 * 10, 2 * 40 * 10, world, 40, 10, 1, oi.data_ptr(), od.data_ptr(), oc.data_ptr())
+    si = torch.zeros(40, 10, dtype=torch.int64, device="cuda"); sd = torch.zeros(40, 10, device="cuda"); sc = torch.zeros(40, dtype=torch.int32, device="cuda")
+    ix.search_exhaustive_sharded_dev(gather.ptr(), Qd.data_ptr(), D, 40, 10, capi.METRIC_L2SQ, si.data_ptr(), sd.data_ptr(), sc.data_ptr())
+    ix.poll(); torch.cuda.synchronize()
+    assert torch.equal(si, oi) and torch.equal(sd.view(torch.int32), od.view(torch.int32)) and torch.equal(sc, oc)
+    assert gather.calls == 3
     ret[rank] = dict(kept=kept, cent=np.ascontiguousarray(ix.get_centroids()).view(np.uint32).copy(), asg=ix.local_assignments.copy(),
                      cost=np.float32(ix.cost).view(np.uint32), iters=ix.iterations.copy(), lens=lens, own=own, lists=lists,
                      peak=peak, res=res, calls=dict(comm.calls), bytes=dict(comm.bytes))

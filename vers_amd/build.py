@@ -38,6 +38,25 @@ def _stale(target: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps)
 
 
+RCCL_SRC = os.path.join(CSRC, "rccl", "vers_comm_rccl.hip")
+RCCL_LIB = os.path.join(LIBDIR, "libvers_rccl.so")
+
+
+def build_rccl(force: bool = False, verbose: bool = False) -> str:
+    """libvers_rccl.so: the optional RCCL adapter (include/vers_comm_rccl.h).  Links librccl; libvers_hip.so does not."""
+    os.makedirs(LIBDIR, exist_ok=True)
+    deps = [RCCL_SRC, os.path.join(os.path.dirname(_HERE), "include", "vers_comm_rccl.h"),
+            os.path.join(os.path.dirname(_HERE), "include", "vers_hip.h")]
+    if force or _stale(RCCL_LIB, deps):
+        rocm_lib = os.path.join(os.path.dirname(os.path.dirname(_hipcc())), "lib")
+        cmd = [_hipcc(), "-O2", "-std=c++17", "-fPIC", "-shared", f"--offload-arch={ARCH}", "-Wall", RCCL_SRC, "-o", RCCL_LIB,
+               f"-L{rocm_lib}", "-lrccl", f"-Wl,-rpath,{rocm_lib}"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return RCCL_LIB
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(LIBDIR, exist_ok=True)
     os.makedirs(OBJDIR, exist_ok=True)
@@ -65,6 +84,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
+    build_rccl(force, verbose)
     return LIB
 
 

@@ -67,6 +67,8 @@ SIGNATURES = {
     "vers_ivf_coarse_ahead_dev": (C.c_int32, [_vp, _vp, C.c_uint64, C.c_uint32, C.c_uint32, _vp]),
     "vers_ivf_search_exhaustive_partial_dev": (C.c_int32, [_vp, _vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, _vp, _vp, _vp]),
     "vers_ivf_search_partial_dev": (C.c_int32, [_vp, _vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, _vp, _vp, _vp]),
+    "vers_ivf_search_sharded_dev": (C.c_int32, [_vp, _vp, _vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, _vp, _vp, _vp, _vp]),
+    "vers_ivf_search_exhaustive_sharded_dev": (C.c_int32, [_vp, _vp, _vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, _vp, _vp, _vp, _vp]),
     "vers_topk_merge_dev": (C.c_int32, [_vp, _vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _vp, _vp, _vp, _vp]),
     "vers_ivf_last_coarse_ms": (C.c_int32, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
     "vers_ivf_coarse_stats": (C.c_int32, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),

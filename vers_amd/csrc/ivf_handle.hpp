@@ -42,6 +42,7 @@ struct SearchWs {
   DevBuf seg_bounds, stamps, quad_counter, fb_part, fb_ctr, c1_ctr;  // (c1_ctr: coarse1_kernel's finished-blocks counter)
   DevBuf clower, lower;  // lower bounds of multi-pass results (coarse ranking of more than 64 lists; top_k > 64)
   DevBuf qp, qil, cpart, probe, pj, lists, pairs, items, groups, qblocks, partials, status, o_ids, o_dist, o_cnt, xpart;
+  DevBuf g_send, g_recv;  // sharded search without the host in the loop: this rank's [2][b][top_k] partial | the world's
   static constexpr uint32_t kEvRing = 64;  // scan-launch timing ring (measurement hook)
   hipEvent_t ev0[kEvRing] = {}, ev1[kEvRing] = {};
   hipEvent_t evc[3] = {};  // batched coarse quantiser of the most recent search: before the GEMM | after it | after select / re-score

@@ -588,6 +588,67 @@ int32_t vers_ivf_search_partial_dev(vers_ivf_t* h, const float* queries_dev, uin
                            out_keys_dev, (hipStream_t)stream);
 }
 
+// partial search / partial exhaustive scan -> the one exchange -> merge, all on `stream` (vers_hip.h: vers_gather_t)
+static int32_t sharded_common(vers_ivf_t* h, const vers_gather_t* g, const float* queries_dev, uint64_t ldq_floats, uint32_t b, uint32_t top_k,
+                              uint32_t nprobe, int exhaustive_metric, uint64_t* out_ids_dev, float* out_dist_dev, uint32_t* out_count_dev, void* stream) {
+  const char* who = exhaustive_metric >= 0 ? "vers_ivf_search_exhaustive_sharded_dev" : "vers_ivf_search_sharded_dev";
+  if (!h) return fail(VERS_ERR_INVALID, "null handle");
+  if (top_k == 0) return fail(VERS_ERR_INVALID, std::string(who) + ": top_k must be at least 1");
+  if (b && (!queries_dev || ldq_floats < h->d || !out_ids_dev || !out_dist_dev || !out_count_dev))
+    return fail(VERS_ERR_INVALID, std::string(who) + ": bad arguments");
+  if (exhaustive_metric > (int)VERS_METRIC_COSDIST) return fail(VERS_ERR_INVALID, "unknown metric");
+  const uint32_t world = g ? g->world : 1u;
+  if (g && (g->world == 0 || g->rank >= g->world || (g->world > 1 && !g->all_gather_async))) return fail(VERS_ERR_INVALID, std::string(who) + ": incomplete vers_gather_t");
+  if (b == 0) return VERS_OK;
+  std::shared_lock<std::shared_mutex> lk(h->index);
+  if (world != h->world || (g && world > 1 && g->rank != h->rank))
+    return fail(VERS_ERR_INVALID, std::string(who) + ": the handle is sharded as rank " + std::to_string(h->rank) + " of " + std::to_string(h->world) + ", the exchange says otherwise");
+  DeviceGuard gd(h->device);
+  hipStream_t st = (hipStream_t)stream;
+  WsLease lease(h, true, st);
+  if (lease.rc) return lease.rc;
+  if (int32_t rc = lease.order_on(st)) return rc;
+  const size_t part = (size_t)b * top_k;  // keys | ids of one rank
+  if (int32_t rc = W->g_send.reserve(2 * part * sizeof(uint64_t))) return rc;
+  if (int32_t rc = W->g_recv.reserve((size_t)world * 2 * part * sizeof(uint64_t))) return rc;
+  // (no exchange -- g == nullptr, a single process: the partial is the gathered buffer.  A one-rank communicator still gathers:
+  // the call is the same code path as with peers, which is how the RCCL leg is tested on a one-GPU box)
+  const bool exchange = g != nullptr && g->all_gather_async != nullptr;
+  uint64_t* mine = exchange ? W->g_send.as<uint64_t>() : W->g_recv.as<uint64_t>();
+  if (exhaustive_metric >= 0) {
+    if (int32_t rc = ensure_out(h, part, b)) return rc;
+    if (int32_t rc = exhaustive_dev_locked(h, queries_dev, ldq_floats, b, top_k, (uint32_t)exhaustive_metric, W->o_ids.as<uint64_t>(), W->o_dist.as<float>(),
+                                           W->o_cnt.as<uint32_t>(), st)) return rc;
+    hipLaunchKernelGGL(pack_exhaustive_keys_kernel, dim3((unsigned)((part + 255) / 256)), dim3(256), 0, st, (const uint64_t*)W->o_ids.as<uint64_t>(),
+                       (const float*)W->o_dist.as<float>(), (const uint32_t*)W->o_cnt.as<uint32_t>(), b, top_k, mine, mine + part);
+    VERS_HIP_TRY(hipGetLastError());
+  } else {
+    if (int32_t rc = ensure_out(h, part, b)) return rc;
+    if (int32_t rc = search_dev_locked(h, queries_dev, ldq_floats, b, top_k, nprobe, mine + part, W->o_dist.as<float>(), W->o_cnt.as<uint32_t>(), mine, st))
+      return rc;
+  }
+  if (exchange) {
+    if (int32_t rc = g->all_gather_async(g->ctx, W->g_send.p, W->g_recv.p, 2 * part * sizeof(uint64_t), stream))
+      return fail(VERS_ERR_COMM, "vers_gather_t::all_gather_async reported failure (status " + std::to_string(rc) + ")");
+  }
+  hipLaunchKernelGGL(rank_merge_kernel, dim3(b), dim3(kWave), 0, st, (const uint64_t*)W->g_recv.as<uint64_t>(), (const uint64_t*)W->g_recv.as<uint64_t>() + part,
+                     (uint64_t)(2 * part), world, b, top_k, (exhaustive_metric < 0 && nprobe == 0) ? 1 : 0, out_ids_dev, out_dist_dev, out_count_dev);
+  VERS_HIP_TRY(hipGetLastError());
+  return VERS_OK;
+}
+
+int32_t vers_ivf_search_sharded_dev(vers_ivf_t* h, const vers_gather_t* g, const float* queries_dev, uint64_t ldq_floats, uint32_t b, uint32_t top_k,
+                                    uint32_t nprobe, uint64_t* out_ids_dev, float* out_dist_dev, uint32_t* out_count_dev, void* stream) {
+  return sharded_common(h, g, queries_dev, ldq_floats, b, top_k, nprobe, -1, out_ids_dev, out_dist_dev, out_count_dev, stream);
+}
+
+int32_t vers_ivf_search_exhaustive_sharded_dev(vers_ivf_t* h, const vers_gather_t* g, const float* queries_dev, uint64_t ldq_floats, uint32_t b,
+                                               uint32_t top_k, uint32_t metric, uint64_t* out_ids_dev, float* out_dist_dev, uint32_t* out_count_dev,
+                                               void* stream) {
+  if (metric > VERS_METRIC_COSDIST) return fail(VERS_ERR_INVALID, "unknown metric");
+  return sharded_common(h, g, queries_dev, ldq_floats, b, top_k, 1, (int)metric, out_ids_dev, out_dist_dev, out_count_dev, stream);
+}
+
 int32_t vers_ivf_coarse_ahead_dev(vers_ivf_t* h, const float* queries_dev, uint64_t ldq_floats, uint32_t b, uint32_t nprobe, void* stream) {
   if (!h) return fail(VERS_ERR_INVALID, "null handle");
   if (b && (!queries_dev || ldq_floats < h->d)) return fail(VERS_ERR_INVALID, "vers_ivf_coarse_ahead_dev: bad arguments");

@@ -146,7 +146,12 @@ static __global__ void blocked_row_norms_kernel(const float* rows, uint32_t ld, 
 // close to the query's global one.  (With a list per wave the shared threshold stalled near "the kp-th of the best
 // 220 rows": ~900 inserts per query and batch instead of the ~170 a perfectly shared threshold needs; inserts
 // were 0.38 ms of 5.3 ms.)  One partial slot per (query, list, quad) goes to the exact finish.
-constexpr int kPreWavesG = 8;  // 4 items x 2 waves
+#ifndef VERS_PRE_WAVES
+#define VERS_PRE_WAVES 8
+#endif
+constexpr int kPreWavesG = VERS_PRE_WAVES;  // 4 items x kPreParts waves (8: two per SIMD, <= 256 registers; 12: three per SIMD, <= 168)
+constexpr int kPreParts = kPreWavesG / 4;   // waves that share a segment: each walks a contiguous share of its tiles
+static_assert(kPreWavesG % 4 == 0 && kPreWavesG >= 4 && kPreWavesG <= 16, "a quad of segments x 1..4 waves each");
 // Candidate buffer of a query in LDS: `cap` unsorted keys.  kp <= 40 (top_k <= 30 with the default slack): 64 keys, one
 // wave-wide bitonic sort compacts it; wider lists: 128 keys (two sorts + a bitonic merge).  At least 24 free slots after
 // every compaction.
@@ -193,8 +198,9 @@ template <bool BF, class Src, class Stage>
 __device__ __forceinline__ void prescan_item_g(const Src& src, const PreParams& p, uint32_t it, const ItemView<kPreQ>& v, int half, int lane,
                                                const float* qm, uint64_t* cbuf, uint32_t* ctl, Stage&& stage) {
   const uint32_t n_tiles = (v.nrows + kWave - 1) / kWave;
-  const uint32_t t_half = (n_tiles + 1) / 2;
-  const uint32_t t_begin = half ? t_half : 0u, t_end = half ? n_tiles : t_half;
+  const uint32_t t_per = (n_tiles + kPreParts - 1) / kPreParts;  // (half = the wave's index among those of its segment)
+  const uint32_t t_begin = (uint32_t)half * t_per < n_tiles ? (uint32_t)half * t_per : n_tiles;
+  const uint32_t t_end = t_begin + t_per < n_tiles ? t_begin + t_per : n_tiles;
   if (t_begin >= t_end) {  // padding item, or a one-tile item's second half (wave-uniform): only the block-wide part
     stage();
     return;
@@ -262,7 +268,7 @@ __device__ __forceinline__ void prescan_item_g(const Src& src, const PreParams& 
   bool bad = false;
   // The eight waves of the block walk their tiles at the same pace and meet the same full buffers: every wave starts
   // its round over the overflowed query columns at its own offset, so that they do not all queue for the same lock.
-  const int rot = (int)(((it & 3u) << 1 | (uint32_t)half) << 1);
+  const int rot = (int)(((it & 3u) * (uint32_t)kPreParts + (uint32_t)half) << 1);
 
   // End of a tile for query set S: acc already holds val (the |x|^2 term went through the matrix core).  Each lane holds
   // 16 vals of ONE query column (lane & 15), rows 16*(e>>2) + 4*quarter + (e&3): one compare per register against the
@@ -492,7 +498,7 @@ __device__ __forceinline__ void prescan_item_g(const Src& src, const PreParams& 
 }
 
 template <bool BF, class Src>
-__global__ __launch_bounds__(kWave * kPreWavesG) __attribute__((amdgpu_waves_per_eu(2, 2))) void prescan_kernel_g(Src src, PreParams p) {
+__global__ __launch_bounds__(kWave * kPreWavesG) __attribute__((amdgpu_waves_per_eu(kPreWavesG / 4, kPreWavesG / 4))) void prescan_kernel_g(Src src, PreParams p) {
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   extern __shared__ __attribute__((aligned(16))) float qlds[];
@@ -559,7 +565,7 @@ __global__ __launch_bounds__(kWave * kPreWavesG) __attribute__((amdgpu_waves_per
       // the first kStageU loads of every thread go out BEFORE the barriers (they fly while the slowest wave of the
       // previous quad finishes and its lists are written out); one load at a time behind the barriers was ~7 us per
       // quad at d = 768 -- 7 % of the launch
-      constexpr int kStageU = 12;
+      constexpr int kStageU = 96 / kPreWavesG;  // (x the block's threads / 32 slots = 192 column groups: d <= 768 in one round)
       const uint32_t n_cg = p.ld / 4u;
       f32x4 x[kStageU];
 #pragma unroll

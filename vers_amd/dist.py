@@ -196,3 +196,55 @@ class TorchComm:
             if self._staged() and r_tot:
                 r.copy_(hr)
         return self._guard("all_to_all_v", sum(sb), run)
+
+
+# ---- vers_gather_t (include/vers_hip.h): the ONE exchange of vers_ivf_search_sharded_dev --------------------------------------
+_GA = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p)
+
+
+class VersGather(C.Structure):
+    _fields_ = [("ctx", C.c_void_p), ("rank", C.c_uint32), ("world", C.c_uint32), ("all_gather_async", _GA)]
+
+
+class TorchGather:
+    """vers_gather_t over a torch.distributed process group -- the stand-in for libvers_rccl.so's ncclAllGather where RCCL
+    cannot run (tests: several ranks sharing one GPU over gloo; CPU-only runs with device=None).  NOT stream-ordered like the
+    real one: it waits for `stream`, moves the bytes through host memory and returns with them in place -- same results,
+    none of the overlap.  backend nccl: all_gather_into_tensor on the raw device pointers (torch's own stream + a wait)."""
+
+    def __init__(self, device, group=None):
+        self.device, self.group = device, group
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        self.backend = dist.get_backend(group)
+        self.calls = 0
+        self._cb = _GA(self._gather)
+        self.struct = VersGather(None, self.rank, self.world, self._cb)
+
+    def ptr(self):
+        return C.cast(C.byref(self.struct), C.c_void_p)
+
+    def _gather(self, _ctx, send_ptr, recv_ptr, nbytes, stream):
+        try:
+            self.calls += 1
+            if self.device is None:  # host pointers (CPU tests of the protocol)
+                s = torch.from_numpy(np.ctypeslib.as_array(C.cast(send_ptr, C.POINTER(C.c_uint8)), shape=(nbytes,)))
+                r = torch.from_numpy(np.ctypeslib.as_array(C.cast(recv_ptr, C.POINTER(C.c_uint8)), shape=(nbytes * self.world,)))
+                dist.all_gather_into_tensor(r, s, group=self.group)
+                return 0
+            dev = torch.device("cuda", self.device)
+            ext = torch.cuda.ExternalStream(int(stream or 0), device=dev) if stream else torch.cuda.default_stream(dev)
+            s = torch.as_tensor(_Mem(send_ptr, nbytes), device=dev); r = torch.as_tensor(_Mem(recv_ptr, nbytes * self.world), device=dev)
+            ext.synchronize()  # the partial search queued on `stream` has written the send buffer
+            if self.backend == "nccl":
+                dist.all_gather_into_tensor(r, s, group=self.group)
+                torch.cuda.synchronize(dev)
+            else:
+                hr = torch.empty(nbytes * self.world, dtype=torch.uint8)
+                dist.all_gather_into_tensor(hr, s.cpu(), group=self.group)
+                with torch.cuda.stream(ext):
+                    r.copy_(hr)
+                ext.synchronize()
+            return 0
+        except Exception as e:  # never unwind through the C frame
+            print(f"[vers gather] failed on rank {self.rank}: {e!r}", file=sys.stderr, flush=True)
+            return 1

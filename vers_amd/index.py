@@ -247,6 +247,19 @@ class IVFFlatIndex:
             self.local_assignments = asg[:n_local]
         return bool(kept.value)
 
+    def search_sharded_dev(self, gather_ptr, q_ptr: int, ldq: int, b: int, top_k: int, nprobe: int, ids_ptr: int, dist_ptr: int,
+                           cnt_ptr: int, stream: int = 0):
+        """search_approximate over lists sharded by cluster, end to end on `stream` (vers_ivf_search_sharded_dev): partial
+        search -> ONE all-gather (gather_ptr: vers_amd.rccl.RcclComm.gather_ptr() = ncclAllGather on the stream, or
+        dist.TorchGather.ptr()) -> merge.  No host synchronisation."""
+        check(lib().vers_ivf_search_sharded_dev(self._h, gather_ptr, _vp(q_ptr), ldq, b, top_k, nprobe, _vp(ids_ptr), _vp(dist_ptr),
+                                                _vp(cnt_ptr), _vp(stream)))
+
+    def search_exhaustive_sharded_dev(self, gather_ptr, q_ptr: int, ldq: int, b: int, top_k: int, metric: int, ids_ptr: int,
+                                      dist_ptr: int, cnt_ptr: int, stream: int = 0):
+        check(lib().vers_ivf_search_exhaustive_sharded_dev(self._h, gather_ptr, _vp(q_ptr), ldq, b, top_k, metric, _vp(ids_ptr),
+                                                           _vp(dist_ptr), _vp(cnt_ptr), _vp(stream)))
+
     def owners(self):
         _, k, _ = self.info()
         o = np.zeros(max(k, 1), dtype=np.uint8)
