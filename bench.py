@@ -193,13 +193,33 @@ def main():
     st = torch.cuda.current_stream().cuda_stream   # the untimed legs below run one call at a time on the default stream
     torch.cuda.synchronize()
 
+    # The ONE collective per batch.  Default on the GPUs: the library drives RCCL itself (libvers_rccl.so: ncclAllGather queued on
+    # the batch's own stream inside vers_ivf_search_sharded_dev -- no host synchronisation, no second stream, no Python between
+    # the partial search and the merge).  VERS_BENCH_EXCHANGE=torch: the round-3 path (torch.distributed all_gather_into_tensor
+    # between two library calls).  gloo (debugging on fewer GPUs than ranks): the same entry point with gloo behind vers_gather_t.
+    gather, exchange_kind = None, None
+    if world > 1:
+        want = os.environ.get("VERS_BENCH_EXCHANGE", "rccl" if backend == "nccl" else "gloo")
+        if want == "rccl" and backend == "nccl":
+            try:
+                from vers_amd.rccl import RcclComm
+                gather = RcclComm.from_torch(dev_index)
+                exchange_kind = "libvers_rccl.so: ncclAllGather on the batch's stream (vers_ivf_search_sharded_dev)"
+            except Exception as e:  # (the library or RCCL refused: the torch path still measures the same step)
+                log(f"[bench] rank {rank}: RCCL adapter unavailable ({e!r}); falling back to torch.distributed for the exchange")
+            ok_all = torch.tensor([1 if gather is not None else 0], device=dev)
+            dist.all_reduce(ok_all, op=dist.ReduceOp.MIN)   # every rank takes the same path
+            if int(ok_all.item()) == 0:
+                gather = None
+        elif want == "gloo" or backend != "nccl":
+            from vers_amd.dist import TorchGather
+            gather = TorchGather(device=dev_index)
+            exchange_kind = f"vers_gather_t over torch.distributed/{backend} staged through host memory (vers_ivf_search_sharded_dev)"
+        if gather is None:
+            exchange_kind = "torch.distributed all_gather_into_tensor between vers_ivf_search_partial_dev and vers_topk_merge_dev"
+
     def exchange(o):
-        if backend == "nccl":
-            dist.all_gather_into_tensor(o["allp"], o["part"])                   # the ONE collective per batch (RCCL), on the batch's stream
-        else:
-            h = [torch.empty(2, B, top_k, dtype=torch.int64) for _ in range(world)]
-            dist.all_gather(h, o["part"].cpu())
-            o["allp"].copy_(torch.stack(h).to(dev))
+        dist.all_gather_into_tensor(o["allp"], o["part"])                   # (the torch path: RCCL through ProcessGroupNCCL)
 
     def step(i, S=S):
         qb = Q[(i % n_batches) * B:]
@@ -210,6 +230,9 @@ def main():
                 index.coarse_ahead_dev(Q[((i + 1) % n_batches) * B:].data_ptr(), ld, B, nprobe, sh)
             if world == 1:
                 index.search_dev(qb.data_ptr(), ld, B, top_k, nprobe, o["ids"].data_ptr(), o["dst"].data_ptr(), o["cnt"].data_ptr(), sh)
+            elif gather is not None:
+                index.search_sharded_dev(gather.gather_ptr() if hasattr(gather, "gather_ptr") else gather.ptr(), qb.data_ptr(), ld, B, top_k, nprobe,
+                                         o["ids"].data_ptr(), o["dst"].data_ptr(), o["cnt"].data_ptr(), sh)
             else:
                 index.search_partial_dev(qb.data_ptr(), ld, B, top_k, nprobe, o["part"][0].data_ptr(), o["part"][1].data_ptr(), sh)
                 exchange(o)
@@ -812,7 +835,8 @@ def main():
                "config": {"workload": f"IVFFlat search_approximate, {'nprobe extension' if nprobe else 'reference mode (nearest list + spill)'}: N={n} d={d} nlist={nlist} nprobe={nprobe} "
                                       f"batch={B} top_k={top_k}, f32, clustered unit vectors (Dist-C)",
                           "n": n, "d": d, "nlist": nlist, "nprobe": nprobe, "batch": B, "top_k": top_k,
-                          "kmeans_iters": int(index.iterations[0]), "parallelism": f"lists sharded over {world} GPU(s)", "batches_in_flight": S},
+                          "kmeans_iters": int(index.iterations[0]), "parallelism": f"lists sharded over {world} GPU(s)", "batches_in_flight": S,
+                          "exchange": exchange_kind},
                "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_all_cores": cpu_all, "cpu_baseline_kmeans": cpu_km, "extra": extra}
         if shadow and "list_scan_f32_rows" in extra:
             out["value_f32_rows"] = extra["list_scan_f32_rows"]["whole_step_queries_per_sec"]  # the same steps with VERS_SHADOW=0, timed like the headline, after it

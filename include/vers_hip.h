@@ -298,6 +298,11 @@ int32_t vers_topk_merge_dev(const uint64_t* keys_dev, const uint64_t* ids_dev, u
                             uint32_t b, uint32_t top_k, uint32_t nprobe, uint64_t* out_ids_dev,
                             float* out_dist_dev, uint32_t* out_count_dev, void* stream);
 
+/* Bytes of the three copies of the stored rows this handle holds: the f32 tiles (always), the fp16 shadow the batched
+ * list scan streams (vers_ivf_shadow_state), the row-major f32 copy the exact finish gathers from (kept whenever the rows
+ * take at most a quarter of the device's memory; VERS_ROWMAJOR=0 switches it off).  0 = that copy does not exist. */
+int32_t vers_ivf_layout_bytes(vers_ivf_t* h, uint64_t* out_rows, uint64_t* out_shadow, uint64_t* out_rowmajor);
+
 /* ---- sharded search WITHOUT the host in the loop ----------------------------------------------------------------
  * The ONE exchange of a sharded search (all-gather of the per-rank partial top-k) as a stream-ordered
  * callback: all_gather_async queues, on `stream`, an all-gather of `bytes` bytes per rank from send_dev into recv_dev
@@ -327,6 +332,9 @@ int32_t vers_ivf_search_exhaustive_sharded_dev(vers_ivf_t* h, const vers_gather_
  * coarse quantiser -- the queries x centroids contraction on the f32 matrix cores (2*b*k*d flop) and the selection /
  * exact re-score / certificate kernel behind it. */
 int32_t vers_ivf_last_coarse_ms(vers_ivf_t* h, float* out_gemm_ms, float* out_select_ms);
+/* Measurement hook: duration (HIP events on the search's stream) of the exact finish -- ivf_rescore_kernel: merge of the
+ * partial candidate lists, certificate, exact re-score of the survivors, emit -- of the most recent matrix-core batch. */
+int32_t vers_ivf_last_finish_ms(vers_ivf_t* h, float* out_ms);
 /* Batched coarse quantiser statistics: batches that went through the MFMA pre-selection (f32 matrix cores +
  * exact re-score + certificate, csrc/gemm.hip.h) and queries whose certificate failed and were re-done exactly. */
 int32_t vers_ivf_coarse_stats(vers_ivf_t* h, uint64_t* out_mfma_batches, uint64_t* out_fallback_queries);

@@ -3,8 +3,10 @@ batches of 1024).  The index is built ONCE; for every world size W and every ran
 deals to (R, W) from the device-resident fields (vers_ivf_set_shard + vers_ivf_upload_dev) and search_partial_dev is timed on
 the full 1024-query batches, one batch in flight and three (what bench.py runs).  A synchronous all-gather makes the step of
 a W-GPU search the SLOWEST rank's: the table reports per-rank step, max and mean, and the rows each rank scanned.
-Not included: the all-gather itself (it needs the other ranks; 160 KiB per rank); the merge of the gathered partials is
-timed on W copies of a rank's own partial.
+The step includes the exchange's LAUNCH and the merge: after the partial search a one-rank RCCL communicator (libvers_rccl.so)
+gathers the rank's 160 KiB partial on the batch's stream -- RCCL's launch path and a local copy: what the all-gather costs a
+rank before the bytes of its 7 peers travel (those need the other GPUs) -- and vers_topk_merge_dev merges W partials
+(EXCHANGE=0: the partial search alone, as in round 3).
 usage: python scripts/emulate_shard.py [W ...]        (default 1 2 4 8; env STREAMS="1,3" STEPS=20 OUT=gpurun_out/emulate_shard.json)"""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -18,6 +20,7 @@ n = int(os.environ.get("ROWS", 10_000_000)); d = int(os.environ.get("DIM", 768))
 nprobe, B, top_k = 32, int(os.environ.get("BATCH", 1024)), 10
 STREAMS = [int(s) for s in os.environ.get("STREAMS", "1,3").split(",")]
 NSTEP = int(os.environ.get("STEPS", "20"))
+EXCHANGE = os.environ.get("EXCHANGE", "1") != "0"
 RANKS = os.environ.get("RANKS")  # e.g. "0,3": only these ranks of every world (quick looks)
 dev = torch.device("cuda:0")
 X = torch.empty(n, d, dtype=torch.float32, device=dev)
@@ -35,10 +38,15 @@ NQB = 8
 Q = torch.empty(NQB * B, d, dtype=torch.float32, device=dev)
 capi.gen_rows_dev(Q.data_ptr(), NQB * B, d, d, 1, 0x5EED0002, 0x5EEDC0DE, 16 * nlist, float(dg.default_sigma(d)))
 max_s = max(STREAMS)
-keys_s = [torch.empty(B, top_k, dtype=torch.int64, device=dev) for _ in range(max_s)]
-ids_s = [torch.empty(B, top_k, dtype=torch.int64, device=dev) for _ in range(max_s)]
+part_s = [torch.empty(2, B, top_k, dtype=torch.int64, device=dev) for _ in range(max_s)]   # [keys | ids] of this rank
+keys_s = [p_[0] for p_ in part_s]; ids_s = [p_[1] for p_ in part_s]
+res_s = [(torch.zeros(B, top_k, dtype=torch.int64, device=dev), torch.zeros(B, top_k, device=dev), torch.zeros(B, dtype=torch.int32, device=dev)) for _ in range(max_s)]
+gat = None
+if EXCHANGE:
+    from vers_amd import rccl
+    gat = rccl.RcclComm(rccl.RcclComm.unique_id(), 0, 1, 0)
 stream_objs = [torch.cuda.Stream() for _ in range(max_s)]
-out = {"config": dict(rows=n, d=d, nlist=nlist, nprobe=nprobe, batch=B, top_k=top_k, steps=NSTEP), "build_s": round(t_build, 2), "worlds": {}}
+out = {"config": dict(rows=n, d=d, nlist=nlist, nprobe=nprobe, batch=B, top_k=top_k, steps=NSTEP, exchange_launch_and_merge_in_step=EXCHANGE), "build_s": round(t_build, 2), "worlds": {}}
 for W in worlds:
     owner = capi.shard_plan(lens, W) if W > 1 else np.zeros(nlist, np.uint8)
     ranks = range(W) if not RANKS else [int(r) for r in RANKS.split(",") if int(r) < W]
@@ -50,9 +58,15 @@ for W in worlds:
         rec = {"rank": R, "stored_rows": int(lens[owner == R].sum())}
         for NS in STREAMS:
             streams = [torch.cuda.current_stream().cuda_stream] if NS == 1 else [so.cuda_stream for so in stream_objs[:NS]]
+            allp_s = [torch.zeros(W, 2, B, top_k, dtype=torch.int64, device=dev) for _ in range(NS)] if EXCHANGE else None
             def step(i):
                 s = i % NS
                 ix.search_partial_dev(Q[(i % NQB) * B:].data_ptr(), d, B, top_k, nprobe, keys_s[s].data_ptr(), ids_s[s].data_ptr(), streams[s])
+                if EXCHANGE:  # the exchange's launch (one-rank RCCL all-gather of this rank's partial, on the stream) + the merge of W partials
+                    g = gat._gather
+                    assert g.all_gather_async(g.ctx, part_s[s].data_ptr(), allp_s[s].data_ptr(), 2 * B * top_k * 8, streams[s]) == 0
+                    IVFFlatIndex.merge_partials_dev(allp_s[s].data_ptr(), allp_s[s].data_ptr() + 8 * B * top_k, 2 * B * top_k, W, B, top_k, nprobe,
+                                                    res_s[s][0].data_ptr(), res_s[s][1].data_ptr(), res_s[s][2].data_ptr(), streams[s])
             for i in range(6): step(i)
             torch.cuda.synchronize(); ix.scan_times(reset=True); t0 = time.perf_counter()
             for i in range(NSTEP): step(6 + i)

@@ -16,8 +16,10 @@ from tests.golden import make_golden as mg
 from vers_amd.index import IVFFlatIndex
 seed, out_path = int(sys.argv[1]), sys.argv[2]
 rng = np.random.default_rng(seed)
-n = int(rng.integers(300, 20000)); d = int(rng.choice([8, 33, 64, 96, 130, 300, 768]))
-k = int(rng.integers(4, 120)); b = int(rng.integers(20, 400)); nprobe = int(rng.integers(2, min(k, 40) + 1))
+n = int(rng.integers(300, 20000)); d = int(rng.choice([8, 33, 64, 96, 130, 300, 768, 768, 1536, 2100]))   # (1536, 2100: only the narrow 16-query blocks fit LDS)
+if d > 1000: n = min(n, 6000)
+k = int(rng.integers(4, 120)); b = int(rng.integers(2, 400)) if rng.random() < 0.8 else int(rng.integers(2, 20))   # (small batches: < 2 queries per list)
+nprobe = int(rng.integers(2, min(k, 40) + 1))
 top_k = int(rng.choice([1, 5, 10, 20, 40, 54]))
 dup = rng.random() < 0.3
 X = dg.dist_c(seed, n, d, max(2, k), dg.default_sigma(d))
@@ -49,7 +51,10 @@ budget = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 t0 = time.time(); seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1000; n_ok = 0
 while time.time() - t0 < budget:
     # the matrix-core scan on the fp16 shadow rows (the default); every third seed on the f32 rows; against the ordered chains
-    a = run(seed, {"VERS_SHADOW": "0"} if seed % 3 == 0 else {}, "/tmp/fz_a.npz"); bq = run(seed, {"VERS_PRESCAN": "0"}, "/tmp/fz_b.npz")
+    # (every fourth seed with the narrow 16-query blocks forced at any d)
+    ea = {"VERS_SHADOW": "0"} if seed % 3 == 0 else {}
+    if seed % 4 == 1: ea["VERS_PRE_NARROW"] = "1"
+    a = run(seed, ea, "/tmp/fz_a.npz"); bq = run(seed, {"VERS_PRESCAN": "0"}, "/tmp/fz_b.npz")
     A, B = np.load("/tmp/fz_a.npz"), np.load("/tmp/fz_b.npz")
     same = np.array_equal(A["cnt"], B["cnt"]) and all(  # entries past a query's count are undefined
         np.array_equal(A[k_][q, :A["cnt"][q]], B[k_][q, :A["cnt"][q]]) for k_ in ("ids", "dist") for q in range(A["cnt"].shape[0]))

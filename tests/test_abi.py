@@ -10,8 +10,8 @@ from vers_amd import capi
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def header_functions():
-    txt = open(os.path.join(ROOT, "include", "vers_hip.h")).read()
+def header_functions(header="vers_hip.h"):
+    txt = open(os.path.join(ROOT, "include", header)).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
     return sorted(set(re.findall(r"\b(vers_[a-z0-9_]+)\s*\(", txt)))
 
@@ -35,3 +35,20 @@ def test_status_codes_match_header():
                       ("VERS_ERR_INSUFFICIENT", capi.ERR_INSUFFICIENT), ("VERS_ERR_HIP", capi.ERR_HIP),
                       ("VERS_ERR_EMPTY", capi.ERR_EMPTY), ("VERS_MAX_TOPK", capi.MAX_TOPK)]:
         assert re.search(rf"#define {name} {val}\b", txt), name
+
+
+def test_rccl_adapter_builds_exports_every_declared_symbol_and_matches_its_binding():
+    """libvers_rccl.so (include/vers_comm_rccl.h): the optional RCCL adapter.  Loads without a GPU (it only links librccl),
+    exports what its header declares, and libvers_hip.so itself does NOT depend on RCCL."""
+    import subprocess
+    from vers_amd import rccl
+    so = vbuild.build_rccl()
+    names = header_functions("vers_comm_rccl.h")
+    assert "vers_rccl_gather" in names and "vers_rccl_comm" in names
+    assert sorted(rccl.SIGNATURES) == names
+    lib = ctypes.CDLL(so)
+    for n in names:
+        assert hasattr(lib, n), f"{n} declared in include/vers_comm_rccl.h but not exported"
+    needed = subprocess.run(["readelf", "-d", vbuild.LIB], capture_output=True, text=True).stdout
+    assert "rccl" not in needed, "libvers_hip.so must not link RCCL: the adapter is a separate, optional library"
+    assert "rccl" in subprocess.run(["readelf", "-d", so], capture_output=True, text=True).stdout

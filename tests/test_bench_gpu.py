@@ -48,3 +48,4 @@ def test_bench_gpus_2_spawns_ranks_and_builds_row_sharded():
     assert "row-sharded build over 2 ranks: 10000 rows generated per rank" in err
     assert two["recall_at_10"] == one["recall_at_10"]
     assert two["config"]["kmeans_iters"] == one["config"]["kmeans_iters"]
+    assert "vers_ivf_search_sharded_dev" in two["config"]["exchange"]   # partial -> exchange -> merge inside ONE library call per batch

@@ -70,6 +70,15 @@ def worker(rank, world, port, ret):
         exp += [1000 * s + rank] * (int(rb[s]) // 4)
     ok &= np.array_equal(recv[:-1], np.array(exp, dtype=np.uint32))
     ok &= cm.calls["all_to_all_v"] == 1 and cm.calls["all_gather"] == 1
+    # vers_gather_t (the sharded search's one exchange) on host buffers: [2][b][top_k] u64 per rank -> [world][2][b][top_k]
+    from vers_amd.dist import TorchGather
+    tg = TorchGather(device=None)
+    part = (np.arange(2 * 3 * 4, dtype=np.uint64) + np.uint64(1000 * rank)).reshape(2, 3, 4)
+    gathered = np.zeros((world, 2, 3, 4), dtype=np.uint64)
+    g = tg.struct
+    ok &= (g.rank, g.world) == (rank, world)
+    ok &= g.all_gather_async(None, vp(part), vp(gathered), part.nbytes, None) == 0
+    ok &= all(np.array_equal(gathered[r], (np.arange(24, dtype=np.uint64) + np.uint64(1000 * r)).reshape(2, 3, 4)) for r in range(world))
     ret[rank] = bool(ok)
     dist.barrier()
     dist.destroy_process_group()

@@ -33,14 +33,19 @@ total = 0
 # (1) clustered data, several shapes (d = 300 pads to 320 columns; lists are ragged: lengths not multiples of 64)
 for seed, n, d, k, b, nprobe, top_ks in [(0x81, 9000, 96, 48, 160, 8, (1, 10, 26, 54)), (0x82, 5000, 300, 32, 96, 6, (10,)),
                                          (0x83, 3000, 768, 24, 80, 5, (10, 20)),
-                                         # d = 1152: the 32-query block just fits LDS; d = 1536: it does not (ordered chains)
-                                         (0x84, 1500, 1152, 12, 64, 4, (10,)), (0x85, 1200, 1536, 12, 64, 4, (10,))]:
+                                         # d = 1152: the 32-query block just fits LDS; d = 1536: it does not -- the NARROW variant's 16 queries do
+                                         (0x84, 1500, 1152, 12, 64, 4, (10,)), (0x85, 1200, 1536, 12, 64, 4, (10,)), (0x87, 900, 2304, 8, 40, 3, (10,)),
+                                         # a small batch over many lists: < 2 queries per list (round 3: one ordered-chain scan per (query, list) pair)
+                                         (0x86, 6000, 64, 96, 12, 6, (10, 30))]:
     X = dg.dist_c(seed, n, d, 4 * k, dg.default_sigma(d))
     ix = IVFFlatIndex.build_index(k, 1, 3, X, init_indices=mg.init_draws(seed, 1, k, n))
     Q = dg.dist_c(seed + 0x100, b, d, 4 * k, dg.default_sigma(d)); Q[3] = X[17]
+    b0 = ix.prescan_stats()["batches"]
     for top_k in top_ks:
         check(ix, Q, top_k, nprobe)
         total += 1
+    if os.environ.get("VERS_PRESCAN", "1") != "0":   # every one of these shapes is inside the matrix-core scan's domain
+        assert ix.prescan_stats()["batches"] - b0 == len(top_ks), (seed, d, b, ix.prescan_stats()["batches"] - b0)
     if seed == 0x81:
         for i in range(70):  # add(): the new rows' norms are maintained incrementally; one list outgrows its slack
             ix.add(Q[i % 5] * np.float32(1.0 + i / 512.0), 0)
@@ -168,3 +173,14 @@ def test_results_do_not_depend_on_uninitialised_memory():
     out = run({"VERS_POISON_SLACK": "nan", "VERS_POISON_ALLOC": "0x7f"})
     assert out["TIES"][0] == 1 and out["TIES"][1] > 0 and out["HUGE"] == (1, 64)
     assert out["ONE"] == (1,) and out["BIG"] == (0,) and out["TEN"][0] >= 10 and out["SLACK"] == (0,)
+
+
+def test_narrow_query_blocks_are_bit_exact():
+    """VERS_PRE_NARROW=1: 16 queries per block at every d (the variant that d = 1536 .. 2304 need), on the fp16 shadow and on the
+    f32 rows, and with every certificate forced to fail."""
+    out = run({"VERS_PRE_NARROW": "1"})
+    assert out["TIES"][0] == 1 and out["TIES"][1] > 0 and out["HUGE"] == (1, 64) and out["ONE"] == (1,) and out["TEN"][0] >= 10 and out["SLACK"] == (0,)
+    out = run({"VERS_PRE_NARROW": "1", "VERS_SHADOW": "0"})
+    assert out["TIES"][0] == 1 and out["TIES"][1] > 0 and out["HUGE"] == (1, 64) and out["ONE"] == (1,) and out["BIG"] == (0,)
+    out = run({"VERS_PRE_NARROW": "1", "VERS_PRESCAN": "2"})
+    assert out["TIES"] == (1, 64)

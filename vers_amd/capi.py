@@ -71,9 +71,11 @@ SIGNATURES = {
     "vers_ivf_search_exhaustive_sharded_dev": (C.c_int32, [_vp, _vp, _vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, _vp, _vp, _vp, _vp]),
     "vers_topk_merge_dev": (C.c_int32, [_vp, _vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, _vp, _vp, _vp, _vp]),
     "vers_ivf_last_coarse_ms": (C.c_int32, [_vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]),
+    "vers_ivf_last_finish_ms": (C.c_int32, [_vp, C.POINTER(C.c_float)]),
     "vers_ivf_coarse_stats": (C.c_int32, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "vers_ivf_prescan_stats": (C.c_int32, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "vers_ivf_shadow_state": (C.c_int32, [_vp, C.POINTER(C.c_int32), C.POINTER(C.c_uint64)]),
+    "vers_ivf_layout_bytes": (C.c_int32, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "vers_ivf_test_poison_slack": (C.c_int32, [_vp, C.c_float]),
     "vers_ivf_build_sharded_dev": (C.c_int32, [_vp, _vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64,
                                                C.c_uint64, _vp, _vp, _vp, C.POINTER(C.c_float), C.POINTER(C.c_int32), _vp]),

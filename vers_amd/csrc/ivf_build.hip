@@ -187,7 +187,7 @@ int32_t refresh_norms(vers_ivf* h, uint64_t r_begin, uint64_t r_end, hipStream_t
     if (full) h->rows_bf.release();
   }
   {
-    static const int rm_mode = [] { const char* e = getenv("VERS_ROWMAJOR"); return e ? atoi(e) : 0; }();  // opt-in: see vers_ivf::rows_rm
+    static const int rm_mode = [] { const char* e = getenv("VERS_ROWMAJOR"); return e ? atoi(e) : -1; }();  // default: whenever it fits (vers_ivf::rows_rm)
     if (full) {
       size_t free_b = 0, total_b = 0;
       (void)hipMemGetInfo(&free_b, &total_b);

@@ -41,6 +41,7 @@ int32_t ws_init(SearchWs& w) {
     VERS_HIP_TRY(hipEventCreate(&w.ev1[i]));
   }
   for (auto& e : w.evc) VERS_HIP_TRY(hipEventCreate(&e));
+  VERS_HIP_TRY(hipEventCreate(&w.evf));
   VERS_HIP_TRY(hipEventCreateWithFlags(&w.done, hipEventDisableTiming));
   return VERS_OK;
 }
@@ -51,6 +52,7 @@ void ws_destroy(SearchWs& w) {
   }
   for (auto& e : w.evc)
     if (e) (void)hipEventDestroy(e);
+  if (w.evf) (void)hipEventDestroy(w.evf);
   if (w.done) (void)hipEventDestroy(w.done);
   if (w.io_pin) (void)hipHostFree(w.io_pin);
   if (w.io_stream) (void)hipStreamDestroy(w.io_stream);
@@ -217,6 +219,15 @@ int32_t vers_ivf_shadow_state(vers_ivf_t* h, int32_t* out_active, uint64_t* out_
   if (!h) return fail(VERS_ERR_INVALID, "null handle");
   if (out_active) *out_active = (shadow_mode() != 0 && h->shadow_valid && h->rows_bf.p != nullptr && !h->shadow_off) ? 1 : 0;
   if (out_bytes) *out_bytes = h->rows_bf.p ? (uint64_t)h->rows_bf.cap : 0;
+  return VERS_OK;
+}
+
+int32_t vers_ivf_layout_bytes(vers_ivf_t* h, uint64_t* out_rows, uint64_t* out_shadow, uint64_t* out_rowmajor) {
+  if (!h) return fail(VERS_ERR_INVALID, "null handle");
+  std::shared_lock<std::shared_mutex> lk(h->index);
+  if (out_rows) *out_rows = h->rows.p ? (uint64_t)h->cap_rows * h->ld * sizeof(float) : 0;
+  if (out_shadow) *out_shadow = h->rows_bf.p && h->shadow_valid ? (uint64_t)h->cap_rows * h->ld * sizeof(uint16_t) : 0;
+  if (out_rowmajor) *out_rowmajor = h->rows_rm.p ? (uint64_t)h->cap_rows * h->ld * sizeof(float) : 0;
   return VERS_OK;
 }
 

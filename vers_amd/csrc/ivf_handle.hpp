@@ -47,6 +47,9 @@ struct SearchWs {
   hipEvent_t ev0[kEvRing] = {}, ev1[kEvRing] = {};
   hipEvent_t evc[3] = {};  // batched coarse quantiser of the most recent search: before the GEMM | after it | after select / re-score
   bool evc_valid = false;
+  hipEvent_t evf = nullptr;  // recorded behind the exact finish of the most recent matrix-core batch (its start = the scan's ev1)
+  bool evf_valid = false;
+  uint32_t evf_slot = 0;
   uint64_t ev_count = 0;
   bool ev_on = true;  // this search brackets its list-scan launch with event records (scan_events_ref)
   size_t ivf_bounds_off = 0;  // pruning bounds live behind the partial slots (one memset)
@@ -147,11 +150,12 @@ struct vers_ivf {
   // than 1/8 of the queries had to be re-scanned exactly.
   DevBuf rows_bf;
   // Row-major second copy of the stored rows for the exact finish: a candidate row of the lane-transposed tile layout is
-  // 192 separate 16-byte pieces (one per 64-byte sector: 4x the useful bytes, 74 us per batch of 1024 at cfg3 whatever the
-  // shard count); row-major it is 3 KB of whole sectors.  OPT-IN (VERS_ROWMAJOR=1; -1 = whenever the rows take at most a
-  // quarter of the device's memory): measured at cfg3, same box -- exact finish 74 -> 53 us, but the list scan 10 us
-  // slower with twice the rows mapped, net -8 us per step at 8 ranks and nothing on one GPU: not worth doubling the
-  // corpus memory by default.  Same bits either way.
+  // 192 separate 16-byte pieces (one per 64-byte sector: 4x the useful bytes); row-major it is 3 KB of whole sectors.
+  // ON whenever the rows take at most a quarter of the device's memory (VERS_ROWMAJOR=-1, the default since round 4; 1 =
+  // always, 0 = never): measured at cfg3 over every rank of 1 / 8 ranks, same box -- the step with three batches in flight
+  // 2.456 -> 2.379 ms on one GPU and 0.461 -> 0.437 ms at 8 ranks (exact finish 80 -> ~55 us).  It is optional memory: +100 %
+  // of the f32 rows (81 GB instead of 49 GB of 288 at N = 10M d = 768); a failed allocation or rows beyond the quarter
+  // (N > 23M at d = 768) leave the tile gather in charge.  Same bits either way (tests run both).
   DevBuf rows_rm;
   std::atomic<bool> shadow_off{false};
   bool shadow_valid = false;            // rows_bf mirrors every stored row of the CURRENT index (written under the exclusive lock)
@@ -318,6 +322,8 @@ struct SearchKnobs {
   int pre_mode = 1;      // VERS_PRESCAN: 0 ordered chains for batches too, 2 every certificate fails
   bool seg_balanced = true;   // VERS_SEG_BALANCED
   uint32_t hot_ranks = 1;     // VERS_HOT_FIRST
+  bool pre_narrow = false;    // VERS_PRE_NARROW: 16-query blocks in the matrix-core list scan whatever d is
+  uint32_t pre_min_batch = 8; // VERS_PRE_MIN_BATCH: smallest batch whose list scan runs on the matrix cores when lists are shared by < 2 queries
 };
 inline const SearchKnobs& knobs() {
   static const SearchKnobs k = [] {
@@ -330,6 +336,8 @@ inline const SearchKnobs& knobs() {
     s.pre_mode = (int)geti("VERS_PRESCAN", 1);
     s.seg_balanced = geti("VERS_SEG_BALANCED", 1) != 0;
     s.hot_ranks = (uint32_t)geti("VERS_HOT_FIRST", 1);
+    s.pre_narrow = geti("VERS_PRE_NARROW", 0) != 0;
+    s.pre_min_batch = (uint32_t)geti("VERS_PRE_MIN_BATCH", 8);
     return s;
   }();
   return k;

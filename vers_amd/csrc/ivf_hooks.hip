@@ -62,6 +62,16 @@ int32_t vers_ivf_last_coarse_ms(vers_ivf_t* h, float* out_gemm_ms, float* out_se
   return VERS_OK;
 }
 
+int32_t vers_ivf_last_finish_ms(vers_ivf_t* h, float* out_ms) {
+  if (!h || !out_ms) return fail(VERS_ERR_INVALID, "bad arguments");
+  UseLastWs use_ws(h);
+  if (!use_ws.ok || !W->evf_valid) return fail(VERS_ERR_INVALID, "no matrix-core batch with event records has run on this handle");
+  DeviceGuard g(h->device);
+  VERS_HIP_TRY(hipEventSynchronize(W->evf));
+  VERS_HIP_TRY(hipEventElapsedTime(out_ms, W->ev1[W->evf_slot], W->evf));
+  return VERS_OK;
+}
+
 int32_t vers_ivf_coarse_stats(vers_ivf_t* h, uint64_t* out_mfma_batches, uint64_t* out_fallback_queries) {
   if (!h) return fail(VERS_ERR_INVALID, "null handle");
   DeviceGuard g(h->device);

@@ -650,9 +650,18 @@ int32_t plan_search(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint32_t b
   // (fp16 rows: the window is ~2x the f32 one.  At cfg3 a slack of 10 left ~0.5 of 1024 queries per batch uncertified, 16 none)
   if (use_shadow) kp = std::min<uint32_t>(kPreMaxKp, top_k + std::max<uint32_t>(24, top_k));
   if (knobs().pre_slack > 0) kp = std::min<uint32_t>(kPreMaxKp, top_k + (uint32_t)knobs().pre_slack);  // tuning knob
-  const bool use_pre = QG != 1 && !ref_mode && pre_mode != 0 && top_k + 6 <= kPreMaxKp && P <= (uint32_t)kMaxTopK &&
-                       prescan_lds_bytes_g(h->ld, kp) <= 160u * 1024u;  // the query block of 32 padded queries must fit LDS
-  if (use_pre) QG = kPreQ;
+  // The block's query operand must fit LDS next to the candidate buffers: 32 queries up to d = 1152; the NARROW variant's 16 up
+  // to d = 2304 (d = 1536 -- a dimension the reference's own bindings instantiate, vers-py/src/lib.rs:26-65 -- went to the
+  // ordered-chain scan until round 4, ~3x slower).  VERS_PRE_NARROW=1 forces the narrow blocks (tests, A/B).
+  const uint32_t pre_nq = (!knobs().pre_narrow && prescan_lds_bytes_g(h->ld, kp, kPreQ) <= 160u * 1024u) ? (uint32_t)kPreQ
+                          : (prescan_lds_bytes_g(h->ld, kp, kPreQNarrow) <= 160u * 1024u ? (uint32_t)kPreQNarrow : 0u);
+  // Small batches too (round 3 required >= 2 queries per list on average and sent batch 8 .. 128 at nlist = 4096 to one
+  // ordered-chain scan per (query, list) pair -- every list re-read per query, f32 rows): a list probed by ONE query of the batch
+  // is still streamed from the half-size shadow at the chip's rate, and the staging of a mostly empty query block costs less
+  // than the bytes it saves.  VERS_PRE_MIN_BATCH (default 8) is the smallest batch that takes this path.
+  const bool pre_batch = QG != 1 || (b >= knobs().pre_min_batch && b > 1);
+  const bool use_pre = pre_batch && !ref_mode && pre_mode != 0 && top_k + 6 <= kPreMaxKp && P <= (uint32_t)kMaxTopK && pre_nq != 0;
+  if (use_pre) QG = (int)pre_nq;
   const uint32_t k_keep = use_pre ? kp : std::min<uint32_t>(top_k, kMaxTopK);
   // 64 result ranks per pass; no pass beyond the rows the index holds (top_k = 100000 on 1000 rows: 16 passes, not 1563)
   const uint32_t n_pass = use_pre ? 1u : (uint32_t)((std::min<uint64_t>(top_k, std::max<uint64_t>(1, h->n_total)) + kMaxTopK - 1) / kMaxTopK);

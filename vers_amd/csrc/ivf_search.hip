@@ -265,7 +265,8 @@ int32_t launch_scan1(vers_ivf* h, const Scan1Args& a, uint32_t items_bound, hipS
 }
 
 // the matrix-core list scan (prescan.hip.h); timed through the same event ring as launch_ivf_scan
-int32_t launch_prescan(vers_ivf* h, const IvfSrc<kPreQ>& src, uint32_t items_bound, uint32_t kp, uint32_t* qflags, uint32_t* quad_ctr,
+template <int NQ>
+int32_t launch_prescan(vers_ivf* h, const IvfSrc<NQ>& src, uint32_t items_bound, uint32_t kp, uint32_t* qflags, uint32_t* quad_ctr,
                        bool shadow, hipStream_t st) {
   PreParams p;
   p.rows_bf = shadow ? h->rows_bf.as<uint16_t>() : nullptr;
@@ -285,8 +286,8 @@ int32_t launch_prescan(vers_ivf* h, const IvfSrc<kPreQ>& src, uint32_t items_bou
     p.stamps = W->stamps.as<unsigned long long>();
   }
   p.next_quad = (p.debug & 32u) ? nullptr : quad_ctr;  // zeroed with the planning tables
-  const size_t lds = prescan_lds_bytes_g(h->ld, kp);
-  if (int32_t rc = shadow ? scan_prepare_launch(prescan_kernel_g<true, IvfSrc<kPreQ>>, lds) : scan_prepare_launch(prescan_kernel_g<false, IvfSrc<kPreQ>>, lds)) return rc;
+  const size_t lds = prescan_lds_bytes_g(h->ld, kp, NQ);
+  if (int32_t rc = shadow ? scan_prepare_launch(prescan_kernel_g<true, NQ, IvfSrc<NQ>>, lds) : scan_prepare_launch(prescan_kernel_g<false, NQ, IvfSrc<NQ>>, lds)) return rc;
   uint32_t blocks = (items_bound + kWavesPerBlock - 1) / kWavesPerBlock;
   uint32_t per_cu = std::max<uint32_t>(1, std::min<uint32_t>(2, (uint32_t)((160u * 1024u) / lds)));  // 1 at d = 768 (measured: as fast as 2)
   if (knobs().pre_blocks_per_cu > 0) per_cu = (uint32_t)knobs().pre_blocks_per_cu;  // tuning knob
@@ -295,8 +296,8 @@ int32_t launch_prescan(vers_ivf* h, const IvfSrc<kPreQ>& src, uint32_t items_bou
   if (blocks == 0) blocks = 1;
   const uint32_t slot = (uint32_t)(W->ev_count % SearchWs::kEvRing);
   if (W->ev_on) VERS_HIP_TRY(hipEventRecord(W->ev0[slot], st));
-  if (shadow) hipLaunchKernelGGL((prescan_kernel_g<true, IvfSrc<kPreQ>>), dim3(blocks), dim3(kWave * kPreWavesG), lds, st, src, p);
-  else hipLaunchKernelGGL((prescan_kernel_g<false, IvfSrc<kPreQ>>), dim3(blocks), dim3(kWave * kPreWavesG), lds, st, src, p);
+  if (shadow) hipLaunchKernelGGL((prescan_kernel_g<true, NQ, IvfSrc<NQ>>), dim3(blocks), dim3(kWave * kPreWavesG), lds, st, src, p);
+  else hipLaunchKernelGGL((prescan_kernel_g<false, NQ, IvfSrc<NQ>>), dim3(blocks), dim3(kWave * kPreWavesG), lds, st, src, p);
   VERS_HIP_TRY(hipGetLastError());
   if (W->ev_on) {
     VERS_HIP_TRY(hipEventRecord(W->ev1[slot], st));
@@ -340,6 +341,7 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
   int32_t rc;
   if (use_pre) {
     IvfSrc<kPreQ> src; fill_src(src);
+    IvfSrc<kPreQNarrow> src_n; fill_src(src_n);  // (rows too long for a 32-query block: 16 queries per block, plan_search chose QG)
     // partial lists of the exact re-scan (fail_list [b] + its count, qflags [n_pj]: in the zeroed zone above)
     uint32_t fb_blocks = kFallbackBlocks;  // (a power of two; fewer when P x top_k is large: at most 32 MB of partial lists)
     while (fb_blocks > 16 && fallback_part_keys(fb_blocks, P, top_k) * sizeof(uint64_t) > (size_t(32) << 20)) fb_blocks /= 2;
@@ -348,7 +350,8 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
       if (int32_t rc2 = W->fb_ctr.reserve((2 * kFallbackBlocks + 1) * sizeof(uint32_t))) return rc2;
       VERS_HIP_TRY(hipMemsetAsync(W->fb_ctr.p, 0, (2 * kFallbackBlocks + 1) * sizeof(uint32_t), st));
     }
-    if (int32_t rc2 = launch_prescan(h, src, (uint32_t)items_bound, kp, qflags, quad_ctr, use_shadow, st)) return rc2;
+    if (int32_t rc2 = QG == kPreQNarrow ? launch_prescan(h, src_n, (uint32_t)items_bound, kp, qflags, quad_ctr, use_shadow, st)
+                                        : launch_prescan(h, src, (uint32_t)items_bound, kp, qflags, quad_ctr, use_shadow, st)) return rc2;
     if (int32_t rc2 = start_pending_ahead(h, st)) return rc2;  // the next batch's coarse quantiser: under this batch's exact finish
     RescoreArgs a;
     a.partials = W->partials.as<uint64_t>(); a.P = P; a.S_max = S_max; a.kp = kp; a.top_k = top_k; a.d_pad = h->ld;
@@ -361,6 +364,11 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
     if (int32_t rc2 = scan_prepare_launch(ivf_rescore_kernel, rs_lds)) return rc2;
     hipLaunchKernelGGL(ivf_rescore_kernel, dim3(b), dim3(kWave * kRescoreWaves), rs_lds, st, a, stage_rows);
     VERS_HIP_TRY(hipGetLastError());
+    if (W->ev_on) {  // (measurement hook vers_ivf_last_finish_ms: from the scan's end record to here)
+      VERS_HIP_TRY(hipEventRecord(W->evf, st));
+      W->evf_valid = true;
+      W->evf_slot = (uint32_t)((W->ev_count - 1) % SearchWs::kEvRing);
+    }
     hipLaunchKernelGGL(fallback_kernel, dim3(fb_blocks), dim3(kWave * kMergeWaves), 0, st, a, (const uint32_t*)h->slot_len.as<uint32_t>(),
                        (const uint32_t*)fail_list, (const uint32_t*)(fail_list + b), W->fb_part.as<uint64_t>(), W->fb_ctr.as<uint32_t>(),
                        use_shadow ? h->fail_watch : (uint32_t*)nullptr);

@@ -156,9 +156,12 @@ static_assert(kPreWavesG % 4 == 0 && kPreWavesG >= 4 && kPreWavesG <= 16, "a qua
 // wave-wide bitonic sort compacts it; wider lists: 128 keys (two sorts + a bitonic merge).  At least 24 free slots after
 // every compaction.
 __host__ __device__ inline uint32_t pre_cap(uint32_t kp) { return kp <= 40u ? 64u : 128u; }
-inline size_t prescan_lds_bytes_g(uint32_t ld, uint32_t kp) {  // query block | hand-out word | buffers | cnt, done, thr, locks
-  return (size_t)ld * kPreQ * sizeof(float) + 16 + (size_t)kPreQ * pre_cap(kp) * sizeof(uint64_t) + 6 * kPreQ * sizeof(uint32_t);  // (+ pair | sequence base of the quad's queries)
+// nq = queries per block: kPreQ (32), or 16 -- the NARROW variant for rows too long for a 32-query block (d = 1536: 196 KB
+// against the CU's 160 KB of LDS; 16 queries fit up to d = 2304).  Same kernel, same MFMA (half its query columns idle).
+inline size_t prescan_lds_bytes_g(uint32_t ld, uint32_t kp, uint32_t nq = 32) {  // query block | hand-out word | buffers | cnt, done, thr, locks
+  return (size_t)ld * nq * sizeof(float) + 16 + (size_t)nq * pre_cap(kp) * sizeof(uint64_t) + 6 * 32 * sizeof(uint32_t);  // (+ pair | sequence base of the quad's queries)
 }
+constexpr int kPreQNarrow = 16;
 
 // ---- per-query candidate buffers of a block (LDS) ---------------------------------------------------------------
 // The eight waves of a block share, per query, an UNSORTED buffer of `cap` keys with a fill counter.  A lane whose
@@ -194,8 +197,8 @@ __device__ __forceinline__ uint64_t buffer_sorted(const uint64_t* bq, uint32_t n
 // by the (halved) HBM stream alone.  The accumulator layout differs from the f32 path's (16x16x1 in 4 blocks: a lane =
 // one of 16 query columns x 2 sets): here a lane holds query column lane & 31 and 16 of the 32 rows of a tile half h:
 // rows 32*h + 8*(e >> 2) + 4*(lane >> 5) + (e & 3).
-template <bool BF, class Src, class Stage>
-__device__ __forceinline__ void prescan_item_g(const Src& src, const PreParams& p, uint32_t it, const ItemView<kPreQ>& v, int half, int lane,
+template <bool BF, int NQ, class Src, class Stage>
+__device__ __forceinline__ void prescan_item_g(const Src& src, const PreParams& p, uint32_t it, const ItemView<NQ>& v, int half, int lane,
                                                const float* qm, uint64_t* cbuf, uint32_t* ctl, Stage&& stage) {
   const uint32_t n_tiles = (v.nrows + kWave - 1) / kWave;
   const uint32_t t_per = (n_tiles + kPreParts - 1) / kPreParts;  // (half = the wave's index among those of its segment)
@@ -218,7 +221,7 @@ __device__ __forceinline__ void prescan_item_g(const Src& src, const PreParams& 
   // short items expensive
   const uint32_t* const qpair = ctl + 4 * kPreQ;
   const uint32_t* const qpref = ctl + 5 * kPreQ;
-  const bool two = !BF && v.nq > 16;  // wave-uniform
+  const bool two = !BF && NQ > 16 && v.nq > 16;  // wave-uniform
   const bool stamp = (p.debug & 16u) != 0;
   const unsigned long long tp0 = stamp ? __builtin_amdgcn_s_memtime() : 0ull;
   // the first tile loads go out before anything else: they fly while the item is set up and the block stages
@@ -380,7 +383,7 @@ __device__ __forceinline__ void prescan_item_g(const Src& src, const PreParams& 
   // (after the block-wide part: the quad's pair / sequence-base table in LDS is what stage() filled -- or left, for the next quad of a run)
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
-    live[s] = s < kSets && s * 16 + n < (int)v.nq;
+    live[s] = s < kSets && s * 16 + n < (int)v.nq && s * 16 + n < NQ;  // (narrow blocks: the MFMA's query columns 16 .. 31 repeat 0 .. 15 and are ignored)
     thr[s] = -__builtin_inff();  // dead query columns never hit
     if (live[s]) {
       vseq[s] = qpref[s * 16 + n] + v.row0;
@@ -401,28 +404,30 @@ __device__ __forceinline__ void prescan_item_g(const Src& src, const PreParams& 
       if (stamp) { t1 = __builtin_amdgcn_s_memtime(); t_issue += t1 - ti0; }
       if (!(p.debug & 2u)) {
         if constexpr (!BF) {
-          const f32x4* ql = reinterpret_cast<const f32x4*>(qm) + ((size_t)cc * kLoads * kPreQ + n);
+          const f32x4* ql = reinterpret_cast<const f32x4*>(qm) + ((size_t)cc * kLoads * NQ + n);
 #pragma unroll
           for (int i = 0; i < kLoads; ++i) {
-            const f32x4 q4 = ql[i * kPreQ];
+            const f32x4 q4 = ql[i * NQ];
 #pragma unroll
             for (int u = 0; u < 4; ++u) acc[0] = __builtin_amdgcn_mfma_f32_16x16x1f32(__uint_as_float(buf[B][i][u]), q4[u], acc[0], 0, 0, 0);
           }
           if (two) {
 #pragma unroll
             for (int i = 0; i < kLoads; ++i) {
-              const f32x4 q4 = ql[i * kPreQ + 16];
+              const f32x4 q4 = ql[i * NQ + 16];
 #pragma unroll
               for (int u = 0; u < 4; ++u) acc[1] = __builtin_amdgcn_mfma_f32_16x16x1f32(__uint_as_float(buf[B][i][u]), q4[u], acc[1], 0, 0, 0);
             }
           }
         } else {
           // query block: [hi | lo][column block of 16][64 lanes] x 16 bytes, lane = octet * 32 + query (the B operand's layout)
-          const f16x8_t* qh = reinterpret_cast<const f16x8_t*>(qm) + ((size_t)cc * (kLoads / 2) * kWave + lane);
-          const f16x8_t* ql = qh + (size_t)(p.ld / 16u) * kWave;
+          // (narrow blocks: 16 query slots per octet; lane (octet, n) reads slot n & 15)
+          constexpr int kCb = 2 * NQ;  // f16x8 entries per column block: 2 octets x NQ query slots
+          const f16x8_t* qh = reinterpret_cast<const f16x8_t*>(qm) + ((size_t)cc * (kLoads / 2) * kCb + (lane >> 5) * NQ + (n & (NQ - 1)));
+          const f16x8_t* ql = qh + (size_t)(p.ld / 16u) * kCb;
 #pragma unroll
           for (int cb = 0; cb < kLoads / 2; ++cb) {
-            const f16x8_t bh = qh[cb * kWave], bl = ql[cb * kWave];
+            const f16x8_t bh = qh[cb * kCb], bl = ql[cb * kCb];
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf) {
               const f16x8_t ar = __builtin_bit_cast(f16x8_t, buf[B][2 * cb + hf]);
@@ -497,15 +502,16 @@ __device__ __forceinline__ void prescan_item_g(const Src& src, const PreParams& 
   if (stamp && lane == 0) atomicAdd(p.stamps + 11, __builtin_amdgcn_s_memtime() - te0);
 }
 
-template <bool BF, class Src>
+template <bool BF, int NQ, class Src>
 __global__ __launch_bounds__(kWave * kPreWavesG) __attribute__((amdgpu_waves_per_eu(kPreWavesG / 4, kPreWavesG / 4))) void prescan_kernel_g(Src src, PreParams p) {
+  static_assert(NQ == kPreQ || NQ == kPreQNarrow, "32 queries per block, or the narrow variant's 16");
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   extern __shared__ __attribute__((aligned(16))) float qlds[];
-  uint32_t* nq_lds = reinterpret_cast<uint32_t*>(qlds + (size_t)p.ld * kPreQ);
+  uint32_t* nq_lds = reinterpret_cast<uint32_t*>(qlds + (size_t)p.ld * NQ);
   const uint32_t cap = pre_cap(p.kp);
-  uint64_t* buf = reinterpret_cast<uint64_t*>(qlds + (size_t)p.ld * kPreQ + 4);  // [32 queries][cap] candidate keys, shared by the 8 waves
-  uint32_t* ctl = reinterpret_cast<uint32_t*>(buf + (size_t)kPreQ * cap);         // cnt | done | thr | locks, [32] each
+  uint64_t* buf = reinterpret_cast<uint64_t*>(qlds + (size_t)p.ld * NQ + 4);  // [NQ queries][cap] candidate keys, shared by the 8 waves
+  uint32_t* ctl = reinterpret_cast<uint32_t*>(buf + (size_t)NQ * cap);         // cnt | done | thr | locks, [32] each
   const uint32_t n_quads = src.n_items() / 4;
   const unsigned long long clk0 = (p.debug & 16u) ? __builtin_amdgcn_s_memtime() : 0ull;
   const unsigned long long rt0 = (p.debug & 16u) ? __builtin_amdgcn_s_memrealtime() : 0ull;
@@ -551,13 +557,13 @@ __global__ __launch_bounds__(kWave * kPreWavesG) __attribute__((amdgpu_waves_per
     // (block-uniform.  Only the quad right behind the run's last one: the slots written empty must be this block's own)
     const bool cont = run_first != 0xFFFFFFFFu && bi == run_last + 1 && d0.list == cur_list && d0.group == cur_group;
     const uint32_t it = bi * 4 + (wid & 3);
-    ItemView<kPreQ> v;
+    ItemView<NQ> v;
     src.get(it, v);
     const float qscale = p.metric ? -1.0f : -2.0f;
     // The quad's query block: <= 32 padded queries gathered from their rows, scaled by -2 (-1: cosine distance), in the MFMA operand
     // layout l4[column group * 32 + slot].  Every thread serves ONE slot (512 % 32 == 0; 16 slots when the group
     // holds <= 16 queries, so that all threads load) and its row pointer is resolved here, ahead of the barrier.
-    const uint32_t ns = (BF || v.nq > 16) ? 32u : 16u;
+    const uint32_t ns = (NQ > 16 && (BF || v.nq > 16)) ? 32u : 16u;
     const uint32_t slot = threadIdx.x & (ns - 1u), cg0 = threadIdx.x / ns, cg_step = (kWave * kPreWavesG) / ns;
     const float* qrow = (!cont && slot < v.nq) ? src.query_row(it, slot) : nullptr;
     auto stage = [&]() {
@@ -595,11 +601,11 @@ __global__ __launch_bounds__(kWave * kPreWavesG) __attribute__((amdgpu_waves_per
             lo[u] = (_Float16)(y[u] - (float)hi[u]);
           }
           _Float16* qb = reinterpret_cast<_Float16*>(qlds);
-          const uint32_t at = (((cg >> 2) * 2u + ((cg >> 1) & 1u)) * 32u + slot) * 8u + (cg & 1u) * 4u;
+          const uint32_t at = (((cg >> 2) * 2u + ((cg >> 1) & 1u)) * (uint32_t)NQ + slot) * 8u + (cg & 1u) * 4u;
           *reinterpret_cast<f16x4_t*>(qb + at) = hi;
-          *reinterpret_cast<f16x4_t*>(qb + (size_t)p.ld * kPreQ + at) = lo;
+          *reinterpret_cast<f16x4_t*>(qb + (size_t)p.ld * NQ + at) = lo;
         } else {
-          l4[cg * kPreQ + slot] = y;
+          l4[cg * NQ + slot] = y;
         }
       };
 #pragma unroll
@@ -620,10 +626,10 @@ __global__ __launch_bounds__(kWave * kPreWavesG) __attribute__((amdgpu_waves_per
       }
     };
     if (cont) {  // same query block, same buffers: nothing to stage, nothing to wait for
-      prescan_item_g<BF>(src, p, it, v, wid >> 2, lane, qlds, buf, ctl, [] {});
+      prescan_item_g<BF, NQ>(src, p, it, v, wid >> 2, lane, qlds, buf, ctl, [] {});
       run_last = bi;
     } else {
-      prescan_item_g<BF>(src, p, it, v, wid >> 2, lane, qlds, buf, ctl, stage);
+      prescan_item_g<BF, NQ>(src, p, it, v, wid >> 2, lane, qlds, buf, ctl, stage);
       run_first = run_last = bi;
       cur_list = d0.list; cur_group = d0.group;
       prev_nq = v.nq;

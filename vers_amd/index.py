@@ -153,6 +153,16 @@ class IVFFlatIndex:
         check(lib().vers_ivf_prescan_stats(self._h, C.byref(a), C.byref(b)))
         return dict(batches=a.value, fallback_queries=b.value)
 
+    def last_finish_ms(self):
+        ms = C.c_float(0)
+        check(lib().vers_ivf_last_finish_ms(self._h, C.byref(ms)))
+        return ms.value
+
+    def layout_bytes(self):
+        r = C.c_uint64(0); s_ = C.c_uint64(0); m = C.c_uint64(0)
+        check(lib().vers_ivf_layout_bytes(self._h, C.byref(r), C.byref(s_), C.byref(m)))
+        return dict(rows=r.value, shadow=s_.value, rowmajor=m.value)
+
     def shadow_state(self):
         a = C.c_int32(0); b = C.c_uint64(0)
         check(lib().vers_ivf_shadow_state(self._h, C.byref(a), C.byref(b)))
