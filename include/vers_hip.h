@@ -105,6 +105,13 @@ int32_t vers_assign_stats(uint64_t* out_points, uint64_t* out_fallbacks, int32_t
  * + arg-min + exact re-score + exact re-scans), [4] passes, [5] ms in update_centroids (:47-71), [6] ms in the cost fold
  * (:138-149), [7] points whose certificate failed and were settled by the exact kernels.  reset != 0 zeroes them. */
 int32_t vers_build_stats(double* out8, int32_t reset);
+/* The same builds by PHASE, host wall clock in ms (the build synchronises at every phase boundary anyway).  out[10]:
+ * [0] whole build_index calls, [1] the build's device allocations, [2] assign passes (all of them; [3] the FIRST since the
+ * last reset -- it pays the process's cold start: code load, first launches, first touch of 10s of GB -- and [4] their count),
+ * [5] update_centroids, [6] the cost fold, [7] the inverted lists (grouping, storage plan + allocation, row placement; sharded:
+ * + the rows-to-owners exchange), [8] what derives from the stored rows (centroid operands, |x|^2, fp16 shadow, row-major
+ * copy), [9] the rest (init draws, convergence tests, read-back).  reset != 0 zeroes them (and vers_build_stats'). */
+int32_t vers_build_phases(double* out10, int32_t reset);
 /* IVFFlatIndex::update_centroids (ivfflat.rs:47-71): per cluster the f32 sum
  * of its members in ascending row order divided by the count; empty cluster
  * -> zero vector.  out_centroids is packed [k * d]. */
@@ -276,7 +283,10 @@ int32_t vers_ivf_build_sharded_dev(vers_ivf_t* h, const float* rows_dev, uint64_
  * scan (vers_ivf_shadow_state); 0 = none, and searches on existing handles read their f32 rows until it is 1 again.
  * "scan_events": HIP event records around every list-scan launch, the source of vers_ivf_last_scan's / vers_ivf_scan_times'
  * times: 1 always, 0 never, 2 (default; VERS_SCAN_EVENTS) for batches only -- the two records cost a single-query call
- * 5.5-6 us of ~100, so b == 1 calls are not timed unless asked. */
+ * 5.5-6 us of ~100, so b == 1 calls are not timed unless asked.
+ * "pre_min_batch" (default 8; VERS_PRE_MIN_BATCH): the smallest batch of an nprobe search whose list scan runs on the matrix
+ * cores (fp16 shadow, exact finish) even when its lists are shared by fewer than two queries on average; smaller batches
+ * run one ordered-chain scan per (query, list) pair.  Same results either way. */
 int32_t vers_set_option(const char* name, int64_t value);
 /* Device memory the library holds in this process right now (rows, ids, scratch of every handle) and its high-water
  * mark since the last reset -- lets a test assert that no rank of a sharded build ever allocated the whole corpus. */

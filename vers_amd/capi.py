@@ -89,6 +89,7 @@ SIGNATURES = {
     "vers_kmeans_assign": (C.c_int32, [C.c_int32, _vp, C.c_uint64, C.c_uint64, _vp, C.c_uint64, C.c_uint64, C.c_uint32, _vp, _vp]),
     "vers_assign_stats": (C.c_int32, [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_int32]),
     "vers_build_stats": (C.c_int32, [C.POINTER(C.c_double), C.c_int32]),
+    "vers_build_phases": (C.c_int32, [C.POINTER(C.c_double), C.c_int32]),
     "vers_ivf_test_last_vals": (C.c_int32, [_vp, C.c_uint32, _vp, _vp, _vp, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_double)]),
     "vers_test_mfma": (C.c_int32, [C.c_int32, C.c_uint32, _vp, _vp, C.c_uint32, _vp]),
     "vers_kmeans_update": (C.c_int32, [C.c_int32, _vp, C.c_uint64, C.c_uint64, _vp, C.c_uint64, C.c_uint32, _vp]),
@@ -259,6 +260,14 @@ def build_stats(reset=False) -> dict:
     check(lib().vers_build_stats(v, 1 if reset else 0))
     keys = ("gemm_ms", "gemm_launches", "gemm_flop", "assign_ms", "assign_passes", "update_ms", "cost_ms", "redone_points")
     return dict(zip(keys, (float(x) for x in v)))
+
+
+def build_phases(reset=False) -> dict:
+    """build_index by phase, host wall clock in ms (vers_build_phases)."""
+    v = (C.c_double * 10)()
+    check(lib().vers_build_phases(v, 1 if reset else 0))
+    keys = ("total_ms", "alloc_ms", "assign_ms", "assign_first_pass_ms", "assign_passes", "update_ms", "cost_ms", "install_lists_ms", "derive_ms", "other_ms")
+    return dict(zip(keys, (round(float(x), 2) for x in v)))
 
 
 def test_mfma(kind: int, A: np.ndarray, B: np.ndarray, device: int = 0) -> np.ndarray:

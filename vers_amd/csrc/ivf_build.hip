@@ -8,6 +8,8 @@
 // row_ids[] maps a storage row back to its vec_id.  Lists start on 64-row boundaries and the rows
 // themselves are held in lane-transposed 64-row tiles (scan.hip.h), so a list scan is one linear HBM
 // stream of contiguous 1 KiB wave loads.
+#include <chrono>
+
 #include "gemm.hip.h"
 #include "ivf_handle.hpp"
 #include "prescan.hip.h"
@@ -214,6 +216,13 @@ int32_t refresh_norms(vers_ivf* h, uint64_t r_begin, uint64_t r_end, hipStream_t
 }
 
 // ---- build: storage layout, row placement, k-means ------------------------------------------------------------
+// host wall clock of a phase of build_index, added to BuildStats::*field on scope exit (vers_build_phases)
+struct PhaseClock {
+  double BuildStats::*field;
+  std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+  explicit PhaseClock(double BuildStats::*f) : field(f) {}
+  ~PhaseClock() { build_stats_add(field, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count()); }
+};
 // How the rows of a build are spread over processes.  comm == nullptr: one process holds all n rows.
 struct BuildShard {
   const vers_comm_t* comm = nullptr;
@@ -339,6 +348,8 @@ int32_t plan_storage(vers_ivf* h, const uint32_t* lens, uint32_t k, hipStream_t 
 // Everything of the index that derives from h->centroids and the stored rows: centroids in the scan layout and as
 // MFMA operands, |c|^2, |x|^2.  The index is complete (and the stream idle) on return.
 int32_t finish_index(vers_ivf* h, uint32_t k, uint64_t n_total, hipStream_t st) {
+  VERS_HIP_TRY(hipStreamSynchronize(st));  // (the row placement queued ahead belongs to the install phase's clock)
+  PhaseClock derive_clock(&BuildStats::derive_ms);
   if (int32_t rc = h->centroids_b.reserve(std::max<uint64_t>(1, blocked_floats(k, h->ld)) * sizeof(float))) return rc;
   if (int32_t rc = launch_to_blocked(h->centroids.as<float>(), h->ldx, h->d, k, h->centroids_b.as<float>(), h->ld, st)) return rc;
   h->k_pad = round_up(k ? k : 1, kGemmBN);
@@ -645,6 +656,7 @@ int32_t run_build(vers_ivf* h, const float* X, uint32_t ldx, uint64_t n, const B
   DevBuf C, Cn, S, assign, mind, sorted, idx, idx2, bestC, counts_all, counts_g, tmp_rows, ctl, ctl_all;
   const size_t cbytes = ((size_t)k * ld ? (size_t)k * ld : 1) * sizeof(float);
   const int32_t rc_alloc = [&]() -> int32_t {
+    PhaseClock alloc_clock(&BuildStats::alloc_ms);
     if (int32_t rc = C.reserve(cbytes)) return rc;
     if (int32_t rc = Cn.reserve(cbytes)) return rc;
     if (int32_t rc = bestC.reserve(cbytes)) return rc;
@@ -824,6 +836,7 @@ int32_t build_common(vers_ivf* h, const float* X, uint32_t ldx, uint64_t n, cons
                      uint64_t max_iterations, const uint64_t* init_indices, float* out_centroids, uint64_t c_stride_bytes,
                      uint64_t* out_assignments, float* out_cost, int32_t* out_kept, uint64_t* out_iterations) {
   const uint32_t k = (uint32_t)num_clusters;
+  PhaseClock total_clock(&BuildStats::total_ms);
   DevBuf best_assign;
   float cost = INFINITY;
   int32_t kept = 0;
@@ -846,10 +859,16 @@ int32_t build_common(vers_ivf* h, const float* X, uint32_t ldx, uint64_t n, cons
     h->h_len.clear(); h->h_off.clear(); h->h_cap.clear();
     return VERS_OK;
   }
-  if (sh.comm != nullptr && sh.world > 1) {
-    if (int32_t rc = install_index_sharded(h, X, ldx, n, sh, best_assign.as<uint32_t>(), k, nullptr)) return rc;
-  } else {
-    if (int32_t rc = install_index(h, X, ldx, n, best_assign.as<uint32_t>(), k, nullptr)) return rc;
+  {
+    const auto t_in = std::chrono::steady_clock::now();
+    const double derive0 = build_stats().derive_ms;
+    if (sh.comm != nullptr && sh.world > 1) {
+      if (int32_t rc = install_index_sharded(h, X, ldx, n, sh, best_assign.as<uint32_t>(), k, nullptr)) return rc;
+    } else {
+      if (int32_t rc = install_index(h, X, ldx, n, best_assign.as<uint32_t>(), k, nullptr)) return rc;
+    }
+    // (install = everything of this step but what finish_index accounted as derive)
+    build_stats_add(&BuildStats::install_ms, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_in).count() - (build_stats().derive_ms - derive0));
   }
   if (out_centroids && k)
     VERS_HIP_TRY(hipMemcpy2D(out_centroids, (size_t)c_stride_bytes, h->centroids.p, (size_t)h->ldx * 4, (size_t)h->d * 4, k,

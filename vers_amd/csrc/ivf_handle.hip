@@ -164,6 +164,7 @@ int32_t vers_set_option(const char* name, int64_t value) {
   if (!name) return fail(VERS_ERR_INVALID, "vers_set_option: null name");
   if (std::strcmp(name, "gemm_x3") == 0) { set_gemm_x3_mask((int)value); return VERS_OK; }
   if (std::strcmp(name, "shadow") == 0) { shadow_mode_ref().store(value != 0 ? 1 : 0); return VERS_OK; }
+  if (std::strcmp(name, "pre_min_batch") == 0) { pre_min_batch_ref().store(value < 2 ? 2u : (uint32_t)std::min<int64_t>(value, 0x7FFFFFFF)); return VERS_OK; }
   if (std::strcmp(name, "scan_events") == 0) { scan_events_ref().store(value < 0 || value > 2 ? 2 : (int)value); return VERS_OK; }
   return fail(VERS_ERR_INVALID, std::string("vers_set_option: unknown option ") + name);
 }

@@ -312,6 +312,12 @@ inline std::atomic<int>& shadow_mode_ref() {  // VERS_SHADOW (default 1) / vers_
   return m;
 }
 inline int shadow_mode() { return shadow_mode_ref().load(std::memory_order_relaxed); }
+// VERS_PRE_MIN_BATCH (default 8) / vers_set_option("pre_min_batch", v): the smallest batch whose list scan runs on the matrix
+// cores when its lists are shared by fewer than two queries on average (plan_search)
+inline std::atomic<uint32_t>& pre_min_batch_ref() {
+  static std::atomic<uint32_t> m{[] { const char* e = getenv("VERS_PRE_MIN_BATCH"); return e ? (uint32_t)atol(e) : 8u; }()};
+  return m;
+}
 
 // Tuning / A-B knobs of the search path (environment, read ONCE per process; DESIGN.md section 5 "Switches").
 struct SearchKnobs {
@@ -323,7 +329,6 @@ struct SearchKnobs {
   bool seg_balanced = true;   // VERS_SEG_BALANCED
   uint32_t hot_ranks = 1;     // VERS_HOT_FIRST
   bool pre_narrow = false;    // VERS_PRE_NARROW: 16-query blocks in the matrix-core list scan whatever d is
-  uint32_t pre_min_batch = 8; // VERS_PRE_MIN_BATCH: smallest batch whose list scan runs on the matrix cores when lists are shared by < 2 queries
 };
 inline const SearchKnobs& knobs() {
   static const SearchKnobs k = [] {
@@ -337,7 +342,6 @@ inline const SearchKnobs& knobs() {
     s.seg_balanced = geti("VERS_SEG_BALANCED", 1) != 0;
     s.hot_ranks = (uint32_t)geti("VERS_HOT_FIRST", 1);
     s.pre_narrow = geti("VERS_PRE_NARROW", 0) != 0;
-    s.pre_min_batch = (uint32_t)geti("VERS_PRE_MIN_BATCH", 8);
     return s;
   }();
   return k;

@@ -659,7 +659,7 @@ int32_t plan_search(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint32_t b
   // ordered-chain scan per (query, list) pair -- every list re-read per query, f32 rows): a list probed by ONE query of the batch
   // is still streamed from the half-size shadow at the chip's rate, and the staging of a mostly empty query block costs less
   // than the bytes it saves.  VERS_PRE_MIN_BATCH (default 8) is the smallest batch that takes this path.
-  const bool pre_batch = QG != 1 || (b >= knobs().pre_min_batch && b > 1);
+  const bool pre_batch = QG != 1 || (b >= pre_min_batch_ref().load(std::memory_order_relaxed) && b > 1);
   const bool use_pre = pre_batch && !ref_mode && pre_mode != 0 && top_k + 6 <= kPreMaxKp && P <= (uint32_t)kMaxTopK && pre_nq != 0;
   if (use_pre) QG = (int)pre_nq;
   const uint32_t k_keep = use_pre ? kp : std::min<uint32_t>(top_k, kMaxTopK);

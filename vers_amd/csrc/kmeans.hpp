@@ -74,9 +74,16 @@ struct BuildStats {
   double update_ms = 0;      // update_centroids (grouping excluded)
   double cost_ms = 0;        // the one-lane cost fold
   double redone_points = 0;  // points whose certificate failed (settled by the exact kernels)
+  // host wall clock of the phases of build_index (vers_build_phases): the build synchronises at every phase boundary anyway
+  double alloc_ms = 0;       // the build's device allocations (k-means scratch, assignments, centroid copies)
+  double assign_first_ms = 0;  // the FIRST assign pass since the last reset (it pays the cold start: code load, first launches, first touch)
+  double install_ms = 0;     // inverted lists: grouping by list, storage plan + allocation, row placement (sharded: + the rows-to-owners exchange)
+  double derive_ms = 0;      // what derives from the stored rows and centroids: scan-layout / MFMA operands of the centroids, |x|^2, fp16 shadow, row-major copy
+  double total_ms = 0;       // whole build_index calls (entry to return, incl. read-back of centroids / assignments)
 };
 // Every update of the process-wide statistics goes through these (one mutex: builds of several handles may run side by side).
 void build_stats_add(double BuildStats::*field, double v);
+BuildStats build_stats();  // (a copy, under the mutex)
 // Elapsed time of a stretch of a stream, added to BuildStats::*field when the stream next synchronises (km_timers_collect).
 // RAII: the stretch belongs to the scope that opened it -- it is closed on every path out of it (an early error return
 // used to leave it open and its two events leaked), and two builds on two threads cannot close each other's stretches.

@@ -150,12 +150,19 @@ static __global__ void blocked_row_norms_kernel(const float* rows, uint32_t ld, 
 #define VERS_PRE_WAVES 8
 #endif
 constexpr int kPreWavesG = VERS_PRE_WAVES;  // 4 items x kPreParts waves (8: two per SIMD, <= 256 registers; 12: three per SIMD, <= 168)
+#ifndef VERS_PRE_WPE
+#define VERS_PRE_WPE (VERS_PRE_WAVES / 4)
+#endif
+constexpr int kPreWpe = VERS_PRE_WPE;  // waves per SIMD the kernel is compiled for (its register budget: 512 / kPreWpe)
 constexpr int kPreParts = kPreWavesG / 4;   // waves that share a segment: each walks a contiguous share of its tiles
 static_assert(kPreWavesG % 4 == 0 && kPreWavesG >= 4 && kPreWavesG <= 16, "a quad of segments x 1..4 waves each");
 // Candidate buffer of a query in LDS: `cap` unsorted keys.  kp <= 40 (top_k <= 30 with the default slack): 64 keys, one
 // wave-wide bitonic sort compacts it; wider lists: 128 keys (two sorts + a bitonic merge).  At least 24 free slots after
 // every compaction.
-__host__ __device__ inline uint32_t pre_cap(uint32_t kp) { return kp <= 40u ? 64u : 128u; }
+#ifndef VERS_PRE_CAP_SMALL
+#define VERS_PRE_CAP_SMALL 64
+#endif
+__host__ __device__ inline uint32_t pre_cap(uint32_t kp) { return kp <= 40u ? (uint32_t)VERS_PRE_CAP_SMALL : 128u; }
 // nq = queries per block: kPreQ (32), or 16 -- the NARROW variant for rows too long for a 32-query block (d = 1536: 196 KB
 // against the CU's 160 KB of LDS; 16 queries fit up to d = 2304).  Same kernel, same MFMA (half its query columns idle).
 inline size_t prescan_lds_bytes_g(uint32_t ld, uint32_t kp, uint32_t nq = 32) {  // query block | hand-out word | buffers | cnt, done, thr, locks
@@ -246,9 +253,18 @@ __device__ __forceinline__ void prescan_item_g(const Src& src, const PreParams& 
   uint32_t vslot[2] = {0, 0};
   auto issue_next = [&](auto btag, bool with_thr) {
     constexpr int b = decltype(btag)::value;
+#ifndef VERS_PRE_GTHR_EVERY_STEP
+#define VERS_PRE_GTHR_EVERY_STEP 0
+#endif
     if (with_thr) {
-      gthr[b][0] = __hip_atomic_load(p.bounds32 + vslot[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      gthr[b][1] = kSets == 2 ? __hip_atomic_load(p.bounds32 + vslot[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xFFFFFFFFu;
+      // The query's threshold as its other blocks know it is consumed once per TILE (with the step that completes it); the load
+      // stays unconditional -- a branch around a load costs the ring a vmcnt(0) -- but on every other step all lanes read ONE
+      // word (slot 0) instead of 32 different ones.  These are agent-scope loads: they bypass the XCD's L2, and 32 separate
+      // lines per step and wave were ~400 memory-side transactions per 96 KB tile next to the tile's own 96 (round 3 loaded
+      // them with every step: VERS_PRE_GTHR_EVERY_STEP=1).
+      const bool fin = VERS_PRE_GTHR_EVERY_STEP || ci + 1 >= nch;
+      gthr[b][0] = __hip_atomic_load(p.bounds32 + (fin ? vslot[0] : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      gthr[b][1] = kSets == 2 ? __hip_atomic_load(p.bounds32 + (fin ? vslot[1] : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xFFFFFFFFu;
     } else {
       gthr[b][0] = gthr[b][1] = 0xFFFFFFFFu;
     }
@@ -266,8 +282,6 @@ __device__ __forceinline__ void prescan_item_g(const Src& src, const PreParams& 
   uint32_t vseq[2] = {0, 0};
   float thr[2];
   f32x16_t acc[2];
-#pragma unroll
-  for (int e = 0; e < 16; ++e) acc[0][e] = acc[1][e] = 0.0f;
   bool bad = false;
   // The eight waves of the block walk their tiles at the same pace and meet the same full buffers: every wave starts
   // its round over the overflowed query columns at its own offset, so that they do not all queue for the same lock.
@@ -327,6 +341,85 @@ __device__ __forceinline__ void prescan_item_g(const Src& src, const PreParams& 
         if (lane == 0) atomicAdd(p.stamps + 13, nc);
       }
       uint64_t ovf = __ballot(pend != 0);
+#ifndef VERS_PRE_TRYLOCK
+#define VERS_PRE_TRYLOCK 1
+#endif
+#if VERS_PRE_TRYLOCK
+      // Some query's buffer is full.  ONE wave compacts it (the lock decides which); every other wave with candidates for that
+      // query only waits for the counter to re-open and then places what is still worth placing WITHOUT the lock -- appends
+      // never needed it.  (Round 3 made every such wave take the lock in turn, compaction or not: the eight waves of a block
+      // meet the same full buffers at the same time, and at 8 ranks -- looser thresholds, 17 k compactions and 300 k candidates
+      // per launch -- that queueing was most of the 55 us the list inserts cost a 370 us launch.)
+      while (ovf) {
+        const uint64_t ovr = rot ? (ovf >> rot) | (ovf << (64 - rot)) : ovf;
+        const int L = (__ffsll((unsigned long long)ovr) - 1 + rot) & 63;
+        const uint32_t qq = (uint32_t)__builtin_amdgcn_readlane((int)q, L);
+        const bool mine = q == qq && pend != 0;
+        uint64_t* const bqq = cbuf + (size_t)qq * cap;
+        uint32_t cv = (uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(cnt + qq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP));
+        if (cv >= cap) {
+          uint32_t got = 0;
+          if (lane == 0) got = __hip_atomic_exchange(locks + qq, 1u, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0u ? 1u : 0u;
+          got = (uint32_t)__builtin_amdgcn_readfirstlane((int)got);
+          if (!got) {  // somebody else is compacting it (or was, a moment ago): look again -- at the counter AND, if it is still full, at the lock
+            __builtin_amdgcn_s_sleep(1);
+            continue;
+          }
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+          cv = (uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(cnt + qq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
+          if (cv >= cap) {  // (still full under the lock: this wave compacts)
+            // every reservation below cap belongs to a wave that is on its way to store it without needing this lock
+            while ((uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(done + qq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) != cap)
+              __builtin_amdgcn_s_sleep(1);
+#ifndef VERS_PRE_RANK_SELECT
+#define VERS_PRE_RANK_SELECT 1
+#endif
+            uint32_t kb;
+            if (VERS_PRE_RANK_SELECT && cap == (uint32_t)kWave) {
+              // A full 64-key buffer, one key per lane: the kp smallest by RANK COUNTING -- rank = how many of the 64 keys are
+              // smaller (keys are unique: (val, seq)), 64 x (two v_readlane, one 64-bit compare, one add), no LDS round trips --
+              // instead of a bitonic sort through ds_bpermute (21 dependent stages of two permutes: ~3x the cycles, all of them
+              // under the query's lock with the query's other waves waiting; at 8 ranks a launch makes 17 k of these).  The key of
+              // rank r goes to slot r, so the kept prefix comes out sorted like before.
+              const uint64_t mykey = bqq[lane];
+              uint32_t rank = 0;
+#pragma unroll
+              for (int j = 0; j < kWave; ++j) rank += readlane64(mykey, j) < mykey ? 1u : 0u;
+              if (rank < kp) bqq[rank] = mykey;
+              const uint64_t at = __ballot(rank == kp - 1u);  // (exactly one lane)
+              kb = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mykey >> 32), __ffsll((unsigned long long)at) - 1);
+            } else {
+              const uint64_t srt = buffer_sorted(bqq, cap, cap, lane);
+              if (lane < (int)kp) bqq[lane] = srt;
+              kb = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(srt >> 32), (int)kp - 1);  // cap keys >= kp: always a real key
+            }
+            if (lane == 0) {
+              __hip_atomic_store(thrq + qq, kb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+              __hip_atomic_store(done + qq, kp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // buffer, done and threshold before the counter re-opens it
+            if (lane == 0) __hip_atomic_store(cnt + qq, kp, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if (lane == (int)(BF ? qq : (qq & 15u)) && !(p.debug & 8192u)) atomicMin(p.bounds32 + vslot[S], kb);
+            if (stamp && lane == 0) atomicAdd(p.stamps + 12, 1ull);
+          }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+          if (lane == 0) __hip_atomic_store(locks + qq, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+        }
+        uint32_t mp = 0;
+        if (mine) {  // the threshold moved: most of what was pending is no longer a candidate
+          const uint32_t bh = __hip_atomic_load(thrq + qq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+          if (bh != 0xFFFFFFFFu) {
+            const float g = __uint_as_float(order_bits_to_f32_bits(bh));
+            thr[S] = g < thr[S] ? g : thr[S];
+          }
+#pragma unroll
+          for (int e = 0; e < 16; ++e) mp |= ((pend >> e & 1u) && a[e] <= thr[S]) ? 1u << e : 0u;
+        }
+        append(mp);
+        if (mine) pend = mp;
+        ovf = __ballot(pend != 0);
+      }
+#else
       while (ovf) {  // some query's buffer is full: compact it under its lock, then place what is still worth placing
         const uint64_t ovr = rot ? (ovf >> rot) | (ovf << (64 - rot)) : ovf;
         const int L = (__ffsll((unsigned long long)ovr) - 1 + rot) & 63;
@@ -342,9 +435,28 @@ __device__ __forceinline__ void prescan_item_g(const Src& src, const PreParams& 
             // every reservation below cap belongs to a wave that is on its way to store it without needing this lock
             while ((uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(done + qq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) != cap)
               __builtin_amdgcn_s_sleep(1);
-            const uint64_t srt = buffer_sorted(bqq, cap, cap, lane);
-            if (lane < (int)kp) bqq[lane] = srt;
-            const uint32_t kb = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(srt >> 32), (int)kp - 1);  // cap keys >= kp: always a real key
+#ifndef VERS_PRE_RANK_SELECT
+#define VERS_PRE_RANK_SELECT 1
+#endif
+            uint32_t kb;
+            if (VERS_PRE_RANK_SELECT && cap == (uint32_t)kWave) {
+              // A full 64-key buffer, one key per lane: the kp smallest by RANK COUNTING -- rank = how many of the 64 keys are
+              // smaller (keys are unique: (val, seq)), 64 x (two v_readlane, one 64-bit compare, one add), no LDS round trips --
+              // instead of a bitonic sort through ds_bpermute (21 dependent stages of two permutes: ~3x the cycles, all of them
+              // under the query's lock with the query's other waves waiting; at 8 ranks a launch makes 17 k of these).  The key of
+              // rank r goes to slot r, so the kept prefix comes out sorted like before.
+              const uint64_t mykey = bqq[lane];
+              uint32_t rank = 0;
+#pragma unroll
+              for (int j = 0; j < kWave; ++j) rank += readlane64(mykey, j) < mykey ? 1u : 0u;
+              if (rank < kp) bqq[rank] = mykey;
+              const uint64_t at = __ballot(rank == kp - 1u);  // (exactly one lane)
+              kb = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mykey >> 32), __ffsll((unsigned long long)at) - 1);
+            } else {
+              const uint64_t srt = buffer_sorted(bqq, cap, cap, lane);
+              if (lane < (int)kp) bqq[lane] = srt;
+              kb = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(srt >> 32), (int)kp - 1);  // cap keys >= kp: always a real key
+            }
             if (lane == 0) {
               __hip_atomic_store(thrq + qq, kb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
               __hip_atomic_store(done + qq, kp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
@@ -372,6 +484,7 @@ __device__ __forceinline__ void prescan_item_g(const Src& src, const PreParams& 
         if (lane == 0) __hip_atomic_store(locks + qq, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
         ovf = __ballot(pend != 0);
       }
+#endif
     }
 #pragma unroll
     for (int e = 0; e < 16; ++e) a[e] = 0.0f;
@@ -380,6 +493,9 @@ __device__ __forceinline__ void prescan_item_g(const Src& src, const PreParams& 
   using Set1 = std::integral_constant<int, 1>;
 
   stage();
+  // (the accumulators start behind the block-wide part: across it they would be 32 live registers at the kernel's register peak)
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[0][e] = acc[1][e] = 0.0f;
   // (after the block-wide part: the quad's pair / sequence-base table in LDS is what stage() filled -- or left, for the next quad of a run)
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
@@ -503,7 +619,7 @@ __device__ __forceinline__ void prescan_item_g(const Src& src, const PreParams& 
 }
 
 template <bool BF, int NQ, class Src>
-__global__ __launch_bounds__(kWave * kPreWavesG) __attribute__((amdgpu_waves_per_eu(kPreWavesG / 4, kPreWavesG / 4))) void prescan_kernel_g(Src src, PreParams p) {
+__global__ __launch_bounds__(kWave * kPreWavesG) __attribute__((amdgpu_waves_per_eu(kPreWpe, kPreWpe))) void prescan_kernel_g(Src src, PreParams p) {
   static_assert(NQ == kPreQ || NQ == kPreQNarrow, "32 queries per block, or the narrow variant's 16");
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -571,7 +687,10 @@ __global__ __launch_bounds__(kWave * kPreWavesG) __attribute__((amdgpu_waves_per
       // the first kStageU loads of every thread go out BEFORE the barriers (they fly while the slowest wave of the
       // previous quad finishes and its lists are written out); one load at a time behind the barriers was ~7 us per
       // quad at d = 768 -- 7 % of the launch
-      constexpr int kStageU = 96 / kPreWavesG;  // (x the block's threads / 32 slots = 192 column groups: d <= 768 in one round)
+#ifndef VERS_PRE_STAGE_U
+#define VERS_PRE_STAGE_U (96 / VERS_PRE_WAVES)
+#endif
+      constexpr int kStageU = VERS_PRE_STAGE_U;  // (default: x the block's threads / 32 slots = 192 column groups: d <= 768 in one round)
       const uint32_t n_cg = p.ld / 4u;
       f32x4 x[kStageU];
 #pragma unroll
