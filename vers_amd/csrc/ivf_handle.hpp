@@ -328,6 +328,7 @@ struct SearchKnobs {
   int pre_mode = 1;      // VERS_PRESCAN: 0 ordered chains for batches too, 2 every certificate fails
   bool seg_balanced = true;   // VERS_SEG_BALANCED
   uint32_t hot_ranks = 1;     // VERS_HOT_FIRST
+  bool hot_local = false;     // VERS_HOT_LOCAL=1: a query's nearest list AMONG THOSE THIS GPU SCANS counts as hot (tried in round 4: worse, see plan.hip.h)
   bool pre_narrow = false;    // VERS_PRE_NARROW: 16-query blocks in the matrix-core list scan whatever d is
 };
 inline const SearchKnobs& knobs() {
@@ -342,6 +343,7 @@ inline const SearchKnobs& knobs() {
     s.seg_balanced = geti("VERS_SEG_BALANCED", 1) != 0;
     s.hot_ranks = (uint32_t)geti("VERS_HOT_FIRST", 1);
     s.pre_narrow = geti("VERS_PRE_NARROW", 0) != 0;
+    s.hot_local = geti("VERS_HOT_LOCAL", 0) != 0;
     return s;
   }();
   return k;

@@ -747,7 +747,7 @@ int32_t plan_search(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint32_t b
   pq.list_len = h->list_len.as<uint32_t>(); pq.owner = h->world > 1 ? h->owner.as<uint8_t>() : (const uint8_t*)nullptr; pq.rank = h->rank;
   pq.list_slot = h->list_slot.as<uint32_t>();
   pq.pj_list = pj_list; pq.pj_pref = pj_pref; pq.pj_take = pj_take; pq.np = np; pq.pj_nq = use_pre ? pj_nq : nullptr;
-  pq.cnt = cnt; pq.hot = hot; pq.hot_ranks = knobs().hot_ranks; pq.seg_rows = seg_rows; pq.seg_target = seg_target;
+  pq.cnt = cnt; pq.hot = hot; pq.hot_ranks = knobs().hot_ranks; pq.hot_local = knobs().hot_local ? 1u : 0u; pq.seg_rows = seg_rows; pq.seg_target = seg_target;
   pq.status = W->st_word();
   bool planned = false;
   if (!one1) VERS_HIP_TRY(hipMemsetAsync(cnt, 0, zero_words * sizeof(uint32_t), st));
