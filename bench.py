@@ -134,6 +134,7 @@ def main():
         kept = index.build_dev(X.data_ptr(), n, nlist, 1, args.kmeans_iters, init)
     t_build = time.perf_counter() - t0
     assert kept
+    bph = capi.build_phases()           # (before the reset below: the phases and the event-timed stats share one reset)
     bst = capi.build_stats(reset=True)
     del X
     torch.cuda.empty_cache()
@@ -297,11 +298,11 @@ def main():
     # HBM traffic of the same kernel from the PMC passes of the committed rocprofv3 run (bench.py cannot collect
     # counters itself); used only when it was measured on this exact configuration and kernel.
     kernel_id = ("prescan_kernel_g<true" if shadow else "prescan_kernel_g<false") if mfma_scan else "scan_kernel"
-    kernel_name = ("prescan_kernel_g<true, IvfSrc<32>> (inverted-list scan: fp16 shadow rows -> v_mfma_f32_32x32x16_f16; exact f32 finish in ivf_rescore_kernel)" if shadow
-                   else "prescan_kernel_g<false, IvfSrc<32>> (inverted-list scan on the f32 matrix cores; exact finish in ivf_rescore_kernel)" if mfma_scan
+    kernel_name = ("prescan_kernel_g<true, 32, IvfSrc<32>> (inverted-list scan: fp16 shadow rows -> v_mfma_f32_32x32x16_f16; exact f32 finish in ivf_rescore_kernel)" if shadow
+                   else "prescan_kernel_g<false, 32, IvfSrc<32>> (inverted-list scan on the f32 matrix cores; exact finish in ivf_rescore_kernel)" if mfma_scan
                    else "scan_kernel<QG,0,IvfSrc<QG>> (inverted-list scan, ordered f32 chains; QG = 16 at this shape)")
     traffic, traffic_source = None, None
-    for tf in ("r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):  # newest PMC run of this exact configuration
+    for tf in ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):  # newest PMC run of this exact configuration
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", tf)))
             if (tj["config"] == {"rows": n, "d": d, "nlist": nlist, "nprobe": nprobe, "batch": B} and world == 1
@@ -384,26 +385,36 @@ def main():
              "assign_pass_ms": round(bs["assign_ms"] / max(1.0, bs["assign_passes"]), 2), "assign_passes": int(bs["assign_passes"]),
              "points_redone_exactly_pct": round(100.0 * bs["redone_points"] / max(1.0, bs["gemm_flop"] / (2.0 * k_ * d)), 3),
              "update_centroids_ms_total": round(bs["update_ms"], 2), "cost_fold_ms_total": round(bs["cost_ms"], 2), "build_index_s": round(wall_s, 3), "note": note}
-        for pf in ("r03_kmeans.json",):  # MFMA-busy of this kernel from the committed PMC pass (bench.py cannot collect counters itself)
+        for pf in ("r04_kmeans.json", "r03_kmeans.json"):  # MFMA-busy of this kernel from the committed PMC pass (bench.py cannot collect counters itself)
             try:
                 pj = json.load(open(os.path.join(ROOT, "profiles", pf)))
                 e["mfma_busy_pct"] = pj["mfma_busy_pct"].get(str(int(k_)))
                 e["mfma_busy_source"] = f"profiles/{pf}: rocprofv3 --pmc pass (committed; not collected in this run)"
+                break
             except (OSError, KeyError, ValueError, AttributeError):
                 pass
         return e
 
     if rank == 0:
         sst = index.shadow_state()
+        lay = index.layout_bytes()
         hbm_total = int(torch.cuda.get_device_properties(dev).total_memory)
         rows_stored = max(1, n if world == 1 else int(lens[index.owners() == rank].sum()))
         per_row = float(mem_now) / rows_stored
-        per_row_noshadow = float(mem_now - sst["bytes"]) / rows_stored
-        extra["memory"] = {"library_bytes_now": int(mem_now), "library_bytes_peak_during_build": int(mem_peak), "shadow_bytes": int(sst["bytes"]), "shadow_active": bool(sst["active"]),
-                           "bytes_per_stored_row": round(per_row, 1), "bytes_per_stored_row_without_shadow": round(per_row_noshadow, 1), "hbm_bytes": hbm_total,
-                           "max_N_per_gpu_with_shadow": int((hbm_total - (8 << 30)) / per_row), "max_N_per_gpu_without_shadow": int((hbm_total - (8 << 30)) / per_row_noshadow),
-                           "note": "rows incl. list slack + row ids + |x|^2 (+ fp16 shadow); 8 GB set aside for per-batch scratch and the caller"}
+        per_row_noshadow = float(mem_now - sst["bytes"] - lay["rowmajor"]) / rows_stored
+        per_row_shadow_only = float(mem_now - lay["rowmajor"]) / rows_stored
+        extra["memory"] = {"library_bytes_now": int(mem_now), "library_bytes_peak_during_build": int(mem_peak), "f32_tile_rows_bytes": int(lay["rows"]),
+                           "shadow_bytes": int(sst["bytes"]), "shadow_active": bool(sst["active"]), "rowmajor_copy_bytes": int(lay["rowmajor"]),
+                           "bytes_per_stored_row": round(per_row, 1), "bytes_per_stored_row_without_rowmajor_copy": round(per_row_shadow_only, 1),
+                           "bytes_per_stored_row_without_shadow_and_rowmajor_copy": round(per_row_noshadow, 1), "hbm_bytes": hbm_total,
+                           "max_N_per_gpu_as_configured": int((hbm_total - (8 << 30)) / per_row), "max_N_per_gpu_with_shadow": int((hbm_total - (8 << 30)) / per_row_shadow_only),
+                           "max_N_per_gpu_without_shadow": int((hbm_total - (8 << 30)) / per_row_noshadow),
+                           "note": "rows incl. list slack + row ids + |x|^2, + the fp16 shadow the batched scan streams, + the row-major f32 copy the exact finish gathers "
+                                   "from (optional: kept while the rows take <= 1/4 of the device, VERS_ROWMAJOR=0 drops it); 8 GB set aside for per-batch scratch and the caller"}
         extra["build_index_s"] = round(t_build, 3)
+        extra["build_index_phases_ms"] = dict(bph, note="host wall clock per phase of this build (vers_build_phases); assign_first_pass_ms pays the process's cold start "
+                                                        "(code load, first launches, first touch of the 10s of GB just allocated); install_lists = grouping + storage allocation + row "
+                                                        "placement; derive = centroid operands, |x|^2, fp16 shadow, row-major copy")
         if sharded_build:
             extra["sharded_build"] = sharded_build
         ke = assign_entry(bst, min(131072, hi - lo), nlist, t_build, f"the timed index's own build: N={n} over {world} rank(s), k={nlist}, {int(index.iterations[0])} iterations + final assign")
@@ -494,6 +505,11 @@ def main():
         # dominant kernel is therefore taken from the same steps run one batch after the other (--streams 1) right after the
         # timed region, same process, same HIP events; the timed region's own figure stays in the line beside it.
         t1s, ms1s = timed_steps(nprobe, 1)
+        try:
+            extra["exact_finish_us"] = {"us": round(index.last_finish_ms() * 1e3, 1), "kernel": "ivf_rescore_kernel (merge of the partial lists, certificate, exact re-score, emit)",
+                                        "rowmajor_copy": bool(index.layout_bytes()["rowmajor"]), "measured_on": "the last step of the one-batch-in-flight pass (HIP events)"}
+        except capi.VersError:
+            pass
         if len(ms1s):
             m1 = float(np.mean(ms1s))
             roofline["timed_region"] = {"launch_ms": roofline["launch_ms"], "achieved": roofline["achieved"], "frac": roofline["frac"], "launches_timed": roofline["launches_timed"],
@@ -514,11 +530,18 @@ def main():
         try:
             capi.set_option("shadow", 0)
             t32, ms32 = timed_steps(nprobe)
-            if len(ms32):
-                m = float(np.mean(ms32))
-                extra["list_scan_f32_rows"] = {"kernel": "prescan_kernel_g<false, IvfSrc<32>> (f32 rows -> v_mfma_f32_16x16x1_4b_f32)", "launch_ms": round(m, 4),
+            t32_1, ms32_1 = timed_steps(nprobe, 1) if S > 1 else (t32, ms32)   # (the kernel with the chip to itself: the headline's convention)
+            if len(ms32) and len(ms32_1):
+                mq = float(np.mean(ms32))
+                m = float(np.mean(ms32_1))
+                extra["list_scan_f32_rows"] = {"kernel": "prescan_kernel_g<false, 32, IvfSrc<32>> (f32 rows -> v_mfma_f32_16x16x1_4b_f32)", "launch_ms": round(m, 4),
                                                "algorithmic_bytes_per_launch": int(f32_bytes), "achieved_GBs": round(f32_bytes / (m * 1e-3) / 1e9, 1),
-                                               "frac": round(f32_bytes / (m * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "steps": args.steps, "warmup": args.warmup,
+                                               "frac": round(f32_bytes / (m * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                               "measured_on": "the same steps one batch in flight (like roofline.frac of the headline)",
+                                               "timed_region": {"launch_ms": round(mq, 4), "frac": round(f32_bytes / (mq * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
+                                                                "note": f"event pairs with {S} batches in flight: includes queueing behind another batch's scan"},
+                                               "one_batch_in_flight_whole_step_ms": round(t32_1 / args.steps * 1e3, 4),
+                                               "steps": args.steps, "warmup": args.warmup,
                                                "whole_step_ms": round(t32 / args.steps * 1e3, 4), "whole_step_queries_per_sec": round(args.steps * B / t32, 1),
                                                "note": "the same index and batches with vers_set_option('shadow', 0), timed like the headline (after it): round 1's configuration (VERS_SHADOW=0 / --f32-rows makes it the whole run)"}
         finally:
@@ -567,6 +590,93 @@ def main():
                                  "end_to_end_us": round(e2e * 1e6, 1), "end_to_end_qps": round(1.0 / e2e, 1)}
         log(f"[bench] single query: list scan {extra['single_query']['list_scan_us']} us for {np.mean(by1) / 1e6:.0f} MB = "
             f"{gbs1:.0f} GB/s ({gbs1 / HBM_PEAK_GBS:.2f} of peak); end to end {e2e * 1e6:.1f} us per query")
+        # (a2) between batch 1 and the headline's batch: queries/s, us per batch and which list scan ran (the reference's interface is
+        # per query, ivfflat.rs:153: small batches are the realistic serving shape).  One batch per size is kept for the CPU leg.
+        sweep, sweep_keep = {}, {}
+        for bsz in (1, 8, 32, 128, 512, 1024):
+            if bsz > B:
+                continue
+            def sw_step(i, bsz=bsz):
+                o = outs[i % S]
+                index.search_dev(Q[(i * bsz) % (n_batches * B - bsz + 1):].data_ptr(), ld, bsz, top_k, nprobe, o["ids"].data_ptr(), o["dst"].data_ptr(), o["cnt"].data_ptr(),
+                                 streams[i % S].cuda_stream)
+            for i in range(4):
+                sw_step(i)
+            torch.cuda.synchronize(); pb0 = index.prescan_stats()["batches"]; nst = 40 if bsz <= 128 else 12; t0 = time.perf_counter()
+            for i in range(nst):
+                sw_step(4 + i)
+            torch.cuda.synchronize(); dt_ = (time.perf_counter() - t0) / nst
+            for x in streams:
+                index.poll(x.cuda_stream)
+            on_mc = index.prescan_stats()["batches"] - pb0 == nst
+            sweep[str(bsz)] = {"us_per_batch": round(dt_ * 1e6, 1), "queries_per_sec": round(bsz / dt_, 1),
+                               "list_scan": "prescan_kernel_g (matrix cores, fp16 shadow) + exact finish" if on_mc else
+                                            ("scan1_kernel (single-query item records)" if bsz == 1 else "scan_kernel (ordered chains)")}
+            kq = Q[(last % n_batches) * B:(last % n_batches) * B + bsz]
+            ki = torch.zeros(bsz, top_k, dtype=torch.int64, device=dev); kd = torch.zeros(bsz, top_k, device=dev); kc = torch.zeros(bsz, dtype=torch.int32, device=dev)
+            index.search_dev(kq.data_ptr(), ld, bsz, top_k, nprobe, ki.data_ptr(), kd.data_ptr(), kc.data_ptr(), st)
+            index.poll(st)
+            sweep_keep[bsz] = (ki.cpu().numpy().astype(np.uint64), kd.cpu().numpy(), kc.cpu().numpy())
+        extra["batch_sweep"] = {"workload": f"the headline's index and queries at other batch sizes, {S} batches in flight, nprobe={nprobe} top_k={top_k}", "by_batch": sweep}
+        log("[bench] batch sweep: " + ", ".join(f"{k_}: {v_['queries_per_sec'] / 1e3:.1f} k q/s ({v_['us_per_batch']} us)" for k_, v_ in sweep.items()))
+        # (a3) d = 1536 -- a dimension the reference's own bindings instantiate (vers-py/src/lib.rs:26-65); the 32-query block of the
+        # matrix-core scan does not fit LDS there, the narrow 16-query variant does.  Same geometry as the headline at half the rows.
+        d15 = 1536
+        n15 = max(4096, min(5_000_000, n // 2)); nl15 = max(4, nlist // 2)
+        X15 = torch.empty(n15, d15, dtype=torch.float32, device=dev)
+        capi.gen_rows_dev(X15.data_ptr(), n15, d15, d15, 1, SEED_X + 0x1536, SEED_C, args.modes_per_list * nl15, float(dg.default_sigma(d15)))
+        i15 = IVFFlatIndex(d15, device=dev_index)
+        init15 = (dg.mix64(np.uint64(0xB15) + np.arange(nl15, dtype=np.uint64)) % np.uint64(n15)).astype(np.uint64)
+        t0 = time.perf_counter(); i15.build_dev(X15.data_ptr(), n15, nl15, 1, 2, init15); t_b15 = time.perf_counter() - t0
+        del X15
+        torch.cuda.empty_cache()
+        Q15 = torch.empty(4 * B, d15, dtype=torch.float32, device=dev)
+        capi.gen_rows_dev(Q15.data_ptr(), 4 * B, d15, d15, 1, SEED_Q + 0x1536, SEED_C, args.modes_per_list * nl15, float(dg.default_sigma(d15)))
+        np15 = min(nprobe, nl15)
+        def s15(i, S_=S):
+            o = outs[i % S_]
+            i15.search_dev(Q15[(i % 4) * B:].data_ptr(), d15, B, top_k, np15, o["ids"].data_ptr(), o["dst"].data_ptr(), o["cnt"].data_ptr(), streams[i % S_].cuda_stream)
+        for i in range(3):
+            s15(i)
+        torch.cuda.synchronize(); pb0 = i15.prescan_stats()["batches"]; t0 = time.perf_counter()
+        for i in range(10):
+            s15(3 + i)
+        torch.cuda.synchronize(); t15 = (time.perf_counter() - t0) / 10
+        on_mc15 = i15.prescan_stats()["batches"] - pb0 == 10
+        for x in streams:
+            i15.poll(x.cuda_stream)
+        i15.scan_times(reset=True)
+        for i in range(6):
+            s15(i, 1)
+        torch.cuda.synchronize(); i15.poll(streams[0].cuda_stream)
+        ms15 = i15.scan_times(reset=True)[-4:]; l15 = i15.last_scan()
+        by15 = l15["union_rows"] * (d15 * 2 + 4) + nl15 * d15 * 4
+        m15 = float(np.mean(ms15)) if len(ms15) else float("nan")
+        e15 = {"workload": f"IVFFlat N={n15} d={d15} nlist={nl15} nprobe={np15} batch={B} top_k={top_k}, {S} batches in flight", "ms_per_step": round(t15 * 1e3, 4),
+               "queries_per_sec": round(B / t15, 1), "list_scan": "prescan_kernel_g<true, 16> (narrow 16-query blocks, fp16 shadow) + exact finish" if on_mc15 else "scan_kernel (ordered chains)",
+               "list_scan_ms_one_batch_in_flight": round(m15, 4), "algorithmic_bytes_per_launch": int(by15), "achieved_GBs": round(by15 / (m15 * 1e-3) / 1e9, 1),
+               "frac": round(by15 / (m15 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "streamed_over_union_rows": round(l15["streamed_rows"] / max(1, l15["union_rows"]), 3),
+               "build_index_s": round(t_b15, 2)}
+        if not args.no_cpu:   # two queries of the last batch against the CPU restatement, bit for bit
+            from oracle import c_oracle as co15
+            c15 = np.ascontiguousarray(i15.get_centroids()); q15 = Q15[(5 % 4) * B:(5 % 4) * B + 2].cpu().numpy()
+            g_i, g_d, g_c = outs[0]["ids"][:2].cpu().numpy().astype(np.uint64), outs[0]["dst"][:2].cpu().numpy(), outs[0]["cnt"][:2].cpu().numpy()
+            ok15 = True
+            for qi in range(2):
+                ranked, _ = co15.search_exhaustive(c15, q15[qi], nl15)
+                lists15 = [i15.get_list(int(c_)) for c_ in ranked[:np15]]
+                vals = np.concatenate([r_[0] for r_ in lists15]); vid = np.concatenate([r_[1] for r_ in lists15])
+                ids_l = [[] for _ in range(nl15)]
+                off_ = 0
+                for c_, r_ in zip(ranked[:np15], lists15):
+                    ids_l[int(c_)] = list(range(off_, off_ + len(r_[1]))); off_ += len(r_[1])
+                oi_, od_ = co15.search_nprobe(vals, c15, ids_l, q15[qi], top_k, np15)
+                ok15 &= bool(g_c[qi] == len(oi_) and np.array_equal(vid[oi_.astype(np.int64)], g_i[qi, :len(oi_)]) and np.array_equal(od_.view(np.uint32), g_d[qi, :len(od_)].view(np.uint32)))
+            e15["gpu_matches_cpu_bitwise"] = ok15
+        extra["d1536"] = e15
+        log(f"[bench] d = 1536 (N={n15}, nlist={nl15}): {e15['queries_per_sec'] / 1e3:.1f} k q/s, list scan {m15:.3f} ms = {e15['frac']} of peak ({e15['list_scan']})")
+        i15.close(); del Q15
+        torch.cuda.empty_cache()
         # (b) BASELINE.json cfg2: brute-force scan N = 1M, d = 128, one query; FOUR corpora in rotation (2 GB > the 256 MiB
         # Infinity Cache), kernel time from HIP events
         n2, d2, rot = 1_000_000, 128, 4
@@ -740,6 +850,17 @@ def main():
                                  f"reference itself searches serially)", "gpu_matches_cpu_bitwise": bad == 0}
             log(f"[bench] cpu baseline on all {cores} host threads ({model}): {cpu_all['value']} q/s over {n_par} queries; GPU==CPU bitwise: {bad == 0}")
 
+        # ---- the batch sweep's kept batches against vo_search_nprobe, two queries per size, bit for bit ------------------------------
+        if "batch_sweep" in extra:
+            for bsz, (ki_, kd_, kc_) in sweep_keep.items():
+                okb = True
+                for qi in sorted({0, bsz - 1}):
+                    q = np.ascontiguousarray(qh[qi])
+                    _, gi_, gd_ = run_one(q, sub_index(q))
+                    okb &= bool(kc_[qi] == len(gi_) and np.array_equal(gi_, ki_[qi, :len(gi_)]) and np.array_equal(gd_.view(np.uint32), kd_[qi, :len(gd_)].view(np.uint32)))
+                extra["batch_sweep"]["by_batch"][str(bsz)]["gpu_matches_cpu_bitwise"] = okb
+            log(f"[bench] batch sweep: GPU == CPU bitwise at every size: {all(v_['gpu_matches_cpu_bitwise'] for v_ in extra['batch_sweep']['by_batch'].values())}")
+
         # ---- the reference's own mode: GPU batch of extra.reference_mode against vo_search, bit for bit ----------------------
         if "reference_mode" in extra:
             ri, rd, rc_ = refo["ids"].cpu().numpy().astype(np.uint64), refo["dst"].cpu().numpy(), refo["cnt"].cpu().numpy()
@@ -838,6 +959,7 @@ def main():
                           "kmeans_iters": int(index.iterations[0]), "parallelism": f"lists sharded over {world} GPU(s)", "batches_in_flight": S,
                           "exchange": exchange_kind},
                "roofline": roofline, "cpu_baseline": cpu, "cpu_baseline_all_cores": cpu_all, "cpu_baseline_kmeans": cpu_km, "extra": extra}
+        out["row_operand"] = roofline["row_operand"]   # what the DOMINANT KERNEL streams (dtype above = what the path computes and returns)
         if shadow and "list_scan_f32_rows" in extra:
             out["value_f32_rows"] = extra["list_scan_f32_rows"]["whole_step_queries_per_sec"]  # the same steps with VERS_SHADOW=0, timed like the headline, after it
         if shadow:
