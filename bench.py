@@ -649,7 +649,7 @@ def main():
         for i in range(6):
             s15(i, 1)
         torch.cuda.synchronize(); i15.poll(streams[0].cuda_stream)
-        ms15 = i15.scan_times(reset=True)[-4:]; l15 = i15.last_scan()
+        l15 = i15.last_scan(); ms15 = i15.scan_times(reset=True)[-4:]
         by15 = l15["union_rows"] * (d15 * 2 + 4) + nl15 * d15 * 4
         m15 = float(np.mean(ms15)) if len(ms15) else float("nan")
         e15 = {"workload": f"IVFFlat N={n15} d={d15} nlist={nl15} nprobe={np15} batch={B} top_k={top_k}, {S} batches in flight", "ms_per_step": round(t15 * 1e3, 4),
