@@ -228,9 +228,10 @@ def test_row_sharded_build_at_cfg5_cluster_count_equals_the_single_process_build
             assert np.array_equal(ids, one["sample"][c]), (r, c)
         # storage of its lists + send + receive buffers (the rank's own rows are the caller's) + k-means scratch (201 MB of
         # centroids x a few).  At N / k = 16 rows per list the storage is dominated by what every list costs whatever its length
-        # -- a whole 64-row tile of rows plus 64 rows of `add` slack, f32 and fp16 shadow: 128 x d x 6 bytes -- not by the rows;
+        # -- a whole 64-row tile of rows plus 64 rows of `add` slack, f32 tiles, fp16 shadow and row-major copy: 128 x d x 10 bytes -- not by the rows;
         # cfg5 proper has 763 rows per list and that overhead is 9 %.
-        per_list = 128 * BIGK["d"] * 6 * (BIGK["k"] // 2 + 1)
+        # (+ 4 bytes per element for the row-major copy the exact finish gathers from: kept by default since round 4 while it fits)
+        per_list = 128 * BIGK["d"] * 10 * (BIGK["k"] // 2 + 1)
         assert g["peak"] < 3.5 * g["share"] + per_list + (2 << 30), (r, g["peak"], g["share"])
         assert g["calls"]["all_to_all_v"] == 2
     assert set(ret[(2, 0)]["sample"]) | set(ret[(2, 1)]["sample"]) == set(one["sample"])
