@@ -620,9 +620,12 @@ def main():
         extra["batch_sweep"] = {"workload": f"the headline's index and queries at other batch sizes, {S} batches in flight, nprobe={nprobe} top_k={top_k}", "by_batch": sweep}
         log("[bench] batch sweep: " + ", ".join(f"{k_}: {v_['queries_per_sec'] / 1e3:.1f} k q/s ({v_['us_per_batch']} us)" for k_, v_ in sweep.items()))
         # (a3) d = 1536 -- a dimension the reference's own bindings instantiate (vers-py/src/lib.rs:26-65); the 32-query block of the
-        # matrix-core scan does not fit LDS there, the narrow 16-query variant does.  Same geometry as the headline at half the rows.
+        # matrix-core scan does not fit LDS there, the narrow 16-query variant does.  The headline's geometry at half the rows: the same
+        # nlist / nprobe / batch, i.e. the same queries per list (8 on average: a 16-query block serves most lists in one pass) and the
+        # same bytes per list.  (With HALF the lists -- 16 queries per list on average -- most lists need two passes of a narrow block:
+        # measured 0.45 of the HBM roofline on algorithmic bytes with the stream itself at the chip's 6.5 TB/s, streamed / union = 1.8.)
         d15 = 1536
-        n15 = max(4096, min(5_000_000, n // 2)); nl15 = max(4, nlist // 2)
+        n15 = max(4096, min(5_000_000, n // 2)); nl15 = nlist
         X15 = torch.empty(n15, d15, dtype=torch.float32, device=dev)
         capi.gen_rows_dev(X15.data_ptr(), n15, d15, d15, 1, SEED_X + 0x1536, SEED_C, args.modes_per_list * nl15, float(dg.default_sigma(d15)))
         i15 = IVFFlatIndex(d15, device=dev_index)
