@@ -107,7 +107,7 @@ if "1" in out["worlds"]:
     for NS in STREAMS:
         one = out["worlds"]["1"][f"step_ms_s{NS}"]["max"]
         out[f"predicted_speedup_s{NS}"] = {w: round(one / out["worlds"][w][f"step_ms_s{NS}"]["max"], 2) for w in out["worlds"]}
-path = os.environ.get("OUT", "gpurun_out/emulate_shard.json")
+path = os.environ.get("EMU_OUT") or os.environ.get("OUT", "gpurun_out/emulate_shard.json")
 os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
 json.dump(out, open(path, "w"), indent=1)
 print(json.dumps({k: v for k, v in out.items() if k.startswith("predicted")}))
