@@ -340,7 +340,7 @@ __device__ __forceinline__ void prescan_item_g(const Src& src, const PreParams& 
         const unsigned long long nc = (unsigned long long)__popcll(__ballot(pm != 0));
         if (lane == 0) atomicAdd(p.stamps + 13, nc);
       }
-      uint64_t ovf = __ballot(pend != 0);
+      uint64_t ovf = (p.debug & 4096u) ? 0ull : __ballot(pend != 0);  // (diagnosis, VERS_SCAN_DEBUG & 4096: candidates that find their buffer full are DROPPED -- wrong results, the appends' cost without the compactions')
 #ifndef VERS_PRE_TRYLOCK
 #define VERS_PRE_TRYLOCK 1
 #endif
@@ -511,10 +511,36 @@ __device__ __forceinline__ void prescan_item_g(const Src& src, const PreParams& 
   uint32_t tc = t_begin, cc = 0;
   unsigned long long t_math = 0, t_fold = 0, t_issue = 0;
   const unsigned long long tp1 = stamp ? __builtin_amdgcn_s_memtime() : 0ull;
+  bool fold_pending = false;  // (wave-uniform)
+  uint32_t fold_tile = 0;
+  auto run_folds = [&]() {
+    if constexpr (BF) {
+      fold(Set0{}, acc[0], fold_tile, 0u);
+      fold(Set0{}, acc[1], fold_tile, 1u);
+    } else {
+      fold(Set0{}, acc[0], fold_tile, 0u);
+      if (two) fold(Set1{}, acc[1], fold_tile, 0u);
+    }
+  };
   auto step = [&](auto btag, uint32_t s0) {
     constexpr int B = decltype(btag)::value;
     const unsigned long long ti0 = stamp ? __builtin_amdgcn_s_memtime() : 0ull;
     issue_next(std::integral_constant<int, (B + R - 1) % R>{}, true);
+#ifndef VERS_PRE_FOLD_LATE
+#define VERS_PRE_FOLD_LATE 0
+#endif
+    // VERS_PRE_FOLD_LATE=1 (tried in round 4, off): the fold of the tile the PREVIOUS step completed runs here, behind this
+    // step's loads, so that whatever it costs -- appends, a compaction, the wait for another wave's compaction (at 8 ranks a
+    // launch makes 17 k compactions: 35 of its 350 us by ablation) -- the wave has two steps in flight meanwhile instead of one.
+    // Same-box A/B: the scan alone equal (350-361 vs 351-354 us at 8 ranks), the step with three batches in flight WORSE
+    // (0.426-0.436 vs 0.408-0.415 ms): both ring buffers live across the fold take the kernel from 221 to 251 registers, and the
+    // exact finish of another batch (46 registers, 4 waves) no longer fits beside a scan block on a CU.
+    if (VERS_PRE_FOLD_LATE && fold_pending) {
+      const unsigned long long tf0 = stamp ? __builtin_amdgcn_s_memtime() : 0ull;
+      run_folds();
+      fold_pending = false;
+      if (stamp) t_fold += __builtin_amdgcn_s_memtime() - tf0;
+    }
     if (s0 + B < n_steps) {
       unsigned long long t1 = 0, t2 = 0;
       if (stamp) { t1 = __builtin_amdgcn_s_memtime(); t_issue += t1 - ti0; }
@@ -581,18 +607,15 @@ __device__ __forceinline__ void prescan_item_g(const Src& src, const PreParams& 
         if constexpr (BF) {
           // + |x_row|^2 for every query column: A[i][k] = xn of lane (i, k) = row 32k + i of the tile, B[k][j] = (k == h)
           acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(xn[B], quarter == 0 ? nrm : 0.0f, acc[0], 0, 0, 0);
-          fold(Set0{}, acc[0], tc, 0u);
           acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(xn[B], quarter == 1 ? nrm : 0.0f, acc[1], 0, 0, 0);
-          fold(Set0{}, acc[1], tc, 1u);
         } else {
           acc[0] = __builtin_amdgcn_mfma_f32_16x16x1f32(xn[B], nrm, acc[0], 0, 0, 0);  // + |x_row|^2 for every query column
-          fold(Set0{}, acc[0], tc, 0u);
-          if (two) {
-            acc[1] = __builtin_amdgcn_mfma_f32_16x16x1f32(xn[B], nrm, acc[1], 0, 0, 0);
-            fold(Set1{}, acc[1], tc, 0u);
-          }
+          if (two) acc[1] = __builtin_amdgcn_mfma_f32_16x16x1f32(xn[B], nrm, acc[1], 0, 0, 0);
         }
+        fold_tile = tc;
         ++tc;
+        if (VERS_PRE_FOLD_LATE) fold_pending = true;   // (folded at the top of the next step, behind its loads; after the loop for the last tile)
+        else run_folds();
         if (stamp) t_fold += __builtin_amdgcn_s_memtime() - t2;
       }
     }
@@ -602,6 +625,7 @@ __device__ __forceinline__ void prescan_item_g(const Src& src, const PreParams& 
     step(std::integral_constant<int, 1>{}, s0);
     if constexpr (R == 3) step(std::integral_constant<int, 2>{}, s0);
   }
+  if (fold_pending) run_folds();  // (the item's last tile)
   const unsigned long long te0 = stamp ? __builtin_amdgcn_s_memtime() : 0ull;
   if (stamp && lane == 0) {
     atomicAdd(p.stamps + 1, t_math);
