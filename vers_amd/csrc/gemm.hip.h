@@ -699,12 +699,22 @@ inline hipError_t launch_split_bf16(const float* x, uint64_t n_floats, __bf16* h
 // C_rm: centroids row-major [k][ldc] (pad columns zero); qp: padded queries [b][ldq].
 // probe[q][0..P) receives ascending (exact distance, centroid index) keys -- the exact coarse output.
 // pq.b != 0: the query's plan (plan.hip.h step 1) is made right here -- lane j holds the key of probe rank j.
-static __global__ __launch_bounds__(kWave) void coarse_select_rescore_kernel(
+// kSelectWaves queries per block, a wave each, nothing shared between them: the waves of a block never synchronise.  ONE per
+// block is the default, as in round 3.  Tried in round 4 (VERS_SELECT_WAVES=4 | 8: the kernel's 1024 waves on a half / a quarter
+// of the chip's CUs at two waves per SIMD, so that with batches in flight the other CUs keep a list scan running): same-box A/B
+// at 8 ranks -- three in flight 0.394-0.408 (8) / 0.405-0.411 (4) / 0.401-0.412 ms (1): nothing; one batch at a time 0.536-0.546
+// against 0.524-0.531 ms: the packed kernel itself is 12 us slower.
+#ifndef VERS_SELECT_WAVES
+#define VERS_SELECT_WAVES 1
+#endif
+constexpr int kSelectWaves = VERS_SELECT_WAVES;
+static __global__ __launch_bounds__(kWave * kSelectWaves) void coarse_select_rescore_kernel(
     const float* G, uint32_t N_pad, uint32_t k, const float* C_rm, uint32_t ldc, const float* qp, uint32_t ldq, uint32_t d_pad,
     float cmax2, uint32_t P, uint32_t PS, uint64_t* probe, uint32_t* status, uint32_t* fallback_count, int metric,
-    unsigned long long* stamps, PlanQ pq) {
-  const uint32_t q = blockIdx.x;
-  const int lane = threadIdx.x;
+    unsigned long long* stamps, PlanQ pq, uint32_t n_queries) {
+  const uint32_t q = blockIdx.x * kSelectWaves + (threadIdx.x >> 6);
+  if (q >= n_queries) return;  // (whole waves)
+  const int lane = threadIdx.x & 63;
   const unsigned long long t0 = stamps ? __builtin_amdgcn_s_memtime() : 0ull;
   const float* g = G + (uint64_t)q * N_pad;
   // (1) PS smallest approximate values; key = (order bits of G, centroid index).
@@ -714,7 +724,8 @@ static __global__ __launch_bounds__(kWave) void coarse_select_rescore_kernel(
   // 64 compares per lane and one wave reduction -- until PS <= count <= 64; the survivors are compacted through LDS,
   // sorted across the lanes (bitonic network) and merged with the best of the previous chunks.  Every key among the
   // chunk's PS smallest passes the filter (ties at T included), so `sel` is exactly what the serial inserts produce.
-  __shared__ uint64_t s_keys[kWave];
+  __shared__ uint64_t s_keys_all[kSelectWaves][kWave];
+  uint64_t* const s_keys = s_keys_all[threadIdx.x >> 6];  // (this wave's own: LDS operations of one wave execute in order)
   uint64_t sel = kKeyMax;
   constexpr int kR = 64;  // registers per lane and chunk
   for (uint32_t n0 = 0; n0 < k; n0 += kR * kWave) {
@@ -777,10 +788,14 @@ static __global__ __launch_bounds__(kWave) void coarse_select_rescore_kernel(
         if (in) s_keys[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = ((uint64_t)gb[r] << 32) | (n0 + r * kWave + lane);
         base += (uint32_t)__popcll(m);
       }
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-      __builtin_amdgcn_s_barrier();  // (one wave per block: orders the LDS writes before the reads below)
+      // (the wave's own slice: its ds_writes above complete before its ds_reads below -- LDS is in order per wave; the fences only
+      // keep the compiler from moving them across.  Round 3's one-wave blocks used s_barrier here; with several independent waves
+      // per block a block-wide barrier would deadlock on waves that take the serial path.)
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
       cur = (uint32_t)lane < base ? s_keys[lane] : kKeyMax;
-      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
       wave_bitonic_sort64(cur, lane);
       if (n0 == 0) sel = cur;
       else {  // the 64 smallest of (best so far, this chunk)
