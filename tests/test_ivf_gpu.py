@@ -332,3 +332,40 @@ def test_scan_events_option_times_single_query_scans_only_on_request():
     finally:
         capi.set_option("scan_events", 2)
         ix.close()
+
+
+def test_round4_entry_points_and_hooks():
+    """vers_ivf_search_sharded_dev without an exchange (g == NULL: a single process) == vers_ivf_search_dev; its argument checks;
+    the layout / finish-time / build-phase hooks report what the handle holds and ran."""
+    import ctypes as C
+    import torch
+    from vers_amd.dist import VersGather
+    n, d, k = 6000, 96, 24
+    X = dg.dist_c(0x4A, n, d, 48, dg.default_sigma(d))
+    init = mg.init_draws(0x4A, 1, k, n)
+    capi.build_phases(reset=True)
+    ix = IVFFlatIndex.build_index(k, 1, 3, X, init_indices=init)
+    ph = capi.build_phases()
+    assert ph["total_ms"] > 0 and ph["install_lists_ms"] > 0 and ph["derive_ms"] > 0 and ph["total_ms"] >= ph["install_lists_ms"] + ph["derive_ms"]
+    lay = ix.layout_bytes()
+    assert lay["rows"] >= n * d * 4 and lay["shadow"] * 2 == lay["rows"] and lay["rowmajor"] == lay["rows"]   # all three copies by default at this size
+    b, top_k = 96, 10
+    Q = dg.dist_c(0x4B, b, d, 48, dg.default_sigma(d))
+    Qd = torch.from_numpy(Q).cuda()
+    for nprobe in (0, 6):
+        wi, wd, wc = ix.search_batch(Q, top_k, nprobe)
+        oi = torch.zeros(b, top_k, dtype=torch.int64, device="cuda"); od = torch.zeros(b, top_k, device="cuda"); oc = torch.zeros(b, dtype=torch.int32, device="cuda")
+        ix.search_sharded_dev(None, Qd.data_ptr(), d, b, top_k, nprobe, oi.data_ptr(), od.data_ptr(), oc.data_ptr())
+        ix.poll()
+        assert np.array_equal(oc.cpu().numpy(), wc)
+        for q in range(b):
+            c = int(wc[q])
+            assert np.array_equal(oi.cpu().numpy().astype(np.uint64)[q, :c], wi[q, :c]) and np.array_equal(bits(od.cpu().numpy()[q, :c]), bits(wd[q, :c]))
+    assert ix.last_finish_ms() > 0          # (the nprobe batch went through the matrix-core scan and its exact finish)
+    # argument checks: top_k = 0, a gather that says another world than the handle's, one without a callback
+    with pytest.raises(capi.VersError):
+        ix.search_sharded_dev(None, Qd.data_ptr(), d, b, 0, 6, oi.data_ptr(), od.data_ptr(), oc.data_ptr())
+    g = VersGather(None, 0, 2)
+    with pytest.raises(capi.VersError):
+        ix.search_sharded_dev(C.cast(C.byref(g), C.c_void_p), Qd.data_ptr(), d, b, top_k, 6, oi.data_ptr(), od.data_ptr(), oc.data_ptr())
+    ix.close()

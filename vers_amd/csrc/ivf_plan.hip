@@ -253,7 +253,7 @@ struct Plan1Args {
   const uint32_t* list_len; const uint8_t* owner; uint32_t rank, seg_rows;
   uint64_t* probe; uint32_t *pj_list, *pj_pref, *pj_take, *np, *cnt, *pair_off, *group_off, *pairs;
   ItemDesc* items; GroupDesc* groups; GroupTotals* tot; uint32_t* status; const uint32_t* list_slot;
-  Item1Rec* recs = nullptr; const uint32_t *slot_off = nullptr, *slot_len = nullptr; uint32_t S_max = 0;  // recs != nullptr: the items as records (scan1_kernel)
+  Item1Rec* recs = nullptr; const uint32_t* list_off = nullptr; uint32_t S_max = 0;  // recs != nullptr: the items as records (scan1_kernel); list_off: storage row of a list BY CENTROID
   u32x4* ff_begin; uint32_t ff_vec16;  // the list scan's partial slots: filled with all ones (empty) by whoever plans
   unsigned long long* stamps = nullptr;  // diagnosis (VERS_SCAN_DEBUG & 16): [48..50] 100 MHz clock after the merge, the list tables, the plan's stores
 };
@@ -269,8 +269,9 @@ __device__ __forceinline__ void plan1_block(const Plan1Args& a, uint64_t (*sh)[k
   const uint32_t L = key != kKeyMax ? (uint32_t)key : kNoList;
   const uint32_t len = L != kNoList ? a.list_len[L] : 0u;
   const uint32_t slot = L != kNoList ? a.list_slot[L] : kNoList;  // the tables and items name a list by its slot (vers_ivf::list_slot)
-  // (the records' operands depend on the slot: requested here, they arrive under the prefix sums below)
-  const uint32_t loff = (a.recs && slot != kNoList) ? a.slot_off[slot] : 0u, llen = (a.recs && slot != kNoList) ? a.slot_len[slot] : 0u;
+  // (the records' operands by CENTROID index -- list_off[L], and the stored length IS list_len[L] -- so that they are requested
+  // together with the slot instead of a round trip behind it: round 3 read slot_off[slot] / slot_len[slot])
+  const uint32_t loff = (a.recs && L != kNoList) ? a.list_off[L] : 0u, llen = len;
   auto excl_scan = [&](uint32_t v) {  // exclusive prefix sum over the 64 lanes
     uint32_t inc = v;
 #pragma unroll
@@ -782,7 +783,7 @@ int32_t plan_search(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint32_t b
     pa.cnt = cnt; pa.pair_off = pair_off; pa.group_off = group_off; pa.pairs = W->pairs.as<uint32_t>(); pa.items = W->items.as<ItemDesc>();
     pa.groups = W->groups.as<GroupDesc>(); pa.tot = tot; pa.status = W->st_word(); pa.list_slot = h->list_slot.as<uint32_t>();
     pa.ff_begin = reinterpret_cast<u32x4*>(W->partials.p); pa.ff_vec16 = fill_in_kernel ? (uint32_t)((part_bytes + 15) / 16) : 0u;
-    pa.recs = W->items.as<Item1Rec>(); pa.slot_off = h->slot_off.as<uint32_t>(); pa.slot_len = h->slot_len.as<uint32_t>(); pa.S_max = S_max;
+    pa.recs = W->items.as<Item1Rec>(); pa.list_off = h->list_off.as<uint32_t>(); pa.S_max = S_max;
     if (one1_fused) {  // coarse quantiser + plan in one launch: a block per 64-centroid tile, the last one to finish plans
       Coarse1Args ca;
       ca.cent = h->centroids_b.as<float>(); ca.k = k_l; ca.ld = h->ld; ca.n_chunks = h->ld / kChunk; ca.q = qp; ca.cpart = W->cpart.as<uint64_t>();
