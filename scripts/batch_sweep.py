@@ -29,7 +29,7 @@ def run(b, steps):
     for s in streams: ix.poll(s.cuda_stream)
     return dt, ix.prescan_stats()["batches"] - b0 == steps
 res = {}
-for mode, val in (("matrix_cores_from_batch_2", 2), ("ordered_chains_below_2_queries_per_list", 1 << 30), ("default", 8)):
+for mode, val in (("matrix_cores_from_batch_2", 2), ("ordered_chains_below_2_queries_per_list", 1 << 30), ("default", 4)):
     capi.set_option("pre_min_batch", val)
     res[mode] = {}
     for b in (1, 2, 4, 8, 16, 32, 64, 128, 256, 512, 1024):

@@ -312,10 +312,10 @@ inline std::atomic<int>& shadow_mode_ref() {  // VERS_SHADOW (default 1) / vers_
   return m;
 }
 inline int shadow_mode() { return shadow_mode_ref().load(std::memory_order_relaxed); }
-// VERS_PRE_MIN_BATCH (default 8) / vers_set_option("pre_min_batch", v): the smallest batch whose list scan runs on the matrix
+// VERS_PRE_MIN_BATCH (default 4) / vers_set_option("pre_min_batch", v): the smallest batch whose list scan runs on the matrix
 // cores when its lists are shared by fewer than two queries on average (plan_search)
 inline std::atomic<uint32_t>& pre_min_batch_ref() {
-  static std::atomic<uint32_t> m{[] { const char* e = getenv("VERS_PRE_MIN_BATCH"); return e ? (uint32_t)atol(e) : 8u; }()};
+  static std::atomic<uint32_t> m{[] { const char* e = getenv("VERS_PRE_MIN_BATCH"); return e ? (uint32_t)atol(e) : 4u; }()};
   return m;
 }
 

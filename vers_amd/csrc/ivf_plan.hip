@@ -659,7 +659,7 @@ int32_t plan_search(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint32_t b
   // Small batches too (round 3 required >= 2 queries per list on average and sent batch 8 .. 128 at nlist = 4096 to one
   // ordered-chain scan per (query, list) pair -- every list re-read per query, f32 rows): a list probed by ONE query of the batch
   // is still streamed from the half-size shadow at the chip's rate, and the staging of a mostly empty query block costs less
-  // than the bytes it saves.  VERS_PRE_MIN_BATCH (default 8) is the smallest batch that takes this path.
+  // than the bytes it saves.  VERS_PRE_MIN_BATCH (default 4; measured at cfg3: batch 4 171 vs 209 us, batch 2 equal) is the smallest batch that takes this path.
   const bool pre_batch = QG != 1 || (b >= pre_min_batch_ref().load(std::memory_order_relaxed) && b > 1);
   const bool use_pre = pre_batch && !ref_mode && pre_mode != 0 && top_k + 6 <= kPreMaxKp && P <= (uint32_t)kMaxTopK && pre_nq != 0;
   if (use_pre) QG = (int)pre_nq;
