@@ -79,6 +79,15 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != max(1, args.gpus):
         log(f"[bench] --gpus {args.gpus} but the launcher started {world} rank(s): reporting n_gpus = {world}")
+    # VERS_BENCH_FORCE_SHARDED=1: the multi-rank code path with however many ranks there are -- with ONE rank it is the smoke test
+    # of everything `--gpus N` runs on the GPUs (nccl process group, row-sharded build entry, libvers_rccl.so's communicator made
+    # from an id broadcast through torch, vers_ivf_search_sharded_dev with ncclAllGather on the batch's stream) minus the peers
+    multi = world > 1 or os.environ.get("VERS_BENCH_FORCE_SHARDED") == "1"
+    if multi and world == 1 and "MASTER_ADDR" not in os.environ:
+        import socket
+        with socket.socket() as s_:
+            s_.bind(("127.0.0.1", 0))
+            os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(s_.getsockname()[1]), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
     import torch
     # one process per GPU.  (VERS_BENCH_BACKEND=gloo + fewer GPUs than ranks is a debugging aid only: it lets
     # the multi-rank code path run on a 1-GPU box, staging the all-gather through host memory.)
@@ -87,7 +96,7 @@ def main():
     torch.cuda.set_device(dev_index)
     dev = torch.device(f"cuda:{dev_index}")
     dist = None
-    if world > 1:
+    if multi:
         import torch.distributed as dist
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=dev)
@@ -126,7 +135,7 @@ def main():
     capi.build_stats(reset=True)
     t0 = time.perf_counter()
     comm = None
-    if world > 1:
+    if multi:
         from vers_amd.dist import TorchComm
         comm = TorchComm(device=dev_index)
         kept = index.build_sharded_dev(X.data_ptr(), hi - lo, ld, lo, n, nlist, 1, args.kmeans_iters, init, comm)
@@ -149,7 +158,7 @@ def main():
             f"list len min/mean/max {int(lens.min())}/{lens.mean():.0f}/{int(lens.max())}; "
             f"index fingerprint (centroid bits + list lengths) {fp:#010x}; matrix-core assign: {mp} points, {mf} re-done exactly")
     sharded_build = None
-    if world > 1:
+    if multi:
         # every rank's peak of library memory during the row-sharded build (its rows are the caller's: generated above)
         pk = torch.tensor([float(mem_peak), float(mem_now), float(hi - lo) * ld * 4.0], device=dev, dtype=torch.float64)
         allpk = [torch.zeros_like(pk) for _ in range(world)]
@@ -167,7 +176,7 @@ def main():
                              "exchange_seconds_rank0": {k_: round(v_, 3) for k_, v_ in comm.seconds.items()},
                              "chain_hop_ms": round(1e3 * (comm.seconds["send"] + comm.seconds["recv"]) / max(1, comm.calls["send"] + comm.calls["recv"]), 2),
                              "build_index_s": round(t_build, 2), "backend": backend}
-    if world > 1 and rank == 0:
+    if multi and rank == 0:
         own = index.owners()
         log(f"[bench] row-sharded build over {world} ranks: {hi - lo} rows generated per rank, library device memory peak "
             f"{mem_peak / 1e9:.2f} GB / now {mem_now / 1e9:.2f} GB on rank 0 (whole corpus: {n * d * 4 / 1e9:.2f} GB); "
@@ -199,7 +208,7 @@ def main():
     # the partial search and the merge).  VERS_BENCH_EXCHANGE=torch: the round-3 path (torch.distributed all_gather_into_tensor
     # between two library calls).  gloo (debugging on fewer GPUs than ranks): the same entry point with gloo behind vers_gather_t.
     gather, exchange_kind = None, None
-    if world > 1:
+    if multi:
         want = os.environ.get("VERS_BENCH_EXCHANGE", "rccl" if backend == "nccl" else "gloo")
         if want == "rccl" and backend == "nccl":
             try:
@@ -229,7 +238,7 @@ def main():
             sh = streams[i % S].cuda_stream
             if args.ahead:  # the NEXT batch's coarse quantiser runs on a side stream under this batch's list scan
                 index.coarse_ahead_dev(Q[((i + 1) % n_batches) * B:].data_ptr(), ld, B, nprobe, sh)
-            if world == 1:
+            if not multi:
                 index.search_dev(qb.data_ptr(), ld, B, top_k, nprobe, o["ids"].data_ptr(), o["dst"].data_ptr(), o["cnt"].data_ptr(), sh)
             elif gather is not None:
                 index.search_sharded_dev(gather.gather_ptr() if hasattr(gather, "gather_ptr") else gather.ptr(), qb.data_ptr(), ld, B, top_k, nprobe,
@@ -265,7 +274,7 @@ def main():
         elapsed = float(t.item())
     qps = args.steps * B / elapsed
     scan_ms_one = None
-    if world > 1 and S > 1:
+    if multi and S > 1:
         # every rank: the same steps one batch after the other -- the dominant kernel's duration without the queueing behind other
         # batches' scans that an event pair measures when several are in flight (see the one-GPU leg below)
         for i in range(args.warmup):
@@ -305,7 +314,7 @@ def main():
     for tf in ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):  # newest PMC run of this exact configuration
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", tf)))
-            if (tj["config"] == {"rows": n, "d": d, "nlist": nlist, "nprobe": nprobe, "batch": B} and world == 1
+            if (tj["config"] == {"rows": n, "d": d, "nlist": nlist, "nprobe": nprobe, "batch": B} and not multi
                     and tj["kernel"].startswith(kernel_id)):
                 traffic = tj["hbm_read_bytes_per_launch"]
                 traffic_source = f"profiles/{tf}: rocprofv3 --pmc FETCH_SIZE pass of this configuration (committed; not collected in this run)"
@@ -340,7 +349,7 @@ def main():
         index.poll(st)
         t_ex = time.perf_counter() - t0
         e = eids.cpu().numpy().astype(np.uint64)
-        if world > 1:  # each rank scanned only its rows: combine the per-rank exact top-k by (distance, vec id)
+        if multi:  # each rank scanned only its rows: combine the per-rank exact top-k by (distance, vec id)
             ed = edst.cpu().numpy(); ec = ecnt.cpu().numpy()
             ed[np.arange(top_k)[None, :] >= ec[:, None]] = np.inf
             gl = [None] * world
@@ -357,7 +366,7 @@ def main():
     # a stored row queried bit-identically comes back first at distance exactly 0.0 (assign and search use the same
     # symmetric ordered distance and the same first-minimum rule: ivfflat.rs:36-43 vs :159-160)
     self_ok = None
-    if world == 1:
+    if not multi:
         own = [c for c in range(0, nlist, max(1, nlist // 8)) if lens[c] > 0][:8]
         rows_ids = [index.get_list(c) for c in own]
         sq = np.stack([r[0][len(r[1]) // 2] for r in rows_ids]); sid = np.array([r[1][len(r[1]) // 2] for r in rows_ids])
@@ -399,7 +408,7 @@ def main():
         sst = index.shadow_state()
         lay = index.layout_bytes()
         hbm_total = int(torch.cuda.get_device_properties(dev).total_memory)
-        rows_stored = max(1, n if world == 1 else int(lens[index.owners() == rank].sum()))
+        rows_stored = max(1, n if not multi else int(lens[index.owners() == rank].sum()))
         per_row = float(mem_now) / rows_stored
         per_row_noshadow = float(mem_now - sst["bytes"] - lay["rowmajor"]) / rows_stored
         per_row_shadow_only = float(mem_now - lay["rowmajor"]) / rows_stored
@@ -422,7 +431,7 @@ def main():
             extra["kmeans_assign"] = ke
             log(f"[bench] k-means assign contraction [{ke['shape'][0]}x{nlist}x{d}]: {ke['us_per_launch']} us per launch = {ke['algorithmic_tflops']} algorithmic TFLOP/s "
                 f"({ke['points_redone_exactly_pct']} % of the points re-done exactly); update {ke['update_centroids_ms_total']} ms, cost fold {ke['cost_fold_ms_total']} ms in a {t_build:.2f} s build")
-    if rank == 0 and world == 1 and not args.no_extra and d == 768:
+    if rank == 0 and not multi and not args.no_extra and d == 768:
         # cfg5's cluster count on one GPU: N = 1M, k = 65536, one iteration + the final assign (2 passes)
         nk, kk = 1_048_576, 65536
         Xk = torch.empty(nk, ld, dtype=torch.float32, device=dev)
@@ -453,7 +462,7 @@ def main():
             # (the legs above left other calls -- single queries, exact scans -- as the handle's last: a few batches again; with the
             # lists sharded, this rank's part of the search: no collective)
             for i in range(8):
-                if world == 1:
+                if not multi:
                     index.search_dev(Q[(i % n_batches) * B:].data_ptr(), ld, B, top_k, nprobe, ids.data_ptr(), dst.data_ptr(), cnt.data_ptr(), st)
                 else:
                     index.search_partial_dev(Q[(i % n_batches) * B:].data_ptr(), ld, B, top_k, nprobe, outs[0]["part"][0].data_ptr(),
@@ -461,7 +470,7 @@ def main():
             index.poll(st)
             extra["coarse_gemm"] = coarse_entry("dist_gemm_x3_kernel<false> (3 x v_mfma_f32_32x32x16_bf16 on hi/lo-split operands, 128x128 block tiles)",
                                                 index.last_coarse_ms())
-            if world == 1 and not args.no_extra:
+            if not multi and not args.no_extra:
                 capi.set_option("gemm_x3", 1)
                 for i in range(16):  # (the GPU has idled through the recall / CPU legs: a few dozen ms of work bring the clocks back up)
                     index.search_dev(Q[(i % n_batches) * B:].data_ptr(), ld, B, top_k, nprobe, ids.data_ptr(), dst.data_ptr(), cnt.data_ptr(), st)
@@ -492,14 +501,14 @@ def main():
             index.poll(x.cuda_stream)
         return t_, index.scan_times(reset=True)
 
-    if rank == 0 and world > 1 and scan_ms_one is not None and len(scan_ms_one[0]):
+    if rank == 0 and multi and scan_ms_one is not None and len(scan_ms_one[0]):
         m1 = float(np.mean(scan_ms_one[0]))
         roofline["timed_region"] = {"launch_ms": roofline["launch_ms"], "achieved": roofline["achieved"], "frac": roofline["frac"], "launches_timed": roofline["launches_timed"],
                                     "note": f"event pairs around the launches of the timed region, {S} batches in flight: includes the time a launch waits for the CUs another batch's scan still holds"}
         roofline.update({"launch_ms": round(m1, 4), "achieved": round(algo_bytes / (m1 * 1e-3) / 1e9, 1), "frac": round(algo_bytes / (m1 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
                          "launches_timed": int(len(scan_ms_one[0])), "measured_on": f"the same {args.steps} steps, one batch in flight, right after the timed region (rank 0's launches)"})
         roofline["one_batch_in_flight"] = {"whole_step_ms": round(scan_ms_one[1] / args.steps * 1e3, 4), "whole_step_queries_per_sec": round(args.steps * B / scan_ms_one[1], 1)}
-    if rank == 0 and world == 1 and S > 1:
+    if rank == 0 and not multi and S > 1:
         # With several batches in flight an event pair around a list-scan launch also measures how long the launch QUEUED behind
         # another batch's scan (two scans cannot share the chip: each block takes a whole CU) -- not the kernel.  The roofline of the
         # dominant kernel is therefore taken from the same steps run one batch after the other (--streams 1) right after the
@@ -524,7 +533,7 @@ def main():
                                                "note": "the step's latency: the same steps strictly one after the other"}
             log(f"[bench] one batch in flight: {t1s / args.steps * 1e3:.3f} ms per step, list scan {m1:.3f} ms = {roofline['frac']} of peak "
                 f"(timed region, {S} in flight: {roofline['timed_region']['launch_ms']} ms per launch incl. queueing)")
-    if rank == 0 and world == 1 and not args.no_extra and shadow:
+    if rank == 0 and not multi and not args.no_extra and shadow:
         # the same steps with the f32 rows feeding the list scan (round 1's kernel; same index, same results): what the shadow
         # buys, and SURVEY 8d's f32-row figure of the headline -- same warm-up, step count and streams as the timed region
         try:
@@ -546,7 +555,7 @@ def main():
                                                "note": "the same index and batches with vers_set_option('shadow', 0), timed like the headline (after it): round 1's configuration (VERS_SHADOW=0 / --f32-rows makes it the whole run)"}
         finally:
             capi.set_option("shadow", 1)
-    if rank == 0 and world == 1 and not args.no_extra and nprobe != 0:
+    if rank == 0 and not multi and not args.no_extra and nprobe != 0:
         # the reference's OWN mode (nprobe = 0: nearest list, spill while short, ivfflat.rs:166-195) on the same index and batches
         tr, msr = timed_steps(0)
         n1r = 100
@@ -564,7 +573,7 @@ def main():
                                    "list_scan_ms": round(float(np.mean(msr)), 4) if len(msr) else None, "steps": args.steps,
                                    "single_query_end_to_end_us": round(e1r * 1e6, 1)}
         log(f"[bench] reference mode (nprobe=0): {extra['reference_mode']['batch_queries_per_sec']} q/s in batches of {B}, {e1r * 1e6:.1f} us per single query")
-    if rank == 0 and world == 1 and not args.no_extra:
+    if rank == 0 and not multi and not args.no_extra:
         # (a) single query (B = 1): the list-scan kernel alone (HIP events around its launch) over distinct queries, priced
         # on the bytes of the lists each query actually probed; and the pipelined end-to-end time per query
         nq1 = min(64, B)
@@ -770,7 +779,7 @@ def main():
     # every row distance + stable sort.  First on one thread (the reference's search_approximate is serial), then the same
     # call for independent queries on all host cores ("embarrassingly parallel over queries").
     cpu, cpu_all, cpu_km = None, None, None
-    if rank == 0 and world == 1 and not args.no_cpu:
+    if rank == 0 and not multi and not args.no_cpu:
         import ctypes as C
         from concurrent.futures import ThreadPoolExecutor
         from oracle import c_oracle as co

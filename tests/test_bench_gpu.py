@@ -51,3 +51,15 @@ def test_bench_gpus_2_spawns_ranks_and_builds_row_sharded():
     assert two["recall_at_10"] == one["recall_at_10"]
     assert two["config"]["kmeans_iters"] == one["config"]["kmeans_iters"]
     assert "vers_ivf_search_sharded_dev" in two["config"]["exchange"]   # partial -> exchange -> merge inside ONE library call per batch
+
+
+def test_bench_multi_rank_path_through_rccl_with_one_rank():
+    """VERS_BENCH_FORCE_SHARDED=1: everything `bench.py --gpus N` runs on the GPUs -- the nccl process group, the row-sharded
+    build entry, libvers_rccl.so's communicator made from an id broadcast through torch.distributed, vers_ivf_search_sharded_dev
+    with ncclAllGather queued on the batch's stream, three batches in flight -- with the ONE rank a test box has (RCCL refuses
+    two ranks on one GPU).  Same recall as the plain single-GPU run."""
+    one, _ = run_bench("--no-cpu", "--no-extra")
+    rc, err = run_bench("--no-cpu", "--no-extra", env={"VERS_BENCH_FORCE_SHARDED": "1"})
+    assert rc["n_gpus"] == 1 and rc["recall_at_10"] == one["recall_at_10"] and rc["value"] > 0
+    assert "libvers_rccl.so" in rc["config"]["exchange"] and "ncclAllGather" in rc["config"]["exchange"], rc["config"]["exchange"]
+    assert "row-sharded build over 1 ranks" in err
