@@ -516,7 +516,8 @@ int32_t coarse_mfma(vers_ivf* h, const float* qp, uint32_t b, uint32_t P, uint64
   const uint32_t M_pad = round_up(b, kGemmBM);
   const uint32_t PS = std::min<uint32_t>(kMaxTopK, P + 16);
   if (int32_t rc = W->gbuf.reserve((size_t)M_pad * h->k_pad * sizeof(float))) return rc;
-  const bool timed = st != W->ahead_stream || W->ahead_stream == nullptr;  // (the look-ahead stream is not the measured one)
+  // (event records only when the call is timed at all -- vers_set_option("scan_events") -- and never on the look-ahead stream)
+  const bool timed = W->ev_on && (st != W->ahead_stream || W->ahead_stream == nullptr);
   if (timed) VERS_HIP_TRY(hipEventRecord(W->evc[0], st));
   const __bf16* cs = h->centroids_gs.as<__bf16>();
   VERS_HIP_TRY(launch_gemm<false>((gemm_x3_mask() & 2) != 0, M_pad / kGemmBM, h->k_pad / kGemmBN, st, qp, h->centroids_g.as<float>(),
