@@ -639,7 +639,7 @@ def main():
         capi.gen_rows_dev(X15.data_ptr(), n15, d15, d15, 1, SEED_X + 0x1536, SEED_C, args.modes_per_list * nl15, float(dg.default_sigma(d15)))
         i15 = IVFFlatIndex(d15, device=dev_index)
         init15 = (dg.mix64(np.uint64(0xB15) + np.arange(nl15, dtype=np.uint64)) % np.uint64(n15)).astype(np.uint64)
-        t0 = time.perf_counter(); i15.build_dev(X15.data_ptr(), n15, nl15, 1, 2, init15); t_b15 = time.perf_counter() - t0
+        t0 = time.perf_counter(); i15.build_dev(X15.data_ptr(), n15, nl15, 1, args.kmeans_iters, init15); t_b15 = time.perf_counter() - t0
         del X15
         torch.cuda.empty_cache()
         Q15 = torch.empty(4 * B, d15, dtype=torch.float32, device=dev)
@@ -662,13 +662,14 @@ def main():
             s15(i, 1)
         torch.cuda.synchronize(); i15.poll(streams[0].cuda_stream)
         l15 = i15.last_scan(); ms15 = i15.scan_times(reset=True)[-4:]
+        l15_lens = i15.list_lengths()
         by15 = l15["union_rows"] * (d15 * 2 + 4) + nl15 * d15 * 4
         m15 = float(np.mean(ms15)) if len(ms15) else float("nan")
         e15 = {"workload": f"IVFFlat N={n15} d={d15} nlist={nl15} nprobe={np15} batch={B} top_k={top_k}, {S} batches in flight", "ms_per_step": round(t15 * 1e3, 4),
                "queries_per_sec": round(B / t15, 1), "list_scan": "prescan_kernel_g<true, 16> (narrow 16-query blocks, fp16 shadow) + exact finish" if on_mc15 else "scan_kernel (ordered chains)",
                "list_scan_ms_one_batch_in_flight": round(m15, 4), "algorithmic_bytes_per_launch": int(by15), "achieved_GBs": round(by15 / (m15 * 1e-3) / 1e9, 1),
                "frac": round(by15 / (m15 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "streamed_over_union_rows": round(l15["streamed_rows"] / max(1, l15["union_rows"]), 3),
-               "build_index_s": round(t_b15, 2)}
+               "build_index_s": round(t_b15, 2), "list_len_min_mean_max": [int(l15_lens.min()), int(l15_lens.mean()), int(l15_lens.max())]}
         if not args.no_cpu:   # two queries of the last batch against the CPU restatement, bit for bit
             from oracle import c_oracle as co15
             c15 = np.ascontiguousarray(i15.get_centroids()); q15 = Q15[(5 % 4) * B:(5 % 4) * B + 2].cpu().numpy()

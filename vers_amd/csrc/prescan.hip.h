@@ -350,9 +350,10 @@ __device__ __forceinline__ void prescan_item_g(const Src& src, const PreParams& 
       // never needed it.  (Round 3 made every such wave take the lock in turn, compaction or not: the eight waves of a block
       // meet the same full buffers at the same time, and at 8 ranks -- looser thresholds, 17 k compactions and 300 k candidates
       // per launch -- that queueing was most of the 55 us the list inserts cost a 370 us launch.)
+      int rot_cur = rot;  // (wave-uniform) where this wave's round over the overflowed query columns starts
       while (ovf) {
-        const uint64_t ovr = rot ? (ovf >> rot) | (ovf << (64 - rot)) : ovf;
-        const int L = (__ffsll((unsigned long long)ovr) - 1 + rot) & 63;
+        const uint64_t ovr = rot_cur ? (ovf >> rot_cur) | (ovf << (64 - rot_cur)) : ovf;
+        const int L = (__ffsll((unsigned long long)ovr) - 1 + rot_cur) & 63;
         const uint32_t qq = (uint32_t)__builtin_amdgcn_readlane((int)q, L);
         const bool mine = q == qq && pend != 0;
         uint64_t* const bqq = cbuf + (size_t)qq * cap;
@@ -361,8 +362,15 @@ __device__ __forceinline__ void prescan_item_g(const Src& src, const PreParams& 
           uint32_t got = 0;
           if (lane == 0) got = __hip_atomic_exchange(locks + qq, 1u, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) == 0u ? 1u : 0u;
           got = (uint32_t)__builtin_amdgcn_readfirstlane((int)got);
-          if (!got) {  // somebody else is compacting it (or was, a moment ago): look again -- at the counter AND, if it is still full, at the lock
-            __builtin_amdgcn_s_sleep(1);
+          if (!got) {
+            // Somebody else is compacting this buffer (or was, a moment ago).  Rather than wait here, go on with the NEXT query
+            // column that has something pending (its buffer may be free or need a compactor: useful work either way) and come
+            // back to this one on the way round; only when nothing else is pending does the wave sleep before it looks again --
+            // at the counter AND, if the buffer is still full, at the lock.
+            const int next = (L + 1) & 63;
+            const uint64_t others = __ballot(pend != 0 && q != qq);  // (the lanes of the OTHER query columns with something pending)
+            if (others == 0) __builtin_amdgcn_s_sleep(1);
+            rot_cur = next;
             continue;
           }
           __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
