@@ -5,6 +5,7 @@
 // external linkage).
 #pragma once
 #include "prescan.hip.h"
+#include "staged.hip.h"
 
 namespace vers {
 
@@ -106,17 +107,16 @@ __device__ __forceinline__ void emit_topk(uint64_t fin, uint32_t q, uint32_t top
   if (lane == 0) out_count[q] = (uint32_t)__popcll(hm);
 }
 
-// Block of 4 waves per query.  All waves merge the partial lists; wave 0 evaluates the certificate; the surviving
-// candidates' rows are then staged through LDS kRescoreChunk at a time, cooperatively (independent float4 gathers
-// over 256 threads -- a lane walking its own row straight from HBM is a chain of ld/4 dependent-latency loads) and
-// wave 0 runs the ordered chains out of LDS.  The block is a chain of ~8 dependent memory round trips, so what
-// matters is blocks in flight: 8 staged rows (27 KB of LDS at d = 768) allow 5 blocks per CU, the whole batch in
-// one round (staging all k+10 rows at once: 2 blocks per CU, 110 us instead of 45 at cfg3).
-// stage_rows == 0 (rows too long even for that): the chains read HBM directly.
+// Block of 4 waves per query.  All waves merge the partial lists; wave 0 evaluates the certificate; the survivors are dealt
+// round-robin to the four waves, each of which gathers ITS rows coalesced (the row-major copy: 256 contiguous bytes per quarter
+// wave; the tiles: 16-byte pieces), parks the products in its LDS slice and walks the ordered chains over them, one lane per
+// survivor (staged.hip.h); wave 0 sorts and emits.  The block is a chain of ~7 dependent memory round trips, so what matters is
+// blocks in flight: 20 KB of LDS at d = 768 (the query + 4 x 16 staged product rows of 64 columns) and 4 waves allow the whole
+// batch in one round.
+// stage_rows == 0 (a query too long for LDS): the chains read HBM directly.
 constexpr int kRescoreWaves = 4;
-constexpr uint32_t kRescoreChunk = 8;
-inline size_t rescore_lds_bytes(uint32_t ld, bool stage_rows) {
-  return ((size_t)ld + (stage_rows ? (size_t)kRescoreChunk * (ld + 4) : 0)) * sizeof(float);
+inline size_t rescore_lds_bytes(uint32_t ld, bool stage_rows) {  // the query; then 16 staged rows of products per wave
+  return ((size_t)ld + (stage_rows ? (size_t)kRescoreWaves * staged_lds_floats(16) : 0)) * sizeof(float);
 }
 __global__ __launch_bounds__(kWave * kRescoreWaves) void ivf_rescore_kernel(RescoreArgs a, int stage_rows) {
   __shared__ uint64_t sh[kRescoreWaves][kWave];
@@ -238,39 +238,42 @@ __global__ __launch_bounds__(kWave * kRescoreWaves) void ivf_rescore_kernel(Resc
   bool nan_seen = false;
   const f32x4* q4p = reinterpret_cast<const f32x4*>(qs);
   if (stage_rows) {
-    const uint32_t n4 = a.ld / 4, pitch = a.ld + 4;
-    for (uint32_t c0 = 0; c0 < n_surv; c0 += kRescoreChunk) {  // block-uniform
-      const uint32_t nc = n_surv - c0 < kRescoreChunk ? n_surv - c0 : kRescoreChunk;
-      for (uint32_t idx = threadIdx.x; idx < nc * n4; idx += blockDim.x) {
-        const uint32_t c = idx / n4, j = idx - c * n4;
-        const uint32_t row = srow[c0 + c];
-        *reinterpret_cast<f32x4*>(xs + (size_t)c * pitch + 4 * j) =
-            a.rows_rm ? reinterpret_cast<const f32x4*>(a.rows_rm + (uint64_t)row * a.ld)[j]  // consecutive threads: consecutive 16 bytes of a row
-                      : (reinterpret_cast<const f32x4*>(a.rows + (uint64_t)(row >> 6) * 64ull * a.ld) + (row & 63))[(uint64_t)j * 64];
-      }
-      __syncthreads();
-      if (wid == 0 && (uint32_t)lane >= c0 && (uint32_t)lane < c0 + nc) {
-        const f32x4* xp = reinterpret_cast<const f32x4*>(xs + (size_t)((uint32_t)lane - c0) * pitch);
-        float acc = 0.0f;
-        for (uint32_t j = 0; j < n4; ++j) {
-          const f32x4 x4 = xp[j];
-          const f32x4 q4 = q4p[j];
+    // survivor 4 s + w is wave w's staged row s: every wave reads ITS rows coalesced (a quarter wave per row and 64-column
+    // chunk), parks the products in its own LDS slice and lane s walks row s's chain (staged.hip.h) -- all survivors in ONE pass
+    // over the columns, no block-wide barrier inside.  (Rounds 2-4 staged whole rows 8 at a time for wave 0's lanes: a gather
+    // round trip, a barrier and a 3-instruction chain per 8 survivors.)
+    __shared__ uint64_t s_cand[kWave];
+    const uint32_t per_wave = (n_surv + kRescoreWaves - 1) / kRescoreWaves;  // block-uniform, <= 16
+    float acc = 0.0f;
+    if (n_surv != 0) {
+      auto run = [&](auto nl_tag) {
+        constexpr int NL = decltype(nl_tag)::value;
+        const float* rp[NL];
+        const uint32_t xstep = a.rows_rm ? 4u : 256u;
 #pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            if (a.metric == 0) {
-              const float t = __fsub_rn(x4[c], q4[c]);
-              acc = __fadd_rn(acc, __fmul_rn(t, t));
-            } else {
-              acc = __fadd_rn(acc, __fmul_rn(x4[c], q4[c]));
-            }
-          }
+        for (int i = 0; i < NL; ++i) {
+          const uint32_t sv = (uint32_t)(4 * i + (lane >> 4)) * kRescoreWaves + (uint32_t)wid;
+          const uint32_t row = srow[sv < n_surv ? sv : 0u];  // (slots past the end re-read survivor 0: never used)
+          rp[i] = (a.rows_rm ? a.rows_rm + (uint64_t)row * a.ld : a.rows + (uint64_t)(row >> 6) * 64ull * a.ld + (row & 63) * 4u) +
+                  (uint64_t)(lane & 15) * xstep;
         }
-        if (a.metric) acc = __fsub_rn(1.0f, acc);
-        nan_seen |= acc != acc;
-        cand = make_key(acc, (uint32_t)mine);
-      }
-      __syncthreads();  // the chunk's readers are done before the next one is staged
+        const float* ql = qs + 4 * (lane & 15);
+        float* sp = xs + (size_t)wid * staged_lds_floats(16);
+        return a.metric == 0 ? staged_chains<NL, 0>(rp, xstep, ql, a.ld, sp, lane) : staged_chains<NL, 1>(rp, xstep, ql, a.ld, sp, lane);
+      };
+      if (per_wave <= 4) acc = run(std::integral_constant<int, 1>{});
+      else if (per_wave <= 8) acc = run(std::integral_constant<int, 2>{});
+      else if (per_wave <= 12) acc = run(std::integral_constant<int, 3>{});
+      else acc = run(std::integral_constant<int, 4>{});
     }
+    if (a.metric) acc = __fsub_rn(1.0f, acc);
+    const uint32_t sv = (uint32_t)lane * kRescoreWaves + (uint32_t)wid;
+    if (lane < 16 && sv < n_surv) {
+      if (acc != acc) atomicOr(a.status, 1u);
+      s_cand[sv] = (uint64_t)f32_to_order_bits(acc) << 32;  // (wave 0 holds the survivors' sequence numbers)
+    }
+    __syncthreads();
+    if (wid == 0 && (uint32_t)lane < n_surv) cand = s_cand[lane] | (uint32_t)mine;
   } else if (wid == 0 && (uint32_t)lane < n_surv) {
     const uint32_t row = srow[lane];
     const f32x4* xp = a.rows_rm ? reinterpret_cast<const f32x4*>(a.rows_rm + (uint64_t)row * a.ld)

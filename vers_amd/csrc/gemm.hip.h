@@ -22,6 +22,7 @@
 
 #include "plan.hip.h"
 #include "scan.hip.h"
+#include "staged.hip.h"
 
 namespace vers {
 
@@ -725,7 +726,9 @@ static __global__ __launch_bounds__(kWave * kSelectWaves) void coarse_select_res
   // sorted across the lanes (bitonic network) and merged with the best of the previous chunks.  Every key among the
   // chunk's PS smallest passes the filter (ties at T included), so `sel` is exactly what the serial inserts produce.
   __shared__ uint64_t s_keys_all[kSelectWaves][kWave];
+  __shared__ __attribute__((aligned(16))) float s_prod_all[kSelectWaves][staged_lds_floats(kWave)];  // the re-score's staged products
   uint64_t* const s_keys = s_keys_all[threadIdx.x >> 6];  // (this wave's own: LDS operations of one wave execute in order)
+  float* const s_prod = s_prod_all[threadIdx.x >> 6];
   uint64_t sel = kKeyMax;
   constexpr int kR = 64;  // registers per lane and chunk
   for (uint32_t n0 = 0; n0 < k; n0 += kR * kWave) {
@@ -836,41 +839,29 @@ static __global__ __launch_bounds__(kWave * kSelectWaves) void coarse_select_res
   const float gl = __uint_as_float(order_bits_to_f32_bits((uint32_t)(sel >> 32)));
   const bool have = lane < (int)n_sel && !(gl > gP + 2.0f * E);  // (negated: NaN / inf anywhere keeps the candidate)
   const uint32_t ci = have ? (uint32_t)sel : (uint32_t)readlane64(sel, 0);  // idle lanes re-read lane 0's row (one broadcast line)
-  const float* cv = C_rm + (uint64_t)ci * ldc;
+  // The candidates' rows are read coalesced, four rows per load instruction, their products parked in LDS and every lane walks
+  // its own candidate's chain over them (staged.hip.h).  (Rounds 2-4: lane l walked centroid row l straight from the Infinity
+  // Cache, 16 bytes per load and lane -- 64 lines per instruction: 58 k of the kernel's 120 k cycles per query.)
+  // The candidates are sorted by G, so the ones worth their row are a prefix of the lanes (NaN keys sort last and are kept: a gap
+  // between them and the prefix is staged unused).
   float acc = 0.0f;
-  // 64 columns per step, 16 independent 16-byte loads per lane (each lane walks its own row), the NEXT step's loads in
-  // flight under this step's chain (a wave per query and SIMD: nothing else hides the Infinity Cache's latency; the
-  // unpipelined loop spent 82 k of the kernel's 120 k cycles per query here).  Loads are unconditional (clamped to the
-  // last step: a branch around a load costs a vmcnt(0)).
-  auto load16 = [&](f32x4 (&c4)[16], uint32_t j) {
-#pragma unroll
-    for (int w = 0; w < 16; ++w) c4[w] = *reinterpret_cast<const f32x4*>(cv + j + 4 * w);
-  };
-  auto chain16 = [&](const f32x4 (&c4)[16], uint32_t j) {
-#pragma unroll
-    for (int w = 0; w < 16; ++w) {
-      const f32x4 q4 = *reinterpret_cast<const f32x4*>(qv + j + 4 * w);  // wave-uniform
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        if (metric == 0) {
-          const float t = __fsub_rn(c4[w][u], q4[u]);
-          acc = __fadd_rn(acc, __fmul_rn(t, t));
-        } else {
-          acc = __fadd_rn(acc, __fmul_rn(c4[w][u], q4[u]));
-        }
-      }
-    }
-  };
   {
-    f32x4 ca[16], cb[16];
-    const uint32_t last = ldc - 64;  // ldc is a multiple of 64
-    load16(ca, 0);
-    for (uint32_t j = 0; j < ldc; j += 128) {
-      load16(cb, j + 64 <= last ? j + 64 : last);
-      chain16(ca, j);
-      load16(ca, j + 128 <= last ? j + 128 : last);
-      if (j + 64 < ldc) chain16(cb, j + 64);
-    }
+    const uint64_t hm = __ballot(have);
+    const int n_rows = hm ? 64 - __builtin_clzll((unsigned long long)hm) : 0;
+    auto run = [&](auto nl_tag) {
+      constexpr int NL = decltype(nl_tag)::value;
+      const float* rp[NL];
+#pragma unroll
+      for (int i = 0; i < NL; ++i) {
+        const uint32_t c = (uint32_t)__shfl((int)ci, 4 * i + (lane >> 4), kWave);
+        rp[i] = C_rm + (uint64_t)c * ldc + 4 * (lane & 15);
+      }
+      const float* ql = qv + 4 * (lane & 15);
+      return metric == 0 ? staged_chains<NL, 0>(rp, 4u, ql, ldc, s_prod, lane) : staged_chains<NL, 1>(rp, 4u, ql, ldc, s_prod, lane);
+    };
+    if (n_rows <= 36) acc = run(std::integral_constant<int, 9>{});
+    else if (n_rows <= 48) acc = run(std::integral_constant<int, 12>{});
+    else acc = run(std::integral_constant<int, 16>{});
   }
   if (metric) acc = __fsub_rn(1.0f, acc);  // cosine distance: 1 - dot (base.rs:153-155)
   bool nan_seen = have && (acc != acc);
