@@ -36,6 +36,7 @@ struct RescoreArgs {
   float* out_dist;
   uint32_t* out_count;
   uint64_t* out_keys;
+  unsigned long long* stamps = nullptr;  // diagnosis (VERS_SCAN_DEBUG & 16): [52..57] cycles of the exact finish's phases, summed over the blocks
 };
 
 // Storage row of the key held by each lane (nprobe mode): seq = position in the query's concatenated probe order,
@@ -115,20 +116,27 @@ __device__ __forceinline__ void emit_topk(uint64_t fin, uint32_t q, uint32_t top
 // batch in one round.
 // stage_rows == 0 (a query too long for LDS): the chains read HBM directly.
 constexpr int kRescoreWaves = 4;
-inline size_t rescore_lds_bytes(uint32_t ld, bool stage_rows) {  // the query; then 16 staged rows of products per wave
-  return ((size_t)ld + (stage_rows ? (size_t)kRescoreWaves * staged_lds_floats(16) : 0)) * sizeof(float);
+inline size_t rescore_lds_bytes(uint32_t ld, bool stage_rows) {  // the query; then two buffers of 8 staged rows of products per wave
+  const size_t exchange = (size_t)kRescoreWaves * kWave * sizeof(uint64_t);  // (the merge's exchange area: inside the product buffers)
+  return (size_t)ld * sizeof(float) + (stage_rows ? (size_t)kRescoreWaves * 2 * staged_lds_floats(8) * sizeof(float) : exchange);
 }
-__global__ __launch_bounds__(kWave * kRescoreWaves) void ivf_rescore_kernel(RescoreArgs a, int stage_rows) {
-  __shared__ uint64_t sh[kRescoreWaves][kWave];
+static_assert((size_t)kRescoreWaves * 2 * staged_lds_floats(8) * sizeof(float) >= (size_t)kRescoreWaves * kWave * sizeof(uint64_t), "exchange area");
+__global__ __launch_bounds__(kWave * kRescoreWaves) __attribute__((amdgpu_waves_per_eu(8, 8))) void ivf_rescore_kernel(RescoreArgs a, int stage_rows) {
   __shared__ uint32_t srow[kWave];
   __shared__ float sred[kRescoreWaves];
   __shared__ uint32_t s_failed, s_nsurv;
   extern __shared__ __attribute__((aligned(16))) float dyn[];  // the query, padded; then staged rows of pitch ld + 4
   float* qs = dyn;
   float* xs = dyn + a.ld;
+  // the merge's exchange area lives in the product buffers (dead until the chains start, a block barrier later): with it the block
+  // stays under 40 KB of LDS at d = 768 -- four blocks per CU, the whole batch of 1024 in one round
+  uint64_t (*sh)[kWave] = reinterpret_cast<uint64_t(*)[kWave]>(xs);
   const uint32_t q = blockIdx.x;
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  unsigned long long ts[5] = {};
+  auto stamp = [&](int i) { if (a.stamps) ts[i] = __builtin_amdgcn_s_memtime(); };
+  stamp(0);
   const float* qrow = a.qp + (uint64_t)q * a.ldq;
   const uint32_t* pl = a.pj_list + (uint64_t)q * a.P;
   const uint32_t* pp = a.pj_pref + (uint64_t)q * a.P;
@@ -141,9 +149,16 @@ __global__ __launch_bounds__(kWave * kRescoreWaves) void ivf_rescore_kernel(Resc
     qs[i] = v;
     qpart = __fadd_rn(qpart, __fmul_rn(v, v));  // |q|^2 in any order: the bound inflates it
   }
-  // merge the partial lists: every wave folds a strided share of the slots the scan wrote, wave 0 folds the four
-  // results.  Only WRITTEN slots are read -- slot (probe j, quad s) exists iff s < pj_nq[j] -- so the slot array needs
-  // no 0xFF fill per batch (10 MB at cfg3, and at 8 ranks 7/8 of the slots belong to other GPUs' lists).
+  // wave 0 maps sequence numbers to storage rows twice (survivors, emitted keys): the per-probe operands it needs depend on the
+  // query only -- requested here, two dependent round trips off the tail of the merge (P <= 64: a probe per lane)
+  const bool pre_ok = a.P <= (uint32_t)kWave;
+  SeqRowsPre pre = {0u, 0xFFFFFFFFu, 0u};
+  if (wid == 0 && pre_ok) pre = wave_seq_rows_load(lane, pl, pp, a.P);
+  // merge the partial lists: wave w folds the live slots w, w + 4, ... ; the four results are folded pairwise.  Only WRITTEN
+  // slots are read -- slot (probe j, quad s) exists iff s < pj_nq[j] -- so the slot array needs no 0xFF fill per batch (10 MB
+  // at cfg3, and at 8 ranks 7/8 of the slots belong to other GPUs' lists).  A slot is an ascending list (prescan.hip.h,
+  // buffer_sorted): two of them merge through a six-stage network (wave_merge_sorted64) -- the ordered inserts of rounds 2-4
+  // cost ~130 cycles per key that passed: 26 k of the kernel's 91 k cycles per query at 8 ranks.
   const uint64_t* keys = a.partials + (uint64_t)q * a.P * a.S_max * a.kp;
   const uint32_t* nqp = a.pj_nq + (uint64_t)q * a.P;
   uint64_t list = kKeyMax;
@@ -161,11 +176,12 @@ __global__ __launch_bounds__(kWave * kRescoreWaves) void ivf_rescore_kernel(Resc
   const uint32_t excl = incl - my_nq;
   uint32_t n_live = (uint32_t)__shfl(incl, kWave - 1, kWave);
   if (a.debug & 1024u) n_live = n_live / 8;
-  for (uint32_t s0 = (uint32_t)wid * U; s0 < n_live; s0 += kRescoreWaves * U) {
+  if (wid == 0 && pre_ok) wave_seq_rows_load2(pre, a.list_off);  // (the dependent half, in flight under the merge)
+  for (uint32_t i0 = 0; (uint32_t)wid + kRescoreWaves * i0 < n_live; i0 += U) {
     uint64_t cand[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const uint32_t c = s0 + u;  // compact index -> (probe j, quad c - first slot of j): the last lane whose slots start at or before c
+      const uint32_t c = (uint32_t)wid + kRescoreWaves * (i0 + u);  // compact index -> (probe j, quad c - first slot of j): the last lane whose slots start at or before c
       const uint64_t m = __ballot(my_nq != 0 && excl <= c);
       const int j = m ? 63 - __builtin_clzll((unsigned long long)m) : 0;
       const uint32_t e_j = (uint32_t)__builtin_amdgcn_readlane((int)excl, j);
@@ -173,16 +189,22 @@ __global__ __launch_bounds__(kWave * kRescoreWaves) void ivf_rescore_kernel(Resc
       cand[u] = (c < n_live && lane < (int)a.kp) ? keys[(uint64_t)sl * a.kp + lane] : kKeyMax;
     }
 #pragma unroll
-    for (int u = 0; u < U; ++u) wave_topk_update(list, a.kp, cand[u], kKeyMax);
+    for (int u = 0; u < U; ++u) wave_merge_sorted64(list, cand[u], lane);
   }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) qpart += __shfl_xor(qpart, off, kWave);
   sh[wid][lane] = list;
   if (lane == 0) sred[wid] = qpart;
   __syncthreads();
+  if ((wid & 1) == 0) wave_merge_sorted64(list, sh[wid + 1][lane], lane);
+  if (wid == 2) sh[2][lane] = list;
+  __syncthreads();
+  stamp(1);
   uint64_t mine = kKeyMax;  // wave 0: the survivors, compacted to lanes 0..n_surv-1
+  uint32_t rid = 0;         // wave 0: their vec_ids
   if (wid == 0) {
-    for (int w = 1; w < kRescoreWaves; ++w) wave_topk_update(list, a.kp, sh[w][lane], kKeyMax);
+    wave_merge_sorted64(list, sh[2][lane], lane);
+    if (lane >= (int)a.kp) list = kKeyMax;  // (the networks keep 64 keys: the kp smallest are the candidates)
     const bool valid = lane < (int)a.kp && list != kKeyMax;
     const uint32_t cnt = (uint32_t)__popcll(__ballot(valid));
     float qn = 0.0f;
@@ -219,7 +241,9 @@ __global__ __launch_bounds__(kWave * kRescoreWaves) void ivf_rescore_kernel(Resc
     const bool survivor = certified && valid && !((double)val - e_mine > lim);
     const uint32_t n_surv = (uint32_t)__popcll(__ballot(survivor));
     mine = survivor ? list : kKeyMax;
-    srow[lane] = wave_seq_rows(list, survivor, lane, pl, pp, a.P, a.list_off);
+    const uint32_t row = pre_ok ? wave_seq_rows_map(list, survivor, lane, pre) : wave_seq_rows(list, survivor, lane, pl, pp, a.P, a.list_off);
+    srow[lane] = row;
+    if (survivor && row != 0xFFFFFFFFu) rid = a.row_ids[row];  // (the emitted keys' ids: in flight under the chains)
     if (lane == 0) {
       s_failed = certified ? 0u : 1u;
       s_nsurv = n_surv;
@@ -228,6 +252,7 @@ __global__ __launch_bounds__(kWave * kRescoreWaves) void ivf_rescore_kernel(Resc
   }
   __syncthreads();
   if (s_failed) return;
+  stamp(2);
   const uint32_t n_surv = s_nsurv;
   if (a.debug & 512u) {
     if (wid == 0) emit_topk(list, q, a.top_k, lane, pl, pp, a.P, a.list_off, a.row_ids, a.out_ids, a.out_dist, a.out_count, a.out_keys);
@@ -243,34 +268,38 @@ __global__ __launch_bounds__(kWave * kRescoreWaves) void ivf_rescore_kernel(Resc
     // over the columns, no block-wide barrier inside.  (Rounds 2-4 staged whole rows 8 at a time for wave 0's lanes: a gather
     // round trip, a barrier and a 3-instruction chain per 8 survivors.)
     __shared__ uint64_t s_cand[kWave];
-    const uint32_t per_wave = (n_surv + kRescoreWaves - 1) / kRescoreWaves;  // block-uniform, <= 16
-    float acc = 0.0f;
-    if (n_surv != 0) {
+    // (up to 8 rows per wave and pass -- 32 survivors, in practice all of them: kp <= 34 at top_k = 10 -- so that the kernel
+    // stays at 64 registers: beside the two 224-register waves per SIMD of ANOTHER batch's list scan that is what is left, and
+    // with batches in flight the finish then runs under that scan instead of waiting for whole CUs)
+    constexpr uint32_t kPassRows = 8;
+    for (uint32_t base = 0; base < n_surv; base += kPassRows * kRescoreWaves) {  // block-uniform
+      const uint32_t n_pass = n_surv - base < kPassRows * kRescoreWaves ? n_surv - base : kPassRows * kRescoreWaves;
+      const uint32_t per_wave = (n_pass + kRescoreWaves - 1) / kRescoreWaves;
       auto run = [&](auto nl_tag) {
         constexpr int NL = decltype(nl_tag)::value;
         const float* rp[NL];
         const uint32_t xstep = a.rows_rm ? 4u : 256u;
 #pragma unroll
         for (int i = 0; i < NL; ++i) {
-          const uint32_t sv = (uint32_t)(4 * i + (lane >> 4)) * kRescoreWaves + (uint32_t)wid;
-          const uint32_t row = srow[sv < n_surv ? sv : 0u];  // (slots past the end re-read survivor 0: never used)
+          const uint32_t sv = base + (uint32_t)(4 * i + (lane >> 4)) * kRescoreWaves + (uint32_t)wid;
+          uint32_t row = srow[sv < n_surv ? sv : 0u];  // (slots past the end re-read survivor 0: never used)
+          if (a.debug & 2048u) row &= 1023u;  // (diagnosis: the gather without its address translation / HBM misses)
           rp[i] = (a.rows_rm ? a.rows_rm + (uint64_t)row * a.ld : a.rows + (uint64_t)(row >> 6) * 64ull * a.ld + (row & 63) * 4u) +
                   (uint64_t)(lane & 15) * xstep;
         }
         const float* ql = qs + 4 * (lane & 15);
-        float* sp = xs + (size_t)wid * staged_lds_floats(16);
-        return a.metric == 0 ? staged_chains<NL, 0>(rp, xstep, ql, a.ld, sp, lane) : staged_chains<NL, 1>(rp, xstep, ql, a.ld, sp, lane);
+        constexpr uint32_t kBuf = (uint32_t)staged_lds_floats(kPassRows);
+        float* sp = xs + (size_t)wid * 2 * kBuf;
+        return a.metric == 0 ? staged_chains<NL, 0, 2, true, 2, 3>(rp, xstep, ql, a.ld, sp, kBuf, lane)
+                             : staged_chains<NL, 1, 2, true, 2, 3>(rp, xstep, ql, a.ld, sp, kBuf, lane);
       };
-      if (per_wave <= 4) acc = run(std::integral_constant<int, 1>{});
-      else if (per_wave <= 8) acc = run(std::integral_constant<int, 2>{});
-      else if (per_wave <= 12) acc = run(std::integral_constant<int, 3>{});
-      else acc = run(std::integral_constant<int, 4>{});
-    }
-    if (a.metric) acc = __fsub_rn(1.0f, acc);
-    const uint32_t sv = (uint32_t)lane * kRescoreWaves + (uint32_t)wid;
-    if (lane < 16 && sv < n_surv) {
-      if (acc != acc) atomicOr(a.status, 1u);
-      s_cand[sv] = (uint64_t)f32_to_order_bits(acc) << 32;  // (wave 0 holds the survivors' sequence numbers)
+      float acc = per_wave <= 4 ? run(std::integral_constant<int, 1>{}) : run(std::integral_constant<int, 2>{});
+      if (a.metric) acc = __fsub_rn(1.0f, acc);
+      const uint32_t sv = base + (uint32_t)lane * kRescoreWaves + (uint32_t)wid;
+      if (lane < (int)kPassRows && sv < n_surv) {
+        if (acc != acc) atomicOr(a.status, 1u);
+        s_cand[sv] = (uint64_t)f32_to_order_bits(acc) << 32;  // (wave 0 holds the survivors' sequence numbers)
+      }
     }
     __syncthreads();
     if (wid == 0 && (uint32_t)lane < n_surv) cand = s_cand[lane] | (uint32_t)mine;
@@ -299,10 +328,34 @@ __global__ __launch_bounds__(kWave * kRescoreWaves) void ivf_rescore_kernel(Resc
     cand = make_key(acc, (uint32_t)mine);
   }
   if (wid != 0) return;
+  stamp(3);
   if (__ballot(nan_seen) != 0 && lane == 0) atomicOr(a.status, 1u);
   uint64_t fin = kKeyMax;
   wave_topk_update(fin, a.top_k, cand, kKeyMax);
-  emit_topk(fin, q, a.top_k, lane, pl, pp, a.P, a.list_off, a.row_ids, a.out_ids, a.out_dist, a.out_count, a.out_keys);
+  // emit (emit_topk without its three dependent round trips: the id of an emitted key sits in the lane of the survivor with the
+  // same sequence number, loaded before the chains)
+  const bool have = lane < (int)a.top_k && fin != kKeyMax;
+  const uint64_t o = (uint64_t)q * a.top_k + lane;
+  if (lane < (int)a.top_k && a.out_keys) a.out_keys[o] = have ? fin : kKeyMax;
+  uint32_t my_id = 0;
+  for (uint64_t todo = __ballot(have); todo; todo &= todo - 1) {
+    const int t = __ffsll((unsigned long long)todo) - 1;
+    const uint32_t seq = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)fin, t);
+    const uint64_t m = __ballot((uint32_t)lane < n_surv && (uint32_t)mine == seq);
+    const uint32_t idv = (uint32_t)__builtin_amdgcn_readlane((int)rid, m ? __ffsll((unsigned long long)m) - 1 : 0);
+    if (lane == t) my_id = idv;
+  }
+  if (have) {
+    a.out_ids[o] = my_id;
+    a.out_dist[o] = __uint_as_float(order_bits_to_f32_bits((uint32_t)(fin >> 32)));
+  }
+  const uint64_t hm = __ballot(have);
+  if (lane == 0) a.out_count[q] = (uint32_t)__popcll(hm);
+  if (a.stamps && lane == 0) {
+    stamp(4);
+    for (int i = 0; i < 4; ++i) atomicAdd(a.stamps + 52 + i, ts[i + 1] - ts[i]);
+    atomicAdd(a.stamps + 56, 1ull); atomicAdd(a.stamps + 57, (unsigned long long)n_surv);
+  }
 }
 
 // Exact re-scan of the probed lists of the queries that failed the certificate.  ivf_rescore_kernel queued them.

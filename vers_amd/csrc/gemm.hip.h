@@ -717,6 +717,7 @@ static __global__ __launch_bounds__(kWave * kSelectWaves) void coarse_select_res
   if (q >= n_queries) return;  // (whole waves)
   const int lane = threadIdx.x & 63;
   const unsigned long long t0 = stamps ? __builtin_amdgcn_s_memtime() : 0ull;
+  unsigned long long ta = t0, tb = t0;
   const float* g = G + (uint64_t)q * N_pad;
   // (1) PS smallest approximate values; key = (order bits of G, centroid index).
   // A chunk of 4096 values sits in registers (64 per lane, ONE round trip of independent loads).  Instead of offering them
@@ -726,23 +727,26 @@ static __global__ __launch_bounds__(kWave * kSelectWaves) void coarse_select_res
   // sorted across the lanes (bitonic network) and merged with the best of the previous chunks.  Every key among the
   // chunk's PS smallest passes the filter (ties at T included), so `sel` is exactly what the serial inserts produce.
   __shared__ uint64_t s_keys_all[kSelectWaves][kWave];
-  __shared__ __attribute__((aligned(16))) float s_prod_all[kSelectWaves][staged_lds_floats(kWave)];  // the re-score's staged products
+  __shared__ __attribute__((aligned(16))) float s_prod_all[kSelectWaves][2 * staged_lds_floats(kWave)];  // the re-score's staged products (two buffers)
   uint64_t* const s_keys = s_keys_all[threadIdx.x >> 6];  // (this wave's own: LDS operations of one wave execute in order)
   float* const s_prod = s_prod_all[threadIdx.x >> 6];
   uint64_t sel = kKeyMax;
   constexpr int kR = 64;  // registers per lane and chunk
   for (uint32_t n0 = 0; n0 < k; n0 += kR * kWave) {
     uint32_t gb[kR];
-    float gv[kR];
+    // register r of lane l holds G[n0 + 256 (r / 4) + 4 l + r % 4]: sixteen 16-byte loads per lane (any fixed mapping serves: the
+    // keys carry their index).  UNCONDITIONAL loads (clamped to the row's last vector): a branch around a load makes the compiler
+    // wait for each one with vmcnt(0) -- serial round trips, 60 k cycles per query
+    auto idx_of = [&](int r) { return n0 + (uint32_t)(r >> 2) * 256u + 4u * (uint32_t)lane + (uint32_t)(r & 3); };
+    {
+      f32x4 gv[kR / 4];
 #pragma unroll
-    for (int r = 0; r < kR; ++r) {  // UNCONDITIONAL loads (clamped index): a branch around a load makes the compiler wait for
-      const uint32_t n = n0 + r * kWave + lane;  // each one with vmcnt(0) -- 64 serial round trips, 60 k cycles per query
-      gv[r] = g[n < k ? n : k - 1];
-    }
+      for (int r4 = 0; r4 < kR / 4; ++r4) {
+        const uint32_t n = n0 + (uint32_t)r4 * 256u + 4u * (uint32_t)lane;
+        gv[r4] = *reinterpret_cast<const f32x4*>(g + (n + 4u <= N_pad ? n : N_pad - 4u));
+      }
 #pragma unroll
-    for (int r = 0; r < kR; ++r) {
-      const uint32_t n = n0 + r * kWave + lane;
-      gb[r] = n < k ? f32_to_order_bits(gv[r]) : 0xFFFFFFFFu;
+      for (int r = 0; r < kR; ++r) gb[r] = idx_of(r) < k ? f32_to_order_bits(gv[r >> 2][r & 3]) : 0xFFFFFFFFu;
     }
     const uint32_t n_chunk = k - n0 < (uint32_t)(kR * kWave) ? k - n0 : (uint32_t)(kR * kWave);
     auto count_le = [&](uint32_t T) {
@@ -754,41 +758,62 @@ static __global__ __launch_bounds__(kWave * kSelectWaves) void coarse_select_res
     uint32_t T = 0xFFFFFFFFu;  // a chunk of at most 64 values: all of them (padding is excluded by its index below)
     uint64_t cur = kKeyMax;
     bool serial = false;
+    if (stamps && n0 == 0) ta = __builtin_amdgcn_s_memtime();
     if (n_chunk > (uint32_t)kWave) {
-      uint32_t mn = 0xFFFFFFFFu, mx = 0u;
+      // The bracket starts from the LANE MINIMA: PS lanes hold a value at or below the PS-th smallest lane minimum, so that
+      // minimum bounds the chunk's PS-th smallest value from above -- and closely: with 64 values per lane ~90 values lie at or
+      // below it.  (Rounds 2-4 interpolated between the chunk's smallest and largest value: a query's few NEAR centroids lie far
+      // below the bulk, the split point crept up by a sixteenth of the range per counting pass -- ~20 passes of 64 compares per
+      // lane, 16 k of the kernel's 120 k cycles per query.)
+      uint32_t mn = 0xFFFFFFFFu;
 #pragma unroll
-      for (int r = 0; r < kR; ++r) {
-        mn = gb[r] < mn ? gb[r] : mn;
-        mx = (gb[r] != 0xFFFFFFFFu && gb[r] > mx) ? gb[r] : mx;
+      for (int r = 0; r < kR; ++r) mn = gb[r] < mn ? gb[r] : mn;
+      uint32_t rlt = 0, rle = 0;  // lane minima below / at or below this lane's: the order statistics j in [rlt, rle) are this lane's value
+#pragma unroll
+      for (int l = 0; l < kWave; ++l) {
+        const uint32_t o = (uint32_t)__builtin_amdgcn_readlane((int)mn, l);
+        rlt += o < mn ? 1u : 0u;
+        rle += o <= mn ? 1u : 0u;
       }
-      uint32_t lo = wave_min_u32(mn), hi = wave_max_u32(mx), c = count_le(hi);  // c: values that are not NaN
-      if (c < PS) serial = true;  // NaNs would have to fill the list: the ordered inserts handle it (never on sane data)
+      auto ostat = [&](uint32_t j) {  // the (j + 1)-th smallest lane minimum
+        const uint64_t m = __ballot(rlt <= j && j < rle);
+        return (uint32_t)__builtin_amdgcn_readlane((int)mn, m ? __ffsll((unsigned long long)m) - 1 : 0);
+      };
+      auto value = [](uint32_t bits) { return __uint_as_float(order_bits_to_f32_bits(bits)); };
+      uint32_t hi = ostat(PS - 1u);
+      if (hi == 0xFFFFFFFFu) serial = true;  // fewer than PS lanes hold a number at all: NaNs would have to fill the list -- the ordered inserts handle it
       else {
-        // invariant (order bits): count(<= hi) = c >= PS, and the PS-th smallest value is >= lo.  The split point is chosen
-        // in the VALUE domain where the G of a query are spread roughly evenly -- aim at a count a little above PS:
-        // 2-4 counting passes instead of ~25 steps of blind bisection over the 32-bit key space -- and clamped into
-        // [lo, hi - 1] in the bit domain, so that every step shrinks the bracket whatever the values are.
+        // invariant (order bits): count(<= hi) = c >= PS, and the PS-th smallest value is >= lo.  Split points by regula falsi
+        // in the VALUE domain between an anchor below the target (first a lane minimum with its EXPECTED count -- 64 values
+        // per lane, evenly dealt: count(<= the j-th smallest minimum) ~ -64 ln(1 - j / 64) -- then the last split point that
+        // counted short) and hi, aiming at a count midway between PS and 64; clamped into [lo, hi - 1] in the bit domain, so
+        // that every step shrinks the bracket whatever the values are.
+        uint32_t lo = ostat(0u), c = count_le(hi);
+        const uint32_t ja = PS / 2u;
+        float af = value(ostat(ja - 1u)), ac = -64.0f * __logf(1.0f - (float)ja * (1.0f / 64.0f));
+        const float target = 0.5f * (float)(PS + (uint32_t)kWave);
         while (c > (uint32_t)kWave && lo < hi) {
-          const float lf = __uint_as_float(order_bits_to_f32_bits(lo)), hf = __uint_as_float(order_bits_to_f32_bits(hi));
-          float frac = (float)(PS + 8u) / (float)c;
-          frac = frac < 0.0625f ? 0.0625f : (frac > 0.5f ? 0.5f : frac);
-          uint32_t mid = f32_to_order_bits(lf + (hf - lf) * frac);
-          if (!(mid >= lo && mid < hi)) mid = lo + ((hi - lo) >> 1);  // inf / NaN / rounding: plain bisection step
+          const float hf = value(hi);
+          float frac = (target - ac) / ((float)c - ac);
+          frac = frac < 0.1f ? 0.1f : (frac > 0.9f ? 0.9f : frac);
+          uint32_t mid = f32_to_order_bits(af + (hf - af) * frac);
+          if (!(mid >= lo && mid < hi)) mid = lo + ((hi - lo) >> 1);  // inf / NaN / rounding / an anchor off the bracket: plain bisection step
           const uint32_t cm = count_le(mid);
           if (cm >= PS) { hi = mid; c = cm; }
-          else lo = mid + 1;
+          else { lo = mid + 1; af = value(mid); ac = (float)cm; }
         }
         T = hi;
         serial = c > (uint32_t)kWave;  // more than 64 values at or below the PS-th: the ordered inserts decide by index
       }
     }
+    if (stamps && n0 == 0) tb = __builtin_amdgcn_s_memtime();
     if (!serial) {
       uint32_t base = 0;
 #pragma unroll
       for (int r = 0; r < kR; ++r) {
-        const bool in = gb[r] <= T && (n0 + r * kWave + lane) < k;
+        const bool in = gb[r] <= T && idx_of(r) < k;
         const uint64_t m = __ballot(in);
-        if (in) s_keys[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = ((uint64_t)gb[r] << 32) | (n0 + r * kWave + lane);
+        if (in) s_keys[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = ((uint64_t)gb[r] << 32) | idx_of(r);
         base += (uint32_t)__popcll(m);
       }
       // (the wave's own slice: its ds_writes above complete before its ds_reads below -- LDS is in order per wave; the fences only
@@ -809,7 +834,7 @@ static __global__ __launch_bounds__(kWave * kSelectWaves) void coarse_select_res
     } else {
 #pragma unroll
       for (int r = 0; r < kR; ++r) {
-        const uint32_t n = n0 + r * kWave + lane;
+        const uint32_t n = idx_of(r);
         wave_topk_update(sel, kWave, n < k ? (((uint64_t)gb[r] << 32) | n) : kKeyMax, kKeyMax);
       }
     }
@@ -857,7 +882,10 @@ static __global__ __launch_bounds__(kWave * kSelectWaves) void coarse_select_res
         rp[i] = C_rm + (uint64_t)c * ldc + 4 * (lane & 15);
       }
       const float* ql = qv + 4 * (lane & 15);
-      return metric == 0 ? staged_chains<NL, 0>(rp, 4u, ql, ldc, s_prod, lane) : staged_chains<NL, 1>(rp, 4u, ql, ldc, s_prod, lane);
+      constexpr int D = 2;  // chunks in flight (centroid rows: Infinity-Cache hits)
+      constexpr uint32_t kBuf = (uint32_t)staged_lds_floats(kWave);
+      return metric == 0 ? staged_chains<NL, 0, D, false, 4, 2>(rp, 4u, ql, ldc, s_prod, kBuf, lane)
+                         : staged_chains<NL, 1, D, false, 4, 2>(rp, 4u, ql, ldc, s_prod, kBuf, lane);
     };
     if (n_rows <= 36) acc = run(std::integral_constant<int, 9>{});
     else if (n_rows <= 48) acc = run(std::integral_constant<int, 12>{});
@@ -910,6 +938,7 @@ static __global__ __launch_bounds__(kWave * kSelectWaves) void coarse_select_res
   if (stamps && lane == 0) {
     const unsigned long long t3 = __builtin_amdgcn_s_memtime();
     atomicAdd(stamps + 24, t1 - t0); atomicAdd(stamps + 25, t2 - t1); atomicAdd(stamps + 26, t3 - t2); atomicAdd(stamps + 27, 1ull);
+    atomicAdd(stamps + 28, ta - t0); atomicAdd(stamps + 29, tb - ta); atomicAdd(stamps + 30, t1 - tb);  // of the selection: loads + bits, bracket, compact + sort
   }
 }
 

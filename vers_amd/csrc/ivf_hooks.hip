@@ -34,6 +34,13 @@ int32_t vers_ivf_last_scan(vers_ivf_t* h, float* out_ms, uint64_t* out_union_row
     if (sv[27])
       fprintf(stderr, "[vers stamps] coarse select, per query avg cycles: select %.0f  exact re-score %.0f  sort+certify+emit %.0f\n",
               (double)sv[24] / sv[27], (double)sv[25] / sv[27], (double)sv[26] / sv[27]);
+    if (sv[27])
+      fprintf(stderr, "[vers stamps]   of the selection: loads + order bits %.0f  bracket %.0f  compact + sort %.0f\n", (double)sv[28] / sv[27], (double)sv[29] / sv[27],
+              (double)sv[30] / sv[27]);
+    if (sv[56])
+      fprintf(stderr, "[vers stamps] exact finish, per query avg cycles: merge of the partial lists %.0f  certificate + storage rows %.0f  gather + chains %.0f  "
+              "sort + emit %.0f; survivors per query %.1f\n", (double)sv[52] / sv[56], (double)sv[53] / sv[56], (double)sv[54] / sv[56], (double)sv[55] / sv[56],
+              (double)sv[57] / sv[56]);
     if (sv[19])
       fprintf(stderr, "[vers stamps] group / scatter kernel, block 0 (us): fill + prefix sums %.1f  scatter %.1f  items %.1f\n",
               (sv[17] - sv[16]) / 100.0, (sv[18] - sv[17]) / 100.0, (sv[19] - sv[18]) / 100.0);

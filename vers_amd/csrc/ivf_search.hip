@@ -359,6 +359,7 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
     a.rows = h->rows.as<float>(); a.rows_rm = h->rows_rm.as<float>(); a.ld = h->ld; a.qp = qp; a.ldq = h->ldq; a.xmax2_bits = h->pre_misc.as<uint32_t>();
     a.qflags = qflags; a.metric = h->metric; a.force_fail = pre_mode == 2; a.shadow = use_shadow ? 1 : 0; a.debug = scan_debug_flags(); a.fail_list = fail_list; a.stats = h->pre_misc.as<uint32_t>() + 1;
     a.status = W->st_word(); a.out_ids = out_ids; a.out_dist = out_dist; a.out_count = out_count; a.out_keys = out_keys;
+    a.stamps = (scan_debug_flags() & 16u) && W->stamps.p ? W->stamps.as<unsigned long long>() : nullptr;
     const int stage_rows = rescore_lds_bytes(h->ld, true) <= 144u * 1024u ? 1 : 0;
     const size_t rs_lds = rescore_lds_bytes(h->ld, stage_rows != 0);
     if (int32_t rc2 = scan_prepare_launch(ivf_rescore_kernel, rs_lds)) return rc2;

@@ -164,6 +164,15 @@ __device__ __forceinline__ void wave_bitonic_sort64(uint64_t& key, int lane) {
     }
   }
 }
+// Two ascending 64-lane key lists (kKeyMax padded) -> the 64 smallest keys of their union, ascending: one list reversed, the
+// lane-wise minimum is a bitonic sequence, six compare-exchange stages sort it.  (An ordered insert per key -- wave_topk_update
+// -- is ~130 cycles per key that passes the threshold: 34 of them for the first slot merged into an empty list.)
+__device__ __forceinline__ void wave_merge_sorted64(uint64_t& list, uint64_t cand, int lane) {
+  if (__ballot(cand != kKeyMax) == 0) return;  // nothing in it (wave-uniform)
+  const uint64_t rev = shfl_idx64(cand, kWave - 1 - lane);
+  list = list < rev ? list : rev;
+  wave_bitonic_merge64(list, lane);
+}
 // ---- HBM layout: lane-transposed tiles ---------------------------------------------------------
 // A scanned matrix (corpus lists, centroids) is stored in tiles of 64 rows.  Inside tile t
 // (base = t*64*ld floats) element (r, j) lives at ((j/4)*64 + r)*4 + (j%4): for each group of 4
