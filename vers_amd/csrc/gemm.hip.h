@@ -824,7 +824,7 @@ static __global__ __launch_bounds__(kWave * kSelectWaves) void coarse_select_res
       cur = (uint32_t)lane < base ? s_keys[lane] : kKeyMax;
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
       __builtin_amdgcn_wave_barrier();
-      wave_bitonic_sort64(cur, lane);
+      wave_rank_sort64(cur, lane);  // (unique: they carry their index)
       if (n0 == 0) sel = cur;
       else {  // the 64 smallest of (best so far, this chunk)
         const uint64_t rev = shfl_idx64(cur, kWave - 1 - lane);
@@ -895,7 +895,7 @@ static __global__ __launch_bounds__(kWave * kSelectWaves) void coarse_select_res
   bool nan_seen = have && (acc != acc);
   const unsigned long long t2 = stamps ? __builtin_amdgcn_s_memtime() : 0ull;
   uint64_t exact = have ? make_key(acc, ci) : kKeyMax;  // sorted by (exact distance, index): one bitonic network
-  wave_bitonic_sort64(exact, lane);                     // (~35 ordered inserts of ~150 cycles each before)
+  wave_rank_sort64(exact, lane);                     // (~35 ordered inserts of ~150 cycles each before)
   // (3) certificate
   const float dP = __uint_as_float(order_bits_to_f32_bits((uint32_t)(readlane64(exact, (int)Pq - 1) >> 32)));
   // metric 1: G ~ D_ref - 1 with |D_ref - (1 + G)| <= u (1 + 2 |q||c|) + 3.03 d u |q||c| < (5d + 16) u (|q|^2 + max|c|^2 + 1)

@@ -445,7 +445,7 @@ __global__ __launch_bounds__(kWave * kC1Phase) void coarse1_kernel(Coarse1Args c
     const float dist = METRIC == 0 ? acc : __fsub_rn(1.0f, acc);
     if (__ballot(valid && dist != dist) != 0 && lane == 0) atomicOr(c.status, kStNaN);
     uint64_t key = valid ? make_key(dist, row) : kKeyMax;
-    wave_bitonic_sort64(key, lane);
+    wave_rank_sort64(key, lane);  // (unique: they carry their row)
     // The slot is read by ANOTHER BLOCK OF THE SAME LAUNCH: it is stored at agent scope -- written through this XCD's L2 -- so
     // that no L2 write-back (the release fence at agent scope: measured 2 us here with 8 blocks per XCD, 47 us over the 368
     // blocks of a single-query list scan) is needed; once the stores have COMPLETED the block counts itself finished.

@@ -185,10 +185,10 @@ constexpr int kPreQNarrow = 16;
 // are folded in: the 64 smallest of the union come out.  Whole wave.
 __device__ __forceinline__ uint64_t buffer_sorted(const uint64_t* bq, uint32_t n_valid, uint32_t cap, int lane) {
   uint64_t k0 = (uint32_t)lane < n_valid ? bq[lane] : kKeyMax;
-  wave_bitonic_sort64(k0, lane);
+  wave_rank_sort64<true>(k0, lane);
   if (cap > (uint32_t)kWave && n_valid > (uint32_t)kWave) {  // (wave-uniform)
     uint64_t k1 = (uint32_t)lane + kWave < n_valid ? bq[kWave + lane] : kKeyMax;
-    wave_bitonic_sort64(k1, lane);
+    wave_rank_sort64<true>(k1, lane);
     const uint64_t k1r = shfl_idx64(k1, kWave - 1 - lane);
     k0 = k0 < k1r ? k0 : k1r;  // ascending vs descending: the element-wise minimum holds the 64 smallest, as a bitonic sequence
     wave_bitonic_merge64(k0, lane);

@@ -164,6 +164,34 @@ __device__ __forceinline__ void wave_bitonic_sort64(uint64_t& key, int lane) {
     }
   }
 }
+// One key per lane -> ascending over the lanes, by RANK COUNTING: every lane counts the lanes whose DISTANCE BITS lie below its
+// own (64 scalar reads of a lane, a compare and an add each) and sends its key to the lane of that rank (ds_permute): ~200 VALU
+// instructions and two LDS-crossbar round trips against the bitonic network's 21 dependent stages of two ds_bpermute round trips
+// each.  Two keys with the same distance bits would claim the same rank: a lane id sent along the same route first tells
+// whether every lane is somebody's destination; if not (rare: equal f32 distances inside one 64-key set) the network, which
+// orders by (bits, sequence number), does the job.  The kKeyMax lanes take the ranks behind the others in lane order.
+template <bool ROLLED = false>  // ROLLED: the counting loop four lanes per trip (inside a kernel that has no registers to spare)
+__device__ __forceinline__ void wave_rank_sort64(uint64_t& key, int lane) {
+  const uint32_t hi = (uint32_t)(key >> 32);
+  uint32_t rank = 0;
+  if constexpr (ROLLED) {
+#pragma unroll 4
+    for (int l = 0; l < kWave; ++l) rank += (uint32_t)__builtin_amdgcn_readlane((int)hi, l) < hi ? 1u : 0u;
+  } else {
+#pragma unroll
+    for (int l = 0; l < kWave; ++l) rank += (uint32_t)__builtin_amdgcn_readlane((int)hi, l) < hi ? 1u : 0u;
+  }
+  const uint64_t vm = __ballot(key != kKeyMax);
+  if (key == kKeyMax) rank = (uint32_t)__popcll(vm) + (uint32_t)__popcll(~vm & ((1ull << lane) - 1ull));
+  const int got = __builtin_amdgcn_ds_permute((int)(rank << 2), lane + 1);
+  if (__ballot(got == 0) != 0) {  // (wave-uniform)
+    wave_bitonic_sort64(key, lane);
+    return;
+  }
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_ds_permute((int)(rank << 2), (int)(uint32_t)key);
+  const uint32_t h2 = (uint32_t)__builtin_amdgcn_ds_permute((int)(rank << 2), (int)hi);
+  key = ((uint64_t)h2 << 32) | lo;
+}
 // Two ascending 64-lane key lists (kKeyMax padded) -> the 64 smallest keys of their union, ascending: one list reversed, the
 // lane-wise minimum is a bitonic sequence, six compare-exchange stages sort it.  (An ordered insert per key -- wave_topk_update
 // -- is ~130 cycles per key that passes the threshold: 34 of them for the first slot merged into an empty list.)
