@@ -155,6 +155,13 @@ def test_f32_rows_feed_the_scan_without_the_shadow():
     assert out["TIES"][0] == 1 and out["TIES"][1] > 0 and out["HUGE"] == (1, 64) and out["ONE"] == (1,) and out["TEN"][0] >= 10 and out["BIG"] == (0,) and out["SLACK"] == (0,)
 
 
+def test_exact_finish_gathers_from_the_tiles_without_the_row_major_copy():
+    """VERS_ROWMAJOR=0: the survivors' rows come out of the lane-transposed tiles (16-byte pieces 1 KB apart) instead of the
+    row-major second copy: same staged chains (csrc/staged.hip.h), another address pattern."""
+    out = run({"VERS_ROWMAJOR": "0"})
+    assert out["TIES"][0] == 1 and out["TIES"][1] > 0 and out["HUGE"] == (1, 64) and out["ONE"] == (1,) and out["TEN"][0] >= 10 and out["BIG"] == (0,) and out["SLACK"] == (0,)
+
+
 def test_forced_certificate_failure_is_exact():
     out = run({"VERS_PRESCAN": "2"})
     assert out["TIES"] == (1, 64)

@@ -167,14 +167,9 @@ __global__ __launch_bounds__(kWave * kRescoreWaves) __attribute__((amdgpu_waves_
   // 8 ranks 4 of a query's 32 probes are local: 8 live slots of 64 -- one round of independent loads instead of four rounds of
   // a count load followed by a key load each (20 of the kernel's 84 us there).
   const uint32_t my_nq = lane < (int)a.P ? (nqp[lane] < a.S_max ? nqp[lane] : a.S_max) : 0u;
-  uint32_t incl = my_nq;
-#pragma unroll
-  for (int off = 1; off < kWave; off <<= 1) {
-    const uint32_t t = __shfl_up(incl, off, kWave);
-    if (lane >= off) incl += t;
-  }
+  const uint32_t incl = wave_incl_u32(my_nq);
   const uint32_t excl = incl - my_nq;
-  uint32_t n_live = (uint32_t)__shfl(incl, kWave - 1, kWave);
+  uint32_t n_live = (uint32_t)__builtin_amdgcn_readlane((int)incl, kWave - 1);
   if (a.debug & 1024u) n_live = n_live / 8;
   if (wid == 0 && pre_ok) wave_seq_rows_load2(pre, a.list_off);  // (the dependent half, in flight under the merge)
   for (uint32_t i0 = 0; (uint32_t)wid + kRescoreWaves * i0 < n_live; i0 += U) {

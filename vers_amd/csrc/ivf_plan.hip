@@ -77,14 +77,7 @@ __device__ __forceinline__ uint32_t group_lists(const GroupArgs& a, uint32_t* ta
   if (threadIdx.x == 0) { ur = sr = 0; }
   uint32_t cp = 0, cg = 0, ci = 0, ch = 0;  // carries (identical in every thread); ci: other lists' items, ch: hot lists' items
   unsigned long long my_ur = 0, my_sr = 0;
-  auto wave_incl = [&](uint32_t x) {
-#pragma unroll
-    for (int off = 1; off < kWave; off <<= 1) {
-      const uint32_t t = __shfl_up(x, off, kWave);
-      if (lane >= off) x += t;
-    }
-    return x;
-  };
+  auto wave_incl = [&](uint32_t x) { return wave_incl_u32(x); };
   // whole 16-byte vectors when every table starts on one (they are carved out of one allocation: true when k, b are multiples of 4)
   const bool vec_ok = (k_lists & 3u) == 0 &&
                       (((uintptr_t)cnt | (uintptr_t)list_len | (uintptr_t)hot | (uintptr_t)a.pair_off | (uintptr_t)a.group_off | (uintptr_t)a.item_off) & 15u) == 0;
@@ -272,15 +265,8 @@ __device__ __forceinline__ void plan1_block(const Plan1Args& a, uint64_t (*sh)[k
   // (the records' operands by CENTROID index -- list_off[L], and the stored length IS list_len[L] -- so that they are requested
   // together with the slot instead of a round trip behind it: round 3 read slot_off[slot] / slot_len[slot])
   const uint32_t loff = (a.recs && L != kNoList) ? a.list_off[L] : 0u, llen = len;
-  auto excl_scan = [&](uint32_t v) {  // exclusive prefix sum over the 64 lanes
-    uint32_t inc = v;
-#pragma unroll
-    for (int off = 1; off < kWave; off <<= 1) {
-      const uint32_t t = __shfl_up(inc, off, kWave);
-      if (lane >= off) inc += t;
-    }
-    return inc - v;
-  };
+  const uint32_t own = (a.owner != nullptr && L != kNoList) ? (uint32_t)a.owner[L] : a.rank;  // (with the lengths: one round trip, not two)
+  auto excl_scan = [&](uint32_t v) { return wave_incl_u32(v) - v; };  // exclusive prefix sum over the 64 lanes
   const uint32_t pref = excl_scan(len);
   if (a.stamps && lane == 0) a.stamps[49] = __builtin_amdgcn_s_memrealtime();
   const uint32_t total_rows = (uint32_t)__shfl(pref + len, kWave - 1, kWave);
@@ -288,7 +274,7 @@ __device__ __forceinline__ void plan1_block(const Plan1Args& a, uint64_t (*sh)[k
   // fill top_k, and contributes take_j = min(len_j, top_k - rows before it)
   const bool visited = L != kNoList && (!a.ref_mode || pref < top_k);
   const uint32_t take = !visited ? 0u : (a.ref_mode ? (len < top_k - pref ? len : top_k - pref) : top_k);
-  const bool scan = visited && len > 0 && take > 0 && (a.owner == nullptr || a.owner[L] == a.rank);
+  const bool scan = visited && len > 0 && take > 0 && own == a.rank;
   if (lane < (int)P) {
     a.pj_list[lane] = scan ? slot : kNoList;
     a.pj_pref[lane] = pref;

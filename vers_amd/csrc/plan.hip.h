@@ -71,14 +71,9 @@ __device__ __forceinline__ void plan_query_chunk(const PlanQ& a, uint32_t q, int
   const uint32_t len = L != kNoList ? a.list_len[L] : 0u;
   const uint32_t slot = L != kNoList ? a.list_slot[L] : kNoList;
   const uint32_t own = (a.owner != nullptr && L != kNoList) ? (uint32_t)a.owner[L] : a.rank;  // (with the lengths: one round trip, not two)
-  uint32_t inc = len;
-#pragma unroll
-  for (int off = 1; off < kWave; off <<= 1) {
-    const uint32_t t = __shfl_up(inc, off, kWave);
-    if (lane >= off) inc += t;
-  }
+  const uint32_t inc = wave_incl_u32(len);
   const uint32_t pref = carry + inc - len;
-  carry += (uint32_t)__shfl(inc, kWave - 1, kWave);
+  carry += (uint32_t)__builtin_amdgcn_readlane((int)inc, kWave - 1);
   const bool visited = L != kNoList && (!a.ref_mode || pref < a.top_k);
   const uint32_t take = !visited ? 0u : (a.ref_mode ? (len < a.top_k - pref ? len : a.top_k - pref) : a.top_k);
   const bool scan = visited && len > 0 && take > 0 && own == a.rank;

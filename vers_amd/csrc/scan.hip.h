@@ -103,6 +103,17 @@ __device__ __forceinline__ uint32_t wave_sum_u32(uint32_t x) {
   x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);  // row_bcast:31 into rows 2, 3
   return (uint32_t)__builtin_amdgcn_readlane((int)x, 63);
 }
+// Inclusive prefix sum of a u32 over the 64 lanes: the same six DPP steps (lane i ends with x_0 + ... + x_i) -- plain VALU moves
+// where __shfl_up is a ds_bpermute round trip per step.
+__device__ __forceinline__ uint32_t wave_incl_u32(uint32_t x) {
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false);  // row_shr:1
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x112, 0xf, 0xf, false);  // row_shr:2
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x114, 0xf, 0xf, false);  // row_shr:4
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x118, 0xf, 0xf, false);  // row_shr:8: inclusive inside each row of 16
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x142, 0xa, 0xf, false);  // row_bcast:15: row 0's total into row 1, row 2's into row 3
+  x += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x143, 0xc, 0xf, false);  // row_bcast:31: the first half's total into rows 2, 3
+  return x;
+}
 __device__ __forceinline__ uint32_t wave_max_u32(uint32_t x) {
   uint32_t y;
   y = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, 0x111, 0xf, 0xf, false); x = x > y ? x : y;
