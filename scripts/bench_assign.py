@@ -8,7 +8,9 @@ from vers_amd import capi
 from vers_amd.index import IVFFlatIndex
 d = 768
 dev = torch.device("cuda:0")
-for n, k, iters in ((4_194_304, 4096, 2), (1_048_576, 65536, 1)):
+CASES = ((4_194_304, 4096, 2), (1_048_576, 65536, 1))
+if os.environ.get("ONLY"): CASES = (CASES[int(os.environ["ONLY"])],)   # ONLY=0: cfg3's cluster count alone (quick PMC looks)
+for n, k, iters in CASES:
     X = torch.empty(n, d, dtype=torch.float32, device=dev)
     capi.gen_rows_dev(X.data_ptr(), n, d, d, 1, 0x5EED0001, 0x5EEDC0DE, 16 * 4096, float(dg.default_sigma(d)))
     init = (dg.mix64(np.uint64(0xB01D) + np.arange(k, dtype=np.uint64)) % np.uint64(n)).astype(np.uint64)

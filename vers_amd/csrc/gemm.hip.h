@@ -275,7 +275,11 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2
                                                                   const float* __restrict__ cnorm, uint32_t K, uint32_t N_pad,
                                                                   float* __restrict__ G, int metric, uint32_t m_tiles, uint32_t n_tiles, uint32_t grp, uint32_t k_rows = 0,
                                                                   float* __restrict__ part_v1 = nullptr, uint32_t* __restrict__ part_c1 = nullptr,
-                                                                  float* __restrict__ part_v2 = nullptr) {
+                                                                  float* __restrict__ part_v2 = nullptr, uint32_t* __restrict__ zero = nullptr,
+                                                                  uint32_t n_zero = 0) {
+  // (the batch's zero-initialised planning tables, for the launch behind this one: a few words per thread here instead of a
+  // memset launch of their own in front of every batch's coarse quantiser)
+  for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n_zero; i += gridDim.x * 256u) zero[i] = 0u;
   // [buffer][matrix A|B][part hi|lo][128 rows][kX3Pitch] bf16 = 2 x 32 KB: the split tile of step k+1 is written while the
   // MFMAs of step k read the other buffer (ONE barrier per K-tile), and the global loads run TWO tiles ahead in
   // registers -- with the MFMA time of a tile down to ~770 cycles a single tile of prefetch no longer covers the L2 /
@@ -668,7 +672,8 @@ inline hipError_t launch_gemm_wide(uint32_t k_pad, uint32_t nb_pad, hipStream_t 
 template <bool NORM_ROWS>
 inline hipError_t launch_gemm(bool x3, uint32_t m_tiles, uint32_t n_tiles, hipStream_t st, const float* Q, const float* C, const float* cnorm,
                               uint32_t K, uint32_t N_pad, float* G, uint32_t metric, uint32_t k_rows = 0, float* part_v1 = nullptr,
-                              uint32_t* part_c1 = nullptr, float* part_v2 = nullptr, const __bf16* sh = nullptr, const __bf16* sl = nullptr) {
+                              uint32_t* part_c1 = nullptr, float* part_v2 = nullptr, const __bf16* sh = nullptr, const __bf16* sl = nullptr,
+                              uint32_t* zero = nullptr, uint32_t n_zero = 0) {  // zero / n_zero: the bf16x3 kernel only (the caller checks x3)
   const uint32_t grp = NORM_ROWS ? gemm_tile_group(m_tiles) : 0;
   if (!x3) {
     hipLaunchKernelGGL(dist_gemm_kernel<NORM_ROWS>, dim3(m_tiles * n_tiles), dim3(256), 0, st, Q, C, cnorm, K, N_pad, G, metric, m_tiles, n_tiles,
@@ -684,7 +689,7 @@ inline hipError_t launch_gemm(bool x3, uint32_t m_tiles, uint32_t n_tiles, hipSt
     const __bf16* qh = NORM_ROWS ? sh : nullptr; const __bf16* ql = NORM_ROWS ? sl : nullptr;
     const __bf16* ch = NORM_ROWS ? nullptr : sh; const __bf16* cl = NORM_ROWS ? nullptr : sl;
     hipLaunchKernelGGL((dist_gemm_x3_kernel<NORM_ROWS, PRE>), dim3(m_tiles * n_tiles), dim3(256), kX3LdsBytes, st, Q, C, qh, ql, ch, cl, cnorm, K,
-                       N_pad, G, metric, m_tiles, n_tiles, grp, k_rows, part_v1, part_c1, part_v2);
+                       N_pad, G, metric, m_tiles, n_tiles, grp, k_rows, part_v1, part_c1, part_v2, zero, n_zero);
     return hipGetLastError();
   };
   return (sh && sl) ? go(std::integral_constant<int, kPreBit>{}) : go(std::integral_constant<int, 0>{});

@@ -354,6 +354,11 @@ inline int coarse_mode() {  // VERS_COARSE: 1 = always exact, 2 = every certific
   return m;
 }
 inline bool coarse_on_matrix_cores(const vers_ivf* h, uint32_t b) { return b >= 32 && coarse_mode() != 1 && !W->ref_deep; }
+// the whole condition under which coarse() ranks on the matrix cores (the contraction reads whole 128-row tiles: the staged block
+// is padded to them, a caller's block used in place is a whole number of them; the selection keeps P + 16 keys: one per lane)
+inline bool coarse_uses_mfma(const vers_ivf* h, const float* qp, uint32_t b, uint32_t P) {
+  return coarse_on_matrix_cores(h, b) && (qp == W->qp.as<float>() || b % 128u == 0) && P + 16 <= 64u;
+}
 
 // ---- ivf_plan.hip: coarse quantiser + planning -------------------------------------------------------------------------
 int32_t stage_plain_queries(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint32_t b, const float** q_out, hipStream_t st);

@@ -506,9 +506,12 @@ int32_t coarse_mfma(vers_ivf* h, const float* qp, uint32_t b, uint32_t P, uint64
   const bool timed = W->ev_on && (st != W->ahead_stream || W->ahead_stream == nullptr);
   if (timed) VERS_HIP_TRY(hipEventRecord(W->evc[0], st));
   const __bf16* cs = h->centroids_gs.as<__bf16>();
+  // the planning tables the selection's tail counts into: zeroed by the bf16x3 contraction's blocks, by a memset otherwise
+  const bool zero_in_gemm = plan && plan->zero_words && (gemm_x3_mask() & 2) != 0;
+  if (plan && plan->zero_words && !zero_in_gemm) VERS_HIP_TRY(hipMemsetAsync(plan->cnt, 0, (size_t)plan->zero_words * sizeof(uint32_t), st));
   VERS_HIP_TRY(launch_gemm<false>((gemm_x3_mask() & 2) != 0, M_pad / kGemmBM, h->k_pad / kGemmBN, st, qp, h->centroids_g.as<float>(),
                                   h->cnorm.as<float>(), h->ldq, h->k_pad, W->gbuf.as<float>(), h->metric, 0, nullptr, nullptr, nullptr, cs,
-                                  cs ? cs + (size_t)h->k_pad * h->ldq : nullptr));
+                                  cs ? cs + (size_t)h->k_pad * h->ldq : nullptr, zero_in_gemm ? plan->cnt : nullptr, zero_in_gemm ? plan->zero_words : 0u));
   if (timed) VERS_HIP_TRY(hipEventRecord(W->evc[1], st));
   hipLaunchKernelGGL(coarse_select_rescore_kernel, dim3((b + kSelectWaves - 1) / kSelectWaves), dim3(kWave * kSelectWaves), 0, st, W->gbuf.as<float>(), h->k_pad, h->k,
                      h->centroids_g.as<float>(), h->ldq, qp, h->ldq, h->ldq, coarse_mode() == 2 ? __builtin_inff() : h->cmax2, P, PS,
@@ -530,7 +533,8 @@ int32_t coarse(vers_ivf* h, const float* qp, uint32_t b, uint32_t P, hipStream_t
                const PlanQ* plan, bool* planned) {
   // (the contraction reads whole 128-row tiles: the staged block is padded to them, a caller's block used in place is a whole
   // number of them; the selection keeps P + 16 keys: one per lane)
-  if (coarse_on_matrix_cores(h, b) && (qp == W->qp.as<float>() || b % kGemmBM == 0) && P + 16 <= (uint32_t)kMaxTopK) {
+  static_assert(kGemmBM == 128 && kMaxTopK == 64, "coarse_uses_mfma spells these out");
+  if (coarse_uses_mfma(h, qp, b, P)) {
     if (int32_t rc = W->probe.reserve((size_t)b * P * sizeof(uint64_t))) return rc;
     if (planned) *planned = plan != nullptr;
     return coarse_mfma(h, qp, b, P, W->probe.as<uint64_t>(), st, plan);
@@ -738,9 +742,9 @@ int32_t plan_search(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint32_t b
   pq.cnt = cnt; pq.hot = hot; pq.hot_ranks = knobs().hot_ranks; pq.hot_local = knobs().hot_local ? 1u : 0u; pq.seg_rows = seg_rows; pq.seg_target = seg_target;
   pq.status = W->st_word();
   bool planned = false;
-  if (!one1) VERS_HIP_TRY(hipMemsetAsync(cnt, 0, zero_words * sizeof(uint32_t), st));
   uint32_t n_segs_c = 0;
   if (took) {  // staged queries and ranked lists of this batch were computed ahead (vers_ivf_coarse_ahead_dev)
+    if (!one1) VERS_HIP_TRY(hipMemsetAsync(cnt, 0, zero_words * sizeof(uint32_t), st));
     VERS_HIP_TRY(hipStreamWaitEvent(st, took->ready, 0));
     qp = took->qp.as<float>();
     probe = took->probe.as<uint64_t>();
@@ -753,6 +757,10 @@ int32_t plan_search(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint32_t b
     // pitch, and -- the matrix-core contraction reads whole 128-row tiles -- a whole number of tiles (or a single query)
     if (h->d == h->ldq && (reinterpret_cast<uintptr_t>(q_dev) & 15u) == 0 && (b == 1 || (ldq_in == h->ldq && b % kGemmBM == 0))) qp = q_dev;
     else if (int32_t rc = stage_plain_queries(h, q_dev, ldq_in, b, &qp, st)) return rc;
+    // the zeroed zone: by the coarse contraction's own launch when the ranking runs on the matrix cores (coarse_mfma), else here
+    const bool zero_in_coarse = !one1 && zero_words <= 0xFFFFFFFFull && coarse_uses_mfma(h, qp, b, P);
+    if (zero_in_coarse) pq.zero_words = (uint32_t)zero_words;
+    else if (!one1) VERS_HIP_TRY(hipMemsetAsync(cnt, 0, zero_words * sizeof(uint32_t), st));
     if (!one1_fused)
       if (int32_t rc = coarse(h, qp, b, P, st, one1 ? &n_segs_c : nullptr, one1 ? nullptr : &pq, &planned)) return rc;
     probe = W->probe.as<uint64_t>();

@@ -58,6 +58,7 @@ struct PlanQ {
   uint32_t hot_ranks = 0, seg_rows = 0, seg_target = 0;
   uint32_t hot_local = 0;               // 1: hot = the first hot_ranks lists of the query that THIS GPU scans (default: probe ranks < hot_ranks)
   uint32_t* status = nullptr;
+  uint32_t zero_words = 0;              // != 0: the zone that starts at cnt is zeroed by the coarse contraction's launch (no memset in front)
 };
 
 // One chunk (64 probe ranks) of a query's plan: lane j holds the key of probe rank c0 + j (kKeyMax = none).
