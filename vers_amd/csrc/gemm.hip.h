@@ -526,6 +526,93 @@ static __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2
       compute((int)(t & 1));
       __syncthreads();
     }
+  } else if constexpr (SCHED == 2) {
+    // SCHED = 1 with the global loads of tile t + 2 issued as soon as tile t + 1's registers are consumed instead of at the end of
+    // the step: in SCHED = 1 the loads go out just before the barrier and their first consumer -- the split at the top of the next
+    // step -- sits just behind it, so every K-tile began with the whole block waiting out an L2 / Infinity-Cache round trip
+    // (PMC, round 4: a K-tile takes 5.9 k cycles of which the matrix cores are busy 3.1 k).  Here the centroid pieces of tile
+    // t + 1 go to LDS at the TOP of step t (the other buffer's readers left at the last barrier) and their registers take tile
+    // t + 2 at once; each half of the point slots is reloaded right behind its split.  No register is added: round 3's try at
+    // loading a tile earlier kept a third tile in flight and spilled.
+    auto gload_a = [&](uint32_t k0) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int idx = tid + 512 * i;
+        const uint64_t at = (uint64_t)(m0 + (idx >> 2)) * K + k0 + (idx & 3) * 8;
+        ra[i] = *reinterpret_cast<const f32x4*>(Ch + at);
+        ra[2 + i] = *reinterpret_cast<const f32x4*>(Cl + at);
+      }
+    };
+    auto gload_b = [&](int i, uint32_t k0) {
+      const int idx = tid + 512 * i;
+      rb[i] = *reinterpret_cast<const f32x4*>(X + (uint64_t)(n0 + (idx >> 3)) * K + k0 + (idx & 7) * 4);
+    };
+    for (uint32_t t = 0; t < k_tiles; ++t) {
+      const int buf = (int)(t & 1), nbuf = buf ^ 1;
+      const uint32_t k2 = kclamp(t + 2);
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const int ko = x3_chunk(r, 2 * s2 + hh);
+        bf16x8 ah[2], al[2], bh[4], bl[4];
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+          ah[tt] = *reinterpret_cast<const bf16x8*>(Tp(buf, 0, 0) + (wr * 64 + tt * 32 + r) * kX3Pitch + ko);
+          al[tt] = *reinterpret_cast<const bf16x8*>(Tp(buf, 0, 1) + (wr * 64 + tt * 32 + r) * kX3Pitch + ko);
+        }
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+          bh[tt] = *reinterpret_cast<const bf16x8*>(Tp(buf, 1, 0) + (wc * 128 + tt * 32 + r) * kX3Pitch + ko);
+          bl[tt] = *reinterpret_cast<const bf16x8*>(Tp(buf, 1, 1) + (wc * 128 + tt * 32 + r) * kX3Pitch + ko);
+        }
+        if (s2 == 0) {  // tile t + 1's centroid pieces -> the other buffer; their registers take tile t + 2
+#pragma unroll
+          for (int i = 0; i < 2; ++i) {
+            const int idx = tid + 512 * i, row = idx >> 2, at = row * kX3Pitch + x3_chunk(row, idx & 3);
+            *reinterpret_cast<f32x4*>(Tp(nbuf, 0, 0) + at) = ra[i];
+            *reinterpret_cast<f32x4*>(Tp(nbuf, 0, 1) + at) = ra[2 + i];
+          }
+          gload_a(k2);
+        }
+        // (hard scheduling fences between the phases of a k-step: left to itself the compiler hoists both halves of the split --
+        // and with them the waits for their loads -- in front of the first MFMA and sinks the reloads to the end of the step)
+        __builtin_amdgcn_sched_barrier(0);
+        auto mfma_row = [&](int a) {
+#pragma unroll
+          for (int b = 0; b < 4; ++b) {
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a], bh[b], acc[a][b], 0, 0, 0);  // small terms first
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bl[b], acc[a][b], 0, 0, 0);
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bh[b], acc[a][b], 0, 0, 0);
+          }
+        };
+        // first half of the k-step's MFMAs with this k-step's half of the split between them, stored at once
+#pragma unroll
+        for (int i = 2 * s2; i < 2 * s2 + 2; ++i) {
+          bf16x4 sh, sl;
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            sh[u] = (__bf16)rb[i][u];
+            sl[u] = (__bf16)(rb[i][u] - (float)sh[u]);
+          }
+          const int idx = tid + 512 * i, row = idx >> 3, c4 = idx & 7;
+          const int at = row * kX3Pitch + x3_chunk(row, c4 >> 1) + (c4 & 1) * 4;
+          *reinterpret_cast<bf16x4*>(Tp(nbuf, 1, 0) + at) = sh;
+          *reinterpret_cast<bf16x4*>(Tp(nbuf, 1, 1) + at) = sl;
+        }
+        mfma_row(0);
+#pragma unroll
+        for (int g = 0; g < 12; ++g) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one MFMA
+          __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);  // two VALU
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // the split slots' registers take tile t + 2; second half of the MFMAs
+        gload_b(2 * s2, k2);
+        gload_b(2 * s2 + 1, k2);
+        mfma_row(1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      __syncthreads();
+    }
   } else {
     for (uint32_t t = 0; t < k_tiles; ++t) {
       const int buf = (int)(t & 1), nbuf = buf ^ 1;
@@ -639,8 +726,8 @@ static __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2
   }
 }
 // assign pass through the wide kernel when the shapes allow it (VERS_GEMM_WIDE=0: never)
-inline int gemm_wide_mode() {  // VERS_GEMM_WIDE: 0 = never, 1 = plain order, 2 = interleaved (default)
-  static const int m = [] { const char* e = getenv("VERS_GEMM_WIDE"); return e ? atoi(e) : 2; }();
+inline int gemm_wide_mode() {  // VERS_GEMM_WIDE: 0 = never, 1 = plain order, 2 = interleaved, 3 = interleaved + early reloads (default)
+  static const int m = [] { const char* e = getenv("VERS_GEMM_WIDE"); return e ? atoi(e) : 3; }();
   return m;
 }
 inline bool gemm_wide_ok(uint32_t k_pad, uint32_t nb_pad, bool have_split) {
@@ -656,7 +743,12 @@ inline hipError_t launch_gemm_wide(uint32_t k_pad, uint32_t nb_pad, hipStream_t 
   // each XCD keeps `grp` centroid tiles (256 rows x K x 4 B of hi | lo = 768 KB at K = 768) in its L2 and walks the point tiles
   uint32_t grp = 0;
   for (uint32_t g : {2u, 1u}) if (m_tiles % (8u * g) == 0) { grp = g; break; }
-  if (gemm_wide_mode() == 1)
+  static const hipError_t attr2 = hipFuncSetAttribute((const void*)dist_gemm_x3w_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kX3WLdsBytes);
+  if (attr2 != hipSuccess) return attr2;
+  if (gemm_wide_mode() == 3)
+    hipLaunchKernelGGL(dist_gemm_x3w_kernel<2>, dim3(m_tiles * n_tiles), dim3(512), kX3WLdsBytes, st, X, ch, cl, cnorm, K, N_pad, (int)metric, m_tiles,
+                       n_tiles, grp, k_rows, part_v1, part_c1, part_v2);
+  else if (gemm_wide_mode() == 1)
     hipLaunchKernelGGL(dist_gemm_x3w_kernel<0>, dim3(m_tiles * n_tiles), dim3(512), kX3WLdsBytes, st, X, ch, cl, cnorm, K, N_pad, (int)metric, m_tiles,
                        n_tiles, grp, k_rows, part_v1, part_c1, part_v2);
   else
