@@ -388,7 +388,7 @@ def main():
         if bs["gemm_launches"] <= 0 or bs["gemm_ms"] <= 0:
             return None
         tf = bs["gemm_flop"] / (bs["gemm_ms"] * 1e-3) / 1e12
-        e = {"kernel": "dist_gemm_x3_kernel<true> (points x centroids, 3 x v_mfma_f32_32x32x16_bf16 on hi/lo-split operands; arg-min fused into the epilogue)",
+        e = {"kernel": "dist_gemm_x3w_kernel<2> (256 x 256 block tiles of points x centroids, 3 x v_mfma_f32_32x32x16_bf16 on hi/lo-split operands; arg-min fused into the epilogue; dist_gemm_x3_kernel<true> on 128 x 128 tiles when a shape is not a multiple of 256)",
              "shape": [int(shape_pts), int(k_), d], "launches": int(bs["gemm_launches"]), "us_per_launch": round(bs["gemm_ms"] / bs["gemm_launches"] * 1e3, 1),
              "algorithmic_tflops": round(tf, 1), "frac_of_bf16_dense_div3": round(tf / (BF16_DENSE_PEAK_TF / 3.0), 4), "frac_of_f32_mfma_peak": round(tf / MFMA_F32_PEAK_TF, 4),
              "assign_pass_ms": round(bs["assign_ms"] / max(1.0, bs["assign_passes"]), 2), "assign_passes": int(bs["assign_passes"]),

@@ -806,6 +806,7 @@ inline hipError_t launch_split_bf16(const float* x, uint64_t n_floats, __bf16* h
 #define VERS_SELECT_WAVES 1
 #endif
 constexpr int kSelectWaves = VERS_SELECT_WAVES;
+constexpr int kSelRows = 40;  // candidate rows staged per pass of the exact re-score
 static __global__ __launch_bounds__(kWave * kSelectWaves) void coarse_select_rescore_kernel(
     const float* G, uint32_t N_pad, uint32_t k, const float* C_rm, uint32_t ldc, const float* qp, uint32_t ldq, uint32_t d_pad,
     float cmax2, uint32_t P, uint32_t PS, uint64_t* probe, uint32_t* status, uint32_t* fallback_count, int metric,
@@ -824,7 +825,7 @@ static __global__ __launch_bounds__(kWave * kSelectWaves) void coarse_select_res
   // sorted across the lanes (bitonic network) and merged with the best of the previous chunks.  Every key among the
   // chunk's PS smallest passes the filter (ties at T included), so `sel` is exactly what the serial inserts produce.
   __shared__ uint64_t s_keys_all[kSelectWaves][kWave];
-  __shared__ __attribute__((aligned(16))) float s_prod_all[kSelectWaves][2 * staged_lds_floats(kWave)];  // the re-score's staged products (two buffers)
+  __shared__ __attribute__((aligned(16))) float s_prod_all[kSelectWaves][2 * staged_lds_floats(kSelRows)];  // the re-score's staged products (two buffers)
   uint64_t* const s_keys = s_keys_all[threadIdx.x >> 6];  // (this wave's own: LDS operations of one wave execute in order)
   float* const s_prod = s_prod_all[threadIdx.x >> 6];
   uint64_t sel = kKeyMax;
@@ -970,23 +971,32 @@ static __global__ __launch_bounds__(kWave * kSelectWaves) void coarse_select_res
   {
     const uint64_t hm = __ballot(have);
     const int n_rows = hm ? 64 - __builtin_clzll((unsigned long long)hm) : 0;
-    auto run = [&](auto nl_tag) {
+    // At most kSelRows rows are staged per pass (the second pass, n_rows > 40, only when P + 16 > 40 keys were wanted AND worth their
+    // rows): 2 x 40 x 272 bytes of products and <= 248 registers per wave -- with them a wave of this kernel fits on a SIMD BESIDE a
+    // wave of another batch's coarse contraction (248 registers, 64 KB of LDS per CU), so that with batches in flight the two
+    // latency-bound kernels of consecutive batches overlap instead of queueing for whole CUs.
+    auto run = [&](auto nl_tag, int base) {
       constexpr int NL = decltype(nl_tag)::value;
       const float* rp[NL];
 #pragma unroll
       for (int i = 0; i < NL; ++i) {
-        const uint32_t c = (uint32_t)__shfl((int)ci, 4 * i + (lane >> 4), kWave);
+        const int slot = base + 4 * i + (lane >> 4);
+        const uint32_t c = (uint32_t)__shfl((int)ci, slot < kWave ? slot : 0, kWave);
         rp[i] = C_rm + (uint64_t)c * ldc + 4 * (lane & 15);
       }
       const float* ql = qv + 4 * (lane & 15);
       constexpr int D = 2;  // chunks in flight (centroid rows: Infinity-Cache hits)
-      constexpr uint32_t kBuf = (uint32_t)staged_lds_floats(kWave);
+      constexpr uint32_t kBuf = (uint32_t)staged_lds_floats(kSelRows);
       return metric == 0 ? staged_chains<NL, 0, D, false, 4, 2>(rp, 4u, ql, ldc, s_prod, kBuf, lane)
                          : staged_chains<NL, 1, D, false, 4, 2>(rp, 4u, ql, ldc, s_prod, kBuf, lane);
     };
-    if (n_rows <= 36) acc = run(std::integral_constant<int, 9>{});
-    else if (n_rows <= 48) acc = run(std::integral_constant<int, 12>{});
-    else acc = run(std::integral_constant<int, 16>{});
+    if (n_rows <= 36) acc = run(std::integral_constant<int, 9>{}, 0);
+    else acc = run(std::integral_constant<int, kSelRows / 4>{}, 0);
+    if (n_rows > kSelRows) {  // (wave-uniform) rows 40 .. 63: lane l of this pass holds row 40 + l's chain
+      const float acc2 = run(std::integral_constant<int, (kWave - kSelRows) / 4>{}, kSelRows);
+      const float moved = __shfl(acc2, lane >= kSelRows ? lane - kSelRows : 0, kWave);
+      if (lane >= kSelRows) acc = moved;
+    }
   }
   if (metric) acc = __fsub_rn(1.0f, acc);  // cosine distance: 1 - dot (base.rs:153-155)
   bool nan_seen = have && (acc != acc);

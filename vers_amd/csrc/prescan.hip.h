@@ -55,6 +55,8 @@ struct PreParams {
   uint32_t debug;
   uint32_t metric;      // 0: val = |x|^2 - 2<x,q> ~ D_ref - |q|^2 ; 1 (cosine distance 1 - dot): val = -<x,q> ~ D_ref - 1
   unsigned long long* stamps;
+  uint32_t resident = 0;  // blocks that hold CUs at a time (the guided hand-out divides by it); 0: the grid
+  uint32_t quota = 0;     // != 0: a block leaves after this many quads (time slices: the launch has resident x slices blocks)
 };
 
 
@@ -685,12 +687,19 @@ __global__ __launch_bounds__(kWave * kPreWavesG) __attribute__((amdgpu_waves_per
         atomicMin(p.bounds32 + src.bound_slot(run_first * 4, (int)qi), (uint32_t)(srt >> 32));
     }
   };
+  // Time slices (p.quota != 0, VERS_PRE_SLICES > 1): the launch has `slices` times the blocks that fit the chip and a block LEAVES
+  // after its quota of quads, so that several times per launch every CU passes through the dispatcher -- where the waiting blocks of
+  // OTHER batches' kernels (coarse contraction, selection, grouping: too many registers to sit beside a scan block) get their turn
+  // DURING this scan instead of in a gap between two scans.
+  const uint32_t n_res = p.resident ? p.resident : gridDim.x;
+  uint32_t taken = 0;
   for (uint32_t b0 = blockIdx.x;; b0 += gridDim.x) {
+    if (p.quota != 0 && taken >= p.quota) break;
     uint32_t start = b0, count = 1;
     if (p.next_quad != nullptr) {
       if (threadIdx.x == 0) {
         const uint32_t seen = __hip_atomic_load(p.next_quad, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        uint32_t r = seen < n_quads ? (n_quads - seen) / (2u * gridDim.x) : 1u;
+        uint32_t r = seen < n_quads ? (n_quads - seen) / (2u * n_res) : 1u;
         r = r < 1u ? 1u : (r > kMaxRun ? kMaxRun : r);
         nq_lds[0] = atomicAdd(p.next_quad, r);
         nq_lds[1] = r;
@@ -700,6 +709,7 @@ __global__ __launch_bounds__(kWave * kPreWavesG) __attribute__((amdgpu_waves_per
     }
     if (start >= n_quads) break;
     const uint32_t end = start + count < n_quads ? start + count : n_quads;
+    taken += end - start;
     for (uint32_t bi = start; bi < end; ++bi) {
     const ItemDesc d0 = src.items[4 * bi];
     // (block-uniform.  Only the quad right behind the run's last one: the slots written empty must be this block's own)
