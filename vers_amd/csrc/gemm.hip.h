@@ -792,80 +792,101 @@ inline hipError_t launch_split_bf16(const float* x, uint64_t n_floats, __bf16* h
   return hipGetLastError();
 }
 
-// One wave per query: select the PS smallest G of its row, re-score them exactly, sort by the exact key,
+// A block of TWO waves per query: select the PS smallest G of its row, re-score them exactly, sort by the exact key,
 // certify, fall back to the full exact scan for this query if the certificate fails.
 // C_rm: centroids row-major [k][ldc] (pad columns zero); qp: padded queries [b][ldq].
 // probe[q][0..P) receives ascending (exact distance, centroid index) keys -- the exact coarse output.
 // pq.b != 0: the query's plan (plan.hip.h step 1) is made right here -- lane j holds the key of probe rank j.
-// kSelectWaves queries per block, a wave each, nothing shared between them: the waves of a block never synchronise.  ONE per
-// block is the default, as in round 3.  Tried in round 4 (VERS_SELECT_WAVES=4 | 8: the kernel's 1024 waves on a half / a quarter
-// of the chip's CUs at two waves per SIMD, so that with batches in flight the other CUs keep a list scan running): same-box A/B
-// at 8 ranks -- three in flight 0.394-0.408 (8) / 0.405-0.411 (4) / 0.401-0.412 ms (1): nothing; one batch at a time 0.536-0.546
-// against 0.524-0.531 ms: the packed kernel itself is 12 us slower.
-#ifndef VERS_SELECT_WAVES
-#define VERS_SELECT_WAVES 1
-#endif
-constexpr int kSelectWaves = VERS_SELECT_WAVES;
-constexpr int kSelRows = 40;  // candidate rows staged per pass of the exact re-score
-static __global__ __launch_bounds__(kWave * kSelectWaves) void coarse_select_rescore_kernel(
+// Both waves hold HALF of every 4096-value chunk of the row (32 registers per lane) and half of the candidates' rows in the exact
+// re-score; the bracket's counts and the compacted keys meet in LDS (block barriers: every branch around them is block-uniform,
+// both waves see the same numbers); what is cheap and needed by both -- the order statistics of the lane minima, the sort of
+// the 64 candidates, |q|^2 -- is computed twice rather than exchanged.  Wave 1 leaves after the re-score; wave 0 sorts,
+// certifies and plans.  (Rounds 2-4: one wave per query -- the chip's 1024 SIMDs one wave each, every phase a chain of exposed
+// latencies: 26 us after this round's other changes; with two waves per SIMD the phases of different queries overlap.  Several
+// QUERIES per block, their waves independent, was tried in round 4 -- VERS_SELECT_WAVES -- and bought nothing.)
+constexpr int kSelWaves = 2;    // waves per query
+constexpr int kSelRowsW = 32;   // candidate rows a wave stages: 64 candidates dealt alternately
+static __global__ __launch_bounds__(kWave * kSelWaves) void coarse_select_rescore_kernel(
     const float* G, uint32_t N_pad, uint32_t k, const float* C_rm, uint32_t ldc, const float* qp, uint32_t ldq, uint32_t d_pad,
     float cmax2, uint32_t P, uint32_t PS, uint64_t* probe, uint32_t* status, uint32_t* fallback_count, int metric,
     unsigned long long* stamps, PlanQ pq, uint32_t n_queries) {
-  const uint32_t q = blockIdx.x * kSelectWaves + (threadIdx.x >> 6);
-  if (q >= n_queries) return;  // (whole waves)
+  const uint32_t q = blockIdx.x;
+  if (q >= n_queries) return;  // (whole blocks)
   const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const unsigned long long t0 = stamps ? __builtin_amdgcn_s_memtime() : 0ull;
   unsigned long long ta = t0, tb = t0;
   const float* g = G + (uint64_t)q * N_pad;
   // (1) PS smallest approximate values; key = (order bits of G, centroid index).
-  // A chunk of 4096 values sits in registers (64 per lane, ONE round trip of independent loads).  Instead of offering them
-  // to a sorted list one by one (~260 serial inserts of ~150 cycles: 88 k cycles per query, as much as the exact
-  // re-score), the PS-th smallest VALUE is bracketed by bisection on the order bits -- count(g <= T) over the chunk is
-  // 64 compares per lane and one wave reduction -- until PS <= count <= 64; the survivors are compacted through LDS,
-  // sorted across the lanes (bitonic network) and merged with the best of the previous chunks.  Every key among the
-  // chunk's PS smallest passes the filter (ties at T included), so `sel` is exactly what the serial inserts produce.
-  __shared__ uint64_t s_keys_all[kSelectWaves][kWave];
-  __shared__ __attribute__((aligned(16))) float s_prod_all[kSelectWaves][2 * staged_lds_floats(kSelRows)];  // the re-score's staged products (two buffers)
-  uint64_t* const s_keys = s_keys_all[threadIdx.x >> 6];  // (this wave's own: LDS operations of one wave execute in order)
-  float* const s_prod = s_prod_all[threadIdx.x >> 6];
+  // A chunk of 4096 values sits in the two waves' registers (32 per lane, ONE round trip of independent loads).  Instead of
+  // offering them to a sorted list one by one (~260 serial inserts of ~150 cycles), the PS-th smallest VALUE is bracketed on the
+  // order bits -- count(g <= T) over the chunk is 32 compares per lane, a wave reduction and an exchange of two words -- until
+  // PS <= count <= 64; the survivors are compacted through LDS, sorted across the lanes and merged with the best of the previous
+  // chunks.  Every key among the chunk's PS smallest passes the filter (ties at T included), so `sel` is exactly what the serial
+  // inserts produce.
+  __shared__ uint64_t s_keys[kWave];
+  __shared__ uint64_t s_x[kSelWaves][kWave];  // exchange: the waves' lists on the ordered-insert path; the exact keys
+  __shared__ uint32_t s_min[kSelWaves][kWave];
+  __shared__ uint32_t s_cnt[2][kSelWaves];
+  __shared__ __attribute__((aligned(16))) float s_prod_all[kSelWaves][2 * staged_lds_floats(kSelRowsW)];  // the re-score's staged products (two buffers per wave)
+  float* const s_prod = s_prod_all[wid];
   uint64_t sel = kKeyMax;
-  constexpr int kR = 64;  // registers per lane and chunk
-  for (uint32_t n0 = 0; n0 < k; n0 += kR * kWave) {
+  constexpr int kR = 32;  // registers per lane, wave and chunk
+  uint32_t cnt_it = 0;    // (parity of the count exchange: a slow wave may still be reading the previous exchange's words)
+  for (uint32_t n0 = 0; n0 < k; n0 += 2 * kR * kWave) {
     uint32_t gb[kR];
-    // register r of lane l holds G[n0 + 256 (r / 4) + 4 l + r % 4]: sixteen 16-byte loads per lane (any fixed mapping serves: the
-    // keys carry their index).  UNCONDITIONAL loads (clamped to the row's last vector): a branch around a load makes the compiler
-    // wait for each one with vmcnt(0) -- serial round trips, 60 k cycles per query
-    auto idx_of = [&](int r) { return n0 + (uint32_t)(r >> 2) * 256u + 4u * (uint32_t)lane + (uint32_t)(r & 3); };
+    // register r of lane l of wave w holds G[n0 + 2048 w + 256 (r / 4) + 4 l + r % 4]: eight 16-byte loads per lane (any fixed
+    // mapping serves: the keys carry their index).  UNCONDITIONAL loads (clamped to the row's last vector): a branch around a load
+    // makes the compiler wait for each one with vmcnt(0) -- serial round trips
+    auto idx_of = [&](int r) { return n0 + (uint32_t)wid * (uint32_t)(kR * kWave) + (uint32_t)(r >> 2) * 256u + 4u * (uint32_t)lane + (uint32_t)(r & 3); };
     {
       f32x4 gv[kR / 4];
 #pragma unroll
       for (int r4 = 0; r4 < kR / 4; ++r4) {
-        const uint32_t n = n0 + (uint32_t)r4 * 256u + 4u * (uint32_t)lane;
+        const uint32_t n = idx_of(4 * r4);
         gv[r4] = *reinterpret_cast<const f32x4*>(g + (n + 4u <= N_pad ? n : N_pad - 4u));
       }
 #pragma unroll
       for (int r = 0; r < kR; ++r) gb[r] = idx_of(r) < k ? f32_to_order_bits(gv[r >> 2][r & 3]) : 0xFFFFFFFFu;
     }
-    const uint32_t n_chunk = k - n0 < (uint32_t)(kR * kWave) ? k - n0 : (uint32_t)(kR * kWave);
-    auto count_le = [&](uint32_t T) {
+    const uint32_t n_chunk = k - n0 < (uint32_t)(2 * kR * kWave) ? k - n0 : (uint32_t)(2 * kR * kWave);
+    // entries of the chunk (both waves) passing `pred`; c0: wave 0's share -- where wave 1's compacted keys start
+    auto count_if = [&](auto pred, uint32_t& c0) {
       uint32_t c = 0;
 #pragma unroll
-      for (int r = 0; r < kR; ++r) c += gb[r] <= T ? 1u : 0u;
-      return wave_sum_u32(c);  // (padding entries are 0xFFFFFFFF: counted only at T = 0xFFFFFFFF)
+      for (int r = 0; r < kR; ++r) c += pred(r) ? 1u : 0u;
+      c = wave_sum_u32(c);
+      const uint32_t par = cnt_it & 1u;
+      if (lane == 0) s_cnt[par][wid] = c;
+      __syncthreads();
+      c0 = s_cnt[par][0];
+      const uint32_t c1 = s_cnt[par][1];
+      ++cnt_it;
+      return c0 + c1;
     };
-    uint32_t T = 0xFFFFFFFFu;  // a chunk of at most 64 values: all of them (padding is excluded by its index below)
+    auto count_le = [&](uint32_t T, uint32_t& c0) {  // (padding entries are 0xFFFFFFFF: never counted below that)
+      return count_if([&](int r) { return gb[r] <= T; }, c0);
+    };
+    uint32_t T = 0xFFFFFFFFu;  // a chunk of at most 64 values: all of them (padding is excluded by its index)
+    uint32_t cT = 0, c0T = 0;  // entries the compaction will keep; of them in wave 0
     uint64_t cur = kKeyMax;
     bool serial = false;
     if (stamps && n0 == 0) ta = __builtin_amdgcn_s_memtime();
     if (n_chunk > (uint32_t)kWave) {
-      // The bracket starts from the LANE MINIMA: PS lanes hold a value at or below the PS-th smallest lane minimum, so that
-      // minimum bounds the chunk's PS-th smallest value from above -- and closely: with 64 values per lane ~90 values lie at or
-      // below it.  (Rounds 2-4 interpolated between the chunk's smallest and largest value: a query's few NEAR centroids lie far
-      // below the bulk, the split point crept up by a sixteenth of the range per counting pass -- ~20 passes of 64 compares per
-      // lane, 16 k of the kernel's 120 k cycles per query.)
+      // The bracket starts from the LANE MINIMA (lane l's = the smaller of the two waves' lane-l minima: 64 values each): PS lanes
+      // hold a value at or below the PS-th smallest lane minimum, so that minimum bounds the chunk's PS-th smallest value from
+      // above -- and closely: ~90 values lie at or below it.  (Rounds 2-4 interpolated between the chunk's smallest and largest
+      // value: a query's few NEAR centroids lie far below the bulk, the split point crept up by a sixteenth of the range per
+      // counting pass -- ~20 passes, 16 k of the kernel's 120 k cycles per query.)
       uint32_t mn = 0xFFFFFFFFu;
 #pragma unroll
       for (int r = 0; r < kR; ++r) mn = gb[r] < mn ? gb[r] : mn;
+      s_min[wid][lane] = mn;
+      __syncthreads();
+      {
+        const uint32_t m0 = s_min[0][lane], m1 = s_min[1][lane];
+        mn = m0 < m1 ? m0 : m1;
+      }
       uint32_t rlt = 0, rle = 0;  // lane minima below / at or below this lane's: the order statistics j in [rlt, rle) are this lane's value
 #pragma unroll
       for (int l = 0; l < kWave; ++l) {
@@ -886,7 +907,8 @@ static __global__ __launch_bounds__(kWave * kSelectWaves) void coarse_select_res
         // per lane, evenly dealt: count(<= the j-th smallest minimum) ~ -64 ln(1 - j / 64) -- then the last split point that
         // counted short) and hi, aiming at a count midway between PS and 64; clamped into [lo, hi - 1] in the bit domain, so
         // that every step shrinks the bracket whatever the values are.
-        uint32_t lo = ostat(0u), c = count_le(hi);
+        uint32_t c0 = 0;
+        uint32_t lo = ostat(0u), c = count_le(hi, c0);
         const uint32_t ja = PS / 2u;
         float af = value(ostat(ja - 1u)), ac = -64.0f * __logf(1.0f - (float)ja * (1.0f / 64.0f));
         const float target = 0.5f * (float)(PS + (uint32_t)kWave);
@@ -896,17 +918,21 @@ static __global__ __launch_bounds__(kWave * kSelectWaves) void coarse_select_res
           frac = frac < 0.1f ? 0.1f : (frac > 0.9f ? 0.9f : frac);
           uint32_t mid = f32_to_order_bits(af + (hf - af) * frac);
           if (!(mid >= lo && mid < hi)) mid = lo + ((hi - lo) >> 1);  // inf / NaN / rounding / an anchor off the bracket: plain bisection step
-          const uint32_t cm = count_le(mid);
-          if (cm >= PS) { hi = mid; c = cm; }
+          uint32_t cm0 = 0;
+          const uint32_t cm = count_le(mid, cm0);
+          if (cm >= PS) { hi = mid; c = cm; c0 = cm0; }
           else { lo = mid + 1; af = value(mid); ac = (float)cm; }
         }
-        T = hi;
+        T = hi; cT = c; c0T = c0;
         serial = c > (uint32_t)kWave;  // more than 64 values at or below the PS-th: the ordered inserts decide by index
       }
+    } else {
+      cT = count_if([&](int r) { return idx_of(r) < k; }, c0T);
     }
     if (stamps && n0 == 0) tb = __builtin_amdgcn_s_memtime();
+    uint64_t chunk;  // the chunk's 64 smallest keys, ascending over the lanes, in both waves
     if (!serial) {
-      uint32_t base = 0;
+      uint32_t base = wid == 0 ? 0u : c0T;
 #pragma unroll
       for (int r = 0; r < kR; ++r) {
         const bool in = gb[r] <= T && idx_of(r) < k;
@@ -914,35 +940,33 @@ static __global__ __launch_bounds__(kWave * kSelectWaves) void coarse_select_res
         if (in) s_keys[base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = ((uint64_t)gb[r] << 32) | idx_of(r);
         base += (uint32_t)__popcll(m);
       }
-      // (the wave's own slice: its ds_writes above complete before its ds_reads below -- LDS is in order per wave; the fences only
-      // keep the compiler from moving them across.  Round 3's one-wave blocks used s_barrier here; with several independent waves
-      // per block a block-wide barrier would deadlock on waves that take the serial path.)
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
-      cur = (uint32_t)lane < base ? s_keys[lane] : kKeyMax;
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-      __builtin_amdgcn_wave_barrier();
+      __syncthreads();  // (the next chunk's keys are written behind at least one more barrier)
+      cur = (uint32_t)lane < cT ? s_keys[lane] : kKeyMax;
       wave_rank_sort64(cur, lane);  // (unique: they carry their index)
-      if (n0 == 0) sel = cur;
-      else {  // the 64 smallest of (best so far, this chunk)
-        const uint64_t rev = shfl_idx64(cur, kWave - 1 - lane);
-        sel = sel < rev ? sel : rev;
-        wave_bitonic_merge64(sel, lane);
-      }
+      chunk = cur;
     } else {
+      uint64_t mine = kKeyMax;
 #pragma unroll
       for (int r = 0; r < kR; ++r) {
         const uint32_t n = idx_of(r);
-        wave_topk_update(sel, kWave, n < k ? (((uint64_t)gb[r] << 32) | n) : kKeyMax, kKeyMax);
+        wave_topk_update(mine, kWave, n < k ? (((uint64_t)gb[r] << 32) | n) : kKeyMax, kKeyMax);
       }
+      s_x[wid][lane] = mine;
+      __syncthreads();
+      const uint64_t other = s_x[wid ^ 1][lane];
+      __syncthreads();
+      wave_merge_sorted64(mine, other, lane);
+      chunk = mine;
     }
+    if (n0 == 0) sel = chunk;
+    else wave_merge_sorted64(sel, chunk, lane);  // the 64 smallest of (best so far, this chunk)
   }
   // (lanes >= PS hold larger keys of the last merge: not candidates)
   if (lane >= (int)PS) sel = kKeyMax;
   const uint32_t n_sel = PS < k ? PS : k;
   const float tau = __uint_as_float(order_bits_to_f32_bits((uint32_t)(readlane64(sel, (int)n_sel - 1) >> 32)));
   const unsigned long long t1 = stamps ? __builtin_amdgcn_s_memtime() : 0ull;
-  // (2) exact re-score: lane l owns candidate centroid l; the query element is wave-uniform.
+  // (2) exact re-score (both waves compute E and the candidates worth their rows; the rows are dealt to them below).
   // |q|^2 first (any summation order: E covers d u |q|^2, a tree of partial sums errs less), because E decides WHICH
   // candidates are worth their 3 KB row: with g_P the P-th smallest G, the P nearest-by-G candidates all have
   // D_ref <= g_P + |q|^2 + E, so the P-th exact distance is at most that, while a candidate with G > g_P + 2E has
@@ -967,41 +991,42 @@ static __global__ __launch_bounds__(kWave * kSelectWaves) void coarse_select_res
   // Cache, 16 bytes per load and lane -- 64 lines per instruction: 58 k of the kernel's 120 k cycles per query.)
   // The candidates are sorted by G, so the ones worth their row are a prefix of the lanes (NaN keys sort last and are kept: a gap
   // between them and the prefix is staged unused).
-  float acc = 0.0f;
+  // Candidate j is re-scored by wave j & 1 as its staged row j >> 1.
+  const uint64_t hm = __ballot(have);
+  const int n_rows = hm ? 64 - __builtin_clzll((unsigned long long)hm) : 0;
+  float acc;
   {
-    const uint64_t hm = __ballot(have);
-    const int n_rows = hm ? 64 - __builtin_clzll((unsigned long long)hm) : 0;
-    // At most kSelRows rows are staged per pass (the second pass, n_rows > 40, only when P + 16 > 40 keys were wanted AND worth their
-    // rows): 2 x 40 x 272 bytes of products and <= 248 registers per wave -- with them a wave of this kernel fits on a SIMD BESIDE a
-    // wave of another batch's coarse contraction (248 registers, 64 KB of LDS per CU), so that with batches in flight the two
-    // latency-bound kernels of consecutive batches overlap instead of queueing for whole CUs.
-    auto run = [&](auto nl_tag, int base) {
+    auto run = [&](auto nl_tag) {
       constexpr int NL = decltype(nl_tag)::value;
       const float* rp[NL];
 #pragma unroll
       for (int i = 0; i < NL; ++i) {
-        const int slot = base + 4 * i + (lane >> 4);
-        const uint32_t c = (uint32_t)__shfl((int)ci, slot < kWave ? slot : 0, kWave);
+        const int j = 2 * (4 * i + (lane >> 4)) + wid;
+        const uint32_t c = (uint32_t)__shfl((int)ci, j < kWave ? j : 0, kWave);
         rp[i] = C_rm + (uint64_t)c * ldc + 4 * (lane & 15);
       }
       const float* ql = qv + 4 * (lane & 15);
       constexpr int D = 2;  // chunks in flight (centroid rows: Infinity-Cache hits)
-      constexpr uint32_t kBuf = (uint32_t)staged_lds_floats(kSelRows);
+      constexpr uint32_t kBuf = (uint32_t)staged_lds_floats(kSelRowsW);
       return metric == 0 ? staged_chains<NL, 0, D, false, 4, 2>(rp, 4u, ql, ldc, s_prod, kBuf, lane)
                          : staged_chains<NL, 1, D, false, 4, 2>(rp, 4u, ql, ldc, s_prod, kBuf, lane);
     };
-    if (n_rows <= 36) acc = run(std::integral_constant<int, 9>{}, 0);
-    else acc = run(std::integral_constant<int, kSelRows / 4>{}, 0);
-    if (n_rows > kSelRows) {  // (wave-uniform) rows 40 .. 63: lane l of this pass holds row 40 + l's chain
-      const float acc2 = run(std::integral_constant<int, (kWave - kSelRows) / 4>{}, kSelRows);
-      const float moved = __shfl(acc2, lane >= kSelRows ? lane - kSelRows : 0, kWave);
-      if (lane >= kSelRows) acc = moved;
-    }
+    if (n_rows <= 40) acc = run(std::integral_constant<int, 5>{});  // <= 20 rows per wave
+    else acc = run(std::integral_constant<int, kSelRowsW / 4>{});
   }
   if (metric) acc = __fsub_rn(1.0f, acc);  // cosine distance: 1 - dot (base.rs:153-155)
-  bool nan_seen = have && (acc != acc);
+  {  // lane l < 32 of wave w holds candidate 2 l + w's chain: the exact keys meet in LDS, wave 0 goes on alone
+    const int j = (2 * lane + wid) & (kWave - 1);
+    const bool mine_have = lane < kWave / 2 && ((hm >> j) & 1ull) != 0;
+    const uint32_t cj = (uint32_t)__shfl((int)ci, j, kWave);
+    if (lane < kWave / 2) s_x[0][j] = mine_have ? make_key(acc, cj) : kKeyMax;
+    if (__ballot(mine_have && acc != acc) != 0 && lane == 0) atomicOr(status, 1u);
+  }
+  __syncthreads();
+  if (wid != 0) return;
+  bool nan_seen = false;
   const unsigned long long t2 = stamps ? __builtin_amdgcn_s_memtime() : 0ull;
-  uint64_t exact = have ? make_key(acc, ci) : kKeyMax;  // sorted by (exact distance, index): one bitonic network
+  uint64_t exact = s_x[0][lane];                     // sorted by (exact distance, index)
   wave_rank_sort64(exact, lane);                     // (~35 ordered inserts of ~150 cycles each before)
   // (3) certificate
   const float dP = __uint_as_float(order_bits_to_f32_bits((uint32_t)(readlane64(exact, (int)Pq - 1) >> 32)));

@@ -513,7 +513,7 @@ int32_t coarse_mfma(vers_ivf* h, const float* qp, uint32_t b, uint32_t P, uint64
                                   h->cnorm.as<float>(), h->ldq, h->k_pad, W->gbuf.as<float>(), h->metric, 0, nullptr, nullptr, nullptr, cs,
                                   cs ? cs + (size_t)h->k_pad * h->ldq : nullptr, zero_in_gemm ? plan->cnt : nullptr, zero_in_gemm ? plan->zero_words : 0u));
   if (timed) VERS_HIP_TRY(hipEventRecord(W->evc[1], st));
-  hipLaunchKernelGGL(coarse_select_rescore_kernel, dim3((b + kSelectWaves - 1) / kSelectWaves), dim3(kWave * kSelectWaves), 0, st, W->gbuf.as<float>(), h->k_pad, h->k,
+  hipLaunchKernelGGL(coarse_select_rescore_kernel, dim3(b), dim3(kWave * kSelWaves), 0, st, W->gbuf.as<float>(), h->k_pad, h->k,
                      h->centroids_g.as<float>(), h->ldq, qp, h->ldq, h->ldq, coarse_mode() == 2 ? __builtin_inff() : h->cmax2, P, PS,
                      probe_out, W->st_word(), h->coarse_stat.as<uint32_t>(), h->metric,
                      (scan_debug_flags() & 16u) && W->stamps.p ? W->stamps.as<unsigned long long>() : (unsigned long long*)nullptr,
