@@ -431,7 +431,7 @@ template <int SCHED>
 static __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void dist_gemm_x3w_kernel(
     const float* __restrict__ X, const __bf16* __restrict__ Ch, const __bf16* __restrict__ Cl, const float* __restrict__ cnorm, uint32_t K,
     uint32_t N_pad, int metric, uint32_t m_tiles, uint32_t n_tiles, uint32_t grp, uint32_t k_rows, float* __restrict__ part_v1,
-    uint32_t* __restrict__ part_c1, float* __restrict__ part_v2) {
+    uint32_t* __restrict__ part_c1, float* __restrict__ part_v2, const __bf16* __restrict__ Xh = nullptr, const __bf16* __restrict__ Xl = nullptr) {
   extern __shared__ __attribute__((aligned(16))) __bf16 T[];
   constexpr int kPart = kGemmWide * kX3Pitch;
   auto Tp = [&](int buf, int mat, int part) { return T + ((buf * 2 + mat) * 2 + part) * kPart; };
@@ -515,16 +515,80 @@ static __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2
   // last tile and the store goes to a buffer nobody reads any more (no branches around loads: the compiler's counted waits)
   const uint32_t k_tiles = K / kGemmBK, k_last = K - kGemmBK;
   auto kclamp = [&](uint32_t t) { const uint32_t k0 = t * kGemmBK; return k0 < k_last ? k0 : k_last; };
-  gload(0);
-  lstore(0);
-  gload(kclamp(1));
-  __syncthreads();
+  if constexpr (SCHED != 3) {
+    gload(0);
+    lstore(0);
+    gload(kclamp(1));
+    __syncthreads();
+  }
   if constexpr (SCHED == 0) {
     for (uint32_t t = 0; t < k_tiles; ++t) {
       lstore((int)((t + 1) & 1));  // tile t + 1 (its buffer's readers finished before the last barrier)
       gload(kclamp(t + 2));
       compute((int)(t & 1));
       __syncthreads();
+    }
+  } else if constexpr (SCHED == 3) {
+    // BOTH operands pre-split into bf16 hi | lo in global memory (the points by split_bf16_kernel, per batch) and brought in by
+    // LDS-DMA (`global_load_lds_dwordx4`: 64 lanes x 16 bytes = 1 KB of LDS per instruction, no register in between): no split
+    // arithmetic, no LDS store instruction and no staging register in the loop.  Ablation of SCHED = 2 (round 4, VERS_X3W_ABLATE,
+    // same box, 362 algorithmic TFLOP/s): without its LDS stores 457, without the split's conversions 421, without its global
+    // loads 400, without the second k-step's fragment reads 364, without the barrier 367 -- the VGPR -> LDS store path and the
+    // conversions, not the fragment reads or the barrier, are what the matrix cores wait for.
+    // A K-tile is 64 pieces of 1 KB (A | B x hi | lo x 16 pieces of 16 rows): wave w brings pieces 8 w .. 8 w + 7 -- one matrix
+    // and part, rows 128 (w & 1) + 16 i + lane / 4; a lane's 16 bytes are the row's chunk (lane & 3) ^ ((row >> 2) & 3): the
+    // swizzle of x3_chunk on the SOURCE side, the LDS image linear per instruction.  (row >> 2) & 3 = (lane >> 4) & 3 for every i.
+    const int gm = wid >> 2, gp = (wid >> 1) & 1, gr0 = 128 * (wid & 1) + (lane >> 2);
+    const __bf16* gbase = (gm == 0 ? (gp == 0 ? Ch : Cl) : (gp == 0 ? Xh : Xl)) + (uint64_t)((gm == 0 ? m0 : n0) + gr0) * K +
+                          (((lane & 3) ^ ((lane >> 4) & 3)) * 8);
+    auto dma1 = [&](int i, uint32_t k0, int buf) {
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gbase + (uint64_t)(16 * i) * K + k0),
+                                       (__attribute__((address_space(3))) void*)(Tp(buf, gm, gp) + (128 * (wid & 1) + 16 * i) * kX3Pitch), 16, 0, 0);
+    };
+    // (tile 0: by DMA too -- X may be null on this path)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) dma1(i, 0, 0);
+    __syncthreads();
+    bf16x8 ah[2], al[2], bh[4], bl[4];
+    for (uint32_t t = 0; t < k_tiles; ++t) {
+      const int buf = (int)(t & 1), nbuf = buf ^ 1;
+      const uint32_t k1 = kclamp(t + 1);  // (past the end: the last tile once more, into a buffer nobody reads any more)
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const int ko = x3_chunk(r, 2 * s2 + hh);
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+          ah[tt] = *reinterpret_cast<const bf16x8*>(Tp(buf, 0, 0) + (wr * 64 + tt * 32 + r) * kX3Pitch + ko);
+          al[tt] = *reinterpret_cast<const bf16x8*>(Tp(buf, 0, 1) + (wr * 64 + tt * 32 + r) * kX3Pitch + ko);
+        }
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+          bh[tt] = *reinterpret_cast<const bf16x8*>(Tp(buf, 1, 0) + (wc * 128 + tt * 32 + r) * kX3Pitch + ko);
+          bl[tt] = *reinterpret_cast<const bf16x8*>(Tp(buf, 1, 1) + (wc * 128 + tt * 32 + r) * kX3Pitch + ko);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        auto mfma_row = [&](int a) {
+#pragma unroll
+          for (int b = 0; b < 4; ++b) {
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a], bh[b], acc[a][b], 0, 0, 0);  // small terms first
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bl[b], acc[a][b], 0, 0, 0);
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bh[b], acc[a][b], 0, 0, 0);
+          }
+        };
+        // this k-step's half of the next tile's pieces between the first row's MFMAs, one piece per three MFMAs
+#pragma unroll
+        for (int i = 4 * s2; i < 4 * s2 + 4; ++i) dma1(i, k1, nbuf);
+        mfma_row(0);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);  // three MFMAs
+          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // one VMEM read (the DMA piece)
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        mfma_row(1);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      __syncthreads();  // (waits for the DMA too: vmcnt(0))
     }
   } else if constexpr (SCHED == 2) {
     // SCHED = 1 with the global loads of tile t + 2 issued as soon as tile t + 1's registers are consumed instead of at the end of
@@ -547,13 +611,18 @@ static __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2
       const int idx = tid + 512 * i;
       rb[i] = *reinterpret_cast<const f32x4*>(X + (uint64_t)(n0 + (idx >> 3)) * K + k0 + (idx & 7) * 4);
     };
+#ifndef VERS_X3W_ABLATE
+#define VERS_X3W_ABLATE 0  // timing experiments (results are WRONG with any bit set): 1 the second k-step re-uses the first's fragments,
+#endif                     // 2 no LDS stores, 4 no global loads, 8 no barrier, 16 no split arithmetic
+    constexpr int kAbl = VERS_X3W_ABLATE;
+    bf16x8 ah[2], al[2], bh[4], bl[4];
     for (uint32_t t = 0; t < k_tiles; ++t) {
       const int buf = (int)(t & 1), nbuf = buf ^ 1;
       const uint32_t k2 = kclamp(t + 2);
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
         const int ko = x3_chunk(r, 2 * s2 + hh);
-        bf16x8 ah[2], al[2], bh[4], bl[4];
+        if (!((kAbl & 1) && s2 == 1)) {
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) {
           ah[tt] = *reinterpret_cast<const bf16x8*>(Tp(buf, 0, 0) + (wr * 64 + tt * 32 + r) * kX3Pitch + ko);
@@ -564,14 +633,17 @@ static __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2
           bh[tt] = *reinterpret_cast<const bf16x8*>(Tp(buf, 1, 0) + (wc * 128 + tt * 32 + r) * kX3Pitch + ko);
           bl[tt] = *reinterpret_cast<const bf16x8*>(Tp(buf, 1, 1) + (wc * 128 + tt * 32 + r) * kX3Pitch + ko);
         }
+        }
         if (s2 == 0) {  // tile t + 1's centroid pieces -> the other buffer; their registers take tile t + 2
+          if (!(kAbl & 2)) {
 #pragma unroll
           for (int i = 0; i < 2; ++i) {
             const int idx = tid + 512 * i, row = idx >> 2, at = row * kX3Pitch + x3_chunk(row, idx & 3);
             *reinterpret_cast<f32x4*>(Tp(nbuf, 0, 0) + at) = ra[i];
             *reinterpret_cast<f32x4*>(Tp(nbuf, 0, 1) + at) = ra[2 + i];
           }
-          gload_a(k2);
+          }
+          if (!(kAbl & 4)) gload_a(k2);
         }
         // (hard scheduling fences between the phases of a k-step: left to itself the compiler hoists both halves of the split --
         // and with them the waits for their loads -- in front of the first MFMA and sinks the reloads to the end of the step)
@@ -590,13 +662,16 @@ static __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2
           bf16x4 sh, sl;
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
+            if (kAbl & 16) { sh[u] = (__bf16)0.0f; sl[u] = (__bf16)0.0f; continue; }
             sh[u] = (__bf16)rb[i][u];
             sl[u] = (__bf16)(rb[i][u] - (float)sh[u]);
           }
           const int idx = tid + 512 * i, row = idx >> 3, c4 = idx & 7;
           const int at = row * kX3Pitch + x3_chunk(row, c4 >> 1) + (c4 & 1) * 4;
-          *reinterpret_cast<bf16x4*>(Tp(nbuf, 1, 0) + at) = sh;
-          *reinterpret_cast<bf16x4*>(Tp(nbuf, 1, 1) + at) = sl;
+          if (!(kAbl & 2)) {
+            *reinterpret_cast<bf16x4*>(Tp(nbuf, 1, 0) + at) = sh;
+            *reinterpret_cast<bf16x4*>(Tp(nbuf, 1, 1) + at) = sl;
+          }
         }
         mfma_row(0);
 #pragma unroll
@@ -606,12 +681,14 @@ static __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2
         }
         __builtin_amdgcn_sched_barrier(0);
         // the split slots' registers take tile t + 2; second half of the MFMAs
-        gload_b(2 * s2, k2);
-        gload_b(2 * s2 + 1, k2);
+        if (!(kAbl & 4)) {
+          gload_b(2 * s2, k2);
+          gload_b(2 * s2 + 1, k2);
+        }
         mfma_row(1);
         __builtin_amdgcn_sched_barrier(0);
       }
-      __syncthreads();
+      if (!(kAbl & 8)) __syncthreads();
     }
   } else {
     for (uint32_t t = 0; t < k_tiles; ++t) {
@@ -726,7 +803,7 @@ static __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2
   }
 }
 // assign pass through the wide kernel when the shapes allow it (VERS_GEMM_WIDE=0: never)
-inline int gemm_wide_mode() {  // VERS_GEMM_WIDE: 0 = never, 1 = plain order, 2 = interleaved, 3 = interleaved + early reloads (default)
+inline int gemm_wide_mode() {  // VERS_GEMM_WIDE: 0 = never, 1 = plain order, 2 = interleaved, 3 = interleaved + early reloads (default), 4 = both operands pre-split, LDS-DMA
   static const int m = [] { const char* e = getenv("VERS_GEMM_WIDE"); return e ? atoi(e) : 3; }();
   return m;
 }
@@ -734,7 +811,8 @@ inline bool gemm_wide_ok(uint32_t k_pad, uint32_t nb_pad, bool have_split) {
   return gemm_wide_mode() != 0 && have_split && k_pad % kGemmWide == 0 && nb_pad % kGemmWide == 0;
 }
 inline hipError_t launch_gemm_wide(uint32_t k_pad, uint32_t nb_pad, hipStream_t st, const float* X, const __bf16* ch, const __bf16* cl, const float* cnorm,
-                                   uint32_t K, uint32_t N_pad, uint32_t metric, uint32_t k_rows, float* part_v1, uint32_t* part_c1, float* part_v2) {
+                                   uint32_t K, uint32_t N_pad, uint32_t metric, uint32_t k_rows, float* part_v1, uint32_t* part_c1, float* part_v2,
+                                   const __bf16* xh = nullptr, const __bf16* xl = nullptr) {  // xh / xl: the point batch pre-split (mode 4: LDS-DMA)
   static const hipError_t attr0 = hipFuncSetAttribute((const void*)dist_gemm_x3w_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kX3WLdsBytes);
   static const hipError_t attr1 = hipFuncSetAttribute((const void*)dist_gemm_x3w_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kX3WLdsBytes);
   if (attr0 != hipSuccess) return attr0;
@@ -745,6 +823,13 @@ inline hipError_t launch_gemm_wide(uint32_t k_pad, uint32_t nb_pad, hipStream_t 
   for (uint32_t g : {2u, 1u}) if (m_tiles % (8u * g) == 0) { grp = g; break; }
   static const hipError_t attr2 = hipFuncSetAttribute((const void*)dist_gemm_x3w_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kX3WLdsBytes);
   if (attr2 != hipSuccess) return attr2;
+  if (xh != nullptr && xl != nullptr) {
+    static const hipError_t attr3 = hipFuncSetAttribute((const void*)dist_gemm_x3w_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kX3WLdsBytes);
+    if (attr3 != hipSuccess) return attr3;
+    hipLaunchKernelGGL(dist_gemm_x3w_kernel<3>, dim3(m_tiles * n_tiles), dim3(512), kX3WLdsBytes, st, X, ch, cl, cnorm, K, N_pad, (int)metric, m_tiles,
+                       n_tiles, grp, k_rows, part_v1, part_c1, part_v2, xh, xl);
+    return hipGetLastError();
+  }
   if (gemm_wide_mode() == 3)
     hipLaunchKernelGGL(dist_gemm_x3w_kernel<2>, dim3(m_tiles * n_tiles), dim3(512), kX3WLdsBytes, st, X, ch, cl, cnorm, K, N_pad, (int)metric, m_tiles,
                        n_tiles, grp, k_rows, part_v1, part_c1, part_v2);
