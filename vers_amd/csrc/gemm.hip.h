@@ -515,7 +515,7 @@ static __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2
   // last tile and the store goes to a buffer nobody reads any more (no branches around loads: the compiler's counted waits)
   const uint32_t k_tiles = K / kGemmBK, k_last = K - kGemmBK;
   auto kclamp = [&](uint32_t t) { const uint32_t k0 = t * kGemmBK; return k0 < k_last ? k0 : k_last; };
-  if constexpr (SCHED != 3) {
+  if constexpr (SCHED != 3 && SCHED != 4) {
     gload(0);
     lstore(0);
     gload(kclamp(1));
@@ -589,6 +589,69 @@ static __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2
         __builtin_amdgcn_sched_barrier(0);
       }
       __syncthreads();  // (waits for the DMA too: vmcnt(0))
+    }
+  } else if constexpr (SCHED == 4) {
+    // SCHED = 2 with the POINTS pre-split into bf16 hi | lo in global memory too (split_bf16_kernel over the batch): no
+    // conversions in the loop, the points' pieces stored 16 bytes at a time like the centroids' (8 LDS store instructions per
+    // thread and K-tile instead of 12).  The ablation of SCHED = 2 priced the conversions at 16 % of the kernel.
+    auto gload_m = [&](f32x4 (&rr)[4], const __bf16* hi, const __bf16* lo, uint32_t row0, uint32_t k0) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int idx = tid + 512 * i;
+        const uint64_t at = (uint64_t)(row0 + (idx >> 2)) * K + k0 + (idx & 3) * 8;
+        rr[i] = *reinterpret_cast<const f32x4*>(hi + at);
+        rr[2 + i] = *reinterpret_cast<const f32x4*>(lo + at);
+      }
+    };
+    auto lstore_m = [&](int buf, int mat, const f32x4 (&rr)[4]) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i) {
+        const int idx = tid + 512 * i, row = idx >> 2, at = row * kX3Pitch + x3_chunk(row, idx & 3);
+        *reinterpret_cast<f32x4*>(Tp(buf, mat, 0) + at) = rr[i];
+        *reinterpret_cast<f32x4*>(Tp(buf, mat, 1) + at) = rr[2 + i];
+      }
+    };
+    gload_m(ra, Ch, Cl, m0, 0);
+    gload_m(rb, Xh, Xl, n0, 0);
+    lstore_m(0, 0, ra);
+    lstore_m(0, 1, rb);
+    gload_m(ra, Ch, Cl, m0, kclamp(1));
+    gload_m(rb, Xh, Xl, n0, kclamp(1));
+    __syncthreads();
+    bf16x8 ah[2], al[2], bh[4], bl[4];
+    for (uint32_t t = 0; t < k_tiles; ++t) {
+      const int buf = (int)(t & 1), nbuf = buf ^ 1;
+      const uint32_t k2 = kclamp(t + 2);
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2) {
+        const int ko = x3_chunk(r, 2 * s2 + hh);
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) {
+          ah[tt] = *reinterpret_cast<const bf16x8*>(Tp(buf, 0, 0) + (wr * 64 + tt * 32 + r) * kX3Pitch + ko);
+          al[tt] = *reinterpret_cast<const bf16x8*>(Tp(buf, 0, 1) + (wr * 64 + tt * 32 + r) * kX3Pitch + ko);
+        }
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) {
+          bh[tt] = *reinterpret_cast<const bf16x8*>(Tp(buf, 1, 0) + (wc * 128 + tt * 32 + r) * kX3Pitch + ko);
+          bl[tt] = *reinterpret_cast<const bf16x8*>(Tp(buf, 1, 1) + (wc * 128 + tt * 32 + r) * kX3Pitch + ko);
+        }
+        // tile t + 1's pieces of ONE operand per k-step -> the other buffer (its readers left at the last barrier); their registers
+        // take tile t + 2 at once
+        if (s2 == 0) { lstore_m(nbuf, 0, ra); gload_m(ra, Ch, Cl, m0, k2); }
+        else { lstore_m(nbuf, 1, rb); gload_m(rb, Xh, Xl, n0, k2); }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int a = 0; a < 2; ++a) {
+#pragma unroll
+          for (int b = 0; b < 4; ++b) {
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a], bh[b], acc[a][b], 0, 0, 0);  // small terms first
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bl[b], acc[a][b], 0, 0, 0);
+            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bh[b], acc[a][b], 0, 0, 0);
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      __syncthreads();
     }
   } else if constexpr (SCHED == 2) {
     // SCHED = 1 with the global loads of tile t + 2 issued as soon as tile t + 1's registers are consumed instead of at the end of
@@ -803,7 +866,7 @@ static __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2
   }
 }
 // assign pass through the wide kernel when the shapes allow it (VERS_GEMM_WIDE=0: never)
-inline int gemm_wide_mode() {  // VERS_GEMM_WIDE: 0 = never, 1 = plain order, 2 = interleaved, 3 = interleaved + early reloads (default), 4 = both operands pre-split, LDS-DMA
+inline int gemm_wide_mode() {  // VERS_GEMM_WIDE: 0 = never, 1 = plain order, 2 = interleaved, 3 = interleaved + early reloads (default), 4 = both operands pre-split, LDS-DMA, 5 = both pre-split, through registers
   static const int m = [] { const char* e = getenv("VERS_GEMM_WIDE"); return e ? atoi(e) : 3; }();
   return m;
 }
@@ -823,6 +886,13 @@ inline hipError_t launch_gemm_wide(uint32_t k_pad, uint32_t nb_pad, hipStream_t 
   for (uint32_t g : {2u, 1u}) if (m_tiles % (8u * g) == 0) { grp = g; break; }
   static const hipError_t attr2 = hipFuncSetAttribute((const void*)dist_gemm_x3w_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kX3WLdsBytes);
   if (attr2 != hipSuccess) return attr2;
+  if (xh != nullptr && xl != nullptr && gemm_wide_mode() == 5) {
+    static const hipError_t attr4 = hipFuncSetAttribute((const void*)dist_gemm_x3w_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kX3WLdsBytes);
+    if (attr4 != hipSuccess) return attr4;
+    hipLaunchKernelGGL(dist_gemm_x3w_kernel<4>, dim3(m_tiles * n_tiles), dim3(512), kX3WLdsBytes, st, X, ch, cl, cnorm, K, N_pad, (int)metric, m_tiles,
+                       n_tiles, grp, k_rows, part_v1, part_c1, part_v2, xh, xl);
+    return hipGetLastError();
+  }
   if (xh != nullptr && xl != nullptr) {
     static const hipError_t attr3 = hipFuncSetAttribute((const void*)dist_gemm_x3w_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kX3WLdsBytes);
     if (attr3 != hipSuccess) return attr3;
