@@ -76,6 +76,9 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[2][2], float* lds, c
   float* As = lds;
   // epilogue: C/D layout col = lane & 31, row = (reg & 3) + 8 * (reg >> 2) + 4 * (lane >> 5)
   if constexpr (!NORM_ROWS) {
+    // (64 `global_store_dword` of two 128-byte pieces each.  The same values through LDS and out as 16 `global_store_dwordx4` of
+    // whole 256-byte row segments were tried in round 4: 27.4 vs 27.6 us -- the 7 us this epilogue costs are the 16 MB of G on
+    // their way to memory, not the store instructions.)
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -389,25 +392,31 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2
   // waits and a copy of the 64 accumulator registers per step).
   const uint32_t k_tiles = K / kGemmBK, k_last = K - kGemmBK;
   auto kclamp = [&](uint32_t t) { const uint32_t k0 = t * kGemmBK; return k0 < k_last ? k0 : k_last; };
+#ifndef VERS_X3_ABLATE
+#define VERS_X3_ABLATE 0  // timing experiments (results are WRONG with any bit set): 1 no LDS stores in the loop, 2 no global loads in the
+#endif                    // loop, 4 no epilogue, 8 half the K-tiles
+  constexpr int kAbl = VERS_X3_ABLATE;
   gload(S0{}, 0);
   gload(S1{}, kclamp(1));
   lstore(S0{}, 0);
   gload(S0{}, kclamp(2));
   __syncthreads();
-  for (uint32_t t = 0; t < k_tiles; t += 2) {
+  for (uint32_t t = 0; t < ((kAbl & 8) ? k_tiles / 2 : k_tiles); t += 2) {
     // even tile t: LDS buffer 0; registers: slot 1 = tile t+1, slot 0 = tile t+2
-    lstore(S1{}, 1);             // tile t+1 -> buffer 1 (its readers finished before the last barrier)
-    gload(S1{}, kclamp(t + 3));
+    if (!(kAbl & 1)) lstore(S1{}, 1);             // tile t+1 -> buffer 1 (its readers finished before the last barrier)
+    if (!(kAbl & 2)) gload(S1{}, kclamp(t + 3));
     compute(0);
     __syncthreads();
     // odd tile t+1: LDS buffer 1; registers: slot 0 = tile t+2, slot 1 = tile t+3
-    lstore(S0{}, 0);
-    gload(S0{}, kclamp(t + 4));
+    if (!(kAbl & 1)) lstore(S0{}, 0);
+    if (!(kAbl & 2)) gload(S0{}, kclamp(t + 4));
     compute(1);
     __syncthreads();
   }
   __syncthreads();  // (the epilogue re-uses the operand storage)
-  gemm_epilogue<NORM_ROWS>(acc, reinterpret_cast<float*>(T), cnorm, N_pad, G, metric, k_rows, part_v1, part_c1, part_v2, m0, n0, wr, wc, r, hh);
+  if (!(kAbl & 4) || NORM_ROWS)
+    gemm_epilogue<NORM_ROWS>(acc, reinterpret_cast<float*>(T), cnorm, N_pad, G, metric, k_rows, part_v1, part_c1, part_v2, m0, n0, wr, wc, r, hh);
+  else if (acc[0][0][0] == 12345.678f) G[0] = acc[1][1][3];  // (keeps the accumulators alive)
 }
 
 // ---- the assign contraction on 256 x 256 block tiles ---------------------------------------------------------------------
