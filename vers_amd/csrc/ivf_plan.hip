@@ -42,7 +42,14 @@ __global__ __launch_bounds__(256) void plan_queries_kernel(PlanQ a, const uint64
 // All tables are in SLOT order (lists by descending length, see vers_ivf::list_slot).  Work order of the scan = hot
 // lists first (nearest list of some query: their thresholds must be tight before the bulk is scanned), then the others
 // in slot order, i.e. LONGEST FIRST.
-constexpr uint32_t kGroupThreads = 1024, kGroupMaxBlocks = 64;
+#ifndef VERS_GROUP_THREADS
+#define VERS_GROUP_THREADS 1024
+#endif
+// (256-thread blocks -- one wave per SIMD at 112 registers: a block then fits on a CU beside a block of another batch's coarse
+// contraction instead of waiting for whole CUs -- were tried in round 4, -DVERS_GROUP_THREADS=256: 0.399-0.400 vs 0.387-0.393 ms per
+// step at 8 ranks with three batches in flight, 0.474-0.504 vs 0.462-0.469 one at a time: the kernel itself is slower, off)
+constexpr uint32_t kGroupThreads = VERS_GROUP_THREADS, kGroupMaxBlocks = 64;
+constexpr int kGroupWaves = (int)(kGroupThreads / kWave);
 struct GroupArgs {
   uint32_t b, P, k_lists, QG, seg_rows, seg_target;
   const uint32_t* slot_len;   // list lengths in slot order
@@ -69,7 +76,7 @@ __device__ __forceinline__ bool owns_list(uint32_t L) { return ((L >> 2) % gridD
 // thread totals by shuffles, 16 wave totals go through LDS, a running carry links the rounds.  One round and two block
 // barriers at 4096 lists.
 __device__ __forceinline__ uint32_t group_lists(const GroupArgs& a, uint32_t* tab) {
-  __shared__ uint32_t wp[16], wg[16], wi[16], wh[16];
+  __shared__ uint32_t wp[kGroupWaves], wg[kGroupWaves], wi[kGroupWaves], wh[kGroupWaves];
   __shared__ unsigned long long ur, sr;
   const uint32_t* cnt = a.cnt; const uint32_t* list_len = a.slot_len; const uint32_t* hot = a.hot;
   const uint32_t k_lists = a.k_lists, QG = a.QG;
@@ -116,7 +123,7 @@ __device__ __forceinline__ uint32_t group_lists(const GroupArgs& a, uint32_t* ta
     __syncthreads();
     uint32_t bp = 0, bg = 0, bi2 = 0, bh = 0, rp = 0, rg = 0, ri = 0, rh = 0;
 #pragma unroll
-    for (int w = 0; w < 16; ++w) {
+    for (int w = 0; w < kGroupWaves; ++w) {
       if (w < wid) { bp += wp[w]; bg += wg[w]; bi2 += wi[w]; bh += wh[w]; }
       rp += wp[w]; rg += wg[w]; ri += wi[w]; rh += wh[w];
     }
@@ -824,7 +831,7 @@ int32_t plan_search(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint32_t b
     ga.stamps = W->stamps.as<unsigned long long>();
   }
   // blocks: enough that a block's share of the pairs and lists is small next to the (redundant) prefix sums
-  const uint32_t g_blocks = (uint32_t)std::min<uint64_t>(kGroupMaxBlocks, std::max<uint64_t>(1, (n_pj + 2047) / 2048 + k_l / 256));
+  const uint32_t g_blocks = (uint32_t)std::min<uint64_t>(kGroupMaxBlocks, std::max<uint64_t>(1, (n_pj + 2 * kGroupThreads - 1) / (2 * kGroupThreads) + k_l / (kGroupThreads / 4)));
   const size_t g_lds = k_l <= kGroupTabMax ? 3 * (size_t)k_l * sizeof(uint32_t) : 0;
   if (int32_t rc = scan_prepare_launch(group_scatter_kernel, g_lds)) return rc;
   hipLaunchKernelGGL(group_scatter_kernel, dim3(g_blocks), dim3(kGroupThreads), g_lds, st, ga);
