@@ -58,6 +58,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-recall", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the untimed extra measurements (single query, coarse GEMM, flat cfg2, Dist-U recall)")
+    ap.add_argument("--no-nominal", action="store_true", help="skip extra.cfg4_rank / extra.cfg5_rank (one rank's nominal share of the two 8-GPU configs on this GPU; ~1.5 min)")
     ap.add_argument("--f32-rows", action="store_true", help="no fp16 shadow: the f32 rows feed the batched list scan (round 1's configuration; same as VERS_SHADOW=0)")
     ap.add_argument("--streams", type=int, default=3, help="batches in flight: step i is queued on stream i %% S with its own outputs and workspace, so "
                     "the small latency-bound kernels of one batch (coarse quantiser, planning, exact finish) run under the list scan of "
@@ -963,6 +964,24 @@ def main():
         log(f"[bench] k-means on the host: assign {n_as} points x {nlist} centroids in {t_as:.1f} s on {cores} threads = {pass_flop / t_as / 1e9:.0f} GFLOP/s "
             f"(GPU == CPU: {cpu_km['assign_to_clusters']['gpu_matches_cpu']}); update {t_up:.2f} s, cost {t_co:.2f} s for {n_uc} points on 1 core")
         del Xkh
+
+    # ---- cfg4 / cfg5 at ONE RANK'S NOMINAL SIZE on this GPU (scripts/rank_nominal.py; no 8-GPU node has been available in any round):
+    # rank 0 of 8 of IVFFlat N=100M (the corpus streamed through vers_kmeans_assign_dev and vers_ivf_upload_begin / _chunk_dev / _end,
+    # 12.5M rows kept; the rank's step, its scan's roofline fraction, memory, GPU == CPU bitwise over the rank's sub-index) and one
+    # rank's 6.25M x 768 rows of the k = 65536 k-means through vers_ivf_build_sharded_dev.  After everything else: the headline's index is gone.
+    if rank == 0 and not multi and not args.no_extra and not args.no_nominal and d == 768:
+        index.close()
+        torch.cuda.empty_cache()
+        from scripts import rank_nominal as rn
+        for name, fn in (("cfg4_rank", lambda: rn.cfg4_rank(dev_index, log=log, check=0 if args.no_cpu else 32)), ("cfg5_rank", lambda: rn.cfg5_rank(dev_index, log=log))):
+            t0 = time.perf_counter()
+            try:
+                extra[name] = fn()
+                extra[name]["leg_seconds"] = round(time.perf_counter() - t0, 1)
+            except Exception as e:  # (a leg that fails must not take the headline with it: it is reported as failed)
+                extra[name] = {"failed": f"{type(e).__name__}: {e}"}
+                log(f"[bench] {name} FAILED: {e}")
+            torch.cuda.empty_cache()
 
     if rank == 0:
         out = {"metric": "queries/sec + recall@10, IVFFlat N=10M d=768", "value": round(qps, 1), "unit": "queries/sec",

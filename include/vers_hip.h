@@ -95,6 +95,12 @@ int32_t vers_flat_last_scan_ms(vers_flat_t* h, float* out_ms);
 int32_t vers_kmeans_assign(int32_t device, const float* rows, uint64_t n, uint64_t row_stride_bytes,
                            const float* centroids, uint64_t k, uint64_t c_stride_bytes, uint32_t d,
                            uint64_t* out_assign, float* out_min_dist);
+/* The same on DEVICE-resident arrays (row-major, pitches in floats, multiples of 4, >= d; padding columns may hold
+ * anything): out_assign_dev [n] u64 (the reference's usize), out_min_dist_dev [n] f32 or NULL.  Synchronous.  What a host
+ * that streams a corpus larger than one GPU through a trained quantiser calls per chunk (cfg4: 100M rows in chunks). */
+int32_t vers_kmeans_assign_dev(int32_t device, const float* rows_dev, uint64_t n, uint64_t ld_floats,
+                               const float* centroids_dev, uint64_t k, uint64_t c_ld_floats, uint32_t d,
+                               uint64_t* out_assign_dev, float* out_min_dist_dev);
 /* Diagnostics of the matrix-core assign path (large builds; VERS_ASSIGN=1 forces the exact scan, =2 the
  * matrix cores): process-wide number of points assigned through it and how many of those failed the
  * certificate and were re-done by the exact scan.  Results are bit-identical either way. */
@@ -175,6 +181,28 @@ int32_t vers_ivf_upload(vers_ivf_t* h, const float* rows, uint64_t n, uint64_t r
 int32_t vers_ivf_upload_dev(vers_ivf_t* h, const float* rows_dev, uint64_t n, uint64_t ld_floats,
                             const float* centroids_dev, uint64_t k, uint64_t c_ld_floats,
                             const uint64_t* assignments_dev);
+/* STREAMED rebuild of the device cache: the reference's save -> load -> search sequence (utils.rs:140-148, base.rs:45-58)
+ * for an index that no single GPU can hold.  The five fields (ivfflat.rs:8-15) arrive in chunks; a handle sharded with
+ * vers_ivf_set_shard keeps only the rows of the lists it owns, with their GLOBAL vec ids, and no buffer of n_total rows
+ * exists anywhere (device memory = the owned lists + one bounded staging chunk).  vers_ivf_upload is this sequence.
+ *   begin : centroids [k] (pitch c_stride_bytes), list_lengths [k] = ids[c].len() of every list (ALL lists, also the ones
+ *           another rank owns: the search plans with global lengths), n_total = assignments.len().  The handle holds no
+ *           index until _end succeeds (searches in between see an empty index).
+ *   chunk : rows of vec ids first_vec_id .. first_vec_id + n - 1 and their assignments.  Chunks arrive in ascending,
+ *           contiguous order (first_vec_id == rows seen so far; checked): a list then fills in ascending vec id, which is
+ *           what build_index + add produce (ivfflat.rs:123-127, 209-211).  Any chunk size; host rows are staged through a
+ *           bounded pinned buffer, and only the rows this rank owns cross PCIe.
+ *   end   : checks that n_total rows arrived and that every list received exactly list_lengths[c] of them
+ *           (VERS_ERR_INVALID otherwise, the handle stays empty), then derives |x|^2, the shadow and the row-major copy.
+ * Any other build / upload / add on the handle abandons a streamed upload in progress. */
+int32_t vers_ivf_upload_begin(vers_ivf_t* h, const float* centroids, uint64_t k, uint64_t c_stride_bytes,
+                              const uint64_t* list_lengths, uint64_t n_total);
+int32_t vers_ivf_upload_chunk(vers_ivf_t* h, const float* rows, uint64_t row_stride_bytes, const uint64_t* assignments,
+                              uint64_t first_vec_id, uint64_t n);
+/* rows_dev row-major with pitch ld_floats >= d (a multiple of 4; padding columns may hold anything), assignments_dev u64. */
+int32_t vers_ivf_upload_chunk_dev(vers_ivf_t* h, const float* rows_dev, uint64_t ld_floats, const uint64_t* assignments_dev,
+                                  uint64_t first_vec_id, uint64_t n);
+int32_t vers_ivf_upload_end(vers_ivf_t* h);
 /* Index::add (ivfflat.rs:200-213): nearest centroid by first minimum; the new vector gets
  * vec_id = assignments.len() (the reference ignores the caller's vec_id, :209) and is appended
  * to that list.  Returns both so the host can mirror values/assignments/ids. */

@@ -51,6 +51,10 @@ SIGNATURES = {
                                        C.POINTER(C.c_float), C.POINTER(C.c_int32), _vp]),
     "vers_ivf_upload": (C.c_int32, [_vp, _vp, C.c_uint64, C.c_uint64, _vp, C.c_uint64, C.c_uint64, _vp]),
     "vers_ivf_upload_dev": (C.c_int32, [_vp, _vp, C.c_uint64, C.c_uint64, _vp, C.c_uint64, C.c_uint64, _vp]),
+    "vers_ivf_upload_begin": (C.c_int32, [_vp, _vp, C.c_uint64, C.c_uint64, _vp, C.c_uint64]),
+    "vers_ivf_upload_chunk": (C.c_int32, [_vp, _vp, C.c_uint64, _vp, C.c_uint64, C.c_uint64]),
+    "vers_ivf_upload_chunk_dev": (C.c_int32, [_vp, _vp, C.c_uint64, _vp, C.c_uint64, C.c_uint64]),
+    "vers_ivf_upload_end": (C.c_int32, [_vp]),
     "vers_ivf_add": (C.c_int32, [_vp, _vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "vers_ivf_search": (C.c_int32, [_vp, _vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, _vp, _vp, _vp]),
     "vers_ivf_search_dev": (C.c_int32, [_vp, _vp, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32, _vp, _vp, _vp, _vp]),
@@ -87,6 +91,7 @@ SIGNATURES = {
     "vers_gen_rows_dev": (C.c_int32, [_vp, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64, C.c_uint32,
                                       C.c_float, C.c_uint64, _vp]),
     "vers_kmeans_assign": (C.c_int32, [C.c_int32, _vp, C.c_uint64, C.c_uint64, _vp, C.c_uint64, C.c_uint64, C.c_uint32, _vp, _vp]),
+    "vers_kmeans_assign_dev": (C.c_int32, [C.c_int32, _vp, C.c_uint64, C.c_uint64, _vp, C.c_uint64, C.c_uint64, C.c_uint32, _vp, _vp]),
     "vers_assign_stats": (C.c_int32, [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_int32]),
     "vers_build_stats": (C.c_int32, [C.POINTER(C.c_double), C.c_int32]),
     "vers_build_phases": (C.c_int32, [C.POINTER(C.c_double), C.c_int32]),
@@ -214,6 +219,13 @@ def kmeans_assign(X, Cn, device: int = 0, want_min_dist: bool = False):
     check(lib().vers_kmeans_assign(device, _ptr(X), X.shape[0], sx, _ptr(Cn), Cn.shape[0], sc, X.shape[1], _ptr(out),
                                    _ptr(md) if want_min_dist else None))
     return (out, md) if want_min_dist else out
+
+
+def kmeans_assign_dev(rows_ptr: int, n: int, ld: int, centroids_ptr: int, k: int, c_ld: int, d: int, out_assign_ptr: int,
+                      out_min_dist_ptr: int = 0, device: int = 0):
+    """assign_to_clusters (ivfflat.rs:29-46) on device-resident rows / centroids; out_assign u64 [n] on the device."""
+    check(lib().vers_kmeans_assign_dev(device, _vp(rows_ptr), n, ld, _vp(centroids_ptr), k, c_ld, d, _vp(out_assign_ptr),
+                                       _vp(out_min_dist_ptr) if out_min_dist_ptr else None))
 
 
 def kmeans_update(X, assign, k: int, device: int = 0):

@@ -123,6 +123,85 @@ __global__ void u32_to_u64_kernel(const uint32_t* in, uint64_t n, uint64_t* out)
   if (i < n) out[i] = in[i];
 }
 
+
+// ---- streamed upload (vers_ivf_upload_begin / _chunk / _end): chunk placement -------------------------------------------
+// One BLOCK per 64 consecutive positions of a chunk's cluster-sorted order: the source rows are read as they lie (3 KB
+// contiguous each), turned through LDS 64 float4 columns at a time (as gather_tiles_kernel), and written into the
+// lane-transposed tiles of their lists -- consecutive sorted positions of one list are consecutive storage rows, so the 64
+// rows' float4s of a column are runs of contiguous 16-byte pieces.  Row p of the sorted order (source row id = sorted_ids[p],
+// list c) goes to position fill[c] + (p - starts[c]) of list c: the chunks arrive in ascending vec id, so a list fills in
+// the reference's order (ivfflat.rs:123-127).  Rows of lists another rank owns are skipped; a row past its list's announced
+// length is skipped too (advance_fill_kernel reports it).  vec id = ids32[id] (host path: only the owned rows were sent) or
+// first + id.
+__global__ __launch_bounds__(256) void place_chunk_kernel(const float* X, uint32_t ldx, uint32_t d, uint32_t ld, const uint32_t* sorted_ids,
+                                                          const uint32_t* assign, const uint32_t* starts, const uint32_t* list_off,
+                                                          const uint32_t* list_len, const uint32_t* fill, const uint8_t* owner, uint32_t rank,
+                                                          const uint32_t* ids32, uint32_t first, uint32_t n, float* rows, uint32_t* row_ids) {
+  extern __shared__ __attribute__((aligned(16))) f32x4 tl[];  // [64][kGatherCols4 + 1]
+  __shared__ uint32_t s_src[kWave], s_dst[kWave];
+  __shared__ uint32_t s_any;
+  if (threadIdx.x == 0) s_any = 0u;
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const uint32_t p = blockIdx.x * 64u + threadIdx.x;
+    uint32_t src = 0xFFFFFFFFu, dst = 0u;
+    if (p < n) {
+      const uint32_t id = sorted_ids[p], c = assign[id];
+      if (owner == nullptr || owner[c] == rank) {
+        const uint32_t pos = fill[c] + (p - starts[c]);
+        if (pos < list_len[c]) {
+          src = id;
+          dst = list_off[c] + pos;
+          row_ids[dst] = ids32 ? ids32[id] : first + id;
+          s_any = 1u;
+        }
+      }
+    }
+    s_src[threadIdx.x] = src;
+    s_dst[threadIdx.x] = dst;
+  }
+  __syncthreads();
+  if (!s_any) return;
+  const uint32_t ld4 = ld / 4, ldx4 = ldx / 4;
+  constexpr uint32_t kPitch = kGatherCols4 + 1;
+  for (uint32_t c0 = 0; c0 < ld4; c0 += kGatherCols4) {
+    const uint32_t nc = ld4 - c0 < kGatherCols4 ? ld4 - c0 : kGatherCols4;
+    for (uint32_t i = threadIdx.x; i < 64u * kGatherCols4; i += 256u) {  // a row's float4s by consecutive threads
+      const uint32_t r = i / kGatherCols4, j = i % kGatherCols4, c4 = c0 + j;
+      f32x4 v = {0.0f, 0.0f, 0.0f, 0.0f};
+      const uint32_t id = s_src[r];
+      if (j < nc && id != 0xFFFFFFFFu && c4 < ldx4 && c4 * 4 < d) {
+        v = reinterpret_cast<const f32x4*>(X + (uint64_t)id * ldx)[c4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (c4 * 4 + u >= d) v[u] = 0.0f;  // (columns >= d of X are the caller's padding and may hold anything)
+      }
+      tl[r * kPitch + j] = v;
+    }
+    __syncthreads();
+    for (uint32_t i = threadIdx.x; i < 64u * nc; i += 256u) {  // a column's 64 rows by consecutive threads
+      const uint32_t j = i / 64u, r = i % 64u;
+      if (s_src[r] != 0xFFFFFFFFu) *reinterpret_cast<f32x4*>(rows + blocked_index((uint64_t)s_dst[r], (c0 + j) * 4, ld)) = tl[r * kPitch + j];
+    }
+    __syncthreads();
+  }
+}
+
+// after a chunk is placed: fill[c] += its rows of list c (owned lists), seen[c] += them (every list, when the chunk held
+// ALL its rows); *bad |= 2 when a list received more rows than begin announced
+__global__ void advance_fill_kernel(const uint32_t* counts, uint32_t k, const uint8_t* owner, uint32_t rank, const uint32_t* list_len, uint32_t* fill,
+                                    uint32_t* seen, uint32_t* bad) {
+  const uint32_t c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= k) return;
+  const uint32_t cnt = counts[c];
+  if (seen) seen[c] += cnt;
+  if (owner == nullptr || owner[c] == rank) {
+    const uint64_t f = (uint64_t)fill[c] + cnt;
+    if (f > list_len[c]) { *bad |= 2u; fill[c] = list_len[c]; }
+    else fill[c] = (uint32_t)f;
+  }
+}
+
 }  // namespace vers
 
 namespace vers {
@@ -832,10 +911,16 @@ int32_t run_build(vers_ivf* h, const float* X, uint32_t ldx, uint64_t n, const B
   return VERS_OK;
 }
 
+// any other way of (re)making the index abandons a streamed upload in progress (vers_ivf_upload_begin .. _end)
+static void upload_abandon(vers_ivf* h) {
+  if (h->up.open) h->up.close();
+}
+
 int32_t build_common(vers_ivf* h, const float* X, uint32_t ldx, uint64_t n, const BuildShard& sh_in, uint64_t num_clusters, uint64_t num_attempts,
                      uint64_t max_iterations, const uint64_t* init_indices, float* out_centroids, uint64_t c_stride_bytes,
                      uint64_t* out_assignments, float* out_cost, int32_t* out_kept, uint64_t* out_iterations) {
   const uint32_t k = (uint32_t)num_clusters;
+  upload_abandon(h);
   PhaseClock total_clock(&BuildStats::total_ms);
   DevBuf best_assign;
   float cost = INFINITY;
@@ -922,6 +1007,176 @@ int32_t relayout(vers_ivf* h) {
   return VERS_OK;
 }
 
+
+// ---- streamed upload: begin / chunk / end (see vers_hip.h) -----------------------------------------------------------------
+
+int32_t upload_begin_locked(vers_ivf* h, const float* centroids, uint64_t k64, uint64_t c_stride_bytes, const uint64_t* list_lengths,
+                            uint64_t n_total) {
+  const uint32_t k = (uint32_t)k64;
+  VERS_HIP_TRY(hipDeviceSynchronize());  // searches still in flight read the storage this call re-plans
+  upload_abandon(h);
+  h->k = 0;  // no index until _end
+  h->n_total = 0;
+  std::vector<uint32_t> lens(k ? k : 1, 0);
+  uint64_t sum = 0;
+  for (uint32_t c = 0; c < k; ++c) {
+    if (list_lengths[c] > 0xFFFFFFFFull) return fail(VERS_ERR_INVALID, "vers_ivf_upload_begin: a list longer than 2^32-1 rows");
+    lens[c] = (uint32_t)list_lengths[c];
+    sum += list_lengths[c];
+  }
+  if (sum != n_total) return fail(VERS_ERR_INVALID, "vers_ivf_upload_begin: the list lengths do not add up to n_total");
+  const size_t cbytes = ((size_t)k * h->ldx ? (size_t)k * h->ldx : 1) * sizeof(float);
+  if (int32_t rc = h->centroids.reserve(cbytes)) return rc;
+  if (k) {
+    VERS_HIP_TRY(hipMemset(h->centroids.p, 0, cbytes));
+    VERS_HIP_TRY(hipMemcpy2D(h->centroids.p, (size_t)h->ldx * 4, centroids, c_stride_bytes, (size_t)h->d * 4, k, hipMemcpyHostToDevice));
+  }
+  if (int32_t rc = plan_storage(h, lens.data(), k, nullptr)) return rc;
+  // slack behind the lists and tile padding are zero rows, as after build_index (gather_tiles_kernel writes whole tiles)
+  VERS_HIP_TRY(hipMemsetAsync(h->rows.p, 0, (h->cap_rows ? h->cap_rows : 1) * (size_t)h->ld * sizeof(float), nullptr));
+  auto& up = h->up;
+  if (int32_t rc = up.fill.reserve(2 * (size_t)(k ? k : 1) * sizeof(uint32_t))) return rc;
+  VERS_HIP_TRY(hipMemsetAsync(up.fill.p, 0, 2 * (size_t)(k ? k : 1) * sizeof(uint32_t), nullptr));
+  if (int32_t rc = up.bad.reserve(16)) return rc;
+  VERS_HIP_TRY(hipMemsetAsync(up.bad.p, 0, 16, nullptr));
+  if (int32_t rc = h->km.counts.reserve((2 * (size_t)k + 2) * sizeof(uint32_t))) return rc;
+  VERS_HIP_TRY(hipStreamSynchronize(nullptr));
+  up.h_seen.assign(k ? k : 1, 0u);
+  up.cap_rows = h->cap_rows;  // (utils::search_exhaustive over the stored rows sees none until _end)
+  h->cap_rows = 0;
+  up.k = k;
+  up.n_total = n_total;
+  up.seen = 0;
+  up.open = true;
+  return VERS_OK;
+}
+
+// one chunk whose rows are device-resident: a32 = assignments as u32 (range-checked by the caller's kernel: up.bad bit 0),
+// ids32 = the rows' vec ids (nullptr: first + row), count_seen = the chunk holds ALL rows of its vec id range
+static int32_t upload_place(vers_ivf* h, const float* X, uint32_t ldx, const uint32_t* a32, const uint32_t* ids32, uint32_t first, uint32_t n,
+                            bool count_seen, hipStream_t st) {
+  auto& up = h->up;
+  const uint32_t k = up.k;
+  if (n == 0 || k == 0) return VERS_OK;
+  if (int32_t rc = up.sorted.reserve((size_t)n * sizeof(uint32_t))) return rc;
+  uint32_t* counts = h->km.counts.as<uint32_t>();
+  uint32_t* starts = counts + k;
+  if (int32_t rc = km_group(a32, n, k, up.sorted.as<uint32_t>(), counts, starts, h->km, st)) return rc;
+  const uint8_t* owner = h->world > 1 ? h->owner.as<uint8_t>() : (const uint8_t*)nullptr;
+  uint32_t* fill = up.fill.as<uint32_t>();
+  const size_t lds = 64 * (size_t)(kGatherCols4 + 1) * sizeof(f32x4);
+  if (int32_t rc = scan_prepare_launch(place_chunk_kernel, lds)) return rc;
+  hipLaunchKernelGGL(place_chunk_kernel, dim3((n + 63u) / 64u), dim3(256), lds, st, X, ldx, h->d, h->ld, (const uint32_t*)up.sorted.as<uint32_t>(), a32,
+                     (const uint32_t*)starts, (const uint32_t*)h->list_off.as<uint32_t>(), (const uint32_t*)h->list_len.as<uint32_t>(),
+                     (const uint32_t*)fill, owner, h->rank, ids32, first, n, h->rows.as<float>(), h->row_ids.as<uint32_t>());
+  hipLaunchKernelGGL(advance_fill_kernel, dim3((k + 255u) / 256u), dim3(256), 0, st, (const uint32_t*)counts, k, owner, h->rank,
+                     (const uint32_t*)h->list_len.as<uint32_t>(), fill, count_seen ? fill + k : (uint32_t*)nullptr, up.bad.as<uint32_t>());
+  VERS_HIP_TRY(hipGetLastError());
+  return VERS_OK;
+}
+
+static int32_t upload_check_bad(vers_ivf* h, const char* who) {
+  uint32_t bad = 0;
+  VERS_HIP_TRY(hipMemcpy(&bad, h->up.bad.p, 4, hipMemcpyDeviceToHost));  // (synchronises the null stream: the chunk is placed)
+  if (bad) {
+    upload_abandon(h);
+    return fail(VERS_ERR_INVALID, std::string(who) + (bad & 1u ? ": assignment out of range" : ": a list received more rows than vers_ivf_upload_begin announced") +
+                                      " (the streamed upload is abandoned)");
+  }
+  return VERS_OK;
+}
+
+static int32_t upload_chunk_args(vers_ivf* h, const char* who, uint64_t first_vec_id, uint64_t n) {
+  if (!h->up.open) return fail(VERS_ERR_INVALID, std::string(who) + ": no streamed upload in progress (vers_ivf_upload_begin first)");
+  if (first_vec_id != h->up.seen) return fail(VERS_ERR_INVALID, std::string(who) + ": chunks must arrive in ascending contiguous order (first_vec_id != rows received so far)");
+  if (n > h->up.n_total - h->up.seen) return fail(VERS_ERR_INVALID, std::string(who) + ": more rows than vers_ivf_upload_begin announced");
+  return VERS_OK;
+}
+
+int32_t upload_chunk_dev_locked(vers_ivf* h, const float* rows_dev, uint64_t ld_floats, const uint64_t* assignments_dev, uint64_t first_vec_id,
+                                uint64_t n) {
+  if (int32_t rc = upload_chunk_args(h, "vers_ivf_upload_chunk_dev", first_vec_id, n)) return rc;
+  auto& up = h->up;
+  if (n) {
+    if (int32_t rc = up.a32.reserve(n * sizeof(uint32_t))) return rc;
+    hipLaunchKernelGGL(u64_to_u32_checked_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, assignments_dev, n, (uint64_t)up.k,
+                       up.a32.as<uint32_t>(), up.bad.as<uint32_t>());
+    VERS_HIP_TRY(hipGetLastError());
+    if (int32_t rc = upload_place(h, rows_dev, (uint32_t)ld_floats, up.a32.as<uint32_t>(), nullptr, (uint32_t)first_vec_id, (uint32_t)n, true, nullptr)) return rc;
+    if (int32_t rc = upload_check_bad(h, "vers_ivf_upload_chunk_dev")) return rc;
+  }
+  up.seen += n;
+  return VERS_OK;
+}
+
+// Host rows: sub-chunks through ONE bounded pinned buffer.  Only the rows of the lists this rank owns are packed and cross
+// PCIe (1/W of them on a rank of W), with their vec ids; every row is counted on the host for the final check.
+int32_t upload_chunk_host_locked(vers_ivf* h, const float* rows, uint64_t row_stride_bytes, const uint64_t* assignments, uint64_t first_vec_id,
+                                 uint64_t n) {
+  if (int32_t rc = upload_chunk_args(h, "vers_ivf_upload_chunk", first_vec_id, n)) return rc;
+  auto& up = h->up;
+  const uint32_t ldx = h->ldx, d = h->d;
+  const size_t row_b = (size_t)ldx * 4;
+  static const size_t stage_bytes = [] { const char* e = getenv("VERS_UPLOAD_STAGE_MB"); return (size_t)(e ? atol(e) : 256) << 20; }();
+  const uint64_t sub = std::max<uint64_t>(64, std::min<uint64_t>(n ? n : 1, stage_bytes / (row_b + 8)));
+  const size_t pin_need = sub * (row_b + 8);
+  if (up.pin_cap < pin_need) {
+    if (up.pin) { (void)hipHostFree(up.pin); up.pin = nullptr; up.pin_cap = 0; }
+    VERS_HIP_TRY(hipHostMalloc(&up.pin, pin_need, hipHostMallocDefault));
+    up.pin_cap = pin_need;
+  }
+  if (int32_t rc = up.stage.reserve(sub * row_b)) return rc;
+  if (int32_t rc = up.ids.reserve(sub * 4)) return rc;
+  if (int32_t rc = up.a32.reserve(sub * 4)) return rc;
+  float* p_rows = (float*)up.pin;
+  uint32_t* p_ids = (uint32_t*)((char*)up.pin + sub * row_b);
+  uint32_t* p_a = p_ids + sub;
+  const bool sharded = h->world > 1;
+  for (uint64_t s0 = 0; s0 < n; s0 += sub) {
+    const uint64_t m = std::min<uint64_t>(sub, n - s0);
+    uint32_t packed = 0;
+    for (uint64_t i = 0; i < m; ++i) {
+      const uint64_t a = assignments[s0 + i];
+      if (a >= up.k) { upload_abandon(h); return fail(VERS_ERR_INVALID, "vers_ivf_upload_chunk: assignment out of range (the streamed upload is abandoned)"); }
+      up.h_seen[a] += 1;
+      if (sharded && h->h_owner[a] != h->rank) continue;
+      float* dst = p_rows + (size_t)packed * ldx;
+      std::memcpy(dst, (const char*)rows + (s0 + i) * row_stride_bytes, (size_t)d * 4);
+      for (uint32_t j = d; j < ldx; ++j) dst[j] = 0.0f;
+      p_ids[packed] = (uint32_t)(first_vec_id + s0 + i);
+      p_a[packed] = (uint32_t)a;
+      ++packed;
+    }
+    if (packed) {
+      VERS_HIP_TRY(hipMemcpyAsync(up.stage.p, p_rows, (size_t)packed * row_b, hipMemcpyHostToDevice, nullptr));
+      VERS_HIP_TRY(hipMemcpyAsync(up.ids.p, p_ids, (size_t)packed * 4, hipMemcpyHostToDevice, nullptr));
+      VERS_HIP_TRY(hipMemcpyAsync(up.a32.p, p_a, (size_t)packed * 4, hipMemcpyHostToDevice, nullptr));
+      if (int32_t rc = upload_place(h, up.stage.as<float>(), ldx, up.a32.as<uint32_t>(), up.ids.as<uint32_t>(), 0u, packed, false, nullptr)) return rc;
+      if (int32_t rc = upload_check_bad(h, "vers_ivf_upload_chunk")) return rc;  // (also: the pinned buffer is free again)
+    }
+  }
+  up.seen += n;
+  return VERS_OK;
+}
+
+int32_t upload_end_locked(vers_ivf* h) {
+  auto& up = h->up;
+  if (!up.open) return fail(VERS_ERR_INVALID, "vers_ivf_upload_end: no streamed upload in progress");
+  const uint32_t k = up.k;
+  const uint64_t n_total = up.n_total;
+  auto bail = [&](const std::string& m) { upload_abandon(h); return fail(VERS_ERR_INVALID, "vers_ivf_upload_end: " + m + " (the handle stays empty)"); };
+  if (up.seen != n_total) return bail("fewer rows arrived than vers_ivf_upload_begin announced");
+  std::vector<uint32_t> f(2 * (size_t)(k ? k : 1), 0u);
+  VERS_HIP_TRY(hipMemcpy(f.data(), up.fill.p, f.size() * sizeof(uint32_t), hipMemcpyDeviceToHost));
+  for (uint32_t c = 0; c < k; ++c) {
+    if ((uint64_t)f[k + c] + up.h_seen[c] != h->h_len[c]) return bail("list " + std::to_string(c) + " received a different number of rows than announced");
+    if (h->h_owner[c] == h->rank && f[c] != h->h_len[c]) return bail("owned list " + std::to_string(c) + " is not complete");
+  }
+  h->cap_rows = up.cap_rows;
+  up.close();
+  return finish_index(h, k, n_total, nullptr);
+}
+
 }  // namespace ivf
 }  // namespace vers
 
@@ -992,28 +1247,52 @@ int32_t vers_ivf_upload(vers_ivf_t* h, const float* rows, uint64_t n, uint64_t r
   if (!h || (n && (!rows || !assignments)) || (k && !centroids) || row_stride_bytes < (uint64_t)(h ? h->d : 0) * 4 ||
       (k && c_stride_bytes < (uint64_t)h->d * 4) || n > 0xFFFFFFFFull || k > 0xFFFFFFFFull)
     return fail(VERS_ERR_INVALID, "vers_ivf_upload: bad arguments");
-  std::vector<uint32_t> a32(n ? n : 1);
+  // = the streamed sequence in one call: list lengths from the assignments, one chunk (staged through a bounded buffer), end
+  std::vector<uint64_t> lens(k ? k : 1, 0);
   for (uint64_t i = 0; i < n; ++i) {
     if (assignments[i] >= k) return fail(VERS_ERR_INVALID, "vers_ivf_upload: assignment out of range");
-    a32[i] = (uint32_t)assignments[i];
+    lens[assignments[i]] += 1;
   }
   std::unique_lock<std::shared_mutex> lk(h->index);
   DeviceGuard g(h->device);
-  DevBuf X, A;
-  if (int32_t rc = X.reserve((n ? n : 1) * (size_t)h->ldx * sizeof(float))) return rc;
-  if (int32_t rc = A.reserve((n ? n : 1) * 4)) return rc;
-  if (n) {
-    if (h->ldx != h->d) VERS_HIP_TRY(hipMemset(X.p, 0, n * (size_t)h->ldx * sizeof(float)));
-    VERS_HIP_TRY(hipMemcpy2D(X.p, (size_t)h->ldx * 4, rows, row_stride_bytes, (size_t)h->d * 4, n, hipMemcpyHostToDevice));
-    VERS_HIP_TRY(hipMemcpy(A.p, a32.data(), n * 4, hipMemcpyHostToDevice));
-  }
-  const size_t cbytes = ((size_t)k * h->ldx ? (size_t)k * h->ldx : 1) * sizeof(float);
-  if (int32_t rc = h->centroids.reserve(cbytes)) return rc;
-  if (k) {
-    VERS_HIP_TRY(hipMemset(h->centroids.p, 0, cbytes));
-    VERS_HIP_TRY(hipMemcpy2D(h->centroids.p, (size_t)h->ldx * 4, centroids, c_stride_bytes, (size_t)h->d * 4, k, hipMemcpyHostToDevice));
-  }
-  return install_index(h, X.as<float>(), h->ldx, n, A.as<uint32_t>(), (uint32_t)k, nullptr);
+  if (int32_t rc = upload_begin_locked(h, centroids, k, c_stride_bytes, lens.data(), n)) return rc;
+  if (int32_t rc = upload_chunk_host_locked(h, rows, row_stride_bytes, assignments, 0, n)) return rc;
+  return upload_end_locked(h);
+}
+
+int32_t vers_ivf_upload_begin(vers_ivf_t* h, const float* centroids, uint64_t k, uint64_t c_stride_bytes, const uint64_t* list_lengths,
+                              uint64_t n_total) {
+  if (!h || (k && (!centroids || !list_lengths)) || (k && c_stride_bytes < (uint64_t)h->d * 4) || n_total > 0xFFFFFFFFull || k > 0xFFFFFFFFull ||
+      (k == 0 && n_total != 0))
+    return fail(VERS_ERR_INVALID, "vers_ivf_upload_begin: bad arguments");
+  std::unique_lock<std::shared_mutex> lk(h->index);
+  DeviceGuard g(h->device);
+  return upload_begin_locked(h, centroids, k, c_stride_bytes, list_lengths, n_total);
+}
+
+int32_t vers_ivf_upload_chunk(vers_ivf_t* h, const float* rows, uint64_t row_stride_bytes, const uint64_t* assignments, uint64_t first_vec_id,
+                              uint64_t n) {
+  if (!h || (n && (!rows || !assignments)) || row_stride_bytes < (uint64_t)(h ? h->d : 0) * 4)
+    return fail(VERS_ERR_INVALID, "vers_ivf_upload_chunk: bad arguments");
+  std::unique_lock<std::shared_mutex> lk(h->index);
+  DeviceGuard g(h->device);
+  return upload_chunk_host_locked(h, rows, row_stride_bytes, assignments, first_vec_id, n);
+}
+
+int32_t vers_ivf_upload_chunk_dev(vers_ivf_t* h, const float* rows_dev, uint64_t ld_floats, const uint64_t* assignments_dev, uint64_t first_vec_id,
+                                  uint64_t n) {
+  if (!h || (n && (!rows_dev || !assignments_dev)) || ld_floats < (uint64_t)(h ? h->d : 0) || ld_floats % 4 || ld_floats > 0x3FFFFFFFull)
+    return fail(VERS_ERR_INVALID, "vers_ivf_upload_chunk_dev: bad arguments (ld_floats must be >= d and a multiple of 4)");
+  std::unique_lock<std::shared_mutex> lk(h->index);
+  DeviceGuard g(h->device);
+  return upload_chunk_dev_locked(h, rows_dev, ld_floats, assignments_dev, first_vec_id, n);
+}
+
+int32_t vers_ivf_upload_end(vers_ivf_t* h) {
+  if (!h) return fail(VERS_ERR_INVALID, "vers_ivf_upload_end: null handle");
+  std::unique_lock<std::shared_mutex> lk(h->index);
+  DeviceGuard g(h->device);
+  return upload_end_locked(h);
 }
 
 int32_t vers_ivf_upload_dev(vers_ivf_t* h, const float* rows_dev, uint64_t n, uint64_t ld_floats, const float* centroids_dev, uint64_t k,
@@ -1023,6 +1302,7 @@ int32_t vers_ivf_upload_dev(vers_ivf_t* h, const float* rows_dev, uint64_t n, ui
     return fail(VERS_ERR_INVALID, "vers_ivf_upload_dev: bad arguments (ld_floats must be >= d and a multiple of 4)");
   std::unique_lock<std::shared_mutex> lk(h->index);
   DeviceGuard g(h->device);
+  upload_abandon(h);
   DevBuf A, bad;
   if (int32_t rc = A.reserve((n ? n : 1) * 4)) return rc;
   if (int32_t rc = bad.reserve(16)) return rc;

@@ -156,6 +156,7 @@ int32_t vers_ivf_destroy(vers_ivf_t* h) {
   for (auto& w : h->pool) ws_destroy(*w);
   if (h->fail_watch) (void)hipHostFree(h->fail_watch);
   if (h->st_pin) (void)hipHostFree(h->st_pin);
+  h->up.close();
   delete h;
   return VERS_OK;
 }
@@ -183,7 +184,7 @@ int32_t vers_shard_plan(const uint64_t* list_lengths, uint64_t k, uint32_t world
 int32_t vers_ivf_set_shard(vers_ivf_t* h, uint32_t rank, uint32_t world) {
   if (!h || world == 0 || world > 255 || rank >= world) return fail(VERS_ERR_INVALID, "vers_ivf_set_shard: bad arguments");
   std::unique_lock<std::shared_mutex> lk(h->index);
-  if (h->k != 0) return fail(VERS_ERR_INVALID, "vers_ivf_set_shard: call before build / upload");
+  if (h->k != 0 || h->up.open) return fail(VERS_ERR_INVALID, "vers_ivf_set_shard: call before build / upload");
   h->rank = rank;
   h->world = world;
   return VERS_OK;

@@ -142,6 +142,25 @@ struct vers_ivf {
   uint64_t cap_rows = 0;
   uint32_t max_len = 0;
   KMeansScratch km;  // build scratch (build / upload hold the handle exclusively)
+  // A streamed upload in progress (vers_ivf_upload_begin .. _end, ivf_build.hip): the storage plan is made from the GLOBAL
+  // list lengths at begin, chunks of (rows, assignments) fill the owned lists in ascending vec id, nothing of size n_total
+  // is ever held.  h->k stays 0 until _end: searches in between see an empty index.
+  struct UploadState {
+    bool open = false;
+    uint32_t k = 0;
+    uint64_t n_total = 0, seen = 0, cap_rows = 0;
+    DevBuf fill;                   // u32 [k] rows placed in every OWNED list so far | u32 [k] rows of EVERY list counted on the device
+    std::vector<uint32_t> h_seen;  // rows of every list counted by the host path (it sends only the owned ones)
+    DevBuf a32, sorted, ids, a64, stage, bad;  // per-chunk scratch: assignments as u32, cluster-sorted order, vec ids, staging
+    void* pin = nullptr;           // pinned staging of the host path (rows | vec ids | assignments of one sub-chunk)
+    size_t pin_cap = 0;
+    void close() {
+      open = false;
+      fill.release(); a32.release(); sorted.release(); ids.release(); a64.release(); stage.release(); bad.release();
+      h_seen.clear(); h_seen.shrink_to_fit();
+      if (pin) { (void)hipHostFree(pin); pin = nullptr; pin_cap = 0; }
+    }
+  } up;
   // matrix-core list scan (prescan.hip.h): |x|^2 per storage row, [0] max |x|^2 bits, [1] certificate failures (running)
   DevBuf xnorm, pre_misc;
   // fp16 shadow of the rows for the matrix-core pre-selection (+50 % corpus memory; VERS_SHADOW=0 or a failed

@@ -599,6 +599,45 @@ int32_t vers_kmeans_assign(int32_t device, const float* rows, uint64_t n, uint64
   return VERS_OK;
 }
 
+// assign_to_clusters (ivfflat.rs:29-46) on device-resident rows and centroids: what a host that streams a corpus larger than
+// one GPU through a trained quantiser calls per chunk.  The scratch of the matrix-core path is kept per thread between calls
+// (a streamed corpus is hundreds of calls of one shape).
+static __global__ void widen_assign_kernel(const uint32_t* in, uint64_t n, uint64_t* out) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = in[i];
+}
+int32_t vers_kmeans_assign_dev(int32_t device, const float* rows_dev, uint64_t n, uint64_t ld_floats, const float* centroids_dev, uint64_t k,
+                               uint64_t c_ld_floats, uint32_t d, uint64_t* out_assign_dev, float* out_min_dist_dev) {
+  if (d == 0 || (n && (!rows_dev || !out_assign_dev)) || (k && !centroids_dev) || ld_floats < d || ld_floats % 4 || ld_floats > 0x3FFFFFFFull ||
+      (k && c_ld_floats < d) || n > 0xFFFFFFFFull || k > 0xFFFFFFFFull)
+    return fail(VERS_ERR_INVALID, "vers_kmeans_assign_dev: bad arguments (ld_floats must be >= d and a multiple of 4)");
+  if (n == 0) return VERS_OK;
+  if (k == 0) return fail(VERS_ERR_EMPTY, "min_by over zero centroids (reference: unwrap on None)");
+  int n_cu = 0;
+  if (int32_t rc = device_cus(device, &n_cu)) return rc;
+  DeviceGuard g(device);
+  const uint32_t ld = round_up(d, 4);
+  struct Scratch { KMeansScratch ws; DevBuf C, A, M; int device = -1; };
+  static thread_local Scratch* s = nullptr;  // (never freed before the thread ends: DevBuf's destructor must not run after the runtime is gone)
+  if (s == nullptr || s->device != device) { delete s; s = new Scratch(); s->device = device; }
+  const size_t cbytes = (size_t)k * ld * sizeof(float);
+  if (int32_t rc = s->C.reserve(cbytes)) return rc;
+  if (int32_t rc = s->A.reserve(n * sizeof(uint32_t))) return rc;
+  if (int32_t rc = s->M.reserve(n * sizeof(float))) return rc;
+  if (int32_t rc = s->ws.status.reserve(16)) return rc;
+  VERS_HIP_TRY(hipMemset(s->ws.status.p, 0, 16));
+  if (ld != d) VERS_HIP_TRY(hipMemset(s->C.p, 0, cbytes));  // (the kernels read the centroids' padding columns: zeros)
+  VERS_HIP_TRY(hipMemcpy2D(s->C.p, (size_t)ld * 4, centroids_dev, (size_t)c_ld_floats * 4, (size_t)d * 4, k, hipMemcpyDeviceToDevice));
+  if (int32_t rc = (km_use_mfma(n, (uint32_t)k, d) ? km_assign_mfma : km_assign)(rows_dev, (uint32_t)ld_floats, n, s->C.as<float>(), ld, (uint32_t)k, d,
+                                                                                 s->A.as<uint32_t>(), s->M.as<float>(), s->ws, n_cu, nullptr, 0))
+    return rc;
+  hipLaunchKernelGGL(widen_assign_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, nullptr, s->A.as<uint32_t>(), n, out_assign_dev);
+  VERS_HIP_TRY(hipGetLastError());
+  if (out_min_dist_dev) VERS_HIP_TRY(hipMemcpyAsync(out_min_dist_dev, s->M.p, n * sizeof(float), hipMemcpyDeviceToDevice, nullptr));
+  VERS_HIP_TRY(hipDeviceSynchronize());
+  return check_status_word(s->ws.status, (uint32_t)k);
+}
+
 int32_t vers_build_stats(double* out, int32_t reset) {
   km_timers_collect();
   std::lock_guard<std::mutex> lk(g_bs_mu);

@@ -225,6 +225,28 @@ class IVFFlatIndex:
         check(lib().vers_ivf_upload_dev(self._h, _vp(rows_ptr), n, ld, _vp(centroids_ptr), k, c_ld, _vp(assignments_ptr)))
         self.num_centroids = k
 
+    # Streamed rebuild of the device cache (vers_ivf_upload_begin / _chunk / _end): the reference's load_index -> search
+    # sequence (base.rs:45-58, utils.rs:140-148) for an index no single GPU holds -- fields arrive in chunks, a sharded
+    # handle keeps only its own lists, nothing of n_total rows is ever allocated.
+    def upload_begin(self, centroids, list_lengths, n_total: int):
+        c = np.ascontiguousarray(centroids, dtype=np.float32).reshape(-1, self.d)
+        ll = np.ascontiguousarray(list_lengths, dtype=np.uint64)
+        assert ll.shape[0] == c.shape[0]
+        check(lib().vers_ivf_upload_begin(self._h, _ptr(c), c.shape[0], 4 * self.d, _ptr(ll), n_total))
+        self.num_centroids = c.shape[0]
+
+    def upload_chunk(self, rows, assignments, first_vec_id: int):
+        v = np.ascontiguousarray(rows, dtype=np.float32).reshape(-1, self.d)
+        a = np.ascontiguousarray(assignments, dtype=np.uint64)
+        assert a.shape[0] == v.shape[0]
+        check(lib().vers_ivf_upload_chunk(self._h, _ptr(v), 4 * self.d, _ptr(a), first_vec_id, v.shape[0]))
+
+    def upload_chunk_dev(self, rows_ptr: int, ld: int, assignments_ptr: int, first_vec_id: int, n: int):
+        check(lib().vers_ivf_upload_chunk_dev(self._h, _vp(rows_ptr), ld, _vp(assignments_ptr), first_vec_id, n))
+
+    def upload_end(self):
+        check(lib().vers_ivf_upload_end(self._h))
+
     def search_dev(self, q_ptr: int, ldq: int, b: int, top_k: int, nprobe: int, ids_ptr: int, dist_ptr: int, cnt_ptr: int,
                    stream: int = 0):
         check(lib().vers_ivf_search_dev(self._h, _vp(q_ptr), ldq, b, top_k, nprobe, _vp(ids_ptr), _vp(dist_ptr), _vp(cnt_ptr),
