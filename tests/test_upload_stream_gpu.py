@@ -86,17 +86,18 @@ def test_streamed_upload_equals_upload_and_build(d, ld, monkeypatch):
                 for q in range(b):
                     c = int(wc[q])
                     assert np.array_equal(oi.cpu().numpy().astype(np.uint64)[q, :c], wi[q, :c]) and np.array_equal(bits(od.cpu().numpy()[q, :c]), bits(wd[q, :c]))
-        if world == 1:  # a streamed handle is a complete index: add and batched search keep working on it
-            ix = shards[0]
-            x = dg.dist_u(79, 1, d)[0]
-            c = capi.C.c_uint64(0); v = capi.C.c_uint64(0)
-            capi.check(capi.lib().vers_ivf_add(ix._h, capi._ptr(np.ascontiguousarray(x)), capi.C.byref(c), capi.C.byref(v)))
-            assert (c.value, v.value) == whole.add(x)
-            gi, gd, gc = ix.search_batch(Q, top_k, 4); wi, wd, wc = whole.search_batch(Q, top_k, 4)
-            assert np.array_equal(gi, wi) and np.array_equal(bits(gd), bits(wd)) and np.array_equal(gc, wc)
         for ix in shards:
             ix.close()
-    ref.close(); whole.close()
+    # a streamed handle is a complete index: add and batched search keep working on it
+    ix = IVFFlatIndex(d)
+    _stream(ix, Xall, A, k, whole.centroids, cuts, dev_every=3, ld=ld)
+    x = dg.dist_u(79, 1, d)[0]
+    c = capi.C.c_uint64(0); v = capi.C.c_uint64(0)
+    capi.check(capi.lib().vers_ivf_add(ix._h, capi._ptr(np.ascontiguousarray(x)), capi.C.byref(c), capi.C.byref(v)))
+    assert (c.value, v.value) == whole.add(x)
+    gi, gd, gc = ix.search_batch(Q, top_k, 4); wi, wd, wc = whole.search_batch(Q, top_k, 4)
+    assert np.array_equal(gi, wi) and np.array_equal(bits(gd), bits(wd)) and np.array_equal(gc, wc)
+    ix.close(); ref.close(); whole.close()
 
 
 def test_streamed_upload_small_staging_buffer(monkeypatch):
@@ -164,8 +165,9 @@ def test_streamed_upload_refuses_inconsistent_fields():
     # and after all that a correct sequence still works; the empty index too
     ix.upload_begin(cent, lens, n); ix.upload_chunk(X, A, 0); ix.upload_end()
     assert ix.info()[0] == n
-    gi, gd, gc = ix.search_batch(X[:4], 1, 0)
-    assert np.array_equal(gi[:, 0], np.arange(4, dtype=np.uint64)) and np.all(gd[:, 0] == 0.0)
+    for c in range(k):  # (the announced assignments, not the nearest centroids, decide the lists: ids[c] is implied by `assignments`)
+        rows, ids = ix.get_list(c)
+        assert np.array_equal(ids, np.arange(c, n, k, dtype=np.uint64)) and np.array_equal(bits(rows), bits(X[c::k]))
     ix.upload_begin(np.zeros((0, d), np.float32), np.zeros(0, np.uint64), 0); ix.upload_end()
     assert ix.info()[:2] == (0, 0)
     ix.close()
