@@ -136,9 +136,24 @@ def main():
     capi.build_stats(reset=True)
     t0 = time.perf_counter()
     comm = None
+    # On the GPUs (backend nccl = RCCL) the library's OWN adapter drives every exchange of the run: libvers_rccl.so's
+    # vers_rccl_comm callbacks for the row-sharded build (what a Rust host would link), its vers_rccl_gather for the search.
+    # VERS_BENCH_BUILD_COMM=torch puts vers_amd.dist.TorchComm (Python callbacks over torch.distributed) behind the build
+    # instead -- it counts calls / bytes / seconds per exchange.  RcclComm.from_torch is collective-safe: it raises on every
+    # rank or on none.
+    rccl_comm = None
+    if multi and backend == "nccl" and os.environ.get("VERS_BENCH_EXCHANGE", "rccl") == "rccl":
+        try:
+            from vers_amd import rccl as vrccl
+            rccl_comm = vrccl.RcclComm.from_torch(dev_index)
+            if rank == 0:
+                log(f"[bench] libvers_rccl.so: {vrccl.versions()}")
+        except Exception as e:  # (the library or RCCL refused on some rank: every rank is here)
+            log(f"[bench] rank {rank}: RCCL adapter unavailable ({e!r}); torch.distributed carries the exchanges")
     if multi:
         from vers_amd.dist import TorchComm
-        comm = TorchComm(device=dev_index)
+        build_comm_kind = os.environ.get("VERS_BENCH_BUILD_COMM", "rccl" if rccl_comm is not None else "torch")
+        comm = rccl_comm if (build_comm_kind == "rccl" and rccl_comm is not None) else TorchComm(device=dev_index)
         kept = index.build_sharded_dev(X.data_ptr(), hi - lo, ld, lo, n, nlist, 1, args.kmeans_iters, init, comm)
     else:
         kept = index.build_dev(X.data_ptr(), n, nlist, 1, args.kmeans_iters, init)
@@ -173,15 +188,17 @@ def main():
                              "library_mem_peak_gb_per_rank": [round(float(t[0]) / 1e9, 2) for t in allpk],
                              "library_mem_after_build_gb_per_rank": [round(float(t[1]) / 1e9, 2) for t in allpk],
                              "peak_over_rank_rows": round(max(float(t[0]) / max(1.0, float(t[2])) for t in allpk), 3),
-                             "exchange_calls": dict(comm.calls), "exchange_bytes": dict(comm.bytes),
-                             "exchange_seconds_rank0": {k_: round(v_, 3) for k_, v_ in comm.seconds.items()},
-                             "chain_hop_ms": round(1e3 * (comm.seconds["send"] + comm.seconds["recv"]) / max(1, comm.calls["send"] + comm.calls["recv"]), 2),
-                             "build_index_s": round(t_build, 2), "backend": backend}
+                             "build_index_s": round(t_build, 2), "backend": backend,
+                             "exchanges_through": "libvers_rccl.so vers_rccl_comm (native callbacks on the adapter's stream)" if comm is rccl_comm else "vers_amd.dist.TorchComm (Python callbacks over torch.distributed)"}
+            if hasattr(comm, "calls"):   # (TorchComm counts; the native callbacks do not: VERS_BENCH_BUILD_COMM=torch for the counters)
+                sharded_build.update({"exchange_calls": dict(comm.calls), "exchange_bytes": dict(comm.bytes),
+                                      "exchange_seconds_rank0": {k_: round(v_, 3) for k_, v_ in comm.seconds.items()},
+                                      "chain_hop_ms": round(1e3 * (comm.seconds["send"] + comm.seconds["recv"]) / max(1, comm.calls["send"] + comm.calls["recv"]), 2)})
     if multi and rank == 0:
         own = index.owners()
         log(f"[bench] row-sharded build over {world} ranks: {hi - lo} rows generated per rank, library device memory peak "
             f"{mem_peak / 1e9:.2f} GB / now {mem_now / 1e9:.2f} GB on rank 0 (whole corpus: {n * d * 4 / 1e9:.2f} GB); "
-            f"exchange calls {comm.calls}, bytes {comm.bytes}")
+            f"exchanges through {'libvers_rccl.so (vers_rccl_comm)' if comm is rccl_comm else 'TorchComm: calls ' + str(comm.calls) + ', bytes ' + str(comm.bytes)}")
         log(f"[bench] lists sharded over {world} ranks (LPT): rows per rank "
             f"{[int(lens[own == r].sum()) for r in range(world)]}")
 
@@ -212,16 +229,9 @@ def main():
     if multi:
         want = os.environ.get("VERS_BENCH_EXCHANGE", "rccl" if backend == "nccl" else "gloo")
         if want == "rccl" and backend == "nccl":
-            try:
-                from vers_amd.rccl import RcclComm
-                gather = RcclComm.from_torch(dev_index)
+            gather = rccl_comm   # (made before the build, the same on every rank or on none: RcclComm.from_torch)
+            if gather is not None:
                 exchange_kind = "libvers_rccl.so: ncclAllGather on the batch's stream (vers_ivf_search_sharded_dev)"
-            except Exception as e:  # (the library or RCCL refused: the torch path still measures the same step)
-                log(f"[bench] rank {rank}: RCCL adapter unavailable ({e!r}); falling back to torch.distributed for the exchange")
-            ok_all = torch.tensor([1 if gather is not None else 0], device=dev)
-            dist.all_reduce(ok_all, op=dist.ReduceOp.MIN)   # every rank takes the same path
-            if int(ok_all.item()) == 0:
-                gather = None
         elif want == "gloo" or backend != "nccl":
             from vers_amd.dist import TorchGather
             gather = TorchGather(device=dev_index)

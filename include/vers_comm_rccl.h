@@ -32,14 +32,25 @@ int32_t vers_rccl_unique_id(void* out_id128);
 /* Collective over all ranks: ncclCommInitRank on `device`.  The handle owns the communicator and one stream (for the
  * synchronous callbacks of vers_rccl_comm). */
 int32_t vers_rccl_create(const void* id128, uint32_t rank, uint32_t world, int32_t device, vers_rccl_t** out);
-/* The same around a communicator the host already has (`nccl_comm` is an ncclComm_t); it is NOT destroyed with the handle. */
+/* The same around a communicator the host already has (`nccl_comm` is an ncclComm_t); it is NOT destroyed with the handle.
+ * `device` is range-checked and must be the device the communicator was made on (ncclCommCuDevice). */
 int32_t vers_rccl_adopt(void* nccl_comm, int32_t device, vers_rccl_t** out);
-/* ncclCommDestroy (owned communicators) after the handle's stream has drained. */
+/* ncclCommDestroy (owned communicators) after the handle's stream has drained; a communicator marked dead is aborted. */
 int32_t vers_rccl_destroy(vers_rccl_t* c);
+/* ncclCommAbort: what the host calls when ANY rank returned non-zero from a sharded build / search (a rank that left early has
+ * left its peers inside a collective; the communicator cannot be used again).  The handle stays valid for vers_rccl_destroy;
+ * every later exchange through it fails at once with VERS_ERR_COMM. */
+int32_t vers_rccl_abort(vers_rccl_t* c);
+/* RCCL this library was compiled against (NCCL_VERSION_CODE), the one the process actually runs (ncclGetVersion) and the path
+ * of the shared object that provides it (under PyTorch: torch's bundled librccl, mapped first).  A different major version
+ * is refused by vers_rccl_create / _adopt / _unique_id. */
+int32_t vers_rccl_versions(int32_t* out_build_code, int32_t* out_runtime_code, char* out_path, uint64_t path_cap);
 /* Fills *out for vers_ivf_search_sharded_dev / vers_ivf_search_exhaustive_sharded_dev.  `out->ctx` points into the handle:
  * keep the handle alive while searches that use it are in flight. */
 int32_t vers_rccl_gather(vers_rccl_t* c, vers_gather_t* out);
-/* Fills *out for vers_ivf_build_sharded_dev (each callback queues its RCCL call on the handle's stream and waits for it). */
+/* Fills *out for vers_ivf_build_sharded_dev (each callback queues its RCCL call on the handle's stream and waits for it --
+ * a BOUNDED wait: hipStreamQuery polled against VERS_RCCL_TIMEOUT_S (default 600) and the communicator's asynchronous error
+ * state; a dead peer makes the callback return VERS_ERR_COMM instead of hanging the rank inside hipStreamSynchronize). */
 int32_t vers_rccl_comm(vers_rccl_t* c, vers_comm_t* out);
 
 #ifdef __cplusplus

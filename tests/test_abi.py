@@ -42,6 +42,11 @@ def test_rccl_adapter_builds_exports_every_declared_symbol_and_matches_its_bindi
     exports what its header declares, and libvers_hip.so itself does NOT depend on RCCL."""
     import subprocess
     from vers_amd import rccl
+    import os
+    import pytest
+    rocm_lib = os.path.join(os.path.dirname(os.path.dirname(vbuild._hipcc())), "lib")
+    if not any(f.startswith("librccl.so") for f in os.listdir(rocm_lib)):
+        pytest.skip("no librccl under the hipcc prefix: the optional adapter is not built on this box")
     so = vbuild.build_rccl()
     names = header_functions("vers_comm_rccl.h")
     assert "vers_rccl_gather" in names and "vers_rccl_comm" in names

@@ -235,3 +235,61 @@ def test_row_sharded_build_at_cfg5_cluster_count_equals_the_single_process_build
         assert g["peak"] < 3.5 * g["share"] + per_list + (2 << 30), (r, g["peak"], g["share"])
         assert g["calls"]["all_to_all_v"] == 2
     assert set(ret[(2, 0)]["sample"]) | set(ret[(2, 1)]["sample"]) == set(one["sample"])
+
+
+def fail_worker(rank, world, port, ret):
+    """world ranks on one GPU over gloo; rank 1 fails LOCALLY in its second sharded search (test hook) and must still join the
+    batch's all-gather -- with a poisoned partial -- so that rank 0 does not hang and sees the failure through vers_ivf_poll."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    import torch
+    import torch.distributed as dist
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from tests import datagen as dg
+    from tests.golden import make_golden as mg
+    from vers_amd import capi
+    from vers_amd.dist import TorchGather
+    from vers_amd.index import IVFFlatIndex
+    n, d, k = 3000, 48, 24
+    X = dg.dist_c(0xF1, n, d, 40, dg.default_sigma(d)); init = mg.init_draws(0xF1, 1, k, n)
+    ix = IVFFlatIndex(d, device=0); ix.set_shard(rank, world)
+    import ctypes as C
+    cost = C.c_float(0); kept = C.c_int32(0)
+    capi.check(capi.lib().vers_ivf_build(ix._h, capi._ptr(X), n, 4 * d, k, 1, 4, capi._ptr(init), None, 0, None, C.byref(cost), C.byref(kept), None))
+    Qd = torch.from_numpy(dg.dist_c(0xF2, 16, d, 40, dg.default_sigma(d))).cuda()
+    gather = TorchGather(device=0)
+    oi = torch.zeros(16, 5, dtype=torch.int64, device="cuda"); od = torch.zeros(16, 5, device="cuda"); oc = torch.zeros(16, dtype=torch.int32, device="cuda")
+    log = []
+    for it in range(3):
+        if it == 1 and rank == 1:
+            capi.set_option("test_fail_sharded", 1)
+        try:
+            ix.search_sharded_dev(gather.ptr(), Qd.data_ptr(), d, 16, 5, 4, oi.data_ptr(), od.data_ptr(), oc.data_ptr())
+            call = "ok"
+        except capi.VersError as e:
+            call = f"err{e.status}"
+        try:
+            ix.poll()
+            poll = "ok"
+        except capi.VersError as e:
+            poll = f"err{e.status}"
+        log.append((call, poll, oi.cpu().numpy().copy(), oc.cpu().numpy().copy()))
+    ret[rank] = dict(log=log, calls=gather.calls)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_sharded_search_local_failure_does_not_strand_the_peers():
+    from vers_amd import capi
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(fail_worker, args=(2, free_port(), ret), nprocs=2, join=True)   # (a hang here = the failing rank skipped the collective)
+    r0, r1 = ret[0]["log"], ret[1]["log"]
+    assert ret[0]["calls"] == 3 and ret[1]["calls"] == 3          # every rank entered every batch's all-gather
+    # batches 0 and 2: fine everywhere, identical results on both ranks
+    for it in (0, 2):
+        assert r0[it][:2] == ("ok", "ok") and r1[it][:2] == ("ok", "ok")
+        assert np.array_equal(r0[it][2], r1[it][2]) and np.array_equal(r0[it][3], r1[it][3])
+    assert np.array_equal(r0[0][2], r0[2][2])
+    # batch 1: rank 1's call returns its own error; BOTH ranks' polls report the poisoned partial as a communication error
+    assert r1[1][0] == f"err{capi.ERR_HIP}" and r0[1][0] == "ok"
+    assert r0[1][1] == f"err{capi.ERR_COMM}" and r1[1][1] == f"err{capi.ERR_COMM}"

@@ -78,6 +78,8 @@ int32_t sync_status(vers_ivf* h, hipStream_t st) {  // the word of the _dev call
     s = *reinterpret_cast<volatile uint32_t*>(pin);
   }
   if (!s) return VERS_OK;
+  if (s & kStPeerFailed)
+    return fail(VERS_ERR_COMM, "a rank of the sharded search failed locally and sent a poisoned partial: results of batches on this stream miss that rank's lists");
   if (s & kStNaN) return fail(VERS_ERR_NAN, "NaN distance (the reference panics in partial_cmp().unwrap())");
   if (s & kStInsufficient)
     return fail(VERS_ERR_INSUFFICIENT, "fewer than top_k vectors reachable (reference: index out of bounds, ivfflat.rs:169)");
@@ -166,6 +168,7 @@ int32_t vers_set_option(const char* name, int64_t value) {
   if (std::strcmp(name, "gemm_x3") == 0) { set_gemm_x3_mask((int)value); return VERS_OK; }
   if (std::strcmp(name, "shadow") == 0) { shadow_mode_ref().store(value != 0 ? 1 : 0); return VERS_OK; }
   if (std::strcmp(name, "pre_min_batch") == 0) { pre_min_batch_ref().store(value < 2 ? 2u : (uint32_t)std::min<int64_t>(value, 0x7FFFFFFF)); return VERS_OK; }
+  if (std::strcmp(name, "test_fail_sharded") == 0) { test_fail_sharded_ref().store((int)value); return VERS_OK; }  // TEST HOOK: the next `value` sharded searches of this process fail locally
   if (std::strcmp(name, "scan_events") == 0) { scan_events_ref().store(value < 0 || value > 2 ? 2 : (int)value); return VERS_OK; }
   return fail(VERS_ERR_INVALID, std::string("vers_set_option: unknown option ") + name);
 }

@@ -326,6 +326,12 @@ inline std::atomic<int>& scan_events_ref() {
   static std::atomic<int> m{[] { const char* e = getenv("VERS_SCAN_EVENTS"); return e ? atoi(e) : 2; }()};
   return m;
 }
+// TEST HOOK (vers_set_option("test_fail_sharded", n)): the next n sharded searches of this process fail LOCALLY after their
+// exchange buffers are reserved -- what an out-of-memory scratch reservation on one rank looks like to its peers
+inline std::atomic<int>& test_fail_sharded_ref() {
+  static std::atomic<int> m{0};
+  return m;
+}
 inline std::atomic<int>& shadow_mode_ref() {  // VERS_SHADOW (default 1) / vers_set_option("shadow", v)
   static std::atomic<int> m{[] { const char* e = getenv("VERS_SHADOW"); return e ? (atoi(e) != 0 ? 1 : 0) : 1; }()};
   return m;

@@ -132,11 +132,15 @@ __global__ __launch_bounds__(kWave * kMergeWaves) void seg_merge_kernel(const ui
 // cross-GPU merge of per-rank partial results ([world][b][k] keys + ids, kKeyMax padded): one wave per query.
 // nprobe mode: global top-k by key.  reference mode: position p of the output belongs to exactly one rank
 // (the owner of the list that position came from), so the merge is a position-wise minimum.
+// status != nullptr: a rank whose partial is poisoned (it failed locally, see kStPeerFailed) is reported there.
 __global__ __launch_bounds__(kWave) void rank_merge_kernel(const uint64_t* keys, const uint64_t* ids, uint64_t rank_stride,
                                                            uint32_t world, uint32_t b, uint32_t k, int ref_mode,
-                                                           uint64_t* out_ids, float* out_dist, uint32_t* out_count) {
+                                                           uint64_t* out_ids, float* out_dist, uint32_t* out_count, uint32_t* status = nullptr) {
   const uint32_t q = blockIdx.x;
   const int lane = threadIdx.x;
+  if (status != nullptr && q == 0)
+    for (uint32_t r = lane; r < world; r += kWave)
+      if (keys[r * rank_stride] == kKeyMax && ids[r * rank_stride] == kPoisonId) atomicOr(status, kStPeerFailed);
   uint32_t total = 0;
   uint64_t lower = 0;  // nprobe mode, k > 64: 64 ranks per pass, keys at or below the previous pass's last key are skipped
   for (uint32_t r0 = 0; r0 < k; r0 += kWave) {
@@ -624,30 +628,58 @@ static int32_t sharded_common(vers_ivf_t* h, const vers_gather_t* g, const float
   if (lease.rc) return lease.rc;
   if (int32_t rc = lease.order_on(st)) return rc;
   const size_t part = (size_t)b * top_k;  // keys | ids of one rank
-  if (int32_t rc = W->g_send.reserve(2 * part * sizeof(uint64_t))) return rc;
-  if (int32_t rc = W->g_recv.reserve((size_t)world * 2 * part * sizeof(uint64_t))) return rc;
+  // The exchange buffers FIRST.  Up to here a local failure (no workspace, no exchange buffer) leaves this rank unable to take part
+  // in the batch's all-gather at all: the peers have queued theirs and wait -- the host must abort the communicator
+  // (vers_rccl_abort) when a rank returns from here, there is nothing the library can send.
+  const bool exchange = g != nullptr && g->all_gather_async != nullptr;
+  {
+    int32_t rc = W->g_send.reserve(2 * part * sizeof(uint64_t));
+    if (!rc) rc = W->g_recv.reserve((size_t)world * 2 * part * sizeof(uint64_t));
+    if (rc) {
+      if (exchange && world > 1)
+        fail(rc, std::string(who) + ": the exchange buffers could not be reserved -- this rank cannot join the batch's all-gather; abort the communicator (" + vers_last_error() + ")");
+      return rc;
+    }
+  }
   // (no exchange -- g == nullptr, a single process: the partial is the gathered buffer.  A one-rank communicator still gathers:
   // the call is the same code path as with peers, which is how the RCCL leg is tested on a one-GPU box)
-  const bool exchange = g != nullptr && g->all_gather_async != nullptr;
   uint64_t* mine = exchange ? W->g_send.as<uint64_t>() : W->g_recv.as<uint64_t>();
-  if (exhaustive_metric >= 0) {
+  // From here on a LOCAL failure (scratch reservation, a failed launch) must not skip the batch's ONLY collective: the peers have
+  // already queued their ncclAllGather and would block forever, and every later collective on the communicator would be
+  // mismatched.  The rank answers with a POISONED partial instead -- every key kKeyMax (it contributes nothing), first id word
+  // kPoisonId -- so that the gather completes everywhere; every rank's merge sees the mark and latches kStPeerFailed in its
+  // stream's status word (vers_ivf_poll -> VERS_ERR_COMM); this rank also returns its own error from the call.
+  int32_t local_rc = VERS_OK;
+  if (test_fail_sharded_ref().load() > 0 && test_fail_sharded_ref().fetch_sub(1) > 0) local_rc = fail(VERS_ERR_HIP, std::string(who) + ": injected local failure (test hook)");
+  if (!local_rc) local_rc = [&]() -> int32_t {
     if (int32_t rc = ensure_out(h, part, b)) return rc;
-    if (int32_t rc = exhaustive_dev_locked(h, queries_dev, ldq_floats, b, top_k, (uint32_t)exhaustive_metric, W->o_ids.as<uint64_t>(), W->o_dist.as<float>(),
-                                           W->o_cnt.as<uint32_t>(), st)) return rc;
-    hipLaunchKernelGGL(pack_exhaustive_keys_kernel, dim3((unsigned)((part + 255) / 256)), dim3(256), 0, st, (const uint64_t*)W->o_ids.as<uint64_t>(),
-                       (const float*)W->o_dist.as<float>(), (const uint32_t*)W->o_cnt.as<uint32_t>(), b, top_k, mine, mine + part);
-    VERS_HIP_TRY(hipGetLastError());
-  } else {
-    if (int32_t rc = ensure_out(h, part, b)) return rc;
-    if (int32_t rc = search_dev_locked(h, queries_dev, ldq_floats, b, top_k, nprobe, mine + part, W->o_dist.as<float>(), W->o_cnt.as<uint32_t>(), mine, st))
-      return rc;
+    if (exhaustive_metric >= 0) {
+      if (int32_t rc = exhaustive_dev_locked(h, queries_dev, ldq_floats, b, top_k, (uint32_t)exhaustive_metric, W->o_ids.as<uint64_t>(), W->o_dist.as<float>(),
+                                             W->o_cnt.as<uint32_t>(), st)) return rc;
+      hipLaunchKernelGGL(pack_exhaustive_keys_kernel, dim3((unsigned)((part + 255) / 256)), dim3(256), 0, st, (const uint64_t*)W->o_ids.as<uint64_t>(),
+                         (const float*)W->o_dist.as<float>(), (const uint32_t*)W->o_cnt.as<uint32_t>(), b, top_k, mine, mine + part);
+      VERS_HIP_TRY(hipGetLastError());
+      return VERS_OK;
+    }
+    return search_dev_locked(h, queries_dev, ldq_floats, b, top_k, nprobe, mine + part, W->o_dist.as<float>(), W->o_cnt.as<uint32_t>(), mine, st);
+  }();
+  if (local_rc && !exchange) return local_rc;
+  if (local_rc) {  // (stream order: behind whatever the failed search had already queued into `mine`)
+    const std::string why = vers_last_error();
+    const uint64_t mark = kPoisonId;
+    (void)hipMemsetAsync(mine, 0xFF, 2 * part * sizeof(uint64_t), st);
+    (void)hipMemcpyAsync(mine + part, &mark, sizeof(mark), hipMemcpyHostToDevice, st);  // (pageable source: copied before the call returns)
+    (void)hipGetLastError();
+    fail(local_rc, why + " [this rank joined the batch's all-gather with a poisoned partial]");
   }
   if (exchange) {
     if (int32_t rc = g->all_gather_async(g->ctx, W->g_send.p, W->g_recv.p, 2 * part * sizeof(uint64_t), stream))
-      return fail(VERS_ERR_COMM, "vers_gather_t::all_gather_async reported failure (status " + std::to_string(rc) + ")");
+      return local_rc ? local_rc : fail(VERS_ERR_COMM, "vers_gather_t::all_gather_async reported failure (status " + std::to_string(rc) + ")");
   }
   hipLaunchKernelGGL(rank_merge_kernel, dim3(b), dim3(kWave), 0, st, (const uint64_t*)W->g_recv.as<uint64_t>(), (const uint64_t*)W->g_recv.as<uint64_t>() + part,
-                     (uint64_t)(2 * part), world, b, top_k, (exhaustive_metric < 0 && nprobe == 0) ? 1 : 0, out_ids_dev, out_dist_dev, out_count_dev);
+                     (uint64_t)(2 * part), world, b, top_k, (exhaustive_metric < 0 && nprobe == 0) ? 1 : 0, out_ids_dev, out_dist_dev, out_count_dev,
+                     exchange ? W->st_word() : (uint32_t*)nullptr);
+  if (local_rc) { (void)hipGetLastError(); return local_rc; }
   VERS_HIP_TRY(hipGetLastError());
   return VERS_OK;
 }

@@ -19,6 +19,10 @@ namespace vers {
 
 constexpr uint32_t kNoList = 0xFFFFFFFFu;
 constexpr uint32_t kStNaN = 1u, kStInsufficient = 2u, kStSpillTooDeep = 4u;
+// sharded search: a rank that failed LOCALLY still takes part in the batch's one all-gather, with a poisoned partial (every key
+// kKeyMax, first id word kPoisonId); every rank's merge latches kStPeerFailed in its stream's status word (vers_ivf_poll -> VERS_ERR_COMM)
+constexpr uint32_t kStPeerFailed = 8u;
+constexpr uint64_t kPoisonId = 0xDEADFA11DEADFA11ull;
 constexpr uint32_t kNoSeg = 0xFFFFFFFFu;  // padding item of a quad
 
 // Row segments of one list.  seg_target == 0: fixed seg_rows.  Otherwise (matrix-core scan) the list is cut into
