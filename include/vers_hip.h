@@ -314,7 +314,11 @@ int32_t vers_ivf_build_sharded_dev(vers_ivf_t* h, const float* rows_dev, uint64_
  * 5.5-6 us of ~100, so b == 1 calls are not timed unless asked.
  * "pre_min_batch" (default 4; VERS_PRE_MIN_BATCH): the smallest batch of an nprobe search whose list scan runs on the matrix
  * cores (fp16 shadow, exact finish) even when its lists are shared by fewer than two queries on average; smaller batches
- * run one ordered-chain scan per (query, list) pair.  Same results either way. */
+ * run one ordered-chain scan per (query, list) pair.  Same results either way.
+ * "scan_reserve_cus" (default 0; VERS_SCAN_RESERVE_CUS): the persistent matrix-core list scan launches on that many FEWER
+ * compute units.  Its blocks hold 448 of a SIMD's 512 registers, so nothing with a large footprint -- RCCL's all-gather kernel
+ * (256 VGPRs per wave), another batch's coarse contraction / selection -- runs beside them: with batches in flight on a
+ * sharded index the reserved CUs are where those run WHILE a scan streams (the scan is HBM-bound: it loses little). */
 int32_t vers_set_option(const char* name, int64_t value);
 /* Device memory the library holds in this process right now (rows, ids, scratch of every handle) and its high-water
  * mark since the last reset -- lets a test assert that no rank of a sharded build ever allocated the whole corpus. */
@@ -403,6 +407,13 @@ int32_t vers_ivf_test_last_vals(vers_ivf_t* h, uint32_t q, uint64_t* out_vec_ids
  * kind 0 v_mfma_f32_32x32x16_f16, 1 v_mfma_f32_32x32x16_bf16 (A, B: 16-bit patterns), 2 v_mfma_f32_32x32x2_f32,
  * 3 v_mfma_f32_16x16x1_4b_f32 (f32).  A [rows][K], B [K][cols] row-major; rows x cols = 32 x 32 (kind 3: 64 x 16); host pointers. */
 int32_t vers_test_mfma(int32_t device, uint32_t kind, const void* A, const void* B, uint32_t K, float* out_C);
+/* MEASUREMENT HOOK: fills *out with an exchange that is a STAND-IN WITH RCCL's FOOTPRINT for one-GPU emulations of a W-GPU
+ * search (scripts/emulate_shard.py): all_gather_async launches ONE kernel of `workgroups` blocks x `threads` (256 | 512) threads
+ * that hold 256 VGPRs (+ 32 AGPRs at 256 threads) and lds_bytes of LDS -- the resources of RCCL's device kernel on gfx950
+ * (profiles/r05_rccl_kernel_meta.txt) --, copy the rank's partial into every rank's slot and stay resident for spin_us.  Not an
+ * exchange: results of a sharded search through it are this rank's partial merged with itself. */
+int32_t vers_test_standin_gather(vers_gather_t* out, uint32_t rank, uint32_t world, uint32_t workgroups, uint32_t spin_us,
+                                 uint32_t threads, uint32_t lds_bytes);
 /* Durations (ms) of the most recent list-scan launches, oldest first (ring of 64); reset != 0
  * empties the ring.  Lets bench.py time every launch of the timed region without stalling it. */
 int32_t vers_ivf_scan_times(vers_ivf_t* h, float* out_ms, uint32_t cap, uint32_t* out_n, int32_t reset);

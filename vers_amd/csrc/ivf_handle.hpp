@@ -332,6 +332,11 @@ inline std::atomic<int>& test_fail_sharded_ref() {
   static std::atomic<int> m{0};
   return m;
 }
+// vers_set_option("scan_reserve_cus", n) / VERS_SCAN_RESERVE_CUS: compute units the persistent matrix-core list scan leaves free
+inline std::atomic<int>& scan_reserve_cus_ref() {
+  static std::atomic<int> m{[] { const char* e = getenv("VERS_SCAN_RESERVE_CUS"); return e ? atoi(e) : 0; }()};
+  return m;
+}
 inline std::atomic<int>& shadow_mode_ref() {  // VERS_SHADOW (default 1) / vers_set_option("shadow", v)
   static std::atomic<int> m{[] { const char* e = getenv("VERS_SHADOW"); return e ? (atoi(e) != 0 ? 1 : 0) : 1; }()};
   return m;

@@ -3,6 +3,56 @@
 #include "ivf_handle.hpp"
 #include "prescan.hip.h"
 
+
+// =================================================================================================
+// MEASUREMENT HOOK: a vers_gather_t whose exchange is a STAND-IN WITH RCCL's FOOTPRINT (no 8-GPU node has been available in
+// any round; with one rank ncclAllGather degenerates to a copy kernel, which says nothing about what the real device kernel
+// needs).  RCCL's all-gather on gfx950 is ONE kernel of `channels` workgroups (profiles/r05_rccl_kernel_meta.txt, read from the
+// code objects with llvm-readelf --notes):
+//   /opt/rocm 7.2 librccl (2.27.7)  ncclDevKernel_Generic_*   248-256 VGPRs, 37,664 B LDS, 512 threads
+//   torch's bundled librccl (2.26.6) rcclGenericKernel<1|2|4>  244-248 VGPRs + 17-32 AGPRs, 19,744 B LDS, 256 threads, 352 B scratch
+// i.e. a workgroup that needs (nearly) a whole CU's registers and cannot sit beside a list-scan block (448 of a SIMD's 512).
+// The stand-in: `workgroups` blocks of `threads` threads holding 256 VGPRs (+ 32 AGPRs for the 256-thread shape) and `lds`
+// bytes, which copy this rank's partial into every rank's slot of the gathered buffer (the bytes an all-gather writes: the
+// merge then reads `world` well-formed partials) and stay resident for `spin_us` (the time the peers' bytes would take over xGMI).
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void rccl_standin_kernel(const uint64_t* send, uint64_t* recv, uint64_t words, uint32_t world, uint32_t spin_ticks) {
+  extern __shared__ __attribute__((aligned(16))) uint64_t sl[];
+  const unsigned long long t0 = wall_clock64();  // 100 MHz
+  asm volatile("v_mov_b32 v255, 0" ::: "v255");           // the register footprint of RCCL's generic kernel
+  if constexpr (THREADS <= 256) asm volatile("v_accvgpr_write_b32 a31, 0" ::: "a31");
+  sl[threadIdx.x] = t0;
+  for (uint32_t r = 0; r < world; ++r)
+    for (uint64_t i = (uint64_t)blockIdx.x * THREADS + threadIdx.x; i < words; i += (uint64_t)gridDim.x * THREADS) recv[(uint64_t)r * words + i] = send[i];
+  while (wall_clock64() - t0 < spin_ticks) __builtin_amdgcn_s_sleep(8);
+  if (sl[threadIdx.x] == 1ull) recv[0] = 0;  // (keeps the LDS allocation alive; never true)
+}
+struct StandinGather {
+  uint32_t world, workgroups, spin_us, threads, lds;
+};
+static int32_t standin_all_gather(void* ctx, const void* send_dev, void* recv_dev, uint64_t bytes, void* stream) {
+  const StandinGather* sg = (const StandinGather*)ctx;
+  const uint64_t words = bytes / 8;
+  if (sg->threads > 256) {
+    hipLaunchKernelGGL(rccl_standin_kernel<512>, dim3(sg->workgroups), dim3(512), sg->lds, (hipStream_t)stream, (const uint64_t*)send_dev, (uint64_t*)recv_dev, words,
+                       sg->world, sg->spin_us * 100u);
+  } else {
+    hipLaunchKernelGGL(rccl_standin_kernel<256>, dim3(sg->workgroups), dim3(256), sg->lds, (hipStream_t)stream, (const uint64_t*)send_dev, (uint64_t*)recv_dev, words,
+                       sg->world, sg->spin_us * 100u);
+  }
+  return hipGetLastError() == hipSuccess ? 0 : 1;
+}
+extern "C" int32_t vers_test_standin_gather(vers_gather_t* out, uint32_t rank, uint32_t world, uint32_t workgroups, uint32_t spin_us, uint32_t threads, uint32_t lds_bytes) {
+  if (!out || world == 0 || rank >= world || workgroups == 0 || (threads != 256 && threads != 512) || lds_bytes < threads * 8u || lds_bytes > 64u * 1024u)
+    return fail(VERS_ERR_INVALID, "vers_test_standin_gather: bad arguments (threads 256 | 512, lds_bytes in [8 * threads, 64 KiB])");
+  StandinGather* sg = new StandinGather{world, workgroups, spin_us, threads, lds_bytes};  // (lives as long as the process: a measurement hook)
+  out->ctx = sg;
+  out->rank = rank;
+  out->world = world;
+  out->all_gather_async = standin_all_gather;
+  return VERS_OK;
+}
+
 extern "C" {
 
 int32_t vers_ivf_last_scan(vers_ivf_t* h, float* out_ms, uint64_t* out_union_rows, uint64_t* out_streamed_rows,
