@@ -27,7 +27,7 @@ NSTEP = int(os.environ.get("STEPS", "20"))
 EXCHANGE = os.environ.get("EXCHANGE", "standin")
 if EXCHANGE == "1": EXCHANGE = "standin"
 WG, SPIN_US, SHAPE = int(os.environ.get("WG", 32)), int(os.environ.get("SPIN_US", 25)), int(os.environ.get("SHAPE", 512))
-RESERVES = [int(r) for r in os.environ.get("RESERVE", "0").split(",")]
+RESERVES = [int(r) for r in os.environ.get("RESERVE", "-1").split(",")]   # -1 = the library's AUTO policy (production)
 RANKS = os.environ.get("RANKS")  # e.g. "0,3": only these ranks of every world (quick looks)
 dev = torch.device("cuda:0")
 X = torch.empty(n, d, dtype=torch.float32, device=dev)
@@ -75,7 +75,7 @@ for W in worlds:
         sg = standin(R, W) if EXCHANGE == "standin" else None
         for RES in RESERVES:
           capi.set_option("scan_reserve_cus", RES)
-          tag = "" if RES == 0 else f"_r{RES}"
+          tag = "" if RES == RESERVES[0] else f"_r{RES}"
           for NS in STREAMS:
             streams = [torch.cuda.current_stream().cuda_stream] if NS == 1 else [so.cuda_stream for so in stream_objs[:NS]]
             allp_s = [torch.zeros(W, 2, B, top_k, dtype=torch.int64, device=dev) for _ in range(NS)] if EXCHANGE == "rccl1" else None
@@ -102,7 +102,7 @@ for W in worlds:
             except Exception:   # (VERS_SCAN_EVENTS=0: no event records around the scans)
                 rec[f"scan_us_s{NS}{tag}"] = float("nan")
             for s_ in streams: ix.poll(s_)
-        capi.set_option("scan_reserve_cus", 0)
+        capi.set_option("scan_reserve_cus", -1)
         # rows of the batch this rank scanned (the union of its probed lists), averaged over the NQB batches
         ur = []
         for i in range(NQB):
@@ -128,7 +128,7 @@ for W in worlds:
         print(json.dumps({"world": W, **rec}), flush=True)
     summ = {"ranks": rows_w}
     for RES in RESERVES:
-      tag = "" if RES == 0 else f"_r{RES}"
+      tag = "" if RES == RESERVES[0] else f"_r{RES}"
       for NS in STREAMS:
         v = np.array([r[f"step_ms_s{NS}{tag}"] for r in rows_w])
         summ[f"step_ms_s{NS}{tag}"] = {"max": float(v.max()), "mean": round(float(v.mean()), 4), "max_over_mean": round(float(v.max() / v.mean()), 3)}
@@ -138,13 +138,13 @@ for W in worlds:
     summ["probed_rows"] = {"max": int(pr.max()), "mean": int(pr.mean()), "max_over_mean": round(float(pr.max() / pr.mean()), 3)}
     summ["all_gather_bytes_per_rank"] = 2 * B * top_k * 8
     out["worlds"][str(W)] = summ
-    print(f"== world {W}: " + "  ".join(f"S={NS}{'' if RES == 0 else ' reserve ' + str(RES)}: max {summ[f'step_ms_s{NS}' + ('' if RES == 0 else f'_r{RES}')]['max']:.3f} mean {summ[f'step_ms_s{NS}' + ('' if RES == 0 else f'_r{RES}')]['mean']:.3f} ms" for RES in RESERVES for NS in STREAMS) +
+    print(f"== world {W}: " + "  ".join(f"S={NS}{'' if RES == RESERVES[0] else ' reserve ' + str(RES)}: max {summ[f'step_ms_s{NS}' + ('' if RES == RESERVES[0] else f'_r{RES}')]['max']:.3f} mean {summ[f'step_ms_s{NS}' + ('' if RES == RESERVES[0] else f'_r{RES}')]['mean']:.3f} ms" for RES in RESERVES for NS in STREAMS) +
           f"  probed rows max/mean {summ['probed_rows']['max_over_mean']}", flush=True)
 if "1" in out["worlds"]:
     for NS in STREAMS:
         one = out["worlds"]["1"][f"step_ms_s{NS}"]["max"]   # (one GPU: no exchange kernel to make room for, reserve 0)
         for RES in RESERVES:
-            tag = "" if RES == 0 else f"_r{RES}"
+            tag = "" if RES == RESERVES[0] else f"_r{RES}"
             out[f"predicted_speedup_s{NS}{tag}"] = {w: round(one / out["worlds"][w][f"step_ms_s{NS}{tag}"]["max"], 2) for w in out["worlds"]}
 path = os.environ.get("EMU_OUT") or os.environ.get("OUT", "gpurun_out/emulate_shard.json")
 os.makedirs(os.path.dirname(path) or ".", exist_ok=True)

@@ -332,10 +332,33 @@ inline std::atomic<int>& test_fail_sharded_ref() {
   static std::atomic<int> m{0};
   return m;
 }
-// vers_set_option("scan_reserve_cus", n) / VERS_SCAN_RESERVE_CUS: compute units the persistent matrix-core list scan leaves free
+// vers_set_option("scan_reserve_cus", n) / VERS_SCAN_RESERVE_CUS: compute units the persistent matrix-core list scan leaves free.
+// -1 (default) = AUTO: kScanReserveAuto while ANOTHER batch of this handle is in flight on another stream (scan_reserve below), none
+// otherwise.  A scan block holds 448 of a SIMD's 512 registers: nothing with a large footprint -- RCCL's all-gather kernel (256
+// VGPRs per wave, profiles/r05_rccl_kernel_meta.txt), the other batches' coarse contraction (232) / selection (224) / grouping
+// (1024-thread blocks) -- runs beside one, so with batches in flight those waited for a whole scan to leave the chip (a step was
+// scan + 62 us of them).  The scan is HBM-bound: on 192 of 256 CUs it streams as fast (one batch alone: +6 %
+// at 8 ranks, which is why a lone batch keeps every CU), and the reserved CUs run the other batches' latency-bound kernels and the
+// exchange WHILE it streams: 8-rank step with three in flight and an RCCL-footprint exchange kernel 0.402-0.445 -> 0.370 ms, 4
+// ranks 0.682 -> 0.643, one GPU 2.314 -> 2.276 (same box, scripts/emulate_shard.py RESERVE=...).
+constexpr int kScanReserveAuto = 64;
 inline std::atomic<int>& scan_reserve_cus_ref() {
-  static std::atomic<int> m{[] { const char* e = getenv("VERS_SCAN_RESERVE_CUS"); return e ? atoi(e) : 0; }()};
+  static std::atomic<int> m{[] { const char* e = getenv("VERS_SCAN_RESERVE_CUS"); return e ? atoi(e) : -1; }()};
   return m;
+}
+// Is another batch of this handle in flight on ANOTHER stream right now (a workspace leased by another thread, or one whose last
+// call -- on another stream -- has not finished)?  Decides the AUTO value of "scan_reserve_cus".
+inline bool other_batches_in_flight(vers_ivf* h, const SearchWs* me, hipStream_t st) {
+  std::lock_guard<std::mutex> lk(h->pool_mu);
+  if (h->pool.size() - h->free_ws.size() > 1) return true;
+  for (const SearchWs* w : h->free_ws)
+    if (w != me && w->used && w->last_stream != st && w->done != nullptr && hipEventQuery(w->done) == hipErrorNotReady) return true;
+  return false;
+}
+inline uint32_t scan_reserve(vers_ivf* h, hipStream_t st) {
+  const int v = scan_reserve_cus_ref().load(std::memory_order_relaxed);
+  const int r = v >= 0 ? v : (other_batches_in_flight(h, W, st) ? kScanReserveAuto : 0);
+  return (uint32_t)std::min<int>(r, h->n_cu - 1);
 }
 inline std::atomic<int>& shadow_mode_ref() {  // VERS_SHADOW (default 1) / vers_set_option("shadow", v)
   static std::atomic<int> m{[] { const char* e = getenv("VERS_SHADOW"); return e ? (atoi(e) != 0 ? 1 : 0) : 1; }()};
