@@ -642,11 +642,11 @@ def main():
             sweep_keep[bsz] = (ki.cpu().numpy().astype(np.uint64), kd.cpu().numpy(), kc.cpu().numpy())
         extra["batch_sweep"] = {"workload": f"the headline's index and queries at other batch sizes, {S} batches in flight, nprobe={nprobe} top_k={top_k}", "by_batch": sweep}
         log("[bench] batch sweep: " + ", ".join(f"{k_}: {v_['queries_per_sec'] / 1e3:.1f} k q/s ({v_['us_per_batch']} us)" for k_, v_ in sweep.items()))
-        # (a3) d = 1536 -- a dimension the reference's own bindings instantiate (vers-py/src/lib.rs:26-65); the 32-query block of the
-        # matrix-core scan does not fit LDS there, the narrow 16-query variant does.  The headline's geometry at half the rows: the same
-        # nlist / nprobe / batch, i.e. the same queries per list (8 on average: a 16-query block serves most lists in one pass) and the
-        # same bytes per list.  (With HALF the lists -- 16 queries per list on average -- most lists need two passes of a narrow block:
-        # measured 0.45 of the HBM roofline on algorithmic bytes with the stream itself at the chip's 6.5 TB/s, streamed / union = 1.8.)
+        # (a3) d = 1536 -- a dimension the reference's own bindings instantiate (vers-py/src/lib.rs:26-65).  A 32-query block with both
+        # halves of the query's fp16 hi + lo split does not fit LDS there (196 KB); round 4 ran 16-query blocks (every list probed by
+        # more than 16 queries streamed once per extra group: streamed / union rows 2.15, 0.37 of the HBM roofline); round 5 keeps 32
+        # queries per block with the query as fp16 hi ONLY (98 KB) and charges the query's measured fp16 residual to the certificate.
+        # The headline's geometry at half the rows: the same nlist / nprobe / batch, i.e. the same queries per list and bytes per list.
         d15 = 1536
         n15 = max(4096, min(5_000_000, n // 2)); nl15 = nlist
         X15 = torch.empty(n15, d15, dtype=torch.float32, device=dev)
@@ -680,16 +680,20 @@ def main():
         by15 = l15["union_rows"] * (d15 * 2 + 4) + nl15 * d15 * 4
         m15 = float(np.mean(ms15)) if len(ms15) else float("nan")
         e15 = {"workload": f"IVFFlat N={n15} d={d15} nlist={nl15} nprobe={np15} batch={B} top_k={top_k}, {S} batches in flight", "ms_per_step": round(t15 * 1e3, 4),
-               "queries_per_sec": round(B / t15, 1), "list_scan": "prescan_kernel_g<true, 16> (narrow 16-query blocks, fp16 shadow) + exact finish" if on_mc15 else "scan_kernel (ordered chains)",
+               "queries_per_sec": round(B / t15, 1), "list_scan": ("prescan_kernel_g<true, 32, IvfSrc<32>, LO = false> (32-query blocks, query block as fp16 hi only, fp16 shadow rows) + exact finish" if i15.shadow_state()["active"] else
+                             "prescan_kernel_g<false, 16> (narrow 16-query blocks, f32 rows) + exact finish") if on_mc15 else "scan_kernel (ordered chains)",
+               "rescanned_queries": int(i15.prescan_stats()["fallback_queries"]),
                "list_scan_ms_one_batch_in_flight": round(m15, 4), "algorithmic_bytes_per_launch": int(by15), "achieved_GBs": round(by15 / (m15 * 1e-3) / 1e9, 1),
                "frac": round(by15 / (m15 * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "streamed_over_union_rows": round(l15["streamed_rows"] / max(1, l15["union_rows"]), 3),
                "build_index_s": round(t_b15, 2), "list_len_min_mean_max": [int(l15_lens.min()), int(l15_lens.mean()), int(l15_lens.max())]}
-        if not args.no_cpu:   # two queries of the last batch against the CPU restatement, bit for bit
+        if not args.no_cpu:   # 32 queries spread over the last batch against the CPU restatement, bit for bit
             from oracle import c_oracle as co15
-            c15 = np.ascontiguousarray(i15.get_centroids()); q15 = Q15[(5 % 4) * B:(5 % 4) * B + 2].cpu().numpy()
-            g_i, g_d, g_c = outs[0]["ids"][:2].cpu().numpy().astype(np.uint64), outs[0]["dst"][:2].cpu().numpy(), outs[0]["cnt"][:2].cpu().numpy()
+            c15 = np.ascontiguousarray(i15.get_centroids()); q15 = Q15[(5 % 4) * B:(5 % 4) * B + B].cpu().numpy()
+            g_i, g_d, g_c = outs[0]["ids"].cpu().numpy().astype(np.uint64), outs[0]["dst"].cpu().numpy(), outs[0]["cnt"].cpu().numpy()
             ok15 = True
-            for qi in range(2):
+            pick15 = sorted(set(np.linspace(0, B - 1, min(B, 32)).astype(int).tolist()))
+            e15["queries_compared_bitwise"] = len(pick15)
+            for qi in pick15:
                 ranked, _ = co15.search_exhaustive(c15, q15[qi], nl15)
                 lists15 = [i15.get_list(int(c_)) for c_ in ranked[:np15]]
                 vals = np.concatenate([r_[0] for r_ in lists15]); vid = np.concatenate([r_[1] for r_ in lists15])
@@ -881,7 +885,7 @@ def main():
         if "batch_sweep" in extra:
             for bsz, (ki_, kd_, kc_) in sweep_keep.items():
                 okb = True
-                for qi in sorted({0, bsz - 1}):
+                for qi in sorted(set(np.linspace(0, bsz - 1, min(bsz, 8)).astype(int).tolist())):   # (up to 8 queries spread over the kept batch)
                     q = np.ascontiguousarray(qh[qi])
                     _, gi_, gd_ = run_one(q, sub_index(q))
                     okb &= bool(kc_[qi] == len(gi_) and np.array_equal(gi_, ki_[qi, :len(gi_)]) and np.array_equal(gd_.view(np.uint32), kd_[qi, :len(gd_)].view(np.uint32)))

@@ -39,7 +39,7 @@ def test_bench_single_gpu_line():
     for key in ("coarse_gemm", "coarse_gemm_f32", "reference_mode", "list_scan_f32_rows", "memory", "batch_sweep", "d1536", "build_index_phases_ms"):  # (kmeans_assign: matrix-core builds only)
         assert key in ex, (key, sorted(ex))
     assert all(v["gpu_matches_cpu_bitwise"] for v in ex["batch_sweep"]["by_batch"].values()) and ex["d1536"]["gpu_matches_cpu_bitwise"] is True
-    assert "prescan_kernel_g<true, 16>" in ex["d1536"]["list_scan"] and out["row_operand"]
+    assert "prescan_kernel_g<true, 32, IvfSrc<32>, LO = false>" in ex["d1536"]["list_scan"] and ex["d1536"]["queries_compared_bitwise"] >= 2 and out["row_operand"]
     assert ex["coarse_gemm"]["us"] > 0 and ex["coarse_gemm_f32"]["us"] > 0 and ex["single_query"]["end_to_end_us"] > 0
 
 

@@ -123,3 +123,38 @@ def test_more_near_ties_than_a_candidate_list_holds():
         oi, od = co.search_nprobe(ix.values, ix.centroids, ix.ids, Q[qi], top_k, 4)
         assert cnt[qi] == len(oi) and np.array_equal(ids[qi, :len(oi)], oi) and np.array_equal(bits(dist[qi, :len(oi)]), bits(od)), qi
     ix.close()
+
+
+def test_hi_only_query_block_every_val_inside_its_bound_and_query_residuals_aligned_with_the_rows():
+    """d = 1536: the query block of the shadow scan is fp16 hi ONLY (round 5) and the certificate charges the query's measured
+    residual |q' - fp16(q')| (|x| + R).  Ordinary corpora first; then the adversarial one for THAT term: every element of the
+    scaled query -2q sits 0.49 ulp(fp16) off its fp16 value on the side of the rows' common sign pattern, so that q' - fp16(q') is
+    parallel to x~ and the Cauchy-Schwarz step is attained."""
+    n, d, k, b, top_k, nprobe = 2500, 1536, 8, 32, 10, 4
+    for kind in ("dist_c", "mixed_subnormal"):
+        X = corpus(kind, n, d, 0x920); Q = corpus(kind, b, d, 0x921)
+        ix = IVFFlatIndex.build_index(k, 1, 2, X, init_indices=mg.init_draws(0x920, 1, k, n))
+        w, nv = worst_ratio(ix, X, Q, 0, top_k, nprobe, range(0, b, 8))
+        assert ix.last_vals(0)[3]["shadow"] == 2, "d = 1536 on the shadow should run hi-only query blocks"
+        print(f"hi-only query block, {kind:16s}: worst |val - exact| / bound = {w:.4f} over {nv} dumped vals")
+        assert w <= 1.0, (kind, w)
+        ix.close()
+    rng = np.random.default_rng(0x5AE)
+    sgn = rng.choice([-1.0, 1.0], d).astype(np.float32)
+    # rows: exactly representable in fp16 (no shadow residual of their own), all along sgn, |x| ~ 1
+    X = (sgn[None, :] * (0.015625 + rng.integers(0, 1024, (n, d)) * 2.0 ** -16)).astype(np.float32)      # fp16 values in [2^-6, 2^-5)
+    assert np.array_equal(X.astype(np.float16).astype(np.float32), X)
+    # queries: -2 q = -(fp16 value in [2^-5, 2^-4)) * sgn - 0.49 ulp * sgn  ->  the residual of q' is -0.49 ulp * sgn: parallel to every row
+    hq = (0.03125 + rng.integers(0, 1024, (b, d)) * 2.0 ** -15).astype(np.float32)
+    Qp = (-(hq + np.float32(0.49 * 2.0 ** -15)) * sgn[None, :]).astype(np.float32)
+    Q = (Qp / np.float32(-2.0)).astype(np.float32)
+    assert np.array_equal((np.float32(-2.0) * Q), Qp) and not np.any((Qp.astype(np.float16).astype(np.float32)) == Qp)
+    ix = IVFFlatIndex.build_index(k, 1, 2, X, init_indices=mg.init_draws(0x5AE, 1, k, n))
+    w, nv = worst_ratio(ix, X, Q, 0, top_k, k, range(0, b, 6))
+    print(f"aligned query residuals (hi-only block): worst |val - exact| / bound = {w:.4f} over {nv} vals")
+    assert 0.3 < w <= 1.0, w
+    ids, dist, cnt = ix.search_batch(Q, top_k, k)
+    for qi in range(0, b, 5):
+        oi, od = co.search_nprobe(ix.values, ix.centroids, ix.ids, Q[qi], top_k, k)
+        assert np.array_equal(ids[qi, :len(oi)], oi) and np.array_equal(bits(dist[qi, :len(oi)]), bits(od))
+    ix.close()

@@ -34,7 +34,9 @@ total = 0
 for seed, n, d, k, b, nprobe, top_ks in [(0x81, 9000, 96, 48, 160, 8, (1, 10, 26, 54)), (0x82, 5000, 300, 32, 96, 6, (10,)),
                                          (0x83, 3000, 768, 24, 80, 5, (10, 20)),
                                          # d = 1152: the 32-query block just fits LDS; d = 1536: it does not -- the NARROW variant's 16 queries do
+                                         # (round 5, fp16 shadow: 32 queries with the query block as fp16 hi ONLY up to d = 2304, 16 up to d = 4608)
                                          (0x84, 1500, 1152, 12, 64, 4, (10,)), (0x85, 1200, 1536, 12, 64, 4, (10,)), (0x87, 900, 2304, 8, 40, 3, (10,)),
+                                         (0x88, 700, 3072, 6, 36, 3, (10,)), (0x89, 500, 4608, 5, 24, 2, (10,)),
                                          # a small batch over many lists: < 2 queries per list (round 3: one ordered-chain scan per (query, list) pair)
                                          (0x86, 6000, 64, 96, 12, 6, (10, 30))]:
     X = dg.dist_c(seed, n, d, 4 * k, dg.default_sigma(d))
@@ -44,7 +46,8 @@ for seed, n, d, k, b, nprobe, top_ks in [(0x81, 9000, 96, 48, 160, 8, (1, 10, 26
     for top_k in top_ks:
         check(ix, Q, top_k, nprobe)
         total += 1
-    if os.environ.get("VERS_PRESCAN", "1") != "0":   # every one of these shapes is inside the matrix-core scan's domain
+    in_domain = d <= 2304 or os.environ.get("VERS_SHADOW", "1") != "0"   # (f32 rows: d > 2304 stays on the ordered chains)
+    if os.environ.get("VERS_PRESCAN", "1") != "0" and in_domain:   # every one of these shapes is inside the matrix-core scan's domain
         assert ix.prescan_stats()["batches"] - b0 == len(top_ks), (seed, d, b, ix.prescan_stats()["batches"] - b0)
     if seed == 0x81:
         for i in range(70):  # add(): the new rows' norms are maintained incrementally; one list outgrows its slack
@@ -190,4 +193,16 @@ def test_narrow_query_blocks_are_bit_exact():
     out = run({"VERS_PRE_NARROW": "1", "VERS_SHADOW": "0"})
     assert out["TIES"][0] == 1 and out["TIES"][1] > 0 and out["HUGE"] == (1, 64) and out["ONE"] == (1,) and out["BIG"] == (0,)
     out = run({"VERS_PRE_NARROW": "1", "VERS_PRESCAN": "2"})
+    assert out["TIES"] == (1, 64)
+
+
+def test_hi_only_query_blocks_are_bit_exact():
+    """VERS_PRE_HI_ONLY=1: the fp16 shadow scan with the query block as fp16 hi only (prescan_kernel_g<.., LO = false>: what
+    1152 < d <= 2304 take with 32 queries per block and d <= 4608 with 16) at EVERY d, wide and narrow blocks, and with every
+    certificate forced to fail; the certificate charges the query's measured fp16 residual."""
+    out = run({"VERS_PRE_HI_ONLY": "1"})
+    assert out["TIES"][0] == 1 and out["TIES"][1] > 0 and out["HUGE"] == (1, 64) and out["ONE"] == (1,) and out["TEN"][0] >= 10 and out["SLACK"] == (0,)
+    out = run({"VERS_PRE_HI_ONLY": "1", "VERS_PRE_NARROW": "1"})
+    assert out["TIES"][0] == 1 and out["TIES"][1] > 0 and out["HUGE"] == (1, 64) and out["ONE"] == (1,) and out["TEN"][0] >= 10
+    out = run({"VERS_PRE_HI_ONLY": "1", "VERS_PRESCAN": "2"})
     assert out["TIES"] == (1, 64)

@@ -27,7 +27,8 @@ struct RescoreArgs {
   const uint32_t* qflags;  // [b*P], slot q*P
   int metric;              // 0 squared L2, 1 cosine distance 1 - dot (the exact chains and the bound follow it)
   int force_fail;          // testing: nothing certifies
-  int shadow;              // the vals came from the fp16 shadow: the bound grows by its measured residual (xmax2_bits[2])
+  int shadow;              // the vals came from the fp16 shadow: the bound grows by its measured residual (xmax2_bits[2]); 2 = and the query block
+                           // was fp16 hi ONLY: the query's own residual |q' - fp16(q')|, summed here next to |q|^2, is charged too (pre_bound)
   uint32_t debug;          // diagnosis (VERS_SCAN_DEBUG): 512 skip the row gather + chains, 1024 merge only 1/8 of the slots
   uint32_t* fail_list;     // [b] out: queries to redo exactly, [b] = their count
   uint32_t* stats;         // [0] += failed queries
@@ -123,7 +124,7 @@ inline size_t rescore_lds_bytes(uint32_t ld, bool stage_rows) {  // the query; t
 static_assert((size_t)kRescoreWaves * 2 * staged_lds_floats(8) * sizeof(float) >= (size_t)kRescoreWaves * kWave * sizeof(uint64_t), "exchange area");
 __global__ __launch_bounds__(kWave * kRescoreWaves) __attribute__((amdgpu_waves_per_eu(8, 8))) void ivf_rescore_kernel(RescoreArgs a, int stage_rows) {
   __shared__ uint32_t srow[kWave];
-  __shared__ float sred[kRescoreWaves];
+  __shared__ float sred[kRescoreWaves], sres[kRescoreWaves];
   __shared__ uint32_t s_failed, s_nsurv;
   extern __shared__ __attribute__((aligned(16))) float dyn[];  // the query, padded; then staged rows of pitch ld + 4
   float* qs = dyn;
@@ -143,11 +144,16 @@ __global__ __launch_bounds__(kWave * kRescoreWaves) __attribute__((amdgpu_waves_
   // everything that does not depend on the merge is requested up front
   const uint32_t flag0 = a.qflags[(uint64_t)q * a.P];
   const uint32_t xmax_bits = *a.xmax2_bits;
-  float qpart = 0.0f;
+  float qpart = 0.0f, rpart = 0.0f;
+  const float qscale = a.metric ? -1.0f : -2.0f;  // (what prescan_kernel_g stages: exact scalings)
   for (uint32_t i = threadIdx.x; i < a.ld; i += blockDim.x) {
     const float v = qrow[i];
     qs[i] = v;
     qpart = __fadd_rn(qpart, __fmul_rn(v, v));  // |q|^2 in any order: the bound inflates it
+    if (a.shadow == 2) {  // the staged element's fp16 rounding error, exact in f32 (as x - fp16(x) in shadow_residual_kernel); overflow: inf / NaN
+      const float y = qscale * v, dl = y - (float)(_Float16)y;
+      rpart = __fadd_rn(rpart, __fmul_rn(dl, dl));
+    }
   }
   // wave 0 maps sequence numbers to storage rows twice (survivors, emitted keys): the per-probe operands it needs depend on the
   // query only -- requested here, two dependent round trips off the tail of the merge (P <= 64: a probe per lane)
@@ -187,9 +193,9 @@ __global__ __launch_bounds__(kWave * kRescoreWaves) __attribute__((amdgpu_waves_
     for (int u = 0; u < U; ++u) wave_merge_sorted64(list, cand[u], lane);
   }
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) qpart += __shfl_xor(qpart, off, kWave);
+  for (int off = 32; off > 0; off >>= 1) { qpart += __shfl_xor(qpart, off, kWave); rpart += __shfl_xor(rpart, off, kWave); }
   sh[wid][lane] = list;
-  if (lane == 0) sred[wid] = qpart;
+  if (lane == 0) { sred[wid] = qpart; sres[wid] = rpart; }
   __syncthreads();
   if ((wid & 1) == 0) wave_merge_sorted64(list, sh[wid + 1][lane], lane);
   if (wid == 2) sh[2][lane] = list;
@@ -202,10 +208,10 @@ __global__ __launch_bounds__(kWave * kRescoreWaves) __attribute__((amdgpu_waves_
     if (lane >= (int)a.kp) list = kKeyMax;  // (the networks keep 64 keys: the kp smallest are the candidates)
     const bool valid = lane < (int)a.kp && list != kKeyMax;
     const uint32_t cnt = (uint32_t)__popcll(__ballot(valid));
-    float qn = 0.0f;
-    for (int w = 0; w < kRescoreWaves; ++w) qn += sred[w];
+    float qn = 0.0f, rq = 0.0f;
+    for (int w = 0; w < kRescoreWaves; ++w) { qn += sred[w]; rq += sres[w]; }
     const PreBound pb = pre_bound((double)qn, (double)__uint_as_float(xmax_bits), a.shadow ? (double)__uint_as_float(a.xmax2_bits[2]) : 0.0, a.d_pad, a.metric,
-                                  a.shadow);
+                                  a.shadow, (double)rq);
     const float val = __uint_as_float(order_bits_to_f32_bits((uint32_t)(list >> 32)));
     const double e_mine = pb.of((double)val);  // this candidate's own bound (NaN / inf vals: NaN / inf, handled by the negated compares)
     bool certified = true;

@@ -442,6 +442,7 @@ struct SearchPlan {
   int QG = 1;                 // queries per group of the list scan (kPreQ with use_pre)
   bool use_pre = false;       // matrix-core list scan + exact finish (prescan.hip.h)
   bool use_shadow = false;    // ... on the fp16 shadow of the rows
+  bool pre_hi_only = false;   // ... with the query block as fp16 hi only (rows too long for hi + lo in LDS: prescan_kernel_g<.., LO = false>)
   int pre_mode = 1;           // VERS_PRESCAN
   uint32_t kp = 0;            // candidate keys per partial list of the matrix-core scan (top_k + slack)
   uint32_t k_keep = 0;        // keys per partial slot

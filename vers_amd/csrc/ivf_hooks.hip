@@ -188,7 +188,15 @@ int32_t vers_ivf_test_last_vals(vers_ivf_t* h, uint32_t q, uint64_t* out_vec_ids
   for (uint32_t j = 0; j < h->ldq; ++j) qn += (double)qrow[j] * (double)qrow[j];
   float xmax2, r2;
   memcpy(&xmax2, &misc[0], 4); memcpy(&r2, &misc[2], 4);
-  const PreBound pb = pre_bound(qn, (double)xmax2, lp.shadow ? (double)r2 : 0.0, h->ld, h->metric, lp.shadow);
+  double rq2 = 0.0;  // hi-only query blocks: the query's squared fp16 residual as the exact finish sums it (pre_bound)
+  if (lp.shadow == 2) {
+    const float qscale = h->metric ? -1.0f : -2.0f;
+    for (uint32_t j = 0; j < h->ldq; ++j) {
+      const float y = qscale * qrow[j], dl = y - (float)(_Float16)y;
+      rq2 += (double)dl * (double)dl;
+    }
+  }
+  const PreBound pb = pre_bound(qn, (double)xmax2, lp.shadow ? (double)r2 : 0.0, h->ld, h->metric, lp.shadow, rq2);
   if (out_info) { out_info[0] = qn; out_info[1] = xmax2; out_info[2] = lp.shadow ? r2 : 0.0; out_info[3] = pb.global; out_info[4] = pb.common; out_info[5] = kp; out_info[6] = lp.shadow; out_info[7] = h->metric; }
   uint32_t n = 0;
   for (uint32_t j = 0; j < P; ++j) {

@@ -652,8 +652,21 @@ int32_t plan_search(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint32_t b
   // The block's query operand must fit LDS next to the candidate buffers: 32 queries up to d = 1152; the NARROW variant's 16 up
   // to d = 2304 (d = 1536 -- a dimension the reference's own bindings instantiate, vers-py/src/lib.rs:26-65 -- went to the
   // ordered-chain scan until round 4, ~3x slower).  VERS_PRE_NARROW=1 forces the narrow blocks (tests, A/B).
-  const uint32_t pre_nq = (!knobs().pre_narrow && prescan_lds_bytes_g(h->ld, kp, kPreQ) <= 160u * 1024u) ? (uint32_t)kPreQ
-                          : (prescan_lds_bytes_g(h->ld, kp, kPreQNarrow) <= 160u * 1024u ? (uint32_t)kPreQNarrow : 0u);
+  // Round 5: on the fp16 shadow a query block that does not fit with both halves of its fp16 hi + lo split drops the lo half
+  // (prescan_kernel_g<.., LO = false>): 32 queries per block up to d = 2304 -- at d = 1536 the 16-query blocks streamed every list
+  // probed by more than 16 queries once per extra group, 2.15x the union's bytes -- and 16 up to d = 4608; the certificate charges
+  // the query's measured fp16 residual instead (pre_bound).  VERS_PRE_HI_ONLY=1 forces it at every d (tests, A/B).
+  static const bool force_hi = [] { const char* e = getenv("VERS_PRE_HI_ONLY"); return e && atoi(e) != 0; }();
+  uint32_t pre_nq = 0;
+  bool pre_hi_only = false;
+  {
+    const bool narrow = knobs().pre_narrow;
+    auto fits = [&](uint32_t nq, bool hi) { return prescan_lds_bytes_g(h->ld, kp, nq, hi) <= 160u * 1024u; };
+    if (!narrow && !(force_hi && use_shadow) && fits(kPreQ, false)) pre_nq = kPreQ;
+    else if (!narrow && use_shadow && fits(kPreQ, true)) { pre_nq = kPreQ; pre_hi_only = true; }
+    else if (!(force_hi && use_shadow) && fits(kPreQNarrow, false)) pre_nq = kPreQNarrow;
+    else if (use_shadow && fits(kPreQNarrow, true)) { pre_nq = kPreQNarrow; pre_hi_only = true; }
+  }
   // Small batches too (round 3 required >= 2 queries per list on average and sent batch 8 .. 128 at nlist = 4096 to one
   // ordered-chain scan per (query, list) pair -- every list re-read per query, f32 rows): a list probed by ONE query of the batch
   // is still streamed from the half-size shadow at the chip's rate, and the staging of a mostly empty query block costs less
@@ -842,7 +855,7 @@ int32_t plan_search(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint32_t b
     VERS_HIP_TRY(hipGetLastError());
   }
   }  // batch planning
-  s.P = P; s.ref_mode = ref_mode; s.one1 = one1; s.QG = QG; s.use_pre = use_pre; s.use_shadow = use_shadow; s.pre_mode = pre_mode;
+  s.P = P; s.ref_mode = ref_mode; s.one1 = one1; s.QG = QG; s.use_pre = use_pre; s.use_shadow = use_shadow; s.pre_hi_only = use_pre && pre_hi_only; s.pre_mode = pre_mode;
   s.kp = kp; s.k_keep = k_keep; s.n_pass = n_pass; s.seg_rows = seg_rows; s.seg_target = seg_target; s.S_max = S_max;
   s.items_bound = items_bound; s.part_bytes = part_bytes;
   s.pj_list = pj_list; s.pj_pref = pj_pref; s.pj_take = pj_take; s.np = np; s.pj_nq = pj_nq; s.cnt = cnt; s.pair_off = pair_off;

@@ -271,7 +271,7 @@ int32_t launch_scan1(vers_ivf* h, const Scan1Args& a, uint32_t items_bound, hipS
 // the matrix-core list scan (prescan.hip.h); timed through the same event ring as launch_ivf_scan
 template <int NQ>
 int32_t launch_prescan(vers_ivf* h, const IvfSrc<NQ>& src, uint32_t items_bound, uint32_t kp, uint32_t* qflags, uint32_t* quad_ctr,
-                       bool shadow, hipStream_t st) {
+                       bool shadow, bool hi_only, hipStream_t st) {
   PreParams p;
   p.rows_bf = shadow ? h->rows_bf.as<uint16_t>() : nullptr;
   p.ld = h->ld;
@@ -290,8 +290,10 @@ int32_t launch_prescan(vers_ivf* h, const IvfSrc<NQ>& src, uint32_t items_bound,
     p.stamps = W->stamps.as<unsigned long long>();
   }
   p.next_quad = (p.debug & 32u) ? nullptr : quad_ctr;  // zeroed with the planning tables
-  const size_t lds = prescan_lds_bytes_g(h->ld, kp, NQ);
-  if (int32_t rc = shadow ? scan_prepare_launch(prescan_kernel_g<true, NQ, IvfSrc<NQ>>, lds) : scan_prepare_launch(prescan_kernel_g<false, NQ, IvfSrc<NQ>>, lds)) return rc;
+  hi_only = hi_only && shadow;
+  const size_t lds = prescan_lds_bytes_g(h->ld, kp, NQ, hi_only);
+  if (int32_t rc = hi_only ? scan_prepare_launch(prescan_kernel_g<true, NQ, IvfSrc<NQ>, false>, lds)
+                   : shadow ? scan_prepare_launch(prescan_kernel_g<true, NQ, IvfSrc<NQ>>, lds) : scan_prepare_launch(prescan_kernel_g<false, NQ, IvfSrc<NQ>>, lds)) return rc;
   uint32_t blocks = (items_bound + kWavesPerBlock - 1) / kWavesPerBlock;
   uint32_t per_cu = std::max<uint32_t>(1, std::min<uint32_t>(2, (uint32_t)((160u * 1024u) / lds)));  // 1 at d = 768 (measured: as fast as 2)
   if (knobs().pre_blocks_per_cu > 0) per_cu = (uint32_t)knobs().pre_blocks_per_cu;  // tuning knob
@@ -307,7 +309,8 @@ int32_t launch_prescan(vers_ivf* h, const IvfSrc<NQ>& src, uint32_t items_bound,
   }
   const uint32_t slot = (uint32_t)(W->ev_count % SearchWs::kEvRing);
   if (W->ev_on) VERS_HIP_TRY(hipEventRecord(W->ev0[slot], st));
-  if (shadow) hipLaunchKernelGGL((prescan_kernel_g<true, NQ, IvfSrc<NQ>>), dim3(blocks), dim3(kWave * kPreWavesG), lds, st, src, p);
+  if (hi_only) hipLaunchKernelGGL((prescan_kernel_g<true, NQ, IvfSrc<NQ>, false>), dim3(blocks), dim3(kWave * kPreWavesG), lds, st, src, p);
+  else if (shadow) hipLaunchKernelGGL((prescan_kernel_g<true, NQ, IvfSrc<NQ>>), dim3(blocks), dim3(kWave * kPreWavesG), lds, st, src, p);
   else hipLaunchKernelGGL((prescan_kernel_g<false, NQ, IvfSrc<NQ>>), dim3(blocks), dim3(kWave * kPreWavesG), lds, st, src, p);
   VERS_HIP_TRY(hipGetLastError());
   if (W->ev_on) {
@@ -332,7 +335,7 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
   if (int32_t rc = plan_search(h, q_dev, ldq_in, b, top_k, nprobe, st, s)) return rc;
   const uint32_t P = s.P, kp = s.kp, k_keep = s.k_keep, n_pass = s.n_pass, seg_rows = s.seg_rows, seg_target = s.seg_target, S_max = s.S_max;
   const int ref_mode = s.ref_mode, QG = s.QG, pre_mode = s.pre_mode;
-  const bool one1 = s.one1, use_pre = s.use_pre, use_shadow = s.use_shadow;
+  const bool one1 = s.one1, use_pre = s.use_pre, use_shadow = s.use_shadow, hi_only = s.pre_hi_only;
   const uint64_t items_bound = s.items_bound;
   const size_t part_bytes = s.part_bytes;
   uint32_t *const pj_list = s.pj_list, *const pj_pref = s.pj_pref, *const pj_take = s.pj_take, *const np = s.np, *const pj_nq = s.pj_nq;
@@ -361,14 +364,14 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
       if (int32_t rc2 = W->fb_ctr.reserve((2 * kFallbackBlocks + 1) * sizeof(uint32_t))) return rc2;
       VERS_HIP_TRY(hipMemsetAsync(W->fb_ctr.p, 0, (2 * kFallbackBlocks + 1) * sizeof(uint32_t), st));
     }
-    if (int32_t rc2 = QG == kPreQNarrow ? launch_prescan(h, src_n, (uint32_t)items_bound, kp, qflags, quad_ctr, use_shadow, st)
-                                        : launch_prescan(h, src, (uint32_t)items_bound, kp, qflags, quad_ctr, use_shadow, st)) return rc2;
+    if (int32_t rc2 = QG == kPreQNarrow ? launch_prescan(h, src_n, (uint32_t)items_bound, kp, qflags, quad_ctr, use_shadow, hi_only, st)
+                                        : launch_prescan(h, src, (uint32_t)items_bound, kp, qflags, quad_ctr, use_shadow, hi_only, st)) return rc2;
     if (int32_t rc2 = start_pending_ahead(h, st)) return rc2;  // the next batch's coarse quantiser: under this batch's exact finish
     RescoreArgs a;
     a.partials = W->partials.as<uint64_t>(); a.P = P; a.S_max = S_max; a.kp = kp; a.top_k = top_k; a.d_pad = h->ld;
     a.pj_list = pj_list; a.pj_pref = pj_pref; a.pj_nq = pj_nq; a.list_off = h->slot_off.as<uint32_t>(); a.row_ids = h->row_ids.as<uint32_t>();
     a.rows = h->rows.as<float>(); a.rows_rm = h->rows_rm.as<float>(); a.ld = h->ld; a.qp = qp; a.ldq = h->ldq; a.xmax2_bits = h->pre_misc.as<uint32_t>();
-    a.qflags = qflags; a.metric = h->metric; a.force_fail = pre_mode == 2; a.shadow = use_shadow ? 1 : 0; a.debug = scan_debug_flags(); a.fail_list = fail_list; a.stats = h->pre_misc.as<uint32_t>() + 1;
+    a.qflags = qflags; a.metric = h->metric; a.force_fail = pre_mode == 2; a.shadow = use_shadow ? (hi_only ? 2 : 1) : 0; a.debug = scan_debug_flags(); a.fail_list = fail_list; a.stats = h->pre_misc.as<uint32_t>() + 1;
     a.status = W->st_word(); a.out_ids = out_ids; a.out_dist = out_dist; a.out_count = out_count; a.out_keys = out_keys;
     a.stamps = (scan_debug_flags() & 16u) && W->stamps.p ? W->stamps.as<unsigned long long>() : nullptr;
     const int stage_rows = rescore_lds_bytes(h->ld, true) <= 144u * 1024u ? 1 : 0;
@@ -386,7 +389,7 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
                        use_shadow ? h->fail_watch : (uint32_t*)nullptr);
     VERS_HIP_TRY(hipGetLastError());
     W->last_pre.valid = true; W->last_pre.b = b; W->last_pre.P = P; W->last_pre.S_max = S_max; W->last_pre.kp = kp; W->last_pre.top_k = top_k;
-    W->last_pre.qp = qp; W->last_pre.shadow = use_shadow ? 1 : 0;
+    W->last_pre.qp = qp; W->last_pre.shadow = use_shadow ? (hi_only ? 2 : 1) : 0;
     if (use_shadow) h->shadow_queries += b;  // (fallback_kernel writes the running failure count to the pinned watch word)
     h->pre_batches += 1;
     W->tot_valid = true;

@@ -167,8 +167,10 @@ static_assert(kPreWavesG % 4 == 0 && kPreWavesG >= 4 && kPreWavesG <= 16, "a qua
 __host__ __device__ inline uint32_t pre_cap(uint32_t kp) { return kp <= 40u ? (uint32_t)VERS_PRE_CAP_SMALL : 128u; }
 // nq = queries per block: kPreQ (32), or 16 -- the NARROW variant for rows too long for a 32-query block (d = 1536: 196 KB
 // against the CU's 160 KB of LDS; 16 queries fit up to d = 2304).  Same kernel, same MFMA (half its query columns idle).
-inline size_t prescan_lds_bytes_g(uint32_t ld, uint32_t kp, uint32_t nq = 32) {  // query block | hand-out word | buffers | cnt, done, thr, locks
-  return (size_t)ld * nq * sizeof(float) + 16 + (size_t)nq * pre_cap(kp) * sizeof(uint64_t) + 6 * 32 * sizeof(uint32_t);  // (+ pair | sequence base of the quad's queries)
+// hi_only: the fp16 query block WITHOUT its lo half (2 B per element instead of 4): 32 queries fit up to d = 2304, 16 up to
+// d = 4608; the certificate charges the query's measured fp16 residual instead (pre_bound, Rq2).
+inline size_t prescan_lds_bytes_g(uint32_t ld, uint32_t kp, uint32_t nq = 32, bool hi_only = false) {  // query block | hand-out word | buffers | cnt, done, thr, locks
+  return (size_t)ld * nq * (hi_only ? sizeof(uint16_t) : sizeof(float)) + 16 + (size_t)nq * pre_cap(kp) * sizeof(uint64_t) + 6 * 32 * sizeof(uint32_t);  // (+ pair | sequence base of the quad's queries)
 }
 constexpr int kPreQNarrow = 16;
 
@@ -206,7 +208,12 @@ __device__ __forceinline__ uint64_t buffer_sorted(const uint64_t* bq, uint32_t n
 // by the (halved) HBM stream alone.  The accumulator layout differs from the f32 path's (16x16x1 in 4 blocks: a lane =
 // one of 16 query columns x 2 sets): here a lane holds query column lane & 31 and 16 of the 32 rows of a tile half h:
 // rows 32*h + 8*(e >> 2) + 4*(lane >> 5) + (e & 3).
-template <bool BF, int NQ, class Src, class Stage>
+// LO (fp16 shadow only): the query block carries the lo half of the hi + lo split (two MFMAs per piece).  LO = false: hi only --
+// half the LDS (32 queries per block up to d = 2304: rows that long were scanned by 16-query blocks until round 5, every list
+// probed by more than 16 queries streamed again per extra group: 2.15x the union's bytes at d = 1536) and half the MFMAs; what the
+// dropped half would have contributed, |<x~, q' - fp16(q')>| <= |x~| |q' - fp16(q')|, is charged to the certificate with the query's
+// MEASURED residual (ivf_rescore_kernel sums it next to |q|^2).
+template <bool BF, int NQ, bool LO, class Src, class Stage>
 __device__ __forceinline__ void prescan_item_g(const Src& src, const PreParams& p, uint32_t it, const ItemView<NQ>& v, int half, int lane,
                                                const float* qm, uint64_t* cbuf, uint32_t* ctl, Stage&& stage) {
   const uint32_t n_tiles = (v.nrows + kWave - 1) / kWave;
@@ -579,11 +586,13 @@ __device__ __forceinline__ void prescan_item_g(const Src& src, const PreParams& 
           const f16x8_t* ql = qh + (size_t)(p.ld / 16u) * kCb;
 #pragma unroll
           for (int cb = 0; cb < kLoads / 2; ++cb) {
-            const f16x8_t bh = qh[cb * kCb], bl = ql[cb * kCb];
+            const f16x8_t bh = qh[cb * kCb];
+            f16x8_t bl = bh;
+            if constexpr (LO) bl = ql[cb * kCb];
 #pragma unroll
             for (int hf = 0; hf < 2; ++hf) {
               const f16x8_t ar = __builtin_bit_cast(f16x8_t, buf[B][2 * cb + hf]);
-              acc[hf] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ar, bl, acc[hf], 0, 0, 0);  // (small term first)
+              if constexpr (LO) acc[hf] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ar, bl, acc[hf], 0, 0, 0);  // (small term first)
               acc[hf] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ar, bh, acc[hf], 0, 0, 0);
             }
           }
@@ -652,15 +661,17 @@ __device__ __forceinline__ void prescan_item_g(const Src& src, const PreParams& 
   if (stamp && lane == 0) atomicAdd(p.stamps + 11, __builtin_amdgcn_s_memtime() - te0);
 }
 
-template <bool BF, int NQ, class Src>
+template <bool BF, int NQ, class Src, bool LO = true>
 __global__ __launch_bounds__(kWave * kPreWavesG) __attribute__((amdgpu_waves_per_eu(kPreWpe, kPreWpe))) void prescan_kernel_g(Src src, PreParams p) {
   static_assert(NQ == kPreQ || NQ == kPreQNarrow, "32 queries per block, or the narrow variant's 16");
+  static_assert(BF || LO, "the hi-only query block belongs to the fp16 shadow");
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   extern __shared__ __attribute__((aligned(16))) float qlds[];
-  uint32_t* nq_lds = reinterpret_cast<uint32_t*>(qlds + (size_t)p.ld * NQ);
+  const size_t q_floats = LO ? (size_t)p.ld * NQ : (size_t)p.ld * NQ / 2;  // the query block: f32 / fp16 hi + lo (4 B per element), or fp16 hi only
+  uint32_t* nq_lds = reinterpret_cast<uint32_t*>(qlds + q_floats);
   const uint32_t cap = pre_cap(p.kp);
-  uint64_t* buf = reinterpret_cast<uint64_t*>(qlds + (size_t)p.ld * NQ + 4);  // [NQ queries][cap] candidate keys, shared by the 8 waves
+  uint64_t* buf = reinterpret_cast<uint64_t*>(qlds + q_floats + 4);  // [NQ queries][cap] candidate keys, shared by the 8 waves
   uint32_t* ctl = reinterpret_cast<uint32_t*>(buf + (size_t)NQ * cap);         // cnt | done | thr | locks, [32] each
   const uint32_t n_quads = src.n_items() / 4;
   const unsigned long long clk0 = (p.debug & 16u) ? __builtin_amdgcn_s_memtime() : 0ull;
@@ -764,7 +775,7 @@ __global__ __launch_bounds__(kWave * kPreWavesG) __attribute__((amdgpu_waves_per
           _Float16* qb = reinterpret_cast<_Float16*>(qlds);
           const uint32_t at = (((cg >> 2) * 2u + ((cg >> 1) & 1u)) * (uint32_t)NQ + slot) * 8u + (cg & 1u) * 4u;
           *reinterpret_cast<f16x4_t*>(qb + at) = hi;
-          *reinterpret_cast<f16x4_t*>(qb + (size_t)p.ld * NQ + at) = lo;
+          if constexpr (LO) *reinterpret_cast<f16x4_t*>(qb + (size_t)p.ld * NQ + at) = lo;
         } else {
           l4[cg * NQ + slot] = y;
         }
@@ -787,10 +798,10 @@ __global__ __launch_bounds__(kWave * kPreWavesG) __attribute__((amdgpu_waves_per
       }
     };
     if (cont) {  // same query block, same buffers: nothing to stage, nothing to wait for
-      prescan_item_g<BF, NQ>(src, p, it, v, wid >> 2, lane, qlds, buf, ctl, [] {});
+      prescan_item_g<BF, NQ, LO>(src, p, it, v, wid >> 2, lane, qlds, buf, ctl, [] {});
       run_last = bi;
     } else {
-      prescan_item_g<BF, NQ>(src, p, it, v, wid >> 2, lane, qlds, buf, ctl, stage);
+      prescan_item_g<BF, NQ, LO>(src, p, it, v, wid >> 2, lane, qlds, buf, ctl, stage);
       run_first = run_last = bi;
       cur_list = d0.list; cur_group = d0.group;
       prev_nq = v.nq;
@@ -835,7 +846,10 @@ struct PreBound {
     return common + chain_k * T;
   }
 };
-__host__ __device__ inline PreBound pre_bound(double qn, double xmax2, double R2, uint32_t d_pad, int metric, int shadow) {
+// shadow: 0 f32 rows | 1 fp16 shadow, query as fp16 hi + lo | 2 fp16 shadow, query as fp16 hi ONLY (Rq2 = the query's measured
+// squared residual |q' - fp16(q')|^2, q' = -2 q or -q as staged: the dropped half contributes |<x~, q' - hi>| <= |x~| sqrt(Rq2),
+// |x~| <= |x| + R; and the accumulation makes one pass over the columns instead of two)
+__host__ __device__ inline PreBound pre_bound(double qn, double xmax2, double R2, uint32_t d_pad, int metric, int shadow, double Rq2 = 0.0) {
   const double u = 5.9604644775390625e-08, d = (double)d_pad;
   const double qnU = qn * (1.0 + 2.0 * d * u);  // |q|^2 from its rounded sum
   const double S = qnU + xmax2 + (metric ? 1.0 : 0.0);
@@ -844,11 +858,12 @@ __host__ __device__ inline PreBound pre_bound(double qn, double xmax2, double R2
   b.metric = metric;
   double sh = 0.0;
   if (shadow) sh = 1.01 * (2.0 * __builtin_sqrt(R2) * qm + 4.76837158203125e-07 * xm * qm + 5.9604644775390625e-08 * __builtin_sqrt(d) * xm);
+  if (shadow == 2) sh += 1.01 * __builtin_sqrt(Rq2 * (1.0 + 2.0 * d * u)) * (xm + __builtin_sqrt(R2));  // (NaN / inf residual: no certificate holds)
   // the round-2 bound, kept for rows outside the list and for the cosine distance: (5 d + 32) u S (+ shadow)
   b.global = (5.0 * d + 32.0) * u * S * (shadow ? 1.01 : 1.0) + sh;
   // (2) (d + 1) u (max|x|^2 + |q|^2)   (3) d u |x| |2 q| (the hi + lo split doubles the accumulation steps, not the partial sums' size:
   // 2 d roundings of u |x||q'| / ... kept at the model's 2 d u |x||q| per pass: x 2 with the shadow)   (4) 16 u S
-  const double mf = (shadow ? 2.0 : 1.0) * 2.0 * d * u * xm * qm;
+  const double mf = (shadow == 1 ? 2.0 : 1.0) * 2.0 * d * u * xm * qm;
   b.common = ((d + 1.0) * u * (xmax2 + qnU) + mf + 16.0 * u * S) * 1.01 + sh;
   b.chain_k = (d + 3.0) * u;
   b.offset = qnU;
