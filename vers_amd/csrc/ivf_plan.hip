@@ -634,6 +634,10 @@ int32_t plan_search(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint32_t b
   // once per group, so pick the width from the expected queries per list
   int QG = (b == 1 || pairs_est < 2 * lists_est) ? 1 : (pairs_est >= 6 * lists_est ? 16 : 8);
   if (QG != 1 && (knobs().qg == 8 || knobs().qg == 16)) QG = knobs().qg;  // tuning knob
+  // The ordered-chain kernels stage a group's queries in LDS (QG x ld floats): rows too long for a group of 16 take 8, then one
+  // query per item (scalar operands: no LDS at all) -- the reference has no dimension cap (ivfflat.rs:153), neither has this path
+  // (round 4 returned "vector dimension too large" at d > 2560 with 16-query groups).
+  while (QG > 1 && scan_lds_bytes(QG, h->ld) > 160u * 1024u) QG = QG == 16 ? 8 : 1;
   // Batches in nprobe mode: the list scan runs on the matrix cores with an exact finish (prescan.hip.h); same bits.
   // VERS_PRESCAN=0 keeps the ordered-chain scan, =2 makes every certificate fail (exercises the exact fallback).
   const int pre_mode = knobs().pre_mode;
