@@ -652,7 +652,12 @@ def main():
         X15 = torch.empty(n15, d15, dtype=torch.float32, device=dev)
         capi.gen_rows_dev(X15.data_ptr(), n15, d15, d15, 1, SEED_X + 0x1536, SEED_C, args.modes_per_list * nl15, float(dg.default_sigma(d15)))
         i15 = IVFFlatIndex(d15, device=dev_index)
-        init15 = (dg.mix64(np.uint64(0xB15) + np.arange(nl15, dtype=np.uint64)) % np.uint64(n15)).astype(np.uint64)
+        # init draws: one row out of every n15 / nl15, i.e. nl15 DISTINCT modes of the generator (row i belongs to mode i % n_modes).
+        # (Round 4 drew mix64(0xB15 + c) % n15: a few draws fell into the same mode, their clusters ran empty, the reference's
+        # update_centroids turns an empty cluster into the ZERO vector (ivfflat.rs:62-66) and that centroid -- at distance 1 from every
+        # unit vector, nearer than any unrelated mode -- collected 47 k rows and was probed by all 1024 queries of a batch: 32 query
+        # groups streaming one list, streamed / union rows 1.5-2.2.  The headline's own draws give lists of 917 .. 4604 rows; so do these.)
+        init15 = (np.arange(nl15, dtype=np.uint64) * np.uint64(max(1, n15 // nl15))).astype(np.uint64)
         t0 = time.perf_counter(); i15.build_dev(X15.data_ptr(), n15, nl15, 1, args.kmeans_iters, init15); t_b15 = time.perf_counter() - t0
         del X15
         torch.cuda.empty_cache()

@@ -113,27 +113,24 @@ def cfg4_rank(dev_index=0, rows=100_000_000, d=768, nlist=16384, rank=0, world=8
     max_s = max(streams)
     part_s = [torch.empty(2, B, top_k, dtype=torch.int64, device=dev) for _ in range(max_s)]
     res_s = [(torch.zeros(B, top_k, dtype=torch.int64, device=dev), torch.zeros(B, top_k, device=dev), torch.zeros(B, dtype=torch.int32, device=dev)) for _ in range(max_s)]
-    gat = None
-    if exchange:
-        try:
-            from vers_amd import rccl
-            gat = rccl.RcclComm(rccl.RcclComm.unique_id(), 0, 1, dev_index)
-        except Exception as e:  # (no RCCL adapter: the step is then the partial search + merge)
-            log(f"[cfg4_rank] no one-rank RCCL communicator ({e}): exchange launch left out of the step")
+    # The step is ONE library call per batch (vers_ivf_search_sharded_dev: partial search -> exchange on the batch's stream -> merge of
+    # `world` partials) and the exchange is the STAND-IN WITH RCCL's FOOTPRINT (vers_test_standin_gather: 32 workgroups x 512 threads x
+    # 256 VGPRs + 37,664 B of LDS, resident for 25 us, writing `world` partials) -- what the real all-gather needs of the chip while the
+    # peers' bytes travel; the peers themselves need the other GPUs.
+    sg = None
+    if exchange and world > 1:
+        from vers_amd import rccl as vrccl   # (the struct definition only: no RCCL call is made)
+        sg = vrccl.VersGather()
+        capi.check(capi.lib().vers_test_standin_gather(C.cast(C.byref(sg), capi._vp), rank, world, 32, 25, 512, 37664))
+    gp = C.cast(C.byref(sg), capi._vp) if sg is not None else None
     stream_objs = [torch.cuda.Stream(device=dev) for _ in range(max_s)]
     step_ms, scan_us = {}, {}
     for NS in streams:
         sts = [torch.cuda.current_stream(dev).cuda_stream] if NS == 1 else [so.cuda_stream for so in stream_objs[:NS]]
-        allp_s = [torch.zeros(world, 2, B, top_k, dtype=torch.int64, device=dev) for _ in range(NS)]
 
         def step(i):
             s = i % NS
-            ix.search_partial_dev(Q[(i % NQB) * B:].data_ptr(), ld, B, top_k, nprobe, part_s[s][0].data_ptr(), part_s[s][1].data_ptr(), sts[s])
-            if gat is not None:  # the exchange's launch: a one-rank ncclAllGather of this rank's partial on the batch's stream
-                g = gat._gather
-                assert g.all_gather_async(g.ctx, part_s[s].data_ptr(), allp_s[s].data_ptr(), 2 * B * top_k * 8, sts[s]) == 0
-            IVFFlatIndex.merge_partials_dev(allp_s[s].data_ptr(), allp_s[s].data_ptr() + 8 * B * top_k, 2 * B * top_k, world, B, top_k, nprobe,
-                                            res_s[s][0].data_ptr(), res_s[s][1].data_ptr(), res_s[s][2].data_ptr(), sts[s])
+            ix.search_sharded_dev(gp, Q[(i % NQB) * B:].data_ptr(), ld, B, top_k, nprobe, res_s[s][0].data_ptr(), res_s[s][1].data_ptr(), res_s[s][2].data_ptr(), sts[s])
         for i in range(5):
             step(i)
         torch.cuda.synchronize(); ix.scan_times(reset=True); t0 = time.perf_counter()
@@ -160,7 +157,7 @@ def cfg4_rank(dev_index=0, rows=100_000_000, d=768, nlist=16384, rank=0, world=8
                      "list_scan_alone_ms": round(scan_ms, 4), "probed_rows_union": int(np.mean(ur)), "algorithmic_bytes": int(by),
                      "list_scan_frac_of_8TBs": round(by / (scan_ms / 1e3) / 8e12, 4), "row_operand": "fp16 shadow" if shadow else "f32 rows",
                      "rescanned_queries": int(pst["fallback_queries"]), "matrix_core_batches": int(pst["batches"]),
-                     "step_includes": "partial search + " + ("one-rank ncclAllGather launch + " if gat is not None else "") + f"merge of {world} partials"}
+                     "step_includes": "vers_ivf_search_sharded_dev: partial search + " + ("exchange stand-in with RCCL's footprint (32 x 512 threads x 256 VGPRs, 37,664 B LDS, 25 us) + " if sg is not None else "") + f"merge of {world} partials"}
     log(f"[cfg4_rank] step {step_ms} ms; list scan alone {scan_ms:.3f} ms = {out['search']['list_scan_frac_of_8TBs']} of peak on {_gb(by)} GB; re-scanned queries {pst['fallback_queries']}")
     # ---- 5. GPU == CPU restatement, bit for bit, over the rank's own sub-index ---------------------------------------------------------
     if check:
