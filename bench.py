@@ -642,6 +642,29 @@ def main():
             sweep_keep[bsz] = (ki.cpu().numpy().astype(np.uint64), kd.cpu().numpy(), kc.cpu().numpy())
         extra["batch_sweep"] = {"workload": f"the headline's index and queries at other batch sizes, {S} batches in flight, nprobe={nprobe} top_k={top_k}", "by_batch": sweep}
         log("[bench] batch sweep: " + ", ".join(f"{k_}: {v_['queries_per_sec'] / 1e3:.1f} k q/s ({v_['us_per_batch']} us)" for k_, v_ in sweep.items()))
+        # (a2b) the EDGES of the fast domain on the headline's index (the reference has no caps: ivfflat.rs:153): wider results than a
+        # candidate list holds (top_k > 58: ordered chains, 64 ranks per pass), more probes than a key per lane (nprobe > 64) and
+        # batches of 2 - 3 (below pre_min_batch: one ordered-chain scan per (query, list) pair).  Correctness of these shapes is
+        # tests/test_limits_gpu.py's; here: what they cost.
+        edges = {}
+        for name, (bsz, tk, npb) in {"top_k_64": (min(B, 256), 64, nprobe), "top_k_100": (min(B, 256), 100, nprobe), "nprobe_128": (min(B, 256), top_k, min(128, nlist)),
+                                      "batch_2": (2, top_k, nprobe), "batch_3": (3, top_k, nprobe)}.items():
+            if bsz > B or npb < 1:
+                continue
+            ei = torch.zeros(bsz, tk, dtype=torch.int64, device=dev); ed = torch.zeros(bsz, tk, device=dev); ec = torch.zeros(bsz, dtype=torch.int32, device=dev)
+            def ed_step(i, bsz=bsz, tk=tk, npb=npb):
+                index.search_dev(Q[(i * bsz) % (n_batches * B - bsz + 1):].data_ptr(), ld, bsz, tk, npb, ei.data_ptr(), ed.data_ptr(), ec.data_ptr(), st)
+            for i in range(2):
+                ed_step(i)
+            torch.cuda.synchronize(); pb0 = index.prescan_stats()["batches"]; nst = 6 if bsz > 3 else 30; t0 = time.perf_counter()
+            for i in range(nst):
+                ed_step(2 + i)
+            torch.cuda.synchronize(); dt_ = (time.perf_counter() - t0) / nst
+            index.poll(st)
+            edges[name] = {"batch": bsz, "top_k": tk, "nprobe": npb, "us_per_batch": round(dt_ * 1e6, 1), "queries_per_sec": round(bsz / dt_, 1),
+                           "list_scan": "matrix cores + exact finish" if index.prescan_stats()["batches"] - pb0 == nst else "ordered chains"}
+        extra["domain_edges"] = {"workload": "the headline's index, one batch in flight; shapes at and beyond the matrix-core scan's domain (top_k <= 58, nprobe <= 64, batch >= 4)", "by_shape": edges}
+        log("[bench] domain edges: " + ", ".join(f"{k_}: {v_['queries_per_sec'] / 1e3:.1f} k q/s ({v_['list_scan']})" for k_, v_ in edges.items()))
         # (a3) d = 1536 -- a dimension the reference's own bindings instantiate (vers-py/src/lib.rs:26-65).  A 32-query block with both
         # halves of the query's fp16 hi + lo split does not fit LDS there (196 KB); round 4 ran 16-query blocks (every list probed by
         # more than 16 queries streamed once per extra group: streamed / union rows 2.15, 0.37 of the HBM roofline); round 5 keeps 32
