@@ -392,31 +392,25 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2
   // waits and a copy of the 64 accumulator registers per step).
   const uint32_t k_tiles = K / kGemmBK, k_last = K - kGemmBK;
   auto kclamp = [&](uint32_t t) { const uint32_t k0 = t * kGemmBK; return k0 < k_last ? k0 : k_last; };
-#ifndef VERS_X3_ABLATE
-#define VERS_X3_ABLATE 0  // timing experiments (results are WRONG with any bit set): 1 no LDS stores in the loop, 2 no global loads in the
-#endif                    // loop, 4 no epilogue, 8 half the K-tiles
-  constexpr int kAbl = VERS_X3_ABLATE;
   gload(S0{}, 0);
   gload(S1{}, kclamp(1));
   lstore(S0{}, 0);
   gload(S0{}, kclamp(2));
   __syncthreads();
-  for (uint32_t t = 0; t < ((kAbl & 8) ? k_tiles / 2 : k_tiles); t += 2) {
+  for (uint32_t t = 0; t < k_tiles; t += 2) {
     // even tile t: LDS buffer 0; registers: slot 1 = tile t+1, slot 0 = tile t+2
-    if (!(kAbl & 1)) lstore(S1{}, 1);             // tile t+1 -> buffer 1 (its readers finished before the last barrier)
-    if (!(kAbl & 2)) gload(S1{}, kclamp(t + 3));
+    lstore(S1{}, 1);             // tile t+1 -> buffer 1 (its readers finished before the last barrier)
+    gload(S1{}, kclamp(t + 3));
     compute(0);
     __syncthreads();
     // odd tile t+1: LDS buffer 1; registers: slot 0 = tile t+2, slot 1 = tile t+3
-    if (!(kAbl & 1)) lstore(S0{}, 0);
-    if (!(kAbl & 2)) gload(S0{}, kclamp(t + 4));
+    lstore(S0{}, 0);
+    gload(S0{}, kclamp(t + 4));
     compute(1);
     __syncthreads();
   }
   __syncthreads();  // (the epilogue re-uses the operand storage)
-  if (!(kAbl & 4) || NORM_ROWS)
-    gemm_epilogue<NORM_ROWS>(acc, reinterpret_cast<float*>(T), cnorm, N_pad, G, metric, k_rows, part_v1, part_c1, part_v2, m0, n0, wr, wc, r, hh);
-  else if (acc[0][0][0] == 12345.678f) G[0] = acc[1][1][3];  // (keeps the accumulators alive)
+  gemm_epilogue<NORM_ROWS>(acc, reinterpret_cast<float*>(T), cnorm, N_pad, G, metric, k_rows, part_v1, part_c1, part_v2, m0, n0, wr, wc, r, hh);
 }
 
 // ---- the assign contraction on 256 x 256 block tiles ---------------------------------------------------------------------
@@ -431,16 +425,19 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2
 // The coarse quantiser (1024 x 4096) would be 64 such blocks on 256 CUs and stays on the 128 x 128 tiles.
 constexpr int kGemmWide = 256;
 constexpr size_t kX3WLdsBytes = 2 * 2 * 2 * (size_t)kGemmWide * kX3Pitch * 2;  // two buffers x A|B x hi|lo = 128 KB
-// SCHED = 1: the tile step is written as  fragment reads -> [MFMAs with the SPLIT of the next tile's point operand between
-// them] x 2 k-steps -> LDS stores of the next tile -> global loads -> barrier,  with scheduling groups that ask for one MFMA
-// followed by two VALU instructions: the split's conversions issue in the shadow of the matrix cores (a wave cannot issue its
-// next MFMA for ~28 cycles anyway) instead of in a phase of their own in which -- the eight waves of the block moving in
-// lockstep -- the matrix cores idle.  SCHED = 0 is the plain order (stores of tile t + 1, loads of t + 2, compute t).
+// The tile step:  fragment reads -> [MFMAs with the SPLIT of the next tile's point operand between them] x 2 k-steps, with
+// scheduling groups that ask for one MFMA followed by two VALU instructions -- the split's conversions issue in the shadow of
+// the matrix cores (a wave cannot issue its next MFMA for ~28 cycles anyway) instead of in a phase of their own in which, the
+// eight waves of the block moving in lockstep, the matrix cores idle -- and the next-but-one tile's pieces requested as soon as
+// their staging registers are free.  (The template parameter is what is left of rounds 3-4's schedule variants -- plain order,
+// interleaved, both operands pre-split by LDS-DMA / through registers: DESIGN.md Appendix A and the history of this file; the
+// instantiation keeps the kernel's name in the committed profiles.)
 template <int SCHED>
 static __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void dist_gemm_x3w_kernel(
     const float* __restrict__ X, const __bf16* __restrict__ Ch, const __bf16* __restrict__ Cl, const float* __restrict__ cnorm, uint32_t K,
     uint32_t N_pad, int metric, uint32_t m_tiles, uint32_t n_tiles, uint32_t grp, uint32_t k_rows, float* __restrict__ part_v1,
-    uint32_t* __restrict__ part_c1, float* __restrict__ part_v2, const __bf16* __restrict__ Xh = nullptr, const __bf16* __restrict__ Xl = nullptr) {
+    uint32_t* __restrict__ part_c1, float* __restrict__ part_v2) {
+  static_assert(SCHED == 2, "one schedule is shipped");
   extern __shared__ __attribute__((aligned(16))) __bf16 T[];
   constexpr int kPart = kGemmWide * kX3Pitch;
   auto Tp = [&](int buf, int mat, int part) { return T + ((buf * 2 + mat) * 2 + part) * kPart; };
@@ -495,177 +492,18 @@ static __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2
     }
   };
   const int r = lane & 31, hh = lane >> 5;
-  auto compute = [&](int buf) {
-#pragma unroll
-    for (int s2 = 0; s2 < 2; ++s2) {  // two k-steps of 16
-      const int ko = x3_chunk(r, 2 * s2 + hh);  // (row offsets that are multiples of 32 do not change (row >> 2) & 3)
-      bf16x8 ah[2], al[2], bh[4], bl[4];
-#pragma unroll
-      for (int t = 0; t < 2; ++t) {
-        ah[t] = *reinterpret_cast<const bf16x8*>(Tp(buf, 0, 0) + (wr * 64 + t * 32 + r) * kX3Pitch + ko);
-        al[t] = *reinterpret_cast<const bf16x8*>(Tp(buf, 0, 1) + (wr * 64 + t * 32 + r) * kX3Pitch + ko);
-      }
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-        bh[t] = *reinterpret_cast<const bf16x8*>(Tp(buf, 1, 0) + (wc * 128 + t * 32 + r) * kX3Pitch + ko);
-        bl[t] = *reinterpret_cast<const bf16x8*>(Tp(buf, 1, 1) + (wc * 128 + t * 32 + r) * kX3Pitch + ko);
-      }
-#pragma unroll
-      for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a], bh[b], acc[a][b], 0, 0, 0);  // small terms first
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bl[b], acc[a][b], 0, 0, 0);
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bh[b], acc[a][b], 0, 0, 0);
-        }
-    }
-  };
   // tile t is computed out of LDS buffer t & 1 while the registers bring tile t + 2 in; past the end the prefetch re-reads the
   // last tile and the store goes to a buffer nobody reads any more (no branches around loads: the compiler's counted waits)
   const uint32_t k_tiles = K / kGemmBK, k_last = K - kGemmBK;
   auto kclamp = [&](uint32_t t) { const uint32_t k0 = t * kGemmBK; return k0 < k_last ? k0 : k_last; };
-  if constexpr (SCHED != 3 && SCHED != 4) {
-    gload(0);
-    lstore(0);
-    gload(kclamp(1));
-    __syncthreads();
-  }
-  if constexpr (SCHED == 0) {
-    for (uint32_t t = 0; t < k_tiles; ++t) {
-      lstore((int)((t + 1) & 1));  // tile t + 1 (its buffer's readers finished before the last barrier)
-      gload(kclamp(t + 2));
-      compute((int)(t & 1));
-      __syncthreads();
-    }
-  } else if constexpr (SCHED == 3) {
-    // BOTH operands pre-split into bf16 hi | lo in global memory (the points by split_bf16_kernel, per batch) and brought in by
-    // LDS-DMA (`global_load_lds_dwordx4`: 64 lanes x 16 bytes = 1 KB of LDS per instruction, no register in between): no split
-    // arithmetic, no LDS store instruction and no staging register in the loop.  Ablation of SCHED = 2 (round 4, VERS_X3W_ABLATE,
-    // same box, 362 algorithmic TFLOP/s): without its LDS stores 457, without the split's conversions 421, without its global
-    // loads 400, without the second k-step's fragment reads 364, without the barrier 367 -- the VGPR -> LDS store path and the
-    // conversions, not the fragment reads or the barrier, are what the matrix cores wait for.
-    // A K-tile is 64 pieces of 1 KB (A | B x hi | lo x 16 pieces of 16 rows): wave w brings pieces 8 w .. 8 w + 7 -- one matrix
-    // and part, rows 128 (w & 1) + 16 i + lane / 4; a lane's 16 bytes are the row's chunk (lane & 3) ^ ((row >> 2) & 3): the
-    // swizzle of x3_chunk on the SOURCE side, the LDS image linear per instruction.  (row >> 2) & 3 = (lane >> 4) & 3 for every i.
-    const int gm = wid >> 2, gp = (wid >> 1) & 1, gr0 = 128 * (wid & 1) + (lane >> 2);
-    const __bf16* gbase = (gm == 0 ? (gp == 0 ? Ch : Cl) : (gp == 0 ? Xh : Xl)) + (uint64_t)((gm == 0 ? m0 : n0) + gr0) * K +
-                          (((lane & 3) ^ ((lane >> 4) & 3)) * 8);
-    auto dma1 = [&](int i, uint32_t k0, int buf) {
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(gbase + (uint64_t)(16 * i) * K + k0),
-                                       (__attribute__((address_space(3))) void*)(Tp(buf, gm, gp) + (128 * (wid & 1) + 16 * i) * kX3Pitch), 16, 0, 0);
-    };
-    // (tile 0: by DMA too -- X may be null on this path)
-#pragma unroll
-    for (int i = 0; i < 8; ++i) dma1(i, 0, 0);
-    __syncthreads();
-    bf16x8 ah[2], al[2], bh[4], bl[4];
-    for (uint32_t t = 0; t < k_tiles; ++t) {
-      const int buf = (int)(t & 1), nbuf = buf ^ 1;
-      const uint32_t k1 = kclamp(t + 1);  // (past the end: the last tile once more, into a buffer nobody reads any more)
-#pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {
-        const int ko = x3_chunk(r, 2 * s2 + hh);
-#pragma unroll
-        for (int tt = 0; tt < 2; ++tt) {
-          ah[tt] = *reinterpret_cast<const bf16x8*>(Tp(buf, 0, 0) + (wr * 64 + tt * 32 + r) * kX3Pitch + ko);
-          al[tt] = *reinterpret_cast<const bf16x8*>(Tp(buf, 0, 1) + (wr * 64 + tt * 32 + r) * kX3Pitch + ko);
-        }
-#pragma unroll
-        for (int tt = 0; tt < 4; ++tt) {
-          bh[tt] = *reinterpret_cast<const bf16x8*>(Tp(buf, 1, 0) + (wc * 128 + tt * 32 + r) * kX3Pitch + ko);
-          bl[tt] = *reinterpret_cast<const bf16x8*>(Tp(buf, 1, 1) + (wc * 128 + tt * 32 + r) * kX3Pitch + ko);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        auto mfma_row = [&](int a) {
-#pragma unroll
-          for (int b = 0; b < 4; ++b) {
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a], bh[b], acc[a][b], 0, 0, 0);  // small terms first
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bl[b], acc[a][b], 0, 0, 0);
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bh[b], acc[a][b], 0, 0, 0);
-          }
-        };
-        // this k-step's half of the next tile's pieces between the first row's MFMAs, one piece per three MFMAs
-#pragma unroll
-        for (int i = 4 * s2; i < 4 * s2 + 4; ++i) dma1(i, k1, nbuf);
-        mfma_row(0);
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 3, 0);  // three MFMAs
-          __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);  // one VMEM read (the DMA piece)
-        }
-        __builtin_amdgcn_sched_barrier(0);
-        mfma_row(1);
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      __syncthreads();  // (waits for the DMA too: vmcnt(0))
-    }
-  } else if constexpr (SCHED == 4) {
-    // SCHED = 2 with the POINTS pre-split into bf16 hi | lo in global memory too (split_bf16_kernel over the batch): no
-    // conversions in the loop, the points' pieces stored 16 bytes at a time like the centroids' (8 LDS store instructions per
-    // thread and K-tile instead of 12).  The ablation of SCHED = 2 priced the conversions at 16 % of the kernel.
-    auto gload_m = [&](f32x4 (&rr)[4], const __bf16* hi, const __bf16* lo, uint32_t row0, uint32_t k0) {
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int idx = tid + 512 * i;
-        const uint64_t at = (uint64_t)(row0 + (idx >> 2)) * K + k0 + (idx & 3) * 8;
-        rr[i] = *reinterpret_cast<const f32x4*>(hi + at);
-        rr[2 + i] = *reinterpret_cast<const f32x4*>(lo + at);
-      }
-    };
-    auto lstore_m = [&](int buf, int mat, const f32x4 (&rr)[4]) {
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int idx = tid + 512 * i, row = idx >> 2, at = row * kX3Pitch + x3_chunk(row, idx & 3);
-        *reinterpret_cast<f32x4*>(Tp(buf, mat, 0) + at) = rr[i];
-        *reinterpret_cast<f32x4*>(Tp(buf, mat, 1) + at) = rr[2 + i];
-      }
-    };
-    gload_m(ra, Ch, Cl, m0, 0);
-    gload_m(rb, Xh, Xl, n0, 0);
-    lstore_m(0, 0, ra);
-    lstore_m(0, 1, rb);
-    gload_m(ra, Ch, Cl, m0, kclamp(1));
-    gload_m(rb, Xh, Xl, n0, kclamp(1));
-    __syncthreads();
-    bf16x8 ah[2], al[2], bh[4], bl[4];
-    for (uint32_t t = 0; t < k_tiles; ++t) {
-      const int buf = (int)(t & 1), nbuf = buf ^ 1;
-      const uint32_t k2 = kclamp(t + 2);
-#pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {
-        const int ko = x3_chunk(r, 2 * s2 + hh);
-#pragma unroll
-        for (int tt = 0; tt < 2; ++tt) {
-          ah[tt] = *reinterpret_cast<const bf16x8*>(Tp(buf, 0, 0) + (wr * 64 + tt * 32 + r) * kX3Pitch + ko);
-          al[tt] = *reinterpret_cast<const bf16x8*>(Tp(buf, 0, 1) + (wr * 64 + tt * 32 + r) * kX3Pitch + ko);
-        }
-#pragma unroll
-        for (int tt = 0; tt < 4; ++tt) {
-          bh[tt] = *reinterpret_cast<const bf16x8*>(Tp(buf, 1, 0) + (wc * 128 + tt * 32 + r) * kX3Pitch + ko);
-          bl[tt] = *reinterpret_cast<const bf16x8*>(Tp(buf, 1, 1) + (wc * 128 + tt * 32 + r) * kX3Pitch + ko);
-        }
-        // tile t + 1's pieces of ONE operand per k-step -> the other buffer (its readers left at the last barrier); their registers
-        // take tile t + 2 at once
-        if (s2 == 0) { lstore_m(nbuf, 0, ra); gload_m(ra, Ch, Cl, m0, k2); }
-        else { lstore_m(nbuf, 1, rb); gload_m(rb, Xh, Xl, n0, k2); }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int a = 0; a < 2; ++a) {
-#pragma unroll
-          for (int b = 0; b < 4; ++b) {
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a], bh[b], acc[a][b], 0, 0, 0);  // small terms first
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bl[b], acc[a][b], 0, 0, 0);
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bh[b], acc[a][b], 0, 0, 0);
-          }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      __syncthreads();
-    }
-  } else if constexpr (SCHED == 2) {
-    // SCHED = 1 with the global loads of tile t + 2 issued as soon as tile t + 1's registers are consumed instead of at the end of
-    // the step: in SCHED = 1 the loads go out just before the barrier and their first consumer -- the split at the top of the next
-    // step -- sits just behind it, so every K-tile began with the whole block waiting out an L2 / Infinity-Cache round trip
+  gload(0);
+  lstore(0);
+  gload(kclamp(1));
+  __syncthreads();
+  {
+    // The global loads of tile t + 2 are issued as soon as tile t + 1's registers are consumed instead of at the end of the step:
+    // there the loads went out just before the barrier and their first consumer -- the split at the top of the next step -- sat
+    // just behind it, so every K-tile began with the whole block waiting out an L2 / Infinity-Cache round trip
     // (PMC, round 4: a K-tile takes 5.9 k cycles of which the matrix cores are busy 3.1 k).  Here the centroid pieces of tile
     // t + 1 go to LDS at the TOP of step t (the other buffer's readers left at the last barrier) and their registers take tile
     // t + 2 at once; each half of the point slots is reloaded right behind its split.  No register is added: round 3's try at
@@ -683,10 +521,6 @@ static __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2
       const int idx = tid + 512 * i;
       rb[i] = *reinterpret_cast<const f32x4*>(X + (uint64_t)(n0 + (idx >> 3)) * K + k0 + (idx & 7) * 4);
     };
-#ifndef VERS_X3W_ABLATE
-#define VERS_X3W_ABLATE 0  // timing experiments (results are WRONG with any bit set): 1 the second k-step re-uses the first's fragments,
-#endif                     // 2 no LDS stores, 4 no global loads, 8 no barrier, 16 no split arithmetic
-    constexpr int kAbl = VERS_X3W_ABLATE;
     bf16x8 ah[2], al[2], bh[4], bl[4];
     for (uint32_t t = 0; t < k_tiles; ++t) {
       const int buf = (int)(t & 1), nbuf = buf ^ 1;
@@ -694,7 +528,6 @@ static __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2
 #pragma unroll
       for (int s2 = 0; s2 < 2; ++s2) {
         const int ko = x3_chunk(r, 2 * s2 + hh);
-        if (!((kAbl & 1) && s2 == 1)) {
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) {
           ah[tt] = *reinterpret_cast<const bf16x8*>(Tp(buf, 0, 0) + (wr * 64 + tt * 32 + r) * kX3Pitch + ko);
@@ -705,17 +538,14 @@ static __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2
           bh[tt] = *reinterpret_cast<const bf16x8*>(Tp(buf, 1, 0) + (wc * 128 + tt * 32 + r) * kX3Pitch + ko);
           bl[tt] = *reinterpret_cast<const bf16x8*>(Tp(buf, 1, 1) + (wc * 128 + tt * 32 + r) * kX3Pitch + ko);
         }
-        }
         if (s2 == 0) {  // tile t + 1's centroid pieces -> the other buffer; their registers take tile t + 2
-          if (!(kAbl & 2)) {
 #pragma unroll
           for (int i = 0; i < 2; ++i) {
             const int idx = tid + 512 * i, row = idx >> 2, at = row * kX3Pitch + x3_chunk(row, idx & 3);
             *reinterpret_cast<f32x4*>(Tp(nbuf, 0, 0) + at) = ra[i];
             *reinterpret_cast<f32x4*>(Tp(nbuf, 0, 1) + at) = ra[2 + i];
           }
-          }
-          if (!(kAbl & 4)) gload_a(k2);
+          gload_a(k2);
         }
         // (hard scheduling fences between the phases of a k-step: left to itself the compiler hoists both halves of the split --
         // and with them the waits for their loads -- in front of the first MFMA and sinks the reloads to the end of the step)
@@ -734,16 +564,13 @@ static __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2
           bf16x4 sh, sl;
 #pragma unroll
           for (int u = 0; u < 4; ++u) {
-            if (kAbl & 16) { sh[u] = (__bf16)0.0f; sl[u] = (__bf16)0.0f; continue; }
             sh[u] = (__bf16)rb[i][u];
             sl[u] = (__bf16)(rb[i][u] - (float)sh[u]);
           }
           const int idx = tid + 512 * i, row = idx >> 3, c4 = idx & 7;
           const int at = row * kX3Pitch + x3_chunk(row, c4 >> 1) + (c4 & 1) * 4;
-          if (!(kAbl & 2)) {
-            *reinterpret_cast<bf16x4*>(Tp(nbuf, 1, 0) + at) = sh;
-            *reinterpret_cast<bf16x4*>(Tp(nbuf, 1, 1) + at) = sl;
-          }
+          *reinterpret_cast<bf16x4*>(Tp(nbuf, 1, 0) + at) = sh;
+          *reinterpret_cast<bf16x4*>(Tp(nbuf, 1, 1) + at) = sl;
         }
         mfma_row(0);
 #pragma unroll
@@ -753,71 +580,11 @@ static __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2
         }
         __builtin_amdgcn_sched_barrier(0);
         // the split slots' registers take tile t + 2; second half of the MFMAs
-        if (!(kAbl & 4)) {
-          gload_b(2 * s2, k2);
-          gload_b(2 * s2 + 1, k2);
-        }
+        gload_b(2 * s2, k2);
+        gload_b(2 * s2 + 1, k2);
         mfma_row(1);
         __builtin_amdgcn_sched_barrier(0);
       }
-      if (!(kAbl & 8)) __syncthreads();
-    }
-  } else {
-    for (uint32_t t = 0; t < k_tiles; ++t) {
-      const int buf = (int)(t & 1), nbuf = buf ^ 1;
-      bf16x4 sh[4], sl[4];  // the next tile's point slots of this thread, split
-#pragma unroll
-      for (int s2 = 0; s2 < 2; ++s2) {
-        const int ko = x3_chunk(r, 2 * s2 + hh);
-        bf16x8 ah[2], al[2], bh[4], bl[4];
-#pragma unroll
-        for (int tt = 0; tt < 2; ++tt) {
-          ah[tt] = *reinterpret_cast<const bf16x8*>(Tp(buf, 0, 0) + (wr * 64 + tt * 32 + r) * kX3Pitch + ko);
-          al[tt] = *reinterpret_cast<const bf16x8*>(Tp(buf, 0, 1) + (wr * 64 + tt * 32 + r) * kX3Pitch + ko);
-        }
-#pragma unroll
-        for (int tt = 0; tt < 4; ++tt) {
-          bh[tt] = *reinterpret_cast<const bf16x8*>(Tp(buf, 1, 0) + (wc * 128 + tt * 32 + r) * kX3Pitch + ko);
-          bl[tt] = *reinterpret_cast<const bf16x8*>(Tp(buf, 1, 1) + (wc * 128 + tt * 32 + r) * kX3Pitch + ko);
-        }
-#pragma unroll
-        for (int i = 2 * s2; i < 2 * s2 + 2; ++i)  // half of the split per k-step
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            sh[i][u] = (__bf16)rb[i][u];
-            sl[i][u] = (__bf16)(rb[i][u] - (float)sh[i][u]);
-          }
-#pragma unroll
-        for (int a = 0; a < 2; ++a)
-#pragma unroll
-          for (int b = 0; b < 4; ++b) {
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a], bh[b], acc[a][b], 0, 0, 0);  // small terms first
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bl[b], acc[a][b], 0, 0, 0);
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bh[b], acc[a][b], 0, 0, 0);
-          }
-        // the order asked of the scheduler for this k-step: its fragment reads, then MFMA / VALU / VALU ...
-        __builtin_amdgcn_sched_group_barrier(0x100, 12, 0);  // DS reads
-#pragma unroll
-        for (int g = 0; g < 24; ++g) {
-          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one MFMA
-          __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);  // two VALU
-        }
-      }
-      // tile t + 1 into the other buffer (its readers finished before the last barrier), then the loads of tile t + 2
-#pragma unroll
-      for (int i = 0; i < 2; ++i) {
-        const int idx = tid + 512 * i, row = idx >> 2, at = row * kX3Pitch + x3_chunk(row, idx & 3);
-        *reinterpret_cast<f32x4*>(Tp(nbuf, 0, 0) + at) = ra[i];
-        *reinterpret_cast<f32x4*>(Tp(nbuf, 0, 1) + at) = ra[2 + i];
-      }
-#pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int idx = tid + 512 * i, row = idx >> 3, c4 = idx & 7;
-        const int at = row * kX3Pitch + x3_chunk(row, c4 >> 1) + (c4 & 1) * 4;
-        *reinterpret_cast<bf16x4*>(Tp(nbuf, 1, 0) + at) = sh[i];
-        *reinterpret_cast<bf16x4*>(Tp(nbuf, 1, 1) + at) = sl[i];
-      }
-      gload(kclamp(t + 2));
       __syncthreads();
     }
   }
@@ -874,50 +641,20 @@ static __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2
     }
   }
 }
-// assign pass through the wide kernel when the shapes allow it (VERS_GEMM_WIDE=0: never)
-inline int gemm_wide_mode() {  // VERS_GEMM_WIDE: 0 = never, 1 = plain order, 2 = interleaved, 3 = interleaved + early reloads (default), 4 = both operands pre-split, LDS-DMA, 5 = both pre-split, through registers
-  static const int m = [] { const char* e = getenv("VERS_GEMM_WIDE"); return e ? atoi(e) : 3; }();
-  return m;
-}
+// assign pass through the wide kernel whenever the shapes allow it
 inline bool gemm_wide_ok(uint32_t k_pad, uint32_t nb_pad, bool have_split) {
-  return gemm_wide_mode() != 0 && have_split && k_pad % kGemmWide == 0 && nb_pad % kGemmWide == 0;
+  return have_split && k_pad % kGemmWide == 0 && nb_pad % kGemmWide == 0;
 }
 inline hipError_t launch_gemm_wide(uint32_t k_pad, uint32_t nb_pad, hipStream_t st, const float* X, const __bf16* ch, const __bf16* cl, const float* cnorm,
-                                   uint32_t K, uint32_t N_pad, uint32_t metric, uint32_t k_rows, float* part_v1, uint32_t* part_c1, float* part_v2,
-                                   const __bf16* xh = nullptr, const __bf16* xl = nullptr) {  // xh / xl: the point batch pre-split (mode 4: LDS-DMA)
-  static const hipError_t attr0 = hipFuncSetAttribute((const void*)dist_gemm_x3w_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kX3WLdsBytes);
-  static const hipError_t attr1 = hipFuncSetAttribute((const void*)dist_gemm_x3w_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kX3WLdsBytes);
-  if (attr0 != hipSuccess) return attr0;
-  if (attr1 != hipSuccess) return attr1;
+                                   uint32_t K, uint32_t N_pad, uint32_t metric, uint32_t k_rows, float* part_v1, uint32_t* part_c1, float* part_v2) {
+  static const hipError_t attr = hipFuncSetAttribute((const void*)dist_gemm_x3w_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kX3WLdsBytes);
+  if (attr != hipSuccess) return attr;
   const uint32_t m_tiles = k_pad / kGemmWide, n_tiles = nb_pad / kGemmWide;
   // each XCD keeps `grp` centroid tiles (256 rows x K x 4 B of hi | lo = 768 KB at K = 768) in its L2 and walks the point tiles
   uint32_t grp = 0;
   for (uint32_t g : {2u, 1u}) if (m_tiles % (8u * g) == 0) { grp = g; break; }
-  static const hipError_t attr2 = hipFuncSetAttribute((const void*)dist_gemm_x3w_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kX3WLdsBytes);
-  if (attr2 != hipSuccess) return attr2;
-  if (xh != nullptr && xl != nullptr && gemm_wide_mode() == 5) {
-    static const hipError_t attr4 = hipFuncSetAttribute((const void*)dist_gemm_x3w_kernel<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kX3WLdsBytes);
-    if (attr4 != hipSuccess) return attr4;
-    hipLaunchKernelGGL(dist_gemm_x3w_kernel<4>, dim3(m_tiles * n_tiles), dim3(512), kX3WLdsBytes, st, X, ch, cl, cnorm, K, N_pad, (int)metric, m_tiles,
-                       n_tiles, grp, k_rows, part_v1, part_c1, part_v2, xh, xl);
-    return hipGetLastError();
-  }
-  if (xh != nullptr && xl != nullptr) {
-    static const hipError_t attr3 = hipFuncSetAttribute((const void*)dist_gemm_x3w_kernel<3>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kX3WLdsBytes);
-    if (attr3 != hipSuccess) return attr3;
-    hipLaunchKernelGGL(dist_gemm_x3w_kernel<3>, dim3(m_tiles * n_tiles), dim3(512), kX3WLdsBytes, st, X, ch, cl, cnorm, K, N_pad, (int)metric, m_tiles,
-                       n_tiles, grp, k_rows, part_v1, part_c1, part_v2, xh, xl);
-    return hipGetLastError();
-  }
-  if (gemm_wide_mode() == 3)
-    hipLaunchKernelGGL(dist_gemm_x3w_kernel<2>, dim3(m_tiles * n_tiles), dim3(512), kX3WLdsBytes, st, X, ch, cl, cnorm, K, N_pad, (int)metric, m_tiles,
-                       n_tiles, grp, k_rows, part_v1, part_c1, part_v2);
-  else if (gemm_wide_mode() == 1)
-    hipLaunchKernelGGL(dist_gemm_x3w_kernel<0>, dim3(m_tiles * n_tiles), dim3(512), kX3WLdsBytes, st, X, ch, cl, cnorm, K, N_pad, (int)metric, m_tiles,
-                       n_tiles, grp, k_rows, part_v1, part_c1, part_v2);
-  else
-    hipLaunchKernelGGL(dist_gemm_x3w_kernel<1>, dim3(m_tiles * n_tiles), dim3(512), kX3WLdsBytes, st, X, ch, cl, cnorm, K, N_pad, (int)metric, m_tiles,
-                       n_tiles, grp, k_rows, part_v1, part_c1, part_v2);
+  hipLaunchKernelGGL(dist_gemm_x3w_kernel<2>, dim3(m_tiles * n_tiles), dim3(512), kX3WLdsBytes, st, X, ch, cl, cnorm, K, N_pad, (int)metric, m_tiles,
+                     n_tiles, grp, k_rows, part_v1, part_c1, part_v2);
   return hipGetLastError();
 }
 

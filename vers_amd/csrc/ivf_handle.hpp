@@ -378,11 +378,9 @@ struct SearchKnobs {
   int pre_slack = 0;     // VERS_PRE_SLACK: slack keys of the matrix-core lists
   long seg_rows = 0;     // VERS_SEG_ROWS
   int pre_blocks_per_cu = 0;  // VERS_PRE_BLOCKS_PER_CU
-  int pre_slices = 1;         // VERS_PRE_SLICES: time slices of the matrix-core list scan (prescan.hip.h, PreParams::quota)
   int pre_mode = 1;      // VERS_PRESCAN: 0 ordered chains for batches too, 2 every certificate fails
   bool seg_balanced = true;   // VERS_SEG_BALANCED
   uint32_t hot_ranks = 1;     // VERS_HOT_FIRST
-  bool hot_local = false;     // VERS_HOT_LOCAL=1: a query's nearest list AMONG THOSE THIS GPU SCANS counts as hot (tried in round 4: worse, see plan.hip.h)
   bool pre_narrow = false;    // VERS_PRE_NARROW: 16-query blocks in the matrix-core list scan whatever d is
 };
 inline const SearchKnobs& knobs() {
@@ -393,12 +391,10 @@ inline const SearchKnobs& knobs() {
     s.pre_slack = (int)geti("VERS_PRE_SLACK", 0);
     s.seg_rows = geti("VERS_SEG_ROWS", 0);
     s.pre_blocks_per_cu = (int)geti("VERS_PRE_BLOCKS_PER_CU", 0);
-    s.pre_slices = (int)geti("VERS_PRE_SLICES", 1);
     s.pre_mode = (int)geti("VERS_PRESCAN", 1);
     s.seg_balanced = geti("VERS_SEG_BALANCED", 1) != 0;
     s.hot_ranks = (uint32_t)geti("VERS_HOT_FIRST", 1);
     s.pre_narrow = geti("VERS_PRE_NARROW", 0) != 0;
-    s.hot_local = geti("VERS_HOT_LOCAL", 0) != 0;
     return s;
   }();
   return k;

@@ -42,13 +42,8 @@ __global__ __launch_bounds__(256) void plan_queries_kernel(PlanQ a, const uint64
 // All tables are in SLOT order (lists by descending length, see vers_ivf::list_slot).  Work order of the scan = hot
 // lists first (nearest list of some query: their thresholds must be tight before the bulk is scanned), then the others
 // in slot order, i.e. LONGEST FIRST.
-#ifndef VERS_GROUP_THREADS
-#define VERS_GROUP_THREADS 1024
-#endif
-// (256-thread blocks -- one wave per SIMD at 112 registers: a block then fits on a CU beside a block of another batch's coarse
-// contraction instead of waiting for whole CUs -- were tried in round 4, -DVERS_GROUP_THREADS=256: 0.399-0.400 vs 0.387-0.393 ms per
-// step at 8 ranks with three batches in flight, 0.474-0.504 vs 0.462-0.469 one at a time: the kernel itself is slower, off)
-constexpr uint32_t kGroupThreads = VERS_GROUP_THREADS, kGroupMaxBlocks = 64;
+// (256-thread blocks were tried in round 4 and lost -- the kernel itself is slower: DESIGN.md Appendix A)
+constexpr uint32_t kGroupThreads = 1024, kGroupMaxBlocks = 64;
 constexpr int kGroupWaves = (int)(kGroupThreads / kWave);
 struct GroupArgs {
   uint32_t b, P, k_lists, QG, seg_rows, seg_target;
@@ -763,7 +758,7 @@ int32_t plan_search(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint32_t b
   pq.list_len = h->list_len.as<uint32_t>(); pq.owner = h->world > 1 ? h->owner.as<uint8_t>() : (const uint8_t*)nullptr; pq.rank = h->rank;
   pq.list_slot = h->list_slot.as<uint32_t>();
   pq.pj_list = pj_list; pq.pj_pref = pj_pref; pq.pj_take = pj_take; pq.np = np; pq.pj_nq = use_pre ? pj_nq : nullptr;
-  pq.cnt = cnt; pq.hot = hot; pq.hot_ranks = knobs().hot_ranks; pq.hot_local = knobs().hot_local ? 1u : 0u; pq.seg_rows = seg_rows; pq.seg_target = seg_target;
+  pq.cnt = cnt; pq.hot = hot; pq.hot_ranks = knobs().hot_ranks; pq.seg_rows = seg_rows; pq.seg_target = seg_target;
   pq.status = W->st_word();
   bool planned = false;
   uint32_t n_segs_c = 0;

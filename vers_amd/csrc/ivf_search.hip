@@ -301,12 +301,6 @@ int32_t launch_prescan(vers_ivf* h, const IvfSrc<NQ>& src, uint32_t items_bound,
   const uint32_t max_blocks = ((uint32_t)h->n_cu - reserve) * per_cu;
   if (blocks > max_blocks) blocks = max_blocks;
   if (blocks == 0) blocks = 1;
-  if (knobs().pre_slices > 1 && p.next_quad != nullptr && blocks == max_blocks) {  // time slices: see the kernel
-    const uint32_t slices = (uint32_t)knobs().pre_slices, n_quads = items_bound / 4;
-    p.resident = blocks;
-    p.quota = std::max<uint32_t>(1, (n_quads + blocks * slices - 1) / (blocks * slices));
-    blocks *= slices;
-  }
   const uint32_t slot = (uint32_t)(W->ev_count % SearchWs::kEvRing);
   if (W->ev_on) VERS_HIP_TRY(hipEventRecord(W->ev0[slot], st));
   if (hi_only) hipLaunchKernelGGL((prescan_kernel_g<true, NQ, IvfSrc<NQ>, false>), dim3(blocks), dim3(kWave * kPreWavesG), lds, st, src, p);

@@ -295,13 +295,7 @@ int32_t km_assign_mfma(const float* X, uint32_t ldx, uint64_t n, const float* C,
     // (the triples are addressed with pitch mb: nb_pad <= mb)
     {
       KmTimer t(st, &BuildStats::gemm_ms);
-      if (wide && gemm_wide_mode() >= 4) {  // the batch split into bf16 hi | lo first (inside the timed stretch: it is part of the contraction's cost)
-        const size_t ne = (size_t)nb_pad * ldq;
-        if (int32_t rc = ws.xs.reserve(2 * (size_t)mb * ldq * sizeof(uint16_t))) return rc;
-        VERS_HIP_TRY(launch_split_bf16(xb, ne, ws.xs.as<__bf16>(), ws.xs.as<__bf16>() + (size_t)mb * ldq, st));
-        VERS_HIP_TRY(launch_gemm_wide(k_pad, nb_pad, st, xb, cg_h, cg_l, ws.cnorm.as<float>(), ldq, (uint32_t)mb, metric, k, part_v1, part_c1, part_v2,
-                                      ws.xs.as<__bf16>(), ws.xs.as<__bf16>() + (size_t)mb * ldq));
-      } else if (wide)
+      if (wide)
         VERS_HIP_TRY(launch_gemm_wide(k_pad, nb_pad, st, xb, cg_h, cg_l, ws.cnorm.as<float>(), ldq, (uint32_t)mb, metric, k, part_v1, part_c1, part_v2));
       else
         VERS_HIP_TRY(launch_gemm<true>((gemm_x3_mask() & 1) != 0, k_pad / kGemmBM, nb_pad / kGemmBN, st, ws.cg.as<float>(), xb, ws.cnorm.as<float>(), ldq,

@@ -35,7 +35,6 @@ struct KMeansScratch {
   // matrix-core assign (km_assign_mfma)
   DevBuf cg;        // centroids row-major [k_pad][ldq], zero padded
   DevBuf cg_s;      // the same as bf16 hi | lo halves [2][k_pad][ldq] (operand of the bf16x3 contraction, split once per pass)
-  DevBuf xs;        // a point batch as bf16 hi | lo halves [2][mb][ldq] (VERS_GEMM_WIDE=4: both operands by LDS-DMA)
   DevBuf cnorm;     // |c|^2 [k_pad] (+inf padding) + max at [k_pad]
   DevBuf xp;        // staged point batch [mb][ldq] when X cannot be used in place
   DevBuf gt;        // Gt [k_pad][mb]

@@ -60,7 +60,6 @@ struct PlanQ {
   uint32_t* pj_nq = nullptr;            // nullable (matrix-core scan only)
   uint32_t *cnt = nullptr, *hot = nullptr;  // zeroed before the launch that plans
   uint32_t hot_ranks = 0, seg_rows = 0, seg_target = 0;
-  uint32_t hot_local = 0;               // 1: hot = the first hot_ranks lists of the query that THIS GPU scans (default: probe ranks < hot_ranks)
   uint32_t* status = nullptr;
   uint32_t zero_words = 0;              // != 0: the zone that starts at cnt is zeroed by the coarse contraction's launch (no memset in front)
 };
@@ -93,11 +92,8 @@ __device__ __forceinline__ void plan_query_chunk(const PlanQ& a, uint32_t q, int
   }
   if (scan) atomicAdd(&a.cnt[slot], 1u);
   // This query's tightest thresholds come from its nearest list (the group step orders the work: hot lists first).
-  // hot_local (VERS_HOT_LOCAL=1, off): the nearest list AMONG THOSE THIS GPU SCANS instead -- with the lists sharded over 8 GPUs
-  // seven of eight queries have no hot list on a rank.  Measured at 8 ranks, same box: 350 -> 378 us, 283 k -> 328 k candidates
-  // per launch: then most of a rank's lists are somebody's nearest and "hot first" orders nothing.
-  const uint64_t sm = __ballot(scan);
-  if (scan && c0 == 0 && (a.hot_local ? (uint32_t)__popcll(sm & ((1ull << lane) - 1ull)) : j) < a.hot_ranks) a.hot[slot] = 1u;
+  // ("Nearest AMONG THE LISTS THIS GPU SCANS" was tried for sharded indexes in round 4 and lost: DESIGN.md Appendix A.)
+  if (scan && c0 == 0 && j < a.hot_ranks) a.hot[slot] = 1u;
   n_visited += (uint32_t)__popcll(__ballot(visited));
 }
 __device__ __forceinline__ void plan_query_finish(const PlanQ& a, uint32_t q, int lane, uint32_t carry, uint32_t n_visited) {

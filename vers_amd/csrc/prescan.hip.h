@@ -38,10 +38,7 @@ typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
 typedef __attribute__((ext_vector_type(4))) _Float16 f16x4_t;
 
 constexpr int kPreQ = 32;        // queries per group: two sets of 16 (one 16x16x1 4-block MFMA covers 64 rows x 16 queries)
-#ifndef VERS_PRE_AUX
-#define VERS_PRE_AUX 2
-#endif
-constexpr int kPreAux = VERS_PRE_AUX;  // cache policy of the row-tile loads: 2 = nt (streamed once); same-box A/B at cfg3: -1.8 % vs default
+constexpr int kPreAux = 2;  // cache policy of the row-tile loads: 2 = nt (streamed once); same-box A/B at cfg3: -1.8 % vs default
 constexpr uint32_t kPreMaxKp = 64;  // widest list: one sorted key per lane
 
 struct PreParams {
@@ -55,8 +52,6 @@ struct PreParams {
   uint32_t debug;
   uint32_t metric;      // 0: val = |x|^2 - 2<x,q> ~ D_ref - |q|^2 ; 1 (cosine distance 1 - dot): val = -<x,q> ~ D_ref - 1
   unsigned long long* stamps;
-  uint32_t resident = 0;  // blocks that hold CUs at a time (the guided hand-out divides by it); 0: the grid
-  uint32_t quota = 0;     // != 0: a block leaves after this many quads (time slices: the launch has resident x slices blocks)
 };
 
 
@@ -148,23 +143,14 @@ static __global__ void blocked_row_norms_kernel(const float* rows, uint32_t ld, 
 // close to the query's global one.  (With a list per wave the shared threshold stalled near "the kp-th of the best
 // 220 rows": ~900 inserts per query and batch instead of the ~170 a perfectly shared threshold needs; inserts
 // were 0.38 ms of 5.3 ms.)  One partial slot per (query, list, quad) goes to the exact finish.
-#ifndef VERS_PRE_WAVES
-#define VERS_PRE_WAVES 8
-#endif
-constexpr int kPreWavesG = VERS_PRE_WAVES;  // 4 items x kPreParts waves (8: two per SIMD, <= 256 registers; 12: three per SIMD, <= 168)
-#ifndef VERS_PRE_WPE
-#define VERS_PRE_WPE (VERS_PRE_WAVES / 4)
-#endif
-constexpr int kPreWpe = VERS_PRE_WPE;  // waves per SIMD the kernel is compiled for (its register budget: 512 / kPreWpe)
+constexpr int kPreWavesG = 8;  // 4 items x kPreParts waves (8: two per SIMD, <= 256 registers; 12: three per SIMD, <= 168)
+constexpr int kPreWpe = kPreWavesG / 4;  // waves per SIMD the kernel is compiled for (its register budget: 512 / kPreWpe)
 constexpr int kPreParts = kPreWavesG / 4;   // waves that share a segment: each walks a contiguous share of its tiles
 static_assert(kPreWavesG % 4 == 0 && kPreWavesG >= 4 && kPreWavesG <= 16, "a quad of segments x 1..4 waves each");
 // Candidate buffer of a query in LDS: `cap` unsorted keys.  kp <= 40 (top_k <= 30 with the default slack): 64 keys, one
 // wave-wide bitonic sort compacts it; wider lists: 128 keys (two sorts + a bitonic merge).  At least 24 free slots after
 // every compaction.
-#ifndef VERS_PRE_CAP_SMALL
-#define VERS_PRE_CAP_SMALL 64
-#endif
-__host__ __device__ inline uint32_t pre_cap(uint32_t kp) { return kp <= 40u ? (uint32_t)VERS_PRE_CAP_SMALL : 128u; }
+__host__ __device__ inline uint32_t pre_cap(uint32_t kp) { return kp <= 40u ? 64u : 128u; }
 // nq = queries per block: kPreQ (32), or 16 -- the NARROW variant for rows too long for a 32-query block (d = 1536: 196 KB
 // against the CU's 160 KB of LDS; 16 queries fit up to d = 2304).  Same kernel, same MFMA (half its query columns idle).
 // hi_only: the fp16 query block WITHOUT its lo half (2 B per element instead of 4): 32 queries fit up to d = 2304, 16 up to
@@ -250,10 +236,7 @@ __device__ __forceinline__ void prescan_item_g(const Src& src, const PreParams& 
   }
   const uint32_t nch = BF ? p.ld / 64u : p.n_chunks;  // steps per tile: 8 loads = 64 bf16 columns (x 2 row halves) or 32 f32 columns
   const float* xn_item = p.xnorm + src.storage_row(it);
-#ifndef VERS_PRE_RING_G
-#define VERS_PRE_RING_G 2
-#endif
-  constexpr int R = VERS_PRE_RING_G;  // ring of (tile, chunk) steps, 8 KiB each
+  constexpr int R = 2;  // ring of (tile, chunk) steps, 8 KiB each
   u32x4 buf[R][kLoads];
   float xn[R];
   uint32_t gthr[R][2];
@@ -262,16 +245,13 @@ __device__ __forceinline__ void prescan_item_g(const Src& src, const PreParams& 
   uint32_t vslot[2] = {0, 0};
   auto issue_next = [&](auto btag, bool with_thr) {
     constexpr int b = decltype(btag)::value;
-#ifndef VERS_PRE_GTHR_EVERY_STEP
-#define VERS_PRE_GTHR_EVERY_STEP 0
-#endif
     if (with_thr) {
       // The query's threshold as its other blocks know it is consumed once per TILE (with the step that completes it); the load
       // stays unconditional -- a branch around a load costs the ring a vmcnt(0) -- but on every other step all lanes read ONE
       // word (slot 0) instead of 32 different ones.  These are agent-scope loads: they bypass the XCD's L2, and 32 separate
       // lines per step and wave were ~400 memory-side transactions per 96 KB tile next to the tile's own 96 (round 3 loaded
-      // them with every step: VERS_PRE_GTHR_EVERY_STEP=1).
-      const bool fin = VERS_PRE_GTHR_EVERY_STEP || ci + 1 >= nch;
+      // them with every step).
+      const bool fin = ci + 1 >= nch;
       gthr[b][0] = __hip_atomic_load(p.bounds32 + (fin ? vslot[0] : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       gthr[b][1] = kSets == 2 ? __hip_atomic_load(p.bounds32 + (fin ? vslot[1] : 0u), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0xFFFFFFFFu;
     } else {
@@ -285,7 +265,6 @@ __device__ __forceinline__ void prescan_item_g(const Src& src, const PreParams& 
     else if (ti + 1 < t_end) { ci = 0; ++ti; }
   };
   issue_next(std::integral_constant<int, 0>{}, false);
-  if constexpr (R == 3) issue_next(std::integral_constant<int, 1>{}, false);
 
   bool live[2];
   uint32_t vseq[2] = {0, 0};
@@ -350,10 +329,6 @@ __device__ __forceinline__ void prescan_item_g(const Src& src, const PreParams& 
         if (lane == 0) atomicAdd(p.stamps + 13, nc);
       }
       uint64_t ovf = (p.debug & 4096u) ? 0ull : __ballot(pend != 0);  // (diagnosis, VERS_SCAN_DEBUG & 4096: candidates that find their buffer full are DROPPED -- wrong results, the appends' cost without the compactions')
-#ifndef VERS_PRE_TRYLOCK
-#define VERS_PRE_TRYLOCK 1
-#endif
-#if VERS_PRE_TRYLOCK
       // Some query's buffer is full.  ONE wave compacts it (the lock decides which); every other wave with candidates for that
       // query only waits for the counter to re-open and then places what is still worth placing WITHOUT the lock -- appends
       // never needed it.  (Round 3 made every such wave take the lock in turn, compaction or not: the eight waves of a block
@@ -388,11 +363,8 @@ __device__ __forceinline__ void prescan_item_g(const Src& src, const PreParams& 
             // every reservation below cap belongs to a wave that is on its way to store it without needing this lock
             while ((uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(done + qq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) != cap)
               __builtin_amdgcn_s_sleep(1);
-#ifndef VERS_PRE_RANK_SELECT
-#define VERS_PRE_RANK_SELECT 1
-#endif
             uint32_t kb;
-            if (VERS_PRE_RANK_SELECT && cap == (uint32_t)kWave) {
+            if (cap == (uint32_t)kWave) {
               // A full 64-key buffer, one key per lane: the kp smallest by RANK COUNTING -- rank = how many of the 64 keys are
               // smaller (keys are unique: (val, seq)), 64 x (two v_readlane, one 64-bit compare, one add), no LDS round trips --
               // instead of a bitonic sort through ds_bpermute (21 dependent stages of two permutes: ~3x the cycles, all of them
@@ -436,72 +408,6 @@ __device__ __forceinline__ void prescan_item_g(const Src& src, const PreParams& 
         if (mine) pend = mp;
         ovf = __ballot(pend != 0);
       }
-#else
-      while (ovf) {  // some query's buffer is full: compact it under its lock, then place what is still worth placing
-        const uint64_t ovr = rot ? (ovf >> rot) | (ovf << (64 - rot)) : ovf;
-        const int L = (__ffsll((unsigned long long)ovr) - 1 + rot) & 63;
-        const uint32_t qq = (uint32_t)__builtin_amdgcn_readlane((int)q, L);
-        const bool mine = q == qq && pend != 0;
-        uint64_t* const bqq = cbuf + (size_t)qq * cap;
-        if (lane == 0)
-          while (__hip_atomic_exchange(locks + qq, 1u, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != 0u) __builtin_amdgcn_s_sleep(1);
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        for (;;) {
-          const uint32_t cv = (uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(cnt + qq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP));
-          if (cv >= cap) {
-            // every reservation below cap belongs to a wave that is on its way to store it without needing this lock
-            while ((uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(done + qq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) != cap)
-              __builtin_amdgcn_s_sleep(1);
-#ifndef VERS_PRE_RANK_SELECT
-#define VERS_PRE_RANK_SELECT 1
-#endif
-            uint32_t kb;
-            if (VERS_PRE_RANK_SELECT && cap == (uint32_t)kWave) {
-              // A full 64-key buffer, one key per lane: the kp smallest by RANK COUNTING -- rank = how many of the 64 keys are
-              // smaller (keys are unique: (val, seq)), 64 x (two v_readlane, one 64-bit compare, one add), no LDS round trips --
-              // instead of a bitonic sort through ds_bpermute (21 dependent stages of two permutes: ~3x the cycles, all of them
-              // under the query's lock with the query's other waves waiting; at 8 ranks a launch makes 17 k of these).  The key of
-              // rank r goes to slot r, so the kept prefix comes out sorted like before.
-              const uint64_t mykey = bqq[lane];
-              uint32_t rank = 0;
-#pragma unroll
-              for (int j = 0; j < kWave; ++j) rank += readlane64(mykey, j) < mykey ? 1u : 0u;
-              if (rank < kp) bqq[rank] = mykey;
-              const uint64_t at = __ballot(rank == kp - 1u);  // (exactly one lane)
-              kb = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(mykey >> 32), __ffsll((unsigned long long)at) - 1);
-            } else {
-              const uint64_t srt = buffer_sorted(bqq, cap, cap, lane);
-              if (lane < (int)kp) bqq[lane] = srt;
-              kb = (uint32_t)__builtin_amdgcn_readlane((int)(uint32_t)(srt >> 32), (int)kp - 1);  // cap keys >= kp: always a real key
-            }
-            if (lane == 0) {
-              __hip_atomic_store(thrq + qq, kb, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-              __hip_atomic_store(done + qq, kp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // buffer, done and threshold before the counter re-opens it
-            if (lane == 0) __hip_atomic_store(cnt + qq, kp, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (lane == (int)(BF ? qq : (qq & 15u)) && !(p.debug & 8192u)) atomicMin(p.bounds32 + vslot[S], kb);
-            if (stamp && lane == 0) atomicAdd(p.stamps + 12, 1ull);
-          }
-          uint32_t mp = 0;
-          if (mine) {  // the threshold moved: most of what was pending is no longer a candidate
-            const uint32_t bh = __hip_atomic_load(thrq + qq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (bh != 0xFFFFFFFFu) {
-              const float g = __uint_as_float(order_bits_to_f32_bits(bh));
-              thr[S] = g < thr[S] ? g : thr[S];
-            }
-#pragma unroll
-            for (int e = 0; e < 16; ++e) mp |= ((pend >> e & 1u) && a[e] <= thr[S]) ? 1u << e : 0u;
-          }
-          append(mp);
-          if (mine) pend = mp;
-          if (__ballot(mine && pend != 0) == 0) break;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        if (lane == 0) __hip_atomic_store(locks + qq, 0u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-        ovf = __ballot(pend != 0);
-      }
-#endif
     }
 #pragma unroll
     for (int e = 0; e < 16; ++e) a[e] = 0.0f;
@@ -528,7 +434,6 @@ __device__ __forceinline__ void prescan_item_g(const Src& src, const PreParams& 
   uint32_t tc = t_begin, cc = 0;
   unsigned long long t_math = 0, t_fold = 0, t_issue = 0;
   const unsigned long long tp1 = stamp ? __builtin_amdgcn_s_memtime() : 0ull;
-  bool fold_pending = false;  // (wave-uniform)
   uint32_t fold_tile = 0;
   auto run_folds = [&]() {
     if constexpr (BF) {
@@ -543,21 +448,6 @@ __device__ __forceinline__ void prescan_item_g(const Src& src, const PreParams& 
     constexpr int B = decltype(btag)::value;
     const unsigned long long ti0 = stamp ? __builtin_amdgcn_s_memtime() : 0ull;
     issue_next(std::integral_constant<int, (B + R - 1) % R>{}, true);
-#ifndef VERS_PRE_FOLD_LATE
-#define VERS_PRE_FOLD_LATE 0
-#endif
-    // VERS_PRE_FOLD_LATE=1 (tried in round 4, off): the fold of the tile the PREVIOUS step completed runs here, behind this
-    // step's loads, so that whatever it costs -- appends, a compaction, the wait for another wave's compaction (at 8 ranks a
-    // launch makes 17 k compactions: 35 of its 350 us by ablation) -- the wave has two steps in flight meanwhile instead of one.
-    // Same-box A/B: the scan alone equal (350-361 vs 351-354 us at 8 ranks), the step with three batches in flight WORSE
-    // (0.426-0.436 vs 0.408-0.415 ms): both ring buffers live across the fold take the kernel from 221 to 251 registers, and the
-    // exact finish of another batch (46 registers, 4 waves) no longer fits beside a scan block on a CU.
-    if (VERS_PRE_FOLD_LATE && fold_pending) {
-      const unsigned long long tf0 = stamp ? __builtin_amdgcn_s_memtime() : 0ull;
-      run_folds();
-      fold_pending = false;
-      if (stamp) t_fold += __builtin_amdgcn_s_memtime() - tf0;
-    }
     if (s0 + B < n_steps) {
       unsigned long long t1 = 0, t2 = 0;
       if (stamp) { t1 = __builtin_amdgcn_s_memtime(); t_issue += t1 - ti0; }
@@ -633,8 +523,7 @@ __device__ __forceinline__ void prescan_item_g(const Src& src, const PreParams& 
         }
         fold_tile = tc;
         ++tc;
-        if (VERS_PRE_FOLD_LATE) fold_pending = true;   // (folded at the top of the next step, behind its loads; after the loop for the last tile)
-        else run_folds();
+        run_folds();
         if (stamp) t_fold += __builtin_amdgcn_s_memtime() - t2;
       }
     }
@@ -642,9 +531,7 @@ __device__ __forceinline__ void prescan_item_g(const Src& src, const PreParams& 
   for (uint32_t s0 = 0; s0 < n_steps; s0 += R) {
     step(std::integral_constant<int, 0>{}, s0);
     step(std::integral_constant<int, 1>{}, s0);
-    if constexpr (R == 3) step(std::integral_constant<int, 2>{}, s0);
   }
-  if (fold_pending) run_folds();  // (the item's last tile)
   const unsigned long long te0 = stamp ? __builtin_amdgcn_s_memtime() : 0ull;
   if (stamp && lane == 0) {
     atomicAdd(p.stamps + 1, t_math);
@@ -698,14 +585,8 @@ __global__ __launch_bounds__(kWave * kPreWavesG) __attribute__((amdgpu_waves_per
         atomicMin(p.bounds32 + src.bound_slot(run_first * 4, (int)qi), (uint32_t)(srt >> 32));
     }
   };
-  // Time slices (p.quota != 0, VERS_PRE_SLICES > 1): the launch has `slices` times the blocks that fit the chip and a block LEAVES
-  // after its quota of quads, so that several times per launch every CU passes through the dispatcher -- where the waiting blocks of
-  // OTHER batches' kernels (coarse contraction, selection, grouping: too many registers to sit beside a scan block) get their turn
-  // DURING this scan instead of in a gap between two scans.
-  const uint32_t n_res = p.resident ? p.resident : gridDim.x;
-  uint32_t taken = 0;
+  const uint32_t n_res = gridDim.x;
   for (uint32_t b0 = blockIdx.x;; b0 += gridDim.x) {
-    if (p.quota != 0 && taken >= p.quota) break;
     uint32_t start = b0, count = 1;
     if (p.next_quad != nullptr) {
       if (threadIdx.x == 0) {
@@ -720,7 +601,6 @@ __global__ __launch_bounds__(kWave * kPreWavesG) __attribute__((amdgpu_waves_per
     }
     if (start >= n_quads) break;
     const uint32_t end = start + count < n_quads ? start + count : n_quads;
-    taken += end - start;
     for (uint32_t bi = start; bi < end; ++bi) {
     const ItemDesc d0 = src.items[4 * bi];
     // (block-uniform.  Only the quad right behind the run's last one: the slots written empty must be this block's own)
@@ -740,10 +620,7 @@ __global__ __launch_bounds__(kWave * kPreWavesG) __attribute__((amdgpu_waves_per
       // the first kStageU loads of every thread go out BEFORE the barriers (they fly while the slowest wave of the
       // previous quad finishes and its lists are written out); one load at a time behind the barriers was ~7 us per
       // quad at d = 768 -- 7 % of the launch
-#ifndef VERS_PRE_STAGE_U
-#define VERS_PRE_STAGE_U (96 / VERS_PRE_WAVES)
-#endif
-      constexpr int kStageU = VERS_PRE_STAGE_U;  // (default: x the block's threads / 32 slots = 192 column groups: d <= 768 in one round)
+      constexpr int kStageU = 96 / kPreWavesG;  // (default: x the block's threads / 32 slots = 192 column groups: d <= 768 in one round)
       const uint32_t n_cg = p.ld / 4u;
       f32x4 x[kStageU];
 #pragma unroll

@@ -226,11 +226,8 @@ __host__ __device__ __forceinline__ uint64_t blocked_index(uint64_t row, uint32_
 // Cache policy of a tile load: rows that a launch streams once (corpus / inverted lists) are loaded non-temporal
 // (aux = 2) -- same-box A/B: cfg2 flat scan 95.9 -> 91-94 us, single-query list scan 62.2 -> 57.9 us; matrices that
 // every work item re-reads (centroids) keep the default policy so that they stay in L2.  Src::kStreamOnce selects.
-#ifndef VERS_TILE_AUX
-#define VERS_TILE_AUX 2
-#endif
 template <bool STREAM_ONCE>
-constexpr int tile_aux() { return STREAM_ONCE ? VERS_TILE_AUX : 0; }
+constexpr int tile_aux() { return STREAM_ONCE ? 2 : 0; }
 
 struct TileLoader {
   __amdgpu_buffer_rsrc_t rsrc;
