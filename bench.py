@@ -322,7 +322,7 @@ def main():
                    else "prescan_kernel_g<false, 32, IvfSrc<32>> (inverted-list scan on the f32 matrix cores; exact finish in ivf_rescore_kernel)" if mfma_scan
                    else "scan_kernel<QG,0,IvfSrc<QG>> (inverted-list scan, ordered f32 chains; QG = 16 at this shape)")
     traffic, traffic_source = None, None
-    for tf in ("r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):  # newest PMC run of this exact configuration
+    for tf in ("r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):  # newest PMC run of this exact configuration
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", tf)))
             if (tj["config"] == {"rows": n, "d": d, "nlist": nlist, "nprobe": nprobe, "batch": B} and not multi
@@ -405,7 +405,7 @@ def main():
              "assign_pass_ms": round(bs["assign_ms"] / max(1.0, bs["assign_passes"]), 2), "assign_passes": int(bs["assign_passes"]),
              "points_redone_exactly_pct": round(100.0 * bs["redone_points"] / max(1.0, bs["gemm_flop"] / (2.0 * k_ * d)), 3),
              "update_centroids_ms_total": round(bs["update_ms"], 2), "cost_fold_ms_total": round(bs["cost_ms"], 2), "build_index_s": round(wall_s, 3), "note": note}
-        for pf in ("r04_kmeans.json", "r03_kmeans.json"):  # MFMA-busy of this kernel from the committed PMC pass (bench.py cannot collect counters itself)
+        for pf in ("r05_kmeans.json", "r04_kmeans.json", "r03_kmeans.json"):  # MFMA-busy of this kernel from the committed PMC pass (bench.py cannot collect counters itself)
             try:
                 pj = json.load(open(os.path.join(ROOT, "profiles", pf)))
                 e["mfma_busy_pct"] = pj["mfma_busy_pct"].get(str(int(k_)))
@@ -606,13 +606,30 @@ def main():
         e2e = float(np.median(e2e_reps))
         index.poll(st)
         gbs1 = float(np.sum(by1)) / (float(np.sum(ms1)) * 1e-3) / 1e9
+        # the drop-in call itself: vers_ivf_search with HOST pointers, one query per call -- what Index::search_approximate
+        # (ivfflat.rs:153) is behind the Rust shim: query in through the pinned block, three launches, result out, ONE synchronisation
+        import ctypes as C_
+        qh1 = np.ascontiguousarray(Q[:n_e2e, :d].cpu().numpy())
+        hi_, hd_, hc_ = np.zeros(top_k, dtype=np.uint64), np.zeros(top_k, dtype=np.float32), np.zeros(1, dtype=np.uint32)
+        lib_ = capi.lib()
+        hp = [C_.c_void_p(qh1[i].ctypes.data) for i in range(n_e2e)]
+        pi_, pd_, pc_ = C_.c_void_p(hi_.ctypes.data), C_.c_void_p(hd_.ctypes.data), C_.c_void_p(hc_.ctypes.data)
+        host_reps = []
+        for rep in range(3):
+            t0 = time.perf_counter()
+            for i in range(n_e2e):
+                lib_.vers_ivf_search(index._h, hp[i], 4 * d, 1, top_k, nprobe, pi_, pd_, pc_)
+            host_reps.append((time.perf_counter() - t0) / n_e2e)
+        host_call = float(np.median(host_reps))
         extra["single_query"] = {"kernel": "scan1_kernel<0> (ordered f32 chains, one query, one 64-row tile per wave)", "queries": nq1,
                                  "list_scan_us": round(float(np.mean(ms1)) * 1e3, 1), "probed_list_bytes": int(np.mean(by1)),
                                  "achieved_GBs": round(gbs1, 1), "frac": round(gbs1 / HBM_PEAK_GBS, 4),
                                  "end_to_end_us": round(e2e * 1e6, 1), "end_to_end_qps": round(1.0 / e2e, 1),
-                                 "end_to_end_us_stretches": [round(x * 1e6, 1) for x in e2e_reps]}
+                                 "end_to_end_us_stretches": [round(x * 1e6, 1) for x in e2e_reps],
+                                 "host_call_us": round(host_call * 1e6, 1), "host_call_us_stretches": [round(x * 1e6, 1) for x in host_reps],
+                                 "host_call": "vers_ivf_search (host pointers, one query per call, synchronous): the trait call behind the Rust shim, ctypes overhead included"}
         log(f"[bench] single query: list scan {extra['single_query']['list_scan_us']} us for {np.mean(by1) / 1e6:.0f} MB = "
-            f"{gbs1:.0f} GB/s ({gbs1 / HBM_PEAK_GBS:.2f} of peak); end to end {e2e * 1e6:.1f} us per query")
+            f"{gbs1:.0f} GB/s ({gbs1 / HBM_PEAK_GBS:.2f} of peak); end to end {e2e * 1e6:.1f} us per query resident, {host_call * 1e6:.1f} us per host-pointer call")
         # (a2) between batch 1 and the headline's batch: queries/s, us per batch and which list scan ran (the reference's interface is
         # per query, ivfflat.rs:153: small batches are the realistic serving shape).  One batch per size is kept for the CPU leg.
         sweep, sweep_keep = {}, {}
