@@ -609,17 +609,18 @@ def main():
         # the drop-in call itself: vers_ivf_search with HOST pointers, one query per call -- what Index::search_approximate
         # (ivfflat.rs:153) is behind the Rust shim: query in through the pinned block, three launches, result out, ONE synchronisation
         import ctypes as C_
-        qh1 = np.ascontiguousarray(Q[:n_e2e, :d].cpu().numpy())
+        nh = min(n_e2e, int(Q.shape[0]))
+        qh1 = np.ascontiguousarray(Q[:nh, :d].cpu().numpy())
         hi_, hd_, hc_ = np.zeros(top_k, dtype=np.uint64), np.zeros(top_k, dtype=np.float32), np.zeros(1, dtype=np.uint32)
         lib_ = capi.lib()
-        hp = [C_.c_void_p(qh1[i].ctypes.data) for i in range(n_e2e)]
+        hp = [C_.c_void_p(qh1[i].ctypes.data) for i in range(nh)]
         pi_, pd_, pc_ = C_.c_void_p(hi_.ctypes.data), C_.c_void_p(hd_.ctypes.data), C_.c_void_p(hc_.ctypes.data)
         host_reps = []
         for rep in range(3):
             t0 = time.perf_counter()
-            for i in range(n_e2e):
+            for i in range(nh):
                 lib_.vers_ivf_search(index._h, hp[i], 4 * d, 1, top_k, nprobe, pi_, pd_, pc_)
-            host_reps.append((time.perf_counter() - t0) / n_e2e)
+            host_reps.append((time.perf_counter() - t0) / nh)
         host_call = float(np.median(host_reps))
         extra["single_query"] = {"kernel": "scan1_kernel<0> (ordered f32 chains, one query, one 64-row tile per wave)", "queries": nq1,
                                  "list_scan_us": round(float(np.mean(ms1)) * 1e3, 1), "probed_list_bytes": int(np.mean(by1)),
