@@ -82,20 +82,24 @@ def cfg4_rank(dev_index=0, rows=100_000_000, d=768, nlist=16384, rank=0, world=8
     mem0, _ = capi.mem_stats(reset_peak=True)
     t0 = time.perf_counter(); t_gen2 = 0.0
     ix.upload_begin(cent, lens, rows)
+    t_begin = time.perf_counter() - t0
     for a in range(0, rows, chunk):
         m = min(chunk, rows - a)
         tg = time.perf_counter()
         capi.gen_rows_dev(Xc.data_ptr(), m, d, ld, 1, SEED_X, SEED_C, n_modes, sigma, start_row=a)
         torch.cuda.synchronize(); t_gen2 += time.perf_counter() - tg
         ix.upload_chunk_dev(Xc.data_ptr(), ld, A[a:].data_ptr(), a, m)
+    t_chunks = time.perf_counter() - t0 - t_begin - t_gen2
+    te = time.perf_counter()
     ix.upload_end()
+    t_end = time.perf_counter() - te
     t_up = time.perf_counter() - t0 - t_gen2
     mem_now, mem_peak = capi.mem_stats()
     owner = ix.owners()
     stored = int(lens[owner == rank].sum()) if world > 1 else int(lens.sum())
     lay = ix.layout_bytes()
     sh = ix.shadow_state() if hasattr(ix, "shadow_state") else None
-    out["upload"] = {"seconds": round(t_up, 2), "stored_rows": stored, "stored_lists": int((owner == rank).sum()) if world > 1 else nlist,
+    out["upload"] = {"seconds": round(t_up, 2), "begin_s": round(t_begin, 3), "chunks_s": round(t_chunks, 3), "end_s": round(t_end, 3), "stored_rows": stored, "stored_lists": int((owner == rank).sum()) if world > 1 else nlist,
                      "library_bytes_now": int(mem_now - mem0), "library_bytes_peak": int(mem_peak - mem0),
                      "f32_tile_rows_bytes": int(lay["rows"]), "fp16_shadow_bytes": int(lay["shadow"]), "rowmajor_bytes": int(lay["rowmajor"]),
                      "rowmajor_kept": bool(lay["rowmajor"] > 0), "shadow_kept": bool(lay["shadow"] > 0),
