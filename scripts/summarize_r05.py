@@ -50,10 +50,10 @@ def show_trace(title, tag, warm, top=14):
     return agg
 
 
-def mean_of(cnt, kernel_sub, counter, warm=0):
+def mean_of(cnt, kernel_sub, counter, warm=0, stop=None):
     for k, cs in cnt.items():
         if kernel_sub in k and counter in cs:
-            v = cs[counter][warm:] if len(cs[counter]) > warm else cs[counter]
+            v = cs[counter][warm:stop] if len(cs[counter]) > warm else cs[counter]
             return sum(v) / len(v), len(v)
     return None, 0
 
@@ -70,8 +70,8 @@ for k_, v_ in a3x.items():   # (the contractions / f32-row scan exist only in th
     a3.setdefault(k_, v_)
 # the production list-scan kernel: <true = fp16 shadow rows (default), <false = f32 rows (VERS_SHADOW=0; also run by bench.py's extra block)
 PK = "prescan_kernel_g<true" if any("prescan_kernel_g<true" in k for k in a3) else "prescan_kernel_g<false"
-f3, n3 = mean_of(pmc("cfg3/pmc_fetch"), PK, "FETCH_SIZE", 5)
-w3, _ = mean_of(pmc("cfg3/pmc_write"), PK, "WRITE_SIZE", 5)
+f3, n3 = mean_of(pmc("cfg3/pmc_fetch"), PK, "FETCH_SIZE", 5, 25)   # (the 20 timed launches, as for the durations)
+w3, _ = mean_of(pmc("cfg3/pmc_write"), PK, "WRITE_SIZE", 5, 25)
 pk = [v for k, v in a3.items() if PK in k]
 if pk and f3:
     d = pk[0][5:25]   # the 20 TIMED launches (5 warm-up before them; behind them the run's self-retrieval check -- a batch of 8 -- and its result read-backs)
