@@ -1033,7 +1033,10 @@ def main():
         index.close()
         torch.cuda.empty_cache()
         from scripts import rank_nominal as rn
-        for name, fn in (("cfg4_rank", lambda: rn.cfg4_rank(dev_index, log=log, check=0 if args.no_cpu else 32)), ("cfg5_rank", lambda: rn.cfg5_rank(dev_index, log=log))):
+        # (cfg4's nlist is not specified by BASELINE.json: 16384 per SURVEY.md 8d, and the headline's 4096 for comparability)
+        for name, fn in (("cfg4_rank", lambda: rn.cfg4_rank(dev_index, log=log, check=0 if args.no_cpu else 32)),
+                         ("cfg4_rank_nlist4096", lambda: rn.cfg4_rank(dev_index, nlist=4096, log=log, check=0 if args.no_cpu else 32)),
+                         ("cfg5_rank", lambda: rn.cfg5_rank(dev_index, log=log))):
             t0 = time.perf_counter()
             try:
                 extra[name] = fn()
