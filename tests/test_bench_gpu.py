@@ -63,3 +63,13 @@ def test_bench_multi_rank_path_through_rccl_with_one_rank():
     assert rc["n_gpus"] == 1 and rc["recall_at_10"] == one["recall_at_10"] and rc["value"] > 0
     assert "libvers_rccl.so" in rc["config"]["exchange"] and "ncclAllGather" in rc["config"]["exchange"], rc["config"]["exchange"]
     assert "row-sharded build over 1 ranks" in err
+
+
+def test_bench_gpus_8_over_gloo_on_one_gpu():
+    """world 8 -- the size the driver's scaling run ends at -- through every rank-count-dependent piece of the run (LPT over 8
+    owners, the row-sharded build's chain of 7 hops, partials of 8 ranks merged per batch) with the eight ranks sharing the test
+    box's GPU over gloo; same recall as one rank."""
+    one, _ = run_bench("--no-cpu", "--no-extra")
+    eight, err = run_bench("--gpus", "8", "--no-cpu", "--no-extra", env={"VERS_BENCH_BACKEND": "gloo"})
+    assert eight["n_gpus"] == 8 and eight["recall_at_10"] == one["recall_at_10"]
+    assert "lists sharded over 8 ranks (LPT)" in err and "vers_ivf_search_sharded_dev" in eight["config"]["exchange"]
