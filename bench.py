@@ -322,7 +322,13 @@ def main():
     # HBM traffic of the same kernel from the PMC passes of the committed rocprofv3 run (bench.py cannot collect
     # counters itself); used only when it was measured on this exact configuration and kernel.
     kernel_id = ("prescan_kernel_g<true" if shadow else "prescan_kernel_g<false") if mfma_scan else "scan_kernel"
-    kernel_name = ("prescan_kernel_g<true, 32, IvfSrc<32>> (inverted-list scan: fp16 shadow rows -> v_mfma_f32_32x32x16_f16; exact f32 finish in ivf_rescore_kernel)" if shadow
+    # (which instantiation ran follows the planner's rule, ivf_plan.hip: 64-query blocks with the query block as fp16 hi only where they
+    # fit LDS -- d <= 960 --, else 32 queries hi + lo up to d = 1152, 32 hi-only up to 2304, 16 hi-only up to 4608; VERS_PRE_WIDE=0: no 64)
+    wide64 = os.environ.get("VERS_PRE_WIDE", "1") != "0" and os.environ.get("VERS_PRE_NARROW", "0") == "0" and ((d + 63) // 64 * 64) * 64 * 2 + 16 + 64 * 64 * 8 + 6 * 64 * 4 <= 160 * 1024
+    pre_inst = ("prescan_kernel_g<true, 64, IvfSrc<64>, false> (64 queries per block as two sets of 32, query block fp16 hi only" if wide64 else
+                "prescan_kernel_g<true, 32, IvfSrc<32>, true> (32 queries per block, query block fp16 hi + lo" if d <= 1152 else
+                "prescan_kernel_g<true, 32, IvfSrc<32>, false> (32 queries per block, query block fp16 hi only")
+    kernel_name = (pre_inst + "; inverted-list scan: fp16 shadow rows -> v_mfma_f32_32x32x16_f16; exact f32 finish in ivf_rescore_kernel)" if shadow
                    else "prescan_kernel_g<false, 32, IvfSrc<32>> (inverted-list scan on the f32 matrix cores; exact finish in ivf_rescore_kernel)" if mfma_scan
                    else "scan_kernel<QG,0,IvfSrc<QG>> (inverted-list scan, ordered f32 chains; QG = 16 at this shape)")
     traffic, traffic_source = None, None

@@ -54,6 +54,7 @@ while time.time() - t0 < budget:
     # (every fourth seed with the narrow 16-query blocks forced at any d)
     ea = {"VERS_SHADOW": "0"} if seed % 3 == 0 else {}
     if seed % 4 == 1: ea["VERS_PRE_NARROW"] = "1"
+    if seed % 4 == 3: ea["VERS_PRE_WIDE"] = "0"      # (the 32-query hi + lo blocks of rounds 2-4: what d in (960, 1152] still runs)
     a = run(seed, ea, "/tmp/fz_a.npz"); bq = run(seed, {"VERS_PRESCAN": "0"}, "/tmp/fz_b.npz")
     A, B = np.load("/tmp/fz_a.npz"), np.load("/tmp/fz_b.npz")
     same = np.array_equal(A["cnt"], B["cnt"]) and all(  # entries past a query's count are undefined

@@ -77,7 +77,7 @@ if pk and f3:
     d = pk[0][5:25]   # the 20 TIMED launches (5 warm-up before them; behind them the run's self-retrieval check -- a batch of 8 -- and its result read-backs)
     print(f"{PK}...>: mean {sum(d)/len(d):.1f} us over the {len(d)} timed dispatches (min {min(d):.1f}); FETCH_SIZE mean {f3:.0f} KB over {n3} "
           f"dispatches -> HBM read bytes per launch = FETCH_SIZE * 1024 * 2 = {f3*1024*2:.4g}; WRITE_SIZE mean {w3 or 0:.0f} KB")
-    facts["cfg3"] = {"kernel": "prescan_kernel_g<true, 32, IvfSrc<32>, true> (fp16 shadow rows, query block hi + lo)" if "true" in PK else "prescan_kernel_g<false, 32, IvfSrc<32>, true> (f32 rows)", "config": {"rows": 10000000, "d": 768, "nlist": 4096, "nprobe": 32, "batch": 1024},
+    facts["cfg3"] = {"kernel": short([k for k in a3 if PK in k][0]).split("(")[0].replace("void ", "") + (" (fp16 shadow rows)" if "true" in PK else " (f32 rows)"), "config": {"rows": 10000000, "d": 768, "nlist": 4096, "nprobe": 32, "batch": 1024},
                      "FETCH_SIZE_KB_mean": f3, "WRITE_SIZE_KB_mean": w3, "hbm_read_bytes_per_launch": int(f3 * 1024 * 2),
                      "kernel_mean_us": sum(d) / len(d), "kernel_min_us": min(d),
                      "correction": "gfx950 reports half the bytes of wide coalesced streaming reads (MI355X_MICROARCH.md, HBM section): x2",

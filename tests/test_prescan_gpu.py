@@ -206,3 +206,12 @@ def test_hi_only_query_blocks_are_bit_exact():
     assert out["TIES"][0] == 1 and out["TIES"][1] > 0 and out["HUGE"] == (1, 64) and out["ONE"] == (1,) and out["TEN"][0] >= 10
     out = run({"VERS_PRE_HI_ONLY": "1", "VERS_PRESCAN": "2"})
     assert out["TIES"] == (1, 64)
+
+
+def test_32_query_hi_lo_blocks_without_the_wide_variant():
+    """VERS_PRE_WIDE=0: the 32-query blocks with both halves of the query's fp16 split (what every d <= 1152 ran until round 5 and
+    960 < d <= 1152 still runs); the default covers the 64-query hi-only blocks at small d."""
+    out = run({"VERS_PRE_WIDE": "0"})
+    assert out["TIES"][0] == 1 and out["TIES"][1] > 0 and out["HUGE"] == (1, 64) and out["ONE"] == (1,) and out["TEN"][0] >= 10 and out["BIG"] == (0,) and out["SLACK"] == (0,)
+    out = run({"VERS_PRE_WIDE": "0", "VERS_PRESCAN": "2"})
+    assert out["TIES"] == (1, 64)

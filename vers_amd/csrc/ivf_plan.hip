@@ -661,7 +661,11 @@ int32_t plan_search(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint32_t b
   {
     const bool narrow = knobs().pre_narrow;
     auto fits = [&](uint32_t nq, bool hi) { return prescan_lds_bytes_g(h->ld, kp, nq, hi) <= 160u * 1024u; };
-    if (!narrow && !(force_hi && use_shadow) && fits(kPreQ, false)) pre_nq = kPreQ;
+    // 64 queries per block (two sets of 32, hi-only) wherever they fit -- d <= 960 with the default slack --: lists probed by 33 .. 64
+    // queries of the batch are then streamed once instead of twice (VERS_PRE_WIDE=0: the 32-query hi + lo blocks of rounds 2-4)
+    static const bool wide_on = [] { const char* e = getenv("VERS_PRE_WIDE"); return !e || atoi(e) != 0; }();
+    if (!narrow && wide_on && use_shadow && fits(kPreQWide, true)) { pre_nq = kPreQWide; pre_hi_only = true; }
+    else if (!narrow && !(force_hi && use_shadow) && fits(kPreQ, false)) pre_nq = kPreQ;
     else if (!narrow && use_shadow && fits(kPreQ, true)) { pre_nq = kPreQ; pre_hi_only = true; }
     else if (!(force_hi && use_shadow) && fits(kPreQNarrow, false)) pre_nq = kPreQNarrow;
     else if (use_shadow && fits(kPreQNarrow, true)) { pre_nq = kPreQNarrow; pre_hi_only = true; }

@@ -291,9 +291,14 @@ int32_t launch_prescan(vers_ivf* h, const IvfSrc<NQ>& src, uint32_t items_bound,
   }
   p.next_quad = (p.debug & 32u) ? nullptr : quad_ctr;  // zeroed with the planning tables
   hi_only = hi_only && shadow;
+  if (NQ == kPreQWide && !hi_only) return fail(VERS_ERR_INVALID, "internal: 64-query blocks exist on the fp16 shadow with the hi-only query block");
   const size_t lds = prescan_lds_bytes_g(h->ld, kp, NQ, hi_only);
-  if (int32_t rc = hi_only ? scan_prepare_launch(prescan_kernel_g<true, NQ, IvfSrc<NQ>, false>, lds)
-                   : shadow ? scan_prepare_launch(prescan_kernel_g<true, NQ, IvfSrc<NQ>>, lds) : scan_prepare_launch(prescan_kernel_g<false, NQ, IvfSrc<NQ>>, lds)) return rc;
+  if constexpr (NQ == kPreQWide) {
+    if (int32_t rc = scan_prepare_launch(prescan_kernel_g<true, NQ, IvfSrc<NQ>, false>, lds)) return rc;
+  } else {
+    if (int32_t rc = hi_only ? scan_prepare_launch(prescan_kernel_g<true, NQ, IvfSrc<NQ>, false>, lds)
+                     : shadow ? scan_prepare_launch(prescan_kernel_g<true, NQ, IvfSrc<NQ>>, lds) : scan_prepare_launch(prescan_kernel_g<false, NQ, IvfSrc<NQ>>, lds)) return rc;
+  }
   uint32_t blocks = (items_bound + kWavesPerBlock - 1) / kWavesPerBlock;
   uint32_t per_cu = std::max<uint32_t>(1, std::min<uint32_t>(2, (uint32_t)((160u * 1024u) / lds)));  // 1 at d = 768 (measured: as fast as 2)
   if (knobs().pre_blocks_per_cu > 0) per_cu = (uint32_t)knobs().pre_blocks_per_cu;  // tuning knob
@@ -303,9 +308,13 @@ int32_t launch_prescan(vers_ivf* h, const IvfSrc<NQ>& src, uint32_t items_bound,
   if (blocks == 0) blocks = 1;
   const uint32_t slot = (uint32_t)(W->ev_count % SearchWs::kEvRing);
   if (W->ev_on) VERS_HIP_TRY(hipEventRecord(W->ev0[slot], st));
-  if (hi_only) hipLaunchKernelGGL((prescan_kernel_g<true, NQ, IvfSrc<NQ>, false>), dim3(blocks), dim3(kWave * kPreWavesG), lds, st, src, p);
-  else if (shadow) hipLaunchKernelGGL((prescan_kernel_g<true, NQ, IvfSrc<NQ>>), dim3(blocks), dim3(kWave * kPreWavesG), lds, st, src, p);
-  else hipLaunchKernelGGL((prescan_kernel_g<false, NQ, IvfSrc<NQ>>), dim3(blocks), dim3(kWave * kPreWavesG), lds, st, src, p);
+  if constexpr (NQ == kPreQWide) {
+    hipLaunchKernelGGL((prescan_kernel_g<true, NQ, IvfSrc<NQ>, false>), dim3(blocks), dim3(kWave * kPreWavesG), lds, st, src, p);
+  } else {
+    if (hi_only) hipLaunchKernelGGL((prescan_kernel_g<true, NQ, IvfSrc<NQ>, false>), dim3(blocks), dim3(kWave * kPreWavesG), lds, st, src, p);
+    else if (shadow) hipLaunchKernelGGL((prescan_kernel_g<true, NQ, IvfSrc<NQ>>), dim3(blocks), dim3(kWave * kPreWavesG), lds, st, src, p);
+    else hipLaunchKernelGGL((prescan_kernel_g<false, NQ, IvfSrc<NQ>>), dim3(blocks), dim3(kWave * kPreWavesG), lds, st, src, p);
+  }
   VERS_HIP_TRY(hipGetLastError());
   if (W->ev_on) {
     VERS_HIP_TRY(hipEventRecord(W->ev1[slot], st));
@@ -350,6 +359,7 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
   if (use_pre) {
     IvfSrc<kPreQ> src; fill_src(src);
     IvfSrc<kPreQNarrow> src_n; fill_src(src_n);  // (rows too long for a 32-query block: 16 queries per block, plan_search chose QG)
+    IvfSrc<kPreQWide> src_w; fill_src(src_w);    // (64 queries per block on the shadow, query block as fp16 hi only)
     // partial lists of the exact re-scan (fail_list [b] + its count, qflags [n_pj]: in the zeroed zone above)
     uint32_t fb_blocks = kFallbackBlocks;  // (a power of two; fewer when P x top_k is large: at most 32 MB of partial lists)
     while (fb_blocks > 16 && fallback_part_keys(fb_blocks, P, top_k) * sizeof(uint64_t) > (size_t(32) << 20)) fb_blocks /= 2;
@@ -358,8 +368,9 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
       if (int32_t rc2 = W->fb_ctr.reserve((2 * kFallbackBlocks + 1) * sizeof(uint32_t))) return rc2;
       VERS_HIP_TRY(hipMemsetAsync(W->fb_ctr.p, 0, (2 * kFallbackBlocks + 1) * sizeof(uint32_t), st));
     }
-    if (int32_t rc2 = QG == kPreQNarrow ? launch_prescan(h, src_n, (uint32_t)items_bound, kp, qflags, quad_ctr, use_shadow, hi_only, st)
-                                        : launch_prescan(h, src, (uint32_t)items_bound, kp, qflags, quad_ctr, use_shadow, hi_only, st)) return rc2;
+    if (int32_t rc2 = QG == kPreQWide     ? launch_prescan(h, src_w, (uint32_t)items_bound, kp, qflags, quad_ctr, use_shadow, hi_only, st)
+                      : QG == kPreQNarrow ? launch_prescan(h, src_n, (uint32_t)items_bound, kp, qflags, quad_ctr, use_shadow, hi_only, st)
+                                          : launch_prescan(h, src, (uint32_t)items_bound, kp, qflags, quad_ctr, use_shadow, hi_only, st)) return rc2;
     if (int32_t rc2 = start_pending_ahead(h, st)) return rc2;  // the next batch's coarse quantiser: under this batch's exact finish
     RescoreArgs a;
     a.partials = W->partials.as<uint64_t>(); a.P = P; a.S_max = S_max; a.kp = kp; a.top_k = top_k; a.d_pad = h->ld;

@@ -38,6 +38,12 @@ typedef __attribute__((ext_vector_type(8))) _Float16 f16x8_t;
 typedef __attribute__((ext_vector_type(4))) _Float16 f16x4_t;
 
 constexpr int kPreQ = 32;        // queries per group: two sets of 16 (one 16x16x1 4-block MFMA covers 64 rows x 16 queries)
+// Round 5: the WIDE variant on the fp16 shadow -- 64 queries per block as two sets of 32 (two B operands per row piece), the query
+// block as fp16 hi only (64 x 768 x 2 B = 98 KB: the bytes of 32 queries' hi + lo).  A list probed by more than 32 queries of the
+// batch was streamed once per group of 32 (streamed / union rows 1.05 at cfg3, 1.5 on an index with one popular list): with 64 per
+// group almost every list is streamed ONCE.  Groups of up to 32 run the first set alone (half the MFMAs of the hi + lo block).
+constexpr int kPreQWide = 64;
+constexpr int kPreCtl = 64;      // entries per control array of a block (cnt | done | thr | locks | pair | sequence base)
 constexpr int kPreAux = 2;  // cache policy of the row-tile loads: 2 = nt (streamed once); same-box A/B at cfg3: -1.8 % vs default
 constexpr uint32_t kPreMaxKp = 64;  // widest list: one sorted key per lane
 
@@ -156,7 +162,7 @@ __host__ __device__ inline uint32_t pre_cap(uint32_t kp) { return kp <= 40u ? 64
 // hi_only: the fp16 query block WITHOUT its lo half (2 B per element instead of 4): 32 queries fit up to d = 2304, 16 up to
 // d = 4608; the certificate charges the query's measured fp16 residual instead (pre_bound, Rq2).
 inline size_t prescan_lds_bytes_g(uint32_t ld, uint32_t kp, uint32_t nq = 32, bool hi_only = false) {  // query block | hand-out word | buffers | cnt, done, thr, locks
-  return (size_t)ld * nq * (hi_only ? sizeof(uint16_t) : sizeof(float)) + 16 + (size_t)nq * pre_cap(kp) * sizeof(uint64_t) + 6 * 32 * sizeof(uint32_t);  // (+ pair | sequence base of the quad's queries)
+  return (size_t)ld * nq * (hi_only ? sizeof(uint16_t) : sizeof(float)) + 16 + (size_t)nq * pre_cap(kp) * sizeof(uint64_t) + 6 * kPreCtl * sizeof(uint32_t);  // (+ pair | sequence base of the quad's queries)
 }
 constexpr int kPreQNarrow = 16;
 
@@ -210,20 +216,22 @@ __device__ __forceinline__ void prescan_item_g(const Src& src, const PreParams& 
     stage();
     return;
   }
-  constexpr int kSets = BF ? 1 : 2;   // query columns a lane serves (accumulator layouts: see above)
+  constexpr int kSets = BF ? (NQ > 32 ? 2 : 1) : 2;   // query columns a lane serves (accumulator layouts: see above)
+  constexpr int kSetW = BF ? 32 : 16;                  // query columns per set: one MFMA's N
+  constexpr int kAcc = BF ? 2 * kSets : 2;             // accumulators: fp16 rows [set][row half of the tile], f32 rows [set]
   const int n = BF ? (lane & 31) : (lane & 15), quarter = BF ? (lane >> 5) : (lane >> 4);
   const uint32_t kp = p.kp, cap = pre_cap(p.kp);
   uint32_t* const cnt = ctl;                 // [32] slots reserved in the query's buffer (may run past cap: overflow)
-  uint32_t* const done = ctl + kPreQ;        // [32] slots written
-  uint32_t* const thrq = ctl + 2 * kPreQ;    // [32] order bits of the block's threshold of the query (0xFFFFFFFF: none yet)
-  uint32_t* const locks = ctl + 3 * kPreQ;   // [32] compaction locks
+  uint32_t* const done = ctl + kPreCtl;        // slots written
+  uint32_t* const thrq = ctl + 2 * kPreCtl;    // order bits of the block's threshold of the query (0xFFFFFFFF: none yet)
+  uint32_t* const locks = ctl + 3 * kPreCtl;   // compaction locks
   // [32] (query, probe) pair of each query of the quad and [32] the sequence number of that probe's first row: resolved ONCE per
   // staged query block by 32 threads (stage) instead of by every lane of every wave of every item through a chain of five
   // dependent global loads (items -> pair_off -> pairs -> pj_pref, then the bound word): 5-8 us per item, which is what made
   // short items expensive
-  const uint32_t* const qpair = ctl + 4 * kPreQ;
-  const uint32_t* const qpref = ctl + 5 * kPreQ;
-  const bool two = !BF && NQ > 16 && v.nq > 16;  // wave-uniform
+  const uint32_t* const qpair = ctl + 4 * kPreCtl;
+  const uint32_t* const qpref = ctl + 5 * kPreCtl;
+  const bool two = kSets == 2 && NQ > kSetW && v.nq > (uint32_t)kSetW;  // wave-uniform: the group reaches into the second set
   const bool stamp = (p.debug & 16u) != 0;
   const unsigned long long tp0 = stamp ? __builtin_amdgcn_s_memtime() : 0ull;
   // the first tile loads go out before anything else: they fly while the item is set up and the block stages
@@ -269,7 +277,7 @@ __device__ __forceinline__ void prescan_item_g(const Src& src, const PreParams& 
   bool live[2];
   uint32_t vseq[2] = {0, 0};
   float thr[2];
-  f32x16_t acc[2];
+  f32x16_t acc[kAcc];
   bool bad = false;
   // The eight waves of the block walk their tiles at the same pace and meet the same full buffers: every wave starts
   // its round over the overflowed query columns at its own offset, so that they do not all queue for the same lock.
@@ -300,7 +308,7 @@ __device__ __forceinline__ void prescan_item_g(const Src& src, const PreParams& 
 #pragma unroll
     for (int e = 0; e < 16; ++e) pm |= a[e] <= thr[S] ? 1u << e : 0u;
     if (__ballot(pm != 0) != 0 && !(p.debug & 1u)) {
-      const uint32_t q = (uint32_t)(S * 16 + n);
+      const uint32_t q = (uint32_t)(S * kSetW + n);
       uint64_t* const bq = cbuf + (size_t)q * cap;
       const uint32_t sq0 = vseq[S] + r0;
       // reserve + store: every lane for its own query column, the whole wave in one LDS atomic.  Bits of `pend` that found
@@ -388,7 +396,7 @@ __device__ __forceinline__ void prescan_item_g(const Src& src, const PreParams& 
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // buffer, done and threshold before the counter re-opens it
             if (lane == 0) __hip_atomic_store(cnt + qq, kp, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if (lane == (int)(BF ? qq : (qq & 15u)) && !(p.debug & 8192u)) atomicMin(p.bounds32 + vslot[S], kb);
+            if (lane == (int)(BF ? (qq & 31u) : (qq & 15u)) && !(p.debug & 8192u)) atomicMin(p.bounds32 + vslot[S], kb);
             if (stamp && lane == 0) atomicAdd(p.stamps + 12, 1ull);
           }
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -418,15 +426,17 @@ __device__ __forceinline__ void prescan_item_g(const Src& src, const PreParams& 
   stage();
   // (the accumulators start behind the block-wide part: across it they would be 32 live registers at the kernel's register peak)
 #pragma unroll
-  for (int e = 0; e < 16; ++e) acc[0][e] = acc[1][e] = 0.0f;
+  for (int e = 0; e < 16; ++e)
+#pragma unroll
+    for (int a_ = 0; a_ < kAcc; ++a_) acc[a_][e] = 0.0f;
   // (after the block-wide part: the quad's pair / sequence-base table in LDS is what stage() filled -- or left, for the next quad of a run)
 #pragma unroll
   for (int s = 0; s < 2; ++s) {
-    live[s] = s < kSets && s * 16 + n < (int)v.nq && s * 16 + n < NQ;  // (narrow blocks: the MFMA's query columns 16 .. 31 repeat 0 .. 15 and are ignored)
+    live[s] = s < kSets && s * kSetW + n < (int)v.nq && s * kSetW + n < NQ;  // (narrow blocks: the MFMA's query columns 16 .. 31 repeat 0 .. 15 and are ignored)
     thr[s] = -__builtin_inff();  // dead query columns never hit
     if (live[s]) {
-      vseq[s] = qpref[s * 16 + n] + v.row0;
-      vslot[s] = src.slot_of_pair(qpair[s * 16 + n]);
+      vseq[s] = qpref[s * kSetW + n] + v.row0;
+      vslot[s] = src.slot_of_pair(qpair[s * kSetW + n]);
       const uint32_t b0 = __hip_atomic_load(p.bounds32 + vslot[s], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       thr[s] = b0 == 0xFFFFFFFFu ? __builtin_inff() : __uint_as_float(order_bits_to_f32_bits(b0));
     }
@@ -439,6 +449,11 @@ __device__ __forceinline__ void prescan_item_g(const Src& src, const PreParams& 
     if constexpr (BF) {
       fold(Set0{}, acc[0], fold_tile, 0u);
       fold(Set0{}, acc[1], fold_tile, 1u);
+      if constexpr (kSets == 2)
+        if (two) {
+          fold(Set1{}, acc[kAcc - 2], fold_tile, 0u);
+          fold(Set1{}, acc[kAcc - 1], fold_tile, 1u);
+        }
     } else {
       fold(Set0{}, acc[0], fold_tile, 0u);
       if (two) fold(Set1{}, acc[1], fold_tile, 0u);
@@ -485,6 +500,13 @@ __device__ __forceinline__ void prescan_item_g(const Src& src, const PreParams& 
               if constexpr (LO) acc[hf] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ar, bl, acc[hf], 0, 0, 0);  // (small term first)
               acc[hf] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ar, bh, acc[hf], 0, 0, 0);
             }
+            if constexpr (kSets == 2)
+              if (two) {  // the second set of 32 queries: the same row pieces against their B operand (32 slots further)
+                const f16x8_t bh2 = qh[cb * kCb + 32];
+#pragma unroll
+                for (int hf = 0; hf < 2; ++hf)
+                  acc[kAcc - 2 + hf] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8_t, buf[B][2 * cb + hf]), bh2, acc[kAcc - 2 + hf], 0, 0, 0);
+              }
           }
         }
       } else {
@@ -505,7 +527,7 @@ __device__ __forceinline__ void prescan_item_g(const Src& src, const PreParams& 
               thr[s] = g < thr[s] ? g : thr[s];
             }
             // this block's threshold of the query (set by whichever wave compacted its buffer last)
-            const uint32_t bh = __hip_atomic_load(thrq + (uint32_t)(s * 16 + n), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+            const uint32_t bh = __hip_atomic_load(thrq + (uint32_t)(s * kSetW + n), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
             if (bh != 0xFFFFFFFFu) {
               const float g = __uint_as_float(order_bits_to_f32_bits(bh));
               thr[s] = g < thr[s] ? g : thr[s];
@@ -517,6 +539,11 @@ __device__ __forceinline__ void prescan_item_g(const Src& src, const PreParams& 
           // + |x_row|^2 for every query column: A[i][k] = xn of lane (i, k) = row 32k + i of the tile, B[k][j] = (k == h)
           acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(xn[B], quarter == 0 ? nrm : 0.0f, acc[0], 0, 0, 0);
           acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(xn[B], quarter == 1 ? nrm : 0.0f, acc[1], 0, 0, 0);
+          if constexpr (kSets == 2)
+            if (two) {
+              acc[kAcc - 2] = __builtin_amdgcn_mfma_f32_32x32x2f32(xn[B], quarter == 0 ? nrm : 0.0f, acc[kAcc - 2], 0, 0, 0);
+              acc[kAcc - 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(xn[B], quarter == 1 ? nrm : 0.0f, acc[kAcc - 1], 0, 0, 0);
+            }
         } else {
           acc[0] = __builtin_amdgcn_mfma_f32_16x16x1f32(xn[B], nrm, acc[0], 0, 0, 0);  // + |x_row|^2 for every query column
           if (two) acc[1] = __builtin_amdgcn_mfma_f32_16x16x1f32(xn[B], nrm, acc[1], 0, 0, 0);
@@ -550,7 +577,7 @@ __device__ __forceinline__ void prescan_item_g(const Src& src, const PreParams& 
 
 template <bool BF, int NQ, class Src, bool LO = true>
 __global__ __launch_bounds__(kWave * kPreWavesG) __attribute__((amdgpu_waves_per_eu(kPreWpe, kPreWpe))) void prescan_kernel_g(Src src, PreParams p) {
-  static_assert(NQ == kPreQ || NQ == kPreQNarrow, "32 queries per block, or the narrow variant's 16");
+  static_assert(NQ == kPreQ || NQ == kPreQNarrow || (NQ == kPreQWide && BF && !LO), "32 queries per block, the narrow variant's 16, or 64 with the hi-only block on the shadow");
   static_assert(BF || LO, "the hi-only query block belongs to the fp16 shadow");
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -612,7 +639,7 @@ __global__ __launch_bounds__(kWave * kPreWavesG) __attribute__((amdgpu_waves_per
     // The quad's query block: <= 32 padded queries gathered from their rows, scaled by -2 (-1: cosine distance), in the MFMA operand
     // layout l4[column group * 32 + slot].  Every thread serves ONE slot (512 % 32 == 0; 16 slots when the group
     // holds <= 16 queries, so that all threads load) and its row pointer is resolved here, ahead of the barrier.
-    const uint32_t ns = (NQ > 16 && (BF || v.nq > 16)) ? 32u : 16u;
+    const uint32_t ns = (NQ > 32 && v.nq > 32u) ? 64u : ((NQ > 16 && (BF || v.nq > 16)) ? 32u : 16u);
     const uint32_t slot = threadIdx.x & (ns - 1u), cg0 = threadIdx.x / ns, cg_step = (kWave * kPreWavesG) / ns;
     const float* qrow = (!cont && slot < v.nq) ? src.query_row(it, slot) : nullptr;
     auto stage = [&]() {
@@ -633,11 +660,11 @@ __global__ __launch_bounds__(kWave * kPreWavesG) __attribute__((amdgpu_waves_per
       const unsigned long long ts1 = (p.debug & 16u) ? __builtin_amdgcn_s_memtime() : 0ull;
       write_out();
       __syncthreads();
-      if (threadIdx.x < 4 * kPreQ) ctl[threadIdx.x] = (threadIdx.x >> 5) == 2 ? 0xFFFFFFFFu : 0u;  // empty buffers, no threshold, locks open
+      if (threadIdx.x < 4 * kPreCtl) ctl[threadIdx.x] = (threadIdx.x / kPreCtl) == 2 ? 0xFFFFFFFFu : 0u;  // empty buffers, no threshold, locks open
       if (threadIdx.x < v.nq) {  // the quad's queries: their (query, probe) pair and the sequence number of the probe's first row
         const uint32_t pr = src.pair_of(bi * 4, (int)threadIdx.x);
-        ctl[4 * kPreQ + threadIdx.x] = pr;
-        ctl[5 * kPreQ + threadIdx.x] = src.pj_pref[pr];
+        ctl[4 * kPreCtl + threadIdx.x] = pr;
+        ctl[5 * kPreCtl + threadIdx.x] = src.pj_pref[pr];
       }
       f32x4* l4 = reinterpret_cast<f32x4*>(qlds);
       auto put = [&](uint32_t cg, const f32x4& y) {  // columns 4*cg .. 4*cg + 3 of the thread's query, already scaled
