@@ -89,10 +89,8 @@ def main():
         with socket.socket() as s_:
             s_.bind(("127.0.0.1", 0))
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(s_.getsockname()[1]), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
-    # stdout carries ONE JSON line: RCCL's start-up banner (NCCL_DEBUG=VERSION prints it to stdout when a communicator is made)
-    # is replaced by the adapter's own report on stderr (vers_rccl_versions: built against / running on / which librccl)
-    if os.environ.get("NCCL_DEBUG", "").upper() == "VERSION":
-        os.environ["NCCL_DEBUG"] = "WARN"
+    # stdout carries ONE JSON line: whatever RCCL has to say (its start-up banner under NCCL_DEBUG=VERSION, warnings) goes to stderr
+    os.environ.setdefault("NCCL_DEBUG_FILE", "/dev/stderr")
     import torch
     # one process per GPU.  (VERS_BENCH_BACKEND=gloo + fewer GPUs than ranks is a debugging aid only: it lets
     # the multi-rank code path run on a 1-GPU box, staging the all-gather through host memory.)
