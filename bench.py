@@ -89,7 +89,10 @@ def main():
         with socket.socket() as s_:
             s_.bind(("127.0.0.1", 0))
             os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(s_.getsockname()[1]), RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
-    # stdout carries ONE JSON line: whatever RCCL has to say (its start-up banner under NCCL_DEBUG=VERSION, warnings) goes to stderr
+    # stdout carries ONE JSON line.  RCCL prints its start-up banner to stdout under NCCL_DEBUG=VERSION (this pool's default): the
+    # adapter reports the same facts on stderr (vers_rccl_versions), so that level is dropped; any other level's output goes to stderr
+    if os.environ.get("NCCL_DEBUG", "").upper() == "VERSION":
+        del os.environ["NCCL_DEBUG"]
     os.environ.setdefault("NCCL_DEBUG_FILE", "/dev/stderr")
     import torch
     # one process per GPU.  (VERS_BENCH_BACKEND=gloo + fewer GPUs than ranks is a debugging aid only: it lets
