@@ -435,7 +435,7 @@ def main():
         per_row_noshadow = float(mem_now - sst["bytes"] - lay["rowmajor"]) / rows_stored
         per_row_shadow_only = float(mem_now - lay["rowmajor"]) / rows_stored
         extra["memory"] = {"library_bytes_now": int(mem_now), "library_bytes_peak_during_build": int(mem_peak), "f32_tile_rows_bytes": int(lay["rows"]),
-                           "shadow_bytes": int(sst["bytes"]), "shadow_active": bool(sst["active"]), "rowmajor_copy_bytes": int(lay["rowmajor"]),
+                           "shadow_bytes": int(sst["bytes"]), "shadow_active": bool(sst["active"]), "rowmajor_copy_bytes": int(lay["rowmajor"]), "rowmajor_kept": bool(lay["rowmajor"] > 0),
                            "bytes_per_stored_row": round(per_row, 1), "bytes_per_stored_row_without_rowmajor_copy": round(per_row_shadow_only, 1),
                            "bytes_per_stored_row_without_shadow_and_rowmajor_copy": round(per_row_noshadow, 1), "hbm_bytes": hbm_total,
                            "max_N_per_gpu_as_configured": int((hbm_total - (8 << 30)) / per_row), "max_N_per_gpu_with_shadow": int((hbm_total - (8 << 30)) / per_row_shadow_only),
