@@ -1010,8 +1010,18 @@ int32_t relayout(vers_ivf* h) {
 
 // ---- streamed upload: begin / chunk / end (see vers_hip.h) -----------------------------------------------------------------
 
+static int32_t upload_begin_inner(vers_ivf* h, const float* centroids, uint64_t k64, uint64_t c_stride_bytes, const uint64_t* list_lengths, uint64_t n_total);
 int32_t upload_begin_locked(vers_ivf* h, const float* centroids, uint64_t k64, uint64_t c_stride_bytes, const uint64_t* list_lengths,
                             uint64_t n_total) {
+  const int32_t rc = upload_begin_inner(h, centroids, k64, c_stride_bytes, list_lengths, n_total);
+  if (rc) {  // (a failed begin leaves an EMPTY handle: no index, no stored rows for the exhaustive scan, no upload in progress)
+    h->k = 0; h->n_total = 0; h->cap_rows = 0;
+    upload_abandon(h);
+  }
+  return rc;
+}
+static int32_t upload_begin_inner(vers_ivf* h, const float* centroids, uint64_t k64, uint64_t c_stride_bytes, const uint64_t* list_lengths,
+                                  uint64_t n_total) {
   const uint32_t k = (uint32_t)k64;
   VERS_HIP_TRY(hipDeviceSynchronize());  // searches still in flight read the storage this call re-plans
   upload_abandon(h);

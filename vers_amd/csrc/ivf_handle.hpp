@@ -43,6 +43,7 @@ struct SearchWs {
   DevBuf clower, lower;  // lower bounds of multi-pass results (coarse ranking of more than 64 lists; top_k > 64)
   DevBuf qp, qil, cpart, probe, pj, lists, pairs, items, groups, qblocks, partials, status, o_ids, o_dist, o_cnt, xpart;
   DevBuf g_send, g_recv;  // sharded search without the host in the loop: this rank's [2][b][top_k] partial | the world's
+  bool g_poisoned = false;  // g_send holds the poison mark of a locally failed batch (cleared before the next partial is written)
   static constexpr uint32_t kEvRing = 64;  // scan-launch timing ring (measurement hook)
   hipEvent_t ev0[kEvRing] = {}, ev1[kEvRing] = {};
   hipEvent_t evc[3] = {};  // batched coarse quantiser of the most recent search: before the GEMM | after it | after select / re-score

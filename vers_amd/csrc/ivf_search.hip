@@ -659,6 +659,10 @@ static int32_t sharded_common(vers_ivf_t* h, const vers_gather_t* g, const float
   // kPoisonId -- so that the gather completes everywhere; every rank's merge sees the mark and latches kStPeerFailed in its
   // stream's status word (vers_ivf_poll -> VERS_ERR_COMM); this rank also returns its own error from the call.
   int32_t local_rc = VERS_OK;
+  if (W->g_poisoned) {  // (this workspace's send buffer carried the poison mark once: a partial whose first query finds nothing leaves the word as it is)
+    (void)hipMemsetAsync(mine + part, 0, sizeof(uint64_t), st);
+    W->g_poisoned = false;
+  }
   if (test_fail_sharded_ref().load() > 0 && test_fail_sharded_ref().fetch_sub(1) > 0) local_rc = fail(VERS_ERR_HIP, std::string(who) + ": injected local failure (test hook)");
   if (!local_rc) local_rc = [&]() -> int32_t {
     if (int32_t rc = ensure_out(h, part, b)) return rc;
@@ -678,6 +682,7 @@ static int32_t sharded_common(vers_ivf_t* h, const vers_gather_t* g, const float
     const uint64_t mark = kPoisonId;
     (void)hipMemsetAsync(mine, 0xFF, 2 * part * sizeof(uint64_t), st);
     (void)hipMemcpyAsync(mine + part, &mark, sizeof(mark), hipMemcpyHostToDevice, st);  // (pageable source: copied before the call returns)
+    W->g_poisoned = true;
     (void)hipGetLastError();
     fail(local_rc, why + " [this rank joined the batch's all-gather with a poisoned partial]");
   }
