@@ -12,7 +12,6 @@ for rep in 1 2; do
 run "default (rep $rep)" A=1
 for tag in "$@"; do run "variant $tag (rep $rep)" VERS_LIB_PATH=$PWD/vers_amd/lib/variants/libvers_hip_$tag.so; done
 done
-run "hot lists first OFF" VERS_HOT_FIRST=0
 run "no list inserts (debug 1)" VERS_SCAN_DEBUG=1
 run "no math (debug 2)" VERS_SCAN_DEBUG=2
 run "no inserts, no math (debug 3)" VERS_SCAN_DEBUG=3

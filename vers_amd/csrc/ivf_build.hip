@@ -485,8 +485,7 @@ int32_t install_index(vers_ivf* h, const float* X, uint32_t ldx, uint64_t n, con
   VERS_HIP_TRY(hipStreamSynchronize(st));
   if (int32_t rc = plan_storage(h, lens.data(), k, st)) return rc;
   if (n) {
-    static const bool by_tile = [] { const char* e = getenv("VERS_GATHER_TILES"); return !e || atoi(e) != 0; }();
-    if (by_tile && h->cap_rows >= 64) {
+    if (h->cap_rows >= 64) {  // whole destination tiles through LDS; (the float4-wise placement of round 1 is kept for indexes of less than one tile)
       const size_t lds = 64 * (size_t)(kGatherCols4 + 1) * sizeof(f32x4);
       if (int32_t rc = scan_prepare_launch(gather_tiles_kernel, lds)) return rc;
       hipLaunchKernelGGL(gather_tiles_kernel, dim3((unsigned)(h->cap_rows / 64)), dim3(256), lds, st, X, ldx, h->d, h->ld, sorted.as<uint32_t>(),
@@ -673,8 +672,7 @@ int32_t install_index_sharded(vers_ivf* h, const float* X, uint32_t ldx, uint64_
   sbuf.release();
   sids.release();
   // (capacity slack and tile padding of the storage are zero rows: (0 - q)^2 terms never enter a result, ids stay 0xFFFFFFFF)
-  static const bool by_tile = [] { const char* e = getenv("VERS_GATHER_TILES"); return !e || atoi(e) != 0; }();
-  if (by_tile && h->cap_rows >= 64 && !segs.empty()) {
+  if (h->cap_rows >= 64 && !segs.empty()) {
     // whole destination tiles through LDS (gather_tiles_kernel), every tile written completely: no memset of the storage
     DevBuf row_src;
     if (int32_t rc = row_src.reserve(h->cap_rows * sizeof(uint32_t))) return rc;

@@ -375,26 +375,18 @@ inline std::atomic<uint32_t>& pre_min_batch_ref() {
 
 // Tuning / A-B knobs of the search path (environment, read ONCE per process; DESIGN.md section 5 "Switches").
 struct SearchKnobs {
-  int qg = 0;            // VERS_QG: 8 or 16 forces the ordered-chain group width
   int pre_slack = 0;     // VERS_PRE_SLACK: slack keys of the matrix-core lists
   long seg_rows = 0;     // VERS_SEG_ROWS
-  int pre_blocks_per_cu = 0;  // VERS_PRE_BLOCKS_PER_CU
   int pre_mode = 1;      // VERS_PRESCAN: 0 ordered chains for batches too, 2 every certificate fails
-  bool seg_balanced = true;   // VERS_SEG_BALANCED
-  uint32_t hot_ranks = 1;     // VERS_HOT_FIRST
   bool pre_narrow = false;    // VERS_PRE_NARROW: 16-query blocks in the matrix-core list scan whatever d is
 };
 inline const SearchKnobs& knobs() {
   static const SearchKnobs k = [] {
     SearchKnobs s;
     auto geti = [](const char* n, long dflt) { const char* e = getenv(n); return e ? atol(e) : dflt; };
-    s.qg = (int)geti("VERS_QG", 0);
     s.pre_slack = (int)geti("VERS_PRE_SLACK", 0);
     s.seg_rows = geti("VERS_SEG_ROWS", 0);
-    s.pre_blocks_per_cu = (int)geti("VERS_PRE_BLOCKS_PER_CU", 0);
     s.pre_mode = (int)geti("VERS_PRESCAN", 1);
-    s.seg_balanced = geti("VERS_SEG_BALANCED", 1) != 0;
-    s.hot_ranks = (uint32_t)geti("VERS_HOT_FIRST", 1);
     s.pre_narrow = geti("VERS_PRE_NARROW", 0) != 0;
     return s;
   }();

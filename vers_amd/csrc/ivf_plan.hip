@@ -628,7 +628,6 @@ int32_t plan_search(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint32_t b
   // query-group width of the list scan: a list shared by more queries than one group holds is streamed
   // once per group, so pick the width from the expected queries per list
   int QG = (b == 1 || pairs_est < 2 * lists_est) ? 1 : (pairs_est >= 6 * lists_est ? 16 : 8);
-  if (QG != 1 && (knobs().qg == 8 || knobs().qg == 16)) QG = knobs().qg;  // tuning knob
   // The ordered-chain kernels stage a group's queries in LDS (QG x ld floats): rows too long for a group of 16 take 8, then one
   // query per item (scalar operands: no LDS at all) -- the reference has no dimension cap (ivfflat.rs:153), neither has this path
   // (round 4 returned "vector dimension too large" at d > 2560 with 16-query groups).
@@ -696,26 +695,12 @@ int32_t plan_search(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint32_t b
   // matrix-core scan: an average list is one quad of items (per-item set-up and the block's barriers amortise over
   // ~10 tiles; measured at cfg3: 640-row targets beat 256- and 1024-row ones)
   if (use_pre) seg_rows = (uint32_t)round_up64(std::max<uint64_t>(256, (avg_len_all + 3) / 4), kWave);
-  if (use_pre) {
-    // ... unless that leaves fewer than ~8 quads per CU -- the lists sharded over GPUs: 2.7 at 8 ranks, the last third of the
-    // launch half empty.  Then the lists are cut finer; the scan hands quads out in RUNS and stages once per run of one list
-    // (prescan_kernel_g), so the finer cut costs no staging while work is plentiful and balances the tail.
-    const uint64_t lists_here = std::max<uint64_t>(1, lists_est / std::max<uint32_t>(1, h->world));
-    const uint64_t quads_est = lists_here * std::max<uint64_t>(1, pairs_est / std::max<uint64_t>(1, lists_est * kPreQ));
-    // (measured, same box, 8 ranks: 392 us with whole-list quads, 425 with four quads per list, 0.497 / 0.523 / 0.537 ms per step
-    // with three batches in flight at 1 / 2 / 4 -- a short item pays its pipeline fill and its waves' waits for each other
-    // whatever the staging costs: OFF by default, VERS_FINE_QUADS=2|4 to try)
-    static const int fine_max = [] { const char* e = getenv("VERS_FINE_QUADS"); return e ? atoi(e) : 1; }();
-    uint32_t fine = 1;
-    while ((int)fine < fine_max && quads_est * fine < 8ull * (uint64_t)h->n_cu && seg_rows / (2 * fine) >= 128) fine *= 2;
-    seg_rows = (uint32_t)round_up64(seg_rows / fine, kWave);
-  }
+  // (cutting the lists of a SHARDED scan into finer quads -- 2.7 whole-list quads per CU at 8 ranks -- was tried in rounds 3-4 and lost: a
+  // short item pays its pipeline fill and its waves' waits for each other whatever the staging costs)
   if (knobs().seg_rows > 0) seg_rows = (uint32_t)round_up64(std::max(64l, knobs().seg_rows), kWave);  // tuning knob
   // matrix-core scan: per-list balanced segments of about seg_rows rows (list_seg_rows)
-  // per-list balanced segments (list_seg_rows): same-box A/B at cfg3 5.96 ms vs 6.27 ms with fixed 640-row segments;
-  // VERS_SEG_BALANCED=0 switches them off
-  const bool seg_balanced = knobs().seg_balanced;
-  const uint32_t seg_target = use_pre && seg_balanced ? seg_rows : 0u;
+  // (same-box A/B at cfg3, round 1: 5.96 ms vs 6.27 ms with fixed 640-row segments)
+  const uint32_t seg_target = use_pre ? seg_rows : 0u;
   // segments per list at most; partial slots per (query, probe): one per segment, or one per QUAD of segments (matrix-core scan)
   const uint32_t S_seg = seg_target ? 4 * std::max<uint32_t>(1, (h->max_len + 4 * seg_target - 1) / (4 * seg_target))
                                     : std::max<uint32_t>(1, (h->max_len + seg_rows - 1) / seg_rows);
@@ -762,7 +747,7 @@ int32_t plan_search(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint32_t b
   pq.list_len = h->list_len.as<uint32_t>(); pq.owner = h->world > 1 ? h->owner.as<uint8_t>() : (const uint8_t*)nullptr; pq.rank = h->rank;
   pq.list_slot = h->list_slot.as<uint32_t>();
   pq.pj_list = pj_list; pq.pj_pref = pj_pref; pq.pj_take = pj_take; pq.np = np; pq.pj_nq = use_pre ? pj_nq : nullptr;
-  pq.cnt = cnt; pq.hot = hot; pq.hot_ranks = knobs().hot_ranks; pq.seg_rows = seg_rows; pq.seg_target = seg_target;
+  pq.cnt = cnt; pq.hot = hot; pq.hot_ranks = 1u; pq.seg_rows = seg_rows; pq.seg_target = seg_target;
   pq.status = W->st_word();
   bool planned = false;
   uint32_t n_segs_c = 0;

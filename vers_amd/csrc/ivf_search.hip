@@ -301,7 +301,6 @@ int32_t launch_prescan(vers_ivf* h, const IvfSrc<NQ>& src, uint32_t items_bound,
   }
   uint32_t blocks = (items_bound + kWavesPerBlock - 1) / kWavesPerBlock;
   uint32_t per_cu = std::max<uint32_t>(1, std::min<uint32_t>(2, (uint32_t)((160u * 1024u) / lds)));  // 1 at d = 768 (measured: as fast as 2)
-  if (knobs().pre_blocks_per_cu > 0) per_cu = (uint32_t)knobs().pre_blocks_per_cu;  // tuning knob
   const uint32_t reserve = scan_reserve(h, st);  // (vers_set_option "scan_reserve_cus"; auto: only while another batch is in flight)
   const uint32_t max_blocks = ((uint32_t)h->n_cu - reserve) * per_cu;
   if (blocks > max_blocks) blocks = max_blocks;
