@@ -315,6 +315,9 @@ int32_t vers_ivf_build_sharded_dev(vers_ivf_t* h, const float* rows_dev, uint64_
  * "pre_min_batch" (default 4; VERS_PRE_MIN_BATCH): the smallest batch of an nprobe search whose list scan runs on the matrix
  * cores (fp16 shadow, exact finish) even when its lists are shared by fewer than two queries on average; smaller batches
  * run one ordered-chain scan per (query, list) pair.  Same results either way.
+ * "host_spin" (default 1): a host-pointer single-query call (vers_ivf_search, b == 1: what Index::search_approximate is) waits for
+ * its result by spinning on the pinned status word the last launch writes behind the results, for at most 2 ms; 0 = sleep in
+ * hipStreamSynchronize as rounds 1-4 did.
  * "scan_reserve_cus" (default -1 = auto: 64 while another batch of the handle is in flight on another stream, else 0;
  * VERS_SCAN_RESERVE_CUS): the persistent matrix-core list scan launches on that many FEWER compute units.  Its blocks hold 448 of a SIMD's 512 registers, so nothing with a large footprint -- RCCL's all-gather kernel
  * (256 VGPRs per wave), another batch's coarse contraction / selection -- runs beside them: with batches in flight on a

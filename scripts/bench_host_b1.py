@@ -20,13 +20,15 @@ ix.build_dev(X.data_ptr(), n, nlist, 1, 2, init)
 del X
 Q = dg.dist_c(0x77, 256, d, 16 * nlist, dg.default_sigma(d)).astype(np.float32)
 ids = np.zeros(10, dtype=np.uint64); dist = np.zeros(10, dtype=np.float32); cnt = np.zeros(1, dtype=np.uint32)
-for nprobe in (32, 0, 32, 0):  # (the first loop after the build runs ~2x slower whatever the mode: discard it)
+for nprobe, spin in ((32, 1), (0, 1), (32, 1), (32, 0), (32, 1), (32, 0), (0, 1), (0, 0)):  # (the first loop after the build runs ~2x slower whatever the mode: discard it)
+    capi.set_option("host_spin", spin)   # 1 (default): spin on the pinned status word; 0: hipStreamSynchronize (rounds 1-4)
     for rep in range(2):
         t0 = time.perf_counter()
         for i in range(256):
             check(lib().vers_ivf_search(ix._h, _ptr(Q[i]), 4 * d, 1, 10, nprobe, _ptr(ids), _ptr(dist), _ptr(cnt)))
         dt = (time.perf_counter() - t0) / 256
-    print(f"host-pointer single-query call, nprobe={nprobe}: {dt*1e6:.1f} us per call ({1/dt:.0f} q/s)")
+    print(f"host-pointer single-query call, nprobe={nprobe}, host_spin={spin}: {dt*1e6:.1f} us per call ({1/dt:.0f} q/s)")
+    if spin == 0: continue
     # the same through device pointers, synchronised per call, and pipelined (no sync between calls)
     qd = torch.from_numpy(Q).to(dev); idd = torch.zeros(10, dtype=torch.int64, device=dev)
     dd = torch.zeros(10, dtype=torch.float32, device=dev); cd = torch.zeros(1, dtype=torch.int32, device=dev)

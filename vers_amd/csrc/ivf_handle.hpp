@@ -327,6 +327,12 @@ inline std::atomic<int>& scan_events_ref() {
   static std::atomic<int> m{[] { const char* e = getenv("VERS_SCAN_EVENTS"); return e ? atoi(e) : 2; }()};
   return m;
 }
+// vers_set_option("host_spin", 0 | 1): a host-pointer single-query call waits for its result by spinning on the pinned status word
+// (1, default) or in hipStreamSynchronize (0: rounds 1-4; same-process A/B in scripts/bench_host_b1.py)
+inline std::atomic<int>& host_spin_ref() {
+  static std::atomic<int> m{1};
+  return m;
+}
 // TEST HOOK (vers_set_option("test_fail_sharded", n)): the next n sharded searches of this process fail LOCALLY after their
 // exchange buffers are reserved -- what an out-of-memory scratch reservation on one rank looks like to its peers
 inline std::atomic<int>& test_fail_sharded_ref() {

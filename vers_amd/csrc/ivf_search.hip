@@ -2,6 +2,8 @@
 // records; batches in nprobe mode: matrix-core pre-selection + exact finish, prescan.hip.h; otherwise the ordered-chain
 // engine, scan.hip.h), the per-query merges + id mapping, the exhaustive scan of the stored rows (utils.rs:68-82), the
 // cross-GPU merge of partial results, host-pointer staging, and the search entry points of the C ABI.
+#include <chrono>
+
 #include "finish.hip.h"
 #include "ivf_src.hip.h"
 
@@ -101,7 +103,12 @@ __device__ __forceinline__ void ivf_merge_block(const MergeArgs& m, uint32_t q, 
     }
   }
   if (w0 && lane == 0 && written != 0xFFFFFFFFu && (m.ref_mode ? rank0 == 0 : true)) m.out_count[q] = written;
-  if (m.st_host && threadIdx.x == 0) *m.st_host = __hip_atomic_load(m.st_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  // host-pointer single-query call: the status word goes out with the result, LAST and at system scope -- the host spins on this
+  // pinned word instead of sleeping in hipStreamSynchronize (host_io_end), so everything wave 0 wrote above must be visible first
+  if (m.st_host && w0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    if (lane == 0) __hip_atomic_store(m.st_host, __hip_atomic_load(m.st_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
 }
 template <int NW>
 __global__ __launch_bounds__(kWave * NW) void ivf_merge_kernel(MergeArgs m) {
@@ -560,7 +567,19 @@ int32_t host_io_end(vers_ivf* h, const HostIo& io, uint32_t b, uint32_t top_k, u
   const char* pin = (const char*)W->io_pin;
   if (io.direct) {
     pin = (const char*)io.ids_dev - io.ids_off;
-    VERS_HIP_TRY(hipStreamSynchronize(W->io_stream));
+    // The result block is pinned and its status word is the call's LAST store (system scope, behind a release fence): spin on it for
+    // up to 2 ms -- a single query takes ~90 us -- instead of sleeping in hipStreamSynchronize, whose wake-up costs the call several
+    // microseconds; a word that stays "not yet" (an error path that launched no merge, a very slow call) falls back to the synchronisation.
+    const volatile uint32_t* flag = reinterpret_cast<const volatile uint32_t*>(pin + io.st_off);
+    const auto t0 = std::chrono::steady_clock::now();
+    bool seen = false;
+    for (uint32_t spins = 0; host_spin_ref().load(std::memory_order_relaxed) != 0; ++spins) {
+      if (*flag != kStNotYet) { seen = true; break; }
+      if ((spins & 255u) == 255u && std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;
+      __builtin_ia32_pause();
+    }
+    std::atomic_thread_fence(std::memory_order_acquire);
+    if (!seen) VERS_HIP_TRY(hipStreamSynchronize(W->io_stream));
   } else {
     char* base = (char*)W->io_out.p;
     VERS_HIP_TRY(hipMemcpyAsync(base + io.st_off, W->st_word(), sizeof(uint32_t), hipMemcpyDeviceToDevice, W->io_stream));
@@ -759,6 +778,7 @@ int32_t vers_ivf_search(vers_ivf_t* h, const float* queries, uint64_t q_stride_b
     if (io.direct) {  // (nothing of this workspace is in flight: the previous call / attempt ended with a synchronisation)
       std::memset((char*)io.ids_dev - io.ids_off, 0, io.out_bytes);
       W->st_host = (uint32_t*)((char*)io.ids_dev - io.ids_off + io.st_off);
+      *reinterpret_cast<volatile uint32_t*>(W->st_host) = kStNotYet;  // (the last merge launch overwrites it with the status: host_io_end spins on it)
     } else {
       VERS_HIP_TRY(hipMemsetAsync(W->io_out.p, 0, io.out_bytes, W->io_stream));
     }

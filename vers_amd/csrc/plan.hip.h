@@ -23,6 +23,7 @@ constexpr uint32_t kStNaN = 1u, kStInsufficient = 2u, kStSpillTooDeep = 4u;
 // kKeyMax, first id word kPoisonId); every rank's merge latches kStPeerFailed in its stream's status word (vers_ivf_poll -> VERS_ERR_COMM)
 constexpr uint32_t kStPeerFailed = 8u;
 constexpr uint64_t kPoisonId = 0xDEADFA11DEADFA11ull;
+constexpr uint32_t kStNotYet = 0xFFFFFFFFu;  // host-pointer single-query call: the pinned status word before the last merge launch has written it
 constexpr uint32_t kNoSeg = 0xFFFFFFFFu;  // padding item of a quad
 
 // Row segments of one list.  seg_target == 0: fixed seg_rows.  Otherwise (matrix-core scan) the list is cut into
