@@ -329,7 +329,10 @@ def main():
     pre_inst = ("prescan_kernel_g<true, 64, IvfSrc<64>, false> (64 queries per block as two sets of 32, query block fp16 hi only" if wide64 else
                 "prescan_kernel_g<true, 32, IvfSrc<32>, true> (32 queries per block, query block fp16 hi + lo" if d <= 1152 else
                 "prescan_kernel_g<true, 32, IvfSrc<32>, false> (32 queries per block, query block fp16 hi only")
-    kernel_name = (pre_inst + "; inverted-list scan: fp16 shadow rows -> v_mfma_f32_32x32x16_f16; exact f32 finish in ivf_rescore_kernel)" if shadow
+    if B == 1 and shadow:   # (--batch 1: the single query's own scan of the shadow)
+        kernel_id = "scan1h_kernel"
+    kernel_name = ("scan1h_kernel (one query on the fp16 shadow: a 64-row tile per wave, VALU dot products; exact f32 finish in ivf_rescore_kernel<16>)" if B == 1 and shadow else
+                   pre_inst + "; inverted-list scan: fp16 shadow rows -> v_mfma_f32_32x32x16_f16; exact f32 finish in ivf_rescore_kernel)" if shadow
                    else "prescan_kernel_g<false, 32, IvfSrc<32>> (inverted-list scan on the f32 matrix cores; exact finish in ivf_rescore_kernel)" if mfma_scan
                    else "scan_kernel<QG,0,IvfSrc<QG>> (inverted-list scan, ordered f32 chains; QG = 16 at this shape)")
     traffic, traffic_source = None, None
@@ -599,49 +602,65 @@ def main():
         # (a) single query (B = 1): the list-scan kernel alone (HIP events around its launch) over distinct queries, priced
         # on the bytes of the lists each query actually probed; and the pipelined end-to-end time per query
         nq1 = min(64, B)
-        ms1, by1 = [], []
-        capi.set_option("scan_events", 1)   # (single-query calls are not bracketed by event records unless asked: 5.5-6 us per call)
-        for i in range(nq1 + 4):
-            index.search_dev(Q[i:].data_ptr(), ld, 1, top_k, nprobe, ids.data_ptr(), dst.data_ptr(), cnt.data_ptr(), st)
-            l1 = index.last_scan()
-            if i >= 4:
-                ms1.append(l1["ms"]); by1.append(l1["union_rows"] * d * 4)
-        index.poll(st)
-        capi.set_option("scan_events", 2)
-        n_e2e, e2e_reps = 200, []
-        for rep in range(3):   # (three stretches of 200 queries: the median is reported, the spread kept beside it -- one stretch is 18 ms
-            torch.cuda.synchronize(); t0 = time.perf_counter()   # of wall clock and a single hiccup of the host moved it by 10 %)
-            for i in range(n_e2e):
-                index.search_dev(Q[(i % (n_batches * B)):].data_ptr(), ld, 1, top_k, nprobe, ids.data_ptr(), dst.data_ptr(), cnt.data_ptr(), st)
-            torch.cuda.synchronize(); e2e_reps.append((time.perf_counter() - t0) / n_e2e)
-        e2e = float(np.median(e2e_reps))
-        index.poll(st)
-        gbs1 = float(np.sum(by1)) / (float(np.sum(ms1)) * 1e-3) / 1e9
-        # the drop-in call itself: vers_ivf_search with HOST pointers, one query per call -- what Index::search_approximate
-        # (ivfflat.rs:153) is behind the Rust shim: query in through the pinned block, three launches, result out, ONE synchronisation
         import ctypes as C_
+        n_e2e = 200
         nh = min(n_e2e, int(Q.shape[0]))
         qh1 = np.ascontiguousarray(Q[:nh, :d].cpu().numpy())
         hi_, hd_, hc_ = np.zeros(top_k, dtype=np.uint64), np.zeros(top_k, dtype=np.float32), np.zeros(1, dtype=np.uint32)
         lib_ = capi.lib()
         hp = [C_.c_void_p(qh1[i].ctypes.data) for i in range(nh)]
         pi_, pd_, pc_ = C_.c_void_p(hi_.ctypes.data), C_.c_void_p(hd_.ctypes.data), C_.c_void_p(hc_.ctypes.data)
-        host_reps = []
-        for rep in range(3):
-            t0 = time.perf_counter()
-            for i in range(nh):
-                lib_.vers_ivf_search(index._h, hp[i], 4 * d, 1, top_k, nprobe, pi_, pd_, pc_)
-            host_reps.append((time.perf_counter() - t0) / nh)
-        host_call = float(np.median(host_reps))
-        extra["single_query"] = {"kernel": "scan1_kernel<0> (ordered f32 chains, one query, one 64-row tile per wave)", "queries": nq1,
-                                 "list_scan_us": round(float(np.mean(ms1)) * 1e3, 1), "probed_list_bytes": int(np.mean(by1)),
-                                 "achieved_GBs": round(gbs1, 1), "frac": round(gbs1 / HBM_PEAK_GBS, 4),
-                                 "end_to_end_us": round(e2e * 1e6, 1), "end_to_end_qps": round(1.0 / e2e, 1),
-                                 "end_to_end_us_stretches": [round(x * 1e6, 1) for x in e2e_reps],
-                                 "host_call_us": round(host_call * 1e6, 1), "host_call_us_stretches": [round(x * 1e6, 1) for x in host_reps],
-                                 "host_call": "vers_ivf_search (host pointers, one query per call, synchronous): the trait call behind the Rust shim, ctypes overhead included"}
-        log(f"[bench] single query: list scan {extra['single_query']['list_scan_us']} us for {np.mean(by1) / 1e6:.0f} MB = "
-            f"{gbs1:.0f} GB/s ({gbs1 / HBM_PEAK_GBS:.2f} of peak); end to end {e2e * 1e6:.1f} us per query resident, {host_call * 1e6:.1f} us per host-pointer call")
+
+        def single_leg(on_shadow):
+            """list scan alone (HIP events), pipelined resident calls, host-pointer calls -- with the single query's scan on the
+            fp16 shadow (round 5: scan1h_kernel + the exact finish) or on the f32 rows (rounds 1-4: scan1_kernel + merge)"""
+            capi.set_option("single_shadow", 1 if on_shadow else 0)
+            row_bytes = (d * 2 + 4) if on_shadow else d * 4   # (shadow row + its |x|^2 | f32 row)
+            ms1, by1 = [], []
+            capi.set_option("scan_events", 1)   # (single-query calls are not bracketed by event records unless asked: 5.5-6 us per call)
+            for i in range(nq1 + 4):
+                index.search_dev(Q[i:].data_ptr(), ld, 1, top_k, nprobe, ids.data_ptr(), dst.data_ptr(), cnt.data_ptr(), st)
+                l1 = index.last_scan()
+                if i >= 4:
+                    ms1.append(l1["ms"]); by1.append(l1["union_rows"] * row_bytes)
+            index.poll(st)
+            capi.set_option("scan_events", 2)
+            e2e_reps = []
+            for rep in range(3):   # (three stretches of 200 queries: the median is reported, the spread kept beside it -- one stretch is 18 ms
+                torch.cuda.synchronize(); t0 = time.perf_counter()   # of wall clock and a single hiccup of the host moved it by 10 %)
+                for i in range(n_e2e):
+                    index.search_dev(Q[(i % (n_batches * B)):].data_ptr(), ld, 1, top_k, nprobe, ids.data_ptr(), dst.data_ptr(), cnt.data_ptr(), st)
+                torch.cuda.synchronize(); e2e_reps.append((time.perf_counter() - t0) / n_e2e)
+            index.poll(st)
+            # the drop-in call itself: vers_ivf_search with HOST pointers, one query per call -- what Index::search_approximate
+            # (ivfflat.rs:153) is behind the Rust shim: query in through the pinned block, the launches, result out, the host spinning on the status word
+            host_reps = []
+            for rep in range(3):
+                t0 = time.perf_counter()
+                for i in range(nh):
+                    lib_.vers_ivf_search(index._h, hp[i], 4 * d, 1, top_k, nprobe, pi_, pd_, pc_)
+                host_reps.append((time.perf_counter() - t0) / nh)
+            gbs = float(np.sum(by1)) / (float(np.sum(ms1)) * 1e-3) / 1e9
+            return {"list_scan_us": round(float(np.mean(ms1)) * 1e3, 1), "probed_list_bytes": int(np.mean(by1)), "achieved_GBs": round(gbs, 1),
+                    "frac": round(gbs / HBM_PEAK_GBS, 4), "end_to_end_us": round(float(np.median(e2e_reps)) * 1e6, 1),
+                    "end_to_end_qps": round(1.0 / float(np.median(e2e_reps)), 1), "end_to_end_us_stretches": [round(x * 1e6, 1) for x in e2e_reps],
+                    "host_call_us": round(float(np.median(host_reps)) * 1e6, 1), "host_call_us_stretches": [round(x * 1e6, 1) for x in host_reps]}
+        on_shadow = bool(index.shadow_state()["active"]) and nprobe != 0 and top_k + 6 <= 64 and os.environ.get("VERS_SCAN1H", "1") != "0"
+        try:
+            f32_leg = single_leg(False)
+            sq = single_leg(True) if on_shadow else dict(f32_leg)
+        finally:
+            capi.set_option("single_shadow", 1)
+        sq["kernel"] = ("scan1h_kernel (one query on the fp16 shadow: a 64-row tile per wave, VALU dot products) + ivf_rescore_kernel<16> (exact finish)" if on_shadow else
+                        "scan1_kernel<0> (ordered f32 chains, one query, one 64-row tile per wave)")
+        sq["queries"] = nq1
+        sq["host_call"] = "vers_ivf_search (host pointers, one query per call, synchronous): the trait call behind the Rust shim, ctypes overhead included"
+        if on_shadow:
+            sq["f32_rows_path"] = dict(f32_leg, kernel="scan1_kernel<0> + ivf_merge_kernel (rounds 1-4; vers_set_option('single_shadow', 0)), same process")
+        extra["single_query"] = sq
+        log(f"[bench] single query: list scan {sq['list_scan_us']} us for {sq['probed_list_bytes'] / 1e6:.0f} MB = {sq['achieved_GBs']:.0f} GB/s "
+            f"({sq['frac']:.2f} of peak); end to end {sq['end_to_end_us']} us per query resident, {sq['host_call_us']} us per host-pointer call"
+            + (f"  [f32 rows: scan {f32_leg['list_scan_us']} us, {f32_leg['end_to_end_us']} / {f32_leg['host_call_us']} us]" if on_shadow else ""))
         # (a2) between batch 1 and the headline's batch: queries/s, us per batch and which list scan ran (the reference's interface is
         # per query, ivfflat.rs:153: small batches are the realistic serving shape).  One batch per size is kept for the CPU leg.
         sweep, sweep_keep = {}, {}
@@ -662,7 +681,8 @@ def main():
                 index.poll(x.cuda_stream)
             on_mc = index.prescan_stats()["batches"] - pb0 == nst
             sweep[str(bsz)] = {"us_per_batch": round(dt_ * 1e6, 1), "queries_per_sec": round(bsz / dt_, 1),
-                               "list_scan": "prescan_kernel_g (matrix cores, fp16 shadow) + exact finish" if on_mc else
+                               "list_scan": "scan1h_kernel (fp16 shadow, one query) + exact finish" if on_mc and bsz == 1 else
+                                            "prescan_kernel_g (matrix cores, fp16 shadow) + exact finish" if on_mc else
                                             ("scan1_kernel (single-query item records)" if bsz == 1 else "scan_kernel (ordered chains)")}
             kq = Q[(last % n_batches) * B:(last % n_batches) * B + bsz]
             ki = torch.zeros(bsz, top_k, dtype=torch.int64, device=dev); kd = torch.zeros(bsz, top_k, device=dev); kc = torch.zeros(bsz, dtype=torch.int32, device=dev)

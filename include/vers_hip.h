@@ -315,6 +315,9 @@ int32_t vers_ivf_build_sharded_dev(vers_ivf_t* h, const float* rows_dev, uint64_
  * "pre_min_batch" (default 4; VERS_PRE_MIN_BATCH): the smallest batch of an nprobe search whose list scan runs on the matrix
  * cores (fp16 shadow, exact finish) even when its lists are shared by fewer than two queries on average; smaller batches
  * run one ordered-chain scan per (query, list) pair.  Same results either way.
+ * "single_shadow" (default 1; VERS_SCAN1H): a single query's list scan (b == 1, nprobe >= 1) streams the fp16 shadow -- half the
+ * bytes -- and is finished exactly like a batch's (pre-selection, certificate, exact re-score, exact re-scan when the certificate
+ * fails); 0 = the ordered-chain scan of the f32 rows of rounds 1-4.  Same results either way.
  * "host_spin" (default 1): a host-pointer single-query call (vers_ivf_search, b == 1: what Index::search_approximate is) waits for
  * its result by spinning on the pinned status word the last launch writes behind the results, for at most 2 ms; 0 = sleep in
  * hipStreamSynchronize as rounds 1-4 did.
@@ -417,6 +420,11 @@ int32_t vers_test_mfma(int32_t device, uint32_t kind, const void* A, const void*
  * exchange: results of a sharded search through it are this rank's partial merged with itself. */
 int32_t vers_test_standin_gather(vers_gather_t* out, uint32_t rank, uint32_t world, uint32_t workgroups, uint32_t spin_us,
                                  uint32_t threads, uint32_t lds_bytes);
+/* TEST HOOK: the wave-level lane networks of the kernels (scan.hip.h) on 128 host keys in[0..127], one wave on `device`:
+ * out[64 j + l], j = 0..5 = lane l ^ (1 << j) of in[0..63]; out[384 + l] = lane 63 - l; out[448 ..] = in[0..63] sorted ascending
+ * (bitonic network); out[512 ..] = the same by rank counting; out[576 ..] = the 64 smallest of in[0..127], ascending (two sorted
+ * halves merged).  640 words out. */
+int32_t vers_test_wave_net(int32_t device, const uint64_t* in, uint64_t* out);
 /* Durations (ms) of the most recent list-scan launches, oldest first (ring of 64); reset != 0
  * empties the ring.  Lets bench.py time every launch of the timed region without stalling it. */
 int32_t vers_ivf_scan_times(vers_ivf_t* h, float* out_ms, uint32_t cap, uint32_t* out_n, int32_t reset);

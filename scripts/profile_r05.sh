@@ -3,7 +3,7 @@
 # with other trace domains) of
 #   cfg3 batch 1024, one batch in flight   bench.py --streams 1        -> prescan_kernel_g, coarse kernels, group_scatter, ivf_rescore
 #   cfg3 batch 1024, bench default         bench.py (3 in flight)      -> the same launches with other batches beside them
-#   cfg3 single query                      bench.py --batch 1          -> coarse1_kernel, scan1_kernel, ivf_merge_kernel
+#   cfg3 single query                      bench.py --batch 1          -> coarse1_kernel, scan1h_kernel, ivf_rescore_kernel<16>, fallback_kernel
 #   cfg2 flat scan                         scripts/bench_flat.py       -> scan_kernel<1,0,FlatSrc>
 #   k-means assign                         scripts/bench_assign.py     -> dist_gemm_x3w_kernel (+ MFMA-busy by PMC)
 #   d = 1536                               scripts/bench_d1536.py      -> prescan_kernel_g<true, 32, .., LO = false> (query block as fp16 hi only)

@@ -105,19 +105,20 @@ for sub in ("prescan_kernel_g<true", "prescan_kernel_g<false", "coarse_select_re
 print()
 # ---- single query ----
 a1 = show_trace("cfg3 single query (bench.py --batch 1 --steps 300 --warmup 20)", "b1/trace", 20, top=8)
-for nm in ("coarse1_kernel", "scan1_kernel", "ivf_merge_kernel"):  # the query's own three launches (the table above is led by the build)
+for nm in ("coarse1_kernel", "scan1h_kernel", "ivf_rescore_kernel<16>", "fallback_kernel", "scan1_kernel", "ivf_merge_kernel"):  # the query's own launches (the table above is led by the build)
     for k, v in a1.items():
         if nm in k and len(v) > 20:
             d = v[20:]
             print(f"  {short(k)[:70]:70s} mean {sum(d)/len(d):6.1f} us (min {min(d):.1f}) over {len(d)} warm dispatches")
-f1, n1 = mean_of(pmc("b1/pmc_fetch"), "scan1_kernel", "FETCH_SIZE", 20)
-k1 = [v for k, v in a1.items() if "scan1_kernel" in k or "scan_kernel<1, 0, IvfSrc<1>" in k.replace("vers::", "")]
+s1name = "scan1h_kernel" if any("scan1h_kernel" in k for k in a1) else "scan1_kernel"  # (the fp16 shadow scan of round 5, or the f32 ordered-chain scan)
+f1, n1 = mean_of(pmc("b1/pmc_fetch"), s1name, "FETCH_SIZE", 20)
+k1 = [v for k, v in a1.items() if s1name in k or (s1name == "scan1_kernel" and "scan_kernel<1, 0, IvfSrc<1>" in k.replace("vers::", ""))]
 if k1 and f1:
     d = k1[0][20:]
     by = f1 * 1024 * 2
-    print(f"scan1_kernel<0>: mean {sum(d)/len(d):.1f} us (min {min(d):.1f}) over {len(d)} warm dispatches; FETCH_SIZE mean {f1:.0f} KB -> "
+    print(f"{s1name}: mean {sum(d)/len(d):.1f} us (min {min(d):.1f}) over {len(d)} warm dispatches; FETCH_SIZE mean {f1:.0f} KB -> "
           f"{by/1e6:.0f} MB of HBM reads per launch -> {by/(sum(d)/len(d))/1e3:.0f} GB/s of traffic")
-    facts["single_query"] = {"kernel": "scan1_kernel<0>", "kernel_mean_us": sum(d) / len(d), "FETCH_SIZE_KB_mean": f1, "hbm_read_bytes_per_launch": int(by)}
+    facts["single_query"] = {"kernel": s1name, "kernel_mean_us": sum(d) / len(d), "FETCH_SIZE_KB_mean": f1, "hbm_read_bytes_per_launch": int(by)}
 print()
 # ---- flat ----
 af = show_trace("cfg2 flat scan N=1M d=128 (scripts/bench_flat.py, 4 corpora in rotation)", "flat/trace", 4, top=5)

@@ -85,6 +85,7 @@ SIGNATURES = {
                                                C.c_uint64, _vp, _vp, _vp, C.POINTER(C.c_float), C.POINTER(C.c_int32), _vp]),
     "vers_set_option": (C.c_int32, [C.c_char_p, C.c_int64]),
     "vers_mem_stats": (C.c_int32, [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_int32]),
+    "vers_test_wave_net": (C.c_int32, [C.c_int32, _vp, _vp]),
     "vers_test_standin_gather": (C.c_int32, [_vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
     "vers_ivf_scan_times": (C.c_int32, [_vp, _vp, C.c_uint32, C.POINTER(C.c_uint32), C.c_int32]),
     "vers_ivf_get_list": (C.c_int32, [_vp, C.c_uint64, _vp, C.c_uint64, _vp, C.c_uint64, C.POINTER(C.c_uint64)]),

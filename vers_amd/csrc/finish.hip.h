@@ -109,20 +109,24 @@ __device__ __forceinline__ void emit_topk(uint64_t fin, uint32_t q, uint32_t top
   if (lane == 0) out_count[q] = (uint32_t)__popcll(hm);
 }
 
-// Block of 4 waves per query.  All waves merge the partial lists; wave 0 evaluates the certificate; the survivors are dealt
-// round-robin to the four waves, each of which gathers ITS rows coalesced (the row-major copy: 256 contiguous bytes per quarter
+// Block of NW waves per query (4: batches; 16: the single query of scan1h_kernel, whose ~250 slots and ~34 survivors are then one
+// round of loads and one pass of chains).  All waves merge the partial lists; wave 0 evaluates the certificate; the survivors are dealt
+// round-robin to the waves, each of which gathers ITS rows coalesced (the row-major copy: 256 contiguous bytes per quarter
 // wave; the tiles: 16-byte pieces), parks the products in its LDS slice and walks the ordered chains over them, one lane per
 // survivor (staged.hip.h); wave 0 sorts and emits.  The block is a chain of ~7 dependent memory round trips, so what matters is
 // blocks in flight: 20 KB of LDS at d = 768 (the query + 4 x 16 staged product rows of 64 columns) and 4 waves allow the whole
 // batch in one round.
 // stage_rows == 0 (a query too long for LDS): the chains read HBM directly.
 constexpr int kRescoreWaves = 4;
-inline size_t rescore_lds_bytes(uint32_t ld, bool stage_rows) {  // the query; then two buffers of 8 staged rows of products per wave
-  const size_t exchange = (size_t)kRescoreWaves * kWave * sizeof(uint64_t);  // (the merge's exchange area: inside the product buffers)
-  return (size_t)ld * sizeof(float) + (stage_rows ? (size_t)kRescoreWaves * 2 * staged_lds_floats(8) * sizeof(float) : exchange);
+constexpr int kRescoreWaves1 = 16;
+inline size_t rescore_lds_bytes(uint32_t ld, bool stage_rows, int nw = kRescoreWaves) {  // the query; then two buffers of 8 staged rows of products per wave
+  const size_t exchange = (size_t)nw * kWave * sizeof(uint64_t);  // (the merge's exchange area: inside the product buffers)
+  return (size_t)ld * sizeof(float) + (stage_rows ? (size_t)nw * 2 * staged_lds_floats(8) * sizeof(float) : exchange);
 }
-static_assert((size_t)kRescoreWaves * 2 * staged_lds_floats(8) * sizeof(float) >= (size_t)kRescoreWaves * kWave * sizeof(uint64_t), "exchange area");
-__global__ __launch_bounds__(kWave * kRescoreWaves) __attribute__((amdgpu_waves_per_eu(8, 8))) void ivf_rescore_kernel(RescoreArgs a, int stage_rows) {
+static_assert(2 * staged_lds_floats(8) * sizeof(float) >= kWave * sizeof(uint64_t), "exchange area");
+template <int NW>
+__global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(NW == 4 ? 8 : 4, NW == 4 ? 8 : 4))) void ivf_rescore_kernel(RescoreArgs a, int stage_rows) {
+  constexpr int kRescoreWaves = NW;  // (shadows the batch width: everything below is per block)
   __shared__ uint32_t srow[kWave];
   __shared__ float sred[kRescoreWaves], sres[kRescoreWaves];
   __shared__ uint32_t s_failed, s_nsurv;
@@ -135,8 +139,9 @@ __global__ __launch_bounds__(kWave * kRescoreWaves) __attribute__((amdgpu_waves_
   const uint32_t q = blockIdx.x;
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  unsigned long long ts[5] = {};
+  unsigned long long ts[5] = {}, tx[6] = {};
   auto stamp = [&](int i) { if (a.stamps) ts[i] = __builtin_amdgcn_s_memtime(); };
+  auto xstamp = [&](int i) { if (a.stamps) tx[i] = __builtin_amdgcn_s_memtime(); };
   stamp(0);
   const float* qrow = a.qp + (uint64_t)q * a.ldq;
   const uint32_t* pl = a.pj_list + (uint64_t)q * a.P;
@@ -168,50 +173,142 @@ __global__ __launch_bounds__(kWave * kRescoreWaves) __attribute__((amdgpu_waves_
   const uint64_t* keys = a.partials + (uint64_t)q * a.P * a.S_max * a.kp;
   const uint32_t* nqp = a.pj_nq + (uint64_t)q * a.P;
   uint64_t list = kKeyMax;
-  constexpr int U = 4;
-  // lane j = probe j (P <= 64 on this path): the slots it wrote, and where they start in the compact order of LIVE slots.  At
-  // 8 ranks 4 of a query's 32 probes are local: 8 live slots of 64 -- one round of independent loads instead of four rounds of
-  // a count load followed by a key load each (20 of the kernel's 84 us there).
-  const uint32_t my_nq = lane < (int)a.P ? (nqp[lane] < a.S_max ? nqp[lane] : a.S_max) : 0u;
-  const uint32_t incl = wave_incl_u32(my_nq);
-  const uint32_t excl = incl - my_nq;
-  uint32_t n_live = (uint32_t)__builtin_amdgcn_readlane((int)incl, kWave - 1);
-  if (a.debug & 1024u) n_live = n_live / 8;
-  if (wid == 0 && pre_ok) wave_seq_rows_load2(pre, a.list_off);  // (the dependent half, in flight under the merge)
-  for (uint32_t i0 = 0; (uint32_t)wid + kRescoreWaves * i0 < n_live; i0 += U) {
-    uint64_t cand[U];
-#pragma unroll
-    for (int u = 0; u < U; ++u) {
-      const uint32_t c = (uint32_t)wid + kRescoreWaves * (i0 + u);  // compact index -> (probe j, quad c - first slot of j): the last lane whose slots start at or before c
-      const uint64_t m = __ballot(my_nq != 0 && excl <= c);
-      const int j = m ? 63 - __builtin_clzll((unsigned long long)m) : 0;
-      const uint32_t e_j = (uint32_t)__builtin_amdgcn_readlane((int)excl, j);
-      const uint32_t sl = (uint32_t)j * a.S_max + (c - e_j);
-      cand[u] = (c < n_live && lane < (int)a.kp) ? keys[(uint64_t)sl * a.kp + lane] : kKeyMax;
-    }
-#pragma unroll
-    for (int u = 0; u < U; ++u) wave_merge_sorted64(list, cand[u], lane);
-  }
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) { qpart += __shfl_xor(qpart, off, kWave); rpart += __shfl_xor(rpart, off, kWave); }
-  sh[wid][lane] = list;
-  if (lane == 0) { sred[wid] = qpart; sres[wid] = rpart; }
-  __syncthreads();
-  if ((wid & 1) == 0) wave_merge_sorted64(list, sh[wid + 1][lane], lane);
-  if (wid == 2) sh[2][lane] = list;
-  __syncthreads();
+  if (lane == 0) { sred[wid] = qpart; sres[wid] = rpart; }  // (read by wave 0 behind the merge's barriers)
+  if (wid == 0 && pre_ok) wave_seq_rows_load2(pre, a.list_off);  // (the dependent half, in flight under the merge)
+  // 64 keys per wave, ascending (kKeyMax padded) -> wave 0 ends with the 64 smallest of the block's, ascending.  Pairwise: in stage s
+  // the waves at multiples of 2 s fold in the list of the wave s above (stored a stage ago) and store theirs.
+  auto block_fold = [&](uint64_t& v, int nw = NW) {  // nw (a power of two, block-uniform): only the first nw waves hold anything
+    sh[wid][lane] = v;
+    __syncthreads();
+#pragma unroll
+    for (int s = 1; s < NW; s <<= 1) {
+      if (s >= nw) break;
+      if ((wid & (2 * s - 1)) == 0 && wid < nw) {
+        wave_merge_sorted64(v, sh[wid + s][lane], lane);
+        if (2 * s < nw && wid != 0) sh[wid][lane] = v;
+      }
+      if (2 * s < nw) __syncthreads();
+    }
+  };
+  bool flat_done = false;  // (block-uniform)
+  if constexpr (NW == kRescoreWaves1) {
+    // The single query's slots (scan1h_kernel: ~350 at cfg3, 0xFF-filled where nothing was written) as ONE flat array: merging them
+    // slot by slot through the six-stage networks was 16 us of this kernel's 29 (a merge is ~0.6 us of dependent LDS-crossbar round
+    // trips, a lone block has nothing to hide them behind).  Instead, by COUNTING:
+    //   (1) T = the kp-th smallest val among the slots' MINIMA -- at least kp keys lie at or below it, so the kp smallest keys do:
+    //       a sort per wave and four folds (counting here -- 448 minima against 448 -- is 200 k compares: 8 us of VALU time);
+    //   (2) every thread keeps those of its (already loaded) keys whose val is <= T: ~kp + 2 of them when the rows fell into the
+    //       slots at random, the query's whole cluster (~150 at cfg3's 16 modes per list) when its neighbours share a list;
+    //   (3) a thread per kept key counts the kept keys below its own: that is its rank -- ranks < 64 are the merged list.
+    // More than 1024 kept keys, or a slot area beyond ~100 k keys (an index with one very long list): slot by slot, below.
+    constexpr uint32_t kBuf = 1024;
+    __shared__ __attribute__((aligned(16))) uint64_t s_buf[kBuf];
+    __shared__ uint64_t s_out[kWave];
+    __shared__ uint32_t s_T, s_cnt;
+    constexpr int kPre = 16;  // keys per thread in registers: 16 k keys = 480 slots of kp = 34
+    const uint32_t n_slots = a.P * a.S_max;
+    const uint64_t n_keys = (uint64_t)n_slots * a.kp;
+    if (n_keys <= (uint64_t)8 * kPre * kWave * NW && !(a.debug & 1024u)) {
+      xstamp(0);
+      if (threadIdx.x == 0) { s_cnt = 0u; s_T = 0xFFFFFFFFu; }  // (fewer than kp slots hold anything: every key passes)
+      if (threadIdx.x < kWave) s_out[threadIdx.x] = kKeyMax;
+      uint64_t pk[kPre];
+#pragma unroll
+      for (int u = 0; u < kPre; ++u) {
+        const uint32_t idx = threadIdx.x + (uint32_t)u * (kWave * NW);
+        pk[u] = idx < n_keys ? keys[idx] : kKeyMax;
+      }
+      // (a thread takes two neighbouring slots and keeps the smaller minimum -- more when there are more than 2048 slots --: T stays
+      // valid, a little looser, and 448 slots are four waves' worth: two folds instead of three)
+      uint64_t mn = kKeyMax;
+      for (uint32_t sl = 2u * threadIdx.x; sl < n_slots; sl += 2u * kWave * NW) {
+        const uint64_t k0 = keys[(uint64_t)sl * a.kp], k1 = sl + 1u < n_slots ? keys[(uint64_t)(sl + 1u) * a.kp] : kKeyMax;
+        mn = k0 < mn ? k0 : mn;
+        mn = k1 < mn ? k1 : mn;
+      }
+      xstamp(1);
+      int nwa = 1;
+      while (nwa < NW && (uint32_t)nwa * 2u * kWave < n_slots) nwa *= 2;
+      if (wid < nwa) wave_rank_sort64(mn, lane);
+      block_fold(mn, nwa);  // (wave 0: the 64 smallest minima, ascending)
+      if (wid == 0 && lane == (int)a.kp - 1) s_T = (uint32_t)(mn >> 32);  // (kKeyMax: fewer than kp slots hold anything -- every key passes)
+      xstamp(2);
+      __syncthreads();
+      const uint32_t T = s_T;
+      auto keep = [&](uint64_t k) {
+        if ((uint32_t)(k >> 32) <= T && k != kKeyMax) {
+          const uint32_t pos = atomicAdd(&s_cnt, 1u);
+          if (pos < kBuf) s_buf[pos] = k;
+        }
+      };
+#pragma unroll
+      for (int u = 0; u < kPre; ++u) keep(pk[u]);
+      for (uint64_t i0 = (uint64_t)kPre * kWave * NW; i0 < n_keys; i0 += 4u * kWave * NW) {  // (slots beyond the prefetch: S_max follows the LONGEST list)
+        uint64_t k4[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const uint64_t idx = i0 + threadIdx.x + (uint64_t)u * (kWave * NW);
+          k4[u] = idx < n_keys ? keys[idx] : kKeyMax;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) keep(k4[u]);
+      }
+      xstamp(3);
+      __syncthreads();
+      const uint32_t n_in = s_cnt;
+      if (n_in <= kBuf) {
+        flat_done = true;
+        if (threadIdx.x < n_in) {
+          const uint64_t my = s_buf[threadIdx.x];
+          uint32_t rank = 0;
+          for (uint32_t i = 0; i < n_in; ++i) rank += s_buf[i] < my ? 1u : 0u;  // (keys are unique)
+          if (rank < (uint32_t)kWave) s_out[rank] = my;
+        }
+        __syncthreads();
+        if (wid == 0) list = s_out[lane];
+      }
+      xstamp(4);
+    }
+  }
+  if (!flat_done) {
+    constexpr int U = 4;
+    // lane j = probe j (P <= 64 on this path): the slots it wrote, and where they start in the compact order of LIVE slots.  At
+    // 8 ranks 4 of a query's 32 probes are local: 8 live slots of 64 -- one round of independent loads instead of four rounds of
+    // a count load followed by a key load each (20 of the kernel's 84 us there).
+    const uint32_t my_nq = lane < (int)a.P ? (nqp[lane] < a.S_max ? nqp[lane] : a.S_max) : 0u;
+    const uint32_t incl = wave_incl_u32(my_nq);
+    const uint32_t excl = incl - my_nq;
+    uint32_t n_live = (uint32_t)__builtin_amdgcn_readlane((int)incl, kWave - 1);
+    if (a.debug & 1024u) n_live = n_live / 8;
+    for (uint32_t i0 = 0; (uint32_t)wid + kRescoreWaves * i0 < n_live; i0 += U) {
+      uint64_t cand[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const uint32_t c = (uint32_t)wid + kRescoreWaves * (i0 + u);  // compact index -> (probe j, quad c - first slot of j): the last lane whose slots start at or before c
+        const uint64_t m = __ballot(my_nq != 0 && excl <= c);
+        const int j = m ? 63 - __builtin_clzll((unsigned long long)m) : 0;
+        const uint32_t e_j = (uint32_t)__builtin_amdgcn_readlane((int)excl, j);
+        const uint32_t sl = (uint32_t)j * a.S_max + (c - e_j);
+        cand[u] = (c < n_live && lane < (int)a.kp) ? keys[(uint64_t)sl * a.kp + lane] : kKeyMax;
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) wave_merge_sorted64(list, cand[u], lane);
+    }
+    block_fold(list);
+  }
   stamp(1);
   uint64_t mine = kKeyMax;  // wave 0: the survivors, compacted to lanes 0..n_surv-1
   uint32_t rid = 0;         // wave 0: their vec_ids
   if (wid == 0) {
-    wave_merge_sorted64(list, sh[2][lane], lane);
     if (lane >= (int)a.kp) list = kKeyMax;  // (the networks keep 64 keys: the kp smallest are the candidates)
     const bool valid = lane < (int)a.kp && list != kKeyMax;
     const uint32_t cnt = (uint32_t)__popcll(__ballot(valid));
     float qn = 0.0f, rq = 0.0f;
     for (int w = 0; w < kRescoreWaves; ++w) { qn += sred[w]; rq += sres[w]; }
     const PreBound pb = pre_bound((double)qn, (double)__uint_as_float(xmax_bits), a.shadow ? (double)__uint_as_float(a.xmax2_bits[2]) : 0.0, a.d_pad, a.metric,
-                                  a.shadow, (double)rq);
+                                  a.shadow, (double)rq);  // (double-precision square roots: ~2 us on the lone block's critical path; batches hide it)
     const float val = __uint_as_float(order_bits_to_f32_bits((uint32_t)(list >> 32)));
     const double e_mine = pb.of((double)val);  // this candidate's own bound (NaN / inf vals: NaN / inf, handled by the negated compares)
     bool certified = true;
@@ -264,7 +361,7 @@ __global__ __launch_bounds__(kWave * kRescoreWaves) __attribute__((amdgpu_waves_
   bool nan_seen = false;
   const f32x4* q4p = reinterpret_cast<const f32x4*>(qs);
   if (stage_rows) {
-    // survivor 4 s + w is wave w's staged row s: every wave reads ITS rows coalesced (a quarter wave per row and 64-column
+    // survivor NW s + w is wave w's staged row s: every wave reads ITS rows coalesced (a quarter wave per row and 64-column
     // chunk), parks the products in its own LDS slice and lane s walks row s's chain (staged.hip.h) -- all survivors in ONE pass
     // over the columns, no block-wide barrier inside.  (Rounds 2-4 staged whole rows 8 at a time for wave 0's lanes: a gather
     // round trip, a barrier and a 3-instruction chain per 8 survivors.)
@@ -291,8 +388,9 @@ __global__ __launch_bounds__(kWave * kRescoreWaves) __attribute__((amdgpu_waves_
         const float* ql = qs + 4 * (lane & 15);
         constexpr uint32_t kBuf = (uint32_t)staged_lds_floats(kPassRows);
         float* sp = xs + (size_t)wid * 2 * kBuf;
-        return a.metric == 0 ? staged_chains<NL, 0, 2, true, 2, 3>(rp, xstep, ql, a.ld, sp, kBuf, lane)
-                             : staged_chains<NL, 1, 2, true, 2, 3>(rp, xstep, ql, a.ld, sp, kBuf, lane);
+        constexpr int kD = 2;
+        return a.metric == 0 ? staged_chains<NL, 0, kD, true, 2, 3>(rp, xstep, ql, a.ld, sp, kBuf, lane)
+                             : staged_chains<NL, 1, kD, true, 2, 3>(rp, xstep, ql, a.ld, sp, kBuf, lane);
       };
       float acc = per_wave <= 4 ? run(std::integral_constant<int, 1>{}) : run(std::integral_constant<int, 2>{});
       if (a.metric) acc = __fsub_rn(1.0f, acc);
@@ -332,7 +430,13 @@ __global__ __launch_bounds__(kWave * kRescoreWaves) __attribute__((amdgpu_waves_
   stamp(3);
   if (__ballot(nan_seen) != 0 && lane == 0) atomicOr(a.status, 1u);
   uint64_t fin = kKeyMax;
-  wave_topk_update(fin, a.top_k, cand, kKeyMax);
+  if constexpr (NW == kRescoreWaves1) {  // (one sort instead of an ordered insert per survivor)
+    fin = cand;
+    wave_rank_sort64<true>(fin, lane);
+    if (lane >= (int)a.top_k) fin = kKeyMax;
+  } else {
+    wave_topk_update(fin, a.top_k, cand, kKeyMax);
+  }
   // emit (emit_topk without its three dependent round trips: the id of an emitted key sits in the lane of the survivor with the
   // same sequence number, loaded before the chains)
   const bool have = lane < (int)a.top_k && fin != kKeyMax;
@@ -355,6 +459,7 @@ __global__ __launch_bounds__(kWave * kRescoreWaves) __attribute__((amdgpu_waves_
   if (a.stamps && lane == 0) {
     stamp(4);
     for (int i = 0; i < 4; ++i) atomicAdd(a.stamps + 52 + i, ts[i + 1] - ts[i]);
+    if (tx[4]) { atomicAdd(a.stamps + 58, tx[0] - ts[0]); for (int i = 0; i < 4; ++i) atomicAdd(a.stamps + 59 + i, tx[i + 1] - tx[i]); }
     atomicAdd(a.stamps + 56, 1ull); atomicAdd(a.stamps + 57, (unsigned long long)n_surv);
   }
 }
@@ -387,13 +492,22 @@ inline size_t fallback_part_keys(uint32_t blocks, uint32_t P, uint32_t top_k) { 
 }
 __global__ __launch_bounds__(kWave * kMergeWaves) void fallback_kernel(RescoreArgs a, const uint32_t* list_len, const uint32_t* fail_list,
                                                                        const uint32_t* fail_count, uint64_t* fb_part, uint32_t* ctr,
-                                                                       uint32_t* watch) {
+                                                                       uint32_t* watch, const uint32_t* st_word = nullptr, uint32_t* st_host = nullptr) {
   __shared__ uint64_t sh[kMergeWaves][kWave];
   __shared__ uint32_t s_last;
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const uint32_t n_fail = *fail_count;
-  if (n_fail == 0) return;
+  // st_host (host-pointer single-query call on the fp16 shadow: this is the call's last launch): the stream's status word goes out to the
+  // pinned result block LAST, at system scope -- the host spins on it (host_io_end); the finish's results were written by an earlier launch
+  auto publish = [&]() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    __hip_atomic_store(st_host, __hip_atomic_load(st_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  };
+  if (n_fail == 0) {
+    if (st_host != nullptr && blockIdx.x == 0 && threadIdx.x == 0) publish();
+    return;
+  }
   // `watch` (nullable): pinned host word the host polls to retire an fp16 shadow that fails too often; a.stats[0] is final
   // for this batch (ivf_rescore_kernel, which counts, is done) and only moves when queries were queued
   if (watch != nullptr && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(watch, a.stats[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -473,6 +587,7 @@ __global__ __launch_bounds__(kWave * kMergeWaves) void fallback_kernel(RescoreAr
     uint32_t* out_ctr = ctr + 2 * gridDim.x;
     if (__hip_atomic_fetch_add(out_ctr, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) + 1u == gridDim.x) {
       for (uint32_t w = 0; w <= 2 * gridDim.x; ++w) __hip_atomic_store(ctr + w, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (st_host != nullptr) publish();  // (every block's emits happened before its arrival at the counter)
     }
   }
 }

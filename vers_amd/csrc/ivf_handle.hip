@@ -170,6 +170,7 @@ int32_t vers_set_option(const char* name, int64_t value) {
   if (std::strcmp(name, "pre_min_batch") == 0) { pre_min_batch_ref().store(value < 2 ? 2u : (uint32_t)std::min<int64_t>(value, 0x7FFFFFFF)); return VERS_OK; }
   if (std::strcmp(name, "test_fail_sharded") == 0) { test_fail_sharded_ref().store((int)value); return VERS_OK; }  // TEST HOOK: the next `value` sharded searches of this process fail locally
   if (std::strcmp(name, "scan_reserve_cus") == 0) { scan_reserve_cus_ref().store((int)std::max<int64_t>(-1, std::min<int64_t>(value, 1 << 20))); return VERS_OK; }
+  if (std::strcmp(name, "single_shadow") == 0) { single_shadow_ref().store(value != 0 ? 1 : 0); return VERS_OK; }
   if (std::strcmp(name, "host_spin") == 0) { host_spin_ref().store(value != 0 ? 1 : 0); return VERS_OK; }
   if (std::strcmp(name, "scan_events") == 0) { scan_events_ref().store(value < 0 || value > 2 ? 2 : (int)value); return VERS_OK; }
   return fail(VERS_ERR_INVALID, std::string("vers_set_option: unknown option ") + name);

@@ -333,6 +333,12 @@ inline std::atomic<int>& host_spin_ref() {
   static std::atomic<int> m{1};
   return m;
 }
+// vers_set_option("single_shadow", 0 | 1): a single query's list scan streams the fp16 shadow with the exact finish behind it (1,
+// default; VERS_SCAN1H) or the f32 rows through the ordered chains (0: rounds 1-4; same-process A/B in bench.py)
+inline std::atomic<int>& single_shadow_ref() {
+  static std::atomic<int> m{[] { const char* e = getenv("VERS_SCAN1H"); return e ? (atoi(e) != 0 ? 1 : 0) : 1; }()};
+  return m;
+}
 // TEST HOOK (vers_set_option("test_fail_sharded", n)): the next n sharded searches of this process fail LOCALLY after their
 // exchange buffers are reserved -- what an out-of-memory scratch reservation on one rank looks like to its peers
 inline std::atomic<int>& test_fail_sharded_ref() {
@@ -434,6 +440,7 @@ struct SearchPlan {
   uint32_t P = 0;             // ranked lists per query
   int ref_mode = 0;           // nprobe == 0: the reference's own walk (nearest list + spill)
   bool one1 = false;          // single query, P <= 64: items are records (scan1_kernel)
+  bool one1_pre = false;      // ... scanned on the fp16 shadow with the exact finish (scan1h_kernel; use_pre is set too)
   int QG = 1;                 // queries per group of the list scan (kPreQ with use_pre)
   bool use_pre = false;       // matrix-core list scan + exact finish (prescan.hip.h)
   bool use_shadow = false;    // ... on the fp16 shadow of the rows

@@ -53,6 +53,45 @@ extern "C" int32_t vers_test_standin_gather(vers_gather_t* out, uint32_t rank, u
   return VERS_OK;
 }
 
+namespace vers {
+__global__ __launch_bounds__(kWave) void wave_net_test_kernel(const uint64_t* in, uint64_t* out) {
+  const int lane = threadIdx.x;
+  const uint64_t a = in[lane], b = in[kWave + lane];
+  out[0 * kWave + lane] = lane_xor64<1>(a, lane);
+  out[1 * kWave + lane] = lane_xor64<2>(a, lane);
+  out[2 * kWave + lane] = lane_xor64<4>(a, lane);
+  out[3 * kWave + lane] = lane_xor64<8>(a, lane);
+  out[4 * kWave + lane] = lane_xor64<16>(a, lane);
+  out[5 * kWave + lane] = lane_xor64<32>(a, lane);
+  out[6 * kWave + lane] = lane_rev64(a, lane);
+  uint64_t s0 = a, s1 = a, s2 = b;
+  wave_bitonic_sort64(s0, lane);
+  wave_rank_sort64(s1, lane);
+  wave_bitonic_sort64(s2, lane);
+  out[7 * kWave + lane] = s0;
+  out[8 * kWave + lane] = s1;
+  wave_merge_sorted64(s0, s2, lane);
+  out[9 * kWave + lane] = s0;
+}
+}  // namespace vers
+
+extern "C" int32_t vers_test_wave_net(int32_t device, const uint64_t* in, uint64_t* out) {
+  if (!in || !out) return fail(VERS_ERR_INVALID, "vers_test_wave_net: null argument");
+  DeviceGuard g(device);
+  uint64_t *d_in = nullptr, *d_out = nullptr;
+  VERS_HIP_TRY(hipMalloc(&d_in, 128 * sizeof(uint64_t)));
+  if (hipMalloc(&d_out, 640 * sizeof(uint64_t)) != hipSuccess) { (void)hipFree(d_in); return fail(VERS_ERR_HIP, "vers_test_wave_net: out of device memory"); }
+  hipError_t e = hipMemcpy(d_in, in, 128 * sizeof(uint64_t), hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(wave_net_test_kernel, dim3(1), dim3(kWave), 0, 0, d_in, d_out);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpy(out, d_out, 640 * sizeof(uint64_t), hipMemcpyDeviceToHost);
+  (void)hipFree(d_in); (void)hipFree(d_out);
+  if (e != hipSuccess) return fail(VERS_ERR_HIP, std::string("vers_test_wave_net: ") + hipGetErrorString(e));
+  return VERS_OK;
+}
+
 extern "C" {
 
 int32_t vers_ivf_last_scan(vers_ivf_t* h, float* out_ms, uint64_t* out_union_rows, uint64_t* out_streamed_rows,
@@ -91,6 +130,9 @@ int32_t vers_ivf_last_scan(vers_ivf_t* h, float* out_ms, uint64_t* out_union_row
       fprintf(stderr, "[vers stamps] exact finish, per query avg cycles: merge of the partial lists %.0f  certificate + storage rows %.0f  gather + chains %.0f  "
               "sort + emit %.0f; survivors per query %.1f\n", (double)sv[52] / sv[56], (double)sv[53] / sv[56], (double)sv[54] / sv[56], (double)sv[55] / sv[56],
               (double)sv[57] / sv[56]);
+    if (sv[56] && sv[59])
+      fprintf(stderr, "[vers stamps]   single query's merge by counting: preamble %.0f  key + minima loads %.0f  T (sort + folds) %.0f  filter %.0f  ranks %.0f\n", (double)sv[58] / sv[56],
+              (double)sv[59] / sv[56], (double)sv[60] / sv[56], (double)sv[61] / sv[56], (double)sv[62] / sv[56]);
     if (sv[19])
       fprintf(stderr, "[vers stamps] group / scatter kernel, block 0 (us): fill + prefix sums %.1f  scatter %.1f  items %.1f\n",
               (sv[17] - sv[16]) / 100.0, (sv[18] - sv[17]) / 100.0, (sv[19] - sv[18]) / 100.0);

@@ -249,6 +249,7 @@ struct Plan1Args {
   uint64_t* probe; uint32_t *pj_list, *pj_pref, *pj_take, *np, *cnt, *pair_off, *group_off, *pairs;
   ItemDesc* items; GroupDesc* groups; GroupTotals* tot; uint32_t* status; const uint32_t* list_slot;
   Item1Rec* recs = nullptr; const uint32_t* list_off = nullptr; uint32_t S_max = 0;  // recs != nullptr: the items as records (scan1_kernel); list_off: storage row of a list BY CENTROID
+  uint32_t *pj_nq = nullptr, *qflags = nullptr, *fail_cnt = nullptr;  // the shadow scan's exact finish (scan1h_kernel): records per probe; flags and the queue's count, zeroed here
   u32x4* ff_begin; uint32_t ff_vec16;  // the list scan's partial slots: filled with all ones (empty) by whoever plans
   unsigned long long* stamps = nullptr;  // diagnosis (VERS_SCAN_DEBUG & 16): [48..50] 100 MHz clock after the merge, the list tables, the plan's stores
 };
@@ -281,6 +282,13 @@ __device__ __forceinline__ void plan1_block(const Plan1Args& a, uint64_t (*sh)[k
     a.pj_list[lane] = scan ? slot : kNoList;
     a.pj_pref[lane] = pref;
     a.pj_take[lane] = take;
+  }
+  if (a.pj_nq != nullptr) {
+    if (lane < (int)P) {
+      a.pj_nq[lane] = scan ? (len + a.seg_rows - 1) / a.seg_rows : 0u;
+      a.qflags[lane] = 0u;
+    }
+    if (lane == 0) *a.fail_cnt = 0u;
   }
   const uint64_t vmask = __ballot(visited), smask = __ballot(scan);
   if (lane == 0) {
@@ -674,8 +682,11 @@ int32_t plan_search(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint32_t b
   // is still streamed from the half-size shadow at the chip's rate, and the staging of a mostly empty query block costs less
   // than the bytes it saves.  VERS_PRE_MIN_BATCH (default 4; measured at cfg3: batch 4 171 vs 209 us, batch 2 equal) is the smallest batch that takes this path.
   const bool pre_batch = QG != 1 || (b >= pre_min_batch_ref().load(std::memory_order_relaxed) && b > 1);
-  const bool use_pre = pre_batch && !ref_mode && pre_mode != 0 && top_k + 6 <= kPreMaxKp && P <= (uint32_t)kMaxTopK && pre_nq != 0;
-  if (use_pre) QG = (int)pre_nq;
+  // A single query takes the shadow too (round 5, scan1h_kernel in ivf_search.hip): half the bytes of the ordered-chain scan of the
+  // f32 rows, then the same exact finish.  vers_set_option("single_shadow", 0) / VERS_SCAN1H=0: the ordered-chain scan (A/B runs).
+  const bool one1_pre = one1 && single_shadow_ref().load(std::memory_order_relaxed) != 0 && use_shadow && !ref_mode && pre_mode != 0 && top_k + 6 <= kPreMaxKp;
+  const bool use_pre = one1_pre || (pre_batch && !ref_mode && pre_mode != 0 && top_k + 6 <= kPreMaxKp && P <= (uint32_t)kMaxTopK && pre_nq != 0);
+  if (use_pre && !one1_pre) QG = (int)pre_nq;
   const uint32_t k_keep = use_pre ? kp : std::min<uint32_t>(top_k, kMaxTopK);
   // 64 result ranks per pass; no pass beyond the rows the index holds (top_k = 100000 on 1000 rows: 16 passes, not 1563)
   const uint32_t n_pass = use_pre ? 1u : (uint32_t)((std::min<uint64_t>(top_k, std::max<uint64_t>(1, h->n_total)) + kMaxTopK - 1) / kMaxTopK);
@@ -694,17 +705,21 @@ int32_t plan_search(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint32_t b
   }
   // matrix-core scan: an average list is one quad of items (per-item set-up and the block's barriers amortise over
   // ~10 tiles; measured at cfg3: 640-row targets beat 256- and 1024-row ones)
-  if (use_pre) seg_rows = (uint32_t)round_up64(std::max<uint64_t>(256, (avg_len_all + 3) / 4), kWave);
+  if (use_pre && !one1_pre) seg_rows = (uint32_t)round_up64(std::max<uint64_t>(256, (avg_len_all + 3) / 4), kWave);
+  // single query on the shadow: a record is a block's work, a tile per wave -- at most the block's 4 tiles; two blocks fit a CU, so
+  // about 1.5 records per CU keeps every record resident at once whatever the probed lists' lengths (cfg3: 87 k rows -> ~350 records)
+  if (one1_pre) seg_rows = (uint32_t)std::min<uint64_t>(256, round_up64(std::max<uint64_t>(1, ((uint64_t)P * avg_len_all * 2) / (3 * (uint64_t)h->n_cu)), kWave));
   // (cutting the lists of a SHARDED scan into finer quads -- 2.7 whole-list quads per CU at 8 ranks -- was tried in rounds 3-4 and lost: a
   // short item pays its pipeline fill and its waves' waits for each other whatever the staging costs)
   if (knobs().seg_rows > 0) seg_rows = (uint32_t)round_up64(std::max(64l, knobs().seg_rows), kWave);  // tuning knob
+  if (one1_pre && seg_rows > 256) seg_rows = 256;
   // matrix-core scan: per-list balanced segments of about seg_rows rows (list_seg_rows)
   // (same-box A/B at cfg3, round 1: 5.96 ms vs 6.27 ms with fixed 640-row segments)
-  const uint32_t seg_target = use_pre ? seg_rows : 0u;
+  const uint32_t seg_target = use_pre && !one1_pre ? seg_rows : 0u;
   // segments per list at most; partial slots per (query, probe): one per segment, or one per QUAD of segments (matrix-core scan)
   const uint32_t S_seg = seg_target ? 4 * std::max<uint32_t>(1, (h->max_len + 4 * seg_target - 1) / (4 * seg_target))
                                     : std::max<uint32_t>(1, (h->max_len + seg_rows - 1) / seg_rows);
-  const uint32_t S_max = use_pre ? (S_seg + 3) / 4 : S_seg;
+  const uint32_t S_max = use_pre && !one1_pre ? (S_seg + 3) / 4 : S_seg;
   const uint64_t items_bound = groups_bound * (QG == 1 ? S_seg : round_up(S_seg, 4));
   if (items_bound > 0x7FFFFFFFull) return fail(VERS_ERR_INVALID, "search batch too large");
 
@@ -777,6 +792,7 @@ int32_t plan_search(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint32_t b
   if (n_pass > 1)
     if (int32_t rc = W->lower.reserve(n_pj * sizeof(uint64_t))) return rc;
   if (one1) {
+    // (the shadow scan's exact finish reads its slots as one flat array: filled too)
     const bool fill_in_kernel = part_bytes <= (size_t(4) << 20);  // (a block fills a few hundred KB faster than a launch costs)
     if (!fill_in_kernel) VERS_HIP_TRY(hipMemsetAsync(W->partials.p, 0xFF, part_bytes, st));
     Plan1Args pa;
@@ -787,6 +803,7 @@ int32_t plan_search(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint32_t b
     pa.groups = W->groups.as<GroupDesc>(); pa.tot = tot; pa.status = W->st_word(); pa.list_slot = h->list_slot.as<uint32_t>();
     pa.ff_begin = reinterpret_cast<u32x4*>(W->partials.p); pa.ff_vec16 = fill_in_kernel ? (uint32_t)((part_bytes + 15) / 16) : 0u;
     pa.recs = W->items.as<Item1Rec>(); pa.list_off = h->list_off.as<uint32_t>(); pa.S_max = S_max;
+    if (one1_pre) { pa.pj_nq = pj_nq; pa.qflags = qflags; pa.fail_cnt = fail_list + b; }
     if (one1_fused) {  // coarse quantiser + plan in one launch: a block per 64-centroid tile, the last one to finish plans
       Coarse1Args ca;
       ca.cent = h->centroids_b.as<float>(); ca.k = k_l; ca.ld = h->ld; ca.n_chunks = h->ld / kChunk; ca.q = qp; ca.cpart = W->cpart.as<uint64_t>();
@@ -843,7 +860,7 @@ int32_t plan_search(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint32_t b
     VERS_HIP_TRY(hipGetLastError());
   }
   }  // batch planning
-  s.P = P; s.ref_mode = ref_mode; s.one1 = one1; s.QG = QG; s.use_pre = use_pre; s.use_shadow = use_shadow; s.pre_hi_only = use_pre && pre_hi_only; s.pre_mode = pre_mode;
+  s.P = P; s.ref_mode = ref_mode; s.one1 = one1; s.one1_pre = one1_pre; s.QG = QG; s.use_pre = use_pre; s.use_shadow = use_shadow; s.pre_hi_only = use_pre && pre_hi_only; s.pre_mode = pre_mode;
   s.kp = kp; s.k_keep = k_keep; s.n_pass = n_pass; s.seg_rows = seg_rows; s.seg_target = seg_target; s.S_max = S_max;
   s.items_bound = items_bound; s.part_bytes = part_bytes;
   s.pj_list = pj_list; s.pj_pref = pj_pref; s.pj_take = pj_take; s.np = np; s.pj_nq = pj_nq; s.cnt = cnt; s.pair_off = pair_off;

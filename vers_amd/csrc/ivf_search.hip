@@ -34,6 +34,112 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void scan1_kernel(Scan1Args
   if (__ballot(nan_seen) != 0 && lane == 0) atomicOr(p.status, 1u);
 }
 
+// ---- single query on the fp16 shadow (round 5) ---------------------------------------------------------------------------------
+// The ordered-chain scan above streams a query's probed lists as f32 rows: 288 MB at cfg3, 56 us of a 90 us call.  This one streams
+// the SHADOW (half the bytes) and does what the batched path does (prescan.hip.h): val = |x|^2 + <x~, q'> (q' = -2 q; cosine: -<x~, q>)
+// pre-selects, ivf_rescore_kernel merges the kp smallest vals, certifies, recomputes the survivors in the reference's arithmetic and
+// emits; fallback_kernel re-scans exactly when the certificate fails.  Same bits as scan1_kernel + ivf_merge_kernel.
+// One query has no use for the matrix cores (a 32x32 tile with one live column): a lane multiplies the 8 fp16 columns its 16-byte
+// load delivers -- piece (cb, h) of the shadow tile holds row 32 h + (lane & 31), columns 16 cb + 8 (lane >> 5) .. + 7
+// (rows_to_f16_kernel) -- with the f32 query from LDS (v_fma_mix: an fp16 x f32 product is exact in the fma), two independent chains
+// per lane (h = 0, 1); lanes l and l ^ 32 hold the two column halves of the same rows and are added at the end: a val per lane.
+// The bound is pre_bound's with shadow = 1: the rows' measured residual, and an f32 accumulation of d products in any order.
+// A record (plan1_block) is up to 4 tiles of one list: a block, a wave per tile; the waves' 64 keys are sorted and merged pairwise
+// through LDS, the kp smallest go to the record's partial slot.
+constexpr int kS1hWaves = 4;
+struct Scan1hArgs {
+  const uint16_t* rows_h; const float* xnorm; const Item1Rec* recs; const uint32_t* n_items_dev; const float* qp;
+  uint64_t* partials; uint32_t* qflags; uint32_t ld, kp, metric;
+};
+inline size_t scan1h_lds_bytes(uint32_t ld) { return (size_t)ld * sizeof(float) + (size_t)kS1hWaves * kWave * sizeof(uint64_t); }
+__global__ __launch_bounds__(kWave * kS1hWaves) void scan1h_kernel(Scan1hArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float s1h_lds[];
+  float* const qs = s1h_lds;                                                               // the scaled query
+  uint64_t (*sh)[kWave] = reinterpret_cast<uint64_t(*)[kWave]>(s1h_lds + a.ld);            // [waves][64] sorted keys
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  if (blockIdx.x >= *a.n_items_dev) return;  // (block-uniform; the record buffer holds an entry per launched block)
+  const Item1Rec r = a.recs[blockIdx.x];
+  const uint32_t n_tiles = (r.nrows + kWave - 1) / kWave;
+  const bool have = (uint32_t)wid < n_tiles;
+  // the tile: ld / 8 pieces of 1 KiB, walked in groups of 8 (4 column blocks x 2 row halves), three groups in flight
+  constexpr int R = 3, kG = 8;
+  const uint32_t n_groups = a.ld / 64u;
+  const uint32_t tile_bytes = a.ld * 128u;
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      (void*)(a.rows_h + (uint64_t)r.row0 * a.ld), 0, (int)(n_tiles * tile_bytes), 0x00020000);
+  const uint32_t lane_off = (uint32_t)lane * 16u, tile_off = (uint32_t)wid * tile_bytes;
+  u32x4 buf[R][kG];
+  auto issue = [&](auto btag, uint32_t g) {
+    constexpr int B = decltype(btag)::value;
+#pragma unroll
+    for (int i = 0; i < kG; ++i) buf[B][i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane_off, tile_off + g * (kG * 1024u) + (uint32_t)i * 1024u, 2);
+  };
+  float xn = 0.0f;
+  if (have) {  // (wave-uniform) the first groups fly while the block stages the query
+    xn = a.xnorm[(uint64_t)r.row0 + (uint32_t)wid * kWave + lane];
+    issue(std::integral_constant<int, 0>{}, 0u);
+    if (n_groups > 1) issue(std::integral_constant<int, 1>{}, 1u);
+  }
+  const float qscale = a.metric ? -1.0f : -2.0f;
+  for (uint32_t i = threadIdx.x; i < a.ld / 4u; i += kWave * kS1hWaves) {
+    const f32x4 v = reinterpret_cast<const f32x4*>(a.qp)[i];
+    reinterpret_cast<f32x4*>(qs)[i] = qscale * v;
+  }
+  __syncthreads();
+  uint64_t key = kKeyMax;
+  if (have) {
+    float acc0 = 0.0f, acc1 = 0.0f;
+    const f32x4* const q4 = reinterpret_cast<const f32x4*>(qs) + 2 * (lane >> 5);
+    auto step = [&](auto btag, uint32_t g) {
+      constexpr int B = decltype(btag)::value;
+      if (g + 2 < n_groups) issue(std::integral_constant<int, (B + 2) % R>{}, g + 2);
+      if (g < n_groups) {
+#pragma unroll
+        for (int c = 0; c < kG / 2; ++c) {
+          const f32x4 qa = q4[(g * (kG / 2) + c) * 4], qb = q4[(g * (kG / 2) + c) * 4 + 1];
+          const f16x8_t x0 = __builtin_bit_cast(f16x8_t, buf[B][2 * c]), x1 = __builtin_bit_cast(f16x8_t, buf[B][2 * c + 1]);
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            acc0 = __builtin_fmaf((float)x0[u], qa[u], acc0);
+            acc1 = __builtin_fmaf((float)x1[u], qa[u], acc1);
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            acc0 = __builtin_fmaf((float)x0[4 + u], qb[u], acc0);
+            acc1 = __builtin_fmaf((float)x1[4 + u], qb[u], acc1);
+          }
+        }
+      }
+    };
+    for (uint32_t g = 0; g < n_groups; g += R) {
+      step(std::integral_constant<int, 0>{}, g);
+      step(std::integral_constant<int, 1>{}, g + 1);
+      step(std::integral_constant<int, 2>{}, g + 2);
+    }
+    const float t0 = acc0 + __shfl_xor(acc0, 32, kWave), t1 = acc1 + __shfl_xor(acc1, 32, kWave);
+    const float dot = lane < 32 ? t0 : t1;  // row `lane` of the tile
+    const float val = a.metric ? dot : xn + dot;
+    const uint32_t row = (uint32_t)wid * kWave + (uint32_t)lane;
+    const bool live = row < r.nrows;
+    const bool bad = live && !(__builtin_fabsf(val) < __builtin_inff());
+    if (__ballot(bad) != 0 && lane == 0) a.qflags[0] = 1u;  // a non-finite val: the query is re-done exactly (ivf_rescore_kernel)
+    if (live && !bad) key = make_key(val, r.seq0 + row);
+    wave_rank_sort64(key, lane);
+  }
+  sh[wid][lane] = key;
+  __syncthreads();
+#pragma unroll
+  for (int s = 1; s < kS1hWaves; s <<= 1) {
+    if ((wid & (2 * s - 1)) == 0) {
+      wave_merge_sorted64(key, sh[wid + s][lane], lane);
+      if (2 * s < kS1hWaves && wid != 0) sh[wid][lane] = key;
+    }
+    if (2 * s < kS1hWaves) __syncthreads();
+  }
+  if (wid == 0 && lane < (int)a.kp) a.partials[(uint64_t)r.out * a.kp + lane] = key;
+}
+
 // final merge + id mapping: one block per query.  Results wider than 64 keys come 64 ranks per pass (ScanParams::lower):
 // this pass emits ranks rank0 .. rank0+63 of every merge group into output row q (pitch top_k) and leaves the group's
 // last key as the next pass's lower bound.
@@ -275,6 +381,23 @@ int32_t launch_scan1(vers_ivf* h, const Scan1Args& a, uint32_t items_bound, hipS
   return VERS_OK;
 }
 
+// a single query's list scan on the fp16 shadow (scan1h_kernel: a block per record); timed through the same event ring
+int32_t launch_scan1h(vers_ivf* h, const Scan1hArgs& a, uint32_t items_bound, hipStream_t st) {
+  const size_t lds = scan1h_lds_bytes(h->ld);
+  if (int32_t rc = scan_prepare_launch(scan1h_kernel, lds)) return rc;
+  const uint32_t blocks = items_bound ? items_bound : 1u;  // (W->items holds items_bound + 4 records: one per launched block)
+  const bool no_ev = !W->ev_on;
+  const uint32_t slot = (uint32_t)(W->ev_count % SearchWs::kEvRing);
+  if (!no_ev) VERS_HIP_TRY(hipEventRecord(W->ev0[slot], st));
+  hipLaunchKernelGGL(scan1h_kernel, dim3(blocks), dim3(kWave * kS1hWaves), lds, st, a);
+  VERS_HIP_TRY(hipGetLastError());
+  if (!no_ev) {
+    VERS_HIP_TRY(hipEventRecord(W->ev1[slot], st));
+    W->ev_count += 1;
+  }
+  return VERS_OK;
+}
+
 // the matrix-core list scan (prescan.hip.h); timed through the same event ring as launch_ivf_scan
 template <int NQ>
 int32_t launch_prescan(vers_ivf* h, const IvfSrc<NQ>& src, uint32_t items_bound, uint32_t kp, uint32_t* qflags, uint32_t* quad_ctr,
@@ -344,7 +467,7 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
   if (int32_t rc = plan_search(h, q_dev, ldq_in, b, top_k, nprobe, st, s)) return rc;
   const uint32_t P = s.P, kp = s.kp, k_keep = s.k_keep, n_pass = s.n_pass, seg_rows = s.seg_rows, seg_target = s.seg_target, S_max = s.S_max;
   const int ref_mode = s.ref_mode, QG = s.QG, pre_mode = s.pre_mode;
-  const bool one1 = s.one1, use_pre = s.use_pre, use_shadow = s.use_shadow, hi_only = s.pre_hi_only;
+  const bool one1 = s.one1, one1_pre = s.one1_pre, use_pre = s.use_pre, use_shadow = s.use_shadow, hi_only = s.pre_hi_only && !s.one1_pre;
   const uint64_t items_bound = s.items_bound;
   const size_t part_bytes = s.part_bytes;
   uint32_t *const pj_list = s.pj_list, *const pj_pref = s.pj_pref, *const pj_take = s.pj_take, *const np = s.np, *const pj_nq = s.pj_nq;
@@ -374,21 +497,32 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
       if (int32_t rc2 = W->fb_ctr.reserve((2 * kFallbackBlocks + 1) * sizeof(uint32_t))) return rc2;
       VERS_HIP_TRY(hipMemsetAsync(W->fb_ctr.p, 0, (2 * kFallbackBlocks + 1) * sizeof(uint32_t), st));
     }
-    if (int32_t rc2 = QG == kPreQWide     ? launch_prescan(h, src_w, (uint32_t)items_bound, kp, qflags, quad_ctr, use_shadow, hi_only, st)
-                      : QG == kPreQNarrow ? launch_prescan(h, src_n, (uint32_t)items_bound, kp, qflags, quad_ctr, use_shadow, hi_only, st)
-                                          : launch_prescan(h, src, (uint32_t)items_bound, kp, qflags, quad_ctr, use_shadow, hi_only, st)) return rc2;
+    if (one1_pre) {  // a single query: its records (plan1_block) against the shadow, a block each
+      Scan1hArgs sa;
+      sa.rows_h = h->rows_bf.as<uint16_t>(); sa.xnorm = h->xnorm.as<float>(); sa.recs = W->items.as<Item1Rec>(); sa.n_items_dev = &tot->n_items; sa.qp = qp;
+      sa.partials = W->partials.as<uint64_t>(); sa.qflags = qflags; sa.ld = h->ld; sa.kp = kp; sa.metric = (uint32_t)h->metric;
+      if (int32_t rc2 = launch_scan1h(h, sa, (uint32_t)items_bound, st)) return rc2;
+    } else if (int32_t rc2 = QG == kPreQWide     ? launch_prescan(h, src_w, (uint32_t)items_bound, kp, qflags, quad_ctr, use_shadow, hi_only, st)
+                             : QG == kPreQNarrow ? launch_prescan(h, src_n, (uint32_t)items_bound, kp, qflags, quad_ctr, use_shadow, hi_only, st)
+                                                 : launch_prescan(h, src, (uint32_t)items_bound, kp, qflags, quad_ctr, use_shadow, hi_only, st)) return rc2;
     if (int32_t rc2 = start_pending_ahead(h, st)) return rc2;  // the next batch's coarse quantiser: under this batch's exact finish
     RescoreArgs a;
     a.partials = W->partials.as<uint64_t>(); a.P = P; a.S_max = S_max; a.kp = kp; a.top_k = top_k; a.d_pad = h->ld;
     a.pj_list = pj_list; a.pj_pref = pj_pref; a.pj_nq = pj_nq; a.list_off = h->slot_off.as<uint32_t>(); a.row_ids = h->row_ids.as<uint32_t>();
     a.rows = h->rows.as<float>(); a.rows_rm = h->rows_rm.as<float>(); a.ld = h->ld; a.qp = qp; a.ldq = h->ldq; a.xmax2_bits = h->pre_misc.as<uint32_t>();
-    a.qflags = qflags; a.metric = h->metric; a.force_fail = pre_mode == 2; a.shadow = use_shadow ? (hi_only ? 2 : 1) : 0; a.debug = scan_debug_flags(); a.fail_list = fail_list; a.stats = h->pre_misc.as<uint32_t>() + 1;
+    a.qflags = qflags; a.metric = h->metric; a.force_fail = pre_mode == 2; a.shadow = use_shadow ? (hi_only ? 2 : 1) : 0; a.debug = scan_debug_flags(); a.fail_list = fail_list; a.stats = h->pre_misc.as<uint32_t>() + 1;  // (shadow: scan1h_kernel multiplies by the f32 query itself -- no split remainder to charge: 1 covers it)
     a.status = W->st_word(); a.out_ids = out_ids; a.out_dist = out_dist; a.out_count = out_count; a.out_keys = out_keys;
     a.stamps = (scan_debug_flags() & 16u) && W->stamps.p ? W->stamps.as<unsigned long long>() : nullptr;
-    const int stage_rows = rescore_lds_bytes(h->ld, true) <= 144u * 1024u ? 1 : 0;
-    const size_t rs_lds = rescore_lds_bytes(h->ld, stage_rows != 0);
-    if (int32_t rc2 = scan_prepare_launch(ivf_rescore_kernel, rs_lds)) return rc2;
-    hipLaunchKernelGGL(ivf_rescore_kernel, dim3(b), dim3(kWave * kRescoreWaves), rs_lds, st, a, stage_rows);
+    const int rs_waves = one1_pre ? kRescoreWaves1 : kRescoreWaves;  // (one query: sixteen waves merge its ~250 slots and walk its survivors' chains in one pass)
+    const int stage_rows = rescore_lds_bytes(h->ld, true, rs_waves) <= 144u * 1024u ? 1 : 0;
+    const size_t rs_lds = rescore_lds_bytes(h->ld, stage_rows != 0, rs_waves);
+    if (one1_pre) {
+      if (int32_t rc2 = scan_prepare_launch(ivf_rescore_kernel<kRescoreWaves1>, rs_lds)) return rc2;
+      hipLaunchKernelGGL(ivf_rescore_kernel<kRescoreWaves1>, dim3(b), dim3(kWave * kRescoreWaves1), rs_lds, st, a, stage_rows);
+    } else {
+      if (int32_t rc2 = scan_prepare_launch(ivf_rescore_kernel<kRescoreWaves>, rs_lds)) return rc2;
+      hipLaunchKernelGGL(ivf_rescore_kernel<kRescoreWaves>, dim3(b), dim3(kWave * kRescoreWaves), rs_lds, st, a, stage_rows);
+    }
     VERS_HIP_TRY(hipGetLastError());
     if (W->ev_on) {  // (measurement hook vers_ivf_last_finish_ms: from the scan's end record to here)
       VERS_HIP_TRY(hipEventRecord(W->evf, st));
@@ -397,7 +531,7 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
     }
     hipLaunchKernelGGL(fallback_kernel, dim3(fb_blocks), dim3(kWave * kMergeWaves), 0, st, a, (const uint32_t*)h->slot_len.as<uint32_t>(),
                        (const uint32_t*)fail_list, (const uint32_t*)(fail_list + b), W->fb_part.as<uint64_t>(), W->fb_ctr.as<uint32_t>(),
-                       use_shadow ? h->fail_watch : (uint32_t*)nullptr);
+                       use_shadow ? h->fail_watch : (uint32_t*)nullptr, (const uint32_t*)W->st_word(), W->st_host);  // (st_host: host-pointer single-query call)
     VERS_HIP_TRY(hipGetLastError());
     W->last_pre.valid = true; W->last_pre.b = b; W->last_pre.P = P; W->last_pre.S_max = S_max; W->last_pre.kp = kp; W->last_pre.top_k = top_k;
     W->last_pre.qp = qp; W->last_pre.shadow = use_shadow ? (hi_only ? 2 : 1) : 0;

@@ -185,7 +185,7 @@ __device__ __forceinline__ uint64_t buffer_sorted(const uint64_t* bq, uint32_t n
   if (cap > (uint32_t)kWave && n_valid > (uint32_t)kWave) {  // (wave-uniform)
     uint64_t k1 = (uint32_t)lane + kWave < n_valid ? bq[kWave + lane] : kKeyMax;
     wave_rank_sort64<true>(k1, lane);
-    const uint64_t k1r = shfl_idx64(k1, kWave - 1 - lane);
+    const uint64_t k1r = lane_rev64(k1, lane);
     k0 = k0 < k1r ? k0 : k1r;  // ascending vs descending: the element-wise minimum holds the 64 smallest, as a bitonic sequence
     wave_bitonic_merge64(k0, lane);
   }

@@ -11,6 +11,7 @@
 // 64-row tiles (below) so that every wave-level load is one contiguous 1 KiB read
 // that lands directly in the lanes that own the rows -- no LDS, no shuffles.
 #pragma once
+#include <type_traits>
 #include "common.hpp"
 
 // never contract a*b+c: the reference rounds the product and the sum separately
@@ -154,26 +155,72 @@ __device__ __forceinline__ uint64_t shfl_idx64(uint64_t v, int src) {
   const uint32_t lo = (uint32_t)__shfl((int)(uint32_t)v, src, kWave), hi = (uint32_t)__shfl((int)(uint32_t)(v >> 32), src, kWave);
   return ((uint64_t)hi << 32) | lo;
 }
-// the last stage of a bitonic sort: a bitonic sequence over the 64 lanes -> ascending
-__device__ __forceinline__ void wave_bitonic_merge64(uint64_t& key, int lane) {
-#pragma unroll
-  for (int j = 32; j > 0; j >>= 1) {
-    const uint64_t o = shfl_xor64(key, j);
-    const bool lower = (lane & j) == 0;
-    key = (lower == (key < o)) ? key : o;  // lower lane keeps the minimum, upper lane the maximum
+// Lane l <- lane l ^ J of the same wave, on the VALU: DPP inside a row of 16 (quad_perm for J = 1, 2; the two row shifts by 4
+// and a select; row_ror:8), v_permlane16_swap / v_permlane32_swap (gfx950) across rows and halves.  ~2-6 instructions per 32 bits
+// where __shfl_xor is a ds_bpermute: a round trip through the LDS crossbar, ~120 cycles that the six DEPENDENT stages of a merge
+// network cannot overlap -- a 64-lane merge was ~1500 cycles, 0.6 us of every fold of two sorted lists (measured on the single
+// query's lone finish block, round 5).  Whole wave (every lane active).
+typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+template <int J>
+__device__ __forceinline__ uint32_t lane_xor_u32(uint32_t x, int lane) {
+  static_assert(J == 1 || J == 2 || J == 4 || J == 8 || J == 16 || J == 32, "one bit of the lane index");
+  if constexpr (J == 1) return (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0xB1, 0xf, 0xf, false);       // quad_perm [1,0,3,2]
+  else if constexpr (J == 2) return (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x4E, 0xf, 0xf, false);  // quad_perm [2,3,0,1]
+  else if constexpr (J == 4) {
+    const uint32_t up = (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x104, 0xf, 0xf, false);  // row_shl:4: lane i <- i + 4
+    const uint32_t dn = (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x114, 0xf, 0xf, false);  // row_shr:4: lane i <- i - 4
+    return (lane & 4) ? dn : up;
+  } else if constexpr (J == 8) return (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x128, 0xf, 0xf, false);  // row_ror:8
+  else if constexpr (J == 16) {
+    const u32x2_t r = __builtin_amdgcn_permlane16_swap(x, x, false, false);  // {rows [0,0,2,2], rows [1,1,3,3]} of x
+    return (lane & 16) ? r[0] : r[1];
+  } else {
+    const u32x2_t r = __builtin_amdgcn_permlane32_swap(x, x, false, false);  // {halves [lo,lo], halves [hi,hi]}
+    return (lane & 32) ? r[0] : r[1];
   }
 }
+template <int J>
+__device__ __forceinline__ uint64_t lane_xor64(uint64_t v, int lane) {
+  return ((uint64_t)lane_xor_u32<J>((uint32_t)(v >> 32), lane) << 32) | lane_xor_u32<J>((uint32_t)v, lane);
+}
+// lane l <- lane 63 - l: row_mirror (15 - i inside a row), then the rows and the halves swapped
+__device__ __forceinline__ uint64_t lane_rev64(uint64_t v, int lane) {
+  const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)v, (int)(uint32_t)v, 0x140, 0xf, 0xf, false);
+  const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)(v >> 32), (int)(uint32_t)(v >> 32), 0x140, 0xf, 0xf, false);
+  return lane_xor64<32>(lane_xor64<16>(((uint64_t)hi << 32) | lo, lane), lane);
+}
+template <int J>
+__device__ __forceinline__ void bitonic_stage64(uint64_t& key, int lane, bool up) {
+  const uint64_t o = lane_xor64<J>(key, lane);
+  const bool lower = (lane & J) == 0;
+  key = ((lower == up) == (key < o)) ? key : o;  // (up: the lower lane keeps the minimum, the upper lane the maximum)
+}
+// the last stage of a bitonic sort: a bitonic sequence over the 64 lanes -> ascending
+__device__ __forceinline__ void wave_bitonic_merge64(uint64_t& key, int lane) {
+  bitonic_stage64<32>(key, lane, true);
+  bitonic_stage64<16>(key, lane, true);
+  bitonic_stage64<8>(key, lane, true);
+  bitonic_stage64<4>(key, lane, true);
+  bitonic_stage64<2>(key, lane, true);
+  bitonic_stage64<1>(key, lane, true);
+}
 __device__ __forceinline__ void wave_bitonic_sort64(uint64_t& key, int lane) {
-#pragma unroll
-  for (int k = 2; k <= kWave; k <<= 1) {
-#pragma unroll
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      const uint64_t o = shfl_xor64(key, j);
-      const bool up = (lane & k) == 0 || k == kWave;  // direction of this lane's k-block (the last stage: all ascending)
-      const bool lower = (lane & j) == 0;
-      key = ((lower == up) == (key < o)) ? key : o;
-    }
-  }
+  auto block = [&](auto ktag) {  // the k-block's stages j = k / 2 .. 1; direction by the lane's k-block (the last one: all ascending)
+    constexpr int K = decltype(ktag)::value;
+    const bool up = (lane & K) == 0 || K == kWave;
+    if constexpr (K >= 64) bitonic_stage64<32>(key, lane, up);
+    if constexpr (K >= 32) bitonic_stage64<16>(key, lane, up);
+    if constexpr (K >= 16) bitonic_stage64<8>(key, lane, up);
+    if constexpr (K >= 8) bitonic_stage64<4>(key, lane, up);
+    if constexpr (K >= 4) bitonic_stage64<2>(key, lane, up);
+    bitonic_stage64<1>(key, lane, up);
+  };
+  block(std::integral_constant<int, 2>{});
+  block(std::integral_constant<int, 4>{});
+  block(std::integral_constant<int, 8>{});
+  block(std::integral_constant<int, 16>{});
+  block(std::integral_constant<int, 32>{});
+  block(std::integral_constant<int, 64>{});
 }
 // One key per lane -> ascending over the lanes, by RANK COUNTING: every lane counts the lanes whose DISTANCE BITS lie below its
 // own (64 scalar reads of a lane, a compare and an add each) and sends its key to the lane of that rank (ds_permute): ~200 VALU
@@ -208,7 +255,7 @@ __device__ __forceinline__ void wave_rank_sort64(uint64_t& key, int lane) {
 // -- is ~130 cycles per key that passes the threshold: 34 of them for the first slot merged into an empty list.)
 __device__ __forceinline__ void wave_merge_sorted64(uint64_t& list, uint64_t cand, int lane) {
   if (__ballot(cand != kKeyMax) == 0) return;  // nothing in it (wave-uniform)
-  const uint64_t rev = shfl_idx64(cand, kWave - 1 - lane);
+  const uint64_t rev = lane_rev64(cand, lane);
   list = list < rev ? list : rev;
   wave_bitonic_merge64(list, lane);
 }
