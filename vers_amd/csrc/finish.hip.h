@@ -149,6 +149,30 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(NW =
   // everything that does not depend on the merge is requested up front
   const uint32_t flag0 = a.qflags[(uint64_t)q * a.P];
   const uint32_t xmax_bits = *a.xmax2_bits;
+  // (the single query's lone block: its slots' keys and minima are requested before anything else -- see the merge below)
+  constexpr int kPre = 16;  // keys per thread in registers: 16 k keys = 480 slots of kp = 34
+  const uint64_t* keys = a.partials + (uint64_t)q * a.P * a.S_max * a.kp;
+  const uint32_t n_slots = a.P * a.S_max;
+  const uint64_t n_keys = (uint64_t)n_slots * a.kp;
+  const bool flat_ok = NW == kRescoreWaves1 && n_keys <= (uint64_t)8 * kPre * kWave * NW && !(a.debug & 1024u);  // (beyond ~100 k keys -- an index with one very long list -- slot by slot)
+  uint64_t pk[kPre];
+  uint64_t mn = kKeyMax;
+  if constexpr (NW == kRescoreWaves1) {
+    if (flat_ok) {
+#pragma unroll
+      for (int u = 0; u < kPre; ++u) {
+        const uint32_t idx = threadIdx.x + (uint32_t)u * (kWave * NW);
+        pk[u] = idx < n_keys ? keys[idx] : kKeyMax;
+      }
+      // (a thread takes two neighbouring slots and keeps the smaller minimum -- more when there are more than 2048 slots --: T stays
+      // valid, a little looser, and 448 slots are four waves' worth: two folds instead of three)
+      for (uint32_t sl = 2u * threadIdx.x; sl < n_slots; sl += 2u * kWave * NW) {
+        const uint64_t k0 = keys[(uint64_t)sl * a.kp], k1 = sl + 1u < n_slots ? keys[(uint64_t)(sl + 1u) * a.kp] : kKeyMax;
+        mn = k0 < mn ? k0 : mn;
+        mn = k1 < mn ? k1 : mn;
+      }
+    }
+  }
   float qpart = 0.0f, rpart = 0.0f;
   const float qscale = a.metric ? -1.0f : -2.0f;  // (what prescan_kernel_g stages: exact scalings)
   for (uint32_t i = threadIdx.x; i < a.ld; i += blockDim.x) {
@@ -170,12 +194,20 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(NW =
   // at cfg3, and at 8 ranks 7/8 of the slots belong to other GPUs' lists).  A slot is an ascending list (prescan.hip.h,
   // buffer_sorted): two of them merge through a six-stage network (wave_merge_sorted64) -- the ordered inserts of rounds 2-4
   // cost ~130 cycles per key that passed: 26 k of the kernel's 91 k cycles per query at 8 ranks.
-  const uint64_t* keys = a.partials + (uint64_t)q * a.P * a.S_max * a.kp;
   const uint32_t* nqp = a.pj_nq + (uint64_t)q * a.P;
   uint64_t list = kKeyMax;
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) { qpart += __shfl_xor(qpart, off, kWave); rpart += __shfl_xor(rpart, off, kWave); }
   if (lane == 0) { sred[wid] = qpart; sres[wid] = rpart; }  // (read by wave 0 behind the merge's barriers)
+  // The certificate's bound is double-precision arithmetic with four square roots: ~2 us that a batch hides behind its other blocks and
+  // the lone block of a single query does not -- there the last wave, idle during the merge, computes it meanwhile.
+  __shared__ PreBound s_pb;
+  auto make_bound = [&]() {
+    float qn = 0.0f, rq = 0.0f;
+    for (int w = 0; w < kRescoreWaves; ++w) { qn += sred[w]; rq += sres[w]; }
+    return pre_bound((double)qn, (double)__uint_as_float(xmax_bits), a.shadow ? (double)__uint_as_float(a.xmax2_bits[2]) : 0.0, a.d_pad, a.metric, a.shadow, (double)rq);
+  };
+  bool pb_ready = false;  // (block-uniform)
   if (wid == 0 && pre_ok) wave_seq_rows_load2(pre, a.list_off);  // (the dependent half, in flight under the merge)
   // 64 keys per wave, ascending (kKeyMax padded) -> wave 0 ends with the 64 smallest of the block's, ascending.  Pairwise: in stage s
   // the waves at multiples of 2 s fold in the list of the wave s above (stored a stage ago) and store theirs.
@@ -206,28 +238,13 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(NW =
     constexpr uint32_t kBuf = 1024;
     __shared__ __attribute__((aligned(16))) uint64_t s_buf[kBuf];
     __shared__ uint64_t s_out[kWave];
+    __shared__ uint32_t s_rank[kBuf];
     __shared__ uint32_t s_T, s_cnt;
-    constexpr int kPre = 16;  // keys per thread in registers: 16 k keys = 480 slots of kp = 34
-    const uint32_t n_slots = a.P * a.S_max;
-    const uint64_t n_keys = (uint64_t)n_slots * a.kp;
-    if (n_keys <= (uint64_t)8 * kPre * kWave * NW && !(a.debug & 1024u)) {
+    if (flat_ok) {
       xstamp(0);
       if (threadIdx.x == 0) { s_cnt = 0u; s_T = 0xFFFFFFFFu; }  // (fewer than kp slots hold anything: every key passes)
       if (threadIdx.x < kWave) s_out[threadIdx.x] = kKeyMax;
-      uint64_t pk[kPre];
-#pragma unroll
-      for (int u = 0; u < kPre; ++u) {
-        const uint32_t idx = threadIdx.x + (uint32_t)u * (kWave * NW);
-        pk[u] = idx < n_keys ? keys[idx] : kKeyMax;
-      }
-      // (a thread takes two neighbouring slots and keeps the smaller minimum -- more when there are more than 2048 slots --: T stays
-      // valid, a little looser, and 448 slots are four waves' worth: two folds instead of three)
-      uint64_t mn = kKeyMax;
-      for (uint32_t sl = 2u * threadIdx.x; sl < n_slots; sl += 2u * kWave * NW) {
-        const uint64_t k0 = keys[(uint64_t)sl * a.kp], k1 = sl + 1u < n_slots ? keys[(uint64_t)(sl + 1u) * a.kp] : kKeyMax;
-        mn = k0 < mn ? k0 : mn;
-        mn = k1 < mn ? k1 : mn;
-      }
+      s_rank[threadIdx.x] = 0u;
       xstamp(1);
       int nwa = 1;
       while (nwa < NW && (uint32_t)nwa * 2u * kWave < n_slots) nwa *= 2;
@@ -260,11 +277,28 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(NW =
       const uint32_t n_in = s_cnt;
       if (n_in <= kBuf) {
         flat_done = true;
+        pb_ready = true;
+        if (wid == NW - 1) {  // (the last wave has no kept keys to rank unless there are > 960 of them: the certificate's bound meanwhile)
+          const PreBound b = make_bound();
+          if (lane == 0) s_pb = b;
+        }
+        // rank of a kept key = the kept keys below it (keys are unique): up to four threads per key, each counting over a quarter
+        // of the buffer (broadcast reads: the lanes of a wave hold different keys and walk the same entries)
+        const uint32_t parts = n_in == 0 ? 1u : (4u * n_in <= (uint32_t)(kWave * NW) ? 4u : (2u * n_in <= (uint32_t)(kWave * NW) ? 2u : 1u));
+        if (threadIdx.x < parts * n_in) {
+          const uint32_t ki = threadIdx.x % n_in, part = threadIdx.x / n_in;
+          const uint32_t per = (n_in + parts - 1u) / parts, i_begin = part * per, i_end = i_begin + per < n_in ? i_begin + per : n_in;
+          const uint64_t my = s_buf[ki];
+          uint32_t below = 0;
+#pragma unroll 4
+          for (uint32_t i = i_begin; i < i_end; ++i) below += s_buf[i] < my ? 1u : 0u;
+          if (parts == 1u) s_rank[ki] = below;
+          else if (below) atomicAdd(&s_rank[ki], below);
+        }
+        __syncthreads();
         if (threadIdx.x < n_in) {
-          const uint64_t my = s_buf[threadIdx.x];
-          uint32_t rank = 0;
-          for (uint32_t i = 0; i < n_in; ++i) rank += s_buf[i] < my ? 1u : 0u;  // (keys are unique)
-          if (rank < (uint32_t)kWave) s_out[rank] = my;
+          const uint32_t r = s_rank[threadIdx.x];
+          if (r < (uint32_t)kWave) s_out[r] = s_buf[threadIdx.x];
         }
         __syncthreads();
         if (wid == 0) list = s_out[lane];
@@ -305,10 +339,7 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(NW =
     if (lane >= (int)a.kp) list = kKeyMax;  // (the networks keep 64 keys: the kp smallest are the candidates)
     const bool valid = lane < (int)a.kp && list != kKeyMax;
     const uint32_t cnt = (uint32_t)__popcll(__ballot(valid));
-    float qn = 0.0f, rq = 0.0f;
-    for (int w = 0; w < kRescoreWaves; ++w) { qn += sred[w]; rq += sres[w]; }
-    const PreBound pb = pre_bound((double)qn, (double)__uint_as_float(xmax_bits), a.shadow ? (double)__uint_as_float(a.xmax2_bits[2]) : 0.0, a.d_pad, a.metric,
-                                  a.shadow, (double)rq);  // (double-precision square roots: ~2 us on the lone block's critical path; batches hide it)
+    const PreBound pb = pb_ready ? s_pb : make_bound();  // (s_pb: written before the merge's last barrier)
     const float val = __uint_as_float(order_bits_to_f32_bits((uint32_t)(list >> 32)));
     const double e_mine = pb.of((double)val);  // this candidate's own bound (NaN / inf vals: NaN / inf, handled by the negated compares)
     bool certified = true;
@@ -370,16 +401,21 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(NW =
     // stays at 64 registers: beside the two 224-register waves per SIMD of ANOTHER batch's list scan that is what is left, and
     // with batches in flight the finish then runs under that scan instead of waiting for whole CUs)
     constexpr uint32_t kPassRows = 8;
-    for (uint32_t base = 0; base < n_surv; base += kPassRows * kRescoreWaves) {  // block-uniform
-      const uint32_t n_pass = n_surv - base < kPassRows * kRescoreWaves ? n_surv - base : kPassRows * kRescoreWaves;
-      const uint32_t per_wave = (n_pass + kRescoreWaves - 1) / kRescoreWaves;
+    // The lone block of a single query walks its chains on FOUR of its sixteen waves, one per SIMD: a chain costs its wave ~100
+    // VALU instructions per 64 columns whether one lane walks or sixteen do, and with a survivor per wave three chains share each
+    // SIMD's issue slots (19 k cycles for 11 survivors; 768 dependent adds are ~7 k).
+    constexpr int kCW = NW == kRescoreWaves1 ? 4 : NW;
+    if (wid < kCW)
+    for (uint32_t base = 0; base < n_surv; base += kPassRows * kCW) {  // block-uniform
+      const uint32_t n_pass = n_surv - base < kPassRows * kCW ? n_surv - base : kPassRows * kCW;
+      const uint32_t per_wave = (n_pass + kCW - 1) / kCW;
       auto run = [&](auto nl_tag) {
         constexpr int NL = decltype(nl_tag)::value;
         const float* rp[NL];
         const uint32_t xstep = a.rows_rm ? 4u : 256u;
 #pragma unroll
         for (int i = 0; i < NL; ++i) {
-          const uint32_t sv = base + (uint32_t)(4 * i + (lane >> 4)) * kRescoreWaves + (uint32_t)wid;
+          const uint32_t sv = base + (uint32_t)(4 * i + (lane >> 4)) * kCW + (uint32_t)wid;
           uint32_t row = srow[sv < n_surv ? sv : 0u];  // (slots past the end re-read survivor 0: never used)
           if (a.debug & 2048u) row &= 1023u;  // (diagnosis: the gather without its address translation / HBM misses)
           rp[i] = (a.rows_rm ? a.rows_rm + (uint64_t)row * a.ld : a.rows + (uint64_t)(row >> 6) * 64ull * a.ld + (row & 63) * 4u) +
@@ -394,7 +430,7 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(NW =
       };
       float acc = per_wave <= 4 ? run(std::integral_constant<int, 1>{}) : run(std::integral_constant<int, 2>{});
       if (a.metric) acc = __fsub_rn(1.0f, acc);
-      const uint32_t sv = base + (uint32_t)lane * kRescoreWaves + (uint32_t)wid;
+      const uint32_t sv = base + (uint32_t)lane * kCW + (uint32_t)wid;
       if (lane < (int)kPassRows && sv < n_surv) {
         if (acc != acc) atomicOr(a.status, 1u);
         s_cand[sv] = (uint64_t)f32_to_order_bits(acc) << 32;  // (wave 0 holds the survivors' sequence numbers)
@@ -432,7 +468,7 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(NW =
   uint64_t fin = kKeyMax;
   if constexpr (NW == kRescoreWaves1) {  // (one sort instead of an ordered insert per survivor)
     fin = cand;
-    wave_rank_sort64<true>(fin, lane);
+    wave_rank_sort64(fin, lane);
     if (lane >= (int)a.top_k) fin = kKeyMax;
   } else {
     wave_topk_update(fin, a.top_k, cand, kKeyMax);

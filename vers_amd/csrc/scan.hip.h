@@ -803,7 +803,7 @@ inline int32_t scan_prepare_launch(K kernel, size_t lds_bytes) {
 // 23 us of single-block latency around 56-90 us scans.)  Returns the merged list in wave 0, lane i = i-th smallest.
 constexpr int kMergeWaves = 16;
 __device__ __forceinline__ uint64_t wave_merge2_sorted(uint64_t a, uint64_t b, int lane) {  // both ascending over the lanes
-  const uint64_t br = shfl_idx64(b, kWave - 1 - lane);
+  const uint64_t br = lane_rev64(b, lane);
   uint64_t m = a < br ? a : br;  // bitonic, holds the 64 smallest of the union
   wave_bitonic_merge64(m, lane);
   return m;
