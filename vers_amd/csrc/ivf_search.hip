@@ -491,6 +491,7 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
     IvfSrc<kPreQWide> src_w; fill_src(src_w);    // (64 queries per block on the shadow, query block as fp16 hi only)
     // partial lists of the exact re-scan (fail_list [b] + its count, qflags [n_pj]: in the zeroed zone above)
     uint32_t fb_blocks = kFallbackBlocks;  // (a power of two; fewer when P x top_k is large: at most 32 MB of partial lists)
+    if (b == 1) fb_blocks = 32;  // (a single query: the launch that almost always finds nothing to do costs 4.3 us with 128 blocks of 16 waves to dispatch; a list per block when it does)
     while (fb_blocks > 16 && fallback_part_keys(fb_blocks, P, top_k) * sizeof(uint64_t) > (size_t(32) << 20)) fb_blocks /= 2;
     if (int32_t rc2 = W->fb_part.reserve(fallback_part_keys(fb_blocks, P, top_k) * sizeof(uint64_t))) return rc2;
     if (!W->fb_ctr.p) {  // group counters of fallback_kernel: zero once, the kernel leaves them zero

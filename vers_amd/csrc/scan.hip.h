@@ -164,6 +164,9 @@ typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
 template <int J>
 __device__ __forceinline__ uint32_t lane_xor_u32(uint32_t x, int lane) {
   static_assert(J == 1 || J == 2 || J == 4 || J == 8 || J == 16 || J == 32, "one bit of the lane index");
+#ifdef VERS_LANE_NET_LDS  // (A/B builds, scripts/build_variant.sh: the ds_bpermute route of rounds 1-4)
+  return (uint32_t)__shfl_xor((int)x, J, kWave);
+#endif
   if constexpr (J == 1) return (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0xB1, 0xf, 0xf, false);       // quad_perm [1,0,3,2]
   else if constexpr (J == 2) return (uint32_t)__builtin_amdgcn_update_dpp((int)x, (int)x, 0x4E, 0xf, 0xf, false);  // quad_perm [2,3,0,1]
   else if constexpr (J == 4) {
@@ -185,6 +188,9 @@ __device__ __forceinline__ uint64_t lane_xor64(uint64_t v, int lane) {
 }
 // lane l <- lane 63 - l: row_mirror (15 - i inside a row), then the rows and the halves swapped
 __device__ __forceinline__ uint64_t lane_rev64(uint64_t v, int lane) {
+#ifdef VERS_LANE_NET_LDS
+  return ((uint64_t)(uint32_t)__shfl((int)(uint32_t)(v >> 32), kWave - 1 - lane, kWave) << 32) | (uint32_t)__shfl((int)(uint32_t)v, kWave - 1 - lane, kWave);
+#endif
   const uint32_t lo = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)v, (int)(uint32_t)v, 0x140, 0xf, 0xf, false);
   const uint32_t hi = (uint32_t)__builtin_amdgcn_update_dpp((int)(uint32_t)(v >> 32), (int)(uint32_t)(v >> 32), 0x140, 0xf, 0xf, false);
   return lane_xor64<32>(lane_xor64<16>(((uint64_t)hi << 32) | lo, lane), lane);
