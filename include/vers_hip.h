@@ -311,7 +311,7 @@ int32_t vers_ivf_build_sharded_dev(vers_ivf_t* h, const float* rows_dev, uint64_
  * scan (vers_ivf_shadow_state); 0 = none, and searches on existing handles read their f32 rows until it is 1 again.
  * "scan_events": HIP event records around every list-scan launch, the source of vers_ivf_last_scan's / vers_ivf_scan_times'
  * times: 1 always, 0 never, 2 (default; VERS_SCAN_EVENTS) for batches only -- the two records cost a single-query call
- * 5.5-6 us of ~100, so b == 1 calls are not timed unless asked.
+ * 5.5-6 us of ~70, so b == 1 calls (and the batches of 2-3 that run as consecutive single queries) are not timed unless asked.
  * "pre_min_batch" (default 4; VERS_PRE_MIN_BATCH): the smallest batch of an nprobe search whose list scan runs on the matrix
  * cores (fp16 shadow, exact finish) even when its lists are shared by fewer than two queries on average; smaller batches
  * run one ordered-chain scan per (query, list) pair.  Same results either way.

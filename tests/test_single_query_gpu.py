@@ -46,6 +46,13 @@ for seed, n, d, k, metric, top_ks, nprobes in CASES:
                     checked += 1
                 st1 = ix.prescan_stats()
                 took_shadow = st1["batches"] - st0["batches"]
+                for bsz in (2, 3):   # batches below the matrix-core scan's smallest: consecutive single queries on the shadow (single_shadow = 1)
+                    ids, dist, cnt = ix.search_batch(Q[5:5 + bsz], top_k, np_)
+                    for r in range(bsz):
+                        oi, od = co.search_nprobe(ix.values, ix.centroids, ix.ids, Q[5 + r], top_k, np_, metric=metric)
+                        assert cnt[r] == len(oi) and np.array_equal(ids[r, :len(oi)], oi) and np.array_equal(dist[r, :len(oi)].view(np.uint32), od.view(np.uint32)), (seed, top_k, np_, bsz, r)
+                if single_shadow and ix.shadow_state()["active"] and top_k + 6 <= 64:
+                    assert ix.prescan_stats()["batches"] - st1["batches"] == 5
                 if single_shadow and ix.shadow_state()["active"] and top_k + 6 <= 64:
                     assert took_shadow == 12, (took_shadow, "the single queries went through the shadow scan")
                     if FORCED: assert st1["fallback_queries"] - st0["fallback_queries"] == 12   # ... and every one was re-scanned exactly

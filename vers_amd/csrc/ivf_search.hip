@@ -463,6 +463,18 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
     return VERS_OK;
   }
   if (h->k == 0) return fail(VERS_ERR_INSUFFICIENT, "search on an index without centroids (reference: index out of bounds, ivfflat.rs:169)");
+  // Batches below the matrix-core scan's smallest (2 or 3 queries by default) went to one ordered-chain scan of the f32 rows per (query,
+  // list) pair: 204 / 272 us at cfg3.  Since round 5 a single query on the shadow is 66 us: such a batch is its queries one after
+  // the other on the stream (the per-call tables are reused in stream order, like consecutive calls on one stream).  Same results.
+  if (b > 1 && b < pre_min_batch_ref().load(std::memory_order_relaxed) && nprobe != 0 && std::min<uint32_t>(nprobe, h->k) <= (uint32_t)kMaxTopK &&
+      top_k + 6 <= kPreMaxKp && knobs().pre_mode != 0 && single_shadow_ref().load(std::memory_order_relaxed) != 0 && shadow_mode() != 0 &&
+      !h->shadow_off && h->shadow_valid && h->rows_bf.p != nullptr) {
+    int32_t rc = VERS_OK;  // (timed -- scan_events 2 -- like single queries: not at all; two event records per query would be 11 us of a batch of 2)
+    for (uint32_t qi = 0; qi < b && rc == VERS_OK; ++qi)
+      rc = search_dev_locked(h, q_dev + (uint64_t)qi * ldq_in, ldq_in, 1, top_k, nprobe, out_ids + (uint64_t)qi * top_k, out_dist + (uint64_t)qi * top_k,
+                             out_count + qi, out_keys ? out_keys + (uint64_t)qi * top_k : nullptr, st);
+    return rc;
+  }
   SearchPlan s;
   if (int32_t rc = plan_search(h, q_dev, ldq_in, b, top_k, nprobe, st, s)) return rc;
   const uint32_t P = s.P, kp = s.kp, k_keep = s.k_keep, n_pass = s.n_pass, seg_rows = s.seg_rows, seg_target = s.seg_target, S_max = s.S_max;
