@@ -693,7 +693,7 @@ def main():
         log("[bench] batch sweep: " + ", ".join(f"{k_}: {v_['queries_per_sec'] / 1e3:.1f} k q/s ({v_['us_per_batch']} us)" for k_, v_ in sweep.items()))
         # (a2b) the EDGES of the fast domain on the headline's index (the reference has no caps: ivfflat.rs:153): wider results than a
         # candidate list holds (top_k > 58: ordered chains, 64 ranks per pass), more probes than a key per lane (nprobe > 64) and
-        # batches of 2 - 3 (below pre_min_batch: one ordered-chain scan per (query, list) pair).  Correctness of these shapes is
+        # batches of 2 - 3 (below pre_min_batch: consecutive single queries on the shadow since round 5; one ordered-chain scan per (query, list) pair before).  Correctness of these shapes is
         # tests/test_limits_gpu.py's; here: what they cost.
         edges = {}
         for name, (bsz, tk, npb) in {"top_k_64": (min(B, 256), 64, nprobe), "top_k_100": (min(B, 256), 100, nprobe), "nprobe_128": (min(B, 256), top_k, min(128, nlist)),
@@ -711,7 +711,8 @@ def main():
             torch.cuda.synchronize(); dt_ = (time.perf_counter() - t0) / nst
             index.poll(st)
             edges[name] = {"batch": bsz, "top_k": tk, "nprobe": npb, "us_per_batch": round(dt_ * 1e6, 1), "queries_per_sec": round(bsz / dt_, 1),
-                           "list_scan": "matrix cores + exact finish" if index.prescan_stats()["batches"] - pb0 == nst else "ordered chains"}
+                           "list_scan": ("matrix cores + exact finish" if index.prescan_stats()["batches"] - pb0 == nst else
+                                         "consecutive single queries on the fp16 shadow (scan1h_kernel) + exact finish" if index.prescan_stats()["batches"] - pb0 == nst * bsz else "ordered chains")}
         extra["domain_edges"] = {"workload": "the headline's index, one batch in flight; shapes at and beyond the matrix-core scan's domain (top_k <= 58, nprobe <= 64, batch >= 4)", "by_shape": edges}
         log("[bench] domain edges: " + ", ".join(f"{k_}: {v_['queries_per_sec'] / 1e3:.1f} k q/s ({v_['list_scan']})" for k_, v_ in edges.items()))
         # (a3) d = 1536 -- a dimension the reference's own bindings instantiate (vers-py/src/lib.rs:26-65).  A 32-query block with both
