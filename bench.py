@@ -798,24 +798,45 @@ def main():
         Qf = torch.empty(64, d2, dtype=torch.float32, device=dev)
         capi.gen_rows_dev(Qf.data_ptr(), 64, d2, d2, 0, SEED_Q + 0x100)
         fi = torch.zeros(1, top_k, dtype=torch.int64, device=dev); fd = torch.zeros(1, top_k, device=dev); fcn = torch.zeros(1, dtype=torch.int32, device=dev)
-        msf = {0: [], 1: []}
-        for metric in (0, 1):
-            for i in range(8 + 64):
-                fc = flats[i % rot]
-                fc.search_dev(Qf[i % 64:].data_ptr(), d2, 1, top_k, metric, fi.data_ptr(), fd.data_ptr(), fcn.data_ptr(), st)
-                fc.poll(st)
-                if i >= 8:
-                    msf[metric].append(fc.last_scan_ms())
+        def flat_leg(on_shadow):
+            """scan kernel alone (HIP events) per metric and the whole call per query (scan + finish), one query at a time"""
+            capi.set_option("single_shadow", 1 if on_shadow else 0)
+            ms_ = {0: [], 1: []}
+            for metric in (0, 1):
+                for i in range(8 + 64):
+                    fc = flats[i % rot]
+                    fc.search_dev(Qf[i % 64:].data_ptr(), d2, 1, top_k, metric, fi.data_ptr(), fd.data_ptr(), fcn.data_ptr(), st)
+                    fc.poll(st)
+                    if i >= 8:
+                        ms_[metric].append(fc.last_scan_ms())
+            torch.cuda.synchronize(); t0 = time.perf_counter()
+            for i in range(200):
+                flats[i % rot].search_dev(Qf[i % 64:].data_ptr(), d2, 1, top_k, 0, fi.data_ptr(), fd.data_ptr(), fcn.data_ptr(), st)
+            torch.cuda.synchronize(); call = (time.perf_counter() - t0) / 200
+            flats[0].poll(st)
+            by = n2 * (d2 * 2 + 4) if on_shadow else n2 * d2 * 4   # (shadow row + its |x|^2 | f32 row)
+            leg = {"algorithmic_bytes": by, "call_us": round(call * 1e6, 1), "queries_per_sec": round(1.0 / call, 1)}
+            for metric, name in ((0, "l2sq"), (1, "cosdist")):
+                m_ = float(np.mean(ms_[metric]))
+                leg[name] = {"scan_us": round(m_ * 1e3, 1), "achieved_GBs": round(by / (m_ * 1e-3) / 1e9, 1), "frac": round(by / (m_ * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+            return leg
+        flat_shadow = os.environ.get("VERS_SHADOW", "1") != "0" and os.environ.get("VERS_SCAN1H", "1") != "0" and top_k + 6 <= 64
+        try:
+            f32_leg = flat_leg(False)
+            sh_leg = flat_leg(True) if flat_shadow else None
+        finally:
+            capi.set_option("single_shadow", 1)
         for fc in flats:
             fc.close()
         fb = n2 * d2 * 4
+        # (the f32 ordered-chain scan keeps the keys it always had -- SURVEY 8d prices cfg2 on N d 4 bytes; the shadow path of round 5 beside it)
         extra["flat_cfg2"] = {"workload": f"brute-force scan N={n2} d={d2} f32, one query, {rot} corpora in rotation", "algorithmic_bytes": fb,
-                              "l2sq": {"scan_us": round(float(np.mean(msf[0])) * 1e3, 1), "achieved_GBs": round(fb / (np.mean(msf[0]) * 1e-3) / 1e9, 1),
-                                       "frac": round(fb / (np.mean(msf[0]) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
-                              "cosdist": {"scan_us": round(float(np.mean(msf[1])) * 1e3, 1), "achieved_GBs": round(fb / (np.mean(msf[1]) * 1e-3) / 1e9, 1),
-                                          "frac": round(fb / (np.mean(msf[1]) * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}}
-        log(f"[bench] cfg2 flat scan: {extra['flat_cfg2']['l2sq']['scan_us']} us = {extra['flat_cfg2']['l2sq']['frac']} of peak (L2), "
-            f"{extra['flat_cfg2']['cosdist']['scan_us']} us (1 - dot)")
+                              "kernel": "scan_kernel<1, 0, FlatSrc<1>> (ordered f32 chains) + flat_merge_kernel; vers_set_option('single_shadow', 0)" if flat_shadow else "scan_kernel<1, 0, FlatSrc<1>> (ordered f32 chains) + flat_merge_kernel",
+                              "l2sq": f32_leg["l2sq"], "cosdist": f32_leg["cosdist"], "call_us": f32_leg["call_us"], "queries_per_sec": f32_leg["queries_per_sec"]}
+        if sh_leg:
+            extra["flat_cfg2"]["on_the_shadow"] = dict(sh_leg, kernel="flat1h_kernel (the corpus' fp16 shadow, a persistent grid of 64-row tiles per wave, VALU dot products) + ivf_rescore_kernel<16> (exact finish) + fallback_kernel: the default since round 5, same results")
+        log(f"[bench] cfg2 flat scan (f32 rows): {f32_leg['l2sq']['scan_us']} us = {f32_leg['l2sq']['frac']} of peak (L2), {f32_leg['cosdist']['scan_us']} us (1 - dot), {f32_leg['call_us']} us per call"
+            + (f"; on the shadow: scan {sh_leg['l2sq']['scan_us']} us = {sh_leg['l2sq']['frac']} of peak on its {sh_leg['algorithmic_bytes'] / 1e6:.0f} MB, {sh_leg['call_us']} us per call" if sh_leg else ""))
         # (c) recall on the worst case: Dist-U (uniform on the sphere -- nothing for the lists to cluster on), same N / nlist / nprobe
         if not args.no_recall:
             Xu = torch.empty(n, ld, dtype=torch.float32, device=dev)

@@ -48,7 +48,9 @@ for it in range(8):
     fc = corp[it % len(corp)]; run(fc); scan_ms.append(fc.last_scan_ms())
 corp[0].poll(st)
 scan = float(np.median(scan_ms))
-bytes_ = args.n * args.d * 4
+on_shadow = args.b == 1 and args.k + 6 <= 64 and os.environ.get("VERS_SHADOW", "1") != "0" and os.environ.get("VERS_SCAN1H", "1") != "0"
+bytes_ = args.n * (args.d * 2 + 4) if on_shadow else args.n * args.d * 4   # (the fp16 shadow row + its |x|^2, or the f32 row)
+print("list scan on", "the fp16 shadow (flat1h_kernel)" if on_shadow else "the f32 rows (ordered chains)")
 print(f"n={args.n} d={args.d} b={args.b}: call {tot*1e3:.1f} us/batch  scan kernel {scan*1e3:.1f} us  "
       f"-> scan {bytes_/scan/1e6:.1f} GB/s ({bytes_/scan/1e6/8000*100:.1f}% of 8 TB/s), end-to-end {args.b/tot*1e3:.0f} q/s")
 # sanity vs torch

@@ -108,3 +108,55 @@ def test_flat_host_pitch_of_rust_vector_layout():
     oi, od = co.search_exhaustive(X, X[10], 10)
     assert np.array_equal(ids[0], oi) and np.array_equal(bits(dist[0]), bits(od))
     fc.close()
+
+
+SHADOW_BODY = r'''
+import numpy as np
+from oracle import c_oracle as co
+from tests import datagen as dg
+from vers_amd import capi
+def bits(a): return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+checked = 0
+for n, d, kind in [(40000, 128, "u"), (9000, 300, "c"), (130, 64, "u"), (70000, 48, "ties")]:
+    X = dg.dist_u(0x51AD + n, n, d) if kind != "c" else dg.dist_c(0x51AD + n, n, d, 40, dg.default_sigma(d))
+    if kind == "ties":
+        X[n // 2:] = X[: n - n // 2]          # every row twice: equal distances, the lower index first (utils.rs:77)
+    Q = dg.dist_u(0x0DD + n, 6, d); Q[2] = X[n // 3]
+    fc = capi.FlatCorpus(d); fc.upload(X)
+    for metric in (0, 1):
+        for top_k in (1, 10, 58, 64):         # (64: beyond the shadow path's k + slack <= 64 keys -- the ordered chains)
+            for single_shadow in (1, 0):
+                capi.set_option("single_shadow", single_shadow)
+                for qi in range(6):
+                    oi, od = co.search_exhaustive(X, Q[qi], top_k, metric=metric)
+                    ids, dist, cnt = fc.search(Q[qi], top_k, metric)
+                    assert cnt[0] == len(oi), (n, d, metric, top_k, qi)
+                    assert np.array_equal(ids[0, :len(oi)], oi) and np.array_equal(bits(dist[0, :len(oi)]), bits(od)), (n, d, kind, metric, top_k, single_shadow, qi)
+                    checked += 1
+    capi.set_option("single_shadow", 1)
+    fc.close()
+print("checked", checked)
+'''
+
+
+def _run_shadow_body(env_extra):
+    import os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ); env.update(env_extra)
+    r = subprocess.run([sys.executable, "-c", SHADOW_BODY], capture_output=True, text=True, timeout=1500, cwd=root, env=env)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
+    assert "checked" in r.stdout
+
+
+def test_flat_single_query_on_the_shadow_and_on_the_f32_rows():
+    """one query streams the flat corpus' fp16 shadow (flat1h_kernel + the inverted lists' exact finish) or, with
+    vers_set_option("single_shadow", 0), its f32 rows through the ordered chains: the oracle's bits either way"""
+    _run_shadow_body({})
+
+
+def test_flat_single_query_with_every_certificate_forced_to_fail():
+    _run_shadow_body({"VERS_PRESCAN": "2"})
+
+
+def test_flat_single_query_without_a_shadow():
+    _run_shadow_body({"VERS_SHADOW": "0"})

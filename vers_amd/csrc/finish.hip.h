@@ -38,6 +38,10 @@ struct RescoreArgs {
   uint32_t* out_count;
   uint64_t* out_keys;
   unsigned long long* stamps = nullptr;  // diagnosis (VERS_SCAN_DEBUG & 16): [52..57] cycles of the exact finish's phases, summed over the blocks
+  // the flat index's single query (flat_shadow_search1) has no planning kernel to zero its two per-call words: the finish clears the flag it
+  // read once it is done with it, the fallback launch the count of queued queries it served (both nullable)
+  uint32_t* reset_flag = nullptr;
+  uint32_t* reset_count = nullptr;
 };
 
 // Storage row of the key held by each lane (nprobe mode): seq = position in the query's concatenated probe order,
@@ -374,6 +378,7 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(NW =
     srow[lane] = row;
     if (survivor && row != 0xFFFFFFFFu) rid = a.row_ids[row];  // (the emitted keys' ids: in flight under the chains)
     if (lane == 0) {
+      if (a.reset_flag != nullptr) *a.reset_flag = 0u;  // (read into flag0 at the top; the scan that sets it has finished)
       s_failed = certified ? 0u : 1u;
       s_nsurv = n_surv;
       if (!certified) { a.fail_list[atomicAdd(a.fail_list + gridDim.x, 1u)] = q; atomicAdd(a.stats, 1u); }  // the fallback kernels redo it
@@ -623,6 +628,7 @@ __global__ __launch_bounds__(kWave * kMergeWaves) void fallback_kernel(RescoreAr
     uint32_t* out_ctr = ctr + 2 * gridDim.x;
     if (__hip_atomic_fetch_add(out_ctr, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT) + 1u == gridDim.x) {
       for (uint32_t w = 0; w <= 2 * gridDim.x; ++w) __hip_atomic_store(ctr + w, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (a.reset_count != nullptr) *a.reset_count = 0u;
       if (st_host != nullptr) publish();  // (every block's emits happened before its arrival at the counter)
     }
   }

@@ -5,6 +5,7 @@
 #include <new>
 #include <vector>
 
+#include "flat_shadow.hpp"
 #include "scan.hip.h"
 #include "util.hip.h"
 
@@ -97,6 +98,7 @@ struct vers_flat {
   size_t o_cap = 0;
   hipEvent_t ev0 = nullptr, ev1 = nullptr;
   bool ev_valid = false;
+  FlatShadow shadow;  // fp16 shadow of the rows + what a single query's exact finish needs (flat_shadow.hpp); empty when it did not fit
   std::mutex mu;
 };
 
@@ -149,6 +151,18 @@ int32_t flat_search_dev_locked(vers_flat* h, const float* q_dev, uint64_t ldq, u
     if (int32_t rc = launch_stage_queries(q_dev, ldq, h->d, h->q_stage, ldq_pad, b, (uint32_t)QG, st)) return rc;
     q = h->q_stage;
     ldq_use = ldq_pad;
+  }
+  // A single query streams the fp16 shadow when there is one (round 5: half the bytes; pre-selection, certificate, exact re-score
+  // and -- when the certificate fails -- the exact re-scan, like the inverted lists' single query; same results)
+  if (b == 1 && flat_shadow_usable(h->shadow, h->n, h->ld, top_k)) {
+    if ((reinterpret_cast<uintptr_t>(q) & 15u) != 0) {  // (the kernels read the query 16 bytes at a time)
+      if (int32_t rc = grow(h->q_stage, h->q_stage_cap, (size_t)ldq_pad)) return rc;
+      if (int32_t rc = launch_stage_queries(q_dev, ldq, h->d, h->q_stage, ldq_pad, 1, 1, st)) return rc;
+      q = h->q_stage;
+    }
+    if (int32_t rc = flat_shadow_search1(h->shadow, h->rows, h->n, h->ld, h->n_cu, q, top_k, metric, h->status_dev, out_ids, out_dist, out_count, st, h->ev0, h->ev1)) return rc;
+    h->ev_valid = true;
+    return VERS_OK;
   }
   // one item per resident wave when possible (static balance), at least one 64-row tile each
   const uint32_t target_items = (uint32_t)h->n_cu * scan_blocks_per_cu(QG, h->ld) * kWavesPerBlock;
@@ -236,6 +250,7 @@ int32_t vers_flat_destroy(vers_flat_t* h) {
   DeviceGuard g(h->device);
   (void)hipDeviceSynchronize();
   if (h->rows) (void)hipFree(h->rows);
+  h->shadow.release();
   for (void* p : {(void*)h->q_stage, (void*)h->q_up, (void*)h->zero_q, (void*)h->partials, (void*)h->lower, (void*)h->status_dev, (void*)h->o_ids,
                   (void*)h->o_dist, (void*)h->o_cnt})
     if (p) (void)hipFree(p);
@@ -252,6 +267,7 @@ int32_t vers_flat_upload(vers_flat_t* h, const float* rows, uint64_t n, uint64_t
   std::lock_guard<std::mutex> lk(h->mu);
   DeviceGuard g(h->device);
   h->n = 0;
+  h->shadow.release();
   if (int32_t rc = grow(h->rows, h->rows_cap, (size_t)std::max<uint64_t>(1, blocked_floats(n, h->ld)))) return rc;
   if (n == 0) return VERS_OK;
   float* tmp = nullptr;  // row-major staging, re-laid out on the device
@@ -263,6 +279,7 @@ int32_t vers_flat_upload(vers_flat_t* h, const float* rows, uint64_t n, uint64_t
   (void)hipDeviceSynchronize();
   (void)hipFree(tmp);
   if (!rc) h->n = n;
+  if (!rc) rc = flat_shadow_derive(h->shadow, h->rows, n, h->ld, h->n_cu);
   return rc;
 }
 
@@ -272,11 +289,12 @@ int32_t vers_flat_upload_dev(vers_flat_t* h, const float* rows_dev, uint64_t n, 
   std::lock_guard<std::mutex> lk(h->mu);
   DeviceGuard g(h->device);
   h->n = 0;
+  h->shadow.release();
   if (int32_t rc = grow(h->rows, h->rows_cap, (size_t)std::max<uint64_t>(1, blocked_floats(n, h->ld)))) return rc;
   if (int32_t rc = launch_to_blocked(rows_dev, ld_floats, h->d, n, h->rows, h->ld, nullptr)) return rc;
   VERS_HIP_TRY(hipDeviceSynchronize());
   h->n = n;
-  return VERS_OK;
+  return flat_shadow_derive(h->shadow, h->rows, n, h->ld, h->n_cu);
 }
 
 int32_t vers_flat_search_dev(vers_flat_t* h, const float* queries_dev, uint64_t ldq_floats, uint32_t b, uint32_t top_k,

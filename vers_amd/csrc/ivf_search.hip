@@ -3,8 +3,11 @@
 // engine, scan.hip.h), the per-query merges + id mapping, the exhaustive scan of the stored rows (utils.rs:68-82), the
 // cross-GPU merge of partial results, host-pointer staging, and the search entry points of the C ABI.
 #include <chrono>
+#include <cstring>
+#include <limits>
 
 #include "finish.hip.h"
+#include "flat_shadow.hpp"
 #include "ivf_src.hip.h"
 
 namespace vers {
@@ -138,6 +141,117 @@ __global__ __launch_bounds__(kWave * kS1hWaves) void scan1h_kernel(Scan1hArgs a)
     if (2 * s < kS1hWaves) __syncthreads();
   }
   if (wid == 0 && lane < (int)a.kp) a.partials[(uint64_t)r.out * a.kp + lane] = key;
+}
+
+// ---- the flat index's single query on ITS shadow (round 5; flat_shadow.hpp) -------------------------------------------------------
+// utils::search_exhaustive for one query streams every row: 512 MB at cfg2 (N = 1M, d = 128), 92 us through the ordered chains + 8 us of
+// merge.  With a shadow of the flat corpus the same pre-selection / certificate / exact re-score as above applies, the corpus being ONE
+// list.  Rows are short there (a 64-row tile of the shadow is 16 KB at d = 128, 15.6 k tiles): the grid is persistent -- two blocks of
+// four waves per CU, wave w of W walks tiles w, w + W, ... with its load ring running across tile boundaries -- and every wave keeps
+// ONE sorted list of its k + slack smallest keys: a tile's 64 keys are sorted and merged in only when one of them beats the list's
+// last key.  The block's four lists are folded into its slot; ivf_rescore_kernel<16> reads the 2 x CUs slots as a flat array.
+struct Flat1hArgs {
+  const uint16_t* rows_h; const float* xnorm; const float* qp; uint64_t* partials; uint32_t* qflags;
+  uint32_t ld, kp, metric, n_rows;
+};
+__global__ __launch_bounds__(kWave * kS1hWaves) void flat1h_kernel(Flat1hArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float s1h_lds[];
+  float* const qs = s1h_lds;
+  uint64_t (*sh)[kWave] = reinterpret_cast<uint64_t(*)[kWave]>(s1h_lds + a.ld);
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t n_tiles = (a.n_rows + kWave - 1) / kWave;
+  const uint32_t W = gridDim.x * kS1hWaves, w0 = blockIdx.x * kS1hWaves + (uint32_t)wid;
+  const uint32_t my_tiles = w0 < n_tiles ? (n_tiles - w0 + W - 1) / W : 0u;
+  constexpr int R = 3, kG = 8;
+  const uint32_t n_groups = a.ld / 64u, tile_bytes = a.ld * 128u;
+  const uint32_t n_steps = my_tiles * n_groups;
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)a.rows_h, 0, (int)(n_tiles * tile_bytes), 0x00020000);  // (< 4 GB: flat_shadow_usable)
+  const uint32_t lane_off = (uint32_t)lane * 16u;
+  u32x4 buf[R][kG];
+  uint32_t it = w0, ig = 0;  // the load stream's (tile, group)
+  auto issue = [&](auto btag) {
+    constexpr int B = decltype(btag)::value;
+    const uint32_t off = it * tile_bytes + ig * (kG * 1024u);
+#pragma unroll
+    for (int i = 0; i < kG; ++i) buf[B][i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane_off, off + (uint32_t)i * 1024u, 2);
+    if (++ig == n_groups) { ig = 0; it += W; }
+  };
+  if (n_steps > 0) issue(std::integral_constant<int, 0>{});
+  if (n_steps > 1) issue(std::integral_constant<int, 1>{});
+  const float qscale = a.metric ? -1.0f : -2.0f;
+  for (uint32_t i = threadIdx.x; i < a.ld / 4u; i += kWave * kS1hWaves) {
+    const f32x4 v = reinterpret_cast<const f32x4*>(a.qp)[i];
+    reinterpret_cast<f32x4*>(qs)[i] = qscale * v;
+  }
+  __syncthreads();
+  uint64_t list = kKeyMax;  // the wave's kp smallest keys so far, ascending over the lanes
+  bool bad_any = false;
+  {
+    float acc0 = 0.0f, acc1 = 0.0f;
+    // |x|^2 of the tile in work, requested a tile ahead (loaded where it is used it cost every tile a memory round trip)
+    float xn_cur = my_tiles ? a.xnorm[(uint64_t)w0 * kWave + lane] : 0.0f;
+    const f32x4* const q4 = reinterpret_cast<const f32x4*>(qs) + 2 * (lane >> 5);
+    uint32_t ct = w0, cg = 0;  // the compute stream's (tile, group)
+    auto step = [&](auto btag, uint32_t s) {
+      constexpr int B = decltype(btag)::value;
+      if (s + 2 < n_steps) issue(std::integral_constant<int, (B + 2) % R>{});
+      if (s < n_steps) {
+#pragma unroll
+        for (int c = 0; c < kG / 2; ++c) {
+          const f32x4 qa = q4[(cg * (kG / 2) + c) * 4], qb = q4[(cg * (kG / 2) + c) * 4 + 1];
+          const f16x8_t x0 = __builtin_bit_cast(f16x8_t, buf[B][2 * c]), x1 = __builtin_bit_cast(f16x8_t, buf[B][2 * c + 1]);
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            acc0 = __builtin_fmaf((float)x0[u], qa[u], acc0);
+            acc1 = __builtin_fmaf((float)x1[u], qa[u], acc1);
+          }
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            acc0 = __builtin_fmaf((float)x0[4 + u], qb[u], acc0);
+            acc1 = __builtin_fmaf((float)x1[4 + u], qb[u], acc1);
+          }
+        }
+        if (++cg == n_groups) {  // the tile is complete: a val per lane, folded into the wave's list when any of them can enter it
+          const float t0 = acc0 + __shfl_xor(acc0, 32, kWave), t1 = acc1 + __shfl_xor(acc1, 32, kWave);
+          const float dot = lane < 32 ? t0 : t1;
+          const uint32_t row = ct * kWave + (uint32_t)lane;
+          const float val = a.metric ? dot : xn_cur + dot;  // (the last tile's padding rows exist in xnorm)
+          {
+            const uint32_t nt = ct + W < n_tiles ? ct + W : ct;
+            xn_cur = a.xnorm[(uint64_t)nt * kWave + lane];
+          }
+          const bool live = row < a.n_rows;
+          const bool bad = live && !(__builtin_fabsf(val) < __builtin_inff());
+          bad_any |= bad;
+          uint64_t key = live && !bad ? make_key(val, row) : kKeyMax;
+          const uint64_t last = readlane64(list, (int)a.kp - 1);
+          if (__ballot(key < last) != 0) {  // (wave-uniform)
+            wave_rank_sort64(key, lane);
+            wave_merge_sorted64(list, key, lane);
+          }
+          acc0 = acc1 = 0.0f; cg = 0; ct += W;
+        }
+      }
+    };
+    for (uint32_t s = 0; s < n_steps; s += R) {
+      step(std::integral_constant<int, 0>{}, s);
+      step(std::integral_constant<int, 1>{}, s + 1);
+      step(std::integral_constant<int, 2>{}, s + 2);
+    }
+  }
+  if (__ballot(bad_any) != 0 && lane == 0) a.qflags[0] = 1u;
+  sh[wid][lane] = list;
+  __syncthreads();
+#pragma unroll
+  for (int s = 1; s < kS1hWaves; s <<= 1) {
+    if ((wid & (2 * s - 1)) == 0) {
+      wave_merge_sorted64(list, sh[wid + s][lane], lane);
+      if (2 * s < kS1hWaves && wid != 0) sh[wid][lane] = list;
+    }
+    if (2 * s < kS1hWaves) __syncthreads();
+  }
+  if (wid == 0 && lane < (int)a.kp) a.partials[(uint64_t)blockIdx.x * a.kp + lane] = list;
 }
 
 // final merge + id mapping: one block per query.  Results wider than 64 keys come 64 ranks per pass (ScanParams::lower):
@@ -746,6 +860,118 @@ int32_t host_io_end(vers_ivf* h, const HostIo& io, uint32_t b, uint32_t top_k, u
 }
 
 }  // namespace ivf
+}  // namespace vers
+
+namespace vers {
+
+// ---- the flat index's shadow (flat_shadow.hpp): derive, gate, search ------------------------------------------------------------
+namespace {
+__global__ void flat_row_ids_kernel(uint32_t* ids, uint64_t n, uint64_t n_pad) {
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n_pad) ids[i] = i < n ? (uint32_t)i : 0xFFFFFFFFu;
+}
+constexpr uint32_t kFsTables = 8;  // misc[8 ..]: pj_list | pj_pref | pj_nq | list_off | list_len | qflags | fail_list | fail count
+constexpr uint32_t kFsSlotKeys = 64;
+}  // namespace
+
+void FlatShadow::release() {
+  for (void* p : {(void*)rows_h, (void*)xnorm, (void*)row_ids, (void*)misc, (void*)slots, (void*)fb_part, (void*)fb_ctr})
+    if (p) (void)hipFree(p);
+  if (bytes) dev_mem_account(-(int64_t)bytes);
+  *this = FlatShadow();
+}
+
+int32_t flat_shadow_derive(FlatShadow& s, const float* rows_blocked, uint64_t n, uint32_t ld, int n_cu) {
+  s.release();
+  if (n == 0 || shadow_mode() == 0) return VERS_OK;
+  const uint64_t n_pad = (n + 63) / 64 * 64;
+  const size_t b_rows = n_pad * (size_t)ld * sizeof(uint16_t), b_norm = n_pad * sizeof(float), b_ids = n_pad * sizeof(uint32_t);
+  if (b_rows >= (size_t(1) << 32)) return VERS_OK;  // (flat1h_kernel addresses the shadow through one buffer descriptor)
+  s.n_slots = 2u * (uint32_t)n_cu;
+  const uint32_t fb_blocks = kFallbackBlocks;
+  const size_t b_slots = (size_t)s.n_slots * kFsSlotKeys * sizeof(uint64_t), b_fb = fallback_part_keys(fb_blocks, 1, kMaxTopK) * sizeof(uint64_t),
+               b_ctr = (2 * kFallbackBlocks + 1) * sizeof(uint32_t);
+  // optional memory: without it the f32 ordered-chain scan stays in charge
+  size_t free_b = 0, total_b = 0;
+  (void)hipMemGetInfo(&free_b, &total_b);
+  const size_t need = b_rows + b_norm + b_ids + b_slots + b_fb + b_ctr + 256;
+  bool ok = need + (size_t(1) << 30) <= free_b;
+  ok = ok && hipMalloc((void**)&s.rows_h, b_rows) == hipSuccess && hipMalloc((void**)&s.xnorm, b_norm) == hipSuccess &&
+       hipMalloc((void**)&s.row_ids, b_ids) == hipSuccess && hipMalloc((void**)&s.misc, 256) == hipSuccess &&
+       hipMalloc((void**)&s.slots, b_slots) == hipSuccess && hipMalloc((void**)&s.fb_part, b_fb) == hipSuccess &&
+       hipMalloc((void**)&s.fb_ctr, b_ctr) == hipSuccess;
+  if (!ok) {
+    (void)hipGetLastError();
+    s.release();
+    return VERS_OK;
+  }
+  s.bytes = need - 256 + 256;
+  dev_mem_account((int64_t)s.bytes);
+  uint32_t host_misc[64] = {};
+  host_misc[kFsTables + 2] = s.n_slots;  // pj_nq: every slot is written by every search
+  host_misc[kFsTables + 4] = (uint32_t)n;  // list_len
+  VERS_HIP_TRY(hipMemcpy(s.misc, host_misc, sizeof(host_misc), hipMemcpyHostToDevice));
+  VERS_HIP_TRY(hipMemset(s.fb_ctr, 0, b_ctr));
+  VERS_HIP_TRY(hipMemset(s.slots, 0xFF, b_slots));
+  hipLaunchKernelGGL(flat_row_ids_kernel, dim3((unsigned)((n_pad + 255) / 256)), dim3(256), 0, 0, s.row_ids, n, n_pad);
+  const uint64_t work = n_pad * (ld / 8);
+  hipLaunchKernelGGL(rows_to_f16_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, 0, rows_blocked, ld, (uint64_t)0, n_pad, s.rows_h);
+  hipLaunchKernelGGL(shadow_residual_kernel, dim3((unsigned)((n_pad + 255) / 256)), dim3(256), 0, 0, rows_blocked, ld, (const uint32_t*)s.row_ids, (uint64_t)0, n_pad, s.misc + 2);
+  hipLaunchKernelGGL(blocked_row_norms_kernel, dim3((unsigned)((n_pad + 255) / 256)), dim3(256), 0, 0, rows_blocked, ld, (const uint32_t*)s.row_ids, (uint64_t)0, n_pad, s.xnorm, s.misc);
+  VERS_HIP_TRY(hipGetLastError());
+  VERS_HIP_TRY(hipDeviceSynchronize());
+  uint32_t r2 = 0;
+  VERS_HIP_TRY(hipMemcpy(&r2, s.misc + 2, sizeof(r2), hipMemcpyDeviceToHost));
+  float r2f;
+  std::memcpy(&r2f, &r2, sizeof(r2f));
+  if (!(r2f < std::numeric_limits<float>::infinity())) {  // an element overflows fp16: no certificate would hold
+    s.release();
+    return VERS_OK;
+  }
+  s.rows_built = n;
+  return VERS_OK;
+}
+
+bool flat_shadow_usable(const FlatShadow& s, uint64_t n, uint32_t ld, uint32_t top_k) {
+  return s.rows_built == n && n != 0 && s.rows_h != nullptr && shadow_mode() != 0 && single_shadow_ref().load(std::memory_order_relaxed) != 0 &&
+         knobs().pre_mode != 0 && top_k >= 1 && top_k + 6 <= kPreMaxKp && scan1h_lds_bytes(ld) <= 64u * 1024u;
+}
+
+int32_t flat_shadow_search1(FlatShadow& s, const float* rows_blocked, uint64_t n, uint32_t ld, int n_cu, const float* q_padded, uint32_t top_k,
+                            uint32_t metric, uint32_t* status, uint64_t* out_ids, float* out_dist, uint32_t* out_count, hipStream_t st,
+                            hipEvent_t ev0, hipEvent_t ev1) {
+  const uint32_t kp = std::min<uint32_t>(kPreMaxKp, top_k + std::max<uint32_t>(24, top_k));  // (the inverted lists' slack on the shadow: ivf_plan.hip)
+  uint32_t* const tb = s.misc + kFsTables;
+  const uint32_t n_tiles = (uint32_t)((n + 63) / 64);
+  const uint32_t blocks = std::min<uint32_t>(s.n_slots, (n_tiles + kS1hWaves - 1) / kS1hWaves);
+  Flat1hArgs fa;
+  fa.rows_h = s.rows_h; fa.xnorm = s.xnorm; fa.qp = q_padded; fa.partials = s.slots; fa.qflags = tb + 5; fa.ld = ld; fa.kp = kp; fa.metric = metric; fa.n_rows = (uint32_t)n;
+  const size_t lds = scan1h_lds_bytes(ld);
+  if (int32_t rc = scan_prepare_launch(flat1h_kernel, lds)) return rc;
+  if (blocks < s.n_slots)  // (a small corpus: the slots no block writes must read as empty; kp may differ from the last call's)
+    VERS_HIP_TRY(hipMemsetAsync(s.slots, 0xFF, (size_t)s.n_slots * kFsSlotKeys * sizeof(uint64_t), st));
+  if (ev0) VERS_HIP_TRY(hipEventRecord(ev0, st));
+  hipLaunchKernelGGL(flat1h_kernel, dim3(blocks), dim3(kWave * kS1hWaves), lds, st, fa);
+  VERS_HIP_TRY(hipGetLastError());
+  if (ev1) VERS_HIP_TRY(hipEventRecord(ev1, st));
+  RescoreArgs a;
+  a.partials = s.slots; a.P = 1; a.S_max = s.n_slots; a.kp = kp; a.top_k = top_k; a.d_pad = ld;
+  a.pj_list = tb + 0; a.pj_pref = tb + 1; a.pj_nq = tb + 2; a.list_off = tb + 3; a.row_ids = s.row_ids;
+  a.rows = rows_blocked; a.rows_rm = nullptr; a.ld = ld; a.qp = q_padded; a.ldq = ld; a.xmax2_bits = s.misc;
+  a.qflags = tb + 5; a.metric = (int)metric; a.force_fail = knobs().pre_mode == 2; a.shadow = 1; a.debug = 0; a.fail_list = tb + 6; a.stats = s.misc + 1;
+  a.status = status; a.out_ids = out_ids; a.out_dist = out_dist; a.out_count = out_count; a.out_keys = nullptr; a.stamps = nullptr;
+  a.reset_flag = tb + 5; a.reset_count = tb + 7;
+  const int stage_rows = rescore_lds_bytes(ld, true, kRescoreWaves1) <= 144u * 1024u ? 1 : 0;
+  const size_t rs_lds = rescore_lds_bytes(ld, stage_rows != 0, kRescoreWaves1);
+  if (int32_t rc = scan_prepare_launch(ivf_rescore_kernel<kRescoreWaves1>, rs_lds)) return rc;
+  hipLaunchKernelGGL(ivf_rescore_kernel<kRescoreWaves1>, dim3(1), dim3(kWave * kRescoreWaves1), rs_lds, st, a, stage_rows);
+  VERS_HIP_TRY(hipGetLastError());
+  hipLaunchKernelGGL(fallback_kernel, dim3(kFallbackBlocks), dim3(kWave * kMergeWaves), 0, st, a, (const uint32_t*)(tb + 4), (const uint32_t*)(tb + 6),
+                     (const uint32_t*)(tb + 7), s.fb_part, s.fb_ctr, (uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr);
+  VERS_HIP_TRY(hipGetLastError());
+  return VERS_OK;
+}
+
 }  // namespace vers
 
 extern "C" {
