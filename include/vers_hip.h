@@ -63,7 +63,10 @@ typedef struct vers_flat vers_flat_t;
 
 int32_t vers_flat_create(int32_t device, uint32_t d, vers_flat_t** out);
 int32_t vers_flat_destroy(vers_flat_t* h);
-/* Copies n rows (pitch row_stride_bytes >= 4*d) into HBM; position = vec_id. */
+/* Copies n rows (pitch row_stride_bytes >= 4*d) into HBM; position = vec_id.  With vers_set_option("shadow", 1) (default) the
+ * handle also keeps an fp16 shadow of the rows (+ 2 d + 8 bytes per row, optional memory: dropped when it does not fit): a single
+ * query (b == 1, top_k <= 58) then streams the shadow -- half the bytes -- and is finished exactly (pre-selection, certificate,
+ * exact re-score; exact re-scan when the certificate fails); vers_set_option("single_shadow", 0) keeps the f32 scan.  Same results. */
 int32_t vers_flat_upload(vers_flat_t* h, const float* rows, uint64_t n, uint64_t row_stride_bytes);
 /* Same from rows already in HBM (row-major, pitch ld_floats >= d).  The handle keeps its own
  * copy in the scan layout (lane-transposed 64-row tiles); the caller's buffer can be freed. */
