@@ -42,6 +42,11 @@ struct RescoreArgs {
   // read once it is done with it, the fallback launch the count of queued queries it served (both nullable)
   uint32_t* reset_flag = nullptr;
   uint32_t* reset_count = nullptr;
+  // host-pointer single-query call (vers_ivf_search, b == 1, on the shadow): the finish itself stores the stream's status word into the pinned
+  // result block behind its results when the certificate held -- the host, spinning on that word, does not wait for the fallback launch that
+  // follows and finds nothing to do (3.5-4 us); when the certificate failed the fallback launch publishes, after its re-scan
+  const uint32_t* st_word = nullptr;
+  uint32_t* st_host = nullptr;
 };
 
 // Storage row of the key held by each lane (nprobe mode): seq = position in the query's concatenated probe order,
@@ -497,6 +502,10 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(NW =
   }
   const uint64_t hm = __ballot(have);
   if (lane == 0) a.out_count[q] = (uint32_t)__popcll(hm);
+  if (a.st_host != nullptr) {  // (wave 0: everything it wrote above before the status word, at system scope)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    if (lane == 0) __hip_atomic_store(a.st_host, __hip_atomic_load(a.st_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
   if (a.stamps && lane == 0) {
     stamp(4);
     for (int i = 0; i < 4; ++i) atomicAdd(a.stamps + 52 + i, ts[i + 1] - ts[i]);
@@ -539,16 +548,13 @@ __global__ __launch_bounds__(kWave * kMergeWaves) void fallback_kernel(RescoreAr
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const uint32_t n_fail = *fail_count;
-  // st_host (host-pointer single-query call on the fp16 shadow: this is the call's last launch): the stream's status word goes out to the
-  // pinned result block LAST, at system scope -- the host spins on it (host_io_end); the finish's results were written by an earlier launch
+  // st_host (host-pointer single-query call on the fp16 shadow whose certificate FAILED): the stream's status word goes out to the pinned
+  // result block LAST, at system scope, behind the re-scan's results -- the host spins on it (host_io_end)
   auto publish = [&]() {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
     __hip_atomic_store(st_host, __hip_atomic_load(st_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   };
-  if (n_fail == 0) {
-    if (st_host != nullptr && blockIdx.x == 0 && threadIdx.x == 0) publish();
-    return;
-  }
+  if (n_fail == 0) return;  // (a host-pointer single-query call's status word was published by the finish: RescoreArgs::st_host)
   // `watch` (nullable): pinned host word the host polls to retire an fp16 shadow that fails too often; a.stats[0] is final
   // for this batch (ivf_rescore_kernel, which counts, is done) and only moves when queries were queued
   if (watch != nullptr && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(watch, a.stats[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);

@@ -640,6 +640,7 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
     a.qflags = qflags; a.metric = h->metric; a.force_fail = pre_mode == 2; a.shadow = use_shadow ? (hi_only ? 2 : 1) : 0; a.debug = scan_debug_flags(); a.fail_list = fail_list; a.stats = h->pre_misc.as<uint32_t>() + 1;  // (shadow: scan1h_kernel multiplies by the f32 query itself -- no split remainder to charge: 1 covers it)
     a.status = W->st_word(); a.out_ids = out_ids; a.out_dist = out_dist; a.out_count = out_count; a.out_keys = out_keys;
     a.stamps = (scan_debug_flags() & 16u) && W->stamps.p ? W->stamps.as<unsigned long long>() : nullptr;
+    if (W->st_host) { a.st_word = W->st_word(); a.st_host = W->st_host; }  // (host-pointer single-query call: the finish publishes when it certifies)
     const int rs_waves = one1_pre ? kRescoreWaves1 : kRescoreWaves;  // (one query: sixteen waves merge its ~250 slots and walk its survivors' chains in one pass)
     const int stage_rows = rescore_lds_bytes(h->ld, true, rs_waves) <= 144u * 1024u ? 1 : 0;
     const size_t rs_lds = rescore_lds_bytes(h->ld, stage_rows != 0, rs_waves);
