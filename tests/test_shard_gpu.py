@@ -147,3 +147,49 @@ def test_upload_dev_reshards_one_built_index_from_device_fields():
     with pytest.raises(capi.VersError):
         ix.upload_dev(Xd.data_ptr(), n, ld, Cd.data_ptr(), k, d, Ad.data_ptr())
     ix.close(); whole.close()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_single_queries_and_tiny_batches(world):
+    """b = 1 (the single query's own kernels: on the fp16 shadow since round 5, a rank scanning only ITS lists' records -- none
+    at all when it owns nothing the query probes) and b = 2, 3 (consecutive single queries) through the partial search of every
+    rank + the cross-rank merge, with both single-query scans: the unsharded index's results bit for bit."""
+    import torch
+    n, d, k = 4000, 72, 32
+    X = dg.dist_c(0x71, n, d, 40, dg.default_sigma(d))
+    whole = IVFFlatIndex.build_index(k, 1, 4, X, init_indices=mg.init_draws(6, 1, k, n))
+    Xd = torch.from_numpy(X).cuda()
+    Cd = torch.from_numpy(np.ascontiguousarray(whole.centroids)).cuda()
+    Ad = torch.from_numpy(whole.assignments.astype(np.int64)).cuda()
+    shards = []
+    for r in range(world):
+        ix = IVFFlatIndex(d); ix.set_shard(r, world)
+        ix.upload_dev(Xd.data_ptr(), n, d, Cd.data_ptr(), k, d, Ad.data_ptr())
+        shards.append(ix)
+    Q = dg.dist_c(0x72, 9, d, 40, dg.default_sigma(d)); Q[4] = X[123]
+    Qd = torch.from_numpy(Q).cuda()
+    try:
+        for single_shadow in (1, 0):
+            capi.set_option("single_shadow", single_shadow)
+            for b in (1, 2, 3):
+                for nprobe, top_k in [(1, 10), (3, 1), (8, 10), (32, 30), (0, 10)]:
+                    for q0 in (0, 3, 6):
+                        keys = torch.empty(world, b, top_k, dtype=torch.int64, device="cuda")
+                        ids = torch.empty(world, b, top_k, dtype=torch.int64, device="cuda")
+                        for r, ix in enumerate(shards):
+                            ix.search_partial_dev(Qd[q0:].data_ptr(), d, b, top_k, nprobe, keys[r].data_ptr(), ids[r].data_ptr())
+                            ix.poll()
+                        oi = torch.zeros(b, top_k, dtype=torch.int64, device="cuda"); od = torch.zeros(b, top_k, dtype=torch.float32, device="cuda")
+                        oc = torch.zeros(b, dtype=torch.int32, device="cuda")
+                        IVFFlatIndex.merge_partials_dev(keys.data_ptr(), ids.data_ptr(), b * top_k, world, b, top_k, nprobe, oi.data_ptr(), od.data_ptr(), oc.data_ptr())
+                        torch.cuda.synchronize()
+                        wi, wd, wc = whole.search_batch(Q[q0:q0 + b], top_k, nprobe)
+                        assert np.array_equal(oc.cpu().numpy(), wc), (single_shadow, b, nprobe, top_k, q0)
+                        for q in range(b):
+                            c = int(wc[q])
+                            assert np.array_equal(oi.cpu().numpy().astype(np.uint64)[q, :c], wi[q, :c]) and np.array_equal(bits(od.cpu().numpy()[q, :c]), bits(wd[q, :c])), (single_shadow, b, nprobe, top_k, q0, q)
+    finally:
+        capi.set_option("single_shadow", 1)
+        for ix in shards:
+            ix.close()
+        whole.close()
