@@ -37,6 +37,103 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void scan1_kernel(Scan1Args
   if (__ballot(nan_seen) != 0 && lane == 0) atomicOr(p.status, 1u);
 }
 
+// ---- single query, f32 rows, a tile per BLOCK (round 5) ---------------------------------------------------------------------------
+// scan1_kernel gives a 64-row tile to ONE wave, which walks its 192 KiB (d = 768) with 24 KiB in flight: eight dependent round trips.
+// That is what bounds the reference's own mode (nprobe = 0: the nearest list -- 38 tiles at cfg3 -- and whatever spills): 23.4 us of a
+// 52 us call for 7.5 MB.  Here a tile belongs to a block of 16 waves, exactly as in coarse1_kernel (ivf_plan.hip): wave w loads chunk
+// w of every phase of 16 chunks -- the whole tile is in flight at once --, computes its rows' PRODUCTS (x - q)^2 (or x * q), which do
+// not depend on the running sum, into LDS; wave 0 walks the strictly ordered chain acc = acc + m_j over them: the same operations
+// on the same operands in the same order as scan_item's chain (base.rs:119-126).  Same slots, same merge kernel behind it.
+// Blocks stride over the item records (a record = one tile here: plan1_block cuts single queries' lists into 64-row segments).
+constexpr int kT1Waves = 16;  // chunks of a phase = waves of the block
+constexpr size_t kT1LdsBytes = (size_t)kT1Waves * kLoads * kWave * sizeof(f32x4);  // 128 KiB of products
+template <int METRIC>
+__global__ __launch_bounds__(kWave * kT1Waves) void scan1t_kernel(Scan1Args a, ScanParams p) {
+  extern __shared__ __attribute__((aligned(16))) f32x4 t1_prod[];  // [chunk of the phase][load][lane]
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const uint32_t n_items = *a.n_items_dev;
+  const uint32_t tile_bytes = p.ld * 256u;
+  const uint32_t lane_off = (uint32_t)lane * 16u;
+  for (uint32_t it = blockIdx.x; it < n_items; it += gridDim.x) {  // (block-uniform)
+    const Item1Rec r = a.recs[it];
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(a.rows + (uint64_t)r.row0 * p.ld), 0, (int)tile_bytes, 0x00020000);
+    // (chunks past the end of the tile are out of the descriptor's range: they load zeros and are never used)
+    auto issue = [&](u32x4 (&b)[kLoads], uint32_t ch) {
+#pragma unroll
+      for (int i = 0; i < kLoads; ++i) b[i] = __builtin_amdgcn_raw_buffer_load_b128(rsrc, lane_off, ch * (kLoads * 1024u) + (uint32_t)i * 1024u, 2);
+    };
+    auto products = [&](const u32x4 (&b)[kLoads], uint32_t ch) {
+      cfloat_as4* qs = (cfloat_as4*)(a.qp + ch * kChunk);
+#pragma unroll
+      for (int i = 0; i < kLoads; ++i) {
+        f32x4 m;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const float xv = __uint_as_float(b[i][u]);
+          const float sv = qs[i * 4 + u];
+          if (METRIC == 0) {
+            const float t = __fsub_rn(xv, sv);
+            m[u] = __fmul_rn(t, t);
+          } else {
+            m[u] = __fmul_rn(xv, sv);
+          }
+        }
+        t1_prod[(wid * kLoads + i) * kWave + lane] = m;
+      }
+    };
+    u32x4 bufA[kLoads], bufB[kLoads];
+    float acc = 0.0f;
+    auto phase = [&](const u32x4 (&cur)[kLoads], u32x4 (&nxt)[kLoads], uint32_t c0) {
+      issue(nxt, c0 + kT1Waves + (uint32_t)wid);  // the next phase's chunk: in flight under this phase's chain
+      if (c0 + (uint32_t)wid < p.n_chunks) products(cur, c0 + (uint32_t)wid);
+      __syncthreads();
+      if (wid == 0) {
+        const uint32_t nch = p.n_chunks - c0 < (uint32_t)kT1Waves ? p.n_chunks - c0 : (uint32_t)kT1Waves;
+        auto ld = [&](f32x4 (&m)[kLoads], uint32_t s) {
+#pragma unroll
+          for (int i = 0; i < kLoads; ++i) m[i] = t1_prod[(s * kLoads + i) * kWave + lane];
+        };
+        auto add = [&](const f32x4 (&m)[kLoads]) {
+#pragma unroll
+          for (int i = 0; i < kLoads; ++i)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) acc = __fadd_rn(acc, m[i][u]);
+        };
+        f32x4 mA[kLoads], mB[kLoads];
+        const uint32_t last = nch - 1;
+        ld(mA, 0);
+        for (uint32_t s = 0; s < nch; s += 2) {
+          ld(mB, s + 1 < nch ? s + 1 : last);
+          add(mA);
+          if (s + 1 < nch) {
+            ld(mA, s + 2 < nch ? s + 2 : last);
+            add(mB);
+          }
+        }
+      }
+      __syncthreads();
+    };
+    issue(bufA, (uint32_t)wid);
+    for (uint32_t c0 = 0; c0 < p.n_chunks; c0 += 2 * kT1Waves) {
+      phase(bufA, bufB, c0);
+      if (c0 + kT1Waves < p.n_chunks) phase(bufB, bufA, c0 + kT1Waves);
+    }
+    if (wid == 0) {
+      const bool valid = (uint32_t)lane < r.nrows;
+      const float dist = METRIC == 0 ? acc : __fsub_rn(1.0f, acc);
+      if (__ballot(valid && dist != dist) != 0 && lane == 0) atomicOr(p.status, 1u);
+      uint64_t key = valid ? make_key(dist, r.seq0 + (uint32_t)lane) : kKeyMax;
+      if (p.lower != nullptr) {  // (wider results than 64 keys come 64 ranks per pass: keys ranked in an earlier pass are dropped)
+        const uint64_t lw = p.lower[a.bound_per_pair ? r.out / a.S_max : 0u];
+        if (key <= lw) key = kKeyMax;
+      }
+      wave_rank_sort64(key, lane);  // (unique: they carry their sequence number)
+      if (lane < (int)a.k_keep) a.partials[(uint64_t)r.out * a.k_keep + lane] = key;
+    }
+  }
+}
+
 // ---- single query on the fp16 shadow (round 5) ---------------------------------------------------------------------------------
 // The ordered-chain scan above streams a query's probed lists as f32 rows: 288 MB at cfg3, 56 us of a 90 us call.  This one streams
 // the SHADOW (half the bytes) and does what the batched path does (prescan.hip.h): val = |x|^2 + <x~, q'> (q' = -2 q; cosine: -<x~, q>)
@@ -484,9 +581,19 @@ int32_t launch_scan1(vers_ivf* h, const Scan1Args& a, uint32_t items_bound, hipS
   if (blocks == 0) blocks = 1;
   const bool no_ev = !W->ev_on;
   const uint32_t slot = (uint32_t)(W->ev_count % SearchWs::kEvRing);
-  if (!no_ev) VERS_HIP_TRY(hipEventRecord(W->ev0[slot], st));
-  if (h->metric) hipLaunchKernelGGL(scan1_kernel<1>, dim3(blocks), dim3(kWave * kWavesPerBlock), 0, st, a, p);
-  else hipLaunchKernelGGL(scan1_kernel<0>, dim3(blocks), dim3(kWave * kWavesPerBlock), 0, st, a, p);
+  // a tile per block of 16 waves (scan1t_kernel: the whole tile in flight at once) instead of a tile per wave; VERS_SCAN1T=0: the latter
+  static const bool t1_on = [] { const char* e = getenv("VERS_SCAN1T"); return !e || atoi(e) != 0; }();
+  if (t1_on && knobs().seg_rows <= 0) {  // (a record is ONE tile unless the tuning knob cut the lists differently)
+    if (int32_t rc = h->metric ? scan_prepare_launch(scan1t_kernel<1>, kT1LdsBytes) : scan_prepare_launch(scan1t_kernel<0>, kT1LdsBytes)) return rc;
+    const uint32_t t_blocks = std::max<uint32_t>(1u, std::min<uint32_t>(items_bound, (uint32_t)h->n_cu));
+    if (!no_ev) VERS_HIP_TRY(hipEventRecord(W->ev0[slot], st));
+    if (h->metric) hipLaunchKernelGGL(scan1t_kernel<1>, dim3(t_blocks), dim3(kWave * kT1Waves), kT1LdsBytes, st, a, p);
+    else hipLaunchKernelGGL(scan1t_kernel<0>, dim3(t_blocks), dim3(kWave * kT1Waves), kT1LdsBytes, st, a, p);
+  } else {
+    if (!no_ev) VERS_HIP_TRY(hipEventRecord(W->ev0[slot], st));
+    if (h->metric) hipLaunchKernelGGL(scan1_kernel<1>, dim3(blocks), dim3(kWave * kWavesPerBlock), 0, st, a, p);
+    else hipLaunchKernelGGL(scan1_kernel<0>, dim3(blocks), dim3(kWave * kWavesPerBlock), 0, st, a, p);
+  }
   VERS_HIP_TRY(hipGetLastError());
   if (!no_ev) {
     VERS_HIP_TRY(hipEventRecord(W->ev1[slot], st));
