@@ -564,7 +564,7 @@ int32_t launch_ivf_scan(vers_ivf* h, const IvfSrc<QG>& src, uint32_t items_bound
 }
 
 // a single query's list scan over item records (scan1_kernel); timed through the same event ring
-int32_t launch_scan1(vers_ivf* h, const Scan1Args& a, uint32_t items_bound, hipStream_t st, const uint64_t* lower) {
+int32_t launch_scan1(vers_ivf* h, const Scan1Args& a, uint32_t items_bound, hipStream_t st, const uint64_t* lower, bool few_tiles) {
   ScanParams p;
   p.ld = h->ld;
   p.n_chunks = h->ld / kChunk;
@@ -583,7 +583,9 @@ int32_t launch_scan1(vers_ivf* h, const Scan1Args& a, uint32_t items_bound, hipS
   const uint32_t slot = (uint32_t)(W->ev_count % SearchWs::kEvRing);
   // a tile per block of 16 waves (scan1t_kernel: the whole tile in flight at once) instead of a tile per wave; VERS_SCAN1T=0: the latter
   static const bool t1_on = [] { const char* e = getenv("VERS_SCAN1T"); return !e || atoi(e) != 0; }();
-  if (t1_on && knobs().seg_rows <= 0) {  // (a record is ONE tile unless the tuning knob cut the lists differently)
+  // ... when the query visits few tiles -- the reference's own mode, a few probes --: with a tile per CU and round, 1361 tiles (nprobe = 32 at
+  // cfg3 without a shadow) take 72 us against the tile-per-wave kernel's 58
+  if (t1_on && few_tiles && knobs().seg_rows <= 0) {  // (a record is ONE tile unless the tuning knob cut the lists differently)
     if (int32_t rc = h->metric ? scan_prepare_launch(scan1t_kernel<1>, kT1LdsBytes) : scan_prepare_launch(scan1t_kernel<0>, kT1LdsBytes)) return rc;
     const uint32_t t_blocks = std::max<uint32_t>(1u, std::min<uint32_t>(items_bound, (uint32_t)h->n_cu));
     if (!no_ev) VERS_HIP_TRY(hipEventRecord(W->ev0[slot], st));
@@ -790,7 +792,8 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
       Scan1Args sa;
       sa.rows = h->rows.as<float>(); sa.recs = W->items.as<Item1Rec>(); sa.n_items_dev = &tot->n_items; sa.qp = qp;
       sa.partials = W->partials.as<uint64_t>(); sa.k_keep = k_keep; sa.S_max = S_max; sa.bound_per_pair = ref_mode ? 1u : 0u;
-      rc = launch_scan1(h, sa, (uint32_t)items_bound, st, lower);
+      const bool few_tiles = ref_mode || (uint64_t)P * (h->n_total / std::max<uint32_t>(1, h->k)) / kWave <= 2ull * (uint64_t)h->n_cu;
+      rc = launch_scan1(h, sa, (uint32_t)items_bound, st, lower, few_tiles);
     } else if (QG == 1) {
       IvfSrc<1> src; fill_src(src);
       rc = launch_ivf_scan(h, src, (uint32_t)items_bound, st, lower);
