@@ -1016,7 +1016,7 @@ int32_t flat_shadow_derive(FlatShadow& s, const float* rows_blocked, uint64_t n,
     s.release();
     return VERS_OK;
   }
-  s.bytes = need - 256 + 256;
+  s.bytes = need;
   dev_mem_account((int64_t)s.bytes);
   uint32_t host_misc[64] = {};
   host_misc[kFsTables + 2] = s.n_slots;  // pj_nq: every slot is written by every search
