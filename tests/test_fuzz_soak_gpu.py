@@ -24,7 +24,7 @@ def test_random_configurations_soak():
 
 
 def test_random_single_queries_soak():
-    """scripts/fuzz_single.py: single queries (host-pointer call and device pointers: coarse1_kernel -> scan1_kernel -> merge) against
+    """scripts/fuzz_single.py: single queries (host-pointer call and device pointers: coarse1_kernel -> the single query's list scans, single.hip.h -> merge or exact finish) against
     the same queries in a batch and an oracle sample, random shapes / metrics / modes.  15 s in the suite (≈ 200 configurations,
     40 k single queries); 2,100 configurations / 400,512 single queries clean in the round-3 soak."""
     budget = float(os.environ.get("VERS_FUZZ_SINGLE_SECONDS", "15"))
@@ -32,4 +32,16 @@ def test_random_single_queries_soak():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "fuzz_single.py"), str(budget), seed], capture_output=True, text=True,
                        cwd=ROOT, timeout=budget * 3 + 600)
     assert r.returncode == 0 and "MISMATCH" not in r.stdout + r.stderr, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "random configurations" in r.stdout, r.stdout[-500:]
+
+
+def test_random_flat_queries_soak():
+    """scripts/fuzz_flat.py: the flat index's single queries on its fp16 shadow against the f32 ordered chains and an oracle sample,
+    random corpora (tile remainders, padding columns, ties, both metrics).  10 s in the suite (≈ 300 configurations); 8,664
+    configurations / 112 k queries clean in the round-5 soak."""
+    budget = float(os.environ.get("VERS_FUZZ_FLAT_SECONDS", "10"))
+    seed = os.environ.get("VERS_FUZZ_SEED", "9100")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "scripts", "fuzz_flat.py"), str(budget), seed], capture_output=True, text=True,
+                       cwd=ROOT, timeout=budget * 3 + 600)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "random configurations" in r.stdout, r.stdout[-500:]
