@@ -348,6 +348,16 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
     return VERS_OK;
   }
   if (h->k == 0) return fail(VERS_ERR_INSUFFICIENT, "search on an index without centroids (reference: index out of bounds, ivfflat.rs:169)");
+  // The reference's own mode (nprobe = 0: the nearest list, spilling into the next ones while the result is short, ivfflat.rs:166-195) IS
+  // nprobe = 1 whenever no list is shorter than top_k -- nothing can spill: the nearest list's top_k by (distance, list position) either
+  // way.  The handle knows its shortest list (lists_that_always_suffice; add() only lengthens lists), so a BATCH in that mode takes
+  // the nprobe path: the matrix-core scan of the fp16 shadow + exact finish instead of the ordered chains over the f32 rows (half the
+  // bytes: 1.52 -> 0.7 ms per 1024 queries at cfg3).  Single queries keep the f32 tile-per-block scan (scan1t_kernel: one list is
+  // latency-bound, the exact finish would cost more than it saves).  VERS_REF_AS_NPROBE1=0: the ordered chains (A/B runs).
+  static const bool ref_as_np1 = [] { const char* e = getenv("VERS_REF_AS_NPROBE1"); return !e || atoi(e) != 0; }();
+  if (nprobe == 0 && ref_as_np1 && out_keys == nullptr && h->world == 1 && b >= pre_min_batch_ref().load(std::memory_order_relaxed) && top_k + 6 <= kPreMaxKp &&
+      knobs().pre_mode != 0 && h->lists_that_always_suffice(top_k) == 1)
+    nprobe = 1;
   // Batches below the matrix-core scan's smallest (2 or 3 queries by default) went to one ordered-chain scan of the f32 rows per (query,
   // list) pair: 204 / 272 us at cfg3.  Since round 5 a single query on the shadow is 66 us: such a batch is its queries one after
   // the other on the stream (the per-call tables are reused in stream order, like consecutive calls on one stream).  Same results.
