@@ -1359,12 +1359,13 @@ int32_t vers_ivf_add(vers_ivf_t* h, const float* row, uint64_t* out_cluster, uin
   // (round 5: no allocation and three synchronisations fewer per call -- the row goes through the workspace's upload buffer instead of
   // a buffer allocated and freed per call, the ranked list and the status word come back in ONE copy, the three 4-byte table
   // updates are one small kernel instead of three synchronous copies: 196 -> ~100 us per vector at cfg3's geometry)
-  if (int32_t rc = W->io_q.reserve((size_t)h->d * sizeof(float) + 16)) return rc;
+  const size_t back_off = ((size_t)h->d * sizeof(float) + 7) & ~(size_t)7;
+  if (int32_t rc = W->io_q.reserve(back_off + 16)) return rc;
   VERS_HIP_TRY(hipMemcpyAsync(W->io_q.p, row, (size_t)h->d * sizeof(float), hipMemcpyHostToDevice, nullptr));
   const float* qp = nullptr;
   if (int32_t rc = stage_plain_queries(h, W->io_q.as<float>(), h->d, 1, &qp, nullptr)) return rc;
   if (int32_t rc = coarse(h, qp, 1, 1, nullptr)) return rc;  // first-minimum centroid (ivfflat.rs:201-207)
-  uint64_t* const back = reinterpret_cast<uint64_t*>(W->io_q.as<char>() + (((size_t)h->d * sizeof(float) + 7) & ~(size_t)7));  // [0] ranked list | [1] status word
+  uint64_t* const back = reinterpret_cast<uint64_t*>(W->io_q.as<char>() + back_off);  // [0] ranked list | [1] status word
   hipLaunchKernelGGL(add_fetch_kernel, dim3(1), dim3(1), 0, nullptr, (const uint64_t*)W->probe.p, W->st_word(), back);
   VERS_HIP_TRY(hipGetLastError());
   uint64_t got[2] = {0, 0};
