@@ -1078,6 +1078,26 @@ def main():
             f"(GPU == CPU: {cpu_km['assign_to_clusters']['gpu_matches_cpu']}); update {t_up:.2f} s, cost {t_co:.2f} s for {n_uc} points on 1 core")
         del Xkh
 
+    # ---- Index::add (ivfflat.rs:200-213), one vector per call, host pointer: the LAST thing done to the headline's index ----
+    if rank == 0 and not multi and not args.no_extra:
+        try:
+            import ctypes as C_
+            na = 96
+            Xa = torch.empty(na, d, dtype=torch.float32, device=dev)
+            capi.gen_rows_dev(Xa.data_ptr(), na, d, d, 1, SEED_X + 0xADD, SEED_C, n_modes, sigma)
+            xa = np.ascontiguousarray(Xa.cpu().numpy())
+            c_, v_ = C_.c_uint64(0), C_.c_uint64(0)
+            ta = []
+            for i in range(na):
+                t0 = time.perf_counter()
+                capi.check(capi.lib().vers_ivf_add(index._h, C_.c_void_p(xa[i].ctypes.data), C_.byref(c_), C_.byref(v_)))
+                ta.append(time.perf_counter() - t0)
+            extra["add"] = {"us_per_vector": round(float(np.median(ta[32:])) * 1e6, 1), "vectors": na - 32, "last_vec_id": int(v_.value),
+                            "what": "vers_ivf_add (host pointer): nearest centroid, append to its list (f32 tiles, shadow, row-major copy, |x|^2, tables), consistent on return"}
+            log(f"[bench] add: {extra['add']['us_per_vector']} us per vector")
+        except Exception as e:
+            log(f"[bench] add leg failed: {e!r}")
+
     # ---- cfg4 / cfg5 at ONE RANK'S NOMINAL SIZE on this GPU (scripts/rank_nominal.py; no 8-GPU node has been available in any round):
     # rank 0 of 8 of IVFFlat N=100M (the corpus streamed through vers_kmeans_assign_dev and vers_ivf_upload_begin / _chunk_dev / _end,
     # 12.5M rows kept; the rank's step, its scan's roofline fraction, memory, GPU == CPU bitwise over the rank's sub-index) and one
