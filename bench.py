@@ -589,6 +589,17 @@ def main():
             index.search_dev(Q[(i % (n_batches * B)):].data_ptr(), ld, 1, top_k, 0, ids.data_ptr(), dst.data_ptr(), cnt.data_ptr(), st)
         torch.cuda.synchronize(); e1r = (time.perf_counter() - t0) / n1r
         index.poll(st)
+        # ... and the trait call itself in that mode: vers_ivf_search, host pointers, one query per call (Index::search_approximate)
+        import ctypes as Cr_
+        qhr = np.ascontiguousarray(Q[:n1r, :d].cpu().numpy())
+        hir, hdr, hcr = np.zeros(top_k, dtype=np.uint64), np.zeros(top_k, dtype=np.float32), np.zeros(1, dtype=np.uint32)
+        hcall = []
+        for rep in range(3):
+            t0 = time.perf_counter()
+            for i in range(n1r):
+                capi.lib().vers_ivf_search(index._h, Cr_.c_void_p(qhr[i].ctypes.data), 4 * d, 1, top_k, 0, Cr_.c_void_p(hir.ctypes.data), Cr_.c_void_p(hdr.ctypes.data), Cr_.c_void_p(hcr.ctypes.data))
+            hcall.append((time.perf_counter() - t0) / n1r)
+        e1r_host = float(np.median(hcall))
         # one more batch, kept for the bitwise comparison with vo_search in the CPU leg
         refo = dict(ids=torch.zeros(B, top_k, dtype=torch.int64, device=dev), dst=torch.zeros(B, top_k, device=dev), cnt=torch.zeros(B, dtype=torch.int32, device=dev))
         index.search_dev(Q[(last % n_batches) * B:].data_ptr(), ld, B, top_k, 0, refo["ids"].data_ptr(), refo["dst"].data_ptr(), refo["cnt"].data_ptr(), st)
@@ -596,8 +607,8 @@ def main():
         extra["reference_mode"] = {"workload": "search_approximate exactly as the reference walks it (nprobe = 0: nearest list + spill), same index / batches",
                                    "batch_ms_per_step": round(tr / args.steps * 1e3, 4), "batch_queries_per_sec": round(args.steps * B / tr, 1),
                                    "list_scan_ms": round(float(np.mean(msr)), 4) if len(msr) else None, "steps": args.steps,
-                                   "single_query_end_to_end_us": round(e1r * 1e6, 1)}
-        log(f"[bench] reference mode (nprobe=0): {extra['reference_mode']['batch_queries_per_sec']} q/s in batches of {B}, {e1r * 1e6:.1f} us per single query")
+                                   "single_query_end_to_end_us": round(e1r * 1e6, 1), "single_query_host_call_us": round(e1r_host * 1e6, 1)}
+        log(f"[bench] reference mode (nprobe=0): {extra['reference_mode']['batch_queries_per_sec']} q/s in batches of {B}, {e1r * 1e6:.1f} us per single query resident, {e1r_host * 1e6:.1f} us per host-pointer call")
     if rank == 0 and not multi and not args.no_extra:
         # (a) single query (B = 1): the list-scan kernel alone (HIP events around its launch) over distinct queries, priced
         # on the bytes of the lists each query actually probed; and the pipelined end-to-end time per query
