@@ -529,21 +529,27 @@ struct FbSrc {
 // ONE launch of kFallbackBlocks persistent blocks; exits at once when nothing is queued (the normal case: ~3 us).
 // The blocks split into n_groups groups of G (G = the largest power of two <= blocks / queued queries, at most 64): a group
 // takes every n_groups-th queued query and spreads its P probed lists -- in C = ceil(G / P) chunks of tiles each when the
-// group is larger than P -- over its members; a member's 16 waves share a chunk's tiles (the ring-pipelined single-query
-// item of scan.hip.h) and leave 16 partial lists per chunk in the group's slot.  The member that arrives last (a counter per
+// group is larger than P -- over its members; a member's 8 waves share a chunk's tiles (the ring-pipelined single-query
+// item of scan.hip.h) and leave 8 partial lists per chunk in the group's slot.  The member that arrives last (a counter per
 // group) folds the slot and emits; the others wait for that before the slot is reused for the group's next query.  With at
 // least as many queued queries as blocks G = 1: a block per query, no waiting.  (Round 1 and the first cut of this kernel
 // gave a queued query to ONE block: 32 lists = 240 MB at cfg3 through a single CU, ~6 ms -- a cliff behind every failed
 // certificate.  Spread over 64 CUs it is ~60 us.)  ctr: [2 * groups + 1] words, zero between launches (the last block out
 // clears them).
 constexpr uint32_t kFallbackBlocks = 128;
+#ifndef VERS_FB_WAVES
+#define VERS_FB_WAVES 8  // two waves per SIMD, <= 256 registers: 164, none spilled.  (16 -- the merge kernels' width, rounds 1-5 -- capped the kernel at 128
+                         // registers, 95 of them spilled: with EVERY certificate failing 71.6 vs 53.5 ms per 1024 queries at cfg3, same box; the launch
+                         // that finds nothing queued costs 3.7-4.1 us either way)
+#endif
+constexpr int kFbWaves = VERS_FB_WAVES;
 inline size_t fallback_part_keys(uint32_t blocks, uint32_t P, uint32_t top_k) {  // >= n_groups * P * C chunks for every G
-  return (size_t)blocks * (P > 2 ? P : 2) * kMergeWaves * top_k;
+  return (size_t)blocks * (P > 2 ? P : 2) * kFbWaves * top_k;
 }
-__global__ __launch_bounds__(kWave * kMergeWaves) void fallback_kernel(RescoreArgs a, const uint32_t* list_len, const uint32_t* fail_list,
+__global__ __launch_bounds__(kWave * kFbWaves) void fallback_kernel(RescoreArgs a, const uint32_t* list_len, const uint32_t* fail_list,
                                                                        const uint32_t* fail_count, uint64_t* fb_part, uint32_t* ctr,
                                                                        uint32_t* watch, const uint32_t* st_word = nullptr, uint32_t* st_host = nullptr) {
-  __shared__ uint64_t sh[kMergeWaves][kWave];
+  __shared__ uint64_t sh[kFbWaves][kWave];
   __shared__ uint32_t s_last;
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -567,7 +573,7 @@ __global__ __launch_bounds__(kWave * kMergeWaves) void fallback_kernel(RescoreAr
   p.ld = a.ld; p.n_chunks = a.ld / kChunk; p.k = a.top_k; p.status = a.status; p.bounds = nullptr; p.lower = nullptr; p.debug = 0;
   p.next_quad = nullptr; p.stamps = nullptr;
   bool nan_seen = false;
-  uint64_t* slot = fb_part + (uint64_t)gidx * chunks * kMergeWaves * a.top_k;  // the group's chunks x 16 partial lists
+  uint64_t* slot = fb_part + (uint64_t)gidx * chunks * kFbWaves * a.top_k;  // the group's chunks x 8 partial lists
   uint32_t* arrived = ctr + 2 * gidx;
   uint32_t round = 0;
   if (gidx < n_groups) {
@@ -575,14 +581,14 @@ __global__ __launch_bounds__(kWave * kMergeWaves) void fallback_kernel(RescoreAr
       const uint32_t q = fail_list[i];
       for (uint32_t u = g; u < chunks; u += G) {
         const uint32_t j = u / C, c = u % C;
-        uint64_t* out = slot + ((uint64_t)u * kMergeWaves + wid) * a.top_k;
+        uint64_t* out = slot + ((uint64_t)u * kFbWaves + wid) * a.top_k;
         const uint32_t Lj = a.pj_list[(uint64_t)q * a.P + j];
         uint32_t len = 0, t0 = 0, t1 = 0;
         if (Lj != 0xFFFFFFFFu) {
           len = list_len[Lj];
           const uint32_t n_tiles = (len + kWave - 1) / kWave, per_c = (n_tiles + C - 1) / C;
           const uint32_t c0 = c * per_c < n_tiles ? c * per_c : n_tiles, c1 = c0 + per_c < n_tiles ? c0 + per_c : n_tiles;
-          const uint32_t per = (c1 - c0 + kMergeWaves - 1) / kMergeWaves;
+          const uint32_t per = (c1 - c0 + kFbWaves - 1) / kFbWaves;
           t0 = c0 + (uint32_t)wid * per < c1 ? c0 + (uint32_t)wid * per : c1;
           t1 = t0 + per < c1 ? t0 + per : c1;
         }
@@ -614,8 +620,8 @@ __global__ __launch_bounds__(kWave * kMergeWaves) void fallback_kernel(RescoreAr
         if (fold) __threadfence();  // the other members' lists
       }
       if (fold) {
-        const uint32_t n_keys = chunks * kMergeWaves * a.top_k;
-        const uint64_t list = block_merge_keys(slot, n_keys, a.top_k, sh);
+        const uint32_t n_keys = chunks * kFbWaves * a.top_k;
+        const uint64_t list = block_merge_keys<kFbWaves>(slot, n_keys, a.top_k, sh);
         if (threadIdx.x < kWave)
           emit_topk(list, q, a.top_k, lane, a.pj_list + (uint64_t)q * a.P, a.pj_pref + (uint64_t)q * a.P, a.P, a.list_off, a.row_ids, a.out_ids,
                     a.out_dist, a.out_count, a.out_keys);

@@ -438,7 +438,7 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
       W->evf_valid = true;
       W->evf_slot = (uint32_t)((W->ev_count - 1) % SearchWs::kEvRing);
     }
-    hipLaunchKernelGGL(fallback_kernel, dim3(fb_blocks), dim3(kWave * kMergeWaves), 0, st, a, (const uint32_t*)h->slot_len.as<uint32_t>(),
+    hipLaunchKernelGGL(fallback_kernel, dim3(fb_blocks), dim3(kWave * kFbWaves), 0, st, a, (const uint32_t*)h->slot_len.as<uint32_t>(),
                        (const uint32_t*)fail_list, (const uint32_t*)(fail_list + b), W->fb_part.as<uint64_t>(), W->fb_ctr.as<uint32_t>(),
                        use_shadow ? h->fail_watch : (uint32_t*)nullptr, (const uint32_t*)W->st_word(), W->st_host);  // (st_host: host-pointer single-query call)
     VERS_HIP_TRY(hipGetLastError());
@@ -749,7 +749,7 @@ int32_t flat_shadow_search1(FlatShadow& s, const float* rows_blocked, uint64_t n
   if (int32_t rc = scan_prepare_launch(ivf_rescore_kernel<kRescoreWaves1>, rs_lds)) return rc;
   hipLaunchKernelGGL(ivf_rescore_kernel<kRescoreWaves1>, dim3(1), dim3(kWave * kRescoreWaves1), rs_lds, st, a, stage_rows);
   VERS_HIP_TRY(hipGetLastError());
-  hipLaunchKernelGGL(fallback_kernel, dim3(kFallbackBlocks), dim3(kWave * kMergeWaves), 0, st, a, (const uint32_t*)(tb + 4), (const uint32_t*)(tb + 6),
+  hipLaunchKernelGGL(fallback_kernel, dim3(kFallbackBlocks), dim3(kWave * kFbWaves), 0, st, a, (const uint32_t*)(tb + 4), (const uint32_t*)(tb + 6),
                      (const uint32_t*)(tb + 7), s.fb_part, s.fb_ctr, (uint32_t*)nullptr, (const uint32_t*)nullptr, (uint32_t*)nullptr);
   VERS_HIP_TRY(hipGetLastError());
   return VERS_OK;
