@@ -35,7 +35,9 @@ int32_t vers_rccl_create(const void* id128, uint32_t rank, uint32_t world, int32
 /* The same around a communicator the host already has (`nccl_comm` is an ncclComm_t); it is NOT destroyed with the handle.
  * `device` is range-checked and must be the device the communicator was made on (ncclCommCuDevice). */
 int32_t vers_rccl_adopt(void* nccl_comm, int32_t device, vers_rccl_t** out);
-/* ncclCommDestroy (owned communicators) after the handle's stream has drained; a communicator marked dead is aborted. */
+/* ncclCommDestroy (owned communicators) after the handle's stream has drained.  A communicator marked DEAD (a bounded wait
+ * expired, an exchange failed) is aborted BEFORE the stream is touched -- owned or adopted -- because draining the stream would
+ * wait for an RCCL kernel that spins for a peer that is gone. */
 int32_t vers_rccl_destroy(vers_rccl_t* c);
 /* ncclCommAbort: what the host calls when ANY rank returned non-zero from a sharded build / search (a rank that left early has
  * left its peers inside a collective; the communicator cannot be used again).  The handle stays valid for vers_rccl_destroy;

@@ -256,12 +256,20 @@ int32_t vers_rccl_adopt(void* nccl_comm, int32_t device, vers_rccl_t** out) {
 int32_t vers_rccl_destroy(vers_rccl_t* c) {
   if (!c) return VERS_OK;
   DeviceGuard g(c->device);
+  // A DEAD communicator (a bounded wait expired, an exchange failed) may still have an RCCL kernel on the stream spinning for the
+  // peer that is gone.  hipStreamSynchronize AND hipStreamDestroy both drain the stream's queue on ROCm, i.e. either would wait for
+  // that kernel forever -- the hang the bounded wait exists to avoid.  So the communicator is aborted FIRST (owned or adopted: as
+  // vers_rccl_abort does; an adopted communicator that died must not be used by its maker again either), which ends its kernels;
+  // only then is the stream touched.
+  if (c->dead && c->comm) {
+    (void)ncclCommAbort(c->comm);
+    c->comm = nullptr;
+  }
   if (c->stream) {
-    if (!c->dead) (void)hipStreamSynchronize(c->stream);  // (a dead communicator's stream may hold a kernel that never ends)
+    if (!c->dead) (void)hipStreamSynchronize(c->stream);
     (void)hipStreamDestroy(c->stream);
   }
-  // An owned communicator with exchanges that can still be pending (dead) is aborted, not destroyed: ncclCommDestroy waits for them
-  if (c->owned && c->comm) (void)(c->dead ? ncclCommAbort(c->comm) : ncclCommDestroy(c->comm));
+  if (c->owned && c->comm) (void)ncclCommDestroy(c->comm);
   delete c;
   return VERS_OK;
 }
