@@ -438,8 +438,8 @@ def main():
     # counters itself); used only when it was measured on this exact configuration and kernel.
     kernel_id = ("prescan_kernel_g<true" if shadow else "prescan_kernel_g<false") if mfma_scan else "scan_kernel"
     # (which instantiation ran follows the planner's rule, ivf_plan.hip: 64-query blocks with the query block as fp16 hi only where they
-    # fit LDS -- d <= 960 --, else 32 queries hi + lo up to d = 1152, 32 hi-only up to 2304, 16 hi-only up to 4608; VERS_PRE_WIDE=0: no 64)
-    wide64 = os.environ.get("VERS_PRE_WIDE", "1") != "0" and os.environ.get("VERS_PRE_NARROW", "0") == "0" and ((d + 63) // 64 * 64) * 64 * 2 + 16 + 64 * 64 * 8 + 6 * 64 * 4 <= 160 * 1024
+    # fit LDS -- d <= 960 --, else 32 queries hi + lo up to d = 1152, 32 hi-only up to 2304, 16 hi-only up to 4608; option pre_wide=0: no 64)
+    wide64 = capi.env_option("pre_wide", 1) != 0 and capi.env_option("pre_narrow", 0) == 0 and ((d + 63) // 64 * 64) * 64 * 2 + 16 + 64 * 64 * 8 + 6 * 64 * 4 <= 160 * 1024
     pre_inst = ("prescan_kernel_g<true, 64, IvfSrc<64>, false> (64 queries per block as two sets of 32, query block fp16 hi only" if wide64 else
                 "prescan_kernel_g<true, 32, IvfSrc<32>, true> (32 queries per block, query block fp16 hi + lo" if d <= 1152 else
                 "prescan_kernel_g<true, 32, IvfSrc<32>, false> (32 queries per block, query block fp16 hi only")
@@ -770,7 +770,7 @@ def main():
                     "frac": round(gbs / HBM_PEAK_GBS, 4), "end_to_end_us": round(float(np.median(e2e_reps)) * 1e6, 1),
                     "end_to_end_qps": round(1.0 / float(np.median(e2e_reps)), 1), "end_to_end_us_stretches": [round(x * 1e6, 1) for x in e2e_reps],
                     "host_call_us": round(float(np.median(host_reps)) * 1e6, 1), "host_call_us_stretches": [round(x * 1e6, 1) for x in host_reps]}
-        on_shadow = bool(index.shadow_state()["active"]) and nprobe != 0 and top_k + 6 <= 64 and os.environ.get("VERS_SCAN1H", "1") != "0"
+        on_shadow = bool(index.shadow_state()["active"]) and nprobe != 0 and top_k + 6 <= 64 and capi.env_option("single_shadow", 1) != 0
         try:
             f32_leg = single_leg(False)
             sq = single_leg(True) if on_shadow else dict(f32_leg)
@@ -945,7 +945,7 @@ def main():
                 m_ = float(np.mean(ms_[metric]))
                 leg[name] = {"scan_us": round(m_ * 1e3, 1), "achieved_GBs": round(by / (m_ * 1e-3) / 1e9, 1), "frac": round(by / (m_ * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
             return leg
-        flat_shadow = os.environ.get("VERS_SHADOW", "1") != "0" and os.environ.get("VERS_SCAN1H", "1") != "0" and top_k + 6 <= 64
+        flat_shadow = capi.env_option("shadow", 1) != 0 and capi.env_option("single_shadow", 1) != 0 and top_k + 6 <= 64
         try:
             f32_leg = flat_leg(False)
             sh_leg = flat_leg(True) if flat_shadow else None

@@ -306,28 +306,37 @@ int32_t vers_ivf_build_sharded_dev(vers_ivf_t* h, const float* rows_dev, uint64_
                                    uint64_t max_iterations, const uint64_t* init_indices, const vers_comm_t* comm,
                                    uint64_t* out_assignments_local, float* out_cost, int32_t* out_kept,
                                    uint64_t* out_iterations);
-/* Process-wide tuning switches (the environment variables of DESIGN.md section 5 are read once; this sets one at run time
- * for same-process A/B measurements).  "gemm_x3": bit 0 the k-means assign contraction, bit 1 the coarse quantiser's
- * contraction run as three bf16 MFMA products of hi/lo-split operands (default 3) instead of the f32 MFMA kernel (0).
- * Results are bit-identical either way: both are pre-filters behind an exact re-score and a certificate.
- * "shadow": 1 (default) = indexes built / uploaded from now on keep an fp16 shadow of their rows for the batched list
- * scan (vers_ivf_shadow_state); 0 = none, and searches on existing handles read their f32 rows until it is 1 again.
- * "scan_events": HIP event records around every list-scan launch, the source of vers_ivf_last_scan's / vers_ivf_scan_times'
- * times: 1 always, 0 never, 2 (default; VERS_SCAN_EVENTS) for batches only -- the two records cost a single-query call
- * 5.5-6 us of ~70, so b == 1 calls (and the batches of 2-3 that run as consecutive single queries) are not timed unless asked.
- * "pre_min_batch" (default 4; VERS_PRE_MIN_BATCH): the smallest batch of an nprobe search whose list scan runs on the matrix
- * cores (fp16 shadow, exact finish) even when its lists are shared by fewer than two queries on average; smaller batches
- * run one ordered-chain scan per (query, list) pair.  Same results either way.
- * "single_shadow" (default 1; VERS_SCAN1H): a single query's list scan (b == 1, nprobe >= 1) streams the fp16 shadow -- half the
- * bytes -- and is finished exactly like a batch's (pre-selection, certificate, exact re-score, exact re-scan when the certificate
- * fails); 0 = the ordered-chain scan of the f32 rows of rounds 1-4.  Same results either way.
- * "host_spin" (default 1): a host-pointer single-query call (vers_ivf_search, b == 1: what Index::search_approximate is) waits for
- * its result by spinning on the pinned status word the last launch writes behind the results, for at most 2 ms; 0 = sleep in
- * hipStreamSynchronize as rounds 1-4 did.
- * "scan_reserve_cus" (default -1 = auto: 64 while another batch of the handle is in flight on another stream, else 0;
- * VERS_SCAN_RESERVE_CUS): the persistent matrix-core list scan launches on that many FEWER compute units.  Its blocks hold 448 of a SIMD's 512 registers, so nothing with a large footprint -- RCCL's all-gather kernel
- * (256 VGPRs per wave), another batch's coarse contraction / selection -- runs beside them: with batches in flight on a
- * sharded index the reserved CUs are where those run WHILE a scan streams (the scan is HBM-bound: it loses little). */
+/* Process-wide switches: every one is a named option set here (or, for a process one does not control from inside, through the ONE
+ * environment variable VERS_OPTIONS="name=value,name=value", read once; besides it the library reads only VERS_SHADOW and
+ * VERS_ROWMAJOR, the two memory switches of INTEGRATION.md = options "shadow" / "rowmajor").  Unknown name: VERS_ERR_INVALID.
+ * Results are bit-identical under every setting: the switches choose between exact paths and pre-filters behind exact finishes.
+ *  Memory:
+ *   "shadow" (1)        indexes built / uploaded from now on keep an fp16 shadow of their rows for the list scans
+ *                       (vers_ivf_shadow_state); 0 = none, and searches on existing handles read their f32 rows until it is 1 again.
+ *   "rowmajor" (-1)     the row-major f32 copy the exact finish gathers from: -1 = kept while the rows take <= 1/4 of the device,
+ *                       0 never, 1 always.
+ *  Serving:
+ *   "single_shadow" (1) a single query (b == 1, nprobe >= 1) streams the fp16 shadow and is finished exactly like a batch;
+ *                       0 = the ordered-chain scan of the f32 rows.
+ *   "host_spin" (1)     a host-pointer single-query call waits by spinning on the pinned status word (<= 2 ms); 0 = hipStreamSynchronize.
+ *   "pre_min_batch" (4) the smallest batch whose list scan runs on the matrix cores when its lists are shared by fewer than two
+ *                       queries on average; smaller batches run as consecutive single queries.
+ *   "scan_reserve_cus" (-1 = auto: 64 while another batch of the handle is in flight on another stream, else 0) compute units the
+ *                       persistent matrix-core list scan leaves free for the other batches' latency-bound kernels and the exchange.
+ *   "scan_events" (2)   HIP event records around list-scan launches (vers_ivf_last_scan / vers_ivf_scan_times): 1 always, 0 never,
+ *                       2 for batches only (the two records cost a single-query call 5.5-6 us).
+ *  A/B and forced paths (tests, measurements):
+ *   "gemm_x3" (3)       bit 0 the k-means assign contraction, bit 1 the coarse quantiser's contraction as three bf16 MFMA products of
+ *                       hi/lo-split operands instead of the f32 MFMA kernel.
+ *   "prescan" (1)       0 = ordered chains for batches too, 2 = every list-scan certificate fails (the exact re-scan runs).
+ *   "coarse" (0)        1 = the batched coarse quantiser always exact, 2 = every coarse certificate fails.
+ *   "assign" (0)        k-means assign: 1 = never on the matrix cores, 2 = always (default: from 1e11 flop per pass).
+ *   "pre_narrow" (0), "pre_wide" (1), "pre_hi_only" (0)   the list scan's query-block width (16 / 64 queries) and fp16 hi-only query blocks.
+ *   "coarse1" (1), "scan1t" (1), "ref_as_nprobe1" (1), "assign_tiles" (1), "assign_tiles_min" (64), "seg_rows" (0), "pre_slack" (0),
+ *   "upload_stage_mb" (256)   kernel-choice and sizing knobs of DESIGN.md section 5.
+ *   "scan_debug" (0), "poison_alloc" (-1), "poison_slack_bits" (-1), "test_fail_sharded" (0)   diagnosis: phase stamps / skipped
+ *                       phases, new device buffers filled with a byte, slack rows filled with an f32 bit pattern, the next n sharded
+ *                       searches fail locally. */
 int32_t vers_set_option(const char* name, int64_t value);
 /* Device memory the library holds in this process right now (rows, ids, scratch of every handle) and its high-water
  * mark since the last reset -- lets a test assert that no rank of a sharded build ever allocated the whole corpus. */
@@ -399,35 +408,6 @@ int32_t vers_ivf_prescan_stats(vers_ivf_t* h, uint64_t* out_batches, uint64_t* o
  * scan); skipped when its allocation fails; switched off for the handle when more than 1/8 of the queries failed the
  * certificate (data with many near-ties, or elements outside fp16's range).  out_active: 1 = in use. */
 int32_t vers_ivf_shadow_state(vers_ivf_t* h, int32_t* out_active, uint64_t* out_bytes);
-/* TEST HOOK: overwrites every storage row that holds no vector (slack behind the lists, tile padding: uninitialised
- * device memory in production) with `value` (inf, NaN, 1e30 ...) and rebuilds the derived arrays.  Results and certificate
- * statistics must not depend on what those rows hold (tests/test_prescan_gpu.py). */
-int32_t vers_ivf_test_poison_slack(vers_ivf_t* h, float value);
-/* TEST HOOK: the raw pre-filter values of query q of the most recent batched nprobe search on this handle -- every (row, val)
- * the matrix-core list scan left in its partial lists (up to kp per probed list quad), the row as its vec_id, `val` exactly as
- * the certificate saw it (|x|^2 - 2 <x~, q>, or -<x~, q> for the cosine distance) and the bound the certificate charges that
- * candidate.  The test computes the reference's distance of each row and checks | val + |q|^2 - D_ref | <= bound.
- * out_info[8]: |q|^2, max |x|^2, shadow residual R^2, the bound for rows outside the list, its candidate-independent part,
- * kp, shadow in use, metric.  *out_n = values available (may exceed cap). */
-int32_t vers_ivf_test_last_vals(vers_ivf_t* h, uint32_t q, uint64_t* out_vec_ids, float* out_vals, double* out_bound, uint32_t cap,
-                                uint32_t* out_n, double* out_info8);
-/* TEST HOOK: one wave of the matrix-core instruction a pre-filter uses, accumulated over K exactly as the kernels do, on
- * caller-chosen operands (tests/test_mfma_model_gpu.py measures the accumulation error the certificates' bounds assume).
- * kind 0 v_mfma_f32_32x32x16_f16, 1 v_mfma_f32_32x32x16_bf16 (A, B: 16-bit patterns), 2 v_mfma_f32_32x32x2_f32,
- * 3 v_mfma_f32_16x16x1_4b_f32 (f32).  A [rows][K], B [K][cols] row-major; rows x cols = 32 x 32 (kind 3: 64 x 16); host pointers. */
-int32_t vers_test_mfma(int32_t device, uint32_t kind, const void* A, const void* B, uint32_t K, float* out_C);
-/* MEASUREMENT HOOK: fills *out with an exchange that is a STAND-IN WITH RCCL's FOOTPRINT for one-GPU emulations of a W-GPU
- * search (scripts/emulate_shard.py): all_gather_async launches ONE kernel of `workgroups` blocks x `threads` (256 | 512) threads
- * that hold 256 VGPRs (+ 32 AGPRs at 256 threads) and lds_bytes of LDS -- the resources of RCCL's device kernel on gfx950
- * (profiles/r05_rccl_kernel_meta.txt) --, copy the rank's partial into every rank's slot and stay resident for spin_us.  Not an
- * exchange: results of a sharded search through it are this rank's partial merged with itself. */
-int32_t vers_test_standin_gather(vers_gather_t* out, uint32_t rank, uint32_t world, uint32_t workgroups, uint32_t spin_us,
-                                 uint32_t threads, uint32_t lds_bytes);
-/* TEST HOOK: the wave-level lane networks of the kernels (scan.hip.h) on 128 host keys in[0..127], one wave on `device`:
- * out[64 j + l], j = 0..5 = lane l ^ (1 << j) of in[0..63]; out[384 + l] = lane 63 - l; out[448 ..] = in[0..63] sorted ascending
- * (bitonic network); out[512 ..] = the same by rank counting; out[576 ..] = the 64 smallest of in[0..127], ascending (two sorted
- * halves merged).  640 words out. */
-int32_t vers_test_wave_net(int32_t device, const uint64_t* in, uint64_t* out);
 /* Durations (ms) of the most recent list-scan launches, oldest first (ring of 64); reset != 0
  * empties the ring.  Lets bench.py time every launch of the timed region without stalling it. */
 int32_t vers_ivf_scan_times(vers_ivf_t* h, float* out_ms, uint32_t cap, uint32_t* out_n, int32_t reset);

@@ -48,7 +48,7 @@ for it in range(8):
     fc = corp[it % len(corp)]; run(fc); scan_ms.append(fc.last_scan_ms())
 corp[0].poll(st)
 scan = float(np.median(scan_ms))
-on_shadow = args.b == 1 and args.k + 6 <= 64 and os.environ.get("VERS_SHADOW", "1") != "0" and os.environ.get("VERS_SCAN1H", "1") != "0"
+on_shadow = args.b == 1 and args.k + 6 <= 64 and capi.env_option("shadow", 1) != 0 and capi.env_option("single_shadow", 1) != 0
 bytes_ = args.n * (args.d * 2 + 4) if on_shadow else args.n * args.d * 4   # (the fp16 shadow row + its |x|^2, or the f32 row)
 print("list scan on", "the fp16 shadow (flat1h_kernel)" if on_shadow else "the f32 rows (ordered chains)")
 print(f"n={args.n} d={args.d} b={args.b}: call {tot*1e3:.1f} us/batch  scan kernel {scan*1e3:.1f} us  "

@@ -16,7 +16,7 @@ import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
 from tests import datagen as dg
-from vers_amd import capi
+from vers_amd import capi, testhooks
 from vers_amd.index import IVFFlatIndex
 
 worlds = [int(a) for a in sys.argv[1:]] or [1, 2, 4, 8]
@@ -57,7 +57,7 @@ if EXCHANGE == "rccl1":
 
 def standin(R, W):
     g = rccl.VersGather()
-    capi.check(capi.lib().vers_test_standin_gather(C.cast(C.byref(g), capi._vp), R, W, WG, SPIN_US, SHAPE, 37664 if SHAPE == 512 else 19744))
+    testhooks.standin_gather(g, R, W, WG, SPIN_US, SHAPE, 37664 if SHAPE == 512 else 19744)
     return g
 stream_objs = [torch.cuda.Stream() for _ in range(max_s)]
 out = {"config": dict(rows=n, d=d, nlist=nlist, nprobe=nprobe, batch=B, top_k=top_k, steps=NSTEP, exchange=EXCHANGE,
@@ -93,13 +93,13 @@ for W in worlds:
                     IVFFlatIndex.merge_partials_dev(allp_s[s].data_ptr(), allp_s[s].data_ptr() + 8 * B * top_k, 2 * B * top_k, W, B, top_k, nprobe,
                                                     res_s[s][0].data_ptr(), res_s[s][1].data_ptr(), res_s[s][2].data_ptr(), streams[s])
             for i in range(6): step(i)
-            torch.cuda.synchronize(); _ = ix.scan_times(reset=True) if os.environ.get('VERS_SCAN_EVENTS') != '0' else None; t0 = time.perf_counter()
+            torch.cuda.synchronize(); _ = ix.scan_times(reset=True) if capi.env_option('scan_events', 2) != 0 else None; t0 = time.perf_counter()
             for i in range(NSTEP): step(6 + i)
             torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / NSTEP
             rec[f"step_ms_s{NS}{tag}"] = round(dt * 1e3, 4)
             try:
                 rec[f"scan_us_s{NS}{tag}"] = round(float(np.mean(ix.scan_times())) * 1e3, 1)
-            except Exception:   # (VERS_SCAN_EVENTS=0: no event records around the scans)
+            except Exception:   # (option scan_events=0: no event records around the scans)
                 rec[f"scan_us_s{NS}{tag}"] = float("nan")
             for s_ in streams: ix.poll(s_)
         capi.set_option("scan_reserve_cus", -1)

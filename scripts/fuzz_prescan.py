@@ -53,9 +53,9 @@ while time.time() - t0 < budget:
     # the matrix-core scan on the fp16 shadow rows (the default); every third seed on the f32 rows; against the ordered chains
     # (every fourth seed with the narrow 16-query blocks forced at any d)
     ea = {"VERS_SHADOW": "0"} if seed % 3 == 0 else {}
-    if seed % 4 == 1: ea["VERS_PRE_NARROW"] = "1"
-    if seed % 4 == 3: ea["VERS_PRE_WIDE"] = "0"      # (the 32-query hi + lo blocks of rounds 2-4: what d in (960, 1152] still runs)
-    a = run(seed, ea, "/tmp/fz_a.npz"); bq = run(seed, {"VERS_PRESCAN": "0"}, "/tmp/fz_b.npz")
+    if seed % 4 == 1: ea["VERS_OPTIONS"] = "pre_narrow=1"
+    if seed % 4 == 3: ea["VERS_OPTIONS"] = "pre_wide=0"      # (the 32-query hi + lo blocks of rounds 2-4: what d in (960, 1152] still runs)
+    a = run(seed, ea, "/tmp/fz_a.npz"); bq = run(seed, {"VERS_OPTIONS": "prescan=0"}, "/tmp/fz_b.npz")
     A, B = np.load("/tmp/fz_a.npz"), np.load("/tmp/fz_b.npz")
     same = np.array_equal(A["cnt"], B["cnt"]) and all(  # entries past a query's count are undefined
         np.array_equal(A[k_][q, :A["cnt"][q]], B[k_][q, :A["cnt"][q]]) for k_ in ("ids", "dist") for q in range(A["cnt"].shape[0]))

@@ -34,7 +34,7 @@ def cfg4_rank(dev_index=0, rows=100_000_000, d=768, nlist=16384, rank=0, world=8
               nprobe=32, B=1024, top_k=10, steps=20, check=32, streams=(1, 3), modes_per_list=16, log=print, exchange=True):
     import torch
     from tests import datagen as dg
-    from vers_amd import capi
+    from vers_amd import capi, testhooks
     from vers_amd.index import IVFFlatIndex
     dev = torch.device(f"cuda:{dev_index}")
     ld = (d + 3) // 4 * 4
@@ -125,7 +125,7 @@ def cfg4_rank(dev_index=0, rows=100_000_000, d=768, nlist=16384, rank=0, world=8
     if exchange and world > 1:
         from vers_amd import rccl as vrccl   # (the struct definition only: no RCCL call is made)
         sg = vrccl.VersGather()
-        capi.check(capi.lib().vers_test_standin_gather(C.cast(C.byref(sg), capi._vp), rank, world, 32, 25, 512, 37664))
+        testhooks.standin_gather(sg, rank, world, 32, 25, 512, 37664)
     gp = C.cast(C.byref(sg), capi._vp) if sg is not None else None
     stream_objs = [torch.cuda.Stream(device=dev) for _ in range(max_s)]
     step_ms, scan_us = {}, {}

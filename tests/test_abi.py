@@ -29,6 +29,29 @@ def test_binding_table_matches_header():
     assert sorted(capi.SIGNATURES) == header_functions()
 
 
+def test_product_boundary_carries_no_test_hooks():
+    """The drop-in boundary (include/vers_hip.h, libvers_hip.so) declares and exports nothing named *test*: the test / emulation
+    hooks are a second library (libvers_hip_test.so, include/vers_hip_test.h) that links against the product one."""
+    import subprocess
+    from vers_amd import testhooks
+    assert not [n for n in header_functions() if "test" in n]
+    so = vbuild.build()
+    dyn = subprocess.run(["nm", "-D", "--defined-only", so], capture_output=True, text=True).stdout
+    exported_c = [l.split()[-1] for l in dyn.splitlines() if l.split()[-1].startswith("vers_")]
+    assert exported_c and not [n for n in exported_c if "test" in n], [n for n in exported_c if "test" in n]
+    assert sorted(exported_c) == header_functions(), sorted(set(exported_c) ^ set(header_functions()))   # and nothing undeclared either
+    names = header_functions("vers_hip_test.h")
+    names = [n for n in names if "test" in n]   # (the header includes vers_hip.h's names by reference only in comments)
+    assert sorted(testhooks.SIGNATURES) == names and len(names) == 5
+    tso = vbuild.build_test_hooks()
+    needed = subprocess.run(["readelf", "-d", tso], capture_output=True, text=True).stdout
+    assert "libvers_hip.so" in needed and "$ORIGIN" in needed
+    lib = ctypes.CDLL(vbuild.LIB, mode=ctypes.RTLD_GLOBAL)
+    tlib = ctypes.CDLL(tso)
+    for n in names:
+        assert hasattr(tlib, n) and not hasattr(lib, n), n
+
+
 def test_status_codes_match_header():
     txt = open(os.path.join(ROOT, "include", "vers_hip.h")).read()
     for name, val in [("VERS_OK", capi.OK), ("VERS_ERR_INVALID", capi.ERR_INVALID), ("VERS_ERR_NAN", capi.ERR_NAN),

@@ -79,7 +79,7 @@ def run(env_extra):
 
 
 def test_matrix_core_assign_is_bit_exact():
-    out = run({"VERS_ASSIGN": "2"})
+    out = run({"VERS_OPTIONS": "assign=2"})
     pts, fb = out["PRIM"]
     assert pts == 5000 + 4097 + 777 + 300 + 129 + 9
     assert fb < pts // 2          # ties with a duplicate centroid and near-ties fail the certificate; most points pass
@@ -89,5 +89,5 @@ def test_matrix_core_assign_is_bit_exact():
 
 
 def test_exact_scan_still_available():
-    out = run({"VERS_ASSIGN": "1"})
+    out = run({"VERS_OPTIONS": "assign=1"})
     assert out["PRIM"] == (0, 0) and out["BUILD"] == (0, 0)

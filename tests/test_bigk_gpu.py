@@ -40,6 +40,6 @@ print("bigk ok")
 
 
 def test_build_index_k65536_matches_oracle():
-    env = dict(os.environ); env["VERS_ASSIGN"] = "2"
+    env = dict(os.environ); env["VERS_OPTIONS"] = "assign=2"
     r = subprocess.run([sys.executable, "-c", BODY], capture_output=True, text=True, timeout=1500, cwd=ROOT, env=env)
     assert r.returncode == 0 and "bigk ok" in r.stdout, r.stdout[-2000:] + r.stderr[-3000:]

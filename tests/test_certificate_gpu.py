@@ -13,7 +13,7 @@ import pytest
 from oracle import c_oracle as co
 from tests import datagen as dg
 from tests.golden import make_golden as mg
-from vers_amd import capi
+from vers_amd import capi, testhooks
 from vers_amd.index import IVFFlatIndex
 
 pytestmark = pytest.mark.gpu
@@ -32,7 +32,7 @@ def worst_ratio(ix, X_all, Q, metric, top_k, nprobe, queries):
     ix.search_batch(Q, top_k, nprobe)
     worst, n_vals = 0.0, 0
     for qi in queries:
-        ids, vals, bnd, info = ix.last_vals(qi)
+        ids, vals, bnd, info = testhooks.last_vals(ix, qi)
         assert len(ids) > 0 and info["metric"] == metric
         for vid, v, b in zip(ids, vals, bnd):
             D = d_ref(X_all[int(vid)], Q[qi], metric)
@@ -135,7 +135,7 @@ def test_hi_only_query_block_every_val_inside_its_bound_and_query_residuals_alig
         X = corpus(kind, n, d, 0x920); Q = corpus(kind, b, d, 0x921)
         ix = IVFFlatIndex.build_index(k, 1, 2, X, init_indices=mg.init_draws(0x920, 1, k, n))
         w, nv = worst_ratio(ix, X, Q, 0, top_k, nprobe, range(0, b, 8))
-        assert ix.last_vals(0)[3]["shadow"] == 2, "d = 1536 on the shadow should run hi-only query blocks"
+        assert testhooks.last_vals(ix, 0)[3]["shadow"] == 2, "d = 1536 on the shadow should run hi-only query blocks"
         print(f"hi-only query block, {kind:16s}: worst |val - exact| / bound = {w:.4f} over {nv} dumped vals")
         assert w <= 1.0, (kind, w)
         ix.close()

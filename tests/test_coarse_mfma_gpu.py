@@ -1,6 +1,6 @@
 """Batched coarse quantiser on the f32 matrix cores (csrc/gemm.hip.h): MFMA pre-selection + exact re-score +
 certificate must give the SAME probe lists -- hence bit-identical search results -- as the exact path, and the
-certificate's fallback (forced here through VERS_COARSE=2) must too."""
+certificate's fallback (forced here through the option coarse=2) must too."""
 import os
 import subprocess
 import sys
@@ -56,7 +56,7 @@ def run(env_extra):
     assert r.returncode == 0, r.stdout + r.stderr
     line = [l for l in r.stdout.splitlines() if l.startswith("STATS")][0].split()
     extra = [l for l in r.stdout.splitlines() if l.startswith("EXTRA")][0].split()
-    if env_extra.get("VERS_COARSE") != "1":
+    if env_extra.get("VERS_OPTIONS") != "coarse=1":
         assert int(extra[1]) == 1 and int(extra[2]) == 1   # the uniform corpus and the 5000-centroid index ranked on the matrix cores too
     return int(line[1]), int(line[2])
 
@@ -68,10 +68,10 @@ def test_mfma_preselection_is_exact_and_usually_certified():
 
 
 def test_certificate_fallback_is_exact():
-    batches, fallbacks = run({"VERS_COARSE": "2"})   # error bound forced to +inf: nothing certifies
+    batches, fallbacks = run({"VERS_OPTIONS": "coarse=2"})   # error bound forced to +inf: nothing certifies
     assert batches == 3 and fallbacks == 3 * 150
 
 
 def test_exact_coarse_still_available():
-    batches, _ = run({"VERS_COARSE": "1"})
+    batches, _ = run({"VERS_OPTIONS": "coarse=1"})
     assert batches == 0

@@ -29,7 +29,7 @@ def worker(rank, world, port, force_mfma, ret, shape="small"):
     N, D, K, ATTEMPTS, ITERS = SHAPES[shape]
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     if force_mfma:
-        os.environ["VERS_ASSIGN"] = "2"
+        os.environ["VERS_OPTIONS"] = "assign=2"
     import torch
     import torch.distributed as dist
     dist.init_process_group("gloo", rank=rank, world_size=world)

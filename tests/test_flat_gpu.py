@@ -155,7 +155,7 @@ def test_flat_single_query_on_the_shadow_and_on_the_f32_rows():
 
 
 def test_flat_single_query_with_every_certificate_forced_to_fail():
-    _run_shadow_body({"VERS_PRESCAN": "2"})
+    _run_shadow_body({"VERS_OPTIONS": "prescan=2"})
 
 
 def test_flat_single_query_without_a_shadow():

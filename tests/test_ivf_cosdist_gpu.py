@@ -110,8 +110,8 @@ def run_body(env_extra, forced):
 
 
 def test_cosdist_matrix_core_paths_match_oracle():
-    run_body({"VERS_ASSIGN": "2"}, False)          # k-means assign through the matrix cores too
+    run_body({"VERS_OPTIONS": "assign=2"}, False)          # k-means assign through the matrix cores too
 
 
 def test_cosdist_with_every_certificate_forced_to_fail():
-    run_body({"VERS_PRESCAN": "2", "VERS_COARSE": "2", "VERS_ASSIGN": "2"}, True)
+    run_body({"VERS_OPTIONS": "prescan=2,coarse=2,assign=2"}, True)

@@ -18,6 +18,7 @@ import numpy as np
 from oracle import c_oracle as co
 from tests import datagen as dg
 from tests.golden import make_golden as mg
+from vers_amd import capi, testhooks
 from vers_amd.index import IVFFlatIndex
 
 def check(ix, Q, top_k, nprobe, step=7):
@@ -46,8 +47,8 @@ for seed, n, d, k, b, nprobe, top_ks in [(0x81, 9000, 96, 48, 160, 8, (1, 10, 26
     for top_k in top_ks:
         check(ix, Q, top_k, nprobe)
         total += 1
-    in_domain = d <= 2304 or os.environ.get("VERS_SHADOW", "1") != "0"   # (f32 rows: d > 2304 stays on the ordered chains)
-    if os.environ.get("VERS_PRESCAN", "1") != "0" and in_domain:   # every one of these shapes is inside the matrix-core scan's domain
+    in_domain = d <= 2304 or capi.env_option("shadow", 1) != 0   # (f32 rows: d > 2304 stays on the ordered chains)
+    if capi.env_option("prescan", 1) != 0 and in_domain:   # every one of these shapes is inside the matrix-core scan's domain
         assert ix.prescan_stats()["batches"] - b0 == len(top_ks), (seed, d, b, ix.prescan_stats()["batches"] - b0)
     if seed == 0x81:
         for i in range(70):  # add(): the new rows' norms are maintained incrementally; one list outgrows its slack
@@ -72,7 +73,7 @@ st = ix.prescan_stats()
 print("TIES", st["batches"], st["fallback_queries"])
 # ... the fp16 shadow (the default) keeps top_k + 24 keys: 100 copies of every vector defeat its certificate on every query,
 # and then the failure watch must switch it off for the handle (once 1/8 of >= 256 queries had to be re-scanned exactly)
-if os.environ.get("VERS_SHADOW", "1") != "0" and os.environ.get("VERS_PRESCAN", "1") == "1":
+if capi.env_option("shadow", 1) != 0 and capi.env_option("prescan", 1) == 1:
     X2 = np.repeat(B[:60], 100, axis=0)
     ix2 = IVFFlatIndex.build_index(8, 1, 2, X2, init_indices=mg.init_draws(0xA3, 1, 8, X2.shape[0]))
     assert ix2.shadow_state()["active"]
@@ -130,7 +131,7 @@ print("BIG", ix.prescan_stats()["fallback_queries"] - f0)
 Qb = (np.float32(300.0) * dg.dist_c(0xE4, 72, 48, 24, dg.default_sigma(48))).astype(np.float32)
 worst = 0
 for v in (float("inf"), float("nan"), -1.0e30, 1.5e19):
-    ix.test_poison_slack(v)
+    testhooks.poison_slack(ix, v)
     f0 = ix.prescan_stats()["fallback_queries"]
     check(ix, Qb, 10, 5, step=4)
     worst = max(worst, ix.prescan_stats()["fallback_queries"] - f0)
@@ -166,52 +167,52 @@ def test_exact_finish_gathers_from_the_tiles_without_the_row_major_copy():
 
 
 def test_forced_certificate_failure_is_exact():
-    out = run({"VERS_PRESCAN": "2"})
+    out = run({"VERS_OPTIONS": "prescan=2"})
     assert out["TIES"] == (1, 64)
-    out = run({"VERS_PRESCAN": "2", "VERS_SHADOW": "0"})
+    out = run({"VERS_OPTIONS": "prescan=2", "VERS_SHADOW": "0"})
     assert out["TIES"] == (1, 64)
 
 
 def test_ordered_chain_scan_still_available():
-    out = run({"VERS_PRESCAN": "0"})
+    out = run({"VERS_OPTIONS": "prescan=0"})
     assert out["TIES"] == (0, 0) and out["HUGE"] == (0, 0)
 
 
 def test_results_do_not_depend_on_uninitialised_memory():
     """The same body with NaN in every storage row that holds no vector and 0x7f in every new device buffer of the library
     (diagnosis knobs of DESIGN.md section 5): the oracle comparisons inside hold and the certificate statistics do not move."""
-    out = run({"VERS_POISON_SLACK": "nan", "VERS_POISON_ALLOC": "0x7f"})
+    out = run({"VERS_OPTIONS": "poison_slack_bits=0x7fc00000,poison_alloc=0x7f"})
     assert out["TIES"][0] == 1 and out["TIES"][1] > 0 and out["HUGE"] == (1, 64)
     assert out["ONE"] == (1,) and out["BIG"] == (0,) and out["TEN"][0] >= 10 and out["SLACK"] == (0,)
 
 
 def test_narrow_query_blocks_are_bit_exact():
-    """VERS_PRE_NARROW=1: 16 queries per block at every d (the variant that d = 1536 .. 2304 need), on the fp16 shadow and on the
+    """option pre_narrow=1: 16 queries per block at every d (the variant that d = 1536 .. 2304 need), on the fp16 shadow and on the
     f32 rows, and with every certificate forced to fail."""
-    out = run({"VERS_PRE_NARROW": "1"})
+    out = run({"VERS_OPTIONS": "pre_narrow=1"})
     assert out["TIES"][0] == 1 and out["TIES"][1] > 0 and out["HUGE"] == (1, 64) and out["ONE"] == (1,) and out["TEN"][0] >= 10 and out["SLACK"] == (0,)
-    out = run({"VERS_PRE_NARROW": "1", "VERS_SHADOW": "0"})
+    out = run({"VERS_OPTIONS": "pre_narrow=1", "VERS_SHADOW": "0"})
     assert out["TIES"][0] == 1 and out["TIES"][1] > 0 and out["HUGE"] == (1, 64) and out["ONE"] == (1,) and out["BIG"] == (0,)
-    out = run({"VERS_PRE_NARROW": "1", "VERS_PRESCAN": "2"})
+    out = run({"VERS_OPTIONS": "pre_narrow=1,prescan=2"})
     assert out["TIES"] == (1, 64)
 
 
 def test_hi_only_query_blocks_are_bit_exact():
-    """VERS_PRE_HI_ONLY=1: the fp16 shadow scan with the query block as fp16 hi only (prescan_kernel_g<.., LO = false>: what
+    """option pre_hi_only=1: the fp16 shadow scan with the query block as fp16 hi only (prescan_kernel_g<.., LO = false>: what
     1152 < d <= 2304 take with 32 queries per block and d <= 4608 with 16) at EVERY d, wide and narrow blocks, and with every
     certificate forced to fail; the certificate charges the query's measured fp16 residual."""
-    out = run({"VERS_PRE_HI_ONLY": "1"})
+    out = run({"VERS_OPTIONS": "pre_hi_only=1"})
     assert out["TIES"][0] == 1 and out["TIES"][1] > 0 and out["HUGE"] == (1, 64) and out["ONE"] == (1,) and out["TEN"][0] >= 10 and out["SLACK"] == (0,)
-    out = run({"VERS_PRE_HI_ONLY": "1", "VERS_PRE_NARROW": "1"})
+    out = run({"VERS_OPTIONS": "pre_hi_only=1,pre_narrow=1"})
     assert out["TIES"][0] == 1 and out["TIES"][1] > 0 and out["HUGE"] == (1, 64) and out["ONE"] == (1,) and out["TEN"][0] >= 10
-    out = run({"VERS_PRE_HI_ONLY": "1", "VERS_PRESCAN": "2"})
+    out = run({"VERS_OPTIONS": "pre_hi_only=1,prescan=2"})
     assert out["TIES"] == (1, 64)
 
 
 def test_32_query_hi_lo_blocks_without_the_wide_variant():
-    """VERS_PRE_WIDE=0: the 32-query blocks with both halves of the query's fp16 split (what every d <= 1152 ran until round 5 and
+    """option pre_wide=0: the 32-query blocks with both halves of the query's fp16 split (what every d <= 1152 ran until round 5 and
     960 < d <= 1152 still runs); the default covers the 64-query hi-only blocks at small d."""
-    out = run({"VERS_PRE_WIDE": "0"})
+    out = run({"VERS_OPTIONS": "pre_wide=0"})
     assert out["TIES"][0] == 1 and out["TIES"][1] > 0 and out["HUGE"] == (1, 64) and out["ONE"] == (1,) and out["TEN"][0] >= 10 and out["BIG"] == (0,) and out["SLACK"] == (0,)
-    out = run({"VERS_PRE_WIDE": "0", "VERS_PRESCAN": "2"})
+    out = run({"VERS_OPTIONS": "pre_wide=0,prescan=2"})
     assert out["TIES"] == (1, 64)

@@ -81,7 +81,7 @@ def test_single_queries_match_oracle_on_both_scans():
 
 
 def test_single_queries_with_every_certificate_forced_to_fail():
-    run_body(CASES_FORCED, {"VERS_PRESCAN": "2"}, True)
+    run_body(CASES_FORCED, {"VERS_OPTIONS": "prescan=2"}, True)
 
 
 def test_single_queries_without_a_shadow():

@@ -30,9 +30,9 @@ def _run(seconds, env_extra):
 
 @pytest.mark.gpu
 def test_threads_x_streams_with_every_certificate_failing():
-    """4 device-pointer threads x 3 streams each + 1 host-pointer thread; VERS_PRESCAN=2 / VERS_COARSE=2: every query of every
+    """4 device-pointer threads x 3 streams each + 1 host-pointer thread; options prescan=2, coarse=2: every query of every
     batch goes through the exact fallbacks (fallback_kernel's block groups, the exact coarse ranking), all bit-exact."""
-    out = _run(SECONDS * 2 / 3, {"VERS_PRESCAN": "2", "VERS_COARSE": "2"})
+    out = _run(SECONDS * 2 / 3, {"VERS_OPTIONS": "prescan=2,coarse=2"})
     assert int(out["batches"]) >= 12 and int(out["rescanned_queries"]) > 0
 
 

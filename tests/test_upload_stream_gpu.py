@@ -123,7 +123,7 @@ def test_streamed_upload_small_staging_buffer(monkeypatch):
         "        rows, ids = ix.get_list(c)\n"
         "        assert np.array_equal(ids, np.asarray(w.ids[c], dtype=np.uint64)) and np.array_equal(rows.view(np.uint32), X[ids.astype(np.int64)].view(np.uint32))\n"
         "print('ok')\n")
-    env = dict(os.environ, VERS_UPLOAD_STAGE_MB="0")  # 0 MB -> the floor of 64 rows per sub-chunk
+    env = dict(os.environ, VERS_OPTIONS="upload_stage_mb=0")  # 0 MB -> the floor of 64 rows per sub-chunk
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     out = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "ok" in out.stdout, out.stdout + out.stderr

@@ -57,6 +57,25 @@ def build_rccl(force: bool = False, verbose: bool = False) -> str:
     return RCCL_LIB
 
 
+TEST_SRC_DIR = os.path.join(CSRC, "testhooks")
+TEST_LIB = os.path.join(LIBDIR, "libvers_hip_test.so")
+
+
+def build_test_hooks(force: bool = False, verbose: bool = False) -> str:
+    """libvers_hip_test.so (include/vers_hip_test.h): the TEST / emulation hooks, a second library linked AGAINST libvers_hip.so --
+    the product library exports nothing named *test* (tests/test_abi.py)."""
+    hipcc = _hipcc()
+    srcs = sorted(os.path.join(TEST_SRC_DIR, f) for f in os.listdir(TEST_SRC_DIR) if f.endswith(".hip"))
+    deps = srcs + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hpp", ".hip.h", ".h"))]
+    deps += [os.path.join(os.path.dirname(_HERE), "include", h) for h in ("vers_hip.h", "vers_hip_test.h")] + [LIB]
+    if force or _stale(TEST_LIB, deps):
+        cmd = [hipcc] + CXXFLAGS + ["-shared"] + srcs + ["-o", TEST_LIB, f"-L{LIBDIR}", "-lvers_hip", "-Wl,-rpath,$ORIGIN"]
+        if verbose:
+            print(" ".join(cmd))
+        subprocess.check_call(cmd)
+    return TEST_LIB
+
+
 def build(force: bool = False, verbose: bool = False) -> str:
     os.makedirs(LIBDIR, exist_ok=True)
     os.makedirs(OBJDIR, exist_ok=True)
@@ -84,6 +103,7 @@ def build(force: bool = False, verbose: bool = False) -> str:
         if verbose:
             print(" ".join(cmd))
         subprocess.check_call(cmd)
+    build_test_hooks(force, verbose)
     try:  # the adapter is OPTIONAL (libvers_hip.so does not link RCCL): a box without librccl under the hipcc prefix still builds the library
         build_rccl(force, verbose)
     except (subprocess.CalledProcessError, OSError) as e:

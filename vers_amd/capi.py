@@ -80,13 +80,10 @@ SIGNATURES = {
     "vers_ivf_prescan_stats": (C.c_int32, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
     "vers_ivf_shadow_state": (C.c_int32, [_vp, C.POINTER(C.c_int32), C.POINTER(C.c_uint64)]),
     "vers_ivf_layout_bytes": (C.c_int32, [_vp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]),
-    "vers_ivf_test_poison_slack": (C.c_int32, [_vp, C.c_float]),
     "vers_ivf_build_sharded_dev": (C.c_int32, [_vp, _vp, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64, C.c_uint64,
                                                C.c_uint64, _vp, _vp, _vp, C.POINTER(C.c_float), C.POINTER(C.c_int32), _vp]),
     "vers_set_option": (C.c_int32, [C.c_char_p, C.c_int64]),
     "vers_mem_stats": (C.c_int32, [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_int32]),
-    "vers_test_wave_net": (C.c_int32, [C.c_int32, _vp, _vp]),
-    "vers_test_standin_gather": (C.c_int32, [_vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
     "vers_ivf_scan_times": (C.c_int32, [_vp, _vp, C.c_uint32, C.POINTER(C.c_uint32), C.c_int32]),
     "vers_ivf_get_list": (C.c_int32, [_vp, C.c_uint64, _vp, C.c_uint64, _vp, C.c_uint64, C.POINTER(C.c_uint64)]),
     "vers_ivf_get_centroids": (C.c_int32, [_vp, _vp, C.c_uint64]),
@@ -97,8 +94,6 @@ SIGNATURES = {
     "vers_assign_stats": (C.c_int32, [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_int32]),
     "vers_build_stats": (C.c_int32, [C.POINTER(C.c_double), C.c_int32]),
     "vers_build_phases": (C.c_int32, [C.POINTER(C.c_double), C.c_int32]),
-    "vers_ivf_test_last_vals": (C.c_int32, [_vp, C.c_uint32, _vp, _vp, _vp, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_double)]),
-    "vers_test_mfma": (C.c_int32, [C.c_int32, C.c_uint32, _vp, _vp, C.c_uint32, _vp]),
     "vers_kmeans_update": (C.c_int32, [C.c_int32, _vp, C.c_uint64, C.c_uint64, _vp, C.c_uint64, C.c_uint32, _vp]),
     "vers_kmeans_cost": (C.c_int32, [C.c_int32, _vp, C.c_uint64, C.c_uint64, _vp, C.c_uint64, C.c_uint64, _vp, C.c_uint32,
                                      C.POINTER(C.c_float)]),
@@ -135,6 +130,18 @@ def lib():
             fn.restype, fn.argtypes = res, args
         _lib = L
     return _lib
+
+
+def env_option(name: str, default: int) -> int:
+    """What the library starts option `name` with in THIS environment: VERS_OPTIONS="name=value,..." (csrc/core.hip's table; the two
+    documented switches VERS_SHADOW / VERS_ROWMAJOR are options "shadow" / "rowmajor"), else `default`.  vers_set_option overrides."""
+    alias = {"shadow": "VERS_SHADOW", "rowmajor": "VERS_ROWMAJOR"}
+    val = os.environ.get(alias[name]) if name in alias else None
+    for kv in os.environ.get("VERS_OPTIONS", "").split(","):
+        k, _, v = kv.partition("=")
+        if k.strip() == name and v:
+            val = v
+    return default if val is None else int(val, 0)
 
 
 def check(status: int):
@@ -284,18 +291,6 @@ def build_phases(reset=False) -> dict:
     return dict(zip(keys, (round(float(x), 2) for x in v)))
 
 
-def test_mfma(kind: int, A: np.ndarray, B: np.ndarray, device: int = 0) -> np.ndarray:
-    """TEST HOOK (vers_test_mfma): A [rows, K] x B [K, cols] on one wave of the matrix-core instruction `kind`, f32 result."""
-    A = np.ascontiguousarray(A); B = np.ascontiguousarray(B)
-    rows, cols = (64, 16) if kind == 3 else (32, 32)
-    assert A.shape[0] == rows and B.shape[1] == cols and A.shape[1] == B.shape[0] and A.dtype == B.dtype
-    assert A.dtype == (np.uint16 if kind <= 1 else np.float32)
-    out = np.zeros((rows, cols), dtype=np.float32)
-    check(lib().vers_test_mfma(device, kind, _ptr(A), _ptr(B), A.shape[1], _ptr(out)))
-    return out
-
-
-test_mfma.__test__ = False  # (not a pytest test)
 
 
 def set_option(name: str, value: int):

@@ -30,7 +30,10 @@ constexpr int kMaxTopK = 64;     // one sorted key per lane
 
 constexpr uint64_t kKeyMax = 0xFFFFFFFFFFFFFFFFull;
 
-uint32_t scan_debug_flags();  // env VERS_SCAN_DEBUG (diagnosis only; 0 in production)
+// the option table (core.hip): vers_set_option / VERS_OPTIONS="name=value,..." -- the value when set, else `dflt`
+int64_t opt_get(const char* name, int64_t dflt);
+bool opt_set(const char* name, int64_t v);  // false: no such option
+uint32_t scan_debug_flags();  // option "scan_debug" (diagnosis only; 0 in production)
 
 inline uint32_t round_up(uint32_t x, uint32_t m) { return (x + m - 1) / m * m; }
 inline uint64_t round_up64(uint64_t x, uint64_t m) { return (x + m - 1) / m * m; }

@@ -281,7 +281,7 @@ int32_t refresh_norms(vers_ivf* h, uint64_t r_begin, uint64_t r_end, hipStream_t
     if (full) h->rows_bf.release();
   }
   {
-    static const int rm_mode = [] { const char* e = getenv("VERS_ROWMAJOR"); return e ? atoi(e) : -1; }();  // default: whenever it fits (vers_ivf::rows_rm)
+    const int rm_mode = (int)opt_get("rowmajor", -1);  // default: whenever it fits (vers_ivf::rows_rm)
     if (full) {
       size_t free_b = 0, total_b = 0;
       (void)hipMemGetInfo(&free_b, &total_b);
@@ -466,10 +466,12 @@ int32_t finish_index(vers_ivf* h, uint32_t k, uint64_t n_total, hipStream_t st) 
   for (uint32_t c = 0; c < k; ++c) h->cmax2 = std::max(h->cmax2, cn[c]);  // NaN centroids never raise it; they fail the certificate
   h->k = k;
   h->n_total = n_total;
-  {  // diagnosis (VERS_POISON_SLACK=inf|nan|<number>): every new index starts with that value in the rows that hold no vector
-    static const char* poison = getenv("VERS_POISON_SLACK");
-    if (poison && h->cap_rows) {
-      const float v = (float)atof(poison);  // ("inf" and "nan" parse as such)
+  {  // diagnosis (option "poison_slack_bits"): every new index starts with that value in the rows that hold no vector
+    const int64_t poison = opt_get("poison_slack_bits", -1);  // (the f32 bit pattern: 0x7fc00000 NaN, 0x7f800000 inf, ...)
+    if (poison >= 0 && h->cap_rows) {
+      const uint32_t pbits = (uint32_t)poison;
+      float v;
+      std::memcpy(&v, &pbits, sizeof(v));
       const uint64_t work = h->cap_rows * (h->ld / 4);
       hipLaunchKernelGGL(poison_slack_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, st, h->rows.as<float>(), h->ld,
                          (const uint32_t*)h->row_ids.as<uint32_t>(), h->cap_rows, v);
@@ -1138,7 +1140,7 @@ int32_t upload_chunk_host_locked(vers_ivf* h, const float* rows, uint64_t row_st
   auto& up = h->up;
   const uint32_t ldx = h->ldx, d = h->d;
   const size_t row_b = (size_t)ldx * 4;
-  static const size_t stage_bytes = [] { const char* e = getenv("VERS_UPLOAD_STAGE_MB"); return (size_t)(e ? atol(e) : 256) << 20; }();
+  const size_t stage_bytes = (size_t)opt_get("upload_stage_mb", 256) << 20;
   const uint64_t sub = std::max<uint64_t>(64, std::min<uint64_t>(n ? n : 1, stage_bytes / (row_b + 8)));
   const size_t pin_need = sub * (row_b + 8);
   if (up.pin_cap < pin_need) {

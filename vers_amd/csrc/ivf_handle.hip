@@ -173,6 +173,7 @@ int32_t vers_set_option(const char* name, int64_t value) {
   if (std::strcmp(name, "single_shadow") == 0) { single_shadow_ref().store(value != 0 ? 1 : 0); return VERS_OK; }
   if (std::strcmp(name, "host_spin") == 0) { host_spin_ref().store(value != 0 ? 1 : 0); return VERS_OK; }
   if (std::strcmp(name, "scan_events") == 0) { scan_events_ref().store(value < 0 || value > 2 ? 2 : (int)value); return VERS_OK; }
+  if (opt_set(name, value)) return VERS_OK;  // every other switch: read where it is used (core.hip's table)
   return fail(VERS_ERR_INVALID, std::string("vers_set_option: unknown option ") + name);
 }
 

@@ -324,7 +324,7 @@ struct HostStatusSlot {
 // 1 always, 0 never, 2 (default) for batches only: the two records cost a single-query call 5.5-6 us of ~100 (same-box A/B,
 // scripts/bench_host_b1.py), a batch of 1024 nothing measurable.
 inline std::atomic<int>& scan_events_ref() {
-  static std::atomic<int> m{[] { const char* e = getenv("VERS_SCAN_EVENTS"); return e ? atoi(e) : 2; }()};
+  static std::atomic<int> m{(int)opt_get("scan_events", 2)};
   return m;
 }
 // vers_set_option("host_spin", 0 | 1): a host-pointer single-query call waits for its result by spinning on the pinned status word
@@ -334,9 +334,9 @@ inline std::atomic<int>& host_spin_ref() {
   return m;
 }
 // vers_set_option("single_shadow", 0 | 1): a single query's list scan streams the fp16 shadow with the exact finish behind it (1,
-// default; VERS_SCAN1H) or the f32 rows through the ordered chains (0: rounds 1-4; same-process A/B in bench.py)
+// default) or the f32 rows through the ordered chains (0: rounds 1-4; same-process A/B in bench.py)
 inline std::atomic<int>& single_shadow_ref() {
-  static std::atomic<int> m{[] { const char* e = getenv("VERS_SCAN1H"); return e ? (atoi(e) != 0 ? 1 : 0) : 1; }()};
+  static std::atomic<int> m{opt_get("single_shadow", 1) != 0 ? 1 : 0};
   return m;
 }
 // TEST HOOK (vers_set_option("test_fail_sharded", n)): the next n sharded searches of this process fail LOCALLY after their
@@ -345,7 +345,7 @@ inline std::atomic<int>& test_fail_sharded_ref() {
   static std::atomic<int> m{0};
   return m;
 }
-// vers_set_option("scan_reserve_cus", n) / VERS_SCAN_RESERVE_CUS: compute units the persistent matrix-core list scan leaves free.
+// vers_set_option("scan_reserve_cus", n): compute units the persistent matrix-core list scan leaves free.
 // -1 (default) = AUTO: kScanReserveAuto while ANOTHER batch of this handle is in flight on another stream (scan_reserve below), none
 // otherwise.  A scan block holds 448 of a SIMD's 512 registers: nothing with a large footprint -- RCCL's all-gather kernel (256
 // VGPRs per wave, profiles/r05_rccl_kernel_meta.txt), the other batches' coarse contraction (232) / selection (224) / grouping
@@ -356,7 +356,7 @@ inline std::atomic<int>& test_fail_sharded_ref() {
 // ranks 0.682 -> 0.643, one GPU 2.314 -> 2.276 (same box, scripts/emulate_shard.py RESERVE=...).
 constexpr int kScanReserveAuto = 64;
 inline std::atomic<int>& scan_reserve_cus_ref() {
-  static std::atomic<int> m{[] { const char* e = getenv("VERS_SCAN_RESERVE_CUS"); return e ? atoi(e) : -1; }()};
+  static std::atomic<int> m{(int)opt_get("scan_reserve_cus", -1)};
   return m;
 }
 // Is another batch of this handle in flight on ANOTHER stream right now (a workspace leased by another thread, or one whose last
@@ -373,41 +373,36 @@ inline uint32_t scan_reserve(vers_ivf* h, hipStream_t st) {
   const int r = v >= 0 ? v : (other_batches_in_flight(h, W, st) ? kScanReserveAuto : 0);
   return (uint32_t)std::min<int>(r, h->n_cu - 1);
 }
-inline std::atomic<int>& shadow_mode_ref() {  // VERS_SHADOW (default 1) / vers_set_option("shadow", v)
-  static std::atomic<int> m{[] { const char* e = getenv("VERS_SHADOW"); return e ? (atoi(e) != 0 ? 1 : 0) : 1; }()};
+inline std::atomic<int>& shadow_mode_ref() {  // vers_set_option("shadow", v) / VERS_SHADOW (default 1)
+  static std::atomic<int> m{opt_get("shadow", 1) != 0 ? 1 : 0};
   return m;
 }
 inline int shadow_mode() { return shadow_mode_ref().load(std::memory_order_relaxed); }
-// VERS_PRE_MIN_BATCH (default 4) / vers_set_option("pre_min_batch", v): the smallest batch whose list scan runs on the matrix
+// vers_set_option("pre_min_batch", v) (default 4): the smallest batch whose list scan runs on the matrix
 // cores when its lists are shared by fewer than two queries on average (plan_search)
 inline std::atomic<uint32_t>& pre_min_batch_ref() {
-  static std::atomic<uint32_t> m{[] { const char* e = getenv("VERS_PRE_MIN_BATCH"); return e ? (uint32_t)atol(e) : 4u; }()};
+  static std::atomic<uint32_t> m{(uint32_t)opt_get("pre_min_batch", 4)};
   return m;
 }
 
-// Tuning / A-B knobs of the search path (environment, read ONCE per process; DESIGN.md section 5 "Switches").
+// Tuning / A-B knobs of the search path (options "pre_slack", "seg_rows", "prescan", "pre_narrow": core.hip's table).
 struct SearchKnobs {
-  int pre_slack = 0;     // VERS_PRE_SLACK: slack keys of the matrix-core lists
-  long seg_rows = 0;     // VERS_SEG_ROWS
-  int pre_mode = 1;      // VERS_PRESCAN: 0 ordered chains for batches too, 2 every certificate fails
-  bool pre_narrow = false;    // VERS_PRE_NARROW: 16-query blocks in the matrix-core list scan whatever d is
+  int pre_slack = 0;     // "pre_slack": slack keys of the matrix-core lists
+  long seg_rows = 0;     // "seg_rows"
+  int pre_mode = 1;      // "prescan": 0 ordered chains for batches too, 2 every certificate fails
+  bool pre_narrow = false;    // "pre_narrow": 16-query blocks in the matrix-core list scan whatever d is
 };
-inline const SearchKnobs& knobs() {
-  static const SearchKnobs k = [] {
-    SearchKnobs s;
-    auto geti = [](const char* n, long dflt) { const char* e = getenv(n); return e ? atol(e) : dflt; };
-    s.pre_slack = (int)geti("VERS_PRE_SLACK", 0);
-    s.seg_rows = geti("VERS_SEG_ROWS", 0);
-    s.pre_mode = (int)geti("VERS_PRESCAN", 1);
-    s.pre_narrow = geti("VERS_PRE_NARROW", 0) != 0;
-    return s;
-  }();
-  return k;
+inline SearchKnobs knobs() {
+  SearchKnobs s;
+  s.pre_slack = (int)opt_get("pre_slack", 0);
+  s.seg_rows = (long)opt_get("seg_rows", 0);
+  s.pre_mode = (int)opt_get("prescan", 1);
+  s.pre_narrow = opt_get("pre_narrow", 0) != 0;
+  return s;
 }
 
-inline int coarse_mode() {  // VERS_COARSE: 1 = always exact, 2 = every certificate fails
-  static const int m = [] { const char* e = getenv("VERS_COARSE"); return e ? atoi(e) : 0; }();
-  return m;
+inline int coarse_mode() {  // option "coarse": 1 = always exact, 2 = every certificate fails
+  return (int)opt_get("coarse", 0);
 }
 inline bool coarse_on_matrix_cores(const vers_ivf* h, uint32_t b) { return b >= 32 && coarse_mode() != 1 && !W->ref_deep; }
 // the whole condition under which coarse() ranks on the matrix cores (the contraction reads whole 128-row tiles: the staged block

@@ -613,7 +613,7 @@ int32_t plan_search(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint32_t b
   // are produced 64 ranks per pass (ScanParams::lower), on the ordered-chain kernels
   const bool one1 = b == 1 && P <= (uint32_t)kMaxTopK;  // single query: coarse merge + plan fused in plan1_kernel
   // ... and the coarse scan with them in coarse1_kernel (VERS_COARSE1=0: the ordered-chain scan + plan1_kernel, for A/B runs)
-  static const bool c1_on = [] { const char* e = getenv("VERS_COARSE1"); return e ? atoi(e) != 0 : true; }();
+  const bool c1_on = opt_get("coarse1", 1) != 0;
   const bool one1_fused = one1 && c1_on;
   if (one1_fused) {
     if (int32_t rc = W->cpart.reserve((size_t)((h->k + kWave - 1) / kWave) * P * sizeof(uint64_t))) return rc;
@@ -662,7 +662,7 @@ int32_t plan_search(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint32_t b
   // (prescan_kernel_g<.., LO = false>): 32 queries per block up to d = 2304 -- at d = 1536 the 16-query blocks streamed every list
   // probed by more than 16 queries once per extra group, 2.15x the union's bytes -- and 16 up to d = 4608; the certificate charges
   // the query's measured fp16 residual instead (pre_bound).  VERS_PRE_HI_ONLY=1 forces it at every d (tests, A/B).
-  static const bool force_hi = [] { const char* e = getenv("VERS_PRE_HI_ONLY"); return e && atoi(e) != 0; }();
+  const bool force_hi = opt_get("pre_hi_only", 0) != 0;
   uint32_t pre_nq = 0;
   bool pre_hi_only = false;
   {
@@ -670,7 +670,7 @@ int32_t plan_search(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint32_t b
     auto fits = [&](uint32_t nq, bool hi) { return prescan_lds_bytes_g(h->ld, kp, nq, hi) <= 160u * 1024u; };
     // 64 queries per block (two sets of 32, hi-only) wherever they fit -- d <= 960 with the default slack --: lists probed by 33 .. 64
     // queries of the batch are then streamed once instead of twice (VERS_PRE_WIDE=0: the 32-query hi + lo blocks of rounds 2-4)
-    static const bool wide_on = [] { const char* e = getenv("VERS_PRE_WIDE"); return !e || atoi(e) != 0; }();
+    const bool wide_on = opt_get("pre_wide", 1) != 0;
     if (!narrow && wide_on && use_shadow && fits(kPreQWide, true)) { pre_nq = kPreQWide; pre_hi_only = true; }
     else if (!narrow && !(force_hi && use_shadow) && fits(kPreQ, false)) pre_nq = kPreQ;
     else if (!narrow && use_shadow && fits(kPreQ, true)) { pre_nq = kPreQ; pre_hi_only = true; }

@@ -244,7 +244,7 @@ int32_t launch_scan1(vers_ivf* h, const Scan1Args& a, uint32_t items_bound, hipS
   const bool no_ev = !W->ev_on;
   const uint32_t slot = (uint32_t)(W->ev_count % SearchWs::kEvRing);
   // a tile per block of 16 waves (scan1t_kernel: the whole tile in flight at once) instead of a tile per wave; VERS_SCAN1T=0: the latter
-  static const bool t1_on = [] { const char* e = getenv("VERS_SCAN1T"); return !e || atoi(e) != 0; }();
+  const bool t1_on = opt_get("scan1t", 1) != 0;
   // ... when the query visits few tiles -- the reference's own mode, a few probes --: with a tile per CU and round, 1361 tiles (nprobe = 32 at
   // cfg3 without a shadow) take 72 us against the tile-per-wave kernel's 58
   if (t1_on && few_tiles && knobs().seg_rows <= 0) {  // (a record is ONE tile unless the tuning knob cut the lists differently)
@@ -354,7 +354,7 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
   // the nprobe path: the matrix-core scan of the fp16 shadow + exact finish instead of the ordered chains over the f32 rows (half the
   // bytes: 1.52 -> 0.7 ms per 1024 queries at cfg3).  Single queries keep the f32 tile-per-block scan (scan1t_kernel: one list is
   // latency-bound, the exact finish would cost more than it saves).  VERS_REF_AS_NPROBE1=0: the ordered chains (A/B runs).
-  static const bool ref_as_np1 = [] { const char* e = getenv("VERS_REF_AS_NPROBE1"); return !e || atoi(e) != 0; }();
+  const bool ref_as_np1 = opt_get("ref_as_nprobe1", 1) != 0;
   if (nprobe == 0 && ref_as_np1 && out_keys == nullptr && h->world == 1 && b >= pre_min_batch_ref().load(std::memory_order_relaxed) && top_k + 6 <= kPreMaxKp &&
       knobs().pre_mode != 0 && h->lists_that_always_suffice(top_k) == 1)
     nprobe = 1;

@@ -43,9 +43,10 @@ int32_t DevBuf::reserve(size_t bytes) {
   VERS_HIP_TRY(hipMalloc(&p, bytes));
   cap = bytes;
   dev_mem_account((int64_t)bytes);
-  // diagnosis (VERS_POISON_ALLOC=<byte>): every new device buffer starts filled with that byte instead of whatever the
+  // diagnosis (option "poison_alloc" = a byte): every new device buffer starts filled with that byte instead of whatever the
   // allocator hands out -- nothing may depend on uninitialised scratch (the GPU suite passes under 0x7f, 0xa5 and 0x00)
-  static const int poison = [] { const char* e = getenv("VERS_POISON_ALLOC"); return e ? (int)strtol(e, nullptr, 0) & 0xFF : -1; }();
+  const int64_t pa = opt_get("poison_alloc", -1);
+  const int poison = pa >= 0 ? (int)(pa & 0xFF) : -1;
   if (poison >= 0) {
     VERS_HIP_TRY(hipMemset(p, poison, bytes));
     VERS_HIP_TRY(hipDeviceSynchronize());
@@ -207,8 +208,7 @@ static std::atomic<int> g_x3_mask{-1};
 int gemm_x3_mask() {
   int m = g_x3_mask.load();
   if (m < 0) {  // default: both contractions as bf16x3 (build 3.3 -> 2.1 s, coarse GEMM 62 -> ~25 us, same bits)
-    const char* e = getenv("VERS_GEMM_X3");
-    m = e ? atoi(e) : 3;
+    m = (int)opt_get("gemm_x3", 3) & 3;
     g_x3_mask = m;
   }
   return m;
@@ -216,10 +216,7 @@ int gemm_x3_mask() {
 void set_gemm_x3_mask(int m) { g_x3_mask = m & 3; }
 
 bool km_use_mfma(uint64_t n, uint32_t k, uint32_t d) {
-  static const int mode = [] {
-    const char* e = getenv("VERS_ASSIGN");
-    return e ? atoi(e) : 0;
-  }();
+  const int mode = (int)opt_get("assign", 0);
   if (k < 2 || n == 0) return false;
   if (mode == 1) return false;
   if (mode == 2) return true;
@@ -243,10 +240,10 @@ int32_t km_assign_mfma(const float* X, uint32_t ldx, uint64_t n, const float* C,
   VERS_HIP_TRY(hipMemsetAsync(fb_count, 0, sizeof(uint32_t), st));
   // large k: uncertified points first go through the tile-limited re-scan (assign_tile_rescan_kernel); what it cannot settle
   // lands in fb_list like before
-  static const bool tiles_on = [] { const char* e = getenv("VERS_ASSIGN_TILES"); return !e || atoi(e) != 0; }();
+  const bool tiles_on = opt_get("assign_tiles", 1) != 0;
   // (from 64 tiles = k >= 8192 on: measured at k = 4096, N = 4M with VERS_ASSIGN_TILES_MIN=8 the pass gets 3 % SLOWER, 104.6 vs
   // 101.1 ms -- a launch of 2048 waves per batch against one exact scan of the 1.6 % uncertified points at the end; same bits)
-  static const uint32_t tiles_min = [] { const char* e = getenv("VERS_ASSIGN_TILES_MIN"); return e ? (uint32_t)atoi(e) : 64u; }();
+  const uint32_t tiles_min = (uint32_t)opt_get("assign_tiles_min", 64);
   const bool tile_rescan = tiles_on && k_pad / kGemmBM >= tiles_min;
   uint32_t* fbq_list = nullptr; uint32_t* fbq_count = nullptr; float* fbq_thr = nullptr;
   if (tile_rescan) {

@@ -170,7 +170,7 @@ int32_t check_runtime_version() {
   if (v / 10000 != NCCL_VERSION_CODE / 10000)
     return fail(VERS_ERR_COMM, "libvers_rccl.so was built against RCCL " + std::to_string(NCCL_VERSION_CODE) + " but the process loaded RCCL " + std::to_string(v) + ": incompatible major version");
   static bool said = false;
-  if (v != NCCL_VERSION_CODE && !said && getenv("VERS_RCCL_QUIET") == nullptr) {
+  if (v != NCCL_VERSION_CODE && !said) {
     said = true;
     Dl_info info;
     const char* path = dladdr((void*)&ncclGetVersion, &info) && info.dli_fname ? info.dli_fname : "?";

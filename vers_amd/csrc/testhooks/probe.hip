@@ -1,4 +1,4 @@
-// probe.hip -- TEST HOOK: what the matrix cores do to the certificates' error model, measured.
+// probe.hip (libvers_hip_test.so) -- TEST HOOK: what the matrix cores do to the certificates' error model, measured.
 //
 // The three pre-filters (coarse quantiser, list scan, k-means assign) certify their results with a bound that assumes
 // "a matrix-core dot product errs like a chain of f32 additions: at most K roundings of at most u = 2^-24 relative each,
@@ -9,8 +9,9 @@
 // hands the f32 result back; tests/test_mfma_model_gpu.py compares with the exact rational value.
 #include <vector>
 
-#include "gemm.hip.h"
-#include "util.hip.h"
+#include "../gemm.hip.h"
+#include "../util.hip.h"
+#include "../../../include/vers_hip_test.h"
 
 namespace vers {
 

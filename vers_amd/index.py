@@ -168,19 +168,6 @@ class IVFFlatIndex:
         check(lib().vers_ivf_shadow_state(self._h, C.byref(a), C.byref(b)))
         return dict(active=bool(a.value), bytes=int(b.value))
 
-    def test_poison_slack(self, value: float):
-        """Test hook: fill the storage rows that hold no vector with `value` (what uninitialised memory may look like)."""
-        check(lib().vers_ivf_test_poison_slack(self._h, C.c_float(value)))
-
-    def last_vals(self, q: int, cap: int = 8192):
-        """TEST HOOK (vers_ivf_test_last_vals): (vec_ids, vals, per-candidate bounds, info dict) of query q of the last batched nprobe search"""
-        ids = np.zeros(cap, dtype=np.uint64); vals = np.zeros(cap, dtype=np.float32); bnd = np.zeros(cap, dtype=np.float64)
-        n = C.c_uint32(0); info = (C.c_double * 8)()
-        check(lib().vers_ivf_test_last_vals(self._h, q, _ptr(ids), _ptr(vals), _ptr(bnd), cap, C.byref(n), info))
-        m = min(n.value, cap)
-        keys = ("qn", "xmax2", "r2", "bound_outside", "bound_common", "kp", "shadow", "metric")
-        return ids[:m].copy(), vals[:m].copy(), bnd[:m].copy(), dict(zip(keys, (float(x) for x in info)))
-
     def scan_times(self, reset: bool = True):
         ms = np.zeros(1024, dtype=np.float32); n = C.c_uint32(0)   # (a ring of 64 per workspace; one workspace per stream in flight)
         check(lib().vers_ivf_scan_times(self._h, _ptr(ms), 1024, C.byref(n), 1 if reset else 0))
