@@ -94,7 +94,9 @@ def compact_line(out: dict) -> dict:
         "domain_edges_qps": {k: v.get("queries_per_sec") for k, v in ed.items()} or None,
         "d1536": {k: _g(ex, "d1536", k) for k in ("queries_per_sec", "frac", "gpu_matches_cpu_bitwise")} if "d1536" in ex else None,
         "memory": {"bytes_per_row": _g(ex, "memory", "bytes_per_stored_row"), "over_f32_rows": None if not _g(ex, "memory", "bytes_per_stored_row") else
-                   round(_g(ex, "memory", "bytes_per_stored_row") / (4.0 * cfg["d"]), 3), "max_N_per_gpu": _g(ex, "memory", "max_N_per_gpu_as_configured")} if "memory" in ex else None,
+                   round(_g(ex, "memory", "bytes_per_stored_row") / (4.0 * cfg["d"]), 3), "max_N_per_gpu": _g(ex, "memory", "max_N_per_gpu_as_configured"),
+                   "compact_over_f32_rows": _g(ex, "memory_compact", "over_f32_rows"), "compact_step_ms": _g(ex, "memory_compact", "whole_step_ms"),
+                   "compact_step_ms_one_in_flight": _g(ex, "memory_compact", "one_batch_in_flight_whole_step_ms"), "compact_same_results": _g(ex, "memory_compact", "same_results_as_the_headline_bitwise")} if "memory" in ex else None,
         "build_index_s": ex.get("build_index_s"), "add_us": _g(ex, "add", "us_per_vector"),
         "recall_dist_u": _g(ex, "recall_at_10_dist_u", "value"), "recall_vs_nprobe": _g(ex, "recall_vs_nprobe_noisy_dist_c", "recall_at_10"),
     }
@@ -770,7 +772,7 @@ def main():
                     "frac": round(gbs / HBM_PEAK_GBS, 4), "end_to_end_us": round(float(np.median(e2e_reps)) * 1e6, 1),
                     "end_to_end_qps": round(1.0 / float(np.median(e2e_reps)), 1), "end_to_end_us_stretches": [round(x * 1e6, 1) for x in e2e_reps],
                     "host_call_us": round(float(np.median(host_reps)) * 1e6, 1), "host_call_us_stretches": [round(x * 1e6, 1) for x in host_reps]}
-        on_shadow = bool(index.shadow_state()["active"]) and nprobe != 0 and top_k + 6 <= 64 and capi.env_option("single_shadow", 1) != 0
+        on_shadow = bool(index.shadow_state()["active"]) and nprobe != 0 and top_k + 16 <= 64 and capi.env_option("single_shadow", 1) != 0
         try:
             f32_leg = single_leg(False)
             sq = single_leg(True) if on_shadow else dict(f32_leg)
@@ -821,7 +823,7 @@ def main():
         # batches of 2 - 3 (below pre_min_batch: consecutive single queries on the shadow since round 5; one ordered-chain scan per (query, list) pair before).  Correctness of these shapes is
         # tests/test_limits_gpu.py's; here: what they cost.
         edges = {}
-        for name, (bsz, tk, npb) in {"top_k_64": (min(B, 256), 64, nprobe), "top_k_100": (min(B, 256), 100, nprobe), "nprobe_128": (min(B, 256), top_k, min(128, nlist)),
+        for name, (bsz, tk, npb) in {"top_k_64": (min(B, 256), 64, nprobe), "top_k_100": (min(B, 256), 100, nprobe), "nprobe_128": (min(B, 256), top_k, min(128, nlist)), "nprobe_256": (min(B, 256), top_k, min(256, nlist)),
                                       "batch_2": (2, top_k, nprobe), "batch_3": (3, top_k, nprobe)}.items():
             if bsz > B or npb < 1:
                 continue
@@ -945,7 +947,7 @@ def main():
                 m_ = float(np.mean(ms_[metric]))
                 leg[name] = {"scan_us": round(m_ * 1e3, 1), "achieved_GBs": round(by / (m_ * 1e-3) / 1e9, 1), "frac": round(by / (m_ * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
             return leg
-        flat_shadow = capi.env_option("shadow", 1) != 0 and capi.env_option("single_shadow", 1) != 0 and top_k + 6 <= 64
+        flat_shadow = capi.env_option("shadow", 1) != 0 and capi.env_option("single_shadow", 1) != 0 and top_k + 16 <= 64
         try:
             f32_leg = flat_leg(False)
             sh_leg = flat_leg(True) if flat_shadow else None
@@ -1222,6 +1224,42 @@ def main():
             log(f"[bench] add: {extra['add']['us_per_vector']} us per vector")
         except Exception as e:
             log(f"[bench] add leg failed: {e!r}")
+
+    # ---- the COMPACT memory layout (vers_set_option("memory", 1): ONE f32 copy of the rows -- tiles + fp16 shadow, no row-major copy; the
+    # exact finish gathers its survivors from the tiles): the headline's index rebuilt under it, the same timed steps, bytes per row
+    if rank == 0 and not multi and not args.no_extra:
+        try:
+            index.close()
+            torch.cuda.empty_cache()
+            capi.set_option("memory", 1)
+            Xc = torch.empty(n, ld, dtype=torch.float32, device=dev)
+            capi.gen_rows_dev(Xc.data_ptr(), n, d, ld, 1, SEED_X, SEED_C, n_modes, sigma)
+            index = IVFFlatIndex(d, device=dev_index)
+            m0, _ = capi.mem_stats(reset_peak=True)
+            index.build_dev(Xc.data_ptr(), n, nlist, 1, args.kmeans_iters, init)
+            del Xc
+            torch.cuda.empty_cache()
+            mc_now, mc_peak = capi.mem_stats()
+            tcs, msc = timed_steps(nprobe)
+            tc1, msc1 = timed_steps(nprobe, 1) if S > 1 else (tcs, msc)
+            oi_c, od_c, oc_c = torch.zeros(B, top_k, dtype=torch.int64, device=dev), torch.zeros(B, top_k, device=dev), torch.zeros(B, dtype=torch.int32, device=dev)
+            index.search_dev(Q[(last % n_batches) * B:].data_ptr(), ld, B, top_k, nprobe, oi_c.data_ptr(), od_c.data_ptr(), oc_c.data_ptr(), st)
+            index.poll(st)
+            same = bool(np.array_equal(oi_c.cpu().numpy().astype(np.uint64), ids_h) and np.array_equal(od_c.cpu().numpy().view(np.uint32), dst_h.view(np.uint32)) and np.array_equal(oc_c.cpu().numpy(), cnt_h))
+            lay_c = index.layout_bytes()
+            extra["memory_compact"] = {"library_bytes_now": int(mc_now - m0), "library_bytes_peak_during_build": int(mc_peak - m0), "bytes_per_stored_row": round((mc_now - m0) / n, 1),
+                                       "over_f32_rows": round((mc_now - m0) / n / (4.0 * d), 3), "rowmajor_copy_bytes": int(lay_c["rowmajor"]),
+                                       "whole_step_ms": round(tcs / args.steps * 1e3, 4), "whole_step_queries_per_sec": round(args.steps * B / tcs, 1),
+                                       "one_batch_in_flight_whole_step_ms": round(tc1 / args.steps * 1e3, 4), "list_scan_ms": round(float(np.mean(msc1)), 4) if len(msc1) else None,
+                                       "same_results_as_the_headline_bitwise": same, "steps": args.steps, "warmup": args.warmup,
+                                       "note": "vers_set_option('memory', 1) before build_index: the same corpus, index, batches and timed loop as the headline (after it)"}
+            log(f"[bench] compact memory: {extra['memory_compact']['over_f32_rows']} x the f32 rows ({extra['memory_compact']['bytes_per_stored_row']} B per row), "
+                f"{extra['memory_compact']['whole_step_ms']} ms per step ({S} in flight), {extra['memory_compact']['one_batch_in_flight_whole_step_ms']} ms one in flight; same results: {same}")
+        except Exception as e:
+            extra["memory_compact"] = {"failed": f"{type(e).__name__}: {e}"}
+            log(f"[bench] compact memory leg FAILED: {e!r}")
+        finally:
+            capi.set_option("memory", 0)
 
     # ---- cfg4 / cfg5 at ONE RANK'S NOMINAL SIZE on this GPU (scripts/rank_nominal.py; no 8-GPU node has been available in any round):
     # rank 0 of 8 of IVFFlat N=100M (the corpus streamed through vers_kmeans_assign_dev and vers_ivf_upload_begin / _chunk_dev / _end,

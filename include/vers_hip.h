@@ -313,8 +313,11 @@ int32_t vers_ivf_build_sharded_dev(vers_ivf_t* h, const float* rows_dev, uint64_
  *  Memory:
  *   "shadow" (1)        indexes built / uploaded from now on keep an fp16 shadow of their rows for the list scans
  *                       (vers_ivf_shadow_state); 0 = none, and searches on existing handles read their f32 rows until it is 1 again.
- *   "rowmajor" (-1)     the row-major f32 copy the exact finish gathers from: -1 = kept while the rows take <= 1/4 of the device,
- *                       0 never, 1 always.
+ *   "rowmajor" (-1)     the row-major f32 copy the exact finish gathers from: -1 = kept while the rows take <= 1/4 of the device
+ *                       (and "memory" is 0), 0 never, 1 always.
+ *   "memory" (0)        0 = speed: f32 tiles + fp16 shadow + row-major f32 copy (2.7 x the f32 rows at d = 768); 1 = compact: ONE f32
+ *                       copy -- tiles + shadow, 1.7 x --, the exact finish gathers its survivors from the tiles (16-byte pieces).
+ *                       Read when an index is built / uploaded.
  *  Serving:
  *   "single_shadow" (1) a single query (b == 1, nprobe >= 1) streams the fp16 shadow and is finished exactly like a batch;
  *                       0 = the ordered-chain scan of the f32 rows.

@@ -61,7 +61,7 @@ def test_bench_single_gpu_line():
     assert ex["single_query"]["list_scan_us"] > 0 and ex["flat_cfg2"]["l2sq"]["frac"] > 0 and 0 <= ex["recall_at_10_dist_u"]["value"] <= 1
     # every leg the line promises is there (a leg that raises is logged, not dropped silently: the coarse contraction's entries
     # went missing from round 3's line for a while because the legs before it left a single query as the handle's last call)
-    for key in ("coarse_gemm", "coarse_gemm_f32", "reference_mode", "list_scan_f32_rows", "memory", "batch_sweep", "domain_edges", "d1536", "build_index_phases_ms", "add"):  # (kmeans_assign: matrix-core builds only)
+    for key in ("coarse_gemm", "coarse_gemm_f32", "reference_mode", "list_scan_f32_rows", "memory", "memory_compact", "batch_sweep", "domain_edges", "d1536", "build_index_phases_ms", "add"):  # (kmeans_assign: matrix-core builds only)
         assert key in ex, (key, sorted(ex))
     assert all(v["gpu_matches_cpu_bitwise"] for v in ex["batch_sweep"]["by_batch"].values()) and ex["d1536"]["gpu_matches_cpu_bitwise"] is True
     assert "prescan_kernel_g<true, 32, IvfSrc<32>, LO = false>" in ex["d1536"]["list_scan"] and ex["d1536"]["queries_compared_bitwise"] >= 2 and out["row_operand"]

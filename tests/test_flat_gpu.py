@@ -124,7 +124,7 @@ for n, d, kind in [(40000, 128, "u"), (9000, 300, "c"), (130, 64, "u"), (70000, 
     Q = dg.dist_u(0x0DD + n, 6, d); Q[2] = X[n // 3]
     fc = capi.FlatCorpus(d); fc.upload(X)
     for metric in (0, 1):
-        for top_k in (1, 10, 58, 64):         # (64: beyond the shadow path's k + slack <= 64 keys -- the ordered chains)
+        for top_k in (1, 10, 48, 58, 64):     # (58, 64: beyond the shadow path's k + 16 keys of slack <= 64 -- the ordered chains)
             for single_shadow in (1, 0):
                 capi.set_option("single_shadow", single_shadow)
                 for qi in range(6):

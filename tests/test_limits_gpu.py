@@ -47,6 +47,29 @@ def test_wide_top_k_and_many_probes():
     ix.close()
 
 
+def test_many_probes_run_on_the_matrix_cores():
+    """nprobe in (64, 1024]: the list scan stays on the matrix cores (fp16 shadow, exact finish) -- the work items carry (query, list)
+    pairs, only the RANKING of more than 48 lists is exact, 64 ranks per pass (rounds 1-5 sent these shapes to the ordered chains at
+    half the bytes per second).  Against the oracle bit for bit, and again with every certificate failing (the exact re-scan)."""
+    n, d, k = 30000, 64, 320
+    X = dg.dist_c(0x721, n, d, 900, dg.default_sigma(d))
+    X[200:230] = X[11]                                   # ties decided by list position
+    ix = IVFFlatIndex.build_index(k, 1, 3, X, init_indices=mg.init_draws(0x721, 1, k, n))
+    Q = dg.dist_c(0x722, 96, d, 900, dg.default_sigma(d)); Q[9] = X[11]
+    try:
+        for mode in (1, 2):
+            capi.set_option("prescan", mode)
+            for nprobe, top_k in ((65, 10), (128, 10), (128, 48), (256, 10), (300, 20), (1000, 10)):   # 1000 > k: every list
+                st0 = ix.prescan_stats()
+                check(ix, Q, top_k, nprobe, range(0, 96, 7))
+                st1 = ix.prescan_stats()
+                assert st1["batches"] - st0["batches"] == 1, (mode, nprobe, top_k)
+                assert (st1["fallback_queries"] - st0["fallback_queries"] == 96) == (mode == 2), (mode, nprobe, top_k, st0, st1)
+    finally:
+        capi.set_option("prescan", 1)
+    ix.close()
+
+
 def test_reference_spill_through_more_than_64_empty_lists():
     """k = 150 centroids of which 140 are duplicates of one row -> their lists are empty (ties go to the lowest index) and
     ALL rank ahead of the far lists for queries near that row: the walk of ivfflat.rs:166-195 crosses > 64 empty lists."""

@@ -32,7 +32,7 @@ def check(ix, Q, top_k, nprobe, step=7):
 
 total = 0
 # (1) clustered data, several shapes (d = 300 pads to 320 columns; lists are ragged: lengths not multiples of 64)
-for seed, n, d, k, b, nprobe, top_ks in [(0x81, 9000, 96, 48, 160, 8, (1, 10, 26, 54)), (0x82, 5000, 300, 32, 96, 6, (10,)),
+for seed, n, d, k, b, nprobe, top_ks in [(0x81, 9000, 96, 48, 160, 8, (1, 10, 26, 48)), (0x82, 5000, 300, 32, 96, 6, (10,)),
                                          (0x83, 3000, 768, 24, 80, 5, (10, 20)),
                                          # d = 1152: the 32-query block just fits LDS; d = 1536: it does not -- the NARROW variant's 16 queries do
                                          # (round 5, fp16 shadow: 32 queries with the query block as fp16 hi ONLY up to d = 2304, 16 up to d = 4608)
@@ -56,7 +56,8 @@ for seed, n, d, k, b, nprobe, top_ks in [(0x81, 9000, 96, 48, 160, 8, (1, 10, 26
         check(ix, Q, 10, nprobe)
         total += 1
         check(ix, Q, 40, nprobe)   # wide lists (50 keys)
-        check(ix, Q, 60, nprobe)   # top_k + slack > 64 keys: stays on the ordered-chain scan
+        check(ix, Q, 54, nprobe)   # top_k + 16 keys of slack > 64: stays on the ordered-chain scan (round 6: a slack of 6 .. 15 failed the certificate too often)
+        check(ix, Q, 60, nprobe)
 # (2) uniform data: distances concentrate, many near-ties around the k-th
 X = dg.dist_u(0x91, 6000, 64)
 ix = IVFFlatIndex.build_index(40, 1, 2, X, init_indices=mg.init_draws(0x91, 1, 40, 6000))

@@ -51,9 +51,9 @@ for seed, n, d, k, metric, top_ks, nprobes in CASES:
                     for r in range(bsz):
                         oi, od = co.search_nprobe(ix.values, ix.centroids, ix.ids, Q[5 + r], top_k, np_, metric=metric)
                         assert cnt[r] == len(oi) and np.array_equal(ids[r, :len(oi)], oi) and np.array_equal(dist[r, :len(oi)].view(np.uint32), od.view(np.uint32)), (seed, top_k, np_, bsz, r)
-                if single_shadow and ix.shadow_state()["active"] and top_k + 6 <= 64:
+                if single_shadow and ix.shadow_state()["active"] and top_k + 16 <= 64:
                     assert ix.prescan_stats()["batches"] - st1["batches"] == 5
-                if single_shadow and ix.shadow_state()["active"] and top_k + 6 <= 64:
+                if single_shadow and ix.shadow_state()["active"] and top_k + 16 <= 64:
                     assert took_shadow == 12, (took_shadow, "the single queries went through the shadow scan")
                     if FORCED: assert st1["fallback_queries"] - st0["fallback_queries"] == 12   # ... and every one was re-scanned exactly
                 elif not single_shadow:

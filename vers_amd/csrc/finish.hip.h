@@ -317,27 +317,30 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(NW =
   }
   if (!flat_done) {
     constexpr int U = 4;
-    // lane j = probe j (P <= 64 on this path): the slots it wrote, and where they start in the compact order of LIVE slots.  At
-    // 8 ranks 4 of a query's 32 probes are local: 8 live slots of 64 -- one round of independent loads instead of four rounds of
-    // a count load followed by a key load each (20 of the kernel's 84 us there).
-    const uint32_t my_nq = lane < (int)a.P ? (nqp[lane] < a.S_max ? nqp[lane] : a.S_max) : 0u;
-    const uint32_t incl = wave_incl_u32(my_nq);
-    const uint32_t excl = incl - my_nq;
-    uint32_t n_live = (uint32_t)__builtin_amdgcn_readlane((int)incl, kWave - 1);
-    if (a.debug & 1024u) n_live = n_live / 8;
-    for (uint32_t i0 = 0; (uint32_t)wid + kRescoreWaves * i0 < n_live; i0 += U) {
-      uint64_t cand[U];
+    // lane j = probe c0 + j, 64 probes per chunk (nprobe <= 64: one chunk): the slots it wrote, and where they start in the compact
+    // order of the chunk's LIVE slots.  At 8 ranks 4 of a query's 32 probes are local: 8 live slots of 64 -- one round of independent
+    // loads instead of four rounds of a count load followed by a key load each (20 of the kernel's 84 us there).
+    for (uint32_t c0 = 0; c0 < a.P; c0 += kWave) {  // (block-uniform)
+      const uint32_t jp = c0 + (uint32_t)lane;
+      const uint32_t my_nq = jp < a.P ? (nqp[jp] < a.S_max ? nqp[jp] : a.S_max) : 0u;
+      const uint32_t incl = wave_incl_u32(my_nq);
+      const uint32_t excl = incl - my_nq;
+      uint32_t n_live = (uint32_t)__builtin_amdgcn_readlane((int)incl, kWave - 1);
+      if (a.debug & 1024u) n_live = n_live / 8;
+      for (uint32_t i0 = 0; (uint32_t)wid + kRescoreWaves * i0 < n_live; i0 += U) {
+        uint64_t cand[U];
 #pragma unroll
-      for (int u = 0; u < U; ++u) {
-        const uint32_t c = (uint32_t)wid + kRescoreWaves * (i0 + u);  // compact index -> (probe j, quad c - first slot of j): the last lane whose slots start at or before c
-        const uint64_t m = __ballot(my_nq != 0 && excl <= c);
-        const int j = m ? 63 - __builtin_clzll((unsigned long long)m) : 0;
-        const uint32_t e_j = (uint32_t)__builtin_amdgcn_readlane((int)excl, j);
-        const uint32_t sl = (uint32_t)j * a.S_max + (c - e_j);
-        cand[u] = (c < n_live && lane < (int)a.kp) ? keys[(uint64_t)sl * a.kp + lane] : kKeyMax;
+        for (int u = 0; u < U; ++u) {
+          const uint32_t c = (uint32_t)wid + kRescoreWaves * (i0 + u);  // compact index -> (probe j, quad c - first slot of j): the last lane whose slots start at or before c
+          const uint64_t m = __ballot(my_nq != 0 && excl <= c);
+          const int j = m ? 63 - __builtin_clzll((unsigned long long)m) : 0;
+          const uint32_t e_j = (uint32_t)__builtin_amdgcn_readlane((int)excl, j);
+          const uint32_t sl = (c0 + (uint32_t)j) * a.S_max + (c - e_j);
+          cand[u] = (c < n_live && lane < (int)a.kp) ? keys[(uint64_t)sl * a.kp + lane] : kKeyMax;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) wave_merge_sorted64(list, cand[u], lane);
       }
-#pragma unroll
-      for (int u = 0; u < U; ++u) wave_merge_sorted64(list, cand[u], lane);
     }
     block_fold(list);
   }

@@ -281,7 +281,10 @@ int32_t refresh_norms(vers_ivf* h, uint64_t r_begin, uint64_t r_end, hipStream_t
     if (full) h->rows_bf.release();
   }
   {
-    const int rm_mode = (int)opt_get("rowmajor", -1);  // default: whenever it fits (vers_ivf::rows_rm)
+    // option "rowmajor": -1 (default) = whenever it fits (vers_ivf::rows_rm) unless option "memory" is 1 (compact: ONE f32 copy of the
+    // rows -- the tiles; the exact finish then gathers its survivors from them in 16-byte pieces), 0 never, 1 always
+    const int rm_opt = (int)opt_get("rowmajor", -1);
+    const int rm_mode = rm_opt < 0 && opt_get("memory", 0) == 1 ? 0 : rm_opt;
     if (full) {
       size_t free_b = 0, total_b = 0;
       (void)hipMemGetInfo(&free_b, &total_b);
@@ -386,7 +389,10 @@ int32_t plan_storage(vers_ivf* h, const uint32_t* lens, uint32_t k, hipStream_t 
   for (uint32_t c = 0; c < k; ++c) {
     const uint32_t len = h->h_len[c];
     const bool mine = h->h_owner[c] == h->rank;
-    const uint32_t cap = mine ? round_up(len + std::max<uint32_t>(64u, len / 16u), 64u) : 0u;
+    // slack for `add` behind the list: 1/16 of its length, at least 8 rows, then up to the tile boundary the next list starts on.
+    // (Rounds 1-5 kept at least 64: at k = 65536 over 6.25M rows -- lists of ~95 rows -- that alone doubled the storage; a list
+    // that outgrows its slack is re-laid-out with 1/8 of head-room, relayout().)
+    const uint32_t cap = mine ? round_up(len + std::max<uint32_t>(8u, len / 16u), 64u) : 0u;
     h->h_off[c] = (uint32_t)off;
     h->h_cap[c] = cap;
     off += cap;

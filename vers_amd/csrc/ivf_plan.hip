@@ -685,9 +685,11 @@ int32_t plan_search(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint32_t b
   // A single query takes the shadow too (round 5, scan1h_kernel in ivf_search.hip): half the bytes of the ordered-chain scan of the
   // f32 rows, then the same exact finish.  vers_set_option("single_shadow", 0) / VERS_SCAN1H=0: the ordered-chain scan (A/B runs).
   // (its kernels stage the query in LDS: rows beyond ~36 k columns keep the scalar-operand ordered chains -- no dimension cap on this path either)
-  const bool one1_pre = one1 && single_shadow_ref().load(std::memory_order_relaxed) != 0 && use_shadow && !ref_mode && pre_mode != 0 && top_k + 6 <= kPreMaxKp &&
+  const bool one1_pre = one1 && single_shadow_ref().load(std::memory_order_relaxed) != 0 && use_shadow && !ref_mode && pre_mode != 0 && top_k + kPreMinSlack <= kPreMaxKp &&
                         (size_t)h->ld * sizeof(float) + 24576 <= 160u * 1024u;  // (the finish: the query + 8 KB of exchange area + 14 KB of static buffers)
-  const bool use_pre = one1_pre || (pre_batch && !ref_mode && pre_mode != 0 && top_k + 6 <= kPreMaxKp && P <= (uint32_t)kMaxTopK && pre_nq != 0);
+  // (any nprobe up to kPreMaxP: the work items carry (query, list) pairs; only the RANKING of more than 48 lists leaves the matrix cores
+  // -- one key per lane in the selection -- and runs exactly, 64 ranks per pass.  Rounds 1-5 sent nprobe > 64 to the ordered chains.)
+  const bool use_pre = one1_pre || (pre_batch && !ref_mode && pre_mode != 0 && top_k + kPreMinSlack <= kPreMaxKp && P <= kPreMaxP && pre_nq != 0);
   if (use_pre && !one1_pre) QG = (int)pre_nq;
   const uint32_t k_keep = use_pre ? kp : std::min<uint32_t>(top_k, kMaxTopK);
   // 64 result ranks per pass; no pass beyond the rows the index holds (top_k = 100000 on 1000 rows: 16 passes, not 1563)

@@ -355,14 +355,14 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
   // bytes: 1.52 -> 0.7 ms per 1024 queries at cfg3).  Single queries keep the f32 tile-per-block scan (scan1t_kernel: one list is
   // latency-bound, the exact finish would cost more than it saves).  VERS_REF_AS_NPROBE1=0: the ordered chains (A/B runs).
   const bool ref_as_np1 = opt_get("ref_as_nprobe1", 1) != 0;
-  if (nprobe == 0 && ref_as_np1 && out_keys == nullptr && h->world == 1 && b >= pre_min_batch_ref().load(std::memory_order_relaxed) && top_k + 6 <= kPreMaxKp &&
+  if (nprobe == 0 && ref_as_np1 && out_keys == nullptr && h->world == 1 && b >= pre_min_batch_ref().load(std::memory_order_relaxed) && top_k + kPreMinSlack <= kPreMaxKp &&
       knobs().pre_mode != 0 && h->lists_that_always_suffice(top_k) == 1)
     nprobe = 1;
   // Batches below the matrix-core scan's smallest (2 or 3 queries by default) went to one ordered-chain scan of the f32 rows per (query,
   // list) pair: 204 / 272 us at cfg3.  Since round 5 a single query on the shadow is 66 us: such a batch is its queries one after
   // the other on the stream (the per-call tables are reused in stream order, like consecutive calls on one stream).  Same results.
   if (b > 1 && b < pre_min_batch_ref().load(std::memory_order_relaxed) && nprobe != 0 && std::min<uint32_t>(nprobe, h->k) <= (uint32_t)kMaxTopK &&
-      top_k + 6 <= kPreMaxKp && knobs().pre_mode != 0 && single_shadow_ref().load(std::memory_order_relaxed) != 0 && shadow_mode() != 0 &&
+      top_k + kPreMinSlack <= kPreMaxKp && knobs().pre_mode != 0 && single_shadow_ref().load(std::memory_order_relaxed) != 0 && shadow_mode() != 0 &&
       !h->shadow_off && h->shadow_valid && h->rows_bf.p != nullptr) {
     int32_t rc = VERS_OK;  // (timed -- scan_events 2 -- like single queries: not at all; two event records per query would be 11 us of a batch of 2)
     for (uint32_t qi = 0; qi < b && rc == VERS_OK; ++qi)
@@ -717,7 +717,7 @@ int32_t flat_shadow_derive(FlatShadow& s, const float* rows_blocked, uint64_t n,
 
 bool flat_shadow_usable(const FlatShadow& s, uint64_t n, uint32_t ld, uint32_t top_k) {
   return s.rows_built == n && n != 0 && s.rows_h != nullptr && shadow_mode() != 0 && single_shadow_ref().load(std::memory_order_relaxed) != 0 &&
-         knobs().pre_mode != 0 && top_k >= 1 && top_k + 6 <= kPreMaxKp && scan1h_lds_bytes(ld) <= 64u * 1024u;
+         knobs().pre_mode != 0 && top_k >= 1 && top_k + kPreMinSlack <= kPreMaxKp && scan1h_lds_bytes(ld) <= 64u * 1024u;
 }
 
 int32_t flat_shadow_search1(FlatShadow& s, const float* rows_blocked, uint64_t n, uint32_t ld, int n_cu, const float* q_padded, uint32_t top_k,

@@ -46,6 +46,11 @@ constexpr int kPreQWide = 64;
 constexpr int kPreCtl = 64;      // entries per control array of a block (cnt | done | thr | locks | pair | sequence base)
 constexpr int kPreAux = 2;  // cache policy of the row-tile loads: 2 = nt (streamed once); same-box A/B at cfg3: -1.8 % vs default
 constexpr uint32_t kPreMaxKp = 64;  // widest list: one sorted key per lane
+// The candidate lists are one key per lane wide: kp = top_k + slack <= 64.  The certificate needs the slack: measured at cfg3 on the fp16 shadow
+// (batch 256, scripts/bench_edges.py) top_k <= 48 never failed it; top_k = 58 (slack 6) failed it for 141 of 256 queries -- every one an exact
+// re-scan, 18 k q/s where the ordered chains do 64 k.  So results wider than 48 take the ordered chains (rounds 2-5 drew the line at 58).
+constexpr uint32_t kPreMinSlack = 16;
+constexpr uint32_t kPreMaxP = 1024;  // most probed lists per query on the matrix-core scan (tables and slots grow with b x nprobe)
 
 struct PreParams {
   uint32_t ld, n_chunks, kp;
