@@ -100,7 +100,9 @@ int32_t vers_kmeans_assign(int32_t device, const float* rows, uint64_t n, uint64
                            uint64_t* out_assign, float* out_min_dist);
 /* The same on DEVICE-resident arrays (row-major, pitches in floats, multiples of 4, >= d; padding columns may hold
  * anything): out_assign_dev [n] u64 (the reference's usize), out_min_dist_dev [n] f32 or NULL.  Synchronous.  What a host
- * that streams a corpus larger than one GPU through a trained quantiser calls per chunk (cfg4: 100M rows in chunks). */
+ * that streams a corpus larger than one GPU through a trained quantiser calls per chunk (cfg4: 100M rows in chunks).
+ * The call's device scratch (centroid operands, workspaces: up to ~1 GiB at k = 65536) is kept per DEVICE between calls, under a
+ * lock (calls on one device take turns); a call with n == 0 releases it. */
 int32_t vers_kmeans_assign_dev(int32_t device, const float* rows_dev, uint64_t n, uint64_t ld_floats,
                                const float* centroids_dev, uint64_t k, uint64_t c_ld_floats, uint32_t d,
                                uint64_t* out_assign_dev, float* out_min_dist_dev);

@@ -70,6 +70,7 @@ def cfg4_rank(dev_index=0, rows=100_000_000, d=768, nlist=16384, rank=0, world=8
         torch.cuda.synchronize(); t_gen += time.perf_counter() - tg
         capi.kmeans_assign_dev(Xc.data_ptr(), m, ld, Cd.data_ptr(), nlist, d, d, A[a:].data_ptr(), device=dev_index)
     t_assign = time.perf_counter() - t0 - t_gen
+    capi.kmeans_assign_release(dev_index)   # (the quantiser's device scratch: not part of the index's footprint below)
     lens = torch.bincount(A, minlength=nlist).cpu().numpy().astype(np.uint64)
     out["assign_pass"] = {"seconds": round(t_assign, 2), "algorithmic_tflops": round(2.0 * rows * nlist * d / t_assign / 1e12, 1),
                           "generator_seconds": round(t_gen, 2)}

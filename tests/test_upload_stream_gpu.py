@@ -185,3 +185,13 @@ def test_kmeans_assign_dev_equals_host_entry():
         out = torch.zeros(n, dtype=torch.int64, device="cuda"); md = torch.zeros(n, dtype=torch.float32, device="cuda")
         capi.kmeans_assign_dev(Xd.data_ptr(), n, ld, Cd.data_ptr(), k, d, d, out.data_ptr(), md.data_ptr())
         assert np.array_equal(out.cpu().numpy().astype(np.uint64), a_ref) and np.array_equal(bits(md.cpu().numpy()), bits(m_ref))
+    # the scratch is kept per DEVICE between calls (also when another thread calls) and a call with n == 0 releases it
+    import threading
+    held, _ = capi.mem_stats()
+    t = threading.Thread(target=lambda: capi.kmeans_assign_dev(Xd.data_ptr(), n, ld, Cd.data_ptr(), k, d, d, out.data_ptr(), md.data_ptr()))
+    t.start(); t.join()
+    assert capi.mem_stats()[0] == held, "a second calling thread must reuse the device's scratch, not allocate its own"
+    assert np.array_equal(out.cpu().numpy().astype(np.uint64), a_ref)
+    capi.kmeans_assign_release()
+    assert capi.mem_stats()[0] < held
+    capi.kmeans_assign_release()   # (nothing held: a no-op)

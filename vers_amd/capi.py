@@ -237,6 +237,11 @@ def kmeans_assign_dev(rows_ptr: int, n: int, ld: int, centroids_ptr: int, k: int
                                        _vp(out_min_dist_ptr) if out_min_dist_ptr else None))
 
 
+def kmeans_assign_release(device: int = 0):
+    """frees the device scratch vers_kmeans_assign_dev keeps between calls (a call with n == 0)"""
+    check(lib().vers_kmeans_assign_dev(device, None, 0, 4, None, 0, 4, 4, None, None))
+
+
 def kmeans_update(X, assign, k: int, device: int = 0):
     X, sx = _rows(X)
     assign = np.ascontiguousarray(assign, dtype=np.uint64)

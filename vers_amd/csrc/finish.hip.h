@@ -396,8 +396,19 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(NW =
   if (s_failed) return;
   stamp(2);
   const uint32_t n_surv = s_nsurv;
-  if (a.debug & 512u) {
-    if (wid == 0) emit_topk(list, q, a.top_k, lane, pl, pp, a.P, a.list_off, a.row_ids, a.out_ids, a.out_dist, a.out_count, a.out_keys);
+  // PUBLISHER INVARIANT of a host-pointer single-query call (a.st_host != nullptr; the host spins on that pinned word and returns the
+  // moment it changes, while the fallback launch behind this kernel is still queued): exactly ONE kernel writes st_host per call --
+  // this one on every path that ends with its results in place (certified: below and at the end), fallback_kernel when the certificate
+  // failed (it returns before touching anything when nothing is queued, so a stale launch never writes under the next call's kStNotYet).
+  auto publish_status = [&]() {  // (wave 0: everything it wrote before the status word, at system scope)
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+    if (lane == 0) __hip_atomic_store(a.st_host, __hip_atomic_load(a.st_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+  };
+  if (a.debug & 512u) {  // (diagnosis: no row gather, no chains -- the approximate order goes out; published like a real result, or every such call would spin its full 2 ms)
+    if (wid == 0) {
+      emit_topk(list, q, a.top_k, lane, pl, pp, a.P, a.list_off, a.row_ids, a.out_ids, a.out_dist, a.out_count, a.out_keys);
+      if (a.st_host != nullptr) publish_status();
+    }
     return;
   }
   // exact distances of the survivors: lane per candidate, the reference's ordered chain
@@ -505,10 +516,7 @@ __global__ __launch_bounds__(kWave * NW) __attribute__((amdgpu_waves_per_eu(NW =
   }
   const uint64_t hm = __ballot(have);
   if (lane == 0) a.out_count[q] = (uint32_t)__popcll(hm);
-  if (a.st_host != nullptr) {  // (wave 0: everything it wrote above before the status word, at system scope)
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
-    if (lane == 0) __hip_atomic_store(a.st_host, __hip_atomic_load(a.st_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
-  }
+  if (a.st_host != nullptr) publish_status();
   if (a.stamps && lane == 0) {
     stamp(4);
     for (int i = 0; i < 4; ++i) atomicAdd(a.stamps + 52 + i, ts[i + 1] - ts[i]);
@@ -563,7 +571,10 @@ __global__ __launch_bounds__(kWave * kFbWaves) void fallback_kernel(RescoreArgs 
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
     __hip_atomic_store(st_host, __hip_atomic_load(st_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
   };
-  if (n_fail == 0) return;  // (a host-pointer single-query call's status word was published by the finish: RescoreArgs::st_host)
+  // PUBLISHER INVARIANT (see ivf_rescore_kernel): with nothing queued this launch must not write ANYTHING -- the finish has published the
+  // host-pointer call's status, the host may already have returned and started its next call on this workspace (memset of the pinned
+  // block, kStNotYet) while this launch is still queued.  Every store below is behind this return.
+  if (n_fail == 0) return;
   // `watch` (nullable): pinned host word the host polls to retire an fp16 shadow that fails too often; a.stats[0] is final
   // for this batch (ivf_rescore_kernel, which counts, is done) and only moves when queries were queued
   if (watch != nullptr && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(watch, a.stats[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);

@@ -9,6 +9,7 @@
 // themselves are held in lane-transposed 64-row tiles (scan.hip.h), so a list scan is one linear HBM
 // stream of contiguous 1 KiB wave loads.
 #include <chrono>
+#include <thread>
 
 #include "gemm.hip.h"
 #include "ivf_handle.hpp"
@@ -1138,8 +1139,12 @@ int32_t upload_chunk_dev_locked(vers_ivf* h, const float* rows_dev, uint64_t ld_
   return VERS_OK;
 }
 
-// Host rows: sub-chunks through ONE bounded pinned buffer.  Only the rows of the lists this rank owns are packed and cross
-// PCIe (1/W of them on a rank of W), with their vec ids; every row is counted on the host for the final check.
+// Host rows: sub-chunks through a bounded pinned buffer of TWO halves.  Only the rows of the lists this rank owns are packed and cross
+// PCIe (1/W of them on a rank of W), with their vec ids; every row is counted on the host for the final check.  While the copy engine
+// and the placement kernel work on one half (an event per half says when they are done with it) the host packs the next sub-chunk
+// into the other -- with several threads when it is large -- and the device-side `bad` word is read ONCE per chunk, at its end.
+// (Round 5 packed row by row on one thread into ONE buffer and read `bad` back after every sub-chunk: pack, H2D and placement never
+// overlapped.)
 int32_t upload_chunk_host_locked(vers_ivf* h, const float* rows, uint64_t row_stride_bytes, const uint64_t* assignments, uint64_t first_vec_id,
                                  uint64_t n) {
   if (int32_t rc = upload_chunk_args(h, "vers_ivf_upload_chunk", first_vec_id, n)) return rc;
@@ -1147,43 +1152,77 @@ int32_t upload_chunk_host_locked(vers_ivf* h, const float* rows, uint64_t row_st
   const uint32_t ldx = h->ldx, d = h->d;
   const size_t row_b = (size_t)ldx * 4;
   const size_t stage_bytes = (size_t)opt_get("upload_stage_mb", 256) << 20;
-  const uint64_t sub = std::max<uint64_t>(64, std::min<uint64_t>(n ? n : 1, stage_bytes / (row_b + 8)));
-  const size_t pin_need = sub * (row_b + 8);
-  if (up.pin_cap < pin_need) {
+  const uint64_t sub = std::max<uint64_t>(64, std::min<uint64_t>(n ? n : 1, (stage_bytes / 2) / (row_b + 8)));
+  const size_t half_b = (sub * (row_b + 8) + 255) & ~(size_t)255;
+  if (up.pin_cap < 2 * half_b) {
     if (up.pin) { (void)hipHostFree(up.pin); up.pin = nullptr; up.pin_cap = 0; }
-    VERS_HIP_TRY(hipHostMalloc(&up.pin, pin_need, hipHostMallocDefault));
-    up.pin_cap = pin_need;
+    VERS_HIP_TRY(hipHostMalloc(&up.pin, 2 * half_b, hipHostMallocDefault));
+    up.pin_cap = 2 * half_b;
   }
-  if (int32_t rc = up.stage.reserve(sub * row_b)) return rc;
-  if (int32_t rc = up.ids.reserve(sub * 4)) return rc;
-  if (int32_t rc = up.a32.reserve(sub * 4)) return rc;
-  float* p_rows = (float*)up.pin;
-  uint32_t* p_ids = (uint32_t*)((char*)up.pin + sub * row_b);
-  uint32_t* p_a = p_ids + sub;
+  if (int32_t rc = up.stage.reserve(2 * sub * row_b)) return rc;
+  if (int32_t rc = up.ids.reserve(2 * sub * 4)) return rc;
+  if (int32_t rc = up.a32.reserve(2 * sub * 4)) return rc;
+  for (auto& e : up.half_free)
+    if (!e) VERS_HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
   const bool sharded = h->world > 1;
+  std::vector<uint32_t> pos(sub);
+  bool used[2] = {false, false};
+  uint32_t turn = 0;
   for (uint64_t s0 = 0; s0 < n; s0 += sub) {
     const uint64_t m = std::min<uint64_t>(sub, n - s0);
+    const uint32_t hf = turn & 1u;
+    float* p_rows = (float*)((char*)up.pin + hf * half_b);
+    uint32_t* p_ids = (uint32_t*)((char*)p_rows + sub * row_b);
+    uint32_t* p_a = p_ids + sub;
+    // (the half is free once the copies and the placement queued from it two sub-chunks ago are done)
+    if (used[hf]) VERS_HIP_TRY(hipEventSynchronize(up.half_free[hf]));
     uint32_t packed = 0;
-    for (uint64_t i = 0; i < m; ++i) {
+    for (uint64_t i = 0; i < m; ++i) {  // which rows go, where, with which id (serial: the owned rows keep their ascending order)
       const uint64_t a = assignments[s0 + i];
-      if (a >= up.k) { upload_abandon(h); return fail(VERS_ERR_INVALID, "vers_ivf_upload_chunk: assignment out of range (the streamed upload is abandoned)"); }
+      if (a >= up.k) { (void)hipDeviceSynchronize(); upload_abandon(h); return fail(VERS_ERR_INVALID, "vers_ivf_upload_chunk: assignment out of range (the streamed upload is abandoned)"); }
       up.h_seen[a] += 1;
-      if (sharded && h->h_owner[a] != h->rank) continue;
-      float* dst = p_rows + (size_t)packed * ldx;
-      std::memcpy(dst, (const char*)rows + (s0 + i) * row_stride_bytes, (size_t)d * 4);
-      for (uint32_t j = d; j < ldx; ++j) dst[j] = 0.0f;
+      if (sharded && h->h_owner[a] != h->rank) { pos[i] = 0xFFFFFFFFu; continue; }
+      pos[i] = packed;
       p_ids[packed] = (uint32_t)(first_vec_id + s0 + i);
       p_a[packed] = (uint32_t)a;
       ++packed;
     }
-    if (packed) {
-      VERS_HIP_TRY(hipMemcpyAsync(up.stage.p, p_rows, (size_t)packed * row_b, hipMemcpyHostToDevice, nullptr));
-      VERS_HIP_TRY(hipMemcpyAsync(up.ids.p, p_ids, (size_t)packed * 4, hipMemcpyHostToDevice, nullptr));
-      VERS_HIP_TRY(hipMemcpyAsync(up.a32.p, p_a, (size_t)packed * 4, hipMemcpyHostToDevice, nullptr));
-      if (int32_t rc = upload_place(h, up.stage.as<float>(), ldx, up.a32.as<uint32_t>(), up.ids.as<uint32_t>(), 0u, packed, false, nullptr)) return rc;
-      if (int32_t rc = upload_check_bad(h, "vers_ivf_upload_chunk")) return rc;  // (also: the pinned buffer is free again)
+    auto pack = [&](uint64_t i0, uint64_t i1) {
+      for (uint64_t i = i0; i < i1; ++i) {
+        if (pos[i] == 0xFFFFFFFFu) continue;
+        float* dst = p_rows + (size_t)pos[i] * ldx;
+        std::memcpy(dst, (const char*)rows + (s0 + i) * row_stride_bytes, (size_t)d * 4);
+        for (uint32_t j = d; j < ldx; ++j) dst[j] = 0.0f;
+      }
+    };
+    const unsigned hw = std::max(1u, std::thread::hardware_concurrency());
+    const unsigned nt = (size_t)packed * row_b >= (size_t(8) << 20) ? std::min(8u, hw) : 1u;
+    if (nt > 1) {
+      std::vector<std::thread> th;
+      const uint64_t per = (m + nt - 1) / nt;
+      for (unsigned t = 1; t < nt; ++t) th.emplace_back(pack, std::min<uint64_t>(m, t * per), std::min<uint64_t>(m, (t + 1) * per));
+      pack(0, std::min<uint64_t>(m, per));
+      for (auto& t : th) t.join();
+    } else {
+      pack(0, m);
     }
+    if (packed) {
+      float* d_rows = up.stage.as<float>() + (size_t)hf * sub * ldx;
+      uint32_t* d_ids = up.ids.as<uint32_t>() + (size_t)hf * sub;
+      uint32_t* d_a = up.a32.as<uint32_t>() + (size_t)hf * sub;
+      VERS_HIP_TRY(hipMemcpyAsync(d_rows, p_rows, (size_t)packed * row_b, hipMemcpyHostToDevice, nullptr));
+      VERS_HIP_TRY(hipMemcpyAsync(d_ids, p_ids, (size_t)packed * 4, hipMemcpyHostToDevice, nullptr));
+      VERS_HIP_TRY(hipMemcpyAsync(d_a, p_a, (size_t)packed * 4, hipMemcpyHostToDevice, nullptr));
+      if (int32_t rc = upload_place(h, d_rows, ldx, d_a, d_ids, 0u, packed, false, nullptr)) return rc;
+      VERS_HIP_TRY(hipEventRecord(up.half_free[hf], nullptr));
+      used[hf] = true;
+    }
+    ++turn;
   }
+  // once per chunk (synchronises the null stream: everything is placed, both halves are free); a list that received too many rows
+  // would also be caught by the per-list counts checked in _end
+  if (n)
+    if (int32_t rc = upload_check_bad(h, "vers_ivf_upload_chunk")) return rc;
   up.seen += n;
   return VERS_OK;
 }

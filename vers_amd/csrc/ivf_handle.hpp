@@ -153,10 +153,13 @@ struct vers_ivf {
     DevBuf fill;                   // u32 [k] rows placed in every OWNED list so far | u32 [k] rows of EVERY list counted on the device
     std::vector<uint32_t> h_seen;  // rows of every list counted by the host path (it sends only the owned ones)
     DevBuf a32, sorted, ids, a64, stage, bad;  // per-chunk scratch: assignments as u32, cluster-sorted order, vec ids, staging
-    void* pin = nullptr;           // pinned staging of the host path (rows | vec ids | assignments of one sub-chunk)
+    void* pin = nullptr;           // pinned staging of the host path: TWO halves of (rows | vec ids | assignments of one sub-chunk)
     size_t pin_cap = 0;
+    hipEvent_t half_free[2] = {nullptr, nullptr};  // recorded behind the copies + placement that read a half
     void close() {
       open = false;
+      for (auto& e : half_free)
+        if (e) { (void)hipEventDestroy(e); e = nullptr; }
       fill.release(); a32.release(); sorted.release(); ids.release(); a64.release(); stage.release(); bad.release();
       h_seen.clear(); h_seen.shrink_to_fit();
       if (pin) { (void)hipHostFree(pin); pin = nullptr; pin_cap = 0; }

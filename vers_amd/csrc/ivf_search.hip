@@ -931,7 +931,9 @@ int32_t vers_ivf_search(vers_ivf_t* h, const float* queries, uint64_t q_stride_b
     W->ref_deep = attempt == 2;
     W->ref_all = attempt == 3;
     // every attempt starts from zeros: entries past a query's count must not carry a previous attempt's values
-    if (io.direct) {  // (nothing of this workspace is in flight: the previous call / attempt ended with a synchronisation)
+    if (io.direct) {  // (no kernel of this workspace that WRITES is in flight: the previous call ended with its published status or a synchronisation;
+                      // a fallback_kernel launch of that call may still be queued -- it returns before its first store when nothing was queued for it:
+                      // the publisher invariant in finish.hip.h)
       std::memset((char*)io.ids_dev - io.ids_off, 0, io.out_bytes);
       W->st_host = (uint32_t*)((char*)io.ids_dev - io.ids_off + io.st_off);
       *reinterpret_cast<volatile uint32_t*>(W->st_host) = kStNotYet;  // (the last merge launch overwrites it with the status: host_io_end spins on it)

@@ -14,6 +14,7 @@
 #include <vector>
 
 #include <chrono>
+#include <map>
 #include <mutex>
 #include <vector>
 
@@ -591,8 +592,7 @@ int32_t vers_kmeans_assign(int32_t device, const float* rows, uint64_t n, uint64
 }
 
 // assign_to_clusters (ivfflat.rs:29-46) on device-resident rows and centroids: what a host that streams a corpus larger than
-// one GPU through a trained quantiser calls per chunk.  The scratch of the matrix-core path is kept per thread between calls
-// (a streamed corpus is hundreds of calls of one shape).
+// one GPU through a trained quantiser calls per chunk.
 static __global__ void widen_assign_kernel(const uint32_t* in, uint64_t n, uint64_t* out) {
   const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) out[i] = in[i];
@@ -602,15 +602,30 @@ int32_t vers_kmeans_assign_dev(int32_t device, const float* rows_dev, uint64_t n
   if (d == 0 || (n && (!rows_dev || !out_assign_dev)) || (k && !centroids_dev) || ld_floats < d || ld_floats % 4 || ld_floats > 0x3FFFFFFFull ||
       (k && c_ld_floats < d) || n > 0xFFFFFFFFull || k > 0xFFFFFFFFull)
     return fail(VERS_ERR_INVALID, "vers_kmeans_assign_dev: bad arguments (ld_floats must be >= d and a multiple of 4)");
-  if (n == 0) return VERS_OK;
+  // The scratch of the matrix-core path (centroid operands, up to ~1 GiB of query blocks and GEMM workspaces at k = 65536) is kept PER DEVICE
+  // between calls -- a streamed corpus is hundreds of calls of one shape -- under a mutex: calls on one device take turns (they use the null
+  // stream and end with a device synchronisation anyway).  A call with n == 0 RELEASES the device's scratch (rounds 4-5 kept one per calling
+  // THREAD and never freed it: a host streaming from a pool of worker threads leaked that much HBM per thread, inside vers_mem_stats' figure).
+  struct Scratch { KMeansScratch ws; DevBuf C, A, M; };
+  static std::mutex mu;
+  static std::map<int, Scratch*> per_device;  // (never destroyed at exit: DevBuf's destructor must not run after the runtime is gone)
+  std::lock_guard<std::mutex> lk(mu);
+  if (n == 0) {
+    auto it = per_device.find(device);
+    if (it != per_device.end()) {
+      DeviceGuard g0(device);
+      delete it->second;
+      per_device.erase(it);
+    }
+    return VERS_OK;
+  }
   if (k == 0) return fail(VERS_ERR_EMPTY, "min_by over zero centroids (reference: unwrap on None)");
   int n_cu = 0;
   if (int32_t rc = device_cus(device, &n_cu)) return rc;
   DeviceGuard g(device);
   const uint32_t ld = round_up(d, 4);
-  struct Scratch { KMeansScratch ws; DevBuf C, A, M; int device = -1; };
-  static thread_local Scratch* s = nullptr;  // (never freed before the thread ends: DevBuf's destructor must not run after the runtime is gone)
-  if (s == nullptr || s->device != device) { delete s; s = new Scratch(); s->device = device; }
+  Scratch*& s = per_device[device];
+  if (s == nullptr) s = new Scratch();
   const size_t cbytes = (size_t)k * ld * sizeof(float);
   if (int32_t rc = s->C.reserve(cbytes)) return rc;
   if (int32_t rc = s->A.reserve(n * sizeof(uint32_t))) return rc;
