@@ -823,7 +823,7 @@ def main():
         # batches of 2 - 3 (below pre_min_batch: consecutive single queries on the shadow since round 5; one ordered-chain scan per (query, list) pair before).  Correctness of these shapes is
         # tests/test_limits_gpu.py's; here: what they cost.
         edges = {}
-        for name, (bsz, tk, npb) in {"top_k_64": (min(B, 256), 64, nprobe), "top_k_100": (min(B, 256), 100, nprobe), "nprobe_128": (min(B, 256), top_k, min(128, nlist)), "nprobe_256": (min(B, 256), top_k, min(256, nlist)),
+        for name, (bsz, tk, npb) in {"top_k_64": (min(B, 256), 64, nprobe), "top_k_100": (min(B, 256), 100, nprobe), "top_k_128": (min(B, 256), 128, nprobe), "top_k_200": (min(B, 256), 200, nprobe), "nprobe_128": (min(B, 256), top_k, min(128, nlist)), "nprobe_256": (min(B, 256), top_k, min(256, nlist)),
                                       "batch_2": (2, top_k, nprobe), "batch_3": (3, top_k, nprobe)}.items():
             if bsz > B or npb < 1:
                 continue
@@ -840,7 +840,7 @@ def main():
             edges[name] = {"batch": bsz, "top_k": tk, "nprobe": npb, "us_per_batch": round(dt_ * 1e6, 1), "queries_per_sec": round(bsz / dt_, 1),
                            "list_scan": ("matrix cores + exact finish" if index.prescan_stats()["batches"] - pb0 == nst else
                                          "consecutive single queries on the fp16 shadow (scan1h_kernel) + exact finish" if index.prescan_stats()["batches"] - pb0 == nst * bsz else "ordered chains")}
-        extra["domain_edges"] = {"workload": "the headline's index, one batch in flight; shapes at and beyond the matrix-core scan's domain (top_k <= 58, nprobe <= 64, batch >= 4)", "by_shape": edges}
+        extra["domain_edges"] = {"workload": "the headline's index, one batch in flight; shapes at the edges of the matrix-core scan's domain (one key per lane up to top_k = 48, four per lane up to 200; nprobe <= 1024; batch >= 4)", "by_shape": edges}
         log("[bench] domain edges: " + ", ".join(f"{k_}: {v_['queries_per_sec'] / 1e3:.1f} k q/s ({v_['list_scan']})" for k_, v_ in edges.items()))
         # (a3) d = 1536 -- a dimension the reference's own bindings instantiate (vers-py/src/lib.rs:26-65).  A 32-query block with both
         # halves of the query's fp16 hi + lo split does not fit LDS there (196 KB); round 4 ran 16-query blocks (every list probed by

@@ -337,6 +337,8 @@ int32_t vers_ivf_build_sharded_dev(vers_ivf_t* h, const float* rows_dev, uint64_
  *   "coarse" (0)        1 = the batched coarse quantiser always exact, 2 = every coarse certificate fails.
  *   "assign" (0)        k-means assign: 1 = never on the matrix cores, 2 = always (default: from 1e11 flop per pass).
  *   "pre_narrow" (0), "pre_wide" (1), "pre_hi_only" (0)   the list scan's query-block width (16 / 64 queries) and fp16 hi-only query blocks.
+ *   "wide_k" (1)        results of 49 .. 200 keys (batches, nprobe >= 1) stay on the matrix-core list scan with candidate lists four keys
+ *                       per lane wide; 0 = the ordered chains, 64 ranks per pass.
  *   "coarse1" (1), "scan1t" (1), "ref_as_nprobe1" (1), "assign_tiles" (1), "assign_tiles_min" (64), "seg_rows" (0), "pre_slack" (0),
  *   "upload_stage_mb" (256)   kernel-choice and sizing knobs of DESIGN.md section 5.
  *   "scan_debug" (0), "poison_alloc" (-1), "poison_slack_bits" (-1), "test_fail_sharded" (0)   diagnosis: phase stamps / skipped

@@ -37,6 +37,10 @@ int32_t vers_test_standin_gather(vers_gather_t* out, uint32_t rank, uint32_t wor
  * (bitonic network); out[512 ..] = the same by rank counting; out[576 ..] = the 64 smallest of in[0..127], ascending (two sorted
  * halves merged).  640 words out. */
 int32_t vers_test_wave_net(int32_t device, const uint64_t* in, uint64_t* out);
+/* TEST HOOK: the four-keys-per-lane networks of the wide candidate lists (wide.hip.h) on 512 host keys, one wave on `device`:
+ * out[0..255] = in[0..255] sorted ascending, out[256..511] = in[256..511] sorted (the rolled rank sorts), out[512..767] = the 256 smallest
+ * of the union, ascending; out[768..770] = elements 0, 77, 255 of that list as wide_get reads them.  771 words out. */
+int32_t vers_test_wide_net(int32_t device, const uint64_t* in, uint64_t* out);
 #ifdef __cplusplus
 }
 #endif

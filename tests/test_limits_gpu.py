@@ -70,6 +70,49 @@ def test_many_probes_run_on_the_matrix_cores():
     ix.close()
 
 
+def test_wide_results_run_on_the_matrix_cores():
+    """top_k in (48, 200]: candidate lists four keys per lane wide (wide.hip.h) through the matrix-core list scan's compactions and the
+    exact finish (finish_wide.hip.h) -- rounds 1-5 sent these to the ordered chains, 64 ranks per pass.  Against the oracle bit for bit; with
+    every certificate failing the exact re-scan emits 64 ranks per pass inside fallback_kernel; top_k = 201 stays on the ordered chains."""
+    n, d, k = 30000, 64, 120
+    X = dg.dist_c(0x731, n, d, 500, dg.default_sigma(d))
+    X[300:420] = X[13]                                   # 121 identical rows: ties across every boundary, decided by list position
+    ix = IVFFlatIndex.build_index(k, 1, 3, X, init_indices=mg.init_draws(0x731, 1, k, n))
+    Q = dg.dist_c(0x732, 72, d, 500, dg.default_sigma(d)); Q[9] = X[13]; Q[10] = X[13] * np.float32(1.0001)
+    try:
+        for mode in (1, 2):
+            capi.set_option("prescan", mode)
+            if mode == 2:   # (a fresh handle: a shadow that fails more than 1/8 of >= 256 queries retires itself, and the wide lists live on it)
+                ix.close()
+                ix = IVFFlatIndex.build_index(k, 1, 3, X, init_indices=mg.init_draws(0x731, 1, k, n))
+            shapes = ((49, 8), (64, 8), (65, 8), (100, 8), (128, 16), (200, 8), (100, 100), (150, 1)) if mode == 1 else ((65, 8), (128, 16), (200, 8))
+            for top_k, nprobe in shapes:
+                st0 = ix.prescan_stats()
+                check(ix, Q, top_k, nprobe, range(0, 72, 5))
+                st1 = ix.prescan_stats()
+                assert st1["batches"] - st0["batches"] == 1, (mode, top_k, nprobe)
+                assert (st1["fallback_queries"] - st0["fallback_queries"] == 72) == (mode == 2), (mode, top_k, nprobe, st0, st1)
+            st0 = ix.prescan_stats()
+            check(ix, Q, 201, 8, range(0, 72, 9))
+            assert ix.prescan_stats()["batches"] == st0["batches"]
+        capi.set_option("prescan", 1)
+        capi.set_option("wide_k", 0)                      # the ordered chains again: same results
+        st0 = ix.prescan_stats()
+        check(ix, Q, 100, 8, range(0, 72, 9))
+        assert ix.prescan_stats()["batches"] == st0["batches"]
+    finally:
+        capi.set_option("prescan", 1); capi.set_option("wide_k", 1)
+    # a long-row index: the 16-query hi-only blocks carry the wide lists too
+    n2, d2, k2 = 3000, 1536, 10
+    X2 = dg.dist_c(0x733, n2, d2, 40, dg.default_sigma(d2))
+    ix2 = IVFFlatIndex.build_index(k2, 1, 2, X2, init_indices=mg.init_draws(0x733, 1, k2, n2))
+    Q2 = dg.dist_c(0x734, 24, d2, 40, dg.default_sigma(d2))
+    st0 = ix2.prescan_stats()
+    check(ix2, Q2, 100, 4, range(0, 24, 3))
+    assert ix2.prescan_stats()["batches"] - st0["batches"] == 1
+    ix.close(); ix2.close()
+
+
 def test_reference_spill_through_more_than_64_empty_lists():
     """k = 150 centroids of which 140 are duplicates of one row -> their lists are empty (ties go to the lowest index) and
     ALL rank ahead of the far lists for queries near that row: the walk of ivfflat.rs:166-195 crosses > 64 empty lists."""

@@ -579,7 +579,11 @@ __global__ __launch_bounds__(kWave * kFbWaves) void fallback_kernel(RescoreArgs 
   // for this batch (ivf_rescore_kernel, which counts, is done) and only moves when queries were queued
   if (watch != nullptr && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_store(watch, a.stats[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   uint32_t G = 1;
-  while (G < 64u && 2u * G * n_fail <= gridDim.x) G *= 2u;
+  // Results wider than one key per lane (the wide finish, finish_wide.hip.h: top_k in (64, 200]) come 64 ranks per PASS here: a pass
+  // needs the previous one's last key (ScanParams::lower), which only a block that folds its own slot has at hand -- a block per
+  // queued query (G = 1), no cross-block waiting as everywhere else in this kernel.
+  const bool wide = a.top_k > (uint32_t)kMaxTopK;
+  while (!wide && G < 64u && 2u * G * n_fail <= gridDim.x) G *= 2u;
   const uint32_t n_groups = gridDim.x / G;
   const uint32_t gidx = blockIdx.x / G, g = blockIdx.x % G;
   const uint32_t C = (G + a.P - 1) / a.P, chunks = a.P * C;
@@ -590,7 +594,62 @@ __global__ __launch_bounds__(kWave * kFbWaves) void fallback_kernel(RescoreArgs 
   uint64_t* slot = fb_part + (uint64_t)gidx * chunks * kFbWaves * a.top_k;  // the group's chunks x 8 partial lists
   uint32_t* arrived = ctr + 2 * gidx;
   uint32_t round = 0;
-  if (gidx < n_groups) {
+  __shared__ uint64_t s_lower;
+  if (wide && gidx < n_groups) {  // (G == 1: gidx = blockIdx.x, chunks = P, the slot is this block's own)
+    for (uint32_t i = gidx; i < n_fail; i += n_groups) {
+      const uint32_t q = fail_list[i];
+      const uint32_t* pl = a.pj_list + (uint64_t)q * a.P;
+      const uint32_t* pp = a.pj_pref + (uint64_t)q * a.P;
+      uint32_t emitted = 0;
+      for (uint32_t rank0 = 0; rank0 < a.top_k; rank0 += (uint32_t)kMaxTopK) {  // (block-uniform)
+        const uint32_t k_pass = a.top_k - rank0 < (uint32_t)kMaxTopK ? a.top_k - rank0 : (uint32_t)kMaxTopK;
+        p.k = k_pass;
+        p.lower = rank0 ? &s_lower : nullptr;  // (keys at or below the previous pass's last one are dropped: exactly ranks rank0 .. rank0 + 63 remain)
+        for (uint32_t j = 0; j < a.P; ++j) {
+          uint64_t* out = slot + ((uint64_t)j * kFbWaves + wid) * k_pass;
+          const uint32_t Lj = pl[j];
+          uint32_t len = 0, t0 = 0, t1 = 0;
+          if (Lj != 0xFFFFFFFFu) {
+            len = list_len[Lj];
+            const uint32_t n_tiles = (len + kWave - 1) / kWave, per = (n_tiles + kFbWaves - 1) / kFbWaves;
+            t0 = (uint32_t)wid * per < n_tiles ? (uint32_t)wid * per : n_tiles;
+            t1 = t0 + per < n_tiles ? t0 + per : n_tiles;
+          }
+          if (t1 <= t0) {
+            if (lane < (int)k_pass) out[lane] = kKeyMax;
+            continue;
+          }
+          ItemView<1> v;
+          v.rows = a.rows + ((uint64_t)a.list_off[Lj] + (uint64_t)t0 * kWave) * a.ld;
+          v.nrows = (t1 * kWave < len ? t1 * kWave : len) - t0 * kWave;
+          v.nq = 1;
+          v.qb = a.qp + (uint64_t)q * a.ldq;
+          FbSrc src;
+          src.out_ptr = out;
+          src.seq0 = pp[j] + t0 * kWave;
+          if (a.metric == 0) scan_item<1, 1, 0>(src, p, 0u, v, lane, nan_seen);
+          else scan_item<1, 1, 1>(src, p, 0u, v, lane, nan_seen);
+        }
+        __threadfence();  // this pass's partial lists before anybody of the block reads them back (the slot's lines may sit in the L1 from the pass before)
+        __syncthreads();
+        const uint64_t list = block_merge_keys<kFbWaves>(slot, a.P * kFbWaves * k_pass, k_pass, sh);
+        if (threadIdx.x < kWave) {
+          const bool have = lane < (int)k_pass && list != kKeyMax;
+          const uint64_t o = (uint64_t)q * a.top_k + rank0 + (uint32_t)lane;
+          if (lane < (int)k_pass && a.out_keys) a.out_keys[o] = have ? list : kKeyMax;
+          const uint32_t row = wave_seq_rows(list, have, lane, pl, pp, a.P, a.list_off);
+          if (have) {
+            a.out_ids[o] = a.row_ids[row];
+            a.out_dist[o] = __uint_as_float(order_bits_to_f32_bits((uint32_t)(list >> 32)));
+          }
+          emitted += (uint32_t)__popcll(__ballot(have));
+          if (lane == (int)k_pass - 1) s_lower = list;  // (kKeyMax when the rows ran out: the next pass finds nothing)
+        }
+        __syncthreads();  // s_lower, and the slot is free for the next pass
+      }
+      if (threadIdx.x == 0) a.out_count[q] = emitted;
+    }
+  } else if (gidx < n_groups) {
     for (uint32_t i = gidx; i < n_fail; i += n_groups, ++round) {
       const uint32_t q = fail_list[i];
       for (uint32_t u = g; u < chunks; u += G) {

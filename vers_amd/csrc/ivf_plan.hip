@@ -655,6 +655,13 @@ int32_t plan_search(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint32_t b
   // (fp16 rows: the window is ~2x the f32 one.  At cfg3 a slack of 10 left ~0.5 of 1024 queries per batch uncertified, 16 none)
   if (use_shadow) kp = std::min<uint32_t>(kPreMaxKp, top_k + std::max<uint32_t>(24, top_k));
   if (knobs().pre_slack > 0) kp = std::min<uint32_t>(kPreMaxKp, top_k + (uint32_t)knobs().pre_slack);  // tuning knob
+  // Results wider than one key per lane leaves room for (top_k + 16 > 64), up to kWideMaxKp - 32 = 200 keys: WIDE candidate lists, four keys
+  // per lane through the scan's compactions and the finish (wide.hip.h, finish_wide.hip.h), on the fp16 shadow with hi-only query blocks
+  // (round 6; until then the ordered chains, 64 ranks per pass over the f32 rows: 64 k q/s at top_k = 64, 32 k at 100, batch 256, cfg3).
+  // Option "wide_k" = 0: the ordered chains (A/B runs).
+  constexpr uint32_t kWideSlack = 32;
+  const bool wide_k = !ref_mode && b > 1 && use_shadow && top_k + kPreMinSlack > kPreMaxKp && top_k + kWideSlack <= kWideMaxKp && opt_get("wide_k", 1) != 0;
+  if (wide_k) kp = top_k + kWideSlack;
   // The block's query operand must fit LDS next to the candidate buffers: 32 queries up to d = 1152; the NARROW variant's 16 up
   // to d = 2304 (d = 1536 -- a dimension the reference's own bindings instantiate, vers-py/src/lib.rs:26-65 -- went to the
   // ordered-chain scan until round 4, ~3x slower).  VERS_PRE_NARROW=1 forces the narrow blocks (tests, A/B).
@@ -671,7 +678,11 @@ int32_t plan_search(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint32_t b
     // 64 queries per block (two sets of 32, hi-only) wherever they fit -- d <= 960 with the default slack --: lists probed by 33 .. 64
     // queries of the batch are then streamed once instead of twice (VERS_PRE_WIDE=0: the 32-query hi + lo blocks of rounds 2-4)
     const bool wide_on = opt_get("pre_wide", 1) != 0;
-    if (!narrow && wide_on && use_shadow && fits(kPreQWide, true)) { pre_nq = kPreQWide; pre_hi_only = true; }
+    if (wide_k) {  // (256-key buffers: 64 KB for 32 queries next to a hi-only query block)
+      if (!narrow && fits(kPreQ, true)) { pre_nq = kPreQ; pre_hi_only = true; }
+      else if (fits(kPreQNarrow, true)) { pre_nq = kPreQNarrow; pre_hi_only = true; }
+    }
+    else if (!narrow && wide_on && use_shadow && fits(kPreQWide, true)) { pre_nq = kPreQWide; pre_hi_only = true; }
     else if (!narrow && !(force_hi && use_shadow) && fits(kPreQ, false)) pre_nq = kPreQ;
     else if (!narrow && use_shadow && fits(kPreQ, true)) { pre_nq = kPreQ; pre_hi_only = true; }
     else if (!(force_hi && use_shadow) && fits(kPreQNarrow, false)) pre_nq = kPreQNarrow;
@@ -689,7 +700,7 @@ int32_t plan_search(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint32_t b
                         (size_t)h->ld * sizeof(float) + 24576 <= 160u * 1024u;  // (the finish: the query + 8 KB of exchange area + 14 KB of static buffers)
   // (any nprobe up to kPreMaxP: the work items carry (query, list) pairs; only the RANKING of more than 48 lists leaves the matrix cores
   // -- one key per lane in the selection -- and runs exactly, 64 ranks per pass.  Rounds 1-5 sent nprobe > 64 to the ordered chains.)
-  const bool use_pre = one1_pre || (pre_batch && !ref_mode && pre_mode != 0 && top_k + kPreMinSlack <= kPreMaxKp && P <= kPreMaxP && pre_nq != 0);
+  const bool use_pre = one1_pre || (pre_batch && !ref_mode && pre_mode != 0 && (top_k + kPreMinSlack <= kPreMaxKp || wide_k) && P <= kPreMaxP && pre_nq != 0);
   if (use_pre && !one1_pre) QG = (int)pre_nq;
   const uint32_t k_keep = use_pre ? kp : std::min<uint32_t>(top_k, kMaxTopK);
   // 64 result ranks per pass; no pass beyond the rows the index holds (top_k = 100000 on 1000 rows: 16 passes, not 1563)

@@ -10,6 +10,7 @@
 #include "flat_shadow.hpp"
 #include "ivf_src.hip.h"
 #include "single.hip.h"
+#include "finish_wide.hip.h"
 
 namespace vers {
 
@@ -308,8 +309,12 @@ int32_t launch_prescan(vers_ivf* h, const IvfSrc<NQ>& src, uint32_t items_bound,
   hi_only = hi_only && shadow;
   if (NQ == kPreQWide && !hi_only) return fail(VERS_ERR_INVALID, "internal: 64-query blocks exist on the fp16 shadow with the hi-only query block");
   const size_t lds = prescan_lds_bytes_g(h->ld, kp, NQ, hi_only);
+  const bool wide_lists = kp > kPreMaxKp;  // (candidate lists of more than one key per lane: plan_search chose hi-only blocks of 32 or 16 queries on the shadow)
+  if (wide_lists && (!hi_only || NQ == kPreQWide || kp > kWideMaxKp)) return fail(VERS_ERR_INVALID, "internal: wide candidate lists need the fp16 shadow with hi-only query blocks of <= 32 queries");
   if constexpr (NQ == kPreQWide) {
     if (int32_t rc = scan_prepare_launch(prescan_kernel_g<true, NQ, IvfSrc<NQ>, false>, lds)) return rc;
+  } else if (wide_lists) {
+    if (int32_t rc = scan_prepare_launch(prescan_kernel_g<true, NQ, IvfSrc<NQ>, false, true>, lds)) return rc;
   } else {
     if (int32_t rc = hi_only ? scan_prepare_launch(prescan_kernel_g<true, NQ, IvfSrc<NQ>, false>, lds)
                      : shadow ? scan_prepare_launch(prescan_kernel_g<true, NQ, IvfSrc<NQ>>, lds) : scan_prepare_launch(prescan_kernel_g<false, NQ, IvfSrc<NQ>>, lds)) return rc;
@@ -324,6 +329,8 @@ int32_t launch_prescan(vers_ivf* h, const IvfSrc<NQ>& src, uint32_t items_bound,
   if (W->ev_on) VERS_HIP_TRY(hipEventRecord(W->ev0[slot], st));
   if constexpr (NQ == kPreQWide) {
     hipLaunchKernelGGL((prescan_kernel_g<true, NQ, IvfSrc<NQ>, false>), dim3(blocks), dim3(kWave * kPreWavesG), lds, st, src, p);
+  } else if (wide_lists) {
+    hipLaunchKernelGGL((prescan_kernel_g<true, NQ, IvfSrc<NQ>, false, true>), dim3(blocks), dim3(kWave * kPreWavesG), lds, st, src, p);
   } else {
     if (hi_only) hipLaunchKernelGGL((prescan_kernel_g<true, NQ, IvfSrc<NQ>, false>), dim3(blocks), dim3(kWave * kPreWavesG), lds, st, src, p);
     else if (shadow) hipLaunchKernelGGL((prescan_kernel_g<true, NQ, IvfSrc<NQ>>), dim3(blocks), dim3(kWave * kPreWavesG), lds, st, src, p);
@@ -425,7 +432,11 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
     const int rs_waves = one1_pre ? kRescoreWaves1 : kRescoreWaves;  // (one query: sixteen waves merge its ~250 slots and walk its survivors' chains in one pass)
     const int stage_rows = rescore_lds_bytes(h->ld, true, rs_waves) <= 144u * 1024u ? 1 : 0;
     const size_t rs_lds = rescore_lds_bytes(h->ld, stage_rows != 0, rs_waves);
-    if (one1_pre) {
+    if (kp > kPreMaxKp) {  // wide candidate lists (results of 49 .. 200 keys): four keys per lane through the finish (finish_wide.hip.h)
+      const size_t w_lds = rescore_wide_lds_bytes(h->ld);
+      if (int32_t rc2 = scan_prepare_launch(ivf_rescore_wide_kernel, w_lds)) return rc2;
+      hipLaunchKernelGGL(ivf_rescore_wide_kernel, dim3(b), dim3(kWave * kWideWaves), w_lds, st, a);
+    } else if (one1_pre) {
       if (int32_t rc2 = scan_prepare_launch(ivf_rescore_kernel<kRescoreWaves1>, rs_lds)) return rc2;
       hipLaunchKernelGGL(ivf_rescore_kernel<kRescoreWaves1>, dim3(b), dim3(kWave * kRescoreWaves1), rs_lds, st, a, stage_rows);
     } else {

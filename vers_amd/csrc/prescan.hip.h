@@ -30,6 +30,7 @@
 
 #include "plan.hip.h"
 #include "scan.hip.h"
+#include "wide.hip.h"
 
 namespace vers {
 
@@ -161,7 +162,8 @@ static_assert(kPreWavesG % 4 == 0 && kPreWavesG >= 4 && kPreWavesG <= 16, "a qua
 // Candidate buffer of a query in LDS: `cap` unsorted keys.  kp <= 40 (top_k <= 30 with the default slack): 64 keys, one
 // wave-wide bitonic sort compacts it; wider lists: 128 keys (two sorts + a bitonic merge).  At least 24 free slots after
 // every compaction.
-__host__ __device__ inline uint32_t pre_cap(uint32_t kp) { return kp <= 40u ? 64u : 128u; }
+// WIDE lists (round 6: kp in (64, kWideMaxKp], results of 49 .. 200 keys): 256 keys, a four-register sort (wide.hip.h).
+__host__ __device__ inline uint32_t pre_cap(uint32_t kp) { return kp <= 40u ? 64u : (kp <= 64u ? 128u : 256u); }
 // nq = queries per block: kPreQ (32), or 16 -- the NARROW variant for rows too long for a 32-query block (d = 1536: 196 KB
 // against the CU's 160 KB of LDS; 16 queries fit up to d = 2304).  Same kernel, same MFMA (half its query columns idle).
 // hi_only: the fp16 query block WITHOUT its lo half (2 B per element instead of 4): 32 queries fit up to d = 2304, 16 up to
@@ -210,7 +212,8 @@ __device__ __forceinline__ uint64_t buffer_sorted(const uint64_t* bq, uint32_t n
 // probed by more than 16 queries streamed again per extra group: 2.15x the union's bytes at d = 1536) and half the MFMAs; what the
 // dropped half would have contributed, |<x~, q' - fp16(q')>| <= |x~| |q' - fp16(q')|, is charged to the certificate with the query's
 // MEASURED residual (ivf_rescore_kernel sums it next to |q|^2).
-template <bool BF, int NQ, bool LO, class Src, class Stage>
+// WIDE: candidate lists of more than one key per lane (kp in (64, kWideMaxKp], cap 256): the compaction is a four-register sort.
+template <bool BF, int NQ, bool LO, bool WIDE, class Src, class Stage>
 __device__ __forceinline__ void prescan_item_g(const Src& src, const PreParams& p, uint32_t it, const ItemView<NQ>& v, int half, int lane,
                                                const float* qm, uint64_t* cbuf, uint32_t* ctl, Stage&& stage) {
   const uint32_t n_tiles = (v.nrows + kWave - 1) / kWave;
@@ -377,7 +380,17 @@ __device__ __forceinline__ void prescan_item_g(const Src& src, const PreParams& 
             while ((uint32_t)__builtin_amdgcn_readfirstlane((int)__hip_atomic_load(done + qq, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP)) != cap)
               __builtin_amdgcn_s_sleep(1);
             uint32_t kb;
-            if (cap == (uint32_t)kWave) {
+            if constexpr (WIDE) {
+              // 256 keys, four per lane: sorted across the registers (wide.hip.h), the kp smallest go back in order
+              uint64_t wk[kWideR];
+#pragma unroll
+              for (int r = 0; r < kWideR; ++r) wk[r] = bqq[r * kWave + lane];
+              wide_sort<true>(wk, lane);
+#pragma unroll
+              for (int r = 0; r < kWideR; ++r)
+                if ((uint32_t)(r * kWave + lane) < kp) bqq[r * kWave + lane] = wk[r];
+              kb = (uint32_t)(wide_get(wk, kp - 1u) >> 32);  // cap keys >= kp: always a real key
+            } else if (cap == (uint32_t)kWave) {
               // A full 64-key buffer, one key per lane: the kp smallest by RANK COUNTING -- rank = how many of the 64 keys are
               // smaller (keys are unique: (val, seq)), 64 x (two v_readlane, one 64-bit compare, one add), no LDS round trips --
               // instead of a bitonic sort through ds_bpermute (21 dependent stages of two permutes: ~3x the cycles, all of them
@@ -580,10 +593,11 @@ __device__ __forceinline__ void prescan_item_g(const Src& src, const PreParams& 
   if (stamp && lane == 0) atomicAdd(p.stamps + 11, __builtin_amdgcn_s_memtime() - te0);
 }
 
-template <bool BF, int NQ, class Src, bool LO = true>
+template <bool BF, int NQ, class Src, bool LO = true, bool WIDE = false>
 __global__ __launch_bounds__(kWave * kPreWavesG) __attribute__((amdgpu_waves_per_eu(kPreWpe, kPreWpe))) void prescan_kernel_g(Src src, PreParams p) {
   static_assert(NQ == kPreQ || NQ == kPreQNarrow || (NQ == kPreQWide && BF && !LO), "32 queries per block, the narrow variant's 16, or 64 with the hi-only block on the shadow");
   static_assert(BF || LO, "the hi-only query block belongs to the fp16 shadow");
+  static_assert(!WIDE || (BF && !LO && NQ <= kPreQ), "wide lists: fp16 shadow, hi-only query blocks of 32 or 16 queries (256 keys x 32 queries = 64 KB of buffers)");
   const int lane = threadIdx.x & 63;
   const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   extern __shared__ __attribute__((aligned(16))) float qlds[];
@@ -608,6 +622,25 @@ __global__ __launch_bounds__(kWave * kPreWavesG) __attribute__((amdgpu_waves_per
     if (run_first == 0xFFFFFFFFu) return;
     for (uint32_t qi = (uint32_t)wid; qi < prev_nq; qi += kPreWavesG) {  // a wave per query
       const uint32_t cv = ctl[qi];
+      if constexpr (WIDE) {  // up to 256 keys -> ascending over four registers; slot entry e = register e / 64 of lane e % 64
+        const uint32_t nv = cv < cap ? cv : cap;
+        const uint64_t* bq = buf + (size_t)qi * cap;
+        uint64_t wk[kWideR];
+#pragma unroll
+        for (int r = 0; r < kWideR; ++r) wk[r] = (uint32_t)(r * kWave + lane) < nv ? bq[r * kWave + lane] : kKeyMax;
+        wide_sort<true>(wk, lane);
+#pragma unroll
+        for (int r = 0; r < kWideR; ++r) {
+          const uint32_t e = (uint32_t)(r * kWave + lane);
+          if (e < p.kp) {
+            src.out_quad(run_first * 4, (int)qi)[e] = wk[r];
+            for (uint32_t b = run_first + 1; b <= run_last; ++b) src.out_quad(b * 4, (int)qi)[e] = kKeyMax;
+          }
+        }
+        const uint64_t lastk = wide_get(wk, p.kp - 1u);
+        if (lane == 0 && lastk != kKeyMax && !(p.debug & 8192u)) atomicMin(p.bounds32 + src.bound_slot(run_first * 4, (int)qi), (uint32_t)(lastk >> 32));
+        continue;
+      }
       const uint64_t srt = buffer_sorted(buf + (size_t)qi * cap, cv < cap ? cv : cap, cap, lane);
       if (lane < (int)p.kp) {
         src.out_quad(run_first * 4, (int)qi)[lane] = srt;
@@ -707,10 +740,10 @@ __global__ __launch_bounds__(kWave * kPreWavesG) __attribute__((amdgpu_waves_per
       }
     };
     if (cont) {  // same query block, same buffers: nothing to stage, nothing to wait for
-      prescan_item_g<BF, NQ, LO>(src, p, it, v, wid >> 2, lane, qlds, buf, ctl, [] {});
+      prescan_item_g<BF, NQ, LO, WIDE>(src, p, it, v, wid >> 2, lane, qlds, buf, ctl, [] {});
       run_last = bi;
     } else {
-      prescan_item_g<BF, NQ, LO>(src, p, it, v, wid >> 2, lane, qlds, buf, ctl, stage);
+      prescan_item_g<BF, NQ, LO, WIDE>(src, p, it, v, wid >> 2, lane, qlds, buf, ctl, stage);
       run_first = run_last = bi;
       cur_list = d0.list; cur_group = d0.group;
       prev_nq = v.nq;

@@ -3,6 +3,7 @@
 // functions (default symbol visibility), so a handle made by libvers_hip.so is what they take.
 #include "../ivf_handle.hpp"
 #include "../prescan.hip.h"
+#include "../wide.hip.h"
 #include "../../../include/vers_hip_test.h"
 
 
@@ -76,6 +77,41 @@ __global__ __launch_bounds__(kWave) void wave_net_test_kernel(const uint64_t* in
   out[9 * kWave + lane] = s0;
 }
 }  // namespace vers
+
+namespace vers {
+__global__ __launch_bounds__(kWave) void wide_net_test_kernel(const uint64_t* in, uint64_t* out) {
+  const int lane = threadIdx.x;
+  uint64_t a[kWideR], b[kWideR];
+#pragma unroll
+  for (int r = 0; r < kWideR; ++r) { a[r] = in[r * kWave + lane]; b[r] = in[kWideKeys + r * kWave + lane]; }
+  wide_sort(a, lane);
+  wide_sort<true>(b, lane);
+#pragma unroll
+  for (int r = 0; r < kWideR; ++r) { out[r * kWave + lane] = a[r]; out[kWideKeys + r * kWave + lane] = b[r]; }
+  wide_merge_sorted(a, b, lane);
+#pragma unroll
+  for (int r = 0; r < kWideR; ++r) out[2 * kWideKeys + r * kWave + lane] = a[r];
+  if (lane == 0) { out[3 * kWideKeys] = wide_get(a, 0); out[3 * kWideKeys + 1] = wide_get(a, 77); out[3 * kWideKeys + 2] = wide_get(a, 255); }
+}
+}  // namespace vers
+
+extern "C" int32_t vers_test_wide_net(int32_t device, const uint64_t* in, uint64_t* out) {
+  if (!in || !out) return fail(VERS_ERR_INVALID, "vers_test_wide_net: null argument");
+  DeviceGuard g(device);
+  const size_t n_in = 2 * kWideKeys, n_out = 3 * kWideKeys + 3;
+  uint64_t *d_in = nullptr, *d_out = nullptr;
+  VERS_HIP_TRY(hipMalloc(&d_in, n_in * sizeof(uint64_t)));
+  if (hipMalloc(&d_out, n_out * sizeof(uint64_t)) != hipSuccess) { (void)hipFree(d_in); return fail(VERS_ERR_HIP, "vers_test_wide_net: out of device memory"); }
+  hipError_t e = hipMemcpy(d_in, in, n_in * sizeof(uint64_t), hipMemcpyHostToDevice);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(wide_net_test_kernel, dim3(1), dim3(kWave), 0, 0, d_in, d_out);
+    e = hipGetLastError();
+  }
+  if (e == hipSuccess) e = hipMemcpy(out, d_out, n_out * sizeof(uint64_t), hipMemcpyDeviceToHost);
+  (void)hipFree(d_in); (void)hipFree(d_out);
+  if (e != hipSuccess) return fail(VERS_ERR_HIP, std::string("vers_test_wide_net: ") + hipGetErrorString(e));
+  return VERS_OK;
+}
 
 extern "C" int32_t vers_test_wave_net(int32_t device, const uint64_t* in, uint64_t* out) {
   if (!in || !out) return fail(VERS_ERR_INVALID, "vers_test_wave_net: null argument");

@@ -20,6 +20,7 @@ SIGNATURES = {
     "vers_test_mfma": (C.c_int32, [C.c_int32, C.c_uint32, _vp, _vp, C.c_uint32, _vp]),
     "vers_test_standin_gather": (C.c_int32, [_vp, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32]),
     "vers_test_wave_net": (C.c_int32, [C.c_int32, _vp, _vp]),
+    "vers_test_wide_net": (C.c_int32, [C.c_int32, _vp, _vp]),
 }
 _lib = None
 
@@ -70,6 +71,15 @@ def wave_net(keys: np.ndarray, device: int = 0) -> np.ndarray:
     assert keys.size == 128
     out = np.zeros(640, dtype=np.uint64)
     check(lib().vers_test_wave_net(device, _ptr(keys), _ptr(out)))
+    return out
+
+
+def wide_net(keys: np.ndarray, device: int = 0) -> np.ndarray:
+    """the wide lists' networks (wide.hip.h) on 512 keys in one wave -> 771 words (include/vers_hip_test.h)"""
+    keys = np.ascontiguousarray(keys, dtype=np.uint64)
+    assert keys.size == 512
+    out = np.zeros(771, dtype=np.uint64)
+    check(lib().vers_test_wide_net(device, _ptr(keys), _ptr(out)))
     return out
 
 
