@@ -65,8 +65,20 @@ def test_many_probes_run_on_the_matrix_cores():
                 st1 = ix.prescan_stats()
                 assert st1["batches"] - st0["batches"] == 1, (mode, nprobe, top_k)
                 assert (st1["fallback_queries"] - st0["fallback_queries"] == 96) == (mode == 2), (mode, nprobe, top_k, st0, st1)
-    finally:
+        # ... and the RANKING of 49 .. 200 lists stays on the matrix cores too (coarse_select_wide_kernel: candidates four keys per lane wide,
+        # exact re-score, certificate); with every coarse certificate failing (coarse = 2) the query is re-ranked exactly inside the kernel
         capi.set_option("prescan", 1)
+        for cmode in (0, 2):
+            capi.set_option("coarse", cmode)
+            for nprobe in (49, 65, 128, 200, 201):
+                c0 = ix.coarse_stats()
+                check(ix, Q, 10, nprobe, range(0, 96, 7))
+                c1 = ix.coarse_stats()
+                assert c1["mfma_batches"] - c0["mfma_batches"] == (1 if nprobe <= 200 else 0), (cmode, nprobe, c0, c1)
+                if nprobe <= 200:
+                    assert (c1["fallback_queries"] - c0["fallback_queries"] == 96) == (cmode == 2), (cmode, nprobe, c0, c1)
+    finally:
+        capi.set_option("prescan", 1); capi.set_option("coarse", 0)
     ix.close()
 
 

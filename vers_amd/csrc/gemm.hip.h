@@ -23,6 +23,7 @@
 #include "plan.hip.h"
 #include "scan.hip.h"
 #include "staged.hip.h"
+#include "wide.hip.h"
 
 namespace vers {
 
@@ -972,6 +973,163 @@ static __global__ __launch_bounds__(kWave * kSelWaves) void coarse_select_rescor
     const unsigned long long t3 = __builtin_amdgcn_s_memtime();
     atomicAdd(stamps + 24, t1 - t0); atomicAdd(stamps + 25, t2 - t1); atomicAdd(stamps + 26, t3 - t2); atomicAdd(stamps + 27, 1ull);
     atomicAdd(stamps + 28, ta - t0); atomicAdd(stamps + 29, tb - ta); atomicAdd(stamps + 30, t1 - tb);  // of the selection: loads + bits, bracket, compact + sort
+  }
+}
+
+// ---- the same selection for MORE ranked lists than one key per lane holds (round 6: nprobe in (48, 200]) -----------------------------------
+// coarse_select_rescore_kernel keeps P + 16 candidates, a key per lane; beyond 48 ranked lists the batched coarse quantiser went back to
+// the ordered chains, 64 ranks per pass (~450 us per 256 queries at nprobe = 128, cfg3).  Here the candidates are a WIDE list (wide.hip.h:
+// 256 keys, four per lane): a block of four waves per query, every wave folds its quarter of the row's values 256 at a time (sort, merge
+// with the best so far), the four lists are folded, the PS = P + 32 smallest are re-scored exactly -- a thread per candidate walks its
+// centroid's ordered chain --, ranked by counting and certified exactly like the narrow kernel's; a query that fails is re-ranked over
+// ALL centroids with exact keys through the same fold.  probe[q][0..P) and, with pq.b != 0, the query's plan come out the same way.
+constexpr int kSelWideWaves = 4;
+static __global__ __launch_bounds__(kWave * kSelWideWaves) void coarse_select_wide_kernel(
+    const float* G, uint32_t N_pad, uint32_t k, const float* C_rm, uint32_t ldc, const float* qp, uint32_t ldq, uint32_t d_pad,
+    float cmax2, uint32_t P, uint32_t PS, uint64_t* probe, uint32_t* status, uint32_t* fallback_count, int metric, PlanQ pq, uint32_t n_queries) {
+  __shared__ uint64_t sh[kSelWideWaves][kWideR][kWave];
+  __shared__ uint64_t s_key[kWideKeys];
+  __shared__ uint32_t s_ci[kWideKeys];
+  __shared__ float s_qn[kSelWideWaves];
+  __shared__ uint32_t s_nrows, s_fail;
+  __shared__ float s_tau;
+  extern __shared__ __attribute__((aligned(16))) float qs[];  // the query [ldc]
+  const uint32_t q = blockIdx.x;
+  if (q >= n_queries) return;  // (whole blocks)
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const float* g = G + (uint64_t)q * N_pad;
+  const float* qv = qp + (uint64_t)q * ldq;
+  float qpart = 0.0f;
+  for (uint32_t j = threadIdx.x; j < ldc; j += blockDim.x) {
+    const float v = qv[j];
+    qs[j] = v;
+    qpart += v * v;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) qpart += __shfl_xor(qpart, off, kWave);
+  if (lane == 0) s_qn[wid] = qpart;
+  // the 256 smallest keys key_of(n), n < k, ascending, in wave 0 (every wave: its share 256 values at a time, then the fold)
+  auto smallest = [&](auto&& key_of, uint64_t (&best)[kWideR]) {
+#pragma unroll
+    for (int r = 0; r < kWideR; ++r) best[r] = kKeyMax;
+    for (uint32_t n0 = (uint32_t)wid * kWideKeys; n0 < k; n0 += kSelWideWaves * kWideKeys) {  // (wave-uniform)
+      uint64_t c[kWideR];
+#pragma unroll
+      for (int r = 0; r < kWideR; ++r) {
+        const uint32_t n = n0 + (uint32_t)(r * kWave + lane);
+        c[r] = n < k ? key_of(n) : kKeyMax;
+      }
+      wide_sort(c, lane);
+      if (readlane64(c[0], 0) >= readlane64(best[kWideR - 1], kWave - 1)) continue;
+      wide_merge_sorted(best, c, lane);
+    }
+    __syncthreads();  // (`sh` may still be read from a previous fold)
+#pragma unroll
+    for (int r = 0; r < kWideR; ++r) sh[wid][r][lane] = best[r];
+    __syncthreads();
+#pragma unroll
+    for (int s2 = 1; s2 < kSelWideWaves; s2 <<= 1) {
+      if ((wid & (2 * s2 - 1)) == 0) {
+        uint64_t o[kWideR];
+#pragma unroll
+        for (int r = 0; r < kWideR; ++r) o[r] = sh[wid + s2][r][lane];
+        wide_merge_sorted(best, o, lane);
+        if (2 * s2 < kSelWideWaves && wid != 0) {
+#pragma unroll
+          for (int r = 0; r < kWideR; ++r) sh[wid][r][lane] = best[r];
+        }
+      }
+      if (2 * s2 < kSelWideWaves) __syncthreads();
+    }
+  };
+  uint64_t sel[kWideR];
+  smallest([&](uint32_t n) { return ((uint64_t)f32_to_order_bits(g[n]) << 32) | n; }, sel);
+  const uint32_t n_sel = PS < k ? PS : k, Pq = P < k ? P : k;
+  float qn = 0.0f;
+  for (int w = 0; w < kSelWideWaves; ++w) qn += s_qn[w];  // (written before the fold's barriers)
+  const float E = ((5.0f * (float)d_pad + 16.0f) * 5.9604645e-08f + kX3Slack) * (qn + cmax2 + (metric ? 1.0f : 0.0f));
+  if (wid == 0) {
+    // which candidates are worth their row (coarse_select_rescore_kernel (2)): G <= g_P + 2 E; sorted by G, they are a prefix
+    const float gP = __uint_as_float(order_bits_to_f32_bits((uint32_t)(wide_get(sel, Pq - 1u) >> 32)));
+    uint32_t n_rows = 0;
+#pragma unroll
+    for (int r = 0; r < kWideR; ++r) {
+      const uint32_t e = (uint32_t)(r * kWave + lane);
+      const float gl = __uint_as_float(order_bits_to_f32_bits((uint32_t)(sel[r] >> 32)));
+      const bool have = e < n_sel && sel[r] != kKeyMax && !(gl > gP + 2.0f * E);  // (negated: NaN / inf anywhere keeps the candidate)
+      const uint64_t hm = __ballot(have);
+      if (hm) n_rows = (uint32_t)(r * kWave) + 64u - (uint32_t)__builtin_clzll((unsigned long long)hm);
+      s_ci[e] = (uint32_t)sel[r];
+    }
+    const float tau = __uint_as_float(order_bits_to_f32_bits((uint32_t)(wide_get(sel, n_sel - 1u) >> 32)));  // (every lane: wide_get reads a lane of a register)
+    if (lane == 0) {
+      s_nrows = n_rows;
+      s_tau = tau;
+    }
+  }
+  __syncthreads();
+  const uint32_t n_rows = s_nrows;
+  auto exact_of = [&](uint32_t n) {  // the reference's ordered chain of centroid n against the query (ivfflat.rs:159, base.rs:119-126)
+    const f32x4* cc = reinterpret_cast<const f32x4*>(C_rm + (uint64_t)n * ldc);
+    const f32x4* q4p = reinterpret_cast<const f32x4*>(qs);
+    float a2 = 0.0f;
+#pragma unroll 8
+    for (uint32_t j = 0; j < ldc / 4; ++j) {
+      const f32x4 c4 = cc[j], q4 = q4p[j];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (metric == 0) {
+          const float t = __fsub_rn(c4[u], q4[u]);
+          a2 = __fadd_rn(a2, __fmul_rn(t, t));
+        } else {
+          a2 = __fadd_rn(a2, __fmul_rn(c4[u], q4[u]));
+        }
+      }
+    }
+    if (metric) a2 = __fsub_rn(1.0f, a2);
+    if (a2 != a2) atomicOr(status, 1u);
+    return make_key(a2, n);
+  };
+  uint64_t exact = kKeyMax;
+  if (threadIdx.x < n_rows) exact = exact_of(s_ci[threadIdx.x]);
+  s_key[threadIdx.x] = exact;
+  __syncthreads();
+  uint32_t rank = 0xFFFFFFFFu;
+  if (threadIdx.x < n_rows && exact != kKeyMax) {
+    rank = 0;
+    for (uint32_t j = 0; j < n_rows; ++j) rank += s_key[j] < exact ? 1u : 0u;
+  }
+  __syncthreads();  // every thread has read the unranked keys
+  s_key[threadIdx.x] = kKeyMax;
+  __syncthreads();
+  if (rank < kWideKeys) s_key[rank] = exact;  // (unique keys: unique ranks)
+  __syncthreads();
+  // (3) certificate: every unselected centroid has D_ref >= tau + |q|^2 - E
+  if (threadIdx.x == 0) {
+    const float dP = __uint_as_float(order_bits_to_f32_bits((uint32_t)(s_key[Pq - 1u] >> 32)));
+    const bool certified = (n_sel >= k) || (s_key[Pq - 1u] != kKeyMax && dP < s_tau + (metric ? 1.0f : qn) - E);  // NaN anywhere -> false
+    s_fail = certified ? 0u : 1u;
+    if (!certified) atomicAdd(fallback_count, 1u);
+  }
+  __syncthreads();
+  if (s_fail) {  // (block-uniform) every centroid's exact key through the same fold
+    uint64_t ex[kWideR];
+    smallest(exact_of, ex);
+    if (wid == 0) {
+#pragma unroll
+      for (int r = 0; r < kWideR; ++r) s_key[r * kWave + lane] = ex[r];
+    }
+    __syncthreads();
+  }
+  for (uint32_t j = threadIdx.x; j < P; j += blockDim.x) probe[(uint64_t)q * P + j] = j < Pq ? s_key[j] : kKeyMax;
+  if (pq.b && wid == 0) {  // the query's plan (plan.hip.h step 1): lane j of chunk c = probe rank 64 c + j
+    uint32_t carry = 0, n_visited = 0;
+    for (uint32_t c0 = 0; c0 < P; c0 += kWave) {
+      const uint32_t j = c0 + (uint32_t)lane;
+      plan_query_chunk(pq, q, lane, c0, j < Pq ? s_key[j] : kKeyMax, carry, n_visited);
+    }
+    plan_query_finish(pq, q, lane, carry, n_visited);
   }
 }
 

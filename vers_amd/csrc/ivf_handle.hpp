@@ -20,6 +20,7 @@
 #include "kmeans.hpp"
 #include "plan.hip.h"
 #include "util.hip.h"
+#include "wide.hip.h"
 
 namespace vers {
 void shard_plan(const uint64_t* lens, uint64_t k, uint32_t world, uint8_t* owner);
@@ -411,7 +412,8 @@ inline bool coarse_on_matrix_cores(const vers_ivf* h, uint32_t b) { return b >= 
 // the whole condition under which coarse() ranks on the matrix cores (the contraction reads whole 128-row tiles: the staged block
 // is padded to them, a caller's block used in place is a whole number of them; the selection keeps P + 16 keys: one per lane)
 inline bool coarse_uses_mfma(const vers_ivf* h, const float* qp, uint32_t b, uint32_t P) {
-  return coarse_on_matrix_cores(h, b) && (qp == W->qp.as<float>() || b % 128u == 0) && P + 16 <= 64u;
+  // (P + 16 <= 64: a key per lane in coarse_select_rescore_kernel; up to P + 32 <= kWideMaxKp: coarse_select_wide_kernel's four per lane)
+  return coarse_on_matrix_cores(h, b) && (qp == W->qp.as<float>() || b % 128u == 0) && P + 32u <= kWideMaxKp;
 }
 
 // ---- ivf_plan.hip: coarse quantiser + planning -------------------------------------------------------------------------

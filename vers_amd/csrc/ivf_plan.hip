@@ -523,6 +523,13 @@ int32_t coarse_mfma(vers_ivf* h, const float* qp, uint32_t b, uint32_t P, uint64
                                   h->cnorm.as<float>(), h->ldq, h->k_pad, W->gbuf.as<float>(), h->metric, 0, nullptr, nullptr, nullptr, cs,
                                   cs ? cs + (size_t)h->k_pad * h->ldq : nullptr, zero_in_gemm ? plan->cnt : nullptr, zero_in_gemm ? plan->zero_words : 0u));
   if (timed) VERS_HIP_TRY(hipEventRecord(W->evc[1], st));
+  if (P + 16 > (uint32_t)kMaxTopK) {  // more ranked lists than a key per lane: the wide selection (four waves per query, the query in LDS)
+    const size_t lds = (size_t)h->ldq * sizeof(float);
+    if (int32_t rc = scan_prepare_launch(coarse_select_wide_kernel, lds)) return rc;
+    hipLaunchKernelGGL(coarse_select_wide_kernel, dim3(b), dim3(kWave * kSelWideWaves), lds, st, W->gbuf.as<float>(), h->k_pad, h->k,
+                       h->centroids_g.as<float>(), h->ldq, qp, h->ldq, h->ldq, coarse_mode() == 2 ? __builtin_inff() : h->cmax2, P, P + 32u,
+                       probe_out, W->st_word(), h->coarse_stat.as<uint32_t>(), h->metric, plan ? *plan : PlanQ{}, b);
+  } else
   hipLaunchKernelGGL(coarse_select_rescore_kernel, dim3(b), dim3(kWave * kSelWaves), 0, st, W->gbuf.as<float>(), h->k_pad, h->k,
                      h->centroids_g.as<float>(), h->ldq, qp, h->ldq, h->ldq, coarse_mode() == 2 ? __builtin_inff() : h->cmax2, P, PS,
                      probe_out, W->st_word(), h->coarse_stat.as<uint32_t>(), h->metric,

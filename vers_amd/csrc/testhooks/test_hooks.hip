@@ -91,7 +91,8 @@ __global__ __launch_bounds__(kWave) void wide_net_test_kernel(const uint64_t* in
   wide_merge_sorted(a, b, lane);
 #pragma unroll
   for (int r = 0; r < kWideR; ++r) out[2 * kWideKeys + r * kWave + lane] = a[r];
-  if (lane == 0) { out[3 * kWideKeys] = wide_get(a, 0); out[3 * kWideKeys + 1] = wide_get(a, 77); out[3 * kWideKeys + 2] = wide_get(a, 255); }
+  const uint64_t e0 = wide_get(a, 0), e77 = wide_get(a, 77), e255 = wide_get(a, 255);  // (whole wave)
+  if (lane == 0) { out[3 * kWideKeys] = e0; out[3 * kWideKeys + 1] = e77; out[3 * kWideKeys + 2] = e255; }
 }
 }  // namespace vers
 

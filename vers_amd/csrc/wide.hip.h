@@ -55,7 +55,8 @@ __device__ __forceinline__ void wide_merge_sorted(uint64_t (&list)[kWideR], cons
   }
   wide_bitonic_merge<kWideR>(list, lane);
 }
-// element e (wave-uniform) of a wide list
+// element e (wave-uniform) of a wide list.  WHOLE WAVE: the register is picked per lane before one lane of it is read -- under a
+// divergent branch the other lanes' copy would be stale.
 __device__ __forceinline__ uint64_t wide_get(const uint64_t (&k)[kWideR], uint32_t e) {
   const uint32_t r = e >> 6;
   const uint64_t v = r == 0 ? k[0] : (r == 1 ? k[1] : (r == 2 ? k[2] : k[3]));
