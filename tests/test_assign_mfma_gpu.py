@@ -91,3 +91,14 @@ def test_matrix_core_assign_is_bit_exact():
 def test_exact_scan_still_available():
     out = run({"VERS_OPTIONS": "assign=1"})
     assert out["PRIM"] == (0, 0) and out["BUILD"] == (0, 0)
+
+
+def test_cascade_hi_only_first_filter_is_bit_exact():
+    """option assign_terms = 1: the <hi, hi> bf16 product alone as the first filter of every pass (2^-8-wide certificate, the open
+    points through the tile-limited exact re-scan), = 3: never; = 0 (default, the tests above): probed per build.  Same bits always."""
+    for terms in (1, 3):
+        out = run({"VERS_OPTIONS": f"assign=2,assign_terms={terms}"})
+        pts, _ = out["PRIM"]
+        assert pts == 5000 + 4097 + 777 + 300 + 129 + 9
+        pts, _ = out["BUILD"]
+        assert pts >= 6000 * 2 * 2

@@ -244,8 +244,16 @@ static __global__ __launch_bounds__(256) void dist_gemm_kernel(const float* __re
 // rate, three products = 5.3x fewer MFMA cycles; the kernel is then bound by its operand traffic (global -> split in
 // registers -> LDS -> fragments), not by the MFMAs.
 constexpr float kX3Slack = 1.6e-5f;  // >= 2 * 3 * 2^-18 (G = norm - 2 dot doubles the dot's error), rounded up
+// ONE product (dist_gemm_x3w_kernel<2, 1>, the first filter of the assign cascade) on FP16 operands x~ = fp16(x), c~ = fp16(c): the products
+// are exact in the f32 accumulator, so <x, c> - <x~, c~> = <x - x~, c> + <x~, c - c~>, bounded with the MEASURED residuals r_x = |x - x~|
+// (per point, summed by assign_rescore_kernel next to |x|^2) and R_c = max |c - c~| (to_f16_resid_kernel): |.| <= r_x |c| + (|x| + r_x) R_c;
+// G doubles it.  A bf16 single product was tried first: 2^-8 (|x|^2 + |c|^2) = 7e-3 at unit norms left most points of cfg3's corpus open
+// (the pass 3x slower); fp16's 11 bits bring the window to ~1e-3, twice the three-product filter's.  Elements beyond fp16's range make
+// the residual infinite: nothing certifies, the exact paths decide.
 typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
 typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(8))) _Float16 gf16x8;  // (the single-product first filter of the assign cascade runs on fp16)
+typedef __attribute__((ext_vector_type(4))) _Float16 gf16x4;
 // LDS rows are the 32 bf16 of a K-tile, 64 bytes, unpadded; the four 16-byte chunks of row r sit at chunk ^ ((r >> 2) & 3).
 // A ds_read_b128 is served in groups of 16 lanes = 16 rows with r % 4 and (r >> 2) % 4 covering all 16 combinations, so the
 // group touches all 64 banks once; the 8-byte split stores of 16 consecutive threads cover two whole rows = 32 banks once.
@@ -433,12 +441,19 @@ constexpr size_t kX3WLdsBytes = 2 * 2 * 2 * (size_t)kGemmWide * kX3Pitch * 2;  /
 // their staging registers are free.  (The template parameter is what is left of rounds 3-4's schedule variants -- plain order,
 // interleaved, both operands pre-split by LDS-DMA / through registers: DESIGN.md Appendix A and the history of this file; the
 // instantiation keeps the kernel's name in the committed profiles.)
-template <int SCHED>
+// TERMS = 1 (round 6): ONLY the <hi, hi> product -- a third of the MFMAs, half the LDS traffic and split work -- as the FIRST filter of
+// a cascade: its values err by up to 2^-8 (|x|^2 + |c|^2) (kX1Slack), the certificate of assign_rescore_kernel is that much wider, and
+// the points it cannot settle go to the tile-limited exact re-scan (assign_tile_rescan_kernel) instead of a second contraction.  On
+// clustered data almost every point's nearest centroid beats the runner-up by far more than that (km_assign_mfma decides per pass
+// from its first batch).
+template <int SCHED, int TERMS = 3>  // TERMS = 1: Ch holds FP16 bit patterns, the points are converted to fp16
 static __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void dist_gemm_x3w_kernel(
     const float* __restrict__ X, const __bf16* __restrict__ Ch, const __bf16* __restrict__ Cl, const float* __restrict__ cnorm, uint32_t K,
     uint32_t N_pad, int metric, uint32_t m_tiles, uint32_t n_tiles, uint32_t grp, uint32_t k_rows, float* __restrict__ part_v1,
     uint32_t* __restrict__ part_c1, float* __restrict__ part_v2) {
   static_assert(SCHED == 2, "one schedule is shipped");
+  static_assert(TERMS == 3 || TERMS == 1, "hi*hi + hi*lo + lo*hi, or hi*hi alone");
+  constexpr bool LO = TERMS == 3;
   extern __shared__ __attribute__((aligned(16))) __bf16 T[];
   constexpr int kPart = kGemmWide * kX3Pitch;
   auto Tp = [&](int buf, int mat, int part) { return T + ((buf * 2 + mat) * 2 + part) * kPart; };
@@ -463,7 +478,7 @@ static __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2
       const int idx = tid + 512 * i;
       const uint64_t at = (uint64_t)(m0 + (idx >> 2)) * K + k0 + (idx & 3) * 8;
       ra[i] = *reinterpret_cast<const f32x4*>(Ch + at);
-      ra[2 + i] = *reinterpret_cast<const f32x4*>(Cl + at);
+      if constexpr (LO) ra[2 + i] = *reinterpret_cast<const f32x4*>(Cl + at);
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
@@ -476,20 +491,27 @@ static __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2
     for (int i = 0; i < 2; ++i) {
       const int idx = tid + 512 * i, row = idx >> 2, at = row * kX3Pitch + x3_chunk(row, idx & 3);
       *reinterpret_cast<f32x4*>(Tp(buf, 0, 0) + at) = ra[i];
-      *reinterpret_cast<f32x4*>(Tp(buf, 0, 1) + at) = ra[2 + i];
+      if constexpr (LO) *reinterpret_cast<f32x4*>(Tp(buf, 0, 1) + at) = ra[2 + i];
     }
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
       const int idx = tid + 512 * i, row = idx >> 3, c4 = idx & 7;
-      bf16x4 h, l;
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        h[u] = (__bf16)rb[i][u];
-        l[u] = (__bf16)(rb[i][u] - (float)h[u]);
-      }
       const int at = row * kX3Pitch + x3_chunk(row, c4 >> 1) + (c4 & 1) * 4;
-      *reinterpret_cast<bf16x4*>(Tp(buf, 1, 0) + at) = h;
-      *reinterpret_cast<bf16x4*>(Tp(buf, 1, 1) + at) = l;
+      if constexpr (LO) {
+        bf16x4 h, l;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          h[u] = (__bf16)rb[i][u];
+          l[u] = (__bf16)(rb[i][u] - (float)h[u]);
+        }
+        *reinterpret_cast<bf16x4*>(Tp(buf, 1, 0) + at) = h;
+        *reinterpret_cast<bf16x4*>(Tp(buf, 1, 1) + at) = l;
+      } else {
+        gf16x4 h;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) h[u] = (_Float16)rb[i][u];
+        *reinterpret_cast<gf16x4*>(Tp(buf, 1, 0) + at) = h;
+      }
     }
   };
   const int r = lane & 31, hh = lane >> 5;
@@ -515,7 +537,7 @@ static __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2
         const int idx = tid + 512 * i;
         const uint64_t at = (uint64_t)(m0 + (idx >> 2)) * K + k0 + (idx & 3) * 8;
         ra[i] = *reinterpret_cast<const f32x4*>(Ch + at);
-        ra[2 + i] = *reinterpret_cast<const f32x4*>(Cl + at);
+        if constexpr (LO) ra[2 + i] = *reinterpret_cast<const f32x4*>(Cl + at);
       }
     };
     auto gload_b = [&](int i, uint32_t k0) {
@@ -532,19 +554,19 @@ static __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2
 #pragma unroll
         for (int tt = 0; tt < 2; ++tt) {
           ah[tt] = *reinterpret_cast<const bf16x8*>(Tp(buf, 0, 0) + (wr * 64 + tt * 32 + r) * kX3Pitch + ko);
-          al[tt] = *reinterpret_cast<const bf16x8*>(Tp(buf, 0, 1) + (wr * 64 + tt * 32 + r) * kX3Pitch + ko);
+          if constexpr (LO) al[tt] = *reinterpret_cast<const bf16x8*>(Tp(buf, 0, 1) + (wr * 64 + tt * 32 + r) * kX3Pitch + ko);
         }
 #pragma unroll
         for (int tt = 0; tt < 4; ++tt) {
           bh[tt] = *reinterpret_cast<const bf16x8*>(Tp(buf, 1, 0) + (wc * 128 + tt * 32 + r) * kX3Pitch + ko);
-          bl[tt] = *reinterpret_cast<const bf16x8*>(Tp(buf, 1, 1) + (wc * 128 + tt * 32 + r) * kX3Pitch + ko);
+          if constexpr (LO) bl[tt] = *reinterpret_cast<const bf16x8*>(Tp(buf, 1, 1) + (wc * 128 + tt * 32 + r) * kX3Pitch + ko);
         }
         if (s2 == 0) {  // tile t + 1's centroid pieces -> the other buffer; their registers take tile t + 2
 #pragma unroll
           for (int i = 0; i < 2; ++i) {
             const int idx = tid + 512 * i, row = idx >> 2, at = row * kX3Pitch + x3_chunk(row, idx & 3);
             *reinterpret_cast<f32x4*>(Tp(nbuf, 0, 0) + at) = ra[i];
-            *reinterpret_cast<f32x4*>(Tp(nbuf, 0, 1) + at) = ra[2 + i];
+            if constexpr (LO) *reinterpret_cast<f32x4*>(Tp(nbuf, 0, 1) + at) = ra[2 + i];
           }
           gload_a(k2);
         }
@@ -554,28 +576,39 @@ static __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2
         auto mfma_row = [&](int a) {
 #pragma unroll
           for (int b = 0; b < 4; ++b) {
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a], bh[b], acc[a][b], 0, 0, 0);  // small terms first
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bl[b], acc[a][b], 0, 0, 0);
-            acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bh[b], acc[a][b], 0, 0, 0);
+            if constexpr (LO) {
+              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a], bh[b], acc[a][b], 0, 0, 0);  // small terms first
+              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bl[b], acc[a][b], 0, 0, 0);
+              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bh[b], acc[a][b], 0, 0, 0);
+            } else {
+              acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(gf16x8, ah[a]), __builtin_bit_cast(gf16x8, bh[b]), acc[a][b], 0, 0, 0);
+            }
           }
         };
         // first half of the k-step's MFMAs with this k-step's half of the split between them, stored at once
 #pragma unroll
         for (int i = 2 * s2; i < 2 * s2 + 2; ++i) {
-          bf16x4 sh, sl;
-#pragma unroll
-          for (int u = 0; u < 4; ++u) {
-            sh[u] = (__bf16)rb[i][u];
-            sl[u] = (__bf16)(rb[i][u] - (float)sh[u]);
-          }
           const int idx = tid + 512 * i, row = idx >> 3, c4 = idx & 7;
           const int at = row * kX3Pitch + x3_chunk(row, c4 >> 1) + (c4 & 1) * 4;
-          *reinterpret_cast<bf16x4*>(Tp(nbuf, 1, 0) + at) = sh;
-          *reinterpret_cast<bf16x4*>(Tp(nbuf, 1, 1) + at) = sl;
+          if constexpr (LO) {
+            bf16x4 sh, sl;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+              sh[u] = (__bf16)rb[i][u];
+              sl[u] = (__bf16)(rb[i][u] - (float)sh[u]);
+            }
+            *reinterpret_cast<bf16x4*>(Tp(nbuf, 1, 0) + at) = sh;
+            *reinterpret_cast<bf16x4*>(Tp(nbuf, 1, 1) + at) = sl;
+          } else {
+            gf16x4 sh;
+#pragma unroll
+            for (int u = 0; u < 4; ++u) sh[u] = (_Float16)rb[i][u];
+            *reinterpret_cast<gf16x4*>(Tp(nbuf, 1, 0) + at) = sh;
+          }
         }
         mfma_row(0);
 #pragma unroll
-        for (int g = 0; g < 12; ++g) {
+        for (int g = 0; g < 4 * TERMS; ++g) {
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);  // one MFMA
           __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);  // two VALU
         }
@@ -647,15 +680,22 @@ inline bool gemm_wide_ok(uint32_t k_pad, uint32_t nb_pad, bool have_split) {
   return have_split && k_pad % kGemmWide == 0 && nb_pad % kGemmWide == 0;
 }
 inline hipError_t launch_gemm_wide(uint32_t k_pad, uint32_t nb_pad, hipStream_t st, const float* X, const __bf16* ch, const __bf16* cl, const float* cnorm,
-                                   uint32_t K, uint32_t N_pad, uint32_t metric, uint32_t k_rows, float* part_v1, uint32_t* part_c1, float* part_v2) {
+                                   uint32_t K, uint32_t N_pad, uint32_t metric, uint32_t k_rows, float* part_v1, uint32_t* part_c1, float* part_v2,
+                                   bool hi_only = false) {
   static const hipError_t attr = hipFuncSetAttribute((const void*)dist_gemm_x3w_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kX3WLdsBytes);
   if (attr != hipSuccess) return attr;
+  static const hipError_t attr1 = hipFuncSetAttribute((const void*)dist_gemm_x3w_kernel<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kX3WLdsBytes);
+  if (attr1 != hipSuccess) return attr1;
   const uint32_t m_tiles = k_pad / kGemmWide, n_tiles = nb_pad / kGemmWide;
   // each XCD keeps `grp` centroid tiles (256 rows x K x 4 B of hi | lo = 768 KB at K = 768) in its L2 and walks the point tiles
   uint32_t grp = 0;
   for (uint32_t g : {2u, 1u}) if (m_tiles % (8u * g) == 0) { grp = g; break; }
-  hipLaunchKernelGGL(dist_gemm_x3w_kernel<2>, dim3(m_tiles * n_tiles), dim3(512), kX3WLdsBytes, st, X, ch, cl, cnorm, K, N_pad, (int)metric, m_tiles,
-                     n_tiles, grp, k_rows, part_v1, part_c1, part_v2);
+  if (hi_only)
+    hipLaunchKernelGGL((dist_gemm_x3w_kernel<2, 1>), dim3(m_tiles * n_tiles), dim3(512), kX3WLdsBytes, st, X, ch, cl, cnorm, K, N_pad, (int)metric, m_tiles,
+                       n_tiles, grp, k_rows, part_v1, part_c1, part_v2);
+  else
+    hipLaunchKernelGGL(dist_gemm_x3w_kernel<2>, dim3(m_tiles * n_tiles), dim3(512), kX3WLdsBytes, st, X, ch, cl, cnorm, K, N_pad, (int)metric, m_tiles,
+                       n_tiles, grp, k_rows, part_v1, part_c1, part_v2);
   return hipGetLastError();
 }
 
@@ -687,6 +727,30 @@ inline hipError_t launch_gemm(bool x3, uint32_t m_tiles, uint32_t n_tiles, hipSt
     return hipGetLastError();
   };
   return (sh && sl) ? go(std::integral_constant<int, kPreBit>{}) : go(std::integral_constant<int, 0>{});
+}
+// rows of x -> fp16 (round to nearest) and the largest squared residual |row - fp16(row)|^2 over the rows (x - fp16(x) is exact in f32:
+// shadow_residual_kernel's argument; the sum of squares is inflated where it is used).  Block per row.
+static __global__ __launch_bounds__(256) void to_f16_resid_kernel(const float* __restrict__ x, uint32_t ld, uint32_t n_rows, _Float16* __restrict__ out,
+                                                                  uint32_t* __restrict__ rmax2_bits) {
+  __shared__ float part[4];
+  const uint32_t row = blockIdx.x;
+  if (row >= n_rows) return;
+  float acc = 0.0f;
+  for (uint32_t j = threadIdx.x; j < ld; j += blockDim.x) {
+    const float v = x[(uint64_t)row * ld + j];
+    const _Float16 h = (_Float16)v;
+    out[(uint64_t)row * ld + j] = h;
+    const float dl = v - (float)h;
+    acc += dl * dl;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) acc += __shfl_xor(acc, off, kWave);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float t = part[0] + part[1] + part[2] + part[3];
+    atomicMax(rmax2_bits, t == t ? __float_as_uint(t) : 0x7F800000u);  // (t >= 0: bit order == value order; NaN counts as +inf)
+  }
 }
 inline hipError_t launch_split_bf16(const float* x, uint64_t n_floats, __bf16* hi, __bf16* lo, hipStream_t st) {  // n_floats % 4 == 0
   const uint64_t n4 = n_floats / 4;
@@ -1166,13 +1230,14 @@ static __global__ void assign_argmin_merge_kernel(const float* part_v1, const ui
 static __global__ void assign_rescore_kernel(const float* X, uint32_t ldx, const float* C_rm, uint32_t ldc, uint32_t d, uint32_t d_pad,
                                              const float* cmax2_dev, const uint32_t* best, const float* g2, uint32_t nb, uint32_t k,
                                              uint32_t i_base, uint32_t* assign, float* mind, uint32_t* fb_list, uint32_t* fb_count,
-                                             uint32_t* status, int metric, float* fb_thr = nullptr) {
+                                             uint32_t* status, int metric, float* fb_thr = nullptr, const uint32_t* rc2_bits = nullptr) {
+  // rc2_bits != nullptr: the values came from the SINGLE fp16 product (the cascade's first filter): the bound uses the measured residuals
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= nb) return;
   const uint32_t c = best[i];
   const float* x = X + (uint64_t)i * ldx;
   const float* cv = C_rm + (uint64_t)c * ldc;
-  float acc = 0.0f, xn = 0.0f;
+  float acc = 0.0f, xn = 0.0f, rx2 = 0.0f;
   uint32_t j = 0;
   if (((ldx | ldc) & 3u) == 0) {
     for (; j + 4 <= d; j += 4) {
@@ -1187,6 +1252,7 @@ static __global__ void assign_rescore_kernel(const float* X, uint32_t ldx, const
           acc = __fadd_rn(acc, __fmul_rn(x4[u], c4[u]));
         }
         xn = __fadd_rn(xn, __fmul_rn(x4[u], x4[u]));
+        if (rc2_bits) { const float dl = x4[u] - (float)(_Float16)x4[u]; rx2 = __fadd_rn(rx2, __fmul_rn(dl, dl)); }
       }
     }
   }
@@ -1198,10 +1264,15 @@ static __global__ void assign_rescore_kernel(const float* X, uint32_t ldx, const
       acc = __fadd_rn(acc, __fmul_rn(x[j], cv[j]));
     }
     xn = __fadd_rn(xn, __fmul_rn(x[j], x[j]));
+    if (rc2_bits) { const float dl = x[j] - (float)(_Float16)x[j]; rx2 = __fadd_rn(rx2, __fmul_rn(dl, dl)); }
   }
   if (metric) acc = __fsub_rn(1.0f, acc);
   const float tau = g2[i];
-  const float E = ((5.0f * (float)d_pad + 16.0f) * 5.9604645e-08f + kX3Slack) * (xn + *cmax2_dev + (metric ? 1.0f : 0.0f));
+  float E = ((5.0f * (float)d_pad + 16.0f) * 5.9604645e-08f + (rc2_bits ? 0.0f : kX3Slack)) * (xn + *cmax2_dev + (metric ? 1.0f : 0.0f));
+  if (rc2_bits) {  // 2 (r_x |c| + (|x| + r_x) R_c), every factor rounded up by 1 % (the sums of squares, the roots)
+    const float rx = 1.01f * __builtin_sqrtf(rx2), Rc = 1.01f * __builtin_sqrtf(__uint_as_float(*rc2_bits));
+    E += 2.02f * (rx * __builtin_sqrtf(*cmax2_dev) + (__builtin_sqrtf(xn) + rx) * Rc);
+  }
   const float lower = tau + (metric ? 1.0f : xn) - E;  // NaN if anything overflowed
   const bool finite = tau < __builtin_inff() && E < __builtin_inff();
   const bool certified = k == 1 || (finite && acc < lower);
@@ -1223,18 +1294,35 @@ static __global__ void assign_rescore_kernel(const float* X, uint32_t ldx, const
 // More than kRescanTiles candidate tiles (forced-failure tests, degenerate data) or a NaN: the point goes to the full exact
 // scan like before (fb2).  At k = 65536 the full scan of the ~3 % uncertified points was 19 % of a k-means pass.
 constexpr uint32_t kRescanTiles = 8;
+// (Round 6: the candidate tiles are read from the centroids in the SCAN layout -- lane-transposed 64-row tiles, 1 KiB wave loads, the
+// point as the scalar operand: scan_item, the engine of every exact scan -- instead of a lane per centroid walking its own row-major row
+// 16 bytes at a time, 64 lines per load instruction: ~100 us per candidate tile, which made this kernel as expensive as the contraction
+// once the fp16 single-product filter of the assign cascade sent it a few per cent of every batch.)
+struct RescanSrc {
+  static constexpr bool kSeqIds = false;
+  static constexpr bool kStreamOnce = false;
+  uint64_t* out_ptr;
+  uint32_t seq0;
+  __device__ __forceinline__ uint32_t seq_base(uint32_t, int) const { return seq0; }
+  __device__ __forceinline__ const uint32_t* seq_ids(uint32_t) const { return nullptr; }
+  __device__ __forceinline__ uint64_t* out(uint32_t, int) const { return out_ptr; }
+  __device__ __forceinline__ uint32_t bound_slot(uint32_t, int) const { return 0; }
+};
+// Cb: the centroids in the scan layout [tiles of 64][ld]; Xb: THIS batch's rows, zero padded to ld columns (pitch ld), row i = point i_base + i
 static __global__ __launch_bounds__(kWave) void assign_tile_rescan_kernel(
-    const float* X, uint32_t ldx, const float* C_rm, uint32_t ldc, uint32_t d, uint32_t k, const float* part_v1, uint32_t n_tiles,
+    const float* Xb, const float* Cb, uint32_t ld, uint32_t k, const float* part_v1, uint32_t n_tiles,
     uint32_t pitch, uint32_t i_base, uint32_t nb, const uint32_t* fb_list, const float* fb_thr, const uint32_t* fb_count, uint32_t* assign,
     float* mind, uint32_t* fb2_list, uint32_t* fb2_count, int metric) {
+  __shared__ uint64_t s_out[kWave];
   const int lane = threadIdx.x;
   const uint32_t n_q = *fb_count;
+  ScanParams p;
+  p.ld = ld; p.n_chunks = ld / kChunk; p.k = 1; p.status = nullptr; p.bounds = nullptr; p.lower = nullptr; p.debug = 0; p.next_quad = nullptr; p.stamps = nullptr;
   for (uint32_t e = blockIdx.x; e < n_q; e += gridDim.x) {
     const uint32_t idx = fb_list[e];
     if (idx < i_base || idx >= i_base + nb) continue;  // (another batch's entry: its tile minima are gone)
     const uint32_t i = idx - i_base;
     const float T = fb_thr[e];
-    const float* x = X + (uint64_t)idx * ldx;
     uint64_t best = kKeyMax;
     uint32_t n_cand = 0;
     bool nan = false;
@@ -1246,50 +1334,25 @@ static __global__ __launch_bounds__(kWave) void assign_tile_rescan_kernel(
         const uint32_t tl = (uint32_t)__ffsll((unsigned long long)m) - 1u;
         m &= m - 1;
         if (++n_cand > kRescanTiles) break;
-#pragma unroll 1
-        for (uint32_t h = 0; h < 2; ++h) {
-          const uint32_t c = (t0 + tl) * kGemmBM + h * kWave + (uint32_t)lane;
-          if (c < k) {
-            const float* cv = C_rm + (uint64_t)c * ldc;
-            float acc = 0.0f;
-            uint32_t j = 0;
-            if (((ldx | ldc) & 3u) == 0) {
-              for (; j + 4 <= d; j += 4) {
-                const f32x4 x4 = *reinterpret_cast<const f32x4*>(x + j);
-                const f32x4 c4 = *reinterpret_cast<const f32x4*>(cv + j);
-#pragma unroll
-                for (int u = 0; u < 4; ++u) {
-                  if (metric == 0) {
-                    const float tt = __fsub_rn(x4[u], c4[u]);
-                    acc = __fadd_rn(acc, __fmul_rn(tt, tt));
-                  } else {
-                    acc = __fadd_rn(acc, __fmul_rn(x4[u], c4[u]));
-                  }
-                }
-              }
-            }
-            for (; j < d; ++j) {
-              if (metric == 0) {
-                const float tt = __fsub_rn(x[j], cv[j]);
-                acc = __fadd_rn(acc, __fmul_rn(tt, tt));
-              } else {
-                acc = __fadd_rn(acc, __fmul_rn(x[j], cv[j]));
-              }
-            }
-            if (metric) acc = __fsub_rn(1.0f, acc);
-            nan |= acc != acc;
-            const uint64_t key = make_key(acc, c);
-            best = key < best ? key : best;
-          }
-        }
+        const uint32_t c0 = (t0 + tl) * kGemmBM;  // the tile's first centroid (a multiple of 64: whole scan tiles)
+        if (c0 >= k) continue;
+        ItemView<1> iv;
+        iv.rows = Cb + (uint64_t)c0 * ld;
+        iv.nrows = k - c0 < (uint32_t)kGemmBM ? k - c0 : (uint32_t)kGemmBM;
+        iv.nq = 1;
+        iv.qb = Xb + (uint64_t)i * ld;
+        RescanSrc src{s_out, c0};
+        if (metric == 0) scan_item<1, 1, 0>(src, p, 0u, iv, lane, nan);
+        else scan_item<1, 1, 1>(src, p, 0u, iv, lane, nan);
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        const uint64_t key = s_out[0];  // the tile's first minimum by (distance, centroid index)
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        best = key < best ? key : best;
       }
     }
     const bool defer = n_cand > kRescanTiles || n_cand == 0 || __ballot(nan) != 0;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-      const uint64_t o = shfl_xor64(best, off);
-      best = o < best ? o : best;
-    }
     if (lane == 0) {
       if (defer || best == kKeyMax) fb2_list[atomicAdd(fb2_count, 1u)] = idx;
       else {

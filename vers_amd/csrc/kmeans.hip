@@ -241,13 +241,27 @@ int32_t km_assign_mfma(const float* X, uint32_t ldx, uint64_t n, const float* C,
   VERS_HIP_TRY(hipMemsetAsync(fb_count, 0, sizeof(uint32_t), st));
   // large k: uncertified points first go through the tile-limited re-scan (assign_tile_rescan_kernel); what it cannot settle
   // lands in fb_list like before
-  const bool tiles_on = opt_get("assign_tiles", 1) != 0;
+  // THE CASCADE (round 6; option "assign_terms": 0 auto, 1 always, 3 never): the wide contraction with ONE product of FP16 operands --
+  // a third of the MFMAs, half the LDS traffic -- is the first filter; its certificate is as wide as the operands' MEASURED fp16 residuals
+  // make it (gemm.hip.h) and the points it leaves open go to the tile-limited exact re-scan below.  Whether that pays depends on the data (clustered rows beat
+  // their runner-up centroid by far more than the window; rows spread evenly over the sphere do not): in auto mode a pass starts with
+  // a small probing batch and keeps the cascade while at most 1/8 of a batch's points stay open; the verdict is remembered in the
+  // scratch for the following passes over the same (n, k).
+  const int terms_opt = (int)opt_get("assign_terms", 0);
+  const bool wide_shape = (gemm_x3_mask() & 1) != 0 && round_up(k, kGemmBM) % kGemmWide == 0;
+  if (ws.cascade_n != n || ws.cascade_k != k) { ws.cascade_n = n; ws.cascade_k = k; ws.cascade = -1; }
+  bool hi_only = wide_shape && terms_opt != 3 && (terms_opt == 1 || ws.cascade != 0);
+  const bool probing = hi_only && terms_opt == 0 && ws.cascade < 0;
+  const bool tiles_on = opt_get("assign_tiles", 1) != 0 || hi_only;
   // (from 64 tiles = k >= 8192 on: measured at k = 4096, N = 4M with VERS_ASSIGN_TILES_MIN=8 the pass gets 3 % SLOWER, 104.6 vs
   // 101.1 ms -- a launch of 2048 waves per batch against one exact scan of the 1.6 % uncertified points at the end; same bits)
   const uint32_t tiles_min = (uint32_t)opt_get("assign_tiles_min", 64);
-  const bool tile_rescan = tiles_on && k_pad / kGemmBM >= tiles_min;
+  const bool tile_rescan = tiles_on && (k_pad / kGemmBM >= tiles_min || hi_only);
   uint32_t* fbq_list = nullptr; uint32_t* fbq_count = nullptr; float* fbq_thr = nullptr;
   if (tile_rescan) {
+    // the centroids in the scan layout (lane-transposed 64-row tiles): what the re-scan streams
+    if (int32_t rc = ws.cblocked.reserve(blocked_floats(k, ldq) * sizeof(float))) return rc;
+    if (int32_t rc = launch_to_blocked(C, ldc, d, k, ws.cblocked.as<float>(), ldq, st)) return rc;
     if (int32_t rc = ws.fbq.reserve((2 * n + 4) * sizeof(uint32_t))) return rc;
     fbq_list = ws.fbq.as<uint32_t>(); fbq_count = fbq_list + n; fbq_thr = ws.fbq.as<float>() + n + 4;
     VERS_HIP_TRY(hipMemsetAsync(fbq_count, 0, sizeof(uint32_t), st));
@@ -262,6 +276,17 @@ int32_t km_assign_mfma(const float* X, uint32_t ldx, uint64_t n, const float* C,
     if (int32_t rc = ws.cg_s.reserve(2 * ne * sizeof(uint16_t))) return rc;
     VERS_HIP_TRY(launch_split_bf16(ws.cg.as<float>(), ne, ws.cg_s.as<__bf16>(), ws.cg_s.as<__bf16>() + ne, st));
     cg_h = ws.cg_s.as<__bf16>(); cg_l = cg_h + ne;
+  }
+  const __bf16* cg_f16 = nullptr;  // the centroids as fp16 (the cascade's operand) + the largest squared residual of a centroid row
+  uint32_t* rc2_bits = nullptr;
+  if (hi_only) {
+    const size_t ne = (size_t)k_pad * ldq;
+    if (int32_t rc = ws.cg_f16.reserve(ne * sizeof(uint16_t) + 16)) return rc;
+    rc2_bits = reinterpret_cast<uint32_t*>(ws.cg_f16.as<uint16_t>() + ne);
+    VERS_HIP_TRY(hipMemsetAsync(rc2_bits, 0, 16, st));
+    hipLaunchKernelGGL(to_f16_resid_kernel, dim3(k_pad), dim3(256), 0, st, (const float*)ws.cg.as<float>(), ldq, k_pad, ws.cg_f16.as<_Float16>(), rc2_bits);
+    VERS_HIP_TRY(hipGetLastError());
+    cg_f16 = ws.cg_f16.as<__bf16>();
   }
   // point batch: the per-(centroid tile, point) triples stay <= 1 GiB (the GEMM never writes its product)
   const uint32_t n_tiles = k_pad / kGemmBM;
@@ -280,21 +305,27 @@ int32_t km_assign_mfma(const float* X, uint32_t ldx, uint64_t n, const float* C,
   uint32_t* best = ws.best.as<uint32_t>();
   float* g2 = ws.best.as<float>() + mb;
   const bool in_place_ok = ldx == ldq && d == ldq;  // (padding columns of the caller's X may hold anything: stage them away)
-  for (uint64_t i0 = 0; i0 < n; i0 += mb) {
-    const uint32_t nb = (uint32_t)((n - i0 < mb) ? (n - i0) : mb);
+  uint32_t open_before = 0;
+  for (uint64_t i0 = 0, step = 0; i0 < n; i0 += step) {
+    // (a probing pass opens with a batch of at most 16384 points)
+    const uint64_t want = (probing && i0 == 0) ? std::min<uint64_t>(mb, round_up64(16384, bn)) : mb;
+    const uint32_t nb = (uint32_t)((n - i0 < want) ? (n - i0) : want);
+    step = nb;
     const uint32_t nb_pad = round_up(nb, (uint32_t)bn);
     const float* xb = X + i0 * ldx;
+    const float* xb_padded = in_place_ok ? xb : nullptr;  // this batch's rows with zeroed padding columns, pitch ldq (the tile re-scan's operand)
     if (!in_place_ok || nb_pad != nb) {  // pad the columns / the tail rows through a staged copy
       if (int32_t rc = ws.xp.reserve((size_t)mb * ldq * sizeof(float))) return rc;
       if (nb_pad != nb) VERS_HIP_TRY(hipMemsetAsync(ws.xp.as<float>() + (size_t)nb * ldq, 0, (size_t)(nb_pad - nb) * ldq * sizeof(float), st));
       if (int32_t rc = launch_stage_queries(xb, ldx, d, ws.xp.as<float>(), ldq, nb, 1, st)) return rc;
       xb = ws.xp.as<float>();
+      xb_padded = xb;
     }
     // (the triples are addressed with pitch mb: nb_pad <= mb)
     {
       KmTimer t(st, &BuildStats::gemm_ms);
       if (wide)
-        VERS_HIP_TRY(launch_gemm_wide(k_pad, nb_pad, st, xb, cg_h, cg_l, ws.cnorm.as<float>(), ldq, (uint32_t)mb, metric, k, part_v1, part_c1, part_v2));
+        VERS_HIP_TRY(launch_gemm_wide(k_pad, nb_pad, st, xb, hi_only ? cg_f16 : cg_h, cg_l, ws.cnorm.as<float>(), ldq, (uint32_t)mb, metric, k, part_v1, part_c1, part_v2, hi_only));
       else
         VERS_HIP_TRY(launch_gemm<true>((gemm_x3_mask() & 1) != 0, k_pad / kGemmBM, nb_pad / kGemmBN, st, ws.cg.as<float>(), xb, ws.cnorm.as<float>(), ldq,
                                        (uint32_t)mb, (float*)nullptr, metric, k, part_v1, part_c1, part_v2, cg_h, cg_l));
@@ -305,12 +336,27 @@ int32_t km_assign_mfma(const float* X, uint32_t ldx, uint64_t n, const float* C,
                        (const float*)part_v2, n_tiles, (uint32_t)mb, nb, best, g2);
     hipLaunchKernelGGL(assign_rescore_kernel, dim3((nb + 63) / 64), dim3(64), 0, st, X + i0 * ldx, ldx, C, ldc, d, ldq, cmax2_dev, best, g2,
                        nb, k, (uint32_t)i0, out_assign + i0, out_mind ? out_mind + i0 : nullptr, tile_rescan ? fbq_list : fb_list,
-                       tile_rescan ? fbq_count : fb_count, ws.status.as<uint32_t>(), metric, fbq_thr);
-    if (tile_rescan)
-      hipLaunchKernelGGL(assign_tile_rescan_kernel, dim3(2048), dim3(kWave), 0, st, X, ldx, C, ldc, d, k, (const float*)part_v1, n_tiles,
-                         (uint32_t)mb, (uint32_t)i0, nb, (const uint32_t*)fbq_list, (const float*)fbq_thr, (const uint32_t*)fbq_count, out_assign,
-                         out_mind, fb_list, fb_count, metric);
+                       tile_rescan ? fbq_count : fb_count, ws.status.as<uint32_t>(), metric, fbq_thr, hi_only && wide ? (const uint32_t*)rc2_bits : (const uint32_t*)nullptr);
+    if (tile_rescan) {
+      if (xb_padded == nullptr) {  // the re-scan reads this batch's rows zero padded to ldq columns (its scalar operand): staged when the caller's are not
+        if (int32_t rc = ws.xp.reserve((size_t)mb * ldq * sizeof(float))) return rc;
+        if (int32_t rc = launch_stage_queries(X + i0 * ldx, ldx, d, ws.xp.as<float>(), ldq, nb, 1, st)) return rc;
+        xb_padded = ws.xp.as<float>();
+      }
+      hipLaunchKernelGGL(assign_tile_rescan_kernel, dim3(2048), dim3(kWave), 0, st, xb_padded, (const float*)ws.cblocked.as<float>(), ldq, k,
+                         (const float*)part_v1, n_tiles, (uint32_t)mb, (uint32_t)i0, nb, (const uint32_t*)fbq_list, (const float*)fbq_thr,
+                         (const uint32_t*)fbq_count, out_assign, out_mind, fb_list, fb_count, metric);
+    }
     VERS_HIP_TRY(hipGetLastError());
+    if (hi_only && wide && terms_opt == 0 && (i0 == 0 || ws.cascade < 0)) {  // the cascade's verdict: how many of this batch's points stayed open
+      uint32_t open_now = 0;
+      VERS_HIP_TRY(hipMemcpyAsync(&open_now, fbq_count, 4, hipMemcpyDeviceToHost, st));
+      VERS_HIP_TRY(hipStreamSynchronize(st));
+      const bool keep = (uint64_t)(open_now - open_before) * 8u <= nb;
+      ws.cascade = keep ? 1 : 0;
+      if (!keep) hi_only = false;  // (the rest of this pass and the following ones: three products)
+      open_before = open_now;
+    }
   }
   uint32_t nf = 0;
   VERS_HIP_TRY(hipMemcpyAsync(&nf, fb_count, 4, hipMemcpyDeviceToHost, st));

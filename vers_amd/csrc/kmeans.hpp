@@ -25,6 +25,10 @@ void dev_mem_stats(uint64_t* now, uint64_t* peak, bool reset_peak);  // bytes he
 void dev_mem_account(int64_t delta);  // for the one allocation made outside DevBuf::reserve
 
 struct KMeansScratch {
+  // the assign cascade's verdict for passes over (cascade_n, cascade_k): -1 not probed yet, 1 the <hi, hi> first filter pays, 0 it does not (km_assign_mfma)
+  int cascade = -1;
+  uint64_t cascade_n = 0;
+  uint32_t cascade_k = 0;
   DevBuf cblocked;  // centroids in the scan layout (lane-transposed tiles)
   DevBuf qblocks;   // interleaved point blocks of one assign batch
   DevBuf keys;      // u64 argmin keys of one assign batch
@@ -34,6 +38,7 @@ struct KMeansScratch {
   DevBuf misc;      // cost scalar, equality flag
   // matrix-core assign (km_assign_mfma)
   DevBuf cg;        // centroids row-major [k_pad][ldq], zero padded
+  DevBuf cg_f16;    // the same as fp16 [k_pad][ldq] + 16 bytes: the largest squared fp16 residual of a row (operand of the cascade's single-product filter)
   DevBuf cg_s;      // the same as bf16 hi | lo halves [2][k_pad][ldq] (operand of the bf16x3 contraction, split once per pass)
   DevBuf cnorm;     // |c|^2 [k_pad] (+inf padding) + max at [k_pad]
   DevBuf xp;        // staged point batch [mb][ldq] when X cannot be used in place
