@@ -87,7 +87,7 @@ def compact_line(out: dict) -> dict:
                       "gpu_matches_cpu_bitwise": _g(fl, "cpu_baseline", "gpu_matches_cpu_bitwise")} if fl else None,
         "coarse_gemm": {"us": _g(ex, "coarse_gemm", "us"), "tflops": _g(ex, "coarse_gemm", "algorithmic_tflops"), "f32_mfma_us": _g(ex, "coarse_gemm_f32", "us"),
                         "f32_mfma_frac": _g(ex, "coarse_gemm_f32", "frac")} if "coarse_gemm" in ex else None,
-        "kmeans_assign": {"tflops": _g(ex, "kmeans_assign", "algorithmic_tflops"), "frac_bf16_div3": _g(ex, "kmeans_assign", "frac_of_bf16_dense_div3"),
+        "kmeans_assign": {"tflops": _g(ex, "kmeans_assign", "algorithmic_tflops"), "frac_f16_dense": _g(ex, "kmeans_assign", "frac_of_f16_dense"), "assign_pass_ms": _g(ex, "kmeans_assign", "assign_pass_ms"),
                           "mfma_busy_pct": _g(ex, "kmeans_assign", "mfma_busy_pct"), "k65536_tflops": _g(ex, "kmeans_assign_k65536", "algorithmic_tflops")} if "kmeans_assign" in ex else None,
         "batch_sweep_qps": {k: v.get("queries_per_sec") for k, v in sw.items()} or None,
         "batch_sweep_bitwise": all(v.get("gpu_matches_cpu_bitwise", True) for v in sw.values()) if sw else None,
@@ -452,7 +452,7 @@ def main():
                    else "prescan_kernel_g<false, 32, IvfSrc<32>> (inverted-list scan on the f32 matrix cores; exact finish in ivf_rescore_kernel)" if mfma_scan
                    else "scan_kernel<QG,0,IvfSrc<QG>> (inverted-list scan, ordered f32 chains; QG = 16 at this shape)")
     traffic, traffic_source = None, None
-    for tf in ("r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):  # newest PMC run of this exact configuration
+    for tf in ("r06_traffic.json", "r05_traffic.json", "r04_traffic.json", "r03_traffic.json", "r02_traffic.json", "r01_traffic.json"):  # newest PMC run of this exact configuration
         try:
             tj = json.load(open(os.path.join(ROOT, "profiles", tf)))
             if (tj["config"] == {"rows": n, "d": d, "nlist": nlist, "nprobe": nprobe, "batch": B} and not multi
@@ -522,20 +522,21 @@ def main():
     # ---- extra measurements, outside the timed region (north_star's other targets) ---------------
     extra = {}
     MFMA_F32_PEAK_TF = 157.3  # v_mfma_f32_32x32x2_f32 dense peak (MI355X_MICROARCH.md)
-    BF16_DENSE_PEAK_TF = 2500.0  # v_mfma_f32_32x32x16_bf16 dense peak (same guide); the contraction spends THREE bf16 products per f32 one
+    BF16_DENSE_PEAK_TF = 2500.0  # v_mfma_f32_32x32x16_bf16 / _f16 dense peak (same guide); the assign cascade's first filter spends ONE fp16 product per f32 one
 
     def assign_entry(bs, shape_pts, k_, wall_s, note):
         """k-means assign (ivfflat.rs:29-46) as the build just ran it: the contraction launches by HIP events (vers_build_stats)"""
         if bs["gemm_launches"] <= 0 or bs["gemm_ms"] <= 0:
             return None
         tf = bs["gemm_flop"] / (bs["gemm_ms"] * 1e-3) / 1e12
-        e = {"kernel": "dist_gemm_x3w_kernel<2> (256 x 256 block tiles of points x centroids, 3 x v_mfma_f32_32x32x16_bf16 on hi/lo-split operands; arg-min fused into the epilogue; dist_gemm_x3_kernel<true> on 128 x 128 tiles when a shape is not a multiple of 256)",
+        e = {"kernel": "dist_gemm_x3w_kernel<2, 1> (the assign cascade's first filter since round 6: 256 x 256 block tiles of points x centroids, ONE v_mfma_f32_32x32x16_f16 per k-step on fp16 operands, certified with their measured residuals; arg-min fused into the epilogue; the open points through assign_tile_rescan_kernel; "
+                       "dist_gemm_x3w_kernel<2, 3> -- three bf16 products of hi/lo-split operands -- when the probe says the cascade does not pay or vers_set_option('assign_terms', 3))",
              "shape": [int(shape_pts), int(k_), d], "launches": int(bs["gemm_launches"]), "us_per_launch": round(bs["gemm_ms"] / bs["gemm_launches"] * 1e3, 1),
-             "algorithmic_tflops": round(tf, 1), "frac_of_bf16_dense_div3": round(tf / (BF16_DENSE_PEAK_TF / 3.0), 4), "frac_of_f32_mfma_peak": round(tf / MFMA_F32_PEAK_TF, 4),
+             "algorithmic_tflops": round(tf, 1), "frac_of_f16_dense": round(tf / BF16_DENSE_PEAK_TF, 4), "frac_of_f32_mfma_peak": round(tf / MFMA_F32_PEAK_TF, 4),
              "assign_pass_ms": round(bs["assign_ms"] / max(1.0, bs["assign_passes"]), 2), "assign_passes": int(bs["assign_passes"]),
              "points_redone_exactly_pct": round(100.0 * bs["redone_points"] / max(1.0, bs["gemm_flop"] / (2.0 * k_ * d)), 3),
              "update_centroids_ms_total": round(bs["update_ms"], 2), "cost_fold_ms_total": round(bs["cost_ms"], 2), "build_index_s": round(wall_s, 3), "note": note}
-        for pf in ("r05_kmeans.json", "r04_kmeans.json", "r03_kmeans.json"):  # MFMA-busy of this kernel from the committed PMC pass (bench.py cannot collect counters itself)
+        for pf in ("r06_kmeans.json",):  # MFMA-busy of this kernel from the committed PMC pass (bench.py cannot collect counters itself)
             try:
                 pj = json.load(open(os.path.join(ROOT, "profiles", pf)))
                 e["mfma_busy_pct"] = pj["mfma_busy_pct"].get(str(int(k_)))
