@@ -1,5 +1,5 @@
 """The k-means assign contraction as build_index runs it (vers_build_stats: HIP events around the launches), at cfg3's and
-cfg5's cluster counts.  usage: [VERS_SPLIT_POINTS=0] python scripts/bench_assign.py"""
+cfg5's cluster counts.  usage: [VERS_OPTIONS=assign_terms=3] [ONLY=0] python scripts/bench_assign.py"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
