@@ -70,7 +70,7 @@ from vers_amd import capi
 from vers_amd.index import IVFFlatIndex
 M1 = capi.METRIC_COSDIST
 total = 0
-for seed, n, d, k, b, nprobe, top_ks, scale in [(0xC1, 9000, 96, 48, 160, 8, (1, 10, 30), False), (0xC2, 4000, 300, 32, 96, 6, (10,), True),
+for seed, n, d, k, b, nprobe, top_ks, scale in [(0xC1, 9000, 96, 48, 160, 8, (1, 10, 30, 100), False), (0xC2, 4000, 300, 32, 96, 6, (10,), True),
                                                 (0xC3, 3000, 768, 24, 70, 5, (10,), False)]:
     X = dg.dist_c(seed, n, d, 4 * k, dg.default_sigma(d))
     if scale:  # rows of different lengths: cosine distance 1 - dot is then NOT a monotone function of the L2 distance
