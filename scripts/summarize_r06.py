@@ -181,7 +181,8 @@ for name, v in kk:
     for label, sel_, flops, key in (("k=4096 [131072 x 4096 x 768]", small, 2.0 * 131072 * 4096 * 768, "4096"), ("k=65536 [131072 x 65536 x 768]", big, 2.0 * 131072 * 65536 * 768, "65536")):
         if not sel_:
             continue
-        full = [x for x in sel_ if x > 0.8 * max(sel_)]   # whole 131072-point batches (the last batch of a pass may be short)
+        med = sorted(sel_)[len(sel_) // 2]
+        full = [x for x in sel_ if 0.8 * med < x < 1.25 * med]   # whole 131072-point batches (the probing batch of a pass and its last one are short; a cold first launch is long)
         mean = sum(full) / len(full)
         line = f"{short(name)[:60]} {label}: {len(full)} full launches, mean {mean:.1f} us = {flops / mean / 1e6:.1f} algorithmic TFLOP/s"
         if busy and gui and len(busy) == len(v):
