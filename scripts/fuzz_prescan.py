@@ -18,9 +18,9 @@ seed, out_path = int(sys.argv[1]), sys.argv[2]
 rng = np.random.default_rng(seed)
 n = int(rng.integers(300, 20000)); d = int(rng.choice([8, 33, 64, 96, 130, 300, 768, 768, 1536, 2100]))   # (1536, 2100: only the narrow 16-query blocks fit LDS)
 if d > 1000: n = min(n, 6000)
-k = int(rng.integers(4, 120)); b = int(rng.integers(2, 400)) if rng.random() < 0.8 else int(rng.integers(2, 20))   # (small batches: < 2 queries per list)
-nprobe = int(rng.integers(2, min(k, 40) + 1))
-top_k = int(rng.choice([1, 5, 10, 20, 40, 54]))
+k = int(rng.integers(4, 120)) if rng.random() < 0.7 else int(rng.integers(120, 400)); b = int(rng.integers(2, 400)) if rng.random() < 0.8 else int(rng.integers(2, 20))   # (small batches: < 2 queries per list)
+nprobe = int(rng.integers(2, min(k, 40) + 1)) if rng.random() < 0.7 else int(rng.integers(2, min(k, 260) + 1))   # (round 6: up to 200 lists ranked on the matrix cores, any number scanned there)
+top_k = int(rng.choice([1, 5, 10, 20, 40, 48, 49, 54, 64, 100, 150, 200, 230]))   # (49 .. 200: the wide candidate lists; 230: the ordered chains)
 dup = rng.random() < 0.3
 X = dg.dist_c(seed, n, d, max(2, k), dg.default_sigma(d))
 if dup:
