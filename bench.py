@@ -710,10 +710,11 @@ def main():
             sweep_keep[bsz] = (ki.cpu().numpy().astype(np.uint64), kd.cpu().numpy(), kc.cpu().numpy())
         extra["batch_sweep"] = {"workload": f"the headline's index and queries at other batch sizes, {S} batches in flight, nprobe={nprobe} top_k={top_k}", "by_batch": sweep}
         log("[bench] batch sweep: " + ", ".join(f"{k_}: {v_['queries_per_sec'] / 1e3:.1f} k q/s ({v_['us_per_batch']} us)" for k_, v_ in sweep.items()))
-        # (a2b) the EDGES of the fast domain on the headline's index (the reference has no caps: ivfflat.rs:153): wider results than a
-        # candidate list holds (top_k > 58: ordered chains, 64 ranks per pass), more probes than a key per lane (nprobe > 64) and
-        # batches of 2 - 3 (below pre_min_batch: consecutive single queries on the shadow since round 5; one ordered-chain scan per (query, list) pair before).  Correctness of these shapes is
-        # tests/test_limits_gpu.py's; here: what they cost.
+        # (a2b) the EDGES of the fast domain on the headline's index (the reference has no caps: ivfflat.rs:153): results wider than one key per
+        # lane (top_k 64 .. 200: candidate lists four keys per lane wide since round 6 -- the ordered chains, 64 ranks per pass, before), more
+        # probes than a key per lane (nprobe 128: ranked and scanned on the matrix cores; 256: ranked exactly, scanned there) and batches of
+        # 2 - 3 (below pre_min_batch: consecutive single queries on the shadow).  Correctness of these shapes is tests/test_limits_gpu.py's;
+        # here: what they cost.
         edges = {}
         for name, (bsz, tk, npb) in {"top_k_64": (min(B, 256), 64, nprobe), "top_k_100": (min(B, 256), 100, nprobe), "top_k_128": (min(B, 256), 128, nprobe), "top_k_200": (min(B, 256), 200, nprobe), "nprobe_128": (min(B, 256), top_k, min(128, nlist)), "nprobe_256": (min(B, 256), top_k, min(256, nlist)),
                                       "batch_2": (2, top_k, nprobe), "batch_3": (3, top_k, nprobe)}.items():
