@@ -72,6 +72,11 @@ def test_every_dumped_val_is_inside_its_bound(metric, shadow):
             print(f"metric {metric} {'fp16 shadow' if shadow else 'f32 rows   '} {kind:16s}: worst |val - exact| / bound = {w:.4f} over {nv} dumped vals")
             assert w <= 1.0, (kind, w)
             assert ix.prescan_stats()["batches"] >= 1
+            if shadow:   # the WIDE candidate lists (results of 49 .. 200 keys: four keys per lane, hi-only query blocks) dump their vals the same way
+                b0 = ix.prescan_stats()["batches"]
+                w, nv = worst_ratio(ix, X, Q, metric, 100, nprobe, range(0, b, 9))
+                print(f"metric {metric} fp16 shadow, wide lists {kind:16s}: worst |val - exact| / bound = {w:.4f} over {nv} dumped vals")
+                assert w <= 1.0 and ix.prescan_stats()["batches"] == b0 + 1, (kind, w)
             ix.close()
     finally:
         capi.set_option("shadow", 1)
