@@ -685,7 +685,7 @@ __global__ __launch_bounds__(kWave * kPreWavesG) __attribute__((amdgpu_waves_per
       // the first kStageU loads of every thread go out BEFORE the barriers (they fly while the slowest wave of the
       // previous quad finishes and its lists are written out); one load at a time behind the barriers was ~7 us per
       // quad at d = 768 -- 7 % of the launch
-      constexpr int kStageU = 96 / kPreWavesG;  // (default: x the block's threads / 32 slots = 192 column groups: d <= 768 in one round)
+      constexpr int kStageU = (WIDE ? 16 : 96) / kPreWavesG;  // (default: x the block's threads / 32 slots = 192 column groups: d <= 768 in one round; the WIDE kernel has no registers to spare: two rounds)
       const uint32_t n_cg = p.ld / 4u;
       f32x4 x[kStageU];
 #pragma unroll
