@@ -65,7 +65,7 @@ int32_t vers_flat_create(int32_t device, uint32_t d, vers_flat_t** out);
 int32_t vers_flat_destroy(vers_flat_t* h);
 /* Copies n rows (pitch row_stride_bytes >= 4*d) into HBM; position = vec_id.  With vers_set_option("shadow", 1) (default) the
  * handle also keeps an fp16 shadow of the rows (+ 2 d + 8 bytes per row, optional memory: dropped when it does not fit): a single
- * query (b == 1, top_k <= 58) then streams the shadow -- half the bytes -- and is finished exactly (pre-selection, certificate,
+ * query (b == 1, top_k <= 48) then streams the shadow -- half the bytes -- and is finished exactly (pre-selection, certificate,
  * exact re-score; exact re-scan when the certificate fails); vers_set_option("single_shadow", 0) keeps the f32 scan.  Same results. */
 int32_t vers_flat_upload(vers_flat_t* h, const float* rows, uint64_t n, uint64_t row_stride_bytes);
 /* Same from rows already in HBM (row-major, pitch ld_floats >= d).  The handle keeps its own
@@ -409,7 +409,7 @@ int32_t vers_ivf_last_finish_ms(vers_ivf_t* h, float* out_ms);
 int32_t vers_ivf_coarse_stats(vers_ivf_t* h, uint64_t* out_mfma_batches, uint64_t* out_fallback_queries);
 /* Batched list scan statistics (nprobe mode): batches whose list scan ran on the matrix cores (pre-selection +
  * exact re-score + certificate, csrc/prescan.hip.h) and queries whose certificate failed and were re-scanned
- * exactly.  Results are bit-identical either way; VERS_PRESCAN=0 keeps the ordered-chain scan for every batch. */
+ * exactly.  Results are bit-identical either way; option "prescan" = 0 keeps the ordered-chain scan for every batch. */
 int32_t vers_ivf_prescan_stats(vers_ivf_t* h, uint64_t* out_batches, uint64_t* out_fallback_queries);
 /* An fp16 shadow copy of the stored rows (+50 % corpus memory) feeds the matrix-core pre-selection of batched searches:
  * half the HBM bytes per list scan, a ~2x wider certificate window, the same exact f32 finish -- results stay

@@ -29,7 +29,7 @@ struct RescoreArgs {
   int force_fail;          // testing: nothing certifies
   int shadow;              // the vals came from the fp16 shadow: the bound grows by its measured residual (xmax2_bits[2]); 2 = and the query block
                            // was fp16 hi ONLY: the query's own residual |q' - fp16(q')|, summed here next to |q|^2, is charged too (pre_bound)
-  uint32_t debug;          // diagnosis (VERS_SCAN_DEBUG): 512 skip the row gather + chains, 1024 merge only 1/8 of the slots
+  uint32_t debug;          // diagnosis (option "scan_debug"): 512 skip the row gather + chains, 1024 merge only 1/8 of the slots
   uint32_t* fail_list;     // [b] out: queries to redo exactly, [b] = their count
   uint32_t* stats;         // [0] += failed queries
   uint32_t* status;
@@ -37,7 +37,7 @@ struct RescoreArgs {
   float* out_dist;
   uint32_t* out_count;
   uint64_t* out_keys;
-  unsigned long long* stamps = nullptr;  // diagnosis (VERS_SCAN_DEBUG & 16): [52..57] cycles of the exact finish's phases, summed over the blocks
+  unsigned long long* stamps = nullptr;  // diagnosis (option "scan_debug" & 16): [52..57] cycles of the exact finish's phases, summed over the blocks
   // the flat index's single query (flat_shadow_search1) has no planning kernel to zero its two per-call words: the finish clears the flag it
   // read once it is done with it, the fallback launch the count of queued queries it served (both nullable)
   uint32_t* reset_flag = nullptr;

@@ -445,7 +445,7 @@ struct SearchPlan {
   bool use_pre = false;       // matrix-core list scan + exact finish (prescan.hip.h)
   bool use_shadow = false;    // ... on the fp16 shadow of the rows
   bool pre_hi_only = false;   // ... with the query block as fp16 hi only (rows too long for hi + lo in LDS: prescan_kernel_g<.., LO = false>)
-  int pre_mode = 1;           // VERS_PRESCAN
+  int pre_mode = 1;           // option "prescan"
   uint32_t kp = 0;            // candidate keys per partial list of the matrix-core scan (top_k + slack)
   uint32_t k_keep = 0;        // keys per partial slot
   uint32_t n_pass = 1;        // 64 result ranks per pass (ordered-chain scans)
@@ -468,7 +468,7 @@ int32_t upload_queries(const float* queries, uint64_t stride_bytes, uint32_t b, 
 
 // ---- ivf_build.hip -----------------------------------------------------------------------------------------------------
 int32_t refresh_norms(vers_ivf* h, uint64_t r_begin, uint64_t r_end, hipStream_t st);
-int32_t poison_slack(vers_ivf* h, float value, hipStream_t st);  // test hook / VERS_POISON_SLACK: rows that hold no vector <- value
+int32_t poison_slack(vers_ivf* h, float value, hipStream_t st);  // test hook / option "poison_slack_bits": rows that hold no vector <- value
 
 }  // namespace ivf
 }  // namespace vers

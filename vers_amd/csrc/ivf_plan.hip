@@ -59,7 +59,7 @@ struct GroupArgs {
   GroupDesc* groups;
   u32x4* ff_begin;       // 0xFF-filled here: the pruning bounds (matrix-core scan; its slots need no fill: ivf_rescore_kernel
   uint64_t ff_vec16;     // reads written slots only).  This many 16-byte words.
-  unsigned long long* stamps;  // diagnosis (VERS_SCAN_DEBUG & 16): [16..19] 100 MHz clock at the phase boundaries, block 0
+  unsigned long long* stamps;  // diagnosis (option "scan_debug" & 16): [16..19] 100 MHz clock at the phase boundaries, block 0
 };
 // a table entry this block stored itself a phase ago: read past the vector L1 (which may hold the line from before the store)
 __device__ __forceinline__ uint32_t ld_l2(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -251,7 +251,7 @@ struct Plan1Args {
   Item1Rec* recs = nullptr; const uint32_t* list_off = nullptr; uint32_t S_max = 0;  // recs != nullptr: the items as records (scan1_kernel); list_off: storage row of a list BY CENTROID
   uint32_t *pj_nq = nullptr, *qflags = nullptr, *fail_cnt = nullptr;  // the shadow scan's exact finish (scan1h_kernel): records per probe; flags and the queue's count, zeroed here
   u32x4* ff_begin; uint32_t ff_vec16;  // the list scan's partial slots: filled with all ones (empty) by whoever plans
-  unsigned long long* stamps = nullptr;  // diagnosis (VERS_SCAN_DEBUG & 16): [48..50] 100 MHz clock after the merge, the list tables, the plan's stores
+  unsigned long long* stamps = nullptr;  // diagnosis (option "scan_debug" & 16): [48..50] 100 MHz clock after the merge, the list tables, the plan's stores
 };
 template <bool COHERENT>  // the coarse slots come from other blocks of this launch (coarse1_kernel)
 __device__ __forceinline__ void plan1_block(const Plan1Args& a, uint64_t (*sh)[kWave]) {
@@ -345,7 +345,7 @@ struct Coarse1Args {
   uint32_t P;
   uint32_t* ctr;      // zero between launches (the last block resets it)
   uint32_t* status;
-  unsigned long long* stamps;  // diagnosis (VERS_SCAN_DEBUG & 16): [32..39] 100 MHz clock at the phase boundaries of the LAST block
+  unsigned long long* stamps;  // diagnosis (option "scan_debug" & 16): [32..39] 100 MHz clock at the phase boundaries of the LAST block
 };
 constexpr int kC1Phase = 16;  // chunks of a phase = waves of the block
 constexpr size_t kC1LdsBytes = (size_t)kC1Phase * kLoads * kWave * sizeof(f32x4);  // 128 KiB of products
@@ -619,7 +619,7 @@ int32_t plan_search(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint32_t b
   // one key per lane is the width of every list in the kernels: more ranked lists (P > 64) or more results (top_k > 64)
   // are produced 64 ranks per pass (ScanParams::lower), on the ordered-chain kernels
   const bool one1 = b == 1 && P <= (uint32_t)kMaxTopK;  // single query: coarse merge + plan fused in plan1_kernel
-  // ... and the coarse scan with them in coarse1_kernel (VERS_COARSE1=0: the ordered-chain scan + plan1_kernel, for A/B runs)
+  // ... and the coarse scan with them in coarse1_kernel (option "coarse1" = 0: the ordered-chain scan + plan1_kernel, for A/B runs)
   const bool c1_on = opt_get("coarse1", 1) != 0;
   const bool one1_fused = one1 && c1_on;
   if (one1_fused) {
@@ -648,7 +648,7 @@ int32_t plan_search(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint32_t b
   // (round 4 returned "vector dimension too large" at d > 2560 with 16-query groups).
   while (QG > 1 && scan_lds_bytes(QG, h->ld) > 160u * 1024u) QG = QG == 16 ? 8 : 1;
   // Batches in nprobe mode: the list scan runs on the matrix cores with an exact finish (prescan.hip.h); same bits.
-  // VERS_PRESCAN=0 keeps the ordered-chain scan, =2 makes every certificate fail (exercises the exact fallback).
+  // option "prescan" = 0 keeps the ordered-chain scan, = 2 makes every certificate fail (exercises the exact fallback).
   const int pre_mode = knobs().pre_mode;
   // slack of 10 keys: at cfg3 a slack of 6 left ~2 of 1024 queries uncertified per batch, 10 none
   uint32_t kp = std::min<uint32_t>(kPreMaxKp, std::max<uint32_t>(top_k + 10, top_k + top_k / 2));
@@ -671,11 +671,11 @@ int32_t plan_search(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint32_t b
   if (wide_k) kp = top_k + kWideSlack;
   // The block's query operand must fit LDS next to the candidate buffers: 32 queries up to d = 1152; the NARROW variant's 16 up
   // to d = 2304 (d = 1536 -- a dimension the reference's own bindings instantiate, vers-py/src/lib.rs:26-65 -- went to the
-  // ordered-chain scan until round 4, ~3x slower).  VERS_PRE_NARROW=1 forces the narrow blocks (tests, A/B).
+  // ordered-chain scan until round 4, ~3x slower).  option "pre_narrow" = 1 forces the narrow blocks (tests, A/B).
   // Round 5: on the fp16 shadow a query block that does not fit with both halves of its fp16 hi + lo split drops the lo half
   // (prescan_kernel_g<.., LO = false>): 32 queries per block up to d = 2304 -- at d = 1536 the 16-query blocks streamed every list
   // probed by more than 16 queries once per extra group, 2.15x the union's bytes -- and 16 up to d = 4608; the certificate charges
-  // the query's measured fp16 residual instead (pre_bound).  VERS_PRE_HI_ONLY=1 forces it at every d (tests, A/B).
+  // the query's measured fp16 residual instead (pre_bound).  option "pre_hi_only" = 1 forces it at every d (tests, A/B).
   const bool force_hi = opt_get("pre_hi_only", 0) != 0;
   uint32_t pre_nq = 0;
   bool pre_hi_only = false;
@@ -683,7 +683,7 @@ int32_t plan_search(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint32_t b
     const bool narrow = knobs().pre_narrow;
     auto fits = [&](uint32_t nq, bool hi) { return prescan_lds_bytes_g(h->ld, kp, nq, hi) <= 160u * 1024u; };
     // 64 queries per block (two sets of 32, hi-only) wherever they fit -- d <= 960 with the default slack --: lists probed by 33 .. 64
-    // queries of the batch are then streamed once instead of twice (VERS_PRE_WIDE=0: the 32-query hi + lo blocks of rounds 2-4)
+    // queries of the batch are then streamed once instead of twice (option "pre_wide" = 0: the 32-query hi + lo blocks of rounds 2-4)
     const bool wide_on = opt_get("pre_wide", 1) != 0;
     if (wide_k) {  // (256-key buffers: 64 KB for 32 queries next to a hi-only query block)
       if (!narrow && fits(kPreQ, true)) { pre_nq = kPreQ; pre_hi_only = true; }
@@ -698,10 +698,10 @@ int32_t plan_search(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint32_t b
   // Small batches too (round 3 required >= 2 queries per list on average and sent batch 8 .. 128 at nlist = 4096 to one
   // ordered-chain scan per (query, list) pair -- every list re-read per query, f32 rows): a list probed by ONE query of the batch
   // is still streamed from the half-size shadow at the chip's rate, and the staging of a mostly empty query block costs less
-  // than the bytes it saves.  VERS_PRE_MIN_BATCH (default 4; measured at cfg3: batch 4 171 vs 209 us, batch 2 equal) is the smallest batch that takes this path.
+  // than the bytes it saves.  option "pre_min_batch" (default 4; measured at cfg3: batch 4 171 vs 209 us, batch 2 equal) is the smallest batch that takes this path.
   const bool pre_batch = QG != 1 || (b >= pre_min_batch_ref().load(std::memory_order_relaxed) && b > 1);
   // A single query takes the shadow too (round 5, scan1h_kernel in ivf_search.hip): half the bytes of the ordered-chain scan of the
-  // f32 rows, then the same exact finish.  vers_set_option("single_shadow", 0) / VERS_SCAN1H=0: the ordered-chain scan (A/B runs).
+  // f32 rows, then the same exact finish.  vers_set_option("single_shadow", 0): the ordered-chain scan (A/B runs).
   // (its kernels stage the query in LDS: rows beyond ~36 k columns keep the scalar-operand ordered chains -- no dimension cap on this path either)
   const bool one1_pre = one1 && single_shadow_ref().load(std::memory_order_relaxed) != 0 && use_shadow && !ref_mode && pre_mode != 0 && top_k + kPreMinSlack <= kPreMaxKp &&
                         (size_t)h->ld * sizeof(float) + 24576 <= 160u * 1024u;  // (the finish: the query + 8 KB of exchange area + 14 KB of static buffers)

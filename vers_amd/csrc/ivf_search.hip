@@ -199,7 +199,7 @@ int32_t launch_ivf_scan(vers_ivf* h, const IvfSrc<QG>& src, uint32_t items_bound
     p.stamps = W->stamps.as<unsigned long long>();
   }
   // pruning bounds shared between the items of a merge group (they run at different times here, unlike the flat
-  // scans); VERS_SCAN_DEBUG bit 3 switches them off for A/B runs
+  // scans); option "scan_debug" bit 3 switches them off for A/B runs
   p.bounds = (QG != 1 && !(scan_debug_flags() & 8u)) ? W->partials.as<uint64_t>() + W->ivf_bounds_off : nullptr;
   p.lower = lower;
   p.next_quad = nullptr;
@@ -244,7 +244,7 @@ int32_t launch_scan1(vers_ivf* h, const Scan1Args& a, uint32_t items_bound, hipS
   if (blocks == 0) blocks = 1;
   const bool no_ev = !W->ev_on;
   const uint32_t slot = (uint32_t)(W->ev_count % SearchWs::kEvRing);
-  // a tile per block of 16 waves (scan1t_kernel: the whole tile in flight at once) instead of a tile per wave; VERS_SCAN1T=0: the latter
+  // a tile per block of 16 waves (scan1t_kernel: the whole tile in flight at once) instead of a tile per wave; option "scan1t" = 0: the latter
   const bool t1_on = opt_get("scan1t", 1) != 0;
   // ... when the query visits few tiles -- the reference's own mode, a few probes --: with a tile per CU and round, 1361 tiles (nprobe = 32 at
   // cfg3 without a shadow) take 72 us against the tile-per-wave kernel's 58
@@ -360,7 +360,7 @@ int32_t search_dev_locked(vers_ivf* h, const float* q_dev, uint64_t ldq_in, uint
   // way.  The handle knows its shortest list (lists_that_always_suffice; add() only lengthens lists), so a BATCH in that mode takes
   // the nprobe path: the matrix-core scan of the fp16 shadow + exact finish instead of the ordered chains over the f32 rows (half the
   // bytes: 1.52 -> 0.7 ms per 1024 queries at cfg3).  Single queries keep the f32 tile-per-block scan (scan1t_kernel: one list is
-  // latency-bound, the exact finish would cost more than it saves).  VERS_REF_AS_NPROBE1=0: the ordered chains (A/B runs).
+  // latency-bound, the exact finish would cost more than it saves).  option "ref_as_nprobe1" = 0: the ordered chains (A/B runs).
   const bool ref_as_np1 = opt_get("ref_as_nprobe1", 1) != 0;
   if (nprobe == 0 && ref_as_np1 && out_keys == nullptr && h->world == 1 && b >= pre_min_batch_ref().load(std::memory_order_relaxed) && top_k + kPreMinSlack <= kPreMaxKp &&
       knobs().pre_mode != 0 && h->lists_that_always_suffice(top_k) == 1)

@@ -253,7 +253,7 @@ int32_t km_assign_mfma(const float* X, uint32_t ldx, uint64_t n, const float* C,
   bool hi_only = wide_shape && terms_opt != 3 && (terms_opt == 1 || ws.cascade != 0);
   const bool probing = hi_only && terms_opt == 0 && ws.cascade < 0;
   const bool tiles_on = opt_get("assign_tiles", 1) != 0 || hi_only;
-  // (from 64 tiles = k >= 8192 on: measured at k = 4096, N = 4M with VERS_ASSIGN_TILES_MIN=8 the pass gets 3 % SLOWER, 104.6 vs
+  // (from 64 tiles = k >= 8192 on: measured at k = 4096, N = 4M with option "assign_tiles_min" = 8 the pass gets 3 % SLOWER, 104.6 vs
   // 101.1 ms -- a launch of 2048 waves per batch against one exact scan of the 1.6 % uncertified points at the end; same bits)
   const uint32_t tiles_min = (uint32_t)opt_get("assign_tiles_min", 64);
   const bool tile_rescan = tiles_on && (k_pad / kGemmBM >= tiles_min || hi_only);

@@ -61,9 +61,9 @@ int32_t km_assign(const float* X, uint32_t ldx, uint64_t n, const float* C, uint
 // certificate, and the exact scan (km_assign) for the points that fail it.  Synchronises the stream once.
 int32_t km_assign_mfma(const float* X, uint32_t ldx, uint64_t n, const float* C, uint32_t ldc, uint32_t k, uint32_t d,
                        uint32_t* out_assign, float* out_mind, KMeansScratch& ws, int n_cu, hipStream_t st, int metric);
-// policy: VERS_ASSIGN = 1 exact scan, 2 matrix cores always, otherwise by problem size
+// policy: option "assign" = 1 exact scan, 2 matrix cores always, otherwise by problem size
 bool km_use_mfma(uint64_t n, uint32_t k, uint32_t d);
-// VERS_GEMM_X3 (bit mask, read once): bit 0 the k-means assign contraction, bit 1 the coarse quantiser's, as three bf16
+// option "gemm_x3" (bit mask): bit 0 the k-means assign contraction, bit 1 the coarse quantiser's, as three bf16
 // products of hi/lo-split operands (gemm.hip.h: dist_gemm_x3_kernel) instead of the f32 MFMA kernel.  Same results.
 int gemm_x3_mask();
 void set_gemm_x3_mask(int m);  // (vers_set_option: same-process A/B in bench.py)

@@ -344,7 +344,7 @@ __device__ __forceinline__ void prescan_item_g(const Src& src, const PreParams& 
         const unsigned long long nc = (unsigned long long)__popcll(__ballot(pm != 0));
         if (lane == 0) atomicAdd(p.stamps + 13, nc);
       }
-      uint64_t ovf = (p.debug & 4096u) ? 0ull : __ballot(pend != 0);  // (diagnosis, VERS_SCAN_DEBUG & 4096: candidates that find their buffer full are DROPPED -- wrong results, the appends' cost without the compactions')
+      uint64_t ovf = (p.debug & 4096u) ? 0ull : __ballot(pend != 0);  // (diagnosis, option "scan_debug" & 4096: candidates that find their buffer full are DROPPED -- wrong results, the appends' cost without the compactions')
       // Some query's buffer is full.  ONE wave compacts it (the lock decides which); every other wave with candidates for that
       // query only waits for the counter to re-open and then places what is still worth placing WITHOUT the lock -- appends
       // never needed it.  (Round 3 made every such wave take the lock in turn, compaction or not: the eight waves of a block

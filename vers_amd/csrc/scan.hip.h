@@ -464,7 +464,7 @@ struct ScanParams {
   const uint64_t* lower;  // nullable: per merge group (Src::bound_slot) the last key of the PREVIOUS pass -- keys <= it are dropped.
                           // Results wider than one key per lane (top_k or nprobe > 64) are produced 64 ranks per pass: keys are
                           // unique and totally ordered, so pass p holds exactly ranks 64p .. 64p+63 of the full order.
-  uint32_t debug;     // diagnosis only (env VERS_SCAN_DEBUG): 1 skip top-k, 2 skip math, 4 one query column, 16 stamp phases
+  uint32_t debug;     // diagnosis only (option "scan_debug"): 1 skip top-k, 2 skip math, 4 one query column, 16 stamp phases
   uint32_t* next_quad;  // batched kernels: device counter for dynamic quad hand-out (zeroed per launch) or nullptr
   unsigned long long* stamps;  // debug & 16: [0] cycles waiting for loads, [1] math, [2] top-k fold, [3] item setup, [4] waves
 };
@@ -748,7 +748,7 @@ __global__ __launch_bounds__(kWave * kWavesPerBlock) void scan_kernel(Src src, S
       v.qb = qlds;
       if (v.nrows == 0) continue;  // padding item (wave-uniform; barriers are outside)
       // Live query pairs: dead pairs are not computed (wave-uniform dispatch), single-pair granularity (odd counts
-      // take one ds_read_b64).  VERS_SCAN_DEBUG bit 6 = steps of two pairs, for A/B runs: measured 3.5 % slower
+      // take one ds_read_b64).  option "scan_debug" bit 6 = steps of two pairs, for A/B runs: measured 3.5 % slower
       // on the same box at cfg3.
       const uint32_t np = (p.debug & 64u) ? (((v.nq + 3) >> 2) << 1) : ((v.nq + 1) >> 1);
       if constexpr (QG == 8) {
