@@ -1,5 +1,5 @@
 """The edges of the fast domain on the headline's index (cfg3: N=10M d=768 nlist=4096), one batch in flight: nprobe beyond a key per
-lane, wide results, and the same steps under the compact memory layout.  usage: python scripts/bench_edges.py [ROWS=10000000] [MEMORY=0|1]
+lane, wide results, and the same steps under the compact memory layout.  usage: python scripts/bench_edges.py [ROWS=10000000] [MEMORY=0|1] [SHAPES=name:batch:top_k:nprobe,...] [AB=option]
 Prints one JSON object per shape on stdout."""
 import json, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -34,9 +34,12 @@ shapes = [("headline", 1024, 10, 32), ("nprobe_64", 256, 10, 64), ("nprobe_65", 
 if "SHAPES" in kv:   # name:batch:top_k:nprobe,...
     shapes = [(a, int(b_), int(c), int(e)) for a, b_, c, e in (x.split(":") for x in kv["SHAPES"].split(","))]
 only = kv.get("ONLY")
-for name, b, tk, npb in shapes:
+ab = kv.get("AB")    # AB=option: every shape with the option at 0, then at 1
+for name, b, tk, npb, opt in [(sh + (v,)) for sh in shapes for v in ((0, 1) if ab else (None,))]:
     if only and name not in only.split(","):
         continue
+    if ab:
+        capi.set_option(ab, opt)
     oi = torch.zeros(b, tk, dtype=torch.int64, device=dev); od = torch.zeros(b, tk, device=dev); oc = torch.zeros(b, dtype=torch.int32, device=dev)
     def step(i):
         ix.search_dev(Q[(i * b) % (8 * 1024 - b + 1):].data_ptr(), d, b, tk, npb, oi.data_ptr(), od.data_ptr(), oc.data_ptr(), st)
@@ -45,7 +48,7 @@ for name, b, tk, npb in shapes:
     for i in range(nst): step(3 + i)
     torch.cuda.synchronize(); dt = (time.perf_counter() - t0) / nst
     ix.poll(st)
-    rec = {"shape": name, "batch": b, "top_k": tk, "nprobe": npb, "us_per_batch": round(dt * 1e6, 1), "queries_per_sec": round(b / dt, 1),
+    rec = {"shape": name, **({ab: opt} if ab else {}), "batch": b, "top_k": tk, "nprobe": npb, "us_per_batch": round(dt * 1e6, 1), "queries_per_sec": round(b / dt, 1),
            "matrix_core_batches": ix.prescan_stats()["batches"] - pb0, "of": nst,
            "rescanned_queries_per_batch": round((ix.prescan_stats()["fallback_queries"] - fb0) / nst, 1)}
     for key, fn in (("list_scan_us", lambda: round(float(np.mean(ix.scan_times(reset=True))) * 1e3, 1)), ("union_rows", lambda: int(ix.last_scan()["union_rows"])),
