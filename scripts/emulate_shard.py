@@ -29,6 +29,12 @@ if EXCHANGE == "1": EXCHANGE = "standin"
 WG, SPIN_US, SHAPE = int(os.environ.get("WG", 32)), int(os.environ.get("SPIN_US", 25)), int(os.environ.get("SHAPE", 512))
 RESERVES = [int(r) for r in os.environ.get("RESERVE", "-1").split(",")]   # -1 = the library's AUTO policy (production)
 RANKS = os.environ.get("RANKS")  # e.g. "0,3": only these ranks of every world (quick looks)
+SWEEP = os.environ.get("SWEEP")  # e.g. "seg_rows:0,320,448": the steps again with vers_set_option(name, value) for every value (keys tagged _<name><value>)
+if SWEEP:
+    SWEEP_NAME, SWEEP_VALS = SWEEP.split(":")[0], [int(v) for v in SWEEP.split(":")[1].split(",")]
+    RESERVES = SWEEP_VALS
+else:
+    SWEEP_NAME = "scan_reserve_cus"
 dev = torch.device("cuda:0")
 X = torch.empty(n, d, dtype=torch.float32, device=dev)
 capi.gen_rows_dev(X.data_ptr(), n, d, d, 1, 0x5EED0001, 0x5EEDC0DE, 16 * nlist, float(dg.default_sigma(d)))
@@ -74,8 +80,8 @@ for W in worlds:
         rec = {"rank": R, "stored_rows": int(lens[owner == R].sum())}
         sg = standin(R, W) if EXCHANGE == "standin" else None
         for RES in RESERVES:
-          capi.set_option("scan_reserve_cus", RES)
-          tag = "" if RES == RESERVES[0] else f"_r{RES}"
+          capi.set_option(SWEEP_NAME, RES)
+          tag = "" if RES == RESERVES[0] else (f"_r{RES}" if not SWEEP else f"_{SWEEP_NAME}{RES}")
           for NS in STREAMS:
             streams = [torch.cuda.current_stream().cuda_stream] if NS == 1 else [so.cuda_stream for so in stream_objs[:NS]]
             allp_s = [torch.zeros(W, 2, B, top_k, dtype=torch.int64, device=dev) for _ in range(NS)] if EXCHANGE == "rccl1" else None
@@ -102,7 +108,7 @@ for W in worlds:
             except Exception:   # (option scan_events=0: no event records around the scans)
                 rec[f"scan_us_s{NS}{tag}"] = float("nan")
             for s_ in streams: ix.poll(s_)
-        capi.set_option("scan_reserve_cus", -1)
+        capi.set_option(SWEEP_NAME, -1 if not SWEEP else RESERVES[0])
         # rows of the batch this rank scanned (the union of its probed lists), averaged over the NQB batches
         ur = []
         for i in range(NQB):
@@ -128,7 +134,7 @@ for W in worlds:
         print(json.dumps({"world": W, **rec}), flush=True)
     summ = {"ranks": rows_w}
     for RES in RESERVES:
-      tag = "" if RES == RESERVES[0] else f"_r{RES}"
+      tag = "" if RES == RESERVES[0] else (f"_r{RES}" if not SWEEP else f"_{SWEEP_NAME}{RES}")
       for NS in STREAMS:
         v = np.array([r[f"step_ms_s{NS}{tag}"] for r in rows_w])
         summ[f"step_ms_s{NS}{tag}"] = {"max": float(v.max()), "mean": round(float(v.mean()), 4), "max_over_mean": round(float(v.max() / v.mean()), 3)}

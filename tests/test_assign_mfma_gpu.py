@@ -22,8 +22,10 @@ def bits(a):
     return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
 
 # (1) primitive, several shapes: in-place rows (d == 64: pitch == padded length), staged rows, ragged tails,
-#     duplicate centroids (ties -> lower index), points equal to a centroid, k not a multiple of 128
-for n, d, k, kind in [(5000, 64, 130, "u"), (4097, 96, 300, "c"), (777, 20, 3, "u"), (300, 300, 64, "c"), (129, 768, 257, "c"), (9, 5, 20, "u")]:
+#     duplicate centroids (ties -> lower index), points equal to a centroid, k not a multiple of 128; the last two: shapes of the
+#     fp16 x fp16 contraction staged by LDS-DMA (256-centroid tiles, rows of whole 128-column groups; d = 200: padding columns)
+for n, d, k, kind in [(5000, 64, 130, "u"), (4097, 96, 300, "c"), (777, 20, 3, "u"), (300, 300, 64, "c"), (129, 768, 257, "c"), (9, 5, 20, "u"),
+                      (3000, 128, 256, "c"), (2100, 200, 500, "c")]:
     if kind == "u":
         X = dg.dist_u(31 + n, n, d); Cn = dg.dist_u(33 + k, k, d)
     else:
@@ -81,7 +83,7 @@ def run(env_extra):
 def test_matrix_core_assign_is_bit_exact():
     out = run({"VERS_OPTIONS": "assign=2"})
     pts, fb = out["PRIM"]
-    assert pts == 5000 + 4097 + 777 + 300 + 129 + 9
+    assert pts == 5000 + 4097 + 777 + 300 + 129 + 9 + 3000 + 2100
     assert fb < pts // 2          # ties with a duplicate centroid and near-ties fail the certificate; most points pass
     pts, fb = out["BUILD"]
     assert pts >= 6000 * 2 * 2    # every assign pass of both attempts went through the matrix cores
@@ -94,11 +96,12 @@ def test_exact_scan_still_available():
 
 
 def test_cascade_hi_only_first_filter_is_bit_exact():
-    """option assign_terms = 1: the <hi, hi> bf16 product alone as the first filter of every pass (2^-8-wide certificate, the open
-    points through the tile-limited exact re-scan), = 3: never; = 0 (default, the tests above): probed per build.  Same bits always."""
-    for terms in (1, 3):
-        out = run({"VERS_OPTIONS": f"assign=2,assign_terms={terms}"})
+    """option assign_terms = 1: ONE product of fp16 operands as the first filter of every pass (certificate as wide as the operands' measured
+    residuals, the open points through the tile-limited exact re-scan), = 3: never; = 0 (default, the tests above): probed per build;
+    assign_glds = 1 / 0: the LDS-DMA kernel on fp16 copies of both operands / the register-staged kernel, whatever k is.  Same bits always."""
+    for opts in ("assign_terms=1,assign_glds=1", "assign_terms=3", "assign_terms=1,assign_glds=0"):
+        out = run({"VERS_OPTIONS": f"assign=2,{opts}"})
         pts, _ = out["PRIM"]
-        assert pts == 5000 + 4097 + 777 + 300 + 129 + 9
+        assert pts == 5000 + 4097 + 777 + 300 + 129 + 9 + 3000 + 2100
         pts, _ = out["BUILD"]
         assert pts >= 6000 * 2 * 2

@@ -27,7 +27,7 @@ OptEntry g_opts[] = {
     {"shadow"}, {"rowmajor"}, {"single_shadow"}, {"scan_events"}, {"scan_reserve_cus"}, {"pre_min_batch"}, {"host_spin"}, {"gemm_x3"},
     {"prescan"}, {"pre_slack"}, {"seg_rows"}, {"pre_narrow"}, {"pre_wide"}, {"pre_hi_only"}, {"coarse"}, {"coarse1"}, {"scan1t"},
     {"ref_as_nprobe1"}, {"assign"}, {"assign_tiles"}, {"assign_tiles_min"}, {"upload_stage_mb"}, {"scan_debug"},
-    {"poison_alloc"}, {"poison_slack_bits"}, {"test_fail_sharded"}, {"memory"}, {"wide_k"}, {"assign_terms"},
+    {"poison_alloc"}, {"poison_slack_bits"}, {"test_fail_sharded"}, {"memory"}, {"wide_k"}, {"assign_terms"}, {"assign_glds"},
 };
 OptEntry* opt_find(const char* name) {
   for (OptEntry& e : g_opts)

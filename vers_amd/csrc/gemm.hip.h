@@ -102,6 +102,16 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[2][2], float* lds, c
       else { const float t = w1 < v2 ? w1 : v2; v2 = t; }  // includes w1 == v1: second == best
       if (nan) v2 = __builtin_nanf("");
     };
+    // (the tile's 128 centroid norms through LDS, four consecutive rows per ds_read_b128: wide_epilogue's note)
+    __syncthreads();  // the operand tiles are dead
+    float* const cn_s = As + 512;  // (behind the exchange area below: 384 floats)
+    if (threadIdx.x < (unsigned)kGemmBM) cn_s[threadIdx.x] = cnorm[m0 + threadIdx.x];  // (k_pad entries, +inf in the padding)
+    __syncthreads();
+    f32x4 cn4[2][4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) cn4[a][q] = *reinterpret_cast<const f32x4*>(cn_s + wr * 64 + a * 32 + 8 * q + 4 * hh);
     float bv1[2], bv2[2];
     uint32_t bc1[2];
 #pragma unroll
@@ -114,7 +124,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[2][2], float* lds, c
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
           const uint32_t m = m0 + wr * 64 + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
-          float g = metric ? -acc[a][b][e] : cnorm[m] - 2.0f * acc[a][b][e];
+          float g = metric ? -acc[a][b][e] : cn4[a][e >> 2][e & 3] - 2.0f * acc[a][b][e];
           if (m >= k_rows) g = __builtin_inff();  // padding centroids (zero rows) are not candidates
           nan |= g != g;
           if (g < v1) { v2 = v1; v1 = g; c1 = m; }
@@ -434,6 +444,91 @@ static __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2
 // The coarse quantiser (1024 x 4096) would be 64 such blocks on 256 CUs and stays on the 128 x 128 tiles.
 constexpr int kGemmWide = 256;
 constexpr size_t kX3WLdsBytes = 2 * 2 * 2 * (size_t)kGemmWide * kX3Pitch * 2;  // two buffers x A|B x hi|lo = 128 KB
+// Epilogue of the wide (256 x 256) contraction kernels: per point (column) the smallest value, its centroid and the second smallest over each
+// 128-centroid row tile (the unit assign_argmin_merge_kernel / assign_tile_rescan_kernel work in): same rules as gemm_epilogue<true>.
+// `T`: the block's operand storage, dead by now (the callers' loops end on a barrier with no load to LDS in flight).
+__device__ __forceinline__ void wide_epilogue(f32x16 (&acc)[2][4], void* T, const float* __restrict__ cnorm, uint32_t N_pad, int metric, uint32_t k_rows,
+                                              float* __restrict__ part_v1, uint32_t* __restrict__ part_c1, float* __restrict__ part_v2, uint32_t m0,
+                                              uint32_t n0, int wr, int wc, int r, int hh) {
+  auto fold = [](float& v1, uint32_t& c1, float& v2, float w1, uint32_t d1, float w2) {
+    const bool nan = (v2 != v2) || (w2 != w2);
+    if (w1 < v1) { v2 = v1 < w2 ? v1 : w2; v1 = w1; c1 = d1; }
+    else { const float t = w1 < v2 ? w1 : v2; v2 = t; }
+    if (nan) v2 = __builtin_nanf("");
+  };
+  // the block's 256 centroid norms through LDS, four consecutive rows per ds_read_b128.  (Through round 6's first half every element read
+  // cnorm[m] from memory, and with no register to spare the compiler waited for each of the 128 loads of a lane before it issued the
+  // next: 15 us of a block's 42 -- 500 us of the 1.29 ms launch at k = 4096 x 131072 points.)
+  // Staged per metric so that an element is  g = cn - s * acc  with no further case: squared Euclidean s = 2, cn = |c|^2; cosine distance
+  // s = 1, cn = 0 (0 - acc: -acc but for the sign of a zero, which no comparison sees); padding centroids (zero rows) cn = +inf: never a
+  // candidate.
+  float* const cn_s = reinterpret_cast<float*>(T) + 2048;  // (behind the exchange area below: 1536 floats)
+  if (threadIdx.x < (unsigned)kGemmWide) {
+    const uint32_t m = m0 + threadIdx.x;
+    cn_s[threadIdx.x] = m >= k_rows ? __builtin_inff() : (metric ? 0.0f : cnorm[m]);
+  }
+  __syncthreads();
+  f32x4 cn4[2][4];
+  bool cn_nan = false;
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      cn4[a][q] = *reinterpret_cast<const f32x4*>(cn_s + wr * 64 + a * 32 + 8 * q + 4 * hh);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) cn_nan |= cn4[a][q][u] != cn4[a][q][u];
+    }
+  const float sc = metric ? 1.0f : 2.0f;
+  float bv1[4], bv2[4];
+  uint32_t bc1[4];
+#pragma unroll
+  for (int b = 0; b < 4; ++b) {
+    // Nine operations per element (65,536 elements per block: the epilogue is VALU time).  A tie with the candidate makes second == best, a
+    // NaN makes second NaN (below): neither certifies.  A non-finite accumulator -- the only way, besides a NaN norm, an element becomes NaN
+    // -- turns `z` NaN through z = fma(acc, 0, z) (an infinite accumulator too: it would not certify anything worth having).
+    float v1 = __builtin_inff(), v2 = __builtin_inff(), z = 0.0f;
+    uint32_t c1 = m0 + wr * 64 + 4 * hh;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        const uint32_t m = m0 + wr * 64 + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+        const float av = acc[a][b][e];
+        z = __builtin_fmaf(av, 0.0f, z);
+        const float g = cn4[a][e >> 2][e & 3] - sc * av;
+        const bool lt = g < v1;
+        const float mx = lt ? v1 : g;   // the larger of (best so far, g); g when they are equal
+        c1 = lt ? m : c1;
+        v2 = mx < v2 ? mx : v2;
+        v1 = lt ? g : v1;
+      }
+    if (cn_nan || z != z) v2 = __builtin_nanf("");
+    const float w1 = __shfl_xor(v1, 32, kWave), w2 = __shfl_xor(v2, 32, kWave);  // the other half of the rows sits in lane ^ 32
+    const uint32_t d1 = (uint32_t)__shfl_xor((int)c1, 32, kWave);
+    fold(v1, c1, v2, w1, d1, w2);
+    bv1[b] = v1; bc1[b] = c1; bv2[b] = v2;
+  }
+  // rows 64..127 of a 128-centroid tile belong to the odd wave rows: through LDS (the operand tiles are dead by now: the
+  // loop ended on a barrier)
+  float* xs = reinterpret_cast<float*>(T);  // [wr >> 1][wc][b][r][3]: 1536 floats
+  if ((wr & 1) == 1 && hh == 0) {
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      float* t = xs + ((((wr >> 1) * 2 + wc) * 4 + b) * 32 + r) * 3;
+      t[0] = bv1[b]; t[1] = __uint_as_float(bc1[b]); t[2] = bv2[b];
+    }
+  }
+  __syncthreads();
+  if ((wr & 1) == 0 && hh == 0) {
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const float* t = xs + ((((wr >> 1) * 2 + wc) * 4 + b) * 32 + r) * 3;
+      fold(bv1[b], bc1[b], bv2[b], t[0], __float_as_uint(t[1]), t[2]);
+      const uint64_t o = (uint64_t)(m0 / kGemmBM + (wr >> 1)) * N_pad + n0 + wc * 128 + b * 32 + r;
+      part_v1[o] = bv1[b]; part_c1[o] = bc1[b]; part_v2[o] = bv2[b];
+    }
+  }
+}
 // The tile step:  fragment reads -> [MFMAs with the SPLIT of the next tile's point operand between them] x 2 k-steps, with
 // scheduling groups that ask for one MFMA followed by two VALU instructions -- the split's conversions issue in the shadow of
 // the matrix cores (a wave cannot issue its next MFMA for ~28 cycles anyway) instead of in a phase of their own in which, the
@@ -622,58 +717,146 @@ static __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2
       __syncthreads();
     }
   }
-  // epilogue: per point (column) the smallest value, its centroid and the second smallest over each 128-centroid row tile
-  // (the unit assign_argmin_merge_kernel / assign_tile_rescan_kernel work in): same rules as gemm_epilogue<true>
-  auto fold = [](float& v1, uint32_t& c1, float& v2, float w1, uint32_t d1, float w2) {
-    const bool nan = (v2 != v2) || (w2 != w2);
-    if (w1 < v1) { v2 = v1 < w2 ? v1 : w2; v1 = w1; c1 = d1; }
-    else { const float t = w1 < v2 ? w1 : v2; v2 = t; }
-    if (nan) v2 = __builtin_nanf("");
+  wide_epilogue(acc, T, cnorm, N_pad, metric, k_rows, part_v1, part_c1, part_v2, m0, n0, wr, wc, r, hh);
+}
+// The cascade's first filter with BOTH operands already fp16 in memory (round 6, second half): the same 256 x 256 block, 8 waves of
+// 64 x 128, the same products in the same order as dist_gemm_x3w_kernel<2, 1> -- bit for bit the same values -- but K-tiles of 64 columns
+// staged by LDS-DMA (global_load_lds_dwordx4: 1 KiB per wave instruction, no staging registers, no conversion in the loop) in pieces of
+// 8 rows x one whole 128-byte line.  What bounds the register-staged kernel is not the matrix cores (busy 26 % of a K-tile's 4.2 k cycles,
+// profiles/r06_kmeans.json) but the CU's fill path: its 32-column K-tiles take HALF a cache line of every fp16 row per step, the other
+// half is gone from the 32 KB L1 when the next step asks for it (512 lines per step), so a K-tile pulls 64 KB through a 64 B/clk port
+// for 32 KB of operands.  A ring of four such half-line tiles three steps ahead measured the same 1.36 ms per launch at k = 4096
+// (and 17.6 vs 20.4 ms at k = 65536): depth was not it.  Whole lines halve the fill traffic and the address work per flop.
+//   LDS image: rows of 128 bytes (64 columns), the 16-byte chunk c of row `row` at position c ^ ((row >> 1) & 7): the 16 lanes a
+//   ds_read_b128 serves per clock (rows r .. r + 15, one k-chunk) fall on the 16 slots of the 256-byte bank row.  An LDS-DMA writes lane
+//   L's 16 bytes at base + 16 L, so the swizzle sits on the SOURCE side: lane L of the piece that covers rows 8 j .. 8 j + 7 fetches
+//   chunk (L & 7) ^ ((row >> 1) & 7) of row 8 j + (L >> 3) -- the eight lanes of a row still read one whole line.
+//   Ordering (LDS-DMA data is ordered for a ds_read only by the issuing wave's vmcnt followed by a barrier the reader has passed):
+//   step t issues tile t + 1 into the other buffer (read in step t - 1: every wave left it at the barrier that ended that step, its
+//   reads returned -- lgkmcnt(0) in front of the barrier), multiplies tile t, waits for its own pieces and meets the others.
+constexpr int kHBK = 64;                        // columns of a K-tile: one 128-byte line of fp16
+constexpr int kHTile = kGemmWide * kHBK;        // elements of one operand's K-tile (32 KB)
+constexpr size_t kGemmHLdsBytes = (size_t)2 * 2 * kHTile * 2;  // two buffers x A | B = 128 KB
+static __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void dist_gemm_h_kernel(
+    const _Float16* __restrict__ Xh, const _Float16* __restrict__ Ch, const float* __restrict__ cnorm, uint32_t K, uint32_t N_pad, int metric,
+    uint32_t m_tiles, uint32_t n_tiles, uint32_t grp, uint32_t k_rows, float* __restrict__ part_v1, uint32_t* __restrict__ part_c1,
+    float* __restrict__ part_v2) {
+  extern __shared__ __attribute__((aligned(16))) _Float16 TH[];
+  typedef __attribute__((address_space(3))) void lds_void;
+  typedef const __attribute__((address_space(1))) void glb_void;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wid >> 1, wc = wid & 1;  // wave rows 0..3 (64 centroids each), wave columns 0..1 (128 points each)
+  uint32_t tile_m, tile_n;
+  gemm_tile_coords(m_tiles, n_tiles, grp, tile_m, tile_n);
+  const uint32_t m0 = tile_m * kGemmWide, n0 = tile_n * kGemmWide;
+  f32x16 acc[2][4];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.0f;
+  // this wave's eight pieces of a K-tile: rows 8 (wid + 8 i) .. + 7 of the centroid tile and of the point tile, i < 4
+  // ((row >> 1) & 7 of row 8 j + (L >> 3), j = wid + 8 i: 4 (wid & 1) + (L >> 4))
+  const int prow = lane >> 3, pchunk = (lane & 7) ^ (4 * (wid & 1) + (lane >> 4));
+  const _Float16* const asrc = Ch + (uint64_t)(m0 + 8 * wid + prow) * K + pchunk * 8;   // piece i: + 64 i rows
+  const _Float16* const bsrc = Xh + (uint64_t)(n0 + 8 * wid + prow) * K + pchunk * 8;
+  const uint64_t piece_step = (uint64_t)64 * K;
+  auto issue = [&](uint32_t k0, int buf) {
+    _Float16* const A = TH + (buf * 2 + 0) * kHTile + 8 * wid * kHBK;
+    _Float16* const B = TH + (buf * 2 + 1) * kHTile + 8 * wid * kHBK;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      __builtin_amdgcn_global_load_lds((glb_void*)(asrc + i * piece_step + k0), (lds_void*)(A + i * 64 * kHBK), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((glb_void*)(bsrc + i * piece_step + k0), (lds_void*)(B + i * 64 * kHBK), 16, 0, 0);
+    }
   };
-  float bv1[4], bv2[4];
-  uint32_t bc1[4];
+  const int r = lane & 31, hh = lane >> 5;
+  const int rsw = (r >> 1) & 7;
+  const uint32_t k_tiles = K / kHBK, k_last = K - kHBK;
+  auto kclamp = [&](uint32_t t) { const uint32_t k0 = t * kHBK; return k0 < k_last ? k0 : k_last; };
+  issue(0, 0);
+  asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+  __builtin_amdgcn_sched_barrier(0);
+  auto step = [&](auto btag, uint32_t t) {
+    constexpr int BUF = decltype(btag)::value;
+    issue(kclamp(t + 1), BUF ^ 1);  // (past the end: the last tile again, into the buffer nobody reads any more)
+    const _Float16* const A = TH + (BUF * 2 + 0) * kHTile;
+    const _Float16* const B = TH + (BUF * 2 + 1) * kHTile;
+    // the fragments of k-step s + 1 are requested BEFORE the MFMAs of k-step s (two register sets): all eight waves run in step -- what
+    // the barrier leaves of it -- so reads, then MFMAs, would keep the LDS port (768 cycles of reads per 32 columns) and the matrix
+    // cores (1024) busy one after the other
+    gf16x8 fa[2][2], fb[2][4];
+    auto fetch = [&](auto stag, int s4) {
+      constexpr int S = decltype(stag)::value;
+      const int ko = ((2 * s4 + hh) ^ rsw) * 8;
 #pragma unroll
-  for (int b = 0; b < 4; ++b) {
-    float v1 = __builtin_inff(), v2 = __builtin_inff();
-    uint32_t c1 = m0 + wr * 64 + 4 * hh;
-    bool nan = false;
+      for (int tt = 0; tt < 2; ++tt) fa[S][tt] = *reinterpret_cast<const gf16x8*>(A + (wr * 64 + tt * 32 + r) * kHBK + ko);
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+      for (int tt = 0; tt < 4; ++tt) fb[S][tt] = *reinterpret_cast<const gf16x8*>(B + (wc * 128 + tt * 32 + r) * kHBK + ko);
+    };
+    auto mult = [&](auto stag) {
+      constexpr int S = decltype(stag)::value;
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const uint32_t m = m0 + wr * 64 + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
-        float g = metric ? -acc[a][b][e] : cnorm[m] - 2.0f * acc[a][b][e];
-        if (m >= k_rows) g = __builtin_inff();  // padding centroids (zero rows) are not candidates
-        nan |= g != g;
-        if (g < v1) { v2 = v1; v1 = g; c1 = m; }
-        else if (g < v2 || g == v1) v2 = g;
-      }
-    if (nan) v2 = __builtin_nanf("");
-    const float w1 = __shfl_xor(v1, 32, kWave), w2 = __shfl_xor(v2, 32, kWave);  // the other half of the rows sits in lane ^ 32
-    const uint32_t d1 = (uint32_t)__shfl_xor((int)c1, 32, kWave);
-    fold(v1, c1, v2, w1, d1, w2);
-    bv1[b] = v1; bc1[b] = c1; bv2[b] = v2;
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b) {
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[S][a], fb[S][b], acc[a][b], 0, 0, 0);
+        }
+    };
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    fetch(I0{}, 0);
+    fetch(I1{}, 1);
+    __builtin_amdgcn_sched_barrier(0);
+    mult(I0{});
+    __builtin_amdgcn_sched_barrier(0);
+    fetch(I0{}, 2);
+    __builtin_amdgcn_sched_barrier(0);
+    mult(I1{});
+    __builtin_amdgcn_sched_barrier(0);
+    fetch(I1{}, 3);
+    __builtin_amdgcn_sched_barrier(0);
+    mult(I0{});
+    __builtin_amdgcn_sched_barrier(0);
+    mult(I1{});
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  for (uint32_t t = 0; t < k_tiles; t += 2) {  // (an even number of tiles: gemm_h_ok)
+    step(std::integral_constant<int, 0>{}, t);
+    step(std::integral_constant<int, 1>{}, t + 1);
   }
-  // rows 64..127 of a 128-centroid tile belong to the odd wave rows: through LDS (the operand tiles are dead by now: the
-  // loop ended on a barrier)
-  float* xs = reinterpret_cast<float*>(T);  // [wr >> 1][wc][b][r][3]
-  if ((wr & 1) == 1 && hh == 0) {
+  wide_epilogue(acc, TH, cnorm, N_pad, metric, k_rows, part_v1, part_c1, part_v2, m0, n0, wr, wc, r, hh);
+}
+// rows of a point batch -> fp16 (round to nearest: what dist_gemm_x3w_kernel<2, 1> converts on the fly), columns d .. ld_out and rows
+// n_rows .. n_pad zero: thread per 8 columns
+static __global__ __launch_bounds__(256) void rows_to_f16_pad_kernel(const float* __restrict__ x, uint64_t ldx, uint32_t d, uint32_t n_rows, uint32_t n_pad,
+                                                                     uint32_t ld_out, _Float16* __restrict__ out) {
+  const uint32_t per_row = ld_out / 8;
+  const uint64_t i = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= (uint64_t)n_pad * per_row) return;
+  const uint32_t row = (uint32_t)(i / per_row), c0 = (uint32_t)(i % per_row) * 8;
+  gf16x8 h;
 #pragma unroll
-    for (int b = 0; b < 4; ++b) {
-      float* t = xs + ((((wr >> 1) * 2 + wc) * 4 + b) * 32 + r) * 3;
-      t[0] = bv1[b]; t[1] = __uint_as_float(bc1[b]); t[2] = bv2[b];
-    }
+  for (int u = 0; u < 8; ++u) {
+    const uint32_t c = c0 + (uint32_t)u;
+    h[u] = (row < n_rows && c < d) ? (_Float16)x[(uint64_t)row * ldx + c] : (_Float16)0.0f;
   }
-  __syncthreads();
-  if ((wr & 1) == 0 && hh == 0) {
-#pragma unroll
-    for (int b = 0; b < 4; ++b) {
-      const float* t = xs + ((((wr >> 1) * 2 + wc) * 4 + b) * 32 + r) * 3;
-      fold(bv1[b], bc1[b], bv2[b], t[0], __float_as_uint(t[1]), t[2]);
-      const uint64_t o = (uint64_t)(m0 / kGemmBM + (wr >> 1)) * N_pad + n0 + wc * 128 + b * 32 + r;
-      part_v1[o] = bv1[b]; part_c1[o] = bc1[b]; part_v2[o] = bv2[b];
-    }
-  }
+  *reinterpret_cast<gf16x8*>(out + (uint64_t)row * ld_out + c0) = h;
+}
+inline bool gemm_h_ok(uint32_t K) { return K % (2 * kHBK) == 0; }
+inline hipError_t launch_gemm_h(uint32_t k_pad, uint32_t nb_pad, hipStream_t st, const _Float16* Xh, const _Float16* Ch, const float* cnorm, uint32_t K,
+                                uint32_t N_pad, uint32_t metric, uint32_t k_rows, float* part_v1, uint32_t* part_c1, float* part_v2) {
+  static const hipError_t attr = hipFuncSetAttribute((const void*)dist_gemm_h_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGemmHLdsBytes);
+  if (attr != hipSuccess) return attr;
+  const uint32_t m_tiles = k_pad / kGemmWide, n_tiles = nb_pad / kGemmWide;
+  uint32_t grp = 0;
+  for (uint32_t g : {2u, 1u}) if (m_tiles % (8u * g) == 0) { grp = g; break; }
+  hipLaunchKernelGGL(dist_gemm_h_kernel, dim3(m_tiles * n_tiles), dim3(512), kGemmHLdsBytes, st, Xh, Ch, cnorm, K, N_pad, (int)metric, m_tiles, n_tiles, grp, k_rows,
+                     part_v1, part_c1, part_v2);
+  return hipGetLastError();
 }
 // assign pass through the wide kernel whenever the shapes allow it
 inline bool gemm_wide_ok(uint32_t k_pad, uint32_t nb_pad, bool have_split) {

@@ -314,7 +314,14 @@ int32_t km_assign_mfma(const float* X, uint32_t ldx, uint64_t n, const float* C,
     const uint32_t nb_pad = round_up(nb, (uint32_t)bn);
     const float* xb = X + i0 * ldx;
     const float* xb_padded = in_place_ok ? xb : nullptr;  // this batch's rows with zeroed padding columns, pitch ldq (the tile re-scan's operand)
-    if (!in_place_ok || nb_pad != nb) {  // pad the columns / the tail rows through a staged copy
+    // both operands fp16 in memory, staged by LDS-DMA (dist_gemm_h_kernel) from 8192 centroids on: the batch's conversion pass (0.11 ms per
+    // 131072 x 768 points) is a tenth of the contraction at k = 4096 -- 1.13 vs 1.05 ms with the register-staged kernel that converts while
+    // it stages -- and nothing at k = 65536 (13.9 vs 16.3 ms).  Option "assign_glds": 1 always, 0 never.
+    const int glds_opt = (int)opt_get("assign_glds", -1);
+    const bool use_h = hi_only && wide && gemm_h_ok(ldq) && (glds_opt > 0 || (glds_opt < 0 && k_pad >= 8192));
+    if (use_h) {
+      if (int32_t rc = ws.xh.reserve((size_t)mb * ldq * sizeof(uint16_t))) return rc;
+    } else if (!in_place_ok || nb_pad != nb) {  // pad the columns / the tail rows through a staged copy
       if (int32_t rc = ws.xp.reserve((size_t)mb * ldq * sizeof(float))) return rc;
       if (nb_pad != nb) VERS_HIP_TRY(hipMemsetAsync(ws.xp.as<float>() + (size_t)nb * ldq, 0, (size_t)(nb_pad - nb) * ldq * sizeof(float), st));
       if (int32_t rc = launch_stage_queries(xb, ldx, d, ws.xp.as<float>(), ldq, nb, 1, st)) return rc;
@@ -324,7 +331,12 @@ int32_t km_assign_mfma(const float* X, uint32_t ldx, uint64_t n, const float* C,
     // (the triples are addressed with pitch mb: nb_pad <= mb)
     {
       KmTimer t(st, &BuildStats::gemm_ms);
-      if (wide)
+      if (use_h) {  // (the conversion is part of the filter's price: inside the timer)
+        const uint64_t work = (uint64_t)nb_pad * (ldq / 8);
+        hipLaunchKernelGGL(rows_to_f16_pad_kernel, dim3((unsigned)((work + 255) / 256)), dim3(256), 0, st, xb, (uint64_t)ldx, d, nb, nb_pad, ldq, ws.xh.as<_Float16>());
+        VERS_HIP_TRY(launch_gemm_h(k_pad, nb_pad, st, ws.xh.as<_Float16>(), reinterpret_cast<const _Float16*>(cg_f16), ws.cnorm.as<float>(), ldq, (uint32_t)mb, metric, k,
+                                   part_v1, part_c1, part_v2));
+      } else if (wide)
         VERS_HIP_TRY(launch_gemm_wide(k_pad, nb_pad, st, xb, hi_only ? cg_f16 : cg_h, cg_l, ws.cnorm.as<float>(), ldq, (uint32_t)mb, metric, k, part_v1, part_c1, part_v2, hi_only));
       else
         VERS_HIP_TRY(launch_gemm<true>((gemm_x3_mask() & 1) != 0, k_pad / kGemmBM, nb_pad / kGemmBN, st, ws.cg.as<float>(), xb, ws.cnorm.as<float>(), ldq,

@@ -42,6 +42,7 @@ struct KMeansScratch {
   DevBuf cg_s;      // the same as bf16 hi | lo halves [2][k_pad][ldq] (operand of the bf16x3 contraction, split once per pass)
   DevBuf cnorm;     // |c|^2 [k_pad] (+inf padding) + max at [k_pad]
   DevBuf xp;        // staged point batch [mb][ldq] when X cannot be used in place
+  DevBuf xh;        // the point batch as fp16 [mb][ldq], zero padded (operand of dist_gemm_h_kernel)
   DevBuf gt;        // Gt [k_pad][mb]
   DevBuf best;      // u32 [mb] candidate + f32 [mb] second-best value
   DevBuf fb;        // u32 [n] uncertified points + counter at [n]
