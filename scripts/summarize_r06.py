@@ -172,7 +172,7 @@ print()
 # ---- k-means assign contraction (scripts/bench_assign.py: N=4M k=4096 2 iterations, N=1M k=65536 1 iteration) ----
 ak = show_trace("k-means builds (scripts/bench_assign.py)", "kmeans/trace", 0, top=12)
 mk = pmc("kmeans/pmc_mfma")
-kk = [(k, v) for k, v in ak.items() if "dist_gemm_x3w_kernel" in k or "dist_gemm_x3_kernel<true" in k]
+kk = [(k, v) for k, v in ak.items() if "dist_gemm_x3w_kernel" in k or "dist_gemm_h_kernel" in k or "dist_gemm_x3_kernel<true" in k]
 km_facts = {}
 for name, v in kk:
     # launches of the first build (k = 4096: 2.5 ms each) and of the second (k = 65536: 40 ms each) are told apart by duration
@@ -193,7 +193,7 @@ for name, v in kk:
                 km_facts[key] = round(pct, 1)
         print(line)
 if km_facts:
-    json.dump({"kernel": "dist_gemm_x3w_kernel (k-means assign contraction, 256 x 256 block tiles)", "mfma_busy_pct": km_facts,
+    json.dump({"kernel": "dist_gemm_x3w_kernel<2, 1> at k = 4096, dist_gemm_h_kernel at k = 65536 (k-means assign contraction, 256 x 256 block tiles)", "mfma_busy_pct": km_facts,
                "source": "profiles/r06_summary.txt (rocprofv3 --pmc pass of scripts/bench_assign.py)"}, open(os.path.join(out, "kmeans.json"), "w"), indent=1)
 print()
 # ---- sharded search: every rank of every world (no profiler), then rank 0's per-kernel us from the traces ----

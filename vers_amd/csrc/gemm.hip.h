@@ -54,8 +54,7 @@ static __global__ void row_norms_kernel(const float* C, uint32_t ld, uint32_t k,
 // column tile in turn, so a column tile is fetched once per chunk and XCD -- and because the XCDs advance in step, one
 // of those 8 fetches comes from HBM and seven from the Infinity Cache.  The k-means assign pass (M = centroids, N = the
 // batch of points, 400 MB) with the plain order re-read the points from HBM once per centroid tile: 32 x at k = 4096.
-__device__ __forceinline__ void gemm_tile_coords(uint32_t m_tiles, uint32_t n_tiles, uint32_t grp, uint32_t& tm, uint32_t& tn) {
-  const uint32_t L = blockIdx.x;
+__device__ __forceinline__ void gemm_tile_coords(uint32_t m_tiles, uint32_t n_tiles, uint32_t grp, uint32_t& tm, uint32_t& tn, uint32_t L = blockIdx.x) {
   if (grp == 0) { tn = L % n_tiles; tm = L / n_tiles; return; }
   const uint32_t xcd = L & 7u, j = L >> 3, per_xcd = m_tiles >> 3;
   const uint32_t chunk = j / (grp * n_tiles), w = j % (grp * n_tiles);
@@ -447,6 +446,9 @@ constexpr size_t kX3WLdsBytes = 2 * 2 * 2 * (size_t)kGemmWide * kX3Pitch * 2;  /
 // Epilogue of the wide (256 x 256) contraction kernels: per point (column) the smallest value, its centroid and the second smallest over each
 // 128-centroid row tile (the unit assign_argmin_merge_kernel / assign_tile_rescan_kernel work in): same rules as gemm_epilogue<true>.
 // `T`: the block's operand storage, dead by now (the callers' loops end on a barrier with no load to LDS in flight).
+// CN_STAGED: the caller has put the staged norms at T + 2048 floats (and passed a barrier) -- and may have LDS-DMA loads in flight: the
+// barriers here wait for LDS traffic only (a __syncthreads() would drain the loads).
+template <bool CN_STAGED = false>
 __device__ __forceinline__ void wide_epilogue(f32x16 (&acc)[2][4], void* T, const float* __restrict__ cnorm, uint32_t N_pad, int metric, uint32_t k_rows,
                                               float* __restrict__ part_v1, uint32_t* __restrict__ part_c1, float* __restrict__ part_v2, uint32_t m0,
                                               uint32_t n0, int wr, int wc, int r, int hh) {
@@ -463,11 +465,13 @@ __device__ __forceinline__ void wide_epilogue(f32x16 (&acc)[2][4], void* T, cons
   // s = 1, cn = 0 (0 - acc: -acc but for the sign of a zero, which no comparison sees); padding centroids (zero rows) cn = +inf: never a
   // candidate.
   float* const cn_s = reinterpret_cast<float*>(T) + 2048;  // (behind the exchange area below: 1536 floats)
-  if (threadIdx.x < (unsigned)kGemmWide) {
-    const uint32_t m = m0 + threadIdx.x;
-    cn_s[threadIdx.x] = m >= k_rows ? __builtin_inff() : (metric ? 0.0f : cnorm[m]);
+  if constexpr (!CN_STAGED) {
+    if (threadIdx.x < (unsigned)kGemmWide) {
+      const uint32_t m = m0 + threadIdx.x;
+      cn_s[threadIdx.x] = m >= k_rows ? __builtin_inff() : (metric ? 0.0f : cnorm[m]);
+    }
+    __syncthreads();
   }
-  __syncthreads();
   f32x4 cn4[2][4];
   bool cn_nan = false;
 #pragma unroll
@@ -518,7 +522,7 @@ __device__ __forceinline__ void wide_epilogue(f32x16 (&acc)[2][4], void* T, cons
       t[0] = bv1[b]; t[1] = __uint_as_float(bc1[b]); t[2] = bv2[b];
     }
   }
-  __syncthreads();
+  if constexpr (CN_STAGED) lds_barrier(); else __syncthreads();
   if ((wr & 1) == 0 && hh == 0) {
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
@@ -734,9 +738,14 @@ static __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2
 //   Ordering (LDS-DMA data is ordered for a ds_read only by the issuing wave's vmcnt followed by a barrier the reader has passed):
 //   step t issues tile t + 1 into the other buffer (read in step t - 1: every wave left it at the barrier that ended that step, its
 //   reads returned -- lgkmcnt(0) in front of the barrier), multiplies tile t, waits for its own pieces and meets the others.
+//   Persistent: a block per CU walks the tiles L = blockIdx.x, + gridDim.x, ... (the XCD of tile L is L & 7 either way: gemm_tile_coords).
+//   The last step of a tile issues the FIRST K-tile of the block's next tile instead of nothing and does not wait for it: it lands
+//   while the epilogue runs (whose scratch -- exchange area and staged norms -- sits behind the two buffers, and whose barriers wait for
+//   LDS traffic only).  A block per tile paid the first tile's round trip (2.5 us) and the epilogue's VALU time (4 us) 32 times per CU
+//   with nothing else on the CU to run under them.
 constexpr int kHBK = 64;                        // columns of a K-tile: one 128-byte line of fp16
 constexpr int kHTile = kGemmWide * kHBK;        // elements of one operand's K-tile (32 KB)
-constexpr size_t kGemmHLdsBytes = (size_t)2 * 2 * kHTile * 2;  // two buffers x A | B = 128 KB
+constexpr size_t kGemmHLdsBytes = (size_t)2 * 2 * kHTile * 2 + 10240;  // two buffers x A | B = 128 KB, + the epilogue's scratch
 static __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) void dist_gemm_h_kernel(
     const _Float16* __restrict__ Xh, const _Float16* __restrict__ Ch, const float* __restrict__ cnorm, uint32_t K, uint32_t N_pad, int metric,
     uint32_t m_tiles, uint32_t n_tiles, uint32_t grp, uint32_t k_rows, float* __restrict__ part_v1, uint32_t* __restrict__ part_c1,
@@ -744,91 +753,119 @@ static __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2
   extern __shared__ __attribute__((aligned(16))) _Float16 TH[];
   typedef __attribute__((address_space(3))) void lds_void;
   typedef const __attribute__((address_space(1))) void glb_void;
+  float* const scratch = reinterpret_cast<float*>(TH + 4 * kHTile);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wid >> 1, wc = wid & 1;  // wave rows 0..3 (64 centroids each), wave columns 0..1 (128 points each)
-  uint32_t tile_m, tile_n;
-  gemm_tile_coords(m_tiles, n_tiles, grp, tile_m, tile_n);
-  const uint32_t m0 = tile_m * kGemmWide, n0 = tile_n * kGemmWide;
-  f32x16 acc[2][4];
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < 4; ++b)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.0f;
+  const int r = lane & 31, hh = lane >> 5;
+  const int rsw = (r >> 1) & 7;
+  const uint32_t k_tiles = K / kHBK, total = m_tiles * n_tiles;
   // this wave's eight pieces of a K-tile: rows 8 (wid + 8 i) .. + 7 of the centroid tile and of the point tile, i < 4
   // ((row >> 1) & 7 of row 8 j + (L >> 3), j = wid + 8 i: 4 (wid & 1) + (L >> 4))
   const int prow = lane >> 3, pchunk = (lane & 7) ^ (4 * (wid & 1) + (lane >> 4));
-  const _Float16* const asrc = Ch + (uint64_t)(m0 + 8 * wid + prow) * K + pchunk * 8;   // piece i: + 64 i rows
-  const _Float16* const bsrc = Xh + (uint64_t)(n0 + 8 * wid + prow) * K + pchunk * 8;
-  const uint64_t piece_step = (uint64_t)64 * K;
-  auto issue = [&](uint32_t k0, int buf) {
+  // (byte offsets in 32 bits from the operands' bases -- wave-uniform, in scalar registers: both operands are below 4 GB; launch_gemm_h checks)
+  const uint32_t piece_step = 64u * K * 2u;
+  auto tile_at = [&](uint32_t L, uint32_t& m0, uint32_t& n0, uint32_t& aoff, uint32_t& boff) {
+    uint32_t tile_m, tile_n;
+    gemm_tile_coords(m_tiles, n_tiles, grp, tile_m, tile_n, L);
+    m0 = tile_m * kGemmWide; n0 = tile_n * kGemmWide;
+    aoff = ((m0 + 8u * (uint32_t)wid + (uint32_t)prow) * K + (uint32_t)pchunk * 8u) * 2u;   // piece i: + 64 i rows
+    boff = ((n0 + 8u * (uint32_t)wid + (uint32_t)prow) * K + (uint32_t)pchunk * 8u) * 2u;
+  };
+  const char* const Cb = reinterpret_cast<const char*>(Ch);
+  const char* const Xb = reinterpret_cast<const char*>(Xh);
+  auto issue = [&](uint32_t aoff, uint32_t boff, uint32_t k0, int buf) {
     _Float16* const A = TH + (buf * 2 + 0) * kHTile + 8 * wid * kHBK;
     _Float16* const B = TH + (buf * 2 + 1) * kHTile + 8 * wid * kHBK;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      __builtin_amdgcn_global_load_lds((glb_void*)(asrc + i * piece_step + k0), (lds_void*)(A + i * 64 * kHBK), 16, 0, 0);
-      __builtin_amdgcn_global_load_lds((glb_void*)(bsrc + i * piece_step + k0), (lds_void*)(B + i * 64 * kHBK), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((glb_void*)(Cb + (aoff + (uint32_t)i * piece_step + k0 * 2u)), (lds_void*)(A + i * 64 * kHBK), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((glb_void*)(Xb + (boff + (uint32_t)i * piece_step + k0 * 2u)), (lds_void*)(B + i * 64 * kHBK), 16, 0, 0);
     }
   };
-  const int r = lane & 31, hh = lane >> 5;
-  const int rsw = (r >> 1) & 7;
-  const uint32_t k_tiles = K / kHBK, k_last = K - kHBK;
-  auto kclamp = [&](uint32_t t) { const uint32_t k0 = t * kHBK; return k0 < k_last ? k0 : k_last; };
-  issue(0, 0);
-  asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
-  __builtin_amdgcn_sched_barrier(0);
-  auto step = [&](auto btag, uint32_t t) {
-    constexpr int BUF = decltype(btag)::value;
-    issue(kclamp(t + 1), BUF ^ 1);  // (past the end: the last tile again, into the buffer nobody reads any more)
-    const _Float16* const A = TH + (BUF * 2 + 0) * kHTile;
-    const _Float16* const B = TH + (BUF * 2 + 1) * kHTile;
-    // the fragments of k-step s + 1 are requested BEFORE the MFMAs of k-step s (two register sets): all eight waves run in step -- what
-    // the barrier leaves of it -- so reads, then MFMAs, would keep the LDS port (768 cycles of reads per 32 columns) and the matrix
-    // cores (1024) busy one after the other
-    gf16x8 fa[2][2], fb[2][4];
-    auto fetch = [&](auto stag, int s4) {
-      constexpr int S = decltype(stag)::value;
-      const int ko = ((2 * s4 + hh) ^ rsw) * 8;
+  uint32_t L = blockIdx.x;
+  if (L >= total) return;
+  uint32_t m0, n0, asrc, bsrc;
+  tile_at(L, m0, n0, asrc, bsrc);
+  issue(asrc, bsrc, 0, 0);
+  for (;;) {
+    const uint32_t Ln = L + gridDim.x;
+    const bool more = Ln < total;  // (block-uniform)
+    uint32_t m0n = 0, n0n = 0, asrc_n = asrc, bsrc_n = bsrc;
+    if (more) tile_at(Ln, m0n, n0n, asrc_n, bsrc_n);
+    f32x16 acc[2][4];
 #pragma unroll
-      for (int tt = 0; tt < 2; ++tt) fa[S][tt] = *reinterpret_cast<const gf16x8*>(A + (wr * 64 + tt * 32 + r) * kHBK + ko);
+    for (int a = 0; a < 2; ++a)
 #pragma unroll
-      for (int tt = 0; tt < 4; ++tt) fb[S][tt] = *reinterpret_cast<const gf16x8*>(B + (wc * 128 + tt * 32 + r) * kHBK + ko);
+      for (int b = 0; b < 4; ++b)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc[a][b][e] = 0.0f;
+    if (tid < kGemmWide) {  // the tile's norms as the epilogue wants them (wide_epilogue<true>)
+      const uint32_t m = m0 + (uint32_t)tid;
+      scratch[2048 + tid] = m >= k_rows ? __builtin_inff() : (metric ? 0.0f : cnorm[m]);
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");  // the tile's first K-tile has landed (issued a tile ago)
+    __builtin_amdgcn_sched_barrier(0);
+    auto step = [&](auto btag, auto ltag, uint32_t t) {
+      constexpr int BUF = decltype(btag)::value;
+      constexpr bool LAST = decltype(ltag)::value;
+      if constexpr (!LAST) issue(asrc, bsrc, (t + 1) * kHBK, BUF ^ 1);
+      else if (more) issue(asrc_n, bsrc_n, 0, BUF ^ 1);
+      const _Float16* const A = TH + (BUF * 2 + 0) * kHTile;
+      const _Float16* const B = TH + (BUF * 2 + 1) * kHTile;
+      // the fragments of k-step s + 1 are requested BEFORE the MFMAs of k-step s (two register sets): all eight waves run in step --
+      // what the barrier leaves of it -- so reads, then MFMAs, would keep the LDS port (768 cycles of reads per 32 columns) and the
+      // matrix cores (1024) busy one after the other
+      gf16x8 fa[2][2], fb[2][4];
+      auto fetch = [&](auto stag, int s4) {
+        constexpr int S = decltype(stag)::value;
+        const int ko = ((2 * s4 + hh) ^ rsw) * 8;
+#pragma unroll
+        for (int tt = 0; tt < 2; ++tt) fa[S][tt] = *reinterpret_cast<const gf16x8*>(A + (wr * 64 + tt * 32 + r) * kHBK + ko);
+#pragma unroll
+        for (int tt = 0; tt < 4; ++tt) fb[S][tt] = *reinterpret_cast<const gf16x8*>(B + (wc * 128 + tt * 32 + r) * kHBK + ko);
+      };
+      auto mult = [&](auto stag) {
+        constexpr int S = decltype(stag)::value;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int b = 0; b < 4; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[S][a], fb[S][b], acc[a][b], 0, 0, 0);
+      };
+      using I0 = std::integral_constant<int, 0>;
+      using I1 = std::integral_constant<int, 1>;
+      fetch(I0{}, 0);
+      fetch(I1{}, 1);
+      __builtin_amdgcn_sched_barrier(0);
+      mult(I0{});
+      __builtin_amdgcn_sched_barrier(0);
+      fetch(I0{}, 2);
+      __builtin_amdgcn_sched_barrier(0);
+      mult(I1{});
+      __builtin_amdgcn_sched_barrier(0);
+      fetch(I1{}, 3);
+      __builtin_amdgcn_sched_barrier(0);
+      mult(I0{});
+      __builtin_amdgcn_sched_barrier(0);
+      mult(I1{});
+      // (lgkmcnt: this wave's reads of the buffer have returned before anybody re-fills it; LAST: the next tile's pieces stay in flight)
+      if constexpr (LAST) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      __builtin_amdgcn_sched_barrier(0);
     };
-    auto mult = [&](auto stag) {
-      constexpr int S = decltype(stag)::value;
-#pragma unroll
-      for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 4; ++b) {
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fa[S][a], fb[S][b], acc[a][b], 0, 0, 0);
-        }
-    };
-    using I0 = std::integral_constant<int, 0>;
-    using I1 = std::integral_constant<int, 1>;
-    fetch(I0{}, 0);
-    fetch(I1{}, 1);
-    __builtin_amdgcn_sched_barrier(0);
-    mult(I0{});
-    __builtin_amdgcn_sched_barrier(0);
-    fetch(I0{}, 2);
-    __builtin_amdgcn_sched_barrier(0);
-    mult(I1{});
-    __builtin_amdgcn_sched_barrier(0);
-    fetch(I1{}, 3);
-    __builtin_amdgcn_sched_barrier(0);
-    mult(I0{});
-    __builtin_amdgcn_sched_barrier(0);
-    mult(I1{});
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    __builtin_amdgcn_sched_barrier(0);
-  };
-  for (uint32_t t = 0; t < k_tiles; t += 2) {  // (an even number of tiles: gemm_h_ok)
-    step(std::integral_constant<int, 0>{}, t);
-    step(std::integral_constant<int, 1>{}, t + 1);
+    using B0 = std::integral_constant<int, 0>;
+    using B1 = std::integral_constant<int, 1>;
+    uint32_t t = 0;
+    for (; t + 2 < k_tiles; t += 2) {  // (an even number of K-tiles: gemm_h_ok)
+      step(B0{}, std::false_type{}, t);
+      step(B1{}, std::false_type{}, t + 1);
+    }
+    step(B0{}, std::false_type{}, t);
+    step(B1{}, std::true_type{}, t + 1);
+    wide_epilogue<true>(acc, scratch, cnorm, N_pad, metric, k_rows, part_v1, part_c1, part_v2, m0, n0, wr, wc, r, hh);
+    if (!more) break;
+    L = Ln; m0 = m0n; n0 = n0n; asrc = asrc_n; bsrc = bsrc_n;
   }
-  wide_epilogue(acc, TH, cnorm, N_pad, metric, k_rows, part_v1, part_c1, part_v2, m0, n0, wr, wc, r, hh);
 }
 // rows of a point batch -> fp16 (round to nearest: what dist_gemm_x3w_kernel<2, 1> converts on the fly), columns d .. ld_out and rows
 // n_rows .. n_pad zero: thread per 8 columns
@@ -846,7 +883,7 @@ static __global__ __launch_bounds__(256) void rows_to_f16_pad_kernel(const float
   }
   *reinterpret_cast<gf16x8*>(out + (uint64_t)row * ld_out + c0) = h;
 }
-inline bool gemm_h_ok(uint32_t K) { return K % (2 * kHBK) == 0; }
+inline bool gemm_h_ok(uint32_t K) { return K % (2 * kHBK) == 0; }  // (+ both operands below 4 GB: km_assign_mfma's batches and k_pad x K x 2 are)
 inline hipError_t launch_gemm_h(uint32_t k_pad, uint32_t nb_pad, hipStream_t st, const _Float16* Xh, const _Float16* Ch, const float* cnorm, uint32_t K,
                                 uint32_t N_pad, uint32_t metric, uint32_t k_rows, float* part_v1, uint32_t* part_c1, float* part_v2) {
   static const hipError_t attr = hipFuncSetAttribute((const void*)dist_gemm_h_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kGemmHLdsBytes);
@@ -854,7 +891,19 @@ inline hipError_t launch_gemm_h(uint32_t k_pad, uint32_t nb_pad, hipStream_t st,
   const uint32_t m_tiles = k_pad / kGemmWide, n_tiles = nb_pad / kGemmWide;
   uint32_t grp = 0;
   for (uint32_t g : {2u, 1u}) if (m_tiles % (8u * g) == 0) { grp = g; break; }
-  hipLaunchKernelGGL(dist_gemm_h_kernel, dim3(m_tiles * n_tiles), dim3(512), kGemmHLdsBytes, st, Xh, Ch, cnorm, K, N_pad, (int)metric, m_tiles, n_tiles, grp, k_rows,
+  // one block per CU (138 KB of LDS each), persistent
+  static int n_cu_of[16] = {};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) dev = 0;
+  if (n_cu_of[dev] == 0) {
+    int n = 0;
+    if (hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0) n = 256;
+    n_cu_of[dev] = n;
+  }
+  const uint32_t total = m_tiles * n_tiles;
+  uint32_t grid = (uint32_t)n_cu_of[dev] / 8u * 8u;  // (a multiple of the 8 XCDs: tile L stays on XCD L & 7)
+  if (grid == 0 || grid > total) grid = total;
+  hipLaunchKernelGGL(dist_gemm_h_kernel, dim3(grid), dim3(512), kGemmHLdsBytes, st, Xh, Ch, cnorm, K, N_pad, (int)metric, m_tiles, n_tiles, grp, k_rows,
                      part_v1, part_c1, part_v2);
   return hipGetLastError();
 }
