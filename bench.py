@@ -421,7 +421,7 @@ def main():
             return None
         tf = bs["gemm_flop"] / (bs["gemm_ms"] * 1e-3) / 1e12
         e = {"kernel": "the assign cascade's first filter (round 6): 256 x 256 block tiles of points x centroids, ONE v_mfma_f32_32x32x16_f16 per k-step on fp16 operands, certified with their measured residuals; arg-min fused into the epilogue; the open points through assign_tile_rescan_kernel. "
-                       "Below 8192 centroids dist_gemm_x3w_kernel<2, 1> (register staged, converts the f32 batch while it stages it); from 8192 on dist_gemm_h_kernel (persistent, both operands fp16 in memory -- the batch's conversion pass is inside the timed launches --, 64-column K-tiles by LDS-DMA in whole cache lines). "
+                       "Below 4096 centroids dist_gemm_x3w_kernel<2, 1> (register staged, converts the f32 batch while it stages it); from 4096 on dist_gemm_h_kernel (persistent, both operands fp16 in memory -- the batch's conversion pass is inside the timed launches --, 64-column K-tiles by LDS-DMA in whole cache lines). "
                        "dist_gemm_x3w_kernel<2, 3> -- three bf16 products of hi/lo-split operands -- when the probe says the cascade does not pay or vers_set_option('assign_terms', 3)",
              "shape": [int(shape_pts), int(k_), d], "launches": int(bs["gemm_launches"]), "us_per_launch": round(bs["gemm_ms"] / bs["gemm_launches"] * 1e3, 1),
              "algorithmic_tflops": round(tf, 1), "frac_of_f16_dense": round(tf / BF16_DENSE_PEAK_TF, 4), "frac_of_f32_mfma_peak": round(tf / MFMA_F32_PEAK_TF, 4),

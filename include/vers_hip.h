@@ -339,7 +339,7 @@ int32_t vers_ivf_build_sharded_dev(vers_ivf_t* h, const float* rows_dev, uint64_
  *   "assign_terms" (0)  the assign contraction's first filter: 1 = ONE product of fp16 operands (a third of the MFMAs; the points it leaves
  *                       open go to the tile-limited exact re-scan), 3 = all three products of the bf16 hi/lo split, 0 = probe per build.
  *   "assign_glds" (-1)  the one-product filter with both operands fp16 in memory, staged by LDS-DMA in whole cache lines: 1 = always, 0 = never
- *                       (the register-staged kernel that converts the f32 batch while it stages it), -1 = from 8192 centroids on.
+ *                       (the register-staged kernel that converts the f32 batch while it stages it), -1 = from 4096 centroids on.
  *   "pre_narrow" (0), "pre_wide" (1), "pre_hi_only" (0)   the list scan's query-block width (16 / 64 queries) and fp16 hi-only query blocks.
  *   "wide_k" (1)        results of 49 .. 200 keys (batches, nprobe >= 1) stay on the matrix-core list scan with candidate lists four keys
  *                       per lane wide; 0 = the ordered chains, 64 ranks per pass.

@@ -193,7 +193,7 @@ for name, v in kk:
                 km_facts[key] = round(pct, 1)
         print(line)
 if km_facts:
-    json.dump({"kernel": "dist_gemm_x3w_kernel<2, 1> at k = 4096, dist_gemm_h_kernel at k = 65536 (k-means assign contraction, 256 x 256 block tiles)", "mfma_busy_pct": km_facts,
+    json.dump({"kernel": "dist_gemm_h_kernel (k-means assign contraction from 4096 centroids on, 256 x 256 block tiles, persistent)", "mfma_busy_pct": km_facts,
                "source": "profiles/r06_summary.txt (rocprofv3 --pmc pass of scripts/bench_assign.py)"}, open(os.path.join(out, "kmeans.json"), "w"), indent=1)
 print()
 # ---- sharded search: every rank of every world (no profiler), then rank 0's per-kernel us from the traces ----

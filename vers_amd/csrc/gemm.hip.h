@@ -28,6 +28,7 @@
 namespace vers {
 
 typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(2))) float f32x2_t;
 
 constexpr int kGemmBM = 128, kGemmBN = 128, kGemmBK = 32;
 constexpr int kGemmLds = kGemmBK + 4;  // row pitch in floats: 4*odd -> conflict-free ds_read_b128 by row
@@ -487,25 +488,35 @@ __device__ __forceinline__ void wide_epilogue(f32x16 (&acc)[2][4], void* T, cons
   uint32_t bc1[4];
 #pragma unroll
   for (int b = 0; b < 4; ++b) {
-    // Nine operations per element (65,536 elements per block: the epilogue is VALU time).  A tie with the candidate makes second == best, a
+    // Seven operations per element (65,536 elements per block: the epilogue is VALU time -- a fifth of a tile's at k = 65536).  A tie with the candidate makes second == best, a
     // NaN makes second NaN (below): neither certifies.  A non-finite accumulator -- the only way, besides a NaN norm, an element becomes NaN
     // -- turns `z` NaN through z = fma(acc, 0, z) (an infinite accumulator too: it would not certify anything worth having).
-    float v1 = __builtin_inff(), v2 = __builtin_inff(), z = 0.0f;
+    float v1 = __builtin_inff(), v2 = __builtin_inff();
+    f32x2_t z2 = {0.0f, 0.0f};
     uint32_t c1 = m0 + wr * 64 + 4 * hh;
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        const uint32_t m = m0 + wr * 64 + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
-        const float av = acc[a][b][e];
-        z = __builtin_fmaf(av, 0.0f, z);
-        const float g = cn4[a][e >> 2][e & 3] - sc * av;
-        const bool lt = g < v1;
-        const float mx = lt ? v1 : g;   // the larger of (best so far, g); g when they are equal
-        c1 = lt ? m : c1;
-        v2 = mx < v2 ? mx : v2;
-        v1 = lt ? g : v1;
+      for (int e2 = 0; e2 < 8; ++e2) {
+        // two elements per packed operation where there is one (v_pk_fma_f32): g = cn - s acc as fma(-s, acc, cn) -- s acc is exact
+        // (s = 1 or 2), so the fused result is the subtraction's, bit for bit -- and the non-finite detector
+        const f32x2_t av = {acc[a][b][2 * e2], acc[a][b][2 * e2 + 1]};
+        const f32x2_t cn = {cn4[a][e2 >> 1][(2 * e2) & 3], cn4[a][e2 >> 1][(2 * e2 + 1) & 3]};
+        z2 = __builtin_elementwise_fma(av, f32x2_t{0.0f, 0.0f}, z2);
+        const f32x2_t g2 = __builtin_elementwise_fma(f32x2_t{-sc, -sc}, av, cn);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+          const int e = 2 * e2 + u;
+          const uint32_t m = m0 + wr * 64 + a * 32 + (e & 3) + 8 * (e >> 2) + 4 * hh;
+          const float g = g2[u];
+          const bool lt = g < v1;
+          const float mx = lt ? v1 : g;   // the larger of (best so far, g); g when they are equal
+          c1 = lt ? m : c1;
+          v2 = mx < v2 ? mx : v2;
+          v1 = lt ? g : v1;
+        }
       }
+    const float z = z2[0] + z2[1];
     if (cn_nan || z != z) v2 = __builtin_nanf("");
     const float w1 = __shfl_xor(v1, 32, kWave), w2 = __shfl_xor(v2, 32, kWave);  // the other half of the rows sits in lane ^ 32
     const uint32_t d1 = (uint32_t)__shfl_xor((int)c1, 32, kWave);

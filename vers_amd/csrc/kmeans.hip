@@ -314,11 +314,11 @@ int32_t km_assign_mfma(const float* X, uint32_t ldx, uint64_t n, const float* C,
     const uint32_t nb_pad = round_up(nb, (uint32_t)bn);
     const float* xb = X + i0 * ldx;
     const float* xb_padded = in_place_ok ? xb : nullptr;  // this batch's rows with zeroed padding columns, pitch ldq (the tile re-scan's operand)
-    // both operands fp16 in memory, staged by LDS-DMA (dist_gemm_h_kernel) from 8192 centroids on: the batch's conversion pass (0.11 ms per
-    // 131072 x 768 points) is a tenth of the contraction at k = 4096 -- 1.13 vs 1.05 ms with the register-staged kernel that converts while
-    // it stages -- and nothing at k = 65536 (13.9 vs 16.3 ms).  Option "assign_glds": 1 always, 0 never.
+    // both operands fp16 in memory, staged by LDS-DMA (dist_gemm_h_kernel) from 4096 centroids on: the batch's conversion pass (0.11 ms per
+    // 131072 x 768 points) is a tenth of the contraction at k = 4096 -- 1.03 ms with it against 1.04 for the register-staged kernel that
+    // converts while it stages -- and nothing at k = 65536 (12.6 vs 16.2 ms).  Option "assign_glds": 1 always, 0 never.
     const int glds_opt = (int)opt_get("assign_glds", -1);
-    const bool use_h = hi_only && wide && gemm_h_ok(ldq) && (glds_opt > 0 || (glds_opt < 0 && k_pad >= 8192));
+    const bool use_h = hi_only && wide && gemm_h_ok(ldq) && (glds_opt > 0 || (glds_opt < 0 && k_pad >= 4096));
     if (use_h) {
       if (int32_t rc = ws.xh.reserve((size_t)mb * ldq * sizeof(uint16_t))) return rc;
     } else if (!in_place_ok || nb_pad != nb) {  // pad the columns / the tail rows through a staged copy
