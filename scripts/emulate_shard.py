@@ -144,13 +144,15 @@ for W in worlds:
     summ["probed_rows"] = {"max": int(pr.max()), "mean": int(pr.mean()), "max_over_mean": round(float(pr.max() / pr.mean()), 3)}
     summ["all_gather_bytes_per_rank"] = 2 * B * top_k * 8
     out["worlds"][str(W)] = summ
-    print(f"== world {W}: " + "  ".join(f"S={NS}{'' if RES == RESERVES[0] else ' reserve ' + str(RES)}: max {summ[f'step_ms_s{NS}' + ('' if RES == RESERVES[0] else f'_r{RES}')]['max']:.3f} mean {summ[f'step_ms_s{NS}' + ('' if RES == RESERVES[0] else f'_r{RES}')]['mean']:.3f} ms" for RES in RESERVES for NS in STREAMS) +
-          f"  probed rows max/mean {summ['probed_rows']['max_over_mean']}", flush=True)
+    def tag_of(RES):
+        return "" if RES == RESERVES[0] else (f"_r{RES}" if not SWEEP else f"_{SWEEP_NAME}{RES}")
+    print(f"== world {W}: " + "  ".join(f"S={NS}{tag_of(RES)}: max {summ[f'step_ms_s{NS}' + tag_of(RES)]['max']:.3f} mean {summ[f'step_ms_s{NS}' + tag_of(RES)]['mean']:.3f} ms"
+                                        for RES in RESERVES for NS in STREAMS) + f"  probed rows max/mean {summ['probed_rows']['max_over_mean']}", flush=True)
 if "1" in out["worlds"]:
     for NS in STREAMS:
         one = out["worlds"]["1"][f"step_ms_s{NS}"]["max"]   # (one GPU: no exchange kernel to make room for, reserve 0)
         for RES in RESERVES:
-            tag = "" if RES == RESERVES[0] else f"_r{RES}"
+            tag = "" if RES == RESERVES[0] else (f"_r{RES}" if not SWEEP else f"_{SWEEP_NAME}{RES}")
             out[f"predicted_speedup_s{NS}{tag}"] = {w: round(one / out["worlds"][w][f"step_ms_s{NS}{tag}"]["max"], 2) for w in out["worlds"]}
 path = os.environ.get("EMU_OUT") or os.environ.get("OUT", "gpurun_out/emulate_shard.json")
 os.makedirs(os.path.dirname(path) or ".", exist_ok=True)
