@@ -887,10 +887,17 @@ static __global__ __launch_bounds__(256) void rows_to_f16_pad_kernel(const float
   if (i >= (uint64_t)n_pad * per_row) return;
   const uint32_t row = (uint32_t)(i / per_row), c0 = (uint32_t)(i % per_row) * 8;
   gf16x8 h;
+  if (row < n_rows && c0 + 8 <= d && (ldx & 3u) == 0 && (reinterpret_cast<uintptr_t>(x) & 15u) == 0) {  // (the common case: two 16-byte loads)
+    const f32x4 a = *reinterpret_cast<const f32x4*>(x + (uint64_t)row * ldx + c0);
+    const f32x4 b = *reinterpret_cast<const f32x4*>(x + (uint64_t)row * ldx + c0 + 4);
 #pragma unroll
-  for (int u = 0; u < 8; ++u) {
-    const uint32_t c = c0 + (uint32_t)u;
-    h[u] = (row < n_rows && c < d) ? (_Float16)x[(uint64_t)row * ldx + c] : (_Float16)0.0f;
+    for (int u = 0; u < 4; ++u) { h[u] = (_Float16)a[u]; h[4 + u] = (_Float16)b[u]; }
+  } else {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const uint32_t c = c0 + (uint32_t)u;
+      h[u] = (row < n_rows && c < d) ? (_Float16)x[(uint64_t)row * ldx + c] : (_Float16)0.0f;
+    }
   }
   *reinterpret_cast<gf16x8*>(out + (uint64_t)row * ld_out + c0) = h;
 }
@@ -1446,8 +1453,11 @@ static __global__ __launch_bounds__(kWave * kSelWideWaves) void coarse_select_wi
 // |c|^2 - 2 <x, c> (or -<x, c>) and the best's centroid.  Thread per point: fold the k/128 triples in ascending
 // centroid order (coalesced: consecutive threads read consecutive points of one tile row).
 static __global__ void assign_argmin_merge_kernel(const float* part_v1, const uint32_t* part_c1, const float* part_v2, uint32_t n_tiles,
-                                                  uint32_t n_pad, uint32_t nb, uint32_t* best, float* g2) {
+                                                  uint32_t n_pad, uint32_t nb, uint32_t* best, float* g2, uint32_t* q_start = nullptr,
+                                                  const uint32_t* q_count = nullptr) {
   const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+  // (where this batch's entries of the tile re-scan's queue will begin: assign_rescore_kernel, next on the stream, appends them)
+  if (i == 0 && q_start != nullptr) *q_start = *q_count;
   if (i >= nb) return;
   float a1 = part_v1[i], a2 = part_v2[i];
   uint32_t ac = part_c1[i];
@@ -1471,45 +1481,85 @@ static __global__ void assign_argmin_merge_kernel(const float* part_v1, const ui
 // Exact D(x_i, c_best) in reference arithmetic (one lane per point) + certificate: every other centroid has
 // approximate value >= g2, hence exact distance >= g2 + |x|^2 - E; if the candidate's exact distance is strictly
 // below that it is the unique first minimum.  Otherwise the point is queued for the exact scan.
-static __global__ void assign_rescore_kernel(const float* X, uint32_t ldx, const float* C_rm, uint32_t ldc, uint32_t d, uint32_t d_pad,
+// (Round 6, second half: the 64 points of a block -- ONE wave -- fetch their rows and their candidates' rows TOGETHER, 32 columns at a
+// time in whole 128-byte lines, eight rows per load instruction, through a wave-private LDS image from which every lane then walks its own
+// row's chain in the reference's order.  Before, a lane read its own rows 16 bytes at a time: 64 lines per load instruction, each line
+// fetched eight times over because 8 waves x 128 live lines do not fit the L1 -- 242 us per 131072 points, a quarter of the assign pass.)
+constexpr int kRsChunk = 32;  // columns per step
+constexpr int kRsPitch = 36;  // floats per staged row: lane-per-row ds_read_b128 without bank conflicts
+static __global__ __launch_bounds__(kWave) void assign_rescore_kernel(const float* X, uint32_t ldx, const float* C_rm, uint32_t ldc, uint32_t d, uint32_t d_pad,
                                              const float* cmax2_dev, const uint32_t* best, const float* g2, uint32_t nb, uint32_t k,
                                              uint32_t i_base, uint32_t* assign, float* mind, uint32_t* fb_list, uint32_t* fb_count,
                                              uint32_t* status, int metric, float* fb_thr = nullptr, const uint32_t* rc2_bits = nullptr) {
   // rc2_bits != nullptr: the values came from the SINGLE fp16 product (the cascade's first filter): the bound uses the measured residuals
-  const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= nb) return;
+  __shared__ __attribute__((aligned(16))) float sx[kWave * kRsPitch];
+  __shared__ __attribute__((aligned(16))) float sc[kWave * kRsPitch];
+  const int lane = threadIdx.x;  // (a block is one wave: no barrier anywhere, the LDS image is the wave's own and its accesses are in order)
+  const uint32_t i_raw = blockIdx.x * kWave + (uint32_t)lane;
+  const bool live = i_raw < nb;
+  const uint32_t i = live ? i_raw : nb - 1;  // (dead lanes of the last block walk the last point's rows along and drop the result)
   const uint32_t c = best[i];
   const float* x = X + (uint64_t)i * ldx;
   const float* cv = C_rm + (uint64_t)c * ldc;
+  const bool want_r = rc2_bits != nullptr;
   float acc = 0.0f, xn = 0.0f, rx2 = 0.0f;
+  auto element = [&](float xv, float cvv) {
+    if (metric == 0) {
+      const float t = __fsub_rn(xv, cvv);  // data_point.squared_euclidean(centroid): ivfflat.rs:37
+      acc = __fadd_rn(acc, __fmul_rn(t, t));
+    } else {
+      acc = __fadd_rn(acc, __fmul_rn(xv, cvv));
+    }
+    xn = __fadd_rn(xn, __fmul_rn(xv, xv));
+    if (want_r) { const float dl = xv - (float)(_Float16)xv; rx2 = __fadd_rn(rx2, __fmul_rn(dl, dl)); }
+  };
   uint32_t j = 0;
-  if (((ldx | ldc) & 3u) == 0) {
+  const bool vec_ok = ((ldx | ldc) & 3u) == 0 && ((reinterpret_cast<uintptr_t>(X) | reinterpret_cast<uintptr_t>(C_rm)) & 15u) == 0;
+  if (vec_ok && d >= (uint32_t)kRsChunk) {  // (block-uniform)
+    const uint32_t d_st = d & ~(uint32_t)(kRsChunk - 1);
+    const int lrow = lane >> 3, lcol = (lane & 7) * 4;  // piece q of a step: rows 8 q + lrow, this lane's 16 bytes of their 128
+    uint64_t xoff[8], coff[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int src = 8 * q + lrow;
+      xoff[q] = (uint64_t)(uint32_t)__shfl((int)i, src, kWave) * ldx + (uint32_t)lcol;
+      coff[q] = (uint64_t)(uint32_t)__shfl((int)c, src, kWave) * ldc + (uint32_t)lcol;
+    }
+    f32x4 rxv[8], rcv[8];
+    auto gload = [&](uint32_t j0) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        rxv[q] = *reinterpret_cast<const f32x4*>(X + xoff[q] + j0);
+        rcv[q] = *reinterpret_cast<const f32x4*>(C_rm + coff[q] + j0);
+      }
+    };
+    gload(0);
+    for (; j < d_st; j += kRsChunk) {
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        *reinterpret_cast<f32x4*>(sx + (8 * q + lrow) * kRsPitch + lcol) = rxv[q];
+        *reinterpret_cast<f32x4*>(sc + (8 * q + lrow) * kRsPitch + lcol) = rcv[q];
+      }
+      if (j + kRsChunk < d_st) gload(j + kRsChunk);  // the next step's lines: in flight under this step's chain
+#pragma unroll
+      for (int cc = 0; cc < kRsChunk / 4; ++cc) {
+        const f32x4 x4 = *reinterpret_cast<const f32x4*>(sx + lane * kRsPitch + 4 * cc);
+        const f32x4 c4 = *reinterpret_cast<const f32x4*>(sc + lane * kRsPitch + 4 * cc);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) element(x4[u], c4[u]);
+      }
+    }
+  }
+  if (vec_ok) {
     for (; j + 4 <= d; j += 4) {
       const f32x4 x4 = *reinterpret_cast<const f32x4*>(x + j);
       const f32x4 c4 = *reinterpret_cast<const f32x4*>(cv + j);
 #pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        if (metric == 0) {
-          const float t = __fsub_rn(x4[u], c4[u]);  // data_point.squared_euclidean(centroid): ivfflat.rs:37
-          acc = __fadd_rn(acc, __fmul_rn(t, t));
-        } else {
-          acc = __fadd_rn(acc, __fmul_rn(x4[u], c4[u]));
-        }
-        xn = __fadd_rn(xn, __fmul_rn(x4[u], x4[u]));
-        if (rc2_bits) { const float dl = x4[u] - (float)(_Float16)x4[u]; rx2 = __fadd_rn(rx2, __fmul_rn(dl, dl)); }
-      }
+      for (int u = 0; u < 4; ++u) element(x4[u], c4[u]);
     }
   }
-  for (; j < d; ++j) {
-    if (metric == 0) {
-      const float t = __fsub_rn(x[j], cv[j]);
-      acc = __fadd_rn(acc, __fmul_rn(t, t));
-    } else {
-      acc = __fadd_rn(acc, __fmul_rn(x[j], cv[j]));
-    }
-    xn = __fadd_rn(xn, __fmul_rn(x[j], x[j]));
-    if (rc2_bits) { const float dl = x[j] - (float)(_Float16)x[j]; rx2 = __fadd_rn(rx2, __fmul_rn(dl, dl)); }
-  }
+  for (; j < d; ++j) element(x[j], cv[j]);
+  if (!live) return;
   if (metric) acc = __fsub_rn(1.0f, acc);
   const float tau = g2[i];
   float E = ((5.0f * (float)d_pad + 16.0f) * 5.9604645e-08f + (rc2_bits ? 0.0f : kX3Slack)) * (xn + *cmax2_dev + (metric ? 1.0f : 0.0f));
@@ -1556,13 +1606,16 @@ struct RescanSrc {
 static __global__ __launch_bounds__(kWave) void assign_tile_rescan_kernel(
     const float* Xb, const float* Cb, uint32_t ld, uint32_t k, const float* part_v1, uint32_t n_tiles,
     uint32_t pitch, uint32_t i_base, uint32_t nb, const uint32_t* fb_list, const float* fb_thr, const uint32_t* fb_count, uint32_t* assign,
-    float* mind, uint32_t* fb2_list, uint32_t* fb2_count, int metric) {
+    float* mind, uint32_t* fb2_list, uint32_t* fb2_count, int metric, const uint32_t* fb_start) {
   __shared__ uint64_t s_out[kWave];
   const int lane = threadIdx.x;
   const uint32_t n_q = *fb_count;
+  // this batch's entries: the tail of the queue from *fb_start on (assign_argmin_merge_kernel).  (Until round 6's second half every launch
+  // walked the queue from its beginning past the other batches' entries -- 38 us for a pass's first batch, 630 for its last at N = 4M.)
+  const uint32_t e0 = *fb_start;
   ScanParams p;
   p.ld = ld; p.n_chunks = ld / kChunk; p.k = 1; p.status = nullptr; p.bounds = nullptr; p.lower = nullptr; p.debug = 0; p.next_quad = nullptr; p.stamps = nullptr;
-  for (uint32_t e = blockIdx.x; e < n_q; e += gridDim.x) {
+  for (uint32_t e = e0 + blockIdx.x; e < n_q; e += gridDim.x) {
     const uint32_t idx = fb_list[e];
     if (idx < i_base || idx >= i_base + nb) continue;  // (another batch's entry: its tile minima are gone)
     const uint32_t i = idx - i_base;

@@ -264,7 +264,7 @@ int32_t km_assign_mfma(const float* X, uint32_t ldx, uint64_t n, const float* C,
     if (int32_t rc = launch_to_blocked(C, ldc, d, k, ws.cblocked.as<float>(), ldq, st)) return rc;
     if (int32_t rc = ws.fbq.reserve((2 * n + 4) * sizeof(uint32_t))) return rc;
     fbq_list = ws.fbq.as<uint32_t>(); fbq_count = fbq_list + n; fbq_thr = ws.fbq.as<float>() + n + 4;
-    VERS_HIP_TRY(hipMemsetAsync(fbq_count, 0, sizeof(uint32_t), st));
+    VERS_HIP_TRY(hipMemsetAsync(fbq_count, 0, 2 * sizeof(uint32_t), st));  // (the count and, behind it, where the current batch's entries begin)
   }
   if (int32_t rc = launch_stage_queries(C, ldc, d, ws.cg.as<float>(), ldq, k, 1, st)) return rc;
   hipLaunchKernelGGL(row_norms_kernel, dim3((k_pad + 255) / 256), dim3(256), 0, st, ws.cg.as<float>(), ldq, k, k_pad, ws.cnorm.as<float>());
@@ -345,7 +345,8 @@ int32_t km_assign_mfma(const float* X, uint32_t ldx, uint64_t n, const float* C,
     build_stats_add(&BuildStats::gemm_launches, 1.0);
     build_stats_add(&BuildStats::gemm_flop, 2.0 * (double)nb * (double)k * (double)d);
     hipLaunchKernelGGL(assign_argmin_merge_kernel, dim3((nb + 255) / 256), dim3(256), 0, st, (const float*)part_v1, (const uint32_t*)part_c1,
-                       (const float*)part_v2, n_tiles, (uint32_t)mb, nb, best, g2);
+                       (const float*)part_v2, n_tiles, (uint32_t)mb, nb, best, g2, tile_rescan ? fbq_count + 1 : (uint32_t*)nullptr,
+                       (const uint32_t*)fbq_count);
     hipLaunchKernelGGL(assign_rescore_kernel, dim3((nb + 63) / 64), dim3(64), 0, st, X + i0 * ldx, ldx, C, ldc, d, ldq, cmax2_dev, best, g2,
                        nb, k, (uint32_t)i0, out_assign + i0, out_mind ? out_mind + i0 : nullptr, tile_rescan ? fbq_list : fb_list,
                        tile_rescan ? fbq_count : fb_count, ws.status.as<uint32_t>(), metric, fbq_thr, hi_only && wide ? (const uint32_t*)rc2_bits : (const uint32_t*)nullptr);
@@ -357,7 +358,7 @@ int32_t km_assign_mfma(const float* X, uint32_t ldx, uint64_t n, const float* C,
       }
       hipLaunchKernelGGL(assign_tile_rescan_kernel, dim3(2048), dim3(kWave), 0, st, xb_padded, (const float*)ws.cblocked.as<float>(), ldq, k,
                          (const float*)part_v1, n_tiles, (uint32_t)mb, (uint32_t)i0, nb, (const uint32_t*)fbq_list, (const float*)fbq_thr,
-                         (const uint32_t*)fbq_count, out_assign, out_mind, fb_list, fb_count, metric);
+                         (const uint32_t*)fbq_count, out_assign, out_mind, fb_list, fb_count, metric, (const uint32_t*)(fbq_count + 1));
     }
     VERS_HIP_TRY(hipGetLastError());
     if (hi_only && wide && terms_opt == 0 && (i0 == 0 || ws.cascade < 0)) {  // the cascade's verdict: how many of this batch's points stayed open
