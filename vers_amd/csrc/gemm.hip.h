@@ -1603,26 +1603,32 @@ struct RescanSrc {
   __device__ __forceinline__ uint32_t bound_slot(uint32_t, int) const { return 0; }
 };
 // Cb: the centroids in the scan layout [tiles of 64][ld]; Xb: THIS batch's rows, zero padded to ld columns (pitch ld), row i = point i_base + i
-static __global__ __launch_bounds__(kWave) void assign_tile_rescan_kernel(
+// A BLOCK of four waves per queued point: every wave lists the point's candidate tiles (the same list in each), wave w walks the
+// 64-centroid halves w, w + 4, ... of them, the block's first minimum is the smallest of the waves' keys.  (One wave per point walked
+// up to sixteen halves one after the other, 7 us each -- the dependent chain of 768 adds and a 192 KB tile -- with two waves per SIMD
+// on the chip.  Same box, assign pass N = 4M k = 4096: 48.0 ms with one wave per point, 46.8 with two, 46.3 with four.)
+constexpr int kRescanWaves = 4;
+static __global__ __launch_bounds__(kWave * kRescanWaves) void assign_tile_rescan_kernel(
     const float* Xb, const float* Cb, uint32_t ld, uint32_t k, const float* part_v1, uint32_t n_tiles,
     uint32_t pitch, uint32_t i_base, uint32_t nb, const uint32_t* fb_list, const float* fb_thr, const uint32_t* fb_count, uint32_t* assign,
     float* mind, uint32_t* fb2_list, uint32_t* fb2_count, int metric, const uint32_t* fb_start) {
-  __shared__ uint64_t s_out[kWave];
-  const int lane = threadIdx.x;
+  __shared__ uint64_t s_out[kRescanWaves][kWave];
+  __shared__ uint64_t s_best[kRescanWaves];
+  __shared__ uint32_t s_nan[kRescanWaves];
+  const int lane = threadIdx.x & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const uint32_t n_q = *fb_count;
-  // this batch's entries: the tail of the queue from *fb_start on (assign_argmin_merge_kernel).  (Until round 6's second half every launch
-  // walked the queue from its beginning past the other batches' entries -- 38 us for a pass's first batch, 630 for its last at N = 4M.)
+  // this batch's entries: the tail of the queue from *fb_start on (assign_argmin_merge_kernel)
   const uint32_t e0 = *fb_start;
   ScanParams p;
   p.ld = ld; p.n_chunks = ld / kChunk; p.k = 1; p.status = nullptr; p.bounds = nullptr; p.lower = nullptr; p.debug = 0; p.next_quad = nullptr; p.stamps = nullptr;
-  for (uint32_t e = e0 + blockIdx.x; e < n_q; e += gridDim.x) {
+  for (uint32_t e = e0 + blockIdx.x; e < n_q; e += gridDim.x) {  // (block-uniform)
     const uint32_t idx = fb_list[e];
     if (idx < i_base || idx >= i_base + nb) continue;  // (another batch's entry: its tile minima are gone)
     const uint32_t i = idx - i_base;
     const float T = fb_thr[e];
-    uint64_t best = kKeyMax;
-    uint32_t n_cand = 0;
-    bool nan = false;
+    // the candidate tiles, candidate j in lane j (every wave makes the same list)
+    uint32_t n_cand = 0, cand = 0;
     for (uint32_t t0 = 0; t0 < n_tiles && n_cand <= kRescanTiles; t0 += kWave) {
       const uint32_t t = t0 + (uint32_t)lane;
       const float v = t < n_tiles ? part_v1[(uint64_t)t * pitch + i] : __builtin_inff();
@@ -1630,33 +1636,47 @@ static __global__ __launch_bounds__(kWave) void assign_tile_rescan_kernel(
       while (m && n_cand <= kRescanTiles) {
         const uint32_t tl = (uint32_t)__ffsll((unsigned long long)m) - 1u;
         m &= m - 1;
-        if (++n_cand > kRescanTiles) break;
-        const uint32_t c0 = (t0 + tl) * kGemmBM;  // the tile's first centroid (a multiple of 64: whole scan tiles)
+        if (lane == (int)n_cand) cand = t0 + tl;
+        ++n_cand;
+      }
+    }
+    uint64_t best = kKeyMax;
+    bool nan = false;
+    if (n_cand <= kRescanTiles) {
+      for (uint32_t u = (uint32_t)wid; u < 2u * n_cand; u += kRescanWaves) {  // (wave-uniform)
+        const uint32_t c0 = (uint32_t)__shfl((int)cand, (int)(u >> 1), kWave) * kGemmBM + (u & 1u) * kWave;  // a whole scan tile of 64 centroids
         if (c0 >= k) continue;
         ItemView<1> iv;
         iv.rows = Cb + (uint64_t)c0 * ld;
-        iv.nrows = k - c0 < (uint32_t)kGemmBM ? k - c0 : (uint32_t)kGemmBM;
+        iv.nrows = k - c0 < (uint32_t)kWave ? k - c0 : (uint32_t)kWave;
         iv.nq = 1;
         iv.qb = Xb + (uint64_t)i * ld;
-        RescanSrc src{s_out, c0};
+        RescanSrc src{s_out[wid], c0};
         if (metric == 0) scan_item<1, 1, 0>(src, p, 0u, iv, lane, nan);
         else scan_item<1, 1, 1>(src, p, 0u, iv, lane, nan);
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
-        const uint64_t key = s_out[0];  // the tile's first minimum by (distance, centroid index)
+        const uint64_t key = s_out[wid][0];  // the half tile's first minimum by (distance, centroid index)
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         __builtin_amdgcn_wave_barrier();
         best = key < best ? key : best;
       }
     }
-    const bool defer = n_cand > kRescanTiles || n_cand == 0 || __ballot(nan) != 0;
-    if (lane == 0) {
+    const bool wave_nan = __ballot(nan) != 0;  // (the whole wave votes)
+    if (lane == 0) { s_best[wid] = best; s_nan[wid] = wave_nan ? 1u : 0u; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      bool any_nan = false;
+#pragma unroll
+      for (int w = 0; w < kRescanWaves; ++w) { best = s_best[w] < best ? s_best[w] : best; any_nan |= s_nan[w] != 0; }
+      const bool defer = n_cand > kRescanTiles || n_cand == 0 || any_nan;
       if (defer || best == kKeyMax) fb2_list[atomicAdd(fb2_count, 1u)] = idx;
       else {
         assign[idx] = (uint32_t)best;
         if (mind) mind[idx] = __uint_as_float(order_bits_to_f32_bits((uint32_t)(best >> 32)));
       }
     }
+    __syncthreads();  // (s_best / s_nan are the next point's)
   }
 }
 
