@@ -318,7 +318,8 @@ int32_t km_assign_mfma(const float* X, uint32_t ldx, uint64_t n, const float* C,
     // 131072 x 768 points) is a tenth of the contraction at k = 4096 -- 1.03 ms with it against 1.04 for the register-staged kernel that
     // converts while it stages -- and nothing at k = 65536 (12.6 vs 16.2 ms).  Option "assign_glds": 1 always, 0 never.
     const int glds_opt = (int)opt_get("assign_glds", -1);
-    const bool use_h = hi_only && wide && gemm_h_ok(ldq) && (glds_opt > 0 || (glds_opt < 0 && k_pad >= 4096));
+    const bool h_fits = (uint64_t)k_pad * ldq * 2u < (1ull << 32) && (uint64_t)mb * ldq * 2u < (1ull << 32);  // (its source offsets are 32 bits wide)
+    const bool use_h = hi_only && wide && gemm_h_ok(ldq) && h_fits && (glds_opt > 0 || (glds_opt < 0 && k_pad >= 4096));
     if (use_h) {
       if (int32_t rc = ws.xh.reserve((size_t)mb * ldq * sizeof(uint16_t))) return rc;
     } else if (!in_place_ok || nb_pad != nb) {  // pad the columns / the tail rows through a staged copy
