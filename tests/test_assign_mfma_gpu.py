@@ -105,3 +105,43 @@ def test_cascade_hi_only_first_filter_is_bit_exact():
         assert pts == 5000 + 4097 + 777 + 300 + 129 + 9 + 3000 + 2100
         pts, _ = out["BUILD"]
         assert pts >= 6000 * 2 * 2
+
+
+GLDS_BODY = r'''
+import numpy as np
+from oracle import c_oracle as co
+from tests import datagen as dg
+from vers_amd import capi
+
+def bits(a):
+    return np.ascontiguousarray(a, dtype=np.float32).view(np.uint32)
+
+# shapes of dist_gemm_h_kernel (forced: assign_glds=1): fewer tiles than blocks, more tiles than blocks (a block walks several tiles and
+# prefetches the next one's first K-tile under its epilogue), ragged last tiles in both directions, padding columns, both metrics' callers
+for n, d, k, kind in [(700, 128, 256, "c"), (20000, 128, 1024, "c"), (33000, 256, 768, "u"), (5000, 200, 1500, "c"), (1300, 384, 2048, "c"), (9000, 640, 512, "c")]:
+    if kind == "u":
+        X = dg.dist_u(131 + n, n, d); Cn = dg.dist_u(133 + k, k, d)
+    else:
+        X = dg.dist_c(135 + n, n, d, max(4, k // 3), dg.default_sigma(d)); Cn = X[(np.arange(k) * 7919) % n].copy()
+    Cn[2] = Cn[0]
+    a, md = capi.kmeans_assign(X, Cn, want_min_dist=True)
+    want = co.assign_to_clusters(X, Cn)
+    assert np.array_equal(a, want), (n, d, k)
+    idx = np.arange(0, n, max(1, n // 500))
+    ref = np.array([co.squared_euclidean(X[i], Cn[int(want[i])]) for i in idx], dtype=np.float32)
+    assert np.array_equal(bits(md[idx]), bits(ref)), (n, d, k)
+pts, fb = capi.assign_stats(reset=True)
+print("GLDS", pts, fb)
+print("DONE")
+'''
+
+
+def test_lds_dma_contraction_shapes_are_bit_exact():
+    """dist_gemm_h_kernel (the persistent fp16 x fp16 contraction staged by LDS-DMA) forced on at tile counts below, at and above the
+    number of resident blocks: assignments and minimum distances == the oracle's."""
+    env = dict(os.environ); env["VERS_OPTIONS"] = "assign=2,assign_terms=1,assign_glds=1"; env["PYTHONPATH"] = ROOT
+    r = subprocess.run([sys.executable, "-c", GLDS_BODY], capture_output=True, text=True, env=env, cwd=ROOT, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "DONE" in r.stdout
+    pts = int([l for l in r.stdout.splitlines() if l.startswith("GLDS")][0].split()[1])
+    assert pts == 700 + 20000 + 33000 + 5000 + 1300 + 9000
