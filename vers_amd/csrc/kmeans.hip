@@ -359,7 +359,8 @@ int32_t km_assign_mfma(const float* X, uint32_t ldx, uint64_t n, const float* C,
       }
       hipLaunchKernelGGL(assign_tile_rescan_kernel, dim3(2048), dim3(kWave * kRescanWaves), 0, st, xb_padded, (const float*)ws.cblocked.as<float>(), ldq, k,
                          (const float*)part_v1, n_tiles, (uint32_t)mb, (uint32_t)i0, nb, (const uint32_t*)fbq_list, (const float*)fbq_thr,
-                         (const uint32_t*)fbq_count, out_assign, out_mind, fb_list, fb_count, metric, (const uint32_t*)(fbq_count + 1));
+                         (const uint32_t*)fbq_count, out_assign, out_mind, fb_list, fb_count, metric, (const uint32_t*)(fbq_count + 1), (const uint32_t*)part_c1,
+                         (const float*)part_v2);
     }
     VERS_HIP_TRY(hipGetLastError());
     if (hi_only && wide && terms_opt == 0 && (i0 == 0 || ws.cascade < 0)) {  // the cascade's verdict: how many of this batch's points stayed open
