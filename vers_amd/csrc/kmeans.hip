@@ -357,7 +357,7 @@ int32_t km_assign_mfma(const float* X, uint32_t ldx, uint64_t n, const float* C,
         if (int32_t rc = launch_stage_queries(X + i0 * ldx, ldx, d, ws.xp.as<float>(), ldq, nb, 1, st)) return rc;
         xb_padded = ws.xp.as<float>();
       }
-      hipLaunchKernelGGL(assign_tile_rescan_kernel, dim3(2048), dim3(kWave * kRescanWaves), 0, st, xb_padded, (const float*)ws.cblocked.as<float>(), ldq, k,
+      hipLaunchKernelGGL(assign_tile_rescan_kernel, dim3(4096), dim3(kWave * kRescanWaves), 0, st, xb_padded, (const float*)ws.cblocked.as<float>(), ldq, k,
                          (const float*)part_v1, n_tiles, (uint32_t)mb, (uint32_t)i0, nb, (const uint32_t*)fbq_list, (const float*)fbq_thr,
                          (const uint32_t*)fbq_count, out_assign, out_mind, fb_list, fb_count, metric, (const uint32_t*)(fbq_count + 1), (const uint32_t*)part_c1,
                          (const float*)part_v2);
