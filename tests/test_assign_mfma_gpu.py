@@ -145,3 +145,17 @@ def test_lds_dma_contraction_shapes_are_bit_exact():
     assert "DONE" in r.stdout
     pts = int([l for l in r.stdout.splitlines() if l.startswith("GLDS")][0].split()[1])
     assert pts == 700 + 20000 + 33000 + 5000 + 1300 + 9000
+
+
+def test_default_rules_at_4096_centroids_are_bit_exact():
+    """No forcing beyond `assign=2` (matrix cores for a build this small): the cascade is probed, and from 4096 centroids on the LDS-DMA
+    contraction is the default -- assignments and minimum distances == the oracle's."""
+    body = GLDS_BODY.replace('[(700, 128, 256, "c"), (20000, 128, 1024, "c"), (33000, 256, 768, "u"), (5000, 200, 1500, "c"), (1300, 384, 2048, "c"), (9000, 640, 512, "c")]',
+                             '[(12000, 128, 4096, "c"), (3000, 256, 4352, "u")]')
+    assert "4096" in body
+    env = dict(os.environ); env["VERS_OPTIONS"] = "assign=2"; env["PYTHONPATH"] = ROOT
+    r = subprocess.run([sys.executable, "-c", body], capture_output=True, text=True, env=env, cwd=ROOT, timeout=900)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "DONE" in r.stdout
+    pts = int([l for l in r.stdout.splitlines() if l.startswith("GLDS")][0].split()[1])
+    assert pts == 12000 + 3000
